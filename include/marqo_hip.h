@@ -1,0 +1,242 @@
+/*
+ * marqo_hip.h — C ABI of libmarqo_hip.so, the MI355X (gfx950) engine underneath
+ * Marqo's s2_inference.vectorise() hot path.
+ *
+ * The reference (marqo-ai/marqo @ v2.13.0) has NO FFI for this path: its "plugin"
+ * interface is Python duck-typing through the loader map
+ * (src/marqo/s2_inference/model_registry.py:2133-2145) and the arithmetic lives in
+ * un-vendored wheels (open_clip_torch 2.24.0 / transformers 4.41.2).  This header is
+ * therefore the boundary the reference WOULD bind (via ctypes) to
+ * replace, one for one:
+ *
+ *   mq_encode_image_*   <- OPEN_CLIP.encode_image -> open_clip model.encode_image
+ *                          src/marqo/core/inference/embedding_models/open_clip_model.py:249-266
+ *                          (+ the preprocess transform src/marqo/s2_inference/clip_utils.py:48-67
+ *                             when raw uint8 pixels are handed over)
+ *   mq_encode_clip_text <- OPEN_CLIP.encode_text -> open_clip model.encode_text
+ *                          .../open_clip_model.py:268-286
+ *   mq_encode_bert      <- HuggingFaceModel.encode -> AutoModel forward + pooling + F.normalize
+ *                          .../hugging_face_model.py:172-214
+ *   mq_chunk_grid_u8    <- PatchifySimple / chunk_image  src/marqo/s2_inference/processing/image.py:46-151
+ *
+ * Conventions
+ *   - every pointer named d_* is a DEVICE pointer (HBM) owned by the caller (the Python
+ *     host allocates through PyTorch-ROCm; the library never allocates device memory);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); every entry
+ *     point only ENQUEUES work on it and returns; results are valid after the caller
+ *     synchronises that stream;
+ *   - no torch types, no C++ types: plain pointers, ints and POD structs;
+ *   - return value: 0 = MQ_OK, negative = error; mq_last_error() gives the text
+ *     (thread-local).
+ *   - bf16 = the 16 high bits of an IEEE fp32 (round-to-nearest-even when produced here).
+ */
+#ifndef MARQO_HIP_H
+#define MARQO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MQ_OK 0
+#define MQ_ERR_INVALID (-1)   /* bad argument / unsupported shape */
+#define MQ_ERR_HIP (-2)       /* a HIP runtime call or launch failed */
+#define MQ_ERR_WORKSPACE (-3) /* caller's workspace too small */
+
+#define MQ_ABI_VERSION 1
+
+/* ---- activation / mask / pooling selectors ---------------------------------------- */
+#define MQ_ACT_NONE 0
+#define MQ_ACT_GELU 1      /* erf GELU (open_clip nn.GELU, HF "gelu") */
+#define MQ_ACT_QUICKGELU 2 /* x * sigmoid(1.702 x) (OpenAI / *-quickgelu weights) */
+
+#define MQ_MASK_NONE 0   /* ViT: full attention inside a sequence */
+#define MQ_MASK_CAUSAL 1 /* CLIP text tower */
+/* key-padding masks (BERT) are expressed by packing: only real tokens are rows. */
+
+#define MQ_POOL_MEAN 0 /* hugging_face_model.py:205-209 */
+#define MQ_POOL_CLS 1  /* hugging_face_model.py:211-214 */
+
+/* GEMM epilogue flags for mq_gemm_bf16 */
+#define MQ_EPI_BIAS 1      /* + bias[n] (fp32) */
+#define MQ_EPI_GELU 2      /* erf GELU after bias */
+#define MQ_EPI_QUICKGELU 4 /* quick GELU after bias */
+#define MQ_EPI_RESIDUAL 8  /* + residual[m,n] (fp32, leading dim ldc) */
+#define MQ_EPI_OUT_F32 16  /* write fp32 instead of bf16 */
+
+/* ---- transformer encoder description ---------------------------------------------- */
+
+/* One residual block.  Linear weights are bf16, row-major [out_features, in_features]
+ * (PyTorch nn.Linear layout); biases and LayerNorm parameters are fp32. */
+typedef struct mq_block_weights {
+    const float* ln1_g; const float* ln1_b;   /* [W]  pre-LN: before attention; post-LN: after attention */
+    const void*  qkv_w; const float* qkv_b;   /* [3W, W], [3W]  rows: q | k | v */
+    const void*  out_w; const float* out_b;   /* [W, W], [W] */
+    const float* ln2_g; const float* ln2_b;   /* [W] */
+    const void*  fc1_w; const float* fc1_b;   /* [F, W], [F] */
+    const void*  fc2_w; const float* fc2_b;   /* [W, F], [W] */
+} mq_block_weights;
+
+typedef struct mq_encoder_cfg {
+    int32_t width;      /* W, multiple of 64 */
+    int32_t layers;
+    int32_t heads;      /* head dim must be 64 */
+    int32_t mlp_dim;    /* F, multiple of 64 */
+    int32_t act;        /* MQ_ACT_* */
+    int32_t post_ln;    /* 0: pre-LN (CLIP); 1: post-LN (BERT) */
+    int32_t mask;       /* MQ_MASK_* */
+    float   ln_eps;
+} mq_encoder_cfg;
+
+/* ---- towers ------------------------------------------------------------------------ */
+
+typedef struct mq_vit_weights {
+    const void*  patch_w;      /* bf16 [W, Kp]  conv1 weight flattened (c, ky, kx), K zero-padded to Kp = ceil64(3*P*P) */
+    const float* cls;          /* [W]   class embedding */
+    const float* pos;          /* [T, W] positional embedding, T = 1 + (S/P)^2 */
+    const float* ln_pre_g; const float* ln_pre_b;
+    const mq_block_weights* blocks;  /* host array, `layers` entries */
+    const float* ln_post_g; const float* ln_post_b;
+    const void*  proj_w;       /* bf16 [D, W]  (= visual.proj transposed) */
+} mq_vit_weights;
+
+typedef struct mq_vit_cfg {
+    mq_encoder_cfg enc;
+    int32_t image_size;  /* S: 224 */
+    int32_t patch_size;  /* P: 32 / 14 / 16 */
+    int32_t out_dim;     /* D */
+    float mean[3];       /* preprocessing normalisation (clip_utils.py:32-33 by default) */
+    float std[3];
+} mq_vit_cfg;
+
+typedef struct mq_clip_text_weights {
+    const float* tok_emb;      /* fp32 [V, W] token embedding */
+    const float* pos;          /* fp32 [ctx, W] */
+    const mq_block_weights* blocks;
+    const float* ln_final_g; const float* ln_final_b;
+    const void*  proj_w;       /* bf16 [D, W] (= text_projection transposed) */
+} mq_clip_text_weights;
+
+typedef struct mq_clip_text_cfg {
+    mq_encoder_cfg enc;
+    int32_t vocab;
+    int32_t ctx;      /* 77 */
+    int32_t out_dim;
+} mq_clip_text_cfg;
+
+typedef struct mq_bert_weights {
+    const float* word_emb;   /* fp32 [V, W] */
+    const float* pos_emb;    /* fp32 [P, W] */
+    const float* type_emb;   /* fp32 [2, W] (row 0 is used: token_type_ids are all zero) */
+    const float* emb_ln_g; const float* emb_ln_b;
+    const mq_block_weights* blocks;
+} mq_bert_weights;
+
+typedef struct mq_bert_cfg {
+    mq_encoder_cfg enc;
+    int32_t vocab;
+    int32_t max_pos;
+    int32_t pool;     /* MQ_POOL_* */
+} mq_bert_cfg;
+
+/* ---- library info ------------------------------------------------------------------ */
+int         mq_abi_version(void);
+const char* mq_last_error(void);
+/* name of the code object arch this library was built for ("gfx950") */
+const char* mq_build_arch(void);
+
+/* ---- workspace sizing (bytes of device scratch the caller must provide) ------------- */
+/* rows = total token rows in the call (images: n*T; text: sum of sequence lengths);
+ * nseq = number of sequences. */
+size_t mq_encoder_workspace_bytes(const mq_encoder_cfg* cfg, int64_t rows, int64_t nseq);
+size_t mq_vit_workspace_bytes(const mq_vit_cfg* cfg, int64_t n_images);
+size_t mq_clip_text_workspace_bytes(const mq_clip_text_cfg* cfg, int64_t rows, int64_t nseq);
+size_t mq_bert_workspace_bytes(const mq_bert_cfg* cfg, int64_t rows, int64_t nseq);
+
+/* ---- hot-path entry points ----------------------------------------------------------- */
+
+/* Image tower on raw pixels already at model resolution.
+ * d_pixels: uint8 [n, S, S, 3] (HWC, RGB).  ToTensor (/255) + Normalize(mean,std) are fused
+ * into the patch gather.  d_out: fp32 [n, D]; L2-normalised when normalize != 0. */
+int mq_encode_image_u8(const mq_vit_cfg* cfg, const mq_vit_weights* w,
+                       const uint8_t* d_pixels, int64_t n, float* d_out, int normalize,
+                       void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* Image tower on already-preprocessed tensors (what the reference's `.preprocess`
+ * returns, add_docs.py:130-134): d_pixels fp32 [n, 3, S, S] (CHW, normalised). */
+int mq_encode_image_f32(const mq_vit_cfg* cfg, const mq_vit_weights* w,
+                        const float* d_pixels, int64_t n, float* d_out, int normalize,
+                        void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* CLIP text tower.  Sequences are PACKED: d_ids int32 [rows] holds the tokens of sequence
+ * s at [cu_seqlens[s], cu_seqlens[s+1]) where each sequence is SOT ... EOT (the tokens after
+ * EOT never influence the pooled EOT row under the causal mask, so they are not run).
+ * d_cu_seqlens: int32 [nseq+1] on device; h_cu_seqlens: the same array on the host.
+ * The pooled row is the LAST row of each sequence (the EOT token = argmax id,
+ * open_clip text pooling).  To reproduce the reference's padded 77-token execution
+ * exactly, pass every sequence with its full 77 ids and d_pool_rows = argmax rows. */
+int mq_encode_clip_text(const mq_clip_text_cfg* cfg, const mq_clip_text_weights* w,
+                        const int32_t* d_ids, const int32_t* d_cu_seqlens,
+                        const int32_t* h_cu_seqlens, int64_t nseq,
+                        const int32_t* d_pool_rows, /* int32 [nseq] absolute row to pool, or NULL = last row */
+                        float* d_out, int normalize,
+                        void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* BERT-family text tower + pooling (+ L2).  Packed like mq_encode_clip_text: only the
+ * attention_mask==1 tokens of each sequence are rows (results are identical to the
+ * reference's pad-to-longest execution because padded keys are masked out and padded rows
+ * are excluded from the pool: hugging_face_model.py:205-209). */
+int mq_encode_bert(const mq_bert_cfg* cfg, const mq_bert_weights* w,
+                   const int32_t* d_ids, const int32_t* d_cu_seqlens,
+                   const int32_t* h_cu_seqlens, int64_t nseq,
+                   float* d_out, int normalize,
+                   void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* ---- building blocks (exported for parity tests and for callers that compose) -------- */
+
+/* out[M,N] = epilogue(A[M,K] @ W[N,K]^T).  A, W bf16 row-major (lda, ldw in elements);
+ * K % 64 == 0, N % 4 == 0.  bias fp32 [N]; residual fp32 [M, ldc]; out bf16 or fp32 [M, ldc]
+ * (residual may alias out when MQ_EPI_OUT_F32). */
+int mq_gemm_bf16(const void* d_A, int64_t lda, const void* d_W, int64_t ldw,
+                 const float* d_bias, const float* d_residual, void* d_out, int64_t ldc,
+                 int64_t M, int64_t N, int64_t K, int flags, void* stream);
+
+/* y = LayerNorm(x) * g + b over the last dim.  x fp32 [rows, W] gathered through an optional
+ * row index (d_row_idx int32 [rows], NULL = identity).  Writes bf16 (d_out_bf16) and/or fp32
+ * (d_out_f32); either may be NULL. */
+int mq_layernorm(const float* d_x, const int32_t* d_row_idx, const float* d_g, const float* d_b,
+                 void* d_out_bf16, float* d_out_f32, int64_t rows, int32_t W, float eps, void* stream);
+
+/* Multi-head attention over packed sequences.  d_qkv bf16 [rows, 3W] (q | k | v, head h at
+ * columns h*64 .. h*64+63 of each third).  d_out bf16 [rows, W].  Either pass fixed_len > 0
+ * (all sequences have that length, nseq = rows / fixed_len) or d_cu_seqlens int32 [nseq+1]
+ * with max_len = the longest sequence. */
+int mq_attention(const void* d_qkv, void* d_out, const int32_t* d_cu_seqlens, int64_t nseq,
+                 int32_t fixed_len, int32_t max_len, int32_t W, int32_t heads, int32_t mask,
+                 void* stream);
+
+/* One full encoder stack, in place on the fp32 residual stream d_x [rows, W]. */
+int mq_encoder_forward(const mq_encoder_cfg* cfg, const mq_block_weights* blocks,
+                       float* d_x, int64_t rows, const int32_t* d_cu_seqlens, int64_t nseq,
+                       int32_t fixed_len, int32_t max_len,
+                       void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* rows of x: out[r,:] = x[r,:] / ||x[r,:]||_2   (in place allowed) */
+int mq_l2_normalize(const float* d_x, float* d_out, int64_t rows, int32_t D, void* stream);
+
+/* ---- per-kernel timing (bench.py roofline) ------------------------------------------- */
+/* When enabled, every launch of a kernel family is bracketed by hipEvents on its stream.
+ * mq_profile_collect synchronises, sums the elapsed time per family and resets.
+ * family ids: 0 gemm, 1 layernorm, 2 attention, 3 embed/gather, 4 pool/head, 5 preprocess */
+#define MQ_PROF_FAMILIES 6
+int mq_profile_enable(int on);
+int mq_profile_collect(double* ms_per_family /* [MQ_PROF_FAMILIES] */,
+                       int64_t* launches_per_family /* [MQ_PROF_FAMILIES] */,
+                       double* gemm_flops /* total 2*M*N*K over gemm launches */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MARQO_HIP_H */

@@ -1,0 +1,181 @@
+"""ctypes binding of libmarqo_hip.so (the C ABI declared in include/marqo_hip.h).
+
+This is the ONLY way the Python host reaches the GPU arithmetic: PyTorch-ROCm is used for
+device memory, streams and torch.distributed, never for the math of the hot path.  There is
+no CPU fallback: if the shared library is missing or cannot be loaded, importing callers get
+a loud ``MarqoHipUnavailableError``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import sys
+import threading
+from pathlib import Path
+
+PKG_DIR = Path(__file__).resolve().parent
+CSRC_DIR = PKG_DIR / "csrc"
+LIB_DIR = PKG_DIR / "lib"
+LIB_PATH = LIB_DIR / "libmarqo_hip.so"
+HEADER_PATH = PKG_DIR.parent / "include" / "marqo_hip.h"
+
+MQ_OK = 0
+MQ_ACT_GELU, MQ_ACT_QUICKGELU = 1, 2
+MQ_MASK_NONE, MQ_MASK_CAUSAL = 0, 1
+MQ_POOL_MEAN, MQ_POOL_CLS = 0, 1
+MQ_EPI_BIAS, MQ_EPI_GELU, MQ_EPI_QUICKGELU, MQ_EPI_RESIDUAL, MQ_EPI_OUT_F32 = 1, 2, 4, 8, 16
+MQ_PROF_FAMILIES = 6
+PROF_FAMILY_NAMES = ("gemm", "layernorm", "attention", "embed", "pool_head", "preprocess")
+
+
+class MarqoHipUnavailableError(RuntimeError):
+    """The HIP extension is missing / unloadable.  There is deliberately no fallback."""
+
+
+class MarqoHipError(RuntimeError):
+    """A libmarqo_hip entry point returned an error code."""
+
+
+# ---- POD structs (mirror include/marqo_hip.h exactly) ------------------------------------------
+class BlockWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "ln1_g", "ln1_b", "qkv_w", "qkv_b", "out_w", "out_b",
+        "ln2_g", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")]
+
+
+class EncoderCfg(C.Structure):
+    _fields_ = [("width", C.c_int32), ("layers", C.c_int32), ("heads", C.c_int32), ("mlp_dim", C.c_int32),
+                ("act", C.c_int32), ("post_ln", C.c_int32), ("mask", C.c_int32), ("ln_eps", C.c_float)]
+
+
+class VitWeights(C.Structure):
+    _fields_ = [("patch_w", C.c_void_p), ("cls", C.c_void_p), ("pos", C.c_void_p),
+                ("ln_pre_g", C.c_void_p), ("ln_pre_b", C.c_void_p), ("blocks", C.POINTER(BlockWeights)),
+                ("ln_post_g", C.c_void_p), ("ln_post_b", C.c_void_p), ("proj_w", C.c_void_p)]
+
+
+class VitCfg(C.Structure):
+    _fields_ = [("enc", EncoderCfg), ("image_size", C.c_int32), ("patch_size", C.c_int32), ("out_dim", C.c_int32),
+                ("mean", C.c_float * 3), ("std", C.c_float * 3)]
+
+
+class ClipTextWeights(C.Structure):
+    _fields_ = [("tok_emb", C.c_void_p), ("pos", C.c_void_p), ("blocks", C.POINTER(BlockWeights)),
+                ("ln_final_g", C.c_void_p), ("ln_final_b", C.c_void_p), ("proj_w", C.c_void_p)]
+
+
+class ClipTextCfg(C.Structure):
+    _fields_ = [("enc", EncoderCfg), ("vocab", C.c_int32), ("ctx", C.c_int32), ("out_dim", C.c_int32)]
+
+
+class BertWeights(C.Structure):
+    _fields_ = [("word_emb", C.c_void_p), ("pos_emb", C.c_void_p), ("type_emb", C.c_void_p),
+                ("emb_ln_g", C.c_void_p), ("emb_ln_b", C.c_void_p), ("blocks", C.POINTER(BlockWeights))]
+
+
+class BertCfg(C.Structure):
+    _fields_ = [("enc", EncoderCfg), ("vocab", C.c_int32), ("max_pos", C.c_int32), ("pool", C.c_int32)]
+
+
+_P = C.c_void_p
+_SIGNATURES = {
+    # name: (restype, argtypes)
+    "mq_abi_version": (C.c_int, []),
+    "mq_last_error": (C.c_char_p, []),
+    "mq_build_arch": (C.c_char_p, []),
+    "mq_encoder_workspace_bytes": (C.c_size_t, [C.POINTER(EncoderCfg), C.c_int64, C.c_int64]),
+    "mq_vit_workspace_bytes": (C.c_size_t, [C.POINTER(VitCfg), C.c_int64]),
+    "mq_clip_text_workspace_bytes": (C.c_size_t, [C.POINTER(ClipTextCfg), C.c_int64, C.c_int64]),
+    "mq_bert_workspace_bytes": (C.c_size_t, [C.POINTER(BertCfg), C.c_int64, C.c_int64]),
+    "mq_encode_image_u8": (C.c_int, [C.POINTER(VitCfg), C.POINTER(VitWeights), _P, C.c_int64, _P, C.c_int, _P, C.c_size_t, _P]),
+    "mq_encode_image_f32": (C.c_int, [C.POINTER(VitCfg), C.POINTER(VitWeights), _P, C.c_int64, _P, C.c_int, _P, C.c_size_t, _P]),
+    "mq_encode_clip_text": (C.c_int, [C.POINTER(ClipTextCfg), C.POINTER(ClipTextWeights), _P, _P, _P, C.c_int64, _P, _P,
+                                      C.c_int, _P, C.c_size_t, _P]),
+    "mq_encode_bert": (C.c_int, [C.POINTER(BertCfg), C.POINTER(BertWeights), _P, _P, _P, C.c_int64, _P, C.c_int, _P,
+                                 C.c_size_t, _P]),
+    "mq_gemm_bf16": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+                               C.c_int, _P]),
+    "mq_layernorm": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, C.c_int32, C.c_float, _P]),
+    "mq_attention": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "mq_encoder_forward": (C.c_int, [C.POINTER(EncoderCfg), C.POINTER(BlockWeights), _P, C.c_int64, _P, C.c_int64,
+                                     C.c_int32, C.c_int32, _P, C.c_size_t, _P]),
+    "mq_l2_normalize": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P]),
+    "mq_profile_enable": (C.c_int, [C.c_int]),
+    "mq_profile_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def sources() -> list:
+    return sorted(str(p) for p in CSRC_DIR.glob("*.hip"))
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    """Compile csrc/*.hip for gfx950 into lib/libmarqo_hip.so (hipcc cross-compiles without a GPU)."""
+    srcs = sources()
+    deps = srcs + [str(CSRC_DIR / "common.h"), str(HEADER_PATH)]
+    if LIB_PATH.exists() and not force:
+        newest = max(os.path.getmtime(p) for p in deps)
+        if os.path.getmtime(LIB_PATH) >= newest:
+            return LIB_PATH
+    LIB_DIR.mkdir(parents=True, exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
+           *srcs, "-o", str(LIB_PATH)]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise MarqoHipUnavailableError(f"hipcc failed ({res.returncode}):\n{res.stdout}\n{res.stderr}")
+    return LIB_PATH
+
+
+def load():
+    """Load libmarqo_hip.so (after torch, so both share torch's HIP runtime)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        import torch  # noqa: F401  (must be first: pins libamdhip64.so.7 to the copy PyTorch ships)
+        if not LIB_PATH.exists():
+            raise MarqoHipUnavailableError(
+                f"{LIB_PATH} not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"(hipcc --offload-arch=gfx950). There is no CPU fallback for the marqo_amd engine.")
+        try:
+            lib = C.CDLL(str(LIB_PATH), mode=C.RTLD_GLOBAL)
+        except OSError as e:
+            raise MarqoHipUnavailableError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (res, args) in _SIGNATURES.items():
+            try:
+                fn = getattr(lib, name)
+            except AttributeError as e:
+                raise MarqoHipUnavailableError(f"{LIB_PATH} does not export {name}") from e
+            fn.restype = res
+            fn.argtypes = args
+        if lib.mq_abi_version() != 1:
+            raise MarqoHipUnavailableError(f"ABI version mismatch: library {lib.mq_abi_version()} != binding 1")
+        _lib = lib
+        return _lib
+
+
+def check(rc: int, what: str = "libmarqo_hip") -> None:
+    if rc != MQ_OK:
+        msg = load().mq_last_error()
+        raise MarqoHipError(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")
+
+
+def ptr(t) -> int:
+    """Device (or host) address of a tensor / None -> NULL."""
+    return 0 if t is None else t.data_ptr()
+
+
+def current_stream_handle(device=None) -> int:
+    import torch
+    return torch.cuda.current_stream(device).cuda_stream

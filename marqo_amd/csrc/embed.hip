@@ -1,0 +1,293 @@
+// Front/back ends of the towers (K1 gather, K6/K8 gathers, K7, K9, K10-normalise):
+//   * patchify: uint8 HWC (or fp32 CHW) image -> bf16 im2col matrix [n*np, Kp]; since the conv
+//     has stride == kernel this is a pure index remap; ToTensor (/255) + Normalize are fused in.
+//   * vit_assemble: class token + patch embeddings + positional embedding + ln_pre -> fp32 stream.
+//   * embed_tokens: token (+position, +type) embedding gather (+ LayerNorm for BERT).
+//   * pool: masked mean / CLS pooling (+ L2) over packed sequences.
+#include "common.h"
+
+namespace {
+
+// ---- patchify ---------------------------------------------------------------------------------
+// out[(img*np + py*G + px), c*P*P + ky*P + kx] = norm(in[img, py*P+ky, px*P+kx, c]); cols >= 3*P*P are 0.
+// One thread produces 8 consecutive output columns (one 16-byte store).
+template <bool U8>
+__global__ __launch_bounds__(256) void patchify_kernel(const void* __restrict__ in, bf16_t* __restrict__ out,
+                                                       int64_t total_groups, int S, int P, int G, int Kp,
+                                                       float sc0, float sc1, float sc2, float of0, float of1, float of2) {
+    const int groups_per_row = Kp >> 3;
+    const int PP = P * P;
+    for (int64_t gi = (int64_t)blockIdx.x * 256 + threadIdx.x; gi < total_groups; gi += (int64_t)gridDim.x * 256) {
+        const int64_t prow = gi / groups_per_row;
+        const int col0 = (int)(gi - prow * groups_per_row) * 8;
+        const int64_t img = prow / (G * G);
+        const int pidx = (int)(prow - img * (G * G));
+        const int py = pidx / G, px = pidx - py * G;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int col = col0 + e;
+            float val = 0.f;
+            if (col < 3 * PP) {
+                const int c = col / PP;
+                const int rem = col - c * PP;
+                const int ky = rem / P, kx = rem - ky * P;
+                const int y = py * P + ky, x = px * P + kx;
+                const float sc = c == 0 ? sc0 : (c == 1 ? sc1 : sc2);
+                const float of = c == 0 ? of0 : (c == 1 ? of1 : of2);
+                if (U8) {
+                    const uint8_t b = ((const uint8_t*)in)[((img * S + y) * S + x) * 3 + c];
+                    // ToTensor: b / 255 ; Normalize: (t - mean) / std   (clip_utils.py:61-66)
+                    val = ((float)b / 255.0f - of) / sc;
+                } else {
+                    val = ((const float*)in)[((img * 3 + c) * S + y) * (int64_t)S + x];
+                }
+            }
+            v[e] = val;
+        }
+        uint4 p;
+        p.x = pack_bf16x2(v[0], v[1]);
+        p.y = pack_bf16x2(v[2], v[3]);
+        p.z = pack_bf16x2(v[4], v[5]);
+        p.w = pack_bf16x2(v[6], v[7]);
+        *(uint4*)(out + prow * Kp + col0) = p;
+    }
+}
+
+// ---- ViT token assembly + ln_pre ------------------------------------------------------------------
+// row (b, t): t == 0 ? cls : patch_out[b*np + t-1];  + pos[t];  LayerNorm(ln_pre) -> x fp32
+constexpr int MAXC = 8;
+__global__ __launch_bounds__(256) void vit_assemble_kernel(const float* __restrict__ patch_out, const float* __restrict__ cls,
+                                                           const float* __restrict__ pos, const float* __restrict__ gam,
+                                                           const float* __restrict__ bet, float* __restrict__ x,
+                                                           int64_t rows, int T, int W, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int64_t b = row / T;
+    const int t = (int)(row - b * T);
+    const float* src = t == 0 ? cls : patch_out + (b * (T - 1) + (t - 1)) * W;
+    const float* pr = pos + (int64_t)t * W;
+    const int nch = W >> 2;
+    f32x4 v[MAXC];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = lane + i * 64;
+        if (c < nch) {
+            v[i] = *(const f32x4*)(src + c * 4) + *(const f32x4*)(pr + c * 4);
+            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        }
+    }
+    const float mean = wave_sum(s) / (float)W;
+    float s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = lane + i * 64;
+        if (c < nch) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; s2 += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(s2) / (float)W + eps);
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = lane + i * 64;
+        if (c < nch) {
+            const f32x4 gg = *(const f32x4*)(gam + c * 4);
+            const f32x4 bb = *(const f32x4*)(bet + c * 4);
+            f32x4 y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd * gg[e] + bb[e];
+            *(f32x4*)(x + row * W + c * 4) = y;
+        }
+    }
+}
+
+// ---- token embedding (+ pos, + type) (+ LayerNorm) ---------------------------------------------------
+// grid = nseq blocks; the 4 waves of a block walk the sequence's rows.
+template <bool LN>
+__global__ __launch_bounds__(256) void embed_tokens_kernel(const int32_t* __restrict__ ids, const int32_t* __restrict__ cu,
+                                                           const float* __restrict__ tok, const float* __restrict__ pos,
+                                                           const float* __restrict__ type0, const float* __restrict__ gam,
+                                                           const float* __restrict__ bet, float* __restrict__ x,
+                                                           bf16_t* __restrict__ xb, int W, int vocab, float eps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row0 = cu[blockIdx.x], len = cu[blockIdx.x + 1] - row0;
+    const int nch = W >> 2;
+    for (int t = wave; t < len; t += 4) {
+        const int64_t row = row0 + t;
+        int id = ids[row];
+        id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+        const float* tr = tok + (int64_t)id * W;
+        const float* pr = pos + (int64_t)t * W;
+        f32x4 v[MAXC];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = lane + i * 64;
+            if (c < nch) {
+                v[i] = *(const f32x4*)(tr + c * 4) + *(const f32x4*)(pr + c * 4);
+                if (type0) v[i] += *(const f32x4*)(type0 + c * 4);
+                s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+            }
+        }
+        float mean = 0.f, rstd = 1.f;
+        if (LN) {
+            mean = wave_sum(s) / (float)W;
+            float s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < MAXC; ++i) {
+                const int c = lane + i * 64;
+                if (c < nch) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; s2 += d * d; }
+                }
+            }
+            rstd = rsqrtf(wave_sum(s2) / (float)W + eps);
+        }
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = lane + i * 64;
+            if (c < nch) {
+                f32x4 y = v[i];
+                if (LN) {
+                    const f32x4 gg = *(const f32x4*)(gam + c * 4);
+                    const f32x4 bb = *(const f32x4*)(bet + c * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd * gg[e] + bb[e];
+                }
+                *(f32x4*)(x + row * W + c * 4) = y;
+                if (xb) {
+                    uint2 p;
+                    p.x = pack_bf16x2(y[0], y[1]);
+                    p.y = pack_bf16x2(y[2], y[3]);
+                    *(uint2*)(xb + row * W + c * 4) = p;
+                }
+            }
+        }
+    }
+}
+
+// ---- pooling over packed sequences (+ L2) ---------------------------------------------------------------
+// grid = nseq; thread owns columns tid, tid+256, ...  (W <= 2048)
+__global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ x, const int32_t* __restrict__ cu,
+                                                   float* __restrict__ out, int W, int pool, int normalize) {
+    __shared__ float red[4];
+    const int row0 = cu[blockIdx.x], len = cu[blockIdx.x + 1] - row0;
+    float acc[8];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        acc[i] = 0.f;
+        const int c = threadIdx.x + i * 256;
+        if (c < W) {
+            if (pool == MQ_POOL_CLS) {
+                acc[i] = x[(int64_t)row0 * W + c];
+            } else {
+                float s = 0.f;
+                for (int t = 0; t < len; ++t) s += x[(int64_t)(row0 + t) * W + c];
+                // reference divides by attention_mask.sum() with no epsilon (hugging_face_model.py:208-209)
+                acc[i] = s / (float)len;
+            }
+            ss += acc[i] * acc[i];
+        }
+    }
+    float inv = 1.f;
+    if (normalize) {
+        ss = wave_sum(ss);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+        __syncthreads();
+        const float tot = red[0] + red[1] + red[2] + red[3];
+        // F.normalize(p=2, dim=1): x / max(||x||, 1e-12)   (hugging_face_model.py:194-195)
+        inv = 1.0f / fmaxf(sqrtf(tot), 1e-12f);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = threadIdx.x + i * 256;
+        if (c < W) out[(int64_t)blockIdx.x * W + c] = acc[i] * inv;
+    }
+}
+
+// last-row index of every packed sequence (CLIP text EOT pooling when the caller passes no rows)
+__global__ void last_rows_kernel(const int32_t* __restrict__ cu, int32_t* __restrict__ rows, int nseq) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nseq) rows[i] = cu[i + 1] - 1;
+}
+// class-token row of every image
+__global__ void cls_rows_kernel(int32_t* __restrict__ rows, int n, int T) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) rows[i] = i * T;
+}
+
+}  // namespace
+
+// ---- internal host entry points (declared in towers.hip) ---------------------------------------------------
+int mq_patchify(const void* d_in, bool is_u8, void* d_out, int64_t n, int S, int P, int Kp,
+                const float* mean, const float* std, hipStream_t s) {
+    const int G = S / P;
+    const int64_t total = n * G * G * (Kp >> 3);
+    if (total <= 0) return MQ_OK;
+    MqProfScope prof(5, s);
+    const unsigned grid = (unsigned)(cdiv64(total, 256) < 16384 ? cdiv64(total, 256) : 16384);
+    if (is_u8)
+        hipLaunchKernelGGL(patchify_kernel<true>, dim3(grid), dim3(256), 0, s, d_in, (bf16_t*)d_out, total, S, P, G, Kp,
+                           std[0], std[1], std[2], mean[0], mean[1], mean[2]);
+    else
+        hipLaunchKernelGGL(patchify_kernel<false>, dim3(grid), dim3(256), 0, s, d_in, (bf16_t*)d_out, total, S, P, G, Kp,
+                           1.f, 1.f, 1.f, 0.f, 0.f, 0.f);
+    MQ_CHECK_LAUNCH("mq_patchify");
+    return MQ_OK;
+}
+
+int mq_vit_assemble(const float* d_patch_out, const float* cls, const float* pos, const float* g, const float* b,
+                    float* d_x, int64_t n, int T, int W, float eps, hipStream_t s) {
+    MQ_CHECK_ARG(W % 4 == 0 && W <= 64 * 4 * MAXC, "vit_assemble: W=%d unsupported", W);
+    const int64_t rows = n * T;
+    if (rows <= 0) return MQ_OK;
+    MqProfScope prof(3, s);
+    hipLaunchKernelGGL(vit_assemble_kernel, dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, s, d_patch_out, cls, pos, g, b,
+                       d_x, rows, T, W, eps);
+    MQ_CHECK_LAUNCH("vit_assemble");
+    return MQ_OK;
+}
+
+int mq_embed_tokens(const int32_t* d_ids, const int32_t* d_cu, int64_t nseq, const float* tok, const float* pos,
+                    const float* type0, const float* g, const float* b, float* d_x, void* d_xb, int W, int vocab,
+                    float eps, hipStream_t s) {
+    MQ_CHECK_ARG(W % 4 == 0 && W <= 64 * 4 * MAXC, "embed_tokens: W=%d unsupported", W);
+    if (nseq <= 0) return MQ_OK;
+    MqProfScope prof(3, s);
+    if (g)
+        hipLaunchKernelGGL(embed_tokens_kernel<true>, dim3((unsigned)nseq), dim3(256), 0, s, d_ids, d_cu, tok, pos, type0,
+                           g, b, d_x, (bf16_t*)d_xb, W, vocab, eps);
+    else
+        hipLaunchKernelGGL(embed_tokens_kernel<false>, dim3((unsigned)nseq), dim3(256), 0, s, d_ids, d_cu, tok, pos, type0,
+                           g, b, d_x, (bf16_t*)d_xb, W, vocab, eps);
+    MQ_CHECK_LAUNCH("embed_tokens");
+    return MQ_OK;
+}
+
+int mq_pool(const float* d_x, const int32_t* d_cu, int64_t nseq, float* d_out, int W, int pool, int normalize,
+            hipStream_t s) {
+    MQ_CHECK_ARG(W <= 2048, "pool: W=%d unsupported", W);
+    if (nseq <= 0) return MQ_OK;
+    MqProfScope prof(4, s);
+    hipLaunchKernelGGL(pool_kernel, dim3((unsigned)nseq), dim3(256), 0, s, d_x, d_cu, d_out, W, pool, normalize);
+    MQ_CHECK_LAUNCH("pool");
+    return MQ_OK;
+}
+
+int mq_last_rows(const int32_t* d_cu, int32_t* d_rows, int64_t nseq, hipStream_t s) {
+    if (nseq <= 0) return MQ_OK;
+    hipLaunchKernelGGL(last_rows_kernel, dim3((unsigned)cdiv64(nseq, 256)), dim3(256), 0, s, d_cu, d_rows, (int)nseq);
+    MQ_CHECK_LAUNCH("last_rows");
+    return MQ_OK;
+}
+
+int mq_cls_rows(int32_t* d_rows, int64_t n, int T, hipStream_t s) {
+    if (n <= 0) return MQ_OK;
+    hipLaunchKernelGGL(cls_rows_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, d_rows, (int)n, T);
+    MQ_CHECK_LAUNCH("cls_rows");
+    return MQ_OK;
+}

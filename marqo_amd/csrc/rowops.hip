@@ -1,0 +1,119 @@
+// Row-wise HBM-bound kernels: LayerNorm (K2), L2-normalise (tail of K6/K8/K9), fp32->bf16 cast.
+// One wave64 per row, float4 (16 B/lane) accesses, two-pass statistics held in registers so the
+// row is read from HBM exactly once.
+#include "common.h"
+
+namespace {
+
+constexpr int LN_MAX_CHUNKS = 8;  // float4 chunks per lane: W <= 64 * 4 * 8 = 2048
+
+// x row (fp32) -> LN -> bf16 and/or fp32.  row_idx gathers input rows (output rows are dense).
+__global__ __launch_bounds__(256) void layernorm_kernel(
+    const float* __restrict__ x, const int32_t* __restrict__ row_idx, const float* __restrict__ gam,
+    const float* __restrict__ bet, bf16_t* out_bf16, float* out_f32, int64_t rows, int W, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int64_t src = row_idx ? (int64_t)row_idx[row] : row;
+    const float* xr = x + src * W;
+    const int nch = W >> 2;  // float4 chunks in the row
+
+    f32x4 v[LN_MAX_CHUNKS];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+        const int c = lane + i * 64;
+        if (c < nch) {
+            v[i] = *(const f32x4*)(xr + c * 4);
+            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        }
+    }
+    const float mean = wave_sum(s) / (float)W;
+    float s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+        const int c = lane + i * 64;
+        if (c < nch) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; s2 += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(s2) / (float)W + eps);
+#pragma unroll
+    for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+        const int c = lane + i * 64;
+        if (c < nch) {
+            const f32x4 gg = *(const f32x4*)(gam + c * 4);
+            const f32x4 bb = *(const f32x4*)(bet + c * 4);
+            f32x4 y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd * gg[e] + bb[e];
+            if (out_f32) *(f32x4*)(out_f32 + row * W + c * 4) = y;
+            if (out_bf16) {
+                uint2 p;
+                p.x = pack_bf16x2(y[0], y[1]);
+                p.y = pack_bf16x2(y[2], y[3]);
+                *(uint2*)(out_bf16 + row * W + c * 4) = p;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void l2norm_kernel(const float* __restrict__ x, float* out, int64_t rows, int D) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * D;
+    float s = 0.f;
+    for (int c = lane; c < D; c += 64) { const float t = xr[c]; s += t * t; }
+    // reference: outputs /= outputs.norm(dim=-1, keepdim=True)  (open_clip_model.py:262-265)
+    const float inv = 1.0f / sqrtf(wave_sum(s));
+    for (int c = lane; c < D; c += 64) out[row * D + c] = xr[c] * inv;
+}
+
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ x, bf16_t* out, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const f32x4 v = *(const f32x4*)(x + i * 4);
+        uint2 p;
+        p.x = pack_bf16x2(v[0], v[1]);
+        p.y = pack_bf16x2(v[2], v[3]);
+        *(uint2*)(out + i * 4) = p;
+    }
+}
+
+}  // namespace
+
+extern "C" int mq_layernorm(const float* d_x, const int32_t* d_row_idx, const float* d_g, const float* d_b,
+                            void* d_out_bf16, float* d_out_f32, int64_t rows, int32_t W, float eps, void* stream) {
+    MQ_CHECK_ARG(d_x && d_g && d_b && (d_out_bf16 || d_out_f32), "mq_layernorm: null pointer");
+    MQ_CHECK_ARG(W >= 4 && W % 4 == 0 && W <= 64 * 4 * LN_MAX_CHUNKS, "mq_layernorm: W=%d unsupported (multiple of 4, <= 2048)", W);
+    if (rows <= 0) return MQ_OK;
+    hipStream_t s = (hipStream_t)stream;
+    MqProfScope prof(1, s);
+    hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, s, d_x, d_row_idx, d_g, d_b,
+                       (bf16_t*)d_out_bf16, d_out_f32, rows, (int)W, eps);
+    MQ_CHECK_LAUNCH("mq_layernorm");
+    return MQ_OK;
+}
+
+extern "C" int mq_l2_normalize(const float* d_x, float* d_out, int64_t rows, int32_t D, void* stream) {
+    MQ_CHECK_ARG(d_x && d_out && D >= 1, "mq_l2_normalize: bad argument");
+    if (rows <= 0) return MQ_OK;
+    hipStream_t s = (hipStream_t)stream;
+    MqProfScope prof(4, s);
+    hipLaunchKernelGGL(l2norm_kernel, dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, s, d_x, d_out, rows, (int)D);
+    MQ_CHECK_LAUNCH("mq_l2_normalize");
+    return MQ_OK;
+}
+
+// internal (not in the public header): fp32 -> bf16 cast of n elements (n % 4 == 0)
+int mq_cast_bf16(const float* d_x, void* d_out, int64_t n, hipStream_t s) {
+    MQ_CHECK_ARG(n % 4 == 0, "mq_cast_bf16: n must be a multiple of 4");
+    if (n <= 0) return MQ_OK;
+    MqProfScope prof(1, s);
+    const int64_t n4 = n / 4;
+    const unsigned grid = (unsigned)(cdiv64(n4, 256) < 4096 ? cdiv64(n4, 256) : 4096);
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid), dim3(256), 0, s, d_x, (bf16_t*)d_out, n4);
+    MQ_CHECK_LAUNCH("mq_cast_bf16");
+    return MQ_OK;
+}

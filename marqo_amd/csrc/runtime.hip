@@ -1,0 +1,69 @@
+// Library-wide host plumbing: thread-local error text, ABI/arch info, per-family launch timing.
+#include <stdarg.h>
+#include <mutex>
+#include <vector>
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void mq_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* mq_last_error(void) { return g_err; }
+extern "C" int mq_abi_version(void) { return MQ_ABI_VERSION; }
+extern "C" const char* mq_build_arch(void) { return "gfx950"; }
+
+// ---- profiling -----------------------------------------------------------------------------
+namespace {
+struct ProfRec { int family; hipEvent_t start, stop; double flops; };
+std::mutex g_prof_mu;
+std::vector<ProfRec> g_prof;
+bool g_prof_on = false;
+}  // namespace
+
+MqProfScope::MqProfScope(int family, hipStream_t s, double flops)
+    : family_(family), stream_(s), start_(nullptr), on_(g_prof_on) {
+    if (!on_) return;
+    hipEvent_t stop;
+    if (hipEventCreate(&start_) != hipSuccess || hipEventCreate(&stop) != hipSuccess) { on_ = false; return; }
+    (void)hipEventRecord(start_, stream_);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof.push_back(ProfRec{family_, start_, stop, flops});
+}
+
+MqProfScope::~MqProfScope() {
+    if (!on_) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto it = g_prof.rbegin(); it != g_prof.rend(); ++it)
+        if (it->start == start_) { (void)hipEventRecord(it->stop, stream_); break; }
+}
+
+extern "C" int mq_profile_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_on = on != 0;
+    return MQ_OK;
+}
+
+extern "C" int mq_profile_collect(double* ms, int64_t* launches, double* gemm_flops) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (int i = 0; i < MQ_PROF_FAMILIES; ++i) { if (ms) ms[i] = 0.0; if (launches) launches[i] = 0; }
+    if (gemm_flops) *gemm_flops = 0.0;
+    int rc = MQ_OK;
+    for (auto& r : g_prof) {
+        if (hipEventSynchronize(r.stop) != hipSuccess) { rc = MQ_ERR_HIP; mq_set_error("mq_profile_collect: event sync failed"); }
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, r.start, r.stop) == hipSuccess && r.family >= 0 && r.family < MQ_PROF_FAMILIES) {
+            if (ms) ms[r.family] += t;
+            if (launches) launches[r.family] += 1;
+            if (r.family == 0 && gemm_flops) *gemm_flops += r.flops;
+        }
+        (void)hipEventDestroy(r.start);
+        (void)hipEventDestroy(r.stop);
+    }
+    g_prof.clear();
+    return rc;
+}

@@ -1,0 +1,290 @@
+// Host-side orchestration of the three towers on one HIP stream (no allocation, no sync):
+//   ViT image tower          (open_clip VisionTransformer forward,   SURVEY.md §3.5)
+//   CLIP text tower          (open_clip TextTransformer forward)
+//   BERT encoder + pooling   (transformers BertModel + hugging_face_model.py:172-214)
+// Residual stream is fp32 (what fp16-autocast keeps it as in the reference's cuda path:
+// open_clip_model.py:255-260), GEMM inputs bf16, accumulation / LN statistics / softmax fp32.
+#include "common.h"
+
+// kernels in the sibling translation units
+int mq_cast_bf16(const float* d_x, void* d_out, int64_t n, hipStream_t s);
+int mq_patchify(const void* d_in, bool is_u8, void* d_out, int64_t n, int S, int P, int Kp,
+                const float* mean, const float* std, hipStream_t s);
+int mq_vit_assemble(const float* d_patch_out, const float* cls, const float* pos, const float* g, const float* b,
+                    float* d_x, int64_t n, int T, int W, float eps, hipStream_t s);
+int mq_embed_tokens(const int32_t* d_ids, const int32_t* d_cu, int64_t nseq, const float* tok, const float* pos,
+                    const float* type0, const float* g, const float* b, float* d_x, void* d_xb, int W, int vocab,
+                    float eps, hipStream_t s);
+int mq_pool(const float* d_x, const int32_t* d_cu, int64_t nseq, float* d_out, int W, int pool, int normalize,
+            hipStream_t s);
+int mq_last_rows(const int32_t* d_cu, int32_t* d_rows, int64_t nseq, hipStream_t s);
+int mq_cls_rows(int32_t* d_rows, int64_t n, int T, hipStream_t s);
+
+namespace {
+
+constexpr size_t WS_ALIGN = 256;
+
+// bump allocator over the caller's workspace: take() returns the (256-B aligned) OFFSET
+struct Off {
+    size_t off = 0;
+    size_t take(size_t bytes) {
+        off = align_up(off, WS_ALIGN);
+        const size_t o = off;
+        off += bytes;
+        return o;
+    }
+    size_t end() const { return align_up(off, WS_ALIGN); }
+};
+
+int check_encoder_cfg(const mq_encoder_cfg* c) {
+    MQ_CHECK_ARG(c, "encoder cfg is null");
+    MQ_CHECK_ARG(c->width >= 64 && c->width % 64 == 0, "encoder width %d must be a multiple of 64", c->width);
+    MQ_CHECK_ARG(c->heads >= 1 && c->width == c->heads * 64, "encoder head dim must be 64 (width %d, heads %d)", c->width, c->heads);
+    MQ_CHECK_ARG(c->mlp_dim >= 64 && c->mlp_dim % 64 == 0, "encoder mlp_dim %d must be a multiple of 64", c->mlp_dim);
+    MQ_CHECK_ARG(c->layers >= 0, "encoder layers < 0");
+    MQ_CHECK_ARG(c->act == MQ_ACT_GELU || c->act == MQ_ACT_QUICKGELU, "encoder act %d unsupported", c->act);
+    return MQ_OK;
+}
+
+// scratch of one encoder pass: h bf16 [rows,W] | a bf16 [rows,W] | big bf16 [rows, max(3W,F)]
+size_t encoder_ws(const mq_encoder_cfg* c, int64_t rows) {
+    Off cv;
+    const size_t big = (size_t)(3 * c->width > c->mlp_dim ? 3 * c->width : c->mlp_dim);
+    cv.take((size_t)rows * c->width * 2);
+    cv.take((size_t)rows * c->width * 2);
+    cv.take((size_t)rows * big * 2);
+    return cv.end();
+}
+
+int ceil64(int v) { return (v + 63) / 64 * 64; }
+
+}  // namespace
+
+extern "C" size_t mq_encoder_workspace_bytes(const mq_encoder_cfg* cfg, int64_t rows, int64_t nseq) {
+    (void)nseq;
+    if (!cfg || rows <= 0) return 0;
+    return encoder_ws(cfg, rows);
+}
+
+extern "C" int mq_encoder_forward(const mq_encoder_cfg* cfg, const mq_block_weights* blocks, float* d_x, int64_t rows,
+                                  const int32_t* d_cu_seqlens, int64_t nseq, int32_t fixed_len, int32_t max_len,
+                                  void* d_workspace, size_t workspace_bytes, void* stream) {
+    MQ_TRY(check_encoder_cfg(cfg));
+    MQ_CHECK_ARG(d_x && (blocks || cfg->layers == 0), "mq_encoder_forward: null pointer");
+    if (rows <= 0 || cfg->layers == 0) return MQ_OK;
+    if (workspace_bytes < encoder_ws(cfg, rows)) {
+        mq_set_error("mq_encoder_forward: workspace %zu < required %zu", workspace_bytes, encoder_ws(cfg, rows));
+        return MQ_ERR_WORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int W = cfg->width, F = cfg->mlp_dim;
+    const size_t big = (size_t)(3 * W > F ? 3 * W : F);
+    Off cv;
+    char* wsb = (char*)d_workspace;
+    void* h = wsb + cv.take((size_t)rows * W * 2);
+    void* a = wsb + cv.take((size_t)rows * W * 2);
+    void* qf = wsb + cv.take((size_t)rows * big * 2);  // qkv [rows,3W] then fc1 output [rows,F]
+    const int act_flag = cfg->act == MQ_ACT_QUICKGELU ? MQ_EPI_QUICKGELU : MQ_EPI_GELU;
+    const int res_flags = MQ_EPI_BIAS | MQ_EPI_RESIDUAL | MQ_EPI_OUT_F32;
+
+    if (cfg->post_ln) MQ_TRY(mq_cast_bf16(d_x, h, rows * W, s));  // block input as GEMM operand
+
+    for (int l = 0; l < cfg->layers; ++l) {
+        const mq_block_weights& b = blocks[l];
+        MQ_CHECK_ARG(b.qkv_w && b.out_w && b.fc1_w && b.fc2_w && b.ln1_g && b.ln2_g, "mq_encoder_forward: layer %d has null weights", l);
+        if (!cfg->post_ln) {
+            // x += out(attn(qkv(ln1(x)))) ; x += fc2(act(fc1(ln2(x))))
+            MQ_TRY(mq_layernorm(d_x, nullptr, b.ln1_g, b.ln1_b, h, nullptr, rows, W, cfg->ln_eps, s));
+            MQ_TRY(mq_gemm_bf16(h, W, b.qkv_w, W, b.qkv_b, nullptr, qf, 3 * W, rows, 3 * W, W, MQ_EPI_BIAS, s));
+            MQ_TRY(mq_attention(qf, a, d_cu_seqlens, nseq, fixed_len, max_len, W, cfg->heads, cfg->mask, s));
+            MQ_TRY(mq_gemm_bf16(a, W, b.out_w, W, b.out_b, d_x, d_x, W, rows, W, W, res_flags, s));
+            MQ_TRY(mq_layernorm(d_x, nullptr, b.ln2_g, b.ln2_b, h, nullptr, rows, W, cfg->ln_eps, s));
+            MQ_TRY(mq_gemm_bf16(h, W, b.fc1_w, W, b.fc1_b, nullptr, qf, F, rows, F, W, MQ_EPI_BIAS | act_flag, s));
+            MQ_TRY(mq_gemm_bf16(qf, F, b.fc2_w, F, b.fc2_b, d_x, d_x, W, rows, W, F, res_flags, s));
+        } else {
+            // x = ln1(x + out(attn(qkv(x)))) ; x = ln2(x + fc2(act(fc1(x))))
+            MQ_TRY(mq_gemm_bf16(h, W, b.qkv_w, W, b.qkv_b, nullptr, qf, 3 * W, rows, 3 * W, W, MQ_EPI_BIAS, s));
+            MQ_TRY(mq_attention(qf, a, d_cu_seqlens, nseq, fixed_len, max_len, W, cfg->heads, cfg->mask, s));
+            MQ_TRY(mq_gemm_bf16(a, W, b.out_w, W, b.out_b, d_x, d_x, W, rows, W, W, res_flags, s));
+            MQ_TRY(mq_layernorm(d_x, nullptr, b.ln1_g, b.ln1_b, h, d_x, rows, W, cfg->ln_eps, s));
+            MQ_TRY(mq_gemm_bf16(h, W, b.fc1_w, W, b.fc1_b, nullptr, qf, F, rows, F, W, MQ_EPI_BIAS | act_flag, s));
+            MQ_TRY(mq_gemm_bf16(qf, F, b.fc2_w, F, b.fc2_b, d_x, d_x, W, rows, W, F, res_flags, s));
+            MQ_TRY(mq_layernorm(d_x, nullptr, b.ln2_g, b.ln2_b, h, d_x, rows, W, cfg->ln_eps, s));
+        }
+    }
+    return MQ_OK;
+}
+
+// =============================== ViT image tower =================================================
+namespace {
+struct VitPlan {
+    int T, np, Kp; int64_t rows;
+    size_t off_x, off_rows, off_cls, off_enc, off_patches, off_patch_out, total;
+};
+VitPlan vit_plan(const mq_vit_cfg* c, int64_t n) {
+    VitPlan p;
+    const int G = c->image_size / c->patch_size;
+    p.np = G * G; p.T = p.np + 1; p.Kp = ceil64(3 * c->patch_size * c->patch_size); p.rows = n * p.T;
+    const int W = c->enc.width;
+    Off cv;
+    p.off_x = cv.take((size_t)p.rows * W * 4);
+    p.off_rows = cv.take((size_t)n * 4);
+    p.off_cls = cv.take((size_t)n * W * 2);
+    // encoder scratch and the patch buffers are never live together -> they share one region
+    p.off_enc = cv.end();
+    const size_t enc = encoder_ws(&c->enc, p.rows);
+    Off pv;
+    p.off_patches = p.off_enc + pv.take((size_t)n * p.np * p.Kp * 2);
+    p.off_patch_out = p.off_enc + pv.take((size_t)n * p.np * W * 4);
+    const size_t patches = pv.end();
+    p.total = p.off_enc + (enc > patches ? enc : patches);
+    return p;
+}
+
+int encode_image_impl(const mq_vit_cfg* cfg, const mq_vit_weights* w, const void* d_pixels, bool is_u8, int64_t n,
+                      float* d_out, int normalize, void* ws, size_t ws_bytes, hipStream_t s) {
+    MQ_CHECK_ARG(cfg && w && d_out, "mq_encode_image: null pointer");
+    MQ_TRY(check_encoder_cfg(&cfg->enc));
+    MQ_CHECK_ARG(cfg->patch_size > 0 && cfg->image_size % cfg->patch_size == 0, "mq_encode_image: image %d not divisible by patch %d",
+                 cfg->image_size, cfg->patch_size);
+    MQ_CHECK_ARG(cfg->out_dim >= 4 && cfg->out_dim % 4 == 0, "mq_encode_image: out_dim %d must be a multiple of 4", cfg->out_dim);
+    MQ_CHECK_ARG(w->patch_w && w->cls && w->pos && w->ln_pre_g && w->ln_pre_b && w->ln_post_g && w->ln_post_b && w->proj_w,
+                 "mq_encode_image: null weight pointer");
+    if (n <= 0) return MQ_OK;
+    MQ_CHECK_ARG(d_pixels && ws, "mq_encode_image: null input / workspace");
+    const VitPlan p = vit_plan(cfg, n);
+    if (ws_bytes < p.total) { mq_set_error("mq_encode_image: workspace %zu < required %zu", ws_bytes, p.total); return MQ_ERR_WORKSPACE; }
+    char* base = (char*)ws;
+    float* x = (float*)(base + p.off_x);
+    int32_t* rows_idx = (int32_t*)(base + p.off_rows);
+    void* cls_ln = base + p.off_cls;
+    void* patches = base + p.off_patches;
+    float* patch_out = (float*)(base + p.off_patch_out);
+    const int W = cfg->enc.width;
+
+    // K10 (normalise) + K1: im2col gather, conv-as-GEMM, class token + pos + ln_pre
+    MQ_TRY(mq_patchify(d_pixels, is_u8, patches, n, cfg->image_size, cfg->patch_size, p.Kp, cfg->mean, cfg->std, s));
+    MQ_TRY(mq_gemm_bf16(patches, p.Kp, w->patch_w, p.Kp, nullptr, nullptr, patch_out, W, n * p.np, W, p.Kp, MQ_EPI_OUT_F32, s));
+    MQ_TRY(mq_vit_assemble(patch_out, w->cls, w->pos, w->ln_pre_g, w->ln_pre_b, x, n, p.T, W, cfg->enc.ln_eps, s));
+    // K2-K5 x layers
+    MQ_TRY(mq_encoder_forward(&cfg->enc, w->blocks, x, p.rows, nullptr, n, p.T, p.T, base + p.off_enc, ws_bytes - p.off_enc, s));
+    // K6: ln_post(class token) @ proj, L2
+    MQ_TRY(mq_cls_rows(rows_idx, n, p.T, s));
+    MQ_TRY(mq_layernorm(x, rows_idx, w->ln_post_g, w->ln_post_b, cls_ln, nullptr, n, W, cfg->enc.ln_eps, s));
+    MQ_TRY(mq_gemm_bf16(cls_ln, W, w->proj_w, W, nullptr, nullptr, d_out, cfg->out_dim, n, cfg->out_dim, W, MQ_EPI_OUT_F32, s));
+    if (normalize) MQ_TRY(mq_l2_normalize(d_out, d_out, n, cfg->out_dim, s));
+    return MQ_OK;
+}
+}  // namespace
+
+extern "C" size_t mq_vit_workspace_bytes(const mq_vit_cfg* cfg, int64_t n_images) {
+    if (!cfg || n_images <= 0 || cfg->patch_size <= 0) return 0;
+    return vit_plan(cfg, n_images).total;
+}
+
+extern "C" int mq_encode_image_u8(const mq_vit_cfg* cfg, const mq_vit_weights* w, const uint8_t* d_pixels, int64_t n,
+                                  float* d_out, int normalize, void* d_workspace, size_t workspace_bytes, void* stream) {
+    return encode_image_impl(cfg, w, d_pixels, true, n, d_out, normalize, d_workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int mq_encode_image_f32(const mq_vit_cfg* cfg, const mq_vit_weights* w, const float* d_pixels, int64_t n,
+                                   float* d_out, int normalize, void* d_workspace, size_t workspace_bytes, void* stream) {
+    return encode_image_impl(cfg, w, d_pixels, false, n, d_out, normalize, d_workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+// =============================== CLIP text tower ==================================================
+namespace {
+struct TextPlan { size_t off_x, off_rows, off_pool, off_enc, total; };
+TextPlan text_plan(const mq_encoder_cfg* enc, int64_t rows, int64_t nseq) {
+    TextPlan p;
+    Off cv;
+    p.off_x = cv.take((size_t)rows * enc->width * 4);
+    p.off_rows = cv.take((size_t)nseq * 4);
+    p.off_pool = cv.take((size_t)nseq * enc->width * 4);
+    p.off_enc = cv.end();
+    p.total = p.off_enc + encoder_ws(enc, rows);
+    return p;
+}
+int max_seq_len(const int32_t* h_cu, int64_t nseq, int64_t* rows_out) {
+    int mx = 0;
+    for (int64_t i = 0; i < nseq; ++i) {
+        const int l = h_cu[i + 1] - h_cu[i];
+        if (l < 1) return -1;
+        if (l > mx) mx = l;
+    }
+    *rows_out = h_cu[nseq] - h_cu[0];
+    return mx;
+}
+}  // namespace
+
+extern "C" size_t mq_clip_text_workspace_bytes(const mq_clip_text_cfg* cfg, int64_t rows, int64_t nseq) {
+    if (!cfg || rows <= 0 || nseq <= 0) return 0;
+    return text_plan(&cfg->enc, rows, nseq).total;
+}
+
+extern "C" int mq_encode_clip_text(const mq_clip_text_cfg* cfg, const mq_clip_text_weights* w, const int32_t* d_ids,
+                                   const int32_t* d_cu_seqlens, const int32_t* h_cu_seqlens, int64_t nseq,
+                                   const int32_t* d_pool_rows, float* d_out, int normalize, void* d_workspace,
+                                   size_t workspace_bytes, void* stream) {
+    MQ_CHECK_ARG(cfg && w && d_out, "mq_encode_clip_text: null pointer");
+    MQ_TRY(check_encoder_cfg(&cfg->enc));
+    MQ_CHECK_ARG(cfg->out_dim >= 4 && cfg->out_dim % 4 == 0, "mq_encode_clip_text: out_dim %d must be a multiple of 4", cfg->out_dim);
+    MQ_CHECK_ARG(w->tok_emb && w->pos && w->ln_final_g && w->ln_final_b && w->proj_w, "mq_encode_clip_text: null weight pointer");
+    if (nseq <= 0) return MQ_OK;
+    MQ_CHECK_ARG(d_ids && d_cu_seqlens && h_cu_seqlens && d_workspace, "mq_encode_clip_text: null input / workspace");
+    MQ_CHECK_ARG(h_cu_seqlens[0] == 0, "mq_encode_clip_text: cu_seqlens[0] must be 0");
+    int64_t rows = 0;
+    const int maxl = max_seq_len(h_cu_seqlens, nseq, &rows);
+    MQ_CHECK_ARG(maxl >= 1 && maxl <= cfg->ctx, "mq_encode_clip_text: sequence lengths must be in [1, ctx=%d]", cfg->ctx);
+    const TextPlan p = text_plan(&cfg->enc, rows, nseq);
+    if (workspace_bytes < p.total) { mq_set_error("mq_encode_clip_text: workspace %zu < required %zu", workspace_bytes, p.total); return MQ_ERR_WORKSPACE; }
+    hipStream_t s = (hipStream_t)stream;
+    char* base = (char*)d_workspace;
+    float* x = (float*)(base + p.off_x);
+    int32_t* rows_idx = (int32_t*)(base + p.off_rows);
+    void* pooled = base + p.off_pool;  // bf16 [nseq, W]
+    const int W = cfg->enc.width;
+
+    MQ_TRY(mq_embed_tokens(d_ids, d_cu_seqlens, nseq, w->tok_emb, w->pos, nullptr, nullptr, nullptr, x, nullptr, W, cfg->vocab, 0.f, s));
+    MQ_TRY(mq_encoder_forward(&cfg->enc, w->blocks, x, rows, d_cu_seqlens, nseq, 0, maxl, base + p.off_enc, workspace_bytes - p.off_enc, s));
+    const int32_t* pool_rows = d_pool_rows;
+    if (!pool_rows) { MQ_TRY(mq_last_rows(d_cu_seqlens, rows_idx, nseq, s)); pool_rows = rows_idx; }
+    MQ_TRY(mq_layernorm(x, pool_rows, w->ln_final_g, w->ln_final_b, pooled, nullptr, nseq, W, cfg->enc.ln_eps, s));
+    MQ_TRY(mq_gemm_bf16(pooled, W, w->proj_w, W, nullptr, nullptr, d_out, cfg->out_dim, nseq, cfg->out_dim, W, MQ_EPI_OUT_F32, s));
+    if (normalize) MQ_TRY(mq_l2_normalize(d_out, d_out, nseq, cfg->out_dim, s));
+    return MQ_OK;
+}
+
+// =============================== BERT + pooling ====================================================
+extern "C" size_t mq_bert_workspace_bytes(const mq_bert_cfg* cfg, int64_t rows, int64_t nseq) {
+    if (!cfg || rows <= 0 || nseq <= 0) return 0;
+    return text_plan(&cfg->enc, rows, nseq).total;
+}
+
+extern "C" int mq_encode_bert(const mq_bert_cfg* cfg, const mq_bert_weights* w, const int32_t* d_ids,
+                              const int32_t* d_cu_seqlens, const int32_t* h_cu_seqlens, int64_t nseq, float* d_out,
+                              int normalize, void* d_workspace, size_t workspace_bytes, void* stream) {
+    MQ_CHECK_ARG(cfg && w && d_out, "mq_encode_bert: null pointer");
+    MQ_TRY(check_encoder_cfg(&cfg->enc));
+    MQ_CHECK_ARG(cfg->enc.post_ln == 1 && cfg->enc.mask == MQ_MASK_NONE, "mq_encode_bert: BERT is post-LN with full attention");
+    MQ_CHECK_ARG(cfg->pool == MQ_POOL_MEAN || cfg->pool == MQ_POOL_CLS, "mq_encode_bert: bad pooling %d", cfg->pool);
+    MQ_CHECK_ARG(w->word_emb && w->pos_emb && w->type_emb && w->emb_ln_g && w->emb_ln_b, "mq_encode_bert: null weight pointer");
+    if (nseq <= 0) return MQ_OK;
+    MQ_CHECK_ARG(d_ids && d_cu_seqlens && h_cu_seqlens && d_workspace, "mq_encode_bert: null input / workspace");
+    MQ_CHECK_ARG(h_cu_seqlens[0] == 0, "mq_encode_bert: cu_seqlens[0] must be 0");
+    int64_t rows = 0;
+    const int maxl = max_seq_len(h_cu_seqlens, nseq, &rows);
+    MQ_CHECK_ARG(maxl >= 1 && maxl <= cfg->max_pos, "mq_encode_bert: sequence lengths must be in [1, max_pos=%d]", cfg->max_pos);
+    const TextPlan p = text_plan(&cfg->enc, rows, nseq);
+    if (workspace_bytes < p.total) { mq_set_error("mq_encode_bert: workspace %zu < required %zu", workspace_bytes, p.total); return MQ_ERR_WORKSPACE; }
+    hipStream_t s = (hipStream_t)stream;
+    char* base = (char*)d_workspace;
+    float* x = (float*)(base + p.off_x);
+    const int W = cfg->enc.width;
+
+    MQ_TRY(mq_embed_tokens(d_ids, d_cu_seqlens, nseq, w->word_emb, w->pos_emb, w->type_emb, w->emb_ln_g, w->emb_ln_b, x, nullptr, W,
+                           cfg->vocab, cfg->enc.ln_eps, s));
+    MQ_TRY(mq_encoder_forward(&cfg->enc, w->blocks, x, rows, d_cu_seqlens, nseq, 0, maxl, base + p.off_enc, workspace_bytes - p.off_enc, s));
+    MQ_TRY(mq_pool(x, d_cu_seqlens, nseq, d_out, W, cfg->pool, normalize, s));
+    return MQ_OK;
+}
