@@ -1,0 +1,136 @@
+"""Architecture tables for the towers the engine runs.
+
+Shapes are the published open_clip 2.24.0 model configs / HF BERT configs (third-party, not in the
+reference tree; the reference only pins names and output dims in
+src/marqo/s2_inference/model_registry.py:76-610,616-880).  Only towers whose attention head dim is
+64 are runnable by the gfx950 attention kernel; the others are listed so that the error is explicit.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, replace
+from typing import Optional, Tuple
+
+OPENAI_DATASET_MEAN = (0.48145466, 0.4578275, 0.40821073)  # clip_utils.py:32
+OPENAI_DATASET_STD = (0.26862954, 0.26130258, 0.27577711)  # clip_utils.py:33
+
+
+@dataclass(frozen=True)
+class VitArch:
+    image_size: int
+    patch_size: int
+    width: int
+    layers: int
+    heads: int
+    mlp_dim: int
+    out_dim: int
+    quick_gelu: bool = False
+    ln_eps: float = 1e-5
+
+    @property
+    def tokens(self) -> int:
+        return (self.image_size // self.patch_size) ** 2 + 1
+
+    @property
+    def gflop_per_image(self) -> float:
+        """Algorithmic FLOPs (2MNK per GEMM, attention 4 T^2 W per layer) — SURVEY.md §8(d)."""
+        T, W, F = self.tokens, self.width, self.mlp_dim
+        patch = 2 * (T - 1) * W * 3 * self.patch_size ** 2
+        layer = 2 * T * W * (3 * W) + 2 * T * W * W + 2 * 2 * T * W * F + 4 * T * T * W
+        return (patch + self.layers * layer + 2 * W * self.out_dim) / 1e9
+
+
+@dataclass(frozen=True)
+class ClipTextArch:
+    vocab: int
+    ctx: int
+    width: int
+    layers: int
+    heads: int
+    mlp_dim: int
+    out_dim: int
+    quick_gelu: bool = False
+    ln_eps: float = 1e-5
+
+    def gflop_per_text(self, tokens: Optional[int] = None) -> float:
+        T, W, F = tokens or self.ctx, self.width, self.mlp_dim
+        layer = 2 * T * W * (3 * W) + 2 * T * W * W + 2 * 2 * T * W * F + 4 * T * T * W
+        return (self.layers * layer + 2 * W * self.out_dim) / 1e9
+
+
+@dataclass(frozen=True)
+class BertArch:
+    vocab: int = 30522
+    max_pos: int = 512
+    width: int = 768
+    layers: int = 12
+    heads: int = 12
+    mlp_dim: int = 3072
+    ln_eps: float = 1e-12
+
+    def gflop_per_text(self, tokens: int) -> float:
+        T, W, F = tokens, self.width, self.mlp_dim
+        layer = 2 * T * W * (3 * W) + 2 * T * W * W + 2 * 2 * T * W * F + 4 * T * T * W
+        return self.layers * layer / 1e9
+
+
+_TEXT_B = ClipTextArch(vocab=49408, ctx=77, width=512, layers=12, heads=8, mlp_dim=2048, out_dim=512)
+_TEXT_L = ClipTextArch(vocab=49408, ctx=77, width=768, layers=12, heads=12, mlp_dim=3072, out_dim=768)
+
+# open_clip architecture name -> (vision, text)
+OPEN_CLIP_ARCHS = {
+    "ViT-B-32": (VitArch(224, 32, 768, 12, 12, 3072, 512), _TEXT_B),
+    "ViT-B-32-256": (VitArch(256, 32, 768, 12, 12, 3072, 512), _TEXT_B),
+    "ViT-B-16": (VitArch(224, 16, 768, 12, 12, 3072, 512), _TEXT_B),
+    "ViT-L-14": (VitArch(224, 14, 1024, 24, 16, 4096, 768), _TEXT_L),
+    "ViT-L-14-336": (VitArch(336, 14, 1024, 24, 16, 4096, 768), _TEXT_L),
+}
+# architectures the registry names but whose head dim != 64 (ViT-H 80, ViT-g 88, ViT-bigG 104) or which are
+# not plain CLIP ViTs (ResNet, ConvNeXt, EVA02, SigLIP, CoCa, roberta/xlm text towers ...)
+UNSUPPORTED_HINT = ("this open_clip architecture is not runnable by the marqo_amd engine yet "
+                    "(supported: " + ", ".join(sorted(OPEN_CLIP_ARCHS)) + " and their -quickgelu variants)")
+
+# OpenAI `clip` names (clip_utils.py:295-492) -> open_clip architecture (always QuickGELU)
+OPENAI_CLIP_NAMES = {"ViT-B/32": "ViT-B-32", "ViT-B/16": "ViT-B-16", "ViT-L/14": "ViT-L-14", "ViT-L/14@336px": "ViT-L-14-336"}
+
+
+def resolve_open_clip(arch_name: str, pretrained: Optional[str] = None) -> Tuple[VitArch, ClipTextArch]:
+    """'ViT-B-32' / 'ViT-B-32-quickgelu' (+ pretrained tag) -> (vision, text) arch or KeyError."""
+    quick = False
+    base = arch_name
+    if base.endswith("-quickgelu"):
+        base, quick = base[: -len("-quickgelu")], True
+    if pretrained == "openai":  # OpenAI checkpoints were trained with QuickGELU
+        quick = True
+    if base not in OPEN_CLIP_ARCHS:
+        raise KeyError(f"{arch_name}: {UNSUPPORTED_HINT}")
+    v, t = OPEN_CLIP_ARCHS[base]
+    return replace(v, quick_gelu=quick), replace(t, quick_gelu=quick)
+
+
+# HF repo id -> BERT arch for the BERT-family registry entries (model_registry.py:616-880)
+_BERT_BASE = BertArch()
+_BERT_SMALL = BertArch(width=384, layers=12, heads=6, mlp_dim=1536)
+_BERT_LARGE = BertArch(width=1024, layers=24, heads=16, mlp_dim=4096)
+_MINILM_L6 = BertArch(width=384, layers=6, heads=6, mlp_dim=1536)  # head dim 64
+HF_BERT_ARCHS = {
+    "intfloat/e5-base-v2": _BERT_BASE, "intfloat/e5-base": _BERT_BASE,
+    "intfloat/e5-small-v2": _BERT_SMALL, "intfloat/e5-small": _BERT_SMALL,
+    "intfloat/e5-large-v2": _BERT_LARGE, "intfloat/e5-large": _BERT_LARGE,
+    "BAAI/bge-base-en": _BERT_BASE, "BAAI/bge-base-en-v1.5": _BERT_BASE,
+    "BAAI/bge-small-en": _BERT_SMALL, "BAAI/bge-small-en-v1.5": _BERT_SMALL,
+    "BAAI/bge-large-en": _BERT_LARGE, "BAAI/bge-large-en-v1.5": _BERT_LARGE,
+    "sentence-transformers/all-MiniLM-L6-v1": _MINILM_L6, "sentence-transformers/all-MiniLM-L6-v2": _MINILM_L6,
+}
+
+
+def bert_arch_from_hf_config(cfg: dict) -> BertArch:
+    """A local HF `config.json` (model_type bert) -> BertArch."""
+    if cfg.get("model_type", "bert") != "bert":
+        raise KeyError(f"model_type={cfg.get('model_type')} is not a BERT encoder")
+    if cfg.get("position_embedding_type", "absolute") != "absolute":
+        raise KeyError("only absolute position embeddings are supported")
+    if cfg.get("hidden_act", "gelu") != "gelu":
+        raise KeyError(f"hidden_act={cfg.get('hidden_act')} unsupported")
+    return BertArch(vocab=cfg["vocab_size"], max_pos=cfg["max_position_embeddings"], width=cfg["hidden_size"],
+                    layers=cfg["num_hidden_layers"], heads=cfg["num_attention_heads"],
+                    mlp_dim=cfg["intermediate_size"], ln_eps=cfg.get("layer_norm_eps", 1e-12))

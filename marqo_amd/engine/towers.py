@@ -1,0 +1,324 @@
+"""Tower objects: checkpoint tensors -> HBM layout -> one C-ABI call per batch.
+
+PyTorch is used for what the task allows it for — device memory, streams, H2D/D2H copies — and
+nothing else; every FLOP of the forward pass is issued by libmarqo_hip.so (include/marqo_hip.h).
+
+HBM layout (all resident for the life of the tower; a 288 GB MI355X holds every registry model at
+once, so nothing is ever re-uploaded):
+  * linear weights   bf16 row-major [out_features, in_features] (the MFMA "NT" operand as stored)
+  * biases, LayerNorm affine, class/positional/token embeddings   fp32
+  * patch-embed conv weight  bf16 [W, Kp], K = (c, ky, kx) flattened, zero-padded to a multiple of 64
+  * projections      bf16 [D, W] (transposed once at load so they are plain NT GEMM operands)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import threading
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from marqo_amd import _lib as L
+from marqo_amd.engine.archs import BertArch, ClipTextArch, VitArch, OPENAI_DATASET_MEAN, OPENAI_DATASET_STD
+
+Tensor = torch.Tensor
+
+# upper bound of token rows pushed through one C-ABI call (bounds the scratch workspace; with
+# 288 GB of HBM this is deliberately large so GEMMs see M in the 10^5 range)
+MAX_ROWS_PER_CALL = 1 << 18
+
+
+def _require_gpu(device: str) -> torch.device:
+    if not str(device).startswith("cuda"):
+        raise L.MarqoHipUnavailableError(
+            f"the marqo_amd engine only runs on an AMD GPU ('cuda' / 'cuda:N' device strings on ROCm); "
+            f"got device={device!r}. There is no CPU fallback.")
+    if not torch.cuda.is_available():
+        raise L.MarqoHipUnavailableError("no GPU is visible to PyTorch-ROCm; the marqo_amd engine has no CPU fallback")
+    return torch.device(device)
+
+
+class _Holder:
+    """Keeps device tensors alive and hands out raw pointers."""
+
+    def __init__(self, device: torch.device):
+        self.device = device
+        self.tensors: List[Tensor] = []
+
+    def f32(self, t: Tensor) -> int:
+        d = t.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        self.tensors.append(d)
+        return d.data_ptr()
+
+    def bf16(self, t: Tensor) -> int:
+        d = t.detach().to(dtype=torch.float32).to(device=self.device).to(torch.bfloat16).contiguous()
+        self.tensors.append(d)
+        return d.data_ptr()
+
+    def nbytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in self.tensors)
+
+
+def _need(sd: Dict[str, Tensor], key: str, shape: Optional[Tuple[int, ...]] = None) -> Tensor:
+    if key not in sd:
+        raise KeyError(f"checkpoint is missing tensor '{key}'")
+    t = sd[key]
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError(f"checkpoint tensor '{key}' has shape {tuple(t.shape)}, expected {tuple(shape)}")
+    return t
+
+
+def _encoder_cfg(width, layers, heads, mlp_dim, quick_gelu, post_ln, mask, eps) -> L.EncoderCfg:
+    if width != heads * 64:
+        raise ValueError(f"attention head dim must be 64 for the gfx950 attention kernel (width={width}, heads={heads})")
+    return L.EncoderCfg(width=width, layers=layers, heads=heads, mlp_dim=mlp_dim,
+                        act=L.MQ_ACT_QUICKGELU if quick_gelu else L.MQ_ACT_GELU,
+                        post_ln=1 if post_ln else 0, mask=mask, ln_eps=eps)
+
+
+def _clip_blocks(h: _Holder, sd, prefix: str, layers: int, W: int, F: int):
+    arr = (L.BlockWeights * layers)()
+    for i in range(layers):
+        p = f"{prefix}resblocks.{i}."
+        b = arr[i]
+        b.ln1_g = h.f32(_need(sd, p + "ln_1.weight", (W,)))
+        b.ln1_b = h.f32(_need(sd, p + "ln_1.bias", (W,)))
+        b.qkv_w = h.bf16(_need(sd, p + "attn.in_proj_weight", (3 * W, W)))
+        b.qkv_b = h.f32(_need(sd, p + "attn.in_proj_bias", (3 * W,)))
+        b.out_w = h.bf16(_need(sd, p + "attn.out_proj.weight", (W, W)))
+        b.out_b = h.f32(_need(sd, p + "attn.out_proj.bias", (W,)))
+        b.ln2_g = h.f32(_need(sd, p + "ln_2.weight", (W,)))
+        b.ln2_b = h.f32(_need(sd, p + "ln_2.bias", (W,)))
+        b.fc1_w = h.bf16(_need(sd, p + "mlp.c_fc.weight", (F, W)))
+        b.fc1_b = h.f32(_need(sd, p + "mlp.c_fc.bias", (F,)))
+        b.fc2_w = h.bf16(_need(sd, p + "mlp.c_proj.weight", (W, F)))
+        b.fc2_b = h.f32(_need(sd, p + "mlp.c_proj.bias", (W,)))
+    return arr
+
+
+class _TowerBase:
+    def __init__(self, device: str):
+        self.device = _require_gpu(device)
+        self.lib = L.load()
+        self._h = _Holder(self.device)
+        self._ws: Optional[Tensor] = None
+        self._lock = threading.Lock()  # one workspace per tower: serialise concurrent FastAPI threads
+
+    def _workspace(self, nbytes: int) -> Tensor:
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = None
+            self._ws = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def weight_bytes(self) -> int:
+        return self._h.nbytes()
+
+
+class VitTower(_TowerBase):
+    """CLIP ViT image tower (open_clip `visual.*` checkpoint tensors)."""
+
+    def __init__(self, arch: VitArch, sd: Dict[str, Tensor], device: str,
+                 mean: Sequence[float] = OPENAI_DATASET_MEAN, std: Sequence[float] = OPENAI_DATASET_STD):
+        super().__init__(device)
+        self.arch = arch
+        W, P = arch.width, arch.patch_size
+        if arch.image_size % P:
+            raise ValueError("image_size must be a multiple of patch_size")
+        K = 3 * P * P
+        Kp = (K + 63) // 64 * 64
+        conv = _need(sd, "visual.conv1.weight", (W, 3, P, P)).detach().to(torch.float32).reshape(W, K)
+        patch_w = torch.zeros(W, Kp, dtype=torch.float32)
+        patch_w[:, :K] = conv
+        h = self._h
+        self._blocks = _clip_blocks(h, sd, "visual.transformer.", arch.layers, W, arch.mlp_dim)
+        self.w = L.VitWeights(
+            patch_w=h.bf16(patch_w),
+            cls=h.f32(_need(sd, "visual.class_embedding", (W,))),
+            pos=h.f32(_need(sd, "visual.positional_embedding", (arch.tokens, W))),
+            ln_pre_g=h.f32(_need(sd, "visual.ln_pre.weight", (W,))), ln_pre_b=h.f32(_need(sd, "visual.ln_pre.bias", (W,))),
+            blocks=self._blocks,
+            ln_post_g=h.f32(_need(sd, "visual.ln_post.weight", (W,))), ln_post_b=h.f32(_need(sd, "visual.ln_post.bias", (W,))),
+            proj_w=h.bf16(_need(sd, "visual.proj", (W, arch.out_dim)).detach().to(torch.float32).t()))
+        self.cfg = L.VitCfg(enc=_encoder_cfg(W, arch.layers, arch.heads, arch.mlp_dim, arch.quick_gelu, False,
+                                             L.MQ_MASK_NONE, arch.ln_eps),
+                            image_size=arch.image_size, patch_size=P, out_dim=arch.out_dim,
+                            mean=(C.c_float * 3)(*mean), std=(C.c_float * 3)(*std))
+        self.max_images_per_call = max(1, MAX_ROWS_PER_CALL // arch.tokens)
+
+    def _run(self, fn, pixels: Tensor, normalize: bool) -> Tensor:
+        n = pixels.shape[0]
+        out = torch.empty(n, self.arch.out_dim, dtype=torch.float32, device=self.device)
+        with self._lock, torch.cuda.device(self.device):
+            for i in range(0, n, self.max_images_per_call):
+                m = min(self.max_images_per_call, n - i)
+                need = self.lib.mq_vit_workspace_bytes(C.byref(self.cfg), m)
+                ws = self._workspace(need)
+                L.check(fn(C.byref(self.cfg), C.byref(self.w), pixels[i:i + m].data_ptr(), m, out[i:i + m].data_ptr(),
+                           1 if normalize else 0, ws.data_ptr(), ws.numel(), self._stream()), "mq_encode_image")
+        return out
+
+    def encode_u8(self, images_u8: Tensor, normalize: bool = True) -> Tensor:
+        """uint8 [n, S, S, 3] (HWC RGB, on this device) -> fp32 [n, D] on device (async on the current stream)."""
+        S = self.arch.image_size
+        if images_u8.dtype != torch.uint8 or images_u8.ndim != 4 or tuple(images_u8.shape[1:]) != (S, S, 3):
+            raise ValueError(f"expected uint8 [n, {S}, {S}, 3], got {images_u8.dtype} {tuple(images_u8.shape)}")
+        images_u8 = images_u8.to(self.device, non_blocking=True).contiguous()
+        return self._run(self.lib.mq_encode_image_u8, images_u8, normalize)
+
+    def encode_f32(self, pixels: Tensor, normalize: bool = True) -> Tensor:
+        """preprocessed fp32 [n, 3, S, S] -> fp32 [n, D] on device."""
+        S = self.arch.image_size
+        if pixels.ndim != 4 or tuple(pixels.shape[1:]) != (3, S, S):
+            raise ValueError(f"expected float [n, 3, {S}, {S}], got {tuple(pixels.shape)}")
+        pixels = pixels.to(device=self.device, dtype=torch.float32, non_blocking=True).contiguous()
+        return self._run(self.lib.mq_encode_image_f32, pixels, normalize)
+
+
+def _pack(ids: Tensor, lengths: Tensor) -> Tuple[Tensor, Tensor]:
+    """right-padded [n, S] ids + lengths -> (packed int32 ids [rows], cu_seqlens int32 [n+1]) on host."""
+    n, S = ids.shape
+    keep = torch.arange(S).unsqueeze(0) < lengths.unsqueeze(1)
+    packed = ids[keep].to(torch.int32).contiguous()
+    cu = torch.zeros(n + 1, dtype=torch.int32)
+    cu[1:] = lengths.cumsum(0).to(torch.int32)
+    return packed, cu
+
+
+class _TextTowerBase(_TowerBase):
+    def _chunks(self, lengths: Tensor):
+        """Yield (start, stop) sequence ranges with <= MAX_ROWS_PER_CALL rows each."""
+        n = lengths.numel()
+        cum = 0
+        start = 0
+        lens = lengths.tolist()
+        for i, l in enumerate(lens):
+            if cum + l > MAX_ROWS_PER_CALL and i > start:
+                yield start, i
+                start, cum = i, 0
+            cum += l
+        if n > start:
+            yield start, n
+
+
+class ClipTextTower(_TextTowerBase):
+    """CLIP text tower (open_clip `token_embedding`, `transformer.*`, `ln_final`, `text_projection`)."""
+
+    def __init__(self, arch: ClipTextArch, sd: Dict[str, Tensor], device: str):
+        super().__init__(device)
+        self.arch = arch
+        W = arch.width
+        h = self._h
+        self._blocks = _clip_blocks(h, sd, "transformer.", arch.layers, W, arch.mlp_dim)
+        self.w = L.ClipTextWeights(
+            tok_emb=h.f32(_need(sd, "token_embedding.weight", (arch.vocab, W))),
+            pos=h.f32(_need(sd, "positional_embedding", (arch.ctx, W))),
+            blocks=self._blocks,
+            ln_final_g=h.f32(_need(sd, "ln_final.weight", (W,))), ln_final_b=h.f32(_need(sd, "ln_final.bias", (W,))),
+            proj_w=h.bf16(_need(sd, "text_projection", (W, arch.out_dim)).detach().to(torch.float32).t()))
+        self.cfg = L.ClipTextCfg(enc=_encoder_cfg(W, arch.layers, arch.heads, arch.mlp_dim, arch.quick_gelu, False,
+                                                  L.MQ_MASK_CAUSAL, arch.ln_eps),
+                                 vocab=arch.vocab, ctx=arch.ctx, out_dim=arch.out_dim)
+
+    def encode_ids(self, ids: Tensor, normalize: bool = True, pack: bool = True) -> Tensor:
+        """ids: int [n, ctx] zero-padded CLIP token ids (SOT ... EOT 0 0 ...), host or device.
+        pack=True runs each sequence only up to its EOT (= argmax id, the pooled position): the later
+        positions cannot influence that row under the causal mask.  pack=False runs all ctx positions
+        like the reference does."""
+        if ids.ndim != 2 or ids.shape[1] > self.arch.ctx:
+            raise ValueError(f"expected ids [n, <= {self.arch.ctx}], got {tuple(ids.shape)}")
+        ids_h = ids.detach().to("cpu", torch.int64)
+        n, S = ids_h.shape
+        eot = ids_h.argmax(dim=1)
+        lengths = (eot + 1) if pack else torch.full((n,), S, dtype=torch.int64)
+        out = torch.empty(n, self.arch.out_dim, dtype=torch.float32, device=self.device)
+        with self._lock, torch.cuda.device(self.device):
+            for a, b in self._chunks(lengths):
+                packed, cu = _pack(ids_h[a:b], lengths[a:b])
+                pool_rows = None if pack else (cu[:-1].to(torch.int64) + eot[a:b]).to(torch.int32)
+                d_ids = packed.to(self.device, non_blocking=True)
+                d_cu = cu.to(self.device, non_blocking=True)
+                d_pool = pool_rows.to(self.device) if pool_rows is not None else None
+                rows, nseq = packed.numel(), b - a
+                need = self.lib.mq_clip_text_workspace_bytes(C.byref(self.cfg), rows, nseq)
+                ws = self._workspace(need)
+                L.check(self.lib.mq_encode_clip_text(C.byref(self.cfg), C.byref(self.w), d_ids.data_ptr(), d_cu.data_ptr(),
+                                                     cu.data_ptr(), nseq, L.ptr(d_pool), out[a:b].data_ptr(),
+                                                     1 if normalize else 0, ws.data_ptr(), ws.numel(), self._stream()),
+                        "mq_encode_clip_text")
+        return out
+
+
+class BertTower(_TextTowerBase):
+    """BERT-family encoder + pooling (HF `BertModel` checkpoint tensors, with or without a `bert.` prefix)."""
+
+    def __init__(self, arch: BertArch, sd: Dict[str, Tensor], device: str, pooling: str = "mean"):
+        super().__init__(device)
+        self.arch = arch
+        if pooling not in ("mean", "cls"):
+            raise ValueError(f"pooling must be 'mean' or 'cls', got {pooling!r}")
+        self.pooling = pooling
+        if "embeddings.word_embeddings.weight" not in sd and "bert.embeddings.word_embeddings.weight" in sd:
+            sd = {k[len("bert."):]: v for k, v in sd.items() if k.startswith("bert.")}
+        W, F = arch.width, arch.mlp_dim
+        h = self._h
+        arr = (L.BlockWeights * arch.layers)()
+        for i in range(arch.layers):
+            p = f"encoder.layer.{i}."
+            b = arr[i]
+            qkv_w = torch.cat([_need(sd, p + f"attention.self.{n}.weight", (W, W)).detach().float() for n in ("query", "key", "value")], 0)
+            qkv_b = torch.cat([_need(sd, p + f"attention.self.{n}.bias", (W,)).detach().float() for n in ("query", "key", "value")], 0)
+            b.qkv_w, b.qkv_b = h.bf16(qkv_w), h.f32(qkv_b)
+            b.out_w = h.bf16(_need(sd, p + "attention.output.dense.weight", (W, W)))
+            b.out_b = h.f32(_need(sd, p + "attention.output.dense.bias", (W,)))
+            b.ln1_g = h.f32(_need(sd, p + "attention.output.LayerNorm.weight", (W,)))
+            b.ln1_b = h.f32(_need(sd, p + "attention.output.LayerNorm.bias", (W,)))
+            b.fc1_w = h.bf16(_need(sd, p + "intermediate.dense.weight", (F, W)))
+            b.fc1_b = h.f32(_need(sd, p + "intermediate.dense.bias", (F,)))
+            b.fc2_w = h.bf16(_need(sd, p + "output.dense.weight", (W, F)))
+            b.fc2_b = h.f32(_need(sd, p + "output.dense.bias", (W,)))
+            b.ln2_g = h.f32(_need(sd, p + "output.LayerNorm.weight", (W,)))
+            b.ln2_b = h.f32(_need(sd, p + "output.LayerNorm.bias", (W,)))
+        self._blocks = arr
+        self.w = L.BertWeights(
+            word_emb=h.f32(_need(sd, "embeddings.word_embeddings.weight", (arch.vocab, W))),
+            pos_emb=h.f32(_need(sd, "embeddings.position_embeddings.weight", (arch.max_pos, W))),
+            type_emb=h.f32(_need(sd, "embeddings.token_type_embeddings.weight")),
+            emb_ln_g=h.f32(_need(sd, "embeddings.LayerNorm.weight", (W,))),
+            emb_ln_b=h.f32(_need(sd, "embeddings.LayerNorm.bias", (W,))),
+            blocks=arr)
+        self.cfg = L.BertCfg(enc=_encoder_cfg(W, arch.layers, arch.heads, F, False, True, L.MQ_MASK_NONE, arch.ln_eps),
+                             vocab=arch.vocab, max_pos=arch.max_pos,
+                             pool=L.MQ_POOL_MEAN if pooling == "mean" else L.MQ_POOL_CLS)
+
+    def encode_ids(self, ids: Tensor, attention_mask: Tensor, normalize: bool = True) -> Tensor:
+        """ids / attention_mask: int [n, S] as produced by the HF tokenizer call of the reference
+        (hugging_face_model.py:179-185: padding=True, right-padded).  Only mask==1 tokens are run."""
+        if ids.shape != attention_mask.shape or ids.ndim != 2:
+            raise ValueError("ids and attention_mask must both be [n, S]")
+        ids_h = ids.detach().to("cpu", torch.int64)
+        mask_h = attention_mask.detach().to("cpu", torch.int64)
+        n, S = ids_h.shape
+        lengths = mask_h.sum(dim=1)
+        if bool((lengths < 1).any()):
+            raise ValueError("every sequence needs at least one unmasked token")
+        prefix = torch.arange(S).unsqueeze(0) < lengths.unsqueeze(1)
+        if not bool((mask_h.bool() == prefix).all()):
+            raise ValueError("attention_mask must be right-padded (a prefix of ones per row)")
+        if int(lengths.max()) > self.arch.max_pos:
+            raise ValueError(f"sequence longer than max_position_embeddings={self.arch.max_pos}")
+        out = torch.empty(n, self.arch.width, dtype=torch.float32, device=self.device)
+        with self._lock, torch.cuda.device(self.device):
+            for a, b in self._chunks(lengths):
+                packed, cu = _pack(ids_h[a:b], lengths[a:b])
+                d_ids = packed.to(self.device, non_blocking=True)
+                d_cu = cu.to(self.device, non_blocking=True)
+                rows, nseq = packed.numel(), b - a
+                need = self.lib.mq_bert_workspace_bytes(C.byref(self.cfg), rows, nseq)
+                ws = self._workspace(need)
+                L.check(self.lib.mq_encode_bert(C.byref(self.cfg), C.byref(self.w), d_ids.data_ptr(), d_cu.data_ptr(),
+                                                cu.data_ptr(), nseq, out[a:b].data_ptr(), 1 if normalize else 0,
+                                                ws.data_ptr(), ws.numel(), self._stream()), "mq_encode_bert")
+        return out

@@ -1,0 +1,364 @@
+"""ORACLE — test infrastructure only.  Never imported by the product (marqo_amd/*).
+
+CPU fp32 restatement of the arithmetic behind Marqo's ``s2_inference.vectorise()`` hot path.
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this package, and only as the checker / reported baseline.
+
+Where the algorithm lives
+-------------------------
+The reference (marqo-ai/marqo v2.13.0) authors no tensor arithmetic; its wrappers call into
+un-vendored wheels pinned in ``requirements.dev.txt``: ``open_clip_torch==2.24.0`` (ViT image
+tower and CLIP text tower), ``transformers==4.41.2`` (``BertModel`` behind ``AutoModel``),
+``torch==1.12.1``.  The functions below restate the published forward passes of those modules and
+follow the reference's own call sites for everything around them:
+
+* ``vit_forward``        <- ``OPEN_CLIP.encode_image`` -> ``model.encode_image``
+                            (src/marqo/core/inference/embedding_models/open_clip_model.py:249-266;
+                            fp32 path = the ``device == 'cpu'`` branch :259-260)
+* ``clip_text_forward``  <- ``OPEN_CLIP.encode_text`` -> ``model.encode_text`` (:268-286)
+* ``bert_forward`` / ``hf_encode`` <- ``HuggingFaceModel.encode`` + ``_average_pool_func`` /
+                            ``_cls_pool_func`` + ``F.normalize``
+                            (src/marqo/core/inference/embedding_models/hugging_face_model.py:172-214)
+* ``l2_normalize_clip``  <- ``outputs /= self.normalize(outputs)`` (open_clip_model.py:262-265,
+                            abstract_clip_model.py:83-85)
+
+Pinning status
+--------------
+* BERT path: PINNED against ``transformers.BertModel`` (the class the reference instantiates through
+  ``AutoModel``) run in this container with shared weights; golden vectors committed under
+  ``tests/golden/`` by ``tests/golden/make_golden.py`` (transformers 5.15 here vs 4.41.2 pinned by
+  the reference: same BertModel arithmetic).
+* CLIP ViT / text towers: pinned against ``transformers.CLIPVisionModelWithProjection`` /
+  ``CLIPTextModelWithProjection`` (an independent implementation of the same published
+  architecture; ``open_clip`` itself is not installable here).  The reference holds NO golden vector
+  for ``open_clip/ViT-B-32/laion2b_s34b_b79k`` or ``ViT-L-14`` and real checkpoints are unavailable
+  offline -> for real open_clip weights parity remains **unpinned** (SURVEY.md §8c).
+
+State-dict conventions: open_clip names for CLIP (``visual.*``, ``transformer.resblocks.*``,
+``token_embedding.weight`` ...), HuggingFace names for BERT (``embeddings.*``, ``encoder.layer.*``).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+
+OPENAI_DATASET_MEAN = (0.48145466, 0.4578275, 0.40821073)  # clip_utils.py:32
+OPENAI_DATASET_STD = (0.26862954, 0.26130258, 0.27577711)  # clip_utils.py:33
+
+
+# --------------------------------------------------------------------------------------------
+# configs
+# --------------------------------------------------------------------------------------------
+@dataclass
+class VitConfig:
+    image_size: int = 224
+    patch_size: int = 32
+    width: int = 768
+    layers: int = 12
+    heads: int = 12
+    mlp_dim: int = 3072
+    out_dim: int = 512
+    quick_gelu: bool = False
+    ln_eps: float = 1e-5
+
+    @property
+    def tokens(self) -> int:
+        return (self.image_size // self.patch_size) ** 2 + 1
+
+
+@dataclass
+class ClipTextConfig:
+    vocab: int = 49408
+    ctx: int = 77
+    width: int = 512
+    layers: int = 12
+    heads: int = 8
+    mlp_dim: int = 2048
+    out_dim: int = 512
+    quick_gelu: bool = False
+    ln_eps: float = 1e-5
+
+
+@dataclass
+class BertConfig:
+    vocab: int = 30522
+    max_pos: int = 512
+    width: int = 768
+    layers: int = 12
+    heads: int = 12
+    mlp_dim: int = 3072
+    ln_eps: float = 1e-12
+    pooling: str = "mean"  # "mean" | "cls"
+
+
+# --------------------------------------------------------------------------------------------
+# shared pieces
+# --------------------------------------------------------------------------------------------
+def _act(x: Tensor, quick: bool) -> Tensor:
+    if quick:
+        return x * torch.sigmoid(1.702 * x)  # open_clip QuickGELU
+    return F.gelu(x)  # nn.GELU (erf)
+
+
+def _mha(x: Tensor, in_w: Tensor, in_b: Tensor, out_w: Tensor, out_b: Tensor, heads: int,
+         attn_mask: Optional[Tensor]) -> Tensor:
+    """nn.MultiheadAttention(batch_first) forward, self-attention, no dropout.  x: [B, T, W];
+    attn_mask: additive, broadcastable to [B, heads, T, T]."""
+    B, T, W = x.shape
+    hd = W // heads
+    qkv = F.linear(x, in_w, in_b)
+    q, k, v = qkv.split(W, dim=-1)
+    q = q.view(B, T, heads, hd).transpose(1, 2)
+    k = k.view(B, T, heads, hd).transpose(1, 2)
+    v = v.view(B, T, heads, hd).transpose(1, 2)
+    s = (q @ k.transpose(-1, -2)) / math.sqrt(hd)
+    if attn_mask is not None:
+        s = s + attn_mask
+    p = torch.softmax(s, dim=-1)
+    o = (p @ v).transpose(1, 2).reshape(B, T, W)
+    return F.linear(o, out_w, out_b)
+
+
+def _clip_resblocks(x: Tensor, sd: Dict[str, Tensor], prefix: str, layers: int, heads: int, quick: bool,
+                    eps: float, attn_mask: Optional[Tensor]) -> Tensor:
+    """open_clip ResidualAttentionBlock stack (pre-LN):
+    x = x + attn(ln_1(x)); x = x + mlp(ln_2(x))."""
+    W = x.shape[-1]
+    for i in range(layers):
+        p = f"{prefix}resblocks.{i}."
+        h = F.layer_norm(x, (W,), sd[p + "ln_1.weight"], sd[p + "ln_1.bias"], eps)
+        x = x + _mha(h, sd[p + "attn.in_proj_weight"], sd[p + "attn.in_proj_bias"],
+                     sd[p + "attn.out_proj.weight"], sd[p + "attn.out_proj.bias"], heads, attn_mask)
+        h = F.layer_norm(x, (W,), sd[p + "ln_2.weight"], sd[p + "ln_2.bias"], eps)
+        h = _act(F.linear(h, sd[p + "mlp.c_fc.weight"], sd[p + "mlp.c_fc.bias"]), quick)
+        x = x + F.linear(h, sd[p + "mlp.c_proj.weight"], sd[p + "mlp.c_proj.bias"])
+    return x
+
+
+def l2_normalize_clip(x: Tensor) -> Tensor:
+    """open_clip_model.py:262-265: outputs /= outputs.norm(dim=-1, keepdim=True)"""
+    return x / x.norm(dim=-1, keepdim=True)
+
+
+# --------------------------------------------------------------------------------------------
+# towers
+# --------------------------------------------------------------------------------------------
+@torch.no_grad()
+def vit_forward(sd: Dict[str, Tensor], cfg: VitConfig, pixels: Tensor, normalize: bool = True) -> Tensor:
+    """open_clip VisionTransformer.forward + encode_image's projection.
+    pixels: fp32 [B, 3, S, S], already preprocessed (clip_utils.py:48-67)."""
+    W = cfg.width
+    x = F.conv2d(pixels, sd["visual.conv1.weight"], None, stride=cfg.patch_size)  # [B, W, G, G], no bias
+    B = x.shape[0]
+    x = x.reshape(B, W, -1).permute(0, 2, 1)  # [B, np, W]
+    cls = sd["visual.class_embedding"].to(x.dtype).expand(B, 1, W)
+    x = torch.cat([cls, x], dim=1) + sd["visual.positional_embedding"]
+    x = F.layer_norm(x, (W,), sd["visual.ln_pre.weight"], sd["visual.ln_pre.bias"], cfg.ln_eps)
+    x = _clip_resblocks(x, sd, "visual.transformer.", cfg.layers, cfg.heads, cfg.quick_gelu, cfg.ln_eps, None)
+    pooled = F.layer_norm(x[:, 0], (W,), sd["visual.ln_post.weight"], sd["visual.ln_post.bias"], cfg.ln_eps)
+    out = pooled @ sd["visual.proj"]
+    return l2_normalize_clip(out) if normalize else out
+
+
+@torch.no_grad()
+def clip_text_forward(sd: Dict[str, Tensor], cfg: ClipTextConfig, ids: Tensor, normalize: bool = True) -> Tensor:
+    """open_clip CLIP.encode_text: token embedding + positional, causal pre-LN transformer, ln_final,
+    row at argmax(id) (EOT), @ text_projection.  ids: int64 [B, ctx] zero-padded."""
+    B, T = ids.shape
+    W = cfg.width
+    x = sd["token_embedding.weight"][ids] + sd["positional_embedding"][:T]
+    mask = torch.full((T, T), float("-inf")).triu(1)
+    x = _clip_resblocks(x, sd, "transformer.", cfg.layers, cfg.heads, cfg.quick_gelu, cfg.ln_eps, mask)
+    x = F.layer_norm(x, (W,), sd["ln_final.weight"], sd["ln_final.bias"], cfg.ln_eps)
+    pooled = x[torch.arange(B), ids.argmax(dim=-1)]
+    out = pooled @ sd["text_projection"]
+    return l2_normalize_clip(out) if normalize else out
+
+
+@torch.no_grad()
+def bert_forward(sd: Dict[str, Tensor], cfg: BertConfig, ids: Tensor, attention_mask: Tensor) -> Tensor:
+    """transformers BertModel forward (absolute positions, token_type_ids = 0, eval mode)
+    -> last_hidden_state [B, S, W]."""
+    B, S = ids.shape
+    W, H = cfg.width, cfg.heads
+    x = (sd["embeddings.word_embeddings.weight"][ids]
+         + sd["embeddings.token_type_embeddings.weight"][torch.zeros_like(ids)]
+         + sd["embeddings.position_embeddings.weight"][:S])
+    x = F.layer_norm(x, (W,), sd["embeddings.LayerNorm.weight"], sd["embeddings.LayerNorm.bias"], cfg.ln_eps)
+    # additive key-padding mask: (1 - mask) * finfo.min
+    add_mask = (1.0 - attention_mask[:, None, None, :].to(x.dtype)) * torch.finfo(x.dtype).min
+    hd = W // H
+    for i in range(cfg.layers):
+        p = f"encoder.layer.{i}."
+        q = F.linear(x, sd[p + "attention.self.query.weight"], sd[p + "attention.self.query.bias"])
+        k = F.linear(x, sd[p + "attention.self.key.weight"], sd[p + "attention.self.key.bias"])
+        v = F.linear(x, sd[p + "attention.self.value.weight"], sd[p + "attention.self.value.bias"])
+        q = q.view(B, S, H, hd).transpose(1, 2)
+        k = k.view(B, S, H, hd).transpose(1, 2)
+        v = v.view(B, S, H, hd).transpose(1, 2)
+        s = (q @ k.transpose(-1, -2)) / math.sqrt(hd) + add_mask
+        a = (torch.softmax(s, dim=-1) @ v).transpose(1, 2).reshape(B, S, W)
+        a = F.linear(a, sd[p + "attention.output.dense.weight"], sd[p + "attention.output.dense.bias"])
+        x = F.layer_norm(a + x, (W,), sd[p + "attention.output.LayerNorm.weight"],
+                         sd[p + "attention.output.LayerNorm.bias"], cfg.ln_eps)
+        h = F.gelu(F.linear(x, sd[p + "intermediate.dense.weight"], sd[p + "intermediate.dense.bias"]))
+        h = F.linear(h, sd[p + "output.dense.weight"], sd[p + "output.dense.bias"])
+        x = F.layer_norm(h + x, (W,), sd[p + "output.LayerNorm.weight"], sd[p + "output.LayerNorm.bias"], cfg.ln_eps)
+    return x
+
+
+@torch.no_grad()
+def hf_encode(sd: Dict[str, Tensor], cfg: BertConfig, ids: Tensor, attention_mask: Tensor,
+              normalize: bool = True) -> Tensor:
+    """HuggingFaceModel.encode after tokenisation (hugging_face_model.py:187-197)."""
+    last = bert_forward(sd, cfg, ids, attention_mask)
+    if cfg.pooling == "mean":  # _average_pool_func :205-209
+        last = last.masked_fill(~attention_mask[..., None].bool(), 0.0)
+        emb = last.sum(dim=1) / attention_mask.sum(dim=1)[..., None]
+    elif cfg.pooling == "cls":  # _cls_pool_func :211-214
+        emb = last[:, 0]
+    else:
+        raise ValueError(cfg.pooling)
+    if normalize:
+        emb = F.normalize(emb, p=2, dim=1)
+    return emb
+
+
+# --------------------------------------------------------------------------------------------
+# synthetic weights (seeded) in the checkpoint naming the loaders consume
+# --------------------------------------------------------------------------------------------
+def _g(seed: int) -> torch.Generator:
+    return torch.Generator().manual_seed(seed)
+
+
+def _blocks_clip(sd, prefix, layers, W, F_, g, std):
+    for i in range(layers):
+        p = f"{prefix}resblocks.{i}."
+        sd[p + "ln_1.weight"] = 1 + 0.1 * torch.randn(W, generator=g)
+        sd[p + "ln_1.bias"] = 0.05 * torch.randn(W, generator=g)
+        sd[p + "attn.in_proj_weight"] = std * torch.randn(3 * W, W, generator=g)
+        sd[p + "attn.in_proj_bias"] = 0.02 * torch.randn(3 * W, generator=g)
+        sd[p + "attn.out_proj.weight"] = std * torch.randn(W, W, generator=g)
+        sd[p + "attn.out_proj.bias"] = 0.02 * torch.randn(W, generator=g)
+        sd[p + "ln_2.weight"] = 1 + 0.1 * torch.randn(W, generator=g)
+        sd[p + "ln_2.bias"] = 0.05 * torch.randn(W, generator=g)
+        sd[p + "mlp.c_fc.weight"] = std * torch.randn(F_, W, generator=g)
+        sd[p + "mlp.c_fc.bias"] = 0.02 * torch.randn(F_, generator=g)
+        sd[p + "mlp.c_proj.weight"] = std * torch.randn(W, F_, generator=g)
+        sd[p + "mlp.c_proj.bias"] = 0.02 * torch.randn(W, generator=g)
+
+
+def synthetic_vit_state_dict(cfg: VitConfig, seed: int = 0) -> Dict[str, Tensor]:
+    """Seeded weights with non-trivial LN affine / biases (so a dropped bias or swapped gamma/beta
+    cannot pass), scaled so activations stay O(1) through the stack."""
+    g = _g(seed)
+    W = cfg.width
+    std = 1.0 / math.sqrt(W)
+    sd: Dict[str, Tensor] = {}
+    sd["visual.conv1.weight"] = torch.randn(W, 3, cfg.patch_size, cfg.patch_size, generator=g) / math.sqrt(3 * cfg.patch_size ** 2)
+    sd["visual.class_embedding"] = 0.5 * torch.randn(W, generator=g)
+    sd["visual.positional_embedding"] = 0.3 * torch.randn(cfg.tokens, W, generator=g)
+    sd["visual.ln_pre.weight"] = 1 + 0.1 * torch.randn(W, generator=g)
+    sd["visual.ln_pre.bias"] = 0.05 * torch.randn(W, generator=g)
+    _blocks_clip(sd, "visual.transformer.", cfg.layers, W, cfg.mlp_dim, g, 0.6 * std)
+    sd["visual.ln_post.weight"] = 1 + 0.1 * torch.randn(W, generator=g)
+    sd["visual.ln_post.bias"] = 0.05 * torch.randn(W, generator=g)
+    sd["visual.proj"] = std * torch.randn(W, cfg.out_dim, generator=g)
+    return sd
+
+
+def synthetic_clip_text_state_dict(cfg: ClipTextConfig, seed: int = 0) -> Dict[str, Tensor]:
+    g = _g(seed + 1000)
+    W = cfg.width
+    std = 1.0 / math.sqrt(W)
+    sd: Dict[str, Tensor] = {}
+    sd["token_embedding.weight"] = 0.5 * torch.randn(cfg.vocab, W, generator=g)
+    sd["positional_embedding"] = 0.3 * torch.randn(cfg.ctx, W, generator=g)
+    _blocks_clip(sd, "transformer.", cfg.layers, W, cfg.mlp_dim, g, 0.6 * std)
+    sd["ln_final.weight"] = 1 + 0.1 * torch.randn(W, generator=g)
+    sd["ln_final.bias"] = 0.05 * torch.randn(W, generator=g)
+    sd["text_projection"] = std * torch.randn(W, cfg.out_dim, generator=g)
+    return sd
+
+
+def synthetic_bert_state_dict(cfg: BertConfig, seed: int = 0) -> Dict[str, Tensor]:
+    g = _g(seed + 2000)
+    W, F_ = cfg.width, cfg.mlp_dim
+    std = 0.6 / math.sqrt(W)
+    sd: Dict[str, Tensor] = {}
+    sd["embeddings.word_embeddings.weight"] = 0.5 * torch.randn(cfg.vocab, W, generator=g)
+    sd["embeddings.position_embeddings.weight"] = 0.3 * torch.randn(cfg.max_pos, W, generator=g)
+    sd["embeddings.token_type_embeddings.weight"] = 0.3 * torch.randn(2, W, generator=g)
+    sd["embeddings.LayerNorm.weight"] = 1 + 0.1 * torch.randn(W, generator=g)
+    sd["embeddings.LayerNorm.bias"] = 0.05 * torch.randn(W, generator=g)
+    for i in range(cfg.layers):
+        p = f"encoder.layer.{i}."
+        for nm in ("query", "key", "value"):
+            sd[p + f"attention.self.{nm}.weight"] = std * torch.randn(W, W, generator=g)
+            sd[p + f"attention.self.{nm}.bias"] = 0.02 * torch.randn(W, generator=g)
+        sd[p + "attention.output.dense.weight"] = std * torch.randn(W, W, generator=g)
+        sd[p + "attention.output.dense.bias"] = 0.02 * torch.randn(W, generator=g)
+        sd[p + "attention.output.LayerNorm.weight"] = 1 + 0.1 * torch.randn(W, generator=g)
+        sd[p + "attention.output.LayerNorm.bias"] = 0.05 * torch.randn(W, generator=g)
+        sd[p + "intermediate.dense.weight"] = std * torch.randn(F_, W, generator=g)
+        sd[p + "intermediate.dense.bias"] = 0.02 * torch.randn(F_, generator=g)
+        sd[p + "output.dense.weight"] = std * torch.randn(W, F_, generator=g)
+        sd[p + "output.dense.bias"] = 0.02 * torch.randn(W, generator=g)
+        sd[p + "output.LayerNorm.weight"] = 1 + 0.1 * torch.randn(W, generator=g)
+        sd[p + "output.LayerNorm.bias"] = 0.05 * torch.randn(W, generator=g)
+    return sd
+
+
+# --------------------------------------------------------------------------------------------
+# synthetic inputs
+# --------------------------------------------------------------------------------------------
+def synthetic_images_u8(n: int, size: int = 224, seed: int = 0) -> torch.Tensor:
+    """uint8 HWC [n, size, size, 3] ~ U{0..255}."""
+    return torch.randint(0, 256, (n, size, size, 3), generator=_g(seed + 3000), dtype=torch.uint8)
+
+
+def preprocess_u8_exact_size(images_u8: Tensor, mean: Sequence[float] = OPENAI_DATASET_MEAN,
+                             std: Sequence[float] = OPENAI_DATASET_STD) -> Tensor:
+    """The tail of clip_utils.py:61-66 for images already at model resolution (Resize and CenterCrop
+    are identities): ToTensor (/255, HWC->CHW) then Normalize(mean, std).  fp32 [n, 3, S, S]."""
+    x = images_u8.permute(0, 3, 1, 2).to(torch.float32).div(255)
+    m = torch.tensor(mean, dtype=torch.float32).view(1, 3, 1, 1)
+    s = torch.tensor(std, dtype=torch.float32).view(1, 3, 1, 1)
+    return (x - m) / s
+
+
+def synthetic_clip_ids(n: int, ctx: int = 77, vocab: int = 49408, seed: int = 0, full_length: bool = False
+                       ) -> torch.Tensor:
+    """int64 [n, ctx]: SOT (vocab-2), L_i tokens in [1, vocab-3], EOT (vocab-1, the max id), zero pad.
+    full_length=True puts EOT at the last position (every sequence runs all ctx tokens)."""
+    g = _g(seed + 4000)
+    ids = torch.zeros(n, ctx, dtype=torch.int64)
+    for i in range(n):
+        L = ctx - 2 if full_length else int(torch.randint(5, ctx - 1, (1,), generator=g))
+        ids[i, 0] = vocab - 2
+        ids[i, 1:1 + L] = torch.randint(1, vocab - 2, (L,), generator=g)
+        ids[i, 1 + L] = vocab - 1
+    return ids
+
+
+def synthetic_bert_batch(n: int, min_len: int = 8, max_len: int = 32, vocab: int = 30522, seed: int = 0,
+                         fixed_len: Optional[int] = None):
+    """ids int64 [n, S] right-padded with 0 + attention_mask: [CLS]=101 ... [SEP]=102."""
+    g = _g(seed + 5000)
+    lens = [fixed_len or int(torch.randint(min_len, max_len + 1, (1,), generator=g)) for _ in range(n)]
+    S = max(lens)
+    ids = torch.zeros(n, S, dtype=torch.int64)
+    mask = torch.zeros(n, S, dtype=torch.int64)
+    lo = min(1000, vocab // 2)
+    for i, L in enumerate(lens):
+        ids[i, 0] = 101 if vocab > 102 else 1
+        ids[i, 1:L - 1] = torch.randint(lo, vocab, (L - 2,), generator=g)
+        ids[i, L - 1] = 102 if vocab > 102 else 2
+        mask[i, :L] = 1
+    return ids, mask

@@ -1,0 +1,172 @@
+"""Generate the golden fixtures that PIN oracle/towers.py to an independent implementation.
+
+Run in the build container (no GPU needed):  python tests/golden/make_golden.py
+
+For each tower a SMALL model of the real architecture is instantiated from ``transformers``
+(5.15 here; the reference pins 4.41.2 — same module arithmetic) with seeded random weights,
+run on seeded inputs in fp32 on CPU, and the (weights, inputs, outputs) triple is stored as
+``tests/golden/<name>.npz`` with the weights renamed to the checkpoint naming the loaders consume
+(open_clip names for CLIP, HuggingFace names for BERT).
+
+* ``bert_small``      transformers.BertModel  == what HuggingFaceModel loads through AutoModel
+                      (hugging_face_model.py:125-130); pooled / normalised exactly as
+                      hugging_face_model.py:187-214.
+* ``clip_vit_small``  transformers.CLIPVisionModelWithProjection (gelu and quick_gelu variants)
+* ``clip_text_small`` transformers.CLIPTextModelWithProjection (argmax-EOT pooling)
+
+Head dim is 64 in every fixture (the engine's attention kernel is specialised for d_head = 64, as
+are all four towers of BASELINE.json's configs).
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+
+def _np(sd):
+    return {k: v.detach().cpu().numpy().astype(np.float32) for k, v in sd.items()}
+
+
+def _jitter(model, seed):
+    """HF init leaves LayerNorm at (1, 0) and biases at 0; perturb them so that a dropped bias or a
+    swapped gamma/beta cannot pass the parity tests."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if p.ndim == 1:
+                p.add_(0.1 * torch.randn(p.shape, generator=g))
+            else:
+                p.mul_(3.0)  # HF init std 0.02 would make every block a near no-op
+
+
+def make_bert():
+    from transformers import BertConfig, BertModel
+    torch.manual_seed(0)
+    cfg = BertConfig(vocab_size=300, hidden_size=128, num_hidden_layers=2, num_attention_heads=2,
+                     intermediate_size=256, max_position_embeddings=64, layer_norm_eps=1e-12,
+                     hidden_act="gelu", hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    m = BertModel(cfg).eval()
+    _jitter(m, 1)
+    g = torch.Generator().manual_seed(2)
+    lens = [5, 17, 1 + 1, 33, 64, 9]
+    S = max(lens)
+    ids = torch.zeros(len(lens), S, dtype=torch.int64)
+    mask = torch.zeros(len(lens), S, dtype=torch.int64)
+    for i, L in enumerate(lens):
+        ids[i, :L] = torch.randint(3, 300, (L,), generator=g)
+        mask[i, :L] = 1
+    with torch.no_grad():
+        out = m(input_ids=ids, attention_mask=mask)
+    last = out.last_hidden_state
+    # hugging_face_model.py:205-209, 194-195
+    lh = last.masked_fill(~mask[..., None].bool(), 0.0)
+    mean = lh.sum(1) / mask.sum(1)[..., None]
+    mean_n = torch.nn.functional.normalize(mean, p=2, dim=1)
+    cls = last[:, 0]
+    cls_n = torch.nn.functional.normalize(cls, p=2, dim=1)
+    sd = {k: v for k, v in m.state_dict().items() if not k.startswith("pooler.")}
+    np.savez_compressed(os.path.join(HERE, "bert_small.npz"),
+                        ids=ids.numpy(), mask=mask.numpy(), last_hidden=last.numpy(),
+                        mean=mean.numpy(), mean_norm=mean_n.numpy(), cls=cls.numpy(), cls_norm=cls_n.numpy(),
+                        cfg=np.array([300, 64, 128, 2, 2, 256], dtype=np.int64),  # vocab max_pos W layers heads F
+                        **{"w:" + k: v for k, v in _np(sd).items()})
+
+
+def _clip_blocks_to_open_clip(hf_sd, hf_prefix, oc_prefix, layers):
+    out = {}
+    for i in range(layers):
+        s = f"{hf_prefix}encoder.layers.{i}."
+        d = f"{oc_prefix}resblocks.{i}."
+        out[d + "ln_1.weight"] = hf_sd[s + "layer_norm1.weight"]
+        out[d + "ln_1.bias"] = hf_sd[s + "layer_norm1.bias"]
+        out[d + "attn.in_proj_weight"] = torch.cat([hf_sd[s + f"self_attn.{n}_proj.weight"] for n in "qkv"], 0)
+        out[d + "attn.in_proj_bias"] = torch.cat([hf_sd[s + f"self_attn.{n}_proj.bias"] for n in "qkv"], 0)
+        out[d + "attn.out_proj.weight"] = hf_sd[s + "self_attn.out_proj.weight"]
+        out[d + "attn.out_proj.bias"] = hf_sd[s + "self_attn.out_proj.bias"]
+        out[d + "ln_2.weight"] = hf_sd[s + "layer_norm2.weight"]
+        out[d + "ln_2.bias"] = hf_sd[s + "layer_norm2.bias"]
+        out[d + "mlp.c_fc.weight"] = hf_sd[s + "mlp.fc1.weight"]
+        out[d + "mlp.c_fc.bias"] = hf_sd[s + "mlp.fc1.bias"]
+        out[d + "mlp.c_proj.weight"] = hf_sd[s + "mlp.fc2.weight"]
+        out[d + "mlp.c_proj.bias"] = hf_sd[s + "mlp.fc2.bias"]
+    return out
+
+
+def make_clip_vit():
+    from transformers import CLIPVisionConfig, CLIPVisionModelWithProjection
+    outs = {}
+    sd_oc = None
+    px = None
+    for act in ("gelu", "quick_gelu"):
+        torch.manual_seed(3)
+        cfg = CLIPVisionConfig(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2,
+                               image_size=64, patch_size=16, projection_dim=64, hidden_act=act, layer_norm_eps=1e-5,
+                               attention_dropout=0.0)
+        m = CLIPVisionModelWithProjection(cfg).eval()
+        _jitter(m, 4)
+        hf = m.state_dict()
+        g = torch.Generator().manual_seed(5)
+        px = torch.randn(5, 3, 64, 64, generator=g)
+        with torch.no_grad():
+            emb = m(pixel_values=px).image_embeds
+        outs[act] = emb.numpy()
+        sd_oc = {
+            "visual.conv1.weight": hf["vision_model.embeddings.patch_embedding.weight"],
+            "visual.class_embedding": hf["vision_model.embeddings.class_embedding"],
+            "visual.positional_embedding": hf["vision_model.embeddings.position_embedding.weight"],
+            "visual.ln_pre.weight": hf["vision_model.pre_layrnorm.weight"],
+            "visual.ln_pre.bias": hf["vision_model.pre_layrnorm.bias"],
+            "visual.ln_post.weight": hf["vision_model.post_layernorm.weight"],
+            "visual.ln_post.bias": hf["vision_model.post_layernorm.bias"],
+            "visual.proj": hf["visual_projection.weight"].t().contiguous(),
+        }
+        sd_oc.update(_clip_blocks_to_open_clip(hf, "vision_model.", "visual.transformer.", 2))
+    np.savez_compressed(os.path.join(HERE, "clip_vit_small.npz"), pixels=px.numpy(),
+                        emb_gelu=outs["gelu"], emb_quick_gelu=outs["quick_gelu"],
+                        cfg=np.array([64, 16, 128, 2, 2, 256, 64], dtype=np.int64),  # S P W layers heads F D
+                        **{"w:" + k: v for k, v in _np(sd_oc).items()})
+
+
+def make_clip_text():
+    from transformers import CLIPTextConfig, CLIPTextModelWithProjection
+    torch.manual_seed(6)
+    V, ctx = 300, 16
+    cfg = CLIPTextConfig(vocab_size=V, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                         num_attention_heads=2, max_position_embeddings=ctx, projection_dim=64, hidden_act="gelu",
+                         layer_norm_eps=1e-5, attention_dropout=0.0, eos_token_id=2, bos_token_id=1, pad_token_id=0)
+    m = CLIPTextModelWithProjection(cfg).eval()
+    _jitter(m, 7)
+    hf = m.state_dict()
+    g = torch.Generator().manual_seed(8)
+    lens = [3, 16, 9, 5, 12]
+    ids = torch.zeros(len(lens), ctx, dtype=torch.int64)
+    for i, L in enumerate(lens):
+        ids[i, 0] = V - 2
+        ids[i, 1:L - 1] = torch.randint(1, V - 2, (L - 2,), generator=g)
+        ids[i, L - 1] = V - 1  # EOT = max id -> argmax pooling
+    with torch.no_grad():
+        emb = m(input_ids=ids).text_embeds
+    sd_oc = {
+        "token_embedding.weight": hf["text_model.embeddings.token_embedding.weight"],
+        "positional_embedding": hf["text_model.embeddings.position_embedding.weight"],
+        "ln_final.weight": hf["text_model.final_layer_norm.weight"],
+        "ln_final.bias": hf["text_model.final_layer_norm.bias"],
+        "text_projection": hf["text_projection.weight"].t().contiguous(),
+    }
+    sd_oc.update(_clip_blocks_to_open_clip(hf, "text_model.", "transformer.", 2))
+    np.savez_compressed(os.path.join(HERE, "clip_text_small.npz"), ids=ids.numpy(), emb=emb.numpy(),
+                        cfg=np.array([V, ctx, 128, 2, 2, 256, 64], dtype=np.int64),  # V ctx W layers heads F D
+                        **{"w:" + k: v for k, v in _np(sd_oc).items()})
+
+
+if __name__ == "__main__":
+    make_bert()
+    make_clip_vit()
+    make_clip_text()
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(HERE, f)))

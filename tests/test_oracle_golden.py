@@ -1,0 +1,82 @@
+"""Pins oracle/towers.py: the CPU restatement must reproduce the outputs of the independent
+`transformers` implementations stored in tests/golden/ (fp32, tolerance 2e-5 absolute on O(1)
+values — accumulation-order noise only)."""
+import numpy as np
+import torch
+
+from oracle import towers as O
+from tests import golden_util as G
+
+TOL = 2e-5
+
+
+def test_bert_matches_transformers_bertmodel():
+    sd, z = G.load("bert_small")
+    V, P, W, L, H, F = [int(v) for v in z["cfg"]]
+    ids, mask = torch.from_numpy(z["ids"]), torch.from_numpy(z["mask"])
+    cfg = O.BertConfig(vocab=V, max_pos=P, width=W, layers=L, heads=H, mlp_dim=F, pooling="mean")
+    last = O.bert_forward(sd, cfg, ids, mask)
+    valid = mask.bool()
+    assert np.abs(last.numpy() - z["last_hidden"])[valid.numpy()].max() < TOL
+    assert np.abs(O.hf_encode(sd, cfg, ids, mask, normalize=False).numpy() - z["mean"]).max() < TOL
+    assert np.abs(O.hf_encode(sd, cfg, ids, mask, normalize=True).numpy() - z["mean_norm"]).max() < TOL
+    cfg.pooling = "cls"
+    assert np.abs(O.hf_encode(sd, cfg, ids, mask, normalize=False).numpy() - z["cls"]).max() < TOL
+    assert np.abs(O.hf_encode(sd, cfg, ids, mask, normalize=True).numpy() - z["cls_norm"]).max() < TOL
+
+
+def test_bert_padding_invariance():
+    """pad-to-longest changes S but not results."""
+    sd, z = G.load("bert_small")
+    V, P, W, L, H, F = [int(v) for v in z["cfg"]]
+    cfg = O.BertConfig(vocab=V, max_pos=P, width=W, layers=L, heads=H, mlp_dim=F)
+    ids, mask = torch.from_numpy(z["ids"]), torch.from_numpy(z["mask"])
+    full = O.hf_encode(sd, cfg, ids, mask)
+    one = O.hf_encode(sd, cfg, ids[:1, :5], mask[:1, :5])
+    assert torch.allclose(full[:1], one, atol=1e-5)
+
+
+def test_clip_vit_matches_transformers():
+    sd, z = G.load("clip_vit_small")
+    S, P, W, L, H, F, D = [int(v) for v in z["cfg"]]
+    px = torch.from_numpy(z["pixels"])
+    for quick, key in ((False, "emb_gelu"), (True, "emb_quick_gelu")):
+        cfg = O.VitConfig(image_size=S, patch_size=P, width=W, layers=L, heads=H, mlp_dim=F, out_dim=D, quick_gelu=quick)
+        out = O.vit_forward(sd, cfg, px, normalize=False)
+        assert np.abs(out.numpy() - z[key]).max() < TOL, key
+    assert np.abs(z["emb_gelu"] - z["emb_quick_gelu"]).max() > 1e-3  # the two activations are distinguishable
+
+
+def test_clip_text_matches_transformers():
+    sd, z = G.load("clip_text_small")
+    V, ctx, W, L, H, F, D = [int(v) for v in z["cfg"]]
+    cfg = O.ClipTextConfig(vocab=V, ctx=ctx, width=W, layers=L, heads=H, mlp_dim=F, out_dim=D)
+    out = O.clip_text_forward(sd, cfg, torch.from_numpy(z["ids"]), normalize=False)
+    assert np.abs(out.numpy() - z["emb"]).max() < TOL
+
+
+def test_clip_text_tokens_after_eot_do_not_matter():
+    """Basis for packing CLIP text to [SOT..EOT]: under the causal mask the pooled EOT row cannot see
+    later positions."""
+    sd, z = G.load("clip_text_small")
+    V, ctx, W, L, H, F, D = [int(v) for v in z["cfg"]]
+    cfg = O.ClipTextConfig(vocab=V, ctx=ctx, width=W, layers=L, heads=H, mlp_dim=F, out_dim=D)
+    ids = torch.from_numpy(z["ids"]).clone()
+    base = O.clip_text_forward(sd, cfg, ids)
+    eot = ids.argmax(-1)
+    for i in range(ids.shape[0]):
+        ids[i, eot[i] + 1:] = 7  # garbage (< EOT id) after EOT
+    assert torch.allclose(O.clip_text_forward(sd, cfg, ids), base, atol=1e-6)
+
+
+def test_unit_norm_and_preprocess_tail():
+    cfg = O.VitConfig(image_size=64, patch_size=16, width=128, layers=1, heads=2, mlp_dim=256, out_dim=64)
+    sd = O.synthetic_vit_state_dict(cfg, seed=0)
+    u8 = O.synthetic_images_u8(3, 64)
+    px = O.preprocess_u8_exact_size(u8)
+    assert px.shape == (3, 3, 64, 64) and px.dtype == torch.float32
+    # ToTensor + Normalize on a known pixel
+    r = float(u8[0, 0, 0, 0]) / 255.0
+    assert abs(px[0, 0, 0, 0].item() - (r - O.OPENAI_DATASET_MEAN[0]) / O.OPENAI_DATASET_STD[0]) < 1e-6
+    out = O.vit_forward(sd, cfg, px)
+    assert torch.allclose(out.norm(dim=-1), torch.ones(3), atol=1e-6)
