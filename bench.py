@@ -1,0 +1,191 @@
+#!/usr/bin/env python
+"""bench.py — embeddings/sec of the vectorise() hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+Workload (BASELINE.json configs[1], the config the metric is quoted on): open_clip ViT-B/32 image
+tower, synthetic uint8 224x224 RGB images already resident in HBM, 256 images per GPU per step,
+random-init weights of that architecture (no network for checkpoints).  One "step" = one pass of the
+hot path over one batch: normalise + patchify -> patch-embed GEMM -> 12 pre-LN blocks -> ln_post ->
+projection -> L2, i.e. exactly mq_encode_image_u8; for N > 1 the [256, 512] fp32 shards are then
+all-gathered over RCCL (the only collective on the path).  Work per GPU is fixed -> weak scaling.
+
+Rank 0 prints ONE JSON line.  Besides the contract keys it carries
+  roofline     — the dominant kernel (bf16 MFMA GEMM): algorithmic FLOPs / HIP-event time of its launches
+  cpu_baseline — the CPU fp32 oracle (oracle/towers.py) run with the reference's 16-item batch loop
+                 (s2_inference.py:135-146) on a bounded sample, all host cores
+  cos_err_vs_cpu — max (1 - cosine) of the GPU embeddings vs that CPU path on the same sample
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+BF16_DENSE_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
+WORKLOADS = {
+    "vit_b32_image": dict(arch="ViT-B-32", desc="open_clip ViT-B/32 image tower, uint8 224x224, batch 256/GPU", batch=256),
+    "vit_l14_image": dict(arch="ViT-L-14", desc="open_clip ViT-L/14 image tower, uint8 224x224, batch 64/GPU", batch=64),
+}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="vit_b32_image", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="images per GPU per step (default: the workload's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(sd, arch, images_u8_cpu, target_seconds):
+    """Reference-equivalent CPU path on a bounded sample; returns (emb/s, n, embeddings, cores)."""
+    from oracle import towers as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = O.VitConfig(arch.image_size, arch.patch_size, arch.width, arch.layers, arch.heads, arch.mlp_dim,
+                      arch.out_dim, arch.quick_gelu)
+
+    def run(imgs):
+        outs = []
+        for i in range(0, imgs.shape[0], 16):  # MARQO_MAX_VECTORISE_BATCH_SIZE default (api/configs.py:38)
+            outs.append(O.vit_forward(sd, cfg, O.preprocess_u8_exact_size(imgs[i:i + 16])).numpy())
+        import numpy as np
+        return np.concatenate(outs, axis=0)
+
+    run(images_u8_cpu[:16])  # warm-up
+    t0 = time.perf_counter()
+    first = run(images_u8_cpu[:16])
+    dt16 = time.perf_counter() - t0
+    n = int(min(images_u8_cpu.shape[0], max(16, (target_seconds / max(dt16, 1e-3)) * 16) // 16 * 16))
+    if n <= 16:
+        return 16 / dt16, 16, torch.from_numpy(first), cores
+    t0 = time.perf_counter()
+    emb = run(images_u8_cpu[:n])
+    dt = time.perf_counter() - t0
+    return n / dt, n, torch.from_numpy(emb), cores
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+
+    from marqo_amd import _lib as L
+    from marqo_amd.engine import archs, synthetic, towers
+    from marqo_amd.parallel import gather_embeddings
+
+    wl = WORKLOADS[args.workload]
+    batch = args.batch or wl["batch"]
+    varch, _ = archs.resolve_open_clip(wl["arch"])
+    sd = synthetic.random_open_clip_state_dict(vision=varch, seed=0)
+    tower = towers.VitTower(varch, sd, dev)
+    lib = L.load()
+
+    g = torch.Generator().manual_seed(1234 + rank)
+    images_cpu = torch.randint(0, 256, (batch, varch.image_size, varch.image_size, 3), generator=g, dtype=torch.uint8)
+    images = images_cpu.to(dev)
+
+    def step():
+        emb = tower.encode_u8(images)          # [batch, D] fp32 on device
+        if world > 1:
+            emb = gather_embeddings(emb)       # RCCL all_gather of the shards (final concat)
+        return emb
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = batch * world * args.steps / elapsed
+
+    # ---- roofline of the dominant kernel, HIP events on the launch stream (separate, instrumented steps) ----
+    lib.mq_profile_enable(1)
+    prof_steps = min(args.steps, 10)
+    for _ in range(prof_steps):
+        tower.encode_u8(images)
+    ms = (C.c_double * L.MQ_PROF_FAMILIES)()
+    cnt = (C.c_int64 * L.MQ_PROF_FAMILIES)()
+    flops = C.c_double(0.0)
+    L.check(lib.mq_profile_collect(ms, cnt, C.byref(flops)), "mq_profile_collect")
+    lib.mq_profile_enable(0)
+    gemm_ms, gemm_launches = ms[0], cnt[0]
+    achieved = flops.value / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    families = {L.PROF_FAMILY_NAMES[i]: {"ms_per_step": ms[i] / prof_steps, "launches_per_step": cnt[i] // prof_steps}
+                for i in range(L.MQ_PROF_FAMILIES) if cnt[i]}
+    roofline = {
+        "kernel": "gemm_nt_kernel (bf16 MFMA 16x16x32, 128x128x64 tiles, fused epilogues)",
+        "bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(achieved / BF16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
+        "flops_per_launch": flops.value / max(gemm_launches, 1),
+        "avg_launch_us": gemm_ms * 1e3 / max(gemm_launches, 1),
+        "launches_per_step": gemm_launches // prof_steps,
+        "per_family": families,
+    }
+    e2e_tflops = value * varch.gflop_per_image / 1e3
+    result = {
+        "metric": "embeddings/sec", "value": round(value, 1), "unit": "embeddings/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": wl["desc"], "global_batch": batch * world, "image": f"{varch.image_size}x{varch.image_size}x3 uint8",
+                   "tokens": varch.tokens, "gflop_per_embedding": round(varch.gflop_per_image, 3),
+                   "parallelism": f"dp{world} (replicated weights, sharded items, RCCL all_gather of embeddings)",
+                   "weights": "random-init (seed 0) open_clip " + wl["arch"]},
+        "e2e_tflops": round(e2e_tflops, 1), "e2e_frac_of_bf16_peak": round(e2e_tflops / (BF16_DENSE_PEAK_TFLOPS * world), 4),
+        "roofline": roofline,
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_rate, n_cpu, cpu_emb, cores = cpu_baseline(sd, varch, images_cpu, args.cpu_seconds)
+        gpu_emb = out[:n_cpu].float().cpu()
+        cos = (gpu_emb.double() * cpu_emb.double()).sum(-1) / (gpu_emb.double().norm(dim=-1) * cpu_emb.double().norm(dim=-1))
+        result["cpu_baseline"] = {"value": round(cpu_rate, 2), "unit": "embeddings/s", "cores": cores, "kind": "port",
+                                  "sample": f"{n_cpu} of the step's {batch} images, fp32 PyTorch eager, 16-image batches "
+                                            f"(reference loop s2_inference.py:135-146), {cores} threads"}
+        result["cos_err_vs_cpu"] = float((1 - cos).max())
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

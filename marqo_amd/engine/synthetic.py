@@ -1,0 +1,85 @@
+"""Random-init checkpoints of the supported architectures (there is no network for real weights).
+
+Used by bench.py and by loaders when `model_properties["synthetic_seed"]` is given explicitly; the
+tensors use the same names and shapes as real open_clip / HuggingFace checkpoints, so everything
+downstream (layout conversion, kernels) is exercised exactly as with real weights.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict
+
+import torch
+
+from marqo_amd.engine.archs import BertArch, ClipTextArch, VitArch
+
+Tensor = torch.Tensor
+
+
+def _ln(sd, name, W, g):
+    sd[name + ".weight"] = 1.0 + 0.1 * torch.randn(W, generator=g)
+    sd[name + ".bias"] = 0.05 * torch.randn(W, generator=g)
+
+
+def _lin(sd, name, out_f, in_f, g, std):
+    sd[name + ".weight"] = std * torch.randn(out_f, in_f, generator=g)
+    sd[name + ".bias"] = 0.02 * torch.randn(out_f, generator=g)
+
+
+def _resblocks(sd, prefix, layers, W, F, g):
+    std = 0.6 / math.sqrt(W)
+    for i in range(layers):
+        p = f"{prefix}resblocks.{i}."
+        _ln(sd, p + "ln_1", W, g)
+        sd[p + "attn.in_proj_weight"] = std * torch.randn(3 * W, W, generator=g)
+        sd[p + "attn.in_proj_bias"] = 0.02 * torch.randn(3 * W, generator=g)
+        _lin(sd, p + "attn.out_proj", W, W, g, std)
+        _ln(sd, p + "ln_2", W, g)
+        _lin(sd, p + "mlp.c_fc", F, W, g, std)
+        _lin(sd, p + "mlp.c_proj", W, F, g, std)
+
+
+def random_open_clip_state_dict(vision: VitArch = None, text: ClipTextArch = None, seed: int = 0) -> Dict[str, Tensor]:
+    """open_clip-named state dict for the given towers (either may be None)."""
+    g = torch.Generator().manual_seed(seed)
+    sd: Dict[str, Tensor] = {}
+    if vision is not None:
+        W, P = vision.width, vision.patch_size
+        sd["visual.conv1.weight"] = torch.randn(W, 3, P, P, generator=g) / math.sqrt(3 * P * P)
+        sd["visual.class_embedding"] = 0.5 * torch.randn(W, generator=g)
+        sd["visual.positional_embedding"] = 0.3 * torch.randn(vision.tokens, W, generator=g)
+        _ln(sd, "visual.ln_pre", W, g)
+        _resblocks(sd, "visual.transformer.", vision.layers, W, vision.mlp_dim, g)
+        _ln(sd, "visual.ln_post", W, g)
+        sd["visual.proj"] = torch.randn(W, vision.out_dim, generator=g) / math.sqrt(W)
+    if text is not None:
+        W = text.width
+        sd["token_embedding.weight"] = 0.5 * torch.randn(text.vocab, W, generator=g)
+        sd["positional_embedding"] = 0.3 * torch.randn(text.ctx, W, generator=g)
+        _resblocks(sd, "transformer.", text.layers, W, text.mlp_dim, g)
+        _ln(sd, "ln_final", W, g)
+        sd["text_projection"] = torch.randn(W, text.out_dim, generator=g) / math.sqrt(W)
+        sd["logit_scale"] = torch.tensor(math.log(1 / 0.07))
+    return sd
+
+
+def random_bert_state_dict(arch: BertArch, seed: int = 0) -> Dict[str, Tensor]:
+    """HuggingFace BertModel-named state dict."""
+    g = torch.Generator().manual_seed(seed)
+    W, F = arch.width, arch.mlp_dim
+    std = 0.6 / math.sqrt(W)
+    sd: Dict[str, Tensor] = {}
+    sd["embeddings.word_embeddings.weight"] = 0.5 * torch.randn(arch.vocab, W, generator=g)
+    sd["embeddings.position_embeddings.weight"] = 0.3 * torch.randn(arch.max_pos, W, generator=g)
+    sd["embeddings.token_type_embeddings.weight"] = 0.3 * torch.randn(2, W, generator=g)
+    _ln(sd, "embeddings.LayerNorm", W, g)
+    for i in range(arch.layers):
+        p = f"encoder.layer.{i}."
+        for n in ("query", "key", "value"):
+            _lin(sd, p + f"attention.self.{n}", W, W, g, std)
+        _lin(sd, p + "attention.output.dense", W, W, g, std)
+        _ln(sd, p + "attention.output.LayerNorm", W, g)
+        _lin(sd, p + "intermediate.dense", F, W, g, std)
+        _lin(sd, p + "output.dense", W, F, g, std)
+        _ln(sd, p + "output.LayerNorm", W, g)
+    return sd
