@@ -26,8 +26,21 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 }
 
 // ---- activations (fp32) ------------------------------------------------------------------
+// erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. fp32-roundoff class): 1 v_rcp + 1 v_exp +
+// 6 FMAs instead of libm erff's ~40-instruction branchy polynomial — the GELU epilogue of the fc1 GEMM
+// was costing as much as its MFMA main loop at K = 768.
+__device__ __forceinline__ float fast_erf(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float y = 1.0f - p * t * __expf(-ax * ax);
+    return copysignf(y, x);
+}
 __device__ __forceinline__ float gelu_erf(float x) {
-    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+    return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752440f));
 }
 __device__ __forceinline__ float quick_gelu(float x) {
     return x / (1.0f + __expf(-1.702f * x));
@@ -77,6 +90,43 @@ struct MqProfScope {
     ~MqProfScope();
     int family_; hipStream_t stream_; hipEvent_t start_; bool on_;
 };
+
+// ---- shared row LayerNorm body: one wave64 per row, CH float4 chunks per lane -----------------
+// v[] holds the row (already loaded, possibly summed with other rows); returns normalised values in v.
+template <int CH>
+__device__ __forceinline__ void ln_normalize_row(f32x4 (&v)[CH], int lane, int nch, int W, float eps) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < CH; ++i)
+        if (lane + i * 64 < nch) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    const float mean = wave_sum(s) / (float)W;
+    float s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < CH; ++i)
+        if (lane + i * 64 < nch) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; s2 += d * d; }
+        }
+    const float rstd = rsqrtf(wave_sum(s2) / (float)W + eps);
+#pragma unroll
+    for (int i = 0; i < CH; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[i][e] = (v[i][e] - mean) * rstd;
+}
+
+// dispatch a kernel template on the number of float4 chunks per lane (W <= 2048)
+#define MQ_DISPATCH_CH(W, CALL)                                   \
+    do {                                                          \
+        const int ch__ = ((W) / 4 + 63) / 64;                     \
+        switch (ch__) {                                           \
+            case 1: { constexpr int CH = 1; CALL; } break;        \
+            case 2: { constexpr int CH = 2; CALL; } break;        \
+            case 3: { constexpr int CH = 3; CALL; } break;        \
+            case 4: { constexpr int CH = 4; CALL; } break;        \
+            case 5: case 6: { constexpr int CH = 6; CALL; } break; \
+            default: { constexpr int CH = 8; CALL; } break;       \
+        }                                                         \
+    } while (0)
 
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

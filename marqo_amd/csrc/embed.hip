@@ -24,6 +24,17 @@ __global__ __launch_bounds__(256) void patchify_kernel(const void* __restrict__ 
         const int pidx = (int)(prow - img * (G * G));
         const int py = pidx / G, px = pidx - py * G;
         float v[8];
+        if (U8 && (P & 7) == 0 && col0 < 3 * PP) {
+            // fast path: the 8 columns are 8 consecutive kx of one (c, ky) row -> one div chain per thread
+            const int c = col0 / PP;
+            const int rem = col0 - c * PP;
+            const int ky = rem / P, kx = rem - ky * P;
+            const float sc = c == 0 ? sc0 : (c == 1 ? sc1 : sc2);
+            const float of = c == 0 ? of0 : (c == 1 ? of1 : of2);
+            const uint8_t* src = (const uint8_t*)in + ((img * S + (py * P + ky)) * S + (px * P + kx)) * 3 + c;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = ((float)src[e * 3] / 255.0f - of) / sc;
+        } else
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int col = col0 + e;
@@ -57,10 +68,10 @@ __global__ __launch_bounds__(256) void patchify_kernel(const void* __restrict__ 
 // ---- ViT token assembly + ln_pre ------------------------------------------------------------------
 // row (b, t): t == 0 ? cls : patch_out[b*np + t-1];  + pos[t];  LayerNorm(ln_pre) -> x fp32
 constexpr int MAXC = 8;
-__global__ __launch_bounds__(256) void vit_assemble_kernel(const float* __restrict__ patch_out, const float* __restrict__ cls,
-                                                           const float* __restrict__ pos, const float* __restrict__ gam,
-                                                           const float* __restrict__ bet, float* __restrict__ x,
-                                                           int64_t rows, int T, int W, float eps) {
+template <int CH>
+__global__ __launch_bounds__(256, (CH <= 4 ? 8 : 4)) void vit_assemble_kernel(
+    const float* __restrict__ patch_out, const float* __restrict__ cls, const float* __restrict__ pos,
+    const float* __restrict__ gam, const float* __restrict__ bet, float* __restrict__ x, int64_t rows, int T, int W, float eps) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -69,36 +80,22 @@ __global__ __launch_bounds__(256) void vit_assemble_kernel(const float* __restri
     const float* src = t == 0 ? cls : patch_out + (b * (T - 1) + (t - 1)) * W;
     const float* pr = pos + (int64_t)t * W;
     const int nch = W >> 2;
-    f32x4 v[MAXC];
-    float s = 0.f;
+    f32x4 v[CH];
 #pragma unroll
-    for (int i = 0; i < MAXC; ++i) {
+    for (int i = 0; i < CH; ++i) {
         const int c = lane + i * 64;
-        if (c < nch) {
-            v[i] = *(const f32x4*)(src + c * 4) + *(const f32x4*)(pr + c * 4);
-            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
-        }
+        v[i] = c < nch ? *(const f32x4*)(src + c * 4) + *(const f32x4*)(pr + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    const float mean = wave_sum(s) / (float)W;
-    float s2 = 0.f;
+    ln_normalize_row<CH>(v, lane, nch, W, eps);
 #pragma unroll
-    for (int i = 0; i < MAXC; ++i) {
-        const int c = lane + i * 64;
-        if (c < nch) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; s2 += d * d; }
-        }
-    }
-    const float rstd = rsqrtf(wave_sum(s2) / (float)W + eps);
-#pragma unroll
-    for (int i = 0; i < MAXC; ++i) {
+    for (int i = 0; i < CH; ++i) {
         const int c = lane + i * 64;
         if (c < nch) {
             const f32x4 gg = *(const f32x4*)(gam + c * 4);
             const f32x4 bb = *(const f32x4*)(bet + c * 4);
             f32x4 y;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd * gg[e] + bb[e];
+            for (int e = 0; e < 4; ++e) y[e] = v[i][e] * gg[e] + bb[e];
             *(f32x4*)(x + row * W + c * 4) = y;
         }
     }
@@ -106,12 +103,11 @@ __global__ __launch_bounds__(256) void vit_assemble_kernel(const float* __restri
 
 // ---- token embedding (+ pos, + type) (+ LayerNorm) ---------------------------------------------------
 // grid = nseq blocks; the 4 waves of a block walk the sequence's rows.
-template <bool LN>
-__global__ __launch_bounds__(256) void embed_tokens_kernel(const int32_t* __restrict__ ids, const int32_t* __restrict__ cu,
-                                                           const float* __restrict__ tok, const float* __restrict__ pos,
-                                                           const float* __restrict__ type0, const float* __restrict__ gam,
-                                                           const float* __restrict__ bet, float* __restrict__ x,
-                                                           bf16_t* __restrict__ xb, int W, int vocab, float eps) {
+template <bool LN, int CH>
+__global__ __launch_bounds__(256, (CH <= 4 ? 8 : 4)) void embed_tokens_kernel(
+    const int32_t* __restrict__ ids, const int32_t* __restrict__ cu, const float* __restrict__ tok,
+    const float* __restrict__ pos, const float* __restrict__ type0, const float* __restrict__ gam,
+    const float* __restrict__ bet, float* __restrict__ x, bf16_t* __restrict__ xb, int W, int vocab, float eps) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row0 = cu[blockIdx.x], len = cu[blockIdx.x + 1] - row0;
     const int nch = W >> 2;
@@ -121,33 +117,19 @@ __global__ __launch_bounds__(256) void embed_tokens_kernel(const int32_t* __rest
         id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
         const float* tr = tok + (int64_t)id * W;
         const float* pr = pos + (int64_t)t * W;
-        f32x4 v[MAXC];
-        float s = 0.f;
+        f32x4 v[CH];
 #pragma unroll
-        for (int i = 0; i < MAXC; ++i) {
+        for (int i = 0; i < CH; ++i) {
             const int c = lane + i * 64;
+            v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (c < nch) {
                 v[i] = *(const f32x4*)(tr + c * 4) + *(const f32x4*)(pr + c * 4);
                 if (type0) v[i] += *(const f32x4*)(type0 + c * 4);
-                s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
             }
         }
-        float mean = 0.f, rstd = 1.f;
-        if (LN) {
-            mean = wave_sum(s) / (float)W;
-            float s2 = 0.f;
+        if (LN) ln_normalize_row<CH>(v, lane, nch, W, eps);
 #pragma unroll
-            for (int i = 0; i < MAXC; ++i) {
-                const int c = lane + i * 64;
-                if (c < nch) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; s2 += d * d; }
-                }
-            }
-            rstd = rsqrtf(wave_sum(s2) / (float)W + eps);
-        }
-#pragma unroll
-        for (int i = 0; i < MAXC; ++i) {
+        for (int i = 0; i < CH; ++i) {
             const int c = lane + i * 64;
             if (c < nch) {
                 f32x4 y = v[i];
@@ -155,7 +137,7 @@ __global__ __launch_bounds__(256) void embed_tokens_kernel(const int32_t* __rest
                     const f32x4 gg = *(const f32x4*)(gam + c * 4);
                     const f32x4 bb = *(const f32x4*)(bet + c * 4);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd * gg[e] + bb[e];
+                    for (int e = 0; e < 4; ++e) y[e] = v[i][e] * gg[e] + bb[e];
                 }
                 *(f32x4*)(x + row * W + c * 4) = y;
                 if (xb) {
@@ -246,8 +228,8 @@ int mq_vit_assemble(const float* d_patch_out, const float* cls, const float* pos
     const int64_t rows = n * T;
     if (rows <= 0) return MQ_OK;
     MqProfScope prof(3, s);
-    hipLaunchKernelGGL(vit_assemble_kernel, dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, s, d_patch_out, cls, pos, g, b,
-                       d_x, rows, T, W, eps);
+    MQ_DISPATCH_CH(W, hipLaunchKernelGGL(vit_assemble_kernel<CH>, dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, s, d_patch_out,
+                                         cls, pos, g, b, d_x, rows, T, W, eps));
     MQ_CHECK_LAUNCH("vit_assemble");
     return MQ_OK;
 }
@@ -259,11 +241,11 @@ int mq_embed_tokens(const int32_t* d_ids, const int32_t* d_cu, int64_t nseq, con
     if (nseq <= 0) return MQ_OK;
     MqProfScope prof(3, s);
     if (g)
-        hipLaunchKernelGGL(embed_tokens_kernel<true>, dim3((unsigned)nseq), dim3(256), 0, s, d_ids, d_cu, tok, pos, type0,
-                           g, b, d_x, (bf16_t*)d_xb, W, vocab, eps);
+        MQ_DISPATCH_CH(W, hipLaunchKernelGGL((embed_tokens_kernel<true, CH>), dim3((unsigned)nseq), dim3(256), 0, s, d_ids, d_cu,
+                                             tok, pos, type0, g, b, d_x, (bf16_t*)d_xb, W, vocab, eps));
     else
-        hipLaunchKernelGGL(embed_tokens_kernel<false>, dim3((unsigned)nseq), dim3(256), 0, s, d_ids, d_cu, tok, pos, type0,
-                           g, b, d_x, (bf16_t*)d_xb, W, vocab, eps);
+        MQ_DISPATCH_CH(W, hipLaunchKernelGGL((embed_tokens_kernel<false, CH>), dim3((unsigned)nseq), dim3(256), 0, s, d_ids, d_cu,
+                                             tok, pos, type0, g, b, d_x, (bf16_t*)d_xb, W, vocab, eps));
     MQ_CHECK_LAUNCH("embed_tokens");
     return MQ_OK;
 }

@@ -4,25 +4,24 @@
 //                                                PyTorch nn.Linear weight as stored)
 //
 // Design (MI355X-first, not a CUDA tiling):
-//   * 128x128x64 block tile, 4 wave64s as 2x2, each wave a 64x64 sub-tile = 4x4
-//     v_mfma_f32_16x16x32_bf16 accumulators (64 fp32 acc VGPRs / lane).
+//   * (32*MT)x128x64 block tile (MT = 2/4/5/6 -> 64..192 rows), 4 wave64s as 2x2, each wave a
+//     (16*MT)x64 sub-tile = MT x 4 v_mfma_f32_16x16x32_bf16 accumulators.
 //   * global -> LDS by direct LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave instruction),
-//     2 stages x (16 KiB A + 16 KiB W) = 64 KiB LDS -> 2 workgroups per CU.
-//   * LDS tiles are [128 rows][128 B]; the 16-B chunk index is XOR-swizzled with (row & 7).
+//     2 stages x (BM*128 B of A + 16 KiB of W) = 48..80 KiB LDS -> 2 workgroups per CU.
+//   * LDS tiles are [rows][128 B]; the 16-B chunk index is XOR-swizzled with (row & 7).
 //     LDS-DMA writes lane-linear, so the swizzle is applied to each lane's GLOBAL source
 //     address and again on the ds_read_b128 side (same involution) -> conflict-free reads.
 //   * operands are fed swapped (mfma(Wfrag, Afrag)) so each lane ends up owning 4
 //     CONSECUTIVE n of one output row: bias/residual/out are 8/16-byte vector accesses.
 //   * workgroup -> tile map is XCD-aware: the 8 XCDs (block b runs on XCD b % 8) each take a
 //     contiguous range of tiles, so tiles sharing an A row-panel hit the same private L2.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = BM * BK * 2;      // 16 KiB (A or W tile)
-constexpr int STAGE_BYTES = 2 * TILE_BYTES;  // A + W
-constexpr int GEMM_LDS = 2 * STAGE_BYTES;    // 64 KiB
+constexpr int BN = 128, BK = 64;
+constexpr int W_TILE_BYTES = BN * BK * 2;  // 16 KiB
 
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
     // 16 B per lane, LDS destination = wave-uniform base + lane * 16.
@@ -30,11 +29,19 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int FLAGS>
+// MT = 16-row MFMA sub-tiles per wave along M  ->  block tile BM = 32*MT rows (64 .. 192).
+// The tile HEIGHT is a free parameter because rows are guarded anyway; the launcher picks the MT
+// that minimises (rounds of resident workgroups) x (tile cost), which removes most of the tile
+// quantisation loss at the towers' shapes (e.g. M=12800,N=768: 600 128-row tiles = 2 rounds on
+// 512 slots, 480 160-row tiles = 1 round).
+template <int FLAGS, int MT>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
     const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ Wt, int64_t ldw,
     const float* __restrict__ bias, const float* residual, void* out, int64_t ldc,
     int M, int N, int K, int tiles_n, int num_tiles) {
+    constexpr int BM = 32 * MT;
+    constexpr int A_TILE_BYTES = BM * BK * 2;
+    constexpr int STAGE_BYTES = A_TILE_BYTES + W_TILE_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     // ---- XCD-aware, bijective block -> tile map -------------------------------------------
@@ -51,46 +58,47 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
     const int wm = wave >> 1, wn = wave & 1;
     const int l15 = lane & 15, g = lane >> 4;
 
-    // ---- staging: wave w owns rows [32w, 32w+32) of both tiles, 8 rows per LDS-DMA ---------
-    // lane -> (row = base + lane/8, physical chunk = lane%8); it fetches logical chunk
+    // ---- staging: wave w owns A rows [8*MT*w, 8*MT*(w+1)) and W rows [32w, 32w+32), 8 rows per
+    // LDS-DMA.  lane -> (row = base + lane/8, physical chunk = lane%8); it fetches logical chunk
     // (lane%8) ^ (row&7) of that row, so physical chunk p of row r holds logical chunk p^(r&7).
     const int srow = lane >> 3;
-    const bf16_t* a_src[4];
+    const bf16_t* a_src[MT];
     const bf16_t* w_src[4];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int row = wave * (8 * MT) + i * 8 + srow;
+        int gm = m0 + row; gm = gm < M ? gm : M - 1;
+        a_src[i] = A + (int64_t)gm * lda + ((lane & 7) ^ (row & 7)) * 8;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = wave * 32 + i * 8 + srow;
-        const int chunk = (lane & 7) ^ (row & 7);
-        int gm = m0 + row; gm = gm < M ? gm : M - 1;
         int gn = n0 + row; gn = gn < N ? gn : N - 1;
-        a_src[i] = A + (int64_t)gm * lda + chunk * 8;
-        w_src[i] = Wt + (int64_t)gn * ldw + chunk * 8;
+        w_src[i] = Wt + (int64_t)gn * ldw + ((lane & 7) ^ (row & 7)) * 8;
     }
     auto stage = [&](int buf, int kt) {
-        char* sa = smem + buf * STAGE_BYTES + wave * (32 * 128);
-        char* sw = sa + TILE_BYTES;
+        char* sa = smem + buf * STAGE_BYTES + wave * (8 * MT * 128);
+        char* sw = smem + buf * STAGE_BYTES + A_TILE_BYTES + wave * (32 * 128);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            glds16(a_src[i] + (int64_t)kt * BK, sa + i * (8 * 128));
-            glds16(w_src[i] + (int64_t)kt * BK, sw + i * (8 * 128));
-        }
+        for (int i = 0; i < MT; ++i) glds16(a_src[i] + (int64_t)kt * BK, sa + i * (8 * 128));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16(w_src[i] + (int64_t)kt * BK, sw + i * (8 * 128));
     };
 
     // ---- fragment read offsets (bytes inside a tile), fixed per lane ------------------------
     // logical chunk for k-half kk is g + 4*kk; (row & 7) == (l15 & 7) because sub-tile bases are
     // multiples of 16.
-    int a_off[4], w_off[4];
+    int a_off[MT], w_off[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        a_off[t] = (wm * 64 + t * 16 + l15) * 128;
-        w_off[t] = (wn * 64 + t * 16 + l15) * 128;
-    }
+    for (int t = 0; t < MT; ++t) a_off[t] = (wm * (16 * MT) + t * 16 + l15) * 128;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) w_off[t] = (wn * 64 + t * 16 + l15) * 128;
     const int sw0 = ((g) ^ (l15 & 7)) << 4;      // kk = 0
     const int sw1 = ((g + 4) ^ (l15 & 7)) << 4;  // kk = 1
 
-    f32x4 acc[4][4];
+    f32x4 acc[MT][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -103,18 +111,17 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
         if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
 
         const char* sa = smem + (kt & 1) * STAGE_BYTES;
-        const char* sw = sa + TILE_BYTES;
+        const char* sw = sa + A_TILE_BYTES;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int swz = kk ? sw1 : sw0;
-            bf16x8 af[4], wf[4];
+            bf16x8 af[MT], wf[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                af[t] = *(const bf16x8*)(sa + a_off[t] + swz);
-                wf[t] = *(const bf16x8*)(sw + w_off[t] + swz);
-            }
+            for (int t = 0; t < 4; ++t) wf[t] = *(const bf16x8*)(sw + w_off[t] + swz);
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+            for (int t = 0; t < MT; ++t) af[t] = *(const bf16x8*)(sa + a_off[t] + swz);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[mt], acc[mt][nt], 0, 0, 0);
@@ -124,8 +131,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
     // ---- epilogue: lane owns out[m][n .. n+3] for each (mt, nt) -----------------------------
     // D[i][j] = sum_k Wfrag[i][k] * Afrag[j][k]: column j = lane & 15 -> m, row i = 4*g + reg -> n.
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const int m = m0 + wm * 64 + mt * 16 + l15;
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = m0 + wm * (16 * MT) + mt * 16 + l15;
         if (m >= M) continue;
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
@@ -161,13 +168,34 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
     }
 }
 
-template <int FLAGS>
-int launch_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
-                const float* residual, void* out, int64_t ldc, int M, int N, int K, hipStream_t s) {
+constexpr int RESIDENT_SLOTS = 512;  // 256 CUs x 2 workgroups (64..80 KiB LDS each)
+
+// pick the tile height: minimise rounds x (MT + fixed per-tile overhead in 16-row units)
+int choose_mt(int M, int N) {
+    const int tiles_n = (N + BN - 1) / BN;
+    const int cands[4] = {2, 4, 5, 6};
+    int best = 4;
+    double best_cost = 1e30;
+    for (int c = 0; c < 4; ++c) {
+        const int mt = cands[c];
+        const int bm = 32 * mt;
+        const int64_t tiles = (int64_t)((M + bm - 1) / bm) * tiles_n;
+        const int64_t rounds = (tiles + RESIDENT_SLOTS - 1) / RESIDENT_SLOTS;
+        const double cost = (double)rounds * (mt + 1.25);
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = mt; }
+    }
+    return best;
+}
+
+template <int FLAGS, int MT>
+int launch_gemm_mt(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                   const float* residual, void* out, int64_t ldc, int M, int N, int K, hipStream_t s) {
+    constexpr int BM = 32 * MT;
+    constexpr int LDS = 2 * (BM * BK * 2 + W_TILE_BYTES);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_kernel<FLAGS>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_kernel<FLAGS, MT>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) {
             mq_set_error("mq_gemm_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e));
             return MQ_ERR_HIP;
@@ -176,11 +204,24 @@ int launch_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const fl
     }
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     const int num_tiles = tiles_m * tiles_n;
-    hipLaunchKernelGGL(gemm_nt_kernel<FLAGS>, dim3(num_tiles), dim3(256), GEMM_LDS, s,
+    hipLaunchKernelGGL((gemm_nt_kernel<FLAGS, MT>), dim3(num_tiles), dim3(256), LDS, s,
                        (const bf16_t*)A, lda, (const bf16_t*)W, ldw, bias, residual, out, ldc,
                        M, N, K, tiles_n, num_tiles);
     MQ_CHECK_LAUNCH("mq_gemm_bf16");
     return MQ_OK;
+}
+
+template <int FLAGS>
+int launch_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                const float* residual, void* out, int64_t ldc, int M, int N, int K, hipStream_t s) {
+    static const int force_mt = getenv("MQ_GEMM_MT") ? atoi(getenv("MQ_GEMM_MT")) : 0;  // tuning knob
+    const int mt = force_mt ? force_mt : choose_mt(M, N);
+    switch (mt) {
+        case 2: return launch_gemm_mt<FLAGS, 2>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s);
+        case 5: return launch_gemm_mt<FLAGS, 5>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s);
+        case 6: return launch_gemm_mt<FLAGS, 6>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s);
+        default: return launch_gemm_mt<FLAGS, 4>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s);
+    }
 }
 
 }  // namespace
@@ -205,11 +246,9 @@ extern "C" int mq_gemm_bf16(const void* d_A, int64_t lda, const void* d_W, int64
         MQ_GEMM_CASE(0);
         MQ_GEMM_CASE(MQ_EPI_OUT_F32);
         MQ_GEMM_CASE(MQ_EPI_BIAS);
-        MQ_GEMM_CASE(MQ_EPI_BIAS | MQ_EPI_OUT_F32);
         MQ_GEMM_CASE(MQ_EPI_BIAS | MQ_EPI_GELU);
         MQ_GEMM_CASE(MQ_EPI_BIAS | MQ_EPI_QUICKGELU);
         MQ_GEMM_CASE(MQ_EPI_BIAS | MQ_EPI_RESIDUAL | MQ_EPI_OUT_F32);
-        MQ_GEMM_CASE(MQ_EPI_RESIDUAL | MQ_EPI_OUT_F32);
         default:
             mq_set_error("mq_gemm_bf16: unsupported epilogue flag combination 0x%x", flags);
             return MQ_ERR_INVALID;

@@ -8,7 +8,11 @@ namespace {
 constexpr int LN_MAX_CHUNKS = 8;  // float4 chunks per lane: W <= 64 * 4 * 8 = 2048
 
 // x row (fp32) -> LN -> bf16 and/or fp32.  row_idx gathers input rows (output rows are dense).
-__global__ __launch_bounds__(256) void layernorm_kernel(
+// CH = float4 chunks per lane (compile time, so the row lives in CH*4 VGPRs and the kernel keeps
+// 8 waves/SIMD in flight — the first version sized its arrays for the maximum W, compiled to 220
+// VGPRs / occupancy 2 and ran at 2 TB/s).
+template <int CH>
+__global__ __launch_bounds__(256, (CH <= 4 ? 8 : 4)) void layernorm_kernel(
     const float* __restrict__ x, const int32_t* __restrict__ row_idx, const float* __restrict__ gam,
     const float* __restrict__ bet, bf16_t* out_bf16, float* out_f32, int64_t rows, int W, float eps) {
     const int lane = threadIdx.x & 63;
@@ -18,36 +22,22 @@ __global__ __launch_bounds__(256) void layernorm_kernel(
     const float* xr = x + src * W;
     const int nch = W >> 2;  // float4 chunks in the row
 
-    f32x4 v[LN_MAX_CHUNKS];
-    float s = 0.f;
+    f32x4 v[CH];
 #pragma unroll
-    for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+    for (int i = 0; i < CH; ++i) {
         const int c = lane + i * 64;
-        if (c < nch) {
-            v[i] = *(const f32x4*)(xr + c * 4);
-            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
-        }
+        v[i] = c < nch ? *(const f32x4*)(xr + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    const float mean = wave_sum(s) / (float)W;
-    float s2 = 0.f;
+    ln_normalize_row<CH>(v, lane, nch, W, eps);
 #pragma unroll
-    for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
-        const int c = lane + i * 64;
-        if (c < nch) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; s2 += d * d; }
-        }
-    }
-    const float rstd = rsqrtf(wave_sum(s2) / (float)W + eps);
-#pragma unroll
-    for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+    for (int i = 0; i < CH; ++i) {
         const int c = lane + i * 64;
         if (c < nch) {
             const f32x4 gg = *(const f32x4*)(gam + c * 4);
             const f32x4 bb = *(const f32x4*)(bet + c * 4);
             f32x4 y;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd * gg[e] + bb[e];
+            for (int e = 0; e < 4; ++e) y[e] = v[i][e] * gg[e] + bb[e];
             if (out_f32) *(f32x4*)(out_f32 + row * W + c * 4) = y;
             if (out_bf16) {
                 uint2 p;
@@ -90,8 +80,8 @@ extern "C" int mq_layernorm(const float* d_x, const int32_t* d_row_idx, const fl
     if (rows <= 0) return MQ_OK;
     hipStream_t s = (hipStream_t)stream;
     MqProfScope prof(1, s);
-    hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, s, d_x, d_row_idx, d_g, d_b,
-                       (bf16_t*)d_out_bf16, d_out_f32, rows, (int)W, eps);
+    MQ_DISPATCH_CH(W, hipLaunchKernelGGL(layernorm_kernel<CH>, dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, s, d_x, d_row_idx,
+                                         d_g, d_b, (bf16_t*)d_out_bf16, d_out_f32, rows, (int)W, eps));
     MQ_CHECK_LAUNCH("mq_layernorm");
     return MQ_OK;
 }

@@ -1,0 +1,65 @@
+"""Micro-benchmark of mq_gemm_bf16 at the shapes the towers launch (and a 4096^3 reference point).
+python tools/gemm_bench.py [--iters 50]"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from marqo_amd import _lib as L
+
+SHAPES = [
+    # name, M, N, K, flags
+    ("b32 qkv", 12800, 2304, 768, L.MQ_EPI_BIAS),
+    ("b32 out", 12800, 768, 768, L.MQ_EPI_BIAS | L.MQ_EPI_RESIDUAL | L.MQ_EPI_OUT_F32),
+    ("b32 fc1", 12800, 3072, 768, L.MQ_EPI_BIAS | L.MQ_EPI_GELU),
+    ("b32 fc2", 12800, 768, 3072, L.MQ_EPI_BIAS | L.MQ_EPI_RESIDUAL | L.MQ_EPI_OUT_F32),
+    ("b32 patch", 12544, 768, 3072, L.MQ_EPI_OUT_F32),
+    ("l14 qkv", 16448, 3072, 1024, L.MQ_EPI_BIAS),
+    ("l14 out", 16448, 1024, 1024, L.MQ_EPI_BIAS | L.MQ_EPI_RESIDUAL | L.MQ_EPI_OUT_F32),
+    ("l14 fc1", 16448, 4096, 1024, L.MQ_EPI_BIAS | L.MQ_EPI_GELU),
+    ("l14 fc2", 16448, 1024, 4096, L.MQ_EPI_BIAS | L.MQ_EPI_RESIDUAL | L.MQ_EPI_OUT_F32),
+    ("4096^3", 4096, 4096, 4096, 0),
+    ("8192^3", 8192, 8192, 8192, 0),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=30)
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    lib = L.load()
+    s = torch.cuda.current_stream().cuda_stream
+    tot_t = tot_f = 0.0
+    for name, M, N, K, flags in SHAPES:
+        if args.only and args.only not in name:
+            continue
+        A = torch.randn(M, K, device="cuda").to(torch.bfloat16)
+        W = (torch.randn(N, K, device="cuda") * 0.03).to(torch.bfloat16)
+        b = torch.randn(N, device="cuda")
+        f32 = bool(flags & L.MQ_EPI_OUT_F32)
+        out = torch.zeros(M, N, device="cuda", dtype=torch.float32 if f32 else torch.bfloat16)
+        res = out if flags & L.MQ_EPI_RESIDUAL else None
+
+        def run():
+            L.check(lib.mq_gemm_bf16(A.data_ptr(), K, W.data_ptr(), K, b.data_ptr(), L.ptr(res), out.data_ptr(), N, M, N, K, flags, s))
+        for _ in range(5):
+            run()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.iters):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / args.iters
+        fl = 2.0 * M * N * K
+        print(f"{name:10s} M={M:6d} N={N:5d} K={K:5d}  {us:9.1f} us  {fl / us / 1e6:8.1f} TF/s")
+        if name.startswith("b32") and "patch" not in name:
+            tot_t += us; tot_f += fl
+    if tot_t:
+        print(f"b32 layer GEMMs: {tot_t:.1f} us/layer  {tot_f / tot_t / 1e6:.1f} TF/s")
+
+
+if __name__ == "__main__":
+    main()
