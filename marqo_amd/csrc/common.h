@@ -21,8 +21,14 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
     u += 0x7fffu + ((u >> 16) & 1u);
     return (bf16_t)(u >> 16);
 }
+// two fp32 -> packed bf16x2 (RNE).  Written as a native __bf16 vector conversion so hipcc emits one
+// v_cvt_pk_bf16_f32 instead of ~12 integer ops (the hand-rolled rounding above is kept for scalars).
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+    const f32x2_t f = {lo, hi};
+    const bf16x2_t v = __builtin_convertvector(f, bf16x2_t);
+    return __builtin_bit_cast(uint32_t, v);
 }
 
 // ---- activations (fp32) ------------------------------------------------------------------

@@ -16,6 +16,7 @@
 //   * workgroup -> tile map is XCD-aware: the 8 XCDs (block b runs on XCD b % 8) each take a
 //     contiguous range of tiles, so tiles sharing an A row-panel hit the same private L2.
 #include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -102,31 +103,65 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = K / BK;
-    stage(0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-        // tile kt has landed for every wave, and every wave is done reading buffer (kt+1)&1
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
-
+    // one k-step: fragments for both 32-deep halves are read up front, then the MT*8 MFMAs run with
+    // the NEXT stage's LDS-DMA issues sprinkled between them (an LDS-DMA issue costs the wave ~60-180
+    // cycles; bunched at the top of the step they serialised in front of the MFMAs and held the matrix
+    // pipe at 25-40 %).  PREFETCH is a template flag so the steady-state loop has no branch in it.
+    auto kstep = [&](int kt, auto prefetch_tag) {
+        constexpr bool PREFETCH = decltype(prefetch_tag)::value;
         const char* sa = smem + (kt & 1) * STAGE_BYTES;
         const char* sw = sa + A_TILE_BYTES;
+        char* na = smem + ((kt + 1) & 1) * STAGE_BYTES + wave * (8 * MT * 128);
+        char* nw = smem + ((kt + 1) & 1) * STAGE_BYTES + A_TILE_BYTES + wave * (32 * 128);
+        const int64_t koff = (int64_t)(kt + 1) * BK;
+        bf16x8 af[2][MT], wf[2][4];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int swz = kk ? sw1 : sw0;
-            bf16x8 af[MT], wf[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) wf[t] = *(const bf16x8*)(sw + w_off[t] + swz);
+            for (int t = 0; t < 4; ++t) wf[kk][t] = *(const bf16x8*)(sw + w_off[t] + swz);
 #pragma unroll
-            for (int t = 0; t < MT; ++t) af[t] = *(const bf16x8*)(sa + a_off[t] + swz);
+            for (int t = 0; t < MT; ++t) af[kk][t] = *(const bf16x8*)(sa + a_off[t] + swz);
+        }
+        constexpr int NL = MT + 4;            // LDS-DMA pieces per wave per step
+        constexpr int NM = 8 * MT;            // MFMAs per wave per step
+        constexpr int GAP = NM / NL;          // MFMAs between two pieces
+        int issued = 0;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[mt], acc[mt][nt], 0, 0, 0);
+                for (int nt = 0; nt < 4; ++nt) {
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][nt], af[kk][mt], acc[mt][nt], 0, 0, 0);
+                    const int done = (kk * MT + mt) * 4 + nt + 1;
+                    if (PREFETCH && done % GAP == 0 && issued < NL) {
+                        if (issued < MT) glds16(a_src[issued] + koff, na + issued * (8 * 128));
+                        else glds16(w_src[issued - MT] + koff, nw + (issued - MT) * (8 * 128));
+                        ++issued;
+                    }
+                }
+        if (PREFETCH) {
+            // pin the interleave: GAP MFMAs, one VMEM, ... (sched_group_barrier masks: 0x8 MFMA, 0x10 VMEM)
+#pragma unroll
+            for (int i = 0; i < NL; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, GAP, 0);
+                __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+            }
         }
+    };
+
+    const int nk = K / BK;
+    stage(0, 0);
+    for (int kt = 0; kt < nk - 1; ++kt) {
+        // tile kt has landed for every wave, and every wave is done reading buffer (kt+1)&1
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        kstep(kt, std::true_type{});
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    kstep(nk - 1, std::false_type{});
 
     // ---- epilogue: lane owns out[m][n .. n+3] for each (mt, nt) -----------------------------
     // D[i][j] = sum_k Wfrag[i][k] * Afrag[j][k]: column j = lane & 15 -> m, row i = 4*g + reg -> n.
