@@ -194,6 +194,47 @@ int mq_encode_bert(const mq_bert_cfg* cfg, const mq_bert_weights* w,
                    float* d_out, int normalize,
                    void* d_workspace, size_t workspace_bytes, void* stream);
 
+/* ---- image preprocessing on device (K10 / K11) ----------------------------------------- */
+/* All images are uint8 HWC RGB, dense (row stride = w*3), image i at d_src + h_src_off[i] with
+ * size h_heights[i] x h_widths[i] (host arrays: the planning — Pillow's coefficient tables — is host
+ * work, the pixel passes are device work).  Results are bit-identical to Pillow's
+ * Image.resize(..., BICUBIC) (antialiased two-pass 8-bit resampler), which is what the reference's
+ * transforms run on the CPU. */
+
+/* CLIP transform up to uint8  (clip_utils.py:61-63: Resize(S, BICUBIC) -> CenterCrop(S)):
+ * d_out uint8 [n, S, S, 3].  Feed it to mq_encode_image_u8 (which fuses ToTensor + Normalize) or to
+ * mq_to_tensor_normalize. */
+size_t mq_clip_resize_workspace_bytes(const int32_t* h_heights, const int32_t* h_widths, int64_t n, int32_t S);
+int mq_clip_resize_crop_u8(const uint8_t* d_src, const int64_t* h_src_off, const int32_t* h_heights,
+                           const int32_t* h_widths, int64_t n, int32_t S, uint8_t* d_out,
+                           void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* Grid chunker (PatchifySimple, processing/image.py:120-151; 'simple' / 'overlap' patch methods):
+ * every image is resized to 240x240 (no aspect preservation), cut into the whole image + the
+ * generate_boxes(hn, wn, overlap) grid (image_utils.py:165-202), and every crop is put through the CLIP
+ * transform above.  d_out uint8 [n * count, S, S, 3] with count = mq_chunk_grid_count(hn, wn, overlap);
+ * h_boxes (host, may be NULL) float [n * count, 4] = (x1, y1, x2, y2) in ORIGINAL pixel coordinates
+ * (rescale_box, image_utils.py:141-163). */
+int    mq_chunk_grid_count(int32_t hn, int32_t wn, int32_t overlap);
+size_t mq_chunk_grid_workspace_bytes(const int32_t* h_heights, const int32_t* h_widths, int64_t n,
+                                     int32_t hn, int32_t wn, int32_t overlap, int32_t S);
+int mq_chunk_grid_u8(const uint8_t* d_src, const int64_t* h_src_off, const int32_t* h_heights,
+                     const int32_t* h_widths, int64_t n, int32_t hn, int32_t wn, int32_t overlap, int32_t S,
+                     uint8_t* d_out, float* h_boxes, void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* ToTensor + Normalize (clip_utils.py:65-66): uint8 [n, S, S, 3] -> fp32 [n, 3, S, S]; this is the
+ * tensor the reference's `.preprocess` hands to add_docs.py:130-134. mean/std: host float[3]. */
+int mq_to_tensor_normalize(const uint8_t* d_u8, float* d_out, int64_t n, int32_t S,
+                           const float* mean, const float* std, void* stream);
+
+/* Pillow's fixed-point bicubic coefficient table of one axis (host only; exported for parity tests):
+ * for output positions [first, first+count) of an in_size -> out_size resize, h_bounds int32
+ * [count, 2] = (first source index, tap count), h_kk int32 [count, ksize] 22-bit fixed-point weights,
+ * ksize = mq_resample_ksize(in_size, out_size). */
+int mq_resample_ksize(int32_t in_size, int32_t out_size);
+int mq_resample_coeffs(int32_t in_size, int32_t out_size, int32_t first, int32_t count,
+                       int32_t* h_bounds, int32_t* h_kk);
+
 /* ---- building blocks (exported for parity tests and for callers that compose) -------- */
 
 /* out[M,N] = epilogue(A[M,K] @ W[N,K]^T).  A, W bf16 row-major (lda, ldw in elements);

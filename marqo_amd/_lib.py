@@ -101,6 +101,15 @@ _SIGNATURES = {
     "mq_encoder_forward": (C.c_int, [C.POINTER(EncoderCfg), C.POINTER(BlockWeights), _P, C.c_int64, _P, C.c_int64,
                                      C.c_int32, C.c_int32, _P, C.c_size_t, _P]),
     "mq_l2_normalize": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P]),
+    "mq_clip_resize_workspace_bytes": (C.c_size_t, [_P, _P, C.c_int64, C.c_int32]),
+    "mq_clip_resize_crop_u8": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, _P, _P, C.c_size_t, _P]),
+    "mq_chunk_grid_count": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
+    "mq_chunk_grid_workspace_bytes": (C.c_size_t, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "mq_chunk_grid_u8": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P,
+                                   C.c_size_t, _P]),
+    "mq_to_tensor_normalize": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float), _P]),
+    "mq_resample_ksize": (C.c_int, [C.c_int32, C.c_int32]),
+    "mq_resample_coeffs": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     "mq_profile_enable": (C.c_int, [C.c_int]),
     "mq_profile_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
 }

@@ -1,0 +1,123 @@
+"""Device-side image preprocessing (K10 / K11): host packing + the C-ABI calls of csrc/preprocess.hip.
+
+Replaces the per-image PIL work the reference does in Python download threads
+(src/marqo/s2_inference/clip_utils.py:48-67 through add_docs.py:121-134, and
+src/marqo/s2_inference/processing/image.py:120-151): raw decoded uint8 pixels of a whole batch go to the
+GPU in ONE pinned H2D copy and are resized / cropped / chunked there, bit-identically to Pillow.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+
+from marqo_amd import _lib as L
+from marqo_amd.engine.archs import OPENAI_DATASET_MEAN, OPENAI_DATASET_STD
+
+ArrayLike = Union[np.ndarray, torch.Tensor]
+
+
+def _as_u8_hwc(img: ArrayLike) -> torch.Tensor:
+    t = torch.from_numpy(img) if isinstance(img, np.ndarray) else img
+    if t.dtype != torch.uint8 or t.ndim != 3 or t.shape[2] != 3:
+        raise ValueError(f"expected a uint8 [H, W, 3] RGB image, got {t.dtype} {tuple(t.shape)}")
+    return t.contiguous()
+
+
+class PackedImages:
+    """A batch of variable-size uint8 RGB images packed back to back in one device buffer."""
+
+    def __init__(self, images: Sequence[ArrayLike], device: torch.device):
+        imgs = [_as_u8_hwc(i) for i in images]
+        self.n = len(imgs)
+        self.heights = np.asarray([i.shape[0] for i in imgs], dtype=np.int32)
+        self.widths = np.asarray([i.shape[1] for i in imgs], dtype=np.int32)
+        sizes = self.heights.astype(np.int64) * self.widths.astype(np.int64) * 3
+        padded = (sizes + 255) // 256 * 256  # keep every image 256-B aligned
+        self.offsets = np.zeros(self.n, dtype=np.int64)
+        if self.n > 1:
+            self.offsets[1:] = np.cumsum(padded)[:-1]
+        total = int(padded.sum()) if self.n else 0
+        if all(i.device.type == "cuda" for i in imgs) and self.n:
+            buf = torch.empty(total, dtype=torch.uint8, device=device)
+            for i, o, s in zip(imgs, self.offsets, sizes):
+                buf[int(o):int(o + s)] = i.reshape(-1).to(device)
+        else:
+            host = torch.empty(total, dtype=torch.uint8, pin_memory=torch.cuda.is_available())
+            for i, o, s in zip(imgs, self.offsets, sizes):
+                host[int(o):int(o + s)] = i.reshape(-1).cpu()
+            buf = host.to(device, non_blocking=True)
+        self.buffer = buf
+
+
+class ImagePreprocessor:
+    """Owns the scratch workspace; thread-compatible (one instance per calling thread or externally locked)."""
+
+    def __init__(self, device: str, image_size: int, mean: Sequence[float] = OPENAI_DATASET_MEAN,
+                 std: Sequence[float] = OPENAI_DATASET_STD):
+        if not str(device).startswith("cuda") or not torch.cuda.is_available():
+            raise L.MarqoHipUnavailableError("image preprocessing runs on the GPU only; there is no CPU fallback in marqo_amd")
+        self.device = torch.device(device)
+        self.lib = L.load()
+        self.S = int(image_size)
+        self.mean = (C.c_float * 3)(*mean)
+        self.std = (C.c_float * 3)(*std)
+        self._ws = None
+
+    def _workspace(self, nbytes: int) -> torch.Tensor:
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = None
+            self._ws = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def resize_crop_u8(self, images: Sequence[ArrayLike]) -> torch.Tensor:
+        """Resize(S, bicubic) + CenterCrop(S): list of uint8 [H_i, W_i, 3] -> uint8 [n, S, S, 3] on device."""
+        with torch.cuda.device(self.device):
+            p = PackedImages(images, self.device)
+            out = torch.empty(p.n, self.S, self.S, 3, dtype=torch.uint8, device=self.device)
+            if p.n == 0:
+                return out
+            need = self.lib.mq_clip_resize_workspace_bytes(p.heights.ctypes.data, p.widths.ctypes.data, p.n, self.S)
+            ws = self._workspace(need)
+            L.check(self.lib.mq_clip_resize_crop_u8(p.buffer.data_ptr(), p.offsets.ctypes.data, p.heights.ctypes.data,
+                                                    p.widths.ctypes.data, p.n, self.S, out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                    self._stream()), "mq_clip_resize_crop_u8")
+            self._keep = p  # the packed source must outlive the enqueued kernels
+        return out
+
+    def chunk_grid_u8(self, images: Sequence[ArrayLike], hn: int = 3, wn: int = 3, overlap: bool = False
+                      ) -> Tuple[torch.Tensor, np.ndarray]:
+        """'simple' / 'overlap' patch methods: -> (uint8 [n*count, S, S, 3] on device, boxes float32 [n, count, 4])."""
+        count = self.lib.mq_chunk_grid_count(hn, wn, 1 if overlap else 0)
+        if count <= 0:
+            raise ValueError(f"bad chunk grid hn={hn} wn={wn}")
+        with torch.cuda.device(self.device):
+            p = PackedImages(images, self.device)
+            out = torch.empty(p.n * count, self.S, self.S, 3, dtype=torch.uint8, device=self.device)
+            boxes = np.zeros((p.n, count, 4), dtype=np.float32)
+            if p.n == 0:
+                return out, boxes
+            need = self.lib.mq_chunk_grid_workspace_bytes(p.heights.ctypes.data, p.widths.ctypes.data, p.n, hn, wn,
+                                                          1 if overlap else 0, self.S)
+            ws = self._workspace(need)
+            L.check(self.lib.mq_chunk_grid_u8(p.buffer.data_ptr(), p.offsets.ctypes.data, p.heights.ctypes.data,
+                                              p.widths.ctypes.data, p.n, hn, wn, 1 if overlap else 0, self.S, out.data_ptr(),
+                                              boxes.ctypes.data, ws.data_ptr(), ws.numel(), self._stream()), "mq_chunk_grid_u8")
+            self._keep = p
+        return out, boxes
+
+    def to_tensor_normalize(self, u8: torch.Tensor) -> torch.Tensor:
+        """uint8 [n, S, S, 3] -> fp32 [n, 3, S, S] (ToTensor + Normalize)."""
+        if u8.dtype != torch.uint8 or u8.ndim != 4 or tuple(u8.shape[1:]) != (self.S, self.S, 3):
+            raise ValueError(f"expected uint8 [n, {self.S}, {self.S}, 3], got {u8.dtype} {tuple(u8.shape)}")
+        with torch.cuda.device(self.device):
+            u8 = u8.to(self.device).contiguous()
+            out = torch.empty(u8.shape[0], 3, self.S, self.S, dtype=torch.float32, device=self.device)
+            L.check(self.lib.mq_to_tensor_normalize(u8.data_ptr(), out.data_ptr(), u8.shape[0], self.S, self.mean, self.std,
+                                                    self._stream()), "mq_to_tensor_normalize")
+        return out

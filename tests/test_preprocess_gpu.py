@@ -1,0 +1,98 @@
+"""K10 / K11 parity: the HIP resize / crop / chunk kernels (through the C ABI) must be BIT-EXACT against
+the CPU oracle (oracle/resample.c, itself pinned to Pillow in test_oracle_resample.py)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import preprocess as OP
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [(224, 224), (225, 224), (224, 225), (300, 200), (200, 300), (480, 640), (640, 480), (1000, 37), (37, 1000),
+         (64, 64), (17, 23), (1, 1), (1, 500), (1201, 1600), (2048, 1536), (223, 223), (449, 449)]
+
+
+def _imgs(sizes, seed=0):
+    rng = np.random.default_rng(seed)
+    return [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for h, w in sizes]
+
+
+@pytest.fixture(scope="module")
+def pre():
+    from marqo_amd.engine.preprocess import ImagePreprocessor
+    return ImagePreprocessor("cuda:0", 224)
+
+
+def test_resize_crop_bit_exact(pre):
+    imgs = _imgs(SIZES)
+    out = pre.resize_crop_u8(imgs).cpu().numpy()
+    assert out.shape == (len(imgs), 224, 224, 3)
+    for i, im in enumerate(imgs):
+        ref = OP.clip_resize_crop_u8(im, 224, backend="c")
+        assert np.array_equal(out[i], ref), f"image {i} size {im.shape}: max |d| = {np.abs(out[i].astype(int) - ref).max()}"
+
+
+def test_resize_crop_matches_pillow_directly(pre):
+    imgs = _imgs([(333, 517), (800, 600)], seed=3)
+    out = pre.resize_crop_u8(imgs).cpu().numpy()
+    for i, im in enumerate(imgs):
+        assert np.array_equal(out[i], OP.clip_resize_crop_u8(im, 224, backend="pil"))
+
+
+def test_other_model_resolution():
+    from marqo_amd.engine.preprocess import ImagePreprocessor
+    p = ImagePreprocessor("cuda:0", 336)
+    imgs = _imgs([(500, 400), (336, 336), (100, 700)], seed=5)
+    out = p.resize_crop_u8(imgs).cpu().numpy()
+    for i, im in enumerate(imgs):
+        assert np.array_equal(out[i], OP.clip_resize_crop_u8(im, 336, backend="c"))
+
+
+def test_empty_and_exact_size(pre):
+    assert pre.resize_crop_u8([]).shape == (0, 224, 224, 3)
+    im = _imgs([(224, 224)], seed=9)
+    assert np.array_equal(pre.resize_crop_u8(im).cpu().numpy()[0], im[0])  # Pillow returns a copy when the size matches
+
+
+@pytest.mark.parametrize("hn,wn,overlap", [(3, 3, False), (3, 3, True), (2, 4, False), (1, 1, False), (5, 7, True)])
+def test_chunk_grid_bit_exact(pre, hn, wn, overlap):
+    imgs = _imgs([(480, 640), (240, 240), (100, 333), (900, 50)], seed=11)
+    out, boxes = pre.chunk_grid_u8(imgs, hn, wn, overlap)
+    out = out.cpu().numpy()
+    for i, im in enumerate(imgs):
+        patches, bbs = OP.chunk_image_simple(im, hn, wn, overlap, backend="c")
+        assert boxes.shape[1] == len(patches)
+        for k, (patch, bb) in enumerate(zip(patches, bbs)):
+            ref = OP.clip_resize_crop_u8(patch, 224, backend="c")
+            assert np.array_equal(out[i * len(patches) + k], ref), (i, k, patch.shape)
+            assert np.allclose(boxes[i, k], np.asarray(bb, dtype=np.float32), rtol=1e-6)
+
+
+def test_chunk_count_known_answers(pre):
+    """reference tests/processing/test_image_chunking.py: 3x3 simple -> 1 + 9 patches."""
+    out, boxes = pre.chunk_grid_u8(_imgs([(300, 400)]), 3, 3, False)
+    assert out.shape[0] == 10 and boxes.shape == (1, 10, 4)
+    assert np.allclose(boxes[0, 0], [0, 0, 400, 300])
+
+
+def test_to_tensor_normalize_bit_exact(pre):
+    u8 = torch.from_numpy(np.random.default_rng(2).integers(0, 256, (3, 224, 224, 3), dtype=np.uint8))
+    out = pre.to_tensor_normalize(u8.cuda()).cpu().numpy()
+    ref = np.stack([OP.to_tensor_normalize(u.numpy()) for u in u8])
+    assert out.shape == (3, 3, 224, 224)
+    # same IEEE fp32 ops in the same order: (b/255 - mean)/std
+    assert np.abs(out - ref).max() <= 2.4e-7 * np.abs(ref).max()
+
+
+def test_preprocess_then_tower_equals_u8_path(pre):
+    """`.preprocess`-style fp32 tensors and the fused uint8 path must give the same embeddings."""
+    from marqo_amd.engine import archs, towers
+    from oracle import towers as O
+    arch = archs.VitArch(224, 32, 128, 2, 2, 256, 64)
+    cfg = O.VitConfig(224, 32, 128, 2, 2, 256, 64)
+    sd = O.synthetic_vit_state_dict(cfg, seed=0)
+    tower = towers.VitTower(arch, sd, "cuda:0")
+    u8 = pre.resize_crop_u8(_imgs([(300, 500), (640, 480)], seed=4))
+    a = tower.encode_u8(u8)
+    b = tower.encode_f32(pre.to_tensor_normalize(u8))
+    assert torch.allclose(a, b, atol=2e-3)
