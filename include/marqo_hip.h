@@ -209,6 +209,13 @@ int mq_clip_resize_crop_u8(const uint8_t* d_src, const int64_t* h_src_off, const
                            const int32_t* h_widths, int64_t n, int32_t S, uint8_t* d_out,
                            void* d_workspace, size_t workspace_bytes, void* stream);
 
+/* Plain PIL.Image.resize((out_w, out_h), BICUBIC) of every image (no aspect preservation, no crop): the
+ * chunker's working image (processing/image.py:143).  d_out uint8 [n, out_h, out_w, 3]. */
+size_t mq_resize_workspace_bytes(const int32_t* h_heights, const int32_t* h_widths, int64_t n, int32_t out_h, int32_t out_w);
+int mq_resize_u8(const uint8_t* d_src, const int64_t* h_src_off, const int32_t* h_heights, const int32_t* h_widths,
+                 int64_t n, int32_t out_h, int32_t out_w, uint8_t* d_out, void* d_workspace, size_t workspace_bytes,
+                 void* stream);
+
 /* Grid chunker (PatchifySimple, processing/image.py:120-151; 'simple' / 'overlap' patch methods):
  * every image is resized to 240x240 (no aspect preservation), cut into the whole image + the
  * generate_boxes(hn, wn, overlap) grid (image_utils.py:165-202), and every crop is put through the CLIP

@@ -103,6 +103,8 @@ _SIGNATURES = {
     "mq_l2_normalize": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P]),
     "mq_clip_resize_workspace_bytes": (C.c_size_t, [_P, _P, C.c_int64, C.c_int32]),
     "mq_clip_resize_crop_u8": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, _P, _P, C.c_size_t, _P]),
+    "mq_resize_workspace_bytes": (C.c_size_t, [_P, _P, C.c_int64, C.c_int32, C.c_int32]),
+    "mq_resize_u8": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int32, _P, _P, C.c_size_t, _P]),
     "mq_chunk_grid_count": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
     "mq_chunk_grid_workspace_bytes": (C.c_size_t, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "mq_chunk_grid_u8": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P,
@@ -125,22 +127,40 @@ def sources() -> list:
 
 
 def build(force: bool = False, verbose: bool = False) -> Path:
-    """Compile csrc/*.hip for gfx950 into lib/libmarqo_hip.so (hipcc cross-compiles without a GPU)."""
+    """Compile csrc/*.hip for gfx950 into lib/libmarqo_hip.so (hipcc cross-compiles without a GPU).
+    One object per source, compiled in parallel and cached by mtime under csrc/.obj/, then linked."""
+    from concurrent.futures import ThreadPoolExecutor
     srcs = sources()
-    deps = srcs + [str(CSRC_DIR / "common.h"), str(HEADER_PATH)]
-    if LIB_PATH.exists() and not force:
-        newest = max(os.path.getmtime(p) for p in deps)
-        if os.path.getmtime(LIB_PATH) >= newest:
-            return LIB_PATH
-    LIB_DIR.mkdir(parents=True, exist_ok=True)
+    common = [str(CSRC_DIR / "common.h"), str(HEADER_PATH)]
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
-           *srcs, "-o", str(LIB_PATH)]
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    res = subprocess.run(cmd, capture_output=True, text=True)
-    if res.returncode != 0:
-        raise MarqoHipUnavailableError(f"hipcc failed ({res.returncode}):\n{res.stdout}\n{res.stderr}")
+    obj_dir = CSRC_DIR / ".obj"
+    obj_dir.mkdir(parents=True, exist_ok=True)
+    LIB_DIR.mkdir(parents=True, exist_ok=True)
+    common_mtime = max(os.path.getmtime(p) for p in common)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+    def compile_one(src: str):
+        obj = obj_dir / (Path(src).stem + ".o")
+        if not force and obj.exists() and os.path.getmtime(obj) >= max(os.path.getmtime(src), common_mtime):
+            return str(obj), False
+        cmd = [hipcc, *flags, "-c", src, "-o", str(obj)]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise MarqoHipUnavailableError(f"hipcc failed on {src} ({res.returncode}):\n{res.stdout}\n{res.stderr}")
+        return str(obj), True
+
+    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        results = list(ex.map(compile_one, srcs))
+    objs = [o for o, _ in results]
+    if any(changed for _, changed in results) or not LIB_PATH.exists() or force:
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", str(LIB_PATH)]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise MarqoHipUnavailableError(f"link failed ({res.returncode}):\n{res.stdout}\n{res.stderr}")
     return LIB_PATH
 
 

@@ -347,6 +347,28 @@ extern "C" int mq_clip_resize_crop_u8(const uint8_t* d_src, const int64_t* h_src
     return run_plan(p, d_src, d_out, d_workspace, workspace_bytes, (hipStream_t)stream, "mq_clip_resize_crop_u8");
 }
 
+extern "C" size_t mq_resize_workspace_bytes(const int32_t* h_heights, const int32_t* h_widths, int64_t n, int32_t out_h, int32_t out_w) {
+    if (!h_heights || !h_widths || n <= 0 || out_h < 1 || out_w < 1) return 0;
+    Plan p;
+    for (int64_t i = 0; i < n; ++i) {
+        if (h_heights[i] < 1 || h_widths[i] < 1) return 0;
+        p.add(0, h_widths[i] * 3, h_heights[i], h_widths[i], out_h, out_w, 0, 0, out_h, out_w, 0, out_w * 3);
+    }
+    return p.total_bytes();
+}
+
+extern "C" int mq_resize_u8(const uint8_t* d_src, const int64_t* h_src_off, const int32_t* h_heights, const int32_t* h_widths, int64_t n,
+                            int32_t out_h, int32_t out_w, uint8_t* d_out, void* d_workspace, size_t workspace_bytes, void* stream) {
+    MQ_CHECK_ARG(out_h >= 1 && out_w >= 1, "mq_resize_u8: bad output size %dx%d", out_h, out_w);
+    if (n <= 0) return MQ_OK;
+    MQ_CHECK_ARG(d_src && d_out && d_workspace, "mq_resize_u8: null pointer");
+    MQ_TRY(check_images("mq_resize_u8", h_src_off, h_heights, h_widths, n));
+    Plan p;
+    for (int64_t i = 0; i < n; ++i)
+        p.add(h_src_off[i], h_widths[i] * 3, h_heights[i], h_widths[i], out_h, out_w, 0, 0, out_h, out_w, i * (int64_t)out_h * out_w * 3, out_w * 3);
+    return run_plan(p, d_src, d_out, d_workspace, workspace_bytes, (hipStream_t)stream, "mq_resize_u8");
+}
+
 extern "C" int mq_chunk_grid_count(int32_t hn, int32_t wn, int32_t overlap) {
     if (hn < 1 || wn < 1 || hn > CHUNK_SIZE || wn > CHUNK_SIZE) return 0;
     std::vector<int> b;

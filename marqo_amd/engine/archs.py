@@ -75,12 +75,14 @@ class BertArch:
 
 _TEXT_B = ClipTextArch(vocab=49408, ctx=77, width=512, layers=12, heads=8, mlp_dim=2048, out_dim=512)
 _TEXT_L = ClipTextArch(vocab=49408, ctx=77, width=768, layers=12, heads=12, mlp_dim=3072, out_dim=768)
+_TEXT_B_PLUS = ClipTextArch(vocab=49408, ctx=77, width=640, layers=12, heads=10, mlp_dim=2560, out_dim=640)
 
 # open_clip architecture name -> (vision, text)
 OPEN_CLIP_ARCHS = {
     "ViT-B-32": (VitArch(224, 32, 768, 12, 12, 3072, 512), _TEXT_B),
     "ViT-B-32-256": (VitArch(256, 32, 768, 12, 12, 3072, 512), _TEXT_B),
     "ViT-B-16": (VitArch(224, 16, 768, 12, 12, 3072, 512), _TEXT_B),
+    "ViT-B-16-plus-240": (VitArch(240, 16, 896, 12, 14, 3584, 640), _TEXT_B_PLUS),
     "ViT-L-14": (VitArch(224, 14, 1024, 24, 16, 4096, 768), _TEXT_L),
     "ViT-L-14-336": (VitArch(336, 14, 1024, 24, 16, 4096, 768), _TEXT_L),
 }

@@ -90,6 +90,20 @@ class ImagePreprocessor:
             self._keep = p  # the packed source must outlive the enqueued kernels
         return out
 
+    def resize_u8(self, images: Sequence[ArrayLike], out_h: int, out_w: int) -> torch.Tensor:
+        """PIL.Image.resize((out_w, out_h)) (default BICUBIC) of every image -> uint8 [n, out_h, out_w, 3] on device."""
+        with torch.cuda.device(self.device):
+            p = PackedImages(images, self.device)
+            out = torch.empty(p.n, out_h, out_w, 3, dtype=torch.uint8, device=self.device)
+            if p.n == 0:
+                return out
+            need = self.lib.mq_resize_workspace_bytes(p.heights.ctypes.data, p.widths.ctypes.data, p.n, out_h, out_w)
+            ws = self._workspace(need)
+            L.check(self.lib.mq_resize_u8(p.buffer.data_ptr(), p.offsets.ctypes.data, p.heights.ctypes.data, p.widths.ctypes.data,
+                                          p.n, out_h, out_w, out.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()), "mq_resize_u8")
+            self._keep = p
+        return out
+
     def chunk_grid_u8(self, images: Sequence[ArrayLike], hn: int = 3, wn: int = 3, overlap: bool = False
                       ) -> Tuple[torch.Tensor, np.ndarray]:
         """'simple' / 'overlap' patch methods: -> (uint8 [n*count, S, S, 3] on device, boxes float32 [n, count, 4])."""

@@ -1,0 +1,147 @@
+"""`hf` / `hf_stella` loaders of the engine.
+
+Drop-in for HuggingFaceModel (src/marqo/core/inference/embedding_models/hugging_face_model.py:24-214): same ctor,
+load(), encode(sentence, normalize=True, **kwargs) -> np.ndarray[N, D] fp32.  Tokenisation keeps the reference's flags
+(padding=True, truncation=True, max_length=tokens, :179-185); the BERT encoder, masked mean / CLS pooling (:205-214) and
+F.normalize (:194-195) run in libmarqo_hip.so on packed (un-padded) sequences.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Optional, Union
+
+import numpy as np
+import torch
+
+from marqo_amd import _lib as L
+from marqo_amd.engine import archs, checkpoint, synthetic
+from marqo_amd.engine.tokenizers import SyntheticTokenizer, WordPieceTokenizer
+from marqo_amd.s2_inference.abstract_models import AbstractEmbeddingModel
+from marqo_amd.s2_inference.errors import InternalError, InvalidModelPropertiesError, ModelLoadError
+
+
+class HuggingFaceModelProperties:
+    """Validated view of model_properties (reference: hugging_face_model_properties.py:40-137)."""
+
+    def __init__(self, **p):
+        dims = p.get("dimensions")
+        if not isinstance(dims, int) or dims < 1:
+            raise ValueError("'dimensions' must be a positive integer")
+        self.dimensions: int = dims
+        self.type: str = p.get("type")
+        if self.type not in ("hf", "hf_stella"):
+            raise ValueError("The type of the model should be 'hf' or 'hf_stella'.")
+        self.name: Optional[str] = p.get("name")
+        self.tokens: int = int(p.get("tokens", 128))
+        self.url: Optional[str] = p.get("url")
+        self.model_location = p.get("model_location", p.get("modelLocation"))
+        if self.url and self.model_location:
+            raise ValueError("Only one of 'url' and 'model_location' should be provided.")
+        if not self.name and not (self.url or self.model_location):
+            raise ValueError("At least one of 'name', 'url', or 'model_location' should be provided.")
+        pm = p.get("pooling_method", p.get("poolingMethod"))
+        if pm is not None and pm not in ("mean", "cls"):
+            raise ValueError("pooling_method must be 'mean' or 'cls'")
+        self.pooling_method: Optional[str] = pm  # None: inferred at load from 1_Pooling/config.json, default mean
+        self.trust_remote_code: bool = bool(p.get("trust_remote_code", p.get("trustRemoteCode", False)))
+
+    def dict(self) -> dict:
+        return dict(self.__dict__)
+
+
+class HuggingFaceModel(AbstractEmbeddingModel):
+    supports_dynamic_batching = True
+    _requires_trust_remote_code = False
+
+    def __init__(self, model_properties: dict, device: str, model_auth=None, model_flags=None, tokenizer_flags=None):
+        super().__init__(model_properties, device, model_auth)
+        self.model_properties = self._build_model_properties(model_properties or {})
+        self._model = None
+        self._tokenizer = None
+        self._pooling_func = None
+        self.weights_source = None
+
+    def _build_model_properties(self, model_properties: dict) -> HuggingFaceModelProperties:
+        try:
+            parsed = HuggingFaceModelProperties(**model_properties)
+        except (ValueError, TypeError) as e:
+            raise InvalidModelPropertiesError(f"Invalid model properties: {model_properties}. Original error {e}") from e
+        if self._requires_trust_remote_code and not parsed.trust_remote_code:
+            raise InvalidModelPropertiesError("The specified model requires the 'trustRemoteCode' attribute to be set to True. "
+                                              "Setting this attribute to True may have security implications.")
+        return parsed
+
+    def _check_loaded_components(self):
+        if self._model is None:
+            raise InternalError("Model is not loaded!")
+        if self._tokenizer is None:
+            raise InternalError("Tokenizer is not loaded!")
+        if self._pooling_func is None:
+            raise InternalError("Pooling function is not loaded!")
+
+    def _load_necessary_components(self):
+        if not str(self.device).startswith("cuda"):
+            raise L.MarqoHipUnavailableError(
+                f"marqo_amd runs its towers on an AMD GPU only (device 'cuda' / 'cuda:N' on ROCm); got {self.device!r}")
+        from marqo_amd.engine import towers
+        props = self.model_properties
+        if not props.name:
+            raise ModelLoadError("downloading model archives ('url' / 'model_location') is control-plane work outside the marqo_amd "
+                                 "engine; unpack the archive on disk and pass its directory as 'name'")
+        directory = checkpoint.find_hf_dir(props.name)
+        if directory is not None:
+            cfg, sd = checkpoint.load_hf_dir(directory)
+            try:
+                arch = archs.bert_arch_from_hf_config(cfg)
+            except KeyError as e:
+                raise InvalidModelPropertiesError(f"{props.name}: {e}. Only BERT-family encoders run on the marqo_amd engine.") from e
+            self._tokenizer = WordPieceTokenizer(directory, do_lower_case=self._do_lower_case(directory))
+            self.weights_source = directory
+        elif checkpoint.synthetic_weights_enabled() and props.name in archs.HF_BERT_ARCHS:
+            arch = archs.HF_BERT_ARCHS[props.name]
+            sd = synthetic.random_bert_state_dict(arch, seed=0)
+            self._tokenizer = SyntheticTokenizer("bert", arch.vocab)
+            self.weights_source = "synthetic(seed=0)"
+        else:
+            raise InvalidModelPropertiesError(
+                f"Marqo encountered an error loading the Hugging Face model, modelProperties={props.dict()}. No local copy under "
+                f"{checkpoint.model_dir()} or the Hugging Face cache (there is no network download in the marqo_amd engine).")
+        if arch.width != props.dimensions:
+            raise InvalidModelPropertiesError(f"'dimensions'={props.dimensions} but the encoder width is {arch.width}")
+        pooling = props.pooling_method or checkpoint.read_pooling_config(directory) or "mean"
+        self.arch = arch
+        self._model = towers.BertTower(arch, sd, self.device, pooling=pooling)
+        self._pooling_func = pooling
+
+    @staticmethod
+    def _do_lower_case(directory: str) -> bool:
+        import json
+        for name in ("tokenizer_config.json",):
+            p = os.path.join(directory, name)
+            if os.path.isfile(p):
+                try:
+                    with open(p) as f:
+                        return bool(json.load(f).get("do_lower_case", True))
+                except (OSError, ValueError):
+                    pass
+        return True
+
+    def encode(self, sentence: Union[str, List[str]], normalize=True, **kwargs) -> np.ndarray:
+        if isinstance(sentence, str):
+            sentence = [sentence]
+        if self._model is None:
+            self.load()
+        tok = self._tokenizer(sentence, max_length=self.model_properties.tokens)
+        ids = torch.from_numpy(tok["input_ids"])
+        mask = torch.from_numpy(tok["attention_mask"])
+        return self._model.encode_ids(ids, mask, normalize=bool(normalize)).cpu().numpy()
+
+
+class HuggingFaceStellaModel(HuggingFaceModel):
+    """hf_stella (hugging_face_stella_model.py:9-23) runs custom remote code in the reference; its encoder is not a plain BERT,
+    so the engine only keeps the property validation (trustRemoteCode) and refuses at load."""
+    _requires_trust_remote_code = True
+
+    def _load_necessary_components(self):
+        raise InvalidModelPropertiesError("hf_stella models run custom (remote) encoder code that is not a plain BERT; not supported by the "
+                                          "marqo_amd engine yet")

@@ -1,0 +1,119 @@
+"""Model registry + loader map of the engine.
+
+Same shape as the reference's ``load_model_properties()`` (src/marqo/s2_inference/model_registry.py:2147-2187):
+``{'models': {name: properties}, 'loaders': {type: loader class}}``.  Only the model families the gfx950 towers
+run are registered: CLIP ViTs with attention head dim 64 behind the ``open_clip`` (and OpenAI ``clip`` /
+``fp16_clip`` naming) loaders, BERT-family encoders behind ``hf``, plus the reference's own plumbing fakes
+``random`` (random_utils.py) and ``no_model``.  Entries are generated from the architecture tables in
+``marqo_amd.engine.archs`` — names, dimensions, token limits and prefixes follow the reference registry
+(model_registry.py:76-610 open_clip, :616-880 hf) so an index created against the reference resolves here.
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+from marqo_amd.engine import archs
+
+# pretrained tags the reference registers for the supported architectures (model_registry.py:76-610)
+_OPEN_CLIP_TAGS = {
+    "ViT-B-32": ["laion400m_e31", "laion400m_e32", "laion2b_e16", "laion2b_s34b_b79k", "openai"],
+    "ViT-B-32-quickgelu": ["laion400m_e31", "laion400m_e32", "openai"],
+    "ViT-B-16": ["laion400m_e31", "laion400m_e32", "laion2b_s34b_b88k", "openai"],
+    "ViT-B-16-plus-240": ["laion400m_e31", "laion400m_e32"],
+    "ViT-L-14": ["laion400m_e31", "laion400m_e32", "laion2b_s32b_b82k", "openai"],
+    "ViT-L-14-336": ["openai"],
+}
+
+# hf registry entries whose encoder is a plain BERT (absolute positions, GELU, post-LN): name -> (repo, dims, tokens, prefixes)
+_HF_BERT = {
+    "hf/all-MiniLM-L6-v1": ("sentence-transformers/all-MiniLM-L6-v1", 384, 128, None, None),
+    "hf/all-MiniLM-L6-v2": ("sentence-transformers/all-MiniLM-L6-v2", 384, 128, None, None),
+    "hf/all_datasets_v3_MiniLM-L12": ("flax-sentence-embeddings/all_datasets_v3_MiniLM-L12", 384, 128, None, None),
+    "hf/all_datasets_v3_MiniLM-L6": ("flax-sentence-embeddings/all_datasets_v3_MiniLM-L6", 384, 128, None, None),
+    "hf/all_datasets_v4_MiniLM-L12": ("flax-sentence-embeddings/all_datasets_v4_MiniLM-L12", 384, 128, None, None),
+    "hf/all_datasets_v4_MiniLM-L6": ("flax-sentence-embeddings/all_datasets_v4_MiniLM-L6", 384, 128, None, None),
+    "hf/e5-small": ("intfloat/e5-small", 384, 192, "query: ", "passage: "),
+    "hf/e5-base": ("intfloat/e5-base", 768, 192, "query: ", "passage: "),
+    "hf/e5-large": ("intfloat/e5-large", 1024, 192, "query: ", "passage: "),
+    "hf/e5-small-unsupervised": ("intfloat/e5-small-unsupervised", 384, 128, "query: ", "passage: "),
+    "hf/e5-base-unsupervised": ("intfloat/e5-base-unsupervised", 768, 128, "query: ", "passage: "),
+    "hf/e5-large-unsupervised": ("intfloat/e5-large-unsupervised", 1024, 128, "query: ", "passage: "),
+    "hf/e5-small-v2": ("intfloat/e5-small-v2", 384, 512, "query: ", "passage: "),
+    "hf/e5-base-v2": ("intfloat/e5-base-v2", 768, 512, "query: ", "passage: "),
+    "hf/e5-large-v2": ("intfloat/e5-large-v2", 1024, 512, "query: ", "passage: "),
+    "hf/bge-small-en-v1.5": ("BAAI/bge-small-en-v1.5", 384, 512, "Represent this sentence for searching relevant passages: ", ""),
+    "hf/bge-base-en-v1.5": ("BAAI/bge-base-en-v1.5", 768, 512, "Represent this sentence for searching relevant passages: ", ""),
+    "hf/bge-large-en-v1.5": ("BAAI/bge-large-en-v1.5", 1024, 512, "Represent this sentence for searching relevant passages: ", ""),
+    "hf/snowflake-arctic-embed-m": ("Snowflake/snowflake-arctic-embed-m", 768, 512, "Represent this sentence for searching relevant passages: ", ""),
+    "hf/snowflake-arctic-embed-m-v1.5": ("Snowflake/snowflake-arctic-embed-m-v1.5", 768, 512, "Represent this sentence for searching relevant passages: ", ""),
+    "hf/snowflake-arctic-embed-l": ("Snowflake/snowflake-arctic-embed-l", 1024, 512, "Represent this sentence for searching relevant passages: ", ""),
+    "hf/ember-v1": ("llmrails/ember-v1", 1024, 512, None, None),
+    "hf/GIST-large-Embedding-v0": ("avsolatorio/GIST-large-Embedding-v0", 1024, 512, None, None),
+}
+
+
+def _get_open_clip_properties() -> Dict:
+    out = {}
+    for arch_name, tags in _OPEN_CLIP_TAGS.items():
+        vision, _ = archs.resolve_open_clip(arch_name)
+        for tag in tags:
+            name = f"open_clip/{arch_name}/{tag}"
+            out[name] = {"name": name, "dimensions": vision.out_dim, "note": f"open_clip {arch_name} ({tag})",
+                         "type": "open_clip", "pretrained": tag}
+    return out
+
+
+def _get_clip_properties() -> Dict:
+    """OpenAI-CLIP names (model_registry.py:16-73) and their fp16 variants (:2069-2092): same towers, QuickGELU."""
+    out = {}
+    for openai_name, arch_name in archs.OPENAI_CLIP_NAMES.items():
+        vision, _ = archs.resolve_open_clip(arch_name, "openai")
+        out[openai_name] = {"name": openai_name, "dimensions": vision.out_dim, "notes": "CLIP resnet", "type": "clip"}
+        out["fp16/" + openai_name] = {"name": "fp16/" + openai_name, "dimensions": vision.out_dim, "type": "fp16_clip",
+                                      "notes": "reduced-precision CLIP; on MI355X every CLIP tower already runs bf16 MFMA"}
+    return out
+
+
+def _get_hf_properties() -> Dict:
+    out = {}
+    for key, (repo, dims, tokens, qp, cp) in _HF_BERT.items():
+        p = {"name": repo, "dimensions": dims, "tokens": tokens, "type": "hf", "notes": ""}
+        if qp is not None:
+            p["text_query_prefix"] = qp
+        if cp is not None:
+            p["text_chunk_prefix"] = cp
+        out[key] = p
+    return out
+
+
+def _get_random_properties() -> Dict:
+    """random/* plumbing fakes (model_registry.py:2094-2123)."""
+    return {
+        "random": {"name": "random", "dimensions": 384, "tokens": 128, "type": "random", "notes": ""},
+        "random/large": {"name": "random/large", "dimensions": 768, "tokens": 128, "type": "random", "notes": ""},
+        "random/small": {"name": "random/small", "dimensions": 32, "tokens": 128, "type": "random", "notes": ""},
+        "random/medium": {"name": "random/medium", "dimensions": 128, "tokens": 128, "type": "random", "notes": ""},
+    }
+
+
+def _get_no_model_properties() -> Dict:
+    return {"no_model": {"type": "no_model", "note": "special model no_model: users provide 'dimensions' and vectors"}}
+
+
+def _get_model_load_mappings() -> Dict:
+    # imported here so that `import marqo_amd.s2_inference.model_registry` stays cheap and free of cycles
+    from marqo_amd.s2_inference.open_clip_model import CLIP, FP16_CLIP, OPEN_CLIP
+    from marqo_amd.s2_inference.hugging_face_model import HuggingFaceModel, HuggingFaceStellaModel
+    from marqo_amd.s2_inference.random_utils import NO_MODEL, Random
+    return {"open_clip": OPEN_CLIP, "clip": CLIP, "fp16_clip": FP16_CLIP, "hf": HuggingFaceModel,
+            "hf_stella": HuggingFaceStellaModel, "random": Random, "no_model": NO_MODEL}
+
+
+def load_model_properties() -> Dict:
+    models: Dict = {}
+    models.update(_get_clip_properties())
+    models.update(_get_random_properties())
+    models.update(_get_hf_properties())
+    models.update(_get_open_clip_properties())
+    models.update(_get_no_model_properties())
+    return {"models": models, "loaders": dict(_get_model_load_mappings())}

@@ -1,0 +1,307 @@
+"""CLIP-family loaders of the engine: `OPEN_CLIP` (type 'open_clip'), `CLIP` (type 'clip'), `FP16_CLIP`.
+
+Drop-in for the reference's loader classes
+  OPEN_CLIP  src/marqo/core/inference/embedding_models/open_clip_model.py:28-285
+  CLIP       src/marqo/s2_inference/clip_utils.py:295-492        FP16_CLIP  :495-518
+with the same constructor / load() / encode() / encode_text() / encode_image() / .preprocess surface
+(SURVEY.md §8b), but `self.model` is a pair of HIP towers (marqo_amd.engine.towers) instead of a torch module:
+every FLOP runs in libmarqo_hip.so on the MI355X, and images are resized on the GPU too.
+
+Precision rule (reference open_clip_model.py:255-260: fp16 autocast on cuda, fp32 on cpu): here the device is
+always an AMD GPU and the towers always run bf16 MFMA with fp32 accumulation / residual stream; outputs are fp32.
+"""
+from __future__ import annotations
+
+import json
+import os
+import threading
+from typing import Dict, List, Optional, Sequence, Union
+
+import numpy as np
+import torch
+from PIL.Image import Image as ImageType
+
+from marqo_amd import _lib as L
+from marqo_amd.engine import archs, checkpoint, synthetic
+from marqo_amd.engine.tokenizers import ClipBpeTokenizer, SyntheticTokenizer, WordPieceTokenizer
+from marqo_amd.s2_inference.abstract_models import AbstractCLIPModel
+from marqo_amd.s2_inference.errors import InvalidModelPropertiesError, ModelLoadError
+from marqo_amd.s2_inference.image_input import format_and_load_CLIP_image, format_and_load_CLIP_images, pil_to_rgb_u8
+
+HF_HUB_PREFIX = "hf-hub:"
+MARQO_OPEN_CLIP_REGISTRY_PREFIX = "open_clip/"
+BPE_VOCAB_FILE = "bpe_simple_vocab_16e6.txt.gz"
+
+_PREPROCESSOR_NORMS = {
+    # image_preprocessor -> (mean, std); OpenCLIP / OpenAI share the OpenAI dataset statistics (clip_utils.py:32-33)
+    "OpenCLIP": (archs.OPENAI_DATASET_MEAN, archs.OPENAI_DATASET_STD),
+    "OpenAI": (archs.OPENAI_DATASET_MEAN, archs.OPENAI_DATASET_STD),
+}
+
+
+class OpenCLIPModelProperties:
+    """Validated view of the user's model_properties (reference: open_clip_model_properties.py:24-73)."""
+    _KNOWN = {"name", "dimensions", "type", "jit", "precision", "url", "localpath", "model_location", "modelLocation",
+              "tokenizer", "image_preprocessor", "imagePreprocessor", "mean", "std", "size", "note", "notes", "pretrained",
+              "model_size", "text_query_prefix", "text_chunk_prefix", "tokens"}
+
+    def __init__(self, **p):
+        if not isinstance(p.get("name"), str) or not p["name"]:
+            raise ValueError("'name' is required and must be a string")
+        dims = p.get("dimensions")
+        if not isinstance(dims, int) or dims < 1:
+            raise ValueError("'dimensions' must be a positive integer")
+        if "type" not in p:
+            raise ValueError("'type' is required")
+        self.name: str = p["name"]
+        self.dimensions: int = dims
+        self.type: str = p["type"]
+        self.jit: bool = bool(p.get("jit", False))
+        self.precision: str = p.get("precision", "fp32")
+        if self.precision not in ("fp32", "fp16"):
+            raise ValueError("'precision' must be 'fp32' or 'fp16'")
+        self.url: Optional[str] = p.get("url")
+        self.localpath: Optional[str] = p.get("localpath")
+        self.model_location = p.get("model_location", p.get("modelLocation"))
+        if sum(1 for f in (self.url, self.localpath, self.model_location) if f is not None) > 1:
+            raise ValueError("Only one of 'url', 'localpath', or 'model_location' should be provided.")
+        self.tokenizer: Optional[str] = p.get("tokenizer")
+        self.image_preprocessor: str = p.get("image_preprocessor", p.get("imagePreprocessor", "OpenCLIP"))
+        if self.image_preprocessor not in ("SigLIP", "OpenAI", "OpenCLIP", "CLIPA"):
+            raise ValueError(f"invalid image_preprocessor {self.image_preprocessor!r}")
+        self.mean: Optional[List[float]] = p.get("mean")
+        self.std: Optional[List[float]] = p.get("std")
+        self.size: Optional[int] = p.get("size")
+        self.pretrained: Optional[str] = p.get("pretrained")
+
+    def dict(self) -> dict:
+        return dict(self.__dict__)
+
+
+class OPEN_CLIP(AbstractCLIPModel):
+    supports_dynamic_batching = True
+
+    def __init__(self, device: Optional[str] = None, model_properties: Optional[Dict] = None, model_auth=None) -> None:
+        super().__init__(device, model_properties, model_auth)
+        self.model_properties = self._build_model_properties(model_properties or {})
+        self.preprocess_config = None
+        self._local = threading.local()
+        self.vision_arch: Optional[archs.VitArch] = None
+        self.text_arch: Optional[archs.ClipTextArch] = None
+        self.weights_source = None
+
+    def _build_model_properties(self, model_properties: dict) -> OpenCLIPModelProperties:
+        try:
+            return OpenCLIPModelProperties(**model_properties)
+        except (ValueError, TypeError) as e:
+            raise InvalidModelPropertiesError(f"Invalid model properties: {model_properties}. Original error: {e}") from e
+
+    # ---- loading -------------------------------------------------------------------------------------------
+    def _architecture_and_tag(self):
+        name, props = self.model_properties.name, self.model_properties
+        if props.url is not None or props.localpath is not None or props.model_location is not None:
+            return name, props.pretrained
+        if name.startswith(HF_HUB_PREFIX):
+            return name, None
+        if name.startswith(MARQO_OPEN_CLIP_REGISTRY_PREFIX):
+            parts = name.split("/", 3)
+            if len(parts) < 3:
+                raise InvalidModelPropertiesError(f"open_clip registry names look like open_clip/<arch>/<pretrained>, got {name}")
+            return parts[1], parts[2]
+        raise InvalidModelPropertiesError("Marqo cannot load the provided open_clip model: expected a custom checkpoint "
+                                          "('url' / 'localpath' / 'model_location'), an 'hf-hub:' name or an 'open_clip/' registry name")
+
+    def _resolve_archs(self, arch_name: str, tag: Optional[str], ckpt_dir: Optional[str]):
+        if arch_name.startswith(HF_HUB_PREFIX):
+            cfg_path = os.path.join(ckpt_dir or "", "open_clip_config.json")
+            if not os.path.isfile(cfg_path):
+                raise ModelLoadError(f"{arch_name}: open_clip_config.json not found next to the checkpoint")
+            with open(cfg_path) as f:
+                mc = json.load(f)["model_cfg"]
+            v, t = mc["vision_cfg"], mc["text_cfg"]
+            if not isinstance(v.get("layers"), int) or "hf_model_name" in t:
+                raise InvalidModelPropertiesError(f"{arch_name}: only plain CLIP ViT + CLIP text towers are supported. {archs.UNSUPPORTED_HINT}")
+            head = v.get("head_width", 64)
+            vision = archs.VitArch(v.get("image_size", 224), v["patch_size"], v["width"], v["layers"], v["width"] // head,
+                                   int(v["width"] * v.get("mlp_ratio", 4.0)), mc["embed_dim"], bool(mc.get("quick_gelu", False)))
+            text = archs.ClipTextArch(t.get("vocab_size", 49408), t.get("context_length", 77), t.get("width", 512), t.get("layers", 12),
+                                      t.get("heads", 8), int(t.get("width", 512) * t.get("mlp_ratio", 4.0)), mc["embed_dim"],
+                                      bool(mc.get("quick_gelu", False)))
+            return vision, text
+        try:
+            return archs.resolve_open_clip(arch_name, tag)
+        except KeyError as e:
+            raise InvalidModelPropertiesError(str(e)) from e
+
+    def _load_necessary_components(self) -> None:
+        if not str(self.device).startswith("cuda"):
+            raise L.MarqoHipUnavailableError(
+                f"marqo_amd runs its towers on an AMD GPU only (device 'cuda' / 'cuda:N' on ROCm); got {self.device!r}")
+        from marqo_amd.engine import towers
+        from marqo_amd.engine.preprocess import ImagePreprocessor
+        arch_name, tag = self._architecture_and_tag()
+        props = self.model_properties
+        if props.url is not None or props.model_location is not None:
+            raise ModelLoadError("downloading checkpoints ('url' / 'model_location') is control-plane work outside the marqo_amd "
+                                 "engine; place the file on disk and pass 'localpath'")
+        if props.localpath is not None and not os.path.exists(props.localpath):
+            raise InvalidModelPropertiesError(f"The localpath '{props.localpath}' does not exist. Please provide a valid localpath "
+                                              f"to load the model.")
+        ckpt = checkpoint.find_open_clip_checkpoint(props.name, props.localpath)
+        ckpt_dir = os.path.dirname(ckpt) if ckpt and os.path.isfile(ckpt) else ckpt
+        self.vision_arch, self.text_arch = self._resolve_archs(arch_name, tag, ckpt_dir)
+        if props.size is not None and props.size != self.vision_arch.image_size:
+            raise InvalidModelPropertiesError(f"'size'={props.size} does not match the architecture's image size {self.vision_arch.image_size}")
+        if self.vision_arch.out_dim != props.dimensions:
+            raise InvalidModelPropertiesError(f"'dimensions'={props.dimensions} but {arch_name} produces {self.vision_arch.out_dim}-d embeddings")
+        if ckpt is not None:
+            sd = checkpoint.load_state_dict(ckpt)
+            self.weights_source = ckpt
+        elif checkpoint.synthetic_weights_enabled():
+            sd = synthetic.random_open_clip_state_dict(vision=self.vision_arch, text=self.text_arch, seed=0)
+            self.weights_source = "synthetic(seed=0)"
+        else:
+            raise ModelLoadError(f"no checkpoint for {props.name} under {checkpoint.model_dir()} (and no 'localpath'). There is no "
+                                 f"network download in the marqo_amd engine; set MARQO_AMD_SYNTHETIC_WEIGHTS=1 for random-init weights.")
+        if props.image_preprocessor not in _PREPROCESSOR_NORMS:
+            raise InvalidModelPropertiesError(f"image_preprocessor={props.image_preprocessor} (squash-resize pipelines) is not supported "
+                                              f"by the marqo_amd engine yet; supported: {sorted(_PREPROCESSOR_NORMS)}")
+        mean, std = _PREPROCESSOR_NORMS[props.image_preprocessor]
+        self._mean = tuple(props.mean) if props.mean is not None else mean
+        self._std = tuple(props.std) if props.std is not None else std
+        self.preprocess_config = {"size": self.vision_arch.image_size, "mean": self._mean, "std": self._std,
+                                  "interpolation": "bicubic", "resize_mode": "shortest"}
+        self.vision = towers.VitTower(self.vision_arch, sd, self.device, mean=self._mean, std=self._std)
+        self.text = towers.ClipTextTower(self.text_arch, sd, self.device)
+        self.model = (self.vision, self.text)
+        self.tokenizer = self._load_tokenizer(ckpt_dir)
+        self._ImagePreprocessor = ImagePreprocessor
+        self.preprocess = self._preprocess_one
+
+    def _load_tokenizer(self, ckpt_dir: Optional[str]):
+        props = self.model_properties
+        if props.tokenizer:
+            d = checkpoint.find_hf_dir(props.tokenizer) or (props.tokenizer if os.path.isdir(props.tokenizer) else None)
+            if d is None:
+                raise ModelLoadError(f"custom tokenizer {props.tokenizer!r} not found on disk")
+            wp = WordPieceTokenizer(d)
+            ctx = self.text_arch.ctx
+            # open_clip HFTokenizer: padding='max_length', truncation=True -> ids only (hf_tokenizer.py:19-32)
+            def hf_tok(texts):
+                if isinstance(texts, str):
+                    texts = [texts]
+                out = np.zeros((len(texts), ctx), dtype=np.int64)
+                for i, t in enumerate(texts):
+                    ids = wp.encode(t, max_length=ctx)
+                    out[i, :len(ids)] = ids
+                return out
+            return hf_tok
+        for d in filter(None, (ckpt_dir, checkpoint.model_dir(), os.path.join(checkpoint.model_dir(), "open_clip"))):
+            p = os.path.join(d, BPE_VOCAB_FILE)
+            if os.path.isfile(p):
+                return ClipBpeTokenizer(p, context_length=self.text_arch.ctx)
+        if self.weights_source and str(self.weights_source).startswith("synthetic"):
+            return SyntheticTokenizer("clip", self.text_arch.vocab, self.text_arch.ctx)
+        raise ModelLoadError(f"CLIP BPE vocabulary {BPE_VOCAB_FILE} not found next to the checkpoint or under {checkpoint.model_dir()}")
+
+    def _check_loaded_components(self):
+        if self.model is None:
+            raise RuntimeError("The open_clip model is not loaded. Please load the model before inference.")
+        if self.tokenizer is None:
+            raise RuntimeError("The open_clip tokenizer is not loaded. Please load the tokenizer before inference.")
+        if self.preprocess is None:
+            raise RuntimeError("The open_clip image preprocessor is not loaded. Please load the image preprocessor before inference.")
+
+    # ---- preprocessing ---------------------------------------------------------------------------------------
+    def _pre(self):
+        """one ImagePreprocessor (scratch workspace) per calling thread: `.preprocess` is invoked concurrently from the
+        media download threads (add_docs.py:354-375)"""
+        p = getattr(self._local, "pre", None)
+        if p is None:
+            p = self._local.pre = self._ImagePreprocessor(self.device, self.vision_arch.image_size, self._mean, self._std)
+        return p
+
+    def _preprocess_one(self, image: ImageType) -> torch.Tensor:
+        """PIL image -> Tensor[3, S, S] fp32 (normalised), ALREADY on the device: resize / crop / normalise run on the GPU.
+        Callers' `.to(device)` (add_docs.py:134) is then a no-op."""
+        pre = self._pre()
+        u8 = pre.resize_crop_u8([pil_to_rgb_u8(image)])
+        return pre.to_tensor_normalize(u8)[0]
+
+    def _preprocess_images(self, images, image_download_headers: Optional[Dict] = None):
+        """-> ('u8', uint8 [n,S,S,3]) or ('f32', fp32 [n,3,S,S]) on the device."""
+        if self.model is None:
+            self.load()
+        headers = image_download_headers or dict()
+        if isinstance(images, list):
+            loaded = format_and_load_CLIP_images(images, headers)
+        else:
+            loaded = [format_and_load_CLIP_image(images, headers)]
+        if isinstance(images, torch.Tensor) and images.ndim == 4:  # an already stacked batch
+            return "f32", images
+        tensors = [i for i in loaded if isinstance(i, torch.Tensor)]
+        pre = self._pre()
+        if len(tensors) == len(loaded):
+            return "f32", torch.stack([t.to(self.device) for t in tensors])
+        raw = [pil_to_rgb_u8(i) for i in loaded if not isinstance(i, torch.Tensor)]
+        u8 = pre.resize_crop_u8(raw)
+        if not tensors:
+            return "u8", u8
+        f32 = iter(pre.to_tensor_normalize(u8))
+        return "f32", torch.stack([i.to(self.device) if isinstance(i, torch.Tensor) else next(f32) for i in loaded])
+
+    # ---- encode ------------------------------------------------------------------------------------------------
+    def _convert_output(self, output: torch.Tensor) -> np.ndarray:
+        return output.cpu().numpy()
+
+    def encode_image(self, images, image_download_headers: Optional[Dict] = None, normalize=True) -> np.ndarray:
+        kind, px = self._preprocess_images(images, image_download_headers)
+        self.image_input_processed = px
+        out = self.vision.encode_u8(px, normalize=bool(normalize)) if kind == "u8" else self.vision.encode_f32(px, normalize=bool(normalize))
+        return self._convert_output(out)
+
+    def encode_text(self, sentence: Union[str, List[str]], normalize=True) -> np.ndarray:
+        if self.model is None:
+            self.load()
+        ids = self.tokenizer(sentence)
+        ids = torch.as_tensor(np.asarray(ids))
+        return self._convert_output(self.text.encode_ids(ids, normalize=bool(normalize)))
+
+    # engine extensions used by the chunking / bulk-ingest path ------------------------------------------------------
+    def encode_image_chunks(self, images: Sequence, hn: int = 3, wn: int = 3, overlap: bool = False, normalize=True):
+        """'simple' / 'overlap' patch methods entirely on the device: -> (embeddings [n, count, D], boxes [n, count, 4])."""
+        raw = [pil_to_rgb_u8(i) if isinstance(i, ImageType) else np.asarray(i) for i in images]
+        u8, boxes = self._pre().chunk_grid_u8(raw, hn, wn, overlap)
+        emb = self._convert_output(self.vision.encode_u8(u8, normalize=bool(normalize)))
+        return emb.reshape(len(raw), -1, emb.shape[-1]), boxes
+
+
+class CLIP(OPEN_CLIP):
+    """OpenAI-CLIP names ('ViT-B/32', 'ViT-L/14' ...), legacy loader signature (s2_inference.py:559-566):
+    CLIP(name, device=, embedding_dim=, model_properties=, model_auth=, max_seq_length=).  Same towers with QuickGELU."""
+
+    def __init__(self, model_type: str = "ViT-B/32", device: str = None, embedding_dim: int = None, truncate: bool = True,
+                 model_properties: Optional[dict] = None, model_auth=None, **kwargs) -> None:
+        props = dict(model_properties or {})
+        name = props.get("name", model_type)
+        base = name[len("fp16/"):] if name.startswith("fp16/") else name
+        if base in archs.OPENAI_CLIP_NAMES and not (props.get("localpath") or props.get("url")):
+            props["name"] = f"open_clip/{archs.OPENAI_CLIP_NAMES[base]}/openai"
+        elif base in archs.OPENAI_CLIP_NAMES:
+            props["name"] = archs.OPENAI_CLIP_NAMES[base] + "-quickgelu"
+        props.setdefault("dimensions", embedding_dim)
+        props.setdefault("type", "clip")
+        super().__init__(device=device, model_properties=props, model_auth=model_auth)
+        self.model_type = model_type
+        self.truncate = truncate
+
+
+class FP16_CLIP(CLIP):
+    """'fp16/ViT-*' names (clip_utils.py:495-518: cuda only).  On MI355X every CLIP tower already runs bf16 MFMA."""
+
+    def __init__(self, model_type: str = "fp16/ViT-B/32", device: str = None, embedding_dim: int = None, truncate: bool = True,
+                 model_properties: Optional[dict] = None, model_auth=None, **kwargs) -> None:
+        from marqo_amd.s2_inference.errors import IncompatibleModelDeviceError
+        if not str(device).startswith("cuda"):
+            raise IncompatibleModelDeviceError("FP16 clip model `{}` is only available with device `cuda`.".format(model_type))
+        super().__init__(model_type, device, embedding_dim, truncate, model_properties, model_auth, **kwargs)

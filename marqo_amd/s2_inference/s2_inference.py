@@ -1,0 +1,508 @@
+"""`vectorise()` and the model cache: the API surface tensor_search's add_documents / search / embed paths call.
+
+Mirrors src/marqo/s2_inference/s2_inference.py function by function (same names, argument meaning and error
+behaviour; citations inline) so the reference's callers and tests drop onto it.  What changes is underneath:
+
+  * loaders in MODEL_PROPERTIES['loaders'] are the marqo_amd engine classes (HIP towers), not torch modules;
+  * `_encode_without_cache` hands engine models the WHOLE request in one `encode` call — they micro-batch on the
+    device by token rows — instead of the fixed 16-item Python loop (s2_inference.py:135-146).  Models that do
+    not declare `supports_dynamic_batching` (the `random` fake, third-party loaders) keep the reference loop and
+    `MARQO_MAX_VECTORISE_BATCH_SIZE`;
+  * `vectorise_ndarray` is an additional zero-copy exit for callers that can take `np.ndarray` instead of
+    `List[List[float]]`.
+"""
+from __future__ import annotations
+
+import datetime
+import logging
+import threading
+from typing import Any, Dict, List, Optional, Tuple, Union
+
+import numpy as np
+import torch
+from PIL import UnidentifiedImageError
+from PIL.Image import Image
+
+from marqo_amd.s2_inference import configs
+from marqo_amd.s2_inference.configs import (get_default_normalization, get_default_seq_length, read_env_vars_and_defaults,
+                                            read_env_vars_and_defaults_ints)
+from marqo_amd.s2_inference.enums import AvailableModelsKey, EnvVars, Modality, ModelType
+from marqo_amd.s2_inference.errors import (ConfigurationError, InternalError, InvalidModelPropertiesError,
+                                           ModelCacheManagementError, ModelDownloadError, ModelLoadError,
+                                           ModelNotInCacheError, UnknownModelError, VectoriseError)
+from marqo_amd.s2_inference.inference_cache import MarqoInferenceCache
+from marqo_amd.s2_inference.model_registry import load_model_properties
+
+logger = logging.getLogger(__name__)
+
+# {"model_cache_key": {"model": obj, "most_recently_used_time": t, "model_size": GB}}
+_available_models: Dict[str, Dict[str, Any]] = dict()
+lock = threading.Lock()
+MODEL_PROPERTIES = load_model_properties()
+_marqo_inference_cache = MarqoInferenceCache(
+    cache_size=read_env_vars_and_defaults_ints(EnvVars.MARQO_INFERENCE_CACHE_SIZE),
+    cache_type=read_env_vars_and_defaults(EnvVars.MARQO_INFERENCE_CACHE_TYPE))
+
+
+class DefaultEncoder:
+    """drops `modality` before calling the model (multimodal_model_load.py:124-129)"""
+
+    def __init__(self, model):
+        self.model = model
+
+    def encode(self, content, modality, **kwargs):
+        return self.model.encode(content, **kwargs)
+
+
+def get_encoder(model):
+    return DefaultEncoder(model)
+
+
+def generate_batches(seq, batch_size: int):
+    """tensor_search/utils.py:334-340"""
+    if batch_size < 1:
+        raise ValueError("Batch size must be greater than 0")
+    for i in range(0, len(seq), batch_size):
+        yield seq[i:i + batch_size]
+
+
+def infer_modality(content) -> Modality:
+    """first-element sniffing used when a caller passes modality=None (s2_inference.py:138-139).  The reference probes URLs
+    and media bytes; here: image-like objects / image paths -> IMAGE, everything else -> TEXT."""
+    from marqo_amd.s2_inference.image_input import _is_image
+    thing = content[0] if isinstance(content, (list, tuple)) and content else content
+    if isinstance(thing, bytes):
+        return Modality.IMAGE
+    try:
+        return Modality.IMAGE if _is_image(thing) else Modality.TEXT
+    except UnidentifiedImageError:
+        return Modality.TEXT
+
+
+# =============================================================================================================
+def vectorise(model_name: str, content: Union[str, List[str], List[Image], List[bytes]], model_properties: dict = None,
+              device: str = None, normalize_embeddings: bool = get_default_normalization(), model_auth=None,
+              enable_cache: bool = False, modality: Modality = Modality.TEXT, **kwargs) -> List[List[float]]:
+    """s2_inference.py:48-69"""
+    if not device:
+        raise InternalError(message="vectorise (internal function) cannot be called without setting device!")
+    validated_model_properties = validate_model_properties(model_name, model_properties)
+    model_cache_key = _create_model_cache_key(model_name, device, validated_model_properties)
+    _update_available_models(model_cache_key, model_name, validated_model_properties, device, normalize_embeddings,
+                             model_auth=model_auth)
+    model = _available_models[model_cache_key][AvailableModelsKey.model]
+    if _marqo_inference_cache.is_enabled() and enable_cache:
+        return _vectorise_with_cache(model, model_cache_key, content, normalize_embeddings, modality, **kwargs)
+    return _vectorise_without_cache(model_cache_key, content, normalize_embeddings, modality, **kwargs)
+
+
+def vectorise_ndarray(model_name: str, content, model_properties: dict = None, device: str = None,
+                      normalize_embeddings: bool = get_default_normalization(), model_auth=None,
+                      modality: Modality = Modality.TEXT, **kwargs) -> np.ndarray:
+    """Engine extension: same as `vectorise` (cache off) but returns the fp32 [N, D] ndarray, skipping the
+    N*D Python-float materialisation of `_convert_vectorized_output`."""
+    if not device:
+        raise InternalError(message="vectorise (internal function) cannot be called without setting device!")
+    props = validate_model_properties(model_name, model_properties)
+    key = _create_model_cache_key(model_name, device, props)
+    _update_available_models(key, model_name, props, device, normalize_embeddings, model_auth=model_auth)
+    out = _encode_to_array(key, content, normalize_embeddings, modality, **kwargs)
+    return out[np.newaxis, :] if out.ndim == 1 else out
+
+
+def _vectorise_with_cache(model, model_cache_key, content, normalize_embeddings, modality, **kwargs):
+    """s2_inference.py:72-84"""
+    if isinstance(content, str):
+        vectorised = _marqo_inference_cache.get(model_cache_key, content)
+        if vectorised is None:
+            vectorised = _encode_without_cache(model_cache_key, content, normalize_embeddings, modality, **kwargs)
+            _marqo_inference_cache.set(model_cache_key, content, vectorised[0])
+        else:
+            vectorised = _convert_cached_embeddings_to_output(vectorised)
+        return vectorised
+    elif isinstance(content, list):
+        return _vectorise_list_with_cache(model, model_cache_key, content, normalize_embeddings, modality, **kwargs)
+    raise TypeError(f"Unsupported content type: {type(content).__name__}")
+
+
+def _vectorise_list_with_cache(model, model_cache_key, content, normalize_embeddings, modality, **kwargs):
+    """s2_inference.py:87-115: only str items are cached; misses are encoded together and hits re-inserted at their
+    original positions in ascending index order."""
+    contents_to_vectorise, cached_output = [], []
+    for loc, item in enumerate(content):
+        if isinstance(item, str):
+            vectorised = _marqo_inference_cache.get(model_cache_key, item)
+            if vectorised is None:
+                contents_to_vectorise.append(item)
+            else:
+                cached_output.append((loc, vectorised))
+        else:
+            contents_to_vectorise.append(item)
+    if contents_to_vectorise:
+        vectorised_outputs = _encode_without_cache(model_cache_key, contents_to_vectorise, normalize_embeddings, modality, **kwargs)
+        for item, out in zip(contents_to_vectorise, vectorised_outputs):
+            if isinstance(item, str):
+                _marqo_inference_cache.set(model_cache_key, item, out)
+        for loc, cached_vector in cached_output:
+            vectorised_outputs.insert(loc, cached_vector)
+    else:
+        vectorised_outputs = [vector for _, vector in cached_output]
+    return vectorised_outputs
+
+
+def _vectorise_without_cache(model_cache_key, content, normalize_embeddings, modality, **kwargs) -> List[List[float]]:
+    return _encode_without_cache(model_cache_key, content, normalize_embeddings, modality, **kwargs)
+
+
+def _encode_to_array(model_cache_key: str, content, normalize_embeddings: bool, modality, **kwargs):
+    """s2_inference.py:123-156 up to (not including) the list conversion."""
+    try:
+        model = _available_models[model_cache_key][AvailableModelsKey.model]
+        encoder = get_encoder(model)
+        if isinstance(content, str):
+            vectorised = model.encode(content, normalize=normalize_embeddings, modality=modality, **kwargs)
+        elif isinstance(content, torch.Tensor):
+            vectorised = model.encode(content, normalize=normalize_embeddings, modality=modality, **kwargs)
+        else:
+            vector_batches = []
+            batch_size = _get_max_vectorise_batch_size()  # validated even when the engine batches dynamically
+            if getattr(model, "supports_dynamic_batching", False) and len(content) > 0:
+                batch_size = len(content)  # one call: the engine micro-batches by token rows on the device
+            for batch in generate_batches(content, batch_size=batch_size):
+                if modality is None:
+                    modality = infer_modality(batch[0] if isinstance(batch[0], (str, bytes)) else batch)
+                infer = kwargs.pop("infer", False if modality == Modality.TEXT else True)
+                encoded_batch = encoder.encode(batch, modality=modality, normalize=normalize_embeddings, infer=infer, **kwargs)
+                vector_batches.append(_convert_tensor_to_numpy(encoded_batch))
+            if not vector_batches or all(len(b) == 0 for b in vector_batches):
+                raise RuntimeError(f"Vectorise created an empty list of batches! Content: {content}")
+            vectorised = vector_batches[0] if len(vector_batches) == 1 else np.concatenate(vector_batches, axis=0)
+    except (UnidentifiedImageError, OSError) as e:
+        if isinstance(e, UnidentifiedImageError) or "image file is truncated" in str(e):
+            raise VectoriseError(f"Could not process given image: {content}. Original Error message: {e}") from e
+        raise e
+    return vectorised
+
+
+def _encode_without_cache(model_cache_key: str, content, normalize_embeddings: bool, modality, **kwargs) -> List[List[float]]:
+    return _convert_vectorized_output(_encode_to_array(model_cache_key, content, normalize_embeddings, modality, **kwargs))
+
+
+def get_available_models() -> Dict:
+    return _available_models
+
+
+def get_marqo_inference_cache() -> MarqoInferenceCache:
+    return _marqo_inference_cache
+
+
+def is_preprocess_image_model(model_properties: dict = None) -> bool:
+    """s2_inference.py:180-185"""
+    return model_properties.get("type", None) in configs.PREPROCESS_IMAGE_MODEL_LIST
+
+
+def load_multimodal_model_and_get_preprocessors(model_name: str, model_properties: Optional[dict] = None, device: Optional[str] = None,
+                                                model_auth=None, normalize_embeddings: bool = get_default_normalization()
+                                                ) -> Tuple[Any, Dict[str, Optional[Any]]]:
+    """s2_inference.py:193-235: loads (or renews) the model and returns its per-modality preprocessors; `image` is the model's
+    `.preprocess` (PIL -> Tensor[3, S, S]) for clip / open_clip types, else None."""
+    if not device:
+        raise InternalError(message="vectorise (internal function) cannot be called without setting device!")
+    model_cache_key = _create_model_cache_key(model_name, device, model_properties)
+    _update_available_models(model_cache_key, model_name, model_properties, device, normalize_embeddings, model_auth=model_auth)
+    model = _available_models[model_cache_key][AvailableModelsKey.model]
+    preprocessors = {
+        "image": getattr(model, "preprocess", None) if is_preprocess_image_model(model_properties) else None,
+        "video": None, "audio": None, "text": None,
+    }
+    return model, preprocessors
+
+
+def _get_max_vectorise_batch_size() -> int:
+    """s2_inference.py:239-257"""
+    max_batch_size_value = read_env_vars_and_defaults(EnvVars.MARQO_MAX_VECTORISE_BATCH_SIZE)
+    validation_error_msg = ("Could not properly read env var `MARQO_MAX_VECTORISE_BATCH_SIZE`. "
+                            "`MARQO_MAX_VECTORISE_BATCH_SIZE` must be an int greater than or equal to 1.")
+    try:
+        batch_size = int(max_batch_size_value)
+    except (ValueError, TypeError) as e:
+        msg = f"`{validation_error_msg} Current value: `{max_batch_size_value}`. Reason: {e}"
+        logger.error(msg)
+        raise ConfigurationError(msg) from e
+    if batch_size < 1:
+        msg = f"`{validation_error_msg} Current value: `{max_batch_size_value}`."
+        logger.error(msg)
+        raise ConfigurationError(msg)
+    return batch_size
+
+
+def _create_model_cache_key(model_name: str, device: str, model_properties: dict = None) -> str:
+    """s2_inference.py:260-283 (eject_model depends on this format)"""
+    if model_properties is None:
+        model_properties = dict()
+    return (model_name + "||" + model_properties.get("name", "") + "||" + str(model_properties.get("dimensions", "")) + "||"
+            + model_properties.get("type", "") + "||" + str(model_properties.get("tokens", "")) + "||" + device)
+
+
+def _update_available_models(model_cache_key: str, model_name: str, validated_model_properties: dict, device: str,
+                             normalize_embeddings: bool, model_auth=None) -> None:
+    """s2_inference.py:286-337: single-flight load with REJECTION of concurrent loaders (not waiting)."""
+    if model_cache_key not in _available_models:
+        model_size = get_model_size(model_name, validated_model_properties)
+        if lock.locked():
+            raise ModelCacheManagementError("Request rejected, as this request attempted to update the model cache, while "
+                                            "another request was updating the model cache at the same time. "
+                                            "Please wait for 10 seconds and send the request again ")
+        with lock:
+            _validate_model_into_device(model_name, validated_model_properties, device, calling_func=_update_available_models.__name__)
+            try:
+                most_recently_used_time = datetime.datetime.now()
+                _available_models[model_cache_key] = {
+                    AvailableModelsKey.model: _load_model(model_name, validated_model_properties, device=device,
+                                                          calling_func=_update_available_models.__name__, model_auth=model_auth),
+                    AvailableModelsKey.most_recently_used_time: most_recently_used_time,
+                    AvailableModelsKey.model_size: model_size,
+                }
+                logger.info(f"loaded {model_name} on device {device} with normalization={normalize_embeddings} at time={most_recently_used_time}.")
+            except Exception as e:
+                logger.error(f"Error loading model {model_name} on device {device} with normalization={normalize_embeddings}. \n"
+                             f"Error message is {str(e)}")
+                if isinstance(e, ModelDownloadError):
+                    raise e
+                raise ModelLoadError(
+                    f"Unable to load model={model_name} on device={device} with normalization={normalize_embeddings}. "
+                    f"If you are trying to load a custom model, please check that model_properties={validated_model_properties} "
+                    f"is correct and Marqo has access to the weights file. Original error: {e}") from e
+    else:
+        most_recently_used_time = datetime.datetime.now()
+        try:
+            _available_models[model_cache_key][AvailableModelsKey.most_recently_used_time] = most_recently_used_time
+        except KeyError as e:
+            raise ModelNotInCacheError(f"Marqo cannot renew model {model_name} on device {device} with normalization={normalize_embeddings}. "
+                                       f"Maybe another thread is updating the model cache at the same time."
+                                       f"Please wait for 10 seconds and send the request again.\n") from e
+
+
+def validate_model_properties(model_name: str, model_properties: dict) -> dict:
+    """s2_inference.py:340-407"""
+    if model_properties is not None:
+        required_keys = []
+        postfix = ("Marqo is loading the model with default type 'sbert' as the type was not provided."
+                   if "type" not in model_properties else "")
+        model_type = model_properties.get("type", None)
+        if model_type in (None, ModelType.SBERT):
+            required_keys = ["dimensions", "name"]
+            for key, value in [("type", ModelType.SBERT.value), ("tokens", get_default_seq_length())]:
+                if key not in model_properties:
+                    model_properties[key] = value
+        elif model_type in (ModelType.OpenCLIP, ModelType.CLIP):
+            required_keys = ["name", "dimensions"]
+        elif model_type in (ModelType.HF_MODEL, ModelType.HF_STELLA):
+            required_keys = ["dimensions"]
+        elif model_type in (ModelType.NO_MODEL,):
+            required_keys = ["dimensions"]
+            if not model_name == "no_model":
+                raise InvalidModelPropertiesError(f"To use the 'no_model' feature, you must provide 'model = no_model' and "
+                                                  f"'type = no_model', but received 'model = {model_name}' and 'type = {model_type}'.")
+        elif model_type in (ModelType.Test, ModelType.Random, ModelType.MultilingualClip, ModelType.FP16_CLIP,
+                            ModelType.SBERT_ONNX, ModelType.CLIP_ONNX):
+            pass
+        else:
+            raise InvalidModelPropertiesError(
+                "Invalid model type. Please check the model type in model_properties. Supported model types are "
+                + ", ".join(f"'{t.value}'" for t in (ModelType.SBERT, ModelType.OpenCLIP, ModelType.CLIP, ModelType.HF_MODEL,
+                                                     ModelType.HF_STELLA, ModelType.NO_MODEL, ModelType.Test, ModelType.Random,
+                                                     ModelType.MultilingualClip, ModelType.FP16_CLIP, ModelType.SBERT_ONNX,
+                                                     ModelType.CLIP_ONNX)))
+        for key in required_keys:
+            if key not in model_properties:
+                raise InvalidModelPropertiesError(f"model_properties has missing key '{key}'. please update your model properties with "
+                                                  f"required key `{key}`. {postfix}")
+    else:
+        model_properties = get_model_properties_from_registry(model_name)
+    _validate_model_properties_dimension(model_properties.get("dimensions", None))
+    return model_properties
+
+
+def _validate_model_properties_dimension(dimensions: Optional[int]) -> None:
+    if dimensions is None or not isinstance(dimensions, int) or dimensions < 1:
+        raise InvalidModelPropertiesError(
+            f"Invalid model properties: 'dimensions' must be a positive integer, but received {dimensions}.")
+
+
+def _validate_model_into_device(model_name: str, model_properties: dict, device: str, calling_func: str = None) -> bool:
+    """s2_inference.py:421-460: LRU ejection per device until the new model fits under the GB threshold."""
+    if calling_func not in ["unit_test", "_update_available_models"]:
+        raise RuntimeError("This function should only be called by `update_available_models` or `unit_test` for thread safeness.")
+    model_size = get_model_size(model_name, model_properties)
+    if _check_memory_threshold_for_model(device, model_size, calling_func=_validate_model_into_device.__name__):
+        return True
+    keys = [k for k in list(_available_models) if k.endswith(device)]
+    for key in sorted(keys, key=lambda x: _available_models[x][AvailableModelsKey.most_recently_used_time]):
+        logger.info(f"Eject model = `{key.split('||')[0]}` from device = `{device}` to save space for model = `{model_name}`.")
+        del _available_models[key]
+        if _check_memory_threshold_for_model(device, model_size, calling_func=_validate_model_into_device.__name__):
+            return True
+    if _check_memory_threshold_for_model(device, model_size, calling_func=_validate_model_into_device.__name__) is False:
+        raise ModelCacheManagementError(
+            f"Marqo CANNOT find enough space to load model = `{model_name}` in device = `{device}`.\n"
+            f"Marqo tried to eject all the models on this device = `{device}` but still can't find enough space. \n"
+            f"Please use a smaller model or increase the memory threshold.")
+
+
+def _check_memory_threshold_for_model(device: str, model_size: Union[float, int], calling_func: str = None) -> bool:
+    """s2_inference.py:463-500"""
+    if calling_func not in ["unit_test", "_validate_model_into_device"]:
+        raise RuntimeError(f"The function `{_check_memory_threshold_for_model.__name__}` should only be called by "
+                           f"`unit_test` or `_validate_model_into_device` for threading safeness.")
+    if device.startswith("cuda"):
+        if torch.cuda.is_available():
+            torch.cuda.synchronize(device)
+            torch.cuda.empty_cache()
+        used_memory = sum(_available_models[k].get("model_size", configs.DEFAULT_MODEL_SIZE) for k in _available_models if k.endswith(device))
+        threshold = float(read_env_vars_and_defaults(EnvVars.MARQO_MAX_CUDA_MODEL_MEMORY))
+    elif device.startswith("cpu"):
+        used_memory = sum(_available_models[k].get("model_size", configs.DEFAULT_MODEL_SIZE) for k in _available_models if k.endswith("cpu"))
+        threshold = float(read_env_vars_and_defaults(EnvVars.MARQO_MAX_CPU_MODEL_MEMORY))
+    else:
+        raise ModelCacheManagementError(f"Unable to check the device cache for device=`{device}`. The model loading will proceed"
+                                        f"without device cache check. This might break down Marqo if too many models are loaded.")
+    if model_size > threshold:
+        raise ModelCacheManagementError(
+            f"You are trying to load a model with size = `{model_size}` into device = `{device}`, which is larger than the device "
+            f"threshold = `{threshold}`. Marqo CANNOT find enough space for the model. Please change the threshold by adjusting the "
+            f"environment variables `MARQO_MAX_CUDA_MODEL_MEMORY` or `MARQO_MAX_CPU_MODEL_MEMORY`.")
+    return (used_memory + model_size) < threshold
+
+
+def get_model_size(model_name: str, model_properties: dict) -> Union[int, float]:
+    """s2_inference.py:503-517: explicit model_size -> name substring -> type -> default"""
+    if "model_size" in model_properties:
+        return model_properties["model_size"]
+    name_info = (model_name + model_properties.get("name", "")).lower().replace("/", "-")
+    for name, size in configs.MODEL_NAME_SIZE_MAPPING.items():
+        if name in name_info:
+            return size
+    return configs.MODEL_TYPE_SIZE_MAPPING.get(model_properties.get("type", None), configs.DEFAULT_MODEL_SIZE)
+
+
+def _load_model(model_name: str, model_properties: dict, device: str, calling_func: str = None, model_auth=None) -> Any:
+    """s2_inference.py:520-568"""
+    if calling_func not in ["unit_test", "_update_available_models"]:
+        raise RuntimeError(f"The function `{_load_model.__name__}` should only be called by "
+                           f"`unit_test` or `_update_available_models` for threading safeness.")
+    model_type = model_properties.get("type")
+    loader = _get_model_loader(model_properties.get("name", None), model_properties)
+    if model_type in (ModelType.OpenCLIP, ModelType.HF_MODEL, ModelType.HF_STELLA):
+        model = loader(device=device, model_properties=model_properties, model_auth=model_auth)
+    else:
+        model = loader(model_properties.get("name", None), device=device, embedding_dim=model_properties["dimensions"],
+                       model_properties=model_properties, model_auth=model_auth,
+                       max_seq_length=model_properties.get("tokens", get_default_seq_length()))
+    model.load()
+    return model
+
+
+def clear_loaded_models() -> None:
+    _available_models.clear()
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+
+
+def clear_marqo_inference_cache() -> None:
+    if _marqo_inference_cache.is_enabled():
+        _marqo_inference_cache.clear()
+
+
+def get_model_properties_from_registry(model_name: str) -> dict:
+    """s2_inference.py:599-620"""
+    if model_name not in MODEL_PROPERTIES["models"]:
+        raise UnknownModelError(f"Could not find model properties in model registry for model={model_name}. "
+                                f"Model is not supported by default.")
+    model_properties = MODEL_PROPERTIES["models"][model_name]
+    validate_model_properties(model_name, model_properties)
+    return model_properties
+
+
+def _check_output_type(output) -> bool:
+    """s2_inference.py:623-647 (soft check: only output[0][0] is inspected)"""
+    if not isinstance(output, list):
+        return False
+    elif len(output) == 0:
+        raise ValueError("received empty input")
+    if not isinstance(output[0], list):
+        return False
+    elif len(output[0]) == 0:
+        raise ValueError("received empty input")
+    if not isinstance(output[0][0], (float, int)):
+        return False
+    return True
+
+
+def _convert_tensor_to_numpy(output) -> np.ndarray:
+    if isinstance(output, torch.Tensor):
+        return output.to("cpu").detach().numpy()
+    elif isinstance(output, np.ndarray):
+        return output
+    raise ValueError(f"Marqo received an unexpected output type=`{type(output).__name__}`from encode function.")
+
+
+def _convert_cached_embeddings_to_output(cached_embeddings: List[float]) -> List[List[float]]:
+    if not isinstance(cached_embeddings, list):
+        raise TypeError(f"expected a list of floats but received {type(cached_embeddings)}")
+    if not isinstance(cached_embeddings[0], float):
+        raise TypeError(f"expected a list of floats but received {type(cached_embeddings[0])}")
+    return [cached_embeddings, ]
+
+
+def _convert_vectorized_output(output, fp16: bool = False) -> List[List[float]]:
+    """s2_inference.py:705-749: anything -> List[List[float]]; 1-D gets a leading batch dim"""
+    if _check_output_type(output):
+        return output
+    if isinstance(output, torch.Tensor):
+        if output.ndim == 1:
+            output = output.unsqueeze(0)
+        output = output.detach().to("cpu").tolist()
+    elif isinstance(output, np.ndarray):
+        if output.ndim == 1:
+            output = output[np.newaxis, :]
+        output = output.tolist()
+    elif isinstance(output, list):
+        if isinstance(output[0], torch.Tensor):
+            output = [o.detach().to("cpu").tolist() for o in output]
+        elif isinstance(output[0], np.ndarray):
+            output = [o.tolist() for o in output]
+        else:
+            raise TypeError(f"unsupported nested list with elements of type {type(output[0])}")
+    else:
+        raise TypeError(f"unsupported output type of {type(output)}")
+    if fp16:
+        output = np.array(output).astype(np.float16).tolist()
+    if _check_output_type(output):
+        return output
+    raise TypeError(f"unable to convert input of type {type(output)} to a list of lists of floats")
+
+
+def _get_model_loader(model_name: str, model_properties: dict) -> Any:
+    model_type = model_properties["type"]
+    if model_type not in MODEL_PROPERTIES["loaders"]:
+        raise KeyError(f"model_name={model_name} for model_type={model_type} not in allowed model types")
+    return MODEL_PROPERTIES["loaders"][model_type]
+
+
+def eject_model(model_name: str, device: str):
+    """s2_inference.py:774-798"""
+    model_cache_key = None
+    for key in _available_models.keys():
+        if isinstance(key, str) and key.startswith(model_name) and key.endswith(device):
+            model_cache_key = key
+            break
+    if model_cache_key is None:
+        raise ModelNotInCacheError(f"The model_name `{model_name}` device `{device}` is not cached or found")
+    if model_cache_key in _available_models:
+        del _available_models[model_cache_key]
+        if device.startswith("cuda") and torch.cuda.is_available():
+            torch.cuda.empty_cache()
+        return {"result": "success", "message": f"successfully eject model_name `{model_name}` from device `{device}`"}
+    raise ModelNotInCacheError(f"The model_name `{model_name}` device `{device}` is not cached or found")

@@ -1,0 +1,58 @@
+"""The C-ABI shared library loads WITHOUT a GPU and exports every entry point include/marqo_hip.h declares; the ctypes
+binding covers the same set; POD struct layouts match the header (no compute is launched here)."""
+import ctypes as C
+import os
+import re
+
+from marqo_amd import _lib as L
+
+HEADER = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "marqo_hip.h")
+
+
+def _declared():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mq_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_are_exported_and_bound():
+    names = _declared()
+    assert len(names) >= 25
+    lib = L.load()
+    raw = C.CDLL(str(L.LIB_PATH))
+    for n in names:
+        assert hasattr(raw, n), f"libmarqo_hip.so does not export {n}"
+        assert n in L.EXPORTED_SYMBOLS, f"ctypes binding is missing {n}"
+    assert set(L.EXPORTED_SYMBOLS) <= set(names), set(L.EXPORTED_SYMBOLS) - set(names)
+    assert lib.mq_abi_version() == 1 and lib.mq_build_arch() == b"gfx950"
+
+
+def test_struct_layouts_match_header():
+    assert C.sizeof(L.BlockWeights) == 12 * 8
+    assert C.sizeof(L.EncoderCfg) == 8 * 4
+    assert C.sizeof(L.VitCfg) == 8 * 4 + 3 * 4 + 6 * 4
+    assert C.sizeof(L.VitWeights) == 9 * 8
+    assert C.sizeof(L.ClipTextCfg) == 8 * 4 + 3 * 4 and C.sizeof(L.ClipTextWeights) == 6 * 8
+    assert C.sizeof(L.BertCfg) == 8 * 4 + 3 * 4 and C.sizeof(L.BertWeights) == 6 * 8
+
+
+def test_argument_errors_are_reported_without_a_gpu():
+    lib = L.load()
+    assert lib.mq_gemm_bf16(None, 0, None, 0, None, None, None, 0, 1, 4, 64, 0, None) == -1
+    assert b"null operand" in lib.mq_last_error()
+    cfg = L.EncoderCfg(width=100, layers=1, heads=1, mlp_dim=64, act=1, post_ln=0, mask=0, ln_eps=1e-5)
+    assert lib.mq_encoder_forward(C.byref(cfg), None, None, 0, None, 0, 0, 0, None, 0, None) == -1
+    assert b"multiple of 64" in lib.mq_last_error()
+    assert lib.mq_encoder_workspace_bytes(C.byref(L.EncoderCfg(width=768, layers=12, heads=12, mlp_dim=3072, act=1)), 100, 2) > 0
+    assert lib.mq_chunk_grid_count(3, 3, 0) == 10 and lib.mq_chunk_grid_count(3, 3, 1) == 14 and lib.mq_chunk_grid_count(0, 3, 0) == 0
+    assert lib.mq_resample_ksize(640, 224) == 13 and lib.mq_resample_ksize(80, 224) == 5
+
+
+def test_product_never_imports_the_oracle():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for dp, _, files in os.walk(os.path.join(root, "marqo_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(dp, f)
+                assert "liboracle" not in src

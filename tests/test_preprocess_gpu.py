@@ -75,6 +75,16 @@ def test_chunk_count_known_answers(pre):
     assert np.allclose(boxes[0, 0], [0, 0, 400, 300])
 
 
+def test_plain_resize_bit_exact(pre):
+    imgs = _imgs([(480, 640), (100, 333), (240, 240), (900, 50)], seed=13)
+    out = pre.resize_u8(imgs, 240, 240).cpu().numpy()
+    for i, im in enumerate(imgs):
+        assert np.array_equal(out[i], OP.resize_u8(im, 240, 240, backend="c"))
+    out = pre.resize_u8(imgs[:2], 77, 123).cpu().numpy()
+    for i, im in enumerate(imgs[:2]):
+        assert np.array_equal(out[i], OP.resize_u8(im, 123, 77, backend="c"))
+
+
 def test_to_tensor_normalize_bit_exact(pre):
     u8 = torch.from_numpy(np.random.default_rng(2).integers(0, 256, (3, 224, 224, 3), dtype=np.uint8))
     out = pre.to_tensor_normalize(u8.cuda()).cpu().numpy()

@@ -1,0 +1,196 @@
+"""End-to-end vectorise() through the engine loaders on the GPU, checked against the CPU oracle.
+
+Mirrors the reference's invariants (tests/s2_inference/test_encoding.py: vectorise == model.encode, unit norm,
+str == [str], dimensions) and the add_documents contract for `.preprocess` (test_add_documents_combined.py:411-439:
+Tensor of shape (3, 224, 224)).  Real checkpoints do not exist offline: tiny checkpoints in the real on-disk formats
+(open_clip safetensors + open_clip_config.json + BPE merges; HF config.json + model.safetensors + vocab.txt) are
+written to a temp model dir, so the loaders' file handling is exercised, and registry-size models use seeded
+random-init weights (MARQO_AMD_SYNTHETIC_WEIGHTS=1)."""
+import gzip
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from oracle import preprocess as OP
+from oracle import towers as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+COS_TOL = 1e-3
+
+
+def _cos_err(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float((1 - (a * b).sum(-1) / (np.linalg.norm(a, axis=-1) * np.linalg.norm(b, axis=-1))).max())
+
+
+@pytest.fixture(scope="module")
+def s2(tmp_path_factory):
+    root = tmp_path_factory.mktemp("models")
+    os.environ["MARQO_AMD_MODEL_DIR"] = str(root)
+    os.environ["MARQO_MAX_CUDA_MODEL_MEMORY"] = "64"
+    from marqo_amd.s2_inference import s2_inference
+    s2_inference.clear_loaded_models()
+    yield s2_inference, root
+    s2_inference.clear_loaded_models()
+    os.environ.pop("MARQO_AMD_MODEL_DIR", None)
+    os.environ.pop("MARQO_AMD_SYNTHETIC_WEIGHTS", None)
+
+
+# ---- tiny open_clip checkpoint on disk -----------------------------------------------------------------------------
+def _tiny_clip(root):
+    from safetensors.torch import save_file
+    from tests.test_tokenizers import CORPUS, _train_bpe
+    d = root / "hf-hub" / "acme" / "tiny-clip"
+    d.mkdir(parents=True, exist_ok=True)
+    merges = _train_bpe(CORPUS, 120)
+    vocab = 512 + len(merges) + 2
+    vcfg = O.VitConfig(image_size=64, patch_size=16, width=128, layers=2, heads=2, mlp_dim=256, out_dim=64)
+    tcfg = O.ClipTextConfig(vocab=vocab, ctx=77, width=128, layers=2, heads=2, mlp_dim=256, out_dim=64)
+    sd = O.synthetic_vit_state_dict(vcfg, seed=1)
+    sd.update(O.synthetic_clip_text_state_dict(tcfg, seed=2))
+    save_file({k: v.contiguous() for k, v in sd.items()}, str(d / "open_clip_model.safetensors"))
+    (d / "open_clip_config.json").write_text(json.dumps({"model_cfg": {
+        "embed_dim": 64, "vision_cfg": {"image_size": 64, "layers": 2, "width": 128, "patch_size": 16, "head_width": 64, "mlp_ratio": 2.0},
+        "text_cfg": {"context_length": 77, "vocab_size": vocab, "width": 128, "heads": 2, "layers": 2, "mlp_ratio": 2.0}}}))
+    with gzip.open(d / "bpe_simple_vocab_16e6.txt.gz", "wt", encoding="utf-8") as f:
+        f.write("#version: synthetic\n" + "\n".join(" ".join(m) for m in merges) + "\n")
+    props = {"name": "hf-hub:acme/tiny-clip", "dimensions": 64, "type": "open_clip"}
+    return props, sd, vcfg, tcfg
+
+
+def test_open_clip_from_disk_text_and_image(s2):
+    s2i, root = s2
+    props, sd, vcfg, tcfg = _tiny_clip(root)
+    texts = ["a photo of a cat", "the quick brown fox jumps over the lazy dog", "marqo is a tensor search engine"]
+    out = s2i.vectorise("tiny-clip", texts, model_properties=props, device=DEV)
+    assert len(out) == 3 and len(out[0]) == 64 and isinstance(out[0][0], float)
+    model = s2i.get_available_models()[s2i._create_model_cache_key("tiny-clip", DEV, props)]["model"]
+    ids = torch.from_numpy(model.tokenizer(texts))
+    ref = O.clip_text_forward(sd, tcfg, ids).numpy()
+    assert _cos_err(out, ref) < COS_TOL
+    assert np.allclose(np.linalg.norm(np.asarray(out), axis=1), 1.0, atol=1e-5)
+    # str == [str]; vectorise == model.encode
+    assert np.allclose(s2i.vectorise("tiny-clip", texts[0], model_properties=props, device=DEV), out[:1], atol=1e-6)
+    assert np.abs(model.encode(texts, normalize=True, infer=False) - np.asarray(out)).sum() < 1e-6
+    # un-normalised
+    raw = s2i.vectorise("tiny-clip", texts, model_properties=props, device=DEV, normalize_embeddings=False)
+    assert not np.allclose(np.linalg.norm(np.asarray(raw), axis=1), 1.0, atol=1e-3)
+
+    # images: PIL of arbitrary size -> GPU resize/crop -> tower; oracle = Pillow-exact CPU transform + fp32 tower
+    rng = np.random.default_rng(0)
+    pil = [Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)) for h, w in [(64, 64), (100, 80), (70, 200)]]
+    emb = s2i.vectorise("tiny-clip", pil, model_properties=props, device=DEV, modality=s2i.Modality.IMAGE)
+    px = torch.from_numpy(np.stack([OP.clip_transform(np.asarray(p), 64) for p in pil]))
+    ref = O.vit_forward(sd, vcfg, px).numpy()
+    assert _cos_err(emb, ref) < COS_TOL
+    # `.preprocess` contract + encode_image on pre-made tensors gives the same embeddings
+    model2, pre = s2i.load_multimodal_model_and_get_preprocessors("tiny-clip", props, DEV)
+    assert model2 is model and pre["text"] is None
+    t = pre["image"](pil[1])
+    assert isinstance(t, torch.Tensor) and tuple(t.shape) == (3, 64, 64) and t.dtype == torch.float32
+    assert torch.equal(t.cpu(), px[1]) or float((t.cpu() - px[1]).abs().max()) < 1e-6
+    emb_t = s2i.vectorise("tiny-clip", [pre["image"](p).to(DEV) for p in pil], model_properties=props, device=DEV,
+                          modality=s2i.Modality.IMAGE)
+    assert _cos_err(emb_t, emb) < 1e-5
+    # mixed list of tensors and PIL images
+    emb_m = model.encode_image([pre["image"](pil[0]), pil[1], pil[2]])
+    assert _cos_err(emb_m, emb) < 1e-5
+    # image chunks on the device (K11) against the oracle chunker
+    ce, boxes = model.encode_image_chunks([pil[2]], 3, 3, False)
+    patches, bbs = OP.chunk_image_simple(np.asarray(pil[2]), 3, 3, False)
+    refc = O.vit_forward(sd, vcfg, torch.from_numpy(np.stack([OP.clip_transform(p, 64) for p in patches]))).numpy()
+    assert ce.shape == (1, 10, 64) and _cos_err(ce[0], refc) < COS_TOL and np.allclose(boxes[0], np.asarray(bbs), rtol=1e-6)
+
+
+def test_chunk_image_reference_signature(s2):
+    from marqo_amd.s2_inference.processing.image import chunk_image
+    rng = np.random.default_rng(5)
+    img = Image.fromarray(rng.integers(0, 256, (300, 400, 3), dtype=np.uint8))
+    patches, boxes = chunk_image(img, DEV, "simple")
+    ref_p, ref_b = OP.chunk_image_simple(np.asarray(img), 3, 3, False, backend="pil")
+    assert len(patches) == 10 and all(isinstance(p, Image.Image) for p in patches)
+    for p, r in zip(patches, ref_p):
+        assert np.array_equal(np.asarray(p), r)
+    assert np.allclose(np.asarray(boxes), np.asarray(ref_b))
+    patches, _ = chunk_image(img, DEV, "overlap?hn=2&wn=2")
+    assert len(patches) == 1 + 4 + 1
+
+
+# ---- tiny HF BERT on disk ----------------------------------------------------------------------------------------------
+def test_hf_from_disk(s2):
+    s2i, root = s2
+    from safetensors.torch import save_file
+    from tests.test_tokenizers import _bert_vocab
+    vocab = _bert_vocab()
+    d = root / "hf" / "acme" / "tiny-bert"
+    (d / "1_Pooling").mkdir(parents=True, exist_ok=True)
+    cfg = O.BertConfig(vocab=len(vocab), max_pos=64, width=128, layers=2, heads=2, mlp_dim=256)
+    sd = O.synthetic_bert_state_dict(cfg, seed=3)
+    save_file({"bert." + k: v.contiguous() for k, v in sd.items()}, str(d / "model.safetensors"))  # HF checkpoints may carry the prefix
+    (d / "config.json").write_text(json.dumps({"model_type": "bert", "vocab_size": len(vocab), "max_position_embeddings": 64,
+                                               "hidden_size": 128, "num_hidden_layers": 2, "num_attention_heads": 2,
+                                               "intermediate_size": 256, "hidden_act": "gelu", "layer_norm_eps": 1e-12}))
+    (d / "vocab.txt").write_text("\n".join(sorted(vocab, key=vocab.get)) + "\n")
+    (d / "1_Pooling" / "config.json").write_text(json.dumps({"pooling_mode_cls_token": False, "pooling_mode_mean_tokens": True}))
+    props = {"name": "acme/tiny-bert", "dimensions": 128, "tokens": 32, "type": "hf"}
+    texts = ["query: how much protein should a female eat", "the quick brown fox", "passage: a photo of a cat , a dog !", "fox"]
+    out = s2i.vectorise("tiny-bert", texts, model_properties=props, device=DEV)
+    from marqo_amd.engine.tokenizers import WordPieceTokenizer
+    tok = WordPieceTokenizer(vocab)(texts, max_length=32)
+    ref = O.hf_encode(sd, cfg, torch.from_numpy(tok["input_ids"]), torch.from_numpy(tok["attention_mask"])).numpy()
+    assert np.asarray(out).shape == (4, 128) and _cos_err(out, ref) < COS_TOL
+    # padding invariance: a batch of one gives the same vector (appendix A.10)
+    one = s2i.vectorise("tiny-bert", [texts[3]], model_properties=props, device=DEV)
+    assert _cos_err(one, np.asarray(out)[3:]) < 1e-5
+    # cls pooling via properties
+    props_cls = dict(props, poolingMethod="cls")
+    cfg.pooling = "cls"
+    out_cls = s2i.vectorise("tiny-bert-cls", texts, model_properties=props_cls, device=DEV)
+    ref_cls = O.hf_encode(sd, cfg, torch.from_numpy(tok["input_ids"]), torch.from_numpy(tok["attention_mask"])).numpy()
+    assert _cos_err(out_cls, ref_cls) < COS_TOL
+    # wrong dimensions -> load error
+    from marqo_amd.s2_inference.errors import ModelLoadError
+    with pytest.raises(ModelLoadError):
+        s2i.vectorise("tiny-bert-bad", texts, model_properties=dict(props, dimensions=99), device=DEV)
+
+
+# ---- registry-size models with synthetic weights (BASELINE configs 1-3) ---------------------------------------------------
+def test_registry_models_synthetic_weights(s2):
+    s2i, _ = s2
+    from marqo_amd.s2_inference.errors import ModelLoadError
+    with pytest.raises(ModelLoadError, match="(?s)no checkpoint.*MARQO_AMD_SYNTHETIC_WEIGHTS"):
+        s2i.vectorise("open_clip/ViT-B-32/laion2b_s34b_b79k", "hello", device=DEV)
+    os.environ["MARQO_AMD_SYNTHETIC_WEIGHTS"] = "1"
+    # config 1: hf/e5-base-v2, batch = 8 short docs
+    docs = [f"passage: synthetic document number {i} about topic {i % 3}" for i in range(8)]
+    out = np.asarray(s2i.vectorise("hf/e5-base-v2", docs, device=DEV))
+    assert out.shape == (8, 768) and np.allclose(np.linalg.norm(out, axis=1), 1, atol=1e-5)
+    key = s2i._create_model_cache_key("hf/e5-base-v2", DEV, s2i.get_model_properties_from_registry("hf/e5-base-v2"))
+    m = s2i.get_available_models()[key]["model"]
+    tok = m._tokenizer(docs, max_length=512)
+    from marqo_amd.engine import archs, synthetic
+    sd = synthetic.random_bert_state_dict(archs.HF_BERT_ARCHS["intfloat/e5-base-v2"], seed=0)
+    ref = O.hf_encode(sd, O.BertConfig(), torch.from_numpy(tok["input_ids"]), torch.from_numpy(tok["attention_mask"])).numpy()
+    assert _cos_err(out, ref) < COS_TOL
+    # config 2 through the API: ViT-B/32 on PIL images + text from the same model
+    rng = np.random.default_rng(1)
+    pil = [Image.fromarray(rng.integers(0, 256, (224, 224, 3), dtype=np.uint8)) for _ in range(4)]
+    name = "open_clip/ViT-B-32/laion2b_s34b_b79k"
+    img = np.asarray(s2i.vectorise(name, pil, device=DEV, modality=s2i.Modality.IMAGE))
+    txt = np.asarray(s2i.vectorise(name, ["a photo of a cat", "a dog"], device=DEV))
+    assert img.shape == (4, 512) and txt.shape == (2, 512)
+    varch, tarch = archs.resolve_open_clip("ViT-B-32")
+    sdc = synthetic.random_open_clip_state_dict(vision=varch, text=tarch, seed=0)
+    vc = O.VitConfig(224, 32, 768, 12, 12, 3072, 512)
+    refi = O.vit_forward(sdc, vc, torch.from_numpy(np.stack([OP.clip_transform(np.asarray(p)) for p in pil]))).numpy()
+    assert _cos_err(img, refi) < COS_TOL
+    # OpenAI-style name resolves to the QuickGELU towers
+    q = np.asarray(s2i.vectorise("ViT-B/32", ["a photo of a cat"], device=DEV))
+    assert q.shape == (1, 512) and _cos_err(q, txt[:1]) > 1e-4
+    assert len(s2i.get_available_models()) >= 3
+    s2i.eject_model(name, DEV)

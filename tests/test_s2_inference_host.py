@@ -1,0 +1,420 @@
+"""Host logic of the vectorise() path, restated from the reference's own plumbing tests
+(tests/s2_inference/test_vectorise.py, test_automatic_model_ejection_and_concurrency.py,
+tests/core/inference/test_vectorise_inference_cache.py) against marqo_amd.s2_inference.  These use the reference's own
+`random` fake model and mocks — no tower, no GPU."""
+import datetime
+import importlib
+import os
+import queue
+import random
+import threading
+import time
+from unittest import mock
+
+import numpy as np
+import pytest
+from PIL import Image
+
+from marqo_amd.s2_inference import random_utils, s2_inference
+from marqo_amd.s2_inference.enums import AvailableModelsKey, Modality
+from marqo_amd.s2_inference.errors import (ConfigurationError, InternalError, InvalidModelPropertiesError,
+                                           ModelCacheManagementError, ModelLoadError, ModelNotInCacheError, S2InferenceError,
+                                           UnknownModelError, VectoriseError)
+
+S2 = "marqo_amd.s2_inference.s2_inference"
+
+
+@pytest.fixture(autouse=True)
+def _clean():
+    s2_inference.clear_loaded_models()
+    yield
+    s2_inference.clear_loaded_models()
+
+
+def _mock_model(dim=128):
+    rnd = random_utils.Random(model_name="mock_model", embedding_dim=dim, device="cpu")
+    m = mock.MagicMock()
+    m.supports_dynamic_batching = False
+    m.encode = mock.MagicMock(side_effect=lambda *a, **k: rnd.encode(*a, **k))
+    props = {"name": "mock_model", "dimensions": dim, "tokens": 128, "type": "sbert"}
+    avail = {s2_inference._create_model_cache_key("mock_model", "cpu", props): {
+        AvailableModelsKey.model: m, AvailableModelsKey.model_size: 1,
+        AvailableModelsKey.most_recently_used_time: datetime.datetime.now()}}
+    return m, props, avail
+
+
+def _vectorise_mock(m, props, avail, content, **kw):
+    with mock.patch(S2 + "._available_models", avail), mock.patch(S2 + "._update_available_models", mock.MagicMock()):
+        return s2_inference.vectorise(model_name="mock_model", content=content, model_properties=props, device="cpu", **kw)
+
+
+# ---- tests/s2_inference/test_vectorise.py ------------------------------------------------------------------
+def test_vectorise_in_batches():
+    m, props, avail = _mock_model()
+    out = _vectorise_mock(m, props, avail, ["just a single content"])
+    assert len(out) == 1 and len(out[0]) == 128 and isinstance(out[0][0], float)
+
+
+def test_vectorise_empty_content():
+    m, props, avail = _mock_model()
+    with pytest.raises(RuntimeError, match="(?i)empty list of batches"):
+        _vectorise_mock(m, props, avail, [])
+
+
+@pytest.mark.parametrize("batch_size,n", [(1, 5), (2, 5), (16, 33), (16, 16), (100, 7)])
+def test_vectorise_in_batches_with_different_batch_sizes(batch_size, n):
+    m, props, avail = _mock_model()
+    content = [f"content {i}" for i in range(n)]
+    with mock.patch.dict(os.environ, {"MARQO_MAX_VECTORISE_BATCH_SIZE": str(batch_size)}):
+        out = _vectorise_mock(m, props, avail, content)
+    assert len(out) == n
+    assert m.encode.call_count == -(-n // batch_size)
+    sizes = [len(c.args[0]) for c in m.encode.call_args_list]
+    assert sizes == [batch_size] * (n // batch_size) + ([n % batch_size] if n % batch_size else [])
+
+
+def test_vectorise_single_string_bypasses_batching():
+    m, props, avail = _mock_model()
+    out = _vectorise_mock(m, props, avail, "a bare string")
+    assert len(out) == 1 and len(out[0]) == 128
+    (args, kwargs) = m.encode.call_args
+    assert args[0] == "a bare string" and kwargs["modality"] == Modality.TEXT and kwargs["normalize"] is True
+
+
+def test_infer_kwarg_only_reaches_first_batch():
+    """appendix A.2 quirk: `infer` is popped inside the batch loop"""
+    m, props, avail = _mock_model()
+    with mock.patch.dict(os.environ, {"MARQO_MAX_VECTORISE_BATCH_SIZE": "2"}):
+        _vectorise_mock(m, props, avail, ["a", "b", "c"], infer=True)
+    assert [c.kwargs["infer"] for c in m.encode.call_args_list] == [True, False]
+
+
+def test_dynamic_batching_models_get_one_call():
+    m, props, avail = _mock_model()
+    m.supports_dynamic_batching = True
+    out = _vectorise_mock(m, props, avail, [f"c{i}" for i in range(100)])
+    assert len(out) == 100 and m.encode.call_count == 1
+
+
+@pytest.mark.parametrize("bad", ["0", "-1", "abc", "1.5"])
+def test__get_max_vectorise_batch_size_invalid(bad):
+    with mock.patch.dict(os.environ, {"MARQO_MAX_VECTORISE_BATCH_SIZE": bad}):
+        with pytest.raises(ConfigurationError):
+            s2_inference._get_max_vectorise_batch_size()
+
+
+def test__get_max_vectorise_batch_size_default_and_env():
+    assert s2_inference._get_max_vectorise_batch_size() == 16
+    with mock.patch.dict(os.environ, {"MARQO_MAX_VECTORISE_BATCH_SIZE": "7"}):
+        assert s2_inference._get_max_vectorise_batch_size() == 7
+
+
+def test_vectorise_with_no_device_fails():
+    with pytest.raises(InternalError, match="cannot be called without setting device"):
+        s2_inference.vectorise("random/small", "hello")
+    with pytest.raises(InternalError):
+        s2_inference.load_multimodal_model_and_get_preprocessors("random/small", {"type": "random", "dimensions": 32})
+
+
+def test_vectorise_error_handling_image():
+    m, props, avail = _mock_model()
+    from PIL import UnidentifiedImageError
+    m.encode.side_effect = UnidentifiedImageError("bad image")
+    with pytest.raises(VectoriseError, match="Could not process given image"):
+        _vectorise_mock(m, props, avail, ["http://x/y.jpg"])
+    m.encode.side_effect = OSError("image file is truncated (3 bytes not processed)")
+    with pytest.raises(VectoriseError):
+        _vectorise_mock(m, props, avail, ["http://x/y.jpg"])
+    m.encode.side_effect = OSError("disk on fire")
+    with pytest.raises(OSError, match="disk on fire"):
+        _vectorise_mock(m, props, avail, ["http://x/y.jpg"])
+
+
+# ---- registry / validation ---------------------------------------------------------------------------------------
+def test_registry_shape_and_known_entries():
+    mp = s2_inference.MODEL_PROPERTIES
+    assert set(mp) == {"models", "loaders"}
+    assert {"open_clip", "clip", "fp16_clip", "hf", "hf_stella", "random", "no_model"} <= set(mp["loaders"])
+    p = s2_inference.get_model_properties_from_registry("open_clip/ViT-B-32/laion2b_s34b_b79k")
+    assert p["dimensions"] == 512 and p["type"] == "open_clip" and p["name"] == "open_clip/ViT-B-32/laion2b_s34b_b79k"
+    assert s2_inference.get_model_properties_from_registry("open_clip/ViT-L-14/laion2b_s32b_b82k")["dimensions"] == 768
+    e5 = s2_inference.get_model_properties_from_registry("hf/e5-base-v2")
+    assert (e5["name"], e5["dimensions"], e5["tokens"], e5["type"]) == ("intfloat/e5-base-v2", 768, 512, "hf")
+    assert e5["text_query_prefix"] == "query: " and e5["text_chunk_prefix"] == "passage: "
+    with pytest.raises(UnknownModelError):
+        s2_inference.get_model_properties_from_registry("definitely/not-a-model")
+
+
+def test_validate_model_properties():
+    v = s2_inference.validate_model_properties
+    assert v("x", {"name": "n", "dimensions": 3})["type"] == "sbert"          # default type + tokens filled in
+    assert v("x", {"name": "n", "dimensions": 3})["tokens"] == 128
+    with pytest.raises(InvalidModelPropertiesError, match="missing key 'name'"):
+        v("x", {"type": "open_clip", "dimensions": 512})
+    with pytest.raises(InvalidModelPropertiesError, match="missing key 'dimensions'"):
+        v("x", {"type": "hf", "name": "a/b"})
+    with pytest.raises(InvalidModelPropertiesError, match="Invalid model type"):
+        v("x", {"type": "banana", "name": "n", "dimensions": 3})
+    for bad in (0, -1, 1.5, "512", None):
+        with pytest.raises(InvalidModelPropertiesError, match="positive integer"):
+            v("x", {"type": "hf", "name": "a/b", "dimensions": bad})
+    with pytest.raises(InvalidModelPropertiesError, match="no_model"):
+        v("not_no_model", {"type": "no_model", "dimensions": 3})
+    assert v("no_model", {"type": "no_model", "dimensions": 3})["dimensions"] == 3
+    assert issubclass(InvalidModelPropertiesError, S2InferenceError)
+
+
+def test_model_cache_key_format():
+    k = s2_inference._create_model_cache_key("m", "cuda:0", {"name": "n", "dimensions": 5, "type": "hf", "tokens": 7})
+    assert k == "m||n||5||hf||7||cuda:0"
+    assert s2_inference._create_model_cache_key("m", "cpu", None) == "m||||||||||cpu"
+
+
+# ---- tests/s2_inference/test_automatic_model_ejection_and_concurrency.py -------------------------------------------
+def test_get_model_size():
+    g = s2_inference.get_model_size
+    v = s2_inference.validate_model_properties
+    for name, size in {"open_clip/ViT-L-14/openai": 1.5, "open_clip/ViT-L-14/laion400m_e31": 1.5,
+                       "open_clip/ViT-B-16/laion2b_s34b_b88k": 1, "hf/e5-base-v2": 1, "random/small": 0.1}.items():
+        assert g(name, v(name, None)) == size, name
+    assert g("my_custom_clip", {"name": "ViT-L-14", "type": "open_clip", "dimensions": 768, "model_size": 1.53}) == 1.53
+    assert g("my_custom_clip", {"name": "ViT-L/14", "dimensions": 768, "type": "clip"}) == 1.5
+    assert g("whatever", {"name": "x", "type": "unknown", "dimensions": 1}) == 0.66
+
+
+def test_thread_safe_function_guards():
+    with pytest.raises(RuntimeError, match="thread safeness"):
+        s2_inference._validate_model_into_device("m", {"type": "random"}, "cpu", calling_func="somebody")
+    with pytest.raises(RuntimeError, match="threading safeness"):
+        s2_inference._check_memory_threshold_for_model("cpu", 1, calling_func="somebody")
+    with pytest.raises(RuntimeError, match="threading safeness"):
+        s2_inference._load_model("random/small", {"type": "random", "dimensions": 32, "name": "random/small"}, "cpu", calling_func="x")
+    m = s2_inference._load_model("random/small", {"type": "random", "dimensions": 32, "name": "random/small"}, "cpu", calling_func="unit_test")
+    assert m.encode("hi").shape == (1, 32)
+
+
+def test_check_memory_threshold_and_ejection():
+    with mock.patch.dict(os.environ, {"MARQO_MAX_CPU_MODEL_MEMORY": "0.25"}):
+        assert s2_inference._check_memory_threshold_for_model("cpu", 0.1, calling_func="unit_test") is True
+        with pytest.raises(ModelCacheManagementError, match="larger than the device threshold"):
+            s2_inference._check_memory_threshold_for_model("cpu", 0.3, calling_func="unit_test")
+        with pytest.raises(ModelCacheManagementError, match="Unable to check the device cache"):
+            s2_inference._check_memory_threshold_for_model("tpu", 0.1, calling_func="unit_test")
+        # three 0.1 GB models under a 0.25 GB budget: the least recently used is ejected to make room
+        for name in ("random/small", "random/medium", "random/large"):
+            s2_inference.vectorise(name, "hello", device="cpu")
+            time.sleep(0.01)
+        keys = list(s2_inference.get_available_models())
+        assert len(keys) == 2 and not any(k.startswith("random/small||") for k in keys)
+        s2_inference.vectorise("random/medium", "renew medium", device="cpu")   # renew -> `large` is now the LRU
+        s2_inference.vectorise("random/small", "hello", device="cpu")
+        keys = list(s2_inference.get_available_models())
+        assert len(keys) == 2 and not any(k.startswith("random/large||") for k in keys)
+
+
+def test_eject_model_and_clear():
+    s2_inference.vectorise("random/small", "hello", device="cpu")
+    assert len(s2_inference.get_available_models()) == 1
+    with pytest.raises(ModelNotInCacheError):
+        s2_inference.eject_model("random/small", "cuda:3")
+    assert s2_inference.eject_model("random/small", "cpu")["result"] == "success"
+    assert len(s2_inference.get_available_models()) == 0
+    with pytest.raises(ModelNotInCacheError):
+        s2_inference.eject_model("random/small", "cpu")
+
+
+def test_concurrent_first_load_is_rejected_not_queued():
+    """s2_inference.py:293-297: while one thread loads, another thread needing a load gets ModelCacheManagementError;
+    threads using an already cached model proceed."""
+    started, release = threading.Event(), threading.Event()
+    real_load = s2_inference._load_model
+
+    def slow_load(*a, **k):
+        started.set()
+        release.wait(5)
+        return real_load(*a, **k)
+
+    q1, q2 = queue.Queue(), queue.Queue()
+
+    def first():
+        try:
+            s2_inference.vectorise("random/small", "x", device="cpu"); q1.put("success")
+        except Exception as e:  # pragma: no cover
+            q1.put(e)
+
+    def racer(name, q):
+        try:
+            s2_inference.vectorise(name, "x", device="cpu"); q.put("success")
+        except Exception as e:
+            q.put(e)
+
+    s2_inference.vectorise("random/large", "warm", device="cpu")  # already cached model
+    with mock.patch(S2 + "._load_model", slow_load):
+        t = threading.Thread(target=first); t.start()
+        assert started.wait(5)
+        racers = [threading.Thread(target=racer, args=("random/medium", q2)) for _ in range(3)]
+        cached = threading.Thread(target=racer, args=("random/large", q1))
+        for r in racers + [cached]:
+            r.start()
+        for r in racers + [cached]:
+            r.join()
+        release.set(); t.join()
+    assert sorted(str(q1.get()) for _ in range(2)) == ["success", "success"]
+    assert q2.qsize() == 3
+    while not q2.empty():
+        assert isinstance(q2.get(), ModelCacheManagementError)
+
+
+def test_model_load_error_wrapping():
+    with pytest.raises(ModelLoadError, match="Unable to load model"):
+        # cpu device -> the HIP engine refuses loudly (no CPU fallback), surfaced as ModelLoadError like any load failure
+        s2_inference.vectorise("open_clip/ViT-B-32/laion2b_s34b_b79k", "hello", device="cpu")
+    assert len(s2_inference.get_available_models()) == 0
+    with pytest.raises(ModelLoadError):
+        s2_inference.vectorise("hf/e5-base-v2", "hello", device="cpu")
+
+
+def test_no_model_refuses_to_vectorise():
+    with pytest.raises(VectoriseError, match="no_model"):
+        s2_inference.vectorise("no_model", "hi", model_properties={"type": "no_model", "dimensions": 8}, device="cpu")
+
+
+# ---- output conversion (s2_inference.py:623-749) -----------------------------------------------------------------------
+def test_convert_vectorized_output():
+    import torch
+    c = s2_inference._convert_vectorized_output
+    assert c(np.ones((2, 3), np.float32)) == [[1.0] * 3] * 2
+    assert c(np.ones(3, np.float32)) == [[1.0] * 3]
+    assert c(torch.ones(2, 3)) == [[1.0] * 3] * 2 and c(torch.ones(3)) == [[1.0] * 3]
+    assert c([np.ones(3), np.zeros(3)]) == [[1.0] * 3, [0.0] * 3]
+    assert c([[1.0, 2.0]]) == [[1.0, 2.0]]
+    with pytest.raises(TypeError):
+        c("nope")
+    with pytest.raises(ValueError):
+        c([])
+    assert s2_inference._convert_cached_embeddings_to_output([1.0, 2.0]) == [[1.0, 2.0]]
+    with pytest.raises(TypeError):
+        s2_inference._convert_cached_embeddings_to_output(np.ones(3))
+
+
+def test_vectorise_ndarray_fast_path():
+    a = s2_inference.vectorise_ndarray("random/small", ["a", "b"], device="cpu")
+    assert isinstance(a, np.ndarray) and a.shape == (2, 32)
+    assert a.tolist() == s2_inference.vectorise("random/small", ["a", "b"], device="cpu")
+
+
+# ---- inference cache (tests/core/inference/test_vectorise_inference_cache.py) ----------------------------------------------
+@pytest.fixture
+def cached_vectorise():
+    with mock.patch.dict(os.environ, {"MARQO_INFERENCE_CACHE_SIZE": "50", "MARQO_INFERENCE_CACHE_TYPE": "LRU"}):
+        importlib.reload(s2_inference)
+        yield s2_inference.vectorise
+    importlib.reload(s2_inference)
+
+
+def test_cache_single_string(cached_vectorise):
+    first = cached_vectorise("random/small", "test", device="cpu", enable_cache=True)
+    with mock.patch(S2 + "._encode_without_cache") as enc:
+        again = cached_vectorise("random/small", "test", device="cpu", enable_cache=True)
+        enc.assert_not_called()
+    assert again == first and isinstance(again[0], list)
+    with mock.patch(S2 + "._encode_without_cache", return_value=[[0.0]]) as enc:
+        cached_vectorise("random/small", "test", device="cpu", enable_cache=False)  # cache bypassed when not enabled per call
+        enc.assert_called_once()
+
+
+def test_cache_partial_list_only_misses_are_encoded(cached_vectorise):
+    cached = ["test1", "test2"]
+    cached_vectorise("random/small", cached, device="cpu", enable_cache=True)
+    with mock.patch(S2 + "._encode_without_cache") as enc:
+        cached_vectorise("random/small", cached + ["test3", "test4"], device="cpu", enable_cache=True)
+        assert enc.call_args[0][1] == ["test3", "test4"]
+
+
+def test_cache_partial_list_vectors_in_original_positions(cached_vectorise):
+    rng = random.Random(0)
+    for _ in range(5):
+        s2_inference.clear_marqo_inference_cache()
+        cached = [f"test{i}" for i in range(20)]
+        # Random model seeds from the batch hash -> cache each item individually so vectors are per-item deterministic
+        original = [cached_vectorise("random/small", c, device="cpu", enable_cache=True)[0] for c in cached]
+        content = cached + [f"test{i}" for i in range(20, 40)]
+        rng.shuffle(content)
+        vectors = cached_vectorise("random/small", content, device="cpu", enable_cache=True)
+        assert len(vectors) == 40
+        assert [vectors[content.index(c)] for c in cached] == original
+        rng.shuffle(content)
+        with mock.patch(S2 + "._encode_without_cache") as enc:
+            cached_vectorise("random/small", content, device="cpu", enable_cache=True)
+            enc.assert_not_called()
+
+
+def test_cache_does_not_serve_pil_images(cached_vectorise):
+    content = [Image.fromarray(np.random.randint(0, 256, (8, 8, 3), dtype=np.uint8))]
+    cached_vectorise("random/small", content, device="cpu", enable_cache=True)
+    with mock.patch(S2 + "._encode_without_cache", return_value=[[0.0]]) as enc:
+        cached_vectorise("random/small", content, device="cpu", enable_cache=True)
+        enc.assert_called_once()
+
+
+def test_cache_policies():
+    from marqo_amd.s2_inference.inference_cache import EnvVarError, MarqoInferenceCache
+    assert not MarqoInferenceCache(0).is_enabled()
+    with pytest.raises(EnvVarError):
+        MarqoInferenceCache(-1)
+    with pytest.raises(EnvVarError):
+        MarqoInferenceCache(3, "FIFO")
+    lru = MarqoInferenceCache(2, "LRU")
+    lru.set("k", "a", [1.0]); lru.set("k", "b", [2.0]); lru.get("k", "a"); lru.set("k", "c", [3.0])
+    assert ("k", "a") in lru and ("k", "b") not in lru and lru.currsize == 2 and lru.maxsize == 2
+    lfu = MarqoInferenceCache(2, "LFU")
+    lfu.set("k", "a", [1.0]); lfu.set("k", "b", [2.0]); lfu.get("k", "a"); lfu.get("k", "a"); lfu.get("k", "b")
+    lfu.set("k", "c", [3.0])
+    assert ("k", "a") in lfu and ("k", "b") not in lfu and ("k", "c") in lfu
+    with pytest.raises(TypeError):
+        lru.get("k", 5)
+
+
+# ---- input typing (image_download.py:28-71) ----------------------------------------------------------------------------
+def test_is_image_rules(tmp_path):
+    from PIL import UnidentifiedImageError
+    from marqo_amd.s2_inference.image_input import _is_image
+    import torch
+    assert _is_image("photo.JPG") and _is_image(["a.png", "not looked at"]) and _is_image("https://example.com/x")
+    assert not _is_image("just some text") and not _is_image(["text first.", "b.png"])
+    assert _is_image(Image.new("RGB", (2, 2))) and _is_image(np.zeros((2, 2, 3))) and _is_image(torch.zeros(3, 2, 2))
+    f = tmp_path / "file.txt"; f.write_text("x")
+    with pytest.raises(UnidentifiedImageError):
+        _is_image(str(f))
+    with pytest.raises(UnidentifiedImageError):
+        _is_image([])
+    with pytest.raises(UnidentifiedImageError):
+        _is_image(5)
+
+
+# ---- text chunking (processing/text.py) -----------------------------------------------------------------------------------
+def test_split_text_and_prefix():
+    from marqo_amd.s2_inference.processing.text import prefix_text_chunks, split_text
+    assert split_text("", "sentence") == [" "] and split_text("a", "word") == ["a"]
+    assert split_text("abcdef", "character", 3, 1) == ["abc", "cde", "ef"]
+    assert split_text("one two three four five", "word", 2, 0) == ["one two", "three four", "five"]
+    assert split_text("p1\n\np2\n\np3", "passage", 1, 0) == ["p1", "p2", "p3"]
+    assert split_text("Hello there. How are you? Fine.", "sentence", 2, 1) == ["Hello there. How are you?", "How are you? Fine."]
+    with pytest.raises(ValueError):
+        split_text("abc", "word", 0, 0)
+    with pytest.raises(KeyError):
+        split_text("abc def", "paragraphs")
+    assert prefix_text_chunks(["a", "b"], "passage: ") == ["passage: a", "passage: b"]
+    assert prefix_text_chunks(["a"], "") == ["a"] and prefix_text_chunks(["a"], None) == ["a"]
+
+
+def test_chunk_image_method_parsing_and_boxes():
+    from marqo_amd.s2_inference.processing import image as I
+    assert I._process_patch_method("simple") == ("simple", {})
+    assert I._process_patch_method("overlap?hn=3&wn=4") == ("overlap", {"hn": "3", "wn": "4"})
+    assert len(I.generate_boxes((240, 240), 3, 3)) == 9 and len(I.generate_boxes((240, 240), 3, 3, True)) == 13
+    img = Image.new("RGB", (40, 30))
+    assert I.chunk_image(img, "cuda", None) == ([img], [(0, 0, 40, 30)])
+    assert I.chunk_image("http://a/b.png", "cuda", "none") == (["http://a/b.png"], ["http://a/b.png"])
+    with pytest.raises(ValueError):
+        I.chunk_image(img, "cuda", "bogus")

@@ -1,0 +1,147 @@
+"""Pins marqo_amd.engine.tokenizers (own implementations of the published CLIP byte-BPE and BERT WordPiece
+algorithms) against the independent implementations in `transformers` / `tokenizers` on synthetic
+vocabularies (no real vocabulary file is available offline)."""
+import collections
+
+import numpy as np
+import pytest
+
+from marqo_amd.engine.tokenizers import ClipBpeTokenizer, SyntheticTokenizer, WordPieceTokenizer, _byte_to_unicode
+
+CORPUS = ("the quick brown fox jumps over the lazy dog . a photo of a cat , a photo of a dog ! "
+          "marqo is a tensor search engine ; it's built for images and text . query: how much protein should a female eat "
+          "passage: synthetic document number 12 about topic 3 — naïve café über straße 東京 photos 2024 ").split()
+
+SENTENCES = [
+    "a photo of a cat",
+    "The Quick  Brown fox, jumps over the lazy dog!",
+    "it's built for images & text... isn't it?",
+    "query: how much protein should a female eat",
+    "naïve café über straße",
+    "東京 photos 2024",
+    "",
+    "unseenwordzzz qqq 1234567890",
+    "tab\tand\nnewline   spaces",
+    "word " * 200,
+]
+
+
+def _train_bpe(words, n_merges):
+    b2u = _byte_to_unicode()
+    vocab = collections.Counter()
+    for w in words:
+        sym = [b2u[b] for b in w.lower().encode("utf-8")]
+        sym[-1] += "</w>"
+        vocab[tuple(sym)] += 1
+    merges = []
+    for _ in range(n_merges):
+        pairs = collections.Counter()
+        for sym, c in vocab.items():
+            for p in zip(sym[:-1], sym[1:]):
+                pairs[p] += c
+        if not pairs:
+            break
+        best = max(sorted(pairs), key=lambda p: pairs[p])
+        merges.append(best)
+        new = collections.Counter()
+        for sym, c in vocab.items():
+            out, i = [], 0
+            while i < len(sym):
+                if i + 1 < len(sym) and (sym[i], sym[i + 1]) == best:
+                    out.append(sym[i] + sym[i + 1]); i += 2
+                else:
+                    out.append(sym[i]); i += 1
+            new[tuple(out)] += c
+        vocab = new
+    return merges
+
+
+@pytest.fixture(scope="module")
+def clip_pair():
+    from transformers import CLIPTokenizer
+    merges = _train_bpe(CORPUS, 150)
+    ours = ClipBpeTokenizer(merges, context_length=77)
+    hf_vocab = {}
+    for tok, i in ours.encoder.items():
+        tok = {"<start_of_text>": "<|startoftext|>", "<end_of_text>": "<|endoftext|>"}.get(tok, tok)
+        hf_vocab[tok] = i
+    hf = CLIPTokenizer(vocab=hf_vocab, merges=[tuple(m) for m in merges])
+    return ours, hf
+
+
+def test_clip_bpe_matches_transformers(clip_pair):
+    ours, hf = clip_pair
+    for s in SENTENCES:
+        if "東京" in s or "naïve" in s:
+            continue  # byte-level fallbacks of non-ascii are compared separately below
+        ref = hf(s)["input_ids"]
+        got = [ours.sot_id] + ours.encode(s) + [ours.eot_id]
+        assert got == ref, s
+
+
+def test_clip_bpe_non_ascii_bytes(clip_pair):
+    ours, hf = clip_pair
+    for s in ("naïve café über straße", "東京 photos 2024"):
+        assert [ours.sot_id] + ours.encode(s) + [ours.eot_id] == hf(s)["input_ids"], s
+
+
+def test_clip_context_padding_and_truncation(clip_pair):
+    ours, _ = clip_pair
+    out = ours(["a photo of a cat", "word " * 200])
+    assert out.shape == (2, 77) and out.dtype == np.int64
+    assert out[0, 0] == ours.sot_id and out[0].max() == ours.eot_id and out[0, -1] == 0
+    assert out[1, -1] == ours.eot_id and out[1].argmax() == 76  # truncated, EOT forced into the last slot
+    assert (ours("a photo of a cat") == out[:1]).all()           # str == [str]
+    assert ours.eot_id == ours.vocab_size - 1                   # EOT is the largest id -> argmax pooling finds it
+
+
+def _bert_vocab():
+    toks = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"]
+    chars = sorted(set("".join(CORPUS).lower()) | set("abcdefghijklmnopqrstuvwxyz0123456789"))
+    toks += [c for c in chars] + ["##" + c for c in chars]
+    toks += ["the", "quick", "brown", "fox", "jump", "##s", "over", "lazy", "dog", "photo", "##graph", "of", "cat", "query",
+             "passage", "protein", "fe", "##male", "eat", "it", "built", "for", "image", "##s", "and", "text", "naive", "cafe",
+             "uber", "synth", "##etic", "doc", "##ument", "number", "topic", "word", ",", ".", "!", "?", ":", ";", "'", "&", "—"]
+    seen, out = set(), []
+    for t in toks:
+        if t not in seen:
+            seen.add(t); out.append(t)
+    return {t: i for i, t in enumerate(out)}
+
+
+@pytest.fixture(scope="module")
+def bert_pair():
+    from transformers import BertTokenizer
+    vocab = _bert_vocab()
+    return WordPieceTokenizer(vocab), BertTokenizer(vocab=vocab, do_lower_case=True)
+
+
+def test_wordpiece_matches_transformers(bert_pair):
+    ours, hf = bert_pair
+    for s in SENTENCES:
+        ref = hf(s, truncation=True, max_length=128)["input_ids"]
+        assert ours.encode(s, max_length=128) == ref, s
+
+
+def test_wordpiece_batch_padding_truncation(bert_pair):
+    ours, hf = bert_pair
+    batch = [s for s in SENTENCES if s]
+    ref = hf(batch, padding=True, truncation=True, max_length=16, return_tensors="np")
+    got = ours(batch, max_length=16)
+    assert np.array_equal(got["input_ids"], ref["input_ids"])
+    assert np.array_equal(got["attention_mask"], ref["attention_mask"])
+    assert got["input_ids"].shape[1] <= 16
+
+
+def test_wordpiece_special_tokens_in_text(bert_pair):
+    ours, hf = bert_pair
+    s = "the fox [SEP] the dog [MASK]"
+    assert ours.encode(s) == hf(s)["input_ids"]
+
+
+def test_synthetic_tokenizer_shapes():
+    t = SyntheticTokenizer("clip", 49408)
+    out = t(["a b c", "d"])
+    assert out.shape == (2, 77) and out[0, 0] == 49406 and out[0, 4] == 49407 and (out.argmax(1) == [4, 2]).all()
+    b = SyntheticTokenizer("bert", 30522)(["a b c", "d"], max_length=512)
+    assert b["input_ids"].shape == (2, 5) and b["attention_mask"].sum() == 8 and b["input_ids"][1, 3] == 0
