@@ -274,6 +274,12 @@ int mq_encoder_forward(const mq_encoder_cfg* cfg, const mq_block_weights* blocks
 /* rows of x: out[r,:] = x[r,:] / ||x[r,:]||_2   (in place allowed) */
 int mq_l2_normalize(const float* d_x, float* d_out, int64_t rows, int32_t D, void* stream);
 
+/* Run-time selection of a kernel variant (benchmark A/B and parity tests of every variant in one process).
+ * keys: "gemm_mt" (0 = auto, else GEMM tile height in 32-row units), "gemm_spec" (1 = producer/consumer wave
+ * specialisation), "gemm_big" (4 / 6 / 8 = one-workgroup-per-CU (32*v) x 256 tile, 0 = off).  Initial values come from
+ * the environment (MQ_GEMM_MT, MQ_GEMM_SPEC, MQ_GEMM_BIG). */
+int mq_tune(const char* key, int value);
+
 /* ---- per-kernel timing (bench.py roofline) ------------------------------------------- */
 /* When enabled, every launch of a kernel family is bracketed by hipEvents on its stream.
  * mq_profile_collect synchronises, sums the elapsed time per family and resets.

@@ -112,6 +112,7 @@ _SIGNATURES = {
     "mq_to_tensor_normalize": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float), _P]),
     "mq_resample_ksize": (C.c_int, [C.c_int32, C.c_int32]),
     "mq_resample_coeffs": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
+    "mq_tune": (C.c_int, [C.c_char_p, C.c_int]),
     "mq_profile_enable": (C.c_int, [C.c_int]),
     "mq_profile_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
 }
@@ -131,7 +132,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     One object per source, compiled in parallel and cached by mtime under csrc/.obj/, then linked."""
     from concurrent.futures import ThreadPoolExecutor
     srcs = sources()
-    common = [str(CSRC_DIR / "common.h"), str(HEADER_PATH)]
+    common = sorted(str(p) for p in CSRC_DIR.glob("*.h")) + [str(HEADER_PATH)]
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     obj_dir = CSRC_DIR / ".obj"
     obj_dir.mkdir(parents=True, exist_ok=True)

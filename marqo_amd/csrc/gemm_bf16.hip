@@ -16,8 +16,15 @@
 //   * workgroup -> tile map is XCD-aware: the 8 XCDs (block b runs on XCD b % 8) each take a
 //     contiguous range of tiles, so tiles sharing an A row-panel hit the same private L2.
 #include <stdlib.h>
+#include <string>
 #include <type_traits>
 #include "common.h"
+#include "gemm_epilogue.h"
+
+// CU-sized-tile main loop (gemm_big.hip)
+template <int FLAGS>
+int mq_launch_gemm_big(int mt, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* residual,
+                       void* out, int64_t ldc, int M, int N, int K, hipStream_t s);
 
 namespace {
 
@@ -35,8 +42,11 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 // that minimises (rounds of resident workgroups) x (tile cost), which removes most of the tile
 // quantisation loss at the towers' shapes (e.g. M=12800,N=768: 600 128-row tiles = 2 rounds on
 // 512 slots, 480 160-row tiles = 1 round).
-template <int FLAGS, int MT>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
+// SPEC (wave specialisation): the workgroup has 8 waves; waves 4..7 are PRODUCERS that only issue the LDS-DMA
+// of the next stage (an LDS-DMA issue stalls the issuing wave for 60-180 cycles — in the 4-wave form those stalls
+// sit in front of the same wave's MFMAs), waves 0..3 are CONSUMERS whose k-loop is ds_read + MFMA only.
+template <int FLAGS, int MT, bool SPEC>
+__global__ __launch_bounds__(SPEC ? 512 : 256, SPEC ? 4 : 2) void gemm_nt_kernel(
     const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ Wt, int64_t ldw,
     const float* __restrict__ bias, const float* residual, void* out, int64_t ldc,
     int M, int N, int K, int tiles_n, int num_tiles) {
@@ -55,7 +65,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave_id & 3;  // share of the tile this wave stages (producer) / computes (consumer)
+    const bool producer = SPEC && wave_id >= 4;
     const int wm = wave >> 1, wn = wave & 1;
     const int l15 = lane & 15, g = lane >> 4;
 
@@ -152,6 +164,24 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
     };
 
     const int nk = K / BK;
+    if (SPEC) {
+        if (producer) {
+            stage(0, 0);
+            for (int kt = 0; kt < nk; ++kt) {
+                // stage kt has landed (this wave's share) and, past the barrier, every consumer is done with buffer (kt+1)&1
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+            }
+            return;
+        }
+        for (int kt = 0; kt < nk; ++kt) {
+            __syncthreads();
+            __builtin_amdgcn_s_setprio(1);
+            kstep(kt, std::false_type{});
+            __builtin_amdgcn_s_setprio(0);
+        }
+    } else {
     stage(0, 0);
     for (int kt = 0; kt < nk - 1; ++kt) {
         // tile kt has landed for every wave, and every wave is done reading buffer (kt+1)&1
@@ -162,46 +192,18 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     kstep(nk - 1, std::false_type{});
-
-    // ---- epilogue: lane owns out[m][n .. n+3] for each (mt, nt) -----------------------------
-    // D[i][j] = sum_k Wfrag[i][k] * Afrag[j][k]: column j = lane & 15 -> m, row i = 4*g + reg -> n.
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int m = m0 + wm * (16 * MT) + mt * 16 + l15;
-        if (m >= M) continue;
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            const int n = n0 + wn * 64 + nt * 16 + g * 4;
-            if (n >= N) continue;
-            f32x4 v = acc[mt][nt];
-            if (FLAGS & MQ_EPI_BIAS) {
-                const f32x4 b = *(const f32x4*)(bias + n);
-                v += b;
-            }
-            if (FLAGS & MQ_EPI_GELU) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-            }
-            if (FLAGS & MQ_EPI_QUICKGELU) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
-            }
-            const int64_t o = (int64_t)m * ldc + n;
-            if (FLAGS & MQ_EPI_RESIDUAL) {
-                const f32x4 rr = *(const f32x4*)(residual + o);
-                v += rr;
-            }
-            if (FLAGS & MQ_EPI_OUT_F32) {
-                *(f32x4*)((float*)out + o) = v;
-            } else {
-                uint2 p;
-                p.x = pack_bf16x2(v[0], v[1]);
-                p.y = pack_bf16x2(v[2], v[3]);
-                *(uint2*)((bf16_t*)out + o) = p;
-            }
-        }
     }
+
+    gemm_epilogue<FLAGS, MT>(acc, bias, residual, out, ldc, M, N, m0 + wm * (16 * MT), n0 + wn * 64, l15, g);
 }
+
+// tuning knobs: initialised from the environment (MQ_GEMM_MT / _SPEC / _BIG), overridable through mq_tune()
+struct GemmTune {
+    int mt, spec, big;
+    static int env(const char* k, int d) { const char* v = getenv(k); return v ? atoi(v) : d; }
+    GemmTune() : mt(env("MQ_GEMM_MT", 0)), spec(env("MQ_GEMM_SPEC", 0)), big(env("MQ_GEMM_BIG", 0)) {}
+};
+GemmTune g_tune;
 
 constexpr int RESIDENT_SLOTS = 512;  // 256 CUs x 2 workgroups (64..80 KiB LDS each)
 
@@ -222,14 +224,14 @@ int choose_mt(int M, int N) {
     return best;
 }
 
-template <int FLAGS, int MT>
+template <int FLAGS, int MT, bool SPEC>
 int launch_gemm_mt(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
                    const float* residual, void* out, int64_t ldc, int M, int N, int K, hipStream_t s) {
     constexpr int BM = 32 * MT;
     constexpr int LDS = 2 * (BM * BK * 2 + W_TILE_BYTES);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_kernel<FLAGS, MT>,
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_kernel<FLAGS, MT, SPEC>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) {
             mq_set_error("mq_gemm_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -239,7 +241,7 @@ int launch_gemm_mt(const void* A, int64_t lda, const void* W, int64_t ldw, const
     }
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     const int num_tiles = tiles_m * tiles_n;
-    hipLaunchKernelGGL((gemm_nt_kernel<FLAGS, MT>), dim3(num_tiles), dim3(256), LDS, s,
+    hipLaunchKernelGGL((gemm_nt_kernel<FLAGS, MT, SPEC>), dim3(num_tiles), dim3(SPEC ? 512 : 256), LDS, s,
                        (const bf16_t*)A, lda, (const bf16_t*)W, ldw, bias, residual, out, ldc,
                        M, N, K, tiles_n, num_tiles);
     MQ_CHECK_LAUNCH("mq_gemm_bf16");
@@ -249,14 +251,23 @@ int launch_gemm_mt(const void* A, int64_t lda, const void* W, int64_t ldw, const
 template <int FLAGS>
 int launch_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
                 const float* residual, void* out, int64_t ldc, int M, int N, int K, hipStream_t s) {
-    static const int force_mt = getenv("MQ_GEMM_MT") ? atoi(getenv("MQ_GEMM_MT")) : 0;  // tuning knob
+    const int force_mt = g_tune.mt;
+    const int spec = g_tune.spec;
     const int mt = force_mt ? force_mt : choose_mt(M, N);
+    if (g_tune.big) return mq_launch_gemm_big<FLAGS>(g_tune.big, A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s);
+#define MQ_MT_CASE(T)                                                                                              \
+    case T:                                                                                                        \
+        return spec ? launch_gemm_mt<FLAGS, T, true>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s)        \
+                    : launch_gemm_mt<FLAGS, T, false>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s)
     switch (mt) {
-        case 2: return launch_gemm_mt<FLAGS, 2>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s);
-        case 5: return launch_gemm_mt<FLAGS, 5>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s);
-        case 6: return launch_gemm_mt<FLAGS, 6>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s);
-        default: return launch_gemm_mt<FLAGS, 4>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s);
+        MQ_MT_CASE(2);
+        MQ_MT_CASE(5);
+        MQ_MT_CASE(6);
+        default:
+            return spec ? launch_gemm_mt<FLAGS, 4, true>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s)
+                        : launch_gemm_mt<FLAGS, 4, false>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s);
     }
+#undef MQ_MT_CASE
 }
 
 }  // namespace
@@ -289,4 +300,16 @@ extern "C" int mq_gemm_bf16(const void* d_A, int64_t lda, const void* d_W, int64
             return MQ_ERR_INVALID;
     }
 #undef MQ_GEMM_CASE
+}
+
+// Select a GEMM main-loop variant at run time (A/B benchmarking and parity tests of every variant in one process).
+// key: "gemm_mt" (0 = auto, else tile height in 32-row units), "gemm_spec", "gemm_big" (0 / 4 / 6 / 8).
+extern "C" int mq_tune(const char* key, int value) {
+    MQ_CHECK_ARG(key, "mq_tune: null key");
+    const std::string k(key);
+    if (k == "gemm_mt") g_tune.mt = value;
+    else if (k == "gemm_spec") g_tune.spec = value;
+    else if (k == "gemm_big") g_tune.big = value;
+    else { mq_set_error("mq_tune: unknown key %s", key); return MQ_ERR_INVALID; }
+    return MQ_OK;
 }

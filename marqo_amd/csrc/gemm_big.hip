@@ -1,0 +1,183 @@
+// bf16 MFMA GEMM, CU-sized tile:  out[M,N] = epi( A[M,K] @ W[N,K]^T )   (same contract as gemm_bf16.hip)
+//
+// Measurements on the (32*MT)x128 kernel (2 workgroups/CU) show throughput proportional to 1/(bytes staged per FLOP):
+// the global->LDS path sustains ~24 B/clk/CU, and two independent 160x128 tiles per CU ask for 57.6 B/clk at full
+// MFMA rate.  This kernel gives ONE workgroup the whole CU: 8 wave64s as 2(M) x 4(N), tile (32*MT) x 256 x 64,
+// each wave a (16*MT) x 64 sub-tile (MT x 4 v_mfma_f32_16x16x32_bf16 accumulators, MT = 4 / 6 / 8).  The W stage
+// is shared by both wave rows and the A stage by all four wave columns, so a 256x256 tile needs 32 B/clk — and every
+// wave issues half as many LDS-DMA pieces per MFMA.  2 stages x (BM*128 B + 32 KiB) = 96..128 KiB of LDS.
+// LDS image, swizzle and epilogue are the ones of gemm_bf16.hip.
+#include <stdlib.h>
+#include <type_traits>
+#include "common.h"
+#include "gemm_epilogue.h"
+
+namespace {
+
+constexpr int BN = 256, BK = 64;
+constexpr int W_TILE_BYTES = BN * BK * 2;  // 32 KiB
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int FLAGS, int MT>
+__global__ __launch_bounds__(512, 2) void gemm_big_kernel(
+    const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ Wt, int64_t ldw,
+    const float* __restrict__ bias, const float* residual, void* out, int64_t ldc,
+    int M, int N, int K, int tiles_n, int num_tiles) {
+    static_assert(MT % 2 == 0, "A staging hands each of the 8 waves MT/2 eight-row pieces");
+    constexpr int BM = 32 * MT;
+    constexpr int A_TILE_BYTES = BM * BK * 2;
+    constexpr int STAGE_BYTES = A_TILE_BYTES + W_TILE_BYTES;
+    constexpr int PA = MT / 2, PW = 4;  // 1-KiB (8 rows x 128 B) pieces per wave per stage
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    // ---- XCD-aware, bijective block -> tile map -------------------------------------------
+    const int bid = blockIdx.x;
+    const int q = num_tiles >> 3, r = num_tiles & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0..7
+    const int wm = wave >> 2, wn = wave & 3;
+    const int l15 = lane & 15, g = lane >> 4;
+
+    // ---- staging: wave w owns A rows [4*MT*w, 4*MT*(w+1)) and W rows [32w, 32w+32), 8 rows per LDS-DMA
+    const int srow = lane >> 3;
+    const bf16_t* a_src[PA];
+    const bf16_t* w_src[PW];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        const int row = wave * (4 * MT) + i * 8 + srow;
+        int gm = m0 + row; gm = gm < M ? gm : M - 1;
+        a_src[i] = A + (int64_t)gm * lda + ((lane & 7) ^ (row & 7)) * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < PW; ++i) {
+        const int row = wave * 32 + i * 8 + srow;
+        int gn = n0 + row; gn = gn < N ? gn : N - 1;
+        w_src[i] = Wt + (int64_t)gn * ldw + ((lane & 7) ^ (row & 7)) * 8;
+    }
+    auto stage = [&](int buf, int kt) {
+        char* sa = smem + buf * STAGE_BYTES + wave * (4 * MT * 128);
+        char* sw = smem + buf * STAGE_BYTES + A_TILE_BYTES + wave * (32 * 128);
+#pragma unroll
+        for (int i = 0; i < PA; ++i) glds16(a_src[i] + (int64_t)kt * BK, sa + i * (8 * 128));
+#pragma unroll
+        for (int i = 0; i < PW; ++i) glds16(w_src[i] + (int64_t)kt * BK, sw + i * (8 * 128));
+    };
+
+    int a_off[MT], w_off[4];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) a_off[t] = (wm * (16 * MT) + t * 16 + l15) * 128;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) w_off[t] = (wn * 64 + t * 16 + l15) * 128;
+    const int sw0 = ((g) ^ (l15 & 7)) << 4;      // kk = 0
+    const int sw1 = ((g + 4) ^ (l15 & 7)) << 4;  // kk = 1
+
+    f32x4 acc[MT][4];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // one k-step, in two 32-deep halves: fragments of a half are read, then its 4*MT MFMAs run with the next stage's
+    // LDS-DMA issues sprinkled between them (registers hold one half's fragments at a time: MT + 4 b128 values)
+    auto kstep = [&](int kt, auto prefetch_tag) {
+        constexpr bool PREFETCH = decltype(prefetch_tag)::value;
+        const char* sa = smem + (kt & 1) * STAGE_BYTES;
+        const char* sw = sa + A_TILE_BYTES;
+        char* na = smem + ((kt + 1) & 1) * STAGE_BYTES + wave * (4 * MT * 128);
+        char* nw = smem + ((kt + 1) & 1) * STAGE_BYTES + A_TILE_BYTES + wave * (32 * 128);
+        const int64_t koff = (int64_t)(kt + 1) * BK;
+        constexpr int NL = PA + PW;      // LDS-DMA pieces per wave per step
+        constexpr int NM = 8 * MT;       // MFMAs per wave per step
+        constexpr int GAP = NM / NL;
+        int issued = 0;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int swz = kk ? sw1 : sw0;
+            bf16x8 af[MT], wf[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) wf[t] = *(const bf16x8*)(sw + w_off[t] + swz);
+#pragma unroll
+            for (int t = 0; t < MT; ++t) af[t] = *(const bf16x8*)(sa + a_off[t] + swz);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[mt], acc[mt][nt], 0, 0, 0);
+                    const int done = (kk * MT + mt) * 4 + nt + 1;
+                    if (PREFETCH && done % GAP == 0 && issued < NL) {
+                        if (issued < PA) glds16(a_src[issued] + koff, na + issued * (8 * 128));
+                        else glds16(w_src[issued - PA] + koff, nw + (issued - PA) * (8 * 128));
+                        ++issued;
+                    }
+                }
+        }
+    };
+
+    const int nk = K / BK;
+    stage(0, 0);
+    for (int kt = 0; kt < nk - 1; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        kstep(kt, std::true_type{});
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    kstep(nk - 1, std::false_type{});
+
+    gemm_epilogue<FLAGS, MT>(acc, bias, residual, out, ldc, M, N, m0 + wm * (16 * MT), n0 + wn * 64, l15, g);
+}
+
+template <int FLAGS, int MT>
+int launch_big_mt(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* residual,
+                  void* out, int64_t ldc, int M, int N, int K, hipStream_t s) {
+    constexpr int BM = 32 * MT;
+    constexpr int LDS = 2 * (BM * BK * 2 + W_TILE_BYTES);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_big_kernel<FLAGS, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) {
+            mq_set_error("mq_gemm_bf16(big): hipFuncSetAttribute: %s", hipGetErrorString(e));
+            return MQ_ERR_HIP;
+        }
+        attr_set = true;
+    }
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+    const int num_tiles = tiles_m * tiles_n;
+    hipLaunchKernelGGL((gemm_big_kernel<FLAGS, MT>), dim3(num_tiles), dim3(512), LDS, s, (const bf16_t*)A, lda, (const bf16_t*)W, ldw,
+                       bias, residual, out, ldc, M, N, K, tiles_n, num_tiles);
+    MQ_CHECK_LAUNCH("mq_gemm_bf16(big)");
+    return MQ_OK;
+}
+
+}  // namespace
+
+// called from gemm_bf16.hip's dispatcher; mt in {4, 6, 8}
+template <int FLAGS>
+int mq_launch_gemm_big(int mt, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* residual,
+                       void* out, int64_t ldc, int M, int N, int K, hipStream_t s) {
+    switch (mt) {
+        case 4: return launch_big_mt<FLAGS, 4>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s);
+        case 6: return launch_big_mt<FLAGS, 6>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s);
+        default: return launch_big_mt<FLAGS, 8>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s);
+    }
+}
+
+#define MQ_BIG_INST(F)                                                                                                   \
+    template int mq_launch_gemm_big<(F)>(int, const void*, int64_t, const void*, int64_t, const float*, const float*, void*, \
+                                         int64_t, int, int, int, hipStream_t)
+MQ_BIG_INST(0);
+MQ_BIG_INST(MQ_EPI_OUT_F32);
+MQ_BIG_INST(MQ_EPI_BIAS);
+MQ_BIG_INST(MQ_EPI_BIAS | MQ_EPI_GELU);
+MQ_BIG_INST(MQ_EPI_BIAS | MQ_EPI_QUICKGELU);
+MQ_BIG_INST(MQ_EPI_BIAS | MQ_EPI_RESIDUAL | MQ_EPI_OUT_F32);

@@ -1,0 +1,95 @@
+"""Every GEMM main-loop variant (2-stage, wave-specialised, CU-sized tile) x tile height must give the same result as a
+fp32 reference on the bf16-rounded operands, on ragged shapes, with every fused epilogue; repeated launches screen for
+LDS-ring races (a racy pipeline shows up as run-to-run differences)."""
+import ctypes as C
+
+import pytest
+import torch
+
+from marqo_amd import _lib as L
+
+pytestmark = pytest.mark.gpu
+
+VARIANTS = [dict(gemm_spec=0), dict(gemm_spec=1)]
+SHAPES = [(50, 64, 64), (257, 768, 128), (1000, 132, 192), (4097, 2304, 768), (12800, 768, 3072), (333, 3072, 64), (16, 4, 64)]
+
+
+def _tune(lib, **kw):
+    for k, v in kw.items():
+        L.check(lib.mq_tune(k.encode(), v), "mq_tune")
+
+
+def _gemm(lib, A, W, bias, res, flags):
+    M, K = A.shape
+    N = W.shape[0]
+    f32 = bool(flags & L.MQ_EPI_OUT_F32)
+    out = res.clone() if (flags & L.MQ_EPI_RESIDUAL) else torch.empty(M, N, device="cuda", dtype=torch.float32 if f32 else torch.bfloat16)
+    L.check(lib.mq_gemm_bf16(A.data_ptr(), K, W.data_ptr(), K, L.ptr(bias), out.data_ptr() if flags & L.MQ_EPI_RESIDUAL else 0,
+                             out.data_ptr(), N, M, N, K, flags, torch.cuda.current_stream().cuda_stream))
+    return out
+
+
+@pytest.mark.parametrize("variant", VARIANTS, ids=lambda v: "spec%d" % v["gemm_spec"])
+@pytest.mark.parametrize("mt", [0, 2, 4, 5, 6])
+def test_variant_matches_reference(variant, mt):
+    lib = L.load()
+    try:
+        _tune(lib, gemm_mt=mt, **variant)
+        g = torch.Generator(device="cuda").manual_seed(mt * 7 + variant["gemm_spec"])
+        for (M, N, K) in SHAPES:
+            A = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+            W = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).to(torch.bfloat16)
+            bias = torch.randn(N, device="cuda", generator=g)
+            res = torch.randn(M, N, device="cuda", generator=g)
+            ref = A.float() @ W.float().t()
+            for flags, want in ((0, ref), (L.MQ_EPI_OUT_F32, ref), (L.MQ_EPI_BIAS, ref + bias),
+                                (L.MQ_EPI_BIAS | L.MQ_EPI_GELU, torch.nn.functional.gelu(ref + bias)),
+                                (L.MQ_EPI_BIAS | L.MQ_EPI_RESIDUAL | L.MQ_EPI_OUT_F32, ref + bias + res)):
+                out = _gemm(lib, A, W, bias, res, flags).float()
+                tol = 2e-2 if not (flags & L.MQ_EPI_OUT_F32) else 2e-3
+                err = (out - want).abs().max().item() / (want.abs().max().item() + 1e-6)
+                assert err < tol, (variant, mt, (M, N, K), flags, err)
+    finally:
+        _tune(lib, gemm_mt=0, gemm_spec=0, gemm_big=0)
+
+
+@pytest.mark.parametrize("variant", VARIANTS[1:], ids=lambda v: "spec%d" % v["gemm_spec"])
+def test_variant_is_bitwise_stable_and_equal_to_baseline(variant):
+    """same k-order of MFMAs in every variant -> bit-identical to the 2-stage kernel; 25 launches under load screen races"""
+    lib = L.load()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    try:
+        for (M, N, K) in [(12800, 768, 768), (4099, 384, 3072), (12800, 2304, 768)]:
+            A = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+            W = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).to(torch.bfloat16)
+            for mt in (0, 4, 6):
+                _tune(lib, gemm_mt=mt, gemm_spec=0)
+                base = _gemm(lib, A, W, None, None, L.MQ_EPI_OUT_F32)
+                _tune(lib, gemm_mt=mt, **variant)
+                for _ in range(25):
+                    out = _gemm(lib, A, W, None, None, L.MQ_EPI_OUT_F32)
+                    assert torch.equal(out, base), (variant, mt, (M, N, K))
+    finally:
+        _tune(lib, gemm_mt=0, gemm_spec=0, gemm_big=0)
+
+
+@pytest.mark.parametrize("big", [4, 6, 8])
+def test_cu_sized_tile_variant(big):
+    """gemm_big.hip: 8-wave (32*MT)x256 tile, one workgroup per CU"""
+    lib = L.load()
+    g = torch.Generator(device="cuda").manual_seed(big)
+    try:
+        for (M, N, K) in SHAPES + [(12800, 2304, 768), (600, 260, 128)]:
+            A = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+            W = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).to(torch.bfloat16)
+            bias = torch.randn(N, device="cuda", generator=g)
+            res = torch.randn(M, N, device="cuda", generator=g)
+            _tune(lib, gemm_big=0)
+            base = _gemm(lib, A, W, bias, res, L.MQ_EPI_BIAS | L.MQ_EPI_RESIDUAL | L.MQ_EPI_OUT_F32)
+            base_g = _gemm(lib, A, W, bias, res, L.MQ_EPI_BIAS | L.MQ_EPI_GELU)
+            _tune(lib, gemm_big=big)
+            for _ in range(10):
+                assert torch.equal(_gemm(lib, A, W, bias, res, L.MQ_EPI_BIAS | L.MQ_EPI_RESIDUAL | L.MQ_EPI_OUT_F32), base), (big, M, N, K)
+            assert torch.equal(_gemm(lib, A, W, bias, res, L.MQ_EPI_BIAS | L.MQ_EPI_GELU), base_g)
+    finally:
+        _tune(lib, gemm_mt=0, gemm_spec=0, gemm_big=0)
