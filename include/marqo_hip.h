@@ -45,7 +45,7 @@ extern "C" {
 #define MQ_ERR_HIP (-2)       /* a HIP runtime call or launch failed */
 #define MQ_ERR_WORKSPACE (-3) /* caller's workspace too small */
 
-#define MQ_ABI_VERSION 1
+#define MQ_ABI_VERSION 2
 
 /* ---- activation / mask / pooling selectors ---------------------------------------- */
 #define MQ_ACT_NONE 0
@@ -56,6 +56,9 @@ extern "C" {
 #define MQ_MASK_CAUSAL 1 /* CLIP text tower */
 /* key-padding masks (BERT) are expressed by packing: only real tokens are rows. */
 
+#define MQ_PREC_BF16 0
+#define MQ_PREC_FP8 1
+
 #define MQ_POOL_MEAN 0 /* hugging_face_model.py:205-209 */
 #define MQ_POOL_CLS 1  /* hugging_face_model.py:211-214 */
 
@@ -65,6 +68,7 @@ extern "C" {
 #define MQ_EPI_QUICKGELU 4 /* quick GELU after bias */
 #define MQ_EPI_RESIDUAL 8  /* + residual[m,n] (fp32, leading dim ldc) */
 #define MQ_EPI_OUT_F32 16  /* write fp32 instead of bf16 */
+#define MQ_EPI_OUT_FP8 32  /* (mq_gemm_fp8 only) write e4m3 codes = value / out_scale, saturating at +-448 */
 
 /* ---- transformer encoder description ---------------------------------------------- */
 
@@ -77,6 +81,12 @@ typedef struct mq_block_weights {
     const float* ln2_g; const float* ln2_b;   /* [W] */
     const void*  fc1_w; const float* fc1_b;   /* [F, W], [F] */
     const void*  fc2_w; const float* fc2_b;   /* [W, F], [W] */
+    /* fp8 path (precision == MQ_PREC_FP8, else ignored / NULL): e4m3 codes in the same [out, in] layout and the
+     * per-output-channel fp32 scales written by mq_quantize_weights_fp8 */
+    const void*  qkv_w8; const float* qkv_ws; /* [3W, W], [3W] */
+    const void*  out_w8; const float* out_ws; /* [W, W],  [W]  */
+    const void*  fc1_w8; const float* fc1_ws; /* [F, W],  [F]  */
+    const void*  fc2_w8; const float* fc2_ws; /* [W, F],  [W]  */
 } mq_block_weights;
 
 typedef struct mq_encoder_cfg {
@@ -88,6 +98,12 @@ typedef struct mq_encoder_cfg {
     int32_t post_ln;    /* 0: pre-LN (CLIP); 1: post-LN (BERT) */
     int32_t mask;       /* MQ_MASK_* */
     float   ln_eps;
+    int32_t precision;  /* MQ_PREC_BF16 (0) or MQ_PREC_FP8 (pre-LN encoders only; width and mlp_dim multiples of 128) */
+    int32_t reserved;
+    /* fp8 path: static per-tensor activation scales, device fp32 [layers][2] = (attention output, MLP hidden), and the
+     * calibration accumulator of the same shape (NULL = frozen scales; non-NULL = fold max|value| of this pass into it) */
+    const float* d_fp8_act_scale;
+    float*       d_fp8_act_amax;
 } mq_encoder_cfg;
 
 /* ---- towers ------------------------------------------------------------------------ */
@@ -244,6 +260,27 @@ int mq_resample_coeffs(int32_t in_size, int32_t out_size, int32_t first, int32_t
 
 /* ---- building blocks (exported for parity tests and for callers that compose) -------- */
 
+/* fp8 (OCP e4m3) GEMM, K13:  out[M,N] = epilogue( (A8[M,K] @ W8[N,K]^T) * a_scale * w_scale[n] ).
+ * A8, W8: e4m3 codes, row-major (lda, ldw in bytes, multiples of 16); K % 128 == 0.  d_a_scale: fp32 [M] when
+ * a_scale_per_row != 0 (written by mq_layernorm_fp8), else one device scalar (static per-tensor scale).
+ * d_w_scale fp32 [N] per output channel (mq_quantize_weights_fp8).  flags: one of
+ *   OUT_F32 | BIAS (bf16 out) | BIAS|GELU|OUT_FP8 | BIAS|QUICKGELU|OUT_FP8 | BIAS|RESIDUAL|OUT_F32.
+ * With OUT_FP8 the result is divided by *d_out_scale (device scalar) before conversion and, when d_amax != NULL,
+ * max|value| is atomically folded into *d_amax (calibration of the static scale). */
+int mq_gemm_fp8(const void* d_A8, int64_t lda, const void* d_W8, int64_t ldw, const float* d_a_scale,
+                int a_scale_per_row, const float* d_w_scale, const float* d_bias, const float* d_residual,
+                void* d_out, int64_t ldc, const float* d_out_scale, float* d_amax,
+                int64_t M, int64_t N, int64_t K, int flags, void* stream);
+
+/* W bf16 [N,K] -> e4m3 codes [N,K] + per-row scale[N] = absmax / 448 (done once at model load). */
+int mq_quantize_weights_fp8(const void* d_W_bf16, int64_t ldw, void* d_W8, int64_t ld8, float* d_scale,
+                            int64_t N, int64_t K, void* stream);
+
+/* LayerNorm with e4m3 output and a dynamic per-row scale: q[r,:] = LN(x[r,:]) / s[r], s[r] = max|LN(x[r,:])| / 448. */
+int mq_layernorm_fp8(const float* d_x, const float* d_g, const float* d_b, void* d_out_fp8, float* d_row_scale,
+                     float* d_out_f32 /* optional fp32 copy of LN(x) (post-LN models), may be NULL */,
+                     int64_t rows, int32_t W, float eps, void* stream);
+
 /* out[M,N] = epilogue(A[M,K] @ W[N,K]^T).  A, W bf16 row-major (lda, ldw in elements);
  * K % 64 == 0, N % 4 == 0.  bias fp32 [N]; residual fp32 [M, ldc]; out bf16 or fp32 [M, ldc]
  * (residual may alias out when MQ_EPI_OUT_F32). */
@@ -264,6 +301,12 @@ int mq_layernorm(const float* d_x, const int32_t* d_row_idx, const float* d_g, c
 int mq_attention(const void* d_qkv, void* d_out, const int32_t* d_cu_seqlens, int64_t nseq,
                  int32_t fixed_len, int32_t max_len, int32_t W, int32_t heads, int32_t mask,
                  void* stream);
+
+/* mq_attention with an optional e4m3 output (out_fp8 != 0: d_out holds codes = value / *d_out_scale; max|value| is
+ * folded into *d_amax when it is non-NULL). */
+int mq_attention_ex(const void* d_qkv, void* d_out, const int32_t* d_cu_seqlens, int64_t nseq,
+                    int32_t fixed_len, int32_t max_len, int32_t W, int32_t heads, int32_t mask,
+                    int32_t out_fp8, const float* d_out_scale, float* d_amax, void* stream);
 
 /* One full encoder stack, in place on the fp32 residual stream d_x [rows, W]. */
 int mq_encoder_forward(const mq_encoder_cfg* cfg, const mq_block_weights* blocks,

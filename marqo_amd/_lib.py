@@ -21,10 +21,12 @@ LIB_PATH = LIB_DIR / "libmarqo_hip.so"
 HEADER_PATH = PKG_DIR.parent / "include" / "marqo_hip.h"
 
 MQ_OK = 0
+ABI_VERSION = 2
+MQ_PREC_BF16, MQ_PREC_FP8 = 0, 1
 MQ_ACT_GELU, MQ_ACT_QUICKGELU = 1, 2
 MQ_MASK_NONE, MQ_MASK_CAUSAL = 0, 1
 MQ_POOL_MEAN, MQ_POOL_CLS = 0, 1
-MQ_EPI_BIAS, MQ_EPI_GELU, MQ_EPI_QUICKGELU, MQ_EPI_RESIDUAL, MQ_EPI_OUT_F32 = 1, 2, 4, 8, 16
+MQ_EPI_BIAS, MQ_EPI_GELU, MQ_EPI_QUICKGELU, MQ_EPI_RESIDUAL, MQ_EPI_OUT_F32, MQ_EPI_OUT_FP8 = 1, 2, 4, 8, 16, 32
 MQ_PROF_FAMILIES = 6
 PROF_FAMILY_NAMES = ("gemm", "layernorm", "attention", "embed", "pool_head", "preprocess")
 
@@ -41,12 +43,14 @@ class MarqoHipError(RuntimeError):
 class BlockWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "ln1_g", "ln1_b", "qkv_w", "qkv_b", "out_w", "out_b",
-        "ln2_g", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")]
+        "ln2_g", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b",
+        "qkv_w8", "qkv_ws", "out_w8", "out_ws", "fc1_w8", "fc1_ws", "fc2_w8", "fc2_ws")]
 
 
 class EncoderCfg(C.Structure):
     _fields_ = [("width", C.c_int32), ("layers", C.c_int32), ("heads", C.c_int32), ("mlp_dim", C.c_int32),
-                ("act", C.c_int32), ("post_ln", C.c_int32), ("mask", C.c_int32), ("ln_eps", C.c_float)]
+                ("act", C.c_int32), ("post_ln", C.c_int32), ("mask", C.c_int32), ("ln_eps", C.c_float),
+                ("precision", C.c_int32), ("reserved", C.c_int32), ("d_fp8_act_scale", C.c_void_p), ("d_fp8_act_amax", C.c_void_p)]
 
 
 class VitWeights(C.Structure):
@@ -96,7 +100,12 @@ _SIGNATURES = {
                                  C.c_size_t, _P]),
     "mq_gemm_bf16": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
                                C.c_int, _P]),
+    "mq_gemm_fp8": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, C.c_int, _P, _P, _P, _P, C.c_int64, _P, _P, C.c_int64, C.c_int64,
+                              C.c_int64, C.c_int, _P]),
+    "mq_quantize_weights_fp8": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, C.c_int64, C.c_int64, _P]),
+    "mq_layernorm_fp8": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, C.c_int32, C.c_float, _P]),
     "mq_layernorm": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, C.c_int32, C.c_float, _P]),
+    "mq_attention_ex": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
     "mq_attention": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "mq_encoder_forward": (C.c_int, [C.POINTER(EncoderCfg), C.POINTER(BlockWeights), _P, C.c_int64, _P, C.c_int64,
                                      C.c_int32, C.c_int32, _P, C.c_size_t, _P]),
@@ -189,8 +198,8 @@ def load():
                 raise MarqoHipUnavailableError(f"{LIB_PATH} does not export {name}") from e
             fn.restype = res
             fn.argtypes = args
-        if lib.mq_abi_version() != 1:
-            raise MarqoHipUnavailableError(f"ABI version mismatch: library {lib.mq_abi_version()} != binding 1")
+        if lib.mq_abi_version() != ABI_VERSION:
+            raise MarqoHipUnavailableError(f"ABI version mismatch: library {lib.mq_abi_version()} != binding {ABI_VERSION}")
         _lib = lib
         return _lib
 

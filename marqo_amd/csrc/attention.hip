@@ -18,10 +18,13 @@
 
 namespace {
 
-template <int MASK>
+// OUT_FP8: the output is written as e4m3 codes = value / *out_scale (static per-tensor scale of the fp8 path, K13) and
+// max|value| is folded into *amax when it is non-null (calibration).
+template <int MASK, bool OUT_FP8>
 __global__ __launch_bounds__(256) void attention_kernel(
-    const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, const int32_t* __restrict__ cu,
-    int fixed_len, int W, int heads, int kpad, float scale_log2e) {
+    const bf16_t* __restrict__ qkv, void* __restrict__ out_v, const int32_t* __restrict__ cu,
+    int fixed_len, int W, int heads, int kpad, float scale_log2e, const float* __restrict__ out_scale, float* amax_out) {
+    bf16_t* out = (bf16_t*)out_v;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sK = smem;                                   // [kpad][128 B], 16-B chunks XOR-swizzled by (key & 7)
     bf16_t* sVt = (bf16_t*)(smem + (size_t)kpad * 128);  // [64][kpad + 4]
@@ -60,6 +63,7 @@ __global__ __launch_bounds__(256) void attention_kernel(
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, g = lane >> 4;
     const int nqb = (len + 15) >> 4;
+    float amax_local = 0.f;
 
     for (int qblk = wave; qblk < nqb; qblk += 4) {
         const int q = qblk * 16 + l15;           // this lane's query (B-operand column / output row)
@@ -141,23 +145,45 @@ __global__ __launch_bounds__(256) void attention_kernel(
         l_tot += __shfl_xor(l_tot, 32, 64);
         const float inv = 1.0f / l_tot;
         if (q < len) {
-            bf16_t* orow = out + (int64_t)(row0 + q) * W + h * 64 + 4 * g;
+            if (OUT_FP8) {
+                const float qs = 1.0f / out_scale[0];
+                uint8_t* orow8 = (uint8_t*)out_v + (int64_t)(row0 + q) * W + h * 64 + 4 * g;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                uint2 p;
-                p.x = pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv);
-                p.y = pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv);
-                *(uint2*)(orow + dt * 16) = p;
+                for (int dt = 0; dt < 4; ++dt) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = o[dt][e] * inv;
+                        amax_local = fmaxf(amax_local, fabsf(v[e]));
+                        v[e] = fminf(fmaxf(v[e] * qs, -448.f), 448.f);
+                    }
+                    int w = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
+                    w = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], w, true);
+                    *(int*)(orow8 + dt * 16) = w;
+                }
+            } else {
+                bf16_t* orow = out + (int64_t)(row0 + q) * W + h * 64 + 4 * g;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    uint2 p;
+                    p.x = pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv);
+                    p.y = pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv);
+                    *(uint2*)(orow + dt * 16) = p;
+                }
             }
         }
+    }
+    if (OUT_FP8 && amax_out) {
+        amax_local = wave_max(amax_local);
+        if (lane == 0) atomicMax((int*)amax_out, __float_as_int(amax_local));
     }
 }
 
 }  // namespace
 
-extern "C" int mq_attention(const void* d_qkv, void* d_out, const int32_t* d_cu_seqlens, int64_t nseq,
-                            int32_t fixed_len, int32_t max_len, int32_t W, int32_t heads, int32_t mask,
-                            void* stream) {
+extern "C" int mq_attention_ex(const void* d_qkv, void* d_out, const int32_t* d_cu_seqlens, int64_t nseq,
+                               int32_t fixed_len, int32_t max_len, int32_t W, int32_t heads, int32_t mask,
+                               int32_t out_fp8, const float* d_out_scale, float* d_amax, void* stream) {
     MQ_CHECK_ARG(d_qkv && d_out, "mq_attention: null pointer");
     MQ_CHECK_ARG(heads >= 1 && W == heads * 64, "mq_attention: head dim must be 64 (W=%d heads=%d)", W, heads);
     MQ_CHECK_ARG(fixed_len > 0 || d_cu_seqlens, "mq_attention: need fixed_len or cu_seqlens");
@@ -178,11 +204,19 @@ extern "C" int mq_attention(const void* d_qkv, void* d_out, const int32_t* d_cu_
             if (e != hipSuccess) { mq_set_error("mq_attention: hipFuncSetAttribute: %s", hipGetErrorString(e)); return MQ_ERR_HIP; }
         }
         hipLaunchKernelGGL(kern, dim3((unsigned)(nseq * heads)), dim3(256), lds, s, (const bf16_t*)d_qkv,
-                           (bf16_t*)d_out, d_cu_seqlens, (int)fixed_len, (int)W, (int)heads, kpad, scale_log2e);
+                           d_out, d_cu_seqlens, (int)fixed_len, (int)W, (int)heads, kpad, scale_log2e, d_out_scale, d_amax);
         return MQ_OK;
     };
-    int rc = (mask == MQ_MASK_CAUSAL) ? launch(attention_kernel<MQ_MASK_CAUSAL>) : launch(attention_kernel<MQ_MASK_NONE>);
+    MQ_CHECK_ARG(!out_fp8 || d_out_scale, "mq_attention: fp8 output needs an out_scale");
+    int rc;
+    if (out_fp8) rc = (mask == MQ_MASK_CAUSAL) ? launch(attention_kernel<MQ_MASK_CAUSAL, true>) : launch(attention_kernel<MQ_MASK_NONE, true>);
+    else rc = (mask == MQ_MASK_CAUSAL) ? launch(attention_kernel<MQ_MASK_CAUSAL, false>) : launch(attention_kernel<MQ_MASK_NONE, false>);
     if (rc != MQ_OK) return rc;
     MQ_CHECK_LAUNCH("mq_attention");
     return MQ_OK;
+}
+
+extern "C" int mq_attention(const void* d_qkv, void* d_out, const int32_t* d_cu_seqlens, int64_t nseq, int32_t fixed_len,
+                            int32_t max_len, int32_t W, int32_t heads, int32_t mask, void* stream) {
+    return mq_attention_ex(d_qkv, d_out, d_cu_seqlens, nseq, fixed_len, max_len, W, heads, mask, 0, nullptr, nullptr, stream);
 }

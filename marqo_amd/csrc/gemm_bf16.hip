@@ -21,6 +21,8 @@
 #include "common.h"
 #include "gemm_epilogue.h"
 
+extern int mq_gemm_fp8_force_mt;  // gemm_fp8.hip
+
 // CU-sized-tile main loop (gemm_big.hip)
 template <int FLAGS>
 int mq_launch_gemm_big(int mt, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* residual,
@@ -307,7 +309,7 @@ extern "C" int mq_gemm_bf16(const void* d_A, int64_t lda, const void* d_W, int64
 extern "C" int mq_tune(const char* key, int value) {
     MQ_CHECK_ARG(key, "mq_tune: null key");
     const std::string k(key);
-    if (k == "gemm_mt") g_tune.mt = value;
+    if (k == "gemm_mt") { g_tune.mt = value; mq_gemm_fp8_force_mt = value; }
     else if (k == "gemm_spec") g_tune.spec = value;
     else if (k == "gemm_big") g_tune.big = value;
     else { mq_set_error("mq_tune: unknown key %s", key); return MQ_ERR_INVALID; }

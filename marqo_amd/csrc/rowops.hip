@@ -49,6 +49,50 @@ __global__ __launch_bounds__(256, (CH <= 4 ? 8 : 4)) void layernorm_kernel(
     }
 }
 
+// LN with e4m3 output and a dynamic per-row scale (the row is already in registers, so the absmax is one wave reduction)
+template <int CH>
+__global__ __launch_bounds__(256, (CH <= 4 ? 8 : 4)) void layernorm_fp8_kernel(
+    const float* __restrict__ x, const float* __restrict__ gam, const float* __restrict__ bet, uint8_t* __restrict__ out8,
+    float* __restrict__ row_scale, float* out_f32, int64_t rows, int W, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * W;
+    const int nch = W >> 2;
+    f32x4 v[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        const int c = lane + i * 64;
+        v[i] = c < nch ? *(const f32x4*)(xr + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    ln_normalize_row<CH>(v, lane, nch, W, eps);
+    float mx = 0.f;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        const int c = lane + i * 64;
+        if (c < nch) {
+            const f32x4 gg = *(const f32x4*)(gam + c * 4);
+            const f32x4 bb = *(const f32x4*)(bet + c * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[i][e] = v[i][e] * gg[e] + bb[e]; mx = fmaxf(mx, fabsf(v[i][e])); }
+            if (out_f32) *(f32x4*)(out_f32 + row * W + c * 4) = v[i];
+        }
+    }
+    mx = wave_max(mx);
+    const float sc = mx > 0.f ? mx * (1.0f / 448.f) : 1.f;
+    const float inv = 1.0f / sc;
+    if (lane == 0) row_scale[row] = sc;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        const int c = lane + i * 64;
+        if (c < nch) {
+            int w = __builtin_amdgcn_cvt_pk_fp8_f32(v[i][0] * inv, v[i][1] * inv, 0, false);
+            w = __builtin_amdgcn_cvt_pk_fp8_f32(v[i][2] * inv, v[i][3] * inv, w, true);
+            *(int*)(out8 + row * W + c * 4) = w;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void l2norm_kernel(const float* __restrict__ x, float* out, int64_t rows, int D) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -83,6 +127,19 @@ extern "C" int mq_layernorm(const float* d_x, const int32_t* d_row_idx, const fl
     MQ_DISPATCH_CH(W, hipLaunchKernelGGL(layernorm_kernel<CH>, dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, s, d_x, d_row_idx,
                                          d_g, d_b, (bf16_t*)d_out_bf16, d_out_f32, rows, (int)W, eps));
     MQ_CHECK_LAUNCH("mq_layernorm");
+    return MQ_OK;
+}
+
+extern "C" int mq_layernorm_fp8(const float* d_x, const float* d_g, const float* d_b, void* d_out_fp8, float* d_row_scale, float* d_out_f32,
+                                int64_t rows, int32_t W, float eps, void* stream) {
+    MQ_CHECK_ARG(d_x && d_g && d_b && d_out_fp8 && d_row_scale, "mq_layernorm_fp8: null pointer");
+    MQ_CHECK_ARG(W >= 4 && W % 4 == 0 && W <= 64 * 4 * LN_MAX_CHUNKS, "mq_layernorm_fp8: W=%d unsupported (multiple of 4, <= 2048)", W);
+    if (rows <= 0) return MQ_OK;
+    hipStream_t s = (hipStream_t)stream;
+    MqProfScope prof(1, s);
+    MQ_DISPATCH_CH(W, hipLaunchKernelGGL(layernorm_fp8_kernel<CH>, dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, s, d_x, d_g, d_b,
+                                         (uint8_t*)d_out_fp8, d_row_scale, d_out_f32, rows, (int)W, eps));
+    MQ_CHECK_LAUNCH("mq_layernorm_fp8");
     return MQ_OK;
 }
 

@@ -20,6 +20,11 @@ int mq_pool(const float* d_x, const int32_t* d_cu, int64_t nseq, float* d_out, i
 int mq_last_rows(const int32_t* d_cu, int32_t* d_rows, int64_t nseq, hipStream_t s);
 int mq_cls_rows(int32_t* d_rows, int64_t n, int T, hipStream_t s);
 
+// layouts the ctypes binding (marqo_amd/_lib.py) and tests/test_abi.py assume
+static_assert(sizeof(mq_block_weights) == 20 * 8, "mq_block_weights layout");
+static_assert(sizeof(mq_encoder_cfg) == 56, "mq_encoder_cfg layout");
+static_assert(sizeof(mq_vit_cfg) == 96 && sizeof(mq_clip_text_cfg) == 72 && sizeof(mq_bert_cfg) == 72, "tower cfg layouts");
+
 namespace {
 
 constexpr size_t WS_ALIGN = 256;
@@ -43,6 +48,12 @@ int check_encoder_cfg(const mq_encoder_cfg* c) {
     MQ_CHECK_ARG(c->mlp_dim >= 64 && c->mlp_dim % 64 == 0, "encoder mlp_dim %d must be a multiple of 64", c->mlp_dim);
     MQ_CHECK_ARG(c->layers >= 0, "encoder layers < 0");
     MQ_CHECK_ARG(c->act == MQ_ACT_GELU || c->act == MQ_ACT_QUICKGELU, "encoder act %d unsupported", c->act);
+    MQ_CHECK_ARG(c->precision == MQ_PREC_BF16 || c->precision == MQ_PREC_FP8, "encoder precision %d unsupported", c->precision);
+    if (c->precision == MQ_PREC_FP8) {
+        MQ_CHECK_ARG(!c->post_ln, "the fp8 path supports pre-LN (CLIP) encoders only");
+        MQ_CHECK_ARG(c->width % 128 == 0 && c->mlp_dim % 128 == 0, "fp8 path needs width / mlp_dim multiples of 128");
+        MQ_CHECK_ARG(c->d_fp8_act_scale, "fp8 path needs d_fp8_act_scale");
+    }
     return MQ_OK;
 }
 
@@ -53,6 +64,7 @@ size_t encoder_ws(const mq_encoder_cfg* c, int64_t rows) {
     cv.take((size_t)rows * c->width * 2);
     cv.take((size_t)rows * c->width * 2);
     cv.take((size_t)rows * big * 2);
+    cv.take((size_t)rows * 4);  // per-row activation scales of the fp8 path
     return cv.end();
 }
 
@@ -84,6 +96,7 @@ extern "C" int mq_encoder_forward(const mq_encoder_cfg* cfg, const mq_block_weig
     void* h = wsb + cv.take((size_t)rows * W * 2);
     void* a = wsb + cv.take((size_t)rows * W * 2);
     void* qf = wsb + cv.take((size_t)rows * big * 2);  // qkv [rows,3W] then fc1 output [rows,F]
+    float* row_scale = (float*)(wsb + cv.take((size_t)rows * 4));
     const int act_flag = cfg->act == MQ_ACT_QUICKGELU ? MQ_EPI_QUICKGELU : MQ_EPI_GELU;
     const int res_flags = MQ_EPI_BIAS | MQ_EPI_RESIDUAL | MQ_EPI_OUT_F32;
 
@@ -92,7 +105,25 @@ extern "C" int mq_encoder_forward(const mq_encoder_cfg* cfg, const mq_block_weig
     for (int l = 0; l < cfg->layers; ++l) {
         const mq_block_weights& b = blocks[l];
         MQ_CHECK_ARG(b.qkv_w && b.out_w && b.fc1_w && b.fc2_w && b.ln1_g && b.ln2_g, "mq_encoder_forward: layer %d has null weights", l);
-        if (!cfg->post_ln) {
+        if (cfg->precision == MQ_PREC_FP8) {
+            // same dataflow with e4m3 GEMM operands: h / a / fc1-out are fp8 (h with a dynamic per-row scale from the LN,
+            // a and fc1-out with static per-tensor scales), qkv stays bf16 for the attention MFMAs, x stays fp32
+            MQ_CHECK_ARG(b.qkv_w8 && b.qkv_ws && b.out_w8 && b.out_ws && b.fc1_w8 && b.fc1_ws && b.fc2_w8 && b.fc2_ws,
+                         "mq_encoder_forward: layer %d has no fp8 weights", l);
+            const float* s_attn = cfg->d_fp8_act_scale + 2 * l;
+            const float* s_mlp = s_attn + 1;
+            float* m_attn = cfg->d_fp8_act_amax ? cfg->d_fp8_act_amax + 2 * l : nullptr;
+            float* m_mlp = m_attn ? m_attn + 1 : nullptr;
+            const int act8 = (cfg->act == MQ_ACT_QUICKGELU ? MQ_EPI_QUICKGELU : MQ_EPI_GELU) | MQ_EPI_BIAS | MQ_EPI_OUT_FP8;
+            MQ_TRY(mq_layernorm_fp8(d_x, b.ln1_g, b.ln1_b, h, row_scale, nullptr, rows, W, cfg->ln_eps, s));
+            MQ_TRY(mq_gemm_fp8(h, W, b.qkv_w8, W, row_scale, 1, b.qkv_ws, b.qkv_b, nullptr, qf, 3 * W, nullptr, nullptr, rows, 3 * W, W,
+                               MQ_EPI_BIAS, s));
+            MQ_TRY(mq_attention_ex(qf, a, d_cu_seqlens, nseq, fixed_len, max_len, W, cfg->heads, cfg->mask, 1, s_attn, m_attn, s));
+            MQ_TRY(mq_gemm_fp8(a, W, b.out_w8, W, s_attn, 0, b.out_ws, b.out_b, d_x, d_x, W, nullptr, nullptr, rows, W, W, res_flags, s));
+            MQ_TRY(mq_layernorm_fp8(d_x, b.ln2_g, b.ln2_b, h, row_scale, nullptr, rows, W, cfg->ln_eps, s));
+            MQ_TRY(mq_gemm_fp8(h, W, b.fc1_w8, W, row_scale, 1, b.fc1_ws, b.fc1_b, nullptr, qf, F, s_mlp, m_mlp, rows, F, W, act8, s));
+            MQ_TRY(mq_gemm_fp8(qf, F, b.fc2_w8, F, s_mlp, 0, b.fc2_ws, b.fc2_b, d_x, d_x, W, nullptr, nullptr, rows, W, F, res_flags, s));
+        } else if (!cfg->post_ln) {
             // x += out(attn(qkv(ln1(x)))) ; x += fc2(act(fc1(ln2(x))))
             MQ_TRY(mq_layernorm(d_x, nullptr, b.ln1_g, b.ln1_b, h, nullptr, rows, W, cfg->ln_eps, s));
             MQ_TRY(mq_gemm_bf16(h, W, b.qkv_w, W, b.qkv_b, nullptr, qf, 3 * W, rows, 3 * W, W, MQ_EPI_BIAS, s));

@@ -73,7 +73,40 @@ def _encoder_cfg(width, layers, heads, mlp_dim, quick_gelu, post_ln, mask, eps) 
         raise ValueError(f"attention head dim must be 64 for the gfx950 attention kernel (width={width}, heads={heads})")
     return L.EncoderCfg(width=width, layers=layers, heads=heads, mlp_dim=mlp_dim,
                         act=L.MQ_ACT_QUICKGELU if quick_gelu else L.MQ_ACT_GELU,
-                        post_ln=1 if post_ln else 0, mask=mask, ln_eps=eps)
+                        post_ln=1 if post_ln else 0, mask=mask, ln_eps=eps, precision=L.MQ_PREC_BF16, reserved=0,
+                        d_fp8_act_scale=None, d_fp8_act_amax=None)
+
+
+class _Fp8State:
+    """fp8 (e4m3) side of an encoder: per-channel-quantised copies of the four block GEMM weights and the static
+    per-tensor activation scales [layers, 2] = (attention output, MLP hidden) with their calibration accumulator."""
+
+    def __init__(self, lib, holder: "_Holder", blocks, layers: int, W: int, F: int, device: torch.device):
+        self.scale = torch.full((layers, 2), 16.0 / 448.0, dtype=torch.float32, device=device)  # pre-calibration guess
+        self.amax = torch.zeros(layers, 2, dtype=torch.float32, device=device)
+        stream = torch.cuda.current_stream(device).cuda_stream
+        for i in range(layers):
+            b = blocks[i]
+            for name, (n, k) in (("qkv", (3 * W, W)), ("out", (W, W)), ("fc1", (F, W)), ("fc2", (W, F))):
+                w8 = torch.empty(n, k, dtype=torch.uint8, device=device)
+                ws = torch.empty(n, dtype=torch.float32, device=device)
+                L.check(lib.mq_quantize_weights_fp8(getattr(b, name + "_w"), k, w8.data_ptr(), k, ws.data_ptr(), n, k, stream),
+                        "mq_quantize_weights_fp8")
+                holder.tensors += [w8, ws]
+                setattr(b, name + "_w8", w8.data_ptr())
+                setattr(b, name + "_ws", ws.data_ptr())
+        self.calibrated = False
+
+    def attach(self, enc: L.EncoderCfg, calibrating: bool) -> None:
+        enc.precision = L.MQ_PREC_FP8
+        enc.d_fp8_act_scale = self.scale.data_ptr()
+        enc.d_fp8_act_amax = self.amax.data_ptr() if calibrating else None
+
+    def fold(self, margin: float = 1.0) -> None:
+        """scale <- observed amax * margin / 448 (entries never observed keep their value); reset the accumulator"""
+        seen = self.amax > 0
+        self.scale[seen] = (self.amax[seen] * (margin / 448.0))
+        self.amax.zero_()
 
 
 def _clip_blocks(h: _Holder, sd, prefix: str, layers: int, W: int, F: int):
@@ -97,6 +130,29 @@ def _clip_blocks(h: _Holder, sd, prefix: str, layers: int, W: int, F: int):
 
 
 class _TowerBase:
+    _fp8: Optional[_Fp8State] = None
+
+    def _enable_fp8(self, blocks, layers: int, W: int, F: int) -> None:
+        if W % 128 or F % 128:
+            raise ValueError(f"the fp8 path needs width / mlp_dim multiples of 128 (got {W}, {F})")
+        with torch.cuda.device(self.device):
+            self._fp8 = _Fp8State(self.lib, self._h, blocks, layers, W, F, self.device)
+            self._fp8.attach(self.cfg.enc, calibrating=False)
+
+    def calibrate_fp8(self, run, passes: int = 2, margin: float = 1.0) -> None:
+        """Static activation-scale calibration: `run()` must push a representative batch through this tower.  Each pass
+        records max|activation| of the two fp8 activation tensors per layer on the device and folds it into the scales
+        (2 passes: the first one runs on the pre-calibration guess).  Afterwards the scales are frozen (deterministic)."""
+        if self._fp8 is None:
+            raise RuntimeError("tower was not built with precision='fp8'")
+        for _ in range(passes):
+            self._fp8.attach(self.cfg.enc, calibrating=True)
+            run()
+            torch.cuda.synchronize(self.device)
+            self._fp8.fold(margin)
+        self._fp8.attach(self.cfg.enc, calibrating=False)
+        self._fp8.calibrated = True
+
     def __init__(self, device: str):
         self.device = _require_gpu(device)
         self.lib = L.load()
@@ -121,8 +177,12 @@ class VitTower(_TowerBase):
     """CLIP ViT image tower (open_clip `visual.*` checkpoint tensors)."""
 
     def __init__(self, arch: VitArch, sd: Dict[str, Tensor], device: str,
-                 mean: Sequence[float] = OPENAI_DATASET_MEAN, std: Sequence[float] = OPENAI_DATASET_STD):
+                 mean: Sequence[float] = OPENAI_DATASET_MEAN, std: Sequence[float] = OPENAI_DATASET_STD,
+                 precision: str = "bf16"):
         super().__init__(device)
+        if precision not in ("bf16", "fp8"):
+            raise ValueError(f"precision must be 'bf16' or 'fp8', got {precision!r}")
+        self.precision = precision
         self.arch = arch
         W, P = arch.width, arch.patch_size
         if arch.image_size % P:
@@ -147,6 +207,8 @@ class VitTower(_TowerBase):
                             image_size=arch.image_size, patch_size=P, out_dim=arch.out_dim,
                             mean=(C.c_float * 3)(*mean), std=(C.c_float * 3)(*std))
         self.max_images_per_call = max(1, MAX_ROWS_PER_CALL // arch.tokens)
+        if precision == "fp8":
+            self._enable_fp8(self._blocks, arch.layers, W, arch.mlp_dim)
 
     def _run(self, fn, pixels: Tensor, normalize: bool) -> Tensor:
         n = pixels.shape[0]
@@ -206,8 +268,11 @@ class _TextTowerBase(_TowerBase):
 class ClipTextTower(_TextTowerBase):
     """CLIP text tower (open_clip `token_embedding`, `transformer.*`, `ln_final`, `text_projection`)."""
 
-    def __init__(self, arch: ClipTextArch, sd: Dict[str, Tensor], device: str):
+    def __init__(self, arch: ClipTextArch, sd: Dict[str, Tensor], device: str, precision: str = "bf16"):
         super().__init__(device)
+        if precision not in ("bf16", "fp8"):
+            raise ValueError(f"precision must be 'bf16' or 'fp8', got {precision!r}")
+        self.precision = precision
         self.arch = arch
         W = arch.width
         h = self._h
@@ -221,6 +286,8 @@ class ClipTextTower(_TextTowerBase):
         self.cfg = L.ClipTextCfg(enc=_encoder_cfg(W, arch.layers, arch.heads, arch.mlp_dim, arch.quick_gelu, False,
                                                   L.MQ_MASK_CAUSAL, arch.ln_eps),
                                  vocab=arch.vocab, ctx=arch.ctx, out_dim=arch.out_dim)
+        if precision == "fp8":
+            self._enable_fp8(self._blocks, arch.layers, W, arch.mlp_dim)
 
     def encode_ids(self, ids: Tensor, normalize: bool = True, pack: bool = True) -> Tensor:
         """ids: int [n, ctx] zero-padded CLIP token ids (SOT ... EOT 0 0 ...), host or device.

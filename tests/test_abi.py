@@ -24,16 +24,17 @@ def test_header_symbols_are_exported_and_bound():
         assert hasattr(raw, n), f"libmarqo_hip.so does not export {n}"
         assert n in L.EXPORTED_SYMBOLS, f"ctypes binding is missing {n}"
     assert set(L.EXPORTED_SYMBOLS) <= set(names), set(L.EXPORTED_SYMBOLS) - set(names)
-    assert lib.mq_abi_version() == 1 and lib.mq_build_arch() == b"gfx950"
+    assert lib.mq_abi_version() == L.ABI_VERSION == 2 and lib.mq_build_arch() == b"gfx950"
 
 
 def test_struct_layouts_match_header():
-    assert C.sizeof(L.BlockWeights) == 12 * 8
-    assert C.sizeof(L.EncoderCfg) == 8 * 4
-    assert C.sizeof(L.VitCfg) == 8 * 4 + 3 * 4 + 6 * 4
+    assert C.sizeof(L.BlockWeights) == 20 * 8
+    ENC = 8 * 4 + 2 * 4 + 2 * 8
+    assert C.sizeof(L.EncoderCfg) == ENC
+    assert C.sizeof(L.VitCfg) == ENC + 3 * 4 + 6 * 4 + 4  # + tail padding to 8
     assert C.sizeof(L.VitWeights) == 9 * 8
-    assert C.sizeof(L.ClipTextCfg) == 8 * 4 + 3 * 4 and C.sizeof(L.ClipTextWeights) == 6 * 8
-    assert C.sizeof(L.BertCfg) == 8 * 4 + 3 * 4 and C.sizeof(L.BertWeights) == 6 * 8
+    assert C.sizeof(L.ClipTextCfg) == ENC + 3 * 4 + 4 and C.sizeof(L.ClipTextWeights) == 6 * 8
+    assert C.sizeof(L.BertCfg) == ENC + 3 * 4 + 4 and C.sizeof(L.BertWeights) == 6 * 8
 
 
 def test_argument_errors_are_reported_without_a_gpu():

@@ -1,0 +1,143 @@
+"""K13: fp8 (OCP e4m3) path.  The fp8 GEMM must reproduce, to fp32-accumulation accuracy, the exact product of the
+DEQUANTISED operands (this pins the MFMA operand mapping, swizzle, scales and epilogues independent of quantisation
+error); quantisation kernels must round like torch.float8_e4m3fn; the fp8 tower is then compared with the fp32 oracle and
+its cosine error REPORTED against the bf16 path (north-star tolerance 1e-3 is stated for bf16; fp8 is config 5)."""
+import ctypes as C
+
+import pytest
+import torch
+
+from marqo_amd import _lib as L
+
+pytestmark = pytest.mark.gpu
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _quant_rows(lib, Wb):
+    N, K = Wb.shape
+    W8 = torch.empty(N, K, dtype=torch.uint8, device="cuda")
+    sc = torch.empty(N, dtype=torch.float32, device="cuda")
+    L.check(lib.mq_quantize_weights_fp8(Wb.data_ptr(), K, W8.data_ptr(), K, sc.data_ptr(), N, K, _stream()))
+    return W8, sc
+
+
+def _deq(q8, scale):
+    return q8.view(torch.float8_e4m3fn).float() * (scale[:, None] if scale.ndim == 1 and scale.numel() == q8.shape[0] else scale)
+
+
+def test_quantize_weights_matches_torch_e4m3():
+    lib = L.load()
+    g = torch.Generator(device="cuda").manual_seed(0)
+    Wb = (torch.randn(300, 768, device="cuda", generator=g) * torch.rand(300, 1, device="cuda", generator=g) * 3).to(torch.bfloat16)
+    Wb[7] = 0
+    W8, sc = _quant_rows(lib, Wb)
+    ref_sc = Wb.float().abs().amax(1) / 448.0
+    ref_sc[7] = 1.0
+    assert torch.allclose(sc, ref_sc, rtol=1e-6)
+    ref8 = (Wb.float() / sc[:, None]).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8)
+    assert (W8 != ref8).float().mean().item() < 1e-3  # ties may differ by one code when x/s vs x*(1/s) differ in the last bit
+    err = (_deq(W8, sc) - Wb.float()).abs().amax(1) / (Wb.float().abs().amax(1) + 1e-9)
+    assert err.max().item() <= 2 ** -4 + 1e-3
+
+
+def test_layernorm_fp8_rowscale():
+    lib = L.load()
+    g = torch.Generator(device="cuda").manual_seed(1)
+    for W in (512, 768, 1024):
+        x = torch.randn(1000, W, device="cuda", generator=g) * 3 + 0.5
+        gam = torch.rand(W, device="cuda", generator=g) + 0.5
+        bet = torch.randn(W, device="cuda", generator=g) * 0.1
+        q = torch.empty(1000, W, dtype=torch.uint8, device="cuda")
+        s = torch.empty(1000, device="cuda")
+        f = torch.empty(1000, W, device="cuda")
+        L.check(lib.mq_layernorm_fp8(x.data_ptr(), gam.data_ptr(), bet.data_ptr(), q.data_ptr(), s.data_ptr(), f.data_ptr(), 1000, W, 1e-5, _stream()))
+        ref = torch.nn.functional.layer_norm(x, (W,), gam, bet, 1e-5)
+        assert torch.allclose(f, ref, atol=2e-5)
+        assert torch.allclose(s, ref.abs().amax(1) / 448, rtol=1e-4)
+        deq = _deq(q, s)
+        assert ((deq - ref).abs().amax(1) / ref.abs().amax(1)).max().item() <= 2 ** -4 + 1e-3
+
+
+@pytest.mark.parametrize("mt", [0, 2, 4, 5, 6])
+def test_gemm_fp8_equals_product_of_dequantised_operands(mt):
+    lib = L.load()
+    L.check(lib.mq_tune(b"gemm_mt", mt))
+    try:
+        g = torch.Generator(device="cuda").manual_seed(2 + mt)
+        for (M, N, K) in [(50, 64, 128), (257, 768, 256), (1000, 132, 384), (4097, 2304, 768), (12800, 768, 3072), (16, 4, 128)]:
+            A8 = torch.randint(0, 256, (M, K), dtype=torch.uint8, device="cuda", generator=g)
+            A8[(A8 & 0x7F) == 0x7F] = 0x30  # no NaN codes (0x7F / 0xFF)
+            W8 = torch.randint(0, 256, (N, K), dtype=torch.uint8, device="cuda", generator=g)
+            W8[(W8 & 0x7F) == 0x7F] = 0x30
+            # keep magnitudes moderate: clear the top exponent bit
+            A8 &= 0xBF; W8 &= 0xBF
+            sa = torch.rand(M, device="cuda", generator=g) + 0.5
+            sw = torch.rand(N, device="cuda", generator=g) + 0.5
+            bias = torch.randn(N, device="cuda", generator=g)
+            res = torch.randn(M, N, device="cuda", generator=g)
+            ref = (_deq(A8, sa).double() @ _deq(W8, sw).double().t())
+            scal = torch.tensor([0.75], device="cuda")
+            ref_s = ((A8.view(torch.float8_e4m3fn).double() * 0.75) @ _deq(W8, sw).double().t())
+            tol = 3e-4 * ref.abs().max().item() + 1e-6  # the MX MFMA aligns the 128 products of a block before adding them
+
+            def run(flags, rowscale, out_dtype, residual=None, out_scale=None, amax=None):
+                out = residual.clone() if residual is not None else torch.empty(M, N, device="cuda", dtype=out_dtype)
+                L.check(lib.mq_gemm_fp8(A8.data_ptr(), K, W8.data_ptr(), K, (sa if rowscale else scal).data_ptr(), 1 if rowscale else 0,
+                                        sw.data_ptr(), bias.data_ptr(), out.data_ptr() if residual is not None else 0, out.data_ptr(), N,
+                                        L.ptr(out_scale), L.ptr(amax), M, N, K, flags, _stream()))
+                return out
+
+            o = run(L.MQ_EPI_OUT_F32, True, torch.float32)
+            assert (o.double() - ref).abs().max().item() < tol, (mt, M, N, K)
+            o = run(L.MQ_EPI_OUT_F32, False, torch.float32)
+            assert (o.double() - ref_s).abs().max().item() < 3e-4 * ref_s.abs().max().item() + 1e-6
+            o = run(L.MQ_EPI_BIAS | L.MQ_EPI_RESIDUAL | L.MQ_EPI_OUT_F32, True, torch.float32, residual=res)
+            assert (o.double() - (ref + bias + res)).abs().max().item() < tol + 1e-4
+            o = run(L.MQ_EPI_BIAS, True, torch.bfloat16)
+            assert (o.double() - (ref + bias)).abs().max().item() < 1e-2 * (ref.abs().max().item() + 3)
+            want = torch.nn.functional.gelu((ref + bias).float())
+            osc = (want.abs().max() / 448).reshape(1)
+            amax = torch.zeros(1, device="cuda")
+            o = run(L.MQ_EPI_BIAS | L.MQ_EPI_GELU | L.MQ_EPI_OUT_FP8, True, torch.uint8, out_scale=osc, amax=amax)
+            assert abs(amax.item() - want.abs().max().item()) < 1e-3 * want.abs().max().item() + 1e-4
+            deq = o.view(torch.float8_e4m3fn).float() * osc
+            assert (deq - want).abs().max().item() <= (2 ** -4) * want.abs().max().item() + 1e-3
+    finally:
+        L.check(lib.mq_tune(b"gemm_mt", 0))
+
+
+def _cos_err(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((1 - (a * b).sum(-1) / (a.norm(dim=-1) * b.norm(dim=-1))).max())
+
+
+def test_fp8_towers_vs_oracle_and_bf16():
+    """ViT-B/32-shaped towers at reduced depth (6 layers keeps the CPU oracle quick): the fp8 path must stay close to
+    the fp32 oracle; the bound asserted here (1e-2) is the honest fp8 figure, the measured values are printed."""
+    from marqo_amd.engine import archs, synthetic, towers
+    from oracle import towers as O
+    varch = archs.VitArch(224, 32, 768, 6, 12, 3072, 512)
+    tarch = archs.ClipTextArch(49408, 77, 512, 6, 8, 2048, 512)
+    sd = synthetic.random_open_clip_state_dict(vision=varch, text=tarch, seed=0)
+    u8 = O.synthetic_images_u8(24, 224, seed=3).cuda()
+    ref = O.vit_forward(sd, O.VitConfig(224, 32, 768, 6, 12, 3072, 512), O.preprocess_u8_exact_size(u8.cpu()))
+    bf = towers.VitTower(varch, sd, "cuda:0").encode_u8(u8)
+    t8 = towers.VitTower(varch, sd, "cuda:0", precision="fp8")
+    t8.calibrate_fp8(lambda: t8.encode_u8(u8[:16]))
+    f8 = t8.encode_u8(u8)
+    e_bf, e_f8 = _cos_err(bf, ref), _cos_err(f8, ref)
+    print(f"ViT 6L: 1-cos vs fp32 oracle  bf16 {e_bf:.2e}  fp8 {e_f8:.2e}")
+    assert e_bf < 3e-4 and e_f8 < 1e-2
+    assert torch.equal(t8.encode_u8(u8), f8)  # frozen scales -> deterministic
+    ids = O.synthetic_clip_ids(16, seed=4)
+    reft = O.clip_text_forward(sd, O.ClipTextConfig(49408, 77, 512, 6, 8, 2048, 512), ids)
+    tt8 = towers.ClipTextTower(tarch, sd, "cuda:0", precision="fp8")
+    tt8.calibrate_fp8(lambda: tt8.encode_ids(ids))
+    e_t8 = _cos_err(tt8.encode_ids(ids), reft)
+    print(f"CLIP text 6L: 1-cos vs fp32 oracle  fp8 {e_t8:.2e}")
+    assert e_t8 < 1e-2
+    with pytest.raises(RuntimeError):
+        towers.VitTower(varch, sd, "cuda:0").calibrate_fp8(lambda: None)

@@ -28,12 +28,45 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--only", default="")
+    ap.add_argument("--fp8", action="store_true", help="time mq_gemm_fp8 (K taken as-is; fp8 operands)")
     args = ap.parse_args()
     lib = L.load()
     s = torch.cuda.current_stream().cuda_stream
     tot_t = tot_f = 0.0
     for name, M, N, K, flags in SHAPES:
         if args.only and not __import__("re").search(args.only, name):
+            continue
+        if args.fp8:
+            if K % 128:
+                continue
+            A8 = torch.randint(0, 0x78, (M, K), dtype=torch.uint8, device="cuda")
+            W8 = torch.randint(0, 0x78, (N, K), dtype=torch.uint8, device="cuda")
+            sa = torch.rand(M, device="cuda") + 0.5
+            sw = torch.rand(N, device="cuda") * 1e-4
+            b8 = torch.randn(N, device="cuda")
+            f32 = bool(flags & L.MQ_EPI_OUT_F32)
+            gelu = bool(flags & L.MQ_EPI_GELU)
+            fl8 = flags | (L.MQ_EPI_OUT_FP8 if gelu else 0) if flags else L.MQ_EPI_OUT_F32
+            o8 = torch.zeros(M, N, device="cuda", dtype=torch.float32 if (fl8 & L.MQ_EPI_OUT_F32) else (torch.uint8 if gelu else torch.bfloat16))
+            osc = torch.ones(1, device="cuda")
+            res8 = o8 if fl8 & L.MQ_EPI_RESIDUAL else None
+
+            def run8():
+                L.check(lib.mq_gemm_fp8(A8.data_ptr(), K, W8.data_ptr(), K, sa.data_ptr(), 1, sw.data_ptr(), b8.data_ptr(), L.ptr(res8),
+                                        o8.data_ptr(), N, osc.data_ptr(), 0, M, N, K, fl8, s))
+            for _ in range(5):
+                run8()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.iters):
+                run8()
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / args.iters
+            fl = 2.0 * M * N * K
+            print(f"fp8 {name:10s} M={M:6d} N={N:5d} K={K:5d}  {us:9.1f} us  {fl / us / 1e6:8.1f} TF/s")
+            if name.startswith("b32") and "patch" not in name:
+                tot_t += us; tot_f += fl
             continue
         A = torch.randn(M, K, device="cuda").to(torch.bfloat16)
         W = (torch.randn(N, K, device="cuda") * 0.03).to(torch.bfloat16)
