@@ -1,9 +1,11 @@
 // Multi-head attention for short sequences (T = 50 / 77 / 257 / <= 512), d_head = 64 (K4).
 //
-// One workgroup (4 wave64s) per (sequence, head).  The whole K [len,64] and V^T [64,len] of that
-// (sequence, head) are staged ONCE in LDS (160 KB/CU makes this possible up to 512 keys: 64 KB +
-// 64 KB), then each wave owns 16-query blocks and runs a flash-style online softmax over 64-key
-// tiles with both GEMMs on v_mfma_f32_16x16x32_bf16:
+// One workgroup (4 wave64s) per (sequence, head).  The whole K [len,64] and V [len,64] of that
+// (sequence, head) are staged ONCE in LDS by LDS-DMA (global_load_lds: every 1-KiB piece is in flight at once, no
+// register round trip; 160 KB/CU makes this possible up to 512 keys: 64 KB + 64 KB), both row-major with the 16-B
+// chunks XOR-swizzled by (key & 7).  Each wave then owns 16-query blocks and runs a flash-style online softmax over
+// 64-key tiles with both GEMMs on v_mfma_f32_16x16x32_bf16; the V^T operand of the second GEMM is produced by
+// ds_read_b64_tr_b16 (the hardware 4x4 transpose read) straight from the row-major V — no transposed copy exists:
 //
 //   S^T = K . Q^T  (operands swapped so every lane's 16 scores belong to ONE query: the row max /
 //                   row sum need only two xor-shuffles, no LDS round trip)
@@ -16,6 +18,8 @@
 // tokens are simply not rows.  MASK_CAUSAL implements the CLIP text tower's mask.
 #include "common.h"
 
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
 namespace {
 
 // OUT_FP8: the output is written as e4m3 codes = value / *out_scale (static per-tensor scale of the fp8 path, K13) and
@@ -26,9 +30,8 @@ __global__ __launch_bounds__(256) void attention_kernel(
     int fixed_len, int W, int heads, int kpad, float scale_log2e, const float* __restrict__ out_scale, float* amax_out) {
     bf16_t* out = (bf16_t*)out_v;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sK = smem;                                   // [kpad][128 B], 16-B chunks XOR-swizzled by (key & 7)
-    bf16_t* sVt = (bf16_t*)(smem + (size_t)kpad * 128);  // [64][kpad + 4]
-    const int vstride = kpad + 4;
+    char* sK = smem;                      // [kpad][128 B], 16-B chunks XOR-swizzled by (key & 7)
+    char* sV = smem + (size_t)kpad * 128; // [kpad][128 B], same image
 
     const int seq = blockIdx.x / heads, h = blockIdx.x - seq * heads;
     int row0, len;
@@ -41,36 +44,51 @@ __global__ __launch_bounds__(256) void attention_kernel(
     const bf16_t* vb = qb + 2 * W;
     const int nkt = (len + 63) >> 6;
     const int kp = nkt << 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
-    // ---- stage K (row-major, swizzled) and V^T (transposed scatter) ----------------------------
-    for (int idx = threadIdx.x; idx < kp * 8; idx += 256) {
-        const int key = idx >> 3, chunk = idx & 7;
-        uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
-        if (key < len) {
-            kv = *(const uint4*)(kb + (int64_t)key * ld + chunk * 8);
-            vv = *(const uint4*)(vb + (int64_t)key * ld + chunk * 8);
-        }
-        *(uint4*)(sK + key * 128 + ((chunk ^ (key & 7)) << 4)) = kv;
-        const uint32_t w[4] = {vv.x, vv.y, vv.z, vv.w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            sVt[(chunk * 8 + 2 * j) * vstride + key] = (bf16_t)(w[j] & 0xffffu);
-            sVt[(chunk * 8 + 2 * j + 1) * vstride + key] = (bf16_t)(w[j] >> 16);
+    // ---- stage K and V: 8 rows x 128 B per LDS-DMA; lane -> (row = 8*piece + lane/8, physical chunk = lane%8) fetches the
+    // logical chunk that lives there.  Rows past the sequence re-read its last row (finite values; their scores are
+    // masked and their probabilities are exactly 0).
+    {
+        const int np8 = kp >> 3;
+        const int srow = lane >> 3, pchunk = lane & 7;
+        for (int p = wave; p < 2 * np8; p += 4) {
+            const bool is_v = p >= np8;
+            const int piece = is_v ? p - np8 : p;
+            const int row = piece * 8 + srow;
+            const int key = row < len ? row : len - 1;
+            const bf16_t* src = (is_v ? vb : kb) + (int64_t)key * ld + ((pchunk ^ (row & 7)) << 3);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)((is_v ? sV : sK) + piece * 1024), 16, 0, 0);
         }
     }
-    __syncthreads();
-
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, g = lane >> 4;
     const int nqb = (len + 15) >> 4;
     float amax_local = 0.f;
+    // first Q fragments are fetched while the K/V DMA is in flight
+    bf16x8 qn[2];
+    {
+        const int q0 = wave * 16 + l15;
+        const int qr = q0 < len ? q0 : len - 1;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) qn[kk] = *(const bf16x8*)(qb + (int64_t)qr * ld + 8 * g + 32 * kk);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // per-lane constants of the V^T transpose reads: source lane (g, l15) fetches 4 consecutive d of key 4g + l15/4
+    const int vkey = 4 * g + (l15 >> 2);
+    const int vcol = (l15 & 3) >> 1, vhalf = (l15 & 1) << 3;
 
     for (int qblk = wave; qblk < nqb; qblk += 4) {
         const int q = qblk * 16 + l15;           // this lane's query (B-operand column / output row)
-        const int qr = q < len ? q : len - 1;    // clamp loads of the ragged tail
-        bf16x8 qf[2];
+        bf16x8 qf[2] = {qn[0], qn[1]};
+        if (qblk + 4 < nqb) {                    // next block's Q streams in behind this block's math
+            const int q2 = q + 64;
+            const int qr = q2 < len ? q2 : len - 1;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) qf[kk] = *(const bf16x8*)(qb + (int64_t)qr * ld + 8 * g + 32 * kk);
+            for (int kk = 0; kk < 2; ++kk) qn[kk] = *(const bf16x8*)(qb + (int64_t)qr * ld + 8 * g + 32 * kk);
+        }
 
         float m_run = -1e30f, l_run = 0.f;
         f32x4 o[4];
@@ -95,33 +113,44 @@ __global__ __launch_bounds__(256) void attention_kernel(
                     sc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], sc[t], 0, 0, 0);
                 }
             }
-            float mx = -1e30f;
+            // masking is needed only on the ragged last tile and (causal) on tiles that reach past the block's first query:
+            // a wave-uniform test, so interior tiles skip the per-element compares / selects
+            bool need_mask = (kt == nkt - 1) && (len & 63);
+            if (MASK == MQ_MASK_CAUSAL) need_mask = need_mask || (kt * 64 + 63 > qblk * 16);
+            if (need_mask) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+                for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = kt * 64 + t * 16 + g * 4 + r;
-                    bool valid = key < len;
-                    if (MASK == MQ_MASK_CAUSAL) valid = valid && (key <= q);
-                    sc[t][r] = valid ? sc[t][r] * scale_log2e : -INFINITY;
-                    mx = fmaxf(mx, sc[t][r]);
-                }
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = kt * 64 + t * 16 + g * 4 + r;
+                        bool valid = key < len;
+                        if (MASK == MQ_MASK_CAUSAL) valid = valid && (key <= q);
+                        sc[t][r] = valid ? sc[t][r] : -INFINITY;
+                    }
+            }
+            // running max on the RAW scores (the softmax scale is positive); scale and shift fold into one FMA per element
+            float mx = fmaxf(fmaxf(fmaxf(sc[0][0], sc[0][1]), fmaxf(sc[0][2], sc[0][3])), fmaxf(fmaxf(sc[1][0], sc[1][1]), fmaxf(sc[1][2], sc[1][3])));
+            mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(sc[2][0], sc[2][1]), fmaxf(sc[2][2], sc[2][3])), fmaxf(fmaxf(sc[3][0], sc[3][1]), fmaxf(sc[3][2], sc[3][3]))));
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run, mx);
-            const float alpha = exp2f(m_run - m_new);
+            const float m_new = fmaxf(m_run, mx);   // finite: every query sees at least key 0
+            const float neg_mc = -m_new * scale_log2e;
             float psum = 0.f;
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    sc[t][r] = exp2f(sc[t][r] - m_new);
+                    sc[t][r] = __builtin_amdgcn_exp2f(fmaf(sc[t][r], scale_log2e, neg_mc));
                     psum += sc[t][r];
                 }
-            l_run = l_run * alpha + psum;
-            m_run = m_new;
+            if (__any(m_new != m_run)) {  // rescale only when some query's running max moved (rare after the first tiles)
+                const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
+                l_run *= alpha;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) o[dt] *= alpha;
+                for (int dt = 0; dt < 4; ++dt) o[dt] *= alpha;
+            }
+            l_run += psum;
+            m_run = m_new;
 
             // ---- O^T += V^T . P^T over the tile's two 32-key halves --------------------------------
 #pragma unroll
@@ -133,10 +162,16 @@ __global__ __launch_bounds__(256) void attention_kernel(
                 pf.w[3] = pack_bf16x2(sc[2 * u + 1][2], sc[2 * u + 1][3]);
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
-                    const bf16_t* vrow = sVt + (dt * 16 + l15) * vstride + kt * 64 + 32 * u + 4 * g;
-                    union { uint2 h[2]; bf16x8 v; } vf;
-                    vf.h[0] = *(const uint2*)(vrow);        // keys 16*(2u)   + 4g .. +3
-                    vf.h[1] = *(const uint2*)(vrow + 16);   // keys 16*(2u+1) + 4g .. +3
+                    // lane (d = dt*16 + l15, g) needs V[keys 16*(2u) + 4g .. +3][d] and V[keys 16*(2u+1) + 4g .. +3][d]:
+                    // ds_read_b64_tr_b16 hands output lane 4r+c of a 16-lane block element c of the 8 bytes fetched by
+                    // lanes r, r+4, r+8, r+12 of that block, so source lane (g, l15) fetches V[key0 + 4g + l15/4][4*(l15%4) .. +3]
+                    union { s16x4 t[2]; bf16x8 v; } vf;
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt) {
+                        const int key = kt * 64 + (2 * u + tt) * 16 + vkey;
+                        const char* vp = sV + key * 128 + ((((dt << 1) | vcol) ^ (key & 7)) << 4) + vhalf;
+                        vf.t[tt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)vp);
+                    }
                     o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf.v, o[dt], 0, 0, 0);
                 }
             }
@@ -193,7 +228,7 @@ extern "C" int mq_attention_ex(const void* d_qkv, void* d_out, const int32_t* d_
     MQ_CHECK_ARG(maxl >= 1 && maxl <= 1024, "mq_attention: max sequence length %d unsupported (1..1024)", maxl);
     MQ_CHECK_ARG(nseq * heads < (1LL << 31), "mq_attention: grid too large");
     const int kpad = ((maxl + 63) / 64) * 64;
-    const size_t lds = (size_t)kpad * 128 + (size_t)64 * (kpad + 4) * 2;
+    const size_t lds = (size_t)kpad * 256;
     MQ_CHECK_ARG(lds <= 160 * 1024, "mq_attention: sequence length %d needs %zu B of LDS (> 160 KiB)", maxl, lds);
     hipStream_t s = (hipStream_t)stream;
     const float scale_log2e = 0.125f * 1.44269504088896340736f;  // 1/sqrt(64) * log2(e)

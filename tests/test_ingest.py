@@ -1,0 +1,85 @@
+"""BulkVectoriser (caller-side batching): call-count known answers in the style of the reference's
+tests/core/vespa_index/test_add_documents_handler.py:221-249, on the `random` fake (CPU) and world-size-2 gloo."""
+import os
+import socket
+from unittest import mock
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+from marqo_amd.ingest import BulkVectoriser
+from marqo_amd.s2_inference import s2_inference
+from marqo_amd.s2_inference.enums import Modality
+
+
+def test_one_vectorise_call_per_modality_and_order():
+    calls = []
+
+    def fake(model, content, **kw):
+        calls.append((kw["modality"], list(content)))
+        return np.asarray([[float(len(str(c))), 1.0] for c in content], dtype=np.float32)
+
+    bv = BulkVectoriser("m", "cpu", vectorise_fn=fake)
+    for d in range(5):
+        bv.add((d, "title"), f"title {d}")
+        bv.add((d, "img"), f"http://x/{d}.png", Modality.IMAGE)
+        bv.add((d, "body"), f"body of doc {d}")
+    assert bv.pending() == 15
+    out = bv.flush()
+    assert len(calls) == 2 and {c[0] for c in calls} == {Modality.TEXT, Modality.IMAGE}
+    assert [len(c[1]) for c in calls] == [10, 5]
+    assert set(out) == {(d, f) for d in range(5) for f in ("title", "img", "body")}
+    assert out[(3, "body")][0] == len("body of doc 3") and bv.pending() == 0 and bv.flush() == {}
+
+
+def test_auto_flush_bounds_the_queue():
+    fake = mock.MagicMock(side_effect=lambda m, c, **k: np.zeros((len(c), 4), np.float32))
+    bv = BulkVectoriser("m", "cpu", max_pending=4, vectorise_fn=fake)
+    for i in range(10):
+        bv.add(i, f"t{i}")
+    assert fake.call_count == 2 and bv.pending() == 2
+    assert len(bv.flush()) == 10
+
+
+def test_against_the_random_model_through_vectorise_ndarray():
+    bv = BulkVectoriser("random/small", "cpu")
+    for i in range(6):
+        bv.add(i, f"text {i}")
+    out = bv.flush()
+    ref = s2_inference.vectorise_ndarray("random/small", [f"text {i}" for i in range(6)], device="cpu")
+    assert np.allclose(np.stack([out[i] for i in range(6)]), ref)
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        seen = []
+
+        def fake(model, content, **kw):  # embedding of item i = [i, i, i] -> order is checkable after the gather
+            seen.append(list(content))
+            return np.asarray([[float(c.split()[-1])] * 3 for c in content], dtype=np.float32)
+
+        bv = BulkVectoriser("m", "cpu", vectorise_fn=fake)
+        for i in range(7):
+            bv.add(i, f"item {i}")
+        out = bv.flush()
+        ok = all(np.allclose(out[i], [i, i, i]) for i in range(7)) and len(seen[0]) == (4 if rank == 0 else 3)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_flush_world_size_2():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert sorted(q.get(timeout=5) for _ in range(2)) == [(0, True), (1, True)]
