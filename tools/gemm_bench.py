@@ -19,6 +19,11 @@ SHAPES = [
     ("l14 out", 16448, 1024, 1024, L.MQ_EPI_BIAS | L.MQ_EPI_RESIDUAL | L.MQ_EPI_OUT_F32),
     ("l14 fc1", 16448, 4096, 1024, L.MQ_EPI_BIAS | L.MQ_EPI_GELU),
     ("l14 fc2", 16448, 1024, 4096, L.MQ_EPI_BIAS | L.MQ_EPI_RESIDUAL | L.MQ_EPI_OUT_F32),
+    ("epi fc1 f32out", 12800, 3072, 768, L.MQ_EPI_OUT_F32),
+    ("epi fc1 bf16", 12800, 3072, 768, 0),
+    ("epi fc1 bias", 12800, 3072, 768, L.MQ_EPI_BIAS),
+    ("epi fc1 gelu", 12800, 3072, 768, L.MQ_EPI_BIAS | L.MQ_EPI_GELU),
+    ("epi fc1 res", 12800, 3072, 768, L.MQ_EPI_BIAS | L.MQ_EPI_RESIDUAL | L.MQ_EPI_OUT_F32),
     ("4096^3", 4096, 4096, 4096, 0),
     ("8192^3", 8192, 8192, 8192, 0),
 ]
