@@ -87,52 +87,60 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // one k-step, in two 32-deep halves: fragments of a half are read, then its 4*MT MFMAs run with the next stage's
-    // LDS-DMA issues sprinkled between them (registers hold one half's fragments at a time: MT + 4 b128 values)
-    auto kstep = [&](int kt, auto prefetch_tag) {
-        constexpr bool PREFETCH = decltype(prefetch_tag)::value;
+    // ---- role-split k-loop ----------------------------------------------------------------------------------------
+    // A k-step is four barrier-separated segments per wave:  R0 | M0 | R1 | M1 |   (R = ds_read the fragments of a 32-deep
+    // half [+ in R0: issue this wave's LDS-DMA pieces of the NEXT stage], M = that half's 4*MT MFMAs under s_setprio 1).
+    // Waves 4..7 (the second wave of every SIMD) run ONE segment behind waves 0..3 (one extra barrier up front), so on each
+    // SIMD one wave is always in an M segment while the other is in an R segment: the matrix pipe sees a pure MFMA stream
+    // and every LDS / VMEM issue stall happens beside it instead of in front of it.
+    //   slot:      4k      4k+1    4k+2    4k+3    4k+4
+    //   waves 0-3  R0(k)   M0(k)   R1(k)   M1(k)   R0(k+1)
+    //   waves 4-7  M1(k-1) R0(k)   M0(k)   R1(k)   M1(k)
+    // Stage k+1 goes into the buffer of stage k-1, whose last reader is waves 4-7's R1(k-1) in slot 4k-1, so issuing from
+    // slot 4k on is safe; every wave retires its own pieces (vmcnt(0)) at the end of its R1, i.e. by the end of slot 4k+3,
+    // before the first reader (waves 0-3's R0(k+1) in slot 4k+4).  Reads are drained (lgkmcnt(0)) before the barrier that
+    // ends an R segment, so no ds_read is pending when another wave's DMA may target that buffer.
+    auto wg_barrier = [] { asm volatile("s_barrier" ::: "memory"); };
+    const int nk = K / BK;
+    const bool late = wave >= 4;
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wg_barrier();
+    if (late) wg_barrier();
+    for (int kt = 0; kt < nk; ++kt) {
         const char* sa = smem + (kt & 1) * STAGE_BYTES;
         const char* sw = sa + A_TILE_BYTES;
-        char* na = smem + ((kt + 1) & 1) * STAGE_BYTES + wave * (4 * MT * 128);
-        char* nw = smem + ((kt + 1) & 1) * STAGE_BYTES + A_TILE_BYTES + wave * (32 * 128);
-        const int64_t koff = (int64_t)(kt + 1) * BK;
-        constexpr int NL = PA + PW;      // LDS-DMA pieces per wave per step
-        constexpr int NM = 8 * MT;       // MFMAs per wave per step
-        constexpr int GAP = NM / NL;
-        int issued = 0;
+        const bool prefetch = kt + 1 < nk;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
+            // ---- R segment
             const int swz = kk ? sw1 : sw0;
             bf16x8 af[MT], wf[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) wf[t] = *(const bf16x8*)(sw + w_off[t] + swz);
 #pragma unroll
             for (int t = 0; t < MT; ++t) af[t] = *(const bf16x8*)(sa + a_off[t] + swz);
+            if (kk == 0) {
+                if (prefetch) stage((kt + 1) & 1, kt + 1);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            wg_barrier();
+            // ---- M segment
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
+                for (int nt = 0; nt < 4; ++nt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[mt], acc[mt][nt], 0, 0, 0);
-                    const int done = (kk * MT + mt) * 4 + nt + 1;
-                    if (PREFETCH && done % GAP == 0 && issued < NL) {
-                        if (issued < PA) glds16(a_src[issued] + koff, na + issued * (8 * 128));
-                        else glds16(w_src[issued - PA] + koff, nw + (issued - PA) * (8 * 128));
-                        ++issued;
-                    }
-                }
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            wg_barrier();
         }
-    };
-
-    const int nk = K / BK;
-    stage(0, 0);
-    for (int kt = 0; kt < nk - 1; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        kstep(kt, std::true_type{});
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    kstep(nk - 1, std::false_type{});
+    if (!late) wg_barrier();  // balance the stagger barrier
 
     gemm_epilogue<FLAGS, MT>(acc, bias, residual, out, ldc, M, N, m0 + wm * (16 * MT), n0 + wn * 64, l15, g);
 }
