@@ -13,6 +13,7 @@ once, so nothing is ever re-uploaded):
 from __future__ import annotations
 
 import ctypes as C
+import os
 import threading
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -207,12 +208,36 @@ class VitTower(_TowerBase):
                             image_size=arch.image_size, patch_size=P, out_dim=arch.out_dim,
                             mean=(C.c_float * 3)(*mean), std=(C.c_float * 3)(*std))
         self.max_images_per_call = max(1, MAX_ROWS_PER_CALL // arch.tokens)
+        self.n_streams = max(1, int(os.environ.get("MARQO_AMD_STREAMS", "1")))
+        self._side: list = []
         if precision == "fp8":
             self._enable_fp8(self._blocks, arch.layers, W, arch.mlp_dim)
 
     def _run(self, fn, pixels: Tensor, normalize: bool) -> Tensor:
         n = pixels.shape[0]
         out = torch.empty(n, self.arch.out_dim, dtype=torch.float32, device=self.device)
+        k = self.n_streams
+        if k > 1 and n >= 2 * k:
+            # independent images: run k sub-batches on k HIP streams so that one sub-batch's kernels fill the tail /
+            # prologue / epilogue bubbles of the other's (every kernel of the tower is a dependent chain on ONE stream)
+            with self._lock, torch.cuda.device(self.device):
+                cur = torch.cuda.current_stream(self.device)
+                start = torch.cuda.Event()
+                start.record(cur)
+                if len(self._side) < k:
+                    self._side = [(torch.cuda.Stream(self.device), [None]) for _ in range(k)]
+                bounds = [(j * n // k, (j + 1) * n // k) for j in range(k)]
+                for (a, b), (st, ws_box) in zip(bounds, self._side):
+                    st.wait_event(start)
+                    need = self.lib.mq_vit_workspace_bytes(C.byref(self.cfg), b - a)
+                    if ws_box[0] is None or ws_box[0].numel() < need:
+                        ws_box[0] = torch.empty(int(need * 1.25) + 256, dtype=torch.uint8, device=self.device)
+                    L.check(fn(C.byref(self.cfg), C.byref(self.w), pixels[a:b].data_ptr(), b - a, out[a:b].data_ptr(),
+                               1 if normalize else 0, ws_box[0].data_ptr(), ws_box[0].numel(), st.cuda_stream), "mq_encode_image")
+                    done = torch.cuda.Event()
+                    done.record(st)
+                    cur.wait_event(done)
+            return out
         with self._lock, torch.cuda.device(self.device):
             for i in range(0, n, self.max_images_per_call):
                 m = min(self.max_images_per_call, n - i)
@@ -251,18 +276,26 @@ def _pack(ids: Tensor, lengths: Tensor) -> Tuple[Tensor, Tensor]:
 
 class _TextTowerBase(_TowerBase):
     def _chunks(self, lengths: Tensor):
-        """Yield (start, stop) sequence ranges with <= MAX_ROWS_PER_CALL rows each."""
+        """Yield (start, stop) sequence ranges with <= MAX_ROWS_PER_CALL rows each (greedy, vectorised: the common
+        case of one chunk costs one cumsum)."""
         n = lengths.numel()
-        cum = 0
-        start = 0
-        lens = lengths.tolist()
-        for i, l in enumerate(lens):
-            if cum + l > MAX_ROWS_PER_CALL and i > start:
-                yield start, i
-                start, cum = i, 0
-            cum += l
-        if n > start:
-            yield start, n
+        if n == 0:
+            return
+        cum = torch.cumsum(lengths, 0)
+        if int(cum[-1]) <= MAX_ROWS_PER_CALL:
+            yield 0, n
+            return
+        start, base = 0, 0
+        while start < n:
+            stop = int(torch.searchsorted(cum, base + MAX_ROWS_PER_CALL, right=True))
+            stop = max(stop, start + 1)
+            yield start, stop
+            base = int(cum[stop - 1])
+            start = stop
+
+    def _to_device(self, t: Tensor) -> Tensor:
+        """small host -> device copy through pinned memory (a pageable copy would synchronise the stream)"""
+        return t.pin_memory().to(self.device, non_blocking=True)
 
 
 class ClipTextTower(_TextTowerBase):
@@ -305,9 +338,9 @@ class ClipTextTower(_TextTowerBase):
             for a, b in self._chunks(lengths):
                 packed, cu = _pack(ids_h[a:b], lengths[a:b])
                 pool_rows = None if pack else (cu[:-1].to(torch.int64) + eot[a:b]).to(torch.int32)
-                d_ids = packed.to(self.device, non_blocking=True)
-                d_cu = cu.to(self.device, non_blocking=True)
-                d_pool = pool_rows.to(self.device) if pool_rows is not None else None
+                d_ids = self._to_device(packed)
+                d_cu = self._to_device(cu)
+                d_pool = self._to_device(pool_rows) if pool_rows is not None else None
                 rows, nseq = packed.numel(), b - a
                 need = self.lib.mq_clip_text_workspace_bytes(C.byref(self.cfg), rows, nseq)
                 ws = self._workspace(need)
@@ -380,8 +413,8 @@ class BertTower(_TextTowerBase):
         with self._lock, torch.cuda.device(self.device):
             for a, b in self._chunks(lengths):
                 packed, cu = _pack(ids_h[a:b], lengths[a:b])
-                d_ids = packed.to(self.device, non_blocking=True)
-                d_cu = cu.to(self.device, non_blocking=True)
+                d_ids = self._to_device(packed)
+                d_cu = self._to_device(cu)
                 rows, nseq = packed.numel(), b - a
                 need = self.lib.mq_bert_workspace_bytes(C.byref(self.cfg), rows, nseq)
                 ws = self._workspace(need)
