@@ -45,7 +45,7 @@ extern "C" {
 #define MQ_ERR_HIP (-2)       /* a HIP runtime call or launch failed */
 #define MQ_ERR_WORKSPACE (-3) /* caller's workspace too small */
 
-#define MQ_ABI_VERSION 2
+#define MQ_ABI_VERSION 3
 
 /* ---- activation / mask / pooling selectors ---------------------------------------- */
 #define MQ_ACT_NONE 0
@@ -314,12 +314,23 @@ int mq_encoder_forward(const mq_encoder_cfg* cfg, const mq_block_weights* blocks
                        int32_t fixed_len, int32_t max_len,
                        void* d_workspace, size_t workspace_bytes, void* stream);
 
+/* mq_encoder_forward when only the rows listed in d_out_rows (int32 [n_out_rows], absolute row numbers) are read
+ * afterwards — class-token / EOT / CLS pooling.  Every row still feeds the last block's keys and values, but its
+ * out-projection, MLP and LayerNorms run on the listed rows only; those rows come out bit-identical to
+ * mq_encoder_forward, every other row of d_x is unspecified on return.  The towers use this internally. */
+int mq_encoder_forward_rows(const mq_encoder_cfg* cfg, const mq_block_weights* blocks,
+                            float* d_x, int64_t rows, const int32_t* d_cu_seqlens, int64_t nseq,
+                            int32_t fixed_len, int32_t max_len,
+                            const int32_t* d_out_rows, int64_t n_out_rows,
+                            void* d_workspace, size_t workspace_bytes, void* stream);
+
 /* rows of x: out[r,:] = x[r,:] / ||x[r,:]||_2   (in place allowed) */
 int mq_l2_normalize(const float* d_x, float* d_out, int64_t rows, int32_t D, void* stream);
 
 /* Run-time selection of a kernel variant (benchmark A/B and parity tests of every variant in one process).
  * keys: "gemm_mt" (0 = auto, else GEMM tile height in 32-row units), "gemm_spec" (1 = producer/consumer wave
- * specialisation), "gemm_big" (4 / 6 / 8 = one-workgroup-per-CU (32*v) x 256 tile, 0 = off).  Initial values come from
+ * specialisation), "gemm_big" (4 / 6 / 8 = one-workgroup-per-CU (32*v) x 256 tile, 0 = off), "row_select" (0 = the towers run their last
+ * block on every row instead of the pooled rows only).  Initial values come from
  * the environment (MQ_GEMM_MT, MQ_GEMM_SPEC, MQ_GEMM_BIG). */
 int mq_tune(const char* key, int value);
 

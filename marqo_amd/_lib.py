@@ -21,7 +21,7 @@ LIB_PATH = LIB_DIR / "libmarqo_hip.so"
 HEADER_PATH = PKG_DIR.parent / "include" / "marqo_hip.h"
 
 MQ_OK = 0
-ABI_VERSION = 2
+ABI_VERSION = 3
 MQ_PREC_BF16, MQ_PREC_FP8 = 0, 1
 MQ_ACT_GELU, MQ_ACT_QUICKGELU = 1, 2
 MQ_MASK_NONE, MQ_MASK_CAUSAL = 0, 1
@@ -109,6 +109,8 @@ _SIGNATURES = {
     "mq_attention": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "mq_encoder_forward": (C.c_int, [C.POINTER(EncoderCfg), C.POINTER(BlockWeights), _P, C.c_int64, _P, C.c_int64,
                                      C.c_int32, C.c_int32, _P, C.c_size_t, _P]),
+    "mq_encoder_forward_rows": (C.c_int, [C.POINTER(EncoderCfg), C.POINTER(BlockWeights), _P, C.c_int64, _P, C.c_int64,
+                                          C.c_int32, C.c_int32, _P, C.c_int64, _P, C.c_size_t, _P]),
     "mq_l2_normalize": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P]),
     "mq_clip_resize_workspace_bytes": (C.c_size_t, [_P, _P, C.c_int64, C.c_int32]),
     "mq_clip_resize_crop_u8": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, _P, _P, C.c_size_t, _P]),

@@ -202,6 +202,20 @@ __global__ void cls_rows_kernel(int32_t* __restrict__ rows, int n, int T) {
     if (i < n) rows[i] = i * T;
 }
 
+// dense[i,:] <- sparse[idx[i],:] (SCATTER = false) or sparse[idx[i],:] <- dense[i,:] (true); rows are `chunks` 16-B pieces
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void move_rows_kernel(uint4* __restrict__ sparse, const int32_t* __restrict__ idx,
+                                                         uint4* __restrict__ dense, int64_t n, int chunks) {
+    const int64_t total = n * chunks;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / chunks;
+        const int c = (int)(i - r * chunks);
+        uint4* sp = sparse + (int64_t)idx[r] * chunks + c;
+        if (SCATTER) *sp = dense[i];
+        else dense[i] = *sp;
+    }
+}
+
 }  // namespace
 
 // ---- internal host entry points (declared in towers.hip) ---------------------------------------------------
@@ -264,6 +278,20 @@ int mq_last_rows(const int32_t* d_cu, int32_t* d_rows, int64_t nseq, hipStream_t
     if (nseq <= 0) return MQ_OK;
     hipLaunchKernelGGL(last_rows_kernel, dim3((unsigned)cdiv64(nseq, 256)), dim3(256), 0, s, d_cu, d_rows, (int)nseq);
     MQ_CHECK_LAUNCH("last_rows");
+    return MQ_OK;
+}
+
+// row gather / scatter through an int32 row index (the pooled-rows-only last encoder block, towers.hip)
+int mq_move_rows(void* d_sparse, const int32_t* d_idx, void* d_dense, int64_t n, int64_t row_bytes, bool scatter, hipStream_t s) {
+    MQ_CHECK_ARG(row_bytes % 16 == 0 && row_bytes / 16 < (1 << 30), "move_rows: row_bytes=%ld must be a multiple of 16", (long)row_bytes);
+    if (n <= 0) return MQ_OK;
+    MqProfScope prof(3, s);
+    const int chunks = (int)(row_bytes / 16);
+    const int64_t blocks = cdiv64(n * chunks, 256);
+    const unsigned grid = (unsigned)(blocks < 8192 ? blocks : 8192);
+    if (scatter) hipLaunchKernelGGL(move_rows_kernel<true>, dim3(grid), dim3(256), 0, s, (uint4*)d_sparse, d_idx, (uint4*)d_dense, n, chunks);
+    else hipLaunchKernelGGL(move_rows_kernel<false>, dim3(grid), dim3(256), 0, s, (uint4*)d_sparse, d_idx, (uint4*)d_dense, n, chunks);
+    MQ_CHECK_LAUNCH("move_rows");
     return MQ_OK;
 }
 

@@ -22,6 +22,7 @@
 #include "gemm_epilogue.h"
 
 extern int mq_gemm_fp8_force_mt;  // gemm_fp8.hip
+extern int mq_tower_row_select;   // towers.hip
 
 // CU-sized-tile main loop (gemm_big.hip)
 template <int FLAGS>
@@ -312,6 +313,7 @@ extern "C" int mq_tune(const char* key, int value) {
     if (k == "gemm_mt") { g_tune.mt = value; mq_gemm_fp8_force_mt = value; }
     else if (k == "gemm_spec") g_tune.spec = value;
     else if (k == "gemm_big") g_tune.big = value;
+    else if (k == "row_select") mq_tower_row_select = value;
     else { mq_set_error("mq_tune: unknown key %s", key); return MQ_ERR_INVALID; }
     return MQ_OK;
 }

@@ -19,11 +19,15 @@ int mq_pool(const float* d_x, const int32_t* d_cu, int64_t nseq, float* d_out, i
             hipStream_t s);
 int mq_last_rows(const int32_t* d_cu, int32_t* d_rows, int64_t nseq, hipStream_t s);
 int mq_cls_rows(int32_t* d_rows, int64_t n, int T, hipStream_t s);
+int mq_move_rows(void* d_sparse, const int32_t* d_idx, void* d_dense, int64_t n, int64_t row_bytes, bool scatter, hipStream_t s);
 
 // layouts the ctypes binding (marqo_amd/_lib.py) and tests/test_abi.py assume
 static_assert(sizeof(mq_block_weights) == 20 * 8, "mq_block_weights layout");
 static_assert(sizeof(mq_encoder_cfg) == 56, "mq_encoder_cfg layout");
 static_assert(sizeof(mq_vit_cfg) == 96 && sizeof(mq_clip_text_cfg) == 72 && sizeof(mq_bert_cfg) == 72, "tower cfg layouts");
+
+// mq_tune("row_select", 0) runs the last block on every row (A/B and parity tests of the pooled-rows-only last block)
+int mq_tower_row_select = 1;
 
 namespace {
 
@@ -78,9 +82,64 @@ extern "C" size_t mq_encoder_workspace_bytes(const mq_encoder_cfg* cfg, int64_t 
     return encoder_ws(cfg, rows);
 }
 
-extern "C" int mq_encoder_forward(const mq_encoder_cfg* cfg, const mq_block_weights* blocks, float* d_x, int64_t rows,
-                                  const int32_t* d_cu_seqlens, int64_t nseq, int32_t fixed_len, int32_t max_len,
-                                  void* d_workspace, size_t workspace_bytes, void* stream) {
+namespace {
+
+// The LAST block when only `nsel` rows of the residual stream are read afterwards (class-token / EOT / CLS pooling).
+// Every row still feeds K and V, so LN1 (pre-LN), the QKV GEMM and the attention run on all rows; the out-projection,
+// the MLP and their LayerNorms are row-wise, so they run on the gathered rows only and are scattered back.  The
+// selected rows come out bit-identical to the full block (same k-order of MFMAs per output element); the other rows
+// of d_x are left as they were after the previous block.
+// Scratch reuse: a_sel -> head of `h`, LN2 output -> head of `a`, fc1 output -> head of `qf`, x_sel (fp32) -> `qf`
+// behind the fc1 output (all of h / a / qkv are dead by the time they are overwritten).
+int last_block_selected(const mq_encoder_cfg* cfg, const mq_block_weights& b, int l, float* d_x, int64_t rows,
+                        const int32_t* d_cu_seqlens, int64_t nseq, int32_t fixed_len, int32_t max_len,
+                        const int32_t* d_sel, int64_t nsel, void* h, void* a, void* qf, float* row_scale, float* x_sel,
+                        hipStream_t s) {
+    const int W = cfg->width, F = cfg->mlp_dim;
+    const int act_flag = cfg->act == MQ_ACT_QUICKGELU ? MQ_EPI_QUICKGELU : MQ_EPI_GELU;
+    const int res_flags = MQ_EPI_BIAS | MQ_EPI_RESIDUAL | MQ_EPI_OUT_F32;
+    if (cfg->precision == MQ_PREC_FP8) {
+        const float* s_attn = cfg->d_fp8_act_scale + 2 * l;
+        const float* s_mlp = s_attn + 1;
+        const int act8 = act_flag | MQ_EPI_BIAS | MQ_EPI_OUT_FP8;
+        MQ_TRY(mq_layernorm_fp8(d_x, b.ln1_g, b.ln1_b, h, row_scale, nullptr, rows, W, cfg->ln_eps, s));
+        MQ_TRY(mq_gemm_fp8(h, W, b.qkv_w8, W, row_scale, 1, b.qkv_ws, b.qkv_b, nullptr, qf, 3 * W, nullptr, nullptr, rows, 3 * W, W,
+                           MQ_EPI_BIAS, s));
+        MQ_TRY(mq_attention_ex(qf, a, d_cu_seqlens, nseq, fixed_len, max_len, W, cfg->heads, cfg->mask, 1, s_attn, nullptr, s));
+        MQ_TRY(mq_move_rows(a, d_sel, h, nsel, (int64_t)W, false, s));
+        MQ_TRY(mq_move_rows(d_x, d_sel, x_sel, nsel, (int64_t)W * 4, false, s));
+        MQ_TRY(mq_gemm_fp8(h, W, b.out_w8, W, s_attn, 0, b.out_ws, b.out_b, x_sel, x_sel, W, nullptr, nullptr, nsel, W, W, res_flags, s));
+        MQ_TRY(mq_layernorm_fp8(x_sel, b.ln2_g, b.ln2_b, a, row_scale, nullptr, nsel, W, cfg->ln_eps, s));
+        MQ_TRY(mq_gemm_fp8(a, W, b.fc1_w8, W, row_scale, 1, b.fc1_ws, b.fc1_b, nullptr, qf, F, s_mlp, nullptr, nsel, F, W, act8, s));
+        MQ_TRY(mq_gemm_fp8(qf, F, b.fc2_w8, F, s_mlp, 0, b.fc2_ws, b.fc2_b, x_sel, x_sel, W, nullptr, nullptr, nsel, W, F, res_flags, s));
+    } else if (!cfg->post_ln) {
+        MQ_TRY(mq_layernorm(d_x, nullptr, b.ln1_g, b.ln1_b, h, nullptr, rows, W, cfg->ln_eps, s));
+        MQ_TRY(mq_gemm_bf16(h, W, b.qkv_w, W, b.qkv_b, nullptr, qf, 3 * W, rows, 3 * W, W, MQ_EPI_BIAS, s));
+        MQ_TRY(mq_attention(qf, a, d_cu_seqlens, nseq, fixed_len, max_len, W, cfg->heads, cfg->mask, s));
+        MQ_TRY(mq_move_rows(a, d_sel, h, nsel, (int64_t)W * 2, false, s));
+        MQ_TRY(mq_move_rows(d_x, d_sel, x_sel, nsel, (int64_t)W * 4, false, s));
+        MQ_TRY(mq_gemm_bf16(h, W, b.out_w, W, b.out_b, x_sel, x_sel, W, nsel, W, W, res_flags, s));
+        MQ_TRY(mq_layernorm(x_sel, nullptr, b.ln2_g, b.ln2_b, a, nullptr, nsel, W, cfg->ln_eps, s));
+        MQ_TRY(mq_gemm_bf16(a, W, b.fc1_w, W, b.fc1_b, nullptr, qf, F, nsel, F, W, MQ_EPI_BIAS | act_flag, s));
+        MQ_TRY(mq_gemm_bf16(qf, F, b.fc2_w, F, b.fc2_b, x_sel, x_sel, W, nsel, W, F, res_flags, s));
+    } else {
+        MQ_TRY(mq_gemm_bf16(h, W, b.qkv_w, W, b.qkv_b, nullptr, qf, 3 * W, rows, 3 * W, W, MQ_EPI_BIAS, s));
+        MQ_TRY(mq_attention(qf, a, d_cu_seqlens, nseq, fixed_len, max_len, W, cfg->heads, cfg->mask, s));
+        MQ_TRY(mq_move_rows(a, d_sel, h, nsel, (int64_t)W * 2, false, s));
+        MQ_TRY(mq_move_rows(d_x, d_sel, x_sel, nsel, (int64_t)W * 4, false, s));
+        MQ_TRY(mq_gemm_bf16(h, W, b.out_w, W, b.out_b, x_sel, x_sel, W, nsel, W, W, res_flags, s));
+        MQ_TRY(mq_layernorm(x_sel, nullptr, b.ln1_g, b.ln1_b, a, x_sel, nsel, W, cfg->ln_eps, s));
+        MQ_TRY(mq_gemm_bf16(a, W, b.fc1_w, W, b.fc1_b, nullptr, qf, F, nsel, F, W, MQ_EPI_BIAS | act_flag, s));
+        MQ_TRY(mq_gemm_bf16(qf, F, b.fc2_w, F, b.fc2_b, x_sel, x_sel, W, nsel, W, F, res_flags, s));
+        MQ_TRY(mq_layernorm(x_sel, nullptr, b.ln2_g, b.ln2_b, nullptr, x_sel, nsel, W, cfg->ln_eps, s));
+    }
+    MQ_TRY(mq_move_rows(d_x, d_sel, x_sel, nsel, (int64_t)W * 4, true, s));
+    return MQ_OK;
+}
+
+int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* blocks, float* d_x, int64_t rows,
+                         const int32_t* d_cu_seqlens, int64_t nseq, int32_t fixed_len, int32_t max_len,
+                         const int32_t* d_sel, int64_t nsel, void* d_workspace, size_t workspace_bytes, hipStream_t s) {
     MQ_TRY(check_encoder_cfg(cfg));
     MQ_CHECK_ARG(d_x && (blocks || cfg->layers == 0), "mq_encoder_forward: null pointer");
     if (rows <= 0 || cfg->layers == 0) return MQ_OK;
@@ -88,7 +147,6 @@ extern "C" int mq_encoder_forward(const mq_encoder_cfg* cfg, const mq_block_weig
         mq_set_error("mq_encoder_forward: workspace %zu < required %zu", workspace_bytes, encoder_ws(cfg, rows));
         return MQ_ERR_WORKSPACE;
     }
-    hipStream_t s = (hipStream_t)stream;
     const int W = cfg->width, F = cfg->mlp_dim;
     const size_t big = (size_t)(3 * W > F ? 3 * W : F);
     Off cv;
@@ -100,16 +158,29 @@ extern "C" int mq_encoder_forward(const mq_encoder_cfg* cfg, const mq_block_weig
     const int act_flag = cfg->act == MQ_ACT_QUICKGELU ? MQ_EPI_QUICKGELU : MQ_EPI_GELU;
     const int res_flags = MQ_EPI_BIAS | MQ_EPI_RESIDUAL | MQ_EPI_OUT_F32;
 
+    // pooled-rows-only last block: worth it when it at least halves the row count; not during fp8 calibration (the
+    // activation maxima must see every row); x_sel must fit behind the fc1 output inside `qf`
+    const size_t xsel_off = align_up((size_t)(nsel > 0 ? nsel : 0) * F * 2, WS_ALIGN);
+    const bool select_last = d_sel && nsel > 0 && nsel * 2 <= rows && mq_tower_row_select &&
+                             !(cfg->precision == MQ_PREC_FP8 && cfg->d_fp8_act_amax) &&
+                             xsel_off + (size_t)nsel * W * 4 <= (size_t)rows * big * 2;
+
     if (cfg->post_ln) MQ_TRY(mq_cast_bf16(d_x, h, rows * W, s));  // block input as GEMM operand
 
     for (int l = 0; l < cfg->layers; ++l) {
         const mq_block_weights& b = blocks[l];
         MQ_CHECK_ARG(b.qkv_w && b.out_w && b.fc1_w && b.fc2_w && b.ln1_g && b.ln2_g, "mq_encoder_forward: layer %d has null weights", l);
+        if (cfg->precision == MQ_PREC_FP8)
+            MQ_CHECK_ARG(b.qkv_w8 && b.qkv_ws && b.out_w8 && b.out_ws && b.fc1_w8 && b.fc1_ws && b.fc2_w8 && b.fc2_ws,
+                         "mq_encoder_forward: layer %d has no fp8 weights", l);
+        if (select_last && l == cfg->layers - 1) {
+            MQ_TRY(last_block_selected(cfg, b, l, d_x, rows, d_cu_seqlens, nseq, fixed_len, max_len, d_sel, nsel, h, a, qf, row_scale,
+                                       (float*)((char*)qf + xsel_off), s));
+            break;
+        }
         if (cfg->precision == MQ_PREC_FP8) {
             // same dataflow with e4m3 GEMM operands: h / a / fc1-out are fp8 (h with a dynamic per-row scale from the LN,
             // a and fc1-out with static per-tensor scales), qkv stays bf16 for the attention MFMAs, x stays fp32
-            MQ_CHECK_ARG(b.qkv_w8 && b.qkv_ws && b.out_w8 && b.out_ws && b.fc1_w8 && b.fc1_ws && b.fc2_w8 && b.fc2_ws,
-                         "mq_encoder_forward: layer %d has no fp8 weights", l);
             const float* s_attn = cfg->d_fp8_act_scale + 2 * l;
             const float* s_mlp = s_attn + 1;
             float* m_attn = cfg->d_fp8_act_amax ? cfg->d_fp8_act_amax + 2 * l : nullptr;
@@ -144,6 +215,24 @@ extern "C" int mq_encoder_forward(const mq_encoder_cfg* cfg, const mq_block_weig
         }
     }
     return MQ_OK;
+}
+
+}  // namespace
+
+extern "C" int mq_encoder_forward(const mq_encoder_cfg* cfg, const mq_block_weights* blocks, float* d_x, int64_t rows,
+                                  const int32_t* d_cu_seqlens, int64_t nseq, int32_t fixed_len, int32_t max_len,
+                                  void* d_workspace, size_t workspace_bytes, void* stream) {
+    return encoder_forward_impl(cfg, blocks, d_x, rows, d_cu_seqlens, nseq, fixed_len, max_len, nullptr, 0, d_workspace, workspace_bytes,
+                                (hipStream_t)stream);
+}
+
+extern "C" int mq_encoder_forward_rows(const mq_encoder_cfg* cfg, const mq_block_weights* blocks, float* d_x, int64_t rows,
+                                       const int32_t* d_cu_seqlens, int64_t nseq, int32_t fixed_len, int32_t max_len,
+                                       const int32_t* d_out_rows, int64_t n_out_rows, void* d_workspace, size_t workspace_bytes,
+                                       void* stream) {
+    MQ_CHECK_ARG(d_out_rows && n_out_rows > 0, "mq_encoder_forward_rows: empty row selection");
+    return encoder_forward_impl(cfg, blocks, d_x, rows, d_cu_seqlens, nseq, fixed_len, max_len, d_out_rows, n_out_rows, d_workspace,
+                                workspace_bytes, (hipStream_t)stream);
 }
 
 // =============================== ViT image tower =================================================
@@ -197,10 +286,11 @@ int encode_image_impl(const mq_vit_cfg* cfg, const mq_vit_weights* w, const void
     MQ_TRY(mq_patchify(d_pixels, is_u8, patches, n, cfg->image_size, cfg->patch_size, p.Kp, cfg->mean, cfg->std, s));
     MQ_TRY(mq_gemm_bf16(patches, p.Kp, w->patch_w, p.Kp, nullptr, nullptr, patch_out, W, n * p.np, W, p.Kp, MQ_EPI_OUT_F32, s));
     MQ_TRY(mq_vit_assemble(patch_out, w->cls, w->pos, w->ln_pre_g, w->ln_pre_b, x, n, p.T, W, cfg->enc.ln_eps, s));
-    // K2-K5 x layers
-    MQ_TRY(mq_encoder_forward(&cfg->enc, w->blocks, x, p.rows, nullptr, n, p.T, p.T, base + p.off_enc, ws_bytes - p.off_enc, s));
-    // K6: ln_post(class token) @ proj, L2
+    // K2-K5 x layers (only the class-token rows are read afterwards -> the last block's row-wise half runs on them alone)
     MQ_TRY(mq_cls_rows(rows_idx, n, p.T, s));
+    MQ_TRY(encoder_forward_impl(&cfg->enc, w->blocks, x, p.rows, nullptr, n, p.T, p.T, rows_idx, n, base + p.off_enc,
+                                ws_bytes - p.off_enc, s));
+    // K6: ln_post(class token) @ proj, L2
     MQ_TRY(mq_layernorm(x, rows_idx, w->ln_post_g, w->ln_post_b, cls_ln, nullptr, n, W, cfg->enc.ln_eps, s));
     MQ_TRY(mq_gemm_bf16(cls_ln, W, w->proj_w, W, nullptr, nullptr, d_out, cfg->out_dim, n, cfg->out_dim, W, MQ_EPI_OUT_F32, s));
     if (normalize) MQ_TRY(mq_l2_normalize(d_out, d_out, n, cfg->out_dim, s));
@@ -277,9 +367,10 @@ extern "C" int mq_encode_clip_text(const mq_clip_text_cfg* cfg, const mq_clip_te
     const int W = cfg->enc.width;
 
     MQ_TRY(mq_embed_tokens(d_ids, d_cu_seqlens, nseq, w->tok_emb, w->pos, nullptr, nullptr, nullptr, x, nullptr, W, cfg->vocab, 0.f, s));
-    MQ_TRY(mq_encoder_forward(&cfg->enc, w->blocks, x, rows, d_cu_seqlens, nseq, 0, maxl, base + p.off_enc, workspace_bytes - p.off_enc, s));
     const int32_t* pool_rows = d_pool_rows;
     if (!pool_rows) { MQ_TRY(mq_last_rows(d_cu_seqlens, rows_idx, nseq, s)); pool_rows = rows_idx; }
+    MQ_TRY(encoder_forward_impl(&cfg->enc, w->blocks, x, rows, d_cu_seqlens, nseq, 0, maxl, pool_rows, nseq, base + p.off_enc,
+                                workspace_bytes - p.off_enc, s));
     MQ_TRY(mq_layernorm(x, pool_rows, w->ln_final_g, w->ln_final_b, pooled, nullptr, nseq, W, cfg->enc.ln_eps, s));
     MQ_TRY(mq_gemm_bf16(pooled, W, w->proj_w, W, nullptr, nullptr, d_out, cfg->out_dim, nseq, cfg->out_dim, W, MQ_EPI_OUT_F32, s));
     if (normalize) MQ_TRY(mq_l2_normalize(d_out, d_out, nseq, cfg->out_dim, s));
@@ -315,7 +406,10 @@ extern "C" int mq_encode_bert(const mq_bert_cfg* cfg, const mq_bert_weights* w, 
 
     MQ_TRY(mq_embed_tokens(d_ids, d_cu_seqlens, nseq, w->word_emb, w->pos_emb, w->type_emb, w->emb_ln_g, w->emb_ln_b, x, nullptr, W,
                            cfg->vocab, cfg->enc.ln_eps, s));
-    MQ_TRY(mq_encoder_forward(&cfg->enc, w->blocks, x, rows, d_cu_seqlens, nseq, 0, maxl, base + p.off_enc, workspace_bytes - p.off_enc, s));
+    // CLS pooling reads only the first row of every sequence (= d_cu_seqlens[0..nseq-1]); mean pooling reads them all
+    const int32_t* sel = cfg->pool == MQ_POOL_CLS ? d_cu_seqlens : nullptr;
+    MQ_TRY(encoder_forward_impl(&cfg->enc, w->blocks, x, rows, d_cu_seqlens, nseq, 0, maxl, sel, sel ? nseq : 0, base + p.off_enc,
+                                workspace_bytes - p.off_enc, s));
     MQ_TRY(mq_pool(x, d_cu_seqlens, nseq, d_out, W, cfg->pool, normalize, s));
     return MQ_OK;
 }

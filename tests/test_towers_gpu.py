@@ -152,3 +152,66 @@ def test_tower_input_validation():
     from marqo_amd._lib import MarqoHipUnavailableError
     with pytest.raises(MarqoHipUnavailableError):
         T.BertTower(A.BertArch(vocab=V, max_pos=P, width=W, layers=L, heads=H, mlp_dim=F), sd, "cpu")
+
+
+def _tune(key: str, value: int):
+    from marqo_amd import _lib as L
+    L.check(L.load().mq_tune(key.encode(), value))
+
+
+def test_row_selected_last_block_is_bit_identical():
+    """The towers run the out-projection / MLP of the LAST block only on the rows that are pooled afterwards
+    (class token, EOT, CLS).  That is dead-row elimination, not an approximation: embeddings must be bit-identical to
+    the all-rows execution (mq_tune("row_select", 0)), in bf16 and fp8, for every tower that pools single rows."""
+    T, A = _towers()
+    sd, z = G.load("clip_vit_small")
+    S, P, W, L_, H, F, D = [int(v) for v in z["cfg"]]
+    px = torch.from_numpy(z["pixels"])
+    vit = T.VitTower(A.VitArch(S, P, W, L_, H, F, D), sd, "cuda")
+    sdt, zt = G.load("clip_text_small")
+    V, ctx, Wt, Lt, Ht, Ft, Dt = [int(v) for v in zt["cfg"]]
+    txt = T.ClipTextTower(A.ClipTextArch(V, ctx, Wt, Lt, Ht, Ft, Dt), sdt, "cuda")
+    ids = torch.from_numpy(zt["ids"])
+    sdb, zb = G.load("bert_small")
+    Vb, Pb, Wb, Lb, Hb, Fb = [int(v) for v in zb["cfg"]]
+    bert = T.BertTower(A.BertArch(vocab=Vb, max_pos=Pb, width=Wb, layers=Lb, heads=Hb, mlp_dim=Fb), sdb, "cuda", pooling="cls")
+    bids, bmask = torch.from_numpy(zb["ids"]), torch.from_numpy(zb["mask"])
+    runs = {
+        "vit": lambda: vit.encode_f32(px, normalize=False),
+        "text_packed": lambda: txt.encode_ids(ids, normalize=False, pack=True),
+        "text_padded": lambda: txt.encode_ids(ids, normalize=False, pack=False),
+        "bert_cls": lambda: bert.encode_ids(bids, bmask, normalize=False),
+    }
+    try:
+        for name, run in runs.items():
+            _tune("row_select", 1)
+            sel = run().cpu()
+            _tune("row_select", 0)
+            full = run().cpu()
+            assert torch.isfinite(sel).all()
+            assert torch.equal(sel, full), f"{name}: max |diff| = {(sel - full).abs().max().item():.3e}"
+    finally:
+        _tune("row_select", 1)
+
+
+def test_row_selected_last_block_full_size_fp8():
+    """Same property at the ViT-B/32 shape on the fp8 path (frozen scales): selected-row and all-row runs agree bit for bit."""
+    T, A = _towers()
+    arch, _ = A.resolve_open_clip("ViT-B-32")
+    cfg = O.VitConfig(arch.image_size, arch.patch_size, arch.width, 2, arch.heads, arch.mlp_dim, arch.out_dim)
+    import dataclasses
+    arch2 = dataclasses.replace(arch, layers=2)
+    sd = O.synthetic_vit_state_dict(cfg, seed=3)
+    u8 = O.synthetic_images_u8(9, 224, seed=5).to("cuda")
+    for precision in ("bf16", "fp8"):
+        tower = T.VitTower(arch2, sd, "cuda", precision=precision)
+        if precision == "fp8":
+            tower.calibrate_fp8(lambda: tower.encode_u8(u8))
+        try:
+            _tune("row_select", 1)
+            sel = tower.encode_u8(u8).cpu()
+            _tune("row_select", 0)
+            full = tower.encode_u8(u8).cpu()
+        finally:
+            _tune("row_select", 1)
+        assert torch.equal(sel, full), precision
