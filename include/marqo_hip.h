@@ -327,6 +327,19 @@ int mq_encoder_forward_rows(const mq_encoder_cfg* cfg, const mq_block_weights* b
 /* rows of x: out[r,:] = x[r,:] / ||x[r,:]||_2   (in place allowed) */
 int mq_l2_normalize(const float* d_x, float* d_out, int64_t rows, int32_t D, void* stream);
 
+/* Weighted combination of sub-embeddings (multimodal-combination fields and weighted multi-term queries):
+ *   out[g,:] = mean over the group's terms t of ( d_weights[t] * d_emb[d_rows[t], :] ),  t in [d_cu_terms[g], d_cu_terms[g+1])
+ * replacing the host numpy of  src/marqo/core/inference/tensor_fields_container.py:346-365  (mode MQ_COMBINE_NORMALIZE:
+ * divide by the L2 norm unconditionally, a zero vector gives NaN like numpy) and
+ * src/marqo/tensor_search/tensor_search.py:1954-1963  (mode MQ_COMBINE_NORMALIZE_IF_NONZERO).  Accumulation is fp64 like
+ * the reference; d_emb fp32 [*, ld]; d_rows int32 [terms] (NULL = term t reads row t); d_out fp32 [n_groups, D]. */
+#define MQ_COMBINE_RAW 0
+#define MQ_COMBINE_NORMALIZE 1
+#define MQ_COMBINE_NORMALIZE_IF_NONZERO 2
+int mq_weighted_combine(const float* d_emb, int64_t ld, const int32_t* d_rows, const float* d_weights,
+                        const int32_t* d_cu_terms, int64_t n_groups, int32_t D, int32_t mode, float* d_out,
+                        void* stream);
+
 /* Run-time selection of a kernel variant (benchmark A/B and parity tests of every variant in one process).
  * keys: "gemm_mt" (0 = auto, else GEMM tile height in 32-row units), "gemm_spec" (1 = producer/consumer wave
  * specialisation), "gemm_big" (4 / 6 / 8 = one-workgroup-per-CU (32*v) x 256 tile, 0 = off), "row_select" (0 = the towers run their last

@@ -27,6 +27,7 @@ MQ_ACT_GELU, MQ_ACT_QUICKGELU = 1, 2
 MQ_MASK_NONE, MQ_MASK_CAUSAL = 0, 1
 MQ_POOL_MEAN, MQ_POOL_CLS = 0, 1
 MQ_EPI_BIAS, MQ_EPI_GELU, MQ_EPI_QUICKGELU, MQ_EPI_RESIDUAL, MQ_EPI_OUT_F32, MQ_EPI_OUT_FP8 = 1, 2, 4, 8, 16, 32
+MQ_COMBINE_RAW, MQ_COMBINE_NORMALIZE, MQ_COMBINE_NORMALIZE_IF_NONZERO = 0, 1, 2
 MQ_PROF_FAMILIES = 6
 PROF_FAMILY_NAMES = ("gemm", "layernorm", "attention", "embed", "pool_head", "preprocess")
 
@@ -123,6 +124,7 @@ _SIGNATURES = {
     "mq_to_tensor_normalize": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float), _P]),
     "mq_resample_ksize": (C.c_int, [C.c_int32, C.c_int32]),
     "mq_resample_coeffs": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
+    "mq_weighted_combine": (C.c_int, [_P, C.c_int64, _P, _P, _P, C.c_int64, C.c_int32, C.c_int32, _P, _P]),
     "mq_tune": (C.c_int, [C.c_char_p, C.c_int]),
     "mq_profile_enable": (C.c_int, [C.c_int]),
     "mq_profile_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),

@@ -4,6 +4,7 @@
 //   BERT encoder + pooling   (transformers BertModel + hugging_face_model.py:172-214)
 // Residual stream is fp32 (what fp16-autocast keeps it as in the reference's cuda path:
 // open_clip_model.py:255-260), GEMM inputs bf16, accumulation / LN statistics / softmax fp32.
+#include <stdlib.h>
 #include "common.h"
 
 // kernels in the sibling translation units
@@ -27,7 +28,7 @@ static_assert(sizeof(mq_encoder_cfg) == 56, "mq_encoder_cfg layout");
 static_assert(sizeof(mq_vit_cfg) == 96 && sizeof(mq_clip_text_cfg) == 72 && sizeof(mq_bert_cfg) == 72, "tower cfg layouts");
 
 // mq_tune("row_select", 0) runs the last block on every row (A/B and parity tests of the pooled-rows-only last block)
-int mq_tower_row_select = 1;
+int mq_tower_row_select = getenv("MQ_ROW_SELECT") ? atoi(getenv("MQ_ROW_SELECT")) : 1;
 
 namespace {
 
