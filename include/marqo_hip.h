@@ -327,6 +327,46 @@ int mq_encoder_forward_rows(const mq_encoder_cfg* cfg, const mq_block_weights* b
 /* rows of x: out[r,:] = x[r,:] / ||x[r,:]||_2   (in place allowed) */
 int mq_l2_normalize(const float* d_x, float* d_out, int64_t rows, int32_t D, void* stream);
 
+/* ---- text tokenisation on device (K14) ------------------------------------------------------------------- */
+/* The reference tokenises on the host with third-party code (open_clip SimpleTokenizer at
+ * src/marqo/core/inference/embedding_models/open_clip_model.py:277, transformers BertTokenizer at
+ * .../hugging_face_model.py:179-185).  These entry points run the same published algorithms one GPU thread per text for
+ * texts inside the device scope — printable ASCII + \t \n \r — and flag every other text (d_status[i] = 1, d_lens[i] = 0)
+ * so that the caller tokenises it with the host tokeniser; results for in-scope texts are identical to the host ones.
+ * Texts are UTF-8 bytes packed back to back: text i = d_text[d_offsets[i] .. d_offsets[i+1]).
+ * The hash tables are built once per vocabulary by the host (marqo_amd/engine/gpu_tokenizers.py); layouts: tokenize_algo.h. */
+typedef struct mq_wordpiece_vocab {
+    const void*    d_slots;   /* mq_wp_entry[n_slots]: {u64 fnv1a hash, i32 id (-1 empty), u32 (pool_off << 8 | cont << 7 | len)} */
+    const uint8_t* d_pool;    /* piece bytes (without the "##" prefix) */
+    uint32_t n_slots;         /* power of two */
+    int32_t unk_id, cls_id, sep_id, pad_id;
+    int32_t lower;            /* do_lower_case */
+    int32_t max_word_chars;   /* 100 */
+} mq_wordpiece_vocab;
+
+typedef struct mq_clip_bpe_vocab {
+    const void*     d_slots;        /* mq_bpe_entry[n_slots]: {u32 key = a << 16 | b (0xffffffff empty), u32 rank, u32 merged id, u32 pad} */
+    const uint16_t* d_byte_id;      /* [256] id of the one-byte symbol */
+    const uint16_t* d_byte_end_id;  /* [256] id of the word-final one-byte symbol (unit + "</w>") */
+    uint32_t n_slots;               /* power of two */
+    int32_t sot_id, eot_id;
+    int32_t lower;
+} mq_clip_bpe_vocab;
+
+/* BERT WordPiece: d_ids int32 [n, ld] rows = [CLS] pieces... [SEP] then pad_id (truncated to max_length like
+ * truncation=True, max_length=...), d_lens[i] = tokens in row i including CLS / SEP. */
+int mq_tokenize_wordpiece(const mq_wordpiece_vocab* v, const uint8_t* d_text, const int64_t* d_offsets, int64_t n,
+                          int32_t max_length, int32_t* d_ids, int64_t ld, int32_t* d_lens, int32_t* d_status, void* stream);
+
+/* CLIP byte-level BPE: d_ids int32 [n, ctx] rows = SOT ids... EOT, zero padded; over-long texts are cut to ctx with EOT in
+ * the last position (open_clip tokenize).  d_lens[i] = SOT..EOT length (what mq_encode_clip_text packs to). */
+int mq_tokenize_clip_bpe(const mq_clip_bpe_vocab* v, const uint8_t* d_text, const int64_t* d_offsets, int64_t n,
+                         int32_t ctx, int32_t* d_ids, int32_t* d_lens, int32_t* d_status, void* stream);
+
+/* padded id rows -> the packed layout of the text towers: d_packed[cu[s] + j] = d_padded[s * ld + j], j < cu[s+1] - cu[s] */
+int mq_pack_ids(const int32_t* d_padded, int64_t ld, const int32_t* d_cu_seqlens, int64_t nseq, int32_t* d_packed,
+                void* stream);
+
 /* Weighted combination of sub-embeddings (multimodal-combination fields and weighted multi-term queries):
  *   out[g,:] = mean over the group's terms t of ( d_weights[t] * d_emb[d_rows[t], :] ),  t in [d_cu_terms[g], d_cu_terms[g+1])
  * replacing the host numpy of  src/marqo/core/inference/tensor_fields_container.py:346-365  (mode MQ_COMBINE_NORMALIZE:

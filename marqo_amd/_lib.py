@@ -83,6 +83,16 @@ class BertCfg(C.Structure):
     _fields_ = [("enc", EncoderCfg), ("vocab", C.c_int32), ("max_pos", C.c_int32), ("pool", C.c_int32)]
 
 
+class WordPieceVocab(C.Structure):
+    _fields_ = [("d_slots", C.c_void_p), ("d_pool", C.c_void_p), ("n_slots", C.c_uint32), ("unk_id", C.c_int32), ("cls_id", C.c_int32),
+                ("sep_id", C.c_int32), ("pad_id", C.c_int32), ("lower", C.c_int32), ("max_word_chars", C.c_int32)]
+
+
+class ClipBpeVocab(C.Structure):
+    _fields_ = [("d_slots", C.c_void_p), ("d_byte_id", C.c_void_p), ("d_byte_end_id", C.c_void_p), ("n_slots", C.c_uint32),
+                ("sot_id", C.c_int32), ("eot_id", C.c_int32), ("lower", C.c_int32)]
+
+
 _P = C.c_void_p
 _SIGNATURES = {
     # name: (restype, argtypes)
@@ -124,6 +134,9 @@ _SIGNATURES = {
     "mq_to_tensor_normalize": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float), _P]),
     "mq_resample_ksize": (C.c_int, [C.c_int32, C.c_int32]),
     "mq_resample_coeffs": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
+    "mq_tokenize_wordpiece": (C.c_int, [C.POINTER(WordPieceVocab), _P, _P, C.c_int64, C.c_int32, _P, C.c_int64, _P, _P, _P]),
+    "mq_tokenize_clip_bpe": (C.c_int, [C.POINTER(ClipBpeVocab), _P, _P, C.c_int64, C.c_int32, _P, _P, _P, _P]),
+    "mq_pack_ids": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P]),
     "mq_weighted_combine": (C.c_int, [_P, C.c_int64, _P, _P, _P, C.c_int64, C.c_int32, C.c_int32, _P, _P]),
     "mq_tune": (C.c_int, [C.c_char_p, C.c_int]),
     "mq_profile_enable": (C.c_int, [C.c_int]),

@@ -45,32 +45,53 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 // that minimises (rounds of resident workgroups) x (tile cost), which removes most of the tile
 // quantisation loss at the towers' shapes (e.g. M=12800,N=768: 600 128-row tiles = 2 rounds on
 // 512 slots, 480 160-row tiles = 1 round).
-// SPEC (wave specialisation): the workgroup has 8 waves; waves 4..7 are PRODUCERS that only issue the LDS-DMA
-// of the next stage (an LDS-DMA issue stalls the issuing wave for 60-180 cycles — in the 4-wave form those stalls
-// sit in front of the same wave's MFMAs), waves 0..3 are CONSUMERS whose k-loop is ds_read + MFMA only.
-template <int FLAGS, int MT, bool SPEC>
-__global__ __launch_bounds__(SPEC ? 512 : 256, SPEC ? 4 : 2) void gemm_nt_kernel(
+// PERSIST: the grid is the number of resident slots and every workgroup walks tiles bid, bid + grid, ...; the LAST
+// k-step of a tile prefetches stage 0 of the workgroup's next tile, so only the first tile pays the cold first-stage
+// fetch (at K = 768 a tile is 12 k-steps: the cold fetch is ~10 % of it).
+template <int FLAGS, int MT, bool PERSIST>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
     const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ Wt, int64_t ldw,
     const float* __restrict__ bias, const float* residual, void* out, int64_t ldc,
-    int M, int N, int K, int tiles_n, int num_tiles) {
+    int M, int N, int K, int tiles_n, int num_tiles, int cgroup, int band_rows, int wide_store) {
     constexpr int BM = 32 * MT;
     constexpr int A_TILE_BYTES = BM * BK * 2;
     constexpr int STAGE_BYTES = A_TILE_BYTES + W_TILE_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    // ---- XCD-aware, bijective block -> tile map -------------------------------------------
-    const int bid = blockIdx.x;
+    // ---- XCD-aware, bijective (virtual) block -> tile map ----------------------------------
     const int q = num_tiles >> 3, r = num_tiles & 7;
-    const int xcd = bid & 7, idx = bid >> 3;
-    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int tiles_m = (M + BM - 1) / BM;
+    auto tile_origin = [&](int vbid, int& m0, int& n0) {
+        const int xcd = vbid & 7, idx = vbid >> 3;
+        const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        int tm, tn;
+        if (cgroup > 0) {
+            // L2-blocked order inside an XCD's share: the linear order is (row band, column group, row panel, column) with a
+            // band = band_rows row panels (about one XCD's share) and a group = cgroup column tiles, so the ~64 tiles resident
+            // on an XCD at any time are ~64/cgroup row panels x cgroup column tiles: their A panels + W column tiles fit the
+            // XCD's 4 MiB L2 and the W group stays put while the A panels stream past.  (The plain row-major order swept ALL
+            // column tiles per panel: W alone — 4.7 MB at N = 3072, K = 768 — overflowed L2 and the fabric-side read traffic
+            // measured 7x the operand bytes, profiles/r01_traffic_*.)
+            const int band_tiles = band_rows * tiles_n;
+            const int band = tile / band_tiles, rb = tile - band * band_tiles;
+            const int rows_here = min(band_rows, tiles_m - band * band_rows);
+            const int full = rows_here * cgroup, ncg_full = tiles_n / cgroup;
+            int cg = rb / full, r2 = rb - cg * full, cw = cgroup;
+            if (cg >= ncg_full) { cg = ncg_full; r2 = rb - ncg_full * full; cw = tiles_n - ncg_full * cgroup; }
+            const int rr = r2 / cw;
+            tm = band * band_rows + rr;
+            tn = cg * cgroup + (r2 - rr * cw);
+        } else {
+            tm = tile / tiles_n;
+            tn = tile - tm * tiles_n;
+        }
+        m0 = tm * BM;
+        n0 = tn * BN;
+    };
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wave = wave_id & 3;  // share of the tile this wave stages (producer) / computes (consumer)
-    const bool producer = SPEC && wave_id >= 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int l15 = lane & 15, g = lane >> 4;
 
@@ -80,18 +101,20 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, SPEC ? 4 : 2) void gemm_nt_kernel
     const int srow = lane >> 3;
     const bf16_t* a_src[MT];
     const bf16_t* w_src[4];
+    auto set_sources = [&](int m0, int n0) {
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        const int row = wave * (8 * MT) + i * 8 + srow;
-        int gm = m0 + row; gm = gm < M ? gm : M - 1;
-        a_src[i] = A + (int64_t)gm * lda + ((lane & 7) ^ (row & 7)) * 8;
-    }
+        for (int i = 0; i < MT; ++i) {
+            const int row = wave * (8 * MT) + i * 8 + srow;
+            int gm = m0 + row; gm = gm < M ? gm : M - 1;
+            a_src[i] = A + (int64_t)gm * lda + ((lane & 7) ^ (row & 7)) * 8;
+        }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = wave * 32 + i * 8 + srow;
-        int gn = n0 + row; gn = gn < N ? gn : N - 1;
-        w_src[i] = Wt + (int64_t)gn * ldw + ((lane & 7) ^ (row & 7)) * 8;
-    }
+        for (int i = 0; i < 4; ++i) {
+            const int row = wave * 32 + i * 8 + srow;
+            int gn = n0 + row; gn = gn < N ? gn : N - 1;
+            w_src[i] = Wt + (int64_t)gn * ldw + ((lane & 7) ^ (row & 7)) * 8;
+        }
+    };
     auto stage = [&](int buf, int kt) {
         char* sa = smem + buf * STAGE_BYTES + wave * (8 * MT * 128);
         char* sw = smem + buf * STAGE_BYTES + A_TILE_BYTES + wave * (32 * 128);
@@ -113,22 +136,18 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, SPEC ? 4 : 2) void gemm_nt_kernel
     const int sw1 = ((g + 4) ^ (l15 & 7)) << 4;  // kk = 1
 
     f32x4 acc[MT][4];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // one k-step: fragments for both 32-deep halves are read up front, then the MT*8 MFMAs run with
-    // the NEXT stage's LDS-DMA issues sprinkled between them (an LDS-DMA issue costs the wave ~60-180
-    // cycles; bunched at the top of the step they serialised in front of the MFMAs and held the matrix
-    // pipe at 25-40 %).  PREFETCH is a template flag so the steady-state loop has no branch in it.
-    auto kstep = [&](int kt, auto prefetch_tag) {
+    // one k-step on LDS buffer `buf`: fragments for both 32-deep halves are read up front, then the MT*8 MFMAs run with
+    // the NEXT stage's LDS-DMA issues (k offset `koff` of the current a_src / w_src, into the other buffer) sprinkled
+    // between them (an LDS-DMA issue costs the wave ~60-180 cycles; bunched at the top of the step they serialised in
+    // front of the MFMAs and held the matrix pipe at 25-40 %).  PREFETCH is a template flag so the steady-state loop has
+    // no branch in it.
+    auto kstep = [&](int buf, int64_t koff, auto prefetch_tag) {
         constexpr bool PREFETCH = decltype(prefetch_tag)::value;
-        const char* sa = smem + (kt & 1) * STAGE_BYTES;
+        const char* sa = smem + buf * STAGE_BYTES;
         const char* sw = sa + A_TILE_BYTES;
-        char* na = smem + ((kt + 1) & 1) * STAGE_BYTES + wave * (8 * MT * 128);
-        char* nw = smem + ((kt + 1) & 1) * STAGE_BYTES + A_TILE_BYTES + wave * (32 * 128);
-        const int64_t koff = (int64_t)(kt + 1) * BK;
+        char* na = smem + (buf ^ 1) * STAGE_BYTES + wave * (8 * MT * 128);
+        char* nw = smem + (buf ^ 1) * STAGE_BYTES + A_TILE_BYTES + wave * (32 * 128);
         bf16x8 af[2][MT], wf[2][4];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -167,44 +186,49 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, SPEC ? 4 : 2) void gemm_nt_kernel
     };
 
     const int nk = K / BK;
-    if (SPEC) {
-        if (producer) {
-            stage(0, 0);
-            for (int kt = 0; kt < nk; ++kt) {
-                // stage kt has landed (this wave's share) and, past the barrier, every consumer is done with buffer (kt+1)&1
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
-            }
-            return;
-        }
-        for (int kt = 0; kt < nk; ++kt) {
-            __syncthreads();
-            __builtin_amdgcn_s_setprio(1);
-            kstep(kt, std::false_type{});
-            __builtin_amdgcn_s_setprio(0);
-        }
-    } else {
+    int vbid = blockIdx.x;
+    int m0, n0;
+    tile_origin(vbid, m0, n0);
+    set_sources(m0, n0);
     stage(0, 0);
-    for (int kt = 0; kt < nk - 1; ++kt) {
-        // tile kt has landed for every wave, and every wave is done reading buffer (kt+1)&1
+    int buf = 0;  // LDS buffer of the next k-step (runs on across tiles in the persistent form)
+    for (;;) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int kt = 0; kt < nk - 1; ++kt) {
+            // stage kt has landed for every wave, and every wave is done reading the other buffer
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            kstep(buf, (int64_t)(kt + 1) * BK, std::true_type{});
+            buf ^= 1;
+        }
+        const int cm0 = m0, cn0 = n0;
+        bool more = false;
+        if (PERSIST) {
+            vbid += gridDim.x;
+            more = vbid < num_tiles;
+            if (more) {  // from here on a_src / w_src address the NEXT tile (this tile's last stage is already in flight / landed)
+                tile_origin(vbid, m0, n0);
+                set_sources(m0, n0);
+            }
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        kstep(kt, std::true_type{});
+        if (PERSIST && more) kstep(buf, 0, std::true_type{});
+        else kstep(buf, 0, std::false_type{});
+        buf ^= 1;
+        gemm_epilogue<FLAGS, MT>(acc, bias, residual, out, ldc, M, N, cm0 + wm * (16 * MT), cn0 + wn * 64, l15, g, wide_store != 0);
+        if (!PERSIST || !more) break;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    kstep(nk - 1, std::false_type{});
-    }
-
-    gemm_epilogue<FLAGS, MT>(acc, bias, residual, out, ldc, M, N, m0 + wm * (16 * MT), n0 + wn * 64, l15, g);
 }
 
-// tuning knobs: initialised from the environment (MQ_GEMM_MT / _SPEC / _BIG), overridable through mq_tune()
+// tuning knobs: initialised from the environment (MQ_GEMM_MT / _PERSIST / _CGROUP / _WIDE / _BIG), overridable through mq_tune()
 struct GemmTune {
-    int mt, spec, big;
+    int mt, persist, big, cgroup, wide;
     static int env(const char* k, int d) { const char* v = getenv(k); return v ? atoi(v) : d; }
-    GemmTune() : mt(env("MQ_GEMM_MT", 0)), spec(env("MQ_GEMM_SPEC", 0)), big(env("MQ_GEMM_BIG", 0)) {}
+    GemmTune() : mt(env("MQ_GEMM_MT", 0)), persist(env("MQ_GEMM_PERSIST", 0)), big(env("MQ_GEMM_BIG", 0)), cgroup(env("MQ_GEMM_CGROUP", 8)), wide(env("MQ_GEMM_WIDE", 1)) {}
 };
 GemmTune g_tune;
 
@@ -227,14 +251,14 @@ int choose_mt(int M, int N) {
     return best;
 }
 
-template <int FLAGS, int MT, bool SPEC>
+template <int FLAGS, int MT, bool PERSIST>
 int launch_gemm_mt(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
                    const float* residual, void* out, int64_t ldc, int M, int N, int K, hipStream_t s) {
     constexpr int BM = 32 * MT;
     constexpr int LDS = 2 * (BM * BK * 2 + W_TILE_BYTES);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_kernel<FLAGS, MT, SPEC>,
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_kernel<FLAGS, MT, PERSIST>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) {
             mq_set_error("mq_gemm_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -244,9 +268,15 @@ int launch_gemm_mt(const void* A, int64_t lda, const void* W, int64_t ldw, const
     }
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     const int num_tiles = tiles_m * tiles_n;
-    hipLaunchKernelGGL((gemm_nt_kernel<FLAGS, MT, SPEC>), dim3(num_tiles), dim3(SPEC ? 512 : 256), LDS, s,
+    // L2 blocking only when there is something to block: more column tiles than one group and at least two row panels per XCD
+    const int cgroup = (g_tune.cgroup > 0 && tiles_n > g_tune.cgroup && tiles_m >= 16) ? g_tune.cgroup : 0;
+    const int band_rows = (tiles_m + 7) / 8;
+    // 16-byte bf16 epilogue stores need 16-B aligned rows
+    const int wide = (g_tune.wide && !(FLAGS & MQ_EPI_OUT_F32) && ldc % 8 == 0 && ((uintptr_t)out & 15) == 0) ? 1 : 0;
+    const int grid = PERSIST && num_tiles > RESIDENT_SLOTS ? RESIDENT_SLOTS : num_tiles;
+    hipLaunchKernelGGL((gemm_nt_kernel<FLAGS, MT, PERSIST>), dim3(grid), dim3(256), LDS, s,
                        (const bf16_t*)A, lda, (const bf16_t*)W, ldw, bias, residual, out, ldc,
-                       M, N, K, tiles_n, num_tiles);
+                       M, N, K, tiles_n, num_tiles, cgroup, band_rows, wide);
     MQ_CHECK_LAUNCH("mq_gemm_bf16");
     return MQ_OK;
 }
@@ -255,20 +285,21 @@ template <int FLAGS>
 int launch_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
                 const float* residual, void* out, int64_t ldc, int M, int N, int K, hipStream_t s) {
     const int force_mt = g_tune.mt;
-    const int spec = g_tune.spec;
+    const int persist = g_tune.persist;
     const int mt = force_mt ? force_mt : choose_mt(M, N);
     if (g_tune.big) return mq_launch_gemm_big<FLAGS>(g_tune.big, A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s);
 #define MQ_MT_CASE(T)                                                                                              \
     case T:                                                                                                        \
-        return spec ? launch_gemm_mt<FLAGS, T, true>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s)        \
-                    : launch_gemm_mt<FLAGS, T, false>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s)
+        return persist ? launch_gemm_mt<FLAGS, T, true>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s)     \
+                       : launch_gemm_mt<FLAGS, T, false>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s)
     switch (mt) {
         MQ_MT_CASE(2);
         MQ_MT_CASE(5);
-        MQ_MT_CASE(6);
+        case 6:  // the persistent form of the 192-row tile spills (256-VGPR cap at 2 workgroups per CU): plain form only
+            return launch_gemm_mt<FLAGS, 6, false>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s);
         default:
-            return spec ? launch_gemm_mt<FLAGS, 4, true>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s)
-                        : launch_gemm_mt<FLAGS, 4, false>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s);
+            return persist ? launch_gemm_mt<FLAGS, 4, true>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s)
+                           : launch_gemm_mt<FLAGS, 4, false>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s);
     }
 #undef MQ_MT_CASE
 }
@@ -306,13 +337,15 @@ extern "C" int mq_gemm_bf16(const void* d_A, int64_t lda, const void* d_W, int64
 }
 
 // Select a GEMM main-loop variant at run time (A/B benchmarking and parity tests of every variant in one process).
-// key: "gemm_mt" (0 = auto, else tile height in 32-row units), "gemm_spec", "gemm_big" (0 / 4 / 6 / 8).
+// key: "gemm_mt" (0 = auto, else tile height in 32-row units), "gemm_persist", "gemm_cgroup", "gemm_big" (0 / 4 / 6 / 8), "row_select".
 extern "C" int mq_tune(const char* key, int value) {
     MQ_CHECK_ARG(key, "mq_tune: null key");
     const std::string k(key);
     if (k == "gemm_mt") { g_tune.mt = value; mq_gemm_fp8_force_mt = value; }
-    else if (k == "gemm_spec") g_tune.spec = value;
+    else if (k == "gemm_persist") g_tune.persist = value;
     else if (k == "gemm_big") g_tune.big = value;
+    else if (k == "gemm_cgroup") g_tune.cgroup = value;
+    else if (k == "gemm_wide") g_tune.wide = value;
     else if (k == "row_select") mq_tower_row_select = value;
     else { mq_set_error("mq_tune: unknown key %s", key); return MQ_ERR_INVALID; }
     return MQ_OK;

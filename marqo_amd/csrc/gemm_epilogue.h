@@ -1,25 +1,31 @@
-// Shared epilogue of the bf16 MFMA GEMM kernels (gemm_bf16.hip, gemm_ring.hip).
+// Shared epilogue of the bf16 MFMA GEMM kernels (gemm_bf16.hip, gemm_big.hip).
 // Accumulator layout (operands are fed swapped, mfma(Wfrag, Afrag)): for sub-tile (mt, nt)
 //   D[i][j] = sum_k Wfrag[i][k] * Afrag[j][k]: column j = lane & 15 -> m, row i = 4*g + reg -> n,
-// so a lane owns out[m][n .. n+3]: bias / residual / out are 8- or 16-byte vector accesses.
+// so a lane owns out[m][n .. n+3]: bias / residual / fp32 out are 16-byte vector accesses.
+// bf16 out: a lane's 4 values are only 8 bytes, and the 4 stores of a row (nt = 0..3) each cover 32-B row segments.  With
+// WIDE the two 16-column blocks of a pair (nt, nt+1) are exchanged between the lanes 16 apart (v_permlane16_swap: odd
+// 16-lane rows of the first operand <-> even rows of the second), after which a lane holds 8 CONSECUTIVE n (16 bytes) and a
+// store instruction covers 64 contiguous bytes per row: half the store instructions for the same bytes (the store tail of a
+// K = 768 tile is issue-bound, cdna_hip_programming.md T21).
 #pragma once
 #include "common.h"
 
 template <int FLAGS, int MT>
 __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][4], const float* __restrict__ bias, const float* residual, void* out,
-                                              int64_t ldc, int M, int N, int wave_m0, int wave_n0, int l15, int g) {
+                                              int64_t ldc, int M, int N, int wave_m0, int wave_n0, int l15, int g, bool wide = false) {
+    constexpr bool BF16_OUT = !(FLAGS & MQ_EPI_OUT_F32);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int m = wave_m0 + mt * 16 + l15;
-        if (m >= M) continue;
+        const bool m_ok = m < M;
+        uint2 pk[4];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             const int n = wave_n0 + nt * 16 + g * 4;
-            if (n >= N) continue;
+            const bool ok = m_ok && n < N;
             f32x4 v = acc[mt][nt];
             if (FLAGS & MQ_EPI_BIAS) {
-                const f32x4 b = *(const f32x4*)(bias + n);
-                v += b;
+                if (n < N) v += *(const f32x4*)(bias + n);
             }
             if (FLAGS & MQ_EPI_GELU) {
 #pragma unroll
@@ -31,16 +37,27 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][4], const float* 
             }
             const int64_t o = (int64_t)m * ldc + n;
             if (FLAGS & MQ_EPI_RESIDUAL) {
-                const f32x4 rr = *(const f32x4*)(residual + o);
-                v += rr;
+                if (ok) v += *(const f32x4*)(residual + o);
             }
-            if (FLAGS & MQ_EPI_OUT_F32) {
-                *(f32x4*)((float*)out + o) = v;
+            if (!BF16_OUT) {
+                if (ok) *(f32x4*)((float*)out + o) = v;
             } else {
-                uint2 p;
-                p.x = pack_bf16x2(v[0], v[1]);
-                p.y = pack_bf16x2(v[2], v[3]);
-                *(uint2*)((bf16_t*)out + o) = p;
+                pk[nt].x = pack_bf16x2(v[0], v[1]);
+                pk[nt].y = pack_bf16x2(v[2], v[3]);
+                if (!wide && ok) *(uint2*)((bf16_t*)out + o) = pk[nt];
+            }
+        }
+        if (BF16_OUT && wide) {  // `wide` is wave-uniform: every lane takes part in the swaps
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                uint2 a = pk[2 * p], b = pk[2 * p + 1];
+                const auto r0 = __builtin_amdgcn_permlane16_swap(a.x, b.x, false, false);
+                const auto r1 = __builtin_amdgcn_permlane16_swap(a.y, b.y, false, false);
+                // lane now owns n = base .. base+7 with base = pair block + (g&1)*16 + (g>>1)*8, low half in (r0[0], r1[0])
+                const int n = wave_n0 + p * 32 + (g & 1) * 16 + (g >> 1) * 8;
+                bf16_t* dst = (bf16_t*)out + (int64_t)m * ldc + n;
+                if (m_ok && n + 8 <= N) *(uint4*)dst = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+                else if (m_ok && n < N) *(uint2*)dst = make_uint2(r0[0], r1[0]);  // N % 4 == 0: exactly the low half is in range
             }
         }
     }

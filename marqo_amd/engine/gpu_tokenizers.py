@@ -1,0 +1,257 @@
+"""Device-side tokenisation (K14): hash-table builders + thin wrappers over mq_tokenize_wordpiece / mq_tokenize_clip_bpe.
+
+The reference tokenises on the host (open_clip_model.py:277, hugging_face_model.py:179-185).  Here the host tokenisers of
+``engine/tokenizers.py`` stay the definition of record; for texts inside the device scope — printable ASCII + ``\\t \\n \\r``
+with no special-token spelling (and, for CLIP, no ``&`` that ``html.unescape`` could rewrite) — the same algorithms run on
+the GPU, one thread per text, and produce IDENTICAL ids (tests/test_gpu_tokenizers.py).  Every other text is tokenised by
+the host tokeniser and patched into the same id matrix, so callers see one result regardless of the route.
+
+The table builders are plain numpy (no GPU needed) so that the CPU test suite can feed the very same tables to the host
+build of the product algorithm (oracle/tokenize_host.cpp).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import re
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from marqo_amd import _lib as L
+from marqo_amd.engine.tokenizers import ClipBpeTokenizer, WordPieceTokenizer, _byte_to_unicode
+
+WP_ENTRY = np.dtype([("hash", "<u8"), ("id", "<i4"), ("off_len", "<u4")])
+BPE_ENTRY = np.dtype([("key", "<u4"), ("rank", "<u4"), ("merged", "<u4"), ("pad", "<u4")])
+assert WP_ENTRY.itemsize == 16 and BPE_ENTRY.itemsize == 16
+
+_FNV_OFFSET, _FNV_PRIME, _CONT_SEED, _M64 = 0xcbf29ce484222325, 0x100000001b3, 0x9e3779b97f4a7c15, (1 << 64) - 1
+MAX_WORD_CHARS_DEVICE = 100
+_SCOPE = re.compile(r"[\x20-\x7e\t\n\r]*")
+
+
+def _fnv(data: bytes, cont: bool) -> int:
+    h = _FNV_OFFSET ^ _CONT_SEED if cont else _FNV_OFFSET
+    for b in data:
+        h = ((h ^ b) * _FNV_PRIME) & _M64
+    return h
+
+
+def _pow2_at_least(n: int) -> int:
+    p = 1024
+    while p < n:
+        p *= 2
+    return p
+
+
+def build_wordpiece_table(tok: WordPieceTokenizer) -> Dict[str, object]:
+    """vocabulary -> open-addressing table (layout: csrc/tokenize_algo.h mq_wp_entry).  Only pieces that an in-scope word
+    can produce are stored: pure-ASCII strings of at most 127 bytes; '##x...' entries are continuation pieces."""
+    if tok.max_chars > MAX_WORD_CHARS_DEVICE:
+        raise ValueError(f"max_chars_per_word {tok.max_chars} > {MAX_WORD_CHARS_DEVICE} is not supported on the device")
+    items: List[Tuple[bytes, bool, int]] = []
+    for s, idx in tok.vocab.items():
+        if not s.isascii():
+            continue
+        cont = s.startswith("##") and len(s) > 2
+        data = (s[2:] if cont else s).encode("ascii")
+        if 0 < len(data) <= 127:
+            items.append((data, cont, int(idx)))
+    n_slots = _pow2_at_least(2 * len(items) + 1)
+    slots = np.zeros(n_slots, dtype=WP_ENTRY)
+    slots["id"] = -1
+    pool = bytearray()
+    mask = n_slots - 1
+    for data, cont, idx in items:
+        h = _fnv(data, cont)
+        slot = ((h ^ (h >> 32)) & 0xffffffff) & mask
+        while slots["id"][slot] >= 0:
+            slot = (slot + 1) & mask
+        slots[slot] = (h, idx, (len(pool) << 8) | (int(cont) << 7) | len(data))
+        pool += data
+    if len(pool) >= 1 << 24:
+        raise ValueError("vocabulary string pool too large for the 24-bit offsets")
+    return dict(slots=slots, pool=np.frombuffer(bytes(pool) + b"\0" * 16, dtype=np.uint8).copy(), n_slots=n_slots,
+                unk_id=tok.unk_id, cls_id=tok.cls_id, sep_id=tok.sep_id, pad_id=tok.pad_id, lower=int(bool(tok.lower)),
+                max_word_chars=int(tok.max_chars))
+
+
+def build_bpe_table(tok: ClipBpeTokenizer) -> Dict[str, object]:
+    """merges -> pair table (layout: mq_bpe_entry).  Symbols are vocabulary ids; python-dict semantics are kept for
+    duplicated merges (the LAST rank wins) and duplicated vocabulary strings (the LAST id wins)."""
+    if tok.vocab_size > 65535:
+        raise ValueError("CLIP BPE device path needs vocabulary ids < 65536")
+    enc = tok.encoder
+    pairs: Dict[int, Tuple[int, int]] = {}
+    for (x, y), r in tok.rank.items():
+        pairs[(enc[x] << 16) | enc[y]] = (r, enc[x + y])
+    n_slots = _pow2_at_least(2 * len(pairs) + 1)
+    slots = np.zeros(n_slots, dtype=BPE_ENTRY)
+    slots["key"] = 0xffffffff
+    mask = n_slots - 1
+    for key, (r, m) in pairs.items():
+        slot = ((((key * 0x9e3779b1) & 0xffffffff) >> 7) & mask)
+        while slots["key"][slot] != 0xffffffff:
+            slot = (slot + 1) & mask
+        slots[slot] = (key, r, m, 0)
+    b2u = _byte_to_unicode()
+    byte_id = np.array([enc[b2u[b]] for b in range(256)], dtype=np.uint16)
+    byte_end_id = np.array([enc[b2u[b] + "</w>"] for b in range(256)], dtype=np.uint16)
+    return dict(slots=slots, byte_id=byte_id, byte_end_id=byte_end_id, n_slots=n_slots, sot_id=tok.sot_id, eot_id=tok.eot_id,
+                lower=int(bool(tok.lower)))
+
+
+def pack_texts(texts: Sequence[str]) -> Tuple[np.ndarray, np.ndarray]:
+    """in-scope (ASCII) texts -> (uint8 blob, int64 offsets [n+1])"""
+    blob = "".join(texts).encode("ascii")
+    offsets = np.zeros(len(texts) + 1, dtype=np.int64)
+    np.cumsum([len(t) for t in texts], out=offsets[1:])
+    return np.frombuffer(blob + b"\0", dtype=np.uint8), offsets
+
+
+def wordpiece_in_scope(tok: WordPieceTokenizer, text: str) -> bool:
+    return _SCOPE.fullmatch(text) is not None and ("[" not in text or not any(s in text for s in tok._specials))
+
+
+def clip_in_scope(tok: ClipBpeTokenizer, text: str) -> bool:
+    if _SCOPE.fullmatch(text) is None or "&" in text:
+        return False
+    if "<" in text:
+        low = text.lower()
+        return tok.SOT not in low and tok.EOT not in low
+    return True
+
+
+class _DeviceTokenizerBase:
+    def __init__(self, device: str):
+        self.device = torch.device(device)
+        if self.device.type != "cuda" or not torch.cuda.is_available():
+            raise L.MarqoHipUnavailableError(f"device tokenisation needs a cuda device (got {device!r}); there is no CPU fallback here — "
+                                             f"use the host tokenisers of engine/tokenizers.py")
+        self.lib = L.load()
+        self._keep: List[torch.Tensor] = []
+
+    def _up(self, arr: np.ndarray) -> torch.Tensor:
+        t = torch.from_numpy(np.ascontiguousarray(arr).view(np.uint8).reshape(-1)).to(self.device)
+        self._keep.append(t)
+        return t
+
+    def _stage(self, texts: Sequence[str]):
+        blob, offsets = pack_texts(texts)
+        d_blob = torch.from_numpy(blob).pin_memory().to(self.device, non_blocking=True)
+        d_off = torch.from_numpy(offsets).pin_memory().to(self.device, non_blocking=True)
+        return d_blob, d_off
+
+
+class DeviceWordPieceTokenizer(_DeviceTokenizerBase):
+    """BERT WordPiece on the GPU for in-scope texts; `host` (a WordPieceTokenizer) handles the rest and defines the result."""
+
+    def __init__(self, host: WordPieceTokenizer, device: str):
+        super().__init__(device)
+        self.host = host
+        t = build_wordpiece_table(host)
+        self.vocab = L.WordPieceVocab(d_slots=self._up(t["slots"]).data_ptr(), d_pool=self._up(t["pool"]).data_ptr(), n_slots=t["n_slots"],
+                                      unk_id=t["unk_id"], cls_id=t["cls_id"], sep_id=t["sep_id"], pad_id=t["pad_id"], lower=t["lower"],
+                                      max_word_chars=t["max_word_chars"])
+
+    def encode_device(self, texts: Sequence[str], max_length: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        """-> (ids int32 [n, max_length] on device, right-padded with pad_id; lengths int64 [n] on host)"""
+        n = len(texts)
+        ids = torch.full((n, max_length), self.host.pad_id, dtype=torch.int32, device=self.device)
+        lens = torch.zeros(n, dtype=torch.int64)
+        if n == 0:
+            return ids, lens
+        on_dev = [i for i, t in enumerate(texts) if wordpiece_in_scope(self.host, t)]
+        dev_set = set(on_dev)
+        if on_dev:
+            sel = [texts[i] for i in on_dev]
+            d_blob, d_off = self._stage(sel)
+            m = len(sel)
+            d_ids = ids if m == n else torch.empty(m, max_length, dtype=torch.int32, device=self.device)
+            d_meta = torch.empty(2, m, dtype=torch.int32, device=self.device)
+            with torch.cuda.device(self.device):
+                L.check(self.lib.mq_tokenize_wordpiece(C.byref(self.vocab), d_blob.data_ptr(), d_off.data_ptr(), m, max_length, d_ids.data_ptr(),
+                                                       max_length, d_meta[0].data_ptr(), d_meta[1].data_ptr(),
+                                                       torch.cuda.current_stream(self.device).cuda_stream), "mq_tokenize_wordpiece")
+            meta = d_meta.cpu()
+            if bool((meta[1] != 0).any()):  # defensive: the kernel disagreed with the host-side scope test
+                bad = [on_dev[j] for j in torch.nonzero(meta[1]).flatten().tolist()]
+                dev_set.difference_update(bad)
+            idx = torch.tensor(on_dev, dtype=torch.int64)
+            lens[idx] = meta[0].to(torch.int64)
+            if m != n:
+                ids[idx.to(self.device)] = d_ids
+        rest = [i for i in range(n) if i not in dev_set]
+        if rest:
+            enc = [self.host.encode(texts[i], max_length) for i in rest]
+            block = torch.full((len(rest), max_length), self.host.pad_id, dtype=torch.int32)
+            for j, e in enumerate(enc):
+                block[j, :len(e)] = torch.tensor(e, dtype=torch.int32)
+                lens[rest[j]] = len(e)
+            ids[torch.tensor(rest, device=self.device)] = block.to(self.device)
+        return ids, lens
+
+    def __call__(self, texts, max_length: Optional[int] = None) -> Dict[str, np.ndarray]:
+        """drop-in for WordPieceTokenizer.__call__ (padding to the longest, truncation)"""
+        if isinstance(texts, str):
+            texts = [texts]
+        cap = max_length if max_length is not None else 2 + max((len(t) for t in texts), default=0)
+        ids, lens = self.encode_device(texts, cap)
+        S = int(lens.max()) if len(texts) else 0
+        out = ids[:, :S].cpu().to(torch.int64).numpy()
+        mask = (np.arange(S)[None, :] < lens.numpy()[:, None]).astype(np.int64)
+        return {"input_ids": out, "attention_mask": mask}
+
+
+class DeviceClipBpeTokenizer(_DeviceTokenizerBase):
+    """CLIP byte-level BPE on the GPU for in-scope texts; `host` (a ClipBpeTokenizer) handles the rest."""
+
+    def __init__(self, host: ClipBpeTokenizer, device: str):
+        super().__init__(device)
+        self.host = host
+        t = build_bpe_table(host)
+        self.vocab = L.ClipBpeVocab(d_slots=self._up(t["slots"]).data_ptr(), d_byte_id=self._up(t["byte_id"]).data_ptr(),
+                                    d_byte_end_id=self._up(t["byte_end_id"]).data_ptr(), n_slots=t["n_slots"], sot_id=t["sot_id"],
+                                    eot_id=t["eot_id"], lower=t["lower"])
+
+    def encode_device(self, texts: Sequence[str], context_length: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """-> (ids int32 [n, ctx] on device, zero padded; lengths int64 [n] on host = SOT..EOT)"""
+        ctx = context_length or self.host.context_length
+        n = len(texts)
+        ids = torch.zeros(n, ctx, dtype=torch.int32, device=self.device)
+        lens = torch.zeros(n, dtype=torch.int64)
+        if n == 0:
+            return ids, lens
+        on_dev = [i for i, t in enumerate(texts) if clip_in_scope(self.host, t)]
+        dev_set = set(on_dev)
+        if on_dev:
+            sel = [texts[i] for i in on_dev]
+            d_blob, d_off = self._stage(sel)
+            m = len(sel)
+            d_ids = ids if m == n else torch.empty(m, ctx, dtype=torch.int32, device=self.device)
+            d_meta = torch.empty(2, m, dtype=torch.int32, device=self.device)
+            with torch.cuda.device(self.device):
+                L.check(self.lib.mq_tokenize_clip_bpe(C.byref(self.vocab), d_blob.data_ptr(), d_off.data_ptr(), m, ctx, d_ids.data_ptr(),
+                                                      d_meta[0].data_ptr(), d_meta[1].data_ptr(),
+                                                      torch.cuda.current_stream(self.device).cuda_stream), "mq_tokenize_clip_bpe")
+            meta = d_meta.cpu()
+            if bool((meta[1] != 0).any()):  # e.g. a pre-token longer than the device scratch
+                bad = [on_dev[j] for j in torch.nonzero(meta[1]).flatten().tolist()]
+                dev_set.difference_update(bad)
+            idx = torch.tensor(on_dev, dtype=torch.int64)
+            lens[idx] = meta[0].to(torch.int64)
+            if m != n:
+                ids[idx.to(self.device)] = d_ids
+        rest = [i for i in range(n) if i not in dev_set]
+        if rest:
+            block = torch.from_numpy(self.host([texts[i] for i in rest], ctx)).to(torch.int32)
+            lens[torch.tensor(rest)] = block.argmax(dim=1).to(torch.int64) + 1
+            ids[torch.tensor(rest, device=self.device)] = block.to(self.device)
+        return ids, lens
+
+    def __call__(self, texts, context_length: Optional[int] = None) -> np.ndarray:
+        """drop-in for ClipBpeTokenizer.__call__: int64 [n, ctx] on the host"""
+        if isinstance(texts, str):
+            texts = [texts]
+        ids, _ = self.encode_device(texts, context_length)
+        return ids.cpu().to(torch.int64).numpy()

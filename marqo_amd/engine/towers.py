@@ -297,6 +297,39 @@ class _TextTowerBase(_TowerBase):
         """small host -> device copy through pinned memory (a pageable copy would synchronise the stream)"""
         return t.pin_memory().to(self.device, non_blocking=True)
 
+    def _encode_device(self, d_ids: Tensor, lengths: Tensor, max_len: int, normalize: bool, clip: bool) -> Tensor:
+        """device-resident right-padded ids + host lengths -> embeddings; packing to the towers' layout on the GPU"""
+        if d_ids.ndim != 2 or d_ids.dtype != torch.int32 or d_ids.device != self.device:
+            raise ValueError(f"expected int32 [n, S] ids on {self.device}, got {d_ids.dtype} {tuple(d_ids.shape)} on {d_ids.device}")
+        d_ids = d_ids.contiguous()
+        n, S = d_ids.shape
+        lengths = lengths.detach().to("cpu", torch.int64)
+        if lengths.shape != (n,) or (n and (int(lengths.min()) < 1 or int(lengths.max()) > min(S, max_len))):
+            raise ValueError(f"lengths must be [n] within [1, {min(S, max_len)}]")
+        out_dim = self.arch.out_dim if clip else self.arch.width
+        out = torch.empty(n, out_dim, dtype=torch.float32, device=self.device)
+        with self._lock, torch.cuda.device(self.device):
+            for a, b in self._chunks(lengths):
+                cu = torch.zeros(b - a + 1, dtype=torch.int32)
+                cu[1:] = lengths[a:b].cumsum(0).to(torch.int32)
+                rows, nseq = int(cu[-1]), b - a
+                d_cu = self._to_device(cu)
+                d_packed = torch.empty(rows, dtype=torch.int32, device=self.device)
+                L.check(self.lib.mq_pack_ids(d_ids[a:b].data_ptr(), S, d_cu.data_ptr(), nseq, d_packed.data_ptr(), self._stream()), "mq_pack_ids")
+                if clip:
+                    need = self.lib.mq_clip_text_workspace_bytes(C.byref(self.cfg), rows, nseq)
+                    ws = self._workspace(need)
+                    L.check(self.lib.mq_encode_clip_text(C.byref(self.cfg), C.byref(self.w), d_packed.data_ptr(), d_cu.data_ptr(), cu.data_ptr(),
+                                                         nseq, 0, out[a:b].data_ptr(), 1 if normalize else 0, ws.data_ptr(), ws.numel(),
+                                                         self._stream()), "mq_encode_clip_text")
+                else:
+                    need = self.lib.mq_bert_workspace_bytes(C.byref(self.cfg), rows, nseq)
+                    ws = self._workspace(need)
+                    L.check(self.lib.mq_encode_bert(C.byref(self.cfg), C.byref(self.w), d_packed.data_ptr(), d_cu.data_ptr(), cu.data_ptr(), nseq,
+                                                    out[a:b].data_ptr(), 1 if normalize else 0, ws.data_ptr(), ws.numel(), self._stream()),
+                            "mq_encode_bert")
+        return out
+
 
 class ClipTextTower(_TextTowerBase):
     """CLIP text tower (open_clip `token_embedding`, `transformer.*`, `ln_final`, `text_projection`)."""
@@ -349,6 +382,12 @@ class ClipTextTower(_TextTowerBase):
                                                      1 if normalize else 0, ws.data_ptr(), ws.numel(), self._stream()),
                         "mq_encode_clip_text")
         return out
+
+
+    def encode_device(self, d_ids: Tensor, lengths: Tensor, normalize: bool = True) -> Tensor:
+        """ids already on the device (engine/gpu_tokenizers.py): int32 [n, S] rows SOT ... EOT 0 ..., lengths int64 [n] on the
+        host = SOT..EOT length.  Same as encode_ids(pack=True), but the packing runs on the GPU (mq_pack_ids)."""
+        return self._encode_device(d_ids, lengths, self.arch.ctx, normalize, clip=True)
 
 
 class BertTower(_TextTowerBase):
@@ -422,3 +461,8 @@ class BertTower(_TextTowerBase):
                                                 cu.data_ptr(), nseq, out[a:b].data_ptr(), 1 if normalize else 0,
                                                 ws.data_ptr(), ws.numel(), self._stream()), "mq_encode_bert")
         return out
+
+    def encode_device(self, d_ids: Tensor, lengths: Tensor, normalize: bool = True) -> Tensor:
+        """ids already on the device (engine/gpu_tokenizers.py): int32 [n, S] rows [CLS] ... [SEP] pad..., lengths int64 [n] on the
+        host.  Same as encode_ids with the right-padded mask those lengths imply; packing runs on the GPU."""
+        return self._encode_device(d_ids, lengths, self.arch.max_pos, normalize, clip=False)

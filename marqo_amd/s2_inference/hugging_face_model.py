@@ -112,6 +112,12 @@ class HuggingFaceModel(AbstractEmbeddingModel):
         self.arch = arch
         self._model = towers.BertTower(arch, sd, self.device, pooling=pooling)
         self._pooling_func = pooling
+        # K14: WordPiece on the device for ASCII texts (identical ids; the host tokeniser stays the definition of record and
+        # handles every other text).  MARQO_AMD_HOST_TOKENIZER=1 keeps everything on the host.
+        self._device_tokenizer = None
+        if isinstance(self._tokenizer, WordPieceTokenizer) and os.environ.get("MARQO_AMD_HOST_TOKENIZER", "0") != "1":
+            from marqo_amd.engine.gpu_tokenizers import DeviceWordPieceTokenizer
+            self._device_tokenizer = DeviceWordPieceTokenizer(self._tokenizer, self.device)
 
     @staticmethod
     def _do_lower_case(directory: str) -> bool:
@@ -131,6 +137,9 @@ class HuggingFaceModel(AbstractEmbeddingModel):
             sentence = [sentence]
         if self._model is None:
             self.load()
+        if getattr(self, "_device_tokenizer", None) is not None:
+            d_ids, lens = self._device_tokenizer.encode_device(sentence, self.model_properties.tokens)
+            return self._model.encode_device(d_ids, lens, normalize=bool(normalize)).cpu().numpy()
         tok = self._tokenizer(sentence, max_length=self.model_properties.tokens)
         ids = torch.from_numpy(tok["input_ids"])
         mask = torch.from_numpy(tok["attention_mask"])

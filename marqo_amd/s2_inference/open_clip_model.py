@@ -175,6 +175,11 @@ class OPEN_CLIP(AbstractCLIPModel):
         self.text = towers.ClipTextTower(self.text_arch, sd, self.device)
         self.model = (self.vision, self.text)
         self.tokenizer = self._load_tokenizer(ckpt_dir)
+        # K14: byte-level BPE on the device for ASCII texts (identical ids; the host tokeniser handles the rest)
+        self._device_tokenizer = None
+        if isinstance(self.tokenizer, ClipBpeTokenizer) and os.environ.get("MARQO_AMD_HOST_TOKENIZER", "0") != "1":
+            from marqo_amd.engine.gpu_tokenizers import DeviceClipBpeTokenizer
+            self._device_tokenizer = DeviceClipBpeTokenizer(self.tokenizer, self.device)
         self._ImagePreprocessor = ImagePreprocessor
         self.preprocess = self._preprocess_one
 
@@ -263,6 +268,9 @@ class OPEN_CLIP(AbstractCLIPModel):
     def encode_text(self, sentence: Union[str, List[str]], normalize=True) -> np.ndarray:
         if self.model is None:
             self.load()
+        if getattr(self, "_device_tokenizer", None) is not None:
+            d_ids, lens = self._device_tokenizer.encode_device([sentence] if isinstance(sentence, str) else list(sentence))
+            return self._convert_output(self.text.encode_device(d_ids, lens, normalize=bool(normalize)))
         ids = self.tokenizer(sentence)
         ids = torch.as_tensor(np.asarray(ids))
         return self._convert_output(self.text.encode_ids(ids, normalize=bool(normalize)))

@@ -1,0 +1,45 @@
+// ORACLE-SIDE TEST SHIM — test infrastructure only, never loaded by the product.
+// Compiles the product's tokenisation algorithms (marqo_amd/csrc/tokenize_algo.h — the very functions the HIP kernels
+// instantiate) for the HOST with g++, so that tests/test_gpu_tokenizers.py can pin them without a GPU against the Python
+// tokenisers (marqo_amd/engine/tokenizers.py), which tests/test_tokenizers.py pins against `transformers`.
+#include <stdint.h>
+#include "../marqo_amd/csrc/tokenize_algo.h"
+
+extern "C" {
+
+void tokhost_wordpiece(const void* slots, const uint8_t* pool, uint32_t n_slots, int32_t unk_id, int32_t cls_id, int32_t sep_id,
+                       int32_t pad_id, int32_t lower, int32_t max_word_chars, const uint8_t* text, const int64_t* offsets, int64_t n,
+                       int32_t max_length, int32_t* ids, int64_t ld, int32_t* lens, int32_t* status) {
+    mq_wp_table T;
+    T.slots = (const mq_wp_entry*)slots; T.pool = pool; T.mask = n_slots - 1;
+    T.unk_id = unk_id; T.cls_id = cls_id; T.sep_id = sep_id; T.pad_id = pad_id; T.lower = lower; T.max_word_chars = max_word_chars;
+    uint8_t word[MQ_WP_MAX_WORD];
+    const int max_tokens = max_length - 2 > 0 ? max_length - 2 : 0;
+    for (int64_t t = 0; t < n; ++t) {
+        int32_t* row = ids + t * ld;
+        int st;
+        const int cnt = mq_wordpiece_text(T, text + offsets[t], (int)(offsets[t + 1] - offsets[t]), max_tokens, row + 1, 1, word, 1, &st);
+        row[0] = cls_id;
+        row[1 + cnt] = sep_id;
+        for (int64_t j = cnt + 2; j < ld; ++j) row[j] = pad_id;
+        lens[t] = st == MQ_TOK_OK ? cnt + 2 : 0;
+        status[t] = st;
+    }
+}
+
+void tokhost_clip_bpe(const void* slots, const uint16_t* byte_id, const uint16_t* byte_end_id, uint32_t n_slots, int32_t sot_id,
+                      int32_t eot_id, int32_t lower, const uint8_t* text, const int64_t* offsets, int64_t n, int32_t ctx, int32_t* ids,
+                      int32_t* lens, int32_t* status) {
+    mq_bpe_table T;
+    T.slots = (const mq_bpe_entry*)slots; T.byte_id = byte_id; T.byte_end_id = byte_end_id; T.mask = n_slots - 1;
+    T.sot_id = sot_id; T.eot_id = eot_id; T.lower = lower;
+    uint16_t sym[MQ_BPE_MAX_SYMS];
+    for (int64_t t = 0; t < n; ++t) {
+        int st;
+        const int cnt = mq_clip_bpe_text(T, text + offsets[t], (int)(offsets[t + 1] - offsets[t]), ctx, ids + t * ctx, 1, sym, 1, &st);
+        lens[t] = st == MQ_TOK_OK ? cnt : 0;
+        status[t] = st;
+    }
+}
+
+}  // extern "C"

@@ -1,6 +1,6 @@
-"""Every GEMM main-loop variant (2-stage, wave-specialised, CU-sized tile) x tile height must give the same result as a
-fp32 reference on the bf16-rounded operands, on ragged shapes, with every fused epilogue; repeated launches screen for
-LDS-ring races (a racy pipeline shows up as run-to-run differences)."""
+"""Every GEMM variant (2-stage, persistent tile loop with cross-tile prefetch, L2-blocked tile order, widened bf16 stores,
+CU-sized tile) x tile height must give the same result as a fp32 reference on the bf16-rounded operands, on ragged shapes,
+with every fused epilogue; repeated launches screen for LDS-ring races (a racy pipeline shows up as run-to-run differences)."""
 import ctypes as C
 
 import pytest
@@ -10,8 +10,15 @@ from marqo_amd import _lib as L
 
 pytestmark = pytest.mark.gpu
 
-VARIANTS = [dict(gemm_spec=0), dict(gemm_spec=1)]
-SHAPES = [(50, 64, 64), (257, 768, 128), (1000, 132, 192), (4097, 2304, 768), (12800, 768, 3072), (333, 3072, 64), (16, 4, 64)]
+VARIANTS = [dict(gemm_persist=0, gemm_cgroup=0, gemm_wide=0), dict(gemm_persist=1, gemm_cgroup=0, gemm_wide=0),
+            dict(gemm_persist=0, gemm_cgroup=8, gemm_wide=1), dict(gemm_persist=1, gemm_cgroup=4, gemm_wide=1)]
+DEFAULTS = dict(gemm_mt=0, gemm_persist=0, gemm_cgroup=8, gemm_wide=1, gemm_big=0)
+
+
+def _vid(v):
+    return "p%dc%dw%d" % (v["gemm_persist"], v["gemm_cgroup"], v["gemm_wide"])
+SHAPES = [(50, 64, 64), (257, 768, 128), (1000, 132, 192), (4097, 2304, 768), (12800, 768, 3072), (333, 3072, 64), (16, 4, 64),
+          (20000, 1160, 64), (3000, 1288, 128)]
 
 
 def _tune(lib, **kw):
@@ -29,13 +36,13 @@ def _gemm(lib, A, W, bias, res, flags):
     return out
 
 
-@pytest.mark.parametrize("variant", VARIANTS, ids=lambda v: "spec%d" % v["gemm_spec"])
+@pytest.mark.parametrize("variant", VARIANTS, ids=_vid)
 @pytest.mark.parametrize("mt", [0, 2, 4, 5, 6])
 def test_variant_matches_reference(variant, mt):
     lib = L.load()
     try:
         _tune(lib, gemm_mt=mt, **variant)
-        g = torch.Generator(device="cuda").manual_seed(mt * 7 + variant["gemm_spec"])
+        g = torch.Generator(device="cuda").manual_seed(mt * 7 + variant["gemm_persist"])
         for (M, N, K) in SHAPES:
             A = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
             W = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).to(torch.bfloat16)
@@ -50,10 +57,10 @@ def test_variant_matches_reference(variant, mt):
                 err = (out - want).abs().max().item() / (want.abs().max().item() + 1e-6)
                 assert err < tol, (variant, mt, (M, N, K), flags, err)
     finally:
-        _tune(lib, gemm_mt=0, gemm_spec=0, gemm_big=0)
+        _tune(lib, **DEFAULTS)
 
 
-@pytest.mark.parametrize("variant", VARIANTS[1:], ids=lambda v: "spec%d" % v["gemm_spec"])
+@pytest.mark.parametrize("variant", VARIANTS[1:], ids=_vid)
 def test_variant_is_bitwise_stable_and_equal_to_baseline(variant):
     """same k-order of MFMAs in every variant -> bit-identical to the 2-stage kernel; 25 launches under load screen races"""
     lib = L.load()
@@ -63,14 +70,14 @@ def test_variant_is_bitwise_stable_and_equal_to_baseline(variant):
             A = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
             W = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).to(torch.bfloat16)
             for mt in (0, 4, 6):
-                _tune(lib, gemm_mt=mt, gemm_spec=0)
+                _tune(lib, gemm_mt=mt, **VARIANTS[0])
                 base = _gemm(lib, A, W, None, None, L.MQ_EPI_OUT_F32)
                 _tune(lib, gemm_mt=mt, **variant)
                 for _ in range(25):
                     out = _gemm(lib, A, W, None, None, L.MQ_EPI_OUT_F32)
                     assert torch.equal(out, base), (variant, mt, (M, N, K))
     finally:
-        _tune(lib, gemm_mt=0, gemm_spec=0, gemm_big=0)
+        _tune(lib, **DEFAULTS)
 
 
 @pytest.mark.parametrize("big", [4, 6, 8])
@@ -92,4 +99,4 @@ def test_cu_sized_tile_variant(big):
                 assert torch.equal(_gemm(lib, A, W, bias, res, L.MQ_EPI_BIAS | L.MQ_EPI_RESIDUAL | L.MQ_EPI_OUT_F32), base), (big, M, N, K)
             assert torch.equal(_gemm(lib, A, W, bias, res, L.MQ_EPI_BIAS | L.MQ_EPI_GELU), base_g)
     finally:
-        _tune(lib, gemm_mt=0, gemm_spec=0, gemm_big=0)
+        _tune(lib, **DEFAULTS)

@@ -1,0 +1,207 @@
+"""K14 — tokenisation on the device.
+
+CPU part (not gpu): the PRODUCT algorithm source (marqo_amd/csrc/tokenize_algo.h, the functions the HIP kernels instantiate)
+is compiled for the host by oracle/Makefile (oracle/tokenize_host.cpp) and pinned, with the product's own table builders,
+against the Python tokenisers (which tests/test_tokenizers.py pins against `transformers`) and against `transformers`
+directly — on fixed edge cases and on seeded random ASCII texts.
+GPU part: the kernels through the C ABI give the same ids, and the routing wrapper (device for in-scope texts, host for the
+rest) equals the host tokeniser on every text."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from marqo_amd.engine import gpu_tokenizers as GT
+from marqo_amd.engine.tokenizers import ClipBpeTokenizer, WordPieceTokenizer
+from tests.test_tokenizers import CORPUS, SENTENCES, _bert_vocab, _train_bpe
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+ASCII_CASES = [
+    "a photo of a cat", "The Quick  Brown fox, jumps over the lazy dog!", "it's built for images and text... isn't it?",
+    "don't you'll we've they're I'M he'D 'tis 'station rock'n'roll ''s !'s 's's 1's x'", "'", "''", " ' s", "'S 'T 'RE 'Ve 'LL",
+    "query: how much protein should a female eat", "", " ", "\t\n\r", "unseenwordzzz qqq 1234567890 007", "tab\tand\nnewline   spaces",
+    "word " * 200, "x" * 90, "y" * 101 + " z", "a" * 96 + "!", "hello_world foo-bar (baz) [qux] {quux} <tag> #hash ##double @at",
+    "UPPER lower MiXeD 123abc abc123 1a2b3c", "...!!!???", "a.b,c;d:e!f?g", "trailing space ", " leading", "the" * 30,
+    "jumps jumping jumped photograph photographs synthetic documents", "$100 50% 3.14 1,000 a+b=c a/b\\c ~tilde^caret`tick|pipe",
+]
+
+
+def _random_texts(seed, n, alphabet=None):
+    rng = np.random.default_rng(seed)
+    words = [w for w in CORPUS if w.isascii()] + ["it's", "don't", "we'll", "x", "zzz", "Photo", "DOG!", "(cat)", "1234", "a1b2", "'re", "''",
+                                                    "jumps", "photographs", "unseenword", "q" * 40, "##x", "#", "&amp", "e-mail", "U.S.A."]
+    seps = [" ", " ", " ", "  ", "\t", "\n", ", ", ".", "! ", "'", "-"]
+    out = []
+    for _ in range(n):
+        k = int(rng.integers(0, 40))
+        s = "".join(words[int(rng.integers(len(words)))] + seps[int(rng.integers(len(seps)))] for _ in range(k))
+        if rng.random() < 0.3:  # raw printable noise
+            s += "".join(chr(int(c)) for c in rng.integers(0x20, 0x7f, size=int(rng.integers(1, 30))))
+        out.append(s)
+    return out
+
+
+@pytest.fixture(scope="module")
+def tokhost():
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
+    lib = C.CDLL(os.path.join(ROOT, "oracle", "_build", "libtokhost.so"))
+    return lib
+
+
+@pytest.fixture(scope="module")
+def bert_tok():
+    return WordPieceTokenizer(_bert_vocab())
+
+
+@pytest.fixture(scope="module")
+def clip_tok():
+    return ClipBpeTokenizer(_train_bpe(CORPUS, 150), context_length=77)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _host_wordpiece(lib, tok, texts, max_length):
+    t = GT.build_wordpiece_table(tok)
+    blob, off = GT.pack_texts(texts)
+    n = len(texts)
+    ids = np.zeros((n, max_length), np.int32)
+    lens, status = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    lib.tokhost_wordpiece(_p(t["slots"]), _p(t["pool"]), C.c_uint32(t["n_slots"]), t["unk_id"], t["cls_id"], t["sep_id"], t["pad_id"],
+                          t["lower"], t["max_word_chars"], _p(blob), _p(off), C.c_int64(n), max_length, _p(ids), C.c_int64(max_length),
+                          _p(lens), _p(status))
+    return ids, lens, status
+
+
+def _host_clip(lib, tok, texts, ctx):
+    t = GT.build_bpe_table(tok)
+    blob, off = GT.pack_texts(texts)
+    n = len(texts)
+    ids = np.zeros((n, ctx), np.int32)
+    lens, status = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    lib.tokhost_clip_bpe(_p(t["slots"]), _p(t["byte_id"]), _p(t["byte_end_id"]), C.c_uint32(t["n_slots"]), t["sot_id"], t["eot_id"], t["lower"],
+                         _p(blob), _p(off), C.c_int64(n), ctx, _p(ids), _p(lens), _p(status))
+    return ids, lens, status
+
+
+def test_scope_routing(bert_tok, clip_tok):
+    assert GT.wordpiece_in_scope(bert_tok, "plain ascii, with punct!") and GT.clip_in_scope(clip_tok, "plain ascii <b> 'quoted'")
+    for bad in ("naïve", "東京", "bell\x07", "del\x7f", "vt\x0b"):
+        assert not GT.wordpiece_in_scope(bert_tok, bad) and not GT.clip_in_scope(clip_tok, bad)
+    assert not GT.wordpiece_in_scope(bert_tok, "the fox [SEP] dog") and GT.wordpiece_in_scope(bert_tok, "the fox [sep] dog [x]")
+    assert not GT.clip_in_scope(clip_tok, "fish &amp; chips") and not GT.clip_in_scope(clip_tok, "x <START_OF_TEXT> y")
+
+
+@pytest.mark.parametrize("max_length", [512, 16, 3, 2])
+def test_wordpiece_algorithm_matches_python_tokenizer(tokhost, bert_tok, max_length):
+    texts = [t for t in ASCII_CASES + _random_texts(1, 300) if GT.wordpiece_in_scope(bert_tok, t)]
+    assert len(texts) > 250
+    ids, lens, status = _host_wordpiece(tokhost, bert_tok, texts, max_length)
+    assert (status == 0).all()
+    for i, t in enumerate(texts):
+        ref = bert_tok.encode(t, max_length)
+        assert lens[i] == len(ref) and ids[i, :lens[i]].tolist() == ref, repr(t)
+        assert (ids[i, lens[i]:] == bert_tok.pad_id).all()
+
+
+def test_wordpiece_algorithm_matches_transformers(tokhost, bert_tok):
+    from transformers import BertTokenizer
+    hf = BertTokenizer(vocab=_bert_vocab(), do_lower_case=True)
+    texts = [t for t in ASCII_CASES + _random_texts(2, 100) if GT.wordpiece_in_scope(bert_tok, t)]
+    ids, lens, _ = _host_wordpiece(tokhost, bert_tok, texts, 64)
+    for i, t in enumerate(texts):
+        assert ids[i, :lens[i]].tolist() == hf(t, truncation=True, max_length=64)["input_ids"], repr(t)
+
+
+def test_wordpiece_cased_vocab(tokhost):
+    vocab = {t: i for i, t in enumerate(["[PAD]", "[UNK]", "[CLS]", "[SEP]", "The", "the", "Fox", "fox", "##es", "F", "##ox"])}
+    tok = WordPieceTokenizer(vocab, do_lower_case=False)
+    texts = ["The fox Foxes the Fox", "THE FOX"]
+    ids, lens, _ = _host_wordpiece(tokhost, tok, texts, 32)
+    for i, t in enumerate(texts):
+        assert ids[i, :lens[i]].tolist() == tok.encode(t, 32)
+
+
+def test_out_of_scope_bytes_are_flagged(tokhost, bert_tok, clip_tok):
+    blob = np.frombuffer("ok text\0caf\xc3\xa9 x\0".encode("latin1"), dtype=np.uint8)
+    off = np.array([0, 7, 8 + 6], dtype=np.int64)
+    t = GT.build_wordpiece_table(bert_tok)
+    ids, lens, status = np.zeros((2, 16), np.int32), np.zeros(2, np.int32), np.zeros(2, np.int32)
+    tokhost.tokhost_wordpiece(_p(t["slots"]), _p(t["pool"]), C.c_uint32(t["n_slots"]), t["unk_id"], t["cls_id"], t["sep_id"], t["pad_id"],
+                              t["lower"], t["max_word_chars"], _p(blob), _p(off), C.c_int64(2), 16, _p(ids), C.c_int64(16), _p(lens), _p(status))
+    assert status.tolist() == [0, 1] and lens[1] == 0
+    b = GT.build_bpe_table(clip_tok)
+    ids, lens, status = np.zeros((2, 77), np.int32), np.zeros(2, np.int32), np.zeros(2, np.int32)
+    tokhost.tokhost_clip_bpe(_p(b["slots"]), _p(b["byte_id"]), _p(b["byte_end_id"]), C.c_uint32(b["n_slots"]), b["sot_id"], b["eot_id"], b["lower"],
+                             _p(blob), _p(off), C.c_int64(2), 77, _p(ids), _p(lens), _p(status))
+    assert status.tolist() == [0, 1]
+
+
+@pytest.mark.parametrize("ctx", [77, 8, 2])
+def test_clip_bpe_algorithm_matches_python_tokenizer(tokhost, clip_tok, ctx):
+    texts = [t for t in ASCII_CASES + _random_texts(3, 300) if GT.clip_in_scope(clip_tok, t)]
+    assert len(texts) > 250
+    ids, lens, status = _host_clip(tokhost, clip_tok, texts, ctx)
+    ref = clip_tok(texts, ctx)
+    for i, t in enumerate(texts):
+        if status[i]:  # a pre-token longer than the device scratch is handed back to the host, never mis-tokenised
+            assert max(len(w) for w in t.split()) > 90, repr(t)
+            continue
+        assert ids[i].tolist() == ref[i].tolist(), repr(t)
+        assert lens[i] == int(ref[i].argmax()) + 1
+    assert status.sum() <= 3
+
+
+def test_clip_bpe_algorithm_matches_transformers(tokhost, clip_tok):
+    from transformers import CLIPTokenizer
+    hf_vocab = {{"<start_of_text>": "<|startoftext|>", "<end_of_text>": "<|endoftext|>"}.get(t, t): i for t, i in clip_tok.encoder.items()}
+    hf = CLIPTokenizer(vocab=hf_vocab, merges=[tuple(m) for m in clip_tok.merges])
+    texts = [t for t in ASCII_CASES[:12] + _random_texts(4, 60) if GT.clip_in_scope(clip_tok, t) and len(t) < 150]
+    ids, lens, status = _host_clip(tokhost, clip_tok, texts, 300)
+    for i, t in enumerate(texts):
+        if not status[i]:
+            assert ids[i, :lens[i]].tolist() == hf(t)["input_ids"], repr(t)
+
+
+def test_clip_uncased_and_duplicate_merges(tokhost):
+    merges = _train_bpe(CORPUS, 60)
+    merges = merges + [merges[3]]  # a duplicated merge line: python's dict keeps the LAST rank
+    tok = ClipBpeTokenizer(merges, context_length=32, lower=False)
+    texts = ["The QUICK brown Fox it'S", "photo of a DOG"]
+    ids, lens, status = _host_clip(tokhost, tok, texts, 32)
+    assert (status == 0).all() and np.array_equal(ids, tok(texts, 32).astype(np.int32))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_device_wordpiece_equals_host(bert_tok):
+    dev = GT.DeviceWordPieceTokenizer(bert_tok, "cuda")
+    texts = ASCII_CASES + SENTENCES + _random_texts(5, 2000) + ["the fox [SEP] the dog [MASK]", "bell\x07char"]
+    for max_length in (512, 16):
+        got = dev(texts, max_length=max_length)
+        ref = bert_tok(texts, max_length=max_length)
+        assert np.array_equal(got["input_ids"], ref["input_ids"]) and np.array_equal(got["attention_mask"], ref["attention_mask"])
+    ids, lens = dev.encode_device(["a photo of a cat"], 32)
+    assert ids.is_cuda and ids.shape == (1, 32) and ids[0, :int(lens[0])].tolist() == bert_tok.encode("a photo of a cat", 32)
+    assert dev([], max_length=8)["input_ids"].shape[0] == 0
+
+
+@pytest.mark.gpu
+def test_device_clip_bpe_equals_host(clip_tok):
+    dev = GT.DeviceClipBpeTokenizer(clip_tok, "cuda")
+    texts = ASCII_CASES + SENTENCES + _random_texts(6, 2000) + ["fish &amp; chips", "x <start_of_text> y", "z" * 300]
+    for ctx in (77, 8):
+        assert np.array_equal(dev(texts, ctx), clip_tok(texts, ctx))
+    ids, lens = dev.encode_device(texts)
+    ref = clip_tok(texts)
+    assert np.array_equal(lens.numpy(), ref.argmax(1) + 1)
+
+
+def test_device_tokenizers_refuse_cpu(bert_tok):
+    from marqo_amd._lib import MarqoHipUnavailableError
+    with pytest.raises(MarqoHipUnavailableError):
+        GT.DeviceWordPieceTokenizer(bert_tok, "cpu")

@@ -77,6 +77,12 @@ def test_open_clip_from_disk_text_and_image(s2):
     # str == [str]; vectorise == model.encode
     assert np.allclose(s2i.vectorise("tiny-clip", texts[0], model_properties=props, device=DEV), out[:1], atol=1e-6)
     assert np.abs(model.encode(texts, normalize=True, infer=False) - np.asarray(out)).sum() < 1e-6
+    # K14: the loader tokenises ASCII texts on the device; ids (hence embeddings) are identical to the host-tokeniser route,
+    # also when a batch mixes in texts that must take the host route
+    assert model._device_tokenizer is not None
+    mixed = texts + ["naïve café über straße", "fish &amp; chips", "it's a dog's life"]
+    via_host = model.text.encode_ids(torch.from_numpy(model.tokenizer(mixed))).cpu().numpy()
+    assert np.array_equal(model.encode_text(mixed), via_host)
     # un-normalised
     raw = s2i.vectorise("tiny-clip", texts, model_properties=props, device=DEV, normalize_embeddings=False)
     assert not np.allclose(np.linalg.norm(np.asarray(raw), axis=1), 1.0, atol=1e-3)
@@ -144,6 +150,13 @@ def test_hf_from_disk(s2):
     tok = WordPieceTokenizer(vocab)(texts, max_length=32)
     ref = O.hf_encode(sd, cfg, torch.from_numpy(tok["input_ids"]), torch.from_numpy(tok["attention_mask"])).numpy()
     assert np.asarray(out).shape == (4, 128) and _cos_err(out, ref) < COS_TOL
+    # K14: device WordPiece == host WordPiece route, bit for bit, including texts that fall back to the host tokeniser
+    model = s2i.get_available_models()[s2i._create_model_cache_key("tiny-bert", DEV, props)]["model"]
+    assert model._device_tokenizer is not None
+    mixed = texts + ["naïve café", "the fox [SEP] the dog", "", "word " * 100]
+    th = model._tokenizer(mixed, max_length=32)
+    via_host = model._model.encode_ids(torch.from_numpy(th["input_ids"]), torch.from_numpy(th["attention_mask"])).cpu().numpy()
+    assert np.array_equal(model.encode(mixed), via_host)
     # padding invariance: a batch of one gives the same vector (appendix A.10)
     one = s2i.vectorise("tiny-bert", [texts[3]], model_properties=props, device=DEV)
     assert _cos_err(one, np.asarray(out)[3:]) < 1e-5

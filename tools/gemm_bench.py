@@ -34,10 +34,14 @@ def main():
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--only", default="")
     ap.add_argument("--fp8", action="store_true", help="time mq_gemm_fp8 (K taken as-is; fp8 operands)")
+    ap.add_argument("--ab", default="", help="interleaved within-process A/B (cdna_hip_programming.md §5.4 rule 24): "
+                    "'name:key=v,key=v;name2:key=v' — every variant is timed in every round, medians are reported")
+    ap.add_argument("--rounds", type=int, default=7)
     args = ap.parse_args()
     lib = L.load()
     s = torch.cuda.current_stream().cuda_stream
     tot_t = tot_f = 0.0
+    ab_tot = {}
     for name, M, N, K, flags in SHAPES:
         if args.only and not __import__("re").search(args.only, name):
             continue
@@ -82,6 +86,34 @@ def main():
 
         def run():
             L.check(lib.mq_gemm_bf16(A.data_ptr(), K, W.data_ptr(), K, b.data_ptr(), L.ptr(res), out.data_ptr(), N, M, N, K, flags, s))
+        if args.ab:
+            variants = []
+            for spec in args.ab.split(";"):
+                vname, _, kv = spec.partition(":")
+                variants.append((vname, [(k, int(v)) for k, v in (p.split("=") for p in kv.split(",") if p)]))
+            times = {vn: [] for vn, _ in variants}
+            for rnd in range(args.rounds + 1):
+                for vn, kvs in variants:
+                    for k, v in kvs:
+                        L.check(lib.mq_tune(k.encode(), v))
+                    run(); run()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(args.iters):
+                        run()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    if rnd:  # round 0 is warm-up
+                        times[vn].append(e0.elapsed_time(e1) * 1e3 / args.iters)
+            fl = 2.0 * M * N * K
+            med = {vn: sorted(t)[len(t) // 2] for vn, t in times.items()}
+            base = med[variants[0][0]]
+            print(f"{name:10s} M={M:6d} N={N:5d} K={K:5d} " + "  ".join(
+                f"{vn}={med[vn]:7.1f}us ({fl / med[vn] / 1e6:6.0f}TF {100 * (med[vn] / base - 1):+5.1f}%)" for vn, _ in variants))
+            if name.startswith("b32") and "patch" not in name:
+                for vn in med:
+                    ab_tot[vn] = ab_tot.get(vn, 0.0) + med[vn]
+            continue
         for _ in range(5):
             run()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -95,6 +127,8 @@ def main():
         print(f"{name:10s} M={M:6d} N={N:5d} K={K:5d}  {us:9.1f} us  {fl / us / 1e6:8.1f} TF/s")
         if name.startswith("b32") and "patch" not in name:
             tot_t += us; tot_f += fl
+    if ab_tot:
+        print("b32 layer GEMMs: " + "  ".join(f"{vn}={t:.1f}us" for vn, t in ab_tot.items()))
     if tot_t:
         print(f"b32 layer GEMMs: {tot_t:.1f} us/layer  {tot_f / tot_t / 1e6:.1f} TF/s")
 
