@@ -234,6 +234,23 @@ def main():
         "launches_per_step": gemm_launches // prof_steps,
         "per_family": families,
     }
+    # HBM-side traffic of the dominant kernel from the committed PMC passes of this same command (tools/gpu_evidence.sh:
+    # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH doubled per MI355X_MICROARCH.md; PMC cannot be sampled
+    # from inside this process).  Bytes per launch, averaged over the GEMM launches like `achieved`.
+    tpath = os.path.join(ROOT, "profiles", f"r01_traffic_{args.workload}_{args.precision}.json")
+    if os.path.isfile(tpath):
+        try:
+            with open(tpath) as f:
+                tj = json.load(f)
+            fam = "gemm_fp8_kernel" if args.precision == "fp8" else "gemm_nt_kernel"
+            rows = [v for k, v in tj.items() if k.startswith(fam) or k.startswith("gemm_big_kernel")]
+            n_l = sum(v["launches"] for v in rows)
+            if n_l:
+                roofline["traffic"] = round(sum(v["launches"] * (v["read_bytes"] + v["write_bytes"]) for v in rows) / n_l, 1)
+                roofline["traffic_unit"] = "bytes/launch (fabric-side reads incl. Infinity-Cache hits + writes)"
+                roofline["traffic_source"] = os.path.relpath(tpath, ROOT)
+        except (OSError, ValueError, KeyError):
+            pass
     e2e_tflops = value * gflop_per_emb / 1e3
     result = {
         "metric": "embeddings/sec", "value": round(value, 1), "unit": "embeddings/s",

@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
 struct GemmTune {
     int mt, persist, big, cgroup, wide;
     static int env(const char* k, int d) { const char* v = getenv(k); return v ? atoi(v) : d; }
-    GemmTune() : mt(env("MQ_GEMM_MT", 0)), persist(env("MQ_GEMM_PERSIST", 0)), big(env("MQ_GEMM_BIG", 0)), cgroup(env("MQ_GEMM_CGROUP", 8)), wide(env("MQ_GEMM_WIDE", 1)) {}
+    GemmTune() : mt(env("MQ_GEMM_MT", 0)), persist(env("MQ_GEMM_PERSIST", 1)), big(env("MQ_GEMM_BIG", 0)), cgroup(env("MQ_GEMM_CGROUP", 8)), wide(env("MQ_GEMM_WIDE", 2)) {}
 };
 GemmTune g_tune;
 
@@ -272,7 +272,9 @@ int launch_gemm_mt(const void* A, int64_t lda, const void* W, int64_t ldw, const
     const int cgroup = (g_tune.cgroup > 0 && tiles_n > g_tune.cgroup && tiles_m >= 16) ? g_tune.cgroup : 0;
     const int band_rows = (tiles_m + 7) / 8;
     // 16-byte bf16 epilogue stores need 16-B aligned rows
-    const int wide = (g_tune.wide && !(FLAGS & MQ_EPI_OUT_F32) && ldc % 8 == 0 && ((uintptr_t)out & 15) == 0) ? 1 : 0;
+    // (gemm_wide = 2, the default: everywhere; 1: not beside the GELU epilogues; 0: off.  profiles/r01b_gemm_knobs_ab.txt)
+    const bool act = (FLAGS & (MQ_EPI_GELU | MQ_EPI_QUICKGELU)) != 0;
+    const int wide = (g_tune.wide && (g_tune.wide >= 2 || !act) && !(FLAGS & MQ_EPI_OUT_F32) && ldc % 8 == 0 && ((uintptr_t)out & 15) == 0) ? 1 : 0;
     const int grid = PERSIST && num_tiles > RESIDENT_SLOTS ? RESIDENT_SLOTS : num_tiles;
     hipLaunchKernelGGL((gemm_nt_kernel<FLAGS, MT, PERSIST>), dim3(grid), dim3(256), LDS, s,
                        (const bf16_t*)A, lda, (const bf16_t*)W, ldw, bias, residual, out, ldc,

@@ -14,50 +14,67 @@ template <int FLAGS, int MT>
 __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][4], const float* __restrict__ bias, const float* residual, void* out,
                                               int64_t ldc, int M, int N, int wave_m0, int wave_n0, int l15, int g, bool wide = false) {
     constexpr bool BF16_OUT = !(FLAGS & MQ_EPI_OUT_F32);
+    // value of one (mt, nt) sub-tile after bias / activation / residual; `ok` guards the residual read
+    auto value = [&](int mt, int nt, int m, int n, bool ok) {
+        f32x4 v = acc[mt][nt];
+        if (FLAGS & MQ_EPI_BIAS) {
+            if (n < N) v += *(const f32x4*)(bias + n);
+        }
+        if (FLAGS & MQ_EPI_GELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+        }
+        if (FLAGS & MQ_EPI_QUICKGELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
+        }
+        if (FLAGS & MQ_EPI_RESIDUAL) {
+            if (ok) v += *(const f32x4*)(residual + (int64_t)m * ldc + n);
+        }
+        return v;
+    };
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int m = wave_m0 + mt * 16 + l15;
         const bool m_ok = m < M;
-        uint2 pk[4];
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            const int n = wave_n0 + nt * 16 + g * 4;
-            const bool ok = m_ok && n < N;
-            f32x4 v = acc[mt][nt];
-            if (FLAGS & MQ_EPI_BIAS) {
-                if (n < N) v += *(const f32x4*)(bias + n);
-            }
-            if (FLAGS & MQ_EPI_GELU) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-            }
-            if (FLAGS & MQ_EPI_QUICKGELU) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
-            }
-            const int64_t o = (int64_t)m * ldc + n;
-            if (FLAGS & MQ_EPI_RESIDUAL) {
-                if (ok) v += *(const f32x4*)(residual + o);
-            }
-            if (!BF16_OUT) {
-                if (ok) *(f32x4*)((float*)out + o) = v;
-            } else {
-                pk[nt].x = pack_bf16x2(v[0], v[1]);
-                pk[nt].y = pack_bf16x2(v[2], v[3]);
-                if (!wide && ok) *(uint2*)((bf16_t*)out + o) = pk[nt];
-            }
-        }
         if (BF16_OUT && wide) {  // `wide` is wave-uniform: every lane takes part in the swaps
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
-                uint2 a = pk[2 * p], b = pk[2 * p + 1];
+                uint2 a, b;
+                {
+                    const int n = wave_n0 + (2 * p) * 16 + g * 4;
+                    const f32x4 v = value(mt, 2 * p, m, n, m_ok && n < N);
+                    a.x = pack_bf16x2(v[0], v[1]); a.y = pack_bf16x2(v[2], v[3]);
+                }
+                {
+                    const int n = wave_n0 + (2 * p + 1) * 16 + g * 4;
+                    const f32x4 v = value(mt, 2 * p + 1, m, n, m_ok && n < N);
+                    b.x = pack_bf16x2(v[0], v[1]); b.y = pack_bf16x2(v[2], v[3]);
+                }
                 const auto r0 = __builtin_amdgcn_permlane16_swap(a.x, b.x, false, false);
                 const auto r1 = __builtin_amdgcn_permlane16_swap(a.y, b.y, false, false);
-                // lane now owns n = base .. base+7 with base = pair block + (g&1)*16 + (g>>1)*8, low half in (r0[0], r1[0])
+                // the lane now owns n = base .. base+7 with base = pair block + (g&1)*16 + (g>>1)*8, low half in (r0[0], r1[0])
                 const int n = wave_n0 + p * 32 + (g & 1) * 16 + (g >> 1) * 8;
                 bf16_t* dst = (bf16_t*)out + (int64_t)m * ldc + n;
                 if (m_ok && n + 8 <= N) *(uint4*)dst = make_uint4(r0[0], r1[0], r0[1], r1[1]);
                 else if (m_ok && n < N) *(uint2*)dst = make_uint2(r0[0], r1[0]);  // N % 4 == 0: exactly the low half is in range
+            }
+        } else {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int n = wave_n0 + nt * 16 + g * 4;
+                const bool ok = m_ok && n < N;
+                const f32x4 v = value(mt, nt, m, n, ok);
+                const int64_t o = (int64_t)m * ldc + n;
+                if (!ok) continue;
+                if (!BF16_OUT) {
+                    *(f32x4*)((float*)out + o) = v;
+                } else {
+                    uint2 pk;
+                    pk.x = pack_bf16x2(v[0], v[1]);
+                    pk.y = pack_bf16x2(v[2], v[3]);
+                    *(uint2*)((bf16_t*)out + o) = pk;
+                }
             }
         }
     }

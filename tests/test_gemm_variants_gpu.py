@@ -11,8 +11,8 @@ from marqo_amd import _lib as L
 pytestmark = pytest.mark.gpu
 
 VARIANTS = [dict(gemm_persist=0, gemm_cgroup=0, gemm_wide=0), dict(gemm_persist=1, gemm_cgroup=0, gemm_wide=0),
-            dict(gemm_persist=0, gemm_cgroup=8, gemm_wide=1), dict(gemm_persist=1, gemm_cgroup=4, gemm_wide=1)]
-DEFAULTS = dict(gemm_mt=0, gemm_persist=0, gemm_cgroup=8, gemm_wide=1, gemm_big=0)
+            dict(gemm_persist=0, gemm_cgroup=8, gemm_wide=1), dict(gemm_persist=1, gemm_cgroup=4, gemm_wide=2)]
+DEFAULTS = dict(gemm_mt=0, gemm_persist=1, gemm_cgroup=8, gemm_wide=2, gemm_big=0)
 
 
 def _vid(v):
