@@ -87,6 +87,11 @@ typedef struct mq_block_weights {
     const void*  out_w8; const float* out_ws; /* [W, W],  [W]  */
     const void*  fc1_w8; const float* fc1_ws; /* [F, W],  [F]  */
     const void*  fc2_w8; const float* fc2_ws; /* [W, F],  [W]  */
+    /* LayerNorm folding (pre-LN bf16 encoders; all six NULL = off): the LayerNorm in front of the QKV / fc1 GEMM folded into
+     * that GEMM, LN(x) @ W^T = rstd * (x @ (g*W)^T - mean * colsum(g*W)) + (b + W @ beta):
+     * *_wf = bf16(g[k] * W[n,k]) [out, in], *_sf = fp32 sum_k of those bf16 values [out], *_bf = fp32 b + W @ beta [out]. */
+    const void*  qkv_wf; const float* qkv_sf; const float* qkv_bf;
+    const void*  fc1_wf; const float* fc1_sf; const float* fc1_bf;
 } mq_block_weights;
 
 typedef struct mq_encoder_cfg {
@@ -288,6 +293,18 @@ int mq_gemm_bf16(const void* d_A, int64_t lda, const void* d_W, int64_t ldw,
                  const float* d_bias, const float* d_residual, void* d_out, int64_t ldc,
                  int64_t M, int64_t N, int64_t K, int flags, void* stream);
 
+/* mq_gemm_bf16 with a folded LayerNorm on one side (pre-LN blocks; csrc/gemm_epilogue.h):
+ *   flags = BIAS|RESIDUAL|OUT_F32|MQ_EPI_LN_STATS  — producer (the residual GEMM): also writes bf16(out) to d_out2 [M, ldc] and
+ *           per row the partial (sum, sum of squares) of every 64-column slot to d_stats fp32 [M][ceil(N/64)][2];
+ *   flags = BIAS[|GELU|QUICKGELU]|MQ_EPI_LN_APPLY — consumer: d_A is that bf16 copy (un-normalised rows, K = normalised
+ *           width), d_W / d_bias / d_colsum are the pre-folded (*_wf, *_bf, *_sf) tensors, d_stats the producer's partials
+ *           [M][ceil(K/64)][2]; out bf16 = act( rstd*(A@W^T - mean*colsum) + bias ). */
+#define MQ_EPI_LN_STATS 64
+#define MQ_EPI_LN_APPLY 128
+int mq_gemm_bf16_ln(const void* d_A, int64_t lda, const void* d_W, int64_t ldw, const float* d_bias,
+                    const float* d_residual, void* d_out, int64_t ldc, int64_t M, int64_t N, int64_t K, int flags,
+                    float* d_stats, void* d_out2, const float* d_colsum, float eps, void* stream);
+
 /* y = LayerNorm(x) * g + b over the last dim.  x fp32 [rows, W] gathered through an optional
  * row index (d_row_idx int32 [rows], NULL = identity).  Writes bf16 (d_out_bf16) and/or fp32
  * (d_out_f32); either may be NULL. */
@@ -383,7 +400,8 @@ int mq_weighted_combine(const float* d_emb, int64_t ld, const int32_t* d_rows, c
 /* Run-time selection of a kernel variant (benchmark A/B and parity tests of every variant in one process).
  * keys: "gemm_mt" (0 = auto, else GEMM tile height in 32-row units), "gemm_spec" (1 = producer/consumer wave
  * specialisation), "gemm_big" (4 / 6 / 8 = one-workgroup-per-CU (32*v) x 256 tile, 0 = off), "row_select" (0 = the towers run their last
- * block on every row instead of the pooled rows only).  Initial values come from
+ * block on every row instead of the pooled rows only), "ln_fold" (0 = keep the separate LayerNorm kernels), "gemm_persist",
+ * "gemm_cgroup", "gemm_wide" (GEMM scheduling knobs, see csrc/gemm_bf16.hip).  Initial values come from
  * the environment (MQ_GEMM_MT, MQ_GEMM_SPEC, MQ_GEMM_BIG). */
 int mq_tune(const char* key, int value);
 

@@ -27,6 +27,7 @@ MQ_ACT_GELU, MQ_ACT_QUICKGELU = 1, 2
 MQ_MASK_NONE, MQ_MASK_CAUSAL = 0, 1
 MQ_POOL_MEAN, MQ_POOL_CLS = 0, 1
 MQ_EPI_BIAS, MQ_EPI_GELU, MQ_EPI_QUICKGELU, MQ_EPI_RESIDUAL, MQ_EPI_OUT_F32, MQ_EPI_OUT_FP8 = 1, 2, 4, 8, 16, 32
+MQ_EPI_LN_STATS, MQ_EPI_LN_APPLY = 64, 128
 MQ_COMBINE_RAW, MQ_COMBINE_NORMALIZE, MQ_COMBINE_NORMALIZE_IF_NONZERO = 0, 1, 2
 MQ_PROF_FAMILIES = 6
 PROF_FAMILY_NAMES = ("gemm", "layernorm", "attention", "embed", "pool_head", "preprocess")
@@ -45,7 +46,8 @@ class BlockWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "ln1_g", "ln1_b", "qkv_w", "qkv_b", "out_w", "out_b",
         "ln2_g", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b",
-        "qkv_w8", "qkv_ws", "out_w8", "out_ws", "fc1_w8", "fc1_ws", "fc2_w8", "fc2_ws")]
+        "qkv_w8", "qkv_ws", "out_w8", "out_ws", "fc1_w8", "fc1_ws", "fc2_w8", "fc2_ws",
+        "qkv_wf", "qkv_sf", "qkv_bf", "fc1_wf", "fc1_sf", "fc1_bf")]
 
 
 class EncoderCfg(C.Structure):
@@ -111,6 +113,8 @@ _SIGNATURES = {
                                  C.c_size_t, _P]),
     "mq_gemm_bf16": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
                                C.c_int, _P]),
+    "mq_gemm_bf16_ln": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int,
+                                  _P, _P, _P, C.c_float, _P]),
     "mq_gemm_fp8": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, C.c_int, _P, _P, _P, _P, C.c_int64, _P, _P, C.c_int64, C.c_int64,
                               C.c_int64, C.c_int, _P]),
     "mq_quantize_weights_fp8": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, C.c_int64, C.c_int64, _P]),

@@ -23,6 +23,7 @@
 
 extern int mq_gemm_fp8_force_mt;  // gemm_fp8.hip
 extern int mq_tower_row_select;   // towers.hip
+extern int mq_tower_ln_fold;      // towers.hip
 
 // CU-sized-tile main loop (gemm_big.hip)
 template <int FLAGS>
@@ -52,7 +53,7 @@ template <int FLAGS, int MT, bool PERSIST>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
     const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ Wt, int64_t ldw,
     const float* __restrict__ bias, const float* residual, void* out, int64_t ldc,
-    int M, int N, int K, int tiles_n, int num_tiles, int cgroup, int band_rows, int wide_store) {
+    int M, int N, int K, int tiles_n, int num_tiles, int cgroup, int band_rows, int wide_store, GemmLn ln) {
     constexpr int BM = 32 * MT;
     constexpr int A_TILE_BYTES = BM * BK * 2;
     constexpr int STAGE_BYTES = A_TILE_BYTES + W_TILE_BYTES;
@@ -124,66 +125,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
         for (int i = 0; i < 4; ++i) glds16(w_src[i] + (int64_t)kt * BK, sw + i * (8 * 128));
     };
 
-    // ---- fragment read offsets (bytes inside a tile), fixed per lane ------------------------
-    // logical chunk for k-half kk is g + 4*kk; (row & 7) == (l15 & 7) because sub-tile bases are
-    // multiples of 16.
-    int a_off[MT], w_off[4];
-#pragma unroll
-    for (int t = 0; t < MT; ++t) a_off[t] = (wm * (16 * MT) + t * 16 + l15) * 128;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) w_off[t] = (wn * 64 + t * 16 + l15) * 128;
-    const int sw0 = ((g) ^ (l15 & 7)) << 4;      // kk = 0
-    const int sw1 = ((g + 4) ^ (l15 & 7)) << 4;  // kk = 1
-
     f32x4 acc[MT][4];
-
-    // one k-step on LDS buffer `buf`: fragments for both 32-deep halves are read up front, then the MT*8 MFMAs run with
-    // the NEXT stage's LDS-DMA issues (k offset `koff` of the current a_src / w_src, into the other buffer) sprinkled
-    // between them (an LDS-DMA issue costs the wave ~60-180 cycles; bunched at the top of the step they serialised in
-    // front of the MFMAs and held the matrix pipe at 25-40 %).  PREFETCH is a template flag so the steady-state loop has
-    // no branch in it.
-    auto kstep = [&](int buf, int64_t koff, auto prefetch_tag) {
-        constexpr bool PREFETCH = decltype(prefetch_tag)::value;
-        const char* sa = smem + buf * STAGE_BYTES;
-        const char* sw = sa + A_TILE_BYTES;
-        char* na = smem + (buf ^ 1) * STAGE_BYTES + wave * (8 * MT * 128);
-        char* nw = smem + (buf ^ 1) * STAGE_BYTES + A_TILE_BYTES + wave * (32 * 128);
-        bf16x8 af[2][MT], wf[2][4];
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int swz = kk ? sw1 : sw0;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) wf[kk][t] = *(const bf16x8*)(sw + w_off[t] + swz);
-#pragma unroll
-            for (int t = 0; t < MT; ++t) af[kk][t] = *(const bf16x8*)(sa + a_off[t] + swz);
-        }
-        constexpr int NL = MT + 4;            // LDS-DMA pieces per wave per step
-        constexpr int NM = 8 * MT;            // MFMAs per wave per step
-        constexpr int GAP = NM / NL;          // MFMAs between two pieces
-        int issued = 0;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][nt], af[kk][mt], acc[mt][nt], 0, 0, 0);
-                    const int done = (kk * MT + mt) * 4 + nt + 1;
-                    if (PREFETCH && done % GAP == 0 && issued < NL) {
-                        if (issued < MT) glds16(a_src[issued] + koff, na + issued * (8 * 128));
-                        else glds16(w_src[issued - MT] + koff, nw + (issued - MT) * (8 * 128));
-                        ++issued;
-                    }
-                }
-        if (PREFETCH) {
-            // pin the interleave: GAP MFMAs, one VMEM, ... (sched_group_barrier masks: 0x8 MFMA, 0x10 VMEM)
-#pragma unroll
-            for (int i = 0; i < NL; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, GAP, 0);
-                __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-            }
-        }
-    };
 
     const int nk = K / BK;
     int vbid = blockIdx.x;
@@ -197,6 +139,67 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // ---- fragment read offsets (bytes inside a tile), fixed per lane ----------------------
+        // logical chunk for k-half kk is g + 4*kk; (row & 7) == (l15 & 7) because sub-tile bases are multiples of 16.
+        // Persistent form: recomputed per tile from a laundered lane id, so that these 11 registers are NOT live across the
+        // epilogue (kept live they pushed the 160-row persistent kernels to the 256-VGPR cap and into scratch spills).
+        int l15f = l15, gf = g;
+        if (PERSIST) asm volatile("" : "+v"(l15f), "+v"(gf));
+        int a_off[MT], w_off[4];
+#pragma unroll
+        for (int t = 0; t < MT; ++t) a_off[t] = (wm * (16 * MT) + t * 16 + l15f) * 128;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) w_off[t] = (wn * 64 + t * 16 + l15f) * 128;
+        const int sw0 = ((gf) ^ (l15f & 7)) << 4;      // kk = 0
+        const int sw1 = ((gf + 4) ^ (l15f & 7)) << 4;  // kk = 1
+        // one k-step on LDS buffer `buf`: fragments for both 32-deep halves are read up front, then the MT*8 MFMAs run with
+        // the NEXT stage's LDS-DMA issues (k offset `koff` of the current a_src / w_src, into the other buffer) sprinkled
+        // between them (an LDS-DMA issue costs the wave ~60-180 cycles; bunched at the top of the step they serialised in
+        // front of the MFMAs and held the matrix pipe at 25-40 %).  PREFETCH is a template flag so the steady-state loop has
+        // no branch in it.
+        auto kstep = [&](int buf, int64_t koff, auto prefetch_tag) {
+            constexpr bool PREFETCH = decltype(prefetch_tag)::value;
+            const char* sa = smem + buf * STAGE_BYTES;
+            const char* sw = sa + A_TILE_BYTES;
+            char* na = smem + (buf ^ 1) * STAGE_BYTES + wave * (8 * MT * 128);
+            char* nw = smem + (buf ^ 1) * STAGE_BYTES + A_TILE_BYTES + wave * (32 * 128);
+            bf16x8 af[2][MT], wf[2][4];
+    #pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int swz = kk ? sw1 : sw0;
+    #pragma unroll
+                for (int t = 0; t < 4; ++t) wf[kk][t] = *(const bf16x8*)(sw + w_off[t] + swz);
+    #pragma unroll
+                for (int t = 0; t < MT; ++t) af[kk][t] = *(const bf16x8*)(sa + a_off[t] + swz);
+            }
+            constexpr int NL = MT + 4;            // LDS-DMA pieces per wave per step
+            constexpr int NM = 8 * MT;            // MFMAs per wave per step
+            constexpr int GAP = NM / NL;          // MFMAs between two pieces
+            int issued = 0;
+    #pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+    #pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+    #pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][nt], af[kk][mt], acc[mt][nt], 0, 0, 0);
+                        const int done = (kk * MT + mt) * 4 + nt + 1;
+                        if (PREFETCH && done % GAP == 0 && issued < NL) {
+                            if (issued < MT) glds16(a_src[issued] + koff, na + issued * (8 * 128));
+                            else glds16(w_src[issued - MT] + koff, nw + (issued - MT) * (8 * 128));
+                            ++issued;
+                        }
+                    }
+            if (PREFETCH) {
+                // pin the interleave: GAP MFMAs, one VMEM, ... (sched_group_barrier masks: 0x8 MFMA, 0x10 VMEM)
+    #pragma unroll
+                for (int i = 0; i < NL; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, GAP, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+                }
+            }
+        };
+
         for (int kt = 0; kt < nk - 1; ++kt) {
             // stage kt has landed for every wave, and every wave is done reading the other buffer
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -219,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
         if (PERSIST && more) kstep(buf, 0, std::true_type{});
         else kstep(buf, 0, std::false_type{});
         buf ^= 1;
-        gemm_epilogue<FLAGS, MT>(acc, bias, residual, out, ldc, M, N, cm0 + wm * (16 * MT), cn0 + wn * 64, l15, g, wide_store != 0);
+        gemm_epilogue<FLAGS, MT>(acc, bias, residual, out, ldc, M, N, cm0 + wm * (16 * MT), cn0 + wn * 64, l15, g, wide_store != 0, &ln);
         if (!PERSIST || !more) break;
     }
 }
@@ -253,7 +256,7 @@ int choose_mt(int M, int N) {
 
 template <int FLAGS, int MT, bool PERSIST>
 int launch_gemm_mt(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
-                   const float* residual, void* out, int64_t ldc, int M, int N, int K, hipStream_t s) {
+                   const float* residual, void* out, int64_t ldc, int M, int N, int K, hipStream_t s, const GemmLn& ln) {
     constexpr int BM = 32 * MT;
     constexpr int LDS = 2 * (BM * BK * 2 + W_TILE_BYTES);
     static bool attr_set = false;
@@ -278,30 +281,32 @@ int launch_gemm_mt(const void* A, int64_t lda, const void* W, int64_t ldw, const
     const int grid = PERSIST && num_tiles > RESIDENT_SLOTS ? RESIDENT_SLOTS : num_tiles;
     hipLaunchKernelGGL((gemm_nt_kernel<FLAGS, MT, PERSIST>), dim3(grid), dim3(256), LDS, s,
                        (const bf16_t*)A, lda, (const bf16_t*)W, ldw, bias, residual, out, ldc,
-                       M, N, K, tiles_n, num_tiles, cgroup, band_rows, wide);
+                       M, N, K, tiles_n, num_tiles, cgroup, band_rows, wide, ln);
     MQ_CHECK_LAUNCH("mq_gemm_bf16");
     return MQ_OK;
 }
 
 template <int FLAGS>
 int launch_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
-                const float* residual, void* out, int64_t ldc, int M, int N, int K, hipStream_t s) {
+                const float* residual, void* out, int64_t ldc, int M, int N, int K, hipStream_t s, const GemmLn& ln = GemmLn{}) {
     const int force_mt = g_tune.mt;
     const int persist = g_tune.persist;
     const int mt = force_mt ? force_mt : choose_mt(M, N);
-    if (g_tune.big) return mq_launch_gemm_big<FLAGS>(g_tune.big, A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s);
+    if constexpr ((FLAGS & (MQ_EPI_LN_STATS | MQ_EPI_LN_APPLY)) == 0) {
+        if (g_tune.big) return mq_launch_gemm_big<FLAGS>(g_tune.big, A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s);
+    }
 #define MQ_MT_CASE(T)                                                                                              \
     case T:                                                                                                        \
-        return persist ? launch_gemm_mt<FLAGS, T, true>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s)     \
-                       : launch_gemm_mt<FLAGS, T, false>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s)
+        return persist ? launch_gemm_mt<FLAGS, T, true>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s, ln) \
+                       : launch_gemm_mt<FLAGS, T, false>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s, ln)
     switch (mt) {
         MQ_MT_CASE(2);
         MQ_MT_CASE(5);
         case 6:  // the persistent form of the 192-row tile spills (256-VGPR cap at 2 workgroups per CU): plain form only
-            return launch_gemm_mt<FLAGS, 6, false>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s);
+            return launch_gemm_mt<FLAGS, 6, false>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s, ln);
         default:
-            return persist ? launch_gemm_mt<FLAGS, 4, true>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s)
-                           : launch_gemm_mt<FLAGS, 4, false>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s);
+            return persist ? launch_gemm_mt<FLAGS, 4, true>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s, ln)
+                           : launch_gemm_mt<FLAGS, 4, false>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s, ln);
     }
 #undef MQ_MT_CASE
 }
@@ -338,6 +343,47 @@ extern "C" int mq_gemm_bf16(const void* d_A, int64_t lda, const void* d_W, int64
 #undef MQ_GEMM_CASE
 }
 
+// GEMM with a folded LayerNorm on either side (see gemm_epilogue.h).  flags & MQ_EPI_LN_STATS: the residual epilogue also
+// writes bf16(out) to d_out2 and the per-row partial sums to d_stats [M][ceil(N/64)][2].  flags & MQ_EPI_LN_APPLY: A is the
+// bf16 copy of the UN-normalised rows, W / bias / d_colsum are pre-folded with the LayerNorm's gamma / beta, d_stats holds the
+// producer's partials over the K columns of A ([M][ceil(K/64)][2]).
+extern "C" int mq_gemm_bf16_ln(const void* d_A, int64_t lda, const void* d_W, int64_t ldw, const float* d_bias,
+                               const float* d_residual, void* d_out, int64_t ldc, int64_t M, int64_t N, int64_t K, int flags,
+                               float* d_stats, void* d_out2, const float* d_colsum, float eps, void* stream) {
+    MQ_CHECK_ARG(d_A && d_W && d_out && d_bias && d_stats, "mq_gemm_bf16_ln: null operand");
+    MQ_CHECK_ARG(M >= 1 && N >= 4 && K >= BK && K % BK == 0 && N % 4 == 0, "mq_gemm_bf16_ln: bad shape M=%ld N=%ld K=%ld", (long)M, (long)N, (long)K);
+    MQ_CHECK_ARG(lda % 8 == 0 && ldw % 8 == 0 && ldc % 4 == 0, "mq_gemm_bf16_ln: leading dims must keep 16-byte rows");
+    MQ_CHECK_ARG(M < (1 << 30) && N < (1 << 30) && K < (1 << 30), "mq_gemm_bf16_ln: shape too large");
+    hipStream_t s = (hipStream_t)stream;
+    MqProfScope prof(0, s, 2.0 * (double)M * (double)N * (double)K);
+    const int m = (int)M, n = (int)N, k = (int)K;
+    GemmLn ln{};
+    ln.eps = eps;
+    if (flags & MQ_EPI_LN_STATS) {
+        MQ_CHECK_ARG(d_residual && d_out2, "mq_gemm_bf16_ln: LN_STATS needs residual and out2");
+        ln.stats_out = d_stats;
+        ln.out2 = (bf16_t*)d_out2;
+    } else {
+        MQ_CHECK_ARG(d_colsum, "mq_gemm_bf16_ln: LN_APPLY needs colsum");
+        ln.stats_in = d_stats;
+        ln.colsum = d_colsum;
+        ln.nslots_in = (k + 63) >> 6;
+        ln.inv_w = 1.0f / (float)k;
+    }
+#define MQ_GEMM_LN_CASE(F) \
+    case (F): return launch_gemm<(F)>(d_A, lda, d_W, ldw, d_bias, d_residual, d_out, ldc, m, n, k, s, ln)
+    switch (flags) {
+        MQ_GEMM_LN_CASE(MQ_EPI_BIAS | MQ_EPI_RESIDUAL | MQ_EPI_OUT_F32 | MQ_EPI_LN_STATS);
+        MQ_GEMM_LN_CASE(MQ_EPI_BIAS | MQ_EPI_LN_APPLY);
+        MQ_GEMM_LN_CASE(MQ_EPI_BIAS | MQ_EPI_GELU | MQ_EPI_LN_APPLY);
+        MQ_GEMM_LN_CASE(MQ_EPI_BIAS | MQ_EPI_QUICKGELU | MQ_EPI_LN_APPLY);
+        default:
+            mq_set_error("mq_gemm_bf16_ln: unsupported epilogue flag combination 0x%x", flags);
+            return MQ_ERR_INVALID;
+    }
+#undef MQ_GEMM_LN_CASE
+}
+
 // Select a GEMM main-loop variant at run time (A/B benchmarking and parity tests of every variant in one process).
 // key: "gemm_mt" (0 = auto, else tile height in 32-row units), "gemm_persist", "gemm_cgroup", "gemm_big" (0 / 4 / 6 / 8), "row_select".
 extern "C" int mq_tune(const char* key, int value) {
@@ -349,6 +395,7 @@ extern "C" int mq_tune(const char* key, int value) {
     else if (k == "gemm_cgroup") g_tune.cgroup = value;
     else if (k == "gemm_wide") g_tune.wide = value;
     else if (k == "row_select") mq_tower_row_select = value;
+    else if (k == "ln_fold") mq_tower_ln_fold = value;
     else { mq_set_error("mq_tune: unknown key %s", key); return MQ_ERR_INVALID; }
     return MQ_OK;
 }

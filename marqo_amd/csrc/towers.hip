@@ -23,12 +23,19 @@ int mq_cls_rows(int32_t* d_rows, int64_t n, int T, hipStream_t s);
 int mq_move_rows(void* d_sparse, const int32_t* d_idx, void* d_dense, int64_t n, int64_t row_bytes, bool scatter, hipStream_t s);
 
 // layouts the ctypes binding (marqo_amd/_lib.py) and tests/test_abi.py assume
-static_assert(sizeof(mq_block_weights) == 20 * 8, "mq_block_weights layout");
+static_assert(sizeof(mq_block_weights) == 26 * 8, "mq_block_weights layout");
 static_assert(sizeof(mq_encoder_cfg) == 56, "mq_encoder_cfg layout");
 static_assert(sizeof(mq_vit_cfg) == 96 && sizeof(mq_clip_text_cfg) == 72 && sizeof(mq_bert_cfg) == 72, "tower cfg layouts");
 
 // mq_tune("row_select", 0) runs the last block on every row (A/B and parity tests of the pooled-rows-only last block)
 int mq_tower_row_select = getenv("MQ_ROW_SELECT") ? atoi(getenv("MQ_ROW_SELECT")) : 1;
+// LayerNorm folding runs only when the blocks carry folded weights AND this knob is on (mq_tune("ln_fold", 1) / MQ_LN_FOLD=1);
+// it is off by default: on MI355X the folded epilogues cost more than the LayerNorm launches they remove
+int mq_tower_ln_fold = getenv("MQ_LN_FOLD") ? atoi(getenv("MQ_LN_FOLD")) : 0;
+
+extern "C" int mq_gemm_bf16_ln(const void* d_A, int64_t lda, const void* d_W, int64_t ldw, const float* d_bias, const float* d_residual,
+                               void* d_out, int64_t ldc, int64_t M, int64_t N, int64_t K, int flags, float* d_stats, void* d_out2,
+                               const float* d_colsum, float eps, void* stream);
 
 namespace {
 
@@ -70,6 +77,7 @@ size_t encoder_ws(const mq_encoder_cfg* c, int64_t rows) {
     cv.take((size_t)rows * c->width * 2);
     cv.take((size_t)rows * big * 2);
     cv.take((size_t)rows * 4);  // per-row activation scales of the fp8 path
+    cv.take((size_t)rows * ((c->width + 63) / 64) * 8);  // LayerNorm-fold partials: (sum, sum of squares) per row and 64-column slot
     return cv.end();
 }
 
@@ -95,7 +103,7 @@ namespace {
 int last_block_selected(const mq_encoder_cfg* cfg, const mq_block_weights& b, int l, float* d_x, int64_t rows,
                         const int32_t* d_cu_seqlens, int64_t nseq, int32_t fixed_len, int32_t max_len,
                         const int32_t* d_sel, int64_t nsel, void* h, void* a, void* qf, float* row_scale, float* x_sel,
-                        hipStream_t s) {
+                        float* stats /* non-NULL: h holds bf16(x) and stats its LayerNorm partials (folded path) */, hipStream_t s) {
     const int W = cfg->width, F = cfg->mlp_dim;
     const int act_flag = cfg->act == MQ_ACT_QUICKGELU ? MQ_EPI_QUICKGELU : MQ_EPI_GELU;
     const int res_flags = MQ_EPI_BIAS | MQ_EPI_RESIDUAL | MQ_EPI_OUT_F32;
@@ -114,8 +122,13 @@ int last_block_selected(const mq_encoder_cfg* cfg, const mq_block_weights& b, in
         MQ_TRY(mq_gemm_fp8(a, W, b.fc1_w8, W, row_scale, 1, b.fc1_ws, b.fc1_b, nullptr, qf, F, s_mlp, nullptr, nsel, F, W, act8, s));
         MQ_TRY(mq_gemm_fp8(qf, F, b.fc2_w8, F, s_mlp, 0, b.fc2_ws, b.fc2_b, x_sel, x_sel, W, nullptr, nullptr, nsel, W, F, res_flags, s));
     } else if (!cfg->post_ln) {
-        MQ_TRY(mq_layernorm(d_x, nullptr, b.ln1_g, b.ln1_b, h, nullptr, rows, W, cfg->ln_eps, s));
-        MQ_TRY(mq_gemm_bf16(h, W, b.qkv_w, W, b.qkv_b, nullptr, qf, 3 * W, rows, 3 * W, W, MQ_EPI_BIAS, s));
+        if (stats) {
+            MQ_TRY(mq_gemm_bf16_ln(h, W, b.qkv_wf, W, b.qkv_bf, nullptr, qf, 3 * W, rows, 3 * W, W, MQ_EPI_BIAS | MQ_EPI_LN_APPLY, stats, nullptr,
+                                   b.qkv_sf, cfg->ln_eps, s));
+        } else {
+            MQ_TRY(mq_layernorm(d_x, nullptr, b.ln1_g, b.ln1_b, h, nullptr, rows, W, cfg->ln_eps, s));
+            MQ_TRY(mq_gemm_bf16(h, W, b.qkv_w, W, b.qkv_b, nullptr, qf, 3 * W, rows, 3 * W, W, MQ_EPI_BIAS, s));
+        }
         MQ_TRY(mq_attention(qf, a, d_cu_seqlens, nseq, fixed_len, max_len, W, cfg->heads, cfg->mask, s));
         MQ_TRY(mq_move_rows(a, d_sel, h, nsel, (int64_t)W * 2, false, s));
         MQ_TRY(mq_move_rows(d_x, d_sel, x_sel, nsel, (int64_t)W * 4, false, s));
@@ -156,8 +169,17 @@ int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* bloc
     void* a = wsb + cv.take((size_t)rows * W * 2);
     void* qf = wsb + cv.take((size_t)rows * big * 2);  // qkv [rows,3W] then fc1 output [rows,F]
     float* row_scale = (float*)(wsb + cv.take((size_t)rows * 4));
+    float* ln_stats = (float*)(wsb + cv.take((size_t)rows * ((W + 63) / 64) * 8));
     const int act_flag = cfg->act == MQ_ACT_QUICKGELU ? MQ_EPI_QUICKGELU : MQ_EPI_GELU;
     const int res_flags = MQ_EPI_BIAS | MQ_EPI_RESIDUAL | MQ_EPI_OUT_F32;
+
+    // LayerNorm folding (pre-LN bf16 encoders whose blocks all carry the folded tensors): the residual GEMMs emit bf16(x) + row
+    // partials, the QKV / fc1 GEMMs apply mean / rstd in their epilogue -> no LayerNorm launch between them.  `h` then holds
+    // bf16(x) instead of LN(x); `folded` says whether (h, ln_stats) describe the current x (false before the first block).
+    bool fold = mq_tower_ln_fold && cfg->precision == MQ_PREC_BF16 && !cfg->post_ln;
+    for (int l = 0; fold && l < cfg->layers; ++l)
+        fold = blocks[l].qkv_wf && blocks[l].qkv_sf && blocks[l].qkv_bf && blocks[l].fc1_wf && blocks[l].fc1_sf && blocks[l].fc1_bf;
+    bool folded = false;
 
     // pooled-rows-only last block: worth it when it at least halves the row count; not during fp8 calibration (the
     // activation maxima must see every row); x_sel must fit behind the fc1 output inside `qf`
@@ -176,8 +198,26 @@ int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* bloc
                          "mq_encoder_forward: layer %d has no fp8 weights", l);
         if (select_last && l == cfg->layers - 1) {
             MQ_TRY(last_block_selected(cfg, b, l, d_x, rows, d_cu_seqlens, nseq, fixed_len, max_len, d_sel, nsel, h, a, qf, row_scale,
-                                       (float*)((char*)qf + xsel_off), s));
+                                       (float*)((char*)qf + xsel_off), folded ? ln_stats : nullptr, s));
             break;
+        }
+        if (fold) {
+            // x += out(attn(qkv(ln1(x)))) ; x += fc2(act(fc1(ln2(x)))) with both LayerNorms folded into the GEMMs around them
+            const int stat_flags = res_flags | MQ_EPI_LN_STATS, apply = MQ_EPI_BIAS | MQ_EPI_LN_APPLY;
+            if (folded) {
+                MQ_TRY(mq_gemm_bf16_ln(h, W, b.qkv_wf, W, b.qkv_bf, nullptr, qf, 3 * W, rows, 3 * W, W, apply, ln_stats, nullptr, b.qkv_sf,
+                                       cfg->ln_eps, s));
+            } else {  // first block: x comes from the embedding kernels, not from a GEMM epilogue
+                MQ_TRY(mq_layernorm(d_x, nullptr, b.ln1_g, b.ln1_b, h, nullptr, rows, W, cfg->ln_eps, s));
+                MQ_TRY(mq_gemm_bf16(h, W, b.qkv_w, W, b.qkv_b, nullptr, qf, 3 * W, rows, 3 * W, W, MQ_EPI_BIAS, s));
+            }
+            MQ_TRY(mq_attention(qf, a, d_cu_seqlens, nseq, fixed_len, max_len, W, cfg->heads, cfg->mask, s));
+            MQ_TRY(mq_gemm_bf16_ln(a, W, b.out_w, W, b.out_b, d_x, d_x, W, rows, W, W, stat_flags, ln_stats, h, nullptr, cfg->ln_eps, s));
+            MQ_TRY(mq_gemm_bf16_ln(h, W, b.fc1_wf, W, b.fc1_bf, nullptr, qf, F, rows, F, W, apply | act_flag, ln_stats, nullptr, b.fc1_sf,
+                                   cfg->ln_eps, s));
+            MQ_TRY(mq_gemm_bf16_ln(qf, F, b.fc2_w, F, b.fc2_b, d_x, d_x, W, rows, W, F, stat_flags, ln_stats, h, nullptr, cfg->ln_eps, s));
+            folded = true;
+            continue;
         }
         if (cfg->precision == MQ_PREC_FP8) {
             // same dataflow with e4m3 GEMM operands: h / a / fc1-out are fp8 (h with a dynamic per-row scale from the LN,

@@ -110,6 +110,11 @@ class _Fp8State:
         self.amax.zero_()
 
 
+# LayerNorm folding of the pre-LN CLIP blocks: opt-in (MARQO_AMD_LN_FOLD=1).  Measured on MI355X it removes the LayerNorm
+# launches (-0.32 ms per ViT-B/32 step) but the two epilogues cost more than that (+0.45 ms): DESIGN.md §6.2.
+LN_FOLD = os.environ.get("MARQO_AMD_LN_FOLD", "0") == "1"
+
+
 def _clip_blocks(h: _Holder, sd, prefix: str, layers: int, W: int, F: int):
     arr = (L.BlockWeights * layers)()
     for i in range(layers):
@@ -127,6 +132,17 @@ def _clip_blocks(h: _Holder, sd, prefix: str, layers: int, W: int, F: int):
         b.fc1_b = h.f32(_need(sd, p + "mlp.c_fc.bias", (F,)))
         b.fc2_w = h.bf16(_need(sd, p + "mlp.c_proj.weight", (W, F)))
         b.fc2_b = h.f32(_need(sd, p + "mlp.c_proj.bias", (W,)))
+        if LN_FOLD:
+            # LayerNorm folding (csrc/gemm_epilogue.h): LN(x) @ W^T = rstd * (x @ (g*W)^T - mean * colsum(g*W)) + (b + W @ beta).
+            # colsum is taken over the bf16-ROUNDED folded weight (what the MFMA multiplies), the bias in fp32 from the fp32 W.
+            for name, wk, bk, lg, lb in (("qkv", "attn.in_proj_weight", "attn.in_proj_bias", "ln_1.weight", "ln_1.bias"),
+                                         ("fc1", "mlp.c_fc.weight", "mlp.c_fc.bias", "ln_2.weight", "ln_2.bias")):
+                w32 = sd[p + wk].detach().to(torch.float32)
+                gam, bet = sd[p + lg].detach().to(torch.float32), sd[p + lb].detach().to(torch.float32)
+                wf = (w32 * gam.unsqueeze(0)).to(torch.bfloat16)
+                setattr(b, name + "_wf", h.bf16(wf))
+                setattr(b, name + "_sf", h.f32(wf.to(torch.float32).sum(dim=1)))
+                setattr(b, name + "_bf", h.f32(sd[p + bk].detach().to(torch.float32) + w32 @ bet))
     return arr
 
 

@@ -43,7 +43,7 @@ class OpenCLIPModelProperties:
     """Validated view of the user's model_properties (reference: open_clip_model_properties.py:24-73)."""
     _KNOWN = {"name", "dimensions", "type", "jit", "precision", "url", "localpath", "model_location", "modelLocation",
               "tokenizer", "image_preprocessor", "imagePreprocessor", "mean", "std", "size", "note", "notes", "pretrained",
-              "model_size", "text_query_prefix", "text_chunk_prefix", "tokens"}
+              "model_size", "text_query_prefix", "text_chunk_prefix", "tokens", "enginePrecision", "engine_precision"}
 
     def __init__(self, **p):
         if not isinstance(p.get("name"), str) or not p["name"]:
@@ -73,6 +73,12 @@ class OpenCLIPModelProperties:
         self.std: Optional[List[float]] = p.get("std")
         self.size: Optional[int] = p.get("size")
         self.pretrained: Optional[str] = p.get("pretrained")
+        # engine extension (BASELINE config 5): operand type of the encoder-block GEMMs.  "bf16" (default) or "fp8" (OCP e4m3,
+        # MX-MFMA at twice the bf16 rate; static activation scales are calibrated on the first batch of each tower).  The
+        # reference's own 'precision' key (fp32 / fp16 autocast) keeps its meaning and is accepted for both.
+        self.engine_precision: str = p.get("enginePrecision", p.get("engine_precision", os.environ.get("MARQO_AMD_PRECISION", "bf16")))
+        if self.engine_precision not in ("bf16", "fp8"):
+            raise ValueError("'enginePrecision' must be 'bf16' or 'fp8'")
 
     def dict(self) -> dict:
         return dict(self.__dict__)
@@ -171,8 +177,12 @@ class OPEN_CLIP(AbstractCLIPModel):
         self._std = tuple(props.std) if props.std is not None else std
         self.preprocess_config = {"size": self.vision_arch.image_size, "mean": self._mean, "std": self._std,
                                   "interpolation": "bicubic", "resize_mode": "shortest"}
-        self.vision = towers.VitTower(self.vision_arch, sd, self.device, mean=self._mean, std=self._std)
-        self.text = towers.ClipTextTower(self.text_arch, sd, self.device)
+        try:
+            self.vision = towers.VitTower(self.vision_arch, sd, self.device, mean=self._mean, std=self._std, precision=props.engine_precision)
+            self.text = towers.ClipTextTower(self.text_arch, sd, self.device, precision=props.engine_precision)
+        except ValueError as e:  # e.g. fp8 needs width / mlp_dim multiples of 128
+            raise InvalidModelPropertiesError(str(e)) from e
+        self._calib_lock = threading.Lock()
         self.model = (self.vision, self.text)
         self.tokenizer = self._load_tokenizer(ckpt_dir)
         # K14: byte-level BPE on the device for ASCII texts (identical ids; the host tokeniser handles the rest)
@@ -259,9 +269,18 @@ class OPEN_CLIP(AbstractCLIPModel):
     def _convert_output(self, output: torch.Tensor) -> np.ndarray:
         return output.cpu().numpy()
 
+    def _calibrated(self, tower, run) -> None:
+        """fp8 towers: freeze the static activation scales on the first batch this tower sees (two recording passes), once."""
+        fp8 = getattr(tower, "_fp8", None)
+        if fp8 is not None and not fp8.calibrated:
+            with self._calib_lock:
+                if not fp8.calibrated:
+                    tower.calibrate_fp8(run)
+
     def encode_image(self, images, image_download_headers: Optional[Dict] = None, normalize=True) -> np.ndarray:
         kind, px = self._preprocess_images(images, image_download_headers)
         self.image_input_processed = px
+        self._calibrated(self.vision, lambda: self.vision.encode_u8(px) if kind == "u8" else self.vision.encode_f32(px))
         out = self.vision.encode_u8(px, normalize=bool(normalize)) if kind == "u8" else self.vision.encode_f32(px, normalize=bool(normalize))
         return self._convert_output(out)
 
@@ -270,9 +289,11 @@ class OPEN_CLIP(AbstractCLIPModel):
             self.load()
         if getattr(self, "_device_tokenizer", None) is not None:
             d_ids, lens = self._device_tokenizer.encode_device([sentence] if isinstance(sentence, str) else list(sentence))
+            self._calibrated(self.text, lambda: self.text.encode_device(d_ids, lens))
             return self._convert_output(self.text.encode_device(d_ids, lens, normalize=bool(normalize)))
         ids = self.tokenizer(sentence)
         ids = torch.as_tensor(np.asarray(ids))
+        self._calibrated(self.text, lambda: self.text.encode_ids(ids))
         return self._convert_output(self.text.encode_ids(ids, normalize=bool(normalize)))
 
     # engine extensions used by the chunking / bulk-ingest path ------------------------------------------------------
@@ -280,6 +301,7 @@ class OPEN_CLIP(AbstractCLIPModel):
         """'simple' / 'overlap' patch methods entirely on the device: -> (embeddings [n, count, D], boxes [n, count, 4])."""
         raw = [pil_to_rgb_u8(i) if isinstance(i, ImageType) else np.asarray(i) for i in images]
         u8, boxes = self._pre().chunk_grid_u8(raw, hn, wn, overlap)
+        self._calibrated(self.vision, lambda: self.vision.encode_u8(u8))
         emb = self._convert_output(self.vision.encode_u8(u8, normalize=bool(normalize)))
         return emb.reshape(len(raw), -1, emb.shape[-1]), boxes
 
