@@ -154,11 +154,9 @@ def main():
         gflop_per_emb = tarch.gflop_per_text(77)
         run_local = lambda: tower.encode_ids(ids)
     elif kind == "bert":
-        if args.precision != "bf16":
-            raise SystemExit("the fp8 path covers the pre-LN CLIP towers only")
         barch = archs.HF_BERT_ARCHS[wl["arch"]]
         sd = synthetic.random_bert_state_dict(barch, seed=0)
-        tower = towers.BertTower(barch, sd, dev)
+        tower = towers.BertTower(barch, sd, dev, precision=args.precision)
         ids = torch.randint(1000, barch.vocab, (batch, 77), generator=g)
         ids[:, 0], ids[:, -1] = 101, 102
         mask = torch.ones(batch, 77, dtype=torch.int64)

@@ -103,7 +103,7 @@ typedef struct mq_encoder_cfg {
     int32_t post_ln;    /* 0: pre-LN (CLIP); 1: post-LN (BERT) */
     int32_t mask;       /* MQ_MASK_* */
     float   ln_eps;
-    int32_t precision;  /* MQ_PREC_BF16 (0) or MQ_PREC_FP8 (pre-LN encoders only; width and mlp_dim multiples of 128) */
+    int32_t precision;  /* MQ_PREC_BF16 (0) or MQ_PREC_FP8 (width and mlp_dim multiples of 128) */
     int32_t reserved;
     /* fp8 path: static per-tensor activation scales, device fp32 [layers][2] = (attention output, MLP hidden), and the
      * calibration accumulator of the same shape (NULL = frozen scales; non-NULL = fold max|value| of this pass into it) */
@@ -285,6 +285,10 @@ int mq_quantize_weights_fp8(const void* d_W_bf16, int64_t ldw, void* d_W8, int64
 int mq_layernorm_fp8(const float* d_x, const float* d_g, const float* d_b, void* d_out_fp8, float* d_row_scale,
                      float* d_out_f32 /* optional fp32 copy of LN(x) (post-LN models), may be NULL */,
                      int64_t rows, int32_t W, float eps, void* stream);
+
+/* Per-row e4m3 quantisation without normalisation: q[r,:] = x[r,:] / s[r], s[r] = max|x[r,:]| / 448 (the GEMM operand of the
+ * first block of a post-LN fp8 encoder). */
+int mq_rowquant_fp8(const float* d_x, void* d_out_fp8, float* d_row_scale, int64_t rows, int32_t W, void* stream);
 
 /* out[M,N] = epilogue(A[M,K] @ W[N,K]^T).  A, W bf16 row-major (lda, ldw in elements);
  * K % 64 == 0, N % 4 == 0.  bias fp32 [N]; residual fp32 [M, ldc]; out bf16 or fp32 [M, ldc]

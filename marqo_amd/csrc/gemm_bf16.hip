@@ -234,6 +234,10 @@ struct GemmTune {
     GemmTune() : mt(env("MQ_GEMM_MT", 0)), persist(env("MQ_GEMM_PERSIST", 1)), big(env("MQ_GEMM_BIG", 0)), cgroup(env("MQ_GEMM_CGROUP", 8)), wide(env("MQ_GEMM_WIDE", 2)) {}
 };
 GemmTune g_tune;
+}  // namespace
+// mirrors of the knobs for gemm_fp8.hip
+int mq_gemm_knob_persist = g_tune.persist, mq_gemm_knob_cgroup = g_tune.cgroup, mq_gemm_knob_wide = g_tune.wide;
+namespace {
 
 constexpr int RESIDENT_SLOTS = 512;  // 256 CUs x 2 workgroups (64..80 KiB LDS each)
 
@@ -390,10 +394,10 @@ extern "C" int mq_tune(const char* key, int value) {
     MQ_CHECK_ARG(key, "mq_tune: null key");
     const std::string k(key);
     if (k == "gemm_mt") { g_tune.mt = value; mq_gemm_fp8_force_mt = value; }
-    else if (k == "gemm_persist") g_tune.persist = value;
+    else if (k == "gemm_persist") mq_gemm_knob_persist = g_tune.persist = value;
     else if (k == "gemm_big") g_tune.big = value;
-    else if (k == "gemm_cgroup") g_tune.cgroup = value;
-    else if (k == "gemm_wide") g_tune.wide = value;
+    else if (k == "gemm_cgroup") mq_gemm_knob_cgroup = g_tune.cgroup = value;
+    else if (k == "gemm_wide") mq_gemm_knob_wide = g_tune.wide = value;
     else if (k == "row_select") mq_tower_row_select = value;
     else if (k == "ln_fold") mq_tower_ln_fold = value;
     else { mq_set_error("mq_tune: unknown key %s", key); return MQ_ERR_INVALID; }

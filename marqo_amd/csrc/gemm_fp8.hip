@@ -19,11 +19,15 @@
 
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 
+// scheduling knobs shared with gemm_bf16.hip (mq_tune "gemm_persist" / "gemm_cgroup" / "gemm_wide")
+extern int mq_gemm_knob_persist, mq_gemm_knob_cgroup, mq_gemm_knob_wide;
+
 namespace {
 
 constexpr int BN = 128, BK = 128;          // BK in fp8 elements == bytes
 constexpr int W_TILE_BYTES = BN * BK;      // 16 KiB
 constexpr int UNIT_SCALE = 0x7F7F7F7F;     // e8m0 127 = 2^0 in every byte
+constexpr int RESIDENT_SLOTS = 512;        // 256 CUs x 2 workgroups
 
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
@@ -38,25 +42,47 @@ __device__ __forceinline__ int fswz(int row) {
 
 __device__ __forceinline__ float clamp448(float v) { return fminf(fmaxf(v, -448.f), 448.f); }
 
-// FLAGS: MQ_EPI_BIAS / GELU / QUICKGELU / RESIDUAL / OUT_F32 / OUT_FP8; ROWSCALE: a_scale is per row (else scalar)
-template <int FLAGS, int MT, bool ROWSCALE>
+// FLAGS: MQ_EPI_BIAS / GELU / QUICKGELU / RESIDUAL / OUT_F32 / OUT_FP8; ROWSCALE: a_scale is per row (else scalar).
+// PERSIST / cgroup / wide: the same persistent tile loop with cross-tile prefetch, L2-blocked tile order and widened
+// epilogue stores as gemm_bf16.hip (at K = 768 a tile is only SIX 128-deep k-steps here, so the per-tile overheads weigh
+// even more than in the bf16 kernel).  Widened stores: bf16 out -> 16 B per lane after one v_permlane16_swap per pair;
+// e4m3 out -> a lane's 4 codes per sub-tile become 16 CONSECUTIVE codes after a permlane16 stage (pairs of sub-tiles) and a
+// permlane32 stage (the two pairs), i.e. one 16-byte store per 16-row sub-tile instead of four 4-byte ones.
+template <int FLAGS, int MT, bool ROWSCALE, bool PERSIST>
 __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(
     const uint8_t* __restrict__ A, int64_t lda, const uint8_t* __restrict__ Wt, int64_t ldw,
     const float* __restrict__ a_scale, const float* __restrict__ w_scale,
     const float* __restrict__ bias, const float* residual, void* out, int64_t ldc,
     const float* __restrict__ out_scale, float* amax_out,
-    int M, int N, int K, int tiles_n, int num_tiles) {
+    int M, int N, int K, int tiles_n, int num_tiles, int cgroup, int band_rows, int wide) {
     constexpr int BM = 32 * MT;
     constexpr int A_TILE_BYTES = BM * BK;
     constexpr int STAGE_BYTES = A_TILE_BYTES + W_TILE_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const int bid = blockIdx.x;
     const int q = num_tiles >> 3, r = num_tiles & 7;
-    const int xcd = bid & 7, idx = bid >> 3;
-    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int tiles_m = (M + BM - 1) / BM;
+    auto tile_origin = [&](int vbid, int& m0, int& n0) {  // XCD-aware + L2-blocked map, see gemm_bf16.hip
+        const int xcd = vbid & 7, idx = vbid >> 3;
+        const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        int tm, tn;
+        if (cgroup > 0) {
+            const int band_tiles = band_rows * tiles_n;
+            const int band = tile / band_tiles, rb = tile - band * band_tiles;
+            const int rows_here = min(band_rows, tiles_m - band * band_rows);
+            const int full = rows_here * cgroup, ncg_full = tiles_n / cgroup;
+            int cg = rb / full, r2 = rb - cg * full, cw = cgroup;
+            if (cg >= ncg_full) { cg = ncg_full; r2 = rb - ncg_full * full; cw = tiles_n - ncg_full * cgroup; }
+            const int rr = r2 / cw;
+            tm = band * band_rows + rr;
+            tn = cg * cgroup + (r2 - rr * cw);
+        } else {
+            tm = tile / tiles_n;
+            tn = tile - tm * tiles_n;
+        }
+        m0 = tm * BM;
+        n0 = tn * BN;
+    };
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -68,18 +94,20 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(
     const int srow = lane >> 3;
     const uint8_t* a_src[MT];
     const uint8_t* w_src[4];
+    auto set_sources = [&](int m0, int n0) {
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        const int row = wave * (8 * MT) + i * 8 + srow;
-        int gm = m0 + row; gm = gm < M ? gm : M - 1;
-        a_src[i] = A + (int64_t)gm * lda + ((lane & 7) ^ fswz(row)) * 16;
-    }
+        for (int i = 0; i < MT; ++i) {
+            const int row = wave * (8 * MT) + i * 8 + srow;
+            int gm = m0 + row; gm = gm < M ? gm : M - 1;
+            a_src[i] = A + (int64_t)gm * lda + ((lane & 7) ^ fswz(row)) * 16;
+        }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = wave * 32 + i * 8 + srow;
-        int gn = n0 + row; gn = gn < N ? gn : N - 1;
-        w_src[i] = Wt + (int64_t)gn * ldw + ((lane & 7) ^ fswz(row)) * 16;
-    }
+        for (int i = 0; i < 4; ++i) {
+            const int row = wave * 32 + i * 8 + srow;
+            int gn = n0 + row; gn = gn < N ? gn : N - 1;
+            w_src[i] = Wt + (int64_t)gn * ldw + ((lane & 7) ^ fswz(row)) * 16;
+        }
+    };
     auto stage = [&](int buf, int kt) {
         char* sa = smem + buf * STAGE_BYTES + wave * (8 * MT * 128);
         char* sw = smem + buf * STAGE_BYTES + A_TILE_BYTES + wave * (32 * 128);
@@ -89,94 +117,107 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(
         for (int i = 0; i < 4; ++i) glds16(w_src[i] + (int64_t)kt * BK, sw + i * (8 * 128));
     };
 
-    // ---- fragment offsets: lane (l15, g) reads logical chunks 2g and 2g+1 of row base16 + l15 ---------------------
-    const int fr = fswz(l15);  // sub-tile bases are multiples of 16 rows
-    const int c0 = ((2 * g) ^ fr) << 4, c1 = ((2 * g + 1) ^ fr) << 4;
-    int a_off[MT], w_off[4];
-#pragma unroll
-    for (int t = 0; t < MT; ++t) a_off[t] = (wm * (16 * MT) + t * 16 + l15) * 128;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) w_off[t] = (wn * 64 + t * 16 + l15) * 128;
-
     f32x4 acc[MT][4];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    auto load_frag = [&](const char* base) -> i32x8 {
-        const uint4 lo = *(const uint4*)(base + c0);
-        const uint4 hi = *(const uint4*)(base + c1);
-        return i32x8{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
-    };
-
-    auto kstep = [&](int kt, auto prefetch_tag) {
-        constexpr bool PREFETCH = decltype(prefetch_tag)::value;
-        const char* sa = smem + (kt & 1) * STAGE_BYTES;
-        const char* sw = sa + A_TILE_BYTES;
-        char* na = smem + ((kt + 1) & 1) * STAGE_BYTES + wave * (8 * MT * 128);
-        char* nw = smem + ((kt + 1) & 1) * STAGE_BYTES + A_TILE_BYTES + wave * (32 * 128);
-        const int64_t koff = (int64_t)(kt + 1) * BK;
-        i32x8 af[MT], wf[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) wf[t] = load_frag(sw + w_off[t]);
-#pragma unroll
-        for (int t = 0; t < MT; ++t) af[t] = load_frag(sa + a_off[t]);
-        constexpr int NL = MT + 4;
-        constexpr int NM = 4 * MT;
-        constexpr int GAP = NM / NL > 0 ? NM / NL : 1;
-        int issued = 0;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                acc[mt][nt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[nt], af[mt], acc[mt][nt], 0, 0, 0, UNIT_SCALE, 0,
-                                                                              UNIT_SCALE);
-                const int done = mt * 4 + nt + 1;
-                if (PREFETCH && done % GAP == 0 && issued < NL) {
-                    if (issued < MT) glds16(a_src[issued] + koff, na + issued * (8 * 128));
-                    else glds16(w_src[issued - MT] + koff, nw + (issued - MT) * (8 * 128));
-                    ++issued;
-                }
-            }
-        if (PREFETCH) {
-#pragma unroll
-            for (; issued < NL; ++issued) {
-                if (issued < MT) glds16(a_src[issued] + koff, na + issued * (8 * 128));
-                else glds16(w_src[issued - MT] + koff, nw + (issued - MT) * (8 * 128));
-            }
-        }
-    };
-
-    const int nk = K / BK;
-    stage(0, 0);
-    for (int kt = 0; kt < nk - 1; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        kstep(kt, std::true_type{});
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    kstep(nk - 1, std::false_type{});
-
-    // ---- epilogue: lane owns out[m][n .. n+3]; dequantise with a_scale[m] * w_scale[n] -------------------------------
     const float a_scalar = ROWSCALE ? 1.f : a_scale[0];
     const float inv_out = (FLAGS & MQ_EPI_OUT_FP8) ? 1.0f / out_scale[0] : 1.f;
     float amax = 0.f;
+
+    const int nk = K / BK;
+    int vbid = blockIdx.x;
+    int m0, n0;
+    tile_origin(vbid, m0, n0);
+    set_sources(m0, n0);
+    stage(0, 0);
+    int buf = 0;
+    for (;;) {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int m = m0 + wm * (16 * MT) + mt * 16 + l15;
-        if (m >= M) continue;
-        const float sa = ROWSCALE ? a_scale[m] : a_scalar;
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            const int n = n0 + wn * 64 + nt * 16 + g * 4;
-            if (n >= N) continue;
-            const f32x4 sw4 = *(const f32x4*)(w_scale + n);
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // ---- fragment offsets: lane (l15, g) reads logical chunks 2g and 2g+1 of row base16 + l15 (recomputed per tile in
+        // the persistent form so that they are not live across the epilogue, cf. gemm_bf16.hip)
+        int l15f = l15, gf = g;
+        if (PERSIST) asm volatile("" : "+v"(l15f), "+v"(gf));
+        const int fr = fswz(l15f);  // sub-tile bases are multiples of 16 rows
+        const int c0 = ((2 * gf) ^ fr) << 4, c1 = ((2 * gf + 1) ^ fr) << 4;
+        int a_off[MT], w_off[4];
+#pragma unroll
+        for (int t = 0; t < MT; ++t) a_off[t] = (wm * (16 * MT) + t * 16 + l15f) * 128;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) w_off[t] = (wn * 64 + t * 16 + l15f) * 128;
+        auto load_frag = [&](const char* base) -> i32x8 {
+            const uint4 lo = *(const uint4*)(base + c0);
+            const uint4 hi = *(const uint4*)(base + c1);
+            return i32x8{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+        };
+        auto kstep = [&](int cur, int64_t koff, auto prefetch_tag) {
+            constexpr bool PREFETCH = decltype(prefetch_tag)::value;
+            const char* sa = smem + cur * STAGE_BYTES;
+            const char* sw = sa + A_TILE_BYTES;
+            char* na = smem + (cur ^ 1) * STAGE_BYTES + wave * (8 * MT * 128);
+            char* nw = smem + (cur ^ 1) * STAGE_BYTES + A_TILE_BYTES + wave * (32 * 128);
+            i32x8 af[MT], wf[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) wf[t] = load_frag(sw + w_off[t]);
+#pragma unroll
+            for (int t = 0; t < MT; ++t) af[t] = load_frag(sa + a_off[t]);
+            constexpr int NL = MT + 4;
+            constexpr int NM = 4 * MT;
+            constexpr int GAP = NM / NL > 0 ? NM / NL : 1;
+            int issued = 0;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    acc[mt][nt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[nt], af[mt], acc[mt][nt], 0, 0, 0, UNIT_SCALE, 0,
+                                                                                  UNIT_SCALE);
+                    const int done = mt * 4 + nt + 1;
+                    if (PREFETCH && done % GAP == 0 && issued < NL) {
+                        if (issued < MT) glds16(a_src[issued] + koff, na + issued * (8 * 128));
+                        else glds16(w_src[issued - MT] + koff, nw + (issued - MT) * (8 * 128));
+                        ++issued;
+                    }
+                }
+            if (PREFETCH) {
+#pragma unroll
+                for (; issued < NL; ++issued) {
+                    if (issued < MT) glds16(a_src[issued] + koff, na + issued * (8 * 128));
+                    else glds16(w_src[issued - MT] + koff, nw + (issued - MT) * (8 * 128));
+                }
+            }
+        };
+
+        for (int kt = 0; kt < nk - 1; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            kstep(buf, (int64_t)(kt + 1) * BK, std::true_type{});
+            buf ^= 1;
+        }
+        const int cm0 = m0, cn0 = n0;
+        bool more = false;
+        if (PERSIST) {
+            vbid += gridDim.x;
+            more = vbid < num_tiles;
+            if (more) {
+                tile_origin(vbid, m0, n0);
+                set_sources(m0, n0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (PERSIST && more) kstep(buf, 0, std::true_type{});
+        else kstep(buf, 0, std::false_type{});
+        buf ^= 1;
+
+        // ---- epilogue: lane owns out[m][n .. n+3]; dequantise with a_scale[m] * w_scale[n] ----------------------------
+        auto value = [&](int mt, int nt, int m, int n, bool ok, float sa) {
             f32x4 v = acc[mt][nt];
+            if (n < N) {
+                const f32x4 sw4 = *(const f32x4*)(w_scale + n);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] *= sa * sw4[e];
-            if (FLAGS & MQ_EPI_BIAS) v += *(const f32x4*)(bias + n);
+                for (int e = 0; e < 4; ++e) v[e] *= sa * sw4[e];
+                if (FLAGS & MQ_EPI_BIAS) v += *(const f32x4*)(bias + n);
+            }
             if (FLAGS & MQ_EPI_GELU) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
@@ -185,22 +226,98 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
             }
-            const int64_t o = (int64_t)m * ldc + n;
-            if (FLAGS & MQ_EPI_RESIDUAL) v += *(const f32x4*)(residual + o);
-            if (FLAGS & MQ_EPI_OUT_F32) {
-                *(f32x4*)((float*)out + o) = v;
-            } else if (FLAGS & MQ_EPI_OUT_FP8) {
-                amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
-                int w = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(v[0] * inv_out), clamp448(v[1] * inv_out), 0, false);
-                w = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(v[2] * inv_out), clamp448(v[3] * inv_out), w, true);
-                *(int*)((uint8_t*)out + o) = w;
+            if (FLAGS & MQ_EPI_RESIDUAL) {
+                if (ok) v += *(const f32x4*)(residual + (int64_t)m * ldc + n);
+            }
+            return v;
+        };
+        auto to_fp8 = [&](const f32x4& v) {
+            int w = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(v[0] * inv_out), clamp448(v[1] * inv_out), 0, false);
+            return __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(v[2] * inv_out), clamp448(v[3] * inv_out), w, true);
+        };
+        const int wave_n0 = cn0 + wn * 64;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = cm0 + wm * (16 * MT) + mt * 16 + l15;
+            const bool m_ok = m < M;
+            const float sa = ROWSCALE ? a_scale[m_ok ? m : M - 1] : a_scalar;
+            if (!(FLAGS & MQ_EPI_OUT_F32) && wide) {  // `wide` is wave-uniform: every lane takes part in the swaps
+                if (FLAGS & MQ_EPI_OUT_FP8) {
+                    unsigned int pr[2][2];  // pr[p] = 8 consecutive codes of pair p after the first exchange
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+                        int cw[2];
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const int n = wave_n0 + (2 * p + h) * 16 + g * 4;
+                            const bool ok = m_ok && n < N;
+                            const f32x4 v = value(mt, 2 * p + h, m, n, ok, sa);
+                            if (ok) amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+                            cw[h] = to_fp8(v);
+                        }
+                        const auto r0 = __builtin_amdgcn_permlane16_swap((unsigned)cw[0], (unsigned)cw[1], false, false);
+                        pr[p][0] = r0[0]; pr[p][1] = r0[1];  // n = pair block + (g&1)*16 + (g>>1)*8 .. +7
+                    }
+                    // lanes 32 apart (g and g^2) hold the two 8-code halves of the same 16 columns: lanes 32-63 of the first
+                    // operand <-> lanes 0-31 of the second
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(pr[0][0], pr[1][0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(pr[0][1], pr[1][1], false, false);
+                    // g < 2: (s0[0], s1[0]) = own pair-0 half, (s0[1], s1[1]) = lane g+2's pair-0 half (the next 8 columns)
+                    // g >= 2: (s0[0], s1[0]) = lane g-2's pair-1 half, (s0[1], s1[1]) = own pair-1 half
+                    const int n = wave_n0 + (g >> 1) * 32 + (g & 1) * 16;
+                    uint8_t* dst = (uint8_t*)out + (int64_t)m * ldc + n;
+                    if (m_ok && n + 16 <= N) *(uint4*)dst = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                    else if (m_ok && n < N) {  // ragged right edge (N % 4 == 0): dword by dword
+                        const unsigned int wds[4] = {s0[0], s1[0], s0[1], s1[1]};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (n + 4 * e < N) *(unsigned int*)(dst + 4 * e) = wds[e];
+                    }
+                } else {
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+                        uint2 a, b;
+                        {
+                            const int n = wave_n0 + (2 * p) * 16 + g * 4;
+                            const f32x4 v = value(mt, 2 * p, m, n, m_ok && n < N, sa);
+                            a.x = pack_bf16x2(v[0], v[1]); a.y = pack_bf16x2(v[2], v[3]);
+                        }
+                        {
+                            const int n = wave_n0 + (2 * p + 1) * 16 + g * 4;
+                            const f32x4 v = value(mt, 2 * p + 1, m, n, m_ok && n < N, sa);
+                            b.x = pack_bf16x2(v[0], v[1]); b.y = pack_bf16x2(v[2], v[3]);
+                        }
+                        const auto r0 = __builtin_amdgcn_permlane16_swap(a.x, b.x, false, false);
+                        const auto r1 = __builtin_amdgcn_permlane16_swap(a.y, b.y, false, false);
+                        const int n = wave_n0 + p * 32 + (g & 1) * 16 + (g >> 1) * 8;
+                        bf16_t* dst = (bf16_t*)out + (int64_t)m * ldc + n;
+                        if (m_ok && n + 8 <= N) *(uint4*)dst = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+                        else if (m_ok && n < N) *(uint2*)dst = make_uint2(r0[0], r1[0]);
+                    }
+                }
             } else {
-                uint2 p;
-                p.x = pack_bf16x2(v[0], v[1]);
-                p.y = pack_bf16x2(v[2], v[3]);
-                *(uint2*)((bf16_t*)out + o) = p;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const int n = wave_n0 + nt * 16 + g * 4;
+                    const bool ok = m_ok && n < N;
+                    const f32x4 v = value(mt, nt, m, n, ok, sa);
+                    if (!ok) continue;
+                    const int64_t o = (int64_t)m * ldc + n;
+                    if (FLAGS & MQ_EPI_OUT_F32) {
+                        *(f32x4*)((float*)out + o) = v;
+                    } else if (FLAGS & MQ_EPI_OUT_FP8) {
+                        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+                        *(int*)((uint8_t*)out + o) = to_fp8(v);
+                    } else {
+                        uint2 p;
+                        p.x = pack_bf16x2(v[0], v[1]);
+                        p.y = pack_bf16x2(v[2], v[3]);
+                        *(uint2*)((bf16_t*)out + o) = p;
+                    }
+                }
             }
         }
+        if (!PERSIST || !more) break;
     }
     if ((FLAGS & MQ_EPI_OUT_FP8) && amax_out) {
         amax = wave_max(amax);
@@ -208,7 +325,6 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(
     }
 }
 
-constexpr int RESIDENT_SLOTS = 512;
 int choose_mt(int M, int N) {
     const int tiles_n = (N + BN - 1) / BN;
     const int cands[4] = {2, 4, 5, 6};
@@ -229,21 +345,27 @@ struct Fp8Args {
     const float* residual; void* out; int64_t ldc; const float* out_scale; float* amax; int M, N, K;
 };
 
-template <int FLAGS, int MT, bool ROWSCALE>
+template <int FLAGS, int MT, bool ROWSCALE, bool PERSIST>
 int launch_fp8_mt(const Fp8Args& a, hipStream_t s) {
     constexpr int BM = 32 * MT;
     constexpr int LDS = 2 * (BM * BK + W_TILE_BYTES);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_fp8_kernel<FLAGS, MT, ROWSCALE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_fp8_kernel<FLAGS, MT, ROWSCALE, PERSIST>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) { mq_set_error("mq_gemm_fp8: hipFuncSetAttribute: %s", hipGetErrorString(e)); return MQ_ERR_HIP; }
         attr_set = true;
     }
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
     const int num_tiles = tiles_m * tiles_n;
-    hipLaunchKernelGGL((gemm_fp8_kernel<FLAGS, MT, ROWSCALE>), dim3(num_tiles), dim3(256), LDS, s, (const uint8_t*)a.A, a.lda,
+    const int cgroup = (mq_gemm_knob_cgroup > 0 && tiles_n > mq_gemm_knob_cgroup && tiles_m >= 16) ? mq_gemm_knob_cgroup : 0;
+    const int band_rows = (tiles_m + 7) / 8;
+    // 16-byte epilogue stores need 16-B aligned rows (bf16: ldc % 8; e4m3: ldc % 16)
+    const int row_align = (FLAGS & MQ_EPI_OUT_FP8) ? 16 : 8;
+    const int wide = (mq_gemm_knob_wide && !(FLAGS & MQ_EPI_OUT_F32) && a.ldc % row_align == 0 && ((uintptr_t)a.out & 15) == 0) ? 1 : 0;
+    const int grid = PERSIST && num_tiles > RESIDENT_SLOTS ? RESIDENT_SLOTS : num_tiles;
+    hipLaunchKernelGGL((gemm_fp8_kernel<FLAGS, MT, ROWSCALE, PERSIST>), dim3(grid), dim3(256), LDS, s, (const uint8_t*)a.A, a.lda,
                        (const uint8_t*)a.W, a.ldw, a.a_scale, a.w_scale, a.bias, a.residual, a.out, a.ldc, a.out_scale, a.amax, a.M, a.N,
-                       a.K, tiles_n, num_tiles);
+                       a.K, tiles_n, num_tiles, cgroup, band_rows, wide);
     MQ_CHECK_LAUNCH("mq_gemm_fp8");
     return MQ_OK;
 }
@@ -251,11 +373,12 @@ int launch_fp8_mt(const Fp8Args& a, hipStream_t s) {
 template <int FLAGS, bool ROWSCALE>
 int launch_fp8(const Fp8Args& a, int force_mt, hipStream_t s) {
     const int mt = force_mt ? force_mt : choose_mt(a.M, a.N);
+    const bool persist = mq_gemm_knob_persist != 0;
     switch (mt) {
-        case 2: return launch_fp8_mt<FLAGS, 2, ROWSCALE>(a, s);
-        case 5: return launch_fp8_mt<FLAGS, 5, ROWSCALE>(a, s);
-        case 6: return launch_fp8_mt<FLAGS, 6, ROWSCALE>(a, s);
-        default: return launch_fp8_mt<FLAGS, 4, ROWSCALE>(a, s);
+        case 2: return persist ? launch_fp8_mt<FLAGS, 2, ROWSCALE, true>(a, s) : launch_fp8_mt<FLAGS, 2, ROWSCALE, false>(a, s);
+        case 5: return persist ? launch_fp8_mt<FLAGS, 5, ROWSCALE, true>(a, s) : launch_fp8_mt<FLAGS, 5, ROWSCALE, false>(a, s);
+        case 6: return launch_fp8_mt<FLAGS, 6, ROWSCALE, false>(a, s);  // one-tile form only (register budget, as in gemm_bf16.hip)
+        default: return persist ? launch_fp8_mt<FLAGS, 4, ROWSCALE, true>(a, s) : launch_fp8_mt<FLAGS, 4, ROWSCALE, false>(a, s);
     }
 }
 

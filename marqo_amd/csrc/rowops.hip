@@ -50,7 +50,9 @@ __global__ __launch_bounds__(256, (CH <= 4 ? 8 : 4)) void layernorm_kernel(
 }
 
 // LN with e4m3 output and a dynamic per-row scale (the row is already in registers, so the absmax is one wave reduction)
-template <int CH>
+// NORM = false: no normalisation / affine, only the per-row e4m3 quantisation of x itself (the first block of a post-LN fp8
+// encoder, whose input rows come from the embedding kernels)
+template <int CH, bool NORM = true>
 __global__ __launch_bounds__(256, (CH <= 4 ? 8 : 4)) void layernorm_fp8_kernel(
     const float* __restrict__ x, const float* __restrict__ gam, const float* __restrict__ bet, uint8_t* __restrict__ out8,
     float* __restrict__ row_scale, float* out_f32, int64_t rows, int W, float eps) {
@@ -65,17 +67,21 @@ __global__ __launch_bounds__(256, (CH <= 4 ? 8 : 4)) void layernorm_fp8_kernel(
         const int c = lane + i * 64;
         v[i] = c < nch ? *(const f32x4*)(xr + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    ln_normalize_row<CH>(v, lane, nch, W, eps);
+    if (NORM) ln_normalize_row<CH>(v, lane, nch, W, eps);
     float mx = 0.f;
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
         const int c = lane + i * 64;
         if (c < nch) {
-            const f32x4 gg = *(const f32x4*)(gam + c * 4);
-            const f32x4 bb = *(const f32x4*)(bet + c * 4);
+            if (NORM) {
+                const f32x4 gg = *(const f32x4*)(gam + c * 4);
+                const f32x4 bb = *(const f32x4*)(bet + c * 4);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { v[i][e] = v[i][e] * gg[e] + bb[e]; mx = fmaxf(mx, fabsf(v[i][e])); }
-            if (out_f32) *(f32x4*)(out_f32 + row * W + c * 4) = v[i];
+                for (int e = 0; e < 4; ++e) v[i][e] = v[i][e] * gg[e] + bb[e];
+                if (out_f32) *(f32x4*)(out_f32 + row * W + c * 4) = v[i];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) mx = fmaxf(mx, fabsf(v[i][e]));
         }
     }
     mx = wave_max(mx);
@@ -140,6 +146,19 @@ extern "C" int mq_layernorm_fp8(const float* d_x, const float* d_g, const float*
     MQ_DISPATCH_CH(W, hipLaunchKernelGGL(layernorm_fp8_kernel<CH>, dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, s, d_x, d_g, d_b,
                                          (uint8_t*)d_out_fp8, d_row_scale, d_out_f32, rows, (int)W, eps));
     MQ_CHECK_LAUNCH("mq_layernorm_fp8");
+    return MQ_OK;
+}
+
+extern "C" int mq_rowquant_fp8(const float* d_x, void* d_out_fp8, float* d_row_scale, int64_t rows, int32_t W, void* stream) {
+    MQ_CHECK_ARG(d_x && d_out_fp8 && d_row_scale, "mq_rowquant_fp8: null pointer");
+    MQ_CHECK_ARG(W >= 4 && W % 4 == 0 && W <= 64 * 4 * LN_MAX_CHUNKS, "mq_rowquant_fp8: W=%d unsupported (multiple of 4, <= 2048)", W);
+    if (rows <= 0) return MQ_OK;
+    hipStream_t s = (hipStream_t)stream;
+    MqProfScope prof(1, s);
+    MQ_DISPATCH_CH(W, hipLaunchKernelGGL((layernorm_fp8_kernel<CH, false>), dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, s, d_x,
+                                         (const float*)nullptr, (const float*)nullptr, (uint8_t*)d_out_fp8, d_row_scale, (float*)nullptr, rows,
+                                         (int)W, 0.f));
+    MQ_CHECK_LAUNCH("mq_rowquant_fp8");
     return MQ_OK;
 }
 

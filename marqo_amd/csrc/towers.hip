@@ -21,6 +21,7 @@ int mq_pool(const float* d_x, const int32_t* d_cu, int64_t nseq, float* d_out, i
 int mq_last_rows(const int32_t* d_cu, int32_t* d_rows, int64_t nseq, hipStream_t s);
 int mq_cls_rows(int32_t* d_rows, int64_t n, int T, hipStream_t s);
 int mq_move_rows(void* d_sparse, const int32_t* d_idx, void* d_dense, int64_t n, int64_t row_bytes, bool scatter, hipStream_t s);
+extern "C" int mq_rowquant_fp8(const float* d_x, void* d_out_fp8, float* d_row_scale, int64_t rows, int32_t W, void* stream);
 
 // layouts the ctypes binding (marqo_amd/_lib.py) and tests/test_abi.py assume
 static_assert(sizeof(mq_block_weights) == 26 * 8, "mq_block_weights layout");
@@ -62,7 +63,6 @@ int check_encoder_cfg(const mq_encoder_cfg* c) {
     MQ_CHECK_ARG(c->act == MQ_ACT_GELU || c->act == MQ_ACT_QUICKGELU, "encoder act %d unsupported", c->act);
     MQ_CHECK_ARG(c->precision == MQ_PREC_BF16 || c->precision == MQ_PREC_FP8, "encoder precision %d unsupported", c->precision);
     if (c->precision == MQ_PREC_FP8) {
-        MQ_CHECK_ARG(!c->post_ln, "the fp8 path supports pre-LN (CLIP) encoders only");
         MQ_CHECK_ARG(c->width % 128 == 0 && c->mlp_dim % 128 == 0, "fp8 path needs width / mlp_dim multiples of 128");
         MQ_CHECK_ARG(c->d_fp8_act_scale, "fp8 path needs d_fp8_act_scale");
     }
@@ -185,10 +185,12 @@ int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* bloc
     // activation maxima must see every row); x_sel must fit behind the fc1 output inside `qf`
     const size_t xsel_off = align_up((size_t)(nsel > 0 ? nsel : 0) * F * 2, WS_ALIGN);
     const bool select_last = d_sel && nsel > 0 && nsel * 2 <= rows && mq_tower_row_select &&
-                             !(cfg->precision == MQ_PREC_FP8 && cfg->d_fp8_act_amax) &&
+                             !(cfg->precision == MQ_PREC_FP8 && (cfg->d_fp8_act_amax || cfg->post_ln)) &&
                              xsel_off + (size_t)nsel * W * 4 <= (size_t)rows * big * 2;
 
-    if (cfg->post_ln) MQ_TRY(mq_cast_bf16(d_x, h, rows * W, s));  // block input as GEMM operand
+    // block input as GEMM operand (post-LN: afterwards every LayerNorm leaves it behind)
+    if (cfg->post_ln && cfg->precision == MQ_PREC_FP8) MQ_TRY(mq_rowquant_fp8(d_x, h, row_scale, rows, W, s));
+    else if (cfg->post_ln) MQ_TRY(mq_cast_bf16(d_x, h, rows * W, s));
 
     for (int l = 0; l < cfg->layers; ++l) {
         const mq_block_weights& b = blocks[l];
@@ -227,6 +229,19 @@ int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* bloc
             float* m_attn = cfg->d_fp8_act_amax ? cfg->d_fp8_act_amax + 2 * l : nullptr;
             float* m_mlp = m_attn ? m_attn + 1 : nullptr;
             const int act8 = (cfg->act == MQ_ACT_QUICKGELU ? MQ_EPI_QUICKGELU : MQ_EPI_GELU) | MQ_EPI_BIAS | MQ_EPI_OUT_FP8;
+            if (cfg->post_ln) {
+                // x = ln1(x + out(attn(qkv(x)))) ; x = ln2(x + fc2(act(fc1(x)))): each LayerNorm rewrites x (fp32, in place:
+                // a wave holds its whole row before it stores) and leaves the e4m3 row + scale for the next GEMM
+                MQ_TRY(mq_gemm_fp8(h, W, b.qkv_w8, W, row_scale, 1, b.qkv_ws, b.qkv_b, nullptr, qf, 3 * W, nullptr, nullptr, rows, 3 * W, W,
+                                   MQ_EPI_BIAS, s));
+                MQ_TRY(mq_attention_ex(qf, a, d_cu_seqlens, nseq, fixed_len, max_len, W, cfg->heads, cfg->mask, 1, s_attn, m_attn, s));
+                MQ_TRY(mq_gemm_fp8(a, W, b.out_w8, W, s_attn, 0, b.out_ws, b.out_b, d_x, d_x, W, nullptr, nullptr, rows, W, W, res_flags, s));
+                MQ_TRY(mq_layernorm_fp8(d_x, b.ln1_g, b.ln1_b, h, row_scale, d_x, rows, W, cfg->ln_eps, s));
+                MQ_TRY(mq_gemm_fp8(h, W, b.fc1_w8, W, row_scale, 1, b.fc1_ws, b.fc1_b, nullptr, qf, F, s_mlp, m_mlp, rows, F, W, act8, s));
+                MQ_TRY(mq_gemm_fp8(qf, F, b.fc2_w8, F, s_mlp, 0, b.fc2_ws, b.fc2_b, d_x, d_x, W, nullptr, nullptr, rows, W, F, res_flags, s));
+                MQ_TRY(mq_layernorm_fp8(d_x, b.ln2_g, b.ln2_b, h, row_scale, d_x, rows, W, cfg->ln_eps, s));
+                continue;
+            }
             MQ_TRY(mq_layernorm_fp8(d_x, b.ln1_g, b.ln1_b, h, row_scale, nullptr, rows, W, cfg->ln_eps, s));
             MQ_TRY(mq_gemm_fp8(h, W, b.qkv_w8, W, row_scale, 1, b.qkv_ws, b.qkv_b, nullptr, qf, 3 * W, nullptr, nullptr, rows, 3 * W, W,
                                MQ_EPI_BIAS, s));

@@ -409,8 +409,11 @@ class ClipTextTower(_TextTowerBase):
 class BertTower(_TextTowerBase):
     """BERT-family encoder + pooling (HF `BertModel` checkpoint tensors, with or without a `bert.` prefix)."""
 
-    def __init__(self, arch: BertArch, sd: Dict[str, Tensor], device: str, pooling: str = "mean"):
+    def __init__(self, arch: BertArch, sd: Dict[str, Tensor], device: str, pooling: str = "mean", precision: str = "bf16"):
         super().__init__(device)
+        if precision not in ("bf16", "fp8"):
+            raise ValueError(f"precision must be 'bf16' or 'fp8', got {precision!r}")
+        self.precision = precision
         self.arch = arch
         if pooling not in ("mean", "cls"):
             raise ValueError(f"pooling must be 'mean' or 'cls', got {pooling!r}")
@@ -447,6 +450,8 @@ class BertTower(_TextTowerBase):
         self.cfg = L.BertCfg(enc=_encoder_cfg(W, arch.layers, arch.heads, F, False, True, L.MQ_MASK_NONE, arch.ln_eps),
                              vocab=arch.vocab, max_pos=arch.max_pos,
                              pool=L.MQ_POOL_MEAN if pooling == "mean" else L.MQ_POOL_CLS)
+        if precision == "fp8":
+            self._enable_fp8(self._blocks, arch.layers, W, F)
 
     def encode_ids(self, ids: Tensor, attention_mask: Tensor, normalize: bool = True) -> Tensor:
         """ids / attention_mask: int [n, S] as produced by the HF tokenizer call of the reference

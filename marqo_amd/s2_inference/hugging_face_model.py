@@ -8,6 +8,7 @@ F.normalize (:194-195) run in libmarqo_hip.so on packed (un-padded) sequences.
 from __future__ import annotations
 
 import os
+import threading
 from typing import List, Optional, Union
 
 import numpy as np
@@ -44,6 +45,11 @@ class HuggingFaceModelProperties:
             raise ValueError("pooling_method must be 'mean' or 'cls'")
         self.pooling_method: Optional[str] = pm  # None: inferred at load from 1_Pooling/config.json, default mean
         self.trust_remote_code: bool = bool(p.get("trust_remote_code", p.get("trustRemoteCode", False)))
+        # engine extension: operand type of the encoder-block GEMMs, "bf16" (default) or "fp8" (e4m3 MX-MFMA; static activation
+        # scales calibrated on the first batch), see open_clip_model.OpenCLIPModelProperties
+        self.engine_precision: str = p.get("enginePrecision", p.get("engine_precision", os.environ.get("MARQO_AMD_PRECISION", "bf16")))
+        if self.engine_precision not in ("bf16", "fp8"):
+            raise ValueError("'enginePrecision' must be 'bf16' or 'fp8'")
 
     def dict(self) -> dict:
         return dict(self.__dict__)
@@ -60,6 +66,7 @@ class HuggingFaceModel(AbstractEmbeddingModel):
         self._tokenizer = None
         self._pooling_func = None
         self.weights_source = None
+        self._calib_lock = threading.Lock()
 
     def _build_model_properties(self, model_properties: dict) -> HuggingFaceModelProperties:
         try:
@@ -110,7 +117,10 @@ class HuggingFaceModel(AbstractEmbeddingModel):
             raise InvalidModelPropertiesError(f"'dimensions'={props.dimensions} but the encoder width is {arch.width}")
         pooling = props.pooling_method or checkpoint.read_pooling_config(directory) or "mean"
         self.arch = arch
-        self._model = towers.BertTower(arch, sd, self.device, pooling=pooling)
+        try:
+            self._model = towers.BertTower(arch, sd, self.device, pooling=pooling, precision=props.engine_precision)
+        except ValueError as e:  # e.g. fp8 needs width / mlp_dim multiples of 128
+            raise InvalidModelPropertiesError(str(e)) from e
         self._pooling_func = pooling
         # K14: WordPiece on the device for ASCII texts (identical ids; the host tokeniser stays the definition of record and
         # handles every other text).  MARQO_AMD_HOST_TOKENIZER=1 keeps everything on the host.
@@ -118,6 +128,14 @@ class HuggingFaceModel(AbstractEmbeddingModel):
         if isinstance(self._tokenizer, WordPieceTokenizer) and os.environ.get("MARQO_AMD_HOST_TOKENIZER", "0") != "1":
             from marqo_amd.engine.gpu_tokenizers import DeviceWordPieceTokenizer
             self._device_tokenizer = DeviceWordPieceTokenizer(self._tokenizer, self.device)
+
+    def _calibrated(self, run) -> None:
+        """fp8 tower: freeze the static activation scales on the first batch (two recording passes), once"""
+        fp8 = getattr(self._model, "_fp8", None)
+        if fp8 is not None and not fp8.calibrated:
+            with self._calib_lock:
+                if not fp8.calibrated:
+                    self._model.calibrate_fp8(run)
 
     @staticmethod
     def _do_lower_case(directory: str) -> bool:
@@ -139,9 +157,11 @@ class HuggingFaceModel(AbstractEmbeddingModel):
             self.load()
         if getattr(self, "_device_tokenizer", None) is not None:
             d_ids, lens = self._device_tokenizer.encode_device(sentence, self.model_properties.tokens)
+            self._calibrated(lambda: self._model.encode_device(d_ids, lens))
             return self._model.encode_device(d_ids, lens, normalize=bool(normalize)).cpu().numpy()
         tok = self._tokenizer(sentence, max_length=self.model_properties.tokens)
         ids = torch.from_numpy(tok["input_ids"])
+        self._calibrated(lambda: self._model.encode_ids(ids, torch.from_numpy(tok["attention_mask"])))
         mask = torch.from_numpy(tok["attention_mask"])
         return self._model.encode_ids(ids, mask, normalize=bool(normalize)).cpu().numpy()
 

@@ -67,7 +67,8 @@ def test_gemm_fp8_equals_product_of_dequantised_operands(mt):
     L.check(lib.mq_tune(b"gemm_mt", mt))
     try:
         g = torch.Generator(device="cuda").manual_seed(2 + mt)
-        for (M, N, K) in [(50, 64, 128), (257, 768, 256), (1000, 132, 384), (4097, 2304, 768), (12800, 768, 3072), (16, 4, 128)]:
+        for (M, N, K) in [(50, 64, 128), (257, 768, 256), (1000, 132, 384), (4097, 2304, 768), (12800, 768, 3072), (16, 4, 128),
+                          (300, 176, 128), (300, 1160, 256), (20000, 1168, 128)]:
             A8 = torch.randint(0, 256, (M, K), dtype=torch.uint8, device="cuda", generator=g)
             A8[(A8 & 0x7F) == 0x7F] = 0x30  # no NaN codes (0x7F / 0xFF)
             W8 = torch.randint(0, 256, (N, K), dtype=torch.uint8, device="cuda", generator=g)
@@ -109,6 +110,41 @@ def test_gemm_fp8_equals_product_of_dequantised_operands(mt):
         L.check(lib.mq_tune(b"gemm_mt", 0))
 
 
+def test_gemm_fp8_scheduling_knobs_are_bit_identical():
+    """persistent tile loop / L2-blocked order / widened stores change scheduling and store width only: every epilogue form
+    must give bit-identical results with the knobs off and on, on shapes with ragged right edges and many tiles per workgroup"""
+    lib = L.load()
+    g = torch.Generator(device="cuda").manual_seed(99)
+    knobs_off = dict(gemm_persist=0, gemm_cgroup=0, gemm_wide=0)
+    knobs_on = dict(gemm_persist=1, gemm_cgroup=8, gemm_wide=2)
+    try:
+        for (M, N, K) in [(12800, 3072, 768), (12800, 2304, 768), (20000, 1168, 128), (300, 176, 256), (5000, 1552, 384)]:
+            A8 = torch.randint(0, 256, (M, K), dtype=torch.uint8, device="cuda", generator=g) & 0xBF
+            W8 = torch.randint(0, 256, (N, K), dtype=torch.uint8, device="cuda", generator=g) & 0xBF
+            sa = torch.rand(M, device="cuda", generator=g) + 0.5
+            sw = (torch.rand(N, device="cuda", generator=g) + 0.5) * 0.01
+            bias = torch.randn(N, device="cuda", generator=g)
+            osc = torch.tensor([0.05], device="cuda")
+            outs = {}
+            for name, knobs in (("off", knobs_off), ("on", knobs_on)):
+                for k, v in knobs.items():
+                    L.check(lib.mq_tune(k.encode(), v))
+                res = []
+                for flags, dt in ((L.MQ_EPI_BIAS, torch.bfloat16), (L.MQ_EPI_BIAS | L.MQ_EPI_GELU | L.MQ_EPI_OUT_FP8, torch.uint8),
+                                  (L.MQ_EPI_OUT_F32, torch.float32)):
+                    out = torch.zeros(M, N, device="cuda", dtype=dt)
+                    amax = torch.zeros(1, device="cuda")
+                    L.check(lib.mq_gemm_fp8(A8.data_ptr(), K, W8.data_ptr(), K, sa.data_ptr(), 1, sw.data_ptr(), bias.data_ptr(), 0, out.data_ptr(), N,
+                                            osc.data_ptr(), amax.data_ptr(), M, N, K, flags, _stream()))
+                    res += [out, amax.clone()]
+                outs[name] = res
+            for a, b in zip(outs["off"], outs["on"]):
+                assert torch.equal(a, b), (M, N, K, a.dtype)
+    finally:
+        for k, v in knobs_on.items():
+            L.check(lib.mq_tune(k.encode(), v))
+
+
 def _cos_err(a, b):
     a, b = a.double().cpu(), b.double().cpu()
     return float((1 - (a * b).sum(-1) / (a.norm(dim=-1) * b.norm(dim=-1))).max())
@@ -141,3 +177,45 @@ def test_fp8_towers_vs_oracle_and_bf16():
     assert e_t8 < 1e-2
     with pytest.raises(RuntimeError):
         towers.VitTower(varch, sd, "cuda:0").calibrate_fp8(lambda: None)
+
+
+def test_rowquant_fp8_matches_torch():
+    lib = L.load()
+    g = torch.Generator(device="cuda").manual_seed(21)
+    x = torch.randn(333, 768, device="cuda", generator=g) * torch.rand(333, 1, device="cuda", generator=g) * 5
+    x[5] = 0.0
+    q = torch.empty(333, 768, dtype=torch.uint8, device="cuda")
+    sc = torch.empty(333, device="cuda")
+    L.check(lib.mq_rowquant_fp8(x.data_ptr(), q.data_ptr(), sc.data_ptr(), 333, 768, _stream()))
+    want_sc = x.abs().amax(1) / 448
+    want_sc[5] = 1.0
+    assert torch.allclose(sc, want_sc, rtol=1e-6)
+    ref = (x / want_sc[:, None]).to(torch.float8_e4m3fn)
+    assert torch.equal(q.view(torch.float8_e4m3fn).float(), ref.float())
+
+
+def test_fp8_bert_vs_oracle_and_bf16():
+    """post-LN (BERT) encoder on the fp8 path: every LayerNorm rewrites the fp32 stream and leaves the e4m3 operand of the next
+    GEMM.  BERT-base shape at 4 layers, ragged packed sequences, mean and CLS pooling."""
+    from marqo_amd.engine import archs, towers
+    from oracle import towers as O
+    cfg = O.BertConfig(vocab=30522, max_pos=512, width=768, layers=4, heads=12, mlp_dim=3072)
+    arch = archs.BertArch(vocab=30522, max_pos=512, width=768, layers=4, heads=12, mlp_dim=3072)
+    sd = O.synthetic_bert_state_dict(cfg, seed=1)
+    g = torch.Generator().manual_seed(3)
+    n, S = 24, 40
+    lens = torch.randint(3, S + 1, (n,), generator=g)
+    ids = torch.randint(1000, 30522, (n, S), generator=g)
+    mask = (torch.arange(S)[None, :] < lens[:, None]).long()
+    ids = ids * mask
+    for pooling in ("mean", "cls"):
+        cfg.pooling = pooling
+        ref = O.hf_encode(sd, cfg, ids, mask)
+        bf = towers.BertTower(arch, sd, "cuda:0", pooling=pooling).encode_ids(ids, mask)
+        t8 = towers.BertTower(arch, sd, "cuda:0", pooling=pooling, precision="fp8")
+        t8.calibrate_fp8(lambda: t8.encode_ids(ids[:16], mask[:16]))
+        f8 = t8.encode_ids(ids, mask)
+        e_bf, e_f8 = _cos_err(bf, ref), _cos_err(f8, ref)
+        print(f"BERT 4L {pooling}: 1-cos vs fp32 oracle  bf16 {e_bf:.2e}  fp8 {e_f8:.2e}")
+        assert e_bf < 3e-4 and e_f8 < 1e-2
+        assert torch.equal(t8.encode_ids(ids, mask), f8)
