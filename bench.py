@@ -152,17 +152,19 @@ def main():
         ids = clip_ids(batch, 75, 75)
         towers_used = [tower]
         gflop_per_emb = tarch.gflop_per_text(77)
-        run_local = lambda: tower.encode_ids(ids)
+        # ids resident in HBM like the images (what the device tokeniser hands over); only the n lengths live on the host
+        d_ids, lens = ids.to(torch.int32).to(dev), ids.argmax(1) + 1
+        run_local = lambda: tower.encode_device(d_ids, lens)
     elif kind == "bert":
         barch = archs.HF_BERT_ARCHS[wl["arch"]]
         sd = synthetic.random_bert_state_dict(barch, seed=0)
         tower = towers.BertTower(barch, sd, dev, precision=args.precision)
         ids = torch.randint(1000, barch.vocab, (batch, 77), generator=g)
         ids[:, 0], ids[:, -1] = 101, 102
-        mask = torch.ones(batch, 77, dtype=torch.int64)
         towers_used = [tower]
         gflop_per_emb = barch.gflop_per_text(77)
-        run_local = lambda: tower.encode_ids(ids, mask)
+        d_ids, lens = ids.to(torch.int32).to(dev), torch.full((batch,), 77, dtype=torch.int64)
+        run_local = lambda: tower.encode_device(d_ids, lens)
     else:  # mixed: half images, half texts of ragged length through the two towers of one model
         sd = synthetic.random_open_clip_state_dict(vision=varch, text=tarch, seed=0)
         vt = towers.VitTower(varch, sd, dev, precision=args.precision)
@@ -172,9 +174,10 @@ def main():
         images = images_cpu.to(dev)
         ids = clip_ids(batch - n_img, 5, 75)
         towers_used = [vt, tt]
+        d_ids, lens = ids.to(torch.int32).to(dev), ids.argmax(1) + 1
         mean_tokens = float((ids.argmax(1) + 1).float().mean())
         gflop_per_emb = (n_img * varch.gflop_per_image + (batch - n_img) * tarch.gflop_per_text(int(round(mean_tokens)))) / batch
-        run_local = lambda: torch.cat([vt.encode_u8(images), tt.encode_ids(ids)], dim=0)
+        run_local = lambda: torch.cat([vt.encode_u8(images), tt.encode_device(d_ids, lens)], dim=0)
     tower = towers_used[0]
 
     if args.precision == "fp8":

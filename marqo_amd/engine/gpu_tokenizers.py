@@ -106,7 +106,7 @@ def pack_texts(texts: Sequence[str]) -> Tuple[np.ndarray, np.ndarray]:
     blob = "".join(texts).encode("ascii")
     offsets = np.zeros(len(texts) + 1, dtype=np.int64)
     np.cumsum([len(t) for t in texts], out=offsets[1:])
-    return np.frombuffer(blob + b"\0", dtype=np.uint8), offsets
+    return np.frombuffer(bytearray(blob + b"\0"), dtype=np.uint8), offsets
 
 
 def wordpiece_in_scope(tok: WordPieceTokenizer, text: str) -> bool:
