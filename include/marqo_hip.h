@@ -351,7 +351,8 @@ int mq_l2_normalize(const float* d_x, float* d_out, int64_t rows, int32_t D, voi
 /* ---- text tokenisation on device (K14) ------------------------------------------------------------------- */
 /* The reference tokenises on the host with third-party code (open_clip SimpleTokenizer at
  * src/marqo/core/inference/embedding_models/open_clip_model.py:277, transformers BertTokenizer at
- * .../hugging_face_model.py:179-185).  These entry points run the same published algorithms one GPU thread per text for
+ * .../hugging_face_model.py:179-185).  These entry points run the same published algorithms (one GPU thread per text for the
+ * splitting, one per word for the vocabulary work) for
  * texts inside the device scope — printable ASCII + \t \n \r — and flag every other text (d_status[i] = 1, d_lens[i] = 0)
  * so that the caller tokenises it with the host tokeniser; results for in-scope texts are identical to the host ones.
  * Texts are UTF-8 bytes packed back to back: text i = d_text[d_offsets[i] .. d_offsets[i+1]).
@@ -374,15 +375,21 @@ typedef struct mq_clip_bpe_vocab {
     int32_t lower;
 } mq_clip_bpe_vocab;
 
+/* Scratch of one tokenisation call (spans, counts, per-byte piece slots): total_bytes = d_offsets[n], cap_tokens = max_length
+ * (WordPiece) or ctx (CLIP). */
+size_t mq_tokenize_workspace_bytes(int64_t n, int64_t total_bytes, int32_t cap_tokens);
+
 /* BERT WordPiece: d_ids int32 [n, ld] rows = [CLS] pieces... [SEP] then pad_id (truncated to max_length like
  * truncation=True, max_length=...), d_lens[i] = tokens in row i including CLS / SEP. */
 int mq_tokenize_wordpiece(const mq_wordpiece_vocab* v, const uint8_t* d_text, const int64_t* d_offsets, int64_t n,
-                          int32_t max_length, int32_t* d_ids, int64_t ld, int32_t* d_lens, int32_t* d_status, void* stream);
+                          int64_t total_bytes, int32_t max_length, int32_t* d_ids, int64_t ld, int32_t* d_lens,
+                          int32_t* d_status, void* d_workspace, size_t workspace_bytes, void* stream);
 
 /* CLIP byte-level BPE: d_ids int32 [n, ctx] rows = SOT ids... EOT, zero padded; over-long texts are cut to ctx with EOT in
  * the last position (open_clip tokenize).  d_lens[i] = SOT..EOT length (what mq_encode_clip_text packs to). */
 int mq_tokenize_clip_bpe(const mq_clip_bpe_vocab* v, const uint8_t* d_text, const int64_t* d_offsets, int64_t n,
-                         int32_t ctx, int32_t* d_ids, int32_t* d_lens, int32_t* d_status, void* stream);
+                         int64_t total_bytes, int32_t ctx, int32_t* d_ids, int32_t* d_lens, int32_t* d_status,
+                         void* d_workspace, size_t workspace_bytes, void* stream);
 
 /* padded id rows -> the packed layout of the text towers: d_packed[cu[s] + j] = d_padded[s * ld + j], j < cu[s+1] - cu[s] */
 int mq_pack_ids(const int32_t* d_padded, int64_t ld, const int32_t* d_cu_seqlens, int64_t nseq, int32_t* d_packed,

@@ -139,8 +139,10 @@ _SIGNATURES = {
     "mq_to_tensor_normalize": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float), _P]),
     "mq_resample_ksize": (C.c_int, [C.c_int32, C.c_int32]),
     "mq_resample_coeffs": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
-    "mq_tokenize_wordpiece": (C.c_int, [C.POINTER(WordPieceVocab), _P, _P, C.c_int64, C.c_int32, _P, C.c_int64, _P, _P, _P]),
-    "mq_tokenize_clip_bpe": (C.c_int, [C.POINTER(ClipBpeVocab), _P, _P, C.c_int64, C.c_int32, _P, _P, _P, _P]),
+    "mq_tokenize_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int32]),
+    "mq_tokenize_wordpiece": (C.c_int, [C.POINTER(WordPieceVocab), _P, _P, C.c_int64, C.c_int64, C.c_int32, _P, C.c_int64, _P, _P, _P,
+                                        C.c_size_t, _P]),
+    "mq_tokenize_clip_bpe": (C.c_int, [C.POINTER(ClipBpeVocab), _P, _P, C.c_int64, C.c_int64, C.c_int32, _P, _P, _P, _P, C.c_size_t, _P]),
     "mq_pack_ids": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P]),
     "mq_weighted_combine": (C.c_int, [_P, C.c_int64, _P, _P, _P, C.c_int64, C.c_int32, C.c_int32, _P, _P]),
     "mq_tune": (C.c_int, [C.c_char_p, C.c_int]),

@@ -1,9 +1,10 @@
 // K14 — text tokenisation on the device (BASELINE north_star: "text tokenisation staged on-GPU").
-// The algorithms are the host+device functions of tokenize_algo.h; here they run one GPU thread per text (texts are
-// independent; a 1024-text batch is 16 wave64s).  This is HBM/latency-bound byte and integer work: per-thread scratch (the
-// current word / the BPE symbols of the current pre-token) lives in LDS, lane-strided so that lane t touches bank
-// (i*64 + t) and the waves never conflict; vocabulary hash tables (0.5-2 MB) sit in L2.  Deliberately not reshaped into
-// anything matrix-like.
+// The algorithms are the host+device functions of tokenize_algo.h, in three launches per call: A splits every text into
+// word / pre-token spans (one thread per text, no table access), B runs the vocabulary work — greedy WordPiece matching / BPE
+// merging, dependent hash-table lookups in L2 — one thread per WORD (a 1024-text batch is ~60 k threads instead of the 1 k
+// of a thread-per-text form, which measured 3 ms per batch), C concatenates per text.  Latency-bound byte and integer work:
+// per-thread scratch (the current word / its BPE symbols) lives in LDS, lane-strided so that lane t touches bank
+// (i*64 + t) and the waves never conflict.  Deliberately not reshaped into anything matrix-like.
 #include "common.h"
 #include "tokenize_algo.h"
 
@@ -13,37 +14,90 @@ namespace {
 
 constexpr int TOK_THREADS = 64;
 
-__global__ __launch_bounds__(TOK_THREADS) void wordpiece_kernel(mq_wp_table T, const uint8_t* __restrict__ text,
-                                                                const int64_t* __restrict__ offsets, int n, int max_length,
-                                                                int32_t* __restrict__ ids, int64_t ld, int32_t* __restrict__ lens,
-                                                                int32_t* __restrict__ status) {
-    __shared__ uint8_t word[MQ_WP_MAX_WORD * TOK_THREADS];
+// workspace of one call: spans u32 [n, cap] | totals i32 [n] | counts u8 [n, cap] | pieces (i32 per text byte: WordPiece; u16: BPE)
+struct TokWs {
+    uint32_t* spans; int32_t* totals; uint8_t* counts; void* pieces; size_t bytes;
+};
+TokWs tok_ws(void* base, int64_t n, int64_t total_bytes, int cap, int piece_size) {
+    TokWs w;
+    size_t off = 0;
+    auto take = [&](size_t b) { const size_t o = off; off = align_up(off + b, 256); return o; };
+    const size_t o_sp = take((size_t)n * cap * 4), o_tot = take((size_t)n * 4), o_cnt = take((size_t)n * cap), o_pc = take((size_t)(total_bytes + 16) * piece_size);
+    w.spans = (uint32_t*)((char*)base + o_sp); w.totals = (int32_t*)((char*)base + o_tot); w.counts = (uint8_t*)((char*)base + o_cnt);
+    w.pieces = (char*)base + o_pc; w.bytes = off;
+    return w;
+}
+
+// ---- phase A: one thread per text, no table access ---------------------------------------------------------------------
+template <bool BPE>
+__global__ __launch_bounds__(TOK_THREADS) void split_kernel(const uint8_t* __restrict__ text, const int64_t* __restrict__ offsets, int n, int cap,
+                                                            uint32_t* __restrict__ spans, int32_t* __restrict__ totals,
+                                                            int32_t* __restrict__ status) {
     const int t = blockIdx.x * TOK_THREADS + threadIdx.x;
     if (t >= n) return;
     const int64_t b0 = offsets[t], b1 = offsets[t + 1];
-    int32_t* row = ids + (int64_t)t * ld;
-    const int max_tokens = max_length - 2 > 0 ? max_length - 2 : 0;
     int st;
-    const int cnt = mq_wordpiece_text(T, text + b0, (int)(b1 - b0), max_tokens, row + 1, 1, word + threadIdx.x, TOK_THREADS, &st);
-    row[0] = T.cls_id;
-    row[1 + cnt] = T.sep_id;
-    for (int j = cnt + 2; j < ld; ++j) row[j] = T.pad_id;
-    lens[t] = st == MQ_TOK_OK ? cnt + 2 : 0;
+    const int cnt = BPE ? mq_clip_split(text + b0, (int)(b1 - b0), cap, spans + (int64_t)t * cap, &st)
+                        : mq_wp_split(text + b0, (int)(b1 - b0), cap, spans + (int64_t)t * cap, &st);
+    totals[t] = cnt;
     status[t] = st;
 }
 
-__global__ __launch_bounds__(TOK_THREADS) void clip_bpe_kernel(mq_bpe_table T, const uint8_t* __restrict__ text,
-                                                               const int64_t* __restrict__ offsets, int n, int ctx,
-                                                               int32_t* __restrict__ ids, int32_t* __restrict__ lens,
-                                                               int32_t* __restrict__ status) {
+// ---- phase B: one thread per word / pre-token (the table lookups); scratch in LDS, lane-strided -------------------------
+__global__ __launch_bounds__(TOK_THREADS) void wp_pieces_kernel(mq_wp_table T, const uint8_t* __restrict__ text, const int64_t* __restrict__ offsets,
+                                                                int cap, int blocks_per_text, const uint32_t* __restrict__ spans,
+                                                                const int32_t* __restrict__ totals, uint8_t* __restrict__ counts,
+                                                                int32_t* __restrict__ pieces) {
+    __shared__ uint8_t word[MQ_WP_MAX_WORD * TOK_THREADS];
+    const int t = blockIdx.x / blocks_per_text;
+    const int j = (blockIdx.x - t * blocks_per_text) * TOK_THREADS + threadIdx.x;
+    const int nw = min(totals[t], cap);
+    if (j >= nw) return;
+    const int64_t b0 = offsets[t];
+    const uint32_t span = spans[(int64_t)t * cap + j];
+    counts[(int64_t)t * cap + j] = (uint8_t)mq_wp_pieces(T, text + b0, span, pieces + b0 + (span >> 8), word + threadIdx.x, TOK_THREADS);
+}
+
+__global__ __launch_bounds__(TOK_THREADS) void bpe_merge_kernel(mq_bpe_table T, const uint8_t* __restrict__ text, const int64_t* __restrict__ offsets,
+                                                                int cap, int blocks_per_text, const uint32_t* __restrict__ spans,
+                                                                const int32_t* __restrict__ totals, uint8_t* __restrict__ counts,
+                                                                uint16_t* __restrict__ syms) {
     __shared__ uint16_t sym[MQ_BPE_MAX_SYMS * TOK_THREADS];
+    const int t = blockIdx.x / blocks_per_text;
+    const int j = (blockIdx.x - t * blocks_per_text) * TOK_THREADS + threadIdx.x;
+    const int nw = min(totals[t], cap);
+    if (j >= nw) return;
+    const int64_t b0 = offsets[t];
+    const uint32_t span = spans[(int64_t)t * cap + j];
+    counts[(int64_t)t * cap + j] = (uint8_t)mq_clip_merge_span(T, text + b0, span, syms + b0 + (span >> 8), sym + threadIdx.x, TOK_THREADS);
+}
+
+// ---- phase C: one thread per text, copies only ----------------------------------------------------------------------------
+__global__ __launch_bounds__(TOK_THREADS) void wp_gather_kernel(mq_wp_table T, const int64_t* __restrict__ offsets, int n, int cap, int max_tokens,
+                                                                const uint32_t* __restrict__ spans, const int32_t* __restrict__ totals,
+                                                                const uint8_t* __restrict__ counts, const int32_t* __restrict__ pieces,
+                                                                int32_t* __restrict__ ids, int64_t ld, int32_t* __restrict__ lens,
+                                                                const int32_t* __restrict__ status) {
     const int t = blockIdx.x * TOK_THREADS + threadIdx.x;
     if (t >= n) return;
-    const int64_t b0 = offsets[t], b1 = offsets[t + 1];
-    int st;
-    const int cnt = mq_clip_bpe_text(T, text + b0, (int)(b1 - b0), ctx, ids + (int64_t)t * ctx, 1, sym + threadIdx.x, TOK_THREADS, &st);
-    lens[t] = st == MQ_TOK_OK ? cnt : 0;
-    status[t] = st;
+    const int ok = status[t] == MQ_TOK_OK;
+    const int len = mq_wp_gather(T, spans + (int64_t)t * cap, counts + (int64_t)t * cap, pieces + offsets[t], ok ? min(totals[t], cap) : 0, max_tokens,
+                                 ids + (int64_t)t * ld, (int)ld);
+    lens[t] = ok ? len : 0;
+}
+
+__global__ __launch_bounds__(TOK_THREADS) void bpe_gather_kernel(mq_bpe_table T, const int64_t* __restrict__ offsets, int n, int cap, int ctx,
+                                                                 const uint32_t* __restrict__ spans, const int32_t* __restrict__ totals,
+                                                                 const uint8_t* __restrict__ counts, const uint16_t* __restrict__ syms,
+                                                                 int32_t* __restrict__ ids, int32_t* __restrict__ lens,
+                                                                 const int32_t* __restrict__ status) {
+    const int t = blockIdx.x * TOK_THREADS + threadIdx.x;
+    if (t >= n) return;
+    const int ok = status[t] == MQ_TOK_OK;
+    const int tot = ok ? totals[t] : 0;
+    const int len = mq_clip_gather(T, spans + (int64_t)t * cap, counts + (int64_t)t * cap, syms + offsets[t], min(tot, cap), tot, ctx,
+                                   ids + (int64_t)t * ctx);
+    lens[t] = ok ? len : 0;
 }
 
 // packed[cu[s] + j] = padded[s, j] for j < cu[s+1] - cu[s]
@@ -58,42 +112,65 @@ bool pow2(uint32_t v) { return v && !(v & (v - 1)); }
 
 }  // namespace
 
+extern "C" size_t mq_tokenize_workspace_bytes(int64_t n, int64_t total_bytes, int32_t cap_tokens) {
+    if (n <= 0 || cap_tokens <= 0 || total_bytes < 0) return 0;
+    return tok_ws(nullptr, n, total_bytes, cap_tokens, 4).bytes;  // sized for the larger (WordPiece) piece type
+}
+
 extern "C" int mq_tokenize_wordpiece(const mq_wordpiece_vocab* v, const uint8_t* d_text, const int64_t* d_offsets, int64_t n,
-                                     int32_t max_length, int32_t* d_ids, int64_t ld, int32_t* d_lens, int32_t* d_status,
-                                     void* stream) {
+                                     int64_t total_bytes, int32_t max_length, int32_t* d_ids, int64_t ld, int32_t* d_lens,
+                                     int32_t* d_status, void* d_workspace, size_t workspace_bytes, void* stream) {
     MQ_CHECK_ARG(v && v->d_slots && v->d_pool && pow2(v->n_slots), "mq_tokenize_wordpiece: bad vocabulary table");
     MQ_CHECK_ARG(v->max_word_chars >= 1 && v->max_word_chars <= MQ_WP_MAX_WORD - 4, "mq_tokenize_wordpiece: max_word_chars %d unsupported",
                  v->max_word_chars);
     MQ_CHECK_ARG(max_length >= 2 && ld >= max_length, "mq_tokenize_wordpiece: need 2 <= max_length (%d) <= ld (%ld)", max_length, (long)ld);
     if (n <= 0) return MQ_OK;
-    MQ_CHECK_ARG(d_text && d_offsets && d_ids && d_lens && d_status, "mq_tokenize_wordpiece: null pointer");
-    MQ_CHECK_ARG(n < (1LL << 30), "mq_tokenize_wordpiece: too many texts");
+    MQ_CHECK_ARG(d_text && d_offsets && d_ids && d_lens && d_status && d_workspace, "mq_tokenize_wordpiece: null pointer");
+    MQ_CHECK_ARG(n < (1LL << 24) && total_bytes >= 0 && total_bytes < (1LL << 40), "mq_tokenize_wordpiece: too many texts / bytes");
+    const int max_tokens = max_length - 2;
+    const int cap = max_tokens > 0 ? max_tokens : 1;
+    const TokWs w = tok_ws(d_workspace, n, total_bytes, cap, 4);
+    if (workspace_bytes < w.bytes) { mq_set_error("mq_tokenize_wordpiece: workspace %zu < required %zu", workspace_bytes, w.bytes); return MQ_ERR_WORKSPACE; }
     mq_wp_table T;
     T.slots = (const mq_wp_entry*)v->d_slots; T.pool = v->d_pool; T.mask = v->n_slots - 1;
     T.unk_id = v->unk_id; T.cls_id = v->cls_id; T.sep_id = v->sep_id; T.pad_id = v->pad_id;
     T.lower = v->lower; T.max_word_chars = v->max_word_chars;
     hipStream_t s = (hipStream_t)stream;
     MqProfScope prof(3, s);
-    hipLaunchKernelGGL(wordpiece_kernel, dim3((unsigned)cdiv64(n, TOK_THREADS)), dim3(TOK_THREADS), 0, s, T, d_text, d_offsets, (int)n,
-                       max_length, d_ids, ld, d_lens, d_status);
+    const unsigned per_text = (unsigned)cdiv64(n, TOK_THREADS);
+    const int bpt = (cap + TOK_THREADS - 1) / TOK_THREADS;
+    hipLaunchKernelGGL(split_kernel<false>, dim3(per_text), dim3(TOK_THREADS), 0, s, d_text, d_offsets, (int)n, cap, w.spans, w.totals, d_status);
+    hipLaunchKernelGGL(wp_pieces_kernel, dim3((unsigned)(n * bpt)), dim3(TOK_THREADS), 0, s, T, d_text, d_offsets, cap, bpt, w.spans, w.totals, w.counts,
+                       (int32_t*)w.pieces);
+    hipLaunchKernelGGL(wp_gather_kernel, dim3(per_text), dim3(TOK_THREADS), 0, s, T, d_offsets, (int)n, cap, max_tokens, w.spans, w.totals, w.counts,
+                       (const int32_t*)w.pieces, d_ids, ld, d_lens, d_status);
     MQ_CHECK_LAUNCH("mq_tokenize_wordpiece");
     return MQ_OK;
 }
 
 extern "C" int mq_tokenize_clip_bpe(const mq_clip_bpe_vocab* v, const uint8_t* d_text, const int64_t* d_offsets, int64_t n,
-                                    int32_t ctx, int32_t* d_ids, int32_t* d_lens, int32_t* d_status, void* stream) {
+                                    int64_t total_bytes, int32_t ctx, int32_t* d_ids, int32_t* d_lens, int32_t* d_status,
+                                    void* d_workspace, size_t workspace_bytes, void* stream) {
     MQ_CHECK_ARG(v && v->d_slots && v->d_byte_id && v->d_byte_end_id && pow2(v->n_slots), "mq_tokenize_clip_bpe: bad merge table");
     MQ_CHECK_ARG(ctx >= 2, "mq_tokenize_clip_bpe: context length %d < 2", ctx);
     if (n <= 0) return MQ_OK;
-    MQ_CHECK_ARG(d_text && d_offsets && d_ids && d_lens && d_status, "mq_tokenize_clip_bpe: null pointer");
-    MQ_CHECK_ARG(n < (1LL << 30), "mq_tokenize_clip_bpe: too many texts");
+    MQ_CHECK_ARG(d_text && d_offsets && d_ids && d_lens && d_status && d_workspace, "mq_tokenize_clip_bpe: null pointer");
+    MQ_CHECK_ARG(n < (1LL << 24) && total_bytes >= 0 && total_bytes < (1LL << 40), "mq_tokenize_clip_bpe: too many texts / bytes");
+    const int cap = ctx;
+    const TokWs w = tok_ws(d_workspace, n, total_bytes, cap, 2);
+    if (workspace_bytes < w.bytes) { mq_set_error("mq_tokenize_clip_bpe: workspace %zu < required %zu", workspace_bytes, w.bytes); return MQ_ERR_WORKSPACE; }
     mq_bpe_table T;
     T.slots = (const mq_bpe_entry*)v->d_slots; T.byte_id = v->d_byte_id; T.byte_end_id = v->d_byte_end_id; T.mask = v->n_slots - 1;
     T.sot_id = v->sot_id; T.eot_id = v->eot_id; T.lower = v->lower;
     hipStream_t s = (hipStream_t)stream;
     MqProfScope prof(3, s);
-    hipLaunchKernelGGL(clip_bpe_kernel, dim3((unsigned)cdiv64(n, TOK_THREADS)), dim3(TOK_THREADS), 0, s, T, d_text, d_offsets, (int)n, ctx,
-                       d_ids, d_lens, d_status);
+    const unsigned per_text = (unsigned)cdiv64(n, TOK_THREADS);
+    const int bpt = (cap + TOK_THREADS - 1) / TOK_THREADS;
+    hipLaunchKernelGGL(split_kernel<true>, dim3(per_text), dim3(TOK_THREADS), 0, s, d_text, d_offsets, (int)n, cap, w.spans, w.totals, d_status);
+    hipLaunchKernelGGL(bpe_merge_kernel, dim3((unsigned)(n * bpt)), dim3(TOK_THREADS), 0, s, T, d_text, d_offsets, cap, bpt, w.spans, w.totals, w.counts,
+                       (uint16_t*)w.pieces);
+    hipLaunchKernelGGL(bpe_gather_kernel, dim3(per_text), dim3(TOK_THREADS), 0, s, T, d_offsets, (int)n, cap, ctx, w.spans, w.totals, w.counts,
+                       (const uint16_t*)w.pieces, d_ids, d_lens, d_status);
     MQ_CHECK_LAUNCH("mq_tokenize_clip_bpe");
     return MQ_OK;
 }

@@ -107,41 +107,64 @@ MQ_TOK_FN void mq_wp_word(const mq_wp_table& T, const uint8_t* w, int ws, int L,
     *cnt = n;
 }
 
-// One text -> ids (WITHOUT [CLS]/[SEP]); returns the untruncated... no: returns min(count, max_tokens) after the
-// reference's truncation ids[:max_tokens]; *status = MQ_TOK_NEEDS_HOST when a byte is outside the device scope.
-// Basic tokenisation for in-scope bytes: whitespace splits, every ASCII punctuation char is its own word, the rest are
-// words (lower-cased when T.lower); accent stripping / NFC / CJK / control-char removal never fire for these bytes.
-MQ_TOK_FN int mq_wordpiece_text(const mq_wp_table& T, const uint8_t* text, int nbytes, int max_tokens, int32_t* out, int os,
-                                uint8_t* word, int ws, int* status) {
+// The work of one text is split into three phases so that the expensive part (hash-table lookups) runs one GPU thread per
+// WORD instead of per text:
+//   A  mq_wp_split   (per text)  basic tokenisation -> word spans  (start << 8 | min(len, 255)); no table access
+//   B  mq_wp_pieces  (per word)  lower-case + greedy WordPiece -> piece ids, stored at the word's own byte positions
+//   C  mq_wp_gather  (per text)  concatenate the pieces, truncate, add [CLS] / [SEP], pad
+// Basic tokenisation for in-scope bytes: whitespace splits, every ASCII punctuation char is its own word, the rest are words;
+// accent stripping / NFC / CJK / control-char removal never fire for these bytes.
+
+// A: returns the number of words found, at most `cap` of them written (a word yields >= 1 id, so words beyond max_tokens can
+// never reach the output); *status = MQ_TOK_NEEDS_HOST when a byte is outside the device scope.
+MQ_TOK_FN int mq_wp_split(const uint8_t* text, int nbytes, int cap, uint32_t* spans, int* status) {
     int cnt = 0, i = 0;
     *status = MQ_TOK_OK;
-    while (i < nbytes && cnt < max_tokens) {  // whole words only: a word is finished before the truncation test
+    while (i < nbytes) {
         const uint8_t c = text[i];
         if (!mq_in_scope(c)) { *status = MQ_TOK_NEEDS_HOST; return 0; }
         if (mq_is_ws(c)) { ++i; continue; }
-        int L = 0;
+        const int start = i;
         if (mq_is_ascii_punct(c)) {
-            word[0] = c;
-            L = 1;
             ++i;
         } else {
-            int total = 0;  // true word length (may exceed the scratch: only "is it > max_word_chars" matters then)
             while (i < nbytes) {
                 const uint8_t d = text[i];
                 if (!mq_in_scope(d)) { *status = MQ_TOK_NEEDS_HOST; return 0; }
                 if (mq_is_ws(d) || mq_is_ascii_punct(d)) break;
-                if (total < MQ_WP_MAX_WORD) word[total * ws] = T.lower ? mq_lower(d) : d;
-                ++total;
                 ++i;
             }
-            L = total;
         }
-        mq_wp_word(T, word, ws, L, out, os, max_tokens, &cnt);
+        const int len = i - start;
+        if (cnt < cap) spans[cnt] = ((uint32_t)start << 8) | (uint32_t)(len < 255 ? len : 255);
+        ++cnt;
     }
-    // bytes after the cut-off are not tokenised, but they still decide whether the text is in scope
-    for (; i < nbytes; ++i)
-        if (!mq_in_scope(text[i])) { *status = MQ_TOK_NEEDS_HOST; return 0; }
-    return cnt < max_tokens ? cnt : max_tokens;
+    return cnt;
+}
+
+// B: pieces of one word (span from A) -> out[0 .. count) (out has room for one id per byte of the word); returns count.
+MQ_TOK_FN int mq_wp_pieces(const mq_wp_table& T, const uint8_t* text, uint32_t span, int32_t* out, uint8_t* word, int ws) {
+    const int start = (int)(span >> 8), len = (int)(span & 255u);
+    if (len > T.max_word_chars) { out[0] = T.unk_id; return 1; }  // (255 stands for "255 or more")
+    for (int j = 0; j < len; ++j) word[j * ws] = T.lower ? mq_lower(text[start + j]) : text[start + j];
+    int cnt = 0;
+    mq_wp_word(T, word, ws, len, out, 1, len, &cnt);
+    return cnt;
+}
+
+// C: row = [CLS] pieces... [SEP] pad...; returns the row length.  piece_cnt[j] / pieces at piece_buf[start_j ...] are B's output.
+MQ_TOK_FN int mq_wp_gather(const mq_wp_table& T, const uint32_t* spans, const uint8_t* piece_cnt, const int32_t* piece_buf, int nwords,
+                           int max_tokens, int32_t* row, int ld) {
+    int cnt = 0;
+    row[0] = T.cls_id;
+    for (int j = 0; j < nwords && cnt < max_tokens; ++j) {
+        const int32_t* src = piece_buf + (spans[j] >> 8);
+        const int k = piece_cnt[j];
+        for (int e = 0; e < k && cnt < max_tokens; ++e) row[1 + cnt++] = src[e];
+    }
+    row[1 + cnt] = T.sep_id;
+    for (int j = cnt + 2; j < ld; ++j) row[j] = T.pad_id;
+    return cnt + 2;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -218,15 +241,16 @@ MQ_TOK_FN int mq_contraction(const uint8_t* text, int i, int n) {
     return 0;
 }
 
-// One text -> row[0..ctx): SOT, BPE ids, EOT, zero padding; over-long inputs are truncated to ctx and the last kept
-// position overwritten with EOT (open_clip tokenize()).  Returns the sequence length including SOT / EOT.
+// Three phases like WordPiece (A per text: regex pre-split into spans; B per pre-token: byte symbols + merges, the surviving
+// symbols stored at the pre-token's own byte positions; C per text: SOT, ids, EOT, zero padding / truncation).
 // Pre-tokenisation = the SimpleTokenizer regex restricted to ASCII (the text is lower-cased first when T.lower):
 //   contraction | letters+ | one digit | (not whitespace / letter / digit)+      scanned left to right.
-MQ_TOK_FN int mq_clip_bpe_text(const mq_bpe_table& T, const uint8_t* text, int nbytes, int ctx, int32_t* row, int rs,
-                               uint16_t* sym, int ss, int* status) {
+
+// A: returns the number of pre-tokens, at most `cap` written as (start << 8 | len); pre-tokens longer than the BPE scratch or
+// bytes outside the device scope set *status = MQ_TOK_NEEDS_HOST.
+MQ_TOK_FN int mq_clip_split(const uint8_t* text, int nbytes, int cap, uint32_t* spans, int* status) {
     *status = MQ_TOK_OK;
-    int cnt = 1, i = 0;
-    row[0] = T.sot_id;
+    int cnt = 0, i = 0;
     while (i < nbytes) {
         const uint8_t c = text[i];
         if (!mq_in_scope(c)) { *status = MQ_TOK_NEEDS_HOST; return 0; }
@@ -247,29 +271,50 @@ MQ_TOK_FN int mq_clip_bpe_text(const mq_bpe_table& T, const uint8_t* text, int n
                 ++len;
             }
         }
-        if (len > MQ_BPE_MAX_SYMS) { *status = MQ_TOK_NEEDS_HOST; return 0; }
-        if (cnt < ctx) {  // tokens past the context window cannot change the kept ones
-            for (int j = 0; j < len; ++j) {
-                const uint8_t b = T.lower ? mq_lower(text[i + j]) : text[i + j];
-                sym[j * ss] = (j == len - 1) ? T.byte_end_id[b] : T.byte_id[b];
-            }
-            const int L = mq_bpe_merge(T, sym, ss, len);
-            for (int j = 0; j < L; ++j) {
-                if (cnt < ctx) row[cnt * rs] = (int32_t)sym[j * ss];
-                ++cnt;
-            }
-        } else {
-            ++cnt;  // at least one more id: the row is already full
+        if (cnt < cap) {  // pre-tokens past the context window cannot change the kept ids (each yields >= 1 id)
+            if (len > MQ_BPE_MAX_SYMS) { *status = MQ_TOK_NEEDS_HOST; return 0; }
+            spans[cnt] = ((uint32_t)i << 8) | (uint32_t)len;
         }
+        ++cnt;
         i += len;
     }
-    ++cnt;  // EOT
+    return cnt;
+}
+
+// B: BPE of one pre-token -> out[0 .. count) (room for one symbol per byte); returns count.
+MQ_TOK_FN int mq_clip_merge_span(const mq_bpe_table& T, const uint8_t* text, uint32_t span, uint16_t* out, uint16_t* sym, int ss) {
+    const int start = (int)(span >> 8), len = (int)(span & 255u);
+    for (int j = 0; j < len; ++j) {
+        const uint8_t b = T.lower ? mq_lower(text[start + j]) : text[start + j];
+        sym[j * ss] = (j == len - 1) ? T.byte_end_id[b] : T.byte_id[b];
+    }
+    const int L = mq_bpe_merge(T, sym, ss, len);
+    for (int j = 0; j < L; ++j) out[j] = sym[j * ss];
+    return L;
+}
+
+// C: row[0..ctx) = SOT ids... EOT 0...; over-long inputs are truncated to ctx and the last kept position overwritten with EOT
+// (open_clip tokenize()).  `total` = A's return value (pre-tokens beyond the written ones each stand for >= 1 more id).
+MQ_TOK_FN int mq_clip_gather(const mq_bpe_table& T, const uint32_t* spans, const uint8_t* sym_cnt, const uint16_t* sym_buf, int nwritten,
+                             int total, int ctx, int32_t* row) {
+    int cnt = 1;
+    row[0] = T.sot_id;
+    for (int j = 0; j < nwritten; ++j) {
+        const uint16_t* src = sym_buf + (spans[j] >> 8);
+        const int k = sym_cnt[j];
+        for (int e = 0; e < k; ++e) {
+            if (cnt < ctx) row[cnt] = (int32_t)src[e];
+            ++cnt;
+        }
+    }
+    cnt += total - nwritten;  // >= one id each: only "the row overflows" matters
+    ++cnt;                    // EOT
     if (cnt > ctx) {
-        row[(ctx - 1) * rs] = T.eot_id;
+        row[ctx - 1] = T.eot_id;
         cnt = ctx;
     } else {
-        row[(cnt - 1) * rs] = T.eot_id;
-        for (int j = cnt; j < ctx; ++j) row[j * rs] = 0;
+        row[cnt - 1] = T.eot_id;
+        for (int j = cnt; j < ctx; ++j) row[j] = 0;
     }
     return cnt;
 }

@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import ctypes as C
 import re
+import threading
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -28,6 +29,7 @@ assert WP_ENTRY.itemsize == 16 and BPE_ENTRY.itemsize == 16
 _FNV_OFFSET, _FNV_PRIME, _CONT_SEED, _M64 = 0xcbf29ce484222325, 0x100000001b3, 0x9e3779b97f4a7c15, (1 << 64) - 1
 MAX_WORD_CHARS_DEVICE = 100
 _SCOPE = re.compile(r"[\x20-\x7e\t\n\r]*")
+MAX_TEXT_BYTES_DEVICE = 1 << 20  # span offsets are 24-bit
 
 
 def _fnv(data: bytes, cont: bool) -> int:
@@ -110,11 +112,12 @@ def pack_texts(texts: Sequence[str]) -> Tuple[np.ndarray, np.ndarray]:
 
 
 def wordpiece_in_scope(tok: WordPieceTokenizer, text: str) -> bool:
-    return _SCOPE.fullmatch(text) is not None and ("[" not in text or not any(s in text for s in tok._specials))
+    return (len(text) < MAX_TEXT_BYTES_DEVICE and _SCOPE.fullmatch(text) is not None
+            and ("[" not in text or not any(s in text for s in tok._specials)))
 
 
 def clip_in_scope(tok: ClipBpeTokenizer, text: str) -> bool:
-    if _SCOPE.fullmatch(text) is None or "&" in text:
+    if len(text) >= MAX_TEXT_BYTES_DEVICE or _SCOPE.fullmatch(text) is None or "&" in text:
         return False
     if "<" in text:
         low = text.lower()
@@ -130,17 +133,41 @@ class _DeviceTokenizerBase:
                                              f"use the host tokenisers of engine/tokenizers.py")
         self.lib = L.load()
         self._keep: List[torch.Tensor] = []
+        self._pin: Optional[torch.Tensor] = None   # reusable pinned staging buffer (allocating pinned memory per call costs ms)
+        self._ws: Optional[torch.Tensor] = None
+        self._lock = threading.Lock()              # staging buffer + workspace are per tokenizer: serialise concurrent callers
 
     def _up(self, arr: np.ndarray) -> torch.Tensor:
         t = torch.from_numpy(np.ascontiguousarray(arr).view(np.uint8).reshape(-1)).to(self.device)
         self._keep.append(t)
         return t
 
+    def _split_routes(self, texts: Sequence[str], in_scope) -> List[int]:
+        """indices of the texts that take the device route.  Fast path: ONE scope test over the concatenation (a batch is almost
+        always all-ASCII); only when that fails are the texts tested one by one."""
+        joined = "\n".join(texts)
+        if len(joined) < MAX_TEXT_BYTES_DEVICE * 64 and in_scope(joined) and all(len(t) < MAX_TEXT_BYTES_DEVICE for t in texts):
+            return list(range(len(texts)))
+        return [i for i, t in enumerate(texts) if in_scope(t)]
+
     def _stage(self, texts: Sequence[str]):
+        """-> (device blob uint8, device offsets int64, total bytes): one pinned staging buffer, two async H2D copies"""
         blob, offsets = pack_texts(texts)
-        d_blob = torch.from_numpy(blob).pin_memory().to(self.device, non_blocking=True)
-        d_off = torch.from_numpy(offsets).pin_memory().to(self.device, non_blocking=True)
-        return d_blob, d_off
+        need = blob.nbytes + offsets.nbytes + 64
+        if self._pin is None or self._pin.numel() < need:
+            self._pin = torch.empty(int(need * 1.5) + 4096, dtype=torch.uint8).pin_memory()
+        nb = (blob.nbytes + 15) // 16 * 16
+        pin = self._pin.numpy()
+        pin[:blob.nbytes] = blob
+        pin[nb:nb + offsets.nbytes] = offsets.view(np.uint8)
+        d = self._pin[:nb + offsets.nbytes].to(self.device, non_blocking=True)
+        return d[:blob.nbytes], d[nb:].view(torch.int64), int(offsets[-1])
+
+    def _workspace(self, n: int, total_bytes: int, cap: int) -> torch.Tensor:
+        need = int(self.lib.mq_tokenize_workspace_bytes(n, total_bytes, cap))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(int(need * 1.25) + 256, dtype=torch.uint8, device=self.device)
+        return self._ws
 
 
 class DeviceWordPieceTokenizer(_DeviceTokenizerBase):
@@ -161,19 +188,20 @@ class DeviceWordPieceTokenizer(_DeviceTokenizerBase):
         lens = torch.zeros(n, dtype=torch.int64)
         if n == 0:
             return ids, lens
-        on_dev = [i for i, t in enumerate(texts) if wordpiece_in_scope(self.host, t)]
+        on_dev = self._split_routes(texts, lambda t: wordpiece_in_scope(self.host, t))
         dev_set = set(on_dev)
         if on_dev:
-            sel = [texts[i] for i in on_dev]
-            d_blob, d_off = self._stage(sel)
+            sel = texts if len(on_dev) == n else [texts[i] for i in on_dev]
             m = len(sel)
-            d_ids = ids if m == n else torch.empty(m, max_length, dtype=torch.int32, device=self.device)
-            d_meta = torch.empty(2, m, dtype=torch.int32, device=self.device)
-            with torch.cuda.device(self.device):
-                L.check(self.lib.mq_tokenize_wordpiece(C.byref(self.vocab), d_blob.data_ptr(), d_off.data_ptr(), m, max_length, d_ids.data_ptr(),
-                                                       max_length, d_meta[0].data_ptr(), d_meta[1].data_ptr(),
-                                                       torch.cuda.current_stream(self.device).cuda_stream), "mq_tokenize_wordpiece")
-            meta = d_meta.cpu()
+            with self._lock, torch.cuda.device(self.device):
+                d_blob, d_off, total = self._stage(sel)
+                d_ids = ids if m == n else torch.empty(m, max_length, dtype=torch.int32, device=self.device)
+                d_meta = torch.empty(2, m, dtype=torch.int32, device=self.device)
+                ws = self._workspace(m, total, max(max_length - 2, 1))
+                L.check(self.lib.mq_tokenize_wordpiece(C.byref(self.vocab), d_blob.data_ptr(), d_off.data_ptr(), m, total, max_length,
+                                                       d_ids.data_ptr(), max_length, d_meta[0].data_ptr(), d_meta[1].data_ptr(), ws.data_ptr(),
+                                                       ws.numel(), torch.cuda.current_stream(self.device).cuda_stream), "mq_tokenize_wordpiece")
+                meta = d_meta.cpu()  # (also the sync after which the pinned staging buffer may be reused)
             if bool((meta[1] != 0).any()):  # defensive: the kernel disagreed with the host-side scope test
                 bad = [on_dev[j] for j in torch.nonzero(meta[1]).flatten().tolist()]
                 dev_set.difference_update(bad)
@@ -222,19 +250,20 @@ class DeviceClipBpeTokenizer(_DeviceTokenizerBase):
         lens = torch.zeros(n, dtype=torch.int64)
         if n == 0:
             return ids, lens
-        on_dev = [i for i, t in enumerate(texts) if clip_in_scope(self.host, t)]
+        on_dev = self._split_routes(texts, lambda t: clip_in_scope(self.host, t))
         dev_set = set(on_dev)
         if on_dev:
-            sel = [texts[i] for i in on_dev]
-            d_blob, d_off = self._stage(sel)
+            sel = texts if len(on_dev) == n else [texts[i] for i in on_dev]
             m = len(sel)
-            d_ids = ids if m == n else torch.empty(m, ctx, dtype=torch.int32, device=self.device)
-            d_meta = torch.empty(2, m, dtype=torch.int32, device=self.device)
-            with torch.cuda.device(self.device):
-                L.check(self.lib.mq_tokenize_clip_bpe(C.byref(self.vocab), d_blob.data_ptr(), d_off.data_ptr(), m, ctx, d_ids.data_ptr(),
-                                                      d_meta[0].data_ptr(), d_meta[1].data_ptr(),
+            with self._lock, torch.cuda.device(self.device):
+                d_blob, d_off, total = self._stage(sel)
+                d_ids = ids if m == n else torch.empty(m, ctx, dtype=torch.int32, device=self.device)
+                d_meta = torch.empty(2, m, dtype=torch.int32, device=self.device)
+                ws = self._workspace(m, total, ctx)
+                L.check(self.lib.mq_tokenize_clip_bpe(C.byref(self.vocab), d_blob.data_ptr(), d_off.data_ptr(), m, total, ctx, d_ids.data_ptr(),
+                                                      d_meta[0].data_ptr(), d_meta[1].data_ptr(), ws.data_ptr(), ws.numel(),
                                                       torch.cuda.current_stream(self.device).cuda_stream), "mq_tokenize_clip_bpe")
-            meta = d_meta.cpu()
+                meta = d_meta.cpu()  # (also the sync after which the pinned staging buffer may be reused)
             if bool((meta[1] != 0).any()):  # e.g. a pre-token longer than the device scratch
                 bad = [on_dev[j] for j in torch.nonzero(meta[1]).flatten().tolist()]
                 dev_set.difference_update(bad)

@@ -5,6 +5,8 @@
 #include <stdint.h>
 #include "../marqo_amd/csrc/tokenize_algo.h"
 
+#include <vector>
+
 extern "C" {
 
 void tokhost_wordpiece(const void* slots, const uint8_t* pool, uint32_t n_slots, int32_t unk_id, int32_t cls_id, int32_t sep_id,
@@ -15,14 +17,19 @@ void tokhost_wordpiece(const void* slots, const uint8_t* pool, uint32_t n_slots,
     T.unk_id = unk_id; T.cls_id = cls_id; T.sep_id = sep_id; T.pad_id = pad_id; T.lower = lower; T.max_word_chars = max_word_chars;
     uint8_t word[MQ_WP_MAX_WORD];
     const int max_tokens = max_length - 2 > 0 ? max_length - 2 : 0;
-    for (int64_t t = 0; t < n; ++t) {
-        int32_t* row = ids + t * ld;
+    const int cap = max_tokens > 0 ? max_tokens : 1;
+    std::vector<uint32_t> spans(cap);
+    std::vector<uint8_t> counts(cap);
+    for (int64_t t = 0; t < n; ++t) {  // the three phases of tokenize.hip, one text at a time
+        const uint8_t* tx = text + offsets[t];
+        const int nb = (int)(offsets[t + 1] - offsets[t]);
+        std::vector<int32_t> pieces(nb + 16);
         int st;
-        const int cnt = mq_wordpiece_text(T, text + offsets[t], (int)(offsets[t + 1] - offsets[t]), max_tokens, row + 1, 1, word, 1, &st);
-        row[0] = cls_id;
-        row[1 + cnt] = sep_id;
-        for (int64_t j = cnt + 2; j < ld; ++j) row[j] = pad_id;
-        lens[t] = st == MQ_TOK_OK ? cnt + 2 : 0;
+        const int total = mq_wp_split(tx, nb, cap, spans.data(), &st);                                             // A
+        const int nw = st == MQ_TOK_OK ? (total < cap ? total : cap) : 0;
+        for (int j = 0; j < nw; ++j) counts[j] = (uint8_t)mq_wp_pieces(T, tx, spans[j], pieces.data() + (spans[j] >> 8), word, 1);  // B
+        const int len = mq_wp_gather(T, spans.data(), counts.data(), pieces.data(), nw, max_tokens, ids + t * ld, (int)ld);        // C
+        lens[t] = st == MQ_TOK_OK ? len : 0;
         status[t] = st;
     }
 }
@@ -34,10 +41,20 @@ void tokhost_clip_bpe(const void* slots, const uint16_t* byte_id, const uint16_t
     T.slots = (const mq_bpe_entry*)slots; T.byte_id = byte_id; T.byte_end_id = byte_end_id; T.mask = n_slots - 1;
     T.sot_id = sot_id; T.eot_id = eot_id; T.lower = lower;
     uint16_t sym[MQ_BPE_MAX_SYMS];
+    const int cap = ctx;
+    std::vector<uint32_t> spans(cap);
+    std::vector<uint8_t> counts(cap);
     for (int64_t t = 0; t < n; ++t) {
+        const uint8_t* tx = text + offsets[t];
+        const int nb = (int)(offsets[t + 1] - offsets[t]);
+        std::vector<uint16_t> syms(nb + 16);
         int st;
-        const int cnt = mq_clip_bpe_text(T, text + offsets[t], (int)(offsets[t + 1] - offsets[t]), ctx, ids + t * ctx, 1, sym, 1, &st);
-        lens[t] = st == MQ_TOK_OK ? cnt : 0;
+        const int total = mq_clip_split(tx, nb, cap, spans.data(), &st);                                            // A
+        const int tot = st == MQ_TOK_OK ? total : 0;
+        const int nw = tot < cap ? tot : cap;
+        for (int j = 0; j < nw; ++j) counts[j] = (uint8_t)mq_clip_merge_span(T, tx, spans[j], syms.data() + (spans[j] >> 8), sym, 1);  // B
+        const int len = mq_clip_gather(T, spans.data(), counts.data(), syms.data(), nw, tot, ctx, ids + t * ctx);                      // C
+        lens[t] = st == MQ_TOK_OK ? len : 0;
         status[t] = st;
     }
 }
