@@ -24,6 +24,7 @@
 extern int mq_gemm_fp8_force_mt;  // gemm_fp8.hip
 extern int mq_tower_row_select;   // towers.hip
 extern int mq_tower_ln_fold;      // towers.hip
+extern int mq_ln_rows_per_wave;   // rowops.hip
 
 // CU-sized-tile main loop (gemm_big.hip)
 template <int FLAGS>
@@ -400,6 +401,7 @@ extern "C" int mq_tune(const char* key, int value) {
     else if (k == "gemm_wide") mq_gemm_knob_wide = g_tune.wide = value;
     else if (k == "row_select") mq_tower_row_select = value;
     else if (k == "ln_fold") mq_tower_ln_fold = value;
+    else if (k == "ln_rows") mq_ln_rows_per_wave = value;
     else { mq_set_error("mq_tune: unknown key %s", key); return MQ_ERR_INVALID; }
     return MQ_OK;
 }

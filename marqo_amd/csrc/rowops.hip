@@ -1,7 +1,10 @@
 // Row-wise HBM-bound kernels: LayerNorm (K2), L2-normalise (tail of K6/K8/K9), fp32->bf16 cast.
 // One wave64 per row, float4 (16 B/lane) accesses, two-pass statistics held in registers so the
 // row is read from HBM exactly once.
+#include <stdlib.h>
 #include "common.h"
+
+int mq_ln_rows_per_wave = getenv("MQ_LN_ROWS") ? atoi(getenv("MQ_LN_ROWS")) : 2;  // mq_tune("ln_rows", 1 | 2)
 
 namespace {
 
@@ -11,39 +14,82 @@ constexpr int LN_MAX_CHUNKS = 8;  // float4 chunks per lane: W <= 64 * 4 * 8 = 2
 // CH = float4 chunks per lane (compile time, so the row lives in CH*4 VGPRs and the kernel keeps
 // 8 waves/SIMD in flight — the first version sized its arrays for the maximum W, compiled to 220
 // VGPRs / occupancy 2 and ran at 2 TB/s).
-template <int CH>
-__global__ __launch_bounds__(256, (CH <= 4 ? 8 : 4)) void layernorm_kernel(
+// R = rows per wave: the loads of R rows are issued back to back and the 2R wave reductions interleave, which doubles
+// the bytes in flight per wave (the one-row form is latency-bound: 4.9 TB/s with the data sitting in the Infinity Cache).
+template <int CH, int R>
+__global__ __launch_bounds__(256, (CH * R <= 4 ? 8 : 4)) void layernorm_kernel(
     const float* __restrict__ x, const int32_t* __restrict__ row_idx, const float* __restrict__ gam,
     const float* __restrict__ bet, bf16_t* out_bf16, float* out_f32, int64_t rows, int W, float eps) {
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const int64_t src = row_idx ? (int64_t)row_idx[row] : row;
-    const float* xr = x + src * W;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+    if (row0 >= rows) return;
     const int nch = W >> 2;  // float4 chunks in the row
 
-    f32x4 v[CH];
+    f32x4 v[R][CH];
 #pragma unroll
-    for (int i = 0; i < CH; ++i) {
-        const int c = lane + i * 64;
-        v[i] = c < nch ? *(const f32x4*)(xr + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < R; ++r) {
+        const int64_t row = row0 + r < rows ? row0 + r : rows - 1;  // a ragged last wave re-reads the last row (never stored)
+        const int64_t src = row_idx ? (int64_t)row_idx[row] : row;
+        const float* xr = x + src * W;
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int c = lane + i * 64;
+            v[r][i] = c < nch ? *(const f32x4*)(xr + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
     }
-    ln_normalize_row<CH>(v, lane, nch, W, eps);
+    // same arithmetic per row as ln_normalize_row (sum -> mean, sum of squared deviations -> rstd), the R rows interleaved
+    float mean[R], rstd[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        float s1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < CH; ++i)
+            if (lane + i * 64 < nch) s1 += (v[r][i][0] + v[r][i][1]) + (v[r][i][2] + v[r][i][3]);
+        mean[r] = s1;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int r = 0; r < R; ++r) mean[r] += __shfl_xor(mean[r], o, 64);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        mean[r] = mean[r] / (float)W;
+        float s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < CH; ++i)
+            if (lane + i * 64 < nch) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float d = v[r][i][e] - mean[r]; s2 += d * d; }
+            }
+        rstd[r] = s2;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int r = 0; r < R; ++r) rstd[r] += __shfl_xor(rstd[r], o, 64);
+#pragma unroll
+    for (int r = 0; r < R; ++r) rstd[r] = rsqrtf(rstd[r] / (float)W + eps);
+
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
         const int c = lane + i * 64;
         if (c < nch) {
             const f32x4 gg = *(const f32x4*)(gam + c * 4);
             const f32x4 bb = *(const f32x4*)(bet + c * 4);
-            f32x4 y;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) y[e] = v[i][e] * gg[e] + bb[e];
-            if (out_f32) *(f32x4*)(out_f32 + row * W + c * 4) = y;
-            if (out_bf16) {
-                uint2 p;
-                p.x = pack_bf16x2(y[0], y[1]);
-                p.y = pack_bf16x2(y[2], y[3]);
-                *(uint2*)(out_bf16 + row * W + c * 4) = p;
+            for (int r = 0; r < R; ++r) {
+                const int64_t row = row0 + r;
+                if (row >= rows) continue;
+                f32x4 y;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = (v[r][i][e] - mean[r]) * rstd[r] * gg[e] + bb[e];
+                if (out_f32) *(f32x4*)(out_f32 + row * W + c * 4) = y;
+                if (out_bf16) {
+                    uint2 p;
+                    p.x = pack_bf16x2(y[0], y[1]);
+                    p.y = pack_bf16x2(y[2], y[3]);
+                    *(uint2*)(out_bf16 + row * W + c * 4) = p;
+                }
             }
         }
     }
@@ -130,8 +176,13 @@ extern "C" int mq_layernorm(const float* d_x, const int32_t* d_row_idx, const fl
     if (rows <= 0) return MQ_OK;
     hipStream_t s = (hipStream_t)stream;
     MqProfScope prof(1, s);
-    MQ_DISPATCH_CH(W, hipLaunchKernelGGL(layernorm_kernel<CH>, dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, s, d_x, d_row_idx,
-                                         d_g, d_b, (bf16_t*)d_out_bf16, d_out_f32, rows, (int)W, eps));
+    // two rows per wave once there are enough rows to fill the chip that way (and the row fits: CH * 2 float4 per lane)
+    if (mq_ln_rows_per_wave >= 2 && rows >= 8192 && W <= 1024)
+        MQ_DISPATCH_CH(W, hipLaunchKernelGGL((layernorm_kernel<CH, 2>), dim3((unsigned)cdiv64(rows, 8)), dim3(256), 0, s, d_x, d_row_idx,
+                                             d_g, d_b, (bf16_t*)d_out_bf16, d_out_f32, rows, (int)W, eps));
+    else
+        MQ_DISPATCH_CH(W, hipLaunchKernelGGL((layernorm_kernel<CH, 1>), dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, s, d_x, d_row_idx,
+                                             d_g, d_b, (bf16_t*)d_out_bf16, d_out_f32, rows, (int)W, eps));
     MQ_CHECK_LAUNCH("mq_layernorm");
     return MQ_OK;
 }

@@ -215,3 +215,40 @@ def test_row_selected_last_block_full_size_fp8():
         finally:
             _tune("row_select", 1)
         assert torch.equal(sel, full), precision
+
+
+def test_full_size_batch_properties_config2_and_config3():
+    """BASELINE configs 2 and 3 at their FULL sizes (256 ViT-B/32 images; ViT-L/14 with 128 images + 128 ragged texts), where the
+    CPU oracle would take minutes: size-independent properties of an embarrassingly row-parallel map instead —
+    every embedding is independent of what else is in the batch (bitwise: permutation equivariance and batch-split invariance),
+    unit norm, run-to-run determinism — plus the oracle itself on a small sample of the same batch."""
+    T, A = _towers()
+    for name, n_img, n_txt, oracle_n in (("ViT-B-32", 256, 0, 4), ("ViT-L-14", 128, 128, 2)):
+        varch, tarch = A.resolve_open_clip(name)
+        from marqo_amd.engine import synthetic
+        sd = synthetic.random_open_clip_state_dict(vision=varch, text=tarch if n_txt else None, seed=0)
+        g = torch.Generator().manual_seed(11)
+        u8 = torch.randint(0, 256, (n_img, varch.image_size, varch.image_size, 3), generator=g, dtype=torch.uint8)
+        vt = T.VitTower(varch, sd, "cuda")
+        full = vt.encode_u8(u8.cuda())
+        assert torch.equal(full, vt.encode_u8(u8.cuda()))                                   # deterministic
+        perm = torch.randperm(n_img, generator=g)
+        assert torch.equal(vt.encode_u8(u8[perm].cuda()), full[perm.cuda()])                # permutation equivariance
+        halves = torch.cat([vt.encode_u8(u8[:n_img // 2].cuda()), vt.encode_u8(u8[n_img // 2:].cuda())])
+        assert torch.equal(halves, full)                                                    # batch-split invariance
+        assert torch.equal(vt.encode_u8(u8[5:6].cuda()), full[5:6])                         # a batch of one
+        assert torch.allclose(full.norm(dim=-1), torch.ones(n_img, device="cuda"), atol=1e-5)
+        cfg = O.VitConfig(varch.image_size, varch.patch_size, varch.width, varch.layers, varch.heads, varch.mlp_dim, varch.out_dim)
+        ref = O.vit_forward(sd, cfg, O.preprocess_u8_exact_size(u8[:oracle_n]))
+        assert _cos_err(full[:oracle_n], ref) < COS_TIGHT, name
+        if n_txt:
+            tt = T.ClipTextTower(tarch, sd, "cuda")
+            ids = O.synthetic_clip_ids(n_txt, seed=12)                                      # ragged lengths, EOT = max id
+            ft = tt.encode_ids(ids)
+            assert torch.equal(ft, tt.encode_ids(ids))
+            p2 = torch.randperm(n_txt, generator=g)
+            assert torch.equal(tt.encode_ids(ids[p2]), ft[p2.cuda()])
+            assert torch.equal(torch.cat([tt.encode_ids(ids[:50]), tt.encode_ids(ids[50:])]), ft)
+            assert torch.allclose(ft.norm(dim=-1), torch.ones(n_txt, device="cuda"), atol=1e-5)
+            tcfg = O.ClipTextConfig(tarch.vocab, tarch.ctx, tarch.width, tarch.layers, tarch.heads, tarch.mlp_dim, tarch.out_dim)
+            assert _cos_err(ft[:oracle_n], O.clip_text_forward(sd, tcfg, ids[:oracle_n])) < COS_TIGHT
