@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import re
 import subprocess
 import sys
 import threading
@@ -17,10 +18,11 @@ from pathlib import Path
 PKG_DIR = Path(__file__).resolve().parent
 CSRC_DIR = PKG_DIR / "csrc"
 LIB_DIR = PKG_DIR / "lib"
-LIB_PATH = LIB_DIR / "libmarqo_hip.so"
+LIB_PATH = Path(os.environ["MARQO_AMD_LIB"]) if os.environ.get("MARQO_AMD_LIB") else LIB_DIR / "libmarqo_hip.so"  # override: diagnostic builds
 HEADER_PATH = PKG_DIR.parent / "include" / "marqo_hip.h"
 
 MQ_OK = 0
+NO_SCRATCH_UNITS = ("gemm_bf16", "gemm_big", "gemm_fp8", "attention")  # build() refuses register spills in these
 ABI_VERSION = 3
 MQ_PREC_BF16, MQ_PREC_FP8 = 0, 1
 MQ_ACT_GELU, MQ_ACT_QUICKGELU = 1, 2
@@ -171,7 +173,8 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     obj_dir.mkdir(parents=True, exist_ok=True)
     LIB_DIR.mkdir(parents=True, exist_ok=True)
     common_mtime = max(os.path.getmtime(p) for p in common)
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+             "-Rpass-analysis=kernel-resource-usage"]  # the remarks feed the no-scratch check below
 
     def compile_one(src: str):
         obj = obj_dir / (Path(src).stem + ".o")
@@ -183,6 +186,13 @@ def build(force: bool = False, verbose: bool = False) -> Path:
         res = subprocess.run(cmd, capture_output=True, text=True)
         if res.returncode != 0:
             raise MarqoHipUnavailableError(f"hipcc failed on {src} ({res.returncode}):\n{res.stdout}\n{res.stderr}")
+        # The LDS-DMA / MFMA kernels must not use scratch: they sit at the 256-VGPR cap of 2 workgroups per CU, and a variant
+        # that spilled (fp8 GEMM, 192-row tile with a whole-tile residual prefetch) returned wrong tiles on MI355X.
+        spilled = [ln.strip() for ln in res.stderr.splitlines()
+                   if any(int(v) > 0 for v in re.findall(r"(?:VGPRs Spill|ScratchSize \[bytes/lane\]): (\d+)", ln))]
+        if spilled and Path(src).stem in NO_SCRATCH_UNITS:
+            os.unlink(obj)
+            raise MarqoHipUnavailableError(f"{src}: a kernel spills registers to scratch (not allowed, see _lib.build):\n" + "\n".join(spilled[:6]))
         return str(obj), True
 
     with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:

@@ -31,6 +31,18 @@ template <int FLAGS>
 int mq_launch_gemm_big(int mt, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* residual,
                        void* out, int64_t ldc, int M, int N, int K, hipStream_t s);
 
+#ifdef MQ_GEMM_TRACE
+// Diagnostic build only (tools/probes/gemm_trace.py): per-wave cycle sums of the main loop's phases, written once at kernel
+// end by the first MQ_TRACE_BLOCKS workgroups: [block][wave][0..5] = k-steps, cycles parked at s_waitcnt vmcnt(0), cycles at the
+// barrier, cycles in the k-step body (ds_reads + MFMAs + next-stage LDS-DMA issues), cycles in the epilogue, tiles.
+#define MQ_TRACE_BLOCKS 64
+__device__ unsigned long long mq_gemm_trace_buf[MQ_TRACE_BLOCKS * 4 * 6];
+extern "C" int mq_gemm_trace_read(unsigned long long* h_out) {
+    return hipMemcpyFromSymbol(h_out, HIP_SYMBOL(mq_gemm_trace_buf), sizeof(mq_gemm_trace_buf)) == hipSuccess ? 0 : -2;
+}
+#define MQ_TR_NOW() __builtin_amdgcn_s_memtime()
+#endif
+
 namespace {
 
 constexpr int BN = 128, BK = 64;
@@ -135,6 +147,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
     set_sources(m0, n0);
     stage(0, 0);
     int buf = 0;  // LDS buffer of the next k-step (runs on across tiles in the persistent form)
+#ifdef MQ_GEMM_TRACE
+    unsigned long long tr_steps = 0, tr_vm = 0, tr_bar = 0, tr_body = 0, tr_epi = 0, tr_tiles = 0;
+#endif
     for (;;) {
 #pragma unroll
         for (int i = 0; i < MT; ++i)
@@ -203,9 +218,21 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
 
         for (int kt = 0; kt < nk - 1; ++kt) {
             // stage kt has landed for every wave, and every wave is done reading the other buffer
+#ifdef MQ_GEMM_TRACE
+            const unsigned long long t0 = MQ_TR_NOW();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned long long t1 = MQ_TR_NOW();
+            __syncthreads();
+            const unsigned long long t2 = MQ_TR_NOW();
+            kstep(buf, (int64_t)(kt + 1) * BK, std::true_type{});
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long t3 = MQ_TR_NOW();
+            tr_steps += 1; tr_vm += t1 - t0; tr_bar += t2 - t1; tr_body += t3 - t2;
+#else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             kstep(buf, (int64_t)(kt + 1) * BK, std::true_type{});
+#endif
             buf ^= 1;
         }
         const int cm0 = m0, cn0 = n0;
@@ -223,9 +250,23 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
         if (PERSIST && more) kstep(buf, 0, std::true_type{});
         else kstep(buf, 0, std::false_type{});
         buf ^= 1;
+#ifdef MQ_GEMM_TRACE
+        const unsigned long long te0 = MQ_TR_NOW();
+#endif
         gemm_epilogue<FLAGS, MT>(acc, bias, residual, out, ldc, M, N, cm0 + wm * (16 * MT), cn0 + wn * 64, l15, g, wide_store != 0, &ln);
+#ifdef MQ_GEMM_TRACE
+        __builtin_amdgcn_sched_barrier(0);
+        tr_epi += MQ_TR_NOW() - te0;  // issue time of the epilogue (its stores retire later)
+        tr_tiles += 1;
+#endif
         if (!PERSIST || !more) break;
     }
+#ifdef MQ_GEMM_TRACE
+    if (blockIdx.x < MQ_TRACE_BLOCKS && lane == 0) {
+        unsigned long long* o = mq_gemm_trace_buf + (blockIdx.x * 4 + wave) * 6;
+        o[0] = tr_steps; o[1] = tr_vm; o[2] = tr_bar; o[3] = tr_body; o[4] = tr_epi; o[5] = tr_tiles;
+    }
+#endif
 }
 
 // tuning knobs: initialised from the environment (MQ_GEMM_MT / _PERSIST / _CGROUP / _WIDE / _BIG), overridable through mq_tune()
@@ -300,20 +341,22 @@ int launch_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const fl
     if constexpr ((FLAGS & (MQ_EPI_LN_STATS | MQ_EPI_LN_APPLY)) == 0) {
         if (g_tune.big) return mq_launch_gemm_big<FLAGS>(g_tune.big, A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s);
     }
-#define MQ_MT_CASE(T)                                                                                              \
-    case T:                                                                                                        \
-        return persist ? launch_gemm_mt<FLAGS, T, true>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s, ln) \
-                       : launch_gemm_mt<FLAGS, T, false>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s, ln)
+    // persistent form unless the epilogue does not fit its register budget (LN_STATS: a one-VGPR scratch spill)
+    auto run = [&](auto mt_tag) {
+        constexpr int T = decltype(mt_tag)::value;
+        if constexpr ((FLAGS & MQ_EPI_LN_STATS) != 0 || T == 6) {  // T == 6: the 192-row tile spills in the persistent form
+            return launch_gemm_mt<FLAGS, T, false>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s, ln);
+        } else {
+            return persist ? launch_gemm_mt<FLAGS, T, true>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s, ln)
+                           : launch_gemm_mt<FLAGS, T, false>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s, ln);
+        }
+    };
     switch (mt) {
-        MQ_MT_CASE(2);
-        MQ_MT_CASE(5);
-        case 6:  // the persistent form of the 192-row tile spills (256-VGPR cap at 2 workgroups per CU): plain form only
-            return launch_gemm_mt<FLAGS, 6, false>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s, ln);
-        default:
-            return persist ? launch_gemm_mt<FLAGS, 4, true>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s, ln)
-                           : launch_gemm_mt<FLAGS, 4, false>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s, ln);
+        case 2: return run(std::integral_constant<int, 2>{});
+        case 5: return run(std::integral_constant<int, 5>{});
+        case 6: return run(std::integral_constant<int, 6>{});
+        default: return run(std::integral_constant<int, 4>{});
     }
-#undef MQ_MT_CASE
 }
 
 }  // namespace

@@ -142,7 +142,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(
     }
     if (!late) wg_barrier();  // balance the stagger barrier
 
-    gemm_epilogue<FLAGS, MT>(acc, bias, residual, out, ldc, M, N, m0 + wm * (16 * MT), n0 + wn * 64, l15, g);
+    gemm_epilogue<FLAGS, MT, 2>(acc, bias, residual, out, ldc, M, N, m0 + wm * (16 * MT), n0 + wn * 64, l15, g);
 }
 
 template <int FLAGS, int MT>

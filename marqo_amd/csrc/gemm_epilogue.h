@@ -28,7 +28,9 @@ struct GemmLn {
     float eps;
 };
 
-template <int FLAGS, int MT>
+// RG = rows (16-row units) whose residual is prefetched together: the whole tile where the registers allow (the 4-wave kernel
+// after its k-loop), a few rows at a time in the 8-wave kernel whose accumulators already fill the file.
+template <int FLAGS, int MT, int RG = MT>
 __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][4], const float* __restrict__ bias, const float* residual, void* out,
                                               int64_t ldc, int M, int N, int wave_m0, int wave_n0, int l15, int g, bool wide = false,
                                               const GemmLn* lnp = nullptr) {
@@ -37,19 +39,44 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][4], const float* 
     static_assert(!LN_STATS || ((FLAGS & MQ_EPI_RESIDUAL) && (FLAGS & MQ_EPI_OUT_F32)), "LN_STATS rides on the residual epilogue");
     static_assert(!LN_APPLY || BF16_OUT, "LN_APPLY produces a bf16 GEMM operand");
     float row_mean = 0.f, row_rstd = 1.f;
-    // value of one (mt, nt) sub-tile after (LN apply) / bias / activation / residual; `ok` guards the residual read
+    // Everything the epilogue READS is fetched up front, the long-latency residual tile first.  Measured with the phase trace
+    // (tools/probes/gemm_trace.py): left inside the (mt, nt) loop, each sub-tile's bias / residual load was waited for on its
+    // own — the compiler cannot move a load of `residual` above the earlier stores to `out` (they alias: the update is in
+    // place) and did not hoist the bias either — which cost 20 serialised L2 / HBM round trips per tile: 9 k cycles for a
+    // bias, 24 k for bias + fp32 residual, against 17 k for the whole 12-step k-loop at K = 768.
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);  // keep the prefetch below the k-loop (hoisted into it, it collides with the fragments' registers)
+    f32x4 res_v[(FLAGS & MQ_EPI_RESIDUAL) ? RG : 1][4];
+    auto prefetch_residual = [&](int mt_lo) {
+        if (FLAGS & MQ_EPI_RESIDUAL) {
+#pragma unroll
+            for (int h = 0; h < RG; ++h) {
+                const int m = wave_m0 + (mt_lo + h) * 16 + l15;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const int n = wave_n0 + nt * 16 + g * 4;
+                    res_v[h][nt] = (mt_lo + h < MT && m < M && n < N) ? *(const f32x4*)(residual + (int64_t)m * ldc + n)
+                                                                    : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        }
+    };
+    prefetch_residual(0);
+    f32x4 bias_v[4], cs_v[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int n = wave_n0 + nt * 16 + g * 4;
+        bias_v[nt] = ((FLAGS & MQ_EPI_BIAS) && n < N) ? *(const f32x4*)(bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+        cs_v[nt] = (LN_APPLY && n < N) ? *(const f32x4*)(lnp->colsum + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // value of one (mt, nt) sub-tile after (LN apply) / bias / activation / residual
     auto value = [&](int mt, int nt, int m, int n, bool ok) {
         f32x4 v = acc[mt][nt];
         if (LN_APPLY) {
-            if (n < N) {
-                const f32x4 cs = *(const f32x4*)(lnp->colsum + n);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = row_rstd * (v[e] - row_mean * cs[e]);
-            }
+            for (int e = 0; e < 4; ++e) v[e] = row_rstd * (v[e] - row_mean * cs_v[nt][e]);
         }
-        if (FLAGS & MQ_EPI_BIAS) {
-            if (n < N) v += *(const f32x4*)(bias + n);
-        }
+        if (FLAGS & MQ_EPI_BIAS) v += bias_v[nt];
         if (FLAGS & MQ_EPI_GELU) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
@@ -58,13 +85,12 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][4], const float* 
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
         }
-        if (FLAGS & MQ_EPI_RESIDUAL) {
-            if (ok) v += *(const f32x4*)(residual + (int64_t)m * ldc + n);
-        }
+        if (FLAGS & MQ_EPI_RESIDUAL) v += res_v[(FLAGS & MQ_EPI_RESIDUAL) ? (mt % RG) : 0][nt];
         return v;
     };
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
+        if (mt > 0 && mt % RG == 0) prefetch_residual(mt);  // (the previous group is finished: its registers are free)
         const int m = wave_m0 + mt * 16 + l15;
         const bool m_ok = m < M;
         if (LN_APPLY) {

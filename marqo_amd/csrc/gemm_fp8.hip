@@ -210,14 +210,48 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(
         buf ^= 1;
 
         // ---- epilogue: lane owns out[m][n .. n+3]; dequantise with a_scale[m] * w_scale[n] ----------------------------
+        // everything the epilogue READS is fetched up front (residual tile first): left inside the (mt, nt) loop every
+        // sub-tile's scale / bias / residual load was waited for on its own (gemm_epilogue.h, tools/probes/gemm_trace.py)
+        const int wave_n0 = cn0 + wn * 64;
+        asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);  // keep the prefetch below the k-loop: hoisted into it, it collides with the fragments' registers
+        // (the residual tile is prefetched in 2-3 groups of the tile's rows: the whole 160-row tile next to the e4m3 fragments'
+        // registers spilled; 2-3 exposed latencies instead of twenty)
+        constexpr int HALF = MT >= 6 ? 1 : (MT + 1) / 2;  // rows (in 16-row units) per prefetch group (192-row tile: no register room)
+        f32x4 res_v[(FLAGS & MQ_EPI_RESIDUAL) ? HALF : 1][4];
+        auto prefetch_residual = [&](int mt_lo) {
+            if (FLAGS & MQ_EPI_RESIDUAL) {
+#pragma unroll
+                for (int h = 0; h < HALF; ++h) {
+                    const int m = cm0 + wm * (16 * MT) + (mt_lo + h) * 16 + l15;
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+                        const int n = wave_n0 + nt * 16 + g * 4;
+                        res_v[h][nt] = (mt_lo + h < MT && m < M && n < N) ? *(const f32x4*)(residual + (int64_t)m * ldc + n)
+                                                                        : f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                }
+            }
+        };
+        prefetch_residual(0);
+        float sa_v[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = cm0 + wm * (16 * MT) + mt * 16 + l15;
+            sa_v[mt] = ROWSCALE ? a_scale[m < M ? m : M - 1] : a_scalar;
+        }
+        f32x4 sw_v[4], bias_v[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int n = wave_n0 + nt * 16 + g * 4;
+            sw_v[nt] = n < N ? *(const f32x4*)(w_scale + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+            bias_v[nt] = ((FLAGS & MQ_EPI_BIAS) && n < N) ? *(const f32x4*)(bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
         auto value = [&](int mt, int nt, int m, int n, bool ok, float sa) {
             f32x4 v = acc[mt][nt];
-            if (n < N) {
-                const f32x4 sw4 = *(const f32x4*)(w_scale + n);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] *= sa * sw4[e];
-                if (FLAGS & MQ_EPI_BIAS) v += *(const f32x4*)(bias + n);
-            }
+            for (int e = 0; e < 4; ++e) v[e] *= sa * sw_v[nt][e];
+            if (FLAGS & MQ_EPI_BIAS) v += bias_v[nt];
             if (FLAGS & MQ_EPI_GELU) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
@@ -226,21 +260,19 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
             }
-            if (FLAGS & MQ_EPI_RESIDUAL) {
-                if (ok) v += *(const f32x4*)(residual + (int64_t)m * ldc + n);
-            }
+            if (FLAGS & MQ_EPI_RESIDUAL) v += res_v[(FLAGS & MQ_EPI_RESIDUAL) ? (mt % HALF) : 0][nt];
             return v;
         };
         auto to_fp8 = [&](const f32x4& v) {
             int w = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(v[0] * inv_out), clamp448(v[1] * inv_out), 0, false);
             return __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(v[2] * inv_out), clamp448(v[3] * inv_out), w, true);
         };
-        const int wave_n0 = cn0 + wn * 64;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
+            if (mt > 0 && mt % HALF == 0) prefetch_residual(mt);  // (the previous group is finished: its registers are free)
             const int m = cm0 + wm * (16 * MT) + mt * 16 + l15;
             const bool m_ok = m < M;
-            const float sa = ROWSCALE ? a_scale[m_ok ? m : M - 1] : a_scalar;
+            const float sa = sa_v[mt];
             if (!(FLAGS & MQ_EPI_OUT_F32) && wide) {  // `wide` is wave-uniform: every lane takes part in the swaps
                 if (FLAGS & MQ_EPI_OUT_FP8) {
                     unsigned int pr[2][2];  // pr[p] = 8 consecutive codes of pair p after the first exchange
