@@ -37,6 +37,14 @@ __global__ __launch_bounds__(256, (CH * R <= 4 ? 8 : 4)) void layernorm_kernel(
             v[r][i] = c < nch ? *(const f32x4*)(xr + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
+    // gamma / beta are fetched now, not after the reductions: their (L2) latency hides behind the row loads and the shuffles
+    f32x4 gv[CH], bv[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        const int c = lane + i * 64;
+        gv[i] = c < nch ? *(const f32x4*)(gam + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        bv[i] = c < nch ? *(const f32x4*)(bet + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     // same arithmetic per row as ln_normalize_row (sum -> mean, sum of squared deviations -> rstd), the R rows interleaved
     float mean[R], rstd[R];
 #pragma unroll
@@ -74,8 +82,7 @@ __global__ __launch_bounds__(256, (CH * R <= 4 ? 8 : 4)) void layernorm_kernel(
     for (int i = 0; i < CH; ++i) {
         const int c = lane + i * 64;
         if (c < nch) {
-            const f32x4 gg = *(const f32x4*)(gam + c * 4);
-            const f32x4 bb = *(const f32x4*)(bet + c * 4);
+            const f32x4 gg = gv[i], bb = bv[i];
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const int64_t row = row0 + r;
