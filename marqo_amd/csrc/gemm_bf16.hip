@@ -43,6 +43,11 @@ extern "C" int mq_gemm_trace_read(unsigned long long* h_out) {
 #define MQ_TR_NOW() __builtin_amdgcn_s_memtime()
 #endif
 
+// short-k-step / 3-4 workgroups per CU form (gemm_k32.hip)
+template <int FLAGS>
+int mq_launch_gemm_k32(int wgs, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* residual,
+                       void* out, int64_t ldc, int M, int N, int K, int cgroup_knob, int wide_knob, hipStream_t s);
+
 namespace {
 
 constexpr int BN = 128, BK = 64;
@@ -271,9 +276,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
 
 // tuning knobs: initialised from the environment (MQ_GEMM_MT / _PERSIST / _CGROUP / _WIDE / _BIG), overridable through mq_tune()
 struct GemmTune {
-    int mt, persist, big, cgroup, wide;
+    int mt, persist, big, cgroup, wide, k32;
     static int env(const char* k, int d) { const char* v = getenv(k); return v ? atoi(v) : d; }
-    GemmTune() : mt(env("MQ_GEMM_MT", 0)), persist(env("MQ_GEMM_PERSIST", 1)), big(env("MQ_GEMM_BIG", 0)), cgroup(env("MQ_GEMM_CGROUP", 8)), wide(env("MQ_GEMM_WIDE", 2)) {}
+    GemmTune() : mt(env("MQ_GEMM_MT", 0)), persist(env("MQ_GEMM_PERSIST", 1)), big(env("MQ_GEMM_BIG", 0)), cgroup(env("MQ_GEMM_CGROUP", 8)), wide(env("MQ_GEMM_WIDE", 2)), k32(env("MQ_GEMM_K32", 0)) {}
 };
 GemmTune g_tune;
 }  // namespace
@@ -340,6 +345,7 @@ int launch_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const fl
     const int mt = force_mt ? force_mt : choose_mt(M, N);
     if constexpr ((FLAGS & (MQ_EPI_LN_STATS | MQ_EPI_LN_APPLY)) == 0) {
         if (g_tune.big) return mq_launch_gemm_big<FLAGS>(g_tune.big, A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s);
+        if (g_tune.k32) return mq_launch_gemm_k32<FLAGS>(g_tune.k32, A, lda, W, ldw, bias, residual, out, ldc, M, N, K, g_tune.cgroup, g_tune.wide, s);
     }
     // persistent form unless the epilogue does not fit its register budget (LN_STATS: a one-VGPR scratch spill)
     auto run = [&](auto mt_tag) {
@@ -442,6 +448,7 @@ extern "C" int mq_tune(const char* key, int value) {
     else if (k == "gemm_big") g_tune.big = value;
     else if (k == "gemm_cgroup") mq_gemm_knob_cgroup = g_tune.cgroup = value;
     else if (k == "gemm_wide") mq_gemm_knob_wide = g_tune.wide = value;
+    else if (k == "gemm_k32") g_tune.k32 = value;
     else if (k == "row_select") mq_tower_row_select = value;
     else if (k == "ln_fold") mq_tower_ln_fold = value;
     else if (k == "ln_rows") mq_ln_rows_per_wave = value;

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 VARIANTS = [dict(gemm_persist=0, gemm_cgroup=0, gemm_wide=0), dict(gemm_persist=1, gemm_cgroup=0, gemm_wide=0),
             dict(gemm_persist=0, gemm_cgroup=8, gemm_wide=1), dict(gemm_persist=1, gemm_cgroup=4, gemm_wide=2)]
-DEFAULTS = dict(gemm_mt=0, gemm_persist=1, gemm_cgroup=8, gemm_wide=2, gemm_big=0)
+DEFAULTS = dict(gemm_mt=0, gemm_persist=1, gemm_cgroup=8, gemm_wide=2, gemm_big=0, gemm_k32=0)
 
 
 def _vid(v):
@@ -76,6 +76,29 @@ def test_variant_is_bitwise_stable_and_equal_to_baseline(variant):
                 for _ in range(25):
                     out = _gemm(lib, A, W, None, None, L.MQ_EPI_OUT_F32)
                     assert torch.equal(out, base), (variant, mt, (M, N, K))
+    finally:
+        _tune(lib, **DEFAULTS)
+
+
+def test_short_kstep_three_workgroup_variant():
+    """gemm_k32.hip: 128x128x32 tiles under the 64-byte-row LDS swizzle, three workgroups per CU.  Same k-order of MFMAs as the
+    shipped kernel -> bit-identical; ragged shapes, every epilogue, repeated launches as a race screen."""
+    lib = L.load()
+    g = torch.Generator(device="cuda").manual_seed(77)
+    try:
+        for (M, N, K) in SHAPES + [(12800, 2304, 768), (12800, 768, 3072)]:
+            A = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+            W = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).to(torch.bfloat16)
+            bias = torch.randn(N, device="cuda", generator=g)
+            res = torch.randn(M, N, device="cuda", generator=g)
+            for flags in (0, L.MQ_EPI_OUT_F32, L.MQ_EPI_BIAS, L.MQ_EPI_BIAS | L.MQ_EPI_GELU, L.MQ_EPI_BIAS | L.MQ_EPI_QUICKGELU,
+                          L.MQ_EPI_BIAS | L.MQ_EPI_RESIDUAL | L.MQ_EPI_OUT_F32):
+                _tune(lib, gemm_k32=0)
+                base = _gemm(lib, A, W, bias, res, flags)
+                _tune(lib, gemm_k32=3)
+                for _ in range(4):
+                    out = _gemm(lib, A, W, bias, res, flags)
+                    assert torch.equal(out, base), ((M, N, K), flags, (out.float() - base.float()).abs().max().item())
     finally:
         _tune(lib, **DEFAULTS)
 
