@@ -66,6 +66,7 @@ class BertArch:
     heads: int = 12
     mlp_dim: int = 3072
     ln_eps: float = 1e-12
+    pos_offset: int = 0  # XLM-RoBERTa / RoBERTa checkpoints: position ids start at padding_idx + 1 = 2; max_pos counts USABLE positions
 
     def gflop_per_text(self, tokens: int) -> float:
         T, W, F = tokens, self.width, self.mlp_dim
@@ -122,17 +123,24 @@ HF_BERT_ARCHS = {
     "BAAI/bge-small-en": _BERT_SMALL, "BAAI/bge-small-en-v1.5": _BERT_SMALL,
     "BAAI/bge-large-en": _BERT_LARGE, "BAAI/bge-large-en-v1.5": _BERT_LARGE,
     "sentence-transformers/all-MiniLM-L6-v1": _MINILM_L6, "sentence-transformers/all-MiniLM-L6-v2": _MINILM_L6,
+    # XLM-RoBERTa encoders (multilingual-e5-small has 32-wide heads and is not runnable: the attention kernel needs 64)
+    "intfloat/multilingual-e5-base": BertArch(vocab=250002, max_pos=512, ln_eps=1e-5, pos_offset=2),
+    "intfloat/multilingual-e5-large": BertArch(vocab=250002, max_pos=512, width=1024, layers=24, heads=16, mlp_dim=4096, ln_eps=1e-5, pos_offset=2),
 }
 
 
 def bert_arch_from_hf_config(cfg: dict) -> BertArch:
-    """A local HF `config.json` (model_type bert) -> BertArch."""
-    if cfg.get("model_type", "bert") != "bert":
-        raise KeyError(f"model_type={cfg.get('model_type')} is not a BERT encoder")
+    """A local HF `config.json` -> BertArch.  model_type bert, or xlm-roberta / roberta: the same encoder with the position ids
+    shifted by padding_idx + 1 (the multilingual-e5 family)."""
+    mtype = cfg.get("model_type", "bert")
+    if mtype not in ("bert", "xlm-roberta", "roberta"):
+        raise KeyError(f"model_type={mtype} is not a BERT-family encoder")
     if cfg.get("position_embedding_type", "absolute") != "absolute":
         raise KeyError("only absolute position embeddings are supported")
     if cfg.get("hidden_act", "gelu") != "gelu":
         raise KeyError(f"hidden_act={cfg.get('hidden_act')} unsupported")
-    return BertArch(vocab=cfg["vocab_size"], max_pos=cfg["max_position_embeddings"], width=cfg["hidden_size"],
+    off = 0 if mtype == "bert" else int(cfg.get("pad_token_id", 1)) + 1
+    return BertArch(vocab=cfg["vocab_size"], max_pos=cfg["max_position_embeddings"] - off, width=cfg["hidden_size"],
                     layers=cfg["num_hidden_layers"], heads=cfg["num_attention_heads"],
-                    mlp_dim=cfg["intermediate_size"], ln_eps=cfg.get("layer_norm_eps", 1e-12))
+                    mlp_dim=cfg["intermediate_size"], ln_eps=cfg.get("layer_norm_eps", 1e-12 if mtype == "bert" else 1e-5),
+                    pos_offset=off)

@@ -70,7 +70,7 @@ def random_bert_state_dict(arch: BertArch, seed: int = 0) -> Dict[str, Tensor]:
     std = 0.6 / math.sqrt(W)
     sd: Dict[str, Tensor] = {}
     sd["embeddings.word_embeddings.weight"] = 0.5 * torch.randn(arch.vocab, W, generator=g)
-    sd["embeddings.position_embeddings.weight"] = 0.3 * torch.randn(arch.max_pos, W, generator=g)
+    sd["embeddings.position_embeddings.weight"] = 0.3 * torch.randn(arch.max_pos + arch.pos_offset, W, generator=g)
     sd["embeddings.token_type_embeddings.weight"] = 0.3 * torch.randn(2, W, generator=g)
     _ln(sd, "embeddings.LayerNorm", W, g)
     for i in range(arch.layers):

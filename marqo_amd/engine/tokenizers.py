@@ -293,6 +293,50 @@ class WordPieceTokenizer:
 
 
 # ---------------------------------------------------------------------------------------------------
+# XLM-RoBERTa SentencePiece (multilingual-e5 family)
+# ---------------------------------------------------------------------------------------------------
+class XlmRobertaTokenizer:
+    """transformers.XLMRobertaTokenizer over the checkpoint's `sentencepiece.bpe.model` (a unigram SentencePiece model; the
+    `sentencepiece` wheel is the third-party dependency the reference reaches through AutoTokenizer, hugging_face_model.py:125-130).
+    fairseq id layout: <s> 0, <pad> 1, </s> 2, <unk> 3, then every SentencePiece id shifted by one (SentencePiece's own id 0 =
+    <unk> maps to 3); a sequence is <s> pieces... </s>, truncated to max_length, padded to the longest with <pad>."""
+    FAIRSEQ_OFFSET = 1
+
+    def __init__(self, model_file: str):
+        import sentencepiece as spm
+        if os.path.isdir(model_file):
+            model_file = os.path.join(model_file, "sentencepiece.bpe.model")
+        self.sp = spm.SentencePieceProcessor(model_file=model_file)
+        self.cls_id, self.pad_id, self.sep_id, self.unk_id = 0, 1, 2, 3
+        self._fairseq = {"<s>": 0, "<pad>": 1, "</s>": 2, "<unk>": 3}
+        self.vocab_size = len(self.sp) + self.FAIRSEQ_OFFSET + 1  # + <mask>
+
+    def _piece_id(self, piece: str) -> int:
+        if piece in self._fairseq:
+            return self._fairseq[piece]
+        i = self.sp.PieceToId(piece)
+        return i + self.FAIRSEQ_OFFSET if i else self.unk_id
+
+    def encode(self, text: str, max_length: Optional[int] = None) -> List[int]:
+        ids = [self._piece_id(p) for p in self.sp.encode(text, out_type=str)]
+        if max_length is not None and len(ids) > max_length - 2:
+            ids = ids[:max(max_length - 2, 0)]
+        return [self.cls_id] + ids + [self.sep_id]
+
+    def __call__(self, texts: Union[str, Sequence[str]], max_length: Optional[int] = None) -> Dict[str, np.ndarray]:
+        if isinstance(texts, str):
+            texts = [texts]
+        enc = [self.encode(t, max_length) for t in texts]
+        S = max((len(e) for e in enc), default=0)
+        ids = np.full((len(enc), S), self.pad_id, dtype=np.int64)
+        mask = np.zeros((len(enc), S), dtype=np.int64)
+        for i, e in enumerate(enc):
+            ids[i, :len(e)] = e
+            mask[i, :len(e)] = 1
+        return {"input_ids": ids, "attention_mask": mask}
+
+
+# ---------------------------------------------------------------------------------------------------
 # stand-in for random-init models (no vocabulary exists for them)
 # ---------------------------------------------------------------------------------------------------
 class SyntheticTokenizer:

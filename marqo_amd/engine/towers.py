@@ -418,8 +418,9 @@ class BertTower(_TextTowerBase):
         if pooling not in ("mean", "cls"):
             raise ValueError(f"pooling must be 'mean' or 'cls', got {pooling!r}")
         self.pooling = pooling
-        if "embeddings.word_embeddings.weight" not in sd and "bert.embeddings.word_embeddings.weight" in sd:
-            sd = {k[len("bert."):]: v for k, v in sd.items() if k.startswith("bert.")}
+        for prefix in ("bert.", "roberta."):  # HF checkpoints may carry the task-model prefix
+            if "embeddings.word_embeddings.weight" not in sd and prefix + "embeddings.word_embeddings.weight" in sd:
+                sd = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
         W, F = arch.width, arch.mlp_dim
         h = self._h
         arr = (L.BlockWeights * arch.layers)()
@@ -442,7 +443,8 @@ class BertTower(_TextTowerBase):
         self._blocks = arr
         self.w = L.BertWeights(
             word_emb=h.f32(_need(sd, "embeddings.word_embeddings.weight", (arch.vocab, W))),
-            pos_emb=h.f32(_need(sd, "embeddings.position_embeddings.weight", (arch.max_pos, W))),
+            # XLM-RoBERTa: position ids start at pos_offset -> hand the library the table from that row on
+            pos_emb=h.f32(_need(sd, "embeddings.position_embeddings.weight", (arch.max_pos + arch.pos_offset, W))[arch.pos_offset:]),
             type_emb=h.f32(_need(sd, "embeddings.token_type_embeddings.weight")),
             emb_ln_g=h.f32(_need(sd, "embeddings.LayerNorm.weight", (W,))),
             emb_ln_b=h.f32(_need(sd, "embeddings.LayerNorm.bias", (W,))),

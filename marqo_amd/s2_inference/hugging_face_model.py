@@ -16,7 +16,7 @@ import torch
 
 from marqo_amd import _lib as L
 from marqo_amd.engine import archs, checkpoint, synthetic
-from marqo_amd.engine.tokenizers import SyntheticTokenizer, WordPieceTokenizer
+from marqo_amd.engine.tokenizers import SyntheticTokenizer, WordPieceTokenizer, XlmRobertaTokenizer
 from marqo_amd.s2_inference.abstract_models import AbstractEmbeddingModel
 from marqo_amd.s2_inference.errors import InternalError, InvalidModelPropertiesError, ModelLoadError
 
@@ -102,12 +102,15 @@ class HuggingFaceModel(AbstractEmbeddingModel):
                 arch = archs.bert_arch_from_hf_config(cfg)
             except KeyError as e:
                 raise InvalidModelPropertiesError(f"{props.name}: {e}. Only BERT-family encoders run on the marqo_amd engine.") from e
-            self._tokenizer = WordPieceTokenizer(directory, do_lower_case=self._do_lower_case(directory))
+            if os.path.isfile(os.path.join(directory, "sentencepiece.bpe.model")):  # XLM-RoBERTa checkpoints (multilingual-e5)
+                self._tokenizer = XlmRobertaTokenizer(directory)
+            else:
+                self._tokenizer = WordPieceTokenizer(directory, do_lower_case=self._do_lower_case(directory))
             self.weights_source = directory
         elif checkpoint.synthetic_weights_enabled() and props.name in archs.HF_BERT_ARCHS:
             arch = archs.HF_BERT_ARCHS[props.name]
             sd = synthetic.random_bert_state_dict(arch, seed=0)
-            self._tokenizer = SyntheticTokenizer("bert", arch.vocab)
+            self._tokenizer = SyntheticTokenizer("bert", arch.vocab)  # (for XLM-R archs too: ids only need to be in range)
             self.weights_source = "synthetic(seed=0)"
         else:
             raise InvalidModelPropertiesError(

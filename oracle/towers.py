@@ -95,6 +95,7 @@ class BertConfig:
     mlp_dim: int = 3072
     ln_eps: float = 1e-12
     pooling: str = "mean"  # "mean" | "cls"
+    pos_offset: int = 0    # XLM-RoBERTa / RoBERTa: position ids start at padding_idx + 1 = 2 (0 for BERT)
 
 
 # --------------------------------------------------------------------------------------------
@@ -184,12 +185,14 @@ def clip_text_forward(sd: Dict[str, Tensor], cfg: ClipTextConfig, ids: Tensor, n
 @torch.no_grad()
 def bert_forward(sd: Dict[str, Tensor], cfg: BertConfig, ids: Tensor, attention_mask: Tensor) -> Tensor:
     """transformers BertModel forward (absolute positions, token_type_ids = 0, eval mode)
-    -> last_hidden_state [B, S, W]."""
+    -> last_hidden_state [B, S, W].  With cfg.pos_offset = 2 it is transformers XLMRobertaModel / RobertaModel: the same
+    encoder, position ids = cumsum(mask) * mask + padding_idx (= offset + index for the real tokens of a right-padded row; the
+    padded rows are masked out of the attention and of the pooling, so their position does not matter)."""
     B, S = ids.shape
     W, H = cfg.width, cfg.heads
     x = (sd["embeddings.word_embeddings.weight"][ids]
          + sd["embeddings.token_type_embeddings.weight"][torch.zeros_like(ids)]
-         + sd["embeddings.position_embeddings.weight"][:S])
+         + sd["embeddings.position_embeddings.weight"][cfg.pos_offset:cfg.pos_offset + S])
     x = F.layer_norm(x, (W,), sd["embeddings.LayerNorm.weight"], sd["embeddings.LayerNorm.bias"], cfg.ln_eps)
     # additive key-padding mask: (1 - mask) * finfo.min
     add_mask = (1.0 - attention_mask[:, None, None, :].to(x.dtype)) * torch.finfo(x.dtype).min

@@ -76,6 +76,37 @@ def make_bert():
                         **{"w:" + k: v for k, v in _np(sd).items()})
 
 
+def make_xlmr():
+    """transformers.XLMRobertaModel == what HuggingFaceModel loads through AutoModel for the multilingual-e5 family:
+    BERT encoder, position ids offset by padding_idx + 1 = 2, one token type."""
+    from transformers import XLMRobertaConfig, XLMRobertaModel
+    torch.manual_seed(0)
+    cfg = XLMRobertaConfig(vocab_size=300, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                           max_position_embeddings=66, type_vocab_size=1, layer_norm_eps=1e-5, hidden_act="gelu",
+                           hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, pad_token_id=1, bos_token_id=0, eos_token_id=2)
+    m = XLMRobertaModel(cfg, add_pooling_layer=False).eval()
+    _jitter(m, 5)
+    g = torch.Generator().manual_seed(6)
+    lens = [5, 17, 2, 33, 64, 9]
+    S = max(lens)
+    ids = torch.full((len(lens), S), 1, dtype=torch.int64)  # <pad> = 1
+    mask = torch.zeros(len(lens), S, dtype=torch.int64)
+    for i, L in enumerate(lens):
+        ids[i, :L] = torch.randint(4, 300, (L,), generator=g)
+        ids[i, 0], ids[i, L - 1] = 0, 2  # <s> ... </s>
+        mask[i, :L] = 1
+    with torch.no_grad():
+        last = m(input_ids=ids, attention_mask=mask).last_hidden_state
+    lh = last.masked_fill(~mask[..., None].bool(), 0.0)
+    mean = lh.sum(1) / mask.sum(1)[..., None]
+    mean_n = torch.nn.functional.normalize(mean, p=2, dim=1)
+    sd = dict(m.state_dict())
+    np.savez_compressed(os.path.join(HERE, "xlmr_small.npz"), ids=ids.numpy(), mask=mask.numpy(), last_hidden=last.numpy(),
+                        mean=mean.numpy(), mean_norm=mean_n.numpy(),
+                        cfg=np.array([300, 66, 128, 2, 2, 256], dtype=np.int64),  # vocab max_pos W layers heads F
+                        **{"w:" + k: v for k, v in _np(sd).items()})
+
+
 def _clip_blocks_to_open_clip(hf_sd, hf_prefix, oc_prefix, layers):
     out = {}
     for i in range(layers):
@@ -165,6 +196,7 @@ def make_clip_text():
 
 if __name__ == "__main__":
     make_bert()
+    make_xlmr()
     make_clip_vit()
     make_clip_text()
     for f in sorted(os.listdir(HERE)):

@@ -80,3 +80,17 @@ def test_unit_norm_and_preprocess_tail():
     assert abs(px[0, 0, 0, 0].item() - (r - O.OPENAI_DATASET_MEAN[0]) / O.OPENAI_DATASET_STD[0]) < 1e-6
     out = O.vit_forward(sd, cfg, px)
     assert torch.allclose(out.norm(dim=-1), torch.ones(3), atol=1e-6)
+
+
+def test_xlm_roberta_matches_transformers():
+    """multilingual-e5 family: transformers.XLMRobertaModel = the BERT encoder with position ids offset by 2"""
+    sd, z = G.load("xlmr_small")
+    V, P, W, L, H, F = [int(v) for v in z["cfg"]]
+    ids, mask = torch.from_numpy(z["ids"]), torch.from_numpy(z["mask"])
+    cfg = O.BertConfig(vocab=V, max_pos=P, width=W, layers=L, heads=H, mlp_dim=F, ln_eps=1e-5, pooling="mean", pos_offset=2)
+    last = O.bert_forward(sd, cfg, ids, mask)
+    assert np.abs(last.numpy() - z["last_hidden"])[mask.bool().numpy()].max() < TOL
+    assert np.abs(O.hf_encode(sd, cfg, ids, mask, normalize=False).numpy() - z["mean"]).max() < TOL
+    assert np.abs(O.hf_encode(sd, cfg, ids, mask, normalize=True).numpy() - z["mean_norm"]).max() < TOL
+    cfg.pos_offset = 0
+    assert np.abs(O.bert_forward(sd, cfg, ids, mask).numpy() - z["last_hidden"])[mask.bool().numpy()].max() > 1e-2  # the offset matters

@@ -207,3 +207,36 @@ def test_registry_models_synthetic_weights(s2):
     assert q.shape == (1, 512) and _cos_err(q, txt[:1]) > 1e-4
     assert len(s2i.get_available_models()) >= 3
     s2i.eject_model(name, DEV)
+
+
+def test_hf_xlm_roberta_from_disk(s2, tmp_path):
+    """an XLM-RoBERTa checkpoint directory (multilingual-e5 layout: config.json model_type xlm-roberta, `roberta.`-prefixed
+    safetensors, sentencepiece.bpe.model) through the `hf` loader: SentencePiece tokeniser on the host, BERT tower with the
+    position offset on the GPU, against the fp32 oracle on the same ids"""
+    s2i, root = s2
+    import sentencepiece as spm
+    from safetensors.torch import save_file
+    from tests.test_tokenizers import CORPUS, SENTENCES
+    d = root / "hf" / "acme" / "tiny-xlmr"
+    d.mkdir(parents=True, exist_ok=True)
+    corpus = tmp_path / "corpus.txt"
+    corpus.write_text("\n".join([" ".join(CORPUS)] * 20 + SENTENCES[:6] * 5), encoding="utf-8")
+    spm.SentencePieceTrainer.train(input=str(corpus), model_prefix=str(d / "sentencepiece.bpe"), vocab_size=120, model_type="unigram",
+                                   character_coverage=1.0, hard_vocab_limit=False, minloglevel=2)
+    from marqo_amd.engine.tokenizers import XlmRobertaTokenizer
+    tok = XlmRobertaTokenizer(str(d))
+    cfg = O.BertConfig(vocab=tok.vocab_size, max_pos=66, width=128, layers=2, heads=2, mlp_dim=256, ln_eps=1e-5, pos_offset=2)
+    sd = O.synthetic_bert_state_dict(cfg, seed=4)
+    sd["embeddings.token_type_embeddings.weight"] = sd["embeddings.token_type_embeddings.weight"][:1].clone()  # type_vocab_size 1
+    save_file({"roberta." + k: v.contiguous() for k, v in sd.items()}, str(d / "model.safetensors"))
+    (d / "config.json").write_text(json.dumps({"model_type": "xlm-roberta", "vocab_size": tok.vocab_size, "max_position_embeddings": 66,
+                                               "hidden_size": 128, "num_hidden_layers": 2, "num_attention_heads": 2, "intermediate_size": 256,
+                                               "hidden_act": "gelu", "layer_norm_eps": 1e-5, "pad_token_id": 1, "type_vocab_size": 1}))
+    props = {"name": "acme/tiny-xlmr", "dimensions": 128, "tokens": 32, "type": "hf"}
+    texts = ["query: how much protein should a female eat", "naïve café über straße", "東京 photos 2024", "fox"]
+    out = s2i.vectorise("tiny-xlmr", texts, model_properties=props, device=DEV)
+    t = tok(texts, max_length=32)
+    ref = O.hf_encode(sd, cfg, torch.from_numpy(t["input_ids"]), torch.from_numpy(t["attention_mask"])).numpy()
+    assert np.asarray(out).shape == (4, 128) and _cos_err(out, ref) < COS_TOL
+    model = s2i.get_available_models()[s2i._create_model_cache_key("tiny-xlmr", DEV, props)]["model"]
+    assert type(model._tokenizer).__name__ == "XlmRobertaTokenizer" and model._device_tokenizer is None and model.arch.pos_offset == 2

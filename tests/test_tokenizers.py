@@ -145,3 +145,24 @@ def test_synthetic_tokenizer_shapes():
     assert out.shape == (2, 77) and out[0, 0] == 49406 and out[0, 4] == 49407 and (out.argmax(1) == [4, 2]).all()
     b = SyntheticTokenizer("bert", 30522)(["a b c", "d"], max_length=512)
     assert b["input_ids"].shape == (2, 5) and b["attention_mask"].sum() == 8 and b["input_ids"][1, 3] == 0
+
+
+def test_xlm_roberta_sentencepiece_matches_transformers(tmp_path):
+    """multilingual-e5 family: our wrapper over the checkpoint's SentencePiece model == transformers.XLMRobertaTokenizer (a tiny
+    unigram model is trained here: no real vocabulary exists offline)"""
+    import sentencepiece as spm
+    from transformers import XLMRobertaTokenizer
+    from marqo_amd.engine.tokenizers import XlmRobertaTokenizer
+    corpus = tmp_path / "corpus.txt"
+    corpus.write_text("\n".join([" ".join(CORPUS)] * 20 + SENTENCES[:6] * 5), encoding="utf-8")
+    spm.SentencePieceTrainer.train(input=str(corpus), model_prefix=str(tmp_path / "sentencepiece.bpe"), vocab_size=120, model_type="unigram",
+                                   character_coverage=1.0, hard_vocab_limit=False, minloglevel=2)
+    ours = XlmRobertaTokenizer(str(tmp_path))
+    hf = XLMRobertaTokenizer.from_pretrained(str(tmp_path))  # (converts the SentencePiece model to its `tokenizers` backend)
+    texts = [s for s in SENTENCES if s] + ["query: naïve café 東京 2024!", "  leading and   double  spaces ", "UPPER lower"]
+    for t in texts:
+        assert ours.encode(t, max_length=64) == hf(t, truncation=True, max_length=64)["input_ids"], t
+    ref = hf(texts, padding=True, truncation=True, max_length=16, return_tensors="np")
+    got = ours(texts, max_length=16)
+    assert np.array_equal(got["input_ids"], ref["input_ids"]) and np.array_equal(got["attention_mask"], ref["attention_mask"])
+    assert (ours.cls_id, ours.pad_id, ours.sep_id, ours.unk_id) == (hf.cls_token_id, hf.pad_token_id, hf.sep_token_id, hf.unk_token_id)

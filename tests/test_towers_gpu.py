@@ -252,3 +252,17 @@ def test_full_size_batch_properties_config2_and_config3():
             assert torch.allclose(ft.norm(dim=-1), torch.ones(n_txt, device="cuda"), atol=1e-5)
             tcfg = O.ClipTextConfig(tarch.vocab, tarch.ctx, tarch.width, tarch.layers, tarch.heads, tarch.mlp_dim, tarch.out_dim)
             assert _cos_err(ft[:oracle_n], O.clip_text_forward(sd, tcfg, ids[:oracle_n])) < COS_TIGHT
+
+
+def test_golden_xlm_roberta_small():
+    """multilingual-e5 family (transformers.XLMRobertaModel): BERT encoder, position table used from row 2 on"""
+    T, A = _towers()
+    sd, z = G.load("xlmr_small")
+    V, P, W, L_, H, F = [int(v) for v in z["cfg"]]
+    ids, mask = torch.from_numpy(z["ids"]), torch.from_numpy(z["mask"])
+    arch = A.BertArch(vocab=V, max_pos=P - 2, width=W, layers=L_, heads=H, mlp_dim=F, ln_eps=1e-5, pos_offset=2)
+    tower = T.BertTower(arch, sd, "cuda", pooling="mean")
+    assert _cos_err(tower.encode_ids(ids, mask, normalize=False), torch.from_numpy(z["mean"])) < COS_TIGHT
+    assert _cos_err(tower.encode_ids(ids, mask, normalize=True), torch.from_numpy(z["mean_norm"])) < COS_TIGHT
+    wrong = T.BertTower(A.BertArch(vocab=V, max_pos=P, width=W, layers=L_, heads=H, mlp_dim=F, ln_eps=1e-5, pos_offset=0), sd, "cuda")
+    assert _cos_err(wrong.encode_ids(ids, mask, normalize=False), torch.from_numpy(z["mean"])) > 10 * COS_TIGHT  # the offset is honoured
