@@ -57,24 +57,31 @@ struct Off {
 int check_encoder_cfg(const mq_encoder_cfg* c) {
     MQ_CHECK_ARG(c, "encoder cfg is null");
     MQ_CHECK_ARG(c->width >= 64 && c->width % 64 == 0, "encoder width %d must be a multiple of 64", c->width);
-    MQ_CHECK_ARG(c->heads >= 1 && c->width == c->heads * 64, "encoder head dim must be 64 (width %d, heads %d)", c->width, c->heads);
+    const int wa = c->attn_width ? c->attn_width : c->width;
+    MQ_CHECK_ARG(c->heads >= 1 && wa == c->heads * 64, "encoder attention width must be heads * 64 (attention width %d, heads %d)", wa, c->heads);
     MQ_CHECK_ARG(c->mlp_dim >= 64 && c->mlp_dim % 64 == 0, "encoder mlp_dim %d must be a multiple of 64", c->mlp_dim);
     MQ_CHECK_ARG(c->layers >= 0, "encoder layers < 0");
     MQ_CHECK_ARG(c->act == MQ_ACT_GELU || c->act == MQ_ACT_QUICKGELU, "encoder act %d unsupported", c->act);
     MQ_CHECK_ARG(c->precision == MQ_PREC_BF16 || c->precision == MQ_PREC_FP8, "encoder precision %d unsupported", c->precision);
     if (c->precision == MQ_PREC_FP8) {
-        MQ_CHECK_ARG(c->width % 128 == 0 && c->mlp_dim % 128 == 0, "fp8 path needs width / mlp_dim multiples of 128");
+        MQ_CHECK_ARG(c->width % 128 == 0 && c->mlp_dim % 128 == 0 && wa % 128 == 0, "fp8 path needs width / mlp_dim multiples of 128");
         MQ_CHECK_ARG(c->d_fp8_act_scale, "fp8 path needs d_fp8_act_scale");
     }
     return MQ_OK;
 }
 
-// scratch of one encoder pass: h bf16 [rows,W] | a bf16 [rows,W] | big bf16 [rows, max(3W,F)]
+// attention width: heads * 64.  Equal to the model width for every CLIP tower and BERT-base/large; models with narrower heads
+// (e5-small, bge-small, MiniLM: 384 wide, 12 heads of 32) are loaded with their Q/K/V rows and out-projection columns zero-padded
+// to 64 per head (engine/towers.py), so QKV is [rows, 3*Wa], the attention output [rows, Wa] and the out-projection has K = Wa.
+int attn_width(const mq_encoder_cfg* c) { return c->attn_width ? c->attn_width : c->width; }
+
+// scratch of one encoder pass: h bf16 [rows,W] | a bf16 [rows,Wa] | big bf16 [rows, max(3Wa,F)]
 size_t encoder_ws(const mq_encoder_cfg* c, int64_t rows) {
     Off cv;
-    const size_t big = (size_t)(3 * c->width > c->mlp_dim ? 3 * c->width : c->mlp_dim);
+    const int wa = attn_width(c);
+    const size_t big = (size_t)(3 * wa > c->mlp_dim ? 3 * wa : c->mlp_dim);
     cv.take((size_t)rows * c->width * 2);
-    cv.take((size_t)rows * c->width * 2);
+    cv.take((size_t)rows * wa * 2);
     cv.take((size_t)rows * big * 2);
     cv.take((size_t)rows * 4);  // per-row activation scales of the fp8 path
     cv.take((size_t)rows * ((c->width + 63) / 64) * 8);  // LayerNorm-fold partials: (sum, sum of squares) per row and 64-column slot
@@ -104,7 +111,7 @@ int last_block_selected(const mq_encoder_cfg* cfg, const mq_block_weights& b, in
                         const int32_t* d_cu_seqlens, int64_t nseq, int32_t fixed_len, int32_t max_len,
                         const int32_t* d_sel, int64_t nsel, void* h, void* a, void* qf, float* row_scale, float* x_sel,
                         float* stats /* non-NULL: h holds bf16(x) and stats its LayerNorm partials (folded path) */, hipStream_t s) {
-    const int W = cfg->width, F = cfg->mlp_dim;
+    const int W = cfg->width, F = cfg->mlp_dim, Wa = attn_width(cfg);
     const int act_flag = cfg->act == MQ_ACT_QUICKGELU ? MQ_EPI_QUICKGELU : MQ_EPI_GELU;
     const int res_flags = MQ_EPI_BIAS | MQ_EPI_RESIDUAL | MQ_EPI_OUT_F32;
     if (cfg->precision == MQ_PREC_FP8) {
@@ -112,36 +119,36 @@ int last_block_selected(const mq_encoder_cfg* cfg, const mq_block_weights& b, in
         const float* s_mlp = s_attn + 1;
         const int act8 = act_flag | MQ_EPI_BIAS | MQ_EPI_OUT_FP8;
         MQ_TRY(mq_layernorm_fp8(d_x, b.ln1_g, b.ln1_b, h, row_scale, nullptr, rows, W, cfg->ln_eps, s));
-        MQ_TRY(mq_gemm_fp8(h, W, b.qkv_w8, W, row_scale, 1, b.qkv_ws, b.qkv_b, nullptr, qf, 3 * W, nullptr, nullptr, rows, 3 * W, W,
+        MQ_TRY(mq_gemm_fp8(h, W, b.qkv_w8, W, row_scale, 1, b.qkv_ws, b.qkv_b, nullptr, qf, 3 * Wa, nullptr, nullptr, rows, 3 * Wa, W,
                            MQ_EPI_BIAS, s));
-        MQ_TRY(mq_attention_ex(qf, a, d_cu_seqlens, nseq, fixed_len, max_len, W, cfg->heads, cfg->mask, 1, s_attn, nullptr, s));
-        MQ_TRY(mq_move_rows(a, d_sel, h, nsel, (int64_t)W, false, s));
+        MQ_TRY(mq_attention_ex(qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, cfg->heads, cfg->mask, 1, s_attn, nullptr, s));
+        MQ_TRY(mq_move_rows(a, d_sel, h, nsel, (int64_t)Wa, false, s));
         MQ_TRY(mq_move_rows(d_x, d_sel, x_sel, nsel, (int64_t)W * 4, false, s));
-        MQ_TRY(mq_gemm_fp8(h, W, b.out_w8, W, s_attn, 0, b.out_ws, b.out_b, x_sel, x_sel, W, nullptr, nullptr, nsel, W, W, res_flags, s));
+        MQ_TRY(mq_gemm_fp8(h, Wa, b.out_w8, Wa, s_attn, 0, b.out_ws, b.out_b, x_sel, x_sel, W, nullptr, nullptr, nsel, W, Wa, res_flags, s));
         MQ_TRY(mq_layernorm_fp8(x_sel, b.ln2_g, b.ln2_b, a, row_scale, nullptr, nsel, W, cfg->ln_eps, s));
         MQ_TRY(mq_gemm_fp8(a, W, b.fc1_w8, W, row_scale, 1, b.fc1_ws, b.fc1_b, nullptr, qf, F, s_mlp, nullptr, nsel, F, W, act8, s));
         MQ_TRY(mq_gemm_fp8(qf, F, b.fc2_w8, F, s_mlp, 0, b.fc2_ws, b.fc2_b, x_sel, x_sel, W, nullptr, nullptr, nsel, W, F, res_flags, s));
     } else if (!cfg->post_ln) {
         if (stats) {
-            MQ_TRY(mq_gemm_bf16_ln(h, W, b.qkv_wf, W, b.qkv_bf, nullptr, qf, 3 * W, rows, 3 * W, W, MQ_EPI_BIAS | MQ_EPI_LN_APPLY, stats, nullptr,
+            MQ_TRY(mq_gemm_bf16_ln(h, W, b.qkv_wf, W, b.qkv_bf, nullptr, qf, 3 * Wa, rows, 3 * Wa, W, MQ_EPI_BIAS | MQ_EPI_LN_APPLY, stats, nullptr,
                                    b.qkv_sf, cfg->ln_eps, s));
         } else {
             MQ_TRY(mq_layernorm(d_x, nullptr, b.ln1_g, b.ln1_b, h, nullptr, rows, W, cfg->ln_eps, s));
-            MQ_TRY(mq_gemm_bf16(h, W, b.qkv_w, W, b.qkv_b, nullptr, qf, 3 * W, rows, 3 * W, W, MQ_EPI_BIAS, s));
+            MQ_TRY(mq_gemm_bf16(h, W, b.qkv_w, W, b.qkv_b, nullptr, qf, 3 * Wa, rows, 3 * Wa, W, MQ_EPI_BIAS, s));
         }
-        MQ_TRY(mq_attention(qf, a, d_cu_seqlens, nseq, fixed_len, max_len, W, cfg->heads, cfg->mask, s));
-        MQ_TRY(mq_move_rows(a, d_sel, h, nsel, (int64_t)W * 2, false, s));
+        MQ_TRY(mq_attention(qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, cfg->heads, cfg->mask, s));
+        MQ_TRY(mq_move_rows(a, d_sel, h, nsel, (int64_t)Wa * 2, false, s));
         MQ_TRY(mq_move_rows(d_x, d_sel, x_sel, nsel, (int64_t)W * 4, false, s));
-        MQ_TRY(mq_gemm_bf16(h, W, b.out_w, W, b.out_b, x_sel, x_sel, W, nsel, W, W, res_flags, s));
+        MQ_TRY(mq_gemm_bf16(h, Wa, b.out_w, Wa, b.out_b, x_sel, x_sel, W, nsel, W, Wa, res_flags, s));
         MQ_TRY(mq_layernorm(x_sel, nullptr, b.ln2_g, b.ln2_b, a, nullptr, nsel, W, cfg->ln_eps, s));
         MQ_TRY(mq_gemm_bf16(a, W, b.fc1_w, W, b.fc1_b, nullptr, qf, F, nsel, F, W, MQ_EPI_BIAS | act_flag, s));
         MQ_TRY(mq_gemm_bf16(qf, F, b.fc2_w, F, b.fc2_b, x_sel, x_sel, W, nsel, W, F, res_flags, s));
     } else {
-        MQ_TRY(mq_gemm_bf16(h, W, b.qkv_w, W, b.qkv_b, nullptr, qf, 3 * W, rows, 3 * W, W, MQ_EPI_BIAS, s));
-        MQ_TRY(mq_attention(qf, a, d_cu_seqlens, nseq, fixed_len, max_len, W, cfg->heads, cfg->mask, s));
-        MQ_TRY(mq_move_rows(a, d_sel, h, nsel, (int64_t)W * 2, false, s));
+        MQ_TRY(mq_gemm_bf16(h, W, b.qkv_w, W, b.qkv_b, nullptr, qf, 3 * Wa, rows, 3 * Wa, W, MQ_EPI_BIAS, s));
+        MQ_TRY(mq_attention(qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, cfg->heads, cfg->mask, s));
+        MQ_TRY(mq_move_rows(a, d_sel, h, nsel, (int64_t)Wa * 2, false, s));
         MQ_TRY(mq_move_rows(d_x, d_sel, x_sel, nsel, (int64_t)W * 4, false, s));
-        MQ_TRY(mq_gemm_bf16(h, W, b.out_w, W, b.out_b, x_sel, x_sel, W, nsel, W, W, res_flags, s));
+        MQ_TRY(mq_gemm_bf16(h, Wa, b.out_w, Wa, b.out_b, x_sel, x_sel, W, nsel, W, Wa, res_flags, s));
         MQ_TRY(mq_layernorm(x_sel, nullptr, b.ln1_g, b.ln1_b, a, x_sel, nsel, W, cfg->ln_eps, s));
         MQ_TRY(mq_gemm_bf16(a, W, b.fc1_w, W, b.fc1_b, nullptr, qf, F, nsel, F, W, MQ_EPI_BIAS | act_flag, s));
         MQ_TRY(mq_gemm_bf16(qf, F, b.fc2_w, F, b.fc2_b, x_sel, x_sel, W, nsel, W, F, res_flags, s));
@@ -161,12 +168,12 @@ int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* bloc
         mq_set_error("mq_encoder_forward: workspace %zu < required %zu", workspace_bytes, encoder_ws(cfg, rows));
         return MQ_ERR_WORKSPACE;
     }
-    const int W = cfg->width, F = cfg->mlp_dim;
-    const size_t big = (size_t)(3 * W > F ? 3 * W : F);
+    const int W = cfg->width, F = cfg->mlp_dim, Wa = attn_width(cfg);
+    const size_t big = (size_t)(3 * Wa > F ? 3 * Wa : F);
     Off cv;
     char* wsb = (char*)d_workspace;
     void* h = wsb + cv.take((size_t)rows * W * 2);
-    void* a = wsb + cv.take((size_t)rows * W * 2);
+    void* a = wsb + cv.take((size_t)rows * Wa * 2);
     void* qf = wsb + cv.take((size_t)rows * big * 2);  // qkv [rows,3W] then fc1 output [rows,F]
     float* row_scale = (float*)(wsb + cv.take((size_t)rows * 4));
     float* ln_stats = (float*)(wsb + cv.take((size_t)rows * ((W + 63) / 64) * 8));
@@ -176,7 +183,7 @@ int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* bloc
     // LayerNorm folding (pre-LN bf16 encoders whose blocks all carry the folded tensors): the residual GEMMs emit bf16(x) + row
     // partials, the QKV / fc1 GEMMs apply mean / rstd in their epilogue -> no LayerNorm launch between them.  `h` then holds
     // bf16(x) instead of LN(x); `folded` says whether (h, ln_stats) describe the current x (false before the first block).
-    bool fold = mq_tower_ln_fold && cfg->precision == MQ_PREC_BF16 && !cfg->post_ln;
+    bool fold = mq_tower_ln_fold && cfg->precision == MQ_PREC_BF16 && !cfg->post_ln && Wa == W;
     for (int l = 0; fold && l < cfg->layers; ++l)
         fold = blocks[l].qkv_wf && blocks[l].qkv_sf && blocks[l].qkv_bf && blocks[l].fc1_wf && blocks[l].fc1_sf && blocks[l].fc1_bf;
     bool folded = false;
@@ -207,14 +214,14 @@ int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* bloc
             // x += out(attn(qkv(ln1(x)))) ; x += fc2(act(fc1(ln2(x)))) with both LayerNorms folded into the GEMMs around them
             const int stat_flags = res_flags | MQ_EPI_LN_STATS, apply = MQ_EPI_BIAS | MQ_EPI_LN_APPLY;
             if (folded) {
-                MQ_TRY(mq_gemm_bf16_ln(h, W, b.qkv_wf, W, b.qkv_bf, nullptr, qf, 3 * W, rows, 3 * W, W, apply, ln_stats, nullptr, b.qkv_sf,
+                MQ_TRY(mq_gemm_bf16_ln(h, W, b.qkv_wf, W, b.qkv_bf, nullptr, qf, 3 * Wa, rows, 3 * Wa, W, apply, ln_stats, nullptr, b.qkv_sf,
                                        cfg->ln_eps, s));
             } else {  // first block: x comes from the embedding kernels, not from a GEMM epilogue
                 MQ_TRY(mq_layernorm(d_x, nullptr, b.ln1_g, b.ln1_b, h, nullptr, rows, W, cfg->ln_eps, s));
-                MQ_TRY(mq_gemm_bf16(h, W, b.qkv_w, W, b.qkv_b, nullptr, qf, 3 * W, rows, 3 * W, W, MQ_EPI_BIAS, s));
+                MQ_TRY(mq_gemm_bf16(h, W, b.qkv_w, W, b.qkv_b, nullptr, qf, 3 * Wa, rows, 3 * Wa, W, MQ_EPI_BIAS, s));
             }
-            MQ_TRY(mq_attention(qf, a, d_cu_seqlens, nseq, fixed_len, max_len, W, cfg->heads, cfg->mask, s));
-            MQ_TRY(mq_gemm_bf16_ln(a, W, b.out_w, W, b.out_b, d_x, d_x, W, rows, W, W, stat_flags, ln_stats, h, nullptr, cfg->ln_eps, s));
+            MQ_TRY(mq_attention(qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, cfg->heads, cfg->mask, s));
+            MQ_TRY(mq_gemm_bf16_ln(a, Wa, b.out_w, Wa, b.out_b, d_x, d_x, W, rows, W, Wa, stat_flags, ln_stats, h, nullptr, cfg->ln_eps, s));
             MQ_TRY(mq_gemm_bf16_ln(h, W, b.fc1_wf, W, b.fc1_bf, nullptr, qf, F, rows, F, W, apply | act_flag, ln_stats, nullptr, b.fc1_sf,
                                    cfg->ln_eps, s));
             MQ_TRY(mq_gemm_bf16_ln(qf, F, b.fc2_w, F, b.fc2_b, d_x, d_x, W, rows, W, F, stat_flags, ln_stats, h, nullptr, cfg->ln_eps, s));
@@ -232,10 +239,10 @@ int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* bloc
             if (cfg->post_ln) {
                 // x = ln1(x + out(attn(qkv(x)))) ; x = ln2(x + fc2(act(fc1(x)))): each LayerNorm rewrites x (fp32, in place:
                 // a wave holds its whole row before it stores) and leaves the e4m3 row + scale for the next GEMM
-                MQ_TRY(mq_gemm_fp8(h, W, b.qkv_w8, W, row_scale, 1, b.qkv_ws, b.qkv_b, nullptr, qf, 3 * W, nullptr, nullptr, rows, 3 * W, W,
+                MQ_TRY(mq_gemm_fp8(h, W, b.qkv_w8, W, row_scale, 1, b.qkv_ws, b.qkv_b, nullptr, qf, 3 * Wa, nullptr, nullptr, rows, 3 * Wa, W,
                                    MQ_EPI_BIAS, s));
-                MQ_TRY(mq_attention_ex(qf, a, d_cu_seqlens, nseq, fixed_len, max_len, W, cfg->heads, cfg->mask, 1, s_attn, m_attn, s));
-                MQ_TRY(mq_gemm_fp8(a, W, b.out_w8, W, s_attn, 0, b.out_ws, b.out_b, d_x, d_x, W, nullptr, nullptr, rows, W, W, res_flags, s));
+                MQ_TRY(mq_attention_ex(qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, cfg->heads, cfg->mask, 1, s_attn, m_attn, s));
+                MQ_TRY(mq_gemm_fp8(a, Wa, b.out_w8, Wa, s_attn, 0, b.out_ws, b.out_b, d_x, d_x, W, nullptr, nullptr, rows, W, Wa, res_flags, s));
                 MQ_TRY(mq_layernorm_fp8(d_x, b.ln1_g, b.ln1_b, h, row_scale, d_x, rows, W, cfg->ln_eps, s));
                 MQ_TRY(mq_gemm_fp8(h, W, b.fc1_w8, W, row_scale, 1, b.fc1_ws, b.fc1_b, nullptr, qf, F, s_mlp, m_mlp, rows, F, W, act8, s));
                 MQ_TRY(mq_gemm_fp8(qf, F, b.fc2_w8, F, s_mlp, 0, b.fc2_ws, b.fc2_b, d_x, d_x, W, nullptr, nullptr, rows, W, F, res_flags, s));
@@ -243,27 +250,27 @@ int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* bloc
                 continue;
             }
             MQ_TRY(mq_layernorm_fp8(d_x, b.ln1_g, b.ln1_b, h, row_scale, nullptr, rows, W, cfg->ln_eps, s));
-            MQ_TRY(mq_gemm_fp8(h, W, b.qkv_w8, W, row_scale, 1, b.qkv_ws, b.qkv_b, nullptr, qf, 3 * W, nullptr, nullptr, rows, 3 * W, W,
+            MQ_TRY(mq_gemm_fp8(h, W, b.qkv_w8, W, row_scale, 1, b.qkv_ws, b.qkv_b, nullptr, qf, 3 * Wa, nullptr, nullptr, rows, 3 * Wa, W,
                                MQ_EPI_BIAS, s));
-            MQ_TRY(mq_attention_ex(qf, a, d_cu_seqlens, nseq, fixed_len, max_len, W, cfg->heads, cfg->mask, 1, s_attn, m_attn, s));
-            MQ_TRY(mq_gemm_fp8(a, W, b.out_w8, W, s_attn, 0, b.out_ws, b.out_b, d_x, d_x, W, nullptr, nullptr, rows, W, W, res_flags, s));
+            MQ_TRY(mq_attention_ex(qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, cfg->heads, cfg->mask, 1, s_attn, m_attn, s));
+            MQ_TRY(mq_gemm_fp8(a, Wa, b.out_w8, Wa, s_attn, 0, b.out_ws, b.out_b, d_x, d_x, W, nullptr, nullptr, rows, W, Wa, res_flags, s));
             MQ_TRY(mq_layernorm_fp8(d_x, b.ln2_g, b.ln2_b, h, row_scale, nullptr, rows, W, cfg->ln_eps, s));
             MQ_TRY(mq_gemm_fp8(h, W, b.fc1_w8, W, row_scale, 1, b.fc1_ws, b.fc1_b, nullptr, qf, F, s_mlp, m_mlp, rows, F, W, act8, s));
             MQ_TRY(mq_gemm_fp8(qf, F, b.fc2_w8, F, s_mlp, 0, b.fc2_ws, b.fc2_b, d_x, d_x, W, nullptr, nullptr, rows, W, F, res_flags, s));
         } else if (!cfg->post_ln) {
             // x += out(attn(qkv(ln1(x)))) ; x += fc2(act(fc1(ln2(x))))
             MQ_TRY(mq_layernorm(d_x, nullptr, b.ln1_g, b.ln1_b, h, nullptr, rows, W, cfg->ln_eps, s));
-            MQ_TRY(mq_gemm_bf16(h, W, b.qkv_w, W, b.qkv_b, nullptr, qf, 3 * W, rows, 3 * W, W, MQ_EPI_BIAS, s));
-            MQ_TRY(mq_attention(qf, a, d_cu_seqlens, nseq, fixed_len, max_len, W, cfg->heads, cfg->mask, s));
-            MQ_TRY(mq_gemm_bf16(a, W, b.out_w, W, b.out_b, d_x, d_x, W, rows, W, W, res_flags, s));
+            MQ_TRY(mq_gemm_bf16(h, W, b.qkv_w, W, b.qkv_b, nullptr, qf, 3 * Wa, rows, 3 * Wa, W, MQ_EPI_BIAS, s));
+            MQ_TRY(mq_attention(qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, cfg->heads, cfg->mask, s));
+            MQ_TRY(mq_gemm_bf16(a, Wa, b.out_w, Wa, b.out_b, d_x, d_x, W, rows, W, Wa, res_flags, s));
             MQ_TRY(mq_layernorm(d_x, nullptr, b.ln2_g, b.ln2_b, h, nullptr, rows, W, cfg->ln_eps, s));
             MQ_TRY(mq_gemm_bf16(h, W, b.fc1_w, W, b.fc1_b, nullptr, qf, F, rows, F, W, MQ_EPI_BIAS | act_flag, s));
             MQ_TRY(mq_gemm_bf16(qf, F, b.fc2_w, F, b.fc2_b, d_x, d_x, W, rows, W, F, res_flags, s));
         } else {
             // x = ln1(x + out(attn(qkv(x)))) ; x = ln2(x + fc2(act(fc1(x))))
-            MQ_TRY(mq_gemm_bf16(h, W, b.qkv_w, W, b.qkv_b, nullptr, qf, 3 * W, rows, 3 * W, W, MQ_EPI_BIAS, s));
-            MQ_TRY(mq_attention(qf, a, d_cu_seqlens, nseq, fixed_len, max_len, W, cfg->heads, cfg->mask, s));
-            MQ_TRY(mq_gemm_bf16(a, W, b.out_w, W, b.out_b, d_x, d_x, W, rows, W, W, res_flags, s));
+            MQ_TRY(mq_gemm_bf16(h, W, b.qkv_w, W, b.qkv_b, nullptr, qf, 3 * Wa, rows, 3 * Wa, W, MQ_EPI_BIAS, s));
+            MQ_TRY(mq_attention(qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, cfg->heads, cfg->mask, s));
+            MQ_TRY(mq_gemm_bf16(a, Wa, b.out_w, Wa, b.out_b, d_x, d_x, W, rows, W, Wa, res_flags, s));
             MQ_TRY(mq_layernorm(d_x, nullptr, b.ln1_g, b.ln1_b, h, d_x, rows, W, cfg->ln_eps, s));
             MQ_TRY(mq_gemm_bf16(h, W, b.fc1_w, W, b.fc1_b, nullptr, qf, F, rows, F, W, MQ_EPI_BIAS | act_flag, s));
             MQ_TRY(mq_gemm_bf16(qf, F, b.fc2_w, F, b.fc2_b, d_x, d_x, W, rows, W, F, res_flags, s));

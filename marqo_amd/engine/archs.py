@@ -112,9 +112,9 @@ def resolve_open_clip(arch_name: str, pretrained: Optional[str] = None) -> Tuple
 
 # HF repo id -> BERT arch for the BERT-family registry entries (model_registry.py:616-880)
 _BERT_BASE = BertArch()
-_BERT_SMALL = BertArch(width=384, layers=12, heads=6, mlp_dim=1536)
+_BERT_SMALL = BertArch(width=384, layers=12, heads=12, mlp_dim=1536)  # 12 heads of 32 (zero-padded to 64 at load)
 _BERT_LARGE = BertArch(width=1024, layers=24, heads=16, mlp_dim=4096)
-_MINILM_L6 = BertArch(width=384, layers=6, heads=6, mlp_dim=1536)  # head dim 64
+_MINILM_L6 = BertArch(width=384, layers=6, heads=12, mlp_dim=1536)   # 12 heads of 32
 HF_BERT_ARCHS = {
     "intfloat/e5-base-v2": _BERT_BASE, "intfloat/e5-base": _BERT_BASE,
     "intfloat/e5-small-v2": _BERT_SMALL, "intfloat/e5-small": _BERT_SMALL,
@@ -123,7 +123,9 @@ HF_BERT_ARCHS = {
     "BAAI/bge-small-en": _BERT_SMALL, "BAAI/bge-small-en-v1.5": _BERT_SMALL,
     "BAAI/bge-large-en": _BERT_LARGE, "BAAI/bge-large-en-v1.5": _BERT_LARGE,
     "sentence-transformers/all-MiniLM-L6-v1": _MINILM_L6, "sentence-transformers/all-MiniLM-L6-v2": _MINILM_L6,
-    # XLM-RoBERTa encoders (multilingual-e5-small has 32-wide heads and is not runnable: the attention kernel needs 64)
+    "sentence-transformers/all-MiniLM-L12-v2": _BERT_SMALL,
+    # XLM-RoBERTa encoders
+    "intfloat/multilingual-e5-small": BertArch(vocab=250037, max_pos=512, width=384, layers=12, heads=12, mlp_dim=1536, ln_eps=1e-5, pos_offset=2),
     "intfloat/multilingual-e5-base": BertArch(vocab=250002, max_pos=512, ln_eps=1e-5, pos_offset=2),
     "intfloat/multilingual-e5-large": BertArch(vocab=250002, max_pos=512, width=1024, layers=24, heads=16, mlp_dim=4096, ln_eps=1e-5, pos_offset=2),
 }

@@ -69,26 +69,53 @@ def _need(sd: Dict[str, Tensor], key: str, shape: Optional[Tuple[int, ...]] = No
     return t
 
 
+def _head_dim(width: int, heads: int) -> int:
+    """the attention kernel runs 64-wide heads; narrower heads (32, 16) are zero-padded to 64 at load (_pad_heads)"""
+    if heads < 1 or width % heads:
+        raise ValueError(f"width {width} is not divisible by heads {heads}")
+    d = width // heads
+    if d > 64 or 64 % d:
+        raise ValueError(f"attention head dim must be 64 (or 32 / 16, zero-padded to 64) for the gfx950 attention kernel "
+                         f"(width={width}, heads={heads}: {d})")
+    return d
+
+
+def _pad_heads(qkv_w: Tensor, qkv_b: Tensor, out_w: Tensor, heads: int, d: int) -> Tuple[Tensor, Tensor, Tensor]:
+    """[3W, W] / [3W] / [W, W] with d-wide heads -> [3*heads*64, W] / [3*heads*64] / [W, heads*64]: each head's Q / K / V rows and
+    out-projection columns are zero-padded to 64 (zero key / query dims add nothing to q.k, zero value dims meet zero out-proj
+    columns), and Q is scaled by sqrt(64 / d) so that the kernel's 1/sqrt(64) softmax scale equals the model's 1/sqrt(d)."""
+    W = out_w.shape[0]
+    q, k, v = qkv_w.float().view(3, heads, d, W).unbind(0)
+    qb, kb, vb = qkv_b.float().view(3, heads, d).unbind(0)
+    sc = (64.0 / d) ** 0.5
+    pad_w = lambda t: torch.nn.functional.pad(t, (0, 0, 0, 64 - d)).reshape(heads * 64, W)
+    pad_b = lambda t: torch.nn.functional.pad(t, (0, 64 - d)).reshape(heads * 64)
+    qkv_w2 = torch.cat([pad_w(q * sc), pad_w(k), pad_w(v)], 0)
+    qkv_b2 = torch.cat([pad_b(qb * sc), pad_b(kb), pad_b(vb)], 0)
+    out_w2 = torch.nn.functional.pad(out_w.float().view(W, heads, d), (0, 64 - d)).reshape(W, heads * 64)
+    return qkv_w2, qkv_b2, out_w2
+
+
 def _encoder_cfg(width, layers, heads, mlp_dim, quick_gelu, post_ln, mask, eps) -> L.EncoderCfg:
-    if width != heads * 64:
-        raise ValueError(f"attention head dim must be 64 for the gfx950 attention kernel (width={width}, heads={heads})")
+    d = _head_dim(width, heads)
     return L.EncoderCfg(width=width, layers=layers, heads=heads, mlp_dim=mlp_dim,
                         act=L.MQ_ACT_QUICKGELU if quick_gelu else L.MQ_ACT_GELU,
-                        post_ln=1 if post_ln else 0, mask=mask, ln_eps=eps, precision=L.MQ_PREC_BF16, reserved=0,
-                        d_fp8_act_scale=None, d_fp8_act_amax=None)
+                        post_ln=1 if post_ln else 0, mask=mask, ln_eps=eps, precision=L.MQ_PREC_BF16,
+                        attn_width=0 if d == 64 else heads * 64, d_fp8_act_scale=None, d_fp8_act_amax=None)
 
 
 class _Fp8State:
     """fp8 (e4m3) side of an encoder: per-channel-quantised copies of the four block GEMM weights and the static
     per-tensor activation scales [layers, 2] = (attention output, MLP hidden) with their calibration accumulator."""
 
-    def __init__(self, lib, holder: "_Holder", blocks, layers: int, W: int, F: int, device: torch.device):
+    def __init__(self, lib, holder: "_Holder", blocks, layers: int, W: int, F: int, device: torch.device, Wa: Optional[int] = None):
+        Wa = Wa or W  # attention width (heads * 64)
         self.scale = torch.full((layers, 2), 16.0 / 448.0, dtype=torch.float32, device=device)  # pre-calibration guess
         self.amax = torch.zeros(layers, 2, dtype=torch.float32, device=device)
         stream = torch.cuda.current_stream(device).cuda_stream
         for i in range(layers):
             b = blocks[i]
-            for name, (n, k) in (("qkv", (3 * W, W)), ("out", (W, W)), ("fc1", (F, W)), ("fc2", (W, F))):
+            for name, (n, k) in (("qkv", (3 * Wa, W)), ("out", (W, Wa)), ("fc1", (F, W)), ("fc2", (W, F))):
                 w8 = torch.empty(n, k, dtype=torch.uint8, device=device)
                 ws = torch.empty(n, dtype=torch.float32, device=device)
                 L.check(lib.mq_quantize_weights_fp8(getattr(b, name + "_w"), k, w8.data_ptr(), k, ws.data_ptr(), n, k, stream),
@@ -153,7 +180,7 @@ class _TowerBase:
         if W % 128 or F % 128:
             raise ValueError(f"the fp8 path needs width / mlp_dim multiples of 128 (got {W}, {F})")
         with torch.cuda.device(self.device):
-            self._fp8 = _Fp8State(self.lib, self._h, blocks, layers, W, F, self.device)
+            self._fp8 = _Fp8State(self.lib, self._h, blocks, layers, W, F, self.device, Wa=self.cfg.enc.attn_width or W)
             self._fp8.attach(self.cfg.enc, calibrating=False)
 
     def calibrate_fp8(self, run, passes: int = 2, margin: float = 1.0) -> None:
@@ -422,6 +449,7 @@ class BertTower(_TextTowerBase):
             if "embeddings.word_embeddings.weight" not in sd and prefix + "embeddings.word_embeddings.weight" in sd:
                 sd = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
         W, F = arch.width, arch.mlp_dim
+        hd = _head_dim(W, arch.heads)
         h = self._h
         arr = (L.BlockWeights * arch.layers)()
         for i in range(arch.layers):
@@ -429,8 +457,11 @@ class BertTower(_TextTowerBase):
             b = arr[i]
             qkv_w = torch.cat([_need(sd, p + f"attention.self.{n}.weight", (W, W)).detach().float() for n in ("query", "key", "value")], 0)
             qkv_b = torch.cat([_need(sd, p + f"attention.self.{n}.bias", (W,)).detach().float() for n in ("query", "key", "value")], 0)
+            out_w = _need(sd, p + "attention.output.dense.weight", (W, W)).detach().float()
+            if hd != 64:  # e5-small / bge-small / MiniLM: 12 heads of 32
+                qkv_w, qkv_b, out_w = _pad_heads(qkv_w, qkv_b, out_w, arch.heads, hd)
             b.qkv_w, b.qkv_b = h.bf16(qkv_w), h.f32(qkv_b)
-            b.out_w = h.bf16(_need(sd, p + "attention.output.dense.weight", (W, W)))
+            b.out_w = h.bf16(out_w)
             b.out_b = h.f32(_need(sd, p + "attention.output.dense.bias", (W,)))
             b.ln1_g = h.f32(_need(sd, p + "attention.output.LayerNorm.weight", (W,)))
             b.ln1_b = h.f32(_need(sd, p + "attention.output.LayerNorm.bias", (W,)))

@@ -43,10 +43,10 @@ def _jitter(model, seed):
                 p.mul_(3.0)  # HF init std 0.02 would make every block a near no-op
 
 
-def make_bert():
+def make_bert(heads=2, name="bert_small.npz"):
     from transformers import BertConfig, BertModel
     torch.manual_seed(0)
-    cfg = BertConfig(vocab_size=300, hidden_size=128, num_hidden_layers=2, num_attention_heads=2,
+    cfg = BertConfig(vocab_size=300, hidden_size=128, num_hidden_layers=2, num_attention_heads=heads,
                      intermediate_size=256, max_position_embeddings=64, layer_norm_eps=1e-12,
                      hidden_act="gelu", hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
     m = BertModel(cfg).eval()
@@ -69,10 +69,10 @@ def make_bert():
     cls = last[:, 0]
     cls_n = torch.nn.functional.normalize(cls, p=2, dim=1)
     sd = {k: v for k, v in m.state_dict().items() if not k.startswith("pooler.")}
-    np.savez_compressed(os.path.join(HERE, "bert_small.npz"),
+    np.savez_compressed(os.path.join(HERE, name),
                         ids=ids.numpy(), mask=mask.numpy(), last_hidden=last.numpy(),
                         mean=mean.numpy(), mean_norm=mean_n.numpy(), cls=cls.numpy(), cls_norm=cls_n.numpy(),
-                        cfg=np.array([300, 64, 128, 2, 2, 256], dtype=np.int64),  # vocab max_pos W layers heads F
+                        cfg=np.array([300, 64, 128, 2, heads, 256], dtype=np.int64),  # vocab max_pos W layers heads F
                         **{"w:" + k: v for k, v in _np(sd).items()})
 
 
@@ -196,6 +196,7 @@ def make_clip_text():
 
 if __name__ == "__main__":
     make_bert()
+    make_bert(heads=4, name="bert_small_h32.npz")  # 32-wide heads (e5-small / bge-small / MiniLM class)
     make_xlmr()
     make_clip_vit()
     make_clip_text()

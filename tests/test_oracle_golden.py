@@ -94,3 +94,14 @@ def test_xlm_roberta_matches_transformers():
     assert np.abs(O.hf_encode(sd, cfg, ids, mask, normalize=True).numpy() - z["mean_norm"]).max() < TOL
     cfg.pos_offset = 0
     assert np.abs(O.bert_forward(sd, cfg, ids, mask).numpy() - z["last_hidden"])[mask.bool().numpy()].max() > 1e-2  # the offset matters
+
+
+def test_bert_with_32_wide_heads_matches_transformers():
+    """e5-small / bge-small / MiniLM class: 32-wide attention heads"""
+    sd, z = G.load("bert_small_h32")
+    V, P, W, L, H, F = [int(v) for v in z["cfg"]]
+    assert W // H == 32
+    ids, mask = torch.from_numpy(z["ids"]), torch.from_numpy(z["mask"])
+    cfg = O.BertConfig(vocab=V, max_pos=P, width=W, layers=L, heads=H, mlp_dim=F, pooling="mean")
+    assert np.abs(O.bert_forward(sd, cfg, ids, mask).numpy() - z["last_hidden"])[mask.bool().numpy()].max() < TOL
+    assert np.abs(O.hf_encode(sd, cfg, ids, mask, normalize=True).numpy() - z["mean_norm"]).max() < TOL

@@ -266,3 +266,22 @@ def test_golden_xlm_roberta_small():
     assert _cos_err(tower.encode_ids(ids, mask, normalize=True), torch.from_numpy(z["mean_norm"])) < COS_TIGHT
     wrong = T.BertTower(A.BertArch(vocab=V, max_pos=P, width=W, layers=L_, heads=H, mlp_dim=F, ln_eps=1e-5, pos_offset=0), sd, "cuda")
     assert _cos_err(wrong.encode_ids(ids, mask, normalize=False), torch.from_numpy(z["mean"])) > 10 * COS_TIGHT  # the offset is honoured
+
+
+def test_golden_bert_32_wide_heads():
+    """12-heads-of-32 checkpoints (e5-small, bge-small, MiniLM) run on the 64-wide attention kernel through zero-padded heads
+    (engine/towers.py::_pad_heads); bf16 and fp8, mean and CLS pooling, against the transformers golden"""
+    T, A = _towers()
+    sd, z = G.load("bert_small_h32")
+    V, P, W, L_, H, F = [int(v) for v in z["cfg"]]
+    ids, mask = torch.from_numpy(z["ids"]), torch.from_numpy(z["mask"])
+    arch = A.BertArch(vocab=V, max_pos=P, width=W, layers=L_, heads=H, mlp_dim=F)
+    for pooling, key in (("mean", "mean"), ("cls", "cls")):
+        tower = T.BertTower(arch, sd, "cuda", pooling=pooling)
+        assert tower.cfg.enc.attn_width == H * 64 and tower.cfg.enc.width == W
+        assert _cos_err(tower.encode_ids(ids, mask, normalize=False), torch.from_numpy(z[key])) < COS_TIGHT, pooling
+    t8 = T.BertTower(arch, sd, "cuda", pooling="mean", precision="fp8")
+    t8.calibrate_fp8(lambda: t8.encode_ids(ids, mask))
+    assert _cos_err(t8.encode_ids(ids, mask, normalize=False), torch.from_numpy(z["mean"])) < 1e-2
+    with pytest.raises(ValueError):
+        T.BertTower(A.BertArch(vocab=V, max_pos=P, width=W, layers=L_, heads=3, mlp_dim=F), sd, "cuda")  # 128 / 3 heads
