@@ -260,7 +260,12 @@ def main():
         "config": {"workload": wl["desc"], "global_batch": batch * world,
                    "gflop_per_embedding": round(gflop_per_emb, 3),
                    "parallelism": f"dp{world} (replicated weights, sharded items, RCCL all_gather of embeddings)",
-                   "weights": "random-init (seed 0) " + wl["arch"]},
+                   "weights": "random-init (seed 0) " + wl["arch"],
+                   # transparency: the towers run the out-projection / MLP of the LAST block only on the pooled rows (class token /
+                   # EOT): dead-row elimination with bit-identical embeddings (tests/test_towers_gpu.py::test_row_selected_*), 5.8 % of
+                   # ViT-B/32's GEMM FLOPs.  e2e_tflops counts the full algorithmic FLOPs per embedding;
+                   # roofline.achieved counts only the FLOPs of the GEMMs actually launched.  MQ_ROW_SELECT=0 runs every row.
+                   "last_block_rows": "pooled" if os.environ.get("MQ_ROW_SELECT", "1") != "0" and kind != "bert" else "all"},
         "e2e_tflops": round(e2e_tflops, 1), "e2e_frac_of_peak": round(e2e_tflops / (peak * world), 4),
         "roofline": roofline,
     }
