@@ -1,4 +1,5 @@
-// Multi-head attention for short sequences (T = 50 / 77 / 257 / <= 512), d_head = 64 (K4).
+// Multi-head attention for short sequences (T = 50 / 77 / 257 / <= 512), d_head = 64 (K4) — or 128 (HD template parameter: the
+// 80 / 88 / 104-wide heads of ViT-H / g / bigG are zero-padded to 128 at load; rows are then 256 B, 16 chunks swizzled by key & 15).
 //
 // One workgroup (4 wave64s) per (sequence, head).  The whole K [len,64] and V [len,64] of that
 // (sequence, head) are staged ONCE in LDS by LDS-DMA (global_load_lds: every 1-KiB piece is in flight at once, no
@@ -24,14 +25,19 @@ namespace {
 
 // OUT_FP8: the output is written as e4m3 codes = value / *out_scale (static per-tensor scale of the fp8 path, K13) and
 // max|value| is folded into *amax when it is non-null (calibration).
-template <int MASK, bool OUT_FP8>
+template <int MASK, bool OUT_FP8, int HD>
 __global__ __launch_bounds__(256) void attention_kernel(
     const bf16_t* __restrict__ qkv, void* __restrict__ out_v, const int32_t* __restrict__ cu,
     int fixed_len, int W, int heads, int kpad, float scale_log2e, const float* __restrict__ out_scale, float* amax_out) {
     bf16_t* out = (bf16_t*)out_v;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sK = smem;                      // [kpad][128 B], 16-B chunks XOR-swizzled by (key & 7)
-    char* sV = smem + (size_t)kpad * 128; // [kpad][128 B], same image
+    constexpr int RB = HD * 2;       // bytes per K / V row (128 or 256)
+    constexpr int NC = HD / 8;       // 16-byte chunks per row (8 or 16)
+    constexpr int NKK = HD / 32;     // 32-deep MFMA k-chunks of a Q.K dot product (2 or 4)
+    constexpr int NDT = HD / 16;     // 16-wide output-dim tiles (4 or 8)
+    constexpr int RPP = 1024 / RB;   // rows per 1-KiB LDS-DMA piece (8 or 4)
+    char* sK = smem;                      // [kpad][RB], 16-B chunks XOR-swizzled by (key & (NC-1))
+    char* sV = smem + (size_t)kpad * RB;  // [kpad][RB], same image
 
     const int seq = blockIdx.x / heads, h = blockIdx.x - seq * heads;
     int row0, len;
@@ -39,25 +45,25 @@ __global__ __launch_bounds__(256) void attention_kernel(
     else { row0 = cu[seq]; len = cu[seq + 1] - row0; }
     if (len <= 0) return;
     const int ld = 3 * W;
-    const bf16_t* qb = qkv + (int64_t)row0 * ld + h * 64;
+    const bf16_t* qb = qkv + (int64_t)row0 * ld + h * HD;
     const bf16_t* kb = qb + W;
     const bf16_t* vb = qb + 2 * W;
     const int nkt = (len + 63) >> 6;
     const int kp = nkt << 6;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
-    // ---- stage K and V: 8 rows x 128 B per LDS-DMA; lane -> (row = 8*piece + lane/8, physical chunk = lane%8) fetches the
-    // logical chunk that lives there.  Rows past the sequence re-read its last row (finite values; their scores are
+    // ---- stage K and V: RPP rows x RB bytes per LDS-DMA; lane -> (row = RPP*piece + lane/NC, physical chunk = lane%NC) fetches
+    // the logical chunk that lives there.  Rows past the sequence re-read its last row (finite values; their scores are
     // masked and their probabilities are exactly 0).
     {
-        const int np8 = kp >> 3;
-        const int srow = lane >> 3, pchunk = lane & 7;
+        const int np8 = kp / RPP;
+        const int srow = lane / NC, pchunk = lane % NC;
         for (int p = wave; p < 2 * np8; p += 4) {
             const bool is_v = p >= np8;
             const int piece = is_v ? p - np8 : p;
-            const int row = piece * 8 + srow;
+            const int row = piece * RPP + srow;
             const int key = row < len ? row : len - 1;
-            const bf16_t* src = (is_v ? vb : kb) + (int64_t)key * ld + ((pchunk ^ (row & 7)) << 3);
+            const bf16_t* src = (is_v ? vb : kb) + (int64_t)key * ld + ((pchunk ^ (row & (NC - 1))) << 3);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)((is_v ? sV : sK) + piece * 1024), 16, 0, 0);
         }
@@ -66,12 +72,12 @@ __global__ __launch_bounds__(256) void attention_kernel(
     const int nqb = (len + 15) >> 4;
     float amax_local = 0.f;
     // first Q fragments are fetched while the K/V DMA is in flight
-    bf16x8 qn[2];
+    bf16x8 qn[NKK];
     {
         const int q0 = wave * 16 + l15;
         const int qr = q0 < len ? q0 : len - 1;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) qn[kk] = *(const bf16x8*)(qb + (int64_t)qr * ld + 8 * g + 32 * kk);
+        for (int kk = 0; kk < NKK; ++kk) qn[kk] = *(const bf16x8*)(qb + (int64_t)qr * ld + 8 * g + 32 * kk);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -82,18 +88,20 @@ __global__ __launch_bounds__(256) void attention_kernel(
 
     for (int qblk = wave; qblk < nqb; qblk += 4) {
         const int q = qblk * 16 + l15;           // this lane's query (B-operand column / output row)
-        bf16x8 qf[2] = {qn[0], qn[1]};
+        bf16x8 qf[NKK];
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) qf[kk] = qn[kk];
         if (qblk + 4 < nqb) {                    // next block's Q streams in behind this block's math
             const int q2 = q + 64;
             const int qr = q2 < len ? q2 : len - 1;
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) qn[kk] = *(const bf16x8*)(qb + (int64_t)qr * ld + 8 * g + 32 * kk);
+            for (int kk = 0; kk < NKK; ++kk) qn[kk] = *(const bf16x8*)(qb + (int64_t)qr * ld + 8 * g + 32 * kk);
         }
 
         float m_run = -1e30f, l_run = 0.f;
-        f32x4 o[4];
+        f32x4 o[NDT];
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int dt = 0; dt < NDT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
         int kt_end = nkt;
         if (MASK == MQ_MASK_CAUSAL) {
@@ -108,8 +116,8 @@ __global__ __launch_bounds__(256) void attention_kernel(
                 sc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
                 const int key = kt * 64 + t * 16 + l15;  // A-operand row
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    const bf16x8 kf = *(const bf16x8*)(sK + key * 128 + (((g + 4 * kk) ^ (key & 7)) << 4));
+                for (int kk = 0; kk < NKK; ++kk) {
+                    const bf16x8 kf = *(const bf16x8*)(sK + key * RB + (((g + 4 * kk) ^ (key & (NC - 1))) << 4));
                     sc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], sc[t], 0, 0, 0);
                 }
             }
@@ -147,7 +155,7 @@ __global__ __launch_bounds__(256) void attention_kernel(
                 const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
                 l_run *= alpha;
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt) o[dt] *= alpha;
+                for (int dt = 0; dt < NDT; ++dt) o[dt] *= alpha;
             }
             l_run += psum;
             m_run = m_new;
@@ -161,7 +169,7 @@ __global__ __launch_bounds__(256) void attention_kernel(
                 pf.w[2] = pack_bf16x2(sc[2 * u + 1][0], sc[2 * u + 1][1]);
                 pf.w[3] = pack_bf16x2(sc[2 * u + 1][2], sc[2 * u + 1][3]);
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
+                for (int dt = 0; dt < NDT; ++dt) {
                     // lane (d = dt*16 + l15, g) needs V[keys 16*(2u) + 4g .. +3][d] and V[keys 16*(2u+1) + 4g .. +3][d]:
                     // ds_read_b64_tr_b16 hands output lane 4r+c of a 16-lane block element c of the 8 bytes fetched by
                     // lanes r, r+4, r+8, r+12 of that block, so source lane (g, l15) fetches V[key0 + 4g + l15/4][4*(l15%4) .. +3]
@@ -169,7 +177,7 @@ __global__ __launch_bounds__(256) void attention_kernel(
 #pragma unroll
                     for (int tt = 0; tt < 2; ++tt) {
                         const int key = kt * 64 + (2 * u + tt) * 16 + vkey;
-                        const char* vp = sV + key * 128 + ((((dt << 1) | vcol) ^ (key & 7)) << 4) + vhalf;
+                        const char* vp = sV + key * RB + ((((dt << 1) | vcol) ^ (key & (NC - 1))) << 4) + vhalf;
                         vf.t[tt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)vp);
                     }
                     o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf.v, o[dt], 0, 0, 0);
@@ -182,9 +190,9 @@ __global__ __launch_bounds__(256) void attention_kernel(
         if (q < len) {
             if (OUT_FP8) {
                 const float qs = 1.0f / out_scale[0];
-                uint8_t* orow8 = (uint8_t*)out_v + (int64_t)(row0 + q) * W + h * 64 + 4 * g;
+                uint8_t* orow8 = (uint8_t*)out_v + (int64_t)(row0 + q) * W + h * HD + 4 * g;
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
+                for (int dt = 0; dt < NDT; ++dt) {
                     float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -197,9 +205,9 @@ __global__ __launch_bounds__(256) void attention_kernel(
                     *(int*)(orow8 + dt * 16) = w;
                 }
             } else {
-                bf16_t* orow = out + (int64_t)(row0 + q) * W + h * 64 + 4 * g;
+                bf16_t* orow = out + (int64_t)(row0 + q) * W + h * HD + 4 * g;
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
+                for (int dt = 0; dt < NDT; ++dt) {
                     uint2 p;
                     p.x = pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv);
                     p.y = pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv);
@@ -220,7 +228,8 @@ extern "C" int mq_attention_ex(const void* d_qkv, void* d_out, const int32_t* d_
                                int32_t fixed_len, int32_t max_len, int32_t W, int32_t heads, int32_t mask,
                                int32_t out_fp8, const float* d_out_scale, float* d_amax, void* stream) {
     MQ_CHECK_ARG(d_qkv && d_out, "mq_attention: null pointer");
-    MQ_CHECK_ARG(heads >= 1 && W == heads * 64, "mq_attention: head dim must be 64 (W=%d heads=%d)", W, heads);
+    MQ_CHECK_ARG(heads >= 1 && (W == heads * 64 || W == heads * 128), "mq_attention: head dim must be 64 or 128 (W=%d heads=%d)", W, heads);
+    const int hd = W / heads;
     MQ_CHECK_ARG(fixed_len > 0 || d_cu_seqlens, "mq_attention: need fixed_len or cu_seqlens");
     MQ_CHECK_ARG(mask == MQ_MASK_NONE || mask == MQ_MASK_CAUSAL, "mq_attention: bad mask %d", mask);
     if (nseq <= 0) return MQ_OK;
@@ -228,10 +237,10 @@ extern "C" int mq_attention_ex(const void* d_qkv, void* d_out, const int32_t* d_
     MQ_CHECK_ARG(maxl >= 1 && maxl <= 1024, "mq_attention: max sequence length %d unsupported (1..1024)", maxl);
     MQ_CHECK_ARG(nseq * heads < (1LL << 31), "mq_attention: grid too large");
     const int kpad = ((maxl + 63) / 64) * 64;
-    const size_t lds = (size_t)kpad * 256;
+    const size_t lds = (size_t)kpad * hd * 4;  // K + V rows of hd bf16 each
     MQ_CHECK_ARG(lds <= 160 * 1024, "mq_attention: sequence length %d needs %zu B of LDS (> 160 KiB)", maxl, lds);
     hipStream_t s = (hipStream_t)stream;
-    const float scale_log2e = 0.125f * 1.44269504088896340736f;  // 1/sqrt(64) * log2(e)
+    const float scale_log2e = (hd == 64 ? 0.125f : 0.08838834764831845f) * 1.44269504088896340736f;  // 1/sqrt(hd) * log2(e)
     MqProfScope prof(2, s);
     auto launch = [&](auto kern) -> int {
         if (lds > 64 * 1024) {
@@ -244,8 +253,13 @@ extern "C" int mq_attention_ex(const void* d_qkv, void* d_out, const int32_t* d_
     };
     MQ_CHECK_ARG(!out_fp8 || d_out_scale, "mq_attention: fp8 output needs an out_scale");
     int rc;
-    if (out_fp8) rc = (mask == MQ_MASK_CAUSAL) ? launch(attention_kernel<MQ_MASK_CAUSAL, true>) : launch(attention_kernel<MQ_MASK_NONE, true>);
-    else rc = (mask == MQ_MASK_CAUSAL) ? launch(attention_kernel<MQ_MASK_CAUSAL, false>) : launch(attention_kernel<MQ_MASK_NONE, false>);
+    if (hd == 64) {
+        if (out_fp8) rc = (mask == MQ_MASK_CAUSAL) ? launch(attention_kernel<MQ_MASK_CAUSAL, true, 64>) : launch(attention_kernel<MQ_MASK_NONE, true, 64>);
+        else rc = (mask == MQ_MASK_CAUSAL) ? launch(attention_kernel<MQ_MASK_CAUSAL, false, 64>) : launch(attention_kernel<MQ_MASK_NONE, false, 64>);
+    } else {
+        if (out_fp8) rc = (mask == MQ_MASK_CAUSAL) ? launch(attention_kernel<MQ_MASK_CAUSAL, true, 128>) : launch(attention_kernel<MQ_MASK_NONE, true, 128>);
+        else rc = (mask == MQ_MASK_CAUSAL) ? launch(attention_kernel<MQ_MASK_CAUSAL, false, 128>) : launch(attention_kernel<MQ_MASK_NONE, false, 128>);
+    }
     if (rc != MQ_OK) return rc;
     MQ_CHECK_LAUNCH("mq_attention");
     return MQ_OK;

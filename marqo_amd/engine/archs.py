@@ -77,6 +77,8 @@ class BertArch:
 _TEXT_B = ClipTextArch(vocab=49408, ctx=77, width=512, layers=12, heads=8, mlp_dim=2048, out_dim=512)
 _TEXT_L = ClipTextArch(vocab=49408, ctx=77, width=768, layers=12, heads=12, mlp_dim=3072, out_dim=768)
 _TEXT_B_PLUS = ClipTextArch(vocab=49408, ctx=77, width=640, layers=12, heads=10, mlp_dim=2560, out_dim=640)
+_TEXT_H = ClipTextArch(vocab=49408, ctx=77, width=1024, layers=24, heads=16, mlp_dim=4096, out_dim=1024)
+_TEXT_BIGG = ClipTextArch(vocab=49408, ctx=77, width=1280, layers=32, heads=20, mlp_dim=5120, out_dim=1280)
 
 # open_clip architecture name -> (vision, text)
 OPEN_CLIP_ARCHS = {
@@ -86,9 +88,13 @@ OPEN_CLIP_ARCHS = {
     "ViT-B-16-plus-240": (VitArch(240, 16, 896, 12, 14, 3584, 640), _TEXT_B_PLUS),
     "ViT-L-14": (VitArch(224, 14, 1024, 24, 16, 4096, 768), _TEXT_L),
     "ViT-L-14-336": (VitArch(336, 14, 1024, 24, 16, 4096, 768), _TEXT_L),
+    # 16 heads of 80 / 88 / 104: zero-padded to 128-wide heads at load (engine/towers.py::_pad_heads)
+    "ViT-H-14": (VitArch(224, 14, 1280, 32, 16, 5120, 1024), _TEXT_H),
+    "ViT-g-14": (VitArch(224, 14, 1408, 40, 16, 6144, 1024), _TEXT_H),
+    "ViT-bigG-14": (VitArch(224, 14, 1664, 48, 16, 8192, 1280), _TEXT_BIGG),
 }
-# architectures the registry names but whose head dim != 64 (ViT-H 80, ViT-g 88, ViT-bigG 104) or which are
-# not plain CLIP ViTs (ResNet, ConvNeXt, EVA02, SigLIP, CoCa, roberta/xlm text towers ...)
+# architectures the registry names but which are not plain CLIP ViTs (ResNet, ConvNeXt, EVA02, SigLIP, CoCa, roberta/xlm text
+# towers ...) or whose token count does not fit the LDS-resident attention at 128-wide heads (ViT-H-14-378: 730 tokens)
 UNSUPPORTED_HINT = ("this open_clip architecture is not runnable by the marqo_amd engine yet "
                     "(supported: " + ", ".join(sorted(OPEN_CLIP_ARCHS)) + " and their -quickgelu variants)")
 

@@ -70,38 +70,45 @@ def _need(sd: Dict[str, Tensor], key: str, shape: Optional[Tuple[int, ...]] = No
 
 
 def _head_dim(width: int, heads: int) -> int:
-    """the attention kernel runs 64-wide heads; narrower heads (32, 16) are zero-padded to 64 at load (_pad_heads)"""
+    """model head dim; the attention kernel runs 64- or 128-wide heads, anything else is zero-padded at load (_pad_heads)"""
     if heads < 1 or width % heads:
         raise ValueError(f"width {width} is not divisible by heads {heads}")
     d = width // heads
-    if d > 64 or 64 % d:
-        raise ValueError(f"attention head dim must be 64 (or 32 / 16, zero-padded to 64) for the gfx950 attention kernel "
-                         f"(width={width}, heads={heads}: {d})")
+    if d > 128:
+        raise ValueError(f"attention head dim must be <= 128 for the gfx950 attention kernel (width={width}, heads={heads}: {d})")
     return d
 
 
+def _kernel_head_dim(d: int) -> int:
+    """head width the kernel runs for a model head dim d: 32 / 16 -> 64 (e5-small, MiniLM), 80 / 88 / 104 -> 128 (ViT-H / g / bigG)"""
+    return 64 if d <= 64 else 128
+
+
 def _pad_heads(qkv_w: Tensor, qkv_b: Tensor, out_w: Tensor, heads: int, d: int) -> Tuple[Tensor, Tensor, Tensor]:
-    """[3W, W] / [3W] / [W, W] with d-wide heads -> [3*heads*64, W] / [3*heads*64] / [W, heads*64]: each head's Q / K / V rows and
-    out-projection columns are zero-padded to 64 (zero key / query dims add nothing to q.k, zero value dims meet zero out-proj
-    columns), and Q is scaled by sqrt(64 / d) so that the kernel's 1/sqrt(64) softmax scale equals the model's 1/sqrt(d)."""
+    """[3W, W] / [3W] / [W, W] with d-wide heads -> [3*heads*hp, W] / [3*heads*hp] / [W, heads*hp] (hp = 64 or 128): each head's
+    Q / K / V rows and out-projection columns are zero-padded to hp (zero key / query dims add nothing to q.k, zero value dims meet
+    zero out-proj columns), and Q is scaled by sqrt(hp / d) so that the kernel's 1/sqrt(hp) softmax scale equals the model's
+    1/sqrt(d)."""
     W = out_w.shape[0]
+    hp = _kernel_head_dim(d)
     q, k, v = qkv_w.float().view(3, heads, d, W).unbind(0)
     qb, kb, vb = qkv_b.float().view(3, heads, d).unbind(0)
-    sc = (64.0 / d) ** 0.5
-    pad_w = lambda t: torch.nn.functional.pad(t, (0, 0, 0, 64 - d)).reshape(heads * 64, W)
-    pad_b = lambda t: torch.nn.functional.pad(t, (0, 64 - d)).reshape(heads * 64)
+    sc = (float(hp) / d) ** 0.5
+    pad_w = lambda t: torch.nn.functional.pad(t, (0, 0, 0, hp - d)).reshape(heads * hp, W)
+    pad_b = lambda t: torch.nn.functional.pad(t, (0, hp - d)).reshape(heads * hp)
     qkv_w2 = torch.cat([pad_w(q * sc), pad_w(k), pad_w(v)], 0)
     qkv_b2 = torch.cat([pad_b(qb * sc), pad_b(kb), pad_b(vb)], 0)
-    out_w2 = torch.nn.functional.pad(out_w.float().view(W, heads, d), (0, 64 - d)).reshape(W, heads * 64)
+    out_w2 = torch.nn.functional.pad(out_w.float().view(W, heads, d), (0, hp - d)).reshape(W, heads * hp)
     return qkv_w2, qkv_b2, out_w2
 
 
 def _encoder_cfg(width, layers, heads, mlp_dim, quick_gelu, post_ln, mask, eps) -> L.EncoderCfg:
     d = _head_dim(width, heads)
+    hp = _kernel_head_dim(d)
     return L.EncoderCfg(width=width, layers=layers, heads=heads, mlp_dim=mlp_dim,
                         act=L.MQ_ACT_QUICKGELU if quick_gelu else L.MQ_ACT_GELU,
                         post_ln=1 if post_ln else 0, mask=mask, ln_eps=eps, precision=L.MQ_PREC_BF16,
-                        attn_width=0 if d == 64 else heads * 64, d_fp8_act_scale=None, d_fp8_act_amax=None)
+                        attn_width=0 if d == hp else heads * hp, d_fp8_act_scale=None, d_fp8_act_amax=None)
 
 
 class _Fp8State:
@@ -109,7 +116,7 @@ class _Fp8State:
     per-tensor activation scales [layers, 2] = (attention output, MLP hidden) with their calibration accumulator."""
 
     def __init__(self, lib, holder: "_Holder", blocks, layers: int, W: int, F: int, device: torch.device, Wa: Optional[int] = None):
-        Wa = Wa or W  # attention width (heads * 64)
+        Wa = Wa or W  # attention width (heads * 64 or heads * 128)
         self.scale = torch.full((layers, 2), 16.0 / 448.0, dtype=torch.float32, device=device)  # pre-calibration guess
         self.amax = torch.zeros(layers, 2, dtype=torch.float32, device=device)
         stream = torch.cuda.current_stream(device).cuda_stream
@@ -142,16 +149,22 @@ class _Fp8State:
 LN_FOLD = os.environ.get("MARQO_AMD_LN_FOLD", "0") == "1"
 
 
-def _clip_blocks(h: _Holder, sd, prefix: str, layers: int, W: int, F: int):
+def _clip_blocks(h: _Holder, sd, prefix: str, layers: int, W: int, F: int, heads: int):
+    d = _head_dim(W, heads)
+    padded = d != _kernel_head_dim(d)  # ViT-H / g / bigG: 80 / 88 / 104-wide heads run as 128
+    if padded and LN_FOLD:
+        raise ValueError("MARQO_AMD_LN_FOLD=1 is not supported for models whose heads are padded")
     arr = (L.BlockWeights * layers)()
     for i in range(layers):
         p = f"{prefix}resblocks.{i}."
         b = arr[i]
         b.ln1_g = h.f32(_need(sd, p + "ln_1.weight", (W,)))
         b.ln1_b = h.f32(_need(sd, p + "ln_1.bias", (W,)))
-        b.qkv_w = h.bf16(_need(sd, p + "attn.in_proj_weight", (3 * W, W)))
-        b.qkv_b = h.f32(_need(sd, p + "attn.in_proj_bias", (3 * W,)))
-        b.out_w = h.bf16(_need(sd, p + "attn.out_proj.weight", (W, W)))
+        qkv_w, qkv_b = _need(sd, p + "attn.in_proj_weight", (3 * W, W)), _need(sd, p + "attn.in_proj_bias", (3 * W,))
+        out_w = _need(sd, p + "attn.out_proj.weight", (W, W))
+        if padded:
+            qkv_w, qkv_b, out_w = _pad_heads(qkv_w.detach(), qkv_b.detach(), out_w.detach(), heads, d)
+        b.qkv_w, b.qkv_b, b.out_w = h.bf16(qkv_w), h.f32(qkv_b), h.bf16(out_w)
         b.out_b = h.f32(_need(sd, p + "attn.out_proj.bias", (W,)))
         b.ln2_g = h.f32(_need(sd, p + "ln_2.weight", (W,)))
         b.ln2_b = h.f32(_need(sd, p + "ln_2.bias", (W,)))
@@ -237,7 +250,7 @@ class VitTower(_TowerBase):
         patch_w = torch.zeros(W, Kp, dtype=torch.float32)
         patch_w[:, :K] = conv
         h = self._h
-        self._blocks = _clip_blocks(h, sd, "visual.transformer.", arch.layers, W, arch.mlp_dim)
+        self._blocks = _clip_blocks(h, sd, "visual.transformer.", arch.layers, W, arch.mlp_dim, arch.heads)
         self.w = L.VitWeights(
             patch_w=h.bf16(patch_w),
             cls=h.f32(_need(sd, "visual.class_embedding", (W,))),
@@ -385,7 +398,7 @@ class ClipTextTower(_TextTowerBase):
         self.arch = arch
         W = arch.width
         h = self._h
-        self._blocks = _clip_blocks(h, sd, "transformer.", arch.layers, W, arch.mlp_dim)
+        self._blocks = _clip_blocks(h, sd, "transformer.", arch.layers, W, arch.mlp_dim, arch.heads)
         self.w = L.ClipTextWeights(
             tok_emb=h.f32(_need(sd, "token_embedding.weight", (arch.vocab, W))),
             pos=h.f32(_need(sd, "positional_embedding", (arch.ctx, W))),
@@ -458,7 +471,7 @@ class BertTower(_TextTowerBase):
             qkv_w = torch.cat([_need(sd, p + f"attention.self.{n}.weight", (W, W)).detach().float() for n in ("query", "key", "value")], 0)
             qkv_b = torch.cat([_need(sd, p + f"attention.self.{n}.bias", (W,)).detach().float() for n in ("query", "key", "value")], 0)
             out_w = _need(sd, p + "attention.output.dense.weight", (W, W)).detach().float()
-            if hd != 64:  # e5-small / bge-small / MiniLM: 12 heads of 32
+            if hd != _kernel_head_dim(hd):  # e5-small / bge-small / MiniLM: 12 heads of 32
                 qkv_w, qkv_b, out_w = _pad_heads(qkv_w, qkv_b, out_w, arch.heads, hd)
             b.qkv_w, b.qkv_b = h.bf16(qkv_w), h.f32(qkv_b)
             b.out_w = h.bf16(out_w)

@@ -2,7 +2,7 @@
 
 Same shape as the reference's ``load_model_properties()`` (src/marqo/s2_inference/model_registry.py:2147-2187):
 ``{'models': {name: properties}, 'loaders': {type: loader class}}``.  Only the model families the gfx950 towers
-run are registered: CLIP ViTs with attention head dim 64 behind the ``open_clip`` (and OpenAI ``clip`` /
+run are registered: CLIP ViTs (B/32 … bigG/14) behind the ``open_clip`` (and OpenAI ``clip`` /
 ``fp16_clip`` naming) loaders, BERT-family encoders behind ``hf``, plus the reference's own plumbing fakes
 ``random`` (random_utils.py) and ``no_model``.  Entries are generated from the architecture tables in
 ``marqo_amd.engine.archs`` — names, dimensions, token limits and prefixes follow the reference registry
@@ -22,6 +22,10 @@ _OPEN_CLIP_TAGS = {
     "ViT-B-16-plus-240": ["laion400m_e31", "laion400m_e32"],
     "ViT-L-14": ["laion400m_e31", "laion400m_e32", "laion2b_s32b_b82k", "openai"],
     "ViT-L-14-336": ["openai"],
+    "ViT-H-14": ["laion2b_s32b_b79k"],
+    "ViT-H-14-quickgelu": ["dfn5b"],
+    "ViT-g-14": ["laion2b_s12b_b42k", "laion2b_s34b_b88k"],
+    "ViT-bigG-14": ["laion2b_s39b_b160k"],
 }
 
 # hf registry entries whose encoder is a plain BERT (absolute positions, GELU, post-LN): name -> (repo, dims, tokens, prefixes)

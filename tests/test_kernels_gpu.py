@@ -115,17 +115,17 @@ def test_layernorm(lib, rows, W):
     assert torch.allclose(og, ref[idx.long()], rtol=1e-5, atol=1e-5)
 
 
-def _ref_attention(qkv, lens, heads, causal):
+def _ref_attention(qkv, lens, heads, causal, hd=64):
     W = qkv.shape[1] // 3
     out = torch.zeros(qkv.shape[0], W, device=qkv.device)
     r0 = 0
     for ln in lens:
         blk = qkv[r0:r0 + ln].float()
         q, k, v = blk[:, :W], blk[:, W:2 * W], blk[:, 2 * W:]
-        q = q.view(ln, heads, 64).transpose(0, 1)
-        k = k.view(ln, heads, 64).transpose(0, 1)
-        v = v.view(ln, heads, 64).transpose(0, 1)
-        s = q @ k.transpose(1, 2) / 8.0
+        q = q.view(ln, heads, hd).transpose(0, 1)
+        k = k.view(ln, heads, hd).transpose(0, 1)
+        v = v.view(ln, heads, hd).transpose(0, 1)
+        s = q @ k.transpose(1, 2) / hd ** 0.5
         if causal:
             s = s + torch.full((ln, ln), float("-inf"), device=qkv.device).triu(1)
         p = torch.softmax(s, dim=-1)
@@ -134,16 +134,19 @@ def _ref_attention(qkv, lens, heads, causal):
     return out
 
 
-@pytest.mark.parametrize("lens,heads,causal", [([50] * 6, 12, False), ([257] * 3, 16, False), ([77] * 5, 8, True),
-                                                 ([5, 77, 1, 33, 64, 65], 12, True), ([9, 512, 17, 128], 12, False),
-                                                 ([16], 2, False)])
-def test_attention(lib, lens, heads, causal):
+@pytest.mark.parametrize("lens,heads,causal,hd", [([50] * 6, 12, False, 64), ([257] * 3, 16, False, 64), ([77] * 5, 8, True, 64),
+                                                    ([5, 77, 1, 33, 64, 65], 12, True, 64), ([9, 512, 17, 128], 12, False, 64),
+                                                    ([16], 2, False, 64),
+                                                    # 128-wide heads (ViT-H / g / bigG after padding): 257 tokens fill the 160 KiB of LDS
+                                                    ([257] * 3, 16, False, 128), ([5, 77, 1, 33, 64, 65, 320], 3, True, 128),
+                                                    ([50] * 4, 5, False, 128), ([16], 1, False, 128)])
+def test_attention(lib, lens, heads, causal, hd):
     from marqo_amd import _lib as L
     g = torch.Generator(device="cuda").manual_seed(5)
-    W = heads * 64
+    W = heads * hd
     rows = sum(lens)
     qkv = torch.randn(rows, 3 * W, device="cuda", generator=g).to(torch.bfloat16)
-    ref = _ref_attention(qkv, lens, heads, causal)
+    ref = _ref_attention(qkv, lens, heads, causal, hd)
     out = torch.empty(rows, W, device="cuda", dtype=torch.bfloat16)
     fixed = lens[0] if len(set(lens)) == 1 else 0
     cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), device="cuda", dtype=torch.int32)
