@@ -121,6 +121,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
     const bf16_t* a_src[MT];
     const bf16_t* w_src[4];
     auto set_sources = [&](int m0, int n0) {
+#ifdef MQ_GEMM_ALIAS
+        // diagnostic build (tools/probes/build_gemm_alias.sh): operands are fetched from an aliased origin while results still go to
+        // the tile's own place.  1: every tile reads the SAME A / W tile (L1- and L2-resident); 2: origins folded into 4 row
+        // panels x 4 column tiles (L2-resident on every XCD, far larger than a CU's L1).  Wrong results by construction.
+        if (MQ_GEMM_ALIAS == 1) { m0 = 0; n0 = 0; }
+        else { m0 %= 4 * BM; n0 %= 4 * BN; }
+#endif
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int row = wave * (8 * MT) + i * 8 + srow;
