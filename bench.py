@@ -237,6 +237,12 @@ def main():
         "launches_per_step": gemm_launches // prof_steps,
         "per_family": families,
     }
+    if args.precision == "bf16":
+        # informational: what a register-resident v_mfma_f32_16x16x32_bf16 burn sustains on this chip with random operands at
+        # the clock it then holds (2.04 GHz) — tools/probes/mfma_peak.hip, profiles/r01f_mfma_sustained_peak.txt.  `peak` / `frac`
+        # above stay priced against the guide's 2.4 GHz figure.
+        roofline["peak_sustained_measured"] = 2114.0
+        roofline["frac_of_sustained"] = round(achieved / 2114.0, 4)
     # HBM-side traffic of the dominant kernel from the committed PMC passes of this same command (tools/gpu_evidence.sh:
     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH doubled per MI355X_MICROARCH.md; PMC cannot be sampled
     # from inside this process).  Bytes per launch, averaged over the GEMM launches like `achieved`.
