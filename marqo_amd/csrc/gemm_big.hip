@@ -3,7 +3,7 @@
 // Measurements on the (32*MT)x128 kernel (2 workgroups/CU) show throughput proportional to 1/(bytes staged per FLOP):
 // the global->LDS path sustains ~24 B/clk/CU, and two independent 160x128 tiles per CU ask for 57.6 B/clk at full
 // MFMA rate.  This kernel gives ONE workgroup the whole CU: 8 wave64s as 2(M) x 4(N), tile (32*MT) x 256 x 64,
-// each wave a (16*MT) x 64 sub-tile (MT x 4 v_mfma_f32_16x16x32_bf16 accumulators, MT = 4 / 6 / 8).  The W stage
+// each wave a (16*MT) x 64 sub-tile (MT x 4 v_mfma_f32_16x16x32_bf16 accumulators, MT = 4 / 5 / 6 / 8).  The W stage
 // is shared by both wave rows and the A stage by all four wave columns, so a 256x256 tile needs 32 B/clk — and every
 // wave issues half as many LDS-DMA pieces per MFMA.  2 stages x (BM*128 B + 32 KiB) = 96..128 KiB of LDS.
 // LDS image, swizzle and epilogue are the ones of gemm_bf16.hip.
@@ -27,11 +27,11 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(
     const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ Wt, int64_t ldw,
     const float* __restrict__ bias, const float* residual, void* out, int64_t ldc,
     int M, int N, int K, int tiles_n, int num_tiles) {
-    static_assert(MT % 2 == 0, "A staging hands each of the 8 waves MT/2 eight-row pieces");
     constexpr int BM = 32 * MT;
     constexpr int A_TILE_BYTES = BM * BK * 2;
     constexpr int STAGE_BYTES = A_TILE_BYTES + W_TILE_BYTES;
-    constexpr int PA = MT / 2, PW = 4;  // 1-KiB (8 rows x 128 B) pieces per wave per stage
+    constexpr int NA = 4 * MT;                  // 1-KiB (8 rows x 128 B) pieces of the A stage, dealt round-robin to the 8 waves
+    constexpr int PA = (NA + 7) / 8, PW = 4;    // pieces per wave per stage (odd MT: waves 4..7 own one A piece fewer)
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     // ---- XCD-aware, bijective block -> tile map -------------------------------------------
@@ -48,13 +48,13 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(
     const int wm = wave >> 2, wn = wave & 3;
     const int l15 = lane & 15, g = lane >> 4;
 
-    // ---- staging: wave w owns A rows [4*MT*w, 4*MT*(w+1)) and W rows [32w, 32w+32), 8 rows per LDS-DMA
+    // ---- staging: wave w owns A pieces w, w+8, w+16, ... (piece p = rows [8p, 8p+8)) and W rows [32w, 32w+32), 8 rows per LDS-DMA
     const int srow = lane >> 3;
     const bf16_t* a_src[PA];
     const bf16_t* w_src[PW];
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
-        const int row = wave * (4 * MT) + i * 8 + srow;
+        const int row = (i * 8 + wave) * 8 + srow;
         int gm = m0 + row; gm = gm < M ? gm : M - 1;
         a_src[i] = A + (int64_t)gm * lda + ((lane & 7) ^ (row & 7)) * 8;
     }
@@ -65,10 +65,11 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(
         w_src[i] = Wt + (int64_t)gn * ldw + ((lane & 7) ^ (row & 7)) * 8;
     }
     auto stage = [&](int buf, int kt) {
-        char* sa = smem + buf * STAGE_BYTES + wave * (4 * MT * 128);
+        char* sa = smem + buf * STAGE_BYTES + wave * (8 * 128);
         char* sw = smem + buf * STAGE_BYTES + A_TILE_BYTES + wave * (32 * 128);
 #pragma unroll
-        for (int i = 0; i < PA; ++i) glds16(a_src[i] + (int64_t)kt * BK, sa + i * (8 * 128));
+        for (int i = 0; i < PA; ++i)
+            if (i * 8 + wave < NA) glds16(a_src[i] + (int64_t)kt * BK, sa + i * (64 * 128));  // wave-uniform guard
 #pragma unroll
         for (int i = 0; i < PW; ++i) glds16(w_src[i] + (int64_t)kt * BK, sw + i * (8 * 128));
     };
@@ -169,12 +170,13 @@ int launch_big_mt(const void* A, int64_t lda, const void* W, int64_t ldw, const 
 
 }  // namespace
 
-// called from gemm_bf16.hip's dispatcher; mt in {4, 6, 8}
+// called from gemm_bf16.hip's dispatcher; mt in {4, 5, 6, 8}
 template <int FLAGS>
 int mq_launch_gemm_big(int mt, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* residual,
                        void* out, int64_t ldc, int M, int N, int K, hipStream_t s) {
     switch (mt) {
         case 4: return launch_big_mt<FLAGS, 4>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s);
+        case 5: return launch_big_mt<FLAGS, 5>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s);
         case 6: return launch_big_mt<FLAGS, 6>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s);
         default: return launch_big_mt<FLAGS, 8>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s);
     }

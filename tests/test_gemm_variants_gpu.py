@@ -103,7 +103,7 @@ def test_short_kstep_three_workgroup_variant():
         _tune(lib, **DEFAULTS)
 
 
-@pytest.mark.parametrize("big", [4, 6, 8])
+@pytest.mark.parametrize("big", [4, 5, 6, 8])
 def test_cu_sized_tile_variant(big):
     """gemm_big.hip: 8-wave (32*MT)x256 tile, one workgroup per CU"""
     lib = L.load()
