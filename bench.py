@@ -37,8 +37,8 @@ WORKLOADS = {
     # the headline workload (BASELINE.json configs[1]) is the default; the others are reported in DESIGN.md §6
     "vit_b32_image": dict(kind="image", arch="ViT-B-32", desc="open_clip ViT-B/32 image tower, uint8 224x224, batch 256/GPU", batch=256),
     "vit_l14_image": dict(kind="image", arch="ViT-L-14", desc="open_clip ViT-L/14 image tower, uint8 224x224, batch 64/GPU", batch=64),
-    "vit_h14_image": dict(kind="image", arch="ViT-H-14", desc="open_clip ViT-H/14 image tower (80-wide heads run as 128), uint8 224x224, batch 64/GPU", batch=64),
-    "vit_bigg14_image": dict(kind="image", arch="ViT-bigG-14", desc="open_clip ViT-bigG/14 image tower (104-wide heads run as 128), uint8 224x224, batch 32/GPU", batch=32),
+    "vit_h14_image": dict(kind="image", arch="ViT-H-14", desc="open_clip ViT-H/14 image tower (80-wide heads run as 96), uint8 224x224, batch 64/GPU", batch=64),
+    "vit_bigg14_image": dict(kind="image", arch="ViT-bigG-14", desc="open_clip ViT-bigG/14 image tower (104-wide heads run as 112), uint8 224x224, batch 32/GPU", batch=32),
     "clip_text_b32": dict(kind="clip_text", arch="ViT-B-32", desc="open_clip ViT-B/32 text tower, 77-token ids, batch 1024/GPU", batch=1024),
     "clip_text_l14": dict(kind="clip_text", arch="ViT-L-14", desc="open_clip ViT-L/14 text tower, 77-token ids, batch 1024/GPU", batch=1024),
     "bert_base_77": dict(kind="bert", arch="intfloat/e5-base-v2", desc="e5-base-v2 (BERT-base) + mean-pool + L2, 77-token ids, batch 1024/GPU", batch=1024),

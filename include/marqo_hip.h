@@ -97,14 +97,14 @@ typedef struct mq_block_weights {
 typedef struct mq_encoder_cfg {
     int32_t width;      /* W, multiple of 64 */
     int32_t layers;
-    int32_t heads;      /* attention runs 64- or 128-wide heads: heads * 64 or heads * 128 == attn_width (or width) */
+    int32_t heads;      /* attention runs 64-, 96-, 112- or 128-wide heads: heads * that == attn_width (or width) */
     int32_t mlp_dim;    /* F, multiple of 64 */
     int32_t act;        /* MQ_ACT_* */
     int32_t post_ln;    /* 0: pre-LN (CLIP); 1: post-LN (BERT) */
     int32_t mask;       /* MQ_MASK_* */
     float   ln_eps;
     int32_t precision;  /* MQ_PREC_BF16 (0) or MQ_PREC_FP8 (width and mlp_dim multiples of 128) */
-    int32_t attn_width; /* 0 = width.  heads * 64 (or * 128) when the checkpoint's heads are narrower and were zero-padded at load
+    int32_t attn_width; /* 0 = width.  heads * {64, 96, 112, 128} when the checkpoint's heads are narrower and were zero-padded at load
                          * (QKV weights [3*attn_width, W], out-projection [W, attn_width]) */
     /* fp8 path: static per-tensor activation scales, device fp32 [layers][2] = (attention output, MLP hidden), and the
      * calibration accumulator of the same shape (NULL = frozen scales; non-NULL = fold max|value| of this pass into it) */

@@ -1,5 +1,6 @@
-// Multi-head attention for short sequences (T = 50 / 77 / 257 / <= 512), d_head = 64 (K4) — or 128 (HD template parameter: the
-// 80 / 88 / 104-wide heads of ViT-H / g / bigG are zero-padded to 128 at load; rows are then 256 B, 16 chunks swizzled by key & 15).
+// Multi-head attention for short sequences (T = 50 / 77 / 257 / <= 512), d_head = 64 (K4) — or up to 128: template parameter
+// HD = 128 makes the LDS rows 256 B (16 chunk slots swizzled by key & 15) and HS = 96 / 112 / 128 is the head stride in global
+// memory = the dims actually computed (the 80 / 88 / 104-wide heads of ViT-H / g / bigG are zero-padded to 96 / 96 / 112 at load).
 //
 // One workgroup (4 wave64s) per (sequence, head).  The whole K [len,64] and V [len,64] of that
 // (sequence, head) are staged ONCE in LDS by LDS-DMA (global_load_lds: every 1-KiB piece is in flight at once, no
@@ -17,6 +18,7 @@
 //
 // Sequences are packed (cu_seqlens) or fixed-length; there is no key-padding mask: padded
 // tokens are simply not rows.  MASK_CAUSAL implements the CLIP text tower's mask.
+#include <type_traits>
 #include "common.h"
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -25,16 +27,18 @@ namespace {
 
 // OUT_FP8: the output is written as e4m3 codes = value / *out_scale (static per-tensor scale of the fp8 path, K13) and
 // max|value| is folded into *amax when it is non-null (calibration).
-template <int MASK, bool OUT_FP8, int HD>
+template <int MASK, bool OUT_FP8, int HD, int HS>
 __global__ __launch_bounds__(256) void attention_kernel(
     const bf16_t* __restrict__ qkv, void* __restrict__ out_v, const int32_t* __restrict__ cu,
     int fixed_len, int W, int heads, int kpad, float scale_log2e, const float* __restrict__ out_scale, float* amax_out) {
     bf16_t* out = (bf16_t*)out_v;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int RB = HD * 2;       // bytes per K / V row (128 or 256)
-    constexpr int NC = HD / 8;       // 16-byte chunks per row (8 or 16)
-    constexpr int NKK = HD / 32;     // 32-deep MFMA k-chunks of a Q.K dot product (2 or 4)
-    constexpr int NDT = HD / 16;     // 16-wide output-dim tiles (4 or 8)
+    static_assert(HS <= HD && HS % 16 == 0 && (HD == 64 || HD == 128), "head stride: multiple of 16, at most the LDS row");
+    constexpr int RB = HD * 2;       // bytes per K / V row in LDS (128 or 256)
+    constexpr int NC = HD / 8;       // 16-byte chunk slots per LDS row (8 or 16)
+    constexpr int NCS = HS / 8;      // chunks a head really has in global memory (slots past them are never consumed)
+    constexpr int NKK = (HS + 31) / 32;  // 32-deep MFMA k-chunks of a Q.K dot product (2 .. 4)
+    constexpr int NDT = HS / 16;     // 16-wide output-dim tiles (4 .. 8)
     constexpr int RPP = 1024 / RB;   // rows per 1-KiB LDS-DMA piece (8 or 4)
     char* sK = smem;                      // [kpad][RB], 16-B chunks XOR-swizzled by (key & (NC-1))
     char* sV = smem + (size_t)kpad * RB;  // [kpad][RB], same image
@@ -45,7 +49,7 @@ __global__ __launch_bounds__(256) void attention_kernel(
     else { row0 = cu[seq]; len = cu[seq + 1] - row0; }
     if (len <= 0) return;
     const int ld = 3 * W;
-    const bf16_t* qb = qkv + (int64_t)row0 * ld + h * HD;
+    const bf16_t* qb = qkv + (int64_t)row0 * ld + h * HS;
     const bf16_t* kb = qb + W;
     const bf16_t* vb = qb + 2 * W;
     const int nkt = (len + 63) >> 6;
@@ -63,7 +67,9 @@ __global__ __launch_bounds__(256) void attention_kernel(
             const int piece = is_v ? p - np8 : p;
             const int row = piece * RPP + srow;
             const int key = row < len ? row : len - 1;
-            const bf16_t* src = (is_v ? vb : kb) + (int64_t)key * ld + ((pchunk ^ (row & (NC - 1))) << 3);
+            int lc = pchunk ^ (row & (NC - 1));
+            if (HS < HD) lc = lc < NCS ? lc : 0;  // slots of chunks the head does not have: any finite filler (they meet zero Q dims)
+            const bf16_t* src = (is_v ? vb : kb) + (int64_t)key * ld + (lc << 3);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)((is_v ? sV : sK) + piece * 1024), 16, 0, 0);
         }
@@ -71,13 +77,20 @@ __global__ __launch_bounds__(256) void attention_kernel(
     const int l15 = lane & 15, g = lane >> 4;
     const int nqb = (len + 15) >> 4;
     float amax_local = 0.f;
+    // Q fragment of query row qr, k-chunk kk: dims 32kk + 8g .. +7; dims past the head (HS = 112: the last 16) are zeros, so
+    // whatever sits in the matching K slots contributes nothing
+    auto load_q = [&](int qr, int kk) -> bf16x8 {
+        const int col = 8 * g + 32 * kk;
+        if (HS % 32 != 0 && col >= HS) return bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        return *(const bf16x8*)(qb + (int64_t)qr * ld + col);
+    };
     // first Q fragments are fetched while the K/V DMA is in flight
     bf16x8 qn[NKK];
     {
         const int q0 = wave * 16 + l15;
         const int qr = q0 < len ? q0 : len - 1;
 #pragma unroll
-        for (int kk = 0; kk < NKK; ++kk) qn[kk] = *(const bf16x8*)(qb + (int64_t)qr * ld + 8 * g + 32 * kk);
+        for (int kk = 0; kk < NKK; ++kk) qn[kk] = load_q(qr, kk);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -95,7 +108,7 @@ __global__ __launch_bounds__(256) void attention_kernel(
             const int q2 = q + 64;
             const int qr = q2 < len ? q2 : len - 1;
 #pragma unroll
-            for (int kk = 0; kk < NKK; ++kk) qn[kk] = *(const bf16x8*)(qb + (int64_t)qr * ld + 8 * g + 32 * kk);
+            for (int kk = 0; kk < NKK; ++kk) qn[kk] = load_q(qr, kk);
         }
 
         float m_run = -1e30f, l_run = 0.f;
@@ -190,7 +203,7 @@ __global__ __launch_bounds__(256) void attention_kernel(
         if (q < len) {
             if (OUT_FP8) {
                 const float qs = 1.0f / out_scale[0];
-                uint8_t* orow8 = (uint8_t*)out_v + (int64_t)(row0 + q) * W + h * HD + 4 * g;
+                uint8_t* orow8 = (uint8_t*)out_v + (int64_t)(row0 + q) * W + h * HS + 4 * g;
 #pragma unroll
                 for (int dt = 0; dt < NDT; ++dt) {
                     float v[4];
@@ -205,7 +218,7 @@ __global__ __launch_bounds__(256) void attention_kernel(
                     *(int*)(orow8 + dt * 16) = w;
                 }
             } else {
-                bf16_t* orow = out + (int64_t)(row0 + q) * W + h * HD + 4 * g;
+                bf16_t* orow = out + (int64_t)(row0 + q) * W + h * HS + 4 * g;
 #pragma unroll
                 for (int dt = 0; dt < NDT; ++dt) {
                     uint2 p;
@@ -228,8 +241,10 @@ extern "C" int mq_attention_ex(const void* d_qkv, void* d_out, const int32_t* d_
                                int32_t fixed_len, int32_t max_len, int32_t W, int32_t heads, int32_t mask,
                                int32_t out_fp8, const float* d_out_scale, float* d_amax, void* stream) {
     MQ_CHECK_ARG(d_qkv && d_out, "mq_attention: null pointer");
-    MQ_CHECK_ARG(heads >= 1 && (W == heads * 64 || W == heads * 128), "mq_attention: head dim must be 64 or 128 (W=%d heads=%d)", W, heads);
-    const int hd = W / heads;
+    MQ_CHECK_ARG(heads >= 1 && W % heads == 0, "mq_attention: W=%d is not a multiple of heads=%d", W, heads);
+    const int hs = W / heads;             // head stride in memory = dims computed
+    MQ_CHECK_ARG(hs == 64 || hs == 96 || hs == 112 || hs == 128, "mq_attention: head dim must be 64, 96, 112 or 128 (W=%d heads=%d)", W, heads);
+    const int hd = hs == 64 ? 64 : 128;   // LDS row width
     MQ_CHECK_ARG(fixed_len > 0 || d_cu_seqlens, "mq_attention: need fixed_len or cu_seqlens");
     MQ_CHECK_ARG(mask == MQ_MASK_NONE || mask == MQ_MASK_CAUSAL, "mq_attention: bad mask %d", mask);
     if (nseq <= 0) return MQ_OK;
@@ -240,7 +255,7 @@ extern "C" int mq_attention_ex(const void* d_qkv, void* d_out, const int32_t* d_
     const size_t lds = (size_t)kpad * hd * 4;  // K + V rows of hd bf16 each
     MQ_CHECK_ARG(lds <= 160 * 1024, "mq_attention: sequence length %d needs %zu B of LDS (> 160 KiB)", maxl, lds);
     hipStream_t s = (hipStream_t)stream;
-    const float scale_log2e = (hd == 64 ? 0.125f : 0.08838834764831845f) * 1.44269504088896340736f;  // 1/sqrt(hd) * log2(e)
+    const float scale_log2e = 1.44269504088896340736f / sqrtf((float)hs);  // 1/sqrt(head dim) * log2(e)
     MqProfScope prof(2, s);
     auto launch = [&](auto kern) -> int {
         if (lds > 64 * 1024) {
@@ -253,12 +268,17 @@ extern "C" int mq_attention_ex(const void* d_qkv, void* d_out, const int32_t* d_
     };
     MQ_CHECK_ARG(!out_fp8 || d_out_scale, "mq_attention: fp8 output needs an out_scale");
     int rc;
-    if (hd == 64) {
-        if (out_fp8) rc = (mask == MQ_MASK_CAUSAL) ? launch(attention_kernel<MQ_MASK_CAUSAL, true, 64>) : launch(attention_kernel<MQ_MASK_NONE, true, 64>);
-        else rc = (mask == MQ_MASK_CAUSAL) ? launch(attention_kernel<MQ_MASK_CAUSAL, false, 64>) : launch(attention_kernel<MQ_MASK_NONE, false, 64>);
-    } else {
-        if (out_fp8) rc = (mask == MQ_MASK_CAUSAL) ? launch(attention_kernel<MQ_MASK_CAUSAL, true, 128>) : launch(attention_kernel<MQ_MASK_NONE, true, 128>);
-        else rc = (mask == MQ_MASK_CAUSAL) ? launch(attention_kernel<MQ_MASK_CAUSAL, false, 128>) : launch(attention_kernel<MQ_MASK_NONE, false, 128>);
+    auto pick = [&](auto hd_tag, auto hs_tag) -> int {
+        constexpr int HD_ = decltype(hd_tag)::value, HS_ = decltype(hs_tag)::value;
+        if (out_fp8) return (mask == MQ_MASK_CAUSAL) ? launch(attention_kernel<MQ_MASK_CAUSAL, true, HD_, HS_>) : launch(attention_kernel<MQ_MASK_NONE, true, HD_, HS_>);
+        return (mask == MQ_MASK_CAUSAL) ? launch(attention_kernel<MQ_MASK_CAUSAL, false, HD_, HS_>) : launch(attention_kernel<MQ_MASK_NONE, false, HD_, HS_>);
+    };
+    using std::integral_constant;
+    switch (hs) {
+        case 64: rc = pick(integral_constant<int, 64>{}, integral_constant<int, 64>{}); break;
+        case 96: rc = pick(integral_constant<int, 128>{}, integral_constant<int, 96>{}); break;
+        case 112: rc = pick(integral_constant<int, 128>{}, integral_constant<int, 112>{}); break;
+        default: rc = pick(integral_constant<int, 128>{}, integral_constant<int, 128>{}); break;
     }
     if (rc != MQ_OK) return rc;
     MQ_CHECK_LAUNCH("mq_attention");

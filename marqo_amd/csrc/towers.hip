@@ -58,8 +58,8 @@ int check_encoder_cfg(const mq_encoder_cfg* c) {
     MQ_CHECK_ARG(c, "encoder cfg is null");
     MQ_CHECK_ARG(c->width >= 64 && c->width % 64 == 0, "encoder width %d must be a multiple of 64", c->width);
     const int wa = c->attn_width ? c->attn_width : c->width;
-    MQ_CHECK_ARG(c->heads >= 1 && (wa == c->heads * 64 || wa == c->heads * 128),
-                 "encoder attention width must be heads * 64 or heads * 128 (attention width %d, heads %d)", wa, c->heads);
+    MQ_CHECK_ARG(c->heads >= 1 && (wa == c->heads * 64 || wa == c->heads * 96 || wa == c->heads * 112 || wa == c->heads * 128),
+                 "encoder attention width must be heads * {64, 96, 112, 128} (attention width %d, heads %d)", wa, c->heads);
     MQ_CHECK_ARG(c->mlp_dim >= 64 && c->mlp_dim % 64 == 0, "encoder mlp_dim %d must be a multiple of 64", c->mlp_dim);
     MQ_CHECK_ARG(c->layers >= 0, "encoder layers < 0");
     MQ_CHECK_ARG(c->act == MQ_ACT_GELU || c->act == MQ_ACT_QUICKGELU, "encoder act %d unsupported", c->act);
@@ -71,9 +71,9 @@ int check_encoder_cfg(const mq_encoder_cfg* c) {
     return MQ_OK;
 }
 
-// attention width: heads * 64 (or heads * 128).  Equal to the model width for the B / L CLIP towers and BERT-base/large; models with
+// attention width: heads * {64, 96, 112, 128}.  Equal to the model width for the B / L CLIP towers and BERT-base/large; models with
 // other head dims (e5-small, bge-small, MiniLM: 12 heads of 32; ViT-H / g / bigG: 16 heads of 80 / 88 / 104) are loaded with their
-// Q/K/V rows and out-projection columns zero-padded to 64 / 128 per head (engine/towers.py), so QKV is [rows, 3*Wa], the attention output [rows, Wa] and the out-projection has K = Wa.
+// Q/K/V rows and out-projection columns zero-padded to 64 / 96 / 96 / 112 per head (engine/towers.py), so QKV is [rows, 3*Wa], the attention output [rows, Wa] and the out-projection has K = Wa.
 int attn_width(const mq_encoder_cfg* c) { return c->attn_width ? c->attn_width : c->width; }
 
 // scratch of one encoder pass: h bf16 [rows,W] | a bf16 [rows,Wa] | big bf16 [rows, max(3Wa,F)]

@@ -88,13 +88,13 @@ OPEN_CLIP_ARCHS = {
     "ViT-B-16-plus-240": (VitArch(240, 16, 896, 12, 14, 3584, 640), _TEXT_B_PLUS),
     "ViT-L-14": (VitArch(224, 14, 1024, 24, 16, 4096, 768), _TEXT_L),
     "ViT-L-14-336": (VitArch(336, 14, 1024, 24, 16, 4096, 768), _TEXT_L),
-    # 16 heads of 80 / 88 / 104: zero-padded to 128-wide heads at load (engine/towers.py::_pad_heads)
+    # 16 heads of 80 / 88 / 104: zero-padded to 96 / 96 / 112-wide heads at load (engine/towers.py::_pad_heads)
     "ViT-H-14": (VitArch(224, 14, 1280, 32, 16, 5120, 1024), _TEXT_H),
     "ViT-g-14": (VitArch(224, 14, 1408, 40, 16, 6144, 1024), _TEXT_H),
     "ViT-bigG-14": (VitArch(224, 14, 1664, 48, 16, 8192, 1280), _TEXT_BIGG),
 }
 # architectures the registry names but which are not plain CLIP ViTs (ResNet, ConvNeXt, EVA02, SigLIP, CoCa, roberta/xlm text
-# towers ...) or whose token count does not fit the LDS-resident attention at 128-wide heads (ViT-H-14-378: 730 tokens)
+# towers ...) or whose token count does not fit the LDS-resident attention with 256-byte LDS rows (ViT-H-14-378: 730 tokens)
 UNSUPPORTED_HINT = ("this open_clip architecture is not runnable by the marqo_amd engine yet "
                     "(supported: " + ", ".join(sorted(OPEN_CLIP_ARCHS)) + " and their -quickgelu variants)")
 

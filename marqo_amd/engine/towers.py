@@ -70,7 +70,7 @@ def _need(sd: Dict[str, Tensor], key: str, shape: Optional[Tuple[int, ...]] = No
 
 
 def _head_dim(width: int, heads: int) -> int:
-    """model head dim; the attention kernel runs 64- or 128-wide heads, anything else is zero-padded at load (_pad_heads)"""
+    """model head dim; the attention kernel runs 64- / 96- / 112- / 128-wide heads, anything else is zero-padded at load (_pad_heads)"""
     if heads < 1 or width % heads:
         raise ValueError(f"width {width} is not divisible by heads {heads}")
     d = width // heads
@@ -79,18 +79,25 @@ def _head_dim(width: int, heads: int) -> int:
     return d
 
 
-def _kernel_head_dim(d: int) -> int:
-    """head width the kernel runs for a model head dim d: 32 / 16 -> 64 (e5-small, MiniLM), 80 / 88 / 104 -> 128 (ViT-H / g / bigG)"""
-    return 64 if d <= 64 else 128
+KERNEL_HEAD_DIMS = (64, 96, 112, 128)  # head strides csrc/attention.hip is instantiated for
+
+
+def _kernel_head_dim(d: int, heads: int = 2) -> int:
+    """head width the kernel runs for a model head dim d: the smallest instantiated stride >= d whose attention width heads * hp
+    keeps the GEMM's K a multiple of 64: 32 / 16 -> 64 (e5-small, MiniLM), 80 / 88 -> 96 (ViT-H / g), 104 -> 112 (ViT-bigG)"""
+    for hp in KERNEL_HEAD_DIMS:
+        if hp >= d and (heads * hp) % 64 == 0:
+            return hp
+    return 128
 
 
 def _pad_heads(qkv_w: Tensor, qkv_b: Tensor, out_w: Tensor, heads: int, d: int) -> Tuple[Tensor, Tensor, Tensor]:
-    """[3W, W] / [3W] / [W, W] with d-wide heads -> [3*heads*hp, W] / [3*heads*hp] / [W, heads*hp] (hp = 64 or 128): each head's
-    Q / K / V rows and out-projection columns are zero-padded to hp (zero key / query dims add nothing to q.k, zero value dims meet
-    zero out-proj columns), and Q is scaled by sqrt(hp / d) so that the kernel's 1/sqrt(hp) softmax scale equals the model's
-    1/sqrt(d)."""
+    """[3W, W] / [3W] / [W, W] with d-wide heads -> [3*heads*hp, W] / [3*heads*hp] / [W, heads*hp] (hp = _kernel_head_dim): each
+    head's Q / K / V rows and out-projection columns are zero-padded to hp (zero key / query dims add nothing to q.k, zero value
+    dims meet zero out-proj columns), and Q is scaled by sqrt(hp / d) so that the kernel's 1/sqrt(hp) softmax scale equals the
+    model's 1/sqrt(d)."""
     W = out_w.shape[0]
-    hp = _kernel_head_dim(d)
+    hp = _kernel_head_dim(d, heads)
     q, k, v = qkv_w.float().view(3, heads, d, W).unbind(0)
     qb, kb, vb = qkv_b.float().view(3, heads, d).unbind(0)
     sc = (float(hp) / d) ** 0.5
@@ -104,7 +111,7 @@ def _pad_heads(qkv_w: Tensor, qkv_b: Tensor, out_w: Tensor, heads: int, d: int) 
 
 def _encoder_cfg(width, layers, heads, mlp_dim, quick_gelu, post_ln, mask, eps) -> L.EncoderCfg:
     d = _head_dim(width, heads)
-    hp = _kernel_head_dim(d)
+    hp = _kernel_head_dim(d, heads)
     return L.EncoderCfg(width=width, layers=layers, heads=heads, mlp_dim=mlp_dim,
                         act=L.MQ_ACT_QUICKGELU if quick_gelu else L.MQ_ACT_GELU,
                         post_ln=1 if post_ln else 0, mask=mask, ln_eps=eps, precision=L.MQ_PREC_BF16,
@@ -116,7 +123,7 @@ class _Fp8State:
     per-tensor activation scales [layers, 2] = (attention output, MLP hidden) with their calibration accumulator."""
 
     def __init__(self, lib, holder: "_Holder", blocks, layers: int, W: int, F: int, device: torch.device, Wa: Optional[int] = None):
-        Wa = Wa or W  # attention width (heads * 64 or heads * 128)
+        Wa = Wa or W  # attention width (heads * kernel head dim)
         self.scale = torch.full((layers, 2), 16.0 / 448.0, dtype=torch.float32, device=device)  # pre-calibration guess
         self.amax = torch.zeros(layers, 2, dtype=torch.float32, device=device)
         stream = torch.cuda.current_stream(device).cuda_stream
@@ -151,7 +158,7 @@ LN_FOLD = os.environ.get("MARQO_AMD_LN_FOLD", "0") == "1"
 
 def _clip_blocks(h: _Holder, sd, prefix: str, layers: int, W: int, F: int, heads: int):
     d = _head_dim(W, heads)
-    padded = d != _kernel_head_dim(d)  # ViT-H / g / bigG: 80 / 88 / 104-wide heads run as 128
+    padded = d != _kernel_head_dim(d, heads)  # ViT-H / g / bigG: 80 / 88 / 104-wide heads run as 96 / 96 / 112
     if padded and LN_FOLD:
         raise ValueError("MARQO_AMD_LN_FOLD=1 is not supported for models whose heads are padded")
     arr = (L.BlockWeights * layers)()
@@ -471,7 +478,7 @@ class BertTower(_TextTowerBase):
             qkv_w = torch.cat([_need(sd, p + f"attention.self.{n}.weight", (W, W)).detach().float() for n in ("query", "key", "value")], 0)
             qkv_b = torch.cat([_need(sd, p + f"attention.self.{n}.bias", (W,)).detach().float() for n in ("query", "key", "value")], 0)
             out_w = _need(sd, p + "attention.output.dense.weight", (W, W)).detach().float()
-            if hd != _kernel_head_dim(hd):  # e5-small / bge-small / MiniLM: 12 heads of 32
+            if hd != _kernel_head_dim(hd, arch.heads):  # e5-small / bge-small / MiniLM: 12 heads of 32
                 qkv_w, qkv_b, out_w = _pad_heads(qkv_w, qkv_b, out_w, arch.heads, hd)
             b.qkv_w, b.qkv_b = h.bf16(qkv_w), h.f32(qkv_b)
             b.out_w = h.bf16(out_w)

@@ -139,7 +139,10 @@ def _ref_attention(qkv, lens, heads, causal, hd=64):
                                                     ([16], 2, False, 64),
                                                     # 128-wide heads (ViT-H / g / bigG after padding): 257 tokens fill the 160 KiB of LDS
                                                     ([257] * 3, 16, False, 128), ([5, 77, 1, 33, 64, 65, 320], 3, True, 128),
-                                                    ([50] * 4, 5, False, 128), ([16], 1, False, 128)])
+                                                    ([50] * 4, 5, False, 128), ([16], 1, False, 128),
+                                                    # head strides 96 / 112 (80 / 88 / 104-wide heads padded): LDS rows stay 256 B
+                                                    ([257] * 3, 16, False, 96), ([257] * 2, 16, False, 112), ([5, 77, 1, 33, 64, 65, 320], 3, True, 96),
+                                                    ([5, 77, 1, 33, 64, 65, 320], 3, True, 112), ([50] * 4, 5, False, 96), ([16], 1, False, 112)])
 def test_attention(lib, lens, heads, causal, hd):
     from marqo_amd import _lib as L
     g = torch.Generator(device="cuda").manual_seed(5)

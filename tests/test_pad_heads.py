@@ -14,7 +14,7 @@ def _mha(x, qkv_w, qkv_b, out_w, heads, hd, scale):
     return (p @ v).transpose(0, 1).reshape(n, heads * hd) @ out_w.t()
 
 
-@pytest.mark.parametrize("d,hp", [(32, 64), (16, 64), (48, 64), (80, 128), (88, 128), (104, 128)])
+@pytest.mark.parametrize("d,hp", [(32, 64), (16, 64), (48, 64), (80, 96), (88, 96), (104, 112), (120, 128)])
 def test_pad_heads_preserves_attention(d, hp):
     heads, n = 4, 9
     W = heads * d
@@ -24,7 +24,7 @@ def test_pad_heads_preserves_attention(d, hp):
     qkv_b = torch.randn(3 * W, generator=g, dtype=torch.float64) * 0.1
     out_w = torch.randn(W, W, generator=g, dtype=torch.float64) * W ** -0.5
     ref = _mha(x, qkv_w, qkv_b, out_w, heads, d, d ** -0.5)
-    assert T._kernel_head_dim(d) == hp and T._head_dim(W, heads) == d
+    assert T._kernel_head_dim(d, heads) == hp and T._head_dim(W, heads) == d
     w2, b2, o2 = T._pad_heads(qkv_w, qkv_b, out_w, heads, d)
     assert w2.shape == (3 * heads * hp, W) and b2.shape == (3 * heads * hp,) and o2.shape == (W, heads * hp)
     got = _mha(x.float(), w2, b2, o2, heads, hp, hp ** -0.5)   # the kernel's scale is 1/sqrt(hp)
@@ -34,7 +34,9 @@ def test_pad_heads_preserves_attention(d, hp):
 def test_encoder_cfg_attention_width():
     assert T._encoder_cfg(768, 12, 12, 3072, False, False, 0, 1e-5).attn_width == 0          # 64-wide heads: nothing padded
     assert T._encoder_cfg(384, 12, 12, 1536, False, True, 0, 1e-12).attn_width == 12 * 64    # e5-small
-    assert T._encoder_cfg(1280, 32, 16, 5120, False, False, 0, 1e-5).attn_width == 16 * 128  # ViT-H-14
+    assert T._encoder_cfg(1280, 32, 16, 5120, False, False, 0, 1e-5).attn_width == 16 * 96   # ViT-H-14: 80 -> 96
+    assert T._encoder_cfg(1664, 48, 16, 8192, False, False, 0, 1e-5).attn_width == 16 * 112  # ViT-bigG-14: 104 -> 112
+    assert T._encoder_cfg(240, 2, 3, 960, False, False, 0, 1e-5).attn_width == 3 * 128        # 3 heads of 80: 3 * 96 is not a multiple of 64
     assert T._encoder_cfg(2048, 2, 16, 8192, False, False, 0, 1e-5).attn_width == 0          # native 128-wide heads
     with pytest.raises(ValueError):
         T._encoder_cfg(2048, 2, 8, 8192, False, False, 0, 1e-5)                               # 256-wide heads
