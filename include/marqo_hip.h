@@ -410,11 +410,12 @@ int mq_weighted_combine(const float* d_emb, int64_t ld, const int32_t* d_rows, c
                         void* stream);
 
 /* Run-time selection of a kernel variant (benchmark A/B and parity tests of every variant in one process).
- * keys: "gemm_mt" (0 = auto, else GEMM tile height in 32-row units), "gemm_spec" (1 = producer/consumer wave
- * specialisation), "gemm_big" (4 / 6 / 8 = one-workgroup-per-CU (32*v) x 256 tile, 0 = off), "row_select" (0 = the towers run their last
- * block on every row instead of the pooled rows only), "ln_fold" (0 = keep the separate LayerNorm kernels), "gemm_persist",
- * "gemm_cgroup", "gemm_wide" (GEMM scheduling knobs, see csrc/gemm_bf16.hip).  Initial values come from
- * the environment (MQ_GEMM_MT, MQ_GEMM_SPEC, MQ_GEMM_BIG). */
+ * keys: "gemm_mt" (0 = auto, else GEMM tile height in 32-row units), "gemm_big" (4 / 5 / 6 / 8 = one-workgroup-per-CU
+ * (32*v) x 256 tile, 0 = off), "gemm_k32" (3 = 128x128x32 tiles, three workgroups per CU), "gemm_persist", "gemm_cgroup",
+ * "gemm_wide" (GEMM scheduling knobs, see csrc/gemm_bf16.hip), "row_select" (0 = the towers run their last block on every row
+ * instead of the pooled rows only), "ln_fold" (1 = LayerNorm folded into the GEMM epilogues, needs folded weights), "ln_rows"
+ * (rows per LayerNorm wave), "attn_waves" (0 = auto, 4 / 8 wave64s per attention workgroup).  Initial values come from the
+ * environment (MQ_GEMM_MT, MQ_GEMM_BIG, MQ_GEMM_PERSIST, MQ_GEMM_CGROUP, MQ_GEMM_WIDE, MQ_GEMM_K32, MQ_ROW_SELECT, MQ_LN_FOLD). */
 int mq_tune(const char* key, int value);
 
 /* ---- per-kernel timing (bench.py roofline) ------------------------------------------- */

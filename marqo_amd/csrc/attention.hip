@@ -27,8 +27,10 @@ namespace {
 
 // OUT_FP8: the output is written as e4m3 codes = value / *out_scale (static per-tensor scale of the fp8 path, K13) and
 // max|value| is folded into *amax when it is non-null (calibration).
-template <int MASK, bool OUT_FP8, int HD, int HS>
-__global__ __launch_bounds__(256) void attention_kernel(
+// NW = wave64s per workgroup: 4, or 8 for sequences of more than 128 tokens (>= 9 sixteen-query blocks): their K / V image lets
+// only one or two workgroups share a CU, so the extra waves per SIMD have to come from inside the workgroup.
+template <int MASK, bool OUT_FP8, int HD, int HS, int NW>
+__global__ __launch_bounds__(NW * 64) void attention_kernel(
     const bf16_t* __restrict__ qkv, void* __restrict__ out_v, const int32_t* __restrict__ cu,
     int fixed_len, int W, int heads, int kpad, float scale_log2e, const float* __restrict__ out_scale, float* amax_out) {
     bf16_t* out = (bf16_t*)out_v;
@@ -62,7 +64,7 @@ __global__ __launch_bounds__(256) void attention_kernel(
     {
         const int np8 = kp / RPP;
         const int srow = lane / NC, pchunk = lane % NC;
-        for (int p = wave; p < 2 * np8; p += 4) {
+        for (int p = wave; p < 2 * np8; p += NW) {
             const bool is_v = p >= np8;
             const int piece = is_v ? p - np8 : p;
             const int row = piece * RPP + srow;
@@ -99,13 +101,13 @@ __global__ __launch_bounds__(256) void attention_kernel(
     const int vkey = 4 * g + (l15 >> 2);
     const int vcol = (l15 & 3) >> 1, vhalf = (l15 & 1) << 3;
 
-    for (int qblk = wave; qblk < nqb; qblk += 4) {
+    for (int qblk = wave; qblk < nqb; qblk += NW) {
         const int q = qblk * 16 + l15;           // this lane's query (B-operand column / output row)
         bf16x8 qf[NKK];
 #pragma unroll
         for (int kk = 0; kk < NKK; ++kk) qf[kk] = qn[kk];
-        if (qblk + 4 < nqb) {                    // next block's Q streams in behind this block's math
-            const int q2 = q + 64;
+        if (qblk + NW < nqb) {                   // next block's Q streams in behind this block's math
+            const int q2 = q + 16 * NW;
             const int qr = q2 < len ? q2 : len - 1;
 #pragma unroll
             for (int kk = 0; kk < NKK; ++kk) qn[kk] = load_q(qr, kk);
@@ -237,6 +239,8 @@ __global__ __launch_bounds__(256) void attention_kernel(
 
 }  // namespace
 
+int mq_attention_waves = 0;  // mq_tune("attn_waves", 0 = auto / 4 / 8): A/B knob
+
 extern "C" int mq_attention_ex(const void* d_qkv, void* d_out, const int32_t* d_cu_seqlens, int64_t nseq,
                                int32_t fixed_len, int32_t max_len, int32_t W, int32_t heads, int32_t mask,
                                int32_t out_fp8, const float* d_out_scale, float* d_amax, void* stream) {
@@ -255,6 +259,10 @@ extern "C" int mq_attention_ex(const void* d_qkv, void* d_out, const int32_t* d_
     const size_t lds = (size_t)kpad * hd * 4;  // K + V rows of hd bf16 each
     MQ_CHECK_ARG(lds <= 160 * 1024, "mq_attention: sequence length %d needs %zu B of LDS (> 160 KiB)", maxl, lds);
     hipStream_t s = (hipStream_t)stream;
+    // 8 waves from 9 query blocks up (measured, profiles/r01f_attention_waves_ab.txt: -25..-33 % at 257 / 512 / 577 tokens, where a
+    // workgroup's K / V image leaves room for one or two workgroups per CU; +6..+25 % at 77 / 50 tokens, whose 5 / 4 blocks leave
+    // the extra waves idle)
+    const int nw = mq_attention_waves == 4 || mq_attention_waves == 8 ? mq_attention_waves : (maxl > 128 ? 8 : 4);
     const float scale_log2e = 1.44269504088896340736f / sqrtf((float)hs);  // 1/sqrt(head dim) * log2(e)
     MqProfScope prof(2, s);
     auto launch = [&](auto kern) -> int {
@@ -262,16 +270,19 @@ extern "C" int mq_attention_ex(const void* d_qkv, void* d_out, const int32_t* d_
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) { mq_set_error("mq_attention: hipFuncSetAttribute: %s", hipGetErrorString(e)); return MQ_ERR_HIP; }
         }
-        hipLaunchKernelGGL(kern, dim3((unsigned)(nseq * heads)), dim3(256), lds, s, (const bf16_t*)d_qkv,
+        hipLaunchKernelGGL(kern, dim3((unsigned)(nseq * heads)), dim3(nw * 64), lds, s, (const bf16_t*)d_qkv,
                            d_out, d_cu_seqlens, (int)fixed_len, (int)W, (int)heads, kpad, scale_log2e, d_out_scale, d_amax);
         return MQ_OK;
     };
     MQ_CHECK_ARG(!out_fp8 || d_out_scale, "mq_attention: fp8 output needs an out_scale");
     int rc;
+    auto pick_nw = [&](auto hd_tag, auto hs_tag, auto nw_tag) -> int {
+        constexpr int HD_ = decltype(hd_tag)::value, HS_ = decltype(hs_tag)::value, NW_ = decltype(nw_tag)::value;
+        if (out_fp8) return (mask == MQ_MASK_CAUSAL) ? launch(attention_kernel<MQ_MASK_CAUSAL, true, HD_, HS_, NW_>) : launch(attention_kernel<MQ_MASK_NONE, true, HD_, HS_, NW_>);
+        return (mask == MQ_MASK_CAUSAL) ? launch(attention_kernel<MQ_MASK_CAUSAL, false, HD_, HS_, NW_>) : launch(attention_kernel<MQ_MASK_NONE, false, HD_, HS_, NW_>);
+    };
     auto pick = [&](auto hd_tag, auto hs_tag) -> int {
-        constexpr int HD_ = decltype(hd_tag)::value, HS_ = decltype(hs_tag)::value;
-        if (out_fp8) return (mask == MQ_MASK_CAUSAL) ? launch(attention_kernel<MQ_MASK_CAUSAL, true, HD_, HS_>) : launch(attention_kernel<MQ_MASK_NONE, true, HD_, HS_>);
-        return (mask == MQ_MASK_CAUSAL) ? launch(attention_kernel<MQ_MASK_CAUSAL, false, HD_, HS_>) : launch(attention_kernel<MQ_MASK_NONE, false, HD_, HS_>);
+        return nw == 8 ? pick_nw(hd_tag, hs_tag, std::integral_constant<int, 8>{}) : pick_nw(hd_tag, hs_tag, std::integral_constant<int, 4>{});
     };
     using std::integral_constant;
     switch (hs) {

@@ -25,6 +25,7 @@ extern int mq_gemm_fp8_force_mt;  // gemm_fp8.hip
 extern int mq_tower_row_select;   // towers.hip
 extern int mq_tower_ln_fold;      // towers.hip
 extern int mq_ln_rows_per_wave;   // rowops.hip
+extern int mq_attention_waves;    // attention.hip
 
 // CU-sized-tile main loop (gemm_big.hip)
 template <int FLAGS>
@@ -459,6 +460,7 @@ extern "C" int mq_tune(const char* key, int value) {
     else if (k == "row_select") mq_tower_row_select = value;
     else if (k == "ln_fold") mq_tower_ln_fold = value;
     else if (k == "ln_rows") mq_ln_rows_per_wave = value;
+    else if (k == "attn_waves") mq_attention_waves = value;
     else { mq_set_error("mq_tune: unknown key %s", key); return MQ_ERR_INVALID; }
     return MQ_OK;
 }

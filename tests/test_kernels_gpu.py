@@ -159,3 +159,14 @@ def test_attention(lib, lens, heads, causal, hd):
     err = (out.float() - ref).abs().max().item()
     # P is rounded to bf16 before P.V (8 mantissa bits) and the output is bf16
     assert err < 2e-2, err
+    # 4 or 8 waves per workgroup (auto: 8 once K + V exceed 80 KiB of LDS) walk the same query blocks: identical bits
+    try:
+        for nw in (4, 8):
+            L.check(lib.mq_tune(b"attn_waves", nw))
+            out2 = torch.empty_like(out)
+            L.check(lib.mq_attention(qkv.data_ptr(), out2.data_ptr(), 0 if fixed else cu.data_ptr(), len(lens), fixed, max(lens), W, heads,
+                                     L.MQ_MASK_CAUSAL if causal else L.MQ_MASK_NONE, _stream()))
+            torch.cuda.synchronize()
+            assert torch.equal(out2, out), nw
+    finally:
+        L.check(lib.mq_tune(b"attn_waves", 0))
