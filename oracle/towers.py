@@ -21,6 +21,10 @@ follow the reference's own call sites for everything around them:
                             (src/marqo/core/inference/embedding_models/hugging_face_model.py:172-214)
 * ``l2_normalize_clip``  <- ``outputs /= self.normalize(outputs)`` (open_clip_model.py:262-265,
                             abstract_clip_model.py:83-85)
+* ``siglip_vit_forward`` / ``siglip_text_forward`` <- the same two call sites for the SigLIP registry entries
+                            (model_registry.py:371-432, 489-494: ``ViT-*-SigLIP*/webli``, ``Marqo/marqo-fashionSigLIP``):
+                            open_clip builds them as ``TimmModel`` (timm ``vit_*_siglip_*``: no class token, no ln_pre,
+                            attention-pool head) + ``TextTransformer(no_causal_mask, pool_type='last', proj_bias)``
 
 Pinning status
 --------------
@@ -33,6 +37,9 @@ Pinning status
   architecture; ``open_clip`` itself is not installable here).  The reference holds NO golden vector
   for ``open_clip/ViT-B-32/laion2b_s34b_b79k`` or ``ViT-L-14`` and real checkpoints are unavailable
   offline -> for real open_clip weights parity remains **unpinned** (SURVEY.md §8c).
+
+* SigLIP towers: pinned against ``transformers.SiglipVisionModel`` / ``SiglipTextModel`` (``hidden_act='gelu'``: timm's
+  SigLIP ViTs use nn.GELU) with the weights renamed to the open_clip / timm checkpoint naming; ``timm`` itself is not installed.
 
 State-dict conventions: open_clip names for CLIP (``visual.*``, ``transformer.resblocks.*``,
 ``token_embedding.weight`` ...), HuggingFace names for BERT (``embeddings.*``, ``encoder.layer.*``).
@@ -101,6 +108,34 @@ class BertConfig:
 # --------------------------------------------------------------------------------------------
 # shared pieces
 # --------------------------------------------------------------------------------------------
+@dataclass
+class SiglipVitConfig:
+    """timm ``vit_{base,large}_patch16_siglip_*`` behind open_clip's TimmModel (pool 'map', proj 'none': out dim = width)"""
+    image_size: int = 224
+    patch_size: int = 16
+    width: int = 768
+    layers: int = 12
+    heads: int = 12
+    mlp_dim: int = 3072
+    ln_eps: float = 1e-6
+
+    @property
+    def tokens(self) -> int:
+        return (self.image_size // self.patch_size) ** 2
+
+
+@dataclass
+class SiglipTextConfig:
+    vocab: int = 32000
+    ctx: int = 64
+    width: int = 768
+    layers: int = 12
+    heads: int = 12
+    mlp_dim: int = 3072
+    out_dim: int = 768
+    ln_eps: float = 1e-6
+
+
 def _act(x: Tensor, quick: bool) -> Tensor:
     if quick:
         return x * torch.sigmoid(1.702 * x)  # open_clip QuickGELU
@@ -179,6 +214,52 @@ def clip_text_forward(sd: Dict[str, Tensor], cfg: ClipTextConfig, ids: Tensor, n
     x = F.layer_norm(x, (W,), sd["ln_final.weight"], sd["ln_final.bias"], cfg.ln_eps)
     pooled = x[torch.arange(B), ids.argmax(dim=-1)]
     out = pooled @ sd["text_projection"]
+    return l2_normalize_clip(out) if normalize else out
+
+
+@torch.no_grad()
+def siglip_vit_forward(sd: Dict[str, Tensor], cfg: SiglipVitConfig, pixels: Tensor, normalize: bool = True) -> Tensor:
+    """timm VisionTransformer (class_token=False, global_pool='map', pre-LN blocks, nn.GELU, LayerNorm eps 1e-6) as open_clip's
+    ``visual.trunk``: patch_embed (conv WITH bias) + pos_embed -> blocks -> norm -> AttentionPoolLatent -> (head = Identity).
+    AttentionPoolLatent: q = Linear(latent) [1 query], k, v = Linear(x).chunk(2), softmax(q k^T / sqrt(hd)) v -> proj;
+    x = x + mlp(norm(x)); pooled = x[:, 0].   pixels: fp32 [B, 3, S, S] preprocessed."""
+    W, H = cfg.width, cfg.heads
+    t = "visual.trunk."
+    x = F.conv2d(pixels, sd[t + "patch_embed.proj.weight"], sd[t + "patch_embed.proj.bias"], stride=cfg.patch_size)
+    B = x.shape[0]
+    x = x.reshape(B, W, -1).permute(0, 2, 1) + sd[t + "pos_embed"]  # [B, N, W]
+    for i in range(cfg.layers):
+        p = f"{t}blocks.{i}."
+        h = F.layer_norm(x, (W,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], cfg.ln_eps)
+        x = x + _mha(h, sd[p + "attn.qkv.weight"], sd[p + "attn.qkv.bias"], sd[p + "attn.proj.weight"], sd[p + "attn.proj.bias"], H, None)
+        h = F.layer_norm(x, (W,), sd[p + "norm2.weight"], sd[p + "norm2.bias"], cfg.ln_eps)
+        h = F.gelu(F.linear(h, sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"]))
+        x = x + F.linear(h, sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"])
+    x = F.layer_norm(x, (W,), sd[t + "norm.weight"], sd[t + "norm.bias"], cfg.ln_eps)
+    a = t + "attn_pool."
+    N, hd = x.shape[1], W // H
+    q = F.linear(sd[a + "latent"].expand(B, -1, -1), sd[a + "q.weight"], sd[a + "q.bias"]).view(B, 1, H, hd).transpose(1, 2)
+    kv = F.linear(x, sd[a + "kv.weight"], sd[a + "kv.bias"]).view(B, N, 2, H, hd).permute(2, 0, 3, 1, 4)
+    k, v = kv[0], kv[1]
+    o = torch.softmax((q @ k.transpose(-1, -2)) / math.sqrt(hd), dim=-1) @ v           # [B, H, 1, hd]
+    y = F.linear(o.transpose(1, 2).reshape(B, 1, W), sd[a + "proj.weight"], sd[a + "proj.bias"])
+    h = F.layer_norm(y, (W,), sd[a + "norm.weight"], sd[a + "norm.bias"], cfg.ln_eps)
+    y = y + F.linear(F.gelu(F.linear(h, sd[a + "mlp.fc1.weight"], sd[a + "mlp.fc1.bias"])), sd[a + "mlp.fc2.weight"], sd[a + "mlp.fc2.bias"])
+    out = y[:, 0]
+    return l2_normalize_clip(out) if normalize else out
+
+
+@torch.no_grad()
+def siglip_text_forward(sd: Dict[str, Tensor], cfg: SiglipTextConfig, ids: Tensor, normalize: bool = True) -> Tensor:
+    """open_clip TextTransformer(no_causal_mask=True, pool_type='last', proj_bias=True) under CustomTextCLIP (``text.*`` keys):
+    every one of the ctx positions (padding included — there is no padding mask) attends to every other; the pooled row is the
+    LAST position; text_projection is a Linear with bias.  ids: int64 [B, ctx] padded with the pad id (1)."""
+    B, T = ids.shape
+    W = cfg.width
+    x = sd["text.token_embedding.weight"][ids] + sd["text.positional_embedding"][:T]
+    x = _clip_resblocks(x, sd, "text.transformer.", cfg.layers, cfg.heads, False, cfg.ln_eps, None)
+    x = F.layer_norm(x, (W,), sd["text.ln_final.weight"], sd["text.ln_final.bias"], cfg.ln_eps)
+    out = F.linear(x[:, -1], sd["text.text_projection.weight"], sd["text.text_projection.bias"])
     return l2_normalize_clip(out) if normalize else out
 
 
@@ -287,6 +368,38 @@ def synthetic_clip_text_state_dict(cfg: ClipTextConfig, seed: int = 0) -> Dict[s
     sd["ln_final.weight"] = 1 + 0.1 * torch.randn(W, generator=g)
     sd["ln_final.bias"] = 0.05 * torch.randn(W, generator=g)
     sd["text_projection"] = std * torch.randn(W, cfg.out_dim, generator=g)
+    return sd
+
+
+def synthetic_siglip_state_dict(vcfg: SiglipVitConfig, tcfg: Optional[SiglipTextConfig] = None, seed: int = 0) -> Dict[str, Tensor]:
+    """random-init SigLIP towers in the open_clip / timm checkpoint naming (visual.trunk.*, text.*)"""
+    g = _g(seed)
+    W, F_, std = vcfg.width, vcfg.mlp_dim, 0.02
+    rn = lambda *shape, sc=std: torch.randn(*shape, generator=g) * sc
+    t = "visual.trunk."
+    sd = {t + "patch_embed.proj.weight": rn(W, 3, vcfg.patch_size, vcfg.patch_size), t + "patch_embed.proj.bias": rn(W, sc=0.1),
+          t + "pos_embed": rn(1, vcfg.tokens, W), t + "norm.weight": 1.0 + rn(W, sc=0.1), t + "norm.bias": rn(W, sc=0.1)}
+    for i in range(vcfg.layers):
+        p = f"{t}blocks.{i}."
+        sd.update({p + "norm1.weight": 1.0 + rn(W, sc=0.1), p + "norm1.bias": rn(W, sc=0.1),
+                   p + "attn.qkv.weight": rn(3 * W, W), p + "attn.qkv.bias": rn(3 * W, sc=0.1),
+                   p + "attn.proj.weight": rn(W, W), p + "attn.proj.bias": rn(W, sc=0.1),
+                   p + "norm2.weight": 1.0 + rn(W, sc=0.1), p + "norm2.bias": rn(W, sc=0.1),
+                   p + "mlp.fc1.weight": rn(F_, W), p + "mlp.fc1.bias": rn(F_, sc=0.1),
+                   p + "mlp.fc2.weight": rn(W, F_), p + "mlp.fc2.bias": rn(W, sc=0.1)})
+    a = t + "attn_pool."
+    sd.update({a + "latent": rn(1, 1, W, sc=W ** -0.5), a + "q.weight": rn(W, W, sc=0.05), a + "q.bias": rn(W, sc=0.1),
+               a + "kv.weight": rn(2 * W, W, sc=0.05), a + "kv.bias": rn(2 * W, sc=0.1),
+               a + "proj.weight": rn(W, W, sc=0.05), a + "proj.bias": rn(W, sc=0.1),
+               a + "norm.weight": 1.0 + rn(W, sc=0.1), a + "norm.bias": rn(W, sc=0.1),
+               a + "mlp.fc1.weight": rn(F_, W), a + "mlp.fc1.bias": rn(F_, sc=0.1),
+               a + "mlp.fc2.weight": rn(W, F_), a + "mlp.fc2.bias": rn(W, sc=0.1)})
+    if tcfg is not None:
+        Wt = tcfg.width
+        sd.update({"text.token_embedding.weight": rn(tcfg.vocab, Wt), "text.positional_embedding": rn(tcfg.ctx, Wt, sc=0.01),
+                   "text.ln_final.weight": 1.0 + rn(Wt, sc=0.1), "text.ln_final.bias": rn(Wt, sc=0.1),
+                   "text.text_projection.weight": rn(tcfg.out_dim, Wt, sc=Wt ** -0.5), "text.text_projection.bias": rn(tcfg.out_dim, sc=0.1)})
+        _blocks_clip(sd, "text.transformer.", tcfg.layers, Wt, tcfg.mlp_dim, g, std)
     return sd
 
 

@@ -13,6 +13,9 @@ run on seeded inputs in fp32 on CPU, and the (weights, inputs, outputs) triple i
                       hugging_face_model.py:187-214.
 * ``clip_vit_small``  transformers.CLIPVisionModelWithProjection (gelu and quick_gelu variants)
 * ``clip_text_small`` transformers.CLIPTextModelWithProjection (argmax-EOT pooling)
+* ``siglip_small``    transformers.SiglipVisionModel (attention-pool head) + SiglipTextModel (no mask, last-token pooling,
+                      biased projection), hidden_act='gelu' like timm's SigLIP ViTs; weights renamed to the open_clip / timm
+                      checkpoint naming (visual.trunk.*, text.*)
 
 Head dim is 64 in every fixture (the engine's attention kernel is specialised for d_head = 64, as
 are all four towers of BASELINE.json's configs).
@@ -194,12 +197,72 @@ def make_clip_text():
                         **{"w:" + k: v for k, v in _np(sd_oc).items()})
 
 
+def make_siglip():
+    from transformers import SiglipTextConfig, SiglipTextModel, SiglipVisionConfig, SiglipVisionModel
+    torch.manual_seed(9)
+    W, Fd, Lyr, H, S, P = 128, 256, 2, 2, 64, 16
+    vc = SiglipVisionConfig(hidden_size=W, intermediate_size=Fd, num_hidden_layers=Lyr, num_attention_heads=H, image_size=S,
+                            patch_size=P, hidden_act="gelu", layer_norm_eps=1e-6, attention_dropout=0.0)
+    vm = SiglipVisionModel(vc).eval()
+    _jitter(vm, 10)
+    with torch.no_grad():
+        dict(vm.named_parameters())[[k for k, _ in vm.named_parameters() if k.endswith("head.probe")][0]].mul_(1.0 / 3.0).add_(0.3 * torch.randn(1, 1, W, generator=torch.Generator().manual_seed(11)))
+    hf = {k.replace("vision_model.", "", 1) if k.startswith("vision_model.") else k: v for k, v in vm.state_dict().items()}
+    g = torch.Generator().manual_seed(12)
+    px = torch.randn(5, 3, S, S, generator=g)
+    with torch.no_grad():
+        img = vm(pixel_values=px).pooler_output
+    t = "visual.trunk."
+    sd = {t + "patch_embed.proj.weight": hf["embeddings.patch_embedding.weight"], t + "patch_embed.proj.bias": hf["embeddings.patch_embedding.bias"],
+          t + "pos_embed": hf["embeddings.position_embedding.weight"].unsqueeze(0),
+          t + "norm.weight": hf["post_layernorm.weight"], t + "norm.bias": hf["post_layernorm.bias"]}
+    for i in range(Lyr):
+        s_, d = f"encoder.layers.{i}.", f"{t}blocks.{i}."
+        sd[d + "norm1.weight"], sd[d + "norm1.bias"] = hf[s_ + "layer_norm1.weight"], hf[s_ + "layer_norm1.bias"]
+        sd[d + "attn.qkv.weight"] = torch.cat([hf[s_ + f"self_attn.{n}_proj.weight"] for n in "qkv"], 0)
+        sd[d + "attn.qkv.bias"] = torch.cat([hf[s_ + f"self_attn.{n}_proj.bias"] for n in "qkv"], 0)
+        sd[d + "attn.proj.weight"], sd[d + "attn.proj.bias"] = hf[s_ + "self_attn.out_proj.weight"], hf[s_ + "self_attn.out_proj.bias"]
+        sd[d + "norm2.weight"], sd[d + "norm2.bias"] = hf[s_ + "layer_norm2.weight"], hf[s_ + "layer_norm2.bias"]
+        for n in ("fc1", "fc2"):
+            sd[d + f"mlp.{n}.weight"], sd[d + f"mlp.{n}.bias"] = hf[s_ + f"mlp.{n}.weight"], hf[s_ + f"mlp.{n}.bias"]
+    a = t + "attn_pool."
+    ipw, ipb = hf["head.attention.in_proj_weight"], hf["head.attention.in_proj_bias"]
+    sd.update({a + "latent": hf["head.probe"], a + "q.weight": ipw[:W], a + "q.bias": ipb[:W], a + "kv.weight": ipw[W:], a + "kv.bias": ipb[W:],
+               a + "proj.weight": hf["head.attention.out_proj.weight"], a + "proj.bias": hf["head.attention.out_proj.bias"],
+               a + "norm.weight": hf["head.layernorm.weight"], a + "norm.bias": hf["head.layernorm.bias"]})
+    for n in ("fc1", "fc2"):
+        sd[a + f"mlp.{n}.weight"], sd[a + f"mlp.{n}.bias"] = hf[f"head.mlp.{n}.weight"], hf[f"head.mlp.{n}.bias"]
+
+    V, ctx, D = 300, 16, 64
+    tc = SiglipTextConfig(vocab_size=V, hidden_size=W, intermediate_size=Fd, num_hidden_layers=Lyr, num_attention_heads=H,
+                          max_position_embeddings=ctx, hidden_act="gelu", layer_norm_eps=1e-6, attention_dropout=0.0, projection_size=D)
+    tm = SiglipTextModel(tc).eval()
+    _jitter(tm, 13)
+    ht = {(k if k.startswith("text_model.") else "text_model." + k): v for k, v in tm.state_dict().items()}
+    lens = [3, 16, 9, 5, 12]
+    ids = torch.ones(len(lens), ctx, dtype=torch.int64)  # pad id 1 (= </s>), which is also the EOS that ends each text
+    for i, n in enumerate(lens):
+        ids[i, :n - 1] = torch.randint(2, V, (n - 1,), generator=g)
+    with torch.no_grad():
+        txt = tm(input_ids=ids).pooler_output
+    tp = "text_model."
+    sd.update({"text.token_embedding.weight": ht[tp + "embeddings.token_embedding.weight"],
+               "text.positional_embedding": ht[tp + "embeddings.position_embedding.weight"],
+               "text.ln_final.weight": ht[tp + "final_layer_norm.weight"], "text.ln_final.bias": ht[tp + "final_layer_norm.bias"],
+               "text.text_projection.weight": ht[tp + "head.weight"], "text.text_projection.bias": ht[tp + "head.bias"]})
+    sd.update(_clip_blocks_to_open_clip(ht, tp, "text.transformer.", Lyr))
+    np.savez_compressed(os.path.join(HERE, "siglip_small.npz"), pixels=px.numpy(), image_emb=img.numpy(), ids=ids.numpy(), text_emb=txt.numpy(),
+                        cfg=np.array([S, P, W, Lyr, H, Fd, V, ctx, D], dtype=np.int64),  # S P W layers heads F | vocab ctx D (text: same W/L/H/F)
+                        **{"w:" + k: v for k, v in _np(sd).items()})
+
+
 if __name__ == "__main__":
     make_bert()
     make_bert(heads=4, name="bert_small_h32.npz")  # 32-wide heads (e5-small / bge-small / MiniLM class)
     make_xlmr()
     make_clip_vit()
     make_clip_text()
+    make_siglip()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -105,3 +105,20 @@ def test_bert_with_32_wide_heads_matches_transformers():
     cfg = O.BertConfig(vocab=V, max_pos=P, width=W, layers=L, heads=H, mlp_dim=F, pooling="mean")
     assert np.abs(O.bert_forward(sd, cfg, ids, mask).numpy() - z["last_hidden"])[mask.bool().numpy()].max() < TOL
     assert np.abs(O.hf_encode(sd, cfg, ids, mask, normalize=True).numpy() - z["mean_norm"]).max() < TOL
+
+
+def test_siglip_towers_match_transformers():
+    """SigLIP (model_registry.py:371-432, 489-494): timm-style ViT with attention-pool head, unmasked text tower with
+    last-token pooling and a biased projection; pinned to transformers.SiglipVisionModel / SiglipTextModel (tolerance
+    relative to the O(5) outputs)."""
+    sd, z = G.load("siglip_small")
+    S, P, W, Lyr, H, Fd, V, ctx, D = [int(v) for v in z["cfg"]]
+    img = O.siglip_vit_forward(sd, O.SiglipVitConfig(S, P, W, Lyr, H, Fd), torch.from_numpy(z["pixels"]), normalize=False)
+    assert np.abs(img.numpy() - z["image_emb"]).max() < 5 * TOL
+    txt = O.siglip_text_forward(sd, O.SiglipTextConfig(V, ctx, W, Lyr, H, Fd, D), torch.from_numpy(z["ids"]), normalize=False)
+    assert np.abs(txt.numpy() - z["text_emb"]).max() < 5 * TOL
+    n = O.siglip_vit_forward(sd, O.SiglipVitConfig(S, P, W, Lyr, H, Fd), torch.from_numpy(z["pixels"]))
+    assert torch.allclose(n.norm(dim=-1), torch.ones(n.shape[0]), atol=1e-6)
+    # the synthetic state dict used by the GPU parity tests has the same key set / shapes
+    syn = O.synthetic_siglip_state_dict(O.SiglipVitConfig(S, P, W, Lyr, H, Fd), O.SiglipTextConfig(V, ctx, W, Lyr, H, Fd, D), seed=1)
+    assert {k: tuple(v.shape) for k, v in syn.items()} == {k: tuple(v.shape) for k, v in sd.items()}
