@@ -45,7 +45,7 @@ extern "C" {
 #define MQ_ERR_HIP (-2)       /* a HIP runtime call or launch failed */
 #define MQ_ERR_WORKSPACE (-3) /* caller's workspace too small */
 
-#define MQ_ABI_VERSION 3
+#define MQ_ABI_VERSION 4
 
 /* ---- activation / mask / pooling selectors ---------------------------------------- */
 #define MQ_ACT_NONE 0
@@ -61,6 +61,9 @@ extern "C" {
 
 #define MQ_POOL_MEAN 0 /* hugging_face_model.py:205-209 */
 #define MQ_POOL_CLS 1  /* hugging_face_model.py:211-214 */
+
+#define MQ_VIT_POOL_CLS 0 /* open_clip VisionTransformer: class token */
+#define MQ_VIT_POOL_MAP 1 /* timm SigLIP ViT: attention-pool ('map') head */
 
 /* GEMM epilogue flags for mq_gemm_bf16 */
 #define MQ_EPI_BIAS 1      /* + bias[n] (fp32) */
@@ -114,14 +117,26 @@ typedef struct mq_encoder_cfg {
 
 /* ---- towers ------------------------------------------------------------------------ */
 
+/* timm AttentionPoolLatent, the 'map' pooling head of the SigLIP ViTs (open_clip TimmModel, pool = "map"): one learned query
+ * attends over all tokens, then x = x + mlp(norm(x)) */
+typedef struct mq_map_head {
+    const float* q;                            /* fp32 [W]: Linear_q(latent), computed once at load, times 1/sqrt(W / heads) */
+    const void*  kv_w;   const float* kv_b;    /* bf16 [2W, W], fp32 [2W]  (keys | values) */
+    const void*  proj_w; const float* proj_b;  /* bf16 [W, W], fp32 [W] */
+    const float* ln_g;   const float* ln_b;    /* fp32 [W] */
+    const void*  fc1_w;  const float* fc1_b;   /* bf16 [F, W], fp32 [F] */
+    const void*  fc2_w;  const float* fc2_b;   /* bf16 [W, F], fp32 [W] */
+} mq_map_head;
+
 typedef struct mq_vit_weights {
     const void*  patch_w;      /* bf16 [W, Kp]  conv1 weight flattened (c, ky, kx), K zero-padded to Kp = ceil64(3*P*P) */
-    const float* cls;          /* [W]   class embedding */
-    const float* pos;          /* [T, W] positional embedding, T = 1 + (S/P)^2 */
-    const float* ln_pre_g; const float* ln_pre_b;
+    const float* cls;          /* [W]   class embedding (MQ_VIT_POOL_MAP: NULL, there is no class token) */
+    const float* pos;          /* [T, W] positional embedding, T = 1 + (S/P)^2 (MQ_VIT_POOL_MAP: T = (S/P)^2, patch bias added in) */
+    const float* ln_pre_g; const float* ln_pre_b;   /* MQ_VIT_POOL_MAP: NULL (no pre-LayerNorm) */
     const mq_block_weights* blocks;  /* host array, `layers` entries */
-    const float* ln_post_g; const float* ln_post_b;
-    const void*  proj_w;       /* bf16 [D, W]  (= visual.proj transposed) */
+    const float* ln_post_g; const float* ln_post_b; /* CLIP: on the class token; MQ_VIT_POOL_MAP: the trunk's final norm, all tokens */
+    const void*  proj_w;       /* bf16 [D, W]  (= visual.proj transposed); MQ_VIT_POOL_MAP: NULL (D == W, no projection) */
+    const mq_map_head* map;    /* MQ_VIT_POOL_MAP only, else NULL */
 } mq_vit_weights;
 
 typedef struct mq_vit_cfg {
@@ -131,6 +146,9 @@ typedef struct mq_vit_cfg {
     int32_t out_dim;     /* D */
     float mean[3];       /* preprocessing normalisation (clip_utils.py:32-33 by default) */
     float std[3];
+    int32_t pool;        /* MQ_VIT_POOL_CLS (0): open_clip VisionTransformer — class token, ln_pre, ln_post(class token) @ proj;
+                          * MQ_VIT_POOL_MAP (1): timm SigLIP ViT — no class token, no ln_pre, norm(all tokens) -> attention-pool head */
+    int32_t map_mlp_dim; /* F of the attention-pool head's MLP (MQ_VIT_POOL_MAP) */
 } mq_vit_cfg;
 
 typedef struct mq_clip_text_weights {
@@ -139,6 +157,7 @@ typedef struct mq_clip_text_weights {
     const mq_block_weights* blocks;
     const float* ln_final_g; const float* ln_final_b;
     const void*  proj_w;       /* bf16 [D, W] (= text_projection transposed) */
+    const float* proj_b;       /* fp32 [D] or NULL (SigLIP text towers: text_projection is a Linear with bias) */
 } mq_clip_text_weights;
 
 typedef struct mq_clip_text_cfg {

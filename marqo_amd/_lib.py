@@ -23,11 +23,12 @@ HEADER_PATH = PKG_DIR.parent / "include" / "marqo_hip.h"
 
 MQ_OK = 0
 NO_SCRATCH_UNITS = ("gemm_bf16", "gemm_big", "gemm_k32", "gemm_fp8", "attention")  # build() refuses register spills in these
-ABI_VERSION = 3
+ABI_VERSION = 4
 MQ_PREC_BF16, MQ_PREC_FP8 = 0, 1
 MQ_ACT_GELU, MQ_ACT_QUICKGELU = 1, 2
 MQ_MASK_NONE, MQ_MASK_CAUSAL = 0, 1
 MQ_POOL_MEAN, MQ_POOL_CLS = 0, 1
+MQ_VIT_POOL_CLS, MQ_VIT_POOL_MAP = 0, 1
 MQ_EPI_BIAS, MQ_EPI_GELU, MQ_EPI_QUICKGELU, MQ_EPI_RESIDUAL, MQ_EPI_OUT_F32, MQ_EPI_OUT_FP8 = 1, 2, 4, 8, 16, 32
 MQ_EPI_LN_STATS, MQ_EPI_LN_APPLY = 64, 128
 MQ_COMBINE_RAW, MQ_COMBINE_NORMALIZE, MQ_COMBINE_NORMALIZE_IF_NONZERO = 0, 1, 2
@@ -58,20 +59,27 @@ class EncoderCfg(C.Structure):
                 ("precision", C.c_int32), ("attn_width", C.c_int32), ("d_fp8_act_scale", C.c_void_p), ("d_fp8_act_amax", C.c_void_p)]
 
 
+class MapHead(C.Structure):
+    """mq_map_head: timm AttentionPoolLatent (SigLIP 'map' pooling)"""
+    _fields_ = [("q", C.c_void_p), ("kv_w", C.c_void_p), ("kv_b", C.c_void_p), ("proj_w", C.c_void_p), ("proj_b", C.c_void_p),
+                ("ln_g", C.c_void_p), ("ln_b", C.c_void_p), ("fc1_w", C.c_void_p), ("fc1_b", C.c_void_p),
+                ("fc2_w", C.c_void_p), ("fc2_b", C.c_void_p)]
+
+
 class VitWeights(C.Structure):
     _fields_ = [("patch_w", C.c_void_p), ("cls", C.c_void_p), ("pos", C.c_void_p),
                 ("ln_pre_g", C.c_void_p), ("ln_pre_b", C.c_void_p), ("blocks", C.POINTER(BlockWeights)),
-                ("ln_post_g", C.c_void_p), ("ln_post_b", C.c_void_p), ("proj_w", C.c_void_p)]
+                ("ln_post_g", C.c_void_p), ("ln_post_b", C.c_void_p), ("proj_w", C.c_void_p), ("map", C.POINTER(MapHead))]
 
 
 class VitCfg(C.Structure):
     _fields_ = [("enc", EncoderCfg), ("image_size", C.c_int32), ("patch_size", C.c_int32), ("out_dim", C.c_int32),
-                ("mean", C.c_float * 3), ("std", C.c_float * 3)]
+                ("mean", C.c_float * 3), ("std", C.c_float * 3), ("pool", C.c_int32), ("map_mlp_dim", C.c_int32)]
 
 
 class ClipTextWeights(C.Structure):
     _fields_ = [("tok_emb", C.c_void_p), ("pos", C.c_void_p), ("blocks", C.POINTER(BlockWeights)),
-                ("ln_final_g", C.c_void_p), ("ln_final_b", C.c_void_p), ("proj_w", C.c_void_p)]
+                ("ln_final_g", C.c_void_p), ("ln_final_b", C.c_void_p), ("proj_w", C.c_void_p), ("proj_b", C.c_void_p)]
 
 
 class ClipTextCfg(C.Structure):

@@ -84,6 +84,15 @@ void mq_set_error(const char* fmt, ...);
         }                                                                           \
     } while (0)
 
+#define MQ_CHECK_HIP(expr)                                                          \
+    do {                                                                            \
+        hipError_t e__ = (expr);                                                    \
+        if (e__ != hipSuccess) {                                                    \
+            mq_set_error("%s: %s", #expr, hipGetErrorString(e__));                  \
+            return MQ_ERR_HIP;                                                      \
+        }                                                                           \
+    } while (0)
+
 #define MQ_TRY(expr)                 \
     do {                             \
         int rc__ = (expr);           \

@@ -105,6 +105,7 @@ __global__ __launch_bounds__(256) void patchify_u8x8_kernel(const uint8_t* __res
 
 // ---- ViT token assembly + ln_pre ------------------------------------------------------------------
 // row (b, t): t == 0 ? cls : patch_out[b*np + t-1];  + pos[t];  LayerNorm(ln_pre) -> x fp32
+// cls == nullptr: no class token (T = np; timm / SigLIP ViTs), gam == nullptr: no ln_pre (their patch bias is folded into pos)
 constexpr int MAXC = 8;
 template <int CH>
 __global__ __launch_bounds__(256, (CH <= 4 ? 8 : 4)) void vit_assemble_kernel(
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(256, (CH <= 4 ? 8 : 4)) void vit_assemble_kernel(
     if (row >= rows) return;
     const int64_t b = row / T;
     const int t = (int)(row - b * T);
-    const float* src = t == 0 ? cls : patch_out + (b * (T - 1) + (t - 1)) * W;
+    const float* src = !cls ? patch_out + row * W : (t == 0 ? cls : patch_out + (b * (T - 1) + (t - 1)) * W);
     const float* pr = pos + (int64_t)t * W;
     const int nch = W >> 2;
     f32x4 v[CH];
@@ -123,6 +124,14 @@ __global__ __launch_bounds__(256, (CH <= 4 ? 8 : 4)) void vit_assemble_kernel(
     for (int i = 0; i < CH; ++i) {
         const int c = lane + i * 64;
         v[i] = c < nch ? *(const f32x4*)(src + c * 4) + *(const f32x4*)(pr + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (!gam) {  // wave-uniform
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int c = lane + i * 64;
+            if (c < nch) *(f32x4*)(x + row * W + c * 4) = v[i];
+        }
+        return;
     }
     ln_normalize_row<CH>(v, lane, nch, W, eps);
 #pragma unroll
@@ -136,6 +145,63 @@ __global__ __launch_bounds__(256, (CH <= 4 ? 8 : 4)) void vit_assemble_kernel(
             for (int e = 0; e < 4; ++e) y[e] = v[i][e] * gg[e] + bb[e];
             *(f32x4*)(x + row * W + c * 4) = y;
         }
+    }
+}
+
+// ---- attention pooling with ONE learned query (timm AttentionPoolLatent, SigLIP's 'map' head) --------------------------------
+// kv: bf16 [n*T, 2W] = (K | V) rows of every token; q: fp32 [W], already scaled by 1/sqrt(hd); out: bf16 [n, W].
+// One wave per (image, head): lanes take keys t = lane, lane + 64, ... for the scores (each reads its key's hd-wide row), a wave
+// softmax, then lanes take output dims (hd <= 128: dims lane, lane + 64) and walk the keys with the probabilities in LDS.
+// HBM-bound on the kv read (n*T*2W*2 bytes, once).
+__global__ __launch_bounds__(256) void map_pool_kernel(const bf16_t* __restrict__ kv, const float* __restrict__ q, bf16_t* __restrict__ out,
+                                                       int64_t nh, int T, int W, int heads, int hd) {
+    extern __shared__ float sp[];  // [4 waves][T]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t item = (int64_t)blockIdx.x * 4 + wave;
+    if (item >= nh) return;
+    const int64_t img = item / heads;
+    const int h = (int)(item - img * heads);
+    float* p = sp + wave * T;
+    const bf16_t* kbase = kv + img * T * (int64_t)(2 * W) + h * hd;
+    const float* qh = q + h * hd;
+    float mx = -INFINITY;
+    for (int t = lane; t < T; t += 64) {
+        const bf16_t* kr = kbase + (int64_t)t * (2 * W);
+        float s = 0.f;
+        for (int d = 0; d < hd; d += 8) {
+            const uint4 k8 = *(const uint4*)(kr + d);
+            const uint32_t kw[4] = {k8.x, k8.y, k8.z, k8.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                s += __uint_as_float(kw[e] << 16) * qh[d + 2 * e] + __uint_as_float(kw[e] & 0xffff0000u) * qh[d + 2 * e + 1];
+        }
+        p[t] = s;
+        mx = fmaxf(mx, s);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int t = lane; t < T; t += 64) {
+        const float e = __expf(p[t] - mx);
+        p[t] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // this wave's LDS writes above are read by its other lanes below
+    __builtin_amdgcn_wave_barrier();
+    const bf16_t* vbase = kbase + W;
+    float o0 = 0.f, o1 = 0.f;
+    const bool two = lane + 64 < hd;
+    if (lane < hd) {
+        for (int t = 0; t < T; ++t) {
+            const bf16_t* vr = vbase + (int64_t)t * (2 * W);
+            const float pt = p[t];
+            o0 += pt * bf16_to_f32(vr[lane]);
+            if (two) o1 += pt * bf16_to_f32(vr[lane + 64]);
+        }
+        bf16_t* orow = out + img * W + h * hd;
+        orow[lane] = f32_to_bf16(o0 * inv);
+        if (two) orow[lane + 64] = f32_to_bf16(o1 * inv);
     }
 }
 
@@ -288,6 +354,20 @@ int mq_vit_assemble(const float* d_patch_out, const float* cls, const float* pos
     MQ_DISPATCH_CH(W, hipLaunchKernelGGL(vit_assemble_kernel<CH>, dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, s, d_patch_out,
                                          cls, pos, g, b, d_x, rows, T, W, eps));
     MQ_CHECK_LAUNCH("vit_assemble");
+    return MQ_OK;
+}
+
+int mq_map_pool(const void* d_kv, const float* d_q, void* d_out, int64_t n, int T, int W, int heads, hipStream_t s) {
+    MQ_CHECK_ARG(heads >= 1 && W % heads == 0, "map_pool: W=%d heads=%d", W, heads);
+    const int hd = W / heads;
+    MQ_CHECK_ARG(hd % 8 == 0 && hd <= 128, "map_pool: head dim %d unsupported (multiple of 8, <= 128)", hd);
+    MQ_CHECK_ARG(T >= 1 && T <= 4096, "map_pool: %d tokens unsupported", T);
+    if (n <= 0) return MQ_OK;
+    MqProfScope prof(4, s);
+    const int64_t nh = n * heads;
+    hipLaunchKernelGGL(map_pool_kernel, dim3((unsigned)cdiv64(nh, 4)), dim3(256), (size_t)4 * T * sizeof(float), s, (const bf16_t*)d_kv, d_q,
+                       (bf16_t*)d_out, nh, T, W, heads, hd);
+    MQ_CHECK_LAUNCH("map_pool");
     return MQ_OK;
 }
 

@@ -20,13 +20,15 @@ int mq_pool(const float* d_x, const int32_t* d_cu, int64_t nseq, float* d_out, i
             hipStream_t s);
 int mq_last_rows(const int32_t* d_cu, int32_t* d_rows, int64_t nseq, hipStream_t s);
 int mq_cls_rows(int32_t* d_rows, int64_t n, int T, hipStream_t s);
+int mq_map_pool(const void* d_kv, const float* d_q, void* d_out, int64_t n, int T, int W, int heads, hipStream_t s);
 int mq_move_rows(void* d_sparse, const int32_t* d_idx, void* d_dense, int64_t n, int64_t row_bytes, bool scatter, hipStream_t s);
 extern "C" int mq_rowquant_fp8(const float* d_x, void* d_out_fp8, float* d_row_scale, int64_t rows, int32_t W, void* stream);
 
 // layouts the ctypes binding (marqo_amd/_lib.py) and tests/test_abi.py assume
 static_assert(sizeof(mq_block_weights) == 26 * 8, "mq_block_weights layout");
 static_assert(sizeof(mq_encoder_cfg) == 56, "mq_encoder_cfg layout");
-static_assert(sizeof(mq_vit_cfg) == 96 && sizeof(mq_clip_text_cfg) == 72 && sizeof(mq_bert_cfg) == 72, "tower cfg layouts");
+static_assert(sizeof(mq_vit_cfg) == 104 && sizeof(mq_clip_text_cfg) == 72 && sizeof(mq_bert_cfg) == 72, "tower cfg layouts");
+static_assert(sizeof(mq_vit_weights) == 10 * 8 && sizeof(mq_map_head) == 11 * 8 && sizeof(mq_clip_text_weights) == 7 * 8, "tower weight layouts");
 
 // mq_tune("row_select", 0) runs the last block on every row (A/B and parity tests of the pooled-rows-only last block)
 int mq_tower_row_select = getenv("MQ_ROW_SELECT") ? atoi(getenv("MQ_ROW_SELECT")) : 1;
@@ -304,19 +306,34 @@ namespace {
 struct VitPlan {
     int T, np, Kp; int64_t rows;
     size_t off_x, off_rows, off_cls, off_enc, off_patches, off_patch_out, total;
+    size_t off_map_y, off_map_z, off_map_h, off_tok, off_kv;  // MQ_VIT_POOL_MAP (off_tok / off_kv inside the encoder's region)
 };
 VitPlan vit_plan(const mq_vit_cfg* c, int64_t n) {
     VitPlan p;
     const int G = c->image_size / c->patch_size;
-    p.np = G * G; p.T = p.np + 1; p.Kp = ceil64(3 * c->patch_size * c->patch_size); p.rows = n * p.T;
+    const bool map = c->pool == MQ_VIT_POOL_MAP;
+    p.np = G * G; p.T = p.np + (map ? 0 : 1); p.Kp = ceil64(3 * c->patch_size * c->patch_size); p.rows = n * p.T;
     const int W = c->enc.width;
     Off cv;
     p.off_x = cv.take((size_t)p.rows * W * 4);
     p.off_rows = cv.take((size_t)n * 4);
-    p.off_cls = cv.take((size_t)n * W * 2);
-    // encoder scratch and the patch buffers are never live together -> they share one region
+    p.off_cls = cv.take((size_t)n * W * 2);       // CLIP: ln_post(class token) bf16; MAP: pooled attention output bf16
+    p.off_map_y = p.off_map_z = p.off_map_h = p.off_tok = p.off_kv = 0;
+    if (map) {
+        p.off_map_y = cv.take((size_t)n * W * 4);                 // fp32 [n, W] head stream
+        p.off_map_z = cv.take((size_t)n * W * 2);                 // bf16 norm(y)
+        p.off_map_h = cv.take((size_t)n * c->map_mlp_dim * 2);    // bf16 MLP hidden
+    }
+    // encoder scratch and the patch buffers are never live together -> they share one region (so do, after the encoder, the
+    // MAP head's normalised tokens bf16 [rows, W] and their keys | values bf16 [rows, 2W])
     p.off_enc = cv.end();
-    const size_t enc = encoder_ws(&c->enc, p.rows);
+    size_t enc = encoder_ws(&c->enc, p.rows);
+    if (map) {
+        Off mv;
+        p.off_tok = p.off_enc + mv.take((size_t)p.rows * W * 2);
+        p.off_kv = p.off_enc + mv.take((size_t)p.rows * 2 * W * 2);
+        if (mv.end() > enc) enc = mv.end();
+    }
     Off pv;
     p.off_patches = p.off_enc + pv.take((size_t)n * p.np * p.Kp * 2);
     p.off_patch_out = p.off_enc + pv.take((size_t)n * p.np * W * 4);
@@ -332,8 +349,20 @@ int encode_image_impl(const mq_vit_cfg* cfg, const mq_vit_weights* w, const void
     MQ_CHECK_ARG(cfg->patch_size > 0 && cfg->image_size % cfg->patch_size == 0, "mq_encode_image: image %d not divisible by patch %d",
                  cfg->image_size, cfg->patch_size);
     MQ_CHECK_ARG(cfg->out_dim >= 4 && cfg->out_dim % 4 == 0, "mq_encode_image: out_dim %d must be a multiple of 4", cfg->out_dim);
-    MQ_CHECK_ARG(w->patch_w && w->cls && w->pos && w->ln_pre_g && w->ln_pre_b && w->ln_post_g && w->ln_post_b && w->proj_w,
-                 "mq_encode_image: null weight pointer");
+    const bool map = cfg->pool == MQ_VIT_POOL_MAP;
+    MQ_CHECK_ARG(cfg->pool == MQ_VIT_POOL_CLS || map, "mq_encode_image: bad pool %d", cfg->pool);
+    MQ_CHECK_ARG(w->patch_w && w->pos && w->ln_post_g && w->ln_post_b, "mq_encode_image: null weight pointer");
+    const int W = cfg->enc.width;
+    if (map) {
+        const mq_map_head* m = w->map;
+        MQ_CHECK_ARG(m && m->q && m->kv_w && m->kv_b && m->proj_w && m->proj_b && m->ln_g && m->ln_b && m->fc1_w && m->fc1_b && m->fc2_w && m->fc2_b,
+                     "mq_encode_image: MQ_VIT_POOL_MAP needs the attention-pool head's weights");
+        MQ_CHECK_ARG(!w->cls && !w->ln_pre_g && !w->ln_pre_b, "mq_encode_image: MQ_VIT_POOL_MAP has no class token / ln_pre");
+        MQ_CHECK_ARG(cfg->map_mlp_dim >= 64 && cfg->map_mlp_dim % 64 == 0, "mq_encode_image: map_mlp_dim %d must be a multiple of 64", cfg->map_mlp_dim);
+        MQ_CHECK_ARG(w->proj_w || cfg->out_dim == W, "mq_encode_image: without a projection out_dim (%d) must equal the width (%d)", cfg->out_dim, W);
+    } else {
+        MQ_CHECK_ARG(w->cls && w->ln_pre_g && w->ln_pre_b && w->proj_w, "mq_encode_image: null weight pointer");
+    }
     if (n <= 0) return MQ_OK;
     MQ_CHECK_ARG(d_pixels && ws, "mq_encode_image: null input / workspace");
     const VitPlan p = vit_plan(cfg, n);
@@ -344,12 +373,43 @@ int encode_image_impl(const mq_vit_cfg* cfg, const mq_vit_weights* w, const void
     void* cls_ln = base + p.off_cls;
     void* patches = base + p.off_patches;
     float* patch_out = (float*)(base + p.off_patch_out);
-    const int W = cfg->enc.width;
 
-    // K10 (normalise) + K1: im2col gather, conv-as-GEMM, class token + pos + ln_pre
+    // K10 (normalise) + K1: im2col gather, conv-as-GEMM, class token + pos + ln_pre (MAP: + pos, which carries the conv bias)
     MQ_TRY(mq_patchify(d_pixels, is_u8, patches, n, cfg->image_size, cfg->patch_size, p.Kp, cfg->mean, cfg->std, s));
     MQ_TRY(mq_gemm_bf16(patches, p.Kp, w->patch_w, p.Kp, nullptr, nullptr, patch_out, W, n * p.np, W, p.Kp, MQ_EPI_OUT_F32, s));
     MQ_TRY(mq_vit_assemble(patch_out, w->cls, w->pos, w->ln_pre_g, w->ln_pre_b, x, n, p.T, W, cfg->enc.ln_eps, s));
+    if (map) {
+        // K2-K5 x layers on every token, then the trunk's norm on every token and the attention-pool head:
+        //   k | v = norm(x) @ kv_w^T + kv_b;  o = softmax(q k^T) v per head (one learned query);  y = o @ proj^T + b;
+        //   y = y + fc2(gelu(fc1(LN(y))))  -> [n, W]  (timm AttentionPoolLatent; pooled = y, no further projection)
+        const mq_map_head* m = w->map;
+        const int F = cfg->map_mlp_dim;
+        MQ_TRY(encoder_forward_impl(&cfg->enc, w->blocks, x, p.rows, nullptr, n, p.T, p.T, nullptr, 0, base + p.off_enc,
+                                    ws_bytes - p.off_enc, s));
+        void* tok = base + p.off_tok;
+        void* kv = base + p.off_kv;
+        float* y = (float*)(base + p.off_map_y);
+        void* z = base + p.off_map_z;
+        void* hmid = base + p.off_map_h;
+        MQ_TRY(mq_layernorm(x, nullptr, w->ln_post_g, w->ln_post_b, tok, nullptr, p.rows, W, cfg->enc.ln_eps, s));
+        MQ_TRY(mq_gemm_bf16(tok, W, m->kv_w, W, m->kv_b, nullptr, kv, 2 * W, p.rows, 2 * W, W, MQ_EPI_BIAS, s));
+        MQ_TRY(mq_map_pool(kv, m->q, cls_ln, n, p.T, W, cfg->enc.heads, s));
+        MQ_CHECK_HIP(hipMemsetAsync(y, 0, (size_t)n * W * 4, s));   // bias-only epilogue = the residual epilogue over zeros
+        MQ_TRY(mq_gemm_bf16(cls_ln, W, m->proj_w, W, m->proj_b, y, y, W, n, W, W, MQ_EPI_BIAS | MQ_EPI_RESIDUAL | MQ_EPI_OUT_F32, s));
+        MQ_TRY(mq_layernorm(y, nullptr, m->ln_g, m->ln_b, z, nullptr, n, W, cfg->enc.ln_eps, s));
+        MQ_TRY(mq_gemm_bf16(z, W, m->fc1_w, W, m->fc1_b, nullptr, hmid, F, n, F, W, MQ_EPI_BIAS | MQ_EPI_GELU, s));
+        MQ_TRY(mq_gemm_bf16(hmid, F, m->fc2_w, F, m->fc2_b, y, y, W, n, W, F, MQ_EPI_BIAS | MQ_EPI_RESIDUAL | MQ_EPI_OUT_F32, s));
+        if (w->proj_w) {
+            MQ_TRY(mq_cast_bf16(y, z, (int64_t)n * W, s));
+            MQ_TRY(mq_gemm_bf16(z, W, w->proj_w, W, nullptr, nullptr, d_out, cfg->out_dim, n, cfg->out_dim, W, MQ_EPI_OUT_F32, s));
+            if (normalize) MQ_TRY(mq_l2_normalize(d_out, d_out, n, cfg->out_dim, s));
+        } else if (normalize) {
+            MQ_TRY(mq_l2_normalize(y, d_out, n, W, s));
+        } else {
+            MQ_CHECK_HIP(hipMemcpyAsync(d_out, y, (size_t)n * W * 4, hipMemcpyDeviceToDevice, s));
+        }
+        return MQ_OK;
+    }
     // K2-K5 x layers (only the class-token rows are read afterwards -> the last block's row-wise half runs on them alone)
     MQ_TRY(mq_cls_rows(rows_idx, n, p.T, s));
     MQ_TRY(encoder_forward_impl(&cfg->enc, w->blocks, x, p.rows, nullptr, n, p.T, p.T, rows_idx, n, base + p.off_enc,
@@ -436,7 +496,12 @@ extern "C" int mq_encode_clip_text(const mq_clip_text_cfg* cfg, const mq_clip_te
     MQ_TRY(encoder_forward_impl(&cfg->enc, w->blocks, x, rows, d_cu_seqlens, nseq, 0, maxl, pool_rows, nseq, base + p.off_enc,
                                 workspace_bytes - p.off_enc, s));
     MQ_TRY(mq_layernorm(x, pool_rows, w->ln_final_g, w->ln_final_b, pooled, nullptr, nseq, W, cfg->enc.ln_eps, s));
-    MQ_TRY(mq_gemm_bf16(pooled, W, w->proj_w, W, nullptr, nullptr, d_out, cfg->out_dim, nseq, cfg->out_dim, W, MQ_EPI_OUT_F32, s));
+    if (w->proj_b) {  // SigLIP: Linear with bias = the residual epilogue over zeros
+        MQ_CHECK_HIP(hipMemsetAsync(d_out, 0, (size_t)nseq * cfg->out_dim * 4, s));
+        MQ_TRY(mq_gemm_bf16(pooled, W, w->proj_w, W, w->proj_b, d_out, d_out, cfg->out_dim, nseq, cfg->out_dim, W,
+                            MQ_EPI_BIAS | MQ_EPI_RESIDUAL | MQ_EPI_OUT_F32, s));
+    } else
+        MQ_TRY(mq_gemm_bf16(pooled, W, w->proj_w, W, nullptr, nullptr, d_out, cfg->out_dim, nseq, cfg->out_dim, W, MQ_EPI_OUT_F32, s));
     if (normalize) MQ_TRY(mq_l2_normalize(d_out, d_out, nseq, cfg->out_dim, s));
     return MQ_OK;
 }

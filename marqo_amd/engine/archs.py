@@ -25,18 +25,24 @@ class VitArch:
     out_dim: int
     quick_gelu: bool = False
     ln_eps: float = 1e-5
+    pool: str = "cls"  # "cls": open_clip VisionTransformer (class token, ln_pre, ln_post(class token) @ proj);
+    #                    "map": timm SigLIP ViT behind open_clip's TimmModel (no class token, no ln_pre, attention-pool head, no proj)
 
     @property
     def tokens(self) -> int:
-        return (self.image_size // self.patch_size) ** 2 + 1
+        return (self.image_size // self.patch_size) ** 2 + (1 if self.pool == "cls" else 0)
 
     @property
     def gflop_per_image(self) -> float:
         """Algorithmic FLOPs (2MNK per GEMM, attention 4 T^2 W per layer) — SURVEY.md §8(d)."""
         T, W, F = self.tokens, self.width, self.mlp_dim
-        patch = 2 * (T - 1) * W * 3 * self.patch_size ** 2
+        patch = 2 * (self.image_size // self.patch_size) ** 2 * W * 3 * self.patch_size ** 2
         layer = 2 * T * W * (3 * W) + 2 * T * W * W + 2 * 2 * T * W * F + 4 * T * T * W
-        return (patch + self.layers * layer + 2 * W * self.out_dim) / 1e9
+        if self.pool == "map":  # keys | values of every token, one query per head, proj + MLP on the pooled row
+            head = 2 * T * W * (2 * W) + 4 * T * W + 2 * W * W + 2 * 2 * W * F
+        else:
+            head = 2 * W * self.out_dim
+        return (patch + self.layers * layer + head) / 1e9
 
 
 @dataclass(frozen=True)
@@ -50,6 +56,10 @@ class ClipTextArch:
     out_dim: int
     quick_gelu: bool = False
     ln_eps: float = 1e-5
+    causal: bool = True       # False: SigLIP (no_causal_mask; every one of the ctx positions is run, pooled row = the last one)
+    proj_bias: bool = False   # SigLIP: text_projection is a Linear with bias
+    prefix: str = ""          # checkpoint key prefix: "" for CLIP, "text." under open_clip's CustomTextCLIP (SigLIP)
+    pad_id: int = 0
 
     def gflop_per_text(self, tokens: Optional[int] = None) -> float:
         T, W, F = tokens or self.ctx, self.width, self.mlp_dim
@@ -80,6 +90,15 @@ _TEXT_B_PLUS = ClipTextArch(vocab=49408, ctx=77, width=640, layers=12, heads=10,
 _TEXT_H = ClipTextArch(vocab=49408, ctx=77, width=1024, layers=24, heads=16, mlp_dim=4096, out_dim=1024)
 _TEXT_BIGG = ClipTextArch(vocab=49408, ctx=77, width=1280, layers=32, heads=20, mlp_dim=5120, out_dim=1280)
 
+# SigLIP (open_clip model configs ViT-{B,L}-16-SigLIP*: timm vit_{base,large}_patch16_siglip_* + TextTransformer, ctx 64,
+# 32k sentencepiece vocabulary, LayerNorm eps 1e-6 everywhere)
+def _siglip(image_size: int, large: bool = False) -> Tuple[VitArch, ClipTextArch]:
+    W, Lyr, H, Fd = (1024, 24, 16, 4096) if large else (768, 12, 12, 3072)
+    return (VitArch(image_size, 16, W, Lyr, H, Fd, W, ln_eps=1e-6, pool="map"),
+            ClipTextArch(vocab=32000, ctx=64, width=W, layers=Lyr, heads=H, mlp_dim=Fd, out_dim=W, ln_eps=1e-6, causal=False,
+                         proj_bias=True, prefix="text.", pad_id=1))
+
+
 # open_clip architecture name -> (vision, text)
 OPEN_CLIP_ARCHS = {
     "ViT-B-32": (VitArch(224, 32, 768, 12, 12, 3072, 512), _TEXT_B),
@@ -92,9 +111,12 @@ OPEN_CLIP_ARCHS = {
     "ViT-H-14": (VitArch(224, 14, 1280, 32, 16, 5120, 1024), _TEXT_H),
     "ViT-g-14": (VitArch(224, 14, 1408, 40, 16, 6144, 1024), _TEXT_H),
     "ViT-bigG-14": (VitArch(224, 14, 1664, 48, 16, 8192, 1280), _TEXT_BIGG),
+    "ViT-B-16-SigLIP": _siglip(224), "ViT-B-16-SigLIP-256": _siglip(256), "ViT-B-16-SigLIP-384": _siglip(384),
+    "ViT-L-16-SigLIP-256": _siglip(256, large=True), "ViT-L-16-SigLIP-384": _siglip(384, large=True),
 }
 # architectures the registry names but which are not plain CLIP ViTs (ResNet, ConvNeXt, EVA02, SigLIP, CoCa, roberta/xlm text
-# towers ...) or whose token count does not fit the LDS-resident attention with 256-byte LDS rows (ViT-H-14-378: 730 tokens)
+# towers ...) or whose token count does not fit the LDS-resident attention (ViT-H-14-378: 730 tokens at 256-byte LDS rows;
+# ViT-B-16-SigLIP-512: 1024 tokens, ViT-SO400M-14-SigLIP-384: 729 tokens of 72-wide heads)
 UNSUPPORTED_HINT = ("this open_clip architecture is not runnable by the marqo_amd engine yet "
                     "(supported: " + ", ".join(sorted(OPEN_CLIP_ARCHS)) + " and their -quickgelu variants)")
 

@@ -156,36 +156,43 @@ class _Fp8State:
 LN_FOLD = os.environ.get("MARQO_AMD_LN_FOLD", "0") == "1"
 
 
-def _clip_blocks(h: _Holder, sd, prefix: str, layers: int, W: int, F: int, heads: int):
+# per-block tensor names: open_clip ResidualAttentionBlock / timm Block (the SigLIP trunks)
+_OPEN_CLIP_KEYS = dict(block="resblocks.{}.", ln1="ln_1", qkv_w="attn.in_proj_weight", qkv_b="attn.in_proj_bias", out="attn.out_proj",
+                       ln2="ln_2", fc1="mlp.c_fc", fc2="mlp.c_proj")
+_TIMM_KEYS = dict(block="blocks.{}.", ln1="norm1", qkv_w="attn.qkv.weight", qkv_b="attn.qkv.bias", out="attn.proj",
+                  ln2="norm2", fc1="mlp.fc1", fc2="mlp.fc2")
+
+
+def _clip_blocks(h: _Holder, sd, prefix: str, layers: int, W: int, F: int, heads: int, keys=_OPEN_CLIP_KEYS):
     d = _head_dim(W, heads)
     padded = d != _kernel_head_dim(d, heads)  # ViT-H / g / bigG: 80 / 88 / 104-wide heads run as 96 / 96 / 112
     if padded and LN_FOLD:
         raise ValueError("MARQO_AMD_LN_FOLD=1 is not supported for models whose heads are padded")
     arr = (L.BlockWeights * layers)()
+    k = keys
     for i in range(layers):
-        p = f"{prefix}resblocks.{i}."
+        p = prefix + k["block"].format(i)
         b = arr[i]
-        b.ln1_g = h.f32(_need(sd, p + "ln_1.weight", (W,)))
-        b.ln1_b = h.f32(_need(sd, p + "ln_1.bias", (W,)))
-        qkv_w, qkv_b = _need(sd, p + "attn.in_proj_weight", (3 * W, W)), _need(sd, p + "attn.in_proj_bias", (3 * W,))
-        out_w = _need(sd, p + "attn.out_proj.weight", (W, W))
+        b.ln1_g = h.f32(_need(sd, p + k["ln1"] + ".weight", (W,)))
+        b.ln1_b = h.f32(_need(sd, p + k["ln1"] + ".bias", (W,)))
+        qkv_w, qkv_b = _need(sd, p + k["qkv_w"], (3 * W, W)), _need(sd, p + k["qkv_b"], (3 * W,))
+        out_w = _need(sd, p + k["out"] + ".weight", (W, W))
         if padded:
             qkv_w, qkv_b, out_w = _pad_heads(qkv_w.detach(), qkv_b.detach(), out_w.detach(), heads, d)
         b.qkv_w, b.qkv_b, b.out_w = h.bf16(qkv_w), h.f32(qkv_b), h.bf16(out_w)
-        b.out_b = h.f32(_need(sd, p + "attn.out_proj.bias", (W,)))
-        b.ln2_g = h.f32(_need(sd, p + "ln_2.weight", (W,)))
-        b.ln2_b = h.f32(_need(sd, p + "ln_2.bias", (W,)))
-        b.fc1_w = h.bf16(_need(sd, p + "mlp.c_fc.weight", (F, W)))
-        b.fc1_b = h.f32(_need(sd, p + "mlp.c_fc.bias", (F,)))
-        b.fc2_w = h.bf16(_need(sd, p + "mlp.c_proj.weight", (W, F)))
-        b.fc2_b = h.f32(_need(sd, p + "mlp.c_proj.bias", (W,)))
+        b.out_b = h.f32(_need(sd, p + k["out"] + ".bias", (W,)))
+        b.ln2_g = h.f32(_need(sd, p + k["ln2"] + ".weight", (W,)))
+        b.ln2_b = h.f32(_need(sd, p + k["ln2"] + ".bias", (W,)))
+        b.fc1_w = h.bf16(_need(sd, p + k["fc1"] + ".weight", (F, W)))
+        b.fc1_b = h.f32(_need(sd, p + k["fc1"] + ".bias", (F,)))
+        b.fc2_w = h.bf16(_need(sd, p + k["fc2"] + ".weight", (W, F)))
+        b.fc2_b = h.f32(_need(sd, p + k["fc2"] + ".bias", (W,)))
         if LN_FOLD:
             # LayerNorm folding (csrc/gemm_epilogue.h): LN(x) @ W^T = rstd * (x @ (g*W)^T - mean * colsum(g*W)) + (b + W @ beta).
             # colsum is taken over the bf16-ROUNDED folded weight (what the MFMA multiplies), the bias in fp32 from the fp32 W.
-            for name, wk, bk, lg, lb in (("qkv", "attn.in_proj_weight", "attn.in_proj_bias", "ln_1.weight", "ln_1.bias"),
-                                         ("fc1", "mlp.c_fc.weight", "mlp.c_fc.bias", "ln_2.weight", "ln_2.bias")):
+            for name, wk, bk, lg in (("qkv", k["qkv_w"], k["qkv_b"], k["ln1"]), ("fc1", k["fc1"] + ".weight", k["fc1"] + ".bias", k["ln2"])):
                 w32 = sd[p + wk].detach().to(torch.float32)
-                gam, bet = sd[p + lg].detach().to(torch.float32), sd[p + lb].detach().to(torch.float32)
+                gam, bet = sd[p + lg + ".weight"].detach().to(torch.float32), sd[p + lg + ".bias"].detach().to(torch.float32)
                 wf = (w32 * gam.unsqueeze(0)).to(torch.bfloat16)
                 setattr(b, name + "_wf", h.bf16(wf))
                 setattr(b, name + "_sf", h.f32(wf.to(torch.float32).sum(dim=1)))
@@ -238,7 +245,8 @@ class _TowerBase:
 
 
 class VitTower(_TowerBase):
-    """CLIP ViT image tower (open_clip `visual.*` checkpoint tensors)."""
+    """CLIP ViT image tower (open_clip `visual.*` checkpoint tensors); arch.pool == "map": the timm SigLIP ViT behind open_clip's
+    TimmModel (`visual.trunk.*`)."""
 
     def __init__(self, arch: VitArch, sd: Dict[str, Tensor], device: str,
                  mean: Sequence[float] = OPENAI_DATASET_MEAN, std: Sequence[float] = OPENAI_DATASET_STD,
@@ -253,23 +261,48 @@ class VitTower(_TowerBase):
             raise ValueError("image_size must be a multiple of patch_size")
         K = 3 * P * P
         Kp = (K + 63) // 64 * 64
-        conv = _need(sd, "visual.conv1.weight", (W, 3, P, P)).detach().to(torch.float32).reshape(W, K)
-        patch_w = torch.zeros(W, Kp, dtype=torch.float32)
-        patch_w[:, :K] = conv
         h = self._h
-        self._blocks = _clip_blocks(h, sd, "visual.transformer.", arch.layers, W, arch.mlp_dim, arch.heads)
-        self.w = L.VitWeights(
-            patch_w=h.bf16(patch_w),
-            cls=h.f32(_need(sd, "visual.class_embedding", (W,))),
-            pos=h.f32(_need(sd, "visual.positional_embedding", (arch.tokens, W))),
-            ln_pre_g=h.f32(_need(sd, "visual.ln_pre.weight", (W,))), ln_pre_b=h.f32(_need(sd, "visual.ln_pre.bias", (W,))),
-            blocks=self._blocks,
-            ln_post_g=h.f32(_need(sd, "visual.ln_post.weight", (W,))), ln_post_b=h.f32(_need(sd, "visual.ln_post.bias", (W,))),
-            proj_w=h.bf16(_need(sd, "visual.proj", (W, arch.out_dim)).detach().to(torch.float32).t()))
+        patch_w = torch.zeros(W, Kp, dtype=torch.float32)
+        if arch.pool == "map":
+            # timm SigLIP ViT as open_clip's `visual.trunk` (no class token, no ln_pre, conv bias, attention-pool head, no proj)
+            t = "visual.trunk."
+            F = arch.mlp_dim
+            hd = _head_dim(W, arch.heads)
+            if arch.out_dim != W:
+                raise ValueError(f"SigLIP towers have no visual projection: out_dim {arch.out_dim} must equal the width {W}")
+            patch_w[:, :K] = _need(sd, t + "patch_embed.proj.weight", (W, 3, P, P)).detach().to(torch.float32).reshape(W, K)
+            pos = _need(sd, t + "pos_embed", (1, arch.tokens, W)).detach().to(torch.float32)[0] + \
+                _need(sd, t + "patch_embed.proj.bias", (W,)).detach().to(torch.float32)  # the conv bias rides on the position table
+            self._blocks = _clip_blocks(h, sd, t, arch.layers, W, F, arch.heads, keys=_TIMM_KEYS)
+            a = t + "attn_pool."
+            f32 = lambda k, shape: _need(sd, a + k, shape).detach().to(torch.float32)
+            # the single learned query is a constant of the model: q = Linear_q(latent) / sqrt(head dim), in fp32 at load
+            q = (f32("latent", (1, 1, W)).reshape(W) @ f32("q.weight", (W, W)).t() + f32("q.bias", (W,))) * hd ** -0.5
+            self._map = L.MapHead(q=h.f32(q), kv_w=h.bf16(f32("kv.weight", (2 * W, W))), kv_b=h.f32(f32("kv.bias", (2 * W,))),
+                                  proj_w=h.bf16(f32("proj.weight", (W, W))), proj_b=h.f32(f32("proj.bias", (W,))),
+                                  ln_g=h.f32(f32("norm.weight", (W,))), ln_b=h.f32(f32("norm.bias", (W,))),
+                                  fc1_w=h.bf16(f32("mlp.fc1.weight", (F, W))), fc1_b=h.f32(f32("mlp.fc1.bias", (F,))),
+                                  fc2_w=h.bf16(f32("mlp.fc2.weight", (W, F))), fc2_b=h.f32(f32("mlp.fc2.bias", (W,))))
+            self.w = L.VitWeights(patch_w=h.bf16(patch_w), cls=None, pos=h.f32(pos), ln_pre_g=None, ln_pre_b=None, blocks=self._blocks,
+                                  ln_post_g=h.f32(_need(sd, t + "norm.weight", (W,))), ln_post_b=h.f32(_need(sd, t + "norm.bias", (W,))),
+                                  proj_w=None, map=C.pointer(self._map))
+            pool, map_mlp = L.MQ_VIT_POOL_MAP, F
+        else:
+            patch_w[:, :K] = _need(sd, "visual.conv1.weight", (W, 3, P, P)).detach().to(torch.float32).reshape(W, K)
+            self._blocks = _clip_blocks(h, sd, "visual.transformer.", arch.layers, W, arch.mlp_dim, arch.heads)
+            self.w = L.VitWeights(
+                patch_w=h.bf16(patch_w),
+                cls=h.f32(_need(sd, "visual.class_embedding", (W,))),
+                pos=h.f32(_need(sd, "visual.positional_embedding", (arch.tokens, W))),
+                ln_pre_g=h.f32(_need(sd, "visual.ln_pre.weight", (W,))), ln_pre_b=h.f32(_need(sd, "visual.ln_pre.bias", (W,))),
+                blocks=self._blocks,
+                ln_post_g=h.f32(_need(sd, "visual.ln_post.weight", (W,))), ln_post_b=h.f32(_need(sd, "visual.ln_post.bias", (W,))),
+                proj_w=h.bf16(_need(sd, "visual.proj", (W, arch.out_dim)).detach().to(torch.float32).t()), map=None)
+            pool, map_mlp = L.MQ_VIT_POOL_CLS, 0
         self.cfg = L.VitCfg(enc=_encoder_cfg(W, arch.layers, arch.heads, arch.mlp_dim, arch.quick_gelu, False,
                                              L.MQ_MASK_NONE, arch.ln_eps),
                             image_size=arch.image_size, patch_size=P, out_dim=arch.out_dim,
-                            mean=(C.c_float * 3)(*mean), std=(C.c_float * 3)(*std))
+                            mean=(C.c_float * 3)(*mean), std=(C.c_float * 3)(*std), pool=pool, map_mlp_dim=map_mlp)
         self.max_images_per_call = max(1, MAX_ROWS_PER_CALL // arch.tokens)
         self.n_streams = max(1, int(os.environ.get("MARQO_AMD_STREAMS", "1")))
         self._side: list = []
@@ -405,15 +438,22 @@ class ClipTextTower(_TextTowerBase):
         self.arch = arch
         W = arch.width
         h = self._h
-        self._blocks = _clip_blocks(h, sd, "transformer.", arch.layers, W, arch.mlp_dim, arch.heads)
+        px = arch.prefix  # "" (CLIP) / "text." (SigLIP under open_clip's CustomTextCLIP)
+        self._blocks = _clip_blocks(h, sd, px + "transformer.", arch.layers, W, arch.mlp_dim, arch.heads)
+        if arch.proj_bias:  # SigLIP: text_projection is a Linear (weight [D, W] + bias)
+            proj_w = _need(sd, px + "text_projection.weight", (arch.out_dim, W)).detach().to(torch.float32)
+            proj_b = h.f32(_need(sd, px + "text_projection.bias", (arch.out_dim,)))
+        else:
+            proj_w = _need(sd, px + "text_projection", (W, arch.out_dim)).detach().to(torch.float32).t()
+            proj_b = None
         self.w = L.ClipTextWeights(
-            tok_emb=h.f32(_need(sd, "token_embedding.weight", (arch.vocab, W))),
-            pos=h.f32(_need(sd, "positional_embedding", (arch.ctx, W))),
+            tok_emb=h.f32(_need(sd, px + "token_embedding.weight", (arch.vocab, W))),
+            pos=h.f32(_need(sd, px + "positional_embedding", (arch.ctx, W))),
             blocks=self._blocks,
-            ln_final_g=h.f32(_need(sd, "ln_final.weight", (W,))), ln_final_b=h.f32(_need(sd, "ln_final.bias", (W,))),
-            proj_w=h.bf16(_need(sd, "text_projection", (W, arch.out_dim)).detach().to(torch.float32).t()))
+            ln_final_g=h.f32(_need(sd, px + "ln_final.weight", (W,))), ln_final_b=h.f32(_need(sd, px + "ln_final.bias", (W,))),
+            proj_w=h.bf16(proj_w), proj_b=proj_b)
         self.cfg = L.ClipTextCfg(enc=_encoder_cfg(W, arch.layers, arch.heads, arch.mlp_dim, arch.quick_gelu, False,
-                                                  L.MQ_MASK_CAUSAL, arch.ln_eps),
+                                                  L.MQ_MASK_CAUSAL if arch.causal else L.MQ_MASK_NONE, arch.ln_eps),
                                  vocab=arch.vocab, ctx=arch.ctx, out_dim=arch.out_dim)
         if precision == "fp8":
             self._enable_fp8(self._blocks, arch.layers, W, arch.mlp_dim)
@@ -427,7 +467,13 @@ class ClipTextTower(_TextTowerBase):
             raise ValueError(f"expected ids [n, <= {self.arch.ctx}], got {tuple(ids.shape)}")
         ids_h = ids.detach().to("cpu", torch.int64)
         n, S = ids_h.shape
-        eot = ids_h.argmax(dim=1)
+        if not self.arch.causal:
+            # SigLIP: no mask at all — every one of the ctx positions (padding included) is attended to and the pooled row is the
+            # last one, so all S = ctx positions run and there is nothing to pack away
+            if S != self.arch.ctx:
+                raise ValueError(f"an unmasked text tower runs exactly ctx = {self.arch.ctx} positions per text, got {S}")
+            pack = False
+        eot = torch.full((n,), S - 1, dtype=torch.int64) if not self.arch.causal else ids_h.argmax(dim=1)
         lengths = (eot + 1) if pack else torch.full((n,), S, dtype=torch.int64)
         out = torch.empty(n, self.arch.out_dim, dtype=torch.float32, device=self.device)
         with self._lock, torch.cuda.device(self.device):
@@ -450,6 +496,8 @@ class ClipTextTower(_TextTowerBase):
     def encode_device(self, d_ids: Tensor, lengths: Tensor, normalize: bool = True) -> Tensor:
         """ids already on the device (engine/gpu_tokenizers.py): int32 [n, S] rows SOT ... EOT 0 ..., lengths int64 [n] on the
         host = SOT..EOT length.  Same as encode_ids(pack=True), but the packing runs on the GPU (mq_pack_ids)."""
+        if not self.arch.causal and (d_ids.shape[1] != self.arch.ctx or int(lengths.min()) != self.arch.ctx):
+            raise ValueError(f"an unmasked text tower runs exactly ctx = {self.arch.ctx} positions per text")
         return self._encode_device(d_ids, lengths, self.arch.ctx, normalize, clip=True)
 
 

@@ -310,3 +310,62 @@ def test_vit_wide_heads_vs_oracle(name, layers):
         t8 = T.VitTower(arch, sd, "cuda", precision="fp8")
         t8.calibrate_fp8(lambda: t8.encode_u8(u8.cuda()))
         assert _cos_err(t8.encode_u8(u8.cuda()), ref) < 1e-2
+
+
+def test_golden_siglip_small():
+    """SigLIP image (attention-pool head, no class token) and text (no mask, last-token pooling, biased projection) towers against
+    the transformers.Siglip* golden (tests/golden/make_golden.py::make_siglip)"""
+    T, A = _towers()
+    sd, z = G.load("siglip_small")
+    S, P, W, Lyr, H, Fd, V, ctx, D = [int(v) for v in z["cfg"]]
+    varch = A.VitArch(S, P, W, Lyr, H, Fd, W, ln_eps=1e-6, pool="map")
+    vt = T.VitTower(varch, sd, "cuda")
+    assert vt.cfg.pool == 1 and varch.tokens == (S // P) ** 2
+    px = torch.from_numpy(z["pixels"])
+    ref = torch.from_numpy(z["image_emb"])
+    # 1e-3 = the north-star tolerance: this fixture's weights are scaled 3x (make_golden._jitter) and a CPU emulation of the bf16
+    # dataflow (bf16 GEMM operands / LN outputs / P, fp32 accumulation and residual) already sits at 4.1e-4 on its third image
+    assert _cos_err(vt.encode_f32(px, normalize=False), ref) < 1e-3
+    out_n = vt.encode_f32(px)
+    assert torch.allclose(out_n.norm(dim=-1).cpu(), torch.ones(px.shape[0]), atol=1e-5)
+    assert _cos_err(vt.encode_f32(px[1:2]), out_n[1:2]) < 1e-5  # batching invariance
+    tarch = A.ClipTextArch(vocab=V, ctx=ctx, width=W, layers=Lyr, heads=H, mlp_dim=Fd, out_dim=D, ln_eps=1e-6, causal=False,
+                           proj_bias=True, prefix="text.", pad_id=1)
+    tt = T.ClipTextTower(tarch, sd, "cuda")
+    ids = torch.from_numpy(z["ids"])
+    assert _cos_err(tt.encode_ids(ids, normalize=False), torch.from_numpy(z["text_emb"])) < 1e-3
+    with pytest.raises(ValueError):
+        tt.encode_ids(ids[:, :ctx - 1])  # an unmasked tower must see all ctx positions
+    lengths = torch.full((ids.shape[0],), ctx, dtype=torch.int64)
+    dev = tt.encode_device(ids.to(torch.int32).to(tt.device), lengths, normalize=False)
+    assert _cos_err(dev, torch.from_numpy(z["text_emb"])) < 1e-3
+
+
+@pytest.mark.parametrize("name,layers,n", [("ViT-B-16-SigLIP", 3, 5), ("ViT-L-16-SigLIP-384", 2, 2)])
+def test_siglip_full_size_vs_oracle(name, layers, n):
+    """registry shapes (model_registry.py:385-432): 196 tokens x 768 and 576 tokens x 1024 (the 8-wave attention path), depth cut
+    to keep the fp32 CPU oracle in seconds; bf16 and fp8; text tower at ctx 64 over the 32 000-piece vocabulary"""
+    from dataclasses import replace
+    T, A = _towers()
+    varch, tarch = A.resolve_open_clip(name)
+    varch, tarch = replace(varch, layers=layers), replace(tarch, layers=layers)
+    vcfg = O.SiglipVitConfig(varch.image_size, varch.patch_size, varch.width, layers, varch.heads, varch.mlp_dim)
+    tcfg = O.SiglipTextConfig(tarch.vocab, tarch.ctx, tarch.width, layers, tarch.heads, tarch.mlp_dim, tarch.out_dim)
+    sd = O.synthetic_siglip_state_dict(vcfg, tcfg, seed=4)
+    mean = std = (0.5, 0.5, 0.5)
+    u8 = O.synthetic_images_u8(n, varch.image_size, seed=4)
+    ref = O.siglip_vit_forward(sd, vcfg, O.preprocess_u8_exact_size(u8, mean, std))
+    vt = T.VitTower(varch, sd, "cuda", mean=mean, std=std)
+    out = vt.encode_u8(u8.cuda())
+    assert _cos_err(out, ref) < COS_TIGHT
+    if name == "ViT-B-16-SigLIP":
+        v8 = T.VitTower(varch, sd, "cuda", mean=mean, std=std, precision="fp8")
+        v8.calibrate_fp8(lambda: v8.encode_u8(u8.cuda()))
+        assert _cos_err(v8.encode_u8(u8.cuda()), ref) < 1e-2
+        g = torch.Generator().manual_seed(4)
+        ids = torch.ones(7, tarch.ctx, dtype=torch.int64)
+        for i, ln in enumerate([3, 64, 9, 17, 40, 2, 33]):
+            ids[i, :ln - 1] = torch.randint(2, tarch.vocab, (ln - 1,), generator=g)
+        tref = O.siglip_text_forward(sd, tcfg, ids)
+        tt = T.ClipTextTower(tarch, sd, "cuda")
+        assert _cos_err(tt.encode_ids(ids), tref) < COS_TIGHT
