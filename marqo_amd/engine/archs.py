@@ -120,6 +120,10 @@ OPEN_CLIP_ARCHS = {
 UNSUPPORTED_HINT = ("this open_clip architecture is not runnable by the marqo_amd engine yet "
                     "(supported: " + ", ".join(sorted(OPEN_CLIP_ARCHS)) + " and their -quickgelu variants)")
 
+# hf-hub repos the reference registry names (model_registry.py:483-494) -> the open_clip architecture their open_clip_config.json
+# describes (used when that file is not on disk, e.g. with synthetic weights)
+KNOWN_HF_HUB_ARCHS = {"hf-hub:Marqo/marqo-fashionCLIP": "ViT-B-16", "hf-hub:Marqo/marqo-fashionSigLIP": "ViT-B-16-SigLIP"}
+
 # OpenAI `clip` names (clip_utils.py:295-492) -> open_clip architecture (always QuickGELU)
 OPENAI_CLIP_NAMES = {"ViT-B/32": "ViT-B-32", "ViT-B/16": "ViT-B-16", "ViT-L/14": "ViT-L-14", "ViT-L/14@336px": "ViT-L-14-336"}
 

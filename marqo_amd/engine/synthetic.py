@@ -43,7 +43,31 @@ def random_open_clip_state_dict(vision: VitArch = None, text: ClipTextArch = Non
     """open_clip-named state dict for the given towers (either may be None)."""
     g = torch.Generator().manual_seed(seed)
     sd: Dict[str, Tensor] = {}
-    if vision is not None:
+    if vision is not None and vision.pool == "map":
+        # timm SigLIP ViT as open_clip's visual.trunk (no class token, conv bias, attention-pool head)
+        W, P, F, t = vision.width, vision.patch_size, vision.mlp_dim, "visual.trunk."
+        std = 0.6 / math.sqrt(W)
+        sd[t + "patch_embed.proj.weight"] = torch.randn(W, 3, P, P, generator=g) / math.sqrt(3 * P * P)
+        sd[t + "patch_embed.proj.bias"] = 0.05 * torch.randn(W, generator=g)
+        sd[t + "pos_embed"] = 0.3 * torch.randn(1, vision.tokens, W, generator=g)
+        for i in range(vision.layers):
+            p = f"{t}blocks.{i}."
+            _ln(sd, p + "norm1", W, g)
+            _lin(sd, p + "attn.qkv", 3 * W, W, g, std)
+            _lin(sd, p + "attn.proj", W, W, g, std)
+            _ln(sd, p + "norm2", W, g)
+            _lin(sd, p + "mlp.fc1", F, W, g, std)
+            _lin(sd, p + "mlp.fc2", W, F, g, std / 2)
+        _ln(sd, t + "norm", W, g)
+        a = t + "attn_pool."
+        sd[a + "latent"] = torch.randn(1, 1, W, generator=g) / math.sqrt(W)
+        _lin(sd, a + "q", W, W, g, std)
+        _lin(sd, a + "kv", 2 * W, W, g, std)
+        _lin(sd, a + "proj", W, W, g, std)
+        _ln(sd, a + "norm", W, g)
+        _lin(sd, a + "mlp.fc1", F, W, g, std)
+        _lin(sd, a + "mlp.fc2", W, F, g, std / 2)
+    elif vision is not None:
         W, P = vision.width, vision.patch_size
         sd["visual.conv1.weight"] = torch.randn(W, 3, P, P, generator=g) / math.sqrt(3 * P * P)
         sd["visual.class_embedding"] = 0.5 * torch.randn(W, generator=g)
@@ -53,12 +77,15 @@ def random_open_clip_state_dict(vision: VitArch = None, text: ClipTextArch = Non
         _ln(sd, "visual.ln_post", W, g)
         sd["visual.proj"] = torch.randn(W, vision.out_dim, generator=g) / math.sqrt(W)
     if text is not None:
-        W = text.width
-        sd["token_embedding.weight"] = 0.5 * torch.randn(text.vocab, W, generator=g)
-        sd["positional_embedding"] = 0.3 * torch.randn(text.ctx, W, generator=g)
-        _resblocks(sd, "transformer.", text.layers, W, text.mlp_dim, g)
-        _ln(sd, "ln_final", W, g)
-        sd["text_projection"] = torch.randn(W, text.out_dim, generator=g) / math.sqrt(W)
+        W, px = text.width, text.prefix
+        sd[px + "token_embedding.weight"] = 0.5 * torch.randn(text.vocab, W, generator=g)
+        sd[px + "positional_embedding"] = 0.3 * torch.randn(text.ctx, W, generator=g)
+        _resblocks(sd, px + "transformer.", text.layers, W, text.mlp_dim, g)
+        _ln(sd, px + "ln_final", W, g)
+        if text.proj_bias:
+            _lin(sd, px + "text_projection", text.out_dim, W, g, 1.0 / math.sqrt(W))
+        else:
+            sd[px + "text_projection"] = torch.randn(W, text.out_dim, generator=g) / math.sqrt(W)
         sd["logit_scale"] = torch.tensor(math.log(1 / 0.07))
     return sd
 

@@ -339,15 +339,72 @@ class XlmRobertaTokenizer:
 # ---------------------------------------------------------------------------------------------------
 # stand-in for random-init models (no vocabulary exists for them)
 # ---------------------------------------------------------------------------------------------------
+def canonicalize_text(text: str) -> str:
+    """open_clip's `canonicalize_text` (tokenizer.py; the `clean: canonicalize` of the SigLIP model configs, after big_vision):
+    underscores to spaces, every `string.punctuation` character removed, lower-cased, whitespace runs collapsed, stripped."""
+    text = text.replace("_", " ").translate(_PUNCT_TABLE).lower()
+    return " ".join(text.split())
+
+
+_PUNCT_TABLE = str.maketrans("", "", __import__("string").punctuation)
+
+
+class SiglipTokenizer:
+    """open_clip HFTokenizer over the SigLIP checkpoints' T5-style SentencePiece vocabulary (32 000 pieces; `timm/ViT-B-16-SigLIP`
+    and the Marqo fashion / e-commerce repos ship `tokenizer.json` + `spiece.model`): canonicalize -> pieces + </s> (id 1),
+    truncated to and padded (with </s>, the pad token of these tokenizers) to context_length = 64 -> int64 [n, 64].
+    `tokenizer.json` is read with the `tokenizers` wheel (what AutoTokenizer's fast path runs); a bare `spiece.model` with
+    `sentencepiece`."""
+
+    def __init__(self, path: str, context_length: int = 64):
+        self.context_length = context_length
+        self.eos_id = self.pad_id = 1
+        self._fast = self._sp = None
+        d = path if os.path.isdir(path) else os.path.dirname(path)
+        tj = path if path.endswith(".json") else os.path.join(d, "tokenizer.json")
+        sm = path if path.endswith(".model") else os.path.join(d, "spiece.model")
+        if os.path.isfile(tj) and not path.endswith(".model"):
+            from tokenizers import Tokenizer
+            self._fast = Tokenizer.from_file(tj)
+            self._fast.enable_truncation(max_length=context_length)
+            self._fast.no_padding()
+            self.vocab_size = self._fast.get_vocab_size()
+        elif os.path.isfile(sm):
+            import sentencepiece as spm
+            self._sp = spm.SentencePieceProcessor(model_file=sm)
+            self.vocab_size = len(self._sp)
+        else:
+            raise FileNotFoundError(f"no tokenizer.json / spiece.model under {d}")
+
+    def encode(self, text: str) -> List[int]:
+        text = canonicalize_text(text)
+        if self._fast is not None:
+            return list(self._fast.encode(text).ids)
+        ids = list(self._sp.encode(text))[: self.context_length - 1]
+        return ids + [self.eos_id]
+
+    def __call__(self, texts: Union[str, Sequence[str]]) -> np.ndarray:
+        if isinstance(texts, str):
+            texts = [texts]
+        out = np.full((len(texts), self.context_length), self.pad_id, dtype=np.int64)
+        for i, t in enumerate(texts):
+            ids = self.encode(t)
+            out[i, :len(ids)] = ids
+        return out
+
+
 class SyntheticTokenizer:
     """Deterministic whitespace-word hash -> id map.  kind='clip': [n, ctx] SOT ... EOT zero-padded with EOT the
-    largest id (so argmax pooling finds it); kind='bert': CLS ... SEP, padded to the longest, with a mask."""
+    largest id (so argmax pooling finds it); kind='siglip': [n, ctx] words ... </s> padded with </s> (id 1);
+    kind='bert': CLS ... SEP, padded to the longest, with a mask."""
 
     def __init__(self, kind: str, vocab_size: int, context_length: int = 77):
-        assert kind in ("clip", "bert")
+        assert kind in ("clip", "bert", "siglip")
         self.kind, self.vocab_size, self.context_length = kind, vocab_size, context_length
         if kind == "clip":
             self.sot_id, self.eot_id, self.lo, self.hi = vocab_size - 2, vocab_size - 1, 1, vocab_size - 2
+        elif kind == "siglip":
+            self.eos_id, self.lo, self.hi = 1, 2, vocab_size
         else:
             self.cls_id, self.sep_id, self.pad_id, self.lo, self.hi = 101, 102, 0, 1000, vocab_size
 
@@ -361,6 +418,13 @@ class SyntheticTokenizer:
     def __call__(self, texts, max_length: Optional[int] = None):
         if isinstance(texts, str):
             texts = [texts]
+        if self.kind == "siglip":
+            L = self.context_length
+            out = np.full((len(texts), L), self.eos_id, dtype=np.int64)
+            for i, t in enumerate(texts):
+                ids = self.encode_words(canonicalize_text(t))[:L - 1]
+                out[i, :len(ids)] = ids
+            return out
         if self.kind == "clip":
             L = self.context_length
             out = np.zeros((len(texts), L), dtype=np.int64)

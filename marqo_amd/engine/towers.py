@@ -36,7 +36,9 @@ def _require_gpu(device: str) -> torch.device:
             f"got device={device!r}. There is no CPU fallback.")
     if not torch.cuda.is_available():
         raise L.MarqoHipUnavailableError("no GPU is visible to PyTorch-ROCm; the marqo_amd engine has no CPU fallback")
-    return torch.device(device)
+    d = torch.device(device)
+    # 'cuda' -> 'cuda:<current>': tensors report an indexed device, and the towers compare devices
+    return d if d.index is not None else torch.device("cuda", torch.cuda.current_device())
 
 
 class _Holder:

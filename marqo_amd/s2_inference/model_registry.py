@@ -26,6 +26,9 @@ _OPEN_CLIP_TAGS = {
     "ViT-H-14-quickgelu": ["dfn5b"],
     "ViT-g-14": ["laion2b_s12b_b42k", "laion2b_s34b_b88k"],
     "ViT-bigG-14": ["laion2b_s39b_b160k"],
+    # SigLIP (model_registry.py:385-432); -512 (1024 tokens) and SO400M-14-384 (729 tokens) exceed the LDS-resident attention
+    "ViT-B-16-SigLIP": ["webli"], "ViT-B-16-SigLIP-256": ["webli"], "ViT-B-16-SigLIP-384": ["webli"],
+    "ViT-L-16-SigLIP-256": ["webli"], "ViT-L-16-SigLIP-384": ["webli"],
 }
 
 # hf registry entries whose encoder is a plain BERT (absolute positions, GELU, post-LN): name -> (repo, dims, tokens, prefixes)
@@ -64,6 +67,9 @@ def _get_open_clip_properties() -> Dict:
             name = f"open_clip/{arch_name}/{tag}"
             out[name] = {"name": name, "dimensions": vision.out_dim, "note": f"open_clip {arch_name} ({tag})",
                          "type": "open_clip", "pretrained": tag}
+    for hub_name, arch_name in archs.KNOWN_HF_HUB_ARCHS.items():  # Marqo's fashion models (model_registry.py:483-494)
+        vision, _ = archs.resolve_open_clip(arch_name)
+        out[hub_name[len("hf-hub:"):]] = {"name": hub_name, "dimensions": vision.out_dim, "note": f"{hub_name} ({arch_name})", "type": "open_clip"}
     return out
 
 

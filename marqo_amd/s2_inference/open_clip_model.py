@@ -23,7 +23,7 @@ from PIL.Image import Image as ImageType
 
 from marqo_amd import _lib as L
 from marqo_amd.engine import archs, checkpoint, synthetic
-from marqo_amd.engine.tokenizers import ClipBpeTokenizer, SyntheticTokenizer, WordPieceTokenizer
+from marqo_amd.engine.tokenizers import ClipBpeTokenizer, SiglipTokenizer, SyntheticTokenizer, WordPieceTokenizer
 from marqo_amd.s2_inference.abstract_models import AbstractCLIPModel
 from marqo_amd.s2_inference.errors import InvalidModelPropertiesError, ModelLoadError
 from marqo_amd.s2_inference.image_input import format_and_load_CLIP_image, format_and_load_CLIP_images, pil_to_rgb_u8
@@ -33,10 +33,14 @@ MARQO_OPEN_CLIP_REGISTRY_PREFIX = "open_clip/"
 BPE_VOCAB_FILE = "bpe_simple_vocab_16e6.txt.gz"
 
 _PREPROCESSOR_NORMS = {
-    # image_preprocessor -> (mean, std); OpenCLIP / OpenAI share the OpenAI dataset statistics (clip_utils.py:32-33)
-    "OpenCLIP": (archs.OPENAI_DATASET_MEAN, archs.OPENAI_DATASET_STD),
-    "OpenAI": (archs.OPENAI_DATASET_MEAN, archs.OPENAI_DATASET_STD),
+    # image_preprocessor -> (mean, std, resize_mode): open_clip's _pcfg() / _slpcfg() base configs the reference starts from
+    # (open_clip_model.py:87-97).  OpenCLIP / OpenAI share the OpenAI dataset statistics (clip_utils.py:32-33) and resize the shorter
+    # side then centre-crop; SigLIP normalises with 0.5 / 0.5 and squashes the image to S x S.  (CLIPA's bilinear squash is not built.)
+    "OpenCLIP": (archs.OPENAI_DATASET_MEAN, archs.OPENAI_DATASET_STD, "shortest"),
+    "OpenAI": (archs.OPENAI_DATASET_MEAN, archs.OPENAI_DATASET_STD, "shortest"),
+    "SigLIP": ((0.5, 0.5, 0.5), (0.5, 0.5, 0.5), "squash"),
 }
+_TIMM_SIGLIP = __import__("re").compile(r"^vit_(base|large)_patch16_siglip_(\d+)$")
 
 
 class OpenCLIPModelProperties:
@@ -120,11 +124,24 @@ class OPEN_CLIP(AbstractCLIPModel):
     def _resolve_archs(self, arch_name: str, tag: Optional[str], ckpt_dir: Optional[str]):
         if arch_name.startswith(HF_HUB_PREFIX):
             cfg_path = os.path.join(ckpt_dir or "", "open_clip_config.json")
+            if not os.path.isfile(cfg_path) and arch_name in archs.KNOWN_HF_HUB_ARCHS:
+                return archs.resolve_open_clip(archs.KNOWN_HF_HUB_ARCHS[arch_name])
             if not os.path.isfile(cfg_path):
                 raise ModelLoadError(f"{arch_name}: open_clip_config.json not found next to the checkpoint")
             with open(cfg_path) as f:
                 mc = json.load(f)["model_cfg"]
             v, t = mc["vision_cfg"], mc["text_cfg"]
+            m = _TIMM_SIGLIP.match(str(v.get("timm_model_name", "")))
+            if m and "hf_model_name" not in t:
+                # SigLIP: timm trunk + TextTransformer(no_causal_mask, pool 'last', proj_bias) — marqo-fashionSigLIP, marqo-ecommerce-*
+                if v.get("timm_pool", "map") != "map" or v.get("timm_proj", "none") not in ("none", None, ""):
+                    raise InvalidModelPropertiesError(f"{arch_name}: timm towers are supported with pool 'map' and no projection only")
+                vision, text = archs._siglip(int(v.get("image_size", m.group(2))), large=m.group(1) == "large")
+                if mc["embed_dim"] != vision.width or t.get("width", vision.width) != text.width or t.get("layers", text.layers) != text.layers:
+                    raise InvalidModelPropertiesError(f"{arch_name}: unexpected SigLIP dimensions in open_clip_config.json")
+                from dataclasses import replace
+                return vision, replace(text, vocab=t.get("vocab_size", text.vocab), ctx=t.get("context_length", text.ctx),
+                                       causal=not t.get("no_causal_mask", True), proj_bias=bool(t.get("proj_bias", True)))
             if not isinstance(v.get("layers"), int) or "hf_model_name" in t:
                 raise InvalidModelPropertiesError(f"{arch_name}: only plain CLIP ViT + CLIP text towers are supported. {archs.UNSUPPORTED_HINT}")
             head = v.get("head_width", 64)
@@ -169,14 +186,18 @@ class OPEN_CLIP(AbstractCLIPModel):
         else:
             raise ModelLoadError(f"no checkpoint for {props.name} under {checkpoint.model_dir()} (and no 'localpath'). There is no "
                                  f"network download in the marqo_amd engine; set MARQO_AMD_SYNTHETIC_WEIGHTS=1 for random-init weights.")
-        if props.image_preprocessor not in _PREPROCESSOR_NORMS:
-            raise InvalidModelPropertiesError(f"image_preprocessor={props.image_preprocessor} (squash-resize pipelines) is not supported "
-                                              f"by the marqo_amd engine yet; supported: {sorted(_PREPROCESSOR_NORMS)}")
-        mean, std = _PREPROCESSOR_NORMS[props.image_preprocessor]
+        # preprocessing: a custom checkpoint follows 'image_preprocessor' (open_clip_model.py:87-104); registry and hf-hub names
+        # get open_clip's own transform for that model (create_model_and_transforms, :183-205) — the SigLIP pipeline for SigLIP towers
+        custom = props.localpath is not None
+        kind = props.image_preprocessor if custom else ("SigLIP" if self.vision_arch.pool == "map" else "OpenCLIP")
+        if kind not in _PREPROCESSOR_NORMS:
+            raise InvalidModelPropertiesError(f"image_preprocessor={kind} (bilinear squash) is not supported by the marqo_amd engine yet; "
+                                              f"supported: {sorted(_PREPROCESSOR_NORMS)}")
+        mean, std, self._resize_mode = _PREPROCESSOR_NORMS[kind]
         self._mean = tuple(props.mean) if props.mean is not None else mean
         self._std = tuple(props.std) if props.std is not None else std
         self.preprocess_config = {"size": self.vision_arch.image_size, "mean": self._mean, "std": self._std,
-                                  "interpolation": "bicubic", "resize_mode": "shortest"}
+                                  "interpolation": "bicubic", "resize_mode": self._resize_mode}
         try:
             self.vision = towers.VitTower(self.vision_arch, sd, self.device, mean=self._mean, std=self._std, precision=props.engine_precision)
             self.text = towers.ClipTextTower(self.text_arch, sd, self.device, precision=props.engine_precision)
@@ -211,6 +232,14 @@ class OPEN_CLIP(AbstractCLIPModel):
                     out[i, :len(ids)] = ids
                 return out
             return hf_tok
+        if not self.text_arch.causal:  # SigLIP: T5-style SentencePiece vocabulary next to the checkpoint (tokenizer.json / spiece.model)
+            for d in filter(None, (ckpt_dir, os.path.join(checkpoint.model_dir(), "siglip"))):
+                if os.path.isfile(os.path.join(d, "tokenizer.json")) or os.path.isfile(os.path.join(d, "spiece.model")):
+                    return SiglipTokenizer(d, context_length=self.text_arch.ctx)
+            if self.weights_source and str(self.weights_source).startswith("synthetic"):
+                return SyntheticTokenizer("siglip", self.text_arch.vocab, self.text_arch.ctx)
+            raise ModelLoadError(f"SigLIP tokenizer (tokenizer.json / spiece.model) not found next to the checkpoint or under "
+                                 f"{os.path.join(checkpoint.model_dir(), 'siglip')}")
         for d in filter(None, (ckpt_dir, checkpoint.model_dir(), os.path.join(checkpoint.model_dir(), "open_clip"))):
             p = os.path.join(d, BPE_VOCAB_FILE)
             if os.path.isfile(p):
@@ -240,8 +269,13 @@ class OPEN_CLIP(AbstractCLIPModel):
         """PIL image -> Tensor[3, S, S] fp32 (normalised), ALREADY on the device: resize / crop / normalise run on the GPU.
         Callers' `.to(device)` (add_docs.py:134) is then a no-op."""
         pre = self._pre()
-        u8 = pre.resize_crop_u8([pil_to_rgb_u8(image)])
+        u8 = self._resize(pre, [pil_to_rgb_u8(image)])
         return pre.to_tensor_normalize(u8)[0]
+
+    def _resize(self, pre, raw) -> torch.Tensor:
+        """list of uint8 [H, W, 3] -> uint8 [n, S, S, 3] on the device: Resize(S) + CenterCrop(S), or Resize((S, S)) ('squash')"""
+        S = self.vision_arch.image_size
+        return pre.resize_u8(raw, S, S) if self._resize_mode == "squash" else pre.resize_crop_u8(raw)
 
     def _preprocess_images(self, images, image_download_headers: Optional[Dict] = None):
         """-> ('u8', uint8 [n,S,S,3]) or ('f32', fp32 [n,3,S,S]) on the device."""
@@ -259,7 +293,7 @@ class OPEN_CLIP(AbstractCLIPModel):
         if len(tensors) == len(loaded):
             return "f32", torch.stack([t.to(self.device) for t in tensors])
         raw = [pil_to_rgb_u8(i) for i in loaded if not isinstance(i, torch.Tensor)]
-        u8 = pre.resize_crop_u8(raw)
+        u8 = self._resize(pre, raw)
         if not tensors:
             return "u8", u8
         f32 = iter(pre.to_tensor_normalize(u8))
@@ -301,6 +335,9 @@ class OPEN_CLIP(AbstractCLIPModel):
         """'simple' / 'overlap' patch methods entirely on the device: -> (embeddings [n, count, D], boxes [n, count, 4])."""
         raw = [pil_to_rgb_u8(i) if isinstance(i, ImageType) else np.asarray(i) for i in images]
         u8, boxes = self._pre().chunk_grid_u8(raw, hn, wn, overlap)
+        if self._resize_mode == "squash" and len(raw):
+            # the grid crops are square (shorter-side resize + crop == squash); chunk 0, the whole image, is not
+            u8[0::u8.shape[0] // len(raw)] = self._resize(self._pre(), raw)
         self._calibrated(self.vision, lambda: self.vision.encode_u8(u8))
         emb = self._convert_output(self.vision.encode_u8(u8, normalize=bool(normalize)))
         return emb.reshape(len(raw), -1, emb.shape[-1]), boxes

@@ -240,3 +240,70 @@ def test_hf_xlm_roberta_from_disk(s2, tmp_path):
     assert np.asarray(out).shape == (4, 128) and _cos_err(out, ref) < COS_TOL
     model = s2i.get_available_models()[s2i._create_model_cache_key("tiny-xlmr", DEV, props)]["model"]
     assert type(model._tokenizer).__name__ == "XlmRobertaTokenizer" and model._device_tokenizer is None and model.arch.pos_offset == 2
+
+
+def test_siglip_from_disk_text_and_image(s2, tmp_path, monkeypatch):
+    """A SigLIP checkpoint through the loader: open_clip / timm tensor names (visual.trunk.*, text.*), SentencePiece tokenizer with
+    canonicalize, SigLIP preprocessing (squash to S x S, mean = std = 0.5), 'open_clip' loader type — against the fp32 oracle.
+    (Real SigLIP shapes come from the architecture table; a small one is registered for this test.)"""
+    s2i, root = s2
+    import sentencepiece as spm
+    from safetensors.torch import save_file
+    from marqo_amd.engine import archs as A
+    from marqo_amd.engine.tokenizers import SiglipTokenizer
+    from tests.test_tokenizers import CORPUS, SENTENCES
+    S, P, W, Lyr, H, Fd, ctx = 64, 16, 128, 2, 2, 256, 64
+    d = tmp_path / "tiny-siglip"
+    d.mkdir()
+    (d / "corpus.txt").write_text("\n".join([" ".join(CORPUS)] * 20 + SENTENCES[:6] * 5).lower(), encoding="utf-8")
+    spm.SentencePieceTrainer.train(input=str(d / "corpus.txt"), model_prefix=str(d / "spiece"), vocab_size=120, model_type="unigram",
+                                   character_coverage=1.0, hard_vocab_limit=False, minloglevel=2, pad_id=0, eos_id=1, unk_id=2, bos_id=-1)
+    tok = SiglipTokenizer(str(d / "spiece.model"), context_length=ctx)
+    V = tok.vocab_size
+    vcfg = O.SiglipVitConfig(S, P, W, Lyr, H, Fd)
+    tcfg = O.SiglipTextConfig(V, ctx, W, Lyr, H, Fd, W)
+    sd = O.synthetic_siglip_state_dict(vcfg, tcfg, seed=6)
+    save_file({k: v.contiguous() for k, v in sd.items()}, str(d / "open_clip_model.safetensors"))
+    monkeypatch.setitem(A.OPEN_CLIP_ARCHS, "tiny-SigLIP", (
+        A.VitArch(S, P, W, Lyr, H, Fd, W, ln_eps=1e-6, pool="map"),
+        A.ClipTextArch(vocab=V, ctx=ctx, width=W, layers=Lyr, heads=H, mlp_dim=Fd, out_dim=W, ln_eps=1e-6, causal=False,
+                       proj_bias=True, prefix="text.", pad_id=1)))
+    props = {"name": "tiny-SigLIP", "dimensions": W, "type": "open_clip", "localpath": str(d / "open_clip_model.safetensors"),
+             "image_preprocessor": "SigLIP"}
+    texts = ["A photo of a CAT!", "the quick_brown fox, jumps over the lazy dog", "marqo is a tensor search engine", "fox " * 100]
+    out = s2i.vectorise("tiny-siglip", texts, model_properties=props, device=DEV)
+    ref = O.siglip_text_forward(sd, tcfg, torch.from_numpy(tok(texts))).numpy()
+    assert np.asarray(out).shape == (4, W) and _cos_err(out, ref) < COS_TOL
+    assert np.allclose(np.linalg.norm(np.asarray(out), axis=1), 1.0, atol=1e-5)
+    assert np.allclose(s2i.vectorise("tiny-siglip", "a photo of a cat", model_properties=props, device=DEV), out[:1], atol=1e-6)  # canonicalize
+    model = s2i.get_available_models()[s2i._create_model_cache_key("tiny-siglip", DEV, props)]["model"]
+    assert model.preprocess_config["resize_mode"] == "squash" and model.preprocess_config["mean"] == (0.5, 0.5, 0.5)
+    # images: squash = PIL resize((S, S), BICUBIC), no crop
+    rng = np.random.default_rng(1)
+    pil = [Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)) for h, w in [(64, 64), (100, 80), (70, 200)]]
+    emb = s2i.vectorise("tiny-siglip", pil, model_properties=props, device=DEV, modality=s2i.Modality.IMAGE)
+    half = (0.5, 0.5, 0.5)
+    px = torch.from_numpy(np.stack([OP.to_tensor_normalize(np.asarray(p.resize((S, S), Image.BICUBIC)), half, half) for p in pil]))
+    refi = O.siglip_vit_forward(sd, vcfg, px).numpy()
+    assert _cos_err(emb, refi) < COS_TOL
+    t = model.preprocess(pil[2])
+    assert tuple(t.shape) == (3, S, S) and float((t.cpu() - px[2]).abs().max()) < 1e-6
+    # chunking with the squash pipeline: chunk 0 is the whole image squashed, the grid crops are square
+    ce, boxes = model.encode_image_chunks([pil[2]], 3, 3, False)
+    patches, _ = OP.chunk_image_simple(np.asarray(pil[2]), 3, 3, False)
+    pc = [OP.to_tensor_normalize(np.asarray(Image.fromarray(p).resize((S, S), Image.BICUBIC)), half, half) for p in patches]
+    refc = O.siglip_vit_forward(sd, vcfg, torch.from_numpy(np.stack(pc))).numpy()
+    assert ce.shape == (1, 10, W) and _cos_err(ce[0], refc) < COS_TOL
+    # registry / hf-hub names pick the SigLIP pipeline by themselves
+    os.environ["MARQO_AMD_SYNTHETIC_WEIGHTS"] = "1"
+    try:
+        for name in ("open_clip/ViT-B-16-SigLIP/webli", "Marqo/marqo-fashionSigLIP"):
+            v = s2i.vectorise(name, ["a red dress", "blue denim jeans"], device=DEV)
+            assert np.asarray(v).shape == (2, 768)
+            m = next(x["model"] for k, x in s2i.get_available_models().items() if k.startswith(name))
+            assert m.preprocess_config["resize_mode"] == "squash" and m.vision_arch.pool == "map" and not m.text_arch.causal
+            iv = s2i.vectorise(name, pil[:2], device=DEV, modality=s2i.Modality.IMAGE)
+            assert np.asarray(iv).shape == (2, 768) and np.allclose(np.linalg.norm(np.asarray(iv), axis=1), 1.0, atol=1e-5)
+            s2i.eject_model(name, DEV)
+    finally:
+        os.environ.pop("MARQO_AMD_SYNTHETIC_WEIGHTS", None)

@@ -166,3 +166,30 @@ def test_xlm_roberta_sentencepiece_matches_transformers(tmp_path):
     got = ours(texts, max_length=16)
     assert np.array_equal(got["input_ids"], ref["input_ids"]) and np.array_equal(got["attention_mask"], ref["attention_mask"])
     assert (ours.cls_id, ours.pad_id, ours.sep_id, ours.unk_id) == (hf.cls_token_id, hf.pad_token_id, hf.sep_token_id, hf.unk_token_id)
+
+
+def test_siglip_tokenizer_matches_transformers_t5(tmp_path):
+    """SigLIP text towers: open_clip HFTokenizer(clean='canonicalize', context 64) over a T5-style SentencePiece vocabulary ==
+    canonicalize + transformers' T5 tokenizer called the way open_clip calls it (max_length padding with </s>, truncation).
+    A tiny unigram model is trained here: no real vocabulary exists offline."""
+    import sentencepiece as spm
+    from transformers import T5Tokenizer
+    from marqo_amd.engine.tokenizers import SiglipTokenizer, canonicalize_text
+    corpus = tmp_path / "corpus.txt"
+    corpus.write_text("\n".join([" ".join(CORPUS)] * 20 + SENTENCES[:6] * 5).lower(), encoding="utf-8")
+    spm.SentencePieceTrainer.train(input=str(corpus), model_prefix=str(tmp_path / "spiece"), vocab_size=120, model_type="unigram",
+                                   character_coverage=1.0, hard_vocab_limit=False, minloglevel=2, pad_id=0, eos_id=1, unk_id=2, bos_id=-1)
+    hf = T5Tokenizer.from_pretrained(str(tmp_path), pad_token="</s>", extra_ids=0)   # SigLIP's tokenizer config: pad = </s> (id 1)
+    hf.save_pretrained(str(tmp_path / "hf"))
+    assert canonicalize_text("  Hello,  World_foo! (a-b)\tX ") == "hello world foo ab x"
+    texts = [s for s in SENTENCES if s] + ["A red_dress, size: M (new!)", "  leading and   double  spaces ", "UPPER lower", "word " * 100]
+    ctx = 16
+    ref = np.asarray(hf([canonicalize_text(t) for t in texts], max_length=ctx, padding="max_length", truncation=True)["input_ids"])
+    assert ref.shape == (len(texts), ctx) and (ref[:, -1] == 1).all()
+    backends = [SiglipTokenizer(str(tmp_path / "spiece.model"), context_length=ctx)]
+    if (tmp_path / "hf" / "tokenizer.json").exists():
+        backends.append(SiglipTokenizer(str(tmp_path / "hf"), context_length=ctx))
+    for tok in backends:
+        got = tok(texts)
+        assert got.dtype == np.int64 and np.array_equal(got, ref), (tok._fast is not None)
+    assert np.array_equal(backends[0]("UPPER lower"), backends[0](["upper, lower!"]))
