@@ -39,6 +39,9 @@ WORKLOADS = {
     "vit_l14_image": dict(kind="image", arch="ViT-L-14", desc="open_clip ViT-L/14 image tower, uint8 224x224, batch 64/GPU", batch=64),
     "vit_h14_image": dict(kind="image", arch="ViT-H-14", desc="open_clip ViT-H/14 image tower (80-wide heads run as 96), uint8 224x224, batch 64/GPU", batch=64),
     "vit_bigg14_image": dict(kind="image", arch="ViT-bigG-14", desc="open_clip ViT-bigG/14 image tower (104-wide heads run as 112), uint8 224x224, batch 32/GPU", batch=32),
+    "siglip_b16_image": dict(kind="image", arch="ViT-B-16-SigLIP", desc="open_clip ViT-B-16-SigLIP image tower (196 tokens, attention-pool head), uint8 224x224, batch 128/GPU", batch=128),
+    "siglip_l16_384_image": dict(kind="image", arch="ViT-L-16-SigLIP-384", desc="open_clip ViT-L-16-SigLIP-384 image tower (576 tokens), uint8 384x384, batch 32/GPU", batch=32),
+    "siglip_b16_text": dict(kind="clip_text", arch="ViT-B-16-SigLIP", desc="open_clip ViT-B-16-SigLIP text tower (unmasked, 64 positions), batch 1024/GPU", batch=1024),
     "clip_text_b32": dict(kind="clip_text", arch="ViT-B-32", desc="open_clip ViT-B/32 text tower, 77-token ids, batch 1024/GPU", batch=1024),
     "clip_text_l14": dict(kind="clip_text", arch="ViT-L-14", desc="open_clip ViT-L/14 text tower, 77-token ids, batch 1024/GPU", batch=1024),
     "bert_base_77": dict(kind="bert", arch="intfloat/e5-base-v2", desc="e5-base-v2 (BERT-base) + mean-pool + L2, 77-token ids, batch 1024/GPU", batch=1024),
@@ -67,13 +70,16 @@ def cpu_baseline(sd, arch, images_u8_cpu, target_seconds):
     import numpy as np
     from oracle import towers as O
     cores = os.cpu_count() or 1
-    cfg = O.VitConfig(arch.image_size, arch.patch_size, arch.width, arch.layers, arch.heads, arch.mlp_dim,
-                      arch.out_dim, arch.quick_gelu)
+    if arch.pool == "map":
+        cfg, fwd = O.SiglipVitConfig(arch.image_size, arch.patch_size, arch.width, arch.layers, arch.heads, arch.mlp_dim), O.siglip_vit_forward
+    else:
+        cfg, fwd = O.VitConfig(arch.image_size, arch.patch_size, arch.width, arch.layers, arch.heads, arch.mlp_dim,
+                               arch.out_dim, arch.quick_gelu), O.vit_forward
 
     def run(imgs):
         outs = []
         for i in range(0, imgs.shape[0], 16):  # MARQO_MAX_VECTORISE_BATCH_SIZE default (api/configs.py:38)
-            outs.append(O.vit_forward(sd, cfg, O.preprocess_u8_exact_size(imgs[i:i + 16])).numpy())
+            outs.append(fwd(sd, cfg, O.preprocess_u8_exact_size(imgs[i:i + 16])).numpy())
         return np.concatenate(outs, axis=0)
 
     t_start = time.perf_counter()
@@ -151,11 +157,16 @@ def main():
     elif kind == "clip_text":
         sd = synthetic.random_open_clip_state_dict(text=tarch, seed=0)
         tower = towers.ClipTextTower(tarch, sd, dev, precision=args.precision)
-        ids = clip_ids(batch, 75, 75)
         towers_used = [tower]
-        gflop_per_emb = tarch.gflop_per_text(77)
+        gflop_per_emb = tarch.gflop_per_text(tarch.ctx)
         # ids resident in HBM like the images (what the device tokeniser hands over); only the n lengths live on the host
-        d_ids, lens = ids.to(torch.int32).to(dev), ids.argmax(1) + 1
+        if tarch.causal:
+            ids = clip_ids(batch, 75, 75)
+            d_ids, lens = ids.to(torch.int32).to(dev), ids.argmax(1) + 1
+        else:  # SigLIP: every text is ctx positions (pieces ... </s> then </s> padding), all of them run
+            ids = torch.ones(batch, tarch.ctx, dtype=torch.int64)
+            ids[:, :20] = torch.randint(2, tarch.vocab, (batch, 20), generator=g)
+            d_ids, lens = ids.to(torch.int32).to(dev), torch.full((batch,), tarch.ctx, dtype=torch.int64)
         run_local = lambda: tower.encode_device(d_ids, lens)
     elif kind == "bert":
         barch = archs.HF_BERT_ARCHS[wl["arch"]]
