@@ -2,8 +2,9 @@
 // HD = 128 makes the LDS rows 256 B (16 chunk slots swizzled by key & 15) and HS = 96 / 112 / 128 is the head stride in global
 // memory = the dims actually computed (the 80 / 88 / 104-wide heads of ViT-H / g / bigG are zero-padded to 96 / 96 / 112 at load).
 //
-// One workgroup (4 wave64s) per (sequence, head).  The whole K [len,64] and V [len,64] of that
-// (sequence, head) are staged ONCE in LDS by LDS-DMA (global_load_lds: every 1-KiB piece is in flight at once, no
+// One workgroup (4 or 8 wave64s) per (sequence, head).  The whole K [len,64] and V [len,64] of that
+// (sequence, head) are staged ONCE in LDS by LDS-DMA (sequences longer than the LDS holds — 640 keys at 128-byte rows, 320 at
+// 256-byte rows — stream through it in pieces, re-staged for every round of query blocks) (global_load_lds: every 1-KiB piece is in flight at once, no
 // register round trip; 160 KB/CU makes this possible up to 512 keys: 64 KB + 64 KB), both row-major with the 16-B
 // chunks XOR-swizzled by (key & 7).  Each wave then owns 16-query blocks and runs a flash-style online softmax over
 // 64-key tiles with both GEMMs on v_mfma_f32_16x16x32_bf16; the V^T operand of the second GEMM is produced by
@@ -60,22 +61,27 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(
 
     // ---- stage K and V: RPP rows x RB bytes per LDS-DMA; lane -> (row = RPP*piece + lane/NC, physical chunk = lane%NC) fetches
     // the logical chunk that lives there.  Rows past the sequence re-read its last row (finite values; their scores are
-    // masked and their probabilities are exactly 0).
-    {
-        const int np8 = kp / RPP;
+    // masked and their probabilities are exactly 0).  The LDS holds kpad keys: the whole sequence when it fits (nchunks == 1,
+    // staged once), else the sequence goes through it in nchunks pieces of kpad keys for every round of query blocks.
+    const int nchunks = (kp + kpad - 1) / kpad;
+    auto stage = [&](int c) {
+        const int base = c * kpad;
+        const int rows_here = kp - base < kpad ? kp - base : kpad;
+        const int np8 = rows_here / RPP;
         const int srow = lane / NC, pchunk = lane % NC;
         for (int p = wave; p < 2 * np8; p += NW) {
             const bool is_v = p >= np8;
             const int piece = is_v ? p - np8 : p;
-            const int row = piece * RPP + srow;
-            const int key = row < len ? row : len - 1;
+            const int row = piece * RPP + srow;        // LDS row; the key is base + row (base is a multiple of 64: same swizzle)
+            const int key = base + row < len ? base + row : len - 1;
             int lc = pchunk ^ (row & (NC - 1));
             if (HS < HD) lc = lc < NCS ? lc : 0;  // slots of chunks the head does not have: any finite filler (they meet zero Q dims)
             const bf16_t* src = (is_v ? vb : kb) + (int64_t)key * ld + (lc << 3);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)((is_v ? sV : sK) + piece * 1024), 16, 0, 0);
         }
-    }
+    };
+    if (nchunks == 1) stage(0);
     const int l15 = lane & 15, g = lane >> 4;
     const int nqb = (len + 15) >> 4;
     float amax_local = 0.f;
@@ -101,12 +107,16 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(
     const int vkey = 4 * g + (l15 >> 2);
     const int vcol = (l15 & 3) >> 1, vhalf = (l15 & 1) << 3;
 
-    for (int qblk = wave; qblk < nqb; qblk += NW) {
+    const int nrounds = (nqb + NW - 1) / NW;
+    for (int rnd = 0; rnd < nrounds; ++rnd) {
+        const int qblk = rnd * NW + wave;
+        const bool active = qblk < nqb;          // wave-uniform; with nchunks > 1 an idle wave still stages and keeps the barriers
+        if (nchunks == 1 && !active) break;
         const int q = qblk * 16 + l15;           // this lane's query (B-operand column / output row)
         bf16x8 qf[NKK];
 #pragma unroll
         for (int kk = 0; kk < NKK; ++kk) qf[kk] = qn[kk];
-        if (qblk + NW < nqb) {                   // next block's Q streams in behind this block's math
+        if (active && qblk + NW < nqb) {         // next block's Q streams in behind this block's math
             const int q2 = q + 16 * NW;
             const int qr = q2 < len ? q2 : len - 1;
 #pragma unroll
@@ -123,7 +133,17 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(
             const int last = (qblk * 16 + 15) >> 6;  // last key tile any query of this block may see
             kt_end = last + 1 < nkt ? last + 1 : nkt;
         }
-        for (int kt = 0; kt < kt_end; ++kt) {
+        for (int c = 0; c < nchunks; ++c) {
+        if (nchunks > 1) {   // (re)fill the LDS with keys [c * kpad, (c + 1) * kpad)
+            __syncthreads();
+            stage(c);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        const int kt0 = c * (kpad >> 6);
+        const int kt1 = !active ? kt0 : (kt_end < kt0 + (kpad >> 6) ? kt_end : kt0 + (kpad >> 6));
+        const int cb = c * kpad;                         // LDS row of global key `key` is key - cb (cb is a multiple of 64)
+        for (int kt = kt0; kt < kt1; ++kt) {
             // ---- S^T tile: keys 64kt + 16t + 4g + r for this lane's query -----------------------
             f32x4 sc[4];
 #pragma unroll
@@ -132,7 +152,7 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(
                 const int key = kt * 64 + t * 16 + l15;  // A-operand row
 #pragma unroll
                 for (int kk = 0; kk < NKK; ++kk) {
-                    const bf16x8 kf = *(const bf16x8*)(sK + key * RB + (((g + 4 * kk) ^ (key & (NC - 1))) << 4));
+                    const bf16x8 kf = *(const bf16x8*)(sK + (key - cb) * RB + (((g + 4 * kk) ^ (key & (NC - 1))) << 4));
                     sc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], sc[t], 0, 0, 0);
                 }
             }
@@ -192,13 +212,15 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(
 #pragma unroll
                     for (int tt = 0; tt < 2; ++tt) {
                         const int key = kt * 64 + (2 * u + tt) * 16 + vkey;
-                        const char* vp = sV + key * RB + ((((dt << 1) | vcol) ^ (key & (NC - 1))) << 4) + vhalf;
+                        const char* vp = sV + (key - cb) * RB + ((((dt << 1) | vcol) ^ (key & (NC - 1))) << 4) + vhalf;
                         vf.t[tt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)vp);
                     }
                     o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf.v, o[dt], 0, 0, 0);
                 }
             }
         }
+        }  // chunks
+        if (!active) continue;
         float l_tot = l_run + __shfl_xor(l_run, 16, 64);
         l_tot += __shfl_xor(l_tot, 32, 64);
         const float inv = 1.0f / l_tot;
@@ -253,11 +275,14 @@ extern "C" int mq_attention_ex(const void* d_qkv, void* d_out, const int32_t* d_
     MQ_CHECK_ARG(mask == MQ_MASK_NONE || mask == MQ_MASK_CAUSAL, "mq_attention: bad mask %d", mask);
     if (nseq <= 0) return MQ_OK;
     const int maxl = fixed_len > 0 ? fixed_len : max_len;
-    MQ_CHECK_ARG(maxl >= 1 && maxl <= 1024, "mq_attention: max sequence length %d unsupported (1..1024)", maxl);
+    MQ_CHECK_ARG(maxl >= 1 && maxl <= 8192, "mq_attention: max sequence length %d unsupported (1..8192)", maxl);
     MQ_CHECK_ARG(nseq * heads < (1LL << 31), "mq_attention: grid too large");
-    const int kpad = ((maxl + 63) / 64) * 64;
-    const size_t lds = (size_t)kpad * hd * 4;  // K + V rows of hd bf16 each
-    MQ_CHECK_ARG(lds <= 160 * 1024, "mq_attention: sequence length %d needs %zu B of LDS (> 160 KiB)", maxl, lds);
+    // K + V rows of hd bf16 each live in the CU's 160 KiB of LDS: whole sequences up to 640 keys (hd 64) / 320 keys (hd 128),
+    // longer ones stream through it in pieces of that many keys (ViT-H-14-378: 730 tokens, ViT-B-16-SigLIP-512: 1024)
+    const int cap = hd == 64 ? 640 : 320;
+    const int need = ((maxl + 63) / 64) * 64;
+    const int kpad = need < cap ? need : cap;
+    const size_t lds = (size_t)kpad * hd * 4;
     hipStream_t s = (hipStream_t)stream;
     // 8 waves from 9 query blocks up (measured, profiles/r01f_attention_waves_ab.txt: -25..-33 % at 257 / 512 / 577 tokens, where a
     // workgroup's K / V image leaves room for one or two workgroups per CU; +6..+25 % at 77 / 50 tokens, whose 5 / 4 blocks leave

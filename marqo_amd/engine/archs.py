@@ -109,14 +109,15 @@ OPEN_CLIP_ARCHS = {
     "ViT-L-14-336": (VitArch(336, 14, 1024, 24, 16, 4096, 768), _TEXT_L),
     # 16 heads of 80 / 88 / 104: zero-padded to 96 / 96 / 112-wide heads at load (engine/towers.py::_pad_heads)
     "ViT-H-14": (VitArch(224, 14, 1280, 32, 16, 5120, 1024), _TEXT_H),
+    "ViT-H-14-378": (VitArch(378, 14, 1280, 32, 16, 5120, 1024), _TEXT_H),  # 730 tokens: K / V stream through the LDS in pieces
     "ViT-g-14": (VitArch(224, 14, 1408, 40, 16, 6144, 1024), _TEXT_H),
     "ViT-bigG-14": (VitArch(224, 14, 1664, 48, 16, 8192, 1280), _TEXT_BIGG),
     "ViT-B-16-SigLIP": _siglip(224), "ViT-B-16-SigLIP-256": _siglip(256), "ViT-B-16-SigLIP-384": _siglip(384),
+    "ViT-B-16-SigLIP-512": _siglip(512),
     "ViT-L-16-SigLIP-256": _siglip(256, large=True), "ViT-L-16-SigLIP-384": _siglip(384, large=True),
 }
-# architectures the registry names but which are not plain CLIP ViTs (ResNet, ConvNeXt, EVA02, SigLIP, CoCa, roberta/xlm text
-# towers ...) or whose token count does not fit the LDS-resident attention (ViT-H-14-378: 730 tokens at 256-byte LDS rows;
-# ViT-B-16-SigLIP-512: 1024 tokens, ViT-SO400M-14-SigLIP-384: 729 tokens of 72-wide heads)
+# architectures the registry names but which are not plain CLIP / SigLIP ViTs (ResNet, ConvNeXt, EVA02, CoCa, roberta / xlm / NLLB
+# text towers ...)
 UNSUPPORTED_HINT = ("this open_clip architecture is not runnable by the marqo_amd engine yet "
                     "(supported: " + ", ".join(sorted(OPEN_CLIP_ARCHS)) + " and their -quickgelu variants)")
 

@@ -24,10 +24,11 @@ _OPEN_CLIP_TAGS = {
     "ViT-L-14-336": ["openai"],
     "ViT-H-14": ["laion2b_s32b_b79k"],
     "ViT-H-14-quickgelu": ["dfn5b"],
+    "ViT-H-14-378-quickgelu": ["dfn5b"],
     "ViT-g-14": ["laion2b_s12b_b42k", "laion2b_s34b_b88k"],
     "ViT-bigG-14": ["laion2b_s39b_b160k"],
-    # SigLIP (model_registry.py:385-432); -512 (1024 tokens) and SO400M-14-384 (729 tokens) exceed the LDS-resident attention
-    "ViT-B-16-SigLIP": ["webli"], "ViT-B-16-SigLIP-256": ["webli"], "ViT-B-16-SigLIP-384": ["webli"],
+    # SigLIP (model_registry.py:371-432)
+    "ViT-B-16-SigLIP": ["webli"], "ViT-B-16-SigLIP-256": ["webli"], "ViT-B-16-SigLIP-384": ["webli"], "ViT-B-16-SigLIP-512": ["webli"],
     "ViT-L-16-SigLIP-256": ["webli"], "ViT-L-16-SigLIP-384": ["webli"],
 }
 

@@ -142,7 +142,10 @@ def _ref_attention(qkv, lens, heads, causal, hd=64):
                                                     ([50] * 4, 5, False, 128), ([16], 1, False, 128),
                                                     # head strides 96 / 112 (80 / 88 / 104-wide heads padded): LDS rows stay 256 B
                                                     ([257] * 3, 16, False, 96), ([257] * 2, 16, False, 112), ([5, 77, 1, 33, 64, 65, 320], 3, True, 96),
-                                                    ([5, 77, 1, 33, 64, 65, 320], 3, True, 112), ([50] * 4, 5, False, 96), ([16], 1, False, 112)])
+                                                    ([5, 77, 1, 33, 64, 65, 320], 3, True, 112), ([50] * 4, 5, False, 96), ([16], 1, False, 112),
+                                                    # longer than the LDS holds (640 keys at 64-wide, 320 at wider heads): K / V stream through it
+                                                    ([730, 1000, 65], 2, False, 96), ([729] * 2, 3, False, 128), ([1024, 700], 2, False, 64),
+                                                    ([900, 100, 641], 2, True, 64), ([700, 321], 1, True, 112)])
 def test_attention(lib, lens, heads, causal, hd):
     from marqo_amd import _lib as L
     g = torch.Generator(device="cuda").manual_seed(5)
