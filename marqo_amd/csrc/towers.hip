@@ -346,8 +346,8 @@ int encode_image_impl(const mq_vit_cfg* cfg, const mq_vit_weights* w, const void
                       float* d_out, int normalize, void* ws, size_t ws_bytes, hipStream_t s) {
     MQ_CHECK_ARG(cfg && w && d_out, "mq_encode_image: null pointer");
     MQ_TRY(check_encoder_cfg(&cfg->enc));
-    MQ_CHECK_ARG(cfg->patch_size > 0 && cfg->image_size % cfg->patch_size == 0, "mq_encode_image: image %d not divisible by patch %d",
-                 cfg->image_size, cfg->patch_size);
+    MQ_CHECK_ARG(cfg->patch_size > 0 && cfg->image_size >= cfg->patch_size, "mq_encode_image: image %d smaller than patch %d",
+                 cfg->image_size, cfg->patch_size);  // floor(S / P) patches per side, like the strided conv (trailing pixels unread)
     MQ_CHECK_ARG(cfg->out_dim >= 4 && cfg->out_dim % 4 == 0, "mq_encode_image: out_dim %d must be a multiple of 4", cfg->out_dim);
     const bool map = cfg->pool == MQ_VIT_POOL_MAP;
     MQ_CHECK_ARG(cfg->pool == MQ_VIT_POOL_CLS || map, "mq_encode_image: bad pool %d", cfg->pool);

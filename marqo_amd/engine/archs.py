@@ -92,9 +92,11 @@ _TEXT_BIGG = ClipTextArch(vocab=49408, ctx=77, width=1280, layers=32, heads=20, 
 
 # SigLIP (open_clip model configs ViT-{B,L}-16-SigLIP*: timm vit_{base,large}_patch16_siglip_* + TextTransformer, ctx 64,
 # 32k sentencepiece vocabulary, LayerNorm eps 1e-6 everywhere)
-def _siglip(image_size: int, large: bool = False) -> Tuple[VitArch, ClipTextArch]:
+def _siglip(image_size: int, large: bool = False, so400m: bool = False) -> Tuple[VitArch, ClipTextArch]:
     W, Lyr, H, Fd = (1024, 24, 16, 4096) if large else (768, 12, 12, 3072)
-    return (VitArch(image_size, 16, W, Lyr, H, Fd, W, ln_eps=1e-6, pool="map"),
+    if so400m:  # shape-optimised 400M: 72-wide heads (run as 96), MLP 4304 (zero-padded to 4352 at load), patch 14
+        W, Lyr, H, Fd = 1152, 27, 16, 4304
+    return (VitArch(image_size, 14 if so400m else 16, W, Lyr, H, Fd, W, ln_eps=1e-6, pool="map"),
             ClipTextArch(vocab=32000, ctx=64, width=W, layers=Lyr, heads=H, mlp_dim=Fd, out_dim=W, ln_eps=1e-6, causal=False,
                          proj_bias=True, prefix="text.", pad_id=1))
 
@@ -114,6 +116,7 @@ OPEN_CLIP_ARCHS = {
     "ViT-bigG-14": (VitArch(224, 14, 1664, 48, 16, 8192, 1280), _TEXT_BIGG),
     "ViT-B-16-SigLIP": _siglip(224), "ViT-B-16-SigLIP-256": _siglip(256), "ViT-B-16-SigLIP-384": _siglip(384),
     "ViT-B-16-SigLIP-512": _siglip(512),
+    "ViT-SO400M-14-SigLIP": _siglip(224, so400m=True), "ViT-SO400M-14-SigLIP-384": _siglip(384, so400m=True),
     "ViT-L-16-SigLIP-256": _siglip(256, large=True), "ViT-L-16-SigLIP-384": _siglip(384, large=True),
 }
 # architectures the registry names but which are not plain CLIP / SigLIP ViTs (ResNet, ConvNeXt, EVA02, CoCa, roberta / xlm / NLLB

@@ -111,7 +111,23 @@ def _pad_heads(qkv_w: Tensor, qkv_b: Tensor, out_w: Tensor, heads: int, d: int) 
     return qkv_w2, qkv_b2, out_w2
 
 
+def _ceil64(v: int) -> int:
+    return (v + 63) // 64 * 64
+
+
+def _pad_mlp(fc1_w: Tensor, fc1_b: Tensor, fc2_w: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+    """MLP hidden sizes that are not a multiple of 64 (ViT-SO400M: 4304) are zero-padded: the extra hidden units are act(0 + 0) = 0
+    for GELU / QuickGELU and meet zero fc2 columns — exact."""
+    F = fc1_w.shape[0]
+    Fp = _ceil64(F)
+    if Fp == F:
+        return fc1_w, fc1_b, fc2_w
+    pad = torch.nn.functional.pad
+    return pad(fc1_w.detach().float(), (0, 0, 0, Fp - F)), pad(fc1_b.detach().float(), (0, Fp - F)), pad(fc2_w.detach().float(), (0, Fp - F))
+
+
 def _encoder_cfg(width, layers, heads, mlp_dim, quick_gelu, post_ln, mask, eps) -> L.EncoderCfg:
+    mlp_dim = _ceil64(mlp_dim)
     d = _head_dim(width, heads)
     hp = _kernel_head_dim(d, heads)
     return L.EncoderCfg(width=width, layers=layers, heads=heads, mlp_dim=mlp_dim,
@@ -168,8 +184,8 @@ _TIMM_KEYS = dict(block="blocks.{}.", ln1="norm1", qkv_w="attn.qkv.weight", qkv_
 def _clip_blocks(h: _Holder, sd, prefix: str, layers: int, W: int, F: int, heads: int, keys=_OPEN_CLIP_KEYS):
     d = _head_dim(W, heads)
     padded = d != _kernel_head_dim(d, heads)  # ViT-H / g / bigG: 80 / 88 / 104-wide heads run as 96 / 96 / 112
-    if padded and LN_FOLD:
-        raise ValueError("MARQO_AMD_LN_FOLD=1 is not supported for models whose heads are padded")
+    if (padded or F % 64) and LN_FOLD:
+        raise ValueError("MARQO_AMD_LN_FOLD=1 is not supported for models whose heads or MLP are padded")
     arr = (L.BlockWeights * layers)()
     k = keys
     for i in range(layers):
@@ -185,9 +201,9 @@ def _clip_blocks(h: _Holder, sd, prefix: str, layers: int, W: int, F: int, heads
         b.out_b = h.f32(_need(sd, p + k["out"] + ".bias", (W,)))
         b.ln2_g = h.f32(_need(sd, p + k["ln2"] + ".weight", (W,)))
         b.ln2_b = h.f32(_need(sd, p + k["ln2"] + ".bias", (W,)))
-        b.fc1_w = h.bf16(_need(sd, p + k["fc1"] + ".weight", (F, W)))
-        b.fc1_b = h.f32(_need(sd, p + k["fc1"] + ".bias", (F,)))
-        b.fc2_w = h.bf16(_need(sd, p + k["fc2"] + ".weight", (W, F)))
+        fc1_w, fc1_b, fc2_w = _pad_mlp(_need(sd, p + k["fc1"] + ".weight", (F, W)), _need(sd, p + k["fc1"] + ".bias", (F,)),
+                                       _need(sd, p + k["fc2"] + ".weight", (W, F)))
+        b.fc1_w, b.fc1_b, b.fc2_w = h.bf16(fc1_w), h.f32(fc1_b), h.bf16(fc2_w)
         b.fc2_b = h.f32(_need(sd, p + k["fc2"] + ".bias", (W,)))
         if LN_FOLD:
             # LayerNorm folding (csrc/gemm_epilogue.h): LN(x) @ W^T = rstd * (x @ (g*W)^T - mean * colsum(g*W)) + (b + W @ beta).
@@ -259,8 +275,10 @@ class VitTower(_TowerBase):
         self.precision = precision
         self.arch = arch
         W, P = arch.width, arch.patch_size
-        if arch.image_size % P:
-            raise ValueError("image_size must be a multiple of patch_size")
+        if arch.image_size < P:
+            raise ValueError("image_size must be at least one patch")
+        # (an image size that is not a multiple of the patch — ViT-SO400M-14-SigLIP-384: 384 = 27 * 14 + 6 — follows the strided conv:
+        # floor(S / P) patches per side, the trailing pixels are not read)
         K = 3 * P * P
         Kp = (K + 63) // 64 * 64
         h = self._h
@@ -280,15 +298,15 @@ class VitTower(_TowerBase):
             f32 = lambda k, shape: _need(sd, a + k, shape).detach().to(torch.float32)
             # the single learned query is a constant of the model: q = Linear_q(latent) / sqrt(head dim), in fp32 at load
             q = (f32("latent", (1, 1, W)).reshape(W) @ f32("q.weight", (W, W)).t() + f32("q.bias", (W,))) * hd ** -0.5
+            m1_w, m1_b, m2_w = _pad_mlp(f32("mlp.fc1.weight", (F, W)), f32("mlp.fc1.bias", (F,)), f32("mlp.fc2.weight", (W, F)))
             self._map = L.MapHead(q=h.f32(q), kv_w=h.bf16(f32("kv.weight", (2 * W, W))), kv_b=h.f32(f32("kv.bias", (2 * W,))),
                                   proj_w=h.bf16(f32("proj.weight", (W, W))), proj_b=h.f32(f32("proj.bias", (W,))),
                                   ln_g=h.f32(f32("norm.weight", (W,))), ln_b=h.f32(f32("norm.bias", (W,))),
-                                  fc1_w=h.bf16(f32("mlp.fc1.weight", (F, W))), fc1_b=h.f32(f32("mlp.fc1.bias", (F,))),
-                                  fc2_w=h.bf16(f32("mlp.fc2.weight", (W, F))), fc2_b=h.f32(f32("mlp.fc2.bias", (W,))))
+                                  fc1_w=h.bf16(m1_w), fc1_b=h.f32(m1_b), fc2_w=h.bf16(m2_w), fc2_b=h.f32(f32("mlp.fc2.bias", (W,))))
             self.w = L.VitWeights(patch_w=h.bf16(patch_w), cls=None, pos=h.f32(pos), ln_pre_g=None, ln_pre_b=None, blocks=self._blocks,
                                   ln_post_g=h.f32(_need(sd, t + "norm.weight", (W,))), ln_post_b=h.f32(_need(sd, t + "norm.bias", (W,))),
                                   proj_w=None, map=C.pointer(self._map))
-            pool, map_mlp = L.MQ_VIT_POOL_MAP, F
+            pool, map_mlp = L.MQ_VIT_POOL_MAP, _ceil64(F)
         else:
             patch_w[:, :K] = _need(sd, "visual.conv1.weight", (W, 3, P, P)).detach().to(torch.float32).reshape(W, K)
             self._blocks = _clip_blocks(h, sd, "visual.transformer.", arch.layers, W, arch.mlp_dim, arch.heads)
@@ -309,7 +327,7 @@ class VitTower(_TowerBase):
         self.n_streams = max(1, int(os.environ.get("MARQO_AMD_STREAMS", "1")))
         self._side: list = []
         if precision == "fp8":
-            self._enable_fp8(self._blocks, arch.layers, W, arch.mlp_dim)
+            self._enable_fp8(self._blocks, arch.layers, W, _ceil64(arch.mlp_dim))
 
     def _run(self, fn, pixels: Tensor, normalize: bool) -> Tensor:
         n = pixels.shape[0]
@@ -458,7 +476,7 @@ class ClipTextTower(_TextTowerBase):
                                                   L.MQ_MASK_CAUSAL if arch.causal else L.MQ_MASK_NONE, arch.ln_eps),
                                  vocab=arch.vocab, ctx=arch.ctx, out_dim=arch.out_dim)
         if precision == "fp8":
-            self._enable_fp8(self._blocks, arch.layers, W, arch.mlp_dim)
+            self._enable_fp8(self._blocks, arch.layers, W, _ceil64(arch.mlp_dim))
 
     def encode_ids(self, ids: Tensor, normalize: bool = True, pack: bool = True) -> Tensor:
         """ids: int [n, ctx] zero-padded CLIP token ids (SOT ... EOT 0 0 ...), host or device.

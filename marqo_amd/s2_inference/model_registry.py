@@ -29,7 +29,7 @@ _OPEN_CLIP_TAGS = {
     "ViT-bigG-14": ["laion2b_s39b_b160k"],
     # SigLIP (model_registry.py:371-432)
     "ViT-B-16-SigLIP": ["webli"], "ViT-B-16-SigLIP-256": ["webli"], "ViT-B-16-SigLIP-384": ["webli"], "ViT-B-16-SigLIP-512": ["webli"],
-    "ViT-L-16-SigLIP-256": ["webli"], "ViT-L-16-SigLIP-384": ["webli"],
+    "ViT-L-16-SigLIP-256": ["webli"], "ViT-L-16-SigLIP-384": ["webli"], "ViT-SO400M-14-SigLIP-384": ["webli"],
 }
 
 # hf registry entries whose encoder is a plain BERT (absolute positions, GELU, post-LN): name -> (repo, dims, tokens, prefixes)

@@ -40,7 +40,7 @@ _PREPROCESSOR_NORMS = {
     "OpenAI": (archs.OPENAI_DATASET_MEAN, archs.OPENAI_DATASET_STD, "shortest"),
     "SigLIP": ((0.5, 0.5, 0.5), (0.5, 0.5, 0.5), "squash"),
 }
-_TIMM_SIGLIP = __import__("re").compile(r"^vit_(base|large)_patch16_siglip_(\d+)$")
+_TIMM_SIGLIP = __import__("re").compile(r"^vit_(base|large|so400m)_patch1[46]_siglip_(\d+)$")
 
 
 class OpenCLIPModelProperties:
@@ -136,7 +136,7 @@ class OPEN_CLIP(AbstractCLIPModel):
                 # SigLIP: timm trunk + TextTransformer(no_causal_mask, pool 'last', proj_bias) — marqo-fashionSigLIP, marqo-ecommerce-*
                 if v.get("timm_pool", "map") != "map" or v.get("timm_proj", "none") not in ("none", None, ""):
                     raise InvalidModelPropertiesError(f"{arch_name}: timm towers are supported with pool 'map' and no projection only")
-                vision, text = archs._siglip(int(v.get("image_size", m.group(2))), large=m.group(1) == "large")
+                vision, text = archs._siglip(int(v.get("image_size", m.group(2))), large=m.group(1) == "large", so400m=m.group(1) == "so400m")
                 if mc["embed_dim"] != vision.width or t.get("width", vision.width) != text.width or t.get("layers", text.layers) != text.layers:
                     raise InvalidModelPropertiesError(f"{arch_name}: unexpected SigLIP dimensions in open_clip_config.json")
                 from dataclasses import replace

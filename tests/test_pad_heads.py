@@ -42,3 +42,19 @@ def test_encoder_cfg_attention_width():
         T._encoder_cfg(2048, 2, 8, 8192, False, False, 0, 1e-5)                               # 256-wide heads
     with pytest.raises(ValueError):
         T._encoder_cfg(100, 2, 3, 400, False, False, 0, 1e-5)
+
+
+def test_pad_mlp_is_exact():
+    """MLP hidden sizes that are not a multiple of 64 (ViT-SO400M: 4304 -> 4352): zero rows / columns change nothing"""
+    g = torch.Generator().manual_seed(0)
+    W, F = 24, 100
+    x = torch.randn(5, W, generator=g, dtype=torch.float64)
+    w1, b1, w2 = torch.randn(F, W, generator=g, dtype=torch.float64), torch.randn(F, generator=g, dtype=torch.float64), torch.randn(W, F, generator=g, dtype=torch.float64)
+    p1, pb, p2 = T._pad_mlp(w1, b1, w2)
+    assert p1.shape == (128, W) and pb.shape == (128,) and p2.shape == (W, 128)
+    for act in (torch.nn.functional.gelu, lambda t: t * torch.sigmoid(1.702 * t)):
+        ref = act(x @ w1.t() + b1) @ w2.t()
+        got = act(x.float() @ p1.t() + pb) @ p2.t()
+        assert torch.allclose(got.double(), ref, atol=1e-4, rtol=1e-4)
+    same = T._pad_mlp(torch.zeros(128, W), torch.zeros(128), torch.zeros(W, 128))
+    assert same[0].shape == (128, W)

@@ -287,7 +287,7 @@ def test_golden_bert_32_wide_heads():
         T.BertTower(A.BertArch(vocab=V, max_pos=P, width=W, layers=L_, heads=3, mlp_dim=F), sd, "cuda")  # 128 / 3 heads
 
 
-@pytest.mark.parametrize("name,layers", [("ViT-H-14", 3), ("ViT-g-14", 2), ("ViT-bigG-14", 2)])
+@pytest.mark.parametrize("name,layers", [("ViT-H-14", 3), ("ViT-g-14", 2), ("ViT-bigG-14", 2), ("ViT-H-14-378", 2)])
 def test_vit_wide_heads_vs_oracle(name, layers):
     """ViT-H / g / bigG (model_registry.py:237-256): 16 heads of 80 / 88 / 104 run as zero-padded 96 / 96 / 112-wide heads
     (engine/towers.py::_pad_heads, attention_kernel<HD=128, HS>: 257 tokens = the full 160 KiB of LDS).  Real widths / MLP dims /
@@ -299,7 +299,7 @@ def test_vit_wide_heads_vs_oracle(name, layers):
     arch = replace(arch, layers=layers)
     cfg = O.VitConfig(arch.image_size, arch.patch_size, arch.width, arch.layers, arch.heads, arch.mlp_dim, arch.out_dim)
     sd = O.synthetic_vit_state_dict(cfg, seed=3)
-    u8 = O.synthetic_images_u8(3, 224, seed=3)
+    u8 = O.synthetic_images_u8(3 if arch.image_size == 224 else 2, arch.image_size, seed=3)  # (-378: 730 tokens, K / V streamed through the LDS)
     ref = O.vit_forward(sd, cfg, O.preprocess_u8_exact_size(u8))
     tower = T.VitTower(arch, sd, "cuda")
     assert tower.cfg.enc.attn_width == arch.heads * (112 if name == "ViT-bigG-14" else 96) and tower.cfg.enc.width == arch.width
@@ -341,10 +341,11 @@ def test_golden_siglip_small():
     assert _cos_err(dev, torch.from_numpy(z["text_emb"])) < 1e-3
 
 
-@pytest.mark.parametrize("name,layers,n", [("ViT-B-16-SigLIP", 3, 5), ("ViT-L-16-SigLIP-384", 2, 2)])
+@pytest.mark.parametrize("name,layers,n", [("ViT-B-16-SigLIP", 3, 5), ("ViT-L-16-SigLIP-384", 2, 2), ("ViT-SO400M-14-SigLIP-384", 2, 2)])
 def test_siglip_full_size_vs_oracle(name, layers, n):
-    """registry shapes (model_registry.py:385-432): 196 tokens x 768 and 576 tokens x 1024 (the 8-wave attention path), depth cut
-    to keep the fp32 CPU oracle in seconds; bf16 and fp8; text tower at ctx 64 over the 32 000-piece vocabulary"""
+    """registry shapes (model_registry.py:371-432): 196 tokens x 768, 576 tokens x 1024 (the 8-wave attention path) and SO400M's
+    729 tokens x 1152 (72-wide heads run as 96, K / V streamed through the LDS, MLP 4304 zero-padded to 4352), depth cut to keep
+    the fp32 CPU oracle in seconds; bf16 and fp8; text tower at ctx 64 over the 32 000-piece vocabulary"""
     from dataclasses import replace
     T, A = _towers()
     varch, tarch = A.resolve_open_clip(name)
@@ -358,6 +359,11 @@ def test_siglip_full_size_vs_oracle(name, layers, n):
     vt = T.VitTower(varch, sd, "cuda", mean=mean, std=std)
     out = vt.encode_u8(u8.cuda())
     assert _cos_err(out, ref) < COS_TIGHT
+    if name == "ViT-SO400M-14-SigLIP-384":
+        assert vt.cfg.enc.mlp_dim == 4352 and vt.cfg.map_mlp_dim == 4352 and vt.cfg.enc.attn_width == 16 * 96
+        ids = torch.ones(3, tarch.ctx, dtype=torch.int64)
+        ids[:, :10] = torch.randint(2, tarch.vocab, (3, 10), generator=torch.Generator().manual_seed(5))
+        assert _cos_err(T.ClipTextTower(tarch, sd, "cuda").encode_ids(ids), O.siglip_text_forward(sd, tcfg, ids)) < COS_TIGHT
     if name == "ViT-B-16-SigLIP":
         v8 = T.VitTower(varch, sd, "cuda", mean=mean, std=std, precision="fp8")
         v8.calibrate_fp8(lambda: v8.encode_u8(u8.cuda()))
