@@ -143,6 +143,14 @@ def test_registry_shape_and_known_entries():
     assert e5["text_query_prefix"] == "query: " and e5["text_chunk_prefix"] == "passage: "
     with pytest.raises(UnknownModelError):
         s2_inference.get_model_properties_from_registry("definitely/not-a-model")
+    # names and dimensions of the wider families follow the reference registry (model_registry.py:237-256, 371-432, 483-494)
+    for name, dims in {"open_clip/ViT-H-14/laion2b_s32b_b79k": 1024, "open_clip/ViT-g-14/laion2b_s34b_b88k": 1024,
+                       "open_clip/ViT-bigG-14/laion2b_s39b_b160k": 1280, "open_clip/ViT-H-14-378-quickgelu/dfn5b": 1024,
+                       "open_clip/ViT-B-16-SigLIP-512/webli": 768, "open_clip/ViT-L-16-SigLIP-384/webli": 1024,
+                       "open_clip/ViT-SO400M-14-SigLIP-384/webli": 1152, "Marqo/marqo-fashionSigLIP": 768, "Marqo/marqo-fashionCLIP": 512}.items():
+        p = s2_inference.get_model_properties_from_registry(name)
+        assert p["dimensions"] == dims and p["type"] == "open_clip", name
+    assert s2_inference.get_model_properties_from_registry("Marqo/marqo-fashionSigLIP")["name"] == "hf-hub:Marqo/marqo-fashionSigLIP"
 
 
 def test_validate_model_properties():
@@ -418,3 +426,48 @@ def test_chunk_image_method_parsing_and_boxes():
     assert I.chunk_image("http://a/b.png", "cuda", "none") == (["http://a/b.png"], ["http://a/b.png"])
     with pytest.raises(ValueError):
         I.chunk_image(img, "cuda", "bogus")
+
+
+def test_open_clip_architecture_resolution(tmp_path):
+    """registry names, -quickgelu variants and hf-hub `open_clip_config.json` files -> tower architectures (no GPU involved):
+    CLIP ViTs with any head width <= 128, SigLIP / timm trunks, and loud errors for what the engine does not run."""
+    import json
+    from marqo_amd.engine import archs as A
+    from marqo_amd.s2_inference.errors import InvalidModelPropertiesError, ModelLoadError
+    from marqo_amd.s2_inference.open_clip_model import OPEN_CLIP
+    v, t = A.resolve_open_clip("ViT-H-14-378-quickgelu", "dfn5b")
+    assert (v.tokens, v.width // v.heads, v.quick_gelu, t.width // t.heads) == (730, 80, True, 64)
+    v, t = A.resolve_open_clip("ViT-SO400M-14-SigLIP-384")
+    assert (v.tokens, v.pool, v.mlp_dim, v.out_dim, t.ctx, t.vocab, t.causal, t.proj_bias, t.prefix) == (729, "map", 4304, 1152, 64, 32000, False, True, "text.")
+    with pytest.raises(KeyError):
+        A.resolve_open_clip("RN50")
+    m = OPEN_CLIP(device="cuda", model_properties={"name": "hf-hub:acme/x", "dimensions": 768, "type": "open_clip"})
+
+    def cfg(d):
+        (tmp_path / "open_clip_config.json").write_text(json.dumps({"model_cfg": d}))
+        return m._resolve_archs("hf-hub:acme/x", None, str(tmp_path))
+    # Marqo/marqo-fashionSigLIP style: timm trunk + custom text tower
+    v, t = cfg({"embed_dim": 768, "custom_text": True,
+                "vision_cfg": {"image_size": 224, "timm_model_name": "vit_base_patch16_siglip_224", "timm_pool": "map", "timm_proj": "none"},
+                "text_cfg": {"context_length": 64, "vocab_size": 32000, "hf_tokenizer_name": "timm/ViT-B-16-SigLIP", "width": 768, "heads": 12,
+                             "layers": 12, "no_causal_mask": True, "proj_bias": True, "pool_type": "last"}})
+    assert (v.pool, v.tokens, v.width, v.ln_eps, t.causal, t.ctx, t.out_dim) == ("map", 196, 768, 1e-6, False, 64, 768)
+    v, t = cfg({"embed_dim": 1024, "vision_cfg": {"image_size": 384, "timm_model_name": "vit_large_patch16_siglip_384", "timm_pool": "map", "timm_proj": "none"},
+                "text_cfg": {"context_length": 64, "vocab_size": 32000, "width": 1024, "heads": 16, "layers": 24, "no_causal_mask": True, "proj_bias": True}})
+    assert (v.tokens, v.width, v.layers, t.width) == (576, 1024, 24, 1024)
+    # plain CLIP config with 80-wide heads (ViT-H class)
+    v, t = cfg({"embed_dim": 1024, "vision_cfg": {"image_size": 224, "layers": 32, "width": 1280, "head_width": 80, "patch_size": 14},
+                "text_cfg": {"context_length": 77, "vocab_size": 49408, "width": 1024, "heads": 16, "layers": 24}})
+    assert (v.heads, v.mlp_dim, v.pool, t.causal) == (16, 5120, "cls", True)
+    # not runnable: a timm trunk with a projection, an HF text tower, an embed_dim that is not the SigLIP width
+    with pytest.raises(InvalidModelPropertiesError):
+        cfg({"embed_dim": 768, "vision_cfg": {"timm_model_name": "vit_base_patch16_siglip_224", "timm_pool": "map", "timm_proj": "linear"}, "text_cfg": {}})
+    with pytest.raises(InvalidModelPropertiesError):
+        cfg({"embed_dim": 512, "vision_cfg": {"image_size": 224, "layers": 12, "width": 768, "patch_size": 16},
+             "text_cfg": {"hf_model_name": "xlm-roberta-base", "hf_tokenizer_name": "xlm-roberta-base"}})
+    with pytest.raises(InvalidModelPropertiesError):
+        cfg({"embed_dim": 512, "vision_cfg": {"timm_model_name": "vit_base_patch16_siglip_224"}, "text_cfg": {"width": 768}})
+    (tmp_path / "open_clip_config.json").unlink()
+    with pytest.raises(ModelLoadError):
+        m._resolve_archs("hf-hub:acme/x", None, str(tmp_path))
+    assert m._resolve_archs("hf-hub:Marqo/marqo-fashionSigLIP", None, str(tmp_path))[0].pool == "map"  # known repo: table fallback
