@@ -218,6 +218,33 @@ def _clip_blocks(h: _Holder, sd, prefix: str, layers: int, W: int, F: int, heads
     return arr
 
 
+# Single-request calls (the search path: one query text / one image per vectorise()) are ~75-150 dependent launches of 5-10 us.
+# The launch sequence of such a call depends only on (tower, token count), so it is captured once per shape in a hipGraph
+# (torch.cuda.CUDAGraph over the stream the C ABI enqueues on) with static input / output / workspace buffers and replayed.
+# Measured (profiles/r01f_latency.txt): p50 -3..-4 %, p95 -15 % (0.81 -> 0.68 ms, CLIP text B/32): the host enqueue was already
+# hidden behind the GPU; what remains is the GPU-side latency of ~75 dependent small kernels (~9 us each).
+GRAPHS = os.environ.get("MARQO_AMD_GRAPHS", "1") != "0"
+MAX_GRAPHS_PER_TOWER = 192   # each entry owns a small workspace; calls of rarer shapes launch eagerly
+
+
+class _GraphedCall:
+    """One captured launch sequence: `launch()` must enqueue on the current stream and touch only `inp`, `out` and buffers it owns."""
+
+    def __init__(self, device: torch.device, inp: Tensor, out: Tensor, keep: tuple, launch) -> None:
+        self.inp, self.out, self._keep = inp, out, keep
+        launch()                                   # eager once: lazy one-time host work (kernel attributes) happens outside the capture
+        torch.cuda.synchronize(device)
+        self.graph = torch.cuda.CUDAGraph()
+        # thread_local: other request threads keep allocating / launching on their own streams while this one captures
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+            launch()
+
+    def __call__(self, src: Tensor) -> Tensor:
+        self.inp.copy_(src, non_blocking=True)
+        self.graph.replay()
+        return self.out.clone()                    # the static output is overwritten by the next replay
+
+
 class _TowerBase:
     _fp8: Optional[_Fp8State] = None
 
@@ -234,6 +261,7 @@ class _TowerBase:
         (2 passes: the first one runs on the pre-calibration guess).  Afterwards the scales are frozen (deterministic)."""
         if self._fp8 is None:
             raise RuntimeError("tower was not built with precision='fp8'")
+        self._fp8.calibrated = False  # (single-request graphs are not replayed while the recording passes run)
         for _ in range(passes):
             self._fp8.attach(self.cfg.enc, calibrating=True)
             run()
@@ -248,6 +276,25 @@ class _TowerBase:
         self._h = _Holder(self.device)
         self._ws: Optional[Tensor] = None
         self._lock = threading.Lock()  # one workspace per tower: serialise concurrent FastAPI threads
+        self._graphs: Dict[tuple, "_GraphedCall"] = {}
+        self._graphs_off = False
+
+    def _graphs_ok(self) -> bool:
+        """single-request calls replay a captured hipGraph (MARQO_AMD_GRAPHS=0 turns that off); an fp8 tower only once its scales are frozen"""
+        return GRAPHS and not self._graphs_off and len(self._graphs) < MAX_GRAPHS_PER_TOWER and (self._fp8 is None or self._fp8.calibrated)
+
+    def _capture(self, key: tuple, make) -> Optional["_GraphedCall"]:
+        """graph for `key`, captured on first use; a failed capture turns graph replay off for this tower (eager launches remain)"""
+        g = self._graphs.get(key)
+        if g is None:
+            try:
+                g = self._graphs[key] = make()
+            except RuntimeError as e:
+                self._graphs_off = True
+                import logging
+                logging.getLogger(__name__).warning("hipGraph capture failed (%s); this tower keeps launching eagerly", e)
+                return None
+        return g
 
     def _workspace(self, nbytes: int) -> Tensor:
         if self._ws is None or self._ws.numel() < nbytes:
@@ -331,6 +378,19 @@ class VitTower(_TowerBase):
 
     def _run(self, fn, pixels: Tensor, normalize: bool) -> Tensor:
         n = pixels.shape[0]
+        if n == 1 and self._graphs_ok():
+            with self._lock, torch.cuda.device(self.device):
+                def make():
+                    inp = torch.empty_like(pixels)
+                    o = torch.empty(1, self.arch.out_dim, dtype=torch.float32, device=self.device)
+                    ws = torch.empty(self.lib.mq_vit_workspace_bytes(C.byref(self.cfg), 1) + 256, dtype=torch.uint8, device=self.device)
+                    inp.copy_(pixels)
+                    return _GraphedCall(self.device, inp, o, (ws,), lambda: L.check(
+                        fn(C.byref(self.cfg), C.byref(self.w), inp.data_ptr(), 1, o.data_ptr(), 1 if normalize else 0, ws.data_ptr(),
+                           ws.numel(), self._stream()), "mq_encode_image"))
+                g = self._capture((pixels.dtype, bool(normalize)), make)
+                if g is not None:
+                    return g(pixels)
         out = torch.empty(n, self.arch.out_dim, dtype=torch.float32, device=self.device)
         k = self.n_streams
         if k > 1 and n >= 2 * k:
@@ -413,6 +473,33 @@ class _TextTowerBase(_TowerBase):
         """small host -> device copy through pinned memory (a pageable copy would synchronise the stream)"""
         return t.pin_memory().to(self.device, non_blocking=True)
 
+    def _encode_one(self, src_ids: Tensor, normalize: bool, clip: bool) -> Optional[Tensor]:
+        """ONE sequence (1-D ids of its real length, host or device) through the captured launch sequence of that token count
+        (None: capture is not available, the caller launches eagerly)"""
+        n_tok = int(src_ids.numel())
+        with self._lock, torch.cuda.device(self.device):
+            def make():
+                d_packed = torch.empty(n_tok, dtype=torch.int32, device=self.device)
+                cu = torch.tensor([0, n_tok], dtype=torch.int32)
+                d_cu = cu.to(self.device)
+                o = torch.empty(1, self.arch.out_dim if clip else self.arch.width, dtype=torch.float32, device=self.device)
+                if clip:
+                    ws = torch.empty(self.lib.mq_clip_text_workspace_bytes(C.byref(self.cfg), n_tok, 1) + 256, dtype=torch.uint8, device=self.device)
+                    launch = lambda: L.check(self.lib.mq_encode_clip_text(
+                        C.byref(self.cfg), C.byref(self.w), d_packed.data_ptr(), d_cu.data_ptr(), cu.data_ptr(), 1, 0, o.data_ptr(),
+                        1 if normalize else 0, ws.data_ptr(), ws.numel(), self._stream()), "mq_encode_clip_text")
+                else:
+                    ws = torch.empty(self.lib.mq_bert_workspace_bytes(C.byref(self.cfg), n_tok, 1) + 256, dtype=torch.uint8, device=self.device)
+                    launch = lambda: L.check(self.lib.mq_encode_bert(
+                        C.byref(self.cfg), C.byref(self.w), d_packed.data_ptr(), d_cu.data_ptr(), cu.data_ptr(), 1, o.data_ptr(),
+                        1 if normalize else 0, ws.data_ptr(), ws.numel(), self._stream()), "mq_encode_bert")
+                d_packed.copy_(src_ids)
+                return _GraphedCall(self.device, d_packed, o, (cu, d_cu, ws), launch)
+            g = self._capture((n_tok, bool(normalize)), make)
+            if g is None:
+                return None
+            return g(src_ids.to(torch.int32) if src_ids.dtype != torch.int32 else src_ids)
+
     def _encode_device(self, d_ids: Tensor, lengths: Tensor, max_len: int, normalize: bool, clip: bool) -> Tensor:
         """device-resident right-padded ids + host lengths -> embeddings; packing to the towers' layout on the GPU"""
         if d_ids.ndim != 2 or d_ids.dtype != torch.int32 or d_ids.device != self.device:
@@ -422,6 +509,10 @@ class _TextTowerBase(_TowerBase):
         lengths = lengths.detach().to("cpu", torch.int64)
         if lengths.shape != (n,) or (n and (int(lengths.min()) < 1 or int(lengths.max()) > min(S, max_len))):
             raise ValueError(f"lengths must be [n] within [1, {min(S, max_len)}]")
+        if n == 1 and self._graphs_ok():
+            one = self._encode_one(d_ids[0, :int(lengths[0])], normalize, clip)
+            if one is not None:
+                return one
         out_dim = self.arch.out_dim if clip else self.arch.width
         out = torch.empty(n, out_dim, dtype=torch.float32, device=self.device)
         with self._lock, torch.cuda.device(self.device):
@@ -495,6 +586,10 @@ class ClipTextTower(_TextTowerBase):
             pack = False
         eot = torch.full((n,), S - 1, dtype=torch.int64) if not self.arch.causal else ids_h.argmax(dim=1)
         lengths = (eot + 1) if pack else torch.full((n,), S, dtype=torch.int64)
+        if n == 1 and (pack or not self.arch.causal) and self._graphs_ok():
+            one = self._encode_one(ids_h[0, :int(lengths[0])], normalize, clip=True)
+            if one is not None:
+                return one
         out = torch.empty(n, self.arch.out_dim, dtype=torch.float32, device=self.device)
         with self._lock, torch.cuda.device(self.device):
             for a, b in self._chunks(lengths):
@@ -590,6 +685,10 @@ class BertTower(_TextTowerBase):
             raise ValueError("attention_mask must be right-padded (a prefix of ones per row)")
         if int(lengths.max()) > self.arch.max_pos:
             raise ValueError(f"sequence longer than max_position_embeddings={self.arch.max_pos}")
+        if n == 1 and self._graphs_ok():
+            one = self._encode_one(ids_h[0, :int(lengths[0])], normalize, clip=False)
+            if one is not None:
+                return one
         out = torch.empty(n, self.arch.width, dtype=torch.float32, device=self.device)
         with self._lock, torch.cuda.device(self.device):
             for a, b in self._chunks(lengths):

@@ -375,3 +375,42 @@ def test_siglip_full_size_vs_oracle(name, layers, n):
         tref = O.siglip_text_forward(sd, tcfg, ids)
         tt = T.ClipTextTower(tarch, sd, "cuda")
         assert _cos_err(tt.encode_ids(ids), tref) < COS_TIGHT
+
+
+def test_single_request_graph_replay_is_bit_identical(monkeypatch):
+    """one query text / one image per call replays a hipGraph captured per (tower, token count): same kernels, same bits as the
+    eager launches; new contents and new lengths go through, batches are untouched"""
+    T, A = _towers()
+    varch, tarch = A.resolve_open_clip("ViT-B-32")
+    from dataclasses import replace
+    varch, tarch = replace(varch, layers=2), replace(tarch, layers=2)
+    vcfg = O.VitConfig(varch.image_size, varch.patch_size, varch.width, 2, varch.heads, varch.mlp_dim, varch.out_dim)
+    tcfg = O.ClipTextConfig(vocab=tarch.vocab, ctx=77, width=tarch.width, layers=2, heads=tarch.heads, mlp_dim=tarch.mlp_dim, out_dim=tarch.out_dim)
+    sd = O.synthetic_vit_state_dict(vcfg, seed=7)
+    sd.update(O.synthetic_clip_text_state_dict(tcfg, seed=7))
+    vt, tt = T.VitTower(varch, sd, "cuda"), T.ClipTextTower(tarch, sd, "cuda")
+    bcfg = O.BertConfig(vocab=3000, max_pos=64, width=128, layers=2, heads=2, mlp_dim=256)
+    bt = T.BertTower(A.BertArch(vocab=3000, max_pos=64, width=128, layers=2, heads=2, mlp_dim=256), O.synthetic_bert_state_dict(bcfg, seed=7), "cuda")
+    u8 = O.synthetic_images_u8(3, 224, seed=7)
+    ids = O.synthetic_clip_ids(4, seed=7)
+    bids, bmask = O.synthetic_bert_batch(3, vocab=3000, seed=7)
+
+    def run_all():
+        outs = [vt.encode_u8(u8[i:i + 1]).cpu() for i in range(3)] + [vt.encode_f32(O.preprocess_u8_exact_size(u8[:1])).cpu()]
+        outs += [tt.encode_ids(ids[i:i + 1]).cpu() for i in range(4)] + [tt.encode_ids(ids[1:2], normalize=False).cpu()]
+        outs += [tt.encode_device(ids[2:3].to(torch.int32).to(tt.device), ids[2:3].argmax(1) + 1).cpu()]
+        for i in range(3):
+            n = int(bmask[i].sum())
+            outs.append(bt.encode_ids(bids[i:i + 1, :n], bmask[i:i + 1, :n]).cpu())
+        return outs
+    monkeypatch.setattr(T, "GRAPHS", False)
+    eager = run_all()
+    assert not vt._graphs and not tt._graphs and not bt._graphs
+    monkeypatch.setattr(T, "GRAPHS", True)
+    first = run_all()    # captures
+    again = run_all()    # replays
+    assert vt._graphs and tt._graphs and bt._graphs and not (vt._graphs_off or tt._graphs_off or bt._graphs_off)
+    for e, a, b in zip(eager, first, again):
+        assert torch.equal(e, a) and torch.equal(e, b)
+    # the batch path is the eager one and agrees with the single calls
+    assert _cos_err(vt.encode_u8(u8.cuda()), torch.cat(eager[:3])) < 1e-5
