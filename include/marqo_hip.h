@@ -336,9 +336,10 @@ int mq_layernorm(const float* d_x, const int32_t* d_row_idx, const float* d_g, c
                  void* d_out_bf16, float* d_out_f32, int64_t rows, int32_t W, float eps, void* stream);
 
 /* Multi-head attention over packed sequences.  d_qkv bf16 [rows, 3W] (q | k | v, head h at
- * columns h*64 .. h*64+63 of each third).  d_out bf16 [rows, W].  Either pass fixed_len > 0
- * (all sequences have that length, nseq = rows / fixed_len) or d_cu_seqlens int32 [nseq+1]
- * with max_len = the longest sequence. */
+ * columns h*hd .. h*hd+hd-1 of each third, hd = W / heads in {64, 96, 112, 128}; softmax scale 1/sqrt(hd)).
+ * d_out bf16 [rows, W].  Either pass fixed_len > 0 (all sequences have that length, nseq = rows / fixed_len)
+ * or d_cu_seqlens int32 [nseq+1] with max_len = the longest sequence (<= 8192; sequences beyond 640 keys at
+ * hd = 64 / 320 keys at wider heads stream their K / V through the LDS in pieces). */
 int mq_attention(const void* d_qkv, void* d_out, const int32_t* d_cu_seqlens, int64_t nseq,
                  int32_t fixed_len, int32_t max_len, int32_t W, int32_t heads, int32_t mask,
                  void* stream);

@@ -17,8 +17,8 @@ run on seeded inputs in fp32 on CPU, and the (weights, inputs, outputs) triple i
                       biased projection), hidden_act='gelu' like timm's SigLIP ViTs; weights renamed to the open_clip / timm
                       checkpoint naming (visual.trunk.*, text.*)
 
-Head dim is 64 in every fixture (the engine's attention kernel is specialised for d_head = 64, as
-are all four towers of BASELINE.json's configs).
+Head dim is 64 in the fixtures except ``bert_small_h32`` (32-wide heads, zero-padded to 64 at load); BASELINE.json's four towers
+all have 64-wide heads.
 """
 import os
 import sys
