@@ -281,12 +281,14 @@ class _TowerBase:
 
     def _graphs_ok(self) -> bool:
         """single-request calls replay a captured hipGraph (MARQO_AMD_GRAPHS=0 turns that off); an fp8 tower only once its scales are frozen"""
-        return GRAPHS and not self._graphs_off and len(self._graphs) < MAX_GRAPHS_PER_TOWER and (self._fp8 is None or self._fp8.calibrated)
+        return GRAPHS and not self._graphs_off and (self._fp8 is None or self._fp8.calibrated)
 
     def _capture(self, key: tuple, make) -> Optional["_GraphedCall"]:
         """graph for `key`, captured on first use; a failed capture turns graph replay off for this tower (eager launches remain)"""
         g = self._graphs.get(key)
         if g is None:
+            if len(self._graphs) >= MAX_GRAPHS_PER_TOWER:
+                return None
             try:
                 g = self._graphs[key] = make()
             except RuntimeError as e:
