@@ -471,3 +471,25 @@ def test_open_clip_architecture_resolution(tmp_path):
     with pytest.raises(ModelLoadError):
         m._resolve_archs("hf-hub:acme/x", None, str(tmp_path))
     assert m._resolve_archs("hf-hub:Marqo/marqo-fashionSigLIP", None, str(tmp_path))[0].pool == "map"  # known repo: table fallback
+
+
+def test_bench_workload_table_resolves():
+    """every bench.py workload names an architecture the engine resolves, with a positive algorithmic cost"""
+    import importlib.util
+    import os
+    from marqo_amd.engine import archs as A
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert "vit_b32_image" in bench.WORKLOADS and bench.BF16_DENSE_PEAK_TFLOPS == 2500.0
+    for name, wl in bench.WORKLOADS.items():
+        assert wl["kind"] in ("image", "clip_text", "bert", "mixed") and wl["batch"] > 0, name
+        if wl["kind"] == "bert":
+            assert A.HF_BERT_ARCHS[wl["arch"]].gflop_per_text(77) > 0
+        else:
+            v, t = A.resolve_open_clip(wl["arch"])
+            assert v.gflop_per_image > 0 and t.gflop_per_text(t.ctx) > 0, name
+    v, _ = A.resolve_open_clip("ViT-B-32")
+    assert abs(v.gflop_per_image - 8.82) < 0.01          # the per-embedding figure BASELINE / SURVEY §8(d) quote
+    v, _ = A.resolve_open_clip("ViT-L-14")
+    assert abs(v.gflop_per_image - 162.0) < 0.1
