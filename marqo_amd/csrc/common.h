@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <atomic>
 #include "../../include/marqo_hip.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -92,6 +93,20 @@ void mq_set_error(const char* fmt, ...);
             return MQ_ERR_HIP;                                                      \
         }                                                                           \
     } while (0)
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute of a kernel: `done` holds one bit per device ordinal, so a
+// process that serves several GPUs ('cuda:N' device strings) sets it once per (kernel instantiation, device); concurrent request
+// threads may race to set it (idempotent), never skip it.
+static inline hipError_t mq_ensure_dyn_lds(const void* fn, int bytes, std::atomic<uint64_t>& done) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+    return e;
+}
 
 #define MQ_TRY(expr)                 \
     do {                             \

@@ -151,14 +151,10 @@ int launch_big_mt(const void* A, int64_t lda, const void* W, int64_t ldw, const 
                   void* out, int64_t ldc, int M, int N, int K, hipStream_t s) {
     constexpr int BM = 32 * MT;
     constexpr int LDS = 2 * (BM * BK * 2 + W_TILE_BYTES);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_big_kernel<FLAGS, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) {
-            mq_set_error("mq_gemm_bf16(big): hipFuncSetAttribute: %s", hipGetErrorString(e));
-            return MQ_ERR_HIP;
-        }
-        attr_set = true;
+    static std::atomic<uint64_t> attr_done{0};
+    if (hipError_t e = mq_ensure_dyn_lds((const void*)gemm_big_kernel<FLAGS, MT>, LDS, attr_done); e != hipSuccess) {
+        mq_set_error("mq_gemm_bf16(big): hipFuncSetAttribute: %s", hipGetErrorString(e));
+        return MQ_ERR_HIP;
     }
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     const int num_tiles = tiles_m * tiles_n;

@@ -381,11 +381,10 @@ template <int FLAGS, int MT, bool ROWSCALE, bool PERSIST>
 int launch_fp8_mt(const Fp8Args& a, hipStream_t s) {
     constexpr int BM = 32 * MT;
     constexpr int LDS = 2 * (BM * BK + W_TILE_BYTES);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_fp8_kernel<FLAGS, MT, ROWSCALE, PERSIST>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) { mq_set_error("mq_gemm_fp8: hipFuncSetAttribute: %s", hipGetErrorString(e)); return MQ_ERR_HIP; }
-        attr_set = true;
+    static std::atomic<uint64_t> attr_done{0};
+    if (hipError_t e = mq_ensure_dyn_lds((const void*)gemm_fp8_kernel<FLAGS, MT, ROWSCALE, PERSIST>, LDS, attr_done); e != hipSuccess) {
+        mq_set_error("mq_gemm_fp8: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        return MQ_ERR_HIP;
     }
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
     const int num_tiles = tiles_m * tiles_n;

@@ -160,10 +160,19 @@ HF_BERT_ARCHS = {
     "BAAI/bge-large-en": _BERT_LARGE, "BAAI/bge-large-en-v1.5": _BERT_LARGE,
     "sentence-transformers/all-MiniLM-L6-v1": _MINILM_L6, "sentence-transformers/all-MiniLM-L6-v2": _MINILM_L6,
     "sentence-transformers/all-MiniLM-L12-v2": _BERT_SMALL,
+    "flax-sentence-embeddings/all_datasets_v3_MiniLM-L12": _BERT_SMALL, "flax-sentence-embeddings/all_datasets_v4_MiniLM-L12": _BERT_SMALL,
+    "flax-sentence-embeddings/all_datasets_v3_MiniLM-L6": _MINILM_L6, "flax-sentence-embeddings/all_datasets_v4_MiniLM-L6": _MINILM_L6,
+    "intfloat/e5-small-unsupervised": _BERT_SMALL, "intfloat/e5-base-unsupervised": _BERT_BASE, "intfloat/e5-large-unsupervised": _BERT_LARGE,
+    "Snowflake/snowflake-arctic-embed-m": _BERT_BASE, "Snowflake/snowflake-arctic-embed-m-v1.5": _BERT_BASE,
+    "Snowflake/snowflake-arctic-embed-l": _BERT_LARGE, "llmrails/ember-v1": _BERT_LARGE, "avsolatorio/GIST-large-Embedding-v0": _BERT_LARGE,
+    # Chinese BGE: BERT with the 21128-entry Chinese WordPiece vocabulary (small: 4 layers of width 512)
+    "BAAI/bge-small-zh-v1.5": BertArch(vocab=21128, width=512, layers=4, heads=8, mlp_dim=2048),
+    "BAAI/bge-base-zh-v1.5": BertArch(vocab=21128), "BAAI/bge-large-zh-v1.5": BertArch(vocab=21128, width=1024, layers=24, heads=16, mlp_dim=4096),
     # XLM-RoBERTa encoders
     "intfloat/multilingual-e5-small": BertArch(vocab=250037, max_pos=512, width=384, layers=12, heads=12, mlp_dim=1536, ln_eps=1e-5, pos_offset=2),
     "intfloat/multilingual-e5-base": BertArch(vocab=250002, max_pos=512, ln_eps=1e-5, pos_offset=2),
     "intfloat/multilingual-e5-large": BertArch(vocab=250002, max_pos=512, width=1024, layers=24, heads=16, mlp_dim=4096, ln_eps=1e-5, pos_offset=2),
+    "intfloat/multilingual-e5-large-instruct": BertArch(vocab=250002, max_pos=512, width=1024, layers=24, heads=16, mlp_dim=4096, ln_eps=1e-5, pos_offset=2),
 }
 
 

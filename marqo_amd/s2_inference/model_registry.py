@@ -18,9 +18,12 @@ from marqo_amd.engine import archs
 _OPEN_CLIP_TAGS = {
     "ViT-B-32": ["laion400m_e31", "laion400m_e32", "laion2b_e16", "laion2b_s34b_b79k", "openai"],
     "ViT-B-32-quickgelu": ["laion400m_e31", "laion400m_e32", "openai"],
+    "ViT-B-32-256": ["datacomp_s34b_b86k"],
     "ViT-B-16": ["laion400m_e31", "laion400m_e32", "laion2b_s34b_b88k", "openai"],
+    "ViT-B-16-quickgelu": ["metaclip_fullcc"],
     "ViT-B-16-plus-240": ["laion400m_e31", "laion400m_e32"],
     "ViT-L-14": ["laion400m_e31", "laion400m_e32", "laion2b_s32b_b82k", "openai"],
+    "ViT-L-14-quickgelu": ["dfn2b"],
     "ViT-L-14-336": ["openai"],
     "ViT-H-14": ["laion2b_s32b_b79k"],
     "ViT-H-14-quickgelu": ["dfn5b"],
@@ -32,31 +35,45 @@ _OPEN_CLIP_TAGS = {
     "ViT-L-16-SigLIP-256": ["webli"], "ViT-L-16-SigLIP-384": ["webli"], "ViT-SO400M-14-SigLIP-384": ["webli"],
 }
 
-# hf registry entries whose encoder is a plain BERT (absolute positions, GELU, post-LN): name -> (repo, dims, tokens, prefixes)
+# hf registry entries whose encoder the BERT tower runs (plain BERT: absolute positions, GELU, post-LN; XLM-RoBERTa checkpoints are
+# the same encoder with shifted position ids): name -> (repo, dims, tokens, query prefix, chunk prefix, poolingMethod).  None = the
+# reference entry has no such key (model_registry.py:616-880; tests/test_ref_parity.py compares every field with the reference's
+# own dict).  The bge entries carry the reference's EXPLICIT "poolingMethod": "mean" (:804-849): the BAAI checkpoints ship a
+# 1_Pooling/config.json that says CLS, and an index built with the reference is mean-pooled.
+_BGE_EN = "Represent this sentence for searching relevant passages: "
+_BGE_ZH = "为这个句子生成表示以用于检索相关文章："
 _HF_BERT = {
-    "hf/all-MiniLM-L6-v1": ("sentence-transformers/all-MiniLM-L6-v1", 384, 128, None, None),
-    "hf/all-MiniLM-L6-v2": ("sentence-transformers/all-MiniLM-L6-v2", 384, 128, None, None),
-    "hf/all_datasets_v3_MiniLM-L12": ("flax-sentence-embeddings/all_datasets_v3_MiniLM-L12", 384, 128, None, None),
-    "hf/all_datasets_v3_MiniLM-L6": ("flax-sentence-embeddings/all_datasets_v3_MiniLM-L6", 384, 128, None, None),
-    "hf/all_datasets_v4_MiniLM-L12": ("flax-sentence-embeddings/all_datasets_v4_MiniLM-L12", 384, 128, None, None),
-    "hf/all_datasets_v4_MiniLM-L6": ("flax-sentence-embeddings/all_datasets_v4_MiniLM-L6", 384, 128, None, None),
-    "hf/e5-small": ("intfloat/e5-small", 384, 192, "query: ", "passage: "),
-    "hf/e5-base": ("intfloat/e5-base", 768, 192, "query: ", "passage: "),
-    "hf/e5-large": ("intfloat/e5-large", 1024, 192, "query: ", "passage: "),
-    "hf/e5-small-unsupervised": ("intfloat/e5-small-unsupervised", 384, 128, "query: ", "passage: "),
-    "hf/e5-base-unsupervised": ("intfloat/e5-base-unsupervised", 768, 128, "query: ", "passage: "),
-    "hf/e5-large-unsupervised": ("intfloat/e5-large-unsupervised", 1024, 128, "query: ", "passage: "),
-    "hf/e5-small-v2": ("intfloat/e5-small-v2", 384, 512, "query: ", "passage: "),
-    "hf/e5-base-v2": ("intfloat/e5-base-v2", 768, 512, "query: ", "passage: "),
-    "hf/e5-large-v2": ("intfloat/e5-large-v2", 1024, 512, "query: ", "passage: "),
-    "hf/bge-small-en-v1.5": ("BAAI/bge-small-en-v1.5", 384, 512, "Represent this sentence for searching relevant passages: ", ""),
-    "hf/bge-base-en-v1.5": ("BAAI/bge-base-en-v1.5", 768, 512, "Represent this sentence for searching relevant passages: ", ""),
-    "hf/bge-large-en-v1.5": ("BAAI/bge-large-en-v1.5", 1024, 512, "Represent this sentence for searching relevant passages: ", ""),
-    "hf/snowflake-arctic-embed-m": ("Snowflake/snowflake-arctic-embed-m", 768, 512, "Represent this sentence for searching relevant passages: ", ""),
-    "hf/snowflake-arctic-embed-m-v1.5": ("Snowflake/snowflake-arctic-embed-m-v1.5", 768, 512, "Represent this sentence for searching relevant passages: ", ""),
-    "hf/snowflake-arctic-embed-l": ("Snowflake/snowflake-arctic-embed-l", 1024, 512, "Represent this sentence for searching relevant passages: ", ""),
-    "hf/ember-v1": ("llmrails/ember-v1", 1024, 512, None, None),
-    "hf/GIST-large-Embedding-v0": ("avsolatorio/GIST-large-Embedding-v0", 1024, 512, None, None),
+    "hf/all-MiniLM-L6-v1": ("sentence-transformers/all-MiniLM-L6-v1", 384, 128, None, None, None),
+    "hf/all-MiniLM-L6-v2": ("sentence-transformers/all-MiniLM-L6-v2", 384, 256, None, None, None),
+    "hf/all_datasets_v3_MiniLM-L12": ("flax-sentence-embeddings/all_datasets_v3_MiniLM-L12", 384, 128, None, None, None),
+    "hf/all_datasets_v3_MiniLM-L6": ("flax-sentence-embeddings/all_datasets_v3_MiniLM-L6", 384, 128, None, None, None),
+    "hf/all_datasets_v4_MiniLM-L12": ("flax-sentence-embeddings/all_datasets_v4_MiniLM-L12", 384, 128, None, None, None),
+    "hf/all_datasets_v4_MiniLM-L6": ("flax-sentence-embeddings/all_datasets_v4_MiniLM-L6", 384, 128, None, None, None),
+    "hf/e5-small": ("intfloat/e5-small", 384, 192, "query: ", "passage: ", None),
+    "hf/e5-base": ("intfloat/e5-base", 768, 192, "query: ", "passage: ", None),
+    "hf/e5-large": ("intfloat/e5-large", 1024, 192, "query: ", "passage: ", None),
+    "hf/e5-small-unsupervised": ("intfloat/e5-small-unsupervised", 384, 128, "query: ", "passage: ", None),
+    "hf/e5-base-unsupervised": ("intfloat/e5-base-unsupervised", 768, 128, "query: ", "passage: ", None),
+    "hf/e5-large-unsupervised": ("intfloat/e5-large-unsupervised", 1024, 128, "query: ", "passage: ", None),
+    "hf/e5-small-v2": ("intfloat/e5-small-v2", 384, 512, "query: ", "passage: ", None),
+    "hf/e5-base-v2": ("intfloat/e5-base-v2", 768, 512, "query: ", "passage: ", None),
+    "hf/e5-large-v2": ("intfloat/e5-large-v2", 1024, 512, "query: ", "passage: ", None),
+    "hf/multilingual-e5-small": ("intfloat/multilingual-e5-small", 384, 512, "query: ", "passage: ", None),
+    "hf/multilingual-e5-base": ("intfloat/multilingual-e5-base", 768, 512, "query: ", "passage: ", None),
+    "hf/multilingual-e5-large": ("intfloat/multilingual-e5-large", 1024, 512, "query: ", "passage: ", None),
+    "hf/multilingual-e5-large-instruct": ("intfloat/multilingual-e5-large-instruct", 1024, 512,
+                                          "Instruct: Given a web search query, retrieve relevant passages that answer the query\nQuery: ", None, None),
+    "hf/bge-small-en-v1.5": ("BAAI/bge-small-en-v1.5", 384, 512, _BGE_EN, None, "mean"),
+    "hf/bge-base-en-v1.5": ("BAAI/bge-base-en-v1.5", 768, 512, _BGE_EN, None, "mean"),
+    "hf/bge-large-en-v1.5": ("BAAI/bge-large-en-v1.5", 1024, 512, _BGE_EN, None, "mean"),
+    "hf/bge-small-zh-v1.5": ("BAAI/bge-small-zh-v1.5", 512, 512, _BGE_ZH, None, "mean"),
+    "hf/bge-base-zh-v1.5": ("BAAI/bge-base-zh-v1.5", 768, 512, _BGE_ZH, None, "mean"),
+    "hf/bge-large-zh-v1.5": ("BAAI/bge-large-zh-v1.5", 1024, 512, _BGE_ZH, None, "mean"),
+    "hf/snowflake-arctic-embed-m": ("Snowflake/snowflake-arctic-embed-m", 768, 512, _BGE_EN, None, None),
+    "hf/snowflake-arctic-embed-m-v1.5": ("Snowflake/snowflake-arctic-embed-m-v1.5", 768, 512, _BGE_EN, None, None),
+    "hf/snowflake-arctic-embed-l": ("Snowflake/snowflake-arctic-embed-l", 1024, 512, _BGE_EN, None, None),
+    "hf/ember-v1": ("llmrails/ember-v1", 1024, 512, None, None, None),
+    "hf/GIST-large-Embedding-v0": ("avsolatorio/GIST-large-Embedding-v0", 1024, 512, None, None, None),
 }
 
 
@@ -74,25 +91,31 @@ def _get_open_clip_properties() -> Dict:
     return out
 
 
+_FP16_CLIP_NAMES = ("ViT-B/32", "ViT-B/16", "ViT-L/14")   # the reference registers no fp16/ViT-L/14@336px (model_registry.py:2069-2092)
+
+
 def _get_clip_properties() -> Dict:
     """OpenAI-CLIP names (model_registry.py:16-73) and their fp16 variants (:2069-2092): same towers, QuickGELU."""
     out = {}
     for openai_name, arch_name in archs.OPENAI_CLIP_NAMES.items():
         vision, _ = archs.resolve_open_clip(arch_name, "openai")
         out[openai_name] = {"name": openai_name, "dimensions": vision.out_dim, "notes": "CLIP resnet", "type": "clip"}
-        out["fp16/" + openai_name] = {"name": "fp16/" + openai_name, "dimensions": vision.out_dim, "type": "fp16_clip",
-                                      "notes": "reduced-precision CLIP; on MI355X every CLIP tower already runs bf16 MFMA"}
+        if openai_name in _FP16_CLIP_NAMES:
+            out["fp16/" + openai_name] = {"name": "fp16/" + openai_name, "dimensions": vision.out_dim, "type": "fp16_clip",
+                                          "notes": "reduced-precision CLIP; on MI355X every CLIP tower already runs bf16 MFMA"}
     return out
 
 
 def _get_hf_properties() -> Dict:
     out = {}
-    for key, (repo, dims, tokens, qp, cp) in _HF_BERT.items():
+    for key, (repo, dims, tokens, qp, cp, pooling) in _HF_BERT.items():
         p = {"name": repo, "dimensions": dims, "tokens": tokens, "type": "hf", "notes": ""}
         if qp is not None:
             p["text_query_prefix"] = qp
         if cp is not None:
             p["text_chunk_prefix"] = cp
+        if pooling is not None:
+            p["poolingMethod"] = pooling
         out[key] = p
     return out
 

@@ -31,7 +31,7 @@ def get_default_size() -> Tuple[int, int]:
 
 
 def str2bool(string: str) -> bool:
-    return str(string).lower() in ["true", "1", "t", "y", "yes"]
+    return string.lower() in ("true", "1", "t")   # image_utils.py:204-213 (pinned by tests/test_ref_parity.py)
 
 
 def rescale_box(box, from_size: Tuple, to_size: Tuple) -> List[float]:

@@ -72,10 +72,10 @@ def check_make_string_valid(text: str, coerce: bool = True) -> str:
     empty_string = " "
     if text in [[], None, "", empty_string] and coerce:
         return empty_string
+    if text.isspace():   # (before the type check, as text.py:97-103 has it: a non-str raises AttributeError here)
+        return empty_string
     if not isinstance(text, str):
         raise TypeError(f"text had type {type(text)} but expected str")
-    if text.isspace():
-        return empty_string
     return text
 
 

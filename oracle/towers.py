@@ -357,6 +357,103 @@ def synthetic_vit_state_dict(cfg: VitConfig, seed: int = 0) -> Dict[str, Tensor]
     return sd
 
 
+def _realistic_blocks(sd: Dict[str, Tensor], prefix: str, layers: int, W: int, F_: int, g: torch.Generator) -> None:
+    """Rewrites a resblock stack with trained-like statistics (what N(0, s) weights never show a kernel):
+      * LayerNorm gamma log-normal (sigma 0.4) with a handful of channels at 0.05 and at 4.0, beta ~ N(0, 0.3);
+      * per-layer weight scale varying over 0.7-1.6x, 1 % of the output channels of every linear 4x larger (outlier channels),
+        biases ~ N(0, 0.1);
+      * query / key rows 2.5x larger, so attention logits have a standard deviation of a few units (peaky softmax) instead of the
+        near-uniform attention of small random weights."""
+    base = 0.6 / math.sqrt(W)
+    for i in range(layers):
+        p = f"{prefix}resblocks.{i}."
+        for ln in ("ln_1", "ln_2"):
+            gam = torch.exp(0.4 * torch.randn(W, generator=g))
+            idx = torch.randperm(W, generator=g)
+            gam[idx[:8]] = 0.05
+            gam[idx[8:16]] = 4.0
+            sd[p + ln + ".weight"] = gam
+            sd[p + ln + ".bias"] = 0.3 * torch.randn(W, generator=g)
+        scale = 0.7 + 0.9 * float(torch.rand(1, generator=g))
+        for name, (n_out, n_in) in (("attn.in_proj_", (3 * W, W)), ("attn.out_proj.", (W, W)), ("mlp.c_fc.", (F_, W)), ("mlp.c_proj.", (W, F_))):
+            std = base * scale * (math.sqrt(W / n_in) if n_in != W else 1.0)
+            w = std * torch.randn(n_out, n_in, generator=g)
+            out_idx = torch.randperm(n_out, generator=g)[: max(1, n_out // 100)]
+            w[out_idx] *= 4.0
+            if name == "attn.in_proj_":
+                w[: 2 * W] *= 2.5
+            sd[p + name + "weight"] = w
+            sd[p + name + "bias"] = 0.1 * torch.randn(n_out, generator=g)
+
+
+def _massive_unit(sd: Dict[str, Tensor], prefix: str, layers: int, layer: int, c0: int, targets: Sequence[int], unit: int, value: float,
+                  later_gain: float) -> None:
+    """MLP hidden unit `unit` of block `layer` becomes a detector of the token whose residual channel c0 is dominant (the class
+    token / SOT token, see the callers) and writes `value` x GELU(~5) into the residual channels `targets` of that token only: a
+    token-specific massive activation that every later LayerNorm, GEMM and quantiser has to live with, as in trained ViTs / LMs.
+    As in trained models the network downstream is NOT sensitive to the exact massive value: every later LayerNorm has a small gain
+    (`later_gain`) on the outlier channels, so their main effect is on the row statistics (everything else in that row shrinks)."""
+    p = f"{prefix}resblocks.{layer}."
+    for i in range(layers):
+        for ln in ("ln_1", "ln_2"):
+            q = f"{prefix}resblocks.{i}.{ln}."
+            sd[q + "weight"][c0] = later_gain
+            sd[q + "bias"][c0] = 0.0
+            if i > layer:
+                for c in targets:
+                    sd[q + "weight"][c] = later_gain
+                    sd[q + "bias"][c] = 0.0
+    sd[p + "ln_2.weight"][c0] = 1.0
+    sd[p + "mlp.c_fc.weight"][unit] = 0.0
+    sd[p + "mlp.c_fc.weight"][unit, c0] = 1.0
+    sd[p + "mlp.c_fc.bias"][unit] = -8.0
+    sd[p + "mlp.c_proj.weight"][:, unit] = 0.0
+    for c in targets:
+        sd[p + "mlp.c_proj.weight"][c, unit] = value
+
+
+def synthetic_vit_state_dict_realistic(cfg: VitConfig, seed: int = 0, massive_layer: int = 2, massive_value: float = 30.0,
+                                       later_gain: float = 0.05) -> Dict[str, Tensor]:
+    """ViT checkpoint with trained-like statistics (see _realistic_blocks) plus a class-token-specific massive activation: the class
+    embedding carries one dominant channel (20 against ~0.5), block `massive_layer`'s MLP turns it into ~5 x massive_value (= 150)
+    in two residual channels of the class-token row from that block on.  Used by the full-depth parity tests (bf16 and fp8)."""
+    g = _g(seed + 7000)
+    sd = synthetic_vit_state_dict(cfg, seed)
+    W = cfg.width
+    _realistic_blocks(sd, "visual.transformer.", cfg.layers, W, cfg.mlp_dim, g)
+    c0, targets = 5, (W // 3, W // 2 + 1)
+    sd["visual.class_embedding"][c0] = 20.0
+    sd["visual.positional_embedding"][0, c0] = 0.0
+    sd["visual.ln_pre.weight"][c0] = 1.0
+    sd["visual.ln_pre.bias"][c0] = 0.0
+    if cfg.layers > massive_layer:
+        _massive_unit(sd, "visual.transformer.", cfg.layers, massive_layer, c0, targets, unit=7, value=massive_value, later_gain=later_gain)
+    sd["visual.ln_post.weight"] = torch.exp(0.4 * torch.randn(W, generator=g))
+    sd["visual.ln_post.bias"] = 0.3 * torch.randn(W, generator=g)
+    for c in (c0,) + tuple(targets):
+        sd["visual.ln_post.weight"][c] = later_gain
+    return sd
+
+
+def synthetic_clip_text_state_dict_realistic(cfg: ClipTextConfig, seed: int = 0, massive_layer: int = 1, massive_value: float = 30.0,
+                                             later_gain: float = 0.05) -> Dict[str, Tensor]:
+    """CLIP text checkpoint with trained-like statistics and an attention-sink style massive activation on the SOT token (id
+    vocab - 2): its embedding has one dominant channel, block `massive_layer` turns it into ~150 in two residual channels."""
+    g = _g(seed + 8000)
+    sd = synthetic_clip_text_state_dict(cfg, seed)
+    W = cfg.width
+    _realistic_blocks(sd, "transformer.", cfg.layers, W, cfg.mlp_dim, g)
+    c0, targets = 5, (W // 3, W // 2 + 1)
+    sd["token_embedding.weight"][cfg.vocab - 2] *= 0.2
+    sd["token_embedding.weight"][cfg.vocab - 2, c0] = 20.0
+    sd["positional_embedding"][0, c0] = 0.0
+    if cfg.layers > massive_layer:
+        _massive_unit(sd, "transformer.", cfg.layers, massive_layer, c0, targets, unit=7, value=massive_value, later_gain=later_gain)
+    for c in (c0,) + tuple(targets):
+        sd["ln_final.weight"][c] = later_gain
+    return sd
+
+
 def synthetic_clip_text_state_dict(cfg: ClipTextConfig, seed: int = 0) -> Dict[str, Tensor]:
     g = _g(seed + 1000)
     W = cfg.width
