@@ -3,18 +3,25 @@
 
     python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
 
-Workload (BASELINE.json configs[1], the config the metric is quoted on): open_clip ViT-B/32 image
-tower, synthetic uint8 224x224 RGB images already resident in HBM, 256 images per GPU per step,
-random-init weights of that architecture (no network for checkpoints).  One "step" = one pass of the
-hot path over one batch: normalise + patchify -> patch-embed GEMM -> 12 pre-LN blocks -> ln_post ->
-projection -> L2, i.e. exactly mq_encode_image_u8; for N > 1 the [256, 512] fp32 shards are then
-all-gathered over RCCL (the only collective on the path).  Work per GPU is fixed -> weak scaling.
+Headline workload (BASELINE.json configs[1], the config the metric is quoted on): open_clip ViT-B/32 image tower, synthetic uint8
+224x224 RGB images ALREADY RESIDENT IN HBM (tower-only: `value` excludes host packing, H2D, D2H and list conversion — those are
+reported beside it under `e2e_vectorise`), 256 images per GPU per step, random-init weights of that architecture (no network for
+checkpoints).  One "step" = one pass of the hot path over one batch: normalise + patchify -> patch-embed GEMM -> 12 pre-LN blocks ->
+ln_post -> projection -> L2, i.e. exactly mq_encode_image_u8; for N > 1 the [256, 512] fp32 shards are then all-gathered over RCCL
+(the only collective on the path).  Work per GPU is fixed -> weak scaling.
 
 Rank 0 prints ONE JSON line.  Besides the contract keys it carries
-  roofline     — the dominant kernel (bf16 MFMA GEMM): algorithmic FLOPs / HIP-event time of its launches
-  cpu_baseline — the CPU fp32 oracle (oracle/towers.py) run with the reference's 16-item batch loop
-                 (s2_inference.py:135-146) on a bounded sample, all host cores
-  cos_err_vs_cpu — max (1 - cosine) of the GPU embeddings vs that CPU path on the same sample
+  roofline        — the dominant kernel (bf16 MFMA GEMM): algorithmic FLOPs / HIP-event time of its launches
+  cpu_baseline    — the CPU fp32 oracle (oracle/towers.py) run with the reference's 16-item batch loop (s2_inference.py:135-146) on a
+                    bounded sample; `cores` = host cores, `threads_used` = the torch thread count that was fastest
+  cos_err_vs_cpu  — max (1 - cosine) of the GPU embeddings vs that CPU path on the same sample
+  e2e_vectorise   — (N = 1) the same 256 images through the product's `vectorise_ndarray()` / `vectorise()` from HOST memory, as
+                    SURVEY.md §8(d) defines end-to-end: pack + H2D + K10 + tower + D2H (+ `.tolist()`), for each hand-over form
+                    (PIL list / uint8 ndarray list / `.preprocess`ed device tensors), single caller and 4 concurrent callers
+  also            — (N = 1) the text half of the "images + text" metric and BASELINE configs[2] on the same box: CLIP text B/32,
+                    e5-base-v2 @ 77 tokens and the ViT-L/14 mixed batch, each tower-only with its own cpu_baseline
+`--workload add_documents_mixed` is BASELINE configs[3] in miniature: mixed text + image documents in 128-document requests through
+marqo_amd.ingest.BulkVectoriser, sharded over the ranks, gathered in request order.
 """
 from __future__ import annotations
 
@@ -23,19 +30,21 @@ import ctypes as C
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 BF16_DENSE_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
 FP8_DENSE_PEAK_TFLOPS = 5000.0   # MX-scaled fp8 MFMA (K = 128), ~5 PF dense
 WORKLOADS = {
     # the headline workload (BASELINE.json configs[1]) is the default; the others are reported in DESIGN.md §6
-    "vit_b32_image": dict(kind="image", arch="ViT-B-32", desc="open_clip ViT-B/32 image tower, uint8 224x224, batch 256/GPU", batch=256),
+    "vit_b32_image": dict(kind="image", arch="ViT-B-32", desc="open_clip ViT-B/32 image tower, uint8 224x224 resident in HBM (tower-only), batch 256/GPU", batch=256),
     "vit_l14_image": dict(kind="image", arch="ViT-L-14", desc="open_clip ViT-L/14 image tower, uint8 224x224, batch 64/GPU", batch=64),
     "vit_h14_image": dict(kind="image", arch="ViT-H-14", desc="open_clip ViT-H/14 image tower (80-wide heads run as 96), uint8 224x224, batch 64/GPU", batch=64),
     "vit_bigg14_image": dict(kind="image", arch="ViT-bigG-14", desc="open_clip ViT-bigG/14 image tower (104-wide heads run as 112), uint8 224x224, batch 32/GPU", batch=32),
@@ -46,7 +55,10 @@ WORKLOADS = {
     "clip_text_l14": dict(kind="clip_text", arch="ViT-L-14", desc="open_clip ViT-L/14 text tower, 77-token ids, batch 1024/GPU", batch=1024),
     "bert_base_77": dict(kind="bert", arch="intfloat/e5-base-v2", desc="e5-base-v2 (BERT-base) + mean-pool + L2, 77-token ids, batch 1024/GPU", batch=1024),
     "vit_l14_mixed": dict(kind="mixed", arch="ViT-L-14", desc="open_clip ViT-L/14 dual encoder, 128 images + 128 texts (5..75 tokens) per GPU (BASELINE configs[2])", batch=256),
+    "add_documents_mixed": dict(kind="ingest", arch="ViT-B-32", desc="add_documents bulk ingest in miniature (BASELINE configs[3]): documents {text, 224x224 image} in "
+                                "128-document requests through BulkVectoriser (host PIL images + strings -> vectorise -> gather in order), ViT-B/32", batch=128),
 }
+ALSO_DEFAULT = ("clip_text_b32", "bert_base_77", "vit_l14_mixed")
 
 
 def parse_args():
@@ -55,40 +67,25 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="vit_b32_image", choices=sorted(WORKLOADS))
-    ap.add_argument("--batch", type=int, default=0, help="images per GPU per step (default: the workload's)")
+    ap.add_argument("--batch", type=int, default=0, help="items per GPU per step (default: the workload's)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp8"],
                     help="GEMM operand type of the encoder blocks (fp8 = e4m3, BASELINE config 5; not the headline metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the headline baseline sample")
+    ap.add_argument("--no-extras", action="store_true", help="skip e2e_vectorise and the `also` workloads (profiling runs)")
     return ap.parse_args()
 
 
-def cpu_baseline(sd, arch, images_u8_cpu, target_seconds):
-    """Reference-equivalent CPU path (fp32 PyTorch eager, the reference's 16-item batch loop) on a bounded sample.
-    The thread count is the best of a short ladder (all host threads is often NOT the fastest on a 2-socket SMT box);
-    returns (emb/s, n, embeddings, threads used, total host threads)."""
-    import numpy as np
-    from oracle import towers as O
+# ---- CPU baselines (oracle/ is the checker; it is only ever timed here, never on the product path) ---------------------------------
+def _best_threads(run16, target_seconds):
     cores = os.cpu_count() or 1
-    if arch.pool == "map":
-        cfg, fwd = O.SiglipVitConfig(arch.image_size, arch.patch_size, arch.width, arch.layers, arch.heads, arch.mlp_dim), O.siglip_vit_forward
-    else:
-        cfg, fwd = O.VitConfig(arch.image_size, arch.patch_size, arch.width, arch.layers, arch.heads, arch.mlp_dim,
-                               arch.out_dim, arch.quick_gelu), O.vit_forward
-
-    def run(imgs):
-        outs = []
-        for i in range(0, imgs.shape[0], 16):  # MARQO_MAX_VECTORISE_BATCH_SIZE default (api/configs.py:38)
-            outs.append(fwd(sd, cfg, O.preprocess_u8_exact_size(imgs[i:i + 16])).numpy())
-        return np.concatenate(outs, axis=0)
-
     t_start = time.perf_counter()
     best_threads, best_dt = None, None
     for th in [t for t in (16, 32, 64, 128) if t < cores] + [cores]:
         torch.set_num_threads(th)
-        run(images_u8_cpu[:16])  # warm-up at this thread count
+        run16()  # warm-up at this thread count
         t0 = time.perf_counter()
-        run(images_u8_cpu[:16])
+        run16()
         dt = time.perf_counter() - t0
         if best_dt is None or dt < best_dt:
             best_threads, best_dt = th, dt
@@ -97,12 +94,343 @@ def cpu_baseline(sd, arch, images_u8_cpu, target_seconds):
         if time.perf_counter() - t_start > 0.5 * target_seconds:
             break
     torch.set_num_threads(best_threads)
-    budget = max(target_seconds - (time.perf_counter() - t_start), best_dt)
-    n = int(min(images_u8_cpu.shape[0], max(16, (budget / max(best_dt, 1e-3)) * 16) // 16 * 16))
+    return best_threads, best_dt, cores, max(target_seconds - (time.perf_counter() - t_start), best_dt)
+
+
+def cpu_baseline_run(run_items, n_total, target_seconds):
+    """run_items(lo, hi) -> fp32 embeddings of items [lo, hi) through the reference-equivalent CPU path (fp32 PyTorch eager, the
+    reference's 16-item batch loop).  The thread count is the best of a short ladder (all host threads is often NOT the fastest on
+    a 2-socket SMT box).  -> (emb/s, n, embeddings, threads used, host cores)."""
+    def run(lo, hi):
+        outs = [run_items(i, min(i + 16, hi)) for i in range(lo, hi, 16)]  # MARQO_MAX_VECTORISE_BATCH_SIZE default (api/configs.py:38)
+        return torch.cat(outs, dim=0)
+    threads, dt16, cores, budget = _best_threads(lambda: run(0, min(16, n_total)), target_seconds)
+    n = int(min(n_total, max(16, (budget / max(dt16, 1e-3)) * 16) // 16 * 16))
     t0 = time.perf_counter()
-    emb = run(images_u8_cpu[:n])
+    emb = run(0, n)
     dt = time.perf_counter() - t0
-    return n / dt, n, torch.from_numpy(emb), best_threads, cores
+    return n / dt, n, emb, threads, cores
+
+
+def _cos_err(gpu, cpu):
+    g, c = gpu.double(), cpu.double()
+    return float((1 - (g * c).sum(-1) / (g.norm(dim=-1) * c.norm(dim=-1))).max())
+
+
+def _baseline_dict(rate, n, threads, cores, what):
+    return {"value": round(rate, 2), "unit": "embeddings/s", "cores": cores, "threads_used": threads, "kind": "port",
+            "sample": f"{n} {what}, fp32 PyTorch eager, 16-item batches (reference loop s2_inference.py:135-146), best of a 16/32/64/128/all thread ladder"}
+
+
+# ---- workloads ------------------------------------------------------------------------------------------------------------------
+class Workload:
+    """towers + HBM-resident synthetic inputs of one bench workload; `run()` enqueues one step and returns [batch, D] on device"""
+
+    def __init__(self, name, precision, batch, dev, seed):
+        from marqo_amd.engine import archs, synthetic, towers
+        wl = WORKLOADS[name]
+        self.name, self.wl, self.kind, self.batch, self.dev = name, wl, wl["kind"], batch or wl["batch"], dev
+        batch = self.batch
+        g = torch.Generator().manual_seed(seed)
+        self.varch = self.tarch = self.barch = None
+        if self.kind in ("image", "clip_text", "mixed"):
+            self.varch, self.tarch = archs.resolve_open_clip(wl["arch"])
+
+        def clip_ids(n, lo, hi):
+            ids = torch.zeros(n, 77, dtype=torch.int64)
+            lens = torch.randint(lo, hi + 1, (n,), generator=g)
+            for i in range(n):
+                li = int(lens[i])
+                ids[i, 0] = 49406
+                ids[i, 1:1 + li] = torch.randint(1, 49406, (li,), generator=g)
+                ids[i, 1 + li] = 49407
+            return ids
+
+        self.images_cpu = self.ids_cpu = None
+        if self.kind == "image":
+            self.sd = synthetic.random_open_clip_state_dict(vision=self.varch, seed=0)
+            tower = towers.VitTower(self.varch, self.sd, dev, precision=precision)
+            self.images_cpu = torch.randint(0, 256, (batch, self.varch.image_size, self.varch.image_size, 3), generator=g, dtype=torch.uint8)
+            images = self.images_cpu.to(dev)
+            self.towers = [tower]
+            self.gflop_per_emb = self.varch.gflop_per_image
+            self.run = lambda: tower.encode_u8(images)
+        elif self.kind == "clip_text":
+            tarch = self.tarch
+            self.sd = synthetic.random_open_clip_state_dict(text=tarch, seed=0)
+            tower = towers.ClipTextTower(tarch, self.sd, dev, precision=precision)
+            self.towers = [tower]
+            self.gflop_per_emb = tarch.gflop_per_text(tarch.ctx)
+            # ids resident in HBM like the images (what the device tokeniser hands over); only the n lengths live on the host
+            if tarch.causal:
+                ids = clip_ids(batch, 75, 75)
+                d_ids, lens = ids.to(torch.int32).to(dev), ids.argmax(1) + 1
+            else:  # SigLIP: every text is ctx positions (pieces ... </s> then </s> padding), all of them run
+                ids = torch.ones(batch, tarch.ctx, dtype=torch.int64)
+                ids[:, :20] = torch.randint(2, tarch.vocab, (batch, 20), generator=g)
+                d_ids, lens = ids.to(torch.int32).to(dev), torch.full((batch,), tarch.ctx, dtype=torch.int64)
+            self.ids_cpu = ids
+            self.run = lambda: tower.encode_device(d_ids, lens)
+        elif self.kind == "bert":
+            self.barch = archs.HF_BERT_ARCHS[wl["arch"]]
+            self.sd = synthetic.random_bert_state_dict(self.barch, seed=0)
+            tower = towers.BertTower(self.barch, self.sd, dev, precision=precision)
+            ids = torch.randint(1000, self.barch.vocab, (batch, 77), generator=g)
+            ids[:, 0], ids[:, -1] = 101, 102
+            self.ids_cpu = ids
+            self.towers = [tower]
+            self.gflop_per_emb = self.barch.gflop_per_text(77)
+            d_ids, lens = ids.to(torch.int32).to(dev), torch.full((batch,), 77, dtype=torch.int64)
+            self.run = lambda: tower.encode_device(d_ids, lens)
+        elif self.kind == "mixed":  # half images, half texts of ragged length through the two towers of one model
+            self.sd = synthetic.random_open_clip_state_dict(vision=self.varch, text=self.tarch, seed=0)
+            vt = towers.VitTower(self.varch, self.sd, dev, precision=precision)
+            tt = towers.ClipTextTower(self.tarch, self.sd, dev, precision=precision)
+            n_img = batch // 2
+            self.n_img = n_img
+            self.images_cpu = torch.randint(0, 256, (n_img, self.varch.image_size, self.varch.image_size, 3), generator=g, dtype=torch.uint8)
+            images = self.images_cpu.to(dev)
+            ids = clip_ids(batch - n_img, 5, 75)
+            self.ids_cpu = ids
+            self.towers = [vt, tt]
+            d_ids, lens = ids.to(torch.int32).to(dev), ids.argmax(1) + 1
+            mean_tokens = float((ids.argmax(1) + 1).float().mean())
+            self.gflop_per_emb = (n_img * self.varch.gflop_per_image + (batch - n_img) * self.tarch.gflop_per_text(int(round(mean_tokens)))) / batch
+            self.run = lambda: torch.cat([vt.encode_u8(images), tt.encode_device(d_ids, lens)], dim=0)
+        else:
+            raise ValueError(self.kind)
+        self.fp8_policy = None
+        if precision == "fp8":
+            # load-time policy of the product (engine/towers.py::tune_fp8): static scales + how many trailing blocks run on e4m3 inside
+            # MARQO_AMD_FP8_BUDGET (default 7e-4 vs the bf16 tower; set it to 1 to force every block onto fp8), outside the timed region
+            self.fp8_policy = [{"layers": t.cfg.enc.layers, "fp8_first_layer": t.tune_fp8_default(), "calibration_err_vs_bf16": t.fp8_calibration_error,
+                                "all_blocks_err_vs_bf16": t.fp8_all_blocks_error} for t in self.towers]
+
+    def cpu_baseline(self, gpu_out, target_seconds):
+        """reference-equivalent CPU path on a bounded sample of this workload's own inputs + cosine error of the GPU result"""
+        from oracle import towers as O
+        if self.kind == "image":
+            a = self.varch
+            if a.pool == "map":
+                cfg, fwd = O.SiglipVitConfig(a.image_size, a.patch_size, a.width, a.layers, a.heads, a.mlp_dim), O.siglip_vit_forward
+            else:
+                cfg, fwd = O.VitConfig(a.image_size, a.patch_size, a.width, a.layers, a.heads, a.mlp_dim, a.out_dim, a.quick_gelu), O.vit_forward
+            rate, n, emb, th, cores = cpu_baseline_run(lambda lo, hi: fwd(self.sd, cfg, O.preprocess_u8_exact_size(self.images_cpu[lo:hi])),
+                                                       self.batch, target_seconds)
+            what = f"of the step's {self.batch} images"
+        elif self.kind == "clip_text" and self.tarch.causal:
+            t = self.tarch
+            cfg = O.ClipTextConfig(t.vocab, t.ctx, t.width, t.layers, t.heads, t.mlp_dim, t.out_dim, t.quick_gelu)
+            rate, n, emb, th, cores = cpu_baseline_run(lambda lo, hi: O.clip_text_forward(self.sd, cfg, self.ids_cpu[lo:hi]), self.batch, target_seconds)
+            what = f"of the step's {self.batch} texts (all 77 positions, as the reference runs them)"
+        elif self.kind == "bert":
+            b = self.barch
+            cfg = O.BertConfig(b.vocab, b.max_pos, b.width, b.layers, b.heads, b.mlp_dim, b.ln_eps, "mean", b.pos_offset)
+            rate, n, emb, th, cores = cpu_baseline_run(lambda lo, hi: O.hf_encode(self.sd, cfg, self.ids_cpu[lo:hi], torch.ones_like(self.ids_cpu[lo:hi])),
+                                                       self.batch, target_seconds)
+            what = f"of the step's {self.batch} texts of 77 tokens"
+        elif self.kind == "mixed":
+            a, t = self.varch, self.tarch
+            vcfg = O.VitConfig(a.image_size, a.patch_size, a.width, a.layers, a.heads, a.mlp_dim, a.out_dim, a.quick_gelu)
+            tcfg = O.ClipTextConfig(t.vocab, t.ctx, t.width, t.layers, t.heads, t.mlp_dim, t.out_dim, t.quick_gelu)
+            # interleave so that a bounded sample keeps the 50/50 mix: item 2i = image i, item 2i+1 = text i
+            def run_items(lo, hi):
+                i0, i1 = lo // 2, hi // 2
+                im = O.vit_forward(self.sd, vcfg, O.preprocess_u8_exact_size(self.images_cpu[i0:i1]))
+                tx = O.clip_text_forward(self.sd, tcfg, self.ids_cpu[i0:i1])
+                return torch.stack([im, tx], dim=1).reshape(-1, im.shape[1])
+            rate, n, emb, th, cores = cpu_baseline_run(run_items, 2 * min(self.n_img, self.batch - self.n_img), target_seconds)
+            k = n // 2
+            gpu_out = torch.stack([gpu_out[:k], gpu_out[self.n_img:self.n_img + k]], dim=1).reshape(-1, gpu_out.shape[1])
+            what = f"items ({k} images + {k} texts) of the step's {self.batch}"
+        else:
+            return None, None
+        return _baseline_dict(rate, n, th, cores, what), _cos_err(gpu_out[:n].float().cpu(), emb)
+
+
+def timed(run, steps, warmup, fence):
+    for _ in range(warmup):
+        run()
+    fence()
+    t0 = time.perf_counter()
+    out = None
+    for _ in range(steps):
+        out = run()
+    fence()
+    return time.perf_counter() - t0, out
+
+
+def gemm_roofline(lib, L, run_local, prof_steps, precision, workload_name):
+    """HIP-event timing of the GEMM family on the launch stream (separate, instrumented steps)"""
+    lib.mq_profile_enable(1)
+    for _ in range(prof_steps):
+        run_local()
+    ms = (C.c_double * L.MQ_PROF_FAMILIES)()
+    cnt = (C.c_int64 * L.MQ_PROF_FAMILIES)()
+    flops = C.c_double(0.0)
+    L.check(lib.mq_profile_collect(ms, cnt, C.byref(flops)), "mq_profile_collect")
+    lib.mq_profile_enable(0)
+    gemm_ms, gemm_launches = ms[0], cnt[0]
+    achieved = flops.value / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    peak = FP8_DENSE_PEAK_TFLOPS if precision == "fp8" else BF16_DENSE_PEAK_TFLOPS
+    families = {L.PROF_FAMILY_NAMES[i]: {"ms_per_step": ms[i] / prof_steps, "launches_per_step": cnt[i] // prof_steps}
+                for i in range(L.MQ_PROF_FAMILIES) if cnt[i]}
+    roofline = {
+        "kernel": ("gemm_fp8_kernel (e4m3 MX MFMA 16x16x128, (32*MT)x128x128 tiles, fused epilogues)" if precision == "fp8"
+                   else "gemm_nt_kernel (bf16 MFMA 16x16x32, (32*MT)x128x64 tiles, fused epilogues)"),
+        "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+        "frac": round(achieved / peak, 4), "traffic": None,
+        "flops_per_launch": flops.value / max(gemm_launches, 1),
+        "avg_launch_us": gemm_ms * 1e3 / max(gemm_launches, 1),
+        "launches_per_step": gemm_launches // max(prof_steps, 1),
+        "per_family": families,
+    }
+    if precision == "bf16":
+        # informational: what a register-resident v_mfma_f32_16x16x32_bf16 burn sustains on this chip with random operands at
+        # the clock it then holds (2.04 GHz) — tools/probes/mfma_peak.hip, profiles/r01f_mfma_sustained_peak.txt.  `peak` / `frac`
+        # above stay priced against the guide's 2.4 GHz figure.
+        roofline["peak_sustained_measured"] = 2114.0
+        roofline["frac_of_sustained"] = round(achieved / 2114.0, 4)
+    # HBM-side traffic of the dominant kernel from the committed PMC passes of this same command (tools/gpu_evidence.sh:
+    # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH doubled per MI355X_MICROARCH.md; PMC cannot be sampled
+    # from inside this process).  Bytes per launch, averaged over the GEMM launches like `achieved`.
+    for rnd in ("r02", "r01"):
+        tpath = os.path.join(ROOT, "profiles", f"{rnd}_traffic_{workload_name}_{precision}.json")
+        if not os.path.isfile(tpath):
+            continue
+        try:
+            with open(tpath) as f:
+                tj = json.load(f)
+            fam = "gemm_fp8_kernel" if precision == "fp8" else "gemm_nt_kernel"
+            rows = [v for k, v in tj.items() if k.startswith(fam) or k.startswith("gemm_big_kernel")]
+            n_l = sum(v["launches"] for v in rows)
+            if n_l:
+                roofline["traffic"] = round(sum(v["launches"] * (v["read_bytes"] + v["write_bytes"]) for v in rows) / n_l, 1)
+                roofline["traffic_unit"] = "bytes/launch (fabric-side reads incl. Infinity-Cache hits + writes)"
+                roofline["traffic_source"] = os.path.relpath(tpath, ROOT)
+                break
+        except (OSError, ValueError, KeyError):
+            pass
+    return roofline
+
+
+# ---- end-to-end vectorise() from host memory (SURVEY.md §8d: wall time includes preprocessing + H2D + towers + D2H) -------------------
+def e2e_vectorise(dev, images_cpu_u8, tower_only_rate, reps=6):
+    """the SAME images as the headline step, but handed over from HOST memory through the product API (random-init weights via
+    MARQO_AMD_SYNTHETIC_WEIGHTS, the registry name of the headline model)"""
+    from PIL import Image
+    os.environ["MARQO_AMD_SYNTHETIC_WEIGHTS"] = "1"
+    os.environ.setdefault("MARQO_MAX_CUDA_MODEL_MEMORY", "64")
+    from marqo_amd.s2_inference import s2_inference as s2
+    from marqo_amd.s2_inference.enums import Modality
+    name = "open_clip/ViT-B-32/laion2b_s34b_b79k"
+    n = images_cpu_u8.shape[0]
+    arrs = [images_cpu_u8[i].numpy() for i in range(n)]
+    pil = [Image.fromarray(a) for a in arrs]
+    model, pre = s2.load_multimodal_model_and_get_preprocessors(name, None, dev)
+    dev_tensors = [pre["image"](p) for p in pil]        # what add_documents' download threads hand over (add_docs.py:130-134)
+    torch.cuda.synchronize()
+
+    def rate(fn, reps=reps):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return n * reps / (time.perf_counter() - t0)
+
+    kw = dict(device=dev, modality=Modality.IMAGE)
+    out = {"n_images": n, "model": name, "unit": "embeddings/s",
+           "note": "one synchronous vectorise_ndarray() call per 256 images: host pack -> pinned H2D -> K10 resize -> tower -> D2H"}
+    out["ndarray_from_pil"] = round(rate(lambda: s2.vectorise_ndarray(name, pil, **kw)), 1)
+    out["ndarray_from_u8_arrays"] = round(rate(lambda: s2.vectorise_ndarray(name, arrs, **kw)), 1)
+    out["ndarray_from_device_tensors"] = round(rate(lambda: s2.vectorise_ndarray(name, dev_tensors, **kw)), 1)
+    out["list_from_pil"] = round(rate(lambda: s2.vectorise(name, pil, **kw)), 1)
+    emb = s2.vectorise_ndarray(name, pil, **kw)
+    t0 = time.perf_counter()
+    for _ in range(20):
+        s2._convert_vectorized_output(emb)
+    out["tolist_ms_per_call"] = round((time.perf_counter() - t0) / 20 * 1e3, 3)
+    # the reference serves up to 8 indexing threads (api/configs.py:27): 4 concurrent callers, each its own 256-image requests
+    def concurrent(content, threads=4, reps=4):
+        def worker():
+            for _ in range(reps):
+                s2.vectorise_ndarray(name, content, **kw)
+        s2.vectorise_ndarray(name, content, **kw)
+        torch.cuda.synchronize()
+        ts = [threading.Thread(target=worker) for _ in range(threads)]
+        t0 = time.perf_counter()
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        torch.cuda.synchronize()
+        return n * reps * threads / (time.perf_counter() - t0)
+    out["ndarray_from_u8_arrays_4_callers"] = round(concurrent(arrs), 1)
+    out["ndarray_from_device_tensors_4_callers"] = round(concurrent(dev_tensors), 1)
+    out["ndarray_from_pil_4_callers"] = round(concurrent(pil), 1)
+    out["tower_only"] = round(tower_only_rate, 1)
+    best = max(out["ndarray_from_u8_arrays_4_callers"], out["ndarray_from_device_tensors_4_callers"], out["ndarray_from_u8_arrays"],
+               out["ndarray_from_device_tensors"])
+    out["best_e2e_over_tower_only"] = round(best / tower_only_rate, 3)
+    s2.clear_loaded_models()
+    return out
+
+
+# ---- BASELINE configs[3] in miniature ------------------------------------------------------------------------------------------------
+def run_ingest(args, dev, rank, world, dist):
+    from PIL import Image
+    os.environ["MARQO_AMD_SYNTHETIC_WEIGHTS"] = "1"
+    os.environ.setdefault("MARQO_MAX_CUDA_MODEL_MEMORY", "64")
+    from marqo_amd.engine import archs
+    from marqo_amd.ingest import BulkVectoriser
+    from marqo_amd.s2_inference import s2_inference as s2
+    from marqo_amd.s2_inference.enums import Modality
+    wl = WORKLOADS["add_documents_mixed"]
+    docs = args.batch or wl["batch"]
+    name = "open_clip/ViT-B-32/laion2b_s34b_b79k"
+    varch, tarch = archs.resolve_open_clip("ViT-B-32")
+    rng = np.random.default_rng(7)     # every rank builds the same request (in production: the same request broadcast by the API layer)
+    imgs = [Image.fromarray(rng.integers(0, 256, (224, 224, 3), dtype=np.uint8)) for _ in range(docs)]
+    words = ["alpha", "beta", "gamma", "delta", "marqo", "tensor", "search", "image", "text", "vector"]
+    texts = [" ".join(words[int(j) % 10] for j in rng.integers(0, 10, int(rng.integers(3, 60)))) + f" {i}" for i in range(docs)]
+    bv = BulkVectoriser(name, dev)
+
+    def step():
+        for i in range(docs):
+            bv.add((i, "t"), texts[i])
+            bv.add((i, "i"), imgs[i], Modality.IMAGE)
+        return bv.flush()
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    elapsed, out = timed(step, args.steps, args.warmup, fence)
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert len(out) == 2 * docs
+    n_emb = 2 * docs
+    value = n_emb * args.steps / elapsed
+    gf = (varch.gflop_per_image + tarch.gflop_per_text(30)) / 2
+    result = {
+        "metric": "embeddings/sec", "value": round(value, 1), "unit": "embeddings/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": args.precision, "data": "synthetic",
+        "config": {"workload": wl["desc"], "global_batch": n_emb, "docs_per_request": docs,
+                   "parallelism": f"dp{world} (replicated weights; texts sharded by token estimate, images contiguously; ONE RCCL all_gather per modality from HBM; "
+                                  f"every rank returns the request's embeddings in order)",
+                   "weights": "random-init (seed 0) ViT-B-32", "gflop_per_embedding": round(gf, 3)},
+        "roofline": None, "cpu_baseline": None,
+        "note": "end-to-end through the Python boundary (host PIL -> uint8 pack -> H2D -> K10 -> towers -> gather -> D2H -> per-key rows); "
+                "the request (total work) is fixed, ranks split it: strong scaling",
+    }
+    if rank == 0:
+        print(json.dumps(result), flush=True)
 
 
 def main():
@@ -123,82 +451,21 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
 
     from marqo_amd import _lib as L
-    from marqo_amd.engine import archs, synthetic, towers
     from marqo_amd.parallel import gather_embeddings
-
-    wl = WORKLOADS[args.workload]
-    batch = args.batch or wl["batch"]
-    kind = wl["kind"]
     lib = L.load()
-    g = torch.Generator().manual_seed(1234 + rank)
-    varch = tarch = barch = None
-    if kind in ("image", "clip_text", "mixed"):
-        varch, tarch = archs.resolve_open_clip(wl["arch"])
 
-    def clip_ids(n, lo, hi):
-        ids = torch.zeros(n, 77, dtype=torch.int64)
-        lens = torch.randint(lo, hi + 1, (n,), generator=g)
-        for i in range(n):
-            li = int(lens[i])
-            ids[i, 0] = 49406
-            ids[i, 1:1 + li] = torch.randint(1, 49406, (li,), generator=g)
-            ids[i, 1 + li] = 49407
-        return ids
+    if WORKLOADS[args.workload]["kind"] == "ingest":
+        run_ingest(args, dev, rank, world, dist)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
-    towers_used, images, images_cpu, sd = [], None, None, None
-    if kind == "image":
-        sd = synthetic.random_open_clip_state_dict(vision=varch, seed=0)
-        tower = towers.VitTower(varch, sd, dev, precision=args.precision)
-        images_cpu = torch.randint(0, 256, (batch, varch.image_size, varch.image_size, 3), generator=g, dtype=torch.uint8)
-        images = images_cpu.to(dev)
-        towers_used = [tower]
-        gflop_per_emb = varch.gflop_per_image
-        run_local = lambda: tower.encode_u8(images)
-    elif kind == "clip_text":
-        sd = synthetic.random_open_clip_state_dict(text=tarch, seed=0)
-        tower = towers.ClipTextTower(tarch, sd, dev, precision=args.precision)
-        towers_used = [tower]
-        gflop_per_emb = tarch.gflop_per_text(tarch.ctx)
-        # ids resident in HBM like the images (what the device tokeniser hands over); only the n lengths live on the host
-        if tarch.causal:
-            ids = clip_ids(batch, 75, 75)
-            d_ids, lens = ids.to(torch.int32).to(dev), ids.argmax(1) + 1
-        else:  # SigLIP: every text is ctx positions (pieces ... </s> then </s> padding), all of them run
-            ids = torch.ones(batch, tarch.ctx, dtype=torch.int64)
-            ids[:, :20] = torch.randint(2, tarch.vocab, (batch, 20), generator=g)
-            d_ids, lens = ids.to(torch.int32).to(dev), torch.full((batch,), tarch.ctx, dtype=torch.int64)
-        run_local = lambda: tower.encode_device(d_ids, lens)
-    elif kind == "bert":
-        barch = archs.HF_BERT_ARCHS[wl["arch"]]
-        sd = synthetic.random_bert_state_dict(barch, seed=0)
-        tower = towers.BertTower(barch, sd, dev, precision=args.precision)
-        ids = torch.randint(1000, barch.vocab, (batch, 77), generator=g)
-        ids[:, 0], ids[:, -1] = 101, 102
-        towers_used = [tower]
-        gflop_per_emb = barch.gflop_per_text(77)
-        d_ids, lens = ids.to(torch.int32).to(dev), torch.full((batch,), 77, dtype=torch.int64)
-        run_local = lambda: tower.encode_device(d_ids, lens)
-    else:  # mixed: half images, half texts of ragged length through the two towers of one model
-        sd = synthetic.random_open_clip_state_dict(vision=varch, text=tarch, seed=0)
-        vt = towers.VitTower(varch, sd, dev, precision=args.precision)
-        tt = towers.ClipTextTower(tarch, sd, dev, precision=args.precision)
-        n_img = batch // 2
-        images_cpu = torch.randint(0, 256, (n_img, varch.image_size, varch.image_size, 3), generator=g, dtype=torch.uint8)
-        images = images_cpu.to(dev)
-        ids = clip_ids(batch - n_img, 5, 75)
-        towers_used = [vt, tt]
-        d_ids, lens = ids.to(torch.int32).to(dev), ids.argmax(1) + 1
-        mean_tokens = float((ids.argmax(1) + 1).float().mean())
-        gflop_per_emb = (n_img * varch.gflop_per_image + (batch - n_img) * tarch.gflop_per_text(int(round(mean_tokens)))) / batch
-        run_local = lambda: torch.cat([vt.encode_u8(images), tt.encode_device(d_ids, lens)], dim=0)
-    tower = towers_used[0]
-
-    if args.precision == "fp8":
-        for t in towers_used:
-            t.calibrate_fp8(run_local)  # static activation scales, outside the timed region
+    w = Workload(args.workload, args.precision, args.batch, dev, 1234 + rank)
+    batch, kind, wl = w.batch, w.kind, w.wl
 
     def step():
-        emb = run_local()                      # [batch, D] fp32 on device
+        emb = w.run()                          # [batch, D] fp32 on device
         if world > 1:
             emb = gather_embeddings(emb)       # RCCL all_gather of the shards (final concat)
         return emb
@@ -208,14 +475,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    fence()
-    elapsed = time.perf_counter() - t0
+    elapsed, out = timed(step, args.steps, args.warmup, fence)
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -223,81 +483,60 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = batch * world * args.steps / elapsed
 
-    # ---- roofline of the dominant kernel, HIP events on the launch stream (separate, instrumented steps) ----
-    lib.mq_profile_enable(1)
-    prof_steps = min(args.steps, 10)
-    for _ in range(prof_steps):
-        run_local()
-    ms = (C.c_double * L.MQ_PROF_FAMILIES)()
-    cnt = (C.c_int64 * L.MQ_PROF_FAMILIES)()
-    flops = C.c_double(0.0)
-    L.check(lib.mq_profile_collect(ms, cnt, C.byref(flops)), "mq_profile_collect")
-    lib.mq_profile_enable(0)
-    gemm_ms, gemm_launches = ms[0], cnt[0]
-    achieved = flops.value / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-    peak = FP8_DENSE_PEAK_TFLOPS if args.precision == "fp8" else BF16_DENSE_PEAK_TFLOPS
-    families = {L.PROF_FAMILY_NAMES[i]: {"ms_per_step": ms[i] / prof_steps, "launches_per_step": cnt[i] // prof_steps}
-                for i in range(L.MQ_PROF_FAMILIES) if cnt[i]}
-    roofline = {
-        "kernel": ("gemm_fp8_kernel (e4m3 MFMA 16x16x128 unit-scale MX, (32*MT)x128x128 tiles, fused epilogues)" if args.precision == "fp8"
-                   else "gemm_nt_kernel (bf16 MFMA 16x16x32, (32*MT)x128x64 tiles, fused epilogues)"),
-        "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-        "frac": round(achieved / peak, 4), "traffic": None,
-        "flops_per_launch": flops.value / max(gemm_launches, 1),
-        "avg_launch_us": gemm_ms * 1e3 / max(gemm_launches, 1),
-        "launches_per_step": gemm_launches // prof_steps,
-        "per_family": families,
-    }
-    if args.precision == "bf16":
-        # informational: what a register-resident v_mfma_f32_16x16x32_bf16 burn sustains on this chip with random operands at
-        # the clock it then holds (2.04 GHz) — tools/probes/mfma_peak.hip, profiles/r01f_mfma_sustained_peak.txt.  `peak` / `frac`
-        # above stay priced against the guide's 2.4 GHz figure.
-        roofline["peak_sustained_measured"] = 2114.0
-        roofline["frac_of_sustained"] = round(achieved / 2114.0, 4)
-    # HBM-side traffic of the dominant kernel from the committed PMC passes of this same command (tools/gpu_evidence.sh:
-    # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH doubled per MI355X_MICROARCH.md; PMC cannot be sampled
-    # from inside this process).  Bytes per launch, averaged over the GEMM launches like `achieved`.
-    tpath = os.path.join(ROOT, "profiles", f"r01_traffic_{args.workload}_{args.precision}.json")
-    if os.path.isfile(tpath):
-        try:
-            with open(tpath) as f:
-                tj = json.load(f)
-            fam = "gemm_fp8_kernel" if args.precision == "fp8" else "gemm_nt_kernel"
-            rows = [v for k, v in tj.items() if k.startswith(fam) or k.startswith("gemm_big_kernel")]
-            n_l = sum(v["launches"] for v in rows)
-            if n_l:
-                roofline["traffic"] = round(sum(v["launches"] * (v["read_bytes"] + v["write_bytes"]) for v in rows) / n_l, 1)
-                roofline["traffic_unit"] = "bytes/launch (fabric-side reads incl. Infinity-Cache hits + writes)"
-                roofline["traffic_source"] = os.path.relpath(tpath, ROOT)
-        except (OSError, ValueError, KeyError):
-            pass
-    e2e_tflops = value * gflop_per_emb / 1e3
+    roofline = gemm_roofline(lib, L, w.run, min(args.steps, 10), args.precision, args.workload)
+    peak = roofline["peak"]
+    e2e_tflops = value * w.gflop_per_emb / 1e3
     result = {
         "metric": "embeddings/sec", "value": round(value, 1), "unit": "embeddings/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
         "config": {"workload": wl["desc"], "global_batch": batch * world,
-                   "gflop_per_embedding": round(gflop_per_emb, 3),
+                   "inputs": "resident in HBM when the timed region starts (tower-only); host-resident hand-over is reported under e2e_vectorise",
+                   "gflop_per_embedding": round(w.gflop_per_emb, 3),
                    "parallelism": f"dp{world} (replicated weights, sharded items, RCCL all_gather of embeddings)",
                    "weights": "random-init (seed 0) " + wl["arch"],
                    # transparency: the towers run the out-projection / MLP of the LAST block only on the pooled rows (class token /
                    # EOT): dead-row elimination with bit-identical embeddings (tests/test_towers_gpu.py::test_row_selected_*), 5.8 % of
                    # ViT-B/32's GEMM FLOPs.  e2e_tflops counts the full algorithmic FLOPs per embedding;
                    # roofline.achieved counts only the FLOPs of the GEMMs actually launched.  MQ_ROW_SELECT=0 runs every row.
-                   "last_block_rows": "pooled" if os.environ.get("MQ_ROW_SELECT", "1") != "0" and kind != "bert" else "all"},
+                   "last_block_rows": "pooled" if os.environ.get("MQ_ROW_SELECT", "1") != "0" and kind != "bert" else "all",
+                   **({"fp8_policy": w.fp8_policy} if w.fp8_policy else {})},
         "e2e_tflops": round(e2e_tflops, 1), "e2e_frac_of_peak": round(e2e_tflops / (peak * world), 4),
         "roofline": roofline,
     }
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and kind == "image":
-        cpu_rate, n_cpu, cpu_emb, cores, host_threads = cpu_baseline(sd, varch, images_cpu, args.cpu_seconds)
-        gpu_emb = out[:n_cpu].float().cpu()
-        cos = (gpu_emb.double() * cpu_emb.double()).sum(-1) / (gpu_emb.double().norm(dim=-1) * cpu_emb.double().norm(dim=-1))
-        result["cpu_baseline"] = {"value": round(cpu_rate, 2), "unit": "embeddings/s", "cores": cores, "kind": "port",
-                                  "sample": f"{n_cpu} of the step's {batch} images, fp32 PyTorch eager, 16-image batches "
-                                            f"(reference loop s2_inference.py:135-146), {cores} of {host_threads} host threads "
-                                            f"(best of a 16/32/64/128/all ladder)"}
-        result["cos_err_vs_cpu"] = float((1 - cos).max())
+    solo = rank == 0 and world == 1
+    if solo and not args.no_cpu_baseline:
+        base, cos = w.cpu_baseline(out, args.cpu_seconds)
+        if base is not None:
+            result["cpu_baseline"] = base
+            result["cos_err_vs_cpu"] = cos
+    if solo and not args.no_extras and args.workload == "vit_b32_image" and args.precision == "bf16":
+        try:
+            result["e2e_vectorise"] = e2e_vectorise(dev, w.images_cpu, value)
+        except Exception as e:  # noqa: BLE001 - never lose the headline line to an extras failure
+            result["e2e_vectorise"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        also = []
+        del w
+        torch.cuda.empty_cache()
+        for name in ALSO_DEFAULT:
+            try:
+                x = Workload(name, args.precision, 0, dev, 1234)
+                el, o = timed(x.run, 10, 3, torch.cuda.synchronize)
+                v = x.batch * 10 / el
+                rf = gemm_roofline(lib, L, x.run, 5, args.precision, name)
+                row = {"workload": WORKLOADS[name]["desc"], "value": round(v, 1), "unit": "embeddings/s", "ms_per_step": round(el / 10 * 1e3, 4),
+                       "steps": 10, "warmup": 3, "gflop_per_embedding": round(x.gflop_per_emb, 3),
+                       "e2e_tflops": round(v * x.gflop_per_emb / 1e3, 1), "gemm_tflops": rf["achieved"], "gemm_frac": rf["frac"]}
+                if not args.no_cpu_baseline:
+                    base, cos = x.cpu_baseline(o, 8.0)
+                    row["cpu_baseline"], row["cos_err_vs_cpu"] = base, cos
+                also.append(row)
+                del x
+                torch.cuda.empty_cache()
+            except Exception as e:  # noqa: BLE001
+                also.append({"workload": name, "error": f"{type(e).__name__}: {e}"[:300]})
+        result["also"] = also
     if rank == 0:
         print(json.dumps(result), flush=True)
     if dist is not None:

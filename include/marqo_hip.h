@@ -109,6 +109,11 @@ typedef struct mq_encoder_cfg {
     int32_t precision;  /* MQ_PREC_BF16 (0) or MQ_PREC_FP8 (width and mlp_dim multiples of 128) */
     int32_t attn_width; /* 0 = width.  heads * {64, 96, 112, 128} when the checkpoint's heads are narrower and were zero-padded at load
                          * (QKV weights [3*attn_width, W], out-projection [W, attn_width]) */
+    int32_t fp8_first_layer; /* MQ_PREC_FP8: blocks [0, fp8_first_layer) run their GEMMs on bf16 operands, blocks from here on on e4m3.
+                              * Quantisation noise injected in EARLY blocks is amplified by every later one (measured: the first 12 of
+                              * ViT-L/14's 24 blocks cost 2-7x the cosine error of the last 12), so the loaders pick the smallest value
+                              * that keeps the calibrated error inside the budget (engine/towers.py::tune_fp8); 0 = every block fp8 */
+    int32_t reserved0;
     /* fp8 path: static per-tensor activation scales, device fp32 [layers][2] = (attention output, MLP hidden), and the
      * calibration accumulator of the same shape (NULL = frozen scales; non-NULL = fold max|value| of this pass into it) */
     const float* d_fp8_act_scale;

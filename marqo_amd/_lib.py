@@ -56,7 +56,8 @@ class BlockWeights(C.Structure):
 class EncoderCfg(C.Structure):
     _fields_ = [("width", C.c_int32), ("layers", C.c_int32), ("heads", C.c_int32), ("mlp_dim", C.c_int32),
                 ("act", C.c_int32), ("post_ln", C.c_int32), ("mask", C.c_int32), ("ln_eps", C.c_float),
-                ("precision", C.c_int32), ("attn_width", C.c_int32), ("d_fp8_act_scale", C.c_void_p), ("d_fp8_act_amax", C.c_void_p)]
+                ("precision", C.c_int32), ("attn_width", C.c_int32), ("fp8_first_layer", C.c_int32), ("reserved0", C.c_int32),
+                ("d_fp8_act_scale", C.c_void_p), ("d_fp8_act_amax", C.c_void_p)]
 
 
 class MapHead(C.Structure):

@@ -26,8 +26,8 @@ extern "C" int mq_rowquant_fp8(const float* d_x, void* d_out_fp8, float* d_row_s
 
 // layouts the ctypes binding (marqo_amd/_lib.py) and tests/test_abi.py assume
 static_assert(sizeof(mq_block_weights) == 26 * 8, "mq_block_weights layout");
-static_assert(sizeof(mq_encoder_cfg) == 56, "mq_encoder_cfg layout");
-static_assert(sizeof(mq_vit_cfg) == 104 && sizeof(mq_clip_text_cfg) == 72 && sizeof(mq_bert_cfg) == 72, "tower cfg layouts");
+static_assert(sizeof(mq_encoder_cfg) == 64, "mq_encoder_cfg layout");
+static_assert(sizeof(mq_vit_cfg) == 112 && sizeof(mq_clip_text_cfg) == 80 && sizeof(mq_bert_cfg) == 80, "tower cfg layouts");
 static_assert(sizeof(mq_vit_weights) == 10 * 8 && sizeof(mq_map_head) == 11 * 8 && sizeof(mq_clip_text_weights) == 7 * 8, "tower weight layouts");
 
 // mq_tune("row_select", 0) runs the last block on every row (A/B and parity tests of the pooled-rows-only last block)
@@ -69,6 +69,7 @@ int check_encoder_cfg(const mq_encoder_cfg* c) {
     if (c->precision == MQ_PREC_FP8) {
         MQ_CHECK_ARG(c->width % 128 == 0 && c->mlp_dim % 128 == 0 && wa % 128 == 0, "fp8 path needs width / mlp_dim multiples of 128");
         MQ_CHECK_ARG(c->d_fp8_act_scale, "fp8 path needs d_fp8_act_scale");
+        MQ_CHECK_ARG(c->fp8_first_layer >= 0, "fp8_first_layer < 0");
     }
     return MQ_OK;
 }
@@ -113,11 +114,11 @@ namespace {
 int last_block_selected(const mq_encoder_cfg* cfg, const mq_block_weights& b, int l, float* d_x, int64_t rows,
                         const int32_t* d_cu_seqlens, int64_t nseq, int32_t fixed_len, int32_t max_len,
                         const int32_t* d_sel, int64_t nsel, void* h, void* a, void* qf, float* row_scale, float* x_sel,
-                        float* stats /* non-NULL: h holds bf16(x) and stats its LayerNorm partials (folded path) */, hipStream_t s) {
+                        float* stats /* non-NULL: h holds bf16(x) and stats its LayerNorm partials (folded path) */, bool f8, hipStream_t s) {
     const int W = cfg->width, F = cfg->mlp_dim, Wa = attn_width(cfg);
     const int act_flag = cfg->act == MQ_ACT_QUICKGELU ? MQ_EPI_QUICKGELU : MQ_EPI_GELU;
     const int res_flags = MQ_EPI_BIAS | MQ_EPI_RESIDUAL | MQ_EPI_OUT_F32;
-    if (cfg->precision == MQ_PREC_FP8) {
+    if (f8) {
         const float* s_attn = cfg->d_fp8_act_scale + 2 * l;
         const float* s_mlp = s_attn + 1;
         const int act8 = act_flag | MQ_EPI_BIAS | MQ_EPI_OUT_FP8;
@@ -198,19 +199,25 @@ int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* bloc
                              !(cfg->precision == MQ_PREC_FP8 && (cfg->d_fp8_act_amax || cfg->post_ln)) &&
                              xsel_off + (size_t)nsel * W * 4 <= (size_t)rows * big * 2;
 
+    // mixed precision: blocks [0, first8) on bf16 operands, [first8, layers) on e4m3 (mq_encoder_cfg.fp8_first_layer)
+    const int first8 = cfg->precision == MQ_PREC_FP8 ? (cfg->fp8_first_layer < cfg->layers ? cfg->fp8_first_layer : cfg->layers) : cfg->layers;
+
     // block input as GEMM operand (post-LN: afterwards every LayerNorm leaves it behind)
-    if (cfg->post_ln && cfg->precision == MQ_PREC_FP8) MQ_TRY(mq_rowquant_fp8(d_x, h, row_scale, rows, W, s));
+    if (cfg->post_ln && first8 == 0) MQ_TRY(mq_rowquant_fp8(d_x, h, row_scale, rows, W, s));
     else if (cfg->post_ln) MQ_TRY(mq_cast_bf16(d_x, h, rows * W, s));
 
     for (int l = 0; l < cfg->layers; ++l) {
         const mq_block_weights& b = blocks[l];
+        const bool f8 = l >= first8;
         MQ_CHECK_ARG(b.qkv_w && b.out_w && b.fc1_w && b.fc2_w && b.ln1_g && b.ln2_g, "mq_encoder_forward: layer %d has null weights", l);
-        if (cfg->precision == MQ_PREC_FP8)
+        if (f8)
             MQ_CHECK_ARG(b.qkv_w8 && b.qkv_ws && b.out_w8 && b.out_ws && b.fc1_w8 && b.fc1_ws && b.fc2_w8 && b.fc2_ws,
                          "mq_encoder_forward: layer %d has no fp8 weights", l);
+        // post-LN: the previous (bf16) block left its output as a bf16 operand; the first e4m3 block wants e4m3 rows + row scales
+        if (cfg->post_ln && f8 && l == first8 && l > 0) MQ_TRY(mq_rowquant_fp8(d_x, h, row_scale, rows, W, s));
         if (select_last && l == cfg->layers - 1) {
             MQ_TRY(last_block_selected(cfg, b, l, d_x, rows, d_cu_seqlens, nseq, fixed_len, max_len, d_sel, nsel, h, a, qf, row_scale,
-                                       (float*)((char*)qf + xsel_off), folded ? ln_stats : nullptr, s));
+                                       (float*)((char*)qf + xsel_off), folded ? ln_stats : nullptr, f8, s));
             break;
         }
         if (fold) {
@@ -231,7 +238,7 @@ int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* bloc
             folded = true;
             continue;
         }
-        if (cfg->precision == MQ_PREC_FP8) {
+        if (f8) {
             // same dataflow with e4m3 GEMM operands: h / a / fc1-out are fp8 (h with a dynamic per-row scale from the LN,
             // a and fc1-out with static per-tensor scales), qkv stays bf16 for the attention MFMAs, x stays fp32
             const float* s_attn = cfg->d_fp8_act_scale + 2 * l;

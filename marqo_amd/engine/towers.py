@@ -133,7 +133,7 @@ def _encoder_cfg(width, layers, heads, mlp_dim, quick_gelu, post_ln, mask, eps) 
     return L.EncoderCfg(width=width, layers=layers, heads=heads, mlp_dim=mlp_dim,
                         act=L.MQ_ACT_QUICKGELU if quick_gelu else L.MQ_ACT_GELU,
                         post_ln=1 if post_ln else 0, mask=mask, ln_eps=eps, precision=L.MQ_PREC_BF16,
-                        attn_width=0 if d == hp else heads * hp, d_fp8_act_scale=None, d_fp8_act_amax=None)
+                        attn_width=0 if d == hp else heads * hp, fp8_first_layer=0, reserved0=0, d_fp8_act_scale=None, d_fp8_act_amax=None)
 
 
 class _Fp8State:
@@ -239,10 +239,72 @@ class _GraphedCall:
         with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             launch()
 
+        self._last: Optional[torch.cuda.Event] = None
+
     def __call__(self, src: Tensor) -> Tensor:
+        """(called under the tower's lock) callers may sit on different streams: order this use of the static buffers behind the
+        previous one on the GPU, not just on the host"""
+        cur = torch.cuda.current_stream(self.inp.device)
+        if self._last is not None:
+            cur.wait_event(self._last)
         self.inp.copy_(src, non_blocking=True)
         self.graph.replay()
-        return self.out.clone()                    # the static output is overwritten by the next replay
+        out = self.out.clone()                     # the static output is overwritten by the next replay
+        self._last = torch.cuda.Event()
+        self._last.record(cur)
+        return out
+
+
+# Every request thread enqueues on its own HIP stream (MARQO_AMD_THREAD_STREAMS=0: the caller's current stream), so that one
+# request's pinned H2D copy / host packing overlaps another request's kernels instead of queueing behind them on the shared
+# default stream.
+THREAD_STREAMS = os.environ.get("MARQO_AMD_THREAD_STREAMS", "1") != "0"
+_request_tls = threading.local()
+
+
+class request_stream:
+    """`with request_stream(device, device_output):` — run the body on the calling thread's private stream.  Inputs produced on the
+    caller's current stream are ordered before it; outputs are handed back either synchronised (the loaders' D2H copy) or, for
+    device-resident results (`device_output=True`), ordered before the caller's stream continues."""
+
+    def __init__(self, device, device_output: bool = False):
+        self.device = torch.device(device) if not isinstance(device, torch.device) else device
+        self.device_output = device_output
+        self._ctx = None
+
+    def __enter__(self):
+        if not THREAD_STREAMS or not torch.cuda.is_available() or self.device.type != "cuda":
+            return self
+        streams = getattr(_request_tls, "streams", None)
+        if streams is None:
+            streams = _request_tls.streams = {}
+        if getattr(_request_tls, "depth", 0):      # nested (encode_image inside encode): already on the private stream
+            _request_tls.depth += 1
+            self._nested = True
+            return self
+        self._nested = False
+        key = (self.device.type, self.device.index if self.device.index is not None else torch.cuda.current_device())
+        s = streams.get(key)
+        if s is None:
+            s = streams[key] = torch.cuda.Stream(torch.device(*key))
+        self._outer = torch.cuda.current_stream(torch.device(*key))
+        s.wait_stream(self._outer)
+        self._s = s
+        self._ctx = torch.cuda.stream(s)
+        self._ctx.__enter__()
+        _request_tls.depth = 1
+        return self
+
+    def __exit__(self, *exc):
+        if getattr(self, "_nested", False):
+            _request_tls.depth -= 1
+            return False
+        if self._ctx is not None:
+            self._ctx.__exit__(*exc)
+            _request_tls.depth = 0
+            if self.device_output:
+                self._outer.wait_stream(self._s)
+        return False
 
 
 class _TowerBase:
@@ -270,12 +332,72 @@ class _TowerBase:
         self._fp8.attach(self.cfg.enc, calibrating=False)
         self._fp8.calibrated = True
 
+    # ---- fp8 policy --------------------------------------------------------------------------------------------------------
+    # e4m3 operands carry ~2.6 % rms relative rounding noise each, whatever the scaling granularity (per tensor, per row or MX
+    # blocks: oracle/fp8_sim.py, tools/fp8_study.py -> profiles/r02_fp8_numerics_sim.txt): a GEMM output is ~3.7 % noise, a 24-block
+    # ViT-L/14 with every block on fp8 ends at 1 - cos = 2e-3 on benign weights and 5e-3 on trained-like ones — outside the 1e-3
+    # north-star tolerance.  Noise injected in early blocks is amplified by all later ones, so the policy keeps the FIRST blocks on
+    # bf16 operands and runs the LAST ones on fp8: `tune_fp8` measures, on a fixed seeded calibration batch at load, the error of
+    # each split against the tower's own bf16 output and keeps the most fp8 blocks that stay inside the budget.
+    FP8_BUDGET = float(os.environ.get("MARQO_AMD_FP8_BUDGET", "7e-4"))   # max (1 - cos) vs the tower's own bf16 output
+    FP8_SCALE_MARGIN = 2.0   # static activation scales = calibration amax x margin / 448: one binade of head-room for unseen inputs
+    fp8_first_layer: int = 0
+    fp8_calibration_error: Optional[float] = None
+    fp8_all_blocks_error: Optional[float] = None
+
+    def tune_fp8(self, run, budget: Optional[float] = None, margin: Optional[float] = None) -> int:
+        """Deterministic load-time calibration of an fp8 tower on the caller's fixed calibration batch (`run()` pushes it through this
+        tower and returns the [n, D] embeddings): (1) static activation scales from two recording passes with every block on fp8,
+        x `margin`; (2) the split `fp8_first_layer` = the smallest first fp8 block whose max (1 - cos) against the bf16 run of the same
+        batch is <= budget (binary search: the error grows as the split moves towards block 0).  Returns the split."""
+        if self._fp8 is None:
+            raise RuntimeError("tower was not built with precision='fp8'")
+        budget = self.FP8_BUDGET if budget is None else float(budget)
+        enc, layers = self.cfg.enc, self.cfg.enc.layers
+        enc.fp8_first_layer = 0
+        self.calibrate_fp8(run, passes=2, margin=self.FP8_SCALE_MARGIN if margin is None else margin)
+        self._fp8.calibrated = False           # no graph capture while the split is being searched
+        enc.precision = L.MQ_PREC_BF16
+        ref = run().double()
+        enc.precision = L.MQ_PREC_FP8
+
+        def err(first: int) -> float:
+            enc.fp8_first_layer = first
+            out = run().double()
+            cos = (out * ref).sum(-1) / (out.norm(dim=-1) * ref.norm(dim=-1))
+            return float((1 - cos).max())
+        e0 = err(0)
+        self.fp8_all_blocks_error = e0
+        if e0 <= budget:
+            first, e = 0, e0
+        else:
+            lo, hi, e = 0, layers, 0.0          # err(lo) > budget, err(hi) <= budget (hi == layers: every block bf16)
+            while hi - lo > 1:
+                mid = (lo + hi) // 2
+                em = err(mid)
+                if em <= budget:
+                    hi, e = mid, em
+                else:
+                    lo = mid
+            first = hi
+        enc.fp8_first_layer = first
+        self.fp8_first_layer, self.fp8_calibration_error = first, e
+        self._fp8.calibrated = True
+        import logging
+        logging.getLogger(__name__).info("fp8 policy: blocks [%d, %d) on e4m3, 1 - cos vs bf16 on the calibration batch %.2e (all blocks: %.2e, "
+                                         "budget %.1e)", first, layers, e, e0, budget)
+        return first
+
     def __init__(self, device: str):
         self.device = _require_gpu(device)
         self.lib = L.load()
         self._h = _Holder(self.device)
-        self._ws: Optional[Tensor] = None
-        self._lock = threading.Lock()  # one workspace per tower: serialise concurrent FastAPI threads
+        # Concurrent callers (the reference serves 8 index + 8 search FastAPI threads, api/configs.py:27-28) do not serialise on the
+        # tower: every calling thread owns its scratch workspace (bump-allocated per call, a few hundred MB against 288 GB of HBM) and
+        # enqueues on ITS current stream, so one request's H2D / host work overlaps another's kernels.  Only the hipGraph cache
+        # (static buffers shared by all callers of one shape) stays behind the lock.
+        self._tls = threading.local()
+        self._lock = threading.Lock()
         self._graphs: Dict[tuple, "_GraphedCall"] = {}
         self._graphs_off = False
 
@@ -299,10 +421,15 @@ class _TowerBase:
         return g
 
     def _workspace(self, nbytes: int) -> Tensor:
-        if self._ws is None or self._ws.numel() < nbytes:
-            self._ws = None
-            self._ws = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=self.device)
-        return self._ws
+        """this thread's scratch buffer.  It is allocated on, and only ever used from, the stream the thread enqueues on; a thread
+        that switches streams between calls gets a fresh buffer (the old one returns to the caching allocator, which orders reuse)."""
+        ws = getattr(self._tls, "ws", None)
+        stream = torch.cuda.current_stream(self.device)
+        if ws is None or ws.numel() < nbytes or getattr(self._tls, "ws_stream", None) != stream:
+            self._tls.ws = None
+            ws = self._tls.ws = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=self.device)
+            self._tls.ws_stream = stream
+        return ws
 
     def _stream(self) -> int:
         return torch.cuda.current_stream(self.device).cuda_stream
@@ -416,7 +543,7 @@ class VitTower(_TowerBase):
                     done.record(st)
                     cur.wait_event(done)
             return out
-        with self._lock, torch.cuda.device(self.device):
+        with torch.cuda.device(self.device):
             for i in range(0, n, self.max_images_per_call):
                 m = min(self.max_images_per_call, n - i)
                 need = self.lib.mq_vit_workspace_bytes(C.byref(self.cfg), m)
@@ -424,6 +551,22 @@ class VitTower(_TowerBase):
                 L.check(fn(C.byref(self.cfg), C.byref(self.w), pixels[i:i + m].data_ptr(), m, out[i:i + m].data_ptr(),
                            1 if normalize else 0, ws.data_ptr(), ws.numel(), self._stream()), "mq_encode_image")
         return out
+
+    def calibration_images(self, n: int = 16, seed: int = 0) -> Tensor:
+        """the fixed, seeded calibration batch of the fp8 policy: half uniform pixel noise, half smooth low-frequency fields plus
+        mild noise (closer to the spectrum of photographs) — uint8 [n, S, S, 3] on the device.  The same for every load of a
+        checkpoint, so scales and block split are reproducible across restarts and replicas."""
+        S = self.arch.image_size
+        g = torch.Generator().manual_seed(1000 + seed)
+        noise = torch.randint(0, 256, (n - n // 2, S, S, 3), generator=g, dtype=torch.uint8)
+        coarse = torch.rand(n // 2, 3, 8, 8, generator=g)
+        smooth = torch.nn.functional.interpolate(coarse, size=(S, S), mode="bilinear", align_corners=False)
+        smooth = (smooth * 255 + 12 * torch.randn(smooth.shape, generator=g)).clamp(0, 255).permute(0, 2, 3, 1).to(torch.uint8)
+        return torch.cat([noise, smooth], dim=0).contiguous().to(self.device)
+
+    def tune_fp8_default(self, budget: Optional[float] = None) -> int:
+        u8 = self.calibration_images()
+        return self.tune_fp8(lambda: self.encode_u8(u8), budget=budget)
 
     def encode_u8(self, images_u8: Tensor, normalize: bool = True) -> Tensor:
         """uint8 [n, S, S, 3] (HWC RGB, on this device) -> fp32 [n, D] on device (async on the current stream)."""
@@ -517,7 +660,7 @@ class _TextTowerBase(_TowerBase):
                 return one
         out_dim = self.arch.out_dim if clip else self.arch.width
         out = torch.empty(n, out_dim, dtype=torch.float32, device=self.device)
-        with self._lock, torch.cuda.device(self.device):
+        with torch.cuda.device(self.device):
             for a, b in self._chunks(lengths):
                 cu = torch.zeros(b - a + 1, dtype=torch.int32)
                 cu[1:] = lengths[a:b].cumsum(0).to(torch.int32)
@@ -571,6 +714,29 @@ class ClipTextTower(_TextTowerBase):
         if precision == "fp8":
             self._enable_fp8(self._blocks, arch.layers, W, _ceil64(arch.mlp_dim))
 
+    def calibration_ids(self, n: int = 32, seed: int = 0) -> Tensor:
+        """fixed, seeded calibration texts of the fp8 policy: int64 [n, ctx] rows SOT, L random ids, EOT, zero padding with L spread
+        over 3 .. ctx - 2 (SigLIP towers: random ids then pad-id padding, all ctx positions run)"""
+        a = self.arch
+        g = torch.Generator().manual_seed(2000 + seed)
+        if not a.causal:
+            ids = torch.full((n, a.ctx), a.pad_id, dtype=torch.int64)
+            for i in range(n):
+                L_ = 3 + (i * (a.ctx - 4)) // max(n - 1, 1)
+                ids[i, :L_] = torch.randint(2, a.vocab, (L_,), generator=g)
+            return ids
+        ids = torch.zeros(n, a.ctx, dtype=torch.int64)
+        for i in range(n):
+            L_ = 3 + (i * (a.ctx - 5)) // max(n - 1, 1)
+            ids[i, 0] = a.vocab - 2
+            ids[i, 1:1 + L_] = torch.randint(1, a.vocab - 2, (L_,), generator=g)
+            ids[i, 1 + L_] = a.vocab - 1
+        return ids
+
+    def tune_fp8_default(self, budget: Optional[float] = None) -> int:
+        ids = self.calibration_ids()
+        return self.tune_fp8(lambda: self.encode_ids(ids), budget=budget)
+
     def encode_ids(self, ids: Tensor, normalize: bool = True, pack: bool = True) -> Tensor:
         """ids: int [n, ctx] zero-padded CLIP token ids (SOT ... EOT 0 0 ...), host or device.
         pack=True runs each sequence only up to its EOT (= argmax id, the pooled position): the later
@@ -593,7 +759,7 @@ class ClipTextTower(_TextTowerBase):
             if one is not None:
                 return one
         out = torch.empty(n, self.arch.out_dim, dtype=torch.float32, device=self.device)
-        with self._lock, torch.cuda.device(self.device):
+        with torch.cuda.device(self.device):
             for a, b in self._chunks(lengths):
                 packed, cu = _pack(ids_h[a:b], lengths[a:b])
                 pool_rows = None if pack else (cu[:-1].to(torch.int64) + eot[a:b]).to(torch.int32)
@@ -671,6 +837,25 @@ class BertTower(_TextTowerBase):
         if precision == "fp8":
             self._enable_fp8(self._blocks, arch.layers, W, F)
 
+    def calibration_batch(self, n: int = 32, seed: int = 0) -> Tuple[Tensor, Tensor]:
+        """fixed, seeded calibration texts of the fp8 policy: (ids, attention_mask) int64 [n, S], lengths spread over 4 .. min(128, max_pos)"""
+        a = self.arch
+        g = torch.Generator().manual_seed(3000 + seed)
+        S = min(128, a.max_pos)
+        ids = torch.zeros(n, S, dtype=torch.int64)
+        mask = torch.zeros(n, S, dtype=torch.int64)
+        lo = min(1000, a.vocab // 2)
+        for i in range(n):
+            L_ = 4 + (i * (S - 4)) // max(n - 1, 1)
+            ids[i, :L_] = torch.randint(lo, a.vocab, (L_,), generator=g)
+            ids[i, 0], ids[i, L_ - 1] = (101, 102) if a.vocab > 102 and a.pos_offset == 0 else (0, 2)
+            mask[i, :L_] = 1
+        return ids, mask
+
+    def tune_fp8_default(self, budget: Optional[float] = None) -> int:
+        ids, mask = self.calibration_batch()
+        return self.tune_fp8(lambda: self.encode_ids(ids, mask), budget=budget)
+
     def encode_ids(self, ids: Tensor, attention_mask: Tensor, normalize: bool = True) -> Tensor:
         """ids / attention_mask: int [n, S] as produced by the HF tokenizer call of the reference
         (hugging_face_model.py:179-185: padding=True, right-padded).  Only mask==1 tokens are run."""
@@ -692,7 +877,7 @@ class BertTower(_TextTowerBase):
             if one is not None:
                 return one
         out = torch.empty(n, self.arch.width, dtype=torch.float32, device=self.device)
-        with self._lock, torch.cuda.device(self.device):
+        with torch.cuda.device(self.device):
             for a, b in self._chunks(lengths):
                 packed, cu = _pack(ids_h[a:b], lengths[a:b])
                 d_ids = self._to_device(packed)

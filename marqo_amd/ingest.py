@@ -5,27 +5,36 @@ src/marqo/core/vespa_index/add_documents_handler.py:264-290 + tensor_fields_cont
 `vectorise` call, which starves any GPU.  `BulkVectoriser` is the PER_BATCH / cross-request form: callers `add()` chunks
 (text or image) tagged with an opaque key as they are produced by the chunkers / download threads, and `flush()` issues
 ONE `vectorise` call per (model, modality) for everything queued — the engine loaders then micro-batch on the device —
-and hands the embeddings back per key, in insertion order.  With `torch.distributed` initialised (one process per GPU)
-`flush()` shards the queue contiguously across ranks and all-gathers the embedding shards (the only collective on the
-path, marqo_amd.parallel), so every rank returns the full result.
+and hands the embeddings back per key, in insertion order.
+
+With `torch.distributed` initialised (one process per GPU) `flush()` shards each modality's queue across the ranks — images
+contiguously (equal cost after the resize), texts balanced by estimated token count (marqo_amd.parallel.balanced_shards) — every
+rank encodes its shard and keeps it IN HBM (`vectorise_device`), and ONE all_gather per modality (RCCL over xGMI) rebuilds the full
+[N, D] matrix in request order on every rank; the embedding width comes from the model properties, nothing else is exchanged.
 """
 from __future__ import annotations
 
 import threading
-from typing import Any, Dict, Hashable, List, Optional, Tuple
+from typing import Any, Callable, Dict, Hashable, List, Optional, Tuple
 
 import numpy as np
 
-from marqo_amd.parallel import shard_bounds
+from marqo_amd.parallel import balanced_shards, contiguous_shards, gather_embeddings
 from marqo_amd.s2_inference.enums import Modality
+
+
+def estimate_tokens(text: Any) -> float:
+    """cheap per-item cost for balancing text shards: ~ BPE / WordPiece tokens of a string (4 characters per token + the two
+    specials); anything that is not a string costs 1"""
+    return 2.0 + len(text) / 4.0 if isinstance(text, str) else 1.0
 
 
 class BulkVectoriser:
     def __init__(self, model_name: str, device: str, model_properties: Optional[dict] = None, normalize_embeddings: bool = True,
-                 max_pending: int = 0, vectorise_fn=None):
-        """max_pending > 0: `add()` flushes automatically once that many items are queued (bounded memory)."""
-        if vectorise_fn is None:
-            from marqo_amd.s2_inference.s2_inference import vectorise_ndarray as vectorise_fn
+                 max_pending: int = 0, vectorise_fn: Optional[Callable] = None):
+        """max_pending > 0: `add()` flushes automatically once that many items are queued (bounded memory).
+        vectorise_fn(model_name, contents, model_properties=, device=, normalize_embeddings=, modality=) -> [n, D] ndarray or
+        torch.Tensor; default: `vectorise_ndarray`, or `vectorise_device` when sharding over a cuda process group."""
         self._vectorise = vectorise_fn
         self.model_name, self.device, self.model_properties = model_name, device, model_properties
         self.normalize = normalize_embeddings
@@ -33,6 +42,7 @@ class BulkVectoriser:
         self._lock = threading.Lock()
         self._pending: Dict[Modality, List[Tuple[Hashable, Any]]] = {Modality.TEXT: [], Modality.IMAGE: []}
         self._done: Dict[Hashable, np.ndarray] = {}
+        self.force_collective = False   # tests: take the sharded path (and run the collective) even in a 1-rank process group
 
     def add(self, key: Hashable, content: Any, modality: Modality = Modality.TEXT) -> None:
         if modality not in self._pending:
@@ -47,37 +57,82 @@ class BulkVectoriser:
         with self._lock:
             return sum(len(v) for v in self._pending.values())
 
+    def _call(self, fn, contents, modality):
+        return fn(self.model_name, contents, model_properties=self.model_properties, device=self.device,
+                  normalize_embeddings=self.normalize, modality=modality)
+
+    def _dimensions(self) -> Optional[int]:
+        props = self.model_properties
+        if props is None:
+            try:
+                from marqo_amd.s2_inference.s2_inference import get_model_properties_from_registry
+                props = get_model_properties_from_registry(self.model_name)
+            except Exception:  # noqa: BLE001 - unknown to the registry: the width is taken from the local shard below
+                props = None
+        d = (props or {}).get("dimensions")
+        return int(d) if isinstance(d, int) and d > 0 else None
+
     def _encode(self, contents: List[Any], modality: Modality) -> np.ndarray:
-        """one vectorise call for the local shard (+ all-gather when running one process per GPU)"""
+        """one vectorise call for the local shard (+ ONE all-gather when running one process per GPU)"""
         import torch
         import torch.distributed as dist
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-        if world == 1:
-            return self._vectorise(self.model_name, contents, model_properties=self.model_properties, device=self.device,
-                                   normalize_embeddings=self.normalize, modality=modality)
-        from marqo_amd.parallel import gather_embeddings
-        bounds = shard_bounds(len(contents), world)
-        s, e = bounds[dist.get_rank()]
-        local = self._vectorise(self.model_name, contents[s:e], model_properties=self.model_properties, device=self.device,
-                                normalize_embeddings=self.normalize, modality=modality) if e > s else None
-        dim = torch.tensor([0 if local is None else local.shape[1]], device=self.device if self.device.startswith("cuda") else "cpu")
-        dist.all_reduce(dim, op=dist.ReduceOp.MAX)
-        D = int(dim.item())
-        t = torch.zeros(e - s, D, dtype=torch.float32) if local is None else torch.from_numpy(np.ascontiguousarray(local, dtype=np.float32))
-        t = t.to(self.device if self.device.startswith("cuda") else "cpu")
-        return gather_embeddings(t, counts=[b - a for a, b in bounds]).cpu().numpy()
+        if world == 1 and not (self.force_collective and dist.is_available() and dist.is_initialized()):
+            fn = self._vectorise
+            if fn is None:
+                from marqo_amd.s2_inference.s2_inference import vectorise_ndarray as fn
+            out = self._call(fn, contents, modality)
+            return out.cpu().numpy() if isinstance(out, torch.Tensor) else out
+        on_gpu = dist.get_backend() == "nccl" and str(self.device).startswith("cuda")
+        fn = self._vectorise
+        if fn is None:
+            if on_gpu:
+                from marqo_amd.s2_inference.s2_inference import vectorise_device as fn
+            else:
+                from marqo_amd.s2_inference.s2_inference import vectorise_ndarray as fn
+        plan = (balanced_shards([estimate_tokens(c) for c in contents], world) if modality == Modality.TEXT
+                else contiguous_shards(len(contents), world))
+        mine = plan.items[dist.get_rank()]
+        local = self._call(fn, [contents[i] for i in mine], modality) if mine else None
+        if local is not None and not isinstance(local, torch.Tensor):
+            local = torch.from_numpy(np.ascontiguousarray(local, dtype=np.float32))
+        D = self._dimensions() or (local.shape[1] if local is not None else None)
+        if D is None:
+            raise RuntimeError("BulkVectoriser: this rank received no items and the model properties carry no 'dimensions'")
+        where = self.device if on_gpu else "cpu"
+        local = torch.zeros(0, D, dtype=torch.float32, device=where) if local is None else local.to(device=where, dtype=torch.float32)
+        full = plan.restore(gather_embeddings(local, counts=plan.counts, force_collective=self.force_collective))
+        return full.cpu().numpy()
 
     def _run_pending(self) -> None:
-        with self._lock:
-            work = {m: v for m, v in self._pending.items() if v}
-            self._pending = {Modality.TEXT: [], Modality.IMAGE: []}
-        for modality, items in work.items():
-            emb = self._encode([c for _, c in items], modality)
-            if emb.shape[0] != len(items):
-                raise RuntimeError(f"vectorise returned {emb.shape[0]} embeddings for {len(items)} items")
+        """pops ONE modality at a time; if its vectorise call raises (e.g. one undecodable image) the popped items go back to the
+        front of the queue — nothing is lost, the caller sees the exception and may drop the offending key and flush again"""
+        for modality in (Modality.TEXT, Modality.IMAGE):
+            with self._lock:
+                items, self._pending[modality] = self._pending[modality], []
+            if not items:
+                continue
+            try:
+                emb = self._encode([c for _, c in items], modality)
+                if emb.shape[0] != len(items):
+                    raise RuntimeError(f"vectorise returned {emb.shape[0]} embeddings for {len(items)} items")
+            except BaseException:
+                with self._lock:
+                    self._pending[modality] = items + self._pending[modality]
+                raise
             with self._lock:
                 for (key, _), row in zip(items, emb):
                     self._done[key] = row
+
+    def discard(self, key: Hashable) -> int:
+        """drop every queued item with this key (e.g. the image a failed flush reported); returns how many were dropped"""
+        with self._lock:
+            n = 0
+            for m, items in self._pending.items():
+                kept = [(k, c) for k, c in items if k != key]
+                n += len(items) - len(kept)
+                self._pending[m] = kept
+            return n
 
     def flush(self) -> Dict[Hashable, np.ndarray]:
         """Vectorise everything still queued; returns {key: float32 [D]} for every key added since the last flush()."""

@@ -3,14 +3,23 @@
 Every embedding is independent (no cross-item reduction, per-row normalisation), so the path shards
 trivially: one process per GPU (torch.distributed, backend "nccl" == RCCL over xGMI on ROCm), weights
 replicated on every GPU (<= 0.85 GB bf16 for ViT-L/14 — nothing against 288 GB of HBM), the item list
-split contiguously by rank, and ONE collective: an all_gather of the [n_i, D] fp32 embedding shards for
-the final concat.  xGMI is point-to-point, so this is a single fat message per peer pair (8 GPUs x
-38 MB for 100k x 768 fp32) rather than many small ones.  The reference has nothing to translate here:
-it only exposes `device="cuda:N"` (src/marqo/tensor_search/utils.py:90-123).
+split across ranks, and ONE collective: an all_gather of the [n_i, D] fp32 embedding shards, straight
+from HBM, for the final concat.  xGMI is point-to-point, so this is a single fat message per peer pair
+(8 GPUs x 38 MB for 100k x 768 fp32) rather than many small ones.  The reference has nothing to
+translate here: it only exposes `device="cuda:N"` (src/marqo/tensor_search/utils.py:90-123).
+
+Two ways to split:
+  * `shard_bounds`      contiguous, equal item counts (images after the resize all cost the same);
+  * `balanced_shards`   ragged text: items are dealt to ranks by estimated cost (token count), longest first onto the least
+                        loaded rank, so that every GPU runs the same number of token rows; `ShardPlan.restore` puts the gathered
+                        rows back into request order with one index_select.  The plan is a pure function of the costs, so every
+                        rank computes the same one and nothing but the embeddings crosses the fabric.
 """
 from __future__ import annotations
 
-from typing import List, Sequence, Tuple
+import heapq
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
 
 import torch
 
@@ -28,15 +37,59 @@ def shard_bounds(n_items: int, world: int) -> List[Tuple[int, int]]:
     return out
 
 
-def gather_embeddings(local: torch.Tensor, counts: Sequence[int] = None) -> torch.Tensor:
-    """All-gather row shards [n_r, D] (fp32) from every rank into [sum n_r, D] in rank order.
+@dataclass
+class ShardPlan:
+    """which items each rank encodes (`items[r]`, ascending request index) and how to undo it after the gather"""
+    items: List[List[int]]
+    n_items: int
 
-    counts: per-rank row counts when shards are ragged (known from shard_bounds, so no size exchange is
-    needed).  Equal shards use a single all_gather_into_tensor; ragged shards are padded to the max count
-    so it is still ONE collective, then trimmed on the host side of the result view.
+    @property
+    def counts(self) -> List[int]:
+        return [len(x) for x in self.items]
+
+    def restore(self, gathered: torch.Tensor) -> torch.Tensor:
+        """rows in rank order (rank 0's items, then rank 1's ...) -> rows in request order"""
+        order = [i for part in self.items for i in part]
+        if order == list(range(self.n_items)):
+            return gathered
+        inv = torch.empty(self.n_items, dtype=torch.int64)
+        inv[torch.tensor(order, dtype=torch.int64)] = torch.arange(self.n_items, dtype=torch.int64)
+        return gathered.index_select(0, inv.to(gathered.device))
+
+
+def balanced_shards(costs: Sequence[float], world: int) -> ShardPlan:
+    """Longest-processing-time-first assignment of items to ranks by cost (ties broken by index, so the plan is deterministic).
+    Guarantees max load <= 4/3 of the optimum; with thousands of short texts per request the loads differ by < 1 item."""
+    if world < 1:
+        raise ValueError("world must be >= 1")
+    n = len(costs)
+    if world == 1:
+        return ShardPlan([list(range(n))], n)
+    heap = [(0.0, r) for r in range(world)]
+    items: List[List[int]] = [[] for _ in range(world)]
+    for i in sorted(range(n), key=lambda j: (-float(costs[j]), j)):
+        load, r = heapq.heappop(heap)
+        items[r].append(i)
+        heapq.heappush(heap, (load + max(float(costs[i]), 0.0), r))
+    for part in items:
+        part.sort()
+    return ShardPlan(items, n)
+
+
+def contiguous_shards(n_items: int, world: int) -> ShardPlan:
+    return ShardPlan([list(range(a, b)) for a, b in shard_bounds(n_items, world)], n_items)
+
+
+def gather_embeddings(local: torch.Tensor, counts: Optional[Sequence[int]] = None, force_collective: bool = False) -> torch.Tensor:
+    """All-gather row shards [n_r, D] (fp32) from every rank into [sum n_r, D] in rank order — ONE collective.
+
+    counts: per-rank row counts when shards are ragged (known from the shard plan, so no size exchange is needed).  Equal shards
+    use a single all_gather_into_tensor; ragged shards are padded to the max count so it is still ONE collective, then trimmed.
     """
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
+        return local
+    if dist.get_world_size() == 1 and not force_collective:   # (force_collective: run the 1-rank collective anyway, for RCCL tests)
         return local
     world = dist.get_world_size()
     D = local.shape[1]

@@ -65,7 +65,8 @@ class AbstractCLIPModel(AbstractEmbeddingModel):
             is_image = True
         else:
             raise UnidentifiedImageError(f"expected default='image' or default='text' but received {default}")
+        extra = {"return_device": True} if kwargs.get("return_device") else {}   # engine extension: keep the result in HBM
         if is_image:
             return self.encode_image(inputs, normalize=normalize,
-                                     image_download_headers=kwargs.get("image_download_headers", dict()))
-        return self.encode_text(inputs, normalize=normalize)
+                                     image_download_headers=kwargs.get("image_download_headers", dict()), **extra)
+        return self.encode_text(inputs, normalize=normalize, **extra)

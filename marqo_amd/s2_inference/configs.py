@@ -18,6 +18,7 @@ def default_env_vars() -> dict:
         EnvVars.MARQO_AMD_MODEL_DIR: os.path.join(os.environ.get("MARQO_ROOT_PATH", os.path.expanduser("~/.marqo")), "cache", "models"),
         EnvVars.MARQO_AMD_SYNTHETIC_WEIGHTS: "0",
         EnvVars.MARQO_AMD_MICRO_BATCH_ROWS: 65536,
+        EnvVars.MARQO_AMD_MAX_ITEMS_PER_ENCODE: 1024,
     }
 
 

@@ -43,3 +43,4 @@ class EnvVars:
     MARQO_AMD_MODEL_DIR = "MARQO_AMD_MODEL_DIR"                  # where checkpoints / vocab files are looked up
     MARQO_AMD_SYNTHETIC_WEIGHTS = "MARQO_AMD_SYNTHETIC_WEIGHTS"  # "1": random-init weights when a checkpoint is absent
     MARQO_AMD_MICRO_BATCH_ROWS = "MARQO_AMD_MICRO_BATCH_ROWS"    # token rows per device micro-batch
+    MARQO_AMD_MAX_ITEMS_PER_ENCODE = "MARQO_AMD_MAX_ITEMS_PER_ENCODE"  # non-text items (images) staged per engine encode() call

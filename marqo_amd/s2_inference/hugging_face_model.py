@@ -16,6 +16,7 @@ import torch
 
 from marqo_amd import _lib as L
 from marqo_amd.engine import archs, checkpoint, synthetic
+from marqo_amd.engine.towers import request_stream
 from marqo_amd.engine.tokenizers import SyntheticTokenizer, WordPieceTokenizer, XlmRobertaTokenizer
 from marqo_amd.s2_inference.abstract_models import AbstractEmbeddingModel
 from marqo_amd.s2_inference.errors import InternalError, InvalidModelPropertiesError, ModelLoadError
@@ -45,11 +46,15 @@ class HuggingFaceModelProperties:
             raise ValueError("pooling_method must be 'mean' or 'cls'")
         self.pooling_method: Optional[str] = pm  # None: inferred at load from 1_Pooling/config.json, default mean
         self.trust_remote_code: bool = bool(p.get("trust_remote_code", p.get("trustRemoteCode", False)))
-        # engine extension: operand type of the encoder-block GEMMs, "bf16" (default) or "fp8" (e4m3 MX-MFMA; static activation
-        # scales calibrated on the first batch), see open_clip_model.OpenCLIPModelProperties
+        # engine extension: operand type of the encoder-block GEMMs, "bf16" (default) or "fp8" (e4m3 MX-MFMA; calibrated at load on
+        # fixed seeded inputs, 'fp8Budget' bounds the error), see open_clip_model.OpenCLIPModelProperties
         self.engine_precision: str = p.get("enginePrecision", p.get("engine_precision", os.environ.get("MARQO_AMD_PRECISION", "bf16")))
         if self.engine_precision not in ("bf16", "fp8"):
             raise ValueError("'enginePrecision' must be 'bf16' or 'fp8'")
+        b = p.get("fp8Budget", p.get("fp8_budget"))
+        if b is not None and not (isinstance(b, (int, float)) and b > 0):
+            raise ValueError("'fp8Budget' must be a positive number")
+        self.fp8_budget: Optional[float] = None if b is None else float(b)
 
     def dict(self) -> dict:
         return dict(self.__dict__)
@@ -125,20 +130,14 @@ class HuggingFaceModel(AbstractEmbeddingModel):
         except ValueError as e:  # e.g. fp8 needs width / mlp_dim multiples of 128
             raise InvalidModelPropertiesError(str(e)) from e
         self._pooling_func = pooling
+        if props.engine_precision == "fp8":   # deterministic load-time calibration on fixed seeded inputs (see open_clip_model.py)
+            self._model.tune_fp8_default(props.fp8_budget)
         # K14: WordPiece on the device for ASCII texts (identical ids; the host tokeniser stays the definition of record and
         # handles every other text).  MARQO_AMD_HOST_TOKENIZER=1 keeps everything on the host.
         self._device_tokenizer = None
         if isinstance(self._tokenizer, WordPieceTokenizer) and os.environ.get("MARQO_AMD_HOST_TOKENIZER", "0") != "1":
             from marqo_amd.engine.gpu_tokenizers import DeviceWordPieceTokenizer
             self._device_tokenizer = DeviceWordPieceTokenizer(self._tokenizer, self.device)
-
-    def _calibrated(self, run) -> None:
-        """fp8 tower: freeze the static activation scales on the first batch (two recording passes), once"""
-        fp8 = getattr(self._model, "_fp8", None)
-        if fp8 is not None and not fp8.calibrated:
-            with self._calib_lock:
-                if not fp8.calibrated:
-                    self._model.calibrate_fp8(run)
 
     @staticmethod
     def _do_lower_case(directory: str) -> bool:
@@ -154,19 +153,22 @@ class HuggingFaceModel(AbstractEmbeddingModel):
         return True
 
     def encode(self, sentence: Union[str, List[str]], normalize=True, **kwargs) -> np.ndarray:
+        """-> np.ndarray [n, D] fp32 (hugging_face_model.py:172-203); engine extension `return_device=True`: the same rows as a device
+        tensor.  Other kwargs the callers pass (`modality`, `infer`, `image_download_headers`) are tolerated and ignored."""
         if isinstance(sentence, str):
             sentence = [sentence]
         if self._model is None:
             self.load()
-        if getattr(self, "_device_tokenizer", None) is not None:
-            d_ids, lens = self._device_tokenizer.encode_device(sentence, self.model_properties.tokens)
-            self._calibrated(lambda: self._model.encode_device(d_ids, lens))
-            return self._model.encode_device(d_ids, lens, normalize=bool(normalize)).cpu().numpy()
-        tok = self._tokenizer(sentence, max_length=self.model_properties.tokens)
-        ids = torch.from_numpy(tok["input_ids"])
-        self._calibrated(lambda: self._model.encode_ids(ids, torch.from_numpy(tok["attention_mask"])))
-        mask = torch.from_numpy(tok["attention_mask"])
-        return self._model.encode_ids(ids, mask, normalize=bool(normalize)).cpu().numpy()
+        return_device = bool(kwargs.get("return_device", False))
+        with request_stream(self.device, device_output=return_device):
+            if getattr(self, "_device_tokenizer", None) is not None:
+                d_ids, lens = self._device_tokenizer.encode_device(sentence, self.model_properties.tokens)
+                out = self._model.encode_device(d_ids, lens, normalize=bool(normalize))
+            else:
+                tok = self._tokenizer(sentence, max_length=self.model_properties.tokens)
+                ids, mask = torch.from_numpy(tok["input_ids"]), torch.from_numpy(tok["attention_mask"])
+                out = self._model.encode_ids(ids, mask, normalize=bool(normalize))
+            return out if return_device else out.cpu().numpy()
 
 
 class HuggingFaceStellaModel(HuggingFaceModel):

@@ -23,6 +23,7 @@ from PIL.Image import Image as ImageType
 
 from marqo_amd import _lib as L
 from marqo_amd.engine import archs, checkpoint, synthetic
+from marqo_amd.engine.towers import request_stream
 from marqo_amd.engine.tokenizers import ClipBpeTokenizer, SiglipTokenizer, SyntheticTokenizer, WordPieceTokenizer
 from marqo_amd.s2_inference.abstract_models import AbstractCLIPModel
 from marqo_amd.s2_inference.errors import InvalidModelPropertiesError, ModelLoadError
@@ -47,7 +48,7 @@ class OpenCLIPModelProperties:
     """Validated view of the user's model_properties (reference: open_clip_model_properties.py:24-73)."""
     _KNOWN = {"name", "dimensions", "type", "jit", "precision", "url", "localpath", "model_location", "modelLocation",
               "tokenizer", "image_preprocessor", "imagePreprocessor", "mean", "std", "size", "note", "notes", "pretrained",
-              "model_size", "text_query_prefix", "text_chunk_prefix", "tokens", "enginePrecision", "engine_precision"}
+              "model_size", "text_query_prefix", "text_chunk_prefix", "tokens", "enginePrecision", "engine_precision", "fp8Budget", "fp8_budget"}
 
     def __init__(self, **p):
         if not isinstance(p.get("name"), str) or not p["name"]:
@@ -78,11 +79,17 @@ class OpenCLIPModelProperties:
         self.size: Optional[int] = p.get("size")
         self.pretrained: Optional[str] = p.get("pretrained")
         # engine extension (BASELINE config 5): operand type of the encoder-block GEMMs.  "bf16" (default) or "fp8" (OCP e4m3,
-        # MX-MFMA at twice the bf16 rate; static activation scales are calibrated on the first batch of each tower).  The
-        # reference's own 'precision' key (fp32 / fp16 autocast) keeps its meaning and is accepted for both.
+        # MX-MFMA at twice the bf16 rate).  fp8 is calibrated deterministically at load on fixed seeded inputs: static activation
+        # scales and the number of trailing blocks that run on fp8 while max (1 - cos) vs the bf16 tower stays <= 'fp8Budget'
+        # (default MARQO_AMD_FP8_BUDGET = 7e-4; a larger budget moves more blocks to fp8).  The reference's own 'precision' key
+        # (fp32 / fp16 autocast) keeps its meaning and is accepted for both.
         self.engine_precision: str = p.get("enginePrecision", p.get("engine_precision", os.environ.get("MARQO_AMD_PRECISION", "bf16")))
         if self.engine_precision not in ("bf16", "fp8"):
             raise ValueError("'enginePrecision' must be 'bf16' or 'fp8'")
+        b = p.get("fp8Budget", p.get("fp8_budget"))
+        if b is not None and not (isinstance(b, (int, float)) and b > 0):
+            raise ValueError("'fp8Budget' must be a positive number")
+        self.fp8_budget: Optional[float] = None if b is None else float(b)
 
     def dict(self) -> dict:
         return dict(self.__dict__)
@@ -203,7 +210,11 @@ class OPEN_CLIP(AbstractCLIPModel):
             self.text = towers.ClipTextTower(self.text_arch, sd, self.device, precision=props.engine_precision)
         except ValueError as e:  # e.g. fp8 needs width / mlp_dim multiples of 128
             raise InvalidModelPropertiesError(str(e)) from e
-        self._calib_lock = threading.Lock()
+        if props.engine_precision == "fp8":
+            # deterministic load-time calibration on fixed seeded inputs (NOT on whatever request arrives first): static activation
+            # scales with head-room + the bf16 / fp8 block split that keeps the measured error inside props.fp8_budget
+            self.vision.tune_fp8_default(props.fp8_budget)
+            self.text.tune_fp8_default(props.fp8_budget)
         self.model = (self.vision, self.text)
         self.tokenizer = self._load_tokenizer(ckpt_dir)
         # K14: byte-level BPE on the device for ASCII texts (identical ids; the host tokeniser handles the rest)
@@ -282,17 +293,24 @@ class OPEN_CLIP(AbstractCLIPModel):
         if self.model is None:
             self.load()
         headers = image_download_headers or dict()
-        if isinstance(images, list):
-            loaded = format_and_load_CLIP_images(images, headers)
-        else:
-            loaded = [format_and_load_CLIP_image(images, headers)]
         if isinstance(images, torch.Tensor) and images.ndim == 4:  # an already stacked batch
             return "f32", images
+
+        def load(i):
+            # decoded pixels (uint8 [H, W, 3] arrays, e.g. from a decoder pool) go to the pinned staging buffer as they are; the
+            # reference wraps them in a PIL image first (image_download.py:107-108), which changes no pixel
+            if isinstance(i, np.ndarray) and i.dtype == np.uint8 and i.ndim == 3 and i.shape[2] == 3:
+                return i
+            return format_and_load_CLIP_image(i, headers)
+        if isinstance(images, list):
+            loaded = [load(i) for i in images]
+        else:
+            loaded = [load(images)]
         tensors = [i for i in loaded if isinstance(i, torch.Tensor)]
         pre = self._pre()
         if len(tensors) == len(loaded):
             return "f32", torch.stack([t.to(self.device) for t in tensors])
-        raw = [pil_to_rgb_u8(i) for i in loaded if not isinstance(i, torch.Tensor)]
+        raw = [i if isinstance(i, np.ndarray) else pil_to_rgb_u8(i) for i in loaded if not isinstance(i, torch.Tensor)]
         u8 = self._resize(pre, raw)
         if not tensors:
             return "u8", u8
@@ -303,32 +321,28 @@ class OPEN_CLIP(AbstractCLIPModel):
     def _convert_output(self, output: torch.Tensor) -> np.ndarray:
         return output.cpu().numpy()
 
-    def _calibrated(self, tower, run) -> None:
-        """fp8 towers: freeze the static activation scales on the first batch this tower sees (two recording passes), once."""
-        fp8 = getattr(tower, "_fp8", None)
-        if fp8 is not None and not fp8.calibrated:
-            with self._calib_lock:
-                if not fp8.calibrated:
-                    tower.calibrate_fp8(run)
-
-    def encode_image(self, images, image_download_headers: Optional[Dict] = None, normalize=True) -> np.ndarray:
-        kind, px = self._preprocess_images(images, image_download_headers)
-        self.image_input_processed = px
-        self._calibrated(self.vision, lambda: self.vision.encode_u8(px) if kind == "u8" else self.vision.encode_f32(px))
-        out = self.vision.encode_u8(px, normalize=bool(normalize)) if kind == "u8" else self.vision.encode_f32(px, normalize=bool(normalize))
-        return self._convert_output(out)
-
-    def encode_text(self, sentence: Union[str, List[str]], normalize=True) -> np.ndarray:
+    def encode_image(self, images, image_download_headers: Optional[Dict] = None, normalize=True, return_device: bool = False):
+        """-> np.ndarray [n, D] fp32 (reference contract), or with the engine extension `return_device=True` the same rows as a
+        device tensor (no D2H: bulk ingest gathers shards over RCCL straight from HBM)"""
         if self.model is None:
             self.load()
-        if getattr(self, "_device_tokenizer", None) is not None:
-            d_ids, lens = self._device_tokenizer.encode_device([sentence] if isinstance(sentence, str) else list(sentence))
-            self._calibrated(self.text, lambda: self.text.encode_device(d_ids, lens))
-            return self._convert_output(self.text.encode_device(d_ids, lens, normalize=bool(normalize)))
-        ids = self.tokenizer(sentence)
-        ids = torch.as_tensor(np.asarray(ids))
-        self._calibrated(self.text, lambda: self.text.encode_ids(ids))
-        return self._convert_output(self.text.encode_ids(ids, normalize=bool(normalize)))
+        with request_stream(self.device, device_output=return_device):
+            kind, px = self._preprocess_images(images, image_download_headers)
+            self.image_input_processed = px
+            out = self.vision.encode_u8(px, normalize=bool(normalize)) if kind == "u8" else self.vision.encode_f32(px, normalize=bool(normalize))
+            return out if return_device else self._convert_output(out)
+
+    def encode_text(self, sentence: Union[str, List[str]], normalize=True, return_device: bool = False):
+        if self.model is None:
+            self.load()
+        with request_stream(self.device, device_output=return_device):
+            if getattr(self, "_device_tokenizer", None) is not None:
+                d_ids, lens = self._device_tokenizer.encode_device([sentence] if isinstance(sentence, str) else list(sentence))
+                out = self.text.encode_device(d_ids, lens, normalize=bool(normalize))
+            else:
+                ids = torch.as_tensor(np.asarray(self.tokenizer(sentence)))
+                out = self.text.encode_ids(ids, normalize=bool(normalize))
+            return out if return_device else self._convert_output(out)
 
     # engine extensions used by the chunking / bulk-ingest path ------------------------------------------------------
     def encode_image_chunks(self, images: Sequence, hn: int = 3, wn: int = 3, overlap: bool = False, normalize=True):
@@ -338,8 +352,8 @@ class OPEN_CLIP(AbstractCLIPModel):
         if self._resize_mode == "squash" and len(raw):
             # the grid crops are square (shorter-side resize + crop == squash); chunk 0, the whole image, is not
             u8[0::u8.shape[0] // len(raw)] = self._resize(self._pre(), raw)
-        self._calibrated(self.vision, lambda: self.vision.encode_u8(u8))
-        emb = self._convert_output(self.vision.encode_u8(u8, normalize=bool(normalize)))
+        with request_stream(self.device):
+            emb = self._convert_output(self.vision.encode_u8(u8, normalize=bool(normalize)))
         return emb.reshape(len(raw), -1, emb.shape[-1]), boxes
 
 

@@ -110,6 +110,28 @@ def vectorise_ndarray(model_name: str, content, model_properties: dict = None, d
     return out[np.newaxis, :] if out.ndim == 1 else out
 
 
+def vectorise_device(model_name: str, content, model_properties: dict = None, device: str = None,
+                     normalize_embeddings: bool = get_default_normalization(), model_auth=None,
+                     modality: Modality = Modality.TEXT, **kwargs) -> torch.Tensor:
+    """Engine extension: same flow as `vectorise` (cache off) but the fp32 [N, D] result STAYS IN HBM as a
+    torch.Tensor on `device` — no D2H, no Python floats.  The bulk-ingest path (marqo_amd.ingest.BulkVectoriser) hands these
+    shards straight to the RCCL all_gather.  Models that cannot produce device tensors (random / no_model fakes) are copied up."""
+    if not device:
+        raise InternalError(message="vectorise (internal function) cannot be called without setting device!")
+    props = validate_model_properties(model_name, model_properties)
+    key = _create_model_cache_key(model_name, device, props)
+    _update_available_models(key, model_name, props, device, normalize_embeddings, model_auth=model_auth)
+    model = _available_models[key][AvailableModelsKey.model]
+    if getattr(model, "supports_dynamic_batching", False):
+        kwargs["return_device"] = True
+    out = _encode_to_array(key, content, normalize_embeddings, modality, **kwargs)
+    if not isinstance(out, torch.Tensor):
+        out = torch.from_numpy(np.ascontiguousarray(out, dtype=np.float32))
+        if str(device).startswith("cuda") and torch.cuda.is_available():
+            out = out.to(device)
+    return out[None, :] if out.ndim == 1 else out
+
+
 def _vectorise_with_cache(model, model_cache_key, content, normalize_embeddings, modality, **kwargs):
     """s2_inference.py:72-84"""
     if isinstance(content, str):
@@ -165,18 +187,30 @@ def _encode_to_array(model_cache_key: str, content, normalize_embeddings: bool, 
             vectorised = model.encode(content, normalize=normalize_embeddings, modality=modality, **kwargs)
         else:
             vector_batches = []
+            on_device = bool(kwargs.get("return_device"))
             batch_size = _get_max_vectorise_batch_size()  # validated even when the engine batches dynamically
             if getattr(model, "supports_dynamic_batching", False) and len(content) > 0:
-                batch_size = len(content)  # one call: the engine micro-batches by token rows on the device
+                # one call: the engine micro-batches by token rows on the device.  Non-text items (decoded images: ~MBs of pinned
+                # staging + HBM each) are still bounded per call, by MARQO_AMD_MAX_ITEMS_PER_ENCODE (default 1024), so a request of
+                # thousands of large images cannot stage tens of GB at once.
+                batch_size = len(content)
+                if not isinstance(content[0], str):
+                    batch_size = min(batch_size, max(1, read_env_vars_and_defaults_ints(EnvVars.MARQO_AMD_MAX_ITEMS_PER_ENCODE)))
             for batch in generate_batches(content, batch_size=batch_size):
                 if modality is None:
                     modality = infer_modality(batch[0] if isinstance(batch[0], (str, bytes)) else batch)
                 infer = kwargs.pop("infer", False if modality == Modality.TEXT else True)
                 encoded_batch = encoder.encode(batch, modality=modality, normalize=normalize_embeddings, infer=infer, **kwargs)
-                vector_batches.append(_convert_tensor_to_numpy(encoded_batch))
+                vector_batches.append(encoded_batch if on_device and isinstance(encoded_batch, torch.Tensor)
+                                      else _convert_tensor_to_numpy(encoded_batch))
             if not vector_batches or all(len(b) == 0 for b in vector_batches):
                 raise RuntimeError(f"Vectorise created an empty list of batches! Content: {content}")
-            vectorised = vector_batches[0] if len(vector_batches) == 1 else np.concatenate(vector_batches, axis=0)
+            if len(vector_batches) == 1:
+                vectorised = vector_batches[0]
+            elif on_device and all(isinstance(b, torch.Tensor) for b in vector_batches):
+                vectorised = torch.cat(vector_batches, dim=0)
+            else:
+                vectorised = np.concatenate([_convert_tensor_to_numpy(b) for b in vector_batches], axis=0)
     except (UnidentifiedImageError, OSError) as e:
         if isinstance(e, UnidentifiedImageError) or "image file is truncated" in str(e):
             raise VectoriseError(f"Could not process given image: {content}. Original Error message: {e}") from e

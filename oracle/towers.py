@@ -362,7 +362,7 @@ def _realistic_blocks(sd: Dict[str, Tensor], prefix: str, layers: int, W: int, F
       * LayerNorm gamma log-normal (sigma 0.4) with a handful of channels at 0.05 and at 4.0, beta ~ N(0, 0.3);
       * per-layer weight scale varying over 0.7-1.6x, 1 % of the output channels of every linear 4x larger (outlier channels),
         biases ~ N(0, 0.1);
-      * query / key rows 2.5x larger, so attention logits have a standard deviation of a few units (peaky softmax) instead of the
+      * query / key rows 2x larger, so attention logits have a standard deviation of a few units (peaky softmax) instead of the
         near-uniform attention of small random weights."""
     base = 0.6 / math.sqrt(W)
     for i in range(layers):
@@ -381,7 +381,7 @@ def _realistic_blocks(sd: Dict[str, Tensor], prefix: str, layers: int, W: int, F
             out_idx = torch.randperm(n_out, generator=g)[: max(1, n_out // 100)]
             w[out_idx] *= 4.0
             if name == "attn.in_proj_":
-                w[: 2 * W] *= 2.5
+                w[: 2 * W] *= 2.0
             sd[p + name + "weight"] = w
             sd[p + name + "bias"] = 0.1 * torch.randn(n_out, generator=g)
 

@@ -51,6 +51,47 @@ def test_against_the_random_model_through_vectorise_ndarray():
     assert np.allclose(np.stack([out[i] for i in range(6)]), ref)
 
 
+def test_failed_flush_keeps_the_queue():
+    """a vectorise error must not lose queued items (of either modality): they stay queued and can be flushed again"""
+    state = {"fail": True}
+
+    def flaky(model, content, **kw):
+        if kw["modality"] == Modality.IMAGE and state["fail"]:
+            raise OSError("image file is truncated")
+        return np.asarray([[float(len(str(c)))] for c in content], dtype=np.float32)
+
+    bv = BulkVectoriser("m", "cpu", vectorise_fn=flaky)
+    bv.add("t0", "hello")
+    bv.add("i0", "bad.png", Modality.IMAGE)
+    bv.add("i1", "good.png", Modality.IMAGE)
+    with pytest.raises(OSError):
+        bv.flush()
+    assert bv.pending() == 2                      # the text was encoded; both images are still queued, in order
+    assert bv.discard("i0") == 1
+    state["fail"] = False
+    out = bv.flush()
+    assert set(out) == {"t0", "i1"} and out["i1"][0] == len("good.png") and bv.pending() == 0
+
+
+def test_shard_plans():
+    from marqo_amd.ingest import estimate_tokens
+    from marqo_amd.parallel import balanced_shards, contiguous_shards
+    import torch
+    costs = [estimate_tokens("x" * n) for n in (400, 8, 8, 8, 300, 8, 8, 120, 8, 8, 8, 8, 8)]
+    plan = balanced_shards(costs, 2)
+    assert sorted(plan.items[0] + plan.items[1]) == list(range(13)) and plan.n_items == 13
+    loads = [sum(costs[i] for i in part) for part in plan.items]
+    assert abs(loads[0] - loads[1]) <= max(costs) * 0.35      # token rows per rank are balanced although the item counts are not
+    assert balanced_shards(costs, 2).items == plan.items   # deterministic
+    assert balanced_shards([estimate_tokens("x" * n) for n in [800] + [8] * 12], 2).counts == [1, 12]   # one long text vs twelve short ones
+    rows = torch.arange(13.0).unsqueeze(1)
+    gathered = torch.cat([rows[plan.items[0]], rows[plan.items[1]]])
+    assert torch.equal(plan.restore(gathered), rows)
+    assert balanced_shards([], 3).counts == [0, 0, 0] and balanced_shards([1.0], 1).items == [[0]]
+    c = contiguous_shards(7, 2)
+    assert c.items == [[0, 1, 2, 3], [4, 5, 6]] and torch.equal(c.restore(rows[:7]), rows[:7])
+
+
 def _worker(rank, world, port, q):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
@@ -66,7 +107,20 @@ def _worker(rank, world, port, q):
         for i in range(7):
             bv.add(i, f"item {i}")
         out = bv.flush()
-        ok = all(np.allclose(out[i], [i, i, i]) for i in range(7)) and len(seen[0]) == (4 if rank == 0 else 3)
+        ok = all(np.allclose(out[i], [i, i, i]) for i in range(7)) and len(seen) == 1 and len(seen[0]) == (4 if rank == 0 else 3)
+        # ragged texts: shards balanced by estimated tokens, results still in request order; images: contiguous halves
+        texts = [("w " * (1 + 37 * (i % 5))).strip() + f" {i}" for i in range(11)]
+        for i, t in enumerate(texts):
+            bv.add(("t", i), t)
+        for i in range(5):
+            bv.add(("i", i), f"img {100 + i}", Modality.IMAGE)
+        seen.clear()
+        out = bv.flush()
+        ok = ok and all(np.allclose(out[("t", i)], [i] * 3) for i in range(11)) and all(np.allclose(out[("i", i)], [100 + i] * 3) for i in range(5))
+        from marqo_amd.ingest import estimate_tokens
+        from marqo_amd.parallel import balanced_shards
+        plan = balanced_shards([estimate_tokens(t) for t in texts], world)
+        ok = ok and seen[0] == [texts[i] for i in plan.items[rank]] and seen[1] == [f"img {100 + i}" for i in (range(0, 3) if rank == 0 else range(3, 5))]
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()

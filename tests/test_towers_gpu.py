@@ -414,3 +414,32 @@ def test_single_request_graph_replay_is_bit_identical(monkeypatch):
         assert torch.equal(e, a) and torch.equal(e, b)
     # the batch path is the eager one and agrees with the single calls
     assert _cos_err(vt.encode_u8(u8.cuda()), torch.cat(eager[:3])) < 1e-5
+
+
+# ---- trained-like statistics at full depth (every kernel had only ever seen N(0, s) weights) --------------------------------
+def test_vit_l14_full_depth_realistic_weights_bf16():
+    """ViT-L/14 at its real depth with LayerNorm gains spread over 0.05..4, outlier output channels, peaky attention and a class-token
+    massive activation (~120 in two residual channels from block 2 on, against an rms of ~2): bf16 path vs the fp32 CPU oracle"""
+    from marqo_amd.engine import archs, towers
+    varch, _ = archs.resolve_open_clip("ViT-L-14")
+    cfg = O.VitConfig(224, 14, 1024, 24, 16, 4096, 768)
+    sd = O.synthetic_vit_state_dict_realistic(cfg, 0)
+    u8 = O.synthetic_images_u8(3, 224, seed=9)
+    ref = O.vit_forward(sd, cfg, O.preprocess_u8_exact_size(u8))
+    out = towers.VitTower(varch, sd, "cuda:0").encode_u8(u8.to("cuda:0")).cpu()
+    e = float((1 - torch.nn.functional.cosine_similarity(out.double(), ref.double(), dim=-1)).max())
+    print(f"ViT-L/14 24L realistic weights: bf16 1-cos vs fp32 oracle {e:.2e}")
+    assert e < 3e-4
+
+
+def test_clip_text_full_depth_realistic_weights_bf16():
+    from marqo_amd.engine import archs, towers
+    _, tarch = archs.resolve_open_clip("ViT-L-14")
+    cfg = O.ClipTextConfig(49408, 77, 768, 12, 12, 3072, 768)
+    sd = O.synthetic_clip_text_state_dict_realistic(cfg, 0)
+    ids = O.synthetic_clip_ids(12, seed=6)
+    ref = O.clip_text_forward(sd, cfg, ids)
+    out = towers.ClipTextTower(tarch, sd, "cuda:0").encode_ids(ids).cpu()
+    e = float((1 - torch.nn.functional.cosine_similarity(out.double(), ref.double(), dim=-1)).max())
+    print(f"CLIP text L/14 12L realistic weights (SOT attention-sink massive activation): bf16 1-cos vs fp32 oracle {e:.2e}")
+    assert e < 3e-4
