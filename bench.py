@@ -327,7 +327,8 @@ def e2e_vectorise(dev, images_cpu_u8, tower_only_rate, reps=6):
     n = images_cpu_u8.shape[0]
     arrs = [images_cpu_u8[i].numpy() for i in range(n)]
     pil = [Image.fromarray(a) for a in arrs]
-    model, pre = s2.load_multimodal_model_and_get_preprocessors(name, None, dev)
+    props = s2.get_model_properties_from_registry(name)
+    model, pre = s2.load_multimodal_model_and_get_preprocessors(name, props, dev)
     dev_tensors = [pre["image"](p) for p in pil]        # what add_documents' download threads hand over (add_docs.py:130-134)
     torch.cuda.synchronize()
 
@@ -340,7 +341,7 @@ def e2e_vectorise(dev, images_cpu_u8, tower_only_rate, reps=6):
         torch.cuda.synchronize()
         return n * reps / (time.perf_counter() - t0)
 
-    kw = dict(device=dev, modality=Modality.IMAGE)
+    kw = dict(device=dev, modality=Modality.IMAGE, model_properties=props)
     out = {"n_images": n, "model": name, "unit": "embeddings/s",
            "note": "one synchronous vectorise_ndarray() call per 256 images: host pack -> pinned H2D -> K10 resize -> tower -> D2H"}
     out["ndarray_from_pil"] = round(rate(lambda: s2.vectorise_ndarray(name, pil, **kw)), 1)

@@ -36,20 +36,29 @@ double bicubic_filter(double x) {
     return 0.0;
 }
 
-int coeff_ksize(int in_size, int out_size) {
+// Pillow's triangle filter (Image.BILINEAR, support 1): CLIPA's preprocessing (open_clip _apcfg: bilinear squash)
+double bilinear_filter(double x) {
+    if (x < 0.0) x = -x;
+    return x < 1.0 ? 1.0 - x : 0.0;
+}
+
+constexpr int FILTER_BILINEAR = 2, FILTER_BICUBIC = 3;  // Pillow's Image.BILINEAR / Image.BICUBIC
+double filter_support(int filter) { return filter == FILTER_BILINEAR ? 1.0 : 2.0; }
+
+int coeff_ksize(int in_size, int out_size, int filter = FILTER_BICUBIC) {
     double filterscale = (double)((float)in_size - 0.0f) / out_size;
     if (filterscale < 1.0) filterscale = 1.0;
-    return (int)ceil(2.0 * filterscale) * 2 + 1;
+    return (int)ceil(filter_support(filter) * filterscale) * 2 + 1;
 }
 
 // Pillow precompute_coeffs + normalize_coeffs_8bpc for output positions [first, first+count).
 // bounds: (xmin, n) pairs; kk: [count][ksize]
-void compute_coeffs(int in_size, int out_size, int first, int count, int ksize, int32_t* bounds, int32_t* kk) {
+void compute_coeffs(int in_size, int out_size, int first, int count, int ksize, int32_t* bounds, int32_t* kk, int filter = FILTER_BICUBIC) {
     const float in0 = 0.0f, in1 = (float)in_size;
     double scale, filterscale;
     filterscale = scale = (double)(in1 - in0) / out_size;
     if (filterscale < 1.0) filterscale = 1.0;
-    const double support = 2.0 * filterscale;
+    const double support = filter_support(filter) * filterscale;
     std::vector<double> k(ksize);
     for (int i = 0; i < count; ++i) {
         const int xx = first + i;
@@ -63,7 +72,8 @@ void compute_coeffs(int in_size, int out_size, int first, int count, int ksize, 
         xmax -= xmin;
         int x;
         for (x = 0; x < xmax; x++) {
-            const double w = bicubic_filter((x + xmin - center + 0.5) * ss);
+            const double xa = (x + xmin - center + 0.5) * ss;
+            const double w = filter == FILTER_BILINEAR ? bilinear_filter(xa) : bicubic_filter(xa);
             k[x] = w;
             ww += w;
         }
@@ -179,6 +189,7 @@ struct Plan {
     std::vector<int32_t> coeffs;
     size_t tmp_bytes = 0;
     int max_rows = 0, max_out_h = 0, max_cols = 0;
+    int filter = FILTER_BICUBIC;
 
     // add a job: source sub-image (in_h x in_w) resized to (rs_h x rs_w), keep [top, top+out_h) x [left, left+out_w)
     void add(int64_t src_off, int src_stride, int in_h, int in_w, int rs_h, int rs_w, int top, int left, int out_h, int out_w,
@@ -191,10 +202,10 @@ struct Plan {
         if (rs_w == in_w) {
             j.hb = j.hk = -1; j.h_first = left; j.col0 = left; j.cols = out_w; j.ksize_h = 0;
         } else {
-            j.ksize_h = coeff_ksize(in_w, rs_w);
+            j.ksize_h = coeff_ksize(in_w, rs_w, filter);
             j.hb = (int64_t)coeffs.size(); coeffs.resize(coeffs.size() + 2 * (size_t)out_w);
             j.hk = (int64_t)coeffs.size(); coeffs.resize(coeffs.size() + (size_t)out_w * j.ksize_h);
-            compute_coeffs(in_w, rs_w, left, out_w, j.ksize_h, coeffs.data() + j.hb, coeffs.data() + j.hk);
+            compute_coeffs(in_w, rs_w, left, out_w, j.ksize_h, coeffs.data() + j.hb, coeffs.data() + j.hk, filter);
             int lo = in_w, hi = 0;
             for (int x = 0; x < out_w; ++x) {
                 const int a = coeffs[j.hb + 2 * x], b = a + coeffs[j.hb + 2 * x + 1];
@@ -207,10 +218,10 @@ struct Plan {
         if (rs_h == in_h) {
             j.vb = j.vk = -1; j.v_first = top; j.row0 = top; j.rows = out_h; j.ksize_v = 0;
         } else {
-            j.ksize_v = coeff_ksize(in_h, rs_h);
+            j.ksize_v = coeff_ksize(in_h, rs_h, filter);
             j.vb = (int64_t)coeffs.size(); coeffs.resize(coeffs.size() + 2 * (size_t)out_h);
             j.vk = (int64_t)coeffs.size(); coeffs.resize(coeffs.size() + (size_t)out_h * j.ksize_v);
-            compute_coeffs(in_h, rs_h, top, out_h, j.ksize_v, coeffs.data() + j.vb, coeffs.data() + j.vk);
+            compute_coeffs(in_h, rs_h, top, out_h, j.ksize_v, coeffs.data() + j.vb, coeffs.data() + j.vk, filter);
             int lo = in_h, hi = 0;
             for (int y = 0; y < out_h; ++y) {
                 const int a = coeffs[j.vb + 2 * y], b = a + coeffs[j.vb + 2 * y + 1];
@@ -367,6 +378,35 @@ extern "C" int mq_resize_u8(const uint8_t* d_src, const int64_t* h_src_off, cons
     for (int64_t i = 0; i < n; ++i)
         p.add(h_src_off[i], h_widths[i] * 3, h_heights[i], h_widths[i], out_h, out_w, 0, 0, out_h, out_w, i * (int64_t)out_h * out_w * 3, out_w * 3);
     return run_plan(p, d_src, d_out, d_workspace, workspace_bytes, (hipStream_t)stream, "mq_resize_u8");
+}
+
+// PIL.Image.resize((out_w, out_h), resample=filter) with filter = 2 (Image.BILINEAR) or 3 (Image.BICUBIC): CLIPA's preprocessing is a
+// bilinear squash (open_clip _apcfg(), selected by the reference at open_clip_model.py:87-97)
+extern "C" size_t mq_resize_filter_workspace_bytes(const int32_t* h_heights, const int32_t* h_widths, int64_t n, int32_t out_h, int32_t out_w,
+                                                   int32_t filter) {
+    if (!h_heights || !h_widths || n <= 0 || out_h < 1 || out_w < 1 || (filter != FILTER_BILINEAR && filter != FILTER_BICUBIC)) return 0;
+    Plan p;
+    p.filter = filter;
+    for (int64_t i = 0; i < n; ++i) {
+        if (h_heights[i] < 1 || h_widths[i] < 1) return 0;
+        p.add(0, h_widths[i] * 3, h_heights[i], h_widths[i], out_h, out_w, 0, 0, out_h, out_w, 0, out_w * 3);
+    }
+    return p.total_bytes();
+}
+
+extern "C" int mq_resize_filter_u8(const uint8_t* d_src, const int64_t* h_src_off, const int32_t* h_heights, const int32_t* h_widths, int64_t n,
+                                   int32_t out_h, int32_t out_w, int32_t filter, uint8_t* d_out, void* d_workspace, size_t workspace_bytes,
+                                   void* stream) {
+    MQ_CHECK_ARG(out_h >= 1 && out_w >= 1, "mq_resize_filter_u8: bad output size %dx%d", out_h, out_w);
+    MQ_CHECK_ARG(filter == FILTER_BILINEAR || filter == FILTER_BICUBIC, "mq_resize_filter_u8: filter %d (2 = bilinear, 3 = bicubic)", filter);
+    if (n <= 0) return MQ_OK;
+    MQ_CHECK_ARG(d_src && d_out && d_workspace, "mq_resize_filter_u8: null pointer");
+    MQ_TRY(check_images("mq_resize_filter_u8", h_src_off, h_heights, h_widths, n));
+    Plan p;
+    p.filter = filter;
+    for (int64_t i = 0; i < n; ++i)
+        p.add(h_src_off[i], h_widths[i] * 3, h_heights[i], h_widths[i], out_h, out_w, 0, 0, out_h, out_w, i * (int64_t)out_h * out_w * 3, out_w * 3);
+    return run_plan(p, d_src, d_out, d_workspace, workspace_bytes, (hipStream_t)stream, "mq_resize_filter_u8");
 }
 
 extern "C" int mq_chunk_grid_count(int32_t hn, int32_t wn, int32_t overlap) {
