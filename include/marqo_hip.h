@@ -113,11 +113,17 @@ typedef struct mq_encoder_cfg {
                               * Quantisation noise injected in EARLY blocks is amplified by every later one (measured: the first 12 of
                               * ViT-L/14's 24 blocks cost 2-7x the cosine error of the last 12), so the loaders pick the smallest value
                               * that keeps the calibrated error inside the budget (engine/towers.py::tune_fp8); 0 = every block fp8 */
-    int32_t reserved0;
+    int32_t mlp_glu;         /* 1: gated MLP of the "NewModel" encoders (stella_en_400M_v5, gte-*-en-v1.5): fc1_w is [2F, W] = (up | gate) rows,
+                              * hidden = up * act(gate), fc2 takes the F-wide product.  bf16 post-LN path only. */
     /* fp8 path: static per-tensor activation scales, device fp32 [layers][2] = (attention output, MLP hidden), and the
      * calibration accumulator of the same shape (NULL = frozen scales; non-NULL = fold max|value| of this pass into it) */
     const float* d_fp8_act_scale;
     float*       d_fp8_act_amax;
+    /* rotary position embedding (NULL: none — learned absolute positions are added by the embedding kernel instead): device fp32
+     * [head_dim / 2] inverse frequencies (theta scaling, NTK factor etc. are folded in by the loader).  Applied to the Q and K columns
+     * of the QKV buffer in place, HF "rotate_half" convention: (x1, x2) = (x[d], x[d + hd/2]) -> (x1 cos - x2 sin, x2 cos + x1 sin),
+     * angle = position_in_sequence * inv_freq[d].  bf16 path only. */
+    const float* d_rope_inv_freq;
 } mq_encoder_cfg;
 
 /* ---- towers ------------------------------------------------------------------------ */
@@ -261,6 +267,15 @@ size_t mq_resize_workspace_bytes(const int32_t* h_heights, const int32_t* h_widt
 int mq_resize_u8(const uint8_t* d_src, const int64_t* h_src_off, const int32_t* h_heights, const int32_t* h_widths,
                  int64_t n, int32_t out_h, int32_t out_w, uint8_t* d_out, void* d_workspace, size_t workspace_bytes,
                  void* stream);
+
+/* The same with the resampling filter chosen: filter = 2 (PIL.Image.BILINEAR) or 3 (PIL.Image.BICUBIC).  CLIPA checkpoints are
+ * preprocessed with a BILINEAR squash to S x S (open_clip's _apcfg(), which the reference selects for
+ * image_preprocessor = "CLIPA": core/inference/embedding_models/open_clip_model.py:87-97). */
+size_t mq_resize_filter_workspace_bytes(const int32_t* h_heights, const int32_t* h_widths, int64_t n, int32_t out_h, int32_t out_w,
+                                        int32_t filter);
+int mq_resize_filter_u8(const uint8_t* d_src, const int64_t* h_src_off, const int32_t* h_heights, const int32_t* h_widths,
+                        int64_t n, int32_t out_h, int32_t out_w, int32_t filter, uint8_t* d_out, void* d_workspace,
+                        size_t workspace_bytes, void* stream);
 
 /* Grid chunker (PatchifySimple, processing/image.py:120-151; 'simple' / 'overlap' patch methods):
  * every image is resized to 240x240 (no aspect preservation), cut into the whole image + the

@@ -56,8 +56,8 @@ class BlockWeights(C.Structure):
 class EncoderCfg(C.Structure):
     _fields_ = [("width", C.c_int32), ("layers", C.c_int32), ("heads", C.c_int32), ("mlp_dim", C.c_int32),
                 ("act", C.c_int32), ("post_ln", C.c_int32), ("mask", C.c_int32), ("ln_eps", C.c_float),
-                ("precision", C.c_int32), ("attn_width", C.c_int32), ("fp8_first_layer", C.c_int32), ("reserved0", C.c_int32),
-                ("d_fp8_act_scale", C.c_void_p), ("d_fp8_act_amax", C.c_void_p)]
+                ("precision", C.c_int32), ("attn_width", C.c_int32), ("fp8_first_layer", C.c_int32), ("mlp_glu", C.c_int32),
+                ("d_fp8_act_scale", C.c_void_p), ("d_fp8_act_amax", C.c_void_p), ("d_rope_inv_freq", C.c_void_p)]
 
 
 class MapHead(C.Structure):
@@ -143,6 +143,8 @@ _SIGNATURES = {
     "mq_clip_resize_crop_u8": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, _P, _P, C.c_size_t, _P]),
     "mq_resize_workspace_bytes": (C.c_size_t, [_P, _P, C.c_int64, C.c_int32, C.c_int32]),
     "mq_resize_u8": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int32, _P, _P, C.c_size_t, _P]),
+    "mq_resize_filter_workspace_bytes": (C.c_size_t, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
+    "mq_resize_filter_u8": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.c_size_t, _P]),
     "mq_chunk_grid_count": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
     "mq_chunk_grid_workspace_bytes": (C.c_size_t, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "mq_chunk_grid_u8": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P,

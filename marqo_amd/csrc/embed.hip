@@ -220,14 +220,15 @@ __global__ __launch_bounds__(256, (CH <= 4 ? 8 : 4)) void embed_tokens_kernel(
         int id = ids[row];
         id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
         const float* tr = tok + (int64_t)id * W;
-        const float* pr = pos + (int64_t)t * W;
+        const float* pr = pos ? pos + (int64_t)t * W : nullptr;   // (rotary models carry no absolute position table)
         f32x4 v[CH];
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
             const int c = lane + i * 64;
             v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (c < nch) {
-                v[i] = *(const f32x4*)(tr + c * 4) + *(const f32x4*)(pr + c * 4);
+                v[i] = *(const f32x4*)(tr + c * 4);
+                if (pr) v[i] += *(const f32x4*)(pr + c * 4);
                 if (type0) v[i] += *(const f32x4*)(type0 + c * 4);
             }
         }
@@ -384,6 +385,84 @@ int mq_embed_tokens(const int32_t* d_ids, const int32_t* d_cu, int64_t nseq, con
         MQ_DISPATCH_CH(W, hipLaunchKernelGGL((embed_tokens_kernel<false, CH>), dim3((unsigned)nseq), dim3(256), 0, s, d_ids, d_cu,
                                              tok, pos, type0, g, b, d_x, (bf16_t*)d_xb, W, vocab, eps));
     MQ_CHECK_LAUNCH("embed_tokens");
+    return MQ_OK;
+}
+
+// ---- rotary position embedding on the Q and K columns of the QKV buffer, in place (NewModel encoders: stella / gte-*-en-v1.5) -------
+// grid = sequences; a thread owns 8 consecutive dims d .. d+7 (< hd/2) of one (row, q|k, head) and their partners d + hd/2 ..:
+// two 16-byte loads, fp32 rotation with accurate sincosf (angles reach hundreds of radians), two 16-byte stores.
+__global__ __launch_bounds__(256) void rope_kernel(bf16_t* __restrict__ qkv, const int32_t* __restrict__ cu, int fixed_len, int Wa, int heads,
+                                                   int hs, int hd, const float* __restrict__ inv_freq) {
+    const int row0 = cu ? cu[blockIdx.x] : blockIdx.x * fixed_len;
+    const int len = cu ? cu[blockIdx.x + 1] - row0 : fixed_len;
+    const int half = hd >> 1, chunks = half >> 3;           // 16-byte chunks per half head
+    const int per_row = 2 * heads * chunks;
+    for (int it = threadIdx.x; it < len * per_row; it += 256) {
+        const int t = it / per_row, r = it - t * per_row;
+        const int qk = r / (heads * chunks), r2 = r - qk * heads * chunks;
+        const int h = r2 / chunks, c = r2 - h * chunks;
+        bf16_t* p = qkv + (int64_t)(row0 + t) * (3 * Wa) + qk * Wa + h * hs + c * 8;
+        uint4 lo = *(const uint4*)p, hi = *(const uint4*)(p + half);
+        uint32_t* l = (uint32_t*)&lo;
+        uint32_t* u = (uint32_t*)&hi;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float x1[2] = {bf16_to_f32((bf16_t)(l[e] & 0xffff)), bf16_to_f32((bf16_t)(l[e] >> 16))};
+            float x2[2] = {bf16_to_f32((bf16_t)(u[e] & 0xffff)), bf16_to_f32((bf16_t)(u[e] >> 16))};
+            float y1[2], y2[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                float sn, cs;
+                sincosf((float)t * inv_freq[c * 8 + e * 2 + k], &sn, &cs);
+                y1[k] = x1[k] * cs - x2[k] * sn;
+                y2[k] = x2[k] * cs + x1[k] * sn;
+            }
+            l[e] = pack_bf16x2(y1[0], y1[1]);
+            u[e] = pack_bf16x2(y2[0], y2[1]);
+        }
+        *(uint4*)p = lo;
+        *(uint4*)(p + half) = hi;
+    }
+}
+
+int mq_rope(void* d_qkv, const int32_t* d_cu, int64_t nseq, int fixed_len, int Wa, int heads, const float* d_inv_freq, hipStream_t s) {
+    const int hs = Wa / heads;
+    MQ_CHECK_ARG(hs * heads == Wa && hs % 16 == 0, "rope: head width %d must be a multiple of 16", hs);
+    if (nseq <= 0) return MQ_OK;
+    MqProfScope prof(3, s);
+    hipLaunchKernelGGL(rope_kernel, dim3((unsigned)nseq), dim3(256), 0, s, (bf16_t*)d_qkv, d_cu, fixed_len, Wa, heads, hs, hs, d_inv_freq);
+    MQ_CHECK_LAUNCH("rope");
+    return MQ_OK;
+}
+
+// ---- gated MLP: buf [rows, 2F] = (up | gate) from the fc1 GEMM -> buf[:, :F] = up * act(gate), in place (row stride stays 2F) -----
+__global__ __launch_bounds__(256) void glu_kernel(bf16_t* __restrict__ buf, int64_t rows, int F, int quick) {
+    const int chunks = F >> 3;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < rows * chunks; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / chunks;
+        const int c = (int)(i - r * chunks);
+        bf16_t* p = buf + r * (2 * (int64_t)F) + c * 8;
+        uint4 up = *(const uint4*)p;
+        const uint4 gt = *(const uint4*)(p + F);
+        uint32_t* a = (uint32_t*)&up;
+        const uint32_t* g = (const uint32_t*)&gt;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float u0 = bf16_to_f32((bf16_t)(a[e] & 0xffff)), u1 = bf16_to_f32((bf16_t)(a[e] >> 16));
+            const float g0 = bf16_to_f32((bf16_t)(g[e] & 0xffff)), g1 = bf16_to_f32((bf16_t)(g[e] >> 16));
+            a[e] = pack_bf16x2(u0 * (quick ? quick_gelu(g0) : gelu_erf(g0)), u1 * (quick ? quick_gelu(g1) : gelu_erf(g1)));
+        }
+        *(uint4*)p = up;
+    }
+}
+
+int mq_glu(void* d_buf, int64_t rows, int F, int quick, hipStream_t s) {
+    MQ_CHECK_ARG(F % 8 == 0, "glu: F=%d must be a multiple of 8", F);
+    if (rows <= 0) return MQ_OK;
+    MqProfScope prof(3, s);
+    const int64_t blocks = cdiv64(rows * (F >> 3), 256);
+    hipLaunchKernelGGL(glu_kernel, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, s, (bf16_t*)d_buf, rows, F, quick);
+    MQ_CHECK_LAUNCH("glu");
     return MQ_OK;
 }
 

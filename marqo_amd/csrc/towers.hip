@@ -22,12 +22,14 @@ int mq_last_rows(const int32_t* d_cu, int32_t* d_rows, int64_t nseq, hipStream_t
 int mq_cls_rows(int32_t* d_rows, int64_t n, int T, hipStream_t s);
 int mq_map_pool(const void* d_kv, const float* d_q, void* d_out, int64_t n, int T, int W, int heads, hipStream_t s);
 int mq_move_rows(void* d_sparse, const int32_t* d_idx, void* d_dense, int64_t n, int64_t row_bytes, bool scatter, hipStream_t s);
+int mq_rope(void* d_qkv, const int32_t* d_cu, int64_t nseq, int fixed_len, int Wa, int heads, const float* d_inv_freq, hipStream_t s);
+int mq_glu(void* d_buf, int64_t rows, int F, int quick, hipStream_t s);
 extern "C" int mq_rowquant_fp8(const float* d_x, void* d_out_fp8, float* d_row_scale, int64_t rows, int32_t W, void* stream);
 
 // layouts the ctypes binding (marqo_amd/_lib.py) and tests/test_abi.py assume
 static_assert(sizeof(mq_block_weights) == 26 * 8, "mq_block_weights layout");
-static_assert(sizeof(mq_encoder_cfg) == 64, "mq_encoder_cfg layout");
-static_assert(sizeof(mq_vit_cfg) == 112 && sizeof(mq_clip_text_cfg) == 80 && sizeof(mq_bert_cfg) == 80, "tower cfg layouts");
+static_assert(sizeof(mq_encoder_cfg) == 72, "mq_encoder_cfg layout");
+static_assert(sizeof(mq_vit_cfg) == 120 && sizeof(mq_clip_text_cfg) == 88 && sizeof(mq_bert_cfg) == 88, "tower cfg layouts");
 static_assert(sizeof(mq_vit_weights) == 10 * 8 && sizeof(mq_map_head) == 11 * 8 && sizeof(mq_clip_text_weights) == 7 * 8, "tower weight layouts");
 
 // mq_tune("row_select", 0) runs the last block on every row (A/B and parity tests of the pooled-rows-only last block)
@@ -70,7 +72,10 @@ int check_encoder_cfg(const mq_encoder_cfg* c) {
         MQ_CHECK_ARG(c->width % 128 == 0 && c->mlp_dim % 128 == 0 && wa % 128 == 0, "fp8 path needs width / mlp_dim multiples of 128");
         MQ_CHECK_ARG(c->d_fp8_act_scale, "fp8 path needs d_fp8_act_scale");
         MQ_CHECK_ARG(c->fp8_first_layer >= 0, "fp8_first_layer < 0");
+        MQ_CHECK_ARG(!c->mlp_glu && !c->d_rope_inv_freq, "the gated-MLP / rotary encoder variant runs on the bf16 path only");
     }
+    if (c->mlp_glu || c->d_rope_inv_freq)
+        MQ_CHECK_ARG(c->post_ln == 1 && wa == c->width, "the gated-MLP / rotary encoder variant is the post-LN NewModel family (un-padded heads)");
     return MQ_OK;
 }
 
@@ -83,7 +88,8 @@ int attn_width(const mq_encoder_cfg* c) { return c->attn_width ? c->attn_width :
 size_t encoder_ws(const mq_encoder_cfg* c, int64_t rows) {
     Off cv;
     const int wa = attn_width(c);
-    const size_t big = (size_t)(3 * wa > c->mlp_dim ? 3 * wa : c->mlp_dim);
+    const int fcols = c->mlp_glu ? 2 * c->mlp_dim : c->mlp_dim;   // gated MLP: fc1 writes (up | gate)
+    const size_t big = (size_t)(3 * wa > fcols ? 3 * wa : fcols);
     cv.take((size_t)rows * c->width * 2);
     cv.take((size_t)rows * wa * 2);
     cv.take((size_t)rows * big * 2);
@@ -173,7 +179,8 @@ int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* bloc
         return MQ_ERR_WORKSPACE;
     }
     const int W = cfg->width, F = cfg->mlp_dim, Wa = attn_width(cfg);
-    const size_t big = (size_t)(3 * Wa > F ? 3 * Wa : F);
+    const int fcols = cfg->mlp_glu ? 2 * F : F;
+    const size_t big = (size_t)(3 * Wa > fcols ? 3 * Wa : fcols);
     Off cv;
     char* wsb = (char*)d_workspace;
     void* h = wsb + cv.take((size_t)rows * W * 2);
@@ -195,7 +202,7 @@ int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* bloc
     // pooled-rows-only last block: worth it when it at least halves the row count; not during fp8 calibration (the
     // activation maxima must see every row); x_sel must fit behind the fc1 output inside `qf`
     const size_t xsel_off = align_up((size_t)(nsel > 0 ? nsel : 0) * F * 2, WS_ALIGN);
-    const bool select_last = d_sel && nsel > 0 && nsel * 2 <= rows && mq_tower_row_select &&
+    const bool select_last = d_sel && nsel > 0 && nsel * 2 <= rows && mq_tower_row_select && !cfg->mlp_glu && !cfg->d_rope_inv_freq &&
                              !(cfg->precision == MQ_PREC_FP8 && (cfg->d_fp8_act_amax || cfg->post_ln)) &&
                              xsel_off + (size_t)nsel * W * 4 <= (size_t)rows * big * 2;
 
@@ -279,11 +286,19 @@ int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* bloc
         } else {
             // x = ln1(x + out(attn(qkv(x)))) ; x = ln2(x + fc2(act(fc1(x))))
             MQ_TRY(mq_gemm_bf16(h, W, b.qkv_w, W, b.qkv_b, nullptr, qf, 3 * Wa, rows, 3 * Wa, W, MQ_EPI_BIAS, s));
+            if (cfg->d_rope_inv_freq) MQ_TRY(mq_rope(qf, d_cu_seqlens, nseq, fixed_len, Wa, cfg->heads, cfg->d_rope_inv_freq, s));
             MQ_TRY(mq_attention(qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, cfg->heads, cfg->mask, s));
             MQ_TRY(mq_gemm_bf16(a, Wa, b.out_w, Wa, b.out_b, d_x, d_x, W, rows, W, Wa, res_flags, s));
             MQ_TRY(mq_layernorm(d_x, nullptr, b.ln1_g, b.ln1_b, h, d_x, rows, W, cfg->ln_eps, s));
-            MQ_TRY(mq_gemm_bf16(h, W, b.fc1_w, W, b.fc1_b, nullptr, qf, F, rows, F, W, MQ_EPI_BIAS | act_flag, s));
-            MQ_TRY(mq_gemm_bf16(qf, F, b.fc2_w, F, b.fc2_b, d_x, d_x, W, rows, W, F, res_flags, s));
+            if (cfg->mlp_glu) {
+                // gated MLP: fc1 = (up | gate) rows [2F, W] (bias optional), hidden = up * act(gate) in place, fc2 reads it with lda = 2F
+                MQ_TRY(mq_gemm_bf16(h, W, b.fc1_w, W, b.fc1_b, nullptr, qf, 2 * F, rows, 2 * F, W, b.fc1_b ? MQ_EPI_BIAS : 0, s));
+                MQ_TRY(mq_glu(qf, rows, F, cfg->act == MQ_ACT_QUICKGELU, s));
+                MQ_TRY(mq_gemm_bf16(qf, 2 * F, b.fc2_w, F, b.fc2_b, d_x, d_x, W, rows, W, F, res_flags, s));
+            } else {
+                MQ_TRY(mq_gemm_bf16(h, W, b.fc1_w, W, b.fc1_b, nullptr, qf, F, rows, F, W, MQ_EPI_BIAS | act_flag, s));
+                MQ_TRY(mq_gemm_bf16(qf, F, b.fc2_w, F, b.fc2_b, d_x, d_x, W, rows, W, F, res_flags, s));
+            }
             MQ_TRY(mq_layernorm(d_x, nullptr, b.ln2_g, b.ln2_b, h, d_x, rows, W, cfg->ln_eps, s));
         }
     }
@@ -526,7 +541,7 @@ extern "C" int mq_encode_bert(const mq_bert_cfg* cfg, const mq_bert_weights* w, 
     MQ_TRY(check_encoder_cfg(&cfg->enc));
     MQ_CHECK_ARG(cfg->enc.post_ln == 1 && cfg->enc.mask == MQ_MASK_NONE, "mq_encode_bert: BERT is post-LN with full attention");
     MQ_CHECK_ARG(cfg->pool == MQ_POOL_MEAN || cfg->pool == MQ_POOL_CLS, "mq_encode_bert: bad pooling %d", cfg->pool);
-    MQ_CHECK_ARG(w->word_emb && w->pos_emb && w->type_emb && w->emb_ln_g && w->emb_ln_b, "mq_encode_bert: null weight pointer");
+    MQ_CHECK_ARG(w->word_emb && (w->pos_emb || cfg->enc.d_rope_inv_freq) && w->emb_ln_g && w->emb_ln_b, "mq_encode_bert: null weight pointer");
     if (nseq <= 0) return MQ_OK;
     MQ_CHECK_ARG(d_ids && d_cu_seqlens && h_cu_seqlens && d_workspace, "mq_encode_bert: null input / workspace");
     MQ_CHECK_ARG(h_cu_seqlens[0] == 0, "mq_encode_bert: cu_seqlens[0] must be 0");

@@ -77,10 +77,28 @@ class BertArch:
     mlp_dim: int = 3072
     ln_eps: float = 1e-12
     pos_offset: int = 0  # XLM-RoBERTa / RoBERTa checkpoints: position ids start at padding_idx + 1 = 2; max_pos counts USABLE positions
+    # "NewModel" encoders (Alibaba-NLP/new-impl: stella_en_400M_v5 = the reference's hf_stella entry, gte-*-en-v1.5): rotary positions
+    # instead of a learned table, packed qkv_proj, gated-GELU MLP (up_gate_proj [2F, W] without bias), post-LN
+    rope_theta: Optional[float] = None       # None: learned absolute positions (BERT)
+    rope_ntk_factor: Optional[float] = None  # rope_scaling {"type": "ntk", "factor": f}
+    glu: bool = False
+    type_vocab: int = 2
+
+    def rope_inv_freq(self):
+        """[head_dim / 2] inverse frequencies exactly as NewModel builds them: base^-(2i/d); with NTK scaling the module re-derives
+        its cache for max_pos * factor > max_pos at construction, which fixes base *= factor and inv_freq /= factor^(2/d) for every
+        sequence length (NTKScalingRotaryEmbedding.__init__ -> _set_cos_sin_cache, mixed_b = None)."""
+        import torch
+        d = self.width // self.heads
+        base = float(self.rope_theta) * (self.rope_ntk_factor or 1.0)
+        inv = 1.0 / (base ** (torch.arange(0, d, 2, dtype=torch.float32) / d))
+        if self.rope_ntk_factor:
+            inv = inv / (self.rope_ntk_factor ** (2.0 / d))
+        return inv
 
     def gflop_per_text(self, tokens: int) -> float:
         T, W, F = tokens, self.width, self.mlp_dim
-        layer = 2 * T * W * (3 * W) + 2 * T * W * W + 2 * 2 * T * W * F + 4 * T * T * W
+        layer = 2 * T * W * (3 * W) + 2 * T * W * W + 2 * (3 if self.glu else 2) * T * W * F + 4 * T * T * W
         return self.layers * layer / 1e9
 
 
@@ -176,10 +194,28 @@ HF_BERT_ARCHS = {
 }
 
 
+# the reference's hf_stella registry entry (model_registry.py:898-904): NewModel-large, rope theta 160000 with NTK factor 2, 8192 positions
+STELLA_EN_400M = BertArch(vocab=30528, max_pos=8192, width=1024, layers=24, heads=16, mlp_dim=4096, rope_theta=160000.0, rope_ntk_factor=2.0,
+                          glu=True)
+HF_BERT_ARCHS["Marqo/dunzhang-stella_en_400M_v5"] = STELLA_EN_400M
+
+
 def bert_arch_from_hf_config(cfg: dict) -> BertArch:
     """A local HF `config.json` -> BertArch.  model_type bert, or xlm-roberta / roberta: the same encoder with the position ids
     shifted by padding_idx + 1 (the multilingual-e5 family)."""
     mtype = cfg.get("model_type", "bert")
+    if mtype == "new":  # Alibaba-NLP/new-impl NewModel (custom remote code in the reference: hf_stella)
+        if cfg.get("position_embedding_type", "rope") != "rope" or cfg.get("hidden_act", "gelu") != "gelu":
+            raise KeyError("NewModel checkpoints are supported with rotary positions and the gated-GELU MLP")
+        if cfg.get("layer_norm_type", "layer_norm") != "layer_norm" or not cfg.get("pack_qkv", True):
+            raise KeyError("NewModel variants with rms_norm / unpacked qkv are not supported")
+        rs = cfg.get("rope_scaling") or {}
+        if rs and rs.get("type") != "ntk" or rs.get("mixed_b") is not None:
+            raise KeyError(f"rope_scaling={rs} unsupported (ntk without mixed_b only)")
+        return BertArch(vocab=cfg["vocab_size"], max_pos=cfg["max_position_embeddings"], width=cfg["hidden_size"],
+                        layers=cfg["num_hidden_layers"], heads=cfg["num_attention_heads"], mlp_dim=cfg["intermediate_size"],
+                        ln_eps=cfg.get("layer_norm_eps", 1e-12), rope_theta=float(cfg.get("rope_theta", 10000.0)),
+                        rope_ntk_factor=float(rs["factor"]) if rs else None, glu=True, type_vocab=int(cfg.get("type_vocab_size", 2)))
     if mtype not in ("bert", "xlm-roberta", "roberta"):
         raise KeyError(f"model_type={mtype} is not a BERT-family encoder")
     if cfg.get("position_embedding_type", "absolute") != "absolute":

@@ -90,17 +90,19 @@ class ImagePreprocessor:
             self._keep = p  # the packed source must outlive the enqueued kernels
         return out
 
-    def resize_u8(self, images: Sequence[ArrayLike], out_h: int, out_w: int) -> torch.Tensor:
-        """PIL.Image.resize((out_w, out_h)) (default BICUBIC) of every image -> uint8 [n, out_h, out_w, 3] on device."""
+    def resize_u8(self, images: Sequence[ArrayLike], out_h: int, out_w: int, interpolation: str = "bicubic") -> torch.Tensor:
+        """PIL.Image.resize((out_w, out_h), BICUBIC | BILINEAR) of every image -> uint8 [n, out_h, out_w, 3] on device."""
+        filt = {"bicubic": 3, "bilinear": 2}[interpolation]   # Pillow's Image.BICUBIC / Image.BILINEAR
         with torch.cuda.device(self.device):
             p = PackedImages(images, self.device)
             out = torch.empty(p.n, out_h, out_w, 3, dtype=torch.uint8, device=self.device)
             if p.n == 0:
                 return out
-            need = self.lib.mq_resize_workspace_bytes(p.heights.ctypes.data, p.widths.ctypes.data, p.n, out_h, out_w)
+            need = self.lib.mq_resize_filter_workspace_bytes(p.heights.ctypes.data, p.widths.ctypes.data, p.n, out_h, out_w, filt)
             ws = self._workspace(need)
-            L.check(self.lib.mq_resize_u8(p.buffer.data_ptr(), p.offsets.ctypes.data, p.heights.ctypes.data, p.widths.ctypes.data,
-                                          p.n, out_h, out_w, out.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()), "mq_resize_u8")
+            L.check(self.lib.mq_resize_filter_u8(p.buffer.data_ptr(), p.offsets.ctypes.data, p.heights.ctypes.data, p.widths.ctypes.data,
+                                                 p.n, out_h, out_w, filt, out.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()),
+                    "mq_resize_filter_u8")
             self._keep = p
         return out
 

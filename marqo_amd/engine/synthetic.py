@@ -96,6 +96,19 @@ def random_bert_state_dict(arch: BertArch, seed: int = 0) -> Dict[str, Tensor]:
     W, F = arch.width, arch.mlp_dim
     std = 0.6 / math.sqrt(W)
     sd: Dict[str, Tensor] = {}
+    if arch.glu or arch.rope_theta is not None:   # Alibaba-NLP NewModel naming (stella_en_400M_v5)
+        sd["embeddings.word_embeddings.weight"] = 0.5 * torch.randn(arch.vocab, W, generator=g)
+        sd["embeddings.token_type_embeddings.weight"] = 0.3 * torch.randn(2, W, generator=g)
+        _ln(sd, "embeddings.LayerNorm", W, g)
+        for i in range(arch.layers):
+            p = f"encoder.layer.{i}."
+            _lin(sd, p + "attention.qkv_proj", 3 * W, W, g, std)
+            _lin(sd, p + "attention.o_proj", W, W, g, std)
+            _ln(sd, p + "attn_ln", W, g)
+            sd[p + "mlp.up_gate_proj.weight"] = std * torch.randn(2 * F, W, generator=g)
+            _lin(sd, p + "mlp.down_proj", W, F, g, 0.6 / math.sqrt(F))
+            _ln(sd, p + "mlp_ln", W, g)
+        return sd
     sd["embeddings.word_embeddings.weight"] = 0.5 * torch.randn(arch.vocab, W, generator=g)
     sd["embeddings.position_embeddings.weight"] = 0.3 * torch.randn(arch.max_pos + arch.pos_offset, W, generator=g)
     sd["embeddings.token_type_embeddings.weight"] = 0.3 * torch.randn(2, W, generator=g)

@@ -133,7 +133,8 @@ def _encoder_cfg(width, layers, heads, mlp_dim, quick_gelu, post_ln, mask, eps) 
     return L.EncoderCfg(width=width, layers=layers, heads=heads, mlp_dim=mlp_dim,
                         act=L.MQ_ACT_QUICKGELU if quick_gelu else L.MQ_ACT_GELU,
                         post_ln=1 if post_ln else 0, mask=mask, ln_eps=eps, precision=L.MQ_PREC_BF16,
-                        attn_width=0 if d == hp else heads * hp, fp8_first_layer=0, reserved0=0, d_fp8_act_scale=None, d_fp8_act_amax=None)
+                        attn_width=0 if d == hp else heads * hp, fp8_first_layer=0, mlp_glu=0, d_fp8_act_scale=None, d_fp8_act_amax=None,
+                        d_rope_inv_freq=None)
 
 
 class _Fp8State:
@@ -796,16 +797,32 @@ class BertTower(_TextTowerBase):
         if pooling not in ("mean", "cls"):
             raise ValueError(f"pooling must be 'mean' or 'cls', got {pooling!r}")
         self.pooling = pooling
-        for prefix in ("bert.", "roberta."):  # HF checkpoints may carry the task-model prefix
+        for prefix in ("bert.", "roberta.", "new."):  # HF checkpoints may carry the task-model prefix
             if "embeddings.word_embeddings.weight" not in sd and prefix + "embeddings.word_embeddings.weight" in sd:
                 sd = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
         W, F = arch.width, arch.mlp_dim
         hd = _head_dim(W, arch.heads)
         h = self._h
         arr = (L.BlockWeights * arch.layers)()
+        new_model = arch.glu or arch.rope_theta is not None   # Alibaba-NLP NewModel naming (stella_en_400M_v5, gte-*-en-v1.5)
+        if new_model and (precision != "bf16" or hd != _kernel_head_dim(hd, arch.heads)):
+            raise ValueError("NewModel (rotary / gated-MLP) encoders run on the bf16 path with 64-wide heads")
         for i in range(arch.layers):
             p = f"encoder.layer.{i}."
             b = arr[i]
+            if new_model:
+                qkv_w = _need(sd, p + "attention.qkv_proj.weight", (3 * W, W)).detach().float()
+                qkv_b = _need(sd, p + "attention.qkv_proj.bias", (3 * W,)).detach().float()
+                b.qkv_w, b.qkv_b = h.bf16(qkv_w), h.f32(qkv_b)
+                b.out_w = h.bf16(_need(sd, p + "attention.o_proj.weight", (W, W)))
+                b.out_b = h.f32(_need(sd, p + "attention.o_proj.bias", (W,)))
+                b.ln1_g, b.ln1_b = h.f32(_need(sd, p + "attn_ln.weight", (W,))), h.f32(_need(sd, p + "attn_ln.bias", (W,)))
+                b.fc1_w = h.bf16(_need(sd, p + "mlp.up_gate_proj.weight", (2 * F, W)))      # rows [0, F) = up, [F, 2F) = gate
+                b.fc1_b = h.f32(sd[p + "mlp.up_gate_proj.bias"]) if p + "mlp.up_gate_proj.bias" in sd else None
+                b.fc2_w = h.bf16(_need(sd, p + "mlp.down_proj.weight", (W, F)))
+                b.fc2_b = h.f32(_need(sd, p + "mlp.down_proj.bias", (W,)))
+                b.ln2_g, b.ln2_b = h.f32(_need(sd, p + "mlp_ln.weight", (W,))), h.f32(_need(sd, p + "mlp_ln.bias", (W,)))
+                continue
             qkv_w = torch.cat([_need(sd, p + f"attention.self.{n}.weight", (W, W)).detach().float() for n in ("query", "key", "value")], 0)
             qkv_b = torch.cat([_need(sd, p + f"attention.self.{n}.bias", (W,)).detach().float() for n in ("query", "key", "value")], 0)
             out_w = _need(sd, p + "attention.output.dense.weight", (W, W)).detach().float()
@@ -825,15 +842,22 @@ class BertTower(_TextTowerBase):
         self._blocks = arr
         self.w = L.BertWeights(
             word_emb=h.f32(_need(sd, "embeddings.word_embeddings.weight", (arch.vocab, W))),
-            # XLM-RoBERTa: position ids start at pos_offset -> hand the library the table from that row on
-            pos_emb=h.f32(_need(sd, "embeddings.position_embeddings.weight", (arch.max_pos + arch.pos_offset, W))[arch.pos_offset:]),
-            type_emb=h.f32(_need(sd, "embeddings.token_type_embeddings.weight")),
+            # XLM-RoBERTa: position ids start at pos_offset -> hand the library the table from that row on; rotary models have no table
+            pos_emb=None if arch.rope_theta is not None else
+            h.f32(_need(sd, "embeddings.position_embeddings.weight", (arch.max_pos + arch.pos_offset, W))[arch.pos_offset:]),
+            type_emb=h.f32(sd["embeddings.token_type_embeddings.weight"]) if "embeddings.token_type_embeddings.weight" in sd or not new_model
+            else None,
             emb_ln_g=h.f32(_need(sd, "embeddings.LayerNorm.weight", (W,))),
             emb_ln_b=h.f32(_need(sd, "embeddings.LayerNorm.bias", (W,))),
             blocks=arr)
         self.cfg = L.BertCfg(enc=_encoder_cfg(W, arch.layers, arch.heads, F, False, True, L.MQ_MASK_NONE, arch.ln_eps),
                              vocab=arch.vocab, max_pos=arch.max_pos,
                              pool=L.MQ_POOL_MEAN if pooling == "mean" else L.MQ_POOL_CLS)
+        if arch.glu:
+            self.cfg.enc.mlp_glu = 1
+        if arch.rope_theta is not None:
+            self._rope = arch.rope_inv_freq().to(self.device).contiguous()
+            self.cfg.enc.d_rope_inv_freq = self._rope.data_ptr()
         if precision == "fp8":
             self._enable_fp8(self._blocks, arch.layers, W, F)
 

@@ -107,6 +107,10 @@ class HuggingFaceModel(AbstractEmbeddingModel):
                 arch = archs.bert_arch_from_hf_config(cfg)
             except KeyError as e:
                 raise InvalidModelPropertiesError(f"{props.name}: {e}. Only BERT-family encoders run on the marqo_amd engine.") from e
+            if (arch.glu or arch.rope_theta is not None) and not props.trust_remote_code:
+                # a NewModel checkpoint is custom remote code to the reference's AutoModel: refused unless trustRemoteCode is set
+                raise InvalidModelPropertiesError(f"{props.name} is a custom-code (NewModel) checkpoint: the reference loads it only with "
+                                                  f"'trustRemoteCode': True (type 'hf_stella')")
             if os.path.isfile(os.path.join(directory, "sentencepiece.bpe.model")):  # XLM-RoBERTa checkpoints (multilingual-e5)
                 self._tokenizer = XlmRobertaTokenizer(directory)
             else:
@@ -172,10 +176,11 @@ class HuggingFaceModel(AbstractEmbeddingModel):
 
 
 class HuggingFaceStellaModel(HuggingFaceModel):
-    """hf_stella (hugging_face_stella_model.py:9-23) runs custom remote code in the reference; its encoder is not a plain BERT,
-    so the engine only keeps the property validation (trustRemoteCode) and refuses at load."""
+    """hf_stella (hugging_face_stella_model.py:9-23): the reference loads `Marqo/dunzhang-stella_en_400M_v5` through
+    AutoModel(trust_remote_code=True, use_memory_efficient_attention=False, unpad_inputs=False) — Alibaba-NLP's `NewModel` encoder
+    (rotary positions, packed qkv, gated-GELU MLP, post-LN) — and keeps HuggingFaceModel.encode as is: tokenizer -> last_hidden_state
+    -> mean pooling -> F.normalize (the sentence-transformers `2_Dense` head is NOT applied: AutoModel returns the bare encoder, and
+    the registry's 1024 dimensions are its hidden size).  The engine runs that encoder natively (engine/towers.py::BertTower with
+    BertArch.glu / rope_theta; kernels rope_kernel / glu_kernel): no remote code is executed, `trustRemoteCode` is only validated like
+    the reference validates it."""
     _requires_trust_remote_code = True
-
-    def _load_necessary_components(self):
-        raise InvalidModelPropertiesError("hf_stella models run custom (remote) encoder code that is not a plain BERT; not supported by the "
-                                          "marqo_amd engine yet")

@@ -117,6 +117,9 @@ def _get_hf_properties() -> Dict:
         if pooling is not None:
             p["poolingMethod"] = pooling
         out[key] = p
+    # the hf_stella entry (model_registry.py:898-904): Alibaba-NLP NewModel encoder, run natively (no remote code)
+    out["Marqo/dunzhang-stella_en_400M_v5"] = {"name": "Marqo/dunzhang-stella_en_400M_v5", "dimensions": 1024, "tokens": 512,
+                                              "type": "hf_stella", "trustRemoteCode": True}
     return out
 
 

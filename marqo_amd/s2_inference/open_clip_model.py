@@ -34,12 +34,14 @@ MARQO_OPEN_CLIP_REGISTRY_PREFIX = "open_clip/"
 BPE_VOCAB_FILE = "bpe_simple_vocab_16e6.txt.gz"
 
 _PREPROCESSOR_NORMS = {
-    # image_preprocessor -> (mean, std, resize_mode): open_clip's _pcfg() / _slpcfg() base configs the reference starts from
-    # (open_clip_model.py:87-97).  OpenCLIP / OpenAI share the OpenAI dataset statistics (clip_utils.py:32-33) and resize the shorter
-    # side then centre-crop; SigLIP normalises with 0.5 / 0.5 and squashes the image to S x S.  (CLIPA's bilinear squash is not built.)
-    "OpenCLIP": (archs.OPENAI_DATASET_MEAN, archs.OPENAI_DATASET_STD, "shortest"),
-    "OpenAI": (archs.OPENAI_DATASET_MEAN, archs.OPENAI_DATASET_STD, "shortest"),
-    "SigLIP": ((0.5, 0.5, 0.5), (0.5, 0.5, 0.5), "squash"),
+    # image_preprocessor -> (mean, std, resize_mode, interpolation): open_clip's _pcfg() / _slpcfg() / _apcfg() base configs the
+    # reference starts from (open_clip_model.py:87-97).  OpenCLIP / OpenAI share the OpenAI dataset statistics (clip_utils.py:32-33) and
+    # resize the shorter side (bicubic) then centre-crop; SigLIP normalises with 0.5 / 0.5 and squashes the image to S x S (bicubic);
+    # CLIPA uses the ImageNet statistics and a BILINEAR squash.
+    "OpenCLIP": (archs.OPENAI_DATASET_MEAN, archs.OPENAI_DATASET_STD, "shortest", "bicubic"),
+    "OpenAI": (archs.OPENAI_DATASET_MEAN, archs.OPENAI_DATASET_STD, "shortest", "bicubic"),
+    "SigLIP": ((0.5, 0.5, 0.5), (0.5, 0.5, 0.5), "squash", "bicubic"),
+    "CLIPA": ((0.485, 0.456, 0.406), (0.229, 0.224, 0.225), "squash", "bilinear"),
 }
 _TIMM_SIGLIP = __import__("re").compile(r"^vit_(base|large|so400m)_patch1[46]_siglip_(\d+)$")
 
@@ -197,14 +199,11 @@ class OPEN_CLIP(AbstractCLIPModel):
         # get open_clip's own transform for that model (create_model_and_transforms, :183-205) — the SigLIP pipeline for SigLIP towers
         custom = props.localpath is not None
         kind = props.image_preprocessor if custom else ("SigLIP" if self.vision_arch.pool == "map" else "OpenCLIP")
-        if kind not in _PREPROCESSOR_NORMS:
-            raise InvalidModelPropertiesError(f"image_preprocessor={kind} (bilinear squash) is not supported by the marqo_amd engine yet; "
-                                              f"supported: {sorted(_PREPROCESSOR_NORMS)}")
-        mean, std, self._resize_mode = _PREPROCESSOR_NORMS[kind]
+        mean, std, self._resize_mode, self._interpolation = _PREPROCESSOR_NORMS[kind]
         self._mean = tuple(props.mean) if props.mean is not None else mean
         self._std = tuple(props.std) if props.std is not None else std
         self.preprocess_config = {"size": self.vision_arch.image_size, "mean": self._mean, "std": self._std,
-                                  "interpolation": "bicubic", "resize_mode": self._resize_mode}
+                                  "interpolation": self._interpolation, "resize_mode": self._resize_mode}
         try:
             self.vision = towers.VitTower(self.vision_arch, sd, self.device, mean=self._mean, std=self._std, precision=props.engine_precision)
             self.text = towers.ClipTextTower(self.text_arch, sd, self.device, precision=props.engine_precision)
@@ -286,7 +285,7 @@ class OPEN_CLIP(AbstractCLIPModel):
     def _resize(self, pre, raw) -> torch.Tensor:
         """list of uint8 [H, W, 3] -> uint8 [n, S, S, 3] on the device: Resize(S) + CenterCrop(S), or Resize((S, S)) ('squash')"""
         S = self.vision_arch.image_size
-        return pre.resize_u8(raw, S, S) if self._resize_mode == "squash" else pre.resize_crop_u8(raw)
+        return pre.resize_u8(raw, S, S, self._interpolation) if self._resize_mode == "squash" else pre.resize_crop_u8(raw)
 
     def _preprocess_images(self, images, image_download_headers: Optional[Dict] = None):
         """-> ('u8', uint8 [n,S,S,3]) or ('f32', fp32 [n,3,S,S]) on the device."""

@@ -297,6 +297,108 @@ def bert_forward(sd: Dict[str, Tensor], cfg: BertConfig, ids: Tensor, attention_
     return x
 
 
+@dataclass
+class NewModelConfig:
+    """Alibaba-NLP/new-impl `NewModel` (custom remote code: the reference's hf_stella loader runs it through AutoModel with
+    trust_remote_code, hugging_face_stella_model.py:9-23; stella_en_400M_v5 and gte-*-en-v1.5 use it).  PARITY UNPINNED: the remote
+    code is un-vendored and not available offline; this restates its published forward pass — rotary positions (rotate_half
+    convention, NTK-scaled base), packed qkv_proj with bias, o_proj, gated-GELU MLP (up_gate_proj without bias, down_proj with
+    bias), post-LN (attn_ln / mlp_ln), embeddings = word + token_type(0) -> LayerNorm."""
+    vocab: int = 30528
+    max_pos: int = 8192
+    width: int = 1024
+    layers: int = 24
+    heads: int = 16
+    mlp_dim: int = 4096
+    ln_eps: float = 1e-12
+    rope_theta: float = 160000.0
+    rope_ntk_factor: Optional[float] = 2.0
+    pooling: str = "mean"
+
+
+def new_model_inv_freq(cfg: NewModelConfig) -> Tensor:
+    d = cfg.width // cfg.heads
+    base = cfg.rope_theta * (cfg.rope_ntk_factor or 1.0)
+    inv = 1.0 / (base ** (torch.arange(0, d, 2, dtype=torch.float32) / d))
+    return inv / (cfg.rope_ntk_factor ** (2.0 / d)) if cfg.rope_ntk_factor else inv
+
+
+def rotate_half(x: Tensor) -> Tensor:
+    x1, x2 = x[..., : x.shape[-1] // 2], x[..., x.shape[-1] // 2:]
+    return torch.cat((-x2, x1), dim=-1)
+
+
+@torch.no_grad()
+def new_model_forward(sd: Dict[str, Tensor], cfg: NewModelConfig, ids: Tensor, attention_mask: Tensor) -> Tensor:
+    """-> last_hidden_state [B, S, W]"""
+    B, S = ids.shape
+    W, H = cfg.width, cfg.heads
+    hd = W // H
+    x = sd["embeddings.word_embeddings.weight"][ids]
+    if "embeddings.token_type_embeddings.weight" in sd:
+        x = x + sd["embeddings.token_type_embeddings.weight"][torch.zeros_like(ids)]
+    x = F.layer_norm(x, (W,), sd["embeddings.LayerNorm.weight"], sd["embeddings.LayerNorm.bias"], cfg.ln_eps)
+    freqs = torch.arange(S, dtype=torch.float32)[:, None] * new_model_inv_freq(cfg)[None, :]
+    emb = torch.cat((freqs, freqs), dim=-1)
+    cos, sin = emb.cos()[None, None], emb.sin()[None, None]          # [1, 1, S, hd]
+    add_mask = (1.0 - attention_mask[:, None, None, :].to(x.dtype)) * torch.finfo(x.dtype).min
+    for i in range(cfg.layers):
+        p = f"encoder.layer.{i}."
+        qkv = F.linear(x, sd[p + "attention.qkv_proj.weight"], sd[p + "attention.qkv_proj.bias"])
+        q, k, v = qkv.split(W, dim=-1)
+        q = q.view(B, S, H, hd).transpose(1, 2)
+        k = k.view(B, S, H, hd).transpose(1, 2)
+        v = v.view(B, S, H, hd).transpose(1, 2)
+        q, k = q * cos + rotate_half(q) * sin, k * cos + rotate_half(k) * sin
+        s = (q @ k.transpose(-1, -2)) / math.sqrt(hd) + add_mask
+        a = (torch.softmax(s, dim=-1) @ v).transpose(1, 2).reshape(B, S, W)
+        a = F.linear(a, sd[p + "attention.o_proj.weight"], sd[p + "attention.o_proj.bias"])
+        x = F.layer_norm(x + a, (W,), sd[p + "attn_ln.weight"], sd[p + "attn_ln.bias"], cfg.ln_eps)
+        up_gate = F.linear(x, sd[p + "mlp.up_gate_proj.weight"])
+        up, gate = up_gate.split(cfg.mlp_dim, dim=-1)
+        h = F.linear(F.gelu(gate) * up, sd[p + "mlp.down_proj.weight"], sd[p + "mlp.down_proj.bias"])
+        x = F.layer_norm(x + h, (W,), sd[p + "mlp_ln.weight"], sd[p + "mlp_ln.bias"], cfg.ln_eps)
+    return x
+
+
+@torch.no_grad()
+def new_model_encode(sd: Dict[str, Tensor], cfg: NewModelConfig, ids: Tensor, attention_mask: Tensor, normalize: bool = True) -> Tensor:
+    """HuggingFaceModel.encode (hugging_face_model.py:187-197) over NewModel: mean (or CLS) pool of last_hidden_state + F.normalize"""
+    last = new_model_forward(sd, cfg, ids, attention_mask)
+    if cfg.pooling == "mean":
+        last = last.masked_fill(~attention_mask[..., None].bool(), 0.0)
+        emb = last.sum(dim=1) / attention_mask.sum(dim=1)[..., None]
+    else:
+        emb = last[:, 0]
+    return F.normalize(emb, p=2, dim=1) if normalize else emb
+
+
+def synthetic_new_model_state_dict(cfg: NewModelConfig, seed: int = 0) -> Dict[str, Tensor]:
+    g = _g(seed + 9000)
+    W, Fd = cfg.width, cfg.mlp_dim
+    std = 0.6 / math.sqrt(W)
+    sd: Dict[str, Tensor] = {}
+    sd["embeddings.word_embeddings.weight"] = 0.5 * torch.randn(cfg.vocab, W, generator=g)
+    sd["embeddings.token_type_embeddings.weight"] = 0.3 * torch.randn(2, W, generator=g)
+    sd["embeddings.LayerNorm.weight"] = 1 + 0.1 * torch.randn(W, generator=g)
+    sd["embeddings.LayerNorm.bias"] = 0.05 * torch.randn(W, generator=g)
+    for i in range(cfg.layers):
+        p = f"encoder.layer.{i}."
+        sd[p + "attention.qkv_proj.weight"] = std * torch.randn(3 * W, W, generator=g)
+        sd[p + "attention.qkv_proj.weight"][: 2 * W] *= 2.0      # so that the rotary phases matter to the softmax
+        sd[p + "attention.qkv_proj.bias"] = 0.02 * torch.randn(3 * W, generator=g)
+        sd[p + "attention.o_proj.weight"] = std * torch.randn(W, W, generator=g)
+        sd[p + "attention.o_proj.bias"] = 0.02 * torch.randn(W, generator=g)
+        sd[p + "attn_ln.weight"] = 1 + 0.1 * torch.randn(W, generator=g)
+        sd[p + "attn_ln.bias"] = 0.05 * torch.randn(W, generator=g)
+        sd[p + "mlp.up_gate_proj.weight"] = std * torch.randn(2 * Fd, W, generator=g)
+        sd[p + "mlp.down_proj.weight"] = (0.6 / math.sqrt(Fd)) * torch.randn(W, Fd, generator=g)
+        sd[p + "mlp.down_proj.bias"] = 0.02 * torch.randn(W, generator=g)
+        sd[p + "mlp_ln.weight"] = 1 + 0.1 * torch.randn(W, generator=g)
+        sd[p + "mlp_ln.bias"] = 0.05 * torch.randn(W, generator=g)
+    return sd
+
+
 @torch.no_grad()
 def hf_encode(sd: Dict[str, Tensor], cfg: BertConfig, ids: Tensor, attention_mask: Tensor,
               normalize: bool = True) -> Tensor:

@@ -29,7 +29,7 @@ def test_header_symbols_are_exported_and_bound():
 
 def test_struct_layouts_match_header():
     assert C.sizeof(L.BlockWeights) == 26 * 8
-    ENC = 8 * 4 + 4 * 4 + 2 * 8
+    ENC = 8 * 4 + 4 * 4 + 3 * 8
     assert C.sizeof(L.EncoderCfg) == ENC
     assert C.sizeof(L.VitCfg) == ENC + 3 * 4 + 6 * 4 + 2 * 4 + 4  # + tail padding to 8
     assert C.sizeof(L.VitWeights) == 10 * 8 and C.sizeof(L.MapHead) == 11 * 8

@@ -91,3 +91,14 @@ def test_product_host_coefficients_match_oracle():
         b = np.zeros((count, 2), np.int32); k = np.zeros((count, ks), np.int32)
         L.check(lib.mq_resample_coeffs(n_in, n_out, first, count, b.ctypes.data, k.ctypes.data))
         assert np.array_equal(b, ob[first:]) and np.array_equal(k, ok[first:])
+
+
+def test_bilinear_filter_matches_pillow():
+    """CLIPA's preprocessing (open_clip _apcfg: BILINEAR squash): the C restatement with the triangle filter == Pillow"""
+    from PIL import Image
+    rng = np.random.default_rng(31)
+    for (h, w), (oh, ow) in [((224, 224), (224, 224)), ((300, 200), (224, 224)), ((17, 23), (224, 224)), ((1201, 1600), (224, 224)),
+                              ((64, 500), (336, 336)), ((500, 64), (96, 160))]:
+        im = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        ref = np.asarray(Image.fromarray(im).resize((ow, oh), Image.BILINEAR))
+        assert np.array_equal(OP.resize_u8(im, ow, oh, backend="c", filt=OP.FILTER_BILINEAR), ref), (h, w, oh, ow)

@@ -106,3 +106,20 @@ def test_preprocess_then_tower_equals_u8_path(pre):
     a = tower.encode_u8(u8)
     b = tower.encode_f32(pre.to_tensor_normalize(u8))
     assert torch.allclose(a, b, atol=2e-3)
+
+
+@pytest.mark.parametrize("interp,filt", [("bilinear", OP.FILTER_BILINEAR), ("bicubic", OP.FILTER_BICUBIC)])
+def test_squash_resize_filters_bit_exact_vs_pillow(pre, interp, filt):
+    """the 'squash' preprocessors: SigLIP (bicubic) and CLIPA (BILINEAR, open_clip _apcfg, selected by the reference at
+    open_clip_model.py:87-97) — PIL.Image.resize((S, S), filter) reproduced bit for bit, up- and down-scaling, extreme aspect ratios"""
+    from PIL import Image
+    imgs = _imgs([(224, 224), (300, 200), (64, 64), (17, 23), (1, 500), (1201, 1600), (449, 223), (37, 1000)], seed=21)
+    out = pre.resize_u8(imgs, 224, 224, interpolation=interp).cpu().numpy()
+    res = {"bilinear": Image.BILINEAR, "bicubic": Image.BICUBIC}[interp]
+    for i, im in enumerate(imgs):
+        ref = np.asarray(Image.fromarray(im).resize((224, 224), res))
+        assert np.array_equal(out[i], ref), f"{interp} image {i} {im.shape}: max |d| = {np.abs(out[i].astype(int) - ref.astype(int)).max()}"
+        assert np.array_equal(OP.resize_u8(im, 224, 224, backend="c", filt=filt), ref)       # and the C oracle agrees with Pillow
+    out2 = pre.resize_u8(imgs[:3], 96, 160, interpolation=interp).cpu().numpy()               # non-square target
+    for i in range(3):
+        assert np.array_equal(out2[i], np.asarray(Image.fromarray(imgs[i]).resize((160, 96), res)))
