@@ -393,9 +393,12 @@ int mq_l2_normalize(const float* d_x, float* d_out, int64_t rows, int32_t D, voi
 /* The reference tokenises on the host with third-party code (open_clip SimpleTokenizer at
  * src/marqo/core/inference/embedding_models/open_clip_model.py:277, transformers BertTokenizer at
  * .../hugging_face_model.py:179-185).  These entry points run the same published algorithms (one GPU thread per text for the
- * splitting, one per word for the vocabulary work) for
- * texts inside the device scope — printable ASCII + \t \n \r — and flag every other text (d_status[i] = 1, d_lens[i] = 0)
- * so that the caller tokenises it with the host tokeniser; results for in-scope texts are identical to the host ones.
+ * splitting, one per word for the vocabulary work) on any UTF-8 text.  Character handling is table-driven (d_unicode: one 64-bit
+ * entry per code point below 0x30000 — flags drop / whitespace / isolate / needs-host / letter / number / Hangul plus the
+ * lower-cased, accent-stripped output code points — built on the host from Python's unicodedata / str.lower / regex, so it agrees
+ * with the host tokenisers by construction).  Texts whose treatment depends on context the table cannot express (a flagged code
+ * point, a code point >= 0x30000, a word longer than the per-thread scratch) come back with d_status[i] = 1, d_lens[i] = 0 and
+ * are tokenised by the host tokeniser; every other text gets ids identical to the host ones.
  * Texts are UTF-8 bytes packed back to back: text i = d_text[d_offsets[i] .. d_offsets[i+1]).
  * The hash tables are built once per vocabulary by the host (marqo_amd/engine/gpu_tokenizers.py); layouts: tokenize_algo.h. */
 typedef struct mq_wordpiece_vocab {
@@ -403,8 +406,9 @@ typedef struct mq_wordpiece_vocab {
     const uint8_t* d_pool;    /* piece bytes (without the "##" prefix) */
     uint32_t n_slots;         /* power of two */
     int32_t unk_id, cls_id, sep_id, pad_id;
-    int32_t lower;            /* do_lower_case */
+    int32_t lower;            /* do_lower_case (informational: the behaviour is in d_unicode) */
     int32_t max_word_chars;   /* 100 */
+    const uint64_t* d_unicode;  /* [0x30000] character table for this vocabulary's basic tokenisation (tokenize_algo.h) */
 } mq_wordpiece_vocab;
 
 typedef struct mq_clip_bpe_vocab {
@@ -414,6 +418,7 @@ typedef struct mq_clip_bpe_vocab {
     uint32_t n_slots;               /* power of two */
     int32_t sot_id, eot_id;
     int32_t lower;
+    const uint64_t* d_unicode;      /* [0x30000] character table: lower-casing + the \s / \p{L} / \p{N} classes of the pre-tokeniser regex */
 } mq_clip_bpe_vocab;
 
 /* Scratch of one tokenisation call (spans, counts, per-byte piece slots): total_bytes = d_offsets[n], cap_tokens = max_length

@@ -98,12 +98,12 @@ class BertCfg(C.Structure):
 
 class WordPieceVocab(C.Structure):
     _fields_ = [("d_slots", C.c_void_p), ("d_pool", C.c_void_p), ("n_slots", C.c_uint32), ("unk_id", C.c_int32), ("cls_id", C.c_int32),
-                ("sep_id", C.c_int32), ("pad_id", C.c_int32), ("lower", C.c_int32), ("max_word_chars", C.c_int32)]
+                ("sep_id", C.c_int32), ("pad_id", C.c_int32), ("lower", C.c_int32), ("max_word_chars", C.c_int32), ("d_unicode", C.c_void_p)]
 
 
 class ClipBpeVocab(C.Structure):
     _fields_ = [("d_slots", C.c_void_p), ("d_byte_id", C.c_void_p), ("d_byte_end_id", C.c_void_p), ("n_slots", C.c_uint32),
-                ("sot_id", C.c_int32), ("eot_id", C.c_int32), ("lower", C.c_int32)]
+                ("sot_id", C.c_int32), ("eot_id", C.c_int32), ("lower", C.c_int32), ("d_unicode", C.c_void_p)]
 
 
 _P = C.c_void_p

@@ -9,93 +9,100 @@
 #include "tokenize_algo.h"
 
 static_assert(sizeof(mq_wp_entry) == 16 && sizeof(mq_bpe_entry) == 16, "hash-table entry layouts (mirrored in engine/gpu_tokenizers.py)");
+static_assert(sizeof(mq_wordpiece_vocab) == 56 && sizeof(mq_clip_bpe_vocab) == 48, "tokeniser vocabulary structs (mirrored in _lib.py)");
 
 namespace {
 
 constexpr int TOK_THREADS = 64;
 
-// workspace of one call: spans u32 [n, cap] | totals i32 [n] | counts u8 [n, cap] | pieces (i32 per text byte: WordPiece; u16: BPE)
+// workspace of one call: spans u64 [n, cap] | totals i32 [n] | counts i16 [n, cap] | norm u8 (normalised text: text i at 3 * offsets[i]
+// + 16 i) | pieces (one slot per normalised byte: i32 WordPiece, u16 BPE)
 struct TokWs {
-    uint32_t* spans; int32_t* totals; uint8_t* counts; void* pieces; size_t bytes;
+    uint64_t* spans; int32_t* totals; int16_t* counts; uint8_t* norm; void* pieces; size_t bytes;
 };
+__host__ __device__ inline int64_t norm_base(int64_t byte_offset, int64_t t) { return 3 * byte_offset + 16 * t; }
 TokWs tok_ws(void* base, int64_t n, int64_t total_bytes, int cap, int piece_size) {
     TokWs w;
     size_t off = 0;
     auto take = [&](size_t b) { const size_t o = off; off = align_up(off + b, 256); return o; };
-    const size_t o_sp = take((size_t)n * cap * 4), o_tot = take((size_t)n * 4), o_cnt = take((size_t)n * cap), o_pc = take((size_t)(total_bytes + 16) * piece_size);
-    w.spans = (uint32_t*)((char*)base + o_sp); w.totals = (int32_t*)((char*)base + o_tot); w.counts = (uint8_t*)((char*)base + o_cnt);
-    w.pieces = (char*)base + o_pc; w.bytes = off;
+    const size_t norm_bytes = (size_t)norm_base(total_bytes, n) + 16;
+    const size_t o_sp = take((size_t)n * cap * 8), o_tot = take((size_t)n * 4), o_cnt = take((size_t)n * cap * 2), o_nm = take(norm_bytes),
+                 o_pc = take(norm_bytes * piece_size);
+    w.spans = (uint64_t*)((char*)base + o_sp); w.totals = (int32_t*)((char*)base + o_tot); w.counts = (int16_t*)((char*)base + o_cnt);
+    w.norm = (uint8_t*)base + o_nm; w.pieces = (char*)base + o_pc; w.bytes = off;
     return w;
 }
 
 // ---- phase A: one thread per text, no table access ---------------------------------------------------------------------
 template <bool BPE>
-__global__ __launch_bounds__(TOK_THREADS) void split_kernel(const uint8_t* __restrict__ text, const int64_t* __restrict__ offsets, int n, int cap,
-                                                            uint32_t* __restrict__ spans, int32_t* __restrict__ totals,
-                                                            int32_t* __restrict__ status) {
+__global__ __launch_bounds__(TOK_THREADS) void split_kernel(mq_uni_table U, const uint8_t* __restrict__ text, const int64_t* __restrict__ offsets, int n,
+                                                            int cap, uint64_t* __restrict__ spans, uint8_t* __restrict__ norm,
+                                                            int32_t* __restrict__ totals, int32_t* __restrict__ status) {
     const int t = blockIdx.x * TOK_THREADS + threadIdx.x;
     if (t >= n) return;
     const int64_t b0 = offsets[t], b1 = offsets[t + 1];
     int st;
-    const int cnt = BPE ? mq_clip_split(text + b0, (int)(b1 - b0), cap, spans + (int64_t)t * cap, &st)
-                        : mq_wp_split(text + b0, (int)(b1 - b0), cap, spans + (int64_t)t * cap, &st);
+    const int cnt = BPE ? mq_clip_split(U, text + b0, (int)(b1 - b0), cap, spans + (int64_t)t * cap, norm + norm_base(b0, t), &st)
+                        : mq_wp_split(U, text + b0, (int)(b1 - b0), cap, spans + (int64_t)t * cap, norm + norm_base(b0, t), &st);
     totals[t] = cnt;
     status[t] = st;
 }
 
 // ---- phase B: one thread per word / pre-token (the table lookups); scratch in LDS, lane-strided -------------------------
-__global__ __launch_bounds__(TOK_THREADS) void wp_pieces_kernel(mq_wp_table T, const uint8_t* __restrict__ text, const int64_t* __restrict__ offsets,
-                                                                int cap, int blocks_per_text, const uint32_t* __restrict__ spans,
-                                                                const int32_t* __restrict__ totals, uint8_t* __restrict__ counts,
-                                                                int32_t* __restrict__ pieces) {
+__global__ __launch_bounds__(TOK_THREADS) void wp_pieces_kernel(mq_wp_table T, const uint8_t* __restrict__ norm, const int64_t* __restrict__ offsets,
+                                                                int cap, int blocks_per_text, const uint64_t* __restrict__ spans,
+                                                                const int32_t* __restrict__ totals, int16_t* __restrict__ counts,
+                                                                int32_t* __restrict__ pieces, int32_t* __restrict__ status) {
     __shared__ uint8_t word[MQ_WP_MAX_WORD * TOK_THREADS];
     const int t = blockIdx.x / blocks_per_text;
     const int j = (blockIdx.x - t * blocks_per_text) * TOK_THREADS + threadIdx.x;
     const int nw = min(totals[t], cap);
     if (j >= nw) return;
-    const int64_t b0 = offsets[t];
-    const uint32_t span = spans[(int64_t)t * cap + j];
-    counts[(int64_t)t * cap + j] = (uint8_t)mq_wp_pieces(T, text + b0, span, pieces + b0 + (span >> 8), word + threadIdx.x, TOK_THREADS);
+    const int64_t nb = norm_base(offsets[t], t);
+    const uint64_t span = spans[(int64_t)t * cap + j];
+    const int c = mq_wp_pieces(T, norm + nb, span, pieces + nb + mq_span_start(span), word + threadIdx.x, TOK_THREADS);
+    if (c < 0) status[t] = MQ_TOK_NEEDS_HOST;   // (benign race: every writer stores the same value)
+    counts[(int64_t)t * cap + j] = (int16_t)(c < 0 ? 0 : c);
 }
 
-__global__ __launch_bounds__(TOK_THREADS) void bpe_merge_kernel(mq_bpe_table T, const uint8_t* __restrict__ text, const int64_t* __restrict__ offsets,
-                                                                int cap, int blocks_per_text, const uint32_t* __restrict__ spans,
-                                                                const int32_t* __restrict__ totals, uint8_t* __restrict__ counts,
+__global__ __launch_bounds__(TOK_THREADS) void bpe_merge_kernel(mq_bpe_table T, const uint8_t* __restrict__ norm, const int64_t* __restrict__ offsets,
+                                                                int cap, int blocks_per_text, const uint64_t* __restrict__ spans,
+                                                                const int32_t* __restrict__ totals, int16_t* __restrict__ counts,
                                                                 uint16_t* __restrict__ syms) {
     __shared__ uint16_t sym[MQ_BPE_MAX_SYMS * TOK_THREADS];
     const int t = blockIdx.x / blocks_per_text;
     const int j = (blockIdx.x - t * blocks_per_text) * TOK_THREADS + threadIdx.x;
     const int nw = min(totals[t], cap);
     if (j >= nw) return;
-    const int64_t b0 = offsets[t];
-    const uint32_t span = spans[(int64_t)t * cap + j];
-    counts[(int64_t)t * cap + j] = (uint8_t)mq_clip_merge_span(T, text + b0, span, syms + b0 + (span >> 8), sym + threadIdx.x, TOK_THREADS);
+    const int64_t nb = norm_base(offsets[t], t);
+    const uint64_t span = spans[(int64_t)t * cap + j];
+    counts[(int64_t)t * cap + j] = (int16_t)mq_clip_merge_span(T, norm + nb, span, syms + nb + mq_span_start(span), sym + threadIdx.x, TOK_THREADS);
 }
 
 // ---- phase C: one thread per text, copies only ----------------------------------------------------------------------------
 __global__ __launch_bounds__(TOK_THREADS) void wp_gather_kernel(mq_wp_table T, const int64_t* __restrict__ offsets, int n, int cap, int max_tokens,
-                                                                const uint32_t* __restrict__ spans, const int32_t* __restrict__ totals,
-                                                                const uint8_t* __restrict__ counts, const int32_t* __restrict__ pieces,
+                                                                const uint64_t* __restrict__ spans, const int32_t* __restrict__ totals,
+                                                                const int16_t* __restrict__ counts, const int32_t* __restrict__ pieces,
                                                                 int32_t* __restrict__ ids, int64_t ld, int32_t* __restrict__ lens,
                                                                 const int32_t* __restrict__ status) {
     const int t = blockIdx.x * TOK_THREADS + threadIdx.x;
     if (t >= n) return;
     const int ok = status[t] == MQ_TOK_OK;
-    const int len = mq_wp_gather(T, spans + (int64_t)t * cap, counts + (int64_t)t * cap, pieces + offsets[t], ok ? min(totals[t], cap) : 0, max_tokens,
-                                 ids + (int64_t)t * ld, (int)ld);
+    const int len = mq_wp_gather(T, spans + (int64_t)t * cap, counts + (int64_t)t * cap, pieces + norm_base(offsets[t], t), ok ? min(totals[t], cap) : 0,
+                                 max_tokens, ids + (int64_t)t * ld, (int)ld);
     lens[t] = ok ? len : 0;
 }
 
 __global__ __launch_bounds__(TOK_THREADS) void bpe_gather_kernel(mq_bpe_table T, const int64_t* __restrict__ offsets, int n, int cap, int ctx,
-                                                                 const uint32_t* __restrict__ spans, const int32_t* __restrict__ totals,
-                                                                 const uint8_t* __restrict__ counts, const uint16_t* __restrict__ syms,
+                                                                 const uint64_t* __restrict__ spans, const int32_t* __restrict__ totals,
+                                                                 const int16_t* __restrict__ counts, const uint16_t* __restrict__ syms,
                                                                  int32_t* __restrict__ ids, int32_t* __restrict__ lens,
                                                                  const int32_t* __restrict__ status) {
     const int t = blockIdx.x * TOK_THREADS + threadIdx.x;
     if (t >= n) return;
     const int ok = status[t] == MQ_TOK_OK;
     const int tot = ok ? totals[t] : 0;
-    const int len = mq_clip_gather(T, spans + (int64_t)t * cap, counts + (int64_t)t * cap, syms + offsets[t], min(tot, cap), tot, ctx,
+    const int len = mq_clip_gather(T, spans + (int64_t)t * cap, counts + (int64_t)t * cap, syms + norm_base(offsets[t], t), min(tot, cap), tot, ctx,
                                    ids + (int64_t)t * ctx);
     lens[t] = ok ? len : 0;
 }
@@ -120,8 +127,8 @@ extern "C" size_t mq_tokenize_workspace_bytes(int64_t n, int64_t total_bytes, in
 extern "C" int mq_tokenize_wordpiece(const mq_wordpiece_vocab* v, const uint8_t* d_text, const int64_t* d_offsets, int64_t n,
                                      int64_t total_bytes, int32_t max_length, int32_t* d_ids, int64_t ld, int32_t* d_lens,
                                      int32_t* d_status, void* d_workspace, size_t workspace_bytes, void* stream) {
-    MQ_CHECK_ARG(v && v->d_slots && v->d_pool && pow2(v->n_slots), "mq_tokenize_wordpiece: bad vocabulary table");
-    MQ_CHECK_ARG(v->max_word_chars >= 1 && v->max_word_chars <= MQ_WP_MAX_WORD - 4, "mq_tokenize_wordpiece: max_word_chars %d unsupported",
+    MQ_CHECK_ARG(v && v->d_slots && v->d_pool && v->d_unicode && pow2(v->n_slots), "mq_tokenize_wordpiece: bad vocabulary table");
+    MQ_CHECK_ARG(v->max_word_chars >= 1 && v->max_word_chars <= MQ_WP_MAX_WORD, "mq_tokenize_wordpiece: max_word_chars %d unsupported",
                  v->max_word_chars);
     MQ_CHECK_ARG(max_length >= 2 && ld >= max_length, "mq_tokenize_wordpiece: need 2 <= max_length (%d) <= ld (%ld)", max_length, (long)ld);
     if (n <= 0) return MQ_OK;
@@ -139,9 +146,11 @@ extern "C" int mq_tokenize_wordpiece(const mq_wordpiece_vocab* v, const uint8_t*
     MqProfScope prof(3, s);
     const unsigned per_text = (unsigned)cdiv64(n, TOK_THREADS);
     const int bpt = (cap + TOK_THREADS - 1) / TOK_THREADS;
-    hipLaunchKernelGGL(split_kernel<false>, dim3(per_text), dim3(TOK_THREADS), 0, s, d_text, d_offsets, (int)n, cap, w.spans, w.totals, d_status);
-    hipLaunchKernelGGL(wp_pieces_kernel, dim3((unsigned)(n * bpt)), dim3(TOK_THREADS), 0, s, T, d_text, d_offsets, cap, bpt, w.spans, w.totals, w.counts,
-                       (int32_t*)w.pieces);
+    const mq_uni_table U{v->d_unicode};
+    hipLaunchKernelGGL(split_kernel<false>, dim3(per_text), dim3(TOK_THREADS), 0, s, U, d_text, d_offsets, (int)n, cap, w.spans, w.norm, w.totals,
+                       d_status);
+    hipLaunchKernelGGL(wp_pieces_kernel, dim3((unsigned)(n * bpt)), dim3(TOK_THREADS), 0, s, T, w.norm, d_offsets, cap, bpt, w.spans, w.totals, w.counts,
+                       (int32_t*)w.pieces, d_status);
     hipLaunchKernelGGL(wp_gather_kernel, dim3(per_text), dim3(TOK_THREADS), 0, s, T, d_offsets, (int)n, cap, max_tokens, w.spans, w.totals, w.counts,
                        (const int32_t*)w.pieces, d_ids, ld, d_lens, d_status);
     MQ_CHECK_LAUNCH("mq_tokenize_wordpiece");
@@ -151,7 +160,7 @@ extern "C" int mq_tokenize_wordpiece(const mq_wordpiece_vocab* v, const uint8_t*
 extern "C" int mq_tokenize_clip_bpe(const mq_clip_bpe_vocab* v, const uint8_t* d_text, const int64_t* d_offsets, int64_t n,
                                     int64_t total_bytes, int32_t ctx, int32_t* d_ids, int32_t* d_lens, int32_t* d_status,
                                     void* d_workspace, size_t workspace_bytes, void* stream) {
-    MQ_CHECK_ARG(v && v->d_slots && v->d_byte_id && v->d_byte_end_id && pow2(v->n_slots), "mq_tokenize_clip_bpe: bad merge table");
+    MQ_CHECK_ARG(v && v->d_slots && v->d_byte_id && v->d_byte_end_id && v->d_unicode && pow2(v->n_slots), "mq_tokenize_clip_bpe: bad merge table");
     MQ_CHECK_ARG(ctx >= 2, "mq_tokenize_clip_bpe: context length %d < 2", ctx);
     if (n <= 0) return MQ_OK;
     MQ_CHECK_ARG(d_text && d_offsets && d_ids && d_lens && d_status && d_workspace, "mq_tokenize_clip_bpe: null pointer");
@@ -166,8 +175,10 @@ extern "C" int mq_tokenize_clip_bpe(const mq_clip_bpe_vocab* v, const uint8_t* d
     MqProfScope prof(3, s);
     const unsigned per_text = (unsigned)cdiv64(n, TOK_THREADS);
     const int bpt = (cap + TOK_THREADS - 1) / TOK_THREADS;
-    hipLaunchKernelGGL(split_kernel<true>, dim3(per_text), dim3(TOK_THREADS), 0, s, d_text, d_offsets, (int)n, cap, w.spans, w.totals, d_status);
-    hipLaunchKernelGGL(bpe_merge_kernel, dim3((unsigned)(n * bpt)), dim3(TOK_THREADS), 0, s, T, d_text, d_offsets, cap, bpt, w.spans, w.totals, w.counts,
+    const mq_uni_table U{v->d_unicode};
+    hipLaunchKernelGGL(split_kernel<true>, dim3(per_text), dim3(TOK_THREADS), 0, s, U, d_text, d_offsets, (int)n, cap, w.spans, w.norm, w.totals,
+                       d_status);
+    hipLaunchKernelGGL(bpe_merge_kernel, dim3((unsigned)(n * bpt)), dim3(TOK_THREADS), 0, s, T, w.norm, d_offsets, cap, bpt, w.spans, w.totals, w.counts,
                        (uint16_t*)w.pieces);
     hipLaunchKernelGGL(bpe_gather_kernel, dim3(per_text), dim3(TOK_THREADS), 0, s, T, d_offsets, (int)n, cap, ctx, w.spans, w.totals, w.counts,
                        (const uint16_t*)w.pieces, d_ids, d_lens, d_status);

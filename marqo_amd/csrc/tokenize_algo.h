@@ -9,9 +9,13 @@
 //   CLIP BPE   open_clip 2.24.0 SimpleTokenizer (lower-case, regex pre-split, byte-level BPE merges by rank), called at
 //              src/marqo/core/inference/embedding_models/open_clip_model.py:277
 //
-// Scope of the device path: texts made only of printable ASCII plus \t \n \r (the host routes every other text — and texts
-// that spell a special token or an HTML entity — through the Python tokenisers, exactly as the reference tokenises on the
-// host).  Inside that scope the functions are EXACT: every table hit is verified byte for byte.
+// Scope of the device path: any UTF-8 text.  Character handling (whitespace / punctuation / CJK isolation / control removal /
+// lower-casing / accent stripping by canonical decomposition / letter and number classes) is table-driven: one 64-bit entry per
+// code point below MQ_UNI_LIMIT, built on the host from Python's own `unicodedata` / `str.lower` / `regex` so that it agrees with the
+// host tokenisers by construction (engine/gpu_tokenizers.py::build_unicode_table).  The few code points whose treatment depends on
+// their NEIGHBOURS (Greek capital sigma's final form, combining marks under a cased vocabulary's NFC step, ...) carry a flag that
+// hands the whole text back to the host tokeniser — as do texts that spell a special token or an HTML entity.  Inside that scope
+// the functions are EXACT: every vocabulary hit is verified byte for byte.
 #pragma once
 #include <stdint.h>
 
@@ -47,17 +51,78 @@ struct mq_wp_table {
 #define MQ_FNV_OFFSET 0xcbf29ce484222325ULL
 #define MQ_FNV_PRIME 0x100000001b3ULL
 #define MQ_WP_CONT_SEED 0x9e3779b97f4a7c15ULL
-#define MQ_WP_MAX_WORD 104  // scratch bytes per text for the current word (max_word_chars = 100)
+#define MQ_WP_MAX_WORD 256  // scratch bytes per thread for the current word (max_word_chars = 100 characters; longer byte strings go to the host)
 
 MQ_TOK_FN uint64_t mq_wp_seed(int cont) { return cont ? (MQ_FNV_OFFSET ^ MQ_WP_CONT_SEED) : MQ_FNV_OFFSET; }
 MQ_TOK_FN uint64_t mq_wp_step(uint64_t h, uint8_t c) { return (h ^ (uint64_t)c) * MQ_FNV_PRIME; }
 
-MQ_TOK_FN int mq_is_ws(uint8_t c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r'; }
-MQ_TOK_FN int mq_is_ascii_punct(uint8_t c) {
-    return (c >= 33 && c <= 47) || (c >= 58 && c <= 64) || (c >= 91 && c <= 96) || (c >= 123 && c <= 126);
-}
 MQ_TOK_FN uint8_t mq_lower(uint8_t c) { return (c >= 'A' && c <= 'Z') ? (uint8_t)(c + 32) : c; }
-MQ_TOK_FN int mq_in_scope(uint8_t c) { return (c >= 0x20 && c <= 0x7e) || c == '\t' || c == '\n' || c == '\r'; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Unicode character table: entry(cp) for cp < limit
+//   bits 0-7   flags
+//   bits 8-9   number of output code points (0..2) after the tokeniser's per-character normalisation
+//   bits 10-30 first output code point, bits 31-51 second output code point
+// ---------------------------------------------------------------------------------------------------------------
+#define MQ_UNI_LIMIT 0x30000u
+#define MQ_U_DROP 0x01u     // removed from the text (control characters, U+0000, U+FFFD; stripped accents)
+#define MQ_U_WS 0x02u       // whitespace: separates words
+#define MQ_U_ISOLATE 0x04u  // a word of its own (punctuation, CJK ideographs)
+#define MQ_U_HOST 0x08u     // context-dependent treatment: the whole text goes to the host tokeniser
+#define MQ_U_LETTER 0x10u   // \p{L}   (CLIP pre-tokenisation)
+#define MQ_U_NUMBER 0x20u   // \p{N}
+#define MQ_U_HANGUL 0x40u   // precomposed Hangul syllable under an accent-stripping vocabulary: arithmetic decomposition into jamo
+#define MQ_U_STRIP 0x80u    // CLIP: removed by Python's str.strip() at the ends of the text although the regex's \\s does not match it
+                            // (U+001C..U+001F); regex-whitespace characters are strippable too
+
+struct mq_uni_table {
+    const uint64_t* e;
+};
+
+MQ_TOK_FN uint32_t mq_u_flags(uint64_t e) { return (uint32_t)(e & 0xffu); }
+MQ_TOK_FN int mq_u_nout(uint64_t e) { return (int)((e >> 8) & 3u); }
+MQ_TOK_FN uint32_t mq_u_cp0(uint64_t e) { return (uint32_t)((e >> 10) & 0x1fffffu); }
+MQ_TOK_FN uint32_t mq_u_cp1(uint64_t e) { return (uint32_t)((e >> 31) & 0x1fffffu); }
+
+// next code point of well-formed UTF-8: returns its length in bytes (1..4), 0 when malformed / truncated
+MQ_TOK_FN int mq_utf8_next(const uint8_t* s, int n, int i, uint32_t* cp) {
+    const uint8_t c = s[i];
+    if (c < 0x80) { *cp = c; return 1; }
+    int len;
+    uint32_t v;
+    if ((c & 0xe0) == 0xc0) { len = 2; v = c & 0x1fu; }
+    else if ((c & 0xf0) == 0xe0) { len = 3; v = c & 0x0fu; }
+    else if ((c & 0xf8) == 0xf0) { len = 4; v = c & 0x07u; }
+    else return 0;
+    if (i + len > n) return 0;
+    for (int k = 1; k < len; ++k) {
+        const uint8_t d = s[i + k];
+        if ((d & 0xc0) != 0x80) return 0;
+        v = (v << 6) | (d & 0x3fu);
+    }
+    *cp = v;
+    return len;
+}
+
+MQ_TOK_FN int mq_utf8_put(uint32_t cp, uint8_t* o) {
+    if (cp < 0x80) { o[0] = (uint8_t)cp; return 1; }
+    if (cp < 0x800) { o[0] = (uint8_t)(0xc0 | (cp >> 6)); o[1] = (uint8_t)(0x80 | (cp & 0x3f)); return 2; }
+    if (cp < 0x10000) { o[0] = (uint8_t)(0xe0 | (cp >> 12)); o[1] = (uint8_t)(0x80 | ((cp >> 6) & 0x3f)); o[2] = (uint8_t)(0x80 | (cp & 0x3f)); return 3; }
+    o[0] = (uint8_t)(0xf0 | (cp >> 18)); o[1] = (uint8_t)(0x80 | ((cp >> 12) & 0x3f)); o[2] = (uint8_t)(0x80 | ((cp >> 6) & 0x3f));
+    o[3] = (uint8_t)(0x80 | (cp & 0x3f));
+    return 4;
+}
+
+// word / pre-token span in the NORMALISED text of one input text: (first byte << 32) | (bytes << 16) | characters
+MQ_TOK_FN uint64_t mq_span(int start, int nbytes, int nchars) {
+    return ((uint64_t)(uint32_t)start << 32) | ((uint64_t)(nbytes < 0xffff ? nbytes : 0xffff) << 16) | (uint64_t)(nchars < 0xffff ? nchars : 0xffff);
+}
+MQ_TOK_FN int mq_span_start(uint64_t s) { return (int)(s >> 32); }
+MQ_TOK_FN int mq_span_bytes(uint64_t s) { return (int)((s >> 16) & 0xffffu); }
+MQ_TOK_FN int mq_span_chars(uint64_t s) { return (int)(s & 0xffffu); }
+// normalised bytes one input text of nbytes can produce: a 3-byte Hangul syllable becomes three 3-byte jamo, a 2-byte letter may
+// lower-case / decompose into two 3-byte code points
+MQ_TOK_FN int64_t mq_norm_capacity(int64_t nbytes) { return 3 * nbytes + 16; }
 
 // word bytes live in scratch `w` with element stride `ws` (LDS lane-strided on the device, 1 on the host)
 MQ_TOK_FN int32_t mq_wp_lookup(const mq_wp_table& T, uint64_t h, const uint8_t* w, int ws, int start, int len, int cont) {
@@ -76,11 +141,12 @@ MQ_TOK_FN int32_t mq_wp_lookup(const mq_wp_table& T, uint64_t h, const uint8_t* 
     }
 }
 
-// Greedy longest-match-first WordPiece of the word w[0..L): appends ids at out[*cnt ...] (only positions < cap are
-// written, *cnt always advances); a word with an unmatchable remainder becomes ONE unk token.
-MQ_TOK_FN void mq_wp_word(const mq_wp_table& T, const uint8_t* w, int ws, int L, int32_t* out, int os, int cap, int* cnt) {
+// Greedy longest-match-first WordPiece of the word w[0..L) (UTF-8 bytes, `nchars` characters): appends ids at out[*cnt ...] (only
+// positions < cap are written, *cnt always advances); a word with an unmatchable remainder becomes ONE unk token.  Pieces start and
+// end on character boundaries (the host matches substrings of the character string).
+MQ_TOK_FN void mq_wp_word(const mq_wp_table& T, const uint8_t* w, int ws, int L, int nchars, int32_t* out, int os, int cap, int* cnt) {
     const int c0 = *cnt;
-    if (L > T.max_word_chars) {
+    if (nchars > T.max_word_chars) {
         if (c0 < cap) out[c0 * os] = T.unk_id;
         *cnt = c0 + 1;
         return;
@@ -92,6 +158,8 @@ MQ_TOK_FN void mq_wp_word(const mq_wp_table& T, const uint8_t* w, int ws, int L,
         int32_t best_id = -1;
         for (int e = start; e < L; ++e) {
             h = mq_wp_step(h, w[e * ws]);
+            if (e + 1 < L && (w[(e + 1) * ws] & 0xc0) == 0x80) continue;   // inside a character
+            if (e + 1 - start > 127) break;                                   // no vocabulary piece is that long
             const int32_t id = mq_wp_lookup(T, h, w, ws, start, e + 1 - start, start > 0);
             if (id >= 0) { best_end = e + 1; best_id = id; }
         }
@@ -109,56 +177,78 @@ MQ_TOK_FN void mq_wp_word(const mq_wp_table& T, const uint8_t* w, int ws, int L,
 
 // The work of one text is split into three phases so that the expensive part (hash-table lookups) runs one GPU thread per
 // WORD instead of per text:
-//   A  mq_wp_split   (per text)  basic tokenisation -> word spans  (start << 8 | min(len, 255)); no table access
-//   B  mq_wp_pieces  (per word)  lower-case + greedy WordPiece -> piece ids, stored at the word's own byte positions
+//   A  mq_wp_split   (per text)  basic tokenisation: decode UTF-8, per-character table (drop / whitespace / isolate / lower-case +
+//                                accent strip), write the NORMALISED bytes and the word spans; no vocabulary access
+//   B  mq_wp_pieces  (per word)  greedy WordPiece -> piece ids, stored at the word's own (normalised) byte positions
 //   C  mq_wp_gather  (per text)  concatenate the pieces, truncate, add [CLS] / [SEP], pad
-// Basic tokenisation for in-scope bytes: whitespace splits, every ASCII punctuation char is its own word, the rest are words;
-// accent stripping / NFC / CJK / control-char removal never fire for these bytes.
 
 // A: returns the number of words found, at most `cap` of them written (a word yields >= 1 id, so words beyond max_tokens can
-// never reach the output); *status = MQ_TOK_NEEDS_HOST when a byte is outside the device scope.
-MQ_TOK_FN int mq_wp_split(const uint8_t* text, int nbytes, int cap, uint32_t* spans, int* status) {
-    int cnt = 0, i = 0;
+// never reach the output); *status = MQ_TOK_NEEDS_HOST when the text needs the host tokeniser.  norm has mq_norm_capacity(nbytes) bytes.
+MQ_TOK_FN int mq_wp_split(const mq_uni_table& U, const uint8_t* text, int nbytes, int cap, uint64_t* spans, uint8_t* norm, int* status) {
+    int cnt = 0, i = 0, pos = 0, wstart = -1, wchars = 0;
     *status = MQ_TOK_OK;
     while (i < nbytes) {
-        const uint8_t c = text[i];
-        if (!mq_in_scope(c)) { *status = MQ_TOK_NEEDS_HOST; return 0; }
-        if (mq_is_ws(c)) { ++i; continue; }
-        const int start = i;
-        if (mq_is_ascii_punct(c)) {
-            ++i;
-        } else {
-            while (i < nbytes) {
-                const uint8_t d = text[i];
-                if (!mq_in_scope(d)) { *status = MQ_TOK_NEEDS_HOST; return 0; }
-                if (mq_is_ws(d) || mq_is_ascii_punct(d)) break;
-                ++i;
+        uint32_t cp;
+        const int len = mq_utf8_next(text, nbytes, i, &cp);
+        if (len == 0 || cp >= MQ_UNI_LIMIT) { *status = MQ_TOK_NEEDS_HOST; return 0; }
+        i += len;
+        const uint64_t e = U.e[cp];
+        const uint32_t f = mq_u_flags(e);
+        if (f & MQ_U_HOST) { *status = MQ_TOK_NEEDS_HOST; return 0; }
+        if (f & MQ_U_DROP) continue;
+        if (f & (MQ_U_WS | MQ_U_ISOLATE)) {
+            if (wstart >= 0) {
+                if (cnt < cap) spans[cnt] = mq_span(wstart, pos - wstart, wchars);
+                ++cnt;
+                wstart = -1;
             }
+            if (f & MQ_U_ISOLATE) {
+                const int s0 = pos;
+                pos += mq_utf8_put(mq_u_cp0(e), norm + pos);
+                if (cnt < cap) spans[cnt] = mq_span(s0, pos - s0, 1);
+                ++cnt;
+            }
+            continue;
         }
-        const int len = i - start;
-        if (cnt < cap) spans[cnt] = ((uint32_t)start << 8) | (uint32_t)(len < 255 ? len : 255);
+        if (wstart < 0) { wstart = pos; wchars = 0; }
+        if (f & MQ_U_HANGUL) {  // NFD of a precomposed syllable: L V (T) conjoining jamo
+            const uint32_t sidx = cp - 0xac00u, tj = sidx % 28u;
+            pos += mq_utf8_put(0x1100u + sidx / 588u, norm + pos);
+            pos += mq_utf8_put(0x1161u + (sidx % 588u) / 28u, norm + pos);
+            wchars += 2;
+            if (tj) { pos += mq_utf8_put(0x11a7u + tj, norm + pos); ++wchars; }
+            continue;
+        }
+        const int no = mq_u_nout(e);
+        if (no >= 1) { pos += mq_utf8_put(mq_u_cp0(e), norm + pos); ++wchars; }
+        if (no >= 2) { pos += mq_utf8_put(mq_u_cp1(e), norm + pos); ++wchars; }
+    }
+    if (wstart >= 0) {
+        if (cnt < cap) spans[cnt] = mq_span(wstart, pos - wstart, wchars);
         ++cnt;
     }
     return cnt;
 }
 
-// B: pieces of one word (span from A) -> out[0 .. count) (out has room for one id per byte of the word); returns count.
-MQ_TOK_FN int mq_wp_pieces(const mq_wp_table& T, const uint8_t* text, uint32_t span, int32_t* out, uint8_t* word, int ws) {
-    const int start = (int)(span >> 8), len = (int)(span & 255u);
-    if (len > T.max_word_chars) { out[0] = T.unk_id; return 1; }  // (255 stands for "255 or more")
-    for (int j = 0; j < len; ++j) word[j * ws] = T.lower ? mq_lower(text[start + j]) : text[start + j];
+// B: pieces of one word (span from A, bytes in `norm`) -> out[0 .. count) (out has room for one id per byte of the word); returns
+// count, or -1 when the word does not fit the per-thread scratch (the text then goes to the host)
+MQ_TOK_FN int mq_wp_pieces(const mq_wp_table& T, const uint8_t* norm, uint64_t span, int32_t* out, uint8_t* word, int ws) {
+    const int start = mq_span_start(span), len = mq_span_bytes(span), nchars = mq_span_chars(span);
+    if (nchars > T.max_word_chars) { out[0] = T.unk_id; return 1; }
+    if (len > MQ_WP_MAX_WORD) return -1;
+    for (int j = 0; j < len; ++j) word[j * ws] = norm[start + j];
     int cnt = 0;
-    mq_wp_word(T, word, ws, len, out, 1, len, &cnt);
+    mq_wp_word(T, word, ws, len, nchars, out, 1, len, &cnt);
     return cnt;
 }
 
 // C: row = [CLS] pieces... [SEP] pad...; returns the row length.  piece_cnt[j] / pieces at piece_buf[start_j ...] are B's output.
-MQ_TOK_FN int mq_wp_gather(const mq_wp_table& T, const uint32_t* spans, const uint8_t* piece_cnt, const int32_t* piece_buf, int nwords,
+MQ_TOK_FN int mq_wp_gather(const mq_wp_table& T, const uint64_t* spans, const int16_t* piece_cnt, const int32_t* piece_buf, int nwords,
                            int max_tokens, int32_t* row, int ld) {
     int cnt = 0;
     row[0] = T.cls_id;
     for (int j = 0; j < nwords && cnt < max_tokens; ++j) {
-        const int32_t* src = piece_buf + (spans[j] >> 8);
+        const int32_t* src = piece_buf + mq_span_start(spans[j]);
         const int k = piece_cnt[j];
         for (int e = 0; e < k && cnt < max_tokens; ++e) row[1 + cnt++] = src[e];
     }
@@ -186,7 +276,7 @@ struct mq_bpe_table {
     int32_t lower;
 };
 
-#define MQ_BPE_MAX_SYMS 96  // scratch symbols per text (longest pre-token handled on the device)
+#define MQ_BPE_MAX_SYMS 128  // scratch symbols per thread (longest pre-token, in UTF-8 bytes, handled on the device)
 #define MQ_BPE_EMPTY 0xffffffffu
 
 MQ_TOK_FN int mq_bpe_lookup(const mq_bpe_table& T, uint32_t a, uint32_t b, uint32_t* rank, uint32_t* merged) {
@@ -227,65 +317,121 @@ MQ_TOK_FN int mq_bpe_merge(const mq_bpe_table& T, uint16_t* sym, int ss, int L) 
     return L;
 }
 
-MQ_TOK_FN int mq_is_alpha(uint8_t c) { return (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z'); }
-MQ_TOK_FN int mq_is_digit(uint8_t c) { return c >= '0' && c <= '9'; }
+// Three phases like WordPiece (A per text: lower-case + regex pre-split into spans of the normalised text; B per pre-token: byte
+// symbols + merges, the surviving symbols stored at the pre-token's own byte positions; C per text: SOT, ids, EOT, zero padding /
+// truncation).  Pre-tokenisation = the SimpleTokenizer regex on the lower-cased text, scanned left to right:
+//   's 't 're 've 'm 'll 'd | \p{L}+ | \p{N} | [^\s\p{L}\p{N}]+
+// with \s, \p{L}, \p{N} taken from the character table (built from the `regex` module the host tokeniser runs).
 
-// length of the contraction ('s 't 're 've 'm 'll 'd, case-insensitive) starting at text[i] == '\'', or 0
-MQ_TOK_FN int mq_contraction(const uint8_t* text, int i, int n) {
-    if (i + 1 >= n) return 0;
-    const uint8_t a = mq_lower(text[i + 1]);
-    if (a == 's' || a == 't' || a == 'm' || a == 'd') return 2;
-    if (i + 2 >= n) return 0;
-    const uint8_t b = mq_lower(text[i + 2]);
-    if ((a == 'r' && b == 'e') || (a == 'v' && b == 'e') || (a == 'l' && b == 'l')) return 3;
-    return 0;
-}
+// class of an OUTPUT character: 0 whitespace, 1 letter, 2 number, 3 other
+MQ_TOK_FN int mq_clip_class(uint32_t f) { return (f & MQ_U_WS) ? 0 : (f & MQ_U_LETTER) ? 1 : (f & MQ_U_NUMBER) ? 2 : 3; }
 
-// Three phases like WordPiece (A per text: regex pre-split into spans; B per pre-token: byte symbols + merges, the surviving
-// symbols stored at the pre-token's own byte positions; C per text: SOT, ids, EOT, zero padding / truncation).
-// Pre-tokenisation = the SimpleTokenizer regex restricted to ASCII (the text is lower-cased first when T.lower):
-//   contraction | letters+ | one digit | (not whitespace / letter / digit)+      scanned left to right.
-
-// A: returns the number of pre-tokens, at most `cap` written as (start << 8 | len); pre-tokens longer than the BPE scratch or
-// bytes outside the device scope set *status = MQ_TOK_NEEDS_HOST.
-MQ_TOK_FN int mq_clip_split(const uint8_t* text, int nbytes, int cap, uint32_t* spans, int* status) {
+// A: returns the number of pre-tokens, at most `cap` written; pre-tokens longer than the BPE scratch or characters that need the
+// host set *status = MQ_TOK_NEEDS_HOST.  norm has mq_norm_capacity(nbytes) bytes; lower-cased characters are written there.
+MQ_TOK_FN int mq_clip_split(const mq_uni_table& U, const uint8_t* text, int nbytes, int cap, uint64_t* spans, uint8_t* norm, int* status) {
     *status = MQ_TOK_OK;
-    int cnt = 0, i = 0;
+    int cnt = 0, i = 0, pos = 0;
+    int tstart = -1, tclass = -1, tchars = 0;   // open pre-token (class 1 = letters, 3 = other run)
+    // the host cleans the text with str.strip() first: characters Python calls whitespace vanish at both ENDS even where the regex
+    // would treat them as ordinary symbols (U+001C..U+001F)
+    {
+        int k = 0, first = -1, last_end = 0;
+        while (k < nbytes) {
+            uint32_t cp;
+            const int len = mq_utf8_next(text, nbytes, k, &cp);
+            if (len == 0 || cp >= MQ_UNI_LIMIT) { *status = MQ_TOK_NEEDS_HOST; return 0; }
+            if (!(mq_u_flags(U.e[cp]) & (MQ_U_STRIP | MQ_U_WS))) {
+                if (first < 0) first = k;
+                last_end = k + len;
+            }
+            k += len;
+        }
+        if (first < 0) return 0;
+        i = first;
+        nbytes = last_end;
+    }
     while (i < nbytes) {
-        const uint8_t c = text[i];
-        if (!mq_in_scope(c)) { *status = MQ_TOK_NEEDS_HOST; return 0; }
-        if (mq_is_ws(c)) { ++i; continue; }
-        int len;
-        if (c == '\'' && (len = mq_contraction(text, i, nbytes)) > 0) {
-        } else if (mq_is_alpha(c)) {
-            len = 1;
-            while (i + len < nbytes && mq_is_alpha(text[i + len])) ++len;
-        } else if (mq_is_digit(c)) {
-            len = 1;
-        } else {
-            len = 1;
-            while (i + len < nbytes) {
-                const uint8_t d = text[i + len];
-                if (!mq_in_scope(d)) { *status = MQ_TOK_NEEDS_HOST; return 0; }
-                if (mq_is_ws(d) || mq_is_alpha(d) || mq_is_digit(d)) break;
-                ++len;
+        uint32_t cp;
+        const int len = mq_utf8_next(text, nbytes, i, &cp);
+        if (len == 0 || cp >= MQ_UNI_LIMIT) { *status = MQ_TOK_NEEDS_HOST; return 0; }
+        const uint64_t e = U.e[cp];
+        const uint32_t f = mq_u_flags(e);
+        if (f & MQ_U_HOST) { *status = MQ_TOK_NEEDS_HOST; return 0; }
+        const uint32_t oc = mq_u_cp0(e);        // lower-cased character (exactly one: multi-character lowerings are HOST)
+        const int cls = mq_clip_class(f);
+        // a contraction is tried wherever a pre-token could START with an apostrophe: at the beginning of a match, i.e. when no
+        // letters / "other" run is open, or right after a letters run (the regex then closes the run and starts a new match)
+        if (oc == '\'' && (tstart < 0 || tclass == 1)) {
+            // look ahead in the RAW text: the next one or two characters, lower-cased through the table (a character that needs the
+            // host is met by the main loop right after and sends the text there)
+            uint32_t a = 0, b = 0;
+            int la = 0, lb = 0;
+            if (i + len < nbytes) {
+                uint32_t c1;
+                la = mq_utf8_next(text, nbytes, i + len, &c1);
+                if (la && c1 < MQ_UNI_LIMIT) a = mq_u_cp0(U.e[c1]);
+                if (la && i + len + la < nbytes) {
+                    uint32_t c2;
+                    lb = mq_utf8_next(text, nbytes, i + len + la, &c2);
+                    if (lb && c2 < MQ_UNI_LIMIT) b = mq_u_cp0(U.e[c2]);
+                }
+            }
+            int clen = 0;   // characters after the apostrophe that belong to the contraction (the regex is IGNORECASE: a cased
+                            // vocabulary keeps 'S as typed)
+            const uint32_t al = (a >= 'A' && a <= 'Z') ? a + 32 : a, bl = (b >= 'A' && b <= 'Z') ? b + 32 : b;
+            if (al == 's' || al == 't' || al == 'm' || al == 'd') clen = 1;
+            else if ((al == 'r' && bl == 'e') || (al == 'v' && bl == 'e') || (al == 'l' && bl == 'l')) clen = 2;
+            if (clen) {
+                if (tstart >= 0) {
+                    if (cnt < cap) { if (pos - tstart > MQ_BPE_MAX_SYMS) { *status = MQ_TOK_NEEDS_HOST; return 0; } spans[cnt] = mq_span(tstart, pos - tstart, tchars); }
+                    ++cnt;
+                    tstart = -1;
+                }
+                const int s0 = pos;
+                norm[pos++] = '\'';
+                norm[pos++] = (uint8_t)a;
+                if (clen == 2) norm[pos++] = (uint8_t)b;
+                if (cnt < cap) spans[cnt] = mq_span(s0, pos - s0, 1 + clen);
+                ++cnt;
+                i += len + la + (clen == 2 ? lb : 0);
+                continue;
             }
         }
-        if (cnt < cap) {  // pre-tokens past the context window cannot change the kept ids (each yields >= 1 id)
-            if (len > MQ_BPE_MAX_SYMS) { *status = MQ_TOK_NEEDS_HOST; return 0; }
-            spans[cnt] = ((uint32_t)i << 8) | (uint32_t)len;
-        }
-        ++cnt;
         i += len;
+        if (cls == 0) {
+            if (tstart >= 0) {
+                if (cnt < cap) { if (pos - tstart > MQ_BPE_MAX_SYMS) { *status = MQ_TOK_NEEDS_HOST; return 0; } spans[cnt] = mq_span(tstart, pos - tstart, tchars); }
+                ++cnt;
+                tstart = -1;
+            }
+            continue;
+        }
+        if (tstart >= 0 && (cls != tclass || cls == 2)) {   // class change closes the run; every number is a pre-token of its own
+            if (cnt < cap) { if (pos - tstart > MQ_BPE_MAX_SYMS) { *status = MQ_TOK_NEEDS_HOST; return 0; } spans[cnt] = mq_span(tstart, pos - tstart, tchars); }
+            ++cnt;
+            tstart = -1;
+        }
+        if (tstart < 0) { tstart = pos; tclass = cls; tchars = 0; }
+        pos += mq_utf8_put(oc, norm + pos);
+        ++tchars;
+        if (cls == 2) {   // single number
+            if (cnt < cap) spans[cnt] = mq_span(tstart, pos - tstart, 1);
+            ++cnt;
+            tstart = -1;
+        }
+    }
+    if (tstart >= 0) {
+        if (cnt < cap) { if (pos - tstart > MQ_BPE_MAX_SYMS) { *status = MQ_TOK_NEEDS_HOST; return 0; } spans[cnt] = mq_span(tstart, pos - tstart, tchars); }
+        ++cnt;
     }
     return cnt;
 }
 
-// B: BPE of one pre-token -> out[0 .. count) (room for one symbol per byte); returns count.
-MQ_TOK_FN int mq_clip_merge_span(const mq_bpe_table& T, const uint8_t* text, uint32_t span, uint16_t* out, uint16_t* sym, int ss) {
-    const int start = (int)(span >> 8), len = (int)(span & 255u);
+// B: BPE of one pre-token (bytes in `norm`) -> out[0 .. count) (room for one symbol per byte); returns count.
+MQ_TOK_FN int mq_clip_merge_span(const mq_bpe_table& T, const uint8_t* norm, uint64_t span, uint16_t* out, uint16_t* sym, int ss) {
+    const int start = mq_span_start(span), len = mq_span_bytes(span);
     for (int j = 0; j < len; ++j) {
-        const uint8_t b = T.lower ? mq_lower(text[start + j]) : text[start + j];
+        const uint8_t b = norm[start + j];
         sym[j * ss] = (j == len - 1) ? T.byte_end_id[b] : T.byte_id[b];
     }
     const int L = mq_bpe_merge(T, sym, ss, len);
@@ -295,12 +441,12 @@ MQ_TOK_FN int mq_clip_merge_span(const mq_bpe_table& T, const uint8_t* text, uin
 
 // C: row[0..ctx) = SOT ids... EOT 0...; over-long inputs are truncated to ctx and the last kept position overwritten with EOT
 // (open_clip tokenize()).  `total` = A's return value (pre-tokens beyond the written ones each stand for >= 1 more id).
-MQ_TOK_FN int mq_clip_gather(const mq_bpe_table& T, const uint32_t* spans, const uint8_t* sym_cnt, const uint16_t* sym_buf, int nwritten,
+MQ_TOK_FN int mq_clip_gather(const mq_bpe_table& T, const uint64_t* spans, const int16_t* sym_cnt, const uint16_t* sym_buf, int nwritten,
                              int total, int ctx, int32_t* row) {
     int cnt = 1;
     row[0] = T.sot_id;
     for (int j = 0; j < nwritten; ++j) {
-        const uint16_t* src = sym_buf + (spans[j] >> 8);
+        const uint16_t* src = sym_buf + mq_span_start(spans[j]);
         const int k = sym_cnt[j];
         for (int e = 0; e < k; ++e) {
             if (cnt < ctx) row[cnt] = (int32_t)src[e];

@@ -1,10 +1,14 @@
-"""Device-side tokenisation (K14): hash-table builders + thin wrappers over mq_tokenize_wordpiece / mq_tokenize_clip_bpe.
+"""Device-side tokenisation (K14): hash-table / character-table builders + thin wrappers over mq_tokenize_wordpiece / mq_tokenize_clip_bpe.
 
 The reference tokenises on the host (open_clip_model.py:277, hugging_face_model.py:179-185).  Here the host tokenisers of
-``engine/tokenizers.py`` stay the definition of record; for texts inside the device scope — printable ASCII + ``\\t \\n \\r``
-with no special-token spelling (and, for CLIP, no ``&`` that ``html.unescape`` could rewrite) — the same algorithms run on
-the GPU, one thread per text, and produce IDENTICAL ids (tests/test_gpu_tokenizers.py).  Every other text is tokenised by
-the host tokeniser and patched into the same id matrix, so callers see one result regardless of the route.
+``engine/tokenizers.py`` stay the definition of record; the same algorithms run on the GPU for ANY UTF-8 text (one thread per text
+for the splitting, one per word for the vocabulary work) and produce IDENTICAL ids (tests/test_gpu_tokenizers.py: fixed cases + a
+seeded multi-script fuzz).  Per-character behaviour — whitespace, punctuation, CJK isolation, control-character removal,
+lower-casing, accent stripping, the regex classes \\s / \\p{L} / \\p{N} — comes from a 64-bit-per-code-point table built HERE from
+Python's own `unicodedata` / `str.lower` / `regex`, i.e. from the very functions the host tokenisers call.  What the table cannot
+express (context-dependent characters: Greek capital sigma's final form, combining marks under a cased vocabulary's NFC step, code
+points beyond U+2FFFF, ...), special-token spellings and — for CLIP — `&` (html.unescape) send a text to the host tokeniser; its ids
+are patched into the same matrix, so callers see one result regardless of the route.
 
 The table builders are plain numpy (no GPU needed) so that the CPU test suite can feed the very same tables to the host
 build of the product algorithm (oracle/tokenize_host.cpp).
@@ -12,6 +16,7 @@ build of the product algorithm (oracle/tokenize_host.cpp).
 from __future__ import annotations
 
 import ctypes as C
+import functools
 import re
 import threading
 from typing import Dict, List, Optional, Sequence, Tuple
@@ -28,8 +33,95 @@ assert WP_ENTRY.itemsize == 16 and BPE_ENTRY.itemsize == 16
 
 _FNV_OFFSET, _FNV_PRIME, _CONT_SEED, _M64 = 0xcbf29ce484222325, 0x100000001b3, 0x9e3779b97f4a7c15, (1 << 64) - 1
 MAX_WORD_CHARS_DEVICE = 100
-_SCOPE = re.compile(r"[\x20-\x7e\t\n\r]*")
-MAX_TEXT_BYTES_DEVICE = 1 << 20  # span offsets are 24-bit
+MAX_TEXT_BYTES_DEVICE = 1 << 20
+
+# ---- Unicode character table (layout: csrc/tokenize_algo.h) ---------------------------------------------------------------------
+UNI_LIMIT = 0x30000
+U_DROP, U_WS, U_ISOLATE, U_HOST, U_LETTER, U_NUMBER, U_HANGUL, U_STRIP = 0x01, 0x02, 0x04, 0x08, 0x10, 0x20, 0x40, 0x80
+
+
+def _entry(flags: int, out: Sequence[int] = ()) -> int:
+    e = flags | (len(out) << 8)
+    if len(out) > 0:
+        e |= out[0] << 10
+    if len(out) > 1:
+        e |= out[1] << 31
+    return e
+
+
+@functools.lru_cache(maxsize=4)
+def build_unicode_table(kind: str, lower: bool) -> np.ndarray:
+    """uint64 [UNI_LIMIT]: what the HOST tokeniser of `kind` ('wordpiece' | 'clip') does to each code point on its own, derived by
+    calling the host tokeniser's own helpers, plus U_HOST where a code point's treatment depends on its neighbours:
+
+      wordpiece (WordPieceTokenizer._basic): drop (U+0000, U+FFFD, category C*) | whitespace (\\t \\n \\r, Zs, anything str.split
+        splits on) | CJK ideograph -> isolated | NFC | lower() + NFD + drop Mn (lower-casing vocabularies) | punctuation -> isolated.
+        lower = True: a combining mark (Mn) vanishes whatever it follows, so it is a plain DROP; precomposed Hangul decomposes
+        arithmetically (U_HANGUL); U+03A3 (final-sigma rule of str.lower) and non-Mn characters with a canonical combining class
+        (reordered by NFD) are U_HOST.   lower = False: NFC is contextual -> every mark (M*), conjoining jamo vowel / trailing
+        consonant and anything with a combining class is U_HOST.
+      clip (ClipBpeTokenizer.encode): lower() then the regex classes \\s, \\p{L}, \\p{N} (from the `regex` module, as the host);
+        U+03A3, U+0130 (two-character lowering) and U+017F (matches 's' under IGNORECASE in the contraction alternatives) are U_HOST.
+    """
+    import unicodedata
+    import regex
+    from marqo_amd.engine.tokenizers import _is_cjk, _is_control, _is_punct, _is_ws
+    tab = np.zeros(UNI_LIMIT, dtype=np.uint64)
+    re_s, re_l, re_n = regex.compile(r"\s"), regex.compile(r"\p{L}"), regex.compile(r"\p{N}")
+    for cp in range(UNI_LIMIT):
+        if 0xD800 <= cp <= 0xDFFF:
+            tab[cp] = _entry(U_HOST)
+            continue
+        ch = chr(cp)
+        if kind == "wordpiece":
+            cat = unicodedata.category(ch)
+            if cp == 0 or cp == 0xFFFD or _is_control(ch):
+                tab[cp] = _entry(U_DROP)
+            elif _is_ws(ch) or ch.isspace():
+                tab[cp] = _entry(U_WS)
+            elif _is_cjk(cp):
+                out = unicodedata.normalize("NFD" if lower else "NFC", unicodedata.normalize("NFC", ch))
+                tab[cp] = _entry(U_ISOLATE, [ord(out)]) if len(out) == 1 and not _is_punct(out) else _entry(U_HOST)
+            elif lower:
+                if cp == 0x03A3 or (unicodedata.combining(ch) != 0 and cat != "Mn"):
+                    tab[cp] = _entry(U_HOST)
+                    continue
+                if 0xAC00 <= cp <= 0xD7A3:
+                    tab[cp] = _entry(U_HANGUL)
+                    continue
+                w = unicodedata.normalize("NFC", ch).lower()
+                out = [c for c in unicodedata.normalize("NFD", w) if unicodedata.category(c) != "Mn"]
+                if not out:
+                    tab[cp] = _entry(U_DROP)
+                elif len(out) == 1 and _is_punct(out[0]):
+                    tab[cp] = _entry(U_ISOLATE, [ord(out[0])])
+                elif len(out) <= 2 and not any(_is_punct(c) or _is_ws(c) or c.isspace() or _is_cjk(ord(c)) or _is_control(c) for c in out):
+                    tab[cp] = _entry(0, [ord(c) for c in out])
+                else:
+                    tab[cp] = _entry(U_HOST)
+            else:
+                if cat.startswith("M") or unicodedata.combining(ch) != 0 or 0x1161 <= cp <= 0x1175 or 0x11A8 <= cp <= 0x11C2:
+                    tab[cp] = _entry(U_HOST)
+                    continue
+                out = unicodedata.normalize("NFC", ch)
+                if len(out) == 1 and _is_punct(out):
+                    tab[cp] = _entry(U_ISOLATE, [ord(out)])
+                elif len(out) <= 2 and not any(_is_punct(c) or _is_ws(c) or c.isspace() or _is_cjk(ord(c)) or _is_control(c) for c in out):
+                    tab[cp] = _entry(0, [ord(c) for c in out])
+                else:
+                    tab[cp] = _entry(U_HOST)
+        elif kind == "clip":
+            out = ch.lower() if lower else ch
+            if cp in (0x03A3, 0x017F) or len(out) != 1:
+                tab[cp] = _entry(U_HOST)
+                continue
+            flags = U_WS if re_s.match(out) else (U_LETTER if re_l.match(out) else (U_NUMBER if re_n.match(out) else 0))
+            if ch.isspace() and not (flags & U_WS):   # _clean_text's str.strip() removes these at the ends of a text (U+001C..U+001F)
+                flags |= U_STRIP
+            tab[cp] = _entry(flags, [ord(out)])
+        else:
+            raise ValueError(kind)
+    return tab
 
 
 def _fnv(data: bytes, cont: bool) -> int:
@@ -47,17 +139,21 @@ def _pow2_at_least(n: int) -> int:
 
 
 def build_wordpiece_table(tok: WordPieceTokenizer) -> Dict[str, object]:
-    """vocabulary -> open-addressing table (layout: csrc/tokenize_algo.h mq_wp_entry).  Only pieces that an in-scope word
-    can produce are stored: pure-ASCII strings of at most 127 bytes; '##x...' entries are continuation pieces."""
+    """vocabulary -> open-addressing table (layout: csrc/tokenize_algo.h mq_wp_entry), keyed by the UTF-8 bytes of every piece of at
+    most 127 bytes ('##x...' entries are continuation pieces).  A vocabulary holding a longer piece cannot be matched exactly by the
+    device path and is refused."""
     if tok.max_chars > MAX_WORD_CHARS_DEVICE:
         raise ValueError(f"max_chars_per_word {tok.max_chars} > {MAX_WORD_CHARS_DEVICE} is not supported on the device")
     items: List[Tuple[bytes, bool, int]] = []
     for s, idx in tok.vocab.items():
-        if not s.isascii():
-            continue
         cont = s.startswith("##") and len(s) > 2
-        data = (s[2:] if cont else s).encode("ascii")
-        if 0 < len(data) <= 127:
+        try:
+            data = (s[2:] if cont else s).encode("utf-8")
+        except UnicodeEncodeError:  # lone surrogates: such a piece can never equal a substring of well-formed text
+            continue
+        if len(data) > 127:
+            raise ValueError(f"vocabulary piece of {len(data)} bytes is too long for the device WordPiece table")
+        if len(data) > 0:
             items.append((data, cont, int(idx)))
     n_slots = _pow2_at_least(2 * len(items) + 1)
     slots = np.zeros(n_slots, dtype=WP_ENTRY)
@@ -104,20 +200,38 @@ def build_bpe_table(tok: ClipBpeTokenizer) -> Dict[str, object]:
 
 
 def pack_texts(texts: Sequence[str]) -> Tuple[np.ndarray, np.ndarray]:
-    """in-scope (ASCII) texts -> (uint8 blob, int64 offsets [n+1])"""
-    blob = "".join(texts).encode("ascii")
+    """texts -> (UTF-8 uint8 blob, int64 byte offsets [n+1]).  Texts that cannot be encoded (lone surrogates) must have been routed to
+    the host by the scope test."""
+    if all(t.isascii() for t in texts):
+        blob = "".join(texts).encode("ascii")
+        lens = [len(t) for t in texts]
+    else:
+        enc = [t.encode("utf-8") for t in texts]
+        blob = b"".join(enc)
+        lens = [len(e) for e in enc]
     offsets = np.zeros(len(texts) + 1, dtype=np.int64)
-    np.cumsum([len(t) for t in texts], out=offsets[1:])
+    np.cumsum(lens, out=offsets[1:])
     return np.frombuffer(bytearray(blob + b"\0"), dtype=np.uint8), offsets
 
 
+def _encodable(text: str) -> bool:
+    if text.isascii():
+        return True
+    try:
+        text.encode("utf-8")
+        return True
+    except UnicodeEncodeError:
+        return False
+
+
 def wordpiece_in_scope(tok: WordPieceTokenizer, text: str) -> bool:
-    return (len(text) < MAX_TEXT_BYTES_DEVICE and _SCOPE.fullmatch(text) is not None
+    """host-side routing test (the kernel flags character-level reasons itself): size, encodability, special-token spellings"""
+    return (len(text) < MAX_TEXT_BYTES_DEVICE // 4 and _encodable(text)
             and ("[" not in text or not any(s in text for s in tok._specials)))
 
 
 def clip_in_scope(tok: ClipBpeTokenizer, text: str) -> bool:
-    if len(text) >= MAX_TEXT_BYTES_DEVICE or _SCOPE.fullmatch(text) is None or "&" in text:
+    if len(text) >= MAX_TEXT_BYTES_DEVICE // 4 or "&" in text or not _encodable(text):
         return False
     if "<" in text:
         low = text.lower()
@@ -179,7 +293,8 @@ class DeviceWordPieceTokenizer(_DeviceTokenizerBase):
         t = build_wordpiece_table(host)
         self.vocab = L.WordPieceVocab(d_slots=self._up(t["slots"]).data_ptr(), d_pool=self._up(t["pool"]).data_ptr(), n_slots=t["n_slots"],
                                       unk_id=t["unk_id"], cls_id=t["cls_id"], sep_id=t["sep_id"], pad_id=t["pad_id"], lower=t["lower"],
-                                      max_word_chars=t["max_word_chars"])
+                                      max_word_chars=t["max_word_chars"],
+                                      d_unicode=self._up(build_unicode_table("wordpiece", bool(host.lower))).data_ptr())
 
     def encode_device(self, texts: Sequence[str], max_length: int) -> Tuple[torch.Tensor, torch.Tensor]:
         """-> (ids int32 [n, max_length] on device, right-padded with pad_id; lengths int64 [n] on host)"""
@@ -240,7 +355,8 @@ class DeviceClipBpeTokenizer(_DeviceTokenizerBase):
         t = build_bpe_table(host)
         self.vocab = L.ClipBpeVocab(d_slots=self._up(t["slots"]).data_ptr(), d_byte_id=self._up(t["byte_id"]).data_ptr(),
                                     d_byte_end_id=self._up(t["byte_end_id"]).data_ptr(), n_slots=t["n_slots"], sot_id=t["sot_id"],
-                                    eot_id=t["eot_id"], lower=t["lower"])
+                                    eot_id=t["eot_id"], lower=t["lower"],
+                                    d_unicode=self._up(build_unicode_table("clip", bool(host.lower))).data_ptr())
 
     def encode_device(self, texts: Sequence[str], context_length: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
         """-> (ids int32 [n, ctx] on device, zero padded; lengths int64 [n] on host = SOT..EOT)"""

@@ -71,8 +71,9 @@ def _host_wordpiece(lib, tok, texts, max_length):
     n = len(texts)
     ids = np.zeros((n, max_length), np.int32)
     lens, status = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    uni = GT.build_unicode_table("wordpiece", bool(tok.lower))
     lib.tokhost_wordpiece(_p(t["slots"]), _p(t["pool"]), C.c_uint32(t["n_slots"]), t["unk_id"], t["cls_id"], t["sep_id"], t["pad_id"],
-                          t["lower"], t["max_word_chars"], _p(blob), _p(off), C.c_int64(n), max_length, _p(ids), C.c_int64(max_length),
+                          t["lower"], t["max_word_chars"], _p(uni), _p(blob), _p(off), C.c_int64(n), max_length, _p(ids), C.c_int64(max_length),
                           _p(lens), _p(status))
     return ids, lens, status
 
@@ -83,17 +84,20 @@ def _host_clip(lib, tok, texts, ctx):
     n = len(texts)
     ids = np.zeros((n, ctx), np.int32)
     lens, status = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    uni = GT.build_unicode_table("clip", bool(tok.lower))
     lib.tokhost_clip_bpe(_p(t["slots"]), _p(t["byte_id"]), _p(t["byte_end_id"]), C.c_uint32(t["n_slots"]), t["sot_id"], t["eot_id"], t["lower"],
-                         _p(blob), _p(off), C.c_int64(n), ctx, _p(ids), _p(lens), _p(status))
+                         _p(uni), _p(blob), _p(off), C.c_int64(n), ctx, _p(ids), _p(lens), _p(status))
     return ids, lens, status
 
 
 def test_scope_routing(bert_tok, clip_tok):
+    """host-side routing: only special-token spellings, `&` (CLIP: html.unescape), un-encodable and huge texts skip the device"""
     assert GT.wordpiece_in_scope(bert_tok, "plain ascii, with punct!") and GT.clip_in_scope(clip_tok, "plain ascii <b> 'quoted'")
-    for bad in ("naïve", "東京", "bell\x07", "del\x7f", "vt\x0b"):
-        assert not GT.wordpiece_in_scope(bert_tok, bad) and not GT.clip_in_scope(clip_tok, bad)
+    for ok in ("naïve", "東京", "bell\x07", "del\x7f", "vt\x0b", "Ελληνικά", "한국어", "हिन्दी", "😀 emoji"):
+        assert GT.wordpiece_in_scope(bert_tok, ok) and GT.clip_in_scope(clip_tok, ok)
     assert not GT.wordpiece_in_scope(bert_tok, "the fox [SEP] dog") and GT.wordpiece_in_scope(bert_tok, "the fox [sep] dog [x]")
     assert not GT.clip_in_scope(clip_tok, "fish &amp; chips") and not GT.clip_in_scope(clip_tok, "x <START_OF_TEXT> y")
+    assert not GT.wordpiece_in_scope(bert_tok, "lone \ud800 surrogate") and not GT.clip_in_scope(clip_tok, "lone \udfff surrogate")
 
 
 @pytest.mark.parametrize("max_length", [512, 16, 3, 2])
@@ -126,19 +130,23 @@ def test_wordpiece_cased_vocab(tokhost):
         assert ids[i, :lens[i]].tolist() == tok.encode(t, 32)
 
 
-def test_out_of_scope_bytes_are_flagged(tokhost, bert_tok, clip_tok):
-    blob = np.frombuffer("ok text\0caf\xc3\xa9 x\0".encode("latin1"), dtype=np.uint8)
-    off = np.array([0, 7, 8 + 6], dtype=np.int64)
+def test_context_dependent_characters_are_flagged(tokhost, bert_tok, clip_tok):
+    """characters whose treatment depends on their neighbours (final sigma), code points beyond the table and malformed UTF-8 hand the
+    text back to the host; everything else is tokenised"""
+    texts = ["ok text", "caf\u00e9 x", "ΟΔΟΣ", "\U00030000 far plane", "plain"]
+    ids, lens, status = _host_wordpiece(tokhost, bert_tok, texts, 16)
+    assert status.tolist() == [0, 0, 1, 1, 0] and lens[2] == 0 and lens[1] > 0
+    ids, lens, status = _host_clip(tokhost, clip_tok, texts + ["\u0130stanbul", "long\u017f"], 77)
+    assert status.tolist() == [0, 0, 1, 1, 0, 1, 1]
+    # malformed UTF-8 (cannot come from a Python str, but the C ABI takes bytes)
+    blob = np.frombuffer(b"ok\xff\xfe bad\0", dtype=np.uint8)
+    off = np.array([0, 8], dtype=np.int64)
     t = GT.build_wordpiece_table(bert_tok)
-    ids, lens, status = np.zeros((2, 16), np.int32), np.zeros(2, np.int32), np.zeros(2, np.int32)
+    ids, lens, status = np.zeros((1, 16), np.int32), np.zeros(1, np.int32), np.zeros(1, np.int32)
     tokhost.tokhost_wordpiece(_p(t["slots"]), _p(t["pool"]), C.c_uint32(t["n_slots"]), t["unk_id"], t["cls_id"], t["sep_id"], t["pad_id"],
-                              t["lower"], t["max_word_chars"], _p(blob), _p(off), C.c_int64(2), 16, _p(ids), C.c_int64(16), _p(lens), _p(status))
-    assert status.tolist() == [0, 1] and lens[1] == 0
-    b = GT.build_bpe_table(clip_tok)
-    ids, lens, status = np.zeros((2, 77), np.int32), np.zeros(2, np.int32), np.zeros(2, np.int32)
-    tokhost.tokhost_clip_bpe(_p(b["slots"]), _p(b["byte_id"]), _p(b["byte_end_id"]), C.c_uint32(b["n_slots"]), b["sot_id"], b["eot_id"], b["lower"],
-                             _p(blob), _p(off), C.c_int64(2), 77, _p(ids), _p(lens), _p(status))
-    assert status.tolist() == [0, 1]
+                              t["lower"], t["max_word_chars"], _p(GT.build_unicode_table("wordpiece", True)), _p(blob), _p(off), C.c_int64(1), 16,
+                              _p(ids), C.c_int64(16), _p(lens), _p(status))
+    assert status.tolist() == [1]
 
 
 @pytest.mark.parametrize("ctx", [77, 8, 2])
@@ -188,6 +196,14 @@ def test_device_wordpiece_equals_host(bert_tok):
     ids, lens = dev.encode_device(["a photo of a cat"], 32)
     assert ids.is_cuda and ids.shape == (1, 32) and ids[0, :int(lens[0])].tolist() == bert_tok.encode("a photo of a cat", 32)
     assert dev([], max_length=8)["input_ids"].shape[0] == 0
+    # Unicode on the device: multi-script vocabulary, >= 10k fuzz texts over both casings; the wrapper equals the host tokeniser on every
+    # text (the few context-dependent ones take the host route inside it)
+    for lower, seed in ((True, 31), (False, 32)):
+        tok = WordPieceTokenizer(_multiscript_vocab(), do_lower_case=lower)
+        d = GT.DeviceWordPieceTokenizer(tok, "cuda")
+        texts = _unicode_texts(seed, 5200) + ["ΟΔΟΣ final sigma", "the fox [SEP] dog", "\U00030000 far", "lone \ud800"]
+        got, ref = d(texts, max_length=48), tok(texts, max_length=48)
+        assert np.array_equal(got["input_ids"], ref["input_ids"]) and np.array_equal(got["attention_mask"], ref["attention_mask"])
 
 
 @pytest.mark.gpu
@@ -199,9 +215,135 @@ def test_device_clip_bpe_equals_host(clip_tok):
     ids, lens = dev.encode_device(texts)
     ref = clip_tok(texts)
     assert np.array_equal(lens.numpy(), ref.argmax(1) + 1)
+    corpus = " ".join(_unicode_texts(21, 400)).split()
+    tok = ClipBpeTokenizer(_train_bpe([w for w in corpus if w][:3000], 200), context_length=77)
+    d = GT.DeviceClipBpeTokenizer(tok, "cuda")
+    texts = _unicode_texts(33, 10500) + ["İstanbul", "ΟΔΟΣ", "fish &amp; chips", "x <start_of_text> y", "lone \udfff", "\x1c'm \x1d"]
+    assert np.array_equal(d(texts, 77), tok(texts, 77))
 
 
 def test_device_tokenizers_refuse_cpu(bert_tok):
     from marqo_amd._lib import MarqoHipUnavailableError
     with pytest.raises(MarqoHipUnavailableError):
         GT.DeviceWordPieceTokenizer(bert_tok, "cpu")
+
+
+# ---- Unicode: multi-script fuzz of the product algorithm (host build) against the Python tokenisers -----------------------------------
+_SCRIPTS = {
+    "latin": "abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ",
+    "latin_ext": "àáâãäåæçèéêëìíîïñòóôõöøùúûüýÿÀÁÂÃÄÅÆÇÈÉÊËÌÍÎÏÑÒÓÔÕÖØÙÚÛÜÝßœŒšŠžŽłŁđĐığĞşŞőŐ",
+    "greek": "αβγδεζηθικλμνξοπρστυφχψωάέήίόύώΑΒΓΔΕΖΗΘΙΚΛΜΝΞΟΠΡΤΥΦΧΨΩς",       # (capital sigma is the context-dependent one: added separately)
+    "cyrillic": "абвгдежзийклмнопрстуфхцчшщъыьэюяАБВГДЕЖЗИЙКЛМНОПРСТУФХЦЧШЩЪЫЬЭЮЯёЁ",
+    "cjk": "東京都日本語中文汉字學校愛国",
+    "kana": "あいうえおかがきぎくぐけげこごさざしじすずせぜそぞたアイウエオカガキギクグパピプペポ",
+    "hangul": "한국어안녕하세요서울대학교감사합니다",
+    "devanagari": "हिन्दीकखगघचछजझटठडढणतथदधनपफबभमयरलवशषसह़ािीुूेैोौ्",
+    "arabic": "العربيةمرحبابكمفيهذاالنصًٌٍَُِّْ",
+    "hebrew": "שלוםעולםעבריתבְּרֵאשִׁית",
+    "thai": "ภาษาไทยสวัสดีครับขอบคุณ",
+    "digits": "0123456789٠١٢٣٤٥٦٧٨٩０１２３²³½",
+    "punct": ".,;:!?'\"()[]{}<>-–—…«»“”‘’·•¿¡。、「」！？",
+    "symbols": "$€£¥©®™°±×÷=+*/\\^~`|@#%_",
+    "emoji": "😀😂🎉🔥👍🏽❤️🇯🇵",
+    "marks": "゙゚̧̣́̀̈̂̃̊̇",
+    "space": " \t\n\r  　  ​­﻿\x0b\x0c\x1c\x85\x00\x07\x7f�",
+}
+
+
+def _unicode_texts(seed, n):
+    rng = np.random.default_rng(seed)
+    names = list(_SCRIPTS)
+    out = []
+    for _ in range(n):
+        k = int(rng.integers(0, 14))
+        parts = []
+        main = names[int(rng.integers(len(names)))]
+        for _ in range(k):
+            script = main if rng.random() < 0.6 else names[int(rng.integers(len(names)))]
+            chars = _SCRIPTS[script]
+            L = int(rng.integers(1, 9))
+            w = "".join(chars[int(rng.integers(len(chars)))] for _ in range(L))
+            r = rng.random()
+            if r < 0.08:
+                w += "'" + ["s", "t", "re", "ve", "m", "ll", "d", "S", "x", ""][int(rng.integers(10))]
+            elif r < 0.12:
+                w += _SCRIPTS["marks"][int(rng.integers(len(_SCRIPTS["marks"])))]
+            parts.append(w)
+            parts.append([" ", " ", " ", "", "  ", ", ", ". ", "\n", "-", "'"][int(rng.integers(10))])
+        out.append("".join(parts))
+    return out
+
+
+def _multiscript_vocab():
+    chars = sorted({c for v in _SCRIPTS.values() for c in v} | {c.lower() for v in _SCRIPTS.values() for c in v})
+    import unicodedata
+    extra = set()
+    for c in chars:  # what lower + NFD leaves behind (base letters, jamo, kana without dakuten ...)
+        extra.update(unicodedata.normalize("NFD", c.lower()))
+    chars = sorted(set(chars) | extra)
+    toks = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"] + chars + ["##" + c for c in chars]
+    toks += ["ab", "##cd", "the", "abc", "東京", "αβ", "##γδ", "при", "##вет", "한", "ᄒ", "하", "한", "か", "##き", "हि", "مر", "##حب", "שלום", "ภา", "##ษา", "éa", "ea", "e", "naive", "cafe"]
+    seen, out = set(), []
+    for t in toks:
+        if t not in seen and t not in ("##",):
+            seen.add(t)
+            out.append(t)
+    return {t: i for i, t in enumerate(out)}
+
+
+@pytest.mark.parametrize("lower", [True, False])
+def test_wordpiece_unicode_fuzz_matches_python_tokenizer(tokhost, lower):
+    """>= 5k texts per casing over a dozen scripts, combining marks, exotic whitespace and control characters: ids identical to the
+    Python tokeniser for every text the device path accepts, and it accepts (almost) all of them"""
+    tok = WordPieceTokenizer(_multiscript_vocab(), do_lower_case=lower)
+    texts = _unicode_texts(11 if lower else 12, 5500) + ["naïve café über straße", "東京 photos 2024", "İstanbul ǅ ǆ ﬁ ŉ ẞ", "ｆｕｌｌｗｉｄｔｈ Ａ１",
+                                                          "é vs é", "が ga が", "한국어 한", "ﬁ Ω Å µ ẛ̣"]
+    texts = [t for t in texts if GT.wordpiece_in_scope(tok, t)]
+    ids, lens, status = _host_wordpiece(tokhost, tok, texts, 64)
+    flagged = 0
+    for i, t in enumerate(texts):
+        if status[i]:
+            flagged += 1
+            continue
+        ref = tok.encode(t, 64)
+        assert lens[i] == len(ref) and ids[i, :lens[i]].tolist() == ref, (repr(t), ids[i, :lens[i]].tolist(), ref)
+    assert len(texts) > 5000
+    # lower-casing vocabularies (every registry model): only final-sigma-capable text is handed back.  Cased vocabularies run NFC, which
+    # is contextual: every text holding a combining mark (most Devanagari / Arabic-with-harakat / Hebrew-with-niqqud / Thai texts of this
+    # mark-heavy fuzz) goes back to the host
+    assert flagged < (0.02 if lower else 0.75) * len(texts), flagged
+
+
+def test_wordpiece_unicode_fuzz_matches_transformers(tokhost):
+    """the same algorithm against transformers' own BertTokenizer (slow tokenizer, the implementation the reference calls) on the
+    multi-script vocabulary"""
+    from transformers import BertTokenizer
+    vocab = _multiscript_vocab()
+    tok = WordPieceTokenizer(vocab, do_lower_case=True)
+    hf = BertTokenizer(vocab=vocab, do_lower_case=True)
+    texts = [t for t in _unicode_texts(13, 1500) if GT.wordpiece_in_scope(tok, t)]
+    ids, lens, status = _host_wordpiece(tokhost, tok, texts, 48)
+    checked = 0
+    for i, t in enumerate(texts):
+        if status[i]:
+            continue
+        assert ids[i, :lens[i]].tolist() == hf(t, truncation=True, max_length=48)["input_ids"], repr(t)
+        checked += 1
+    assert checked > 1300
+
+
+def test_clip_bpe_unicode_fuzz_matches_python_tokenizer(tokhost):
+    corpus = " ".join(_unicode_texts(21, 400)).split()
+    tok = ClipBpeTokenizer(_train_bpe([w for w in corpus if w][:3000], 200), context_length=77)
+    texts = _unicode_texts(22, 5500) + ["naïve café über straße", "東京 photos 2024", "it's l'été d'accord 'S 'RE", "ǅ ǆ ﬁ ẞ ｆｕｌｌ １２３ ²³½"]
+    texts = [t for t in texts if GT.clip_in_scope(tok, t)]
+    ids, lens, status = _host_clip(tokhost, tok, texts, 77)
+    ref = tok(texts, 77)
+    flagged = 0
+    for i, t in enumerate(texts):
+        if status[i]:
+            flagged += 1
+            continue
+        assert ids[i].tolist() == ref[i].tolist(), (repr(t), ids[i, :12].tolist(), ref[i, :12].tolist())
+        assert lens[i] == int(ref[i].argmax()) + 1
+    assert len(texts) > 5000 and flagged < 0.02 * len(texts), flagged
