@@ -437,6 +437,28 @@ int mq_tokenize_clip_bpe(const mq_clip_bpe_vocab* v, const uint8_t* d_text, cons
                          int64_t total_bytes, int32_t ctx, int32_t* d_ids, int32_t* d_lens, int32_t* d_status,
                          void* d_workspace, size_t workspace_bytes, void* stream);
 
+/* SentencePiece unigram (XLM-RoBERTa checkpoints of the multilingual-e5 family; T5-style vocabularies of the SigLIP towers): the model's
+ * own normaliser as a per-code-point map + whitespace rules, then the unigram Viterbi search (tokenize_algo.h).  Rows are
+ * [prefix_id] ids + id_offset ... suffix_id pad_id..., truncated to max_length; <unk> is written as unk_out. */
+typedef struct mq_sentencepiece_vocab {
+    const void*     d_slots;      /* mq_sp_entry[n_slots]: every piece and every proper prefix of a piece */
+    const uint8_t*  d_pool;       /* piece bytes */
+    const float*    d_score;      /* [vocab] */
+    const uint32_t* d_nmap;       /* [0x30000] (npool offset << 8) | normalised bytes; 0xff = needs host */
+    const uint8_t*  d_npool;
+    const uint8_t*  d_ccc;        /* [0x30000] canonical combining classes */
+    uint32_t n_slots;             /* power of two */
+    int32_t unk_id;
+    float   unk_score;            /* min piece score - 10 */
+    int32_t add_dummy_prefix, remove_extra_ws, max_piece_bytes;
+    int32_t prefix_id, suffix_id, pad_id, id_offset, unk_out;
+} mq_sentencepiece_vocab;
+
+size_t mq_tokenize_sentencepiece_workspace_bytes(int64_t n, int64_t total_bytes, int32_t max_length);
+int mq_tokenize_sentencepiece(const mq_sentencepiece_vocab* v, const uint8_t* d_text, const int64_t* d_offsets, int64_t n,
+                              int64_t total_bytes, int32_t max_length, int32_t* d_ids, int64_t ld, int32_t* d_lens,
+                              int32_t* d_status, void* d_workspace, size_t workspace_bytes, void* stream);
+
 /* padded id rows -> the packed layout of the text towers: d_packed[cu[s] + j] = d_padded[s * ld + j], j < cu[s+1] - cu[s] */
 int mq_pack_ids(const int32_t* d_padded, int64_t ld, const int32_t* d_cu_seqlens, int64_t nseq, int32_t* d_packed,
                 void* stream);

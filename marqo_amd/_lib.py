@@ -106,6 +106,13 @@ class ClipBpeVocab(C.Structure):
                 ("sot_id", C.c_int32), ("eot_id", C.c_int32), ("lower", C.c_int32), ("d_unicode", C.c_void_p)]
 
 
+class SentencePieceVocab(C.Structure):
+    _fields_ = [("d_slots", C.c_void_p), ("d_pool", C.c_void_p), ("d_score", C.c_void_p), ("d_nmap", C.c_void_p), ("d_npool", C.c_void_p),
+                ("d_ccc", C.c_void_p), ("n_slots", C.c_uint32), ("unk_id", C.c_int32), ("unk_score", C.c_float), ("add_dummy_prefix", C.c_int32),
+                ("remove_extra_ws", C.c_int32), ("max_piece_bytes", C.c_int32), ("prefix_id", C.c_int32), ("suffix_id", C.c_int32),
+                ("pad_id", C.c_int32), ("id_offset", C.c_int32), ("unk_out", C.c_int32)]
+
+
 _P = C.c_void_p
 _SIGNATURES = {
     # name: (restype, argtypes)
@@ -156,6 +163,9 @@ _SIGNATURES = {
     "mq_tokenize_wordpiece": (C.c_int, [C.POINTER(WordPieceVocab), _P, _P, C.c_int64, C.c_int64, C.c_int32, _P, C.c_int64, _P, _P, _P,
                                         C.c_size_t, _P]),
     "mq_tokenize_clip_bpe": (C.c_int, [C.POINTER(ClipBpeVocab), _P, _P, C.c_int64, C.c_int64, C.c_int32, _P, _P, _P, _P, C.c_size_t, _P]),
+    "mq_tokenize_sentencepiece_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int32]),
+    "mq_tokenize_sentencepiece": (C.c_int, [C.POINTER(SentencePieceVocab), _P, _P, C.c_int64, C.c_int64, C.c_int32, _P, C.c_int64, _P, _P, _P,
+                                            C.c_size_t, _P]),
     "mq_pack_ids": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P]),
     "mq_weighted_combine": (C.c_int, [_P, C.c_int64, _P, _P, _P, C.c_int64, C.c_int32, C.c_int32, _P, _P]),
     "mq_tune": (C.c_int, [C.c_char_p, C.c_int]),

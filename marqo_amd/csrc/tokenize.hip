@@ -9,7 +9,8 @@
 #include "tokenize_algo.h"
 
 static_assert(sizeof(mq_wp_entry) == 16 && sizeof(mq_bpe_entry) == 16, "hash-table entry layouts (mirrored in engine/gpu_tokenizers.py)");
-static_assert(sizeof(mq_wordpiece_vocab) == 56 && sizeof(mq_clip_bpe_vocab) == 48, "tokeniser vocabulary structs (mirrored in _lib.py)");
+static_assert(sizeof(mq_wordpiece_vocab) == 56 && sizeof(mq_clip_bpe_vocab) == 48 && sizeof(mq_sentencepiece_vocab) == 96 && sizeof(mq_sp_entry) == 16,
+              "tokeniser vocabulary structs (mirrored in _lib.py)");
 
 namespace {
 
@@ -107,6 +108,39 @@ __global__ __launch_bounds__(TOK_THREADS) void bpe_gather_kernel(mq_bpe_table T,
     lens[t] = ok ? len : 0;
 }
 
+// ---- SentencePiece unigram: one thread per text (normalise -> Viterbi -> frame); the search is a dependent chain per text -------------
+struct SpWs {
+    uint8_t* norm; float* best; int32_t* bstart; int32_t* bid; int32_t* pieces; size_t bytes;
+};
+SpWs sp_ws(void* base, int64_t n, int64_t total_bytes, int max_length) {
+    SpWs w;
+    size_t off = 0;
+    auto take = [&](size_t b) { const size_t o = off; off = align_up(off + b, 256); return o; };
+    const size_t cells = (size_t)norm_base(total_bytes, n) + 16 + (size_t)n;   // (+1 cell per text: positions 0 .. length)
+    const size_t o_nm = take(cells), o_b = take(cells * 4), o_s = take(cells * 4), o_i = take(cells * 4), o_p = take((size_t)n * max_length * 4);
+    w.norm = (uint8_t*)base + o_nm; w.best = (float*)((char*)base + o_b); w.bstart = (int32_t*)((char*)base + o_s);
+    w.bid = (int32_t*)((char*)base + o_i); w.pieces = (int32_t*)((char*)base + o_p); w.bytes = off;
+    return w;
+}
+
+__global__ __launch_bounds__(TOK_THREADS) void sp_kernel(mq_sp_table T, mq_sp_frame F, const uint8_t* __restrict__ text, const int64_t* __restrict__ offsets,
+                                                         int n, int max_length, uint8_t* __restrict__ norm, float* __restrict__ best,
+                                                         int32_t* __restrict__ bstart, int32_t* __restrict__ bid, int32_t* __restrict__ pieces,
+                                                         int32_t* __restrict__ ids, int64_t ld, int32_t* __restrict__ lens, int32_t* __restrict__ status) {
+    const int t = blockIdx.x * TOK_THREADS + threadIdx.x;
+    if (t >= n) return;
+    const int64_t b0 = offsets[t], b1 = offsets[t + 1];
+    const int64_t nb = norm_base(b0, t) + t;
+    int st;
+    const int nl = mq_sp_normalize(T, text + b0, (int)(b1 - b0), norm + nb, &st);
+    int total = 0;
+    int32_t* pc = pieces + (int64_t)t * max_length;
+    if (st == MQ_TOK_OK) total = mq_sp_viterbi(T, norm + nb, nl, best + nb, bstart + nb, bid + nb, pc, max_length);
+    const int len = mq_sp_gather(T, F, pc, st == MQ_TOK_OK ? total : 0, max_length, max_length, ids + (int64_t)t * ld, (int)ld);
+    lens[t] = st == MQ_TOK_OK ? len : 0;
+    status[t] = st;
+}
+
 // packed[cu[s] + j] = padded[s, j] for j < cu[s+1] - cu[s]
 __global__ __launch_bounds__(256) void pack_ids_kernel(const int32_t* __restrict__ padded, int64_t ld, const int32_t* __restrict__ cu,
                                                        int32_t* __restrict__ packed) {
@@ -183,6 +217,36 @@ extern "C" int mq_tokenize_clip_bpe(const mq_clip_bpe_vocab* v, const uint8_t* d
     hipLaunchKernelGGL(bpe_gather_kernel, dim3(per_text), dim3(TOK_THREADS), 0, s, T, d_offsets, (int)n, cap, ctx, w.spans, w.totals, w.counts,
                        (const uint16_t*)w.pieces, d_ids, d_lens, d_status);
     MQ_CHECK_LAUNCH("mq_tokenize_clip_bpe");
+    return MQ_OK;
+}
+
+extern "C" size_t mq_tokenize_sentencepiece_workspace_bytes(int64_t n, int64_t total_bytes, int32_t max_length) {
+    if (n <= 0 || max_length <= 0 || total_bytes < 0) return 0;
+    return sp_ws(nullptr, n, total_bytes, max_length).bytes;
+}
+
+extern "C" int mq_tokenize_sentencepiece(const mq_sentencepiece_vocab* v, const uint8_t* d_text, const int64_t* d_offsets, int64_t n,
+                                         int64_t total_bytes, int32_t max_length, int32_t* d_ids, int64_t ld, int32_t* d_lens,
+                                         int32_t* d_status, void* d_workspace, size_t workspace_bytes, void* stream) {
+    MQ_CHECK_ARG(v && v->d_slots && v->d_pool && v->d_score && v->d_nmap && v->d_npool && v->d_ccc && pow2(v->n_slots),
+                 "mq_tokenize_sentencepiece: bad vocabulary tables");
+    MQ_CHECK_ARG(max_length >= 2 && ld >= max_length && v->max_piece_bytes >= 1, "mq_tokenize_sentencepiece: need 2 <= max_length (%d) <= ld (%ld)",
+                 max_length, (long)ld);
+    if (n <= 0) return MQ_OK;
+    MQ_CHECK_ARG(d_text && d_offsets && d_ids && d_lens && d_status && d_workspace, "mq_tokenize_sentencepiece: null pointer");
+    MQ_CHECK_ARG(n < (1LL << 24) && total_bytes >= 0 && total_bytes < (1LL << 28), "mq_tokenize_sentencepiece: too many texts / bytes");
+    const SpWs w = sp_ws(d_workspace, n, total_bytes, max_length);
+    if (workspace_bytes < w.bytes) { mq_set_error("mq_tokenize_sentencepiece: workspace %zu < required %zu", workspace_bytes, w.bytes); return MQ_ERR_WORKSPACE; }
+    mq_sp_table T;
+    T.slots = (const mq_sp_entry*)v->d_slots; T.pool = v->d_pool; T.score = v->d_score; T.nmap = v->d_nmap; T.npool = v->d_npool; T.ccc = v->d_ccc;
+    T.mask = v->n_slots - 1; T.unk_id = v->unk_id; T.unk_score = v->unk_score; T.add_dummy_prefix = v->add_dummy_prefix;
+    T.remove_extra_ws = v->remove_extra_ws; T.max_piece_bytes = v->max_piece_bytes;
+    const mq_sp_frame F{v->prefix_id, v->suffix_id, v->pad_id, v->id_offset, v->unk_out};
+    hipStream_t s = (hipStream_t)stream;
+    MqProfScope prof(3, s);
+    hipLaunchKernelGGL(sp_kernel, dim3((unsigned)cdiv64(n, TOK_THREADS)), dim3(TOK_THREADS), 0, s, T, F, d_text, d_offsets, (int)n, max_length, w.norm,
+                       w.best, w.bstart, w.bid, w.pieces, d_ids, ld, d_lens, d_status);
+    MQ_CHECK_LAUNCH("mq_tokenize_sentencepiece");
     return MQ_OK;
 }
 

@@ -464,3 +464,173 @@ MQ_TOK_FN int mq_clip_gather(const mq_bpe_table& T, const uint64_t* spans, const
     }
     return cnt;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// SentencePiece unigram (XLM-RoBERTa: the multilingual-e5 family; T5-style vocabularies: SigLIP).  Reference behaviour being
+// reproduced (third-party, un-vendored): sentencepiece's normaliser (precompiled character map + whitespace rules) followed by the
+// unigram model's EncodeOptimized Viterbi search, as called through transformers at hugging_face_model.py:179-185.
+//   A  mq_sp_normalize  per-character normalisation through a table built on the host from SentencePieceProcessor.Normalize itself
+//                       (so it IS the model's own character map), then the normaliser's whitespace rules: leading / trailing /
+//                       repeated spaces removed, the remaining ones escaped to U+2581, a dummy U+2581 prefix
+//   B  mq_sp_viterbi    best segmentation under the piece scores: for every start (character boundary, left to right) every piece
+//                       that begins there proposes `best[start] + score` to its end position, strictly-greater wins (first proposal
+//                       wins ties, as in sentencepiece); a start with no one-character piece proposes <unk> with min_score - 10.
+//                       Pieces are found by extending a prefix through a hash table that holds every piece AND every proper prefix of
+//                       a piece (trie semantics: the extension stops at the first absent prefix).  Consecutive <unk> are merged.
+// Characters the per-character table cannot express (combining marks and conjoining jamo, which the NFKC-based map composes with their
+// neighbour; mappings that expand more than 3x) flag the text for the host tokeniser.
+// ---------------------------------------------------------------------------------------------------------------
+struct mq_sp_entry {
+    uint64_t hash;
+    int32_t id;        // >= 0: piece id; -2: proper prefix of some piece only; -1: empty slot
+    uint32_t off_len;  // (pool offset << 8) | length in bytes (<= 255)
+};
+
+struct mq_sp_table {
+    const mq_sp_entry* slots;
+    const uint8_t* pool;
+    const float* score;      // [vocab] (used for id >= 0)
+    const uint32_t* nmap;    // [MQ_UNI_LIMIT] per code point: (pool2 offset << 8) | normalised byte length; 0xff = needs host; 0 = removed
+    const uint8_t* npool;    // normalised strings
+    const uint8_t* ccc;      // [MQ_UNI_LIMIT] canonical combining class (two adjacent marks in descending class order would be reordered by
+                             // the NFKC-based map: such a text goes to the host)
+    uint32_t mask;
+    int32_t unk_id;          // SentencePiece's own id of <unk>
+    float unk_score;         // min piece score - 10
+    int32_t add_dummy_prefix, remove_extra_ws;
+    int32_t max_piece_bytes;
+};
+
+#define MQ_SP_HOST 0xffu
+
+// A: -> normalised length in bytes (norm has mq_norm_capacity(nbytes)); *status = MQ_TOK_NEEDS_HOST for flagged characters
+MQ_TOK_FN int mq_sp_normalize(const mq_sp_table& T, const uint8_t* text, int nbytes, uint8_t* norm, int* status) {
+    *status = MQ_TOK_OK;
+    int i = 0, pos = 0;
+    int started = 0;       // a non-space character has been emitted
+    int pending_space = 0; // a (collapsed) space waits for the next non-space character
+    int prev_ccc = 0;
+    while (i < nbytes) {
+        uint32_t cp;
+        const int len = mq_utf8_next(text, nbytes, i, &cp);
+        if (len == 0 || cp >= MQ_UNI_LIMIT) { *status = MQ_TOK_NEEDS_HOST; return 0; }
+        i += len;
+        const int cc = T.ccc[cp];
+        if (cc != 0 && prev_ccc > cc) { *status = MQ_TOK_NEEDS_HOST; return 0; }   // canonical reordering
+        prev_ccc = cc;
+        const uint32_t m = T.nmap[cp];
+        const int nl = (int)(m & 0xffu);
+        if (nl == (int)MQ_SP_HOST) { *status = MQ_TOK_NEEDS_HOST; return 0; }
+        const uint8_t* src = T.npool + (m >> 8);
+        for (int k = 0; k < nl; ++k) {
+            const uint8_t b = src[k];
+            if (b == ' ') {
+                if (T.remove_extra_ws) { if (started) pending_space = 1; }       // leading spaces vanish, runs collapse, trailing ones never flush
+                else { norm[pos++] = 0xe2; norm[pos++] = 0x96; norm[pos++] = 0x81; }
+                continue;
+            }
+            if (!started) {
+                started = 1;
+                if (T.add_dummy_prefix) { norm[pos++] = 0xe2; norm[pos++] = 0x96; norm[pos++] = 0x81; }
+            }
+            if (pending_space) { norm[pos++] = 0xe2; norm[pos++] = 0x96; norm[pos++] = 0x81; pending_space = 0; }
+            norm[pos++] = b;
+        }
+    }
+    return pos;
+}
+
+MQ_TOK_FN int32_t mq_sp_find(const mq_sp_table& T, uint64_t h, const uint8_t* s, int len, int* found) {
+    uint32_t slot = (uint32_t)(h ^ (h >> 32)) & T.mask;
+    for (;;) {
+        const mq_sp_entry e = T.slots[slot];
+        if (e.id == -1) { *found = 0; return -1; }
+        if (e.hash == h && (int)(e.off_len & 0xffu) == len) {
+            const uint8_t* p = T.pool + (e.off_len >> 8);
+            int same = 1;
+            for (int k = 0; k < len; ++k)
+                if (p[k] != s[k]) { same = 0; break; }
+            if (same) { *found = 1; return e.id; }
+        }
+        slot = (slot + 1) & T.mask;
+    }
+}
+
+MQ_TOK_FN int mq_utf8_len(uint8_t c) { return c < 0x80 ? 1 : ((c & 0xe0) == 0xc0 ? 2 : ((c & 0xf0) == 0xe0 ? 3 : 4)); }
+
+// B: Viterbi over norm[0..n).  Scratch: best [n+1] floats, bstart [n+1] int32 (-1 = unreached), bid [n+1] int32.
+// Writes the piece ids (SentencePiece numbering, consecutive <unk> merged) to out[0..count) for count <= cap and returns the TOTAL count.
+MQ_TOK_FN int mq_sp_viterbi(const mq_sp_table& T, const uint8_t* norm, int n, float* best, int32_t* bstart, int32_t* bid, int32_t* out, int cap) {
+    if (n <= 0) return 0;
+    for (int k = 0; k <= n; ++k) bstart[k] = -1;
+    best[0] = 0.f;
+    bstart[0] = 0;
+    int s = 0;
+    while (s < n) {
+        const float here = best[s];
+        const int mblen = mq_utf8_len(norm[s]) < n - s ? mq_utf8_len(norm[s]) : n - s;
+        int has_single = 0;
+        uint64_t h = MQ_FNV_OFFSET;
+        int e = s;
+        while (e < n && e - s < T.max_piece_bytes) {
+            const int cl = mq_utf8_len(norm[e]);
+            if (e + cl > n) break;
+            for (int k = 0; k < cl; ++k) h = mq_wp_step(h, norm[e + k]);
+            e += cl;
+            int found;
+            const int32_t id = mq_sp_find(T, h, norm + s, e - s, &found);
+            if (!found) break;                       // no piece continues this prefix
+            if (id >= 0) {
+                const float cand = T.score[id] + here;
+                if (bstart[e] < 0 || cand > best[e]) { best[e] = cand; bstart[e] = s; bid[e] = id; }
+                if (e - s == mblen) has_single = 1;
+            }
+        }
+        if (!has_single) {
+            const int t = s + mblen;
+            const float cand = T.unk_score + here;
+            if (bstart[t] < 0 || cand > best[t]) { best[t] = cand; bstart[t] = s; bid[t] = T.unk_id; }
+        }
+        s += mblen;
+    }
+    // backtrack: count the pieces (consecutive <unk> merged), then write them front to back
+    int total = 0, prev_unk = 0;
+    for (int e = n; e > 0; e = bstart[e]) {
+        const int unk = bid[e] == T.unk_id;
+        if (!(unk && prev_unk)) ++total;
+        prev_unk = unk;
+    }
+    int idx = total;
+    prev_unk = 0;
+    for (int e = n; e > 0; e = bstart[e]) {
+        const int unk = bid[e] == T.unk_id;
+        if (!(unk && prev_unk)) {
+            --idx;
+            if (idx < cap) out[idx] = bid[e];
+        }
+        prev_unk = unk;
+    }
+    return total;
+}
+
+// framing of a row: [prefix_id] ids... [suffix_id] pad...   (XLM-R: <s> ... </s> <pad>; T5 / SigLIP: ... </s>, padded with </s>)
+struct mq_sp_frame {
+    int32_t prefix_id;   // -1: none
+    int32_t suffix_id;
+    int32_t pad_id;
+    int32_t id_offset;   // added to every SentencePiece id (fairseq layout of XLM-R: 1)
+    int32_t unk_out;     // output id of <unk> (XLM-R: 3)
+};
+
+// C: pieces[0..min(total, cap)) -> row of `ld` ids, truncated to max_length including the specials; returns the row length
+MQ_TOK_FN int mq_sp_gather(const mq_sp_table& T, const mq_sp_frame& F, const int32_t* pieces, int total, int cap, int max_length, int32_t* row, int ld) {
+    const int specials = (F.prefix_id >= 0 ? 1 : 0) + 1;
+    int keep = total < cap ? total : cap;
+    if (keep > max_length - specials) keep = max_length - specials > 0 ? max_length - specials : 0;
+    int cnt = 0;
+    if (F.prefix_id >= 0) row[cnt++] = F.prefix_id;
+    for (int j = 0; j < keep; ++j) row[cnt++] = pieces[j] == T.unk_id ? F.unk_out : pieces[j] + F.id_offset;
+    row[cnt++] = F.suffix_id;
+    for (int j = cnt; j < ld; ++j) row[j] = F.pad_id;
+    return cnt;
+}

@@ -400,3 +400,252 @@ class DeviceClipBpeTokenizer(_DeviceTokenizerBase):
             texts = [texts]
         ids, _ = self.encode_device(texts, context_length)
         return ids.cpu().to(torch.int64).numpy()
+
+
+# =====================================================================================================================================
+# SentencePiece unigram on the device (XLM-RoBERTa: multilingual-e5; T5-style vocabularies: SigLIP)
+# =====================================================================================================================================
+SP_ENTRY = np.dtype([("hash", "<u8"), ("id", "<i4"), ("off_len", "<u4")])
+SP_HOST = 0xFF
+
+
+def _fnv_columns(mat: np.ndarray, lens: np.ndarray):
+    """rolling FNV-1a-64 over the rows of a zero-padded uint8 matrix: yields (k, hash after k + 1 bytes) for every column"""
+    h = np.full(mat.shape[0], _FNV_OFFSET, dtype=np.uint64)
+    prime = np.uint64(_FNV_PRIME)
+    with np.errstate(over="ignore"):
+        for k in range(mat.shape[1]):
+            live = lens > k
+            h = np.where(live, (h ^ mat[:, k].astype(np.uint64)) * prime, h)
+            yield k, h
+
+
+def _insert_open_addressing(home: np.ndarray, n_slots: int) -> np.ndarray:
+    """linear-probing placement of keys with the given home slots -> slot index of every key (vectorised: every pass places, among the
+    keys that want the same free slot, the lowest-numbered one and moves the others on by one — exactly what sequential insertion in
+    key order guarantees: no free slot between a key's home and its place)"""
+    mask = n_slots - 1
+    pos = home.astype(np.int64) & mask
+    used = np.zeros(n_slots, dtype=bool)
+    place = np.full(home.shape[0], -1, dtype=np.int64)
+    pending = np.arange(home.shape[0], dtype=np.int64)
+    while pending.size:
+        p = pos[pending]
+        free = ~used[p]
+        cand, cp = pending[free], p[free]
+        if cand.size:
+            uniq, first = np.unique(cp, return_index=True)
+            winners = cand[first]
+            used[uniq] = True
+            place[winners] = uniq
+        pending = pending[place[pending] < 0]
+        pos[pending] = (pos[pending] + 1) & mask
+    return place
+
+
+def build_sentencepiece_table(sp) -> Dict[str, object]:
+    """SentencePieceProcessor (unigram) -> the device tables of csrc/tokenize_algo.h::mq_sp_table:
+      * hash table over every NORMAL piece AND every proper prefix (at character boundaries) of one, keyed by FNV-1a-64 of the bytes;
+      * scores[id];
+      * per-code-point normalisation map, read off the model's OWN normaliser: X(c) = Normalize('a' + c + 'b') minus the frame, checked in
+        a second context; characters whose mapping depends on neighbours (marks, conjoining jamo — the NFKC-based map composes them),
+        U+2581 itself and mappings that grow more than 3x are flagged for the host."""
+    import unicodedata
+    from sentencepiece import sentencepiece_model_pb2 as pb
+    m = pb.ModelProto.FromString(sp.serialized_model_proto())
+    if m.trainer_spec.model_type != 1:
+        raise ValueError("device SentencePiece supports unigram models only")
+    if m.trainer_spec.byte_fallback or any(p.type in (4, 6) for p in m.pieces):
+        raise ValueError("device SentencePiece does not support byte-fallback / user-defined symbols")
+    if m.trainer_spec.treat_whitespace_as_suffix or not m.normalizer_spec.escape_whitespaces:
+        raise ValueError("device SentencePiece expects escaped whitespace as a prefix")
+    unk_id = int(m.trainer_spec.unk_id)
+    normal = [(i, p.piece.encode("utf-8"), float(p.score)) for i, p in enumerate(m.pieces) if p.type == 1]
+    if not normal or max(len(b) for _, b, _ in normal) > 255:
+        raise ValueError("vocabulary without pieces / with a piece longer than 255 bytes")
+    scores = np.zeros(len(m.pieces), dtype=np.float32)
+    for i, _, sc in normal:
+        scores[i] = sc
+    min_score = float(np.float32(min(sc for _, _, sc in normal)))
+    # ---- pieces + prefixes -> keys
+    ids = np.array([i for i, _, _ in normal], dtype=np.int64)
+    lens = np.array([len(b) for _, b, _ in normal], dtype=np.int64)
+    max_len = int(lens.max())
+    mat = np.zeros((len(normal), max_len), dtype=np.uint8)
+    pool = bytearray()
+    starts = np.zeros(len(normal), dtype=np.int64)
+    for r, (_, b, _) in enumerate(normal):
+        mat[r, :len(b)] = np.frombuffer(b, dtype=np.uint8)
+        starts[r] = len(pool)
+        pool += b
+    key_hash, key_len, key_row, key_full = [], [], [], []
+    nxt = np.concatenate([mat[:, 1:], np.zeros((len(normal), 1), np.uint8)], axis=1)
+    for k, h in _fnv_columns(mat, lens):
+        boundary = (lens > k) & ((lens == k + 1) | ((nxt[:, k] & 0xC0) != 0x80))      # a character ends at byte k
+        rows = np.nonzero(boundary)[0]
+        key_hash.append(h[rows])
+        key_len.append(np.full(rows.size, k + 1, dtype=np.int64))
+        key_row.append(rows)
+        key_full.append(lens[rows] == k + 1)
+    key_hash, key_len, key_row, key_full = (np.concatenate(x) for x in (key_hash, key_len, key_row, key_full))
+    # one entry per distinct (hash, length); a full piece wins over a mere prefix.  (64-bit collisions between DIFFERENT strings of one
+    # length would merge two keys: the lookup verifies bytes, so a collision could only hide a key — checked below.)
+    order = np.lexsort((~key_full, key_len, key_hash))
+    kh, kl, kr, kf = key_hash[order], key_len[order], key_row[order], key_full[order]
+    first = np.ones(kh.size, dtype=bool)
+    first[1:] = (kh[1:] != kh[:-1]) | (kl[1:] != kl[:-1])
+    kh, kl, kr, kf = kh[first], kl[first], kr[first], kf[first]
+    n_keys = int(kh.size)
+    n_slots = _pow2_at_least(2 * n_keys + 1)
+    place = _insert_open_addressing((kh ^ (kh >> np.uint64(32))) & np.uint64(0xffffffff), n_slots)
+    slots = np.zeros(n_slots, dtype=SP_ENTRY)
+    slots["id"] = -1
+    slots["hash"][place] = kh
+    slots["id"][place] = np.where(kf, ids[kr], -2).astype(np.int32)
+    slots["off_len"][place] = ((starts[kr] << 8) | kl).astype(np.uint32)
+    distinct = {bytes(b[:k]) for _, b, _ in normal for k in range(1, len(b) + 1) if k == len(b) or (b[k] & 0xC0) != 0x80}
+    if len(distinct) != n_keys:
+        raise ValueError("FNV-1a-64 collision inside the SentencePiece vocabulary")
+    # ---- per-code-point normalisation map
+    nmap = np.zeros(UNI_LIMIT, dtype=np.uint32)
+    npool = bytearray()
+    cache: Dict[str, int] = {}
+    host = SP_HOST
+    norm = sp.normalize
+    frame = norm("ab")
+    pre, suf = frame[:-1], "b"
+    if frame != pre + suf or not norm("a b").startswith(pre):
+        raise ValueError("unexpected normaliser framing")
+    frame2 = norm("かア")
+    composing = set()
+    for c in range(0x110000):
+        d = unicodedata.decomposition(chr(c))
+        if d and not d.startswith("<"):
+            parts = d.split()
+            # (composition exclusions — Hebrew points, Devanagari nukta ... — decompose but never re-compose: they stay context-free)
+            if len(parts) == 2 and len(unicodedata.normalize("NFC", chr(int(parts[0], 16)) + chr(int(parts[1], 16)))) == 1:
+                composing.add(int(parts[1], 16))
+    ccc = np.zeros(UNI_LIMIT, dtype=np.uint8)
+    for cp in range(UNI_LIMIT):
+        if 0xD800 <= cp <= 0xDFFF or cp == 0x2581:
+            nmap[cp] = host
+            continue
+        ch = chr(cp)
+        # contextual under the NFKC-based map: a character that is the SECOND half of a canonical composition (it merges with the
+        # character before it), conjoining jamo vowels / trailing consonants (algorithmic composition) -> host.  Other marks pass
+        # through on their own; their canonical REORDERING (two adjacent marks with descending combining classes) is caught on the
+        # device from the ccc table
+        if cp in composing or 0x1160 <= cp <= 0x11FF or 0xD7B0 <= cp <= 0xD7FF:
+            nmap[cp] = host
+            continue
+        ccc[cp] = unicodedata.combining(ch)
+        r = norm("a" + ch + "b")
+        if not (r.startswith(pre) and r.endswith(suf)):
+            nmap[cp] = host
+            continue
+        x = r[len(pre):len(r) - 1]
+        r2 = norm("か" + ch + "ア")
+        if not (r2.startswith(frame2[:-1]) and r2.endswith(frame2[-1])) or r2[len(frame2) - 1:len(r2) - 1] != x:
+            nmap[cp] = host
+            continue
+        x = x.replace("▁", " ")
+        xb = x.encode("utf-8")
+        if len(xb) > 3 * len(ch.encode("utf-8")) or len(xb) >= host:
+            nmap[cp] = host
+            continue
+        off = cache.get(x)
+        if off is None:
+            off = cache[x] = len(npool)
+            npool += xb
+        nmap[cp] = (off << 8) | len(xb)
+    return dict(slots=slots, pool=np.frombuffer(bytes(pool) + b"\0" * 16, dtype=np.uint8).copy(), scores=scores, nmap=nmap,
+                npool=np.frombuffer(bytes(npool) + b"\0" * 16, dtype=np.uint8).copy(), ccc=ccc, n_slots=n_slots, unk_id=unk_id,
+                unk_score=float(np.float32(min_score) - np.float32(10.0)), add_dummy_prefix=int(m.normalizer_spec.add_dummy_prefix),
+                remove_extra_ws=int(m.normalizer_spec.remove_extra_whitespaces), max_piece_bytes=max_len)
+
+
+class DeviceSentencePieceTokenizer(_DeviceTokenizerBase):
+    """SentencePiece unigram on the GPU.  `host` is the host tokeniser of record: an XlmRobertaTokenizer (rows <s> ids + 1 ... </s>, <pad>
+    padding, <unk> = 3) or a SiglipTokenizer backed by `spiece.model` (canonicalize on the host — three string operations — then rows
+    ids ... </s> padded with </s> to the context length).  Texts the kernel flags (composing marks, conjoining jamo, reordering mark
+    sequences, code points beyond U+2FFFF) are tokenised by `host` and patched in."""
+
+    def __init__(self, host, device: str):
+        super().__init__(device)
+        self.host = host
+        from marqo_amd.engine.tokenizers import SiglipTokenizer, XlmRobertaTokenizer
+        if isinstance(host, XlmRobertaTokenizer):
+            sp, frame = host.sp, dict(prefix_id=host.cls_id, suffix_id=host.sep_id, pad_id=host.pad_id, id_offset=host.FAIRSEQ_OFFSET, unk_out=host.unk_id)
+            self.kind = "xlmr"
+        elif isinstance(host, SiglipTokenizer) and host._sp is not None:
+            sp, frame = host._sp, dict(prefix_id=-1, suffix_id=host.eos_id, pad_id=host.pad_id, id_offset=0, unk_out=int(host._sp.unk_id()))
+            self.kind = "siglip"
+        else:
+            raise ValueError("DeviceSentencePieceTokenizer needs an XlmRobertaTokenizer or a sentencepiece-backed SiglipTokenizer")
+        t = build_sentencepiece_table(sp)
+        self.pad_id = frame["pad_id"]
+        self.vocab = L.SentencePieceVocab(
+            d_slots=self._up(t["slots"]).data_ptr(), d_pool=self._up(t["pool"]).data_ptr(), d_score=self._up(t["scores"]).data_ptr(),
+            d_nmap=self._up(t["nmap"]).data_ptr(), d_npool=self._up(t["npool"]).data_ptr(), d_ccc=self._up(t["ccc"]).data_ptr(),
+            n_slots=t["n_slots"], unk_id=t["unk_id"], unk_score=t["unk_score"], add_dummy_prefix=t["add_dummy_prefix"],
+            remove_extra_ws=t["remove_extra_ws"], max_piece_bytes=t["max_piece_bytes"], **frame)
+
+    def encode_device(self, texts: Sequence[str], max_length: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        """-> (ids int32 [n, max_length] on device, padded with the pad id; lengths int64 [n] on host, specials included)"""
+        n = len(texts)
+        ids = torch.full((n, max_length), self.pad_id, dtype=torch.int32, device=self.device)
+        lens = torch.zeros(n, dtype=torch.int64)
+        if n == 0:
+            return ids, lens
+        if self.kind == "siglip":
+            from marqo_amd.engine.tokenizers import canonicalize_text
+            texts = [canonicalize_text(t) for t in texts]
+        on_dev = [i for i, t in enumerate(texts) if len(t) < MAX_TEXT_BYTES_DEVICE // 4 and _encodable(t)]
+        dev_set = set(on_dev)
+        if on_dev:
+            sel = texts if len(on_dev) == n else [texts[i] for i in on_dev]
+            m = len(sel)
+            with self._lock, torch.cuda.device(self.device):
+                d_blob, d_off, total = self._stage(sel)
+                d_ids = ids if m == n else torch.empty(m, max_length, dtype=torch.int32, device=self.device)
+                d_meta = torch.empty(2, m, dtype=torch.int32, device=self.device)
+                need = int(self.lib.mq_tokenize_sentencepiece_workspace_bytes(m, total, max_length))
+                if self._ws is None or self._ws.numel() < need:
+                    self._ws = torch.empty(int(need * 1.25) + 256, dtype=torch.uint8, device=self.device)
+                L.check(self.lib.mq_tokenize_sentencepiece(C.byref(self.vocab), d_blob.data_ptr(), d_off.data_ptr(), m, total, max_length,
+                                                           d_ids.data_ptr(), max_length, d_meta[0].data_ptr(), d_meta[1].data_ptr(),
+                                                           self._ws.data_ptr(), self._ws.numel(),
+                                                           torch.cuda.current_stream(self.device).cuda_stream), "mq_tokenize_sentencepiece")
+                meta = d_meta.cpu()
+            if bool((meta[1] != 0).any()):
+                dev_set.difference_update(on_dev[j] for j in torch.nonzero(meta[1]).flatten().tolist())
+            idx = torch.tensor(on_dev, dtype=torch.int64)
+            lens[idx] = meta[0].to(torch.int64)
+            if m != n:
+                ids[idx.to(self.device)] = d_ids
+        rest = [i for i in range(n) if i not in dev_set]
+        if rest:
+            block = torch.full((len(rest), max_length), self.pad_id, dtype=torch.int32)
+            for j, i in enumerate(rest):
+                if self.kind == "xlmr":
+                    e = self.host.encode(texts[i], max_length)
+                else:  # (already canonicalised above)
+                    e = (list(self.host._sp.encode(texts[i]))[: max_length - 1]) + [self.host.eos_id]
+                block[j, :len(e)] = torch.tensor(e, dtype=torch.int32)
+                lens[i] = len(e)
+            ids[torch.tensor(rest, device=self.device)] = block.to(self.device)
+        return ids, lens
+
+    def __call__(self, texts, max_length: Optional[int] = None):
+        """drop-in for the host tokeniser's __call__ (XLM-R: dict padded to the longest; SigLIP: int64 [n, ctx])"""
+        if isinstance(texts, str):
+            texts = [texts]
+        if self.kind == "siglip":
+            ids, _ = self.encode_device(texts, self.host.context_length)
+            return ids.cpu().to(torch.int64).numpy()
+        cap = max_length if max_length is not None else 2 + 4 * max((len(t) for t in texts), default=0)
+        ids, lens = self.encode_device(texts, cap)
+        S = int(lens.max()) if len(texts) else 0
+        out = ids[:, :S].cpu().to(torch.int64).numpy()
+        mask = (np.arange(S)[None, :] < lens.numpy()[:, None]).astype(np.int64)
+        return {"input_ids": out, "attention_mask": mask}

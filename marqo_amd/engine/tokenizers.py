@@ -369,6 +369,9 @@ class SiglipTokenizer:
             self._fast.enable_truncation(max_length=context_length)
             self._fast.no_padding()
             self.vocab_size = self._fast.get_vocab_size()
+            if os.path.isfile(sm):  # the SentencePiece model beside it feeds the device tokeniser's tables (engine/gpu_tokenizers.py)
+                import sentencepiece as spm
+                self._sp = spm.SentencePieceProcessor(model_file=sm)
         elif os.path.isfile(sm):
             import sentencepiece as spm
             self._sp = spm.SentencePieceProcessor(model_file=sm)

@@ -142,6 +142,12 @@ class HuggingFaceModel(AbstractEmbeddingModel):
         if isinstance(self._tokenizer, WordPieceTokenizer) and os.environ.get("MARQO_AMD_HOST_TOKENIZER", "0") != "1":
             from marqo_amd.engine.gpu_tokenizers import DeviceWordPieceTokenizer
             self._device_tokenizer = DeviceWordPieceTokenizer(self._tokenizer, self.device)
+        elif isinstance(self._tokenizer, XlmRobertaTokenizer) and os.environ.get("MARQO_AMD_HOST_TOKENIZER", "0") != "1":
+            from marqo_amd.engine.gpu_tokenizers import DeviceSentencePieceTokenizer
+            try:   # unigram Viterbi on the device (multilingual-e5); models it cannot express (byte fallback ...) stay on the host
+                self._device_tokenizer = DeviceSentencePieceTokenizer(self._tokenizer, self.device)
+            except ValueError:
+                self._device_tokenizer = None
 
     @staticmethod
     def _do_lower_case(directory: str) -> bool:

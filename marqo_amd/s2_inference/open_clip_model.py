@@ -221,6 +221,12 @@ class OPEN_CLIP(AbstractCLIPModel):
         if isinstance(self.tokenizer, ClipBpeTokenizer) and os.environ.get("MARQO_AMD_HOST_TOKENIZER", "0") != "1":
             from marqo_amd.engine.gpu_tokenizers import DeviceClipBpeTokenizer
             self._device_tokenizer = DeviceClipBpeTokenizer(self.tokenizer, self.device)
+        elif isinstance(self.tokenizer, SiglipTokenizer) and self.tokenizer._sp is not None and os.environ.get("MARQO_AMD_HOST_TOKENIZER", "0") != "1":
+            from marqo_amd.engine.gpu_tokenizers import DeviceSentencePieceTokenizer
+            try:
+                self._device_tokenizer = DeviceSentencePieceTokenizer(self.tokenizer, self.device)
+            except ValueError:
+                self._device_tokenizer = None
         self._ImagePreprocessor = ImagePreprocessor
         self.preprocess = self._preprocess_one
 
@@ -336,7 +342,12 @@ class OPEN_CLIP(AbstractCLIPModel):
             self.load()
         with request_stream(self.device, device_output=return_device):
             if getattr(self, "_device_tokenizer", None) is not None:
-                d_ids, lens = self._device_tokenizer.encode_device([sentence] if isinstance(sentence, str) else list(sentence))
+                texts = [sentence] if isinstance(sentence, str) else list(sentence)
+                if self.text_arch.causal:
+                    d_ids, lens = self._device_tokenizer.encode_device(texts)
+                else:  # SigLIP: every row is ctx positions (pieces, </s>, </s> padding) and all of them run
+                    d_ids, _ = self._device_tokenizer.encode_device(texts, self.text_arch.ctx)
+                    lens = torch.full((len(texts),), self.text_arch.ctx, dtype=torch.int64)
                 out = self.text.encode_device(d_ids, lens, normalize=bool(normalize))
             else:
                 ids = torch.as_tensor(np.asarray(self.tokenizer(sentence)))

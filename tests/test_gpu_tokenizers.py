@@ -347,3 +347,87 @@ def test_clip_bpe_unicode_fuzz_matches_python_tokenizer(tokhost):
         assert ids[i].tolist() == ref[i].tolist(), (repr(t), ids[i, :12].tolist(), ref[i, :12].tolist())
         assert lens[i] == int(ref[i].argmax()) + 1
     assert len(texts) > 5000 and flagged < 0.02 * len(texts), flagged
+
+
+# ---- SentencePiece unigram ---------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def sp_model(tmp_path_factory):
+    import sentencepiece as spm
+    d = tmp_path_factory.mktemp("spm")
+    corpus = [" ".join(CORPUS)] * 20 + SENTENCES[:6] * 5 + _unicode_texts(41, 600)
+    (d / "c.txt").write_text("\n".join(t.replace("\n", " ").replace("\x00", "") for t in corpus), encoding="utf-8")
+    spm.SentencePieceTrainer.train(input=str(d / "c.txt"), model_prefix=str(d / "sentencepiece.bpe"), vocab_size=600, model_type="unigram",
+                                   character_coverage=0.98, hard_vocab_limit=False, minloglevel=2)
+    return d
+
+
+def _host_sentencepiece(lib, T, texts, max_length, frame):
+    blob, off = GT.pack_texts(texts)
+    n = len(texts)
+    ids, lens, st = np.zeros((n, max_length), np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32)
+    normout = np.zeros(3 * len(blob) + 16 * n + 64, np.uint8)
+    nlen = np.zeros(n, np.int32)
+    lib.tokhost_sentencepiece(_p(T["slots"]), _p(T["pool"]), _p(T["scores"]), _p(T["nmap"]), _p(T["npool"]), _p(T["ccc"]), C.c_uint32(T["n_slots"]),
+                              T["unk_id"], C.c_float(T["unk_score"]), T["add_dummy_prefix"], T["remove_extra_ws"], T["max_piece_bytes"], *frame,
+                              _p(blob), _p(off), C.c_int64(n), max_length, _p(ids), C.c_int64(max_length), _p(lens), _p(st), _p(normout), _p(nlen))
+    norms = [bytes(normout[3 * int(off[i]) + 16 * i: 3 * int(off[i]) + 16 * i + nlen[i]]).decode("utf-8") if not st[i] else None for i in range(n)]
+    return ids, lens, st, norms
+
+
+def test_sentencepiece_unigram_algorithm_matches_sentencepiece(tokhost, sp_model):
+    """the product's normaliser + Viterbi (host build) against the sentencepiece library itself and against the XLM-R wrapper: the
+    normalised text equals SentencePieceProcessor.Normalize, the ids equal XlmRobertaTokenizer.encode, on >= 5k multi-script texts"""
+    from marqo_amd.engine.tokenizers import XlmRobertaTokenizer
+    tok = XlmRobertaTokenizer(str(sp_model))
+    T = GT.build_sentencepiece_table(tok.sp)
+    texts = _unicode_texts(42, 5500) + ["hello world", "  Hello   World\t x ", "", "   ", "ｆｕｌｌ ㍿ ﬁ", "東京都 x", "naïve café", "▁ literal", "á decomposed"]
+    texts = [t for t in texts if GT._encodable(t)]
+    for max_length in (64, 6):
+        ids, lens, st, norms = _host_sentencepiece(tokhost, T, texts, max_length, (0, 2, 1, 1, 3))
+        flagged = 0
+        for i, t in enumerate(texts):
+            if st[i]:
+                flagged += 1
+                continue
+            assert norms[i] == tok.sp.normalize(t), repr(t)
+            ref = tok.encode(t, max_length)
+            assert lens[i] == len(ref) and ids[i, :lens[i]].tolist() == ref, (repr(t), ids[i, :lens[i]].tolist(), ref)
+            assert (ids[i, lens[i]:] == 1).all()
+        # this fuzz appends a raw combining accent to ~1 word in 25 and strings marks together at random: those texts (composition /
+        # canonical reordering is contextual) are the ones handed back
+        assert len(texts) > 5000 and flagged < 0.5 * len(texts)
+    plain = [t for t in texts if all(ord(c) < 0x300 or 0x370 <= ord(c) < 0x3000 and not __import__("unicodedata").combining(c) for c in t)]
+    ids, lens, st, _ = _host_sentencepiece(tokhost, T, plain[:800], 64, (0, 2, 1, 1, 3))
+    assert st.sum() <= 0.02 * len(st)          # precomposed Latin / Greek / Cyrillic text stays on the device
+
+
+def test_sentencepiece_table_properties(sp_model):
+    import sentencepiece as spm
+    sp = spm.SentencePieceProcessor(model_file=str(sp_model / "sentencepiece.bpe.model"))
+    T = GT.build_sentencepiece_table(sp)
+    used = T["slots"]["id"] != -1
+    assert used.sum() >= sum(1 for i in range(len(sp)) if sp.IsUnknown(i) is False and not sp.IsControl(i)) and (T["n_slots"] & (T["n_slots"] - 1)) == 0
+    assert T["unk_score"] == pytest.approx(min(sp.GetScore(i) for i in range(len(sp)) if not sp.IsControl(i) and not sp.IsUnknown(i)) - 10.0)
+    nm = T["nmap"]
+    assert (nm[0x0301] & 0xff) == 0xff and (nm[0x3099] & 0xff) == 0xff and (nm[0x2581] & 0xff) == 0xff     # composing marks, U+2581 -> host
+    assert (nm[0x05B4] & 0xff) != 0xff and (nm[ord("é")] & 0xff) == 2 and (nm[ord(" ")] & 0xff) == 1         # Hebrew point: context-free
+    assert bytes(T["npool"][nm[0x3000] >> 8: (nm[0x3000] >> 8) + 1]) == b" "                                 # ideographic space -> space
+
+
+@pytest.mark.gpu
+def test_device_sentencepiece_equals_host(sp_model, tmp_path):
+    from marqo_amd.engine.tokenizers import SiglipTokenizer, XlmRobertaTokenizer
+    tok = XlmRobertaTokenizer(str(sp_model))
+    dev = GT.DeviceSentencePieceTokenizer(tok, "cuda")
+    texts = _unicode_texts(43, 10500) + ["hello world", "", "   ", "ｆｕｌｌ ㍿ ﬁ", "á decomposed", "\U00030000 far", "lone \ud800"]
+    texts = [t for t in texts if GT._encodable(t)] + ["word " * 300]
+    for max_length in (64, 8):
+        got, ref = dev(texts, max_length=max_length), tok(texts, max_length=max_length)
+        assert np.array_equal(got["input_ids"], ref["input_ids"]) and np.array_equal(got["attention_mask"], ref["attention_mask"])
+    # SigLIP framing over a T5-style model: canonicalize -> pieces -> </s>, padded with </s> to the context length
+    import shutil
+    shutil.copy(str(sp_model / "sentencepiece.bpe.model"), str(tmp_path / "spiece.model"))
+    stok = SiglipTokenizer(str(tmp_path / "spiece.model"), context_length=16)
+    sdev = GT.DeviceSentencePieceTokenizer(stok, "cuda")
+    sample = texts[:3000] + ["A red_dress, size: M (new!)", "UPPER lower"]
+    assert np.array_equal(sdev(sample), stok(sample))
