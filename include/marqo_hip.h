@@ -354,6 +354,9 @@ int mq_gemm_bf16_ln(const void* d_A, int64_t lda, const void* d_W, int64_t ldw, 
  * (d_out_f32); either may be NULL. */
 int mq_layernorm(const float* d_x, const int32_t* d_row_idx, const float* d_g, const float* d_b,
                  void* d_out_bf16, float* d_out_f32, int64_t rows, int32_t W, float eps, void* stream);
+/* the same with the input rows in bf16 (x_bf16 != 0): the LayerNorm of the towers' bf16 residual-stream form (mq_tune("residual_bf16", 1)) */
+int mq_layernorm_ex(const void* d_x, int x_bf16, const int32_t* d_row_idx, const float* d_g, const float* d_b,
+                    void* d_out_bf16, float* d_out_f32, int64_t rows, int32_t W, float eps, void* stream);
 
 /* Multi-head attention over packed sequences.  d_qkv bf16 [rows, 3W] (q | k | v, head h at
  * columns h*hd .. h*hd+hd-1 of each third, hd = W / heads in {64, 96, 112, 128}; softmax scale 1/sqrt(hd)).

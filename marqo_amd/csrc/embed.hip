@@ -110,10 +110,20 @@ constexpr int MAXC = 8;
 template <int CH>
 __global__ __launch_bounds__(256, (CH <= 4 ? 8 : 4)) void vit_assemble_kernel(
     const float* __restrict__ patch_out, const float* __restrict__ cls, const float* __restrict__ pos,
-    const float* __restrict__ gam, const float* __restrict__ bet, float* __restrict__ x, int64_t rows, int T, int W, float eps) {
+    const float* __restrict__ gam, const float* __restrict__ bet, float* __restrict__ x, int64_t rows, int T, int W, float eps, int x_bf16) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
+    auto put = [&](int c, const f32x4& y) {   // the residual stream is fp32, or bf16 when the tower runs its bf16-stream form
+        if (x_bf16) {
+            uint2 q;
+            q.x = pack_bf16x2(y[0], y[1]);
+            q.y = pack_bf16x2(y[2], y[3]);
+            *(uint2*)((bf16_t*)x + row * W + c * 4) = q;
+        } else {
+            *(f32x4*)(x + row * W + c * 4) = y;
+        }
+    };
     const int64_t b = row / T;
     const int t = (int)(row - b * T);
     const float* src = !cls ? patch_out + row * W : (t == 0 ? cls : patch_out + (b * (T - 1) + (t - 1)) * W);
@@ -129,7 +139,7 @@ __global__ __launch_bounds__(256, (CH <= 4 ? 8 : 4)) void vit_assemble_kernel(
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
             const int c = lane + i * 64;
-            if (c < nch) *(f32x4*)(x + row * W + c * 4) = v[i];
+            if (c < nch) put(c, v[i]);
         }
         return;
     }
@@ -143,7 +153,7 @@ __global__ __launch_bounds__(256, (CH <= 4 ? 8 : 4)) void vit_assemble_kernel(
             f32x4 y;
 #pragma unroll
             for (int e = 0; e < 4; ++e) y[e] = v[i][e] * gg[e] + bb[e];
-            *(f32x4*)(x + row * W + c * 4) = y;
+            put(c, y);
         }
     }
 }
@@ -244,7 +254,7 @@ __global__ __launch_bounds__(256, (CH <= 4 ? 8 : 4)) void embed_tokens_kernel(
 #pragma unroll
                     for (int e = 0; e < 4; ++e) y[e] = v[i][e] * gg[e] + bb[e];
                 }
-                *(f32x4*)(x + row * W + c * 4) = y;
+                if (x) *(f32x4*)(x + row * W + c * 4) = y;
                 if (xb) {
                     uint2 p;
                     p.x = pack_bf16x2(y[0], y[1]);
@@ -347,13 +357,13 @@ int mq_patchify(const void* d_in, bool is_u8, void* d_out, int64_t n, int S, int
 }
 
 int mq_vit_assemble(const float* d_patch_out, const float* cls, const float* pos, const float* g, const float* b,
-                    float* d_x, int64_t n, int T, int W, float eps, hipStream_t s) {
+                    float* d_x, int64_t n, int T, int W, float eps, hipStream_t s, int x_bf16) {
     MQ_CHECK_ARG(W % 4 == 0 && W <= 64 * 4 * MAXC, "vit_assemble: W=%d unsupported", W);
     const int64_t rows = n * T;
     if (rows <= 0) return MQ_OK;
     MqProfScope prof(3, s);
     MQ_DISPATCH_CH(W, hipLaunchKernelGGL(vit_assemble_kernel<CH>, dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, s, d_patch_out,
-                                         cls, pos, g, b, d_x, rows, T, W, eps));
+                                         cls, pos, g, b, d_x, rows, T, W, eps, x_bf16));
     MQ_CHECK_LAUNCH("vit_assemble");
     return MQ_OK;
 }

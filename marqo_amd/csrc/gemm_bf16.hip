@@ -26,6 +26,7 @@ extern int mq_tower_row_select;   // towers.hip
 extern int mq_tower_ln_fold;      // towers.hip
 extern int mq_ln_rows_per_wave;   // rowops.hip
 extern int mq_attention_waves;    // attention.hip
+extern int mq_tower_residual_bf16;  // towers.hip
 
 // CU-sized-tile main loop (gemm_big.hip)
 template <int FLAGS>
@@ -393,6 +394,7 @@ extern "C" int mq_gemm_bf16(const void* d_A, int64_t lda, const void* d_W, int64
         MQ_GEMM_CASE(MQ_EPI_BIAS | MQ_EPI_GELU);
         MQ_GEMM_CASE(MQ_EPI_BIAS | MQ_EPI_QUICKGELU);
         MQ_GEMM_CASE(MQ_EPI_BIAS | MQ_EPI_RESIDUAL | MQ_EPI_OUT_F32);
+        MQ_GEMM_CASE(MQ_EPI_BIAS | MQ_EPI_RESIDUAL);   // bf16 residual in (d_residual is bf16), bf16 out
         default:
             mq_set_error("mq_gemm_bf16: unsupported epilogue flag combination 0x%x", flags);
             return MQ_ERR_INVALID;
@@ -456,6 +458,7 @@ extern "C" int mq_tune(const char* key, int value) {
     else if (k == "ln_fold") mq_tower_ln_fold = value;
     else if (k == "ln_rows") mq_ln_rows_per_wave = value;
     else if (k == "attn_waves") mq_attention_waves = value;
+    else if (k == "residual_bf16") mq_tower_residual_bf16 = value;
     else { mq_set_error("mq_tune: unknown key %s", key); return MQ_ERR_INVALID; }
     return MQ_OK;
 }

@@ -187,3 +187,4 @@ MQ_BIG_INST(MQ_EPI_BIAS);
 MQ_BIG_INST(MQ_EPI_BIAS | MQ_EPI_GELU);
 MQ_BIG_INST(MQ_EPI_BIAS | MQ_EPI_QUICKGELU);
 MQ_BIG_INST(MQ_EPI_BIAS | MQ_EPI_RESIDUAL | MQ_EPI_OUT_F32);
+MQ_BIG_INST(MQ_EPI_BIAS | MQ_EPI_RESIDUAL);

@@ -35,6 +35,9 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][4], const float* 
                                               int64_t ldc, int M, int N, int wave_m0, int wave_n0, int l15, int g, bool wide = false,
                                               const GemmLn* lnp = nullptr) {
     constexpr bool BF16_OUT = !(FLAGS & MQ_EPI_OUT_F32);
+    // bf16 residual stream (towers.hip): MQ_EPI_RESIDUAL without MQ_EPI_OUT_F32 = the residual is read as bf16 and the sum written
+    // as bf16, in place — half the epilogue bytes of the fp32 stream, the memory-bound part of the K = 768 residual GEMMs
+    constexpr bool RES_BF16 = (FLAGS & MQ_EPI_RESIDUAL) && BF16_OUT;
     constexpr bool LN_STATS = (FLAGS & MQ_EPI_LN_STATS) != 0, LN_APPLY = (FLAGS & MQ_EPI_LN_APPLY) != 0;
     static_assert(!LN_STATS || ((FLAGS & MQ_EPI_RESIDUAL) && (FLAGS & MQ_EPI_OUT_F32)), "LN_STATS rides on the residual epilogue");
     static_assert(!LN_APPLY || BF16_OUT, "LN_APPLY produces a bf16 GEMM operand");
@@ -55,8 +58,15 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][4], const float* 
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) {
                     const int n = wave_n0 + nt * 16 + g * 4;
-                    res_v[h][nt] = (mt_lo + h < MT && m < M && n < N) ? *(const f32x4*)(residual + (int64_t)m * ldc + n)
-                                                                    : f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (RES_BF16) {
+                        uint2 q = make_uint2(0u, 0u);
+                        if (mt_lo + h < MT && m < M && n < N) q = *(const uint2*)((const bf16_t*)residual + (int64_t)m * ldc + n);
+                        res_v[h][nt] = f32x4{__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u), __uint_as_float(q.y << 16),
+                                             __uint_as_float(q.y & 0xffff0000u)};
+                    } else {
+                        res_v[h][nt] = (mt_lo + h < MT && m < M && n < N) ? *(const f32x4*)(residual + (int64_t)m * ldc + n)
+                                                                        : f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
                 }
             }
         }

@@ -218,3 +218,4 @@ MQ_K32_INST(MQ_EPI_BIAS);
 MQ_K32_INST(MQ_EPI_BIAS | MQ_EPI_GELU);
 MQ_K32_INST(MQ_EPI_BIAS | MQ_EPI_QUICKGELU);
 MQ_K32_INST(MQ_EPI_BIAS | MQ_EPI_RESIDUAL | MQ_EPI_OUT_F32);
+MQ_K32_INST(MQ_EPI_BIAS | MQ_EPI_RESIDUAL);

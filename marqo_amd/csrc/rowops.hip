@@ -16,9 +16,10 @@ constexpr int LN_MAX_CHUNKS = 8;  // float4 chunks per lane: W <= 64 * 4 * 8 = 2
 // VGPRs / occupancy 2 and ran at 2 TB/s).
 // R = rows per wave: the loads of R rows are issued back to back and the 2R wave reductions interleave, which doubles
 // the bytes in flight per wave (the one-row form is latency-bound: 4.9 TB/s with the data sitting in the Infinity Cache).
-template <int CH, int R>
+// XB = the input rows are bf16 (the bf16 residual stream of the pre-LN towers, towers.hip): 8-byte loads, same arithmetic in fp32
+template <int CH, int R, bool XB = false>
 __global__ __launch_bounds__(256, (CH * R <= 4 ? 8 : 4)) void layernorm_kernel(
-    const float* __restrict__ x, const int32_t* __restrict__ row_idx, const float* __restrict__ gam,
+    const void* __restrict__ xv, const int32_t* __restrict__ row_idx, const float* __restrict__ gam,
     const float* __restrict__ bet, bf16_t* out_bf16, float* out_f32, int64_t rows, int W, float eps) {
     const int lane = threadIdx.x & 63;
     const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
@@ -30,11 +31,16 @@ __global__ __launch_bounds__(256, (CH * R <= 4 ? 8 : 4)) void layernorm_kernel(
     for (int r = 0; r < R; ++r) {
         const int64_t row = row0 + r < rows ? row0 + r : rows - 1;  // a ragged last wave re-reads the last row (never stored)
         const int64_t src = row_idx ? (int64_t)row_idx[row] : row;
-        const float* xr = x + src * W;
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
             const int c = lane + i * 64;
-            v[r][i] = c < nch ? *(const f32x4*)(xr + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (c >= nch) { v[r][i] = f32x4{0.f, 0.f, 0.f, 0.f}; continue; }
+            if (XB) {
+                const uint2 q = *(const uint2*)((const bf16_t*)xv + src * W + c * 4);
+                v[r][i] = f32x4{__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u), __uint_as_float(q.y << 16), __uint_as_float(q.y & 0xffff0000u)};
+            } else {
+                v[r][i] = *(const f32x4*)((const float*)xv + src * W + c * 4);
+            }
         }
     }
     // gamma / beta are fetched now, not after the reductions: their (L2) latency hides behind the row loads and the shuffles
@@ -178,13 +184,25 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict_
 
 extern "C" int mq_layernorm(const float* d_x, const int32_t* d_row_idx, const float* d_g, const float* d_b,
                             void* d_out_bf16, float* d_out_f32, int64_t rows, int32_t W, float eps, void* stream) {
+    return mq_layernorm_ex(d_x, 0, d_row_idx, d_g, d_b, d_out_bf16, d_out_f32, rows, W, eps, stream);
+}
+
+extern "C" int mq_layernorm_ex(const void* d_x, int x_bf16, const int32_t* d_row_idx, const float* d_g, const float* d_b,
+                               void* d_out_bf16, float* d_out_f32, int64_t rows, int32_t W, float eps, void* stream) {
     MQ_CHECK_ARG(d_x && d_g && d_b && (d_out_bf16 || d_out_f32), "mq_layernorm: null pointer");
     MQ_CHECK_ARG(W >= 4 && W % 4 == 0 && W <= 64 * 4 * LN_MAX_CHUNKS, "mq_layernorm: W=%d unsupported (multiple of 4, <= 2048)", W);
     if (rows <= 0) return MQ_OK;
     hipStream_t s = (hipStream_t)stream;
     MqProfScope prof(1, s);
     // two rows per wave once there are enough rows to fill the chip that way (and the row fits: CH * 2 float4 per lane)
-    if (mq_ln_rows_per_wave >= 2 && rows >= 8192 && W <= 1024)
+    if (x_bf16) {
+        if (mq_ln_rows_per_wave >= 2 && rows >= 8192 && W <= 1024)
+            MQ_DISPATCH_CH(W, hipLaunchKernelGGL((layernorm_kernel<CH, 2, true>), dim3((unsigned)cdiv64(rows, 8)), dim3(256), 0, s, d_x, d_row_idx,
+                                                 d_g, d_b, (bf16_t*)d_out_bf16, d_out_f32, rows, (int)W, eps));
+        else
+            MQ_DISPATCH_CH(W, hipLaunchKernelGGL((layernorm_kernel<CH, 1, true>), dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, s, d_x, d_row_idx,
+                                                 d_g, d_b, (bf16_t*)d_out_bf16, d_out_f32, rows, (int)W, eps));
+    } else if (mq_ln_rows_per_wave >= 2 && rows >= 8192 && W <= 1024)
         MQ_DISPATCH_CH(W, hipLaunchKernelGGL((layernorm_kernel<CH, 2>), dim3((unsigned)cdiv64(rows, 8)), dim3(256), 0, s, d_x, d_row_idx,
                                              d_g, d_b, (bf16_t*)d_out_bf16, d_out_f32, rows, (int)W, eps));
     else

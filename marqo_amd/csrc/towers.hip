@@ -12,7 +12,7 @@ int mq_cast_bf16(const float* d_x, void* d_out, int64_t n, hipStream_t s);
 int mq_patchify(const void* d_in, bool is_u8, void* d_out, int64_t n, int S, int P, int Kp,
                 const float* mean, const float* std, hipStream_t s);
 int mq_vit_assemble(const float* d_patch_out, const float* cls, const float* pos, const float* g, const float* b,
-                    float* d_x, int64_t n, int T, int W, float eps, hipStream_t s);
+                    float* d_x, int64_t n, int T, int W, float eps, hipStream_t s, int x_bf16 = 0);
 int mq_embed_tokens(const int32_t* d_ids, const int32_t* d_cu, int64_t nseq, const float* tok, const float* pos,
                     const float* type0, const float* g, const float* b, float* d_x, void* d_xb, int W, int vocab,
                     float eps, hipStream_t s);
@@ -37,6 +37,18 @@ int mq_tower_row_select = getenv("MQ_ROW_SELECT") ? atoi(getenv("MQ_ROW_SELECT")
 // LayerNorm folding runs only when the blocks carry folded weights AND this knob is on (mq_tune("ln_fold", 1) / MQ_LN_FOLD=1);
 // it is off by default: on MI355X the folded epilogues cost more than the LayerNorm launches they remove
 int mq_tower_ln_fold = getenv("MQ_LN_FOLD") ? atoi(getenv("MQ_LN_FOLD")) : 0;
+// bf16 residual stream for the pre-LN bf16 towers (mq_tune("residual_bf16", 1) / MQ_RESIDUAL_BF16=1): x is kept in bf16 between
+// blocks.  The residual GEMMs of a K = 768 tower are memory-bound on their epilogue (out-proj: 15 GFLOP against 39 MB read + 39 MB
+// written of fp32 residual) and every LayerNorm re-reads the stream: bf16 halves those bytes.  Cost: one bf16 rounding per residual
+// add (measured 1 - cos 5e-5 .. 1.2e-4 against the fp32 oracle at full depth, well inside the 1e-3 tolerance; the reference's own GPU path
+// keeps its activations in fp16 under autocast, open_clip_model.py:255-260).  Post-LN (BERT) and fp8 towers keep the fp32 stream.
+int mq_tower_residual_bf16 = getenv("MQ_RESIDUAL_BF16") ? atoi(getenv("MQ_RESIDUAL_BF16")) : 0;
+extern "C" int mq_layernorm_ex(const void* d_x, int x_bf16, const int32_t* d_row_idx, const float* d_g, const float* d_b, void* d_out_bf16,
+                               float* d_out_f32, int64_t rows, int32_t W, float eps, void* stream);
+// true when a tower with this encoder config keeps its residual stream in bf16
+static bool stream_bf16(const mq_encoder_cfg* c) {
+    return mq_tower_residual_bf16 && c->precision == MQ_PREC_BF16 && !c->post_ln && !(mq_tower_ln_fold) && !c->mlp_glu && !c->d_rope_inv_freq;
+}
 
 extern "C" int mq_gemm_bf16_ln(const void* d_A, int64_t lda, const void* d_W, int64_t ldw, const float* d_bias, const float* d_residual,
                                void* d_out, int64_t ldc, int64_t M, int64_t N, int64_t K, int flags, float* d_stats, void* d_out2,
@@ -139,20 +151,23 @@ int last_block_selected(const mq_encoder_cfg* cfg, const mq_block_weights& b, in
         MQ_TRY(mq_gemm_fp8(a, W, b.fc1_w8, W, row_scale, 1, b.fc1_ws, b.fc1_b, nullptr, qf, F, s_mlp, nullptr, nsel, F, W, act8, s));
         MQ_TRY(mq_gemm_fp8(qf, F, b.fc2_w8, F, s_mlp, 0, b.fc2_ws, b.fc2_b, x_sel, x_sel, W, nullptr, nullptr, nsel, W, F, res_flags, s));
     } else if (!cfg->post_ln) {
+        const int xb = stream_bf16(cfg) ? 1 : 0;                 // bf16 residual stream: rows of 2 bytes per element, bf16 RMW epilogues
+        const int rflags = xb ? (MQ_EPI_BIAS | MQ_EPI_RESIDUAL) : res_flags;
+        const int64_t xrow = (int64_t)W * (xb ? 2 : 4);
         if (stats) {
             MQ_TRY(mq_gemm_bf16_ln(h, W, b.qkv_wf, W, b.qkv_bf, nullptr, qf, 3 * Wa, rows, 3 * Wa, W, MQ_EPI_BIAS | MQ_EPI_LN_APPLY, stats, nullptr,
                                    b.qkv_sf, cfg->ln_eps, s));
         } else {
-            MQ_TRY(mq_layernorm(d_x, nullptr, b.ln1_g, b.ln1_b, h, nullptr, rows, W, cfg->ln_eps, s));
+            MQ_TRY(mq_layernorm_ex(d_x, xb, nullptr, b.ln1_g, b.ln1_b, h, nullptr, rows, W, cfg->ln_eps, s));
             MQ_TRY(mq_gemm_bf16(h, W, b.qkv_w, W, b.qkv_b, nullptr, qf, 3 * Wa, rows, 3 * Wa, W, MQ_EPI_BIAS, s));
         }
         MQ_TRY(mq_attention(qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, cfg->heads, cfg->mask, s));
         MQ_TRY(mq_move_rows(a, d_sel, h, nsel, (int64_t)Wa * 2, false, s));
-        MQ_TRY(mq_move_rows(d_x, d_sel, x_sel, nsel, (int64_t)W * 4, false, s));
-        MQ_TRY(mq_gemm_bf16(h, Wa, b.out_w, Wa, b.out_b, x_sel, x_sel, W, nsel, W, Wa, res_flags, s));
-        MQ_TRY(mq_layernorm(x_sel, nullptr, b.ln2_g, b.ln2_b, a, nullptr, nsel, W, cfg->ln_eps, s));
+        MQ_TRY(mq_move_rows(d_x, d_sel, x_sel, nsel, xrow, false, s));
+        MQ_TRY(mq_gemm_bf16(h, Wa, b.out_w, Wa, b.out_b, x_sel, x_sel, W, nsel, W, Wa, rflags, s));
+        MQ_TRY(mq_layernorm_ex(x_sel, xb, nullptr, b.ln2_g, b.ln2_b, a, nullptr, nsel, W, cfg->ln_eps, s));
         MQ_TRY(mq_gemm_bf16(a, W, b.fc1_w, W, b.fc1_b, nullptr, qf, F, nsel, F, W, MQ_EPI_BIAS | act_flag, s));
-        MQ_TRY(mq_gemm_bf16(qf, F, b.fc2_w, F, b.fc2_b, x_sel, x_sel, W, nsel, W, F, res_flags, s));
+        MQ_TRY(mq_gemm_bf16(qf, F, b.fc2_w, F, b.fc2_b, x_sel, x_sel, W, nsel, W, F, rflags, s));
     } else {
         MQ_TRY(mq_gemm_bf16(h, W, b.qkv_w, W, b.qkv_b, nullptr, qf, 3 * Wa, rows, 3 * Wa, W, MQ_EPI_BIAS, s));
         MQ_TRY(mq_attention(qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, cfg->heads, cfg->mask, s));
@@ -164,7 +179,7 @@ int last_block_selected(const mq_encoder_cfg* cfg, const mq_block_weights& b, in
         MQ_TRY(mq_gemm_bf16(qf, F, b.fc2_w, F, b.fc2_b, x_sel, x_sel, W, nsel, W, F, res_flags, s));
         MQ_TRY(mq_layernorm(x_sel, nullptr, b.ln2_g, b.ln2_b, nullptr, x_sel, nsel, W, cfg->ln_eps, s));
     }
-    MQ_TRY(mq_move_rows(d_x, d_sel, x_sel, nsel, (int64_t)W * 4, true, s));
+    MQ_TRY(mq_move_rows(d_x, d_sel, x_sel, nsel, (int64_t)W * (!f8 && stream_bf16(cfg) ? 2 : 4), true, s));
     return MQ_OK;
 }
 
@@ -275,14 +290,16 @@ int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* bloc
             MQ_TRY(mq_gemm_fp8(h, W, b.fc1_w8, W, row_scale, 1, b.fc1_ws, b.fc1_b, nullptr, qf, F, s_mlp, m_mlp, rows, F, W, act8, s));
             MQ_TRY(mq_gemm_fp8(qf, F, b.fc2_w8, F, s_mlp, 0, b.fc2_ws, b.fc2_b, d_x, d_x, W, nullptr, nullptr, rows, W, F, res_flags, s));
         } else if (!cfg->post_ln) {
-            // x += out(attn(qkv(ln1(x)))) ; x += fc2(act(fc1(ln2(x))))
-            MQ_TRY(mq_layernorm(d_x, nullptr, b.ln1_g, b.ln1_b, h, nullptr, rows, W, cfg->ln_eps, s));
+            // x += out(attn(qkv(ln1(x)))) ; x += fc2(act(fc1(ln2(x))))   (x fp32, or bf16 in the bf16-stream form)
+            const int xb = stream_bf16(cfg) ? 1 : 0;
+            const int rflags = xb ? (MQ_EPI_BIAS | MQ_EPI_RESIDUAL) : res_flags;
+            MQ_TRY(mq_layernorm_ex(d_x, xb, nullptr, b.ln1_g, b.ln1_b, h, nullptr, rows, W, cfg->ln_eps, s));
             MQ_TRY(mq_gemm_bf16(h, W, b.qkv_w, W, b.qkv_b, nullptr, qf, 3 * Wa, rows, 3 * Wa, W, MQ_EPI_BIAS, s));
             MQ_TRY(mq_attention(qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, cfg->heads, cfg->mask, s));
-            MQ_TRY(mq_gemm_bf16(a, Wa, b.out_w, Wa, b.out_b, d_x, d_x, W, rows, W, Wa, res_flags, s));
-            MQ_TRY(mq_layernorm(d_x, nullptr, b.ln2_g, b.ln2_b, h, nullptr, rows, W, cfg->ln_eps, s));
+            MQ_TRY(mq_gemm_bf16(a, Wa, b.out_w, Wa, b.out_b, (const float*)d_x, d_x, W, rows, W, Wa, rflags, s));
+            MQ_TRY(mq_layernorm_ex(d_x, xb, nullptr, b.ln2_g, b.ln2_b, h, nullptr, rows, W, cfg->ln_eps, s));
             MQ_TRY(mq_gemm_bf16(h, W, b.fc1_w, W, b.fc1_b, nullptr, qf, F, rows, F, W, MQ_EPI_BIAS | act_flag, s));
-            MQ_TRY(mq_gemm_bf16(qf, F, b.fc2_w, F, b.fc2_b, d_x, d_x, W, rows, W, F, res_flags, s));
+            MQ_TRY(mq_gemm_bf16(qf, F, b.fc2_w, F, b.fc2_b, (const float*)d_x, d_x, W, rows, W, F, rflags, s));
         } else {
             // x = ln1(x + out(attn(qkv(x)))) ; x = ln2(x + fc2(act(fc1(x))))
             MQ_TRY(mq_gemm_bf16(h, W, b.qkv_w, W, b.qkv_b, nullptr, qf, 3 * Wa, rows, 3 * Wa, W, MQ_EPI_BIAS, s));
@@ -399,7 +416,8 @@ int encode_image_impl(const mq_vit_cfg* cfg, const mq_vit_weights* w, const void
     // K10 (normalise) + K1: im2col gather, conv-as-GEMM, class token + pos + ln_pre (MAP: + pos, which carries the conv bias)
     MQ_TRY(mq_patchify(d_pixels, is_u8, patches, n, cfg->image_size, cfg->patch_size, p.Kp, cfg->mean, cfg->std, s));
     MQ_TRY(mq_gemm_bf16(patches, p.Kp, w->patch_w, p.Kp, nullptr, nullptr, patch_out, W, n * p.np, W, p.Kp, MQ_EPI_OUT_F32, s));
-    MQ_TRY(mq_vit_assemble(patch_out, w->cls, w->pos, w->ln_pre_g, w->ln_pre_b, x, n, p.T, W, cfg->enc.ln_eps, s));
+    const int xb = stream_bf16(&cfg->enc) ? 1 : 0;   // residual stream in bf16 (same buffer, half of it used)
+    MQ_TRY(mq_vit_assemble(patch_out, w->cls, w->pos, w->ln_pre_g, w->ln_pre_b, x, n, p.T, W, cfg->enc.ln_eps, s, xb));
     if (map) {
         // K2-K5 x layers on every token, then the trunk's norm on every token and the attention-pool head:
         //   k | v = norm(x) @ kv_w^T + kv_b;  o = softmax(q k^T) v per head (one learned query);  y = o @ proj^T + b;
@@ -413,7 +431,7 @@ int encode_image_impl(const mq_vit_cfg* cfg, const mq_vit_weights* w, const void
         float* y = (float*)(base + p.off_map_y);
         void* z = base + p.off_map_z;
         void* hmid = base + p.off_map_h;
-        MQ_TRY(mq_layernorm(x, nullptr, w->ln_post_g, w->ln_post_b, tok, nullptr, p.rows, W, cfg->enc.ln_eps, s));
+        MQ_TRY(mq_layernorm_ex(x, xb, nullptr, w->ln_post_g, w->ln_post_b, tok, nullptr, p.rows, W, cfg->enc.ln_eps, s));
         MQ_TRY(mq_gemm_bf16(tok, W, m->kv_w, W, m->kv_b, nullptr, kv, 2 * W, p.rows, 2 * W, W, MQ_EPI_BIAS, s));
         MQ_TRY(mq_map_pool(kv, m->q, cls_ln, n, p.T, W, cfg->enc.heads, s));
         MQ_CHECK_HIP(hipMemsetAsync(y, 0, (size_t)n * W * 4, s));   // bias-only epilogue = the residual epilogue over zeros
@@ -437,7 +455,7 @@ int encode_image_impl(const mq_vit_cfg* cfg, const mq_vit_weights* w, const void
     MQ_TRY(encoder_forward_impl(&cfg->enc, w->blocks, x, p.rows, nullptr, n, p.T, p.T, rows_idx, n, base + p.off_enc,
                                 ws_bytes - p.off_enc, s));
     // K6: ln_post(class token) @ proj, L2
-    MQ_TRY(mq_layernorm(x, rows_idx, w->ln_post_g, w->ln_post_b, cls_ln, nullptr, n, W, cfg->enc.ln_eps, s));
+    MQ_TRY(mq_layernorm_ex(x, xb, rows_idx, w->ln_post_g, w->ln_post_b, cls_ln, nullptr, n, W, cfg->enc.ln_eps, s));
     MQ_TRY(mq_gemm_bf16(cls_ln, W, w->proj_w, W, nullptr, nullptr, d_out, cfg->out_dim, n, cfg->out_dim, W, MQ_EPI_OUT_F32, s));
     if (normalize) MQ_TRY(mq_l2_normalize(d_out, d_out, n, cfg->out_dim, s));
     return MQ_OK;
@@ -512,12 +530,14 @@ extern "C" int mq_encode_clip_text(const mq_clip_text_cfg* cfg, const mq_clip_te
     void* pooled = base + p.off_pool;  // bf16 [nseq, W]
     const int W = cfg->enc.width;
 
-    MQ_TRY(mq_embed_tokens(d_ids, d_cu_seqlens, nseq, w->tok_emb, w->pos, nullptr, nullptr, nullptr, x, nullptr, W, cfg->vocab, 0.f, s));
+    const int xb = stream_bf16(&cfg->enc) ? 1 : 0;   // residual stream in bf16: the embedding kernel writes its bf16 output into x
+    MQ_TRY(mq_embed_tokens(d_ids, d_cu_seqlens, nseq, w->tok_emb, w->pos, nullptr, nullptr, nullptr, xb ? nullptr : x, xb ? (void*)x : nullptr, W,
+                           cfg->vocab, 0.f, s));
     const int32_t* pool_rows = d_pool_rows;
     if (!pool_rows) { MQ_TRY(mq_last_rows(d_cu_seqlens, rows_idx, nseq, s)); pool_rows = rows_idx; }
     MQ_TRY(encoder_forward_impl(&cfg->enc, w->blocks, x, rows, d_cu_seqlens, nseq, 0, maxl, pool_rows, nseq, base + p.off_enc,
                                 workspace_bytes - p.off_enc, s));
-    MQ_TRY(mq_layernorm(x, pool_rows, w->ln_final_g, w->ln_final_b, pooled, nullptr, nseq, W, cfg->enc.ln_eps, s));
+    MQ_TRY(mq_layernorm_ex(x, xb, pool_rows, w->ln_final_g, w->ln_final_b, pooled, nullptr, nseq, W, cfg->enc.ln_eps, s));
     if (w->proj_b) {  // SigLIP: Linear with bias = the residual epilogue over zeros
         MQ_CHECK_HIP(hipMemsetAsync(d_out, 0, (size_t)nseq * cfg->out_dim * 4, s));
         MQ_TRY(mq_gemm_bf16(pooled, W, w->proj_w, W, w->proj_b, d_out, d_out, cfg->out_dim, nseq, cfg->out_dim, W,

@@ -443,3 +443,40 @@ def test_clip_text_full_depth_realistic_weights_bf16():
     e = float((1 - torch.nn.functional.cosine_similarity(out.double(), ref.double(), dim=-1)).max())
     print(f"CLIP text L/14 12L realistic weights (SOT attention-sink massive activation): bf16 1-cos vs fp32 oracle {e:.2e}")
     assert e < 3e-4
+
+
+def test_bf16_residual_stream_parity():
+    """mq_tune("residual_bf16", 1): the pre-LN towers keep x in bf16 between blocks (half the bytes of every residual epilogue and
+    LayerNorm).  Full registry depth, plain and trained-like weights: still inside the 3e-4 the fp32-stream form is held to, and the
+    pooled-rows-only last block stays bit-identical to the all-rows execution in this form too."""
+    from marqo_amd import _lib as L
+    from marqo_amd.engine import archs, towers
+    lib = L.load()
+    try:
+        L.check(lib.mq_tune(b"residual_bf16", 1))
+        for arch_name, cfg in (("ViT-B-32", O.VitConfig(224, 32, 768, 12, 12, 3072, 512)), ("ViT-L-14", O.VitConfig(224, 14, 1024, 24, 16, 4096, 768))):
+            varch, tarch = archs.resolve_open_clip(arch_name)
+            for weights in ("plain", "realistic"):
+                sd = O.synthetic_vit_state_dict(cfg, 0) if weights == "plain" else O.synthetic_vit_state_dict_realistic(cfg, 0)
+                u8 = O.synthetic_images_u8(3, 224, seed=9)
+                ref = O.vit_forward(sd, cfg, O.preprocess_u8_exact_size(u8))
+                tower = towers.VitTower(varch, sd, "cuda:0")
+                out = tower.encode_u8(u8.to("cuda:0"))
+                e = float((1 - torch.nn.functional.cosine_similarity(out.cpu().double(), ref.double(), dim=-1)).max())
+                print(f"bf16 residual stream, {arch_name} {weights}: 1-cos vs fp32 oracle {e:.2e}")
+                assert e < 3e-4
+                L.check(lib.mq_tune(b"row_select", 0))
+                full = tower.encode_u8(u8.to("cuda:0"))
+                L.check(lib.mq_tune(b"row_select", 1))
+                assert torch.equal(full, out)
+        tcfg = O.ClipTextConfig(49408, 77, 768, 12, 12, 3072, 768)
+        _, tarch = archs.resolve_open_clip("ViT-L-14")
+        sd = O.synthetic_clip_text_state_dict_realistic(tcfg, 0)
+        ids = O.synthetic_clip_ids(12, seed=6)
+        out = towers.ClipTextTower(tarch, sd, "cuda:0").encode_ids(ids).cpu()
+        e = float((1 - torch.nn.functional.cosine_similarity(out.double(), O.clip_text_forward(sd, tcfg, ids).double(), dim=-1)).max())
+        print(f"bf16 residual stream, CLIP text L/14 realistic: 1-cos vs fp32 oracle {e:.2e}")
+        assert e < 5e-4
+    finally:
+        L.check(lib.mq_tune(b"residual_bf16", 0))
+        L.check(lib.mq_tune(b"row_select", 1))

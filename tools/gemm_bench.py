@@ -14,6 +14,8 @@ SHAPES = [
     ("b32 out", 12800, 768, 768, L.MQ_EPI_BIAS | L.MQ_EPI_RESIDUAL | L.MQ_EPI_OUT_F32),
     ("b32 fc1", 12800, 3072, 768, L.MQ_EPI_BIAS | L.MQ_EPI_GELU),
     ("b32 fc2", 12800, 768, 3072, L.MQ_EPI_BIAS | L.MQ_EPI_RESIDUAL | L.MQ_EPI_OUT_F32),
+    ("b32 out16", 12800, 768, 768, L.MQ_EPI_BIAS | L.MQ_EPI_RESIDUAL),      # bf16 residual stream form (mq_tune residual_bf16)
+    ("b32 fc2_16", 12800, 768, 3072, L.MQ_EPI_BIAS | L.MQ_EPI_RESIDUAL),
     ("b32 patch", 12544, 768, 3072, L.MQ_EPI_OUT_F32),
     ("l14 qkv", 16448, 3072, 1024, L.MQ_EPI_BIAS),
     ("l14 out", 16448, 1024, 1024, L.MQ_EPI_BIAS | L.MQ_EPI_RESIDUAL | L.MQ_EPI_OUT_F32),
