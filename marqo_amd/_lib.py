@@ -139,6 +139,7 @@ _SIGNATURES = {
     "mq_layernorm_fp8": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, C.c_int32, C.c_float, _P]),
     "mq_rowquant_fp8": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, _P]),
     "mq_layernorm": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, C.c_int32, C.c_float, _P]),
+    "mq_layernorm_ex": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, C.c_int64, C.c_int32, C.c_float, _P]),
     "mq_attention_ex": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
     "mq_attention": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "mq_encoder_forward": (C.c_int, [C.POINTER(EncoderCfg), C.POINTER(BlockWeights), _P, C.c_int64, _P, C.c_int64,
