@@ -131,6 +131,9 @@ _SIGNATURES = {
                                  C.c_size_t, _P]),
     "mq_gemm_bf16": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
                                C.c_int, _P]),
+    "mq_gemm_small_bf16": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, _P]),
+    "mq_ln_gemm_small_bf16": (C.c_int, [_P, C.c_int64, C.c_int, _P, _P, C.c_float, _P, C.c_int64, _P, _P, C.c_int64, C.c_int64, C.c_int64,
+                                        C.c_int64, C.c_int, _P]),
     "mq_gemm_bf16_ln": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int,
                                   _P, _P, _P, C.c_float, _P]),
     "mq_gemm_fp8": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, C.c_int, _P, _P, _P, _P, C.c_int64, _P, _P, C.c_int64, C.c_int64,

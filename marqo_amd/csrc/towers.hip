@@ -45,6 +45,17 @@ int mq_tower_ln_fold = getenv("MQ_LN_FOLD") ? atoi(getenv("MQ_LN_FOLD")) : 0;
 int mq_tower_residual_bf16 = getenv("MQ_RESIDUAL_BF16") ? atoi(getenv("MQ_RESIDUAL_BF16")) : 0;
 extern "C" int mq_layernorm_ex(const void* d_x, int x_bf16, const int32_t* d_row_idx, const float* d_g, const float* d_b, void* d_out_bf16,
                                float* d_out_f32, int64_t rows, int32_t W, float eps, void* stream);
+// search path (rows <= 80): LayerNorm fused into the skinny GEMM's prologue (gemm_small.hip)
+bool mq_gemm_small_ok(int64_t M, int64_t N, int64_t K, bool ln);
+int mq_ln_gemm_small(const void* d_x, int64_t ldx, int x_bf16, const float* ln_g, const float* ln_b, float eps, const void* d_W, int64_t ldw,
+                     const float* d_bias, void* d_out, int64_t ldc, int64_t M, int64_t N, int64_t K, int flags, hipStream_t s);
+// h = LN(x) ; out = epi(h @ W^T): one fused launch when the rows fit the skinny kernel, else LayerNorm kernel + tiled GEMM
+static int ln_gemm(const void* d_x, int xb, const float* g, const float* b, float eps, void* h, const void* W, const float* bias, void* out,
+                   int64_t rows, int N, int K, int flags, hipStream_t s) {
+    if (mq_gemm_small_ok(rows, N, K, true)) return mq_ln_gemm_small(d_x, K, xb, g, b, eps, W, K, bias, out, N, rows, N, K, flags, s);
+    MQ_TRY(mq_layernorm_ex(d_x, xb, nullptr, g, b, h, nullptr, rows, K, eps, s));
+    return mq_gemm_bf16(h, K, W, K, bias, nullptr, out, N, rows, N, K, flags, s);
+}
 // true when a tower with this encoder config keeps its residual stream in bf16
 static bool stream_bf16(const mq_encoder_cfg* c) {
     return mq_tower_residual_bf16 && c->precision == MQ_PREC_BF16 && !c->post_ln && !(mq_tower_ln_fold) && !c->mlp_glu && !c->d_rope_inv_freq;
@@ -165,8 +176,7 @@ int last_block_selected(const mq_encoder_cfg* cfg, const mq_block_weights& b, in
         MQ_TRY(mq_move_rows(a, d_sel, h, nsel, (int64_t)Wa * 2, false, s));
         MQ_TRY(mq_move_rows(d_x, d_sel, x_sel, nsel, xrow, false, s));
         MQ_TRY(mq_gemm_bf16(h, Wa, b.out_w, Wa, b.out_b, x_sel, x_sel, W, nsel, W, Wa, rflags, s));
-        MQ_TRY(mq_layernorm_ex(x_sel, xb, nullptr, b.ln2_g, b.ln2_b, a, nullptr, nsel, W, cfg->ln_eps, s));
-        MQ_TRY(mq_gemm_bf16(a, W, b.fc1_w, W, b.fc1_b, nullptr, qf, F, nsel, F, W, MQ_EPI_BIAS | act_flag, s));
+        MQ_TRY(ln_gemm(x_sel, xb, b.ln2_g, b.ln2_b, cfg->ln_eps, a, b.fc1_w, b.fc1_b, qf, nsel, F, W, MQ_EPI_BIAS | act_flag, s));
         MQ_TRY(mq_gemm_bf16(qf, F, b.fc2_w, F, b.fc2_b, x_sel, x_sel, W, nsel, W, F, rflags, s));
     } else {
         MQ_TRY(mq_gemm_bf16(h, W, b.qkv_w, W, b.qkv_b, nullptr, qf, 3 * Wa, rows, 3 * Wa, W, MQ_EPI_BIAS, s));
@@ -293,12 +303,10 @@ int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* bloc
             // x += out(attn(qkv(ln1(x)))) ; x += fc2(act(fc1(ln2(x))))   (x fp32, or bf16 in the bf16-stream form)
             const int xb = stream_bf16(cfg) ? 1 : 0;
             const int rflags = xb ? (MQ_EPI_BIAS | MQ_EPI_RESIDUAL) : res_flags;
-            MQ_TRY(mq_layernorm_ex(d_x, xb, nullptr, b.ln1_g, b.ln1_b, h, nullptr, rows, W, cfg->ln_eps, s));
-            MQ_TRY(mq_gemm_bf16(h, W, b.qkv_w, W, b.qkv_b, nullptr, qf, 3 * Wa, rows, 3 * Wa, W, MQ_EPI_BIAS, s));
+            MQ_TRY(ln_gemm(d_x, xb, b.ln1_g, b.ln1_b, cfg->ln_eps, h, b.qkv_w, b.qkv_b, qf, rows, 3 * Wa, W, MQ_EPI_BIAS, s));
             MQ_TRY(mq_attention(qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, cfg->heads, cfg->mask, s));
             MQ_TRY(mq_gemm_bf16(a, Wa, b.out_w, Wa, b.out_b, (const float*)d_x, d_x, W, rows, W, Wa, rflags, s));
-            MQ_TRY(mq_layernorm_ex(d_x, xb, nullptr, b.ln2_g, b.ln2_b, h, nullptr, rows, W, cfg->ln_eps, s));
-            MQ_TRY(mq_gemm_bf16(h, W, b.fc1_w, W, b.fc1_b, nullptr, qf, F, rows, F, W, MQ_EPI_BIAS | act_flag, s));
+            MQ_TRY(ln_gemm(d_x, xb, b.ln2_g, b.ln2_b, cfg->ln_eps, h, b.fc1_w, b.fc1_b, qf, rows, F, W, MQ_EPI_BIAS | act_flag, s));
             MQ_TRY(mq_gemm_bf16(qf, F, b.fc2_w, F, b.fc2_b, (const float*)d_x, d_x, W, rows, W, F, rflags, s));
         } else {
             // x = ln1(x + out(attn(qkv(x)))) ; x = ln2(x + fc2(act(fc1(x))))

@@ -68,7 +68,7 @@ def test_clip_text_minimal_and_full_length():
         tower.encode_ids(torch.zeros(1, 78, dtype=torch.int64))
 
 
-def test_vit_batch_of_one_chunked_calls_and_threads(monkeypatch):
+def test_vit_batch_of_one_chunked_calls_and_threads(monkeypatch, tiled_gemm_only):
     from marqo_amd.engine import archs, towers
     cfg = O.VitConfig(image_size=64, patch_size=16, width=128, layers=2, heads=2, mlp_dim=256, out_dim=64)
     sd = O.synthetic_vit_state_dict(cfg, seed=7)

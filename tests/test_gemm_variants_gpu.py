@@ -10,6 +10,12 @@ from marqo_amd import _lib as L
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True)
+def _tiled_family(tiled_gemm_only):
+    """this file exercises the tiled kernels on every shape, the small ones included (the skinny kernels: tests/test_small_m_gpu.py)"""
+    yield
+
 VARIANTS = [dict(gemm_persist=0, gemm_cgroup=0, gemm_wide=0), dict(gemm_persist=1, gemm_cgroup=0, gemm_wide=0),
             dict(gemm_persist=0, gemm_cgroup=8, gemm_wide=1), dict(gemm_persist=1, gemm_cgroup=4, gemm_wide=2)]
 DEFAULTS = dict(gemm_mt=0, gemm_persist=1, gemm_cgroup=8, gemm_wide=2, gemm_big=0, gemm_k32=0)

@@ -218,8 +218,10 @@ def test_device_clip_bpe_equals_host(clip_tok):
     corpus = " ".join(_unicode_texts(21, 400)).split()
     tok = ClipBpeTokenizer(_train_bpe([w for w in corpus if w][:3000], 200), context_length=77)
     d = GT.DeviceClipBpeTokenizer(tok, "cuda")
-    texts = _unicode_texts(33, 10500) + ["İstanbul", "ΟΔΟΣ", "fish &amp; chips", "x <start_of_text> y", "lone \udfff", "\x1c'm \x1d"]
+    texts = _unicode_texts(33, 10500) + ["İstanbul", "ΟΔΟΣ", "fish &amp; chips", "x <start_of_text> y", "\x1c'm \x1d"]
     assert np.array_equal(d(texts, 77), tok(texts, 77))
+    with pytest.raises(UnicodeEncodeError):   # a lone surrogate has no UTF-8 bytes: the host tokenizer (and open_clip's) raises, so does the device route
+        d(["lone \udfff"], 77)
 
 
 def test_device_tokenizers_refuse_cpu(bert_tok):

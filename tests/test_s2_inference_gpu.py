@@ -239,7 +239,8 @@ def test_hf_xlm_roberta_from_disk(s2, tmp_path):
     ref = O.hf_encode(sd, cfg, torch.from_numpy(t["input_ids"]), torch.from_numpy(t["attention_mask"])).numpy()
     assert np.asarray(out).shape == (4, 128) and _cos_err(out, ref) < COS_TOL
     model = s2i.get_available_models()[s2i._create_model_cache_key("tiny-xlmr", DEV, props)]["model"]
-    assert type(model._tokenizer).__name__ == "XlmRobertaTokenizer" and model._device_tokenizer is None and model.arch.pos_offset == 2
+    assert type(model._tokenizer).__name__ == "XlmRobertaTokenizer" and model.arch.pos_offset == 2
+    assert type(model._device_tokenizer).__name__ == "DeviceSentencePieceTokenizer"   # the unigram Viterbi runs on the GPU (K14)
 
 
 def test_siglip_from_disk_text_and_image(s2, tmp_path, monkeypatch):

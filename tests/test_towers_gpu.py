@@ -159,7 +159,7 @@ def _tune(key: str, value: int):
     L.check(L.load().mq_tune(key.encode(), value))
 
 
-def test_row_selected_last_block_is_bit_identical():
+def test_row_selected_last_block_is_bit_identical(tiled_gemm_only):
     """The towers run the out-projection / MLP of the LAST block only on the rows that are pooled afterwards
     (class token, EOT, CLS).  That is dead-row elimination, not an approximation: embeddings must be bit-identical to
     the all-rows execution (mq_tune("row_select", 0)), in bf16 and fp8, for every tower that pools single rows."""
@@ -194,7 +194,7 @@ def test_row_selected_last_block_is_bit_identical():
         _tune("row_select", 1)
 
 
-def test_row_selected_last_block_full_size_fp8():
+def test_row_selected_last_block_full_size_fp8(tiled_gemm_only):
     """Same property at the ViT-B/32 shape on the fp8 path (frozen scales): selected-row and all-row runs agree bit for bit."""
     T, A = _towers()
     arch, _ = A.resolve_open_clip("ViT-B-32")
@@ -217,7 +217,7 @@ def test_row_selected_last_block_full_size_fp8():
         assert torch.equal(sel, full), precision
 
 
-def test_full_size_batch_properties_config2_and_config3():
+def test_full_size_batch_properties_config2_and_config3(tiled_gemm_only):
     """BASELINE configs 2 and 3 at their FULL sizes (256 ViT-B/32 images; ViT-L/14 with 128 images + 128 ragged texts), where the
     CPU oracle would take minutes: size-independent properties of an embarrassingly row-parallel map instead —
     every embedding is independent of what else is in the batch (bitwise: permutation equivariance and batch-split invariance),

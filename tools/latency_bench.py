@@ -25,9 +25,15 @@ def timeit(fn, n=300, warm=20):
 
 
 def main():
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="", help="substring of the model names to run")
+    args = ap.parse_args()
     dev = "cuda"
     rows = []
     for name in ("ViT-B-32", "ViT-L-14", "ViT-B-16-SigLIP"):
+        if args.only and args.only not in name:
+            continue
         v, t = archs.resolve_open_clip(name)
         sd = synthetic.random_open_clip_state_dict(vision=v, text=t, seed=0)
         vt, tt = towers.VitTower(v, sd, dev), towers.ClipTextTower(t, sd, dev)
@@ -42,10 +48,11 @@ def main():
         rows.append((name + " image, 1 x u8 on device", *timeit(lambda: vt.encode_u8(img_d))))
         rows.append((name + " text, 16 queries", *timeit(lambda: tt.encode_ids(ids.repeat(16, 1)))))
         del vt, tt
-    b = archs.HF_BERT_ARCHS["intfloat/e5-base-v2"]
-    bt = towers.BertTower(b, synthetic.random_bert_state_dict(b, seed=0), dev)
-    ids = torch.randint(1000, b.vocab, (1, 12)); mask = torch.ones(1, 12, dtype=torch.int64)
-    rows.append(("e5-base-v2 text, 1 query (12 tokens)", *timeit(lambda: bt.encode_ids(ids, mask))))
+    if not args.only or args.only in "e5-base-v2":
+        b = archs.HF_BERT_ARCHS["intfloat/e5-base-v2"]
+        bt = towers.BertTower(b, synthetic.random_bert_state_dict(b, seed=0), dev)
+        ids = torch.randint(1000, b.vocab, (1, 12)); mask = torch.ones(1, 12, dtype=torch.int64)
+        rows.append(("e5-base-v2 text, 1 query (12 tokens)", *timeit(lambda: bt.encode_ids(ids, mask))))
     for r in rows:
         print(f"{r[0]:44s} p50 {r[1]:7.3f} ms   p95 {r[2]:7.3f} ms")
 
