@@ -338,17 +338,19 @@ int mq_gemm_bf16(const void* d_A, int64_t lda, const void* d_W, int64_t ldw,
                  int64_t M, int64_t N, int64_t K, int flags, void* stream);
 
 /* The search path (tensor_search.py:1876-1911 -> vectorise() with ONE query; s2_inference.py:135-146 with a one-item batch): GEMMs of
- * M <= 80 rows.  Column-sliced skinny kernels (csrc/gemm_small.hip): one workgroup per 16 output columns, its 4 waves split K, so the
+ * M <= 272 rows (a query text, or one image: 50 .. 257 tokens).  Column-sliced skinny kernels (csrc/gemm_small.hip): one workgroup per 16 output columns, its 4 waves split K, so the
  * weight matrix is streamed once by the whole chip.  mq_gemm_bf16 routes such calls here by itself (mq_tune("small_m", rows), 0 = off);
  * the entry points are public for tests and for callers that hold a normalisation to fuse.
  *   mq_gemm_small_bf16:    flags as mq_gemm_bf16 (BIAS | RESIDUAL without OUT_F32 = bf16 residual in / out); K % 32 == 0, N % 4 == 0.
  *   mq_ln_gemm_small_bf16: out = act(LayerNorm(x) @ W^T + bias), the LayerNorm computed in the kernel's prologue (x fp32 [M, ldx], or the
- *                          bf16 residual stream when x_bf16 != 0); M <= 32, K <= 1280; flags BIAS [| GELU | QUICKGELU]; bf16 out. */
+ *                          bf16 residual stream when x_bf16 != 0); M <= 32, K <= 1280; flags BIAS [| GELU | QUICKGELU]; bf16 out.
+ *                          d_ln_out (may be NULL; fp32 [M, K]; must not alias d_x) receives the normalised rows — what a post-LN
+ *                          encoder (BERT) carries on as its residual. */
 int mq_gemm_small_bf16(const void* d_A, int64_t lda, const void* d_W, int64_t ldw, const float* d_bias, const void* d_residual,
                        void* d_out, int64_t ldc, int64_t M, int64_t N, int64_t K, int flags, void* stream);
 int mq_ln_gemm_small_bf16(const void* d_x, int64_t ldx, int x_bf16, const float* d_ln_g, const float* d_ln_b, float eps, const void* d_W,
                           int64_t ldw, const float* d_bias, void* d_out, int64_t ldc, int64_t M, int64_t N, int64_t K, int flags,
-                          void* stream);
+                          float* d_ln_out, void* stream);
 
 /* mq_gemm_bf16 with a folded LayerNorm on one side (pre-LN blocks; csrc/gemm_epilogue.h):
  *   flags = BIAS|RESIDUAL|OUT_F32|MQ_EPI_LN_STATS  — producer (the residual GEMM): also writes bf16(out) to d_out2 [M, ldc] and

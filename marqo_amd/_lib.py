@@ -22,7 +22,7 @@ LIB_PATH = Path(os.environ["MARQO_AMD_LIB"]) if os.environ.get("MARQO_AMD_LIB") 
 HEADER_PATH = PKG_DIR.parent / "include" / "marqo_hip.h"
 
 MQ_OK = 0
-NO_SCRATCH_UNITS = ("gemm_bf16", "gemm_big", "gemm_k32", "gemm_fp8", "attention")  # build() refuses register spills in these
+NO_SCRATCH_UNITS = ("gemm_bf16", "gemm_big", "gemm_k32", "gemm_fp8", "gemm_small", "attention")  # build() refuses register spills in these
 ABI_VERSION = 4
 MQ_PREC_BF16, MQ_PREC_FP8 = 0, 1
 MQ_ACT_GELU, MQ_ACT_QUICKGELU = 1, 2
@@ -133,7 +133,7 @@ _SIGNATURES = {
                                C.c_int, _P]),
     "mq_gemm_small_bf16": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, _P]),
     "mq_ln_gemm_small_bf16": (C.c_int, [_P, C.c_int64, C.c_int, _P, _P, C.c_float, _P, C.c_int64, _P, _P, C.c_int64, C.c_int64, C.c_int64,
-                                        C.c_int64, C.c_int, _P]),
+                                        C.c_int64, C.c_int, _P, _P]),
     "mq_gemm_bf16_ln": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int,
                                   _P, _P, _P, C.c_float, _P]),
     "mq_gemm_fp8": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, C.c_int, _P, _P, _P, _P, C.c_int64, _P, _P, C.c_int64, C.c_int64,

@@ -47,6 +47,13 @@ extern "C" int mq_gemm_trace_read(unsigned long long* h_out) {
     return hipMemcpyFromSymbol(h_out, HIP_SYMBOL(mq_gemm_trace_buf), sizeof(mq_gemm_trace_buf)) == hipSuccess ? 0 : -2;
 }
 #define MQ_TR_NOW() __builtin_amdgcn_s_memtime()
+// per-WORKGROUP spans on the device-wide constant 100 MHz counter (s_memrealtime): [block][0..3] = start, end, HW_ID | XCC_ID << 32, tiles —
+// launch ramp, residency (workgroups per CU) and tail of a launch
+#define MQ_SPAN_BLOCKS 2048
+__device__ unsigned long long mq_gemm_span_buf[MQ_SPAN_BLOCKS * 4];
+extern "C" int mq_gemm_span_read(unsigned long long* h_out) {
+    return hipMemcpyFromSymbol(h_out, HIP_SYMBOL(mq_gemm_span_buf), sizeof(mq_gemm_span_buf)) == hipSuccess ? 0 : -2;
+}
 #endif
 
 // short-k-step / 3-4 workgroups per CU form (gemm_k32.hip)
@@ -167,6 +174,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
     int buf = 0;  // LDS buffer of the next k-step (runs on across tiles in the persistent form)
 #ifdef MQ_GEMM_TRACE
     unsigned long long tr_steps = 0, tr_vm = 0, tr_bar = 0, tr_body = 0, tr_epi = 0, tr_tiles = 0;
+    const unsigned long long span_t0 = wall_clock64();
 #endif
     for (;;) {
 #pragma unroll
@@ -283,6 +291,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
     if (blockIdx.x < MQ_TRACE_BLOCKS && lane == 0) {
         unsigned long long* o = mq_gemm_trace_buf + (blockIdx.x * 4 + wave) * 6;
         o[0] = tr_steps; o[1] = tr_vm; o[2] = tr_bar; o[3] = tr_body; o[4] = tr_epi; o[5] = tr_tiles;
+    }
+    if (blockIdx.x < MQ_SPAN_BLOCKS && tid == 0) {
+        unsigned long long* o = mq_gemm_span_buf + blockIdx.x * 4;
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        o[0] = span_t0; o[1] = wall_clock64(); o[2] = (unsigned long long)hw | ((unsigned long long)xcc << 32); o[3] = tr_tiles;
     }
 #endif
 }

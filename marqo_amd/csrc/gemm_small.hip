@@ -1,6 +1,6 @@
 // Skinny GEMM for the search path (one query / a handful of rows per vectorise() call: tensor_search.py:1876-1911 in the reference).
 //
-//   out[M, N] = epi( A[M, K] @ W[N, K]^T ),  M <= 80,   optionally A = LayerNorm(x) computed in the kernel's prologue
+//   out[M, N] = epi( A[M, K] @ W[N, K]^T ),  M <= 272,   optionally A = LayerNorm(x) computed in the kernel's prologue
 //
 // The tiled kernel of gemm_bf16.hip gives such a call N/128 workgroups (4 .. 24 of 256 CUs), each walking the whole K serially: a
 // 10-token CLIP text costs ~7 us per GEMM and 0.68 ms per query although it is < 0.1 GFLOP.  Here the work is cut the other way:
@@ -10,15 +10,21 @@
 //     with the fused LayerNorm, from the normalised bf16 rows the workgroup just wrote to LDS;
 //   * partial sums meet in LDS and are added in wave order 0..3 (deterministic), then the usual epilogue: bias / GELU / QuickGELU /
 //     residual (fp32 or bf16 stream) with 16-byte (fp32) / 8-byte (bf16) stores.
+//   * GEMMs with few column slices (N <= 1024: the out-projection and fc2, 32 .. 64 workgroups) run 8 waves per workgroup instead of 4, so
+//     the K walk of a slice is cut twice as fine and twice as many weight loads are in flight per CU; every wave fetches the fragments of
+//     a group of k-chunks (4, or 2 for M > 32) before the first MFMA of the group: one exposed memory latency per group, not per chunk.
 // LayerNorm fusion: every workgroup normalises all M rows itself (M x K fp32 reads from L2, ~0.1 us) — redundant arithmetic, but it removes
 // the LayerNorm launch and its dependent-kernel boundary (~1.5 us each, MI355X_MICROARCH.md price list), 24 of them per CLIP text query.
+// Post-LN encoders (BERT) need the normalised rows as the next residual too: workgroup 0 also writes them out in fp32 (ln_out, a buffer
+// other than x: the other workgroups are still reading x).
 #include "common.h"
 
 namespace {
 
 constexpr int SM_BN = 16;        // output columns per workgroup
-constexpr int SM_MAX_MT = 5;     // 16-row tiles: M <= 80
+constexpr int SM_MAX_MT = 17;    // 16-row tiles: M <= 272 (one ViT-L/14 image = 257 rows)
 constexpr int SM_LDS_LIMIT = 150 * 1024;
+constexpr int SM_WIDE_WG_MAX_N = 1024;  // up to 64 column slices: 8 waves per workgroup
 constexpr int SM_LN_CH = 5;     // fused LayerNorm: float4 chunks per lane, K <= 1280
 constexpr int SM_LN_MAX_MT = 2; // fused LayerNorm: M <= 32 (a wave keeps its 4 * MT rows in registers)
 
@@ -26,11 +32,12 @@ constexpr int SM_LN_MAX_MT = 2; // fused LayerNorm: M <= 32 (a wave keeps its 4 
 // different banks)
 __host__ __device__ inline int ln_row_bytes(int K) { return K * 2 + 16; }
 
-template <int FLAGS, int MT, bool LN>
-__global__ __launch_bounds__(256) void gemm_small_kernel(const void* __restrict__ Av, int64_t lda, int a_bf16_stream, const bf16_t* __restrict__ Wt,
-                                                         int64_t ldw, const float* __restrict__ bias, const void* residual, void* out, int64_t ldc,
-                                                         int M, int N, int K, const float* __restrict__ ln_g, const float* __restrict__ ln_b,
-                                                         float eps) {
+template <int FLAGS, int MT, bool LN, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_small_kernel(const void* __restrict__ Av, int64_t lda, int a_bf16_stream,
+                                                             const bf16_t* __restrict__ Wt, int64_t ldw, const float* __restrict__ bias,
+                                                             const void* residual, void* out, int64_t ldc, int M, int N, int K,
+                                                             const float* __restrict__ ln_g, const float* __restrict__ ln_b, float eps,
+                                                             float* ln_out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr bool BF16_OUT = !(FLAGS & MQ_EPI_OUT_F32);
     constexpr bool RES_BF16 = (FLAGS & MQ_EPI_RESIDUAL) && BF16_OUT;
@@ -38,19 +45,19 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const void* __restrict_
     const int l15 = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.x * SM_BN;
     const int rowb = ln_row_bytes(K);
-    // partial sums: [4 waves][MT][64 lanes] f32x4 — behind the LN image when there is one
+    // partial sums: [NW waves][MT][64 lanes] f32x4 — behind the LN image when there is one
     f32x4* part = (f32x4*)(smem + (LN ? ((MT * 16 * rowb + 255) & ~255) : 0));
 
     if (LN) {
         // ---- prologue: LayerNorm of rows wave, wave + 4, ... of x [M, K] (fp32, or the bf16 residual stream) into the LDS image.  All of a
         // wave's rows are fetched before the first reduction (one exposed L2 latency, not one per row); same arithmetic as layernorm_kernel
         // (rowops.hip): sum -> mean, sum of squared deviations -> rstd ----
-        constexpr int RPW = MT * 4;                   // rows per wave
+        constexpr int RPW = (MT * 16 + NW - 1) / NW;  // rows per wave
         const int nch = K >> 2;                       // float4 chunks per row
         f32x4 v[RPW][SM_LN_CH];
 #pragma unroll
         for (int i = 0; i < RPW; ++i) {
-            const int r = wave + 4 * i;
+            const int r = wave + NW * i;
 #pragma unroll
             for (int j = 0; j < SM_LN_CH; ++j) {
                 const int c = lane + j * 64;
@@ -101,62 +108,68 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const void* __restrict_
             for (int i = 0; i < RPW; ++i) rstd[i] += __shfl_xor(rstd[i], o, 64);
 #pragma unroll
         for (int i = 0; i < RPW; ++i) {
-            const int r = wave + 4 * i;               // rows >= M hold zeros: they normalise to beta, and are never stored by the epilogue
+            const int r = wave + NW * i;              // rows >= M hold zeros: they normalise to beta, and are never stored by the epilogue
+            if (r >= MT * 16) continue;
             rstd[i] = rsqrtf(rstd[i] / (float)K + eps);
             char* dst = smem + (size_t)r * rowb;
 #pragma unroll
             for (int j = 0; j < SM_LN_CH; ++j) {
                 const int c = lane + j * 64;
                 if (c >= nch) continue;
+                f32x4 y;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = (v[i][j][e] - mean[i]) * rstd[i] * gv[j][e] + bv[j][e];
                 uint2 q;
-                q.x = pack_bf16x2((v[i][j][0] - mean[i]) * rstd[i] * gv[j][0] + bv[j][0], (v[i][j][1] - mean[i]) * rstd[i] * gv[j][1] + bv[j][1]);
-                q.y = pack_bf16x2((v[i][j][2] - mean[i]) * rstd[i] * gv[j][2] + bv[j][2], (v[i][j][3] - mean[i]) * rstd[i] * gv[j][3] + bv[j][3]);
+                q.x = pack_bf16x2(y[0], y[1]);
+                q.y = pack_bf16x2(y[2], y[3]);
                 *(uint2*)(dst + c * 8) = q;
+                if (ln_out && blockIdx.x == 0 && r < M) *(f32x4*)(ln_out + (int64_t)r * K + c * 4) = y;   // post-LN: the new residual
             }
         }
         __syncthreads();
     }
 
-    // ---- main loop: this wave's share of the 32-deep k-chunks ----
+    // ---- main loop: this wave's share of the 32-deep k-chunks, G chunks per group (all of a group's loads are issued before its MFMAs) ----
+    constexpr int G = MT <= 2 ? 4 : MT <= 5 ? 2 : 1;
     const int nchunks = K >> 5;
-    const int per = (nchunks + 3) >> 2;
+    const int per = (nchunks + NW - 1) / NW;
     const int c0 = wave * per, c1 = min(c0 + per, nchunks);
     f32x4 acc[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int wn = n0 + l15;
     const bf16_t* wrow = Wt + (int64_t)(wn < N ? wn : N - 1) * ldw + g * 8;
-    // software prefetch of the weight fragment (the only HBM stream): two chunks in flight
-    bf16x8 wf = c0 < c1 ? *(const bf16x8*)(wrow + (int64_t)c0 * 32) : bf16x8{};
-    for (int kc = c0; kc < c1; ++kc) {
-        const bf16x8 wcur = wf;
-        if (kc + 1 < c1) wf = *(const bf16x8*)(wrow + (int64_t)(kc + 1) * 32);
+    for (int kc = c0; kc < c1; kc += G) {
+        bf16x8 wf[G], af[G][MT];
 #pragma unroll
-        for (int t = 0; t < MT; ++t) {
-            const int m = t * 16 + l15;
-            bf16x8 af;
-            if (LN) {
-                af = *(const bf16x8*)(smem + (size_t)m * rowb + (kc * 32 + g * 8) * 2);
-            } else {
-                af = m < M ? *(const bf16x8*)((const bf16_t*)Av + (int64_t)m * lda + kc * 32 + g * 8) : bf16x8{};
+        for (int j = 0; j < G; ++j) wf[j] = kc + j < c1 ? *(const bf16x8*)(wrow + (int64_t)(kc + j) * 32) : bf16x8{};   // the HBM stream
+#pragma unroll
+        for (int j = 0; j < G; ++j)
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                const int m = t * 16 + l15;
+                const int kk = (kc + j < c1 ? kc + j : c0) * 32 + g * 8;     // (a chunk past the end multiplies a zero weight fragment)
+                if (LN) af[j][t] = *(const bf16x8*)(smem + (size_t)m * rowb + kk * 2);
+                else af[j][t] = m < M ? *(const bf16x8*)((const bf16_t*)Av + (int64_t)m * lda + kk) : bf16x8{};
             }
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wcur, af, acc[t], 0, 0, 0);
-        }
+#pragma unroll
+        for (int j = 0; j < G; ++j)
+#pragma unroll
+            for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[j][t], acc[t], 0, 0, 0);
     }
     // ---- cross-wave reduction in LDS, fixed order ----
 #pragma unroll
     for (int t = 0; t < MT; ++t) part[(wave * MT + t) * 64 + lane] = acc[t];
     __syncthreads();
-    // ---- epilogue: wave w finishes row tiles w, w + 4, ...; a lane owns out[m][n .. n+3], m = t*16 + l15, n = n0 + 4g ----
+    // ---- epilogue: wave w finishes row tiles w, w + NW, ...; a lane owns out[m][n .. n+3], m = t*16 + l15, n = n0 + 4g ----
     const int n = n0 + g * 4;
     f32x4 bias_v = f32x4{0.f, 0.f, 0.f, 0.f};
     if ((FLAGS & MQ_EPI_BIAS) && n < N) bias_v = *(const f32x4*)(bias + n);
-    for (int t = wave; t < MT; t += 4) {
+    for (int t = wave; t < MT; t += NW) {
         const int m = t * 16 + l15;
         f32x4 v = part[(0 * MT + t) * 64 + lane];
-        v += part[(1 * MT + t) * 64 + lane];
-        v += part[(2 * MT + t) * 64 + lane];
-        v += part[(3 * MT + t) * 64 + lane];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) v += part[(w * MT + t) * 64 + lane];
         if (m >= M || n >= N) continue;
         if (FLAGS & MQ_EPI_BIAS) v += bias_v;
         if (FLAGS & MQ_EPI_GELU) {
@@ -187,43 +200,58 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const void* __restrict_
     }
 }
 
-template <int FLAGS, int MT, bool LN>
+template <int FLAGS, int MT, bool LN, int NW>
 int launch_small(const void* A, int64_t lda, int a_stream16, const void* W, int64_t ldw, const float* bias, const void* residual, void* out,
-                 int64_t ldc, int M, int N, int K, const float* ln_g, const float* ln_b, float eps, hipStream_t s) {
-    const size_t lds = (LN ? (((size_t)MT * 16 * ln_row_bytes(K) + 255) & ~(size_t)255) : 0) + (size_t)4 * MT * 64 * 16;
+                 int64_t ldc, int M, int N, int K, const float* ln_g, const float* ln_b, float eps, float* ln_out, hipStream_t s) {
+    const size_t lds = (LN ? (((size_t)MT * 16 * ln_row_bytes(K) + 255) & ~(size_t)255) : 0) + (size_t)NW * MT * 64 * 16;
     static std::atomic<uint64_t> attr_done{0};
     if (lds > 64 * 1024) {
-        if (hipError_t e = mq_ensure_dyn_lds((const void*)gemm_small_kernel<FLAGS, MT, LN>, 160 * 1024, attr_done); e != hipSuccess) {
+        if (hipError_t e = mq_ensure_dyn_lds((const void*)gemm_small_kernel<FLAGS, MT, LN, NW>, 160 * 1024, attr_done); e != hipSuccess) {
             mq_set_error("mq_gemm_small: hipFuncSetAttribute: %s", hipGetErrorString(e));
             return MQ_ERR_HIP;
         }
     }
-    hipLaunchKernelGGL((gemm_small_kernel<FLAGS, MT, LN>), dim3((unsigned)((N + SM_BN - 1) / SM_BN)), dim3(256), lds, s, A, lda, a_stream16,
-                       (const bf16_t*)W, ldw, bias, residual, out, ldc, M, N, K, ln_g, ln_b, eps);
+    hipLaunchKernelGGL((gemm_small_kernel<FLAGS, MT, LN, NW>), dim3((unsigned)((N + SM_BN - 1) / SM_BN)), dim3(NW * 64), lds, s, A, lda, a_stream16,
+                       (const bf16_t*)W, ldw, bias, residual, out, ldc, M, N, K, ln_g, ln_b, eps, ln_out);
     MQ_CHECK_LAUNCH("mq_gemm_small");
     return MQ_OK;
 }
 
-template <int FLAGS, bool LN>
+template <int FLAGS, bool LN, int NW>
 int dispatch_mt(const void* A, int64_t lda, int a_stream16, const void* W, int64_t ldw, const float* bias, const void* residual, void* out, int64_t ldc,
-                int M, int N, int K, const float* ln_g, const float* ln_b, float eps, hipStream_t s) {
-    if (LN) {  // mq_gemm_small_ok(.., ln = true) admits M <= 32 only
-        if (M <= 16) return launch_small<FLAGS, 1, LN>(A, lda, a_stream16, W, ldw, bias, residual, out, ldc, M, N, K, ln_g, ln_b, eps, s);
-        return launch_small<FLAGS, 2, LN>(A, lda, a_stream16, W, ldw, bias, residual, out, ldc, M, N, K, ln_g, ln_b, eps, s);
+                int M, int N, int K, const float* ln_g, const float* ln_b, float eps, float* ln_out, hipStream_t s) {
+#define MQ_SM_MT(T) return launch_small<FLAGS, T, LN, NW>(A, lda, a_stream16, W, ldw, bias, residual, out, ldc, M, N, K, ln_g, ln_b, eps, ln_out, s)
+    if constexpr (LN) {  // mq_gemm_small_ok(.., ln = true) admits M <= 32 only
+        if (M <= 16) MQ_SM_MT(1);
+        MQ_SM_MT(2);
+    } else {
+        const int mt = (M + 15) / 16;   // row tiles are guarded: the next instantiated height
+        if (mt <= 1) MQ_SM_MT(1);
+        if (mt <= 2) MQ_SM_MT(2);
+        if (mt <= 3) MQ_SM_MT(3);
+        if (mt <= 4) MQ_SM_MT(4);
+        if (mt <= 5) MQ_SM_MT(5);
+        if (mt <= 7) MQ_SM_MT(7);
+        if (mt <= 10) MQ_SM_MT(10);
+        if (mt <= 13) MQ_SM_MT(13);
+        MQ_SM_MT(17);
     }
-    switch ((M + 15) / 16) {
-        case 1: return launch_small<FLAGS, 1, LN>(A, lda, a_stream16, W, ldw, bias, residual, out, ldc, M, N, K, ln_g, ln_b, eps, s);
-        case 2: return launch_small<FLAGS, 2, LN>(A, lda, a_stream16, W, ldw, bias, residual, out, ldc, M, N, K, ln_g, ln_b, eps, s);
-        case 3: return launch_small<FLAGS, 3, LN>(A, lda, a_stream16, W, ldw, bias, residual, out, ldc, M, N, K, ln_g, ln_b, eps, s);
-        case 4: return launch_small<FLAGS, 4, LN>(A, lda, a_stream16, W, ldw, bias, residual, out, ldc, M, N, K, ln_g, ln_b, eps, s);
-        default: return launch_small<FLAGS, 5, LN>(A, lda, a_stream16, W, ldw, bias, residual, out, ldc, M, N, K, ln_g, ln_b, eps, s);
-    }
+#undef MQ_SM_MT
+}
+
+// few column slices (N <= 1024): 8 waves per workgroup
+template <int FLAGS, bool LN>
+int dispatch_nw(const void* A, int64_t lda, int a_stream16, const void* W, int64_t ldw, const float* bias, const void* residual, void* out, int64_t ldc,
+                int M, int N, int K, const float* ln_g, const float* ln_b, float eps, float* ln_out, hipStream_t s) {
+    if (N <= SM_WIDE_WG_MAX_N && K >= 512)
+        return dispatch_mt<FLAGS, LN, 8>(A, lda, a_stream16, W, ldw, bias, residual, out, ldc, M, N, K, ln_g, ln_b, eps, ln_out, s);
+    return dispatch_mt<FLAGS, LN, 4>(A, lda, a_stream16, W, ldw, bias, residual, out, ldc, M, N, K, ln_g, ln_b, eps, ln_out, s);
 }
 
 }  // namespace
 
 // knob: rows up to which the towers take the skinny path (0 = never).  mq_tune("small_m", v) / MQ_SMALL_M
-int mq_gemm_small_max_rows = getenv("MQ_SMALL_M") ? atoi(getenv("MQ_SMALL_M")) : 80;
+int mq_gemm_small_max_rows = getenv("MQ_SMALL_M") ? atoi(getenv("MQ_SMALL_M")) : 272;
 
 // can this call run on the skinny kernel?  (shape rules + LDS budget of the fused LayerNorm)
 bool mq_gemm_small_ok(int64_t M, int64_t N, int64_t K, bool ln) {
@@ -231,7 +259,7 @@ bool mq_gemm_small_ok(int64_t M, int64_t N, int64_t K, bool ln) {
     if (N % 4 != 0 || K % 32 != 0 || K < 32) return false;
     if (ln) {
         const size_t mt = (size_t)((M + 15) / 16);
-        if (mt > SM_LN_MAX_MT || K > SM_LN_CH * 256 || mt * 16 * ln_row_bytes((int)K) + 4 * mt * 64 * 16 + 256 > (size_t)SM_LDS_LIMIT) return false;
+        if (mt > SM_LN_MAX_MT || K > SM_LN_CH * 256 || mt * 16 * ln_row_bytes((int)K) + 8 * mt * 64 * 16 + 256 > (size_t)SM_LDS_LIMIT) return false;
     }
     return true;
 }
@@ -242,7 +270,7 @@ int mq_gemm_small(const void* d_A, int64_t lda, const void* d_W, int64_t ldw, co
     MQ_CHECK_ARG(mq_gemm_small_ok(M, N, K, false), "mq_gemm_small: shape M=%ld N=%ld K=%ld unsupported", (long)M, (long)N, (long)K);
     MqProfScope prof(0, s, 2.0 * (double)M * (double)N * (double)K);
 #define MQ_SM_CASE(F) \
-    case (F): return dispatch_mt<(F), false>(d_A, lda, 0, d_W, ldw, d_bias, d_residual, d_out, ldc, (int)M, (int)N, (int)K, nullptr, nullptr, 0.f, s)
+    case (F): return dispatch_nw<(F), false>(d_A, lda, 0, d_W, ldw, d_bias, d_residual, d_out, ldc, (int)M, (int)N, (int)K, nullptr, nullptr, 0.f, nullptr, s)
     switch (flags) {
         MQ_SM_CASE(0);
         MQ_SM_CASE(MQ_EPI_OUT_F32);
@@ -259,13 +287,15 @@ int mq_gemm_small(const void* d_A, int64_t lda, const void* d_W, int64_t ldw, co
 }
 
 // out = epi(LayerNorm(x) @ W^T): x fp32 [M, K] (x_bf16 != 0: the bf16 residual stream), gamma / beta fp32 [K].  bf16 out.
+// d_ln_out (optional, fp32 [M, K], must not alias d_x): the normalised rows, written once (post-LN encoders: the next residual).
 int mq_ln_gemm_small(const void* d_x, int64_t ldx, int x_bf16, const float* ln_g, const float* ln_b, float eps, const void* d_W, int64_t ldw,
-                     const float* d_bias, void* d_out, int64_t ldc, int64_t M, int64_t N, int64_t K, int flags, hipStream_t s) {
+                     const float* d_bias, void* d_out, int64_t ldc, int64_t M, int64_t N, int64_t K, int flags, float* d_ln_out, hipStream_t s) {
     MQ_CHECK_ARG(mq_gemm_small_ok(M, N, K, true), "mq_ln_gemm_small: shape M=%ld N=%ld K=%ld unsupported", (long)M, (long)N, (long)K);
     MQ_CHECK_ARG(d_x && ln_g && ln_b && d_W && d_out, "mq_ln_gemm_small: null pointer");
+    MQ_CHECK_ARG((const void*)d_ln_out != d_x, "mq_ln_gemm_small: d_ln_out must not alias d_x (every workgroup reads x while workgroup 0 writes)");
     MqProfScope prof(0, s, 2.0 * (double)M * (double)N * (double)K);
 #define MQ_SM_CASE(F) \
-    case (F): return dispatch_mt<(F), true>(d_x, ldx, x_bf16, d_W, ldw, d_bias, nullptr, d_out, ldc, (int)M, (int)N, (int)K, ln_g, ln_b, eps, s)
+    case (F): return dispatch_nw<(F), true>(d_x, ldx, x_bf16, d_W, ldw, d_bias, nullptr, d_out, ldc, (int)M, (int)N, (int)K, ln_g, ln_b, eps, d_ln_out, s)
     switch (flags) {
         MQ_SM_CASE(MQ_EPI_BIAS);
         MQ_SM_CASE(MQ_EPI_BIAS | MQ_EPI_GELU);
@@ -289,8 +319,8 @@ extern "C" int mq_gemm_small_bf16(const void* d_A, int64_t lda, const void* d_W,
 
 extern "C" int mq_ln_gemm_small_bf16(const void* d_x, int64_t ldx, int x_bf16, const float* d_ln_g, const float* d_ln_b, float eps, const void* d_W,
                                      int64_t ldw, const float* d_bias, void* d_out, int64_t ldc, int64_t M, int64_t N, int64_t K, int flags,
-                                     void* stream) {
+                                     float* d_ln_out, void* stream) {
     MQ_CHECK_ARG(!(flags & MQ_EPI_BIAS) || d_bias, "mq_ln_gemm_small_bf16: MQ_EPI_BIAS without bias");
     MQ_CHECK_ARG(ldx % 4 == 0 && ldw % 8 == 0 && ldc % 4 == 0, "mq_ln_gemm_small_bf16: leading dims must keep 16-byte rows");
-    return mq_ln_gemm_small(d_x, ldx, x_bf16, d_ln_g, d_ln_b, eps, d_W, ldw, d_bias, d_out, ldc, M, N, K, flags, (hipStream_t)stream);
+    return mq_ln_gemm_small(d_x, ldx, x_bf16, d_ln_g, d_ln_b, eps, d_W, ldw, d_bias, d_out, ldc, M, N, K, flags, d_ln_out, (hipStream_t)stream);
 }

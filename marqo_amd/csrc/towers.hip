@@ -48,11 +48,11 @@ extern "C" int mq_layernorm_ex(const void* d_x, int x_bf16, const int32_t* d_row
 // search path (rows <= 80): LayerNorm fused into the skinny GEMM's prologue (gemm_small.hip)
 bool mq_gemm_small_ok(int64_t M, int64_t N, int64_t K, bool ln);
 int mq_ln_gemm_small(const void* d_x, int64_t ldx, int x_bf16, const float* ln_g, const float* ln_b, float eps, const void* d_W, int64_t ldw,
-                     const float* d_bias, void* d_out, int64_t ldc, int64_t M, int64_t N, int64_t K, int flags, hipStream_t s);
+                     const float* d_bias, void* d_out, int64_t ldc, int64_t M, int64_t N, int64_t K, int flags, float* d_ln_out, hipStream_t s);
 // h = LN(x) ; out = epi(h @ W^T): one fused launch when the rows fit the skinny kernel, else LayerNorm kernel + tiled GEMM
 static int ln_gemm(const void* d_x, int xb, const float* g, const float* b, float eps, void* h, const void* W, const float* bias, void* out,
                    int64_t rows, int N, int K, int flags, hipStream_t s) {
-    if (mq_gemm_small_ok(rows, N, K, true)) return mq_ln_gemm_small(d_x, K, xb, g, b, eps, W, K, bias, out, N, rows, N, K, flags, s);
+    if (mq_gemm_small_ok(rows, N, K, true)) return mq_ln_gemm_small(d_x, K, xb, g, b, eps, W, K, bias, out, N, rows, N, K, flags, nullptr, s);
     MQ_TRY(mq_layernorm_ex(d_x, xb, nullptr, g, b, h, nullptr, rows, K, eps, s));
     return mq_gemm_bf16(h, K, W, K, bias, nullptr, out, N, rows, N, K, flags, s);
 }
@@ -107,6 +107,8 @@ int check_encoder_cfg(const mq_encoder_cfg* c) {
 // Q/K/V rows and out-projection columns zero-padded to 64 / 96 / 96 / 112 per head (engine/towers.py), so QKV is [rows, 3*Wa], the attention output [rows, Wa] and the out-projection has K = Wa.
 int attn_width(const mq_encoder_cfg* c) { return c->attn_width ? c->attn_width : c->width; }
 
+constexpr int64_t SMALL_LN_ROWS = 32;  // rows up to which the skinny GEMMs fuse the LayerNorm (gemm_small.hip)
+
 // scratch of one encoder pass: h bf16 [rows,W] | a bf16 [rows,Wa] | big bf16 [rows, max(3Wa,F)]
 size_t encoder_ws(const mq_encoder_cfg* c, int64_t rows) {
     Off cv;
@@ -118,6 +120,7 @@ size_t encoder_ws(const mq_encoder_cfg* c, int64_t rows) {
     cv.take((size_t)rows * big * 2);
     cv.take((size_t)rows * 4);  // per-row activation scales of the fp8 path
     cv.take((size_t)rows * ((c->width + 63) / 64) * 8);  // LayerNorm-fold partials: (sum, sum of squares) per row and 64-column slot
+    cv.take((size_t)(rows < SMALL_LN_ROWS ? rows : SMALL_LN_ROWS) * c->width * 4);  // search path, post-LN: the normalised residual (fp32)
     return cv.end();
 }
 
@@ -213,6 +216,7 @@ int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* bloc
     void* qf = wsb + cv.take((size_t)rows * big * 2);  // qkv [rows,3W] then fc1 output [rows,F]
     float* row_scale = (float*)(wsb + cv.take((size_t)rows * 4));
     float* ln_stats = (float*)(wsb + cv.take((size_t)rows * ((W + 63) / 64) * 8));
+    float* xn = (float*)(wsb + cv.take((size_t)(rows < SMALL_LN_ROWS ? rows : SMALL_LN_ROWS) * W * 4));
     const int act_flag = cfg->act == MQ_ACT_QUICKGELU ? MQ_EPI_QUICKGELU : MQ_EPI_GELU;
     const int res_flags = MQ_EPI_BIAS | MQ_EPI_RESIDUAL | MQ_EPI_OUT_F32;
 
@@ -227,13 +231,18 @@ int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* bloc
     // pooled-rows-only last block: worth it when it at least halves the row count; not during fp8 calibration (the
     // activation maxima must see every row); x_sel must fit behind the fc1 output inside `qf`
     const size_t xsel_off = align_up((size_t)(nsel > 0 ? nsel : 0) * F * 2, WS_ALIGN);
+    // (not on the search path either: a call of a few rows is bound by its launch count, and the selection costs 4 launches more)
     const bool select_last = d_sel && nsel > 0 && nsel * 2 <= rows && mq_tower_row_select && !cfg->mlp_glu && !cfg->d_rope_inv_freq &&
+                             !mq_gemm_small_ok(rows, W, W, false) &&
                              !(cfg->precision == MQ_PREC_FP8 && (cfg->d_fp8_act_amax || cfg->post_ln)) &&
                              xsel_off + (size_t)nsel * W * 4 <= (size_t)rows * big * 2;
 
     // mixed precision: blocks [0, first8) on bf16 operands, [first8, layers) on e4m3 (mq_encoder_cfg.fp8_first_layer)
     const int first8 = cfg->precision == MQ_PREC_FP8 ? (cfg->fp8_first_layer < cfg->layers ? cfg->fp8_first_layer : cfg->layers) : cfg->layers;
 
+    // post-LN on the search path: LayerNorms fused into the skinny GEMMs (plain bf16 encoder only)
+    const bool small_post_ln = cfg->post_ln && first8 >= cfg->layers && !cfg->mlp_glu && !cfg->d_rope_inv_freq && rows <= SMALL_LN_ROWS &&
+                               mq_gemm_small_ok(rows, 3 * Wa, W, true) && mq_gemm_small_ok(rows, F, W, true) && mq_gemm_small_ok(rows, W, F, false);
     // block input as GEMM operand (post-LN: afterwards every LayerNorm leaves it behind)
     if (cfg->post_ln && first8 == 0) MQ_TRY(mq_rowquant_fp8(d_x, h, row_scale, rows, W, s));
     else if (cfg->post_ln) MQ_TRY(mq_cast_bf16(d_x, h, rows * W, s));
@@ -308,6 +317,22 @@ int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* bloc
             MQ_TRY(mq_gemm_bf16(a, Wa, b.out_w, Wa, b.out_b, (const float*)d_x, d_x, W, rows, W, Wa, rflags, s));
             MQ_TRY(ln_gemm(d_x, xb, b.ln2_g, b.ln2_b, cfg->ln_eps, h, b.fc1_w, b.fc1_b, qf, rows, F, W, MQ_EPI_BIAS | act_flag, s));
             MQ_TRY(mq_gemm_bf16(qf, F, b.fc2_w, F, b.fc2_b, (const float*)d_x, d_x, W, rows, W, F, rflags, s));
+        } else if (small_post_ln) {
+            // search path: both LayerNorms ride in the prologue of the GEMM that consumes them (gemm_small.hip).  d_x holds the pre-LN sums
+            // t, xn the normalised rows (the residual): t1 = r + out(attn(qkv(r))) ; fc1 normalises t1 -> xn ; t2 = xn + fc2(..) ;
+            // the NEXT block's QKV GEMM normalises t2 -> xn (its ln2 belongs to this block); after the last block a plain LayerNorm.
+            const float* res = d_x;      // block 0: the embedding LayerNorm's output is the residual, h its bf16 copy
+            if (l == 0) MQ_TRY(mq_gemm_bf16(h, W, b.qkv_w, W, b.qkv_b, nullptr, qf, 3 * Wa, rows, 3 * Wa, W, MQ_EPI_BIAS, s));
+            else {
+                const mq_block_weights& pb = blocks[l - 1];
+                MQ_TRY(mq_ln_gemm_small(d_x, W, 0, pb.ln2_g, pb.ln2_b, cfg->ln_eps, b.qkv_w, W, b.qkv_b, qf, 3 * Wa, rows, 3 * Wa, W, MQ_EPI_BIAS, xn, s));
+                res = xn;
+            }
+            MQ_TRY(mq_attention(qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, cfg->heads, cfg->mask, s));
+            MQ_TRY(mq_gemm_bf16(a, Wa, b.out_w, Wa, b.out_b, res, d_x, W, rows, W, Wa, res_flags, s));
+            MQ_TRY(mq_ln_gemm_small(d_x, W, 0, b.ln1_g, b.ln1_b, cfg->ln_eps, b.fc1_w, W, b.fc1_b, qf, F, rows, F, W, MQ_EPI_BIAS | act_flag, xn, s));
+            MQ_TRY(mq_gemm_bf16(qf, F, b.fc2_w, F, b.fc2_b, xn, d_x, W, rows, W, F, res_flags, s));
+            if (l == cfg->layers - 1) MQ_TRY(mq_layernorm(d_x, nullptr, b.ln2_g, b.ln2_b, h, d_x, rows, W, cfg->ln_eps, s));
         } else {
             // x = ln1(x + out(attn(qkv(x)))) ; x = ln2(x + fc2(act(fc1(x))))
             MQ_TRY(mq_gemm_bf16(h, W, b.qkv_w, W, b.qkv_b, nullptr, qf, 3 * Wa, rows, 3 * Wa, W, MQ_EPI_BIAS, s));

@@ -24,11 +24,12 @@ def _small(lib, A, W, bias, res, flags, out_dtype):
     return out
 
 
-@pytest.mark.parametrize("M", [1, 7, 16, 17, 33, 50, 64, 80])
+@pytest.mark.parametrize("M", [1, 7, 16, 17, 33, 50, 64, 80, 81, 112, 197, 257, 272])
 def test_skinny_gemm_matches_reference(M):
     lib = L.load()
     g = torch.Generator(device="cuda").manual_seed(M)
-    for (N, K) in ((512, 512), (2304, 768), (768, 3072), (100, 96), (4, 32), (1024, 4096), (3072, 1024), (1288, 64)):
+    shapes = ((512, 512), (2304, 768), (768, 3072), (100, 96), (4, 32), (1024, 4096), (3072, 1024), (1288, 64))
+    for (N, K) in (shapes if M <= 80 else shapes[1:6]):
         A = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
         W = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).to(torch.bfloat16)
         bias = torch.randn(N, device="cuda", generator=g)
@@ -72,11 +73,14 @@ def test_fused_layernorm_gemm(M):
             W = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).to(torch.bfloat16)
             bias = torch.randn(N, device="cuda", generator=g)
             h = torch.empty(M, K, device="cuda", dtype=torch.bfloat16)
-            L.check(lib.mq_layernorm_ex(x.data_ptr(), xb, 0, gam.data_ptr(), bet.data_ptr(), h.data_ptr(), 0, M, K, 1e-5, _stream()))
+            hf = torch.empty(M, K, device="cuda")
+            L.check(lib.mq_layernorm_ex(x.data_ptr(), xb, 0, gam.data_ptr(), bet.data_ptr(), h.data_ptr(), hf.data_ptr(), M, K, 1e-5, _stream()))
             for flags in (L.MQ_EPI_BIAS, L.MQ_EPI_BIAS | L.MQ_EPI_GELU, L.MQ_EPI_BIAS | L.MQ_EPI_QUICKGELU):
                 out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+                xn = torch.full((M, K), float("nan"), device="cuda")
                 L.check(lib.mq_ln_gemm_small_bf16(x.data_ptr(), K, xb, gam.data_ptr(), bet.data_ptr(), 1e-5, W.data_ptr(), K, bias.data_ptr(),
-                                                  out.data_ptr(), N, M, N, K, flags, _stream()), "mq_ln_gemm_small_bf16")
+                                                  out.data_ptr(), N, M, N, K, flags, xn.data_ptr(), _stream()), "mq_ln_gemm_small_bf16")
+                assert torch.equal(xn, hf)                                             # the fp32 normalised rows (post-LN residual)
                 two = _small(lib, h, W, bias, None, flags, torch.bfloat16)
                 assert torch.equal(out, two), (M, N, K, xb, flags, (out.float() - two.float()).abs().max().item())
                 ref = torch.nn.functional.layer_norm(x.float(), (K,), gam, bet, 1e-5).to(torch.bfloat16).float() @ W.float().t() + bias
@@ -89,7 +93,10 @@ def test_fused_layernorm_gemm(M):
     # shapes outside the fused kernel's range are refused, not mis-run
     x = torch.zeros(33, 768, device="cuda")
     assert lib.mq_ln_gemm_small_bf16(x.data_ptr(), 768, 0, x.data_ptr(), x.data_ptr(), 1e-5, x.data_ptr(), 768, x.data_ptr(), x.data_ptr(), 768,
-                                     33, 768, 768, L.MQ_EPI_BIAS, _stream()) != 0
+                                     33, 768, 768, L.MQ_EPI_BIAS, 0, _stream()) != 0
+    y = torch.zeros(8, 768, device="cuda")   # in-place normalisation would race with the other workgroups' reads
+    assert lib.mq_ln_gemm_small_bf16(y.data_ptr(), 768, 0, y.data_ptr(), y.data_ptr(), 1e-5, y.data_ptr(), 768, y.data_ptr(), x.data_ptr(), 768,
+                                     8, 768, 768, L.MQ_EPI_BIAS, y.data_ptr(), _stream()) != 0
 
 
 def _cos_err(a, b):
@@ -128,7 +135,7 @@ def test_single_query_towers_on_the_skinny_path():
         assert _cos_err(skinny_t, ref_t) < 1e-4 and _cos_err(skinny_v, ref_v) < 1e-4 and _cos_err(skinny_b, ref_b) < 1e-4
         print(f"single-query skinny path: 1-cos vs fp32 oracle  text {_cos_err(skinny_t, ref_t):.2e}  image {_cos_err(skinny_v, ref_v):.2e}  "
               f"e5 {_cos_err(skinny_b, ref_b):.2e}")
-        # a query inside a small batch (still <= 80 rows): the same bits as on its own — rows are independent in the skinny kernels, and the
+        # a query inside a small batch (still <= 272 rows): the same bits as on its own — rows are independent in the skinny kernels, and the
         # fused LayerNorm (<= 32 rows) has the arithmetic of the stand-alone one
         short = ids[:3]
         assert torch.equal(tt.encode_ids(short), skinny_t[:3])
@@ -142,4 +149,4 @@ def test_single_query_towers_on_the_skinny_path():
         for a, c in ((skinny_t, tiled_t), (skinny_v, tiled_v), (skinny_b, tiled_b)):
             assert _cos_err(a, c) < 2e-5                                              # two bf16 summation orders of the same products
     finally:
-        L.check(lib.mq_tune(b"small_m", 80))
+        L.check(lib.mq_tune(b"small_m", 272))

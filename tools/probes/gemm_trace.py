@@ -55,6 +55,22 @@ def main():
         tot = vm + bar + body + epi
         if os.environ.get("MQ_TRACE_VERBOSE"):
             print("   per-wave epilogue cycles/tile:", np.round(t[:8, 4] / np.maximum(t[:8, 5], 1)).astype(int).tolist())
+        span = np.zeros(2048 * 4, dtype=np.uint64)
+        sp = lib.mq_gemm_span_read
+        sp.restype, sp.argtypes = C.c_int, [C.c_void_p]
+        assert sp(span.ctypes.data) == 0
+        span = span.reshape(2048, 4)
+        span = span[span[:, 1] > 0]
+        t0, t1 = span[:, 0].astype(np.float64) / 100.0, span[:, 1].astype(np.float64) / 100.0      # us (100 MHz counter)
+        base = t0.min()
+        cu = (span[:, 2] & 0xFFFFFFFF).astype(np.int64)
+        cu_key = ((span[:, 2] >> 32).astype(np.int64) & 0xF) * 4096 + ((cu >> 8) & 0xF) + 16 * ((cu >> 12) & 0x1) + 32 * ((cu >> 13) & 0x7)
+        per_cu = np.bincount(np.unique(cu_key, return_inverse=True)[1])
+        dur = t1 - t0
+        print(f"   spans ({len(span)} workgroups on {len(per_cu)} CUs, {per_cu.min()}..{per_cu.max()} per CU): starts 0..{(t0 - base).max():.1f} us "
+              f"(p50 {np.median(t0 - base):.1f}), ends {(t1 - base).min():.1f}..{(t1 - base).max():.1f} us (p50 {np.median(t1 - base):.1f}), "
+              f"duration mean {dur.mean():.1f} max {dur.max():.1f} us; by tiles: "
+              + ", ".join(f"{int(k)} tiles: n={int((span[:, 3] == k).sum())} dur {dur[span[:, 3] == k].mean():.1f} us" for k in np.unique(span[:, 3])))
         print(f"{name:10s} {us:7.1f} {2.0 * M * N * K / us / 1e6:6.0f} | {'':16s} {steps:7.1f} {tiles:5.1f} {(vm + bar + body) / steps:10.0f} | "
               f"{vm / tot:6.1%} {bar / tot:7.1%} {body / tot:6.1%} {epi / tot:8.1%}")
 
