@@ -338,7 +338,7 @@ int mq_gemm_bf16(const void* d_A, int64_t lda, const void* d_W, int64_t ldw,
                  int64_t M, int64_t N, int64_t K, int flags, void* stream);
 
 /* The search path (tensor_search.py:1876-1911 -> vectorise() with ONE query; s2_inference.py:135-146 with a one-item batch): GEMMs of
- * M <= 272 rows (a query text, or one image: 50 .. 257 tokens).  Column-sliced skinny kernels (csrc/gemm_small.hip): one workgroup per 16 output columns, its 4 waves split K, so the
+ * M <= 80 rows (a query text; one ViT-B/32 image = 50 tokens).  Column-sliced skinny kernels (csrc/gemm_small.hip): one workgroup per 16 output columns, its 4 waves split K, so the
  * weight matrix is streamed once by the whole chip.  mq_gemm_bf16 routes such calls here by itself (mq_tune("small_m", rows), 0 = off);
  * the entry points are public for tests and for callers that hold a normalisation to fuse.
  *   mq_gemm_small_bf16:    flags as mq_gemm_bf16 (BIAS | RESIDUAL without OUT_F32 = bf16 residual in / out); K % 32 == 0, N % 4 == 0.

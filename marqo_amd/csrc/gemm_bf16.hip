@@ -88,7 +88,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
     constexpr int BM = 32 * MT;
     constexpr int A_TILE_BYTES = BM * BK * 2;
     constexpr int STAGE_BYTES = A_TILE_BYTES + W_TILE_BYTES;
+    // the tile's 128 bias values ride through LDS (two 512-B slots behind the stages, alternating per tile): fetched at the top of the
+    // tile, parked in LDS after the first landed stage, read by the epilogue.  Not at MT = 6, whose stages fill the CU's LDS budget.
+    constexpr bool LDS_BIAS = (FLAGS & MQ_EPI_BIAS) && MT <= 5;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* const bias_lds = (float*)(smem + 2 * STAGE_BYTES);
+    int bias_slot = 0;
 
     // ---- XCD-aware, bijective (virtual) block -> tile map ----------------------------------
     const int q = num_tiles >> 3, r = num_tiles & 7;
@@ -171,12 +176,21 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
     tile_origin(vbid, m0, n0);
     set_sources(m0, n0);
     stage(0, 0);
+    // experiment knob (mq_tune("gemm_stagger", n)): the second resident workgroup of every CU starts n x 1024 cycles late, so that the two
+    // workgroups' epilogues (matrix pipe idle) do not coincide on multi-tile persistent launches
+    if (PERSIST && (wide_store >> 8) && blockIdx.x >= (gridDim.x >> 1))
+        for (int i = 0; i < (wide_store >> 8); ++i) __builtin_amdgcn_s_sleep(16);
+    const bool lds_bias_on = LDS_BIAS && (wide_store & 2);   // knob mq_tune("gemm_lds_bias", 0 / 1)
+    wide_store &= 1;
     int buf = 0;  // LDS buffer of the next k-step (runs on across tiles in the persistent form)
 #ifdef MQ_GEMM_TRACE
     unsigned long long tr_steps = 0, tr_vm = 0, tr_bar = 0, tr_body = 0, tr_epi = 0, tr_tiles = 0;
     const unsigned long long span_t0 = wall_clock64();
 #endif
     for (;;) {
+        float bias_reg = 0.f;
+        if (lds_bias_on && tid < BN && n0 + tid < N) bias_reg = bias[n0 + tid];
+        bool bias_parked = !lds_bias_on;
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -248,6 +262,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
             const unsigned long long t0 = MQ_TR_NOW();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const unsigned long long t1 = MQ_TR_NOW();
+            if (!bias_parked) {
+                if (tid < BN) bias_lds[bias_slot * BN + tid] = bias_reg;
+                bias_parked = true;
+            }
             __syncthreads();
             const unsigned long long t2 = MQ_TR_NOW();
             kstep(buf, (int64_t)(kt + 1) * BK, std::true_type{});
@@ -256,6 +274,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
             tr_steps += 1; tr_vm += t1 - t0; tr_bar += t2 - t1; tr_body += t3 - t2;
 #else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!bias_parked) {  // (the wait above covered the bias load too; the barrier below publishes the slot)
+                if (tid < BN) bias_lds[bias_slot * BN + tid] = bias_reg;
+                bias_parked = true;
+            }
             __syncthreads();
             kstep(buf, (int64_t)(kt + 1) * BK, std::true_type{});
 #endif
@@ -272,6 +294,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!bias_parked && tid < BN) bias_lds[bias_slot * BN + tid] = bias_reg;  // K == 64: no prefetching k-step ran
         __syncthreads();
         if (PERSIST && more) kstep(buf, 0, std::true_type{});
         else kstep(buf, 0, std::false_type{});
@@ -279,7 +302,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
 #ifdef MQ_GEMM_TRACE
         const unsigned long long te0 = MQ_TR_NOW();
 #endif
-        gemm_epilogue<FLAGS, MT>(acc, bias, residual, out, ldc, M, N, cm0 + wm * (16 * MT), cn0 + wn * 64, l15, g, wide_store != 0, &ln);
+        gemm_epilogue<FLAGS, MT>(acc, bias, residual, out, ldc, M, N, cm0 + wm * (16 * MT), cn0 + wn * 64, l15, g, wide_store != 0, &ln,
+                                 lds_bias_on ? bias_lds + bias_slot * BN + wn * 64 : nullptr);
+        bias_slot ^= 1;
 #ifdef MQ_GEMM_TRACE
         __builtin_amdgcn_sched_barrier(0);
         tr_epi += MQ_TR_NOW() - te0;  // issue time of the epilogue (its stores retire later)
@@ -302,7 +327,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
 
 // tuning knobs: initialised from the environment (MQ_GEMM_MT / _PERSIST / _CGROUP / _WIDE / _BIG), overridable through mq_tune()
 struct GemmTune {
-    int mt, persist, big, cgroup, wide, k32;
+    int mt, persist, big, cgroup, wide, k32, stagger = 0, lds_bias = 1;
     static int env(const char* k, int d) { const char* v = getenv(k); return v ? atoi(v) : d; }
     GemmTune() : mt(env("MQ_GEMM_MT", 0)), persist(env("MQ_GEMM_PERSIST", 1)), big(env("MQ_GEMM_BIG", 0)), cgroup(env("MQ_GEMM_CGROUP", 8)), wide(env("MQ_GEMM_WIDE", 2)), k32(env("MQ_GEMM_K32", 0)) {}
 };
@@ -335,7 +360,7 @@ template <int FLAGS, int MT, bool PERSIST>
 int launch_gemm_mt(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
                    const float* residual, void* out, int64_t ldc, int M, int N, int K, hipStream_t s, const GemmLn& ln) {
     constexpr int BM = 32 * MT;
-    constexpr int LDS = 2 * (BM * BK * 2 + W_TILE_BYTES);
+    constexpr int LDS = 2 * (BM * BK * 2 + W_TILE_BYTES) + (((FLAGS & MQ_EPI_BIAS) && MT <= 5) ? 2 * BN * 4 : 0);
     static std::atomic<uint64_t> attr_done{0};
     if (hipError_t e = mq_ensure_dyn_lds((const void*)gemm_nt_kernel<FLAGS, MT, PERSIST>, LDS, attr_done); e != hipSuccess) {
         mq_set_error("mq_gemm_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -351,9 +376,10 @@ int launch_gemm_mt(const void* A, int64_t lda, const void* W, int64_t ldw, const
     const bool act = (FLAGS & (MQ_EPI_GELU | MQ_EPI_QUICKGELU)) != 0;
     const int wide = (g_tune.wide && (g_tune.wide >= 2 || !act) && !(FLAGS & MQ_EPI_OUT_F32) && ldc % 8 == 0 && ((uintptr_t)out & 15) == 0) ? 1 : 0;
     const int grid = PERSIST && num_tiles > RESIDENT_SLOTS ? RESIDENT_SLOTS : num_tiles;
+    const int stagger = (PERSIST && num_tiles >= 2 * RESIDENT_SLOTS) ? g_tune.stagger : 0;
     hipLaunchKernelGGL((gemm_nt_kernel<FLAGS, MT, PERSIST>), dim3(grid), dim3(256), LDS, s,
                        (const bf16_t*)A, lda, (const bf16_t*)W, ldw, bias, residual, out, ldc,
-                       M, N, K, tiles_n, num_tiles, cgroup, band_rows, wide, ln);
+                       M, N, K, tiles_n, num_tiles, cgroup, band_rows, wide | (g_tune.lds_bias ? 2 : 0) | (stagger << 8), ln);
     MQ_CHECK_LAUNCH("mq_gemm_bf16");
     return MQ_OK;
 }
@@ -473,6 +499,8 @@ extern "C" int mq_tune(const char* key, int value) {
     else if (k == "gemm_big") g_tune.big = value;
     else if (k == "gemm_cgroup") mq_gemm_knob_cgroup = g_tune.cgroup = value;
     else if (k == "gemm_wide") mq_gemm_knob_wide = g_tune.wide = value;
+    else if (k == "gemm_stagger") g_tune.stagger = value;
+    else if (k == "gemm_lds_bias") g_tune.lds_bias = value;
     else if (k == "gemm_k32") g_tune.k32 = value;
     else if (k == "row_select") mq_tower_row_select = value;
     else if (k == "ln_fold") mq_tower_ln_fold = value;

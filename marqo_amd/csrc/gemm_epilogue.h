@@ -33,7 +33,7 @@ struct GemmLn {
 template <int FLAGS, int MT, int RG = MT>
 __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][4], const float* __restrict__ bias, const float* residual, void* out,
                                               int64_t ldc, int M, int N, int wave_m0, int wave_n0, int l15, int g, bool wide = false,
-                                              const GemmLn* lnp = nullptr) {
+                                              const GemmLn* lnp = nullptr, const float* lds_bias = nullptr) {
     constexpr bool BF16_OUT = !(FLAGS & MQ_EPI_OUT_F32);
     // bf16 residual stream (towers.hip): MQ_EPI_RESIDUAL without MQ_EPI_OUT_F32 = the residual is read as bf16 and the sum written
     // as bf16, in place — half the epilogue bytes of the fp32 stream, the memory-bound part of the K = 768 residual GEMMs
@@ -76,7 +76,10 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][4], const float* 
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
         const int n = wave_n0 + nt * 16 + g * 4;
-        bias_v[nt] = ((FLAGS & MQ_EPI_BIAS) && n < N) ? *(const f32x4*)(bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+        // lds_bias: the wave's 64 bias values staged in LDS during the k-loop (zero past N) — an L2 round trip (~1.5-3 k cycles at the
+        // head of every tile's epilogue, profiles/r01d_gemm_phase_trace.txt: "qkv plain" vs "qkv bias") becomes a ds_read
+        if ((FLAGS & MQ_EPI_BIAS) && lds_bias) bias_v[nt] = *(const f32x4*)(lds_bias + nt * 16 + g * 4);
+        else bias_v[nt] = ((FLAGS & MQ_EPI_BIAS) && n < N) ? *(const f32x4*)(bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
         cs_v[nt] = (LN_APPLY && n < N) ? *(const f32x4*)(lnp->colsum + n) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     // value of one (mt, nt) sub-tile after (LN apply) / bias / activation / residual

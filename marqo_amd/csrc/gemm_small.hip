@@ -1,6 +1,6 @@
 // Skinny GEMM for the search path (one query / a handful of rows per vectorise() call: tensor_search.py:1876-1911 in the reference).
 //
-//   out[M, N] = epi( A[M, K] @ W[N, K]^T ),  M <= 272,   optionally A = LayerNorm(x) computed in the kernel's prologue
+//   out[M, N] = epi( A[M, K] @ W[N, K]^T ),  M <= 80,   optionally A = LayerNorm(x) computed in the kernel's prologue
 //
 // The tiled kernel of gemm_bf16.hip gives such a call N/128 workgroups (4 .. 24 of 256 CUs), each walking the whole K serially: a
 // 10-token CLIP text costs ~7 us per GEMM and 0.68 ms per query although it is < 0.1 GFLOP.  Here the work is cut the other way:
@@ -22,7 +22,7 @@
 namespace {
 
 constexpr int SM_BN = 16;        // output columns per workgroup
-constexpr int SM_MAX_MT = 17;    // 16-row tiles: M <= 272 (one ViT-L/14 image = 257 rows)
+constexpr int SM_MAX_MT = 5;     // 16-row tiles: M <= 80
 constexpr int SM_LDS_LIMIT = 150 * 1024;
 constexpr int SM_WIDE_WG_MAX_N = 1024;  // up to 64 column slices: 8 waves per workgroup
 constexpr int SM_LN_CH = 5;     // fused LayerNorm: float4 chunks per lane, K <= 1280
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(const void* __restr
                                                              const bf16_t* __restrict__ Wt, int64_t ldw, const float* __restrict__ bias,
                                                              const void* residual, void* out, int64_t ldc, int M, int N, int K,
                                                              const float* __restrict__ ln_g, const float* __restrict__ ln_b, float eps,
-                                                             float* ln_out) {
+                                                             float* ln_out, const int32_t* __restrict__ ln_rows) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr bool BF16_OUT = !(FLAGS & MQ_EPI_OUT_F32);
     constexpr bool RES_BF16 = (FLAGS & MQ_EPI_RESIDUAL) && BF16_OUT;
@@ -62,11 +62,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(const void* __restr
             for (int j = 0; j < SM_LN_CH; ++j) {
                 const int c = lane + j * 64;
                 if (r >= M || c >= nch) { v[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; continue; }
+                const int64_t rs = ln_rows ? (int64_t)ln_rows[r] : (int64_t)r;   // pooled rows (class token / EOT) are gathered
                 if (a_bf16_stream) {
-                    const uint2 q = *(const uint2*)((const bf16_t*)Av + (int64_t)r * lda + c * 4);
+                    const uint2 q = *(const uint2*)((const bf16_t*)Av + rs * lda + c * 4);
                     v[i][j] = f32x4{__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u), __uint_as_float(q.y << 16), __uint_as_float(q.y & 0xffff0000u)};
                 } else {
-                    v[i][j] = *(const f32x4*)((const float*)Av + (int64_t)r * lda + c * 4);
+                    v[i][j] = *(const f32x4*)((const float*)Av + rs * lda + c * 4);
                 }
             }
         }
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(const void* __restr
     }
 
     // ---- main loop: this wave's share of the 32-deep k-chunks, G chunks per group (all of a group's loads are issued before its MFMAs) ----
-    constexpr int G = MT <= 2 ? 4 : MT <= 5 ? 2 : 1;
+    constexpr int G = MT <= 2 ? 4 : 2;
     const int nchunks = K >> 5;
     const int per = (nchunks + NW - 1) / NW;
     const int c0 = wave * per, c1 = min(c0 + per, nchunks);
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(const void* __restr
 
 template <int FLAGS, int MT, bool LN, int NW>
 int launch_small(const void* A, int64_t lda, int a_stream16, const void* W, int64_t ldw, const float* bias, const void* residual, void* out,
-                 int64_t ldc, int M, int N, int K, const float* ln_g, const float* ln_b, float eps, float* ln_out, hipStream_t s) {
+                 int64_t ldc, int M, int N, int K, const float* ln_g, const float* ln_b, float eps, float* ln_out, const int32_t* ln_rows, hipStream_t s) {
     const size_t lds = (LN ? (((size_t)MT * 16 * ln_row_bytes(K) + 255) & ~(size_t)255) : 0) + (size_t)NW * MT * 64 * 16;
     static std::atomic<uint64_t> attr_done{0};
     if (lds > 64 * 1024) {
@@ -212,15 +213,15 @@ int launch_small(const void* A, int64_t lda, int a_stream16, const void* W, int6
         }
     }
     hipLaunchKernelGGL((gemm_small_kernel<FLAGS, MT, LN, NW>), dim3((unsigned)((N + SM_BN - 1) / SM_BN)), dim3(NW * 64), lds, s, A, lda, a_stream16,
-                       (const bf16_t*)W, ldw, bias, residual, out, ldc, M, N, K, ln_g, ln_b, eps, ln_out);
+                       (const bf16_t*)W, ldw, bias, residual, out, ldc, M, N, K, ln_g, ln_b, eps, ln_out, ln_rows);
     MQ_CHECK_LAUNCH("mq_gemm_small");
     return MQ_OK;
 }
 
 template <int FLAGS, bool LN, int NW>
 int dispatch_mt(const void* A, int64_t lda, int a_stream16, const void* W, int64_t ldw, const float* bias, const void* residual, void* out, int64_t ldc,
-                int M, int N, int K, const float* ln_g, const float* ln_b, float eps, float* ln_out, hipStream_t s) {
-#define MQ_SM_MT(T) return launch_small<FLAGS, T, LN, NW>(A, lda, a_stream16, W, ldw, bias, residual, out, ldc, M, N, K, ln_g, ln_b, eps, ln_out, s)
+                int M, int N, int K, const float* ln_g, const float* ln_b, float eps, float* ln_out, const int32_t* ln_rows, hipStream_t s) {
+#define MQ_SM_MT(T) return launch_small<FLAGS, T, LN, NW>(A, lda, a_stream16, W, ldw, bias, residual, out, ldc, M, N, K, ln_g, ln_b, eps, ln_out, ln_rows, s)
     if constexpr (LN) {  // mq_gemm_small_ok(.., ln = true) admits M <= 32 only
         if (M <= 16) MQ_SM_MT(1);
         MQ_SM_MT(2);
@@ -230,11 +231,9 @@ int dispatch_mt(const void* A, int64_t lda, int a_stream16, const void* W, int64
         if (mt <= 2) MQ_SM_MT(2);
         if (mt <= 3) MQ_SM_MT(3);
         if (mt <= 4) MQ_SM_MT(4);
-        if (mt <= 5) MQ_SM_MT(5);
-        if (mt <= 7) MQ_SM_MT(7);
-        if (mt <= 10) MQ_SM_MT(10);
-        if (mt <= 13) MQ_SM_MT(13);
-        MQ_SM_MT(17);
+        // (taller slices measured slower than the tiled kernel: 257 rows — one ViT-L/14 image — 3.97 ms vs 3.2 ms per image; every
+        // workgroup re-reads all of A through its CU's 64 B/clk vector-memory path.  profiles/r02d_latency.txt)
+        MQ_SM_MT(5);
     }
 #undef MQ_SM_MT
 }
@@ -242,16 +241,16 @@ int dispatch_mt(const void* A, int64_t lda, int a_stream16, const void* W, int64
 // few column slices (N <= 1024): 8 waves per workgroup
 template <int FLAGS, bool LN>
 int dispatch_nw(const void* A, int64_t lda, int a_stream16, const void* W, int64_t ldw, const float* bias, const void* residual, void* out, int64_t ldc,
-                int M, int N, int K, const float* ln_g, const float* ln_b, float eps, float* ln_out, hipStream_t s) {
+                int M, int N, int K, const float* ln_g, const float* ln_b, float eps, float* ln_out, const int32_t* ln_rows, hipStream_t s) {
     if (N <= SM_WIDE_WG_MAX_N && K >= 512)
-        return dispatch_mt<FLAGS, LN, 8>(A, lda, a_stream16, W, ldw, bias, residual, out, ldc, M, N, K, ln_g, ln_b, eps, ln_out, s);
-    return dispatch_mt<FLAGS, LN, 4>(A, lda, a_stream16, W, ldw, bias, residual, out, ldc, M, N, K, ln_g, ln_b, eps, ln_out, s);
+        return dispatch_mt<FLAGS, LN, 8>(A, lda, a_stream16, W, ldw, bias, residual, out, ldc, M, N, K, ln_g, ln_b, eps, ln_out, ln_rows, s);
+    return dispatch_mt<FLAGS, LN, 4>(A, lda, a_stream16, W, ldw, bias, residual, out, ldc, M, N, K, ln_g, ln_b, eps, ln_out, ln_rows, s);
 }
 
 }  // namespace
 
 // knob: rows up to which the towers take the skinny path (0 = never).  mq_tune("small_m", v) / MQ_SMALL_M
-int mq_gemm_small_max_rows = getenv("MQ_SMALL_M") ? atoi(getenv("MQ_SMALL_M")) : 272;
+int mq_gemm_small_max_rows = getenv("MQ_SMALL_M") ? atoi(getenv("MQ_SMALL_M")) : 80;
 
 // can this call run on the skinny kernel?  (shape rules + LDS budget of the fused LayerNorm)
 bool mq_gemm_small_ok(int64_t M, int64_t N, int64_t K, bool ln) {
@@ -270,7 +269,7 @@ int mq_gemm_small(const void* d_A, int64_t lda, const void* d_W, int64_t ldw, co
     MQ_CHECK_ARG(mq_gemm_small_ok(M, N, K, false), "mq_gemm_small: shape M=%ld N=%ld K=%ld unsupported", (long)M, (long)N, (long)K);
     MqProfScope prof(0, s, 2.0 * (double)M * (double)N * (double)K);
 #define MQ_SM_CASE(F) \
-    case (F): return dispatch_nw<(F), false>(d_A, lda, 0, d_W, ldw, d_bias, d_residual, d_out, ldc, (int)M, (int)N, (int)K, nullptr, nullptr, 0.f, nullptr, s)
+    case (F): return dispatch_nw<(F), false>(d_A, lda, 0, d_W, ldw, d_bias, d_residual, d_out, ldc, (int)M, (int)N, (int)K, nullptr, nullptr, 0.f, nullptr, nullptr, s)
     switch (flags) {
         MQ_SM_CASE(0);
         MQ_SM_CASE(MQ_EPI_OUT_F32);
@@ -288,15 +287,18 @@ int mq_gemm_small(const void* d_A, int64_t lda, const void* d_W, int64_t ldw, co
 
 // out = epi(LayerNorm(x) @ W^T): x fp32 [M, K] (x_bf16 != 0: the bf16 residual stream), gamma / beta fp32 [K].  bf16 out.
 // d_ln_out (optional, fp32 [M, K], must not alias d_x): the normalised rows, written once (post-LN encoders: the next residual).
+// d_rows (optional, int32 [M]): row m of the GEMM is row d_rows[m] of x (the heads: class token / EOT rows).
 int mq_ln_gemm_small(const void* d_x, int64_t ldx, int x_bf16, const float* ln_g, const float* ln_b, float eps, const void* d_W, int64_t ldw,
-                     const float* d_bias, void* d_out, int64_t ldc, int64_t M, int64_t N, int64_t K, int flags, float* d_ln_out, hipStream_t s) {
+                     const float* d_bias, void* d_out, int64_t ldc, int64_t M, int64_t N, int64_t K, int flags, float* d_ln_out,
+                     const int32_t* d_rows, hipStream_t s) {
     MQ_CHECK_ARG(mq_gemm_small_ok(M, N, K, true), "mq_ln_gemm_small: shape M=%ld N=%ld K=%ld unsupported", (long)M, (long)N, (long)K);
     MQ_CHECK_ARG(d_x && ln_g && ln_b && d_W && d_out, "mq_ln_gemm_small: null pointer");
     MQ_CHECK_ARG((const void*)d_ln_out != d_x, "mq_ln_gemm_small: d_ln_out must not alias d_x (every workgroup reads x while workgroup 0 writes)");
     MqProfScope prof(0, s, 2.0 * (double)M * (double)N * (double)K);
 #define MQ_SM_CASE(F) \
-    case (F): return dispatch_nw<(F), true>(d_x, ldx, x_bf16, d_W, ldw, d_bias, nullptr, d_out, ldc, (int)M, (int)N, (int)K, ln_g, ln_b, eps, d_ln_out, s)
+    case (F): return dispatch_nw<(F), true>(d_x, ldx, x_bf16, d_W, ldw, d_bias, nullptr, d_out, ldc, (int)M, (int)N, (int)K, ln_g, ln_b, eps, d_ln_out, d_rows, s)
     switch (flags) {
+        MQ_SM_CASE(MQ_EPI_OUT_F32);   // the towers' heads: proj(ln(pooled row)), fp32 out
         MQ_SM_CASE(MQ_EPI_BIAS);
         MQ_SM_CASE(MQ_EPI_BIAS | MQ_EPI_GELU);
         MQ_SM_CASE(MQ_EPI_BIAS | MQ_EPI_QUICKGELU);
@@ -322,5 +324,5 @@ extern "C" int mq_ln_gemm_small_bf16(const void* d_x, int64_t ldx, int x_bf16, c
                                      float* d_ln_out, void* stream) {
     MQ_CHECK_ARG(!(flags & MQ_EPI_BIAS) || d_bias, "mq_ln_gemm_small_bf16: MQ_EPI_BIAS without bias");
     MQ_CHECK_ARG(ldx % 4 == 0 && ldw % 8 == 0 && ldc % 4 == 0, "mq_ln_gemm_small_bf16: leading dims must keep 16-byte rows");
-    return mq_ln_gemm_small(d_x, ldx, x_bf16, d_ln_g, d_ln_b, eps, d_W, ldw, d_bias, d_out, ldc, M, N, K, flags, d_ln_out, (hipStream_t)stream);
+    return mq_ln_gemm_small(d_x, ldx, x_bf16, d_ln_g, d_ln_b, eps, d_W, ldw, d_bias, d_out, ldc, M, N, K, flags, d_ln_out, nullptr, (hipStream_t)stream);
 }

@@ -48,11 +48,12 @@ extern "C" int mq_layernorm_ex(const void* d_x, int x_bf16, const int32_t* d_row
 // search path (rows <= 80): LayerNorm fused into the skinny GEMM's prologue (gemm_small.hip)
 bool mq_gemm_small_ok(int64_t M, int64_t N, int64_t K, bool ln);
 int mq_ln_gemm_small(const void* d_x, int64_t ldx, int x_bf16, const float* ln_g, const float* ln_b, float eps, const void* d_W, int64_t ldw,
-                     const float* d_bias, void* d_out, int64_t ldc, int64_t M, int64_t N, int64_t K, int flags, float* d_ln_out, hipStream_t s);
+                     const float* d_bias, void* d_out, int64_t ldc, int64_t M, int64_t N, int64_t K, int flags, float* d_ln_out,
+                     const int32_t* d_rows, hipStream_t s);
 // h = LN(x) ; out = epi(h @ W^T): one fused launch when the rows fit the skinny kernel, else LayerNorm kernel + tiled GEMM
 static int ln_gemm(const void* d_x, int xb, const float* g, const float* b, float eps, void* h, const void* W, const float* bias, void* out,
                    int64_t rows, int N, int K, int flags, hipStream_t s) {
-    if (mq_gemm_small_ok(rows, N, K, true)) return mq_ln_gemm_small(d_x, K, xb, g, b, eps, W, K, bias, out, N, rows, N, K, flags, nullptr, s);
+    if (mq_gemm_small_ok(rows, N, K, true)) return mq_ln_gemm_small(d_x, K, xb, g, b, eps, W, K, bias, out, N, rows, N, K, flags, nullptr, nullptr, s);
     MQ_TRY(mq_layernorm_ex(d_x, xb, nullptr, g, b, h, nullptr, rows, K, eps, s));
     return mq_gemm_bf16(h, K, W, K, bias, nullptr, out, N, rows, N, K, flags, s);
 }
@@ -325,12 +326,12 @@ int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* bloc
             if (l == 0) MQ_TRY(mq_gemm_bf16(h, W, b.qkv_w, W, b.qkv_b, nullptr, qf, 3 * Wa, rows, 3 * Wa, W, MQ_EPI_BIAS, s));
             else {
                 const mq_block_weights& pb = blocks[l - 1];
-                MQ_TRY(mq_ln_gemm_small(d_x, W, 0, pb.ln2_g, pb.ln2_b, cfg->ln_eps, b.qkv_w, W, b.qkv_b, qf, 3 * Wa, rows, 3 * Wa, W, MQ_EPI_BIAS, xn, s));
+                MQ_TRY(mq_ln_gemm_small(d_x, W, 0, pb.ln2_g, pb.ln2_b, cfg->ln_eps, b.qkv_w, W, b.qkv_b, qf, 3 * Wa, rows, 3 * Wa, W, MQ_EPI_BIAS, xn, nullptr, s));
                 res = xn;
             }
             MQ_TRY(mq_attention(qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, cfg->heads, cfg->mask, s));
             MQ_TRY(mq_gemm_bf16(a, Wa, b.out_w, Wa, b.out_b, res, d_x, W, rows, W, Wa, res_flags, s));
-            MQ_TRY(mq_ln_gemm_small(d_x, W, 0, b.ln1_g, b.ln1_b, cfg->ln_eps, b.fc1_w, W, b.fc1_b, qf, F, rows, F, W, MQ_EPI_BIAS | act_flag, xn, s));
+            MQ_TRY(mq_ln_gemm_small(d_x, W, 0, b.ln1_g, b.ln1_b, cfg->ln_eps, b.fc1_w, W, b.fc1_b, qf, F, rows, F, W, MQ_EPI_BIAS | act_flag, xn, nullptr, s));
             MQ_TRY(mq_gemm_bf16(qf, F, b.fc2_w, F, b.fc2_b, xn, d_x, W, rows, W, F, res_flags, s));
             if (l == cfg->layers - 1) MQ_TRY(mq_layernorm(d_x, nullptr, b.ln2_g, b.ln2_b, h, d_x, rows, W, cfg->ln_eps, s));
         } else {
@@ -488,8 +489,13 @@ int encode_image_impl(const mq_vit_cfg* cfg, const mq_vit_weights* w, const void
     MQ_TRY(encoder_forward_impl(&cfg->enc, w->blocks, x, p.rows, nullptr, n, p.T, p.T, rows_idx, n, base + p.off_enc,
                                 ws_bytes - p.off_enc, s));
     // K6: ln_post(class token) @ proj, L2
-    MQ_TRY(mq_layernorm_ex(x, xb, rows_idx, w->ln_post_g, w->ln_post_b, cls_ln, nullptr, n, W, cfg->enc.ln_eps, s));
-    MQ_TRY(mq_gemm_bf16(cls_ln, W, w->proj_w, W, nullptr, nullptr, d_out, cfg->out_dim, n, cfg->out_dim, W, MQ_EPI_OUT_F32, s));
+    if (mq_gemm_small_ok(n, cfg->out_dim, W, true))   // search path: ln_post rides in the head GEMM's prologue
+        MQ_TRY(mq_ln_gemm_small(x, W, xb, w->ln_post_g, w->ln_post_b, cfg->enc.ln_eps, w->proj_w, W, nullptr, d_out, cfg->out_dim, n, cfg->out_dim,
+                                W, MQ_EPI_OUT_F32, nullptr, rows_idx, s));
+    else {
+        MQ_TRY(mq_layernorm_ex(x, xb, rows_idx, w->ln_post_g, w->ln_post_b, cls_ln, nullptr, n, W, cfg->enc.ln_eps, s));
+        MQ_TRY(mq_gemm_bf16(cls_ln, W, w->proj_w, W, nullptr, nullptr, d_out, cfg->out_dim, n, cfg->out_dim, W, MQ_EPI_OUT_F32, s));
+    }
     if (normalize) MQ_TRY(mq_l2_normalize(d_out, d_out, n, cfg->out_dim, s));
     return MQ_OK;
 }
@@ -570,6 +576,12 @@ extern "C" int mq_encode_clip_text(const mq_clip_text_cfg* cfg, const mq_clip_te
     if (!pool_rows) { MQ_TRY(mq_last_rows(d_cu_seqlens, rows_idx, nseq, s)); pool_rows = rows_idx; }
     MQ_TRY(encoder_forward_impl(&cfg->enc, w->blocks, x, rows, d_cu_seqlens, nseq, 0, maxl, pool_rows, nseq, base + p.off_enc,
                                 workspace_bytes - p.off_enc, s));
+    if (!w->proj_b && mq_gemm_small_ok(nseq, cfg->out_dim, W, true)) {   // search path: ln_final rides in the head GEMM's prologue
+        MQ_TRY(mq_ln_gemm_small(x, W, xb, w->ln_final_g, w->ln_final_b, cfg->enc.ln_eps, w->proj_w, W, nullptr, d_out, cfg->out_dim, nseq,
+                                cfg->out_dim, W, MQ_EPI_OUT_F32, nullptr, pool_rows, s));
+        if (normalize) MQ_TRY(mq_l2_normalize(d_out, d_out, nseq, cfg->out_dim, s));
+        return MQ_OK;
+    }
     MQ_TRY(mq_layernorm_ex(x, xb, pool_rows, w->ln_final_g, w->ln_final_b, pooled, nullptr, nseq, W, cfg->enc.ln_eps, s));
     if (w->proj_b) {  // SigLIP: Linear with bias = the residual epilogue over zeros
         MQ_CHECK_HIP(hipMemsetAsync(d_out, 0, (size_t)nseq * cfg->out_dim * 4, s));

@@ -250,6 +250,15 @@ class _GraphedCall:
             cur.wait_event(self._last)
         self.inp.copy_(src, non_blocking=True)
         self.graph.replay()
+        if getattr(_request_tls, "host_output", False):
+            # the loaders hand the embedding to the host anyway (vectorise() returns lists / ndarrays): one D2H copy straight out of the
+            # static buffer instead of a device clone + the caller's .cpu()
+            out = torch.empty(self.out.shape, dtype=self.out.dtype, pin_memory=True)
+            out.copy_(self.out, non_blocking=True)
+            self._last = torch.cuda.Event()
+            self._last.record(cur)
+            self._last.synchronize()
+            return out
         out = self.out.clone()                     # the static output is overwritten by the next replay
         self._last = torch.cuda.Event()
         self._last.record(cur)
@@ -274,6 +283,8 @@ class request_stream:
         self._ctx = None
 
     def __enter__(self):
+        if not getattr(_request_tls, "depth", 0):
+            _request_tls.host_output = not self.device_output
         if not THREAD_STREAMS or not torch.cuda.is_available() or self.device.type != "cuda":
             return self
         streams = getattr(_request_tls, "streams", None)
@@ -300,6 +311,7 @@ class request_stream:
         if getattr(self, "_nested", False):
             _request_tls.depth -= 1
             return False
+        _request_tls.host_output = False
         if self._ctx is not None:
             self._ctx.__exit__(*exc)
             _request_tls.depth = 0
@@ -629,10 +641,13 @@ class _TextTowerBase(_TowerBase):
                 cu = torch.tensor([0, n_tok], dtype=torch.int32)
                 d_cu = cu.to(self.device)
                 o = torch.empty(1, self.arch.out_dim if clip else self.arch.width, dtype=torch.float32, device=self.device)
+                keep = []
                 if clip:
                     ws = torch.empty(self.lib.mq_clip_text_workspace_bytes(C.byref(self.cfg), n_tok, 1) + 256, dtype=torch.uint8, device=self.device)
+                    d_pool = torch.tensor([n_tok - 1], dtype=torch.int32).to(self.device)   # the pooled row (last = EOT) is known at capture
+                    keep.append(d_pool)
                     launch = lambda: L.check(self.lib.mq_encode_clip_text(
-                        C.byref(self.cfg), C.byref(self.w), d_packed.data_ptr(), d_cu.data_ptr(), cu.data_ptr(), 1, 0, o.data_ptr(),
+                        C.byref(self.cfg), C.byref(self.w), d_packed.data_ptr(), d_cu.data_ptr(), cu.data_ptr(), 1, d_pool.data_ptr(), o.data_ptr(),
                         1 if normalize else 0, ws.data_ptr(), ws.numel(), self._stream()), "mq_encode_clip_text")
                 else:
                     ws = torch.empty(self.lib.mq_bert_workspace_bytes(C.byref(self.cfg), n_tok, 1) + 256, dtype=torch.uint8, device=self.device)
@@ -640,7 +655,7 @@ class _TextTowerBase(_TowerBase):
                         C.byref(self.cfg), C.byref(self.w), d_packed.data_ptr(), d_cu.data_ptr(), cu.data_ptr(), 1, o.data_ptr(),
                         1 if normalize else 0, ws.data_ptr(), ws.numel(), self._stream()), "mq_encode_bert")
                 d_packed.copy_(src_ids)
-                return _GraphedCall(self.device, d_packed, o, (cu, d_cu, ws), launch)
+                return _GraphedCall(self.device, d_packed, o, (cu, d_cu, ws, *keep), launch)
             g = self._capture((n_tok, bool(normalize)), make)
             if g is None:
                 return None

@@ -29,10 +29,10 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture
 def tiled_gemm_only():
     """Bitwise batch-invariance tests: an embedding is bit-identical whatever else shares its batch as long as the same GEMM kernel family
-    runs it.  Calls of <= 272 rows take the column-sliced skinny kernels (csrc/gemm_small.hip: a different, fixed k-summation order), so
+    runs it.  Calls of <= 80 rows take the column-sliced skinny kernels (csrc/gemm_small.hip: a different, fixed k-summation order), so
     tests that compare a tiny call with a large one bit for bit pin the tiled family; tests/test_small_m_gpu.py bounds the difference."""
     from marqo_amd import _lib as L
     lib = L.load()
     L.check(lib.mq_tune(b"small_m", 0))
     yield
-    L.check(lib.mq_tune(b"small_m", 272))
+    L.check(lib.mq_tune(b"small_m", 80))

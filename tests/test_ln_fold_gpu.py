@@ -11,6 +11,12 @@ from oracle import towers as O
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _tiled_family(tiled_gemm_only):
+    """the folded epilogues live in the tiled kernels: compare against that family on the small shapes too"""
+    yield
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 

@@ -24,12 +24,12 @@ def _small(lib, A, W, bias, res, flags, out_dtype):
     return out
 
 
-@pytest.mark.parametrize("M", [1, 7, 16, 17, 33, 50, 64, 80, 81, 112, 197, 257, 272])
+@pytest.mark.parametrize("M", [1, 7, 16, 17, 33, 50, 64, 80])
 def test_skinny_gemm_matches_reference(M):
     lib = L.load()
     g = torch.Generator(device="cuda").manual_seed(M)
     shapes = ((512, 512), (2304, 768), (768, 3072), (100, 96), (4, 32), (1024, 4096), (3072, 1024), (1288, 64))
-    for (N, K) in (shapes if M <= 80 else shapes[1:6]):
+    for (N, K) in shapes:
         A = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
         W = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).to(torch.bfloat16)
         bias = torch.randn(N, device="cuda", generator=g)
@@ -135,7 +135,7 @@ def test_single_query_towers_on_the_skinny_path():
         assert _cos_err(skinny_t, ref_t) < 1e-4 and _cos_err(skinny_v, ref_v) < 1e-4 and _cos_err(skinny_b, ref_b) < 1e-4
         print(f"single-query skinny path: 1-cos vs fp32 oracle  text {_cos_err(skinny_t, ref_t):.2e}  image {_cos_err(skinny_v, ref_v):.2e}  "
               f"e5 {_cos_err(skinny_b, ref_b):.2e}")
-        # a query inside a small batch (still <= 272 rows): the same bits as on its own — rows are independent in the skinny kernels, and the
+        # a query inside a small batch (still <= 80 rows): the same bits as on its own — rows are independent in the skinny kernels, and the
         # fused LayerNorm (<= 32 rows) has the arithmetic of the stand-alone one
         short = ids[:3]
         assert torch.equal(tt.encode_ids(short), skinny_t[:3])
@@ -149,4 +149,4 @@ def test_single_query_towers_on_the_skinny_path():
         for a, c in ((skinny_t, tiled_t), (skinny_v, tiled_v), (skinny_b, tiled_b)):
             assert _cos_err(a, c) < 2e-5                                              # two bf16 summation orders of the same products
     finally:
-        L.check(lib.mq_tune(b"small_m", 272))
+        L.check(lib.mq_tune(b"small_m", 80))
