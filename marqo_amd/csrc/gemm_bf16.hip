@@ -159,6 +159,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
             w_src[i] = Wt + (int64_t)gn * ldw + ((lane & 7) ^ (row & 7)) * 8;
         }
     };
+#ifdef MQ_GEMM_DIAG
+    // diagnostic builds (tools/probes/build_gemm_diag.sh; timing only, results wrong by construction): which resource bounds the k-loop?
+    //   1 = no global -> LDS traffic after the first stage (MFMA + ds_read + epilogue ceiling)
+    //   2 = no MFMAs / fragment reads (global -> LDS fill + barriers + epilogue ceiling)
+    //   3 = no epilogue (k-loop only)
+#endif
     auto stage = [&](int buf, int kt) {
         char* sa = smem + buf * STAGE_BYTES + wave * (8 * MT * 128);
         char* sw = smem + buf * STAGE_BYTES + A_TILE_BYTES + wave * (32 * 128);
@@ -238,9 +244,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
                 for (int mt = 0; mt < MT; ++mt)
     #pragma unroll
                     for (int nt = 0; nt < 4; ++nt) {
+#if !defined(MQ_GEMM_DIAG) || MQ_GEMM_DIAG != 2
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][nt], af[kk][mt], acc[mt][nt], 0, 0, 0);
+#endif
                         const int done = (kk * MT + mt) * 4 + nt + 1;
+#if defined(MQ_GEMM_DIAG) && MQ_GEMM_DIAG == 1
+                        if (false) {
+#else
                         if (PREFETCH && done % GAP == 0 && issued < NL) {
+#endif
                             if (issued < MT) glds16(a_src[issued] + koff, na + issued * (8 * 128));
                             else glds16(w_src[issued - MT] + koff, nw + (issued - MT) * (8 * 128));
                             ++issued;
@@ -302,8 +314,19 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
 #ifdef MQ_GEMM_TRACE
         const unsigned long long te0 = MQ_TR_NOW();
 #endif
+#if defined(MQ_GEMM_DIAG) && MQ_GEMM_DIAG == 3
+        {   // 3 = no epilogue (the accumulators are folded into one never-true store so that the MFMAs stay live)
+            f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sum += acc[i][j];
+            if (sum[0] + sum[1] + sum[2] + sum[3] == 1.2345678e33f) ((float*)out)[0] = sum[0];
+        }
+#else
         gemm_epilogue<FLAGS, MT>(acc, bias, residual, out, ldc, M, N, cm0 + wm * (16 * MT), cn0 + wn * 64, l15, g, wide_store != 0, &ln,
                                  lds_bias_on ? bias_lds + bias_slot * BN + wn * 64 : nullptr);
+#endif
         bias_slot ^= 1;
 #ifdef MQ_GEMM_TRACE
         __builtin_amdgcn_sched_barrier(0);

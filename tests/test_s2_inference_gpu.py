@@ -75,7 +75,7 @@ def test_open_clip_from_disk_text_and_image(s2):
     assert _cos_err(out, ref) < COS_TOL
     assert np.allclose(np.linalg.norm(np.asarray(out), axis=1), 1.0, atol=1e-5)
     # str == [str]; vectorise == model.encode
-    assert np.allclose(s2i.vectorise("tiny-clip", texts[0], model_properties=props, device=DEV), out[:1], atol=1e-6)
+    assert _cos_err(s2i.vectorise("tiny-clip", texts[0], model_properties=props, device=DEV), out[:1]) < 3e-5   # one text = str, not list
     assert np.abs(model.encode(texts, normalize=True, infer=False) - np.asarray(out)).sum() < 1e-6
     # K14: the loader tokenises ASCII texts on the device; ids (hence embeddings) are identical to the host-tokeniser route,
     # also when a batch mixes in texts that must take the host route
@@ -276,7 +276,9 @@ def test_siglip_from_disk_text_and_image(s2, tmp_path, monkeypatch):
     ref = O.siglip_text_forward(sd, tcfg, torch.from_numpy(tok(texts))).numpy()
     assert np.asarray(out).shape == (4, W) and _cos_err(out, ref) < COS_TOL
     assert np.allclose(np.linalg.norm(np.asarray(out), axis=1), 1.0, atol=1e-5)
-    assert np.allclose(s2i.vectorise("tiny-siglip", "a photo of a cat", model_properties=props, device=DEV), out[:1], atol=1e-6)  # canonicalize
+    # canonicalize: the same text after lower-casing / punctuation stripping (a one-query call runs the skinny GEMM family, the batch the
+    # tiled one: same products, another bf16 summation order)
+    assert _cos_err(s2i.vectorise("tiny-siglip", "a photo of a cat", model_properties=props, device=DEV), out[:1]) < 3e-5
     model = s2i.get_available_models()[s2i._create_model_cache_key("tiny-siglip", DEV, props)]["model"]
     assert model.preprocess_config["resize_mode"] == "squash" and model.preprocess_config["mean"] == (0.5, 0.5, 0.5)
     # images: squash = PIL resize((S, S), BICUBIC), no crop
