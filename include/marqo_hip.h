@@ -290,6 +290,13 @@ int mq_chunk_grid_u8(const uint8_t* d_src, const int64_t* h_src_off, const int32
                      const int32_t* h_widths, int64_t n, int32_t hn, int32_t wn, int32_t overlap, int32_t S,
                      uint8_t* d_out, float* h_boxes, void* d_workspace, size_t workspace_bytes, void* stream);
 
+/* Decoded Pillow images hold 4 bytes per pixel (R, G, B, pad: Imaging "RGB" storage); the loaders stage those bytes as they are (a
+ * zero-copy view through Pillow's Arrow export instead of PIL's 4 -> 3 byte repack on the host, which is what Image.tobytes /
+ * np.asarray — and torchvision's ToTensor in the reference, clip_utils.py:65 — spend their time on) and repack on the device.
+ * d_staging: one buffer holding the pixel bytes and, at jobs_off (multiple of 8), n records {int64 src_off, int64 dst_off, int64 npix}
+ * (byte offsets into d_staging / d_rgb, both multiples of 256).  d_rgb receives packed RGB. */
+int mq_unpack_rgbx(const uint8_t* d_staging, int64_t jobs_off, int64_t n, int64_t max_npix, uint8_t* d_rgb, void* stream);
+
 /* ToTensor + Normalize (clip_utils.py:65-66): uint8 [n, S, S, 3] -> fp32 [n, 3, S, S]; this is the
  * tensor the reference's `.preprocess` hands to add_docs.py:130-134. mean/std: host float[3]. */
 int mq_to_tensor_normalize(const uint8_t* d_u8, float* d_out, int64_t n, int32_t S,

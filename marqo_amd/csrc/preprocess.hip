@@ -470,6 +470,39 @@ extern "C" int mq_chunk_grid_u8(const uint8_t* d_src, const int64_t* h_src_off, 
     return MQ_OK;
 }
 
+// ---- RGBX -> RGB: decoded Pillow images keep 4 bytes per pixel (R, G, B, pad); they are staged as they are and packed here -------
+struct UnpackJob { int64_t src_off, dst_off, npix; };   // byte offsets into the staging / packed buffers
+
+__global__ __launch_bounds__(256) void unpack_rgbx_kernel(const uint8_t* __restrict__ staging, const UnpackJob* __restrict__ jobs, uint8_t* __restrict__ dst) {
+    const UnpackJob j = jobs[blockIdx.y];
+    const uint8_t* in = staging + j.src_off;
+    uint8_t* out = dst + j.dst_off;
+    const int64_t quads = j.npix >> 2;   // 4 pixels: 16 bytes in, 12 bytes out (both offsets are 256-byte aligned)
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < quads; q += (int64_t)gridDim.x * 256) {
+        const uint4 v = *(const uint4*)(in + q * 16);
+        uint32_t* o = (uint32_t*)(out + q * 12);
+        o[0] = (v.x & 0x00ffffffu) | (v.y << 24);
+        o[1] = ((v.y >> 8) & 0x0000ffffu) | (v.z << 16);
+        o[2] = ((v.z >> 16) & 0x000000ffu) | (v.w << 8);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(j.npix & 3)) {
+        const int64_t px = (quads << 2) + threadIdx.x;
+        out[px * 3] = in[px * 4]; out[px * 3 + 1] = in[px * 4 + 1]; out[px * 3 + 2] = in[px * 4 + 2];
+    }
+}
+
+extern "C" int mq_unpack_rgbx(const uint8_t* d_staging, int64_t jobs_off, int64_t n, int64_t max_npix, uint8_t* d_rgb, void* stream) {
+    if (n <= 0) return MQ_OK;
+    MQ_CHECK_ARG(d_staging && d_rgb && jobs_off >= 0 && jobs_off % 8 == 0 && max_npix >= 1, "mq_unpack_rgbx: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    MqProfScope prof(5, s);
+    const int64_t bx = cdiv64(cdiv64(max_npix, 4), 256);
+    hipLaunchKernelGGL(unpack_rgbx_kernel, dim3((unsigned)(bx < 64 ? bx : 64), (unsigned)n), dim3(256), 0, s, d_staging,
+                       (const UnpackJob*)(d_staging + jobs_off), d_rgb);
+    MQ_CHECK_LAUNCH("mq_unpack_rgbx");
+    return MQ_OK;
+}
+
 extern "C" int mq_to_tensor_normalize(const uint8_t* d_u8, float* d_out, int64_t n, int32_t S, const float* mean, const float* std, void* stream) {
     MQ_CHECK_ARG(S >= 1 && mean && std, "mq_to_tensor_normalize: bad argument");
     if (n <= 0) return MQ_OK;

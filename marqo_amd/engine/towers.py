@@ -347,7 +347,7 @@ class _TowerBase:
 
     # ---- fp8 policy --------------------------------------------------------------------------------------------------------
     # e4m3 operands carry ~2.6 % rms relative rounding noise each, whatever the scaling granularity (per tensor, per row or MX
-    # blocks: oracle/fp8_sim.py, tools/fp8_study.py -> profiles/r02_fp8_numerics_sim.txt): a GEMM output is ~3.7 % noise, a 24-block
+    # blocks: oracle/fp8_sim.py, tests/studies/fp8_numerics_study.py -> profiles/r02_fp8_numerics_sim.txt): a GEMM output is ~3.7 % noise, a 24-block
     # ViT-L/14 with every block on fp8 ends at 1 - cos = 2e-3 on benign weights and 5e-3 on trained-like ones — outside the 1e-3
     # north-star tolerance.  Noise injected in early blocks is amplified by all later ones, so the policy keeps the FIRST blocks on
     # bf16 operands and runs the LAST ones on fp8: `tune_fp8` measures, on a fixed seeded calibration batch at load, the error of

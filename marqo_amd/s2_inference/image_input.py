@@ -107,6 +107,15 @@ def format_and_load_CLIP_images(images: List, image_download_headers: dict) -> L
     return [format_and_load_CLIP_image(i, image_download_headers) for i in images]
 
 
+def pil_to_pixels(img: ImageType):
+    """PIL image -> what the GPU preprocessing packs: a zero-copy RGBX view of Pillow's own memory where this Pillow exports one
+    (engine/preprocess.py: Rgbx, repacked to RGB on the device), else uint8 [H, W, 3] like pil_to_rgb_u8.  Same mode handling."""
+    from marqo_amd.engine.preprocess import pil_pixels
+    if img.mode != "RGB":
+        img = img.convert("RGB")
+    return pil_pixels(img)
+
+
 def pil_to_rgb_u8(img: ImageType) -> np.ndarray:
     """PIL image -> uint8 [H, W, 3].  The reference converts to RGB AFTER Resize/CenterCrop (clip_utils.py:61-64);
     for RGB and L inputs the order is immaterial.  Modes with alpha / palettes are flattened to RGB here before the

@@ -27,7 +27,7 @@ from marqo_amd.engine.towers import request_stream
 from marqo_amd.engine.tokenizers import ClipBpeTokenizer, SiglipTokenizer, SyntheticTokenizer, WordPieceTokenizer
 from marqo_amd.s2_inference.abstract_models import AbstractCLIPModel
 from marqo_amd.s2_inference.errors import InvalidModelPropertiesError, ModelLoadError
-from marqo_amd.s2_inference.image_input import format_and_load_CLIP_image, format_and_load_CLIP_images, pil_to_rgb_u8
+from marqo_amd.s2_inference.image_input import format_and_load_CLIP_image, format_and_load_CLIP_images, pil_to_pixels, pil_to_rgb_u8
 
 HF_HUB_PREFIX = "hf-hub:"
 MARQO_OPEN_CLIP_REGISTRY_PREFIX = "open_clip/"
@@ -95,6 +95,9 @@ class OpenCLIPModelProperties:
 
     def dict(self) -> dict:
         return dict(self.__dict__)
+
+
+PIPELINE_CHUNK = int(os.environ.get("MARQO_AMD_IMAGE_PIPELINE_CHUNK", "64"))   # images per host-pack / GPU-encode pipeline stage
 
 
 class OPEN_CLIP(AbstractCLIPModel):
@@ -285,7 +288,7 @@ class OPEN_CLIP(AbstractCLIPModel):
         """PIL image -> Tensor[3, S, S] fp32 (normalised), ALREADY on the device: resize / crop / normalise run on the GPU.
         Callers' `.to(device)` (add_docs.py:134) is then a no-op."""
         pre = self._pre()
-        u8 = self._resize(pre, [pil_to_rgb_u8(image)])
+        u8 = self._resize(pre, [pil_to_pixels(image)])
         return pre.to_tensor_normalize(u8)[0]
 
     def _resize(self, pre, raw) -> torch.Tensor:
@@ -315,7 +318,7 @@ class OPEN_CLIP(AbstractCLIPModel):
         pre = self._pre()
         if len(tensors) == len(loaded):
             return "f32", torch.stack([t.to(self.device) for t in tensors])
-        raw = [i if isinstance(i, np.ndarray) else pil_to_rgb_u8(i) for i in loaded if not isinstance(i, torch.Tensor)]
+        raw = [i if isinstance(i, np.ndarray) else pil_to_pixels(i) for i in loaded if not isinstance(i, torch.Tensor)]
         u8 = self._resize(pre, raw)
         if not tensors:
             return "u8", u8
@@ -332,9 +335,22 @@ class OPEN_CLIP(AbstractCLIPModel):
         if self.model is None:
             self.load()
         with request_stream(self.device, device_output=return_device):
-            kind, px = self._preprocess_images(images, image_download_headers)
-            self.image_input_processed = px
-            out = self.vision.encode_u8(px, normalize=bool(normalize)) if kind == "u8" else self.vision.encode_f32(px, normalize=bool(normalize))
+            run = lambda kind, px: (self.vision.encode_u8(px, normalize=bool(normalize)) if kind == "u8"
+                                    else self.vision.encode_f32(px, normalize=bool(normalize)))
+            if isinstance(images, list) and len(images) >= 2 * PIPELINE_CHUNK:
+                # large calls go through in chunks: everything the GPU does is enqueued asynchronously, so the host packs chunk k + 1
+                # (pinned staging, a few copy threads) while the GPU resizes and encodes chunk k; one D2H copy at the end
+                outs, pxs = [], []
+                for a in range(0, len(images), PIPELINE_CHUNK):
+                    kind, px = self._preprocess_images(images[a:a + PIPELINE_CHUNK], image_download_headers)
+                    pxs.append(px)
+                    outs.append(run(kind, px))
+                self.image_input_processed = torch.cat(pxs) if len({(p.dtype, p.shape[1:]) for p in pxs}) == 1 else pxs[-1]
+                out = torch.cat(outs)
+            else:
+                kind, px = self._preprocess_images(images, image_download_headers)
+                self.image_input_processed = px
+                out = run(kind, px)
             return out if return_device else self._convert_output(out)
 
     def encode_text(self, sentence: Union[str, List[str]], normalize=True, return_device: bool = False):
@@ -357,7 +373,7 @@ class OPEN_CLIP(AbstractCLIPModel):
     # engine extensions used by the chunking / bulk-ingest path ------------------------------------------------------
     def encode_image_chunks(self, images: Sequence, hn: int = 3, wn: int = 3, overlap: bool = False, normalize=True):
         """'simple' / 'overlap' patch methods entirely on the device: -> (embeddings [n, count, D], boxes [n, count, 4])."""
-        raw = [pil_to_rgb_u8(i) if isinstance(i, ImageType) else np.asarray(i) for i in images]
+        raw = [pil_to_pixels(i) if isinstance(i, ImageType) else np.asarray(i) for i in images]
         u8, boxes = self._pre().chunk_grid_u8(raw, hn, wn, overlap)
         if self._resize_mode == "squash" and len(raw):
             # the grid crops are square (shorter-side resize + crop == squash); chunk 0, the whole image, is not

@@ -21,7 +21,7 @@ from PIL import Image
 from PIL.Image import Image as ImageType
 
 from marqo_amd.s2_inference.errors import ChunkerError, ChunkerMethodProcessError
-from marqo_amd.s2_inference.image_input import format_and_load_CLIP_image, pil_to_rgb_u8
+from marqo_amd.s2_inference.image_input import format_and_load_CLIP_image, pil_to_pixels, pil_to_rgb_u8
 
 _local = threading.local()
 
@@ -95,7 +95,7 @@ class PatchifySimple:
     def infer(self, image: Union[str, ImageType]):
         self.image = format_and_load_CLIP_image(image, {})
         self.original_size = self.image.size
-        u8 = _preprocessor(self.device).resize_u8([pil_to_rgb_u8(self.image)], self.size[1], self.size[0])
+        u8 = _preprocessor(self.device).resize_u8([pil_to_pixels(self.image)], self.size[1], self.size[0])
         self.image_resized = Image.fromarray(u8[0].cpu().numpy(), "RGB")
         self.bboxes_simple = generate_boxes(self.size, self.hn, self.wn, overlap=self.overlap)
 
@@ -137,7 +137,7 @@ def chunk_images_to_tensors(images: List[Union[str, ImageType, np.ndarray]], mod
     if method not in ("simple", "overlap"):
         raise ValueError(f"unexpected image chunking type. found {method}")
     hn, wn = int(params.get("hn", 3)), int(params.get("wn", 3))
-    raw = [pil_to_rgb_u8(format_and_load_CLIP_image(i, {})) if not isinstance(i, np.ndarray) else i for i in images]
+    raw = [pil_to_pixels(format_and_load_CLIP_image(i, {})) if not isinstance(i, np.ndarray) else i for i in images]
     pre = model._pre()
     u8, boxes = pre.chunk_grid_u8(raw, hn, wn, method == "overlap")
     t = pre.to_tensor_normalize(u8)

@@ -123,3 +123,32 @@ def test_squash_resize_filters_bit_exact_vs_pillow(pre, interp, filt):
     out2 = pre.resize_u8(imgs[:3], 96, 160, interpolation=interp).cpu().numpy()               # non-square target
     for i in range(3):
         assert np.array_equal(out2[i], np.asarray(Image.fromarray(imgs[i]).resize((160, 96), res)))
+
+
+def test_packed_images_rgbx_staging_and_threaded_copies(pre):
+    """PIL images travel as Pillow's in-memory RGBX bytes (zero-copy Arrow view) and are repacked to RGB on the device (mq_unpack_rgbx);
+    arrays / CPU tensors are copied by the pack threads: the packed device buffer must hold every image's RGB bytes at its offset, for
+    all-PIL, all-array and mixed batches, odd pixel counts included."""
+    from PIL import Image
+    from marqo_amd.engine import preprocess as P
+    sizes = [(224, 224), (1, 1), (3, 5), (333, 77), (64, 64), (17, 23), (480, 640), (2, 3)] + [(50 + i, 40 + 2 * i) for i in range(24)]
+    arrs = _imgs(sizes, seed=9)
+    pils = [Image.fromarray(a) for a in arrs]
+    views = [P.pil_pixels(p) for p in pils]
+    if not all(isinstance(v, P.Rgbx) for v in views):
+        pytest.skip("this Pillow / pyarrow pair has no Arrow export")
+    mixed = [views[i] if i % 3 == 0 else (arrs[i] if i % 3 == 1 else torch.from_numpy(arrs[i])) for i in range(len(arrs))]
+    for batch in (views, arrs, mixed, [v for v in views[:3]]):
+        p = P.PackedImages(batch, torch.device("cuda:0"))
+        buf = p.buffer.cpu().numpy()
+        for a, off in zip(arrs, p.offsets):
+            assert np.array_equal(buf[int(off):int(off) + a.size], a.reshape(-1)), a.shape
+    # and through the resize: PIL route == array route == oracle
+    out_pil = pre.resize_crop_u8(views).cpu().numpy()
+    out_arr = pre.resize_crop_u8(arrs).cpu().numpy()
+    assert np.array_equal(out_pil, out_arr)
+    assert np.array_equal(out_arr[3], OP.clip_resize_crop_u8(arrs[3], 224, backend="c"))
+    # device tensors of one size are stacked, of several sizes copied one by one: same packed bytes
+    same = [torch.from_numpy(a).cuda() for a in _imgs([(64, 64)] * 5, seed=2)]
+    p = P.PackedImages(same, torch.device("cuda:0"))
+    assert torch.equal(p.buffer.reshape(5, 64, 64, 3), torch.stack(same))

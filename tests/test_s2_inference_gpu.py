@@ -310,3 +310,20 @@ def test_siglip_from_disk_text_and_image(s2, tmp_path, monkeypatch):
             s2i.eject_model(name, DEV)
     finally:
         os.environ.pop("MARQO_AMD_SYNTHETIC_WEIGHTS", None)
+
+
+def test_large_image_call_is_pipelined_in_chunks(s2, monkeypatch):
+    """>= 2 * PIPELINE_CHUNK images go through host-pack / GPU-encode in chunks: same embeddings as one pass, in order; mixed PIL / array
+    inputs; `image_input_processed` still holds the whole preprocessed batch."""
+    s2i, root = s2
+    props, sd, vcfg, _ = _tiny_clip(root)
+    from marqo_amd.s2_inference import open_clip_model as M
+    rng = np.random.default_rng(5)
+    imgs = [rng.integers(0, 256, (40 + (i % 7) * 9, 50 + (i % 5) * 11, 3), dtype=np.uint8) for i in range(37)]
+    imgs = [Image.fromarray(a) if i % 2 else a for i, a in enumerate(imgs)]
+    whole = np.asarray(s2i.vectorise("tiny-clip", imgs, model_properties=props, device=DEV, modality=s2i.Modality.IMAGE))
+    monkeypatch.setattr(M, "PIPELINE_CHUNK", 8)
+    model = s2i.get_available_models()[s2i._create_model_cache_key("tiny-clip", DEV, props)]["model"]
+    chunked = model.encode_image(imgs)
+    assert chunked.shape == whole.shape and _cos_err(chunked, whole) < 3e-5      # (8-image chunks of 17 tokens cross GEMM kernel families)
+    assert tuple(model.image_input_processed.shape) == (37, 64, 64, 3)

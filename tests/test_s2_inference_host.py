@@ -493,3 +493,27 @@ def test_bench_workload_table_resolves():
     assert abs(v.gflop_per_image - 8.82) < 0.01          # the per-embedding figure BASELINE / SURVEY §8(d) quote
     v, _ = A.resolve_open_clip("ViT-L-14")
     assert abs(v.gflop_per_image - 162.0) < 0.1
+
+
+def test_pil_pixels_zero_copy_view_matches_asarray():
+    """engine/preprocess.pil_pixels: the Arrow view of a decoded Pillow image is its RGB bytes + one pad byte per pixel, for every size,
+    for lazily opened files, and other modes fall back to the converted array."""
+    import io
+    from marqo_amd.engine import preprocess as P
+    from marqo_amd.s2_inference.image_input import pil_to_pixels, pil_to_rgb_u8
+    rng = np.random.default_rng(0)
+    for h, w in [(224, 224), (1, 1), (3, 5), (1080, 1920), (333, 77)]:
+        a = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        r = P.pil_pixels(Image.fromarray(a))
+        got = r.view[..., :3] if isinstance(r, P.Rgbx) else r
+        assert r.shape == (h, w, 3) and np.array_equal(got, a)
+    b = io.BytesIO()
+    Image.fromarray(rng.integers(0, 256, (100, 120, 3), dtype=np.uint8)).save(b, "PNG")
+    lazy = Image.open(io.BytesIO(b.getvalue()))
+    r = P.pil_pixels(lazy)
+    assert np.array_equal(r.view[..., :3] if isinstance(r, P.Rgbx) else r, np.asarray(lazy))
+    for mode in ("L", "RGBA", "P", "CMYK"):
+        im = Image.fromarray(rng.integers(0, 256, (8, 9, 3), dtype=np.uint8)).convert(mode)
+        r = pil_to_pixels(im)
+        got = r.view[..., :3] if isinstance(r, P.Rgbx) else r
+        assert np.array_equal(got, pil_to_rgb_u8(im))
