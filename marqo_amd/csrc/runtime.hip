@@ -67,3 +67,43 @@ extern "C" int mq_profile_collect(double* ms, int64_t* launches, double* gemm_fl
     g_prof.clear();
     return rc;
 }
+
+
+// ---- host-side staging helper -------------------------------------------------------------------------------------------------
+// Gather n host buffers into one (pinned) staging buffer with a few copy threads, in ONE foreign call: the Python loaders release the GIL
+// once for the whole pack instead of once per image (with several request threads, every per-image re-acquisition of the GIL waited for
+// the interpreter's switch interval: 256-image calls went from 3 ms to 30-55 ms of packing under 4 concurrent callers).
+#include <cstring>
+#include <thread>
+#include <vector>
+extern "C" int mq_host_gather(const void* const* h_src, const int64_t* h_bytes, const int64_t* h_dst_off, int64_t n, void* h_dst, int32_t threads) {
+    if (n <= 0) return MQ_OK;
+    MQ_CHECK_ARG(h_src && h_bytes && h_dst_off && h_dst, "mq_host_gather: null pointer");
+    int64_t total = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        MQ_CHECK_ARG(h_bytes[i] >= 0 && h_dst_off[i] >= 0 && (h_bytes[i] == 0 || h_src[i]), "mq_host_gather: bad item %ld", (long)i);
+        total += h_bytes[i];
+    }
+    int t = threads < 1 ? 1 : (threads > 16 ? 16 : threads);
+    if (total < (4 << 20)) t = 1;   // small packs: a thread start costs more than the copy
+    auto work = [&](int64_t lo, int64_t hi) {
+        for (int64_t i = lo; i < hi; ++i)
+            if (h_bytes[i]) memcpy((char*)h_dst + h_dst_off[i], h_src[i], (size_t)h_bytes[i]);
+    };
+    if (t == 1) { work(0, n); return MQ_OK; }
+    // contiguous item ranges of about total / t bytes each
+    std::vector<std::thread> pool;
+    int64_t lo = 0, acc = 0;
+    const int64_t share = (total + t - 1) / t;
+    for (int64_t i = 0; i < n; ++i) {
+        acc += h_bytes[i];
+        if (acc >= share || i == n - 1) {
+            if (i == n - 1 || (int)pool.size() == t - 1) { work(lo, n); break; }   // the calling thread takes the last range
+            pool.emplace_back(work, lo, i + 1);
+            lo = i + 1;
+            acc = 0;
+        }
+    }
+    for (auto& th : pool) th.join();
+    return MQ_OK;
+}

@@ -9,8 +9,6 @@ from __future__ import annotations
 
 import ctypes as C
 import os
-import threading
-from concurrent.futures import ThreadPoolExecutor
 from typing import List, Optional, Sequence, Tuple, Union
 
 import numpy as np
@@ -27,21 +25,7 @@ except Exception:  # pragma: no cover
 ArrayLike = Union[np.ndarray, torch.Tensor, "Rgbx"]
 
 
-PACK_THREADS = int(os.environ.get("MARQO_AMD_PACK_THREADS", str(max(1, min(8, (os.cpu_count() or 2) // 2)))))
-_pack_pool: Optional[ThreadPoolExecutor] = None
-_pack_pool_lock = threading.Lock()
-
-
-def _pool() -> Optional[ThreadPoolExecutor]:
-    """shared copy threads of the host packing (numpy releases the GIL while it copies)"""
-    global _pack_pool
-    if PACK_THREADS <= 1:
-        return None
-    if _pack_pool is None:
-        with _pack_pool_lock:
-            if _pack_pool is None:
-                _pack_pool = ThreadPoolExecutor(max_workers=PACK_THREADS, thread_name_prefix="marqo-amd-pack")
-    return _pack_pool
+PACK_THREADS = int(os.environ.get("MARQO_AMD_PACK_THREADS", str(max(1, min(8, (os.cpu_count() or 2) // 2)))))   # memcpy threads of a pack
 
 
 class Rgbx:
@@ -86,7 +70,7 @@ def _align256(v):
 class PackedImages:
     """A batch of variable-size uint8 RGB images packed back to back (256-byte aligned) in one device buffer.
 
-    Host images are copied once, into a pinned staging buffer, by a few threads (numpy copies release the GIL), then cross PCIe in ONE
+    Host images are copied once, into a pinned staging buffer, by a few memcpy threads inside one C call, then cross PCIe in ONE
     asynchronous transfer; Pillow images travel as their in-memory RGBX bytes and are repacked to RGB by mq_unpack_rgbx."""
 
     def __init__(self, images: Sequence[ArrayLike], device: torch.device):
@@ -124,21 +108,22 @@ class PackedImages:
         host = torch.empty(max(stage_bytes, 1), dtype=torch.uint8, pin_memory=torch.cuda.is_available())
         hnp = host.numpy()
 
-        def copy_one(k):
-            i = imgs[k]
+        # one foreign call copies everything (mq_host_gather: a few memcpy threads, the GIL released once for the whole pack)
+        srcs, nbytes, dsts = (C.c_void_p * self.n)(), np.empty(self.n, dtype=np.int64), np.empty(self.n, dtype=np.int64)
+        keep = []
+        for k, i in enumerate(imgs):
             if is_x[k]:
-                np.copyto(hnp[x_off[k]:x_off[k] + int(npix[k]) * 4].reshape(i.view.shape), i.view)
+                a, dsts[k] = i.view, x_off[k]
             else:
-                src = i if isinstance(i, np.ndarray) else (i.numpy() if i.device.type == "cpu" else i.cpu().numpy())
-                np.copyto(hnp[int(self.offsets[k]):int(self.offsets[k] + sizes[k])].reshape(src.shape), src)
-
-        pool = _pool()
-        if pool is not None and self.n >= 2 * PACK_THREADS and total + (cur - total) >= (1 << 20):
-            chunks = [range(t, self.n, PACK_THREADS) for t in range(PACK_THREADS)]
-            list(pool.map(lambda r: [copy_one(k) for k in r], chunks))
-        else:
-            for k in range(self.n):
-                copy_one(k)
+                a = i if isinstance(i, np.ndarray) else (i.numpy() if i.device.type == "cpu" else i.cpu().numpy())
+                dsts[k] = self.offsets[k]
+            if not a.flags.c_contiguous:
+                a = np.ascontiguousarray(a)
+            keep.append(a)
+            srcs[k] = a.__array_interface__["data"][0]
+            nbytes[k] = a.nbytes
+        L.check(L.load().mq_host_gather(srcs, nbytes.ctypes.data, dsts.ctypes.data, self.n, host.data_ptr(), PACK_THREADS), "mq_host_gather")
+        del keep
         if nx:
             jobs = np.asarray([(x_off[k], int(self.offsets[k]), int(npix[k])) for k in range(self.n) if is_x[k]], dtype=np.int64)
             hnp[jobs_off:jobs_off + nx * 24] = jobs.view(np.uint8).reshape(-1)

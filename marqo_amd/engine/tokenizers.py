@@ -404,6 +404,7 @@ class SyntheticTokenizer:
     def __init__(self, kind: str, vocab_size: int, context_length: int = 77):
         assert kind in ("clip", "bert", "siglip")
         self.kind, self.vocab_size, self.context_length = kind, vocab_size, context_length
+        self._ids: Dict[str, int] = {}
         if kind == "clip":
             self.sot_id, self.eot_id, self.lo, self.hi = vocab_size - 2, vocab_size - 1, 1, vocab_size - 2
         elif kind == "siglip":
@@ -412,8 +413,13 @@ class SyntheticTokenizer:
             self.cls_id, self.sep_id, self.pad_id, self.lo, self.hi = 101, 102, 0, 1000, vocab_size
 
     def _word_id(self, w: str) -> int:
-        h = int.from_bytes(hashlib.blake2b(w.encode("utf-8"), digest_size=8).digest(), "little")
-        return self.lo + h % (self.hi - self.lo)
+        hit = self._ids.get(w)
+        if hit is None:
+            h = int.from_bytes(hashlib.blake2b(w.encode("utf-8"), digest_size=8).digest(), "little")
+            hit = self.lo + h % (self.hi - self.lo)
+            if len(self._ids) < 1 << 16:
+                self._ids[w] = hit
+        return hit
 
     def encode_words(self, text: str) -> List[int]:
         return [self._word_id(w) for w in text.lower().split()]

@@ -97,7 +97,7 @@ class OpenCLIPModelProperties:
         return dict(self.__dict__)
 
 
-PIPELINE_CHUNK = int(os.environ.get("MARQO_AMD_IMAGE_PIPELINE_CHUNK", "64"))   # images per host-pack / GPU-encode pipeline stage
+PIPELINE_CHUNK = int(os.environ.get("MARQO_AMD_IMAGE_PIPELINE_CHUNK", "512"))  # images per host-pack / GPU-encode pipeline stage (smaller chunks cost GEMM efficiency: 64-image chunks ran 256 images in 5.5 ms instead of 3.2, profiles/r02g_e2e_profile.txt)
 
 
 class OPEN_CLIP(AbstractCLIPModel):
