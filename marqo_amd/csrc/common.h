@@ -46,8 +46,37 @@ __device__ __forceinline__ float fast_erf(float x) {
     const float y = 1.0f - p * t * __expf(-ax * ax);
     return copysignf(y, x);
 }
+// erf-GELU without transcendentals: gelu(x) = x * Phi(x), Phi(x) = 0.5 + xc * Q(xc^2) with xc = clamp(x, -4.5, 4.5) and Q a degree-8
+// weighted-minimax polynomial (tools/fit_gelu.py regenerates the coefficients).  |error| <= 7e-5 absolute in fp32 Horner form over all
+// x (|relative| <= 1e-4 for x > 0.5; beyond the clamp Phi stays at Phi(+-4.5) = 1 - 3.4e-6 / 3.4e-6), an order of magnitude below
+// the bf16 rounding of the value it feeds.  11 VALU operations, all of them packable two lanes-elements at a time (v_pk_mul_f32 /
+// v_pk_fma_f32), against 1 v_rcp + 1 v_exp + ~15 VALU of the Abramowitz-Stegun form above: the GELU was 6.8 k of the fc1 tile
+// epilogue's 12.4 k cycles (profiles/r01d_gemm_phase_trace.txt) and the only place where the tower GEMMs trailed the vendor
+// library's bias-only kernels (profiles/r02g_vendor_gemm_calibration.txt).  fast_erf stays for callers that need erf itself.
+__device__ __forceinline__ f32x2_t gelu_erf2(f32x2_t x) {
+#ifdef MQ_GELU_AS   // A/B build (tools/probes/build_gelu_ab.sh): the Abramowitz-Stegun form this replaced
+    return f32x2_t{0.5f * x[0] * (1.0f + fast_erf(x[0] * 0.70710678118654752440f)), 0.5f * x[1] * (1.0f + fast_erf(x[1] * 0.70710678118654752440f))};
+#endif
+    f32x2_t xc = {__builtin_amdgcn_fmed3f(x[0], -4.5f, 4.5f), __builtin_amdgcn_fmed3f(x[1], -4.5f, 4.5f)};
+    const f32x2_t s = xc * xc;
+    f32x2_t q = {3.036425686e-11f, 3.036425686e-11f};
+    q = __builtin_elementwise_fma(q, s, (f32x2_t){-3.314666682e-09f, -3.314666682e-09f});
+    q = __builtin_elementwise_fma(q, s, (f32x2_t){1.590999455e-07f, 1.590999455e-07f});
+    q = __builtin_elementwise_fma(q, s, (f32x2_t){-4.451734438e-06f, -4.451734438e-06f});
+    q = __builtin_elementwise_fma(q, s, (f32x2_t){8.142522511e-05f, 8.142522511e-05f});
+    q = __builtin_elementwise_fma(q, s, (f32x2_t){-1.037591685e-03f, -1.037591685e-03f});
+    q = __builtin_elementwise_fma(q, s, (f32x2_t){9.585204319e-03f, 9.585204319e-03f});
+    q = __builtin_elementwise_fma(q, s, (f32x2_t){-6.598465809e-02f, -6.598465809e-02f});
+    q = __builtin_elementwise_fma(q, s, (f32x2_t){3.987126077e-01f, 3.987126077e-01f});
+    const f32x2_t ph = __builtin_elementwise_fma(xc, q, (f32x2_t){0.5f, 0.5f});
+    return x * ph;
+}
 __device__ __forceinline__ float gelu_erf(float x) {
-    return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752440f));
+    return gelu_erf2((f32x2_t){x, x})[0];
+}
+__device__ __forceinline__ f32x4 gelu_erf4(f32x4 v) {
+    const f32x2_t lo = gelu_erf2((f32x2_t){v[0], v[1]}), hi = gelu_erf2((f32x2_t){v[2], v[3]});
+    return f32x4{lo[0], lo[1], hi[0], hi[1]};
 }
 __device__ __forceinline__ float quick_gelu(float x) {
     return x / (1.0f + __expf(-1.702f * x));

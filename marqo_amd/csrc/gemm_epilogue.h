@@ -91,8 +91,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][4], const float* 
         }
         if (FLAGS & MQ_EPI_BIAS) v += bias_v[nt];
         if (FLAGS & MQ_EPI_GELU) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+            v = gelu_erf4(v);
         }
         if (FLAGS & MQ_EPI_QUICKGELU) {
 #pragma unroll

@@ -253,8 +253,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(
             for (int e = 0; e < 4; ++e) v[e] *= sa * sw_v[nt][e];
             if (FLAGS & MQ_EPI_BIAS) v += bias_v[nt];
             if (FLAGS & MQ_EPI_GELU) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                v = gelu_erf4(v);
             }
             if (FLAGS & MQ_EPI_QUICKGELU) {
 #pragma unroll

@@ -174,8 +174,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(const void* __restr
         if (m >= M || n >= N) continue;
         if (FLAGS & MQ_EPI_BIAS) v += bias_v;
         if (FLAGS & MQ_EPI_GELU) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+            v = gelu_erf4(v);
         }
         if (FLAGS & MQ_EPI_QUICKGELU) {
 #pragma unroll

@@ -445,10 +445,11 @@ def test_clip_text_full_depth_realistic_weights_bf16():
     assert e < 3e-4
 
 
-def test_bf16_residual_stream_parity():
+def test_bf16_residual_stream_parity(tiled_gemm_only):
     """mq_tune("residual_bf16", 1): the pre-LN towers keep x in bf16 between blocks (half the bytes of every residual epilogue and
     LayerNorm).  Full registry depth, plain and trained-like weights: still inside the 3e-4 the fp32-stream form is held to, and the
-    pooled-rows-only last block stays bit-identical to the all-rows execution in this form too."""
+    pooled-rows-only last block stays bit-identical to the all-rows execution in this form too (within the tiled GEMM family: the
+    fixture keeps the few pooled rows off the skinny kernel, whose split-K summation order differs)."""
     from marqo_amd import _lib as L
     from marqo_amd.engine import archs, towers
     lib = L.load()
