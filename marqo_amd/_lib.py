@@ -20,6 +20,8 @@ CSRC_DIR = PKG_DIR / "csrc"
 LIB_DIR = PKG_DIR / "lib"
 LIB_PATH = Path(os.environ["MARQO_AMD_LIB"]) if os.environ.get("MARQO_AMD_LIB") else LIB_DIR / "libmarqo_hip.so"  # override: diagnostic builds
 HEADER_PATH = PKG_DIR.parent / "include" / "marqo_hip.h"
+TORCH_OPS_SRC = CSRC_DIR / "torch_ops.cpp"
+TORCH_OPS_PATH = LIB_DIR / "libmarqo_torch_ops.so"   # torch.ops.marqo_hip.*: the PyTorch custom-op face of the same C ABI
 
 MQ_OK = 0
 NO_SCRATCH_UNITS = ("gemm_bf16", "gemm_big", "gemm_k32", "gemm_fp8", "gemm_small", "attention")  # build() refuses register spills in these
@@ -233,6 +235,75 @@ def build(force: bool = False, verbose: bool = False) -> Path:
         if res.returncode != 0:
             raise MarqoHipUnavailableError(f"link failed ({res.returncode}):\n{res.stdout}\n{res.stderr}")
     return LIB_PATH
+
+
+def build_torch_ops(force: bool = False, verbose: bool = False) -> Path:
+    """Compile csrc/torch_ops.cpp (host code only: TORCH_LIBRARY registrations that forward to the C ABI on PyTorch's current HIP
+    stream) with g++ against the installed torch headers and link it to lib/libmarqo_hip.so -> lib/libmarqo_torch_ops.so."""
+    import torch
+    deps = [str(TORCH_OPS_SRC), str(HEADER_PATH)]
+    if not force and TORCH_OPS_PATH.exists() and os.path.getmtime(TORCH_OPS_PATH) >= max(os.path.getmtime(p) for p in deps):
+        return TORCH_OPS_PATH
+    if not LIB_PATH.exists():
+        raise MarqoHipUnavailableError(f"{LIB_PATH} must be built before the torch ops library")
+    ti = Path(torch.__file__).resolve().parent
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", f"-I{ti}/include", f"-I{ti}/include/torch/csrc/api/include",
+           f"-I{rocm}/include", str(TORCH_OPS_SRC), "-o", str(TORCH_OPS_PATH), f"-L{ti}/lib", "-ltorch", "-ltorch_cpu", "-lc10", "-lc10_hip",
+           "-ltorch_hip", f"-L{LIB_DIR}", "-lmarqo_hip", "-Wl,-rpath,$ORIGIN", f"-Wl,-rpath,{ti}/lib"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise MarqoHipUnavailableError(f"g++ failed on {TORCH_OPS_SRC} ({res.returncode}):\n{res.stdout}\n{res.stderr[-4000:]}")
+    return TORCH_OPS_PATH
+
+
+_ops = None
+
+
+def boundary() -> str:
+    """'torch_ops' (default): the towers call torch.ops.marqo_hip.* (PyTorch-ROCm custom ops over the C ABI); 'ctypes': they call
+    the C ABI directly (MARQO_AMD_BOUNDARY=ctypes, non-torch hosts, and whenever MARQO_AMD_LIB points at a diagnostic build, which
+    the ops library is not linked against)."""
+    b = os.environ.get("MARQO_AMD_BOUNDARY", "torch_ops")
+    if b not in ("torch_ops", "ctypes"):
+        raise ValueError(f"MARQO_AMD_BOUNDARY must be 'torch_ops' or 'ctypes', got {b!r}")
+    return "ctypes" if os.environ.get("MARQO_AMD_LIB") else b
+
+
+def load_torch_ops():
+    """Register torch.ops.marqo_hip.* (after libmarqo_hip.so itself, so both resolve to the one mapped copy) and return the namespace.
+    Missing library -> MarqoHipUnavailableError: like the C ABI itself, the custom ops have no fallback."""
+    global _ops
+    if _ops is not None:
+        return _ops
+    load()
+    with _lib_lock:
+        if _ops is not None:
+            return _ops
+        import torch
+        if not TORCH_OPS_PATH.exists():
+            raise MarqoHipUnavailableError(
+                f"{TORCH_OPS_PATH} not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"(or run with MARQO_AMD_BOUNDARY=ctypes to call the C ABI directly).")
+        try:
+            torch.ops.load_library(str(TORCH_OPS_PATH))
+        except OSError as e:
+            raise MarqoHipUnavailableError(f"cannot load {TORCH_OPS_PATH}: {e}") from e
+        ops = torch.ops.marqo_hip
+        if ops.abi_version() != ABI_VERSION:
+            raise MarqoHipUnavailableError(f"ABI version mismatch: torch ops library {ops.abi_version()} != binding {ABI_VERSION}")
+        _ops = ops
+        return _ops
+
+
+def struct_blob(st):
+    """CPU uint8 tensor ALIASING a ctypes struct (zero copy: later edits of the struct — fp8 policy, scales — are seen by the ops):
+    how the POD descriptors of the C ABI travel through torch.ops.marqo_hip.*"""
+    import torch
+    return torch.frombuffer(st, dtype=torch.uint8)
 
 
 def load():

@@ -152,6 +152,7 @@ class ImagePreprocessor:
             raise L.MarqoHipUnavailableError("image preprocessing runs on the GPU only; there is no CPU fallback in marqo_amd")
         self.device = torch.device(device)
         self.lib = L.load()
+        self._ops = L.load_torch_ops() if L.boundary() == "torch_ops" else None
         self.S = int(image_size)
         self.mean = (C.c_float * 3)(*mean)
         self.std = (C.c_float * 3)(*std)
@@ -175,9 +176,13 @@ class ImagePreprocessor:
                 return out
             need = self.lib.mq_clip_resize_workspace_bytes(p.heights.ctypes.data, p.widths.ctypes.data, p.n, self.S)
             ws = self._workspace(need)
-            L.check(self.lib.mq_clip_resize_crop_u8(p.buffer.data_ptr(), p.offsets.ctypes.data, p.heights.ctypes.data,
-                                                    p.widths.ctypes.data, p.n, self.S, out.data_ptr(), ws.data_ptr(), ws.numel(),
-                                                    self._stream()), "mq_clip_resize_crop_u8")
+            if self._ops is not None:   # the PyTorch custom-op face of the same entry point (csrc/torch_ops.cpp)
+                self._ops.clip_resize_crop_u8(p.buffer, torch.from_numpy(p.offsets), torch.from_numpy(p.heights), torch.from_numpy(p.widths),
+                                              self.S, out, ws)
+            else:
+                L.check(self.lib.mq_clip_resize_crop_u8(p.buffer.data_ptr(), p.offsets.ctypes.data, p.heights.ctypes.data,
+                                                        p.widths.ctypes.data, p.n, self.S, out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                        self._stream()), "mq_clip_resize_crop_u8")
             self._keep = p  # the packed source must outlive the enqueued kernels
         return out
 

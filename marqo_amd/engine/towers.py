@@ -413,6 +413,46 @@ class _TowerBase:
         self._lock = threading.Lock()
         self._graphs: Dict[tuple, "_GraphedCall"] = {}
         self._graphs_off = False
+        # The drop-in boundary as north_star words it: the towers' entry points are PyTorch-ROCm custom ops (torch.ops.marqo_hip.*,
+        # csrc/torch_ops.cpp) that forward to the C ABI on PyTorch's current stream; MARQO_AMD_BOUNDARY=ctypes calls the C ABI directly
+        # (what a non-torch host binds).  Same kernels, same arguments either way (tests/test_torch_ops_gpu.py: bit-identical).
+        self._ops = L.load_torch_ops() if L.boundary() == "torch_ops" else None
+        self._blobs = None
+
+    def _desc(self):
+        """(cfg, weights) descriptors as the CPU byte tensors the custom ops take — zero-copy aliases of the ctypes structs"""
+        if self._blobs is None:
+            self._blobs = (L.struct_blob(self.cfg), L.struct_blob(self.w))
+        return self._blobs
+
+    def _call_image(self, kind: str, pixels: Tensor, n: int, out: Tensor, normalize: bool, ws: Tensor) -> None:
+        """mq_encode_image_u8 / _f32 on the current stream of this thread, through the selected boundary"""
+        if self._ops is not None:
+            cfg, w = self._desc()
+            (self._ops.encode_image_u8 if kind == "u8" else self._ops.encode_image_f32)(cfg, w, pixels, out, bool(normalize), ws)
+            return
+        fn = self.lib.mq_encode_image_u8 if kind == "u8" else self.lib.mq_encode_image_f32
+        L.check(fn(C.byref(self.cfg), C.byref(self.w), pixels.data_ptr(), n, out.data_ptr(), 1 if normalize else 0, ws.data_ptr(),
+                   ws.numel(), self._stream()), "mq_encode_image")
+
+    def _call_text(self, clip: bool, d_packed: Tensor, d_cu: Tensor, cu: Tensor, nseq: int, d_pool: Optional[Tensor], out: Tensor,
+                   normalize: bool, ws: Tensor) -> None:
+        """mq_encode_clip_text / mq_encode_bert on the current stream of this thread, through the selected boundary"""
+        if self._ops is not None:
+            cfg, w = self._desc()
+            if clip:
+                self._ops.encode_clip_text(cfg, w, d_packed, d_cu, cu, d_pool, out, bool(normalize), ws)
+            else:
+                self._ops.encode_bert(cfg, w, d_packed, d_cu, cu, out, bool(normalize), ws)
+            return
+        if clip:
+            L.check(self.lib.mq_encode_clip_text(C.byref(self.cfg), C.byref(self.w), d_packed.data_ptr(), d_cu.data_ptr(), cu.data_ptr(), nseq,
+                                                 L.ptr(d_pool), out.data_ptr(), 1 if normalize else 0, ws.data_ptr(), ws.numel(),
+                                                 self._stream()), "mq_encode_clip_text")
+        else:
+            L.check(self.lib.mq_encode_bert(C.byref(self.cfg), C.byref(self.w), d_packed.data_ptr(), d_cu.data_ptr(), cu.data_ptr(), nseq,
+                                            out.data_ptr(), 1 if normalize else 0, ws.data_ptr(), ws.numel(), self._stream()),
+                    "mq_encode_bert")
 
     def _graphs_ok(self) -> bool:
         """single-request calls replay a captured hipGraph (MARQO_AMD_GRAPHS=0 turns that off); an fp8 tower only once its scales are frozen"""
@@ -518,7 +558,8 @@ class VitTower(_TowerBase):
         if precision == "fp8":
             self._enable_fp8(self._blocks, arch.layers, W, _ceil64(arch.mlp_dim))
 
-    def _run(self, fn, pixels: Tensor, normalize: bool) -> Tensor:
+    def _run(self, kind: str, pixels: Tensor, normalize: bool) -> Tensor:
+        fn = self.lib.mq_encode_image_u8 if kind == "u8" else self.lib.mq_encode_image_f32   # (the multi-stream experiment below)
         n = pixels.shape[0]
         if n == 1 and self._graphs_ok():
             with self._lock, torch.cuda.device(self.device):
@@ -527,9 +568,7 @@ class VitTower(_TowerBase):
                     o = torch.empty(1, self.arch.out_dim, dtype=torch.float32, device=self.device)
                     ws = torch.empty(self.lib.mq_vit_workspace_bytes(C.byref(self.cfg), 1) + 256, dtype=torch.uint8, device=self.device)
                     inp.copy_(pixels)
-                    return _GraphedCall(self.device, inp, o, (ws,), lambda: L.check(
-                        fn(C.byref(self.cfg), C.byref(self.w), inp.data_ptr(), 1, o.data_ptr(), 1 if normalize else 0, ws.data_ptr(),
-                           ws.numel(), self._stream()), "mq_encode_image"))
+                    return _GraphedCall(self.device, inp, o, (ws,), lambda: self._call_image(kind, inp, 1, o, normalize, ws))
                 g = self._capture((pixels.dtype, bool(normalize)), make)
                 if g is not None:
                     return g(pixels)
@@ -561,8 +600,7 @@ class VitTower(_TowerBase):
                 m = min(self.max_images_per_call, n - i)
                 need = self.lib.mq_vit_workspace_bytes(C.byref(self.cfg), m)
                 ws = self._workspace(need)
-                L.check(fn(C.byref(self.cfg), C.byref(self.w), pixels[i:i + m].data_ptr(), m, out[i:i + m].data_ptr(),
-                           1 if normalize else 0, ws.data_ptr(), ws.numel(), self._stream()), "mq_encode_image")
+                self._call_image(kind, pixels[i:i + m], m, out[i:i + m], normalize, ws)
         return out
 
     def calibration_images(self, n: int = 16, seed: int = 0) -> Tensor:
@@ -587,7 +625,7 @@ class VitTower(_TowerBase):
         if images_u8.dtype != torch.uint8 or images_u8.ndim != 4 or tuple(images_u8.shape[1:]) != (S, S, 3):
             raise ValueError(f"expected uint8 [n, {S}, {S}, 3], got {images_u8.dtype} {tuple(images_u8.shape)}")
         images_u8 = images_u8.to(self.device, non_blocking=True).contiguous()
-        return self._run(self.lib.mq_encode_image_u8, images_u8, normalize)
+        return self._run("u8", images_u8, normalize)
 
     def encode_f32(self, pixels: Tensor, normalize: bool = True) -> Tensor:
         """preprocessed fp32 [n, 3, S, S] -> fp32 [n, D] on device."""
@@ -595,7 +633,7 @@ class VitTower(_TowerBase):
         if pixels.ndim != 4 or tuple(pixels.shape[1:]) != (3, S, S):
             raise ValueError(f"expected float [n, 3, {S}, {S}], got {tuple(pixels.shape)}")
         pixels = pixels.to(device=self.device, dtype=torch.float32, non_blocking=True).contiguous()
-        return self._run(self.lib.mq_encode_image_f32, pixels, normalize)
+        return self._run("f32", pixels, normalize)
 
 
 def _pack(ids: Tensor, lengths: Tensor) -> Tuple[Tensor, Tensor]:
@@ -641,19 +679,14 @@ class _TextTowerBase(_TowerBase):
                 cu = torch.tensor([0, n_tok], dtype=torch.int32)
                 d_cu = cu.to(self.device)
                 o = torch.empty(1, self.arch.out_dim if clip else self.arch.width, dtype=torch.float32, device=self.device)
-                keep = []
+                keep, d_pool = [], None
                 if clip:
                     ws = torch.empty(self.lib.mq_clip_text_workspace_bytes(C.byref(self.cfg), n_tok, 1) + 256, dtype=torch.uint8, device=self.device)
                     d_pool = torch.tensor([n_tok - 1], dtype=torch.int32).to(self.device)   # the pooled row (last = EOT) is known at capture
                     keep.append(d_pool)
-                    launch = lambda: L.check(self.lib.mq_encode_clip_text(
-                        C.byref(self.cfg), C.byref(self.w), d_packed.data_ptr(), d_cu.data_ptr(), cu.data_ptr(), 1, d_pool.data_ptr(), o.data_ptr(),
-                        1 if normalize else 0, ws.data_ptr(), ws.numel(), self._stream()), "mq_encode_clip_text")
                 else:
                     ws = torch.empty(self.lib.mq_bert_workspace_bytes(C.byref(self.cfg), n_tok, 1) + 256, dtype=torch.uint8, device=self.device)
-                    launch = lambda: L.check(self.lib.mq_encode_bert(
-                        C.byref(self.cfg), C.byref(self.w), d_packed.data_ptr(), d_cu.data_ptr(), cu.data_ptr(), 1, o.data_ptr(),
-                        1 if normalize else 0, ws.data_ptr(), ws.numel(), self._stream()), "mq_encode_bert")
+                launch = lambda: self._call_text(clip, d_packed, d_cu, cu, 1, d_pool, o, normalize, ws)
                 d_packed.copy_(src_ids)
                 return _GraphedCall(self.device, d_packed, o, (cu, d_cu, ws, *keep), launch)
             g = self._capture((n_tok, bool(normalize)), make)
@@ -684,18 +717,8 @@ class _TextTowerBase(_TowerBase):
                 d_cu = self._to_device(cu)
                 d_packed = torch.empty(rows, dtype=torch.int32, device=self.device)
                 L.check(self.lib.mq_pack_ids(d_ids[a:b].data_ptr(), S, d_cu.data_ptr(), nseq, d_packed.data_ptr(), self._stream()), "mq_pack_ids")
-                if clip:
-                    need = self.lib.mq_clip_text_workspace_bytes(C.byref(self.cfg), rows, nseq)
-                    ws = self._workspace(need)
-                    L.check(self.lib.mq_encode_clip_text(C.byref(self.cfg), C.byref(self.w), d_packed.data_ptr(), d_cu.data_ptr(), cu.data_ptr(),
-                                                         nseq, 0, out[a:b].data_ptr(), 1 if normalize else 0, ws.data_ptr(), ws.numel(),
-                                                         self._stream()), "mq_encode_clip_text")
-                else:
-                    need = self.lib.mq_bert_workspace_bytes(C.byref(self.cfg), rows, nseq)
-                    ws = self._workspace(need)
-                    L.check(self.lib.mq_encode_bert(C.byref(self.cfg), C.byref(self.w), d_packed.data_ptr(), d_cu.data_ptr(), cu.data_ptr(), nseq,
-                                                    out[a:b].data_ptr(), 1 if normalize else 0, ws.data_ptr(), ws.numel(), self._stream()),
-                            "mq_encode_bert")
+                need = (self.lib.mq_clip_text_workspace_bytes if clip else self.lib.mq_bert_workspace_bytes)(C.byref(self.cfg), rows, nseq)
+                self._call_text(clip, d_packed, d_cu, cu, nseq, None, out[a:b], normalize, self._workspace(need))
         return out
 
 
@@ -784,11 +807,7 @@ class ClipTextTower(_TextTowerBase):
                 d_pool = self._to_device(pool_rows) if pool_rows is not None else None
                 rows, nseq = packed.numel(), b - a
                 need = self.lib.mq_clip_text_workspace_bytes(C.byref(self.cfg), rows, nseq)
-                ws = self._workspace(need)
-                L.check(self.lib.mq_encode_clip_text(C.byref(self.cfg), C.byref(self.w), d_ids.data_ptr(), d_cu.data_ptr(),
-                                                     cu.data_ptr(), nseq, L.ptr(d_pool), out[a:b].data_ptr(),
-                                                     1 if normalize else 0, ws.data_ptr(), ws.numel(), self._stream()),
-                        "mq_encode_clip_text")
+                self._call_text(True, d_ids, d_cu, cu, nseq, d_pool, out[a:b], normalize, self._workspace(need))
         return out
 
 
@@ -923,10 +942,7 @@ class BertTower(_TextTowerBase):
                 d_cu = self._to_device(cu)
                 rows, nseq = packed.numel(), b - a
                 need = self.lib.mq_bert_workspace_bytes(C.byref(self.cfg), rows, nseq)
-                ws = self._workspace(need)
-                L.check(self.lib.mq_encode_bert(C.byref(self.cfg), C.byref(self.w), d_ids.data_ptr(), d_cu.data_ptr(),
-                                                cu.data_ptr(), nseq, out[a:b].data_ptr(), 1 if normalize else 0,
-                                                ws.data_ptr(), ws.numel(), self._stream()), "mq_encode_bert")
+                self._call_text(False, d_ids, d_cu, cu, nseq, None, out[a:b], normalize, self._workspace(need))
         return out
 
     def encode_device(self, d_ids: Tensor, lengths: Tensor, normalize: bool = True) -> Tensor:

@@ -25,7 +25,13 @@ def _launch(n):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tests", "nccl_worker.py")]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
-    rows = [json.loads(l.split("NCCL_WORKER ", 1)[1]) for l in r.stdout.splitlines() if "NCCL_WORKER " in l]
+    # (two ranks share one stdout: their lines can arrive glued together, so every marker is decoded on its own)
+    rows, dec = [], json.JSONDecoder()
+    for part in r.stdout.split("NCCL_WORKER ")[1:]:
+        try:
+            rows.append(dec.raw_decode(part.lstrip())[0])
+        except json.JSONDecodeError:
+            pass
     return r, rows
 
 
