@@ -294,6 +294,27 @@ int mq_chunk_grid_u8(const uint8_t* d_src, const int64_t* h_src_off, const int32
                      const int32_t* h_widths, int64_t n, int32_t hn, int32_t wn, int32_t overlap, int32_t S,
                      uint8_t* d_out, float* h_boxes, void* d_workspace, size_t workspace_bytes, void* stream);
 
+/* Resize by the source image's MODE, as Pillow itself resizes it.  The reference's transform calls PIL's Image.resize on whatever mode
+ * the decoder produced and converts to RGB only afterwards (src/marqo/s2_inference/clip_utils.py:61-64; open_clip image_transform,
+ * open_clip_model.py:84-97), and Image.resize is mode dependent:
+ *   MQ_IMG_RGB      uint8 [h, w, 3]: the given filter (2 = Image.BILINEAR, 3 = Image.BICUBIC) — what mq_clip_resize_crop_u8 /
+ *                   mq_resize_filter_u8 do; also right for "L" images replicated to RGB by the caller (the filter is per band);
+ *   MQ_IMG_NEAREST  uint8 [h, w, 3] converted from a palette ("P") or bilevel ("1") image: Pillow forces NEAREST for these modes
+ *                   (nearest sampling commutes with the palette lookup, so the caller converts first);
+ *   MQ_IMG_RGBA     uint8 [h, w, 4] (RGBA; LA expanded to RGBA by the caller), images 4-byte aligned: premultiply by alpha, resample
+ *                   all four bands, un-premultiply (Pillow's "RGBa" round trip), alpha dropped = the transform's .convert("RGB").
+ *                   An image that needs no resize at all passes its colour bytes through untouched, as in the reference.
+ * crop != 0: Resize(out_h) on the shorter side + CenterCrop(out_h) (the CLIP transform; out_w == out_h); crop == 0: plain
+ * Image.resize((out_w, out_h)).  d_out uint8 [n, out_h, out_w, 3] in every mode; bit-identical to Pillow. */
+#define MQ_IMG_RGB 0
+#define MQ_IMG_NEAREST 1
+#define MQ_IMG_RGBA 2
+size_t mq_resize_mode_workspace_bytes(const int32_t* h_heights, const int32_t* h_widths, int64_t n, int32_t out_h, int32_t out_w,
+                                      int32_t filter, int32_t crop, int32_t mode);
+int mq_resize_mode_u8(const uint8_t* d_src, const int64_t* h_src_off, const int32_t* h_heights, const int32_t* h_widths, int64_t n,
+                      int32_t out_h, int32_t out_w, int32_t filter, int32_t crop, int32_t mode, uint8_t* d_out,
+                      void* d_workspace, size_t workspace_bytes, void* stream);
+
 /* Decoded Pillow images hold 4 bytes per pixel (R, G, B, pad: Imaging "RGB" storage); the loaders stage those bytes as they are (a
  * zero-copy view through Pillow's Arrow export instead of PIL's 4 -> 3 byte repack on the host, which is what Image.tobytes /
  * np.asarray — and torchvision's ToTensor in the reference, clip_utils.py:65 — spend their time on) and repack on the device.

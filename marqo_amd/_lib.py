@@ -34,6 +34,7 @@ MQ_VIT_POOL_CLS, MQ_VIT_POOL_MAP = 0, 1
 MQ_EPI_BIAS, MQ_EPI_GELU, MQ_EPI_QUICKGELU, MQ_EPI_RESIDUAL, MQ_EPI_OUT_F32, MQ_EPI_OUT_FP8 = 1, 2, 4, 8, 16, 32
 MQ_EPI_LN_STATS, MQ_EPI_LN_APPLY = 64, 128
 MQ_COMBINE_RAW, MQ_COMBINE_NORMALIZE, MQ_COMBINE_NORMALIZE_IF_NONZERO = 0, 1, 2
+MQ_IMG_RGB, MQ_IMG_NEAREST, MQ_IMG_RGBA = 0, 1, 2
 MQ_PROF_FAMILIES = 6
 PROF_FAMILY_NAMES = ("gemm", "layernorm", "attention", "embed", "pool_head", "preprocess")
 
@@ -158,6 +159,8 @@ _SIGNATURES = {
     "mq_resize_u8": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int32, _P, _P, C.c_size_t, _P]),
     "mq_resize_filter_workspace_bytes": (C.c_size_t, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
     "mq_resize_filter_u8": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.c_size_t, _P]),
+    "mq_resize_mode_workspace_bytes": (C.c_size_t, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "mq_resize_mode_u8": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.c_size_t, _P]),
     "mq_chunk_grid_count": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
     "mq_chunk_grid_workspace_bytes": (C.c_size_t, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "mq_chunk_grid_u8": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P,

@@ -42,10 +42,11 @@ double bilinear_filter(double x) {
     return x < 1.0 ? 1.0 - x : 0.0;
 }
 
-constexpr int FILTER_BILINEAR = 2, FILTER_BICUBIC = 3;  // Pillow's Image.BILINEAR / Image.BICUBIC
+constexpr int FILTER_NEAREST = 0, FILTER_BILINEAR = 2, FILTER_BICUBIC = 3;  // Pillow's Image.NEAREST / BILINEAR / BICUBIC
 double filter_support(int filter) { return filter == FILTER_BILINEAR ? 1.0 : 2.0; }
 
 int coeff_ksize(int in_size, int out_size, int filter = FILTER_BICUBIC) {
+    if (filter == FILTER_NEAREST) return 1;
     double filterscale = (double)((float)in_size - 0.0f) / out_size;
     if (filterscale < 1.0) filterscale = 1.0;
     return (int)ceil(filter_support(filter) * filterscale) * 2 + 1;
@@ -54,6 +55,26 @@ int coeff_ksize(int in_size, int out_size, int filter = FILTER_BICUBIC) {
 // Pillow precompute_coeffs + normalize_coeffs_8bpc for output positions [first, first+count).
 // bounds: (xmin, n) pairs; kk: [count][ksize]
 void compute_coeffs(int in_size, int out_size, int first, int count, int ksize, int32_t* bounds, int32_t* kk, int filter = FILTER_BICUBIC) {
+    if (filter == FILTER_NEAREST) {
+        // Image.resize(..., NEAREST) — what Pillow runs for palette ("P") and bilevel ("1") images WHATEVER filter the caller asked
+        // for (Image.resize: `if self.mode in ("1", "P"): resample = NEAREST`): _imaging.c::_resize builds the affine
+        // a0 = in / out and Geometry.c::ImagingScaleAffine tabulates xin = COORD(xo), xo starting at a0 * 0.5 and advanced by
+        // REPEATED ADDITION of a0 (so the table is reproduced with the same accumulation, not with a product).  As a one-tap
+        // "filter" of weight 1.0 it runs through the same two integer passes: clip8(2^21 + p * 2^22) == p.
+        const double a0 = (double)in_size / out_size;
+        double xo = a0 * 0.5;
+        for (int xx = 0; xx < first + count; ++xx) {
+            if (xx >= first) {
+                int xin = xo < 0.0 ? 0 : (int)xo;
+                if (xin > in_size - 1) xin = in_size - 1;
+                bounds[2 * (xx - first)] = xin;
+                bounds[2 * (xx - first) + 1] = 1;
+                kk[(size_t)(xx - first) * ksize] = 1 << PRECISION_BITS;
+            }
+            xo += a0;
+        }
+        return;
+    }
     const float in0 = 0.0f, in1 = (float)in_size;
     double scale, filterscale;
     filterscale = scale = (double)(in1 - in0) / out_size;
@@ -110,20 +131,50 @@ __device__ __forceinline__ uint8_t clip8(int v) {
     return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
 }
 
+// Pillow's premultiplied-alpha round trip around the resize of RGBA / LA images (Image.resize converts RGBA -> "RGBa", resamples all four
+// bands, converts back; Convert.c): premultiply = MULDIV255(c, a), un-premultiply = c if a is 0 or 255 else CLIP8(255 * c / a).
+__device__ __forceinline__ uint32_t premultiply_rgba(uint32_t px) {
+    const uint32_t a = px >> 24;
+    uint32_t out = px & 0xff000000u;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const uint32_t t = ((px >> (8 * c)) & 0xffu) * a + 128u;
+        out |= (((t >> 8) + t) >> 8) << (8 * c);
+    }
+    return out;
+}
+__device__ __forceinline__ uint8_t unpremultiply(int c, int a) {
+    if (a == 255 || a == 0) return (uint8_t)c;
+    const int v = (255 * c) / a;
+    return (uint8_t)(v > 255 ? 255 : v);
+}
+
 // ---- horizontal pass: tmp[r][x][c], r in [0, rows), x in [0, out_w) ---------------------------------
+// C = bytes per pixel: 3 (RGB) or 4 (RGBA sources: premultiplied while the row is staged in LDS, all four bands resampled)
+template <int C>
 __global__ __launch_bounds__(256) void resample_h_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ tmp,
                                                         const Job* __restrict__ jobs, const int32_t* __restrict__ coeffs) {
     extern __shared__ __attribute__((aligned(16))) uint8_t srow[];
     const Job j = jobs[blockIdx.y];
     const int r = blockIdx.x;
     if (r >= j.rows) return;
-    const uint8_t* in = src + j.src_off + (int64_t)(j.row0 + r) * j.src_stride + (int64_t)j.col0 * 3;
-    const int nbytes = j.cols * 3;
-    for (int i = threadIdx.x; i < nbytes; i += 256) srow[i] = in[i];
+    const uint8_t* in = src + j.src_off + (int64_t)(j.row0 + r) * j.src_stride + (int64_t)j.col0 * C;
+    if (C == 4) {  // (rows are 4-byte aligned: images start on 256-byte boundaries and a row is 4 * w bytes)
+        // an image that is not resized at all (both axes identity: torchvision's Resize returns it untouched, Image.resize copies) never
+        // takes the premultiplied round trip, which is lossy — its colour bytes pass through as they are
+        const bool raw = j.hb < 0 && j.vb < 0;
+        for (int i = threadIdx.x; i < j.cols; i += 256) {
+            const uint32_t px = ((const uint32_t*)in)[i];
+            ((uint32_t*)srow)[i] = raw ? px : premultiply_rgba(px);
+        }
+    } else {
+        const int nbytes = j.cols * C;
+        for (int i = threadIdx.x; i < nbytes; i += 256) srow[i] = in[i];
+    }
     __syncthreads();
-    uint8_t* out = tmp + j.tmp_off + (int64_t)r * j.out_w * 3;
+    uint8_t* out = tmp + j.tmp_off + (int64_t)r * j.out_w * C;
     if (j.hb < 0) {  // identity axis: plain crop copy
-        for (int i = threadIdx.x; i < j.out_w * 3; i += 256) out[i] = srow[i];
+        for (int i = threadIdx.x; i < j.out_w * C; i += 256) out[i] = srow[i];
         return;
     }
     const int32_t* bounds = coeffs + j.hb;
@@ -131,29 +182,59 @@ __global__ __launch_bounds__(256) void resample_h_kernel(const uint8_t* __restri
     for (int x = threadIdx.x; x < j.out_w; x += 256) {
         const int xmin = bounds[2 * x] - j.col0, n = bounds[2 * x + 1];
         const int32_t* k = kk + (int64_t)x * j.ksize_h;
-        int s0 = 1 << (PRECISION_BITS - 1), s1 = s0, s2 = s0;
-        const uint8_t* p = srow + xmin * 3;
+        int s[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) s[c] = 1 << (PRECISION_BITS - 1);
+        const uint8_t* p = srow + xmin * C;
         for (int t = 0; t < n; ++t) {
             const int w = k[t];
-            s0 += (int)p[3 * t] * w;
-            s1 += (int)p[3 * t + 1] * w;
-            s2 += (int)p[3 * t + 2] * w;
+#pragma unroll
+            for (int c = 0; c < C; ++c) s[c] += (int)p[C * t + c] * w;
         }
-        out[3 * x] = clip8(s0);
-        out[3 * x + 1] = clip8(s1);
-        out[3 * x + 2] = clip8(s2);
+#pragma unroll
+        for (int c = 0; c < C; ++c) out[C * x + c] = clip8(s[c]);
     }
 }
 
 // ---- vertical pass: dst[y][x*3+c] -------------------------------------------------------------------------
+// C = 3: a thread owns a byte column.  C = 4: a thread owns a pixel (it needs the pixel's resampled alpha to un-premultiply) and writes
+// its three colour bytes — the `.convert("RGB")` that follows in the reference's transform only drops the alpha band.
+template <int C>
 __global__ __launch_bounds__(256) void resample_v_kernel(const uint8_t* __restrict__ tmp, uint8_t* __restrict__ dst,
                                                         const Job* __restrict__ jobs, const int32_t* __restrict__ coeffs) {
     const Job j = jobs[blockIdx.y];
     const int y = blockIdx.x;
     if (y >= j.out_h) return;
-    const int rowbytes = j.out_w * 3;
+    const int rowbytes = j.out_w * C;
     const uint8_t* in = tmp + j.tmp_off;
     uint8_t* out = dst + j.dst_off + (int64_t)y * j.dst_stride;
+    if (C == 4) {
+        const bool ident = j.vb < 0;
+        const int ymin = ident ? y : (coeffs + j.vb)[2 * y] - j.row0, n = ident ? 1 : (coeffs + j.vb)[2 * y + 1];
+        const int32_t* k = ident ? nullptr : coeffs + j.vk + (int64_t)y * j.ksize_v;
+        for (int x = threadIdx.x; x < j.out_w; x += 256) {
+            const uint8_t* p = in + (int64_t)ymin * rowbytes + x * 4;
+            int v[4];
+            if (ident) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = p[c];
+            } else {
+                int s[4] = {1 << (PRECISION_BITS - 1), 1 << (PRECISION_BITS - 1), 1 << (PRECISION_BITS - 1), 1 << (PRECISION_BITS - 1)};
+                for (int t = 0; t < n; ++t) {
+                    const uint32_t q = *(const uint32_t*)(p + (int64_t)t * rowbytes);
+                    const int w = k[t];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) s[c] += (int)((q >> (8 * c)) & 0xffu) * w;
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = clip8(s[c]);
+            }
+            const int a = (j.hb < 0 && j.vb < 0) ? 255 : v[3];   // (un-resized image: colour bytes as they are, see the H pass)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) out[3 * x + c] = unpremultiply(v[c], a);
+        }
+        return;
+    }
     if (j.vb < 0) {
         const uint8_t* p = in + (int64_t)y * rowbytes;  // rows were already restricted to the crop
         for (int i = threadIdx.x; i < rowbytes; i += 256) out[i] = p[i];
@@ -190,6 +271,7 @@ struct Plan {
     size_t tmp_bytes = 0;
     int max_rows = 0, max_out_h = 0, max_cols = 0;
     int filter = FILTER_BICUBIC;
+    int ch = 3;   // source bytes per pixel: 3 (RGB), 4 (RGBA: premultiplied resize of all four bands, RGB written)
 
     // add a job: source sub-image (in_h x in_w) resized to (rs_h x rs_w), keep [top, top+out_h) x [left, left+out_w)
     void add(int64_t src_off, int src_stride, int in_h, int in_w, int rs_h, int rs_w, int top, int left, int out_h, int out_w,
@@ -231,7 +313,7 @@ struct Plan {
             j.v_first = top; j.row0 = lo; j.rows = hi - lo;
         }
         j.tmp_off = (int64_t)tmp_bytes;
-        tmp_bytes = align_up(tmp_bytes + (size_t)j.rows * out_w * 3, 256);
+        tmp_bytes = align_up(tmp_bytes + (size_t)j.rows * out_w * ch, 256);
         if (j.rows > max_rows) max_rows = j.rows;
         if (j.out_h > max_out_h) max_out_h = j.out_h;
         if (j.cols > max_cols) max_cols = j.cols;
@@ -247,7 +329,7 @@ constexpr int MAX_LDS_ROW = 150 * 1024;
 int run_plan(const Plan& p, const uint8_t* d_src, uint8_t* d_dst, void* ws, size_t ws_bytes, hipStream_t s, const char* who) {
     if (p.jobs.empty()) return MQ_OK;
     if (ws_bytes < p.total_bytes()) { mq_set_error("%s: workspace %zu < required %zu", who, ws_bytes, p.total_bytes()); return MQ_ERR_WORKSPACE; }
-    MQ_CHECK_ARG(p.max_cols * 3 <= MAX_LDS_ROW, "%s: source row span of %d pixels does not fit in LDS (max %d)", who, p.max_cols, MAX_LDS_ROW / 3);
+    MQ_CHECK_ARG(p.max_cols * p.ch <= MAX_LDS_ROW, "%s: source row span of %d pixels does not fit in LDS (max %d)", who, p.max_cols, MAX_LDS_ROW / p.ch);
     char* base = (char*)ws;
     Job* d_jobs = (Job*)base;
     int32_t* d_coeffs = (int32_t*)(base + align_up(p.jobs.size() * sizeof(Job), 256));
@@ -259,9 +341,10 @@ int run_plan(const Plan& p, const uint8_t* d_src, uint8_t* d_dst, void* ws, size
         return MQ_ERR_HIP;
     }
     MqProfScope prof(5, s);
-    const size_t lds = align_up((size_t)p.max_cols * 3, 16);
+    const size_t lds = align_up((size_t)p.max_cols * p.ch, 16);
+    const void* hk = p.ch == 4 ? (const void*)resample_h_kernel<4> : (const void*)resample_h_kernel<3>;
     if (lds > 64 * 1024) {
-        if (hipFuncSetAttribute((const void*)resample_h_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        if (hipFuncSetAttribute(hk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             mq_set_error("%s: hipFuncSetAttribute failed", who);
             return MQ_ERR_HIP;
         }
@@ -269,8 +352,13 @@ int run_plan(const Plan& p, const uint8_t* d_src, uint8_t* d_dst, void* ws, size
     const size_t nj = p.jobs.size();
     for (size_t j0 = 0; j0 < nj; j0 += 65535) {  // gridDim.y limit
         const unsigned cnt = (unsigned)(nj - j0 < 65535 ? nj - j0 : 65535);
-        hipLaunchKernelGGL(resample_h_kernel, dim3((unsigned)p.max_rows, cnt), dim3(256), lds, s, d_src, d_tmp, d_jobs + j0, d_coeffs);
-        hipLaunchKernelGGL(resample_v_kernel, dim3((unsigned)p.max_out_h, cnt), dim3(256), 0, s, d_tmp, d_dst, d_jobs + j0, d_coeffs);
+        if (p.ch == 4) {
+            hipLaunchKernelGGL(resample_h_kernel<4>, dim3((unsigned)p.max_rows, cnt), dim3(256), lds, s, d_src, d_tmp, d_jobs + j0, d_coeffs);
+            hipLaunchKernelGGL(resample_v_kernel<4>, dim3((unsigned)p.max_out_h, cnt), dim3(256), 0, s, d_tmp, d_dst, d_jobs + j0, d_coeffs);
+        } else {
+            hipLaunchKernelGGL(resample_h_kernel<3>, dim3((unsigned)p.max_rows, cnt), dim3(256), lds, s, d_src, d_tmp, d_jobs + j0, d_coeffs);
+            hipLaunchKernelGGL(resample_v_kernel<3>, dim3((unsigned)p.max_out_h, cnt), dim3(256), 0, s, d_tmp, d_dst, d_jobs + j0, d_coeffs);
+        }
     }
     MQ_CHECK_LAUNCH(who);
     return MQ_OK;
@@ -407,6 +495,54 @@ extern "C" int mq_resize_filter_u8(const uint8_t* d_src, const int64_t* h_src_of
     for (int64_t i = 0; i < n; ++i)
         p.add(h_src_off[i], h_widths[i] * 3, h_heights[i], h_widths[i], out_h, out_w, 0, 0, out_h, out_w, i * (int64_t)out_h * out_w * 3, out_w * 3);
     return run_plan(p, d_src, d_out, d_workspace, workspace_bytes, (hipStream_t)stream, "mq_resize_filter_u8");
+}
+
+// Resize by source image MODE, as Pillow itself resizes (the reference's transform calls Image.resize on whatever mode the decoder
+// produced and converts to RGB afterwards: clip_utils.py:61-64, open_clip image_transform):
+//   MQ_IMG_RGB (0):     uint8 [h, w, 3], the given filter (2 = bilinear, 3 = bicubic)
+//   MQ_IMG_NEAREST (1): uint8 [h, w, 3] that came out of a palette ("P") or bilevel ("1") image: Pillow forces NEAREST for these modes,
+//                       and nearest sampling commutes with the palette lookup, so the caller converts to RGB first
+//   MQ_IMG_RGBA (2):    uint8 [h, w, 4] (RGBA; LA expanded by the caller): premultiply, resample all four bands, un-premultiply; RGB out
+// crop != 0: the CLIP transform, Resize(out_h) on the shorter side + CenterCrop(out_h) (out_w must equal out_h); crop == 0: plain
+// Image.resize((out_w, out_h)) ("squash").  d_out is uint8 [n, out_h, out_w, 3] in every mode.
+namespace {
+int mode_plan(Plan& p, const char* who, const int64_t* off, const int32_t* hs, const int32_t* ws, int64_t n, int out_h, int out_w, int filter,
+              int crop, int mode) {
+    MQ_CHECK_ARG(out_h >= 1 && out_w >= 1 && (!crop || out_h == out_w), "%s: bad output size %dx%d (crop needs a square)", who, out_h, out_w);
+    MQ_CHECK_ARG(filter == FILTER_BILINEAR || filter == FILTER_BICUBIC, "%s: filter %d (2 = bilinear, 3 = bicubic)", who, filter);
+    MQ_CHECK_ARG(mode >= 0 && mode <= 2, "%s: mode %d (0 = RGB, 1 = palette / bilevel source, 2 = RGBA)", who, mode);
+    p.filter = mode == 1 ? FILTER_NEAREST : filter;
+    p.ch = mode == 2 ? 4 : 3;
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t so = off ? off[i] : 0, dof = off ? i * (int64_t)out_h * out_w * 3 : 0;
+        if (crop) add_clip_job(p, so, ws[i] * p.ch, hs[i], ws[i], out_h, dof);
+        else p.add(so, ws[i] * p.ch, hs[i], ws[i], out_h, out_w, 0, 0, out_h, out_w, dof, out_w * 3);
+    }
+    return MQ_OK;
+}
+}  // namespace
+
+extern "C" size_t mq_resize_mode_workspace_bytes(const int32_t* h_heights, const int32_t* h_widths, int64_t n, int32_t out_h, int32_t out_w,
+                                                 int32_t filter, int32_t crop, int32_t mode) {
+    if (!h_heights || !h_widths || n <= 0) return 0;
+    for (int64_t i = 0; i < n; ++i)
+        if (h_heights[i] < 1 || h_widths[i] < 1) return 0;
+    Plan p;
+    if (mode_plan(p, "mq_resize_mode_workspace_bytes", nullptr, h_heights, h_widths, n, out_h, out_w, filter, crop, mode) != MQ_OK) return 0;
+    return p.total_bytes();
+}
+
+extern "C" int mq_resize_mode_u8(const uint8_t* d_src, const int64_t* h_src_off, const int32_t* h_heights, const int32_t* h_widths, int64_t n,
+                                 int32_t out_h, int32_t out_w, int32_t filter, int32_t crop, int32_t mode, uint8_t* d_out, void* d_workspace,
+                                 size_t workspace_bytes, void* stream) {
+    if (n <= 0) return MQ_OK;
+    MQ_CHECK_ARG(d_src && d_out && d_workspace, "mq_resize_mode_u8: null pointer");
+    MQ_TRY(check_images("mq_resize_mode_u8", h_src_off, h_heights, h_widths, n));
+    if (mode == 2)
+        for (int64_t i = 0; i < n; ++i) MQ_CHECK_ARG(h_src_off[i] % 4 == 0, "mq_resize_mode_u8: RGBA image %ld must start on a 4-byte boundary", (long)i);
+    Plan p;
+    MQ_TRY(mode_plan(p, "mq_resize_mode_u8", h_src_off, h_heights, h_widths, n, out_h, out_w, filter, crop, mode));
+    return run_plan(p, d_src, d_out, d_workspace, workspace_bytes, (hipStream_t)stream, "mq_resize_mode_u8");
 }
 
 extern "C" int mq_chunk_grid_count(int32_t hn, int32_t wn, int32_t overlap) {

@@ -22,7 +22,7 @@ try:  # Pillow >= 11.3 exports its image memory through the Arrow C interface; p
 except Exception:  # pragma: no cover
     _arrow = None
 
-ArrayLike = Union[np.ndarray, torch.Tensor, "Rgbx"]
+ArrayLike = Union[np.ndarray, torch.Tensor, "Rgbx", "Rgba", "NearestRgb"]
 
 
 PACK_THREADS = int(os.environ.get("MARQO_AMD_PACK_THREADS", str(max(1, min(8, (os.cpu_count() or 2) // 2)))))   # memcpy threads of a pack
@@ -39,8 +39,49 @@ class Rgbx:
         self.shape = (view.shape[0], view.shape[1], 3)
 
 
+class Rgba:
+    """Pixels of an RGBA / LA image with real transparency: uint8 [H, W, 4].  The reference's transform resizes such an image in its OWN
+    mode — Pillow premultiplies by alpha, resamples all four bands and un-premultiplies — and only then drops the alpha band
+    (`.convert("RGB")`, clip_utils.py:61-64): flattening first gives different colours wherever alpha < 255.  `shape` is the logical (H, W, 3)."""
+    __slots__ = ("array", "shape")
+
+    def __init__(self, array: np.ndarray) -> None:
+        self.array = np.ascontiguousarray(array)
+        self.shape = (array.shape[0], array.shape[1], 3)
+
+
+class NearestRgb:
+    """RGB pixels (uint8 [H, W, 3]) of a palette ("P") or bilevel ("1") image: Pillow resizes those modes with NEAREST whatever filter the
+    transform asks for (Image.resize), and nearest sampling commutes with the palette lookup, so the lookup is done first."""
+    __slots__ = ("array", "shape")
+
+    def __init__(self, array: np.ndarray) -> None:
+        self.array = np.ascontiguousarray(array)
+        self.shape = tuple(array.shape)
+
+
+def flatten_pixels(px):
+    """any pixel container -> something the 3-channel RGB paths take (chunk grids; the alpha band is dropped as `.convert("RGB")` does)"""
+    if isinstance(px, Rgba):
+        return np.ascontiguousarray(px.array[..., :3])
+    if isinstance(px, NearestRgb):
+        return px.array
+    return px
+
+
 def pil_pixels(img):
-    """PIL image (mode RGB) -> Rgbx view when this Pillow / pyarrow pair exports one, else uint8 [H, W, 3] via np.asarray"""
+    """PIL image -> the pixel container the GPU preprocessing packs, by MODE, so that the device resize follows what Pillow does for
+    that mode: RGB -> Rgbx view (when this Pillow / pyarrow pair exports one) or uint8 [H, W, 3]; RGBA / LA with transparency -> Rgba;
+    P / 1 -> NearestRgb; every other mode (L, CMYK, I, F, ...) -> uint8 [H, W, 3] via convert("RGB") — exact for L (the filter is per
+    band), flatten-first for the rest."""
+    mode = img.mode
+    if mode in ("RGBA", "LA"):
+        a = np.asarray(img if mode == "RGBA" else img.convert("RGBA"))
+        if a.size and int(a[..., 3].min()) == 255:   # opaque: the premultiplied round trip is the identity, take the RGB path
+            return np.ascontiguousarray(a[..., :3])
+        return Rgba(a)
+    if mode in ("P", "1"):
+        return NearestRgb(np.asarray(img.convert("RGB")))
     if _arrow is not None and img.mode == "RGB" and hasattr(img, "__arrow_c_array__") and img.width > 0 and img.height > 0:
         try:
             flat = _arrow.array(img).flatten().to_numpy(zero_copy_only=True)
@@ -51,16 +92,21 @@ def pil_pixels(img):
     return np.asarray(img if img.mode == "RGB" else img.convert("RGB"))
 
 
-def _as_u8_hwc(img):
+def _as_u8_hwc(img, channels: int = 3):
     if isinstance(img, Rgbx):
         return img
     if isinstance(img, np.ndarray):
-        if img.dtype != np.uint8 or img.ndim != 3 or img.shape[2] != 3:
-            raise ValueError(f"expected a uint8 [H, W, 3] RGB image, got {img.dtype} {tuple(img.shape)}")
+        if img.dtype != np.uint8 or img.ndim != 3 or img.shape[2] != channels:
+            raise ValueError(f"expected a uint8 [H, W, {channels}] image, got {img.dtype} {tuple(img.shape)}")
         return img
-    if img.dtype != torch.uint8 or img.ndim != 3 or img.shape[2] != 3:
-        raise ValueError(f"expected a uint8 [H, W, 3] RGB image, got {img.dtype} {tuple(img.shape)}")
+    if img.dtype != torch.uint8 or img.ndim != 3 or img.shape[2] != channels:
+        raise ValueError(f"expected a uint8 [H, W, {channels}] image, got {img.dtype} {tuple(img.shape)}")
     return img.contiguous()
+
+
+def _kind(img) -> int:
+    """MQ_IMG_* mode of a pixel container (include/marqo_hip.h)"""
+    return L.MQ_IMG_RGBA if isinstance(img, Rgba) else L.MQ_IMG_NEAREST if isinstance(img, NearestRgb) else L.MQ_IMG_RGB
 
 
 def _align256(v):
@@ -73,13 +119,13 @@ class PackedImages:
     Host images are copied once, into a pinned staging buffer, by a few memcpy threads inside one C call, then cross PCIe in ONE
     asynchronous transfer; Pillow images travel as their in-memory RGBX bytes and are repacked to RGB by mq_unpack_rgbx."""
 
-    def __init__(self, images: Sequence[ArrayLike], device: torch.device):
-        imgs = [_as_u8_hwc(i) for i in images]
+    def __init__(self, images: Sequence[ArrayLike], device: torch.device, channels: int = 3):
+        imgs = [_as_u8_hwc(i, channels) for i in images]   # channels = 4: RGBA sources of mq_resize_mode_u8 (no Rgbx views among them)
         self.n = len(imgs)
         self.heights = np.asarray([i.shape[0] for i in imgs], dtype=np.int32)
         self.widths = np.asarray([i.shape[1] for i in imgs], dtype=np.int32)
         npix = self.heights.astype(np.int64) * self.widths.astype(np.int64)
-        sizes = npix * 3
+        sizes = npix * channels
         padded = _align256(sizes)
         self.offsets = np.zeros(self.n, dtype=np.int64)
         if self.n > 1:
@@ -167,8 +213,36 @@ class ImagePreprocessor:
     def _stream(self) -> int:
         return torch.cuda.current_stream(self.device).cuda_stream
 
+    def _resize_by_mode(self, images: Sequence, out_h: int, out_w: int, filt: int, crop: bool) -> torch.Tensor:
+        """a batch that holds palette / bilevel or translucent RGBA sources: every mode group goes through the call that resizes it as
+        Pillow resizes that mode (mq_resize_mode_u8) and lands at its request positions"""
+        kinds = [_kind(i) for i in images]
+        with torch.cuda.device(self.device):
+            out = torch.empty(len(images), out_h, out_w, 3, dtype=torch.uint8, device=self.device)
+            keep = []
+            for mode in sorted(set(kinds)):
+                idx = [k for k, m in enumerate(kinds) if m == mode]
+                group = [images[k] if mode == L.MQ_IMG_RGB else images[k].array for k in idx]
+                p = PackedImages(group, self.device, channels=4 if mode == L.MQ_IMG_RGBA else 3)
+                sub = out if len(idx) == len(images) else torch.empty(len(idx), out_h, out_w, 3, dtype=torch.uint8, device=self.device)
+                need = self.lib.mq_resize_mode_workspace_bytes(p.heights.ctypes.data, p.widths.ctypes.data, p.n, out_h, out_w, filt,
+                                                               1 if crop else 0, mode)
+                # (one scratch buffer per group: the groups' kernels are all in flight on this stream before the first one has run)
+                ws = torch.empty(int(need) + 256, dtype=torch.uint8, device=self.device)
+                L.check(self.lib.mq_resize_mode_u8(p.buffer.data_ptr(), p.offsets.ctypes.data, p.heights.ctypes.data, p.widths.ctypes.data,
+                                                   p.n, out_h, out_w, filt, 1 if crop else 0, mode, sub.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                   self._stream()), "mq_resize_mode_u8")
+                if sub is not out:
+                    out.index_copy_(0, torch.as_tensor(idx, dtype=torch.int64).to(self.device, non_blocking=True), sub)
+                keep.append((p, ws, sub))
+            self._keep = keep   # sources / scratch must outlive the enqueued kernels
+        return out
+
     def resize_crop_u8(self, images: Sequence[ArrayLike]) -> torch.Tensor:
-        """Resize(S, bicubic) + CenterCrop(S): list of uint8 [H_i, W_i, 3] -> uint8 [n, S, S, 3] on device."""
+        """Resize(S, bicubic) + CenterCrop(S): list of uint8 [H_i, W_i, 3] (or pixel containers of other image modes, pil_pixels)
+        -> uint8 [n, S, S, 3] on device."""
+        if any(isinstance(i, (Rgba, NearestRgb)) for i in images):
+            return self._resize_by_mode(images, self.S, self.S, 3, crop=True)
         with torch.cuda.device(self.device):
             p = PackedImages(images, self.device)
             out = torch.empty(p.n, self.S, self.S, 3, dtype=torch.uint8, device=self.device)
@@ -189,6 +263,8 @@ class ImagePreprocessor:
     def resize_u8(self, images: Sequence[ArrayLike], out_h: int, out_w: int, interpolation: str = "bicubic") -> torch.Tensor:
         """PIL.Image.resize((out_w, out_h), BICUBIC | BILINEAR) of every image -> uint8 [n, out_h, out_w, 3] on device."""
         filt = {"bicubic": 3, "bilinear": 2}[interpolation]   # Pillow's Image.BICUBIC / Image.BILINEAR
+        if any(isinstance(i, (Rgba, NearestRgb)) for i in images):
+            return self._resize_by_mode(images, out_h, out_w, filt, crop=False)
         with torch.cuda.device(self.device):
             p = PackedImages(images, self.device)
             out = torch.empty(p.n, out_h, out_w, 3, dtype=torch.uint8, device=self.device)
@@ -208,6 +284,7 @@ class ImagePreprocessor:
         count = self.lib.mq_chunk_grid_count(hn, wn, 1 if overlap else 0)
         if count <= 0:
             raise ValueError(f"bad chunk grid hn={hn} wn={wn}")
+        images = [flatten_pixels(i) for i in images]   # (the chunker keeps the flatten-first treatment of palette / translucent sources)
         with torch.cuda.device(self.device):
             p = PackedImages(images, self.device)
             out = torch.empty(p.n * count, self.S, self.S, 3, dtype=torch.uint8, device=self.device)

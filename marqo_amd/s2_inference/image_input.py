@@ -108,18 +108,18 @@ def format_and_load_CLIP_images(images: List, image_download_headers: dict) -> L
 
 
 def pil_to_pixels(img: ImageType):
-    """PIL image -> what the GPU preprocessing packs: a zero-copy RGBX view of Pillow's own memory where this Pillow exports one
-    (engine/preprocess.py: Rgbx, repacked to RGB on the device), else uint8 [H, W, 3] like pil_to_rgb_u8.  Same mode handling."""
+    """PIL image -> what the GPU preprocessing packs, by image mode (engine/preprocess.py::pil_pixels): RGB images as a zero-copy RGBX
+    view of Pillow's own memory where this Pillow exports one (repacked to RGB on the device) or uint8 [H, W, 3]; translucent RGBA / LA
+    images and palette / bilevel images in containers that make the device resize them the way Pillow resizes those modes (the
+    reference converts to RGB AFTER Resize / CenterCrop, clip_utils.py:61-64)."""
     from marqo_amd.engine.preprocess import pil_pixels
-    if img.mode != "RGB":
-        img = img.convert("RGB")
     return pil_pixels(img)
 
 
 def pil_to_rgb_u8(img: ImageType) -> np.ndarray:
-    """PIL image -> uint8 [H, W, 3].  The reference converts to RGB AFTER Resize/CenterCrop (clip_utils.py:61-64);
-    for RGB and L inputs the order is immaterial.  Modes with alpha / palettes are flattened to RGB here before the
-    GPU resize (the reference would resize RGBA premultiplied) — documented deviation for translucent images."""
+    """PIL image -> uint8 [H, W, 3], flattened to RGB up front (chunk grids, callers that want plain arrays).  The reference converts to
+    RGB AFTER Resize / CenterCrop (clip_utils.py:61-64); for RGB and L inputs the order is immaterial, for translucent or palette
+    images use pil_to_pixels, which keeps the mode-dependent resize."""
     if img.mode != "RGB":
         img = img.convert("RGB")
     return np.asarray(img)

@@ -105,6 +105,28 @@ def clip_resize_crop_u8(img: np.ndarray, n_px: int = 224, backend: str = "c") ->
     return np.ascontiguousarray(r[top:top + n_px, left:left + n_px])
 
 
+def clip_resize_crop_pil_image(img, n_px: int = 224) -> np.ndarray:
+    """The integer part of the reference's CLIP transform applied to a PIL image IN ITS OWN MODE, with Pillow itself
+    (src/marqo/s2_inference/clip_utils.py:61-64: Resize(n_px, BICUBIC) -> CenterCrop(n_px) -> _convert_image_to_rgb; torchvision
+    0.13 functional_pil.resize: an image whose shorter side already equals n_px is returned untouched, otherwise
+    img.resize((new_w, new_h), BICUBIC)).  Image.resize is mode dependent — NEAREST for "P" / "1", a premultiplied round trip for
+    "RGBA" / "LA" — which is exactly what this checker exists for.  -> uint8 [n_px, n_px, 3]."""
+    from PIL import Image
+    w, h = img.size
+    nh, nw = resize_output_size(h, w, n_px)
+    r = img if (nh, nw) == (h, w) else img.resize((nw, nh), Image.BICUBIC)
+    top, left = center_crop_offsets(nh, nw, n_px)
+    r = r.crop((left, top, left + n_px, top + n_px))
+    return np.ascontiguousarray(np.asarray(r.convert("RGB")))
+
+
+def squash_pil_image(img, out_h: int, out_w: int, bilinear: bool = False) -> np.ndarray:
+    """Image.resize((out_w, out_h), BICUBIC | BILINEAR) of a PIL image in its own mode, then convert("RGB") (the SigLIP / CLIPA
+    squash transforms and the chunker's working image, processing/image.py:143)."""
+    from PIL import Image
+    return np.ascontiguousarray(np.asarray(img.resize((out_w, out_h), Image.BILINEAR if bilinear else Image.BICUBIC).convert("RGB")))
+
+
 def to_tensor_normalize(u8: np.ndarray, mean: Sequence[float] = OPENAI_DATASET_MEAN, std: Sequence[float] = OPENAI_DATASET_STD) -> np.ndarray:
     """ToTensor (/255, HWC -> CHW, fp32) + Normalize."""
     x = u8.astype(np.float32) / np.float32(255.0)

@@ -152,3 +152,86 @@ def test_packed_images_rgbx_staging_and_threaded_copies(pre):
     same = [torch.from_numpy(a).cuda() for a in _imgs([(64, 64)] * 5, seed=2)]
     p = P.PackedImages(same, torch.device("cuda:0"))
     assert torch.equal(p.buffer.reshape(5, 64, 64, 3), torch.stack(same))
+
+
+# ---- image modes: the device resize follows what Pillow does for the source image's mode -------------------------------------------
+def _mode_images(seed=21):
+    """PIL images of the modes Image.resize treats specially, with sizes that exercise down- / up-scaling, both crop axes and the
+    no-resize case (shorter side already 224)"""
+    from PIL import Image
+    rng = np.random.default_rng(seed)
+    out = []
+    for k, (h, w) in enumerate([(300, 400), (224, 224), (100, 90), (640, 224), (511, 333), (224, 500)]):
+        a = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+        a[: h // 3, :, 3] = 0                      # a fully transparent band (arbitrary colour bytes under it)
+        a[h // 3: h // 2, :, 3] = 255              # an opaque band
+        out.append(("RGBA", Image.fromarray(a, "RGBA")))
+        out.append(("LA", Image.fromarray(np.ascontiguousarray(a[..., [0, 3]]), "LA")))
+        p = Image.fromarray(rng.integers(0, 256, (h, w), dtype=np.uint8), "P")
+        p.putpalette([int(v) for v in rng.integers(0, 256, 768)])
+        if k % 2:
+            p.info["transparency"] = 3
+        out.append(("P", p))
+        out.append(("1", Image.fromarray(rng.integers(0, 2, (h, w), dtype=np.uint8) * 255).convert("1")))
+        out.append(("L", Image.fromarray(rng.integers(0, 256, (h, w), dtype=np.uint8), "L")))
+        out.append(("RGB", Image.fromarray(np.ascontiguousarray(a[..., :3]), "RGB")))
+    opaque = rng.integers(0, 256, (260, 300, 4), dtype=np.uint8)
+    opaque[..., 3] = 255
+    out.append(("RGBA-opaque", Image.fromarray(opaque, "RGBA")))
+    return out
+
+
+def test_image_modes_clip_transform_is_bit_exact_vs_pillow(pre):
+    """translucent RGBA / LA (premultiplied round trip), palette / bilevel (forced NEAREST), L and RGB in ONE mixed batch: every image
+    equals the reference's own transform run by Pillow on the image in its own mode"""
+    from marqo_amd.engine import preprocess as P
+    imgs = _mode_images()
+    px = [P.pil_pixels(im) for _, im in imgs]
+    kinds = {m: type(x).__name__ for (m, _), x in zip(imgs, px)}
+    assert kinds["RGBA"] == "Rgba" and kinds["LA"] == "Rgba" and kinds["P"] == "NearestRgb" and kinds["1"] == "NearestRgb"
+    assert kinds["RGBA-opaque"] in ("ndarray",) and kinds["L"] == "ndarray"
+    out = pre.resize_crop_u8(px).cpu().numpy()
+    for k, (mode, im) in enumerate(imgs):
+        ref = OP.clip_resize_crop_pil_image(im, 224)
+        assert np.array_equal(out[k], ref), f"image {k} mode {mode} size {im.size}: max |d| = {np.abs(out[k].astype(int) - ref).max()}"
+    # and the flatten-first treatment this replaces really differs for translucent / palette sources (the test is not vacuous)
+    flat = pre.resize_crop_u8([np.asarray(im.convert("RGB")) for _, im in imgs[:3]]).cpu().numpy()
+    assert not np.array_equal(flat[0], out[0]) and not np.array_equal(flat[2], out[2])
+
+
+def test_image_modes_squash_is_bit_exact_vs_pillow(pre):
+    from marqo_amd.engine import preprocess as P
+    imgs = _mode_images(seed=22)
+    px = [P.pil_pixels(im) for _, im in imgs]
+    for interpolation in ("bicubic", "bilinear"):
+        out = pre.resize_u8(px, 224, 224, interpolation).cpu().numpy()
+        for k, (mode, im) in enumerate(imgs):
+            ref = OP.squash_pil_image(im, 224, 224, bilinear=interpolation == "bilinear")
+            assert np.array_equal(out[k], ref), f"{interpolation}: image {k} mode {mode} size {im.size}"
+    out = pre.resize_u8(px[:6], 240, 200).cpu().numpy()
+    for k, (mode, im) in enumerate(imgs[:6]):
+        assert np.array_equal(out[k], OP.squash_pil_image(im, 240, 200)), (k, mode)
+
+
+def test_mode_call_agrees_with_the_rgb_entry_points(pre):
+    """mq_resize_mode_u8 in MQ_IMG_RGB mode == mq_clip_resize_crop_u8 / mq_resize_filter_u8 (one planner, one pair of kernels)"""
+    import ctypes as C
+    from marqo_amd import _lib as L
+    from marqo_amd.engine.preprocess import PackedImages
+    lib = L.load()
+    imgs = _imgs([(333, 517), (224, 224), (90, 700)], seed=31)
+    dev = torch.device("cuda:0")
+    p = PackedImages(imgs, dev)
+    s = torch.cuda.current_stream().cuda_stream
+    for crop in (1, 0):
+        need = lib.mq_resize_mode_workspace_bytes(p.heights.ctypes.data, p.widths.ctypes.data, p.n, 224, 224, 3, crop, L.MQ_IMG_RGB)
+        ws = torch.empty(need + 256, dtype=torch.uint8, device=dev)
+        got = torch.empty(p.n, 224, 224, 3, dtype=torch.uint8, device=dev)
+        L.check(lib.mq_resize_mode_u8(p.buffer.data_ptr(), p.offsets.ctypes.data, p.heights.ctypes.data, p.widths.ctypes.data, p.n, 224, 224, 3,
+                                      crop, L.MQ_IMG_RGB, got.data_ptr(), ws.data_ptr(), ws.numel(), s))
+        want = pre.resize_crop_u8(imgs) if crop else pre.resize_u8(imgs, 224, 224)
+        assert torch.equal(got, want)
+    assert lib.mq_resize_mode_u8(p.buffer.data_ptr(), p.offsets.ctypes.data, p.heights.ctypes.data, p.widths.ctypes.data, p.n, 224, 200, 3, 1, 0,
+                                 got.data_ptr(), ws.data_ptr(), ws.numel(), s) == -1      # crop needs a square
+    assert lib.mq_resize_mode_u8(p.buffer.data_ptr(), p.offsets.ctypes.data, p.heights.ctypes.data, p.widths.ctypes.data, p.n, 224, 224, 3, 1, 7,
+                                 got.data_ptr(), ws.data_ptr(), ws.numel(), s) == -1      # unknown mode

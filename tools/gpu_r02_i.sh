@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 2, GPU call I: evidence run — full GPU suite, rocprofv3 kernel trace + PMC passes of the bench command, default bench line, workload table,
 # latency, ingest
-TAG=${1:-r02i}
+TAG=${1:-r02m}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
 bash tools/gpu_round_evidence.sh $TAG
