@@ -30,8 +30,20 @@ namespace {
 // max|value| is folded into *amax when it is non-null (calibration).
 // NW = wave64s per workgroup: 4, or 8 for sequences of more than 128 tokens (>= 9 sixteen-query blocks): their K / V image lets
 // only one or two workgroups share a CU, so the extra waves per SIMD have to come from inside the workgroup.
+// Register budget: the 64-wide-head kernels are asked to fit 5 waves per SIMD (92 VGPRs, no spill; left alone the allocator takes 100 ->
+// 4 waves).  These short-sequence launches (T = 50 / 77: one key tile per wave) are a latency chain — K / V DMA, QK^T, softmax, PV, store —
+// so a fifth resident workgroup per CU is the cover: attention -8 % on ViT-B/32, -1..2 % on the text towers
+// (profiles/r02o_attention_occupancy_ab.txt).  The 128-byte-row kernels would spill at that budget and keep the default.
+#ifndef MQ_ATTN_WAVES_PER_EU
+#define MQ_ATTN_WAVES_PER_EU 5   // 0: no request (A/B builds, tools/probes/build_attn_occupancy.sh)
+#endif
+#if MQ_ATTN_WAVES_PER_EU > 0
+#define MQ_ATTN_OCC __attribute__((amdgpu_waves_per_eu(HD == 64 ? MQ_ATTN_WAVES_PER_EU : 1, 8)))
+#else
+#define MQ_ATTN_OCC
+#endif
 template <int MASK, bool OUT_FP8, int HD, int HS, int NW>
-__global__ __launch_bounds__(NW * 64) void attention_kernel(
+__global__ __launch_bounds__(NW * 64) MQ_ATTN_OCC void attention_kernel(
     const bf16_t* __restrict__ qkv, void* __restrict__ out_v, const int32_t* __restrict__ cu,
     int fixed_len, int W, int heads, int kpad, float scale_log2e, const float* __restrict__ out_scale, float* amax_out) {
     bf16_t* out = (bf16_t*)out_v;
