@@ -273,7 +273,7 @@ __global__ __launch_bounds__(NW * 64) MQ_ATTN_OCC void attention_kernel(
 
 }  // namespace
 
-int mq_attention_waves = 0;  // mq_tune("attn_waves", 0 = auto / 4 / 8): A/B knob
+int mq_attention_waves = 0;  // mq_tune("attn_waves", 0 = auto / 4 / 8 / 5 = five waves for 65..80-token sequences, else auto): A/B knob
 
 extern "C" int mq_attention_ex(const void* d_qkv, void* d_out, const int32_t* d_cu_seqlens, int64_t nseq,
                                int32_t fixed_len, int32_t max_len, int32_t W, int32_t heads, int32_t mask,
@@ -299,7 +299,11 @@ extern "C" int mq_attention_ex(const void* d_qkv, void* d_out, const int32_t* d_
     // 8 waves from 9 query blocks up (measured, profiles/r01f_attention_waves_ab.txt: -25..-33 % at 257 / 512 / 577 tokens, where a
     // workgroup's K / V image leaves room for one or two workgroups per CU; +6..+25 % at 77 / 50 tokens, whose 5 / 4 blocks leave
     // the extra waves idle)
-    const int nw = mq_attention_waves == 4 || mq_attention_waves == 8 ? mq_attention_waves : (maxl > 128 ? 8 : 4);
+    // (65..80 tokens are FIVE query blocks — the 77-token CLIP / BERT rows; five-wave workgroups, one block per wave instead of a second round
+    // with three waves idle, measured neutral to slower: CLIP text -0.7 %, BERT-base +3.6 % attention time, profiles/r02p_attention_five_waves_ab.txt;
+    // kept behind mq_tune("attn_waves", 5) with its bit-identity test)
+    const bool five = mq_attention_waves == 5 && maxl > 64 && maxl <= 80 && hs == 64;
+    const int nw = five ? 5 : (mq_attention_waves == 4 || mq_attention_waves == 8 ? mq_attention_waves : (maxl > 128 ? 8 : 4));
     const float scale_log2e = 1.44269504088896340736f / sqrtf((float)hs);  // 1/sqrt(head dim) * log2(e)
     MqProfScope prof(2, s);
     auto launch = [&](auto kern) -> int {
@@ -319,6 +323,8 @@ extern "C" int mq_attention_ex(const void* d_qkv, void* d_out, const int32_t* d_
         return (mask == MQ_MASK_CAUSAL) ? launch(attention_kernel<MQ_MASK_CAUSAL, false, HD_, HS_, NW_>) : launch(attention_kernel<MQ_MASK_NONE, false, HD_, HS_, NW_>);
     };
     auto pick = [&](auto hd_tag, auto hs_tag) -> int {
+        if constexpr (decltype(hd_tag)::value == 64)
+            if (nw == 5) return pick_nw(hd_tag, hs_tag, std::integral_constant<int, 5>{});
         return nw == 8 ? pick_nw(hd_tag, hs_tag, std::integral_constant<int, 8>{}) : pick_nw(hd_tag, hs_tag, std::integral_constant<int, 4>{});
     };
     using std::integral_constant;

@@ -137,6 +137,8 @@ def _ref_attention(qkv, lens, heads, causal, hd=64):
 @pytest.mark.parametrize("lens,heads,causal,hd", [([50] * 6, 12, False, 64), ([257] * 3, 16, False, 64), ([77] * 5, 8, True, 64),
                                                     ([5, 77, 1, 33, 64, 65], 12, True, 64), ([9, 512, 17, 128], 12, False, 64),
                                                     ([16], 2, False, 64),
+                                                    # 65..80 tokens: five query blocks (the opt-in five-wave workgroups are checked bit for bit below)
+                                                    ([77, 77, 66, 80, 3, 77], 12, False, 64), ([80] * 3, 4, True, 64),
                                                     # 128-wide heads (ViT-H / g / bigG after padding): 257 tokens fill the 160 KiB of LDS
                                                     ([257] * 3, 16, False, 128), ([5, 77, 1, 33, 64, 65, 320], 3, True, 128),
                                                     ([50] * 4, 5, False, 128), ([16], 1, False, 128),
@@ -164,7 +166,7 @@ def test_attention(lib, lens, heads, causal, hd):
     assert err < 2e-2, err
     # 4 or 8 waves per workgroup (auto: 8 once K + V exceed 80 KiB of LDS) walk the same query blocks: identical bits
     try:
-        for nw in (4, 8):
+        for nw in (4, 8, 5):
             L.check(lib.mq_tune(b"attn_waves", nw))
             out2 = torch.empty_like(out)
             L.check(lib.mq_attention(qkv.data_ptr(), out2.data_ptr(), 0 if fixed else cu.data_ptr(), len(lens), fixed, max(lens), W, heads,
