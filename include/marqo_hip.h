@@ -45,7 +45,7 @@ extern "C" {
 #define MQ_ERR_HIP (-2)       /* a HIP runtime call or launch failed */
 #define MQ_ERR_WORKSPACE (-3) /* caller's workspace too small */
 
-#define MQ_ABI_VERSION 4
+#define MQ_ABI_VERSION 5
 
 /* ---- activation / mask / pooling selectors ---------------------------------------- */
 #define MQ_ACT_NONE 0
@@ -124,6 +124,13 @@ typedef struct mq_encoder_cfg {
      * of the QKV buffer in place, HF "rotate_half" convention: (x1, x2) = (x[d], x[d + hd/2]) -> (x1 cos - x2 sin, x2 cos + x1 sin),
      * angle = position_in_sequence * inv_freq[d].  bf16 path only. */
     const float* d_rope_inv_freq;
+    /* relative-position attention bias (NULL: none).  MPNet (sentence-transformers all-mpnet-base-*, transformers MPNetModel: one T5-style
+     * bucketed bias table shared by every layer, added to the attention scores before the softmax): device fp32
+     * [heads][2 * rel_span - 1], entry (h, d + rel_span - 1) = bias(h, key - query == d) * sqrt(head_dim) (i.e. divided by the softmax
+     * scale, which the kernel applies to the sum), rel_span >= the longest sequence run.  bf16 path, 64-wide heads, unmasked attention. */
+    const float* d_rel_bias;
+    int32_t      rel_span;
+    int32_t      reserved0;
 } mq_encoder_cfg;
 
 /* ---- towers ------------------------------------------------------------------------ */
@@ -413,6 +420,11 @@ int mq_layernorm_ex(const void* d_x, int x_bf16, const int32_t* d_row_idx, const
 int mq_attention(const void* d_qkv, void* d_out, const int32_t* d_cu_seqlens, int64_t nseq,
                  int32_t fixed_len, int32_t max_len, int32_t W, int32_t heads, int32_t mask,
                  void* stream);
+
+/* mq_attention (unmasked, bf16 out, 64-wide heads) with an additive relative-position bias on the scores: d_rel_bias as described at
+ * mq_encoder_cfg.d_rel_bias. */
+int mq_attention_bias(const void* d_qkv, void* d_out, const int32_t* d_cu_seqlens, int64_t nseq, int32_t fixed_len,
+                      int32_t max_len, int32_t W, int32_t heads, const float* d_rel_bias, int32_t rel_span, void* stream);
 
 /* mq_attention with an optional e4m3 output (out_fp8 != 0: d_out holds codes = value / *d_out_scale; max|value| is
  * folded into *d_amax when it is non-NULL). */

@@ -25,7 +25,7 @@ TORCH_OPS_PATH = LIB_DIR / "libmarqo_torch_ops.so"   # torch.ops.marqo_hip.*: th
 
 MQ_OK = 0
 NO_SCRATCH_UNITS = ("gemm_bf16", "gemm_big", "gemm_k32", "gemm_fp8", "gemm_small", "attention")  # build() refuses register spills in these
-ABI_VERSION = 4
+ABI_VERSION = 5
 MQ_PREC_BF16, MQ_PREC_FP8 = 0, 1
 MQ_ACT_GELU, MQ_ACT_QUICKGELU = 1, 2
 MQ_MASK_NONE, MQ_MASK_CAUSAL = 0, 1
@@ -60,7 +60,8 @@ class EncoderCfg(C.Structure):
     _fields_ = [("width", C.c_int32), ("layers", C.c_int32), ("heads", C.c_int32), ("mlp_dim", C.c_int32),
                 ("act", C.c_int32), ("post_ln", C.c_int32), ("mask", C.c_int32), ("ln_eps", C.c_float),
                 ("precision", C.c_int32), ("attn_width", C.c_int32), ("fp8_first_layer", C.c_int32), ("mlp_glu", C.c_int32),
-                ("d_fp8_act_scale", C.c_void_p), ("d_fp8_act_amax", C.c_void_p), ("d_rope_inv_freq", C.c_void_p)]
+                ("d_fp8_act_scale", C.c_void_p), ("d_fp8_act_amax", C.c_void_p), ("d_rope_inv_freq", C.c_void_p),
+                ("d_rel_bias", C.c_void_p), ("rel_span", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class MapHead(C.Structure):
@@ -147,6 +148,7 @@ _SIGNATURES = {
     "mq_layernorm": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, C.c_int32, C.c_float, _P]),
     "mq_layernorm_ex": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, C.c_int64, C.c_int32, C.c_float, _P]),
     "mq_attention_ex": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
+    "mq_attention_bias": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P]),
     "mq_attention": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "mq_encoder_forward": (C.c_int, [C.POINTER(EncoderCfg), C.POINTER(BlockWeights), _P, C.c_int64, _P, C.c_int64,
                                      C.c_int32, C.c_int32, _P, C.c_size_t, _P]),

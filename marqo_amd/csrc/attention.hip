@@ -42,10 +42,14 @@ namespace {
 #else
 #define MQ_ATTN_OCC
 #endif
-template <int MASK, bool OUT_FP8, int HD, int HS, int NW>
+// BIAS: an additive relative-position bias on the scores (MPNet: T5-style bucketed bias shared by all layers).  rel_bias is fp32
+// [heads][2 * rel_span - 1], entry (h, d + rel_span - 1) = bias of key - query == d, ALREADY divided by the softmax scale (the kernel adds
+// it to the raw q.k sums and scales everything once); rel_span >= the longest sequence.
+template <int MASK, bool OUT_FP8, int HD, int HS, int NW, bool BIAS = false>
 __global__ __launch_bounds__(NW * 64) MQ_ATTN_OCC void attention_kernel(
     const bf16_t* __restrict__ qkv, void* __restrict__ out_v, const int32_t* __restrict__ cu,
-    int fixed_len, int W, int heads, int kpad, float scale_log2e, const float* __restrict__ out_scale, float* amax_out) {
+    int fixed_len, int W, int heads, int kpad, float scale_log2e, const float* __restrict__ out_scale, float* amax_out,
+    const float* __restrict__ rel_bias = nullptr, int rel_span = 0) {
     bf16_t* out = (bf16_t*)out_v;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     static_assert(HS <= HD && HS % 16 == 0 && (HD == 64 || HD == 128), "head stride: multiple of 16, at most the LDS row");
@@ -168,6 +172,16 @@ __global__ __launch_bounds__(NW * 64) MQ_ATTN_OCC void attention_kernel(
                     sc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], sc[t], 0, 0, 0);
                 }
             }
+            if (BIAS) {   // (rows of padded query lanes / key columns past the sequence are clamped: their scores are masked or never stored)
+                const float* rb = rel_bias + (int64_t)h * (2 * rel_span - 1) + (rel_span - 1) - (q < len ? q : len - 1);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = kt * 64 + t * 16 + g * 4 + r;
+                        sc[t][r] += rb[key < len ? key : len - 1];
+                    }
+            }
             // masking is needed only on the ragged last tile and (causal) on tiles that reach past the block's first query:
             // a wave-uniform test, so interior tiles skip the per-element compares / selects
             bool need_mask = (kt == nkt - 1) && (len & 63);
@@ -275,9 +289,9 @@ __global__ __launch_bounds__(NW * 64) MQ_ATTN_OCC void attention_kernel(
 
 int mq_attention_waves = 0;  // mq_tune("attn_waves", 0 = auto / 4 / 8 / 5 = five waves for 65..80-token sequences, else auto): A/B knob
 
-extern "C" int mq_attention_ex(const void* d_qkv, void* d_out, const int32_t* d_cu_seqlens, int64_t nseq,
-                               int32_t fixed_len, int32_t max_len, int32_t W, int32_t heads, int32_t mask,
-                               int32_t out_fp8, const float* d_out_scale, float* d_amax, void* stream) {
+static int attention_impl(const void* d_qkv, void* d_out, const int32_t* d_cu_seqlens, int64_t nseq,
+                          int32_t fixed_len, int32_t max_len, int32_t W, int32_t heads, int32_t mask,
+                          int32_t out_fp8, const float* d_out_scale, float* d_amax, const float* d_rel_bias, int32_t rel_span, void* stream) {
     MQ_CHECK_ARG(d_qkv && d_out, "mq_attention: null pointer");
     MQ_CHECK_ARG(heads >= 1 && W % heads == 0, "mq_attention: W=%d is not a multiple of heads=%d", W, heads);
     const int hs = W / heads;             // head stride in memory = dims computed
@@ -288,6 +302,9 @@ extern "C" int mq_attention_ex(const void* d_qkv, void* d_out, const int32_t* d_
     if (nseq <= 0) return MQ_OK;
     const int maxl = fixed_len > 0 ? fixed_len : max_len;
     MQ_CHECK_ARG(maxl >= 1 && maxl <= 8192, "mq_attention: max sequence length %d unsupported (1..8192)", maxl);
+    MQ_CHECK_ARG(!d_rel_bias || (hs == 64 && mask == MQ_MASK_NONE && !out_fp8 && rel_span >= maxl),
+                 "mq_attention_bias: the relative-position bias runs with 64-wide heads, no mask, bf16 output and rel_span (%d) >= the longest "
+                 "sequence (%d)", rel_span, maxl);
     MQ_CHECK_ARG(nseq * heads < (1LL << 31), "mq_attention: grid too large");
     // K + V rows of hd bf16 each live in the CU's 160 KiB of LDS: whole sequences up to 640 keys (hd 64) / 320 keys (hd 128),
     // longer ones stream through it in pieces of that many keys (ViT-H-14-378: 730 tokens, ViT-B-16-SigLIP-512: 1024)
@@ -302,7 +319,7 @@ extern "C" int mq_attention_ex(const void* d_qkv, void* d_out, const int32_t* d_
     // (65..80 tokens are FIVE query blocks — the 77-token CLIP / BERT rows; five-wave workgroups, one block per wave instead of a second round
     // with three waves idle, measured neutral to slower: CLIP text -0.7 %, BERT-base +3.6 % attention time, profiles/r02p_attention_five_waves_ab.txt;
     // kept behind mq_tune("attn_waves", 5) with its bit-identity test)
-    const bool five = mq_attention_waves == 5 && maxl > 64 && maxl <= 80 && hs == 64;
+    const bool five = mq_attention_waves == 5 && maxl > 64 && maxl <= 80 && hs == 64 && !d_rel_bias;
     const int nw = five ? 5 : (mq_attention_waves == 4 || mq_attention_waves == 8 ? mq_attention_waves : (maxl > 128 ? 8 : 4));
     const float scale_log2e = 1.44269504088896340736f / sqrtf((float)hs);  // 1/sqrt(head dim) * log2(e)
     MqProfScope prof(2, s);
@@ -312,9 +329,15 @@ extern "C" int mq_attention_ex(const void* d_qkv, void* d_out, const int32_t* d_
             if (e != hipSuccess) { mq_set_error("mq_attention: hipFuncSetAttribute: %s", hipGetErrorString(e)); return MQ_ERR_HIP; }
         }
         hipLaunchKernelGGL(kern, dim3((unsigned)(nseq * heads)), dim3(nw * 64), lds, s, (const bf16_t*)d_qkv,
-                           d_out, d_cu_seqlens, (int)fixed_len, (int)W, (int)heads, kpad, scale_log2e, d_out_scale, d_amax);
+                           d_out, d_cu_seqlens, (int)fixed_len, (int)W, (int)heads, kpad, scale_log2e, d_out_scale, d_amax, d_rel_bias, (int)rel_span);
         return MQ_OK;
     };
+    if (d_rel_bias) {
+        const int rcb = nw == 8 ? launch(attention_kernel<MQ_MASK_NONE, false, 64, 64, 8, true>) : launch(attention_kernel<MQ_MASK_NONE, false, 64, 64, 4, true>);
+        if (rcb != MQ_OK) return rcb;
+        MQ_CHECK_LAUNCH("mq_attention_bias");
+        return MQ_OK;
+    }
     MQ_CHECK_ARG(!out_fp8 || d_out_scale, "mq_attention: fp8 output needs an out_scale");
     int rc;
     auto pick_nw = [&](auto hd_tag, auto hs_tag, auto nw_tag) -> int {
@@ -337,6 +360,18 @@ extern "C" int mq_attention_ex(const void* d_qkv, void* d_out, const int32_t* d_
     if (rc != MQ_OK) return rc;
     MQ_CHECK_LAUNCH("mq_attention");
     return MQ_OK;
+}
+
+extern "C" int mq_attention_ex(const void* d_qkv, void* d_out, const int32_t* d_cu_seqlens, int64_t nseq,
+                               int32_t fixed_len, int32_t max_len, int32_t W, int32_t heads, int32_t mask,
+                               int32_t out_fp8, const float* d_out_scale, float* d_amax, void* stream) {
+    return attention_impl(d_qkv, d_out, d_cu_seqlens, nseq, fixed_len, max_len, W, heads, mask, out_fp8, d_out_scale, d_amax, nullptr, 0, stream);
+}
+
+extern "C" int mq_attention_bias(const void* d_qkv, void* d_out, const int32_t* d_cu_seqlens, int64_t nseq, int32_t fixed_len,
+                                 int32_t max_len, int32_t W, int32_t heads, const float* d_rel_bias, int32_t rel_span, void* stream) {
+    MQ_CHECK_ARG(d_rel_bias, "mq_attention_bias: null bias table");
+    return attention_impl(d_qkv, d_out, d_cu_seqlens, nseq, fixed_len, max_len, W, heads, MQ_MASK_NONE, 0, nullptr, nullptr, d_rel_bias, rel_span, stream);
 }
 
 extern "C" int mq_attention(const void* d_qkv, void* d_out, const int32_t* d_cu_seqlens, int64_t nseq, int32_t fixed_len,

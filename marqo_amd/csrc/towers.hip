@@ -28,8 +28,8 @@ extern "C" int mq_rowquant_fp8(const float* d_x, void* d_out_fp8, float* d_row_s
 
 // layouts the ctypes binding (marqo_amd/_lib.py) and tests/test_abi.py assume
 static_assert(sizeof(mq_block_weights) == 26 * 8, "mq_block_weights layout");
-static_assert(sizeof(mq_encoder_cfg) == 72, "mq_encoder_cfg layout");
-static_assert(sizeof(mq_vit_cfg) == 120 && sizeof(mq_clip_text_cfg) == 88 && sizeof(mq_bert_cfg) == 88, "tower cfg layouts");
+static_assert(sizeof(mq_encoder_cfg) == 88, "mq_encoder_cfg layout");
+static_assert(sizeof(mq_vit_cfg) == 136 && sizeof(mq_clip_text_cfg) == 104 && sizeof(mq_bert_cfg) == 104, "tower cfg layouts");
 static_assert(sizeof(mq_vit_weights) == 10 * 8 && sizeof(mq_map_head) == 11 * 8 && sizeof(mq_clip_text_weights) == 7 * 8, "tower weight layouts");
 
 // mq_tune("row_select", 0) runs the last block on every row (A/B and parity tests of the pooled-rows-only last block)
@@ -67,6 +67,15 @@ extern "C" int mq_gemm_bf16_ln(const void* d_A, int64_t lda, const void* d_W, in
                                const float* d_colsum, float eps, void* stream);
 
 namespace {
+// attention of one block: with the model's relative-position bias when the encoder has one (MPNet), else the plain kernel
+inline int attn_bf16(const mq_encoder_cfg* cfg, const void* qf, void* a, const int32_t* d_cu_seqlens, int64_t nseq, int32_t fixed_len,
+                     int32_t max_len, int32_t Wa, hipStream_t s) {
+    if (cfg->d_rel_bias) return mq_attention_bias(qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, cfg->heads, cfg->d_rel_bias, cfg->rel_span, s);
+    return mq_attention(qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, cfg->heads, cfg->mask, s);
+}
+}  // namespace
+
+namespace {
 
 constexpr size_t WS_ALIGN = 256;
 
@@ -100,6 +109,9 @@ int check_encoder_cfg(const mq_encoder_cfg* c) {
     }
     if (c->mlp_glu || c->d_rope_inv_freq)
         MQ_CHECK_ARG(c->post_ln == 1 && wa == c->width, "the gated-MLP / rotary encoder variant is the post-LN NewModel family (un-padded heads)");
+    if (c->d_rel_bias)
+        MQ_CHECK_ARG(c->precision == MQ_PREC_BF16 && c->mask == MQ_MASK_NONE && wa == c->width && wa == c->heads * 64 && c->rel_span >= 1,
+                     "the relative-position attention bias (MPNet) runs on the bf16 path with un-padded 64-wide heads and no mask");
     return MQ_OK;
 }
 
@@ -176,7 +188,7 @@ int last_block_selected(const mq_encoder_cfg* cfg, const mq_block_weights& b, in
             MQ_TRY(mq_layernorm_ex(d_x, xb, nullptr, b.ln1_g, b.ln1_b, h, nullptr, rows, W, cfg->ln_eps, s));
             MQ_TRY(mq_gemm_bf16(h, W, b.qkv_w, W, b.qkv_b, nullptr, qf, 3 * Wa, rows, 3 * Wa, W, MQ_EPI_BIAS, s));
         }
-        MQ_TRY(mq_attention(qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, cfg->heads, cfg->mask, s));
+        MQ_TRY(attn_bf16(cfg, qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, s));
         MQ_TRY(mq_move_rows(a, d_sel, h, nsel, (int64_t)Wa * 2, false, s));
         MQ_TRY(mq_move_rows(d_x, d_sel, x_sel, nsel, xrow, false, s));
         MQ_TRY(mq_gemm_bf16(h, Wa, b.out_w, Wa, b.out_b, x_sel, x_sel, W, nsel, W, Wa, rflags, s));
@@ -184,7 +196,7 @@ int last_block_selected(const mq_encoder_cfg* cfg, const mq_block_weights& b, in
         MQ_TRY(mq_gemm_bf16(qf, F, b.fc2_w, F, b.fc2_b, x_sel, x_sel, W, nsel, W, F, rflags, s));
     } else {
         MQ_TRY(mq_gemm_bf16(h, W, b.qkv_w, W, b.qkv_b, nullptr, qf, 3 * Wa, rows, 3 * Wa, W, MQ_EPI_BIAS, s));
-        MQ_TRY(mq_attention(qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, cfg->heads, cfg->mask, s));
+        MQ_TRY(attn_bf16(cfg, qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, s));
         MQ_TRY(mq_move_rows(a, d_sel, h, nsel, (int64_t)Wa * 2, false, s));
         MQ_TRY(mq_move_rows(d_x, d_sel, x_sel, nsel, (int64_t)W * 4, false, s));
         MQ_TRY(mq_gemm_bf16(h, Wa, b.out_w, Wa, b.out_b, x_sel, x_sel, W, nsel, W, Wa, res_flags, s));
@@ -272,7 +284,7 @@ int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* bloc
                 MQ_TRY(mq_layernorm(d_x, nullptr, b.ln1_g, b.ln1_b, h, nullptr, rows, W, cfg->ln_eps, s));
                 MQ_TRY(mq_gemm_bf16(h, W, b.qkv_w, W, b.qkv_b, nullptr, qf, 3 * Wa, rows, 3 * Wa, W, MQ_EPI_BIAS, s));
             }
-            MQ_TRY(mq_attention(qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, cfg->heads, cfg->mask, s));
+            MQ_TRY(attn_bf16(cfg, qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, s));
             MQ_TRY(mq_gemm_bf16_ln(a, Wa, b.out_w, Wa, b.out_b, d_x, d_x, W, rows, W, Wa, stat_flags, ln_stats, h, nullptr, cfg->ln_eps, s));
             MQ_TRY(mq_gemm_bf16_ln(h, W, b.fc1_wf, W, b.fc1_bf, nullptr, qf, F, rows, F, W, apply | act_flag, ln_stats, nullptr, b.fc1_sf,
                                    cfg->ln_eps, s));
@@ -314,7 +326,7 @@ int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* bloc
             const int xb = stream_bf16(cfg) ? 1 : 0;
             const int rflags = xb ? (MQ_EPI_BIAS | MQ_EPI_RESIDUAL) : res_flags;
             MQ_TRY(ln_gemm(d_x, xb, b.ln1_g, b.ln1_b, cfg->ln_eps, h, b.qkv_w, b.qkv_b, qf, rows, 3 * Wa, W, MQ_EPI_BIAS, s));
-            MQ_TRY(mq_attention(qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, cfg->heads, cfg->mask, s));
+            MQ_TRY(attn_bf16(cfg, qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, s));
             MQ_TRY(mq_gemm_bf16(a, Wa, b.out_w, Wa, b.out_b, (const float*)d_x, d_x, W, rows, W, Wa, rflags, s));
             MQ_TRY(ln_gemm(d_x, xb, b.ln2_g, b.ln2_b, cfg->ln_eps, h, b.fc1_w, b.fc1_b, qf, rows, F, W, MQ_EPI_BIAS | act_flag, s));
             MQ_TRY(mq_gemm_bf16(qf, F, b.fc2_w, F, b.fc2_b, (const float*)d_x, d_x, W, rows, W, F, rflags, s));
@@ -329,7 +341,7 @@ int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* bloc
                 MQ_TRY(mq_ln_gemm_small(d_x, W, 0, pb.ln2_g, pb.ln2_b, cfg->ln_eps, b.qkv_w, W, b.qkv_b, qf, 3 * Wa, rows, 3 * Wa, W, MQ_EPI_BIAS, xn, nullptr, s));
                 res = xn;
             }
-            MQ_TRY(mq_attention(qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, cfg->heads, cfg->mask, s));
+            MQ_TRY(attn_bf16(cfg, qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, s));
             MQ_TRY(mq_gemm_bf16(a, Wa, b.out_w, Wa, b.out_b, res, d_x, W, rows, W, Wa, res_flags, s));
             MQ_TRY(mq_ln_gemm_small(d_x, W, 0, b.ln1_g, b.ln1_b, cfg->ln_eps, b.fc1_w, W, b.fc1_b, qf, F, rows, F, W, MQ_EPI_BIAS | act_flag, xn, nullptr, s));
             MQ_TRY(mq_gemm_bf16(qf, F, b.fc2_w, F, b.fc2_b, xn, d_x, W, rows, W, F, res_flags, s));
@@ -338,7 +350,7 @@ int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* bloc
             // x = ln1(x + out(attn(qkv(x)))) ; x = ln2(x + fc2(act(fc1(x))))
             MQ_TRY(mq_gemm_bf16(h, W, b.qkv_w, W, b.qkv_b, nullptr, qf, 3 * Wa, rows, 3 * Wa, W, MQ_EPI_BIAS, s));
             if (cfg->d_rope_inv_freq) MQ_TRY(mq_rope(qf, d_cu_seqlens, nseq, fixed_len, Wa, cfg->heads, cfg->d_rope_inv_freq, s));
-            MQ_TRY(mq_attention(qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, cfg->heads, cfg->mask, s));
+            MQ_TRY(attn_bf16(cfg, qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, s));
             MQ_TRY(mq_gemm_bf16(a, Wa, b.out_w, Wa, b.out_b, d_x, d_x, W, rows, W, Wa, res_flags, s));
             MQ_TRY(mq_layernorm(d_x, nullptr, b.ln1_g, b.ln1_b, h, d_x, rows, W, cfg->ln_eps, s));
             if (cfg->mlp_glu) {

@@ -83,6 +83,28 @@ class BertArch:
     rope_ntk_factor: Optional[float] = None  # rope_scaling {"type": "ntk", "factor": f}
     glu: bool = False
     type_vocab: int = 2
+    # MPNet (sentence-transformers all-mpnet-base-*): the BERT post-LN encoder without token types, RoBERTa-style position offset, and one
+    # T5-style relative-position bias table [rel_buckets, heads] shared by all layers (0 = no relative bias)
+    rel_buckets: int = 0
+    rel_max_distance: int = 128
+
+    def rel_bias_table(self, weight):
+        """`encoder.relative_attention_bias.weight` [rel_buckets, heads] -> fp32 [heads, 2 * max_pos - 1] indexed by (key - query) +
+        max_pos - 1 and multiplied by sqrt(head_dim) (= divided by the softmax scale the attention kernel applies to the sum): MPNet's
+        `compute_position_bias`, bucketed exactly as transformers' MPNetEncoder.relative_position_bucket (torch ops in the same order)."""
+        import math
+        import torch
+        span = self.max_pos
+        rel = torch.arange(-(span - 1), span, dtype=torch.long)           # key position - query position
+        n = -rel
+        nb = self.rel_buckets // 2
+        ret = (n < 0).to(torch.long) * nb
+        n = torch.abs(n)
+        max_exact = nb // 2
+        large = max_exact + (torch.log(n.float() / max_exact) / math.log(self.rel_max_distance / max_exact) * (nb - max_exact)).to(torch.long)
+        large = torch.min(large, torch.full_like(large, nb - 1))
+        bucket = ret + torch.where(n < max_exact, n, large)
+        return (weight.detach().to(torch.float32)[bucket].t() * math.sqrt(self.width // self.heads)).contiguous()
 
     def rope_inv_freq(self):
         """[head_dim / 2] inverse frequencies exactly as NewModel builds them: base^-(2i/d); with NTK scaling the module re-derives
@@ -169,6 +191,7 @@ _BERT_BASE = BertArch()
 _BERT_SMALL = BertArch(width=384, layers=12, heads=12, mlp_dim=1536)  # 12 heads of 32 (zero-padded to 64 at load)
 _BERT_LARGE = BertArch(width=1024, layers=24, heads=16, mlp_dim=4096)
 _MINILM_L6 = BertArch(width=384, layers=6, heads=12, mlp_dim=1536)   # 12 heads of 32
+_MPNET_BASE = BertArch(vocab=30527, max_pos=512, ln_eps=1e-5, pos_offset=2, type_vocab=0, rel_buckets=32)
 HF_BERT_ARCHS = {
     "intfloat/e5-base-v2": _BERT_BASE, "intfloat/e5-base": _BERT_BASE,
     "intfloat/e5-small-v2": _BERT_SMALL, "intfloat/e5-small": _BERT_SMALL,
@@ -186,6 +209,9 @@ HF_BERT_ARCHS = {
     # Chinese BGE: BERT with the 21128-entry Chinese WordPiece vocabulary (small: 4 layers of width 512)
     "BAAI/bge-small-zh-v1.5": BertArch(vocab=21128, width=512, layers=4, heads=8, mlp_dim=2048),
     "BAAI/bge-base-zh-v1.5": BertArch(vocab=21128), "BAAI/bge-large-zh-v1.5": BertArch(vocab=21128, width=1024, layers=24, heads=16, mlp_dim=4096),
+    # MPNet encoders (relative-position attention bias, no token types, position ids from 2; vocabulary = BERT's + <s> <pad> </s> <unk> ... <mask>)
+    "sentence-transformers/all-mpnet-base-v1": _MPNET_BASE, "sentence-transformers/all-mpnet-base-v2": _MPNET_BASE,
+    "flax-sentence-embeddings/all_datasets_v3_mpnet-base": _MPNET_BASE, "flax-sentence-embeddings/all_datasets_v4_mpnet-base": _MPNET_BASE,
     # XLM-RoBERTa encoders
     "intfloat/multilingual-e5-small": BertArch(vocab=250037, max_pos=512, width=384, layers=12, heads=12, mlp_dim=1536, ln_eps=1e-5, pos_offset=2),
     "intfloat/multilingual-e5-base": BertArch(vocab=250002, max_pos=512, ln_eps=1e-5, pos_offset=2),
@@ -216,6 +242,14 @@ def bert_arch_from_hf_config(cfg: dict) -> BertArch:
                         layers=cfg["num_hidden_layers"], heads=cfg["num_attention_heads"], mlp_dim=cfg["intermediate_size"],
                         ln_eps=cfg.get("layer_norm_eps", 1e-12), rope_theta=float(cfg.get("rope_theta", 10000.0)),
                         rope_ntk_factor=float(rs["factor"]) if rs else None, glu=True, type_vocab=int(cfg.get("type_vocab_size", 2)))
+    if mtype == "mpnet":   # sentence-transformers all-mpnet-base-v1 / -v2, flax all_datasets_v{3,4}_mpnet-base
+        if cfg.get("hidden_act", "gelu") != "gelu":
+            raise KeyError(f"hidden_act={cfg.get('hidden_act')} unsupported")
+        off = int(cfg.get("pad_token_id", 1)) + 1
+        return BertArch(vocab=cfg["vocab_size"], max_pos=cfg["max_position_embeddings"] - off, width=cfg["hidden_size"],
+                        layers=cfg["num_hidden_layers"], heads=cfg["num_attention_heads"], mlp_dim=cfg["intermediate_size"],
+                        ln_eps=cfg.get("layer_norm_eps", 1e-5), pos_offset=off, type_vocab=0,
+                        rel_buckets=int(cfg.get("relative_attention_num_buckets", 32)))
     if mtype not in ("bert", "xlm-roberta", "roberta"):
         raise KeyError(f"model_type={mtype} is not a BERT-family encoder")
     if cfg.get("position_embedding_type", "absolute") != "absolute":

@@ -226,8 +226,11 @@ def _encodable(text: str) -> bool:
 
 def wordpiece_in_scope(tok: WordPieceTokenizer, text: str) -> bool:
     """host-side routing test (the kernel flags character-level reasons itself): size, encodability, special-token spellings"""
+    firsts = getattr(tok, "_special_firsts", None)
+    if firsts is None:   # first characters of the special-token spellings: "[" for BERT vocabularies, "<" and "[" for MPNet's
+        firsts = tok._special_firsts = "".join(sorted({s[0] for s in tok._specials if s}))
     return (len(text) < MAX_TEXT_BYTES_DEVICE // 4 and _encodable(text)
-            and ("[" not in text or not any(s in text for s in tok._specials)))
+            and (not any(c in text for c in firsts) or not any(s in text for s in tok._specials)))
 
 
 def clip_in_scope(tok: ClipBpeTokenizer, text: str) -> bool:

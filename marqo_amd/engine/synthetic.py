@@ -111,14 +111,18 @@ def random_bert_state_dict(arch: BertArch, seed: int = 0) -> Dict[str, Tensor]:
         return sd
     sd["embeddings.word_embeddings.weight"] = 0.5 * torch.randn(arch.vocab, W, generator=g)
     sd["embeddings.position_embeddings.weight"] = 0.3 * torch.randn(arch.max_pos + arch.pos_offset, W, generator=g)
-    sd["embeddings.token_type_embeddings.weight"] = 0.3 * torch.randn(2, W, generator=g)
+    mpnet = arch.rel_buckets > 0   # MPNetModel naming, no token types, one relative-position bias table
+    if mpnet:
+        sd["encoder.relative_attention_bias.weight"] = 0.5 * torch.randn(arch.rel_buckets, arch.heads, generator=g)
+    else:
+        sd["embeddings.token_type_embeddings.weight"] = 0.3 * torch.randn(2, W, generator=g)
     _ln(sd, "embeddings.LayerNorm", W, g)
     for i in range(arch.layers):
         p = f"encoder.layer.{i}."
-        for n in ("query", "key", "value"):
-            _lin(sd, p + f"attention.self.{n}", W, W, g, std)
-        _lin(sd, p + "attention.output.dense", W, W, g, std)
-        _ln(sd, p + "attention.output.LayerNorm", W, g)
+        for n in (("attn.q", "attn.k", "attn.v") if mpnet else ("self.query", "self.key", "self.value")):
+            _lin(sd, p + f"attention.{n}", W, W, g, std)
+        _lin(sd, p + ("attention.attn.o" if mpnet else "attention.output.dense"), W, W, g, std)
+        _ln(sd, p + ("attention.LayerNorm" if mpnet else "attention.output.LayerNorm"), W, g)
         _lin(sd, p + "intermediate.dense", F, W, g, std)
         _lin(sd, p + "output.dense", W, F, g, std)
         _ln(sd, p + "output.LayerNorm", W, g)

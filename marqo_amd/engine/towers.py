@@ -831,7 +831,7 @@ class BertTower(_TextTowerBase):
         if pooling not in ("mean", "cls"):
             raise ValueError(f"pooling must be 'mean' or 'cls', got {pooling!r}")
         self.pooling = pooling
-        for prefix in ("bert.", "roberta.", "new."):  # HF checkpoints may carry the task-model prefix
+        for prefix in ("bert.", "roberta.", "new.", "mpnet."):  # HF checkpoints may carry the task-model prefix
             if "embeddings.word_embeddings.weight" not in sd and prefix + "embeddings.word_embeddings.weight" in sd:
                 sd = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
         W, F = arch.width, arch.mlp_dim
@@ -841,6 +841,12 @@ class BertTower(_TextTowerBase):
         new_model = arch.glu or arch.rope_theta is not None   # Alibaba-NLP NewModel naming (stella_en_400M_v5, gte-*-en-v1.5)
         if new_model and (precision != "bf16" or hd != _kernel_head_dim(hd, arch.heads)):
             raise ValueError("NewModel (rotary / gated-MLP) encoders run on the bf16 path with 64-wide heads")
+        mpnet = arch.rel_buckets > 0   # MPNetModel naming: attention.attn.{q,k,v,o}, attention.LayerNorm, + one relative-position bias table
+        if mpnet and (precision != "bf16" or hd != 64):
+            raise ValueError("MPNet encoders (relative-position attention bias) run on the bf16 path with 64-wide heads")
+        # checkpoint key names of the attention sub-block: (q, k, v, out-projection, LayerNorm)
+        ak = ("attention.attn.q", "attention.attn.k", "attention.attn.v", "attention.attn.o", "attention.LayerNorm") if mpnet else \
+             ("attention.self.query", "attention.self.key", "attention.self.value", "attention.output.dense", "attention.output.LayerNorm")
         for i in range(arch.layers):
             p = f"encoder.layer.{i}."
             b = arr[i]
@@ -857,16 +863,16 @@ class BertTower(_TextTowerBase):
                 b.fc2_b = h.f32(_need(sd, p + "mlp.down_proj.bias", (W,)))
                 b.ln2_g, b.ln2_b = h.f32(_need(sd, p + "mlp_ln.weight", (W,))), h.f32(_need(sd, p + "mlp_ln.bias", (W,)))
                 continue
-            qkv_w = torch.cat([_need(sd, p + f"attention.self.{n}.weight", (W, W)).detach().float() for n in ("query", "key", "value")], 0)
-            qkv_b = torch.cat([_need(sd, p + f"attention.self.{n}.bias", (W,)).detach().float() for n in ("query", "key", "value")], 0)
-            out_w = _need(sd, p + "attention.output.dense.weight", (W, W)).detach().float()
+            qkv_w = torch.cat([_need(sd, p + f"{n}.weight", (W, W)).detach().float() for n in ak[:3]], 0)
+            qkv_b = torch.cat([_need(sd, p + f"{n}.bias", (W,)).detach().float() for n in ak[:3]], 0)
+            out_w = _need(sd, p + ak[3] + ".weight", (W, W)).detach().float()
             if hd != _kernel_head_dim(hd, arch.heads):  # e5-small / bge-small / MiniLM: 12 heads of 32
                 qkv_w, qkv_b, out_w = _pad_heads(qkv_w, qkv_b, out_w, arch.heads, hd)
             b.qkv_w, b.qkv_b = h.bf16(qkv_w), h.f32(qkv_b)
             b.out_w = h.bf16(out_w)
-            b.out_b = h.f32(_need(sd, p + "attention.output.dense.bias", (W,)))
-            b.ln1_g = h.f32(_need(sd, p + "attention.output.LayerNorm.weight", (W,)))
-            b.ln1_b = h.f32(_need(sd, p + "attention.output.LayerNorm.bias", (W,)))
+            b.out_b = h.f32(_need(sd, p + ak[3] + ".bias", (W,)))
+            b.ln1_g = h.f32(_need(sd, p + ak[4] + ".weight", (W,)))
+            b.ln1_b = h.f32(_need(sd, p + ak[4] + ".bias", (W,)))
             b.fc1_w = h.bf16(_need(sd, p + "intermediate.dense.weight", (F, W)))
             b.fc1_b = h.f32(_need(sd, p + "intermediate.dense.bias", (F,)))
             b.fc2_w = h.bf16(_need(sd, p + "output.dense.weight", (W, F)))
@@ -879,7 +885,7 @@ class BertTower(_TextTowerBase):
             # XLM-RoBERTa: position ids start at pos_offset -> hand the library the table from that row on; rotary models have no table
             pos_emb=None if arch.rope_theta is not None else
             h.f32(_need(sd, "embeddings.position_embeddings.weight", (arch.max_pos + arch.pos_offset, W))[arch.pos_offset:]),
-            type_emb=h.f32(sd["embeddings.token_type_embeddings.weight"]) if "embeddings.token_type_embeddings.weight" in sd or not new_model
+            type_emb=h.f32(sd["embeddings.token_type_embeddings.weight"]) if "embeddings.token_type_embeddings.weight" in sd or not (new_model or mpnet)
             else None,
             emb_ln_g=h.f32(_need(sd, "embeddings.LayerNorm.weight", (W,))),
             emb_ln_b=h.f32(_need(sd, "embeddings.LayerNorm.bias", (W,))),
@@ -887,6 +893,10 @@ class BertTower(_TextTowerBase):
         self.cfg = L.BertCfg(enc=_encoder_cfg(W, arch.layers, arch.heads, F, False, True, L.MQ_MASK_NONE, arch.ln_eps),
                              vocab=arch.vocab, max_pos=arch.max_pos,
                              pool=L.MQ_POOL_MEAN if pooling == "mean" else L.MQ_POOL_CLS)
+        if mpnet:
+            self._rel_bias = arch.rel_bias_table(_need(sd, "encoder.relative_attention_bias.weight", (arch.rel_buckets, arch.heads))).to(self.device)
+            self.cfg.enc.d_rel_bias = self._rel_bias.data_ptr()
+            self.cfg.enc.rel_span = arch.max_pos
         if arch.glu:
             self.cfg.enc.mlp_glu = 1
         if arch.rope_theta is not None:

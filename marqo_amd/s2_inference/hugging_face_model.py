@@ -113,6 +113,11 @@ class HuggingFaceModel(AbstractEmbeddingModel):
                                                   f"'trustRemoteCode': True (type 'hf_stella')")
             if os.path.isfile(os.path.join(directory, "sentencepiece.bpe.model")):  # XLM-RoBERTa checkpoints (multilingual-e5)
                 self._tokenizer = XlmRobertaTokenizer(directory)
+            elif arch.rel_buckets:
+                # MPNetTokenizer = BERT's basic + WordPiece tokenisation around "<s> ... </s>" (transformers tokenization_mpnet.py); the
+                # special-token spellings come from the checkpoint's tokenizer_config.json / special_tokens_map.json
+                self._tokenizer = WordPieceTokenizer(directory, do_lower_case=self._do_lower_case(directory),
+                                                     **self._special_tokens(directory, unk="[UNK]", cls="<s>", sep="</s>", pad="<pad>", mask="<mask>"))
             else:
                 self._tokenizer = WordPieceTokenizer(directory, do_lower_case=self._do_lower_case(directory))
             self.weights_source = directory
@@ -148,6 +153,28 @@ class HuggingFaceModel(AbstractEmbeddingModel):
                 self._device_tokenizer = DeviceSentencePieceTokenizer(self._tokenizer, self.device)
             except ValueError:
                 self._device_tokenizer = None
+
+    @staticmethod
+    def _special_tokens(directory: str, **defaults) -> dict:
+        """unk / cls / sep / pad / mask spellings of a checkpoint (tokenizer_config.json, then special_tokens_map.json), else the family's"""
+        import json
+        out = dict(defaults)
+        for name in ("special_tokens_map.json", "tokenizer_config.json"):
+            p = os.path.join(directory, name)
+            if not os.path.isfile(p):
+                continue
+            try:
+                with open(p) as f:
+                    j = json.load(f)
+            except (OSError, ValueError):
+                continue
+            for k in out:
+                v = j.get(k + "_token")
+                if isinstance(v, dict):   # AddedToken serialisation
+                    v = v.get("content")
+                if isinstance(v, str) and v:
+                    out[k] = v
+        return out
 
     @staticmethod
     def _do_lower_case(directory: str) -> bool:

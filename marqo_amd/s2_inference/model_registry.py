@@ -36,7 +36,7 @@ _OPEN_CLIP_TAGS = {
 }
 
 # hf registry entries whose encoder the BERT tower runs (plain BERT: absolute positions, GELU, post-LN; XLM-RoBERTa checkpoints are
-# the same encoder with shifted position ids): name -> (repo, dims, tokens, query prefix, chunk prefix, poolingMethod).  None = the
+# the same encoder with shifted position ids; MPNet checkpoints add a relative-position attention bias): name -> (repo, dims, tokens, query prefix, chunk prefix, poolingMethod).  None = the
 # reference entry has no such key (model_registry.py:616-880; tests/test_ref_parity.py compares every field with the reference's
 # own dict).  The bge entries carry the reference's EXPLICIT "poolingMethod": "mean" (:804-849): the BAAI checkpoints ship a
 # 1_Pooling/config.json that says CLS, and an index built with the reference is mean-pooled.
@@ -45,6 +45,10 @@ _BGE_ZH = "为这个句子生成表示以用于检索相关文章："
 _HF_BERT = {
     "hf/all-MiniLM-L6-v1": ("sentence-transformers/all-MiniLM-L6-v1", 384, 128, None, None, None),
     "hf/all-MiniLM-L6-v2": ("sentence-transformers/all-MiniLM-L6-v2", 384, 256, None, None, None),
+    "hf/all-mpnet-base-v1": ("sentence-transformers/all-mpnet-base-v1", 768, 128, None, None, None),
+    "hf/all-mpnet-base-v2": ("sentence-transformers/all-mpnet-base-v2", 768, 128, None, None, None),
+    "hf/all_datasets_v3_mpnet-base": ("flax-sentence-embeddings/all_datasets_v3_mpnet-base", 768, 128, None, None, None),
+    "hf/all_datasets_v4_mpnet-base": ("flax-sentence-embeddings/all_datasets_v4_mpnet-base", 768, 128, None, None, None),
     "hf/all_datasets_v3_MiniLM-L12": ("flax-sentence-embeddings/all_datasets_v3_MiniLM-L12", 384, 128, None, None, None),
     "hf/all_datasets_v3_MiniLM-L6": ("flax-sentence-embeddings/all_datasets_v3_MiniLM-L6", 384, 128, None, None, None),
     "hf/all_datasets_v4_MiniLM-L12": ("flax-sentence-embeddings/all_datasets_v4_MiniLM-L12", 384, 128, None, None, None),

@@ -297,6 +297,75 @@ def bert_forward(sd: Dict[str, Tensor], cfg: BertConfig, ids: Tensor, attention_
     return x
 
 
+# ---- MPNet (sentence-transformers all-mpnet-base-*: the reference loads it through AutoModel, hugging_face_model.py:125-130) ------------------
+MPNET_REL_BUCKETS, MPNET_REL_MAX_DISTANCE = 32, 128
+
+
+def mpnet_relative_position_bucket(relative_position: Tensor, num_buckets: int = MPNET_REL_BUCKETS,
+                                   max_distance: int = MPNET_REL_MAX_DISTANCE) -> Tensor:
+    """transformers MPNetEncoder.relative_position_bucket (third-party, un-vendored: transformers==4.41.2 in the reference's
+    requirements; modeling_mpnet.py), restated: T5's bidirectional log-spaced buckets of (key position - query position)."""
+    ret = 0
+    n = -relative_position
+    num_buckets //= 2
+    ret += (n < 0).to(torch.long) * num_buckets
+    n = torch.abs(n)
+    max_exact = num_buckets // 2
+    is_small = n < max_exact
+    val_if_large = max_exact + (torch.log(n.float() / max_exact) / math.log(max_distance / max_exact)
+                                * (num_buckets - max_exact)).to(torch.long)
+    val_if_large = torch.min(val_if_large, torch.full_like(val_if_large, num_buckets - 1))
+    return ret + torch.where(is_small, n, val_if_large)
+
+
+def mpnet_forward(sd: Dict[str, Tensor], cfg: BertConfig, ids: Tensor, attention_mask: Tensor) -> Tensor:
+    """transformers MPNetModel forward (eval mode) -> last_hidden_state [B, S, W]: a post-LN BERT-style encoder WITHOUT token types,
+    position ids = padding_idx + 1 + index (cfg.pos_offset = 2, as RoBERTa), and ONE relative-position bias table
+    (`encoder.relative_attention_bias.weight` [32 buckets, heads]) shared by every layer and added to the scaled q.k scores before the
+    key-padding mask and the softmax (MPNetSelfAttention.forward: scores / sqrt(d) + position_bias + mask)."""
+    B, S = ids.shape
+    W, H = cfg.width, cfg.heads
+    x = sd["embeddings.word_embeddings.weight"][ids] + sd["embeddings.position_embeddings.weight"][cfg.pos_offset:cfg.pos_offset + S]
+    x = F.layer_norm(x, (W,), sd["embeddings.LayerNorm.weight"], sd["embeddings.LayerNorm.bias"], cfg.ln_eps)
+    add_mask = (1.0 - attention_mask[:, None, None, :].to(x.dtype)) * torch.finfo(x.dtype).min
+    pos = torch.arange(S, dtype=torch.long)
+    bucket = mpnet_relative_position_bucket(pos[None, :] - pos[:, None])                 # memory - context = key - query
+    bias = sd["encoder.relative_attention_bias.weight"][bucket].permute(2, 0, 1)[None]    # [1, H, S(query), S(key)]
+    hd = W // H
+    for i in range(cfg.layers):
+        p = f"encoder.layer.{i}."
+        q, k, v = (F.linear(x, sd[p + f"attention.attn.{n}.weight"], sd[p + f"attention.attn.{n}.bias"]).view(B, S, H, hd).transpose(1, 2)
+                   for n in ("q", "k", "v"))
+        s = (q @ k.transpose(-1, -2)) / math.sqrt(hd) + bias + add_mask
+        a = (torch.softmax(s, dim=-1) @ v).transpose(1, 2).reshape(B, S, W)
+        a = F.linear(a, sd[p + "attention.attn.o.weight"], sd[p + "attention.attn.o.bias"])
+        x = F.layer_norm(a + x, (W,), sd[p + "attention.LayerNorm.weight"], sd[p + "attention.LayerNorm.bias"], cfg.ln_eps)
+        h = F.gelu(F.linear(x, sd[p + "intermediate.dense.weight"], sd[p + "intermediate.dense.bias"]))
+        h = F.linear(h, sd[p + "output.dense.weight"], sd[p + "output.dense.bias"])
+        x = F.layer_norm(h + x, (W,), sd[p + "output.LayerNorm.weight"], sd[p + "output.LayerNorm.bias"], cfg.ln_eps)
+    return x
+
+
+def synthetic_mpnet_state_dict(cfg: BertConfig, seed: int = 0) -> Dict[str, Tensor]:
+    """seeded weights in the MPNetModel checkpoint naming (biases / LayerNorm perturbed off their init so a dropped term cannot pass)"""
+    g = torch.Generator().manual_seed(seed)
+    W, F_ = cfg.width, cfg.mlp_dim
+    rn = lambda *shape, std=0.02: torch.randn(*shape, generator=g) * std
+    sd = {"embeddings.word_embeddings.weight": rn(cfg.vocab, W, std=0.05),
+          "embeddings.position_embeddings.weight": rn(cfg.max_pos + cfg.pos_offset, W, std=0.05),
+          "embeddings.LayerNorm.weight": 1 + rn(W, std=0.1), "embeddings.LayerNorm.bias": rn(W, std=0.1),
+          "encoder.relative_attention_bias.weight": rn(MPNET_REL_BUCKETS, cfg.heads, std=0.5)}
+    for i in range(cfg.layers):
+        p = f"encoder.layer.{i}."
+        for n in ("q", "k", "v", "o"):
+            sd[p + f"attention.attn.{n}.weight"], sd[p + f"attention.attn.{n}.bias"] = rn(W, W, std=0.06), rn(W, std=0.1)
+        sd[p + "attention.LayerNorm.weight"], sd[p + "attention.LayerNorm.bias"] = 1 + rn(W, std=0.1), rn(W, std=0.1)
+        sd[p + "intermediate.dense.weight"], sd[p + "intermediate.dense.bias"] = rn(F_, W, std=0.06), rn(F_, std=0.1)
+        sd[p + "output.dense.weight"], sd[p + "output.dense.bias"] = rn(W, F_, std=0.06), rn(W, std=0.1)
+        sd[p + "output.LayerNorm.weight"], sd[p + "output.LayerNorm.bias"] = 1 + rn(W, std=0.1), rn(W, std=0.1)
+    return sd
+
+
 @dataclass
 class NewModelConfig:
     """Alibaba-NLP/new-impl `NewModel` (custom remote code: the reference's hf_stella loader runs it through AutoModel with
@@ -403,7 +472,8 @@ def synthetic_new_model_state_dict(cfg: NewModelConfig, seed: int = 0) -> Dict[s
 def hf_encode(sd: Dict[str, Tensor], cfg: BertConfig, ids: Tensor, attention_mask: Tensor,
               normalize: bool = True) -> Tensor:
     """HuggingFaceModel.encode after tokenisation (hugging_face_model.py:187-197)."""
-    last = bert_forward(sd, cfg, ids, attention_mask)
+    mpnet = "encoder.relative_attention_bias.weight" in sd
+    last = (mpnet_forward if mpnet else bert_forward)(sd, cfg, ids, attention_mask)
     if cfg.pooling == "mean":  # _average_pool_func :205-209
         last = last.masked_fill(~attention_mask[..., None].bool(), 0.0)
         emb = last.sum(dim=1) / attention_mask.sum(dim=1)[..., None]

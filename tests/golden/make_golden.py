@@ -79,6 +79,40 @@ def make_bert(heads=2, name="bert_small.npz"):
                         **{"w:" + k: v for k, v in _np(sd).items()})
 
 
+def make_mpnet():
+    """transformers.MPNetModel == what HuggingFaceModel loads through AutoModel for hf/all-mpnet-base-v1 / -v2 and the flax
+    all_datasets_v{3,4}_mpnet-base entries: post-LN encoder, no token types, position ids offset by 2, one relative-position bias
+    table shared by all layers.  Sequences up to 200 tokens so that the log-spaced buckets beyond the exact range (|d| >= 8) and the
+    clamp at max_distance = 128 are all exercised."""
+    from transformers import MPNetConfig, MPNetModel
+    torch.manual_seed(0)
+    cfg = MPNetConfig(vocab_size=300, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                      max_position_embeddings=258, layer_norm_eps=1e-5, hidden_act="gelu", hidden_dropout_prob=0.0,
+                      attention_probs_dropout_prob=0.0, relative_attention_num_buckets=32, pad_token_id=1, bos_token_id=0, eos_token_id=2)
+    m = MPNetModel(cfg).eval()
+    _jitter(m, 5)
+    with torch.no_grad():
+        m.encoder.relative_attention_bias.weight.mul_(10.0)   # (a bias the softmax can feel: dropping it must fail the parity tests)
+    g = torch.Generator().manual_seed(6)
+    lens = [5, 17, 2, 33, 200, 9, 130]
+    S = max(lens)
+    ids = torch.ones(len(lens), S, dtype=torch.int64)          # pad id 1
+    mask = torch.zeros(len(lens), S, dtype=torch.int64)
+    for i, L in enumerate(lens):
+        ids[i, :L] = torch.randint(4, 300, (L,), generator=g)
+        ids[i, 0], ids[i, L - 1] = 0, 2
+        mask[i, :L] = 1
+    with torch.no_grad():
+        last = m(input_ids=ids, attention_mask=mask).last_hidden_state
+    lh = last.masked_fill(~mask[..., None].bool(), 0.0)
+    mean = lh.sum(1) / mask.sum(1)[..., None]
+    sd = {k: v for k, v in m.state_dict().items() if not k.startswith("pooler.") and not k.endswith("position_ids")}
+    np.savez_compressed(os.path.join(HERE, "mpnet_small.npz"), ids=ids.numpy(), mask=mask.numpy(), last_hidden=last.numpy(),
+                        mean=mean.numpy(), mean_norm=torch.nn.functional.normalize(mean, p=2, dim=1).numpy(),
+                        cfg=np.array([300, 256, 128, 2, 2, 256], dtype=np.int64),   # vocab, usable positions, W, layers, heads, F
+                        **{"w:" + k: v for k, v in _np(sd).items()})
+
+
 def make_xlmr():
     """transformers.XLMRobertaModel == what HuggingFaceModel loads through AutoModel for the multilingual-e5 family:
     BERT encoder, position ids offset by padding_idx + 1 = 2, one token type."""
@@ -260,6 +294,7 @@ if __name__ == "__main__":
     make_bert()
     make_bert(heads=4, name="bert_small_h32.npz")  # 32-wide heads (e5-small / bge-small / MiniLM class)
     make_xlmr()
+    make_mpnet()
     make_clip_vit()
     make_clip_text()
     make_siglip()

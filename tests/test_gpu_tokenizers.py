@@ -90,6 +90,16 @@ def _host_clip(lib, tok, texts, ctx):
     return ids, lens, status
 
 
+def test_scope_routing_follows_the_vocabularys_own_specials():
+    """special-token spellings go to the host tokeniser whatever they look like: MPNet's <s> / </s> / <mask> as well as BERT's [SEP]"""
+    from tests.test_tokenizers import _bert_vocab
+    toks = ["<s>", "<pad>", "</s>", "<unk>"] + [t for t in _bert_vocab() if t not in ("[PAD]", "[CLS]", "[SEP]", "[MASK]")] + ["<mask>"]
+    mp = WordPieceTokenizer({t: i for i, t in enumerate(toks)}, unk="[UNK]", cls="<s>", sep="</s>", pad="<pad>", mask="<mask>")
+    assert GT.wordpiece_in_scope(mp, "the fox < the dog > [x]") and GT.wordpiece_in_scope(mp, "plain text")
+    for s in ("the fox </s> the dog", "<s> again", "a <mask> b", "an [UNK] word", "<pad>"):
+        assert not GT.wordpiece_in_scope(mp, s), s
+
+
 def test_scope_routing(bert_tok, clip_tok):
     """host-side routing: only special-token spellings, `&` (CLIP: html.unescape), un-encodable and huge texts skip the device"""
     assert GT.wordpiece_in_scope(bert_tok, "plain ascii, with punct!") and GT.clip_in_scope(clip_tok, "plain ascii <b> 'quoted'")

@@ -175,3 +175,41 @@ def test_attention(lib, lens, heads, causal, hd):
             assert torch.equal(out2, out), nw
     finally:
         L.check(lib.mq_tune(b"attn_waves", 0))
+
+
+@pytest.mark.parametrize("lens,heads", [([50] * 4, 12), ([5, 77, 1, 33, 64, 65], 12), ([200, 129, 17], 2), ([512], 3)])
+def test_attention_with_relative_position_bias(lib, lens, heads):
+    """mq_attention_bias: scores / sqrt(d) + bias[h][key - query] before the softmax (MPNet), the table pre-multiplied by sqrt(d)"""
+    from marqo_amd import _lib as L
+    g = torch.Generator(device="cuda").manual_seed(7)
+    hd, W, rows, span = 64, heads * 64, sum(lens), 512
+    qkv = torch.randn(rows, 3 * W, device="cuda", generator=g).to(torch.bfloat16)
+    bias = torch.randn(heads, 2 * span - 1, device="cuda", generator=g) * 2.0
+    ref = torch.empty(rows, W, device="cuda")
+    r0 = 0
+    for ln in lens:
+        blk = qkv[r0:r0 + ln].float()
+        q, k, v = [t.reshape(ln, heads, hd).transpose(0, 1) for t in blk.split(W, dim=1)]
+        pos = torch.arange(ln, device="cuda")
+        b = bias[:, (pos[None, :] - pos[:, None]) + span - 1]          # [H, q, k]
+        p = torch.softmax(q @ k.transpose(1, 2) / hd ** 0.5 + b, dim=-1)
+        ref[r0:r0 + ln] = (p @ v).transpose(0, 1).reshape(ln, W)
+        r0 += ln
+    out = torch.empty(rows, W, device="cuda", dtype=torch.bfloat16)
+    fixed = lens[0] if len(set(lens)) == 1 else 0
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), device="cuda", dtype=torch.int32)
+    table = (bias * hd ** 0.5).contiguous()
+    L.check(lib.mq_attention_bias(qkv.data_ptr(), out.data_ptr(), 0 if fixed else cu.data_ptr(), len(lens), fixed, max(lens), W, heads,
+                                  table.data_ptr(), span, _stream()))
+    torch.cuda.synchronize()
+    assert (out.float() - ref).abs().max().item() < 2e-2
+    plain = torch.empty_like(out)
+    L.check(lib.mq_attention(qkv.data_ptr(), plain.data_ptr(), 0 if fixed else cu.data_ptr(), len(lens), fixed, max(lens), W, heads,
+                             L.MQ_MASK_NONE, _stream()))
+    zero = torch.zeros_like(table)
+    L.check(lib.mq_attention_bias(qkv.data_ptr(), out.data_ptr(), 0 if fixed else cu.data_ptr(), len(lens), fixed, max(lens), W, heads,
+                                  zero.data_ptr(), span, _stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(out, plain)                                   # a zero table is exactly the plain kernel
+    assert lib.mq_attention_bias(qkv.data_ptr(), out.data_ptr(), 0 if fixed else cu.data_ptr(), len(lens), fixed, max(lens), W, heads,
+                                 table.data_ptr(), max(lens) - 1, _stream()) == -1   # rel_span must cover the longest sequence

@@ -96,6 +96,36 @@ def test_xlm_roberta_matches_transformers():
     assert np.abs(O.bert_forward(sd, cfg, ids, mask).numpy() - z["last_hidden"])[mask.bool().numpy()].max() > 1e-2  # the offset matters
 
 
+def test_mpnet_matches_transformers():
+    """hf/all-mpnet-base-* family: transformers.MPNetModel = post-LN encoder, no token types, position ids from 2, one relative-position
+    bias table shared by all layers (sequences up to 200 tokens: every bucket class, incl. the clamp at max_distance, is exercised)"""
+    sd, z = G.load("mpnet_small")
+    V, P, W, L, H, F = [int(v) for v in z["cfg"]]
+    ids, mask = torch.from_numpy(z["ids"]), torch.from_numpy(z["mask"])
+    cfg = O.BertConfig(vocab=V, max_pos=P, width=W, layers=L, heads=H, mlp_dim=F, ln_eps=1e-5, pooling="mean", pos_offset=2)
+    last = O.mpnet_forward(sd, cfg, ids, mask)
+    assert np.abs(last.numpy() - z["last_hidden"])[mask.bool().numpy()].max() < TOL
+    assert np.abs(O.hf_encode(sd, cfg, ids, mask, normalize=False).numpy() - z["mean"]).max() < TOL
+    assert np.abs(O.hf_encode(sd, cfg, ids, mask, normalize=True).numpy() - z["mean_norm"]).max() < TOL
+    nobias = dict(sd)
+    nobias["encoder.relative_attention_bias.weight"] = torch.zeros_like(sd["encoder.relative_attention_bias.weight"])
+    assert np.abs(O.mpnet_forward(nobias, cfg, ids, mask).numpy() - z["last_hidden"])[mask.bool().numpy()].max() > 1e-1  # the bias matters
+
+
+def test_mpnet_bias_table_of_the_engine_matches_the_oracle_buckets():
+    """the [heads, 2 * span - 1] table the attention kernel indexes by (key - query) == MPNet's bucketed bias, times sqrt(head dim)"""
+    from marqo_amd.engine.archs import BertArch
+    arch = BertArch(vocab=300, max_pos=300, width=128, layers=1, heads=2, mlp_dim=256, pos_offset=2, type_vocab=0, rel_buckets=32)
+    w = torch.randn(32, 2, generator=torch.Generator().manual_seed(0))
+    table = arch.rel_bias_table(w)
+    assert table.shape == (2, 599)
+    pos = torch.arange(300)
+    rel = pos[None, :] - pos[:, None]                                   # key - query
+    want = w[O.mpnet_relative_position_bucket(rel)].permute(2, 0, 1)    # [H, q, k]
+    got = table[:, rel + 299] / 8.0
+    assert torch.equal(got, want)
+
+
 def test_bert_with_32_wide_heads_matches_transformers():
     """e5-small / bge-small / MiniLM class: 32-wide attention heads"""
     sd, z = G.load("bert_small_h32")

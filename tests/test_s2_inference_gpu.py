@@ -243,6 +243,42 @@ def test_hf_xlm_roberta_from_disk(s2, tmp_path):
     assert type(model._device_tokenizer).__name__ == "DeviceSentencePieceTokenizer"   # the unigram Viterbi runs on the GPU (K14)
 
 
+def test_mpnet_from_disk(s2, tmp_path):
+    """An MPNet checkpoint (the hf/all-mpnet-base-* registry family) through the 'hf' loader: config.json model_type 'mpnet', MPNetModel
+    tensor names under the `mpnet.` task prefix, vocab.txt with <s> / <pad> / </s> specials -> WordPiece between <s> and </s> (on the
+    device: K14), positions from 2, the relative-position bias inside the attention kernel — against the fp32 oracle on the ids
+    transformers' own MPNetTokenizer produces"""
+    s2i, root = s2
+    from safetensors.torch import save_file
+    from transformers import MPNetTokenizer
+    from tests.test_tokenizers import _bert_vocab
+    d = root / "hf" / "acme" / "tiny-mpnet"
+    d.mkdir(parents=True, exist_ok=True)
+    toks = ["<s>", "<pad>", "</s>", "<unk>"] + [t for t in _bert_vocab() if t not in ("[PAD]", "[CLS]", "[SEP]", "[MASK]")] + ["<mask>"]
+    (d / "vocab.txt").write_text("\n".join(toks) + "\n", encoding="utf-8")
+    (d / "tokenizer_config.json").write_text(json.dumps({"do_lower_case": True, "cls_token": "<s>", "sep_token": "</s>", "pad_token": "<pad>",
+                                                         "unk_token": "[UNK]", "mask_token": "<mask>"}))
+    cfg = O.BertConfig(vocab=len(toks), max_pos=64, width=128, layers=2, heads=2, mlp_dim=256, ln_eps=1e-5, pos_offset=2)
+    sd = O.synthetic_mpnet_state_dict(cfg, seed=8)
+    save_file({"mpnet." + k: v.contiguous() for k, v in sd.items()}, str(d / "model.safetensors"))
+    (d / "config.json").write_text(json.dumps({"model_type": "mpnet", "vocab_size": len(toks), "max_position_embeddings": 66, "hidden_size": 128,
+                                               "num_hidden_layers": 2, "num_attention_heads": 2, "intermediate_size": 256, "hidden_act": "gelu",
+                                               "layer_norm_eps": 1e-5, "pad_token_id": 1, "relative_attention_num_buckets": 32}))
+    props = {"name": "acme/tiny-mpnet", "dimensions": 128, "tokens": 32, "type": "hf"}
+    texts = ["query: how much protein should a female eat", "the quick brown fox jumps over the lazy dog", "naive cafe uber", "fox",
+             "the fox </s> the dog"]
+    out = s2i.vectorise("tiny-mpnet", texts, model_properties=props, device=DEV)
+    hf = MPNetTokenizer(str(d / "vocab.txt"), do_lower_case=True)
+    t = hf(texts, padding=True, truncation=True, max_length=32, return_tensors="pt")
+    ref = O.hf_encode(sd, cfg, t["input_ids"], t["attention_mask"]).numpy()
+    assert np.asarray(out).shape == (5, 128) and _cos_err(out, ref) < COS_TOL
+    model = s2i.get_available_models()[s2i._create_model_cache_key("tiny-mpnet", DEV, props)]["model"]
+    assert model.arch.rel_buckets == 32 and model.arch.pos_offset == 2 and model._tokenizer.cls == "<s>"
+    assert type(model._device_tokenizer).__name__ == "DeviceWordPieceTokenizer"
+    one = s2i.vectorise("tiny-mpnet", texts[1], model_properties=props, device=DEV)       # the single-query route
+    assert _cos_err(one, ref[1:2]) < COS_TOL
+
+
 def test_siglip_from_disk_text_and_image(s2, tmp_path, monkeypatch):
     """A SigLIP checkpoint through the loader: open_clip / timm tensor names (visual.trunk.*, text.*), SentencePiece tokenizer with
     canonicalize, SigLIP preprocessing (squash to S x S, mean = std = 0.5), 'open_clip' loader type — against the fp32 oracle.

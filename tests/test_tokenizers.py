@@ -139,6 +139,29 @@ def test_wordpiece_special_tokens_in_text(bert_pair):
     assert ours.encode(s) == hf(s)["input_ids"]
 
 
+def test_mpnet_wordpiece_matches_transformers():
+    """MPNetTokenizer (hf/all-mpnet-base-*): BERT's basic + WordPiece tokenisation between <s> and </s>, [UNK] for unknown words"""
+    from transformers import MPNetTokenizer
+    base = [t for t in _bert_vocab() if t not in ("[PAD]", "[CLS]", "[SEP]", "[MASK]")]
+    toks = ["<s>", "<pad>", "</s>", "<unk>"] + base + ["<mask>"]
+    vocab = {t: i for i, t in enumerate(toks)}
+    import os, tempfile
+    with tempfile.TemporaryDirectory() as d:
+        with open(os.path.join(d, "vocab.txt"), "w", encoding="utf-8") as f:
+            f.write("\n".join(toks) + "\n")
+        hf = MPNetTokenizer(os.path.join(d, "vocab.txt"), do_lower_case=True)
+        ours = WordPieceTokenizer(vocab, do_lower_case=True, unk="[UNK]", cls="<s>", sep="</s>", pad="<pad>", mask="<mask>")
+        assert (ours.cls_id, ours.pad_id, ours.sep_id) == (0, 1, 2)
+        for s in SENTENCES:
+            assert ours.encode(s, max_length=128) == hf(s, truncation=True, max_length=128)["input_ids"], s
+        batch = [s for s in SENTENCES if s]
+        ref = hf(batch, padding=True, truncation=True, max_length=16, return_tensors="np")
+        got = ours(batch, max_length=16)
+        assert np.array_equal(got["input_ids"], ref["input_ids"]) and np.array_equal(got["attention_mask"], ref["attention_mask"])
+        s = "the fox </s> the dog <mask>"
+        assert ours.encode(s) == hf(s)["input_ids"]
+
+
 def test_synthetic_tokenizer_shapes():
     t = SyntheticTokenizer("clip", 49408)
     out = t(["a b c", "d"])

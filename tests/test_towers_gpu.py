@@ -268,6 +268,32 @@ def test_golden_xlm_roberta_small():
     assert _cos_err(wrong.encode_ids(ids, mask, normalize=False), torch.from_numpy(z["mean"])) > 10 * COS_TIGHT  # the offset is honoured
 
 
+def test_golden_mpnet_small():
+    """hf/all-mpnet-base-* family (transformers.MPNetModel): the BERT tower with MPNet's checkpoint naming, no token types, positions from
+    2 and the relative-position bias added to the attention scores inside the kernel (attention_kernel<..., BIAS>): batched rows of up
+    to 200 tokens (8-wave form), a short batch (4-wave form) and the single-query route, against the transformers golden"""
+    T, A = _towers()
+    sd, z = G.load("mpnet_small")
+    V, P, W, L_, H, F = [int(v) for v in z["cfg"]]
+    ids, mask = torch.from_numpy(z["ids"]), torch.from_numpy(z["mask"])
+    arch = A.BertArch(vocab=V, max_pos=P, width=W, layers=L_, heads=H, mlp_dim=F, ln_eps=1e-5, pos_offset=2, type_vocab=0, rel_buckets=32)
+    tower = T.BertTower(arch, sd, "cuda", pooling="mean")
+    assert _cos_err(tower.encode_ids(ids, mask, normalize=False), torch.from_numpy(z["mean"])) < COS_TIGHT
+    assert _cos_err(tower.encode_ids(ids, mask, normalize=True), torch.from_numpy(z["mean_norm"])) < COS_TIGHT
+    short = [0, 1, 2, 3, 5]                                     # rows of <= 33 tokens
+    out = tower.encode_ids(ids[short, :33], mask[short, :33])
+    assert _cos_err(out, torch.from_numpy(z["mean_norm"])[short]) < COS_TIGHT
+    for r in (1, 4):                                            # one query per call (skinny GEMMs, graph replay): 17 and 200 tokens
+        n = int(mask[r].sum())
+        one = tower.encode_ids(ids[r:r + 1, :n], mask[r:r + 1, :n])
+        assert _cos_err(one, torch.from_numpy(z["mean_norm"])[r:r + 1]) < COS_TIGHT
+        assert _cos_err(tower.encode_ids(ids[r:r + 1, :n], mask[r:r + 1, :n]), torch.from_numpy(z["mean_norm"])[r:r + 1]) < COS_TIGHT
+    nobias = dict(sd)
+    nobias["encoder.relative_attention_bias.weight"] = torch.zeros_like(sd["encoder.relative_attention_bias.weight"])
+    wrong = T.BertTower(arch, nobias, "cuda", pooling="mean")
+    assert _cos_err(wrong.encode_ids(ids, mask, normalize=False), torch.from_numpy(z["mean"])) > 5 * COS_TIGHT    # the bias is honoured
+
+
 def test_golden_bert_32_wide_heads():
     """12-heads-of-32 checkpoints (e5-small, bge-small, MiniLM) run on the 64-wide attention kernel through zero-padded heads
     (engine/towers.py::_pad_heads); bf16 and fp8, mean and CLS pooling, against the transformers golden"""
