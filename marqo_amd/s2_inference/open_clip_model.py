@@ -97,6 +97,7 @@ class OpenCLIPModelProperties:
         return dict(self.__dict__)
 
 
+STAGE_BYTES = int(os.environ.get("MARQO_AMD_IMAGE_STAGE_BYTES", str(1 << 30)))   # decoded pixel bytes staged per resize call (pinned host + HBM)
 PIPELINE_CHUNK = int(os.environ.get("MARQO_AMD_IMAGE_PIPELINE_CHUNK", "512"))  # images per host-pack / GPU-encode pipeline stage (smaller chunks cost GEMM efficiency: 64-image chunks ran 256 images in 5.5 ms instead of 3.2, profiles/r02g_e2e_profile.txt)
 
 
@@ -292,9 +293,23 @@ class OPEN_CLIP(AbstractCLIPModel):
         return pre.to_tensor_normalize(u8)[0]
 
     def _resize(self, pre, raw) -> torch.Tensor:
-        """list of uint8 [H, W, 3] -> uint8 [n, S, S, 3] on the device: Resize(S) + CenterCrop(S), or Resize((S, S)) ('squash')"""
+        """list of uint8 [H, W, 3] -> uint8 [n, S, S, 3] on the device: Resize(S) + CenterCrop(S), or Resize((S, S)) ('squash').
+        The decoded pixels are staged (pinned host buffer + HBM copy) in groups of at most STAGE_BYTES, so a request of thousands of
+        multi-megapixel images cannot pin tens of GB at once; the resized outputs (S x S x 3 bytes each) are what accumulates."""
         S = self.vision_arch.image_size
-        return pre.resize_u8(raw, S, S, self._interpolation) if self._resize_mode == "squash" else pre.resize_crop_u8(raw)
+        run = (lambda g: pre.resize_u8(g, S, S, self._interpolation)) if self._resize_mode == "squash" else pre.resize_crop_u8
+        groups, cur, cur_bytes = [], [], 0
+        for img in raw:
+            nbytes = int(img.shape[0]) * int(img.shape[1]) * 4
+            if cur and cur_bytes + nbytes > STAGE_BYTES:
+                groups.append(cur)
+                cur, cur_bytes = [], 0
+            cur.append(img)
+            cur_bytes += nbytes
+        if len(groups) == 0:
+            return run(raw)
+        groups.append(cur)
+        return torch.cat([run(g) for g in groups])
 
     def _preprocess_images(self, images, image_download_headers: Optional[Dict] = None):
         """-> ('u8', uint8 [n,S,S,3]) or ('f32', fp32 [n,3,S,S]) on the device."""

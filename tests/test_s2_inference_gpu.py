@@ -363,3 +363,30 @@ def test_large_image_call_is_pipelined_in_chunks(s2, monkeypatch):
     chunked = model.encode_image(imgs)
     assert chunked.shape == whole.shape and _cos_err(chunked, whole) < 3e-5      # (8-image chunks of 17 tokens cross GEMM kernel families)
     assert tuple(model.image_input_processed.shape) == (37, 64, 64, 3)
+
+
+def test_image_staging_is_bounded_by_bytes(s2, monkeypatch):
+    """MARQO_AMD_IMAGE_STAGE_BYTES bounds the pinned / HBM staging of decoded pixels — a call whose images exceed the budget is
+    resized in several groups (same pixels, same order, image modes mixed), not packed in one buffer"""
+    s2i, root = s2
+    props, sd, vcfg, _ = _tiny_clip(root)
+    from marqo_amd.engine import preprocess as P
+    from marqo_amd.s2_inference import open_clip_model as M
+    rng = np.random.default_rng(6)
+    arrs = [rng.integers(0, 256, (90 + (i % 4) * 30, 120 + (i % 3) * 25, 4), dtype=np.uint8) for i in range(21)]
+    imgs = [Image.fromarray(a, "RGBA") if i % 3 == 0 else Image.fromarray(np.ascontiguousarray(a[..., :3])) for i, a in enumerate(arrs)]
+    s2i.vectorise("tiny-clip", imgs[:2], model_properties=props, device=DEV, modality=s2i.Modality.IMAGE)
+    model = s2i.get_available_models()[s2i._create_model_cache_key("tiny-clip", DEV, props)]["model"]
+    whole = model.encode_image(imgs)
+    whole_px = model.image_input_processed.clone()
+    calls = []
+    real = P.PackedImages.__init__
+
+    def spy(self, images, device, channels=3):
+        calls.append(len(images))
+        real(self, images, device, channels)
+    monkeypatch.setattr(P.PackedImages, "__init__", spy)
+    monkeypatch.setattr(M, "STAGE_BYTES", 200_000)            # ~3 images per group
+    split = model.encode_image(imgs)
+    assert len(calls) >= 5 and sum(calls) == 21 and max(calls) <= 6
+    assert torch.equal(model.image_input_processed, whole_px) and _cos_err(split, whole) < 3e-5
