@@ -191,6 +191,12 @@ typedef struct mq_bert_weights {
     const float* type_emb;   /* fp32 [2, W] (row 0 is used: token_type_ids are all zero) */
     const float* emb_ln_g; const float* emb_ln_b;
     const mq_block_weights* blocks;
+    /* optional projection head on the pooled row (NULL: none) — open_clip's HFTextEncoder with proj "mlp" (the text tower of
+     * open_clip/xlm-roberta-base-ViT-B-32 and xlm-roberta-large-ViT-H-14): Linear(W, proj_hidden) -> GELU -> Linear(proj_hidden, out_dim),
+     * both without bias in open_clip (proj1_b: fp32 [proj_hidden], zeros then).  bf16 row-major [out_features, in_features]. */
+    const void*  proj1_w;
+    const float* proj1_b;
+    const void*  proj2_w;
 } mq_bert_weights;
 
 typedef struct mq_bert_cfg {
@@ -198,6 +204,8 @@ typedef struct mq_bert_cfg {
     int32_t vocab;
     int32_t max_pos;
     int32_t pool;     /* MQ_POOL_* */
+    int32_t proj_hidden; /* 0: no projection head, d_out is [nseq, W]; else multiples of 64 with out_dim: d_out is [nseq, out_dim] */
+    int32_t out_dim;
 } mq_bert_cfg;
 
 /* ---- library info ------------------------------------------------------------------ */

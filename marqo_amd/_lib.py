@@ -93,11 +93,13 @@ class ClipTextCfg(C.Structure):
 
 class BertWeights(C.Structure):
     _fields_ = [("word_emb", C.c_void_p), ("pos_emb", C.c_void_p), ("type_emb", C.c_void_p),
-                ("emb_ln_g", C.c_void_p), ("emb_ln_b", C.c_void_p), ("blocks", C.POINTER(BlockWeights))]
+                ("emb_ln_g", C.c_void_p), ("emb_ln_b", C.c_void_p), ("blocks", C.POINTER(BlockWeights)),
+                ("proj1_w", C.c_void_p), ("proj1_b", C.c_void_p), ("proj2_w", C.c_void_p)]
 
 
 class BertCfg(C.Structure):
-    _fields_ = [("enc", EncoderCfg), ("vocab", C.c_int32), ("max_pos", C.c_int32), ("pool", C.c_int32)]
+    _fields_ = [("enc", EncoderCfg), ("vocab", C.c_int32), ("max_pos", C.c_int32), ("pool", C.c_int32),
+                ("proj_hidden", C.c_int32), ("out_dim", C.c_int32)]
 
 
 class WordPieceVocab(C.Structure):

@@ -29,7 +29,7 @@ extern "C" int mq_rowquant_fp8(const float* d_x, void* d_out_fp8, float* d_row_s
 // layouts the ctypes binding (marqo_amd/_lib.py) and tests/test_abi.py assume
 static_assert(sizeof(mq_block_weights) == 26 * 8, "mq_block_weights layout");
 static_assert(sizeof(mq_encoder_cfg) == 88, "mq_encoder_cfg layout");
-static_assert(sizeof(mq_vit_cfg) == 136 && sizeof(mq_clip_text_cfg) == 104 && sizeof(mq_bert_cfg) == 104, "tower cfg layouts");
+static_assert(sizeof(mq_vit_cfg) == 136 && sizeof(mq_clip_text_cfg) == 104 && sizeof(mq_bert_cfg) == 112, "tower cfg layouts");
 static_assert(sizeof(mq_vit_weights) == 10 * 8 && sizeof(mq_map_head) == 11 * 8 && sizeof(mq_clip_text_weights) == 7 * 8, "tower weight layouts");
 
 // mq_tune("row_select", 0) runs the last block on every row (A/B and parity tests of the pooled-rows-only last block)
@@ -618,6 +618,10 @@ extern "C" int mq_encode_bert(const mq_bert_cfg* cfg, const mq_bert_weights* w, 
     MQ_TRY(check_encoder_cfg(&cfg->enc));
     MQ_CHECK_ARG(cfg->enc.post_ln == 1 && cfg->enc.mask == MQ_MASK_NONE, "mq_encode_bert: BERT is post-LN with full attention");
     MQ_CHECK_ARG(cfg->pool == MQ_POOL_MEAN || cfg->pool == MQ_POOL_CLS, "mq_encode_bert: bad pooling %d", cfg->pool);
+    if (cfg->proj_hidden)
+        MQ_CHECK_ARG(cfg->proj_hidden % 64 == 0 && cfg->proj_hidden <= 3 * cfg->enc.width && cfg->out_dim >= 4 && cfg->out_dim % 4 == 0 &&
+                     w->proj1_w && w->proj1_b && w->proj2_w,
+                     "mq_encode_bert: projection head needs proj_hidden %% 64 == 0 (<= 3 W), out_dim %% 4 == 0 and its three weight pointers");
     MQ_CHECK_ARG(w->word_emb && (w->pos_emb || cfg->enc.d_rope_inv_freq) && w->emb_ln_g && w->emb_ln_b, "mq_encode_bert: null weight pointer");
     if (nseq <= 0) return MQ_OK;
     MQ_CHECK_ARG(d_ids && d_cu_seqlens && h_cu_seqlens && d_workspace, "mq_encode_bert: null input / workspace");
@@ -638,6 +642,20 @@ extern "C" int mq_encode_bert(const mq_bert_cfg* cfg, const mq_bert_weights* w, 
     const int32_t* sel = cfg->pool == MQ_POOL_CLS ? d_cu_seqlens : nullptr;
     MQ_TRY(encoder_forward_impl(&cfg->enc, w->blocks, x, rows, d_cu_seqlens, nseq, 0, maxl, sel, sel ? nseq : 0, base + p.off_enc,
                                 workspace_bytes - p.off_enc, s));
-    MQ_TRY(mq_pool(x, d_cu_seqlens, nseq, d_out, W, cfg->pool, normalize, s));
+    if (!cfg->proj_hidden) {
+        MQ_TRY(mq_pool(x, d_cu_seqlens, nseq, d_out, W, cfg->pool, normalize, s));
+        return MQ_OK;
+    }
+    // projection head of open_clip's HFTextEncoder (pooler -> Linear -> GELU -> Linear, then the caller's L2 normalisation): the
+    // pooled rows go through two small GEMMs; their operands live in the encoder's scratch, which is free by now
+    float* pooled = (float*)(base + p.off_pool);
+    bf16_t* pb = (bf16_t*)(base + p.off_enc);
+    bf16_t* h1 = pb + (size_t)nseq * W;
+    MQ_TRY(mq_pool(x, d_cu_seqlens, nseq, pooled, W, cfg->pool, 0, s));
+    MQ_TRY(mq_cast_bf16(pooled, pb, (int64_t)nseq * W, s));
+    MQ_TRY(mq_gemm_bf16(pb, W, w->proj1_w, W, w->proj1_b, nullptr, h1, cfg->proj_hidden, nseq, cfg->proj_hidden, W, MQ_EPI_BIAS | MQ_EPI_GELU, s));
+    MQ_TRY(mq_gemm_bf16(h1, cfg->proj_hidden, w->proj2_w, cfg->proj_hidden, nullptr, nullptr, d_out, cfg->out_dim, nseq, cfg->out_dim,
+                        cfg->proj_hidden, MQ_EPI_OUT_F32, s));
+    if (normalize) MQ_TRY(mq_l2_normalize(d_out, d_out, nseq, cfg->out_dim, s));
     return MQ_OK;
 }

@@ -124,6 +124,35 @@ class BertArch:
         return self.layers * layer / 1e9
 
 
+@dataclass(frozen=True)
+class HfClipTextArch:
+    """open_clip's HFTextEncoder text tower (CustomTextCLIP checkpoints `text.transformer.*` + `text.proj.*`): a Hugging Face encoder
+    (XLM-RoBERTa here), masked-mean pooler, projection MLP Linear(W, hidden) -> GELU -> Linear(hidden, out_dim) without biases,
+    hidden = (W + out_dim) // 2 (open_clip hf_model.py: proj "mlp", pooler "mean_pooler").  Texts are tokenised by the HF tokenizer
+    padded to ctx = 77 with <pad>; attention mask = ids != pad_id."""
+    bert: "BertArch"
+    out_dim: int
+    ctx: int = 77
+    pad_id: int = 1
+    quick_gelu: bool = False   # (the towers' activation is the HF encoder's own GELU; kept so that resolve_open_clip can `replace` it)
+    causal: bool = False
+
+    @property
+    def proj_hidden(self) -> int:
+        return (self.bert.width + self.out_dim) // 2
+
+    @property
+    def vocab(self) -> int:
+        return self.bert.vocab
+
+    @property
+    def width(self) -> int:
+        return self.bert.width
+
+    def gflop_per_text(self, tokens: Optional[int] = None) -> float:
+        return self.bert.gflop_per_text(tokens or self.ctx) + 2 * (self.bert.width + self.out_dim) * self.proj_hidden / 1e9
+
+
 _TEXT_B = ClipTextArch(vocab=49408, ctx=77, width=512, layers=12, heads=8, mlp_dim=2048, out_dim=512)
 _TEXT_L = ClipTextArch(vocab=49408, ctx=77, width=768, layers=12, heads=12, mlp_dim=3072, out_dim=768)
 _TEXT_B_PLUS = ClipTextArch(vocab=49408, ctx=77, width=640, layers=12, heads=10, mlp_dim=2560, out_dim=640)
@@ -151,6 +180,10 @@ OPEN_CLIP_ARCHS = {
     "ViT-L-14-336": (VitArch(336, 14, 1024, 24, 16, 4096, 768), _TEXT_L),
     # 16 heads of 80 / 88 / 104: zero-padded to 96 / 96 / 112-wide heads at load (engine/towers.py::_pad_heads)
     "ViT-H-14": (VitArch(224, 14, 1280, 32, 16, 5120, 1024), _TEXT_H),
+    # multilingual CLIPs: the ViT towers above with an XLM-RoBERTa text tower (open_clip model configs xlm-roberta-base-ViT-B-32 /
+    # xlm-roberta-large-ViT-H-14; model_registry.py:262-273 in the reference)
+    "xlm-roberta-base-ViT-B-32": (VitArch(224, 32, 768, 12, 12, 3072, 512), "xlmr-base:512"),
+    "xlm-roberta-large-ViT-H-14": (VitArch(224, 14, 1280, 32, 16, 5120, 1024), "xlmr-large:1024"),
     "ViT-H-14-378": (VitArch(378, 14, 1280, 32, 16, 5120, 1024), _TEXT_H),  # 730 tokens: K / V stream through the LDS in pieces
     "ViT-g-14": (VitArch(224, 14, 1408, 40, 16, 6144, 1024), _TEXT_H),
     "ViT-bigG-14": (VitArch(224, 14, 1664, 48, 16, 8192, 1280), _TEXT_BIGG),
@@ -183,6 +216,12 @@ def resolve_open_clip(arch_name: str, pretrained: Optional[str] = None) -> Tuple
     if base not in OPEN_CLIP_ARCHS:
         raise KeyError(f"{arch_name}: {UNSUPPORTED_HINT}")
     v, t = OPEN_CLIP_ARCHS[base]
+    if isinstance(t, str):   # HF text tower: "xlmr-<size>:<out_dim>" (BertArch is defined further down)
+        size, out_dim = t.split(":")
+        xl = {"xlmr-base": BertArch(vocab=250002, max_pos=512, ln_eps=1e-5, pos_offset=2, type_vocab=1),
+              "xlmr-large": BertArch(vocab=250002, max_pos=512, width=1024, layers=24, heads=16, mlp_dim=4096, ln_eps=1e-5, pos_offset=2,
+                                     type_vocab=1)}[size]
+        t = HfClipTextArch(bert=xl, out_dim=int(out_dim))
     return replace(v, quick_gelu=quick), replace(t, quick_gelu=quick)
 
 

@@ -76,7 +76,17 @@ def random_open_clip_state_dict(vision: VitArch = None, text: ClipTextArch = Non
         _resblocks(sd, "visual.transformer.", vision.layers, W, vision.mlp_dim, g)
         _ln(sd, "visual.ln_post", W, g)
         sd["visual.proj"] = torch.randn(W, vision.out_dim, generator=g) / math.sqrt(W)
-    if text is not None:
+    if text is not None and hasattr(text, "bert"):
+        # open_clip HFTextEncoder (CustomTextCLIP): HF-named encoder under text.transformer.*, projection MLP under text.proj.{0,2}
+        for k, v in random_bert_state_dict(text.bert, seed=seed + 1).items():
+            sd["text.transformer." + k] = v
+        if text.bert.type_vocab == 1:
+            sd["text.transformer.embeddings.token_type_embeddings.weight"] = sd["text.transformer.embeddings.token_type_embeddings.weight"][:1].clone()
+        W, Hd = text.bert.width, text.proj_hidden
+        sd["text.proj.0.weight"] = torch.randn(Hd, W, generator=g) / math.sqrt(W)
+        sd["text.proj.2.weight"] = torch.randn(text.out_dim, Hd, generator=g) / math.sqrt(Hd)
+        sd["logit_scale"] = torch.tensor(math.log(1 / 0.07))
+    elif text is not None:
         W, px = text.width, text.prefix
         sd[px + "token_embedding.weight"] = 0.5 * torch.randn(text.vocab, W, generator=g)
         sd[px + "positional_embedding"] = 0.3 * torch.randn(text.ctx, W, generator=g)

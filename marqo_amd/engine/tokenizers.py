@@ -402,9 +402,13 @@ class SyntheticTokenizer:
     kind='bert': CLS ... SEP, padded to the longest, with a mask."""
 
     def __init__(self, kind: str, vocab_size: int, context_length: int = 77):
-        assert kind in ("clip", "bert", "siglip")
+        assert kind in ("clip", "bert", "siglip", "xlmr")
         self.kind, self.vocab_size, self.context_length = kind, vocab_size, context_length
         self._ids: Dict[str, int] = {}
+        if kind == "xlmr":   # XLM-RoBERTa framing (<s> 0 ... </s> 2, <pad> 1), otherwise the 'bert' behaviour
+            self.kind = "bert"
+            self.cls_id, self.sep_id, self.pad_id, self.lo, self.hi = 0, 2, 1, 4, vocab_size
+            return
         if kind == "clip":
             self.sot_id, self.eot_id, self.lo, self.hi = vocab_size - 2, vocab_size - 1, 1, vocab_size - 2
         elif kind == "siglip":

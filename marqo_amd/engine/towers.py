@@ -678,7 +678,7 @@ class _TextTowerBase(_TowerBase):
                 d_packed = torch.empty(n_tok, dtype=torch.int32, device=self.device)
                 cu = torch.tensor([0, n_tok], dtype=torch.int32)
                 d_cu = cu.to(self.device)
-                o = torch.empty(1, self.arch.out_dim if clip else self.arch.width, dtype=torch.float32, device=self.device)
+                o = torch.empty(1, self.arch.out_dim if clip else self.out_width, dtype=torch.float32, device=self.device)
                 keep, d_pool = [], None
                 if clip:
                     ws = torch.empty(self.lib.mq_clip_text_workspace_bytes(C.byref(self.cfg), n_tok, 1) + 256, dtype=torch.uint8, device=self.device)
@@ -707,7 +707,7 @@ class _TextTowerBase(_TowerBase):
             one = self._encode_one(d_ids[0, :int(lengths[0])], normalize, clip)
             if one is not None:
                 return one
-        out_dim = self.arch.out_dim if clip else self.arch.width
+        out_dim = self.arch.out_dim if clip else self.out_width
         out = torch.empty(n, out_dim, dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
             for a, b in self._chunks(lengths):
@@ -905,6 +905,11 @@ class BertTower(_TextTowerBase):
         if precision == "fp8":
             self._enable_fp8(self._blocks, arch.layers, W, F)
 
+    @property
+    def out_width(self) -> int:
+        """columns of the embeddings: the encoder width, or the projection head's out_dim (HfClipTextTower)"""
+        return int(self.cfg.out_dim) if self.cfg.proj_hidden else self.arch.width
+
     def calibration_batch(self, n: int = 32, seed: int = 0) -> Tuple[Tensor, Tensor]:
         """fixed, seeded calibration texts of the fp8 policy: (ids, attention_mask) int64 [n, S], lengths spread over 4 .. min(128, max_pos)"""
         a = self.arch
@@ -944,7 +949,7 @@ class BertTower(_TextTowerBase):
             one = self._encode_one(ids_h[0, :int(lengths[0])], normalize, clip=False)
             if one is not None:
                 return one
-        out = torch.empty(n, self.arch.width, dtype=torch.float32, device=self.device)
+        out = torch.empty(n, self.out_width, dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
             for a, b in self._chunks(lengths):
                 packed, cu = _pack(ids_h[a:b], lengths[a:b])
@@ -959,3 +964,39 @@ class BertTower(_TextTowerBase):
         """ids already on the device (engine/gpu_tokenizers.py): int32 [n, S] rows [CLS] ... [SEP] pad..., lengths int64 [n] on the
         host.  Same as encode_ids with the right-padded mask those lengths imply; packing runs on the GPU."""
         return self._encode_device(d_ids, lengths, self.arch.max_pos, normalize, clip=False)
+
+
+class HfClipTextTower(BertTower):
+    """Text tower of open_clip's CustomTextCLIP checkpoints with an HF encoder (open_clip/xlm-roberta-base-ViT-B-32,
+    xlm-roberta-large-ViT-H-14): `text.transformer.*` = the Hugging Face XLM-RoBERTa encoder (run by the BERT tower: post-LN, positions
+    from 2), open_clip's MeanPooler over the non-pad tokens, then `text.proj` = Linear -> GELU -> Linear (no biases) inside
+    mq_encode_bert (mq_bert_cfg.proj_hidden / out_dim); OPEN_CLIP.encode_text L2-normalises as for every CLIP."""
+
+    def __init__(self, arch, sd: Dict[str, Tensor], device: str, precision: str = "bf16"):
+        t = "text.transformer."
+        enc = {k[len(t):]: v for k, v in sd.items() if k.startswith(t)}
+        if not enc:
+            raise ValueError("checkpoint has no text.transformer.* tensors (an HF text tower was expected)")
+        super().__init__(arch.bert, enc, device, pooling="mean", precision=precision)
+        self.clip_arch = arch
+        W, Hd, D = arch.bert.width, arch.proj_hidden, arch.out_dim
+        h = self._h
+        # hidden units beyond Hd (zero-padded to the GEMMs' multiple of 64) are GELU(0) = 0 and meet zero columns of the second layer
+        Hp = _ceil64(Hd)
+        p1 = torch.zeros(Hp, W)
+        p1[:Hd] = _need(sd, "text.proj.0.weight", (Hd, W)).detach().float()
+        b1 = torch.zeros(Hp)
+        if "text.proj.0.bias" in sd:
+            b1[:Hd] = sd["text.proj.0.bias"].detach().float()
+        p2 = torch.zeros(D, Hp)
+        p2[:, :Hd] = _need(sd, "text.proj.2.weight", (D, Hd)).detach().float()
+        if "text.proj.2.bias" in sd:
+            raise ValueError("a biased second projection layer is not supported (open_clip builds text.proj without biases)")
+        self.w.proj1_w, self.w.proj1_b, self.w.proj2_w = h.bf16(p1), h.f32(b1), h.bf16(p2)
+        self.cfg.proj_hidden, self.cfg.out_dim = Hp, D
+
+    def encode_padded(self, ids: Tensor, normalize: bool = True) -> Tensor:
+        """ids int [n, <= ctx] padded with pad_id, as open_clip's HFTokenizer hands them over; attention mask = ids != pad_id
+        (hf_model.py HFTextEncoder.forward)"""
+        ids = ids.detach().to("cpu", torch.int64)
+        return self.encode_ids(ids, (ids != self.clip_arch.pad_id).to(torch.int64), normalize=normalize)

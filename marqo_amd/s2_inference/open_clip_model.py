@@ -24,7 +24,7 @@ from PIL.Image import Image as ImageType
 from marqo_amd import _lib as L
 from marqo_amd.engine import archs, checkpoint, synthetic
 from marqo_amd.engine.towers import request_stream
-from marqo_amd.engine.tokenizers import ClipBpeTokenizer, SiglipTokenizer, SyntheticTokenizer, WordPieceTokenizer
+from marqo_amd.engine.tokenizers import ClipBpeTokenizer, SiglipTokenizer, SyntheticTokenizer, WordPieceTokenizer, XlmRobertaTokenizer, _clean_text
 from marqo_amd.s2_inference.abstract_models import AbstractCLIPModel
 from marqo_amd.s2_inference.errors import InvalidModelPropertiesError, ModelLoadError
 from marqo_amd.s2_inference.image_input import format_and_load_CLIP_image, format_and_load_CLIP_images, pil_to_pixels, pil_to_rgb_u8
@@ -99,6 +99,27 @@ class OpenCLIPModelProperties:
 
 STAGE_BYTES = int(os.environ.get("MARQO_AMD_IMAGE_STAGE_BYTES", str(1 << 30)))   # decoded pixel bytes staged per resize call (pinned host + HBM)
 PIPELINE_CHUNK = int(os.environ.get("MARQO_AMD_IMAGE_PIPELINE_CHUNK", "512"))  # images per host-pack / GPU-encode pipeline stage (smaller chunks cost GEMM efficiency: 64-image chunks ran 256 images in 5.5 ms instead of 3.2, profiles/r02g_e2e_profile.txt)
+
+
+class HfClipTokenizer:
+    """open_clip's HFTokenizer (tokenizer.py: `clean_fn` = ftfy / html-unescape / whitespace clean, then the Hugging Face tokenizer with
+    max_length = context_length, padding = 'max_length', truncation = True -> input_ids): `hf` is the XLM-RoBERTa SentencePiece tokenizer
+    of record (engine/tokenizers.py), rows <s> pieces </s> padded to ctx with <pad>."""
+
+    def __init__(self, hf, context_length: int = 77):
+        self.hf, self.context_length = hf, context_length
+        self.pad_id = getattr(hf, "pad_id", 1)
+
+    def ids(self, cleaned_texts) -> np.ndarray:
+        out = np.full((len(cleaned_texts), self.context_length), self.pad_id, dtype=np.int64)
+        enc = self.hf(list(cleaned_texts), max_length=self.context_length)["input_ids"]
+        out[:, :enc.shape[1]] = enc
+        return out
+
+    def __call__(self, texts) -> np.ndarray:
+        if isinstance(texts, str):
+            texts = [texts]
+        return self.ids([_clean_text(t) for t in texts])
 
 
 class OPEN_CLIP(AbstractCLIPModel):
@@ -210,7 +231,10 @@ class OPEN_CLIP(AbstractCLIPModel):
                                   "interpolation": self._interpolation, "resize_mode": self._resize_mode}
         try:
             self.vision = towers.VitTower(self.vision_arch, sd, self.device, mean=self._mean, std=self._std, precision=props.engine_precision)
-            self.text = towers.ClipTextTower(self.text_arch, sd, self.device, precision=props.engine_precision)
+            if isinstance(self.text_arch, archs.HfClipTextArch):   # open_clip HFTextEncoder: XLM-RoBERTa encoder + mean pooler + projection MLP
+                self.text = towers.HfClipTextTower(self.text_arch, sd, self.device, precision=props.engine_precision)
+            else:
+                self.text = towers.ClipTextTower(self.text_arch, sd, self.device, precision=props.engine_precision)
         except ValueError as e:  # e.g. fp8 needs width / mlp_dim multiples of 128
             raise InvalidModelPropertiesError(str(e)) from e
         if props.engine_precision == "fp8":
@@ -225,6 +249,12 @@ class OPEN_CLIP(AbstractCLIPModel):
         if isinstance(self.tokenizer, ClipBpeTokenizer) and os.environ.get("MARQO_AMD_HOST_TOKENIZER", "0") != "1":
             from marqo_amd.engine.gpu_tokenizers import DeviceClipBpeTokenizer
             self._device_tokenizer = DeviceClipBpeTokenizer(self.tokenizer, self.device)
+        elif isinstance(self.tokenizer, HfClipTokenizer) and os.environ.get("MARQO_AMD_HOST_TOKENIZER", "0") != "1":
+            from marqo_amd.engine.gpu_tokenizers import DeviceSentencePieceTokenizer
+            try:
+                self._device_tokenizer = DeviceSentencePieceTokenizer(self.tokenizer.hf, self.device)
+            except ValueError:
+                self._device_tokenizer = None
         elif isinstance(self.tokenizer, SiglipTokenizer) and self.tokenizer._sp is not None and os.environ.get("MARQO_AMD_HOST_TOKENIZER", "0") != "1":
             from marqo_amd.engine.gpu_tokenizers import DeviceSentencePieceTokenizer
             try:
@@ -252,6 +282,17 @@ class OPEN_CLIP(AbstractCLIPModel):
                     out[i, :len(ids)] = ids
                 return out
             return hf_tok
+        if isinstance(self.text_arch, archs.HfClipTextArch):
+            # open_clip HFTokenizer(hf_tokenizer_name = xlm-roberta-base / -large): the SentencePiece model next to the checkpoint, or the HF
+            # repo of that name on disk
+            size = "large" if self.text_arch.bert.width == 1024 else "base"
+            for d in filter(None, (ckpt_dir, checkpoint.find_hf_dir(f"xlm-roberta-{size}"), checkpoint.find_hf_dir(f"FacebookAI/xlm-roberta-{size}"))):
+                if os.path.isfile(os.path.join(d, "sentencepiece.bpe.model")):
+                    return HfClipTokenizer(XlmRobertaTokenizer(d), self.text_arch.ctx)
+            if self.weights_source and str(self.weights_source).startswith("synthetic"):
+                return HfClipTokenizer(SyntheticTokenizer("xlmr", self.text_arch.vocab), self.text_arch.ctx)
+            raise ModelLoadError(f"XLM-RoBERTa tokenizer (sentencepiece.bpe.model) not found next to the checkpoint or under "
+                                 f"{os.path.join(checkpoint.model_dir(), 'hf', 'xlm-roberta-' + size)}")
         if not self.text_arch.causal:  # SigLIP: T5-style SentencePiece vocabulary next to the checkpoint (tokenizer.json / spiece.model)
             for d in filter(None, (ckpt_dir, os.path.join(checkpoint.model_dir(), "siglip"))):
                 if os.path.isfile(os.path.join(d, "tokenizer.json")) or os.path.isfile(os.path.join(d, "spiece.model")):
@@ -372,7 +413,14 @@ class OPEN_CLIP(AbstractCLIPModel):
         if self.model is None:
             self.load()
         with request_stream(self.device, device_output=return_device):
-            if getattr(self, "_device_tokenizer", None) is not None:
+            if isinstance(self.text_arch, archs.HfClipTextArch):
+                texts = [_clean_text(t) for t in ([sentence] if isinstance(sentence, str) else list(sentence))]
+                if getattr(self, "_device_tokenizer", None) is not None:
+                    d_ids, lens = self._device_tokenizer.encode_device(texts, self.text_arch.ctx)
+                    out = self.text.encode_device(d_ids, lens, normalize=bool(normalize))
+                else:
+                    out = self.text.encode_padded(torch.as_tensor(self.tokenizer.ids(texts)), normalize=bool(normalize))
+            elif getattr(self, "_device_tokenizer", None) is not None:
                 texts = [sentence] if isinstance(sentence, str) else list(sentence)
                 if self.text_arch.causal:
                     d_ids, lens = self._device_tokenizer.encode_device(texts)

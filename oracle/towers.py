@@ -366,6 +366,21 @@ def synthetic_mpnet_state_dict(cfg: BertConfig, seed: int = 0) -> Dict[str, Tens
     return sd
 
 
+def hf_clip_text_forward(sd: Dict[str, Tensor], cfg: BertConfig, ids: Tensor, pad_id: int = 1, normalize: bool = True) -> Tensor:
+    """Text tower of open_clip's CustomTextCLIP with an HF encoder (open_clip/xlm-roberta-base-ViT-B-32, xlm-roberta-large-ViT-H-14; the
+    reference calls it through `self.model.encode_text(text)` + its own normalisation, open_clip_model.py:268-286).  open_clip_torch
+    2.24.0 hf_model.py (third-party, un-vendored) HFTextEncoder.forward, restated: attention mask = ids != pad; the HF encoder
+    (`text.transformer.*`, XLM-RoBERTa = bert_forward with positions from 2); MeanPooler = sum of the masked last_hidden_state /
+    number of real tokens; `text.proj` = Linear(W, (W + D) // 2, bias=False) -> GELU -> Linear(., D, bias=False)."""
+    t = "text.transformer."
+    enc = {k[len(t):]: v for k, v in sd.items() if k.startswith(t)}
+    mask = (ids != pad_id).to(torch.int64)
+    last = bert_forward(enc, cfg, ids, mask)
+    pooled = (last * mask[..., None].to(last.dtype)).sum(dim=1) / mask.sum(dim=-1, keepdim=True)
+    out = F.linear(F.gelu(F.linear(pooled, sd["text.proj.0.weight"])), sd["text.proj.2.weight"])
+    return l2_normalize_clip(out) if normalize else out
+
+
 @dataclass
 class NewModelConfig:
     """Alibaba-NLP/new-impl `NewModel` (custom remote code: the reference's hf_stella loader runs it through AutoModel with

@@ -34,7 +34,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(L.VitCfg) == ENC + 3 * 4 + 6 * 4 + 2 * 4 + 4  # + tail padding to 8
     assert C.sizeof(L.VitWeights) == 10 * 8 and C.sizeof(L.MapHead) == 11 * 8
     assert C.sizeof(L.ClipTextCfg) == ENC + 3 * 4 + 4 and C.sizeof(L.ClipTextWeights) == 7 * 8
-    assert C.sizeof(L.BertCfg) == ENC + 3 * 4 + 4 and C.sizeof(L.BertWeights) == 6 * 8
+    assert C.sizeof(L.BertCfg) == ENC + 5 * 4 + 4 and C.sizeof(L.BertWeights) == 9 * 8   # + proj_hidden, out_dim / proj1_w, proj1_b, proj2_w
 
 
 def test_argument_errors_are_reported_without_a_gpu():

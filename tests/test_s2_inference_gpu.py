@@ -279,6 +279,58 @@ def test_mpnet_from_disk(s2, tmp_path):
     assert _cos_err(one, ref[1:2]) < COS_TOL
 
 
+def test_multilingual_clip_with_hf_text_tower_from_disk(s2, tmp_path, monkeypatch):
+    """open_clip CustomTextCLIP with an XLM-RoBERTa text tower (the open_clip/xlm-roberta-*-ViT-* registry family) through the 'open_clip'
+    loader: `visual.*` + `text.transformer.*` + `text.proj.*` tensors, the SentencePiece model next to the checkpoint, open_clip's
+    HFTokenizer semantics (clean, pad to ctx with <pad>), unigram Viterbi on the device — text and image against the fp32 oracle"""
+    s2i, root = s2
+    import sentencepiece as spm
+    from safetensors.torch import save_file
+    from marqo_amd.engine import archs as A
+    from marqo_amd.engine.tokenizers import XlmRobertaTokenizer
+    from tests.test_tokenizers import CORPUS, SENTENCES
+    S, P, W, Lyr, H, Fd, D, ctx = 64, 16, 128, 2, 2, 256, 64, 32
+    d = tmp_path / "tiny-xlmr-clip"
+    d.mkdir()
+    (d / "corpus.txt").write_text("\n".join([" ".join(CORPUS)] * 20 + SENTENCES[:6] * 5), encoding="utf-8")
+    spm.SentencePieceTrainer.train(input=str(d / "corpus.txt"), model_prefix=str(d / "sentencepiece.bpe"), vocab_size=120, model_type="unigram",
+                                   character_coverage=1.0, hard_vocab_limit=False, minloglevel=2)
+    tok = XlmRobertaTokenizer(str(d))
+    bert = A.BertArch(vocab=tok.vocab_size, max_pos=64, width=W, layers=Lyr, heads=H, mlp_dim=Fd, ln_eps=1e-5, pos_offset=2, type_vocab=1)
+    tarch = A.HfClipTextArch(bert=bert, out_dim=D, ctx=ctx)
+    vcfg = O.VitConfig(S, P, W, Lyr, H, Fd, D)
+    bcfg = O.BertConfig(vocab=tok.vocab_size, max_pos=66, width=W, layers=Lyr, heads=H, mlp_dim=Fd, ln_eps=1e-5, pos_offset=2)
+    sd = O.synthetic_vit_state_dict(vcfg, seed=3)
+    enc = O.synthetic_bert_state_dict(bcfg, seed=4)
+    enc["embeddings.token_type_embeddings.weight"] = enc["embeddings.token_type_embeddings.weight"][:1].clone()
+    sd.update({"text.transformer." + k: v for k, v in enc.items()})
+    g = torch.Generator().manual_seed(5)
+    sd["text.proj.0.weight"] = torch.randn(tarch.proj_hidden, W, generator=g) / W ** 0.5
+    sd["text.proj.2.weight"] = torch.randn(D, tarch.proj_hidden, generator=g) / tarch.proj_hidden ** 0.5
+    save_file({k: v.contiguous() for k, v in sd.items()}, str(d / "open_clip_model.safetensors"))
+    monkeypatch.setitem(A.OPEN_CLIP_ARCHS, "tiny-xlmr-ViT", (A.VitArch(S, P, W, Lyr, H, Fd, D), tarch))
+    props = {"name": "tiny-xlmr-ViT", "dimensions": D, "type": "open_clip", "localpath": str(d / "open_clip_model.safetensors")}
+    texts = ["A photo of a CAT!", "naïve café über straße", "東京 photos 2024", "fox " * 60, "Tom &amp; Jerry   together"]
+    out = np.asarray(s2i.vectorise("tiny-xlmr-clip", texts, model_properties=props, device=DEV))
+    from marqo_amd.engine.tokenizers import _clean_text
+    t = tok([_clean_text(x) for x in texts], max_length=ctx)
+    ids = np.full((len(texts), ctx), 1, dtype=np.int64)
+    ids[:, :t["input_ids"].shape[1]] = t["input_ids"]
+    ref = O.hf_clip_text_forward(sd, bcfg, torch.from_numpy(ids)).numpy()
+    assert out.shape == (5, D) and _cos_err(out, ref) < COS_TOL
+    model = s2i.get_available_models()[s2i._create_model_cache_key("tiny-xlmr-clip", DEV, props)]["model"]
+    assert type(model.text).__name__ == "HfClipTextTower" and type(model.tokenizer).__name__ == "HfClipTokenizer"
+    assert type(model._device_tokenizer).__name__ == "DeviceSentencePieceTokenizer"
+    assert np.array_equal(model.tokenizer(texts), ids)                      # open_clip HFTokenizer output: ids padded to ctx with <pad>
+    one = np.asarray(s2i.vectorise("tiny-xlmr-clip", texts[0], model_properties=props, device=DEV))
+    assert _cos_err(one, ref[:1]) < COS_TOL
+    rng = np.random.default_rng(2)
+    pil = [Image.fromarray(rng.integers(0, 256, (80, 100, 3), dtype=np.uint8)) for _ in range(3)]
+    img = np.asarray(s2i.vectorise("tiny-xlmr-clip", pil, model_properties=props, device=DEV, modality=s2i.Modality.IMAGE))
+    refi = O.vit_forward(sd, vcfg, torch.from_numpy(np.stack([OP.clip_transform(np.asarray(p), S) for p in pil]))).numpy()
+    assert _cos_err(img, refi) < COS_TOL
+
+
 def test_siglip_from_disk_text_and_image(s2, tmp_path, monkeypatch):
     """A SigLIP checkpoint through the loader: open_clip / timm tensor names (visual.trunk.*, text.*), SentencePiece tokenizer with
     canonicalize, SigLIP preprocessing (squash to S x S, mean = std = 0.5), 'open_clip' loader type — against the fp32 oracle.

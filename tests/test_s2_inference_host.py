@@ -514,6 +514,6 @@ def test_pil_pixels_zero_copy_view_matches_asarray():
     assert np.array_equal(r.view[..., :3] if isinstance(r, P.Rgbx) else r, np.asarray(lazy))
     for mode in ("L", "RGBA", "P", "CMYK"):
         im = Image.fromarray(rng.integers(0, 256, (8, 9, 3), dtype=np.uint8)).convert(mode)
-        r = pil_to_pixels(im)
-        got = r.view[..., :3] if isinstance(r, P.Rgbx) else r
+        r = pil_to_pixels(im)   # (palette sources arrive in the NEAREST-resize container; flatten_pixels is the plain RGB view of any container)
+        got = r.view[..., :3] if isinstance(r, P.Rgbx) else P.flatten_pixels(r)
         assert np.array_equal(got, pil_to_rgb_u8(im))

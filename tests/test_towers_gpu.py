@@ -268,6 +268,35 @@ def test_golden_xlm_roberta_small():
     assert _cos_err(wrong.encode_ids(ids, mask, normalize=False), torch.from_numpy(z["mean"])) > 10 * COS_TIGHT  # the offset is honoured
 
 
+def test_hf_text_tower_of_multilingual_clip():
+    """open_clip CustomTextCLIP with an HF text tower (open_clip/xlm-roberta-base-ViT-B-32, xlm-roberta-large-ViT-H-14): the XLM-RoBERTa
+    encoder of the transformers golden (`text.transformer.*`), open_clip's mean pooler over the non-pad tokens and the projection MLP
+    inside mq_encode_bert, against the oracle (whose encoder is pinned to transformers.XLMRobertaModel by the same fixture)"""
+    T, A = _towers()
+    sd0, z = G.load("xlmr_small")
+    V, P, W, L_, H, F = [int(v) for v in z["cfg"]]
+    D = 64
+    bert = A.BertArch(vocab=V, max_pos=P - 2, width=W, layers=L_, heads=H, mlp_dim=F, ln_eps=1e-5, pos_offset=2, type_vocab=1)
+    arch = A.HfClipTextArch(bert=bert, out_dim=D, ctx=64)
+    g = torch.Generator().manual_seed(12)
+    sd = {"text.transformer." + k: v for k, v in sd0.items()}
+    sd["text.proj.0.weight"] = torch.randn(arch.proj_hidden, W, generator=g) / W ** 0.5
+    sd["text.proj.2.weight"] = torch.randn(D, arch.proj_hidden, generator=g) / arch.proj_hidden ** 0.5
+    assert arch.proj_hidden == (W + D) // 2 == 96
+    ids = torch.from_numpy(z["ids"]).clone()
+    mask = torch.from_numpy(z["mask"])
+    assert int((ids[mask == 1] == 1).sum()) == 0          # (no real token equals the pad id)
+    ids[mask == 0] = 1                                     # open_clip's HFTokenizer pads with <pad> = 1
+    cfg = O.BertConfig(vocab=V, max_pos=P, width=W, layers=L_, heads=H, mlp_dim=F, ln_eps=1e-5, pooling="mean", pos_offset=2)
+    tower = T.HfClipTextTower(arch, sd, "cuda")
+    for normalize in (True, False):
+        ref = O.hf_clip_text_forward(sd, cfg, ids, pad_id=1, normalize=normalize)
+        assert _cos_err(tower.encode_padded(ids, normalize=normalize), ref) < COS_TIGHT
+    one = tower.encode_padded(ids[1:2])                    # single query: skinny GEMMs + graph replay, projection head included
+    assert one.shape == (1, D) and _cos_err(one, O.hf_clip_text_forward(sd, cfg, ids[1:2])) < COS_TIGHT
+    assert _cos_err(tower.encode_padded(ids[1:2]), O.hf_clip_text_forward(sd, cfg, ids[1:2])) < COS_TIGHT
+
+
 def test_golden_mpnet_small():
     """hf/all-mpnet-base-* family (transformers.MPNetModel): the BERT tower with MPNet's checkpoint naming, no token types, positions from
     2 and the relative-position bias added to the attention scores inside the kernel (attention_kernel<..., BIAS>): batched rows of up
