@@ -12,6 +12,7 @@ import os
 import re
 import subprocess
 import sys
+import sysconfig
 import threading
 from pathlib import Path
 
@@ -256,7 +257,8 @@ def build_torch_ops(force: bool = False, verbose: bool = False) -> Path:
     ti = Path(torch.__file__).resolve().parent
     rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
     cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
-           f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", f"-I{ti}/include", f"-I{ti}/include/torch/csrc/api/include",
+           f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", f"-I{sysconfig.get_paths()['include']}", f"-I{ti}/include",
+           f"-I{ti}/include/torch/csrc/api/include",
            f"-I{rocm}/include", str(TORCH_OPS_SRC), "-o", str(TORCH_OPS_PATH), f"-L{ti}/lib", "-ltorch", "-ltorch_cpu", "-lc10", "-lc10_hip",
            "-ltorch_hip", f"-L{LIB_DIR}", "-lmarqo_hip", "-Wl,-rpath,$ORIGIN", f"-Wl,-rpath,{ti}/lib"]
     if verbose:

@@ -14,6 +14,8 @@
 //
 // Built by marqo_amd/_lib.py::build_torch_ops() with g++ against the installed torch headers (host code only: nothing here is device
 // code, the kernels are in the .hip translation units).
+#include <Python.h>
+
 #include <ATen/ATen.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/library.h>
@@ -25,6 +27,16 @@ namespace {
 void* stream_of(const at::Tensor& t) {
     return (void*)c10::hip::getCurrentHIPStream(t.device().index()).stream();
 }
+
+// The tower ops enqueue ~100-800 kernel launches (0.5 - 2 ms of host time) and touch no Python object meanwhile: like the ctypes binding,
+// they run WITHOUT the GIL, so that concurrent request threads (the reference serves 8 + 8) can pack / tokenise while one thread enqueues.
+struct NoGil {
+    PyThreadState* st;
+    NoGil() : st(Py_IsInitialized() && PyGILState_Check() ? PyEval_SaveThread() : nullptr) {}
+    ~NoGil() { if (st) PyEval_RestoreThread(st); }
+    NoGil(const NoGil&) = delete;
+    NoGil& operator=(const NoGil&) = delete;
+};
 
 void check_rc(int rc, const char* what) {
     TORCH_CHECK(rc == MQ_OK, "marqo_hip::", what, " failed (", rc, "): ", mq_last_error());
@@ -50,6 +62,7 @@ void encode_image_u8(const at::Tensor& cfg, const at::Tensor& weights, const at:
     need_dev(out, at::kFloat, "out");
     need_dev(workspace, at::kByte, "workspace");
     TORCH_CHECK(pixels.dim() == 4 && out.dim() == 2 && out.size(0) == pixels.size(0), "marqo_hip::encode_image_u8: pixels [n,S,S,3], out [n,D]");
+    NoGil nogil;
     check_rc(mq_encode_image_u8(blob<mq_vit_cfg>(cfg, "mq_vit_cfg"), blob<mq_vit_weights>(weights, "mq_vit_weights"),
                                 (const uint8_t*)pixels.data_ptr(), pixels.size(0), (float*)out.data_ptr(), normalize ? 1 : 0,
                                 workspace.data_ptr(), (size_t)workspace.numel(), stream_of(pixels)), "encode_image_u8");
@@ -61,6 +74,7 @@ void encode_image_f32(const at::Tensor& cfg, const at::Tensor& weights, const at
     need_dev(out, at::kFloat, "out");
     need_dev(workspace, at::kByte, "workspace");
     TORCH_CHECK(pixels.dim() == 4 && out.dim() == 2 && out.size(0) == pixels.size(0), "marqo_hip::encode_image_f32: pixels [n,3,S,S], out [n,D]");
+    NoGil nogil;
     check_rc(mq_encode_image_f32(blob<mq_vit_cfg>(cfg, "mq_vit_cfg"), blob<mq_vit_weights>(weights, "mq_vit_weights"),
                                  (const float*)pixels.data_ptr(), pixels.size(0), (float*)out.data_ptr(), normalize ? 1 : 0,
                                  workspace.data_ptr(), (size_t)workspace.numel(), stream_of(pixels)), "encode_image_f32");
@@ -85,6 +99,7 @@ void encode_clip_text(const at::Tensor& cfg, const at::Tensor& weights, const at
         need_dev(*pool_rows, at::kInt, "pool_rows");
         pr = (const int32_t*)pool_rows->data_ptr();
     }
+    NoGil nogil;
     check_rc(mq_encode_clip_text(blob<mq_clip_text_cfg>(cfg, "mq_clip_text_cfg"), blob<mq_clip_text_weights>(weights, "mq_clip_text_weights"),
                                  (const int32_t*)ids.data_ptr(), (const int32_t*)cu.data_ptr(), (const int32_t*)cu_host.data_ptr(),
                                  cu.numel() - 1, pr, (float*)out.data_ptr(), normalize ? 1 : 0, workspace.data_ptr(),
@@ -95,6 +110,7 @@ void encode_bert(const at::Tensor& cfg, const at::Tensor& weights, const at::Ten
                  at::Tensor out, bool normalize, at::Tensor workspace) {
     check_packed(ids, cu, cu_host, out);
     need_dev(workspace, at::kByte, "workspace");
+    NoGil nogil;
     check_rc(mq_encode_bert(blob<mq_bert_cfg>(cfg, "mq_bert_cfg"), blob<mq_bert_weights>(weights, "mq_bert_weights"),
                             (const int32_t*)ids.data_ptr(), (const int32_t*)cu.data_ptr(), (const int32_t*)cu_host.data_ptr(),
                             cu.numel() - 1, (float*)out.data_ptr(), normalize ? 1 : 0, workspace.data_ptr(), (size_t)workspace.numel(),
@@ -113,6 +129,7 @@ void clip_resize_crop_u8(const at::Tensor& packed, const at::Tensor& offsets, co
                 widths.device().is_cpu() && widths.scalar_type() == at::kInt && widths.is_contiguous() && widths.numel() == n,
                 "marqo_hip::clip_resize_crop_u8: offsets int64 [n], heights / widths int32 [n] on the CPU (the resampling plan is host work)");
     TORCH_CHECK(out.dim() == 4 && out.size(0) == n && out.size(1) == S && out.size(2) == S && out.size(3) == 3, "marqo_hip::clip_resize_crop_u8: out uint8 [n,S,S,3]");
+    NoGil nogil;
     check_rc(mq_clip_resize_crop_u8((const uint8_t*)packed.data_ptr(), (const int64_t*)offsets.data_ptr(), (const int32_t*)heights.data_ptr(),
                                     (const int32_t*)widths.data_ptr(), n, (int32_t)S, (uint8_t*)out.data_ptr(), workspace.data_ptr(),
                                     (size_t)workspace.numel(), stream_of(packed)), "clip_resize_crop_u8");

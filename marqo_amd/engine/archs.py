@@ -180,8 +180,9 @@ OPEN_CLIP_ARCHS = {
     "ViT-L-14-336": (VitArch(336, 14, 1024, 24, 16, 4096, 768), _TEXT_L),
     # 16 heads of 80 / 88 / 104: zero-padded to 96 / 96 / 112-wide heads at load (engine/towers.py::_pad_heads)
     "ViT-H-14": (VitArch(224, 14, 1280, 32, 16, 5120, 1024), _TEXT_H),
-    # multilingual CLIPs: the ViT towers above with an XLM-RoBERTa text tower (open_clip model configs xlm-roberta-base-ViT-B-32 /
-    # xlm-roberta-large-ViT-H-14; model_registry.py:262-273 in the reference)
+    # CLIPs with a Hugging Face text tower: the ViT towers above with a RoBERTa / XLM-RoBERTa encoder (open_clip model configs
+    # roberta-ViT-B-32, xlm-roberta-base-ViT-B-32, xlm-roberta-large-ViT-H-14; model_registry.py:257-273 in the reference)
+    "roberta-ViT-B-32": (VitArch(224, 32, 768, 12, 12, 3072, 512, quick_gelu=True), "roberta-base:512"),   # (its model config sets quick_gelu)
     "xlm-roberta-base-ViT-B-32": (VitArch(224, 32, 768, 12, 12, 3072, 512), "xlmr-base:512"),
     "xlm-roberta-large-ViT-H-14": (VitArch(224, 14, 1280, 32, 16, 5120, 1024), "xlmr-large:1024"),
     "ViT-H-14-378": (VitArch(378, 14, 1280, 32, 16, 5120, 1024), _TEXT_H),  # 730 tokens: K / V stream through the LDS in pieces
@@ -216,9 +217,11 @@ def resolve_open_clip(arch_name: str, pretrained: Optional[str] = None) -> Tuple
     if base not in OPEN_CLIP_ARCHS:
         raise KeyError(f"{arch_name}: {UNSUPPORTED_HINT}")
     v, t = OPEN_CLIP_ARCHS[base]
+    quick = quick or v.quick_gelu
     if isinstance(t, str):   # HF text tower: "xlmr-<size>:<out_dim>" (BertArch is defined further down)
         size, out_dim = t.split(":")
-        xl = {"xlmr-base": BertArch(vocab=250002, max_pos=512, ln_eps=1e-5, pos_offset=2, type_vocab=1),
+        xl = {"roberta-base": BertArch(vocab=50265, max_pos=512, ln_eps=1e-5, pos_offset=2, type_vocab=1),
+              "xlmr-base": BertArch(vocab=250002, max_pos=512, ln_eps=1e-5, pos_offset=2, type_vocab=1),
               "xlmr-large": BertArch(vocab=250002, max_pos=512, width=1024, layers=24, heads=16, mlp_dim=4096, ln_eps=1e-5, pos_offset=2,
                                      type_vocab=1)}[size]
         t = HfClipTextArch(bert=xl, out_dim=int(out_dim))

@@ -293,6 +293,92 @@ class WordPieceTokenizer:
 
 
 # ---------------------------------------------------------------------------------------------------
+# RoBERTa byte-level BPE (the text tower of open_clip/roberta-ViT-B-32: HFTokenizer("roberta-base"))
+# ---------------------------------------------------------------------------------------------------
+class RobertaBpeTokenizer:
+    """GPT-2 / RoBERTa byte-level BPE (transformers RobertaTokenizer, third-party and un-vendored; restated from its published
+    algorithm and pinned against transformers.RobertaTokenizer in tests/test_tokenizers.py): the text is split by GPT-2's pre-token
+    pattern (a leading space belongs to the word that follows), every pre-token's UTF-8 bytes are mapped to printable code points,
+    adjacent pairs are merged lowest rank first, pieces are looked up in vocab.json; a row is <s> pieces </s>, truncated to max_length,
+    padded with <pad>.  Case is kept.  Special-token spellings inside a text map to their ids (<mask> absorbs the space before it)."""
+    PAT = r"""'s|'t|'re|'ve|'m|'ll|'d| ?\p{L}+| ?\p{N}+| ?[^\s\p{L}\p{N}]+|\s+(?!\S)|\s+"""
+
+    def __init__(self, directory: str):
+        with open(os.path.join(directory, "vocab.json"), encoding="utf-8") as f:
+            self.encoder: Dict[str, int] = json.load(f)
+        with open(os.path.join(directory, "merges.txt"), encoding="utf-8") as f:
+            lines = [l for l in f.read().split("\n") if l and not l.startswith("#version")]
+        self.rank = {tuple(l.split()): i for i, l in enumerate(lines)}
+        for t in ("<s>", "<pad>", "</s>", "<unk>"):
+            if t not in self.encoder:
+                raise ValueError(f"vocab.json has no {t} token")
+        self.cls_id, self.pad_id, self.sep_id, self.unk_id = (self.encoder[t] for t in ("<s>", "<pad>", "</s>", "<unk>"))
+        self._pat = re.compile(self.PAT)
+        specials = [t for t in ("<s>", "<pad>", "</s>", "<unk>", "<mask>") if t in self.encoder]
+        self._special_split = re.compile("(" + "|".join((r" ?" if t == "<mask>" else "") + re.escape(t) for t in specials) + ")")
+        self._specials = set(specials)
+        self._cache: Dict[str, List[int]] = {}
+
+    @property
+    def vocab_size(self) -> int:
+        return len(self.encoder)
+
+    def _bpe_ids(self, token: str) -> List[int]:
+        hit = self._cache.get(token)
+        if hit is not None:
+            return hit
+        b2u = _byte_to_unicode()
+        word = [b2u[b] for b in token.encode("utf-8")]
+        while len(word) > 1:
+            best, best_rank = None, None
+            for pair in zip(word[:-1], word[1:]):
+                r = self.rank.get(pair)
+                if r is not None and (best_rank is None or r < best_rank):
+                    best, best_rank = pair, r
+            if best is None:
+                break
+            merged, i = [], 0
+            while i < len(word):
+                if i + 1 < len(word) and word[i] == best[0] and word[i + 1] == best[1]:
+                    merged.append(word[i] + word[i + 1])
+                    i += 2
+                else:
+                    merged.append(word[i])
+                    i += 1
+            word = merged
+        ids = [self.encoder.get(w, self.unk_id) for w in word]
+        if len(self._cache) < 1 << 18:
+            self._cache[token] = ids
+        return ids
+
+    def encode(self, text: str, max_length: Optional[int] = None) -> List[int]:
+        ids: List[int] = []
+        for part in self._special_split.split(text):
+            if not part:
+                continue
+            if part.lstrip(" ") in self._specials and (part in self._specials or part.lstrip(" ") == "<mask>"):
+                ids.append(self.encoder[part.lstrip(" ")])
+                continue
+            for tok in self._pat.findall(part):
+                ids.extend(self._bpe_ids(tok))
+        if max_length is not None and len(ids) > max_length - 2:
+            ids = ids[:max(max_length - 2, 0)]
+        return [self.cls_id] + ids + [self.sep_id]
+
+    def __call__(self, texts: Union[str, Sequence[str]], max_length: Optional[int] = None) -> Dict[str, np.ndarray]:
+        if isinstance(texts, str):
+            texts = [texts]
+        enc = [self.encode(t, max_length) for t in texts]
+        S = max((len(e) for e in enc), default=0)
+        ids = np.full((len(enc), S), self.pad_id, dtype=np.int64)
+        mask = np.zeros((len(enc), S), dtype=np.int64)
+        for i, e in enumerate(enc):
+            ids[i, :len(e)] = e
+            mask[i, :len(e)] = 1
+        return {"input_ids": ids, "attention_mask": mask}
+
+
+# ---------------------------------------------------------------------------------------------------
 # XLM-RoBERTa SentencePiece (multilingual-e5 family)
 # ---------------------------------------------------------------------------------------------------
 class XlmRobertaTokenizer:

@@ -24,7 +24,8 @@ from PIL.Image import Image as ImageType
 from marqo_amd import _lib as L
 from marqo_amd.engine import archs, checkpoint, synthetic
 from marqo_amd.engine.towers import request_stream
-from marqo_amd.engine.tokenizers import ClipBpeTokenizer, SiglipTokenizer, SyntheticTokenizer, WordPieceTokenizer, XlmRobertaTokenizer, _clean_text
+from marqo_amd.engine.tokenizers import (ClipBpeTokenizer, RobertaBpeTokenizer, SiglipTokenizer, SyntheticTokenizer, WordPieceTokenizer,
+                                          XlmRobertaTokenizer, _clean_text)
 from marqo_amd.s2_inference.abstract_models import AbstractCLIPModel
 from marqo_amd.s2_inference.errors import InvalidModelPropertiesError, ModelLoadError
 from marqo_amd.s2_inference.image_input import format_and_load_CLIP_image, format_and_load_CLIP_images, pil_to_pixels, pil_to_rgb_u8
@@ -249,7 +250,8 @@ class OPEN_CLIP(AbstractCLIPModel):
         if isinstance(self.tokenizer, ClipBpeTokenizer) and os.environ.get("MARQO_AMD_HOST_TOKENIZER", "0") != "1":
             from marqo_amd.engine.gpu_tokenizers import DeviceClipBpeTokenizer
             self._device_tokenizer = DeviceClipBpeTokenizer(self.tokenizer, self.device)
-        elif isinstance(self.tokenizer, HfClipTokenizer) and os.environ.get("MARQO_AMD_HOST_TOKENIZER", "0") != "1":
+        elif isinstance(self.tokenizer, HfClipTokenizer) and isinstance(self.tokenizer.hf, XlmRobertaTokenizer) and \
+                os.environ.get("MARQO_AMD_HOST_TOKENIZER", "0") != "1":
             from marqo_amd.engine.gpu_tokenizers import DeviceSentencePieceTokenizer
             try:
                 self._device_tokenizer = DeviceSentencePieceTokenizer(self.tokenizer.hf, self.device)
@@ -286,13 +288,17 @@ class OPEN_CLIP(AbstractCLIPModel):
             # open_clip HFTokenizer(hf_tokenizer_name = xlm-roberta-base / -large): the SentencePiece model next to the checkpoint, or the HF
             # repo of that name on disk
             size = "large" if self.text_arch.bert.width == 1024 else "base"
+            if self.text_arch.bert.vocab == 50265:   # roberta-base: GPT-2 byte-level BPE (vocab.json + merges.txt)
+                for d in filter(None, (ckpt_dir, checkpoint.find_hf_dir("roberta-base"), checkpoint.find_hf_dir("FacebookAI/roberta-base"))):
+                    if os.path.isfile(os.path.join(d, "vocab.json")) and os.path.isfile(os.path.join(d, "merges.txt")):
+                        return HfClipTokenizer(RobertaBpeTokenizer(d), self.text_arch.ctx)
             for d in filter(None, (ckpt_dir, checkpoint.find_hf_dir(f"xlm-roberta-{size}"), checkpoint.find_hf_dir(f"FacebookAI/xlm-roberta-{size}"))):
                 if os.path.isfile(os.path.join(d, "sentencepiece.bpe.model")):
                     return HfClipTokenizer(XlmRobertaTokenizer(d), self.text_arch.ctx)
             if self.weights_source and str(self.weights_source).startswith("synthetic"):
                 return HfClipTokenizer(SyntheticTokenizer("xlmr", self.text_arch.vocab), self.text_arch.ctx)
-            raise ModelLoadError(f"XLM-RoBERTa tokenizer (sentencepiece.bpe.model) not found next to the checkpoint or under "
-                                 f"{os.path.join(checkpoint.model_dir(), 'hf', 'xlm-roberta-' + size)}")
+            raise ModelLoadError(f"the text tower's Hugging Face tokenizer (sentencepiece.bpe.model, or vocab.json + merges.txt for roberta-base) "
+                                 f"was not found next to the checkpoint or under {os.path.join(checkpoint.model_dir(), 'hf')}")
         if not self.text_arch.causal:  # SigLIP: T5-style SentencePiece vocabulary next to the checkpoint (tokenizer.json / spiece.model)
             for d in filter(None, (ckpt_dir, os.path.join(checkpoint.model_dir(), "siglip"))):
                 if os.path.isfile(os.path.join(d, "tokenizer.json")) or os.path.isfile(os.path.join(d, "spiece.model")):

@@ -331,6 +331,50 @@ def test_multilingual_clip_with_hf_text_tower_from_disk(s2, tmp_path, monkeypatc
     assert _cos_err(img, refi) < COS_TOL
 
 
+def test_clip_with_roberta_text_tower_from_disk(s2, tmp_path, monkeypatch):
+    """open_clip/roberta-ViT-B-32 family: the same HF text tower with RoBERTa's byte-level BPE (vocab.json + merges.txt next to the
+    checkpoint, host tokeniser) and a QuickGELU vision tower"""
+    s2i, root = s2
+    from safetensors.torch import save_file
+    from marqo_amd.engine import archs as A
+    from marqo_amd.engine.tokenizers import RobertaBpeTokenizer, _clean_text
+    from tests.test_tokenizers import CORPUS, SENTENCES, _train_byte_level_bpe
+    S, P, W, Lyr, H, Fd, D, ctx = 64, 16, 128, 2, 2, 256, 64, 32
+    d = tmp_path / "tiny-roberta-clip"
+    d.mkdir()
+    vocab, merges = _train_byte_level_bpe(CORPUS + SENTENCES, 120)
+    (d / "vocab.json").write_text(json.dumps(vocab), encoding="utf-8")
+    (d / "merges.txt").write_text("#version: 0.2\n" + "\n".join(" ".join(m) for m in merges) + "\n", encoding="utf-8")
+    tok = RobertaBpeTokenizer(str(d))
+    bert = A.BertArch(vocab=50265, max_pos=64, width=W, layers=Lyr, heads=H, mlp_dim=Fd, ln_eps=1e-5, pos_offset=2, type_vocab=1)
+    tarch = A.HfClipTextArch(bert=bert, out_dim=D, ctx=ctx)
+    vcfg = O.VitConfig(S, P, W, Lyr, H, Fd, D, quick_gelu=True)
+    bcfg = O.BertConfig(vocab=50265, max_pos=66, width=W, layers=Lyr, heads=H, mlp_dim=Fd, ln_eps=1e-5, pos_offset=2)
+    sd = O.synthetic_vit_state_dict(vcfg, seed=3)
+    enc = O.synthetic_bert_state_dict(bcfg, seed=4)
+    enc["embeddings.token_type_embeddings.weight"] = enc["embeddings.token_type_embeddings.weight"][:1].clone()
+    sd.update({"text.transformer." + k: v for k, v in enc.items()})
+    g = torch.Generator().manual_seed(5)
+    sd["text.proj.0.weight"] = torch.randn(tarch.proj_hidden, W, generator=g) / W ** 0.5
+    sd["text.proj.2.weight"] = torch.randn(D, tarch.proj_hidden, generator=g) / tarch.proj_hidden ** 0.5
+    save_file({k: v.contiguous() for k, v in sd.items()}, str(d / "open_clip_model.safetensors"))
+    monkeypatch.setitem(A.OPEN_CLIP_ARCHS, "tiny-roberta-ViT", (A.VitArch(S, P, W, Lyr, H, Fd, D, quick_gelu=True), tarch))
+    props = {"name": "tiny-roberta-ViT", "dimensions": D, "type": "open_clip", "localpath": str(d / "open_clip_model.safetensors")}
+    texts = ["A photo of a CAT!", "it's the quick brown fox", "naïve café", "fox " * 60]
+    out = np.asarray(s2i.vectorise("tiny-roberta-clip", texts, model_properties=props, device=DEV))
+    t = tok([_clean_text(x) for x in texts], max_length=ctx)
+    ids = np.full((len(texts), ctx), 1, dtype=np.int64)
+    ids[:, :t["input_ids"].shape[1]] = t["input_ids"]
+    assert out.shape == (4, D) and _cos_err(out, O.hf_clip_text_forward(sd, bcfg, torch.from_numpy(ids)).numpy()) < COS_TOL
+    model = s2i.get_available_models()[s2i._create_model_cache_key("tiny-roberta-clip", DEV, props)]["model"]
+    assert type(model.tokenizer.hf).__name__ == "RobertaBpeTokenizer" and model._device_tokenizer is None and model.vision_arch.quick_gelu
+    rng = np.random.default_rng(2)
+    pil = [Image.fromarray(rng.integers(0, 256, (80, 100, 3), dtype=np.uint8)) for _ in range(2)]
+    img = np.asarray(s2i.vectorise("tiny-roberta-clip", pil, model_properties=props, device=DEV, modality=s2i.Modality.IMAGE))
+    refi = O.vit_forward(sd, vcfg, torch.from_numpy(np.stack([OP.clip_transform(np.asarray(p), S) for p in pil]))).numpy()
+    assert _cos_err(img, refi) < COS_TOL
+
+
 def test_siglip_from_disk_text_and_image(s2, tmp_path, monkeypatch):
     """A SigLIP checkpoint through the loader: open_clip / timm tensor names (visual.trunk.*, text.*), SentencePiece tokenizer with
     canonicalize, SigLIP preprocessing (squash to S x S, mean = std = 0.5), 'open_clip' loader type — against the fp32 oracle.
