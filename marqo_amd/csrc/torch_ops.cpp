@@ -15,6 +15,7 @@
 // Built by marqo_amd/_lib.py::build_torch_ops() with g++ against the installed torch headers (host code only: nothing here is device
 // code, the kernels are in the .hip translation units).
 #include <Python.h>
+#include <stdlib.h>
 
 #include <ATen/ATen.h>
 #include <c10/hip/HIPStream.h>
@@ -28,11 +29,14 @@ void* stream_of(const at::Tensor& t) {
     return (void*)c10::hip::getCurrentHIPStream(t.device().index()).stream();
 }
 
-// The tower ops enqueue ~100-800 kernel launches (0.5 - 2 ms of host time) and touch no Python object meanwhile: like the ctypes binding,
-// they run WITHOUT the GIL, so that concurrent request threads (the reference serves 8 + 8) can pack / tokenise while one thread enqueues.
+// The tower ops enqueue ~100-800 kernel launches (0.5 - 2 ms of host time) and touch no Python object meanwhile, so they MAY run without
+// the GIL (MARQO_AMD_OPS_RELEASE_GIL=1).  Measured with 4 concurrent 256-image callers (profiles/r02t_gil_boundary_ab.txt): holding the
+// GIL 63-65 k embeddings/s, releasing it 62 k (re-acquiring it costs what the release buys), the ctypes boundary 69-73 k; one caller:
+// 40-41 k all three.  Default: hold.
+const bool g_release_gil = [] { const char* v = getenv("MARQO_AMD_OPS_RELEASE_GIL"); return v && v[0] == '1'; }();
 struct NoGil {
     PyThreadState* st;
-    NoGil() : st(Py_IsInitialized() && PyGILState_Check() ? PyEval_SaveThread() : nullptr) {}
+    NoGil() : st(g_release_gil && Py_IsInitialized() && PyGILState_Check() ? PyEval_SaveThread() : nullptr) {}
     ~NoGil() { if (st) PyEval_RestoreThread(st); }
     NoGil(const NoGil&) = delete;
     NoGil& operator=(const NoGil&) = delete;
