@@ -187,7 +187,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
     if (PERSIST && (wide_store >> 8) && blockIdx.x >= (gridDim.x >> 1))
         for (int i = 0; i < (wide_store >> 8); ++i) __builtin_amdgcn_s_sleep(16);
     const bool lds_bias_on = LDS_BIAS && (wide_store & 2);   // knob mq_tune("gemm_lds_bias", 0 / 1)
+    // experiment knobs (profiles/r02u_gemm_vmcnt_prio_ab.txt):
+    //  * mq_tune("gemm_vmcnt", 1): after an epilogue the first k-step of the next tile waits only for the stage-0 LDS-DMA that was issued
+    //    BEFORE the epilogue's stores (vmcnt retires in issue order on gfx9: the tile's EPI_STORES stores may stay in flight) instead of
+    //    draining them with vmcnt(0); only for waves whose tile was fully inside the matrix (every store instruction issued)
+    //  * mq_tune("gemm_prio", 1): static s_setprio 1 for the second-dispatched workgroup of every CU (MI355X_MICROARCH.md item 4)
+    const bool counted_vmcnt = PERSIST && (wide_store & 4) && !(FLAGS & (MQ_EPI_LN_STATS | MQ_EPI_LN_APPLY));
+    if ((wide_store & 8) && blockIdx.x >= (gridDim.x >> 1)) __builtin_amdgcn_s_setprio(1);
     wide_store &= 1;
+    bool stores_pending = false;   // the previous tile's epilogue stores are still in flight and may be skipped by the next wait
     int buf = 0;  // LDS buffer of the next k-step (runs on across tiles in the persistent form)
 #ifdef MQ_GEMM_TRACE
     unsigned long long tr_steps = 0, tr_vm = 0, tr_bar = 0, tr_body = 0, tr_epi = 0, tr_tiles = 0;
@@ -270,6 +278,24 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
 
         for (int kt = 0; kt < nk - 1; ++kt) {
             // stage kt has landed for every wave, and every wave is done reading the other buffer
+#ifndef MQ_GEMM_TRACE
+            if (stores_pending) {   // (first k-step after an epilogue: the stage's DMA was issued before the stores)
+                stores_pending = false;
+                constexpr int EPI_STORES = (FLAGS & MQ_EPI_OUT_F32) ? 4 * MT : 2 * MT;   // fp32: one 16-B store per sub-tile; bf16 (wide): one per pair
+                if (EPI_STORES == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else if (EPI_STORES == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+                else if (EPI_STORES == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                else if (EPI_STORES == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else if (EPI_STORES == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // (the tile's bias values — a load issued AFTER the stores — are parked one k-step later, behind that step's full wait:
+                // consuming them here would make the compiler drain the stores after all)
+                __syncthreads();
+                kstep(buf, (int64_t)(kt + 1) * BK, std::true_type{});
+                buf ^= 1;
+                continue;
+            }
+#endif
 #ifdef MQ_GEMM_TRACE
             const unsigned long long t0 = MQ_TR_NOW();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -334,6 +360,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
         tr_tiles += 1;
 #endif
         if (!PERSIST || !more) break;
+        // every store instruction of the epilogue was issued by this wave iff its sub-tile lay fully inside the matrix (wave-uniform);
+        // the bf16 count holds for the widened-store form only
+        stores_pending = counted_vmcnt && nk > 1 && (wide_store != 0 || (FLAGS & MQ_EPI_OUT_F32)) &&
+                         cm0 + wm * (16 * MT) + 16 * MT <= M && cn0 + wn * 64 + 64 <= N;
     }
 #ifdef MQ_GEMM_TRACE
     if (blockIdx.x < MQ_TRACE_BLOCKS && lane == 0) {
@@ -350,7 +380,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
 
 // tuning knobs: initialised from the environment (MQ_GEMM_MT / _PERSIST / _CGROUP / _WIDE / _BIG), overridable through mq_tune()
 struct GemmTune {
-    int mt, persist, big, cgroup, wide, k32, stagger = 0, lds_bias = 1;
+    int mt, persist, big, cgroup, wide, k32, stagger = 0, lds_bias = 1, vmcnt = 0, prio = 0;
     static int env(const char* k, int d) { const char* v = getenv(k); return v ? atoi(v) : d; }
     GemmTune() : mt(env("MQ_GEMM_MT", 0)), persist(env("MQ_GEMM_PERSIST", 1)), big(env("MQ_GEMM_BIG", 0)), cgroup(env("MQ_GEMM_CGROUP", 8)), wide(env("MQ_GEMM_WIDE", 2)), k32(env("MQ_GEMM_K32", 0)) {}
 };
@@ -402,7 +432,8 @@ int launch_gemm_mt(const void* A, int64_t lda, const void* W, int64_t ldw, const
     const int stagger = (PERSIST && num_tiles >= 2 * RESIDENT_SLOTS) ? g_tune.stagger : 0;
     hipLaunchKernelGGL((gemm_nt_kernel<FLAGS, MT, PERSIST>), dim3(grid), dim3(256), LDS, s,
                        (const bf16_t*)A, lda, (const bf16_t*)W, ldw, bias, residual, out, ldc,
-                       M, N, K, tiles_n, num_tiles, cgroup, band_rows, wide | (g_tune.lds_bias ? 2 : 0) | (stagger << 8), ln);
+                       M, N, K, tiles_n, num_tiles, cgroup, band_rows,
+                       wide | (g_tune.lds_bias ? 2 : 0) | (g_tune.vmcnt ? 4 : 0) | (g_tune.prio ? 8 : 0) | (stagger << 8), ln);
     MQ_CHECK_LAUNCH("mq_gemm_bf16");
     return MQ_OK;
 }
@@ -524,6 +555,8 @@ extern "C" int mq_tune(const char* key, int value) {
     else if (k == "gemm_wide") mq_gemm_knob_wide = g_tune.wide = value;
     else if (k == "gemm_stagger") g_tune.stagger = value;
     else if (k == "gemm_lds_bias") g_tune.lds_bias = value;
+    else if (k == "gemm_vmcnt") g_tune.vmcnt = value;
+    else if (k == "gemm_prio") g_tune.prio = value;
     else if (k == "gemm_k32") g_tune.k32 = value;
     else if (k == "row_select") mq_tower_row_select = value;
     else if (k == "ln_fold") mq_tower_ln_fold = value;

@@ -129,3 +129,27 @@ def test_cu_sized_tile_variant(big):
             assert torch.equal(_gemm(lib, A, W, bias, res, L.MQ_EPI_BIAS | L.MQ_EPI_GELU), base_g)
     finally:
         _tune(lib, **DEFAULTS)
+
+
+def test_counted_vmcnt_and_static_priority_knobs_are_bit_identical():
+    """mq_tune("gemm_vmcnt", 1): the first k-step after an epilogue waits only for the stage-0 LDS-DMA (the epilogue's stores stay in
+    flight); mq_tune("gemm_prio", 1): static priority for the second workgroup of a CU.  Same arithmetic, same order: identical bits,
+    on multi-tile persistent shapes (where the counted wait is actually taken), ragged edges included; repeated as a race screen."""
+    lib = L.load()
+    g = torch.Generator(device="cuda").manual_seed(91)
+    try:
+        for (M, N, K) in [(12800, 2304, 768), (12800, 3072, 768), (16448, 4096, 1024), (12801, 2308, 768), (9000, 1540, 192)]:
+            A = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+            W = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).to(torch.bfloat16)
+            bias = torch.randn(N, device="cuda", generator=g)
+            res = torch.randn(M, N, device="cuda", generator=g)
+            for flags in (0, L.MQ_EPI_OUT_F32, L.MQ_EPI_BIAS, L.MQ_EPI_BIAS | L.MQ_EPI_GELU, L.MQ_EPI_BIAS | L.MQ_EPI_RESIDUAL | L.MQ_EPI_OUT_F32):
+                _tune(lib, gemm_vmcnt=0, gemm_prio=0)
+                base = _gemm(lib, A, W, bias, res, flags)
+                for vm, pr in ((1, 0), (0, 1), (1, 1)):
+                    _tune(lib, gemm_vmcnt=vm, gemm_prio=pr)
+                    for _ in range(6):
+                        assert torch.equal(_gemm(lib, A, W, bias, res, flags), base), ((M, N, K), flags, vm, pr)
+    finally:
+        _tune(lib, gemm_vmcnt=0, gemm_prio=0)
+        _tune(lib, **DEFAULTS)
