@@ -270,16 +270,30 @@ def build_torch_ops(force: bool = False, verbose: bool = False) -> Path:
 
 
 _ops = None
+_warned_no_ops = False
 
 
 def boundary() -> str:
     """'torch_ops' (default): the towers call torch.ops.marqo_hip.* (PyTorch-ROCm custom ops over the C ABI); 'ctypes': they call
     the C ABI directly (MARQO_AMD_BOUNDARY=ctypes, non-torch hosts, and whenever MARQO_AMD_LIB points at a diagnostic build, which
     the ops library is not linked against)."""
-    b = os.environ.get("MARQO_AMD_BOUNDARY", "torch_ops")
-    if b not in ("torch_ops", "ctypes"):
+    b = os.environ.get("MARQO_AMD_BOUNDARY")
+    if b not in (None, "torch_ops", "ctypes"):
         raise ValueError(f"MARQO_AMD_BOUNDARY must be 'torch_ops' or 'ctypes', got {b!r}")
-    return "ctypes" if os.environ.get("MARQO_AMD_LIB") else b
+    if os.environ.get("MARQO_AMD_LIB"):
+        return "ctypes"
+    if b is None:
+        # default: the custom ops — unless only the C-ABI library was built (a host without a C++ toolchain for torch_ops.cpp): the
+        # same kernels are then reached through the direct binding (both are native paths; the loud failure is a missing libmarqo_hip.so)
+        if not TORCH_OPS_PATH.exists():
+            global _warned_no_ops
+            if not _warned_no_ops:
+                _warned_no_ops = True
+                import logging
+                logging.getLogger(__name__).warning("%s not built: the towers call the C ABI through ctypes (MARQO_AMD_BOUNDARY=ctypes)", TORCH_OPS_PATH)
+            return "ctypes"
+        return "torch_ops"
+    return b
 
 
 def load_torch_ops():
