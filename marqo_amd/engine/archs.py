@@ -255,6 +255,7 @@ HF_BERT_ARCHS = {
     "sentence-transformers/all-mpnet-base-v1": _MPNET_BASE, "sentence-transformers/all-mpnet-base-v2": _MPNET_BASE,
     "flax-sentence-embeddings/all_datasets_v3_mpnet-base": _MPNET_BASE, "flax-sentence-embeddings/all_datasets_v4_mpnet-base": _MPNET_BASE,
     # XLM-RoBERTa encoders
+    "sentence-transformers/stsb-xlm-r-multilingual": BertArch(vocab=250002, max_pos=512, ln_eps=1e-5, pos_offset=2),
     "intfloat/multilingual-e5-small": BertArch(vocab=250037, max_pos=512, width=384, layers=12, heads=12, mlp_dim=1536, ln_eps=1e-5, pos_offset=2),
     "intfloat/multilingual-e5-base": BertArch(vocab=250002, max_pos=512, ln_eps=1e-5, pos_offset=2),
     "intfloat/multilingual-e5-large": BertArch(vocab=250002, max_pos=512, width=1024, layers=24, heads=16, mlp_dim=4096, ln_eps=1e-5, pos_offset=2),

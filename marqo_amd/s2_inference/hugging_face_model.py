@@ -63,6 +63,7 @@ class HuggingFaceModelProperties:
 class HuggingFaceModel(AbstractEmbeddingModel):
     supports_dynamic_batching = True
     _requires_trust_remote_code = False
+    _check_dimensions = True
 
     def __init__(self, model_properties: dict, device: str, model_auth=None, model_flags=None, tokenizer_flags=None):
         super().__init__(model_properties, device, model_auth)
@@ -130,7 +131,7 @@ class HuggingFaceModel(AbstractEmbeddingModel):
             raise InvalidModelPropertiesError(
                 f"Marqo encountered an error loading the Hugging Face model, modelProperties={props.dict()}. No local copy under "
                 f"{checkpoint.model_dir()} or the Hugging Face cache (there is no network download in the marqo_amd engine).")
-        if arch.width != props.dimensions:
+        if self._check_dimensions and arch.width != props.dimensions:
             raise InvalidModelPropertiesError(f"'dimensions'={props.dimensions} but the encoder width is {arch.width}")
         pooling = props.pooling_method or checkpoint.read_pooling_config(directory) or "mean"
         self.arch = arch

@@ -131,6 +131,31 @@ def _get_hf_properties() -> Dict:
     return out
 
 
+# `sbert` entries (model_registry.py:538-613): SentenceTransformer checkpoints = an HF encoder + mean pooling (+ Normalize); every one of
+# them also under its name without the organisation prefix (load_model_properties, :2149-2150)
+_SBERT = {
+    "sentence-transformers/all-MiniLM-L6-v1": (384, 128), "sentence-transformers/all-MiniLM-L6-v2": (384, 256),
+    "sentence-transformers/all-MiniLM-L12-v2": (384, 256), "sentence-transformers/all-mpnet-base-v1": (768, 128),
+    "sentence-transformers/all-mpnet-base-v2": (768, 128), "sentence-transformers/stsb-xlm-r-multilingual": (768, 128),
+    "flax-sentence-embeddings/all_datasets_v3_MiniLM-L12": (384, 128), "flax-sentence-embeddings/all_datasets_v3_MiniLM-L6": (384, 128),
+    "flax-sentence-embeddings/all_datasets_v4_MiniLM-L12": (384, 128), "flax-sentence-embeddings/all_datasets_v4_MiniLM-L6": (384, 128),
+    "flax-sentence-embeddings/all_datasets_v3_mpnet-base": (768, 128), "flax-sentence-embeddings/all_datasets_v4_mpnet-base": (768, 128),
+}
+
+
+def _get_sbert_properties() -> Dict:
+    out = {name: {"name": name, "dimensions": d, "tokens": t, "type": "sbert", "notes": ""} for name, (d, t) in _SBERT.items()}
+    out.update({k.split("/")[-1]: v for k, v in list(out.items())})
+    return out
+
+
+def _get_sbert_test_properties() -> Dict:
+    """the reference's plumbing entries (model_registry.py:976-999): all-MiniLM-L6-v1 truncated to 16 dimensions"""
+    base = {"name": "sentence-transformers/all-MiniLM-L6-v1", "dimensions": 16, "tokens": 128, "type": "test", "notes": ""}
+    return {"sentence-transformers/test": dict(base), "test": dict(base),
+            "test_prefix": {**base, "text_query_prefix": "test query: ", "text_chunk_prefix": "test passage: "}}
+
+
 def _get_random_properties() -> Dict:
     """random/* plumbing fakes (model_registry.py:2094-2123)."""
     return {
@@ -150,13 +175,16 @@ def _get_model_load_mappings() -> Dict:
     from marqo_amd.s2_inference.open_clip_model import CLIP, FP16_CLIP, OPEN_CLIP
     from marqo_amd.s2_inference.hugging_face_model import HuggingFaceModel, HuggingFaceStellaModel
     from marqo_amd.s2_inference.random_utils import NO_MODEL, Random
+    from marqo_amd.s2_inference.sbert_utils import SBERT, TEST
     return {"open_clip": OPEN_CLIP, "clip": CLIP, "fp16_clip": FP16_CLIP, "hf": HuggingFaceModel,
-            "hf_stella": HuggingFaceStellaModel, "random": Random, "no_model": NO_MODEL}
+            "hf_stella": HuggingFaceStellaModel, "random": Random, "no_model": NO_MODEL, "sbert": SBERT, "test": TEST}
 
 
 def load_model_properties() -> Dict:
     models: Dict = {}
     models.update(_get_clip_properties())
+    models.update(_get_sbert_properties())
+    models.update(_get_sbert_test_properties())
     models.update(_get_random_properties())
     models.update(_get_hf_properties())
     models.update(_get_open_clip_properties())

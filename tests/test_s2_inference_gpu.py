@@ -172,6 +172,61 @@ def test_hf_from_disk(s2):
         s2i.vectorise("tiny-bert-bad", texts, model_properties=dict(props, dimensions=99), device=DEV)
 
 
+def test_sbert_and_test_loader_types_from_disk(s2):
+    """the reference's `sbert` / `test` loader types (sbert_utils.py:39-111) over a SentenceTransformer checkpoint directory: modules.json
+    (Transformer -> Pooling -> Normalize), sentence_bert_config.json (max_seq_length), 1_Pooling; constructor and encode() contract of the
+    reference; a pipeline that ends in Normalize returns unit vectors even for normalize=False; `test` truncates to 16 dimensions"""
+    s2i, root = s2
+    from safetensors.torch import save_file
+    from marqo_amd.engine.tokenizers import WordPieceTokenizer
+    from tests.test_tokenizers import _bert_vocab
+    vocab = _bert_vocab()
+    cfg = O.BertConfig(vocab=len(vocab), max_pos=64, width=128, layers=2, heads=2, mlp_dim=256)
+    sd = O.synthetic_bert_state_dict(cfg, seed=7)
+    texts = ["query: how much protein should a female eat", "the quick brown fox jumps over the lazy dog " * 3, "fox"]
+    for repo, normalize_module in (("tiny-st", True), ("tiny-st-plain", False)):
+        d = root / "hf" / "acme" / repo
+        (d / "1_Pooling").mkdir(parents=True, exist_ok=True)
+        save_file({k: v.contiguous() for k, v in sd.items()}, str(d / "model.safetensors"))
+        (d / "config.json").write_text(json.dumps({"model_type": "bert", "vocab_size": len(vocab), "max_position_embeddings": 64, "hidden_size": 128,
+                                                   "num_hidden_layers": 2, "num_attention_heads": 2, "intermediate_size": 256,
+                                                   "hidden_act": "gelu", "layer_norm_eps": 1e-12}))
+        (d / "vocab.txt").write_text("\n".join(sorted(vocab, key=vocab.get)) + "\n")
+        (d / "1_Pooling" / "config.json").write_text(json.dumps({"pooling_mode_cls_token": False, "pooling_mode_mean_tokens": True}))
+        (d / "sentence_bert_config.json").write_text(json.dumps({"max_seq_length": 24, "do_lower_case": False}))
+        mods = [{"idx": 0, "name": "0", "path": "", "type": "sentence_transformers.models.Transformer"},
+                {"idx": 1, "name": "1", "path": "1_Pooling", "type": "sentence_transformers.models.Pooling"}]
+        if normalize_module:
+            mods.append({"idx": 2, "name": "2", "path": "2_Normalize", "type": "sentence_transformers.models.Normalize"})
+        (d / "modules.json").write_text(json.dumps(mods))
+    tok = WordPieceTokenizer(vocab)
+    # registry-style call: tokens from the properties
+    props = {"name": "acme/tiny-st", "dimensions": 128, "tokens": 16, "type": "sbert"}
+    out = np.asarray(s2i.vectorise("tiny-st", texts, model_properties=props, device=DEV))
+    t = tok(texts, max_length=16)
+    ref = O.hf_encode(sd, cfg, torch.from_numpy(t["input_ids"]), torch.from_numpy(t["attention_mask"])).numpy()
+    assert out.shape == (3, 128) and _cos_err(out, ref) < COS_TOL
+    raw = np.asarray(s2i.vectorise("tiny-st", texts, model_properties=props, device=DEV, normalize_embeddings=False))
+    assert np.allclose(np.linalg.norm(raw, axis=1), 1, atol=1e-5)          # the checkpoint's own Normalize module
+    # the loader class as the reference constructs it; max_seq_length from sentence_bert_config.json when none is given
+    from marqo_amd.s2_inference.sbert_utils import SBERT, TEST
+    m = SBERT("acme/tiny-st-plain", device=DEV, embedding_dim=128)
+    m.load()
+    assert m.max_seq_length == 24 and not m.always_normalized
+    t24 = tok(texts, max_length=24)
+    cfg_raw = O.hf_encode(sd, cfg, torch.from_numpy(t24["input_ids"]), torch.from_numpy(t24["attention_mask"]), normalize=False).numpy()
+    got = m.encode(texts, normalize=False)
+    assert isinstance(got, np.ndarray) and _cos_err(got, cfg_raw) < COS_TOL and not np.allclose(np.linalg.norm(got, axis=1), 1, atol=1e-3)
+    with pytest.raises(Exception):
+        SBERT("acme/tiny-st", device=None)
+    # `test` type: the first 16 dimensions, normalised afterwards
+    tprops = {"name": "acme/tiny-st-plain", "dimensions": 16, "tokens": 16, "type": "test"}
+    t16 = np.asarray(s2i.vectorise("tiny-test", texts, model_properties=tprops, device=DEV))
+    raw16 = O.hf_encode(sd, cfg, torch.from_numpy(t["input_ids"]), torch.from_numpy(t["attention_mask"]), normalize=False)[:, :16]
+    assert t16.shape == (3, 16) and _cos_err(t16, torch.nn.functional.normalize(raw16, dim=1).numpy()) < COS_TOL
+    assert isinstance(TEST("acme/tiny-st-plain", device=DEV).encode(texts[:1]), torch.Tensor)
+
+
 # ---- registry-size models with synthetic weights (BASELINE configs 1-3) ---------------------------------------------------
 def test_registry_models_synthetic_weights(s2):
     s2i, _ = s2
