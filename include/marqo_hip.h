@@ -193,7 +193,9 @@ typedef struct mq_bert_weights {
     const mq_block_weights* blocks;
     /* optional projection head on the pooled row (NULL: none) — open_clip's HFTextEncoder with proj "mlp" (the text tower of
      * open_clip/xlm-roberta-base-ViT-B-32 and xlm-roberta-large-ViT-H-14): Linear(W, proj_hidden) -> GELU -> Linear(proj_hidden, out_dim),
-     * both without bias in open_clip (proj1_b: fp32 [proj_hidden], zeros then).  bf16 row-major [out_features, in_features]. */
+     * both without bias in open_clip (proj1_b: fp32 [proj_hidden], zeros then).  bf16 row-major [out_features, in_features].
+     * proj2_w == NULL with proj1_w set: ONE biased Linear(W, out_dim) instead (multilingual_clip's `LinearTransformation`, the M-CLIP text
+     * encoders of the reference's multilingual_clip loader: clip_utils.py:521-565); mq_bert_cfg.proj_hidden is 0 then. */
     const void*  proj1_w;
     const float* proj1_b;
     const void*  proj2_w;
@@ -204,8 +206,8 @@ typedef struct mq_bert_cfg {
     int32_t vocab;
     int32_t max_pos;
     int32_t pool;     /* MQ_POOL_* */
-    int32_t proj_hidden; /* 0: no projection head, d_out is [nseq, W]; else multiples of 64 with out_dim: d_out is [nseq, out_dim] */
-    int32_t out_dim;
+    int32_t proj_hidden; /* hidden width of the MLP head (multiple of 64), 0 for the single-Linear head / no head */
+    int32_t out_dim;     /* 0: no projection head, d_out is [nseq, W]; else d_out is [nseq, out_dim] */
 } mq_bert_cfg;
 
 /* ---- library info ------------------------------------------------------------------ */

@@ -490,6 +490,7 @@ extern "C" int mq_gemm_bf16(const void* d_A, int64_t lda, const void* d_W, int64
     switch (flags) {
         MQ_GEMM_CASE(0);
         MQ_GEMM_CASE(MQ_EPI_OUT_F32);
+        MQ_GEMM_CASE(MQ_EPI_BIAS | MQ_EPI_OUT_F32);   // biased fp32 heads (M-CLIP LinearTransformation)
         MQ_GEMM_CASE(MQ_EPI_BIAS);
         MQ_GEMM_CASE(MQ_EPI_BIAS | MQ_EPI_GELU);
         MQ_GEMM_CASE(MQ_EPI_BIAS | MQ_EPI_QUICKGELU);

@@ -183,6 +183,7 @@ int mq_launch_gemm_big(int mt, const void* A, int64_t lda, const void* W, int64_
                                          int64_t, int, int, int, hipStream_t)
 MQ_BIG_INST(0);
 MQ_BIG_INST(MQ_EPI_OUT_F32);
+MQ_BIG_INST(MQ_EPI_BIAS | MQ_EPI_OUT_F32);
 MQ_BIG_INST(MQ_EPI_BIAS);
 MQ_BIG_INST(MQ_EPI_BIAS | MQ_EPI_GELU);
 MQ_BIG_INST(MQ_EPI_BIAS | MQ_EPI_QUICKGELU);

@@ -214,6 +214,7 @@ int mq_launch_gemm_k32(int wgs, const void* A, int64_t lda, const void* W, int64
                                          int64_t, int, int, int, int, int, hipStream_t)
 MQ_K32_INST(0);
 MQ_K32_INST(MQ_EPI_OUT_F32);
+MQ_K32_INST(MQ_EPI_BIAS | MQ_EPI_OUT_F32);
 MQ_K32_INST(MQ_EPI_BIAS);
 MQ_K32_INST(MQ_EPI_BIAS | MQ_EPI_GELU);
 MQ_K32_INST(MQ_EPI_BIAS | MQ_EPI_QUICKGELU);

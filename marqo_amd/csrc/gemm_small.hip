@@ -272,6 +272,7 @@ int mq_gemm_small(const void* d_A, int64_t lda, const void* d_W, int64_t ldw, co
     switch (flags) {
         MQ_SM_CASE(0);
         MQ_SM_CASE(MQ_EPI_OUT_F32);
+        MQ_SM_CASE(MQ_EPI_BIAS | MQ_EPI_OUT_F32);
         MQ_SM_CASE(MQ_EPI_BIAS);
         MQ_SM_CASE(MQ_EPI_BIAS | MQ_EPI_GELU);
         MQ_SM_CASE(MQ_EPI_BIAS | MQ_EPI_QUICKGELU);

@@ -618,10 +618,11 @@ extern "C" int mq_encode_bert(const mq_bert_cfg* cfg, const mq_bert_weights* w, 
     MQ_TRY(check_encoder_cfg(&cfg->enc));
     MQ_CHECK_ARG(cfg->enc.post_ln == 1 && cfg->enc.mask == MQ_MASK_NONE, "mq_encode_bert: BERT is post-LN with full attention");
     MQ_CHECK_ARG(cfg->pool == MQ_POOL_MEAN || cfg->pool == MQ_POOL_CLS, "mq_encode_bert: bad pooling %d", cfg->pool);
-    if (cfg->proj_hidden)
-        MQ_CHECK_ARG(cfg->proj_hidden % 64 == 0 && cfg->proj_hidden <= 3 * cfg->enc.width && cfg->out_dim >= 4 && cfg->out_dim % 4 == 0 &&
-                     w->proj1_w && w->proj1_b && w->proj2_w,
-                     "mq_encode_bert: projection head needs proj_hidden %% 64 == 0 (<= 3 W), out_dim %% 4 == 0 and its three weight pointers");
+    if (cfg->out_dim)
+        MQ_CHECK_ARG(cfg->out_dim >= 4 && cfg->out_dim % 4 == 0 && w->proj1_w && w->proj1_b &&
+                     (w->proj2_w ? (cfg->proj_hidden >= 64 && cfg->proj_hidden % 64 == 0 && cfg->proj_hidden <= 3 * cfg->enc.width) : cfg->proj_hidden == 0),
+                     "mq_encode_bert: projection head needs out_dim %% 4 == 0, proj1_w / proj1_b, and either proj2_w with proj_hidden %% 64 == 0 "
+                     "(<= 3 W: the MLP head) or neither (one biased Linear)");
     MQ_CHECK_ARG(w->word_emb && (w->pos_emb || cfg->enc.d_rope_inv_freq) && w->emb_ln_g && w->emb_ln_b, "mq_encode_bert: null weight pointer");
     if (nseq <= 0) return MQ_OK;
     MQ_CHECK_ARG(d_ids && d_cu_seqlens && h_cu_seqlens && d_workspace, "mq_encode_bert: null input / workspace");
@@ -642,7 +643,7 @@ extern "C" int mq_encode_bert(const mq_bert_cfg* cfg, const mq_bert_weights* w, 
     const int32_t* sel = cfg->pool == MQ_POOL_CLS ? d_cu_seqlens : nullptr;
     MQ_TRY(encoder_forward_impl(&cfg->enc, w->blocks, x, rows, d_cu_seqlens, nseq, 0, maxl, sel, sel ? nseq : 0, base + p.off_enc,
                                 workspace_bytes - p.off_enc, s));
-    if (!cfg->proj_hidden) {
+    if (!cfg->out_dim) {
         MQ_TRY(mq_pool(x, d_cu_seqlens, nseq, d_out, W, cfg->pool, normalize, s));
         return MQ_OK;
     }
@@ -653,9 +654,13 @@ extern "C" int mq_encode_bert(const mq_bert_cfg* cfg, const mq_bert_weights* w, 
     bf16_t* h1 = pb + (size_t)nseq * W;
     MQ_TRY(mq_pool(x, d_cu_seqlens, nseq, pooled, W, cfg->pool, 0, s));
     MQ_TRY(mq_cast_bf16(pooled, pb, (int64_t)nseq * W, s));
-    MQ_TRY(mq_gemm_bf16(pb, W, w->proj1_w, W, w->proj1_b, nullptr, h1, cfg->proj_hidden, nseq, cfg->proj_hidden, W, MQ_EPI_BIAS | MQ_EPI_GELU, s));
-    MQ_TRY(mq_gemm_bf16(h1, cfg->proj_hidden, w->proj2_w, cfg->proj_hidden, nullptr, nullptr, d_out, cfg->out_dim, nseq, cfg->out_dim,
-                        cfg->proj_hidden, MQ_EPI_OUT_F32, s));
+    if (!w->proj2_w) {   // M-CLIP: one biased Linear(W, out_dim) on the pooled row (multilingual_clip's LinearTransformation)
+        MQ_TRY(mq_gemm_bf16(pb, W, w->proj1_w, W, w->proj1_b, nullptr, d_out, cfg->out_dim, nseq, cfg->out_dim, W, MQ_EPI_BIAS | MQ_EPI_OUT_F32, s));
+    } else {
+        MQ_TRY(mq_gemm_bf16(pb, W, w->proj1_w, W, w->proj1_b, nullptr, h1, cfg->proj_hidden, nseq, cfg->proj_hidden, W, MQ_EPI_BIAS | MQ_EPI_GELU, s));
+        MQ_TRY(mq_gemm_bf16(h1, cfg->proj_hidden, w->proj2_w, cfg->proj_hidden, nullptr, nullptr, d_out, cfg->out_dim, nseq, cfg->out_dim,
+                            cfg->proj_hidden, MQ_EPI_OUT_F32, s));
+    }
     if (normalize) MQ_TRY(mq_l2_normalize(d_out, d_out, nseq, cfg->out_dim, s));
     return MQ_OK;
 }

@@ -908,7 +908,7 @@ class BertTower(_TextTowerBase):
     @property
     def out_width(self) -> int:
         """columns of the embeddings: the encoder width, or the projection head's out_dim (HfClipTextTower)"""
-        return int(self.cfg.out_dim) if self.cfg.proj_hidden else self.arch.width
+        return int(self.cfg.out_dim) if self.cfg.out_dim else self.arch.width
 
     def calibration_batch(self, n: int = 32, seed: int = 0) -> Tuple[Tensor, Tensor]:
         """fixed, seeded calibration texts of the fp8 policy: (ids, attention_mask) int64 [n, S], lengths spread over 4 .. min(128, max_pos)"""
@@ -1000,3 +1000,21 @@ class HfClipTextTower(BertTower):
         (hf_model.py HFTextEncoder.forward)"""
         ids = ids.detach().to("cpu", torch.int64)
         return self.encode_ids(ids, (ids != self.clip_arch.pad_id).to(torch.int64), normalize=normalize)
+
+
+class MclipTextTower(BertTower):
+    """Text encoder of the reference's `multilingual_clip` loader (clip_utils.py:521-565: pt_multilingual_clip.MultilingualCLIP, third-party
+    and un-vendored): `transformer.*` = a Hugging Face encoder (XLM-RoBERTa large, or LaBSE = BERT), the attention-masked mean of its last
+    hidden state, then `LinearTransformation` = ONE biased Linear to the paired CLIP image tower's embedding width — inside mq_encode_bert
+    (mq_bert_weights.proj1_w / proj1_b with proj2_w NULL).  The loader normalises afterwards."""
+
+    def __init__(self, bert_arch, out_dim: int, sd: Dict[str, Tensor], device: str, precision: str = "bf16"):
+        t = "transformer."
+        enc = {k[len(t):]: v for k, v in sd.items() if k.startswith(t)}
+        if not enc:
+            raise ValueError("checkpoint has no transformer.* tensors (a MultilingualCLIP text encoder was expected)")
+        super().__init__(bert_arch, enc, device, pooling="mean", precision=precision)
+        W = bert_arch.width
+        self.w.proj1_w = self._h.bf16(_need(sd, "LinearTransformation.weight", (out_dim, W)))
+        self.w.proj1_b = self._h.f32(_need(sd, "LinearTransformation.bias", (out_dim,)))
+        self.cfg.proj_hidden, self.cfg.out_dim = 0, out_dim

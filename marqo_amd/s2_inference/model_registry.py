@@ -172,12 +172,13 @@ def _get_no_model_properties() -> Dict:
 
 def _get_model_load_mappings() -> Dict:
     # imported here so that `import marqo_amd.s2_inference.model_registry` stays cheap and free of cycles
-    from marqo_amd.s2_inference.open_clip_model import CLIP, FP16_CLIP, OPEN_CLIP
+    from marqo_amd.s2_inference.open_clip_model import CLIP, FP16_CLIP, MULTILINGUAL_CLIP, OPEN_CLIP
     from marqo_amd.s2_inference.hugging_face_model import HuggingFaceModel, HuggingFaceStellaModel
     from marqo_amd.s2_inference.random_utils import NO_MODEL, Random
     from marqo_amd.s2_inference.sbert_utils import SBERT, TEST
     return {"open_clip": OPEN_CLIP, "clip": CLIP, "fp16_clip": FP16_CLIP, "hf": HuggingFaceModel,
-            "hf_stella": HuggingFaceStellaModel, "random": Random, "no_model": NO_MODEL, "sbert": SBERT, "test": TEST}
+            "hf_stella": HuggingFaceStellaModel, "random": Random, "no_model": NO_MODEL, "sbert": SBERT, "test": TEST,
+            "multilingual_clip": MULTILINGUAL_CLIP}
 
 
 def load_model_properties() -> Dict:
@@ -189,4 +190,6 @@ def load_model_properties() -> Dict:
     models.update(_get_hf_properties())
     models.update(_get_open_clip_properties())
     models.update(_get_no_model_properties())
+    from marqo_amd.s2_inference.open_clip_model import get_multilingual_clip_properties
+    models.update(get_multilingual_clip_properties())
     return {"models": models, "loaders": dict(_get_model_load_mappings())}

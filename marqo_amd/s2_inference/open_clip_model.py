@@ -125,6 +125,7 @@ class HfClipTokenizer:
 
 class OPEN_CLIP(AbstractCLIPModel):
     supports_dynamic_batching = True
+    _own_text_tower = False   # subclasses that pair the CLIP image tower with a text encoder of their own (MULTILINGUAL_CLIP)
 
     def __init__(self, device: Optional[str] = None, model_properties: Optional[Dict] = None, model_auth=None) -> None:
         super().__init__(device, model_properties, model_auth)
@@ -216,7 +217,7 @@ class OPEN_CLIP(AbstractCLIPModel):
             sd = checkpoint.load_state_dict(ckpt)
             self.weights_source = ckpt
         elif checkpoint.synthetic_weights_enabled():
-            sd = synthetic.random_open_clip_state_dict(vision=self.vision_arch, text=self.text_arch, seed=0)
+            sd = synthetic.random_open_clip_state_dict(vision=self.vision_arch, text=None if self._own_text_tower else self.text_arch, seed=0)
             self.weights_source = "synthetic(seed=0)"
         else:
             raise ModelLoadError(f"no checkpoint for {props.name} under {checkpoint.model_dir()} (and no 'localpath'). There is no "
@@ -232,10 +233,7 @@ class OPEN_CLIP(AbstractCLIPModel):
                                   "interpolation": self._interpolation, "resize_mode": self._resize_mode}
         try:
             self.vision = towers.VitTower(self.vision_arch, sd, self.device, mean=self._mean, std=self._std, precision=props.engine_precision)
-            if isinstance(self.text_arch, archs.HfClipTextArch):   # open_clip HFTextEncoder: XLM-RoBERTa encoder + mean pooler + projection MLP
-                self.text = towers.HfClipTextTower(self.text_arch, sd, self.device, precision=props.engine_precision)
-            else:
-                self.text = towers.ClipTextTower(self.text_arch, sd, self.device, precision=props.engine_precision)
+            self.text = self._make_text_tower(sd, props.engine_precision)
         except ValueError as e:  # e.g. fp8 needs width / mlp_dim multiples of 128
             raise InvalidModelPropertiesError(str(e)) from e
         if props.engine_precision == "fp8":
@@ -250,6 +248,15 @@ class OPEN_CLIP(AbstractCLIPModel):
         if isinstance(self.tokenizer, ClipBpeTokenizer) and os.environ.get("MARQO_AMD_HOST_TOKENIZER", "0") != "1":
             from marqo_amd.engine.gpu_tokenizers import DeviceClipBpeTokenizer
             self._device_tokenizer = DeviceClipBpeTokenizer(self.tokenizer, self.device)
+        elif isinstance(self.tokenizer, XlmRobertaTokenizer) and os.environ.get("MARQO_AMD_HOST_TOKENIZER", "0") != "1":
+            from marqo_amd.engine.gpu_tokenizers import DeviceSentencePieceTokenizer
+            try:
+                self._device_tokenizer = DeviceSentencePieceTokenizer(self.tokenizer, self.device)
+            except ValueError:
+                self._device_tokenizer = None
+        elif isinstance(self.tokenizer, WordPieceTokenizer) and os.environ.get("MARQO_AMD_HOST_TOKENIZER", "0") != "1":
+            from marqo_amd.engine.gpu_tokenizers import DeviceWordPieceTokenizer
+            self._device_tokenizer = DeviceWordPieceTokenizer(self.tokenizer, self.device)
         elif isinstance(self.tokenizer, HfClipTokenizer) and isinstance(self.tokenizer.hf, XlmRobertaTokenizer) and \
                 os.environ.get("MARQO_AMD_HOST_TOKENIZER", "0") != "1":
             from marqo_amd.engine.gpu_tokenizers import DeviceSentencePieceTokenizer
@@ -265,6 +272,12 @@ class OPEN_CLIP(AbstractCLIPModel):
                 self._device_tokenizer = None
         self._ImagePreprocessor = ImagePreprocessor
         self.preprocess = self._preprocess_one
+
+    def _make_text_tower(self, sd, precision: str):
+        from marqo_amd.engine import towers
+        if isinstance(self.text_arch, archs.HfClipTextArch):   # open_clip HFTextEncoder: XLM-RoBERTa encoder + mean pooler + projection MLP
+            return towers.HfClipTextTower(self.text_arch, sd, self.device, precision=precision)
+        return towers.ClipTextTower(self.text_arch, sd, self.device, precision=precision)
 
     def _load_tokenizer(self, ckpt_dir: Optional[str]):
         props = self.model_properties
@@ -481,3 +494,108 @@ class FP16_CLIP(CLIP):
         if not str(device).startswith("cuda"):
             raise IncompatibleModelDeviceError("FP16 clip model `{}` is only available with device `cuda`.".format(model_type))
         super().__init__(model_type, device, embedding_dim, truncate, model_properties, model_auth, **kwargs)
+
+
+# ---- multilingual_clip ------------------------------------------------------------------------------------------------------------------
+def get_multilingual_clip_properties() -> Dict:
+    """the reference's multilingual_clip registry entries (clip_utils.py:599-641): an OpenAI / open_clip image tower paired with an M-CLIP
+    text encoder (github.com/FreddeFrallan/Multilingual-CLIP)"""
+    return {
+        "multilingual-clip/XLM-Roberta-Large-Vit-L-14": {
+            "name": "multilingual-clip/XLM-Roberta-Large-Vit-L-14", "visual_model": "openai/ViT-L/14",
+            "textual_model": "M-CLIP/XLM-Roberta-Large-Vit-L-14", "dimensions": 768, "type": "multilingual_clip"},
+        "multilingual-clip/XLM-R Large Vit-B/16+": {
+            "name": "multilingual-clip/XLM-R Large Vit-B/16+", "visual_model": "open_clip/ViT-B-16-plus-240/laion400m_e32",
+            "textual_model": "M-CLIP/XLM-Roberta-Large-Vit-B-16Plus", "dimensions": 640, "type": "multilingual_clip"},
+        "multilingual-clip/XLM-Roberta-Large-Vit-B-32": {
+            "name": "multilingual-clip/XLM-Roberta-Large-Vit-B-32", "visual_model": "openai/ViT-B/32",
+            "textual_model": "M-CLIP/XLM-Roberta-Large-Vit-B-32", "dimensions": 512, "type": "multilingual_clip"},
+        "multilingual-clip/LABSE-Vit-L-14": {
+            "name": "multilingual-clip/LABSE-Vit-L-14", "visual_model": "openai/ViT-L/14",
+            "textual_model": "M-CLIP/LABSE-Vit-L-14", "dimensions": 768, "type": "multilingual_clip"},
+    }
+
+
+# M-CLIP text encoders: `modelBase` of their MCLIPConfig -> the encoder architecture (the M-CLIP repos carry no Hugging Face config of it)
+_MCLIP_BASES = {
+    "xlm-roberta-large": archs.BertArch(vocab=250002, max_pos=512, width=1024, layers=24, heads=16, mlp_dim=4096, ln_eps=1e-5, pos_offset=2,
+                                        type_vocab=1),
+    "sentence-transformers/LaBSE": archs.BertArch(vocab=501153, max_pos=512),
+}
+_MCLIP_TEXTUAL = {"M-CLIP/XLM-Roberta-Large-Vit-L-14": "xlm-roberta-large", "M-CLIP/XLM-Roberta-Large-Vit-B-16Plus": "xlm-roberta-large",
+                  "M-CLIP/XLM-Roberta-Large-Vit-B-32": "xlm-roberta-large", "M-CLIP/LABSE-Vit-L-14": "sentence-transformers/LaBSE"}
+
+
+class MULTILINGUAL_CLIP(OPEN_CLIP):
+    """`multilingual_clip` loader type (clip_utils.py:521-597): `MULTILINGUAL_CLIP(model_type, device=, embedding_dim=, truncate=, **kwargs)`;
+    `visual_model` = the image tower of an OpenAI / open_clip checkpoint (the projected image features, as `model.visual.forward`),
+    `textual_model` = pt_multilingual_clip.MultilingualCLIP: HF encoder -> attention-masked mean -> one biased Linear
+    (engine/towers.py::MclipTextTower), tokenised by the textual model's own HF tokenizer with padding (sequences beyond the encoder's
+    512 positions, which the reference cannot run at all, are truncated)."""
+    _own_text_tower = True
+
+    def __init__(self, model_type: str = "multilingual-clip/ViT-L/14", device: str = None, embedding_dim: int = None, truncate: bool = True,
+                 model_properties: Optional[dict] = None, model_auth=None, **kwargs) -> None:
+        from marqo_amd.s2_inference.errors import InternalError
+        if not device:
+            raise InternalError("`device` is required for loading MULTILINGUAL CLIP models!")
+        table = get_multilingual_clip_properties()
+        if model_type not in table:
+            raise InvalidModelPropertiesError(f"unknown multilingual_clip model {model_type!r}")
+        self.model_name = model_type
+        self.model_info = table[model_type]
+        self.visual_name, self.textual_name = self.model_info["visual_model"], self.model_info["textual_model"]
+        v = self.visual_name
+        oc = (f"open_clip/{archs.OPENAI_CLIP_NAMES[v[len('openai/'):]]}/openai" if v.startswith("openai/") else v)
+        props = {"name": oc, "dimensions": self.model_info["dimensions"], "type": "open_clip"}
+        for k in ("enginePrecision", "fp8Budget"):
+            if model_properties and k in model_properties:
+                props[k] = model_properties[k]
+        super().__init__(device=device, model_properties=props, model_auth=model_auth)
+        self.truncate = truncate
+
+    def _make_text_tower(self, sd, precision: str):
+        from marqo_amd.engine import towers
+        base = _MCLIP_TEXTUAL.get(self.textual_name)
+        bert_arch = _MCLIP_BASES[base]
+        self._text_dir = checkpoint.find_hf_dir(self.textual_name)
+        if self._text_dir is not None:
+            cfg, tsd = checkpoint.load_hf_dir(self._text_dir)
+            if cfg.get("numDims", self.model_info["dimensions"]) != self.model_info["dimensions"]:
+                raise InvalidModelPropertiesError(f"{self.textual_name}: numDims {cfg.get('numDims')} != {self.model_info['dimensions']}")
+        elif checkpoint.synthetic_weights_enabled():
+            tsd = {"transformer." + k: v for k, v in synthetic.random_bert_state_dict(bert_arch, seed=1).items()}
+            g = torch.Generator().manual_seed(2)
+            D, W = self.model_info["dimensions"], bert_arch.width
+            tsd["LinearTransformation.weight"] = torch.randn(D, W, generator=g) / W ** 0.5
+            tsd["LinearTransformation.bias"] = 0.02 * torch.randn(D, generator=g)
+        else:
+            raise ModelLoadError(f"no checkpoint for {self.textual_name} under {checkpoint.model_dir()} (there is no network download in the "
+                                 f"marqo_amd engine; set MARQO_AMD_SYNTHETIC_WEIGHTS=1 for random-init weights)")
+        self.text_arch = archs.HfClipTextArch(bert=bert_arch, out_dim=self.model_info["dimensions"], ctx=bert_arch.max_pos)
+        return towers.MclipTextTower(bert_arch, self.model_info["dimensions"], tsd, self.device, precision=precision)
+
+    def _load_tokenizer(self, ckpt_dir: Optional[str]):
+        d = getattr(self, "_text_dir", None)
+        if d is not None:
+            if os.path.isfile(os.path.join(d, "sentencepiece.bpe.model")):
+                return XlmRobertaTokenizer(d)
+            if os.path.isfile(os.path.join(d, "vocab.txt")):
+                return WordPieceTokenizer(d, do_lower_case=False)   # LaBSE: cased WordPiece
+            raise ModelLoadError(f"{self.textual_name}: no tokenizer files (sentencepiece.bpe.model / vocab.txt) in {d}")
+        kind = "xlmr" if self.text_arch.bert.pos_offset else "bert"
+        return SyntheticTokenizer(kind, self.text_arch.vocab)
+
+    def encode_text(self, sentence: Union[str, List[str]], normalize=True, return_device: bool = False):
+        if self.model is None:
+            self.load()
+        texts = [sentence] if isinstance(sentence, str) else list(sentence)
+        max_len = self.text_arch.bert.max_pos
+        with request_stream(self.device, device_output=return_device):
+            if getattr(self, "_device_tokenizer", None) is not None:
+                d_ids, lens = self._device_tokenizer.encode_device(texts, max_len)
+                out = self.text.encode_device(d_ids, lens, normalize=bool(normalize))
+            else:
+                tok = self.tokenizer(texts, max_length=max_len)
+                out = self.text.encode_ids(torch.from_numpy(tok["input_ids"]), torch.from_numpy(tok["attention_mask"]), normalize=bool(normalize))
+            return out if return_device else self._convert_output(out)

@@ -381,6 +381,19 @@ def hf_clip_text_forward(sd: Dict[str, Tensor], cfg: BertConfig, ids: Tensor, pa
     return l2_normalize_clip(out) if normalize else out
 
 
+def mclip_text_forward(sd: Dict[str, Tensor], cfg: BertConfig, ids: Tensor, attention_mask: Tensor, normalize: bool = True) -> Tensor:
+    """Text encoder of the reference's multilingual_clip loader (clip_utils.py:553-565 -> `self.textual_model.forward(sentence, tokenizer)`
+    + its own normalisation).  multilingual_clip's pt_multilingual_clip.MultilingualCLIP.forward (third-party, un-vendored), restated:
+    embs = transformer(**tokens)[0]; embs = (embs * att[..., None]).sum(1) / att.sum(1)[:, None]; LinearTransformation(embs)."""
+    t = "transformer."
+    enc = {k[len(t):]: v for k, v in sd.items() if k.startswith(t)}
+    last = bert_forward(enc, cfg, ids, attention_mask)
+    att = attention_mask.to(last.dtype)
+    pooled = (last * att[..., None]).sum(dim=1) / att.sum(dim=1)[:, None]
+    out = F.linear(pooled, sd["LinearTransformation.weight"], sd["LinearTransformation.bias"])
+    return l2_normalize_clip(out) if normalize else out
+
+
 @dataclass
 class NewModelConfig:
     """Alibaba-NLP/new-impl `NewModel` (custom remote code: the reference's hf_stella loader runs it through AutoModel with

@@ -101,7 +101,7 @@ def test_registry_entries_match_reference(host):
         assert name in ref, f"{name} is registered here but not in the reference registry"
         r = ref[name]
         for field in ("name", "dimensions", "type", "tokens", "text_query_prefix", "text_chunk_prefix", "poolingMethod", "pretrained",
-                      "trustRemoteCode"):
+                      "trustRemoteCode", "visual_model", "textual_model"):
             if field in r:
                 assert p.get(field) == r[field], f"{name}.{field}: {p.get(field)!r} != reference {r[field]!r}"
                 checked += 1

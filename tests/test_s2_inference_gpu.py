@@ -430,6 +430,57 @@ def test_clip_with_roberta_text_tower_from_disk(s2, tmp_path, monkeypatch):
     assert _cos_err(img, refi) < COS_TOL
 
 
+def test_multilingual_clip_loader_type(s2, tmp_path, monkeypatch):
+    """the reference's `multilingual_clip` loader type (clip_utils.py:521-597): an OpenAI CLIP image tower paired with an M-CLIP text
+    encoder (HF encoder -> masked mean -> one biased Linear) from its own checkpoint directory; registry-name call through vectorise()"""
+    s2i, root = s2
+    import sentencepiece as spm
+    from safetensors.torch import save_file
+    from marqo_amd.engine import archs as A
+    from marqo_amd.engine.tokenizers import XlmRobertaTokenizer
+    from marqo_amd.s2_inference import open_clip_model as M
+    from tests.test_tokenizers import CORPUS, SENTENCES
+    monkeypatch.setenv("MARQO_AMD_SYNTHETIC_WEIGHTS", "1")      # the image tower: random-init ViT-B/32 (QuickGELU, OpenAI naming)
+    W, Lyr, H, Fd, D = 128, 2, 2, 256, 512
+    d = root / "hf" / "M-CLIP" / "XLM-Roberta-Large-Vit-B-32"
+    d.mkdir(parents=True, exist_ok=True)
+    (tmp_path / "corpus.txt").write_text("\n".join([" ".join(CORPUS)] * 20 + SENTENCES[:6] * 5), encoding="utf-8")
+    spm.SentencePieceTrainer.train(input=str(tmp_path / "corpus.txt"), model_prefix=str(d / "sentencepiece.bpe"), vocab_size=120,
+                                   model_type="unigram", character_coverage=1.0, hard_vocab_limit=False, minloglevel=2)
+    tok = XlmRobertaTokenizer(str(d))
+    small = A.BertArch(vocab=tok.vocab_size, max_pos=64, width=W, layers=Lyr, heads=H, mlp_dim=Fd, ln_eps=1e-5, pos_offset=2, type_vocab=1)
+    monkeypatch.setitem(M._MCLIP_BASES, "xlm-roberta-large", small)
+    bcfg = O.BertConfig(vocab=tok.vocab_size, max_pos=66, width=W, layers=Lyr, heads=H, mlp_dim=Fd, ln_eps=1e-5, pos_offset=2)
+    enc = O.synthetic_bert_state_dict(bcfg, seed=9)
+    enc["embeddings.token_type_embeddings.weight"] = enc["embeddings.token_type_embeddings.weight"][:1].clone()
+    sd = {"transformer." + k: v for k, v in enc.items()}
+    g = torch.Generator().manual_seed(10)
+    sd["LinearTransformation.weight"] = torch.randn(D, W, generator=g) / W ** 0.5
+    sd["LinearTransformation.bias"] = 0.1 * torch.randn(D, generator=g)
+    save_file({k: v.contiguous() for k, v in sd.items()}, str(d / "model.safetensors"))
+    (d / "config.json").write_text(json.dumps({"modelBase": "xlm-roberta-large", "transformerDimensions": W, "numDims": D}))
+    name = "multilingual-clip/XLM-Roberta-Large-Vit-B-32"
+    texts = ["A photo of a CAT!", "naïve café über straße", "東京 photos 2024", "fox " * 80]
+    out = np.asarray(s2i.vectorise(name, texts, device=DEV))
+    t = tok(texts, max_length=64)
+    ref = O.mclip_text_forward(sd, bcfg, torch.from_numpy(t["input_ids"]), torch.from_numpy(t["attention_mask"])).numpy()
+    assert out.shape == (4, D) and _cos_err(out, ref) < COS_TOL
+    model = s2i.get_available_models()[s2i._create_model_cache_key(name, DEV, s2i.get_model_properties_from_registry(name))]["model"]
+    assert type(model).__name__ == "MULTILINGUAL_CLIP" and type(model.text).__name__ == "MclipTextTower" and model.vision_arch.quick_gelu
+    assert type(model._device_tokenizer).__name__ == "DeviceSentencePieceTokenizer"
+    raw = np.asarray(s2i.vectorise(name, texts[:2], device=DEV, normalize_embeddings=False))
+    assert _cos_err(raw, O.mclip_text_forward(sd, bcfg, torch.from_numpy(t["input_ids"][:2]), torch.from_numpy(t["attention_mask"][:2]),
+                                              normalize=False).numpy()) < COS_TOL and not np.allclose(np.linalg.norm(raw, axis=1), 1, atol=1e-3)
+    rng = np.random.default_rng(2)
+    pil = [Image.fromarray(rng.integers(0, 256, (240, 300, 3), dtype=np.uint8)) for _ in range(2)]
+    img = np.asarray(s2i.vectorise(name, pil, device=DEV, modality=s2i.Modality.IMAGE))
+    assert img.shape == (2, D) and np.allclose(np.linalg.norm(img, axis=1), 1, atol=1e-5)
+    from marqo_amd.s2_inference.errors import InternalError
+    with pytest.raises(InternalError):
+        M.MULTILINGUAL_CLIP(name, device=None)
+    s2i.eject_model(name, DEV)
+
+
 def test_siglip_from_disk_text_and_image(s2, tmp_path, monkeypatch):
     """A SigLIP checkpoint through the loader: open_clip / timm tensor names (visual.trunk.*, text.*), SentencePiece tokenizer with
     canonicalize, SigLIP preprocessing (squash to S x S, mean = std = 0.5), 'open_clip' loader type — against the fp32 oracle.
