@@ -156,6 +156,44 @@ def _get_sbert_test_properties() -> Dict:
             "test_prefix": {**base, "text_query_prefix": "test query: ", "text_chunk_prefix": "test passage: "}}
 
 
+def _get_sbert_onnx_properties() -> Dict:
+    """`onnx/*` entries (model_registry.py:908-972): ONNX exports of the sbert checkpoints, served by the same HIP towers"""
+    out = {}
+    for repo, (d, t) in _SBERT.items():
+        short = repo.split("/")[-1]
+        if short in ("all-MiniLM-L12-v2", "stsb-xlm-r-multilingual"):   # (the reference registers no onnx export of these two)
+            continue
+        out["onnx/" + short] = {"name": repo, "dimensions": d, "tokens": t, "type": "sbert_onnx", "notes": ""}
+    return out
+
+
+# `onnx32/...` / `onnx16/...` entries (model_registry.py:1001-2065): ONNX exports of OpenAI / open_clip checkpoints; the ViT ones are served
+# by the HIP towers of the checkpoint they were exported from.  model -> (dimensions, resolution)
+_ONNX_CLIP = {
+    "openai/ViT-L/14": (768, 224), "open_clip/ViT-L-14/openai": (768, 224), "open_clip/ViT-L-14/laion400m_e32": (768, 224),
+    "open_clip/ViT-L-14/laion2b_s32b_b82k": (768, 224), "open_clip/ViT-L-14-336/openai": (768, 336),
+    "open_clip/ViT-B-32/openai": (512, 224), "open_clip/ViT-B-32/laion400m_e31": (512, 224), "open_clip/ViT-B-32/laion400m_e32": (512, 224),
+    "open_clip/ViT-B-32/laion2b_e16": (512, 224), "open_clip/ViT-B-32-quickgelu/openai": (512, 224),
+    "open_clip/ViT-B-32-quickgelu/laion400m_e31": (512, 224), "open_clip/ViT-B-32-quickgelu/laion400m_e32": (512, 224),
+    "open_clip/ViT-B-16/openai": (512, 224), "open_clip/ViT-B-16/laion400m_e31": (512, 224), "open_clip/ViT-B-16/laion400m_e32": (512, 224),
+    "open_clip/ViT-B-16-plus-240/laion400m_e31": (640, 240), "open_clip/ViT-B-16-plus-240/laion400m_e32": (640, 240),
+    "open_clip/ViT-H-14/laion2b_s32b_b79k": (1024, 224), "open_clip/ViT-g-14/laion2b_s12b_b42k": (1024, 224),
+}
+
+
+def _get_onnx_clip_properties() -> Dict:
+    out = {}
+    for model, (d, res) in _ONNX_CLIP.items():
+        for prec, bits in (("onnx32", "float32"), ("onnx16", "float16")):
+            name = f"{prec}/{model}"
+            out[name] = {"name": name, "dimensions": d, "type": "clip_onnx", "resolution": res,
+                         "note": f"the onnx {bits} export of {model}: served by the bf16 HIP towers of the same checkpoint"}
+            if model.startswith("open_clip/"):
+                # (metadata only; "laionb_s32b_b82k" sic: the spelling of the reference's own entry, model_registry.py:1090,1106)
+                out[name]["pretrained"] = "laionb_s32b_b82k" if model == "open_clip/ViT-L-14/laion2b_s32b_b82k" else model.split("/")[2]
+    return out
+
+
 def _get_random_properties() -> Dict:
     """random/* plumbing fakes (model_registry.py:2094-2123)."""
     return {
@@ -172,13 +210,13 @@ def _get_no_model_properties() -> Dict:
 
 def _get_model_load_mappings() -> Dict:
     # imported here so that `import marqo_amd.s2_inference.model_registry` stays cheap and free of cycles
-    from marqo_amd.s2_inference.open_clip_model import CLIP, FP16_CLIP, MULTILINGUAL_CLIP, OPEN_CLIP
+    from marqo_amd.s2_inference.open_clip_model import CLIP, CLIP_ONNX, FP16_CLIP, MULTILINGUAL_CLIP, OPEN_CLIP
     from marqo_amd.s2_inference.hugging_face_model import HuggingFaceModel, HuggingFaceStellaModel
     from marqo_amd.s2_inference.random_utils import NO_MODEL, Random
-    from marqo_amd.s2_inference.sbert_utils import SBERT, TEST
+    from marqo_amd.s2_inference.sbert_utils import SBERT, SBERT_ONNX, TEST
     return {"open_clip": OPEN_CLIP, "clip": CLIP, "fp16_clip": FP16_CLIP, "hf": HuggingFaceModel,
             "hf_stella": HuggingFaceStellaModel, "random": Random, "no_model": NO_MODEL, "sbert": SBERT, "test": TEST,
-            "multilingual_clip": MULTILINGUAL_CLIP}
+            "multilingual_clip": MULTILINGUAL_CLIP, "sbert_onnx": SBERT_ONNX, "clip_onnx": CLIP_ONNX}
 
 
 def load_model_properties() -> Dict:
@@ -186,6 +224,8 @@ def load_model_properties() -> Dict:
     models.update(_get_clip_properties())
     models.update(_get_sbert_properties())
     models.update(_get_sbert_test_properties())
+    models.update(_get_sbert_onnx_properties())
+    models.update(_get_onnx_clip_properties())
     models.update(_get_random_properties())
     models.update(_get_hf_properties())
     models.update(_get_open_clip_properties())

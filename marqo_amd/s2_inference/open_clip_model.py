@@ -599,3 +599,35 @@ class MULTILINGUAL_CLIP(OPEN_CLIP):
                 tok = self.tokenizer(texts, max_length=max_len)
                 out = self.text.encode_ids(torch.from_numpy(tok["input_ids"]), torch.from_numpy(tok["attention_mask"]), normalize=bool(normalize))
             return out if return_device else self._convert_output(out)
+
+
+# ---- clip_onnx ------------------------------------------------------------------------------------------------------------------------
+class CLIP_ONNX(OPEN_CLIP):
+    """`clip_onnx` loader type (onnx_clip_utils.py:55-175): `onnx32/...` / `onnx16/...` names are ONNX exports of OpenAI / open_clip CLIP
+    checkpoints (visual + textual graphs run by onnxruntime in fp32 / fp16).  Same weights: here they are served by the HIP towers of the
+    checkpoint they were exported from (there is no onnxruntime in the engine; both precisions run the bf16 MFMA path), behind the
+    reference's constructor `CLIP_ONNX(model_name, device=, embedding_dim=, truncate=, load=True)`.  Only the ViT exports are registered."""
+
+    def __init__(self, model_name: str = "onnx32/openai/ViT-L/14", device: str = None, embedding_dim: int = None, truncate: bool = True,
+                 load: bool = True, model_properties: Optional[dict] = None, model_auth=None, **kwargs) -> None:
+        from marqo_amd.s2_inference.errors import InternalError
+        if not device:
+            raise InternalError("`device` is required for loading CLIP ONNX models!")
+        try:
+            self.onnx_type, self.source, self.clip_model = model_name.split("/", 2)
+        except ValueError:
+            raise InvalidModelPropertiesError(f"clip_onnx names look like onnx32/<source>/<model>, got {model_name!r}")
+        if self.onnx_type not in ("onnx16", "onnx32") or self.source not in ("openai", "open_clip"):
+            raise InvalidModelPropertiesError(f"clip_onnx names look like onnx16|onnx32/openai|open_clip/<model>, got {model_name!r}")
+        if self.source == "openai":
+            if self.clip_model not in archs.OPENAI_CLIP_NAMES:
+                raise InvalidModelPropertiesError(f"{model_name}: {archs.UNSUPPORTED_HINT}")
+            name = f"open_clip/{archs.OPENAI_CLIP_NAMES[self.clip_model]}/openai"
+        else:
+            name = "open_clip/" + self.clip_model
+        props = {"name": name, "dimensions": (model_properties or {}).get("dimensions", embedding_dim), "type": "open_clip"}
+        for k in ("enginePrecision", "fp8Budget"):
+            if model_properties and k in model_properties:
+                props[k] = model_properties[k]
+        super().__init__(device=device, model_properties=props, model_auth=model_auth)
+        self.model_name, self.truncate = model_name, truncate

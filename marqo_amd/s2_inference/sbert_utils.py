@@ -130,3 +130,25 @@ class TEST(SBERT):
                 L.check(L.load().mq_l2_normalize(emb.data_ptr(), emb.data_ptr(), emb.shape[0], emb.shape[1],
                                                  torch.cuda.current_stream(emb.device).cuda_stream), "mq_l2_normalize")
         return emb if kwargs.get("return_device") else emb.cpu()
+
+
+class SBERT_ONNX(SBERT):
+    """`sbert_onnx` loader type (sbert_onnx_utils.py:19-218: the encoder exported to ONNX, run by onnxruntime, then the loader's own
+    attention-masked mean and optional L2).  Same weights, same arithmetic as the `sbert` entries: here the `onnx/*` names are served by
+    the HIP towers (there is no onnxruntime in the engine); the checkpoint's SentenceTransformer Normalize module is NOT applied, as in the
+    reference's exported graph.  Constructor as the reference: SBERT_ONNX(model_name_or_path, device=, embedding_dim=, max_seq_length=128, ...)."""
+
+    def __init__(self, model_name_or_path: Optional[str] = None, device: Optional[str] = None, embedding_dim=None, max_seq_length: int = 128,
+                 lower_case: bool = True, **kwargs) -> None:
+        kwargs.pop("cache_folder", None), kwargs.pop("onnx_folder", None), kwargs.pop("onnx_model_name", None), kwargs.pop("enable_overwrite", None)
+        super().__init__(model_name_or_path, device=device, embedding_dim=embedding_dim, max_seq_length=max_seq_length, **kwargs)
+        self.model_name_or_path = model_name_or_path
+
+    def load(self) -> None:
+        super().load()
+        self.always_normalized = False
+
+    def encode(self, sentences: Union[str, List[str]], normalize: bool = True, **kwargs):
+        kw = {"return_device": True} if kwargs.get("return_device") else {}
+        out = self._embed(sentences, normalize, **kw)
+        return out if kw else torch.from_numpy(self._convert_output(out))   # (the reference returns a CPU FloatTensor)

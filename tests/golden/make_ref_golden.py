@@ -86,7 +86,7 @@ def main(out_dir: str) -> None:
     keep = ("name", "dimensions", "type", "tokens", "text_query_prefix", "text_chunk_prefix", "poolingMethod", "pretrained",
             "trustRemoteCode", "image_preprocessor", "imagePreprocessor", "tokenizer", "visual_model", "textual_model")
     host["registry_models"] = {k: {f: v[f] for f in keep if f in v} for k, v in sorted(reg["models"].items())
-                               if v.get("type") in ("open_clip", "hf", "clip", "fp16_clip", "random", "no_model", "hf_stella", "sbert", "test", "multilingual_clip")}
+                               if v.get("type") in ("open_clip", "hf", "clip", "fp16_clip", "random", "no_model", "hf_stella", "sbert", "test", "multilingual_clip", "sbert_onnx", "clip_onnx")}
     host["registry_loader_types"] = sorted(reg["loaders"].keys())
     host["registry_all_types"] = {t: sum(1 for v in reg["models"].values() if v.get("type") == t)
                                   for t in sorted({v.get("type") for v in reg["models"].values()})}

@@ -481,6 +481,32 @@ def test_multilingual_clip_loader_type(s2, tmp_path, monkeypatch):
     s2i.eject_model(name, DEV)
 
 
+def test_onnx_loader_types_are_served_by_the_same_towers(s2, monkeypatch):
+    """`clip_onnx` / `sbert_onnx` registry names are ONNX exports of checkpoints the engine already runs: same embeddings as the entry they
+    were exported from (the reference's constructors and return types kept)"""
+    s2i, root = s2
+    monkeypatch.setenv("MARQO_AMD_SYNTHETIC_WEIGHTS", "1")
+    texts = ["a photo of a cat", "a dog on the beach"]
+    for onnx, plain in (("onnx32/open_clip/ViT-B-32/laion400m_e32", "open_clip/ViT-B-32/laion400m_e32"), ("onnx16/openai/ViT-L/14", "ViT-L/14")):
+        a = np.asarray(s2i.vectorise(onnx, texts, device=DEV))
+        b = np.asarray(s2i.vectorise(plain, texts, device=DEV))
+        assert a.shape == b.shape and np.array_equal(a, b), onnx
+        key = s2i._create_model_cache_key(onnx, DEV, s2i.get_model_properties_from_registry(onnx))
+        assert type(s2i.get_available_models()[key]["model"]).__name__ == "CLIP_ONNX"
+        s2i.eject_model(onnx, DEV), s2i.eject_model(plain, DEV)
+    a = np.asarray(s2i.vectorise("onnx/all-MiniLM-L6-v2", texts, device=DEV))
+    b = np.asarray(s2i.vectorise("sentence-transformers/all-MiniLM-L6-v2", texts, device=DEV))
+    assert a.shape == (2, 384) and np.array_equal(a, b)
+    from marqo_amd.s2_inference.sbert_utils import SBERT_ONNX
+    m = SBERT_ONNX("sentence-transformers/all-MiniLM-L6-v2", device=DEV, embedding_dim=384, max_seq_length=256)
+    out = m.encode(texts)
+    assert isinstance(out, torch.Tensor) and out.device.type == "cpu" and np.allclose(out.numpy(), a, atol=1e-6)
+    from marqo_amd.s2_inference.errors import InvalidModelPropertiesError
+    from marqo_amd.s2_inference.open_clip_model import CLIP_ONNX
+    with pytest.raises(InvalidModelPropertiesError):
+        CLIP_ONNX("onnx32/open_clip/RN50/openai", device=DEV, embedding_dim=1024).load()
+
+
 def test_siglip_from_disk_text_and_image(s2, tmp_path, monkeypatch):
     """A SigLIP checkpoint through the loader: open_clip / timm tensor names (visual.trunk.*, text.*), SentencePiece tokenizer with
     canonicalize, SigLIP preprocessing (squash to S x S, mean = std = 0.5), 'open_clip' loader type — against the fp32 oracle.
