@@ -29,10 +29,11 @@ void* stream_of(const at::Tensor& t) {
     return (void*)c10::hip::getCurrentHIPStream(t.device().index()).stream();
 }
 
-// The tower ops enqueue ~100-800 kernel launches (0.5 - 2 ms of host time) and touch no Python object meanwhile, so they MAY run without
-// the GIL (MARQO_AMD_OPS_RELEASE_GIL=1).  Measured with 4 concurrent 256-image callers (profiles/r02t_gil_boundary_ab.txt): holding the
-// GIL 63-65 k embeddings/s, releasing it 62 k (re-acquiring it costs what the release buys), the ctypes boundary 69-73 k; one caller:
-// 40-41 k all three.  Default: hold.
+// The tower ops enqueue ~100-800 kernel launches (0.5 - 2 ms of host time) and touch no Python object meanwhile.  torch's Python binding
+// already drops the GIL around an operator call (so PyGILState_Check() is false here and this guard is a no-op on that route); the guard
+// only matters for callers that invoke the ops from C++ while holding the GIL (MARQO_AMD_OPS_RELEASE_GIL=1).  Measured with 4 concurrent
+// 256-image callers (profiles/r02t_gil_boundary_ab.txt, r02z_chain_large_calls_ab.txt): 62-73 k embeddings/s with or without it and
+// through the ctypes boundary alike (run-to-run spread).
 const bool g_release_gil = [] { const char* v = getenv("MARQO_AMD_OPS_RELEASE_GIL"); return v && v[0] == '1'; }();
 struct NoGil {
     PyThreadState* st;

@@ -320,6 +320,42 @@ class request_stream:
         return False
 
 
+# Experiment knob (MARQO_AMD_CHAIN_LARGE_CALLS=1, off by default): chain chip-filling tower calls of concurrent request threads on the GPU
+# instead of letting their kernels interleave.  A call of >= LARGE_CALL_ROWS token rows launches kernels that each fill the 256 CUs, so the
+# idea was that FIFO execution (each such call waits, on the GPU, for the completion event of the previous one on that device, while its own
+# pack / H2D / resize still overlap) keeps cache residency.  Measured with 256-image callers (profiles/r02z_chain_large_calls_ab.txt):
+# 2 callers 70.0 k vs 67.6 k embeddings/s unchained (+3 %), 4 callers 61 k vs 68-73 k (-10 %): the hardware's own interleaving of four
+# streams hides the tails of one call behind another's kernels better than strict FIFO does.
+CHAIN_LARGE_CALLS = os.environ.get("MARQO_AMD_CHAIN_LARGE_CALLS", "0") == "1"
+LARGE_CALL_ROWS = int(os.environ.get("MARQO_AMD_LARGE_CALL_ROWS", "4096"))
+_chain_lock = threading.Lock()
+_chain_last: Dict[int, "torch.cuda.Event"] = {}
+
+
+class _large_call:
+    """`with _large_call(device, rows):` around the enqueue of one tower call"""
+
+    def __init__(self, device: torch.device, rows: int):
+        self.on = CHAIN_LARGE_CALLS and rows >= LARGE_CALL_ROWS and not torch.cuda.is_current_stream_capturing()
+        self.device = device
+
+    def __enter__(self):
+        if self.on:
+            idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+            self._idx, self._mine = idx, torch.cuda.Event()
+            with _chain_lock:
+                prev, _chain_last[idx] = _chain_last.get(idx), self._mine
+            self._stream = torch.cuda.current_stream(self.device)
+            if prev is not None:
+                self._stream.wait_event(prev)
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self._mine.record(self._stream)   # (recorded even when the body raised: later callers must never wait on an unrecorded event)
+        return False
+
+
 class _TowerBase:
     _fp8: Optional[_Fp8State] = None
 
@@ -595,7 +631,7 @@ class VitTower(_TowerBase):
                     done.record(st)
                     cur.wait_event(done)
             return out
-        with torch.cuda.device(self.device):
+        with torch.cuda.device(self.device), _large_call(self.device, n * self.arch.tokens):
             for i in range(0, n, self.max_images_per_call):
                 m = min(self.max_images_per_call, n - i)
                 need = self.lib.mq_vit_workspace_bytes(C.byref(self.cfg), m)
@@ -709,7 +745,7 @@ class _TextTowerBase(_TowerBase):
                 return one
         out_dim = self.arch.out_dim if clip else self.out_width
         out = torch.empty(n, out_dim, dtype=torch.float32, device=self.device)
-        with torch.cuda.device(self.device):
+        with torch.cuda.device(self.device), _large_call(self.device, int(lengths.sum())):
             for a, b in self._chunks(lengths):
                 cu = torch.zeros(b - a + 1, dtype=torch.int32)
                 cu[1:] = lengths[a:b].cumsum(0).to(torch.int32)
@@ -798,7 +834,7 @@ class ClipTextTower(_TextTowerBase):
             if one is not None:
                 return one
         out = torch.empty(n, self.arch.out_dim, dtype=torch.float32, device=self.device)
-        with torch.cuda.device(self.device):
+        with torch.cuda.device(self.device), _large_call(self.device, int(lengths.sum())):
             for a, b in self._chunks(lengths):
                 packed, cu = _pack(ids_h[a:b], lengths[a:b])
                 pool_rows = None if pack else (cu[:-1].to(torch.int64) + eot[a:b]).to(torch.int32)
@@ -950,7 +986,7 @@ class BertTower(_TextTowerBase):
             if one is not None:
                 return one
         out = torch.empty(n, self.out_width, dtype=torch.float32, device=self.device)
-        with torch.cuda.device(self.device):
+        with torch.cuda.device(self.device), _large_call(self.device, int(lengths.sum())):
             for a, b in self._chunks(lengths):
                 packed, cu = _pack(ids_h[a:b], lengths[a:b])
                 d_ids = self._to_device(packed)
