@@ -64,6 +64,8 @@ extern "C" {
 
 #define MQ_VIT_POOL_CLS 0 /* open_clip VisionTransformer: class token */
 #define MQ_VIT_POOL_MAP 1 /* timm SigLIP ViT: attention-pool ('map') head */
+#define MQ_VIT_POOL_AVG 2 /* open_clip VisionTransformer pool_type 'avg' with final_ln_after_pool (CLIPA): mean of the patch tokens -> ln_post -> proj;
+                           * ln_pre_g / ln_pre_b may be NULL (no_ln_pre) */
 
 /* GEMM epilogue flags for mq_gemm_bf16 */
 #define MQ_EPI_BIAS 1      /* + bias[n] (fp32) */

@@ -31,7 +31,7 @@ MQ_PREC_BF16, MQ_PREC_FP8 = 0, 1
 MQ_ACT_GELU, MQ_ACT_QUICKGELU = 1, 2
 MQ_MASK_NONE, MQ_MASK_CAUSAL = 0, 1
 MQ_POOL_MEAN, MQ_POOL_CLS = 0, 1
-MQ_VIT_POOL_CLS, MQ_VIT_POOL_MAP = 0, 1
+MQ_VIT_POOL_CLS, MQ_VIT_POOL_MAP, MQ_VIT_POOL_AVG = 0, 1, 2
 MQ_EPI_BIAS, MQ_EPI_GELU, MQ_EPI_QUICKGELU, MQ_EPI_RESIDUAL, MQ_EPI_OUT_F32, MQ_EPI_OUT_FP8 = 1, 2, 4, 8, 16, 32
 MQ_EPI_LN_STATS, MQ_EPI_LN_APPLY = 64, 128
 MQ_COMBINE_RAW, MQ_COMBINE_NORMALIZE, MQ_COMBINE_NORMALIZE_IF_NONZERO = 0, 1, 2

@@ -368,6 +368,34 @@ int mq_vit_assemble(const float* d_patch_out, const float* cls, const float* pos
     return MQ_OK;
 }
 
+// mean over the tokens [first, T) of every image (open_clip VisionTransformer pool_type 'avg': the patch tokens, without the class token)
+__global__ __launch_bounds__(256) void avg_tokens_kernel(const void* __restrict__ xv, int x_bf16, float* __restrict__ out, int T, int first, int W) {
+    const int64_t img = blockIdx.x;
+    const float inv = 1.0f / (float)(T - first);
+    for (int c = threadIdx.x * 4; c < W; c += 256 * 4) {
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = first; t < T; ++t) {
+            const int64_t o = (img * T + t) * (int64_t)W + c;
+            if (x_bf16) {
+                const uint2 q = *(const uint2*)((const bf16_t*)xv + o);
+                acc += f32x4{__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u), __uint_as_float(q.y << 16), __uint_as_float(q.y & 0xffff0000u)};
+            } else {
+                acc += *(const f32x4*)((const float*)xv + o);
+            }
+        }
+        *(f32x4*)(out + img * W + c) = acc * inv;
+    }
+}
+
+int mq_avg_tokens(const void* d_x, int x_bf16, float* d_out, int64_t n, int T, int first, int W, hipStream_t s) {
+    MQ_CHECK_ARG(W % 4 == 0 && first >= 0 && first < T, "avg_tokens: bad shape W=%d T=%d first=%d", W, T, first);
+    if (n <= 0) return MQ_OK;
+    MqProfScope prof(4, s);
+    hipLaunchKernelGGL(avg_tokens_kernel, dim3((unsigned)n), dim3(256), 0, s, d_x, x_bf16, d_out, T, first, W);
+    MQ_CHECK_LAUNCH("avg_tokens");
+    return MQ_OK;
+}
+
 int mq_map_pool(const void* d_kv, const float* d_q, void* d_out, int64_t n, int T, int W, int heads, hipStream_t s) {
     MQ_CHECK_ARG(heads >= 1 && W % heads == 0, "map_pool: W=%d heads=%d", W, heads);
     const int hd = W / heads;

@@ -21,6 +21,7 @@ int mq_pool(const float* d_x, const int32_t* d_cu, int64_t nseq, float* d_out, i
 int mq_last_rows(const int32_t* d_cu, int32_t* d_rows, int64_t nseq, hipStream_t s);
 int mq_cls_rows(int32_t* d_rows, int64_t n, int T, hipStream_t s);
 int mq_map_pool(const void* d_kv, const float* d_q, void* d_out, int64_t n, int T, int W, int heads, hipStream_t s);
+int mq_avg_tokens(const void* d_x, int x_bf16, float* d_out, int64_t n, int T, int first, int W, hipStream_t s);
 int mq_move_rows(void* d_sparse, const int32_t* d_idx, void* d_dense, int64_t n, int64_t row_bytes, bool scatter, hipStream_t s);
 int mq_rope(void* d_qkv, const int32_t* d_cu, int64_t nseq, int fixed_len, int Wa, int heads, const float* d_inv_freq, hipStream_t s);
 int mq_glu(void* d_buf, int64_t rows, int F, int quick, hipStream_t s);
@@ -435,7 +436,8 @@ int encode_image_impl(const mq_vit_cfg* cfg, const mq_vit_weights* w, const void
                  cfg->image_size, cfg->patch_size);  // floor(S / P) patches per side, like the strided conv (trailing pixels unread)
     MQ_CHECK_ARG(cfg->out_dim >= 4 && cfg->out_dim % 4 == 0, "mq_encode_image: out_dim %d must be a multiple of 4", cfg->out_dim);
     const bool map = cfg->pool == MQ_VIT_POOL_MAP;
-    MQ_CHECK_ARG(cfg->pool == MQ_VIT_POOL_CLS || map, "mq_encode_image: bad pool %d", cfg->pool);
+    const bool avg = cfg->pool == MQ_VIT_POOL_AVG;
+    MQ_CHECK_ARG(cfg->pool == MQ_VIT_POOL_CLS || map || avg, "mq_encode_image: bad pool %d", cfg->pool);
     MQ_CHECK_ARG(w->patch_w && w->pos && w->ln_post_g && w->ln_post_b, "mq_encode_image: null weight pointer");
     const int W = cfg->enc.width;
     if (map) {
@@ -446,7 +448,8 @@ int encode_image_impl(const mq_vit_cfg* cfg, const mq_vit_weights* w, const void
         MQ_CHECK_ARG(cfg->map_mlp_dim >= 64 && cfg->map_mlp_dim % 64 == 0, "mq_encode_image: map_mlp_dim %d must be a multiple of 64", cfg->map_mlp_dim);
         MQ_CHECK_ARG(w->proj_w || cfg->out_dim == W, "mq_encode_image: without a projection out_dim (%d) must equal the width (%d)", cfg->out_dim, W);
     } else {
-        MQ_CHECK_ARG(w->cls && w->ln_pre_g && w->ln_pre_b && w->proj_w, "mq_encode_image: null weight pointer");
+        MQ_CHECK_ARG(w->cls && w->proj_w && (avg || (w->ln_pre_g && w->ln_pre_b)) && (!w->ln_pre_g == !w->ln_pre_b),
+                     "mq_encode_image: null weight pointer (ln_pre may be absent only with MQ_VIT_POOL_AVG)");
     }
     if (n <= 0) return MQ_OK;
     MQ_CHECK_ARG(d_pixels && ws, "mq_encode_image: null input / workspace");
@@ -494,6 +497,17 @@ int encode_image_impl(const mq_vit_cfg* cfg, const mq_vit_weights* w, const void
         } else {
             MQ_CHECK_HIP(hipMemcpyAsync(d_out, y, (size_t)n * W * 4, hipMemcpyDeviceToDevice, s));
         }
+        return MQ_OK;
+    }
+    if (avg) {
+        // open_clip VisionTransformer with pool_type 'avg' + final_ln_after_pool (the CLIPA towers): every token runs every block, the PATCH
+        // tokens are averaged, ln_post normalises the pooled row, then the projection
+        MQ_TRY(encoder_forward_impl(&cfg->enc, w->blocks, x, p.rows, nullptr, n, p.T, p.T, nullptr, 0, base + p.off_enc, ws_bytes - p.off_enc, s));
+        float* pooled = (float*)(base + p.off_enc);   // (the encoder's scratch is free again)
+        MQ_TRY(mq_avg_tokens(x, xb, pooled, n, p.T, 1, W, s));
+        MQ_TRY(mq_layernorm(pooled, nullptr, w->ln_post_g, w->ln_post_b, cls_ln, nullptr, n, W, cfg->enc.ln_eps, s));
+        MQ_TRY(mq_gemm_bf16(cls_ln, W, w->proj_w, W, nullptr, nullptr, d_out, cfg->out_dim, n, cfg->out_dim, W, MQ_EPI_OUT_F32, s));
+        if (normalize) MQ_TRY(mq_l2_normalize(d_out, d_out, n, cfg->out_dim, s));
         return MQ_OK;
     }
     // K2-K5 x layers (only the class-token rows are read afterwards -> the last block's row-wise half runs on them alone)

@@ -26,11 +26,15 @@ class VitArch:
     quick_gelu: bool = False
     ln_eps: float = 1e-5
     pool: str = "cls"  # "cls": open_clip VisionTransformer (class token, ln_pre, ln_post(class token) @ proj);
-    #                    "map": timm SigLIP ViT behind open_clip's TimmModel (no class token, no ln_pre, attention-pool head, no proj)
+    #                    "map": timm SigLIP ViT behind open_clip's TimmModel (no class token, no ln_pre, attention-pool head, no proj);
+    #                    "avg": open_clip VisionTransformer with pool_type 'avg' + final_ln_after_pool (CLIPA): class token kept in the sequence,
+    #                           mean of the PATCH tokens -> ln_post -> proj
+    ln_pre: bool = True          # False: `no_ln_pre` (CLIPA)
+    preprocessor: Optional[str] = None   # open_clip preprocess config of the registry entry when it is not the default ("CLIPA")
 
     @property
     def tokens(self) -> int:
-        return (self.image_size // self.patch_size) ** 2 + (1 if self.pool == "cls" else 0)
+        return (self.image_size // self.patch_size) ** 2 + (0 if self.pool == "map" else 1)
 
     @property
     def gflop_per_image(self) -> float:
@@ -60,6 +64,8 @@ class ClipTextArch:
     proj_bias: bool = False   # SigLIP: text_projection is a Linear with bias
     prefix: str = ""          # checkpoint key prefix: "" for CLIP, "text." under open_clip's CustomTextCLIP (SigLIP)
     pad_id: int = 0
+    hf_tokenizer: Optional[str] = None   # open_clip HFTokenizer(<name>) instead of the CLIP BPE (CLIPA: "bert-base-uncased")
+    strip_sep: bool = False              # HFTokenizer(strip_sep_token=True): [SEP] ids are replaced by 0 after tokenisation
 
     def gflop_per_text(self, tokens: Optional[int] = None) -> float:
         T, W, F = tokens or self.ctx, self.width, self.mlp_dim
@@ -182,6 +188,11 @@ OPEN_CLIP_ARCHS = {
     "ViT-H-14": (VitArch(224, 14, 1280, 32, 16, 5120, 1024), _TEXT_H),
     # CLIPs with a Hugging Face text tower: the ViT towers above with a RoBERTa / XLM-RoBERTa encoder (open_clip model configs
     # roberta-ViT-B-32, xlm-roberta-base-ViT-B-32, xlm-roberta-large-ViT-H-14; model_registry.py:257-273 in the reference)
+    # CLIPA (open_clip ViT-L-14-CLIPA-336: no ln_pre, average pooling of the patch tokens with the final LayerNorm after it; unmasked text
+    # tower with last-position pooling over bert-base-uncased WordPiece ids without [SEP], 32 positions; bilinear-squash preprocessing)
+    "ViT-L-14-CLIPA-336": (VitArch(336, 14, 1024, 24, 16, 4096, 768, pool="avg", ln_pre=False, preprocessor="CLIPA"),
+                           ClipTextArch(vocab=32000, ctx=32, width=768, layers=12, heads=12, mlp_dim=3072, out_dim=768, causal=False,
+                                        hf_tokenizer="bert-base-uncased", strip_sep=True)),
     "roberta-ViT-B-32": (VitArch(224, 32, 768, 12, 12, 3072, 512, quick_gelu=True), "roberta-base:512"),   # (its model config sets quick_gelu)
     "xlm-roberta-base-ViT-B-32": (VitArch(224, 32, 768, 12, 12, 3072, 512), "xlmr-base:512"),
     "xlm-roberta-large-ViT-H-14": (VitArch(224, 14, 1280, 32, 16, 5120, 1024), "xlmr-large:1024"),

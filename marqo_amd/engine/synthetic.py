@@ -72,7 +72,8 @@ def random_open_clip_state_dict(vision: VitArch = None, text: ClipTextArch = Non
         sd["visual.conv1.weight"] = torch.randn(W, 3, P, P, generator=g) / math.sqrt(3 * P * P)
         sd["visual.class_embedding"] = 0.5 * torch.randn(W, generator=g)
         sd["visual.positional_embedding"] = 0.3 * torch.randn(vision.tokens, W, generator=g)
-        _ln(sd, "visual.ln_pre", W, g)
+        if vision.ln_pre:
+            _ln(sd, "visual.ln_pre", W, g)
         _resblocks(sd, "visual.transformer.", vision.layers, W, vision.mlp_dim, g)
         _ln(sd, "visual.ln_post", W, g)
         sd["visual.proj"] = torch.randn(W, vision.out_dim, generator=g) / math.sqrt(W)

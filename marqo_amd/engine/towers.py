@@ -575,15 +575,18 @@ class VitTower(_TowerBase):
         else:
             patch_w[:, :K] = _need(sd, "visual.conv1.weight", (W, 3, P, P)).detach().to(torch.float32).reshape(W, K)
             self._blocks = _clip_blocks(h, sd, "visual.transformer.", arch.layers, W, arch.mlp_dim, arch.heads)
+            if arch.pool == "avg" and arch.ln_pre:
+                raise ValueError("pool 'avg' is built for the no_ln_pre / final_ln_after_pool form (CLIPA)")
             self.w = L.VitWeights(
                 patch_w=h.bf16(patch_w),
                 cls=h.f32(_need(sd, "visual.class_embedding", (W,))),
                 pos=h.f32(_need(sd, "visual.positional_embedding", (arch.tokens, W))),
-                ln_pre_g=h.f32(_need(sd, "visual.ln_pre.weight", (W,))), ln_pre_b=h.f32(_need(sd, "visual.ln_pre.bias", (W,))),
+                ln_pre_g=h.f32(_need(sd, "visual.ln_pre.weight", (W,))) if arch.ln_pre else None,
+                ln_pre_b=h.f32(_need(sd, "visual.ln_pre.bias", (W,))) if arch.ln_pre else None,
                 blocks=self._blocks,
                 ln_post_g=h.f32(_need(sd, "visual.ln_post.weight", (W,))), ln_post_b=h.f32(_need(sd, "visual.ln_post.bias", (W,))),
                 proj_w=h.bf16(_need(sd, "visual.proj", (W, arch.out_dim)).detach().to(torch.float32).t()), map=None)
-            pool, map_mlp = L.MQ_VIT_POOL_CLS, 0
+            pool, map_mlp = (L.MQ_VIT_POOL_AVG if arch.pool == "avg" else L.MQ_VIT_POOL_CLS), 0
         self.cfg = L.VitCfg(enc=_encoder_cfg(W, arch.layers, arch.heads, arch.mlp_dim, arch.quick_gelu, False,
                                              L.MQ_MASK_NONE, arch.ln_eps),
                             image_size=arch.image_size, patch_size=P, out_dim=arch.out_dim,

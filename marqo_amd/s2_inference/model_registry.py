@@ -17,6 +17,7 @@ from marqo_amd.engine import archs
 # pretrained tags the reference registers for the supported architectures (model_registry.py:76-610)
 _OPEN_CLIP_TAGS = {
     # multilingual CLIPs: ViT image tower + XLM-RoBERTa text tower (open_clip HFTextEncoder; model_registry.py:262-273)
+    "ViT-L-14-CLIPA-336": ("datacomp1b",),
     "roberta-ViT-B-32": ("laion2b_s12b_b32k",),
     "xlm-roberta-base-ViT-B-32": ("laion5b_s13b_b90k",),
     "xlm-roberta-large-ViT-H-14": ("frozen_laion5b_s13b_b90k",),

@@ -225,7 +225,7 @@ class OPEN_CLIP(AbstractCLIPModel):
         # preprocessing: a custom checkpoint follows 'image_preprocessor' (open_clip_model.py:87-104); registry and hf-hub names
         # get open_clip's own transform for that model (create_model_and_transforms, :183-205) — the SigLIP pipeline for SigLIP towers
         custom = props.localpath is not None
-        kind = props.image_preprocessor if custom else ("SigLIP" if self.vision_arch.pool == "map" else "OpenCLIP")
+        kind = props.image_preprocessor if custom else (self.vision_arch.preprocessor or ("SigLIP" if self.vision_arch.pool == "map" else "OpenCLIP"))
         mean, std, self._resize_mode, self._interpolation = _PREPROCESSOR_NORMS[kind]
         self._mean = tuple(props.mean) if props.mean is not None else mean
         self._std = tuple(props.std) if props.std is not None else std
@@ -281,20 +281,27 @@ class OPEN_CLIP(AbstractCLIPModel):
 
     def _load_tokenizer(self, ckpt_dir: Optional[str]):
         props = self.model_properties
-        if props.tokenizer:
-            d = checkpoint.find_hf_dir(props.tokenizer) or (props.tokenizer if os.path.isdir(props.tokenizer) else None)
+        hf_name = props.tokenizer or getattr(self.text_arch, "hf_tokenizer", None)
+        if hf_name and not isinstance(self.text_arch, archs.HfClipTextArch):
+            d = checkpoint.find_hf_dir(hf_name) or (hf_name if os.path.isdir(hf_name) else None) or \
+                (ckpt_dir if ckpt_dir and os.path.isfile(os.path.join(ckpt_dir, "vocab.txt")) else None)
             if d is None:
-                raise ModelLoadError(f"custom tokenizer {props.tokenizer!r} not found on disk")
+                if self.weights_source and str(self.weights_source).startswith("synthetic"):
+                    return SyntheticTokenizer("clip", self.text_arch.vocab, self.text_arch.ctx)
+                raise ModelLoadError(f"tokenizer {hf_name!r} (vocab.txt / tokenizer.json) not found on disk")
             wp = WordPieceTokenizer(d)
             ctx = self.text_arch.ctx
-            # open_clip HFTokenizer: padding='max_length', truncation=True -> ids only (hf_tokenizer.py:19-32)
+            strip_sep = bool(getattr(self.text_arch, "strip_sep", False))
+            # open_clip HFTokenizer: clean, padding='max_length', truncation=True -> ids only; strip_sep_token: [SEP] -> 0 (tokenizer.py)
             def hf_tok(texts):
                 if isinstance(texts, str):
                     texts = [texts]
                 out = np.zeros((len(texts), ctx), dtype=np.int64)
                 for i, t in enumerate(texts):
-                    ids = wp.encode(t, max_length=ctx)
+                    ids = wp.encode(_clean_text(t), max_length=ctx)
                     out[i, :len(ids)] = ids
+                if strip_sep:
+                    out[out == wp.sep_id] = 0
                 return out
             return hf_tok
         if isinstance(self.text_arch, archs.HfClipTextArch):

@@ -73,6 +73,8 @@ class VitConfig:
     out_dim: int = 512
     quick_gelu: bool = False
     ln_eps: float = 1e-5
+    ln_pre: bool = True       # False: open_clip `no_ln_pre` (CLIPA)
+    pool: str = "cls"         # "avg": pool_type 'avg' with final_ln_after_pool (CLIPA): mean of the patch tokens -> ln_post -> proj
 
     @property
     def tokens(self) -> int:
@@ -90,6 +92,8 @@ class ClipTextConfig:
     out_dim: int = 512
     quick_gelu: bool = False
     ln_eps: float = 1e-5
+    causal: bool = True   # False: `no_causal_mask` with pool_type 'last' (CLIPA text tower: every position attends to every other, the
+    #                       pooled row is the LAST of the ctx positions; un-prefixed keys and an un-biased projection, unlike SigLIP)
 
 
 @dataclass
@@ -195,9 +199,13 @@ def vit_forward(sd: Dict[str, Tensor], cfg: VitConfig, pixels: Tensor, normalize
     x = x.reshape(B, W, -1).permute(0, 2, 1)  # [B, np, W]
     cls = sd["visual.class_embedding"].to(x.dtype).expand(B, 1, W)
     x = torch.cat([cls, x], dim=1) + sd["visual.positional_embedding"]
-    x = F.layer_norm(x, (W,), sd["visual.ln_pre.weight"], sd["visual.ln_pre.bias"], cfg.ln_eps)
+    if cfg.ln_pre:
+        x = F.layer_norm(x, (W,), sd["visual.ln_pre.weight"], sd["visual.ln_pre.bias"], cfg.ln_eps)
     x = _clip_resblocks(x, sd, "visual.transformer.", cfg.layers, cfg.heads, cfg.quick_gelu, cfg.ln_eps, None)
-    pooled = F.layer_norm(x[:, 0], (W,), sd["visual.ln_post.weight"], sd["visual.ln_post.bias"], cfg.ln_eps)
+    # open_clip transformer.py VisionTransformer.forward (open_clip_torch 2.24.0, un-vendored): `final_ln_after_pool` pools first
+    # (_global_pool: 'avg' = x[:, 1:].mean(dim=1), the patch tokens) and applies ln_post to the pooled row; else ln_post(class token)
+    pooled = x[:, 1:].mean(dim=1) if cfg.pool == "avg" else x[:, 0]
+    pooled = F.layer_norm(pooled, (W,), sd["visual.ln_post.weight"], sd["visual.ln_post.bias"], cfg.ln_eps)
     out = pooled @ sd["visual.proj"]
     return l2_normalize_clip(out) if normalize else out
 
@@ -209,10 +217,10 @@ def clip_text_forward(sd: Dict[str, Tensor], cfg: ClipTextConfig, ids: Tensor, n
     B, T = ids.shape
     W = cfg.width
     x = sd["token_embedding.weight"][ids] + sd["positional_embedding"][:T]
-    mask = torch.full((T, T), float("-inf")).triu(1)
+    mask = torch.full((T, T), float("-inf")).triu(1) if cfg.causal else None
     x = _clip_resblocks(x, sd, "transformer.", cfg.layers, cfg.heads, cfg.quick_gelu, cfg.ln_eps, mask)
     x = F.layer_norm(x, (W,), sd["ln_final.weight"], sd["ln_final.bias"], cfg.ln_eps)
-    pooled = x[torch.arange(B), ids.argmax(dim=-1)]
+    pooled = x[torch.arange(B), ids.argmax(dim=-1)] if cfg.causal else x[:, -1]   # text_global_pool: 'argmax' / 'last
     out = pooled @ sd["text_projection"]
     return l2_normalize_clip(out) if normalize else out
 

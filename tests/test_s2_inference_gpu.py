@@ -507,6 +507,51 @@ def test_onnx_loader_types_are_served_by_the_same_towers(s2, monkeypatch):
         CLIP_ONNX("onnx32/open_clip/RN50/openai", device=DEV, embedding_dim=1024).load()
 
 
+def test_clipa_family_through_the_loader(s2, tmp_path, monkeypatch):
+    """a CLIPA-style open_clip entry end to end: avg-pool / no-ln_pre vision tower behind the bilinear-squash preprocessing with ImageNet
+    statistics (the architecture's own preprocess config), and open_clip's HFTokenizer(bert-base-uncased, strip_sep_token=True) — WordPiece
+    ids, [SEP] replaced by 0, padded to the context — feeding the unmasked last-position text tower"""
+    s2i, root = s2
+    from safetensors.torch import save_file
+    from marqo_amd.engine import archs as A
+    from marqo_amd.engine.tokenizers import WordPieceTokenizer, _clean_text
+    from tests.test_tokenizers import _bert_vocab
+    S, P, W, Lyr, H, Fd, D, ctx = 64, 16, 128, 2, 2, 256, 64, 16
+    d = tmp_path / "tiny-clipa"
+    d.mkdir()
+    vocab = _bert_vocab()
+    (d / "vocab.txt").write_text("\n".join(sorted(vocab, key=vocab.get)) + "\n")
+    vcfg = O.VitConfig(S, P, W, Lyr, H, Fd, D, ln_pre=False, pool="avg")
+    tcfg = O.ClipTextConfig(vocab=len(vocab), ctx=ctx, width=W, layers=Lyr, heads=H, mlp_dim=Fd, out_dim=D, causal=False)
+    sd = {k: v for k, v in O.synthetic_vit_state_dict(vcfg, seed=31).items() if not k.startswith("visual.ln_pre.")}
+    sd.update(O.synthetic_clip_text_state_dict(tcfg, seed=32))
+    save_file({k: v.contiguous() for k, v in sd.items()}, str(d / "open_clip_model.safetensors"))
+    monkeypatch.setitem(A.OPEN_CLIP_ARCHS, "tiny-CLIPA", (
+        A.VitArch(S, P, W, Lyr, H, Fd, D, pool="avg", ln_pre=False, preprocessor="CLIPA"),
+        A.ClipTextArch(vocab=len(vocab), ctx=ctx, width=W, layers=Lyr, heads=H, mlp_dim=Fd, out_dim=D, causal=False,
+                       hf_tokenizer="bert-base-uncased", strip_sep=True)))
+    props = {"name": "tiny-CLIPA", "dimensions": D, "type": "open_clip", "localpath": str(d / "open_clip_model.safetensors"),
+             "image_preprocessor": "CLIPA"}
+    texts = ["A photo of a CAT!", "the quick brown fox jumps over the lazy dog and the cat " * 2, "Tom &amp; Jerry", "fox"]
+    out = np.asarray(s2i.vectorise("tiny-clipa", texts, model_properties=props, device=DEV))
+    wp = WordPieceTokenizer(vocab)
+    ids = np.zeros((len(texts), ctx), dtype=np.int64)
+    for i, t in enumerate(texts):
+        e = wp.encode(_clean_text(t), max_length=ctx)
+        ids[i, :len(e)] = e
+    ids[ids == wp.sep_id] = 0
+    assert (ids[:, 0] == wp.cls_id).all() and not (ids == wp.sep_id).any()
+    model = s2i.get_available_models()[s2i._create_model_cache_key("tiny-clipa", DEV, props)]["model"]
+    assert np.array_equal(model.tokenizer(texts), ids)
+    assert out.shape == (4, D) and _cos_err(out, O.clip_text_forward(sd, tcfg, torch.from_numpy(ids)).numpy()) < COS_TOL
+    assert model.preprocess_config["interpolation"] == "bilinear" and model.preprocess_config["resize_mode"] == "squash"
+    rng = np.random.default_rng(3)
+    pil = [Image.fromarray(rng.integers(0, 256, (90, 130, 3), dtype=np.uint8)) for _ in range(3)]
+    img = np.asarray(s2i.vectorise("tiny-clipa", pil, model_properties=props, device=DEV, modality=s2i.Modality.IMAGE))
+    px = np.stack([OP.to_tensor_normalize(OP.squash_pil_image(p, S, S, bilinear=True), (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)) for p in pil])
+    assert _cos_err(img, O.vit_forward(sd, vcfg, torch.from_numpy(px)).numpy()) < COS_TOL
+
+
 def test_siglip_from_disk_text_and_image(s2, tmp_path, monkeypatch):
     """A SigLIP checkpoint through the loader: open_clip / timm tensor names (visual.trunk.*, text.*), SentencePiece tokenizer with
     canonicalize, SigLIP preprocessing (squash to S x S, mean = std = 0.5), 'open_clip' loader type — against the fp32 oracle.

@@ -268,6 +268,39 @@ def test_golden_xlm_roberta_small():
     assert _cos_err(wrong.encode_ids(ids, mask, normalize=False), torch.from_numpy(z["mean"])) > 10 * COS_TIGHT  # the offset is honoured
 
 
+def test_clipa_style_towers():
+    """open_clip ViT-L-14-CLIPA-336's forms at a small size: vision = no ln_pre, mean of the PATCH tokens, ln_post after the pooling, projection
+    (MQ_VIT_POOL_AVG); text = unmasked transformer with last-position pooling over all ctx positions, un-biased projection — against the
+    fp32 oracle, batched and single-item calls, f32 and u8 pixels"""
+    T, A = _towers()
+    S, P, W, L_, H, F, D = 64, 16, 128, 2, 2, 256, 64
+    vcfg = O.VitConfig(S, P, W, L_, H, F, D, ln_pre=False, pool="avg")
+    sd = O.synthetic_vit_state_dict(vcfg, seed=21)
+    sd = {k: v for k, v in sd.items() if not k.startswith("visual.ln_pre.")}      # a no_ln_pre checkpoint has no such tensors
+    arch = A.VitArch(S, P, W, L_, H, F, D, pool="avg", ln_pre=False)
+    assert arch.tokens == 17
+    tower = T.VitTower(arch, sd, "cuda")
+    u8 = O.synthetic_images_u8(5, S, seed=22)
+    px = O.preprocess_u8_exact_size(u8)
+    ref = O.vit_forward(sd, vcfg, px)
+    assert _cos_err(tower.encode_u8(u8.to("cuda")), ref) < COS_TIGHT
+    assert _cos_err(tower.encode_f32(px.to("cuda")), ref) < COS_TIGHT
+    assert _cos_err(tower.encode_u8(u8[:1].to("cuda")), ref[:1]) < COS_TIGHT and _cos_err(tower.encode_u8(u8[:1].to("cuda")), ref[:1]) < COS_TIGHT
+    cls_cfg = O.VitConfig(S, P, W, L_, H, F, D, ln_pre=False, pool="cls")
+    assert _cos_err(tower.encode_u8(u8.to("cuda")), O.vit_forward(sd, cls_cfg, px)) > 10 * COS_TIGHT     # not the class-token pooling
+    with pytest.raises(ValueError):
+        T.VitTower(A.VitArch(S, P, W, L_, H, F, D, pool="avg", ln_pre=True), sd, "cuda")
+    tcfg = O.ClipTextConfig(vocab=300, ctx=16, width=W, layers=L_, heads=H, mlp_dim=F, out_dim=D, causal=False)
+    tsd = O.synthetic_clip_text_state_dict(tcfg, seed=23)
+    txt = T.ClipTextTower(A.ClipTextArch(vocab=300, ctx=16, width=W, layers=L_, heads=H, mlp_dim=F, out_dim=D, causal=False), tsd, "cuda")
+    g = torch.Generator().manual_seed(24)
+    ids = torch.zeros(6, 16, dtype=torch.int64)
+    for i, n in enumerate((3, 16, 7, 1, 12, 9)):
+        ids[i, :n] = torch.randint(1, 300, (n,), generator=g)
+    tref = O.clip_text_forward(tsd, tcfg, ids)
+    assert _cos_err(txt.encode_ids(ids), tref) < COS_TIGHT and _cos_err(txt.encode_ids(ids[2:3]), tref[2:3]) < COS_TIGHT
+
+
 def test_hf_text_tower_of_multilingual_clip():
     """open_clip CustomTextCLIP with an HF text tower (open_clip/xlm-roberta-base-ViT-B-32, xlm-roberta-large-ViT-H-14): the XLM-RoBERTa
     encoder of the transformers golden (`text.transformer.*`), open_clip's mean pooler over the non-pad tokens and the projection MLP
