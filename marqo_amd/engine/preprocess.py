@@ -25,6 +25,10 @@ except Exception:  # pragma: no cover
 ArrayLike = Union[np.ndarray, torch.Tensor, "Rgbx", "Rgba", "NearestRgb"]
 
 
+# pieces of a pack -> H2D pipeline (1, the default: pack everything, then one copy).  Measured with 4 pieces (profiles/r02ab_pack_chunks_ab.txt):
+# uint8 arrays -1.5 % with one caller and -18 % with four (four times the native calls and copies per request), Pillow images +7 % with
+# one caller, neutral with four -> off
+PACK_CHUNKS = max(1, int(os.environ.get("MARQO_AMD_PACK_CHUNKS", "1")))
 PACK_THREADS = int(os.environ.get("MARQO_AMD_PACK_THREADS", str(max(1, min(8, (os.cpu_count() or 2) // 2)))))   # memcpy threads of a pack
 
 
@@ -168,12 +172,31 @@ class PackedImages:
             keep.append(a)
             srcs[k] = a.__array_interface__["data"][0]
             nbytes[k] = a.nbytes
-        L.check(L.load().mq_host_gather(srcs, nbytes.ctypes.data, dsts.ctypes.data, self.n, host.data_ptr(), PACK_THREADS), "mq_host_gather")
+        lib = L.load()
+        # Experiment knob: a batch of one kind (all plain RGB arrays, or all Pillow RGBX views) fills the staging buffer front to back, so it
+        # CAN be packed and shipped in PACK_CHUNKS pieces, the pinned H2D copy of piece c running while the memcpy threads pack piece c + 1.
+        pieces = PACK_CHUNKS if (nx in (0, self.n) and self.n >= 16 * PACK_CHUNKS and torch.cuda.is_available()) else 1
+        if pieces > 1:
+            staged = torch.empty(max(stage_bytes, 1), dtype=torch.uint8, device=device)
+            end = cur if nx else total
+            for c in range(pieces):
+                k0, k1 = c * self.n // pieces, (c + 1) * self.n // pieces
+                sub = (C.c_void_p * (k1 - k0))(*srcs[k0:k1])
+                L.check(lib.mq_host_gather(sub, nbytes[k0:k1].ctypes.data, dsts[k0:k1].ctypes.data, k1 - k0, host.data_ptr(), PACK_THREADS),
+                        "mq_host_gather")
+                lo, hi = int(dsts[k0]), (int(dsts[k1]) if k1 < self.n else end)
+                staged[lo:hi].copy_(host[lo:hi], non_blocking=True)
+        else:
+            L.check(lib.mq_host_gather(srcs, nbytes.ctypes.data, dsts.ctypes.data, self.n, host.data_ptr(), PACK_THREADS), "mq_host_gather")
         del keep
         if nx:
             jobs = np.asarray([(x_off[k], int(self.offsets[k]), int(npix[k])) for k in range(self.n) if is_x[k]], dtype=np.int64)
             hnp[jobs_off:jobs_off + nx * 24] = jobs.view(np.uint8).reshape(-1)
-        staged = host.to(device, non_blocking=True)
+            if pieces > 1:
+                staged[jobs_off:jobs_off + nx * 24].copy_(host[jobs_off:jobs_off + nx * 24], non_blocking=True)
+        if pieces == 1:
+            staged = host.to(device, non_blocking=True)
+        self._host = host   # (pinned source of the asynchronous copies: kept until the consumer's kernels are enqueued behind them)
         if not nx:
             self.buffer = staged[:total] if stage_bytes != total else staged
             return
