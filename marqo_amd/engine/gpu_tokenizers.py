@@ -303,7 +303,8 @@ class DeviceWordPieceTokenizer(_DeviceTokenizerBase):
         """-> (ids int32 [n, max_length] on device, right-padded with pad_id; lengths int64 [n] on host)"""
         n = len(texts)
         ids = torch.full((n, max_length), self.host.pad_id, dtype=torch.int32, device=self.device)
-        lens = torch.zeros(n, dtype=torch.int64)
+        lens_np = np.zeros(n, dtype=np.int64)   # (host bookkeeping in NumPy: see engine/towers.py::_host_i64)
+        lens = torch.from_numpy(lens_np)
         if n == 0:
             return ids, lens
         on_dev = self._split_routes(texts, lambda t: wordpiece_in_scope(self.host, t))
@@ -319,22 +320,21 @@ class DeviceWordPieceTokenizer(_DeviceTokenizerBase):
                 L.check(self.lib.mq_tokenize_wordpiece(C.byref(self.vocab), d_blob.data_ptr(), d_off.data_ptr(), m, total, max_length,
                                                        d_ids.data_ptr(), max_length, d_meta[0].data_ptr(), d_meta[1].data_ptr(), ws.data_ptr(),
                                                        ws.numel(), torch.cuda.current_stream(self.device).cuda_stream), "mq_tokenize_wordpiece")
-                meta = d_meta.cpu()  # (also the sync after which the pinned staging buffer may be reused)
-            if bool((meta[1] != 0).any()):  # defensive: the kernel disagreed with the host-side scope test
-                bad = [on_dev[j] for j in torch.nonzero(meta[1]).flatten().tolist()]
+                meta = d_meta.cpu().numpy()  # (also the sync after which the pinned staging buffer may be reused)
+            if meta[1].any():  # defensive: the kernel disagreed with the host-side scope test
+                bad = [on_dev[j] for j in np.nonzero(meta[1])[0].tolist()]
                 dev_set.difference_update(bad)
-            idx = torch.tensor(on_dev, dtype=torch.int64)
-            lens[idx] = meta[0].to(torch.int64)
+            lens_np[on_dev] = meta[0]
             if m != n:
-                ids[idx.to(self.device)] = d_ids
+                ids[torch.tensor(on_dev, dtype=torch.int64).to(self.device)] = d_ids
         rest = [i for i in range(n) if i not in dev_set]
         if rest:
             enc = [self.host.encode(texts[i], max_length) for i in rest]
-            block = torch.full((len(rest), max_length), self.host.pad_id, dtype=torch.int32)
+            block = np.full((len(rest), max_length), self.host.pad_id, dtype=np.int32)
             for j, e in enumerate(enc):
-                block[j, :len(e)] = torch.tensor(e, dtype=torch.int32)
-                lens[rest[j]] = len(e)
-            ids[torch.tensor(rest, device=self.device)] = block.to(self.device)
+                block[j, :len(e)] = e
+                lens_np[rest[j]] = len(e)
+            ids[torch.tensor(rest, device=self.device)] = torch.from_numpy(block).to(self.device)
         return ids, lens
 
     def __call__(self, texts, max_length: Optional[int] = None) -> Dict[str, np.ndarray]:
@@ -343,9 +343,10 @@ class DeviceWordPieceTokenizer(_DeviceTokenizerBase):
             texts = [texts]
         cap = max_length if max_length is not None else 2 + max((len(t) for t in texts), default=0)
         ids, lens = self.encode_device(texts, cap)
+        lens = lens.numpy()
         S = int(lens.max()) if len(texts) else 0
-        out = ids[:, :S].cpu().to(torch.int64).numpy()
-        mask = (np.arange(S)[None, :] < lens.numpy()[:, None]).astype(np.int64)
+        out = ids[:, :S].cpu().numpy().astype(np.int64)
+        mask = (np.arange(S)[None, :] < lens[:, None]).astype(np.int64)
         return {"input_ids": out, "attention_mask": mask}
 
 
@@ -366,7 +367,8 @@ class DeviceClipBpeTokenizer(_DeviceTokenizerBase):
         ctx = context_length or self.host.context_length
         n = len(texts)
         ids = torch.zeros(n, ctx, dtype=torch.int32, device=self.device)
-        lens = torch.zeros(n, dtype=torch.int64)
+        lens_np = np.zeros(n, dtype=np.int64)   # (host bookkeeping in NumPy: see engine/towers.py::_host_i64)
+        lens = torch.from_numpy(lens_np)
         if n == 0:
             return ids, lens
         on_dev = self._split_routes(texts, lambda t: clip_in_scope(self.host, t))
@@ -382,19 +384,18 @@ class DeviceClipBpeTokenizer(_DeviceTokenizerBase):
                 L.check(self.lib.mq_tokenize_clip_bpe(C.byref(self.vocab), d_blob.data_ptr(), d_off.data_ptr(), m, total, ctx, d_ids.data_ptr(),
                                                       d_meta[0].data_ptr(), d_meta[1].data_ptr(), ws.data_ptr(), ws.numel(),
                                                       torch.cuda.current_stream(self.device).cuda_stream), "mq_tokenize_clip_bpe")
-                meta = d_meta.cpu()  # (also the sync after which the pinned staging buffer may be reused)
-            if bool((meta[1] != 0).any()):  # e.g. a pre-token longer than the device scratch
-                bad = [on_dev[j] for j in torch.nonzero(meta[1]).flatten().tolist()]
+                meta = d_meta.cpu().numpy()  # (also the sync after which the pinned staging buffer may be reused)
+            if meta[1].any():  # e.g. a pre-token longer than the device scratch
+                bad = [on_dev[j] for j in np.nonzero(meta[1])[0].tolist()]
                 dev_set.difference_update(bad)
-            idx = torch.tensor(on_dev, dtype=torch.int64)
-            lens[idx] = meta[0].to(torch.int64)
+            lens_np[on_dev] = meta[0]
             if m != n:
-                ids[idx.to(self.device)] = d_ids
+                ids[torch.tensor(on_dev, dtype=torch.int64).to(self.device)] = d_ids
         rest = [i for i in range(n) if i not in dev_set]
         if rest:
-            block = torch.from_numpy(self.host([texts[i] for i in rest], ctx)).to(torch.int32)
-            lens[torch.tensor(rest)] = block.argmax(dim=1).to(torch.int64) + 1
-            ids[torch.tensor(rest, device=self.device)] = block.to(self.device)
+            block = np.ascontiguousarray(self.host([texts[i] for i in rest], ctx), dtype=np.int32)
+            lens_np[rest] = block.argmax(axis=1) + 1
+            ids[torch.tensor(rest, device=self.device)] = torch.from_numpy(block).to(self.device)
         return ids, lens
 
     def __call__(self, texts, context_length: Optional[int] = None) -> np.ndarray:
@@ -402,7 +403,7 @@ class DeviceClipBpeTokenizer(_DeviceTokenizerBase):
         if isinstance(texts, str):
             texts = [texts]
         ids, _ = self.encode_device(texts, context_length)
-        return ids.cpu().to(torch.int64).numpy()
+        return ids.cpu().numpy().astype(np.int64)
 
 
 # =====================================================================================================================================
@@ -597,7 +598,8 @@ class DeviceSentencePieceTokenizer(_DeviceTokenizerBase):
         """-> (ids int32 [n, max_length] on device, padded with the pad id; lengths int64 [n] on host, specials included)"""
         n = len(texts)
         ids = torch.full((n, max_length), self.pad_id, dtype=torch.int32, device=self.device)
-        lens = torch.zeros(n, dtype=torch.int64)
+        lens_np = np.zeros(n, dtype=np.int64)   # (host bookkeeping in NumPy: see engine/towers.py::_host_i64)
+        lens = torch.from_numpy(lens_np)
         if n == 0:
             return ids, lens
         if self.kind == "siglip":
@@ -619,24 +621,23 @@ class DeviceSentencePieceTokenizer(_DeviceTokenizerBase):
                                                            d_ids.data_ptr(), max_length, d_meta[0].data_ptr(), d_meta[1].data_ptr(),
                                                            self._ws.data_ptr(), self._ws.numel(),
                                                            torch.cuda.current_stream(self.device).cuda_stream), "mq_tokenize_sentencepiece")
-                meta = d_meta.cpu()
-            if bool((meta[1] != 0).any()):
-                dev_set.difference_update(on_dev[j] for j in torch.nonzero(meta[1]).flatten().tolist())
-            idx = torch.tensor(on_dev, dtype=torch.int64)
-            lens[idx] = meta[0].to(torch.int64)
+                meta = d_meta.cpu().numpy()
+            if meta[1].any():
+                dev_set.difference_update(on_dev[j] for j in np.nonzero(meta[1])[0].tolist())
+            lens_np[on_dev] = meta[0]
             if m != n:
-                ids[idx.to(self.device)] = d_ids
+                ids[torch.tensor(on_dev, dtype=torch.int64).to(self.device)] = d_ids
         rest = [i for i in range(n) if i not in dev_set]
         if rest:
-            block = torch.full((len(rest), max_length), self.pad_id, dtype=torch.int32)
+            block = np.full((len(rest), max_length), self.pad_id, dtype=np.int32)
             for j, i in enumerate(rest):
                 if self.kind == "xlmr":
                     e = self.host.encode(texts[i], max_length)
                 else:  # (already canonicalised above)
                     e = (list(self.host._sp.encode(texts[i]))[: max_length - 1]) + [self.host.eos_id]
-                block[j, :len(e)] = torch.tensor(e, dtype=torch.int32)
-                lens[i] = len(e)
-            ids[torch.tensor(rest, device=self.device)] = block.to(self.device)
+                block[j, :len(e)] = e
+                lens_np[i] = len(e)
+            ids[torch.tensor(rest, device=self.device)] = torch.from_numpy(block).to(self.device)
         return ids, lens
 
     def __call__(self, texts, max_length: Optional[int] = None):
@@ -645,10 +646,11 @@ class DeviceSentencePieceTokenizer(_DeviceTokenizerBase):
             texts = [texts]
         if self.kind == "siglip":
             ids, _ = self.encode_device(texts, self.host.context_length)
-            return ids.cpu().to(torch.int64).numpy()
+            return ids.cpu().numpy().astype(np.int64)
         cap = max_length if max_length is not None else 2 + 4 * max((len(t) for t in texts), default=0)
         ids, lens = self.encode_device(texts, cap)
+        lens = lens.numpy()
         S = int(lens.max()) if len(texts) else 0
-        out = ids[:, :S].cpu().to(torch.int64).numpy()
-        mask = (np.arange(S)[None, :] < lens.numpy()[:, None]).astype(np.int64)
+        out = ids[:, :S].cpu().numpy().astype(np.int64)
+        mask = (np.arange(S)[None, :] < lens[:, None]).astype(np.int64)
         return {"input_ids": out, "attention_mask": mask}

@@ -17,6 +17,7 @@ import os
 import threading
 from typing import Dict, List, Optional, Sequence, Tuple
 
+import numpy as np
 import torch
 
 from marqo_amd import _lib as L
@@ -675,30 +676,40 @@ class VitTower(_TowerBase):
         return self._run("f32", pixels, normalize)
 
 
-def _pack(ids: Tensor, lengths: Tensor) -> Tuple[Tensor, Tensor]:
-    """right-padded [n, S] ids + lengths -> (packed int32 ids [rows], cu_seqlens int32 [n+1]) on host."""
+def _host_i64(t) -> np.ndarray:
+    """ids / lengths / masks (torch tensor on any device, or array-like) -> int64 ndarray on the host.  The request path does its integer
+    bookkeeping in NumPy on purpose: PyTorch's CPU kernels for boolean-mask indexing, reductions and index_select enter an OpenMP region
+    with torch.get_num_threads() workers (128 on the GPU boxes) that keep spinning after a 10 k-element job; under a container CPU quota
+    that spin throttled the whole process — 128 strings took 20-28 ms to pack instead of 0.07 ms (profiles/r02ae_ingest_phases.txt)."""
+    if isinstance(t, torch.Tensor):
+        t = t.detach().cpu().numpy()
+    return np.ascontiguousarray(t, dtype=np.int64)
+
+
+def _pack(ids: np.ndarray, lengths: np.ndarray) -> Tuple[Tensor, Tensor]:
+    """right-padded [n, S] ids + lengths (host ndarrays) -> (packed int32 ids [rows], cu_seqlens int32 [n+1]) as host tensors."""
     n, S = ids.shape
-    keep = torch.arange(S).unsqueeze(0) < lengths.unsqueeze(1)
-    packed = ids[keep].to(torch.int32).contiguous()
-    cu = torch.zeros(n + 1, dtype=torch.int32)
-    cu[1:] = lengths.cumsum(0).to(torch.int32)
-    return packed, cu
+    keep = np.arange(S)[None, :] < lengths[:, None]
+    packed = np.ascontiguousarray(ids[keep], dtype=np.int32)
+    cu = np.zeros(n + 1, dtype=np.int32)
+    np.cumsum(lengths, out=cu[1:])
+    return torch.from_numpy(packed), torch.from_numpy(cu)
 
 
 class _TextTowerBase(_TowerBase):
-    def _chunks(self, lengths: Tensor):
+    def _chunks(self, lengths: np.ndarray):
         """Yield (start, stop) sequence ranges with <= MAX_ROWS_PER_CALL rows each (greedy, vectorised: the common
         case of one chunk costs one cumsum)."""
-        n = lengths.numel()
+        n = int(lengths.size)
         if n == 0:
             return
-        cum = torch.cumsum(lengths, 0)
+        cum = np.cumsum(lengths)
         if int(cum[-1]) <= MAX_ROWS_PER_CALL:
             yield 0, n
             return
         start, base = 0, 0
         while start < n:
-            stop = int(torch.searchsorted(cum, base + MAX_ROWS_PER_CALL, right=True))
+            stop = int(np.searchsorted(cum, base + MAX_ROWS_PER_CALL, side="right"))
             stop = max(stop, start + 1)
             yield start, stop
             base = int(cum[stop - 1])
@@ -739,7 +750,7 @@ class _TextTowerBase(_TowerBase):
             raise ValueError(f"expected int32 [n, S] ids on {self.device}, got {d_ids.dtype} {tuple(d_ids.shape)} on {d_ids.device}")
         d_ids = d_ids.contiguous()
         n, S = d_ids.shape
-        lengths = lengths.detach().to("cpu", torch.int64)
+        lengths = _host_i64(lengths)
         if lengths.shape != (n,) or (n and (int(lengths.min()) < 1 or int(lengths.max()) > min(S, max_len))):
             raise ValueError(f"lengths must be [n] within [1, {min(S, max_len)}]")
         if n == 1 and self._graphs_ok():
@@ -750,9 +761,10 @@ class _TextTowerBase(_TowerBase):
         out = torch.empty(n, out_dim, dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device), _large_call(self.device, int(lengths.sum())):
             for a, b in self._chunks(lengths):
-                cu = torch.zeros(b - a + 1, dtype=torch.int32)
-                cu[1:] = lengths[a:b].cumsum(0).to(torch.int32)
-                rows, nseq = int(cu[-1]), b - a
+                cu_np = np.zeros(b - a + 1, dtype=np.int32)
+                np.cumsum(lengths[a:b], out=cu_np[1:])
+                cu = torch.from_numpy(cu_np)
+                rows, nseq = int(cu_np[-1]), b - a
                 d_cu = self._to_device(cu)
                 d_packed = torch.empty(rows, dtype=torch.int32, device=self.device)
                 L.check(self.lib.mq_pack_ids(d_ids[a:b].data_ptr(), S, d_cu.data_ptr(), nseq, d_packed.data_ptr(), self._stream()), "mq_pack_ids")
@@ -822,7 +834,7 @@ class ClipTextTower(_TextTowerBase):
         like the reference does."""
         if ids.ndim != 2 or ids.shape[1] > self.arch.ctx:
             raise ValueError(f"expected ids [n, <= {self.arch.ctx}], got {tuple(ids.shape)}")
-        ids_h = ids.detach().to("cpu", torch.int64)
+        ids_h = _host_i64(ids)
         n, S = ids_h.shape
         if not self.arch.causal:
             # SigLIP: no mask at all — every one of the ctx positions (padding included) is attended to and the pooled row is the
@@ -830,17 +842,17 @@ class ClipTextTower(_TextTowerBase):
             if S != self.arch.ctx:
                 raise ValueError(f"an unmasked text tower runs exactly ctx = {self.arch.ctx} positions per text, got {S}")
             pack = False
-        eot = torch.full((n,), S - 1, dtype=torch.int64) if not self.arch.causal else ids_h.argmax(dim=1)
-        lengths = (eot + 1) if pack else torch.full((n,), S, dtype=torch.int64)
+        eot = np.full(n, S - 1, dtype=np.int64) if not self.arch.causal else ids_h.argmax(axis=1)
+        lengths = (eot + 1) if pack else np.full(n, S, dtype=np.int64)
         if n == 1 and (pack or not self.arch.causal) and self._graphs_ok():
-            one = self._encode_one(ids_h[0, :int(lengths[0])], normalize, clip=True)
+            one = self._encode_one(torch.from_numpy(ids_h[0, :int(lengths[0])]), normalize, clip=True)
             if one is not None:
                 return one
         out = torch.empty(n, self.arch.out_dim, dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device), _large_call(self.device, int(lengths.sum())):
             for a, b in self._chunks(lengths):
                 packed, cu = _pack(ids_h[a:b], lengths[a:b])
-                pool_rows = None if pack else (cu[:-1].to(torch.int64) + eot[a:b]).to(torch.int32)
+                pool_rows = None if pack else torch.from_numpy((cu.numpy()[:-1].astype(np.int64) + eot[a:b]).astype(np.int32))
                 d_ids = self._to_device(packed)
                 d_cu = self._to_device(cu)
                 d_pool = self._to_device(pool_rows) if pool_rows is not None else None
@@ -853,7 +865,7 @@ class ClipTextTower(_TextTowerBase):
     def encode_device(self, d_ids: Tensor, lengths: Tensor, normalize: bool = True) -> Tensor:
         """ids already on the device (engine/gpu_tokenizers.py): int32 [n, S] rows SOT ... EOT 0 ..., lengths int64 [n] on the
         host = SOT..EOT length.  Same as encode_ids(pack=True), but the packing runs on the GPU (mq_pack_ids)."""
-        if not self.arch.causal and (d_ids.shape[1] != self.arch.ctx or int(lengths.min()) != self.arch.ctx):
+        if not self.arch.causal and (d_ids.shape[1] != self.arch.ctx or int(_host_i64(lengths).min(initial=self.arch.ctx)) != self.arch.ctx):
             raise ValueError(f"an unmasked text tower runs exactly ctx = {self.arch.ctx} positions per text")
         return self._encode_device(d_ids, lengths, self.arch.ctx, normalize, clip=True)
 
@@ -973,19 +985,19 @@ class BertTower(_TextTowerBase):
         (hugging_face_model.py:179-185: padding=True, right-padded).  Only mask==1 tokens are run."""
         if ids.shape != attention_mask.shape or ids.ndim != 2:
             raise ValueError("ids and attention_mask must both be [n, S]")
-        ids_h = ids.detach().to("cpu", torch.int64)
-        mask_h = attention_mask.detach().to("cpu", torch.int64)
+        ids_h = _host_i64(ids)
+        mask_h = _host_i64(attention_mask)
         n, S = ids_h.shape
-        lengths = mask_h.sum(dim=1)
+        lengths = mask_h.sum(axis=1)
         if bool((lengths < 1).any()):
             raise ValueError("every sequence needs at least one unmasked token")
-        prefix = torch.arange(S).unsqueeze(0) < lengths.unsqueeze(1)
-        if not bool((mask_h.bool() == prefix).all()):
+        prefix = np.arange(S)[None, :] < lengths[:, None]
+        if not bool(((mask_h != 0) == prefix).all()):
             raise ValueError("attention_mask must be right-padded (a prefix of ones per row)")
-        if int(lengths.max()) > self.arch.max_pos:
+        if n and int(lengths.max()) > self.arch.max_pos:
             raise ValueError(f"sequence longer than max_position_embeddings={self.arch.max_pos}")
         if n == 1 and self._graphs_ok():
-            one = self._encode_one(ids_h[0, :int(lengths[0])], normalize, clip=False)
+            one = self._encode_one(torch.from_numpy(ids_h[0, :int(lengths[0])]), normalize, clip=False)
             if one is not None:
                 return one
         out = torch.empty(n, self.out_width, dtype=torch.float32, device=self.device)
@@ -1038,7 +1050,8 @@ class HfClipTextTower(BertTower):
         """ids int [n, <= ctx] padded with pad_id, as open_clip's HFTokenizer hands them over; attention mask = ids != pad_id
         (hf_model.py HFTextEncoder.forward)"""
         ids = ids.detach().to("cpu", torch.int64)
-        return self.encode_ids(ids, (ids != self.clip_arch.pad_id).to(torch.int64), normalize=normalize)
+        ids_h = _host_i64(ids)
+        return self.encode_ids(ids_h, (ids_h != self.clip_arch.pad_id).astype(np.int64), normalize=normalize)
 
 
 class MclipTextTower(BertTower):

@@ -21,6 +21,7 @@ import heapq
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
+import numpy as np
 import torch
 
 
@@ -52,9 +53,11 @@ class ShardPlan:
         order = [i for part in self.items for i in part]
         if order == list(range(self.n_items)):
             return gathered
-        inv = torch.empty(self.n_items, dtype=torch.int64)
-        inv[torch.tensor(order, dtype=torch.int64)] = torch.arange(self.n_items, dtype=torch.int64)
-        return gathered.index_select(0, inv.to(gathered.device))
+        inv = np.empty(self.n_items, dtype=np.int64)   # (host index arithmetic in NumPy: no OpenMP region on the request path)
+        inv[np.asarray(order, dtype=np.int64)] = np.arange(self.n_items, dtype=np.int64)
+        if gathered.device.type == "cpu":
+            return torch.from_numpy(np.ascontiguousarray(gathered.numpy()[inv]))
+        return gathered.index_select(0, torch.from_numpy(inv).to(gathered.device))
 
 
 def balanced_shards(costs: Sequence[float], world: int) -> ShardPlan:
