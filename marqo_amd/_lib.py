@@ -23,6 +23,8 @@ LIB_PATH = Path(os.environ["MARQO_AMD_LIB"]) if os.environ.get("MARQO_AMD_LIB") 
 HEADER_PATH = PKG_DIR.parent / "include" / "marqo_hip.h"
 TORCH_OPS_SRC = CSRC_DIR / "torch_ops.cpp"
 TORCH_OPS_PATH = LIB_DIR / "libmarqo_torch_ops.so"   # torch.ops.marqo_hip.*: the PyTorch custom-op face of the same C ABI
+STAGE_SRC = CSRC_DIR / "py_stage.cpp"
+STAGE_PATH = LIB_DIR / "_mq_stage.so"                # CPython extension: a batch of Pillow images -> the pinned staging buffer in one call
 
 MQ_OK = 0
 NO_SCRATCH_UNITS = ("gemm_bf16", "gemm_big", "gemm_k32", "gemm_fp8", "gemm_small", "attention")  # build() refuses register spills in these
@@ -267,6 +269,52 @@ def build_torch_ops(force: bool = False, verbose: bool = False) -> Path:
     if res.returncode != 0:
         raise MarqoHipUnavailableError(f"g++ failed on {TORCH_OPS_SRC} ({res.returncode}):\n{res.stdout}\n{res.stderr[-4000:]}")
     return TORCH_OPS_PATH
+
+
+def build_stage(force: bool = False, verbose: bool = False) -> Path:
+    """Compile csrc/py_stage.cpp (host code only: CPython C API + the Arrow C data interface) -> lib/_mq_stage.so"""
+    if not force and STAGE_PATH.exists() and os.path.getmtime(STAGE_PATH) >= os.path.getmtime(STAGE_SRC):
+        return STAGE_PATH
+    LIB_DIR.mkdir(parents=True, exist_ok=True)
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", f"-I{sysconfig.get_paths()['include']}",
+           str(STAGE_SRC), "-o", str(STAGE_PATH), "-lpthread"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise MarqoHipUnavailableError(f"g++ failed on {STAGE_SRC} ({res.returncode}):\n{res.stdout}\n{res.stderr[-4000:]}")
+    return STAGE_PATH
+
+
+_stage = None
+_stage_tried = False
+
+
+def load_stage():
+    """The `_mq_stage` extension module, or None when it was not built / MARQO_AMD_NATIVE_STAGE=0.  It is a host-side accelerator of the
+    Pillow -> pinned-buffer copy with byte-identical results (the GPU path is the same either way), so unlike the HIP library its absence
+    is not an error: PackedImages then exports image by image through pyarrow, as before."""
+    global _stage, _stage_tried
+    if _stage_tried:
+        return _stage
+    with _lib_lock:
+        if _stage_tried:
+            return _stage
+        mod = None
+        if os.environ.get("MARQO_AMD_NATIVE_STAGE", "1") != "0" and STAGE_PATH.exists():
+            import importlib.machinery
+            import importlib.util
+            try:
+                loader = importlib.machinery.ExtensionFileLoader("_mq_stage", str(STAGE_PATH))
+                spec = importlib.util.spec_from_loader("_mq_stage", loader)
+                mod = importlib.util.module_from_spec(spec)
+                loader.exec_module(mod)
+            except (ImportError, OSError) as e:
+                import logging
+                logging.getLogger(__name__).warning("cannot load %s (%s): Pillow images are staged one by one", STAGE_PATH, e)
+                mod = None
+        _stage, _stage_tried = mod, True
+        return _stage
 
 
 _ops = None

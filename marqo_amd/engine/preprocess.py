@@ -32,15 +32,38 @@ PACK_CHUNKS = max(1, int(os.environ.get("MARQO_AMD_PACK_CHUNKS", "1")))
 PACK_THREADS = int(os.environ.get("MARQO_AMD_PACK_THREADS", str(max(1, min(8, (os.cpu_count() or 2) // 2)))))   # memcpy threads of a pack
 
 
-class Rgbx:
-    """A decoded Pillow RGB image as it sits in memory: uint8 [H, W, 4] (R, G, B, pad), a zero-copy view through Pillow's Arrow export.
-    `shape` is the logical (H, W, 3).  The bytes are staged as they are and repacked on the device (mq_unpack_rgbx): Image.tobytes /
-    np.asarray spend 80-300 us per 224 x 224 image on the 4 -> 3 byte repack, the view costs ~10 us."""
-    __slots__ = ("view", "shape", "_keep")
+def _export_rgbx(img):
+    """Pillow RGB image -> uint8 [H, W, 4] zero-copy view through its Arrow export, or None (no pyarrow, an image stored in several
+    blocks, any export quirk)"""
+    if _arrow is None or not hasattr(img, "__arrow_c_array__") or img.width <= 0 or img.height <= 0:
+        return None
+    try:
+        flat = _arrow.array(img).flatten().to_numpy(zero_copy_only=True)
+        if flat.dtype == np.uint8 and flat.size == img.height * img.width * 4:
+            return flat.reshape(img.height, img.width, 4)
+    except Exception:  # the plain path is always right
+        pass
+    return None
 
-    def __init__(self, view: np.ndarray, keep) -> None:
-        self.view, self._keep = view, keep
-        self.shape = (view.shape[0], view.shape[1], 3)
+
+class Rgbx:
+    """A decoded Pillow RGB image as it sits in memory: 4 bytes per pixel (R, G, B, pad).  `shape` is the logical (H, W, 3).  The bytes are
+    staged as they are and repacked on the device (mq_unpack_rgbx): Image.tobytes / np.asarray spend 80-300 us per 224 x 224 image on the
+    4 -> 3 byte repack.  `image` is the PIL image; PackedImages hands whole batches of them to the native stager (_mq_stage.gather_rgbx: one
+    call, copies with the GIL released).  `.view` is the uint8 [H, W, 4] array for everybody else, exported on first use (~10 us through
+    pyarrow; an RGBX copy when Pillow cannot export the image zero-copy)."""
+    __slots__ = ("image", "shape", "_view")
+
+    def __init__(self, image, view: Optional[np.ndarray] = None) -> None:
+        self.image, self._view = image, view
+        self.shape = (image.height, image.width, 3)
+
+    @property
+    def view(self) -> np.ndarray:
+        if self._view is None:
+            v = _export_rgbx(self.image)
+            self._view = v if v is not None else np.asarray(self.image.convert("RGBX"))
+        return self._view
 
 
 class Rgba:
@@ -86,13 +109,12 @@ def pil_pixels(img):
         return Rgba(a)
     if mode in ("P", "1"):
         return NearestRgb(np.asarray(img.convert("RGB")))
-    if _arrow is not None and img.mode == "RGB" and hasattr(img, "__arrow_c_array__") and img.width > 0 and img.height > 0:
-        try:
-            flat = _arrow.array(img).flatten().to_numpy(zero_copy_only=True)
-            if flat.dtype == np.uint8 and flat.size == img.height * img.width * 4:
-                return Rgbx(flat.reshape(img.height, img.width, 4), img)
-        except Exception:  # any export quirk (exotic storage, old pyarrow): the plain path is always right
-            pass
+    if mode == "RGB" and img.width > 0 and img.height > 0 and hasattr(img, "__arrow_c_array__"):
+        if L.load_stage() is not None:     # exported in bulk by the native stager when the batch is packed
+            return Rgbx(img)
+        v = _export_rgbx(img)
+        if v is not None:
+            return Rgbx(img, v)
     return np.asarray(img if img.mode == "RGB" else img.convert("RGB"))
 
 
@@ -145,37 +167,49 @@ class PackedImages:
             self.buffer = buf
             return
         # ---- host staging: [RGB images at their final offsets | RGBX images | unpack job table] ----
-        is_x = [isinstance(i, Rgbx) for i in imgs]
-        nx = sum(is_x)
-        x_sizes = [_align256(int(npix[k]) * 4) if is_x[k] else 0 for k in range(self.n)]
-        x_off, cur = [0] * self.n, total
-        for k in range(self.n):
-            if is_x[k]:
-                x_off[k] = cur
-                cur += x_sizes[k]
+        # (layout arithmetic vectorised: per-image Python under the GIL is what serialises concurrent request threads)
+        is_x = np.fromiter((isinstance(i, Rgbx) for i in imgs), dtype=bool, count=self.n)
+        nx = int(is_x.sum())
+        x_sizes = np.where(is_x, _align256(npix * 4), 0)
+        x_off = total + np.cumsum(x_sizes) - x_sizes          # int64 [n]; meaningful where is_x
+        cur = total + int(x_sizes.sum())
         jobs_off = _align256(cur)
         stage_bytes = jobs_off + nx * 24
         host = torch.empty(max(stage_bytes, 1), dtype=torch.uint8, pin_memory=torch.cuda.is_available())
         hnp = host.numpy()
 
-        # one foreign call copies everything (mq_host_gather: a few memcpy threads, the GIL released once for the whole pack)
-        srcs, nbytes, dsts = (C.c_void_p * self.n)(), np.empty(self.n, dtype=np.int64), np.empty(self.n, dtype=np.int64)
+        # Pillow images that have not been exported yet go to the native stager in ONE call (Arrow export + memcpy threads, GIL released
+        # for the copies); everything else is copied by ONE mq_host_gather call (same threads, GIL released once for the whole pack)
+        stager = L.load_stage()
+        lazy = [k for k in np.flatnonzero(is_x).tolist() if imgs[k]._view is None] if (stager is not None and nx) else []
+        lazy_set = set(lazy)
+        eager = [k for k in range(self.n) if k not in lazy_set] if lazy else range(self.n)
+        ne = len(eager)
+        srcs, nbytes, dsts = (C.c_void_p * max(ne, 1))(), np.empty(ne, dtype=np.int64), np.empty(ne, dtype=np.int64)
         keep = []
-        for k, i in enumerate(imgs):
+        for e, k in enumerate(eager):
+            i = imgs[k]
             if is_x[k]:
-                a, dsts[k] = i.view, x_off[k]
+                a, dsts[e] = i.view, x_off[k]
             else:
                 a = i if isinstance(i, np.ndarray) else (i.numpy() if i.device.type == "cpu" else i.cpu().numpy())
-                dsts[k] = self.offsets[k]
+                dsts[e] = self.offsets[k]
             if not a.flags.c_contiguous:
                 a = np.ascontiguousarray(a)
             keep.append(a)
-            srcs[k] = a.__array_interface__["data"][0]
-            nbytes[k] = a.nbytes
+            srcs[e] = a.__array_interface__["data"][0]
+            nbytes[e] = a.nbytes
         lib = L.load()
+        if lazy:
+            lz_off = np.ascontiguousarray(x_off[lazy])
+            lz_len = np.ascontiguousarray(npix[lazy] * 4)
+            for f in stager.gather_rgbx([imgs[k].image for k in lazy], host.data_ptr(), lz_off, lz_len, PACK_THREADS):
+                k = lazy[f]   # Pillow could not export this one zero-copy (e.g. an image stored in several blocks): its .view copies
+                v = imgs[k].view
+                hnp[int(x_off[k]):int(x_off[k]) + v.nbytes] = np.ascontiguousarray(v).reshape(-1)
         # Experiment knob: a batch of one kind (all plain RGB arrays, or all Pillow RGBX views) fills the staging buffer front to back, so it
         # CAN be packed and shipped in PACK_CHUNKS pieces, the pinned H2D copy of piece c running while the memcpy threads pack piece c + 1.
-        pieces = PACK_CHUNKS if (nx in (0, self.n) and self.n >= 16 * PACK_CHUNKS and torch.cuda.is_available()) else 1
+        pieces = PACK_CHUNKS if (not lazy and nx in (0, self.n) and self.n >= 16 * PACK_CHUNKS and torch.cuda.is_available()) else 1
         if pieces > 1:
             staged = torch.empty(max(stage_bytes, 1), dtype=torch.uint8, device=device)
             end = cur if nx else total
@@ -186,11 +220,11 @@ class PackedImages:
                         "mq_host_gather")
                 lo, hi = int(dsts[k0]), (int(dsts[k1]) if k1 < self.n else end)
                 staged[lo:hi].copy_(host[lo:hi], non_blocking=True)
-        else:
-            L.check(lib.mq_host_gather(srcs, nbytes.ctypes.data, dsts.ctypes.data, self.n, host.data_ptr(), PACK_THREADS), "mq_host_gather")
+        elif ne:
+            L.check(lib.mq_host_gather(srcs, nbytes.ctypes.data, dsts.ctypes.data, ne, host.data_ptr(), PACK_THREADS), "mq_host_gather")
         del keep
         if nx:
-            jobs = np.asarray([(x_off[k], int(self.offsets[k]), int(npix[k])) for k in range(self.n) if is_x[k]], dtype=np.int64)
+            jobs = np.ascontiguousarray(np.stack([x_off[is_x], self.offsets[is_x], npix[is_x]], axis=1), dtype=np.int64)
             hnp[jobs_off:jobs_off + nx * 24] = jobs.view(np.uint8).reshape(-1)
             if pieces > 1:
                 staged[jobs_off:jobs_off + nx * 24].copy_(host[jobs_off:jobs_off + nx * 24], non_blocking=True)
@@ -206,7 +240,7 @@ class PackedImages:
                 buf = torch.empty(max(total, 1), dtype=torch.uint8, device=device)
             else:              # mixed: the RGB images already sit at their offsets in the staged copy; unpack the others beside them
                 buf = staged
-            L.check(lib.mq_unpack_rgbx(staged.data_ptr(), jobs_off, nx, int(max(npix[k] for k in range(self.n) if is_x[k])), buf.data_ptr(),
+            L.check(lib.mq_unpack_rgbx(staged.data_ptr(), jobs_off, nx, int(npix[is_x].max()), buf.data_ptr(),
                                        torch.cuda.current_stream(device).cuda_stream), "mq_unpack_rgbx")
         self._staged = staged
         self.buffer = buf

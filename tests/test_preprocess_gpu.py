@@ -138,7 +138,11 @@ def test_packed_images_rgbx_staging_and_threaded_copies(pre):
     if not all(isinstance(v, P.Rgbx) for v in views):
         pytest.skip("this Pillow / pyarrow pair has no Arrow export")
     mixed = [views[i] if i % 3 == 0 else (arrs[i] if i % 3 == 1 else torch.from_numpy(arrs[i])) for i in range(len(arrs))]
-    for batch in (views, arrs, mixed, [v for v in views[:3]]):
+    # containers whose view was already exported (the pyarrow route) next to fresh ones (the native stager's route, when it is built)
+    half = [P.pil_pixels(p) for p in pils]
+    for v in half[::2]:
+        assert v.view.shape[2] == 4
+    for batch in (views, arrs, mixed, [v for v in views[:3]], half):
         p = P.PackedImages(batch, torch.device("cuda:0"))
         buf = p.buffer.cpu().numpy()
         for a, off in zip(arrs, p.offsets):
@@ -148,6 +152,12 @@ def test_packed_images_rgbx_staging_and_threaded_copies(pre):
     out_arr = pre.resize_crop_u8(arrs).cpu().numpy()
     assert np.array_equal(out_pil, out_arr)
     assert np.array_equal(out_arr[3], OP.clip_resize_crop_u8(arrs[3], 224, backend="c"))
+    # an image Pillow stores in several blocks cannot be exported zero-copy: it takes the copying route inside the same pack
+    big = _imgs([(2300, 2300), (30, 40)], seed=11)
+    p = P.PackedImages([P.pil_pixels(Image.fromarray(a)) for a in big], torch.device("cuda:0"))
+    buf = p.buffer.cpu().numpy()
+    for a, off in zip(big, p.offsets):
+        assert np.array_equal(buf[int(off):int(off) + a.size], a.reshape(-1)), a.shape
     # device tensors of one size are stacked, of several sizes copied one by one: same packed bytes
     same = [torch.from_numpy(a).cuda() for a in _imgs([(64, 64)] * 5, seed=2)]
     p = P.PackedImages(same, torch.device("cuda:0"))
