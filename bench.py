@@ -359,21 +359,23 @@ def e2e_vectorise(dev, images_cpu_u8, tower_only_rate, reps=6):
             for _ in range(reps):
                 s2.vectorise_ndarray(name, content, **kw)
         s2.vectorise_ndarray(name, content, **kw)
-        torch.cuda.synchronize()
-        ts = [threading.Thread(target=worker) for _ in range(threads)]
-        t0 = time.perf_counter()
-        for t in ts:
-            t.start()
-        for t in ts:
-            t.join()
-        torch.cuda.synchronize()
-        return n * reps * threads / (time.perf_counter() - t0)
+        for _ in range(2):   # the second pass is the measured one: steady state (pinned staging blocks and per-stream workspaces cached)
+            torch.cuda.synchronize()
+            ts = [threading.Thread(target=worker) for _ in range(threads)]
+            t0 = time.perf_counter()
+            for t in ts:
+                t.start()
+            for t in ts:
+                t.join()
+            torch.cuda.synchronize()
+            elapsed = time.perf_counter() - t0
+        return n * reps * threads / elapsed
     out["ndarray_from_u8_arrays_4_callers"] = round(concurrent(arrs), 1)
     out["ndarray_from_device_tensors_4_callers"] = round(concurrent(dev_tensors), 1)
     out["ndarray_from_pil_4_callers"] = round(concurrent(pil), 1)
     out["tower_only"] = round(tower_only_rate, 1)
     best = max(out["ndarray_from_u8_arrays_4_callers"], out["ndarray_from_device_tensors_4_callers"], out["ndarray_from_u8_arrays"],
-               out["ndarray_from_device_tensors"])
+               out["ndarray_from_device_tensors"], out["ndarray_from_pil_4_callers"], out["ndarray_from_pil"])
     out["best_e2e_over_tower_only"] = round(best / tower_only_rate, 3)
     s2.clear_loaded_models()
     return out
