@@ -72,14 +72,19 @@ class BulkVectoriser:
         d = (props or {}).get("dimensions")
         return int(d) if isinstance(d, int) and d > 0 else None
 
-    def _encode(self, contents: List[Any], modality: Modality) -> np.ndarray:
-        """one vectorise call for the local shard (+ ONE all-gather when running one process per GPU)"""
+    def _encode(self, contents: List[Any], modality: Modality, defer: bool = False):
+        """one vectorise call for the local shard (+ ONE all-gather when running one process per GPU) -> float32 [n, D] ndarray.
+        defer=True (single process on a GPU): the rows may come back as a DEVICE tensor whose kernels are only enqueued — the caller
+        copies it to the host after it has staged the next modality, so that modality's host work overlaps this one's GPU work."""
         import torch
         import torch.distributed as dist
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         if world == 1 and not (self.force_collective and dist.is_available() and dist.is_initialized()):
             fn = self._vectorise
             if fn is None:
+                if defer and str(self.device).startswith("cuda") and torch.cuda.is_available():
+                    from marqo_amd.s2_inference.s2_inference import vectorise_device
+                    return self._call(vectorise_device, contents, modality)
                 from marqo_amd.s2_inference.s2_inference import vectorise_ndarray as fn
             out = self._call(fn, contents, modality)
             return out.cpu().numpy() if isinstance(out, torch.Tensor) else out
@@ -106,23 +111,40 @@ class BulkVectoriser:
 
     def _run_pending(self) -> None:
         """pops ONE modality at a time; if its vectorise call raises (e.g. one undecodable image) the popped items go back to the
-        front of the queue — nothing is lost, the caller sees the exception and may drop the offending key and flush again"""
+        front of the queue — nothing is lost, the caller sees the exception and may drop the offending key and flush again.
+        On a GPU the modalities are pipelined: the first one's kernels are enqueued (rows stay in HBM), the second one is tokenised /
+        packed / enqueued while they run, and only then are both copied to the host."""
+        import torch
+        enqueued, failure = [], None
         for modality in (Modality.TEXT, Modality.IMAGE):
             with self._lock:
                 items, self._pending[modality] = self._pending[modality], []
             if not items:
                 continue
             try:
-                emb = self._encode([c for _, c in items], modality)
+                emb = self._encode([c for _, c in items], modality, defer=True)
                 if emb.shape[0] != len(items):
                     raise RuntimeError(f"vectorise returned {emb.shape[0]} embeddings for {len(items)} items")
-            except BaseException:
+                enqueued.append((modality, items, emb))
+            except BaseException as e:  # noqa: BLE001 - re-raised below, after the modalities that did run are stored
                 with self._lock:
                     self._pending[modality] = items + self._pending[modality]
-                raise
+                failure = e
+                break
+        for modality, items, emb in enqueued:
+            try:
+                if isinstance(emb, torch.Tensor):
+                    emb = emb.cpu().numpy()
+            except BaseException as e:  # noqa: BLE001 - an asynchronous device error surfaces at the copy: same re-queue rule
+                with self._lock:
+                    self._pending[modality] = items + self._pending[modality]
+                failure = failure or e
+                continue
             with self._lock:
                 for (key, _), row in zip(items, emb):
                     self._done[key] = row
+        if failure is not None:
+            raise failure
 
     def discard(self, key: Hashable) -> int:
         """drop every queued item with this key (e.g. the image a failed flush reported); returns how many were dropped"""
