@@ -14,6 +14,7 @@ import subprocess
 import sys
 import sysconfig
 import threading
+from typing import Optional
 from pathlib import Path
 
 PKG_DIR = Path(__file__).resolve().parent
@@ -404,7 +405,56 @@ def load():
         if lib.mq_abi_version() != ABI_VERSION:
             raise MarqoHipUnavailableError(f"ABI version mismatch: library {lib.mq_abi_version()} != binding {ABI_VERSION}")
         _lib = lib
+        note_cpu_quota_once()
         return _lib
+
+
+def cpu_quota(root: str = "/sys/fs/cgroup") -> Optional[float]:
+    """CPUs' worth of time the container grants this process (cgroup v2 cpu.max, v1 cpu.cfs_quota_us / cpu.cfs_period_us), None when
+    unlimited or unknown"""
+    try:
+        with open(os.path.join(root, "cpu.max")) as f:
+            quota, period = f.read().split()[:2]
+        return None if quota == "max" else float(quota) / float(period)
+    except (OSError, ValueError):
+        pass
+    try:
+        with open(os.path.join(root, "cpu", "cpu.cfs_quota_us")) as f:
+            quota = float(f.read())
+        with open(os.path.join(root, "cpu", "cpu.cfs_period_us")) as f:
+            period = float(f.read())
+        return None if quota <= 0 or period <= 0 else quota / period
+    except (OSError, ValueError):
+        return None
+
+
+def oversubscription_note(torch_threads: int, quota: Optional[float]) -> Optional[str]:
+    """Advice for the operator when PyTorch's intra-op pool is much larger than the container's CPU quota (the engine itself keeps
+    PyTorch CPU kernels off the request path, DESIGN.md §6.5 "host bookkeeping"; the host's OTHER torch CPU work — the reference's own
+    CPU models, its post-processing — would still wake the whole pool)."""
+    if quota is None or torch_threads <= max(4.0, 2.0 * quota):
+        return None
+    return (f"torch.get_num_threads() = {torch_threads} but the container's CPU quota is {quota:g} CPUs: an OpenMP region of that size keeps "
+            f"spinning after small jobs and gets the whole process throttled; consider torch.set_num_threads({max(1, int(quota))}) or "
+            f"OMP_NUM_THREADS={max(1, int(quota))} in this service")
+
+
+_quota_checked = False
+
+
+def note_cpu_quota_once() -> None:
+    global _quota_checked
+    if _quota_checked:
+        return
+    _quota_checked = True
+    try:
+        import torch
+        note = oversubscription_note(torch.get_num_threads(), cpu_quota())
+    except Exception:  # noqa: BLE001 - advice only
+        return
+    if note:
+        import logging
+        logging.getLogger(__name__).warning(note)
 
 
 def check(rc: int, what: str = "libmarqo_hip") -> None:

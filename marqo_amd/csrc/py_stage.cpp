@@ -6,7 +6,7 @@
 // pyarrow import + NumPy view: 7-11 us each, all under the GIL, so concurrent request threads queued behind each other: 4 callers of 256
 // images were no faster than one, profiles/r02ab_pack_chunks_ab.txt).  This module does the whole batch in ONE call:
 //
-//   gather_rgbx(images, dst_address, offsets, nbytes, threads) -> list of the indices it could not export
+//   gather_rgbx(images, dst_address, dst_capacity, offsets, nbytes, threads) -> list of the indices it could not export
 //
 //   * under the GIL, per image: `img.__arrow_c_array__()` (the Arrow PyCapsule interface Pillow >= 11.2 implements; it loads lazy images
 //     first) -> ArrowSchema / ArrowArray capsules, checked to be the FixedSizeList<uint8>[4] of an RGB / RGBX image ("+w:4" over "C",
@@ -69,8 +69,9 @@ bool int64_view(PyObject* obj, Py_buffer* view, Py_ssize_t n, const char* what) 
 
 PyObject* gather_rgbx(PyObject*, PyObject* args) {
     PyObject *images, *dst_obj, *off_obj, *len_obj;
+    long long capacity = 0;
     int threads = 1;
-    if (!PyArg_ParseTuple(args, "OOOO|i", &images, &dst_obj, &off_obj, &len_obj, &threads)) return nullptr;
+    if (!PyArg_ParseTuple(args, "OOLOO|i", &images, &dst_obj, &capacity, &off_obj, &len_obj, &threads)) return nullptr;
     if (!PyList_Check(images)) { PyErr_SetString(PyExc_TypeError, "images must be a list"); return nullptr; }
     const Py_ssize_t n = PyList_GET_SIZE(images);
     char* dst = (char*)PyLong_AsVoidPtr(dst_obj);
@@ -81,6 +82,14 @@ PyObject* gather_rgbx(PyObject*, PyObject* args) {
     if (!int64_view(len_obj, &lens, n, "nbytes")) { PyBuffer_Release(&offs); return nullptr; }
     const int64_t* off = (const int64_t*)offs.buf;
     const int64_t* len = (const int64_t*)lens.buf;
+    for (Py_ssize_t i = 0; i < n; ++i)   // a slot outside the destination is the caller's bug, not an image that cannot be exported
+        if (len[i] > 0 && off[i] >= 0 && (off[i] > (int64_t)capacity || len[i] > (int64_t)capacity - off[i])) {
+            PyBuffer_Release(&offs);
+            PyBuffer_Release(&lens);
+            PyErr_Format(PyExc_ValueError, "item %zd: %lld bytes at offset %lld do not fit the %lld-byte destination", i, (long long)len[i],
+                         (long long)off[i], capacity);
+            return nullptr;
+        }
 
     PyObject* failed = PyList_New(0);
     PyObject* method = PyUnicode_InternFromString("__arrow_c_array__");
@@ -93,8 +102,11 @@ PyObject* gather_rgbx(PyObject*, PyObject* args) {
     for (Py_ssize_t i = 0; ok && i < n; ++i) {
         const void* src = nullptr;
         PyObject* caps = nullptr;
-        if (len[i] > 0 && off[i] >= 0) {
-            caps = PyObject_CallMethodNoArgs(PyList_GET_ITEM(images, i), method);
+        if (len[i] > 0 && off[i] >= 0 && i < PyList_GET_SIZE(images)) {   // (the export runs Python code: hold the item, re-check the list)
+            PyObject* img = PyList_GET_ITEM(images, i);
+            Py_INCREF(img);
+            caps = PyObject_CallMethodNoArgs(img, method);
+            Py_DECREF(img);
             if (!caps) PyErr_Clear();                     // (several blocks, unsupported mode, no Arrow interface: the caller's slow route)
             else src = rgbx_block(caps, len[i]);
         }
@@ -127,7 +139,12 @@ PyObject* gather_rgbx(PyObject*, PyObject* args) {
                 acc += items[k].bytes;
                 if (acc >= share || k + 1 == items.size()) {
                     if (k + 1 == items.size() || (int)pool.size() == t - 1) { work(lo, items.size()); break; }   // the caller's thread takes the last range
-                    pool.emplace_back(work, lo, k + 1);
+                    try {
+                        pool.emplace_back(work, lo, k + 1);
+                    } catch (...) {                       // no thread to be had: this thread copies the rest
+                        work(lo, items.size());
+                        break;
+                    }
                     lo = k + 1;
                     acc = 0;
                 }
@@ -146,9 +163,10 @@ PyObject* gather_rgbx(PyObject*, PyObject* args) {
 
 PyMethodDef methods[] = {
     {"gather_rgbx", gather_rgbx, METH_VARARGS,
-     "gather_rgbx(images, dst_address, offsets, nbytes, threads=1) -> [indices not exported]\n"
+     "gather_rgbx(images, dst_address, dst_capacity, offsets, nbytes, threads=1) -> [indices not exported]\n"
      "Copy the RGBX pixel blocks (4 bytes per pixel, Pillow's in-memory layout of RGB images) of a list of PIL images to\n"
-     "dst_address + offsets[i]; nbytes[i] = 4 * height * width.  The copies run with the GIL released."},
+     "dst_address + offsets[i] inside a destination of dst_capacity bytes; nbytes[i] = 4 * height * width.  The copies run\n"
+     "with the GIL released."},
     {nullptr, nullptr, 0, nullptr}};
 
 PyModuleDef module = {PyModuleDef_HEAD_INIT, "_mq_stage", "host-side staging of Pillow images (marqo_amd)", -1, methods, nullptr, nullptr, nullptr, nullptr};

@@ -203,7 +203,7 @@ class PackedImages:
         if lazy:
             lz_off = np.ascontiguousarray(x_off[lazy])
             lz_len = np.ascontiguousarray(npix[lazy] * 4)
-            for f in stager.gather_rgbx([imgs[k].image for k in lazy], host.data_ptr(), lz_off, lz_len, PACK_THREADS):
+            for f in stager.gather_rgbx([imgs[k].image for k in lazy], host.data_ptr(), host.numel(), lz_off, lz_len, PACK_THREADS):
                 k = lazy[f]   # Pillow could not export this one zero-copy (e.g. an image stored in several blocks): its .view copies
                 v = imgs[k].view
                 hnp[int(x_off[k]):int(x_off[k]) + v.nbytes] = np.ascontiguousarray(v).reshape(-1)

@@ -75,3 +75,21 @@ def test_shard_plan_restore_is_the_inverse_permutation():
     assert plan.restore(gathered)[:, 0].tolist() == [0.0, 1.0, 2.0, 3.0, 4.0]
     ident = ShardPlan(items=[[0, 1], [2]], n_items=3)
     assert ident.restore(gathered[:3]) is not None
+
+
+def test_cpu_quota_parsing_and_oversubscription_note(tmp_path):
+    from marqo_amd import _lib as L
+    (tmp_path / "cpu.max").write_text("1600000 100000\n")
+    assert L.cpu_quota(str(tmp_path)) == 16.0
+    (tmp_path / "cpu.max").write_text("max 100000\n")
+    assert L.cpu_quota(str(tmp_path)) is None
+    v1 = tmp_path / "v1"
+    (v1 / "cpu").mkdir(parents=True)
+    (v1 / "cpu" / "cpu.cfs_quota_us").write_text("250000\n")
+    (v1 / "cpu" / "cpu.cfs_period_us").write_text("100000\n")
+    assert L.cpu_quota(str(v1)) == 2.5
+    (v1 / "cpu" / "cpu.cfs_quota_us").write_text("-1\n")
+    assert L.cpu_quota(str(v1)) is None
+    assert L.cpu_quota(str(tmp_path / "missing")) is None
+    assert L.oversubscription_note(128, 16.0) and "set_num_threads(16)" in L.oversubscription_note(128, 16.0)
+    assert L.oversubscription_note(16, 16.0) is None and L.oversubscription_note(128, None) is None and L.oversubscription_note(4, 0.5) is None

@@ -47,7 +47,7 @@ def test_gather_matches_asarray(stage, threads):
     imgs = [Image.fromarray(a) for a in arrs]
     off, nbytes, total = _layout(sizes)
     dst = np.full(total + 64, 0xAB, dtype=np.uint8)
-    failed = stage.gather_rgbx(imgs, dst.ctypes.data, off, nbytes, threads)
+    failed = stage.gather_rgbx(imgs, dst.ctypes.data, dst.size, off, nbytes, threads)
     assert failed == []
     for a, o in zip(arrs, off):
         _check(dst, o, a)
@@ -71,7 +71,7 @@ def test_lazy_files_multi_block_and_other_modes(stage):
     sizes = [(100, 120), (2300, 2300), (10, 12), (10, 12), (9, 9), (1, 1)]
     off, nbytes, total = _layout(sizes)
     dst = np.zeros(total, dtype=np.uint8)
-    failed = stage.gather_rgbx(imgs, dst.ctypes.data, off, nbytes, 2)
+    failed = stage.gather_rgbx(imgs, dst.ctypes.data, dst.size, off, nbytes, 2)
     _check(dst, off[0], a0)
     _check(dst, off[4], a4)
     assert 2 in failed and 5 in failed                                  # mode L is not 4 bytes per pixel; a str has no Arrow interface
@@ -89,10 +89,10 @@ def test_size_mismatch_is_reported_not_copied(stage):
     img = Image.fromarray(np.full((8, 8, 3), 7, dtype=np.uint8))
     dst = np.zeros(4096, dtype=np.uint8)
     for wrong in (8 * 8 * 4 + 4, 8 * 8 * 3, 0, -4):
-        assert stage.gather_rgbx([img], dst.ctypes.data, np.zeros(1, dtype=np.int64), np.asarray([wrong], dtype=np.int64), 1) == [0]
+        assert stage.gather_rgbx([img], dst.ctypes.data, dst.size, np.zeros(1, dtype=np.int64), np.asarray([wrong], dtype=np.int64), 1) == [0]
         assert not dst.any()
-    assert stage.gather_rgbx([img], dst.ctypes.data, np.asarray([-256], dtype=np.int64), np.asarray([256], dtype=np.int64), 1) == [0]
-    assert stage.gather_rgbx([], 0, np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64), 1) == []
+    assert stage.gather_rgbx([img], dst.ctypes.data, dst.size, np.asarray([-256], dtype=np.int64), np.asarray([256], dtype=np.int64), 1) == [0]
+    assert stage.gather_rgbx([], 0, 0, np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64), 1) == []
 
 
 def test_bad_arguments_raise(stage):
@@ -100,15 +100,19 @@ def test_bad_arguments_raise(stage):
     dst = np.zeros(64, dtype=np.uint8)
     z = np.zeros(1, dtype=np.int64)
     with pytest.raises(TypeError):
-        stage.gather_rgbx((img,), dst.ctypes.data, z, z, 1)              # images must be a list
+        stage.gather_rgbx((img,), dst.ctypes.data, dst.size, z, z, 1)              # images must be a list
     with pytest.raises(ValueError):
-        stage.gather_rgbx([img], dst.ctypes.data, np.zeros(1, dtype=np.int32), z, 1)
+        stage.gather_rgbx([img], dst.ctypes.data, dst.size, np.zeros(1, dtype=np.int32), z, 1)
     with pytest.raises(ValueError):
-        stage.gather_rgbx([img], dst.ctypes.data, np.zeros(2, dtype=np.int64), z, 1)
+        stage.gather_rgbx([img], dst.ctypes.data, dst.size, np.zeros(2, dtype=np.int64), z, 1)
     with pytest.raises(ValueError):
-        stage.gather_rgbx([img], 0, z, np.asarray([16], dtype=np.int64), 1)   # null destination
+        stage.gather_rgbx([img], 0, 64, z, np.asarray([16], dtype=np.int64), 1)   # null destination
+    with pytest.raises(ValueError):   # a slot that does not fit the destination is the caller's bug: loud, nothing copied
+        stage.gather_rgbx([img], dst.ctypes.data, dst.size, np.asarray([56], dtype=np.int64), np.asarray([16], dtype=np.int64), 1)
+    with pytest.raises(ValueError):
+        stage.gather_rgbx([img], dst.ctypes.data, 8, z, np.asarray([16], dtype=np.int64), 1)
     with pytest.raises((TypeError, ValueError, BufferError)):
-        stage.gather_rgbx([img], dst.ctypes.data, [0], z, 1)
+        stage.gather_rgbx([img], dst.ctypes.data, dst.size, [0], z, 1)
 
 
 def test_concurrent_callers_share_images(stage):
@@ -123,7 +127,7 @@ def test_concurrent_callers_share_images(stage):
         try:
             for _ in range(5):
                 dst = np.zeros(total, dtype=np.uint8)
-                assert stage.gather_rgbx(imgs, dst.ctypes.data, off, nbytes, 4) == []
+                assert stage.gather_rgbx(imgs, dst.ctypes.data, dst.size, off, nbytes, 4) == []
                 for a, o in zip(arrs[::7], off[::7]):
                     _check(dst, o, a)
         except BaseException as e:  # noqa: BLE001
