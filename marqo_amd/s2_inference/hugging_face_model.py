@@ -16,6 +16,7 @@ import torch
 
 from marqo_amd import _lib as L
 from marqo_amd.engine import archs, checkpoint, synthetic
+from marqo_amd.engine.gpu_tokenizers import prefers_host
 from marqo_amd.engine.towers import request_stream
 from marqo_amd.engine.tokenizers import SyntheticTokenizer, WordPieceTokenizer, XlmRobertaTokenizer
 from marqo_amd.s2_inference.abstract_models import AbstractEmbeddingModel
@@ -199,7 +200,7 @@ class HuggingFaceModel(AbstractEmbeddingModel):
             self.load()
         return_device = bool(kwargs.get("return_device", False))
         with request_stream(self.device, device_output=return_device):
-            if getattr(self, "_device_tokenizer", None) is not None:
+            if getattr(self, "_device_tokenizer", None) is not None and not prefers_host(sentence):
                 d_ids, lens = self._device_tokenizer.encode_device(sentence, self.model_properties.tokens)
                 out = self._model.encode_device(d_ids, lens, normalize=bool(normalize))
             else:

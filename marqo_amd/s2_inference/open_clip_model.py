@@ -23,6 +23,7 @@ from PIL.Image import Image as ImageType
 
 from marqo_amd import _lib as L
 from marqo_amd.engine import archs, checkpoint, synthetic
+from marqo_amd.engine.gpu_tokenizers import prefers_host
 from marqo_amd.engine.towers import request_stream
 from marqo_amd.engine.tokenizers import (ClipBpeTokenizer, RobertaBpeTokenizer, SiglipTokenizer, SyntheticTokenizer, WordPieceTokenizer,
                                           XlmRobertaTokenizer, _clean_text)
@@ -441,12 +442,12 @@ class OPEN_CLIP(AbstractCLIPModel):
         with request_stream(self.device, device_output=return_device):
             if isinstance(self.text_arch, archs.HfClipTextArch):
                 texts = [_clean_text(t) for t in ([sentence] if isinstance(sentence, str) else list(sentence))]
-                if getattr(self, "_device_tokenizer", None) is not None:
+                if getattr(self, "_device_tokenizer", None) is not None and not prefers_host(texts):
                     d_ids, lens = self._device_tokenizer.encode_device(texts, self.text_arch.ctx)
                     out = self.text.encode_device(d_ids, lens, normalize=bool(normalize))
                 else:
                     out = self.text.encode_padded(torch.as_tensor(self.tokenizer.ids(texts)), normalize=bool(normalize))
-            elif getattr(self, "_device_tokenizer", None) is not None:
+            elif getattr(self, "_device_tokenizer", None) is not None and not prefers_host([sentence] if isinstance(sentence, str) else sentence):
                 texts = [sentence] if isinstance(sentence, str) else list(sentence)
                 if self.text_arch.causal:
                     d_ids, lens = self._device_tokenizer.encode_device(texts)
@@ -599,7 +600,7 @@ class MULTILINGUAL_CLIP(OPEN_CLIP):
         texts = [sentence] if isinstance(sentence, str) else list(sentence)
         max_len = self.text_arch.bert.max_pos
         with request_stream(self.device, device_output=return_device):
-            if getattr(self, "_device_tokenizer", None) is not None:
+            if getattr(self, "_device_tokenizer", None) is not None and not prefers_host(texts):
                 d_ids, lens = self._device_tokenizer.encode_device(texts, max_len)
                 out = self.text.encode_device(d_ids, lens, normalize=bool(normalize))
             else:

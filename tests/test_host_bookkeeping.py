@@ -93,3 +93,12 @@ def test_cpu_quota_parsing_and_oversubscription_note(tmp_path):
     assert L.cpu_quota(str(tmp_path / "missing")) is None
     assert L.oversubscription_note(128, 16.0) and "set_num_threads(16)" in L.oversubscription_note(128, 16.0)
     assert L.oversubscription_note(16, 16.0) is None and L.oversubscription_note(128, None) is None and L.oversubscription_note(4, 0.5) is None
+
+
+def test_lone_short_text_prefers_the_host_tokenizer(monkeypatch):
+    """the search path's single query: host tokenisation (0.01-0.07 ms) beats staging + three launches + a D2H sync (0.12-0.15 ms)"""
+    from marqo_amd.engine import gpu_tokenizers as GT
+    assert GT.prefers_host(["a photo of a cat"]) and GT.prefers_host(("q",)) and GT.prefers_host([""])
+    assert not GT.prefers_host(["a", "b"]) and not GT.prefers_host([]) and not GT.prefers_host(["x" * (GT.HOST_TOKENIZE_MAX_CHARS + 1)])
+    monkeypatch.setattr(GT, "HOST_TOKENIZE_MAX_CHARS", -1)    # MARQO_AMD_HOST_TOKENIZE_MAX_CHARS=-1: always the device route
+    assert not GT.prefers_host(["q"])
