@@ -118,7 +118,12 @@ def _cos_err(gpu, cpu):
 
 
 def _baseline_dict(rate, n, threads, cores, what):
-    return {"value": round(rate, 2), "unit": "embeddings/s", "cores": cores, "threads_used": threads, "kind": "port",
+    try:   # the container may grant far less CPU time than the host has hardware threads (the GPU boxes: 16 CPUs' worth of 256)
+        from marqo_amd._lib import cpu_quota
+        quota = cpu_quota()
+    except Exception:  # noqa: BLE001 - informational
+        quota = None
+    return {"value": round(rate, 2), "unit": "embeddings/s", "cores": cores, "threads_used": threads, "cpu_quota": quota, "kind": "port",
             "sample": f"{n} {what}, fp32 PyTorch eager, 16-item batches (reference loop s2_inference.py:135-146), best of a 16/32/64/128/all thread ladder"}
 
 
