@@ -279,3 +279,23 @@ def test_roberta_byte_level_bpe_matches_transformers(tmp_path):
     # (the tokenizers-backed class of the transformers installed here does not, so this one case is stated, not compared)
     a, b = ours.encode("a")[1], ours.encode(" b")[1:-1]
     assert ours.encode("a <mask> b") == [0, a, vocab["<mask>"], *b, 2]
+
+
+def test_wordpiece_ascii_fast_path_equals_the_general_path():
+    """WordPieceTokenizer._basic takes a table-driven route for ASCII text; it must split exactly like the per-character Unicode route
+    (control characters incl. \\x0b \\x0c \\x1c-\\x1f and DEL, every punctuation range, both casings)"""
+    import random
+    tok = WordPieceTokenizer({t: i for i, t in enumerate(_bert_vocab())})
+
+    class NotAscii(str):
+        def isascii(self):
+            return False
+    rng = random.Random(0)
+    alphabet = [chr(c) for c in range(128)]
+    for lower in (True, False):
+        tok.lower = lower
+        for _ in range(4000):
+            t = "".join(rng.choice(alphabet) for _ in range(rng.randint(0, 40)))
+            assert tok._basic(t) == tok._basic(NotAscii(t)), repr(t)
+        for t in ("", " ", "a\tb\nc\rd", "x\x0by\x0cz\x1c\x1f", "Hello, World! (test) [a]{b}~`^_", "\x00\x7f", "don't stop-me_now"):
+            assert tok._basic(t) == tok._basic(NotAscii(t)), repr(t)
