@@ -1,0 +1,78 @@
+"""Run by tests/test_ref_parity.py::test_reference_callers_on_top_of_the_drop_in in a FRESH interpreter (so that marqo_amd sees the host
+package `marqo` at import time, as it would inside a Marqo deployment): the reference's own caller classes
+(core/inference/tensor_fields_container.py: ModelConfig, SingleVectoriser, BatchCachingVectoriser, TensorFieldContent, TextChunker) with
+ONE change — their module's `s2_inference` name bound to marqo_amd's — against the same classes on the reference's own s2_inference.
+Prints one JSON object; exits non-zero on any mismatch.  Test infrastructure (imports oracle/ref_shim.py); never imported by the product."""
+import json
+import sys
+
+import numpy as np
+
+
+def main() -> int:
+    from oracle import ref_shim
+    from marqo_amd.s2_inference.processing import text as product_text   # (the sentence segmenter the reference would get from nltk's punkt
+    ref_shim.install(sent_tokenize=product_text._sentences, word_tokenize=product_text._WORD.findall)   # data: not downloadable here)
+    from marqo.core.inference import tensor_fields_container as T
+    from marqo.core.exceptions import AddDocumentsError, ModelError
+    from marqo.s2_inference import errors as host_errors
+    from marqo.s2_inference.multimodal_model_load import Modality
+    from marqo.tensor_search.telemetry import RequestMetricsStore
+    from marqo.api import exceptions as host_api
+    RequestMetricsStore.set_in_request(r=object())
+    from marqo_amd.s2_inference import errors as our_errors
+    from marqo_amd.s2_inference import s2_inference as ours
+    report = {"host_errors_bound": our_errors._HOST_S2 is host_errors and our_errors._HOST_API is host_api}
+
+    def cfg(name="random/small", normalize=True):
+        return T.ModelConfig(model_name=name, model_properties=None, model_auth=None, device="cpu", normalize_embeddings=normalize)
+    chunks = [("doc1_title_0", "hello world"), ("doc1_title_1", "second chunk"), ("doc2_body_0", "another document"), ("doc2_body_1", "")]
+    ref_batch = T.BatchCachingVectoriser(Modality.TEXT, chunks, cfg())
+    ref_single = T.SingleVectoriser(Modality.TEXT, cfg()).vectorise(["hello world", "second chunk"])
+    ref_raw = T.SingleVectoriser(Modality.TEXT, cfg(normalize=False)).vectorise(["hello world"])
+
+    T.s2_inference = ours          # <- the whole integration: the module the reference's callers call
+    got_batch = T.BatchCachingVectoriser(Modality.TEXT, chunks, cfg())
+    got_single = T.SingleVectoriser(Modality.TEXT, cfg()).vectorise(["hello world", "second chunk"])
+    got_raw = T.SingleVectoriser(Modality.TEXT, cfg(normalize=False)).vectorise(["hello world"])
+    report["batch_keys_equal"] = list(got_batch.embedding_cache) == list(ref_batch.embedding_cache)
+    report["batch_embeddings_equal"] = all(np.array_equal(got_batch.embedding_cache[k], ref_batch.embedding_cache[k]) for k in ref_batch.embedding_cache)
+    report["cached_lookup_equal"] = got_batch.vectorise(["x", "y"], "doc1_title") == ref_batch.vectorise(["x", "y"], "doc1_title")
+    report["single_equal"] = np.array_equal(got_single, ref_single) and np.array_equal(got_raw, ref_raw)
+    report["returns_lists_of_floats"] = isinstance(got_single, list) and isinstance(got_single[0], list) and isinstance(got_single[0][0], float)
+
+    # TensorFieldContent.chunk / vectorise (the add_documents flow of one text field) on top of the drop-in
+    from marqo.core.models.marqo_index import FieldType, TextPreProcessing, TextSplitMethod
+    tp = TextPreProcessing(split_length=2, split_overlap=0, split_method=TextSplitMethod.Sentence)
+    field = T.TensorFieldContent(field_content="One sentence. Another one. A third. And a fourth.", field_type=FieldType.Text, is_tensor_field=True)
+    field.chunk({FieldType.Text: T.TextChunker(tp, "passage: ")})
+    field.vectorise({FieldType.Text: T.SingleVectoriser(Modality.TEXT, cfg())})
+    report["field_chunks"] = field.tensor_field_chunks
+    report["field_embeddings"] = [len(field.tensor_field_embeddings), len(field.tensor_field_embeddings[0])]
+
+    # error mapping through the reference's OWN except clauses (tensor_fields_container.py:155-163)
+    def outcome(fn):
+        try:
+            fn()
+            return "no error"
+        except Exception as e:  # noqa: BLE001
+            return f"{type(e).__module__}.{type(e).__name__}"
+    report["unknown_model"] = outcome(lambda: T.SingleVectoriser(Modality.TEXT, cfg("no/such-model")).vectorise(["a"]))
+    report["bad_properties"] = outcome(lambda: T.SingleVectoriser(Modality.TEXT, T.ModelConfig(
+        model_name="my-model", model_properties={"dimensions": 8}, model_auth=None, device="cpu", normalize_embeddings=True)).vectorise(["a"]))
+    report["empty_content"] = outcome(lambda: T.SingleVectoriser(Modality.TEXT, cfg()).vectorise([]))
+    report["no_device"] = outcome(lambda: ours.vectorise("random/small", "a", device=None))
+    e = ours.errors.UnknownModelError("m") if hasattr(ours, "errors") else our_errors.UnknownModelError("m")
+    report["is_host_class"] = isinstance(e, host_errors.UnknownModelError) and isinstance(our_errors.InternalError("x"), host_api.MarqoWebError)
+    expect = {"host_errors_bound": True, "batch_keys_equal": True, "batch_embeddings_equal": True, "cached_lookup_equal": True, "single_equal": True,
+              "returns_lists_of_floats": True, "unknown_model": f"{ModelError.__module__}.ModelError",
+              "bad_properties": f"{ModelError.__module__}.ModelError", "no_device": "marqo_amd.s2_inference.errors.InternalError",
+              "is_host_class": True}
+    bad = {k: (report.get(k), v) for k, v in expect.items() if report.get(k) != v}
+    report["mismatches"] = {k: list(v) for k, v in bad.items()}
+    print(json.dumps(report))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

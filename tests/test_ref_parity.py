@@ -338,3 +338,35 @@ def test_product_dispatch_errors_match_reference(host):
     assert host["clip_encode_bad_default"]["raises"] == "UnidentifiedImageError"
     assert m.encode(["a.jpg"], infer=True) == "image" and m.encode(["a.jpg is text"], infer=False) == "text"
     assert m.encode(["plain"], default="image", infer=False) == "image"
+
+
+@pytest.mark.skipif(not ref_shim.available(), reason="/root/reference is not present on this machine")
+def test_reference_callers_on_top_of_the_drop_in():
+    """INTEGRATION.md §2 made executable: the reference's OWN caller classes (tensor_fields_container.py: SingleVectoriser,
+    BatchCachingVectoriser, TensorFieldContent + TextChunker) with their `s2_inference` name bound to marqo_amd's module give the same
+    embeddings as on the reference's own module (the CPU-runnable `random/small` model), and the product's errors travel through the
+    reference's own `except` clauses to its ModelError — because, inside a host that has the `marqo` package, the product's error classes
+    derive from the host's (marqo_amd/s2_inference/errors.py).  Runs in a fresh interpreter so that import order is the deployment's."""
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    env.pop("MARQO_AMD_HOST_ERRORS", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "ref_callers_check.py")], capture_output=True, text=True, env=env, timeout=300)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert lines, r.stderr[-2000:]
+    report = json.loads(lines[-1])
+    assert r.returncode == 0 and report["mismatches"] == {}, report
+    assert report["field_chunks"] == ["One sentence. Another one.", "A third. And a fourth."] and report["field_embeddings"] == [2, 32]
+
+
+def test_error_classes_stand_alone_contract():
+    """without a host application the error classes are plain: reference names, hierarchy, constructor, codes (api/exceptions.py:128-130,
+    216-219,246-248)"""
+    r = subprocess.run([sys.executable, "-c", (
+        "import json; from marqo_amd.s2_inference import errors as E; c = E.ConfigurationError('bad'); u = E.UnknownModelError('m');"
+        "print(json.dumps({'host': E._HOST_S2 is None and E._HOST_API is None, 'cfg': [c.code, int(c.status_code), c.message, isinstance(c, E.InternalError)],"
+        "'mc': [E.ModelCacheManagementError('x').code, int(E.ModelCacheManagementError('x').status_code)], 'internal': E.InternalError(message='d').code,"
+        "'s2': [u.message, str(u), isinstance(u, E.S2InferenceError), E.S2InferenceError().message]}))")],
+        capture_output=True, text=True, timeout=120, cwd=ROOT, env=dict(os.environ, MARQO_AMD_HOST_ERRORS="0", PYTHONPATH=ROOT))
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out == {"host": True, "cfg": ["server_configuration_error", 500, "bad", True], "mc": ["model_cache_management_error", 409],
+                   "internal": "internal", "s2": ["m", "m", True, None]}
