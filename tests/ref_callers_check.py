@@ -62,12 +62,52 @@ def main() -> int:
         model_name="my-model", model_properties={"dimensions": 8}, model_auth=None, device="cpu", normalize_embeddings=True)).vectorise(["a"]))
     report["empty_content"] = outcome(lambda: T.SingleVectoriser(Modality.TEXT, cfg()).vectorise([]))
     report["no_device"] = outcome(lambda: ours.vectorise("random/small", "a", device=None))
+    # ---- the search path and model management (tensor_search/tensor_search.py:1876-1911, 2228-2244) --------------------------------
+    from marqo.tensor_search import tensor_search as TS
+    from marqo.tensor_search.models.search import VectorisedJobs
+    from marqo.s2_inference import s2_inference as ref_s2
+
+    def job(name="random/small", content=("what is marqo", "a second query")):
+        props = ref_s2.get_model_properties_from_registry(name) if name == "random/small" else {"dimensions": 8}
+        return VectorisedJobs(model_name=name, model_properties=props, content=list(content), device="cpu", normalize_embeddings=True,
+                              image_download_headers=None, content_type="text", model_auth=None)
+    TS.s2_inference = ref_s2
+    ref_jobs = TS.vectorise_jobs([job()])
+    TS.s2_inference = ours
+    ours.clear_loaded_models()
+    got_jobs = TS.vectorise_jobs([job()])
+    report["search_jobs_equal"] = list(got_jobs) == list(ref_jobs) and all(
+        list(got_jobs[k]) == list(ref_jobs[k]) and all(np.array_equal(got_jobs[k][c], ref_jobs[k][c]) for c in ref_jobs[k]) for k in ref_jobs)
+    # enable_cache=True was passed: a second run must come from the inference cache with the same vectors
+    report["search_jobs_cached_equal"] = all(np.array_equal(TS.vectorise_jobs([job()])[k][c], ref_jobs[k][c]) for k in ref_jobs for c in ref_jobs[k])
+    report["search_unknown_model"] = outcome(lambda: TS.vectorise_jobs([job(name="no/such-model")]))
+    loaded = TS.get_loaded_models()
+    report["loaded_models"] = loaded
+    report["eject"] = TS.eject_model("random/small", "cpu")
+    report["loaded_after_eject"] = TS.get_loaded_models()
+    report["eject_again"] = outcome(lambda: TS.eject_model("random/small", "cpu"))
+    TS.s2_inference = ref_s2
+    ref_s2.vectorise("random/small", "warm", device="cpu")
+    report["ref_eject"] = TS.eject_model("random/small", "cpu")
+
+    # ---- index settings validation (core/models/marqo_index.py:150-200 calls validate_model_properties / get_model_properties_from_registry)
+    from marqo.core.models import marqo_index as MI
+    MI.s2_inference = ours
+    m = MI.Model(name="hf/e5-base-v2")
+    report["index_model_properties"] = {k: m.get_properties().get(k) for k in ("name", "dimensions", "type")}
+    MI.s2_inference = ref_s2
+    report["index_model_properties_ref"] = {k: MI.Model(name="hf/e5-base-v2").get_properties().get(k) for k in ("name", "dimensions", "type")}
+
     e = ours.errors.UnknownModelError("m") if hasattr(ours, "errors") else our_errors.UnknownModelError("m")
     report["is_host_class"] = isinstance(e, host_errors.UnknownModelError) and isinstance(our_errors.InternalError("x"), host_api.MarqoWebError)
     expect = {"host_errors_bound": True, "batch_keys_equal": True, "batch_embeddings_equal": True, "cached_lookup_equal": True, "single_equal": True,
               "returns_lists_of_floats": True, "unknown_model": f"{ModelError.__module__}.ModelError",
               "bad_properties": f"{ModelError.__module__}.ModelError", "no_device": "marqo_amd.s2_inference.errors.InternalError",
-              "is_host_class": True}
+              "is_host_class": True, "search_jobs_equal": True, "search_jobs_cached_equal": True,
+              "search_unknown_model": f"{host_api.BadRequestError.__module__}.BadRequestError",
+              "loaded_models": {"models": [{"model_name": "random/small", "model_device": "cpu"}]}, "loaded_after_eject": {"models": []},
+              "eject": report["ref_eject"], "eject_again": f"{host_api.ModelNotInCacheError.__module__}.ModelNotInCacheError",
+              "index_model_properties": report["index_model_properties_ref"]}
     bad = {k: (report.get(k), v) for k, v in expect.items() if report.get(k) != v}
     report["mismatches"] = {k: list(v) for k, v in bad.items()}
     print(json.dumps(report))

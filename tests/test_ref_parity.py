@@ -346,7 +346,10 @@ def test_reference_callers_on_top_of_the_drop_in():
     BatchCachingVectoriser, TensorFieldContent + TextChunker) with their `s2_inference` name bound to marqo_amd's module give the same
     embeddings as on the reference's own module (the CPU-runnable `random/small` model), and the product's errors travel through the
     reference's own `except` clauses to its ModelError — because, inside a host that has the `marqo` package, the product's error classes
-    derive from the host's (marqo_amd/s2_inference/errors.py).  Runs in a fresh interpreter so that import order is the deployment's."""
+    derive from the host's (marqo_amd/s2_inference/errors.py).  Also the search path (tensor_search.vectorise_jobs with enable_cache=True:
+    same vectors, then served from the inference cache; unknown model -> the host's BadRequestError), model management (get_loaded_models
+    parses the cache keys, eject_model's result dict, ModelNotInCacheError) and the index-settings model validation
+    (core/models/marqo_index.py:150-200).  Runs in a fresh interpreter so that import order is the deployment's."""
     env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
     env.pop("MARQO_AMD_HOST_ERRORS", None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "ref_callers_check.py")], capture_output=True, text=True, env=env, timeout=300)
