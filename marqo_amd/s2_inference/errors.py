@@ -95,3 +95,16 @@ def _api(name: str, code: str, status_code: int, parent: Optional[type] = None) 
 InternalError = _api("InternalError", "internal", 500)
 ModelCacheManagementError = _api("ModelCacheManagementError", "model_cache_management_error", 409)
 ConfigurationError = _api("ConfigurationError", "server_configuration_error", 500, parent=InternalError)
+
+
+# marqo.api.exceptions.EnvVarError (api/exceptions.py:24-28: a MarqoError whose constructor only stores the message), raised by the
+# inference cache for bad MARQO_INFERENCE_CACHE_* settings (inference/inference_cache/marqo_inference_cache.py:31-52)
+_HostEnvVarError = _host_class(_HOST_API, "EnvVarError")
+
+
+class EnvVarError(_HostEnvVarError or Exception):
+    code = "env_var_error"
+
+    def __init__(self, message: Optional[str] = None) -> None:
+        self.message = message
+        Exception.__init__(self, message)

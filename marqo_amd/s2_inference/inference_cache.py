@@ -12,8 +12,7 @@ from collections import OrderedDict
 from typing import Dict, List, Optional, Tuple, Union
 
 
-class EnvVarError(Exception):
-    pass
+from marqo_amd.s2_inference.errors import EnvVarError  # noqa: E402,F401  (the host's marqo.api.exceptions.EnvVarError when there is a host)
 
 
 class _LRU:
@@ -41,6 +40,19 @@ class _LRU:
         with self._lock:
             self._d.move_to_end(key)
             return self._d[key]
+
+    def set(self, key, value) -> None:
+        """(the reference's classes expose both spellings: marqo_lru_cache.py:24-26)"""
+        self[key] = value
+
+    def popitem(self) -> None:
+        """evict the entry the policy would evict next (marqo_lru_cache.py:43-45)"""
+        with self._lock:
+            if self._d:
+                self._pop_victim()
+
+    def _pop_victim(self) -> None:
+        self._d.popitem(last=False)
 
     def __contains__(self, key) -> bool:
         with self._lock:
@@ -87,16 +99,25 @@ class _LFU(_LRU):
                 self._d.move_to_end(key)
                 return
             while len(self._d) >= self.maxsize and self._d:
-                victim = min(self._d, key=lambda k: self._freq[k])  # OrderedDict iteration = recency order -> LRU tie-break
-                del self._d[victim]
-                del self._freq[victim]
+                self._pop_victim()
             self._d[key] = value
             self._freq[key] = 1
+
+    def _pop_victim(self) -> None:
+        victim = min(self._d, key=lambda k: self._freq[k])  # OrderedDict iteration = recency order -> LRU tie-break
+        del self._d[victim]
+        del self._freq[victim]
 
     def clear(self) -> None:
         with self._lock:
             self._d.clear()
             self._freq.clear()
+
+
+# the reference's class names (inference/inference_cache/marqo_lru_cache.py, marqo_lfu_cache.py): same methods — get / set / [] / in / len /
+# popitem / clear / maxsize / currsize
+MarqoLRUCache = _LRU
+MarqoLFUCache = _LFU
 
 
 class MarqoInferenceCache:

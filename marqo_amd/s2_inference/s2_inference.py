@@ -122,7 +122,7 @@ def vectorise_device(model_name: str, content, model_properties: dict = None, de
     key = _create_model_cache_key(model_name, device, props)
     _update_available_models(key, model_name, props, device, normalize_embeddings, model_auth=model_auth)
     model = _available_models[key][AvailableModelsKey.model]
-    if getattr(model, "supports_dynamic_batching", False):
+    if getattr(model, "supports_dynamic_batching", False) is True:
         kwargs["return_device"] = True
     out = _encode_to_array(key, content, normalize_embeddings, modality, **kwargs)
     if not isinstance(out, torch.Tensor):
@@ -189,7 +189,7 @@ def _encode_to_array(model_cache_key: str, content, normalize_embeddings: bool, 
             vector_batches = []
             on_device = bool(kwargs.get("return_device"))
             batch_size = _get_max_vectorise_batch_size()  # validated even when the engine batches dynamically
-            if getattr(model, "supports_dynamic_batching", False) and len(content) > 0:
+            if getattr(model, "supports_dynamic_batching", False) is True and len(content) > 0:   # (`is True`: a mock model answers truthy to any attribute)
                 # one call: the engine micro-batches by token rows on the device.  Non-text items (decoded images: ~MBs of pinned
                 # staging + HBM each) are still bounded per call, by MARQO_AMD_MAX_ITEMS_PER_ENCODE (default 1024), so a request of
                 # thousands of large images cannot stage tens of GB at once.

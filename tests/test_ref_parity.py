@@ -373,3 +373,31 @@ def test_error_classes_stand_alone_contract():
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out == {"host": True, "cfg": ["server_configuration_error", 500, "bad", True], "mc": ["model_cache_management_error", 409],
                    "internal": "internal", "s2": ["m", "m", True, None]}
+
+
+# the reference's own unit-test files for this path that need neither network nor weights (the others load real checkpoints)
+REFERENCE_TEST_FILES = {   # file under /root/reference/tests -> tests it holds
+    "s2_inference/test_vectorise.py": 12,              # vectorise plumbing: batching by MARQO_MAX_VECTORISE_BATCH_SIZE, empty content, errors
+    "s2_inference/test_encoding_random.py": 2,         # the `random` models through vectorise
+    "s2_inference/test_sbert_utils.py": 2,             # Model / SBERT constructors without a device
+    "core/inference/test_inference_cache.py": 14,      # MarqoInferenceCache: LRU / LFU, sizes, env validation, concurrency
+    "core/inference/test_cache.py": 6,                 # MarqoLRUCache / MarqoLFUCache
+    "processing/test_split_text.py": 8,                # split_text / prefix_text_chunks
+}
+
+
+@pytest.mark.skipif(not ref_shim.available(), reason="/root/reference is not present on this machine")
+def test_reference_unit_tests_pass_on_the_product():
+    """The reference's OWN test files, run where they lie, with the module names they import and patch (`marqo.s2_inference.s2_inference`,
+    `...random_utils`, `...sbert_utils`, `...processing.text`, `marqo.inference.inference_cache.*`) bound to marqo_amd's modules
+    (tests/ref_suite_runner.py): every test they hold must pass on the product."""
+    import re
+    files = [os.path.join(os.path.dirname(ref_shim.REFERENCE_SRC), "tests", f) for f in REFERENCE_TEST_FILES]
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    env.pop("MARQO_AMD_HOST_ERRORS", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "ref_suite_runner.py"), *files], capture_output=True, text=True, env=env,
+                       timeout=900, cwd="/tmp")
+    tail = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-2000:]
+    m = re.search(r"(\d+) passed", tail)
+    assert r.returncode == 0 and m and "failed" not in tail and "error" not in tail, r.stdout[-3000:] + r.stderr[-1500:]
+    assert int(m.group(1)) == sum(REFERENCE_TEST_FILES.values()), tail
