@@ -383,6 +383,8 @@ REFERENCE_TEST_FILES = {   # file under /root/reference/tests -> tests it holds
     "core/inference/test_inference_cache.py": 14,      # MarqoInferenceCache: LRU / LFU, sizes, env validation, concurrency
     "core/inference/test_cache.py": 6,                 # MarqoLRUCache / MarqoLFUCache
     "processing/test_split_text.py": 8,                # split_text / prefix_text_chunks
+    "core/inference/test_tensor_field_content.py": 21,      # the caller layer on top of the module: TensorFieldContent chunk / vectorise
+    "core/inference/test_tensor_fields_container.py": 30,   # TensorFieldsContainer (field collection, multimodal sub-fields)
 }
 
 
