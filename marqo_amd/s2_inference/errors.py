@@ -1,17 +1,17 @@
 """Error hierarchy of the vectorise() path.
 
-Same class names and inheritance as the reference (src/marqo/s2_inference/errors.py:4-72), plus the three API-level exceptions the path
-raises (src/marqo/api/exceptions.py:128-130,216-219,246-248: ModelCacheManagementError, InternalError, ConfigurationError).
+Same class names and inheritance as the reference (src/marqo/s2_inference/errors.py:4-72), plus the API-level exceptions the path raises
+(src/marqo/api/exceptions.py:24-28,128-130,216-219,246-248: EnvVarError, ModelCacheManagementError, InternalError, ConfigurationError).
 
 Names alone do not make the callers' `except` clauses work: the reference catches ITS OWN classes
-(`except (s2_inference_errors.UnknownModelError, ...)` in core/inference/tensor_fields_container.py:155-163 and
-tensor_search/tensor_search.py:1899-1911; the FastAPI handlers dispatch on `marqo.api.exceptions.MarqoWebError`).  So when this engine is
-installed INTO the host application — the package `marqo` is importable — every class below also derives from the host's class of the same
-name: an `UnknownModelError` raised here IS a `marqo.s2_inference.errors.UnknownModelError`, an `InternalError` IS a
-`marqo.api.exceptions.InternalError` (message suffix, status code and error code as the host defines them), and swapping the
-`s2_inference` import is the whole integration (tests/test_ref_parity.py runs the reference's own Vectoriser classes on top of this
-module to check exactly that).  Without a host (`MARQO_AMD_HOST_ERRORS=0`, or no `marqo` package: the GPU box, the tests) they are
-plain classes with the reference's constructor, attributes and codes.
+(`except (s2_inference_errors.UnknownModelError, ..., s2_inference.ModelDownloadError)` in core/inference/tensor_fields_container.py:155-163
+and tensor_search/tensor_search.py:1899-1911; the FastAPI handlers dispatch on `marqo.api.exceptions.MarqoWebError`), and its tests raise
+its own classes INTO those clauses.  So when this engine is installed into the host application — the package `marqo` is importable — the
+names below ARE the host's classes (identity: every isinstance / except works in both directions; message suffix, status code and error
+code as the host defines them), and swapping the `s2_inference` import is the whole integration: tests/test_ref_parity.py runs the
+reference's own callers and the reference's own unit tests on top of this package to check exactly that.  Without a host
+(`MARQO_AMD_HOST_ERRORS=0`, or no `marqo` package: the GPU box, most tests) they are plain classes with the reference's constructor,
+attributes and codes.
 """
 import importlib
 import os
@@ -31,25 +31,26 @@ _HOST_S2 = _host_module("marqo.s2_inference.errors")
 _HOST_API = _host_module("marqo.api.exceptions")
 
 
-def _host_class(module, name: str):
+def _host_class(module, name: str, base: Optional[type] = None):
     c = getattr(module, name, None) if module is not None else None
-    return c if isinstance(c, type) and issubclass(c, Exception) else None
+    return c if isinstance(c, type) and issubclass(c, base or Exception) else None
 
 
-_HostS2Base = _host_class(_HOST_S2, "S2InferenceError")
-
-
-class S2InferenceError(_HostS2Base or Exception):
+# ---- s2_inference errors -----------------------------------------------------------------------------------------------------------
+class _StandAloneS2InferenceError(Exception):
     def __init__(self, message: Optional[str] = None) -> None:
         self.message = message
-        Exception.__init__(self, self.message)
+        super().__init__(self.message)
+
+
+_StandAloneS2InferenceError.__name__ = _StandAloneS2InferenceError.__qualname__ = "S2InferenceError"
+S2InferenceError = _host_class(_HOST_S2, "S2InferenceError") or _StandAloneS2InferenceError
 
 
 def _s2(name: str) -> type:
-    """our subclass of S2InferenceError called `name`, also a subclass of the host's class of that name when there is a host"""
-    host = _host_class(_HOST_S2, name)
-    bases = (S2InferenceError, host) if host is not None and _HostS2Base is not None and issubclass(host, _HostS2Base) else (S2InferenceError,)
-    return type(name, bases, {"__module__": __name__, "__doc__": f"src/marqo/s2_inference/errors.py: {name}"})
+    """the host's class of that name (when it derives from the host's S2InferenceError), else a stand-alone subclass"""
+    host = _host_class(_HOST_S2, name, S2InferenceError)
+    return host or type(name, (S2InferenceError,), {"__module__": __name__, "__doc__": f"src/marqo/s2_inference/errors.py: {name}"})
 
 
 MediaMismatchError = _s2("MediaMismatchError")
@@ -70,7 +71,7 @@ UnsupportedModalityError = _s2("UnsupportedModalityError")
 
 # ---- API-level exceptions raised from inside the path (marqo.api.exceptions in the reference) ----
 class MarqoApiError(Exception):
-    """stand-alone base of the three API-level errors (no host application): message / code / status_code as the host's classes carry them"""
+    """stand-alone base of the API-level errors (no host application): message / code / status_code as the host's classes carry them"""
     code = "unhandled_error"
     status_code = 500
 
@@ -80,31 +81,11 @@ class MarqoApiError(Exception):
 
 
 def _api(name: str, code: str, status_code: int, parent: Optional[type] = None) -> type:
-    """With a host: a subclass of the host's class (its __init__, message suffix, code, status code — whatever the host's handlers expect)
-    and of `parent` (our class one level up, so `except InternalError` inside this package still sees a ConfigurationError).
-    Stand-alone: a MarqoApiError subclass with the reference's code / status."""
     host = _host_class(_HOST_API, name)
-    if host is not None:
-        try:
-            return type(name, (parent, host) if parent is not None else (host,), {"__module__": __name__})
-        except TypeError:   # inconsistent MRO in an unexpected host hierarchy: the host's class alone
-            return type(name, (host,), {"__module__": __name__})
-    return type(name, (parent or MarqoApiError,), {"__module__": __name__, "code": code, "status_code": status_code})
+    return host or type(name, (parent or MarqoApiError,), {"__module__": __name__, "code": code, "status_code": status_code})
 
 
 InternalError = _api("InternalError", "internal", 500)
 ModelCacheManagementError = _api("ModelCacheManagementError", "model_cache_management_error", 409)
 ConfigurationError = _api("ConfigurationError", "server_configuration_error", 500, parent=InternalError)
-
-
-# marqo.api.exceptions.EnvVarError (api/exceptions.py:24-28: a MarqoError whose constructor only stores the message), raised by the
-# inference cache for bad MARQO_INFERENCE_CACHE_* settings (inference/inference_cache/marqo_inference_cache.py:31-52)
-_HostEnvVarError = _host_class(_HOST_API, "EnvVarError")
-
-
-class EnvVarError(_HostEnvVarError or Exception):
-    code = "env_var_error"
-
-    def __init__(self, message: Optional[str] = None) -> None:
-        self.message = message
-        Exception.__init__(self, message)
+EnvVarError = _api("EnvVarError", "env_var_error", 500)   # (bad MARQO_INFERENCE_CACHE_* settings: marqo_inference_cache.py:31-52)

@@ -99,10 +99,11 @@ def main() -> int:
     report["index_model_properties_ref"] = {k: MI.Model(name="hf/e5-base-v2").get_properties().get(k) for k in ("name", "dimensions", "type")}
 
     e = ours.errors.UnknownModelError("m") if hasattr(ours, "errors") else our_errors.UnknownModelError("m")
-    report["is_host_class"] = isinstance(e, host_errors.UnknownModelError) and isinstance(our_errors.InternalError("x"), host_api.MarqoWebError)
+    report["is_host_class"] = (our_errors.UnknownModelError is host_errors.UnknownModelError and our_errors.InternalError is host_api.InternalError
+                               and isinstance(e, host_errors.S2InferenceError) and ours.ModelDownloadError is host_errors.ModelDownloadError)
     expect = {"host_errors_bound": True, "batch_keys_equal": True, "batch_embeddings_equal": True, "cached_lookup_equal": True, "single_equal": True,
               "returns_lists_of_floats": True, "unknown_model": f"{ModelError.__module__}.ModelError",
-              "bad_properties": f"{ModelError.__module__}.ModelError", "no_device": "marqo_amd.s2_inference.errors.InternalError",
+              "bad_properties": f"{ModelError.__module__}.ModelError", "no_device": f"{host_api.InternalError.__module__}.InternalError",
               "is_host_class": True, "search_jobs_equal": True, "search_jobs_cached_equal": True,
               "search_unknown_model": f"{host_api.BadRequestError.__module__}.BadRequestError",
               "loaded_models": {"models": [{"model_name": "random/small", "model_device": "cpu"}]}, "loaded_after_eject": {"models": []},

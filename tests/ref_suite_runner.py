@@ -22,6 +22,31 @@ ALIASES = {   # reference module name -> product module that stands in for it
 }
 
 
+def _provide_test_constants() -> None:
+    """Several reference test files do `from tests.marqo_test import TestImageUrls` — an enum of image URLs that sits in a module which
+    also starts a Vespa client on import.  Read just that class out of the reference's file (ast, nothing executed but its constant
+    assignments) and offer it as `tests.marqo_test`."""
+    import ast
+    import enum
+    import types
+    from oracle import ref_shim
+    path = os.path.join(os.path.dirname(ref_shim.REFERENCE_SRC), "tests", "marqo_test.py")
+    members = {}
+    with open(path, encoding="utf-8") as f:
+        for node in ast.parse(f.read()).body:
+            if isinstance(node, ast.ClassDef) and node.name == "TestImageUrls":
+                for stmt in node.body:
+                    if isinstance(stmt, ast.Assign) and isinstance(stmt.value, ast.Constant) and isinstance(stmt.value.value, str):
+                        members[stmt.targets[0].id] = stmt.value.value
+    pkg = types.ModuleType("tests")
+    pkg.__path__ = []
+    mod = types.ModuleType("tests.marqo_test")
+    mod.TestImageUrls = enum.Enum("TestImageUrls", members, type=str)
+    mod.TestImageUrls.__test__ = False
+    pkg.marqo_test = mod
+    sys.modules["tests"], sys.modules["tests.marqo_test"] = pkg, mod
+
+
 def main(argv) -> int:
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     if root not in sys.path:
@@ -38,9 +63,10 @@ def main(argv) -> int:
             setattr(importlib.import_module(parent), leaf, ours)
         except ImportError:
             pass
+    _provide_test_constants()
     import pytest
-    files = [a for a in argv if not a.startswith("-")]
-    extra = [a for a in argv if a.startswith("-")]
+    files = [a for a in argv if a.endswith(".py")]
+    extra = [a for a in argv if not a.endswith(".py")]
     return int(pytest.main(["-q", "-p", "no:cacheprovider", "--noconftest", "--import-mode=importlib", "--rootdir", "/tmp", "-o", "addopts=", *extra, *files]))
 
 
