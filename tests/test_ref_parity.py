@@ -387,8 +387,10 @@ REFERENCE_TEST_FILES = {   # file under /root/reference/tests -> tests it holds
     "core/inference/test_tensor_fields_container.py": 30,   # TensorFieldsContainer (field collection, multimodal sub-fields)
     "core/inference/test_tensor_field_vectorisers.py": 6,   # SingleVectoriser / BatchCachingVectoriser incl. the error mapping of every
                                                             # s2_inference error class (7 tests; one downloads images: deselected below)
+    "core/inference/test_tensor_field_chunkers.py": 4,      # TextChunker (the product's split_text / prefixes underneath), AudioVideoChunker
+                                                            # (8 tests; the four ImageChunker ones download their images: deselected below)
 }
-NEEDS_NETWORK = ["test_batch_vectoriser_should_support_different_content_chunk_types"]
+NEEDS_NETWORK = ["test_batch_vectoriser_should_support_different_content_chunk_types", "test_image_chunker"]
 
 
 @pytest.mark.skipif(not ref_shim.available(), reason="/root/reference is not present on this machine")
