@@ -81,17 +81,81 @@ def generate_batches(seq, batch_size: int):
         yield seq[i:i + batch_size]
 
 
-def infer_modality(content) -> Modality:
-    """first-element sniffing used when a caller passes modality=None (s2_inference.py:138-139).  The reference probes URLs
-    and media bytes; here: image-like objects / image paths -> IMAGE, everything else -> TEXT."""
-    from marqo_amd.s2_inference.image_input import _is_image
-    thing = content[0] if isinstance(content, (list, tuple)) and content else content
-    if isinstance(thing, bytes):
-        return Modality.IMAGE
+def validate_url(url) -> bool:
+    """clip_utils.py:134-144 (`validators.url` there; the same scheme / host test as image_input._is_image here)"""
+    from marqo_amd.s2_inference.image_input import _looks_like_url
+    return isinstance(url, str) and (_looks_like_url(url) or _looks_like_url(encode_url(url)))
+
+
+def encode_url(url: str) -> str:
+    """clip_utils.py:196-214: percent-encoding as requests.utils.requote_uri"""
     try:
-        return Modality.IMAGE if _is_image(thing) else Modality.TEXT
-    except UnidentifiedImageError:
-        return Modality.TEXT
+        import requests
+        return requests.utils.requote_uri(url)
+    except ImportError:
+        from urllib.parse import quote
+        return quote(url, safe="!#$%&'()*+,/:;=?@[]~")
+
+
+_IMAGE_EXT, _VIDEO_EXT, _AUDIO_EXT = ("jpg", "jpeg", "png", "gif", "webp"), ("mp4", "avi", "mov"), ("mp3", "wav", "ogg")
+
+
+def _sniff_mime_family(head: bytes) -> Optional[str]:
+    """'image' / 'video' / 'audio' / None from the first bytes of a file — the container signatures behind the MIME families the reference
+    asks python-magic for (multimodal_model_load.py:171-177,190-198; libmagic is not a dependency of this engine)"""
+    if head.startswith((b"\x89PNG\r\n\x1a\n", b"\xff\xd8\xff", b"GIF87a", b"GIF89a", b"BM")) or head[:4] in (b"II*\x00", b"MM\x00*"):
+        return "image"
+    if head[:4] == b"RIFF" and len(head) >= 12:
+        return {b"WEBP": "image", b"AVI ": "video", b"WAVE": "audio"}.get(head[8:12])
+    if head[4:8] == b"ftyp":
+        brand = head[8:12]
+        return "image" if brand in (b"avif", b"heic", b"heix", b"mif1") else "audio" if brand in (b"M4A ", b"M4B ") else "video"
+    if head.startswith(b"\x1aE\xdf\xa3"):
+        return "video"                                     # Matroska / WebM
+    if head.startswith((b"ID3", b"OggS", b"fLaC")) or (len(head) > 1 and head[0] == 0xFF and head[1] & 0xE0 == 0xE0):
+        return "audio"
+    return None
+
+
+def infer_modality(content) -> Modality:
+    """multimodal_model_load.py:148-203, the function the reference's search and add_documents paths import FROM this module
+    (tensor_search.py:74, add_docs.py:24-25).  A string that is not a URL is text; a URL is classified by its extension (image / video /
+    audio lists of the reference), else by the first 10 KB of what it serves; bytes by their signature; anything else is text.  Video and
+    audio are only NAMED here (the callers answer them with UnsupportedModalityError for every model family this engine runs)."""
+    if isinstance(content, str):
+        if not validate_url(content):
+            return Modality.TEXT
+        encoded = encode_url(content)
+        ext = encoded.split(".")[-1].lower()
+        if ext in _IMAGE_EXT:
+            return Modality.IMAGE
+        if ext in _VIDEO_EXT:
+            return Modality.VIDEO
+        if ext in _AUDIO_EXT:
+            return Modality.AUDIO
+        try:
+            import requests
+        except ImportError:
+            return Modality.TEXT
+        try:
+            resp = requests.get(encoded, stream=True)
+            try:
+                head = b""
+                for chunk in resp.iter_content(chunk_size=8192):
+                    head += chunk
+                    if len(head) >= 10240:
+                        break
+            finally:
+                resp.close()
+        except requests.exceptions.RequestException as e:
+            raise MediaDownloadError(f"Error downloading media file {content}: {e}") from e
+        except IOError as e:
+            raise MediaDownloadError(f"IO error while processing {encoded}: {e}") from e
+        family = _sniff_mime_family(head)
+        return {"image": Modality.IMAGE, "video": Modality.VIDEO, "audio": Modality.AUDIO}.get(family, Modality.TEXT)
+    if isinstance(content, bytes):
+        return {"image": Modality.IMAGE, "video": Modality.VIDEO, "audio": Modality.AUDIO}.get(_sniff_mime_family(content), Modality.TEXT)
+    return Modality.TEXT
 
 
 # =============================================================================================================

@@ -90,6 +90,16 @@ def main() -> int:
     ref_s2.vectorise("random/small", "warm", device="cpu")
     report["ref_eject"] = TS.eject_model("random/small", "cpu")
 
+    # ---- infer_modality, which tensor_search.py:74 and add_docs.py:24-25 import FROM the s2_inference module (no network: strings
+    #      decided by URL-ness and extension, non-strings)
+    from marqo.s2_inference.multimodal_model_load import infer_modality as ref_infer
+    from PIL import Image as PILImage
+    cases = ["a plain query", "", "photo.jpg", "/tmp/local/photo.png", "https://example.com/a.jpg", "https://example.com/a.JPEG",
+             "http://example.com/path/b.png?x=1.webp", "https://example.com/v.mp4", "https://example.com/clip.MOV", "https://example.com/s.mp3",
+             "https://example.com/s.ogg", "ftp://example.com/a.gif", "https://exa mple.com/a.jpg", "https://example.com/ü.png",
+             "www.example.com/a.jpg", ["https://example.com/a.jpg"], PILImage.new("RGB", (2, 2)), 17, None]
+    report["infer_modality_equal"] = [str(c)[:40] for c in cases if ours.infer_modality(c).value != ref_infer(c).value]
+
     # ---- index settings validation (core/models/marqo_index.py:150-200 calls validate_model_properties / get_model_properties_from_registry)
     from marqo.core.models import marqo_index as MI
     MI.s2_inference = ours
@@ -108,7 +118,7 @@ def main() -> int:
               "search_unknown_model": f"{host_api.BadRequestError.__module__}.BadRequestError",
               "loaded_models": {"models": [{"model_name": "random/small", "model_device": "cpu"}]}, "loaded_after_eject": {"models": []},
               "eject": report["ref_eject"], "eject_again": f"{host_api.ModelNotInCacheError.__module__}.ModelNotInCacheError",
-              "index_model_properties": report["index_model_properties_ref"]}
+              "index_model_properties": report["index_model_properties_ref"], "infer_modality_equal": []}
     bad = {k: (report.get(k), v) for k, v in expect.items() if report.get(k) != v}
     report["mismatches"] = {k: list(v) for k, v in bad.items()}
     print(json.dumps(report))

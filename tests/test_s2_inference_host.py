@@ -517,3 +517,24 @@ def test_pil_pixels_zero_copy_view_matches_asarray():
         r = pil_to_pixels(im)   # (palette sources arrive in the NEAREST-resize container; flatten_pixels is the plain RGB view of any container)
         got = r.view[..., :3] if isinstance(r, P.Rgbx) else P.flatten_pixels(r)
         assert np.array_equal(got, pil_to_rgb_u8(im))
+
+
+def test_infer_modality_by_signature_and_extension():
+    """multimodal_model_load.py:148-203 without python-magic: strings by URL-ness + the reference's extension lists (compared with the
+    reference's own function in tests/ref_callers_check.py), bytes by container signature"""
+    import io
+    from PIL import Image as PILImage
+    from marqo_amd.s2_inference import s2_inference as s2
+    M = s2.Modality
+    assert s2.infer_modality("hello") == M.TEXT and s2.infer_modality("photo.jpg") == M.TEXT       # not a URL: text, as in the reference
+    assert s2.infer_modality("https://example.com/a.jpg") == M.IMAGE and s2.infer_modality("https://example.com/a.mp4") == M.VIDEO
+    assert s2.infer_modality("https://example.com/a.wav") == M.AUDIO and s2.infer_modality([1, 2]) == M.TEXT
+    for fmt in ("PNG", "JPEG", "GIF", "BMP", "WEBP", "TIFF"):
+        b = io.BytesIO()
+        PILImage.new("RGB", (4, 4), (10, 20, 30)).save(b, fmt)
+        assert s2.infer_modality(b.getvalue()) == M.IMAGE, fmt
+    assert s2.infer_modality(b"RIFF\x24\x00\x00\x00WAVEfmt ") == M.AUDIO and s2.infer_modality(b"RIFF\x24\x00\x00\x00AVI LIST") == M.VIDEO
+    assert s2.infer_modality(b"\x00\x00\x00\x18ftypmp42\x00\x00") == M.VIDEO and s2.infer_modality(b"ID3\x03\x00") == M.AUDIO
+    assert s2.infer_modality(b"OggS\x00\x02") == M.AUDIO and s2.infer_modality(b"just some text bytes") == M.TEXT and s2.infer_modality(b"") == M.TEXT
+    assert s2.validate_url("https://example.com/x") and not s2.validate_url("not a url") and not s2.validate_url(3)
+    assert s2.encode_url("https://example.com/ü b") == "https://example.com/%C3%BC%20b"
