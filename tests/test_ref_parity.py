@@ -389,8 +389,10 @@ REFERENCE_TEST_FILES = {   # file under /root/reference/tests -> tests it holds
                                                             # s2_inference error class (7 tests; one downloads images: deselected below)
     "core/inference/test_tensor_field_chunkers.py": 4,      # TextChunker (the product's split_text / prefixes underneath), AudioVideoChunker
                                                             # (8 tests; the four ImageChunker ones download their images: deselected below)
+    "core/inference/test_vectorise_inference_cache.py": 9,  # vectorise(enable_cache=True) over the cache, incl. re-importing the module with
+                                                            # other MARQO_INFERENCE_CACHE_* settings (10 tests; one loads a real CLIP on the CPU)
 }
-NEEDS_NETWORK = ["test_batch_vectoriser_should_support_different_content_chunk_types", "test_image_chunker"]
+NEEDS_NETWORK = ["test_batch_vectoriser_should_support_different_content_chunk_types", "test_image_chunker", "test_vectorise_cacheWorkForImagePath"]
 
 
 @pytest.mark.skipif(not ref_shim.available(), reason="/root/reference is not present on this machine")
