@@ -399,14 +399,22 @@ NEEDS_NETWORK = ["test_batch_vectoriser_should_support_different_content_chunk_t
 def test_reference_unit_tests_pass_on_the_product():
     """The reference's OWN test files, run where they lie, with the module names they import and patch (`marqo.s2_inference.s2_inference`,
     `...random_utils`, `...sbert_utils`, `...processing.text`, `marqo.inference.inference_cache.*`) bound to marqo_amd's modules
-    (tests/ref_suite_runner.py): every test they hold must pass on the product."""
+    (tests/ref_suite_runner.py): every test they hold must pass on the product.  (Three interpreters side by side: the two cache files
+    sleep through their expiry / concurrency cases for about a minute each.)"""
     import re
-    files = [os.path.join(os.path.dirname(ref_shim.REFERENCE_SRC), "tests", f) for f in REFERENCE_TEST_FILES]
+    slow = ("core/inference/test_inference_cache.py", "core/inference/test_vectorise_inference_cache.py")
+    groups = [[f] for f in slow] + [[f for f in REFERENCE_TEST_FILES if f not in slow]]
     env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
     env.pop("MARQO_AMD_HOST_ERRORS", None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "ref_suite_runner.py"), *files, "-k", " and ".join(f"not {n}" for n in NEEDS_NETWORK)],
-                       capture_output=True, text=True, env=env, timeout=900, cwd="/tmp")
-    tail = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-2000:]
-    m = re.search(r"(\d+) passed", tail)
-    assert r.returncode == 0 and m and "failed" not in tail and "error" not in tail, r.stdout[-3000:] + r.stderr[-1500:]
-    assert int(m.group(1)) == sum(REFERENCE_TEST_FILES.values()), tail
+    deselect = " and ".join(f"not {n}" for n in NEEDS_NETWORK)
+    procs = []
+    for g in groups:
+        files = [os.path.join(os.path.dirname(ref_shim.REFERENCE_SRC), "tests", f) for f in g]
+        procs.append((g, subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ref_suite_runner.py"), *files, "-k", deselect],
+                                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd="/tmp")))
+    for g, p in procs:
+        out, err = p.communicate(timeout=900)
+        tail = out.strip().splitlines()[-1] if out.strip() else err[-2000:]
+        m = re.search(r"(\d+) passed", tail)
+        assert p.returncode == 0 and m and "failed" not in tail and "error" not in tail, out[-3000:] + err[-1500:]
+        assert int(m.group(1)) == sum(REFERENCE_TEST_FILES[f] for f in g), (g, tail)
