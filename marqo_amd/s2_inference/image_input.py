@@ -80,14 +80,21 @@ def download_image_from_url(image_path: str, image_download_headers: dict, timeo
     return BytesIO(resp.content)
 
 
-def load_image_from_path(image_path: str, image_download_headers: dict, timeout_ms=3000) -> ImageType:
+def load_image_from_path(image_path: str, image_download_headers: dict, timeout_ms=3000, metrics_obj=None) -> ImageType:
+    """clip_utils.py:94-131 / image_download.py:130-163: a local file, else a URL; `metrics_obj` (the caller's RequestMetrics,
+    add_docs.py:140-143) times the download under the key the reference uses"""
     if os.path.isfile(image_path):
         return Image.open(image_path)
     if _looks_like_url(image_path):
+        if metrics_obj is not None:
+            metrics_obj.start(f"image_download.{image_path}")
         try:
             return Image.open(download_image_from_url(image_path, image_download_headers, timeout_ms))
         except ImageDownloadError as e:
             raise UnidentifiedImageError(str(e)) from e
+        finally:
+            if metrics_obj is not None:
+                metrics_obj.stop(f"image_download.{image_path}")
     raise UnidentifiedImageError(f"Input str of {image_path} is not a local file or a valid url.")
 
 

@@ -100,6 +100,44 @@ def main() -> int:
              "www.example.com/a.jpg", ["https://example.com/a.jpg"], PILImage.new("RGB", (2, 2)), 17, None]
     report["infer_modality_equal"] = [str(c)[:40] for c in cases if ours.infer_modality(c).value != ref_infer(c).value]
 
+    # ---- image loading helpers the add_documents path takes from `clip_utils` (add_docs.py:23,139-143): same answers on local inputs
+    import os as _os
+    import tempfile
+    from marqo.s2_inference import clip_utils as ref_clip
+    from marqo_amd.s2_inference import clip_utils as our_clip
+    d = tempfile.mkdtemp()
+    png = _os.path.join(d, "a.png")
+    PILImage.new("RGB", (5, 4), (1, 2, 3)).save(png)
+    txt = _os.path.join(d, "a.txt")
+    open(txt, "w").write("x")
+
+    class Metrics:
+        def __init__(self):
+            self.log = []
+
+        def start(self, k):
+            self.log.append(("start", k))
+
+        def stop(self, k):
+            self.log.append(("stop", k))
+    clip_diffs = []
+    for thing in (png, txt, "https://example.com/a.jpg", "https://example.com/page", "plain text", "photo.bmp", [png], [], PILImage.new("RGB", (2, 2)), 3):
+        a, b = outcome(lambda: str(ref_clip._is_image(thing))), outcome(lambda: str(our_clip._is_image(thing)))
+        if a.split(".")[-1] != b.split(".")[-1]:
+            clip_diffs.append(("_is_image", str(thing)[:30], a, b))
+    ma, mb = Metrics(), Metrics()
+    ia = ref_clip.load_image_from_path(png, {}, timeout_ms=1000, metrics_obj=ma)
+    ib = our_clip.load_image_from_path(png, {}, timeout_ms=1000, metrics_obj=mb)
+    if (ia.size, ia.mode, ma.log) != (ib.size, ib.mode, mb.log):
+        clip_diffs.append(("load_image_from_path", ia.size, ib.size))
+    for bad in ("not a path or url", _os.path.join(d, "missing.png")):
+        a, b = outcome(lambda: ref_clip.load_image_from_path(bad, {})), outcome(lambda: our_clip.load_image_from_path(bad, {}))
+        if a.split(".")[-1] != b.split(".")[-1]:
+            clip_diffs.append(("load_image_from_path", bad, a, b))
+    if list(ref_clip.get_allowed_image_types()) != list(our_clip.get_allowed_image_types()) or ref_clip.OPENAI_DATASET_MEAN != tuple(our_clip.OPENAI_DATASET_MEAN):
+        clip_diffs.append(("constants",))
+    report["clip_utils_diffs"] = clip_diffs
+
     # ---- index settings validation (core/models/marqo_index.py:150-200 calls validate_model_properties / get_model_properties_from_registry)
     from marqo.core.models import marqo_index as MI
     MI.s2_inference = ours
@@ -118,7 +156,7 @@ def main() -> int:
               "search_unknown_model": f"{host_api.BadRequestError.__module__}.BadRequestError",
               "loaded_models": {"models": [{"model_name": "random/small", "model_device": "cpu"}]}, "loaded_after_eject": {"models": []},
               "eject": report["ref_eject"], "eject_again": f"{host_api.ModelNotInCacheError.__module__}.ModelNotInCacheError",
-              "index_model_properties": report["index_model_properties_ref"], "infer_modality_equal": []}
+              "index_model_properties": report["index_model_properties_ref"], "infer_modality_equal": [], "clip_utils_diffs": []}
     bad = {k: (report.get(k), v) for k, v in expect.items() if report.get(k) != v}
     report["mismatches"] = {k: list(v) for k, v in bad.items()}
     print(json.dumps(report))
