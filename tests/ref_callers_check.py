@@ -138,6 +138,20 @@ def main() -> int:
         clip_diffs.append(("constants",))
     report["clip_utils_diffs"] = clip_diffs
 
+    # ---- every function the reference's s2_inference module defines exists here with the same parameter list
+    import inspect
+    api_missing, signature_diffs = [], []
+    for fname, fn in vars(ref_s2).items():
+        if inspect.isfunction(fn) and fn.__module__ == ref_s2.__name__:
+            mine = getattr(ours, fname, None)
+            if mine is None:
+                api_missing.append(fname)
+                continue
+            shape = lambda f: [(p.name, str(p.kind), p.default is not inspect.Parameter.empty) for p in inspect.signature(f).parameters.values()]
+            if shape(fn) != shape(mine):
+                signature_diffs.append(fname)
+    report["api_missing"], report["signature_diffs"] = sorted(api_missing), signature_diffs
+
     # ---- index settings validation (core/models/marqo_index.py:150-200 calls validate_model_properties / get_model_properties_from_registry)
     from marqo.core.models import marqo_index as MI
     MI.s2_inference = ours
@@ -156,7 +170,8 @@ def main() -> int:
               "search_unknown_model": f"{host_api.BadRequestError.__module__}.BadRequestError",
               "loaded_models": {"models": [{"model_name": "random/small", "model_device": "cpu"}]}, "loaded_after_eject": {"models": []},
               "eject": report["ref_eject"], "eject_again": f"{host_api.ModelNotInCacheError.__module__}.ModelNotInCacheError",
-              "index_model_properties": report["index_model_properties_ref"], "infer_modality_equal": [], "clip_utils_diffs": []}
+              "index_model_properties": report["index_model_properties_ref"], "infer_modality_equal": [], "clip_utils_diffs": [], "signature_diffs": [],
+              "api_missing": ["chunk_audio", "chunk_video", "load_multimodal_model"]}   # (the LanguageBind video / audio helpers: out of scope)
     bad = {k: (report.get(k), v) for k, v in expect.items() if report.get(k) != v}
     report["mismatches"] = {k: list(v) for k, v in bad.items()}
     print(json.dumps(report))
