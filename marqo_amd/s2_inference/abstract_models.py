@@ -53,6 +53,11 @@ class AbstractCLIPModel(AbstractEmbeddingModel):
     def encode_image(self, inputs, normalize: bool = True, image_download_headers: dict = None) -> np.ndarray:
         pass
 
+    @staticmethod
+    def normalize(outputs):
+        """abstract_clip_model.py:83-85: the row norms a caller divides by (the towers normalise on the device themselves)"""
+        return outputs.norm(dim=-1, keepdim=True)
+
     def encode(self, inputs, default: str = "text", normalize=True, **kwargs) -> np.ndarray:
         """image-vs-text dispatch (abstract_clip_model.py:56-75): `infer` + first-element sniffing, else `default`.
         `modality` and any other kwarg the callers pass are tolerated and ignored."""

@@ -492,6 +492,11 @@ class CLIP(OPEN_CLIP):
         self.model_type = model_type
         self.truncate = truncate
 
+    def encode_image(self, images, normalize=True, image_download_headers: Optional[Dict] = None, return_device: bool = False):
+        """the legacy loaders take `normalize` BEFORE the headers (clip_utils.py:397-399; OPEN_CLIP has them the other way round,
+        open_clip_model.py:249-251)"""
+        return super().encode_image(images, image_download_headers=image_download_headers, normalize=normalize, return_device=return_device)
+
 
 class FP16_CLIP(CLIP):
     """'fp16/ViT-*' names (clip_utils.py:495-518: cuda only).  On MI355X every CLIP tower already runs bf16 MFMA."""
@@ -561,6 +566,10 @@ class MULTILINGUAL_CLIP(OPEN_CLIP):
                 props[k] = model_properties[k]
         super().__init__(device=device, model_properties=props, model_auth=model_auth)
         self.truncate = truncate
+
+    def encode_image(self, images, normalize=True, image_download_headers: Optional[Dict] = None, return_device: bool = False):
+        """legacy parameter order (clip_utils.py:573-575)"""
+        return super().encode_image(images, image_download_headers=image_download_headers, normalize=normalize, return_device=return_device)
 
     def _make_text_tower(self, sd, precision: str):
         from marqo_amd.engine import towers
@@ -639,3 +648,7 @@ class CLIP_ONNX(OPEN_CLIP):
                 props[k] = model_properties[k]
         super().__init__(device=device, model_properties=props, model_auth=model_auth)
         self.model_name, self.truncate = model_name, truncate
+
+    def encode_image(self, images, normalize=True, image_download_headers: Optional[Dict] = None, return_device: bool = False):
+        """onnx_clip_utils.py:126: (images, normalize=True) — headers are accepted as an extra keyword"""
+        return super().encode_image(images, image_download_headers=image_download_headers, normalize=normalize, return_device=return_device)
