@@ -151,6 +151,42 @@ def main() -> int:
             if shape(fn) != shape(mine):
                 signature_diffs.append(fname)
     report["api_missing"], report["signature_diffs"] = sorted(api_missing), signature_diffs
+    # ... and the loader classes of the loader map: every public method the reference's class has, ours has with the same leading
+    # parameters (ours may append optional engine extensions such as return_device)
+    import importlib
+    pairs = [("marqo.core.inference.embedding_models.open_clip_model", "OPEN_CLIP", "marqo_amd.s2_inference.open_clip_model"),
+             ("marqo.core.inference.embedding_models.hugging_face_model", "HuggingFaceModel", "marqo_amd.s2_inference.hugging_face_model"),
+             ("marqo.s2_inference.clip_utils", "CLIP", "marqo_amd.s2_inference.open_clip_model"),
+             ("marqo.s2_inference.clip_utils", "FP16_CLIP", "marqo_amd.s2_inference.open_clip_model"),
+             ("marqo.s2_inference.clip_utils", "MULTILINGUAL_CLIP", "marqo_amd.s2_inference.open_clip_model"),
+             ("marqo.s2_inference.random_utils", "Random", "marqo_amd.s2_inference.random_utils"),
+             ("marqo.s2_inference.no_model_utils", "NO_MODEL", "marqo_amd.s2_inference.random_utils"),
+             ("marqo.s2_inference.sbert_utils", "SBERT", "marqo_amd.s2_inference.sbert_utils"),
+             ("marqo.s2_inference.sbert_utils", "TEST", "marqo_amd.s2_inference.sbert_utils"),
+             ("marqo.s2_inference.sbert_onnx_utils", "SBERT_ONNX", "marqo_amd.s2_inference.sbert_utils"),
+             ("marqo.inference.inference_cache.marqo_inference_cache", "MarqoInferenceCache", "marqo_amd.s2_inference.inference_cache")]
+    internal = {"custom_clip_load", "extract_huggingface_archive", "mean_pooling"}   # download / onnxruntime helpers: not part of the path
+    class_diffs = []
+    for ref_mod, cls, our_mod in pairs:
+        R, O = getattr(importlib.import_module(ref_mod), cls), getattr(importlib.import_module(our_mod), cls)
+        for mname, fn in inspect.getmembers(R, inspect.isfunction):
+            if (mname.startswith("_") and mname != "__init__") or mname in internal:
+                continue
+            mine = getattr(O, mname, None)
+            if mine is None:
+                if not (cls == "SBERT_ONNX" and mname == "normalize"):
+                    class_diffs.append(f"{cls}.{mname}: missing")
+                continue
+            names = lambda f: [p.name for p in inspect.signature(f).parameters.values() if p.kind not in (p.VAR_POSITIONAL, p.VAR_KEYWORD)]
+            rn, on = names(fn), names(mine)
+            if mname == "__init__":   # constructors: the reference's named parameters must be accepted by name (ours may take **kwargs)
+                accepts_kw = any(p.kind == p.VAR_KEYWORD for p in inspect.signature(mine).parameters.values())
+                lost = [n for n in rn if n not in on and not accepts_kw]
+                if lost:
+                    class_diffs.append(f"{cls}.__init__ does not accept {lost}")
+            elif on[:len(rn)] != rn:
+                class_diffs.append(f"{cls}.{mname}: reference {rn}, product {on}")
+    report["class_diffs"] = class_diffs
 
     # ---- index settings validation (core/models/marqo_index.py:150-200 calls validate_model_properties / get_model_properties_from_registry)
     from marqo.core.models import marqo_index as MI
@@ -170,7 +206,7 @@ def main() -> int:
               "search_unknown_model": f"{host_api.BadRequestError.__module__}.BadRequestError",
               "loaded_models": {"models": [{"model_name": "random/small", "model_device": "cpu"}]}, "loaded_after_eject": {"models": []},
               "eject": report["ref_eject"], "eject_again": f"{host_api.ModelNotInCacheError.__module__}.ModelNotInCacheError",
-              "index_model_properties": report["index_model_properties_ref"], "infer_modality_equal": [], "clip_utils_diffs": [], "signature_diffs": [],
+              "index_model_properties": report["index_model_properties_ref"], "infer_modality_equal": [], "clip_utils_diffs": [], "signature_diffs": [], "class_diffs": [],
               "api_missing": ["chunk_audio", "chunk_video", "load_multimodal_model"]}   # (the LanguageBind video / audio helpers: out of scope)
     bad = {k: (report.get(k), v) for k, v in expect.items() if report.get(k) != v}
     report["mismatches"] = {k: list(v) for k, v in bad.items()}
