@@ -134,7 +134,7 @@ def main() -> int:
         a, b = outcome(lambda: ref_clip.load_image_from_path(bad, {})), outcome(lambda: our_clip.load_image_from_path(bad, {}))
         if a.split(".")[-1] != b.split(".")[-1]:
             clip_diffs.append(("load_image_from_path", bad, a, b))
-    if list(ref_clip.get_allowed_image_types()) != list(our_clip.get_allowed_image_types()) or ref_clip.OPENAI_DATASET_MEAN != tuple(our_clip.OPENAI_DATASET_MEAN):
+    if sorted(ref_clip.get_allowed_image_types()) != sorted(our_clip.get_allowed_image_types()) or ref_clip.OPENAI_DATASET_MEAN != tuple(our_clip.OPENAI_DATASET_MEAN):
         clip_diffs.append(("constants",))
     report["clip_utils_diffs"] = clip_diffs
 
