@@ -153,3 +153,45 @@ def test_counted_vmcnt_and_static_priority_knobs_are_bit_identical():
     finally:
         _tune(lib, gemm_vmcnt=0, gemm_prio=0)
         _tune(lib, **DEFAULTS)
+
+
+@pytest.mark.parametrize("pps", [2, 4])
+def test_two_accumulator_set_kernel_is_bit_identical(pps):
+    """gemm_pp.hip: one 4-wave workgroup per CU, 128x256 tiles, 3-stage LDS ring with the barrier in the middle of the k-step, second
+    accumulator set (the previous tile's epilogue rides under the next tile's MFMAs, stores / residual loads through buffer descriptors).
+    Same k-order of MFMAs and the same epilogue arithmetic as the shipped kernel -> identical bits: every epilogue (fp32 and bf16
+    residual streams included), one-tile and many-tile launches, ragged M / N edges, the shortest legal K; repeated as a race screen."""
+    lib = L.load()
+    g = torch.Generator(device="cuda").manual_seed(300 + pps)
+    F = L
+    try:
+        shapes = [(12800, 2304, 768), (12800, 3072, 768), (12800, 768, 768), (12800, 768, 3072), (16448, 1024, 1024), (12801, 2308, 768),
+                  (9000, 1540, 320), (64, 256, 320), (129, 260, 576), (100000, 512, 512), (40000, 4096, 1024)]
+        for (M, N, K) in shapes:
+            A = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+            W = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).to(torch.bfloat16)
+            bias = torch.randn(N, device="cuda", generator=g)
+            res = torch.randn(M, N, device="cuda", generator=g)
+            res16 = res.to(torch.bfloat16)
+            big = M * N > 3e8
+            for flags in (0, F.MQ_EPI_OUT_F32, F.MQ_EPI_BIAS | F.MQ_EPI_OUT_F32, F.MQ_EPI_BIAS, F.MQ_EPI_BIAS | F.MQ_EPI_GELU,
+                          F.MQ_EPI_BIAS | F.MQ_EPI_QUICKGELU, F.MQ_EPI_BIAS | F.MQ_EPI_RESIDUAL | F.MQ_EPI_OUT_F32,
+                          F.MQ_EPI_BIAS | F.MQ_EPI_RESIDUAL):
+                if big and flags not in (F.MQ_EPI_BIAS, F.MQ_EPI_BIAS | F.MQ_EPI_RESIDUAL | F.MQ_EPI_OUT_F32):
+                    continue
+
+                def run():
+                    if flags == (F.MQ_EPI_BIAS | F.MQ_EPI_RESIDUAL):     # bf16 residual stream: in place on a bf16 tensor
+                        out = res16.clone()
+                        L.check(lib.mq_gemm_bf16(A.data_ptr(), K, W.data_ptr(), K, bias.data_ptr(), out.data_ptr(), out.data_ptr(), N, M, N, K,
+                                                 flags, torch.cuda.current_stream().cuda_stream))
+                        return out
+                    return _gemm(lib, A, W, bias, res, flags)
+                _tune(lib, gemm_pp=0)
+                base = run()
+                _tune(lib, gemm_pp=2, gemm_pp_pps=pps)
+                for _ in range(2 if big else 5):
+                    out = run()
+                    assert torch.equal(out, base), ((M, N, K), flags, pps, (out.float() - base.float()).abs().max().item())
+    finally:
+        _tune(lib, gemm_pp=0, gemm_pp_pps=0, **DEFAULTS)
