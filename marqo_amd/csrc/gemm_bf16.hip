@@ -570,7 +570,7 @@ extern "C" int mq_tune(const char* key, int value) {
     else if (k == "gemm_vmcnt") g_tune.vmcnt = value;
     else if (k == "gemm_prio") g_tune.prio = value;
     else if (k == "gemm_k32") g_tune.k32 = value;
-    else if (k == "gemm_pp" || k == "gemm_pp_pps") mq_gemm_pp_tune(key, value);
+    else if (k == "gemm_pp" || k == "gemm_pp_pps" || k == "gemm_pp_skew") mq_gemm_pp_tune(key, value);
     else if (k == "row_select") mq_tower_row_select = value;
     else if (k == "ln_fold") mq_tower_ln_fold = value;
     else if (k == "ln_rows") mq_ln_rows_per_wave = value;

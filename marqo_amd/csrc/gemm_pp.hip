@@ -64,7 +64,7 @@ template <int FLAGS, int MT, int PPS>
 __global__ __launch_bounds__(256, 1) void gemm_pp_kernel(
     const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ Wt, int64_t ldw,
     const float* __restrict__ bias, const void* residual, void* out, int64_t ldc,
-    int M, int N, int K, int tiles_n, int num_tiles, int cgroup, int band_rows) {
+    int M, int N, int K, int tiles_n, int num_tiles, int cgroup, int band_rows, int skew) {
     constexpr int BM = 32 * MT;
     constexpr int A_BYTES = BM * BK * 2;
     constexpr int STAGE = A_BYTES + W_BYTES;
@@ -257,7 +257,23 @@ __global__ __launch_bounds__(256, 1) void gemm_pp_kernel(
         }
     };
 
-    auto wg_barrier = [] { __builtin_amdgcn_s_barrier(); };
+    // The four waves leave a barrier together and run identical code: every LDS-DMA piece and fragment read of one wave then collides with
+    // the same instruction of the other three at the CU's single address path (16+ cycles per 1-KiB piece), and with one wave per SIMD a
+    // wave blocked in VMEM issue is a matrix pipe without work.  `skew` x ~16 cycles x wave id of delay after each barrier de-phases them.
+    auto wg_barrier = [&] {
+        __builtin_amdgcn_s_barrier();
+        // (one asm block with its own loop: a C++ loop here splits the k-step into more basic blocks and the register allocation with it)
+        int cnt = wave * skew;
+        asm volatile("s_cmp_eq_u32 %0, 0\n\t"
+                     "s_cbranch_scc1 .Lskew_end%=\n"
+                     ".Lskew_loop%=:\n\t"
+                     "s_nop 7\n\t"
+                     "s_sub_u32 %0, %0, 1\n\t"
+                     "s_cmp_lg_u32 %0, 0\n\t"
+                     "s_cbranch_scc1 .Lskew_loop%=\n"
+                     ".Lskew_end%=:"
+                     : "+s"(cnt) : : "scc");
+    };
 
     // ---- prologue: stages 0 and 1 of the first tile, then the kk = 0 fragments of stage 0 --------------------------------------------
 #pragma unroll
@@ -416,9 +432,9 @@ __global__ __launch_bounds__(256, 1) void gemm_pp_kernel(
 }
 
 struct PpTune {
-    int on, mt, pps;
+    int on, mt, pps, skew;
     static int env(const char* k, int d) { const char* v = getenv(k); return v ? atoi(v) : d; }
-    PpTune() : on(env("MQ_GEMM_PP", 0)), mt(env("MQ_GEMM_PP_MT", 0)), pps(env("MQ_GEMM_PP_PPS", 0)) {}
+    PpTune() : on(env("MQ_GEMM_PP", 0)), mt(env("MQ_GEMM_PP_MT", 0)), pps(env("MQ_GEMM_PP_PPS", 0)), skew(env("MQ_GEMM_PP_SKEW", 0)) {}
 };
 PpTune g_pp;
 
@@ -449,7 +465,7 @@ int launch_pp(const void* A, int64_t lda, const void* W, int64_t ldw, const floa
     }
     const int grid = num_tiles < cus ? num_tiles : cus;
     hipLaunchKernelGGL((gemm_pp_kernel<FLAGS, MT, PPS>), dim3(grid), dim3(256), LDS, s, (const bf16_t*)A, lda, (const bf16_t*)W, ldw, bias,
-                       residual, out, ldc, M, N, K, tiles_n, num_tiles, cgroup, band_rows);
+                       residual, out, ldc, M, N, K, tiles_n, num_tiles, cgroup, band_rows, g_pp.skew);
     MQ_CHECK_LAUNCH("mq_gemm_bf16(pp)");
     return MQ_OK;
 }
@@ -463,6 +479,7 @@ void mq_gemm_pp_tune(const char* key, int value) {
     if (k == "gemm_pp") g_pp.on = value;
     else if (k == "gemm_pp_mt") g_pp.mt = value;
     else if (k == "gemm_pp_pps") g_pp.pps = value;
+    else if (k == "gemm_pp_skew") g_pp.skew = value;
 }
 int mq_gemm_pp_mode() { return g_pp.on; }
 

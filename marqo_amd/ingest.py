@@ -19,7 +19,7 @@ from typing import Any, Callable, Dict, Hashable, List, Optional, Tuple
 
 import numpy as np
 
-from marqo_amd.parallel import balanced_shards, contiguous_shards, gather_embeddings
+from marqo_amd.parallel import agree_on_shard, balanced_shards, contiguous_shards, gather_embeddings, gather_embeddings_to_root
 from marqo_amd.s2_inference.enums import Modality
 
 
@@ -27,6 +27,10 @@ def estimate_tokens(text: Any) -> float:
     """cheap per-item cost for balancing text shards: ~ BPE / WordPiece tokens of a string (4 characters per token + the two
     specials); anything that is not a string costs 1"""
     return 2.0 + len(text) / 4.0 if isinstance(text, str) else 1.0
+
+
+class PeerShardError(RuntimeError):
+    """raised on the ranks whose own shard encoded fine when ANOTHER rank's shard of the same flush failed (see BulkVectoriser._encode)"""
 
 
 class BulkVectoriser:
@@ -43,6 +47,7 @@ class BulkVectoriser:
         self._pending: Dict[Modality, List[Tuple[Hashable, Any]]] = {Modality.TEXT: [], Modality.IMAGE: []}
         self._done: Dict[Hashable, np.ndarray] = {}
         self.force_collective = False   # tests: take the sharded path (and run the collective) even in a 1-rank process group
+        self.local_only = False         # RequestShardedIngest: requests are owned by ONE rank, nothing is sharded inside a request
 
     def add(self, key: Hashable, content: Any, modality: Modality = Modality.TEXT) -> None:
         if modality not in self._pending:
@@ -78,7 +83,7 @@ class BulkVectoriser:
         copies it to the host after it has staged the next modality, so that modality's host work overlaps this one's GPU work."""
         import torch
         import torch.distributed as dist
-        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() and not self.local_only else 1
         if world == 1 and not (self.force_collective and dist.is_available() and dist.is_initialized()):
             fn = self._vectorise
             if fn is None:
@@ -98,13 +103,30 @@ class BulkVectoriser:
         plan = (balanced_shards([estimate_tokens(c) for c in contents], world) if modality == Modality.TEXT
                 else contiguous_shards(len(contents), world))
         mine = plan.items[dist.get_rank()]
-        local = self._call(fn, [contents[i] for i in mine], modality) if mine else None
-        if local is not None and not isinstance(local, torch.Tensor):
-            local = torch.from_numpy(np.ascontiguousarray(local, dtype=np.float32))
-        D = self._dimensions() or (local.shape[1] if local is not None else None)
-        if D is None:
-            raise RuntimeError("BulkVectoriser: this rank received no items and the model properties carry no 'dimensions'")
         where = self.device if on_gpu else "cpu"
+        # The local encode may raise (one undecodable image in this rank's shard).  Leaving now would strand the peers in the all_gather
+        # until the RCCL timeout, so failure is made collective: ONE 2-int all_reduce carries (everyone ok?, embedding width) in front of
+        # the data collective; when any rank failed, EVERY rank raises after it (the failing rank its own exception, the others a
+        # PeerShardError) and every rank re-queues — the re-queue contract of _run_pending holds on all ranks alike.
+        local, failure = None, None
+        try:
+            local = self._call(fn, [contents[i] for i in mine], modality) if mine else None
+            if local is not None and not isinstance(local, torch.Tensor):
+                local = torch.from_numpy(np.ascontiguousarray(local, dtype=np.float32))
+            if local is not None and local.shape[0] != len(mine):
+                raise RuntimeError(f"vectorise returned {local.shape[0]} embeddings for {len(mine)} items")
+        except BaseException as e:  # noqa: BLE001 - re-raised below, after the agreement
+            failure, local = e, None
+        # the width comes from the rows actually produced (a loaded model knows its width; the registry's 'dimensions' may not match a
+        # custom checkpoint), agreed over the ranks so that a rank without items sizes its empty shard like everyone else
+        all_ok, D = agree_on_shard(failure is None, local.shape[1] if local is not None else 0, where)
+        if not all_ok:
+            raise failure if failure is not None else PeerShardError(
+                f"BulkVectoriser: another rank failed to encode its shard of this {modality} flush; nothing was gathered")
+        if D <= 0:
+            D = self._dimensions() or 0
+        if D <= 0:
+            raise RuntimeError("BulkVectoriser: no rank received items and the model properties carry no 'dimensions'")
         local = torch.zeros(0, D, dtype=torch.float32, device=where) if local is None else local.to(device=where, dtype=torch.float32)
         full = plan.restore(gather_embeddings(local, counts=plan.counts, force_collective=self.force_collective))
         return full.cpu().numpy()
@@ -161,4 +183,89 @@ class BulkVectoriser:
         self._run_pending()
         with self._lock:
             out, self._done = self._done, {}
+        return out
+
+
+class RequestShardedIngest:
+    """BASELINE configs[3] ("add_documents bulk ingest: mixed text + image docs sharded across the GPUs, RCCL gather"), sharded AT THE
+    SOURCE: ranks own disjoint REQUESTS.  Request i (a batch of <= 128 documents, what one add_documents call carries,
+    add_documents_handler.py:344-373) belongs to rank i % world; only its owner ever touches its documents (decodes its images, tokenises
+    its texts, stages its bytes), runs them through a local BulkVectoriser — the single-GPU path with its text / image pipelining, no
+    collective inside a request — and keeps the [n, D] rows.  `collect()` is the one data-path collective: a `gather` of the ranks' rows
+    onto the root (the process that feeds the document store), NOT an all_gather: nothing is replicated, non-root ranks copy nothing to
+    their host.  The reference has no counterpart (one device string per call, tensor_search/utils.py:90-123).
+
+    usage, same code on every rank:
+        ing = RequestShardedIngest(model, device)
+        for i, request in enumerate(stream):
+            if ing.owns(i): ing.submit(i, request)          # request: [(key, content, Modality), ...]
+        rows = ing.collect()                                # root: {request index: {key: float32 [D]}}, other ranks: {}
+    """
+
+    def __init__(self, model_name: str, device: str, model_properties: Optional[dict] = None, normalize_embeddings: bool = True,
+                 vectorise_fn: Optional[Callable] = None, root: int = 0):
+        import torch.distributed as dist
+        self._dist = dist if dist.is_available() and dist.is_initialized() else None
+        self.world = self._dist.get_world_size() if self._dist else 1
+        self.rank = self._dist.get_rank() if self._dist else 0
+        self.root, self.device = root, device
+        self._bulk = BulkVectoriser(model_name, device, model_properties, normalize_embeddings, vectorise_fn=vectorise_fn)
+        self._bulk.local_only = True
+        self._rows: List[np.ndarray] = []                     # this rank's embeddings, in submission order
+        self._index: List[Tuple[int, Hashable]] = []          # (request index, key) per row
+        self.touched: List[int] = []                          # request indices this rank was handed (tests: ownership)
+
+    def owner(self, request_index: int) -> int:
+        return request_index % self.world
+
+    def owns(self, request_index: int) -> bool:
+        return self.owner(request_index) == self.rank
+
+    def submit(self, request_index: int, items) -> None:
+        """encode one owned request now (its rows stay on this rank until collect())"""
+        if not self.owns(request_index):
+            raise ValueError(f"rank {self.rank} was handed request {request_index}, which belongs to rank {self.owner(request_index)}")
+        self.touched.append(request_index)
+        keys = []
+        for key, content, modality in items:
+            self._bulk.add(key, content, modality)
+            keys.append(key)
+        out = self._bulk.flush()
+        for key in keys:
+            self._rows.append(out[key])
+            self._index.append((request_index, key))
+
+    def collect(self) -> Dict[int, Dict[Hashable, np.ndarray]]:
+        """gather every rank's rows on the root -> {request index: {key: row}} there, {} elsewhere; resets the store"""
+        import torch
+        rows, index = self._rows, self._index
+        self._rows, self._index = [], []
+        local = np.stack(rows).astype(np.float32, copy=False) if rows else None
+        if self.world == 1:
+            out: Dict[int, Dict[Hashable, np.ndarray]] = {}
+            for (ri, key), row in zip(index, rows):
+                out.setdefault(ri, {})[key] = row
+            return out
+        dist = self._dist
+        on_gpu = dist.get_backend() == "nccl" and str(self.device).startswith("cuda")
+        where = self.device if on_gpu else "cpu"
+        # who holds what: (row count, width) per rank + the (request, key) labels, as python objects (tiny next to the rows)
+        meta = [None] * self.world
+        dist.all_gather_object(meta, (len(index), int(local.shape[1]) if local is not None else 0, index if self.rank != self.root else None))
+        D = max(m[1] for m in meta)
+        counts = [m[0] for m in meta]
+        if sum(counts) == 0:
+            return {}
+        t = torch.from_numpy(local).to(where) if local is not None else torch.zeros(0, D, dtype=torch.float32, device=where)
+        full = gather_embeddings_to_root(t, counts, root=self.root)
+        if self.rank != self.root:
+            return {}
+        full = full.cpu().numpy()
+        out = {}
+        pos = 0
+        for r in range(self.world):
+            labels = index if r == self.root else meta[r][2]
+            for (ri, key) in labels:
+                out.setdefault(ri, {})[key] = full[pos]
+                pos += 1
         return out

@@ -110,3 +110,38 @@ def gather_embeddings(local: torch.Tensor, counts: Optional[Sequence[int]] = Non
     buf = torch.empty(world * mx, D, dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(buf, padded.contiguous())
     return torch.cat([buf[r * mx: r * mx + counts[r]] for r in range(world)], dim=0)
+
+
+def gather_embeddings_to_root(local: torch.Tensor, counts: Sequence[int], root: int = 0) -> Optional[torch.Tensor]:
+    """`gather` (not all_gather) of ragged row shards [n_r, D] onto ONE rank: the root receives [sum n_r, D] in rank order, every other
+    rank returns None and keeps nothing — the add_documents stream (BASELINE configs[3]) needs the embeddings in one place (the rank that
+    feeds the document store), and an all_gather would move world x the bytes over xGMI and make every rank copy the full matrix to its
+    host.  counts: rows per rank, known to every rank from the request plan (no size exchange).  Shards are padded to the largest count so
+    that it is ONE collective."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return local
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if len(counts) != world:
+        raise ValueError("counts must have one entry per rank")
+    D, mx = local.shape[1], max(counts)
+    padded = local
+    if local.shape[0] != mx:
+        padded = torch.zeros(mx, D, dtype=local.dtype, device=local.device)
+        padded[: local.shape[0]] = local
+    bufs = [torch.empty(mx, D, dtype=local.dtype, device=local.device) for _ in range(world)] if rank == root else None
+    dist.gather(padded.contiguous(), bufs, dst=root)
+    if rank != root:
+        return None
+    return torch.cat([bufs[r][: counts[r]] for r in range(world)], dim=0)
+
+
+def agree_on_shard(ok: bool, width: int, device) -> Tuple[bool, int]:
+    """One tiny all_reduce in front of a data collective: (every rank's local encode succeeded?, the embedding width as the ranks that
+    encoded something saw it).  A rank whose `vectorise` raised must not simply leave: its peers would sit in the all_gather until the
+    RCCL timeout.  MIN over [ok, -width]: ok = 0 as soon as one rank failed, width = the largest reported (0 = nobody had items)."""
+    import torch.distributed as dist
+    t = torch.tensor([1 if ok else 0, -int(width)], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    v = t.tolist()
+    return bool(v[0]), int(-v[1])

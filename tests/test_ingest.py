@@ -137,3 +137,109 @@ def test_sharded_flush_world_size_2():
         p.join(120)
         assert p.exitcode == 0
     assert sorted(q.get(timeout=5) for _ in range(2)) == [(0, True), (1, True)]
+
+
+def _worker_requests(rank, world, port, q):
+    """RequestShardedIngest: ranks own disjoint REQUESTS (nothing inside a request is sharded), one gather onto rank 0"""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from marqo_amd.ingest import RequestShardedIngest
+        calls = []
+
+        def fake(model, content, **kw):
+            calls.append((kw.get("modality"), list(content)))
+            return np.asarray([[float(str(c).split()[-1])] * 4 for c in content], dtype=np.float32)
+
+        ing = RequestShardedIngest("m", "cpu", vectorise_fn=fake)
+        n_req = 7   # ragged: rank 0 owns 4 requests, rank 1 owns 3; requests of different sizes
+        for i in range(n_req):
+            if not ing.owns(i):
+                continue
+            items = [((i, "t", j), f"text {1000 * i + j}", Modality.TEXT) for j in range(3 + i % 2)]
+            items += [((i, "i", j), f"img {1000 * i + 500 + j}", Modality.IMAGE) for j in range(2)]
+            ing.submit(i, items)
+        ok = ing.touched == [i for i in range(n_req) if i % world == rank]            # no rank touched a request it does not own
+        ok = ok and all(all(int(c.split()[-1]) // 1000 % world == rank for c in content) for _, content in calls)
+        ok = ok and len(calls) == 2 * len(ing.touched)                                   # one call per modality per OWNED request
+        try:
+            ing.submit(rank + 1, [((0, "t", 0), "text 1", Modality.TEXT)])                # a foreign request is refused
+            ok = False
+        except ValueError:
+            pass
+        rows = ing.collect()
+        if rank == 0:
+            ok = ok and sorted(rows) == list(range(n_req))
+            for i in range(n_req):
+                ok = ok and len(rows[i]) == 3 + i % 2 + 2
+                ok = ok and all(np.allclose(rows[i][(i, "t", j)], [1000 * i + j] * 4) for j in range(3 + i % 2))
+                ok = ok and all(np.allclose(rows[i][(i, "i", j)], [1000 * i + 500 + j] * 4) for j in range(2))
+        else:
+            ok = ok and rows == {}                                                        # gather, not all_gather: nothing lands here
+        ok = ok and ing.collect() == {}                                                   # the store is reset (an empty collect is still collective-safe)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_request_sharded_ingest_world_size_2():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_requests, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert sorted(q.get(timeout=5) for _ in range(2)) == [(0, True), (1, True)]
+
+
+def _worker_failure(rank, world, port, q):
+    """one rank's shard fails to encode: EVERY rank must raise (nobody is left waiting in the all_gather), every rank re-queues, and the
+    flush succeeds on all ranks once the offending item is discarded"""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from marqo_amd.ingest import PeerShardError
+
+        def fake(model, content, **kw):
+            if any("bad" in c for c in content):
+                raise ValueError("undecodable item")
+            return np.asarray([[float(c.split()[-1])] * 5 for c in content], dtype=np.float32)   # width 5: NOT what a registry would say
+
+        bv = BulkVectoriser("m", "cpu", vectorise_fn=fake)
+        for i in range(6):
+            bv.add(i, f"img {i}" if i != 4 else "bad 4", Modality.IMAGE)   # contiguous halves: item 4 is in rank 1's shard
+        err = None
+        try:
+            bv.flush()
+        except BaseException as e:  # noqa: BLE001
+            err = e
+        ok = isinstance(err, ValueError) if rank == 1 else isinstance(err, PeerShardError)
+        ok = ok and bv.pending() == 6                       # re-queued on every rank
+        ok = ok and bv.discard(4) == 1
+        out = bv.flush()
+        ok = ok and sorted(out) == [0, 1, 2, 3, 5] and all(np.allclose(out[i], [i] * 5) for i in out)
+        # a rank with an EMPTY shard takes the width from its peers (agreed in the same all_reduce), not from a registry entry
+        bv.add("only", "img 7", Modality.IMAGE)
+        out = bv.flush()
+        ok = ok and np.allclose(out["only"], [7] * 5)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_failed_shard_raises_on_every_rank_world_size_2():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_failure, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert sorted(q.get(timeout=5) for _ in range(2)) == [(0, True), (1, True)]
