@@ -77,6 +77,9 @@ __global__ __launch_bounds__(256, 1) void gemm_pp_kernel(
     constexpr bool OUT_F32 = (FLAGS & MQ_EPI_OUT_F32) != 0;
     constexpr bool RES_BF16 = HAS_RES && !OUT_F32;
     constexpr int ES = OUT_F32 ? 4 : 2;   // bytes per output element
+#ifdef MQ_PP_DIAG
+    bool diag_live = false;   // ablation builds (tools/probes/build_pp_diag.sh): set once the prologue is done
+#endif
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* const bias_lds = (float*)(smem + 3 * STAGE);   // two slots of BN floats
 
@@ -134,6 +137,9 @@ __global__ __launch_bounds__(256, 1) void gemm_pp_kernel(
     };
     // piece q of this wave's NP (q < MT: A, else W) into ring buffer `buf`
     auto dma_piece = [&](int q, char* stage_base) {
+#if defined(MQ_PP_DIAG) && (MQ_PP_DIAG & 1)   // ablation (timing only, wrong results): no global -> LDS traffic in the k-steps
+        if (diag_live) return;
+#endif
         if (q < MT) glds16(a_base + a_voff[q], stage_base + (q * 4 + wave) * 1024);
         else glds16(w_base + w_voff[q - MT], stage_base + A_BYTES + ((q - MT) * 4 + wave) * 1024);
     };
@@ -261,6 +267,9 @@ __global__ __launch_bounds__(256, 1) void gemm_pp_kernel(
     // the same instruction of the other three at the CU's single address path (16+ cycles per 1-KiB piece), and with one wave per SIMD a
     // wave blocked in VMEM issue is a matrix pipe without work.  `skew` x ~16 cycles x wave id of delay after each barrier de-phases them.
     auto wg_barrier = [&] {
+#if defined(MQ_PP_DIAG) && (MQ_PP_DIAG & 4)   // ablation: no workgroup barrier in the k-steps
+        if (diag_live) return;
+#endif
         __builtin_amdgcn_s_barrier();
         // (one asm block with its own loop: a C++ loop here splits the k-step into more basic blocks and the register allocation with it)
         int cnt = wave * skew;
@@ -289,6 +298,9 @@ __global__ __launch_bounds__(256, 1) void gemm_pp_kernel(
 #pragma unroll
     for (int t = 0; t < MT; ++t) af0[t] = *(const bf16x8*)(smem + fa0 + t * 2048);
 
+#ifdef MQ_PP_DIAG
+    diag_live = true;
+#endif
     int sb = 0;                      // ring buffer of the current k-step
     int staged = 2;                  // k-steps of the CURRENT source tile already staged (its stages 0 .. staged-1)
     bool more = false;
@@ -313,10 +325,17 @@ __global__ __launch_bounds__(256, 1) void gemm_pp_kernel(
         if constexpr (E >= 0 && HAS_RES) {   // ahead of the LDS-DMA pieces: complete at the middle wait
             static_for<PPS>([&](auto i) { res_load(ic<E * PPS + decltype(i)::value>{}, rpre[decltype(i)::value]); });
         }
+#if defined(MQ_PP_DIAG) && (MQ_PP_DIAG & 2)   // ablation: no fragment reads in the k-steps (the prologue's fragments are reused)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { wf1[t] = wf0[t]; asm volatile("" : "+v"(wf1[t])); }
+#pragma unroll
+        for (int t = 0; t < MT; ++t) { af1[t] = af0[t]; asm volatile("" : "+v"(af1[t])); }
+#else
 #pragma unroll
         for (int t = 0; t < NT; ++t) wf1[t] = *(const bf16x8*)(cur + fw1 + t * 2048);
 #pragma unroll
         for (int t = 0; t < MT; ++t) af1[t] = *(const bf16x8*)(cur + fa1 + t * 2048);
+#endif
 #pragma unroll
         for (int q = 0; q < NP; ++q) dma_piece(q, dst);
 #pragma unroll
@@ -347,15 +366,26 @@ __global__ __launch_bounds__(256, 1) void gemm_pp_kernel(
         __builtin_amdgcn_sched_barrier(0);
         // ---- middle: stage s+1 landed (all but the NP newest VMEM operations — those of stage s+2 — are complete), kk = 1 fragments here,
         // every wave done with buffer s-1... and with the bias slot
+#if defined(MQ_PP_DIAG) && (MQ_PP_DIAG & 8)   // ablation: no counted wait for the staged data (fragment reads still waited for)
+        __builtin_amdgcn_s_waitcnt(0xC07F);   // vmcnt(63) lgkmcnt(0)
+#else
         wait_vm_lgkm0<NP>();
+#endif
         if (HAS_BIAS && park_bias) { if (tid < BN) bias_lds[c_slot * BN + tid] = bias_val; }
         wg_barrier();
         __builtin_amdgcn_sched_barrier(0);
         // ---- second half: kk = 1 MFMAs | read stage s+1's kk = 0 fragments | epilogue units of the previous tile
+#if defined(MQ_PP_DIAG) && (MQ_PP_DIAG & 2)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) asm volatile("" : "+v"(wf0[t]));
+#pragma unroll
+        for (int t = 0; t < MT; ++t) asm volatile("" : "+v"(af0[t]));
+#else
 #pragma unroll
         for (int t = 0; t < NT; ++t) wf0[t] = *(const bf16x8*)(nxt + fw0 + t * 2048);
 #pragma unroll
         for (int t = 0; t < MT; ++t) af0[t] = *(const bf16x8*)(nxt + fa0 + t * 2048);
+#endif
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -363,7 +393,11 @@ __global__ __launch_bounds__(256, 1) void gemm_pp_kernel(
                 if (LAST) Y[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[nt], af1[mt], X[mt][nt], 0, 0, 0);
                 else X[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[nt], af1[mt], X[mt][nt], 0, 0, 0);
             }
+#if defined(MQ_PP_DIAG) && (MQ_PP_DIAG & 16)   // ablation: no interleaved epilogue (the tail's units keep the accumulators live)
+        if constexpr (false) {
+#else
         if constexpr (E >= 0) {
+#endif
             static_for<PPS>([&](auto i) { epi_unit(ic<E * PPS + decltype(i)::value>{}, rpre[decltype(i)::value], bpre[decltype(i)::value]); });
         }
         {
@@ -490,6 +524,8 @@ int mq_gemm_pp_plan(int M, int N, int K, int flags) {
     if (!g_pp.on) return 0;
     const int nk = K / BK;
     if (nk < 5 || N < 256 || M < 64) return 0;             // MT*4/PPS epilogue-carrying k-steps + the last one must exist: nk >= 4 + 1
+    // QUICKGELU: the interleaved epilogue returns wrong swapped halves next to the division sequences (profiles/r03b_pp_diag.txt) — not routed here
+    if (flags & MQ_EPI_QUICKGELU) return 0;
     // the fp32-residual epilogue at 4 units per k-step (needed below 9 k-steps) is the one instantiation that spills: not built
     if (flags == (MQ_EPI_BIAS | MQ_EPI_RESIDUAL | MQ_EPI_OUT_F32) && (nk < 9 || g_pp.pps == 4)) return 0;
     if (g_pp.on == 1) {
