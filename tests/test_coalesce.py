@@ -1,0 +1,156 @@
+"""Cross-request micro-batching inside vectorise() (marqo_amd/s2_inference/coalesce.py; opt-in MARQO_AMD_COALESCE_US).  CPU: a fake engine
+model that declares `supports_dynamic_batching` and records every encode call."""
+import datetime
+import os
+import threading
+import time
+from unittest import mock
+
+import numpy as np
+import pytest
+
+from marqo_amd.s2_inference import coalesce, s2_inference
+from marqo_amd.s2_inference.enums import AvailableModelsKey, Modality
+
+S2 = "marqo_amd.s2_inference.s2_inference"
+
+
+class FakeEngineModel:
+    supports_dynamic_batching = True
+
+    def __init__(self, dim=8, delay=0.004, bad=None):
+        self.dim, self.delay, self.bad = dim, delay, bad
+        self.calls = []
+        self.lock = threading.Lock()
+
+    def encode(self, content, normalize=True, **kwargs):
+        with self.lock:
+            self.calls.append(list(content))
+        time.sleep(self.delay)                     # the "tower": what concurrent callers queue up behind
+        if self.bad is not None and any(c == self.bad for c in content):
+            raise ValueError(f"cannot encode {self.bad!r}")
+        # embedding = f(item) only: row i of a merged call must equal the row of the item encoded alone
+        return np.asarray([[float(hash(c) % 1000 + j) for j in range(self.dim)] for c in content], dtype=np.float32)
+
+
+def _setup(model):
+    props = {"name": "fake_engine", "dimensions": model.dim, "tokens": 128, "type": "sbert"}
+    key = s2_inference._create_model_cache_key("fake_engine", "cpu", props)
+    avail = {key: {AvailableModelsKey.model: model, AvailableModelsKey.model_size: 1,
+                   AvailableModelsKey.most_recently_used_time: datetime.datetime.now()}}
+    return props, avail
+
+
+def _run_threads(model, props, avail, n_threads, per_call, calls_per_thread, env, fn="vectorise_ndarray"):
+    out, errs = {}, []
+
+    def worker(t):
+        try:
+            for c in range(calls_per_thread):
+                content = [f"t{t} c{c} item{i}" for i in range(per_call)]
+                out[(t, c)] = (content, getattr(s2_inference, fn)("fake_engine", content, model_properties=props, device="cpu"))
+        except BaseException as e:  # noqa: BLE001
+            errs.append((t, e))
+    with mock.patch.dict(os.environ, env), mock.patch(S2 + "._available_models", avail), \
+            mock.patch(S2 + "._update_available_models", mock.MagicMock()):
+        ts = [threading.Thread(target=worker, args=(t,)) for t in range(n_threads)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(60)
+    return out, errs
+
+
+def test_off_by_default_is_the_reference_behaviour():
+    model = FakeEngineModel()
+    props, avail = _setup(model)
+    out, errs = _run_threads(model, props, avail, 4, 3, 2, {"MARQO_AMD_COALESCE_US": ""})
+    assert not errs and len(model.calls) == 8 and all(len(c) == 3 for c in model.calls)    # one engine call per vectorise call
+
+
+def test_concurrent_small_calls_share_engine_calls_with_identical_rows():
+    model = FakeEngineModel()
+    props, avail = _setup(model)
+    before = dict(coalesce.get_coalescer().stats)
+    t0 = time.perf_counter()
+    out, errs = _run_threads(model, props, avail, 16, 4, 6, {"MARQO_AMD_COALESCE_US": "20000"})
+    merged_wall = time.perf_counter() - t0
+    assert not errs and len(out) == 96
+    ref = FakeEngineModel(delay=0.0)
+    for content, emb in out.values():                 # every caller got exactly its own rows, in its own order
+        assert emb.shape == (4, 8) and np.array_equal(emb, ref.encode(content))
+    assert len(model.calls) < 96 / 3, len(model.calls)          # 96 calls of 4 items -> far fewer engine calls
+    assert sum(len(c) for c in model.calls) == 96 * 4           # nothing encoded twice, nothing lost
+    assert max(len(c) for c in model.calls) >= 16               # really merged across threads
+    stats = coalesce.get_coalescer().stats
+    assert stats["calls"] - before["calls"] == 96 and stats["engine_calls"] - before["engine_calls"] == len(model.calls)
+    # 96 serial 4 ms "tower" calls = 384 ms; merged: ~ (number of engine calls) x 4 ms
+    assert merged_wall < 0.25, merged_wall
+
+
+def test_a_lone_caller_is_not_delayed():
+    model = FakeEngineModel(delay=0.0)
+    props, avail = _setup(model)
+    with mock.patch.dict(os.environ, {"MARQO_AMD_COALESCE_US": "50000"}), mock.patch(S2 + "._available_models", avail), \
+            mock.patch(S2 + "._update_available_models", mock.MagicMock()):
+        t0 = time.perf_counter()
+        for i in range(20):
+            s2_inference.vectorise_ndarray("fake_engine", [f"q{i}"], model_properties=props, device="cpu")
+        dt = time.perf_counter() - t0
+    assert len(model.calls) == 20 and dt < 0.05, dt          # the engine is idle: every call fires at once (no 50 ms window waits)
+
+
+def test_a_bad_request_fails_alone():
+    model = FakeEngineModel(bad="t3 c0 item1")
+    props, avail = _setup(model)
+    out, errs = _run_threads(model, props, avail, 8, 3, 1, {"MARQO_AMD_COALESCE_US": "20000"})
+    assert [t for t, _ in errs] == [3] and isinstance(errs[0][1], ValueError)           # only the caller that sent the bad item
+    assert sorted(t for t, _ in out) == [0, 1, 2, 4, 5, 6, 7]
+    ref = FakeEngineModel(delay=0.0)
+    for content, emb in out.values():
+        assert np.array_equal(emb, ref.encode(content))
+
+
+def test_list_output_and_kwargs_partition_the_groups():
+    """vectorise() (List[List[float]]) goes through the same path; calls with different keyword arguments never share a call"""
+    model = FakeEngineModel()
+    props, avail = _setup(model)
+    res = {}
+
+    def worker(t):
+        res[t] = s2_inference.vectorise("fake_engine", [f"x{t}"], model_properties=props, device="cpu", normalize_embeddings=bool(t % 2))
+    with mock.patch.dict(os.environ, {"MARQO_AMD_COALESCE_US": "20000"}), mock.patch(S2 + "._available_models", avail), \
+            mock.patch(S2 + "._update_available_models", mock.MagicMock()):
+        ts = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+        [t.start() for t in ts]
+        [t.join(30) for t in ts]
+    assert all(isinstance(res[t], list) and len(res[t]) == 1 and len(res[t][0]) == 8 and isinstance(res[t][0][0], float) for t in range(8))
+    for c in model.calls:                                   # a merged call never mixes normalize=True and normalize=False callers
+        assert len({int(x[1:]) % 2 for x in c}) == 1
+
+
+def test_large_calls_bypass_the_coalescer():
+    model = FakeEngineModel(delay=0.0)
+    props, avail = _setup(model)
+    with mock.patch.dict(os.environ, {"MARQO_AMD_COALESCE_US": "20000", "MARQO_AMD_COALESCE_MAX_ITEMS": "8"}), \
+            mock.patch(S2 + "._available_models", avail), mock.patch(S2 + "._update_available_models", mock.MagicMock()):
+        before = coalesce.get_coalescer().stats["calls"]
+        out = s2_inference.vectorise_ndarray("fake_engine", [f"i{i}" for i in range(9)], model_properties=props, device="cpu")
+        assert out.shape == (9, 8) and coalesce.get_coalescer().stats["calls"] == before
+
+
+def test_reference_vectorise_tests_pass_with_coalescing_on():
+    """the reference's own tests/s2_inference/test_vectorise.py + test_encoding_random.py run over the product (tests/ref_suite_runner.py)
+    with the coalescer switched on: the opt-in changes nothing a single caller can observe"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ref = "/root/reference/tests/s2_inference"
+    if not os.path.isdir(ref):
+        pytest.skip("reference checkout not present (GPU box)")
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""), MARQO_AMD_COALESCE_US="200")
+    env.pop("MARQO_AMD_HOST_ERRORS", None)
+    p = subprocess.run([sys.executable, os.path.join(root, "tests", "ref_suite_runner.py"), os.path.join(ref, "test_vectorise.py"),
+                        os.path.join(ref, "test_encoding_random.py")], capture_output=True, text=True, env=env, cwd="/tmp", timeout=600)
+    tail = p.stdout.strip().splitlines()[-1] if p.stdout.strip() else p.stderr[-1500:]
+    assert p.returncode == 0 and "14 passed" in tail, p.stdout[-2000:] + p.stderr[-1000:]
