@@ -57,7 +57,7 @@ extern "C" int mq_gemm_span_read(unsigned long long* h_out) {
 #endif
 
 // one workgroup per CU, two accumulator sets: the epilogue of tile i under the k-loop of tile i+1 (gemm_pp.hip)
-int mq_gemm_pp_plan(int M, int N, int K, int flags);
+int mq_gemm_pp_plan(int M, int N, int K, int flags, bool inplace);
 void mq_gemm_pp_tune(const char* key, int value);
 template <int FLAGS>
 int mq_launch_gemm_pp(int mt, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const void* residual, void* out,
@@ -455,7 +455,7 @@ int launch_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const fl
         if (g_tune.big) return mq_launch_gemm_big<FLAGS>(g_tune.big, A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s);
         if (g_tune.k32) return mq_launch_gemm_k32<FLAGS>(g_tune.k32, A, lda, W, ldw, bias, residual, out, ldc, M, N, K, g_tune.cgroup, g_tune.wide, s);
         if (!force_mt && ldc % 8 == 0 && ((uintptr_t)out & 15) == 0 && lda < (1 << 22) && ldw < (1 << 22) && ldc < (1 << 22)) {
-            if (const int pmt = mq_gemm_pp_plan(M, N, K, FLAGS))
+            if (const int pmt = mq_gemm_pp_plan(M, N, K, FLAGS, (const void*)residual == (const void*)out))
                 return mq_launch_gemm_pp<FLAGS>(pmt, A, lda, W, ldw, bias, residual, out, ldc, M, N, K, g_tune.cgroup, s);
         }
     }
@@ -570,7 +570,7 @@ extern "C" int mq_tune(const char* key, int value) {
     else if (k == "gemm_vmcnt") g_tune.vmcnt = value;
     else if (k == "gemm_prio") g_tune.prio = value;
     else if (k == "gemm_k32") g_tune.k32 = value;
-    else if (k == "gemm_pp" || k == "gemm_pp_pps" || k == "gemm_pp_skew") mq_gemm_pp_tune(key, value);
+    else if (k == "gemm_pp" || k == "gemm_pp_pps" || k == "gemm_pp_skew" || k == "gemm_pp_waves") mq_gemm_pp_tune(key, value);
     else if (k == "row_select") mq_tower_row_select = value;
     else if (k == "ln_fold") mq_tower_ln_fold = value;
     else if (k == "ln_rows") mq_ln_rows_per_wave = value;

@@ -30,7 +30,7 @@
 
 namespace {
 
-constexpr int BN = 256, BK = 64, NT = 8;
+constexpr int BN = 256, BK = 64;
 constexpr int W_BYTES = BN * BK * 2;  // 32 KiB
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -59,17 +59,27 @@ __device__ __forceinline__ void wait_vm_lgkm0() {
     __builtin_amdgcn_s_waitcnt((V & 15) | 0x70 | ((V >> 4) << 14));
 }
 
-// PPS = epilogue units (pairs of 16x16 sub-tiles, one 16-byte bf16 store per lane) carried by one k-step of the next tile
-template <int FLAGS, int MT, int PPS>
-__global__ __launch_bounds__(256, 1) void gemm_pp_kernel(
+// PPS = epilogue units (pairs of 16x16 sub-tiles, one 16-byte bf16 store per lane) carried by one k-step of the next tile.
+// WN = waves along N: 2 -> 4 waves (one per SIMD, 512 registers each, wave tile (16*MT) x 128), 4 -> 8 waves (two per SIMD, 256 registers
+// each, wave tile (16*MT) x 64).  Measured (profiles/r03c_pp_ablation.txt): with ONE wave per SIMD nothing covers the wave's own LDS-DMA
+// issue (the CU's address path takes 16 cycles per 1-KiB piece: 26 % of the k-step at 4096^3), its barrier (11 %) or the VALU of the
+// interleaved epilogue (fc1 + GELU: +34 %) — an in-order wave cannot issue MFMAs while it is blocked in any of them.  Two waves per
+// SIMD give every such slot to the partner's MFMAs, at the price of twice the fragment reads per MFMA.
+template <int FLAGS, int MT, int PPS, int WN>
+__global__ __launch_bounds__(128 * WN, WN / 2) void gemm_pp_kernel(
     const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ Wt, int64_t ldw,
     const float* __restrict__ bias, const void* residual, void* out, int64_t ldc,
     int M, int N, int K, int tiles_n, int num_tiles, int cgroup, int band_rows, int skew) {
     constexpr int BM = 32 * MT;
     constexpr int A_BYTES = BM * BK * 2;
     constexpr int STAGE = A_BYTES + W_BYTES;
-    constexpr int NP = MT + 8;            // LDS-DMA pieces (8 rows x 128 B) per wave per stage
-    constexpr int UNITS = MT * 4;         // epilogue units per wave per tile
+    constexpr int WAVES = 2 * WN, NT = 16 / WN;
+    static_assert((4 * MT) % WAVES == 0 && 32 % WAVES == 0, "staging pieces must deal evenly to the waves");
+    constexpr int NPA = 4 * MT / WAVES, NPW = 32 / WAVES;
+    constexpr int NP = NPA + NPW;         // LDS-DMA pieces (8 rows x 128 B) per wave per stage
+    constexpr int NF = MT + NT;           // fragment reads per wave per 32-deep half
+    constexpr int UPR = NT / 2;           // epilogue units per 16-row group
+    constexpr int UNITS = MT * UPR;       // epilogue units per wave per tile
     constexpr int EC = UNITS / PPS;       // k-steps of the next tile that carry an epilogue unit group
     static_assert(UNITS % PPS == 0, "units must divide");
     constexpr bool HAS_BIAS = (FLAGS & MQ_EPI_BIAS) != 0;
@@ -86,7 +96,7 @@ __global__ __launch_bounds__(256, 1) void gemm_pp_kernel(
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int l15 = lane & 15, g = lane >> 4;
     const int srow = lane >> 3, pch = lane & 7;
 
@@ -119,19 +129,19 @@ __global__ __launch_bounds__(256, 1) void gemm_pp_kernel(
     // physical 16-B chunk = lane % 8) fetches logical chunk (lane % 8) ^ (row & 7): the swizzle lives on the SOURCE address (LDS-DMA
     // writes lane-linear) and again on the fragment reads.  32-bit byte offsets from a wave-uniform tile base.
     const char* a_base; const char* w_base;     // advance by 128 B per staged k-step
-    unsigned a_voff[MT], w_voff[8];
+    unsigned a_voff[NPA], w_voff[NPW];
     auto set_sources = [&](int m0, int n0) {
         a_base = (const char*)(A + (int64_t)m0 * lda);
         w_base = (const char*)(Wt + (int64_t)n0 * ldw);
         const int mlim = M - 1 - m0, nlim = N - 1 - n0;
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int row = (i * 4 + wave) * 8 + srow;
+        for (int i = 0; i < NPA; ++i) {
+            const int row = (i * WAVES + wave) * 8 + srow;
             a_voff[i] = (unsigned)min(row, mlim) * (unsigned)(lda * 2) + (unsigned)((pch ^ (row & 7)) * 16);
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int row = (j * 4 + wave) * 8 + srow;
+        for (int j = 0; j < NPW; ++j) {
+            const int row = (j * WAVES + wave) * 8 + srow;
             w_voff[j] = (unsigned)min(row, nlim) * (unsigned)(ldw * 2) + (unsigned)((pch ^ (row & 7)) * 16);
         }
     };
@@ -140,19 +150,19 @@ __global__ __launch_bounds__(256, 1) void gemm_pp_kernel(
 #if defined(MQ_PP_DIAG) && (MQ_PP_DIAG & 1)   // ablation (timing only, wrong results): no global -> LDS traffic in the k-steps
         if (diag_live) return;
 #endif
-        if (q < MT) glds16(a_base + a_voff[q], stage_base + (q * 4 + wave) * 1024);
-        else glds16(w_base + w_voff[q - MT], stage_base + A_BYTES + ((q - MT) * 4 + wave) * 1024);
+        if (q < NPA) glds16(a_base + a_voff[q], stage_base + (q * WAVES + wave) * 1024);
+        else glds16(w_base + w_voff[q - NPA], stage_base + A_BYTES + ((q - NPA) * WAVES + wave) * 1024);
     };
 
     // ---- fragment read offsets (bytes inside a stage): row (l15), 16-B chunk (g + 4 kk) ^ (row & 7)
     const int sw0 = (g ^ (l15 & 7)) << 4, sw1 = ((g + 4) ^ (l15 & 7)) << 4;
     const int fa0 = (wm * (16 * MT) + l15) * 128 + sw0, fa1 = (wm * (16 * MT) + l15) * 128 + sw1;
-    const int fw0 = A_BYTES + (wn * 128 + l15) * 128 + sw0, fw1 = A_BYTES + (wn * 128 + l15) * 128 + sw1;
+    const int fw0 = A_BYTES + (wn * (16 * NT) + l15) * 128 + sw0, fw1 = A_BYTES + (wn * (16 * NT) + l15) * 128 + sw1;
 
     // ---- epilogue geometry of this lane inside a tile (gemm_epilogue.h): operands are fed swapped, so a lane owns out[m][n..n+3]
     const int m_wave = wm * (16 * MT) + l15;          // + mt * 16
-    const int n_lane = wn * 128 + g * 4;              // + nt * 16
-    const int n_wide = wn * 128 + (g & 1) * 16 + (g >> 1) * 8;   // + p * 32 : after the permlane16 exchange a lane owns 8 consecutive n
+    const int n_lane = wn * (16 * NT) + g * 4;        // + nt * 16
+    const int n_wide = wn * (16 * NT) + (g & 1) * 16 + (g >> 1) * 8;   // + p * 32 : after the permlane16 exchange a lane owns 8 consecutive n
 
     const int nk = K / BK;
     int vb = blockIdx.x;
@@ -169,7 +179,7 @@ __global__ __launch_bounds__(256, 1) void gemm_pp_kernel(
 
     // previous tile (the one whose results sit in Y): buffer descriptors with num_records = 0 until there is one
     __amdgpu_buffer_rsrc_t p_out = __builtin_amdgcn_make_buffer_rsrc(out, 0, 0, 0x00020000);
-    __amdgpu_buffer_rsrc_t p_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(residual ? residual : (const void*)out), 0, 0, 0x00020000);
+    // (the residual epilogues run IN PLACE here: residual == out is a condition of mq_gemm_pp_plan — one descriptor serves both)
     int p_mrem = 0, p_nrem = 0;      // rows / columns of the previous tile inside the matrix
     int p_slot = 0;                   // bias slot of the previous tile
     auto describe_prev = [&](int tm0, int tn0) {
@@ -177,7 +187,6 @@ __global__ __launch_bounds__(256, 1) void gemm_pp_kernel(
         const int64_t rem = ((int64_t)M * ldc - first) * ES;
         const int nrec = (int)(rem < 0x7fffffff ? rem : 0x7fffffff);
         p_out = __builtin_amdgcn_make_buffer_rsrc((char*)out + first * ES, 0, nrec, 0x00020000);
-        if (HAS_RES) p_res = __builtin_amdgcn_make_buffer_rsrc((char*)const_cast<void*>(residual) + first * ES, 0, nrec, 0x00020000);
         p_mrem = M - tm0;
         p_nrem = N - tn0;
     };
@@ -190,10 +199,11 @@ __global__ __launch_bounds__(256, 1) void gemm_pp_kernel(
     const unsigned off_wide = (unsigned)(m_wave * (int)ldc + n_wide) * 2u;        // bf16 pair store (after the permlane16 exchange)
     const int ldc16 = (int)ldc * 16;
     constexpr unsigned OOB = 0x80000000u;
+    using res_raw_t = std::conditional_t<RES_BF16, u32x2, u32x4>;   // raw residual of one sub-tile (bf16: 4 values in 8 bytes)
     // raw residual of one epilogue unit (two sub-tiles): bf16 -> .x .y of each, fp32 -> all four
-    auto res_load = [&](auto u_tag, u32x4 (&r)[2]) {
+    auto res_load = [&](auto u_tag, res_raw_t (&r)[2]) {
         constexpr int U = decltype(u_tag)::value;
-        constexpr int mt = U / 4, p = U % 4;
+        constexpr int mt = U / UPR, p = U % UPR;
         const bool m_ok = m_wave < p_mrem - mt * 16;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -201,25 +211,21 @@ __global__ __launch_bounds__(256, 1) void gemm_pp_kernel(
             // row-group delta in the scalar offset, column delta as a constant (folds into the instruction's 12-bit immediate)
             const int soff = mt * ldc16 * ES;
             const unsigned voff = (ok ? off_lane : OOB) + (unsigned)((2 * p + h) * 16 * ES);
-            if (RES_BF16) {
-                const u32x2 q = __builtin_amdgcn_raw_buffer_load_b64(p_res, voff, soff, 0);
-                r[h] = u32x4{q.x, q.y, 0u, 0u};
-            } else {
-                r[h] = __builtin_amdgcn_raw_buffer_load_b128(p_res, voff, soff, 0);
-            }
+            if constexpr (RES_BF16) r[h] = __builtin_amdgcn_raw_buffer_load_b64(p_out, voff, soff, 0);
+            else r[h] = __builtin_amdgcn_raw_buffer_load_b128(p_out, voff, soff, 0);
         }
     };
     // bias of a unit's two sub-tiles from the previous tile's LDS slot
     auto bias_load = [&](auto u_tag, f32x4 (&b)[2]) {
         constexpr int U = decltype(u_tag)::value;
-        constexpr int p = U % 4;
+        constexpr int p = U % UPR;
 #pragma unroll
         for (int h = 0; h < 2; ++h) b[h] = *(const f32x4*)(bias_lds + p_slot * BN + n_lane + (2 * p + h) * 16);
     };
     // one epilogue unit: sub-tiles (mt, 2p) and (mt, 2p+1) of Y -> bias / activation / residual -> store
-    auto epi_unit = [&](auto u_tag, const u32x4 (&r)[2], const f32x4 (&b)[2]) {
+    auto epi_unit = [&](auto u_tag, const res_raw_t (&r)[2], const f32x4 (&b)[2]) {
         constexpr int U = decltype(u_tag)::value;
-        constexpr int mt = U / 4, p = U % 4;
+        constexpr int mt = U / UPR, p = U % UPR;
         const bool m_ok = m_wave < p_mrem - mt * 16;
         f32x4 v[2];
 #pragma unroll
@@ -232,12 +238,11 @@ __global__ __launch_bounds__(256, 1) void gemm_pp_kernel(
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[h][e] = quick_gelu(v[h][e]);
             }
-            if (HAS_RES) {
-                if (RES_BF16)
-                    v[h] += f32x4{__uint_as_float(r[h].x << 16), __uint_as_float(r[h].x & 0xffff0000u), __uint_as_float(r[h].y << 16),
-                                  __uint_as_float(r[h].y & 0xffff0000u)};
-                else
-                    v[h] += f32x4{__uint_as_float(r[h].x), __uint_as_float(r[h].y), __uint_as_float(r[h].z), __uint_as_float(r[h].w)};
+            if constexpr (RES_BF16) {
+                v[h] += f32x4{__uint_as_float(r[h].x << 16), __uint_as_float(r[h].x & 0xffff0000u), __uint_as_float(r[h].y << 16),
+                              __uint_as_float(r[h].y & 0xffff0000u)};
+            } else if constexpr (HAS_RES) {
+                v[h] += f32x4{__uint_as_float(r[h].x), __uint_as_float(r[h].y), __uint_as_float(r[h].z), __uint_as_float(r[h].w)};
             }
         }
         if (OUT_F32) {
@@ -317,9 +322,12 @@ __global__ __launch_bounds__(256, 1) void gemm_pp_kernel(
         // ---- first half: kk = 0 MFMAs | this step's epilogue inputs (bias from LDS, residual) | read the kk = 1 fragments | stage s+2.
         // Source order = issue order wanted: the fragment reads come before the LDS-DMA pieces (LDS reads and LDS-DMA writes may alias
         // for the compiler, so their relative order is fixed by the source).
-        u32x4 rpre[PPS][2];
+        res_raw_t rpre[PPS][2];
         f32x4 bpre[PPS][2];
-        if constexpr (E >= 0 && HAS_BIAS) {
+        // (the bf16-residual epilogue of the 8-wave form is the one place the 256-register budget is short by a handful: its bias is
+        // read in the second half instead of being carried across the barrier)
+        constexpr bool BIAS_PRE = !(RES_BF16 && WN == 4);
+        if constexpr (E >= 0 && HAS_BIAS && BIAS_PRE) {
             static_for<PPS>([&](auto i) { bias_load(ic<E * PPS + decltype(i)::value>{}, bpre[decltype(i)::value]); });
         }
         if constexpr (E >= 0 && HAS_RES) {   // ahead of the LDS-DMA pieces: complete at the middle wait
@@ -347,12 +355,12 @@ __global__ __launch_bounds__(256, 1) void gemm_pp_kernel(
             }
         {   // pin the interleave (masks: 0x8 MFMA, 0x100 DS read, 0x20 VMEM read, 0x10 VMEM): epilogue inputs up front, then one fragment read per
             // MFMA, then one LDS-DMA piece per MFMA, the rest of the MFMAs
-            constexpr int NB = (E >= 0 && HAS_BIAS) ? 2 * PPS : 0, NR = (E >= 0 && HAS_RES) ? 2 * PPS : 0;
-            static_assert(2 * NP <= MT * NT, "one MFMA per staging instruction");
+            constexpr int NB = (E >= 0 && HAS_BIAS && BIAS_PRE) ? 2 * PPS : 0, NR = (E >= 0 && HAS_RES) ? 2 * PPS : 0;
+            static_assert(NF + NP <= MT * NT, "one MFMA per staging instruction");
             if (NB) __builtin_amdgcn_sched_group_barrier(0x100, NB, 0);
             if (NR) __builtin_amdgcn_sched_group_barrier(0x020, NR, 0);
 #pragma unroll
-            for (int i = 0; i < NP; ++i) {
+            for (int i = 0; i < NF; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
@@ -361,7 +369,7 @@ __global__ __launch_bounds__(256, 1) void gemm_pp_kernel(
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, MT * NT - 2 * NP, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, MT * NT - NF - NP, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
         // ---- middle: stage s+1 landed (all but the NP newest VMEM operations — those of stage s+2 — are complete), kk = 1 fragments here,
@@ -398,18 +406,21 @@ __global__ __launch_bounds__(256, 1) void gemm_pp_kernel(
 #else
         if constexpr (E >= 0) {
 #endif
+            if constexpr (HAS_BIAS && !BIAS_PRE) {
+                static_for<PPS>([&](auto i) { bias_load(ic<E * PPS + decltype(i)::value>{}, bpre[decltype(i)::value]); });
+            }
             static_for<PPS>([&](auto i) { epi_unit(ic<E * PPS + decltype(i)::value>{}, rpre[decltype(i)::value], bpre[decltype(i)::value]); });
         }
         {
-            constexpr int G = (MT * NT) / NP;
+            constexpr int G = (MT * NT) / NF;
             constexpr int VPG = (E >= 0) ? ((FLAGS & (MQ_EPI_GELU | MQ_EPI_QUICKGELU)) ? 10 * PPS / 2 + 2 : 2 * PPS + 1) : 0;
 #pragma unroll
-            for (int i = 0; i < NP; ++i) {
+            for (int i = 0; i < NF; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, G, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 if (VPG) __builtin_amdgcn_sched_group_barrier(0x002, VPG, 0);
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, MT * NT - G * NP, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, MT * NT - G * NF, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
         sb = sb1;
@@ -456,7 +467,7 @@ __global__ __launch_bounds__(256, 1) void gemm_pp_kernel(
     }
     // ---- tail: the last tile's epilogue, nothing left to hide it under
     static_for<UNITS>([&](auto u) {
-        u32x4 r[2];
+        res_raw_t r[2];
         f32x4 b[2];
         if (HAS_BIAS) bias_load(u, b);
         if (HAS_RES) res_load(u, r);
@@ -466,20 +477,20 @@ __global__ __launch_bounds__(256, 1) void gemm_pp_kernel(
 }
 
 struct PpTune {
-    int on, mt, pps, skew;
+    int on, mt, pps, skew, waves;
     static int env(const char* k, int d) { const char* v = getenv(k); return v ? atoi(v) : d; }
-    PpTune() : on(env("MQ_GEMM_PP", 0)), mt(env("MQ_GEMM_PP_MT", 0)), pps(env("MQ_GEMM_PP_PPS", 0)), skew(env("MQ_GEMM_PP_SKEW", 0)) {}
+    PpTune() : on(env("MQ_GEMM_PP", 0)), mt(env("MQ_GEMM_PP_MT", 0)), pps(env("MQ_GEMM_PP_PPS", 0)), skew(env("MQ_GEMM_PP_SKEW", 0)), waves(env("MQ_GEMM_PP_WAVES", 8)) {}
 };
 PpTune g_pp;
 
-template <int FLAGS, int MT, int PPS>
+template <int FLAGS, int MT, int PPS, int WN>
 int launch_pp(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const void* residual, void* out, int64_t ldc,
               int M, int N, int K, int cgroup_knob, hipStream_t s) {
     constexpr int BM = 32 * MT;
     constexpr int LDS = 3 * (BM * BK * 2 + W_BYTES) + 2 * BN * 4;
     static_assert(LDS <= 160 * 1024, "three stages must fit the CU's LDS");
     static std::atomic<uint64_t> attr_done{0};
-    if (hipError_t e = mq_ensure_dyn_lds((const void*)gemm_pp_kernel<FLAGS, MT, PPS>, LDS, attr_done); e != hipSuccess) {
+    if (hipError_t e = mq_ensure_dyn_lds((const void*)gemm_pp_kernel<FLAGS, MT, PPS, WN>, LDS, attr_done); e != hipSuccess) {
         mq_set_error("mq_gemm_bf16(pp): hipFuncSetAttribute: %s", hipGetErrorString(e));
         return MQ_ERR_HIP;
     }
@@ -498,7 +509,7 @@ int launch_pp(const void* A, int64_t lda, const void* W, int64_t ldw, const floa
         cus = cached_cus[dev & 63];
     }
     const int grid = num_tiles < cus ? num_tiles : cus;
-    hipLaunchKernelGGL((gemm_pp_kernel<FLAGS, MT, PPS>), dim3(grid), dim3(256), LDS, s, (const bf16_t*)A, lda, (const bf16_t*)W, ldw, bias,
+    hipLaunchKernelGGL((gemm_pp_kernel<FLAGS, MT, PPS, WN>), dim3(grid), dim3(128 * WN), LDS, s, (const bf16_t*)A, lda, (const bf16_t*)W, ldw, bias,
                        residual, out, ldc, M, N, K, tiles_n, num_tiles, cgroup, band_rows, g_pp.skew);
     MQ_CHECK_LAUNCH("mq_gemm_bf16(pp)");
     return MQ_OK;
@@ -507,27 +518,29 @@ int launch_pp(const void* A, int64_t lda, const void* W, int64_t ldw, const floa
 }  // namespace
 
 // knobs (mq_tune): "gemm_pp" 0 = off, 1 = on where the cost model prefers it, 2 = wherever the shape is legal;
-// "gemm_pp_pps" 0 = auto / 2 / 4 epilogue units per k-step
+// "gemm_pp_pps" 2 (default) = the epilogue rides on 8 k-steps of the next tile, 4 = on 4; "gemm_pp_waves" 8 (default) / 4; "gemm_pp_skew"
 void mq_gemm_pp_tune(const char* key, int value) {
     const std::string_view k(key);
     if (k == "gemm_pp") g_pp.on = value;
     else if (k == "gemm_pp_mt") g_pp.mt = value;
     else if (k == "gemm_pp_pps") g_pp.pps = value;
     else if (k == "gemm_pp_skew") g_pp.skew = value;
+    else if (k == "gemm_pp_waves") g_pp.waves = value == 4 ? 4 : 8;
 }
 int mq_gemm_pp_mode() { return g_pp.on; }
 
 // -> 0: not applicable (the caller falls back to the (32*MT) x 128 kernel), else the tile height in 32-row units.
 // Only MT = 4 is instantiated: at MT = 5 the two 160-register accumulator sets + two fragment sets do not fit the 512 registers of a
 // one-wave-per-SIMD kernel without scratch spills (hipcc: 256 VGPRs + 256 AGPRs + 21..109 spilled), and _lib.build() refuses scratch.
-int mq_gemm_pp_plan(int M, int N, int K, int flags) {
+int mq_gemm_pp_plan(int M, int N, int K, int flags, bool inplace) {
     if (!g_pp.on) return 0;
+    if ((flags & MQ_EPI_RESIDUAL) && !inplace) return 0;   // the kernel reads the residual through the output's buffer descriptor
     const int nk = K / BK;
     if (nk < 5 || N < 256 || M < 64) return 0;             // MT*4/PPS epilogue-carrying k-steps + the last one must exist: nk >= 4 + 1
     // QUICKGELU: the interleaved epilogue returns wrong swapped halves next to the division sequences (profiles/r03b_pp_diag.txt) — not routed here
     if (flags & MQ_EPI_QUICKGELU) return 0;
     // the fp32-residual epilogue at 4 units per k-step (needed below 9 k-steps) is the one instantiation that spills: not built
-    if (flags == (MQ_EPI_BIAS | MQ_EPI_RESIDUAL | MQ_EPI_OUT_F32) && (nk < 9 || g_pp.pps == 4)) return 0;
+    if (g_pp.waves == 4 && flags == (MQ_EPI_BIAS | MQ_EPI_RESIDUAL | MQ_EPI_OUT_F32) && (nk < 9 || g_pp.pps == 4)) return 0;
     if (g_pp.on == 1) {
         // cost model against the two-workgroups-per-CU kernel: one-per-CU tiles of 128 x 256 in rounds of 256; a ragged last round
         // costs a whole round.  Take the big tile when its rounds are at least 70 % full.
@@ -542,17 +555,21 @@ template <int FLAGS>
 int mq_launch_gemm_pp(int mt, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const void* residual, void* out,
                       int64_t ldc, int M, int N, int K, int cgroup_knob, hipStream_t s) {
     const int nk = K / BK;
-    // epilogue units per k-step: 2 where the k-loop is long enough to carry all 16 that way (lighter steps), else 4
-    int pps = g_pp.pps;
-    if (pps != 2 && pps != 4) pps = 2;
-    if (16 / pps + 1 > nk) pps = 4;
-    if (pps == 2) return launch_pp<FLAGS, 4, 2>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, cgroup_knob, s);
-    if constexpr (FLAGS == (MQ_EPI_BIAS | MQ_EPI_RESIDUAL | MQ_EPI_OUT_F32)) {
-        mq_set_error("mq_gemm_bf16(pp): fp32-residual epilogue needs K >= 576");   // (mq_gemm_pp_plan never sends it here)
-        return MQ_ERR_INVALID;
-    } else {
-        return launch_pp<FLAGS, 4, 4>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, cgroup_knob, s);
+    // k-steps of the next tile that carry the epilogue: 8 where the k-loop is long enough (lighter steps), else 4  ("gemm_pp_pps" 2 / 4)
+    bool light = g_pp.pps != 4;
+    if (8 + 1 > nk) light = false;
+    constexpr bool F32RES = FLAGS == (MQ_EPI_BIAS | MQ_EPI_RESIDUAL | MQ_EPI_OUT_F32);
+    if (g_pp.waves == 4) {
+        if (light) return launch_pp<FLAGS, 4, 2, 2>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, cgroup_knob, s);
+        if constexpr (F32RES) {
+            mq_set_error("mq_gemm_bf16(pp): fp32-residual epilogue needs K >= 576");   // (mq_gemm_pp_plan never sends it here)
+            return MQ_ERR_INVALID;
+        } else {
+            return launch_pp<FLAGS, 4, 4, 2>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, cgroup_knob, s);
+        }
     }
+    if (light) return launch_pp<FLAGS, 4, 1, 4>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, cgroup_knob, s);
+    return launch_pp<FLAGS, 4, 2, 4>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, cgroup_knob, s);
 }
 
 #define MQ_PP_INST(F)                                                                                                              \

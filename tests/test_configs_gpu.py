@@ -75,14 +75,14 @@ def test_config5_fp8_towers_with_device_chunking(s2):
         patches, bbs = OP.chunk_image_simple(np.asarray(im), 3, 3, False)
         ref = O.vit_forward(sd, vcfg, torch.from_numpy(np.stack([OP.clip_transform(p, 64) for p in patches]))).numpy()
         assert np.allclose(boxes[i], np.asarray(bbs), rtol=1e-6)
-        assert _cos_err(emb[i], ref) < 1e-2  # the honest fp8 bound (bf16 holds 3e-4, north-star 1e-3 is the bf16 tolerance)
+        assert _cos_err(emb[i], ref) < 1e-3  # the north-star tolerance is global: the load-time bf16 / e4m3 block split (7e-4 budget vs bf16) holds it
     again, _ = model.encode_image_chunks(imgs, 3, 3, False)
     assert np.array_equal(emb, again)  # frozen scales: deterministic
     # text side of the same fp8 model, through the device tokeniser
     texts = ["a photo of a cat", "the quick brown fox jumps over the lazy dog"]
     out = np.asarray(s2i.vectorise("tiny-clip-fp8", texts, model_properties=props8, device=DEV))
     ref = O.clip_text_forward(sd, tcfg, torch.from_numpy(model.tokenizer(texts))).numpy()
-    assert _cos_err(out, ref) < 1e-2
+    assert _cos_err(out, ref) < 1e-3
     from marqo_amd.s2_inference.errors import ModelLoadError
     with pytest.raises(ModelLoadError):
         s2i.vectorise("tiny-clip-bad", texts, model_properties=dict(props, enginePrecision="int4"), device=DEV)

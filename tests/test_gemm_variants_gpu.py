@@ -155,14 +155,15 @@ def test_counted_vmcnt_and_static_priority_knobs_are_bit_identical():
         _tune(lib, **DEFAULTS)
 
 
+@pytest.mark.parametrize("waves", [8, 4])
 @pytest.mark.parametrize("pps", [2, 4])
-def test_two_accumulator_set_kernel_is_bit_identical(pps):
-    """gemm_pp.hip: one 4-wave workgroup per CU, 128x256 tiles, 3-stage LDS ring with the barrier in the middle of the k-step, second
+def test_two_accumulator_set_kernel_is_bit_identical(pps, waves):
+    """gemm_pp.hip: one workgroup per CU (8 waves = two per SIMD, or 4 = one per SIMD), 128x256 tiles, 3-stage LDS ring with the barrier in the middle of the k-step, second
     accumulator set (the previous tile's epilogue rides under the next tile's MFMAs, stores / residual loads through buffer descriptors).
     Same k-order of MFMAs and the same epilogue arithmetic as the shipped kernel -> identical bits: every epilogue (fp32 and bf16
     residual streams included), one-tile and many-tile launches, ragged M / N edges, the shortest legal K; repeated as a race screen."""
     lib = L.load()
-    g = torch.Generator(device="cuda").manual_seed(300 + pps)
+    g = torch.Generator(device="cuda").manual_seed(300 + pps + waves)
     F = L
     try:
         shapes = [(12800, 2304, 768), (12800, 3072, 768), (12800, 768, 768), (12800, 768, 3072), (16448, 1024, 1024), (12801, 2308, 768),
@@ -189,9 +190,9 @@ def test_two_accumulator_set_kernel_is_bit_identical(pps):
                     return _gemm(lib, A, W, bias, res, flags)
                 _tune(lib, gemm_pp=0)
                 base = run()
-                _tune(lib, gemm_pp=2, gemm_pp_pps=pps)
+                _tune(lib, gemm_pp=2, gemm_pp_pps=pps, gemm_pp_waves=waves)
                 for _ in range(2 if big else 5):
                     out = run()
-                    assert torch.equal(out, base), ((M, N, K), flags, pps, (out.float() - base.float()).abs().max().item())
+                    assert torch.equal(out, base), ((M, N, K), flags, pps, waves, (out.float() - base.float()).abs().max().item())
     finally:
-        _tune(lib, gemm_pp=0, gemm_pp_pps=0, **DEFAULTS)
+        _tune(lib, gemm_pp=0, gemm_pp_pps=0, gemm_pp_waves=8, **DEFAULTS)

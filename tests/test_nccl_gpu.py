@@ -51,5 +51,5 @@ def test_rccl_two_ranks():
     text = (r.stdout + r.stderr + json.dumps(rows)).lower()
     if len(rows) == 2 and all(x.get("ok") for x in rows):
         return  # an RCCL that accepts two ranks per device: then it really ran
-    assert "duplicate gpu" in text or "invalid usage" in text or "nccl" in text, (r.stdout[-1500:], r.stderr[-1500:])
+    assert "duplicate gpu" in text, (r.stdout[-1500:], r.stderr[-1500:])   # RCCL's own refusal, nothing else counts
     pytest.skip("single-GPU box: RCCL refuses two ranks on one device (Duplicate GPU detected); 2-rank path covered by the gloo tests")
