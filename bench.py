@@ -55,6 +55,12 @@ WORKLOADS = {
     "clip_text_l14": dict(kind="clip_text", arch="ViT-L-14", desc="open_clip ViT-L/14 text tower, 77-token ids, batch 1024/GPU", batch=1024),
     "bert_base_77": dict(kind="bert", arch="intfloat/e5-base-v2", desc="e5-base-v2 (BERT-base) + mean-pool + L2, 77-token ids, batch 1024/GPU", batch=1024),
     "vit_l14_mixed": dict(kind="mixed", arch="ViT-L-14", desc="open_clip ViT-L/14 dual encoder, 128 images + 128 texts (5..75 tokens) per GPU (BASELINE configs[2])", batch=256),
+    "vit_l14_chunked_fp8": dict(kind="chunked", arch="ViT-L-14", desc="BASELINE configs[4]: 480x640 uint8 images resident in HBM -> K11 'simple' 3x3 grid chunking on the GPU "
+                                "(resize to 240x240, whole image + 9 cells = 10 crops per image, each through the CLIP transform) -> ViT-L/14 image tower under the "
+                                "load-time fp8 block-split policy; 24 images = 240 crop embeddings per GPU per step", batch=24),
+    "add_documents_stream": dict(kind="stream", arch="ViT-B-32", desc="BASELINE configs[3] as a stream: mixed {text, 224x224 PIL image} documents in 128-document requests; every "
+                                 "rank owns whole requests (request i -> rank i % N, nothing is sharded inside a request), runs them through the single-GPU "
+                                 "BulkVectoriser path (text tower overlapped with image staging) and ONE gather onto rank 0 closes the stream; ViT-B/32", batch=128),
     "add_documents_mixed": dict(kind="ingest", arch="ViT-B-32", desc="add_documents bulk ingest in miniature (BASELINE configs[3]): documents {text, 224x224 image} in "
                                 "128-document requests through BulkVectoriser (host PIL images + strings -> vectorise -> gather in order), ViT-B/32", batch=128),
 }
@@ -138,7 +144,7 @@ class Workload:
         batch = self.batch
         g = torch.Generator().manual_seed(seed)
         self.varch = self.tarch = self.barch = None
-        if self.kind in ("image", "clip_text", "mixed"):
+        if self.kind in ("image", "clip_text", "mixed", "chunked"):
             self.varch, self.tarch = archs.resolve_open_clip(wl["arch"])
 
         def clip_ids(n, lo, hi):
@@ -187,6 +193,23 @@ class Workload:
             self.gflop_per_emb = self.barch.gflop_per_text(77)
             d_ids, lens = ids.to(torch.int32).to(dev), torch.full((batch,), 77, dtype=torch.int64)
             self.run = lambda: tower.encode_device(d_ids, lens)
+        elif self.kind == "chunked":   # device-resident source images -> grid chunker (K11) -> tower; embeddings = crops
+            from marqo_amd.engine.preprocess import ImagePreprocessor
+            self.sd = synthetic.random_open_clip_state_dict(vision=self.varch, seed=0)
+            tower = towers.VitTower(self.varch, self.sd, dev, precision=precision)
+            self.src_cpu = [torch.randint(0, 256, (480, 640, 3), generator=g, dtype=torch.uint8) for _ in range(batch)]
+            src = [t.to(dev) for t in self.src_cpu]
+            pre = ImagePreprocessor(dev, self.varch.image_size)
+            self.crops_per_image = 10
+            self.towers = [tower]
+            self.gflop_per_emb = self.varch.gflop_per_image
+            self.pre = pre
+
+            def run_chunked():
+                crops, _ = pre.chunk_grid_u8(src, 3, 3, False)       # uint8 [n * 10, S, S, 3] on the device
+                return tower.encode_u8(crops)
+            self.run = run_chunked
+            self.batch = batch * self.crops_per_image                # `value` counts embeddings = crops
         elif self.kind == "mixed":  # half images, half texts of ragged length through the two towers of one model
             self.sd = synthetic.random_open_clip_state_dict(vision=self.varch, text=self.tarch, seed=0)
             vt = towers.VitTower(self.varch, self.sd, dev, precision=precision)
@@ -223,6 +246,24 @@ class Workload:
             rate, n, emb, th, cores = cpu_baseline_run(lambda lo, hi: fwd(self.sd, cfg, O.preprocess_u8_exact_size(self.images_cpu[lo:hi])),
                                                        self.batch, target_seconds)
             what = f"of the step's {self.batch} images"
+        elif self.kind == "chunked":
+            # reference flow on the host: chunk_image 'simple' (PIL resize to 240x240 + crops, processing/image.py:46-151) -> CLIP transform per
+            # crop (clip_utils.py:48-67) -> ViT forward in fp32, 16-item batches
+            from oracle import preprocess as OP
+            a = self.varch
+            cfg = O.VitConfig(a.image_size, a.patch_size, a.width, a.layers, a.heads, a.mlp_dim, a.out_dim, a.quick_gelu)
+            n_src = len(self.src_cpu)
+
+            def crops_of(lo, hi):   # item index = crop index; image = index // 10
+                out = []
+                for im in range(lo // 10, (hi + 9) // 10):
+                    patches, _ = OP.chunk_image_simple(self.src_cpu[im].numpy(), 3, 3, False)
+                    out.extend(OP.clip_transform(p_, a.image_size) for p_ in patches)
+                off = lo - (lo // 10) * 10
+                return torch.from_numpy(np.stack(out[off:off + (hi - lo)]))
+            rate, n, emb, th, cores = cpu_baseline_run(lambda lo, hi: O.vit_forward(self.sd, cfg, crops_of(lo, hi)),
+                                                       n_src * 10, target_seconds)
+            what = f"crops of the step's {n_src} source images (PIL-exact 240x240 resize + 3x3 grid + CLIP transform on the host, then the fp32 tower)"
         elif self.kind == "clip_text" and self.tarch.causal:
             t = self.tarch
             cfg = O.ClipTextConfig(t.vocab, t.ctx, t.width, t.layers, t.heads, t.mlp_dim, t.out_dim, t.quick_gelu)
@@ -459,6 +500,104 @@ def run_ingest(args, dev, rank, world, dist):
         print(json.dumps(result), flush=True)
 
 
+# ---- BASELINE configs[3] as a stream: ranks own whole requests, one gather onto rank 0 ----------------------------------------------
+def run_stream(args, dev, rank, world, dist, lib, L):
+    from PIL import Image
+    os.environ["MARQO_AMD_SYNTHETIC_WEIGHTS"] = "1"
+    os.environ.setdefault("MARQO_MAX_CUDA_MODEL_MEMORY", "64")
+    from marqo_amd.engine import archs
+    from marqo_amd.ingest import RequestShardedIngest
+    from marqo_amd.s2_inference import s2_inference as s2
+    from marqo_amd.s2_inference.enums import Modality
+    wl = WORKLOADS["add_documents_stream"]
+    docs = args.batch or wl["batch"]
+    name = "open_clip/ViT-B-32/laion2b_s34b_b79k"
+    varch, tarch = archs.resolve_open_clip("ViT-B-32")
+    # a pool of 4 distinct synthetic requests per rank (4 x 128 images = 77 MB of pixels), cycled: the stream's requests are independent
+    rng = np.random.default_rng(100 + rank)
+    words = ["alpha", "beta", "gamma", "delta", "marqo", "tensor", "search", "image", "text", "vector"]
+    pool = []
+    for r in range(4):
+        imgs = [Image.fromarray(rng.integers(0, 256, (224, 224, 3), dtype=np.uint8)) for _ in range(docs)]
+        texts = [" ".join(words[int(j) % 10] for j in rng.integers(0, 10, int(rng.integers(3, 60)))) + f" {r} {i}" for i in range(docs)]
+        pool.append((texts, imgs))
+    ing = RequestShardedIngest(name, dev)
+    state = {"next": rank}          # this rank's next request index (rank, rank + world, ...)
+
+    def step():                     # ONE owned request of `docs` documents = 2 * docs embeddings
+        i = state["next"]
+        state["next"] += world
+        texts, imgs = pool[(i // world) % len(pool)]
+        items = [((i, d, "t"), texts[d], Modality.TEXT) for d in range(docs)] + [((i, d, "i"), imgs[d], Modality.IMAGE) for d in range(docs)]
+        ing.submit(i, items)
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ing.collect()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    rows = ing.collect()            # the stream's ONE data-path collective: gather onto rank 0
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    n_emb = 2 * docs
+    if rank == 0:
+        assert len(rows) == args.steps * world and all(len(v) == n_emb for v in rows.values()), (len(rows), args.steps, world)
+    value = n_emb * world * args.steps / elapsed
+    # roofline of the dominant kernel family over a few more requests (HIP events on the launch streams, as in the headline)
+    roofline = gemm_roofline(lib, L, step, min(args.steps, 6), args.precision, "add_documents_stream")
+    ing.collect()
+    gf = (varch.gflop_per_image + tarch.gflop_per_text(30)) / 2
+    result = {
+        "metric": "embeddings/sec", "value": round(value, 1), "unit": "embeddings/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.precision, "data": "synthetic",
+        "config": {"workload": wl["desc"], "global_batch": n_emb * world, "docs_per_request": docs, "documents_in_stream": docs * world * args.steps,
+                   "inputs": "host PIL images + strings (the boundary add_documents hands over); host packing, H2D and the final D2H are INSIDE the timed "
+                             "region — this workload is end-to-end by definition, the tower-only figure is the headline workload's",
+                   "parallelism": f"dp{world}: replicated weights; request i belongs to rank i % {world}; no collective inside a request; ONE gather "
+                                  f"(dist.gather, not all_gather) of the ranks' [n, 512] rows onto rank 0 at the end of the stream",
+                   "weights": "random-init (seed 0) ViT-B-32", "gflop_per_embedding": round(gf, 3)},
+        "e2e_tflops": round(value * gf / 1e3, 1), "roofline": roofline,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # reference-equivalent CPU path on a bounded sample of one request: fp32 towers, 16-item batches (tokeniser time not included)
+        from oracle import towers as O
+        from marqo_amd.engine import synthetic
+        sd = synthetic.random_open_clip_state_dict(vision=varch, text=tarch, seed=0)
+        vcfg = O.VitConfig(varch.image_size, varch.patch_size, varch.width, varch.layers, varch.heads, varch.mlp_dim, varch.out_dim, varch.quick_gelu)
+        tcfg = O.ClipTextConfig(tarch.vocab, tarch.ctx, tarch.width, tarch.layers, tarch.heads, tarch.mlp_dim, tarch.out_dim, tarch.quick_gelu)
+        texts, imgs = pool[0]
+        px = torch.from_numpy(np.stack([np.asarray(im) for im in imgs]))
+        gt = torch.Generator().manual_seed(3)
+        ids = torch.zeros(docs, 77, dtype=torch.int64)
+        for i in range(docs):
+            li = int(torch.randint(5, 62, (1,), generator=gt))
+            ids[i, 0], ids[i, 1:1 + li], ids[i, 1 + li] = 49406, torch.randint(1, 49406, (li,), generator=gt), 49407
+
+        def run_items(lo, hi):      # item 2i = image i, item 2i + 1 = text i: a bounded sample keeps the 50 / 50 mix
+            i0, i1 = lo // 2, hi // 2
+            im = O.vit_forward(sd, vcfg, O.preprocess_u8_exact_size(px[i0:i1]))
+            tx = O.clip_text_forward(sd, tcfg, ids[i0:i1])
+            return torch.stack([im, tx], dim=1).reshape(-1, im.shape[1])
+        rate, n, emb, th, cores = cpu_baseline_run(run_items, 2 * docs, args.cpu_seconds)
+        result["cpu_baseline"] = _baseline_dict(rate, n, th, cores, f"items ({n // 2} images + {n // 2} texts of 5..61 tokens) of one request")
+    elif rank == 0:
+        result["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -480,6 +619,12 @@ def main():
     from marqo_amd.parallel import gather_embeddings
     lib = L.load()
 
+    if WORKLOADS[args.workload]["kind"] == "stream":
+        run_stream(args, dev, rank, world, dist, lib, L)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     if WORKLOADS[args.workload]["kind"] == "ingest":
         run_ingest(args, dev, rank, world, dist)
         if dist is not None:
@@ -487,6 +632,8 @@ def main():
             dist.destroy_process_group()
         return
 
+    if args.workload == "vit_l14_chunked_fp8":
+        args.precision = "fp8"     # the workload IS the fp8 configuration; its bf16 twin is timed beside it (`bf16_twin`)
     w = Workload(args.workload, args.precision, args.batch, dev, 1234 + rank)
     batch, kind, wl = w.batch, w.kind, w.wl
 
@@ -532,6 +679,16 @@ def main():
     }
 
     solo = rank == 0 and world == 1
+    if kind == "chunked":
+        result["config"]["crops_per_image"] = w.crops_per_image
+        result["config"]["inputs"] = "source images resident in HBM when the timed region starts; the chunker (K11) and the tower are inside it"
+        if solo:   # the same step on the bf16 tower: what the fp8 policy buys
+            twin = Workload(args.workload, "bf16", args.batch, dev, 1234 + rank)
+            el, o16 = timed(twin.run, max(3, args.steps // 2), 2, torch.cuda.synchronize)
+            v16 = twin.batch * max(3, args.steps // 2) / el
+            result["bf16_twin"] = {"value": round(v16, 1), "unit": "embeddings/s", "fp8_over_bf16": round(value / v16, 3),
+                                   "cos_err_fp8_vs_bf16": _cos_err(out.float().cpu(), o16.float().cpu())}
+            del twin
     if solo and not args.no_cpu_baseline:
         base, cos = w.cpu_baseline(out, args.cpu_seconds)
         if base is not None:

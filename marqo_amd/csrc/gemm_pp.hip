@@ -540,7 +540,8 @@ int mq_gemm_pp_plan(int M, int N, int K, int flags, bool inplace) {
     // QUICKGELU: the interleaved epilogue returns wrong swapped halves next to the division sequences (profiles/r03b_pp_diag.txt) — not routed here
     if (flags & MQ_EPI_QUICKGELU) return 0;
     // the fp32-residual epilogue at 4 units per k-step (needed below 9 k-steps) is the one instantiation that spills: not built
-    if (g_pp.waves == 4 && flags == (MQ_EPI_BIAS | MQ_EPI_RESIDUAL | MQ_EPI_OUT_F32) && (nk < 9 || g_pp.pps == 4)) return 0;
+    const bool f32res = flags == (MQ_EPI_BIAS | MQ_EPI_RESIDUAL | MQ_EPI_OUT_F32), f32bias = flags == (MQ_EPI_BIAS | MQ_EPI_OUT_F32);
+    if ((f32res || (f32bias && g_pp.waves != 4)) && (nk < 9 || g_pp.pps == 4)) return 0;
     if (g_pp.on == 1) {
         // cost model against the two-workgroups-per-CU kernel: one-per-CU tiles of 128 x 256 in rounds of 256; a ragged last round
         // costs a whole round.  Take the big tile when its rounds are at least 70 % full.
@@ -569,7 +570,12 @@ int mq_launch_gemm_pp(int mt, const void* A, int64_t lda, const void* W, int64_t
         }
     }
     if (light) return launch_pp<FLAGS, 4, 1, 4>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, cgroup_knob, s);
-    return launch_pp<FLAGS, 4, 2, 4>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, cgroup_knob, s);
+    if constexpr (F32RES || FLAGS == (MQ_EPI_BIAS | MQ_EPI_OUT_F32)) {   // (the two 8-wave instantiations that spill: not built)
+        mq_set_error("mq_gemm_bf16(pp): this fp32 epilogue needs K >= 576");   // (mq_gemm_pp_plan never sends it here)
+        return MQ_ERR_INVALID;
+    } else {
+        return launch_pp<FLAGS, 4, 2, 4>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, cgroup_knob, s);
+    }
 }
 
 #define MQ_PP_INST(F)                                                                                                              \

@@ -91,19 +91,39 @@ extern "C" int mq_host_gather(const void* const* h_src, const int64_t* h_bytes, 
             if (h_bytes[i]) memcpy((char*)h_dst + h_dst_off[i], h_src[i], (size_t)h_bytes[i]);
     };
     if (t == 1) { work(0, n); return MQ_OK; }
-    // contiguous item ranges of about total / t bytes each
+    // contiguous item ranges of about total / t bytes each.  A thread that cannot be created (pid / thread limits of a container:
+    // std::system_error) must not escape an extern "C" function — std::terminate would take the whole server down: the calling thread
+    // then copies that range and everything after it itself (as csrc/py_stage.cpp does), and every started thread is joined on all paths.
     std::vector<std::thread> pool;
     int64_t lo = 0, acc = 0;
     const int64_t share = (total + t - 1) / t;
-    for (int64_t i = 0; i < n; ++i) {
-        acc += h_bytes[i];
-        if (acc >= share || i == n - 1) {
-            if (i == n - 1 || (int)pool.size() == t - 1) { work(lo, n); break; }   // the calling thread takes the last range
-            pool.emplace_back(work, lo, i + 1);
-            lo = i + 1;
-            acc = 0;
+    try {
+        pool.reserve((size_t)t);
+        for (int64_t i = 0; i < n; ++i) {
+            acc += h_bytes[i];
+            if (acc >= share || i == n - 1) {
+                if (i == n - 1 || (int)pool.size() == t - 1) break;   // the calling thread takes the last range
+                pool.emplace_back(work, lo, i + 1);
+                lo = i + 1;
+                acc = 0;
+            }
         }
+    } catch (...) {
+        // (lo still names the first item no thread owns)
     }
+    work(lo, n);
     for (auto& th : pool) th.join();
     return MQ_OK;
+}
+
+// same, with the destination's capacity: every item must lie inside [0, dst_bytes)
+extern "C" int mq_host_gather_checked(const void* const* h_src, const int64_t* h_bytes, const int64_t* h_dst_off, int64_t n, void* h_dst,
+                                      int64_t dst_bytes, int32_t threads) {
+    if (n <= 0) return MQ_OK;
+    MQ_CHECK_ARG(h_bytes && h_dst_off && dst_bytes >= 0, "mq_host_gather_checked: null pointer");
+    for (int64_t i = 0; i < n; ++i)
+        MQ_CHECK_ARG(h_bytes[i] >= 0 && h_dst_off[i] >= 0 && h_dst_off[i] <= dst_bytes && h_bytes[i] <= dst_bytes - h_dst_off[i],
+                     "mq_host_gather_checked: item %ld (%ld bytes at %ld) leaves the %ld-byte destination", (long)i, (long)h_bytes[i],
+                     (long)h_dst_off[i], (long)dst_bytes);
+    return mq_host_gather(h_src, h_bytes, h_dst_off, n, h_dst, threads);
 }

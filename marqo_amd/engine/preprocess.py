@@ -260,11 +260,20 @@ class ImagePreprocessor:
         self.mean = (C.c_float * 3)(*mean)
         self.std = (C.c_float * 3)(*std)
         self._ws = None
+        self._ws_stream = None
 
     def _workspace(self, nbytes: int) -> torch.Tensor:
-        if self._ws is None or self._ws.numel() < nbytes:
+        """scratch of the CURRENT stream.  The same thread calls from two streams (`.preprocess` from the download threads' default
+        stream, encode() from its request stream): the caching allocator hands a freed block back to the pool of the stream it was
+        allocated on, where a later allocation may take it while kernels enqueued on the OTHER stream still use it — so a block that was
+        used on another stream is first marked as in use there (record_stream) and a change of stream gets a fresh block."""
+        cur = torch.cuda.current_stream(self.device)
+        if self._ws is not None and (self._ws_stream != cur.cuda_stream or self._ws.numel() < nbytes):
+            self._ws.record_stream(cur)     # whatever was enqueued with it so far must finish before the allocator recycles it
             self._ws = None
+        if self._ws is None:
             self._ws = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=self.device)
+            self._ws_stream = cur.cuda_stream
         return self._ws
 
     def _stream(self) -> int:
