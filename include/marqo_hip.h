@@ -221,6 +221,9 @@ const char* mq_build_arch(void);
 /* Host-side staging helper (no GPU work): copy n host buffers to h_dst + h_dst_off[i] with up to `threads` copy threads, in one call
  * (the Python loaders pack a request's decoded images into one pinned buffer this way: one GIL release per request). */
 int mq_host_gather(const void* const* h_src, const int64_t* h_bytes, const int64_t* h_dst_off, int64_t n, void* h_dst, int32_t threads);
+/* the same with the destination's capacity in bytes: an item that would leave [0, dst_bytes) is refused (MQ_ERR_INVALID) before any copy */
+int mq_host_gather_checked(const void* const* h_src, const int64_t* h_bytes, const int64_t* h_dst_off, int64_t n, void* h_dst,
+                           int64_t dst_bytes, int32_t threads);
 
 /* ---- workspace sizing (bytes of device scratch the caller must provide) ------------- */
 /* rows = total token rows in the call (images: n*T; text: sum of sequence lengths);

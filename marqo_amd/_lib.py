@@ -174,6 +174,7 @@ _SIGNATURES = {
     "mq_chunk_grid_u8": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P,
                                    C.c_size_t, _P]),
     "mq_host_gather": (C.c_int, [_P, _P, _P, C.c_int64, _P, C.c_int32]),
+    "mq_host_gather_checked": (C.c_int, [_P, _P, _P, C.c_int64, _P, C.c_int64, C.c_int32]),
     "mq_unpack_rgbx": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int64, _P, _P]),
     "mq_to_tensor_normalize": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float), _P]),
     "mq_resample_ksize": (C.c_int, [C.c_int32, C.c_int32]),

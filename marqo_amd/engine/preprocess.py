@@ -216,12 +216,13 @@ class PackedImages:
             for c in range(pieces):
                 k0, k1 = c * self.n // pieces, (c + 1) * self.n // pieces
                 sub = (C.c_void_p * (k1 - k0))(*srcs[k0:k1])
-                L.check(lib.mq_host_gather(sub, nbytes[k0:k1].ctypes.data, dsts[k0:k1].ctypes.data, k1 - k0, host.data_ptr(), PACK_THREADS),
-                        "mq_host_gather")
+                L.check(lib.mq_host_gather_checked(sub, nbytes[k0:k1].ctypes.data, dsts[k0:k1].ctypes.data, k1 - k0, host.data_ptr(),
+                                                   host.numel(), PACK_THREADS), "mq_host_gather")
                 lo, hi = int(dsts[k0]), (int(dsts[k1]) if k1 < self.n else end)
                 staged[lo:hi].copy_(host[lo:hi], non_blocking=True)
         elif ne:
-            L.check(lib.mq_host_gather(srcs, nbytes.ctypes.data, dsts.ctypes.data, ne, host.data_ptr(), PACK_THREADS), "mq_host_gather")
+            L.check(lib.mq_host_gather_checked(srcs, nbytes.ctypes.data, dsts.ctypes.data, ne, host.data_ptr(), host.numel(), PACK_THREADS),
+                    "mq_host_gather")
         del keep
         if nx:
             jobs = np.ascontiguousarray(np.stack([x_off[is_x], self.offsets[is_x], npix[is_x]], axis=1), dtype=np.int64)

@@ -118,7 +118,7 @@ def _sniff_mime_family(head: bytes) -> Optional[str]:
     return None
 
 
-def infer_modality(content) -> Modality:
+def infer_modality(content, media_download_headers: Optional[dict] = None, timeout_ms: int = 3000) -> Modality:
     """multimodal_model_load.py:148-203, the function the reference's search and add_documents paths import FROM this module
     (tensor_search.py:74, add_docs.py:24-25).  A string that is not a URL is text; a URL is classified by its extension (image / video /
     audio lists of the reference), else by the first 10 KB of what it serves; bytes by their signature; anything else is text.  Video and
@@ -139,7 +139,9 @@ def infer_modality(content) -> Modality:
         except ImportError:
             return Modality.TEXT
         try:
-            resp = requests.get(encoded, stream=True)
+            # (connect, read) timeouts and the request's media download headers: an unresponsive host must not park a search / add_documents
+            # request thread for ever (the reference's probe has neither, multimodal_model_load.py:171-177)
+            resp = requests.get(encoded, stream=True, timeout=(timeout_ms / 1000.0, timeout_ms / 1000.0), headers=media_download_headers or None)
             try:
                 head = b""
                 for chunk in resp.iter_content(chunk_size=8192):

@@ -57,3 +57,21 @@ def test_product_never_imports_the_oracle():
                 src = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(dp, f)
                 assert "liboracle" not in src
+
+
+def test_host_gather_checked_bounds_and_copies():
+    """mq_host_gather_checked: the destination's capacity is validated before any byte moves; within bounds it is mq_host_gather"""
+    import ctypes as C
+    import numpy as np
+    from marqo_amd import _lib as L
+    lib = L.load()
+    srcs_np = [np.arange(n, dtype=np.uint8) for n in (1000, 0, 5_000_000, 777)]
+    offs = np.asarray([0, 1024, 1024, 5_001_200], dtype=np.int64)
+    nbytes = np.asarray([a.nbytes for a in srcs_np], dtype=np.int64)
+    dst = np.zeros(5_002_000, dtype=np.uint8)
+    srcs = (C.c_void_p * 4)(*[a.ctypes.data for a in srcs_np])
+    L.check(lib.mq_host_gather_checked(srcs, nbytes.ctypes.data, offs.ctypes.data, 4, dst.ctypes.data, dst.nbytes, 4))
+    for a, o in zip(srcs_np, offs):
+        assert np.array_equal(dst[o:o + a.nbytes], a)
+    rc = lib.mq_host_gather_checked(srcs, nbytes.ctypes.data, offs.ctypes.data, 4, dst.ctypes.data, 5_001_900, 4)   # the last item would overrun
+    assert rc != 0 and b"leaves" in lib.mq_last_error()

@@ -483,7 +483,7 @@ def test_bench_workload_table_resolves():
     spec.loader.exec_module(bench)
     assert "vit_b32_image" in bench.WORKLOADS and bench.BF16_DENSE_PEAK_TFLOPS == 2500.0
     for name, wl in bench.WORKLOADS.items():
-        assert wl["kind"] in ("image", "clip_text", "bert", "mixed", "ingest") and wl["batch"] > 0, name
+        assert wl["kind"] in ("image", "clip_text", "bert", "mixed", "ingest", "chunked", "stream") and wl["batch"] > 0, name
         if wl["kind"] == "bert":
             assert A.HF_BERT_ARCHS[wl["arch"]].gflop_per_text(77) > 0
         else:
@@ -538,3 +538,30 @@ def test_infer_modality_by_signature_and_extension():
     assert s2.infer_modality(b"OggS\x00\x02") == M.AUDIO and s2.infer_modality(b"just some text bytes") == M.TEXT and s2.infer_modality(b"") == M.TEXT
     assert s2.validate_url("https://example.com/x") and not s2.validate_url("not a url") and not s2.validate_url(3)
     assert s2.encode_url("https://example.com/ü b") == "https://example.com/%C3%BC%20b"
+
+
+def test_infer_modality_probe_has_a_timeout_and_forwards_headers():
+    """ADVICE r2: the extension-less-URL probe must not hang a request thread: (connect, read) timeout + the request's download headers;
+    a timeout surfaces as MediaDownloadError"""
+    import requests
+    from marqo_amd.s2_inference.errors import MediaDownloadError
+    seen = {}
+
+    class Resp:
+        def iter_content(self, chunk_size):
+            yield b"\x89PNG\r\n\x1a\n" + b"0" * 100
+
+        def close(self):
+            pass
+
+    def fake_get(url, **kw):
+        seen.update(kw, url=url)
+        return Resp()
+    with mock.patch.object(requests, "get", fake_get):
+        m = s2_inference.infer_modality("http://example.com/some/media", media_download_headers={"Authorization": "x"}, timeout_ms=1500)
+    assert m == Modality.IMAGE and seen["timeout"] == (1.5, 1.5) and seen["headers"] == {"Authorization": "x"} and seen["stream"] is True
+
+    def slow_get(url, **kw):
+        raise requests.exceptions.ReadTimeout("too slow")
+    with mock.patch.object(requests, "get", slow_get), pytest.raises(MediaDownloadError):
+        s2_inference.infer_modality("http://example.com/some/media")
