@@ -25,6 +25,7 @@ extern int mq_gemm_fp8_force_mt;  // gemm_fp8.hip
 extern int mq_tower_row_select;   // towers.hip
 extern int mq_tower_ln_fold;      // towers.hip
 extern int mq_ln_rows_per_wave;   // rowops.hip
+extern int mq_ln_bf16_wide;       // rowops.hip
 extern int mq_attention_waves;    // attention.hip
 extern int mq_tower_residual_bf16;  // towers.hip
 extern int mq_gemm_small_max_rows;  // gemm_small.hip
@@ -574,6 +575,7 @@ extern "C" int mq_tune(const char* key, int value) {
     else if (k == "row_select") mq_tower_row_select = value;
     else if (k == "ln_fold") mq_tower_ln_fold = value;
     else if (k == "ln_rows") mq_ln_rows_per_wave = value;
+    else if (k == "ln_bf16_wide") mq_ln_bf16_wide = value;
     else if (k == "attn_waves") mq_attention_waves = value;
     else if (k == "residual_bf16") mq_tower_residual_bf16 = value;
     else if (k == "small_m") mq_gemm_small_max_rows = value;

@@ -5,6 +5,7 @@
 #include "common.h"
 
 int mq_ln_rows_per_wave = getenv("MQ_LN_ROWS") ? atoi(getenv("MQ_LN_ROWS")) : 2;  // mq_tune("ln_rows", 1 | 2)
+int mq_ln_bf16_wide = getenv("MQ_LN_BF16_WIDE") ? atoi(getenv("MQ_LN_BF16_WIDE")) : 1;   // mq_tune("ln_bf16_wide", 0 | 1): 16-byte bf16-input LayerNorm
 
 namespace {
 
@@ -108,6 +109,96 @@ __global__ __launch_bounds__(256, (CH * R <= 4 ? 8 : 4)) void layernorm_kernel(
     }
 }
 
+// bf16 rows in (the bf16 residual stream of the pre-LN towers) -> LN -> bf16 (and / or fp32) out, EIGHT elements per lane and chunk: 16-byte
+// loads AND 16-byte stores (the generic kernel above reads a bf16 row 8 bytes per lane: half the bytes per request of the fp32 form it
+// was written for — on the bf16 stream it took 13.6 us per launch against 12.7 us for TWICE the bytes in fp32, profiles/r03a_*).
+// R rows per wave keep the bytes in flight per wave where the fp32 two-row form has them (a 768-wide bf16 row is only 1.5 KB).
+// Same arithmetic, same reduction order across the lanes' partial sums as ln_normalize_row up to the grouping of a lane's own elements.
+template <int CH8, int R>
+__global__ __launch_bounds__(256, (CH8 * R <= 4 ? 8 : 4)) void layernorm_bf16in_kernel(
+    const bf16_t* __restrict__ x, const int32_t* __restrict__ row_idx, const float* __restrict__ gam, const float* __restrict__ bet,
+    bf16_t* out_bf16, float* out_f32, int64_t rows, int W, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+    if (row0 >= rows) return;
+    const int nch = W >> 3;  // 8-element chunks in the row
+    float v[R][CH8][8];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int64_t row = row0 + r < rows ? row0 + r : rows - 1;
+        const int64_t src = row_idx ? (int64_t)row_idx[row] : row;
+#pragma unroll
+        for (int i = 0; i < CH8; ++i) {
+            const int c = lane + i * 64;
+            uint4 q = make_uint4(0u, 0u, 0u, 0u);
+            if (c < nch) q = *(const uint4*)(x + src * W + c * 8);
+            const unsigned w4[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[r][i][2 * e] = __uint_as_float(w4[e] << 16); v[r][i][2 * e + 1] = __uint_as_float(w4[e] & 0xffff0000u); }
+        }
+    }
+    f32x4 gv[CH8][2], bv[CH8][2];
+#pragma unroll
+    for (int i = 0; i < CH8; ++i) {
+        const int c = lane + i * 64;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            gv[i][h] = c < nch ? *(const f32x4*)(gam + c * 8 + h * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            bv[i][h] = c < nch ? *(const f32x4*)(bet + c * 8 + h * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    float mean[R], rstd[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        float s1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < CH8; ++i)
+            if (lane + i * 64 < nch) s1 += ((v[r][i][0] + v[r][i][1]) + (v[r][i][2] + v[r][i][3])) + ((v[r][i][4] + v[r][i][5]) + (v[r][i][6] + v[r][i][7]));
+        mean[r] = s1;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int r = 0; r < R; ++r) mean[r] += __shfl_xor(mean[r], o, 64);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        mean[r] = mean[r] / (float)W;
+        float s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < CH8; ++i)
+            if (lane + i * 64 < nch) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = v[r][i][e] - mean[r]; s2 += d * d; }
+            }
+        rstd[r] = s2;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int r = 0; r < R; ++r) rstd[r] += __shfl_xor(rstd[r], o, 64);
+#pragma unroll
+    for (int r = 0; r < R; ++r) rstd[r] = rsqrtf(rstd[r] / (float)W + eps);
+#pragma unroll
+    for (int i = 0; i < CH8; ++i) {
+        const int c = lane + i * 64;
+        if (c >= nch) continue;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int64_t row = row0 + r;
+            if (row >= rows) continue;
+            float y[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) y[e] = (v[r][i][e] - mean[r]) * rstd[r] * gv[i][e >> 2][e & 3] + bv[i][e >> 2][e & 3];
+            if (out_f32) {
+                *(f32x4*)(out_f32 + row * W + c * 8) = f32x4{y[0], y[1], y[2], y[3]};
+                *(f32x4*)(out_f32 + row * W + c * 8 + 4) = f32x4{y[4], y[5], y[6], y[7]};
+            }
+            if (out_bf16)
+                *(uint4*)(out_bf16 + row * W + c * 8) = make_uint4(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]), pack_bf16x2(y[6], y[7]));
+        }
+    }
+}
+
 // LN with e4m3 output and a dynamic per-row scale (the row is already in registers, so the absmax is one wave reduction)
 // NORM = false: no normalisation / affine, only the per-row e4m3 quantisation of x itself (the first block of a post-LN fp8
 // encoder, whose input rows come from the embedding kernels)
@@ -195,7 +286,18 @@ extern "C" int mq_layernorm_ex(const void* d_x, int x_bf16, const int32_t* d_row
     hipStream_t s = (hipStream_t)stream;
     MqProfScope prof(1, s);
     // two rows per wave once there are enough rows to fill the chip that way (and the row fits: CH * 2 float4 per lane)
-    if (x_bf16) {
+    if (x_bf16 && mq_ln_bf16_wide && W % 8 == 0 && W <= 1024 && ((uintptr_t)d_x & 15) == 0 && (!d_out_bf16 || ((uintptr_t)d_out_bf16 & 15) == 0)) {
+        // 16-byte form: W / 8 chunks over 64 lanes -> 1 (W <= 512) or 2 chunks per lane; 4 rows per wave once the chip is full that way
+        const bf16_t* xb = (const bf16_t*)d_x;
+        const bool many = rows >= 16384;
+        if (W <= 512) {
+            if (many) hipLaunchKernelGGL((layernorm_bf16in_kernel<1, 4>), dim3((unsigned)cdiv64(rows, 16)), dim3(256), 0, s, xb, d_row_idx, d_g, d_b, (bf16_t*)d_out_bf16, d_out_f32, rows, (int)W, eps);
+            else hipLaunchKernelGGL((layernorm_bf16in_kernel<1, 1>), dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, s, xb, d_row_idx, d_g, d_b, (bf16_t*)d_out_bf16, d_out_f32, rows, (int)W, eps);
+        } else {
+            if (rows >= 8192) hipLaunchKernelGGL((layernorm_bf16in_kernel<2, 2>), dim3((unsigned)cdiv64(rows, 8)), dim3(256), 0, s, xb, d_row_idx, d_g, d_b, (bf16_t*)d_out_bf16, d_out_f32, rows, (int)W, eps);
+            else hipLaunchKernelGGL((layernorm_bf16in_kernel<2, 1>), dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, s, xb, d_row_idx, d_g, d_b, (bf16_t*)d_out_bf16, d_out_f32, rows, (int)W, eps);
+        }
+    } else if (x_bf16) {
         if (mq_ln_rows_per_wave >= 2 && rows >= 8192 && W <= 1024)
             MQ_DISPATCH_CH(W, hipLaunchKernelGGL((layernorm_kernel<CH, 2, true>), dim3((unsigned)cdiv64(rows, 8)), dim3(256), 0, s, d_x, d_row_idx,
                                                  d_g, d_b, (bf16_t*)d_out_bf16, d_out_f32, rows, (int)W, eps));

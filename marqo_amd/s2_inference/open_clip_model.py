@@ -100,11 +100,6 @@ class OpenCLIPModelProperties:
 
 
 STAGE_BYTES = int(os.environ.get("MARQO_AMD_IMAGE_STAGE_BYTES", str(1 << 30)))   # decoded pixel bytes staged per resize call (pinned host + HBM)
-# Experiment knob, off by default and NOT yet measured or parity-checked on the GPU (queued in tools/gpu_next_ab.sh): `.preprocess` keeps the
-# resized uint8 image beside the fp32 tensor it returns; a later encode_image() on a list of such tensors (the add_documents flow:
-# add_docs.py:130-134, then vectorise) stacks 150 KB uint8 images and runs the uint8 tower entry instead of stacking 600 KB fp32 tensors.
-# A tensor modified in place since (its `_version` moved) or moved to another device loses the side-car and takes the fp32 route.
-PREPROCESS_SIDECAR = os.environ.get("MARQO_AMD_PREPROCESS_SIDECAR", "0") == "1"
 PIPELINE_CHUNK = int(os.environ.get("MARQO_AMD_IMAGE_PIPELINE_CHUNK", "512"))  # images per host-pack / GPU-encode pipeline stage (smaller chunks cost GEMM efficiency: 64-image chunks ran 256 images in 5.5 ms instead of 3.2, profiles/r02g_e2e_profile.txt)
 
 
@@ -363,22 +358,7 @@ class OPEN_CLIP(AbstractCLIPModel):
         Callers' `.to(device)` (add_docs.py:134) is then a no-op."""
         pre = self._pre()
         u8 = self._resize(pre, [pil_to_pixels(image)])
-        out = pre.to_tensor_normalize(u8)[0]
-        if PREPROCESS_SIDECAR:
-            out._mq_u8, out._mq_version = u8[0], out._version
-        return out
-
-    def _sidecars(self, tensors) -> Optional[torch.Tensor]:
-        """uint8 [n, S, S, 3] when EVERY tensor still carries the resized image `.preprocess` made it from, else None"""
-        if not PREPROCESS_SIDECAR:
-            return None
-        u8s = []
-        for t in tensors:
-            u8 = getattr(t, "_mq_u8", None)
-            if u8 is None or getattr(t, "_mq_version", -1) != t._version or u8.device != t.device or str(t.device) != str(torch.device(self.device)):
-                return None
-            u8s.append(u8)
-        return torch.stack(u8s) if u8s else None
+        return pre.to_tensor_normalize(u8)[0]
 
     def _resize(self, pre, raw) -> torch.Tensor:
         """list of uint8 [H, W, 3] -> uint8 [n, S, S, 3] on the device: Resize(S) + CenterCrop(S), or Resize((S, S)) ('squash').
@@ -420,9 +400,6 @@ class OPEN_CLIP(AbstractCLIPModel):
         tensors = [i for i in loaded if isinstance(i, torch.Tensor)]
         pre = self._pre()
         if len(tensors) == len(loaded):
-            side = self._sidecars(tensors)
-            if side is not None:
-                return "u8", side
             return "f32", torch.stack([t.to(self.device) for t in tensors])
         raw = [i if isinstance(i, np.ndarray) else pil_to_pixels(i) for i in loaded if not isinstance(i, torch.Tensor)]
         u8 = self._resize(pre, raw)

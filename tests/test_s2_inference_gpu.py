@@ -665,29 +665,3 @@ def test_image_staging_is_bounded_by_bytes(s2, monkeypatch):
     assert torch.equal(model.image_input_processed, whole_px) and _cos_err(split, whole) < 3e-5
 
 
-@pytest.mark.skipif(os.environ.get("MARQO_AMD_PREPROCESS_SIDECAR") != "1",
-                    reason="experiment knob, off by default: run with MARQO_AMD_PREPROCESS_SIDECAR=1 (tools/gpu_next_ab.sh)")
-def test_preprocess_sidecar_route_matches_the_uint8_route(s2):
-    """MARQO_AMD_PREPROCESS_SIDECAR=1: tensors returned by `.preprocess` carry the resized uint8 image; encode_image on a list of them must
-    take the uint8 tower entry (bit-identical to handing over the PIL images) and fall back to the fp32 route as soon as one tensor was
-    modified in place, cloned or came from elsewhere"""
-    s2i, root = s2
-    props, sd, vcfg, tcfg = _tiny_clip(root)
-    model, pre = s2i.load_multimodal_model_and_get_preprocessors("tiny-clip", props, DEV)
-    rng = np.random.default_rng(3)
-    pil = [Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)) for h, w in [(64, 64), (100, 80), (70, 200), (33, 47)]]
-    via_u8 = model.encode_image(pil)
-    tensors = [pre["image"](p) for p in pil]
-    assert all(getattr(t, "_mq_u8", None) is not None for t in tensors)
-    kind, px = model._preprocess_images(tensors)
-    assert kind == "u8" and px.dtype == torch.uint8 and tuple(px.shape) == (4, 64, 64, 3)
-    assert np.array_equal(model.encode_image(tensors), via_u8)
-    assert np.array_equal(model.encode_image([t.to(DEV) for t in tensors]), via_u8)          # add_docs.py:134: .to(device) keeps the object
-    clones = [t.clone() for t in tensors]                                                     # no side-car: the fp32 route
-    kind, _ = model._preprocess_images(clones)
-    assert kind == "f32"
-    via_f32 = model.encode_image(clones)
-    assert _cos_err(via_f32, via_u8) < 3e-5
-    tensors[1].mul_(1.0)                                                                      # in-place edit: the side-car is stale
-    kind, _ = model._preprocess_images(tensors)
-    assert kind == "f32" and np.array_equal(model.encode_image(tensors), via_f32)
