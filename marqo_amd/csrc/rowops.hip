@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256, (CH * R <= 4 ? 8 : 4)) void layernorm_kernel(
 // R rows per wave keep the bytes in flight per wave where the fp32 two-row form has them (a 768-wide bf16 row is only 1.5 KB).
 // Same arithmetic, same reduction order across the lanes' partial sums as ln_normalize_row up to the grouping of a lane's own elements.
 template <int CH8, int R>
-__global__ __launch_bounds__(256, (CH8 * R <= 4 ? 8 : 4)) void layernorm_bf16in_kernel(
+__global__ __launch_bounds__(256) void layernorm_bf16in_kernel(
     const bf16_t* __restrict__ x, const int32_t* __restrict__ row_idx, const float* __restrict__ gam, const float* __restrict__ bet,
     bf16_t* out_bf16, float* out_f32, int64_t rows, int W, float eps) {
     const int lane = threadIdx.x & 63;
@@ -286,15 +286,19 @@ extern "C" int mq_layernorm_ex(const void* d_x, int x_bf16, const int32_t* d_row
     hipStream_t s = (hipStream_t)stream;
     MqProfScope prof(1, s);
     // two rows per wave once there are enough rows to fill the chip that way (and the row fits: CH * 2 float4 per lane)
-    if (x_bf16 && mq_ln_bf16_wide && W % 8 == 0 && W <= 1024 && ((uintptr_t)d_x & 15) == 0 && (!d_out_bf16 || ((uintptr_t)d_out_bf16 & 15) == 0)) {
+    // (batches only: a handful of rows — the search path — keeps the generic kernel, whose summation order the fused LayerNorm prologue of
+    // gemm_small.hip reproduces bit for bit)
+    if (x_bf16 && mq_ln_bf16_wide && rows >= 1024 && W % 8 == 0 && W <= 1024 && ((uintptr_t)d_x & 15) == 0 && (!d_out_bf16 || ((uintptr_t)d_out_bf16 & 15) == 0)) {
         // 16-byte form: W / 8 chunks over 64 lanes -> 1 (W <= 512) or 2 chunks per lane; 4 rows per wave once the chip is full that way
         const bf16_t* xb = (const bf16_t*)d_x;
         const bool many = rows >= 16384;
         if (W <= 512) {
-            if (many) hipLaunchKernelGGL((layernorm_bf16in_kernel<1, 4>), dim3((unsigned)cdiv64(rows, 16)), dim3(256), 0, s, xb, d_row_idx, d_g, d_b, (bf16_t*)d_out_bf16, d_out_f32, rows, (int)W, eps);
+            if (many && mq_ln_bf16_wide < 4) hipLaunchKernelGGL((layernorm_bf16in_kernel<1, 2>), dim3((unsigned)cdiv64(rows, 8)), dim3(256), 0, s, xb, d_row_idx, d_g, d_b, (bf16_t*)d_out_bf16, d_out_f32, rows, (int)W, eps);
+            else if (many) hipLaunchKernelGGL((layernorm_bf16in_kernel<1, 4>), dim3((unsigned)cdiv64(rows, 16)), dim3(256), 0, s, xb, d_row_idx, d_g, d_b, (bf16_t*)d_out_bf16, d_out_f32, rows, (int)W, eps);
             else hipLaunchKernelGGL((layernorm_bf16in_kernel<1, 1>), dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, s, xb, d_row_idx, d_g, d_b, (bf16_t*)d_out_bf16, d_out_f32, rows, (int)W, eps);
         } else {
-            if (rows >= 8192) hipLaunchKernelGGL((layernorm_bf16in_kernel<2, 2>), dim3((unsigned)cdiv64(rows, 8)), dim3(256), 0, s, xb, d_row_idx, d_g, d_b, (bf16_t*)d_out_bf16, d_out_f32, rows, (int)W, eps);
+            if (rows >= 16384 && mq_ln_bf16_wide >= 4) hipLaunchKernelGGL((layernorm_bf16in_kernel<2, 4>), dim3((unsigned)cdiv64(rows, 16)), dim3(256), 0, s, xb, d_row_idx, d_g, d_b, (bf16_t*)d_out_bf16, d_out_f32, rows, (int)W, eps);
+            else if (rows >= 8192) hipLaunchKernelGGL((layernorm_bf16in_kernel<2, 2>), dim3((unsigned)cdiv64(rows, 8)), dim3(256), 0, s, xb, d_row_idx, d_g, d_b, (bf16_t*)d_out_bf16, d_out_f32, rows, (int)W, eps);
             else hipLaunchKernelGGL((layernorm_bf16in_kernel<2, 1>), dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, s, xb, d_row_idx, d_g, d_b, (bf16_t*)d_out_bf16, d_out_f32, rows, (int)W, eps);
         }
     } else if (x_bf16) {
