@@ -132,7 +132,11 @@ typedef struct mq_encoder_cfg {
      * scale, which the kernel applies to the sum), rel_span >= the longest sequence run.  bf16 path, 64-wide heads, unmasked attention. */
     const float* d_rel_bias;
     int32_t      rel_span;
-    int32_t      reserved0;
+    int32_t      residual_stream; /* pre-LN bf16 encoders: 0 = the process default (mq_tune("residual_bf16") / MQ_RESIDUAL_BF16, fp32 unless set),
+                                   * 1 = bf16 residual stream (x kept in bf16 between blocks: half the bytes of every residual epilogue and
+                                   * LayerNorm), 2 = fp32.  The loaders decide 1 / 2 per MODEL at load on a fixed seeded batch
+                                   * (engine/towers.py::tune_residual_stream: bf16 only where it stays within a 1 - cos budget of the fp32
+                                   * stream).  (Took the slot of the former reserved0: the layout is unchanged.) */
 } mq_encoder_cfg;
 
 /* ---- towers ------------------------------------------------------------------------ */

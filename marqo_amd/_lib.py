@@ -65,7 +65,7 @@ class EncoderCfg(C.Structure):
                 ("act", C.c_int32), ("post_ln", C.c_int32), ("mask", C.c_int32), ("ln_eps", C.c_float),
                 ("precision", C.c_int32), ("attn_width", C.c_int32), ("fp8_first_layer", C.c_int32), ("mlp_glu", C.c_int32),
                 ("d_fp8_act_scale", C.c_void_p), ("d_fp8_act_amax", C.c_void_p), ("d_rope_inv_freq", C.c_void_p),
-                ("d_rel_bias", C.c_void_p), ("rel_span", C.c_int32), ("reserved0", C.c_int32)]
+                ("d_rel_bias", C.c_void_p), ("rel_span", C.c_int32), ("residual_stream", C.c_int32)]
 
 
 class MapHead(C.Structure):

@@ -286,9 +286,9 @@ extern "C" int mq_layernorm_ex(const void* d_x, int x_bf16, const int32_t* d_row
     hipStream_t s = (hipStream_t)stream;
     MqProfScope prof(1, s);
     // two rows per wave once there are enough rows to fill the chip that way (and the row fits: CH * 2 float4 per lane)
-    // (batches only: a handful of rows — the search path — keeps the generic kernel, whose summation order the fused LayerNorm prologue of
-    // gemm_small.hip reproduces bit for bit)
-    if (x_bf16 && mq_ln_bf16_wide && rows >= 1024 && W % 8 == 0 && W <= 1024 && ((uintptr_t)d_x & 15) == 0 && (!d_out_bf16 || ((uintptr_t)d_out_bf16 & 15) == 0)) {
+    // (every row count takes the same form: an embedding must not depend on what else shares its batch.  The fused LayerNorm prologue of
+    // gemm_small.hip — the search path — sums a row in the generic kernel's lane order: equal to this one to fp32 rounding, not bit for bit)
+    if (x_bf16 && mq_ln_bf16_wide && W % 8 == 0 && W <= 1024 && ((uintptr_t)d_x & 15) == 0 && (!d_out_bf16 || ((uintptr_t)d_out_bf16 & 15) == 0)) {
         // 16-byte form: W / 8 chunks over 64 lanes -> 1 (W <= 512) or 2 chunks per lane; 4 rows per wave once the chip is full that way
         const bf16_t* xb = (const bf16_t*)d_x;
         const bool many = rows >= 16384;

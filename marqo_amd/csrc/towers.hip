@@ -60,7 +60,8 @@ static int ln_gemm(const void* d_x, int xb, const float* g, const float* b, floa
 }
 // true when a tower with this encoder config keeps its residual stream in bf16
 static bool stream_bf16(const mq_encoder_cfg* c) {
-    return mq_tower_residual_bf16 && c->precision == MQ_PREC_BF16 && !c->post_ln && !(mq_tower_ln_fold) && !c->mlp_glu && !c->d_rope_inv_freq;
+    const bool want = c->residual_stream == 1 || (c->residual_stream == 0 && mq_tower_residual_bf16);   // per-model policy, else the process default
+    return want && c->precision == MQ_PREC_BF16 && !c->post_ln && !(mq_tower_ln_fold) && !c->mlp_glu && !c->d_rope_inv_freq;
 }
 
 extern "C" int mq_gemm_bf16_ln(const void* d_A, int64_t lda, const void* d_W, int64_t ldw, const float* d_bias, const float* d_residual,

@@ -382,6 +382,42 @@ class _TowerBase:
         self._fp8.attach(self.cfg.enc, calibrating=False)
         self._fp8.calibrated = True
 
+    # ---- residual-stream policy -----------------------------------------------------------------------------------------------
+    # Keeping x in bf16 between the blocks of a pre-LN tower halves the bytes of every residual epilogue and LayerNorm: +3.6 % (ViT-B/32),
+    # +7 % (ViT-L/14), +13 % (CLIP text B/32) embeddings/s (profiles/r03f_residual_ln_ab.txt).  What it costs is MODEL dependent: 4.7e-5 ..
+    # 1.2e-4 of cosine error on the registry-shaped fixtures, but 7.8e-3 on the SigLIP-small golden text tower, whose residual stream carries
+    # values two orders of magnitude above its per-block updates (8 mantissa bits then drop most of an update).  So it is decided per model,
+    # deterministically at load, like the fp8 split: the fixed seeded calibration batch runs through both forms and bf16 is kept only when
+    # max (1 - cos) against the fp32 stream is within the budget.  MARQO_AMD_RESIDUAL_STREAM = auto (default) | fp32 | bf16.
+    RESIDUAL_STREAM_BUDGET = float(os.environ.get("MARQO_AMD_RESIDUAL_STREAM_BUDGET", "2e-4"))
+    residual_stream: str = "fp32"
+    residual_stream_error: Optional[float] = None
+
+    def tune_residual_stream(self, run, budget: Optional[float] = None) -> str:
+        """`run()` pushes the tower's fixed calibration batch through it and returns the [n, D] embeddings -> 'bf16' | 'fp32'"""
+        enc = self.cfg.enc
+        mode = os.environ.get("MARQO_AMD_RESIDUAL_STREAM", "auto").lower()
+        if self.precision != "bf16" or enc.post_ln or mode == "fp32":
+            enc.residual_stream, self.residual_stream = 2, "fp32"
+            return self.residual_stream
+        if mode == "bf16":
+            enc.residual_stream, self.residual_stream = 1, "bf16"
+            return self.residual_stream
+        budget = self.RESIDUAL_STREAM_BUDGET if budget is None else float(budget)
+        enc.residual_stream = 2
+        ref = run().double()
+        enc.residual_stream = 1
+        out = run().double()
+        cos = (out * ref).sum(-1) / (out.norm(dim=-1) * ref.norm(dim=-1))
+        e = float((1 - cos).max())
+        self.residual_stream_error = e
+        ok = e <= budget and bool(torch.isfinite(out).all())
+        enc.residual_stream, self.residual_stream = (1, "bf16") if ok else (2, "fp32")
+        import logging
+        logging.getLogger(__name__).info("residual stream: %s (bf16 vs fp32 stream on the calibration batch: 1 - cos %.2e, budget %.1e)",
+                                         self.residual_stream, e, budget)
+        return self.residual_stream
+
     # ---- fp8 policy --------------------------------------------------------------------------------------------------------
     # e4m3 operands carry ~2.6 % rms relative rounding noise each, whatever the scaling granularity (per tensor, per row or MX
     # blocks: oracle/fp8_sim.py, tests/studies/fp8_numerics_study.py -> profiles/r02_fp8_numerics_sim.txt): a GEMM output is ~3.7 % noise, a 24-block
@@ -597,6 +633,13 @@ class VitTower(_TowerBase):
         self._side: list = []
         if precision == "fp8":
             self._enable_fp8(self._blocks, arch.layers, W, _ceil64(arch.mlp_dim))
+        self.cfg.enc.residual_stream = 2
+        if precision == "bf16":
+            self.tune_residual_default()
+
+    def tune_residual_default(self) -> str:
+        u8 = self.calibration_images()
+        return self.tune_residual_stream(lambda: self.encode_u8(u8))
 
     def _run(self, kind: str, pixels: Tensor, normalize: bool) -> Tensor:
         fn = self.lib.mq_encode_image_u8 if kind == "u8" else self.lib.mq_encode_image_f32   # (the multi-stream experiment below)
@@ -803,6 +846,13 @@ class ClipTextTower(_TextTowerBase):
                                  vocab=arch.vocab, ctx=arch.ctx, out_dim=arch.out_dim)
         if precision == "fp8":
             self._enable_fp8(self._blocks, arch.layers, W, _ceil64(arch.mlp_dim))
+        self.cfg.enc.residual_stream = 2
+        if precision == "bf16":
+            self.tune_residual_default()
+
+    def tune_residual_default(self) -> str:
+        ids = self.calibration_ids()
+        return self.tune_residual_stream(lambda: self.encode_ids(ids))
 
     def calibration_ids(self, n: int = 32, seed: int = 0) -> Tensor:
         """fixed, seeded calibration texts of the fp8 policy: int64 [n, ctx] rows SOT, L random ids, EOT, zero padding with L spread

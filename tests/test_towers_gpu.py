@@ -89,7 +89,7 @@ def test_vit_b32_full_size_vs_oracle():
     assert _cos_err(out_f, out) < 1e-5
     # batching invariance: one image alone == the same image inside a batch
     single = tower.encode_u8(u8[2:3].cuda())
-    assert _cos_err(single, out[2:3]) < 1e-5
+    assert _cos_err(single, out[2:3]) < 1e-4   # a lone image takes the skinny GEMM family: another summation order of a bf16-rounded stream
 
 
 def test_vit_l14_vs_oracle():
@@ -533,16 +533,16 @@ def test_clip_text_full_depth_realistic_weights_bf16():
     assert e < 3e-4
 
 
-def test_bf16_residual_stream_parity(tiled_gemm_only):
-    """mq_tune("residual_bf16", 1): the pre-LN towers keep x in bf16 between blocks (half the bytes of every residual epilogue and
-    LayerNorm).  Full registry depth, plain and trained-like weights: still inside the 3e-4 the fp32-stream form is held to, and the
-    pooled-rows-only last block stays bit-identical to the all-rows execution in this form too (within the tiled GEMM family: the
-    fixture keeps the few pooled rows off the skinny kernel, whose split-K summation order differs)."""
+def test_bf16_residual_stream_parity(tiled_gemm_only, monkeypatch):
+    """The bf16 residual stream (pre-LN towers keep x in bf16 between blocks: half the bytes of every residual epilogue and LayerNorm),
+    forced on (MARQO_AMD_RESIDUAL_STREAM=bf16).  Full registry depth, plain and trained-like weights: still inside the 3e-4 the fp32-stream
+    form is held to, and the pooled-rows-only last block stays bit-identical to the all-rows execution in this form too (within the tiled
+    GEMM family: the fixture keeps the few pooled rows off the skinny kernel, whose split-K summation order differs)."""
     from marqo_amd import _lib as L
     from marqo_amd.engine import archs, towers
     lib = L.load()
+    monkeypatch.setenv("MARQO_AMD_RESIDUAL_STREAM", "bf16")
     try:
-        L.check(lib.mq_tune(b"residual_bf16", 1))
         for arch_name, cfg in (("ViT-B-32", O.VitConfig(224, 32, 768, 12, 12, 3072, 512)), ("ViT-L-14", O.VitConfig(224, 14, 1024, 24, 16, 4096, 768))):
             varch, tarch = archs.resolve_open_clip(arch_name)
             for weights in ("plain", "realistic"):
@@ -550,6 +550,7 @@ def test_bf16_residual_stream_parity(tiled_gemm_only):
                 u8 = O.synthetic_images_u8(3, 224, seed=9)
                 ref = O.vit_forward(sd, cfg, O.preprocess_u8_exact_size(u8))
                 tower = towers.VitTower(varch, sd, "cuda:0")
+                assert tower.residual_stream == "bf16" and tower.cfg.enc.residual_stream == 1
                 out = tower.encode_u8(u8.to("cuda:0"))
                 e = float((1 - torch.nn.functional.cosine_similarity(out.cpu().double(), ref.double(), dim=-1)).max())
                 print(f"bf16 residual stream, {arch_name} {weights}: 1-cos vs fp32 oracle {e:.2e}")
@@ -567,5 +568,34 @@ def test_bf16_residual_stream_parity(tiled_gemm_only):
         print(f"bf16 residual stream, CLIP text L/14 realistic: 1-cos vs fp32 oracle {e:.2e}")
         assert e < 5e-4
     finally:
-        L.check(lib.mq_tune(b"residual_bf16", 0))
         L.check(lib.mq_tune(b"row_select", 1))
+
+
+def test_residual_stream_policy_is_decided_per_model_at_load(monkeypatch):
+    """auto (the default): the fixed seeded calibration batch runs through both stream forms at load; bf16 is kept only within the budget of
+    the fp32 stream.  Registry-shaped weights take bf16 (and stay inside the towers' 3e-4 bound vs the fp32 oracle); a tower whose residual
+    stream dwarfs its per-block updates (the SigLIP-small golden text tower: 7.8e-3 with a bf16 stream) keeps fp32; the decision is a
+    pure function of (weights, seed): two loads agree; the environment can force either form."""
+    from marqo_amd.engine import archs, towers
+    monkeypatch.delenv("MARQO_AMD_RESIDUAL_STREAM", raising=False)
+    cfg = O.VitConfig(224, 32, 768, 12, 12, 3072, 512)
+    varch, _ = archs.resolve_open_clip("ViT-B-32")
+    sd = O.synthetic_vit_state_dict_realistic(cfg, 0)
+    t1, t2 = towers.VitTower(varch, sd, "cuda:0"), towers.VitTower(varch, sd, "cuda:0")
+    assert t1.residual_stream == t2.residual_stream == "bf16" and t1.residual_stream_error == t2.residual_stream_error
+    assert t1.residual_stream_error <= t1.RESIDUAL_STREAM_BUDGET
+    u8 = O.synthetic_images_u8(4, 224, seed=3)
+    ref = O.vit_forward(sd, cfg, O.preprocess_u8_exact_size(u8))
+    e = float((1 - torch.nn.functional.cosine_similarity(t1.encode_u8(u8.to("cuda:0")).cpu().double(), ref.double(), dim=-1)).max())
+    assert e < 3e-4, e
+    monkeypatch.setenv("MARQO_AMD_RESIDUAL_STREAM", "fp32")
+    t3 = towers.VitTower(varch, sd, "cuda:0")
+    assert t3.residual_stream == "fp32" and t3.cfg.enc.residual_stream == 2
+    e3 = float((1 - torch.nn.functional.cosine_similarity(t3.encode_u8(u8.to("cuda:0")).cpu().double(), ref.double(), dim=-1)).max())
+    assert e3 < e + 1e-6 or e3 < 5e-5          # the fp32 stream is the tighter form
+    monkeypatch.setenv("MARQO_AMD_RESIDUAL_STREAM_BUDGET", "1e-9")   # an impossible budget: auto must fall back to fp32
+    monkeypatch.setenv("MARQO_AMD_RESIDUAL_STREAM", "auto")
+    import importlib
+    t4 = towers.VitTower(varch, sd, "cuda:0")
+    t4.tune_residual_stream(lambda: t4.encode_u8(t4.calibration_images()), budget=1e-9)
+    assert t4.residual_stream == "fp32" and t4.cfg.enc.residual_stream == 2
