@@ -5,6 +5,7 @@
 #include "common.h"
 
 int mq_ln_rows_per_wave = getenv("MQ_LN_ROWS") ? atoi(getenv("MQ_LN_ROWS")) : 2;  // mq_tune("ln_rows", 1 | 2)
+extern int mq_gemm_small_max_rows;   // gemm_small.hip
 int mq_ln_bf16_wide = getenv("MQ_LN_BF16_WIDE") ? atoi(getenv("MQ_LN_BF16_WIDE")) : 1;   // mq_tune("ln_bf16_wide", 0 | 1): 16-byte bf16-input LayerNorm
 
 namespace {
@@ -286,9 +287,11 @@ extern "C" int mq_layernorm_ex(const void* d_x, int x_bf16, const int32_t* d_row
     hipStream_t s = (hipStream_t)stream;
     MqProfScope prof(1, s);
     // two rows per wave once there are enough rows to fill the chip that way (and the row fits: CH * 2 float4 per lane)
-    // (every row count takes the same form: an embedding must not depend on what else shares its batch.  The fused LayerNorm prologue of
-    // gemm_small.hip — the search path — sums a row in the generic kernel's lane order: equal to this one to fp32 rounding, not bit for bit)
-    if (x_bf16 && mq_ln_bf16_wide && W % 8 == 0 && W <= 1024 && ((uintptr_t)d_x & 15) == 0 && (!d_out_bf16 || ((uintptr_t)d_out_bf16 & 15) == 0)) {
+    // The LayerNorm form follows the GEMM family of the call: at most mq_gemm_small_max_rows rows (the search path: skinny GEMMs, whose fused
+    // LayerNorm prologue sums a row in the generic kernel's lane order) keep the generic kernel, so a query has the same bits alone and inside
+    // a small batch; every larger call takes the 16-byte form whatever its row count, so an embedding does not depend on what else shares a
+    // chip-filling batch either.  (Across the two families results agree to rounding, as their GEMMs do.)
+    if (x_bf16 && mq_ln_bf16_wide && rows > mq_gemm_small_max_rows && W % 8 == 0 && W <= 1024 && ((uintptr_t)d_x & 15) == 0 && (!d_out_bf16 || ((uintptr_t)d_out_bf16 & 15) == 0)) {
         // 16-byte form: W / 8 chunks over 64 lanes -> 1 (W <= 512) or 2 chunks per lane; 4 rows per wave once the chip is full that way
         const bf16_t* xb = (const bf16_t*)d_x;
         const bool many = rows >= 16384;

@@ -389,7 +389,10 @@ class _TowerBase:
     # values two orders of magnitude above its per-block updates (8 mantissa bits then drop most of an update).  So it is decided per model,
     # deterministically at load, like the fp8 split: the fixed seeded calibration batch runs through both forms and bf16 is kept only when
     # max (1 - cos) against the fp32 stream is within the budget.  MARQO_AMD_RESIDUAL_STREAM = auto (default) | fp32 | bf16.
-    RESIDUAL_STREAM_BUDGET = float(os.environ.get("MARQO_AMD_RESIDUAL_STREAM_BUDGET", "2e-4"))
+    # Budget 5e-4 (MARQO_AMD_RESIDUAL_STREAM_BUDGET): trained-like fixtures measure 1.5e-4 .. 4.2e-4 on the calibration batch and 7e-5 ..
+    # 2.8e-4 against the fp32 CPU oracle on held-out inputs (profiles/r03h_residual_policy_report.txt) — inside the 1e-3 north-star
+    # tolerance with a factor of three to spare; the SigLIP-small golden text tower (7.8e-3) is refused.
+    RESIDUAL_STREAM_BUDGET = float(os.environ.get("MARQO_AMD_RESIDUAL_STREAM_BUDGET", "5e-4"))
     residual_stream: str = "fp32"
     residual_stream_error: Optional[float] = None
 
