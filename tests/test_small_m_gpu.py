@@ -147,6 +147,6 @@ def test_single_query_towers_on_the_skinny_path():
         tiled_v = torch.cat([vt.encode_u8(u8[i:i + 1].cuda()) for i in range(2)])
         tiled_b = torch.cat([bt.encode_ids(bids[i:i + 1], bmask[i:i + 1]) for i in range(3)])
         for a, c in ((skinny_t, tiled_t), (skinny_v, tiled_v), (skinny_b, tiled_b)):
-            assert _cos_err(a, c) < 2e-5                                              # two bf16 summation orders of the same products
+            assert _cos_err(a, c) < 1e-4   # two summation orders of the same products (and, under the bf16 residual stream, of the same bf16-rounded x)
     finally:
         L.check(lib.mq_tune(b"small_m", 80))
