@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--threads", type=int, default=16)
     ap.add_argument("--items", type=int, default=4)
     ap.add_argument("--calls", type=int, default=60)
+    ap.add_argument("--windows", default="0,200", help="MARQO_AMD_COALESCE_US values to time")
     args = ap.parse_args()
     dev = "cuda:0"
     words = ["alpha", "beta", "gamma", "delta", "marqo", "tensor", "search", "image", "text", "vector"]
@@ -35,7 +36,7 @@ def main():
         content = {(t, c): texts(t, c) for t in range(args.threads) for c in range(args.calls)}
         s2.vectorise_ndarray(name, content[(0, 0)], model_properties=props, device=dev, **kw)      # load
         ref = {k: s2.vectorise_ndarray(name, v, model_properties=props, device=dev, **kw) for k, v in list(content.items())[:8]}
-        for window in ("0", "200"):
+        for window in args.windows.split(","):
             os.environ["MARQO_AMD_COALESCE_US"] = window
             before = dict(coalesce.get_coalescer().stats)
             out, lat = {}, []
