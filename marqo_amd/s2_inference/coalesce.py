@@ -41,6 +41,15 @@ def max_items() -> int:
         return 512
 
 
+def depth() -> int:
+    """MARQO_AMD_COALESCE_DEPTH: merged engine calls of one key that may be in flight at once.  2 (default): the next group's leader fires
+    while ONE call is still executing, so its host part (tokenising / packing / enqueue) overlaps the GPU part of the call before it"""
+    try:
+        return max(1, int(os.environ.get("MARQO_AMD_COALESCE_DEPTH", "2")))
+    except ValueError:
+        return 2
+
+
 class _Group:
     __slots__ = ("parts", "n", "open", "done", "results", "error")
 
@@ -81,8 +90,9 @@ class Coalescer:
         else:
             deadline = time.perf_counter() + window
             with self._lock:
-                # natural batching: fire as soon as no call of this key is executing; while one is, wait (others join) up to `window`
-                while self._busy.get(key, 0) > 0 and g.n < limit:
+                # natural batching: fire as soon as fewer than `depth` calls of this key are executing; until then wait (others join), `window` at most
+                d = depth()
+                while self._busy.get(key, 0) >= d and g.n < limit:
                     left = deadline - time.perf_counter()
                     if left <= 0:
                         break

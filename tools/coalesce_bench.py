@@ -23,9 +23,11 @@ def main():
     ap.add_argument("--threads", type=int, default=16)
     ap.add_argument("--items", type=int, default=4)
     ap.add_argument("--calls", type=int, default=60)
+    ap.add_argument("--depth", default="2")
     ap.add_argument("--windows", default="0,200", help="MARQO_AMD_COALESCE_US values to time")
     args = ap.parse_args()
     dev = "cuda:0"
+    os.environ["MARQO_AMD_COALESCE_DEPTH"] = args.depth
     words = ["alpha", "beta", "gamma", "delta", "marqo", "tensor", "search", "image", "text", "vector"]
     rng = np.random.default_rng(0)
 
@@ -61,7 +63,7 @@ def main():
             n = args.threads * args.calls * args.items
             worst = max(float((1 - (out[k] * ref[k]).sum(-1) / (np.linalg.norm(out[k], axis=-1) * np.linalg.norm(ref[k], axis=-1))).max()) for k in ref)
             lat.sort()
-            print(f"{name} {args.threads} threads x {args.calls} calls x {args.items} items, MARQO_AMD_COALESCE_US={window}: {n / dt:9.0f} embeddings/s, "
+            print(f"{name} {args.threads} threads x {args.calls} calls x {args.items} items, MARQO_AMD_COALESCE_US={window} depth {args.depth}: {n / dt:9.0f} embeddings/s, "
                   f"call latency p50 {lat[len(lat) // 2] * 1e3:.2f} ms p95 {lat[int(len(lat) * 0.95)] * 1e3:.2f} ms; engine calls "
                   f"{st['engine_calls'] - before['engine_calls']} for {st['calls'] - before['calls']} coalesced-path calls; max 1-cos vs the lone call {worst:.1e}", flush=True)
         # the serial rate: one thread, the same calls
