@@ -45,7 +45,7 @@ extern "C" {
 #define MQ_ERR_HIP (-2)       /* a HIP runtime call or launch failed */
 #define MQ_ERR_WORKSPACE (-3) /* caller's workspace too small */
 
-#define MQ_ABI_VERSION 5
+#define MQ_ABI_VERSION 6
 
 /* ---- activation / mask / pooling selectors ---------------------------------------- */
 #define MQ_ACT_NONE 0
@@ -137,6 +137,11 @@ typedef struct mq_encoder_cfg {
                                    * LayerNorm), 2 = fp32.  The loaders decide 1 / 2 per MODEL at load on a fixed seeded batch
                                    * (engine/towers.py::tune_residual_stream: bf16 only where it stays within a 1 - cos budget of the fp32
                                    * stream).  (Took the slot of the former reserved0: the layout is unchanged.) */
+    int32_t      fp8_mlp_extra;   /* MQ_PREC_FP8, pre-LN encoders: the `fp8_mlp_extra` blocks in FRONT of fp8_first_layer run only their MLP half on e4m3
+                                   * (LayerNorm 2 -> e4m3 rows, fc1 + activation -> e4m3, fc2 + residual) and keep LayerNorm 1 / QKV / attention /
+                                   * out-projection on bf16 operands: two thirds of a block's GEMM FLOPs for the rounding noise of two of its four
+                                   * GEMMs.  0 = none (every block is all-bf16 or all-e4m3).  Must be <= fp8_first_layer.  (ABI 6) */
+    int32_t      reserved1;
 } mq_encoder_cfg;
 
 /* ---- towers ------------------------------------------------------------------------ */

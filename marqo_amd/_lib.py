@@ -29,7 +29,7 @@ STAGE_PATH = LIB_DIR / "_mq_stage.so"                # CPython extension: a batc
 
 MQ_OK = 0
 NO_SCRATCH_UNITS = ("gemm_bf16", "gemm_pp", "gemm_big", "gemm_k32", "gemm_fp8", "gemm_small", "attention")  # build() refuses register spills in these
-ABI_VERSION = 5
+ABI_VERSION = 6
 MQ_PREC_BF16, MQ_PREC_FP8 = 0, 1
 MQ_ACT_GELU, MQ_ACT_QUICKGELU = 1, 2
 MQ_MASK_NONE, MQ_MASK_CAUSAL = 0, 1
@@ -65,7 +65,8 @@ class EncoderCfg(C.Structure):
                 ("act", C.c_int32), ("post_ln", C.c_int32), ("mask", C.c_int32), ("ln_eps", C.c_float),
                 ("precision", C.c_int32), ("attn_width", C.c_int32), ("fp8_first_layer", C.c_int32), ("mlp_glu", C.c_int32),
                 ("d_fp8_act_scale", C.c_void_p), ("d_fp8_act_amax", C.c_void_p), ("d_rope_inv_freq", C.c_void_p),
-                ("d_rel_bias", C.c_void_p), ("rel_span", C.c_int32), ("residual_stream", C.c_int32)]
+                ("d_rel_bias", C.c_void_p), ("rel_span", C.c_int32), ("residual_stream", C.c_int32),
+                ("fp8_mlp_extra", C.c_int32), ("reserved1", C.c_int32)]
 
 
 class MapHead(C.Structure):

@@ -29,8 +29,8 @@ extern "C" int mq_rowquant_fp8(const float* d_x, void* d_out_fp8, float* d_row_s
 
 // layouts the ctypes binding (marqo_amd/_lib.py) and tests/test_abi.py assume
 static_assert(sizeof(mq_block_weights) == 26 * 8, "mq_block_weights layout");
-static_assert(sizeof(mq_encoder_cfg) == 88, "mq_encoder_cfg layout");
-static_assert(sizeof(mq_vit_cfg) == 136 && sizeof(mq_clip_text_cfg) == 104 && sizeof(mq_bert_cfg) == 112, "tower cfg layouts");
+static_assert(sizeof(mq_encoder_cfg) == 96, "mq_encoder_cfg layout");
+static_assert(sizeof(mq_vit_cfg) == 144 && sizeof(mq_clip_text_cfg) == 112 && sizeof(mq_bert_cfg) == 120, "tower cfg layouts");
 static_assert(sizeof(mq_vit_weights) == 10 * 8 && sizeof(mq_map_head) == 11 * 8 && sizeof(mq_clip_text_weights) == 7 * 8, "tower weight layouts");
 
 // mq_tune("row_select", 0) runs the last block on every row (A/B and parity tests of the pooled-rows-only last block)
@@ -107,6 +107,8 @@ int check_encoder_cfg(const mq_encoder_cfg* c) {
         MQ_CHECK_ARG(c->width % 128 == 0 && c->mlp_dim % 128 == 0 && wa % 128 == 0, "fp8 path needs width / mlp_dim multiples of 128");
         MQ_CHECK_ARG(c->d_fp8_act_scale, "fp8 path needs d_fp8_act_scale");
         MQ_CHECK_ARG(c->fp8_first_layer >= 0, "fp8_first_layer < 0");
+        MQ_CHECK_ARG(c->fp8_mlp_extra >= 0 && c->fp8_mlp_extra <= c->fp8_first_layer && (c->fp8_mlp_extra == 0 || !c->post_ln),
+                     "fp8_mlp_extra = %d must lie in [0, fp8_first_layer = %d] (pre-LN encoders only)", c->fp8_mlp_extra, c->fp8_first_layer);
         MQ_CHECK_ARG(!c->mlp_glu && !c->d_rope_inv_freq, "the gated-MLP / rotary encoder variant runs on the bf16 path only");
     }
     if (c->mlp_glu || c->d_rope_inv_freq)
@@ -330,6 +332,17 @@ int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* bloc
             MQ_TRY(ln_gemm(d_x, xb, b.ln1_g, b.ln1_b, cfg->ln_eps, h, b.qkv_w, b.qkv_b, qf, rows, 3 * Wa, W, MQ_EPI_BIAS, s));
             MQ_TRY(attn_bf16(cfg, qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, s));
             MQ_TRY(mq_gemm_bf16(a, Wa, b.out_w, Wa, b.out_b, (const float*)d_x, d_x, W, rows, W, Wa, rflags, s));
+            if (cfg->precision == MQ_PREC_FP8 && l >= first8 - cfg->fp8_mlp_extra) {
+                // MLP-only e4m3 block (fp8_mlp_extra): the attention half above ran on bf16 operands (fp32 stream in an fp8 tower)
+                MQ_CHECK_ARG(b.fc1_w8 && b.fc1_ws && b.fc2_w8 && b.fc2_ws, "mq_encoder_forward: layer %d has no fp8 MLP weights", l);
+                const float* s_mlp = cfg->d_fp8_act_scale + 2 * l + 1;
+                float* m_mlp = cfg->d_fp8_act_amax ? cfg->d_fp8_act_amax + 2 * l + 1 : nullptr;
+                const int act8 = (cfg->act == MQ_ACT_QUICKGELU ? MQ_EPI_QUICKGELU : MQ_EPI_GELU) | MQ_EPI_BIAS | MQ_EPI_OUT_FP8;
+                MQ_TRY(mq_layernorm_fp8(d_x, b.ln2_g, b.ln2_b, h, row_scale, nullptr, rows, W, cfg->ln_eps, s));
+                MQ_TRY(mq_gemm_fp8(h, W, b.fc1_w8, W, row_scale, 1, b.fc1_ws, b.fc1_b, nullptr, qf, F, s_mlp, m_mlp, rows, F, W, act8, s));
+                MQ_TRY(mq_gemm_fp8(qf, F, b.fc2_w8, F, s_mlp, 0, b.fc2_ws, b.fc2_b, d_x, d_x, W, nullptr, nullptr, rows, W, F, res_flags, s));
+                continue;
+            }
             MQ_TRY(ln_gemm(d_x, xb, b.ln2_g, b.ln2_b, cfg->ln_eps, h, b.fc1_w, b.fc1_b, qf, rows, F, W, MQ_EPI_BIAS | act_flag, s));
             MQ_TRY(mq_gemm_bf16(qf, F, b.fc2_w, F, b.fc2_b, (const float*)d_x, d_x, W, rows, W, F, rflags, s));
         } else if (small_post_ln) {

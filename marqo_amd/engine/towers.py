@@ -431,6 +431,8 @@ class _TowerBase:
     FP8_BUDGET = float(os.environ.get("MARQO_AMD_FP8_BUDGET", "7e-4"))   # max (1 - cos) vs the tower's own bf16 output
     FP8_SCALE_MARGIN = 2.0   # static activation scales = calibration amax x margin / 448: one binade of head-room for unseen inputs
     fp8_first_layer: int = 0
+    fp8_mlp_extra: int = 0
+    fp8_policy_trace: Optional[list] = None
     fp8_calibration_error: Optional[float] = None
     fp8_all_blocks_error: Optional[float] = None
 
@@ -443,15 +445,21 @@ class _TowerBase:
             raise RuntimeError("tower was not built with precision='fp8'")
         budget = self.FP8_BUDGET if budget is None else float(budget)
         enc, layers = self.cfg.enc, self.cfg.enc.layers
-        enc.fp8_first_layer = 0
+        enc.fp8_first_layer, enc.fp8_mlp_extra = 0, 0
         self.calibrate_fp8(run, passes=2, margin=self.FP8_SCALE_MARGIN if margin is None else margin)
         self._fp8.calibrated = False           # no graph capture while the split is being searched
         enc.precision = L.MQ_PREC_BF16
         ref = run().double()
         enc.precision = L.MQ_PREC_FP8
 
+        def err_split(first: int, extra: int) -> float:
+            enc.fp8_first_layer, enc.fp8_mlp_extra = first, extra
+            out = run().double()
+            cos = (out * ref).sum(-1) / (out.norm(dim=-1) * ref.norm(dim=-1))
+            return float((1 - cos).max())
+
         def err(first: int) -> float:
-            enc.fp8_first_layer = first
+            enc.fp8_first_layer, enc.fp8_mlp_extra = first, 0
             out = run().double()
             cos = (out * ref).sum(-1) / (out.norm(dim=-1) * ref.norm(dim=-1))
             return float((1 - cos).max())
@@ -469,12 +477,42 @@ class _TowerBase:
                 else:
                     lo = mid
             first = hi
-        enc.fp8_first_layer = first
-        self.fp8_first_layer, self.fp8_calibration_error = first, e
+        # Per-GEMM-type refinement (pre-LN towers): a block in front of the split may run only its MLP half on e4m3 (fp8_mlp_extra: two
+        # thirds of the block's GEMM FLOPs for the noise of two of its four GEMMs).  Two-dimensional search at load: for a few candidate
+        # splits s >= `first`, the largest `extra` <= s whose error stays inside the budget (binary search: the error grows with extra);
+        # keep the (split, extra) with the largest e4m3 share of the GEMM FLOPs = (layers - s) + 2/3 extra.
+        extra = 0
+        self.fp8_policy_trace = [(first, 0, e)]
+        if not enc.post_ln and os.environ.get("MARQO_AMD_FP8_MLP_ONLY", "1") != "0":
+            best = (layers - first + 0.0, first, 0, e)
+            step = max(1, layers // 8)
+            for s_ in sorted({min(layers, first + k * step) for k in range(0, 9)} | {layers}):
+                if s_ == 0:
+                    continue
+                lo_x, hi_x = 0, s_                       # err(s_, lo_x) <= budget is known for lo_x = 0 (s_ >= first)
+                e_s = err_split(s_, 0) if s_ != first else e
+                if e_s > budget:
+                    continue
+                e_at = {0: e_s}
+                while hi_x - lo_x > 0:
+                    mid = (lo_x + hi_x + 1) // 2
+                    em = err_split(s_, mid)
+                    e_at[mid] = em
+                    if em <= budget:
+                        lo_x = mid
+                    else:
+                        hi_x = mid - 1
+                share = (layers - s_) + (2.0 / 3.0) * lo_x
+                self.fp8_policy_trace.append((s_, lo_x, e_at[lo_x]))
+                if share > best[0] + 1e-9:
+                    best = (share, s_, lo_x, e_at[lo_x])
+            _, first, extra, e = best
+        enc.fp8_first_layer, enc.fp8_mlp_extra = first, extra
+        self.fp8_first_layer, self.fp8_mlp_extra, self.fp8_calibration_error = first, extra, e
         self._fp8.calibrated = True
         import logging
-        logging.getLogger(__name__).info("fp8 policy: blocks [%d, %d) on e4m3, 1 - cos vs bf16 on the calibration batch %.2e (all blocks: %.2e, "
-                                         "budget %.1e)", first, layers, e, e0, budget)
+        logging.getLogger(__name__).info("fp8 policy: blocks [%d, %d) on e4m3 + the MLP halves of blocks [%d, %d), 1 - cos vs bf16 on the calibration "
+                                         "batch %.2e (all blocks: %.2e, budget %.1e)", first, layers, first - extra, first, e, e0, budget)
         return first
 
     def __init__(self, device: str):
