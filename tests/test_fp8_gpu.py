@@ -254,6 +254,7 @@ def test_fp8_policy_full_depth_vit_l14_meets_1e3(weights):
     assert torch.equal(t8.encode_u8(u8.cuda()), f8)                       # frozen scales + frozen split: deterministic
     t8b = towers.VitTower(varch, sd, "cuda:0", precision="fp8")
     assert t8b.tune_fp8_default() == first and torch.equal(t8b._fp8.scale, t8._fp8.scale)   # same policy on every load
+    assert t8b.fp8_mlp_extra == t8.fp8_mlp_extra and t8b.cfg.enc.fp8_mlp_extra == t8.fp8_mlp_extra
     assert torch.equal(t8b.encode_u8(u8.cuda()), f8)
     # all blocks on fp8 (budget = infinity): still a valid, deterministic mode; its error is what the format costs
     assert t8b.tune_fp8_default(budget=1.0) == 0
@@ -314,3 +315,36 @@ def test_fp8_policy_post_ln_and_text_towers():
         e = _cos_err(tb.encode_ids(bids, mask).cpu(), bref)
         print(f"BERT-base 12L: fp8 blocks {tb.cfg.enc.fp8_first_layer}..11, 1-cos vs fp32 oracle {e:.2e}")
         assert e < (1e-3 if forced is None else 5e-3)
+
+
+def test_fp8_mlp_only_blocks_in_front_of_the_split():
+    """mq_encoder_cfg.fp8_mlp_extra (ABI 6): the blocks in front of the split run only their MLP half on e4m3.  A forced (split, extra) is a
+    different, deterministic computation from (split, 0) and from (split - extra, 0), its error against the bf16 tower lies between theirs
+    (less e4m3 work than the one, more than the other) up to noise, a bad combination is refused, and the 2-D policy search never returns
+    a configuration outside its budget nor one with a smaller e4m3 share than the one-dimensional split."""
+    from marqo_amd.engine import towers
+    from oracle import towers as O
+    varch, ocfg = _vit_l14()
+    sd = O.synthetic_vit_state_dict_realistic(ocfg, 0)
+    t8 = towers.VitTower(varch, sd, "cuda:0", precision="fp8")
+    cal = t8.calibration_images()
+    t8.calibrate_fp8(lambda: t8.encode_u8(cal), passes=2, margin=t8.FP8_SCALE_MARGIN)
+    bf = towers.VitTower(varch, sd, "cuda:0").encode_u8(cal)
+    enc = t8.cfg.enc
+
+    def run(first, extra):
+        enc.fp8_first_layer, enc.fp8_mlp_extra = first, extra
+        return t8.encode_u8(cal)
+    a, b, c = run(16, 0), run(16, 12), run(4, 0)
+    assert torch.equal(run(16, 12), b) and not torch.equal(a, b) and not torch.equal(b, c)
+    ea, eb, ec = _cos_err(a.cpu(), bf.cpu()), _cos_err(b.cpu(), bf.cpu()), _cos_err(c.cpu(), bf.cpu())
+    print(f"ViT-L/14 realistic, 1-cos vs the bf16 tower: split 16 {ea:.2e} | split 16 + 12 MLP-only blocks {eb:.2e} | split 4 {ec:.2e}")
+    assert ea * 0.7 < eb < ec * 1.3 and eb < 3e-3
+    enc.fp8_first_layer, enc.fp8_mlp_extra = 4, 5
+    with pytest.raises(Exception, match="fp8_mlp_extra"):
+        t8.encode_u8(cal)
+    first = t8.tune_fp8_default()
+    assert t8.fp8_calibration_error <= t8.FP8_BUDGET and 0 <= t8.fp8_mlp_extra <= first
+    one_d = [tr for tr in t8.fp8_policy_trace if tr[1] == 0][0]
+    assert (24 - first) + 2 / 3 * t8.fp8_mlp_extra >= (24 - one_d[0]) - 1e-9
+    print(f"policy: split {first}, MLP-only blocks {t8.fp8_mlp_extra}, error {t8.fp8_calibration_error:.2e}; trace {t8.fp8_policy_trace}")
