@@ -52,10 +52,11 @@ def _exc(fn):
 
 
 def main(out_dir: str) -> None:
-    # the product's segmenters stand in for nltk punkt (not downloadable): same segmentation on both sides, so the
-    # reference's windowing / re-joining code is what the comparison exercises
-    from marqo_amd.s2_inference.processing import text as product_text
-    ref_shim.install(sent_tokenize=product_text._sentences, word_tokenize=product_text._WORD.findall)
+    # nltk punkt is not downloadable here: the reference's split_text runs on the INDEPENDENTLY written segmenters of oracle/segment.py (not
+    # on the product's own, as in round 2 — that made the segmentation half of the comparison circular), so a fixture that the product
+    # reproduces is two implementations of the documented boundary rules agreeing, plus the reference's windowing / re-joining code
+    from oracle import segment
+    ref_shim.install(sent_tokenize=segment.sentences, word_tokenize=segment.words)
 
     import numpy as np
     import torch

@@ -19,7 +19,10 @@ SPLIT_CASES = [  # (split_by, split_length, split_overlap)
     ("sentence", 2, 1), ("sentence", 2, 0), ("sentence", 3, 1), ("sentence", 1, 0), ("sentence", 20, 5),
     ("passage", 1, 0), ("passage", 2, 1), ("passage", 5, 2),
 ]
-SPLIT_EDGE_TEXTS = ["", " ", "a", "One sentence only.", "No terminal punctuation", "   \n  ", "A. B. C. D. E. F. G."]
+SPLIT_EDGE_TEXTS = ["", " ", "a", "One sentence only.", "No terminal punctuation", "   \n  ", "A. B. C. D. E. F. G.",
+                    # closing quotes / brackets belong to the sentence they close (round 3: the product used to drop them)
+                    'He said "Go." Then he left. (Really.) [Ok.] \'Fine.\' Next one, "quoted start." 3 more.',
+                    "lower case after a stop. stays one sentence? yes! It's 5 o'clock. Don't split o'clock."]
 
 WRAPPER_TEXTS = ["a photo of a cat", "The Quick  Brown fox, jumps over the lazy dog!", "query: how much protein should a female eat",
                  "marqo is a tensor search engine", "it's built for images and text", "dog"]

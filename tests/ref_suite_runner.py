@@ -51,9 +51,9 @@ def main(argv) -> int:
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     if root not in sys.path:
         sys.path.insert(0, root)
-    from marqo_amd.s2_inference.processing import text as product_text
-    from oracle import ref_shim
-    ref_shim.install(sent_tokenize=product_text._sentences, word_tokenize=product_text._WORD.findall)
+    from oracle import ref_shim, segment
+    # (punkt is not downloadable: the reference's own code paths that still call nltk get the independent segmenters of oracle/segment.py)
+    ref_shim.install(sent_tokenize=segment.sentences, word_tokenize=segment.words)
     import marqo.s2_inference  # noqa: F401  (the package itself stays the reference's: only the listed modules are replaced)
     for ref_name, our_name in ALIASES.items():
         ours = importlib.import_module(our_name)

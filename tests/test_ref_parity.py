@@ -425,3 +425,19 @@ def test_reference_unit_tests_pass_on_the_product():
             ok, n, log = verdict(launch(g))
         assert ok, log
         assert n == sum(REFERENCE_TEST_FILES[f] for f in g), (g, n)
+
+
+def test_product_segmenters_agree_with_the_independent_ones():
+    """The reference-run fixtures above are produced with oracle/segment.py injected for nltk punkt (character scanners, written without
+    looking at the product's regular expressions); the product's own rule-based splitters must agree with them on the fixture corpus AND on a
+    seeded fuzz of the characters the rules speak about — two implementations of the same published boundary rules."""
+    import random
+    from marqo_amd.s2_inference.processing import text as pt
+    from oracle import segment
+    rng = random.Random(11)
+    alphabet = "abc ABC .!? '\"()[]\n\t0 9dÉé東"
+    corpus = list(RC.SPLIT_EDGE_TEXTS) + [RC.SPLIT_TEXT] + ["".join(rng.choice(alphabet) for _ in range(rng.randint(0, 80))) for _ in range(4000)]
+    for t in corpus:
+        assert pt._sentences(t) == segment.sentences(t), repr(t)
+        assert pt._WORD.findall(t) == segment.words(t), repr(t)
+    assert pt._sentences('He said "Go." Then left.') == ['He said "Go."', "Then left."]     # the closing quote stays with its sentence
