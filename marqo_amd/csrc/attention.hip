@@ -49,7 +49,7 @@ template <int MASK, bool OUT_FP8, int HD, int HS, int NW, bool BIAS = false>
 __global__ __launch_bounds__(NW * 64) MQ_ATTN_OCC void attention_kernel(
     const bf16_t* __restrict__ qkv, void* __restrict__ out_v, const int32_t* __restrict__ cu,
     int fixed_len, int W, int heads, int kpad, float scale_log2e, const float* __restrict__ out_scale, float* amax_out,
-    const float* __restrict__ rel_bias = nullptr, int rel_span = 0) {
+    const float* __restrict__ rel_bias = nullptr, int rel_span = 0, int band = 0) {
     bf16_t* out = (bf16_t*)out_v;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     static_assert(HS <= HD && HS % 16 == 0 && (HD == 64 || HD == 128), "head stride: multiple of 16, at most the LDS row");
@@ -62,7 +62,8 @@ __global__ __launch_bounds__(NW * 64) MQ_ATTN_OCC void attention_kernel(
     char* sK = smem;                      // [kpad][RB], 16-B chunks XOR-swizzled by (key & (NC-1))
     char* sV = smem + (size_t)kpad * RB;  // [kpad][RB], same image
 
-    const int seq = blockIdx.x / heads, h = blockIdx.x - seq * heads;
+    const unsigned vblk = xcd_banded_block(blockIdx.x, gridDim.x, band);   // sequences (rows of qkv / out) in the GEMMs' XCD bands
+    const int seq = vblk / heads, h = vblk - seq * heads;
     int row0, len;
     if (fixed_len > 0) { row0 = seq * fixed_len; len = fixed_len; }
     else { row0 = cu[seq]; len = cu[seq + 1] - row0; }
@@ -329,7 +330,8 @@ static int attention_impl(const void* d_qkv, void* d_out, const int32_t* d_cu_se
             if (e != hipSuccess) { mq_set_error("mq_attention: hipFuncSetAttribute: %s", hipGetErrorString(e)); return MQ_ERR_HIP; }
         }
         hipLaunchKernelGGL(kern, dim3((unsigned)(nseq * heads)), dim3(nw * 64), lds, s, (const bf16_t*)d_qkv,
-                           d_out, d_cu_seqlens, (int)fixed_len, (int)W, (int)heads, kpad, scale_log2e, d_out_scale, d_amax, d_rel_bias, (int)rel_span);
+                           d_out, d_cu_seqlens, (int)fixed_len, (int)W, (int)heads, kpad, scale_log2e, d_out_scale, d_amax, d_rel_bias, (int)rel_span,
+                           (mq_xcd_band && nseq * heads >= 2048) ? 1 : 0);
         return MQ_OK;
     };
     if (d_rel_bias) {

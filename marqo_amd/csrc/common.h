@@ -82,6 +82,18 @@ __device__ __forceinline__ float quick_gelu(float x) {
     return x / (1.0f + __expf(-1.702f * x));
 }
 
+// ---- XCD-banded block order -----------------------------------------------------------------
+// Block b of a launch runs on XCD b % 8 (observed placement, used for speed only).  The tiled GEMMs give XCD k the k-th contiguous
+// band of output tiles, i.e. of activation ROWS; the row-wise kernels between them (LayerNorm, attention) use the same banding, so the
+// rows one XCD writes are the rows the same XCD reads in the next launch and find them in its own L2 (a kernel boundary writes dirty
+// lines back but keeps them) instead of fetching them from the Infinity Cache behind another die's L2.  Bijective for any grid size.
+extern int mq_xcd_band;   // runtime.hip: mq_tune("xcd_band", 0 | 1)
+__device__ __forceinline__ unsigned xcd_banded_block(unsigned b, unsigned nb, int on) {
+    if (!on) return b;
+    const unsigned q = nb >> 3, r = nb & 7, xcd = b & 7, idx = b >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
 // ---- wave reductions ---------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -576,6 +576,7 @@ extern "C" int mq_tune(const char* key, int value) {
     else if (k == "ln_fold") mq_tower_ln_fold = value;
     else if (k == "ln_rows") mq_ln_rows_per_wave = value;
     else if (k == "ln_bf16_wide") mq_ln_bf16_wide = value;
+    else if (k == "xcd_band") mq_xcd_band = value;
     else if (k == "attn_waves") mq_attention_waves = value;
     else if (k == "residual_bf16") mq_tower_residual_bf16 = value;
     else if (k == "small_m") mq_gemm_small_max_rows = value;

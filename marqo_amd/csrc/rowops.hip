@@ -22,9 +22,9 @@ constexpr int LN_MAX_CHUNKS = 8;  // float4 chunks per lane: W <= 64 * 4 * 8 = 2
 template <int CH, int R, bool XB = false>
 __global__ __launch_bounds__(256, (CH * R <= 4 ? 8 : 4)) void layernorm_kernel(
     const void* __restrict__ xv, const int32_t* __restrict__ row_idx, const float* __restrict__ gam,
-    const float* __restrict__ bet, bf16_t* out_bf16, float* out_f32, int64_t rows, int W, float eps) {
+    const float* __restrict__ bet, bf16_t* out_bf16, float* out_f32, int64_t rows, int W, float eps, int band) {
     const int lane = threadIdx.x & 63;
-    const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+    const int64_t row0 = ((int64_t)xcd_banded_block(blockIdx.x, gridDim.x, band) * 4 + (threadIdx.x >> 6)) * R;
     if (row0 >= rows) return;
     const int nch = W >> 2;  // float4 chunks in the row
 
@@ -118,9 +118,9 @@ __global__ __launch_bounds__(256, (CH * R <= 4 ? 8 : 4)) void layernorm_kernel(
 template <int CH8, int R>
 __global__ __launch_bounds__(256) void layernorm_bf16in_kernel(
     const bf16_t* __restrict__ x, const int32_t* __restrict__ row_idx, const float* __restrict__ gam, const float* __restrict__ bet,
-    bf16_t* out_bf16, float* out_f32, int64_t rows, int W, float eps) {
+    bf16_t* out_bf16, float* out_f32, int64_t rows, int W, float eps, int band) {
     const int lane = threadIdx.x & 63;
-    const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+    const int64_t row0 = ((int64_t)xcd_banded_block(blockIdx.x, gridDim.x, band) * 4 + (threadIdx.x >> 6)) * R;
     if (row0 >= rows) return;
     const int nch = W >> 3;  // 8-element chunks in the row
     float v[R][CH8][8];
@@ -286,6 +286,7 @@ extern "C" int mq_layernorm_ex(const void* d_x, int x_bf16, const int32_t* d_row
     if (rows <= 0) return MQ_OK;
     hipStream_t s = (hipStream_t)stream;
     MqProfScope prof(1, s);
+    const int band = (mq_xcd_band && !d_row_idx && rows >= 4096) ? 1 : 0;   // dense batches only (a gather has no row locality to keep)
     // two rows per wave once there are enough rows to fill the chip that way (and the row fits: CH * 2 float4 per lane)
     // The LayerNorm form follows the GEMM family of the call: at most mq_gemm_small_max_rows rows (the search path: skinny GEMMs, whose fused
     // LayerNorm prologue sums a row in the generic kernel's lane order) keep the generic kernel, so a query has the same bits alone and inside
@@ -296,27 +297,27 @@ extern "C" int mq_layernorm_ex(const void* d_x, int x_bf16, const int32_t* d_row
         const bf16_t* xb = (const bf16_t*)d_x;
         const bool many = rows >= 16384;
         if (W <= 512) {
-            if (many && mq_ln_bf16_wide < 4) hipLaunchKernelGGL((layernorm_bf16in_kernel<1, 2>), dim3((unsigned)cdiv64(rows, 8)), dim3(256), 0, s, xb, d_row_idx, d_g, d_b, (bf16_t*)d_out_bf16, d_out_f32, rows, (int)W, eps);
-            else if (many) hipLaunchKernelGGL((layernorm_bf16in_kernel<1, 4>), dim3((unsigned)cdiv64(rows, 16)), dim3(256), 0, s, xb, d_row_idx, d_g, d_b, (bf16_t*)d_out_bf16, d_out_f32, rows, (int)W, eps);
-            else hipLaunchKernelGGL((layernorm_bf16in_kernel<1, 1>), dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, s, xb, d_row_idx, d_g, d_b, (bf16_t*)d_out_bf16, d_out_f32, rows, (int)W, eps);
+            if (many && mq_ln_bf16_wide < 4) hipLaunchKernelGGL((layernorm_bf16in_kernel<1, 2>), dim3((unsigned)cdiv64(rows, 8)), dim3(256), 0, s, xb, d_row_idx, d_g, d_b, (bf16_t*)d_out_bf16, d_out_f32, rows, (int)W, eps, band);
+            else if (many) hipLaunchKernelGGL((layernorm_bf16in_kernel<1, 4>), dim3((unsigned)cdiv64(rows, 16)), dim3(256), 0, s, xb, d_row_idx, d_g, d_b, (bf16_t*)d_out_bf16, d_out_f32, rows, (int)W, eps, band);
+            else hipLaunchKernelGGL((layernorm_bf16in_kernel<1, 1>), dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, s, xb, d_row_idx, d_g, d_b, (bf16_t*)d_out_bf16, d_out_f32, rows, (int)W, eps, band);
         } else {
-            if (rows >= 16384 && mq_ln_bf16_wide >= 4) hipLaunchKernelGGL((layernorm_bf16in_kernel<2, 4>), dim3((unsigned)cdiv64(rows, 16)), dim3(256), 0, s, xb, d_row_idx, d_g, d_b, (bf16_t*)d_out_bf16, d_out_f32, rows, (int)W, eps);
-            else if (rows >= 8192) hipLaunchKernelGGL((layernorm_bf16in_kernel<2, 2>), dim3((unsigned)cdiv64(rows, 8)), dim3(256), 0, s, xb, d_row_idx, d_g, d_b, (bf16_t*)d_out_bf16, d_out_f32, rows, (int)W, eps);
-            else hipLaunchKernelGGL((layernorm_bf16in_kernel<2, 1>), dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, s, xb, d_row_idx, d_g, d_b, (bf16_t*)d_out_bf16, d_out_f32, rows, (int)W, eps);
+            if (rows >= 16384 && mq_ln_bf16_wide >= 4) hipLaunchKernelGGL((layernorm_bf16in_kernel<2, 4>), dim3((unsigned)cdiv64(rows, 16)), dim3(256), 0, s, xb, d_row_idx, d_g, d_b, (bf16_t*)d_out_bf16, d_out_f32, rows, (int)W, eps, band);
+            else if (rows >= 8192) hipLaunchKernelGGL((layernorm_bf16in_kernel<2, 2>), dim3((unsigned)cdiv64(rows, 8)), dim3(256), 0, s, xb, d_row_idx, d_g, d_b, (bf16_t*)d_out_bf16, d_out_f32, rows, (int)W, eps, band);
+            else hipLaunchKernelGGL((layernorm_bf16in_kernel<2, 1>), dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, s, xb, d_row_idx, d_g, d_b, (bf16_t*)d_out_bf16, d_out_f32, rows, (int)W, eps, band);
         }
     } else if (x_bf16) {
         if (mq_ln_rows_per_wave >= 2 && rows >= 8192 && W <= 1024)
             MQ_DISPATCH_CH(W, hipLaunchKernelGGL((layernorm_kernel<CH, 2, true>), dim3((unsigned)cdiv64(rows, 8)), dim3(256), 0, s, d_x, d_row_idx,
-                                                 d_g, d_b, (bf16_t*)d_out_bf16, d_out_f32, rows, (int)W, eps));
+                                                 d_g, d_b, (bf16_t*)d_out_bf16, d_out_f32, rows, (int)W, eps, band));
         else
             MQ_DISPATCH_CH(W, hipLaunchKernelGGL((layernorm_kernel<CH, 1, true>), dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, s, d_x, d_row_idx,
-                                                 d_g, d_b, (bf16_t*)d_out_bf16, d_out_f32, rows, (int)W, eps));
+                                                 d_g, d_b, (bf16_t*)d_out_bf16, d_out_f32, rows, (int)W, eps, band));
     } else if (mq_ln_rows_per_wave >= 2 && rows >= 8192 && W <= 1024)
         MQ_DISPATCH_CH(W, hipLaunchKernelGGL((layernorm_kernel<CH, 2>), dim3((unsigned)cdiv64(rows, 8)), dim3(256), 0, s, d_x, d_row_idx,
-                                             d_g, d_b, (bf16_t*)d_out_bf16, d_out_f32, rows, (int)W, eps));
+                                             d_g, d_b, (bf16_t*)d_out_bf16, d_out_f32, rows, (int)W, eps, band));
     else
         MQ_DISPATCH_CH(W, hipLaunchKernelGGL((layernorm_kernel<CH, 1>), dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, s, d_x, d_row_idx,
-                                             d_g, d_b, (bf16_t*)d_out_bf16, d_out_f32, rows, (int)W, eps));
+                                             d_g, d_b, (bf16_t*)d_out_bf16, d_out_f32, rows, (int)W, eps, band));
     MQ_CHECK_LAUNCH("mq_layernorm");
     return MQ_OK;
 }
@@ -329,7 +330,7 @@ extern "C" int mq_layernorm_fp8(const float* d_x, const float* d_g, const float*
     hipStream_t s = (hipStream_t)stream;
     MqProfScope prof(1, s);
     MQ_DISPATCH_CH(W, hipLaunchKernelGGL(layernorm_fp8_kernel<CH>, dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, s, d_x, d_g, d_b,
-                                         (uint8_t*)d_out_fp8, d_row_scale, d_out_f32, rows, (int)W, eps));
+                                         (uint8_t*)d_out_fp8, d_row_scale, d_out_f32, rows, (int)W, eps, band));
     MQ_CHECK_LAUNCH("mq_layernorm_fp8");
     return MQ_OK;
 }
