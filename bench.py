@@ -323,7 +323,7 @@ def gemm_roofline(lib, L, run_local, prof_steps, precision, workload_name):
     families = {L.PROF_FAMILY_NAMES[i]: {"ms_per_step": ms[i] / prof_steps, "launches_per_step": cnt[i] // prof_steps}
                 for i in range(L.MQ_PROF_FAMILIES) if cnt[i]}
     roofline = {
-        "kernel": ("gemm_fp8_kernel (e4m3 MX MFMA 16x16x128, (32*MT)x128x128 tiles, fused epilogues)" if precision == "fp8"
+        "kernel": ("gemm_fp8_kernel (e4m3 MX MFMA 16x16x128, (32*MT)x128x128 tiles, fused epilogues; bf16 gemm_nt_kernel in the blocks the policy keeps on bf16)" if precision == "fp8"
                    else "gemm_nt_kernel (bf16 MFMA 16x16x32, (32*MT)x128x64 tiles, fused epilogues)"),
         "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
         "frac": round(achieved / peak, 4), "traffic": None,
@@ -341,7 +341,7 @@ def gemm_roofline(lib, L, run_local, prof_steps, precision, workload_name):
     # HBM-side traffic of the dominant kernel from the committed PMC passes of this same command (tools/gpu_evidence.sh:
     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH doubled per MI355X_MICROARCH.md; PMC cannot be sampled
     # from inside this process).  Bytes per launch, averaged over the GEMM launches like `achieved`.
-    for rnd in ("r02", "r01"):
+    for rnd in ("r03", "r02", "r01"):
         tpath = os.path.join(ROOT, "profiles", f"{rnd}_traffic_{workload_name}_{precision}.json")
         if not os.path.isfile(tpath):
             continue
@@ -442,6 +442,10 @@ def e2e_vectorise(dev, images_cpu_u8, tower_only_rate, reps=6):
     best = max(out["ndarray_from_u8_arrays_4_callers"], out["ndarray_from_device_tensors_4_callers"], out["ndarray_from_u8_arrays"],
                out["ndarray_from_device_tensors"], out["ndarray_from_pil_4_callers"], out["ndarray_from_pil"])
     out["best_e2e_over_tower_only"] = round(best / tower_only_rate, 3)
+    # THE end-to-end figure: one synchronous caller handing over PIL images, as add_documents / search hand them to vectorise()
+    out["headline_e2e"] = {"form": "ndarray_from_pil", "value": out["ndarray_from_pil"], "over_tower_only": round(out["ndarray_from_pil"] / tower_only_rate, 3),
+                           "note": "floor of a single synchronous caller: host pack of 51 MB of Pillow RGBX (2.2 ms) + H2D + resize + tower + D2H are serial "
+                                   "(profiles/r03i_e2e_phases_1thread.txt); chunked pipelining inside the call measured slower (r03i_e2e_pipeline_chunk_ab.txt)"}
     s2.clear_loaded_models()
     return out
 

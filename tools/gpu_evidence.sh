@@ -21,7 +21,7 @@ cd $REPO
 python tools/pmc_sq_summary.py $OUT/pmc_SQ > $OUT/sq.txt 2>&1
 python tools/rocpd_summary.py $(ls $OUT/prof/*results.db | head -1) $OUT/kernel_stats.csv 2>>$OUT/prof.err
 python tools/pmc_traffic.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE --json $OUT/traffic.json > $OUT/traffic.txt 2>&1
-cp $OUT/traffic.json profiles/r02_traffic_vit_b32_image_bf16.json   # bench.py reads roofline.traffic from here
+cp $OUT/traffic.json profiles/r03_traffic_vit_b32_image_bf16.json   # bench.py reads roofline.traffic from here
 timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 rm -rf $OUT/prof $OUT/pmc_FETCH_SIZE/*.db $OUT/pmc_WRITE_SIZE/*.db $OUT/pmc_SQ/*.db 2>/dev/null
 cat $OUT/pytest_gpu.log 2>/dev/null; cat $OUT/bench.json; head -9 $OUT/kernel_stats.csv | cut -c1-180; grep -E "gemm|layernorm|attention|patchify" $OUT/traffic.txt | cut -c1-140; cat $OUT/sq.txt
