@@ -30,6 +30,8 @@ extern int mq_attention_waves;    // attention.hip
 extern int mq_tower_residual_bf16;  // towers.hip
 extern int mq_gemm_small_max_rows;  // gemm_small.hip
 bool mq_gemm_small_ok(int64_t M, int64_t N, int64_t K, bool ln);
+bool mq_gemm_small_grouped_ok(int64_t M, int64_t N, int64_t K);
+extern int mq_gemm_small_group_rows;
 int mq_gemm_small(const void* d_A, int64_t lda, const void* d_W, int64_t ldw, const float* d_bias, const void* d_residual, void* d_out,
                   int64_t ldc, int64_t M, int64_t N, int64_t K, int flags, hipStream_t s);
 
@@ -494,7 +496,7 @@ extern "C" int mq_gemm_bf16(const void* d_A, int64_t lda, const void* d_W, int64
     hipStream_t s = (hipStream_t)stream;
     // a handful of rows (single queries, pooled rows of a small batch): the column-sliced skinny kernel spreads the weight stream over the
     // whole chip instead of N/128 workgroups (gemm_small.hip)
-    if (mq_gemm_small_ok(M, N, K, false)) return mq_gemm_small(d_A, lda, d_W, ldw, d_bias, d_residual, d_out, ldc, M, N, K, flags, s);
+    if (mq_gemm_small_ok(M, N, K, false) || mq_gemm_small_grouped_ok(M, N, K)) return mq_gemm_small(d_A, lda, d_W, ldw, d_bias, d_residual, d_out, ldc, M, N, K, flags, s);
     MqProfScope prof(0, s, 2.0 * (double)M * (double)N * (double)K);
     const int m = (int)M, n = (int)N, k = (int)K;
 #define MQ_GEMM_CASE(F) \
@@ -580,6 +582,7 @@ extern "C" int mq_tune(const char* key, int value) {
     else if (k == "attn_waves") mq_attention_waves = value;
     else if (k == "residual_bf16") mq_tower_residual_bf16 = value;
     else if (k == "small_m") mq_gemm_small_max_rows = value;
+    else if (k == "small_m_grouped") mq_gemm_small_group_rows = value;
     else { mq_set_error("mq_tune: unknown key %s", key); return MQ_ERR_INVALID; }
     return MQ_OK;
 }

@@ -44,6 +44,15 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(const void* __restr
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.x * SM_BN;
+    if (!LN && gridDim.y > 1) {
+        // row groups (81 .. mq_gemm_small_group_rows rows): workgroup (x, y) owns the 16 columns of slice x for rows [y * 16 MT, (y + 1) * 16 MT);
+        // the weight slice is fetched once from HBM and then from L2 by the other groups
+        const int64_t r0 = (int64_t)blockIdx.y * (MT * 16);
+        Av = (const bf16_t*)Av + r0 * lda;
+        if (FLAGS & MQ_EPI_RESIDUAL) residual = (const char*)residual + r0 * ldc * (RES_BF16 ? 2 : 4);
+        out = (char*)out + r0 * ldc * (BF16_OUT ? 2 : 4);
+        M = min(M - (int)r0, MT * 16);
+    }
     const int rowb = ln_row_bytes(K);
     // partial sums: [NW waves][MT][64 lanes] f32x4 — behind the LN image when there is one
     f32x4* part = (f32x4*)(smem + (LN ? ((MT * 16 * rowb + 255) & ~255) : 0));
@@ -211,7 +220,8 @@ int launch_small(const void* A, int64_t lda, int a_stream16, const void* W, int6
             return MQ_ERR_HIP;
         }
     }
-    hipLaunchKernelGGL((gemm_small_kernel<FLAGS, MT, LN, NW>), dim3((unsigned)((N + SM_BN - 1) / SM_BN)), dim3(NW * 64), lds, s, A, lda, a_stream16,
+    const unsigned groups = LN ? 1u : (unsigned)((M + MT * 16 - 1) / (MT * 16));
+    hipLaunchKernelGGL((gemm_small_kernel<FLAGS, MT, LN, NW>), dim3((unsigned)((N + SM_BN - 1) / SM_BN), groups), dim3(NW * 64), lds, s, A, lda, a_stream16,
                        (const bf16_t*)W, ldw, bias, residual, out, ldc, M, N, K, ln_g, ln_b, eps, ln_out, ln_rows);
     MQ_CHECK_LAUNCH("mq_gemm_small");
     return MQ_OK;
@@ -225,7 +235,9 @@ int dispatch_mt(const void* A, int64_t lda, int a_stream16, const void* W, int64
         if (M <= 16) MQ_SM_MT(1);
         MQ_SM_MT(2);
     } else {
-        const int mt = (M + 15) / 16;   // row tiles are guarded: the next instantiated height
+        // more than 80 rows: the fewest row groups of at most 5 row tiles, then the smallest height that covers them (256 rows = 4 x 64)
+        const int mt_all = (M + 15) / 16, groups = (mt_all + SM_MAX_MT - 1) / SM_MAX_MT;
+        const int mt = (mt_all + groups - 1) / groups;   // row tiles are guarded: the next instantiated height
         if (mt <= 1) MQ_SM_MT(1);
         if (mt <= 2) MQ_SM_MT(2);
         if (mt <= 3) MQ_SM_MT(3);
@@ -251,7 +263,18 @@ int dispatch_nw(const void* A, int64_t lda, int a_stream16, const void* W, int64
 // knob: rows up to which the towers take the skinny path (0 = never).  mq_tune("small_m", v) / MQ_SMALL_M
 int mq_gemm_small_max_rows = getenv("MQ_SMALL_M") ? atoi(getenv("MQ_SMALL_M")) : 80;
 
-// can this call run on the skinny kernel?  (shape rules + LDS budget of the fused LayerNorm)
+// knob: rows up to which a plain GEMM call (no fused LayerNorm) still takes the skinny kernel, in row groups of <= 80 (0 = no grouping).
+// mq_tune("small_m_grouped", v) / MQ_SMALL_M_GROUPED.  This is what the pooled-rows-only last block of a 256-item batch runs (M = 256: the
+// tiled kernel gave those calls 12-48 workgroups, 11-28 us each) and what a request of a few items runs in every block.
+int mq_gemm_small_group_rows = getenv("MQ_SMALL_M_GROUPED") ? atoi(getenv("MQ_SMALL_M_GROUPED")) : 320;
+
+bool mq_gemm_small_grouped_ok(int64_t M, int64_t N, int64_t K) {
+    if (mq_gemm_small_max_rows <= 0 || M <= mq_gemm_small_max_rows || M <= SM_MAX_MT * 16 || M > mq_gemm_small_group_rows) return false;
+    return N % 4 == 0 && K % 32 == 0 && K >= 32;
+}
+
+// can this call run on the skinny kernel in ONE row group?  (shape rules + LDS budget of the fused LayerNorm)  The towers also read this as
+// "is this call on the search path" (LayerNorm fusion, graph replay, no row selection), which is why the grouped form has its own predicate.
 bool mq_gemm_small_ok(int64_t M, int64_t N, int64_t K, bool ln) {
     if (mq_gemm_small_max_rows <= 0 || M < 1 || M > mq_gemm_small_max_rows || M > SM_MAX_MT * 16) return false;
     if (N % 4 != 0 || K % 32 != 0 || K < 32) return false;
@@ -265,7 +288,8 @@ bool mq_gemm_small_ok(int64_t M, int64_t N, int64_t K, bool ln) {
 // out = epi(A @ W^T): A bf16 [M, K].  flags as mq_gemm_bf16 (incl. MQ_EPI_BIAS | MQ_EPI_RESIDUAL = bf16 residual in / out).
 int mq_gemm_small(const void* d_A, int64_t lda, const void* d_W, int64_t ldw, const float* d_bias, const void* d_residual, void* d_out,
                   int64_t ldc, int64_t M, int64_t N, int64_t K, int flags, hipStream_t s) {
-    MQ_CHECK_ARG(mq_gemm_small_ok(M, N, K, false), "mq_gemm_small: shape M=%ld N=%ld K=%ld unsupported", (long)M, (long)N, (long)K);
+    MQ_CHECK_ARG(mq_gemm_small_ok(M, N, K, false) || mq_gemm_small_grouped_ok(M, N, K), "mq_gemm_small: shape M=%ld N=%ld K=%ld unsupported", (long)M,
+                 (long)N, (long)K);
     MqProfScope prof(0, s, 2.0 * (double)M * (double)N * (double)K);
 #define MQ_SM_CASE(F) \
     case (F): return dispatch_nw<(F), false>(d_A, lda, 0, d_W, ldw, d_bias, d_residual, d_out, ldc, (int)M, (int)N, (int)K, nullptr, nullptr, 0.f, nullptr, nullptr, s)

@@ -330,7 +330,7 @@ extern "C" int mq_layernorm_fp8(const float* d_x, const float* d_g, const float*
     hipStream_t s = (hipStream_t)stream;
     MqProfScope prof(1, s);
     MQ_DISPATCH_CH(W, hipLaunchKernelGGL(layernorm_fp8_kernel<CH>, dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, s, d_x, d_g, d_b,
-                                         (uint8_t*)d_out_fp8, d_row_scale, d_out_f32, rows, (int)W, eps, band));
+                                         (uint8_t*)d_out_fp8, d_row_scale, d_out_f32, rows, (int)W, eps));
     MQ_CHECK_LAUNCH("mq_layernorm_fp8");
     return MQ_OK;
 }
