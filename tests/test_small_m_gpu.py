@@ -150,3 +150,72 @@ def test_single_query_towers_on_the_skinny_path():
             assert _cos_err(a, c) < 1e-4   # two summation orders of the same products (and, under the bf16 residual stream, of the same bf16-rounded x)
     finally:
         L.check(lib.mq_tune(b"small_m", 80))
+
+
+@pytest.mark.parametrize("M", [81, 100, 192, 256, 320])
+def test_skinny_gemm_in_row_groups(M):
+    """81..320 rows (the pooled rows of a 256-item batch's last block; a request of a few items): the same kernel, one workgroup per
+    (16-column slice, <= 80-row group).  Against the fp32 reference for every epilogue, deterministic, and every row bit-identical to the
+    same row in a ONE-group call of its own (a row's arithmetic does not depend on its group), which is also what mq_gemm_bf16 routes."""
+    lib = L.load()
+    g = torch.Generator(device="cuda").manual_seed(1000 + M)
+    B, G, Q, R, F = L.MQ_EPI_BIAS, L.MQ_EPI_GELU, L.MQ_EPI_QUICKGELU, L.MQ_EPI_RESIDUAL, L.MQ_EPI_OUT_F32
+    for (N, K) in ((768, 768), (768, 3072), (3072, 768), (2304, 768), (512, 768), (100, 96), (1024, 4096)):
+        A = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+        W = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).to(torch.bfloat16)
+        bias = torch.randn(N, device="cuda", generator=g)
+        res = torch.randn(M, N, device="cuda", generator=g)
+        ref = A.float() @ W.float().t()
+        rb = ref + bias
+        cases = ((0, None, ref), (F, None, ref), (B, None, rb), (B | G, None, torch.nn.functional.gelu(rb)),
+                 (B | Q, None, rb * torch.sigmoid(1.702 * rb)), (B | R | F, res, rb + res),
+                 (B | R, res.to(torch.bfloat16), rb + res.to(torch.bfloat16).float()))
+        for flags, r, want in cases:
+            f32 = bool(flags & F)
+            dt = torch.float32 if f32 else torch.bfloat16
+            out = _small(lib, A, W, bias, r, flags, dt)
+            err = (out.float() - want).abs().max().item() / (want.abs().max().item() + 1e-6)
+            assert err < (2e-3 if f32 else 2e-2), (M, N, K, flags, err)
+            assert torch.equal(out, _small(lib, A, W, bias, r, flags, dt))
+            for m in (0, 79, 80, M - 1):                       # first group, both sides of a group edge, the ragged tail
+                one = _small(lib, A[m:m + 1].contiguous(), W, bias, None if r is None else r[m:m + 1].contiguous(), flags, dt)
+                assert torch.equal(one[0], out[m]), (M, N, K, flags, m)
+        via = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        L.check(lib.mq_gemm_bf16(A.data_ptr(), K, W.data_ptr(), K, L.ptr(bias), 0, via.data_ptr(), N, M, N, K, B, _stream()))
+        assert torch.equal(via, _small(lib, A, W, bias, None, B, torch.bfloat16))
+    # past the knob the public GEMM is the tiled kernel again, and the skinny entry point refuses
+    A = torch.randn(321, 768, device="cuda", generator=g).to(torch.bfloat16)
+    W = (torch.randn(512, 768, device="cuda", generator=g) / 28).to(torch.bfloat16)
+    out = torch.empty(321, 512, device="cuda", dtype=torch.bfloat16)
+    assert lib.mq_gemm_small_bf16(A.data_ptr(), 768, W.data_ptr(), 768, 0, 0, out.data_ptr(), 512, 321, 512, 768, 0, _stream()) != 0
+    try:
+        L.check(lib.mq_tune(b"small_m_grouped", 0))
+        assert lib.mq_gemm_small_bf16(A.data_ptr(), 768, W.data_ptr(), 768, 0, 0, out.data_ptr(), 512, 256, 512, 768, 0, _stream()) != 0
+    finally:
+        L.check(lib.mq_tune(b"small_m_grouped", 320))
+
+
+def test_few_item_requests_on_the_grouped_path():
+    """4 images (200 rows) / 16 short texts: every block's GEMMs run in row groups.  Against the fp32 oracle and against the tiled kernels."""
+    from marqo_amd.engine import archs, synthetic, towers
+    lib = L.load()
+    v, t = archs.resolve_open_clip("ViT-B-32")
+    sd = synthetic.random_open_clip_state_dict(vision=v, text=t, seed=0)
+    tt, vt = towers.ClipTextTower(t, sd, "cuda"), towers.VitTower(v, sd, "cuda")
+    ids = torch.zeros(16, t.ctx, dtype=torch.int64)
+    for i in range(16):
+        n_tok = 6 + i
+        ids[i, 0], ids[i, 1 + n_tok] = t.vocab - 2, t.vocab - 1
+        ids[i, 1:1 + n_tok] = torch.randint(1, t.vocab - 2, (n_tok,), generator=torch.Generator().manual_seed(i))
+    u8 = O.synthetic_images_u8(4, v.image_size, seed=4)
+    ref_t = O.clip_text_forward(sd, O.ClipTextConfig(t.vocab, t.ctx, t.width, t.layers, t.heads, t.mlp_dim, t.out_dim), ids)
+    ref_v = O.vit_forward(sd, O.VitConfig(v.image_size, v.patch_size, v.width, v.layers, v.heads, v.mlp_dim, v.out_dim), O.preprocess_u8_exact_size(u8))
+    try:
+        grouped_t, grouped_v = tt.encode_ids(ids), vt.encode_u8(u8.cuda())
+        assert _cos_err(grouped_t, ref_t) < 1e-4 and _cos_err(grouped_v, ref_v) < 1e-4
+        L.check(lib.mq_tune(b"small_m_grouped", 0))
+        tiled_t, tiled_v = tt.encode_ids(ids), vt.encode_u8(u8.cuda())
+        assert _cos_err(grouped_t, tiled_t) < 1e-4 and _cos_err(grouped_v, tiled_v) < 1e-4
+        assert not torch.equal(grouped_v, tiled_v)          # (the knob does switch families)
+    finally:
+        L.check(lib.mq_tune(b"small_m_grouped", 320))

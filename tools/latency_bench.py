@@ -47,12 +47,15 @@ def main():
         rows.append((name + " image, 1 x u8 on host", *timeit(lambda: vt.encode_u8(img))))
         rows.append((name + " image, 1 x u8 on device", *timeit(lambda: vt.encode_u8(img_d))))
         rows.append((name + " text, 16 queries", *timeit(lambda: tt.encode_ids(ids.repeat(16, 1)))))
+        img4 = torch.randint(0, 256, (4, v.image_size, v.image_size, 3), dtype=torch.uint8).to(dev)
+        rows.append((name + " image, 4 x u8 on device", *timeit(lambda: vt.encode_u8(img4))))
         del vt, tt
     if not args.only or args.only in "e5-base-v2":
         b = archs.HF_BERT_ARCHS["intfloat/e5-base-v2"]
         bt = towers.BertTower(b, synthetic.random_bert_state_dict(b, seed=0), dev)
         ids = torch.randint(1000, b.vocab, (1, 12)); mask = torch.ones(1, 12, dtype=torch.int64)
         rows.append(("e5-base-v2 text, 1 query (12 tokens)", *timeit(lambda: bt.encode_ids(ids, mask))))
+        rows.append(("e5-base-v2 text, 16 queries (12 tokens)", *timeit(lambda: bt.encode_ids(ids.repeat(16, 1), mask.repeat(16, 1)))))
     for r in rows:
         print(f"{r[0]:44s} p50 {r[1]:7.3f} ms   p95 {r[2]:7.3f} ms")
 
