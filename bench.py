@@ -232,7 +232,7 @@ class Workload:
             # load-time policy of the product (engine/towers.py::tune_fp8): static scales + how many trailing blocks run on e4m3 inside
             # MARQO_AMD_FP8_BUDGET (default 7e-4 vs the bf16 tower; set it to 1 to force every block onto fp8), outside the timed region
             self.fp8_policy = [{"layers": t.cfg.enc.layers, "fp8_first_layer": t.tune_fp8_default(), "fp8_mlp_extra": t.fp8_mlp_extra, "policy_trace": t.fp8_policy_trace,
-                                "calibration_err_vs_bf16": t.fp8_calibration_error,
+                                "residual_stream": t.residual_stream, "calibration_err_vs_bf16": t.fp8_calibration_error,
                                 "all_blocks_err_vs_bf16": t.fp8_all_blocks_error} for t in self.towers]
 
     def cpu_baseline(self, gpu_out, target_seconds):

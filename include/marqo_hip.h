@@ -389,6 +389,10 @@ int mq_layernorm_fp8(const float* d_x, const float* d_g, const float* d_b, void*
                      float* d_out_f32 /* optional fp32 copy of LN(x) (post-LN models), may be NULL */,
                      int64_t rows, int32_t W, float eps, void* stream);
 
+/* the same with the input rows in bf16 (x_bf16 != 0: the bf16 residual stream of an fp8 tower; d_out_f32 must then be NULL) */
+int mq_layernorm_fp8_ex(const void* d_x, int x_bf16, const float* d_g, const float* d_b, void* d_out_fp8, float* d_row_scale,
+                        float* d_out_f32, int64_t rows, int32_t W, float eps, void* stream);
+
 /* Per-row e4m3 quantisation without normalisation: q[r,:] = x[r,:] / s[r], s[r] = max|x[r,:]| / 448 (the GEMM operand of the
  * first block of a post-LN fp8 encoder). */
 int mq_rowquant_fp8(const float* d_x, void* d_out_fp8, float* d_row_scale, int64_t rows, int32_t W, void* stream);

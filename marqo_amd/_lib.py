@@ -151,6 +151,7 @@ _SIGNATURES = {
                               C.c_int64, C.c_int, _P]),
     "mq_quantize_weights_fp8": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, C.c_int64, C.c_int64, _P]),
     "mq_layernorm_fp8": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, C.c_int32, C.c_float, _P]),
+    "mq_layernorm_fp8_ex": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, C.c_int64, C.c_int32, C.c_float, _P]),
     "mq_rowquant_fp8": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, _P]),
     "mq_layernorm": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, C.c_int32, C.c_float, _P]),
     "mq_layernorm_ex": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, C.c_int64, C.c_int32, C.c_float, _P]),

@@ -227,8 +227,14 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt) {
                         const int n = wave_n0 + nt * 16 + g * 4;
-                        res_v[h][nt] = (mt_lo + h < MT && m < M && n < N) ? *(const f32x4*)(residual + (int64_t)m * ldc + n)
-                                                                        : f32x4{0.f, 0.f, 0.f, 0.f};
+                        const bool ok = mt_lo + h < MT && m < M && n < N;
+                        if (FLAGS & MQ_EPI_OUT_F32) {
+                            res_v[h][nt] = ok ? *(const f32x4*)(residual + (int64_t)m * ldc + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+                        } else {   // bf16 residual stream: read-modify-write of the bf16 rows (BIAS | RESIDUAL, bf16 out)
+                            const uint2 q = ok ? *(const uint2*)((const bf16_t*)residual + (int64_t)m * ldc + n) : make_uint2(0u, 0u);
+                            res_v[h][nt] = f32x4{__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u), __uint_as_float(q.y << 16),
+                                                 __uint_as_float(q.y & 0xffff0000u)};
+                        }
                     }
                 }
             }
@@ -467,6 +473,7 @@ extern "C" int mq_gemm_fp8(const void* d_A8, int64_t lda, const void* d_W8, int6
         MQ_FP8_CASE(MQ_EPI_BIAS | MQ_EPI_GELU | MQ_EPI_OUT_FP8);
         MQ_FP8_CASE(MQ_EPI_BIAS | MQ_EPI_QUICKGELU | MQ_EPI_OUT_FP8);
         MQ_FP8_CASE(MQ_EPI_BIAS | MQ_EPI_RESIDUAL | MQ_EPI_OUT_F32);
+        MQ_FP8_CASE(MQ_EPI_BIAS | MQ_EPI_RESIDUAL);   // bf16 residual in / out (d_residual and d_out are bf16 [M, ldc]: the bf16 residual stream)
         default:
             mq_set_error("mq_gemm_fp8: unsupported epilogue flag combination 0x%x", flags);
             return MQ_ERR_INVALID;

@@ -203,20 +203,26 @@ __global__ __launch_bounds__(256) void layernorm_bf16in_kernel(
 // LN with e4m3 output and a dynamic per-row scale (the row is already in registers, so the absmax is one wave reduction)
 // NORM = false: no normalisation / affine, only the per-row e4m3 quantisation of x itself (the first block of a post-LN fp8
 // encoder, whose input rows come from the embedding kernels)
-template <int CH, bool NORM = true>
+// XB = the input rows are bf16 (the bf16 residual stream)
+template <int CH, bool NORM = true, bool XB = false>
 __global__ __launch_bounds__(256, (CH <= 4 ? 8 : 4)) void layernorm_fp8_kernel(
-    const float* __restrict__ x, const float* __restrict__ gam, const float* __restrict__ bet, uint8_t* __restrict__ out8,
+    const void* __restrict__ x, const float* __restrict__ gam, const float* __restrict__ bet, uint8_t* __restrict__ out8,
     float* __restrict__ row_scale, float* out_f32, int64_t rows, int W, float eps) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    const float* xr = x + row * W;
     const int nch = W >> 2;
     f32x4 v[CH];
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
         const int c = lane + i * 64;
-        v[i] = c < nch ? *(const f32x4*)(xr + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (c >= nch) { v[i] = f32x4{0.f, 0.f, 0.f, 0.f}; continue; }
+        if (XB) {
+            const uint2 q = *(const uint2*)((const bf16_t*)x + row * W + c * 4);
+            v[i] = f32x4{__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u), __uint_as_float(q.y << 16), __uint_as_float(q.y & 0xffff0000u)};
+        } else {
+            v[i] = *(const f32x4*)((const float*)x + row * W + c * 4);
+        }
     }
     if (NORM) ln_normalize_row<CH>(v, lane, nch, W, eps);
     float mx = 0.f;
@@ -322,17 +328,28 @@ extern "C" int mq_layernorm_ex(const void* d_x, int x_bf16, const int32_t* d_row
     return MQ_OK;
 }
 
-extern "C" int mq_layernorm_fp8(const float* d_x, const float* d_g, const float* d_b, void* d_out_fp8, float* d_row_scale, float* d_out_f32,
-                                int64_t rows, int32_t W, float eps, void* stream) {
+// x fp32 [rows, W], or (x_bf16) the bf16 residual stream; e4m3 rows + per-row scales out; d_out_f32 (optional, fp32 x only): the normalised rows
+extern "C" int mq_layernorm_fp8_ex(const void* d_x, int x_bf16, const float* d_g, const float* d_b, void* d_out_fp8, float* d_row_scale,
+                                   float* d_out_f32, int64_t rows, int32_t W, float eps, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
     MQ_CHECK_ARG(d_x && d_g && d_b && d_out_fp8 && d_row_scale, "mq_layernorm_fp8: null pointer");
     MQ_CHECK_ARG(W >= 4 && W % 4 == 0 && W <= 64 * 4 * LN_MAX_CHUNKS, "mq_layernorm_fp8: W=%d unsupported (multiple of 4, <= 2048)", W);
+    MQ_CHECK_ARG(!x_bf16 || !d_out_f32, "mq_layernorm_fp8: the fp32 copy of the normalised rows belongs to the fp32 stream");
     if (rows <= 0) return MQ_OK;
-    hipStream_t s = (hipStream_t)stream;
     MqProfScope prof(1, s);
-    MQ_DISPATCH_CH(W, hipLaunchKernelGGL(layernorm_fp8_kernel<CH>, dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, s, d_x, d_g, d_b,
-                                         (uint8_t*)d_out_fp8, d_row_scale, d_out_f32, rows, (int)W, eps));
+    if (x_bf16)
+        MQ_DISPATCH_CH(W, hipLaunchKernelGGL((layernorm_fp8_kernel<CH, true, true>), dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, s, d_x, d_g, d_b,
+                                             (uint8_t*)d_out_fp8, d_row_scale, d_out_f32, rows, (int)W, eps));
+    else
+        MQ_DISPATCH_CH(W, hipLaunchKernelGGL((layernorm_fp8_kernel<CH, true, false>), dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, s, d_x, d_g, d_b,
+                                             (uint8_t*)d_out_fp8, d_row_scale, d_out_f32, rows, (int)W, eps));
     MQ_CHECK_LAUNCH("mq_layernorm_fp8");
     return MQ_OK;
+}
+
+extern "C" int mq_layernorm_fp8(const float* d_x, const float* d_g, const float* d_b, void* d_out_fp8, float* d_row_scale, float* d_out_f32,
+                                int64_t rows, int32_t W, float eps, void* stream) {
+    return mq_layernorm_fp8_ex(d_x, 0, d_g, d_b, d_out_fp8, d_row_scale, d_out_f32, rows, W, eps, stream);
 }
 
 extern "C" int mq_rowquant_fp8(const float* d_x, void* d_out_fp8, float* d_row_scale, int64_t rows, int32_t W, void* stream) {
@@ -341,7 +358,7 @@ extern "C" int mq_rowquant_fp8(const float* d_x, void* d_out_fp8, float* d_row_s
     if (rows <= 0) return MQ_OK;
     hipStream_t s = (hipStream_t)stream;
     MqProfScope prof(1, s);
-    MQ_DISPATCH_CH(W, hipLaunchKernelGGL((layernorm_fp8_kernel<CH, false>), dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, s, d_x,
+    MQ_DISPATCH_CH(W, hipLaunchKernelGGL((layernorm_fp8_kernel<CH, false>), dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, s, (const void*)d_x,
                                          (const float*)nullptr, (const float*)nullptr, (uint8_t*)d_out_fp8, d_row_scale, (float*)nullptr, rows,
                                          (int)W, 0.f));
     MQ_CHECK_LAUNCH("mq_rowquant_fp8");

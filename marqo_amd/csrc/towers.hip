@@ -60,8 +60,10 @@ static int ln_gemm(const void* d_x, int xb, const float* g, const float* b, floa
 }
 // true when a tower with this encoder config keeps its residual stream in bf16
 static bool stream_bf16(const mq_encoder_cfg* c) {
-    const bool want = c->residual_stream == 1 || (c->residual_stream == 0 && mq_tower_residual_bf16);   // per-model policy, else the process default
-    return want && c->precision == MQ_PREC_BF16 && !c->post_ln && !(mq_tower_ln_fold) && !c->mlp_glu && !c->d_rope_inv_freq;
+    // per-model policy, else the process default (bf16 towers only: an fp8 tower takes the bf16 stream when its load-time policy asks for it)
+    const bool want = c->residual_stream == 1 || (c->residual_stream == 0 && mq_tower_residual_bf16 && c->precision == MQ_PREC_BF16);
+    return want && (c->precision == MQ_PREC_BF16 || c->precision == MQ_PREC_FP8) && !c->post_ln && !(mq_tower_ln_fold) && !c->mlp_glu &&
+           !c->d_rope_inv_freq;
 }
 
 extern "C" int mq_gemm_bf16_ln(const void* d_A, int64_t lda, const void* d_W, int64_t ldw, const float* d_bias, const float* d_residual,
@@ -171,16 +173,18 @@ int last_block_selected(const mq_encoder_cfg* cfg, const mq_block_weights& b, in
         const float* s_attn = cfg->d_fp8_act_scale + 2 * l;
         const float* s_mlp = s_attn + 1;
         const int act8 = act_flag | MQ_EPI_BIAS | MQ_EPI_OUT_FP8;
-        MQ_TRY(mq_layernorm_fp8(d_x, b.ln1_g, b.ln1_b, h, row_scale, nullptr, rows, W, cfg->ln_eps, s));
+        const int xb = stream_bf16(cfg) ? 1 : 0;
+        const int rflags = xb ? (MQ_EPI_BIAS | MQ_EPI_RESIDUAL) : res_flags;
+        MQ_TRY(mq_layernorm_fp8_ex(d_x, xb, b.ln1_g, b.ln1_b, h, row_scale, nullptr, rows, W, cfg->ln_eps, s));
         MQ_TRY(mq_gemm_fp8(h, W, b.qkv_w8, W, row_scale, 1, b.qkv_ws, b.qkv_b, nullptr, qf, 3 * Wa, nullptr, nullptr, rows, 3 * Wa, W,
                            MQ_EPI_BIAS, s));
         MQ_TRY(mq_attention_ex(qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, cfg->heads, cfg->mask, 1, s_attn, nullptr, s));
         MQ_TRY(mq_move_rows(a, d_sel, h, nsel, (int64_t)Wa, false, s));
-        MQ_TRY(mq_move_rows(d_x, d_sel, x_sel, nsel, (int64_t)W * 4, false, s));
-        MQ_TRY(mq_gemm_fp8(h, Wa, b.out_w8, Wa, s_attn, 0, b.out_ws, b.out_b, x_sel, x_sel, W, nullptr, nullptr, nsel, W, Wa, res_flags, s));
-        MQ_TRY(mq_layernorm_fp8(x_sel, b.ln2_g, b.ln2_b, a, row_scale, nullptr, nsel, W, cfg->ln_eps, s));
+        MQ_TRY(mq_move_rows(d_x, d_sel, x_sel, nsel, (int64_t)W * (xb ? 2 : 4), false, s));
+        MQ_TRY(mq_gemm_fp8(h, Wa, b.out_w8, Wa, s_attn, 0, b.out_ws, b.out_b, x_sel, x_sel, W, nullptr, nullptr, nsel, W, Wa, rflags, s));
+        MQ_TRY(mq_layernorm_fp8_ex(x_sel, xb, b.ln2_g, b.ln2_b, a, row_scale, nullptr, nsel, W, cfg->ln_eps, s));
         MQ_TRY(mq_gemm_fp8(a, W, b.fc1_w8, W, row_scale, 1, b.fc1_ws, b.fc1_b, nullptr, qf, F, s_mlp, nullptr, nsel, F, W, act8, s));
-        MQ_TRY(mq_gemm_fp8(qf, F, b.fc2_w8, F, s_mlp, 0, b.fc2_ws, b.fc2_b, x_sel, x_sel, W, nullptr, nullptr, nsel, W, F, res_flags, s));
+        MQ_TRY(mq_gemm_fp8(qf, F, b.fc2_w8, F, s_mlp, 0, b.fc2_ws, b.fc2_b, x_sel, x_sel, W, nullptr, nullptr, nsel, W, F, rflags, s));
     } else if (!cfg->post_ln) {
         const int xb = stream_bf16(cfg) ? 1 : 0;                 // bf16 residual stream: rows of 2 bytes per element, bf16 RMW epilogues
         const int rflags = xb ? (MQ_EPI_BIAS | MQ_EPI_RESIDUAL) : res_flags;
@@ -209,7 +213,7 @@ int last_block_selected(const mq_encoder_cfg* cfg, const mq_block_weights& b, in
         MQ_TRY(mq_gemm_bf16(qf, F, b.fc2_w, F, b.fc2_b, x_sel, x_sel, W, nsel, W, F, res_flags, s));
         MQ_TRY(mq_layernorm(x_sel, nullptr, b.ln2_g, b.ln2_b, nullptr, x_sel, nsel, W, cfg->ln_eps, s));
     }
-    MQ_TRY(mq_move_rows(d_x, d_sel, x_sel, nsel, (int64_t)W * (!f8 && stream_bf16(cfg) ? 2 : 4), true, s));
+    MQ_TRY(mq_move_rows(d_x, d_sel, x_sel, nsel, (int64_t)W * (stream_bf16(cfg) ? 2 : 4), true, s));
     return MQ_OK;
 }
 
@@ -317,14 +321,16 @@ int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* bloc
                 MQ_TRY(mq_layernorm_fp8(d_x, b.ln2_g, b.ln2_b, h, row_scale, d_x, rows, W, cfg->ln_eps, s));
                 continue;
             }
-            MQ_TRY(mq_layernorm_fp8(d_x, b.ln1_g, b.ln1_b, h, row_scale, nullptr, rows, W, cfg->ln_eps, s));
+            const int xb = stream_bf16(cfg) ? 1 : 0;     // the stream itself may be bf16 (decided per model at load): bf16 RMW epilogues, bf16-in LN
+            const int rflags = xb ? (MQ_EPI_BIAS | MQ_EPI_RESIDUAL) : res_flags;
+            MQ_TRY(mq_layernorm_fp8_ex(d_x, xb, b.ln1_g, b.ln1_b, h, row_scale, nullptr, rows, W, cfg->ln_eps, s));
             MQ_TRY(mq_gemm_fp8(h, W, b.qkv_w8, W, row_scale, 1, b.qkv_ws, b.qkv_b, nullptr, qf, 3 * Wa, nullptr, nullptr, rows, 3 * Wa, W,
                                MQ_EPI_BIAS, s));
             MQ_TRY(mq_attention_ex(qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, cfg->heads, cfg->mask, 1, s_attn, m_attn, s));
-            MQ_TRY(mq_gemm_fp8(a, Wa, b.out_w8, Wa, s_attn, 0, b.out_ws, b.out_b, d_x, d_x, W, nullptr, nullptr, rows, W, Wa, res_flags, s));
-            MQ_TRY(mq_layernorm_fp8(d_x, b.ln2_g, b.ln2_b, h, row_scale, nullptr, rows, W, cfg->ln_eps, s));
+            MQ_TRY(mq_gemm_fp8(a, Wa, b.out_w8, Wa, s_attn, 0, b.out_ws, b.out_b, d_x, d_x, W, nullptr, nullptr, rows, W, Wa, rflags, s));
+            MQ_TRY(mq_layernorm_fp8_ex(d_x, xb, b.ln2_g, b.ln2_b, h, row_scale, nullptr, rows, W, cfg->ln_eps, s));
             MQ_TRY(mq_gemm_fp8(h, W, b.fc1_w8, W, row_scale, 1, b.fc1_ws, b.fc1_b, nullptr, qf, F, s_mlp, m_mlp, rows, F, W, act8, s));
-            MQ_TRY(mq_gemm_fp8(qf, F, b.fc2_w8, F, s_mlp, 0, b.fc2_ws, b.fc2_b, d_x, d_x, W, nullptr, nullptr, rows, W, F, res_flags, s));
+            MQ_TRY(mq_gemm_fp8(qf, F, b.fc2_w8, F, s_mlp, 0, b.fc2_ws, b.fc2_b, d_x, d_x, W, nullptr, nullptr, rows, W, F, rflags, s));
         } else if (!cfg->post_ln) {
             // x += out(attn(qkv(ln1(x)))) ; x += fc2(act(fc1(ln2(x))))   (x fp32, or bf16 in the bf16-stream form)
             const int xb = stream_bf16(cfg) ? 1 : 0;
@@ -333,14 +339,14 @@ int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* bloc
             MQ_TRY(attn_bf16(cfg, qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, s));
             MQ_TRY(mq_gemm_bf16(a, Wa, b.out_w, Wa, b.out_b, (const float*)d_x, d_x, W, rows, W, Wa, rflags, s));
             if (cfg->precision == MQ_PREC_FP8 && l >= first8 - cfg->fp8_mlp_extra) {
-                // MLP-only e4m3 block (fp8_mlp_extra): the attention half above ran on bf16 operands (fp32 stream in an fp8 tower)
+                // MLP-only e4m3 block (fp8_mlp_extra): the attention half above ran on bf16 operands
                 MQ_CHECK_ARG(b.fc1_w8 && b.fc1_ws && b.fc2_w8 && b.fc2_ws, "mq_encoder_forward: layer %d has no fp8 MLP weights", l);
                 const float* s_mlp = cfg->d_fp8_act_scale + 2 * l + 1;
                 float* m_mlp = cfg->d_fp8_act_amax ? cfg->d_fp8_act_amax + 2 * l + 1 : nullptr;
                 const int act8 = (cfg->act == MQ_ACT_QUICKGELU ? MQ_EPI_QUICKGELU : MQ_EPI_GELU) | MQ_EPI_BIAS | MQ_EPI_OUT_FP8;
-                MQ_TRY(mq_layernorm_fp8(d_x, b.ln2_g, b.ln2_b, h, row_scale, nullptr, rows, W, cfg->ln_eps, s));
+                MQ_TRY(mq_layernorm_fp8_ex(d_x, xb, b.ln2_g, b.ln2_b, h, row_scale, nullptr, rows, W, cfg->ln_eps, s));
                 MQ_TRY(mq_gemm_fp8(h, W, b.fc1_w8, W, row_scale, 1, b.fc1_ws, b.fc1_b, nullptr, qf, F, s_mlp, m_mlp, rows, F, W, act8, s));
-                MQ_TRY(mq_gemm_fp8(qf, F, b.fc2_w8, F, s_mlp, 0, b.fc2_ws, b.fc2_b, d_x, d_x, W, nullptr, nullptr, rows, W, F, res_flags, s));
+                MQ_TRY(mq_gemm_fp8(qf, F, b.fc2_w8, F, s_mlp, 0, b.fc2_ws, b.fc2_b, (const float*)d_x, d_x, W, nullptr, nullptr, rows, W, F, rflags, s));
                 continue;
             }
             MQ_TRY(ln_gemm(d_x, xb, b.ln2_g, b.ln2_b, cfg->ln_eps, h, b.fc1_w, b.fc1_b, qf, rows, F, W, MQ_EPI_BIAS | act_flag, s));

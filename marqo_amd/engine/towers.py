@@ -429,6 +429,7 @@ class _TowerBase:
     # bf16 operands and runs the LAST ones on fp8: `tune_fp8` measures, on a fixed seeded calibration batch at load, the error of
     # each split against the tower's own bf16 output and keeps the most fp8 blocks that stay inside the budget.
     FP8_BUDGET = float(os.environ.get("MARQO_AMD_FP8_BUDGET", "7e-4"))   # max (1 - cos) vs the tower's own bf16 output
+    FP8_STREAM_SHARE = 0.25  # an fp8 tower takes the bf16 residual stream when that alone costs <= this share of the budget
     FP8_SCALE_MARGIN = 2.0   # static activation scales = calibration amax x margin / 448: one binade of head-room for unseen inputs
     fp8_first_layer: int = 0
     fp8_mlp_extra: int = 0
@@ -463,6 +464,18 @@ class _TowerBase:
             out = run().double()
             cos = (out * ref).sum(-1) / (out.norm(dim=-1) * ref.norm(dim=-1))
             return float((1 - cos).max())
+        # The stream itself (pre-LN towers): bf16 rows halve the residual traffic of EVERY block, e4m3 or not.  Its rounding spends part of the
+        # same budget (all errors below are measured against the fp32-stream bf16 run), so it is taken only when it costs at most
+        # FP8_STREAM_SHARE of the budget with every block still on bf16 operands.
+        enc.residual_stream, self.residual_stream, self.residual_stream_error = 2, "fp32", None
+        mode = os.environ.get("MARQO_AMD_RESIDUAL_STREAM", "auto").lower()
+        if not enc.post_ln and mode != "fp32":
+            enc.residual_stream = 1
+            e_stream = err_split(layers, 0)
+            if mode == "bf16" or e_stream <= self.FP8_STREAM_SHARE * budget:       # (NaN compares false)
+                self.residual_stream, self.residual_stream_error = "bf16", e_stream
+            else:
+                enc.residual_stream = 2
         e0 = err(0)
         self.fp8_all_blocks_error = e0
         if e0 <= budget:
@@ -511,8 +524,9 @@ class _TowerBase:
         self.fp8_first_layer, self.fp8_mlp_extra, self.fp8_calibration_error = first, extra, e
         self._fp8.calibrated = True
         import logging
-        logging.getLogger(__name__).info("fp8 policy: blocks [%d, %d) on e4m3 + the MLP halves of blocks [%d, %d), 1 - cos vs bf16 on the calibration "
-                                         "batch %.2e (all blocks: %.2e, budget %.1e)", first, layers, first - extra, first, e, e0, budget)
+        logging.getLogger(__name__).info("fp8 policy: blocks [%d, %d) on e4m3 + the MLP halves of blocks [%d, %d), %s residual stream, 1 - cos vs bf16 on "
+                                         "the calibration batch %.2e (all blocks: %.2e, budget %.1e)", first, layers, first - extra, first,
+                                         self.residual_stream, e, e0, budget)
         return first
 
     def __init__(self, device: str):

@@ -61,6 +61,24 @@ def test_layernorm_fp8_rowscale():
         assert ((deq - ref).abs().amax(1) / ref.abs().amax(1)).max().item() <= 2 ** -4 + 1e-3
 
 
+def test_layernorm_fp8_from_the_bf16_stream():
+    """the fp8 LayerNorm of an fp8 tower whose residual stream is bf16: the same codes and scales as the fp32-input kernel on the same values"""
+    lib = L.load()
+    g = torch.Generator(device="cuda").manual_seed(11)
+    for W in (512, 768, 1024, 1280):
+        x16 = (torch.randn(777, W, device="cuda", generator=g) * 3 + 0.5).to(torch.bfloat16)
+        gam = torch.rand(W, device="cuda", generator=g) + 0.5
+        bet = torch.randn(W, device="cuda", generator=g) * 0.1
+        q, s = torch.empty(777, W, dtype=torch.uint8, device="cuda"), torch.empty(777, device="cuda")
+        q2, s2 = torch.empty_like(q), torch.empty_like(s)
+        L.check(lib.mq_layernorm_fp8_ex(x16.data_ptr(), 1, gam.data_ptr(), bet.data_ptr(), q.data_ptr(), s.data_ptr(), 0, 777, W, 1e-5, _stream()))
+        x32 = x16.float()
+        L.check(lib.mq_layernorm_fp8(x32.data_ptr(), gam.data_ptr(), bet.data_ptr(), q2.data_ptr(), s2.data_ptr(), 0, 777, W, 1e-5, _stream()))
+        assert torch.equal(q, q2) and torch.equal(s, s2)
+        f = torch.empty(4, W, device="cuda")
+        assert lib.mq_layernorm_fp8_ex(x16.data_ptr(), 1, gam.data_ptr(), bet.data_ptr(), q.data_ptr(), s.data_ptr(), f.data_ptr(), 4, W, 1e-5, _stream()) != 0
+
+
 @pytest.mark.parametrize("mt", [0, 2, 4, 5, 6])
 def test_gemm_fp8_equals_product_of_dequantised_operands(mt):
     lib = L.load()
@@ -99,6 +117,11 @@ def test_gemm_fp8_equals_product_of_dequantised_operands(mt):
             assert (o.double() - (ref + bias + res)).abs().max().item() < tol + 1e-4
             o = run(L.MQ_EPI_BIAS, True, torch.bfloat16)
             assert (o.double() - (ref + bias)).abs().max().item() < 1e-2 * (ref.abs().max().item() + 3)
+            # bf16 residual stream: read-modify-write of bf16 rows (fp32 sum, one bf16 rounding at the store)
+            res16 = res.to(torch.bfloat16)
+            o = run(L.MQ_EPI_BIAS | L.MQ_EPI_RESIDUAL, True, torch.bfloat16, residual=res16)
+            want16 = ref + bias + res16.double()
+            assert (o.double() - want16).abs().max().item() < 2 ** -8 * want16.abs().max().item() + tol + 1e-4, (mt, M, N, K)
             want = torch.nn.functional.gelu((ref + bias).float())
             osc = (want.abs().max() / 448).reshape(1)
             amax = torch.zeros(1, device="cuda")
@@ -348,3 +371,41 @@ def test_fp8_mlp_only_blocks_in_front_of_the_split():
     one_d = [tr for tr in t8.fp8_policy_trace if tr[1] == 0][0]
     assert (24 - first) + 2 / 3 * t8.fp8_mlp_extra >= (24 - one_d[0]) - 1e-9
     print(f"policy: split {first}, MLP-only blocks {t8.fp8_mlp_extra}, error {t8.fp8_calibration_error:.2e}; trace {t8.fp8_policy_trace}")
+
+
+def test_fp8_tower_on_the_bf16_residual_stream(tiled_gemm_only, monkeypatch):
+    """An fp8 tower may keep its residual stream in bf16 (decided inside tune_fp8, out of the SAME budget: every error is measured against
+    the fp32-stream bf16 run): forced on and off here — both inside 1e-3 of the fp32 oracle, different computations, each deterministic;
+    the pooled-rows-only last block stays dead-row elimination (bit-identical to all rows) on the bf16 stream too; and the automatic choice
+    takes the bf16 stream only when it costs at most FP8_STREAM_SHARE of the budget."""
+    from marqo_amd.engine import towers
+    from oracle import towers as O
+    varch, ocfg = _vit_l14()
+    sd = O.synthetic_vit_state_dict(ocfg, 0)
+    u8 = O.synthetic_images_u8(3, 224, seed=6)
+    ref = O.vit_forward(sd, ocfg, O.preprocess_u8_exact_size(u8))
+    outs = {}
+    for mode in ("fp32", "bf16", "auto"):
+        monkeypatch.setenv("MARQO_AMD_RESIDUAL_STREAM", mode)
+        t8 = towers.VitTower(varch, sd, "cuda:0", precision="fp8")
+        first = t8.tune_fp8_default()
+        out = t8.encode_u8(u8.cuda())
+        assert torch.equal(t8.encode_u8(u8.cuda()), out)
+        e = _cos_err(out.cpu(), ref)
+        print(f"fp8 ViT-L/14, MARQO_AMD_RESIDUAL_STREAM={mode}: stream {t8.residual_stream} (alone {t8.residual_stream_error}), split {first} + "
+              f"{t8.fp8_mlp_extra} MLP-only, 1-cos vs fp32 oracle {e:.2e}, calibration vs the fp32-stream bf16 run {t8.fp8_calibration_error:.2e}")
+        assert e < 1e-3 and t8.fp8_calibration_error <= t8.FP8_BUDGET
+        assert t8.cfg.enc.residual_stream == (1 if t8.residual_stream == "bf16" else 2)
+        if mode != "auto":
+            assert t8.residual_stream == mode
+        else:
+            assert t8.residual_stream == "fp32" or t8.residual_stream_error <= t8.FP8_STREAM_SHARE * t8.FP8_BUDGET
+        outs[mode] = out
+        if mode == "bf16":
+            try:
+                L.check(L.load().mq_tune(b"row_select", 0))
+                full = t8.encode_u8(u8.cuda())
+            finally:
+                L.check(L.load().mq_tune(b"row_select", 1))
+            assert torch.equal(full, out)
+    assert not torch.equal(outs["fp32"], outs["bf16"])
