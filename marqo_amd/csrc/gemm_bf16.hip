@@ -32,6 +32,7 @@ extern int mq_gemm_small_max_rows;  // gemm_small.hip
 bool mq_gemm_small_ok(int64_t M, int64_t N, int64_t K, bool ln);
 bool mq_gemm_small_grouped_ok(int64_t M, int64_t N, int64_t K);
 extern int mq_gemm_small_group_rows;
+extern int mq_ln_prefetch;        // rowops.hip
 int mq_gemm_small(const void* d_A, int64_t lda, const void* d_W, int64_t ldw, const float* d_bias, const void* d_residual, void* d_out,
                   int64_t ldc, int64_t M, int64_t N, int64_t K, int flags, hipStream_t s);
 
@@ -583,6 +584,7 @@ extern "C" int mq_tune(const char* key, int value) {
     else if (k == "residual_bf16") mq_tower_residual_bf16 = value;
     else if (k == "small_m") mq_gemm_small_max_rows = value;
     else if (k == "small_m_grouped") mq_gemm_small_group_rows = value;
+    else if (k == "ln_prefetch") mq_ln_prefetch = value;
     else { mq_set_error("mq_tune: unknown key %s", key); return MQ_ERR_INVALID; }
     return MQ_OK;
 }

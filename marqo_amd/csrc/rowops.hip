@@ -6,6 +6,8 @@
 
 int mq_ln_rows_per_wave = getenv("MQ_LN_ROWS") ? atoi(getenv("MQ_LN_ROWS")) : 2;  // mq_tune("ln_rows", 1 | 2)
 extern int mq_gemm_small_max_rows;   // gemm_small.hip
+int mq_layernorm_pf(const void* d_x, int x_bf16, const int32_t* d_row_idx, const float* d_g, const float* d_b, void* d_out_bf16, float* d_out_f32,
+                    int64_t rows, int32_t W, float eps, const void* pf_a, size_t bytes_a, const void* pf_b, size_t bytes_b, hipStream_t s);
 int mq_ln_bf16_wide = getenv("MQ_LN_BF16_WIDE") ? atoi(getenv("MQ_LN_BF16_WIDE")) : 1;   // mq_tune("ln_bf16_wide", 0 | 1): 16-byte bf16-input LayerNorm
 
 namespace {
@@ -19,12 +21,45 @@ constexpr int LN_MAX_CHUNKS = 8;  // float4 chunks per lane: W <= 64 * 4 * 8 = 2
 // R = rows per wave: the loads of R rows are issued back to back and the 2R wave reductions interleave, which doubles
 // the bytes in flight per wave (the one-row form is latency-bound: 4.9 TB/s with the data sitting in the Infinity Cache).
 // XB = the input rows are bf16 (the bf16 residual stream of the pre-LN towers, towers.hip): 8-byte loads, same arithmetic in fp32
+// Last kernel argument of the LayerNorm kernels: the XCD banding switch and a WEIGHT PREFETCH.  Inside a tower every GEMM's weights were last
+// touched one step ago and have left the 256 MB Infinity Cache by the time they are needed again (12 layers x 14 MB of weights + ~140 MB of
+// activations cycle through it), and the first round of tiles of a tower GEMM then waits on HBM latency at every k-step: +5..6 us per QKV / fc2
+// launch (tools/gemm_layer_probe.py: the same launches with ONE weight set run at their stand-alone time).  The LayerNorm in front of a GEMM
+// is memory-bound and short, so its threads each also touch one dword per 128-byte line of the NEXT GEMMs' weights (values unused): by the time the GEMM
+// starts its weights sit in the Infinity Cache.  pfa / pfb: two ranges (the next GEMM's weights and the one after it), na / nb in 128-byte lines.
+struct LnExtra {
+    int band;
+    unsigned na, nb;          // 128-byte lines
+    const unsigned* pfa;
+    const unsigned* pfb;
+};
+constexpr int LN_PF = 2;   // lines per thread (one dword of a line brings the line: one VGPR per touched line)
+
+__device__ __forceinline__ void ln_prefetch_issue(const LnExtra& ex, unsigned (&pq)[LN_PF]) {
+#pragma unroll
+    for (int j = 0; j < LN_PF; ++j) pq[j] = 0u;
+    if (ex.na | ex.nb) {
+        const unsigned nt = gridDim.x * 256u, t = blockIdx.x * 256u + threadIdx.x;
+#pragma unroll
+        for (int j = 0; j < LN_PF; ++j) {
+            const unsigned c = t + j * nt;
+            if (c < ex.na) pq[j] = ex.pfa[(size_t)c * 32];
+            else if (c - ex.na < ex.nb) pq[j] = ex.pfb[(size_t)(c - ex.na) * 32];
+        }
+    }
+}
+// the loaded values are "used" by an empty asm at the end of the kernel: keeps the loads alive, and the wait for them out of the row's way
+__device__ __forceinline__ void ln_prefetch_retire(const unsigned (&pq)[LN_PF]) {
+#pragma unroll
+    for (int j = 0; j < LN_PF; ++j) asm volatile("" ::"v"(pq[j]));
+}
+
 template <int CH, int R, bool XB = false>
 __global__ __launch_bounds__(256, (CH * R <= 4 ? 8 : 4)) void layernorm_kernel(
     const void* __restrict__ xv, const int32_t* __restrict__ row_idx, const float* __restrict__ gam,
-    const float* __restrict__ bet, bf16_t* out_bf16, float* out_f32, int64_t rows, int W, float eps, int band) {
+    const float* __restrict__ bet, bf16_t* out_bf16, float* out_f32, int64_t rows, int W, float eps, LnExtra ex) {
     const int lane = threadIdx.x & 63;
-    const int64_t row0 = ((int64_t)xcd_banded_block(blockIdx.x, gridDim.x, band) * 4 + (threadIdx.x >> 6)) * R;
+    const int64_t row0 = ((int64_t)xcd_banded_block(blockIdx.x, gridDim.x, ex.band) * 4 + (threadIdx.x >> 6)) * R;
     if (row0 >= rows) return;
     const int nch = W >> 2;  // float4 chunks in the row
 
@@ -45,6 +80,8 @@ __global__ __launch_bounds__(256, (CH * R <= 4 ? 8 : 4)) void layernorm_kernel(
             }
         }
     }
+    unsigned pq[LN_PF];
+    ln_prefetch_issue(ex, pq);   // behind the row loads (loads return in order: the row must not wait for an HBM miss of the prefetch)
     // gamma / beta are fetched now, not after the reductions: their (L2) latency hides behind the row loads and the shuffles
     f32x4 gv[CH], bv[CH];
 #pragma unroll
@@ -108,6 +145,7 @@ __global__ __launch_bounds__(256, (CH * R <= 4 ? 8 : 4)) void layernorm_kernel(
             }
         }
     }
+    ln_prefetch_retire(pq);
 }
 
 // bf16 rows in (the bf16 residual stream of the pre-LN towers) -> LN -> bf16 (and / or fp32) out, EIGHT elements per lane and chunk: 16-byte
@@ -118,9 +156,9 @@ __global__ __launch_bounds__(256, (CH * R <= 4 ? 8 : 4)) void layernorm_kernel(
 template <int CH8, int R>
 __global__ __launch_bounds__(256) void layernorm_bf16in_kernel(
     const bf16_t* __restrict__ x, const int32_t* __restrict__ row_idx, const float* __restrict__ gam, const float* __restrict__ bet,
-    bf16_t* out_bf16, float* out_f32, int64_t rows, int W, float eps, int band) {
+    bf16_t* out_bf16, float* out_f32, int64_t rows, int W, float eps, LnExtra ex) {
     const int lane = threadIdx.x & 63;
-    const int64_t row0 = ((int64_t)xcd_banded_block(blockIdx.x, gridDim.x, band) * 4 + (threadIdx.x >> 6)) * R;
+    const int64_t row0 = ((int64_t)xcd_banded_block(blockIdx.x, gridDim.x, ex.band) * 4 + (threadIdx.x >> 6)) * R;
     if (row0 >= rows) return;
     const int nch = W >> 3;  // 8-element chunks in the row
     float v[R][CH8][8];
@@ -138,6 +176,8 @@ __global__ __launch_bounds__(256) void layernorm_bf16in_kernel(
             for (int e = 0; e < 4; ++e) { v[r][i][2 * e] = __uint_as_float(w4[e] << 16); v[r][i][2 * e + 1] = __uint_as_float(w4[e] & 0xffff0000u); }
         }
     }
+    unsigned pq[LN_PF];
+    ln_prefetch_issue(ex, pq);   // behind the row loads
     f32x4 gv[CH8][2], bv[CH8][2];
 #pragma unroll
     for (int i = 0; i < CH8; ++i) {
@@ -198,6 +238,7 @@ __global__ __launch_bounds__(256) void layernorm_bf16in_kernel(
                 *(uint4*)(out_bf16 + row * W + c * 8) = make_uint4(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]), pack_bf16x2(y[6], y[7]));
         }
     }
+    ln_prefetch_retire(pq);
 }
 
 // LN with e4m3 output and a dynamic per-row scale (the row is already in registers, so the absmax is one wave reduction)
@@ -285,14 +326,28 @@ extern "C" int mq_layernorm(const float* d_x, const int32_t* d_row_idx, const fl
     return mq_layernorm_ex(d_x, 0, d_row_idx, d_g, d_b, d_out_bf16, d_out_f32, rows, W, eps, stream);
 }
 
+// knob: the LayerNorms of the towers prefetch the weights of the GEMMs behind them (0 = off).  mq_tune("ln_prefetch", v) / MQ_LN_PREFETCH
+int mq_ln_prefetch = getenv("MQ_LN_PREFETCH") ? atoi(getenv("MQ_LN_PREFETCH")) : 1;
+
 extern "C" int mq_layernorm_ex(const void* d_x, int x_bf16, const int32_t* d_row_idx, const float* d_g, const float* d_b,
                                void* d_out_bf16, float* d_out_f32, int64_t rows, int32_t W, float eps, void* stream) {
+    return mq_layernorm_pf(d_x, x_bf16, d_row_idx, d_g, d_b, d_out_bf16, d_out_f32, rows, W, eps, nullptr, 0, nullptr, 0, (hipStream_t)stream);
+}
+
+// mq_layernorm_ex + weight prefetch (LnExtra above): pf_a / pf_b = two 16-byte-aligned device ranges (bytes) that the kernel's threads read and
+// discard, one dword per 128-byte line, as far as its thread count reaches (LN_PF lines per thread); either may be NULL
+int mq_layernorm_pf(const void* d_x, int x_bf16, const int32_t* d_row_idx, const float* d_g, const float* d_b, void* d_out_bf16, float* d_out_f32,
+                    int64_t rows, int32_t W, float eps, const void* pf_a, size_t bytes_a, const void* pf_b, size_t bytes_b, hipStream_t s) {
     MQ_CHECK_ARG(d_x && d_g && d_b && (d_out_bf16 || d_out_f32), "mq_layernorm: null pointer");
     MQ_CHECK_ARG(W >= 4 && W % 4 == 0 && W <= 64 * 4 * LN_MAX_CHUNKS, "mq_layernorm: W=%d unsupported (multiple of 4, <= 2048)", W);
     if (rows <= 0) return MQ_OK;
-    hipStream_t s = (hipStream_t)stream;
     MqProfScope prof(1, s);
-    const int band = (mq_xcd_band && !d_row_idx && rows >= 4096) ? 1 : 0;   // dense batches only (a gather has no row locality to keep)
+    LnExtra band{(mq_xcd_band && !d_row_idx && rows >= 4096) ? 1 : 0, 0u, 0u, nullptr, nullptr};   // banding: dense batches only (a gather has no row locality to keep)
+    if (mq_ln_prefetch && rows >= 1024) {   // (a small call is latency-bound: nothing to hide the extra loads behind)
+        auto lines = [](const void* p, size_t b) { return (p && ((uintptr_t)p & 3) == 0) ? (unsigned)(b < ((size_t)1 << 30) ? b / 128 : 0) : 0u; };
+        band.pfa = (const unsigned*)pf_a; band.na = lines(pf_a, bytes_a);
+        band.pfb = (const unsigned*)pf_b; band.nb = lines(pf_b, bytes_b);
+    }
     // two rows per wave once there are enough rows to fill the chip that way (and the row fits: CH * 2 float4 per lane)
     // The LayerNorm form follows the GEMM family of the call: at most mq_gemm_small_max_rows rows (the search path: skinny GEMMs, whose fused
     // LayerNorm prologue sums a row in the generic kernel's lane order) keep the generic kernel, so a query has the same bits alone and inside

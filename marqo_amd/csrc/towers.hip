@@ -52,10 +52,13 @@ int mq_ln_gemm_small(const void* d_x, int64_t ldx, int x_bf16, const float* ln_g
                      const float* d_bias, void* d_out, int64_t ldc, int64_t M, int64_t N, int64_t K, int flags, float* d_ln_out,
                      const int32_t* d_rows, hipStream_t s);
 // h = LN(x) ; out = epi(h @ W^T): one fused launch when the rows fit the skinny kernel, else LayerNorm kernel + tiled GEMM
+// (the LayerNorm kernel also pulls W and `next_w` — the weights of the GEMM after this one — into the Infinity Cache: rowops.hip, LnExtra)
+int mq_layernorm_pf(const void* d_x, int x_bf16, const int32_t* d_row_idx, const float* d_g, const float* d_b, void* d_out_bf16, float* d_out_f32,
+                    int64_t rows, int32_t W, float eps, const void* pf_a, size_t bytes_a, const void* pf_b, size_t bytes_b, hipStream_t s);
 static int ln_gemm(const void* d_x, int xb, const float* g, const float* b, float eps, void* h, const void* W, const float* bias, void* out,
-                   int64_t rows, int N, int K, int flags, hipStream_t s) {
+                   int64_t rows, int N, int K, int flags, hipStream_t s, const void* next_w = nullptr, size_t next_bytes = 0) {
     if (mq_gemm_small_ok(rows, N, K, true)) return mq_ln_gemm_small(d_x, K, xb, g, b, eps, W, K, bias, out, N, rows, N, K, flags, nullptr, nullptr, s);
-    MQ_TRY(mq_layernorm_ex(d_x, xb, nullptr, g, b, h, nullptr, rows, K, eps, s));
+    MQ_TRY(mq_layernorm_pf(d_x, xb, nullptr, g, b, h, nullptr, rows, K, eps, W, (size_t)N * K * 2, next_w, next_bytes, s));
     return mq_gemm_bf16(h, K, W, K, bias, nullptr, out, N, rows, N, K, flags, s);
 }
 // true when a tower with this encoder config keeps its residual stream in bf16
@@ -193,7 +196,7 @@ int last_block_selected(const mq_encoder_cfg* cfg, const mq_block_weights& b, in
             MQ_TRY(mq_gemm_bf16_ln(h, W, b.qkv_wf, W, b.qkv_bf, nullptr, qf, 3 * Wa, rows, 3 * Wa, W, MQ_EPI_BIAS | MQ_EPI_LN_APPLY, stats, nullptr,
                                    b.qkv_sf, cfg->ln_eps, s));
         } else {
-            MQ_TRY(mq_layernorm_ex(d_x, xb, nullptr, b.ln1_g, b.ln1_b, h, nullptr, rows, W, cfg->ln_eps, s));
+            MQ_TRY(mq_layernorm_pf(d_x, xb, nullptr, b.ln1_g, b.ln1_b, h, nullptr, rows, W, cfg->ln_eps, b.qkv_w, (size_t)3 * Wa * W * 2, nullptr, 0, s));
             MQ_TRY(mq_gemm_bf16(h, W, b.qkv_w, W, b.qkv_b, nullptr, qf, 3 * Wa, rows, 3 * Wa, W, MQ_EPI_BIAS, s));
         }
         MQ_TRY(attn_bf16(cfg, qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, s));
@@ -335,7 +338,7 @@ int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* bloc
             // x += out(attn(qkv(ln1(x)))) ; x += fc2(act(fc1(ln2(x))))   (x fp32, or bf16 in the bf16-stream form)
             const int xb = stream_bf16(cfg) ? 1 : 0;
             const int rflags = xb ? (MQ_EPI_BIAS | MQ_EPI_RESIDUAL) : res_flags;
-            MQ_TRY(ln_gemm(d_x, xb, b.ln1_g, b.ln1_b, cfg->ln_eps, h, b.qkv_w, b.qkv_b, qf, rows, 3 * Wa, W, MQ_EPI_BIAS, s));
+            MQ_TRY(ln_gemm(d_x, xb, b.ln1_g, b.ln1_b, cfg->ln_eps, h, b.qkv_w, b.qkv_b, qf, rows, 3 * Wa, W, MQ_EPI_BIAS, s, b.out_w, (size_t)W * Wa * 2));
             MQ_TRY(attn_bf16(cfg, qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, s));
             MQ_TRY(mq_gemm_bf16(a, Wa, b.out_w, Wa, b.out_b, (const float*)d_x, d_x, W, rows, W, Wa, rflags, s));
             if (cfg->precision == MQ_PREC_FP8 && l >= first8 - cfg->fp8_mlp_extra) {
@@ -349,7 +352,7 @@ int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* bloc
                 MQ_TRY(mq_gemm_fp8(qf, F, b.fc2_w8, F, s_mlp, 0, b.fc2_ws, b.fc2_b, (const float*)d_x, d_x, W, nullptr, nullptr, rows, W, F, rflags, s));
                 continue;
             }
-            MQ_TRY(ln_gemm(d_x, xb, b.ln2_g, b.ln2_b, cfg->ln_eps, h, b.fc1_w, b.fc1_b, qf, rows, F, W, MQ_EPI_BIAS | act_flag, s));
+            MQ_TRY(ln_gemm(d_x, xb, b.ln2_g, b.ln2_b, cfg->ln_eps, h, b.fc1_w, b.fc1_b, qf, rows, F, W, MQ_EPI_BIAS | act_flag, s, b.fc2_w, (size_t)W * F * 2));
             MQ_TRY(mq_gemm_bf16(qf, F, b.fc2_w, F, b.fc2_b, (const float*)d_x, d_x, W, rows, W, F, rflags, s));
         } else if (small_post_ln) {
             // search path: both LayerNorms ride in the prologue of the GEMM that consumes them (gemm_small.hip).  d_x holds the pre-LN sums
@@ -373,7 +376,8 @@ int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* bloc
             if (cfg->d_rope_inv_freq) MQ_TRY(mq_rope(qf, d_cu_seqlens, nseq, fixed_len, Wa, cfg->heads, cfg->d_rope_inv_freq, s));
             MQ_TRY(attn_bf16(cfg, qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, s));
             MQ_TRY(mq_gemm_bf16(a, Wa, b.out_w, Wa, b.out_b, d_x, d_x, W, rows, W, Wa, res_flags, s));
-            MQ_TRY(mq_layernorm(d_x, nullptr, b.ln1_g, b.ln1_b, h, d_x, rows, W, cfg->ln_eps, s));
+            MQ_TRY(mq_layernorm_pf(d_x, 0, nullptr, b.ln1_g, b.ln1_b, h, d_x, rows, W, cfg->ln_eps, b.fc1_w, (size_t)(cfg->mlp_glu ? 2 : 1) * F * W * 2,
+                                   b.fc2_w, (size_t)W * F * 2, s));
             if (cfg->mlp_glu) {
                 // gated MLP: fc1 = (up | gate) rows [2F, W] (bias optional), hidden = up * act(gate) in place, fc2 reads it with lda = 2F
                 MQ_TRY(mq_gemm_bf16(h, W, b.fc1_w, W, b.fc1_b, nullptr, qf, 2 * F, rows, 2 * F, W, b.fc1_b ? MQ_EPI_BIAS : 0, s));
@@ -383,7 +387,9 @@ int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* bloc
                 MQ_TRY(mq_gemm_bf16(h, W, b.fc1_w, W, b.fc1_b, nullptr, qf, F, rows, F, W, MQ_EPI_BIAS | act_flag, s));
                 MQ_TRY(mq_gemm_bf16(qf, F, b.fc2_w, F, b.fc2_b, d_x, d_x, W, rows, W, F, res_flags, s));
             }
-            MQ_TRY(mq_layernorm(d_x, nullptr, b.ln2_g, b.ln2_b, h, d_x, rows, W, cfg->ln_eps, s));
+            const mq_block_weights* nb = l + 1 < cfg->layers && l + 1 < first8 ? &blocks[l + 1] : nullptr;   // the next block's QKV / out-proj weights
+            MQ_TRY(mq_layernorm_pf(d_x, 0, nullptr, b.ln2_g, b.ln2_b, h, d_x, rows, W, cfg->ln_eps, nb ? nb->qkv_w : nullptr, (size_t)3 * Wa * W * 2,
+                                   nb ? nb->out_w : nullptr, (size_t)W * Wa * 2, s));
         }
     }
     return MQ_OK;

@@ -54,16 +54,24 @@ def main():
 
         def nothing(i, A):
             pass
-        res = {}
-        res["warm"] = timed(nothing, lambda i: (As[0], Ws[0], outs[0]))
-        res["cold_w"] = timed(nothing, lambda i: (As[0], Ws[i % NL], outs[0]))
-        res["fresh_a+cold_w"] = timed(ln_into, lambda i: (As[0], Ws[i % NL], outs[0]))          # the tower's situation
-        res["fresh_a+warm_w"] = timed(ln_into, lambda i: (As[0], Ws[0], outs[0]))
-        res["fresh_a+cold_w+cold_out"] = timed(ln_into, lambda i: (As[0], Ws[i % NL], outs[i % NL]))
-        res["cold_all"] = timed(lambda i, A: trash.fill_(i & 255), lambda i: (As[0], Ws[i % NL], outs[i % NL]))
-        res["fresh_a+prefetched_w"] = timed(lambda i, A: (ln_into(i, A), sink.copy_(Ws[(i + 1) % NL].view(-1)))[0], lambda i: (As[0], Ws[i % NL], outs[0]))
+        variants = {
+            "warm": (nothing, lambda i: (As[0], Ws[0], outs[0])),
+            "cold_w": (nothing, lambda i: (As[0], Ws[i % NL], outs[0])),
+            "fresh_a+cold_w": (ln_into, lambda i: (As[0], Ws[i % NL], outs[0])),          # the tower's situation
+            "fresh_a+warm_w": (ln_into, lambda i: (As[0], Ws[0], outs[0])),
+            "fresh_a+cold_w+cold_out": (ln_into, lambda i: (As[0], Ws[i % NL], outs[i % NL])),
+            "cold_all": (lambda i, A: trash.fill_(i & 255), lambda i: (As[0], Ws[i % NL], outs[i % NL])),
+            "fresh_a+prefetched_w": (lambda i, A: (ln_into(i, A), sink.copy_(Ws[(i + 1) % NL].view(-1)))[0], lambda i: (As[0], Ws[i % NL], outs[0])),
+        }
+        timed(*variants["warm"], reps=200)                       # clocks / power state settle before anything is recorded
+        runs = {k: [] for k in variants}
+        for rnd in range(3):                                     # three rounds, every variant in each: order effects show up as spread
+            for k, (pre, pick) in variants.items():
+                runs[k].append(timed(pre, pick, reps=96))
+        res = {k: sorted(v)[1] for k, v in runs.items()}
+        spread = {k: max(v) - min(v) for k, v in runs.items()}
         fl = 2.0 * M * N * K
-        print(f"{name:8s} M={M} N={N} K={K}: " + "  ".join(f"{k} {v:6.1f} us ({fl / v * 1e-6:5.0f} TF)" for k, v in res.items()), flush=True)
+        print(f"{name:8s} M={M} N={N} K={K}: " + "  ".join(f"{k} {v:6.1f} us +-{spread[k] / 2:.1f} ({fl / v * 1e-6:5.0f} TF)" for k, v in res.items()), flush=True)
 
 
 if __name__ == "__main__":
