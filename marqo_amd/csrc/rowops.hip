@@ -8,6 +8,8 @@ int mq_ln_rows_per_wave = getenv("MQ_LN_ROWS") ? atoi(getenv("MQ_LN_ROWS")) : 2;
 extern int mq_gemm_small_max_rows;   // gemm_small.hip
 int mq_layernorm_pf(const void* d_x, int x_bf16, const int32_t* d_row_idx, const float* d_g, const float* d_b, void* d_out_bf16, float* d_out_f32,
                     int64_t rows, int32_t W, float eps, const void* pf_a, size_t bytes_a, const void* pf_b, size_t bytes_b, hipStream_t s);
+int mq_layernorm_fp8_pf(const void* d_x, int x_bf16, const float* d_g, const float* d_b, void* d_out_fp8, float* d_row_scale, float* d_out_f32,
+                        int64_t rows, int32_t W, float eps, const void* pf_a, size_t bytes_a, const void* pf_b, size_t bytes_b, hipStream_t s);
 int mq_ln_bf16_wide = getenv("MQ_LN_BF16_WIDE") ? atoi(getenv("MQ_LN_BF16_WIDE")) : 1;   // mq_tune("ln_bf16_wide", 0 | 1): 16-byte bf16-input LayerNorm
 
 namespace {
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(256) void layernorm_bf16in_kernel(
 template <int CH, bool NORM = true, bool XB = false>
 __global__ __launch_bounds__(256, (CH <= 4 ? 8 : 4)) void layernorm_fp8_kernel(
     const void* __restrict__ x, const float* __restrict__ gam, const float* __restrict__ bet, uint8_t* __restrict__ out8,
-    float* __restrict__ row_scale, float* out_f32, int64_t rows, int W, float eps) {
+    float* __restrict__ row_scale, float* out_f32, int64_t rows, int W, float eps, LnExtra ex) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -265,6 +267,8 @@ __global__ __launch_bounds__(256, (CH <= 4 ? 8 : 4)) void layernorm_fp8_kernel(
             v[i] = *(const f32x4*)((const float*)x + row * W + c * 4);
         }
     }
+    unsigned pq[LN_PF];
+    ln_prefetch_issue(ex, pq);   // the e4m3 weights of the GEMMs behind this LayerNorm (LnExtra above)
     if (NORM) ln_normalize_row<CH>(v, lane, nch, W, eps);
     float mx = 0.f;
 #pragma unroll
@@ -295,6 +299,7 @@ __global__ __launch_bounds__(256, (CH <= 4 ? 8 : 4)) void layernorm_fp8_kernel(
             *(int*)(out8 + row * W + c * 4) = w;
         }
     }
+    ln_prefetch_retire(pq);
 }
 
 __global__ __launch_bounds__(256) void l2norm_kernel(const float* __restrict__ x, float* out, int64_t rows, int D) {
@@ -329,6 +334,17 @@ extern "C" int mq_layernorm(const float* d_x, const int32_t* d_row_idx, const fl
 // knob: the LayerNorms of the towers prefetch the weights of the GEMMs behind them (0 = off).  mq_tune("ln_prefetch", v) / MQ_LN_PREFETCH
 int mq_ln_prefetch = getenv("MQ_LN_PREFETCH") ? atoi(getenv("MQ_LN_PREFETCH")) : 1;
 
+static LnExtra ln_extra(int band, int64_t rows, const void* pf_a, size_t bytes_a, const void* pf_b, size_t bytes_b) {
+    LnExtra ex{band, 0u, 0u, nullptr, nullptr};
+    if (mq_ln_prefetch && rows >= 1024) {   // (a small call is latency-bound: nothing to hide the extra loads behind)
+        auto lines = [](const void* p, size_t b) { return (p && ((uintptr_t)p & 3) == 0) ? (unsigned)(b < ((size_t)1 << 30) ? b / 128 : 0) : 0u; };
+        ex.pfa = (const unsigned*)pf_a; ex.na = lines(pf_a, bytes_a);
+        ex.pfb = (const unsigned*)pf_b; ex.nb = lines(pf_b, bytes_b);
+    }
+    return ex;
+}
+
+
 extern "C" int mq_layernorm_ex(const void* d_x, int x_bf16, const int32_t* d_row_idx, const float* d_g, const float* d_b,
                                void* d_out_bf16, float* d_out_f32, int64_t rows, int32_t W, float eps, void* stream) {
     return mq_layernorm_pf(d_x, x_bf16, d_row_idx, d_g, d_b, d_out_bf16, d_out_f32, rows, W, eps, nullptr, 0, nullptr, 0, (hipStream_t)stream);
@@ -342,12 +358,8 @@ int mq_layernorm_pf(const void* d_x, int x_bf16, const int32_t* d_row_idx, const
     MQ_CHECK_ARG(W >= 4 && W % 4 == 0 && W <= 64 * 4 * LN_MAX_CHUNKS, "mq_layernorm: W=%d unsupported (multiple of 4, <= 2048)", W);
     if (rows <= 0) return MQ_OK;
     MqProfScope prof(1, s);
-    LnExtra band{(mq_xcd_band && !d_row_idx && rows >= 4096) ? 1 : 0, 0u, 0u, nullptr, nullptr};   // banding: dense batches only (a gather has no row locality to keep)
-    if (mq_ln_prefetch && rows >= 1024) {   // (a small call is latency-bound: nothing to hide the extra loads behind)
-        auto lines = [](const void* p, size_t b) { return (p && ((uintptr_t)p & 3) == 0) ? (unsigned)(b < ((size_t)1 << 30) ? b / 128 : 0) : 0u; };
-        band.pfa = (const unsigned*)pf_a; band.na = lines(pf_a, bytes_a);
-        band.pfb = (const unsigned*)pf_b; band.nb = lines(pf_b, bytes_b);
-    }
+    // banding: dense batches only (a gather has no row locality to keep)
+    const LnExtra band = ln_extra((mq_xcd_band && !d_row_idx && rows >= 4096) ? 1 : 0, rows, pf_a, bytes_a, pf_b, bytes_b);
     // two rows per wave once there are enough rows to fill the chip that way (and the row fits: CH * 2 float4 per lane)
     // The LayerNorm form follows the GEMM family of the call: at most mq_gemm_small_max_rows rows (the search path: skinny GEMMs, whose fused
     // LayerNorm prologue sums a row in the generic kernel's lane order) keep the generic kernel, so a query has the same bits alone and inside
@@ -386,18 +398,24 @@ int mq_layernorm_pf(const void* d_x, int x_bf16, const int32_t* d_row_idx, const
 // x fp32 [rows, W], or (x_bf16) the bf16 residual stream; e4m3 rows + per-row scales out; d_out_f32 (optional, fp32 x only): the normalised rows
 extern "C" int mq_layernorm_fp8_ex(const void* d_x, int x_bf16, const float* d_g, const float* d_b, void* d_out_fp8, float* d_row_scale,
                                    float* d_out_f32, int64_t rows, int32_t W, float eps, void* stream) {
-    hipStream_t s = (hipStream_t)stream;
+    return mq_layernorm_fp8_pf(d_x, x_bf16, d_g, d_b, d_out_fp8, d_row_scale, d_out_f32, rows, W, eps, nullptr, 0, nullptr, 0, (hipStream_t)stream);
+}
+
+// mq_layernorm_fp8_ex + weight prefetch (as mq_layernorm_pf)
+int mq_layernorm_fp8_pf(const void* d_x, int x_bf16, const float* d_g, const float* d_b, void* d_out_fp8, float* d_row_scale, float* d_out_f32,
+                        int64_t rows, int32_t W, float eps, const void* pf_a, size_t bytes_a, const void* pf_b, size_t bytes_b, hipStream_t s) {
     MQ_CHECK_ARG(d_x && d_g && d_b && d_out_fp8 && d_row_scale, "mq_layernorm_fp8: null pointer");
     MQ_CHECK_ARG(W >= 4 && W % 4 == 0 && W <= 64 * 4 * LN_MAX_CHUNKS, "mq_layernorm_fp8: W=%d unsupported (multiple of 4, <= 2048)", W);
     MQ_CHECK_ARG(!x_bf16 || !d_out_f32, "mq_layernorm_fp8: the fp32 copy of the normalised rows belongs to the fp32 stream");
     if (rows <= 0) return MQ_OK;
     MqProfScope prof(1, s);
+    const LnExtra ex = ln_extra(0, rows, pf_a, bytes_a, pf_b, bytes_b);
     if (x_bf16)
         MQ_DISPATCH_CH(W, hipLaunchKernelGGL((layernorm_fp8_kernel<CH, true, true>), dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, s, d_x, d_g, d_b,
-                                             (uint8_t*)d_out_fp8, d_row_scale, d_out_f32, rows, (int)W, eps));
+                                             (uint8_t*)d_out_fp8, d_row_scale, d_out_f32, rows, (int)W, eps, ex));
     else
         MQ_DISPATCH_CH(W, hipLaunchKernelGGL((layernorm_fp8_kernel<CH, true, false>), dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, s, d_x, d_g, d_b,
-                                             (uint8_t*)d_out_fp8, d_row_scale, d_out_f32, rows, (int)W, eps));
+                                             (uint8_t*)d_out_fp8, d_row_scale, d_out_f32, rows, (int)W, eps, ex));
     MQ_CHECK_LAUNCH("mq_layernorm_fp8");
     return MQ_OK;
 }
@@ -415,7 +433,7 @@ extern "C" int mq_rowquant_fp8(const float* d_x, void* d_out_fp8, float* d_row_s
     MqProfScope prof(1, s);
     MQ_DISPATCH_CH(W, hipLaunchKernelGGL((layernorm_fp8_kernel<CH, false>), dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, s, (const void*)d_x,
                                          (const float*)nullptr, (const float*)nullptr, (uint8_t*)d_out_fp8, d_row_scale, (float*)nullptr, rows,
-                                         (int)W, 0.f));
+                                         (int)W, 0.f, LnExtra{0, 0u, 0u, nullptr, nullptr}));
     MQ_CHECK_LAUNCH("mq_rowquant_fp8");
     return MQ_OK;
 }

@@ -55,10 +55,21 @@ int mq_ln_gemm_small(const void* d_x, int64_t ldx, int x_bf16, const float* ln_g
 // (the LayerNorm kernel also pulls W and `next_w` — the weights of the GEMM after this one — into the Infinity Cache: rowops.hip, LnExtra)
 int mq_layernorm_pf(const void* d_x, int x_bf16, const int32_t* d_row_idx, const float* d_g, const float* d_b, void* d_out_bf16, float* d_out_f32,
                     int64_t rows, int32_t W, float eps, const void* pf_a, size_t bytes_a, const void* pf_b, size_t bytes_b, hipStream_t s);
+// The prefetch pays only when the weights do not survive in the 256 MB Infinity Cache from one step to the next: the blocks' bf16 weights
+// (x layers) at least half of it.  Measured (profiles/r03r_ln_prefetch_ab.txt): ViT-B/32 image (170 MB) GEMMs -4 %, step +2 %; ViT-L/14 (604 MB)
+// +3 %; CLIP text B/32 (38 MB) and BERT-base (85 MB, ~480 MB of activations per layer) neutral to -1 % -> off there.  Decided per encoder call.
+static thread_local bool t_ln_prefetch = false;
+static bool weights_outlive_cache(const mq_encoder_cfg* c, int Wa) {
+    const double per_layer = ((double)4 * Wa * c->width + (double)(c->mlp_glu ? 3 : 2) * c->width * c->mlp_dim) * 2.0;
+    return per_layer * c->layers >= 128.0 * 1024 * 1024;
+}
+static inline const void* pf(const void* w) { return t_ln_prefetch ? w : nullptr; }
+int mq_layernorm_fp8_pf(const void* d_x, int x_bf16, const float* d_g, const float* d_b, void* d_out_fp8, float* d_row_scale, float* d_out_f32,
+                        int64_t rows, int32_t W, float eps, const void* pf_a, size_t bytes_a, const void* pf_b, size_t bytes_b, hipStream_t s);
 static int ln_gemm(const void* d_x, int xb, const float* g, const float* b, float eps, void* h, const void* W, const float* bias, void* out,
                    int64_t rows, int N, int K, int flags, hipStream_t s, const void* next_w = nullptr, size_t next_bytes = 0) {
     if (mq_gemm_small_ok(rows, N, K, true)) return mq_ln_gemm_small(d_x, K, xb, g, b, eps, W, K, bias, out, N, rows, N, K, flags, nullptr, nullptr, s);
-    MQ_TRY(mq_layernorm_pf(d_x, xb, nullptr, g, b, h, nullptr, rows, K, eps, W, (size_t)N * K * 2, next_w, next_bytes, s));
+    MQ_TRY(mq_layernorm_pf(d_x, xb, nullptr, g, b, h, nullptr, rows, K, eps, pf(W), (size_t)N * K * 2, pf(next_w), next_bytes, s));
     return mq_gemm_bf16(h, K, W, K, bias, nullptr, out, N, rows, N, K, flags, s);
 }
 // true when a tower with this encoder config keeps its residual stream in bf16
@@ -178,7 +189,7 @@ int last_block_selected(const mq_encoder_cfg* cfg, const mq_block_weights& b, in
         const int act8 = act_flag | MQ_EPI_BIAS | MQ_EPI_OUT_FP8;
         const int xb = stream_bf16(cfg) ? 1 : 0;
         const int rflags = xb ? (MQ_EPI_BIAS | MQ_EPI_RESIDUAL) : res_flags;
-        MQ_TRY(mq_layernorm_fp8_ex(d_x, xb, b.ln1_g, b.ln1_b, h, row_scale, nullptr, rows, W, cfg->ln_eps, s));
+        MQ_TRY(mq_layernorm_fp8_pf(d_x, xb, b.ln1_g, b.ln1_b, h, row_scale, nullptr, rows, W, cfg->ln_eps, pf(b.qkv_w8), (size_t)3 * Wa * W, nullptr, 0, s));
         MQ_TRY(mq_gemm_fp8(h, W, b.qkv_w8, W, row_scale, 1, b.qkv_ws, b.qkv_b, nullptr, qf, 3 * Wa, nullptr, nullptr, rows, 3 * Wa, W,
                            MQ_EPI_BIAS, s));
         MQ_TRY(mq_attention_ex(qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, cfg->heads, cfg->mask, 1, s_attn, nullptr, s));
@@ -196,7 +207,7 @@ int last_block_selected(const mq_encoder_cfg* cfg, const mq_block_weights& b, in
             MQ_TRY(mq_gemm_bf16_ln(h, W, b.qkv_wf, W, b.qkv_bf, nullptr, qf, 3 * Wa, rows, 3 * Wa, W, MQ_EPI_BIAS | MQ_EPI_LN_APPLY, stats, nullptr,
                                    b.qkv_sf, cfg->ln_eps, s));
         } else {
-            MQ_TRY(mq_layernorm_pf(d_x, xb, nullptr, b.ln1_g, b.ln1_b, h, nullptr, rows, W, cfg->ln_eps, b.qkv_w, (size_t)3 * Wa * W * 2, nullptr, 0, s));
+            MQ_TRY(mq_layernorm_pf(d_x, xb, nullptr, b.ln1_g, b.ln1_b, h, nullptr, rows, W, cfg->ln_eps, pf(b.qkv_w), (size_t)3 * Wa * W * 2, nullptr, 0, s));
             MQ_TRY(mq_gemm_bf16(h, W, b.qkv_w, W, b.qkv_b, nullptr, qf, 3 * Wa, rows, 3 * Wa, W, MQ_EPI_BIAS, s));
         }
         MQ_TRY(attn_bf16(cfg, qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, s));
@@ -262,6 +273,7 @@ int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* bloc
                              xsel_off + (size_t)nsel * W * 4 <= (size_t)rows * big * 2;
 
     // mixed precision: blocks [0, first8) on bf16 operands, [first8, layers) on e4m3 (mq_encoder_cfg.fp8_first_layer)
+    t_ln_prefetch = weights_outlive_cache(cfg, Wa);
     const int first8 = cfg->precision == MQ_PREC_FP8 ? (cfg->fp8_first_layer < cfg->layers ? cfg->fp8_first_layer : cfg->layers) : cfg->layers;
 
     // post-LN on the search path: LayerNorms fused into the skinny GEMMs (plain bf16 encoder only)
@@ -326,12 +338,14 @@ int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* bloc
             }
             const int xb = stream_bf16(cfg) ? 1 : 0;     // the stream itself may be bf16 (decided per model at load): bf16 RMW epilogues, bf16-in LN
             const int rflags = xb ? (MQ_EPI_BIAS | MQ_EPI_RESIDUAL) : res_flags;
-            MQ_TRY(mq_layernorm_fp8_ex(d_x, xb, b.ln1_g, b.ln1_b, h, row_scale, nullptr, rows, W, cfg->ln_eps, s));
+            MQ_TRY(mq_layernorm_fp8_pf(d_x, xb, b.ln1_g, b.ln1_b, h, row_scale, nullptr, rows, W, cfg->ln_eps, pf(b.qkv_w8), (size_t)3 * Wa * W,
+                                       pf(b.out_w8), (size_t)W * Wa, s));
             MQ_TRY(mq_gemm_fp8(h, W, b.qkv_w8, W, row_scale, 1, b.qkv_ws, b.qkv_b, nullptr, qf, 3 * Wa, nullptr, nullptr, rows, 3 * Wa, W,
                                MQ_EPI_BIAS, s));
             MQ_TRY(mq_attention_ex(qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, cfg->heads, cfg->mask, 1, s_attn, m_attn, s));
             MQ_TRY(mq_gemm_fp8(a, Wa, b.out_w8, Wa, s_attn, 0, b.out_ws, b.out_b, d_x, d_x, W, nullptr, nullptr, rows, W, Wa, rflags, s));
-            MQ_TRY(mq_layernorm_fp8_ex(d_x, xb, b.ln2_g, b.ln2_b, h, row_scale, nullptr, rows, W, cfg->ln_eps, s));
+            MQ_TRY(mq_layernorm_fp8_pf(d_x, xb, b.ln2_g, b.ln2_b, h, row_scale, nullptr, rows, W, cfg->ln_eps, pf(b.fc1_w8), (size_t)F * W,
+                                       pf(b.fc2_w8), (size_t)W * F, s));
             MQ_TRY(mq_gemm_fp8(h, W, b.fc1_w8, W, row_scale, 1, b.fc1_ws, b.fc1_b, nullptr, qf, F, s_mlp, m_mlp, rows, F, W, act8, s));
             MQ_TRY(mq_gemm_fp8(qf, F, b.fc2_w8, F, s_mlp, 0, b.fc2_ws, b.fc2_b, d_x, d_x, W, nullptr, nullptr, rows, W, F, rflags, s));
         } else if (!cfg->post_ln) {
@@ -347,7 +361,8 @@ int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* bloc
                 const float* s_mlp = cfg->d_fp8_act_scale + 2 * l + 1;
                 float* m_mlp = cfg->d_fp8_act_amax ? cfg->d_fp8_act_amax + 2 * l + 1 : nullptr;
                 const int act8 = (cfg->act == MQ_ACT_QUICKGELU ? MQ_EPI_QUICKGELU : MQ_EPI_GELU) | MQ_EPI_BIAS | MQ_EPI_OUT_FP8;
-                MQ_TRY(mq_layernorm_fp8_ex(d_x, xb, b.ln2_g, b.ln2_b, h, row_scale, nullptr, rows, W, cfg->ln_eps, s));
+                MQ_TRY(mq_layernorm_fp8_pf(d_x, xb, b.ln2_g, b.ln2_b, h, row_scale, nullptr, rows, W, cfg->ln_eps, pf(b.fc1_w8), (size_t)F * W,
+                                           pf(b.fc2_w8), (size_t)W * F, s));
                 MQ_TRY(mq_gemm_fp8(h, W, b.fc1_w8, W, row_scale, 1, b.fc1_ws, b.fc1_b, nullptr, qf, F, s_mlp, m_mlp, rows, F, W, act8, s));
                 MQ_TRY(mq_gemm_fp8(qf, F, b.fc2_w8, F, s_mlp, 0, b.fc2_ws, b.fc2_b, (const float*)d_x, d_x, W, nullptr, nullptr, rows, W, F, rflags, s));
                 continue;
@@ -376,8 +391,8 @@ int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* bloc
             if (cfg->d_rope_inv_freq) MQ_TRY(mq_rope(qf, d_cu_seqlens, nseq, fixed_len, Wa, cfg->heads, cfg->d_rope_inv_freq, s));
             MQ_TRY(attn_bf16(cfg, qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, s));
             MQ_TRY(mq_gemm_bf16(a, Wa, b.out_w, Wa, b.out_b, d_x, d_x, W, rows, W, Wa, res_flags, s));
-            MQ_TRY(mq_layernorm_pf(d_x, 0, nullptr, b.ln1_g, b.ln1_b, h, d_x, rows, W, cfg->ln_eps, b.fc1_w, (size_t)(cfg->mlp_glu ? 2 : 1) * F * W * 2,
-                                   b.fc2_w, (size_t)W * F * 2, s));
+            MQ_TRY(mq_layernorm_pf(d_x, 0, nullptr, b.ln1_g, b.ln1_b, h, d_x, rows, W, cfg->ln_eps, pf(b.fc1_w), (size_t)(cfg->mlp_glu ? 2 : 1) * F * W * 2,
+                                   pf(b.fc2_w), (size_t)W * F * 2, s));
             if (cfg->mlp_glu) {
                 // gated MLP: fc1 = (up | gate) rows [2F, W] (bias optional), hidden = up * act(gate) in place, fc2 reads it with lda = 2F
                 MQ_TRY(mq_gemm_bf16(h, W, b.fc1_w, W, b.fc1_b, nullptr, qf, 2 * F, rows, 2 * F, W, b.fc1_b ? MQ_EPI_BIAS : 0, s));
@@ -388,8 +403,8 @@ int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* bloc
                 MQ_TRY(mq_gemm_bf16(qf, F, b.fc2_w, F, b.fc2_b, d_x, d_x, W, rows, W, F, res_flags, s));
             }
             const mq_block_weights* nb = l + 1 < cfg->layers && l + 1 < first8 ? &blocks[l + 1] : nullptr;   // the next block's QKV / out-proj weights
-            MQ_TRY(mq_layernorm_pf(d_x, 0, nullptr, b.ln2_g, b.ln2_b, h, d_x, rows, W, cfg->ln_eps, nb ? nb->qkv_w : nullptr, (size_t)3 * Wa * W * 2,
-                                   nb ? nb->out_w : nullptr, (size_t)W * Wa * 2, s));
+            MQ_TRY(mq_layernorm_pf(d_x, 0, nullptr, b.ln2_g, b.ln2_b, h, d_x, rows, W, cfg->ln_eps, pf(nb ? nb->qkv_w : nullptr), (size_t)3 * Wa * W * 2,
+                                   pf(nb ? nb->out_w : nullptr), (size_t)W * Wa * 2, s));
         }
     }
     return MQ_OK;
