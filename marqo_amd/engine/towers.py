@@ -795,20 +795,29 @@ def _pack(ids: np.ndarray, lengths: np.ndarray) -> Tuple[Tensor, Tensor]:
 
 
 class _TextTowerBase(_TowerBase):
+    # rows (tokens) per engine call.  Towers may lower it: the post-LN BERT encoders (fp32 stream: ~10 KB of activations per row and layer) run
+    # 4-6 % faster per item at 20-40 k rows per call than at 79 k (profiles/r03v_batch_sweep.txt); the pre-LN towers do not (ViT-L/14: larger is better)
+    max_rows_per_call = MAX_ROWS_PER_CALL
+
     def _chunks(self, lengths: np.ndarray):
-        """Yield (start, stop) sequence ranges with <= MAX_ROWS_PER_CALL rows each (greedy, vectorised: the common
-        case of one chunk costs one cumsum)."""
+        """Yield (start, stop) sequence ranges with <= max_rows_per_call rows each, of about EQUAL row counts (a greedy fill would leave a small,
+        badly tiled last call).  Vectorised: the common case of one chunk costs one cumsum."""
         n = int(lengths.size)
         if n == 0:
             return
         cum = np.cumsum(lengths)
-        if int(cum[-1]) <= MAX_ROWS_PER_CALL:
+        total, limit = int(cum[-1]), int(self.max_rows_per_call)
+        if total <= limit:
             yield 0, n
             return
+        pieces = -(-total // limit)
+        target = -(-total // pieces)
         start, base = 0, 0
         while start < n:
-            stop = int(np.searchsorted(cum, base + MAX_ROWS_PER_CALL, side="right"))
+            stop = int(np.searchsorted(cum, base + target, side="right"))
             stop = max(stop, start + 1)
+            if int(cum[stop - 1]) - base > limit and stop - 1 > start:   # (never over the hard limit)
+                stop -= 1
             yield start, stop
             base = int(cum[stop - 1])
             start = stop
@@ -977,6 +986,8 @@ class ClipTextTower(_TextTowerBase):
 
 class BertTower(_TextTowerBase):
     """BERT-family encoder + pooling (HF `BertModel` checkpoint tensors, with or without a `bert.` prefix)."""
+
+    max_rows_per_call = int(os.environ.get("MARQO_AMD_BERT_ROWS_PER_CALL", str(40 * 1024)))   # see _TextTowerBase.max_rows_per_call
 
     def __init__(self, arch: BertArch, sd: Dict[str, Tensor], device: str, pooling: str = "mean", precision: str = "bf16"):
         super().__init__(device)

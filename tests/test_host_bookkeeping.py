@@ -37,8 +37,8 @@ def test_host_i64_accepts_tensors_arrays_and_lists():
 
 
 def test_chunks_cover_everything_within_the_row_cap(monkeypatch):
-    monkeypatch.setattr(towers, "MAX_ROWS_PER_CALL", 100)
     base = towers._TextTowerBase.__new__(towers._TextTowerBase)
+    base.max_rows_per_call = 100
     lengths = np.array([60, 30, 10, 5, 100, 1, 99, 1, 1, 250, 3], dtype=np.int64)   # (a single over-long sequence still forms its own chunk)
     chunks = list(base._chunks(lengths))
     assert chunks[0][0] == 0 and chunks[-1][1] == len(lengths) and all(a[1] == b[0] for a, b in zip(chunks, chunks[1:]))
@@ -46,6 +46,10 @@ def test_chunks_cover_everything_within_the_row_cap(monkeypatch):
         assert b > a and (int(lengths[a:b].sum()) <= 100 or b - a == 1)
     assert list(base._chunks(np.zeros(0, dtype=np.int64))) == []
     assert list(base._chunks(np.array([5, 5], dtype=np.int64))) == [(0, 2)]
+    # pieces come out balanced: 120 equal sequences of 1 row under a cap of 100 -> 60 + 60, not 100 + 20
+    assert list(base._chunks(np.ones(120, dtype=np.int64))) == [(0, 60), (60, 120)]
+    # the post-LN BERT tower runs smaller calls (class attribute), everything else keeps the large default
+    assert towers.BertTower.max_rows_per_call < towers.ClipTextTower.max_rows_per_call == towers.MAX_ROWS_PER_CALL
 
 
 def test_request_path_helpers_do_not_call_torch_cpu_kernels(monkeypatch):
