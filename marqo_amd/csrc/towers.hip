@@ -80,6 +80,14 @@ static bool stream_bf16(const mq_encoder_cfg* c) {
            !c->d_rope_inv_freq;
 }
 
+// post-LN encoders (BERT family) on the bf16 stream: the normalised bf16 rows `h` ARE the residual — the out-projection / fc2 epilogues add
+// into them in place (bf16 read-modify-write), the LayerNorm normalises them in place, and the fp32 copy of x disappears from the block
+// (18 -> 8 bytes per element and sublayer); the last LayerNorm writes the fp32 rows the pooling reads.  Decided per model at load like the
+// pre-LN form (mq_encoder_cfg.residual_stream == 1); plain bf16 encoders only (no e4m3 blocks, no gated MLP / rotary positions).
+static bool stream_post16(const mq_encoder_cfg* c) {
+    return c->residual_stream == 1 && c->post_ln && c->precision == MQ_PREC_BF16 && !c->mlp_glu && !c->d_rope_inv_freq;
+}
+
 extern "C" int mq_gemm_bf16_ln(const void* d_A, int64_t lda, const void* d_W, int64_t ldw, const float* d_bias, const float* d_residual,
                                void* d_out, int64_t ldc, int64_t M, int64_t N, int64_t K, int flags, float* d_stats, void* d_out2,
                                const float* d_colsum, float eps, void* stream);
@@ -279,6 +287,8 @@ int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* bloc
     // post-LN on the search path: LayerNorms fused into the skinny GEMMs (plain bf16 encoder only)
     const bool small_post_ln = cfg->post_ln && first8 >= cfg->layers && !cfg->mlp_glu && !cfg->d_rope_inv_freq && rows <= SMALL_LN_ROWS &&
                                mq_gemm_small_ok(rows, 3 * Wa, W, true) && mq_gemm_small_ok(rows, F, W, true) && mq_gemm_small_ok(rows, W, F, false);
+    // (the selected-rows last block keeps the fp32 form: not taken on the bf16 post-LN stream; a few-row call keeps its fused-LayerNorm path)
+    const bool post16 = stream_post16(cfg) && !small_post_ln;
     // block input as GEMM operand (post-LN: afterwards every LayerNorm leaves it behind)
     if (cfg->post_ln && first8 == 0) MQ_TRY(mq_rowquant_fp8(d_x, h, row_scale, rows, W, s));
     else if (cfg->post_ln) MQ_TRY(mq_cast_bf16(d_x, h, rows * W, s));
@@ -292,7 +302,7 @@ int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* bloc
                          "mq_encoder_forward: layer %d has no fp8 weights", l);
         // post-LN: the previous (bf16) block left its output as a bf16 operand; the first e4m3 block wants e4m3 rows + row scales
         if (cfg->post_ln && f8 && l == first8 && l > 0) MQ_TRY(mq_rowquant_fp8(d_x, h, row_scale, rows, W, s));
-        if (select_last && l == cfg->layers - 1) {
+        if (select_last && !post16 && l == cfg->layers - 1) {
             MQ_TRY(last_block_selected(cfg, b, l, d_x, rows, d_cu_seqlens, nseq, fixed_len, max_len, d_sel, nsel, h, a, qf, row_scale,
                                        (float*)((char*)qf + xsel_off), folded ? ln_stats : nullptr, f8, s));
             break;
@@ -385,6 +395,20 @@ int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* bloc
             MQ_TRY(mq_ln_gemm_small(d_x, W, 0, b.ln1_g, b.ln1_b, cfg->ln_eps, b.fc1_w, W, b.fc1_b, qf, F, rows, F, W, MQ_EPI_BIAS | act_flag, xn, nullptr, s));
             MQ_TRY(mq_gemm_bf16(qf, F, b.fc2_w, F, b.fc2_b, xn, d_x, W, rows, W, F, res_flags, s));
             if (l == cfg->layers - 1) MQ_TRY(mq_layernorm(d_x, nullptr, b.ln2_g, b.ln2_b, h, d_x, rows, W, cfg->ln_eps, s));
+        } else if (post16) {
+            // h = ln1(h + out(attn(qkv(h)))) ; h = ln2(h + fc2(act(fc1(h)))), all in place on the bf16 rows; the LAST LayerNorm writes fp32 x
+            const int rflags = MQ_EPI_BIAS | MQ_EPI_RESIDUAL;
+            const bool last = l == cfg->layers - 1;
+            MQ_TRY(mq_gemm_bf16(h, W, b.qkv_w, W, b.qkv_b, nullptr, qf, 3 * Wa, rows, 3 * Wa, W, MQ_EPI_BIAS, s));
+            MQ_TRY(attn_bf16(cfg, qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, s));
+            MQ_TRY(mq_gemm_bf16(a, Wa, b.out_w, Wa, b.out_b, (const float*)h, h, W, rows, W, Wa, rflags, s));
+            MQ_TRY(mq_layernorm_pf(h, 1, nullptr, b.ln1_g, b.ln1_b, h, nullptr, rows, W, cfg->ln_eps, pf(b.fc1_w), (size_t)F * W * 2, pf(b.fc2_w),
+                                   (size_t)W * F * 2, s));
+            MQ_TRY(mq_gemm_bf16(h, W, b.fc1_w, W, b.fc1_b, nullptr, qf, F, rows, F, W, MQ_EPI_BIAS | act_flag, s));
+            MQ_TRY(mq_gemm_bf16(qf, F, b.fc2_w, F, b.fc2_b, (const float*)h, h, W, rows, W, F, rflags, s));
+            const mq_block_weights* nb = !last ? &blocks[l + 1] : nullptr;
+            MQ_TRY(mq_layernorm_pf(h, 1, nullptr, b.ln2_g, b.ln2_b, last ? nullptr : h, last ? d_x : nullptr, rows, W, cfg->ln_eps,
+                                   pf(nb ? nb->qkv_w : nullptr), (size_t)3 * Wa * W * 2, pf(nb ? nb->out_w : nullptr), (size_t)W * Wa * 2, s));
         } else {
             // x = ln1(x + out(attn(qkv(x)))) ; x = ln2(x + fc2(act(fc1(x))))
             MQ_TRY(mq_gemm_bf16(h, W, b.qkv_w, W, b.qkv_b, nullptr, qf, 3 * Wa, rows, 3 * Wa, W, MQ_EPI_BIAS, s));

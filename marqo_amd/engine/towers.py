@@ -400,7 +400,7 @@ class _TowerBase:
         """`run()` pushes the tower's fixed calibration batch through it and returns the [n, D] embeddings -> 'bf16' | 'fp32'"""
         enc = self.cfg.enc
         mode = os.environ.get("MARQO_AMD_RESIDUAL_STREAM", "auto").lower()
-        if self.precision != "bf16" or enc.post_ln or mode == "fp32":
+        if self.precision != "bf16" or mode == "fp32":
             enc.residual_stream, self.residual_stream = 2, "fp32"
             return self.residual_stream
         if mode == "bf16":
@@ -1071,6 +1071,18 @@ class BertTower(_TextTowerBase):
             self.cfg.enc.d_rope_inv_freq = self._rope.data_ptr()
         if precision == "fp8":
             self._enable_fp8(self._blocks, arch.layers, W, F)
+        self.cfg.enc.residual_stream = 2
+        if precision == "bf16" and type(self) is BertTower:      # (towers with a projection head tune once the head is in place)
+            self.tune_residual_default()
+
+    def tune_residual_default(self) -> str:
+        """post-LN form of the bf16 stream (towers.hip, stream_post16): the normalised bf16 rows are the residual; decided like the pre-LN form,
+        on the fixed calibration batch, against the fp32-stream run of the same tower"""
+        if self.arch.glu or self.arch.rope_theta is not None:
+            self.cfg.enc.residual_stream, self.residual_stream = 2, "fp32"
+            return self.residual_stream
+        ids, mask = self.calibration_batch()
+        return self.tune_residual_stream(lambda: self.encode_ids(ids, mask))
 
     @property
     def out_width(self) -> int:
@@ -1161,6 +1173,8 @@ class HfClipTextTower(BertTower):
             raise ValueError("a biased second projection layer is not supported (open_clip builds text.proj without biases)")
         self.w.proj1_w, self.w.proj1_b, self.w.proj2_w = h.bf16(p1), h.f32(b1), h.bf16(p2)
         self.cfg.proj_hidden, self.cfg.out_dim = Hp, D
+        if precision == "bf16":
+            self.tune_residual_default()
 
     def encode_padded(self, ids: Tensor, normalize: bool = True) -> Tensor:
         """ids int [n, <= ctx] padded with pad_id, as open_clip's HFTokenizer hands them over; attention mask = ids != pad_id
@@ -1186,3 +1200,5 @@ class MclipTextTower(BertTower):
         self.w.proj1_w = self._h.bf16(_need(sd, "LinearTransformation.weight", (out_dim, W)))
         self.w.proj1_b = self._h.f32(_need(sd, "LinearTransformation.bias", (out_dim,)))
         self.cfg.proj_hidden, self.cfg.out_dim = 0, out_dim
+        if precision == "bf16":
+            self.tune_residual_default()

@@ -601,3 +601,50 @@ def test_residual_stream_policy_is_decided_per_model_at_load(monkeypatch):
     t4 = towers.VitTower(varch, sd, "cuda:0")
     t4.tune_residual_stream(lambda: t4.encode_u8(t4.calibration_images()), budget=1e-9)
     assert t4.residual_stream == "fp32" and t4.cfg.enc.residual_stream == 2
+
+
+def test_post_ln_bf16_stream_bert_family(tiled_gemm_only, monkeypatch):
+    """BERT-family (post-LN) towers on the bf16 stream: the normalised bf16 rows are the residual (in-place read-modify-write epilogues,
+    in-place LayerNorm, no fp32 copy of x inside the blocks).  Forced on and off on the golden BERT / MPNet fixtures and on a full-depth
+    e5-base-shaped tower: both forms inside the towers' 3e-4 bound of the fp32 oracle, different computations, deterministic; the load-time
+    policy decides (auto) and two loads agree; CLS pooling works on the bf16 stream (all rows run in the last block there)."""
+    T, A = _towers()
+    from marqo_amd.engine import synthetic
+    sdb, zb = G.load("bert_small")
+    Vb, Pb, Wb, Lb, Hb, Fb = [int(v) for v in zb["cfg"]]
+    bids, bmask = torch.from_numpy(zb["ids"]), torch.from_numpy(zb["mask"])
+    arch_small = A.BertArch(vocab=Vb, max_pos=Pb, width=Wb, layers=Lb, heads=Hb, mlp_dim=Fb)
+    cases = []
+    for pooling in ("mean", "cls"):
+        ref = O.hf_encode({k: v.float() for k, v in sdb.items()}, O.BertConfig(vocab=Vb, max_pos=Pb, width=Wb, layers=Lb, heads=Hb, mlp_dim=Fb, pooling=pooling),
+                          bids, bmask)
+        cases.append((f"bert_small/{pooling}", lambda p=pooling: T.BertTower(arch_small, sdb, "cuda", pooling=p), lambda t: t.encode_ids(bids, bmask), ref))
+    b = A.HF_BERT_ARCHS["intfloat/e5-base-v2"]
+    bsd = synthetic.random_bert_state_dict(b, seed=0)
+    ids = torch.randint(1000, b.vocab, (24, 40), generator=torch.Generator().manual_seed(5))
+    mask = torch.ones(24, 40, dtype=torch.int64)
+    for i in range(24):
+        mask[i, 8 + i:] = 0
+    ref = O.hf_encode(bsd, O.BertConfig(vocab=b.vocab, max_pos=b.max_pos, width=b.width, layers=b.layers, heads=b.heads, mlp_dim=b.mlp_dim, ln_eps=b.ln_eps),
+                      ids, mask)
+    cases.append(("e5-base 12L", lambda: T.BertTower(b, bsd, "cuda"), lambda t: t.encode_ids(ids, mask), ref))
+    for name, make, run, ref in cases:
+        outs = {}
+        for mode in ("fp32", "bf16", "auto"):
+            monkeypatch.setenv("MARQO_AMD_RESIDUAL_STREAM", mode)
+            t = make()
+            out = run(t)
+            assert torch.equal(run(t), out)
+            e = float((1 - torch.nn.functional.cosine_similarity(out.cpu().double(), ref.double(), dim=-1)).max())
+            print(f"post-LN stream, {name}, MARQO_AMD_RESIDUAL_STREAM={mode}: stream {t.residual_stream} (bf16 vs fp32 on the calibration batch "
+                  f"{t.residual_stream_error}), 1-cos vs fp32 oracle {e:.2e}")
+            assert e < 3e-4, (name, mode, e)
+            assert t.cfg.enc.residual_stream == (1 if t.residual_stream == "bf16" else 2)
+            if mode != "auto":
+                assert t.residual_stream == mode
+            else:
+                t2 = make()
+                assert t2.residual_stream == t.residual_stream and t2.residual_stream_error == t.residual_stream_error
+            outs[mode] = out
+        assert not torch.equal(outs["fp32"], outs["bf16"])
+        assert torch.equal(outs["auto"], outs["bf16"] if t.residual_stream == "bf16" else outs["fp32"])
