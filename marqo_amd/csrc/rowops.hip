@@ -31,9 +31,10 @@ constexpr int LN_MAX_CHUNKS = 8;  // float4 chunks per lane: W <= 64 * 4 * 8 = 2
 // starts its weights sit in the Infinity Cache.  pfa / pfb: two ranges (the next GEMM's weights and the one after it), na / nb in 128-byte lines.
 struct LnExtra {
     int band;
-    unsigned na, nb;          // 128-byte lines
+    unsigned na, nb;          // touches (one dword each, `step` dwords apart)
     const unsigned* pfa;
     const unsigned* pfb;
+    unsigned step;            // dwords between touches: 32 = one per 128-byte L2 line, 16 = one per 64-byte fabric request
 };
 constexpr int LN_PF = 2;   // lines per thread (one dword of a line brings the line: one VGPR per touched line)
 
@@ -45,8 +46,8 @@ __device__ __forceinline__ void ln_prefetch_issue(const LnExtra& ex, unsigned (&
 #pragma unroll
         for (int j = 0; j < LN_PF; ++j) {
             const unsigned c = t + j * nt;
-            if (c < ex.na) pq[j] = ex.pfa[(size_t)c * 32];
-            else if (c - ex.na < ex.nb) pq[j] = ex.pfb[(size_t)(c - ex.na) * 32];
+            if (c < ex.na) pq[j] = ex.pfa[(size_t)c * ex.step];
+            else if (c - ex.na < ex.nb) pq[j] = ex.pfb[(size_t)(c - ex.na) * ex.step];
         }
     }
 }
@@ -335,9 +336,11 @@ extern "C" int mq_layernorm(const float* d_x, const int32_t* d_row_idx, const fl
 int mq_ln_prefetch = getenv("MQ_LN_PREFETCH") ? atoi(getenv("MQ_LN_PREFETCH")) : 1;
 
 static LnExtra ln_extra(int band, int64_t rows, const void* pf_a, size_t bytes_a, const void* pf_b, size_t bytes_b) {
-    LnExtra ex{band, 0u, 0u, nullptr, nullptr};
+    LnExtra ex{band, 0u, 0u, nullptr, nullptr, 32u};
     if (mq_ln_prefetch && rows >= 1024) {   // (a small call is latency-bound: nothing to hide the extra loads behind)
-        auto lines = [](const void* p, size_t b) { return (p && ((uintptr_t)p & 3) == 0) ? (unsigned)(b < ((size_t)1 << 30) ? b / 128 : 0) : 0u; };
+        const size_t gran = mq_ln_prefetch == 2 ? 64 : mq_ln_prefetch == 3 ? 32 : 128;      // bytes per touch (knob values 2 / 3: A/B of the granularity)
+        ex.step = (unsigned)(gran / 4);
+        auto lines = [gran](const void* p, size_t b) { return (p && ((uintptr_t)p & 3) == 0) ? (unsigned)(b < ((size_t)1 << 30) ? b / gran : 0) : 0u; };
         ex.pfa = (const unsigned*)pf_a; ex.na = lines(pf_a, bytes_a);
         ex.pfb = (const unsigned*)pf_b; ex.nb = lines(pf_b, bytes_b);
     }
@@ -433,7 +436,7 @@ extern "C" int mq_rowquant_fp8(const float* d_x, void* d_out_fp8, float* d_row_s
     MqProfScope prof(1, s);
     MQ_DISPATCH_CH(W, hipLaunchKernelGGL((layernorm_fp8_kernel<CH, false>), dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, s, (const void*)d_x,
                                          (const float*)nullptr, (const float*)nullptr, (uint8_t*)d_out_fp8, d_row_scale, (float*)nullptr, rows,
-                                         (int)W, 0.f, LnExtra{0, 0u, 0u, nullptr, nullptr}));
+                                         (int)W, 0.f, LnExtra{0, 0u, 0u, nullptr, nullptr, 32u}));
     MQ_CHECK_LAUNCH("mq_rowquant_fp8");
     return MQ_OK;
 }
