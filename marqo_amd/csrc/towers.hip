@@ -224,6 +224,23 @@ int last_block_selected(const mq_encoder_cfg* cfg, const mq_block_weights& b, in
         MQ_TRY(mq_gemm_bf16(h, Wa, b.out_w, Wa, b.out_b, x_sel, x_sel, W, nsel, W, Wa, rflags, s));
         MQ_TRY(ln_gemm(x_sel, xb, b.ln2_g, b.ln2_b, cfg->ln_eps, a, b.fc1_w, b.fc1_b, qf, nsel, F, W, MQ_EPI_BIAS | act_flag, s));
         MQ_TRY(mq_gemm_bf16(qf, F, b.fc2_w, F, b.fc2_b, x_sel, x_sel, W, nsel, W, F, rflags, s));
+    } else if (stream_post16(cfg)) {
+        // post-LN on the bf16 stream (h = the normalised rows = the residual).  Scratch: a_sel -> head of `qf` (the QKV output is dead after the
+        // attention; the fc1 output overwrites it later), h_sel (bf16) -> where x_sel lives, the final fp32 rows -> head of `a` (dead after the gather)
+        const int rflags = MQ_EPI_BIAS | MQ_EPI_RESIDUAL;
+        void* h_sel = x_sel;
+        float* out_sel = (float*)a;
+        MQ_TRY(mq_gemm_bf16(h, W, b.qkv_w, W, b.qkv_b, nullptr, qf, 3 * Wa, rows, 3 * Wa, W, MQ_EPI_BIAS, s));
+        MQ_TRY(attn_bf16(cfg, qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, s));
+        MQ_TRY(mq_move_rows(a, d_sel, qf, nsel, (int64_t)Wa * 2, false, s));
+        MQ_TRY(mq_move_rows(h, d_sel, h_sel, nsel, (int64_t)W * 2, false, s));
+        MQ_TRY(mq_gemm_bf16(qf, Wa, b.out_w, Wa, b.out_b, (const float*)h_sel, h_sel, W, nsel, W, Wa, rflags, s));
+        MQ_TRY(mq_layernorm_ex(h_sel, 1, nullptr, b.ln1_g, b.ln1_b, h_sel, nullptr, nsel, W, cfg->ln_eps, s));
+        MQ_TRY(mq_gemm_bf16(h_sel, W, b.fc1_w, W, b.fc1_b, nullptr, qf, F, nsel, F, W, MQ_EPI_BIAS | act_flag, s));
+        MQ_TRY(mq_gemm_bf16(qf, F, b.fc2_w, F, b.fc2_b, (const float*)h_sel, h_sel, W, nsel, W, F, rflags, s));
+        MQ_TRY(mq_layernorm_ex(h_sel, 1, nullptr, b.ln2_g, b.ln2_b, nullptr, out_sel, nsel, W, cfg->ln_eps, s));
+        MQ_TRY(mq_move_rows(d_x, d_sel, out_sel, nsel, (int64_t)W * 4, true, s));
+        return MQ_OK;
     } else {
         MQ_TRY(mq_gemm_bf16(h, W, b.qkv_w, W, b.qkv_b, nullptr, qf, 3 * Wa, rows, 3 * Wa, W, MQ_EPI_BIAS, s));
         MQ_TRY(attn_bf16(cfg, qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, s));
@@ -287,7 +304,7 @@ int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* bloc
     // post-LN on the search path: LayerNorms fused into the skinny GEMMs (plain bf16 encoder only)
     const bool small_post_ln = cfg->post_ln && first8 >= cfg->layers && !cfg->mlp_glu && !cfg->d_rope_inv_freq && rows <= SMALL_LN_ROWS &&
                                mq_gemm_small_ok(rows, 3 * Wa, W, true) && mq_gemm_small_ok(rows, F, W, true) && mq_gemm_small_ok(rows, W, F, false);
-    // (the selected-rows last block keeps the fp32 form: not taken on the bf16 post-LN stream; a few-row call keeps its fused-LayerNorm path)
+    // (a few-row call keeps its fused-LayerNorm path)
     const bool post16 = stream_post16(cfg) && !small_post_ln;
     // block input as GEMM operand (post-LN: afterwards every LayerNorm leaves it behind)
     if (cfg->post_ln && first8 == 0) MQ_TRY(mq_rowquant_fp8(d_x, h, row_scale, rows, W, s));
@@ -302,7 +319,7 @@ int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* bloc
                          "mq_encoder_forward: layer %d has no fp8 weights", l);
         // post-LN: the previous (bf16) block left its output as a bf16 operand; the first e4m3 block wants e4m3 rows + row scales
         if (cfg->post_ln && f8 && l == first8 && l > 0) MQ_TRY(mq_rowquant_fp8(d_x, h, row_scale, rows, W, s));
-        if (select_last && !post16 && l == cfg->layers - 1) {
+        if (select_last && l == cfg->layers - 1) {
             MQ_TRY(last_block_selected(cfg, b, l, d_x, rows, d_cu_seqlens, nseq, fixed_len, max_len, d_sel, nsel, h, a, qf, row_scale,
                                        (float*)((char*)qf + xsel_off), folded ? ln_stats : nullptr, f8, s));
             break;
