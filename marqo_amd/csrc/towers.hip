@@ -304,8 +304,9 @@ int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* bloc
     // post-LN on the search path: LayerNorms fused into the skinny GEMMs (plain bf16 encoder only)
     const bool small_post_ln = cfg->post_ln && first8 >= cfg->layers && !cfg->mlp_glu && !cfg->d_rope_inv_freq && rows <= SMALL_LN_ROWS &&
                                mq_gemm_small_ok(rows, 3 * Wa, W, true) && mq_gemm_small_ok(rows, F, W, true) && mq_gemm_small_ok(rows, W, F, false);
-    // (a few-row call keeps its fused-LayerNorm path)
-    const bool post16 = stream_post16(cfg) && !small_post_ln;
+    // (the skinny-GEMM family — a search query alone or inside a small batch — keeps the fp32 form and its fused-LayerNorm path: the same
+    // bits for a query whatever shares its call, like the LayerNorm families of rowops.hip)
+    const bool post16 = stream_post16(cfg) && !small_post_ln && !mq_gemm_small_ok(rows, W, W, false);
     // block input as GEMM operand (post-LN: afterwards every LayerNorm leaves it behind)
     if (cfg->post_ln && first8 == 0) MQ_TRY(mq_rowquant_fp8(d_x, h, row_scale, rows, W, s));
     else if (cfg->post_ln) MQ_TRY(mq_cast_bf16(d_x, h, rows * W, s));
