@@ -648,3 +648,26 @@ def test_post_ln_bf16_stream_bert_family(tiled_gemm_only, monkeypatch):
             outs[mode] = out
         assert not torch.equal(outs["fp32"], outs["bf16"])
         assert torch.equal(outs["auto"], outs["bf16"] if t.residual_stream == "bf16" else outs["fp32"])
+
+
+def test_weight_prefetch_changes_no_bit():
+    """The LayerNorm kernels of a tower whose block weights outlive the Infinity Cache (>= 128 MB: ViT-B/32 here) also touch the next GEMMs'
+    weights (rowops.hip, LnExtra).  Loads whose values are discarded: embeddings are bit-identical with the knob off, at every prefetch
+    granularity, in bf16 and on the fp8 policy."""
+    T, A = _towers()
+    from marqo_amd.engine import synthetic
+    v, t = A.resolve_open_clip("ViT-B-32")
+    sd = synthetic.random_open_clip_state_dict(vision=v, text=t, seed=0)
+    u8 = O.synthetic_images_u8(24, v.image_size, seed=9).cuda()          # 1200 rows: above the prefetch's row threshold
+    for precision in ("bf16", "fp8"):
+        tower = T.VitTower(v, sd, "cuda", precision=precision)
+        if precision == "fp8":
+            tower.tune_fp8_default()
+        outs = []
+        try:
+            for knob in (0, 1, 2, 3):
+                _tune("ln_prefetch", knob)
+                outs.append(tower.encode_u8(u8))
+        finally:
+            _tune("ln_prefetch", 1)
+        assert all(torch.equal(outs[0], o) for o in outs[1:]), precision
