@@ -132,11 +132,13 @@ typedef struct mq_encoder_cfg {
      * scale, which the kernel applies to the sum), rel_span >= the longest sequence run.  bf16 path, 64-wide heads, unmasked attention. */
     const float* d_rel_bias;
     int32_t      rel_span;
-    int32_t      residual_stream; /* pre-LN bf16 encoders: 0 = the process default (mq_tune("residual_bf16") / MQ_RESIDUAL_BF16, fp32 unless set),
-                                   * 1 = bf16 residual stream (x kept in bf16 between blocks: half the bytes of every residual epilogue and
-                                   * LayerNorm), 2 = fp32.  The loaders decide 1 / 2 per MODEL at load on a fixed seeded batch
-                                   * (engine/towers.py::tune_residual_stream: bf16 only where it stays within a 1 - cos budget of the fp32
-                                   * stream).  (Took the slot of the former reserved0: the layout is unchanged.) */
+    int32_t      residual_stream; /* 0 = the process default (mq_tune("residual_bf16") / MQ_RESIDUAL_BF16 for pre-LN bf16 encoders, fp32 unless set),
+                                   * 1 = bf16 residual stream, 2 = fp32.  Pre-LN encoders (bf16, and e4m3 towers whose policy asks for it): x is
+                                   * kept in bf16 between blocks (half the bytes of every residual epilogue and LayerNorm).  Post-LN bf16 encoders
+                                   * (BERT family): the normalised bf16 rows are the residual, updated in place; the last LayerNorm writes the fp32
+                                   * rows that are pooled.  The loaders decide 1 / 2 per MODEL at load on a fixed seeded batch
+                                   * (engine/towers.py::tune_residual_stream / tune_fp8: bf16 only where it stays within a 1 - cos budget of the
+                                   * fp32 stream).  (Took the slot of the former reserved0.) */
     int32_t      fp8_mlp_extra;   /* MQ_PREC_FP8, pre-LN encoders: the `fp8_mlp_extra` blocks in FRONT of fp8_first_layer run only their MLP half on e4m3
                                    * (LayerNorm 2 -> e4m3 rows, fc1 + activation -> e4m3, fc2 + residual) and keep LayerNorm 1 / QKV / attention /
                                    * out-projection on bf16 operands: two thirds of a block's GEMM FLOPs for the rounding noise of two of its four
