@@ -457,7 +457,7 @@ def e2e_vectorise(dev, images_cpu_u8, tower_only_rate, reps=9):
 
 
 # ---- BASELINE configs[3] in miniature ------------------------------------------------------------------------------------------------
-def run_ingest(args, dev, rank, world, dist):
+def run_ingest(args, dev, rank, world, dist, lib, L):
     from PIL import Image
     os.environ["MARQO_AMD_SYNTHETIC_WEIGHTS"] = "1"
     os.environ.setdefault("MARQO_MAX_CUDA_MODEL_MEMORY", "64")
@@ -503,7 +503,11 @@ def run_ingest(args, dev, rank, world, dist):
                    "parallelism": f"dp{world} (replicated weights; texts sharded by token estimate, images contiguously; ONE RCCL all_gather per modality from HBM; "
                                   f"every rank returns the request's embeddings in order)",
                    "weights": "random-init (seed 0) ViT-B-32", "gflop_per_embedding": round(gf, 3)},
-        "roofline": None, "cpu_baseline": None,
+        "e2e_tflops": round(value * gf / 1e3, 1),
+        # the dominant kernel family over a few more requests (HIP events on the launch streams, as in the headline)
+        "roofline": gemm_roofline(lib, L, step, min(args.steps, 6), args.precision, "add_documents_mixed"),
+        "cpu_baseline": (mixed_request_cpu_baseline(varch, tarch, imgs, docs, args.cpu_seconds)
+                         if rank == 0 and world == 1 and not args.no_cpu_baseline else None),
         "note": "end-to-end through the Python boundary (host PIL -> uint8 pack -> H2D -> K10 -> towers -> gather -> D2H -> per-key rows); "
                 "the request (total work) is fixed, ranks split it: strong scaling",
     }
@@ -582,31 +586,34 @@ def run_stream(args, dev, rank, world, dist, lib, L):
         "e2e_tflops": round(value * gf / 1e3, 1), "roofline": roofline,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        # reference-equivalent CPU path on a bounded sample of one request: fp32 towers, 16-item batches (tokeniser time not included)
-        from oracle import towers as O
-        from marqo_amd.engine import synthetic
-        sd = synthetic.random_open_clip_state_dict(vision=varch, text=tarch, seed=0)
-        vcfg = O.VitConfig(varch.image_size, varch.patch_size, varch.width, varch.layers, varch.heads, varch.mlp_dim, varch.out_dim, varch.quick_gelu)
-        tcfg = O.ClipTextConfig(tarch.vocab, tarch.ctx, tarch.width, tarch.layers, tarch.heads, tarch.mlp_dim, tarch.out_dim, tarch.quick_gelu)
-        texts, imgs = pool[0]
-        px = torch.from_numpy(np.stack([np.asarray(im) for im in imgs]))
-        gt = torch.Generator().manual_seed(3)
-        ids = torch.zeros(docs, 77, dtype=torch.int64)
-        for i in range(docs):
-            li = int(torch.randint(5, 62, (1,), generator=gt))
-            ids[i, 0], ids[i, 1:1 + li], ids[i, 1 + li] = 49406, torch.randint(1, 49406, (li,), generator=gt), 49407
-
-        def run_items(lo, hi):      # item 2i = image i, item 2i + 1 = text i: a bounded sample keeps the 50 / 50 mix
-            i0, i1 = lo // 2, hi // 2
-            im = O.vit_forward(sd, vcfg, O.preprocess_u8_exact_size(px[i0:i1]))
-            tx = O.clip_text_forward(sd, tcfg, ids[i0:i1])
-            return torch.stack([im, tx], dim=1).reshape(-1, im.shape[1])
-        rate, n, emb, th, cores = cpu_baseline_run(run_items, 2 * docs, args.cpu_seconds)
-        result["cpu_baseline"] = _baseline_dict(rate, n, th, cores, f"items ({n // 2} images + {n // 2} texts of 5..61 tokens) of one request")
+        result["cpu_baseline"] = mixed_request_cpu_baseline(varch, tarch, pool[0][1], docs, args.cpu_seconds)
     elif rank == 0:
         result["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(result), flush=True)
+
+
+def mixed_request_cpu_baseline(varch, tarch, imgs, docs, cpu_seconds):
+    """reference-equivalent CPU path on a bounded sample of one {text, image} request: fp32 towers, 16-item batches (tokeniser time not included)"""
+    from oracle import towers as O
+    from marqo_amd.engine import synthetic
+    sd = synthetic.random_open_clip_state_dict(vision=varch, text=tarch, seed=0)
+    vcfg = O.VitConfig(varch.image_size, varch.patch_size, varch.width, varch.layers, varch.heads, varch.mlp_dim, varch.out_dim, varch.quick_gelu)
+    tcfg = O.ClipTextConfig(tarch.vocab, tarch.ctx, tarch.width, tarch.layers, tarch.heads, tarch.mlp_dim, tarch.out_dim, tarch.quick_gelu)
+    px = torch.from_numpy(np.stack([np.asarray(im) for im in imgs]))
+    gt = torch.Generator().manual_seed(3)
+    ids = torch.zeros(docs, 77, dtype=torch.int64)
+    for i in range(docs):
+        li = int(torch.randint(5, 62, (1,), generator=gt))
+        ids[i, 0], ids[i, 1:1 + li], ids[i, 1 + li] = 49406, torch.randint(1, 49406, (li,), generator=gt), 49407
+
+    def run_items(lo, hi):      # item 2i = image i, item 2i + 1 = text i: a bounded sample keeps the 50 / 50 mix
+        i0, i1 = lo // 2, hi // 2
+        im = O.vit_forward(sd, vcfg, O.preprocess_u8_exact_size(px[i0:i1]))
+        tx = O.clip_text_forward(sd, tcfg, ids[i0:i1])
+        return torch.stack([im, tx], dim=1).reshape(-1, im.shape[1])
+    rate, n, emb, th, cores = cpu_baseline_run(run_items, 2 * docs, cpu_seconds)
+    return _baseline_dict(rate, n, th, cores, f"items ({n // 2} images + {n // 2} texts of 5..61 tokens) of one request")
 
 
 def main():
@@ -637,7 +644,7 @@ def main():
             dist.destroy_process_group()
         return
     if WORKLOADS[args.workload]["kind"] == "ingest":
-        run_ingest(args, dev, rank, world, dist)
+        run_ingest(args, dev, rank, world, dist, lib, L)
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
