@@ -30,6 +30,15 @@ Tensor = torch.Tensor
 MAX_ROWS_PER_CALL = 1 << 18
 
 
+def _env_int(name: str, default: int, lo: int = 1) -> int:
+    """integer knob from the environment; anything unparsable or below `lo` falls back to the default (a typo must not break the import)"""
+    try:
+        v = int(os.environ.get(name, ""))
+    except ValueError:
+        return default
+    return v if v >= lo else default
+
+
 def _require_gpu(device: str) -> torch.device:
     if not str(device).startswith("cuda"):
         raise L.MarqoHipUnavailableError(
@@ -987,7 +996,7 @@ class ClipTextTower(_TextTowerBase):
 class BertTower(_TextTowerBase):
     """BERT-family encoder + pooling (HF `BertModel` checkpoint tensors, with or without a `bert.` prefix)."""
 
-    max_rows_per_call = int(os.environ.get("MARQO_AMD_BERT_ROWS_PER_CALL", str(40 * 1024)))   # see _TextTowerBase.max_rows_per_call
+    max_rows_per_call = _env_int("MARQO_AMD_BERT_ROWS_PER_CALL", 40 * 1024, lo=1024)   # see _TextTowerBase.max_rows_per_call
 
     def __init__(self, arch: BertArch, sd: Dict[str, Tensor], device: str, pooling: str = "mean", precision: str = "bf16"):
         super().__init__(device)

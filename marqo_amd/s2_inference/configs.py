@@ -6,7 +6,25 @@ from typing import Optional
 from marqo_amd.s2_inference.enums import EnvVars
 
 
+_STATIC_DEFAULTS = None
+
+
 def default_env_vars() -> dict:
+    """the defaults; everything but the model directory is constant, and that one depends on two environment values only — vectorise() asks
+    for a default on every call, so the dict is built once and only the directory is looked at again (it was a third of the per-request
+    host time: expanduser + join + a dict literal per call)"""
+    return dict(_defaults())
+
+
+def _defaults() -> dict:
+    global _STATIC_DEFAULTS
+    sig = (os.environ.get("MARQO_ROOT_PATH"), os.environ.get("HOME"))
+    if _STATIC_DEFAULTS is None or _STATIC_DEFAULTS[0] != sig:
+        _STATIC_DEFAULTS = (sig, _build_defaults())
+    return _STATIC_DEFAULTS[1]
+
+
+def _build_defaults() -> dict:
     return {
         # reference defaults (api/configs.py:35-38): 4 GB per device, batch 16.  The 4 GB budget is far too
         # small for a 288 GB MI355X; the mechanism is kept and the default raised for cuda devices.
@@ -27,7 +45,7 @@ def read_env_vars_and_defaults(var: str) -> Optional[str]:
     val = os.environ.get(var)
     if val is not None and val != "":
         return val
-    return default_env_vars().get(var)
+    return _defaults().get(var)
 
 
 def read_env_vars_and_defaults_ints(var: str) -> Optional[int]:
