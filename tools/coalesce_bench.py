@@ -25,7 +25,11 @@ def main():
     ap.add_argument("--calls", type=int, default=60)
     ap.add_argument("--depth", default="2")
     ap.add_argument("--windows", default="0,200", help="MARQO_AMD_COALESCE_US values to time")
+    ap.add_argument("--switch-interval", type=float, default=0.0, help="sys.setswitchinterval (seconds; 0 = leave the interpreter's 5 ms)")
+    ap.add_argument("--only", default="", help="substring of the model names to run")
     args = ap.parse_args()
+    if args.switch_interval > 0:
+        sys.setswitchinterval(args.switch_interval)
     dev = "cuda:0"
     os.environ["MARQO_AMD_COALESCE_DEPTH"] = args.depth
     words = ["alpha", "beta", "gamma", "delta", "marqo", "tensor", "search", "image", "text", "vector"]
@@ -34,6 +38,8 @@ def main():
     def texts(t, c):
         return [" ".join(words[int(j)] for j in rng.integers(0, 10, 12)) + f" {t} {c} {i}" for i in range(args.items)]
     for name, kw in (("open_clip/ViT-B-32/laion2b_s34b_b79k", dict(modality=Modality.TEXT)), ("hf/e5-base-v2", dict(modality=Modality.TEXT))):
+        if args.only and args.only not in name:
+            continue
         props = s2.get_model_properties_from_registry(name)
         content = {(t, c): texts(t, c) for t in range(args.threads) for c in range(args.calls)}
         s2.vectorise_ndarray(name, content[(0, 0)], model_properties=props, device=dev, **kw)      # load
