@@ -13,7 +13,7 @@ ln_post -> projection -> L2, i.e. exactly mq_encode_image_u8; for N > 1 the [256
 Rank 0 prints ONE JSON line.  Besides the contract keys it carries
   roofline        — the dominant kernel (bf16 MFMA GEMM): algorithmic FLOPs / HIP-event time of its launches
   cpu_baseline    — the CPU fp32 oracle (oracle/towers.py) run with the reference's 16-item batch loop (s2_inference.py:135-146) on a
-                    bounded sample; `cores` = host cores, `threads_used` = the torch thread count that was fastest
+                    bounded sample; `cores` = the torch thread count of the fastest run of a thread ladder, `host_hw_threads` / `cpu_quota` = what the box offers
   cos_err_vs_cpu  — max (1 - cosine) of the GPU embeddings vs that CPU path on the same sample
   e2e_vectorise   — (N = 1) the same 256 images through the product's `vectorise_ndarray()` / `vectorise()` from HOST memory, as
                     SURVEY.md §8(d) defines end-to-end: pack + H2D + K10 + tower + D2H (+ `.tolist()`), for each hand-over form
@@ -129,7 +129,9 @@ def _baseline_dict(rate, n, threads, cores, what):
         quota = cpu_quota()
     except Exception:  # noqa: BLE001 - informational
         quota = None
-    return {"value": round(rate, 2), "unit": "embeddings/s", "cores": cores, "threads_used": threads, "cpu_quota": quota, "kind": "port",
+    # `cores` = the threads the winning run of the ladder actually used (the bench contract's meaning); the host's hardware threads and the
+    # container's CPU quota are reported beside it
+    return {"value": round(rate, 2), "unit": "embeddings/s", "cores": threads, "host_hw_threads": cores, "cpu_quota": quota, "kind": "port",
             "sample": f"{n} {what}, fp32 PyTorch eager, 16-item batches (reference loop s2_inference.py:135-146), best of a 16/32/64/128/all thread ladder"}
 
 
