@@ -140,7 +140,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(const void* __restr
     }
 
     // ---- main loop: this wave's share of the 32-deep k-chunks, G chunks per group (all of a group's loads are issued before its MFMAs) ----
-    constexpr int G = (MT <= 2 || (!LN && MT <= 4)) ? 4 : 2;   // chunks in flight per wave (the row-group form is latency-bound: profiles/r03u kernel trace, 22 us at M = 256, K = 3072)
+    constexpr int G = MT <= 2 ? 4 : 2;
     const int nchunks = K >> 5;
     const int per = (nchunks + NW - 1) / NW;
     const int c0 = wave * per, c1 = min(c0 + per, nchunks);
