@@ -33,6 +33,7 @@ bool mq_gemm_small_ok(int64_t M, int64_t N, int64_t K, bool ln);
 bool mq_gemm_small_grouped_ok(int64_t M, int64_t N, int64_t K);
 extern int mq_gemm_small_group_rows;
 extern int mq_ln_prefetch;        // rowops.hip
+extern int mq_attention_items;    // attention.hip
 int mq_gemm_small(const void* d_A, int64_t lda, const void* d_W, int64_t ldw, const float* d_bias, const void* d_residual, void* d_out,
                   int64_t ldc, int64_t M, int64_t N, int64_t K, int flags, hipStream_t s);
 
@@ -585,6 +586,7 @@ extern "C" int mq_tune(const char* key, int value) {
     else if (k == "small_m") mq_gemm_small_max_rows = value;
     else if (k == "small_m_grouped") mq_gemm_small_group_rows = value;
     else if (k == "ln_prefetch") mq_ln_prefetch = value;
+    else if (k == "attn_items") mq_attention_items = value;
     else { mq_set_error("mq_tune: unknown key %s", key); return MQ_ERR_INVALID; }
     return MQ_OK;
 }
