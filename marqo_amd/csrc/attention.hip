@@ -286,8 +286,8 @@ __global__ __launch_bounds__(NW * 64) MQ_ATTN_OCC void attention_kernel(
     }
 }
 
-// ---- short sequences, several (sequence, head) items per workgroup (round 3) -----------------------------------------------------------
-// A launch over 50-token sequences (ViT-B/32: 3072 items per 256 images) is a latency chain per workgroup — K / V DMA, one key tile of
+// ---- short sequences, several (sequence, head) items per workgroup (round 3; OPT-IN experiment, measured slower: see mq_attention_items) ----
+// The idea: a launch over 50-token sequences (ViT-B/32: 3072 items per 256 images) is a latency chain per workgroup — K / V DMA, one key tile of
 // QK^T, softmax, PV, store — of which the DMA latency is the longest link, and the grid is 2.4 rounds of such chains.  Here one workgroup
 // takes ITEMS consecutive items: the K / V images and Q fragments of ALL its items are requested up front (ITEMS x 16 KB of LDS), the
 // wait in front of item i is a counted one (only item i's loads), so item i + 1's latency hides behind item i's math, and the launch is
@@ -464,7 +464,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MQ_ATTN_WAV
 
 }  // namespace
 
-int mq_attention_items = getenv("MQ_ATTN_ITEMS") ? atoi(getenv("MQ_ATTN_ITEMS")) : 2;   // mq_tune("attn_items", 1 = one item per workgroup / 2 / 3)
+// mq_tune("attn_items", 1 = one item per workgroup / 2 / 3) / MQ_ATTN_ITEMS.  Default 1: measured SLOWER (ViT-B/32: attention 0.228 -> 0.247 /
+// 0.259 ms per step with 2 / 3 items, profiles/r03ad_attn_items_ab.txt) — the 50-token launch is not a latency chain per workgroup after all
+// but already moves its 79 MB at 5.3 TB/s; fewer, longer workgroups only lose balance.  Kept as a knob with its bit-identity test.
+int mq_attention_items = getenv("MQ_ATTN_ITEMS") ? atoi(getenv("MQ_ATTN_ITEMS")) : 1;
 int mq_attention_waves = 0;  // mq_tune("attn_waves", 0 = auto / 4 / 8 / 5 = five waves for 65..80-token sequences, else auto): A/B knob
 
 static int attention_impl(const void* d_qkv, void* d_out, const int32_t* d_cu_seqlens, int64_t nseq,

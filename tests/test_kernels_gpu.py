@@ -217,7 +217,8 @@ def test_attention_with_relative_position_bias(lib, lens, heads):
 
 @pytest.mark.parametrize("case", ["vit50", "ragged", "ragged_causal", "odd_items", "fp8"])
 def test_attention_several_items_per_workgroup(lib, case):
-    """Sequences of <= 64 tokens with 64-wide heads in launches of >= 1024 (sequence, head) items run attention_short_kernel: 2 (or 3) items
+    """(opt-in experiment, off by default: measured slower.)  Sequences of <= 64 tokens with 64-wide heads in launches of >= 1024 (sequence, head)
+    items can run attention_short_kernel (mq_tune("attn_items", 2 | 3)): 2 (or 3) items
     per workgroup, all their K / V images requested up front, counted waits in front of each item.  Same arithmetic in the same order as the
     one-item kernel: bit-identical for fixed and ragged lengths (1 .. 64 tokens), with and without the causal mask, with an odd item count
     (the last workgroup repeats an item and stores nothing for it) and with the e4m3 output of the fp8 path (codes and the recorded maximum)."""
@@ -257,4 +258,4 @@ def test_attention_several_items_per_workgroup(lib, case):
             assert torch.equal(out, one), (case, items)
             assert torch.equal(a, a1), (case, items)
     finally:
-        L.check(lib.mq_tune(b"attn_items", 2))
+        L.check(lib.mq_tune(b"attn_items", 1))
