@@ -61,10 +61,12 @@ WORKLOADS = {
     "add_documents_stream": dict(kind="stream", arch="ViT-B-32", desc="BASELINE configs[3] as a stream: mixed {text, 224x224 PIL image} documents in 128-document requests; every "
                                  "rank owns whole requests (request i -> rank i % N, nothing is sharded inside a request), runs them through the single-GPU "
                                  "BulkVectoriser path (text tower overlapped with image staging) and ONE gather onto rank 0 closes the stream; ViT-B/32", batch=128),
+    "stub": dict(kind="stub", arch="-", desc="launcher self-test: no GPU work, one gloo all_gather per step (tests/test_bench_launcher.py)", batch=4),
     "add_documents_mixed": dict(kind="ingest", arch="ViT-B-32", desc="add_documents bulk ingest in miniature (BASELINE configs[3]): documents {text, 224x224 image} in "
                                 "128-document requests through BulkVectoriser (host PIL images + strings -> vectorise -> gather in order), ViT-B/32", batch=128),
 }
-ALSO_DEFAULT = ("clip_text_b32", "bert_base_77", "vit_l14_mixed")
+# the default line's `also` rows: the text half of the metric, BASELINE configs[2], configs[4] (fp8 policy + on-GPU chunker) and configs[3] (ingest stream)
+ALSO_DEFAULT = ("clip_text_b32", "bert_base_77", "vit_l14_mixed", "vit_l14_chunked_fp8", "add_documents_stream")
 
 
 def parse_args():
@@ -79,7 +81,63 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the headline baseline sample")
     ap.add_argument("--no-extras", action="store_true", help="skip e2e_vectorise and the `also` workloads (profiling runs)")
+    ap.add_argument("--master-port", type=int, default=0, help="rendezvous port when bench.py spawns its own ranks (0 = pick a free one)")
     return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` outside torch.distributed.run: re-exec this command under it (one rank per GPU, 127.0.0.1 rendezvous) and
+    pass rank 0's JSON line through.  The driver's own form (`python -m torch.distributed.run ... bench.py --gpus N`) sets WORLD_SIZE and
+    never gets here."""
+    import socket
+    import subprocess
+    port = args.master_port
+    if not port:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    argv = [a for a in sys.argv[1:]]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *argv]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC: RCCL across processes needs it on this host driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.call(cmd, env=env)
+
+
+def run_stub(args, rank, world):
+    """launcher self-test (no GPU): every rank contributes [batch, 8] rows, gloo all_gather, rank 0 prints the contract line"""
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    batch = args.batch or WORKLOADS["stub"]["batch"]
+    rows = torch.full((batch, 8), float(rank))
+
+    def step():
+        if world == 1:
+            return rows
+        outs = [torch.empty_like(rows) for _ in range(world)]
+        dist.all_gather(outs, rows)
+        return torch.cat(outs)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+    elapsed, out = timed(step, args.steps, args.warmup, fence)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert out.shape[0] == batch * world and sorted(set(out[:, 0].tolist())) == [float(r) for r in range(world)]
+    if rank == 0:
+        print(json.dumps({"metric": "embeddings/sec", "value": round(batch * world * args.steps / elapsed, 1), "unit": "embeddings/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "synthetic",
+                          "config": {"workload": WORKLOADS["stub"]["desc"], "global_batch": batch * world, "parallelism": f"dp{world}"}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 # ---- CPU baselines (oracle/ is the checker; it is only ever timed here, never on the product path) ---------------------------------
@@ -103,7 +161,7 @@ def _best_threads(run16, target_seconds):
     return best_threads, best_dt, cores, max(target_seconds - (time.perf_counter() - t_start), best_dt)
 
 
-def cpu_baseline_run(run_items, n_total, target_seconds):
+def cpu_baseline_run(run_items, n_total, target_seconds, min_items=16):
     """run_items(lo, hi) -> fp32 embeddings of items [lo, hi) through the reference-equivalent CPU path (fp32 PyTorch eager, the
     reference's 16-item batch loop).  The thread count is the best of a short ladder (all host threads is often NOT the fastest on
     a 2-socket SMT box).  -> (emb/s, n, embeddings, threads used, host cores)."""
@@ -111,7 +169,7 @@ def cpu_baseline_run(run_items, n_total, target_seconds):
         outs = [run_items(i, min(i + 16, hi)) for i in range(lo, hi, 16)]  # MARQO_MAX_VECTORISE_BATCH_SIZE default (api/configs.py:38)
         return torch.cat(outs, dim=0)
     threads, dt16, cores, budget = _best_threads(lambda: run(0, min(16, n_total)), target_seconds)
-    n = int(min(n_total, max(16, (budget / max(dt16, 1e-3)) * 16) // 16 * 16))
+    n = int(min(n_total, max(min_items, (budget / max(dt16, 1e-3)) * 16) // 16 * 16))
     t0 = time.perf_counter()
     emb = run(0, n)
     dt = time.perf_counter() - t0
@@ -264,8 +322,9 @@ class Workload:
                     out.extend(OP.clip_transform(p_, a.image_size) for p_ in patches)
                 off = lo - (lo // 10) * 10
                 return torch.from_numpy(np.stack(out[off:off + (hi - lo)]))
+            # (>= 64 crops whatever the time budget: the fp8 policy's error is the number this workload exists to show)
             rate, n, emb, th, cores = cpu_baseline_run(lambda lo, hi: O.vit_forward(self.sd, cfg, crops_of(lo, hi)),
-                                                       n_src * 10, target_seconds)
+                                                       n_src * 10, target_seconds, min_items=64)
             what = f"crops of the step's {n_src} source images (PIL-exact 240x240 resize + 3x3 grid + CLIP transform on the host, then the fp32 tower)"
         elif self.kind == "clip_text" and self.tarch.causal:
             t = self.tarch
@@ -587,15 +646,26 @@ def run_stream(args, dev, rank, world, dist, lib, L):
                    "weights": "random-init (seed 0) ViT-B-32", "gflop_per_embedding": round(gf, 3)},
         "e2e_tflops": round(value * gf / 1e3, 1), "roofline": roofline,
     }
+    busy = sum(f["ms_per_step"] for f in roofline.get("per_family", {}).values())
+    result["gpu_busy_ms_per_step"] = round(busy, 4)               # sum of the kernel families' HIP-event time per request
+    result["gpu_idle_share"] = round(max(0.0, 1.0 - busy / (elapsed / args.steps * 1e3)), 4)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = mixed_request_cpu_baseline(varch, tarch, pool[0][1], docs, args.cpu_seconds)
+        # the CPU path runs the SAME request (its images, its texts through the loaded model's tokeniser), so the error below compares like with like
+        model, _ = s2.load_multimodal_model_and_get_preprocessors(name, s2.get_model_properties_from_registry(name), dev)
+        ids = torch.from_numpy(np.asarray(model.tokenizer(pool[0][0])).astype(np.int64))
+        base, emb_cpu = mixed_request_cpu_baseline(varch, tarch, pool[0][1], docs, args.cpu_seconds, ids=ids, return_rows=True)
+        result["cpu_baseline"] = base
+        req0 = rows.get(0) if rows else None
+        if req0 is not None:
+            k = emb_cpu.shape[0] // 2      # CPU rows: image 0, text 0, image 1, text 1, ...
+            gpu = np.stack([req0[(0, d, m)] for d in range(k) for m in ("i", "t")])
+            result["cos_err_vs_cpu"] = _cos_err(torch.from_numpy(gpu).float(), emb_cpu)
     elif rank == 0:
         result["cpu_baseline"] = None
-    if rank == 0:
-        print(json.dumps(result), flush=True)
+    return result if rank == 0 else None
 
 
-def mixed_request_cpu_baseline(varch, tarch, imgs, docs, cpu_seconds):
+def mixed_request_cpu_baseline(varch, tarch, imgs, docs, cpu_seconds, ids=None, return_rows=False):
     """reference-equivalent CPU path on a bounded sample of one {text, image} request: fp32 towers, 16-item batches (tokeniser time not included)"""
     from oracle import towers as O
     from marqo_amd.engine import synthetic
@@ -603,11 +673,12 @@ def mixed_request_cpu_baseline(varch, tarch, imgs, docs, cpu_seconds):
     vcfg = O.VitConfig(varch.image_size, varch.patch_size, varch.width, varch.layers, varch.heads, varch.mlp_dim, varch.out_dim, varch.quick_gelu)
     tcfg = O.ClipTextConfig(tarch.vocab, tarch.ctx, tarch.width, tarch.layers, tarch.heads, tarch.mlp_dim, tarch.out_dim, tarch.quick_gelu)
     px = torch.from_numpy(np.stack([np.asarray(im) for im in imgs]))
-    gt = torch.Generator().manual_seed(3)
-    ids = torch.zeros(docs, 77, dtype=torch.int64)
-    for i in range(docs):
-        li = int(torch.randint(5, 62, (1,), generator=gt))
-        ids[i, 0], ids[i, 1:1 + li], ids[i, 1 + li] = 49406, torch.randint(1, 49406, (li,), generator=gt), 49407
+    if ids is None:
+        gt = torch.Generator().manual_seed(3)
+        ids = torch.zeros(docs, 77, dtype=torch.int64)
+        for i in range(docs):
+            li = int(torch.randint(5, 62, (1,), generator=gt))
+            ids[i, 0], ids[i, 1:1 + li], ids[i, 1 + li] = 49406, torch.randint(1, 49406, (li,), generator=gt), 49407
 
     def run_items(lo, hi):      # item 2i = image i, item 2i + 1 = text i: a bounded sample keeps the 50 / 50 mix
         i0, i1 = lo // 2, hi // 2
@@ -615,16 +686,21 @@ def mixed_request_cpu_baseline(varch, tarch, imgs, docs, cpu_seconds):
         tx = O.clip_text_forward(sd, tcfg, ids[i0:i1])
         return torch.stack([im, tx], dim=1).reshape(-1, im.shape[1])
     rate, n, emb, th, cores = cpu_baseline_run(run_items, 2 * docs, cpu_seconds)
-    return _baseline_dict(rate, n, th, cores, f"items ({n // 2} images + {n // 2} texts of 5..61 tokens) of one request")
+    base = _baseline_dict(rate, n, th, cores, f"items ({n // 2} images + {n // 2} texts of 5..61 tokens) of one request")
+    return (base, emb) if return_rows else base
 
 
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
+    if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+    if args.workload == "stub":
+        return run_stub(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
@@ -640,7 +716,9 @@ def main():
     lib = L.load()
 
     if WORKLOADS[args.workload]["kind"] == "stream":
-        run_stream(args, dev, rank, world, dist, lib, L)
+        result = run_stream(args, dev, rank, world, dist, lib, L)
+        if rank == 0:
+            print(json.dumps(result), flush=True)
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
@@ -724,13 +802,34 @@ def main():
         torch.cuda.empty_cache()
         for name in ALSO_DEFAULT:
             try:
-                x = Workload(name, args.precision, 0, dev, 1234)
+                if WORKLOADS[name]["kind"] == "stream":      # BASELINE configs[3]: end-to-end by definition (host PIL + strings in, host rows out)
+                    sa = argparse.Namespace(**{**vars(args), "steps": 10, "warmup": 3, "batch": 0, "cpu_seconds": 8.0, "workload": name})
+                    r = run_stream(sa, dev, 0, 1, None, lib, L)
+                    also.append({"workload": r["config"]["workload"], "value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "steps": 10, "warmup": 3,
+                                 "gflop_per_embedding": r["config"]["gflop_per_embedding"], "e2e_tflops": r["e2e_tflops"], "gemm_tflops": r["roofline"]["achieved"],
+                                 "gemm_frac": r["roofline"]["frac"], "roofline": r["roofline"], "gpu_busy_ms_per_step": r["gpu_busy_ms_per_step"],
+                                 "gpu_idle_share": r["gpu_idle_share"], "cpu_baseline": r.get("cpu_baseline"), "cos_err_vs_cpu": r.get("cos_err_vs_cpu")})
+                    from marqo_amd.s2_inference import s2_inference as _s2
+                    _s2.clear_loaded_models()
+                    torch.cuda.empty_cache()
+                    continue
+                prec = "fp8" if name == "vit_l14_chunked_fp8" else args.precision     # configs[4] IS the fp8 configuration
+                x = Workload(name, prec, 0, dev, 1234)
                 el, o = timed(x.run, 10, 3, torch.cuda.synchronize)
                 v = x.batch * 10 / el
-                rf = gemm_roofline(lib, L, x.run, 5, args.precision, name)
+                rf = gemm_roofline(lib, L, x.run, 5, prec, name)
                 row = {"workload": WORKLOADS[name]["desc"], "value": round(v, 1), "unit": "embeddings/s", "ms_per_step": round(el / 10 * 1e3, 4),
-                       "steps": 10, "warmup": 3, "gflop_per_embedding": round(x.gflop_per_emb, 3),
+                       "steps": 10, "warmup": 3, "dtype": prec, "gflop_per_embedding": round(x.gflop_per_emb, 3),
                        "e2e_tflops": round(v * x.gflop_per_emb / 1e3, 1), "gemm_tflops": rf["achieved"], "gemm_frac": rf["frac"]}
+                if x.kind == "chunked":
+                    row["roofline"] = rf
+                    row["fp8_policy"] = x.fp8_policy
+                    twin = Workload(name, "bf16", 0, dev, 1234)        # the same step on the bf16 tower: what the policy buys, and at what error
+                    el16, o16 = timed(twin.run, 5, 2, torch.cuda.synchronize)
+                    v16 = twin.batch * 5 / el16
+                    row["bf16_twin"] = {"value": round(v16, 1), "unit": "embeddings/s", "fp8_over_bf16": round(v / v16, 3),
+                                        "cos_err_fp8_vs_bf16": _cos_err(o.float().cpu(), o16.float().cpu())}
+                    del twin
                 if not args.no_cpu_baseline:
                     base, cos = x.cpu_baseline(o, 8.0)
                     row["cpu_baseline"], row["cos_err_vs_cpu"] = base, cos

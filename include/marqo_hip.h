@@ -45,7 +45,7 @@ extern "C" {
 #define MQ_ERR_HIP (-2)       /* a HIP runtime call or launch failed */
 #define MQ_ERR_WORKSPACE (-3) /* caller's workspace too small */
 
-#define MQ_ABI_VERSION 6
+#define MQ_ABI_VERSION 7
 
 /* ---- activation / mask / pooling selectors ---------------------------------------- */
 #define MQ_ACT_NONE 0
@@ -421,17 +421,16 @@ int mq_ln_gemm_small_bf16(const void* d_x, int64_t ldx, int x_bf16, const float*
                           int64_t ldw, const float* d_bias, void* d_out, int64_t ldc, int64_t M, int64_t N, int64_t K, int flags,
                           float* d_ln_out, void* stream);
 
-/* mq_gemm_bf16 with a folded LayerNorm on one side (pre-LN blocks; csrc/gemm_epilogue.h):
- *   flags = BIAS|RESIDUAL|OUT_F32|MQ_EPI_LN_STATS  — producer (the residual GEMM): also writes bf16(out) to d_out2 [M, ldc] and
- *           per row the partial (sum, sum of squares) of every 64-column slot to d_stats fp32 [M][ceil(N/64)][2];
- *   flags = BIAS[|GELU|QUICKGELU]|MQ_EPI_LN_APPLY — consumer: d_A is that bf16 copy (un-normalised rows, K = normalised
- *           width), d_W / d_bias / d_colsum are the pre-folded (*_wf, *_bf, *_sf) tensors, d_stats the producer's partials
- *           [M][ceil(K/64)][2]; out bf16 = act( rstd*(A@W^T - mean*colsum) + bias ). */
-#define MQ_EPI_LN_STATS 64
+/* mq_gemm_bf16 with the LayerNorm of a pre-LN block folded in (csrc/gemm_epilogue.h; the towers' QKV / fc1 GEMMs on the bf16 residual stream):
+ *   out bf16 [M, N] = act( LN(A) @ W0^T + b0 ),  LN over the K columns of A with scale gamma / shift beta, computed as
+ *   act( rstd * (A @ d_W^T - mean * d_colsum) + d_bias )  with  d_W = bf16(gamma * W0) [N, K],  d_bias = b0 + W0 @ beta,  d_colsum[n] = sum_k d_W[n, k].
+ * d_A: the UN-normalised bf16 rows [M, lda]; K = the normalised width (K % 64 == 0); the row statistics are accumulated inside the kernel from the
+ * A tiles it stages anyway — there is no LayerNorm launch and no normalised copy.  flags: MQ_EPI_BIAS [| MQ_EPI_GELU | MQ_EPI_QUICKGELU].
+ * Replaces what open_clip's ResidualAttentionBlock computes as ln_1 -> attn.in_proj / ln_2 -> mlp.c_fc
+ * (called from /root/reference/src/marqo/core/inference/embedding_models/open_clip_model.py:249-266). */
 #define MQ_EPI_LN_APPLY 128
-int mq_gemm_bf16_ln(const void* d_A, int64_t lda, const void* d_W, int64_t ldw, const float* d_bias,
-                    const float* d_residual, void* d_out, int64_t ldc, int64_t M, int64_t N, int64_t K, int flags,
-                    float* d_stats, void* d_out2, const float* d_colsum, float eps, void* stream);
+int mq_gemm_bf16_ln(const void* d_A, int64_t lda, const void* d_W, int64_t ldw, const float* d_bias, const float* d_colsum, void* d_out,
+                    int64_t ldc, int64_t M, int64_t N, int64_t K, int flags, float eps, void* stream);
 
 /* y = LayerNorm(x) * g + b over the last dim.  x fp32 [rows, W] gathered through an optional
  * row index (d_row_idx int32 [rows], NULL = identity).  Writes bf16 (d_out_bf16) and/or fp32

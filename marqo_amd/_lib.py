@@ -28,15 +28,15 @@ STAGE_SRC = CSRC_DIR / "py_stage.cpp"
 STAGE_PATH = LIB_DIR / "_mq_stage.so"                # CPython extension: a batch of Pillow images -> the pinned staging buffer in one call
 
 MQ_OK = 0
-NO_SCRATCH_UNITS = ("gemm_bf16", "gemm_pp", "gemm_big", "gemm_k32", "gemm_fp8", "gemm_small", "attention")  # build() refuses register spills in these
-ABI_VERSION = 6
+NO_SCRATCH_UNITS = ("rowops", "gemm_bf16", "gemm_pl", "gemm_pp", "gemm_big", "gemm_k32", "gemm_fp8", "gemm_small", "attention")  # build() refuses register spills in these
+ABI_VERSION = 7
 MQ_PREC_BF16, MQ_PREC_FP8 = 0, 1
 MQ_ACT_GELU, MQ_ACT_QUICKGELU = 1, 2
 MQ_MASK_NONE, MQ_MASK_CAUSAL = 0, 1
 MQ_POOL_MEAN, MQ_POOL_CLS = 0, 1
 MQ_VIT_POOL_CLS, MQ_VIT_POOL_MAP, MQ_VIT_POOL_AVG = 0, 1, 2
 MQ_EPI_BIAS, MQ_EPI_GELU, MQ_EPI_QUICKGELU, MQ_EPI_RESIDUAL, MQ_EPI_OUT_F32, MQ_EPI_OUT_FP8 = 1, 2, 4, 8, 16, 32
-MQ_EPI_LN_STATS, MQ_EPI_LN_APPLY = 64, 128
+MQ_EPI_LN_APPLY = 128
 MQ_COMBINE_RAW, MQ_COMBINE_NORMALIZE, MQ_COMBINE_NORMALIZE_IF_NONZERO = 0, 1, 2
 MQ_IMG_RGB, MQ_IMG_NEAREST, MQ_IMG_RGBA = 0, 1, 2
 MQ_PROF_FAMILIES = 6
@@ -145,8 +145,7 @@ _SIGNATURES = {
     "mq_gemm_small_bf16": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, _P]),
     "mq_ln_gemm_small_bf16": (C.c_int, [_P, C.c_int64, C.c_int, _P, _P, C.c_float, _P, C.c_int64, _P, _P, C.c_int64, C.c_int64, C.c_int64,
                                         C.c_int64, C.c_int, _P, _P]),
-    "mq_gemm_bf16_ln": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int,
-                                  _P, _P, _P, C.c_float, _P]),
+    "mq_gemm_bf16_ln": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_float, _P]),
     "mq_gemm_fp8": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, C.c_int, _P, _P, _P, _P, C.c_int64, _P, _P, C.c_int64, C.c_int64,
                               C.c_int64, C.c_int, _P]),
     "mq_quantize_weights_fp8": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, C.c_int64, C.c_int64, _P]),

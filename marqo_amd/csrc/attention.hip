@@ -49,7 +49,7 @@ template <int MASK, bool OUT_FP8, int HD, int HS, int NW, bool BIAS = false>
 __global__ __launch_bounds__(NW * 64) MQ_ATTN_OCC void attention_kernel(
     const bf16_t* __restrict__ qkv, void* __restrict__ out_v, const int32_t* __restrict__ cu,
     int fixed_len, int W, int heads, int kpad, float scale_log2e, const float* __restrict__ out_scale, float* amax_out,
-    const float* __restrict__ rel_bias = nullptr, int rel_span = 0, int band = 0) {
+    const float* __restrict__ rel_bias = nullptr, int rel_span = 0, int band = 0, MqPrefetch pf = MqPrefetch{}) {
     bf16_t* out = (bf16_t*)out_v;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     static_assert(HS <= HD && HS % 16 == 0 && (HD == 64 || HD == 128), "head stride: multiple of 16, at most the LDS row");
@@ -284,195 +284,21 @@ __global__ __launch_bounds__(NW * 64) MQ_ATTN_OCC void attention_kernel(
         amax_local = wave_max(amax_local);
         if (lane == 0) atomicMax((int*)amax_out, __float_as_int(amax_local));
     }
+    // weight prefetch for the GEMMs behind this launch (common.h, MqPrefetch), by every thread that reaches the end of the kernel: behind the
+    // wave's last load and store (loads return in order: an HBM miss must not sit in front of a Q fragment), where the registers are free again;
+    // the wave's exit waits for it (s_endpgm drains the counters), nothing else does
+    mq_prefetch_retire(mq_prefetch_issue(pf));
 }
 
-// ---- short sequences, several (sequence, head) items per workgroup (round 3; OPT-IN experiment, measured slower: see mq_attention_items) ----
-// The idea: a launch over 50-token sequences (ViT-B/32: 3072 items per 256 images) is a latency chain per workgroup — K / V DMA, one key tile of
-// QK^T, softmax, PV, store — of which the DMA latency is the longest link, and the grid is 2.4 rounds of such chains.  Here one workgroup
-// takes ITEMS consecutive items: the K / V images and Q fragments of ALL its items are requested up front (ITEMS x 16 KB of LDS), the
-// wait in front of item i is a counted one (only item i's loads), so item i + 1's latency hides behind item i's math, and the launch is
-// ITEMS times fewer workgroups.  Sequences of at most 64 tokens (one key tile, one query block per wave), 64-wide heads, 4 waves.
-// Same arithmetic in the same order as attention_kernel on such a sequence: bit-identical (tests/test_kernels_gpu.py).
-template <int MASK, bool OUT_FP8, int ITEMS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MQ_ATTN_WAVES_PER_EU > 0 ? MQ_ATTN_WAVES_PER_EU : 4, 8))) void attention_short_kernel(
-    const bf16_t* __restrict__ qkv, void* __restrict__ out_v, const int32_t* __restrict__ cu, int fixed_len, int W, int heads, int n_items,
-    float scale_log2e, const float* __restrict__ out_scale, float* amax_out, int band) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int RB = 128, NC = 8, NKK = 2, NDT = 4, IMG = 64 * RB;   // one K (or V) image: 64 keys x 128 B
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int l15 = lane & 15, g = lane >> 4;
-    const unsigned vblk = xcd_banded_block(blockIdx.x, gridDim.x, band);
-    const int ld = 3 * W;
-    int row0[ITEMS], len[ITEMS], hh[ITEMS];
-    bool live[ITEMS];
-    bf16x8 qf[ITEMS][NKK];
-#pragma unroll
-    for (int it = 0; it < ITEMS; ++it) {
-        int item = (int)vblk * ITEMS + it;
-        live[it] = item < n_items;
-        item = live[it] ? item : n_items - 1;            // a ragged last workgroup repeats the last item (same load counts, nothing stored)
-        const int seq = item / heads;
-        hh[it] = item - seq * heads;
-        if (fixed_len > 0) { row0[it] = seq * fixed_len; len[it] = fixed_len; }
-        else { row0[it] = cu[seq]; len[it] = cu[seq + 1] - row0[it]; }
-        if (len[it] <= 0) { len[it] = 1; live[it] = false; }   // (empty sequence: keep the loads legal, store nothing)
-        const bf16_t* qb = qkv + (int64_t)row0[it] * ld + hh[it] * 64;
-        char* sK = smem + it * 2 * IMG;
-        // K then V: 16 one-KiB pieces, 4 per wave; lane -> (row = 8 * piece + lane / 8, physical chunk = lane % 8); rows past the
-        // sequence re-read its last row (their scores are masked)
-        const int srow = lane >> 3, pchunk = lane & 7;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int p = wave + 4 * j;
-            const bool is_v = p >= 8;
-            const int piece = p & 7;
-            const int row = piece * 8 + srow;
-            const int key = row < len[it] ? row : len[it] - 1;
-            const int lc = pchunk ^ (row & (NC - 1));
-            const bf16_t* src = qb + (is_v ? 2 * W : W) + (int64_t)key * ld + (lc << 3);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(sK + (is_v ? IMG : 0) + piece * 1024), 16, 0, 0);
-        }
-        const int q0 = wave * 16 + l15;
-        const int qr = q0 < len[it] ? q0 : len[it] - 1;
-#pragma unroll
-        for (int kk = 0; kk < NKK; ++kk) qf[it][kk] = *(const bf16x8*)(qb + (int64_t)qr * ld + 8 * g + 32 * kk);
-        asm volatile("" ::: "memory");                  // item i's loads are ISSUED before item i + 1's: the counted waits below rely on it
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    const int vkey = 4 * g + (l15 >> 2);
-    const int vcol = (l15 & 3) >> 1, vhalf = (l15 & 1) << 3;
-    float amax_local = 0.f;
-#pragma unroll
-    for (int it = 0; it < ITEMS; ++it) {
-        // item `it` needs its own 4 DMA pieces + 2 Q loads per wave; the (ITEMS - 1 - it) x 6 loads issued after them may still be in flight
-        // (the stores of earlier items were issued later still: from the second item on, everything is waited for)
-        // (the builtin, not inline asm: the compiler's own wait-count bookkeeping then knows item `it`'s Q fragments have landed and does not
-        // add a vmcnt(0) of its own in front of their first use.  simm16 = vmcnt | expcnt 7 << 4 | lgkmcnt 15 << 8: only vmcnt is waited for)
-        if (it == 0 && ITEMS == 2) __builtin_amdgcn_s_waitcnt(0xF70 | 6);
-        else if (it == 0 && ITEMS == 3) __builtin_amdgcn_s_waitcnt(0xF70 | 12);
-        else __builtin_amdgcn_s_waitcnt(0xF70);
-        __builtin_amdgcn_s_barrier();                   // (not __syncthreads(): its fence would drain the loads of the items behind this one)
-        asm volatile("" ::: "memory");
-        const char* sK = smem + it * 2 * IMG;
-        const unsigned v_base = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)smem) + (unsigned)(it * 2 * IMG + IMG);   // LDS address of this item's V image
-        const int L_ = len[it];
-        const int nqb = (L_ + 15) >> 4;
-        if (wave >= nqb || !live[it]) continue;          // (wave-uniform; the barriers above are reached by every wave)
-        const int q = wave * 16 + l15;
-        f32x4 sc[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            sc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const int key = t * 16 + l15;
-#pragma unroll
-            for (int kk = 0; kk < NKK; ++kk) {
-                const bf16x8 kf = *(const bf16x8*)(sK + key * RB + (((g + 4 * kk) ^ (key & (NC - 1))) << 4));
-                sc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[it][kk], sc[t], 0, 0, 0);
-            }
-        }
-        bool need_mask = (L_ & 63) != 0;
-        if (MASK == MQ_MASK_CAUSAL) need_mask = need_mask || (63 > wave * 16);
-        if (need_mask) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = t * 16 + g * 4 + r;
-                    bool valid = key < L_;
-                    if (MASK == MQ_MASK_CAUSAL) valid = valid && (key <= q);
-                    sc[t][r] = valid ? sc[t][r] : -INFINITY;
-                }
-        }
-        float mx = fmaxf(fmaxf(fmaxf(sc[0][0], sc[0][1]), fmaxf(sc[0][2], sc[0][3])), fmaxf(fmaxf(sc[1][0], sc[1][1]), fmaxf(sc[1][2], sc[1][3])));
-        mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(sc[2][0], sc[2][1]), fmaxf(sc[2][2], sc[2][3])), fmaxf(fmaxf(sc[3][0], sc[3][1]), fmaxf(sc[3][2], sc[3][3]))));
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(-1e30f, mx);
-        const float neg_mc = -m_new * scale_log2e;
-        float psum = 0.f;
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                sc[t][r] = __builtin_amdgcn_exp2f(fmaf(sc[t][r], scale_log2e, neg_mc));
-                psum += sc[t][r];
-            }
-        f32x4 o[NDT];
-#pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            union { uint32_t w[4]; bf16x8 v; } pf;
-            pf.w[0] = pack_bf16x2(sc[2 * u][0], sc[2 * u][1]);
-            pf.w[1] = pack_bf16x2(sc[2 * u][2], sc[2 * u][3]);
-            pf.w[2] = pack_bf16x2(sc[2 * u + 1][0], sc[2 * u + 1][1]);
-            pf.w[3] = pack_bf16x2(sc[2 * u + 1][2], sc[2 * u + 1][3]);
-#pragma unroll
-            for (int dt = 0; dt < NDT; ++dt) {
-                // (inline asm: a transposing LDS read the compiler can see would be ordered behind EVERY LDS-DMA still in flight — it cannot tell
-                // this item's image from the next item's — i.e. a vmcnt(0) right here, which is the wait this kernel exists to avoid)
-                union { s16x4 t[2]; bf16x8 v; } vf;
-                unsigned va[2];
-#pragma unroll
-                for (int tt = 0; tt < 2; ++tt) {
-                    const int key = (2 * u + tt) * 16 + vkey;
-                    va[tt] = v_base + key * RB + ((((dt << 1) | vcol) ^ (key & (NC - 1))) << 4) + vhalf;
-                }
-                asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3\n\ts_waitcnt lgkmcnt(0)"
-                             : "=&v"(vf.t[0]), "=&v"(vf.t[1]) : "v"(va[0]), "v"(va[1]) : "memory");
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf.v, o[dt], 0, 0, 0);
-            }
-        }
-        float l_tot = psum + __shfl_xor(psum, 16, 64);
-        l_tot += __shfl_xor(l_tot, 32, 64);
-        const float inv = 1.0f / l_tot;
-        if (q < L_) {
-            if (OUT_FP8) {
-                const float qs = 1.0f / out_scale[0];
-                uint8_t* orow8 = (uint8_t*)out_v + (int64_t)(row0[it] + q) * W + hh[it] * 64 + 4 * g;
-#pragma unroll
-                for (int dt = 0; dt < NDT; ++dt) {
-                    float v[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[e] = o[dt][e] * inv;
-                        amax_local = fmaxf(amax_local, fabsf(v[e]));
-                        v[e] = fminf(fmaxf(v[e] * qs, -448.f), 448.f);
-                    }
-                    int w = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
-                    w = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], w, true);
-                    *(int*)(orow8 + dt * 16) = w;
-                }
-            } else {
-                bf16_t* orow = (bf16_t*)out_v + (int64_t)(row0[it] + q) * W + hh[it] * 64 + 4 * g;
-#pragma unroll
-                for (int dt = 0; dt < NDT; ++dt) {
-                    uint2 pk;
-                    pk.x = pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv);
-                    pk.y = pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv);
-                    *(uint2*)(orow + dt * 16) = pk;
-                }
-            }
-        }
-    }
-    if (OUT_FP8 && amax_out) {
-        amax_local = wave_max(amax_local);
-        if (lane == 0) atomicMax((int*)amax_out, __float_as_int(amax_local));
-    }
-}
+// (round 3's attention_short_kernel — several 50-token items per workgroup — measured slower, profiles/r03ad_attn_items_ab.txt, and left the library in round 4)
 
 }  // namespace
 
-// mq_tune("attn_items", 1 = one item per workgroup / 2 / 3) / MQ_ATTN_ITEMS.  Default 1: measured SLOWER (ViT-B/32: attention 0.228 -> 0.247 /
-// 0.259 ms per step with 2 / 3 items, profiles/r03ad_attn_items_ab.txt) — the 50-token launch is not a latency chain per workgroup after all
-// but already moves its 79 MB at 5.3 TB/s; fewer, longer workgroups only lose balance.  Kept as a knob with its bit-identity test.
-int mq_attention_items = getenv("MQ_ATTN_ITEMS") ? atoi(getenv("MQ_ATTN_ITEMS")) : 1;
 int mq_attention_waves = 0;  // mq_tune("attn_waves", 0 = auto / 4 / 8 / 5 = five waves for 65..80-token sequences, else auto): A/B knob
 
 static int attention_impl(const void* d_qkv, void* d_out, const int32_t* d_cu_seqlens, int64_t nseq,
                           int32_t fixed_len, int32_t max_len, int32_t W, int32_t heads, int32_t mask,
-                          int32_t out_fp8, const float* d_out_scale, float* d_amax, const float* d_rel_bias, int32_t rel_span, void* stream) {
+                          int32_t out_fp8, const float* d_out_scale, float* d_amax, const float* d_rel_bias, int32_t rel_span, void* stream, const MqPrefetch& pf = MqPrefetch{}) {
     MQ_CHECK_ARG(d_qkv && d_out, "mq_attention: null pointer");
     MQ_CHECK_ARG(heads >= 1 && W % heads == 0, "mq_attention: W=%d is not a multiple of heads=%d", W, heads);
     const int hs = W / heads;             // head stride in memory = dims computed
@@ -511,7 +337,7 @@ static int attention_impl(const void* d_qkv, void* d_out, const int32_t* d_cu_se
         }
         hipLaunchKernelGGL(kern, dim3((unsigned)(nseq * heads)), dim3(nw * 64), lds, s, (const bf16_t*)d_qkv,
                            d_out, d_cu_seqlens, (int)fixed_len, (int)W, (int)heads, kpad, scale_log2e, d_out_scale, d_amax, d_rel_bias, (int)rel_span,
-                           (mq_xcd_band && nseq * heads >= 2048) ? 1 : 0);
+                           (mq_xcd_band && nseq * heads >= 2048) ? 1 : 0, pf);
         return MQ_OK;
     };
     if (d_rel_bias) {
@@ -521,27 +347,6 @@ static int attention_impl(const void* d_qkv, void* d_out, const int32_t* d_cu_se
         return MQ_OK;
     }
     MQ_CHECK_ARG(!out_fp8 || d_out_scale, "mq_attention: fp8 output needs an out_scale");
-    // sequences of <= 64 tokens with 64-wide heads (ViT-B/32's 50 tokens, short texts): two items per workgroup (attention_short_kernel)
-    if (mq_attention_items >= 2 && hs == 64 && maxl <= 64 && nw == 4 && nseq * heads >= 1024) {
-        const int64_t n_items = nseq * heads;
-        const int items = mq_attention_items >= 3 ? 3 : 2;
-        const unsigned grid = (unsigned)((n_items + items - 1) / items);
-        const size_t lds2 = (size_t)items * 2 * 64 * 128;
-        const int band2 = (mq_xcd_band && grid >= 1024) ? 1 : 0;
-#define MQ_ATTN_SHORT(M_, F_, I_)                                                                                                            \
-    hipLaunchKernelGGL((attention_short_kernel<M_, F_, I_>), dim3(grid), dim3(256), lds2, s, (const bf16_t*)d_qkv, d_out, d_cu_seqlens, (int)fixed_len, \
-                       (int)W, (int)heads, (int)n_items, scale_log2e, d_out_scale, d_amax, band2)
-        if (items == 3) {
-            if (out_fp8) { if (mask == MQ_MASK_CAUSAL) MQ_ATTN_SHORT(MQ_MASK_CAUSAL, true, 3); else MQ_ATTN_SHORT(MQ_MASK_NONE, true, 3); }
-            else { if (mask == MQ_MASK_CAUSAL) MQ_ATTN_SHORT(MQ_MASK_CAUSAL, false, 3); else MQ_ATTN_SHORT(MQ_MASK_NONE, false, 3); }
-        } else {
-            if (out_fp8) { if (mask == MQ_MASK_CAUSAL) MQ_ATTN_SHORT(MQ_MASK_CAUSAL, true, 2); else MQ_ATTN_SHORT(MQ_MASK_NONE, true, 2); }
-            else { if (mask == MQ_MASK_CAUSAL) MQ_ATTN_SHORT(MQ_MASK_CAUSAL, false, 2); else MQ_ATTN_SHORT(MQ_MASK_NONE, false, 2); }
-        }
-#undef MQ_ATTN_SHORT
-        MQ_CHECK_LAUNCH("mq_attention");
-        return MQ_OK;
-    }
     int rc;
     auto pick_nw = [&](auto hd_tag, auto hs_tag, auto nw_tag) -> int {
         constexpr int HD_ = decltype(hd_tag)::value, HS_ = decltype(hs_tag)::value, NW_ = decltype(nw_tag)::value;
@@ -569,6 +374,12 @@ extern "C" int mq_attention_ex(const void* d_qkv, void* d_out, const int32_t* d_
                                int32_t fixed_len, int32_t max_len, int32_t W, int32_t heads, int32_t mask,
                                int32_t out_fp8, const float* d_out_scale, float* d_amax, void* stream) {
     return attention_impl(d_qkv, d_out, d_cu_seqlens, nseq, fixed_len, max_len, W, heads, mask, out_fp8, d_out_scale, d_amax, nullptr, 0, stream);
+}
+
+// mq_attention + weight prefetch (common.h, MqPrefetch): the four ranges are touched once by the launch's threads (towers.hip)
+int mq_attention_pf(const void* d_qkv, void* d_out, const int32_t* d_cu_seqlens, int64_t nseq, int32_t fixed_len, int32_t max_len, int32_t W,
+                    int32_t heads, int32_t mask, const MqPrefetch& pf, hipStream_t s) {
+    return attention_impl(d_qkv, d_out, d_cu_seqlens, nseq, fixed_len, max_len, W, heads, mask, 0, nullptr, nullptr, nullptr, 0, (void*)s, pf);
 }
 
 extern "C" int mq_attention_bias(const void* d_qkv, void* d_out, const int32_t* d_cu_seqlens, int64_t nseq, int32_t fixed_len,

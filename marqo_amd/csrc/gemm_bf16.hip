@@ -33,7 +33,6 @@ bool mq_gemm_small_ok(int64_t M, int64_t N, int64_t K, bool ln);
 bool mq_gemm_small_grouped_ok(int64_t M, int64_t N, int64_t K);
 extern int mq_gemm_small_group_rows;
 extern int mq_ln_prefetch;        // rowops.hip
-extern int mq_attention_items;    // attention.hip
 int mq_gemm_small(const void* d_A, int64_t lda, const void* d_W, int64_t ldw, const float* d_bias, const void* d_residual, void* d_out,
                   int64_t ldc, int64_t M, int64_t N, int64_t K, int flags, hipStream_t s);
 
@@ -73,6 +72,14 @@ template <int FLAGS>
 int mq_launch_gemm_k32(int wgs, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* residual,
                        void* out, int64_t ldc, int M, int N, int K, int cgroup_knob, int wide_knob, hipStream_t s);
 
+// software-pipelined k-loop (gemm_pl.hip)
+bool mq_gemm_pl_fits(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw);
+int mq_gemm_pl_mode();
+void mq_gemm_pl_tune(const char* key, int value);
+template <int FLAGS>
+int mq_launch_gemm_pl(int mt, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* residual, void* out,
+                      int64_t ldc, int M, int N, int K, int cgroup_knob, int wide_knob, hipStream_t s, const GemmLn& ln);
+
 namespace {
 
 constexpr int BN = 128, BK = 64;
@@ -103,8 +110,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
     // the tile's 128 bias values ride through LDS (two 512-B slots behind the stages, alternating per tile): fetched at the top of the
     // tile, parked in LDS after the first landed stage, read by the epilogue.  Not at MT = 6, whose stages fill the CU's LDS budget.
     constexpr bool LDS_BIAS = (FLAGS & MQ_EPI_BIAS) && MT <= 5;
+    // MQ_EPI_LN_APPLY (gemm_epilogue.h): the rows' (sum x, sum x^2) are accumulated from the A tiles as they pass through LDS — thread t owns
+    // 16-byte chunk t % 8 of tile rows t / 8 + 32 i (i < MT: BM rows x 8 chunks = 256 * MT chunks) — and (mean, rstd) per tile row is left
+    // in LDS behind the bias slots for the epilogue
+    constexpr bool LN_APPLY = (FLAGS & MQ_EPI_LN_APPLY) != 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* const bias_lds = (float*)(smem + 2 * STAGE_BYTES);
+    float2* const rowstats_lds = (float2*)(smem + 2 * STAGE_BYTES + (LDS_BIAS ? 2 * BN * 4 : 0));
     int bias_slot = 0;
 
     // ---- XCD-aware, bijective (virtual) block -> tile map ----------------------------------
@@ -204,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
     //    BEFORE the epilogue's stores (vmcnt retires in issue order on gfx9: the tile's EPI_STORES stores may stay in flight) instead of
     //    draining them with vmcnt(0); only for waves whose tile was fully inside the matrix (every store instruction issued)
     //  * mq_tune("gemm_prio", 1): static s_setprio 1 for the second-dispatched workgroup of every CU (MI355X_MICROARCH.md item 4)
-    const bool counted_vmcnt = PERSIST && (wide_store & 4) && !(FLAGS & (MQ_EPI_LN_STATS | MQ_EPI_LN_APPLY));
+    const bool counted_vmcnt = PERSIST && (wide_store & 4) && !(FLAGS & MQ_EPI_LN_APPLY);
     if ((wide_store & 8) && blockIdx.x >= (gridDim.x >> 1)) __builtin_amdgcn_s_setprio(1);
     wide_store &= 1;
     bool stores_pending = false;   // the previous tile's epilogue stores are still in flight and may be skipped by the next wait
@@ -221,6 +233,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float st1[LN_APPLY ? MT : 1], st2[LN_APPLY ? MT : 1];
+#pragma unroll
+        for (int i = 0; i < (LN_APPLY ? MT : 1); ++i) st1[i] = st2[i] = 0.f;
         // ---- fragment read offsets (bytes inside a tile), fixed per lane ----------------------
         // logical chunk for k-half kk is g + 4*kk; (row & 7) == (l15 & 7) because sub-tile bases are multiples of 16.
         // Persistent form: recomputed per tile from a laundered lane id, so that these 11 registers are NOT live across the
@@ -253,6 +268,25 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
                 for (int t = 0; t < 4; ++t) wf[kk][t] = *(const bf16x8*)(sw + w_off[t] + swz);
     #pragma unroll
                 for (int t = 0; t < MT; ++t) af[kk][t] = *(const bf16x8*)(sa + a_off[t] + swz);
+            }
+            if constexpr (LN_APPLY) {
+                // (these LDS reads sit with the fragment reads, in front of the step's first LDS-DMA issue: behind one, hipcc would wait for it)
+                const bf16x2_t ones = __builtin_bit_cast(bf16x2_t, 0x3f803f80u);
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const uint4 c = *(const uint4*)(sa + (tid + 256 * i) * 16);
+                    const bf16x2_t c0 = __builtin_bit_cast(bf16x2_t, c.x), c1 = __builtin_bit_cast(bf16x2_t, c.y),
+                                   c2 = __builtin_bit_cast(bf16x2_t, c.z), c3 = __builtin_bit_cast(bf16x2_t, c.w);
+                    // v_dot2c_f32_bf16: two elements per VALU operation, fp32 accumulation
+                    st1[i] = __builtin_amdgcn_fdot2_f32_bf16(c0, ones, st1[i], false);
+                    st2[i] = __builtin_amdgcn_fdot2_f32_bf16(c0, c0, st2[i], false);
+                    st1[i] = __builtin_amdgcn_fdot2_f32_bf16(c1, ones, st1[i], false);
+                    st2[i] = __builtin_amdgcn_fdot2_f32_bf16(c1, c1, st2[i], false);
+                    st1[i] = __builtin_amdgcn_fdot2_f32_bf16(c2, ones, st1[i], false);
+                    st2[i] = __builtin_amdgcn_fdot2_f32_bf16(c2, c2, st2[i], false);
+                    st1[i] = __builtin_amdgcn_fdot2_f32_bf16(c3, ones, st1[i], false);
+                    st2[i] = __builtin_amdgcn_fdot2_f32_bf16(c3, c3, st2[i], false);
+                }
             }
             constexpr int NL = MT + 4;            // LDS-DMA pieces per wave per step
             constexpr int NM = 8 * MT;            // MFMAs per wave per step
@@ -362,8 +396,26 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
             if (sum[0] + sum[1] + sum[2] + sum[3] == 1.2345678e33f) ((float*)out)[0] = sum[0];
         }
 #else
+        if constexpr (LN_APPLY) {
+            // the 8 lanes that share a row (lane % 8 = chunk) add up their shares in a fixed order (DPP: xor 1, xor 2, half-row mirror)
+            auto dpp_add = [](float v, auto ctrl_tag) {
+                constexpr int CTRL = decltype(ctrl_tag)::value;
+                return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+            };
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                float a1 = st1[i], a2 = st2[i];
+                a1 = dpp_add(a1, std::integral_constant<int, 0xB1>{}); a2 = dpp_add(a2, std::integral_constant<int, 0xB1>{});     // quad_perm [1,0,3,2]
+                a1 = dpp_add(a1, std::integral_constant<int, 0x4E>{}); a2 = dpp_add(a2, std::integral_constant<int, 0x4E>{});     // quad_perm [2,3,0,1]
+                a1 = dpp_add(a1, std::integral_constant<int, 0x141>{}); a2 = dpp_add(a2, std::integral_constant<int, 0x141>{});   // row_half_mirror
+                const float mean = a1 * ln.inv_w;
+                const float rstd = rsqrtf(fmaxf(a2 * ln.inv_w - mean * mean, 0.f) + ln.eps);
+                if ((tid & 7) == 0) rowstats_lds[(tid >> 3) + 32 * i] = make_float2(mean, rstd);
+            }
+            __syncthreads();   // (rewritten one whole k-loop later: no second barrier needed behind the epilogue's reads)
+        }
         gemm_epilogue<FLAGS, MT>(acc, bias, residual, out, ldc, M, N, cm0 + wm * (16 * MT), cn0 + wn * 64, l15, g, wide_store != 0, &ln,
-                                 lds_bias_on ? bias_lds + bias_slot * BN + wn * 64 : nullptr);
+                                 lds_bias_on ? bias_lds + bias_slot * BN + wn * 64 : nullptr, LN_APPLY ? rowstats_lds + wm * (16 * MT) : nullptr);
 #endif
         bias_slot ^= 1;
 #ifdef MQ_GEMM_TRACE
@@ -425,7 +477,7 @@ template <int FLAGS, int MT, bool PERSIST>
 int launch_gemm_mt(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
                    const float* residual, void* out, int64_t ldc, int M, int N, int K, hipStream_t s, const GemmLn& ln) {
     constexpr int BM = 32 * MT;
-    constexpr int LDS = 2 * (BM * BK * 2 + W_TILE_BYTES) + (((FLAGS & MQ_EPI_BIAS) && MT <= 5) ? 2 * BN * 4 : 0);
+    constexpr int LDS = 2 * (BM * BK * 2 + W_TILE_BYTES) + (((FLAGS & MQ_EPI_BIAS) && MT <= 5) ? 2 * BN * 4 : 0) + ((FLAGS & MQ_EPI_LN_APPLY) ? BM * 8 : 0);
     static std::atomic<uint64_t> attr_done{0};
     if (hipError_t e = mq_ensure_dyn_lds((const void*)gemm_nt_kernel<FLAGS, MT, PERSIST>, LDS, attr_done); e != hipSuccess) {
         mq_set_error("mq_gemm_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -455,8 +507,16 @@ int launch_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const fl
                 const float* residual, void* out, int64_t ldc, int M, int N, int K, hipStream_t s, const GemmLn& ln = GemmLn{}) {
     const int force_mt = g_tune.mt;
     const int persist = g_tune.persist;
-    const int mt = force_mt ? force_mt : choose_mt(M, N);
-    if constexpr ((FLAGS & (MQ_EPI_LN_STATS | MQ_EPI_LN_APPLY)) == 0) {
+    int mt = force_mt ? force_mt : choose_mt(M, N);
+    if ((FLAGS & MQ_EPI_LN_APPLY) && mt == 6) mt = 5;   // the 192-row tile's stages fill the LDS of two workgroups per CU: no room for the row statistics
+    if constexpr ((FLAGS & MQ_EPI_LN_APPLY) != 0) {
+        // the folded-LayerNorm GEMMs run on the software-pipelined loop (persistent at every tile height; the round 1-3 loop below spills there)
+        if (mq_gemm_pl_fits(M, N, K, lda, ldw))
+            return mq_launch_gemm_pl<FLAGS>(mt, A, lda, W, ldw, bias, residual, out, ldc, M, N, K, g_tune.cgroup, g_tune.wide, s, ln);
+    }
+    if constexpr ((FLAGS & MQ_EPI_LN_APPLY) == 0) {
+        if (!g_tune.big && !g_tune.k32 && mq_gemm_pl_mode() && mq_gemm_pl_fits(M, N, K, lda, ldw))
+            return mq_launch_gemm_pl<FLAGS>(mt, A, lda, W, ldw, bias, residual, out, ldc, M, N, K, g_tune.cgroup, g_tune.wide, s, ln);
         if (g_tune.big) return mq_launch_gemm_big<FLAGS>(g_tune.big, A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s);
         if (g_tune.k32) return mq_launch_gemm_k32<FLAGS>(g_tune.k32, A, lda, W, ldw, bias, residual, out, ldc, M, N, K, g_tune.cgroup, g_tune.wide, s);
         if (!force_mt && ldc % 8 == 0 && ((uintptr_t)out & 15) == 0 && lda < (1 << 22) && ldw < (1 << 22) && ldc < (1 << 22)) {
@@ -467,7 +527,7 @@ int launch_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const fl
     // persistent form unless the epilogue does not fit its register budget (LN_STATS: a one-VGPR scratch spill)
     auto run = [&](auto mt_tag) {
         constexpr int T = decltype(mt_tag)::value;
-        if constexpr ((FLAGS & MQ_EPI_LN_STATS) != 0 || T == 6) {  // T == 6: the 192-row tile spills in the persistent form
+        if constexpr (T == 6 || (T == 5 && (FLAGS & MQ_EPI_LN_APPLY))) {  // spills in the persistent form: the 192-row tile; the 160-row tile + row statistics
             return launch_gemm_mt<FLAGS, T, false>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s, ln);
         } else {
             return persist ? launch_gemm_mt<FLAGS, T, true>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s, ln)
@@ -519,14 +579,12 @@ extern "C" int mq_gemm_bf16(const void* d_A, int64_t lda, const void* d_W, int64
 #undef MQ_GEMM_CASE
 }
 
-// GEMM with a folded LayerNorm on either side (see gemm_epilogue.h).  flags & MQ_EPI_LN_STATS: the residual epilogue also
-// writes bf16(out) to d_out2 and the per-row partial sums to d_stats [M][ceil(N/64)][2].  flags & MQ_EPI_LN_APPLY: A is the
-// bf16 copy of the UN-normalised rows, W / bias / d_colsum are pre-folded with the LayerNorm's gamma / beta, d_stats holds the
-// producer's partials over the K columns of A ([M][ceil(K/64)][2]).
-extern "C" int mq_gemm_bf16_ln(const void* d_A, int64_t lda, const void* d_W, int64_t ldw, const float* d_bias,
-                               const float* d_residual, void* d_out, int64_t ldc, int64_t M, int64_t N, int64_t K, int flags,
-                               float* d_stats, void* d_out2, const float* d_colsum, float eps, void* stream) {
-    MQ_CHECK_ARG(d_A && d_W && d_out && d_bias && d_stats, "mq_gemm_bf16_ln: null operand");
+// GEMM over the UN-normalised bf16 rows with the LayerNorm folded in (gemm_epilogue.h): out = act( LN(A) @ W0^T + b0 ) where d_W = bf16(gamma * W0)
+// (the LayerNorm's scale folded into the weight's columns), d_bias = b0 + W0 @ beta, d_colsum[n] = sum_k d_W[n, k] (of the ROUNDED folded weight)
+// and K = the normalised width (a tile spans whole rows).  flags: MQ_EPI_BIAS [| MQ_EPI_GELU | MQ_EPI_QUICKGELU] (MQ_EPI_LN_APPLY implied); bf16 out.
+extern "C" int mq_gemm_bf16_ln(const void* d_A, int64_t lda, const void* d_W, int64_t ldw, const float* d_bias, const float* d_colsum, void* d_out,
+                               int64_t ldc, int64_t M, int64_t N, int64_t K, int flags, float eps, void* stream) {
+    MQ_CHECK_ARG(d_A && d_W && d_out && d_bias && d_colsum, "mq_gemm_bf16_ln: null operand");
     MQ_CHECK_ARG(M >= 1 && N >= 4 && K >= BK && K % BK == 0 && N % 4 == 0, "mq_gemm_bf16_ln: bad shape M=%ld N=%ld K=%ld", (long)M, (long)N, (long)K);
     MQ_CHECK_ARG(lda % 8 == 0 && ldw % 8 == 0 && ldc % 4 == 0, "mq_gemm_bf16_ln: leading dims must keep 16-byte rows");
     MQ_CHECK_ARG(M < (1 << 30) && N < (1 << 30) && K < (1 << 30), "mq_gemm_bf16_ln: shape too large");
@@ -535,21 +593,11 @@ extern "C" int mq_gemm_bf16_ln(const void* d_A, int64_t lda, const void* d_W, in
     const int m = (int)M, n = (int)N, k = (int)K;
     GemmLn ln{};
     ln.eps = eps;
-    if (flags & MQ_EPI_LN_STATS) {
-        MQ_CHECK_ARG(d_residual && d_out2, "mq_gemm_bf16_ln: LN_STATS needs residual and out2");
-        ln.stats_out = d_stats;
-        ln.out2 = (bf16_t*)d_out2;
-    } else {
-        MQ_CHECK_ARG(d_colsum, "mq_gemm_bf16_ln: LN_APPLY needs colsum");
-        ln.stats_in = d_stats;
-        ln.colsum = d_colsum;
-        ln.nslots_in = (k + 63) >> 6;
-        ln.inv_w = 1.0f / (float)k;
-    }
+    ln.colsum = d_colsum;
+    ln.inv_w = 1.0f / (float)k;
 #define MQ_GEMM_LN_CASE(F) \
-    case (F): return launch_gemm<(F)>(d_A, lda, d_W, ldw, d_bias, d_residual, d_out, ldc, m, n, k, s, ln)
-    switch (flags) {
-        MQ_GEMM_LN_CASE(MQ_EPI_BIAS | MQ_EPI_RESIDUAL | MQ_EPI_OUT_F32 | MQ_EPI_LN_STATS);
+    case (F): return launch_gemm<(F)>(d_A, lda, d_W, ldw, d_bias, nullptr, d_out, ldc, m, n, k, s, ln)
+    switch (flags | MQ_EPI_LN_APPLY) {
         MQ_GEMM_LN_CASE(MQ_EPI_BIAS | MQ_EPI_LN_APPLY);
         MQ_GEMM_LN_CASE(MQ_EPI_BIAS | MQ_EPI_GELU | MQ_EPI_LN_APPLY);
         MQ_GEMM_LN_CASE(MQ_EPI_BIAS | MQ_EPI_QUICKGELU | MQ_EPI_LN_APPLY);
@@ -575,6 +623,7 @@ extern "C" int mq_tune(const char* key, int value) {
     else if (k == "gemm_vmcnt") g_tune.vmcnt = value;
     else if (k == "gemm_prio") g_tune.prio = value;
     else if (k == "gemm_k32") g_tune.k32 = value;
+    else if (k == "gemm_pl" || k == "gemm_pl_ord") mq_gemm_pl_tune(key, value);
     else if (k == "gemm_pp" || k == "gemm_pp_pps" || k == "gemm_pp_skew" || k == "gemm_pp_waves") mq_gemm_pp_tune(key, value);
     else if (k == "row_select") mq_tower_row_select = value;
     else if (k == "ln_fold") mq_tower_ln_fold = value;
@@ -586,7 +635,6 @@ extern "C" int mq_tune(const char* key, int value) {
     else if (k == "small_m") mq_gemm_small_max_rows = value;
     else if (k == "small_m_grouped") mq_gemm_small_group_rows = value;
     else if (k == "ln_prefetch") mq_ln_prefetch = value;
-    else if (k == "attn_items") mq_attention_items = value;
     else { mq_set_error("mq_tune: unknown key %s", key); return MQ_ERR_INVALID; }
     return MQ_OK;
 }

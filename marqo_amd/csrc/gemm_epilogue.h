@@ -8,39 +8,38 @@
 // store instruction covers 64 contiguous bytes per row: half the store instructions for the same bytes (the store tail of a
 // K = 768 tile is issue-bound, cdna_hip_programming.md T21).
 //
-// LayerNorm folding (pre-LN blocks): LN(x) @ W^T = rstd * (x @ (gamma*W)^T - mean * colsum(gamma*W)) + (b + W @ beta), so the
-// LayerNorm kernel between a residual GEMM and the next GEMM disappears:
-//   * MQ_EPI_LN_STATS (producer = the residual GEMM): besides x (fp32) the epilogue writes bf16(x) — the next GEMM's A
-//     operand — and, per row and 64-column wave slot, (sum x, sum x^2) into a partials array (plain stores, one writer per
-//     element: deterministic, no atomics);
-//   * MQ_EPI_LN_APPLY (consumer): the epilogue sums a row's partials (in slot order), forms mean / rstd and applies the
-//     identity above with the pre-folded colsum / bias before the activation.
+// LayerNorm folding (pre-LN blocks on the bf16 residual stream, round 4): LN(x) @ W^T = rstd * (x @ (gamma*W)^T - mean * colsum(gamma*W))
+// + (b + W @ beta), so the LayerNorm kernel in front of the QKV / fc1 GEMM disappears.  MQ_EPI_LN_APPLY (the consumer GEMM): A is the
+// UN-normalised bf16 stream itself, W / bias / colsum are pre-folded with gamma / beta at load; the kernel accumulates every row's
+// (sum x, sum x^2) from the A tiles that pass through its LDS anyway (a tile spans all of K = the normalised width) and leaves
+// (mean, rstd) per tile row in LDS for this epilogue.  Nothing else is exchanged between launches (round 1's form — partial sums written
+// by the producer GEMM's epilogue and re-read by the consumer's — cost more than the LayerNorm launches it removed).
 #pragma once
 #include "common.h"
 
 struct GemmLn {
-    float* stats_out;       // LN_STATS: [M][ceil(N/64)][2]
-    bf16_t* out2;           // LN_STATS: bf16 copy of the fp32 output, leading dim ldc
-    const float* stats_in;  // LN_APPLY: [M][nslots_in][2] written by the producer
     const float* colsum;    // LN_APPLY: [N]  sum_k bf16(gamma_k * W[n,k])
-    int nslots_in;          // LN_APPLY: producer's slot count = ceil(K/64)
     float inv_w;            // 1 / K  (K = the normalised width)
     float eps;
 };
 
 // RG = rows (16-row units) whose residual is prefetched together: the whole tile where the registers allow (the 4-wave kernel
 // after its k-loop), a few rows at a time in the 8-wave kernel whose accumulators already fill the file.
-template <int FLAGS, int MT, int RG = MT>
+// WAIT_LOADS (gemm_pl.hip): one explicit, compiler-visible s_waitcnt vmcnt(0) behind the up-front loads.  That kernel has LDS-DMA requests of
+// the next tile in flight here, so hipcc cannot count past them: without the explicit wait it re-waits vmcnt(0) at the first use of the
+// bias in every row group — draining the row groups' own stores one after the other — and, seeing the fragment registers as possibly
+// pending load destinations, puts another vmcnt(0) into the k-loop.
+template <int FLAGS, int MT, int RG = MT, bool WAIT_LOADS = false>
 __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][4], const float* __restrict__ bias, const float* residual, void* out,
                                               int64_t ldc, int M, int N, int wave_m0, int wave_n0, int l15, int g, bool wide = false,
-                                              const GemmLn* lnp = nullptr, const float* lds_bias = nullptr) {
+                                              const GemmLn* lnp = nullptr, const float* lds_bias = nullptr,
+                                              const float2* lds_rowstats = nullptr /* LN_APPLY: (mean, rstd) of the wave's 16*MT tile rows */) {
     constexpr bool BF16_OUT = !(FLAGS & MQ_EPI_OUT_F32);
     // bf16 residual stream (towers.hip): MQ_EPI_RESIDUAL without MQ_EPI_OUT_F32 = the residual is read as bf16 and the sum written
     // as bf16, in place — half the epilogue bytes of the fp32 stream, the memory-bound part of the K = 768 residual GEMMs
     constexpr bool RES_BF16 = (FLAGS & MQ_EPI_RESIDUAL) && BF16_OUT;
-    constexpr bool LN_STATS = (FLAGS & MQ_EPI_LN_STATS) != 0, LN_APPLY = (FLAGS & MQ_EPI_LN_APPLY) != 0;
-    static_assert(!LN_STATS || ((FLAGS & MQ_EPI_RESIDUAL) && (FLAGS & MQ_EPI_OUT_F32)), "LN_STATS rides on the residual epilogue");
-    static_assert(!LN_APPLY || BF16_OUT, "LN_APPLY produces a bf16 GEMM operand");
+    constexpr bool LN_APPLY = (FLAGS & MQ_EPI_LN_APPLY) != 0;
+    static_assert(!LN_APPLY || (BF16_OUT && !(FLAGS & MQ_EPI_RESIDUAL)), "LN_APPLY: the QKV / fc1 epilogues (bf16 out, no residual)");
     float row_mean = 0.f, row_rstd = 1.f;
     // Everything the epilogue READS is fetched up front, the long-latency residual tile first.  Measured with the phase trace
     // (tools/probes/gemm_trace.py): left inside the (mt, nt) loop, each sub-tile's bias / residual load was waited for on its
@@ -82,6 +81,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][4], const float* 
         else bias_v[nt] = ((FLAGS & MQ_EPI_BIAS) && n < N) ? *(const f32x4*)(bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
         cs_v[nt] = (LN_APPLY && n < N) ? *(const f32x4*)(lnp->colsum + n) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    if (WAIT_LOADS) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), lgkmcnt / expcnt untouched
     // value of one (mt, nt) sub-tile after (LN apply) / bias / activation / residual
     auto value = [&](int mt, int nt, int m, int n, bool ok) {
         f32x4 v = acc[mt][nt];
@@ -106,18 +106,10 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][4], const float* 
         const int m = wave_m0 + mt * 16 + l15;
         const bool m_ok = m < M;
         if (LN_APPLY) {
-            // row statistics from the producer's partials: the 4 lanes that share this row (g = 0..3) split the slots
-            float s1 = 0.f, s2 = 0.f;
-            if (m_ok) {
-                const float2* ps = (const float2*)lnp->stats_in + (int64_t)m * lnp->nslots_in;
-                for (int sl = g; sl < lnp->nslots_in; sl += 4) { const float2 pv = ps[sl]; s1 += pv.x; s2 += pv.y; }
-            }
-            s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
-            s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
-            row_mean = s1 * lnp->inv_w;
-            row_rstd = rsqrtf(fmaxf(s2 * lnp->inv_w - row_mean * row_mean, 0.f) + lnp->eps);
+            const float2 ms = lds_rowstats[mt * 16 + l15];
+            row_mean = ms.x;
+            row_rstd = ms.y;
         }
-        float st1 = 0.f, st2 = 0.f;  // LN_STATS: this lane's share of (sum, sum of squares) of row m over the wave's 64 columns
         if (BF16_OUT && wide) {  // `wide` is wave-uniform: every lane takes part in the swaps
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
@@ -150,14 +142,6 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][4], const float* 
                 if (!ok) continue;
                 if (!BF16_OUT) {
                     *(f32x4*)((float*)out + o) = v;
-                    if (LN_STATS) {
-                        uint2 pk;
-                        pk.x = pack_bf16x2(v[0], v[1]);
-                        pk.y = pack_bf16x2(v[2], v[3]);
-                        *(uint2*)(lnp->out2 + o) = pk;
-                        st1 += (v[0] + v[1]) + (v[2] + v[3]);
-                        st2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-                    }
                 } else {
                     uint2 pk;
                     pk.x = pack_bf16x2(v[0], v[1]);
@@ -165,12 +149,6 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][4], const float* 
                     *(uint2*)((bf16_t*)out + o) = pk;
                 }
             }
-        }
-        if (LN_STATS) {  // fixed reduction order over the row's 4 lanes; one writer per (row, slot)
-            st1 += __shfl_xor(st1, 16, 64); st2 += __shfl_xor(st2, 16, 64);
-            st1 += __shfl_xor(st1, 32, 64); st2 += __shfl_xor(st2, 32, 64);
-            if (g == 0 && m_ok && wave_n0 < N)
-                ((float2*)lnp->stats_out)[(int64_t)m * ((N + 63) >> 6) + (wave_n0 >> 6)] = make_float2(st1, st2);
         }
     }
 }

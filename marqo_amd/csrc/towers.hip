@@ -35,9 +35,10 @@ static_assert(sizeof(mq_vit_weights) == 10 * 8 && sizeof(mq_map_head) == 11 * 8 
 
 // mq_tune("row_select", 0) runs the last block on every row (A/B and parity tests of the pooled-rows-only last block)
 int mq_tower_row_select = getenv("MQ_ROW_SELECT") ? atoi(getenv("MQ_ROW_SELECT")) : 1;
-// LayerNorm folding runs only when the blocks carry folded weights AND this knob is on (mq_tune("ln_fold", 1) / MQ_LN_FOLD=1);
-// it is off by default: on MI355X the folded epilogues cost more than the LayerNorm launches they remove
-int mq_tower_ln_fold = getenv("MQ_LN_FOLD") ? atoi(getenv("MQ_LN_FOLD")) : 0;
+// LayerNorm folding (gemm_epilogue.h, MQ_EPI_LN_APPLY): on the bf16 residual stream the QKV / fc1 GEMMs of a pre-LN block read the stream itself and
+// apply the LayerNorm in their epilogue (row statistics accumulated from the A tiles in the kernel) whenever the block carries the folded
+// tensors (*_wf / *_bf / *_sf, engine/towers.py) and the call is large enough for the tiled GEMM.  mq_tune("ln_fold", 0) / MQ_LN_FOLD=0: off.
+int mq_tower_ln_fold = getenv("MQ_LN_FOLD") ? atoi(getenv("MQ_LN_FOLD")) : 1;
 // bf16 residual stream for the pre-LN bf16 towers (mq_tune("residual_bf16", 1) / MQ_RESIDUAL_BF16=1): x is kept in bf16 between
 // blocks.  The residual GEMMs of a K = 768 tower are memory-bound on their epilogue (out-proj: 15 GFLOP against 39 MB read + 39 MB
 // written of fp32 residual) and every LayerNorm re-reads the stream: bf16 halves those bytes.  Cost: one bf16 rounding per residual
@@ -48,6 +49,7 @@ extern "C" int mq_layernorm_ex(const void* d_x, int x_bf16, const int32_t* d_row
                                float* d_out_f32, int64_t rows, int32_t W, float eps, void* stream);
 // search path (rows <= 80): LayerNorm fused into the skinny GEMM's prologue (gemm_small.hip)
 bool mq_gemm_small_ok(int64_t M, int64_t N, int64_t K, bool ln);
+extern int mq_ln_prefetch;   // rowops.hip
 int mq_ln_gemm_small(const void* d_x, int64_t ldx, int x_bf16, const float* ln_g, const float* ln_b, float eps, const void* d_W, int64_t ldw,
                      const float* d_bias, void* d_out, int64_t ldc, int64_t M, int64_t N, int64_t K, int flags, float* d_ln_out,
                      const int32_t* d_rows, hipStream_t s);
@@ -66,9 +68,18 @@ static bool weights_outlive_cache(const mq_encoder_cfg* c, int Wa) {
 static inline const void* pf(const void* w) { return t_ln_prefetch ? w : nullptr; }
 int mq_layernorm_fp8_pf(const void* d_x, int x_bf16, const float* d_g, const float* d_b, void* d_out_fp8, float* d_row_scale, float* d_out_f32,
                         int64_t rows, int32_t W, float eps, const void* pf_a, size_t bytes_a, const void* pf_b, size_t bytes_b, hipStream_t s);
+bool mq_gemm_small_grouped_ok(int64_t M, int64_t N, int64_t K);
+extern "C" int mq_gemm_bf16_ln(const void* d_A, int64_t lda, const void* d_W, int64_t ldw, const float* d_bias, const float* d_colsum, void* d_out,
+                               int64_t ldc, int64_t M, int64_t N, int64_t K, int flags, float eps, void* stream);
+// folded LayerNorm + GEMM: the bf16 stream is the A operand (no LayerNorm launch, no normalised copy)
+static bool fold_ok(int xb, const void* wf, const float* bf, const float* sf, int64_t rows, int N, int K) {
+    return mq_tower_ln_fold && xb && wf && bf && sf && !mq_gemm_small_ok(rows, N, K, false) && !mq_gemm_small_grouped_ok(rows, N, K);
+}
 static int ln_gemm(const void* d_x, int xb, const float* g, const float* b, float eps, void* h, const void* W, const float* bias, void* out,
-                   int64_t rows, int N, int K, int flags, hipStream_t s, const void* next_w = nullptr, size_t next_bytes = 0) {
+                   int64_t rows, int N, int K, int flags, hipStream_t s, const void* next_w = nullptr, size_t next_bytes = 0,
+                   const void* wf = nullptr, const float* bf = nullptr, const float* sf = nullptr) {
     if (mq_gemm_small_ok(rows, N, K, true)) return mq_ln_gemm_small(d_x, K, xb, g, b, eps, W, K, bias, out, N, rows, N, K, flags, nullptr, nullptr, s);
+    if (fold_ok(xb, wf, bf, sf, rows, N, K)) return mq_gemm_bf16_ln(d_x, K, wf, K, bf, sf, out, N, rows, N, K, flags, eps, s);
     MQ_TRY(mq_layernorm_pf(d_x, xb, nullptr, g, b, h, nullptr, rows, K, eps, pf(W), (size_t)N * K * 2, pf(next_w), next_bytes, s));
     return mq_gemm_bf16(h, K, W, K, bias, nullptr, out, N, rows, N, K, flags, s);
 }
@@ -76,8 +87,7 @@ static int ln_gemm(const void* d_x, int xb, const float* g, const float* b, floa
 static bool stream_bf16(const mq_encoder_cfg* c) {
     // per-model policy, else the process default (bf16 towers only: an fp8 tower takes the bf16 stream when its load-time policy asks for it)
     const bool want = c->residual_stream == 1 || (c->residual_stream == 0 && mq_tower_residual_bf16 && c->precision == MQ_PREC_BF16);
-    return want && (c->precision == MQ_PREC_BF16 || c->precision == MQ_PREC_FP8) && !c->post_ln && !(mq_tower_ln_fold) && !c->mlp_glu &&
-           !c->d_rope_inv_freq;
+    return want && (c->precision == MQ_PREC_BF16 || c->precision == MQ_PREC_FP8) && !c->post_ln && !c->mlp_glu && !c->d_rope_inv_freq;
 }
 
 // post-LN encoders (BERT family) on the bf16 stream: the normalised bf16 rows `h` ARE the residual — the out-projection / fc2 epilogues add
@@ -88,14 +98,13 @@ static bool stream_post16(const mq_encoder_cfg* c) {
     return c->residual_stream == 1 && c->post_ln && c->precision == MQ_PREC_BF16 && !c->mlp_glu && !c->d_rope_inv_freq;
 }
 
-extern "C" int mq_gemm_bf16_ln(const void* d_A, int64_t lda, const void* d_W, int64_t ldw, const float* d_bias, const float* d_residual,
-                               void* d_out, int64_t ldc, int64_t M, int64_t N, int64_t K, int flags, float* d_stats, void* d_out2,
-                               const float* d_colsum, float eps, void* stream);
-
+int mq_attention_pf(const void* d_qkv, void* d_out, const int32_t* d_cu_seqlens, int64_t nseq, int32_t fixed_len, int32_t max_len, int32_t W,
+                    int32_t heads, int32_t mask, const MqPrefetch& pf, hipStream_t s);
 namespace {
 // attention of one block: with the model's relative-position bias when the encoder has one (MPNet), else the plain kernel
 inline int attn_bf16(const mq_encoder_cfg* cfg, const void* qf, void* a, const int32_t* d_cu_seqlens, int64_t nseq, int32_t fixed_len,
-                     int32_t max_len, int32_t Wa, hipStream_t s) {
+                     int32_t max_len, int32_t Wa, hipStream_t s, const MqPrefetch* wpf = nullptr) {
+    if (wpf && !cfg->d_rel_bias) return mq_attention_pf(qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, cfg->heads, cfg->mask, *wpf, s);
     if (cfg->d_rel_bias) return mq_attention_bias(qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, cfg->heads, cfg->d_rel_bias, cfg->rel_span, s);
     return mq_attention(qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, cfg->heads, cfg->mask, s);
 }
@@ -160,7 +169,6 @@ size_t encoder_ws(const mq_encoder_cfg* c, int64_t rows) {
     cv.take((size_t)rows * wa * 2);
     cv.take((size_t)rows * big * 2);
     cv.take((size_t)rows * 4);  // per-row activation scales of the fp8 path
-    cv.take((size_t)rows * ((c->width + 63) / 64) * 8);  // LayerNorm-fold partials: (sum, sum of squares) per row and 64-column slot
     cv.take((size_t)(rows < SMALL_LN_ROWS ? rows : SMALL_LN_ROWS) * c->width * 4);  // search path, post-LN: the normalised residual (fp32)
     return cv.end();
 }
@@ -187,7 +195,7 @@ namespace {
 int last_block_selected(const mq_encoder_cfg* cfg, const mq_block_weights& b, int l, float* d_x, int64_t rows,
                         const int32_t* d_cu_seqlens, int64_t nseq, int32_t fixed_len, int32_t max_len,
                         const int32_t* d_sel, int64_t nsel, void* h, void* a, void* qf, float* row_scale, float* x_sel,
-                        float* stats /* non-NULL: h holds bf16(x) and stats its LayerNorm partials (folded path) */, bool f8, hipStream_t s) {
+                        bool f8, hipStream_t s) {
     const int W = cfg->width, F = cfg->mlp_dim, Wa = attn_width(cfg);
     const int act_flag = cfg->act == MQ_ACT_QUICKGELU ? MQ_EPI_QUICKGELU : MQ_EPI_GELU;
     const int res_flags = MQ_EPI_BIAS | MQ_EPI_RESIDUAL | MQ_EPI_OUT_F32;
@@ -211,13 +219,7 @@ int last_block_selected(const mq_encoder_cfg* cfg, const mq_block_weights& b, in
         const int xb = stream_bf16(cfg) ? 1 : 0;                 // bf16 residual stream: rows of 2 bytes per element, bf16 RMW epilogues
         const int rflags = xb ? (MQ_EPI_BIAS | MQ_EPI_RESIDUAL) : res_flags;
         const int64_t xrow = (int64_t)W * (xb ? 2 : 4);
-        if (stats) {
-            MQ_TRY(mq_gemm_bf16_ln(h, W, b.qkv_wf, W, b.qkv_bf, nullptr, qf, 3 * Wa, rows, 3 * Wa, W, MQ_EPI_BIAS | MQ_EPI_LN_APPLY, stats, nullptr,
-                                   b.qkv_sf, cfg->ln_eps, s));
-        } else {
-            MQ_TRY(mq_layernorm_pf(d_x, xb, nullptr, b.ln1_g, b.ln1_b, h, nullptr, rows, W, cfg->ln_eps, pf(b.qkv_w), (size_t)3 * Wa * W * 2, nullptr, 0, s));
-            MQ_TRY(mq_gemm_bf16(h, W, b.qkv_w, W, b.qkv_b, nullptr, qf, 3 * Wa, rows, 3 * Wa, W, MQ_EPI_BIAS, s));
-        }
+        MQ_TRY(ln_gemm(d_x, xb, b.ln1_g, b.ln1_b, cfg->ln_eps, h, b.qkv_w, b.qkv_b, qf, rows, 3 * Wa, W, MQ_EPI_BIAS, s, nullptr, 0, b.qkv_wf, b.qkv_bf, b.qkv_sf));
         MQ_TRY(attn_bf16(cfg, qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, s));
         MQ_TRY(mq_move_rows(a, d_sel, h, nsel, (int64_t)Wa * 2, false, s));
         MQ_TRY(mq_move_rows(d_x, d_sel, x_sel, nsel, xrow, false, s));
@@ -275,18 +277,9 @@ int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* bloc
     void* a = wsb + cv.take((size_t)rows * Wa * 2);
     void* qf = wsb + cv.take((size_t)rows * big * 2);  // qkv [rows,3W] then fc1 output [rows,F]
     float* row_scale = (float*)(wsb + cv.take((size_t)rows * 4));
-    float* ln_stats = (float*)(wsb + cv.take((size_t)rows * ((W + 63) / 64) * 8));
     float* xn = (float*)(wsb + cv.take((size_t)(rows < SMALL_LN_ROWS ? rows : SMALL_LN_ROWS) * W * 4));
     const int act_flag = cfg->act == MQ_ACT_QUICKGELU ? MQ_EPI_QUICKGELU : MQ_EPI_GELU;
     const int res_flags = MQ_EPI_BIAS | MQ_EPI_RESIDUAL | MQ_EPI_OUT_F32;
-
-    // LayerNorm folding (pre-LN bf16 encoders whose blocks all carry the folded tensors): the residual GEMMs emit bf16(x) + row
-    // partials, the QKV / fc1 GEMMs apply mean / rstd in their epilogue -> no LayerNorm launch between them.  `h` then holds
-    // bf16(x) instead of LN(x); `folded` says whether (h, ln_stats) describe the current x (false before the first block).
-    bool fold = mq_tower_ln_fold && cfg->precision == MQ_PREC_BF16 && !cfg->post_ln && Wa == W;
-    for (int l = 0; fold && l < cfg->layers; ++l)
-        fold = blocks[l].qkv_wf && blocks[l].qkv_sf && blocks[l].qkv_bf && blocks[l].fc1_wf && blocks[l].fc1_sf && blocks[l].fc1_bf;
-    bool folded = false;
 
     // pooled-rows-only last block: worth it when it at least halves the row count; not during fp8 calibration (the
     // activation maxima must see every row); x_sel must fit behind the fc1 output inside `qf`
@@ -322,26 +315,8 @@ int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* bloc
         if (cfg->post_ln && f8 && l == first8 && l > 0) MQ_TRY(mq_rowquant_fp8(d_x, h, row_scale, rows, W, s));
         if (select_last && l == cfg->layers - 1) {
             MQ_TRY(last_block_selected(cfg, b, l, d_x, rows, d_cu_seqlens, nseq, fixed_len, max_len, d_sel, nsel, h, a, qf, row_scale,
-                                       (float*)((char*)qf + xsel_off), folded ? ln_stats : nullptr, f8, s));
+                                       (float*)((char*)qf + xsel_off), f8, s));
             break;
-        }
-        if (fold) {
-            // x += out(attn(qkv(ln1(x)))) ; x += fc2(act(fc1(ln2(x)))) with both LayerNorms folded into the GEMMs around them
-            const int stat_flags = res_flags | MQ_EPI_LN_STATS, apply = MQ_EPI_BIAS | MQ_EPI_LN_APPLY;
-            if (folded) {
-                MQ_TRY(mq_gemm_bf16_ln(h, W, b.qkv_wf, W, b.qkv_bf, nullptr, qf, 3 * Wa, rows, 3 * Wa, W, apply, ln_stats, nullptr, b.qkv_sf,
-                                       cfg->ln_eps, s));
-            } else {  // first block: x comes from the embedding kernels, not from a GEMM epilogue
-                MQ_TRY(mq_layernorm(d_x, nullptr, b.ln1_g, b.ln1_b, h, nullptr, rows, W, cfg->ln_eps, s));
-                MQ_TRY(mq_gemm_bf16(h, W, b.qkv_w, W, b.qkv_b, nullptr, qf, 3 * Wa, rows, 3 * Wa, W, MQ_EPI_BIAS, s));
-            }
-            MQ_TRY(attn_bf16(cfg, qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, s));
-            MQ_TRY(mq_gemm_bf16_ln(a, Wa, b.out_w, Wa, b.out_b, d_x, d_x, W, rows, W, Wa, stat_flags, ln_stats, h, nullptr, cfg->ln_eps, s));
-            MQ_TRY(mq_gemm_bf16_ln(h, W, b.fc1_wf, W, b.fc1_bf, nullptr, qf, F, rows, F, W, apply | act_flag, ln_stats, nullptr, b.fc1_sf,
-                                   cfg->ln_eps, s));
-            MQ_TRY(mq_gemm_bf16_ln(qf, F, b.fc2_w, F, b.fc2_b, d_x, d_x, W, rows, W, F, stat_flags, ln_stats, h, nullptr, cfg->ln_eps, s));
-            folded = true;
-            continue;
         }
         if (f8) {
             // same dataflow with e4m3 GEMM operands: h / a / fc1-out are fp8 (h with a dynamic per-row scale from the LN,
@@ -380,8 +355,20 @@ int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* bloc
             // x += out(attn(qkv(ln1(x)))) ; x += fc2(act(fc1(ln2(x))))   (x fp32, or bf16 in the bf16-stream form)
             const int xb = stream_bf16(cfg) ? 1 : 0;
             const int rflags = xb ? (MQ_EPI_BIAS | MQ_EPI_RESIDUAL) : res_flags;
-            MQ_TRY(ln_gemm(d_x, xb, b.ln1_g, b.ln1_b, cfg->ln_eps, h, b.qkv_w, b.qkv_b, qf, rows, 3 * Wa, W, MQ_EPI_BIAS, s, b.out_w, (size_t)W * Wa * 2));
-            MQ_TRY(attn_bf16(cfg, qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, s));
+            MQ_TRY(ln_gemm(d_x, xb, b.ln1_g, b.ln1_b, cfg->ln_eps, h, b.qkv_w, b.qkv_b, qf, rows, 3 * Wa, W, MQ_EPI_BIAS, s, b.out_w, (size_t)W * Wa * 2,
+                           b.qkv_wf, b.qkv_bf, b.qkv_sf));
+            // with the LayerNorms folded away the attention launch carries the weight prefetch of the GEMMs behind it: out-projection, fc1, fc2
+            // and the next block's QKV (the first block's QKV weight is the one nobody prefetches)
+            const bool fold_mlp = fold_ok(xb, b.fc1_wf, b.fc1_bf, b.fc1_sf, rows, F, W) && !(cfg->precision == MQ_PREC_FP8 && l >= first8 - cfg->fp8_mlp_extra) &&
+                                  !(d_sel && nsel > 0 && l == cfg->layers - 1);
+            MqPrefetch wpf{};
+            const bool carry = t_ln_prefetch && fold_ok(xb, b.qkv_wf, b.qkv_bf, b.qkv_sf, rows, 3 * Wa, W) && mq_ln_prefetch;
+            if (carry) {
+                const mq_block_weights* nb = l + 1 < first8 ? &blocks[l + 1] : nullptr;
+                wpf = mq_prefetch_ranges(b.out_w, (size_t)W * Wa * 2, fold_mlp ? b.fc1_wf : nullptr, (size_t)F * W * 2, fold_mlp ? b.fc2_w : nullptr, (size_t)W * F * 2,
+                                         nb && fold_ok(xb, nb->qkv_wf, nb->qkv_bf, nb->qkv_sf, rows, 3 * Wa, W) ? nb->qkv_wf : nullptr, (size_t)3 * Wa * W * 2);
+            }
+            MQ_TRY(attn_bf16(cfg, qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, s, carry ? &wpf : nullptr));
             MQ_TRY(mq_gemm_bf16(a, Wa, b.out_w, Wa, b.out_b, (const float*)d_x, d_x, W, rows, W, Wa, rflags, s));
             if (cfg->precision == MQ_PREC_FP8 && l >= first8 - cfg->fp8_mlp_extra) {
                 // MLP-only e4m3 block (fp8_mlp_extra): the attention half above ran on bf16 operands
@@ -395,7 +382,11 @@ int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* bloc
                 MQ_TRY(mq_gemm_fp8(qf, F, b.fc2_w8, F, s_mlp, 0, b.fc2_ws, b.fc2_b, (const float*)d_x, d_x, W, nullptr, nullptr, rows, W, F, rflags, s));
                 continue;
             }
-            MQ_TRY(ln_gemm(d_x, xb, b.ln2_g, b.ln2_b, cfg->ln_eps, h, b.fc1_w, b.fc1_b, qf, rows, F, W, MQ_EPI_BIAS | act_flag, s, b.fc2_w, (size_t)W * F * 2));
+            // (the LAST block of a call that reads only pooled rows never folds its MLP: the pooled rows take the small-call kernels — LayerNorm
+            // kernel + un-folded weights — and dead-row elimination stays bit-identical to this all-rows form, tests/test_towers_gpu.py)
+            const bool last_pooled = d_sel && nsel > 0 && l == cfg->layers - 1;
+            MQ_TRY(ln_gemm(d_x, xb, b.ln2_g, b.ln2_b, cfg->ln_eps, h, b.fc1_w, b.fc1_b, qf, rows, F, W, MQ_EPI_BIAS | act_flag, s, b.fc2_w, (size_t)W * F * 2,
+                           last_pooled ? nullptr : b.fc1_wf, b.fc1_bf, b.fc1_sf));
             MQ_TRY(mq_gemm_bf16(qf, F, b.fc2_w, F, b.fc2_b, (const float*)d_x, d_x, W, rows, W, F, rflags, s));
         } else if (small_post_ln) {
             // search path: both LayerNorms ride in the prologue of the GEMM that consumes them (gemm_small.hip).  d_x holds the pre-LN sums

@@ -180,9 +180,11 @@ class _Fp8State:
         self.amax.zero_()
 
 
-# LayerNorm folding of the pre-LN CLIP blocks: opt-in (MARQO_AMD_LN_FOLD=1).  Measured on MI355X it removes the LayerNorm
-# launches (-0.32 ms per ViT-B/32 step) but the two epilogues cost more than that (+0.45 ms): DESIGN.md §6.2.
-LN_FOLD = os.environ.get("MARQO_AMD_LN_FOLD", "0") == "1"
+# LayerNorm folding of the pre-LN CLIP blocks (csrc/gemm_epilogue.h, MQ_EPI_LN_APPLY): the loaders prepare gamma-folded copies of the QKV / fc1
+# weights (+ folded bias and column sums); on the bf16 residual stream the tiled GEMMs then read the stream itself and no LayerNorm kernel runs in
+# front of them.  The un-folded weights stay for the small-call kernels (fused-LayerNorm skinny GEMMs) and the fp32-stream towers.
+# MARQO_AMD_LN_FOLD=0: do not build the folded tensors (the towers then always launch their LayerNorms).
+LN_FOLD = os.environ.get("MARQO_AMD_LN_FOLD", "1") != "0"
 
 
 # per-block tensor names: open_clip ResidualAttentionBlock / timm Block (the SigLIP trunks)
@@ -195,8 +197,6 @@ _TIMM_KEYS = dict(block="blocks.{}.", ln1="norm1", qkv_w="attn.qkv.weight", qkv_
 def _clip_blocks(h: _Holder, sd, prefix: str, layers: int, W: int, F: int, heads: int, keys=_OPEN_CLIP_KEYS):
     d = _head_dim(W, heads)
     padded = d != _kernel_head_dim(d, heads)  # ViT-H / g / bigG: 80 / 88 / 104-wide heads run as 96 / 96 / 112
-    if (padded or F % 64) and LN_FOLD:
-        raise ValueError("MARQO_AMD_LN_FOLD=1 is not supported for models whose heads or MLP are padded")
     arr = (L.BlockWeights * layers)()
     k = keys
     for i in range(layers):
@@ -218,14 +218,15 @@ def _clip_blocks(h: _Holder, sd, prefix: str, layers: int, W: int, F: int, heads
         b.fc2_b = h.f32(_need(sd, p + k["fc2"] + ".bias", (W,)))
         if LN_FOLD:
             # LayerNorm folding (csrc/gemm_epilogue.h): LN(x) @ W^T = rstd * (x @ (g*W)^T - mean * colsum(g*W)) + (b + W @ beta).
-            # colsum is taken over the bf16-ROUNDED folded weight (what the MFMA multiplies), the bias in fp32 from the fp32 W.
-            for name, wk, bk, lg in (("qkv", k["qkv_w"], k["qkv_b"], k["ln1"]), ("fc1", k["fc1"] + ".weight", k["fc1"] + ".bias", k["ln2"])):
-                w32 = sd[p + wk].detach().to(torch.float32)
+            # colsum is taken over the bf16-ROUNDED folded weight (what the MFMA multiplies), the bias in fp32 from the fp32 W; the (possibly
+            # head- / MLP-padded) tensors the block really runs are the ones folded.
+            for name, w_t, b_t, lg in (("qkv", qkv_w, qkv_b, k["ln1"]), ("fc1", fc1_w, fc1_b, k["ln2"])):
+                w32 = w_t.detach().to(torch.float32)
                 gam, bet = sd[p + lg + ".weight"].detach().to(torch.float32), sd[p + lg + ".bias"].detach().to(torch.float32)
                 wf = (w32 * gam.unsqueeze(0)).to(torch.bfloat16)
                 setattr(b, name + "_wf", h.bf16(wf))
                 setattr(b, name + "_sf", h.f32(wf.to(torch.float32).sum(dim=1)))
-                setattr(b, name + "_bf", h.f32(sd[p + bk].detach().to(torch.float32) + w32 @ bet))
+                setattr(b, name + "_bf", h.f32(b_t.detach().to(torch.float32) + w32 @ bet))
     return arr
 
 
@@ -408,6 +409,7 @@ class _TowerBase:
     def tune_residual_stream(self, run, budget: Optional[float] = None) -> str:
         """`run()` pushes the tower's fixed calibration batch through it and returns the [n, D] embeddings -> 'bf16' | 'fp32'"""
         enc = self.cfg.enc
+        getattr(self, "_graphs", {}).clear()   # captured single-item graphs bake in the stream's layout and launch sequence: a re-tune must not replay stale ones
         mode = os.environ.get("MARQO_AMD_RESIDUAL_STREAM", "auto").lower()
         if self.precision != "bf16" or mode == "fp32":
             enc.residual_stream, self.residual_stream = 2, "fp32"
@@ -455,6 +457,7 @@ class _TowerBase:
             raise RuntimeError("tower was not built with precision='fp8'")
         budget = self.FP8_BUDGET if budget is None else float(budget)
         enc, layers = self.cfg.enc, self.cfg.enc.layers
+        getattr(self, "_graphs", {}).clear()   # (as in tune_residual_stream: graphs captured under the previous policy would disagree with the eager path)
         enc.fp8_first_layer, enc.fp8_mlp_extra = 0, 0
         self.calibrate_fp8(run, passes=2, margin=self.FP8_SCALE_MARGIN if margin is None else margin)
         self._fp8.calibrated = False           # no graph capture while the split is being searched

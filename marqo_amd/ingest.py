@@ -178,6 +178,16 @@ class BulkVectoriser:
                 self._pending[m] = kept
             return n
 
+    def reset(self) -> int:
+        """forget everything: queued items of both modalities AND rows already encoded but not yet handed out (a failed flush keeps the
+        modality that did run in the store); returns how many items / rows were dropped"""
+        with self._lock:
+            n = sum(len(v) for v in self._pending.values()) + len(self._done)
+            for m in self._pending:
+                self._pending[m] = []
+            self._done = {}
+            return n
+
     def flush(self) -> Dict[Hashable, np.ndarray]:
         """Vectorise everything still queued; returns {key: float32 [D]} for every key added since the last flush()."""
         self._run_pending()
@@ -214,6 +224,8 @@ class RequestShardedIngest:
         self._rows: List[np.ndarray] = []                     # this rank's embeddings, in submission order
         self._index: List[Tuple[int, Hashable]] = []          # (request index, key) per row
         self.touched: List[int] = []                          # request indices this rank was handed (tests: ownership)
+        self.failed: List[int] = []                           # owned requests whose encode raised since the last collect()
+        self.failed_requests: List[int] = []                  # after collect(): every rank's failed requests (root), own ones elsewhere
 
     def owner(self, request_index: int) -> int:
         return request_index % self.world
@@ -230,7 +242,16 @@ class RequestShardedIngest:
         for key, content, modality in items:
             self._bulk.add(key, content, modality)
             keys.append(key)
-        out = self._bulk.flush()
+        try:
+            out = self._bulk.flush()
+        except BaseException:
+            # One bad document (an undecodable image) must not poison this rank's stream: BulkVectoriser re-queues the failed modality and
+            # keeps the other one's rows for a retry, but a request is all-or-nothing here — drop both, so that the NEXT request starts from
+            # an empty queue, and remember the index: the caller may catch the exception and go on, collect() still runs on every rank
+            # (nobody is left waiting in the collective) and reports the request as failed.
+            self._bulk.reset()
+            self.failed.append(request_index)
+            raise
         for key in keys:
             self._rows.append(out[key])
             self._index.append((request_index, key))
@@ -240,6 +261,8 @@ class RequestShardedIngest:
         import torch
         rows, index = self._rows, self._index
         self._rows, self._index = [], []
+        failed, self.failed = self.failed, []
+        self.failed_requests = sorted(failed)
         local = np.stack(rows).astype(np.float32, copy=False) if rows else None
         if self.world == 1:
             out: Dict[int, Dict[Hashable, np.ndarray]] = {}
@@ -251,7 +274,9 @@ class RequestShardedIngest:
         where = self.device if on_gpu else "cpu"
         # who holds what: (row count, width) per rank + the (request, key) labels, as python objects (tiny next to the rows)
         meta = [None] * self.world
-        dist.all_gather_object(meta, (len(index), int(local.shape[1]) if local is not None else 0, index if self.rank != self.root else None))
+        dist.all_gather_object(meta, (len(index), int(local.shape[1]) if local is not None else 0, index if self.rank != self.root else None, failed))
+        if self.rank == self.root:
+            self.failed_requests = sorted(i for m in meta for i in m[3])
         D = max(m[1] for m in meta)
         counts = [m[0] for m in meta]
         if sum(counts) == 0:

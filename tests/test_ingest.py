@@ -243,3 +243,30 @@ def test_failed_shard_raises_on_every_rank_world_size_2():
         p.join(120)
         assert p.exitcode == 0
     assert sorted(q.get(timeout=5) for _ in range(2)) == [(0, True), (1, True)]
+
+
+def test_a_failed_request_does_not_poison_the_stream():
+    """an undecodable image in request 1 must fail request 1 only — request 2 on the same rank encodes from an empty queue,
+    no stale rows leak into it, and collect() reports the failed index"""
+    from marqo_amd.ingest import RequestShardedIngest
+    calls = []
+
+    def flaky(model, content, **kw):
+        calls.append((kw["modality"], list(content)))
+        if any(c == "BAD" for c in content):
+            raise OSError("image file is truncated")
+        return np.asarray([[float(len(str(c))), float(kw["modality"] == Modality.IMAGE)] for c in content], dtype=np.float32)
+
+    ing = RequestShardedIngest("m", "cpu", vectorise_fn=flaky)
+    ing.submit(0, [((0, "t"), "hello", Modality.TEXT), ((0, "i"), "img0", Modality.IMAGE)])
+    with pytest.raises(OSError):
+        ing.submit(1, [((1, "t"), "text of the bad request", Modality.TEXT), ((1, "i"), "BAD", Modality.IMAGE)])
+    assert ing._bulk.pending() == 0 and ing._bulk.flush() == {}
+    n_calls = len(calls)
+    ing.submit(2, [((2, "t"), "fine", Modality.TEXT), ((2, "i"), "img2", Modality.IMAGE)])
+    # request 2 ran exactly its own two items (one call per modality), nothing of request 1 was re-encoded with it
+    assert [c[1] for c in calls[n_calls:]] == [["fine"], ["img2"]]
+    rows = ing.collect()
+    assert sorted(rows) == [0, 2] and set(rows[2]) == {(2, "t"), (2, "i")} and rows[2][(2, "t")][0] == 4.0
+    assert ing.failed_requests == [1] and ing.failed == []
+    assert ing.collect() == {} and ing.failed_requests == []
