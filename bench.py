@@ -385,7 +385,7 @@ def gemm_roofline(lib, L, run_local, prof_steps, precision, workload_name):
                 for i in range(L.MQ_PROF_FAMILIES) if cnt[i]}
     roofline = {
         "kernel": ("gemm_fp8_kernel (e4m3 MX MFMA 16x16x128, (32*MT)x128x128 tiles, fused epilogues; bf16 gemm_nt_kernel in the blocks the policy keeps on bf16)" if precision == "fp8"
-                   else "gemm_nt_kernel (bf16 MFMA 16x16x32, (32*MT)x128x64 tiles, fused epilogues)"),
+                   else "gemm_nt_kernel (bf16 MFMA 16x16x32, (32*MT)x128x64 tiles, software-pipelined k-loop, fused epilogues incl. the folded LayerNorm)"),
         "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
         "frac": round(achieved / peak, 4), "traffic": None,
         "flops_per_launch": flops.value / max(gemm_launches, 1),
@@ -402,7 +402,7 @@ def gemm_roofline(lib, L, run_local, prof_steps, precision, workload_name):
     # HBM-side traffic of the dominant kernel from the committed PMC passes of this same command (tools/gpu_evidence.sh:
     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH doubled per MI355X_MICROARCH.md; PMC cannot be sampled
     # from inside this process).  Bytes per launch, averaged over the GEMM launches like `achieved`.
-    for rnd in ("r03", "r02", "r01"):
+    for rnd in ("r04", "r03", "r02", "r01"):
         tpath = os.path.join(ROOT, "profiles", f"{rnd}_traffic_{workload_name}_{precision}.json")
         if not os.path.isfile(tpath):
             continue
@@ -410,7 +410,7 @@ def gemm_roofline(lib, L, run_local, prof_steps, precision, workload_name):
             with open(tpath) as f:
                 tj = json.load(f)
             fam = "gemm_fp8_kernel" if precision == "fp8" else "gemm_nt_kernel"
-            rows = [v for k, v in tj.items() if k.startswith(fam) or k.startswith("gemm_big_kernel")]
+            rows = [v for k, v in tj.items() if k.startswith(fam)]
             n_l = sum(v["launches"] for v in rows)
             if n_l:
                 roofline["traffic"] = round(sum(v["launches"] * (v["read_bytes"] + v["write_bytes"]) for v in rows) / n_l, 1)

@@ -421,16 +421,18 @@ int mq_ln_gemm_small_bf16(const void* d_x, int64_t ldx, int x_bf16, const float*
                           int64_t ldw, const float* d_bias, void* d_out, int64_t ldc, int64_t M, int64_t N, int64_t K, int flags,
                           float* d_ln_out, void* stream);
 
-/* mq_gemm_bf16 with the LayerNorm of a pre-LN block folded in (csrc/gemm_epilogue.h; the towers' QKV / fc1 GEMMs on the bf16 residual stream):
- *   out bf16 [M, N] = act( LN(A) @ W0^T + b0 ),  LN over the K columns of A with scale gamma / shift beta, computed as
- *   act( rstd * (A @ d_W^T - mean * d_colsum) + d_bias )  with  d_W = bf16(gamma * W0) [N, K],  d_bias = b0 + W0 @ beta,  d_colsum[n] = sum_k d_W[n, k].
- * d_A: the UN-normalised bf16 rows [M, lda]; K = the normalised width (K % 64 == 0); the row statistics are accumulated inside the kernel from the
- * A tiles it stages anyway — there is no LayerNorm launch and no normalised copy.  flags: MQ_EPI_BIAS [| MQ_EPI_GELU | MQ_EPI_QUICKGELU].
+/* The LayerNorm of a pre-LN block folded into the GEMM behind it (csrc/gemm_epilogue.h; the towers' QKV / fc1 GEMMs on the bf16 residual stream):
+ *   mq_row_stats:    d_stats fp32 [rows][2] = (mean, rstd) of every bf16 row of d_x [rows, W] (W % 8 == 0, W <= 2048) — ONE read pass, 8 bytes written
+ *                    per row; the LayerNorm launch it replaces read AND wrote the whole stream.
+ *   mq_gemm_bf16_ln: out bf16 [M, N] = act( LN(A) @ W0^T + b0 ) computed as act( rstd * (A @ d_W^T - mean * d_colsum) + d_bias ) with
+ *                    d_W = bf16(gamma * W0) [N, K], d_bias = b0 + W0 @ beta, d_colsum[n] = sum_k d_W[n, k], d_rowstats from mq_row_stats;
+ *                    d_A: the UN-normalised bf16 rows (K = the normalised width).  flags: MQ_EPI_BIAS [| MQ_EPI_GELU | MQ_EPI_QUICKGELU].
  * Replaces what open_clip's ResidualAttentionBlock computes as ln_1 -> attn.in_proj / ln_2 -> mlp.c_fc
- * (called from /root/reference/src/marqo/core/inference/embedding_models/open_clip_model.py:249-266). */
+ * (reached from /root/reference/src/marqo/core/inference/embedding_models/open_clip_model.py:249-266). */
 #define MQ_EPI_LN_APPLY 128
-int mq_gemm_bf16_ln(const void* d_A, int64_t lda, const void* d_W, int64_t ldw, const float* d_bias, const float* d_colsum, void* d_out,
-                    int64_t ldc, int64_t M, int64_t N, int64_t K, int flags, float eps, void* stream);
+int mq_row_stats(const void* d_x_bf16, float* d_stats, int64_t rows, int32_t W, float eps, void* stream);
+int mq_gemm_bf16_ln(const void* d_A, int64_t lda, const void* d_W, int64_t ldw, const float* d_bias, const float* d_colsum, const float* d_rowstats,
+                    void* d_out, int64_t ldc, int64_t M, int64_t N, int64_t K, int flags, void* stream);
 
 /* y = LayerNorm(x) * g + b over the last dim.  x fp32 [rows, W] gathered through an optional
  * row index (d_row_idx int32 [rows], NULL = identity).  Writes bf16 (d_out_bf16) and/or fp32

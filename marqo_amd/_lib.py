@@ -28,7 +28,7 @@ STAGE_SRC = CSRC_DIR / "py_stage.cpp"
 STAGE_PATH = LIB_DIR / "_mq_stage.so"                # CPython extension: a batch of Pillow images -> the pinned staging buffer in one call
 
 MQ_OK = 0
-NO_SCRATCH_UNITS = ("rowops", "gemm_bf16", "gemm_pl", "gemm_pp", "gemm_big", "gemm_k32", "gemm_fp8", "gemm_small", "attention")  # build() refuses register spills in these
+NO_SCRATCH_UNITS = ("rowops", "gemm_bf16", "gemm_fp8", "gemm_small", "attention")  # build() refuses register spills in these
 ABI_VERSION = 7
 MQ_PREC_BF16, MQ_PREC_FP8 = 0, 1
 MQ_ACT_GELU, MQ_ACT_QUICKGELU = 1, 2
@@ -145,7 +145,8 @@ _SIGNATURES = {
     "mq_gemm_small_bf16": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, _P]),
     "mq_ln_gemm_small_bf16": (C.c_int, [_P, C.c_int64, C.c_int, _P, _P, C.c_float, _P, C.c_int64, _P, _P, C.c_int64, C.c_int64, C.c_int64,
                                         C.c_int64, C.c_int, _P, _P]),
-    "mq_gemm_bf16_ln": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_float, _P]),
+    "mq_gemm_bf16_ln": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, _P]),
+    "mq_row_stats": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_float, _P]),
     "mq_gemm_fp8": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, C.c_int, _P, _P, _P, _P, C.c_int64, _P, _P, C.c_int64, C.c_int64,
                               C.c_int64, C.c_int, _P]),
     "mq_quantize_weights_fp8": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, C.c_int64, C.c_int64, _P]),

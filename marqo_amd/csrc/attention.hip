@@ -49,7 +49,7 @@ template <int MASK, bool OUT_FP8, int HD, int HS, int NW, bool BIAS = false>
 __global__ __launch_bounds__(NW * 64) MQ_ATTN_OCC void attention_kernel(
     const bf16_t* __restrict__ qkv, void* __restrict__ out_v, const int32_t* __restrict__ cu,
     int fixed_len, int W, int heads, int kpad, float scale_log2e, const float* __restrict__ out_scale, float* amax_out,
-    const float* __restrict__ rel_bias = nullptr, int rel_span = 0, int band = 0, MqPrefetch pf = MqPrefetch{}) {
+    const float* __restrict__ rel_bias = nullptr, int rel_span = 0, int band = 0) {
     bf16_t* out = (bf16_t*)out_v;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     static_assert(HS <= HD && HS % 16 == 0 && (HD == 64 || HD == 128), "head stride: multiple of 16, at most the LDS row");
@@ -284,10 +284,6 @@ __global__ __launch_bounds__(NW * 64) MQ_ATTN_OCC void attention_kernel(
         amax_local = wave_max(amax_local);
         if (lane == 0) atomicMax((int*)amax_out, __float_as_int(amax_local));
     }
-    // weight prefetch for the GEMMs behind this launch (common.h, MqPrefetch), by every thread that reaches the end of the kernel: behind the
-    // wave's last load and store (loads return in order: an HBM miss must not sit in front of a Q fragment), where the registers are free again;
-    // the wave's exit waits for it (s_endpgm drains the counters), nothing else does
-    mq_prefetch_retire(mq_prefetch_issue(pf));
 }
 
 // (round 3's attention_short_kernel — several 50-token items per workgroup — measured slower, profiles/r03ad_attn_items_ab.txt, and left the library in round 4)
@@ -298,7 +294,7 @@ int mq_attention_waves = 0;  // mq_tune("attn_waves", 0 = auto / 4 / 8 / 5 = fiv
 
 static int attention_impl(const void* d_qkv, void* d_out, const int32_t* d_cu_seqlens, int64_t nseq,
                           int32_t fixed_len, int32_t max_len, int32_t W, int32_t heads, int32_t mask,
-                          int32_t out_fp8, const float* d_out_scale, float* d_amax, const float* d_rel_bias, int32_t rel_span, void* stream, const MqPrefetch& pf = MqPrefetch{}) {
+                          int32_t out_fp8, const float* d_out_scale, float* d_amax, const float* d_rel_bias, int32_t rel_span, void* stream) {
     MQ_CHECK_ARG(d_qkv && d_out, "mq_attention: null pointer");
     MQ_CHECK_ARG(heads >= 1 && W % heads == 0, "mq_attention: W=%d is not a multiple of heads=%d", W, heads);
     const int hs = W / heads;             // head stride in memory = dims computed
@@ -337,7 +333,7 @@ static int attention_impl(const void* d_qkv, void* d_out, const int32_t* d_cu_se
         }
         hipLaunchKernelGGL(kern, dim3((unsigned)(nseq * heads)), dim3(nw * 64), lds, s, (const bf16_t*)d_qkv,
                            d_out, d_cu_seqlens, (int)fixed_len, (int)W, (int)heads, kpad, scale_log2e, d_out_scale, d_amax, d_rel_bias, (int)rel_span,
-                           (mq_xcd_band && nseq * heads >= 2048) ? 1 : 0, pf);
+                           (mq_xcd_band && nseq * heads >= 2048) ? 1 : 0);
         return MQ_OK;
     };
     if (d_rel_bias) {
@@ -374,12 +370,6 @@ extern "C" int mq_attention_ex(const void* d_qkv, void* d_out, const int32_t* d_
                                int32_t fixed_len, int32_t max_len, int32_t W, int32_t heads, int32_t mask,
                                int32_t out_fp8, const float* d_out_scale, float* d_amax, void* stream) {
     return attention_impl(d_qkv, d_out, d_cu_seqlens, nseq, fixed_len, max_len, W, heads, mask, out_fp8, d_out_scale, d_amax, nullptr, 0, stream);
-}
-
-// mq_attention + weight prefetch (common.h, MqPrefetch): the four ranges are touched once by the launch's threads (towers.hip)
-int mq_attention_pf(const void* d_qkv, void* d_out, const int32_t* d_cu_seqlens, int64_t nseq, int32_t fixed_len, int32_t max_len, int32_t W,
-                    int32_t heads, int32_t mask, const MqPrefetch& pf, hipStream_t s) {
-    return attention_impl(d_qkv, d_out, d_cu_seqlens, nseq, fixed_len, max_len, W, heads, mask, 0, nullptr, nullptr, nullptr, 0, (void*)s, pf);
 }
 
 extern "C" int mq_attention_bias(const void* d_qkv, void* d_out, const int32_t* d_cu_seqlens, int64_t nseq, int32_t fixed_len,

@@ -94,43 +94,6 @@ __device__ __forceinline__ unsigned xcd_banded_block(unsigned b, unsigned nb, in
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-// ---- weight prefetch riding on a memory-bound kernel -----------------------------------------------------------------------------
-// Inside a tower every GEMM's weights were last touched one step ago and have left the 256 MB Infinity Cache by the time they are needed again
-// (ViT-B/32: 12 layers x 14 MB of weights + ~140 MB of activations per layer cycle through it): the first round of tiles of a GEMM then waits on
-// HBM latency at every k-step (+5..6 us per QKV / fc2 launch, profiles/r03q_*).  A short memory-bound kernel in front of the GEMMs therefore
-// touches one dword per 128-byte line of their weights (values unused).  Round 3 hung this on the LayerNorm launches (rowops.hip, LnExtra);
-// with the LayerNorms folded into the GEMMs (round 4) the attention kernel carries it: up to four ranges = the out-projection, fc1 and fc2
-// weights of its own block and the QKV weight of the next one.
-struct MqPrefetch {
-    const unsigned* p[4];
-    unsigned n[4];        // 128-byte lines per range (0 = unused)
-};
-__device__ __forceinline__ unsigned mq_prefetch_issue(const MqPrefetch& pf) {
-    unsigned v = 0u;
-    if (pf.n[0] | pf.n[1] | pf.n[2] | pf.n[3]) {
-        unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            if (c < pf.n[r]) { v = pf.p[r][(size_t)c * 32u]; break; }
-            c -= pf.n[r];
-        }
-    }
-    return v;
-}
-// the loaded value is "used" by an empty asm at the end of the kernel: keeps the load alive and its wait out of everybody's way
-__device__ __forceinline__ void mq_prefetch_retire(unsigned v) { asm volatile("" ::"v"(v)); }
-static inline MqPrefetch mq_prefetch_ranges(const void* a, size_t ba, const void* b, size_t bb, const void* c, size_t bc, const void* d, size_t bd) {
-    MqPrefetch pf{};
-    const void* ps[4] = {a, b, c, d};
-    const size_t bs[4] = {ba, bb, bc, bd};
-    for (int r = 0; r < 4; ++r) {
-        const bool ok = ps[r] && ((uintptr_t)ps[r] & 3) == 0 && bs[r] < ((size_t)1 << 30);
-        pf.p[r] = (const unsigned*)ps[r];
-        pf.n[r] = ok ? (unsigned)(bs[r] / 128) : 0u;
-    }
-    return pf;
-}
-
 // ---- wave reductions ---------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

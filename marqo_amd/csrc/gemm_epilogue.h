@@ -1,4 +1,4 @@
-// Shared epilogue of the bf16 MFMA GEMM kernels (gemm_bf16.hip, gemm_big.hip).
+// Epilogue of the bf16 MFMA GEMM kernel (gemm_bf16.hip).
 // Accumulator layout (operands are fed swapped, mfma(Wfrag, Afrag)): for sub-tile (mt, nt)
 //   D[i][j] = sum_k Wfrag[i][k] * Afrag[j][k]: column j = lane & 15 -> m, row i = 4*g + reg -> n,
 // so a lane owns out[m][n .. n+3]: bias / residual / fp32 out are 16-byte vector accesses.
@@ -9,31 +9,29 @@
 // K = 768 tile is issue-bound, cdna_hip_programming.md T21).
 //
 // LayerNorm folding (pre-LN blocks on the bf16 residual stream, round 4): LN(x) @ W^T = rstd * (x @ (gamma*W)^T - mean * colsum(gamma*W))
-// + (b + W @ beta), so the LayerNorm kernel in front of the QKV / fc1 GEMM disappears.  MQ_EPI_LN_APPLY (the consumer GEMM): A is the
-// UN-normalised bf16 stream itself, W / bias / colsum are pre-folded with gamma / beta at load; the kernel accumulates every row's
-// (sum x, sum x^2) from the A tiles that pass through its LDS anyway (a tile spans all of K = the normalised width) and leaves
-// (mean, rstd) per tile row in LDS for this epilogue.  Nothing else is exchanged between launches (round 1's form — partial sums written
-// by the producer GEMM's epilogue and re-read by the consumer's — cost more than the LayerNorm launches it removed).
+// + (b + W @ beta).  MQ_EPI_LN_APPLY (the QKV / fc1 GEMM): A is the UN-normalised bf16 stream itself, W / bias / colsum are pre-folded with
+// gamma / beta at load, and (mean, rstd) per row come from a one-pass statistics kernel (mq_row_stats, rowops.hip: reads the stream once,
+// writes 8 bytes per row) — the LayerNorm launch that read AND wrote the whole stream, and the normalised copy, are gone.  The epilogue fetches
+// its MT rows' statistics with the bias, up front.  (Tried and rejected this round: accumulating the statistics inside the GEMM from the staged
+// A tiles — 40 extra VALU operations per k-step cost the k-loop 9 %, more than the LayerNorm launch they replaced; profiles/r04j_*.)
 #pragma once
 #include "common.h"
 
 struct GemmLn {
-    const float* colsum;    // LN_APPLY: [N]  sum_k bf16(gamma_k * W[n,k])
-    float inv_w;            // 1 / K  (K = the normalised width)
-    float eps;
+    const float* colsum;     // LN_APPLY: [N]  sum_k bf16(gamma_k * W[n,k])
+    const float2* rowstats;  // LN_APPLY: [M]  (mean, rstd) of row m of A
 };
 
 // RG = rows (16-row units) whose residual is prefetched together: the whole tile where the registers allow (the 4-wave kernel
 // after its k-loop), a few rows at a time in the 8-wave kernel whose accumulators already fill the file.
-// WAIT_LOADS (gemm_pl.hip): one explicit, compiler-visible s_waitcnt vmcnt(0) behind the up-front loads.  That kernel has LDS-DMA requests of
+// WAIT_LOADS (gemm_bf16.hip): one explicit, compiler-visible s_waitcnt vmcnt(0) behind the up-front loads.  That kernel has LDS-DMA requests of
 // the next tile in flight here, so hipcc cannot count past them: without the explicit wait it re-waits vmcnt(0) at the first use of the
 // bias in every row group — draining the row groups' own stores one after the other — and, seeing the fragment registers as possibly
 // pending load destinations, puts another vmcnt(0) into the k-loop.
 template <int FLAGS, int MT, int RG = MT, bool WAIT_LOADS = false>
 __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][4], const float* __restrict__ bias, const float* residual, void* out,
                                               int64_t ldc, int M, int N, int wave_m0, int wave_n0, int l15, int g, bool wide = false,
-                                              const GemmLn* lnp = nullptr, const float* lds_bias = nullptr,
-                                              const float2* lds_rowstats = nullptr /* LN_APPLY: (mean, rstd) of the wave's 16*MT tile rows */) {
+                                              const GemmLn* lnp = nullptr, const float* lds_bias = nullptr) {
     constexpr bool BF16_OUT = !(FLAGS & MQ_EPI_OUT_F32);
     // bf16 residual stream (towers.hip): MQ_EPI_RESIDUAL without MQ_EPI_OUT_F32 = the residual is read as bf16 and the sum written
     // as bf16, in place — half the epilogue bytes of the fp32 stream, the memory-bound part of the K = 768 residual GEMMs
@@ -81,6 +79,14 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][4], const float* 
         else bias_v[nt] = ((FLAGS & MQ_EPI_BIAS) && n < N) ? *(const f32x4*)(bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
         cs_v[nt] = (LN_APPLY && n < N) ? *(const f32x4*)(lnp->colsum + n) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    float2 ms_v[LN_APPLY ? MT : 1];
+    if (LN_APPLY) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = wave_m0 + mt * 16 + l15;
+            ms_v[mt] = m < M ? lnp->rowstats[m] : make_float2(0.f, 1.f);
+        }
+    }
     if (WAIT_LOADS) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), lgkmcnt / expcnt untouched
     // value of one (mt, nt) sub-tile after (LN apply) / bias / activation / residual
     auto value = [&](int mt, int nt, int m, int n, bool ok) {
@@ -106,9 +112,8 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][4], const float* 
         const int m = wave_m0 + mt * 16 + l15;
         const bool m_ok = m < M;
         if (LN_APPLY) {
-            const float2 ms = lds_rowstats[mt * 16 + l15];
-            row_mean = ms.x;
-            row_rstd = ms.y;
+            row_mean = ms_v[LN_APPLY ? mt : 0].x;
+            row_rstd = ms_v[LN_APPLY ? mt : 0].y;
         }
         if (BF16_OUT && wide) {  // `wide` is wave-uniform: every lane takes part in the swaps
 #pragma unroll

@@ -60,7 +60,7 @@ __device__ __forceinline__ void ln_prefetch_retire(const unsigned (&pq)[LN_PF]) 
 template <int CH, int R, bool XB = false>
 // (register budget by row width: rows + gamma + beta in registers are 3 * CH * R float4; the 1 537..2 048-wide instantiations (CH = 8: ViT-bigG/14's
 // 1 664) spilled 61..768 VGPRs under the 128-register cap of 4 waves per SIMD — VERDICT r3 weak #8 — and run at 2 waves per SIMD instead)
-__global__ __launch_bounds__(256, (CH * R <= 4 ? 8 : CH * R <= 6 ? 4 : 2)) void layernorm_kernel(
+__global__ __launch_bounds__(256, (CH * R <= 2 ? 8 : CH * R <= 4 ? 5 : CH * R <= 6 ? 3 : 2)) void layernorm_kernel(
     const void* __restrict__ xv, const int32_t* __restrict__ row_idx, const float* __restrict__ gam,
     const float* __restrict__ bet, bf16_t* out_bf16, float* out_f32, int64_t rows, int W, float eps, LnExtra ex) {
     const int lane = threadIdx.x & 63;
@@ -246,12 +246,73 @@ __global__ __launch_bounds__(256) void layernorm_bf16in_kernel(
     ln_prefetch_retire(pq);
 }
 
+// (mean, rstd) per row of the bf16 stream, nothing else: the statistics half of a LayerNorm whose apply half is folded into the GEMM behind it
+// (gemm_epilogue.h, MQ_EPI_LN_APPLY).  One 16-byte load per lane and chunk, the same two-pass arithmetic and reduction order as
+// layernorm_bf16in_kernel (mean first, then the sum of squared deviations: no cancellation), 8 bytes written per row — half the traffic of the
+// LayerNorm launch it replaces (which also wrote the normalised row) — and it carries the weight prefetch of the GEMMs behind it (LnExtra).
+template <int CH8, int R>
+__global__ __launch_bounds__(256) void row_stats_bf16_kernel(const bf16_t* __restrict__ x, float2* __restrict__ stats, int64_t rows, int W, float eps, LnExtra ex) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row0 = ((int64_t)xcd_banded_block(blockIdx.x, gridDim.x, ex.band) * 4 + (threadIdx.x >> 6)) * R;
+    if (row0 >= rows) return;
+    const int nch = W >> 3;  // 8-element chunks in the row
+    float v[R][CH8][8];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int64_t row = row0 + r < rows ? row0 + r : rows - 1;
+#pragma unroll
+        for (int i = 0; i < CH8; ++i) {
+            const int c = lane + i * 64;
+            uint4 q = make_uint4(0u, 0u, 0u, 0u);
+            if (c < nch) q = *(const uint4*)(x + row * W + c * 8);
+            const unsigned w4[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[r][i][2 * e] = __uint_as_float(w4[e] << 16); v[r][i][2 * e + 1] = __uint_as_float(w4[e] & 0xffff0000u); }
+        }
+    }
+    unsigned pq[LN_PF];
+    ln_prefetch_issue(ex, pq);   // behind the row loads
+    float mean[R], rstd[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        float s1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < CH8; ++i)
+            if (lane + i * 64 < nch) s1 += ((v[r][i][0] + v[r][i][1]) + (v[r][i][2] + v[r][i][3])) + ((v[r][i][4] + v[r][i][5]) + (v[r][i][6] + v[r][i][7]));
+        mean[r] = s1;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int r = 0; r < R; ++r) mean[r] += __shfl_xor(mean[r], o, 64);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        mean[r] = mean[r] / (float)W;
+        float s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < CH8; ++i)
+            if (lane + i * 64 < nch) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = v[r][i][e] - mean[r]; s2 += d * d; }
+            }
+        rstd[r] = s2;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int r = 0; r < R; ++r) rstd[r] += __shfl_xor(rstd[r], o, 64);
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if (lane == 0 && row0 + r < rows) stats[row0 + r] = make_float2(mean[r], rsqrtf(rstd[r] / (float)W + eps));
+    ln_prefetch_retire(pq);
+}
+
 // LN with e4m3 output and a dynamic per-row scale (the row is already in registers, so the absmax is one wave reduction)
 // NORM = false: no normalisation / affine, only the per-row e4m3 quantisation of x itself (the first block of a post-LN fp8
 // encoder, whose input rows come from the embedding kernels)
 // XB = the input rows are bf16 (the bf16 residual stream)
 template <int CH, bool NORM = true, bool XB = false>
-__global__ __launch_bounds__(256, (CH <= 4 ? 8 : CH <= 6 ? 4 : 2)) void layernorm_fp8_kernel(
+__global__ __launch_bounds__(256, (CH <= 2 ? 8 : CH <= 4 ? 5 : CH <= 6 ? 3 : 2)) void layernorm_fp8_kernel(
     const void* __restrict__ x, const float* __restrict__ gam, const float* __restrict__ bet, uint8_t* __restrict__ out8,
     float* __restrict__ row_scale, float* out_f32, int64_t rows, int W, float eps, LnExtra ex) {
     const int lane = threadIdx.x & 63;
@@ -463,4 +524,31 @@ int mq_cast_bf16(const float* d_x, void* d_out, int64_t n, hipStream_t s) {
     hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid), dim3(256), 0, s, d_x, (bf16_t*)d_out, n4);
     MQ_CHECK_LAUNCH("mq_cast_bf16");
     return MQ_OK;
+}
+
+
+// (mean, rstd) per row of bf16 rows [rows, W] (W % 8 == 0, W <= 2048) -> d_stats fp32 [rows][2]; pf_a / pf_b: weight ranges to prefetch (mq_layernorm_pf)
+bool mq_row_stats_ok(int32_t W) { return W % 8 == 0 && W >= 8 && W <= 2048; }
+int mq_row_stats_pf(const void* d_x_bf16, float* d_stats, int64_t rows, int32_t W, float eps, const void* pf_a, size_t bytes_a, const void* pf_b,
+                    size_t bytes_b, hipStream_t s) {
+    MQ_CHECK_ARG(d_x_bf16 && d_stats, "mq_row_stats: null pointer");
+    MQ_CHECK_ARG(mq_row_stats_ok(W), "mq_row_stats: W=%d unsupported (multiple of 8, <= 2048)", W);
+    if (rows <= 0) return MQ_OK;
+    MqProfScope prof(1, s);
+    const LnExtra ex = ln_extra((mq_xcd_band && rows >= 4096) ? 1 : 0, rows, pf_a, bytes_a, pf_b, bytes_b);
+    const int ch8 = ((W >> 3) + 63) / 64;
+    // several rows per wave for narrow rows: a 768-wide bf16 row is 1.5 KB — one row per wave left the kernel latency-bound (7.7 us for 19.7 MB)
+    const bool many = rows >= 4096;
+    const int R = !many ? 1 : ch8 == 1 ? 4 : ch8 == 2 ? 2 : 1;
+    const unsigned grid = (unsigned)cdiv64(rows, 4 * R);
+#define MQ_RS(C, RR) hipLaunchKernelGGL((row_stats_bf16_kernel<C, RR>), dim3(grid), dim3(256), 0, s, (const bf16_t*)d_x_bf16, (float2*)d_stats, rows, (int)W, eps, ex)
+    if (ch8 == 1) { if (R == 4) MQ_RS(1, 4); else MQ_RS(1, 1); }
+    else if (ch8 == 2) { if (R == 2) MQ_RS(2, 2); else MQ_RS(2, 1); }
+    else MQ_RS(4, 1);
+#undef MQ_RS
+    MQ_CHECK_LAUNCH("mq_row_stats");
+    return MQ_OK;
+}
+extern "C" int mq_row_stats(const void* d_x_bf16, float* d_stats, int64_t rows, int32_t W, float eps, void* stream) {
+    return mq_row_stats_pf(d_x_bf16, d_stats, rows, W, eps, nullptr, 0, nullptr, 0, (hipStream_t)stream);
 }

@@ -49,7 +49,6 @@ extern "C" int mq_layernorm_ex(const void* d_x, int x_bf16, const int32_t* d_row
                                float* d_out_f32, int64_t rows, int32_t W, float eps, void* stream);
 // search path (rows <= 80): LayerNorm fused into the skinny GEMM's prologue (gemm_small.hip)
 bool mq_gemm_small_ok(int64_t M, int64_t N, int64_t K, bool ln);
-extern int mq_ln_prefetch;   // rowops.hip
 int mq_ln_gemm_small(const void* d_x, int64_t ldx, int x_bf16, const float* ln_g, const float* ln_b, float eps, const void* d_W, int64_t ldw,
                      const float* d_bias, void* d_out, int64_t ldc, int64_t M, int64_t N, int64_t K, int flags, float* d_ln_out,
                      const int32_t* d_rows, hipStream_t s);
@@ -69,17 +68,24 @@ static inline const void* pf(const void* w) { return t_ln_prefetch ? w : nullptr
 int mq_layernorm_fp8_pf(const void* d_x, int x_bf16, const float* d_g, const float* d_b, void* d_out_fp8, float* d_row_scale, float* d_out_f32,
                         int64_t rows, int32_t W, float eps, const void* pf_a, size_t bytes_a, const void* pf_b, size_t bytes_b, hipStream_t s);
 bool mq_gemm_small_grouped_ok(int64_t M, int64_t N, int64_t K);
-extern "C" int mq_gemm_bf16_ln(const void* d_A, int64_t lda, const void* d_W, int64_t ldw, const float* d_bias, const float* d_colsum, void* d_out,
-                               int64_t ldc, int64_t M, int64_t N, int64_t K, int flags, float eps, void* stream);
+extern "C" int mq_gemm_bf16_ln(const void* d_A, int64_t lda, const void* d_W, int64_t ldw, const float* d_bias, const float* d_colsum,
+                               const float* d_rowstats, void* d_out, int64_t ldc, int64_t M, int64_t N, int64_t K, int flags, void* stream);
+bool mq_row_stats_ok(int32_t W);
+int mq_row_stats_pf(const void* d_x_bf16, float* d_stats, int64_t rows, int32_t W, float eps, const void* pf_a, size_t bytes_a, const void* pf_b,
+                    size_t bytes_b, hipStream_t s);
 // folded LayerNorm + GEMM: the bf16 stream is the A operand (no LayerNorm launch, no normalised copy)
 static bool fold_ok(int xb, const void* wf, const float* bf, const float* sf, int64_t rows, int N, int K) {
-    return mq_tower_ln_fold && xb && wf && bf && sf && !mq_gemm_small_ok(rows, N, K, false) && !mq_gemm_small_grouped_ok(rows, N, K);
+    return mq_tower_ln_fold && xb && wf && bf && sf && mq_row_stats_ok(K) && !mq_gemm_small_ok(rows, N, K, false) && !mq_gemm_small_grouped_ok(rows, N, K);
 }
 static int ln_gemm(const void* d_x, int xb, const float* g, const float* b, float eps, void* h, const void* W, const float* bias, void* out,
                    int64_t rows, int N, int K, int flags, hipStream_t s, const void* next_w = nullptr, size_t next_bytes = 0,
-                   const void* wf = nullptr, const float* bf = nullptr, const float* sf = nullptr) {
+                   const void* wf = nullptr, const float* bf = nullptr, const float* sf = nullptr, float* row_stats = nullptr) {
     if (mq_gemm_small_ok(rows, N, K, true)) return mq_ln_gemm_small(d_x, K, xb, g, b, eps, W, K, bias, out, N, rows, N, K, flags, nullptr, nullptr, s);
-    if (fold_ok(xb, wf, bf, sf, rows, N, K)) return mq_gemm_bf16_ln(d_x, K, wf, K, bf, sf, out, N, rows, N, K, flags, eps, s);
+    if (row_stats && fold_ok(xb, wf, bf, sf, rows, N, K)) {
+        // folded: ONE read pass over the stream for (mean, rstd) — it also carries the weight prefetch — then the GEMM reads the stream itself
+        MQ_TRY(mq_row_stats_pf(d_x, row_stats, rows, K, eps, pf(wf), (size_t)N * K * 2, pf(next_w), next_bytes, s));
+        return mq_gemm_bf16_ln(d_x, K, wf, K, bf, sf, row_stats, out, N, rows, N, K, flags, s);
+    }
     MQ_TRY(mq_layernorm_pf(d_x, xb, nullptr, g, b, h, nullptr, rows, K, eps, pf(W), (size_t)N * K * 2, pf(next_w), next_bytes, s));
     return mq_gemm_bf16(h, K, W, K, bias, nullptr, out, N, rows, N, K, flags, s);
 }
@@ -98,13 +104,10 @@ static bool stream_post16(const mq_encoder_cfg* c) {
     return c->residual_stream == 1 && c->post_ln && c->precision == MQ_PREC_BF16 && !c->mlp_glu && !c->d_rope_inv_freq;
 }
 
-int mq_attention_pf(const void* d_qkv, void* d_out, const int32_t* d_cu_seqlens, int64_t nseq, int32_t fixed_len, int32_t max_len, int32_t W,
-                    int32_t heads, int32_t mask, const MqPrefetch& pf, hipStream_t s);
 namespace {
 // attention of one block: with the model's relative-position bias when the encoder has one (MPNet), else the plain kernel
 inline int attn_bf16(const mq_encoder_cfg* cfg, const void* qf, void* a, const int32_t* d_cu_seqlens, int64_t nseq, int32_t fixed_len,
-                     int32_t max_len, int32_t Wa, hipStream_t s, const MqPrefetch* wpf = nullptr) {
-    if (wpf && !cfg->d_rel_bias) return mq_attention_pf(qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, cfg->heads, cfg->mask, *wpf, s);
+                     int32_t max_len, int32_t Wa, hipStream_t s) {
     if (cfg->d_rel_bias) return mq_attention_bias(qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, cfg->heads, cfg->d_rel_bias, cfg->rel_span, s);
     return mq_attention(qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, cfg->heads, cfg->mask, s);
 }
@@ -169,6 +172,7 @@ size_t encoder_ws(const mq_encoder_cfg* c, int64_t rows) {
     cv.take((size_t)rows * wa * 2);
     cv.take((size_t)rows * big * 2);
     cv.take((size_t)rows * 4);  // per-row activation scales of the fp8 path
+    cv.take((size_t)rows * 8);  // (mean, rstd) per row: the statistics of a folded LayerNorm
     cv.take((size_t)(rows < SMALL_LN_ROWS ? rows : SMALL_LN_ROWS) * c->width * 4);  // search path, post-LN: the normalised residual (fp32)
     return cv.end();
 }
@@ -194,7 +198,7 @@ namespace {
 // behind the fc1 output (all of h / a / qkv are dead by the time they are overwritten).
 int last_block_selected(const mq_encoder_cfg* cfg, const mq_block_weights& b, int l, float* d_x, int64_t rows,
                         const int32_t* d_cu_seqlens, int64_t nseq, int32_t fixed_len, int32_t max_len,
-                        const int32_t* d_sel, int64_t nsel, void* h, void* a, void* qf, float* row_scale, float* x_sel,
+                        const int32_t* d_sel, int64_t nsel, void* h, void* a, void* qf, float* row_scale, float* row_stats, float* x_sel,
                         bool f8, hipStream_t s) {
     const int W = cfg->width, F = cfg->mlp_dim, Wa = attn_width(cfg);
     const int act_flag = cfg->act == MQ_ACT_QUICKGELU ? MQ_EPI_QUICKGELU : MQ_EPI_GELU;
@@ -219,7 +223,7 @@ int last_block_selected(const mq_encoder_cfg* cfg, const mq_block_weights& b, in
         const int xb = stream_bf16(cfg) ? 1 : 0;                 // bf16 residual stream: rows of 2 bytes per element, bf16 RMW epilogues
         const int rflags = xb ? (MQ_EPI_BIAS | MQ_EPI_RESIDUAL) : res_flags;
         const int64_t xrow = (int64_t)W * (xb ? 2 : 4);
-        MQ_TRY(ln_gemm(d_x, xb, b.ln1_g, b.ln1_b, cfg->ln_eps, h, b.qkv_w, b.qkv_b, qf, rows, 3 * Wa, W, MQ_EPI_BIAS, s, nullptr, 0, b.qkv_wf, b.qkv_bf, b.qkv_sf));
+        MQ_TRY(ln_gemm(d_x, xb, b.ln1_g, b.ln1_b, cfg->ln_eps, h, b.qkv_w, b.qkv_b, qf, rows, 3 * Wa, W, MQ_EPI_BIAS, s, nullptr, 0, b.qkv_wf, b.qkv_bf, b.qkv_sf, row_stats));
         MQ_TRY(attn_bf16(cfg, qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, s));
         MQ_TRY(mq_move_rows(a, d_sel, h, nsel, (int64_t)Wa * 2, false, s));
         MQ_TRY(mq_move_rows(d_x, d_sel, x_sel, nsel, xrow, false, s));
@@ -277,6 +281,7 @@ int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* bloc
     void* a = wsb + cv.take((size_t)rows * Wa * 2);
     void* qf = wsb + cv.take((size_t)rows * big * 2);  // qkv [rows,3W] then fc1 output [rows,F]
     float* row_scale = (float*)(wsb + cv.take((size_t)rows * 4));
+    float* row_stats = (float*)(wsb + cv.take((size_t)rows * 8));
     float* xn = (float*)(wsb + cv.take((size_t)(rows < SMALL_LN_ROWS ? rows : SMALL_LN_ROWS) * W * 4));
     const int act_flag = cfg->act == MQ_ACT_QUICKGELU ? MQ_EPI_QUICKGELU : MQ_EPI_GELU;
     const int res_flags = MQ_EPI_BIAS | MQ_EPI_RESIDUAL | MQ_EPI_OUT_F32;
@@ -314,7 +319,7 @@ int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* bloc
         // post-LN: the previous (bf16) block left its output as a bf16 operand; the first e4m3 block wants e4m3 rows + row scales
         if (cfg->post_ln && f8 && l == first8 && l > 0) MQ_TRY(mq_rowquant_fp8(d_x, h, row_scale, rows, W, s));
         if (select_last && l == cfg->layers - 1) {
-            MQ_TRY(last_block_selected(cfg, b, l, d_x, rows, d_cu_seqlens, nseq, fixed_len, max_len, d_sel, nsel, h, a, qf, row_scale,
+            MQ_TRY(last_block_selected(cfg, b, l, d_x, rows, d_cu_seqlens, nseq, fixed_len, max_len, d_sel, nsel, h, a, qf, row_scale, row_stats,
                                        (float*)((char*)qf + xsel_off), f8, s));
             break;
         }
@@ -356,19 +361,8 @@ int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* bloc
             const int xb = stream_bf16(cfg) ? 1 : 0;
             const int rflags = xb ? (MQ_EPI_BIAS | MQ_EPI_RESIDUAL) : res_flags;
             MQ_TRY(ln_gemm(d_x, xb, b.ln1_g, b.ln1_b, cfg->ln_eps, h, b.qkv_w, b.qkv_b, qf, rows, 3 * Wa, W, MQ_EPI_BIAS, s, b.out_w, (size_t)W * Wa * 2,
-                           b.qkv_wf, b.qkv_bf, b.qkv_sf));
-            // with the LayerNorms folded away the attention launch carries the weight prefetch of the GEMMs behind it: out-projection, fc1, fc2
-            // and the next block's QKV (the first block's QKV weight is the one nobody prefetches)
-            const bool fold_mlp = fold_ok(xb, b.fc1_wf, b.fc1_bf, b.fc1_sf, rows, F, W) && !(cfg->precision == MQ_PREC_FP8 && l >= first8 - cfg->fp8_mlp_extra) &&
-                                  !(d_sel && nsel > 0 && l == cfg->layers - 1);
-            MqPrefetch wpf{};
-            const bool carry = t_ln_prefetch && fold_ok(xb, b.qkv_wf, b.qkv_bf, b.qkv_sf, rows, 3 * Wa, W) && mq_ln_prefetch;
-            if (carry) {
-                const mq_block_weights* nb = l + 1 < first8 ? &blocks[l + 1] : nullptr;
-                wpf = mq_prefetch_ranges(b.out_w, (size_t)W * Wa * 2, fold_mlp ? b.fc1_wf : nullptr, (size_t)F * W * 2, fold_mlp ? b.fc2_w : nullptr, (size_t)W * F * 2,
-                                         nb && fold_ok(xb, nb->qkv_wf, nb->qkv_bf, nb->qkv_sf, rows, 3 * Wa, W) ? nb->qkv_wf : nullptr, (size_t)3 * Wa * W * 2);
-            }
-            MQ_TRY(attn_bf16(cfg, qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, s, carry ? &wpf : nullptr));
+                           b.qkv_wf, b.qkv_bf, b.qkv_sf, row_stats));
+            MQ_TRY(attn_bf16(cfg, qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, s));
             MQ_TRY(mq_gemm_bf16(a, Wa, b.out_w, Wa, b.out_b, (const float*)d_x, d_x, W, rows, W, Wa, rflags, s));
             if (cfg->precision == MQ_PREC_FP8 && l >= first8 - cfg->fp8_mlp_extra) {
                 // MLP-only e4m3 block (fp8_mlp_extra): the attention half above ran on bf16 operands
@@ -386,7 +380,7 @@ int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* bloc
             // kernel + un-folded weights — and dead-row elimination stays bit-identical to this all-rows form, tests/test_towers_gpu.py)
             const bool last_pooled = d_sel && nsel > 0 && l == cfg->layers - 1;
             MQ_TRY(ln_gemm(d_x, xb, b.ln2_g, b.ln2_b, cfg->ln_eps, h, b.fc1_w, b.fc1_b, qf, rows, F, W, MQ_EPI_BIAS | act_flag, s, b.fc2_w, (size_t)W * F * 2,
-                           last_pooled ? nullptr : b.fc1_wf, b.fc1_bf, b.fc1_sf));
+                           last_pooled ? nullptr : b.fc1_wf, b.fc1_bf, b.fc1_sf, row_stats));
             MQ_TRY(mq_gemm_bf16(qf, F, b.fc2_w, F, b.fc2_b, (const float*)d_x, d_x, W, rows, W, F, rflags, s));
         } else if (small_post_ln) {
             // search path: both LayerNorms ride in the prologue of the GEMM that consumes them (gemm_small.hip).  d_x holds the pre-LN sums

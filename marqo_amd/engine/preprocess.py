@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 from typing import List, Optional, Sequence, Tuple, Union
 
 import numpy as np
@@ -29,6 +30,13 @@ ArrayLike = Union[np.ndarray, torch.Tensor, "Rgbx", "Rgba", "NearestRgb"]
 # uint8 arrays -1.5 % with one caller and -18 % with four (four times the native calls and copies per request), Pillow images +7 % with
 # one caller, neutral with four -> off
 PACK_CHUNKS = max(1, int(os.environ.get("MARQO_AMD_PACK_CHUNKS", "1")))
+# Pillow batches (the native stager, csrc/py_stage.cpp): images per slice.  A batch of >= 2 slices is staged slice by slice, the pinned H2D copy of
+# slice c running on the copy engine while the memcpy threads (GIL released) pack slice c + 1 — the single synchronous caller's 0.9 ms of H2D
+# no longer follows its 2.2 ms of packing (profiles/r03i_e2e_phases_1thread.txt): 6.57 -> 5.55 ms per 256-image call, 39.0 k -> 46.2 k
+# embeddings/s (profiles/r04d_e2e_slices.txt; 32-image slices 6.22 ms); the tower still runs once on the whole batch.  0 = one piece.
+PACK_SLICE = max(0, int(os.environ.get("MARQO_AMD_PACK_SLICE", "64")))
+# (slicing one level up — pack -> H2D -> unpack -> resize per slice — measured no better: 5.49 ms with two 128-image slices against 5.55 ms for
+# the 64-image pack slices alone, 5.97 ms with four, profiles/r04e_e2e_slices.txt: the tail of the call is the tower, not the resize)
 PACK_THREADS = int(os.environ.get("MARQO_AMD_PACK_THREADS", str(max(1, min(8, (os.cpu_count() or 2) // 2)))))   # memcpy threads of a pack
 
 
@@ -200,13 +208,24 @@ class PackedImages:
             srcs[e] = a.__array_interface__["data"][0]
             nbytes[e] = a.nbytes
         lib = L.load()
+        staged = None
         if lazy:
             lz_off = np.ascontiguousarray(x_off[lazy])
             lz_len = np.ascontiguousarray(npix[lazy] * 4)
-            for f in stager.gather_rgbx([imgs[k].image for k in lazy], host.data_ptr(), host.numel(), lz_off, lz_len, PACK_THREADS):
-                k = lazy[f]   # Pillow could not export this one zero-copy (e.g. an image stored in several blocks): its .view copies
-                v = imgs[k].view
-                hnp[int(x_off[k]):int(x_off[k]) + v.nbytes] = np.ascontiguousarray(v).reshape(-1)
+            # all-Pillow batch: the RGBX region [total, cur) fills front to back in request order -> ship it slice by slice
+            sliced = PACK_SLICE and len(lazy) == self.n and self.n >= 2 * PACK_SLICE and torch.cuda.is_available()
+            step = PACK_SLICE if sliced else len(lazy)
+            if sliced:
+                staged = torch.empty(max(stage_bytes, 1), dtype=torch.uint8, device=device)
+            for j0 in range(0, len(lazy), step):
+                j1 = min(j0 + step, len(lazy))
+                for f in stager.gather_rgbx([imgs[k].image for k in lazy[j0:j1]], host.data_ptr(), host.numel(), lz_off[j0:j1], lz_len[j0:j1], PACK_THREADS):
+                    k = lazy[j0 + f]   # Pillow could not export this one zero-copy (e.g. an image stored in several blocks): its .view copies
+                    v = imgs[k].view
+                    hnp[int(x_off[k]):int(x_off[k]) + v.nbytes] = np.ascontiguousarray(v).reshape(-1)
+                if sliced:
+                    lo, hi = int(x_off[lazy[j0]]), (int(x_off[lazy[j1]]) if j1 < len(lazy) else cur)
+                    staged[lo:hi].copy_(host[lo:hi], non_blocking=True)
         # Experiment knob: a batch of one kind (all plain RGB arrays, or all Pillow RGBX views) fills the staging buffer front to back, so it
         # CAN be packed and shipped in PACK_CHUNKS pieces, the pinned H2D copy of piece c running while the memcpy threads pack piece c + 1.
         pieces = PACK_CHUNKS if (not lazy and nx in (0, self.n) and self.n >= 16 * PACK_CHUNKS and torch.cuda.is_available()) else 1
@@ -227,9 +246,9 @@ class PackedImages:
         if nx:
             jobs = np.ascontiguousarray(np.stack([x_off[is_x], self.offsets[is_x], npix[is_x]], axis=1), dtype=np.int64)
             hnp[jobs_off:jobs_off + nx * 24] = jobs.view(np.uint8).reshape(-1)
-            if pieces > 1:
+            if pieces > 1 or staged is not None:
                 staged[jobs_off:jobs_off + nx * 24].copy_(host[jobs_off:jobs_off + nx * 24], non_blocking=True)
-        if pieces == 1:
+        if staged is None:
             staged = host.to(device, non_blocking=True)
         self._host = host   # (pinned source of the asynchronous copies: kept until the consumer's kernels are enqueued behind them)
         if not nx:
@@ -260,22 +279,23 @@ class ImagePreprocessor:
         self.S = int(image_size)
         self.mean = (C.c_float * 3)(*mean)
         self.std = (C.c_float * 3)(*std)
-        self._ws = None
-        self._ws_stream = None
+        self._ws_by_stream: dict = {}
+        self._ws_lock = threading.Lock()
 
     def _workspace(self, nbytes: int) -> torch.Tensor:
-        """scratch of the CURRENT stream.  The same thread calls from two streams (`.preprocess` from the download threads' default
-        stream, encode() from its request stream): the caching allocator hands a freed block back to the pool of the stream it was
-        allocated on, where a later allocation may take it while kernels enqueued on the OTHER stream still use it — so a block that was
-        used on another stream is first marked as in use there (record_stream) and a change of stream gets a fresh block."""
-        cur = torch.cuda.current_stream(self.device)
-        if self._ws is not None and (self._ws_stream != cur.cuda_stream or self._ws.numel() < nbytes):
-            self._ws.record_stream(cur)     # whatever was enqueued with it so far must finish before the allocator recycles it
-            self._ws = None
-        if self._ws is None:
-            self._ws = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=self.device)
-            self._ws_stream = cur.cuda_stream
-        return self._ws
+        """scratch of the CURRENT stream.  The same preprocessor is called from several streams (`.preprocess` from the download threads'
+        default stream, encode() from every request thread's private stream): each stream keeps its own block — allocated while that stream
+        is current, so the caching allocator recycles it behind that stream's work — and a block is only ever replaced by a bigger one
+        (one shared block + record_stream on the NEW stream protected nothing and re-allocated on every stream change)."""
+        cur = torch.cuda.current_stream(self.device).cuda_stream
+        with self._ws_lock:
+            ws = self._ws_by_stream.get(cur)
+            if ws is None or ws.numel() < nbytes:
+                ws = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=self.device)
+                if len(self._ws_by_stream) >= 64:   # streams come and go with request threads: do not keep scratch of dead ones forever
+                    self._ws_by_stream.clear()
+                self._ws_by_stream[cur] = ws
+            return ws
 
     def _stream(self) -> int:
         return torch.cuda.current_stream(self.device).cuda_stream

@@ -439,7 +439,11 @@ class _TowerBase:
     # north-star tolerance.  Noise injected in early blocks is amplified by all later ones, so the policy keeps the FIRST blocks on
     # bf16 operands and runs the LAST ones on fp8: `tune_fp8` measures, on a fixed seeded calibration batch at load, the error of
     # each split against the tower's own bf16 output and keeps the most fp8 blocks that stay inside the budget.
-    FP8_BUDGET = float(os.environ.get("MARQO_AMD_FP8_BUDGET", "7e-4"))   # max (1 - cos) vs the tower's own bf16 output
+    # max (1 - cos) on the calibration batch.  5e-4 since round 4 (7e-4 before): with every default policy stacked, the trained-like 24-block
+    # ViT-L/14 at the 7e-4 budget (6.8e-4 at load) measured 1.03e-3 against the fp32 oracle on 260 HELD-OUT crops of natural-image statistics —
+    # the calibration batch under-states held-out error by ~1.5x (tests/test_fp8_gpu.py::test_default_policies_together_...); 5e-4 keeps the
+    # held-out figure inside the 1e-3 north-star tolerance with that factor applied
+    FP8_BUDGET = float(os.environ.get("MARQO_AMD_FP8_BUDGET", "5e-4"))
     FP8_STREAM_SHARE = 0.25  # an fp8 tower takes the bf16 residual stream when that alone costs <= this share of the budget
     FP8_SCALE_MARGIN = 2.0   # static activation scales = calibration amax x margin / 448: one binade of head-room for unseen inputs
     fp8_first_layer: int = 0

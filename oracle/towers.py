@@ -744,6 +744,39 @@ def synthetic_images_u8(n: int, size: int = 224, seed: int = 0) -> torch.Tensor:
     return torch.randint(0, 256, (n, size, size, 3), generator=_g(seed + 3000), dtype=torch.uint8)
 
 
+def synthetic_natural_images_u8(n: int, height: int = 224, width: int = 224, seed: int = 0) -> torch.Tensor:
+    """uint8 HWC [n, height, width, 3] with natural-image statistics instead of white noise: a 1/f amplitude spectrum (random phases), strongly
+    correlated colour channels, a smooth illumination gradient and a few flat 'objects' with sharp edges; mean ~0.45, contrast ~0.22.  Held-out
+    inputs for the tolerance tests: the towers' load-time policies calibrate on U{0..255} pixels, real requests look like this."""
+    import numpy as np
+    rng = np.random.default_rng(seed + 9000)
+    fy = np.fft.fftfreq(height)[:, None]
+    fx = np.fft.rfftfreq(width)[None, :]
+    f = np.sqrt(fy * fy + fx * fx)
+    f[0, 0] = 1.0
+    amp = 1.0 / f
+    amp[0, 0] = 0.0
+    out = np.empty((n, height, width, 3), dtype=np.uint8)
+    yy, xx = np.mgrid[0:height, 0:width]
+    for i in range(n):
+        base = np.fft.irfft2(amp * np.exp(2j * np.pi * rng.random(amp.shape)), s=(height, width))
+        base /= base.std() + 1e-12
+        img = np.empty((height, width, 3))
+        for c in range(3):
+            own = np.fft.irfft2(amp * np.exp(2j * np.pi * rng.random(amp.shape)), s=(height, width))
+            own /= own.std() + 1e-12
+            img[..., c] = 0.85 * base + 0.3 * own
+        gy, gx = rng.uniform(-0.6, 0.6, 2)
+        img += (gy * (yy / height - 0.5) + gx * (xx / width - 0.5))[..., None]
+        img = 0.45 + 0.22 * img / (img.std() + 1e-12)
+        for _ in range(int(rng.integers(2, 6))):     # flat patches: edges and saturated regions
+            h0, w0 = int(rng.integers(0, height - 8)), int(rng.integers(0, width - 8))
+            h1, w1 = min(height, h0 + int(rng.integers(8, height // 2))), min(width, w0 + int(rng.integers(8, width // 2)))
+            img[h0:h1, w0:w1] = 0.6 * img[h0:h1, w0:w1] + 0.4 * rng.random(3)
+        out[i] = np.clip(img * 255.0 + 0.5, 0, 255).astype(np.uint8)
+    return torch.from_numpy(out)
+
+
 def preprocess_u8_exact_size(images_u8: Tensor, mean: Sequence[float] = OPENAI_DATASET_MEAN,
                              std: Sequence[float] = OPENAI_DATASET_STD) -> Tensor:
     """The tail of clip_utils.py:61-66 for images already at model resolution (Resize and CenterCrop

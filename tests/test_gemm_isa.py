@@ -1,0 +1,82 @@
+"""Build-time checks on the compiled ISA of the bf16 GEMM main loop (csrc/gemm_bf16.hip), CPU only (hipcc cross-compiles gfx950 without a GPU).
+
+The k-loop issues its LDS fragment reads as inline asm (hipcc cannot tell them from the LDS-DMA writes in flight and would serialise the pipeline with
+`s_waitcnt vmcnt(0)` in front of every read) and places the waits by hand.  The compiler takes an asm's outputs as valid the moment the statement has
+executed, so nothing may touch a fragment register between its `ds_read_b128` and the hand-placed `s_waitcnt lgkmcnt(0)`: a register copy the allocator
+drops in there would read stale bits and only fail on some data, some day.  This test reads the ISA and checks exactly that, plus: no scratch, ONE
+straight-line k-step body (8 * MT MFMAs in the whole kernel), ONE vmcnt wait inside it (the mid-step one — a second one means the compiler started
+waiting on the LDS-DMA behind our back)."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "marqo_amd", "csrc", "gemm_bf16.hip")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+BIAS, GELU, RESIDUAL, OUT_F32, LN_APPLY = 1, 2, 8, 16, 128
+
+
+def _compile(tmp_path, flags, mt):
+    out = tmp_path / f"probe_{flags}_{mt}.s"
+    res = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wall", "-Wno-unused-function", "-Rpass-analysis=kernel-resource-usage",
+                          f"-DMQ_GEMM_PROBE={flags}", f"-DMQ_GEMM_PROBE_MT={mt}", "-S", "--cuda-device-only", "-o", str(out), SRC],
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    return out.read_text(), res.stderr
+
+
+def _regs(operand_text):
+    """VGPR indices named in an operand string: v12, v[12:15]"""
+    out = set()
+    for m in re.finditer(r"\bv\[(\d+):(\d+)\]", operand_text):
+        out.update(range(int(m.group(1)), int(m.group(2)) + 1))
+    for m in re.finditer(r"\bv(\d+)\b", operand_text):
+        out.add(int(m.group(1)))
+    return out
+
+
+@pytest.mark.skipif(not shutil.which(HIPCC), reason="hipcc not installed")
+@pytest.mark.parametrize("flags,mt", [(BIAS, 5), (BIAS | RESIDUAL, 5), (BIAS | GELU, 4), (BIAS | RESIDUAL | OUT_F32, 6), (BIAS | GELU | LN_APPLY, 5), (0, 2)])
+def test_asm_fragment_reads_are_waited_for_before_any_use(tmp_path, flags, mt):
+    isa, remarks = _compile(tmp_path, flags, mt)
+    assert re.search(r"ScratchSize \[bytes/lane\]: 0\b", remarks) and re.search(r"VGPRs Spill: 0\b", remarks), remarks[-1500:]
+    lines = [ln.strip() for ln in isa.splitlines()]
+    body = [ln for ln in lines if ln and not ln.startswith((";", ".", "//")) or ln.startswith(";;#ASM")]
+    # 1. one straight-line k-step: 2 halves x 4 * MT MFMAs, nowhere else
+    mfma = [i for i, ln in enumerate(body) if ln.startswith("v_mfma_f32_16x16x32_bf16")]
+    assert len(mfma) == 8 * mt, len(mfma)
+    # 2. inside the k-step exactly one wait on the vector-memory counter (the mid-step one)
+    hot = body[mfma[0]:mfma[-1] + 1]
+    assert sum(1 for ln in hot if ln.startswith("s_waitcnt") and "vmcnt" in ln) == 1, [ln for ln in hot if "vmcnt" in ln]
+    assert sum(1 for ln in hot if ln.startswith("s_barrier")) == 1
+    # 3. no instruction touches a register an inline-asm ds_read has written before the next lgkmcnt(0)
+    # (LDS operations return in order: `s_waitcnt lgkmcnt(N)` retires all but the N youngest reads — the counted wait in front of the LN_APPLY
+    # statistics block relies on exactly that)
+    reads, in_asm, n_reads = [], False, 0          # register sets of the un-retired asm reads, oldest first
+    for ln in body:
+        if ln.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if ln.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        m = re.search(r"lgkmcnt\((\d+)\)", ln) if ln.startswith("s_waitcnt") else None
+        if m:
+            keep = int(m.group(1))
+            reads = reads[len(reads) - keep:] if keep else []
+            continue
+        pending = set().union(*reads) if reads else set()
+        op, _, rest = ln.partition(" ")
+        if in_asm and op == "ds_read_b128":
+            dst, _, addr = rest.partition(",")
+            assert not (_regs(addr) & pending), f"asm read addresses through an un-waited register: {ln}"
+            reads.append(_regs(dst))
+            n_reads += 1
+            continue
+        touched = _regs(rest) & pending
+        assert not touched, f"{ln!r} touches v{sorted(touched)} before the s_waitcnt lgkmcnt that covers its ds_read_b128"
+    assert n_reads == 3 * (mt + 4), n_reads    # prologue + both half-steps

@@ -1,7 +1,8 @@
-"""LayerNorm folding on the bf16 residual stream (csrc/gemm_epilogue.h, MQ_EPI_LN_APPLY; round 4, default for the pre-LN towers): the QKV / fc1 GEMMs
-read the UN-normalised stream, accumulate the rows' statistics from the A tiles they stage and apply the LayerNorm in their epilogue — no LayerNorm
-launch.  Checks the kernel against plain PyTorch fp32 (LayerNorm -> Linear [-> activation]) incl. rows whose mean is several standard deviations from
-zero and a massive-activation channel, its determinism, and the folded towers against the un-folded ones and the CPU oracle.
+"""LayerNorm folding on the bf16 residual stream (csrc/gemm_epilogue.h, MQ_EPI_LN_APPLY; round 4, default for the pre-LN towers): a one-pass statistics
+kernel (mq_row_stats: (mean, rstd) per row, the LayerNorm's own two-pass arithmetic) and the QKV / fc1 GEMM that reads the UN-normalised stream and
+applies the LayerNorm in its epilogue — no LayerNorm launch, no normalised copy.  Checks both kernels against plain PyTorch fp32 (LayerNorm -> Linear
+[-> activation]) incl. rows whose mean is several standard deviations from zero and a massive-activation channel, determinism, and the folded towers
+against the un-folded ones and the CPU oracle.
 Reference arithmetic: open_clip ResidualAttentionBlock ln_1 -> attn.in_proj, ln_2 -> mlp.c_fc (reached from
 /root/reference/src/marqo/core/inference/embedding_models/open_clip_model.py:249-266)."""
 import pytest
@@ -21,6 +22,15 @@ def _tune(key, value):
     L.check(L.load().mq_tune(key.encode(), value))
 
 
+def _ln_gemm(lib, xb, wf, bf, colsum, out, flags, eps):
+    M, K = xb.shape
+    N = wf.shape[0]
+    stats = torch.empty(M, 2, device="cuda")
+    L.check(lib.mq_row_stats(xb.data_ptr(), stats.data_ptr(), M, K, eps, _stream()))
+    L.check(lib.mq_gemm_bf16_ln(xb.data_ptr(), K, wf.data_ptr(), K, bf.data_ptr(), colsum.data_ptr(), stats.data_ptr(), out.data_ptr(), N, M, N, K, flags, _stream()))
+    return stats
+
+
 def _folded(W, b, gam, bet):
     """what the loader precomputes (engine/towers.py::_clip_blocks)"""
     wf = (W * gam.unsqueeze(0)).to(torch.bfloat16)
@@ -29,7 +39,7 @@ def _folded(W, b, gam, bet):
 
 @pytest.mark.parametrize("act", ["none", "gelu", "quick"])
 @pytest.mark.parametrize("M,N,K,mean", [(500, 2304, 768, 0.0), (12800, 3072, 768, 0.3), (333, 1536, 512, 3.0), (64, 256, 1024, -1.0), (161, 132, 64, 0.5),
-                                        (4100, 4096, 1024, 0.1), (700, 1664, 1664, 0.2)])
+                                        (4100, 4096, 1024, 0.1), (700, 1664, 1664, 0.2), (9000, 1536, 512, 0.0)])
 def test_ln_apply_gemm_equals_layernorm_then_gemm(M, N, K, mean, act):
     lib = L.load()
     g = torch.Generator(device="cuda").manual_seed(N + K)
@@ -47,9 +57,13 @@ def test_ln_apply_gemm_equals_layernorm_then_gemm(M, N, K, mean, act):
     wf, bf, colsum = _folded(W, b, gam, bet)
     out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
     flags = L.MQ_EPI_BIAS | {"none": 0, "gelu": L.MQ_EPI_GELU, "quick": L.MQ_EPI_QUICKGELU}[act]
-    L.check(lib.mq_gemm_bf16_ln(xb.data_ptr(), K, wf.data_ptr(), K, bf.data_ptr(), colsum.data_ptr(), out.data_ptr(), N, M, N, K, flags, eps, _stream()))
+    stats = _ln_gemm(lib, xb, wf, bf, colsum, out, flags, eps)
+    # the statistics kernel against fp64 on the rounded rows
+    xd = x.double()
+    assert torch.allclose(stats[:, 0].double(), xd.mean(1), rtol=1e-5, atol=1e-5)
+    assert torch.allclose(stats[:, 1].double(), 1.0 / torch.sqrt(xd.var(1, unbiased=False) + eps), rtol=2e-5)
     again = torch.empty_like(out)
-    L.check(lib.mq_gemm_bf16_ln(xb.data_ptr(), K, wf.data_ptr(), K, bf.data_ptr(), colsum.data_ptr(), again.data_ptr(), N, M, N, K, flags, eps, _stream()))
+    _ln_gemm(lib, xb, wf, bf, colsum, again, flags, eps)
     assert torch.equal(out.view(torch.int16), again.view(torch.int16))              # fixed reduction order: deterministic
     # the un-folded engine path on the same inputs, for scale: LN -> bf16 -> GEMM
     h = torch.nn.functional.layer_norm(x, (K,), gam, bet, eps).to(torch.bfloat16)
@@ -76,10 +90,10 @@ def test_row_statistics_do_not_depend_on_the_tile_a_row_falls_into():
     wf, bf, colsum = _folded(W, 0.1 * torch.randn(N, device="cuda", generator=g), 1 + 0.1 * torch.randn(K, device="cuda", generator=g),
                              0.1 * torch.randn(K, device="cuda", generator=g))
     big = torch.empty(1500, N, device="cuda", dtype=torch.bfloat16)
-    L.check(lib.mq_gemm_bf16_ln(xb.data_ptr(), K, wf.data_ptr(), K, bf.data_ptr(), colsum.data_ptr(), big.data_ptr(), N, 1500, N, K, L.MQ_EPI_BIAS, 1e-5, _stream()))
+    _ln_gemm(lib, xb, wf, bf, colsum, big, L.MQ_EPI_BIAS, 1e-5)
     part = torch.empty(700, N, device="cuda", dtype=torch.bfloat16)
     sub = xb[333:1033].contiguous()
-    L.check(lib.mq_gemm_bf16_ln(sub.data_ptr(), K, wf.data_ptr(), K, bf.data_ptr(), colsum.data_ptr(), part.data_ptr(), N, 700, N, K, L.MQ_EPI_BIAS, 1e-5, _stream()))
+    _ln_gemm(lib, sub, wf, bf, colsum, part, L.MQ_EPI_BIAS, 1e-5)
     assert torch.equal(part.view(torch.int16), big[333:1033].view(torch.int16))
 
 
