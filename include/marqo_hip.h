@@ -428,8 +428,16 @@ int mq_ln_gemm_small_bf16(const void* d_x, int64_t ldx, int x_bf16, const float*
  *                    d_W = bf16(gamma * W0) [N, K], d_bias = b0 + W0 @ beta, d_colsum[n] = sum_k d_W[n, k], d_rowstats from mq_row_stats;
  *                    d_A: the UN-normalised bf16 rows (K = the normalised width).  flags: MQ_EPI_BIAS [| MQ_EPI_GELU | MQ_EPI_QUICKGELU].
  * Replaces what open_clip's ResidualAttentionBlock computes as ln_1 -> attn.in_proj / ln_2 -> mlp.c_fc
- * (reached from /root/reference/src/marqo/core/inference/embedding_models/open_clip_model.py:249-266). */
+ * (reached from /root/reference/src/marqo/core/inference/embedding_models/open_clip_model.py:249-266).
+ *   mq_gemm_bf16_rs + mq_row_stats_finalize: when the rows were just written by a residual GEMM of the bf16 stream, that GEMM can leave
+ *                    per-row partial sums behind (d_partials fp32 [M][ceil(N/64)][2]: (sum, sum of squares) of the bf16 values it stored per
+ *                    64-column slot) and the statistics pass shrinks to a finalise over those partials — same d_stats layout as mq_row_stats.
+ *                    flags of mq_gemm_bf16_rs: MQ_EPI_BIAS | MQ_EPI_RESIDUAL (bf16 in / out, in place). */
+#define MQ_EPI_ROW_STATS 64
 #define MQ_EPI_LN_APPLY 128
+int mq_gemm_bf16_rs(const void* d_A, int64_t lda, const void* d_W, int64_t ldw, const float* d_bias, const void* d_residual, void* d_out, int64_t ldc,
+                    int64_t M, int64_t N, int64_t K, int flags, float* d_partials, void* stream);
+int mq_row_stats_finalize(const float* d_partials, int32_t nslots, float* d_stats, int64_t rows, int32_t W, float eps, void* stream);
 int mq_row_stats(const void* d_x_bf16, float* d_stats, int64_t rows, int32_t W, float eps, void* stream);
 int mq_gemm_bf16_ln(const void* d_A, int64_t lda, const void* d_W, int64_t ldw, const float* d_bias, const float* d_colsum, const float* d_rowstats,
                     void* d_out, int64_t ldc, int64_t M, int64_t N, int64_t K, int flags, void* stream);

@@ -36,7 +36,7 @@ MQ_MASK_NONE, MQ_MASK_CAUSAL = 0, 1
 MQ_POOL_MEAN, MQ_POOL_CLS = 0, 1
 MQ_VIT_POOL_CLS, MQ_VIT_POOL_MAP, MQ_VIT_POOL_AVG = 0, 1, 2
 MQ_EPI_BIAS, MQ_EPI_GELU, MQ_EPI_QUICKGELU, MQ_EPI_RESIDUAL, MQ_EPI_OUT_F32, MQ_EPI_OUT_FP8 = 1, 2, 4, 8, 16, 32
-MQ_EPI_LN_APPLY = 128
+MQ_EPI_ROW_STATS, MQ_EPI_LN_APPLY = 64, 128
 MQ_COMBINE_RAW, MQ_COMBINE_NORMALIZE, MQ_COMBINE_NORMALIZE_IF_NONZERO = 0, 1, 2
 MQ_IMG_RGB, MQ_IMG_NEAREST, MQ_IMG_RGBA = 0, 1, 2
 MQ_PROF_FAMILIES = 6
@@ -147,6 +147,8 @@ _SIGNATURES = {
                                         C.c_int64, C.c_int, _P, _P]),
     "mq_gemm_bf16_ln": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, _P]),
     "mq_row_stats": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_float, _P]),
+    "mq_row_stats_finalize": (C.c_int, [_P, C.c_int32, _P, C.c_int64, C.c_int32, C.c_float, _P]),
+    "mq_gemm_bf16_rs": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, _P, _P]),
     "mq_gemm_fp8": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, C.c_int, _P, _P, _P, _P, C.c_int64, _P, _P, C.c_int64, C.c_int64,
                               C.c_int64, C.c_int, _P]),
     "mq_quantize_weights_fp8": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, C.c_int64, C.c_int64, _P]),

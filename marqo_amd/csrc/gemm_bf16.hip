@@ -375,6 +375,7 @@ int launch_gemm_mt(const void* A, int64_t lda, const void* W, int64_t ldw, const
         const size_t res_row = (size_t)ldc * (((FLAGS & MQ_EPI_RESIDUAL) && !(FLAGS & MQ_EPI_OUT_F32)) ? 2 : 4);
         GemmLn ln_chunk = ln;
         if (ln_chunk.rowstats) ln_chunk.rowstats += r0;
+        if (ln_chunk.partials) ln_chunk.partials += r0 * ln_chunk.nslots;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS, s, (const bf16_t*)A + r0 * lda, lda, (const bf16_t*)W, ldw, bias,
                            residual ? (const float*)((const char*)residual + (size_t)r0 * res_row) : nullptr, (void*)((char*)out + (size_t)r0 * out_row),
                            ldc, m, N, K, tiles_n, num_tiles, cgroup, band_rows, wide, (unsigned)a_bytes, (unsigned)w_bytes, ln_chunk);
@@ -458,6 +459,23 @@ extern "C" int mq_gemm_bf16_ln(const void* d_A, int64_t lda, const void* d_W, in
             return MQ_ERR_INVALID;
     }
 #undef MQ_GEMM_LN_CASE
+}
+
+// mq_gemm_bf16 (bias + bf16 residual read-modify-write) that also leaves the rows' partial statistics behind (gemm_epilogue.h, MQ_EPI_ROW_STATS):
+// d_partials fp32 [M][ceil(N/64)][2]
+extern "C" int mq_gemm_bf16_rs(const void* d_A, int64_t lda, const void* d_W, int64_t ldw, const float* d_bias, const void* d_residual, void* d_out,
+                               int64_t ldc, int64_t M, int64_t N, int64_t K, int flags, float* d_partials, void* stream) {
+    MQ_CHECK_ARG(d_A && d_W && d_out && d_bias && d_residual && d_partials, "mq_gemm_bf16_rs: null operand");
+    MQ_CHECK_ARG((flags | MQ_EPI_ROW_STATS) == (MQ_EPI_BIAS | MQ_EPI_RESIDUAL | MQ_EPI_ROW_STATS), "mq_gemm_bf16_rs: flags must be MQ_EPI_BIAS | MQ_EPI_RESIDUAL");
+    MQ_CHECK_ARG(M >= 1 && N >= 4 && K >= BK && K % BK == 0 && N % 4 == 0, "mq_gemm_bf16_rs: bad shape M=%ld N=%ld K=%ld", (long)M, (long)N, (long)K);
+    MQ_CHECK_ARG(lda % 8 == 0 && ldw % 8 == 0 && ldc % 4 == 0, "mq_gemm_bf16_rs: leading dims must keep 16-byte rows");
+    MQ_CHECK_ARG(M < (1 << 30) && N < (1 << 30) && K < (1 << 30), "mq_gemm_bf16_rs: shape too large");
+    hipStream_t s = (hipStream_t)stream;
+    MqProfScope prof(0, s, 2.0 * (double)M * (double)N * (double)K);
+    GemmLn ln{};
+    ln.partials = (float2*)d_partials;
+    ln.nslots = (int)((N + 63) / 64);
+    return launch_gemm<MQ_EPI_BIAS | MQ_EPI_RESIDUAL | MQ_EPI_ROW_STATS>(d_A, lda, d_W, ldw, d_bias, (const float*)d_residual, d_out, ldc, (int)M, (int)N, (int)K, s, ln);
 }
 
 // Run-time knobs (A/B benchmarking and the parity tests of every code path in one process).

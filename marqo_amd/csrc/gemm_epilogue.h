@@ -12,7 +12,10 @@
 // + (b + W @ beta).  MQ_EPI_LN_APPLY (the QKV / fc1 GEMM): A is the UN-normalised bf16 stream itself, W / bias / colsum are pre-folded with
 // gamma / beta at load, and (mean, rstd) per row come from a one-pass statistics kernel (mq_row_stats, rowops.hip: reads the stream once,
 // writes 8 bytes per row) — the LayerNorm launch that read AND wrote the whole stream, and the normalised copy, are gone.  The epilogue fetches
-// its MT rows' statistics with the bias, up front.  (Tried and rejected this round: accumulating the statistics inside the GEMM from the staged
+// its MT rows' statistics with the bias, up front.  MQ_EPI_ROW_STATS (the residual GEMM in FRONT of such a LayerNorm, bf16 read-modify-write form): the
+// epilogue also leaves, per row and 64-column wave slot, (sum, sum of squares) of the bf16 values it stores — plain stores, one writer per element,
+// fixed order: deterministic — so the statistics pass shrinks to a finalise over ceil(N / 64) partials per row (mq_row_stats_finalize) instead of a
+// read of the whole stream.  (Tried and rejected this round: accumulating the statistics inside the GEMM from the staged
 // A tiles — 40 extra VALU operations per k-step cost the k-loop 9 %, more than the LayerNorm launch they replaced; profiles/r04j_*.)
 #pragma once
 #include "common.h"
@@ -20,6 +23,8 @@
 struct GemmLn {
     const float* colsum;     // LN_APPLY: [N]  sum_k bf16(gamma_k * W[n,k])
     const float2* rowstats;  // LN_APPLY: [M]  (mean, rstd) of row m of A
+    float2* partials;        // ROW_STATS: [M][nslots]  (sum, sum of squares) of the bf16 values this launch leaves in columns 64 s .. 64 s + 63 of row m
+    int nslots;              // ROW_STATS: ceil(N / 64)
 };
 
 // RG = rows (16-row units) whose residual is prefetched together: the whole tile where the registers allow (the 4-wave kernel
@@ -36,7 +41,8 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][4], const float* 
     // bf16 residual stream (towers.hip): MQ_EPI_RESIDUAL without MQ_EPI_OUT_F32 = the residual is read as bf16 and the sum written
     // as bf16, in place — half the epilogue bytes of the fp32 stream, the memory-bound part of the K = 768 residual GEMMs
     constexpr bool RES_BF16 = (FLAGS & MQ_EPI_RESIDUAL) && BF16_OUT;
-    constexpr bool LN_APPLY = (FLAGS & MQ_EPI_LN_APPLY) != 0;
+    constexpr bool LN_APPLY = (FLAGS & MQ_EPI_LN_APPLY) != 0, ROW_STATS = (FLAGS & MQ_EPI_ROW_STATS) != 0;
+    static_assert(!ROW_STATS || RES_BF16, "ROW_STATS rides on the bf16 read-modify-write residual epilogue");
     static_assert(!LN_APPLY || (BF16_OUT && !(FLAGS & MQ_EPI_RESIDUAL)), "LN_APPLY: the QKV / fc1 epilogues (bf16 out, no residual)");
     float row_mean = 0.f, row_rstd = 1.f;
     // Everything the epilogue READS is fetched up front, the long-latency residual tile first.  Measured with the phase trace
@@ -115,6 +121,15 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][4], const float* 
             row_mean = ms_v[LN_APPLY ? mt : 0].x;
             row_rstd = ms_v[LN_APPLY ? mt : 0].y;
         }
+        float st1 = 0.f, st2 = 0.f;   // ROW_STATS: this lane's share of (sum, sum of squares) of row m over the wave's 64 columns
+        auto stat_add = [&](uint2 pk, bool ok) {   // of the ROUNDED values: they are what the next GEMM multiplies
+            if (ROW_STATS && ok) {
+                const float e0 = __uint_as_float(pk.x << 16), e1 = __uint_as_float(pk.x & 0xffff0000u), e2 = __uint_as_float(pk.y << 16),
+                            e3 = __uint_as_float(pk.y & 0xffff0000u);
+                st1 += (e0 + e1) + (e2 + e3);
+                st2 += (e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3);
+            }
+        };
         if (BF16_OUT && wide) {  // `wide` is wave-uniform: every lane takes part in the swaps
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
@@ -123,11 +138,13 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][4], const float* 
                     const int n = wave_n0 + (2 * p) * 16 + g * 4;
                     const f32x4 v = value(mt, 2 * p, m, n, m_ok && n < N);
                     a.x = pack_bf16x2(v[0], v[1]); a.y = pack_bf16x2(v[2], v[3]);
+                    stat_add(a, m_ok && n < N);
                 }
                 {
                     const int n = wave_n0 + (2 * p + 1) * 16 + g * 4;
                     const f32x4 v = value(mt, 2 * p + 1, m, n, m_ok && n < N);
                     b.x = pack_bf16x2(v[0], v[1]); b.y = pack_bf16x2(v[2], v[3]);
+                    stat_add(b, m_ok && n < N);
                 }
                 const auto r0 = __builtin_amdgcn_permlane16_swap(a.x, b.x, false, false);
                 const auto r1 = __builtin_amdgcn_permlane16_swap(a.y, b.y, false, false);
@@ -152,8 +169,14 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][4], const float* 
                     pk.x = pack_bf16x2(v[0], v[1]);
                     pk.y = pack_bf16x2(v[2], v[3]);
                     *(uint2*)((bf16_t*)out + o) = pk;
+                    stat_add(pk, true);
                 }
             }
+        }
+        if (ROW_STATS) {  // the row's 4 lanes (g = 0..3) add up in a fixed order; one writer per (row, slot)
+            st1 += __shfl_xor(st1, 16, 64); st2 += __shfl_xor(st2, 16, 64);
+            st1 += __shfl_xor(st1, 32, 64); st2 += __shfl_xor(st2, 32, 64);
+            if (g == 0 && m_ok && wave_n0 < N) lnp->partials[(int64_t)m * lnp->nslots + (wave_n0 >> 6)] = make_float2(st1, st2);
         }
     }
 }

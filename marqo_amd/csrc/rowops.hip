@@ -527,6 +527,42 @@ int mq_cast_bf16(const float* d_x, void* d_out, int64_t n, hipStream_t s) {
 }
 
 
+// (mean, rstd) per row from the partial sums a residual GEMM left behind (gemm_epilogue.h, MQ_EPI_ROW_STATS): one thread per row, nslots float2 each
+// (summed in slot order: deterministic); carries the weight prefetch like the LayerNorm kernels
+__global__ __launch_bounds__(256) void row_stats_finalize_kernel(const float2* __restrict__ partials, int nslots, float2* __restrict__ stats, int64_t rows,
+                                                                 float inv_w, float eps, LnExtra ex) {
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    float s1 = 0.f, s2 = 0.f;
+    if (row < rows) {
+        const float2* p = partials + row * nslots;
+        for (int i = 0; i < nslots; ++i) { const float2 v = p[i]; s1 += v.x; s2 += v.y; }
+    }
+    unsigned pq[LN_PF];
+    ln_prefetch_issue(ex, pq);
+    if (row < rows) {
+        const float mean = s1 * inv_w;
+        stats[row] = make_float2(mean, rsqrtf(fmaxf(s2 * inv_w - mean * mean, 0.f) + eps));
+    }
+    ln_prefetch_retire(pq);
+}
+int mq_row_stats_finalize_pf(const float* d_partials, int32_t nslots, float* d_stats, int64_t rows, int32_t W, float eps, const void* pf_a, size_t bytes_a,
+                             const void* pf_b, size_t bytes_b, hipStream_t s) {
+    MQ_CHECK_ARG(d_partials && d_stats && nslots >= 1 && W >= 1, "mq_row_stats_finalize: bad argument");
+    if (rows <= 0) return MQ_OK;
+    MqProfScope prof(1, s);
+    // (a 50-workgroup launch cannot touch ~70 k weight lines with two loads per thread: the prefetch grid is padded with idle row slots)
+    LnExtra ex = ln_extra(0, rows, pf_a, bytes_a, pf_b, bytes_b);
+    const int64_t want = ((int64_t)ex.na + ex.nb + LN_PF - 1) / LN_PF;
+    const int64_t threads = rows > want ? rows : want;
+    hipLaunchKernelGGL(row_stats_finalize_kernel, dim3((unsigned)cdiv64(threads, 256)), dim3(256), 0, s, (const float2*)d_partials, (int)nslots, (float2*)d_stats,
+                       rows, 1.0f / (float)W, eps, ex);
+    MQ_CHECK_LAUNCH("mq_row_stats_finalize");
+    return MQ_OK;
+}
+extern "C" int mq_row_stats_finalize(const float* d_partials, int32_t nslots, float* d_stats, int64_t rows, int32_t W, float eps, void* stream) {
+    return mq_row_stats_finalize_pf(d_partials, nslots, d_stats, rows, W, eps, nullptr, 0, nullptr, 0, (hipStream_t)stream);
+}
+
 // (mean, rstd) per row of bf16 rows [rows, W] (W % 8 == 0, W <= 2048) -> d_stats fp32 [rows][2]; pf_a / pf_b: weight ranges to prefetch (mq_layernorm_pf)
 bool mq_row_stats_ok(int32_t W) { return W % 8 == 0 && W >= 8 && W <= 2048; }
 int mq_row_stats_pf(const void* d_x_bf16, float* d_stats, int64_t rows, int32_t W, float eps, const void* pf_a, size_t bytes_a, const void* pf_b,

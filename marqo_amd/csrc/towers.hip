@@ -36,9 +36,10 @@ static_assert(sizeof(mq_vit_weights) == 10 * 8 && sizeof(mq_map_head) == 11 * 8 
 // mq_tune("row_select", 0) runs the last block on every row (A/B and parity tests of the pooled-rows-only last block)
 int mq_tower_row_select = getenv("MQ_ROW_SELECT") ? atoi(getenv("MQ_ROW_SELECT")) : 1;
 // LayerNorm folding (gemm_epilogue.h, MQ_EPI_LN_APPLY): on the bf16 residual stream the QKV / fc1 GEMMs of a pre-LN block read the stream itself and
-// apply the LayerNorm in their epilogue (row statistics accumulated from the A tiles in the kernel) whenever the block carries the folded
-// tensors (*_wf / *_bf / *_sf, engine/towers.py) and the call is large enough for the tiled GEMM.  mq_tune("ln_fold", 0) / MQ_LN_FOLD=0: off.
-int mq_tower_ln_fold = getenv("MQ_LN_FOLD") ? atoi(getenv("MQ_LN_FOLD")) : 1;
+// apply the LayerNorm in their epilogue ((mean, rstd) per row handed in) whenever the block carries the folded tensors (*_wf / *_bf / *_sf,
+// engine/towers.py) and the call is large enough for the tiled GEMM.  mq_tune("ln_fold", v) / MQ_LN_FOLD=v:
+// 0 = LayerNorm kernels; 1 = folded, statistics from a read pass over the stream; 2 = folded, statistics from the residual GEMMs' partial sums
+int mq_tower_ln_fold = getenv("MQ_LN_FOLD") ? atoi(getenv("MQ_LN_FOLD")) : 2;
 // bf16 residual stream for the pre-LN bf16 towers (mq_tune("residual_bf16", 1) / MQ_RESIDUAL_BF16=1): x is kept in bf16 between
 // blocks.  The residual GEMMs of a K = 768 tower are memory-bound on their epilogue (out-proj: 15 GFLOP against 39 MB read + 39 MB
 // written of fp32 residual) and every LayerNorm re-reads the stream: bf16 halves those bytes.  Cost: one bf16 rounding per residual
@@ -70,6 +71,10 @@ int mq_layernorm_fp8_pf(const void* d_x, int x_bf16, const float* d_g, const flo
 bool mq_gemm_small_grouped_ok(int64_t M, int64_t N, int64_t K);
 extern "C" int mq_gemm_bf16_ln(const void* d_A, int64_t lda, const void* d_W, int64_t ldw, const float* d_bias, const float* d_colsum,
                                const float* d_rowstats, void* d_out, int64_t ldc, int64_t M, int64_t N, int64_t K, int flags, void* stream);
+extern "C" int mq_gemm_bf16_rs(const void* d_A, int64_t lda, const void* d_W, int64_t ldw, const float* d_bias, const void* d_residual, void* d_out,
+                               int64_t ldc, int64_t M, int64_t N, int64_t K, int flags, float* d_partials, void* stream);
+int mq_row_stats_finalize_pf(const float* d_partials, int32_t nslots, float* d_stats, int64_t rows, int32_t W, float eps, const void* pf_a, size_t bytes_a,
+                             const void* pf_b, size_t bytes_b, hipStream_t s);
 bool mq_row_stats_ok(int32_t W);
 int mq_row_stats_pf(const void* d_x_bf16, float* d_stats, int64_t rows, int32_t W, float eps, const void* pf_a, size_t bytes_a, const void* pf_b,
                     size_t bytes_b, hipStream_t s);
@@ -79,11 +84,14 @@ static bool fold_ok(int xb, const void* wf, const float* bf, const float* sf, in
 }
 static int ln_gemm(const void* d_x, int xb, const float* g, const float* b, float eps, void* h, const void* W, const float* bias, void* out,
                    int64_t rows, int N, int K, int flags, hipStream_t s, const void* next_w = nullptr, size_t next_bytes = 0,
-                   const void* wf = nullptr, const float* bf = nullptr, const float* sf = nullptr, float* row_stats = nullptr) {
+                   const void* wf = nullptr, const float* bf = nullptr, const float* sf = nullptr, float* row_stats = nullptr,
+                   const float* row_partials = nullptr /* non-NULL: the GEMM that wrote d_x left its rows' partial sums here */) {
     if (mq_gemm_small_ok(rows, N, K, true)) return mq_ln_gemm_small(d_x, K, xb, g, b, eps, W, K, bias, out, N, rows, N, K, flags, nullptr, nullptr, s);
     if (row_stats && fold_ok(xb, wf, bf, sf, rows, N, K)) {
-        // folded: ONE read pass over the stream for (mean, rstd) — it also carries the weight prefetch — then the GEMM reads the stream itself
-        MQ_TRY(mq_row_stats_pf(d_x, row_stats, rows, K, eps, pf(wf), (size_t)N * K * 2, pf(next_w), next_bytes, s));
+        // folded: (mean, rstd) per row — from the partial sums the residual GEMM in front left behind (a finalise over K / 64 partials per row),
+        // else from ONE read pass over the stream; either launch carries the weight prefetch — then the GEMM reads the stream itself
+        if (row_partials) MQ_TRY(mq_row_stats_finalize_pf(row_partials, (K + 63) / 64, row_stats, rows, K, eps, pf(wf), (size_t)N * K * 2, pf(next_w), next_bytes, s));
+        else MQ_TRY(mq_row_stats_pf(d_x, row_stats, rows, K, eps, pf(wf), (size_t)N * K * 2, pf(next_w), next_bytes, s));
         return mq_gemm_bf16_ln(d_x, K, wf, K, bf, sf, row_stats, out, N, rows, N, K, flags, s);
     }
     MQ_TRY(mq_layernorm_pf(d_x, xb, nullptr, g, b, h, nullptr, rows, K, eps, pf(W), (size_t)N * K * 2, pf(next_w), next_bytes, s));
@@ -173,6 +181,7 @@ size_t encoder_ws(const mq_encoder_cfg* c, int64_t rows) {
     cv.take((size_t)rows * big * 2);
     cv.take((size_t)rows * 4);  // per-row activation scales of the fp8 path
     cv.take((size_t)rows * 8);  // (mean, rstd) per row: the statistics of a folded LayerNorm
+    cv.take((size_t)rows * ((c->width + 63) / 64) * 8);  // ... and the partial sums a residual GEMM leaves for them: (sum, sum of squares) per row and 64-column slot
     cv.take((size_t)(rows < SMALL_LN_ROWS ? rows : SMALL_LN_ROWS) * c->width * 4);  // search path, post-LN: the normalised residual (fp32)
     return cv.end();
 }
@@ -198,7 +207,7 @@ namespace {
 // behind the fc1 output (all of h / a / qkv are dead by the time they are overwritten).
 int last_block_selected(const mq_encoder_cfg* cfg, const mq_block_weights& b, int l, float* d_x, int64_t rows,
                         const int32_t* d_cu_seqlens, int64_t nseq, int32_t fixed_len, int32_t max_len,
-                        const int32_t* d_sel, int64_t nsel, void* h, void* a, void* qf, float* row_scale, float* row_stats, float* x_sel,
+                        const int32_t* d_sel, int64_t nsel, void* h, void* a, void* qf, float* row_scale, float* row_stats, const float* row_partials, float* x_sel,
                         bool f8, hipStream_t s) {
     const int W = cfg->width, F = cfg->mlp_dim, Wa = attn_width(cfg);
     const int act_flag = cfg->act == MQ_ACT_QUICKGELU ? MQ_EPI_QUICKGELU : MQ_EPI_GELU;
@@ -223,7 +232,7 @@ int last_block_selected(const mq_encoder_cfg* cfg, const mq_block_weights& b, in
         const int xb = stream_bf16(cfg) ? 1 : 0;                 // bf16 residual stream: rows of 2 bytes per element, bf16 RMW epilogues
         const int rflags = xb ? (MQ_EPI_BIAS | MQ_EPI_RESIDUAL) : res_flags;
         const int64_t xrow = (int64_t)W * (xb ? 2 : 4);
-        MQ_TRY(ln_gemm(d_x, xb, b.ln1_g, b.ln1_b, cfg->ln_eps, h, b.qkv_w, b.qkv_b, qf, rows, 3 * Wa, W, MQ_EPI_BIAS, s, nullptr, 0, b.qkv_wf, b.qkv_bf, b.qkv_sf, row_stats));
+        MQ_TRY(ln_gemm(d_x, xb, b.ln1_g, b.ln1_b, cfg->ln_eps, h, b.qkv_w, b.qkv_b, qf, rows, 3 * Wa, W, MQ_EPI_BIAS, s, nullptr, 0, b.qkv_wf, b.qkv_bf, b.qkv_sf, row_stats, row_partials));
         MQ_TRY(attn_bf16(cfg, qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, s));
         MQ_TRY(mq_move_rows(a, d_sel, h, nsel, (int64_t)Wa * 2, false, s));
         MQ_TRY(mq_move_rows(d_x, d_sel, x_sel, nsel, xrow, false, s));
@@ -282,6 +291,8 @@ int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* bloc
     void* qf = wsb + cv.take((size_t)rows * big * 2);  // qkv [rows,3W] then fc1 output [rows,F]
     float* row_scale = (float*)(wsb + cv.take((size_t)rows * 4));
     float* row_stats = (float*)(wsb + cv.take((size_t)rows * 8));
+    float* row_part = (float*)(wsb + cv.take((size_t)rows * ((W + 63) / 64) * 8));
+    bool x_has_partials = false;   // row_part describes the current d_x (the last GEMM that wrote it emitted them)
     float* xn = (float*)(wsb + cv.take((size_t)(rows < SMALL_LN_ROWS ? rows : SMALL_LN_ROWS) * W * 4));
     const int act_flag = cfg->act == MQ_ACT_QUICKGELU ? MQ_EPI_QUICKGELU : MQ_EPI_GELU;
     const int res_flags = MQ_EPI_BIAS | MQ_EPI_RESIDUAL | MQ_EPI_OUT_F32;
@@ -319,7 +330,7 @@ int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* bloc
         // post-LN: the previous (bf16) block left its output as a bf16 operand; the first e4m3 block wants e4m3 rows + row scales
         if (cfg->post_ln && f8 && l == first8 && l > 0) MQ_TRY(mq_rowquant_fp8(d_x, h, row_scale, rows, W, s));
         if (select_last && l == cfg->layers - 1) {
-            MQ_TRY(last_block_selected(cfg, b, l, d_x, rows, d_cu_seqlens, nseq, fixed_len, max_len, d_sel, nsel, h, a, qf, row_scale, row_stats,
+            MQ_TRY(last_block_selected(cfg, b, l, d_x, rows, d_cu_seqlens, nseq, fixed_len, max_len, d_sel, nsel, h, a, qf, row_scale, row_stats, x_has_partials ? row_part : nullptr,
                                        (float*)((char*)qf + xsel_off), f8, s));
             break;
         }
@@ -361,10 +372,17 @@ int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* bloc
             const int xb = stream_bf16(cfg) ? 1 : 0;
             const int rflags = xb ? (MQ_EPI_BIAS | MQ_EPI_RESIDUAL) : res_flags;
             MQ_TRY(ln_gemm(d_x, xb, b.ln1_g, b.ln1_b, cfg->ln_eps, h, b.qkv_w, b.qkv_b, qf, rows, 3 * Wa, W, MQ_EPI_BIAS, s, b.out_w, (size_t)W * Wa * 2,
-                           b.qkv_wf, b.qkv_bf, b.qkv_sf, row_stats));
+                           b.qkv_wf, b.qkv_bf, b.qkv_sf, row_stats, x_has_partials ? row_part : nullptr));
+            x_has_partials = false;
             MQ_TRY(attn_bf16(cfg, qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, s));
-            MQ_TRY(mq_gemm_bf16(a, Wa, b.out_w, Wa, b.out_b, (const float*)d_x, d_x, W, rows, W, Wa, rflags, s));
-            if (cfg->precision == MQ_PREC_FP8 && l >= first8 - cfg->fp8_mlp_extra) {
+            // the residual GEMMs leave the rows' partial sums behind whenever the GEMM after them folds its LayerNorm (tiled family, bf16 stream)
+            const bool last_pooled = d_sel && nsel > 0 && l == cfg->layers - 1;
+            const bool mlp_fp8 = cfg->precision == MQ_PREC_FP8 && l >= first8 - cfg->fp8_mlp_extra;
+            const bool fold_mlp = mq_tower_ln_fold >= 2 && !last_pooled && !mlp_fp8 && fold_ok(xb, b.fc1_wf, b.fc1_bf, b.fc1_sf, rows, F, W) &&
+                                  !mq_gemm_small_ok(rows, W, Wa, false) && !mq_gemm_small_grouped_ok(rows, W, Wa);
+            if (fold_mlp) MQ_TRY(mq_gemm_bf16_rs(a, Wa, b.out_w, Wa, b.out_b, d_x, d_x, W, rows, W, Wa, rflags, row_part, s));
+            else MQ_TRY(mq_gemm_bf16(a, Wa, b.out_w, Wa, b.out_b, (const float*)d_x, d_x, W, rows, W, Wa, rflags, s));
+            if (mlp_fp8) {
                 // MLP-only e4m3 block (fp8_mlp_extra): the attention half above ran on bf16 operands
                 MQ_CHECK_ARG(b.fc1_w8 && b.fc1_ws && b.fc2_w8 && b.fc2_ws, "mq_encoder_forward: layer %d has no fp8 MLP weights", l);
                 const float* s_mlp = cfg->d_fp8_act_scale + 2 * l + 1;
@@ -378,10 +396,15 @@ int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* bloc
             }
             // (the LAST block of a call that reads only pooled rows never folds its MLP: the pooled rows take the small-call kernels — LayerNorm
             // kernel + un-folded weights — and dead-row elimination stays bit-identical to this all-rows form, tests/test_towers_gpu.py)
-            const bool last_pooled = d_sel && nsel > 0 && l == cfg->layers - 1;
             MQ_TRY(ln_gemm(d_x, xb, b.ln2_g, b.ln2_b, cfg->ln_eps, h, b.fc1_w, b.fc1_b, qf, rows, F, W, MQ_EPI_BIAS | act_flag, s, b.fc2_w, (size_t)W * F * 2,
-                           last_pooled ? nullptr : b.fc1_wf, b.fc1_bf, b.fc1_sf, row_stats));
-            MQ_TRY(mq_gemm_bf16(qf, F, b.fc2_w, F, b.fc2_b, (const float*)d_x, d_x, W, rows, W, F, rflags, s));
+                           last_pooled ? nullptr : b.fc1_wf, b.fc1_bf, b.fc1_sf, row_stats, fold_mlp ? row_part : nullptr));
+            // fc2 writes the x the NEXT block's QKV normalises
+            const mq_block_weights* nbk = l + 1 < cfg->layers && l + 1 < first8 ? &blocks[l + 1] : nullptr;
+            const bool fold_next = mq_tower_ln_fold >= 2 && nbk && fold_ok(xb, nbk->qkv_wf, nbk->qkv_bf, nbk->qkv_sf, rows, 3 * Wa, W) && !mq_gemm_small_ok(rows, W, F, false) &&
+                                   !mq_gemm_small_grouped_ok(rows, W, F);
+            if (fold_next) MQ_TRY(mq_gemm_bf16_rs(qf, F, b.fc2_w, F, b.fc2_b, d_x, d_x, W, rows, W, F, rflags, row_part, s));
+            else MQ_TRY(mq_gemm_bf16(qf, F, b.fc2_w, F, b.fc2_b, (const float*)d_x, d_x, W, rows, W, F, rflags, s));
+            x_has_partials = fold_next;
         } else if (small_post_ln) {
             // search path: both LayerNorms ride in the prologue of the GEMM that consumes them (gemm_small.hip).  d_x holds the pre-LN sums
             // t, xn the normalised rows (the residual): t1 = r + out(attn(qkv(r))) ; fc1 normalises t1 -> xn ; t2 = xn + fc2(..) ;

@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "marqo_amd", "csrc", "gemm_bf16.hip")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
-BIAS, GELU, RESIDUAL, OUT_F32, LN_APPLY = 1, 2, 8, 16, 128
+BIAS, GELU, RESIDUAL, OUT_F32, ROW_STATS, LN_APPLY = 1, 2, 8, 16, 64, 128
 
 
 def _compile(tmp_path, flags, mt):
@@ -40,7 +40,8 @@ def _regs(operand_text):
 
 
 @pytest.mark.skipif(not shutil.which(HIPCC), reason="hipcc not installed")
-@pytest.mark.parametrize("flags,mt", [(BIAS, 5), (BIAS | RESIDUAL, 5), (BIAS | GELU, 4), (BIAS | RESIDUAL | OUT_F32, 6), (BIAS | GELU | LN_APPLY, 5), (0, 2)])
+@pytest.mark.parametrize("flags,mt", [(BIAS, 5), (BIAS | RESIDUAL, 5), (BIAS | GELU, 4), (BIAS | RESIDUAL | OUT_F32, 6), (BIAS | GELU | LN_APPLY, 5), (BIAS | RESIDUAL | ROW_STATS, 5),
+                                      (BIAS | RESIDUAL | ROW_STATS, 3), (0, 2)])
 def test_asm_fragment_reads_are_waited_for_before_any_use(tmp_path, flags, mt):
     isa, remarks = _compile(tmp_path, flags, mt)
     assert re.search(r"ScratchSize \[bytes/lane\]: 0\b", remarks) and re.search(r"VGPRs Spill: 0\b", remarks), remarks[-1500:]

@@ -97,6 +97,48 @@ def test_row_statistics_do_not_depend_on_the_tile_a_row_falls_into():
     assert torch.equal(part.view(torch.int16), big[333:1033].view(torch.int16))
 
 
+@pytest.mark.parametrize("M,N,K", [(12800, 768, 768), (12800, 768, 3072), (1500, 512, 2048), (333, 1024, 1024), (700, 1664, 1664), (130, 72, 64), (9000, 1280, 5120)])
+def test_residual_gemm_leaves_the_row_sums_the_next_layernorm_needs(M, N, K):
+    """MQ_EPI_ROW_STATS: the out-proj / fc2 GEMM (bf16 read-modify-write of the stream) writes (sum, sum of squares) of every row's ROUNDED new values per
+    64-column slot; mq_row_stats_finalize turns them into the (mean, rstd) mq_row_stats would have read back — the statistics pass over the stream goes"""
+    lib = L.load()
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    a = (torch.randn(M, K, device="cuda", generator=g)).to(torch.bfloat16)
+    W = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).to(torch.bfloat16)
+    b = 0.1 * torch.randn(N, device="cuda", generator=g)
+    x0 = (torch.randn(M, N, device="cuda", generator=g) * 2 + 0.5)
+    x0[:, 5] += 60.0
+    x0 = x0.to(torch.bfloat16)
+    flags = L.MQ_EPI_BIAS | L.MQ_EPI_RESIDUAL
+    plain = x0.clone()
+    L.check(lib.mq_gemm_bf16(a.data_ptr(), K, W.data_ptr(), K, b.data_ptr(), plain.data_ptr(), plain.data_ptr(), N, M, N, K, flags, _stream()))
+    nslots = (N + 63) // 64
+    x = x0.clone()
+    part = torch.full((M, nslots, 2), float("nan"), device="cuda")
+    L.check(lib.mq_gemm_bf16_rs(a.data_ptr(), K, W.data_ptr(), K, b.data_ptr(), x.data_ptr(), x.data_ptr(), N, M, N, K, flags, part.data_ptr(), _stream()))
+    assert torch.equal(x.view(torch.int16), plain.view(torch.int16))                # the stream itself: same bits with and without the by-product
+    assert not torch.isnan(part).any()                                              # every (row, slot) written
+    xd = x.double()
+    pad = torch.zeros(M, nslots * 64, device="cuda", dtype=torch.float64)
+    pad[:, :N] = xd
+    pad = pad.view(M, nslots, 64)
+    assert torch.allclose(part[..., 0].double(), pad.sum(-1), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(part[..., 1].double(), pad.pow(2).sum(-1), rtol=1e-5, atol=1e-3)
+    again = torch.empty_like(part)
+    x2 = x0.clone()
+    L.check(lib.mq_gemm_bf16_rs(a.data_ptr(), K, W.data_ptr(), K, b.data_ptr(), x2.data_ptr(), x2.data_ptr(), N, M, N, K, flags, again.data_ptr(), _stream()))
+    assert torch.equal(part, again)                                                 # fixed order: deterministic
+    if N % 8 == 0 and N <= 2048:
+        eps = 1e-5
+        fin = torch.empty(M, 2, device="cuda")
+        L.check(lib.mq_row_stats_finalize(part.data_ptr(), nslots, fin.data_ptr(), M, N, eps, _stream()))
+        ref = torch.empty(M, 2, device="cuda")
+        L.check(lib.mq_row_stats(x.data_ptr(), ref.data_ptr(), M, N, eps, _stream()))
+        assert torch.allclose(fin[:, 0], ref[:, 0], rtol=1e-5, atol=1e-5)
+        assert torch.allclose(fin[:, 1], ref[:, 1], rtol=1e-4)                      # one-pass variance in fp32 vs the statistics kernel's two passes
+        assert torch.allclose(fin[:, 1].double(), 1.0 / torch.sqrt(xd.var(1, unbiased=False) + eps), rtol=1e-4)
+
+
 def test_folded_towers_match_unfolded_and_oracle():
     from marqo_amd.engine import archs, towers
     assert towers.LN_FOLD
@@ -110,13 +152,16 @@ def test_folded_towers_match_unfolded_and_oracle():
     tower.set_residual_stream(1) if hasattr(tower, "set_residual_stream") else None
     cos = lambda a, b: float((1 - torch.nn.functional.cosine_similarity(a.double().cpu(), b.double().cpu(), dim=-1)).max())
     try:
-        _tune("ln_fold", 1)
+        _tune("ln_fold", 2)                          # statistics from the residual GEMMs' partial sums (default)
         folded = tower.encode_u8(u8.cuda())
         assert torch.equal(folded, tower.encode_u8(u8.cuda()))  # deterministic
+        _tune("ln_fold", 1)                          # statistics from a read pass over the stream
+        folded_rs = tower.encode_u8(u8.cuda())
         _tune("ln_fold", 0)
         plain = tower.encode_u8(u8.cuda())
     finally:
-        _tune("ln_fold", 1)
+        _tune("ln_fold", 2)
+    assert cos(folded, folded_rs) < 2e-5 and cos(folded_rs, ref) < 3e-4
     e_f, e_p, e_fp = cos(folded, ref), cos(plain, ref), cos(folded, plain)
     print(f"ViT-B/32 x4 layers ({tower.residual_stream=}): 1-cos vs oracle folded {e_f:.2e} plain {e_p:.2e}; folded vs plain {e_fp:.2e}")
     assert e_f < 3e-4 and e_p < 3e-4 and e_fp < 1e-4
@@ -128,10 +173,13 @@ def test_folded_towers_match_unfolded_and_oracle():
     tt = towers.ClipTextTower(tarch, sdt, "cuda")
     reft = O.clip_text_forward(sdt, tcfg, ids)
     try:
-        _tune("ln_fold", 1)
+        _tune("ln_fold", 2)
         f = tt.encode_ids(ids)
+        _tune("ln_fold", 1)
+        f1 = tt.encode_ids(ids)
         _tune("ln_fold", 0)
         p = tt.encode_ids(ids)
     finally:
-        _tune("ln_fold", 1)
+        _tune("ln_fold", 2)
+    assert cos(f, f1) < 2e-5
     assert cos(f, reft) < 3e-4 and cos(p, reft) < 3e-4 and cos(f, p) < 1e-4
