@@ -147,6 +147,50 @@ def _align256(v):
     return (v + 255) // 256 * 256
 
 
+# Host -> device copies of a pack run on a copy stream of the calling thread, not on its compute stream: the copy engine then moves request
+# i + 1's pixels while request i's kernels are still running (a pipelined caller — RequestShardedIngest keeps one request in flight — otherwise
+# queues the 19 MB / 0.4 ms transfer BEHIND the previous request's towers).  The destination is allocated on the copy stream (the caching
+# allocator orders a block's reuse per stream) and handed to the compute stream with an event + record_stream.  MARQO_AMD_COPY_STREAM=0: off.
+COPY_STREAM = os.environ.get("MARQO_AMD_COPY_STREAM", "1") != "0"
+_copy_tls = threading.local()
+
+
+class _H2D:
+    """`with _H2D(device) as h:` — inside, torch allocations and copies go to the thread's copy stream; on exit the compute stream (the
+    stream that was current outside) waits for them.  `h.hand_over(t)` marks a tensor allocated inside as used by the compute stream."""
+
+    def __init__(self, device: torch.device):
+        self.on = COPY_STREAM and torch.cuda.is_available() and torch.device(device).type == "cuda"
+        self.device = torch.device(device)
+
+    def __enter__(self):
+        if not self.on:
+            return self
+        streams = getattr(_copy_tls, "streams", None)
+        if streams is None:
+            streams = _copy_tls.streams = {}
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        cs = streams.get(idx)
+        if cs is None:
+            cs = streams[idx] = torch.cuda.Stream(torch.device("cuda", idx))
+        self.compute = torch.cuda.current_stream(torch.device("cuda", idx))
+        self.copy = cs
+        self._ctx = torch.cuda.stream(cs)
+        self._ctx.__enter__()
+        return self
+
+    def hand_over(self, t: torch.Tensor) -> torch.Tensor:
+        if self.on:
+            t.record_stream(self.compute)
+        return t
+
+    def __exit__(self, *exc):
+        if self.on:
+            self._ctx.__exit__(*exc)
+            self.compute.wait_stream(self.copy)
+        return False
+
+
 class PackedImages:
     """A batch of variable-size uint8 RGB images packed back to back (256-byte aligned) in one device buffer.
 
@@ -209,47 +253,49 @@ class PackedImages:
             nbytes[e] = a.nbytes
         lib = L.load()
         staged = None
-        if lazy:
-            lz_off = np.ascontiguousarray(x_off[lazy])
-            lz_len = np.ascontiguousarray(npix[lazy] * 4)
-            # all-Pillow batch: the RGBX region [total, cur) fills front to back in request order -> ship it slice by slice
-            sliced = PACK_SLICE and len(lazy) == self.n and self.n >= 2 * PACK_SLICE and torch.cuda.is_available()
-            step = PACK_SLICE if sliced else len(lazy)
-            if sliced:
-                staged = torch.empty(max(stage_bytes, 1), dtype=torch.uint8, device=device)
-            for j0 in range(0, len(lazy), step):
-                j1 = min(j0 + step, len(lazy))
-                for f in stager.gather_rgbx([imgs[k].image for k in lazy[j0:j1]], host.data_ptr(), host.numel(), lz_off[j0:j1], lz_len[j0:j1], PACK_THREADS):
-                    k = lazy[j0 + f]   # Pillow could not export this one zero-copy (e.g. an image stored in several blocks): its .view copies
-                    v = imgs[k].view
-                    hnp[int(x_off[k]):int(x_off[k]) + v.nbytes] = np.ascontiguousarray(v).reshape(-1)
+        with _H2D(device) as h2d:
+            if lazy:
+                lz_off = np.ascontiguousarray(x_off[lazy])
+                lz_len = np.ascontiguousarray(npix[lazy] * 4)
+                # all-Pillow batch: the RGBX region [total, cur) fills front to back in request order -> ship it slice by slice
+                sliced = PACK_SLICE and len(lazy) == self.n and self.n >= 2 * PACK_SLICE and torch.cuda.is_available()
+                step = PACK_SLICE if sliced else len(lazy)
                 if sliced:
-                    lo, hi = int(x_off[lazy[j0]]), (int(x_off[lazy[j1]]) if j1 < len(lazy) else cur)
+                    staged = torch.empty(max(stage_bytes, 1), dtype=torch.uint8, device=device)
+                for j0 in range(0, len(lazy), step):
+                    j1 = min(j0 + step, len(lazy))
+                    for f in stager.gather_rgbx([imgs[k].image for k in lazy[j0:j1]], host.data_ptr(), host.numel(), lz_off[j0:j1], lz_len[j0:j1], PACK_THREADS):
+                        k = lazy[j0 + f]   # Pillow could not export this one zero-copy (e.g. an image stored in several blocks): its .view copies
+                        v = imgs[k].view
+                        hnp[int(x_off[k]):int(x_off[k]) + v.nbytes] = np.ascontiguousarray(v).reshape(-1)
+                    if sliced:
+                        lo, hi = int(x_off[lazy[j0]]), (int(x_off[lazy[j1]]) if j1 < len(lazy) else cur)
+                        staged[lo:hi].copy_(host[lo:hi], non_blocking=True)
+            # Experiment knob: a batch of one kind (all plain RGB arrays, or all Pillow RGBX views) fills the staging buffer front to back, so it
+            # CAN be packed and shipped in PACK_CHUNKS pieces, the pinned H2D copy of piece c running while the memcpy threads pack piece c + 1.
+            pieces = PACK_CHUNKS if (not lazy and nx in (0, self.n) and self.n >= 16 * PACK_CHUNKS and torch.cuda.is_available()) else 1
+            if pieces > 1:
+                staged = torch.empty(max(stage_bytes, 1), dtype=torch.uint8, device=device)
+                end = cur if nx else total
+                for c in range(pieces):
+                    k0, k1 = c * self.n // pieces, (c + 1) * self.n // pieces
+                    sub = (C.c_void_p * (k1 - k0))(*srcs[k0:k1])
+                    L.check(lib.mq_host_gather_checked(sub, nbytes[k0:k1].ctypes.data, dsts[k0:k1].ctypes.data, k1 - k0, host.data_ptr(),
+                                                       host.numel(), PACK_THREADS), "mq_host_gather")
+                    lo, hi = int(dsts[k0]), (int(dsts[k1]) if k1 < self.n else end)
                     staged[lo:hi].copy_(host[lo:hi], non_blocking=True)
-        # Experiment knob: a batch of one kind (all plain RGB arrays, or all Pillow RGBX views) fills the staging buffer front to back, so it
-        # CAN be packed and shipped in PACK_CHUNKS pieces, the pinned H2D copy of piece c running while the memcpy threads pack piece c + 1.
-        pieces = PACK_CHUNKS if (not lazy and nx in (0, self.n) and self.n >= 16 * PACK_CHUNKS and torch.cuda.is_available()) else 1
-        if pieces > 1:
-            staged = torch.empty(max(stage_bytes, 1), dtype=torch.uint8, device=device)
-            end = cur if nx else total
-            for c in range(pieces):
-                k0, k1 = c * self.n // pieces, (c + 1) * self.n // pieces
-                sub = (C.c_void_p * (k1 - k0))(*srcs[k0:k1])
-                L.check(lib.mq_host_gather_checked(sub, nbytes[k0:k1].ctypes.data, dsts[k0:k1].ctypes.data, k1 - k0, host.data_ptr(),
-                                                   host.numel(), PACK_THREADS), "mq_host_gather")
-                lo, hi = int(dsts[k0]), (int(dsts[k1]) if k1 < self.n else end)
-                staged[lo:hi].copy_(host[lo:hi], non_blocking=True)
-        elif ne:
-            L.check(lib.mq_host_gather_checked(srcs, nbytes.ctypes.data, dsts.ctypes.data, ne, host.data_ptr(), host.numel(), PACK_THREADS),
-                    "mq_host_gather")
-        del keep
-        if nx:
-            jobs = np.ascontiguousarray(np.stack([x_off[is_x], self.offsets[is_x], npix[is_x]], axis=1), dtype=np.int64)
-            hnp[jobs_off:jobs_off + nx * 24] = jobs.view(np.uint8).reshape(-1)
-            if pieces > 1 or staged is not None:
-                staged[jobs_off:jobs_off + nx * 24].copy_(host[jobs_off:jobs_off + nx * 24], non_blocking=True)
-        if staged is None:
-            staged = host.to(device, non_blocking=True)
+            elif ne:
+                L.check(lib.mq_host_gather_checked(srcs, nbytes.ctypes.data, dsts.ctypes.data, ne, host.data_ptr(), host.numel(), PACK_THREADS),
+                        "mq_host_gather")
+            del keep
+            if nx:
+                jobs = np.ascontiguousarray(np.stack([x_off[is_x], self.offsets[is_x], npix[is_x]], axis=1), dtype=np.int64)
+                hnp[jobs_off:jobs_off + nx * 24] = jobs.view(np.uint8).reshape(-1)
+                if pieces > 1 or staged is not None:
+                    staged[jobs_off:jobs_off + nx * 24].copy_(host[jobs_off:jobs_off + nx * 24], non_blocking=True)
+            if staged is None:
+                staged = host.to(device, non_blocking=True)
+            h2d.hand_over(staged)
         self._host = host   # (pinned source of the asynchronous copies: kept until the consumer's kernels are enqueued behind them)
         if not nx:
             self.buffer = staged[:total] if stage_bytes != total else staged

@@ -14,6 +14,7 @@ rank encodes its shard and keeps it IN HBM (`vectorise_device`), and ONE all_gat
 """
 from __future__ import annotations
 
+import os
 import threading
 from typing import Any, Callable, Dict, Hashable, List, Optional, Tuple
 
@@ -21,6 +22,11 @@ import numpy as np
 
 from marqo_amd.parallel import agree_on_shard, balanced_shards, contiguous_shards, gather_embeddings, gather_embeddings_to_root
 from marqo_amd.s2_inference.enums import Modality
+
+
+# a flush with BOTH modalities on a GPU prepares them on two host threads (A/B knob): the text side (tokeniser, launch sequence) runs on a helper
+# thread while the caller's thread exports / packs the images — the native stager and the launches release the GIL
+PARALLEL_MODALITIES = os.environ.get("MARQO_AMD_INGEST_THREADS", "1") != "0"
 
 
 def estimate_tokens(text: Any) -> float:
@@ -31,6 +37,36 @@ def estimate_tokens(text: Any) -> float:
 
 class PeerShardError(RuntimeError):
     """raised on the ranks whose own shard encoded fine when ANOTHER rank's shard of the same flush failed (see BulkVectoriser._encode)"""
+
+
+class _DeferredRows:
+    """[n, D] rows a tower has been ENQUEUED for.  Device rows start their copy into pinned host memory right away, on the caller's stream —
+    which, at this point, waits for exactly the work these rows depend on — and `numpy()` only waits for that copy's event.  (A blocking
+    `.cpu()` issued later would queue behind everything the thread has enqueued SINCE — with a request in flight: behind the next request's
+    towers, which is what kept RequestShardedIngest's pipeline from overlapping anything, profiles/r04s_stream_timeline.txt.)"""
+
+    def __init__(self, rows):
+        import torch
+        self.rows, self.host, self.event = rows, None, None
+        if isinstance(rows, torch.Tensor) and rows.is_cuda:
+            self.host = torch.empty(rows.shape, dtype=rows.dtype, pin_memory=True)
+            self.host.copy_(rows, non_blocking=True)
+            self.event = torch.cuda.Event()
+            self.event.record(torch.cuda.current_stream(rows.device))
+            # `rows` stays referenced until the copy has completed: its block belongs to the tower's stream, the copy runs on this one
+
+    @property
+    def shape(self):
+        return self.rows.shape
+
+    def numpy(self) -> np.ndarray:
+        import torch
+        if self.event is not None:
+            self.event.synchronize()
+            out = self.host.numpy().copy()     # (the pinned block goes back to the host allocator; the rows live on for as long as the caller keeps them)
+            self.rows = self.host = self.event = None
+            return out
+        return self.rows.cpu().numpy() if isinstance(self.rows, torch.Tensor) else self.rows
 
 
 class BulkVectoriser:
@@ -48,6 +84,8 @@ class BulkVectoriser:
         self._done: Dict[Hashable, np.ndarray] = {}
         self.force_collective = False   # tests: take the sharded path (and run the collective) even in a 1-rank process group
         self.local_only = False         # RequestShardedIngest: requests are owned by ONE rank, nothing is sharded inside a request
+        self._helper = None             # second host thread of a two-modality flush (created on first use)
+        self._model_loaded = False      # a vectorise call of this object has returned (the model is in the cache)
 
     def add(self, key: Hashable, content: Any, modality: Modality = Modality.TEXT) -> None:
         if modality not in self._pending:
@@ -92,6 +130,8 @@ class BulkVectoriser:
                     return self._call(vectorise_device, contents, modality)
                 from marqo_amd.s2_inference.s2_inference import vectorise_ndarray as fn
             out = self._call(fn, contents, modality)
+            if defer and isinstance(out, torch.Tensor):
+                return out                       # (a vectorise_fn that hands back tensors: copied by the caller, like vectorise_device's)
             return out.cpu().numpy() if isinstance(out, torch.Tensor) else out
         on_gpu = dist.get_backend() == "nccl" and str(self.device).startswith("cuda")
         fn = self._vectorise
@@ -131,32 +171,70 @@ class BulkVectoriser:
         full = plan.restore(gather_embeddings(local, counts=plan.counts, force_collective=self.force_collective))
         return full.cpu().numpy()
 
-    def _run_pending(self) -> None:
-        """pops ONE modality at a time; if its vectorise call raises (e.g. one undecodable image) the popped items go back to the
+    def _enqueue_one(self, modality: Modality, items):
+        """one modality's vectorise call -> ((modality, items, rows: ndarray | _DeferredRows) or None, exception or None); a failure puts the
+        items back at the front of the queue"""
+        try:
+            emb = self._encode([c for _, c in items], modality, defer=True)
+            self._model_loaded = True
+            if emb.shape[0] != len(items):
+                raise RuntimeError(f"vectorise returned {emb.shape[0]} embeddings for {len(items)} items")
+            return (modality, items, emb if isinstance(emb, np.ndarray) else _DeferredRows(emb)), None
+        except BaseException as e:  # noqa: BLE001 - re-raised by the caller, after the modalities that did run are stored
+            with self._lock:
+                self._pending[modality] = items + self._pending[modality]
+            return None, e
+
+    def _enqueue_pending(self):
+        """pops ONE modality at a time and runs its vectorise call; if that raises (e.g. one undecodable image) the popped items go back to the
         front of the queue — nothing is lost, the caller sees the exception and may drop the offending key and flush again.
-        On a GPU the modalities are pipelined: the first one's kernels are enqueued (rows stay in HBM), the second one is tokenised /
-        packed / enqueued while they run, and only then are both copied to the host."""
-        import torch
+        On a GPU the modalities are pipelined: the first one's kernels are enqueued (rows stay in HBM, their copy to the host is enqueued behind
+        them), the second one is tokenised / packed / enqueued while they run — on a second host thread when the engine's own loaders are
+        used (`_two_threads`).  -> ([(modality, items, rows)], first exception or None)"""
+        if self._two_threads():
+            with self._lock:
+                texts, self._pending[Modality.TEXT] = self._pending[Modality.TEXT], []
+                images, self._pending[Modality.IMAGE] = self._pending[Modality.IMAGE], []
+            if texts and images:
+                if self._helper is None:
+                    from concurrent.futures import ThreadPoolExecutor
+                    self._helper = ThreadPoolExecutor(max_workers=1, thread_name_prefix="marqo-amd-ingest-text")
+                fut = self._helper.submit(self._enqueue_one, Modality.TEXT, texts)
+                img, img_fail = self._enqueue_one(Modality.IMAGE, images)
+                txt, txt_fail = fut.result()
+                return [e for e in (txt, img) if e is not None], txt_fail or img_fail
+            with self._lock:   # one modality only: the sequential form below
+                self._pending[Modality.TEXT] = texts + self._pending[Modality.TEXT]
+                self._pending[Modality.IMAGE] = images + self._pending[Modality.IMAGE]
         enqueued, failure = [], None
         for modality in (Modality.TEXT, Modality.IMAGE):
             with self._lock:
                 items, self._pending[modality] = self._pending[modality], []
             if not items:
                 continue
-            try:
-                emb = self._encode([c for _, c in items], modality, defer=True)
-                if emb.shape[0] != len(items):
-                    raise RuntimeError(f"vectorise returned {emb.shape[0]} embeddings for {len(items)} items")
-                enqueued.append((modality, items, emb))
-            except BaseException as e:  # noqa: BLE001 - re-raised below, after the modalities that did run are stored
-                with self._lock:
-                    self._pending[modality] = items + self._pending[modality]
-                failure = e
+            entry, failure = self._enqueue_one(modality, items)
+            if failure is not None:
                 break
+            enqueued.append(entry)
+        return enqueued, failure
+
+    def _two_threads(self) -> bool:
+        import torch
+        import torch.distributed as dist
+        if not PARALLEL_MODALITIES or self._vectorise is not None or self.force_collective or not self._model_loaded:
+            return False    # (the first flush loads the model: the reference's model cache rejects two concurrent loads, s2_inference.py:348-394)
+        if not (str(self.device).startswith("cuda") and torch.cuda.is_available()):
+            return False
+        return self.local_only or not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+
+    def _store(self, enqueued):
+        """copies what `_enqueue_pending` left in HBM to the host and files the rows under their keys -> first exception or None"""
+        import torch
+        failure = None
         for modality, items, emb in enqueued:
             try:
-                if isinstance(emb, torch.Tensor):
-                    emb = emb.cpu().numpy()
+                if not isinstance(emb, np.ndarray):
+                    emb = emb.numpy()
             except BaseException as e:  # noqa: BLE001 - an asynchronous device error surfaces at the copy: same re-queue rule
                 with self._lock:
                     self._pending[modality] = items + self._pending[modality]
@@ -165,8 +243,27 @@ class BulkVectoriser:
             with self._lock:
                 for (key, _), row in zip(items, emb):
                     self._done[key] = row
+        return failure
+
+    def _run_pending(self) -> None:
+        enqueued, failure = self._enqueue_pending()
+        late = self._store(enqueued)
+        failure = failure or late
         if failure is not None:
             raise failure
+
+    def flush_async(self) -> "PendingFlush":
+        """`flush()` in two halves: everything queued is tokenised / packed / ENQUEUED now (a failure there raises now, with the re-queue
+        rule of flush()); the returned handle's `result()` copies the rows to the host and returns what flush() would have.  Between the two
+        the GPU works on this flush while the caller prepares the next one (RequestShardedIngest keeps one request in flight that way).
+        Until `result()` ran, the keys of this flush are not visible to flush() / another flush_async()."""
+        enqueued, failure = self._enqueue_pending()
+        if failure is not None:
+            self._store(enqueued)      # the modality that did run is kept for the retry, as in flush()
+            raise failure
+        with self._lock:
+            prior, self._done = self._done, {}
+        return PendingFlush(self, enqueued, prior)
 
     def discard(self, key: Hashable) -> int:
         """drop every queued item with this key (e.g. the image a failed flush reported); returns how many were dropped"""
@@ -194,6 +291,35 @@ class BulkVectoriser:
         with self._lock:
             out, self._done = self._done, {}
         return out
+
+
+class PendingFlush:
+    """handle of BulkVectoriser.flush_async(): rows still in HBM (or already on the host, for CPU / stub vectorise functions)"""
+
+    def __init__(self, bulk: BulkVectoriser, enqueued, prior: Dict[Hashable, np.ndarray]):
+        self._bulk, self._enqueued, self._rows = bulk, enqueued, prior
+
+    def result(self) -> Dict[Hashable, np.ndarray]:
+        """{key: float32 [D]} of this flush (+ rows an automatic max_pending flush had already stored); a device error that surfaces at the copy
+        re-queues that modality's items in front of the owner's queue and raises"""
+        import torch
+        if self._enqueued is not None:
+            enqueued, self._enqueued = self._enqueued, None
+            failure = None
+            for modality, items, emb in enqueued:
+                try:
+                    if not isinstance(emb, np.ndarray):
+                        emb = emb.numpy()
+                except BaseException as e:  # noqa: BLE001
+                    with self._bulk._lock:
+                        self._bulk._pending[modality] = items + self._bulk._pending[modality]
+                    failure = failure or e
+                    continue
+                for (key, _), row in zip(items, emb):
+                    self._rows[key] = row
+            if failure is not None:
+                raise failure
+        return self._rows
 
 
 class RequestShardedIngest:
@@ -226,6 +352,12 @@ class RequestShardedIngest:
         self.touched: List[int] = []                          # request indices this rank was handed (tests: ownership)
         self.failed: List[int] = []                           # owned requests whose encode raised since the last collect()
         self.failed_requests: List[int] = []                  # after collect(): every rank's failed requests (root), own ones elsewhere
+        self.errors: Dict[int, BaseException] = {}            # request index -> what its encode raised (since the last collect())
+        # ONE request in flight: submit(i) tokenises / packs / enqueues request i and only THEN copies request i - 1's rows to the host, so the
+        # host side of a request (Python bookkeeping, tokeniser, Pillow -> pinned staging: 40 % of a ViT-B/32 request's wall time, all of it GPU
+        # idle time when requests run strictly one after the other) overlaps the previous request's kernels.  pipeline_depth = 0: synchronous.
+        self.pipeline_depth = 1
+        self._inflight: Optional[Tuple[int, List[Hashable], PendingFlush]] = None
 
     def owner(self, request_index: int) -> int:
         return request_index % self.world
@@ -233,8 +365,32 @@ class RequestShardedIngest:
     def owns(self, request_index: int) -> bool:
         return self.owner(request_index) == self.rank
 
+    def _resolve(self, inflight, reraise: bool) -> None:
+        request_index, keys, handle = inflight
+        try:
+            out = handle.result()
+        except BaseException as e:  # noqa: BLE001 - an asynchronous device error of THAT request, surfacing at its copy
+            self._bulk.reset()
+            self.failed.append(request_index)
+            self.errors[request_index] = e
+            if reraise:
+                raise
+            return
+        for key in keys:
+            self._rows.append(out[key])
+            self._index.append((request_index, key))
+
+    def drain(self) -> None:
+        """wait for the request in flight (if any) and file its rows; raises what its encode raised"""
+        inflight, self._inflight = self._inflight, None
+        if inflight is not None:
+            self._resolve(inflight, reraise=True)
+
     def submit(self, request_index: int, items) -> None:
-        """encode one owned request now (its rows stay on this rank until collect())"""
+        """encode one owned request (its rows stay on this rank until collect()).  Everything that can fail on the HOST for this request —
+        decoding, tokenising, staging, the enqueue itself — fails here, now.  Its device work is left in flight until the next submit() /
+        drain() / collect(): an asynchronous device error of request i is therefore recorded (`failed`, `errors[i]`, collect()'s
+        `failed_requests`) when request i + 1 is submitted, without failing THAT call; call drain() after submit() for the synchronous form."""
         if not self.owns(request_index):
             raise ValueError(f"rank {self.rank} was handed request {request_index}, which belongs to rank {self.owner(request_index)}")
         self.touched.append(request_index)
@@ -243,25 +399,33 @@ class RequestShardedIngest:
             self._bulk.add(key, content, modality)
             keys.append(key)
         try:
-            out = self._bulk.flush()
-        except BaseException:
+            handle = self._bulk.flush_async()
+        except BaseException as e:
             # One bad document (an undecodable image) must not poison this rank's stream: BulkVectoriser re-queues the failed modality and
             # keeps the other one's rows for a retry, but a request is all-or-nothing here — drop both, so that the NEXT request starts from
             # an empty queue, and remember the index: the caller may catch the exception and go on, collect() still runs on every rank
-            # (nobody is left waiting in the collective) and reports the request as failed.
+            # (nobody is left waiting in the collective) and reports the request as failed.  (The request in flight is not touched: its
+            # rows are in its handle, not in the queue that is reset here.)
             self._bulk.reset()
             self.failed.append(request_index)
+            self.errors[request_index] = e
             raise
-        for key in keys:
-            self._rows.append(out[key])
-            self._index.append((request_index, key))
+        previous, self._inflight = self._inflight, (request_index, keys, handle)
+        if previous is not None:
+            self._resolve(previous, reraise=False)
+        if self.pipeline_depth <= 0:
+            self.drain()
 
     def collect(self) -> Dict[int, Dict[Hashable, np.ndarray]]:
         """gather every rank's rows on the root -> {request index: {key: row}} there, {} elsewhere; resets the store"""
         import torch
+        inflight, self._inflight = self._inflight, None
+        if inflight is not None:
+            self._resolve(inflight, reraise=False)     # (a failure is reported through failed_requests; every rank must reach the collective)
         rows, index = self._rows, self._index
         self._rows, self._index = [], []
         failed, self.failed = self.failed, []
+        self.errors = {i: e for i, e in self.errors.items() if i in failed}   # kept until the NEXT collect() for the caller to inspect
         self.failed_requests = sorted(failed)
         local = np.stack(rows).astype(np.float32, copy=False) if rows else None
         if self.world == 1:

@@ -270,3 +270,56 @@ def test_a_failed_request_does_not_poison_the_stream():
     assert sorted(rows) == [0, 2] and set(rows[2]) == {(2, "t"), (2, "i")} and rows[2][(2, "t")][0] == 4.0
     assert ing.failed_requests == [1] and ing.failed == []
     assert ing.collect() == {} and ing.failed_requests == []
+
+
+def test_one_request_stays_in_flight_and_a_late_device_error_fails_only_that_request():
+    """submit(i) enqueues request i and only then copies request i - 1's rows to the host (its host work overlaps the previous request's kernels).
+    Rows come out in submission order whatever the depth; an error that surfaces at the deferred copy (an asynchronous device fault) is charged to
+    ITS request — recorded when the next one is submitted, raised by drain() — and leaves the queue clean"""
+    import torch
+    from marqo_amd.ingest import RequestShardedIngest
+
+    class _Faulty(torch.Tensor):           # stands for rows still in HBM whose kernels faulted: the copy raises
+        def cpu(self, *a, **k):
+            raise RuntimeError("HIP error: an illegal memory access was encountered")
+
+    def fn(model, content, **kw):
+        rows = torch.tensor([[float(len(str(c))), float(kw["modality"] == Modality.IMAGE)] for c in content])
+        return torch.Tensor._make_subclass(_Faulty, rows) if any("FAULT" in str(c) for c in content) else rows
+
+    def request(i, word):
+        return [((i, "t"), word, Modality.TEXT), ((i, "i"), word + "-img", Modality.IMAGE)]
+
+    for depth in (1, 0):
+        ing = RequestShardedIngest("m", "cpu", vectorise_fn=fn)
+        ing.pipeline_depth = depth
+        ing.submit(0, request(0, "a"))
+        assert (ing._inflight is not None) == (depth == 1) and len(ing._rows) == (0 if depth else 2)
+        ing.submit(1, request(1, "bb"))
+        assert len(ing._rows) == (2 if depth else 4)                  # request 0 was filed while request 1 went in flight
+        ing.submit(2, request(2, "ccc"))
+        rows = ing.collect()
+        assert sorted(rows) == [0, 1, 2] and [rows[i][(i, "t")][0] for i in range(3)] == [1.0, 2.0, 3.0] and ing._inflight is None
+    # a late fault
+    ing = RequestShardedIngest("m", "cpu", vectorise_fn=fn)
+    ing.submit(0, request(0, "ok"))
+    ing.submit(1, request(1, "FAULT"))                                # enqueues fine (the fault is asynchronous) ...
+    ing.submit(2, request(2, "fine"))                                 # ... and is charged to request 1 here, without failing request 2's call
+    assert ing.failed == [1] and isinstance(ing.errors[1], RuntimeError) and ing._bulk.pending() == 0
+    ing.submit(3, request(3, "FAULT"))
+    with pytest.raises(RuntimeError):
+        ing.drain()                                                   # the synchronous form: wait for the request in flight, raise its error
+    rows = ing.collect()
+    assert sorted(rows) == [0, 2] and ing.failed_requests == [1, 3] and set(rows[2]) == {(2, "t"), (2, "i")}
+
+
+def test_flush_async_hands_back_what_flush_would():
+    from marqo_amd.ingest import BulkVectoriser
+    fn = lambda model, content, **kw: np.asarray([[float(len(c))] for c in content], dtype=np.float32)   # noqa: E731
+    bulk = BulkVectoriser("m", "cpu", vectorise_fn=fn)
+    bulk.add("a", "x")
+    bulk.add("b", "yy", Modality.IMAGE)
+    h = bulk.flush_async()
+    assert bulk.pending() == 0 and bulk.flush() == {}                 # not visible to another flush before result()
+    out = h.result()
+    assert set(out) == {"a", "b"} and out["b"][0] == 2.0 and h.result() is out

@@ -1,0 +1,60 @@
+"""add_documents_stream (bench.py workload: 128 texts + 128 PIL images per request through RequestShardedIngest) with the request pipeline on / off,
+interleaved in one process, + a cProfile of the pipelined form (where the host time of a request goes).  usage: python tools/stream_quick.py [docs]"""
+import cProfile, io, os, pstats, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["MARQO_AMD_SYNTHETIC_WEIGHTS"] = "1"
+os.environ.setdefault("MARQO_MAX_CUDA_MODEL_MEMORY", "64")
+import numpy as np
+import torch
+from PIL import Image
+from marqo_amd.ingest import RequestShardedIngest
+from marqo_amd.s2_inference.enums import Modality
+
+docs = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+dev, name = "cuda:0", "open_clip/ViT-B-32/laion2b_s34b_b79k"
+rng = np.random.default_rng(100)
+words = ["alpha", "beta", "gamma", "delta", "marqo", "tensor", "search", "image", "text", "vector"]
+pool = []
+for r in range(4):
+    imgs = [Image.fromarray(rng.integers(0, 256, (224, 224, 3), dtype=np.uint8)) for _ in range(docs)]
+    texts = [" ".join(words[int(j) % 10] for j in rng.integers(0, 10, int(rng.integers(3, 60)))) + f" {r} {i}" for i in range(docs)]
+    pool.append((texts, imgs))
+ing = RequestShardedIngest(name, dev)
+state = {"i": 0}
+
+
+def step():
+    i = state["i"]
+    state["i"] += 1
+    texts, imgs = pool[i % len(pool)]
+    ing.submit(i, [((i, d, "t"), texts[d], Modality.TEXT) for d in range(docs)] + [((i, d, "i"), imgs[d], Modality.IMAGE) for d in range(docs)])
+
+
+def run(depth, n):
+    ing.pipeline_depth = depth
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        step()
+    rows = ing.collect()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert len(rows) == n
+    return dt / n
+
+
+for _ in range(6):
+    step()
+ing.collect()
+for rep in range(3):
+    for depth in (0, 1):
+        ms = run(depth, 30) * 1e3
+        print(f"pipeline_depth={depth}: {ms:.3f} ms per {docs}-document request = {2 * docs / ms * 1e3:.0f} embeddings/s")
+ing.pipeline_depth = 1
+pr = cProfile.Profile()
+pr.enable()
+run(1, 30)
+pr.disable()
+out = io.StringIO()
+pstats.Stats(pr, stream=out).sort_stats("tottime").print_stats(18)
+print("\n".join(line[:170] for line in out.getvalue().splitlines()[4:40]))
