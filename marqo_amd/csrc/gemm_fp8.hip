@@ -8,19 +8,28 @@
 // at twice the bf16 rate (the non-scaled 16x16x32_fp8 runs at the bf16 rate), and fp8 operands halve the bytes moved
 // through the LDS-DMA path and the LDS, which is what bounds the bf16 kernel.
 //
-// Structure = gemm_bf16.hip: (32*MT)x128 tile, 4 wave64s as 2x2, BK = 128 elements (= the same 128-B LDS rows),
-// 2 stages, LDS-DMA issues interleaved with the MFMAs, XCD-aware tile map, operands fed swapped so a lane owns 4
-// consecutive n.  A lane's fragment is 32 consecutive k-bytes (two ds_read_b128): 16-B chunk c of row r is stored at
-// c ^ f(r) with f below — chosen so that each 16-lane ds_read_b128 group (8 rows reading chunk 2g+j, 8 rows reading
-// chunk 2g+2+j) touches 16 distinct 16-B slots of the 256-B bank row.
+// Structure = gemm_bf16.hip (one design, round 4): (32*MT)x128 tile, 4 wave64s as 2x2, BK = 128 elements (= the same 128-B LDS rows), a 2-stage
+// LDS ring filled by buffer-descriptor LDS-DMA two stages ahead of the MFMAs (a cursor that walks over tile boundaries, so a tile's first stages
+// land during the previous tile's epilogue), fragment reads as inline-asm ds_read_b128 with hand-placed waits, ONE barrier per k-step placed
+// mid-step, persistent XCD-aware tile walk, operands fed swapped so a lane owns 4 consecutive n.  A lane's fragment is 32 consecutive k-bytes
+// (two ds_read_b128): 16-B chunk c of row r is stored at c ^ f(r) with f below — chosen so that each 16-lane ds_read_b128 group (8 rows
+// reading chunk 2g+j, 8 rows reading chunk 2g+2+j) touches 16 distinct 16-B slots of the 256-B bank row.
+//
+// The k-step (a 16x16x128 MFMA consumes the whole 128-B row: there is no k-half to pipeline over as in the bf16 kernel; the halves are the W side):
+//   top     s_waitcnt lgkmcnt(0): A fragments + W sub-tiles 0, 1 of this stage (read during the previous step) have landed
+//   half A  2 MT MFMAs (mt, nt = 0 | 1); between them the reads of W sub-tiles 2, 3 of this stage
+//   mid     vmcnt(0) (my pieces of the NEXT stage have landed), lgkmcnt(0), s_barrier: the next stage may be read, this buffer may be refilled
+//   half B  2 MT MFMAs (mt, nt = 2 | 3), row group by row group; behind row group mt's last MFMA the read of the NEXT stage's A fragment mt
+//           into the same registers (an MFMA has read its operands long before a ds_read issued behind it returns), the next stage's W
+//           sub-tiles 0, 1, and the LDS-DMA pieces of the stage after next into the buffer this step has finished with
 #include <stdlib.h>
 #include <type_traits>
 #include "common.h"
 
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 
-// scheduling knobs shared with gemm_bf16.hip (mq_tune "gemm_persist" / "gemm_cgroup" / "gemm_wide")
-extern int mq_gemm_knob_persist, mq_gemm_knob_cgroup, mq_gemm_knob_wide;
+// scheduling knobs shared with gemm_bf16.hip (mq_tune "gemm_cgroup"; the widened epilogue stores are always on)
+extern int mq_gemm_knob_cgroup, mq_gemm_knob_wide;
 
 namespace {
 
@@ -29,10 +38,30 @@ constexpr int W_TILE_BYTES = BN * BK;      // 16 KiB
 constexpr int UNIT_SCALE = 0x7F7F7F7F;     // e8m0 127 = 2^0 in every byte
 constexpr int RESIDENT_SLOTS = 512;        // 256 CUs x 2 workgroups
 
-__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, unsigned lds_wave_base) {
+    // 16 B per lane; LDS destination = wave-uniform base (M0) + lane * 16; source = descriptor base + voff (per lane) + soff (scalar)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(uintptr_t)lds_wave_base, 16, voff, soff, 0, 0);
 }
+// a 32-byte fragment = two ds_read_b128 (logical chunks 2g, 2g + 1 of the lane's row) as inline asm: hipcc cannot tell a compiler-visible LDS
+// read from the LDS-DMA writes in flight and would put s_waitcnt vmcnt(0) in front of every one (gemm_bf16.hip)
+template <int OFF>
+__device__ __forceinline__ i32x8 lds_read32(unsigned addr0, unsigned addr1) {
+    i32x4_t lo, hi;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(lo) : "v"(addr0), "n"(OFF));
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(hi) : "v"(addr1), "n"(OFF));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+// ties the consumers of an asm-read fragment to the hand-placed s_waitcnt by data flow (gemm_bf16.hip, `landed`)
+template <class T>
+__device__ __forceinline__ void landed(T& v) { asm volatile("" : "+v"(v)); }
+
+template <int... Is, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F&& f) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
 
 // chunk swizzle: u = (row >> 1) & 7;  f = u for u in {0,1,6,7}, u ^ 2 for u in {2,3,4,5}
 __device__ __forceinline__ int fswz(int row) {
@@ -43,18 +72,17 @@ __device__ __forceinline__ int fswz(int row) {
 __device__ __forceinline__ float clamp448(float v) { return fminf(fmaxf(v, -448.f), 448.f); }
 
 // FLAGS: MQ_EPI_BIAS / GELU / QUICKGELU / RESIDUAL / OUT_F32 / OUT_FP8; ROWSCALE: a_scale is per row (else scalar).
-// PERSIST / cgroup / wide: the same persistent tile loop with cross-tile prefetch, L2-blocked tile order and widened
-// epilogue stores as gemm_bf16.hip (at K = 768 a tile is only SIX 128-deep k-steps here, so the per-tile overheads weigh
-// even more than in the bf16 kernel).  Widened stores: bf16 out -> 16 B per lane after one v_permlane16_swap per pair;
-// e4m3 out -> a lane's 4 codes per sub-tile become 16 CONSECUTIVE codes after a permlane16 stage (pairs of sub-tiles) and a
-// permlane32 stage (the two pairs), i.e. one 16-byte store per 16-row sub-tile instead of four 4-byte ones.
-template <int FLAGS, int MT, bool ROWSCALE, bool PERSIST>
+// cgroup / wide: L2-blocked tile order and widened epilogue stores as in gemm_bf16.hip (at K = 768 a tile is only SIX 128-deep k-steps here, so
+// the per-tile overheads weigh even more than in the bf16 kernel).  Widened stores: bf16 out -> 16 B per lane after one v_permlane16_swap per
+// pair; e4m3 out -> a lane's 4 codes per sub-tile become 16 CONSECUTIVE codes after a permlane16 stage (pairs of sub-tiles) and a permlane32
+// stage (the two pairs), i.e. one 16-byte store per 16-row sub-tile instead of four 4-byte ones.
+template <int FLAGS, int MT, bool ROWSCALE>
 __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(
     const uint8_t* __restrict__ A, int64_t lda, const uint8_t* __restrict__ Wt, int64_t ldw,
     const float* __restrict__ a_scale, const float* __restrict__ w_scale,
     const float* __restrict__ bias, const float* residual, void* out, int64_t ldc,
     const float* __restrict__ out_scale, float* amax_out,
-    int M, int N, int K, int tiles_n, int num_tiles, int cgroup, int band_rows, int wide) {
+    int M, int N, int K, int tiles_n, int num_tiles, int cgroup, int band_rows, int wide, unsigned a_bytes, unsigned w_bytes) {
     constexpr int BM = 32 * MT;
     constexpr int A_TILE_BYTES = BM * BK;
     constexpr int STAGE_BYTES = A_TILE_BYTES + W_TILE_BYTES;
@@ -84,130 +112,171 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(
         n0 = tn * BN;
     };
 
+    constexpr int NL = MT + 4;     // LDS-DMA pieces (8 rows x 128 B) per wave per stage
+    constexpr int NB = 2 * MT;     // MFMAs per wave per half
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int l15 = lane & 15, g = lane >> 4;
 
-    // ---- staging (8 rows x 128 B per LDS-DMA; lane -> row = base + lane/8, physical chunk = lane%8) ------------
+    // ---- staging: wave w owns A rows [8*MT*w, 8*MT*(w+1)) and W rows [32w, 32w+32) of a stage; lane -> (row = base + lane/8, physical 16-B
+    // chunk = lane%8), it fetches logical chunk (lane%8) ^ f(row): the swizzle lives on the SOURCE address, the LDS image is lane-linear
     const int srow = lane >> 3;
-    const uint8_t* a_src[MT];
-    const uint8_t* w_src[4];
+    unsigned a_vo[MT], w_vo[4];
     auto set_sources = [&](int m0, int n0) {
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int row = wave * (8 * MT) + i * 8 + srow;
             int gm = m0 + row; gm = gm < M ? gm : M - 1;
-            a_src[i] = A + (int64_t)gm * lda + ((lane & 7) ^ fswz(row)) * 16;
+            a_vo[i] = (unsigned)gm * (unsigned)lda + (unsigned)(((lane & 7) ^ fswz(row)) * 16);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = wave * 32 + i * 8 + srow;
             int gn = n0 + row; gn = gn < N ? gn : N - 1;
-            w_src[i] = Wt + (int64_t)gn * ldw + ((lane & 7) ^ fswz(row)) * 16;
+            w_vo[i] = (unsigned)gn * (unsigned)ldw + (unsigned)(((lane & 7) ^ fswz(row)) * 16);
         }
     };
-    auto stage = [&](int buf, int kt) {
-        char* sa = smem + buf * STAGE_BYTES + wave * (8 * MT * 128);
-        char* sw = smem + buf * STAGE_BYTES + A_TILE_BYTES + wave * (32 * 128);
-#pragma unroll
-        for (int i = 0; i < MT; ++i) glds16(a_src[i] + (int64_t)kt * BK, sa + i * (8 * 128));
-#pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(w_src[i] + (int64_t)kt * BK, sw + i * (8 * 128));
+    const int nk = K / BK;
+    // DMA cursor: (tile d_vbid, k-step d_k) of the next stage to request, two stages ahead of the MFMAs; past the workgroup's last tile the
+    // descriptors' sizes drop to 0 (the two trailing requests are out of range for every lane: no traffic, no second k-step variant)
+    int d_vbid = blockIdx.x, d_k = 0;
+    unsigned a_rec = a_bytes, w_rec = w_bytes;
+    {
+        int m0, n0;
+        tile_origin(d_vbid, m0, n0);
+        set_sources(m0, n0);
+    }
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned dma_a0 = lds0 + (unsigned)wave * (8 * MT * 128), dma_w0 = lds0 + A_TILE_BYTES + (unsigned)wave * (32 * 128);   // scalars
+    auto issue_piece = [&](int i, unsigned bufoff) {
+        const unsigned soff = (unsigned)d_k * BK;
+        if (i < MT) dma16(__builtin_amdgcn_make_buffer_rsrc((void*)A, 0, a_rec, 0x00020000), a_vo[i < MT ? i : 0], soff, dma_a0 + bufoff + (unsigned)i * 1024u);
+        else dma16(__builtin_amdgcn_make_buffer_rsrc((void*)Wt, 0, w_rec, 0x00020000), w_vo[i >= MT ? i - MT : 0], soff, dma_w0 + bufoff + (unsigned)(i - MT) * 1024u);
+    };
+    auto advance_cursor = [&]() {
+        if (++d_k == nk) {
+            d_k = 0;
+            d_vbid += gridDim.x;
+            if (d_vbid < num_tiles) {
+                int m0, n0;
+                tile_origin(d_vbid, m0, n0);
+                set_sources(m0, n0);
+            } else {
+                a_rec = 0; w_rec = 0;
+            }
+        }
     };
 
+    // ---- fragment read addresses (LDS byte offsets), fixed per lane: logical chunks 2g and 2g + 1 of row base16 + l15 (sub-tile bases are
+    // multiples of 16 rows: f(row) = f(l15))
+    const int fr = fswz(l15);
+    const unsigned c0 = (unsigned)(((2 * g) ^ fr) << 4), c1 = (unsigned)(((2 * g + 1) ^ fr) << 4);
+    const unsigned a_row = lds0 + (unsigned)((wm * (16 * MT) + l15) * 128);
+    const unsigned w_row = lds0 + A_TILE_BYTES + (unsigned)((wn * 64 + l15) * 128);
+    const unsigned aB0 = a_row + c0, aB1 = a_row + c1, wB0 = w_row + c0, wB1 = w_row + c1;
+
     f32x4 acc[MT][4];
+    i32x8 af[MT], wf[4];
     const float a_scalar = ROWSCALE ? 1.f : a_scale[0];
     const float inv_out = (FLAGS & MQ_EPI_OUT_FP8) ? 1.0f / out_scale[0] : 1.f;
     float amax = 0.f;
 
-    const int nk = K / BK;
-    int vbid = blockIdx.x;
-    int m0, n0;
-    tile_origin(vbid, m0, n0);
-    set_sources(m0, n0);
-    stage(0, 0);
-    int buf = 0;
+    // ---- prologue: the workgroup's first two stages, then the first stage's A fragments and W sub-tiles 0, 1
+#pragma unroll
+    for (int i = 0; i < NL; ++i) issue_piece(i, 0);
+    advance_cursor();
+#pragma unroll
+    for (int i = 0; i < NL; ++i) issue_piece(i, STAGE_BYTES);
+    advance_cursor();
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");   // stage 0 landed (loads retire in issue order)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    unsigned bufoff = 0;   // LDS byte offset of the stage the next k-step consumes
+    int c_vbid = blockIdx.x;
+
+    // LAST: a tile's last k-step does not read the next stage's fragments — that stage belongs to the NEXT tile, whose fragments would be live
+    // through the whole epilogue (56 registers at MT = 5 next to 80 accumulators and the epilogue's own: spills).  The tile loop reads them
+    // after the epilogue instead: one exposed LDS latency per tile.
+    auto kstep = [&](auto last_tag) {
+        constexpr bool LAST = decltype(last_tag)::value;
+        // -------- half A: MFMAs (mt, nt = 0 | 1); reads of this stage's W sub-tiles 2, 3 between them
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // af[*], wf[0], wf[1] landed
+        landed(wf[0]); landed(wf[1]);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) landed(af[t]);
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const unsigned b0 = wB0 + bufoff, b1 = wB1 + bufoff;
+            static_for<NB>([&](auto idx_tag) {
+                constexpr int idx = decltype(idx_tag)::value, mt = idx / 2, nt = idx % 2;
+                acc[mt][nt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[nt], af[mt], acc[mt][nt], 0, 0, 0, UNIT_SCALE, 0, UNIT_SCALE);
+                if constexpr (idx == 0 || idx == (NB > 2 ? 2 : 1)) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (idx == 0) wf[2] = lds_read32<2 * 2048>(b0, b1);
+                    else wf[3] = lds_read32<3 * 2048>(b0, b1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
+        }
+        // -------- mid-step: the stage after this one has landed (my pieces), my reads of this buffer are done; after the barrier both hold for
+        // every wave: the next stage may be read, this buffer may be refilled
+        // (the two halves write DIFFERENT accumulators: nothing but these empty asms keeps half A's MFMAs — pure, results unused until the next
+        // k-step — in front of the barrier; without them the optimiser sank all 4 MT MFMAs into the loop latch, behind every wait and read)
+#pragma unroll
+        for (int t = 0; t < MT; ++t) { landed(acc[t][0]); landed(acc[t][1]); }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) — as a builtin: the compiler's own scoreboard must see that nothing is pending
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        landed(wf[2]); landed(wf[3]);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        // -------- half B: MFMAs (mt, nt = 2 | 3); behind MFMA idx: LDS-DMA piece idx of the stage after next (the rest behind the last one);
+        // behind idx 0 / 2 the next stage's W sub-tiles 0 / 1; behind a row group's second MFMA the next stage's A fragment of that row group
+        {
+            const unsigned nb = bufoff ^ (unsigned)STAGE_BYTES;
+            const unsigned nw0 = wB0 + nb, nw1 = wB1 + nb, na0 = aB0 + nb, na1 = aB1 + nb;
+            static_for<NB>([&](auto idx_tag) {
+                constexpr int idx = decltype(idx_tag)::value, mt = idx / 2, nt = 2 + idx % 2;
+                acc[mt][nt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[nt], af[mt], acc[mt][nt], 0, 0, 0, UNIT_SCALE, 0, UNIT_SCALE);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (idx < NL) issue_piece(idx, bufoff);
+                if constexpr (idx == NB - 1) {
+#pragma unroll
+                    for (int i = NB; i < NL; ++i) issue_piece(i, bufoff);
+                }
+                if constexpr (!LAST && idx == 0) wf[0] = lds_read32<0>(nw0, nw1);
+                if constexpr (!LAST && idx == (NB > 2 ? 2 : 1)) wf[1] = lds_read32<2048>(nw0, nw1);
+                if constexpr (!LAST && idx % 2 == 1) af[mt] = lds_read32<mt * 2048>(na0, na1);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        }
+#pragma unroll
+        for (int t = 0; t < MT; ++t) { landed(acc[t][2]); landed(acc[t][3]); }
+        advance_cursor();
+        bufoff ^= (unsigned)STAGE_BYTES;
+    };
+
     for (;;) {
+        int cm0, cn0;
+        tile_origin(c_vbid, cm0, cn0);
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // ---- fragment offsets: lane (l15, g) reads logical chunks 2g and 2g+1 of row base16 + l15 (recomputed per tile in
-        // the persistent form so that they are not live across the epilogue, cf. gemm_bf16.hip)
-        int l15f = l15, gf = g;
-        if (PERSIST) asm volatile("" : "+v"(l15f), "+v"(gf));
-        const int fr = fswz(l15f);  // sub-tile bases are multiples of 16 rows
-        const int c0 = ((2 * gf) ^ fr) << 4, c1 = ((2 * gf + 1) ^ fr) << 4;
-        int a_off[MT], w_off[4];
-#pragma unroll
-        for (int t = 0; t < MT; ++t) a_off[t] = (wm * (16 * MT) + t * 16 + l15f) * 128;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) w_off[t] = (wn * 64 + t * 16 + l15f) * 128;
-        auto load_frag = [&](const char* base) -> i32x8 {
-            const uint4 lo = *(const uint4*)(base + c0);
-            const uint4 hi = *(const uint4*)(base + c1);
-            return i32x8{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
-        };
-        auto kstep = [&](int cur, int64_t koff, auto prefetch_tag) {
-            constexpr bool PREFETCH = decltype(prefetch_tag)::value;
-            const char* sa = smem + cur * STAGE_BYTES;
-            const char* sw = sa + A_TILE_BYTES;
-            char* na = smem + (cur ^ 1) * STAGE_BYTES + wave * (8 * MT * 128);
-            char* nw = smem + (cur ^ 1) * STAGE_BYTES + A_TILE_BYTES + wave * (32 * 128);
-            i32x8 af[MT], wf[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) wf[t] = load_frag(sw + w_off[t]);
-#pragma unroll
-            for (int t = 0; t < MT; ++t) af[t] = load_frag(sa + a_off[t]);
-            constexpr int NL = MT + 4;
-            constexpr int NM = 4 * MT;
-            constexpr int GAP = NM / NL > 0 ? NM / NL : 1;
-            int issued = 0;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    acc[mt][nt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[nt], af[mt], acc[mt][nt], 0, 0, 0, UNIT_SCALE, 0,
-                                                                                  UNIT_SCALE);
-                    const int done = mt * 4 + nt + 1;
-                    if (PREFETCH && done % GAP == 0 && issued < NL) {
-                        if (issued < MT) glds16(a_src[issued] + koff, na + issued * (8 * 128));
-                        else glds16(w_src[issued - MT] + koff, nw + (issued - MT) * (8 * 128));
-                        ++issued;
-                    }
-                }
-            if (PREFETCH) {
-#pragma unroll
-                for (; issued < NL; ++issued) {
-                    if (issued < MT) glds16(a_src[issued] + koff, na + issued * (8 * 128));
-                    else glds16(w_src[issued - MT] + koff, nw + (issued - MT) * (8 * 128));
-                }
-            }
-        };
-
-        for (int kt = 0; kt < nk - 1; ++kt) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            kstep(buf, (int64_t)(kt + 1) * BK, std::true_type{});
-            buf ^= 1;
+        // the tile's first stage is in LDS and visible (the prologue's barrier / the previous tile's last mid-step barrier): its A fragments and W
+        // sub-tiles 0, 1
+        {
+            const unsigned w0 = wB0 + bufoff, w1 = wB1 + bufoff, a0 = aB0 + bufoff, a1 = aB1 + bufoff;
+            wf[0] = lds_read32<0>(w0, w1);
+            wf[1] = lds_read32<2048>(w0, w1);
+            static_for<MT>([&](auto t_tag) { constexpr int t = decltype(t_tag)::value; af[t] = lds_read32<t * 2048>(a0, a1); });
         }
-        const int cm0 = m0, cn0 = n0;
-        bool more = false;
-        if (PERSIST) {
-            vbid += gridDim.x;
-            more = vbid < num_tiles;
-            if (more) {
-                tile_origin(vbid, m0, n0);
-                set_sources(m0, n0);
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (PERSIST && more) kstep(buf, 0, std::true_type{});
-        else kstep(buf, 0, std::false_type{});
-        buf ^= 1;
+        for (int kt = 0; kt < nk - 1; ++kt) kstep(std::false_type{});
+        kstep(std::true_type{});
 
         // ---- epilogue: lane owns out[m][n .. n+3]; dequantise with a_scale[m] * w_scale[n] ----------------------------
         // everything the epilogue READS is fetched up front (residual tile first): left inside the (mt, nt) loop every
@@ -253,6 +322,9 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(
             sw_v[nt] = n < N ? *(const f32x4*)(w_scale + n) : f32x4{0.f, 0.f, 0.f, 0.f};
             bias_v[nt] = ((FLAGS & MQ_EPI_BIAS) && n < N) ? *(const f32x4*)(bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
+        // one explicit, compiler-visible wait behind the up-front loads: with the next tile's LDS-DMA requests in flight hipcc cannot count
+        // past them and would otherwise re-wait vmcnt(0) at the first use in every row group (gemm_epilogue.h, WAIT_LOADS)
+        __builtin_amdgcn_s_waitcnt(0x0F70);
         auto value = [&](int mt, int nt, int m, int n, bool ok, float sa) {
             f32x4 v = acc[mt][nt];
 #pragma unroll
@@ -354,14 +426,21 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(
                 }
             }
         }
-        if (!PERSIST || !more) break;
+        c_vbid += gridDim.x;
+        if (c_vbid >= num_tiles) break;
     }
+    // the trailing (out-of-range) LDS-DMA requests must have retired before the workgroup's LDS can be handed to another one
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if ((FLAGS & MQ_EPI_OUT_FP8) && amax_out) {
         amax = wave_max(amax);
         if (lane == 0) atomicMax((int*)amax_out, __float_as_int(amax));  // amax >= 0: int order == float order
     }
 }
 
+#ifdef MQ_GEMM_PROBE   // compile-and-inspect builds (tests/test_gemm_isa.py): ONE instantiation
+__attribute__((used)) void* mq_gemm_fp8_probe() { return (void*)gemm_fp8_kernel<MQ_GEMM_PROBE, MQ_GEMM_PROBE_MT, (MQ_GEMM_PROBE_WN != 0)>; }
+}  // namespace
+#else
 int choose_mt(int M, int N) {
     const int tiles_n = (N + BN - 1) / BN;
     const int cands[4] = {2, 4, 5, 6};
@@ -382,14 +461,20 @@ struct Fp8Args {
     const float* residual; void* out; int64_t ldc; const float* out_scale; float* amax; int M, N, K;
 };
 
-template <int FLAGS, int MT, bool ROWSCALE, bool PERSIST>
+template <int FLAGS, int MT, bool ROWSCALE>
 int launch_fp8_mt(const Fp8Args& a, hipStream_t s) {
     constexpr int BM = 32 * MT;
     constexpr int LDS = 2 * (BM * BK + W_TILE_BYTES);
     static std::atomic<uint64_t> attr_done{0};
-    if (hipError_t e = mq_ensure_dyn_lds((const void*)gemm_fp8_kernel<FLAGS, MT, ROWSCALE, PERSIST>, LDS, attr_done); e != hipSuccess) {
+    if (hipError_t e = mq_ensure_dyn_lds((const void*)gemm_fp8_kernel<FLAGS, MT, ROWSCALE>, LDS, attr_done); e != hipSuccess) {
         mq_set_error("mq_gemm_fp8: hipFuncSetAttribute: %s", hipGetErrorString(e));
         return MQ_ERR_HIP;
+    }
+    // the LDS-DMA addresses both operands through 32-bit buffer offsets
+    const uint64_t a_bytes = (uint64_t)(a.M - 1) * (uint64_t)a.lda + (uint64_t)a.K, w_bytes = (uint64_t)(a.N - 1) * (uint64_t)a.ldw + (uint64_t)a.K;
+    if (a_bytes > 0xffffffffull || w_bytes > 0xffffffffull) {
+        mq_set_error("mq_gemm_fp8: an operand of %llu bytes exceeds the 4 GiB a launch can address", (unsigned long long)(a_bytes > w_bytes ? a_bytes : w_bytes));
+        return MQ_ERR_INVALID;
     }
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
     const int num_tiles = tiles_m * tiles_n;
@@ -398,10 +483,10 @@ int launch_fp8_mt(const Fp8Args& a, hipStream_t s) {
     // 16-byte epilogue stores need 16-B aligned rows (bf16: ldc % 8; e4m3: ldc % 16)
     const int row_align = (FLAGS & MQ_EPI_OUT_FP8) ? 16 : 8;
     const int wide = (mq_gemm_knob_wide && !(FLAGS & MQ_EPI_OUT_F32) && a.ldc % row_align == 0 && ((uintptr_t)a.out & 15) == 0) ? 1 : 0;
-    const int grid = PERSIST && num_tiles > RESIDENT_SLOTS ? RESIDENT_SLOTS : num_tiles;
-    hipLaunchKernelGGL((gemm_fp8_kernel<FLAGS, MT, ROWSCALE, PERSIST>), dim3(grid), dim3(256), LDS, s, (const uint8_t*)a.A, a.lda,
+    const int grid = num_tiles > RESIDENT_SLOTS ? RESIDENT_SLOTS : num_tiles;
+    hipLaunchKernelGGL((gemm_fp8_kernel<FLAGS, MT, ROWSCALE>), dim3(grid), dim3(256), LDS, s, (const uint8_t*)a.A, a.lda,
                        (const uint8_t*)a.W, a.ldw, a.a_scale, a.w_scale, a.bias, a.residual, a.out, a.ldc, a.out_scale, a.amax, a.M, a.N,
-                       a.K, tiles_n, num_tiles, cgroup, band_rows, wide);
+                       a.K, tiles_n, num_tiles, cgroup, band_rows, wide, (unsigned)a_bytes, (unsigned)w_bytes);
     MQ_CHECK_LAUNCH("mq_gemm_fp8");
     return MQ_OK;
 }
@@ -409,12 +494,11 @@ int launch_fp8_mt(const Fp8Args& a, hipStream_t s) {
 template <int FLAGS, bool ROWSCALE>
 int launch_fp8(const Fp8Args& a, int force_mt, hipStream_t s) {
     const int mt = force_mt ? force_mt : choose_mt(a.M, a.N);
-    const bool persist = mq_gemm_knob_persist != 0;
     switch (mt) {
-        case 2: return persist ? launch_fp8_mt<FLAGS, 2, ROWSCALE, true>(a, s) : launch_fp8_mt<FLAGS, 2, ROWSCALE, false>(a, s);
-        case 5: return persist ? launch_fp8_mt<FLAGS, 5, ROWSCALE, true>(a, s) : launch_fp8_mt<FLAGS, 5, ROWSCALE, false>(a, s);
-        case 6: return launch_fp8_mt<FLAGS, 6, ROWSCALE, false>(a, s);  // one-tile form only (register budget, as in gemm_bf16.hip)
-        default: return persist ? launch_fp8_mt<FLAGS, 4, ROWSCALE, true>(a, s) : launch_fp8_mt<FLAGS, 4, ROWSCALE, false>(a, s);
+        case 2: return launch_fp8_mt<FLAGS, 2, ROWSCALE>(a, s);
+        case 5: return launch_fp8_mt<FLAGS, 5, ROWSCALE>(a, s);
+        case 6: return launch_fp8_mt<FLAGS, 6, ROWSCALE>(a, s);
+        default: return launch_fp8_mt<FLAGS, 4, ROWSCALE>(a, s);
     }
 }
 
@@ -490,3 +574,4 @@ extern "C" int mq_quantize_weights_fp8(const void* d_W_bf16, int64_t ldw, void* 
     MQ_CHECK_LAUNCH("mq_quantize_weights_fp8");
     return MQ_OK;
 }
+#endif  // MQ_GEMM_PROBE

@@ -513,7 +513,7 @@ class _TowerBase:
         extra = 0
         self.fp8_policy_trace = [(first, 0, e)]
         if not enc.post_ln and os.environ.get("MARQO_AMD_FP8_MLP_ONLY", "1") != "0":
-            best = (layers - first + 0.0, first, 0, e)
+            best = (self._fp8_share(layers, first, 0), first, 0, e)
             step = max(1, layers // 8)
             for s_ in sorted({min(layers, first + k * step) for k in range(0, 9)} | {layers}):
                 if s_ == 0:
@@ -531,7 +531,7 @@ class _TowerBase:
                         lo_x = mid
                     else:
                         hi_x = mid - 1
-                share = (layers - s_) + (2.0 / 3.0) * lo_x
+                share = self._fp8_share(layers, s_, lo_x)
                 self.fp8_policy_trace.append((s_, lo_x, e_at[lo_x]))
                 if share > best[0] + 1e-9:
                     best = (share, s_, lo_x, e_at[lo_x])
@@ -544,6 +544,20 @@ class _TowerBase:
                                          "the calibration batch %.2e (all blocks: %.2e, budget %.1e)", first, layers, first - extra, first,
                                          self.residual_stream, e, e0, budget)
         return first
+
+    # towers whose output is ONE row per item (class token / EOT): the last block's out-proj and MLP run on those rows only (towers.hip,
+    # last_block_selected — in bf16, whatever the policy says), so of that block only the QKV GEMM (3 of its 12 W^2) can be e4m3 work at all
+    pools_one_row = False
+
+    def _fp8_share(self, layers: int, split: int, extra: int) -> float:
+        """e4m3 share of a tower's GEMM FLOPs, in blocks: blocks [split, layers) whole, the MLP halves (2/3) of blocks [split - extra, split)"""
+        share = (layers - split) + (2.0 / 3.0) * extra
+        if self.pools_one_row:
+            if split < layers:
+                share -= 0.75                       # the last block counts for its QKV GEMM only
+            elif extra >= 1:
+                share -= 2.0 / 3.0                  # ... and its MLP half for nothing
+        return share
 
     def __init__(self, device: str):
         self.device = _require_gpu(device)
@@ -695,6 +709,7 @@ class VitTower(_TowerBase):
                 ln_post_g=h.f32(_need(sd, "visual.ln_post.weight", (W,))), ln_post_b=h.f32(_need(sd, "visual.ln_post.bias", (W,))),
                 proj_w=h.bf16(_need(sd, "visual.proj", (W, arch.out_dim)).detach().to(torch.float32).t()), map=None)
             pool, map_mlp = (L.MQ_VIT_POOL_AVG if arch.pool == "avg" else L.MQ_VIT_POOL_CLS), 0
+            self.pools_one_row = arch.pool != "avg"
         self.cfg = L.VitCfg(enc=_encoder_cfg(W, arch.layers, arch.heads, arch.mlp_dim, arch.quick_gelu, False,
                                              L.MQ_MASK_NONE, arch.ln_eps),
                             image_size=arch.image_size, patch_size=P, out_dim=arch.out_dim,
@@ -905,6 +920,7 @@ class ClipTextTower(_TextTowerBase):
             raise ValueError(f"precision must be 'bf16' or 'fp8', got {precision!r}")
         self.precision = precision
         self.arch = arch
+        self.pools_one_row = True   # EOT (causal) / last (SigLIP) position
         W = arch.width
         h = self._h
         px = arch.prefix  # "" (CLIP) / "text." (SigLIP under open_clip's CustomTextCLIP)

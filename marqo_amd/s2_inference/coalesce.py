@@ -1,4 +1,5 @@
-"""Transparent cross-request micro-batching inside `vectorise()` (opt-in: MARQO_AMD_COALESCE_US > 0; 0 = the reference's behaviour).
+"""Transparent cross-request micro-batching inside `vectorise()` (on by default for small calls since round 4, see `window_for`;
+MARQO_AMD_COALESCE_US=0 = the reference's behaviour).
 
 Why: the reference's default add_documents handlers call `vectorise` once per document per field — N = 1..10 items per call
 (src/marqo/core/vespa_index/add_documents_handler.py:264-290,307-342, src/marqo/core/inference/tensor_fields_container.py:179-223) — from up
@@ -24,13 +25,32 @@ import time
 from typing import Any, Callable, Dict, Hashable, List, Optional
 
 
+DEFAULT_WINDOW_US = 1000.0
+SMALL_CALL_ITEMS = 16
+
+
 def window_seconds() -> float:
-    """MARQO_AMD_COALESCE_US: the longest a leader waits for the engine to come free / for others to join, in microseconds; 0 = off"""
+    """MARQO_AMD_COALESCE_US: the longest a leader waits for the engine to come free / for others to join, in microseconds; 0 = off;
+    unset = DEFAULT_WINDOW_US (for the small calls `window_for` lets in)"""
     v = os.environ.get("MARQO_AMD_COALESCE_US", "")
     try:
-        return max(0.0, float(v)) * 1e-6 if v else 0.0
+        return max(0.0, float(v)) * 1e-6 if v else DEFAULT_WINDOW_US * 1e-6
     except ValueError:
         return 0.0
+
+
+def window_for(n_items: int) -> float:
+    """the window a call of n_items gets.  Default (MARQO_AMD_COALESCE_US unset): calls of <= SMALL_CALL_ITEMS items (the per-document,
+    per-field calls of an unmodified Marqo, MARQO_AMD_COALESCE_SMALL_ITEMS to change) coalesce, larger ones never wait for anybody.  A lone
+    caller is not delayed either way (natural batching: a call that finds fewer than `depth` calls of its key executing fires at once).
+    MARQO_AMD_COALESCE_US=<us> set explicitly: every call of <= MARQO_AMD_COALESCE_MAX_ITEMS items takes part; =0: off (the reference's behaviour)."""
+    if os.environ.get("MARQO_AMD_COALESCE_US", ""):
+        return window_seconds() if n_items <= max_items() else 0.0
+    try:
+        small = max(0, int(os.environ.get("MARQO_AMD_COALESCE_SMALL_ITEMS", str(SMALL_CALL_ITEMS))))
+    except ValueError:
+        small = SMALL_CALL_ITEMS
+    return DEFAULT_WINDOW_US * 1e-6 if n_items <= small else 0.0
 
 
 def max_items() -> int:
@@ -51,7 +71,7 @@ def depth() -> int:
 
 
 class _Group:
-    __slots__ = ("parts", "n", "open", "done", "results", "error")
+    __slots__ = ("parts", "n", "open", "done", "results", "error", "ready")
 
     def __init__(self):
         self.parts: List[list] = []
@@ -60,6 +80,30 @@ class _Group:
         self.done = threading.Event()
         self.results: Optional[list] = None
         self.error: Optional[BaseException] = None
+        self.ready = None          # device results: event recorded on the leader's stream behind the merged call
+
+
+def _device_event(out):
+    """merged rows that stay in HBM (`vectorise_device`) are written on the LEADER's stream: an event behind them, for the followers"""
+    if hasattr(out, "is_cuda") and out.is_cuda:
+        import torch
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(out.device))
+        return ev
+    return None
+
+
+def _own_rows(rows, ready):
+    """a participant's copy of its slice.  Device rows: the copy runs on the participant's current stream, which first waits for the leader's
+    event; the shared block is marked as used by that stream so that the allocator does not hand it out again before the copy has run"""
+    if hasattr(rows, "clone"):
+        if ready is not None and rows.is_cuda:
+            import torch
+            cur = torch.cuda.current_stream(rows.device)
+            cur.wait_event(ready)
+            rows.record_stream(cur)
+        return rows.clone()
+    return rows.copy()
 
 
 class Coalescer:
@@ -113,6 +157,7 @@ class Coalescer:
                 for part in g.parts:
                     res.append(out[pos:pos + len(part)])
                     pos += len(part)
+                g.ready = _device_event(out) if len(g.parts) > 1 else None
                 g.results = res
             except BaseException as e:  # noqa: BLE001 - handed to every participant below
                 g.error = e
@@ -129,7 +174,7 @@ class Coalescer:
             return run(content)       # whose item was it?  everyone re-runs alone: only the faulty request raises
         rows = g.results[slot]
         if len(g.parts) > 1:
-            rows = rows.clone() if hasattr(rows, "clone") else rows.copy()   # callers own their result (no views into a shared matrix)
+            rows = _own_rows(rows, g.ready)   # callers own their result (no views into a shared matrix)
         return rows
 
 

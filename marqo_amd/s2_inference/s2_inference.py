@@ -290,9 +290,10 @@ def _encode_to_array(model_cache_key: str, content, normalize_embeddings: bool, 
                 batch_size = len(content)
                 if not isinstance(content[0], str):
                     batch_size = min(batch_size, max(1, read_env_vars_and_defaults_ints(EnvVars.MARQO_AMD_MAX_ITEMS_PER_ENCODE)))
-            # opt-in (MARQO_AMD_COALESCE_US > 0): small concurrent calls for the same (model, modality, arguments) share ONE engine call
-            # (coalesce.py) — what feeds the GPU when an unmodified Marqo vectorises per document and field from 8 + 8 request threads
-            coalesce_window = _coalesce.window_seconds() if dynamic and len(content) <= _coalesce.max_items() else 0.0
+            # small concurrent calls for the same (model, modality, arguments) share ONE engine call (coalesce.py; default: calls of <= 16
+            # items, MARQO_AMD_COALESCE_US=0 turns it off) — what feeds the GPU when an unmodified Marqo vectorises per document and field from
+            # 8 + 8 request threads.  A lone caller is never delayed.
+            coalesce_window = _coalesce.window_for(len(content)) if dynamic else 0.0
             for batch in generate_batches(content, batch_size=batch_size):
                 if modality is None:
                     modality = infer_modality(batch[0] if isinstance(batch[0], (str, bytes)) else batch)

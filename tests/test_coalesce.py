@@ -1,4 +1,4 @@
-"""Cross-request micro-batching inside vectorise() (marqo_amd/s2_inference/coalesce.py; opt-in MARQO_AMD_COALESCE_US).  CPU: a fake engine
+"""Cross-request micro-batching inside vectorise() (marqo_amd/s2_inference/coalesce.py; default for small calls, MARQO_AMD_COALESCE_US).  CPU: a fake engine
 model that declares `supports_dynamic_batching` and records every encode call."""
 import datetime
 import os
@@ -61,11 +61,29 @@ def _run_threads(model, props, avail, n_threads, per_call, calls_per_thread, env
     return out, errs
 
 
-def test_off_by_default_is_the_reference_behaviour():
+def test_zero_window_is_the_reference_behaviour():
     model = FakeEngineModel()
     props, avail = _setup(model)
-    out, errs = _run_threads(model, props, avail, 4, 3, 2, {"MARQO_AMD_COALESCE_US": ""})
+    out, errs = _run_threads(model, props, avail, 4, 3, 2, {"MARQO_AMD_COALESCE_US": "0"})
     assert not errs and len(model.calls) == 8 and all(len(c) == 3 for c in model.calls)    # one engine call per vectorise call
+
+
+def test_default_coalesces_small_calls_only_and_never_delays_a_lone_caller():
+    """round 4: on by default for calls of <= 16 items (the per-document, per-field calls of an unmodified Marqo); larger calls never wait"""
+    assert coalesce.window_for(4) > 0 and coalesce.window_for(16) > 0 and coalesce.window_for(17) == 0.0
+    with mock.patch.dict(os.environ, {"MARQO_AMD_COALESCE_US": "0"}):
+        assert coalesce.window_for(4) == 0.0
+    with mock.patch.dict(os.environ, {"MARQO_AMD_COALESCE_US": "300"}):
+        assert coalesce.window_for(400) == pytest.approx(300e-6)
+    model = FakeEngineModel()
+    props, avail = _setup(model)
+    out, errs = _run_threads(model, props, avail, 16, 4, 6, {"MARQO_AMD_COALESCE_US": ""})      # unset: the default
+    assert not errs and len(out) == 96 and len(model.calls) < 96                                   # concurrent small calls shared engine calls
+    lone = FakeEngineModel(delay=0.0)
+    props, avail = _setup(lone)
+    t0 = time.perf_counter()
+    out, errs = _run_threads(lone, props, avail, 1, 4, 5, {"MARQO_AMD_COALESCE_US": ""})
+    assert not errs and len(lone.calls) == 5 and time.perf_counter() - t0 < 0.5                    # 5 windows of waiting would be 5 ms; a hang far more
 
 
 def test_concurrent_small_calls_share_engine_calls_with_identical_rows():

@@ -20,10 +20,10 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 BIAS, GELU, RESIDUAL, OUT_F32, ROW_STATS, LN_APPLY = 1, 2, 8, 16, 64, 128
 
 
-def _compile(tmp_path, flags, mt):
-    out = tmp_path / f"probe_{flags}_{mt}.s"
+def _compile(tmp_path, flags, mt, src=SRC, wn=0):
+    out = tmp_path / f"probe_{os.path.basename(src)}_{flags}_{mt}_{wn}.s"
     res = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wall", "-Wno-unused-function", "-Rpass-analysis=kernel-resource-usage",
-                          f"-DMQ_GEMM_PROBE={flags}", f"-DMQ_GEMM_PROBE_MT={mt}", "-S", "--cuda-device-only", "-o", str(out), SRC],
+                          f"-DMQ_GEMM_PROBE={flags}", f"-DMQ_GEMM_PROBE_MT={mt}", f"-DMQ_GEMM_PROBE_WN={wn}", "-S", "--cuda-device-only", "-o", str(out), src],
                          capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-3000:]
     return out.read_text(), res.stderr
@@ -39,24 +39,22 @@ def _regs(operand_text):
     return out
 
 
-@pytest.mark.skipif(not shutil.which(HIPCC), reason="hipcc not installed")
-@pytest.mark.parametrize("flags,mt", [(BIAS, 5), (BIAS | RESIDUAL, 5), (BIAS | GELU, 4), (BIAS | RESIDUAL | OUT_F32, 6), (BIAS | GELU | LN_APPLY, 5), (BIAS | RESIDUAL | ROW_STATS, 5),
-                                      (BIAS | RESIDUAL | ROW_STATS, 3), (0, 2)])
-def test_asm_fragment_reads_are_waited_for_before_any_use(tmp_path, flags, mt):
-    isa, remarks = _compile(tmp_path, flags, mt)
+def _check(isa, remarks, mfma_name, n_mfma, n_reads_expected, hot_regions=1):
     assert re.search(r"ScratchSize \[bytes/lane\]: 0\b", remarks) and re.search(r"VGPRs Spill: 0\b", remarks), remarks[-1500:]
     lines = [ln.strip() for ln in isa.splitlines()]
     body = [ln for ln in lines if ln and not ln.startswith((";", ".", "//")) or ln.startswith(";;#ASM")]
-    # 1. one straight-line k-step: 2 halves x 4 * MT MFMAs, nowhere else
-    mfma = [i for i, ln in enumerate(body) if ln.startswith("v_mfma_f32_16x16x32_bf16")]
-    assert len(mfma) == 8 * mt, len(mfma)
-    # 2. inside the k-step exactly one wait on the vector-memory counter (the mid-step one)
-    hot = body[mfma[0]:mfma[-1] + 1]
-    assert sum(1 for ln in hot if ln.startswith("s_waitcnt") and "vmcnt" in ln) == 1, [ln for ln in hot if "vmcnt" in ln]
-    assert sum(1 for ln in hot if ln.startswith("s_barrier")) == 1
+    # 1. straight-line k-steps: the expected number of MFMAs, nowhere else
+    mfma = [i for i, ln in enumerate(body) if ln.startswith(mfma_name)]
+    assert len(mfma) == n_mfma, len(mfma)
+    # 2. per k-step body exactly one wait on the vector-memory counter (the mid-step one: a second one means the compiler started waiting on the
+    # LDS-DMA behind our back) and one barrier
+    per = n_mfma // hot_regions
+    for r in range(hot_regions):
+        hot = body[mfma[r * per]:mfma[(r + 1) * per - 1] + 1]
+        assert sum(1 for ln in hot if ln.startswith("s_waitcnt") and "vmcnt" in ln) == 1, [ln for ln in hot if "vmcnt" in ln]
+        assert sum(1 for ln in hot if ln.startswith("s_barrier")) == 1
     # 3. no instruction touches a register an inline-asm ds_read has written before the next lgkmcnt(0)
-    # (LDS operations return in order: `s_waitcnt lgkmcnt(N)` retires all but the N youngest reads — the counted wait in front of the LN_APPLY
-    # statistics block relies on exactly that)
+    # (LDS operations return in order: `s_waitcnt lgkmcnt(N)` retires all but the N youngest reads)
     reads, in_asm, n_reads = [], False, 0          # register sets of the un-retired asm reads, oldest first
     for ln in body:
         if ln.startswith(";;#ASMSTART"):
@@ -80,4 +78,26 @@ def test_asm_fragment_reads_are_waited_for_before_any_use(tmp_path, flags, mt):
             continue
         touched = _regs(rest) & pending
         assert not touched, f"{ln!r} touches v{sorted(touched)} before the s_waitcnt lgkmcnt that covers its ds_read_b128"
-    assert n_reads == 3 * (mt + 4), n_reads    # prologue + both half-steps
+    assert n_reads == n_reads_expected, n_reads
+
+
+@pytest.mark.skipif(not shutil.which(HIPCC), reason="hipcc not installed")
+@pytest.mark.parametrize("flags,mt", [(BIAS, 5), (BIAS | RESIDUAL, 5), (BIAS | GELU, 4), (BIAS | RESIDUAL | OUT_F32, 6), (BIAS | GELU | LN_APPLY, 5), (BIAS | RESIDUAL | ROW_STATS, 5),
+                                      (BIAS | RESIDUAL | ROW_STATS, 3), (0, 2)])
+def test_asm_fragment_reads_are_waited_for_before_any_use(tmp_path, flags, mt):
+    isa, remarks = _compile(tmp_path, flags, mt)
+    _check(isa, remarks, "v_mfma_f32_16x16x32_bf16", 8 * mt, 3 * (mt + 4))    # reads: prologue + both half-steps
+
+
+OUT_FP8 = 32
+
+
+@pytest.mark.skipif(not shutil.which(HIPCC), reason="hipcc not installed")
+@pytest.mark.parametrize("flags,mt,rowscale", [(BIAS, 5, 1), (BIAS | GELU | OUT_FP8, 6, 1), (BIAS | RESIDUAL, 6, 0), (BIAS | RESIDUAL | OUT_F32, 5, 0), (OUT_F32, 4, 0),
+                                               (BIAS | GELU | OUT_FP8, 2, 1)])
+def test_fp8_loop_follows_the_same_rules(tmp_path, flags, mt, rowscale):
+    """csrc/gemm_fp8.hip: the same pipeline (a k-step = two W-side halves; a tile's last k-step is a second body without the next stage's fragment
+    reads, which the tile loop issues after the epilogue): two k-step bodies of 4 * MT MFMAs each; fragment reads (two ds_read_b128 each): MT + 2 at
+    the tile top, MT + 4 in the steady k-step, 2 in the last one"""
+    isa, remarks = _compile(tmp_path, flags, mt, src=SRC.replace("gemm_bf16.hip", "gemm_fp8.hip"), wn=rowscale)
+    _check(isa, remarks, "v_mfma_scale_f32_16x16x128_f8f6f4", 8 * mt, 2 * (mt + 2) + 2 * (mt + 4) + 2 * 2, hot_regions=2)

@@ -131,3 +131,16 @@ def test_residual_stream_policy_decision(monkeypatch):
     assert forced.tune_residual_stream(forced.run) == "bf16" and forced.calls == 0
     monkeypatch.setenv("MARQO_AMD_RESIDUAL_STREAM", "fp32")
     assert forced.tune_residual_stream(forced.run) == "fp32" and forced.cfg.enc.residual_stream == 2
+
+
+def test_fp8_share_of_a_tower_that_pools_one_row_does_not_credit_the_last_blocks_mlp(monkeypatch):
+    """with the pooled-rows-only last block (towers.hip, last_block_selected) that block's out-proj / MLP never run on e4m3, so a
+    (split = layers, extra >= 1) candidate must not be credited an fp8 MLP for it, and a whole last block is worth its QKV GEMM only"""
+    monkeypatch.delenv("MARQO_AMD_FP8_MLP_ONLY", raising=False)
+    t = _FakeTower(24, 1e-4, 0.0)
+    assert t._fp8_share(24, 24, 1) == pytest.approx(2.0 / 3.0) and t._fp8_share(24, 20, 3) == pytest.approx(6.0)
+    t.pools_one_row = True
+    assert t._fp8_share(24, 24, 1) == pytest.approx(0.0) and t._fp8_share(24, 24, 3) == pytest.approx(4.0 / 3.0)
+    assert t._fp8_share(24, 23, 0) == pytest.approx(0.25) and t._fp8_share(24, 20, 3) == pytest.approx(5.25)
+    first = t.tune_fp8(t.run, budget=7e-4)       # the search still ends inside the budget with the corrected shares
+    assert t.error_model() <= 7e-4 * (1 + 1e-6) and first == t.fp8_first_layer
