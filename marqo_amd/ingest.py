@@ -85,6 +85,7 @@ class BulkVectoriser:
         self.force_collective = False   # tests: take the sharded path (and run the collective) even in a 1-rank process group
         self.local_only = False         # RequestShardedIngest: requests are owned by ONE rank, nothing is sharded inside a request
         self._helper = None             # second host thread of a two-modality flush (created on first use)
+        self.two_threads = True         # (False: both modalities on the caller's thread; measurement knob)
         self._model_loaded = False      # a vectorise call of this object has returned (the model is in the cache)
 
     def add(self, key: Hashable, content: Any, modality: Modality = Modality.TEXT) -> None:
@@ -221,7 +222,7 @@ class BulkVectoriser:
     def _two_threads(self) -> bool:
         import torch
         import torch.distributed as dist
-        if not PARALLEL_MODALITIES or self._vectorise is not None or self.force_collective or not self._model_loaded:
+        if not (PARALLEL_MODALITIES and self.two_threads) or self._vectorise is not None or self.force_collective or not self._model_loaded:
             return False    # (the first flush loads the model: the reference's model cache rejects two concurrent loads, s2_inference.py:348-394)
         if not (str(self.device).startswith("cuda") and torch.cuda.is_available()):
             return False
