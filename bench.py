@@ -660,10 +660,12 @@ def run_stream(args, dev, rank, world, dist, lib, L):
         ids = torch.from_numpy(np.asarray(model.tokenizer(pool[0][0])).astype(np.int64))
         base, emb_cpu = mixed_request_cpu_baseline(varch, tarch, pool[0][1], docs, args.cpu_seconds, ids=ids, return_rows=True)
         result["cpu_baseline"] = base
-        req0 = rows.get(0) if rows else None
+        # a timed request that carried pool[0] — the documents the CPU path just ran
+        i0 = next((i for i in sorted(rows or {}) if (i // world) % len(pool) == 0), None)
+        req0 = rows.get(i0) if i0 is not None else None
         if req0 is not None:
             k = emb_cpu.shape[0] // 2      # CPU rows: image 0, text 0, image 1, text 1, ...
-            gpu = np.stack([req0[(0, d, m)] for d in range(k) for m in ("i", "t")])
+            gpu = np.stack([req0[(i0, d, m)] for d in range(k) for m in ("i", "t")])
             result["cos_err_vs_cpu"] = _cos_err(torch.from_numpy(gpu).float(), emb_cpu)
     elif rank == 0:
         result["cpu_baseline"] = None
