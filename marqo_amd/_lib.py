@@ -279,7 +279,8 @@ def build_torch_ops(force: bool = False, verbose: bool = False) -> Path:
 
 def build_stage(force: bool = False, verbose: bool = False) -> Path:
     """Compile csrc/py_stage.cpp (host code only: CPython C API + the Arrow C data interface) -> lib/_mq_stage.so"""
-    if not force and STAGE_PATH.exists() and os.path.getmtime(STAGE_PATH) >= os.path.getmtime(STAGE_SRC):
+    deps = [STAGE_SRC, CSRC_DIR / "copy_pool.h"]
+    if not force and STAGE_PATH.exists() and os.path.getmtime(STAGE_PATH) >= max(os.path.getmtime(d) for d in deps):
         return STAGE_PATH
     LIB_DIR.mkdir(parents=True, exist_ok=True)
     cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", f"-I{sysconfig.get_paths()['include']}",

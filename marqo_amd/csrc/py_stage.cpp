@@ -21,8 +21,10 @@
 
 #include <cstdint>
 #include <cstring>
-#include <thread>
+#include <functional>
 #include <vector>
+
+#include "copy_pool.h"
 
 namespace {
 
@@ -37,6 +39,7 @@ struct ArrowArray {
 };
 
 struct Item { const void* src; int64_t dst_off; int64_t bytes; };
+
 
 // pixel block of one exported image, or nullptr (no Python error left pending)
 const void* rgbx_block(PyObject* capsules, int64_t want_bytes) {
@@ -55,6 +58,36 @@ const void* rgbx_block(PyObject* capsules, int64_t want_bytes) {
     if (c->offset != 0 || c->null_count > 0 || c->n_buffers < 2 || !c->buffers || !c->buffers[1]) return nullptr;
     if (a->length * 4 != want_bytes || c->length != want_bytes) return nullptr;
     return c->buffers[1];
+}
+
+// the same block through the image's ImagingCore (`img.im`), for an image that is loaded and of mode "RGB"; *keep receives the capsule that
+// owns Pillow's reference on the pixels.  nullptr (no Python error pending, *keep possibly set: the caller drops it) when this route does not apply.
+const void* core_rgb_block(PyObject* img, PyObject* s_im, PyObject* s_mode, PyObject* method, int64_t want_bytes, PyObject** keep) {
+    *keep = nullptr;
+    PyObject* mode = PyObject_GetAttr(img, s_mode);
+    if (!mode) { PyErr_Clear(); return nullptr; }
+    const bool rgb = PyUnicode_Check(mode) && PyUnicode_CompareWithASCIIString(mode, "RGB") == 0;
+    Py_DECREF(mode);
+    if (!rgb) return nullptr;
+    PyObject* core = PyObject_GetAttr(img, s_im);
+    if (!core) { PyErr_Clear(); return nullptr; }
+    const void* src = nullptr;
+    if (core != Py_None) {
+        PyObject* cap = PyObject_CallMethodNoArgs(core, method);
+        if (!cap) PyErr_Clear();
+        else if (PyCapsule_IsValid(cap, "arrow_array")) {
+            const ArrowArray* a = (const ArrowArray*)PyCapsule_GetPointer(cap, "arrow_array");
+            if (a && a->release && a->offset == 0 && a->null_count <= 0 && a->n_children == 1 && a->children && a->children[0] && a->length * 4 == want_bytes) {
+                const ArrowArray* c = a->children[0];
+                if (c->offset == 0 && c->null_count <= 0 && c->n_buffers >= 2 && c->buffers && c->buffers[1] && c->length == want_bytes) src = c->buffers[1];
+            }
+            *keep = cap;
+        } else {
+            Py_DECREF(cap);
+        }
+    }
+    Py_DECREF(core);
+    return src;
 }
 
 bool int64_view(PyObject* obj, Py_buffer* view, Py_ssize_t n, const char* what) {
@@ -93,6 +126,8 @@ PyObject* gather_rgbx(PyObject*, PyObject* args) {
 
     PyObject* failed = PyList_New(0);
     PyObject* method = PyUnicode_InternFromString("__arrow_c_array__");
+    PyObject* s_im = PyUnicode_InternFromString("im");
+    PyObject* s_mode = PyUnicode_InternFromString("mode");
     std::vector<PyObject*> keep;      // the capsule pairs: they own Pillow's reference on the pixel blocks until the copies are done
     std::vector<Item> items;
     keep.reserve(n);
@@ -105,10 +140,17 @@ PyObject* gather_rgbx(PyObject*, PyObject* args) {
         if (len[i] > 0 && off[i] >= 0 && i < PyList_GET_SIZE(images)) {   // (the export runs Python code: hold the item, re-check the list)
             PyObject* img = PyList_GET_ITEM(images, i);
             Py_INCREF(img);
-            caps = PyObject_CallMethodNoArgs(img, method);
+            // A loaded RGB image: ask its ImagingCore for the array capsule directly (Image.__arrow_c_array__ is a Python-level wrapper:
+            // load() + TWO capsules, 2.4 us; the core's array capsule alone is 0.55 us; the layout of mode "RGB" is known — 4 bytes per
+            // pixel — and the length is checked below).  Anything else — a lazy file image, another mode — goes through the wrapper.
+            src = s_im && s_mode ? core_rgb_block(img, s_im, s_mode, method, len[i], &caps) : nullptr;
+            if (!src) {
+                Py_XDECREF(caps);
+                caps = PyObject_CallMethodNoArgs(img, method);
+                if (!caps) PyErr_Clear();                 // (several blocks, unsupported mode, no Arrow interface: the caller's slow route)
+                else src = rgbx_block(caps, len[i]);
+            }
             Py_DECREF(img);
-            if (!caps) PyErr_Clear();                     // (several blocks, unsupported mode, no Arrow interface: the caller's slow route)
-            else src = rgbx_block(caps, len[i]);
         }
         if (src) {
             keep.push_back(caps);
@@ -123,45 +165,90 @@ PyObject* gather_rgbx(PyObject*, PyObject* args) {
     }
     if (ok && !items.empty()) {
         int t = threads < 1 ? 1 : (threads > 16 ? 16 : threads);
-        if (total < (4 << 20)) t = 1;                     // small packs: a thread start costs more than the copy
+        if (total < (4 << 20)) t = 1;                     // small packs: waking the workers costs more than the copy
         Py_BEGIN_ALLOW_THREADS
-        auto work = [&](size_t lo, size_t hi) {
-            for (size_t k = lo; k < hi; ++k) memcpy(dst + items[k].dst_off, items[k].src, (size_t)items[k].bytes);
-        };
-        if (t == 1) {
-            work(0, items.size());
-        } else {
-            std::vector<std::thread> pool;
+        // ranges of about equal bytes, whole images each
+        std::vector<std::pair<size_t, size_t>> ranges;
+        {
             const int64_t share = (total + t - 1) / t;
             size_t lo = 0;
             int64_t acc = 0;
             for (size_t k = 0; k < items.size(); ++k) {
                 acc += items[k].bytes;
                 if (acc >= share || k + 1 == items.size()) {
-                    if (k + 1 == items.size() || (int)pool.size() == t - 1) { work(lo, items.size()); break; }   // the caller's thread takes the last range
-                    try {
-                        pool.emplace_back(work, lo, k + 1);
-                    } catch (...) {                       // no thread to be had: this thread copies the rest
-                        work(lo, items.size());
-                        break;
-                    }
+                    ranges.emplace_back(lo, k + 1);
                     lo = k + 1;
                     acc = 0;
                 }
             }
-            for (auto& th : pool) th.join();
         }
+        const std::function<void(int)> job = [&](int r) {
+            for (size_t k = ranges[r].first; k < ranges[r].second; ++k) memcpy(dst + items[k].dst_off, items[k].src, (size_t)items[k].bytes);
+        };
+        mq_copy_pool().run((int)ranges.size(), job);
         Py_END_ALLOW_THREADS
     }
     for (PyObject* c : keep) Py_DECREF(c);
     Py_XDECREF(method);
+    Py_XDECREF(s_im);
+    Py_XDECREF(s_mode);
     PyBuffer_Release(&offs);
     PyBuffer_Release(&lens);
     if (!ok) { Py_XDECREF(failed); return PyErr_Occurred() ? nullptr : PyErr_NoMemory(); }
     return failed;
 }
 
+// rgb_sizes(images, heights, widths) -> True when EVERY item is a loaded Pillow image of mode "RGB" with a non-empty size (heights / widths:
+// writable int32 buffers of len(images) items, filled); False otherwise (nothing to rely on in the buffers).  One call instead of a Python
+// loop of isinstance / mode / size checks per image (~2 us each under the GIL: 0.5 ms of a 256-image request).
+PyObject* rgb_sizes(PyObject*, PyObject* args) {
+    PyObject *images, *h_obj, *w_obj;
+    if (!PyArg_ParseTuple(args, "OOO", &images, &h_obj, &w_obj)) return nullptr;
+    if (!PyList_Check(images)) Py_RETURN_FALSE;
+    const Py_ssize_t n = PyList_GET_SIZE(images);
+    Py_buffer hb, wb;
+    if (PyObject_GetBuffer(h_obj, &hb, PyBUF_WRITABLE | PyBUF_C_CONTIGUOUS) != 0) return nullptr;
+    if (PyObject_GetBuffer(w_obj, &wb, PyBUF_WRITABLE | PyBUF_C_CONTIGUOUS) != 0) { PyBuffer_Release(&hb); return nullptr; }
+    bool ok = hb.len == n * 4 && wb.len == n * 4 && n > 0;
+    PyObject* s_im = PyUnicode_InternFromString("im");
+    PyObject* s_mode = PyUnicode_InternFromString("mode");
+    PyObject* s_size = PyUnicode_InternFromString("size");
+    PyObject* s_arrow = PyUnicode_InternFromString("__arrow_c_array__");
+    ok = ok && s_im && s_mode && s_size && s_arrow;
+    int32_t* hs = (int32_t*)hb.buf;
+    int32_t* ws = (int32_t*)wb.buf;
+    for (Py_ssize_t i = 0; ok && i < n && i < PyList_GET_SIZE(images); ++i) {
+        PyObject* img = PyList_GET_ITEM(images, i);
+        Py_INCREF(img);
+        PyObject* mode = PyObject_GetAttr(img, s_mode);
+        PyObject* core = mode ? PyObject_GetAttr(img, s_im) : nullptr;
+        PyObject* size = core ? PyObject_GetAttr(img, s_size) : nullptr;
+        ok = mode && core && size && PyUnicode_Check(mode) && PyUnicode_CompareWithASCIIString(mode, "RGB") == 0 && core != Py_None &&
+             PyObject_HasAttr(core, s_arrow) && PyTuple_Check(size) && PyTuple_GET_SIZE(size) == 2;
+        if (ok) {
+            const long w = PyLong_AsLong(PyTuple_GET_ITEM(size, 0)), h = PyLong_AsLong(PyTuple_GET_ITEM(size, 1));
+            ok = !PyErr_Occurred() && w > 0 && h > 0 && w < (1 << 30) && h < (1 << 30);
+            if (ok) { hs[i] = (int32_t)h; ws[i] = (int32_t)w; }
+        }
+        PyErr_Clear();
+        Py_XDECREF(mode);
+        Py_XDECREF(core);
+        Py_XDECREF(size);
+        Py_DECREF(img);
+    }
+    Py_XDECREF(s_im);
+    Py_XDECREF(s_mode);
+    Py_XDECREF(s_size);
+    Py_XDECREF(s_arrow);
+    PyBuffer_Release(&hb);
+    PyBuffer_Release(&wb);
+    if (ok) Py_RETURN_TRUE;
+    Py_RETURN_FALSE;
+}
+
 PyMethodDef methods[] = {
+    {"rgb_sizes", rgb_sizes, METH_VARARGS,
+     "rgb_sizes(images, heights_i32, widths_i32) -> bool: every item is a loaded Pillow RGB image; its height / width were written"},
     {"gather_rgbx", gather_rgbx, METH_VARARGS,
      "gather_rgbx(images, dst_address, dst_capacity, offsets, nbytes, threads=1) -> [indices not exported]\n"
      "Copy the RGBX pixel blocks (4 bytes per pixel, Pillow's in-memory layout of RGB images) of a list of PIL images to\n"

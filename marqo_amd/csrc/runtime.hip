@@ -4,6 +4,7 @@
 #include <mutex>
 #include <vector>
 #include "common.h"
+#include "copy_pool.h"
 
 static thread_local char g_err[512] = "";
 
@@ -87,34 +88,31 @@ extern "C" int mq_host_gather(const void* const* h_src, const int64_t* h_bytes, 
         total += h_bytes[i];
     }
     int t = threads < 1 ? 1 : (threads > 16 ? 16 : threads);
-    if (total < (4 << 20)) t = 1;   // small packs: a thread start costs more than the copy
+    if (total < (4 << 20)) t = 1;   // small packs: waking the copy threads costs more than the copy
     auto work = [&](int64_t lo, int64_t hi) {
         for (int64_t i = lo; i < hi; ++i)
             if (h_bytes[i]) memcpy((char*)h_dst + h_dst_off[i], h_src[i], (size_t)h_bytes[i]);
     };
     if (t == 1) { work(0, n); return MQ_OK; }
-    // contiguous item ranges of about total / t bytes each.  A thread that cannot be created (pid / thread limits of a container:
-    // std::system_error) must not escape an extern "C" function — std::terminate would take the whole server down: the calling thread
-    // then copies that range and everything after it itself (as csrc/py_stage.cpp does), and every started thread is joined on all paths.
-    std::vector<std::thread> pool;
-    int64_t lo = 0, acc = 0;
-    const int64_t share = (total + t - 1) / t;
+    // contiguous item ranges of about total / t bytes each, copied by the kept worker threads + the calling thread (copy_pool.h; a worker that
+    // cannot be created — pid / thread limits of a container — just means the calling thread copies more)
     try {
-        pool.reserve((size_t)t);
+        std::vector<std::pair<int64_t, int64_t>> ranges;
+        int64_t lo = 0, acc = 0;
+        const int64_t share = (total + t - 1) / t;
         for (int64_t i = 0; i < n; ++i) {
             acc += h_bytes[i];
             if (acc >= share || i == n - 1) {
-                if (i == n - 1 || (int)pool.size() == t - 1) break;   // the calling thread takes the last range
-                pool.emplace_back(work, lo, i + 1);
+                ranges.emplace_back(lo, i + 1);
                 lo = i + 1;
                 acc = 0;
             }
         }
-    } catch (...) {
-        // (lo still names the first item no thread owns)
+        const std::function<void(int)> job = [&](int r) { work(ranges[r].first, ranges[r].second); };
+        mq_copy_pool().run((int)ranges.size(), job);
+    } catch (...) {   // (allocation failure while setting up: nothing was copied by halves that matter — copy everything here)
+        work(0, n);
     }
-    work(lo, n);
-    for (auto& th : pool) th.join();
     return MQ_OK;
 }
 

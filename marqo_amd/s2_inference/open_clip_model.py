@@ -360,11 +360,28 @@ class OPEN_CLIP(AbstractCLIPModel):
         u8 = self._resize(pre, [pil_to_pixels(image)])
         return pre.to_tensor_normalize(u8)[0]
 
-    def _resize(self, pre, raw) -> torch.Tensor:
+    def _resize(self, pre, raw, pil_sizes=None) -> torch.Tensor:
         """list of uint8 [H, W, 3] -> uint8 [n, S, S, 3] on the device: Resize(S) + CenterCrop(S), or Resize((S, S)) ('squash').
         The decoded pixels are staged (pinned host buffer + HBM copy) in groups of at most STAGE_BYTES, so a request of thousands of
         multi-megapixel images cannot pin tens of GB at once; the resized outputs (S x S x 3 bytes each) are what accumulates."""
         S = self.vision_arch.image_size
+        if pil_sizes is not None:
+            # a batch of loaded Pillow RGB images: sizes came from ONE native scan, the staging groups from a cumulative sum
+            h, w = pil_sizes
+            nbytes = h.astype(np.int64) * w.astype(np.int64) * 4
+            bounds, start, acc = [0], 0, 0
+            if int(nbytes.sum()) > STAGE_BYTES:
+                for k, b in enumerate(nbytes.tolist()):
+                    if k > start and acc + b > STAGE_BYTES:
+                        bounds.append(k)
+                        start, acc = k, 0
+                    acc += b
+            bounds.append(len(raw))
+            outs = []
+            for a0, a1 in zip(bounds[:-1], bounds[1:]):
+                g, sz = (raw, pil_sizes) if (a0, a1) == (0, len(raw)) else (raw[a0:a1], (h[a0:a1], w[a0:a1]))
+                outs.append(pre.resize_u8(g, S, S, self._interpolation, pil_sizes=sz) if self._resize_mode == "squash" else pre.resize_crop_u8(g, pil_sizes=sz))
+            return outs[0] if len(outs) == 1 else torch.cat(outs)
         run = (lambda g: pre.resize_u8(g, S, S, self._interpolation)) if self._resize_mode == "squash" else pre.resize_crop_u8
         groups, cur, cur_bytes = [], [], 0
         for img in raw:
@@ -394,6 +411,12 @@ class OPEN_CLIP(AbstractCLIPModel):
                 return i
             return format_and_load_CLIP_image(i, headers)
         if isinstance(images, list):
+            # (a list of loaded Pillow RGB images — what format_and_load_CLIP_image would hand back unchanged — skips every per-image Python
+            # step below: one native scan vouches for the whole batch, engine/preprocess.py::pil_rgb_sizes)
+            from marqo_amd.engine.preprocess import pil_rgb_sizes
+            sizes = pil_rgb_sizes(images) if len(images) >= 8 and os.environ.get("MARQO_AMD_PIL_BATCH_FAST", "1") != "0" else None
+            if sizes is not None:
+                return "u8", self._resize(self._pre(), images, pil_sizes=sizes)
             loaded = [load(i) for i in images]
         else:
             loaded = [load(images)]

@@ -655,9 +655,9 @@ def test_image_staging_is_bounded_by_bytes(s2, monkeypatch):
     calls = []
     real = P.PackedImages.__init__
 
-    def spy(self, images, device, channels=3):
+    def spy(self, images, device, channels=3, **kw):
         calls.append(len(images))
-        real(self, images, device, channels)
+        real(self, images, device, channels, **kw)
     monkeypatch.setattr(P.PackedImages, "__init__", spy)
     monkeypatch.setattr(M, "STAGE_BYTES", 200_000)            # ~3 images per group
     split = model.encode_image(imgs)

@@ -188,3 +188,57 @@ def test_packed_images_layout_on_host(stage, native, monkeypatch):
         assert p.n == len(batch)
         for a, off in zip(arrs, p.offsets):
             assert np.array_equal(buf[int(off):int(off) + a.size], a.reshape(-1)), a.shape
+
+
+def test_rgb_sizes_vouches_for_whole_batches_only(stage):
+    """the batch fast path of PackedImages (round 4): ONE native scan says whether every item is a loaded Pillow RGB image and fills heights / widths;
+    anything else in the list — another mode, a file that is not decoded yet, an array — sends the whole batch down the per-image route"""
+    rng = np.random.default_rng(3)
+    imgs = [Image.fromarray(rng.integers(0, 256, (20 + i, 30 + 2 * i, 3), dtype=np.uint8)) for i in range(9)]
+    h, w = np.zeros(9, np.int32), np.zeros(9, np.int32)
+    assert stage.rgb_sizes(imgs, h, w) is True
+    assert h.tolist() == [20 + i for i in range(9)] and w.tolist() == [30 + 2 * i for i in range(9)]
+    assert P.pil_rgb_sizes(imgs)[0].tolist() == h.tolist()
+    buf = io.BytesIO()
+    imgs[0].save(buf, format="PNG")
+    buf.seek(0)
+    lazy = Image.open(buf)                                  # not decoded yet: its core does not exist
+    for odd in (imgs[1].convert("L"), imgs[2].convert("RGBA"), lazy, np.zeros((4, 4, 3), np.uint8), "http://x/y.png", None):
+        assert stage.rgb_sizes(imgs + [odd], np.zeros(10, np.int32), np.zeros(10, np.int32)) is False
+        assert P.pil_rgb_sizes(imgs + [odd]) is None
+    assert P.pil_rgb_sizes([]) is None and P.pil_rgb_sizes(tuple(imgs)) is None
+    with pytest.raises((BufferError, TypeError, ValueError)):
+        stage.rgb_sizes(imgs, np.zeros(9, np.int32).tobytes(), w)      # read-only buffer
+    assert stage.rgb_sizes(imgs, np.zeros(3, np.int32), w) is False    # wrong length: refused, nothing written out of bounds
+
+
+def test_copy_pool_survives_fork_and_many_callers(stage):
+    """the copy threads are kept between calls (round 4); a fork()ed child must not wait for workers it does not have"""
+    import os
+    rng = np.random.default_rng(4)
+    arrs = [rng.integers(0, 256, (224, 224, 3), dtype=np.uint8) for _ in range(48)]     # 9.6 MB: above the single-thread cut-off
+    imgs = [Image.fromarray(a) for a in arrs]
+    off, nbytes, total = _layout([(224, 224)] * 48)
+    dst = np.zeros(total, dtype=np.uint8)
+    assert stage.gather_rgbx(imgs, dst.ctypes.data, dst.nbytes, off, nbytes, 4) == []
+    pid = os.fork()
+    if pid == 0:
+        d2 = np.zeros(total, dtype=np.uint8)
+        ok = stage.gather_rgbx(imgs, d2.ctypes.data, d2.nbytes, off, nbytes, 4) == [] and np.array_equal(d2[int(off[7]):int(off[7]) + 224 * 224 * 4].reshape(224, 224, 4)[..., :3], arrs[7])
+        os._exit(0 if ok else 3)
+    _, status = os.waitpid(pid, 0)
+    assert os.waitstatus_to_exitcode(status) == 0
+    errs = []
+
+    def worker():
+        d = np.zeros(total, dtype=np.uint8)
+        for _ in range(10):
+            if stage.gather_rgbx(imgs, d.ctypes.data, d.nbytes, off, nbytes, 4) != [] or not np.array_equal(
+                    d[int(off[5]):int(off[5]) + 224 * 224 * 4].reshape(224, 224, 4)[..., :3], arrs[5]):
+                errs.append(1)
+    ts = [threading.Thread(target=worker) for _ in range(5)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(60)
+    assert not errs
