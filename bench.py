@@ -511,8 +511,8 @@ def e2e_vectorise(dev, images_cpu_u8, tower_only_rate, reps=9):
     out["best_e2e_over_tower_only"] = round(best / tower_only_rate, 3)
     # THE end-to-end figure: one synchronous caller handing over PIL images, as add_documents / search hand them to vectorise()
     out["headline_e2e"] = {"form": "ndarray_from_pil", "value": out["ndarray_from_pil"], "over_tower_only": round(out["ndarray_from_pil"] / tower_only_rate, 3),
-                           "note": "floor of a single synchronous caller: host pack of 51 MB of Pillow RGBX (2.2 ms) + H2D + resize + tower + D2H are serial "
-                                   "(profiles/r03i_e2e_phases_1thread.txt); chunked pipelining inside the call measured slower (r03i_e2e_pipeline_chunk_ab.txt)"}
+                           "note": "a single synchronous caller: host pack of 51 MB of Pillow RGBX (1.3 ms, H2D of 64-image slices under it) + tower enqueue (0.3 ms), then "
+                                   "the GPU's resize + tower + D2H (profiles/r04ah_e2e_phases.txt); the call in pipelined halves is a wash (r04ah)"}
     s2.clear_loaded_models()
     return out
 
