@@ -71,6 +71,17 @@ __global__ __launch_bounds__(256) void patchify_kernel(const void* __restrict__ 
 __global__ __launch_bounds__(256) void patchify_u8x8_kernel(const uint8_t* __restrict__ in, bf16_t* __restrict__ out, int64_t total,
                                                             int S, int P, int G, int Kp, float sc0, float sc1, float sc2,
                                                             float of0, float of1, float of2) {
+    // ToTensor: b / 255 ; Normalize: (t - mean) / std   (clip_utils.py:61-66) — the same expression as the generic path, but evaluated ONCE per
+    // (channel, byte value): two fp32 divisions per element made this kernel VALU-bound (36 us for 115 MB at the headline); a pixel is a byte,
+    // so the 3 x 256 possible results sit in an LDS table and an element costs one ds_read_u16.  Bit-identical by construction.
+    __shared__ bf16_t lut[3 * 256];
+    {
+        const float t = (float)threadIdx.x;
+        lut[threadIdx.x] = f32_to_bf16((t / 255.0f - of0) / sc0);
+        lut[256 + threadIdx.x] = f32_to_bf16((t / 255.0f - of1) / sc1);
+        lut[512 + threadIdx.x] = f32_to_bf16((t / 255.0f - of2) / sc2);
+    }
+    __syncthreads();
     const int per_row = P >> 3, per_patch = P * per_row, PP = P * P;
     for (int64_t gi = (int64_t)blockIdx.x * 256 + threadIdx.x; gi < total; gi += (int64_t)gridDim.x * 256) {
         const int64_t prow = gi / per_patch;
@@ -82,22 +93,21 @@ __global__ __launch_bounds__(256) void patchify_u8x8_kernel(const uint8_t* __res
         const uint2* src = (const uint2*)(in + ((img * S + (py * P + ky)) * S + (px * P + kx)) * 3);
         const uint2 w0 = src[0], w1 = src[1], w2 = src[2];
         const uint32_t words[6] = {w0.x, w0.y, w1.x, w1.y, w2.x, w2.y};
-        float v[3][8];
+        uint32_t v[3][8];
 #pragma unroll
         for (int b = 0; b < 24; ++b) {
-            const float t = (float)((words[b >> 2] >> ((b & 3) * 8)) & 0xffu);
+            const uint32_t byte = (words[b >> 2] >> ((b & 3) * 8)) & 0xffu;
             const int c = b % 3, e = b / 3;
-            // ToTensor: b / 255 ; Normalize: (t - mean) / std   (clip_utils.py:61-66) — same expression as the generic path
-            v[c][e] = (t / 255.0f - (c == 0 ? of0 : (c == 1 ? of1 : of2))) / (c == 0 ? sc0 : (c == 1 ? sc1 : sc2));
+            v[c][e] = (uint32_t)lut[c * 256 + byte];
         }
         bf16_t* dst = out + prow * Kp + ky * P + kx;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             uint4 p;
-            p.x = pack_bf16x2(v[c][0], v[c][1]);
-            p.y = pack_bf16x2(v[c][2], v[c][3]);
-            p.z = pack_bf16x2(v[c][4], v[c][5]);
-            p.w = pack_bf16x2(v[c][6], v[c][7]);
+            p.x = v[c][0] | (v[c][1] << 16);
+            p.y = v[c][2] | (v[c][3] << 16);
+            p.z = v[c][4] | (v[c][5] << 16);
+            p.w = v[c][6] | (v[c][7] << 16);
             *(uint4*)(dst + c * PP) = p;
         }
     }
