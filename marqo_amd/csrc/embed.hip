@@ -17,6 +17,15 @@ __global__ __launch_bounds__(256) void patchify_kernel(const void* __restrict__ 
                                                        float sc0, float sc1, float sc2, float of0, float of1, float of2) {
     const int groups_per_row = Kp >> 3;
     const int PP = P * P;
+    // uint8 pixels: (b / 255 - mean) / std evaluated once per (channel, byte value) into an LDS table (see patchify_u8x8_kernel)
+    __shared__ float lutf[U8 ? 3 * 256 : 1];
+    if (U8) {
+        const float t = (float)threadIdx.x;
+        lutf[threadIdx.x] = (t / 255.0f - of0) / sc0;
+        lutf[(U8 ? 256 : 0) + (U8 ? threadIdx.x : 0)] = (t / 255.0f - of1) / sc1;
+        lutf[(U8 ? 512 : 0) + (U8 ? threadIdx.x : 0)] = (t / 255.0f - of2) / sc2;
+        __syncthreads();
+    }
     for (int64_t gi = (int64_t)blockIdx.x * 256 + threadIdx.x; gi < total_groups; gi += (int64_t)gridDim.x * 256) {
         const int64_t prow = gi / groups_per_row;
         const int col0 = (int)(gi - prow * groups_per_row) * 8;
@@ -29,11 +38,9 @@ __global__ __launch_bounds__(256) void patchify_kernel(const void* __restrict__ 
             const int c = col0 / PP;
             const int rem = col0 - c * PP;
             const int ky = rem / P, kx = rem - ky * P;
-            const float sc = c == 0 ? sc0 : (c == 1 ? sc1 : sc2);
-            const float of = c == 0 ? of0 : (c == 1 ? of1 : of2);
             const uint8_t* src = (const uint8_t*)in + ((img * S + (py * P + ky)) * S + (px * P + kx)) * 3 + c;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = ((float)src[e * 3] / 255.0f - of) / sc;
+            for (int e = 0; e < 8; ++e) v[e] = lutf[U8 ? c * 256 + src[e * 3] : 0];
         } else
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -44,12 +51,10 @@ __global__ __launch_bounds__(256) void patchify_kernel(const void* __restrict__ 
                 const int rem = col - c * PP;
                 const int ky = rem / P, kx = rem - ky * P;
                 const int y = py * P + ky, x = px * P + kx;
-                const float sc = c == 0 ? sc0 : (c == 1 ? sc1 : sc2);
-                const float of = c == 0 ? of0 : (c == 1 ? of1 : of2);
                 if (U8) {
                     const uint8_t b = ((const uint8_t*)in)[((img * S + y) * S + x) * 3 + c];
-                    // ToTensor: b / 255 ; Normalize: (t - mean) / std   (clip_utils.py:61-66)
-                    val = ((float)b / 255.0f - of) / sc;
+                    // ToTensor: b / 255 ; Normalize: (t - mean) / std   (clip_utils.py:61-66), from the table
+                    val = lutf[U8 ? c * 256 + b : 0];
                 } else {
                     val = ((const float*)in)[((img * 3 + c) * S + y) * (int64_t)S + x];
                 }
