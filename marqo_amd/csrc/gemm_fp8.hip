@@ -438,7 +438,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(
 }
 
 #ifdef MQ_GEMM_PROBE   // compile-and-inspect builds (tests/test_gemm_isa.py): ONE instantiation
-__attribute__((used)) void* mq_gemm_fp8_probe() { return (void*)gemm_fp8_kernel<MQ_GEMM_PROBE, MQ_GEMM_PROBE_MT, (MQ_GEMM_PROBE_WN != 0)>; }
+__attribute__((used)) void* mq_gemm_fp8_probe() { return (void*)gemm_fp8_kernel<MQ_GEMM_PROBE, MQ_GEMM_PROBE_MT, (MQ_GEMM_PROBE_ROWSCALE != 0)>; }
 }  // namespace
 #else
 int choose_mt(int M, int N) {

@@ -20,10 +20,10 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 BIAS, GELU, RESIDUAL, OUT_F32, ROW_STATS, LN_APPLY = 1, 2, 8, 16, 64, 128
 
 
-def _compile(tmp_path, flags, mt, src=SRC, wn=0):
-    out = tmp_path / f"probe_{os.path.basename(src)}_{flags}_{mt}_{wn}.s"
+def _compile(tmp_path, flags, mt, src=SRC, rowscale=0):
+    out = tmp_path / f"probe_{os.path.basename(src)}_{flags}_{mt}_{rowscale}.s"
     res = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wall", "-Wno-unused-function", "-Rpass-analysis=kernel-resource-usage",
-                          f"-DMQ_GEMM_PROBE={flags}", f"-DMQ_GEMM_PROBE_MT={mt}", f"-DMQ_GEMM_PROBE_WN={wn}", "-S", "--cuda-device-only", "-o", str(out), src],
+                          f"-DMQ_GEMM_PROBE={flags}", f"-DMQ_GEMM_PROBE_MT={mt}", f"-DMQ_GEMM_PROBE_ROWSCALE={rowscale}", "-S", "--cuda-device-only", "-o", str(out), src],
                          capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-3000:]
     return out.read_text(), res.stderr
@@ -99,5 +99,5 @@ def test_fp8_loop_follows_the_same_rules(tmp_path, flags, mt, rowscale):
     """csrc/gemm_fp8.hip: the same pipeline (a k-step = two W-side halves; a tile's last k-step is a second body without the next stage's fragment
     reads, which the tile loop issues after the epilogue): two k-step bodies of 4 * MT MFMAs each; fragment reads (two ds_read_b128 each): MT + 2 at
     the tile top, MT + 4 in the steady k-step, 2 in the last one"""
-    isa, remarks = _compile(tmp_path, flags, mt, src=SRC.replace("gemm_bf16.hip", "gemm_fp8.hip"), wn=rowscale)
+    isa, remarks = _compile(tmp_path, flags, mt, src=SRC.replace("gemm_bf16.hip", "gemm_fp8.hip"), rowscale=rowscale)
     _check(isa, remarks, "v_mfma_scale_f32_16x16x128_f8f6f4", 8 * mt, 2 * (mt + 2) + 2 * (mt + 4) + 2 * 2, hot_regions=2)
