@@ -60,7 +60,7 @@ WORKLOADS = {
                                 "load-time fp8 block-split policy; 24 images = 240 crop embeddings per GPU per step", batch=24),
     "add_documents_stream": dict(kind="stream", arch="ViT-B-32", desc="BASELINE configs[3] as a stream: mixed {text, 224x224 PIL image} documents in 128-document requests; every "
                                  "rank owns whole requests (request i -> rank i % N, nothing is sharded inside a request), runs them through the single-GPU "
-                                 "BulkVectoriser path with ONE request in flight (request i + 1 is tokenised / packed / enqueued — text and images on two host threads — while request i runs; rows are copied to the host behind their tower) and ONE gather onto rank 0 closes the stream; ViT-B/32", batch=128),
+                                 "BulkVectoriser path, consecutive owned requests MERGED into chip-filling groups (one tower call per modality and group, text and images on two host threads / HIP streams) with ONE group in flight (group g + 1 is tokenised / packed / enqueued while group g runs; rows are copied to the host behind their tower) and ONE gather onto rank 0 closes the stream; ViT-B/32", batch=128),
     "stub": dict(kind="stub", arch="-", desc="launcher self-test: no GPU work, one gloo all_gather per step (tests/test_bench_launcher.py)", batch=4),
     "add_documents_mixed": dict(kind="ingest", arch="ViT-B-32", desc="add_documents bulk ingest in miniature (BASELINE configs[3]): documents {text, 224x224 image} in "
                                 "128-document requests through BulkVectoriser (host PIL images + strings -> vectorise -> gather in order), ViT-B/32", batch=128),
@@ -78,6 +78,7 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=0, help="items per GPU per step (default: the workload's)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp8"],
                     help="GEMM operand type of the encoder blocks (fp8 = e4m3, BASELINE config 5; not the headline metric)")
+    ap.add_argument("--merge-images", type=int, default=None, help="add_documents_stream: images per merged tower call (0 = no cross-request merging; default: marqo_amd.ingest.MERGE_IMAGES)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the headline baseline sample")
     ap.add_argument("--no-extras", action="store_true", help="skip e2e_vectorise and the `also` workloads (profiling runs)")
@@ -290,7 +291,7 @@ class Workload:
         self.fp8_policy = None
         if precision == "fp8":
             # load-time policy of the product (engine/towers.py::tune_fp8): static scales + how many trailing blocks run on e4m3 inside
-            # MARQO_AMD_FP8_BUDGET (default 7e-4 vs the bf16 tower; set it to 1 to force every block onto fp8), outside the timed region
+            # MARQO_AMD_FP8_BUDGET (default 5e-4 vs the bf16 tower; set it to 1 to force every block onto fp8), outside the timed region
             self.fp8_policy = [{"layers": t.cfg.enc.layers, "fp8_first_layer": t.tune_fp8_default(), "fp8_mlp_extra": t.fp8_mlp_extra, "policy_trace": t.fp8_policy_trace,
                                 "residual_stream": t.residual_stream, "calibration_err_vs_bf16": t.fp8_calibration_error,
                                 "all_blocks_err_vs_bf16": t.fp8_all_blocks_error} for t in self.towers]
@@ -368,6 +369,27 @@ def timed(run, steps, warmup, fence):
     return time.perf_counter() - t0, out
 
 
+_SUSTAINED = {}
+
+
+def measure_sustained_peak(lib, L, target_ms=60.0):
+    """mq_probe_mfma_peak once per process (median of 3 burns of ~60 ms); falls back to the round-1 constant if the probe fails"""
+    if not _SUSTAINED:
+        try:
+            scratch = torch.empty(1 << 16, dtype=torch.uint8, device="cuda")
+            tf, mhz = C.c_double(0.0), C.c_double(0.0)
+            runs = []
+            for _ in range(3):
+                L.check(lib.mq_probe_mfma_peak(target_ms, scratch.data_ptr(), scratch.numel(), C.byref(tf), C.byref(mhz),
+                                               torch.cuda.current_stream().cuda_stream), "mq_probe_mfma_peak")
+                runs.append((tf.value, mhz.value))
+            runs.sort()
+            _SUSTAINED.update(tflops=runs[1][0], shader_mhz=runs[1][1], source="mq_probe_mfma_peak in this run (median of 3 x 60 ms burns)")
+        except Exception as e:  # noqa: BLE001 - never lose the line to the probe
+            _SUSTAINED.update(tflops=2114.0, shader_mhz=2036.0, source=f"constant from profiles/r01f_mfma_sustained_peak.txt (probe failed: {type(e).__name__})")
+    return _SUSTAINED
+
+
 def gemm_roofline(lib, L, run_local, prof_steps, precision, workload_name):
     """HIP-event timing of the GEMM family on the launch stream (separate, instrumented steps)"""
     lib.mq_profile_enable(1)
@@ -394,15 +416,22 @@ def gemm_roofline(lib, L, run_local, prof_steps, precision, workload_name):
         "per_family": families,
     }
     if precision == "bf16":
-        # informational: what a register-resident v_mfma_f32_16x16x32_bf16 burn sustains on this chip with random operands at
-        # the clock it then holds (2.04 GHz) — tools/probes/mfma_peak.hip, profiles/r01f_mfma_sustained_peak.txt.  `peak` / `frac`
-        # above stay priced against the guide's 2.4 GHz figure.
-        roofline["peak_sustained_measured"] = 2114.0
-        roofline["frac_of_sustained"] = round(achieved / 2114.0, 4)
+        # what a register-resident v_mfma_f32_16x16x32_bf16 burn sustains on THIS chip, in THIS run, at the clock it holds under full MFMA load
+        # (csrc/probe.hip; boxes of the pool hold 1.86-2.03 GHz): `peak` / `frac` stay priced against the guide's 2.4 GHz dense figure,
+        # `frac_of_sustained` is the number that is comparable across boxes.
+        sustained = measure_sustained_peak(lib, L)
+        roofline["peak_sustained_measured"] = round(sustained["tflops"], 1)
+        roofline["peak_sustained_source"] = sustained["source"]
+        roofline["shader_mhz_under_mfma_load"] = round(sustained["shader_mhz"], 0)
+        roofline["frac_of_sustained"] = round(achieved / sustained["tflops"], 4)
+    # how `achieved` was timed: HIP events around every launch of the family add the event records' own dispatch gaps to the kernel time:
+    # against rocprofv3's kernel trace of the same command the GEMM family read 2.648 vs 2.553 ms per step (round 4) — `achieved` / `frac`
+    # UNDER-state the kernels by about 4 %
+    roofline["timing"] = "HIP events around each launch on the launch stream; overstates kernel time by ~4 % vs rocprofv3 --kernel-trace (profiles/)"
     # HBM-side traffic of the dominant kernel from the committed PMC passes of this same command (tools/gpu_evidence.sh:
     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH doubled per MI355X_MICROARCH.md; PMC cannot be sampled
     # from inside this process).  Bytes per launch, averaged over the GEMM launches like `achieved`.
-    for rnd in ("r04", "r03", "r02", "r01"):
+    for rnd in ("r05", "r04", "r03", "r02", "r01"):
         tpath = os.path.join(ROOT, "profiles", f"{rnd}_traffic_{workload_name}_{precision}.json")
         if not os.path.isfile(tpath):
             continue
@@ -416,6 +445,7 @@ def gemm_roofline(lib, L, run_local, prof_steps, precision, workload_name):
                 roofline["traffic"] = round(sum(v["launches"] * (v["read_bytes"] + v["write_bytes"]) for v in rows) / n_l, 1)
                 roofline["traffic_unit"] = "bytes/launch (fabric-side reads incl. Infinity-Cache hits + writes)"
                 roofline["traffic_source"] = os.path.relpath(tpath, ROOT)
+                roofline["traffic_measured"] = "from_file"     # PMC passes cannot run inside this process: a committed measurement of the same command
                 break
         except (OSError, ValueError, KeyError):
             pass
@@ -587,6 +617,113 @@ def run_stream(args, dev, rank, world, dist, lib, L):
     from marqo_amd.s2_inference.enums import Modality
     wl = WORKLOADS["add_documents_stream"]
     docs = args.batch or wl["batch"]
+    if args.steps <= 0:             # the stream at BASELINE configs[3]'s stated size: 100 000 documents over the ranks
+        args.steps = -(-100000 // (docs * world))
+    name = "open_clip/ViT-B-32/laion2b_s34b_b79k"
+    varch, tarch = archs.resolve_open_clip("ViT-B-32")
+    # a pool of 4 distinct synthetic requests per rank (4 x 128 images = 77 MB of pixels), cycled: the stream's requests are independent
+    rng = np.random.default_rng(100 + rank)
+    words = ["alpha", "beta", "gamma", "delta", "marqo", "tensor", "search", "image", "text", "vector"]
+    pool = []
+    for r in range(4):
+        imgs = [Image.fromarray(rng.integers(0, 256, (224, 224, 3), dtype=np.uint8)) for _ in range(docs)]
+        texts = [" ".join(words[int(j) % 10] for j in rng.integers(0, 10, int(rng.integers(3, 60)))) + f" {r} {i}" for i in range(docs)]
+        pool.append((texts, imgs))
+    ing = RequestShardedIngest(name, dev)
+    if getattr(args, "merge_images", None) is not None:
+        ing.merge_images = args.merge_images
+    group = max(1, -(-ing.merge_images // docs)) if ing.merge_images > 0 else 1       # requests per merged tower call
+    state = {"next": rank}          # this rank's next request index (rank, rank + world, ...)
+
+    def step():                     # ONE owned request of `docs` documents = 2 * docs embeddings
+        i = state["next"]
+        state["next"] += world
+        texts, imgs = pool[(i // world) % len(pool)]
+        items = [((i, d, "t"), texts[d], Modality.TEXT) for d in range(docs)] + [((i, d, "i"), imgs[d], Modality.IMAGE) for d in range(docs)]
+        ing.submit(i, items)
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 2 * group)):
+        step()
+    ing.collect()
+    fence()
+    torch.cuda.reset_peak_memory_stats()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    rows = ing.collect()            # the stream's ONE data-path collective: gather onto rank 0
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    n_emb = 2 * docs
+    if rank == 0:
+        assert len(rows) == args.steps * world and all(len(v) == n_emb for v in rows.values()), (len(rows), args.steps, world)
+    value = n_emb * world * args.steps / elapsed
+    memory = {"device_peak_allocated_mb": round(torch.cuda.max_memory_allocated() / 2**20, 1),
+              "device_peak_reserved_mb": round(torch.cuda.max_memory_reserved() / 2**20, 1)}
+    try:
+        hs = torch.cuda.host_memory_stats()
+        memory["pinned_peak_allocated_mb"] = round(hs.get("allocated_bytes.peak", 0) / 2**20, 1)
+        memory["pinned_reserved_mb"] = round(hs.get("reserved_bytes.current", hs.get("reserved_bytes.peak", 0)) / 2**20, 1)
+    except Exception:  # noqa: BLE001 - statistics of the pinned-memory allocator are not in every build
+        pass
+    # roofline of the dominant kernel family over a few more GROUPS (HIP events on the launch streams, as in the headline)
+    # (groups one at a time, both modalities on the caller's thread: with a group in flight the two towers' kernels share the GPU and every
+    # family's HIP-event time would count the other tower's kernels too)
+    ing.collect()
+    ing.pipeline_depth, ing._bulk.two_threads = 0, False
+
+    def group_step():
+        for _ in range(group):
+            step()
+        ing.drain()
+    prof_groups = max(2, min(args.steps // group, 6))
+    roofline = gemm_roofline(lib, L, group_step, prof_groups, args.precision, "add_documents_stream")
+    ing.collect()
+    ing.pipeline_depth, ing._bulk.two_threads = 1, True
+    ing.close()
+    roofline["requests_per_profiled_step"] = group
+    gf = (varch.gflop_per_image + tarch.gflop_per_text(30)) / 2
+    result = {
+        "metric": "embeddings/sec", "value": round(value, 1), "unit": "embeddings/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": args.precision, "data": "synthetic",
+        "config": {"workload": wl["desc"], "global_batch": n_emb, "docs_per_request": docs,
+                   "parallelism": f"dp{world} (replicated weights; texts sharded by token estimate, images contiguously; ONE RCCL all_gather per modality from HBM; "
+                                  f"every rank returns the request's embeddings in order)",
+                   "weights": "random-init (seed 0) ViT-B-32", "gflop_per_embedding": round(gf, 3)},
+        "e2e_tflops": round(value * gf / 1e3, 1),
+        # the dominant kernel family over a few more requests (HIP events on the launch streams, as in the headline)
+        "roofline": gemm_roofline(lib, L, step, min(args.steps, 6), args.precision, "add_documents_mixed"),
+        "cpu_baseline": (mixed_request_cpu_baseline(varch, tarch, imgs, docs, args.cpu_seconds)
+                         if rank == 0 and world == 1 and not args.no_cpu_baseline else None),
+        "note": "end-to-end through the Python boundary (host PIL -> uint8 pack -> H2D -> K10 -> towers -> gather -> D2H -> per-key rows); "
+                "the request (total work) is fixed, ranks split it: strong scaling",
+    }
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+
+
+# ---- BASELINE configs[3] as a stream: ranks own whole requests, one gather onto rank 0 ----------------------------------------------
+def run_stream(args, dev, rank, world, dist, lib, L):
+    from PIL import Image
+    os.environ["MARQO_AMD_SYNTHETIC_WEIGHTS"] = "1"
+    os.environ.setdefault("MARQO_MAX_CUDA_MODEL_MEMORY", "64")
+    from marqo_amd.engine import archs
+    from marqo_amd.ingest import RequestShardedIngest
+    from marqo_amd.s2_inference import s2_inference as s2
+    from marqo_amd.s2_inference.enums import Modality
+    wl = WORKLOADS["add_documents_stream"]
+    docs = args.batch or wl["batch"]
+    if args.steps <= 0:             # the stream at BASELINE configs[3]'s stated size: 100 000 documents over the ranks
+        args.steps = -(-100000 // (docs * world))
     name = "open_clip/ViT-B-32/laion2b_s34b_b79k"
     varch, tarch = archs.resolve_open_clip("ViT-B-32")
     # a pool of 4 distinct synthetic requests per rank (4 x 128 images = 77 MB of pixels), cycled: the stream's requests are independent
@@ -644,6 +781,8 @@ def run_stream(args, dev, rank, world, dist, lib, L):
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.precision, "data": "synthetic",
         "config": {"workload": wl["desc"], "global_batch": n_emb * world, "docs_per_request": docs, "documents_in_stream": docs * world * args.steps,
+                   "micro_batching": (f"requests merged across the stream until >= {ing.merge_images} images or >= {ing.merge_text_tokens} estimated text tokens "
+                                      f"({group} requests per tower call here) or a {ing.merge_deadline_ms} ms deadline" if ing.merge_images > 0 else "off: one tower call per request and modality"),
                    "inputs": "host PIL images + strings (the boundary add_documents hands over); host packing, H2D and the final D2H are INSIDE the timed "
                              "region — this workload is end-to-end by definition, the tower-only figure is the headline workload's",
                    "parallelism": f"dp{world}: replicated weights; request i belongs to rank i % {world}; no collective inside a request; ONE gather "
@@ -651,8 +790,9 @@ def run_stream(args, dev, rank, world, dist, lib, L):
                    "weights": "random-init (seed 0) ViT-B-32", "gflop_per_embedding": round(gf, 3)},
         "e2e_tflops": round(value * gf / 1e3, 1), "roofline": roofline,
     }
-    busy = sum(f["ms_per_step"] for f in roofline.get("per_family", {}).values())
-    result["gpu_busy_ms_per_step"] = round(busy, 4)               # sum of the kernel families' HIP-event time per request (requests run one at a time)
+    busy = sum(f["ms_per_step"] for f in roofline.get("per_family", {}).values()) / group
+    result["gpu_busy_ms_per_step"] = round(busy, 4)               # sum of the kernel families' HIP-event time per request (groups run one at a time)
+    result["memory"] = memory
     result["gpu_idle_share"] = round(max(0.0, 1.0 - busy / (elapsed / args.steps * 1e3)), 4)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # the CPU path runs the SAME request (its images, its texts through the loaded model's tokeniser), so the error below compares like with like
@@ -810,9 +950,10 @@ def main():
         for name in ALSO_DEFAULT:
             try:
                 if WORKLOADS[name]["kind"] == "stream":      # BASELINE configs[3]: end-to-end by definition (host PIL + strings in, host rows out)
-                    sa = argparse.Namespace(**{**vars(args), "steps": 30, "warmup": 4, "batch": 0, "cpu_seconds": 8.0, "workload": name})
+                    sa = argparse.Namespace(**{**vars(args), "steps": 0, "warmup": 8, "batch": 0, "cpu_seconds": 8.0, "workload": name})   # steps 0 = the full 100 000 documents
                     r = run_stream(sa, dev, 0, 1, None, lib, L)
-                    also.append({"workload": r["config"]["workload"], "value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "steps": 30, "warmup": 4,
+                    also.append({"workload": r["config"]["workload"], "value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "steps": r["steps"], "warmup": r["warmup"], "documents_in_stream": r["config"]["documents_in_stream"],
+                                 "micro_batching": r["config"]["micro_batching"], "memory": r.get("memory"),
                                  "gflop_per_embedding": r["config"]["gflop_per_embedding"], "e2e_tflops": r["e2e_tflops"], "gemm_tflops": r["roofline"]["achieved"],
                                  "gemm_frac": r["roofline"]["frac"], "roofline": r["roofline"], "gpu_busy_ms_per_step": r["gpu_busy_ms_per_step"],
                                  "gpu_idle_share": r["gpu_idle_share"], "cpu_baseline": r.get("cpu_baseline"), "cos_err_vs_cpu": r.get("cos_err_vs_cpu")})

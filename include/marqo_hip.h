@@ -45,7 +45,7 @@ extern "C" {
 #define MQ_ERR_HIP (-2)       /* a HIP runtime call or launch failed */
 #define MQ_ERR_WORKSPACE (-3) /* caller's workspace too small */
 
-#define MQ_ABI_VERSION 7
+#define MQ_ABI_VERSION 8
 
 /* ---- activation / mask / pooling selectors ---------------------------------------- */
 #define MQ_ACT_NONE 0
@@ -577,13 +577,15 @@ int mq_weighted_combine(const float* d_emb, int64_t ld, const int32_t* d_rows, c
                         const int32_t* d_cu_terms, int64_t n_groups, int32_t D, int32_t mode, float* d_out,
                         void* stream);
 
-/* Run-time selection of a kernel variant (benchmark A/B and parity tests of every variant in one process).
- * keys: "gemm_mt" (0 = auto, else GEMM tile height in 32-row units), "gemm_big" (4 / 5 / 6 / 8 = one-workgroup-per-CU
- * (32*v) x 256 tile, 0 = off), "gemm_k32" (3 = 128x128x32 tiles, three workgroups per CU), "gemm_persist", "gemm_cgroup",
- * "gemm_wide" (GEMM scheduling knobs, see csrc/gemm_bf16.hip), "row_select" (0 = the towers run their last block on every row
- * instead of the pooled rows only), "ln_fold" (1 = LayerNorm folded into the GEMM epilogues, needs folded weights), "ln_rows"
- * (rows per LayerNorm wave), "attn_waves" (0 = auto, 4 / 8 wave64s per attention workgroup).  Initial values come from the
- * environment (MQ_GEMM_MT, MQ_GEMM_BIG, MQ_GEMM_PERSIST, MQ_GEMM_CGROUP, MQ_GEMM_WIDE, MQ_GEMM_K32, MQ_ROW_SELECT, MQ_LN_FOLD). */
+/* Run-time selection of a kernel variant (benchmark A/B and parity tests of every variant in one process).  TEST / BENCH ONLY: the
+ * knobs are plain ints read without synchronisation by the launch code of every request thread — set them while no request is in
+ * flight; the loaders never touch them.
+ * keys: "gemm_mt" (0 = auto, else GEMM tile height in 32-row units), "gemm_cgroup" (column tiles per L2 group, 0 = row-major walk),
+ * "gemm_addr_limit_mb" (bytes / 2^20 one launch may address per operand, 0 = the 4 GiB of a 32-bit buffer offset: taller matrices go in
+ * row chunks), "row_select" (0 = the towers run their last block on every row instead of the pooled rows only), "ln_fold" (0 = LayerNorm
+ * kernels, 1 = folded into the QKV GEMM, 2 = and into fc1; needs the folded weights), "residual_bf16", "small_m" / "small_m_grouped"
+ * (row limits of the skinny GEMM kernels), "ln_prefetch", "xcd_band", "attn_waves" (0 = auto, 4 / 8 wave64s per attention workgroup).
+ * Initial values come from the environment (MQ_GEMM_MT, MQ_GEMM_CGROUP, MQ_ROW_SELECT, MQ_LN_FOLD, ...). */
 int mq_tune(const char* key, int value);
 
 /* ---- per-kernel timing (bench.py roofline) ------------------------------------------- */
@@ -595,6 +597,12 @@ int mq_profile_enable(int on);
 int mq_profile_collect(double* ms_per_family /* [MQ_PROF_FAMILIES] */,
                        int64_t* launches_per_family /* [MQ_PROF_FAMILIES] */,
                        double* gemm_flops /* total 2*M*N*K over gemm launches */);
+
+/* ---- measurement support (bench.py `roofline.peak_sustained_measured`; not on the product path) ---------------------------- */
+/* A register-resident v_mfma_f32_16x16x32_bf16 burn (no LDS, no memory; 256 CUs x 4 SIMDs x 2 waves, pseudo-random operand bits) of
+ * about target_ms on `stream`; waits for it.  *tflops = the dense bf16 rate this chip sustains at the clock it holds under full MFMA
+ * load, *shader_mhz = that clock (s_memtime ticks / wall time).  d_scratch: >= 32 KiB of device memory.  No reference counterpart. */
+int mq_probe_mfma_peak(double target_ms, void* d_scratch, int64_t scratch_bytes, double* tflops, double* shader_mhz, void* stream);
 
 #ifdef __cplusplus
 }

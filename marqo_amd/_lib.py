@@ -28,8 +28,8 @@ STAGE_SRC = CSRC_DIR / "py_stage.cpp"
 STAGE_PATH = LIB_DIR / "_mq_stage.so"                # CPython extension: a batch of Pillow images -> the pinned staging buffer in one call
 
 MQ_OK = 0
-NO_SCRATCH_UNITS = ("rowops", "gemm_bf16", "gemm_fp8", "gemm_small", "attention")  # build() refuses register spills in these
-ABI_VERSION = 7
+NO_SCRATCH_UNITS = ("rowops", "gemm_bf16", "gemm_fp8", "gemm_small", "attention", "embed")  # build() refuses register spills in these
+ABI_VERSION = 8
 MQ_PREC_BF16, MQ_PREC_FP8 = 0, 1
 MQ_ACT_GELU, MQ_ACT_QUICKGELU = 1, 2
 MQ_MASK_NONE, MQ_MASK_CAUSAL = 0, 1
@@ -195,6 +195,7 @@ _SIGNATURES = {
     "mq_tune": (C.c_int, [C.c_char_p, C.c_int]),
     "mq_profile_enable": (C.c_int, [C.c_int]),
     "mq_profile_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    "mq_probe_mfma_peak": (C.c_int, [C.c_double, _P, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double), _P]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

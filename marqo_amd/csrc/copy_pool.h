@@ -22,7 +22,13 @@ class CopyPool {
     // run job(k) for k in [0, n) on up to n - 1 workers + the calling thread; returns when all are done.  Callers hold no GIL.
     void run(int n, const std::function<void(int)>& job) {
         if (n <= 1) { if (n == 1) job(0); return; }
-        std::unique_lock<std::mutex> call(call_mu_);              // one pack at a time per process (packs of concurrent request threads queue here)
+        // The workers serve ONE pack at a time.  A second request thread that arrives meanwhile does not queue behind it (with 8 + 8 request
+        // threads that would serialise every pack in the process): it copies its ranges itself — concurrent callers are the parallelism then.
+        std::unique_lock<std::mutex> call(call_mu_, std::try_to_lock);
+        if (!call.owns_lock()) {
+            for (int k = 0; k < n; ++k) job(k);
+            return;
+        }
         {
             std::lock_guard<std::mutex> g(mu_);
             while ((int)workers_.size() < n - 1 && (int)workers_.size() < kMaxWorkers) {

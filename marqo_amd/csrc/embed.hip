@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void map_pool_kernel(const bf16_t* __restrict_
 // ---- token embedding (+ pos, + type) (+ LayerNorm) ---------------------------------------------------
 // grid = nseq blocks; the 4 waves of a block walk the sequence's rows.
 template <bool LN, int CH>
-__global__ __launch_bounds__(256, (CH <= 4 ? 8 : 4)) void embed_tokens_kernel(
+__global__ __launch_bounds__(256, (CH <= 2 ? 8 : 4)) void embed_tokens_kernel(
     const int32_t* __restrict__ ids, const int32_t* __restrict__ cu, const float* __restrict__ tok,
     const float* __restrict__ pos, const float* __restrict__ type0, const float* __restrict__ gam,
     const float* __restrict__ bet, float* __restrict__ x, bf16_t* __restrict__ xb, int W, int vocab, float eps) {

@@ -50,8 +50,7 @@ int mq_gemm_small(const void* d_A, int64_t lda, const void* d_W, int64_t ldw, co
 
 namespace {
 
-constexpr int BN = 128, BK = 64;
-constexpr int W_TILE_BYTES = BN * BK * 2;  // 16 KiB
+constexpr int BK = 64;
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void_t;
@@ -81,20 +80,25 @@ __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...
 template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
 
+// NH: 64-column halves of a wave's sub-tile.  NH = 1: the (32*MT)x128 block tile, two workgroups per CU (the towers' short-K shapes).  NH = 2 (round 5):
+// the WIDE tile, (32*MT)x256 — at MT = 8 the 256x256x64 macro-tile with 128x128 per wave: 64 MFMAs per 16 fragment reads and per 16 LDS-DMA
+// pieces where the 160x128 tile has 20 per 9 and 9 — one workgroup per CU (128 KiB of LDS, 256 accumulator registers per lane: the allocator
+// puts them in AGPRs), everything else — staging, swizzle, the register double-buffering, the hand-placed waits — is the same code.
 // ORD: order of the second half's side work — 0: LDS-DMA pieces first, then the next stage's fragment reads; 1: reads first; 2: alternating
-template <int FLAGS, int MT, int ORD>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
+template <int FLAGS, int MT, int NH, int ORD>
+__global__ __launch_bounds__(256, NH == 1 ? 2 : 1) void gemm_nt_kernel(
     const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ Wt, int64_t ldw,
     const float* __restrict__ bias, const float* residual, void* out, int64_t ldc,
     int M, int N, int K, int tiles_n, int num_tiles, int cgroup, int band_rows, int wide_store,
     unsigned a_bytes, unsigned w_bytes, GemmLn ln) {
-    constexpr int BM = 32 * MT;
-    constexpr int A_TILE_BYTES = BM * BK * 2;
+    constexpr int BM = 32 * MT, BN = 128 * NH;
+    constexpr int NTW = 4 * NH;     // 16-column W sub-tiles per wave
+    constexpr int A_TILE_BYTES = BM * BK * 2, W_TILE_BYTES = BN * BK * 2;
     constexpr int STAGE_BYTES = A_TILE_BYTES + W_TILE_BYTES;
-    constexpr int NL = MT + 4;      // LDS-DMA pieces (1 KiB each) per wave per stage = fragment reads per wave per k-half
-    constexpr int NM = 4 * MT;      // MFMAs per wave per k-half
+    constexpr int NL = MT + NTW;    // LDS-DMA pieces (1 KiB each) per wave per stage = fragment reads per wave per k-half
+    constexpr int NM = NTW * MT;    // MFMAs per wave per k-half
     // residual rows prefetched together by the epilogue (16-row units): the next tile's first fragments are live across it
-    constexpr int ERG = !(FLAGS & MQ_EPI_RESIDUAL) ? MT : (FLAGS & MQ_EPI_OUT_F32) ? (MT <= 3 ? MT : (MT + 1) / 2) : (MT <= 5 ? MT : 3);
+    constexpr int ERG = !(FLAGS & MQ_EPI_RESIDUAL) ? MT : NH == 2 ? MT : (FLAGS & MQ_EPI_OUT_F32) ? (MT <= 3 ? MT : (MT + 1) / 2) : (MT <= 5 ? MT : 3);
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     // ---- XCD-aware, bijective (virtual) block -> tile map, L2-blocked order inside an XCD's share (as in rounds 1-3) --------------
@@ -128,12 +132,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
     const int wm = wave >> 1, wn = wave & 1;
     const int l15 = lane & 15, g = lane >> 4;
 
-    // ---- staging: wave w owns A rows [8*MT*w, 8*MT*(w+1)) and W rows [32w, 32w+32) of a stage, 8 rows per LDS-DMA piece.
+    // ---- staging: wave w owns A rows [8*MT*w, 8*MT*(w+1)) and W rows [32*NH*w, 32*NH*(w+1)) of a stage, 8 rows per LDS-DMA piece.
     // lane -> (row = base + lane/8, physical 16-B chunk = lane%8); it fetches logical chunk (lane%8) ^ (row&7) of that row, so physical
     // chunk p of row r holds logical chunk p ^ (r&7) (the swizzle lives on the SOURCE address; the LDS image is lane-linear).
     const int srow = lane >> 3;
     const unsigned chunk_off = (unsigned)(((lane & 7) ^ (srow & 7)) * 16);   // (row & 7) == (srow & 7): piece bases are multiples of 8 rows
-    unsigned a_vo[MT], w_vo[4];
+    unsigned a_vo[MT], w_vo[NTW];
     auto set_sources = [&](int m0, int n0) {
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
@@ -141,8 +145,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
             a_vo[i] = (unsigned)gm * (unsigned)lda * 2u + chunk_off;
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int gn = n0 + wave * 32 + i * 8 + srow; gn = gn < N ? gn : N - 1;
+        for (int i = 0; i < NTW; ++i) {
+            int gn = n0 + wave * (8 * NTW) + i * 8 + srow; gn = gn < N ? gn : N - 1;
             w_vo[i] = (unsigned)gn * (unsigned)ldw * 2u + chunk_off;
         }
     };
@@ -158,7 +162,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
         set_sources(m0, n0);
     }
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    const unsigned dma_a0 = lds0 + (unsigned)wave * (8 * MT * 128), dma_w0 = lds0 + A_TILE_BYTES + (unsigned)wave * (32 * 128);   // scalars
+    const unsigned dma_a0 = lds0 + (unsigned)wave * (8 * MT * 128), dma_w0 = lds0 + A_TILE_BYTES + (unsigned)wave * (8 * NTW * 128);   // scalars
     auto issue_piece = [&](int i, unsigned bufoff) {
         const unsigned soff = (unsigned)d_k * (BK * 2);
         if (i < MT) dma16(__builtin_amdgcn_make_buffer_rsrc((void*)A, 0, a_rec, 0x00020000), a_vo[i < MT ? i : 0], soff, dma_a0 + bufoff + (unsigned)i * 1024u);
@@ -181,16 +185,16 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
     // ---- fragment read addresses (LDS byte offsets), fixed per lane: logical chunk for k-half kk is g + 4*kk, (row & 7) == (l15 & 7)
     const unsigned sw0 = (unsigned)((g ^ (l15 & 7)) << 4), sw1 = (unsigned)(((g + 4) ^ (l15 & 7)) << 4);
     const unsigned a_row = lds0 + (unsigned)((wm * (16 * MT) + l15) * 128);
-    const unsigned w_row = lds0 + A_TILE_BYTES + (unsigned)((wn * 64 + l15) * 128);
+    const unsigned w_row = lds0 + A_TILE_BYTES + (unsigned)((wn * (16 * NTW) + l15) * 128);
     const unsigned aB0 = a_row + sw0, aB1 = a_row + sw1, wB0 = w_row + sw0, wB1 = w_row + sw1;
 
-    f32x4 acc[MT][4];
-    bf16x8 wf0[4], af0[MT], wf1[4], af1[MT];
-    // one fragment read of a k-half: piece p < 4 -> W sub-tile p, else A sub-tile p - 4 (offsets t * 16 rows * 128 B)
-    auto read_piece = [&](auto p_tag, unsigned wbase, unsigned abase, bf16x8 (&wf)[4], bf16x8 (&af)[MT]) {
+    f32x4 acc[NH][MT][4];
+    bf16x8 wf0[NTW], af0[MT], wf1[NTW], af1[MT];
+    // one fragment read of a k-half: piece p < NTW -> W sub-tile p, else A sub-tile p - NTW (offsets t * 16 rows * 128 B)
+    auto read_piece = [&](auto p_tag, unsigned wbase, unsigned abase, bf16x8 (&wf)[NTW], bf16x8 (&af)[MT]) {
         constexpr int P = decltype(p_tag)::value;
-        if constexpr (P < 4) wf[P] = lds_read16<P * 2048>(wbase);
-        else af[P - 4] = lds_read16<(P - 4) * 2048>(abase);
+        if constexpr (P < NTW) wf[P] = lds_read16<P * 2048>(wbase);
+        else af[P - NTW] = lds_read16<(P - NTW) * 2048>(abase);
     };
 
     // ---- prologue: the workgroup's first two stages, then the kk = 0 fragments of the first -----------------------------------------
@@ -213,7 +217,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
         // -------- first half: MFMAs on (wf0, af0); reads of (wf1, af1) between them
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (wf0, af0) landed
 #pragma unroll
-        for (int t = 0; t < 4; ++t) landed(wf0[t]);
+        for (int t = 0; t < NTW; ++t) landed(wf0[t]);
 #pragma unroll
         for (int t = 0; t < MT; ++t) landed(af0[t]);
         __builtin_amdgcn_sched_barrier(0);
@@ -221,8 +225,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
             const unsigned wb = wB1 + bufoff, ab = aB1 + bufoff;
             constexpr int NS1 = NL;   // side work of the first half: the NL fragment reads of kk = 1
             static_for<NM>([&](auto idx_tag) {
-                constexpr int idx = decltype(idx_tag)::value, mt = idx / 4, nt = idx % 4;
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[nt], af0[mt], acc[mt][nt], 0, 0, 0);
+                constexpr int idx = decltype(idx_tag)::value, mt = idx / NTW, nt = idx % NTW;
+                acc[nt / 4][mt][nt % 4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[nt], af0[mt], acc[nt / 4][mt][nt % 4], 0, 0, 0);
                 constexpr int RG = NM / NL > 0 ? NM / NL : 1;   // one read per RG MFMAs; the last MFMA flushes whatever is left
                 constexpr int lo = idx == 0 ? 0 : (idx / RG < NS1 ? idx / RG : NS1);
                 constexpr int hi = idx == NM - 1 ? NS1 : ((idx + 1) / RG < NS1 ? (idx + 1) / RG : NS1);
@@ -240,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
         __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) — as a builtin: the compiler's own scoreboard must see that nothing is pending
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int t = 0; t < 4; ++t) landed(wf1[t]);
+        for (int t = 0; t < NTW; ++t) landed(wf1[t]);
 #pragma unroll
         for (int t = 0; t < MT; ++t) landed(af1[t]);
         __builtin_amdgcn_s_barrier();
@@ -254,8 +258,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
             const unsigned wb = wB0 + nb, ab = aB0 + nb;
             constexpr int NSIDE = 2 * NL;
             static_for<NM>([&](auto idx_tag) {
-                constexpr int idx = decltype(idx_tag)::value, mt = idx / 4, nt = idx % 4;
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[nt], af1[mt], acc[mt][nt], 0, 0, 0);
+                constexpr int idx = decltype(idx_tag)::value, mt = idx / NTW, nt = idx % NTW;
+                acc[nt / 4][mt][nt % 4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[nt], af1[mt], acc[nt / 4][mt][nt % 4], 0, 0, 0);
                 constexpr int lo = idx == 0 ? 0 : (idx * NSIDE) / NM;                         // side items due after this MFMA: [lo, hi)
                 constexpr int hi = idx == NM - 1 ? NSIDE : ((idx + 1) * NSIDE) / NM;
                 static_for<hi - lo>([&](auto it_tag) {
@@ -277,19 +281,28 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
         int cm0, cn0;
         tile_origin(c_vbid, cm0, cn0);
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+        for (int h = 0; h < NH; ++h)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[h][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int kt = 0; kt < nk; ++kt) kstep();
         // the compiler takes an asm's outputs as valid once the statement has executed: retire the last fragment reads before any code it
         // may place behind the loop (register copies at the tile boundary) can touch them
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int t = 0; t < 4; ++t) landed(wf0[t]);
+        for (int t = 0; t < NTW; ++t) landed(wf0[t]);
 #pragma unroll
         for (int t = 0; t < MT; ++t) landed(af0[t]);
 
-        gemm_epilogue<FLAGS, MT, ERG, true>(acc, bias, residual, out, ldc, M, N, cm0 + wm * (16 * MT), cn0 + wn * 64, l15, g, wide_store != 0, &ln, nullptr);
+        // (wide tile: the lane's row / column ids pass through an empty asm, so that the epilogue's address arithmetic is redone per tile instead of
+        // being hoisted out of the tile loop — kept live across the k-loop next to 128 fragment registers it spilled)
+        int l15e = l15, ge = g;
+        if (NH == 2) asm volatile("" : "+v"(l15e), "+v"(ge));
+        static_for<NH>([&](auto h_tag) {
+            constexpr int h = decltype(h_tag)::value;
+            gemm_epilogue<FLAGS, MT, ERG, true, NH == 2>(acc[h], bias, residual, out, ldc, M, N, cm0 + wm * (16 * MT), cn0 + wn * (16 * NTW) + h * 64, l15e, ge, wide_store != 0, &ln, nullptr);
+        });
 
         c_vbid += gridDim.x;
         if (c_vbid >= num_tiles) break;
@@ -299,27 +312,36 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
 }
 
 #ifdef MQ_GEMM_PROBE   // compile-and-inspect builds (tests/test_gemm_isa.py): ONE instantiation, hipcc -DMQ_GEMM_PROBE=<flags> -DMQ_GEMM_PROBE_MT=<mt> -S
-__attribute__((used)) void* mq_gemm_probe() { return (void*)gemm_nt_kernel<MQ_GEMM_PROBE, MQ_GEMM_PROBE_MT, 2>; }
+#ifndef MQ_GEMM_PROBE_NH
+#define MQ_GEMM_PROBE_NH 1
+#endif
+__attribute__((used)) void* mq_gemm_probe() { return (void*)gemm_nt_kernel<MQ_GEMM_PROBE, MQ_GEMM_PROBE_MT, MQ_GEMM_PROBE_NH, 2>; }
 }  // namespace
 #else
-constexpr int RESIDENT_SLOTS = 512;  // 256 CUs x 2 workgroups
+constexpr int RESIDENT_SLOTS = 512;       // 256 CUs x 2 workgroups (NH = 1)
+constexpr int RESIDENT_SLOTS_WIDE = 256;  // 256 CUs x 1 workgroup (NH = 2: 120 KiB of LDS)
+constexpr int WIDE_MT = 7;                // the wide tile is 224 x 256 (MT = 8 needs ~16 registers more than the 512 a lane has: it spills)
 
-// tuning knobs: initialised from the environment (MQ_GEMM_MT / _CGROUP), overridable through mq_tune()
+// tuning knobs: initialised from the environment (MQ_GEMM_MT / _CGROUP / _NH), overridable through mq_tune()
 struct GemmTune {
-    int mt, cgroup;
+    int mt, cgroup, nh;
     static int env(const char* k, int d) { const char* v = getenv(k); return v ? atoi(v) : d; }
-    GemmTune() : mt(env("MQ_GEMM_MT", 0)), cgroup(env("MQ_GEMM_CGROUP", 8)) {}
+    GemmTune() : mt(env("MQ_GEMM_MT", 0)), cgroup(env("MQ_GEMM_CGROUP", 8)), nh(env("MQ_GEMM_NH", 0)) {}
 };
 GemmTune g_tune;
 }  // namespace
 // mirrors of the knobs for gemm_fp8.hip
 int mq_gemm_knob_persist = 1, mq_gemm_knob_cgroup = g_tune.cgroup, mq_gemm_knob_wide = 2;
+// operands are addressed through 32-bit buffer offsets: bytes below 4 GiB per launch and operand; a taller A goes in row chunks.
+// mq_tune("gemm_addr_limit_mb", v) lowers it so that the chunking can be tested at small sizes (0 = back to 4 GiB).
+uint64_t mq_gemm_addr_limit = 0xffffffffull;
 namespace {
 
 // pick the tile height: minimise rounds x (MT + fixed per-tile overhead in 16-row units).  The tile HEIGHT is a free parameter because rows
 // are guarded anyway; this removes most of the tile-quantisation loss at the towers' shapes (M = 12 800, N = 768: 600 128-row tiles = 2
 // rounds on 512 slots, 480 160-row tiles = 1 round).
 int choose_mt(int M, int N) {
+    constexpr int BN = 128;
     const int tiles_n = (N + BN - 1) / BN;
     const int cands[4] = {2, 4, 5, 6};
     int best = 4;
@@ -335,27 +357,28 @@ int choose_mt(int M, int N) {
     return best;
 }
 
-template <int FLAGS, int MT>
+template <int FLAGS, int MT, int NH = 1>
 int launch_gemm_mt(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* residual, void* out, int64_t ldc,
                    int M, int N, int K, hipStream_t s, const GemmLn& ln) {
-    constexpr int BM = 32 * MT;
-    constexpr int LDS = 2 * (BM * BK * 2 + W_TILE_BYTES);
+    constexpr int BM = 32 * MT, BN = 128 * NH;
+    constexpr int LDS = 2 * (BM + BN) * BK * 2;
+    constexpr int SLOTS = NH == 1 ? RESIDENT_SLOTS : RESIDENT_SLOTS_WIDE;
     static std::atomic<uint64_t> attr_done{0};
-    auto kern = gemm_nt_kernel<FLAGS, MT, 2>;
+    auto kern = gemm_nt_kernel<FLAGS, MT, NH, 2>;
     if (hipError_t e = mq_ensure_dyn_lds((const void*)kern, LDS, attr_done); e != hipSuccess) {
         mq_set_error("mq_gemm_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e));
         return MQ_ERR_HIP;
     }
     // 16-byte bf16 epilogue stores need 16-B aligned rows
     const int wide = (!(FLAGS & MQ_EPI_OUT_F32) && ldc % 8 == 0 && ((uintptr_t)out & 15) == 0) ? 1 : 0;
-    const uint64_t lim = 0xffffffffull;   // operands are addressed through 32-bit buffer offsets: rows x leading dimension x 2 B below 4 GiB per launch
+    const uint64_t lim = mq_gemm_addr_limit;   // rows x leading dimension x 2 B per launch
     const uint64_t w_bytes = ((uint64_t)(N - 1) * (uint64_t)ldw + (uint64_t)K) * 2;
     if (w_bytes > lim) {
-        mq_set_error("mq_gemm_bf16: weight matrix of %llu bytes exceeds the 4 GiB a launch can address", (unsigned long long)w_bytes);
+        mq_set_error("mq_gemm_bf16: weight matrix of %llu bytes exceeds the %llu bytes a launch can address", (unsigned long long)w_bytes, (unsigned long long)lim);
         return MQ_ERR_INVALID;
     }
     // ... and a taller A goes in row chunks (rows are independent; whole tiles per chunk)
-    int64_t max_rows = (int64_t)((lim - (uint64_t)K * 2) / ((uint64_t)lda * 2)) + 1;
+    int64_t max_rows = (uint64_t)K * 2 > lim ? 0 : (int64_t)((lim - (uint64_t)K * 2) / ((uint64_t)lda * 2)) + 1;
     max_rows = max_rows / BM * BM;
     if (max_rows < BM) {
         mq_set_error("mq_gemm_bf16: lda=%ld too large", (long)lda);
@@ -369,7 +392,7 @@ int launch_gemm_mt(const void* A, int64_t lda, const void* W, int64_t ldw, const
         // L2 blocking only when there is something to block: more column tiles than one group and at least two row panels per XCD
         const int cgroup = (g_tune.cgroup > 0 && tiles_n > g_tune.cgroup && tiles_m >= 16) ? g_tune.cgroup : 0;
         const int band_rows = (tiles_m + 7) / 8;
-        const int grid = num_tiles > RESIDENT_SLOTS ? RESIDENT_SLOTS : num_tiles;
+        const int grid = num_tiles > SLOTS ? SLOTS : num_tiles;
         const uint64_t a_bytes = ((uint64_t)(m - 1) * (uint64_t)lda + (uint64_t)K) * 2;
         const size_t out_row = (size_t)ldc * ((FLAGS & MQ_EPI_OUT_F32) ? 4 : 2);
         const size_t res_row = (size_t)ldc * (((FLAGS & MQ_EPI_RESIDUAL) && !(FLAGS & MQ_EPI_OUT_F32)) ? 2 : 4);
@@ -384,9 +407,18 @@ int launch_gemm_mt(const void* A, int64_t lda, const void* W, int64_t ldw, const
     return MQ_OK;
 }
 
+// the wide (224 x 256, one workgroup per CU) tile pays where a k-loop is long enough to amortise a tile's un-overlapped prologue and epilogue and
+// where the tiles fill whole rounds of the 256 workgroups; mq_tune("gemm_nh", 2) forces it, 1 forbids it, 0 = this rule
+bool choose_wide(int M, int N, int K) {
+    if (g_tune.nh == 1 || N < 256) return false;
+    if (g_tune.nh == 2) return true;
+    return false;
+}
+
 template <int FLAGS>
 int launch_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* residual, void* out, int64_t ldc,
                 int M, int N, int K, hipStream_t s, const GemmLn& ln = GemmLn{}) {
+    if (choose_wide(M, N, K)) return launch_gemm_mt<FLAGS, WIDE_MT, 2>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s, ln);
     const int mt = g_tune.mt ? g_tune.mt : choose_mt(M, N);
     switch (mt) {
         case 2: return launch_gemm_mt<FLAGS, 2>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s, ln);
@@ -478,14 +510,16 @@ extern "C" int mq_gemm_bf16_rs(const void* d_A, int64_t lda, const void* d_W, in
     return launch_gemm<MQ_EPI_BIAS | MQ_EPI_RESIDUAL | MQ_EPI_ROW_STATS>(d_A, lda, d_W, ldw, d_bias, (const float*)d_residual, d_out, ldc, (int)M, (int)N, (int)K, s, ln);
 }
 
-// Run-time knobs (A/B benchmarking and the parity tests of every code path in one process).
+// Run-time knobs (A/B benchmarking and the parity tests of every code path in one process).  TEST / BENCH ONLY: plain ints read by the
+// launch code of every request thread without synchronisation — set them while no request is in flight (the loaders never touch them).
 // keys: "gemm_mt" (0 = auto, else tile height in 32-row units), "gemm_cgroup", "row_select", "ln_fold", "residual_bf16", "small_m", "small_m_grouped",
-// "ln_prefetch", "xcd_band", "attn_waves".
+// "ln_prefetch", "xcd_band", "attn_waves", "gemm_addr_limit_mb", "gemm_nh" (0 = auto, 1 = (32*MT) x 128 tiles only, 2 = the wide 224 x 256 tile wherever N >= 256).
 extern "C" int mq_tune(const char* key, int value) {
     MQ_CHECK_ARG(key, "mq_tune: null key");
     const std::string k(key);
     if (k == "gemm_mt") { g_tune.mt = value; mq_gemm_fp8_force_mt = value; }
     else if (k == "gemm_cgroup") mq_gemm_knob_cgroup = g_tune.cgroup = value;
+    else if (k == "gemm_nh") g_tune.nh = value;
     else if (k == "row_select") mq_tower_row_select = value;
     else if (k == "ln_fold") mq_tower_ln_fold = value;
     else if (k == "xcd_band") mq_xcd_band = value;
@@ -494,6 +528,7 @@ extern "C" int mq_tune(const char* key, int value) {
     else if (k == "small_m") mq_gemm_small_max_rows = value;
     else if (k == "small_m_grouped") mq_gemm_small_group_rows = value;
     else if (k == "ln_prefetch") mq_ln_prefetch = value;
+    else if (k == "gemm_addr_limit_mb") mq_gemm_addr_limit = value > 0 ? ((uint64_t)value << 20) - 1 : 0xffffffffull;
     else { mq_set_error("mq_tune: unknown key %s", key); return MQ_ERR_INVALID; }
     return MQ_OK;
 }

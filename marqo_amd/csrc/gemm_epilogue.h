@@ -33,7 +33,10 @@ struct GemmLn {
 // the next tile in flight here, so hipcc cannot count past them: without the explicit wait it re-waits vmcnt(0) at the first use of the
 // bias in every row group — draining the row groups' own stores one after the other — and, seeing the fragment registers as possibly
 // pending load destinations, puts another vmcnt(0) into the k-loop.
-template <int FLAGS, int MT, int RG = MT, bool WAIT_LOADS = false>
+// FENCE_ROWS (the wide tile, whose 256 accumulators live in AGPRs): a scheduling fence behind every 16-row group, so that the copies out of the
+// accumulator file are made group by group — left alone, the scheduler hoists all of a half's 128 v_accvgpr_read in front of the first store
+// and the kernel spills.
+template <int FLAGS, int MT, int RG = MT, bool WAIT_LOADS = false, bool FENCE_ROWS = false>
 __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][4], const float* __restrict__ bias, const float* residual, void* out,
                                               int64_t ldc, int M, int N, int wave_m0, int wave_n0, int l15, int g, bool wide = false,
                                               const GemmLn* lnp = nullptr, const float* lds_bias = nullptr) {
@@ -178,5 +181,6 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][4], const float* 
             st1 += __shfl_xor(st1, 32, 64); st2 += __shfl_xor(st2, 32, 64);
             if (g == 0 && m_ok && wave_n0 < N) lnp->partials[(int64_t)m * lnp->nslots + (wave_n0 >> 6)] = make_float2(st1, st2);
         }
+        if (FENCE_ROWS) __builtin_amdgcn_sched_barrier(0);
     }
 }

@@ -30,6 +30,7 @@ typedef int i32x8 __attribute__((ext_vector_type(8)));
 
 // scheduling knobs shared with gemm_bf16.hip (mq_tune "gemm_cgroup"; the widened epilogue stores are always on)
 extern int mq_gemm_knob_cgroup, mq_gemm_knob_wide;
+extern uint64_t mq_gemm_addr_limit;   // gemm_bf16.hip: bytes one launch may address per operand (4 GiB - 1; tests lower it)
 
 namespace {
 
@@ -470,24 +471,40 @@ int launch_fp8_mt(const Fp8Args& a, hipStream_t s) {
         mq_set_error("mq_gemm_fp8: hipFuncSetAttribute: %s", hipGetErrorString(e));
         return MQ_ERR_HIP;
     }
-    // the LDS-DMA addresses both operands through 32-bit buffer offsets
-    const uint64_t a_bytes = (uint64_t)(a.M - 1) * (uint64_t)a.lda + (uint64_t)a.K, w_bytes = (uint64_t)(a.N - 1) * (uint64_t)a.ldw + (uint64_t)a.K;
-    if (a_bytes > 0xffffffffull || w_bytes > 0xffffffffull) {
-        mq_set_error("mq_gemm_fp8: an operand of %llu bytes exceeds the 4 GiB a launch can address", (unsigned long long)(a_bytes > w_bytes ? a_bytes : w_bytes));
+    // the LDS-DMA addresses both operands through 32-bit buffer offsets: the weight must fit, a taller A goes in row chunks (rows are
+    // independent; whole tiles per chunk), exactly as launch_gemm_mt does in gemm_bf16.hip
+    const uint64_t lim = mq_gemm_addr_limit;
+    const uint64_t w_bytes = (uint64_t)(a.N - 1) * (uint64_t)a.ldw + (uint64_t)a.K;
+    if (w_bytes > lim) {
+        mq_set_error("mq_gemm_fp8: weight matrix of %llu bytes exceeds the %llu bytes a launch can address", (unsigned long long)w_bytes, (unsigned long long)lim);
         return MQ_ERR_INVALID;
     }
-    const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
-    const int num_tiles = tiles_m * tiles_n;
-    const int cgroup = (mq_gemm_knob_cgroup > 0 && tiles_n > mq_gemm_knob_cgroup && tiles_m >= 16) ? mq_gemm_knob_cgroup : 0;
-    const int band_rows = (tiles_m + 7) / 8;
+    int64_t max_rows = (uint64_t)a.K > lim ? 0 : (int64_t)((lim - (uint64_t)a.K) / (uint64_t)a.lda) + 1;
+    max_rows = max_rows / BM * BM;
+    if (max_rows < BM) {
+        mq_set_error("mq_gemm_fp8: lda=%ld too large", (long)a.lda);
+        return MQ_ERR_INVALID;
+    }
+    const int tiles_n = (a.N + BN - 1) / BN;
     // 16-byte epilogue stores need 16-B aligned rows (bf16: ldc % 8; e4m3: ldc % 16)
     const int row_align = (FLAGS & MQ_EPI_OUT_FP8) ? 16 : 8;
     const int wide = (mq_gemm_knob_wide && !(FLAGS & MQ_EPI_OUT_F32) && a.ldc % row_align == 0 && ((uintptr_t)a.out & 15) == 0) ? 1 : 0;
-    const int grid = num_tiles > RESIDENT_SLOTS ? RESIDENT_SLOTS : num_tiles;
-    hipLaunchKernelGGL((gemm_fp8_kernel<FLAGS, MT, ROWSCALE>), dim3(grid), dim3(256), LDS, s, (const uint8_t*)a.A, a.lda,
-                       (const uint8_t*)a.W, a.ldw, a.a_scale, a.w_scale, a.bias, a.residual, a.out, a.ldc, a.out_scale, a.amax, a.M, a.N,
-                       a.K, tiles_n, num_tiles, cgroup, band_rows, wide, (unsigned)a_bytes, (unsigned)w_bytes);
-    MQ_CHECK_LAUNCH("mq_gemm_fp8");
+    const size_t out_row = (size_t)a.ldc * ((FLAGS & MQ_EPI_OUT_F32) ? 4 : (FLAGS & MQ_EPI_OUT_FP8) ? 1 : 2);
+    const size_t res_row = (size_t)a.ldc * (((FLAGS & MQ_EPI_RESIDUAL) && !(FLAGS & MQ_EPI_OUT_F32)) ? 2 : 4);
+    for (int64_t r0 = 0; r0 < a.M; r0 += max_rows) {
+        const int m = (int)((a.M - r0) < max_rows ? (a.M - r0) : max_rows);
+        const int tiles_m = (m + BM - 1) / BM;
+        const int num_tiles = tiles_m * tiles_n;
+        const int cgroup = (mq_gemm_knob_cgroup > 0 && tiles_n > mq_gemm_knob_cgroup && tiles_m >= 16) ? mq_gemm_knob_cgroup : 0;
+        const int band_rows = (tiles_m + 7) / 8;
+        const int grid = num_tiles > RESIDENT_SLOTS ? RESIDENT_SLOTS : num_tiles;
+        const uint64_t a_bytes = (uint64_t)(m - 1) * (uint64_t)a.lda + (uint64_t)a.K;
+        hipLaunchKernelGGL((gemm_fp8_kernel<FLAGS, MT, ROWSCALE>), dim3(grid), dim3(256), LDS, s, (const uint8_t*)a.A + r0 * a.lda, a.lda,
+                           (const uint8_t*)a.W, a.ldw, ROWSCALE ? a.a_scale + r0 : a.a_scale, a.w_scale, a.bias,
+                           a.residual ? (const float*)((const char*)a.residual + (size_t)r0 * res_row) : nullptr, (void*)((char*)a.out + (size_t)r0 * out_row),
+                           a.ldc, a.out_scale, a.amax, m, a.N, a.K, tiles_n, num_tiles, cgroup, band_rows, wide, (unsigned)a_bytes, (unsigned)w_bytes);
+        MQ_CHECK_LAUNCH("mq_gemm_fp8");
+    }
     return MQ_OK;
 }
 

@@ -167,25 +167,32 @@ PyObject* gather_rgbx(PyObject*, PyObject* args) {
         int t = threads < 1 ? 1 : (threads > 16 ? 16 : threads);
         if (total < (4 << 20)) t = 1;                     // small packs: waking the workers costs more than the copy
         Py_BEGIN_ALLOW_THREADS
-        // ranges of about equal bytes, whole images each
-        std::vector<std::pair<size_t, size_t>> ranges;
-        {
-            const int64_t share = (total + t - 1) / t;
-            size_t lo = 0;
-            int64_t acc = 0;
-            for (size_t k = 0; k < items.size(); ++k) {
-                acc += items[k].bytes;
-                if (acc >= share || k + 1 == items.size()) {
-                    ranges.emplace_back(lo, k + 1);
-                    lo = k + 1;
-                    acc = 0;
+        // No C++ exception may unwind through this CPython frame (the GIL is released: it would end in std::terminate): whatever the range setup
+        // or the pool throws (bad_alloc, a system_error from a mutex) falls back to a serial copy of everything — memcpy is idempotent, ranges a
+        // worker already copied are simply copied again.
+        try {
+            // ranges of about equal bytes, whole images each
+            std::vector<std::pair<size_t, size_t>> ranges;
+            {
+                const int64_t share = (total + t - 1) / t;
+                size_t lo = 0;
+                int64_t acc = 0;
+                for (size_t k = 0; k < items.size(); ++k) {
+                    acc += items[k].bytes;
+                    if (acc >= share || k + 1 == items.size()) {
+                        ranges.emplace_back(lo, k + 1);
+                        lo = k + 1;
+                        acc = 0;
+                    }
                 }
             }
+            const std::function<void(int)> job = [&](int r) {
+                for (size_t k = ranges[r].first; k < ranges[r].second; ++k) memcpy(dst + items[k].dst_off, items[k].src, (size_t)items[k].bytes);
+            };
+            mq_copy_pool().run((int)ranges.size(), job);
+        } catch (...) {
+            for (size_t k = 0; k < items.size(); ++k) memcpy(dst + items[k].dst_off, items[k].src, (size_t)items[k].bytes);
         }
-        const std::function<void(int)> job = [&](int r) {
-            for (size_t k = ranges[r].first; k < ranges[r].second; ++k) memcpy(dst + items[k].dst_off, items[k].src, (size_t)items[k].bytes);
-        };
-        mq_copy_pool().run((int)ranges.size(), job);
         Py_END_ALLOW_THREADS
     }
     for (PyObject* c : keep) Py_DECREF(c);

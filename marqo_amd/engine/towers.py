@@ -71,6 +71,14 @@ class _Holder:
     def nbytes(self) -> int:
         return sum(t.numel() * t.element_size() for t in self.tensors)
 
+    def drop(self, ptr: int) -> int:
+        """forget the tensor that starts at `ptr` (its HBM goes back to the allocator once nothing else holds it) -> bytes released"""
+        for i, t in enumerate(self.tensors):
+            if t.data_ptr() == ptr:
+                del self.tensors[i]
+                return t.numel() * t.element_size()
+        return 0
+
 
 def _need(sd: Dict[str, Tensor], key: str, shape: Optional[Tuple[int, ...]] = None) -> Tensor:
     if key not in sd:
@@ -544,6 +552,36 @@ class _TowerBase:
                                          "the calibration batch %.2e (all blocks: %.2e, budget %.1e)", first, layers, first - extra, first,
                                          self.residual_stream, e, e0, budget)
         return first
+
+    def release_unused_folded(self) -> int:
+        """the gamma-folded QKV / fc1 copies (+ bias, column sums: 7/12 of a block's weight bytes again, ~2 GB on ViT-bigG) are read only by
+        blocks that can take the folded path: bf16 residual stream, block in front of the fp8 split (fc1: also in front of the MLP-only fp8 blocks).
+        Called by the loaders once the load-time policies are fixed: every other block's folded tensors are freed and its pointers nulled (towers.hip's
+        fold_ok then takes the LayerNorm path, as with MARQO_AMD_LN_FOLD=0).  A later re-tune keeps working, without the fold on those blocks.
+        -> bytes released"""
+        blocks = getattr(self, "_blocks", None)
+        if blocks is None or not hasattr(blocks[0], "qkv_wf"):
+            return 0
+        enc = self.cfg.enc
+        layers = len(blocks)
+        bf16_stream = enc.residual_stream == 1
+        fp8 = self.precision == "fp8"
+        first = enc.fp8_first_layer if fp8 else layers
+        first_mlp = first - (enc.fp8_mlp_extra if fp8 else 0)
+        freed = 0
+        for i in range(layers):
+            b = blocks[i]
+            for name, alive in (("qkv", bf16_stream and i < first), ("fc1", bf16_stream and i < first_mlp)):
+                if alive:
+                    continue
+                for suffix in ("_wf", "_bf", "_sf"):
+                    ptr = getattr(b, name + suffix)
+                    if ptr:
+                        freed += self._h.drop(ptr)
+                        setattr(b, name + suffix, None)
+        if freed:
+            getattr(self, "_graphs", {}).clear()     # captured launch sequences may have baked the folded form in
+        return freed
 
     # towers whose output is ONE row per item (class token / EOT): the last block's out-proj and MLP run on those rows only (towers.hip,
     # last_block_selected — in bf16, whatever the policy says), so of that block only the QKV GEMM (3 of its 12 W^2) can be e4m3 work at all

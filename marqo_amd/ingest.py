@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import os
 import threading
+import time
 from typing import Any, Callable, Dict, Hashable, List, Optional, Tuple
 
 import numpy as np
@@ -27,6 +28,9 @@ from marqo_amd.s2_inference.enums import Modality
 # a flush with BOTH modalities on a GPU prepares them on two host threads (A/B knob): the text side (tokeniser, launch sequence) runs on a helper
 # thread while the caller's thread exports / packs the images — the native stager and the launches release the GIL
 PARALLEL_MODALITIES = os.environ.get("MARQO_AMD_INGEST_THREADS", "1") != "0"
+
+
+_now = time.perf_counter
 
 
 def estimate_tokens(text: Any) -> float:
@@ -96,6 +100,18 @@ class BulkVectoriser:
             n = sum(len(v) for v in self._pending.values())
         if self.max_pending and n >= self.max_pending:
             self._run_pending()  # results stay in the store until the caller's flush()
+
+    def add_many(self, pairs: List[Tuple[Hashable, Any]], modality: Modality = Modality.TEXT) -> None:
+        """`add()` for a list of (key, content) of one modality under one lock acquisition (no automatic max_pending flush in between)"""
+        if modality not in self._pending:
+            raise ValueError(f"unsupported modality {modality}")
+        if not pairs:
+            return
+        with self._lock:
+            self._pending[modality].extend(pairs)
+            n = sum(len(v) for v in self._pending.values())
+        if self.max_pending and n >= self.max_pending:
+            self._run_pending()
 
     def pending(self) -> int:
         with self._lock:
@@ -323,14 +339,43 @@ class PendingFlush:
         return self._rows
 
 
+# Cross-request micro-batching of the ingest stream (north_star: "documents are dynamically micro-batched").  A 128-document request is
+# 6 400 image rows + ~4 300 packed text rows: every GEMM of its towers fills about half of the chip's 512 resident tile slots, so the stream ran
+# at ~47 % of what the same kernels deliver at full batches (profiles/r04ad_stream_procs.txt).  Requests are therefore MERGED until one side is
+# chip-filling: >= MERGE_IMAGES images or >= MERGE_TEXT_TOKENS estimated text tokens (or MERGE_MAX_REQUESTS requests), or until the oldest waiting
+# request is MERGE_DEADLINE_MS old — then ONE tower call per modality runs for the whole group (text and images on two host threads = two HIP
+# streams) and the rows are scattered back per request.  MARQO_AMD_INGEST_MERGE_IMAGES=0 switches merging off (one group per request).
+MERGE_IMAGES = int(os.environ.get("MARQO_AMD_INGEST_MERGE_IMAGES", "512"))
+MERGE_TEXT_TOKENS = int(os.environ.get("MARQO_AMD_INGEST_MERGE_TEXT_TOKENS", "24576"))
+MERGE_MAX_REQUESTS = int(os.environ.get("MARQO_AMD_INGEST_MERGE_MAX_REQUESTS", "64"))
+MERGE_DEADLINE_MS = float(os.environ.get("MARQO_AMD_INGEST_MERGE_DEADLINE_MS", "2"))
+
+
+def _deadline_loop(ref) -> None:
+    """body of an ingest object's deadline thread; holds the object only while it works, so an abandoned ingest can be collected"""
+    while True:
+        ing = ref()
+        if ing is None or ing._closed:
+            return
+        ing._deadline_tick()
+        del ing
+
+
 class RequestShardedIngest:
     """BASELINE configs[3] ("add_documents bulk ingest: mixed text + image docs sharded across the GPUs, RCCL gather"), sharded AT THE
     SOURCE: ranks own disjoint REQUESTS.  Request i (a batch of <= 128 documents, what one add_documents call carries,
     add_documents_handler.py:344-373) belongs to rank i % world; only its owner ever touches its documents (decodes its images, tokenises
-    its texts, stages its bytes), runs them through a local BulkVectoriser — the single-GPU path with its text / image pipelining, no
-    collective inside a request — and keeps the [n, D] rows.  `collect()` is the one data-path collective: a `gather` of the ranks' rows
+    its texts, stages its bytes) and keeps the [n, D] rows.  On its rank, consecutive owned requests are merged into chip-filling GROUPS (see
+    MERGE_* above: the reference's PER_BATCH idea, add_docs.py:325-381, taken across requests); a group runs through a local BulkVectoriser
+    — one tower call per modality, the two on two host threads / HIP streams, no collective — with ONE group in flight: group g + 1 is
+    tokenised / packed / enqueued while group g's kernels run.  `collect()` is the one data-path collective: a `gather` of the ranks' rows
     onto the root (the process that feeds the document store), NOT an all_gather: nothing is replicated, non-root ranks copy nothing to
     their host.  The reference has no counterpart (one device string per call, tensor_search/utils.py:90-123).
+
+    Failure isolation: a request is all-or-nothing and never takes another one down.  When a merged group fails — on the host (an
+    undecodable image) or at the deferred copy (an asynchronous device fault) — its requests are re-run ONE BY ONE, synchronously: the ones
+    that encode are filed, the ones that raise are recorded (`failed`, `errors[i]`, collect()'s `failed_requests`).  submit(i) raises only
+    what request i itself raised, and only when request i's group was launched by that very call.
 
     usage, same code on every rank:
         ing = RequestShardedIngest(model, device)
@@ -340,7 +385,8 @@ class RequestShardedIngest:
     """
 
     def __init__(self, model_name: str, device: str, model_properties: Optional[dict] = None, normalize_embeddings: bool = True,
-                 vectorise_fn: Optional[Callable] = None, root: int = 0):
+                 vectorise_fn: Optional[Callable] = None, root: int = 0, merge_images: Optional[int] = None,
+                 merge_text_tokens: Optional[int] = None, merge_deadline_ms: Optional[float] = None):
         import torch.distributed as dist
         self._dist = dist if dist.is_available() and dist.is_initialized() else None
         self.world = self._dist.get_world_size() if self._dist else 1
@@ -354,79 +400,208 @@ class RequestShardedIngest:
         self.failed: List[int] = []                           # owned requests whose encode raised since the last collect()
         self.failed_requests: List[int] = []                  # after collect(): every rank's failed requests (root), own ones elsewhere
         self.errors: Dict[int, BaseException] = {}            # request index -> what its encode raised (since the last collect())
-        # ONE request in flight: submit(i) tokenises / packs / enqueues request i and only THEN copies request i - 1's rows to the host, so the
-        # host side of a request (Python bookkeeping, tokeniser, Pillow -> pinned staging: 40 % of a ViT-B/32 request's wall time, all of it GPU
-        # idle time when requests run strictly one after the other) overlaps the previous request's kernels.  pipeline_depth = 0: synchronous.
+        # merging (0 images = off: every request is its own group)
+        self.merge_images = MERGE_IMAGES if merge_images is None else int(merge_images)
+        self.merge_text_tokens = MERGE_TEXT_TOKENS if merge_text_tokens is None else int(merge_text_tokens)
+        self.merge_max_requests = MERGE_MAX_REQUESTS
+        self.merge_deadline_ms = MERGE_DEADLINE_MS if merge_deadline_ms is None else float(merge_deadline_ms)
+        self.groups_launched: List[List[int]] = []            # request indices of every group launched since the last collect() (tests, bench)
+        self._open: List[Tuple[int, list]] = []               # the group being filled: (request index, items)
+        self._open_images = 0
+        self._open_tokens = 0.0
+        self._open_since = 0.0
+        # ONE group in flight: launching group g tokenises / packs / enqueues it and only THEN copies group g - 1's rows to the host, so the
+        # host side of a group (Python bookkeeping, tokeniser, Pillow -> pinned staging) overlaps the previous group's kernels.
+        # pipeline_depth = 0: synchronous.
         self.pipeline_depth = 1
-        self._inflight: Optional[Tuple[int, List[Hashable], PendingFlush]] = None
+        self._inflight: Optional[Tuple[List[Tuple[int, list]], PendingFlush]] = None
+        # submit() / drain() / collect() and the deadline thread all mutate the state above: one re-entrant lock, held across a launch
+        self._lock = threading.RLock()
+        self._cv = threading.Condition(self._lock)
+        self._closed = False
+        self._deadline_thread: Optional[threading.Thread] = None
 
+    # ---- ownership ------------------------------------------------------------------------------------------------------------------------
     def owner(self, request_index: int) -> int:
         return request_index % self.world
 
     def owns(self, request_index: int) -> bool:
         return self.owner(request_index) == self.rank
 
+    # ---- bookkeeping ----------------------------------------------------------------------------------------------------------------------
+    def _fail(self, request_index: int, error: BaseException) -> None:
+        self.failed.append(request_index)
+        self.errors[request_index] = error
+
+    def _file(self, group, out) -> None:
+        for request_index, items in group:
+            for key, _, _ in items:
+                self._rows.append(out[(request_index, key)])
+                self._index.append((request_index, key))
+
+    def _queue(self, group) -> None:
+        """the group's items into the BulkVectoriser's queues; keys are made unique across requests by the request index"""
+        for request_index, items in group:
+            for modality in (Modality.TEXT, Modality.IMAGE):
+                self._bulk.add_many([((request_index, key), content) for key, content, m in items if m == modality], modality)
+
+    def _run_alone(self, group, raise_for: Optional[int] = None) -> Optional[BaseException]:
+        """a merged group failed: its requests one at a time, synchronously — the ones that encode are filed (in submission order), the ones
+        that raise are recorded.  -> the first error (raised instead when it belongs to request `raise_for`)"""
+        first, mine = None, None
+        for request_index, items in group:
+            try:
+                self._queue([(request_index, items)])
+                out = self._bulk.flush()
+            except BaseException as e:  # noqa: BLE001 - recorded per request; the caller's own one is re-raised below
+                self._bulk.reset()
+                self._fail(request_index, e)
+                first = first or e
+                if request_index == raise_for:
+                    mine = e
+                continue
+            self._file([(request_index, items)], out)
+        if mine is not None:
+            raise mine
+        return first
+
     def _resolve(self, inflight, reraise: bool) -> None:
-        request_index, keys, handle = inflight
+        """wait for a launched group's rows and file them; a failure that surfaces here (an asynchronous device error at the deferred copy)
+        fails a lone request, and sends a merged group through `_run_alone`"""
+        group, handle = inflight
         try:
             out = handle.result()
-        except BaseException as e:  # noqa: BLE001 - an asynchronous device error of THAT request, surfacing at its copy
+        except BaseException as e:  # noqa: BLE001
             self._bulk.reset()
-            self.failed.append(request_index)
-            self.errors[request_index] = e
-            if reraise:
-                raise
+            if len(group) == 1:
+                self._fail(group[0][0], e)
+                if reraise:
+                    raise
+                return
+            first = self._run_alone(group)
+            if reraise and first is not None:
+                raise first
             return
-        for key in keys:
-            self._rows.append(out[key])
-            self._index.append((request_index, key))
+        self._file(group, out)
 
-    def drain(self) -> None:
-        """wait for the request in flight (if any) and file its rows; raises what its encode raised"""
+    def _settle(self, reraise: bool) -> None:
         inflight, self._inflight = self._inflight, None
         if inflight is not None:
-            self._resolve(inflight, reraise=True)
+            self._resolve(inflight, reraise)
 
-    def submit(self, request_index: int, items) -> None:
-        """encode one owned request (its rows stay on this rank until collect()).  Everything that can fail on the HOST for this request —
-        decoding, tokenising, staging, the enqueue itself — fails here, now.  Its device work is left in flight until the next submit() /
-        drain() / collect(): an asynchronous device error of request i is therefore recorded (`failed`, `errors[i]`, collect()'s
-        `failed_requests`) when request i + 1 is submitted, without failing THAT call; call drain() after submit() for the synchronous form."""
-        if not self.owns(request_index):
-            raise ValueError(f"rank {self.rank} was handed request {request_index}, which belongs to rank {self.owner(request_index)}")
-        self.touched.append(request_index)
-        keys = []
-        for key, content, modality in items:
-            self._bulk.add(key, content, modality)
-            keys.append(key)
+    def _launch_open(self, raise_for: Optional[int] = None) -> None:
+        """(lock held) everything waiting becomes ONE group: queued, tokenised / packed / enqueued now; the previous group's rows are filed
+        behind it.  A host-side failure is isolated per request (`_run_alone`)."""
+        group, self._open = self._open, []
+        self._open_images, self._open_tokens = 0, 0.0
+        if not group:
+            return
+        self.groups_launched.append([r for r, _ in group])
         try:
+            self._queue(group)
             handle = self._bulk.flush_async()
         except BaseException as e:
             # One bad document (an undecodable image) must not poison this rank's stream: BulkVectoriser re-queues the failed modality and
-            # keeps the other one's rows for a retry, but a request is all-or-nothing here — drop both, so that the NEXT request starts from
-            # an empty queue, and remember the index: the caller may catch the exception and go on, collect() still runs on every rank
-            # (nobody is left waiting in the collective) and reports the request as failed.  (The request in flight is not touched: its
-            # rows are in its handle, not in the queue that is reset here.)
+            # keeps the other one's rows for a retry, but a request is all-or-nothing here — drop both, so that the NEXT group starts from
+            # an empty queue.  (The group in flight is not touched: its rows are in its handle, not in the queue that is reset here.)
             self._bulk.reset()
-            self.failed.append(request_index)
-            self.errors[request_index] = e
-            raise
-        previous, self._inflight = self._inflight, (request_index, keys, handle)
+            if len(group) == 1:
+                self._fail(group[0][0], e)
+                if raise_for == group[0][0]:
+                    raise
+                return
+            self._settle(reraise=False)            # rows are filed in submission order: the group in flight first
+            self._run_alone(group, raise_for)
+            return
+        previous, self._inflight = self._inflight, (group, handle)
         if previous is not None:
             self._resolve(previous, reraise=False)
         if self.pipeline_depth <= 0:
-            self.drain()
+            self._settle(reraise=raise_for is not None and len(group) == 1)
+
+    def _open_is_full(self) -> bool:
+        return (self.merge_images <= 0 or self._open_images >= self.merge_images or self._open_tokens >= self.merge_text_tokens
+                or len(self._open) >= self.merge_max_requests)
+
+    # ---- the deadline: a waiting request is never held longer than merge_deadline_ms by a slow producer ----------------------------------------
+    def _deadline_tick(self) -> None:
+        with self._cv:
+            if not self._open:
+                self._cv.wait(0.05)
+                return
+            left = self._open_since + self.merge_deadline_ms * 1e-3 - _now()
+            if left > 0:
+                self._cv.wait(left)
+                return
+            try:
+                self._launch_open()
+            except BaseException:  # noqa: BLE001 - recorded per request by _launch_open; nobody to raise to on this thread
+                pass
+
+    def _ensure_deadline_thread(self) -> None:
+        if self._deadline_thread is None and self.merge_images > 0 and self.merge_deadline_ms > 0:
+            import weakref
+            self._deadline_thread = threading.Thread(target=_deadline_loop, args=(weakref.ref(self),), name="marqo-amd-ingest-deadline", daemon=True)
+            self._deadline_thread.start()
+
+    def close(self) -> None:
+        """stop the deadline thread (an object that is simply dropped stops it too, within 50 ms of being collected)"""
+        with self._cv:
+            self._closed = True
+            self._cv.notify_all()
+
+    # ---- the stream -----------------------------------------------------------------------------------------------------------------------
+    def drain(self) -> None:
+        """launch what is waiting and wait for everything launched; raises what the LAST group's encode raised (a merged group: its first
+        failing request's error) — every failure is recorded in `failed` / `errors` either way"""
+        with self._lock:
+            pending_error = None
+            try:
+                self._launch_open()
+            except BaseException as e:  # noqa: BLE001
+                pending_error = e
+            self._settle(reraise=True)
+            if pending_error is not None:
+                raise pending_error
+
+    def submit(self, request_index: int, items) -> None:
+        """hand over one owned request (its rows stay on this rank until collect()).  The request joins the group being filled; when that
+        makes the group chip-filling (or merging is off) the group is launched NOW: everything that can fail on the HOST — decoding,
+        tokenising, staging, the enqueue itself — fails here; a failure of request i itself is raised, other requests' failures are only
+        recorded.  Device work stays in flight until the next launch / drain() / collect(): an asynchronous device error is recorded
+        (`failed`, `errors[i]`, collect()'s `failed_requests`) then, without failing that call; drain() after submit() is the synchronous form."""
+        if not self.owns(request_index):
+            raise ValueError(f"rank {self.rank} was handed request {request_index}, which belongs to rank {self.owner(request_index)}")
+        items = list(items)
+        n_images = sum(1 for _, _, m in items if m == Modality.IMAGE)
+        n_tokens = sum(estimate_tokens(c) for _, c, m in items if m == Modality.TEXT)
+        with self._cv:
+            self.touched.append(request_index)
+            if not self._open:
+                self._open_since = _now()
+            self._open.append((request_index, items))
+            self._open_images += n_images
+            self._open_tokens += n_tokens
+            if self._open_is_full():
+                self._launch_open(raise_for=request_index)
+            else:
+                self._ensure_deadline_thread()
+                self._cv.notify_all()
 
     def collect(self) -> Dict[int, Dict[Hashable, np.ndarray]]:
         """gather every rank's rows on the root -> {request index: {key: row}} there, {} elsewhere; resets the store"""
         import torch
-        inflight, self._inflight = self._inflight, None
-        if inflight is not None:
-            self._resolve(inflight, reraise=False)     # (a failure is reported through failed_requests; every rank must reach the collective)
-        rows, index = self._rows, self._index
-        self._rows, self._index = [], []
-        failed, self.failed = self.failed, []
-        self.errors = {i: e for i, e in self.errors.items() if i in failed}   # kept until the NEXT collect() for the caller to inspect
+        with self._lock:
+            try:
+                self._launch_open()
+            except BaseException:  # noqa: BLE001 - reported through failed_requests; every rank must reach the collective
+                pass
+            self._settle(reraise=False)
+            rows, index = self._rows, self._index
+            self._rows, self._index = [], []
+            failed, self.failed = self.failed, []
+            self.groups_launched = []
+            self.errors = {i: e for i, e in self.errors.items() if i in failed}   # kept until the NEXT collect() for the caller to inspect
         self.failed_requests = sorted(failed)
         local = np.stack(rows).astype(np.float32, copy=False) if rows else None
         if self.world == 1:

@@ -53,6 +53,19 @@ def window_for(n_items: int) -> float:
     return DEFAULT_WINDOW_US * 1e-6 if n_items <= small else 0.0
 
 
+def explicit() -> bool:
+    """MARQO_AMD_COALESCE_US set by the operator (to anything): the default's exclusions below no longer apply"""
+    return bool(os.environ.get("MARQO_AMD_COALESCE_US", ""))
+
+
+def fetches_content(batch, is_text: bool) -> bool:
+    """non-text items given as strings are URLs / paths (Marqo's search path hands image-URL queries straight to vectorise): the engine call
+    DOWNLOADS them.  A merged call would do every participant's downloads one after the other on the leader's thread while the followers
+    block — before, every request thread downloaded in parallel — and one slow or failing URL would make the whole group re-run alone and
+    download twice.  Such calls stay out of the default coalescing (they still merge when MARQO_AMD_COALESCE_US is set explicitly)."""
+    return (not is_text) and any(isinstance(item, (str, bytes)) for item in batch)
+
+
 def max_items() -> int:
     """MARQO_AMD_COALESCE_MAX_ITEMS: a merged call carries at most this many items (larger requests are chip-filling on their own)"""
     try:

@@ -143,6 +143,7 @@ class HuggingFaceModel(AbstractEmbeddingModel):
         self._pooling_func = pooling
         if props.engine_precision == "fp8":   # deterministic load-time calibration on fixed seeded inputs (see open_clip_model.py)
             self._model.tune_fp8_default(props.fp8_budget)
+        self._model.release_unused_folded()
         # K14: WordPiece on the device for ASCII texts (identical ids; the host tokeniser stays the definition of record and
         # handles every other text).  MARQO_AMD_HOST_TOKENIZER=1 keeps everything on the host.
         self._device_tokenizer = None

@@ -85,7 +85,7 @@ class OpenCLIPModelProperties:
         # engine extension (BASELINE config 5): operand type of the encoder-block GEMMs.  "bf16" (default) or "fp8" (OCP e4m3,
         # MX-MFMA at twice the bf16 rate).  fp8 is calibrated deterministically at load on fixed seeded inputs: static activation
         # scales and the number of trailing blocks that run on fp8 while max (1 - cos) vs the bf16 tower stays <= 'fp8Budget'
-        # (default MARQO_AMD_FP8_BUDGET = 7e-4; a larger budget moves more blocks to fp8).  The reference's own 'precision' key
+        # (default MARQO_AMD_FP8_BUDGET = 5e-4; a larger budget moves more blocks to fp8).  The reference's own 'precision' key
         # (fp32 / fp16 autocast) keeps its meaning and is accepted for both.
         self.engine_precision: str = p.get("enginePrecision", p.get("engine_precision", os.environ.get("MARQO_AMD_PRECISION", "bf16")))
         if self.engine_precision not in ("bf16", "fp8"):
@@ -242,6 +242,9 @@ class OPEN_CLIP(AbstractCLIPModel):
             # scales with head-room + the bf16 / fp8 block split that keeps the measured error inside props.fp8_budget
             self.vision.tune_fp8_default(props.fp8_budget)
             self.text.tune_fp8_default(props.fp8_budget)
+        # the load-time policies are fixed now: folded-LayerNorm weight copies no block can use any more go back to the allocator
+        self.vision.release_unused_folded()
+        self.text.release_unused_folded()
         self.model = (self.vision, self.text)
         self.tokenizer = self._load_tokenizer(ckpt_dir)
         # K14: byte-level BPE on the device for ASCII texts (identical ids; the host tokeniser handles the rest)

@@ -299,6 +299,8 @@ def _encode_to_array(model_cache_key: str, content, normalize_embeddings: bool, 
                     modality = infer_modality(batch[0] if isinstance(batch[0], (str, bytes)) else batch)
                 infer = kwargs.pop("infer", False if modality == Modality.TEXT else True)
                 ckey = _coalesce_key(model_cache_key, modality, normalize_embeddings, infer, kwargs) if coalesce_window > 0 else None
+                if ckey is not None and not _coalesce.explicit() and _coalesce.fetches_content(batch, modality == Modality.TEXT):
+                    ckey = None         # image URLs: every request thread keeps downloading its own (coalesce.fetches_content)
                 if ckey is not None:
                     def run_merged(items, _m=modality, _i=infer, _kw=dict(kwargs)):
                         return encoder.encode(items, modality=_m, normalize=normalize_embeddings, infer=_i, **_kw)

@@ -172,3 +172,40 @@ def test_reference_vectorise_tests_pass_with_coalescing_on():
                         os.path.join(ref, "test_encoding_random.py")], capture_output=True, text=True, env=env, cwd="/tmp", timeout=600)
     tail = p.stdout.strip().splitlines()[-1] if p.stdout.strip() else p.stderr[-1500:]
     assert p.returncode == 0 and "14 passed" in tail, p.stdout[-2000:] + p.stderr[-1000:]
+
+
+def test_image_url_calls_stay_out_of_the_default_coalescing():
+    """image calls whose content is URL strings download inside the engine call — merged, the leader would download every
+    participant's URLs one after the other.  By default each request thread keeps its own engine call (parallel downloads); decoded content
+    (PIL images, arrays — here: non-string objects) and text still merge; MARQO_AMD_COALESCE_US set explicitly merges URLs too."""
+    assert coalesce.fetches_content(["http://x/a.png", object()], is_text=False) and not coalesce.fetches_content(["http://x/a.png"], is_text=True)
+    assert not coalesce.fetches_content([object(), object()], is_text=False)
+
+    def run(env, make_item):
+        model = FakeEngineModel()
+        props, avail = _setup(model)
+        errs = []
+
+        def worker(t):
+            try:
+                for c in range(4):
+                    s2_inference.vectorise_ndarray("fake_engine", [make_item(t, c, i) for i in range(3)], model_properties=props, device="cpu",
+                                                   modality=Modality.IMAGE)
+            except BaseException as e:  # noqa: BLE001
+                errs.append(e)
+        with mock.patch.dict(os.environ, env), mock.patch(S2 + "._available_models", avail), mock.patch(S2 + "._update_available_models", mock.MagicMock()):
+            ts = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+            for t in ts:
+                t.start()
+            for t in ts:
+                t.join(60)
+        assert not errs, errs
+        return model.calls
+
+    url = lambda t, c, i: f"http://host/{t}/{c}/{i}.png"      # noqa: E731
+    calls = run({"MARQO_AMD_COALESCE_US": ""}, url)
+    assert len(calls) == 32 and all(len(c) == 3 for c in calls)                 # default: one engine call per vectorise call, nothing merged
+    calls = run({"MARQO_AMD_COALESCE_US": "20000"}, url)
+    assert len(calls) < 32                                                      # explicit opt-in: merged
+    calls = run({"MARQO_AMD_COALESCE_US": ""}, lambda t, c, i: (t, c, i))       # decoded content (no I/O in the engine call): merged by default
+    assert len(calls) < 32

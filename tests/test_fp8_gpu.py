@@ -168,6 +168,49 @@ def test_gemm_fp8_scheduling_knobs_are_bit_identical():
             L.check(lib.mq_tune(k.encode(), v))
 
 
+def test_gemm_fp8_taller_than_one_launch_can_address_goes_in_row_chunks():
+    """the fp8 GEMM addresses its operands through 32-bit buffer offsets like the bf16 one; an A above the limit must run as row chunks
+    (per-row scales, residual and output offset per chunk), not be refused.  The limit is lowered (mq_tune gemm_addr_limit_mb) so that 3 MB of A
+    need 4 launches; every epilogue form must be bit-identical to the single launch."""
+    lib = L.load()
+    g = torch.Generator(device="cuda").manual_seed(17)
+    M, N, K = 3000, 388, 1024
+    A8 = torch.randint(0, 256, (M, K), dtype=torch.uint8, device="cuda", generator=g) & 0xBF
+    W8 = torch.randint(0, 256, (N, K), dtype=torch.uint8, device="cuda", generator=g) & 0xBF
+    sa = torch.rand(M, device="cuda", generator=g) + 0.5
+    sw = (torch.rand(N, device="cuda", generator=g) + 0.5) * 0.01
+    bias = torch.randn(N, device="cuda", generator=g)
+    res = torch.randn(M, N, device="cuda", generator=g)
+    osc = torch.tensor([0.05], device="cuda")
+
+    def run_all():
+        outs = []
+        for flags, dt, residual in ((L.MQ_EPI_BIAS, torch.bfloat16, None), (L.MQ_EPI_BIAS | L.MQ_EPI_GELU | L.MQ_EPI_OUT_FP8, torch.uint8, None),
+                                    (L.MQ_EPI_OUT_F32, torch.float32, None), (L.MQ_EPI_BIAS | L.MQ_EPI_RESIDUAL | L.MQ_EPI_OUT_F32, torch.float32, res),
+                                    (L.MQ_EPI_BIAS | L.MQ_EPI_RESIDUAL, torch.bfloat16, res.to(torch.bfloat16))):
+            for rowscale in (1, 0):
+                out = residual.clone() if residual is not None else torch.zeros(M, N, device="cuda", dtype=dt)
+                amax = torch.zeros(1, device="cuda")
+                L.check(lib.mq_gemm_fp8(A8.data_ptr(), K, W8.data_ptr(), K, sa.data_ptr(), rowscale, sw.data_ptr(), bias.data_ptr(),
+                                        out.data_ptr() if residual is not None else 0, out.data_ptr(), N, osc.data_ptr(), amax.data_ptr(), M, N, K, flags, _stream()))
+                outs += [out, amax.clone()]
+        return outs
+    whole = run_all()
+    try:
+        L.check(lib.mq_tune(b"gemm_addr_limit_mb", 1))
+        chunked = run_all()
+        # a weight above the limit cannot be chunked: refused, loudly
+        big_w = torch.zeros(1200, K, dtype=torch.uint8, device="cuda")
+        out = torch.zeros(M, 1200, device="cuda")
+        rc = lib.mq_gemm_fp8(A8.data_ptr(), K, big_w.data_ptr(), K, sa.data_ptr(), 1, torch.ones(1200, device="cuda").data_ptr(), 0, 0, out.data_ptr(), 1200, 0, 0,
+                             M, 1200, K, L.MQ_EPI_OUT_F32, _stream())
+        assert rc != 0
+    finally:
+        L.check(lib.mq_tune(b"gemm_addr_limit_mb", 0))
+    for a, b in zip(whole, chunked):
+        assert torch.equal(a, b), a.dtype
+
+
 def _cos_err(a, b):
     a, b = a.double().cpu(), b.double().cpu()
     return float((1 - (a * b).sum(-1) / (a.norm(dim=-1) * b.norm(dim=-1))).max())

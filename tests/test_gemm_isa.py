@@ -20,10 +20,10 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 BIAS, GELU, RESIDUAL, OUT_F32, ROW_STATS, LN_APPLY = 1, 2, 8, 16, 64, 128
 
 
-def _compile(tmp_path, flags, mt, src=SRC, rowscale=0):
-    out = tmp_path / f"probe_{os.path.basename(src)}_{flags}_{mt}_{rowscale}.s"
+def _compile(tmp_path, flags, mt, src=SRC, rowscale=0, nh=1):
+    out = tmp_path / f"probe_{os.path.basename(src)}_{flags}_{mt}_{rowscale}_{nh}.s"
     res = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wall", "-Wno-unused-function", "-Rpass-analysis=kernel-resource-usage",
-                          f"-DMQ_GEMM_PROBE={flags}", f"-DMQ_GEMM_PROBE_MT={mt}", f"-DMQ_GEMM_PROBE_ROWSCALE={rowscale}", "-S", "--cuda-device-only", "-o", str(out), src],
+                          f"-DMQ_GEMM_PROBE={flags}", f"-DMQ_GEMM_PROBE_MT={mt}", f"-DMQ_GEMM_PROBE_ROWSCALE={rowscale}", f"-DMQ_GEMM_PROBE_NH={nh}", "-S", "--cuda-device-only", "-o", str(out), src],
                          capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-3000:]
     return out.read_text(), res.stderr
@@ -87,6 +87,16 @@ def _check(isa, remarks, mfma_name, n_mfma, n_reads_expected, hot_regions=1):
 def test_asm_fragment_reads_are_waited_for_before_any_use(tmp_path, flags, mt):
     isa, remarks = _compile(tmp_path, flags, mt)
     _check(isa, remarks, "v_mfma_f32_16x16x32_bf16", 8 * mt, 3 * (mt + 4))    # reads: prologue + both half-steps
+
+
+@pytest.mark.skipif(not shutil.which(HIPCC), reason="hipcc not installed")
+@pytest.mark.parametrize("flags", [BIAS, BIAS | RESIDUAL, BIAS | RESIDUAL | OUT_F32, BIAS | GELU | LN_APPLY, BIAS | RESIDUAL | ROW_STATS])
+def test_wide_tile_follows_the_same_rules(tmp_path, flags):
+    """round 5: the 224 x 256 tile (NH = 2: 8 W sub-tiles per wave, one workgroup per CU, accumulators in AGPRs) is the same loop: 2 * 8 * MT MFMAs
+    in ONE k-step body, 3 * (MT + 8) fragment reads, one vmcnt wait, one barrier, no scratch"""
+    isa, remarks = _compile(tmp_path, flags, 7, nh=2)
+    _check(isa, remarks, "v_mfma_f32_16x16x32_bf16", 2 * 8 * 7, 3 * (7 + 8))
+    assert re.search(r"AGPRs: (\d+)", remarks) and int(re.search(r"AGPRs: (\d+)", remarks).group(1)) >= 224      # the accumulators live in the AGPR half
 
 
 OUT_FP8 = 32

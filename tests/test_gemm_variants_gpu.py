@@ -16,7 +16,7 @@ def _tiled_family(tiled_gemm_only):
     yield
 
 
-DEFAULTS = dict(gemm_mt=0, gemm_cgroup=8)
+DEFAULTS = dict(gemm_mt=0, gemm_cgroup=8, gemm_nh=0)
 SHAPES = [(50, 64, 64), (257, 768, 128), (1000, 132, 192), (4097, 2304, 768), (12800, 768, 3072), (333, 3072, 64), (16, 4, 64),
           (20000, 1160, 64), (3000, 1288, 128)]
 
@@ -124,3 +124,48 @@ def test_a_matrix_taller_than_one_launch_can_address_goes_in_row_chunks():
     L.check(lib.mq_gemm_bf16(store.data_ptr(), lda, W.data_ptr(), K, b.data_ptr(), out2.data_ptr(), out2.data_ptr(), N, M, N, K,
                              L.MQ_EPI_BIAS | L.MQ_EPI_RESIDUAL, torch.cuda.current_stream().cuda_stream))
     assert torch.equal(out2.view(torch.int16), want2.view(torch.int16))
+
+
+def test_row_chunks_under_a_lowered_address_limit_are_bit_identical():
+    """the same chunking exercised at a small size (mq_tune gemm_addr_limit_mb): 5 000 x 768 bf16 = 7.7 MB of A under a 2 MB limit = 4 launches"""
+    lib = L.load()
+    g = torch.Generator(device="cuda").manual_seed(23)
+    M, N, K = 5000, 772, 768
+    A = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+    W = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).to(torch.bfloat16)
+    b = torch.randn(N, device="cuda", generator=g)
+    res = torch.randn(M, N, device="cuda", generator=g)
+    forms = [(L.MQ_EPI_BIAS | L.MQ_EPI_GELU, None), (L.MQ_EPI_BIAS | L.MQ_EPI_RESIDUAL | L.MQ_EPI_OUT_F32, res), (L.MQ_EPI_BIAS | L.MQ_EPI_RESIDUAL, res.to(torch.bfloat16))]
+    whole = [_gemm(lib, A, W, b, r, f) for f, r in forms]
+    try:
+        _tune(lib, gemm_addr_limit_mb=2)
+        chunked = [_gemm(lib, A, W, b, r, f) for f, r in forms]
+    finally:
+        _tune(lib, gemm_addr_limit_mb=0)
+    for x, y in zip(whole, chunked):
+        assert torch.equal(x, y)
+
+
+def test_the_wide_tile_is_bit_identical_to_the_narrow_one():
+    """round 5: the 224 x 256 tile (mq_tune gemm_nh = 2) accumulates every output element over k in the same order as the (32*MT) x 128 tiles — same
+    bits with every epilogue, on ragged shapes (M not a multiple of 224, N not a multiple of 256, N < 256 falls back to the narrow tile, K = 64: one
+    k-step per tile); row statistics and the folded LayerNorm included; 20 repeated launches screen the LDS ring for races"""
+    lib = L.load()
+    g = torch.Generator(device="cuda").manual_seed(31)
+    try:
+        for (M, N, K) in [(12800, 768, 768), (4099, 2304, 768), (16448, 1024, 4096), (700, 260, 64), (224, 256, 128), (5000, 132, 192), (9000, 3072, 1024)]:
+            A = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+            W = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).to(torch.bfloat16)
+            b = torch.randn(N, device="cuda", generator=g)
+            res = torch.randn(M, N, device="cuda", generator=g)
+            forms = [(0, None), (L.MQ_EPI_OUT_F32, None), (L.MQ_EPI_BIAS | L.MQ_EPI_GELU, None), (L.MQ_EPI_BIAS | L.MQ_EPI_QUICKGELU, None),
+                     (L.MQ_EPI_BIAS | L.MQ_EPI_RESIDUAL | L.MQ_EPI_OUT_F32, res), (L.MQ_EPI_BIAS | L.MQ_EPI_RESIDUAL, res.to(torch.bfloat16))]
+            _tune(lib, gemm_nh=1)
+            base = [_gemm(lib, A, W, b, r, f) for f, r in forms]
+            _tune(lib, gemm_nh=2)
+            for rep in range(20 if (M, N, K) == (12800, 768, 768) else 2):
+                wide = [_gemm(lib, A, W, b, r, f) for f, r in forms]
+                for x, y, (f, _) in zip(base, wide, forms):
+                    assert torch.equal(x, y), ((M, N, K), f, rep)
+    finally:
+        _tune(lib, **DEFAULTS)

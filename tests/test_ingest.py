@@ -139,7 +139,7 @@ def test_sharded_flush_world_size_2():
     assert sorted(q.get(timeout=5) for _ in range(2)) == [(0, True), (1, True)]
 
 
-def _worker_requests(rank, world, port, q):
+def _worker_requests(rank, world, port, q, merge_images=0):
     """RequestShardedIngest: ranks own disjoint REQUESTS (nothing inside a request is sharded), one gather onto rank 0"""
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
@@ -152,7 +152,7 @@ def _worker_requests(rank, world, port, q):
             calls.append((kw.get("modality"), list(content)))
             return np.asarray([[float(str(c).split()[-1])] * 4 for c in content], dtype=np.float32)
 
-        ing = RequestShardedIngest("m", "cpu", vectorise_fn=fake)
+        ing = RequestShardedIngest("m", "cpu", vectorise_fn=fake, merge_images=merge_images, merge_deadline_ms=0)
         n_req = 7   # ragged: rank 0 owns 4 requests, rank 1 owns 3; requests of different sizes
         for i in range(n_req):
             if not ing.owns(i):
@@ -162,7 +162,10 @@ def _worker_requests(rank, world, port, q):
             ing.submit(i, items)
         ok = ing.touched == [i for i in range(n_req) if i % world == rank]            # no rank touched a request it does not own
         ok = ok and all(all(int(c.split()[-1]) // 1000 % world == rank for c in content) for _, content in calls)
-        ok = ok and len(calls) == 2 * len(ing.touched)                                   # one call per modality per OWNED request
+        if merge_images == 0:
+            ok = ok and len(calls) == 2 * len(ing.touched)                               # one call per modality per OWNED request
+        else:   # merged: groups of >= 4 images = 2 requests; the odd last request of rank 1 waits for collect()
+            ok = ok and ing.groups_launched == ([[0, 2], [4, 6]] if rank == 0 else [[1, 3]]) and len(calls) == 2 * len(ing.groups_launched)
         try:
             ing.submit(rank + 1, [((0, "t", 0), "text 1", Modality.TEXT)])                # a foreign request is refused
             ok = False
@@ -183,11 +186,12 @@ def _worker_requests(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_request_sharded_ingest_world_size_2():
+@pytest.mark.parametrize("merge_images", [0, 4])
+def test_request_sharded_ingest_world_size_2(merge_images):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker_requests, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker_requests, args=(r, 2, port, q, merge_images)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
@@ -257,7 +261,7 @@ def test_a_failed_request_does_not_poison_the_stream():
             raise OSError("image file is truncated")
         return np.asarray([[float(len(str(c))), float(kw["modality"] == Modality.IMAGE)] for c in content], dtype=np.float32)
 
-    ing = RequestShardedIngest("m", "cpu", vectorise_fn=flaky)
+    ing = RequestShardedIngest("m", "cpu", vectorise_fn=flaky, merge_images=0)
     ing.submit(0, [((0, "t"), "hello", Modality.TEXT), ((0, "i"), "img0", Modality.IMAGE)])
     with pytest.raises(OSError):
         ing.submit(1, [((1, "t"), "text of the bad request", Modality.TEXT), ((1, "i"), "BAD", Modality.IMAGE)])
@@ -291,7 +295,7 @@ def test_one_request_stays_in_flight_and_a_late_device_error_fails_only_that_req
         return [((i, "t"), word, Modality.TEXT), ((i, "i"), word + "-img", Modality.IMAGE)]
 
     for depth in (1, 0):
-        ing = RequestShardedIngest("m", "cpu", vectorise_fn=fn)
+        ing = RequestShardedIngest("m", "cpu", vectorise_fn=fn, merge_images=0)
         ing.pipeline_depth = depth
         ing.submit(0, request(0, "a"))
         assert (ing._inflight is not None) == (depth == 1) and len(ing._rows) == (0 if depth else 2)
@@ -301,7 +305,7 @@ def test_one_request_stays_in_flight_and_a_late_device_error_fails_only_that_req
         rows = ing.collect()
         assert sorted(rows) == [0, 1, 2] and [rows[i][(i, "t")][0] for i in range(3)] == [1.0, 2.0, 3.0] and ing._inflight is None
     # a late fault
-    ing = RequestShardedIngest("m", "cpu", vectorise_fn=fn)
+    ing = RequestShardedIngest("m", "cpu", vectorise_fn=fn, merge_images=0)
     ing.submit(0, request(0, "ok"))
     ing.submit(1, request(1, "FAULT"))                                # enqueues fine (the fault is asynchronous) ...
     ing.submit(2, request(2, "fine"))                                 # ... and is charged to request 1 here, without failing request 2's call
@@ -323,3 +327,128 @@ def test_flush_async_hands_back_what_flush_would():
     assert bulk.pending() == 0 and bulk.flush() == {}                 # not visible to another flush before result()
     out = h.result()
     assert set(out) == {"a", "b"} and out["b"][0] == 2.0 and h.result() is out
+
+
+# ---- cross-request micro-batching (merged groups) -------------------------------------------------------------------------------------------
+def _req(i, n_text=2, n_img=2, bad=None, fault=None):
+    items = [(("t", j), f"text {1000 * i + j}", Modality.TEXT) for j in range(n_text)]        # keys COLLIDE across requests on purpose
+    items += [(("i", j), ("BAD" if bad == j else "FAULT" if fault == j else "img") + f" {1000 * i + 500 + j}", Modality.IMAGE) for j in range(n_img)]
+    return items
+
+
+def _numbered(calls):
+    def fn(model, content, **kw):
+        calls.append((kw["modality"], list(content)))
+        if any(str(c).startswith("BAD") for c in content):
+            raise OSError("image file is truncated")
+        return np.asarray([[float(str(c).split()[-1]), float(kw["modality"] == Modality.IMAGE)] for c in content], dtype=np.float32)
+    return fn
+
+
+def _check_rows(rows, i, n_text=2, n_img=2):
+    assert set(rows[i]) == {("t", j) for j in range(n_text)} | {("i", j) for j in range(n_img)}
+    assert all(rows[i][("t", j)][0] == 1000 * i + j for j in range(n_text)) and all(rows[i][("i", j)][0] == 1000 * i + 500 + j for j in range(n_img))
+
+
+def test_requests_merge_until_the_image_target_and_scatter_back_in_order():
+    from marqo_amd.ingest import RequestShardedIngest
+    calls = []
+    ing = RequestShardedIngest("m", "cpu", vectorise_fn=_numbered(calls), merge_images=6, merge_deadline_ms=0)
+    for i in range(7):
+        ing.submit(i, _req(i, n_text=1 + i % 3))
+    # 2 images per request, target 6: groups of 3 requests; request 6 waits for collect()
+    assert ing.groups_launched == [[0, 1, 2], [3, 4, 5]] and len(calls) == 4
+    assert [len(c[1]) for c in calls if c[0] == Modality.IMAGE] == [6, 6] and [len(c[1]) for c in calls if c[0] == Modality.TEXT] == [6, 6]
+    assert len(ing._rows) == 12          # ONE group in flight: the first group was filed when the second one was launched
+    rows = ing.collect()
+    assert len(calls) == 6 and sorted(rows) == list(range(7))
+    for i in range(7):
+        _check_rows(rows, i, n_text=1 + i % 3)
+    assert [k for k in rows[4]] == [("t", 0), ("t", 1), ("i", 0), ("i", 1)]         # submission order inside a request
+    assert ing.failed_requests == [] and ing.collect() == {}
+
+
+def test_text_only_requests_merge_on_the_token_target():
+    from marqo_amd.ingest import RequestShardedIngest, estimate_tokens
+    calls = []
+    per_request = 4 * estimate_tokens("text 1000")
+    ing = RequestShardedIngest("m", "cpu", vectorise_fn=_numbered(calls), merge_images=512, merge_text_tokens=int(2.5 * per_request), merge_deadline_ms=0)
+    for i in range(6):
+        ing.submit(i, _req(i, n_text=4, n_img=0))
+    assert ing.groups_launched == [[0, 1, 2], [3, 4, 5]] and [len(c[1]) for c in calls] == [12, 12]
+    rows = ing.collect()
+    for i in range(6):
+        _check_rows(rows, i, n_text=4, n_img=0)
+
+
+def test_a_bad_request_inside_a_merged_group_fails_alone():
+    """host-side failure of a merged group: its requests are re-run one by one; the bad one is recorded, the others' rows are kept, in order;
+    submit() raises only when the bad request is the one being submitted"""
+    from marqo_amd.ingest import RequestShardedIngest
+    calls = []
+    ing = RequestShardedIngest("m", "cpu", vectorise_fn=_numbered(calls), merge_images=6, merge_deadline_ms=0)
+    ing.submit(0, _req(0))
+    ing.submit(1, _req(1, bad=1))
+    ing.submit(2, _req(2))                        # launches [0, 1, 2]: fails, isolated; request 2 itself is fine -> no raise
+    assert ing.failed == [1] and isinstance(ing.errors[1], OSError) and ing._bulk.pending() == 0
+    assert [i for i, _ in ing._index] == [0] * 4 + [2] * 4
+    ing.submit(3, _req(3))
+    ing.submit(4, _req(4))
+    with pytest.raises(OSError):
+        ing.submit(5, _req(5, bad=0))             # the submitting request is the bad one: raised here
+    assert ing.failed == [1, 5]
+    ing.submit(6, _req(6))
+    rows = ing.collect()
+    assert sorted(rows) == [0, 2, 3, 4, 6] and ing.failed_requests == [1, 5]
+    for i in (0, 2, 3, 4, 6):
+        _check_rows(rows, i)
+    assert [i for grp in [[0, 2], [3, 4], [6]] for i in grp] == sorted(rows)
+
+
+def test_a_late_device_fault_in_a_merged_group_is_isolated_and_order_is_kept():
+    import torch
+    from marqo_amd.ingest import RequestShardedIngest
+
+    class _Faulty(torch.Tensor):
+        def cpu(self, *a, **k):
+            raise RuntimeError("HIP error: an illegal memory access was encountered")
+
+    def fn(model, content, **kw):
+        rows = torch.tensor([[float(str(c).split()[-1]), float(kw["modality"] == Modality.IMAGE)] for c in content])
+        return torch.Tensor._make_subclass(_Faulty, rows) if any("FAULT" in str(c) for c in content) else rows
+
+    ing = RequestShardedIngest("m", "cpu", vectorise_fn=fn, merge_images=4, merge_deadline_ms=0)
+    for i in range(6):
+        ing.submit(i, _req(i, fault=0 if i == 2 else None))      # groups [0,1] [2,3] [4,5]; the fault surfaces when [4,5] is launched
+    assert ing.failed == [2] and [i for i, _ in ing._index] == [0] * 4 + [1] * 4 + [3] * 4
+    rows = ing.collect()
+    assert sorted(rows) == [0, 1, 3, 4, 5] and ing.failed_requests == [2]
+    assert [i for i, _ in sorted(((i, 0) for i in rows))] == [0, 1, 3, 4, 5]
+    ing.submit(6, _req(6, fault=1))
+    ing.submit(7, _req(7))
+    with pytest.raises(RuntimeError):
+        ing.drain()                                             # the synchronous form raises the group's first error
+    assert ing.failed == [6] and sorted(ing.collect()) == [7]
+
+
+def test_the_deadline_launches_a_partial_group():
+    """a slow producer: the waiting request is launched by the deadline thread, not held until the group is full"""
+    import time
+    from marqo_amd.ingest import RequestShardedIngest
+    calls = []
+    ing = RequestShardedIngest("m", "cpu", vectorise_fn=_numbered(calls), merge_images=100, merge_deadline_ms=20)
+    ing.submit(0, _req(0))
+    assert calls == [] and ing.groups_launched == []
+    t0 = time.perf_counter()
+    while not ing.groups_launched and time.perf_counter() - t0 < 5:
+        time.sleep(0.005)
+    assert ing.groups_launched == [[0]] and len(calls) == 2 and time.perf_counter() - t0 < 2
+    ing.submit(1, _req(1))
+    ing.submit(2, _req(2))                        # both arrive inside one window: merged
+    rows = ing.collect()
+    assert sorted(rows) == [0, 1, 2] and len(calls) == 4
+    for i in range(3):
+        _check_rows(rows, i)
+    ing.close()
+    ing._deadline_thread.join(2)
+    assert not ing._deadline_thread.is_alive()

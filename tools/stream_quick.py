@@ -1,5 +1,6 @@
-"""add_documents_stream (bench.py workload: 128 texts + 128 PIL images per request through RequestShardedIngest) with the request pipeline on / off,
-interleaved in one process, + a cProfile of the pipelined form (where the host time of a request goes).  usage: python tools/stream_quick.py [docs]"""
+"""add_documents_stream (bench.py workload: 128 texts + 128 PIL images per request through RequestShardedIngest): cross-request merge targets
+(images per merged tower call; 0 = one call per request) x request pipeline on / off, interleaved in one process, + a cProfile of the default form
+(where the host time of a request goes).  usage: python tools/stream_quick.py [docs] [merge targets, comma separated]"""
 import cProfile, io, os, pstats, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["MARQO_AMD_SYNTHETIC_WEIGHTS"] = "1"
@@ -19,6 +20,7 @@ for r in range(4):
     imgs = [Image.fromarray(rng.integers(0, 256, (224, 224, 3), dtype=np.uint8)) for _ in range(docs)]
     texts = [" ".join(words[int(j) % 10] for j in rng.integers(0, 10, int(rng.integers(3, 60)))) + f" {r} {i}" for i in range(docs)]
     pool.append((texts, imgs))
+merges = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 256, 512, 1024]
 ing = RequestShardedIngest(name, dev)
 state = {"i": 0}
 
@@ -43,17 +45,23 @@ def run(depth, n):
     return dt / n
 
 
-for _ in range(6):
-    step()
-ing.collect()
+for m in merges:            # every group shape once, untimed (workspaces, pinned blocks, LDS attributes)
+    ing.merge_images = m
+    for _ in range(max(4, 2 * (m // docs))):
+        step()
+    ing.collect()
 for rep in range(3):
-    for depth in (0, 1):
-        ms = run(depth, 30) * 1e3
-        print(f"pipeline_depth={depth}: {ms:.3f} ms per {docs}-document request = {2 * docs / ms * 1e3:.0f} embeddings/s")
+    for m in merges:
+        for depth in ((0, 1) if m == 0 or rep == 0 else (1,)):
+            ing.merge_images = m
+            n = 96 if m else 32
+            ms = run(depth, n) * 1e3
+            print(f"merge_images={m:5d} pipeline_depth={depth}: {ms:.3f} ms per {docs}-document request = {2 * docs / ms * 1e3:.0f} embeddings/s", flush=True)
 ing.pipeline_depth = 1
+ing.merge_images = merges[-1] if len(sys.argv) > 2 else 512
 pr = cProfile.Profile()
 pr.enable()
-run(1, 30)
+run(1, 96)
 pr.disable()
 out = io.StringIO()
 pstats.Stats(pr, stream=out).sort_stats("tottime").print_stats(18)
