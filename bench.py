@@ -58,6 +58,10 @@ WORKLOADS = {
     "vit_l14_chunked_fp8": dict(kind="chunked", arch="ViT-L-14", desc="BASELINE configs[4]: 480x640 uint8 images resident in HBM -> K11 'simple' 3x3 grid chunking on the GPU "
                                 "(resize to 240x240, whole image + 9 cells = 10 crops per image, each through the CLIP transform) -> ViT-L/14 image tower under the "
                                 "load-time fp8 block-split policy; 24 images = 240 crop embeddings per GPU per step", batch=24),
+    "vit_l14_chunked_fp8_trained": dict(kind="chunked", arch="ViT-L-14", weights="trained_like", desc="BASELINE configs[4] on a REPRESENTATIVE tower: the same step (480x640 uint8 sources in HBM "
+                                        "-> K11 3x3 grid -> 10 crops per image -> ViT-L/14 under the load-time fp8 policy) with trained-like weight statistics (LayerNorm gain spread, outlier "
+                                        "channels, peaky attention, class-token massive activation: engine/synthetic.py) and source images of natural-image statistics (1/f spectrum, "
+                                        "correlated channels) — what the policy picks on a real checkpoint rather than on N(0, s) weights; 24 images = 240 crop embeddings per GPU per step", batch=24),
     "add_documents_stream": dict(kind="stream", arch="ViT-B-32", desc="BASELINE configs[3] as a stream: mixed {text, 224x224 PIL image} documents in 128-document requests; every "
                                  "rank owns whole requests (request i -> rank i % N, nothing is sharded inside a request), runs them through the single-GPU "
                                  "BulkVectoriser path, consecutive owned requests MERGED into chip-filling groups (one tower call per modality and group, text and images on two host threads / HIP streams) with ONE group in flight (group g + 1 is tokenised / packed / enqueued while group g runs; rows are copied to the host behind their tower) and ONE gather onto rank 0 closes the stream; ViT-B/32", batch=128),
@@ -66,7 +70,7 @@ WORKLOADS = {
                                 "128-document requests through BulkVectoriser (host PIL images + strings -> vectorise -> gather in order), ViT-B/32", batch=128),
 }
 # the default line's `also` rows: the text half of the metric, BASELINE configs[2], configs[4] (fp8 policy + on-GPU chunker) and configs[3] (ingest stream)
-ALSO_DEFAULT = ("clip_text_b32", "bert_base_77", "vit_l14_mixed", "vit_l14_chunked_fp8", "add_documents_stream")
+ALSO_DEFAULT = ("clip_text_b32", "bert_base_77", "vit_l14_mixed", "vit_l14_chunked_fp8", "vit_l14_chunked_fp8_trained", "add_documents_stream")
 
 
 def parse_args():
@@ -256,9 +260,13 @@ class Workload:
             self.run = lambda: tower.encode_device(d_ids, lens)
         elif self.kind == "chunked":   # device-resident source images -> grid chunker (K11) -> tower; embeddings = crops
             from marqo_amd.engine.preprocess import ImagePreprocessor
-            self.sd = synthetic.random_open_clip_state_dict(vision=self.varch, seed=0)
+            if wl.get("weights") == "trained_like":
+                self.sd = synthetic.trained_like_open_clip_state_dict(self.varch, seed=2)
+                self.src_cpu = list(synthetic.natural_images_u8(batch, 480, 640, seed=seed))
+            else:
+                self.sd = synthetic.random_open_clip_state_dict(vision=self.varch, seed=0)
+                self.src_cpu = [torch.randint(0, 256, (480, 640, 3), generator=g, dtype=torch.uint8) for _ in range(batch)]
             tower = towers.VitTower(self.varch, self.sd, dev, precision=precision)
-            self.src_cpu = [torch.randint(0, 256, (480, 640, 3), generator=g, dtype=torch.uint8) for _ in range(batch)]
             src = [t.to(dev) for t in self.src_cpu]
             pre = ImagePreprocessor(dev, self.varch.image_size)
             self.crops_per_image = 10
@@ -693,91 +701,6 @@ def run_stream(args, dev, rank, world, dist, lib, L):
     gf = (varch.gflop_per_image + tarch.gflop_per_text(30)) / 2
     result = {
         "metric": "embeddings/sec", "value": round(value, 1), "unit": "embeddings/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": args.precision, "data": "synthetic",
-        "config": {"workload": wl["desc"], "global_batch": n_emb, "docs_per_request": docs,
-                   "parallelism": f"dp{world} (replicated weights; texts sharded by token estimate, images contiguously; ONE RCCL all_gather per modality from HBM; "
-                                  f"every rank returns the request's embeddings in order)",
-                   "weights": "random-init (seed 0) ViT-B-32", "gflop_per_embedding": round(gf, 3)},
-        "e2e_tflops": round(value * gf / 1e3, 1),
-        # the dominant kernel family over a few more requests (HIP events on the launch streams, as in the headline)
-        "roofline": gemm_roofline(lib, L, step, min(args.steps, 6), args.precision, "add_documents_mixed"),
-        "cpu_baseline": (mixed_request_cpu_baseline(varch, tarch, imgs, docs, args.cpu_seconds)
-                         if rank == 0 and world == 1 and not args.no_cpu_baseline else None),
-        "note": "end-to-end through the Python boundary (host PIL -> uint8 pack -> H2D -> K10 -> towers -> gather -> D2H -> per-key rows); "
-                "the request (total work) is fixed, ranks split it: strong scaling",
-    }
-    if rank == 0:
-        print(json.dumps(result), flush=True)
-
-
-# ---- BASELINE configs[3] as a stream: ranks own whole requests, one gather onto rank 0 ----------------------------------------------
-def run_stream(args, dev, rank, world, dist, lib, L):
-    from PIL import Image
-    os.environ["MARQO_AMD_SYNTHETIC_WEIGHTS"] = "1"
-    os.environ.setdefault("MARQO_MAX_CUDA_MODEL_MEMORY", "64")
-    from marqo_amd.engine import archs
-    from marqo_amd.ingest import RequestShardedIngest
-    from marqo_amd.s2_inference import s2_inference as s2
-    from marqo_amd.s2_inference.enums import Modality
-    wl = WORKLOADS["add_documents_stream"]
-    docs = args.batch or wl["batch"]
-    if args.steps <= 0:             # the stream at BASELINE configs[3]'s stated size: 100 000 documents over the ranks
-        args.steps = -(-100000 // (docs * world))
-    name = "open_clip/ViT-B-32/laion2b_s34b_b79k"
-    varch, tarch = archs.resolve_open_clip("ViT-B-32")
-    # a pool of 4 distinct synthetic requests per rank (4 x 128 images = 77 MB of pixels), cycled: the stream's requests are independent
-    rng = np.random.default_rng(100 + rank)
-    words = ["alpha", "beta", "gamma", "delta", "marqo", "tensor", "search", "image", "text", "vector"]
-    pool = []
-    for r in range(4):
-        imgs = [Image.fromarray(rng.integers(0, 256, (224, 224, 3), dtype=np.uint8)) for _ in range(docs)]
-        texts = [" ".join(words[int(j) % 10] for j in rng.integers(0, 10, int(rng.integers(3, 60)))) + f" {r} {i}" for i in range(docs)]
-        pool.append((texts, imgs))
-    ing = RequestShardedIngest(name, dev)
-    state = {"next": rank}          # this rank's next request index (rank, rank + world, ...)
-
-    def step():                     # ONE owned request of `docs` documents = 2 * docs embeddings
-        i = state["next"]
-        state["next"] += world
-        texts, imgs = pool[(i // world) % len(pool)]
-        items = [((i, d, "t"), texts[d], Modality.TEXT) for d in range(docs)] + [((i, d, "i"), imgs[d], Modality.IMAGE) for d in range(docs)]
-        ing.submit(i, items)
-
-    def fence():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    ing.collect()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    rows = ing.collect()            # the stream's ONE data-path collective: gather onto rank 0
-    fence()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    n_emb = 2 * docs
-    if rank == 0:
-        assert len(rows) == args.steps * world and all(len(v) == n_emb for v in rows.values()), (len(rows), args.steps, world)
-    value = n_emb * world * args.steps / elapsed
-    # roofline of the dominant kernel family over a few more requests (HIP events on the launch streams, as in the headline)
-    # (requests one at a time, both modalities on the caller's thread: with a request in flight the two towers' kernels share the GPU and every
-    # family's HIP-event time would count the other tower's kernels too)
-    ing.collect()
-    ing.pipeline_depth, ing._bulk.two_threads = 0, False
-    roofline = gemm_roofline(lib, L, step, min(args.steps, 6), args.precision, "add_documents_stream")
-    ing.collect()
-    ing.pipeline_depth, ing._bulk.two_threads = 1, True
-    gf = (varch.gflop_per_image + tarch.gflop_per_text(30)) / 2
-    result = {
-        "metric": "embeddings/sec", "value": round(value, 1), "unit": "embeddings/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.precision, "data": "synthetic",
         "config": {"workload": wl["desc"], "global_batch": n_emb * world, "docs_per_request": docs, "documents_in_stream": docs * world * args.steps,
@@ -877,7 +800,7 @@ def main():
             dist.destroy_process_group()
         return
 
-    if args.workload == "vit_l14_chunked_fp8":
+    if args.workload.startswith("vit_l14_chunked_fp8"):
         args.precision = "fp8"     # the workload IS the fp8 configuration; its bf16 twin is timed beside it (`bf16_twin`)
     w = Workload(args.workload, args.precision, args.batch, dev, 1234 + rank)
     batch, kind, wl = w.batch, w.kind, w.wl
@@ -912,7 +835,7 @@ def main():
                    "inputs": "resident in HBM when the timed region starts (tower-only); host-resident hand-over is reported under e2e_vectorise",
                    "gflop_per_embedding": round(w.gflop_per_emb, 3),
                    "parallelism": f"dp{world} (replicated weights, sharded items, RCCL all_gather of embeddings)",
-                   "weights": "random-init (seed 0) " + wl["arch"],
+                   "weights": ("trained-like statistics (engine/synthetic.py, seed 2) " if wl.get("weights") == "trained_like" else "random-init (seed 0) ") + wl["arch"],
                    # transparency: the towers run the out-projection / MLP of the LAST block only on the pooled rows (class token /
                    # EOT): dead-row elimination with bit-identical embeddings (tests/test_towers_gpu.py::test_row_selected_*), 5.8 % of
                    # ViT-B/32's GEMM FLOPs.  e2e_tflops counts the full algorithmic FLOPs per embedding;
@@ -961,7 +884,7 @@ def main():
                     _s2.clear_loaded_models()
                     torch.cuda.empty_cache()
                     continue
-                prec = "fp8" if name == "vit_l14_chunked_fp8" else args.precision     # configs[4] IS the fp8 configuration
+                prec = "fp8" if name.startswith("vit_l14_chunked_fp8") else args.precision     # configs[4] IS the fp8 configuration
                 x = Workload(name, prec, 0, dev, 1234)
                 el, o = timed(x.run, 10, 3, torch.cuda.synchronize)
                 v = x.batch * 10 / el

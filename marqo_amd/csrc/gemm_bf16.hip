@@ -324,7 +324,7 @@ constexpr int WIDE_MT = 7;                // the wide tile is 224 x 256 (MT = 8 
 
 // tuning knobs: initialised from the environment (MQ_GEMM_MT / _CGROUP / _NH), overridable through mq_tune()
 struct GemmTune {
-    int mt, cgroup, nh;
+    int mt, cgroup, nh, ord = 2;
     static int env(const char* k, int d) { const char* v = getenv(k); return v ? atoi(v) : d; }
     GemmTune() : mt(env("MQ_GEMM_MT", 0)), cgroup(env("MQ_GEMM_CGROUP", 8)), nh(env("MQ_GEMM_NH", 0)) {}
 };
@@ -357,14 +357,14 @@ int choose_mt(int M, int N) {
     return best;
 }
 
-template <int FLAGS, int MT, int NH = 1>
+template <int FLAGS, int MT, int NH = 1, int ORD = 2>
 int launch_gemm_mt(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* residual, void* out, int64_t ldc,
                    int M, int N, int K, hipStream_t s, const GemmLn& ln) {
     constexpr int BM = 32 * MT, BN = 128 * NH;
     constexpr int LDS = 2 * (BM + BN) * BK * 2;
     constexpr int SLOTS = NH == 1 ? RESIDENT_SLOTS : RESIDENT_SLOTS_WIDE;
     static std::atomic<uint64_t> attr_done{0};
-    auto kern = gemm_nt_kernel<FLAGS, MT, NH, 2>;
+    auto kern = gemm_nt_kernel<FLAGS, MT, NH, ORD>;
     if (hipError_t e = mq_ensure_dyn_lds((const void*)kern, LDS, attr_done); e != hipSuccess) {
         mq_set_error("mq_gemm_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e));
         return MQ_ERR_HIP;
@@ -418,7 +418,13 @@ bool choose_wide(int M, int N, int K) {
 template <int FLAGS>
 int launch_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* residual, void* out, int64_t ldc,
                 int M, int N, int K, hipStream_t s, const GemmLn& ln = GemmLn{}) {
-    if (choose_wide(M, N, K)) return launch_gemm_mt<FLAGS, WIDE_MT, 2>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s, ln);
+    if (choose_wide(M, N, K)) {
+        if constexpr (FLAGS == 0) {   // experiment (profiles/r05b): order of the second half's side work on the wide tile, plain epilogue only
+            if (g_tune.ord == 0) return launch_gemm_mt<FLAGS, WIDE_MT, 2, 0>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s, ln);
+            if (g_tune.ord == 1) return launch_gemm_mt<FLAGS, WIDE_MT, 2, 1>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s, ln);
+        }
+        return launch_gemm_mt<FLAGS, WIDE_MT, 2>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s, ln);
+    }
     const int mt = g_tune.mt ? g_tune.mt : choose_mt(M, N);
     switch (mt) {
         case 2: return launch_gemm_mt<FLAGS, 2>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s, ln);
@@ -520,6 +526,7 @@ extern "C" int mq_tune(const char* key, int value) {
     if (k == "gemm_mt") { g_tune.mt = value; mq_gemm_fp8_force_mt = value; }
     else if (k == "gemm_cgroup") mq_gemm_knob_cgroup = g_tune.cgroup = value;
     else if (k == "gemm_nh") g_tune.nh = value;
+    else if (k == "gemm_wide_ord") g_tune.ord = value;
     else if (k == "row_select") mq_tower_row_select = value;
     else if (k == "ln_fold") mq_tower_ln_fold = value;
     else if (k == "xcd_band") mq_xcd_band = value;

@@ -138,3 +138,93 @@ def random_bert_state_dict(arch: BertArch, seed: int = 0) -> Dict[str, Tensor]:
         _lin(sd, p + "output.dense", W, F, g, std)
         _ln(sd, p + "output.LayerNorm", W, g)
     return sd
+
+
+# ---- trained-like statistics (bench.py's fp8 row) -------------------------------------------------------------------------------------------
+# N(0, s) weights never show a quantiser what a trained checkpoint does, and the load-time fp8 policy (towers.tune_fp8) decides on measured
+# error: on random-init weights it moves 7 of ViT-L/14's 24 blocks to e4m3, on trained-like ones 13 + 8 MLP halves — the bench row on random
+# weights under-states what a real checkpoint gets.  The recipe (the same one the parity fixtures use, written out here so
+# that the product's bench does not lean on test infrastructure): LayerNorm gains log-normal with a handful of channels at 0.05 and 4, per-layer
+# weight scale 0.7-1.6x, 1 % outlier output channels (4x), peaky attention (q / k rows 2x), and a class-token massive activation (~150 in two
+# residual channels from block 2 on) that every later LayerNorm damps with a small gain.
+def trained_like_open_clip_state_dict(vision: VitArch, seed: int = 0, massive_layer: int = 2, massive_value: float = 30.0,
+                                      later_gain: float = 0.05) -> Dict[str, Tensor]:
+    if vision.pool == "map":
+        raise ValueError("trained_like_open_clip_state_dict: class-token ViTs only")
+    sd = random_open_clip_state_dict(vision=vision, seed=seed)
+    g = torch.Generator().manual_seed(seed + 7000)
+    W, F, layers, pre = vision.width, vision.mlp_dim, vision.layers, "visual.transformer."
+    base = 0.6 / math.sqrt(W)
+    for i in range(layers):
+        p = f"{pre}resblocks.{i}."
+        for ln in ("ln_1", "ln_2"):
+            gam = torch.exp(0.4 * torch.randn(W, generator=g))
+            idx = torch.randperm(W, generator=g)
+            gam[idx[:8]], gam[idx[8:16]] = 0.05, 4.0
+            sd[p + ln + ".weight"] = gam
+            sd[p + ln + ".bias"] = 0.3 * torch.randn(W, generator=g)
+        scale = 0.7 + 0.9 * float(torch.rand(1, generator=g))
+        for name, (n_out, n_in) in (("attn.in_proj_", (3 * W, W)), ("attn.out_proj.", (W, W)), ("mlp.c_fc.", (F, W)), ("mlp.c_proj.", (W, F))):
+            std = base * scale * (math.sqrt(W / n_in) if n_in != W else 1.0)
+            w = std * torch.randn(n_out, n_in, generator=g)
+            w[torch.randperm(n_out, generator=g)[: max(1, n_out // 100)]] *= 4.0
+            if name == "attn.in_proj_":
+                w[: 2 * W] *= 2.0
+            sd[p + name + "weight"] = w
+            sd[p + name + "bias"] = 0.1 * torch.randn(n_out, generator=g)
+    c0, targets, unit = 5, (W // 3, W // 2 + 1), 7
+    sd["visual.class_embedding"][c0] = 20.0
+    sd["visual.positional_embedding"][0, c0] = 0.0
+    sd["visual.ln_pre.weight"][c0] = 1.0
+    sd["visual.ln_pre.bias"][c0] = 0.0
+    if layers > massive_layer:
+        for i in range(layers):
+            for ln in ("ln_1", "ln_2"):
+                q = f"{pre}resblocks.{i}.{ln}."
+                sd[q + "weight"][c0], sd[q + "bias"][c0] = later_gain, 0.0
+                if i > massive_layer:
+                    for c in targets:
+                        sd[q + "weight"][c], sd[q + "bias"][c] = later_gain, 0.0
+        p = f"{pre}resblocks.{massive_layer}."
+        sd[p + "ln_2.weight"][c0] = 1.0
+        sd[p + "mlp.c_fc.weight"][unit] = 0.0
+        sd[p + "mlp.c_fc.weight"][unit, c0] = 1.0
+        sd[p + "mlp.c_fc.bias"][unit] = -8.0
+        sd[p + "mlp.c_proj.weight"][:, unit] = 0.0
+        for c in targets:
+            sd[p + "mlp.c_proj.weight"][c, unit] = massive_value
+    sd["visual.ln_post.weight"] = torch.exp(0.4 * torch.randn(W, generator=g))
+    sd["visual.ln_post.bias"] = 0.3 * torch.randn(W, generator=g)
+    for c in (c0,) + tuple(targets):
+        sd["visual.ln_post.weight"][c] = later_gain
+    return sd
+
+
+def natural_images_u8(n: int, height: int, width: int, seed: int = 0) -> Tensor:
+    """uint8 HWC [n, height, width, 3] with natural-image statistics instead of white noise: 1/f amplitude spectrum with random phases, strongly
+    correlated colour channels, an illumination gradient, a few flat patches with sharp edges (mean ~0.45, contrast ~0.22)"""
+    import numpy as np
+    rng = np.random.default_rng(seed + 9000)
+    fy, fx = np.fft.fftfreq(height)[:, None], np.fft.rfftfreq(width)[None, :]
+    f = np.sqrt(fy * fy + fx * fx)
+    f[0, 0] = 1.0
+    amp = 1.0 / f
+    amp[0, 0] = 0.0
+    out = np.empty((n, height, width, 3), dtype=np.uint8)
+    yy, xx = np.mgrid[0:height, 0:width]
+
+    def field():
+        x = np.fft.irfft2(amp * np.exp(2j * np.pi * rng.random(amp.shape)), s=(height, width))
+        return x / (x.std() + 1e-12)
+    for i in range(n):
+        shared = field()
+        img = np.stack([0.85 * shared + 0.3 * field() for _ in range(3)], axis=-1)
+        gy, gx = rng.uniform(-0.6, 0.6, 2)
+        img += (gy * (yy / height - 0.5) + gx * (xx / width - 0.5))[..., None]
+        img = 0.45 + 0.22 * img / (img.std() + 1e-12)
+        for _ in range(int(rng.integers(2, 6))):
+            h0, w0 = int(rng.integers(0, height - 8)), int(rng.integers(0, width - 8))
+            h1, w1 = min(height, h0 + int(rng.integers(8, height // 2))), min(width, w0 + int(rng.integers(8, width // 2)))
+            img[h0:h1, w0:w1] = 0.6 * img[h0:h1, w0:w1] + 0.4 * rng.random(3)
+        out[i] = np.clip(img * 255.0 + 0.5, 0, 255).astype(np.uint8)
+    return torch.from_numpy(out)

@@ -349,6 +349,7 @@ MERGE_IMAGES = int(os.environ.get("MARQO_AMD_INGEST_MERGE_IMAGES", "512"))
 MERGE_TEXT_TOKENS = int(os.environ.get("MARQO_AMD_INGEST_MERGE_TEXT_TOKENS", "24576"))
 MERGE_MAX_REQUESTS = int(os.environ.get("MARQO_AMD_INGEST_MERGE_MAX_REQUESTS", "64"))
 MERGE_DEADLINE_MS = float(os.environ.get("MARQO_AMD_INGEST_MERGE_DEADLINE_MS", "2"))
+PIPELINE_DEPTH = int(os.environ.get("MARQO_AMD_INGEST_PIPELINE_DEPTH", "1"))     # groups in flight per rank
 
 
 def _deadline_loop(ref) -> None:
@@ -410,11 +411,11 @@ class RequestShardedIngest:
         self._open_images = 0
         self._open_tokens = 0.0
         self._open_since = 0.0
-        # ONE group in flight: launching group g tokenises / packs / enqueues it and only THEN copies group g - 1's rows to the host, so the
-        # host side of a group (Python bookkeeping, tokeniser, Pillow -> pinned staging) overlaps the previous group's kernels.
-        # pipeline_depth = 0: synchronous.
-        self.pipeline_depth = 1
-        self._inflight: Optional[Tuple[List[Tuple[int, list]], PendingFlush]] = None
+        # pipeline_depth groups in flight (default ONE): launching group g tokenises / packs / enqueues it and only THEN copies group
+        # g - pipeline_depth's rows to the host, so the host side of a group (Python bookkeeping, tokeniser, Pillow -> pinned staging) overlaps the
+        # previous groups' kernels.  pipeline_depth = 0: synchronous.
+        self.pipeline_depth = PIPELINE_DEPTH
+        self._inflight_q: List[Tuple[List[Tuple[int, list]], PendingFlush]] = []      # launched groups, oldest first
         # submit() / drain() / collect() and the deadline thread all mutate the state above: one re-entrant lock, held across a launch
         self._lock = threading.RLock()
         self._cv = threading.Condition(self._lock)
@@ -484,10 +485,16 @@ class RequestShardedIngest:
             return
         self._file(group, out)
 
-    def _settle(self, reraise: bool) -> None:
-        inflight, self._inflight = self._inflight, None
-        if inflight is not None:
-            self._resolve(inflight, reraise)
+    @property
+    def _inflight(self):
+        """the youngest group in flight (tests / diagnostics)"""
+        return self._inflight_q[-1] if self._inflight_q else None
+
+    def _settle(self, reraise: bool, keep: int = 0) -> None:
+        """file the rows of all but the `keep` youngest groups in flight, oldest first; `reraise`: raise the LAST settled group's error"""
+        while len(self._inflight_q) > keep:
+            inflight = self._inflight_q.pop(0)
+            self._resolve(inflight, reraise and len(self._inflight_q) == keep)
 
     def _launch_open(self, raise_for: Optional[int] = None) -> None:
         """(lock held) everything waiting becomes ONE group: queued, tokenised / packed / enqueued now; the previous group's rows are filed
@@ -513,11 +520,11 @@ class RequestShardedIngest:
             self._settle(reraise=False)            # rows are filed in submission order: the group in flight first
             self._run_alone(group, raise_for)
             return
-        previous, self._inflight = self._inflight, (group, handle)
-        if previous is not None:
-            self._resolve(previous, reraise=False)
+        self._inflight_q.append((group, handle))
         if self.pipeline_depth <= 0:
             self._settle(reraise=raise_for is not None and len(group) == 1)
+        else:
+            self._settle(reraise=False, keep=self.pipeline_depth)
 
     def _open_is_full(self) -> bool:
         return (self.merge_images <= 0 or self._open_images >= self.merge_images or self._open_tokens >= self.merge_text_tokens

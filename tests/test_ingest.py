@@ -452,3 +452,25 @@ def test_the_deadline_launches_a_partial_group():
     ing.close()
     ing._deadline_thread.join(2)
     assert not ing._deadline_thread.is_alive()
+
+
+def test_two_groups_in_flight_keep_submission_order():
+    """pipeline_depth = 2: rows of group g are filed when group g + 2 is launched; order and failure isolation as with one group in flight"""
+    from marqo_amd.ingest import RequestShardedIngest
+    calls = []
+    ing = RequestShardedIngest("m", "cpu", vectorise_fn=_numbered(calls), merge_images=4, merge_deadline_ms=0)
+    ing.pipeline_depth = 2
+    for i in range(8):
+        if i == 3:
+            with pytest.raises(OSError):              # request 3 launches its own group and is the bad one: raised to its submitter
+                ing.submit(i, _req(i, bad=0))
+        else:
+            ing.submit(i, _req(i))
+        assert len(ing._inflight_q) <= 2
+    # groups [0,1] [2,3] [4,5] [6,7]; [2,3] fails on the host when it is launched: the group in flight is settled first, then 2 runs alone, 3 is recorded
+    assert ing.groups_launched == [[0, 1], [2, 3], [4, 5], [6, 7]] and ing.failed == [3]
+    assert [i for i, _ in ing._index] == [0] * 4 + [1] * 4 + [2] * 4          # [4,5] and [6,7] are still in flight
+    rows = ing.collect()
+    assert sorted(rows) == [0, 1, 2, 4, 5, 6, 7] and ing.failed_requests == [3] and ing._inflight is None
+    for i in rows:
+        _check_rows(rows, i)

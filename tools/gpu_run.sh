@@ -13,6 +13,7 @@ OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 REPO=$PWD
+NPY=0
 line() { python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); pf=d['roofline']['per_family']
@@ -50,7 +51,7 @@ for stage in "$@"; do
       rm -f $OUT/pmc_FETCH_SIZE/*.db $OUT/pmc_WRITE_SIZE/*.db $OUT/pmc_SQ/*.db
       grep -E "gemm|layernorm|attention|patchify" $OUT/traffic.txt | cut -c1-140; cat $OUT/sq.txt ;;
     e2e) timeout 300 python tools/e2e_quick.py 2>/dev/null | tail -1 | tee -a $OUT/e2e.txt ;;
-    py) timeout 900 python $arg 2>&1 | tail -40 | tee $OUT/py.txt ;;
+    py) NPY=$((NPY+1)); timeout 900 python $arg 2>&1 | tail -60 | tee $OUT/py_$NPY.txt ;;
     *) echo "unknown stage $stage" ;;
   esac
 done

@@ -52,11 +52,18 @@ for m in merges:            # every group shape once, untimed (workspaces, pinne
     ing.collect()
 for rep in range(3):
     for m in merges:
-        for depth in ((0, 1) if m == 0 or rep == 0 else (1,)):
+        for depth in ((0, 1) if m == 0 or rep == 0 else (1, 2)):
             ing.merge_images = m
             n = 96 if m else 32
             ms = run(depth, n) * 1e3
             print(f"merge_images={m:5d} pipeline_depth={depth}: {ms:.3f} ms per {docs}-document request = {2 * docs / ms * 1e3:.0f} embeddings/s", flush=True)
+# text and image towers of a group on ONE host thread / HIP stream (two_threads off) against the default two
+for rep in range(2):
+    for two in (True, False):
+        ing.merge_images, ing._bulk.two_threads = 512, two
+        ms = run(1, 96) * 1e3
+        print(f"merge_images=  512 pipeline_depth=1 two_threads={two}: {ms:.3f} ms per request = {2 * docs / ms * 1e3:.0f} embeddings/s", flush=True)
+ing._bulk.two_threads = True
 ing.pipeline_depth = 1
 ing.merge_images = merges[-1] if len(sys.argv) > 2 else 512
 pr = cProfile.Profile()
