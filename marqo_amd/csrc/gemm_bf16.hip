@@ -85,20 +85,26 @@ __device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_in
 // pieces where the 160x128 tile has 20 per 9 and 9 — one workgroup per CU (128 KiB of LDS, 256 accumulator registers per lane: the allocator
 // puts them in AGPRs), everything else — staging, swizzle, the register double-buffering, the hand-placed waits — is the same code.
 // ORD: order of the second half's side work — 0: LDS-DMA pieces first, then the next stage's fragment reads; 1: reads first; 2: alternating
-template <int FLAGS, int MT, int NH, int ORD>
-__global__ __launch_bounds__(256, NH == 1 ? 2 : 1) void gemm_nt_kernel(
+// WM: waves along M (the workgroup is WM x 2 wave64s).  WM = 2: the 4-wave kernels above.  WM = 4 (round 5, second attempt at the big tile): 8 waves,
+// (64*MT) x (128*NH) — at MT = 4, NH = 2 the 256x256x64 macro-tile as 64x128 per wave, ONE workgroup per CU but TWO waves per SIMD again: what
+// sank the 4-wave wide tile (profiles/r05a) is that a wave alone on its SIMD has nobody to cover its LDS-DMA issue stalls; here a wave issues
+// 8 pieces per 64 MFMAs (160x128: 9 per 40) and its partner on the SIMD computes meanwhile.
+template <int FLAGS, int MT, int NH, int WM, int ORD>
+__global__ __launch_bounds__(128 * WM, (NH == 1 && WM == 2) ? 2 : 1) void gemm_nt_kernel(
     const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ Wt, int64_t ldw,
     const float* __restrict__ bias, const float* residual, void* out, int64_t ldc,
     int M, int N, int K, int tiles_n, int num_tiles, int cgroup, int band_rows, int wide_store,
     unsigned a_bytes, unsigned w_bytes, GemmLn ln) {
-    constexpr int BM = 32 * MT, BN = 128 * NH;
-    constexpr int NTW = 4 * NH;     // 16-column W sub-tiles per wave
+    constexpr int BM = 16 * MT * WM, BN = 128 * NH;
+    constexpr int NTW = 4 * NH;     // 16-column W sub-tiles per wave (a wave spans half of BN)
     constexpr int A_TILE_BYTES = BM * BK * 2, W_TILE_BYTES = BN * BK * 2;
     constexpr int STAGE_BYTES = A_TILE_BYTES + W_TILE_BYTES;
-    constexpr int NL = MT + NTW;    // LDS-DMA pieces (1 KiB each) per wave per stage = fragment reads per wave per k-half
+    constexpr int NPA = MT, NPW = 8 * NH / WM;   // LDS-DMA pieces (8 rows = 1 KiB each) per wave per stage: A rows BM / (2 WM), W rows BN / (2 WM)
+    constexpr int NLD = NPA + NPW;  // ... in all
+    constexpr int NLR = MT + NTW;   // fragment reads per wave per k-half (= NLD in the 4-wave kernels)
     constexpr int NM = NTW * MT;    // MFMAs per wave per k-half
     // residual rows prefetched together by the epilogue (16-row units): the next tile's first fragments are live across it
-    constexpr int ERG = !(FLAGS & MQ_EPI_RESIDUAL) ? MT : NH == 2 ? MT : (FLAGS & MQ_EPI_OUT_F32) ? (MT <= 3 ? MT : (MT + 1) / 2) : (MT <= 5 ? MT : 3);
+    constexpr int ERG = !(FLAGS & MQ_EPI_RESIDUAL) ? MT : (NH == 2 || WM == 4) ? MT : (FLAGS & MQ_EPI_OUT_F32) ? (MT <= 3 ? MT : (MT + 1) / 2) : (MT <= 5 ? MT : 3);
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     // ---- XCD-aware, bijective (virtual) block -> tile map, L2-blocked order inside an XCD's share (as in rounds 1-3) --------------
@@ -132,12 +138,12 @@ __global__ __launch_bounds__(256, NH == 1 ? 2 : 1) void gemm_nt_kernel(
     const int wm = wave >> 1, wn = wave & 1;
     const int l15 = lane & 15, g = lane >> 4;
 
-    // ---- staging: wave w owns A rows [8*MT*w, 8*MT*(w+1)) and W rows [32*NH*w, 32*NH*(w+1)) of a stage, 8 rows per LDS-DMA piece.
+    // ---- staging: wave w owns A rows [8*MT*w, 8*MT*(w+1)) and W rows [8*NPW*w, 8*NPW*(w+1)) of a stage, 8 rows per LDS-DMA piece.
     // lane -> (row = base + lane/8, physical 16-B chunk = lane%8); it fetches logical chunk (lane%8) ^ (row&7) of that row, so physical
     // chunk p of row r holds logical chunk p ^ (r&7) (the swizzle lives on the SOURCE address; the LDS image is lane-linear).
     const int srow = lane >> 3;
     const unsigned chunk_off = (unsigned)(((lane & 7) ^ (srow & 7)) * 16);   // (row & 7) == (srow & 7): piece bases are multiples of 8 rows
-    unsigned a_vo[MT], w_vo[NTW];
+    unsigned a_vo[NPA], w_vo[NPW];
     auto set_sources = [&](int m0, int n0) {
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
@@ -145,8 +151,8 @@ __global__ __launch_bounds__(256, NH == 1 ? 2 : 1) void gemm_nt_kernel(
             a_vo[i] = (unsigned)gm * (unsigned)lda * 2u + chunk_off;
         }
 #pragma unroll
-        for (int i = 0; i < NTW; ++i) {
-            int gn = n0 + wave * (8 * NTW) + i * 8 + srow; gn = gn < N ? gn : N - 1;
+        for (int i = 0; i < NPW; ++i) {
+            int gn = n0 + wave * (8 * NPW) + i * 8 + srow; gn = gn < N ? gn : N - 1;
             w_vo[i] = (unsigned)gn * (unsigned)ldw * 2u + chunk_off;
         }
     };
@@ -162,11 +168,11 @@ __global__ __launch_bounds__(256, NH == 1 ? 2 : 1) void gemm_nt_kernel(
         set_sources(m0, n0);
     }
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    const unsigned dma_a0 = lds0 + (unsigned)wave * (8 * MT * 128), dma_w0 = lds0 + A_TILE_BYTES + (unsigned)wave * (8 * NTW * 128);   // scalars
+    const unsigned dma_a0 = lds0 + (unsigned)wave * (8 * MT * 128), dma_w0 = lds0 + A_TILE_BYTES + (unsigned)wave * (8 * NPW * 128);   // scalars
     auto issue_piece = [&](int i, unsigned bufoff) {
         const unsigned soff = (unsigned)d_k * (BK * 2);
-        if (i < MT) dma16(__builtin_amdgcn_make_buffer_rsrc((void*)A, 0, a_rec, 0x00020000), a_vo[i < MT ? i : 0], soff, dma_a0 + bufoff + (unsigned)i * 1024u);
-        else dma16(__builtin_amdgcn_make_buffer_rsrc((void*)Wt, 0, w_rec, 0x00020000), w_vo[i >= MT ? i - MT : 0], soff, dma_w0 + bufoff + (unsigned)(i - MT) * 1024u);
+        if (i < NPA) dma16(__builtin_amdgcn_make_buffer_rsrc((void*)A, 0, a_rec, 0x00020000), a_vo[i < NPA ? i : 0], soff, dma_a0 + bufoff + (unsigned)i * 1024u);
+        else dma16(__builtin_amdgcn_make_buffer_rsrc((void*)Wt, 0, w_rec, 0x00020000), w_vo[i >= NPA ? i - NPA : 0], soff, dma_w0 + bufoff + (unsigned)(i - NPA) * 1024u);
     };
     auto advance_cursor = [&]() {
         if (++d_k == nk) {
@@ -199,15 +205,15 @@ __global__ __launch_bounds__(256, NH == 1 ? 2 : 1) void gemm_nt_kernel(
 
     // ---- prologue: the workgroup's first two stages, then the kk = 0 fragments of the first -----------------------------------------
 #pragma unroll
-    for (int i = 0; i < NL; ++i) issue_piece(i, 0);
+    for (int i = 0; i < NLD; ++i) issue_piece(i, 0);
     advance_cursor();
 #pragma unroll
-    for (int i = 0; i < NL; ++i) issue_piece(i, STAGE_BYTES);
+    for (int i = 0; i < NLD; ++i) issue_piece(i, STAGE_BYTES);
     advance_cursor();
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");   // stage 0 landed (loads retire in issue order)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");   // stage 0 landed (loads retire in issue order)
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    static_for<NL>([&](auto p_tag) { read_piece(p_tag, wB0, aB0, wf0, af0); });
+    static_for<NLR>([&](auto p_tag) { read_piece(p_tag, wB0, aB0, wf0, af0); });
 
     unsigned bufoff = 0;   // LDS byte offset of the stage the next k-step consumes
     int c_vbid = blockIdx.x;
@@ -223,11 +229,11 @@ __global__ __launch_bounds__(256, NH == 1 ? 2 : 1) void gemm_nt_kernel(
         __builtin_amdgcn_sched_barrier(0);
         {
             const unsigned wb = wB1 + bufoff, ab = aB1 + bufoff;
-            constexpr int NS1 = NL;   // side work of the first half: the NL fragment reads of kk = 1
+            constexpr int NS1 = NLR;  // side work of the first half: the NLR fragment reads of kk = 1
             static_for<NM>([&](auto idx_tag) {
                 constexpr int idx = decltype(idx_tag)::value, mt = idx / NTW, nt = idx % NTW;
                 acc[nt / 4][mt][nt % 4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[nt], af0[mt], acc[nt / 4][mt][nt % 4], 0, 0, 0);
-                constexpr int RG = NM / NL > 0 ? NM / NL : 1;   // one read per RG MFMAs; the last MFMA flushes whatever is left
+                constexpr int RG = NM / NLR > 0 ? NM / NLR : 1;   // one read per RG MFMAs; the last MFMA flushes whatever is left
                 constexpr int lo = idx == 0 ? 0 : (idx / RG < NS1 ? idx / RG : NS1);
                 constexpr int hi = idx == NM - 1 ? NS1 : ((idx + 1) / RG < NS1 ? (idx + 1) / RG : NS1);
                 static_for<hi - lo>([&](auto p_tag) {
@@ -250,13 +256,13 @@ __global__ __launch_bounds__(256, NH == 1 ? 2 : 1) void gemm_nt_kernel(
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        // -------- second half: MFMAs on (wf1, af1); side work: the NL DMA pieces of the stage after next (into the buffer this step
-        // just finished with) and the NL reads of the next stage's kk = 0 fragments (the next tile's first stage at a tile's last step;
+        // -------- second half: MFMAs on (wf1, af1); side work: the NLD DMA pieces of the stage after next (into the buffer this step
+        // just finished with) and the NLR reads of the next stage's kk = 0 fragments (the next tile's first stage at a tile's last step;
         // stale bytes nobody uses at the workgroup's very last step)
         {
             const unsigned nb = bufoff ^ (unsigned)STAGE_BYTES;
             const unsigned wb = wB0 + nb, ab = aB0 + nb;
-            constexpr int NSIDE = 2 * NL;
+            constexpr int NSIDE = NLD + NLR;
             static_for<NM>([&](auto idx_tag) {
                 constexpr int idx = decltype(idx_tag)::value, mt = idx / NTW, nt = idx % NTW;
                 acc[nt / 4][mt][nt % 4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[nt], af1[mt], acc[nt / 4][mt][nt % 4], 0, 0, 0);
@@ -265,8 +271,10 @@ __global__ __launch_bounds__(256, NH == 1 ? 2 : 1) void gemm_nt_kernel(
                 static_for<hi - lo>([&](auto it_tag) {
                     constexpr int it = lo + decltype(it_tag)::value;
                     __builtin_amdgcn_sched_barrier(0);
-                    constexpr bool is_dma = ORD == 0 ? it < NL : ORD == 1 ? it >= NL : (it & 1) == 0;
-                    constexpr int ord = ORD == 2 ? it / 2 : it % NL;        // its number among the pieces of its kind
+                    // its kind and its number among the items of that kind; ORD 2 with unequal counts (8 waves): evenly spread (Bresenham)
+                    constexpr int dma_before = (it * NLD) / NSIDE;
+                    constexpr bool is_dma = ORD == 0 ? it < NLD : ORD == 1 ? it >= NLR : NLD == NLR ? (it & 1) == 0 : ((it + 1) * NLD) / NSIDE > dma_before;
+                    constexpr int ord = ORD == 0 ? (is_dma ? it : it - NLD) : ORD == 1 ? (is_dma ? it - NLR : it) : NLD == NLR ? it / 2 : (is_dma ? dma_before : it - dma_before);
                     if constexpr (is_dma) issue_piece(ord, bufoff);
                     else read_piece(std::integral_constant<int, ord>{}, wb, ab, wf0, af0);
                     __builtin_amdgcn_sched_barrier(0);
@@ -298,10 +306,10 @@ __global__ __launch_bounds__(256, NH == 1 ? 2 : 1) void gemm_nt_kernel(
         // (wide tile: the lane's row / column ids pass through an empty asm, so that the epilogue's address arithmetic is redone per tile instead of
         // being hoisted out of the tile loop — kept live across the k-loop next to 128 fragment registers it spilled)
         int l15e = l15, ge = g;
-        if (NH == 2) asm volatile("" : "+v"(l15e), "+v"(ge));
+        if (NH == 2 || WM == 4) asm volatile("" : "+v"(l15e), "+v"(ge));
         static_for<NH>([&](auto h_tag) {
             constexpr int h = decltype(h_tag)::value;
-            gemm_epilogue<FLAGS, MT, ERG, true, NH == 2>(acc[h], bias, residual, out, ldc, M, N, cm0 + wm * (16 * MT), cn0 + wn * (16 * NTW) + h * 64, l15e, ge, wide_store != 0, &ln, nullptr);
+            gemm_epilogue<FLAGS, MT, ERG, true, NH == 2 && WM == 2>(acc[h], bias, residual, out, ldc, M, N, cm0 + wm * (16 * MT), cn0 + wn * (16 * NTW) + h * 64, l15e, ge, wide_store != 0, &ln, nullptr);
         });
 
         c_vbid += gridDim.x;
@@ -315,7 +323,10 @@ __global__ __launch_bounds__(256, NH == 1 ? 2 : 1) void gemm_nt_kernel(
 #ifndef MQ_GEMM_PROBE_NH
 #define MQ_GEMM_PROBE_NH 1
 #endif
-__attribute__((used)) void* mq_gemm_probe() { return (void*)gemm_nt_kernel<MQ_GEMM_PROBE, MQ_GEMM_PROBE_MT, MQ_GEMM_PROBE_NH, 2>; }
+#ifndef MQ_GEMM_PROBE_WM
+#define MQ_GEMM_PROBE_WM 2
+#endif
+__attribute__((used)) void* mq_gemm_probe() { return (void*)gemm_nt_kernel<MQ_GEMM_PROBE, MQ_GEMM_PROBE_MT, MQ_GEMM_PROBE_NH, MQ_GEMM_PROBE_WM, 2>; }
 }  // namespace
 #else
 constexpr int RESIDENT_SLOTS = 512;       // 256 CUs x 2 workgroups (NH = 1)
@@ -324,7 +335,7 @@ constexpr int WIDE_MT = 7;                // the wide tile is 224 x 256 (MT = 8 
 
 // tuning knobs: initialised from the environment (MQ_GEMM_MT / _CGROUP / _NH), overridable through mq_tune()
 struct GemmTune {
-    int mt, cgroup, nh, ord = 2;
+    int mt, cgroup, nh, ord = 2, wide_mt = 3;
     static int env(const char* k, int d) { const char* v = getenv(k); return v ? atoi(v) : d; }
     GemmTune() : mt(env("MQ_GEMM_MT", 0)), cgroup(env("MQ_GEMM_CGROUP", 8)), nh(env("MQ_GEMM_NH", 0)) {}
 };
@@ -357,14 +368,14 @@ int choose_mt(int M, int N) {
     return best;
 }
 
-template <int FLAGS, int MT, int NH = 1, int ORD = 2>
+template <int FLAGS, int MT, int NH = 1, int ORD = 2, int WM = 2>
 int launch_gemm_mt(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* residual, void* out, int64_t ldc,
                    int M, int N, int K, hipStream_t s, const GemmLn& ln) {
-    constexpr int BM = 32 * MT, BN = 128 * NH;
+    constexpr int BM = 16 * MT * WM, BN = 128 * NH;
     constexpr int LDS = 2 * (BM + BN) * BK * 2;
-    constexpr int SLOTS = NH == 1 ? RESIDENT_SLOTS : RESIDENT_SLOTS_WIDE;
+    constexpr int SLOTS = (NH == 1 && WM == 2) ? RESIDENT_SLOTS : RESIDENT_SLOTS_WIDE;
     static std::atomic<uint64_t> attr_done{0};
-    auto kern = gemm_nt_kernel<FLAGS, MT, NH, ORD>;
+    auto kern = gemm_nt_kernel<FLAGS, MT, NH, WM, ORD>;
     if (hipError_t e = mq_ensure_dyn_lds((const void*)kern, LDS, attr_done); e != hipSuccess) {
         mq_set_error("mq_gemm_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e));
         return MQ_ERR_HIP;
@@ -399,7 +410,7 @@ int launch_gemm_mt(const void* A, int64_t lda, const void* W, int64_t ldw, const
         GemmLn ln_chunk = ln;
         if (ln_chunk.rowstats) ln_chunk.rowstats += r0;
         if (ln_chunk.partials) ln_chunk.partials += r0 * ln_chunk.nslots;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS, s, (const bf16_t*)A + r0 * lda, lda, (const bf16_t*)W, ldw, bias,
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(128 * WM), LDS, s, (const bf16_t*)A + r0 * lda, lda, (const bf16_t*)W, ldw, bias,
                            residual ? (const float*)((const char*)residual + (size_t)r0 * res_row) : nullptr, (void*)((char*)out + (size_t)r0 * out_row),
                            ldc, m, N, K, tiles_n, num_tiles, cgroup, band_rows, wide, (unsigned)a_bytes, (unsigned)w_bytes, ln_chunk);
         MQ_CHECK_LAUNCH("mq_gemm_bf16");
@@ -410,7 +421,7 @@ int launch_gemm_mt(const void* A, int64_t lda, const void* W, int64_t ldw, const
 // the wide (224 x 256, one workgroup per CU) tile pays where a k-loop is long enough to amortise a tile's un-overlapped prologue and epilogue and
 // where the tiles fill whole rounds of the 256 workgroups; mq_tune("gemm_nh", 2) forces it, 1 forbids it, 0 = this rule
 bool choose_wide(int M, int N, int K) {
-    if (g_tune.nh == 1 || N < 256) return false;
+    if (g_tune.nh == 1 || g_tune.nh == 3 || N < 256) return false;
     if (g_tune.nh == 2) return true;
     return false;
 }
@@ -418,6 +429,12 @@ bool choose_wide(int M, int N, int K) {
 template <int FLAGS>
 int launch_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* residual, void* out, int64_t ldc,
                 int M, int N, int K, hipStream_t s, const GemmLn& ln = GemmLn{}) {
+    if (g_tune.nh == 3 && N >= 256) {   // experiment (profiles/r05c): the 8-wave big tile, (64*MT) x 256, one workgroup per CU, two waves per SIMD
+        if constexpr (FLAGS == 0 || FLAGS == MQ_EPI_BIAS) {   // 256 x 256 fits the 256 registers of a 2-waves-per-SIMD lane only with the plain epilogues
+            if (g_tune.wide_mt == 4) return launch_gemm_mt<FLAGS, 4, 2, 2, 4>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s, ln);
+        }
+        return launch_gemm_mt<FLAGS, 3, 2, 2, 4>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s, ln);
+    }
     if (choose_wide(M, N, K)) {
         if constexpr (FLAGS == 0) {   // experiment (profiles/r05b): order of the second half's side work on the wide tile, plain epilogue only
             if (g_tune.ord == 0) return launch_gemm_mt<FLAGS, WIDE_MT, 2, 0>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s, ln);
@@ -527,6 +544,7 @@ extern "C" int mq_tune(const char* key, int value) {
     else if (k == "gemm_cgroup") mq_gemm_knob_cgroup = g_tune.cgroup = value;
     else if (k == "gemm_nh") g_tune.nh = value;
     else if (k == "gemm_wide_ord") g_tune.ord = value;
+    else if (k == "gemm_wide_mt") g_tune.wide_mt = value;
     else if (k == "row_select") mq_tower_row_select = value;
     else if (k == "ln_fold") mq_tower_ln_fold = value;
     else if (k == "xcd_band") mq_xcd_band = value;
