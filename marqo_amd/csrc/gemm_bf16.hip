@@ -314,6 +314,15 @@ __global__ __launch_bounds__(128 * WM, (NH == 1 && WM == 2) ? 2 : 1) void gemm_n
 
         c_vbid += gridDim.x;
         if (c_vbid >= num_tiles) break;
+        if (WM == 4) {
+            // 8-wave big tile: 128 accumulator + 96 fragment registers leave the epilogue no room when the next tile's first fragments are held
+            // across it (the 4-wave kernels do that).  Here the copy the last k-step fetched is dropped (retired and dead behind `landed` above) and
+            // the 12 reads are issued again now — the next tile's first stage sits untouched in the buffer at `bufoff` until its mid-step barrier;
+            // one exposed LDS latency per tile.
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<NLR>([&](auto p_tag) { read_piece(p_tag, wB0 + bufoff, aB0 + bufoff, wf0, af0); });
+        }
     }
     // the trailing (out-of-range) LDS-DMA requests must have retired before the workgroup's LDS can be handed to another one
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -426,15 +435,19 @@ bool choose_wide(int M, int N, int K) {
     return false;
 }
 
+// the 8-wave big tile (256 x 256, one workgroup per CU, two waves per SIMD: gemm_nt_kernel WM = 4): 1 440 TF/s at 8192^3 where the narrow tile
+// reaches 1 223 (profiles/r05c_gemm_big_tile_ab.txt) — its k-loop is ~18 % faster, but 256 workgroups of 256 x 256 quantise badly at the towers'
+// shapes.  mq_tune("gemm_nh", 3) forces it (N >= 256), 1 forbids it, 0 = this rule
+bool choose_big(int M, int N, int K) {
+    if (g_tune.nh == 1 || g_tune.nh == 2 || N < 256) return false;
+    if (g_tune.nh == 3) return true;
+    return false;
+}
+
 template <int FLAGS>
 int launch_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* residual, void* out, int64_t ldc,
                 int M, int N, int K, hipStream_t s, const GemmLn& ln = GemmLn{}) {
-    if (g_tune.nh == 3 && N >= 256) {   // experiment (profiles/r05c): the 8-wave big tile, (64*MT) x 256, one workgroup per CU, two waves per SIMD
-        if constexpr (FLAGS == 0 || FLAGS == MQ_EPI_BIAS) {   // 256 x 256 fits the 256 registers of a 2-waves-per-SIMD lane only with the plain epilogues
-            if (g_tune.wide_mt == 4) return launch_gemm_mt<FLAGS, 4, 2, 2, 4>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s, ln);
-        }
-        return launch_gemm_mt<FLAGS, 3, 2, 2, 4>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s, ln);
-    }
+    if (choose_big(M, N, K)) return launch_gemm_mt<FLAGS, 4, 2, 2, 4>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s, ln);
     if (choose_wide(M, N, K)) {
         if constexpr (FLAGS == 0) {   // experiment (profiles/r05b): order of the second half's side work on the wide tile, plain epilogue only
             if (g_tune.ord == 0) return launch_gemm_mt<FLAGS, WIDE_MT, 2, 0>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s, ln);

@@ -20,10 +20,10 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 BIAS, GELU, RESIDUAL, OUT_F32, ROW_STATS, LN_APPLY = 1, 2, 8, 16, 64, 128
 
 
-def _compile(tmp_path, flags, mt, src=SRC, rowscale=0, nh=1):
-    out = tmp_path / f"probe_{os.path.basename(src)}_{flags}_{mt}_{rowscale}_{nh}.s"
+def _compile(tmp_path, flags, mt, src=SRC, rowscale=0, nh=1, wm=2):
+    out = tmp_path / f"probe_{os.path.basename(src)}_{flags}_{mt}_{rowscale}_{nh}_{wm}.s"
     res = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wall", "-Wno-unused-function", "-Rpass-analysis=kernel-resource-usage",
-                          f"-DMQ_GEMM_PROBE={flags}", f"-DMQ_GEMM_PROBE_MT={mt}", f"-DMQ_GEMM_PROBE_ROWSCALE={rowscale}", f"-DMQ_GEMM_PROBE_NH={nh}", "-S", "--cuda-device-only", "-o", str(out), src],
+                          f"-DMQ_GEMM_PROBE={flags}", f"-DMQ_GEMM_PROBE_MT={mt}", f"-DMQ_GEMM_PROBE_ROWSCALE={rowscale}", f"-DMQ_GEMM_PROBE_NH={nh}", f"-DMQ_GEMM_PROBE_WM={wm}", "-S", "--cuda-device-only", "-o", str(out), src],
                          capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-3000:]
     return out.read_text(), res.stderr
@@ -53,31 +53,85 @@ def _check(isa, remarks, mfma_name, n_mfma, n_reads_expected, hot_regions=1):
         hot = body[mfma[r * per]:mfma[(r + 1) * per - 1] + 1]
         assert sum(1 for ln in hot if ln.startswith("s_waitcnt") and "vmcnt" in ln) == 1, [ln for ln in hot if "vmcnt" in ln]
         assert sum(1 for ln in hot if ln.startswith("s_barrier")) == 1
-    # 3. no instruction touches a register an inline-asm ds_read has written before the next lgkmcnt(0)
+    # 3. no instruction touches a register an inline-asm ds_read has written before the next lgkmcnt wait that covers it — followed along the
+    # control flow (the compiler lays blocks out of line: behind an unconditional branch the textually next instruction is NOT the next one executed)
     # (LDS operations return in order: `s_waitcnt lgkmcnt(N)` retires all but the N youngest reads)
-    reads, in_asm, n_reads = [], False, 0          # register sets of the un-retired asm reads, oldest first
-    for ln in body:
-        if ln.startswith(";;#ASMSTART"):
-            in_asm = True
-            continue
-        if ln.startswith(";;#ASMEND"):
-            in_asm = False
-            continue
-        m = re.search(r"lgkmcnt\((\d+)\)", ln) if ln.startswith("s_waitcnt") else None
+    label_re = re.compile(r"^(\.LBB\d+_\d+):")
+    blocks, order, cur = {"<entry>": []}, ["<entry>"], "<entry>"
+    for ln in lines:
+        m = label_re.match(ln)
         if m:
-            keep = int(m.group(1))
-            reads = reads[len(reads) - keep:] if keep else []
+            cur = m.group(1)
+            blocks[cur] = []
+            order.append(cur)
             continue
-        pending = set().union(*reads) if reads else set()
-        op, _, rest = ln.partition(" ")
-        if in_asm and op == "ds_read_b128":
-            dst, _, addr = rest.partition(",")
-            assert not (_regs(addr) & pending), f"asm read addresses through an un-waited register: {ln}"
-            reads.append(_regs(dst))
-            n_reads += 1
-            continue
-        touched = _regs(rest) & pending
-        assert not touched, f"{ln!r} touches v{sorted(touched)} before the s_waitcnt lgkmcnt that covers its ds_read_b128"
+        if ln and (not ln.startswith((";", ".", "//")) or ln.startswith(";;#ASM")):
+            blocks[cur].append(ln)
+
+    def successors(name):
+        out, falls = [], True
+        for ln in blocks[name]:
+            op, _, rest = ln.partition(" ")
+            if op.startswith("s_cbranch"):
+                out.append(rest.strip())
+            elif op == "s_branch":
+                out.append(rest.strip())
+                falls = False
+            elif op in ("s_endpgm", "s_setpc_b64"):
+                falls = False
+        i = order.index(name)
+        if falls and i + 1 < len(order):
+            out.append(order[i + 1])
+        return out
+
+    counted = set()
+
+    def run_block(name, pending_in):
+        """pending_in: tuple of frozensets (un-retired asm reads, oldest first) -> state at the end of the block"""
+        reads, in_asm = list(pending_in), False
+        for k, ln in enumerate(blocks[name]):
+            if ln.startswith(";;#ASMSTART"):
+                in_asm = True
+                continue
+            if ln.startswith(";;#ASMEND"):
+                in_asm = False
+                continue
+            m = re.search(r"lgkmcnt\((\d+)\)", ln) if ln.startswith("s_waitcnt") else None
+            if m:
+                keep = int(m.group(1))
+                reads = reads[len(reads) - keep:] if keep else []
+                continue
+            pending = set().union(*reads) if reads else set()
+            op, _, rest = ln.partition(" ")
+            if in_asm and op == "ds_read_b128":
+                dst, _, addr = rest.partition(",")
+                assert not (_regs(addr) & pending), f"asm read addresses through an un-waited register: {ln}"
+                reads.append(frozenset(_regs(dst)))
+                counted.add((name, k))
+                continue
+            touched = _regs(rest) & pending
+            assert not touched, f"{name}: {ln!r} touches v{sorted(touched)} before the s_waitcnt lgkmcnt that covers its ds_read_b128"
+        return tuple(reads)
+
+    state_in = {"<entry>": ()}
+    work = ["<entry>"]
+    while work:
+        name = work.pop()
+        out = run_block(name, state_in[name])
+        for nxt in successors(name):
+            if nxt not in blocks:
+                continue
+            old = state_in.get(nxt)
+            if old is None:
+                merged = out
+            elif old == out or not out:
+                merged = old
+            else:   # a join with different histories: everything pending on either path, as ONE oldest group (conservative)
+                merged = (frozenset().union(*old, *out),)
+            if merged != old:
+                state_in[nxt] = merged
+                work.append(nxt)
+    n_reads = len(counted)
     assert n_reads == n_reads_expected, n_reads
 
 
@@ -97,6 +151,17 @@ def test_wide_tile_follows_the_same_rules(tmp_path, flags):
     isa, remarks = _compile(tmp_path, flags, 7, nh=2)
     _check(isa, remarks, "v_mfma_f32_16x16x32_bf16", 2 * 8 * 7, 3 * (7 + 8))
     assert re.search(r"AGPRs: (\d+)", remarks) and int(re.search(r"AGPRs: (\d+)", remarks).group(1)) >= 224      # the accumulators live in the AGPR half
+
+
+@pytest.mark.skipif(not shutil.which(HIPCC), reason="hipcc not installed")
+@pytest.mark.parametrize("flags", [0, BIAS, BIAS | GELU, BIAS | RESIDUAL, BIAS | RESIDUAL | OUT_F32, BIAS | GELU | LN_APPLY, BIAS | RESIDUAL | ROW_STATS])
+def test_big_8_wave_tile_follows_the_same_rules(tmp_path, flags):
+    """round 5: the 256 x 256 tile of 8 waves (WM = 4, MT = 4, NH = 2: 64 x 128 per wave, two waves per SIMD, 8 LDS-DMA pieces and 12 fragment reads per
+    wave and k-half): the same loop — 2 * 32 MFMAs in ONE k-step body, one vmcnt wait, one barrier, no scratch inside the 256 registers of a
+    2-waves-per-SIMD lane; fragment reads: prologue + both half-steps + the re-read behind the epilogue = 4 * 12"""
+    isa, remarks = _compile(tmp_path, flags, 4, nh=2, wm=4)
+    _check(isa, remarks, "v_mfma_f32_16x16x32_bf16", 2 * 32, 4 * 12)
+    assert re.search(r"Occupancy \[waves/SIMD\]: 2\b", remarks)
 
 
 OUT_FP8 = 32

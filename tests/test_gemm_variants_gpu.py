@@ -146,8 +146,9 @@ def test_row_chunks_under_a_lowered_address_limit_are_bit_identical():
         assert torch.equal(x, y)
 
 
-def test_the_wide_tile_is_bit_identical_to_the_narrow_one():
-    """round 5: the 224 x 256 tile (mq_tune gemm_nh = 2) accumulates every output element over k in the same order as the (32*MT) x 128 tiles — same
+@pytest.mark.parametrize("nh", [2, 3])
+def test_the_wide_tile_is_bit_identical_to_the_narrow_one(nh):
+    """round 5: the 224 x 256 4-wave tile (mq_tune gemm_nh = 2) and the 256 x 256 8-wave tile (gemm_nh = 3) accumulate every output element over k in the same order as the (32*MT) x 128 tiles — same
     bits with every epilogue, on ragged shapes (M not a multiple of 224, N not a multiple of 256, N < 256 falls back to the narrow tile, K = 64: one
     k-step per tile); row statistics and the folded LayerNorm included; 20 repeated launches screen the LDS ring for races"""
     lib = L.load()
@@ -162,10 +163,10 @@ def test_the_wide_tile_is_bit_identical_to_the_narrow_one():
                      (L.MQ_EPI_BIAS | L.MQ_EPI_RESIDUAL | L.MQ_EPI_OUT_F32, res), (L.MQ_EPI_BIAS | L.MQ_EPI_RESIDUAL, res.to(torch.bfloat16))]
             _tune(lib, gemm_nh=1)
             base = [_gemm(lib, A, W, b, r, f) for f, r in forms]
-            _tune(lib, gemm_nh=2)
+            _tune(lib, gemm_nh=nh)
             for rep in range(20 if (M, N, K) == (12800, 768, 768) else 2):
                 wide = [_gemm(lib, A, W, b, r, f) for f, r in forms]
                 for x, y, (f, _) in zip(base, wide, forms):
-                    assert torch.equal(x, y), ((M, N, K), f, rep)
+                    assert torch.equal(x, y), (nh, (M, N, K), f, rep)
     finally:
         _tune(lib, **DEFAULTS)
