@@ -340,11 +340,10 @@ __attribute__((used)) void* mq_gemm_probe() { return (void*)gemm_nt_kernel<MQ_GE
 #else
 constexpr int RESIDENT_SLOTS = 512;       // 256 CUs x 2 workgroups (NH = 1)
 constexpr int RESIDENT_SLOTS_WIDE = 256;  // 256 CUs x 1 workgroup (NH = 2: 120 KiB of LDS)
-constexpr int WIDE_MT = 7;                // the wide tile is 224 x 256 (MT = 8 needs ~16 registers more than the 512 a lane has: it spills)
 
 // tuning knobs: initialised from the environment (MQ_GEMM_MT / _CGROUP / _NH), overridable through mq_tune()
 struct GemmTune {
-    int mt, cgroup, nh, ord = 2, wide_mt = 3;
+    int mt, cgroup, nh;
     static int env(const char* k, int d) { const char* v = getenv(k); return v ? atoi(v) : d; }
     GemmTune() : mt(env("MQ_GEMM_MT", 0)), cgroup(env("MQ_GEMM_CGROUP", 8)), nh(env("MQ_GEMM_NH", 0)) {}
 };
@@ -427,33 +426,73 @@ int launch_gemm_mt(const void* A, int64_t lda, const void* W, int64_t ldw, const
     return MQ_OK;
 }
 
-// the wide (224 x 256, one workgroup per CU) tile pays where a k-loop is long enough to amortise a tile's un-overlapped prologue and epilogue and
-// where the tiles fill whole rounds of the 256 workgroups; mq_tune("gemm_nh", 2) forces it, 1 forbids it, 0 = this rule
-bool choose_wide(int M, int N, int K) {
-    if (g_tune.nh == 1 || g_tune.nh == 3 || N < 256) return false;
-    if (g_tune.nh == 2) return true;
-    return false;
-}
+// ---- the BIG tile: 256 x 256 x 64 as 8 waves (gemm_nt_kernel WM = 4, MT = 4, NH = 2), one workgroup per CU, two waves per SIMD --------------------
+// Its k-loop is 14-18 % faster than the narrow tiles' (8192^3: 1 354-1 440 vs 1 162-1 223 TF/s; a wave issues 8 LDS-DMA pieces per 64 MFMAs instead of
+// 9 per 40 — profiles/r05c_gemm_big_tile_ab.txt), but 256 workgroups of 256 x 256 quantise badly: the towers' ViT-B/32 shapes (QKV 450 tiles = 1.76
+// rounds, out-proj 150 = 0.59) lose on it, and stream-K does not rescue them — with ~1 tile per workgroup nearly every tile is split, and 256 fp32
+// partials of 256 KB are as many bytes as the GEMM itself moves (built and dropped this round).  What does pay is a ROW SPLIT:
+// the big tile takes the leading rows as long as its tiles fill whole rounds of the 256 workgroups, the narrow kernel takes the few rows left
+// (ViT-L/14 at 128 images: 32 896 rows = 128 row tiles + 128 rows; 128 x {12, 16, 4} column tiles = exactly 6 / 8 / 2 rounds).  Same bits either way.
+// mq_tune("gemm_nh", 3) forces the big tile on every row (N >= 256), 1 forbids it, 0 = the plan below.
+// (The 4-wave 224 x 256 tile, NH = 2 / WM = 2 — one wave per SIMD — lost on every shape, profiles/r05a, r05b: it is not instantiated any more; the
+// template still takes it and tests/test_gemm_isa.py still checks its ISA.)
+constexpr double BIG_TILE_SPEEDUP = 1.12;   // k-loop advantage priced into the plan (measured 1.14-1.18 at full rounds)
 
-// the 8-wave big tile (256 x 256, one workgroup per CU, two waves per SIMD: gemm_nt_kernel WM = 4): 1 440 TF/s at 8192^3 where the narrow tile
-// reaches 1 223 (profiles/r05c_gemm_big_tile_ab.txt) — its k-loop is ~18 % faster, but 256 workgroups of 256 x 256 quantise badly at the towers'
-// shapes.  mq_tune("gemm_nh", 3) forces it (N >= 256), 1 forbids it, 0 = this rule
-bool choose_big(int M, int N, int K) {
-    if (g_tune.nh == 1 || g_tune.nh == 2 || N < 256) return false;
-    if (g_tune.nh == 3) return true;
-    return false;
+// rows (a multiple of 256, 0 = none) the big tile should take of an M x N x K problem
+int plan_big_rows(int M, int N, int K) {
+    if (g_tune.nh == 1 || N < 256 || K < 512) return 0;
+    if (g_tune.nh == 3) return M;                                   // forced: every row (a ragged last row tile is guarded)
+    const int tiles_n = (N + 255) / 256;
+    const double fill_n = (double)N / (tiles_n * 256.0);           // columns of the last tile column that exist
+    const int rt_max = M / 256;
+    if (rt_max < 16 || fill_n < 0.9) return 0;
+    // what the narrow kernel costs for m rows, in (32 rows x 128 columns x K) units per resident slot: rounds x (mt + per-tile overhead), as choose_mt prices it
+    auto narrow_cost = [&](int m) {
+        if (m <= 0) return 0.0;
+        const int mt = choose_mt(m, N);
+        const int64_t tiles = (int64_t)((m + 32 * mt - 1) / (32 * mt)) * ((N + 127) / 128);
+        return (double)((tiles + RESIDENT_SLOTS - 1) / RESIDENT_SLOTS) * (mt + 1.25);
+    };
+    // ... and the big tile for rt row tiles: a 256 x 256 tile is 16 such units on ONE slot per CU where the narrow kernel has two -> 8 per round and
+    // slot pair, divided by its speed-up; + the same per-tile overhead
+    auto big_cost = [&](int rt) {
+        const int64_t tiles = (int64_t)rt * tiles_n;
+        return (double)((tiles + RESIDENT_SLOTS_WIDE - 1) / RESIDENT_SLOTS_WIDE) * (8.0 / BIG_TILE_SPEEDUP + 1.25);
+    };
+    const double all_narrow = narrow_cost(M);
+    int best_rt = 0;
+    double best = all_narrow * 0.97;                                 // the split has to win by 3 % to be worth a second launch
+    for (int rt = rt_max; rt >= rt_max - 32 && rt >= 16; --rt) {
+        const double c = big_cost(rt) + narrow_cost(M - rt * 256);
+        if (c < best) { best = c; best_rt = rt; }
+    }
+    return best_rt * 256;
 }
 
 template <int FLAGS>
 int launch_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* residual, void* out, int64_t ldc,
                 int M, int N, int K, hipStream_t s, const GemmLn& ln = GemmLn{}) {
-    if (choose_big(M, N, K)) return launch_gemm_mt<FLAGS, 4, 2, 2, 4>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s, ln);
-    if (choose_wide(M, N, K)) {
-        if constexpr (FLAGS == 0) {   // experiment (profiles/r05b): order of the second half's side work on the wide tile, plain epilogue only
-            if (g_tune.ord == 0) return launch_gemm_mt<FLAGS, WIDE_MT, 2, 0>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s, ln);
-            if (g_tune.ord == 1) return launch_gemm_mt<FLAGS, WIDE_MT, 2, 1>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s, ln);
+    const int big_rows = plan_big_rows(M, N, K);
+    if (big_rows >= M) return launch_gemm_mt<FLAGS, 4, 2, 2, 4>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s, ln);
+    if (big_rows > 0) {
+        // leading rows on the big tile, the rest on the narrow one (rows are independent: row-offset views of every row-indexed operand)
+        if (int rc = launch_gemm_mt<FLAGS, 4, 2, 2, 4>(A, lda, W, ldw, bias, residual, out, ldc, big_rows, N, K, s, ln); rc != MQ_OK) return rc;
+        const size_t out_row = (size_t)ldc * ((FLAGS & MQ_EPI_OUT_F32) ? 4 : 2);
+        const size_t res_row = (size_t)ldc * (((FLAGS & MQ_EPI_RESIDUAL) && !(FLAGS & MQ_EPI_OUT_F32)) ? 2 : 4);
+        GemmLn ln2 = ln;
+        if (ln2.rowstats) ln2.rowstats += big_rows;
+        if (ln2.partials) ln2.partials += (int64_t)big_rows * ln2.nslots;
+        A = (const bf16_t*)A + (int64_t)big_rows * lda;
+        if (residual) residual = (const float*)((const char*)residual + (size_t)big_rows * res_row);
+        out = (char*)out + (size_t)big_rows * out_row;
+        M -= big_rows;
+        const int mt2 = g_tune.mt ? g_tune.mt : choose_mt(M, N);
+        switch (mt2) {
+            case 2: return launch_gemm_mt<FLAGS, 2>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s, ln2);
+            case 5: return launch_gemm_mt<FLAGS, 5>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s, ln2);
+            case 6: return launch_gemm_mt<FLAGS, 6>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s, ln2);
+            default: return launch_gemm_mt<FLAGS, 4>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s, ln2);
         }
-        return launch_gemm_mt<FLAGS, WIDE_MT, 2>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s, ln);
     }
     const int mt = g_tune.mt ? g_tune.mt : choose_mt(M, N);
     switch (mt) {
@@ -549,15 +588,13 @@ extern "C" int mq_gemm_bf16_rs(const void* d_A, int64_t lda, const void* d_W, in
 // Run-time knobs (A/B benchmarking and the parity tests of every code path in one process).  TEST / BENCH ONLY: plain ints read by the
 // launch code of every request thread without synchronisation — set them while no request is in flight (the loaders never touch them).
 // keys: "gemm_mt" (0 = auto, else tile height in 32-row units), "gemm_cgroup", "row_select", "ln_fold", "residual_bf16", "small_m", "small_m_grouped",
-// "ln_prefetch", "xcd_band", "attn_waves", "gemm_addr_limit_mb", "gemm_nh" (0 = auto, 1 = (32*MT) x 128 tiles only, 2 = the wide 224 x 256 tile wherever N >= 256).
+// "ln_prefetch", "xcd_band", "attn_waves", "gemm_addr_limit_mb", "gemm_nh" (0 = auto: the row-split plan, 1 = (32*MT) x 128 tiles only, 3 = the big 256 x 256 tile on every row wherever N >= 256).
 extern "C" int mq_tune(const char* key, int value) {
     MQ_CHECK_ARG(key, "mq_tune: null key");
     const std::string k(key);
     if (k == "gemm_mt") { g_tune.mt = value; mq_gemm_fp8_force_mt = value; }
     else if (k == "gemm_cgroup") mq_gemm_knob_cgroup = g_tune.cgroup = value;
     else if (k == "gemm_nh") g_tune.nh = value;
-    else if (k == "gemm_wide_ord") g_tune.ord = value;
-    else if (k == "gemm_wide_mt") g_tune.wide_mt = value;
     else if (k == "row_select") mq_tower_row_select = value;
     else if (k == "ln_fold") mq_tower_ln_fold = value;
     else if (k == "xcd_band") mq_xcd_band = value;

@@ -21,6 +21,14 @@ SHAPES = [
     ("l14 out", 16448, 1024, 1024, L.MQ_EPI_BIAS | L.MQ_EPI_RESIDUAL | L.MQ_EPI_OUT_F32),
     ("l14 fc1", 16448, 4096, 1024, L.MQ_EPI_BIAS | L.MQ_EPI_GELU),
     ("l14 fc2", 16448, 1024, 4096, L.MQ_EPI_BIAS | L.MQ_EPI_RESIDUAL | L.MQ_EPI_OUT_F32),
+    ("l14x128 qkv", 32896, 3072, 1024, L.MQ_EPI_BIAS),                       # ViT-L/14 at 128 images (bench configs[2]): the bf16 residual stream forms
+    ("l14x128 out16", 32896, 1024, 1024, L.MQ_EPI_BIAS | L.MQ_EPI_RESIDUAL),
+    ("l14x128 fc1", 32896, 4096, 1024, L.MQ_EPI_BIAS | L.MQ_EPI_GELU),
+    ("l14x128 fc2_16", 32896, 1024, 4096, L.MQ_EPI_BIAS | L.MQ_EPI_RESIDUAL),
+    ("l14x240 qkv", 61680, 3072, 1024, L.MQ_EPI_BIAS),                       # 240 crops (configs[4])
+    ("l14x240 fc2_16", 61680, 1024, 4096, L.MQ_EPI_BIAS | L.MQ_EPI_RESIDUAL),
+    ("text qkv", 78848, 1536, 512, L.MQ_EPI_BIAS),                           # CLIP text B/32, 1024 x 77 rows
+    ("bert fc1", 78848, 3072, 768, L.MQ_EPI_BIAS | L.MQ_EPI_GELU),           # e5-base, 1024 x 77 rows
     ("epi fc1 f32out", 12800, 3072, 768, L.MQ_EPI_OUT_F32),
     ("epi fc1 bf16", 12800, 3072, 768, 0),
     ("epi fc1 bias", 12800, 3072, 768, L.MQ_EPI_BIAS),

@@ -9,13 +9,13 @@ from marqo_amd import _lib as L
 
 lib = L.load()
 variants = []
-for spec in (sys.argv[1] if len(sys.argv) > 1 else "w8m3:gemm_nh=3,gemm_wide_mt=3;w8m4:gemm_nh=3,gemm_wide_mt=4").split(";"):
+for spec in (sys.argv[1] if len(sys.argv) > 1 else "auto:gemm_nh=0;big:gemm_nh=3").split(";"):
     name, _, kv = spec.partition(":")
     variants.append((name, [(k, int(v)) for k, v in (p.split("=") for p in kv.split(",") if p)]))
 g = torch.Generator(device="cuda").manual_seed(3)
 s = torch.cuda.current_stream().cuda_stream
 bad = 0
-for (M, N, K) in [(12800, 768, 768), (4099, 2304, 768), (16448, 1024, 4096), (700, 260, 64), (256, 256, 128), (5000, 388, 192), (8192, 8192, 1024)]:
+for (M, N, K) in [(12800, 768, 768), (12800, 3072, 768), (4099, 2304, 768), (16448, 1024, 4096), (700, 260, 64), (256, 256, 128), (5000, 388, 192), (8192, 8192, 1024), (32896, 1024, 1024)]:
     A = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
     W = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).to(torch.bfloat16)
     b = torch.randn(N, device="cuda", generator=g)
