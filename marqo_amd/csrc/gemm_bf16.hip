@@ -430,10 +430,15 @@ int launch_gemm_mt(const void* A, int64_t lda, const void* W, int64_t ldw, const
 // Its k-loop is 14-18 % faster than the narrow tiles' (8192^3: 1 354-1 440 vs 1 162-1 223 TF/s; a wave issues 8 LDS-DMA pieces per 64 MFMAs instead of
 // 9 per 40 — profiles/r05c_gemm_big_tile_ab.txt), but 256 workgroups of 256 x 256 quantise badly: the towers' ViT-B/32 shapes (QKV 450 tiles = 1.76
 // rounds, out-proj 150 = 0.59) lose on it, and stream-K does not rescue them — with ~1 tile per workgroup nearly every tile is split, and 256 fp32
-// partials of 256 KB are as many bytes as the GEMM itself moves (built and dropped this round).  What does pay is a ROW SPLIT:
-// the big tile takes the leading rows as long as its tiles fill whole rounds of the 256 workgroups, the narrow kernel takes the few rows left
-// (ViT-L/14 at 128 images: 32 896 rows = 128 row tiles + 128 rows; 128 x {12, 16, 4} column tiles = exactly 6 / 8 / 2 rounds).  Same bits either way.
-// mq_tune("gemm_nh", 3) forces the big tile on every row (N >= 256), 1 forbids it, 0 = the plan below.
+// partials of 256 KB are as many bytes as the GEMM itself moves (built and dropped this round).  What is left is a ROW SPLIT: the
+// big tile takes the leading rows as long as its tiles fill whole rounds of the 256 workgroups, the narrow kernel takes the few rows left (ViT-L/14
+// at 128 images: 32 896 rows = 128 row tiles + 128 rows; 128 x {12, 16, 4} column tiles = exactly 6 / 8 / 2 rounds).  Same bits either way.
+// Measured (profiles/r05e_gemm_row_split_ab.txt): stand-alone -13...-15 % at 4096^3 / 8192^3, -4...-9 % at the ViT-L/14 x 128 shapes, -14 % on its fc2 at
+// 240 crops — but +16 % at K = 512, +5 % on some K = 1024 shapes, and INSIDE the towers nothing: ViT-L/14 dual 10 390 embeddings/s with and without.
+// The default plan therefore only takes long-K problems with a predicted gain of 8 % or more (square-ish GEMMs of the C ABI's mq_gemm_bf16, the
+// ViT-L/14 fc2 at large batches); the towers' other GEMMs stay on the narrow tile.
+// mq_tune("gemm_nh", 3) forces the big tile on every row (N >= 256), 4 = the row-split plan without the long-K / 8 % restriction (the A/B above),
+// 1 forbids it, 0 = the default plan.
 // (The 4-wave 224 x 256 tile, NH = 2 / WM = 2 — one wave per SIMD — lost on every shape, profiles/r05a, r05b: it is not instantiated any more; the
 // template still takes it and tests/test_gemm_isa.py still checks its ISA.)
 constexpr double BIG_TILE_SPEEDUP = 1.12;   // k-loop advantage priced into the plan (measured 1.14-1.18 at full rounds)
@@ -442,6 +447,8 @@ constexpr double BIG_TILE_SPEEDUP = 1.12;   // k-loop advantage priced into the 
 int plan_big_rows(int M, int N, int K) {
     if (g_tune.nh == 1 || N < 256 || K < 512) return 0;
     if (g_tune.nh == 3) return M;                                   // forced: every row (a ragged last row tile is guarded)
+    const bool eager = g_tune.nh == 4;
+    if (!eager && K < 2048) return 0;
     const int tiles_n = (N + 255) / 256;
     const double fill_n = (double)N / (tiles_n * 256.0);           // columns of the last tile column that exist
     const int rt_max = M / 256;
@@ -461,7 +468,7 @@ int plan_big_rows(int M, int N, int K) {
     };
     const double all_narrow = narrow_cost(M);
     int best_rt = 0;
-    double best = all_narrow * 0.97;                                 // the split has to win by 3 % to be worth a second launch
+    double best = all_narrow * (eager ? 0.97 : 0.92);               // what the split has to win to be worth a second launch (see the measurements above)
     for (int rt = rt_max; rt >= rt_max - 32 && rt >= 16; --rt) {
         const double c = big_cost(rt) + narrow_cost(M - rt * 256);
         if (c < best) { best = c; best_rt = rt; }
@@ -588,7 +595,7 @@ extern "C" int mq_gemm_bf16_rs(const void* d_A, int64_t lda, const void* d_W, in
 // Run-time knobs (A/B benchmarking and the parity tests of every code path in one process).  TEST / BENCH ONLY: plain ints read by the
 // launch code of every request thread without synchronisation — set them while no request is in flight (the loaders never touch them).
 // keys: "gemm_mt" (0 = auto, else tile height in 32-row units), "gemm_cgroup", "row_select", "ln_fold", "residual_bf16", "small_m", "small_m_grouped",
-// "ln_prefetch", "xcd_band", "attn_waves", "gemm_addr_limit_mb", "gemm_nh" (0 = auto: the row-split plan, 1 = (32*MT) x 128 tiles only, 3 = the big 256 x 256 tile on every row wherever N >= 256).
+// "ln_prefetch", "xcd_band", "attn_waves", "gemm_addr_limit_mb", "gemm_nh" (0 = default plan, 1 = (32*MT) x 128 tiles only, 3 = the big 256 x 256 tile on every row wherever N >= 256, 4 = the eager row-split plan).
 extern "C" int mq_tune(const char* key, int value) {
     MQ_CHECK_ARG(key, "mq_tune: null key");
     const std::string k(key);

@@ -146,9 +146,9 @@ def test_row_chunks_under_a_lowered_address_limit_are_bit_identical():
         assert torch.equal(x, y)
 
 
-@pytest.mark.parametrize("nh", [0, 3])
+@pytest.mark.parametrize("nh", [0, 4, 3])
 def test_the_wide_tile_is_bit_identical_to_the_narrow_one(nh):
-    """round 5: the 256 x 256 8-wave tile — on every row (gemm_nh = 3) and in the default row-split plan (gemm_nh = 0: leading rows on the big tile, the
+    """round 5: the 256 x 256 8-wave tile — on every row (gemm_nh = 3) and in the row-split plans (gemm_nh = 0 default, 4 eager: leading rows on the big tile, the
     rest on the narrow one) — accumulates every output element over k in the same order as the (32*MT) x 128 tiles — same
     bits with every epilogue, on ragged shapes (M not a multiple of 224, N not a multiple of 256, N < 256 falls back to the narrow tile, K = 64: one
     k-step per tile); row statistics and the folded LayerNorm included; 20 repeated launches screen the LDS ring for races"""

@@ -9,7 +9,7 @@ from marqo_amd import _lib as L
 
 lib = L.load()
 variants = []
-for spec in (sys.argv[1] if len(sys.argv) > 1 else "auto:gemm_nh=0;big:gemm_nh=3").split(";"):
+for spec in (sys.argv[1] if len(sys.argv) > 1 else "default:gemm_nh=0;eager:gemm_nh=4;big:gemm_nh=3").split(";"):
     name, _, kv = spec.partition(":")
     variants.append((name, [(k, int(v)) for k, v in (p.split("=") for p in kv.split(",") if p)]))
 g = torch.Generator(device="cuda").manual_seed(3)
