@@ -45,11 +45,6 @@ bool mq_gemm_small_ok(int64_t M, int64_t N, int64_t K, bool ln);
 bool mq_gemm_small_grouped_ok(int64_t M, int64_t N, int64_t K);
 extern int mq_gemm_small_group_rows;
 extern int mq_ln_prefetch;        // rowops.hip
-struct GemmLn;
-extern int mq_gemm_splitk_enabled;   // gemm_splitk.hip
-bool mq_gemm_splitk_ok(int64_t M, int64_t N, int64_t K);
-int mq_gemm_splitk(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* residual, void* out, int64_t ldc,
-                   int M, int N, int K, int flags, const GemmLn& ln, hipStream_t s);
 int mq_gemm_small(const void* d_A, int64_t lda, const void* d_W, int64_t ldw, const float* d_bias, const void* d_residual, void* d_out,
                   int64_t ldc, int64_t M, int64_t N, int64_t K, int flags, hipStream_t s);
 
@@ -443,8 +438,7 @@ int launch_gemm_mt(const void* A, int64_t lda, const void* W, int64_t ldw, const
 // The default plan therefore only takes long-K problems with a predicted gain of 8 % or more (square-ish GEMMs of the C ABI's mq_gemm_bf16, the
 // ViT-L/14 fc2 at large batches); the towers' other GEMMs stay on the narrow tile.
 // mq_tune("gemm_nh", 3) forces the big tile on every row (N >= 256), 4 = the row-split plan without the long-K / 8 % restriction (the A/B above),
-// 1 forbids it, 0 = the default plan.  Round 5, later: the rows left over take the split-K path of gemm_splitk.hip (mq_tune("gemm_splitk_rem", 0) = the narrow
-// kernel as before) — the second launch was what ate the gain inside the towers (profiles/r05g_l14_row_split_per_kernel.txt).
+// 1 forbids it, 0 = the default plan.
 // (The 4-wave 224 x 256 tile, NH = 2 / WM = 2 — one wave per SIMD — lost on every shape, profiles/r05a, r05b: it is not instantiated any more; the
 // template still takes it and tests/test_gemm_isa.py still checks its ISA.)
 constexpr double BIG_TILE_SPEEDUP = 1.12;   // k-loop advantage priced into the plan (measured 1.14-1.18 at full rounds)
@@ -454,7 +448,7 @@ int plan_big_rows(int M, int N, int K) {
     if (g_tune.nh == 1 || N < 256 || K < 512) return 0;
     if (g_tune.nh == 3) return M;                                   // forced: every row (a ragged last row tile is guarded)
     const bool eager = g_tune.nh == 4;
-    if (!eager && K < 1024) return 0;
+    if (!eager && K < 2048) return 0;
     const int tiles_n = (N + 255) / 256;
     const double fill_n = (double)N / (tiles_n * 256.0);           // columns of the last tile column that exist
     const int rt_max = M / 256;
@@ -462,8 +456,6 @@ int plan_big_rows(int M, int N, int K) {
     // what the narrow kernel costs for m rows, in (32 rows x 128 columns x K) units per resident slot: rounds x (mt + per-tile overhead), as choose_mt prices it
     auto narrow_cost = [&](int m) {
         if (m <= 0) return 0.0;
-        // a handful of rows left over: the split-K path (gemm_splitk.hip), ~8 us whatever K is; a unit is ~3.1 ns x K (ViT-L/14 QKV in the tower)
-        if (m < M && mq_gemm_splitk_ok(m, N, K)) return 2600.0 / K + 0.5;
         const int mt = choose_mt(m, N);
         const int64_t tiles = (int64_t)((m + 32 * mt - 1) / (32 * mt)) * ((N + 127) / 128);
         return (double)((tiles + RESIDENT_SLOTS - 1) / RESIDENT_SLOTS) * (mt + 1.25);
@@ -476,7 +468,7 @@ int plan_big_rows(int M, int N, int K) {
     };
     const double all_narrow = narrow_cost(M);
     int best_rt = 0;
-    double best = all_narrow * (eager ? 0.97 : 0.94);               // what the split has to win to be worth a second launch (see the measurements above)
+    double best = all_narrow * (eager ? 0.97 : 0.92);               // what the split has to win to be worth a second launch (see the measurements above)
     for (int rt = rt_max; rt >= rt_max - 32 && rt >= 16; --rt) {
         const double c = big_cost(rt) + narrow_cost(M - rt * 256);
         if (c < best) { best = c; best_rt = rt; }
@@ -501,7 +493,6 @@ int launch_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const fl
         if (residual) residual = (const float*)((const char*)residual + (size_t)big_rows * res_row);
         out = (char*)out + (size_t)big_rows * out_row;
         M -= big_rows;
-        if (mq_gemm_splitk_ok(M, N, K)) return mq_gemm_splitk(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, FLAGS, ln2, s);
         const int mt2 = g_tune.mt ? g_tune.mt : choose_mt(M, N);
         switch (mt2) {
             case 2: return launch_gemm_mt<FLAGS, 2>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s, ln2);
@@ -611,7 +602,6 @@ extern "C" int mq_tune(const char* key, int value) {
     if (k == "gemm_mt") { g_tune.mt = value; mq_gemm_fp8_force_mt = value; }
     else if (k == "gemm_cgroup") mq_gemm_knob_cgroup = g_tune.cgroup = value;
     else if (k == "gemm_nh") g_tune.nh = value;
-    else if (k == "gemm_splitk_rem") mq_gemm_splitk_enabled = value;
     else if (k == "row_select") mq_tower_row_select = value;
     else if (k == "ln_fold") mq_tower_ln_fold = value;
     else if (k == "xcd_band") mq_xcd_band = value;

@@ -37,17 +37,8 @@ for (M, N, K) in [(12800, 768, 768), (12800, 3072, 768), (4099, 2304, 768), (164
             for (f, r), want in zip(forms, base):
                 got = run(f, r)
                 if not torch.equal(got, want):
+                    bad += 1
                     d = (got.float() - want.float()).abs()
-                    rows = (d > 0).any(dim=1).nonzero().flatten()
-                    # the rows a row split leaves over go through split-K (gemm_splitk.hip): same sum, associated differently -> fp32-rounding
-                    # differences (one bf16 ulp after the store); anything else, or anywhere else, is a bug
-                    tol = 2e-2 if got.dtype == torch.bfloat16 else 1e-4
-                    rel = float(d.max()) / (float(want.float().abs().max()) + 1e-9)
-                    tail_only = int(rows.min()) >= (M // 256) * 256 - 256 * 32 and int(rows.min()) % 256 == 0 or int(rows.min()) >= M - 256
-                    if rel > tol or int(rows.min()) < M - 256:
-                        bad += 1
-                        print(f"MISMATCH {name} {(M, N, K)} flags={f} rep={rep}: max abs diff {float(d.max()):.3e} (rel {rel:.2e}), {int((d > 0).sum())} elements, rows {int(rows.min())}..{int(rows.max())}")
-                    elif rep == 0:
-                        print(f"  {name} {(M, N, K)} flags={f}: rows {int(rows.min())}..{int(rows.max())} differ by fp32 association only (rel {rel:.1e}): split-K remainder")
+                    print(f"MISMATCH {name} {(M, N, K)} flags={f} rep={rep}: max abs diff {float(d.max()):.3e}, {int((d > 0).sum())} elements")
         L.check(lib.mq_tune(b"gemm_nh", 0))
 print("gemm_check:", "all variants bit-identical to the narrow tile" if not bad else f"{bad} mismatches")
