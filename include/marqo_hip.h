@@ -45,7 +45,7 @@ extern "C" {
 #define MQ_ERR_HIP (-2)       /* a HIP runtime call or launch failed */
 #define MQ_ERR_WORKSPACE (-3) /* caller's workspace too small */
 
-#define MQ_ABI_VERSION 8
+#define MQ_ABI_VERSION 9
 
 /* ---- activation / mask / pooling selectors ---------------------------------------- */
 #define MQ_ACT_NONE 0
@@ -66,6 +66,9 @@ extern "C" {
 #define MQ_VIT_POOL_MAP 1 /* timm SigLIP ViT: attention-pool ('map') head */
 #define MQ_VIT_POOL_AVG 2 /* open_clip VisionTransformer pool_type 'avg' with final_ln_after_pool (CLIPA): mean of the patch tokens -> ln_post -> proj;
                            * ln_pre_g / ln_pre_b may be NULL (no_ln_pre) */
+#define MQ_VIT_POOL_QUERY 3 /* open_clip VisionTransformer with an AttentionalPooler behind it (CoCa, model_registry.py:344-370): class token and ln_pre as
+                             * in CLIP; every token runs every block; k | v = ln_k(x) @ kv_w^T + kv_b of width pool_dim, ONE query row (query 0 of the
+                             * learned queries, projected at load) -> out-projection -> ln_post -> proj.  mq_map_head carries the pooler (fc1 / fc2 NULL) */
 
 /* GEMM epilogue flags for mq_gemm_bf16 */
 #define MQ_EPI_BIAS 1      /* + bias[n] (fp32) */
@@ -180,6 +183,8 @@ typedef struct mq_vit_cfg {
     int32_t pool;        /* MQ_VIT_POOL_CLS (0): open_clip VisionTransformer — class token, ln_pre, ln_post(class token) @ proj;
                           * MQ_VIT_POOL_MAP (1): timm SigLIP ViT — no class token, no ln_pre, norm(all tokens) -> attention-pool head */
     int32_t map_mlp_dim; /* F of the attention-pool head's MLP (MQ_VIT_POOL_MAP) */
+    int32_t pool_dim;    /* MQ_VIT_POOL_QUERY: width Dp of the attentional pooler (keys, values, output; <= enc.width); else 0 */
+    int32_t pool_heads;  /* MQ_VIT_POOL_QUERY: its heads (Dp / pool_heads = 64 / 96 / 128 ...) */
 } mq_vit_cfg;
 
 typedef struct mq_clip_text_weights {
@@ -196,6 +201,8 @@ typedef struct mq_clip_text_cfg {
     int32_t vocab;
     int32_t ctx;      /* 77 */
     int32_t out_dim;
+    int32_t cls_pos;  /* > 0 (CoCa text towers, open_clip TextTransformer embed_cls): the LAST row of every sequence is the appended class
+                       * embedding — it takes position `cls_pos` (= the text context length) instead of its index; 0 = off */
 } mq_clip_text_cfg;
 
 typedef struct mq_bert_weights {

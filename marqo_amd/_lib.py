@@ -29,12 +29,12 @@ STAGE_PATH = LIB_DIR / "_mq_stage.so"                # CPython extension: a batc
 
 MQ_OK = 0
 NO_SCRATCH_UNITS = ("rowops", "gemm_bf16", "gemm_fp8", "gemm_small", "attention", "embed")  # build() refuses register spills in these
-ABI_VERSION = 8
+ABI_VERSION = 9
 MQ_PREC_BF16, MQ_PREC_FP8 = 0, 1
 MQ_ACT_GELU, MQ_ACT_QUICKGELU = 1, 2
 MQ_MASK_NONE, MQ_MASK_CAUSAL = 0, 1
 MQ_POOL_MEAN, MQ_POOL_CLS = 0, 1
-MQ_VIT_POOL_CLS, MQ_VIT_POOL_MAP, MQ_VIT_POOL_AVG = 0, 1, 2
+MQ_VIT_POOL_CLS, MQ_VIT_POOL_MAP, MQ_VIT_POOL_AVG, MQ_VIT_POOL_QUERY = 0, 1, 2, 3
 MQ_EPI_BIAS, MQ_EPI_GELU, MQ_EPI_QUICKGELU, MQ_EPI_RESIDUAL, MQ_EPI_OUT_F32, MQ_EPI_OUT_FP8 = 1, 2, 4, 8, 16, 32
 MQ_EPI_ROW_STATS, MQ_EPI_LN_APPLY = 64, 128
 MQ_COMBINE_RAW, MQ_COMBINE_NORMALIZE, MQ_COMBINE_NORMALIZE_IF_NONZERO = 0, 1, 2
@@ -84,7 +84,8 @@ class VitWeights(C.Structure):
 
 class VitCfg(C.Structure):
     _fields_ = [("enc", EncoderCfg), ("image_size", C.c_int32), ("patch_size", C.c_int32), ("out_dim", C.c_int32),
-                ("mean", C.c_float * 3), ("std", C.c_float * 3), ("pool", C.c_int32), ("map_mlp_dim", C.c_int32)]
+                ("mean", C.c_float * 3), ("std", C.c_float * 3), ("pool", C.c_int32), ("map_mlp_dim", C.c_int32), ("pool_dim", C.c_int32),
+                ("pool_heads", C.c_int32)]
 
 
 class ClipTextWeights(C.Structure):
@@ -93,7 +94,7 @@ class ClipTextWeights(C.Structure):
 
 
 class ClipTextCfg(C.Structure):
-    _fields_ = [("enc", EncoderCfg), ("vocab", C.c_int32), ("ctx", C.c_int32), ("out_dim", C.c_int32)]
+    _fields_ = [("enc", EncoderCfg), ("vocab", C.c_int32), ("ctx", C.c_int32), ("out_dim", C.c_int32), ("cls_pos", C.c_int32)]
 
 
 class BertWeights(C.Structure):

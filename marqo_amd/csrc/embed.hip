@@ -236,7 +236,7 @@ template <bool LN, int CH>
 __global__ __launch_bounds__(256, (CH <= 2 ? 8 : 4)) void embed_tokens_kernel(
     const int32_t* __restrict__ ids, const int32_t* __restrict__ cu, const float* __restrict__ tok,
     const float* __restrict__ pos, const float* __restrict__ type0, const float* __restrict__ gam,
-    const float* __restrict__ bet, float* __restrict__ x, bf16_t* __restrict__ xb, int W, int vocab, float eps) {
+    const float* __restrict__ bet, float* __restrict__ x, bf16_t* __restrict__ xb, int W, int vocab, float eps, int last_pos) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row0 = cu[blockIdx.x], len = cu[blockIdx.x + 1] - row0;
     const int nch = W >> 2;
@@ -245,7 +245,9 @@ __global__ __launch_bounds__(256, (CH <= 2 ? 8 : 4)) void embed_tokens_kernel(
         int id = ids[row];
         id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
         const float* tr = tok + (int64_t)id * W;
-        const float* pr = pos ? pos + (int64_t)t * W : nullptr;   // (rotary models carry no absolute position table)
+        // (rotary models carry no absolute position table; last_pos > 0: the sequence's last row — CoCa's appended class embedding — sits at that
+        // position whatever the sequence's length, the padding between it and the text is never a row)
+        const float* pr = pos ? pos + (int64_t)((last_pos > 0 && t == len - 1) ? last_pos : t) * W : nullptr;
         f32x4 v[CH];
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
@@ -427,16 +429,16 @@ int mq_map_pool(const void* d_kv, const float* d_q, void* d_out, int64_t n, int 
 
 int mq_embed_tokens(const int32_t* d_ids, const int32_t* d_cu, int64_t nseq, const float* tok, const float* pos,
                     const float* type0, const float* g, const float* b, float* d_x, void* d_xb, int W, int vocab,
-                    float eps, hipStream_t s) {
+                    float eps, hipStream_t s, int last_pos) {
     MQ_CHECK_ARG(W % 4 == 0 && W <= 64 * 4 * MAXC, "embed_tokens: W=%d unsupported", W);
     if (nseq <= 0) return MQ_OK;
     MqProfScope prof(3, s);
     if (g)
         MQ_DISPATCH_CH(W, hipLaunchKernelGGL((embed_tokens_kernel<true, CH>), dim3((unsigned)nseq), dim3(256), 0, s, d_ids, d_cu,
-                                             tok, pos, type0, g, b, d_x, (bf16_t*)d_xb, W, vocab, eps));
+                                             tok, pos, type0, g, b, d_x, (bf16_t*)d_xb, W, vocab, eps, last_pos));
     else
         MQ_DISPATCH_CH(W, hipLaunchKernelGGL((embed_tokens_kernel<false, CH>), dim3((unsigned)nseq), dim3(256), 0, s, d_ids, d_cu,
-                                             tok, pos, type0, g, b, d_x, (bf16_t*)d_xb, W, vocab, eps));
+                                             tok, pos, type0, g, b, d_x, (bf16_t*)d_xb, W, vocab, eps, last_pos));
     MQ_CHECK_LAUNCH("embed_tokens");
     return MQ_OK;
 }

@@ -15,7 +15,7 @@ int mq_vit_assemble(const float* d_patch_out, const float* cls, const float* pos
                     float* d_x, int64_t n, int T, int W, float eps, hipStream_t s, int x_bf16 = 0);
 int mq_embed_tokens(const int32_t* d_ids, const int32_t* d_cu, int64_t nseq, const float* tok, const float* pos,
                     const float* type0, const float* g, const float* b, float* d_x, void* d_xb, int W, int vocab,
-                    float eps, hipStream_t s);
+                    float eps, hipStream_t s, int last_pos = 0);
 int mq_pool(const float* d_x, const int32_t* d_cu, int64_t nseq, float* d_out, int W, int pool, int normalize,
             hipStream_t s);
 int mq_last_rows(const int32_t* d_cu, int32_t* d_rows, int64_t nseq, hipStream_t s);
@@ -30,7 +30,7 @@ extern "C" int mq_rowquant_fp8(const float* d_x, void* d_out_fp8, float* d_row_s
 // layouts the ctypes binding (marqo_amd/_lib.py) and tests/test_abi.py assume
 static_assert(sizeof(mq_block_weights) == 26 * 8, "mq_block_weights layout");
 static_assert(sizeof(mq_encoder_cfg) == 96, "mq_encoder_cfg layout");
-static_assert(sizeof(mq_vit_cfg) == 144 && sizeof(mq_clip_text_cfg) == 112 && sizeof(mq_bert_cfg) == 120, "tower cfg layouts");
+static_assert(sizeof(mq_vit_cfg) == 152 && sizeof(mq_clip_text_cfg) == 112 && sizeof(mq_bert_cfg) == 120, "tower cfg layouts");
 static_assert(sizeof(mq_vit_weights) == 10 * 8 && sizeof(mq_map_head) == 11 * 8 && sizeof(mq_clip_text_weights) == 7 * 8, "tower weight layouts");
 
 // mq_tune("row_select", 0) runs the last block on every row (A/B and parity tests of the pooled-rows-only last block)
@@ -488,8 +488,8 @@ struct VitPlan {
 VitPlan vit_plan(const mq_vit_cfg* c, int64_t n) {
     VitPlan p;
     const int G = c->image_size / c->patch_size;
-    const bool map = c->pool == MQ_VIT_POOL_MAP;
-    p.np = G * G; p.T = p.np + (map ? 0 : 1); p.Kp = ceil64(3 * c->patch_size * c->patch_size); p.rows = n * p.T;
+    const bool map = c->pool == MQ_VIT_POOL_MAP || c->pool == MQ_VIT_POOL_QUERY;   // (the query pooler uses the MAP head's buffers; its tokens keep the class token)
+    p.np = G * G; p.T = p.np + (c->pool == MQ_VIT_POOL_MAP ? 0 : 1); p.Kp = ceil64(3 * c->patch_size * c->patch_size); p.rows = n * p.T;
     const int W = c->enc.width;
     Off cv;
     p.off_x = cv.take((size_t)p.rows * W * 4);
@@ -528,7 +528,8 @@ int encode_image_impl(const mq_vit_cfg* cfg, const mq_vit_weights* w, const void
     MQ_CHECK_ARG(cfg->out_dim >= 4 && cfg->out_dim % 4 == 0, "mq_encode_image: out_dim %d must be a multiple of 4", cfg->out_dim);
     const bool map = cfg->pool == MQ_VIT_POOL_MAP;
     const bool avg = cfg->pool == MQ_VIT_POOL_AVG;
-    MQ_CHECK_ARG(cfg->pool == MQ_VIT_POOL_CLS || map || avg, "mq_encode_image: bad pool %d", cfg->pool);
+    const bool qpool = cfg->pool == MQ_VIT_POOL_QUERY;
+    MQ_CHECK_ARG(cfg->pool == MQ_VIT_POOL_CLS || map || avg || qpool, "mq_encode_image: bad pool %d", cfg->pool);
     MQ_CHECK_ARG(w->patch_w && w->pos && w->ln_post_g && w->ln_post_b, "mq_encode_image: null weight pointer");
     const int W = cfg->enc.width;
     if (map) {
@@ -541,6 +542,12 @@ int encode_image_impl(const mq_vit_cfg* cfg, const mq_vit_weights* w, const void
     } else {
         MQ_CHECK_ARG(w->cls && w->proj_w && (avg || (w->ln_pre_g && w->ln_pre_b)) && (!w->ln_pre_g == !w->ln_pre_b),
                      "mq_encode_image: null weight pointer (ln_pre may be absent only with MQ_VIT_POOL_AVG)");
+    }
+    if (qpool) {
+        const mq_map_head* m = w->map;
+        MQ_CHECK_ARG(m && m->q && m->kv_w && m->kv_b && m->proj_w && m->proj_b && m->ln_g && m->ln_b, "mq_encode_image: MQ_VIT_POOL_QUERY needs the pooler's weights");
+        MQ_CHECK_ARG(cfg->pool_dim >= 64 && cfg->pool_dim % 64 == 0 && cfg->pool_dim <= W && cfg->pool_heads >= 1 && cfg->pool_dim % cfg->pool_heads == 0,
+                     "mq_encode_image: pool_dim %d / pool_heads %d unsupported (pool_dim a multiple of 64, <= the width %d)", cfg->pool_dim, cfg->pool_heads, W);
     }
     if (n <= 0) return MQ_OK;
     MQ_CHECK_ARG(d_pixels && ws, "mq_encode_image: null input / workspace");
@@ -588,6 +595,27 @@ int encode_image_impl(const mq_vit_cfg* cfg, const mq_vit_weights* w, const void
         } else {
             MQ_CHECK_HIP(hipMemcpyAsync(d_out, y, (size_t)n * W * 4, hipMemcpyDeviceToDevice, s));
         }
+        return MQ_OK;
+    }
+    if (qpool) {
+        // open_clip VisionTransformer + AttentionalPooler (CoCa): every token (class token included) runs every block;
+        //   k | v = ln_k(x) @ kv_w^T + kv_b  (width Dp);  o = softmax(q0 k^T) v per pooler head (q0 = the first learned query, projected at load);
+        //   y = o @ out_proj^T + b;  embedding = ln_post(y) @ proj  — the other 255 queries feed CoCa's captioning decoder only
+        const mq_map_head* m = w->map;
+        const int Dp = cfg->pool_dim;
+        MQ_TRY(encoder_forward_impl(&cfg->enc, w->blocks, x, p.rows, nullptr, n, p.T, p.T, nullptr, 0, base + p.off_enc, ws_bytes - p.off_enc, s));
+        void* tok = base + p.off_tok;
+        void* kv = base + p.off_kv;
+        float* y = (float*)(base + p.off_map_y);
+        void* z = base + p.off_map_z;
+        MQ_TRY(mq_layernorm_ex(x, xb, nullptr, w->ln_post_g, w->ln_post_b, tok, nullptr, p.rows, W, cfg->enc.ln_eps, s));      // ln_k
+        MQ_TRY(mq_gemm_bf16(tok, W, m->kv_w, W, m->kv_b, nullptr, kv, 2 * Dp, p.rows, 2 * Dp, W, MQ_EPI_BIAS, s));
+        MQ_TRY(mq_map_pool(kv, m->q, cls_ln, n, p.T, Dp, cfg->pool_heads, s));
+        MQ_CHECK_HIP(hipMemsetAsync(y, 0, (size_t)n * Dp * 4, s));   // bias-only epilogue = the residual epilogue over zeros
+        MQ_TRY(mq_gemm_bf16(cls_ln, Dp, m->proj_w, Dp, m->proj_b, y, y, Dp, n, Dp, Dp, MQ_EPI_BIAS | MQ_EPI_RESIDUAL | MQ_EPI_OUT_F32, s));
+        MQ_TRY(mq_layernorm(y, nullptr, m->ln_g, m->ln_b, z, nullptr, n, Dp, cfg->enc.ln_eps, s));                                // ln_post
+        MQ_TRY(mq_gemm_bf16(z, Dp, w->proj_w, Dp, nullptr, nullptr, d_out, cfg->out_dim, n, cfg->out_dim, Dp, MQ_EPI_OUT_F32, s));
+        if (normalize) MQ_TRY(mq_l2_normalize(d_out, d_out, n, cfg->out_dim, s));
         return MQ_OK;
     }
     if (avg) {
@@ -677,6 +705,7 @@ extern "C" int mq_encode_clip_text(const mq_clip_text_cfg* cfg, const mq_clip_te
     int64_t rows = 0;
     const int maxl = max_seq_len(h_cu_seqlens, nseq, &rows);
     MQ_CHECK_ARG(maxl >= 1 && maxl <= cfg->ctx, "mq_encode_clip_text: sequence lengths must be in [1, ctx=%d]", cfg->ctx);
+    MQ_CHECK_ARG(cfg->cls_pos >= 0 && cfg->cls_pos < cfg->ctx, "mq_encode_clip_text: cls_pos %d outside the position table [0, %d)", cfg->cls_pos, cfg->ctx);
     const TextPlan p = text_plan(&cfg->enc, rows, nseq);
     if (workspace_bytes < p.total) { mq_set_error("mq_encode_clip_text: workspace %zu < required %zu", workspace_bytes, p.total); return MQ_ERR_WORKSPACE; }
     hipStream_t s = (hipStream_t)stream;
@@ -688,7 +717,7 @@ extern "C" int mq_encode_clip_text(const mq_clip_text_cfg* cfg, const mq_clip_te
 
     const int xb = stream_bf16(&cfg->enc) ? 1 : 0;   // residual stream in bf16: the embedding kernel writes its bf16 output into x
     MQ_TRY(mq_embed_tokens(d_ids, d_cu_seqlens, nseq, w->tok_emb, w->pos, nullptr, nullptr, nullptr, xb ? nullptr : x, xb ? (void*)x : nullptr, W,
-                           cfg->vocab, 0.f, s));
+                           cfg->vocab, 0.f, s, cfg->cls_pos));
     const int32_t* pool_rows = d_pool_rows;
     if (!pool_rows) { MQ_TRY(mq_last_rows(d_cu_seqlens, rows_idx, nseq, s)); pool_rows = rows_idx; }
     MQ_TRY(encoder_forward_impl(&cfg->enc, w->blocks, x, rows, d_cu_seqlens, nseq, 0, maxl, pool_rows, nseq, base + p.off_enc,

@@ -29,8 +29,11 @@ class VitArch:
     #                    "map": timm SigLIP ViT behind open_clip's TimmModel (no class token, no ln_pre, attention-pool head, no proj);
     #                    "avg": open_clip VisionTransformer with pool_type 'avg' + final_ln_after_pool (CLIPA): class token kept in the sequence,
     #                           mean of the PATCH tokens -> ln_post -> proj
+    #                    "query": open_clip VisionTransformer + AttentionalPooler (CoCa): class token and ln_pre as in CLIP, every token runs every
+    #                           block, one learned query attends over ln_k(tokens) in a pooler of width out_dim -> ln_post -> proj
     ln_pre: bool = True          # False: `no_ln_pre` (CLIPA)
     preprocessor: Optional[str] = None   # open_clip preprocess config of the registry entry when it is not the default ("CLIPA")
+    pool_heads: int = 8          # pool "query": heads of the attentional pooler (attn_pooler_heads)
 
     @property
     def tokens(self) -> int:
@@ -42,7 +45,10 @@ class VitArch:
         T, W, F = self.tokens, self.width, self.mlp_dim
         patch = 2 * (self.image_size // self.patch_size) ** 2 * W * 3 * self.patch_size ** 2
         layer = 2 * T * W * (3 * W) + 2 * T * W * W + 2 * 2 * T * W * F + 4 * T * T * W
-        if self.pool == "map":  # keys | values of every token, one query per head, proj + MLP on the pooled row
+        if self.pool == "query":  # keys | values of every token at the pooler's width, one query, out-projection, final projection
+            D = self.out_dim
+            head = 2 * T * W * (2 * D) + 4 * T * D + 2 * D * D + 2 * D * D
+        elif self.pool == "map":  # keys | values of every token, one query per head, proj + MLP on the pooled row
             head = 2 * T * W * (2 * W) + 4 * T * W + 2 * W * W + 2 * 2 * W * F
         else:
             head = 2 * W * self.out_dim
@@ -64,6 +70,8 @@ class ClipTextArch:
     proj_bias: bool = False   # SigLIP: text_projection is a Linear with bias
     prefix: str = ""          # checkpoint key prefix: "" for CLIP, "text." under open_clip's CustomTextCLIP (SigLIP)
     pad_id: int = 0
+    cls_embed: bool = False   # CoCa (open_clip TextTransformer embed_cls): ctx - 1 token positions + a learned class embedding appended behind the
+    #                           padding (position ctx - 1); the class row is the pooled one, ln_final runs on it; keys under `text.`
     hf_tokenizer: Optional[str] = None   # open_clip HFTokenizer(<name>) instead of the CLIP BPE (CLIPA: "bert-base-uncased")
     strip_sep: bool = False              # HFTokenizer(strip_sep_token=True): [SEP] ids are replaced by 0 after tokenisation
 
@@ -199,13 +207,18 @@ OPEN_CLIP_ARCHS = {
     "ViT-H-14-378": (VitArch(378, 14, 1280, 32, 16, 5120, 1024), _TEXT_H),  # 730 tokens: K / V stream through the LDS in pieces
     "ViT-g-14": (VitArch(224, 14, 1408, 40, 16, 6144, 1024), _TEXT_H),
     "ViT-bigG-14": (VitArch(224, 14, 1664, 48, 16, 8192, 1280), _TEXT_BIGG),
+    # CoCa (model_registry.py:344-370; open_clip model configs coca_ViT-B-32 / coca_ViT-L-14): the contrastive half — the captioning decoder is not
+    # part of an embedding
+    "coca_ViT-B-32": (VitArch(224, 32, 768, 12, 12, 3072, 512, pool="query", pool_heads=8),
+                      ClipTextArch(49408, 77, 512, 12, 8, 2048, 512, prefix="text.", cls_embed=True)),
+    "coca_ViT-L-14": (VitArch(224, 14, 1024, 24, 16, 4096, 768, pool="query", pool_heads=8),
+                      ClipTextArch(49408, 77, 768, 12, 12, 3072, 768, prefix="text.", cls_embed=True)),
     "ViT-B-16-SigLIP": _siglip(224), "ViT-B-16-SigLIP-256": _siglip(256), "ViT-B-16-SigLIP-384": _siglip(384),
     "ViT-B-16-SigLIP-512": _siglip(512),
     "ViT-SO400M-14-SigLIP": _siglip(224, so400m=True), "ViT-SO400M-14-SigLIP-384": _siglip(384, so400m=True),
     "ViT-L-16-SigLIP-256": _siglip(256, large=True), "ViT-L-16-SigLIP-384": _siglip(384, large=True),
 }
-# architectures the registry names but which are not plain CLIP / SigLIP ViTs (ResNet, ConvNeXt, EVA02, CoCa, roberta / xlm / NLLB
-# text towers ...)
+# architectures the registry names but which are not ViT / CLIP-text / BERT-family towers (ResNet, ConvNeXt, EVA02, NLLB text towers ...)
 UNSUPPORTED_HINT = ("this open_clip architecture is not runnable by the marqo_amd engine yet "
                     "(supported: " + ", ".join(sorted(OPEN_CLIP_ARCHS)) + " and their -quickgelu variants)")
 

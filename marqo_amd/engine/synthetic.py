@@ -75,8 +75,22 @@ def random_open_clip_state_dict(vision: VitArch = None, text: ClipTextArch = Non
         if vision.ln_pre:
             _ln(sd, "visual.ln_pre", W, g)
         _resblocks(sd, "visual.transformer.", vision.layers, W, vision.mlp_dim, g)
-        _ln(sd, "visual.ln_post", W, g)
-        sd["visual.proj"] = torch.randn(W, vision.out_dim, generator=g) / math.sqrt(W)
+        if vision.pool == "query":
+            # CoCa: AttentionalPooler of width D = out_dim behind the trunk (256 learned queries; MultiheadAttention with kdim = vdim = W)
+            D, a = vision.out_dim, "visual.attn_pool."
+            sd[a + "query"] = torch.randn(256, D, generator=g)
+            _ln(sd, a + "ln_q", D, g)
+            _ln(sd, a + "ln_k", W, g)
+            sd[a + "attn.q_proj_weight"] = torch.randn(D, D, generator=g) / math.sqrt(D)
+            sd[a + "attn.k_proj_weight"] = torch.randn(D, W, generator=g) / math.sqrt(W)
+            sd[a + "attn.v_proj_weight"] = torch.randn(D, W, generator=g) / math.sqrt(W)
+            sd[a + "attn.in_proj_bias"] = 0.02 * torch.randn(3 * D, generator=g)
+            _lin(sd, a + "attn.out_proj", D, D, g, 1.0 / math.sqrt(D))
+            _ln(sd, "visual.ln_post", D, g)
+            sd["visual.proj"] = torch.randn(D, D, generator=g) / math.sqrt(D)
+        else:
+            _ln(sd, "visual.ln_post", W, g)
+            sd["visual.proj"] = torch.randn(W, vision.out_dim, generator=g) / math.sqrt(W)
     if text is not None and hasattr(text, "bert"):
         # open_clip HFTextEncoder (CustomTextCLIP): HF-named encoder under text.transformer.*, projection MLP under text.proj.{0,2}
         for k, v in random_bert_state_dict(text.bert, seed=seed + 1).items():
@@ -91,6 +105,8 @@ def random_open_clip_state_dict(vision: VitArch = None, text: ClipTextArch = Non
         W, px = text.width, text.prefix
         sd[px + "token_embedding.weight"] = 0.5 * torch.randn(text.vocab, W, generator=g)
         sd[px + "positional_embedding"] = 0.3 * torch.randn(text.ctx, W, generator=g)
+        if getattr(text, "cls_embed", False):
+            sd[px + "cls_emb"] = 0.5 * torch.randn(W, generator=g)
         _resblocks(sd, px + "transformer.", text.layers, W, text.mlp_dim, g)
         _ln(sd, px + "ln_final", W, g)
         if text.proj_bias:

@@ -732,6 +732,36 @@ class VitTower(_TowerBase):
                                   ln_post_g=h.f32(_need(sd, t + "norm.weight", (W,))), ln_post_b=h.f32(_need(sd, t + "norm.bias", (W,))),
                                   proj_w=None, map=C.pointer(self._map))
             pool, map_mlp = L.MQ_VIT_POOL_MAP, _ceil64(F)
+        elif arch.pool == "query":
+            # open_clip VisionTransformer + AttentionalPooler (CoCa, model_registry.py:344-370): the CLIP trunk, then one learned query over
+            # ln_k(tokens) in a MultiheadAttention of width D = out_dim with kdim = vdim = W, ln_post over D, proj [D, D]
+            D, Hp = arch.out_dim, arch.pool_heads
+            if D % Hp or (D // Hp) % 8 or D // Hp > 128 or D % 64 or D > W:
+                raise ValueError(f"attentional pooler of width {D} with {Hp} heads is not runnable (head dim a multiple of 8, <= 128; width a multiple of 64, <= {W})")
+            patch_w[:, :K] = _need(sd, "visual.conv1.weight", (W, 3, P, P)).detach().to(torch.float32).reshape(W, K)
+            self._blocks = _clip_blocks(h, sd, "visual.transformer.", arch.layers, W, arch.mlp_dim, arch.heads)
+            a = "visual.attn_pool."
+            f32 = lambda k, shape: _need(sd, a + k, shape).detach().to(torch.float32)
+            bias = f32("attn.in_proj_bias", (3 * D,))
+            query = _need(sd, a + "query", None).detach().to(torch.float32)
+            if query.ndim != 2 or query.shape[1] != D:
+                raise ValueError(f"checkpoint tensor '{a}query' has shape {tuple(query.shape)}, expected [n_queries, {D}]")
+            # only the FIRST learned query reaches the contrastive embedding (pooled = attn_pool(x)[:, 0]); it is a constant of the model:
+            # q0 = (ln_q(query)[0] @ Wq^T + bq) / sqrt(head dim), in fp32 at load
+            q0 = torch.nn.functional.layer_norm(query[:1], (D,), f32("ln_q.weight", (D,)), f32("ln_q.bias", (D,)), arch.ln_eps)[0]
+            q0 = (q0 @ f32("attn.q_proj_weight", (D, D)).t() + bias[:D]) * (D // Hp) ** -0.5
+            kv_w = torch.cat([f32("attn.k_proj_weight", (D, W)), f32("attn.v_proj_weight", (D, W))], dim=0)
+            self._map = L.MapHead(q=h.f32(q0), kv_w=h.bf16(kv_w), kv_b=h.f32(bias[D:]),
+                                  proj_w=h.bf16(f32("attn.out_proj.weight", (D, D))), proj_b=h.f32(f32("attn.out_proj.bias", (D,))),
+                                  ln_g=h.f32(_need(sd, "visual.ln_post.weight", (D,))), ln_b=h.f32(_need(sd, "visual.ln_post.bias", (D,))),
+                                  fc1_w=None, fc1_b=None, fc2_w=None, fc2_b=None)
+            self.w = L.VitWeights(
+                patch_w=h.bf16(patch_w), cls=h.f32(_need(sd, "visual.class_embedding", (W,))),
+                pos=h.f32(_need(sd, "visual.positional_embedding", (arch.tokens, W))),
+                ln_pre_g=h.f32(_need(sd, "visual.ln_pre.weight", (W,))), ln_pre_b=h.f32(_need(sd, "visual.ln_pre.bias", (W,))),
+                blocks=self._blocks, ln_post_g=h.f32(f32("ln_k.weight", (W,))), ln_post_b=h.f32(f32("ln_k.bias", (W,))),   # the norm every token takes before k | v
+                proj_w=h.bf16(_need(sd, "visual.proj", (D, D)).detach().to(torch.float32).t()), map=C.pointer(self._map))
+            pool, map_mlp = L.MQ_VIT_POOL_QUERY, 0
         else:
             patch_w[:, :K] = _need(sd, "visual.conv1.weight", (W, 3, P, P)).detach().to(torch.float32).reshape(W, K)
             self._blocks = _clip_blocks(h, sd, "visual.transformer.", arch.layers, W, arch.mlp_dim, arch.heads)
@@ -751,7 +781,8 @@ class VitTower(_TowerBase):
         self.cfg = L.VitCfg(enc=_encoder_cfg(W, arch.layers, arch.heads, arch.mlp_dim, arch.quick_gelu, False,
                                              L.MQ_MASK_NONE, arch.ln_eps),
                             image_size=arch.image_size, patch_size=P, out_dim=arch.out_dim,
-                            mean=(C.c_float * 3)(*mean), std=(C.c_float * 3)(*std), pool=pool, map_mlp_dim=map_mlp)
+                            mean=(C.c_float * 3)(*mean), std=(C.c_float * 3)(*std), pool=pool, map_mlp_dim=map_mlp,
+                            pool_dim=arch.out_dim if arch.pool == "query" else 0, pool_heads=arch.pool_heads if arch.pool == "query" else 0)
         self.max_images_per_call = max(1, MAX_ROWS_PER_CALL // arch.tokens)
         self.n_streams = max(1, int(os.environ.get("MARQO_AMD_STREAMS", "1")))
         self._side: list = []
@@ -969,20 +1000,40 @@ class ClipTextTower(_TextTowerBase):
         else:
             proj_w = _need(sd, px + "text_projection", (W, arch.out_dim)).detach().to(torch.float32).t()
             proj_b = None
+        tok_emb = _need(sd, px + "token_embedding.weight", (arch.vocab, W))
+        if arch.cls_embed:
+            # CoCa: the learned class embedding rides as one more row of the token table (id = vocab); encode_ids appends that id behind every
+            # text's EOT, the embedding kernel gives the sequence's last row position ctx - 1 (cfg.cls_pos) — the padding between the text and
+            # the class token in the reference's layout is never a key of any row that is read (oracle.coca_text_forward restates the mask)
+            tok_emb = torch.cat([tok_emb.detach().to(torch.float32), _need(sd, px + "cls_emb", (W,)).detach().to(torch.float32)[None]], dim=0)
         self.w = L.ClipTextWeights(
-            tok_emb=h.f32(_need(sd, px + "token_embedding.weight", (arch.vocab, W))),
+            tok_emb=h.f32(tok_emb),
             pos=h.f32(_need(sd, px + "positional_embedding", (arch.ctx, W))),
             blocks=self._blocks,
             ln_final_g=h.f32(_need(sd, px + "ln_final.weight", (W,))), ln_final_b=h.f32(_need(sd, px + "ln_final.bias", (W,))),
             proj_w=h.bf16(proj_w), proj_b=proj_b)
         self.cfg = L.ClipTextCfg(enc=_encoder_cfg(W, arch.layers, arch.heads, arch.mlp_dim, arch.quick_gelu, False,
                                                   L.MQ_MASK_CAUSAL if arch.causal else L.MQ_MASK_NONE, arch.ln_eps),
-                                 vocab=arch.vocab, ctx=arch.ctx, out_dim=arch.out_dim)
+                                 vocab=arch.vocab + (1 if arch.cls_embed else 0), ctx=arch.ctx, out_dim=arch.out_dim,
+                                 cls_pos=arch.ctx - 1 if arch.cls_embed else 0)
+        if arch.cls_embed and not arch.causal:
+            raise ValueError("a class-embedding text tower is causal (CoCa)")
         if precision == "fp8":
             self._enable_fp8(self._blocks, arch.layers, W, _ceil64(arch.mlp_dim))
         self.cfg.enc.residual_stream = 2
         if precision == "bf16":
             self.tune_residual_default()
+
+    def _with_cls(self, ids_h: np.ndarray) -> np.ndarray:
+        """CoCa: [n, S <= ctx - 1] token ids (SOT ... EOT 0 ...) -> [n, S + 1] with the class id (= vocab) right behind each text's EOT.
+        The class id is the largest id of its row, so the EOT logic downstream (argmax = pooled position, rows up to it) lands on it."""
+        n, S = ids_h.shape
+        if S > self.arch.ctx - 1:
+            raise ValueError(f"a class-embedding text tower takes at most {self.arch.ctx - 1} token positions, got {S}")
+        out = np.zeros((n, S + 1), dtype=np.int64)
+        out[:, :S] = ids_h
+        out[np.arange(n), ids_h.argmax(axis=1) + 1] = self.arch.vocab
+        return out
 
     def tune_residual_default(self) -> str:
         ids = self.calibration_ids()
@@ -999,9 +1050,10 @@ class ClipTextTower(_TextTowerBase):
                 L_ = 3 + (i * (a.ctx - 4)) // max(n - 1, 1)
                 ids[i, :L_] = torch.randint(2, a.vocab, (L_,), generator=g)
             return ids
-        ids = torch.zeros(n, a.ctx, dtype=torch.int64)
+        S = a.ctx - 1 if a.cls_embed else a.ctx
+        ids = torch.zeros(n, S, dtype=torch.int64)
         for i in range(n):
-            L_ = 3 + (i * (a.ctx - 5)) // max(n - 1, 1)
+            L_ = 3 + (i * (S - 5)) // max(n - 1, 1)
             ids[i, 0] = a.vocab - 2
             ids[i, 1:1 + L_] = torch.randint(1, a.vocab - 2, (L_,), generator=g)
             ids[i, 1 + L_] = a.vocab - 1
@@ -1019,6 +1071,8 @@ class ClipTextTower(_TextTowerBase):
         if ids.ndim != 2 or ids.shape[1] > self.arch.ctx:
             raise ValueError(f"expected ids [n, <= {self.arch.ctx}], got {tuple(ids.shape)}")
         ids_h = _host_i64(ids)
+        if self.arch.cls_embed:
+            ids_h, pack = self._with_cls(ids_h), True     # (the un-packed form would run the padding between the text and the class token)
         n, S = ids_h.shape
         if not self.arch.causal:
             # SigLIP: no mask at all — every one of the ctx positions (padding included) is attended to and the pooled row is the
@@ -1051,6 +1105,9 @@ class ClipTextTower(_TextTowerBase):
         host = SOT..EOT length.  Same as encode_ids(pack=True), but the packing runs on the GPU (mq_pack_ids)."""
         if not self.arch.causal and (d_ids.shape[1] != self.arch.ctx or int(_host_i64(lengths).min(initial=self.arch.ctx)) != self.arch.ctx):
             raise ValueError(f"an unmasked text tower runs exactly ctx = {self.arch.ctx} positions per text")
+        if self.arch.cls_embed:   # the class id is appended on the host (a [n, S] id matrix: KBs)
+            ids_h = _host_i64(d_ids)
+            return self.encode_ids(torch.from_numpy(np.where(np.arange(ids_h.shape[1])[None] < _host_i64(lengths)[:, None], ids_h, 0)), normalize=normalize)
         return self._encode_device(d_ids, lengths, self.arch.ctx, normalize, clip=True)
 
 

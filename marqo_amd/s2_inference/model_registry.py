@@ -35,6 +35,9 @@ _OPEN_CLIP_TAGS = {
     "ViT-H-14-378-quickgelu": ["dfn5b"],
     "ViT-g-14": ["laion2b_s12b_b42k", "laion2b_s34b_b88k"],
     "ViT-bigG-14": ["laion2b_s39b_b160k"],
+    # CoCa (model_registry.py:344-370): the contrastive towers of the captioner
+    "coca_ViT-B-32": ["laion2b_s13b_b90k", "mscoco_finetuned_laion2b_s13b_b90k"],
+    "coca_ViT-L-14": ["laion2b_s13b_b90k", "mscoco_finetuned_laion2b_s13b_b90k"],
     # SigLIP (model_registry.py:371-432)
     "ViT-B-16-SigLIP": ["webli"], "ViT-B-16-SigLIP-256": ["webli"], "ViT-B-16-SigLIP-384": ["webli"], "ViT-B-16-SigLIP-512": ["webli"],
     "ViT-L-16-SigLIP-256": ["webli"], "ViT-L-16-SigLIP-384": ["webli"], "ViT-SO400M-14-SigLIP-384": ["webli"],

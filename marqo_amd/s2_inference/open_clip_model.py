@@ -249,7 +249,8 @@ class OPEN_CLIP(AbstractCLIPModel):
         self.tokenizer = self._load_tokenizer(ckpt_dir)
         # K14: byte-level BPE on the device for ASCII texts (identical ids; the host tokeniser handles the rest)
         self._device_tokenizer = None
-        if isinstance(self.tokenizer, ClipBpeTokenizer) and os.environ.get("MARQO_AMD_HOST_TOKENIZER", "0") != "1":
+        if isinstance(self.tokenizer, ClipBpeTokenizer) and os.environ.get("MARQO_AMD_HOST_TOKENIZER", "0") != "1" \
+                and not getattr(self.text_arch, "cls_embed", False):
             from marqo_amd.engine.gpu_tokenizers import DeviceClipBpeTokenizer
             self._device_tokenizer = DeviceClipBpeTokenizer(self.tokenizer, self.device)
         elif isinstance(self.tokenizer, XlmRobertaTokenizer) and os.environ.get("MARQO_AMD_HOST_TOKENIZER", "0") != "1":
@@ -331,12 +332,14 @@ class OPEN_CLIP(AbstractCLIPModel):
                 return SyntheticTokenizer("siglip", self.text_arch.vocab, self.text_arch.ctx)
             raise ModelLoadError(f"SigLIP tokenizer (tokenizer.json / spiece.model) not found next to the checkpoint or under "
                                  f"{os.path.join(checkpoint.model_dir(), 'siglip')}")
+        # (CoCa: the tokenizer fills ctx - 1 positions, the tower appends the class embedding as the ctx-th)
+        text_ctx = self.text_arch.ctx - (1 if getattr(self.text_arch, "cls_embed", False) else 0)
         for d in filter(None, (ckpt_dir, checkpoint.model_dir(), os.path.join(checkpoint.model_dir(), "open_clip"))):
             p = os.path.join(d, BPE_VOCAB_FILE)
             if os.path.isfile(p):
-                return ClipBpeTokenizer(p, context_length=self.text_arch.ctx)
+                return ClipBpeTokenizer(p, context_length=text_ctx)
         if self.weights_source and str(self.weights_source).startswith("synthetic"):
-            return SyntheticTokenizer("clip", self.text_arch.vocab, self.text_arch.ctx)
+            return SyntheticTokenizer("clip", self.text_arch.vocab, text_ctx)
         raise ModelLoadError(f"CLIP BPE vocabulary {BPE_VOCAB_FILE} not found next to the checkpoint or under {checkpoint.model_dir()}")
 
     def _check_loaded_components(self):

@@ -47,7 +47,7 @@ State-dict conventions: open_clip names for CLIP (``visual.*``, ``transformer.re
 from __future__ import annotations
 
 import math
-from dataclasses import dataclass, field
+from dataclasses import dataclass, replace, field
 from typing import Dict, List, Optional, Sequence
 
 import torch
@@ -223,6 +223,99 @@ def clip_text_forward(sd: Dict[str, Tensor], cfg: ClipTextConfig, ids: Tensor, n
     pooled = x[torch.arange(B), ids.argmax(dim=-1)] if cfg.causal else x[:, -1]   # text_global_pool: 'argmax' / 'last
     out = pooled @ sd["text_projection"]
     return l2_normalize_clip(out) if normalize else out
+
+
+# --------------------------------------------------------------------------------------------
+# CoCa (open_clip coca_model.py + transformer.py, open_clip_torch 2.24.0 — un-vendored; RESTATED, UNPINNED: neither open_clip nor timm is in
+# this image, so these two functions follow the published source from memory of its structure and are pinned to nothing but themselves.
+# The reference only names the models (model_registry.py:344-370) and calls model.encode_image / encode_text on them
+# (core/inference/embedding_models/open_clip_model.py:249-286).)
+# --------------------------------------------------------------------------------------------
+@dataclass
+class CocaVitConfig(VitConfig):
+    pool_heads: int = 8       # attn_pooler_heads
+    n_queries: int = 256      # attn_pooler_queries (only query 0 reaches the contrastive embedding)
+
+
+@torch.no_grad()
+def coca_vit_forward(sd: Dict[str, Tensor], cfg: CocaVitConfig, pixels: Tensor, normalize: bool = True) -> Tensor:
+    """VisionTransformer(attentional_pool=True, output_dim = embed_dim) as CoCa builds it: conv1 -> class token + positions -> ln_pre -> blocks;
+    x = attn_pool(x) with AttentionalPooler(d_model = output_dim, context_dim = width): MultiheadAttention(embed_dim = d_model, kdim = vdim =
+    context_dim) of q = ln_q(query) [n_queries, d_model] over k = v = ln_k(x); x = ln_post(x) [B, n_queries, d_model]; pooled = x[:, 0]
+    ('tok' pooling of the pooler's outputs), tokens = x[:, 1:] (the captioning decoder's input, not computed here); pooled @ proj.
+    CoCa.encode_image L2-normalises by default."""
+    W, D = cfg.width, cfg.out_dim
+    x = F.conv2d(pixels, sd["visual.conv1.weight"], None, stride=cfg.patch_size)
+    B = x.shape[0]
+    x = x.reshape(B, W, -1).permute(0, 2, 1)
+    x = torch.cat([sd["visual.class_embedding"].to(x.dtype).expand(B, 1, W), x], dim=1) + sd["visual.positional_embedding"]
+    x = F.layer_norm(x, (W,), sd["visual.ln_pre.weight"], sd["visual.ln_pre.bias"], cfg.ln_eps)
+    x = _clip_resblocks(x, sd, "visual.transformer.", cfg.layers, cfg.heads, cfg.quick_gelu, cfg.ln_eps, None)
+    a = "visual.attn_pool."
+    kx = F.layer_norm(x, (W,), sd[a + "ln_k.weight"], sd[a + "ln_k.bias"], cfg.ln_eps)                     # [B, T, W]
+    q = F.layer_norm(sd[a + "query"], (D,), sd[a + "ln_q.weight"], sd[a + "ln_q.bias"], cfg.ln_eps)        # [n_queries, D]
+    bq, bk, bv = sd[a + "attn.in_proj_bias"].split(D)
+    H = cfg.pool_heads
+    hd = D // H
+    qh = F.linear(q, sd[a + "attn.q_proj_weight"], bq).view(1, -1, H, hd).transpose(1, 2)                  # [1, H, Q, hd]
+    kh = F.linear(kx, sd[a + "attn.k_proj_weight"], bk).view(B, -1, H, hd).transpose(1, 2)                 # [B, H, T, hd]
+    vh = F.linear(kx, sd[a + "attn.v_proj_weight"], bv).view(B, -1, H, hd).transpose(1, 2)
+    p = torch.softmax((qh @ kh.transpose(-1, -2)) / math.sqrt(hd), dim=-1)                                 # [B, H, Q, T]
+    o = (p @ vh).transpose(1, 2).reshape(B, -1, D)
+    o = F.linear(o, sd[a + "attn.out_proj.weight"], sd[a + "attn.out_proj.bias"])
+    o = F.layer_norm(o, (D,), sd["visual.ln_post.weight"], sd["visual.ln_post.bias"], cfg.ln_eps)
+    out = o[:, 0] @ sd["visual.proj"]
+    return l2_normalize_clip(out) if normalize else out
+
+
+@torch.no_grad()
+def coca_text_forward(sd: Dict[str, Tensor], cfg: ClipTextConfig, ids: Tensor, pad_id: int = 0, normalize: bool = True) -> Tensor:
+    """TextTransformer(embed_cls=True) as CoCa builds it (keys under `text.`): ids int64 [B, ctx - 1] (SOT ... EOT, zero-padded); the learned class
+    embedding is appended BEHIND the padding -> ctx positions; attention mask = causal + a class-token row that is blind to padding keys
+    (build_cls_mask); blocks; pooled = the LAST position (the class token), ln_final applied to the pooled row, @ text_projection."""
+    B, T = ids.shape
+    W = cfg.width
+    if T + 1 != cfg.ctx:
+        raise ValueError(f"CoCa text towers take {cfg.ctx - 1} token positions + the class embedding")
+    x = torch.cat([sd["text.token_embedding.weight"][ids], sd["text.cls_emb"].expand(B, 1, W)], dim=1) + sd["text.positional_embedding"][:T + 1]
+    mask = torch.full((T + 1, T + 1), float("-inf")).triu(1)[None, None].repeat(B, 1, 1, 1)               # causal, [B, 1, T + 1, T + 1]
+    keys_ok = torch.cat([ids != pad_id, torch.ones(B, 1, dtype=torch.bool)], dim=1)                        # the class token sees itself
+    mask[:, 0, T, :] = mask[:, 0, T, :].masked_fill(~keys_ok, float("-inf"))                               # only the class-token QUERY row is masked
+    x = _clip_resblocks(x, sd, "text.transformer.", cfg.layers, cfg.heads, cfg.quick_gelu, cfg.ln_eps, mask)
+    pooled = F.layer_norm(x[:, -1], (W,), sd["text.ln_final.weight"], sd["text.ln_final.bias"], cfg.ln_eps)
+    out = pooled @ sd["text.text_projection"]
+    return l2_normalize_clip(out) if normalize else out
+
+
+def synthetic_coca_state_dict(vcfg: CocaVitConfig, tcfg: ClipTextConfig, seed: int = 0) -> Dict[str, Tensor]:
+    """seeded CoCa checkpoint in open_clip's naming (visual.* incl. attn_pool, text.* incl. cls_emb; the captioning decoder is left out)"""
+    g = _g(seed + 4000)
+    sd = synthetic_vit_state_dict(replace(vcfg, out_dim=vcfg.out_dim), seed)
+    W, D = vcfg.width, vcfg.out_dim
+    a = "visual.attn_pool."
+    sd[a + "query"] = torch.randn(vcfg.n_queries, D, generator=g)
+    for n_, dim in (("ln_q", D), ("ln_k", W)):
+        sd[a + n_ + ".weight"] = 1 + 0.1 * torch.randn(dim, generator=g)
+        sd[a + n_ + ".bias"] = 0.05 * torch.randn(dim, generator=g)
+    sd[a + "attn.q_proj_weight"] = torch.randn(D, D, generator=g) / math.sqrt(D)
+    sd[a + "attn.k_proj_weight"] = torch.randn(D, W, generator=g) / math.sqrt(W)
+    sd[a + "attn.v_proj_weight"] = torch.randn(D, W, generator=g) / math.sqrt(W)
+    sd[a + "attn.in_proj_bias"] = 0.02 * torch.randn(3 * D, generator=g)
+    sd[a + "attn.out_proj.weight"] = torch.randn(D, D, generator=g) / math.sqrt(D)
+    sd[a + "attn.out_proj.bias"] = 0.02 * torch.randn(D, generator=g)
+    sd["visual.ln_post.weight"] = 1 + 0.1 * torch.randn(D, generator=g)      # over the pooler's width
+    sd["visual.ln_post.bias"] = 0.05 * torch.randn(D, generator=g)
+    sd["visual.proj"] = torch.randn(D, D, generator=g) / math.sqrt(D)
+    Wt = tcfg.width
+    std = 1.0 / math.sqrt(Wt)
+    sd["text.token_embedding.weight"] = 0.5 * torch.randn(tcfg.vocab, Wt, generator=g)
+    sd["text.positional_embedding"] = 0.3 * torch.randn(tcfg.ctx, Wt, generator=g)
+    sd["text.cls_emb"] = 0.5 * torch.randn(Wt, generator=g)
+    _blocks_clip(sd, "text.transformer.", tcfg.layers, Wt, tcfg.mlp_dim, g, 0.6 * std)
+    sd["text.ln_final.weight"] = 1 + 0.1 * torch.randn(Wt, generator=g)
+    sd["text.ln_final.bias"] = 0.05 * torch.randn(Wt, generator=g)
+    sd["text.text_projection"] = std * torch.randn(Wt, tcfg.out_dim, generator=g)
+    return sd
 
 
 @torch.no_grad()

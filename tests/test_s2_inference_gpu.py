@@ -257,6 +257,21 @@ def test_registry_models_synthetic_weights(s2):
     vc = O.VitConfig(224, 32, 768, 12, 12, 3072, 512)
     refi = O.vit_forward(sdc, vc, torch.from_numpy(np.stack([OP.clip_transform(np.asarray(p)) for p in pil]))).numpy()
     assert _cos_err(img, refi) < COS_TOL
+    # CoCa through the API (registry name -> loader -> 76-position tokeniser + class embedding; attentional pooler on the image side)
+    cname = "open_clip/coca_ViT-B-32/laion2b_s13b_b90k"
+    cimg = np.asarray(s2i.vectorise(cname, pil, device=DEV, modality=s2i.Modality.IMAGE))
+    ctxt = np.asarray(s2i.vectorise(cname, ["a photo of a cat", "a dog"], device=DEV))
+    assert cimg.shape == (4, 512) and ctxt.shape == (2, 512) and np.allclose(np.linalg.norm(ctxt, axis=1), 1, atol=1e-5)
+    cv, ct = archs.resolve_open_clip("coca_ViT-B-32")
+    csd = synthetic.random_open_clip_state_dict(vision=cv, text=ct, seed=0)
+    crefi = O.coca_vit_forward(csd, O.CocaVitConfig(224, 32, 768, 12, 12, 3072, 512), torch.from_numpy(np.stack([OP.clip_transform(np.asarray(p)) for p in pil]))).numpy()
+    assert _cos_err(cimg, crefi) < COS_TOL
+    ckey = s2i._create_model_cache_key(cname, DEV, s2i.get_model_properties_from_registry(cname))
+    cm = s2i.get_available_models()[ckey]["model"]
+    cids = torch.as_tensor(np.asarray(cm.tokenizer(["a photo of a cat", "a dog"])))
+    assert cids.shape[1] == 76
+    creft = O.coca_text_forward(csd, O.ClipTextConfig(ct.vocab, 77, ct.width, ct.layers, ct.heads, ct.mlp_dim, ct.out_dim), cids).numpy()
+    assert _cos_err(ctxt, creft) < COS_TOL
     # OpenAI-style name resolves to the QuickGELU towers
     q = np.asarray(s2i.vectorise("ViT-B/32", ["a photo of a cat"], device=DEV))
     assert q.shape == (1, 512) and _cos_err(q, txt[:1]) > 1e-4

@@ -470,6 +470,48 @@ def test_siglip_full_size_vs_oracle(name, layers, n):
         assert _cos_err(tt.encode_ids(ids), tref) < COS_TIGHT
 
 
+@pytest.mark.parametrize("name,layers,n", [("coca_ViT-B-32", 12, 9), ("coca_ViT-L-14", 3, 3)])
+def test_coca_towers_vs_oracle(name, layers, n):
+    """CoCa (model_registry.py:344-370): the ViT trunk + attentional pooler (one learned query over ln_k(tokens), pooler width = embedding width, 8
+    heads: 64-wide at B/32, 96-wide at L/14) and the text tower with the appended class embedding (position ctx - 1, pooled row), registry shapes
+    (L/14 depth cut to keep the fp32 CPU oracle in seconds), against oracle.coca_*_forward (restated from open_clip 2.24.0; unpinned — no open_clip
+    in this image).  Ragged texts incl. one that fills all 76 positions; single-text call (graph path); device-id entry point."""
+    from dataclasses import replace
+    T, A = _towers()
+    varch, tarch = A.resolve_open_clip(name)
+    varch, tarch = replace(varch, layers=layers), replace(tarch, layers=layers)
+    vcfg = O.CocaVitConfig(varch.image_size, varch.patch_size, varch.width, layers, varch.heads, varch.mlp_dim, varch.out_dim, pool_heads=varch.pool_heads,
+                           n_queries=256)
+    tcfg = O.ClipTextConfig(tarch.vocab, tarch.ctx, tarch.width, layers, tarch.heads, tarch.mlp_dim, tarch.out_dim)
+    sd = O.synthetic_coca_state_dict(vcfg, tcfg, seed=6)
+    u8 = O.synthetic_images_u8(n, varch.image_size, seed=6)
+    ref = O.coca_vit_forward(sd, vcfg, O.preprocess_u8_exact_size(u8))
+    vt = T.VitTower(varch, sd, "cuda")
+    out = vt.encode_u8(u8.cuda())
+    assert out.shape == (n, varch.out_dim) and _cos_err(out, ref) < COS_TIGHT
+    assert _cos_err(vt.encode_u8(u8[:1].cuda()), ref[:1]) < COS_TIGHT                      # one image (the small-row kernel families)
+    raw = vt.encode_u8(u8.cuda(), normalize=False)
+    assert _cos_err(raw, O.coca_vit_forward(sd, vcfg, O.preprocess_u8_exact_size(u8), normalize=False)) < COS_TIGHT
+    # text: 76 token positions + the class embedding
+    g = torch.Generator().manual_seed(6)
+    S = tarch.ctx - 1
+    ids = torch.zeros(6, S, dtype=torch.int64)
+    for i, ln in enumerate([1, 74, 9, 17, 40, 30]):          # ln random ids between SOT and EOT; 74 fills every position
+        ids[i, 0] = tarch.vocab - 2
+        ids[i, 1:1 + ln] = torch.randint(1, tarch.vocab - 2, (ln,), generator=g)
+        ids[i, 1 + ln] = tarch.vocab - 1
+    tref = O.coca_text_forward(sd, tcfg, ids)
+    tt = T.ClipTextTower(tarch, sd, "cuda")
+    assert tt.cfg.cls_pos == tarch.ctx - 1 and tt.cfg.vocab == tarch.vocab + 1
+    tout = tt.encode_ids(ids)
+    assert tout.shape == (6, tarch.out_dim) and _cos_err(tout, tref) < COS_TIGHT
+    assert _cos_err(tt.encode_ids(ids[2:3]), tref[2:3]) < COS_TIGHT                         # single query
+    lengths = ids.argmax(dim=1) + 1
+    assert _cos_err(tt.encode_device(ids.to(torch.int32).cuda(), lengths), tref) < COS_TIGHT
+    with pytest.raises(ValueError):
+        tt.encode_ids(torch.zeros(1, tarch.ctx, dtype=torch.int64))                         # 77 token positions leave no room for the class embedding
+
+
 def test_single_request_graph_replay_is_bit_identical(monkeypatch):
     """one query text / one image per call replays a hipGraph captured per (tower, token count): same kernels, same bits as the
     eager launches; new contents and new lengths go through, batches are untouched"""
