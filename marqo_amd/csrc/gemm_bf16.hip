@@ -30,6 +30,8 @@
 // -5.7 % ViT-L/14 fc1, +2 % at the ViT-B/32 shapes; inside the towers (cold weights, real launch sequence) +2.9 % ViT-B/32, +2.6 % ViT-L/14,
 // +1.9 % CLIP text embeddings/s.
 #include <stdlib.h>
+#include <map>
+#include <mutex>
 #include <string>
 #include <type_traits>
 #include "common.h"
@@ -80,6 +82,22 @@ __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...
 template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
 
+// The rows that do not fill a 256-row tile (257 tokens per ViT-L/14 image never make a multiple of 256) — the TAIL of the big-tile kernel (WM = 4).
+// A second launch for them is pure latency (tiles_n workgroups walking K / 64 dependent k-steps: 13-33 us, what the big tile saves per GEMM:
+// profiles/r05g) and extra launches for a split-K of them cost more still (r05h).  Inside the SAME launch they are almost free: when the workgroups have
+// finished their full tiles, the one ragged row of tiles is cut along K over ALL of them — workgroup b takes tile b % tiles_n, k-range b / tiles_n
+// of `tail_splits` — a few k-steps each.  Range 0 of a tile owns it: it waits for the flags of the other ranges (every workgroup of the grid is
+// resident and in this phase: nothing can be waited for that has not started), adds their fp32 partials in range order (deterministic) and runs the
+// epilogue; the others leave their accumulators in their slot of `partials` and raise their flag.  Flags carry a per-launch epoch (never reset);
+// a wait of more than ~1 s gives up and raises flags[gridDim.x] instead of hanging the device.  Rows of the tail differ from the tile kernels'
+// results by the fp32 association of the k-sum only.
+struct GemmSk {
+    float* partials;       // [gridDim.x][BM * BN] fp32, one slot per workgroup
+    unsigned* flags;       // [gridDim.x] epoch of the partial that workgroup posted last; [gridDim.x] = error word
+    unsigned epoch;
+    int tail_splits;       // 0 = no tail (M is a multiple of BM, or not the big tile)
+};
+
 // NH: 64-column halves of a wave's sub-tile.  NH = 1: the (32*MT)x128 block tile, two workgroups per CU (the towers' short-K shapes).  NH = 2 (round 5):
 // the WIDE tile, (32*MT)x256 — at MT = 8 the 256x256x64 macro-tile with 128x128 per wave: 64 MFMAs per 16 fragment reads and per 16 LDS-DMA
 // pieces where the 160x128 tile has 20 per 9 and 9 — one workgroup per CU (128 KiB of LDS, 256 accumulator registers per lane: the allocator
@@ -94,8 +112,9 @@ __global__ __launch_bounds__(128 * WM, (NH == 1 && WM == 2) ? 2 : 1) void gemm_n
     const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ Wt, int64_t ldw,
     const float* __restrict__ bias, const float* residual, void* out, int64_t ldc,
     int M, int N, int K, int tiles_n, int num_tiles, int cgroup, int band_rows, int wide_store,
-    unsigned a_bytes, unsigned w_bytes, GemmLn ln) {
+    unsigned a_bytes, unsigned w_bytes, GemmLn ln, GemmSk sk) {
     constexpr int BM = 16 * MT * WM, BN = 128 * NH;
+    constexpr bool TAIL = WM == 4;   // the big tile handles a ragged last row of tiles in-kernel (GemmSk)
     constexpr int NTW = 4 * NH;     // 16-column W sub-tiles per wave (a wave spans half of BN)
     constexpr int A_TILE_BYTES = BM * BK * 2, W_TILE_BYTES = BN * BK * 2;
     constexpr int STAGE_BYTES = A_TILE_BYTES + W_TILE_BYTES;
@@ -162,10 +181,19 @@ __global__ __launch_bounds__(128 * WM, (NH == 1 && WM == 2) ? 2 : 1) void gemm_n
     // memory traffic — which keeps the k-step a single straight-line body without a "nothing left to prefetch" variant.
     int d_vbid = blockIdx.x, d_k = 0;
     unsigned a_rec = a_bytes, w_rec = w_bytes;
-    {
+    bool tail_mode = false;   // TAIL: the cursor walks ONE k-range of a tail tile (d_left steps) instead of whole tiles
+    int d_left = 0;
+    const bool has_main = !TAIL || (int)blockIdx.x < num_tiles;   // (TAIL: the grid is always the 256 workgroups; few full tiles may leave some without one)
+    if (has_main) {
         int m0, n0;
         tile_origin(d_vbid, m0, n0);
         set_sources(m0, n0);
+    } else {
+        a_rec = 0; w_rec = 0;
+#pragma unroll
+        for (int i = 0; i < NPA; ++i) a_vo[i] = 0;
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) w_vo[i] = 0;
     }
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     const unsigned dma_a0 = lds0 + (unsigned)wave * (8 * MT * 128), dma_w0 = lds0 + A_TILE_BYTES + (unsigned)wave * (8 * NPW * 128);   // scalars
@@ -175,6 +203,11 @@ __global__ __launch_bounds__(128 * WM, (NH == 1 && WM == 2) ? 2 : 1) void gemm_n
         else dma16(__builtin_amdgcn_make_buffer_rsrc((void*)Wt, 0, w_rec, 0x00020000), w_vo[i >= NPA ? i - NPA : 0], soff, dma_w0 + bufoff + (unsigned)(i - NPA) * 1024u);
     };
     auto advance_cursor = [&]() {
+        if (TAIL && tail_mode) {
+            ++d_k;
+            if (--d_left <= 0) { a_rec = 0; w_rec = 0; }   // past the k-range: out-of-range requests, no traffic
+            return;
+        }
         if (++d_k == nk) {
             d_k = 0;
             d_vbid += gridDim.x;
@@ -203,19 +236,23 @@ __global__ __launch_bounds__(128 * WM, (NH == 1 && WM == 2) ? 2 : 1) void gemm_n
         else af[P - NTW] = lds_read16<(P - NTW) * 2048>(abase);
     };
 
-    // ---- prologue: the workgroup's first two stages, then the kk = 0 fragments of the first -----------------------------------------
-#pragma unroll
-    for (int i = 0; i < NLD; ++i) issue_piece(i, 0);
-    advance_cursor();
-#pragma unroll
-    for (int i = 0; i < NLD; ++i) issue_piece(i, STAGE_BYTES);
-    advance_cursor();
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");   // stage 0 landed (loads retire in issue order)
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    static_for<NLR>([&](auto p_tag) { read_piece(p_tag, wB0, aB0, wf0, af0); });
-
+    // ---- prologue: the workgroup's first two stages, then the kk = 0 fragments of the first (a lambda: the tail phase primes the ring again) ---------
     unsigned bufoff = 0;   // LDS byte offset of the stage the next k-step consumes
+    auto prime = [&]() {
+        bufoff = 0;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) issue_piece(i, 0);
+        advance_cursor();
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) issue_piece(i, STAGE_BYTES);
+        advance_cursor();
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");   // stage 0 landed (loads retire in issue order)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        static_for<NLR>([&](auto p_tag) { read_piece(p_tag, wB0, aB0, wf0, af0); });
+    };
+    if (has_main) prime();
+
     int c_vbid = blockIdx.x;
 
     // one k-step on the stage at `bufoff`; on entry (wf0, af0) hold (or are about to receive) its kk = 0 fragments
@@ -285,7 +322,7 @@ __global__ __launch_bounds__(128 * WM, (NH == 1 && WM == 2) ? 2 : 1) void gemm_n
         bufoff ^= (unsigned)STAGE_BYTES;
     };
 
-    for (;;) {
+    if (has_main) for (;;) {
         int cm0, cn0;
         tile_origin(c_vbid, cm0, cn0);
 #pragma unroll
@@ -326,6 +363,105 @@ __global__ __launch_bounds__(128 * WM, (NH == 1 && WM == 2) ? 2 : 1) void gemm_n
     }
     // the trailing (out-of-range) LDS-DMA requests must have retired before the workgroup's LDS can be handed to another one
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    if constexpr (TAIL) {
+        // ---- the tail: the ragged last row of tiles, cut along K over the whole grid (see GemmSk) ---------------------------------------------------
+        const int S = sk.tail_splits;
+        const int t_tile = (int)blockIdx.x % tiles_n, t_split = (int)blockIdx.x / tiles_n;
+        if (S <= 0 || t_split >= S) return;
+        const int k0 = (int)((int64_t)t_split * nk / S), k1 = (int)((int64_t)(t_split + 1) * nk / S);
+        const int cm0 = (M / BM) * BM, cn0 = t_tile * BN;
+        __builtin_amdgcn_s_barrier();      // every wave is done with the main phase's LDS ring
+        tail_mode = true;
+        d_k = k0;
+        d_left = k1 - k0;
+        a_rec = a_bytes; w_rec = w_bytes;
+        set_sources(cm0, cn0);
+        prime();
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[h][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // (do-while: the host gives every range at least one k-step; a zero-trip path would merge an all-zero accumulator file with the loop's and the
+        // allocator answers that with 128 register copies and spills)
+        {
+            int kt = k0;
+            do { kstep(); } while (++kt < k1);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) landed(wf0[t]);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) landed(af0[t]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing out-of-range requests
+        // a lane's 32 accumulator quads of a slot: [wave][quad][lane] x 16 B — every store / load instruction moves 1 KiB contiguous per wave
+        constexpr int QUADS = NH * MT * 4;
+        constexpr size_t SLOT_QUADS = (size_t)(BM * BN / 4);
+        const unsigned my_quad = (unsigned)wave * (QUADS * 64) + (unsigned)lane;
+        {
+            // EVERY range — the owner too — leaves its accumulators in its slot: the owner then builds the tile's sum in a FRESH register array from
+            // memory, its own partial first.  (Adding the others' partials into the k-loop's accumulators made the allocator shuffle all 128 of them
+            // between the two loops, through scratch; 256 KB of round trip per tail tile is nothing.)
+            f32x4* dst = (f32x4*)sk.partials + (size_t)blockIdx.x * SLOT_QUADS + my_quad;
+            static_for<NH * MT>([&](auto hi_tag) {   // 4 stores (immediate offsets 0 .. 3 KiB) per pointer, then the pointer moves on
+                constexpr int h = decltype(hi_tag)::value / MT, i = decltype(hi_tag)::value % MT;
+                asm volatile("" : "+v"(dst));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dst[j * 64] = acc[h][i][j];
+                dst += 256;
+            });
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __builtin_amdgcn_s_barrier();
+            if (t_split > 0) {
+                if (tid == 0) __hip_atomic_store(sk.flags + blockIdx.x, sk.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+        }
+        f32x4 sum[NH][MT][4];
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sum[h][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int r2 = 0; r2 < S; ++r2) {          // the k-ranges of my tile in range order, mine first
+            const unsigned bid = (unsigned)(r2 * tiles_n + t_tile);
+            if (r2 > 0 && tid == 0) {
+                int spins = 0;
+                while (__hip_atomic_load(sk.flags + bid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sk.epoch) {
+                    __builtin_amdgcn_s_sleep(8);
+                    if (++spins > (1 << 22)) {   // ~1 s: never hang the device; the launch's result is then wrong and says so
+                        __hip_atomic_store(sk.flags + gridDim.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+            }
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            const f32x4* src = (const f32x4*)sk.partials + (size_t)bid * SLOT_QUADS + my_quad;
+            static_for<NH * MT>([&](auto hi_tag) {   // four quads at a time, fenced (or the scheduler hoists all 32 loads in front of the first add)
+                constexpr int h = decltype(hi_tag)::value / MT, i = decltype(hi_tag)::value % MT;
+                asm volatile("" : "+v"(src));
+                f32x4 t4[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) t4[j] = src[j * 64];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sum[h][i][j] += t4[j];
+                src += 256;
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        int l15e = l15, ge = g;
+        asm volatile("" : "+v"(l15e), "+v"(ge));
+        static_for<NH>([&](auto h_tag) {
+            constexpr int h = decltype(h_tag)::value;
+            gemm_epilogue<FLAGS, MT, ERG, true, false>(sum[h], bias, residual, out, ldc, M, N, cm0 + wm * (16 * MT), cn0 + wn * (16 * NTW) + h * 64, l15e, ge, wide_store != 0, &ln, nullptr);
+        });
+    }
 }
 
 #ifdef MQ_GEMM_PROBE   // compile-and-inspect builds (tests/test_gemm_isa.py): ONE instantiation, hipcc -DMQ_GEMM_PROBE=<flags> -DMQ_GEMM_PROBE_MT=<mt> -S
@@ -343,7 +479,7 @@ constexpr int RESIDENT_SLOTS_WIDE = 256;  // 256 CUs x 1 workgroup (NH = 2: 120 
 
 // tuning knobs: initialised from the environment (MQ_GEMM_MT / _CGROUP / _NH), overridable through mq_tune()
 struct GemmTune {
-    int mt, cgroup, nh;
+    int mt, cgroup, nh, tail = 1;
     static int env(const char* k, int d) { const char* v = getenv(k); return v ? atoi(v) : d; }
     GemmTune() : mt(env("MQ_GEMM_MT", 0)), cgroup(env("MQ_GEMM_CGROUP", 8)), nh(env("MQ_GEMM_NH", 0)) {}
 };
@@ -376,6 +512,40 @@ int choose_mt(int M, int N) {
     return best;
 }
 
+// ---- workspace of the big tile's in-kernel tail (GemmSk): partial-sum slots + flags, one block per HIP stream (launches on a stream are ordered, so
+// its slots are free again when the next launch starts; request threads own their streams).  Allocated on a stream's first big-tile launch with a
+// tail and kept for the process — the ONE place where this library allocates device memory itself (the C ABI's GEMM entry points take no workspace).
+struct SkWorkspace { float* partials = nullptr; unsigned* flags = nullptr; unsigned epoch = 0; };
+std::mutex g_sk_mu;
+std::map<std::pair<int, hipStream_t>, SkWorkspace> g_sk_ws;
+constexpr size_t SK_SLOT_BYTES = 256 * 256 * 4;
+
+int sk_workspace(hipStream_t s, GemmSk& out) {
+    int dev = 0;
+    hipGetDevice(&dev);
+    std::lock_guard<std::mutex> g(g_sk_mu);
+    SkWorkspace& w = g_sk_ws[{dev, s}];
+    if (!w.partials) {
+        void* p = nullptr;
+        const size_t bytes = (size_t)RESIDENT_SLOTS_WIDE * SK_SLOT_BYTES + 4096;
+        if (hipError_t e = hipMalloc(&p, bytes); e != hipSuccess) {
+            mq_set_error("mq_gemm_bf16: tail workspace (%zu bytes): %s", bytes, hipGetErrorString(e));
+            return MQ_ERR_HIP;
+        }
+        w.partials = (float*)p;
+        w.flags = (unsigned*)((char*)p + (size_t)RESIDENT_SLOTS_WIDE * SK_SLOT_BYTES);
+        if (hipError_t e = hipMemsetAsync(w.flags, 0, 4096, s); e != hipSuccess) {
+            mq_set_error("mq_gemm_bf16: tail workspace memset: %s", hipGetErrorString(e));
+            return MQ_ERR_HIP;
+        }
+    }
+    if (++w.epoch == 0) w.epoch = 1;     // (0 is the cleared state)
+    out.partials = w.partials;
+    out.flags = w.flags;
+    out.epoch = w.epoch;
+    return MQ_OK;
+}
+
 template <int FLAGS, int MT, int NH = 1, int ORD = 2, int WM = 2>
 int launch_gemm_mt(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* residual, void* out, int64_t ldc,
                    int M, int N, int K, hipStream_t s, const GemmLn& ln) {
@@ -406,12 +576,22 @@ int launch_gemm_mt(const void* A, int64_t lda, const void* W, int64_t ldw, const
     const int tiles_n = (N + BN - 1) / BN;
     for (int64_t r0 = 0; r0 < M; r0 += max_rows) {
         const int m = (int)((M - r0) < max_rows ? (M - r0) : max_rows);
-        const int tiles_m = (m + BM - 1) / BM;
+        // big tile: a ragged last row of tiles is not a round of its own but the in-kernel tail (GemmSk), cut along K over the whole grid
+        GemmSk sk{};
+        int tiles_m = (m + BM - 1) / BM;
+        if constexpr (WM == 4) {
+            const int nk = K / BK;
+            if (g_tune.tail && m % BM != 0 && m >= BM && tiles_n <= SLOTS) {
+                if (int rc = sk_workspace(s, sk); rc != MQ_OK) return rc;
+                sk.tail_splits = SLOTS / tiles_n < nk ? SLOTS / tiles_n : nk;
+                tiles_m = m / BM;
+            }
+        }
         const int num_tiles = tiles_m * tiles_n;
         // L2 blocking only when there is something to block: more column tiles than one group and at least two row panels per XCD
         const int cgroup = (g_tune.cgroup > 0 && tiles_n > g_tune.cgroup && tiles_m >= 16) ? g_tune.cgroup : 0;
         const int band_rows = (tiles_m + 7) / 8;
-        const int grid = num_tiles > SLOTS ? SLOTS : num_tiles;
+        const int grid = sk.tail_splits > 0 ? SLOTS : (num_tiles > SLOTS ? SLOTS : num_tiles);
         const uint64_t a_bytes = ((uint64_t)(m - 1) * (uint64_t)lda + (uint64_t)K) * 2;
         const size_t out_row = (size_t)ldc * ((FLAGS & MQ_EPI_OUT_F32) ? 4 : 2);
         const size_t res_row = (size_t)ldc * (((FLAGS & MQ_EPI_RESIDUAL) && !(FLAGS & MQ_EPI_OUT_F32)) ? 2 : 4);
@@ -420,7 +600,7 @@ int launch_gemm_mt(const void* A, int64_t lda, const void* W, int64_t ldw, const
         if (ln_chunk.partials) ln_chunk.partials += r0 * ln_chunk.nslots;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(128 * WM), LDS, s, (const bf16_t*)A + r0 * lda, lda, (const bf16_t*)W, ldw, bias,
                            residual ? (const float*)((const char*)residual + (size_t)r0 * res_row) : nullptr, (void*)((char*)out + (size_t)r0 * out_row),
-                           ldc, m, N, K, tiles_n, num_tiles, cgroup, band_rows, wide, (unsigned)a_bytes, (unsigned)w_bytes, ln_chunk);
+                           ldc, m, N, K, tiles_n, num_tiles, cgroup, band_rows, wide, (unsigned)a_bytes, (unsigned)w_bytes, ln_chunk, sk);
         MQ_CHECK_LAUNCH("mq_gemm_bf16");
     }
     return MQ_OK;
@@ -467,13 +647,20 @@ int plan_big_rows(int M, int N, int K) {
         return (double)((tiles + RESIDENT_SLOTS_WIDE - 1) / RESIDENT_SLOTS_WIDE) * (8.0 / BIG_TILE_SPEEDUP + 1.25);
     };
     const double all_narrow = narrow_cost(M);
-    int best_rt = 0;
-    double best = all_narrow * (eager ? 0.97 : 0.92);               // what the split has to win to be worth a second launch (see the measurements above)
+    int best_rows = 0;
+    double best = all_narrow * (eager ? 0.97 : 0.92);               // what the big tile has to win (see the measurements above)
+    // (a) every row on the big tile: the full row tiles in rounds, the ragged rest as the in-kernel tail (a few k-steps per workgroup + the partial
+    // sums' round trip: ~9 us whatever K is; a cost unit is ~3.1 ns x K)
+    if (M % 256 == 0 || (g_tune.tail && tiles_n <= RESIDENT_SLOTS_WIDE)) {
+        const double c = big_cost(rt_max) + (M % 256 ? 2900.0 / K : 0.0);
+        if (c < best) { best = c; best_rows = M; }
+    }
+    // (b) the leading rows that fill whole rounds on the big tile, the rest in a second launch of the narrow kernel
     for (int rt = rt_max; rt >= rt_max - 32 && rt >= 16; --rt) {
         const double c = big_cost(rt) + narrow_cost(M - rt * 256);
-        if (c < best) { best = c; best_rt = rt; }
+        if (c < best) { best = c; best_rows = rt * 256; }
     }
-    return best_rt * 256;
+    return best_rows;
 }
 
 template <int FLAGS>
@@ -602,6 +789,7 @@ extern "C" int mq_tune(const char* key, int value) {
     if (k == "gemm_mt") { g_tune.mt = value; mq_gemm_fp8_force_mt = value; }
     else if (k == "gemm_cgroup") mq_gemm_knob_cgroup = g_tune.cgroup = value;
     else if (k == "gemm_nh") g_tune.nh = value;
+    else if (k == "gemm_tail") g_tune.tail = value;
     else if (k == "row_select") mq_tower_row_select = value;
     else if (k == "ln_fold") mq_tower_ln_fold = value;
     else if (k == "xcd_band") mq_xcd_band = value;

