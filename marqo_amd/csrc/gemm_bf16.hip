@@ -86,9 +86,9 @@ __device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_in
 // A second launch for them is pure latency (tiles_n workgroups walking K / 64 dependent k-steps: 13-33 us, what the big tile saves per GEMM:
 // profiles/r05g) and extra launches for a split-K of them cost more still (r05h).  Inside the SAME launch they are almost free: when the workgroups have
 // finished their full tiles, the one ragged row of tiles is cut along K over ALL of them — workgroup b takes tile b % tiles_n, k-range b / tiles_n
-// of `tail_splits` — a few k-steps each.  Range 0 of a tile owns it: it waits for the flags of the other ranges (every workgroup of the grid is
-// resident and in this phase: nothing can be waited for that has not started), adds their fp32 partials in range order (deterministic) and runs the
-// epilogue; the others leave their accumulators in their slot of `partials` and raise their flag.  Flags carry a per-launch epoch (never reset);
+// of `tail_splits` (a power of two <= 8) — a few k-steps each.  Every range leaves its fp32 accumulators in its slot of `partials`, raises its flag and
+// waits for the flags of the tile's other ranges (every workgroup of the grid is resident and in this phase: nothing can be waited for that has
+// not started); then the ranges share out the tile's sum and epilogue by regions (below): partials added in range order (deterministic).  Flags carry a per-launch epoch (never reset);
 // a wait of more than ~1 s gives up and raises flags[gridDim.x] instead of hanging the device.  Rows of the tail differ from the tile kernels'
 // results by the fp32 association of the k-sum only.
 struct GemmSk {
@@ -399,12 +399,9 @@ __global__ __launch_bounds__(128 * WM, (NH == 1 && WM == 2) ? 2 : 1) void gemm_n
         // a lane's 32 accumulator quads of a slot: [wave][quad][lane] x 16 B — every store / load instruction moves 1 KiB contiguous per wave
         constexpr int QUADS = NH * MT * 4;
         constexpr size_t SLOT_QUADS = (size_t)(BM * BN / 4);
-        const unsigned my_quad = (unsigned)wave * (QUADS * 64) + (unsigned)lane;
         {
-            // EVERY range — the owner too — leaves its accumulators in its slot: the owner then builds the tile's sum in a FRESH register array from
-            // memory, its own partial first.  (Adding the others' partials into the k-loop's accumulators made the allocator shuffle all 128 of them
-            // between the two loops, through scratch; 256 KB of round trip per tail tile is nothing.)
-            f32x4* dst = (f32x4*)sk.partials + (size_t)blockIdx.x * SLOT_QUADS + my_quad;
+            // every range leaves its accumulators in its slot and raises its flag ...
+            f32x4* dst = (f32x4*)sk.partials + (size_t)blockIdx.x * SLOT_QUADS + (size_t)wave * (QUADS * 64) + lane;
             static_for<NH * MT>([&](auto hi_tag) {   // 4 stores (immediate offsets 0 .. 3 KiB) per pointer, then the pointer moves on
                 constexpr int h = decltype(hi_tag)::value / MT, i = decltype(hi_tag)::value % MT;
                 asm volatile("" : "+v"(dst));
@@ -414,53 +411,43 @@ __global__ __launch_bounds__(128 * WM, (NH == 1 && WM == 2) ? 2 : 1) void gemm_n
             });
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             __builtin_amdgcn_s_barrier();
-            if (t_split > 0) {
-                if (tid == 0) __hip_atomic_store(sk.flags + blockIdx.x, sk.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                return;
-            }
-        }
-        f32x4 sum[NH][MT][4];
-#pragma unroll
-        for (int h = 0; h < NH; ++h)
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) sum[h][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int r2 = 0; r2 < S; ++r2) {          // the k-ranges of my tile in range order, mine first
-            const unsigned bid = (unsigned)(r2 * tiles_n + t_tile);
-            if (r2 > 0 && tid == 0) {
-                int spins = 0;
-                while (__hip_atomic_load(sk.flags + bid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sk.epoch) {
-                    __builtin_amdgcn_s_sleep(8);
-                    if (++spins > (1 << 22)) {   // ~1 s: never hang the device; the launch's result is then wrong and says so
-                        __hip_atomic_store(sk.flags + gridDim.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        break;
+            if (tid == 0) {
+                __hip_atomic_store(sk.flags + blockIdx.x, sk.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // ... and waits for the flags of the tile's other ranges (all of them are running this very phase)
+                for (int r2 = 0; r2 < S; ++r2) {
+                    const unsigned* f = sk.flags + (r2 * tiles_n + t_tile);
+                    int spins = 0;
+                    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sk.epoch) {
+                        __builtin_amdgcn_s_sleep(4);
+                        if (++spins > (1 << 22)) {   // ~1 s: never hang the device; the launch's result is then wrong and says so
+                            __hip_atomic_store(sk.flags + gridDim.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            break;
+                        }
                     }
                 }
             }
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            const f32x4* src = (const f32x4*)sk.partials + (size_t)bid * SLOT_QUADS + my_quad;
-            static_for<NH * MT>([&](auto hi_tag) {   // four quads at a time, fenced (or the scheduler hoists all 32 loads in front of the first add)
-                constexpr int h = decltype(hi_tag)::value / MT, i = decltype(hi_tag)::value % MT;
-                asm volatile("" : "+v"(src));
-                f32x4 t4[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) t4[j] = src[j * 64];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) sum[h][i][j] += t4[j];
-                src += 256;
-                __builtin_amdgcn_sched_barrier(0);
-            });
         }
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
+        // The sum and the epilogue are shared out too (one owner per tile adding S partials of 256 KB through one CU took longer than the tile): the
+        // tile is the 8 regions its 8 waves computed (64 x 128 each); range s finishes regions s, s + S, ..., and inside a workgroup wave w takes the
+        // 16 x 64 piece (h, i) = (w / MT, w % MT) of the region — 4 quads per partial and lane, added in range order (deterministic) into the layout of
+        // a one-row-group accumulator, which the very same gemm_epilogue finishes.
+        static_assert(MT * NH == 8 && WM == 4, "the tail shares a tile out as 8 regions x 8 pieces");
+        const int ph = wave / MT, pi = wave % MT;
         int l15e = l15, ge = g;
         asm volatile("" : "+v"(l15e), "+v"(ge));
-        static_for<NH>([&](auto h_tag) {
-            constexpr int h = decltype(h_tag)::value;
-            gemm_epilogue<FLAGS, MT, ERG, true, false>(sum[h], bias, residual, out, ldc, M, N, cm0 + wm * (16 * MT), cn0 + wn * (16 * NTW) + h * 64, l15e, ge, wide_store != 0, &ln, nullptr);
-        });
+        for (int region = t_split; region < 8; region += S) {
+            f32x4 piece[1][4] = {{f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}};
+            for (int r2 = 0; r2 < S; ++r2) {
+                const f32x4* src = (const f32x4*)sk.partials + (size_t)(r2 * tiles_n + t_tile) * SLOT_QUADS + (size_t)region * (QUADS * 64)
+                                   + (size_t)((ph * MT + pi) * 4) * 64 + lane;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) piece[0][j] += src[j * 64];
+            }
+            gemm_epilogue<FLAGS, 1, 1, false, false>(piece, bias, residual, out, ldc, M, N, cm0 + (region >> 1) * (16 * MT) + pi * 16,
+                                                     cn0 + (region & 1) * (16 * NTW) + ph * 64, l15e, ge, wide_store != 0, &ln, nullptr);
+        }
     }
 }
 
@@ -581,9 +568,11 @@ int launch_gemm_mt(const void* A, int64_t lda, const void* W, int64_t ldw, const
         int tiles_m = (m + BM - 1) / BM;
         if constexpr (WM == 4) {
             const int nk = K / BK;
-            if (g_tune.tail && m % BM != 0 && m >= BM && tiles_n <= SLOTS) {
+            if (g_tune.tail && m % BM != 0 && m >= BM && tiles_n <= SLOTS && MT * NH == 8) {
                 if (int rc = sk_workspace(s, sk); rc != MQ_OK) return rc;
-                sk.tail_splits = SLOTS / tiles_n < nk ? SLOTS / tiles_n : nk;
+                int S = 8;                                         // ranges per tail tile: a power of two <= 8 (the tile's 8 regions are shared out over them)
+                while (S > 1 && (S * tiles_n > SLOTS || S > nk)) S >>= 1;
+                sk.tail_splits = S;
                 tiles_m = m / BM;
             }
         }
