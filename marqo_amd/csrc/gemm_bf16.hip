@@ -405,11 +405,15 @@ __global__ __launch_bounds__(128 * WM, (NH == 1 && WM == 2) ? 2 : 1) void gemm_n
             static_for<NH * MT>([&](auto hi_tag) {   // 4 stores (immediate offsets 0 .. 3 KiB) per pointer, then the pointer moves on
                 constexpr int h = decltype(hi_tag)::value / MT, i = decltype(hi_tag)::value % MT;
                 asm volatile("" : "+v"(dst));
+                // (agent-scope relaxed atomics = write-through stores: the partials reach the memory side without the L2 write-back of a release
+                // fence — which at this point would flush the whole main phase's output — and the readers below bypass their L2 the same way)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) dst[j * 64] = acc[h][i][j];
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) __hip_atomic_store((float*)(dst + j * 64) + e, acc[h][i][j][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 dst += 256;
             });
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // my stores have left (vmcnt); no cache maintenance
             __builtin_amdgcn_s_barrier();
             if (tid == 0) {
                 __hip_atomic_store(sk.flags + blockIdx.x, sk.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -427,7 +431,6 @@ __global__ __launch_bounds__(128 * WM, (NH == 1 && WM == 2) ? 2 : 1) void gemm_n
                 }
             }
             __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         // The sum and the epilogue are shared out too (one owner per tile adding S partials of 256 KB through one CU took longer than the tile): the
         // tile is the 8 regions its 8 waves computed (64 x 128 each); range s finishes regions s, s + S, ..., and inside a workgroup wave w takes the
@@ -443,7 +446,9 @@ __global__ __launch_bounds__(128 * WM, (NH == 1 && WM == 2) ? 2 : 1) void gemm_n
                 const f32x4* src = (const f32x4*)sk.partials + (size_t)(r2 * tiles_n + t_tile) * SLOT_QUADS + (size_t)region * (QUADS * 64)
                                    + (size_t)((ph * MT + pi) * 4) * 64 + lane;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) piece[0][j] += src[j * 64];
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) piece[0][j][e] += __hip_atomic_load((const float*)(src + j * 64) + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             gemm_epilogue<FLAGS, 1, 1, false, false>(piece, bias, residual, out, ldc, M, N, cm0 + (region >> 1) * (16 * MT) + pi * 16,
                                                      cn0 + (region & 1) * (16 * NTW) + ph * 64, l15e, ge, wide_store != 0, &ln, nullptr);
