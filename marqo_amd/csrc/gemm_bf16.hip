@@ -365,6 +365,9 @@ __global__ __launch_bounds__(128 * WM, (NH == 1 && WM == 2) ? 2 : 1) void gemm_n
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     if constexpr (TAIL) {
+        // (the compiler routes the tile loop's back edge through its loop-invariant guard, so STATICALLY the re-read block above can fall into this
+        // phase with its ds_reads in flight; it never does, and this wait makes that visible to tests/test_gemm_isa.py's control-flow walk)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         // ---- the tail: the ragged last row of tiles, cut along K over the whole grid (see GemmSk) ---------------------------------------------------
         const int S = sk.tail_splits;
         const int t_tile = (int)blockIdx.x % tiles_n, t_split = (int)blockIdx.x / tiles_n;

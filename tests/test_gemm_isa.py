@@ -160,7 +160,9 @@ def test_big_8_wave_tile_follows_the_same_rules(tmp_path, flags):
     wave and k-half): the same loop — 2 * 32 MFMAs in ONE k-step body, one vmcnt wait, one barrier, no scratch inside the 256 registers of a
     2-waves-per-SIMD lane; fragment reads: prologue + both half-steps + the re-read behind the epilogue = 4 * 12"""
     isa, remarks = _compile(tmp_path, flags, 4, nh=2, wm=4)
-    _check(isa, remarks, "v_mfma_f32_16x16x32_bf16", 2 * 32, 4 * 12)
+    # two k-step bodies: the tile walk's and the in-kernel tail's (the ragged last row of tiles, cut along K over the grid); fragment reads:
+    # (prologue + both half-steps) x 2 phases + the re-read behind the tile walk's epilogue
+    _check(isa, remarks, "v_mfma_f32_16x16x32_bf16", 2 * 2 * 32, 7 * 12, hot_regions=2)
     assert re.search(r"Occupancy \[waves/SIMD\]: 2\b", remarks)
 
 
