@@ -474,9 +474,13 @@ constexpr int RESIDENT_SLOTS_WIDE = 256;  // 256 CUs x 1 workgroup (NH = 2: 120 
 
 // tuning knobs: initialised from the environment (MQ_GEMM_MT / _CGROUP / _NH), overridable through mq_tune()
 struct GemmTune {
-    int mt, cgroup, nh, tail = 1;
+    // tail: the big tile's in-kernel tail (GemmSk).  OFF by default: its rows carry a differently associated k-sum, so an embedding's bits would
+    // depend on whether its tokens sit in the last partial row tile of a batch — the towers promise the same bits wherever an item stands
+    // (tests/test_towers_gpu.py permutation equivariance; the coalescer and the ingest merging lean on it) — for +1.6 % / +3.9 % on the ViT-L/14 rows
+    // (profiles/r05p).  mq_tune("gemm_tail", 1) / MQ_GEMM_TAIL=1 turns it on; without it a ragged last row tile is a tile like any other.
+    int mt, cgroup, nh, tail;
     static int env(const char* k, int d) { const char* v = getenv(k); return v ? atoi(v) : d; }
-    GemmTune() : mt(env("MQ_GEMM_MT", 0)), cgroup(env("MQ_GEMM_CGROUP", 8)), nh(env("MQ_GEMM_NH", 0)) {}
+    GemmTune() : mt(env("MQ_GEMM_MT", 0)), cgroup(env("MQ_GEMM_CGROUP", 8)), nh(env("MQ_GEMM_NH", 0)), tail(env("MQ_GEMM_TAIL", 0)) {}
 };
 GemmTune g_tune;
 }  // namespace

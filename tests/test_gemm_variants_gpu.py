@@ -16,7 +16,7 @@ def _tiled_family(tiled_gemm_only):
     yield
 
 
-DEFAULTS = dict(gemm_mt=0, gemm_cgroup=8, gemm_nh=0, gemm_tail=1)
+DEFAULTS = dict(gemm_mt=0, gemm_cgroup=8, gemm_nh=0, gemm_tail=0)
 SHAPES = [(50, 64, 64), (257, 768, 128), (1000, 132, 192), (4097, 2304, 768), (12800, 768, 3072), (333, 3072, 64), (16, 4, 64),
           (20000, 1160, 64), (3000, 1288, 128)]
 
@@ -146,14 +146,14 @@ def test_row_chunks_under_a_lowered_address_limit_are_bit_identical():
         assert torch.equal(x, y)
 
 
-@pytest.mark.parametrize("nh", [0, 4, 3])
-def test_the_big_tile_is_bit_identical_to_the_narrow_one_except_its_tail(nh):
+@pytest.mark.parametrize("nh,tail", [(0, 0), (4, 0), (3, 0), (4, 1), (3, 1)])
+def test_the_big_tile_is_bit_identical_to_the_narrow_one_except_its_tail(nh, tail):
     """round 5: the 256 x 256 8-wave tile — on every row (gemm_nh = 3) and in the row-split plans (gemm_nh = 0 default, 4 eager) — accumulates every
     output element over k in the same order as the (32*MT) x 128 tiles: same bits with every epilogue, on ragged shapes (N not a multiple of 256,
     N < 256 falls back to the narrow tile, K = 64: one k-step per tile); row statistics and the folded LayerNorm included; 20 repeated launches screen
     the LDS ring and the tail's flags for races.  The rows behind the last full 256-row tile go through the in-kernel TAIL (K cut over the grid,
     fp32 partials added in range order): deterministic, and equal to the narrow tile's rows up to the fp32 association of the k-sum — one bf16 ulp
-    after the store."""
+    after the store.  The tail is opt-in (gemm_tail = 1): by default a ragged last row tile is a tile like any other and EVERY row is bit-identical."""
     lib = L.load()
     g = torch.Generator(device="cuda").manual_seed(31)
     try:
@@ -167,13 +167,13 @@ def test_the_big_tile_is_bit_identical_to_the_narrow_one_except_its_tail(nh):
                      (L.MQ_EPI_BIAS | L.MQ_EPI_RESIDUAL | L.MQ_EPI_OUT_F32, res), (L.MQ_EPI_BIAS | L.MQ_EPI_RESIDUAL, res.to(torch.bfloat16))]
             _tune(lib, gemm_nh=1)
             base = [_gemm(lib, A, W, b, r, f) for f, r in forms]
-            _tune(lib, gemm_nh=nh)
-            full = (M // 256) * 256          # rows in front of the tail
+            _tune(lib, gemm_nh=nh, gemm_tail=tail)
+            full = (M // 256) * 256 if tail else M          # rows in front of the tail
             first = None
             for rep in range(20 if (M, N, K) in ((12800, 768, 768), (16448, 1024, 4096)) else 2):
                 big = [_gemm(lib, A, W, b, r, f) for f, r in forms]
                 for x, y, (f, _) in zip(base, big, forms):
-                    assert torch.equal(x[:full], y[:full]), (nh, (M, N, K), f, rep)
+                    assert torch.equal(x[:full], y[:full]), (nh, tail, (M, N, K), f, rep)
                     if full < M:
                         d = (x[full:].float() - y[full:].float()).abs().max().item()
                         tol = (2 ** -7 if y.dtype == torch.bfloat16 else 2e-5) * (x[full:].float().abs().max().item() + 1e-6)
