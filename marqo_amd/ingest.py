@@ -350,6 +350,7 @@ MERGE_TEXT_TOKENS = int(os.environ.get("MARQO_AMD_INGEST_MERGE_TEXT_TOKENS", "24
 MERGE_MAX_REQUESTS = int(os.environ.get("MARQO_AMD_INGEST_MERGE_MAX_REQUESTS", "64"))
 MERGE_DEADLINE_MS = float(os.environ.get("MARQO_AMD_INGEST_MERGE_DEADLINE_MS", "2"))
 PIPELINE_DEPTH = int(os.environ.get("MARQO_AMD_INGEST_PIPELINE_DEPTH", "1"))     # groups in flight per rank
+OVERLAP_SETTLE = os.environ.get("MARQO_AMD_INGEST_OVERLAP_SETTLE", "1") != "0"
 
 
 def _deadline_loop(ref) -> None:
@@ -421,6 +422,8 @@ class RequestShardedIngest:
         self._cv = threading.Condition(self._lock)
         self._closed = False
         self._deadline_thread: Optional[threading.Thread] = None
+        self.overlap_settle = OVERLAP_SETTLE     # file the leaving group's rows while the next group is being launched (a launcher thread)
+        self._launcher = None
 
     # ---- ownership ------------------------------------------------------------------------------------------------------------------------
     def owner(self, request_index: int) -> int:
@@ -506,7 +509,20 @@ class RequestShardedIngest:
         self.groups_launched.append([r for r, _ in group])
         try:
             self._queue(group)
-            handle = self._bulk.flush_async()
+            if self.overlap_settle and self.pipeline_depth > 0 and self._inflight_q and self._bulk._two_threads():
+                # the launch (tokenise / pack / enqueue: milliseconds of host work) runs on a launcher thread while THIS thread files the rows of
+                # the group(s) that have to leave the pipeline anyway — the wait for their D2H and the per-row bookkeeping no longer sit in front
+                # of the next pack (on a slow host the stream was bound by exactly this thread: profiles/r05t_stream_overlap_settle.txt)
+                if self._launcher is None:
+                    from concurrent.futures import ThreadPoolExecutor
+                    self._launcher = ThreadPoolExecutor(max_workers=1, thread_name_prefix="marqo-amd-ingest-launch")
+                fut = self._launcher.submit(self._bulk.flush_async)
+                try:
+                    self._settle(reraise=False, keep=self.pipeline_depth - 1)
+                finally:
+                    handle = fut.result()
+            else:
+                handle = self._bulk.flush_async()
         except BaseException as e:
             # One bad document (an undecodable image) must not poison this rank's stream: BulkVectoriser re-queues the failed modality and
             # keeps the other one's rows for a retry, but a request is all-or-nothing here — drop both, so that the NEXT group starts from

@@ -474,3 +474,24 @@ def test_two_groups_in_flight_keep_submission_order():
     assert sorted(rows) == [0, 1, 2, 4, 5, 6, 7] and ing.failed_requests == [3] and ing._inflight is None
     for i in rows:
         _check_rows(rows, i)
+
+
+def test_settle_overlaps_the_next_launch_without_changing_order_or_isolation():
+    """on a GPU the launch of group g + 1 runs on a launcher thread while the submitting thread files group g's rows: same order, same rows, same
+    failure isolation (forced here on the CPU fake: the two-thread predicate is what gates it)"""
+    from marqo_amd.ingest import RequestShardedIngest
+    calls = []
+    ing = RequestShardedIngest("m", "cpu", vectorise_fn=_numbered(calls), merge_images=4, merge_deadline_ms=0)
+    ing._bulk._two_threads = lambda: True
+    assert ing.overlap_settle
+    for i in range(9):
+        if i == 5:
+            with pytest.raises(OSError):
+                ing.submit(i, _req(i, bad=1))          # group [4, 5] fails on the launcher thread: isolated, 5 is the submitter's own
+        else:
+            ing.submit(i, _req(i))
+    assert ing._launcher is not None and ing.failed == [5]
+    rows = ing.collect()
+    assert sorted(rows) == [0, 1, 2, 3, 4, 6, 7, 8] and ing.failed_requests == [5]
+    for i in rows:
+        _check_rows(rows, i)
