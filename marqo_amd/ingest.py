@@ -363,6 +363,16 @@ def _deadline_loop(ref) -> None:
         del ing
 
 
+class _Request:
+    """one submitted request, as RequestShardedIngest keeps it until its rows are filed"""
+    __slots__ = ("keys", "texts", "images")
+
+    def __init__(self):
+        self.keys: List[Tuple[int, Hashable]] = []                 # (request index, key) in submission order
+        self.texts: List[Tuple[Tuple[int, Hashable], Any]] = []    # ((request index, key), content) per modality
+        self.images: List[Tuple[Tuple[int, Hashable], Any]] = []
+
+
 class RequestShardedIngest:
     """BASELINE configs[3] ("add_documents bulk ingest: mixed text + image docs sharded across the GPUs, RCCL gather"), sharded AT THE
     SOURCE: ranks own disjoint REQUESTS.  Request i (a batch of <= 128 documents, what one add_documents call carries,
@@ -438,16 +448,17 @@ class RequestShardedIngest:
         self.errors[request_index] = error
 
     def _file(self, group, out) -> None:
-        for request_index, items in group:
-            for key, _, _ in items:
-                self._rows.append(out[(request_index, key)])
-                self._index.append((request_index, key))
+        rows, index = self._rows, self._index
+        for request_index, req in group:
+            for ck in req.keys:
+                rows.append(out[ck])
+            index.extend(req.keys)
 
     def _queue(self, group) -> None:
-        """the group's items into the BulkVectoriser's queues; keys are made unique across requests by the request index"""
-        for request_index, items in group:
-            for modality in (Modality.TEXT, Modality.IMAGE):
-                self._bulk.add_many([((request_index, key), content) for key, content, m in items if m == modality], modality)
+        """the group's items into the BulkVectoriser's queues; keys are made unique across requests by the request index (done once, in submit)"""
+        for _, req in group:
+            self._bulk.add_many(req.texts, Modality.TEXT)
+            self._bulk.add_many(req.images, Modality.IMAGE)
 
     def _run_alone(self, group, raise_for: Optional[int] = None) -> Optional[BaseException]:
         """a merged group failed: its requests one at a time, synchronously — the ones that encode are filed (in submission order), the ones
@@ -595,9 +606,22 @@ class RequestShardedIngest:
         (`failed`, `errors[i]`, collect()'s `failed_requests`) then, without failing that call; drain() after submit() is the synchronous form."""
         if not self.owns(request_index):
             raise ValueError(f"rank {self.rank} was handed request {request_index}, which belongs to rank {self.owner(request_index)}")
-        items = list(items)
-        n_images = sum(1 for _, _, m in items if m == Modality.IMAGE)
-        n_tokens = sum(estimate_tokens(c) for _, c, m in items if m == Modality.TEXT)
+        # ONE pass over the request's items (this thread is the stream's critical path: it also packs the images): per-modality (key, content) lists
+        # as the BulkVectoriser queues them, the (request, key) labels in submission order, the merge counters
+        req = _Request()
+        n_tokens = 0.0
+        for key, content, m in items:
+            ck = (request_index, key)
+            req.keys.append(ck)
+            if m == Modality.TEXT:
+                req.texts.append((ck, content))
+                n_tokens += 2.0 + len(content) / 4.0 if isinstance(content, str) else 1.0     # (= estimate_tokens)
+            elif m == Modality.IMAGE:
+                req.images.append((ck, content))
+            else:
+                raise ValueError(f"unsupported modality {m}")
+        items = req
+        n_images = len(req.images)
         with self._cv:
             self.touched.append(request_index)
             if not self._open:
@@ -626,12 +650,17 @@ class RequestShardedIngest:
             self.groups_launched = []
             self.errors = {i: e for i, e in self.errors.items() if i in failed}   # kept until the NEXT collect() for the caller to inspect
         self.failed_requests = sorted(failed)
-        local = np.stack(rows).astype(np.float32, copy=False) if rows else None
         if self.world == 1:
+            # (no copy: the rows are views of the groups' host arrays — stacking 200 000 of them, which the collective below needs, took as long
+            # as the whole stream's GPU work)
             out: Dict[int, Dict[Hashable, np.ndarray]] = {}
+            cur_ri, cur = None, None
             for (ri, key), row in zip(index, rows):
-                out.setdefault(ri, {})[key] = row
+                if ri != cur_ri:
+                    cur_ri, cur = ri, out.setdefault(ri, {})
+                cur[key] = row
             return out
+        local = np.stack(rows).astype(np.float32, copy=False) if rows else None
         dist = self._dist
         on_gpu = dist.get_backend() == "nccl" and str(self.device).startswith("cuda")
         where = self.device if on_gpu else "cpu"
