@@ -670,14 +670,18 @@ class _TowerBase:
         return g
 
     def _workspace(self, nbytes: int) -> Tensor:
-        """this thread's scratch buffer.  It is allocated on, and only ever used from, the stream the thread enqueues on; a thread
-        that switches streams between calls gets a fresh buffer (the old one returns to the caching allocator, which orders reuse)."""
-        ws = getattr(self._tls, "ws", None)
-        stream = torch.cuda.current_stream(self.device)
-        if ws is None or ws.numel() < nbytes or getattr(self._tls, "ws_stream", None) != stream:
-            self._tls.ws = None
-            ws = self._tls.ws = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=self.device)
-            self._tls.ws_stream = stream
+        """this thread's scratch buffer OF THE CURRENT STREAM.  A block is allocated while its stream is current and only ever used from that
+        stream (the caching allocator then orders its reuse behind that stream's work); a thread that alternates between streams — the
+        two-stream image pipeline of open_clip_model.encode_image — keeps one block per stream instead of re-allocating at every switch."""
+        by_stream = getattr(self._tls, "ws", None)
+        if by_stream is None:
+            by_stream = self._tls.ws = {}
+        key = torch.cuda.current_stream(self.device).cuda_stream
+        ws = by_stream.get(key)
+        if ws is None or ws.numel() < nbytes:
+            if len(by_stream) >= 4:     # (streams a thread no longer uses: do not keep their scratch)
+                by_stream.clear()
+            ws = by_stream[key] = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=self.device)
         return ws
 
     def _stream(self) -> int:

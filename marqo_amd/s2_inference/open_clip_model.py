@@ -100,7 +100,25 @@ class OpenCLIPModelProperties:
 
 
 STAGE_BYTES = int(os.environ.get("MARQO_AMD_IMAGE_STAGE_BYTES", str(1 << 30)))   # decoded pixel bytes staged per resize call (pinned host + HBM)
-PIPELINE_CHUNK = int(os.environ.get("MARQO_AMD_IMAGE_PIPELINE_CHUNK", "512"))  # images per host-pack / GPU-encode pipeline stage (smaller chunks cost GEMM efficiency: 64-image chunks ran 256 images in 5.5 ms instead of 3.2, profiles/r02g_e2e_profile.txt)
+# A list call of >= PIPELINE_MIN images goes through in STAGES: everything the GPU does is enqueued asynchronously, so the host packs stage k + 1
+# (pinned staging, a few copy threads) while the GPU resizes and encodes stage k.  Stage size is a trade: the pack in front of the first stage
+# is the GPU's idle time (1.3 ms for 256 Pillow images, 5 ms for 1 024), a small stage's GEMMs fill fewer of the chip's tile slots (64-image stages
+# ran 256 images in 5.5 ms instead of 3.2, profiles/r02g_e2e_profile.txt).  Measured in round 5 (profiles/r05w_e2e_stages.txt, one synchronous
+# caller, ViT-B/32, Pillow 224 x 224): 256 images 5.21 ms in one batch / 4.97 in two stages / 4.90 with the stages on two streams; 384: 7.96 / 6.88;
+# 512: 8.70 / 7.87 / 7.74; 1 024: 18.3 in one batch, 15.1 in the 512-image stages of rounds 2-4, 13.7 in 256-image ones.  So: stages of about
+# PIPELINE_CHUNK images, equal in size, at least two of them.
+PIPELINE_CHUNK = max(1, int(os.environ.get("MARQO_AMD_IMAGE_PIPELINE_CHUNK", "256")))
+PIPELINE_MIN = max(2, int(os.environ.get("MARQO_AMD_IMAGE_PIPELINE_MIN", "256")))
+# The stages alternate between this many HIP streams (1 = all on the request stream): stage k + 1's tower starts beside the tail of stage k's
+# instead of behind it (+1.5 ... 8 %, same bits).
+PIPELINE_STREAMS = max(1, int(os.environ.get("MARQO_AMD_IMAGE_PIPELINE_STREAMS", "2")))
+
+
+def _pipeline_stages(n: int) -> list:
+    """[(first, last + 1)] of the stages of a pipelined image call: max(2, round(n / PIPELINE_CHUNK)) stages of equal size"""
+    k = max(2, int(n / PIPELINE_CHUNK + 0.5))
+    size = -(-n // k)
+    return [(a, min(a + size, n)) for a in range(0, n, size)]
 
 
 class HfClipTokenizer:
@@ -449,14 +467,23 @@ class OPEN_CLIP(AbstractCLIPModel):
         with request_stream(self.device, device_output=return_device):
             run = lambda kind, px: (self.vision.encode_u8(px, normalize=bool(normalize)) if kind == "u8"
                                     else self.vision.encode_f32(px, normalize=bool(normalize)))
-            if isinstance(images, list) and len(images) >= 2 * PIPELINE_CHUNK:
-                # large calls go through in chunks: everything the GPU does is enqueued asynchronously, so the host packs chunk k + 1
-                # (pinned staging, a few copy threads) while the GPU resizes and encodes chunk k; one D2H copy at the end
+            if isinstance(images, list) and len(images) >= PIPELINE_MIN:      # in stages (above); one D2H copy at the end
                 outs, pxs = [], []
-                for a in range(0, len(images), PIPELINE_CHUNK):
-                    kind, px = self._preprocess_images(images[a:a + PIPELINE_CHUNK], image_download_headers)
+                main = torch.cuda.current_stream(self.device)
+                sides = self._pipeline_streams(main) if PIPELINE_STREAMS > 1 else [main]
+                for k, (a, b) in enumerate(_pipeline_stages(len(images))):
+                    st = sides[k % len(sides)]
+                    with torch.cuda.stream(st):
+                        kind, px = self._preprocess_images(images[a:b], image_download_headers)
+                        o = run(kind, px)
+                    if st is not main:      # allocated on the side stream, read by the request stream below
+                        px.record_stream(main)
+                        o.record_stream(main)
                     pxs.append(px)
-                    outs.append(run(kind, px))
+                    outs.append(o)
+                for st in sides:
+                    if st is not main:
+                        main.wait_stream(st)
                 self.image_input_processed = torch.cat(pxs) if len({(p.dtype, p.shape[1:]) for p in pxs}) == 1 else pxs[-1]
                 out = torch.cat(outs)
             else:
@@ -464,6 +491,18 @@ class OPEN_CLIP(AbstractCLIPModel):
                 self.image_input_processed = px
                 out = run(kind, px)
             return out if return_device else self._convert_output(out)
+
+    _pipeline_tls = threading.local()
+
+    def _pipeline_streams(self, main) -> list:
+        """[the request stream, this thread's side streams ...] of the two-stream image pipeline; the side streams start behind the request
+        stream's current position"""
+        side = getattr(self._pipeline_tls, "streams", None)
+        if side is None or len(side) != PIPELINE_STREAMS - 1 or side[0].device != main.device:
+            side = self._pipeline_tls.streams = [torch.cuda.Stream(main.device) for _ in range(PIPELINE_STREAMS - 1)]
+        for st in side:
+            st.wait_stream(main)
+        return [main] + side
 
     def encode_text(self, sentence: Union[str, List[str]], normalize=True, return_device: bool = False):
         if self.model is None:

@@ -636,21 +636,33 @@ def test_siglip_from_disk_text_and_image(s2, tmp_path, monkeypatch):
         os.environ.pop("MARQO_AMD_SYNTHETIC_WEIGHTS", None)
 
 
-def test_large_image_call_is_pipelined_in_chunks(s2, monkeypatch):
-    """>= 2 * PIPELINE_CHUNK images go through host-pack / GPU-encode in chunks: same embeddings as one pass, in order; mixed PIL / array
-    inputs; `image_input_processed` still holds the whole preprocessed batch."""
+@pytest.mark.parametrize("streams", [1, 2, 3])
+def test_large_image_call_is_pipelined_in_stages(s2, monkeypatch, streams):
+    """>= PIPELINE_MIN images go through host-pack / GPU-encode in stages of about PIPELINE_CHUNK images, alternating between PIPELINE_STREAMS
+    HIP streams: same embeddings as one pass, in order — and the SAME BITS whatever the number of streams; mixed PIL / array inputs;
+    `image_input_processed` still holds the whole preprocessed batch."""
     s2i, root = s2
     props, sd, vcfg, _ = _tiny_clip(root)
     from marqo_amd.s2_inference import open_clip_model as M
     rng = np.random.default_rng(5)
     imgs = [rng.integers(0, 256, (40 + (i % 7) * 9, 50 + (i % 5) * 11, 3), dtype=np.uint8) for i in range(37)]
     imgs = [Image.fromarray(a) if i % 2 else a for i, a in enumerate(imgs)]
+    monkeypatch.setattr(M, "PIPELINE_MIN", 1000)
     whole = np.asarray(s2i.vectorise("tiny-clip", imgs, model_properties=props, device=DEV, modality=s2i.Modality.IMAGE))
+    monkeypatch.setattr(M, "PIPELINE_MIN", 16)
     monkeypatch.setattr(M, "PIPELINE_CHUNK", 8)
+    assert [b - a for a, b in M._pipeline_stages(37)] == [8, 8, 8, 8, 5]
     model = s2i.get_available_models()[s2i._create_model_cache_key("tiny-clip", DEV, props)]["model"]
-    chunked = model.encode_image(imgs)
-    assert chunked.shape == whole.shape and _cos_err(chunked, whole) < 3e-5      # (8-image chunks of 17 tokens cross GEMM kernel families)
+    monkeypatch.setattr(M, "PIPELINE_STREAMS", 1)
+    one_stream = model.encode_image(imgs)
+    monkeypatch.setattr(M, "PIPELINE_STREAMS", streams)
+    for _ in range(3):      # (repeated: the side streams' buffers are recycled between calls)
+        staged = model.encode_image(imgs)
+        assert np.array_equal(staged, one_stream)
+    assert staged.shape == whole.shape and _cos_err(staged, whole) < 3e-5      # (8-image stages of 17 tokens cross GEMM kernel families)
     assert tuple(model.image_input_processed.shape) == (37, 64, 64, 3)
+    dev_rows = model.encode_image(imgs, return_device=True)                   # the ingest path's form: rows stay in HBM, ordered behind the caller's stream
+    assert np.array_equal(dev_rows.cpu().numpy(), one_stream)
 
 
 def test_image_staging_is_bounded_by_bytes(s2, monkeypatch):

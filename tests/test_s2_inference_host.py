@@ -567,3 +567,19 @@ def test_infer_modality_probe_has_a_timeout_and_forwards_headers():
         raise requests.exceptions.ReadTimeout("too slow")
     with mock.patch.object(requests, "get", slow_get), pytest.raises(MediaDownloadError):
         s2_inference.infer_modality("http://example.com/some/media")
+
+
+def test_staged_image_call_covers_every_image_once_in_equal_stages(monkeypatch):
+    """open_clip_model._pipeline_stages: at least two stages, sizes within one image of each other apart from the last, contiguous, in order"""
+    from marqo_amd.s2_inference import open_clip_model as M
+    monkeypatch.setattr(M, "PIPELINE_CHUNK", 256)
+    assert M._pipeline_stages(256) == [(0, 128), (128, 256)]
+    assert M._pipeline_stages(512) == [(0, 256), (256, 512)]
+    assert M._pipeline_stages(1024) == [(0, 256), (256, 512), (512, 768), (768, 1024)]
+    assert [b - a for a, b in M._pipeline_stages(600)] == [300, 300]
+    for n in (2, 3, 255, 257, 383, 385, 641, 1000, 4097):
+        st = M._pipeline_stages(n)
+        assert len(st) >= 2 and st[0][0] == 0 and st[-1][1] == n
+        assert all(a1 == b0 for (_, b0), (a1, _) in zip(st[:-1], st[1:]))
+        sizes = [b - a for a, b in st]
+        assert len(set(sizes[:-1])) <= 1 and 0 < sizes[-1] <= sizes[0]
