@@ -45,12 +45,13 @@ extern "C" {
 #define MQ_ERR_HIP (-2)       /* a HIP runtime call or launch failed */
 #define MQ_ERR_WORKSPACE (-3) /* caller's workspace too small */
 
-#define MQ_ABI_VERSION 9
+#define MQ_ABI_VERSION 10
 
 /* ---- activation / mask / pooling selectors ---------------------------------------- */
 #define MQ_ACT_NONE 0
 #define MQ_ACT_GELU 1      /* erf GELU (open_clip nn.GELU, HF "gelu") */
 #define MQ_ACT_QUICKGELU 2 /* x * sigmoid(1.702 x) (OpenAI / *-quickgelu weights) */
+#define MQ_ACT_SILU 3      /* x * sigmoid(x): the gate of the SwiGLU MLP (EVA02 towers; gated MLPs only) */
 
 #define MQ_MASK_NONE 0   /* ViT: full attention inside a sequence */
 #define MQ_MASK_CAUSAL 1 /* CLIP text tower */
@@ -100,6 +101,11 @@ typedef struct mq_block_weights {
      * *_wf = bf16(g[k] * W[n,k]) [out, in], *_sf = fp32 sum_k of those bf16 values [out], *_bf = fp32 b + W @ beta [out]. */
     const void*  qkv_wf; const float* qkv_sf; const float* qkv_bf;
     const void*  fc1_wf; const float* fc1_sf; const float* fc1_bf;
+    /* sub-LayerNorms of the EVA02 blocks (timm eva.py; ABI 10; NULL = none): attn_ln over the attention output [attn_width], in front of the
+     * out-projection (`scale_attn_inner`); mlp_ln over the gated hidden row up * silu(gate) [F] in front of fc2 (`scale_mlp`; mean and variance
+     * over the first mq_encoder_cfg.mlp_ln_dim columns — the checkpoint's hidden width — when F is that width zero-padded to a multiple of 64). */
+    const float* attn_ln_g; const float* attn_ln_b;
+    const float* mlp_ln_g;  const float* mlp_ln_b;
 } mq_block_weights;
 
 typedef struct mq_encoder_cfg {
@@ -118,8 +124,9 @@ typedef struct mq_encoder_cfg {
                               * Quantisation noise injected in EARLY blocks is amplified by every later one (measured: the first 12 of
                               * ViT-L/14's 24 blocks cost 2-7x the cosine error of the last 12), so the loaders pick the smallest value
                               * that keeps the calibrated error inside the budget (engine/towers.py::tune_fp8); 0 = every block fp8 */
-    int32_t mlp_glu;         /* 1: gated MLP of the "NewModel" encoders (stella_en_400M_v5, gte-*-en-v1.5): fc1_w is [2F, W] = (up | gate) rows,
-                              * hidden = up * act(gate), fc2 takes the F-wide product.  bf16 post-LN path only. */
+    int32_t mlp_glu;         /* 1: gated MLP: fc1_w is [2F, W] = (up | gate) rows, hidden = up * act(gate), fc2 takes the F-wide product.  bf16 path only:
+                              * post-LN = the "NewModel" encoders (stella_en_400M_v5, gte-*-en-v1.5); pre-LN = the EVA02 vision blocks (SwiGLU:
+                              * act = MQ_ACT_SILU, up = fc1_x, gate = fc1_g, optional mlp_ln). */
     /* fp8 path: static per-tensor activation scales, device fp32 [layers][2] = (attention output, MLP hidden), and the
      * calibration accumulator of the same shape (NULL = frozen scales; non-NULL = fold max|value| of this pass into it) */
     const float* d_fp8_act_scale;
@@ -146,7 +153,14 @@ typedef struct mq_encoder_cfg {
                                    * (LayerNorm 2 -> e4m3 rows, fc1 + activation -> e4m3, fc2 + residual) and keep LayerNorm 1 / QKV / attention /
                                    * out-projection on bf16 operands: two thirds of a block's GEMM FLOPs for the rounding noise of two of its four
                                    * GEMMs.  0 = none (every block is all-bf16 or all-e4m3).  Must be <= fp8_first_layer.  (ABI 6) */
-    int32_t      reserved1;
+    int32_t      rope_prefix;     /* d_rope_table: rows at the head of every sequence that are NOT rotated (1 = the class token) */
+    /* 2-D rotary position embedding of the EVA02 vision towers (timm RotaryEmbeddingCat; NULL: none; ABI 10): device fp32
+     * [T - rope_prefix][2][head_dim] = (cos row | sin row) per rotated position, the same for every head.  Applied to the Q and K columns of the QKV
+     * buffer in place, INTERLEAVED pairs: (y[2i], y[2i+1]) = (x[2i] cos[2i] - x[2i+1] sin[2i], x[2i+1] cos[2i+1] + x[2i] sin[2i+1]).  Fixed-length
+     * sequences (images), pre-LN bf16 path only. */
+    const float* d_rope_table;
+    int32_t      mlp_ln_dim;      /* mq_block_weights.mlp_ln_*: the un-padded hidden width the statistics run over (0 = mlp_dim) */
+    int32_t      reserved2;
 } mq_encoder_cfg;
 
 /* ---- towers ------------------------------------------------------------------------ */
@@ -166,11 +180,13 @@ typedef struct mq_vit_weights {
     const void*  patch_w;      /* bf16 [W, Kp]  conv1 weight flattened (c, ky, kx), K zero-padded to Kp = ceil64(3*P*P) */
     const float* cls;          /* [W]   class embedding (MQ_VIT_POOL_MAP: NULL, there is no class token) */
     const float* pos;          /* [T, W] positional embedding, T = 1 + (S/P)^2 (MQ_VIT_POOL_MAP: T = (S/P)^2, patch bias added in) */
-    const float* ln_pre_g; const float* ln_pre_b;   /* MQ_VIT_POOL_MAP: NULL (no pre-LayerNorm) */
+    const float* ln_pre_g; const float* ln_pre_b;   /* NULL: no pre-LayerNorm (MQ_VIT_POOL_MAP; CLIPA; the EVA02 towers) */
     const mq_block_weights* blocks;  /* host array, `layers` entries */
     const float* ln_post_g; const float* ln_post_b; /* CLIP: on the class token; MQ_VIT_POOL_MAP: the trunk's final norm, all tokens */
     const void*  proj_w;       /* bf16 [D, W]  (= visual.proj transposed); MQ_VIT_POOL_MAP: NULL (D == W, no projection) */
     const mq_map_head* map;    /* MQ_VIT_POOL_MAP only, else NULL */
+    const float* proj_b;       /* fp32 [D] or NULL: bias of the projection (MQ_VIT_POOL_CLS; the timm EVA02 towers project through their classifier
+                                * head, a Linear WITH bias; ABI 10) */
 } mq_vit_weights;
 
 typedef struct mq_vit_cfg {

@@ -29,9 +29,9 @@ STAGE_PATH = LIB_DIR / "_mq_stage.so"                # CPython extension: a batc
 
 MQ_OK = 0
 NO_SCRATCH_UNITS = ("rowops", "gemm_bf16", "gemm_fp8", "gemm_small", "attention", "embed")  # build() refuses register spills in these
-ABI_VERSION = 9
+ABI_VERSION = 10
 MQ_PREC_BF16, MQ_PREC_FP8 = 0, 1
-MQ_ACT_GELU, MQ_ACT_QUICKGELU = 1, 2
+MQ_ACT_GELU, MQ_ACT_QUICKGELU, MQ_ACT_SILU = 1, 2, 3
 MQ_MASK_NONE, MQ_MASK_CAUSAL = 0, 1
 MQ_POOL_MEAN, MQ_POOL_CLS = 0, 1
 MQ_VIT_POOL_CLS, MQ_VIT_POOL_MAP, MQ_VIT_POOL_AVG, MQ_VIT_POOL_QUERY = 0, 1, 2, 3
@@ -57,7 +57,8 @@ class BlockWeights(C.Structure):
         "ln1_g", "ln1_b", "qkv_w", "qkv_b", "out_w", "out_b",
         "ln2_g", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b",
         "qkv_w8", "qkv_ws", "out_w8", "out_ws", "fc1_w8", "fc1_ws", "fc2_w8", "fc2_ws",
-        "qkv_wf", "qkv_sf", "qkv_bf", "fc1_wf", "fc1_sf", "fc1_bf")]
+        "qkv_wf", "qkv_sf", "qkv_bf", "fc1_wf", "fc1_sf", "fc1_bf",
+        "attn_ln_g", "attn_ln_b", "mlp_ln_g", "mlp_ln_b")]
 
 
 class EncoderCfg(C.Structure):
@@ -66,7 +67,8 @@ class EncoderCfg(C.Structure):
                 ("precision", C.c_int32), ("attn_width", C.c_int32), ("fp8_first_layer", C.c_int32), ("mlp_glu", C.c_int32),
                 ("d_fp8_act_scale", C.c_void_p), ("d_fp8_act_amax", C.c_void_p), ("d_rope_inv_freq", C.c_void_p),
                 ("d_rel_bias", C.c_void_p), ("rel_span", C.c_int32), ("residual_stream", C.c_int32),
-                ("fp8_mlp_extra", C.c_int32), ("reserved1", C.c_int32)]
+                ("fp8_mlp_extra", C.c_int32), ("rope_prefix", C.c_int32), ("d_rope_table", C.c_void_p), ("mlp_ln_dim", C.c_int32),
+                ("reserved2", C.c_int32)]
 
 
 class MapHead(C.Structure):
@@ -79,7 +81,8 @@ class MapHead(C.Structure):
 class VitWeights(C.Structure):
     _fields_ = [("patch_w", C.c_void_p), ("cls", C.c_void_p), ("pos", C.c_void_p),
                 ("ln_pre_g", C.c_void_p), ("ln_pre_b", C.c_void_p), ("blocks", C.POINTER(BlockWeights)),
-                ("ln_post_g", C.c_void_p), ("ln_post_b", C.c_void_p), ("proj_w", C.c_void_p), ("map", C.POINTER(MapHead))]
+                ("ln_post_g", C.c_void_p), ("ln_post_b", C.c_void_p), ("proj_w", C.c_void_p), ("map", C.POINTER(MapHead)),
+                ("proj_b", C.c_void_p)]
 
 
 class VitCfg(C.Structure):

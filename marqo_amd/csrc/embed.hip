@@ -491,7 +491,10 @@ int mq_rope(void* d_qkv, const int32_t* d_cu, int64_t nseq, int fixed_len, int W
 }
 
 // ---- gated MLP: buf [rows, 2F] = (up | gate) from the fc1 GEMM -> buf[:, :F] = up * act(gate), in place (row stride stays 2F) -----
-__global__ __launch_bounds__(256) void glu_kernel(bf16_t* __restrict__ buf, int64_t rows, int F, int quick) {
+__device__ __forceinline__ float silu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }   // (as quick_gelu: v_rcp_f32, rounded to bf16 right after)
+__device__ __forceinline__ float glu_act(float g, int act) { return act == MQ_ACT_SILU ? silu(g) : act == MQ_ACT_QUICKGELU ? quick_gelu(g) : gelu_erf(g); }
+
+__global__ __launch_bounds__(256) void glu_kernel(bf16_t* __restrict__ buf, int64_t rows, int F, int act) {
     const int chunks = F >> 3;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < rows * chunks; i += (int64_t)gridDim.x * 256) {
         const int64_t r = i / chunks;
@@ -505,19 +508,132 @@ __global__ __launch_bounds__(256) void glu_kernel(bf16_t* __restrict__ buf, int6
         for (int e = 0; e < 4; ++e) {
             const float u0 = bf16_to_f32((bf16_t)(a[e] & 0xffff)), u1 = bf16_to_f32((bf16_t)(a[e] >> 16));
             const float g0 = bf16_to_f32((bf16_t)(g[e] & 0xffff)), g1 = bf16_to_f32((bf16_t)(g[e] >> 16));
-            a[e] = pack_bf16x2(u0 * (quick ? quick_gelu(g0) : gelu_erf(g0)), u1 * (quick ? quick_gelu(g1) : gelu_erf(g1)));
+            a[e] = pack_bf16x2(u0 * glu_act(g0, act), u1 * glu_act(g1, act));
         }
         *(uint4*)p = up;
     }
 }
 
-int mq_glu(void* d_buf, int64_t rows, int F, int quick, hipStream_t s) {
+int mq_glu(void* d_buf, int64_t rows, int F, int act, hipStream_t s) {
     MQ_CHECK_ARG(F % 8 == 0, "glu: F=%d must be a multiple of 8", F);
     if (rows <= 0) return MQ_OK;
     MqProfScope prof(3, s);
     const int64_t blocks = cdiv64(rows * (F >> 3), 256);
-    hipLaunchKernelGGL(glu_kernel, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, s, (bf16_t*)d_buf, rows, F, quick);
+    hipLaunchKernelGGL(glu_kernel, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, s, (bf16_t*)d_buf, rows, F, act);
     MQ_CHECK_LAUNCH("glu");
+    return MQ_OK;
+}
+
+// ---- gated MLP with the LayerNorm of the EVA02 blocks behind the gate (timm SwiGLU with norm_layer): buf [rows, 2F] = (up | gate) ->
+// buf[:, :F] = LN(up * act(gate)) * g + b, in place (row stride stays 2F).  One wave per row, the row's products stay in registers (fp32) between the
+// two passes of the statistics; mean / variance over the first Ft columns (F = Ft zero-padded to a multiple of 64: the padded products are exactly 0,
+// g = b = 0 there, so the padding stays 0 for fc2).  CH = 16-byte chunks per lane: F <= 512 * CH.
+template <int CH>
+__global__ __launch_bounds__(256) void glu_ln_kernel(bf16_t* __restrict__ buf, int64_t rows, int F, int Ft, int act, const float* __restrict__ g,
+                                                     const float* __restrict__ b, float eps) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    bf16_t* p = buf + row * (2 * (int64_t)F);
+    float v[CH][8];
+    float s1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+        const int col = (lane + j * 64) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[j][e] = 0.f;
+        if (col < F) {
+            const uint4 up = *(const uint4*)(p + col), gt = *(const uint4*)(p + F + col);
+            const uint32_t* a = (const uint32_t*)&up;
+            const uint32_t* q = (const uint32_t*)&gt;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[j][2 * e] = bf16_to_f32((bf16_t)(a[e] & 0xffff)) * glu_act(bf16_to_f32((bf16_t)(q[e] & 0xffff)), act);
+                v[j][2 * e + 1] = bf16_to_f32((bf16_t)(a[e] >> 16)) * glu_act(bf16_to_f32((bf16_t)(q[e] >> 16)), act);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (col + e < Ft) s1 += v[j][e];
+        }
+    }
+    const float mean = wave_sum(s1) / (float)Ft;
+    float s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+        const int col = (lane + j * 64) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (col + e < Ft) { const float d = v[j][e] - mean; s2 += d * d; }
+    }
+    const float rstd = rsqrtf(wave_sum(s2) / (float)Ft + eps);
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+        const int col = (lane + j * 64) * 8;
+        if (col < F) {
+            const f32x4 g0 = *(const f32x4*)(g + col), g1 = *(const f32x4*)(g + col + 4), b0 = *(const f32x4*)(b + col), b1 = *(const f32x4*)(b + col + 4);
+            uint4 o;
+            o.x = pack_bf16x2((v[j][0] - mean) * rstd * g0[0] + b0[0], (v[j][1] - mean) * rstd * g0[1] + b0[1]);
+            o.y = pack_bf16x2((v[j][2] - mean) * rstd * g0[2] + b0[2], (v[j][3] - mean) * rstd * g0[3] + b0[3]);
+            o.z = pack_bf16x2((v[j][4] - mean) * rstd * g1[0] + b1[0], (v[j][5] - mean) * rstd * g1[1] + b1[1]);
+            o.w = pack_bf16x2((v[j][6] - mean) * rstd * g1[2] + b1[2], (v[j][7] - mean) * rstd * g1[3] + b1[3]);
+            *(uint4*)(p + col) = o;
+        }
+    }
+}
+
+int mq_glu_ln(void* d_buf, int64_t rows, int F, int Ft, int act, const float* g, const float* b, float eps, hipStream_t s) {
+    MQ_CHECK_ARG(F % 8 == 0 && F >= 8 && F <= 4096 && Ft >= 1 && Ft <= F && g && b, "glu_ln: F=%d (a multiple of 8, <= 4096) / Ft=%d unsupported", F, Ft);
+    if (rows <= 0) return MQ_OK;
+    MqProfScope prof(1, s);
+    const unsigned grid = (unsigned)cdiv64(rows, 4);
+#define MQ_GL(C) hipLaunchKernelGGL((glu_ln_kernel<C>), dim3(grid), dim3(256), 0, s, (bf16_t*)d_buf, rows, F, Ft, act, g, b, eps)
+    if (F <= 1024) MQ_GL(2); else if (F <= 2048) MQ_GL(4); else if (F <= 3072) MQ_GL(6); else MQ_GL(8);
+#undef MQ_GL
+    MQ_CHECK_LAUNCH("glu_ln");
+    return MQ_OK;
+}
+
+// ---- 2-D rotary position embedding of the EVA02 vision towers (timm RotaryEmbeddingCat + apply_rot_embed_cat) on the Q and K columns of the QKV
+// buffer, in place.  table: fp32 [T - prefix][2][hs] = (cos | sin) per rotated position, the same for every head; the first `prefix` rows of every
+// T-row sequence (the class token) are left alone.  A thread owns 8 consecutive dims = 4 interleaved pairs of one (row, q | k, head):
+// (y[2i], y[2i+1]) = (x[2i] cos[2i] - x[2i+1] sin[2i], x[2i+1] cos[2i+1] + x[2i] sin[2i+1])   — x * cos + rot(x) * sin with rot = (-x_odd, x_even).
+__global__ __launch_bounds__(256) void rope_table_kernel(bf16_t* __restrict__ qkv, int64_t rows, int T, int prefix, int Wa, int heads, int hs,
+                                                         const float* __restrict__ table) {
+    const int chunks = hs >> 3;
+    const int per_row = 2 * heads * chunks;
+    for (int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x; it < rows * per_row; it += (int64_t)gridDim.x * 256) {
+        const int64_t row = it / per_row;
+        const int r = (int)(it - row * per_row);
+        const int t = (int)(row % T);
+        if (t < prefix) continue;
+        const int qk = r / (heads * chunks), r2 = r - qk * heads * chunks;
+        const int h = r2 / chunks, c = r2 - h * chunks;
+        bf16_t* p = qkv + row * (3 * (int64_t)Wa) + qk * Wa + h * hs + c * 8;
+        const float* cs = table + (int64_t)(t - prefix) * (2 * hs) + c * 8;
+        const f32x4 c0 = *(const f32x4*)cs, c1 = *(const f32x4*)(cs + 4), s0 = *(const f32x4*)(cs + hs), s1 = *(const f32x4*)(cs + hs + 4);
+        uint4 v = *(const uint4*)p;
+        uint32_t* w = (uint32_t*)&v;
+        const float cosv[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+        const float sinv[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float xe = bf16_to_f32((bf16_t)(w[e] & 0xffff)), xo = bf16_to_f32((bf16_t)(w[e] >> 16));
+            w[e] = pack_bf16x2(xe * cosv[2 * e] - xo * sinv[2 * e], xo * cosv[2 * e + 1] + xe * sinv[2 * e + 1]);
+        }
+        *(uint4*)p = v;
+    }
+}
+
+int mq_rope_table(void* d_qkv, int64_t rows, int T, int prefix, int Wa, int heads, const float* d_table, hipStream_t s) {
+    const int hs = Wa / heads;
+    MQ_CHECK_ARG(hs * heads == Wa && hs % 8 == 0 && T >= 1 && prefix >= 0 && prefix <= T && rows % T == 0 && d_table,
+                 "rope_table: head width %d must be a multiple of 8, rows (%ld) a multiple of the sequence length %d", hs, (long)rows, T);
+    if (rows <= 0 || prefix == T) return MQ_OK;
+    MqProfScope prof(3, s);
+    const int64_t blocks = cdiv64(rows * 2 * heads * (hs >> 3), 256);
+    hipLaunchKernelGGL(rope_table_kernel, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, s, (bf16_t*)d_qkv, rows, T, prefix, Wa, heads, hs,
+                       d_table);
+    MQ_CHECK_LAUNCH("rope_table");
     return MQ_OK;
 }
 

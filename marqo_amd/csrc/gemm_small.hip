@@ -323,6 +323,7 @@ int mq_ln_gemm_small(const void* d_x, int64_t ldx, int x_bf16, const float* ln_g
     case (F): return dispatch_nw<(F), true>(d_x, ldx, x_bf16, d_W, ldw, d_bias, nullptr, d_out, ldc, (int)M, (int)N, (int)K, ln_g, ln_b, eps, d_ln_out, d_rows, s)
     switch (flags) {
         MQ_SM_CASE(MQ_EPI_OUT_F32);   // the towers' heads: proj(ln(pooled row)), fp32 out
+        MQ_SM_CASE(MQ_EPI_BIAS | MQ_EPI_OUT_F32);   // ... with a bias (the EVA02 towers project through a Linear with bias)
         MQ_SM_CASE(MQ_EPI_BIAS);
         MQ_SM_CASE(MQ_EPI_BIAS | MQ_EPI_GELU);
         MQ_SM_CASE(MQ_EPI_BIAS | MQ_EPI_QUICKGELU);

@@ -24,14 +24,16 @@ int mq_map_pool(const void* d_kv, const float* d_q, void* d_out, int64_t n, int 
 int mq_avg_tokens(const void* d_x, int x_bf16, float* d_out, int64_t n, int T, int first, int W, hipStream_t s);
 int mq_move_rows(void* d_sparse, const int32_t* d_idx, void* d_dense, int64_t n, int64_t row_bytes, bool scatter, hipStream_t s);
 int mq_rope(void* d_qkv, const int32_t* d_cu, int64_t nseq, int fixed_len, int Wa, int heads, const float* d_inv_freq, hipStream_t s);
-int mq_glu(void* d_buf, int64_t rows, int F, int quick, hipStream_t s);
+int mq_glu(void* d_buf, int64_t rows, int F, int act, hipStream_t s);
+int mq_glu_ln(void* d_buf, int64_t rows, int F, int Ft, int act, const float* g, const float* b, float eps, hipStream_t s);
+int mq_rope_table(void* d_qkv, int64_t rows, int T, int prefix, int Wa, int heads, const float* d_table, hipStream_t s);
 extern "C" int mq_rowquant_fp8(const float* d_x, void* d_out_fp8, float* d_row_scale, int64_t rows, int32_t W, void* stream);
 
 // layouts the ctypes binding (marqo_amd/_lib.py) and tests/test_abi.py assume
-static_assert(sizeof(mq_block_weights) == 26 * 8, "mq_block_weights layout");
-static_assert(sizeof(mq_encoder_cfg) == 96, "mq_encoder_cfg layout");
-static_assert(sizeof(mq_vit_cfg) == 152 && sizeof(mq_clip_text_cfg) == 112 && sizeof(mq_bert_cfg) == 120, "tower cfg layouts");
-static_assert(sizeof(mq_vit_weights) == 10 * 8 && sizeof(mq_map_head) == 11 * 8 && sizeof(mq_clip_text_weights) == 7 * 8, "tower weight layouts");
+static_assert(sizeof(mq_block_weights) == 30 * 8, "mq_block_weights layout");
+static_assert(sizeof(mq_encoder_cfg) == 112, "mq_encoder_cfg layout");
+static_assert(sizeof(mq_vit_cfg) == 168 && sizeof(mq_clip_text_cfg) == 128 && sizeof(mq_bert_cfg) == 136, "tower cfg layouts");
+static_assert(sizeof(mq_vit_weights) == 11 * 8 && sizeof(mq_map_head) == 11 * 8 && sizeof(mq_clip_text_weights) == 7 * 8, "tower weight layouts");
 
 // mq_tune("row_select", 0) runs the last block on every row (A/B and parity tests of the pooled-rows-only last block)
 int mq_tower_row_select = getenv("MQ_ROW_SELECT") ? atoi(getenv("MQ_ROW_SELECT")) : 1;
@@ -101,8 +103,11 @@ static int ln_gemm(const void* d_x, int xb, const float* g, const float* b, floa
 static bool stream_bf16(const mq_encoder_cfg* c) {
     // per-model policy, else the process default (bf16 towers only: an fp8 tower takes the bf16 stream when its load-time policy asks for it)
     const bool want = c->residual_stream == 1 || (c->residual_stream == 0 && mq_tower_residual_bf16 && c->precision == MQ_PREC_BF16);
-    return want && (c->precision == MQ_PREC_BF16 || c->precision == MQ_PREC_FP8) && !c->post_ln && !c->mlp_glu && !c->d_rope_inv_freq;
+    return want && (c->precision == MQ_PREC_BF16 || c->precision == MQ_PREC_FP8) && !c->post_ln && !c->mlp_glu && !c->d_rope_inv_freq && !c->d_rope_table;
 }
+// the EVA02 vision blocks (timm eva.py EvaBlock): pre-LN with any of — 2-D rotary positions on the patch tokens' Q / K, a LayerNorm between attention and
+// out-projection, a gated (SwiGLU) MLP with a LayerNorm behind the gate.  fp32 residual stream, every row through every block, LayerNorm kernels (no folds).
+static bool eva_form(const mq_encoder_cfg* c) { return !c->post_ln && (c->mlp_glu || c->d_rope_table); }
 
 // post-LN encoders (BERT family) on the bf16 stream: the normalised bf16 rows `h` ARE the residual — the out-projection / fc2 epilogues add
 // into them in place (bf16 read-modify-write), the LayerNorm normalises them in place, and the fp32 copy of x disappears from the block
@@ -145,7 +150,7 @@ int check_encoder_cfg(const mq_encoder_cfg* c) {
                  "encoder attention width must be heads * {64, 96, 112, 128} (attention width %d, heads %d)", wa, c->heads);
     MQ_CHECK_ARG(c->mlp_dim >= 64 && c->mlp_dim % 64 == 0, "encoder mlp_dim %d must be a multiple of 64", c->mlp_dim);
     MQ_CHECK_ARG(c->layers >= 0, "encoder layers < 0");
-    MQ_CHECK_ARG(c->act == MQ_ACT_GELU || c->act == MQ_ACT_QUICKGELU, "encoder act %d unsupported", c->act);
+    MQ_CHECK_ARG(c->act == MQ_ACT_GELU || c->act == MQ_ACT_QUICKGELU || (c->act == MQ_ACT_SILU && c->mlp_glu), "encoder act %d unsupported (MQ_ACT_SILU: gated MLPs only)", c->act);
     MQ_CHECK_ARG(c->precision == MQ_PREC_BF16 || c->precision == MQ_PREC_FP8, "encoder precision %d unsupported", c->precision);
     if (c->precision == MQ_PREC_FP8) {
         MQ_CHECK_ARG(c->width % 128 == 0 && c->mlp_dim % 128 == 0 && wa % 128 == 0, "fp8 path needs width / mlp_dim multiples of 128");
@@ -153,10 +158,15 @@ int check_encoder_cfg(const mq_encoder_cfg* c) {
         MQ_CHECK_ARG(c->fp8_first_layer >= 0, "fp8_first_layer < 0");
         MQ_CHECK_ARG(c->fp8_mlp_extra >= 0 && c->fp8_mlp_extra <= c->fp8_first_layer && (c->fp8_mlp_extra == 0 || !c->post_ln),
                      "fp8_mlp_extra = %d must lie in [0, fp8_first_layer = %d] (pre-LN encoders only)", c->fp8_mlp_extra, c->fp8_first_layer);
-        MQ_CHECK_ARG(!c->mlp_glu && !c->d_rope_inv_freq, "the gated-MLP / rotary encoder variant runs on the bf16 path only");
+        MQ_CHECK_ARG(!c->mlp_glu && !c->d_rope_inv_freq && !c->d_rope_table, "the gated-MLP / rotary encoder variants run on the bf16 path only");
     }
-    if (c->mlp_glu || c->d_rope_inv_freq)
-        MQ_CHECK_ARG(c->post_ln == 1 && wa == c->width, "the gated-MLP / rotary encoder variant is the post-LN NewModel family (un-padded heads)");
+    if (c->d_rope_inv_freq)
+        MQ_CHECK_ARG(c->post_ln == 1, "d_rope_inv_freq: the rotary positions of the post-LN NewModel family (EVA02 towers: d_rope_table)");
+    if (c->mlp_glu || c->d_rope_inv_freq || c->d_rope_table)
+        MQ_CHECK_ARG(wa == c->width, "the gated-MLP / rotary encoder variants run un-padded heads");
+    if (c->d_rope_table)
+        MQ_CHECK_ARG(!c->post_ln && !c->d_rel_bias && c->rope_prefix >= 0 && c->mask == MQ_MASK_NONE, "d_rope_table: pre-LN, unmasked, fixed-length sequences (the EVA02 vision towers)");
+    MQ_CHECK_ARG(c->mlp_ln_dim >= 0 && c->mlp_ln_dim <= c->mlp_dim, "mlp_ln_dim %d must lie in [0, mlp_dim = %d]", c->mlp_ln_dim, c->mlp_dim);
     if (c->d_rel_bias)
         MQ_CHECK_ARG(c->precision == MQ_PREC_BF16 && c->mask == MQ_MASK_NONE && wa == c->width && wa == c->heads * 64 && c->rel_span >= 1,
                      "the relative-position attention bias (MPNet) runs on the bf16 path with un-padded 64-wide heads and no mask");
@@ -301,7 +311,7 @@ int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* bloc
     // activation maxima must see every row); x_sel must fit behind the fc1 output inside `qf`
     const size_t xsel_off = align_up((size_t)(nsel > 0 ? nsel : 0) * F * 2, WS_ALIGN);
     // (not on the search path either: a call of a few rows is bound by its launch count, and the selection costs 4 launches more)
-    const bool select_last = d_sel && nsel > 0 && nsel * 2 <= rows && mq_tower_row_select && !cfg->mlp_glu && !cfg->d_rope_inv_freq &&
+    const bool select_last = d_sel && nsel > 0 && nsel * 2 <= rows && mq_tower_row_select && !cfg->mlp_glu && !cfg->d_rope_inv_freq && !cfg->d_rope_table &&
                              !mq_gemm_small_ok(rows, W, W, false) &&
                              !(cfg->precision == MQ_PREC_FP8 && (cfg->d_fp8_act_amax || cfg->post_ln)) &&
                              xsel_off + (size_t)nsel * W * 4 <= (size_t)rows * big * 2;
@@ -367,6 +377,28 @@ int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* bloc
                                        pf(b.fc2_w8), (size_t)W * F, s));
             MQ_TRY(mq_gemm_fp8(h, W, b.fc1_w8, W, row_scale, 1, b.fc1_ws, b.fc1_b, nullptr, qf, F, s_mlp, m_mlp, rows, F, W, act8, s));
             MQ_TRY(mq_gemm_fp8(qf, F, b.fc2_w8, F, s_mlp, 0, b.fc2_ws, b.fc2_b, d_x, d_x, W, nullptr, nullptr, rows, W, F, rflags, s));
+        } else if (eva_form(cfg)) {
+            // x += out(ln_attn(attn(rope(qkv(ln1(x)))))) ; x += fc2(ln_mlp(up * silu(gate)))  with (up | gate) = fc1(ln2(x))     (x fp32)
+            MQ_CHECK_ARG(!cfg->d_rope_table || (fixed_len > 0 && !d_cu_seqlens && rows == nseq * fixed_len && fixed_len > cfg->rope_prefix),
+                         "mq_encoder_forward: d_rope_table needs fixed-length sequences longer than rope_prefix");
+            MQ_CHECK_ARG(!b.attn_ln_g == !b.attn_ln_b && !b.mlp_ln_g == !b.mlp_ln_b && (!b.mlp_ln_g || cfg->mlp_glu), "mq_encoder_forward: layer %d: sub-LayerNorm weights must come in pairs (mlp_ln: gated MLPs only)", l);
+            MQ_TRY(mq_layernorm_pf(d_x, 0, nullptr, b.ln1_g, b.ln1_b, h, nullptr, rows, W, cfg->ln_eps, pf(b.qkv_w), (size_t)3 * Wa * W * 2, pf(b.out_w), (size_t)W * Wa * 2, s));
+            MQ_TRY(mq_gemm_bf16(h, W, b.qkv_w, W, b.qkv_b, nullptr, qf, 3 * Wa, rows, 3 * Wa, W, MQ_EPI_BIAS, s));
+            if (cfg->d_rope_table) MQ_TRY(mq_rope_table(qf, rows, fixed_len, cfg->rope_prefix, Wa, cfg->heads, cfg->d_rope_table, s));
+            MQ_TRY(attn_bf16(cfg, qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, s));
+            if (b.attn_ln_g) MQ_TRY(mq_layernorm_ex(a, 1, nullptr, b.attn_ln_g, b.attn_ln_b, a, nullptr, rows, Wa, cfg->ln_eps, s));   // (in place: a wave holds its row before it stores)
+            MQ_TRY(mq_gemm_bf16(a, Wa, b.out_w, Wa, b.out_b, d_x, d_x, W, rows, W, Wa, res_flags, s));
+            MQ_TRY(mq_layernorm_pf(d_x, 0, nullptr, b.ln2_g, b.ln2_b, h, nullptr, rows, W, cfg->ln_eps, pf(b.fc1_w), (size_t)(cfg->mlp_glu ? 2 : 1) * F * W * 2, pf(b.fc2_w),
+                                   (size_t)W * F * 2, s));
+            if (cfg->mlp_glu) {
+                MQ_TRY(mq_gemm_bf16(h, W, b.fc1_w, W, b.fc1_b, nullptr, qf, 2 * F, rows, 2 * F, W, b.fc1_b ? MQ_EPI_BIAS : 0, s));
+                if (b.mlp_ln_g) MQ_TRY(mq_glu_ln(qf, rows, F, cfg->mlp_ln_dim ? cfg->mlp_ln_dim : F, cfg->act, b.mlp_ln_g, b.mlp_ln_b, cfg->ln_eps, s));
+                else MQ_TRY(mq_glu(qf, rows, F, cfg->act, s));
+                MQ_TRY(mq_gemm_bf16(qf, 2 * F, b.fc2_w, F, b.fc2_b, d_x, d_x, W, rows, W, F, res_flags, s));
+            } else {
+                MQ_TRY(mq_gemm_bf16(h, W, b.fc1_w, W, b.fc1_b, nullptr, qf, F, rows, F, W, MQ_EPI_BIAS | act_flag, s));
+                MQ_TRY(mq_gemm_bf16(qf, F, b.fc2_w, F, b.fc2_b, d_x, d_x, W, rows, W, F, res_flags, s));
+            }
         } else if (!cfg->post_ln) {
             // x += out(attn(qkv(ln1(x)))) ; x += fc2(act(fc1(ln2(x))))   (x fp32, or bf16 in the bf16-stream form)
             const int xb = stream_bf16(cfg) ? 1 : 0;
@@ -446,7 +478,7 @@ int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* bloc
             if (cfg->mlp_glu) {
                 // gated MLP: fc1 = (up | gate) rows [2F, W] (bias optional), hidden = up * act(gate) in place, fc2 reads it with lda = 2F
                 MQ_TRY(mq_gemm_bf16(h, W, b.fc1_w, W, b.fc1_b, nullptr, qf, 2 * F, rows, 2 * F, W, b.fc1_b ? MQ_EPI_BIAS : 0, s));
-                MQ_TRY(mq_glu(qf, rows, F, cfg->act == MQ_ACT_QUICKGELU, s));
+                MQ_TRY(mq_glu(qf, rows, F, cfg->act, s));
                 MQ_TRY(mq_gemm_bf16(qf, 2 * F, b.fc2_w, F, b.fc2_b, d_x, d_x, W, rows, W, F, res_flags, s));
             } else {
                 MQ_TRY(mq_gemm_bf16(h, W, b.fc1_w, W, b.fc1_b, nullptr, qf, F, rows, F, W, MQ_EPI_BIAS | act_flag, s));
@@ -540,8 +572,9 @@ int encode_image_impl(const mq_vit_cfg* cfg, const mq_vit_weights* w, const void
         MQ_CHECK_ARG(cfg->map_mlp_dim >= 64 && cfg->map_mlp_dim % 64 == 0, "mq_encode_image: map_mlp_dim %d must be a multiple of 64", cfg->map_mlp_dim);
         MQ_CHECK_ARG(w->proj_w || cfg->out_dim == W, "mq_encode_image: without a projection out_dim (%d) must equal the width (%d)", cfg->out_dim, W);
     } else {
-        MQ_CHECK_ARG(w->cls && w->proj_w && (avg || (w->ln_pre_g && w->ln_pre_b)) && (!w->ln_pre_g == !w->ln_pre_b),
-                     "mq_encode_image: null weight pointer (ln_pre may be absent only with MQ_VIT_POOL_AVG)");
+        MQ_CHECK_ARG(w->cls && w->proj_w && (avg || eva_form(&cfg->enc) || (w->ln_pre_g && w->ln_pre_b)) && (!w->ln_pre_g == !w->ln_pre_b),
+                     "mq_encode_image: null weight pointer (ln_pre may be absent only with MQ_VIT_POOL_AVG and in the EVA02 form)");
+        MQ_CHECK_ARG(!w->proj_b || cfg->pool == MQ_VIT_POOL_CLS, "mq_encode_image: proj_b goes with MQ_VIT_POOL_CLS");
     }
     if (qpool) {
         const mq_map_head* m = w->map;
@@ -635,11 +668,11 @@ int encode_image_impl(const mq_vit_cfg* cfg, const mq_vit_weights* w, const void
                                 ws_bytes - p.off_enc, s));
     // K6: ln_post(class token) @ proj, L2
     if (mq_gemm_small_ok(n, cfg->out_dim, W, true))   // search path: ln_post rides in the head GEMM's prologue
-        MQ_TRY(mq_ln_gemm_small(x, W, xb, w->ln_post_g, w->ln_post_b, cfg->enc.ln_eps, w->proj_w, W, nullptr, d_out, cfg->out_dim, n, cfg->out_dim,
-                                W, MQ_EPI_OUT_F32, nullptr, rows_idx, s));
+        MQ_TRY(mq_ln_gemm_small(x, W, xb, w->ln_post_g, w->ln_post_b, cfg->enc.ln_eps, w->proj_w, W, w->proj_b, d_out, cfg->out_dim, n, cfg->out_dim,
+                                W, MQ_EPI_OUT_F32 | (w->proj_b ? MQ_EPI_BIAS : 0), nullptr, rows_idx, s));
     else {
         MQ_TRY(mq_layernorm_ex(x, xb, rows_idx, w->ln_post_g, w->ln_post_b, cls_ln, nullptr, n, W, cfg->enc.ln_eps, s));
-        MQ_TRY(mq_gemm_bf16(cls_ln, W, w->proj_w, W, nullptr, nullptr, d_out, cfg->out_dim, n, cfg->out_dim, W, MQ_EPI_OUT_F32, s));
+        MQ_TRY(mq_gemm_bf16(cls_ln, W, w->proj_w, W, w->proj_b, nullptr, d_out, cfg->out_dim, n, cfg->out_dim, W, MQ_EPI_OUT_F32 | (w->proj_b ? MQ_EPI_BIAS : 0), s));
     }
     if (normalize) MQ_TRY(mq_l2_normalize(d_out, d_out, n, cfg->out_dim, s));
     return MQ_OK;

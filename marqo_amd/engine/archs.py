@@ -34,17 +34,40 @@ class VitArch:
     ln_pre: bool = True          # False: `no_ln_pre` (CLIPA)
     preprocessor: Optional[str] = None   # open_clip preprocess config of the registry entry when it is not the default ("CLIPA")
     pool_heads: int = 8          # pool "query": heads of the attentional pooler (attn_pooler_heads)
+    # timm EVA02 CLIP towers behind open_clip's TimmModel (`visual.trunk.*`, model_registry.py:441-460; timm eva.py eva02_*_clip_*): class token, learned
+    # absolute positions AND 2-D rotary positions on the patch tokens' q / k, conv bias, no ln_pre; blocks with separate q / k / v projections (no k
+    # bias), a LayerNorm between attention and out-projection, SwiGLU MLP (hidden = mlp_dim, e.g. int(1024 * 4 * 2 / 3) = 2730) with a LayerNorm
+    # behind the gate; norm(class token) -> head (a Linear WITH bias = the projection)
+    eva: bool = False
+    rope_ref_grid: int = 16      # eva: `ref_feat_shape` — rotary positions are grid index / grid * rope_ref_grid (the pre-training grid)
+    rope_theta: float = 10000.0
 
     @property
     def tokens(self) -> int:
         return (self.image_size // self.patch_size) ** 2 + (0 if self.pool == "map" else 1)
+
+    def rope_table(self):
+        """eva: fp32 [patches, 2, head_dim] = (cos | sin) per patch position, timm's RotaryEmbeddingCat for in_pixels = False with `ref_feat_shape`
+        (build_rotary_pos_embed / build_fourier_pos_embed / freq_bands, the torch ops in their order): head_dim // 4 bands
+        1 / theta ** (k / (head_dim // 4)); positions t = arange(grid) / grid * ref_grid per axis; angles [y bands | x bands], each repeated twice
+        (the interleaved pairs of apply_rot_embed_cat)."""
+        import torch
+        G, hd = self.image_size // self.patch_size, self.width // self.heads
+        nb = hd // 4
+        bands = 1.0 / (self.rope_theta ** (torch.arange(0, nb, 1, dtype=torch.int64).to(torch.float32) / nb))
+        t = torch.arange(G, dtype=torch.float32) / G * self.rope_ref_grid
+        grid = torch.stack(torch.meshgrid(t, t, indexing="ij"), dim=-1).unsqueeze(-1)     # [G, G, 2, 1]
+        ang = grid * bands                                                                # [G, G, 2, nb]
+        sin = ang.sin().reshape(G * G, -1).repeat_interleave(2, -1)
+        cos = ang.cos().reshape(G * G, -1).repeat_interleave(2, -1)
+        return torch.stack([cos, sin], dim=1).contiguous()
 
     @property
     def gflop_per_image(self) -> float:
         """Algorithmic FLOPs (2MNK per GEMM, attention 4 T^2 W per layer) — SURVEY.md §8(d)."""
         T, W, F = self.tokens, self.width, self.mlp_dim
         patch = 2 * (self.image_size // self.patch_size) ** 2 * W * 3 * self.patch_size ** 2
-        layer = 2 * T * W * (3 * W) + 2 * T * W * W + 2 * 2 * T * W * F + 4 * T * T * W
+        layer = 2 * T * W * (3 * W) + 2 * T * W * W + 2 * (3 if self.eva else 2) * T * W * F + 4 * T * T * W
         if self.pool == "query":  # keys | values of every token at the pooler's width, one query, out-projection, final projection
             D = self.out_dim
             head = 2 * T * W * (2 * D) + 4 * T * D + 2 * D * D + 2 * D * D
@@ -213,12 +236,20 @@ OPEN_CLIP_ARCHS = {
                       ClipTextArch(49408, 77, 512, 12, 8, 2048, 512, prefix="text.", cls_embed=True)),
     "coca_ViT-L-14": (VitArch(224, 14, 1024, 24, 16, 4096, 768, pool="query", pool_heads=8),
                       ClipTextArch(49408, 77, 768, 12, 12, 3072, 768, prefix="text.", cls_embed=True)),
+    # EVA02-CLIP (model_registry.py:441-460; open_clip model configs EVA02-B-16 / EVA02-L-14 / EVA02-L-14-336: timm trunks eva02_base_patch16_clip_224,
+    # eva02_large_patch14_clip_224 / _336; custom_text towers of the CLIP form under `text.`)
+    "EVA02-B-16": (VitArch(224, 16, 768, 12, 12, 2048, 512, ln_eps=1e-6, ln_pre=False, eva=True),
+                   ClipTextArch(49408, 77, 512, 12, 8, 2048, 512, prefix="text.")),
+    "EVA02-L-14": (VitArch(224, 14, 1024, 24, 16, 2730, 768, ln_eps=1e-6, ln_pre=False, eva=True),
+                   ClipTextArch(49408, 77, 768, 12, 12, 3072, 768, prefix="text.")),
+    "EVA02-L-14-336": (VitArch(336, 14, 1024, 24, 16, 2730, 768, ln_eps=1e-6, ln_pre=False, eva=True),
+                       ClipTextArch(49408, 77, 768, 12, 12, 3072, 768, prefix="text.")),
     "ViT-B-16-SigLIP": _siglip(224), "ViT-B-16-SigLIP-256": _siglip(256), "ViT-B-16-SigLIP-384": _siglip(384),
     "ViT-B-16-SigLIP-512": _siglip(512),
     "ViT-SO400M-14-SigLIP": _siglip(224, so400m=True), "ViT-SO400M-14-SigLIP-384": _siglip(384, so400m=True),
     "ViT-L-16-SigLIP-256": _siglip(256, large=True), "ViT-L-16-SigLIP-384": _siglip(384, large=True),
 }
-# architectures the registry names but which are not ViT / CLIP-text / BERT-family towers (ResNet, ConvNeXt, EVA02, NLLB text towers ...)
+# architectures the registry names but which are not ViT / CLIP-text / BERT-family towers (ResNet, ConvNeXt, NLLB text towers ...)
 UNSUPPORTED_HINT = ("this open_clip architecture is not runnable by the marqo_amd engine yet "
                     "(supported: " + ", ".join(sorted(OPEN_CLIP_ARCHS)) + " and their -quickgelu variants)")
 

@@ -67,6 +67,29 @@ def random_open_clip_state_dict(vision: VitArch = None, text: ClipTextArch = Non
         _ln(sd, a + "norm", W, g)
         _lin(sd, a + "mlp.fc1", F, W, g, std)
         _lin(sd, a + "mlp.fc2", W, F, g, std / 2)
+    elif vision is not None and getattr(vision, "eva", False):
+        # timm Eva (eva02_*_clip_*) as open_clip's visual.trunk: separate q / k / v projections (no k bias), attn.norm, SwiGLU with its norm, head
+        W, P, F, t = vision.width, vision.patch_size, vision.mlp_dim, "visual.trunk."
+        std = 0.6 / math.sqrt(W)
+        sd[t + "patch_embed.proj.weight"] = torch.randn(W, 3, P, P, generator=g) / math.sqrt(3 * P * P)
+        sd[t + "patch_embed.proj.bias"] = 0.05 * torch.randn(W, generator=g)
+        sd[t + "cls_token"] = 0.5 * torch.randn(1, 1, W, generator=g)
+        sd[t + "pos_embed"] = 0.3 * torch.randn(1, vision.tokens, W, generator=g)
+        for i in range(vision.layers):
+            p = f"{t}blocks.{i}."
+            _ln(sd, p + "norm1", W, g)
+            _lin(sd, p + "attn.q_proj", W, W, g, std)
+            sd[p + "attn.k_proj.weight"] = torch.randn(W, W, generator=g) * std
+            _lin(sd, p + "attn.v_proj", W, W, g, std)
+            _ln(sd, p + "attn.norm", W, g)
+            _lin(sd, p + "attn.proj", W, W, g, std)
+            _ln(sd, p + "norm2", W, g)
+            _lin(sd, p + "mlp.fc1_g", F, W, g, 2 * std)
+            _lin(sd, p + "mlp.fc1_x", F, W, g, 2 * std)
+            _ln(sd, p + "mlp.norm", F, g)
+            _lin(sd, p + "mlp.fc2", W, F, g, std / 2)
+        _ln(sd, t + "norm", W, g)
+        _lin(sd, t + "head", vision.out_dim, W, g, 1.0 / math.sqrt(W))
     elif vision is not None:
         W, P = vision.width, vision.patch_size
         sd["visual.conv1.weight"] = torch.randn(W, 3, P, P, generator=g) / math.sqrt(3 * P * P)

@@ -238,6 +238,44 @@ def _clip_blocks(h: _Holder, sd, prefix: str, layers: int, W: int, F: int, heads
     return arr
 
 
+def _eva_blocks(h: _Holder, sd, prefix: str, layers: int, W: int, F: int, heads: int):
+    """timm EvaBlock tensors (eva.py; `blocks.{i}.`): norm1, attn.{q_proj, k_proj (no bias), v_proj} or the fused attn.qkv + q_bias / v_bias,
+    attn.norm (the LayerNorm in front of attn.proj; absent without `scale_attn_inner`), attn.proj, norm2, mlp.{fc1_g, fc1_x, norm, fc2}
+    (timm SwiGLU: fc2(norm(silu(fc1_g(x)) * fc1_x(x)))).  fc1 is stored as (up | gate) = (fc1_x | fc1_g) rows, the hidden width F zero-padded
+    to a multiple of 64: silu(0) * 0 = 0 meets zero LayerNorm weights and zero fc2 columns — exact; the statistics run over F (mlp_ln_dim)."""
+    if _head_dim(W, heads) != _kernel_head_dim(_head_dim(W, heads), heads):
+        raise ValueError("EVA02 towers with heads that are not 64 / 96 / 112 / 128 wide are not runnable (rotary positions on padded heads)")
+    Fp = _ceil64(F)
+    pad = torch.nn.functional.pad
+    arr = (L.BlockWeights * layers)()
+    for i in range(layers):
+        p = prefix + f"blocks.{i}."
+        f32 = lambda k, shape: _need(sd, p + k, shape).detach().to(torch.float32)
+        b = arr[i]
+        b.ln1_g, b.ln1_b = h.f32(f32("norm1.weight", (W,))), h.f32(f32("norm1.bias", (W,)))
+        if p + "attn.qkv.weight" in sd:
+            qkv_w = f32("attn.qkv.weight", (3 * W, W))
+            qb = f32("attn.q_bias", (W,)) if p + "attn.q_bias" in sd else torch.zeros(W)
+            vb = f32("attn.v_bias", (W,)) if p + "attn.v_bias" in sd else torch.zeros(W)
+        else:
+            qkv_w = torch.cat([f32("attn.q_proj.weight", (W, W)), f32("attn.k_proj.weight", (W, W)), f32("attn.v_proj.weight", (W, W))], dim=0)
+            qb = f32("attn.q_proj.bias", (W,)) if p + "attn.q_proj.bias" in sd else torch.zeros(W)
+            vb = f32("attn.v_proj.bias", (W,)) if p + "attn.v_proj.bias" in sd else torch.zeros(W)
+        b.qkv_w, b.qkv_b = h.bf16(qkv_w), h.f32(torch.cat([qb, torch.zeros(W), vb]))      # (keys carry no bias)
+        if p + "attn.norm.weight" in sd:
+            b.attn_ln_g, b.attn_ln_b = h.f32(f32("attn.norm.weight", (W,))), h.f32(f32("attn.norm.bias", (W,)))
+        b.out_w, b.out_b = h.bf16(f32("attn.proj.weight", (W, W))), h.f32(f32("attn.proj.bias", (W,)))
+        b.ln2_g, b.ln2_b = h.f32(f32("norm2.weight", (W,))), h.f32(f32("norm2.bias", (W,)))
+        up_w, up_b = f32("mlp.fc1_x.weight", (F, W)), f32("mlp.fc1_x.bias", (F,))
+        gate_w, gate_b = f32("mlp.fc1_g.weight", (F, W)), f32("mlp.fc1_g.bias", (F,))
+        b.fc1_w = h.bf16(torch.cat([pad(up_w, (0, 0, 0, Fp - F)), pad(gate_w, (0, 0, 0, Fp - F))], dim=0))
+        b.fc1_b = h.f32(torch.cat([pad(up_b, (0, Fp - F)), pad(gate_b, (0, Fp - F))]))
+        if p + "mlp.norm.weight" in sd:
+            b.mlp_ln_g, b.mlp_ln_b = h.f32(pad(f32("mlp.norm.weight", (F,)), (0, Fp - F))), h.f32(pad(f32("mlp.norm.bias", (F,)), (0, Fp - F)))
+        b.fc2_w, b.fc2_b = h.bf16(pad(f32("mlp.fc2.weight", (W, F)), (0, Fp - F))), h.f32(f32("mlp.fc2.bias", (W,)))
+    return arr
+
+
 # Single-request calls (the search path: one query text / one image per vectorise()) are ~75-150 dependent launches of 5-10 us.
 # The launch sequence of such a call depends only on (tower, token count), so it is captured once per shape in a hipGraph
 # (torch.cuda.CUDAGraph over the stream the C ABI enqueues on) with static input / output / workspace buffers and replayed.
@@ -766,6 +804,22 @@ class VitTower(_TowerBase):
                 blocks=self._blocks, ln_post_g=h.f32(f32("ln_k.weight", (W,))), ln_post_b=h.f32(f32("ln_k.bias", (W,))),   # the norm every token takes before k | v
                 proj_w=h.bf16(_need(sd, "visual.proj", (D, D)).detach().to(torch.float32).t()), map=C.pointer(self._map))
             pool, map_mlp = L.MQ_VIT_POOL_QUERY, 0
+        elif arch.eva:
+            # timm Eva as open_clip's `visual.trunk` (EVA02-CLIP): class token + learned positions (the conv bias rides on the patch rows of the
+            # position table), rotary table computed here (a non-persistent buffer of the checkpoint), norm(class token) -> head
+            if precision != "bf16" or arch.pool != "cls":
+                raise ValueError("EVA02 towers run on the bf16 path with the class-token head")
+            t = "visual.trunk."
+            f32 = lambda k, shape: _need(sd, t + k, shape).detach().to(torch.float32)
+            patch_w[:, :K] = f32("patch_embed.proj.weight", (W, 3, P, P)).reshape(W, K)
+            pos = f32("pos_embed", (1, arch.tokens, W))[0].clone()
+            pos[1:] += f32("patch_embed.proj.bias", (W,))
+            self._blocks = _eva_blocks(h, sd, t, arch.layers, W, arch.mlp_dim, arch.heads)
+            self._rope = h.f32(arch.rope_table())
+            self.w = L.VitWeights(patch_w=h.bf16(patch_w), cls=h.f32(f32("cls_token", (1, 1, W)).reshape(W)), pos=h.f32(pos), ln_pre_g=None, ln_pre_b=None,
+                                  blocks=self._blocks, ln_post_g=h.f32(f32("norm.weight", (W,))), ln_post_b=h.f32(f32("norm.bias", (W,))),
+                                  proj_w=h.bf16(f32("head.weight", (arch.out_dim, W))), map=None, proj_b=h.f32(f32("head.bias", (arch.out_dim,))))
+            pool, map_mlp = L.MQ_VIT_POOL_CLS, 0
         else:
             patch_w[:, :K] = _need(sd, "visual.conv1.weight", (W, 3, P, P)).detach().to(torch.float32).reshape(W, K)
             self._blocks = _clip_blocks(h, sd, "visual.transformer.", arch.layers, W, arch.mlp_dim, arch.heads)
@@ -787,13 +841,17 @@ class VitTower(_TowerBase):
                             image_size=arch.image_size, patch_size=P, out_dim=arch.out_dim,
                             mean=(C.c_float * 3)(*mean), std=(C.c_float * 3)(*std), pool=pool, map_mlp_dim=map_mlp,
                             pool_dim=arch.out_dim if arch.pool == "query" else 0, pool_heads=arch.pool_heads if arch.pool == "query" else 0)
+        if arch.eva:
+            enc = self.cfg.enc
+            enc.mlp_glu, enc.act, enc.mlp_ln_dim = 1, L.MQ_ACT_SILU, arch.mlp_dim
+            enc.d_rope_table, enc.rope_prefix = self._rope, 1
         self.max_images_per_call = max(1, MAX_ROWS_PER_CALL // arch.tokens)
         self.n_streams = max(1, int(os.environ.get("MARQO_AMD_STREAMS", "1")))
         self._side: list = []
         if precision == "fp8":
             self._enable_fp8(self._blocks, arch.layers, W, _ceil64(arch.mlp_dim))
         self.cfg.enc.residual_stream = 2
-        if precision == "bf16":
+        if precision == "bf16" and not arch.eva:      # (the EVA02 blocks keep the fp32 stream: towers.hip, eva_form)
             self.tune_residual_default()
 
     def tune_residual_default(self) -> str:

@@ -38,6 +38,8 @@ _OPEN_CLIP_TAGS = {
     # CoCa (model_registry.py:344-370): the contrastive towers of the captioner
     "coca_ViT-B-32": ["laion2b_s13b_b90k", "mscoco_finetuned_laion2b_s13b_b90k"],
     "coca_ViT-L-14": ["laion2b_s13b_b90k", "mscoco_finetuned_laion2b_s13b_b90k"],
+    # EVA02-CLIP (model_registry.py:441-460): timm Eva trunks behind open_clip's TimmModel
+    "EVA02-B-16": ["merged2b_s8b_b131k"], "EVA02-L-14": ["merged2b_s4b_b131k"], "EVA02-L-14-336": ["merged2b_s6b_b61k"],
     # SigLIP (model_registry.py:371-432)
     "ViT-B-16-SigLIP": ["webli"], "ViT-B-16-SigLIP-256": ["webli"], "ViT-B-16-SigLIP-384": ["webli"], "ViT-B-16-SigLIP-512": ["webli"],
     "ViT-L-16-SigLIP-256": ["webli"], "ViT-L-16-SigLIP-384": ["webli"], "ViT-SO400M-14-SigLIP-384": ["webli"],

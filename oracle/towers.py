@@ -48,7 +48,7 @@ from __future__ import annotations
 
 import math
 from dataclasses import dataclass, replace, field
-from typing import Dict, List, Optional, Sequence
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 import torch.nn.functional as F
@@ -315,6 +315,117 @@ def synthetic_coca_state_dict(vcfg: CocaVitConfig, tcfg: ClipTextConfig, seed: i
     sd["text.ln_final.weight"] = 1 + 0.1 * torch.randn(Wt, generator=g)
     sd["text.ln_final.bias"] = 0.05 * torch.randn(Wt, generator=g)
     sd["text.text_projection"] = std * torch.randn(Wt, tcfg.out_dim, generator=g)
+    return sd
+
+
+# --------------------------------------------------------------------------------------------
+# EVA02-CLIP vision tower (timm models/eva.py + layers/pos_embed_sincos.py + layers/mlp.py, behind open_clip 2.24.0's TimmModel — un-vendored;
+# RESTATED, UNPINNED: timm is not in this image and transformers holds no model of this block form, so the functions below follow the published
+# source from memory of its structure and are pinned to nothing but themselves.  The reference only names the models
+# (model_registry.py:441-460: EVA02-L-14-336 / EVA02-B-16 / EVA02-L-14) and calls model.encode_image on them
+# (core/inference/embedding_models/open_clip_model.py:249-266).  The text towers of these entries are the plain CLIP form (clip_text_forward with
+# the `text.` prefix stripped).)
+# --------------------------------------------------------------------------------------------
+@dataclass
+class EvaVitConfig(VitConfig):
+    ln_eps: float = 1e-6      # timm LayerNorm default
+    ref_grid: int = 16        # ref_feat_shape = (16, 16): the pre-training grid the rotary positions are rescaled to
+    rope_theta: float = 10000.0
+
+
+def eva_rope(cfg: EvaVitConfig) -> Tuple[Tensor, Tensor]:
+    """timm RotaryEmbeddingCat(dim = head_dim, in_pixels = False, feat_shape = grid, ref_feat_shape) -> (sin, cos), each [patches, head_dim]:
+    build_rotary_pos_embed -> build_fourier_pos_embed(num_bands = head_dim // 4, bands = freq_bands = 1 / theta ** (arange(0, nb) / nb),
+    t = arange(grid) / grid * ref_grid per axis, meshgrid 'ij', pos = grid[..., None] * bands) -> sin / cos reshaped [patches, 2 * nb] (y bands then
+    x bands) and repeat_interleave(2) along the last axis."""
+    G, hd = cfg.image_size // cfg.patch_size, cfg.width // cfg.heads
+    nb = hd // 4
+    bands = 1.0 / (cfg.rope_theta ** (torch.arange(0, nb, 1, dtype=torch.int64).to(torch.float32) / nb))
+    t = [torch.arange(G, dtype=torch.float32) / G * cfg.ref_grid for _ in range(2)]
+    grid = torch.stack(torch.meshgrid(t, indexing="ij"), dim=-1).unsqueeze(-1)
+    pos = grid * bands
+    sin = pos.sin().reshape(G * G, -1).repeat_interleave(2, -1)
+    cos = pos.cos().reshape(G * G, -1).repeat_interleave(2, -1)
+    return sin, cos
+
+
+def _eva_rot(x: Tensor) -> Tensor:
+    """timm `rot`: (x0, x1, x2, x3, ...) -> (-x1, x0, -x3, x2, ...)"""
+    return torch.stack([-x[..., 1::2], x[..., ::2]], -1).reshape(x.shape)
+
+
+@torch.no_grad()
+def eva_vit_forward(sd: Dict[str, Tensor], cfg: EvaVitConfig, pixels: Tensor, normalize: bool = True) -> Tensor:
+    """timm Eva.forward as open_clip's TimmModel(pool='token', proj=None) runs it (keys under `visual.trunk.`): patch_embed (conv WITH bias) ->
+    class token -> + pos_embed -> blocks (EvaBlock without layer scale: x = x + attn(norm1(x), rope); x = x + mlp(norm2(x))) -> norm -> class token
+    -> head (Linear with bias = the projection to the embedding width).
+    EvaAttention (qkv_fused = False): q = q_proj(x), k = k_proj(x) (no bias), v = v_proj(x); the PATCH tokens' q and k are rotated,
+    q[:, :, 1:] = q * cos + rot(q) * sin; softmax(q k^T / sqrt(hd)) v; x = attn.norm(x) (scale_attn_inner); proj.
+    SwiGLU (scale_mlp): fc2(norm(silu(fc1_g(x)) * fc1_x(x)))."""
+    t = "visual.trunk."
+    W, H = cfg.width, cfg.heads
+    hd = W // H
+    x = F.conv2d(pixels, sd[t + "patch_embed.proj.weight"], sd[t + "patch_embed.proj.bias"], stride=cfg.patch_size)
+    B = x.shape[0]
+    x = x.reshape(B, W, -1).permute(0, 2, 1)
+    x = torch.cat([sd[t + "cls_token"].expand(B, 1, W), x], dim=1) + sd[t + "pos_embed"]
+    T = x.shape[1]
+    sin, cos = eva_rope(cfg)
+    for i in range(cfg.layers):
+        p = f"{t}blocks.{i}."
+        ln = lambda v, name, dim: F.layer_norm(v, (dim,), sd[p + name + ".weight"], sd[p + name + ".bias"], cfg.ln_eps)
+        h = ln(x, "norm1", W)
+        q = F.linear(h, sd[p + "attn.q_proj.weight"], sd[p + "attn.q_proj.bias"]).view(B, T, H, hd).transpose(1, 2)
+        k = F.linear(h, sd[p + "attn.k_proj.weight"], None).view(B, T, H, hd).transpose(1, 2)
+        v = F.linear(h, sd[p + "attn.v_proj.weight"], sd[p + "attn.v_proj.bias"]).view(B, T, H, hd).transpose(1, 2)
+        q = torch.cat([q[:, :, :1], q[:, :, 1:] * cos + _eva_rot(q[:, :, 1:]) * sin], dim=2)
+        k = torch.cat([k[:, :, :1], k[:, :, 1:] * cos + _eva_rot(k[:, :, 1:]) * sin], dim=2)
+        a = torch.softmax((q @ k.transpose(-1, -2)) / math.sqrt(hd), dim=-1) @ v
+        a = ln(a.transpose(1, 2).reshape(B, T, W), "attn.norm", W)
+        x = x + F.linear(a, sd[p + "attn.proj.weight"], sd[p + "attn.proj.bias"])
+        h = ln(x, "norm2", W)
+        m = F.silu(F.linear(h, sd[p + "mlp.fc1_g.weight"], sd[p + "mlp.fc1_g.bias"])) * F.linear(h, sd[p + "mlp.fc1_x.weight"], sd[p + "mlp.fc1_x.bias"])
+        m = ln(m, "mlp.norm", cfg.mlp_dim)
+        x = x + F.linear(m, sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"])
+    x = F.layer_norm(x, (W,), sd[t + "norm.weight"], sd[t + "norm.bias"], cfg.ln_eps)
+    out = F.linear(x[:, 0], sd[t + "head.weight"], sd[t + "head.bias"])
+    return l2_normalize_clip(out) if normalize else out
+
+
+def synthetic_eva_state_dict(cfg: EvaVitConfig, seed: int = 0) -> Dict[str, Tensor]:
+    """seeded EVA02-CLIP vision checkpoint in timm's naming under open_clip's `visual.trunk.`"""
+    g = _g(seed + 5000)
+    W, P, Fh, t = cfg.width, cfg.patch_size, cfg.mlp_dim, "visual.trunk."
+    std = 0.6 / math.sqrt(W)
+    sd: Dict[str, Tensor] = {}
+
+    def lin(name, out_f, in_f, scale, bias=True):
+        sd[name + ".weight"] = scale * torch.randn(out_f, in_f, generator=g)
+        if bias:
+            sd[name + ".bias"] = 0.02 * torch.randn(out_f, generator=g)
+
+    def norm(name, dim):
+        sd[name + ".weight"] = 1 + 0.1 * torch.randn(dim, generator=g)
+        sd[name + ".bias"] = 0.05 * torch.randn(dim, generator=g)
+    sd[t + "patch_embed.proj.weight"] = torch.randn(W, 3, P, P, generator=g) / math.sqrt(3 * P * P)
+    sd[t + "patch_embed.proj.bias"] = 0.05 * torch.randn(W, generator=g)
+    sd[t + "cls_token"] = 0.5 * torch.randn(1, 1, W, generator=g)
+    sd[t + "pos_embed"] = 0.3 * torch.randn(1, cfg.tokens, W, generator=g)
+    for i in range(cfg.layers):
+        p = f"{t}blocks.{i}."
+        norm(p + "norm1", W)
+        lin(p + "attn.q_proj", W, W, std)
+        lin(p + "attn.k_proj", W, W, std, bias=False)
+        lin(p + "attn.v_proj", W, W, std)
+        norm(p + "attn.norm", W)
+        lin(p + "attn.proj", W, W, std)
+        norm(p + "norm2", W)
+        lin(p + "mlp.fc1_g", Fh, W, 2 * std)
+        lin(p + "mlp.fc1_x", Fh, W, 2 * std)
+        norm(p + "mlp.norm", Fh)
+        lin(p + "mlp.fc2", W, Fh, std / 2)
+    norm(t + "norm", W)
+    lin(t + "head", cfg.out_dim, W, 1.0 / math.sqrt(W))
     return sd
 
 

@@ -272,6 +272,22 @@ def test_registry_models_synthetic_weights(s2):
     assert cids.shape[1] == 76
     creft = O.coca_text_forward(csd, O.ClipTextConfig(ct.vocab, 77, ct.width, ct.layers, ct.heads, ct.mlp_dim, ct.out_dim), cids).numpy()
     assert _cos_err(ctxt, creft) < COS_TOL
+    # EVA02-CLIP through the API (registry name -> loader -> timm Eva trunk under `visual.trunk.`, CLIP text tower under `text.`)
+    ename = "open_clip/EVA02-B-16/merged2b_s8b_b131k"
+    eimg = np.asarray(s2i.vectorise(ename, pil, device=DEV, modality=s2i.Modality.IMAGE))
+    etxt = np.asarray(s2i.vectorise(ename, ["a photo of a cat", "a dog"], device=DEV))
+    assert eimg.shape == (4, 512) and etxt.shape == (2, 512) and np.allclose(np.linalg.norm(eimg, axis=1), 1, atol=1e-5)
+    ev, et = archs.resolve_open_clip("EVA02-B-16")
+    esd = synthetic.random_open_clip_state_dict(vision=ev, text=et, seed=0)
+    erefi = O.eva_vit_forward(esd, O.EvaVitConfig(224, 16, 768, 12, 12, 2048, 512), torch.from_numpy(np.stack([OP.clip_transform(np.asarray(p)) for p in pil]))).numpy()
+    assert _cos_err(eimg, erefi) < COS_TOL
+    ekey = s2i._create_model_cache_key(ename, DEV, s2i.get_model_properties_from_registry(ename))
+    em = s2i.get_available_models()[ekey]["model"]
+    eids = torch.as_tensor(np.asarray(em.tokenizer(["a photo of a cat", "a dog"])))
+    ereft = O.clip_text_forward({k[len("text."):]: v for k, v in esd.items() if k.startswith("text.")},
+                                O.ClipTextConfig(et.vocab, 77, et.width, et.layers, et.heads, et.mlp_dim, et.out_dim), eids).numpy()
+    assert _cos_err(etxt, ereft) < COS_TOL
+    s2i.eject_model(ename, DEV)
     # OpenAI-style name resolves to the QuickGELU towers
     q = np.asarray(s2i.vectorise("ViT-B/32", ["a photo of a cat"], device=DEV))
     assert q.shape == (1, 512) and _cos_err(q, txt[:1]) > 1e-4

@@ -512,6 +512,44 @@ def test_coca_towers_vs_oracle(name, layers, n):
         tt.encode_ids(torch.zeros(1, tarch.ctx, dtype=torch.int64))                         # 77 token positions leave no room for the class embedding
 
 
+@pytest.mark.parametrize("name,layers,n", [("EVA02-B-16", 12, 5), ("EVA02-L-14", 2, 3), ("EVA02-L-14-336", 1, 2), ("tiny", 2, 7)])
+def test_eva02_tower_vs_oracle(name, layers, n):
+    """EVA02-CLIP vision towers (model_registry.py:441-460; timm Eva behind open_clip's TimmModel): class token + learned positions + 2-D rotary
+    positions on the patch tokens' q / k (the 336 px tower: a 24 x 24 grid rescaled to the 16 x 16 pre-training grid), separate q / k / v with
+    a bias-free k, LayerNorm between attention and out-projection, SwiGLU with a LayerNorm behind the gate (hidden 2 730 at L/14 -> zero-padded
+    to 2 752, statistics over 2 730; 170 -> 192 in the tiny form), norm(class token) -> head with bias; registry shapes (L/14 depth cut to keep
+    the fp32 CPU oracle in seconds) against oracle.eva_vit_forward (restated from timm; unpinned — no timm in this image).  One image (the
+    small-row kernel families), un-normalised output, and the fused-qkv checkpoint form."""
+    from dataclasses import replace
+    T, A = _towers()
+    if name == "tiny":
+        varch = A.VitArch(64, 16, 128, layers, 2, 170, 64, ln_eps=1e-6, ln_pre=False, eva=True)
+    else:
+        varch = replace(A.resolve_open_clip(name)[0], layers=layers)
+    cfg = O.EvaVitConfig(varch.image_size, varch.patch_size, varch.width, layers, varch.heads, varch.mlp_dim, varch.out_dim, ref_grid=varch.rope_ref_grid)
+    sd = O.synthetic_eva_state_dict(cfg, seed=8)
+    u8 = O.synthetic_images_u8(n, varch.image_size, seed=8)
+    ref = O.eva_vit_forward(sd, cfg, O.preprocess_u8_exact_size(u8))
+    vt = T.VitTower(varch, sd, "cuda")
+    assert vt.cfg.enc.mlp_glu == 1 and vt.cfg.enc.mlp_ln_dim == varch.mlp_dim and vt.cfg.enc.mlp_dim % 64 == 0 and vt.residual_stream == "fp32"
+    out = vt.encode_u8(u8.cuda())
+    assert out.shape == (n, varch.out_dim) and _cos_err(out, ref) < COS_TIGHT
+    assert _cos_err(vt.encode_u8(u8[:1].cuda()), ref[:1]) < COS_TIGHT
+    raw = vt.encode_u8(u8.cuda(), normalize=False)
+    assert _cos_err(raw, O.eva_vit_forward(sd, cfg, O.preprocess_u8_exact_size(u8), normalize=False)) < COS_TIGHT
+    assert float((raw.cpu().norm(dim=-1) / O.eva_vit_forward(sd, cfg, O.preprocess_u8_exact_size(u8), normalize=False).norm(dim=-1) - 1).abs().max()) < 5e-3
+    if name in ("tiny", "EVA02-L-14"):
+        # the same weights as a fused-qkv checkpoint (timm qkv_fused=True: attn.qkv.weight + q_bias / v_bias): the same tower, the same bits
+        fused = dict(sd)
+        for i in range(layers):
+            p = f"visual.trunk.blocks.{i}.attn."
+            fused[p + "qkv.weight"] = torch.cat([fused.pop(p + "q_proj.weight"), fused.pop(p + "k_proj.weight"), fused.pop(p + "v_proj.weight")], dim=0)
+            fused[p + "q_bias"], fused[p + "v_bias"] = fused.pop(p + "q_proj.bias"), fused.pop(p + "v_proj.bias")
+        assert torch.equal(T.VitTower(varch, fused, "cuda").encode_u8(u8.cuda()), out)
+    with pytest.raises(ValueError):
+        T.VitTower(varch, sd, "cuda", precision="fp8")
+
+
 def test_single_request_graph_replay_is_bit_identical(monkeypatch):
     """one query text / one image per call replays a hipGraph captured per (tower, token count): same kernels, same bits as the
     eager launches; new contents and new lengths go through, batches are untouched"""
