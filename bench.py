@@ -50,6 +50,8 @@ WORKLOADS = {
     "vit_bigg14_image": dict(kind="image", arch="ViT-bigG-14", desc="open_clip ViT-bigG/14 image tower (104-wide heads run as 112), uint8 224x224, batch 32/GPU", batch=32),
     "siglip_b16_image": dict(kind="image", arch="ViT-B-16-SigLIP", desc="open_clip ViT-B-16-SigLIP image tower (196 tokens, attention-pool head), uint8 224x224, batch 128/GPU", batch=128),
     "siglip_l16_384_image": dict(kind="image", arch="ViT-L-16-SigLIP-384", desc="open_clip ViT-L-16-SigLIP-384 image tower (576 tokens), uint8 384x384, batch 32/GPU", batch=32),
+    "eva02_b16_image": dict(kind="image", arch="EVA02-B-16", desc="open_clip EVA02-B-16 image tower (timm Eva: 197 tokens, 2-D rotary positions, sub-LayerNorms, SwiGLU), uint8 224x224, batch 128/GPU", batch=128),
+    "eva02_l14_image": dict(kind="image", arch="EVA02-L-14", desc="open_clip EVA02-L-14 image tower (257 tokens, SwiGLU hidden 2 730 -> 2 752), uint8 224x224, batch 64/GPU", batch=64),
     "siglip_b16_text": dict(kind="clip_text", arch="ViT-B-16-SigLIP", desc="open_clip ViT-B-16-SigLIP text tower (unmasked, 64 positions), batch 1024/GPU", batch=1024),
     "clip_text_b32": dict(kind="clip_text", arch="ViT-B-32", desc="open_clip ViT-B/32 text tower, 77-token ids, batch 1024/GPU", batch=1024),
     "clip_text_l14": dict(kind="clip_text", arch="ViT-L-14", desc="open_clip ViT-L/14 text tower, 77-token ids, batch 1024/GPU", batch=1024),
@@ -311,6 +313,8 @@ class Workload:
             a = self.varch
             if a.pool == "map":
                 cfg, fwd = O.SiglipVitConfig(a.image_size, a.patch_size, a.width, a.layers, a.heads, a.mlp_dim), O.siglip_vit_forward
+            elif a.eva:
+                cfg, fwd = O.EvaVitConfig(a.image_size, a.patch_size, a.width, a.layers, a.heads, a.mlp_dim, a.out_dim, ref_grid=a.rope_ref_grid), O.eva_vit_forward
             else:
                 cfg, fwd = O.VitConfig(a.image_size, a.patch_size, a.width, a.layers, a.heads, a.mlp_dim, a.out_dim, a.quick_gelu), O.vit_forward
             rate, n, emb, th, cores = cpu_baseline_run(lambda lo, hi: fwd(self.sd, cfg, O.preprocess_u8_exact_size(self.images_cpu[lo:hi])),

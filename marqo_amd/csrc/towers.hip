@@ -103,10 +103,11 @@ static int ln_gemm(const void* d_x, int xb, const float* g, const float* b, floa
 static bool stream_bf16(const mq_encoder_cfg* c) {
     // per-model policy, else the process default (bf16 towers only: an fp8 tower takes the bf16 stream when its load-time policy asks for it)
     const bool want = c->residual_stream == 1 || (c->residual_stream == 0 && mq_tower_residual_bf16 && c->precision == MQ_PREC_BF16);
-    return want && (c->precision == MQ_PREC_BF16 || c->precision == MQ_PREC_FP8) && !c->post_ln && !c->mlp_glu && !c->d_rope_inv_freq && !c->d_rope_table;
+    return want && (c->precision == MQ_PREC_BF16 || c->precision == MQ_PREC_FP8) && !c->post_ln && !c->d_rope_inv_freq;
 }
 // the EVA02 vision blocks (timm eva.py EvaBlock): pre-LN with any of — 2-D rotary positions on the patch tokens' Q / K, a LayerNorm between attention and
-// out-projection, a gated (SwiGLU) MLP with a LayerNorm behind the gate.  fp32 residual stream, every row through every block, LayerNorm kernels (no folds).
+// out-projection, a gated (SwiGLU) MLP with a LayerNorm behind the gate.  Every row runs every block; residual stream and LayerNorm folding as in the
+// plain pre-LN blocks (LN1 into the QKV GEMM, LN2 into the (up | gate) GEMM; the two sub-LayerNorms are kernels).
 static bool eva_form(const mq_encoder_cfg* c) { return !c->post_ln && (c->mlp_glu || c->d_rope_table); }
 
 // post-LN encoders (BERT family) on the bf16 stream: the normalised bf16 rows `h` ARE the residual — the out-projection / fc2 epilogues add
@@ -378,27 +379,36 @@ int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* bloc
             MQ_TRY(mq_gemm_fp8(h, W, b.fc1_w8, W, row_scale, 1, b.fc1_ws, b.fc1_b, nullptr, qf, F, s_mlp, m_mlp, rows, F, W, act8, s));
             MQ_TRY(mq_gemm_fp8(qf, F, b.fc2_w8, F, s_mlp, 0, b.fc2_ws, b.fc2_b, d_x, d_x, W, nullptr, nullptr, rows, W, F, rflags, s));
         } else if (eva_form(cfg)) {
-            // x += out(ln_attn(attn(rope(qkv(ln1(x)))))) ; x += fc2(ln_mlp(up * silu(gate)))  with (up | gate) = fc1(ln2(x))     (x fp32)
+            // x += out(ln_attn(attn(rope(qkv(ln1(x)))))) ; x += fc2(ln_mlp(up * silu(gate)))  with (up | gate) = fc1(ln2(x))     (x fp32, or bf16 in the bf16-stream form)
             MQ_CHECK_ARG(!cfg->d_rope_table || (fixed_len > 0 && !d_cu_seqlens && rows == nseq * fixed_len && fixed_len > cfg->rope_prefix),
                          "mq_encoder_forward: d_rope_table needs fixed-length sequences longer than rope_prefix");
             MQ_CHECK_ARG(!b.attn_ln_g == !b.attn_ln_b && !b.mlp_ln_g == !b.mlp_ln_b && (!b.mlp_ln_g || cfg->mlp_glu), "mq_encoder_forward: layer %d: sub-LayerNorm weights must come in pairs (mlp_ln: gated MLPs only)", l);
-            MQ_TRY(mq_layernorm_pf(d_x, 0, nullptr, b.ln1_g, b.ln1_b, h, nullptr, rows, W, cfg->ln_eps, pf(b.qkv_w), (size_t)3 * Wa * W * 2, pf(b.out_w), (size_t)W * Wa * 2, s));
-            MQ_TRY(mq_gemm_bf16(h, W, b.qkv_w, W, b.qkv_b, nullptr, qf, 3 * Wa, rows, 3 * Wa, W, MQ_EPI_BIAS, s));
+            const int xb = stream_bf16(cfg) ? 1 : 0;
+            const int rflags = xb ? (MQ_EPI_BIAS | MQ_EPI_RESIDUAL) : res_flags;
+            const int fc1_cols = cfg->mlp_glu ? 2 * F : F;
+            MQ_TRY(ln_gemm(d_x, xb, b.ln1_g, b.ln1_b, cfg->ln_eps, h, b.qkv_w, b.qkv_b, qf, rows, 3 * Wa, W, MQ_EPI_BIAS, s, b.out_w, (size_t)W * Wa * 2,
+                           b.qkv_wf, b.qkv_bf, b.qkv_sf, row_stats, x_has_partials ? row_part : nullptr));
+            x_has_partials = false;
             if (cfg->d_rope_table) MQ_TRY(mq_rope_table(qf, rows, fixed_len, cfg->rope_prefix, Wa, cfg->heads, cfg->d_rope_table, s));
             MQ_TRY(attn_bf16(cfg, qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, s));
             if (b.attn_ln_g) MQ_TRY(mq_layernorm_ex(a, 1, nullptr, b.attn_ln_g, b.attn_ln_b, a, nullptr, rows, Wa, cfg->ln_eps, s));   // (in place: a wave holds its row before it stores)
-            MQ_TRY(mq_gemm_bf16(a, Wa, b.out_w, Wa, b.out_b, d_x, d_x, W, rows, W, Wa, res_flags, s));
-            MQ_TRY(mq_layernorm_pf(d_x, 0, nullptr, b.ln2_g, b.ln2_b, h, nullptr, rows, W, cfg->ln_eps, pf(b.fc1_w), (size_t)(cfg->mlp_glu ? 2 : 1) * F * W * 2, pf(b.fc2_w),
-                                   (size_t)W * F * 2, s));
+            const bool fold_mlp = mq_tower_ln_fold >= 2 && fold_ok(xb, b.fc1_wf, b.fc1_bf, b.fc1_sf, rows, fc1_cols, W) && !mq_gemm_small_ok(rows, W, Wa, false) &&
+                                  !mq_gemm_small_grouped_ok(rows, W, Wa);
+            if (fold_mlp) MQ_TRY(mq_gemm_bf16_rs(a, Wa, b.out_w, Wa, b.out_b, d_x, d_x, W, rows, W, Wa, rflags, row_part, s));
+            else MQ_TRY(mq_gemm_bf16(a, Wa, b.out_w, Wa, b.out_b, (const float*)d_x, d_x, W, rows, W, Wa, rflags, s));
+            MQ_TRY(ln_gemm(d_x, xb, b.ln2_g, b.ln2_b, cfg->ln_eps, h, b.fc1_w, b.fc1_b, qf, rows, fc1_cols, W, MQ_EPI_BIAS | (cfg->mlp_glu ? 0 : act_flag), s, b.fc2_w,
+                           (size_t)W * F * 2, b.fc1_wf, b.fc1_bf, b.fc1_sf, row_stats, fold_mlp ? row_part : nullptr));
             if (cfg->mlp_glu) {
-                MQ_TRY(mq_gemm_bf16(h, W, b.fc1_w, W, b.fc1_b, nullptr, qf, 2 * F, rows, 2 * F, W, b.fc1_b ? MQ_EPI_BIAS : 0, s));
                 if (b.mlp_ln_g) MQ_TRY(mq_glu_ln(qf, rows, F, cfg->mlp_ln_dim ? cfg->mlp_ln_dim : F, cfg->act, b.mlp_ln_g, b.mlp_ln_b, cfg->ln_eps, s));
                 else MQ_TRY(mq_glu(qf, rows, F, cfg->act, s));
-                MQ_TRY(mq_gemm_bf16(qf, 2 * F, b.fc2_w, F, b.fc2_b, d_x, d_x, W, rows, W, F, res_flags, s));
-            } else {
-                MQ_TRY(mq_gemm_bf16(h, W, b.fc1_w, W, b.fc1_b, nullptr, qf, F, rows, F, W, MQ_EPI_BIAS | act_flag, s));
-                MQ_TRY(mq_gemm_bf16(qf, F, b.fc2_w, F, b.fc2_b, d_x, d_x, W, rows, W, F, res_flags, s));
             }
+            // fc2 (reads the F-wide product at the (up | gate) buffer's row stride) writes the x the NEXT block's QKV normalises
+            const mq_block_weights* nbk = l + 1 < cfg->layers ? &blocks[l + 1] : nullptr;
+            const bool fold_next = mq_tower_ln_fold >= 2 && nbk && fold_ok(xb, nbk->qkv_wf, nbk->qkv_bf, nbk->qkv_sf, rows, 3 * Wa, W) && !mq_gemm_small_ok(rows, W, F, false) &&
+                                   !mq_gemm_small_grouped_ok(rows, W, F);
+            if (fold_next) MQ_TRY(mq_gemm_bf16_rs(qf, fc1_cols, b.fc2_w, F, b.fc2_b, d_x, d_x, W, rows, W, F, rflags, row_part, s));
+            else MQ_TRY(mq_gemm_bf16(qf, fc1_cols, b.fc2_w, F, b.fc2_b, (const float*)d_x, d_x, W, rows, W, F, rflags, s));
+            x_has_partials = fold_next;
         } else if (!cfg->post_ln) {
             // x += out(attn(qkv(ln1(x)))) ; x += fc2(act(fc1(ln2(x))))   (x fp32, or bf16 in the bf16-stream form)
             const int xb = stream_bf16(cfg) ? 1 : 0;

@@ -261,18 +261,26 @@ def _eva_blocks(h: _Holder, sd, prefix: str, layers: int, W: int, F: int, heads:
             qkv_w = torch.cat([f32("attn.q_proj.weight", (W, W)), f32("attn.k_proj.weight", (W, W)), f32("attn.v_proj.weight", (W, W))], dim=0)
             qb = f32("attn.q_proj.bias", (W,)) if p + "attn.q_proj.bias" in sd else torch.zeros(W)
             vb = f32("attn.v_proj.bias", (W,)) if p + "attn.v_proj.bias" in sd else torch.zeros(W)
-        b.qkv_w, b.qkv_b = h.bf16(qkv_w), h.f32(torch.cat([qb, torch.zeros(W), vb]))      # (keys carry no bias)
+        qkv_b = torch.cat([qb, torch.zeros(W), vb])                                        # (keys carry no bias)
+        b.qkv_w, b.qkv_b = h.bf16(qkv_w), h.f32(qkv_b)
         if p + "attn.norm.weight" in sd:
             b.attn_ln_g, b.attn_ln_b = h.f32(f32("attn.norm.weight", (W,))), h.f32(f32("attn.norm.bias", (W,)))
         b.out_w, b.out_b = h.bf16(f32("attn.proj.weight", (W, W))), h.f32(f32("attn.proj.bias", (W,)))
         b.ln2_g, b.ln2_b = h.f32(f32("norm2.weight", (W,))), h.f32(f32("norm2.bias", (W,)))
         up_w, up_b = f32("mlp.fc1_x.weight", (F, W)), f32("mlp.fc1_x.bias", (F,))
         gate_w, gate_b = f32("mlp.fc1_g.weight", (F, W)), f32("mlp.fc1_g.bias", (F,))
-        b.fc1_w = h.bf16(torch.cat([pad(up_w, (0, 0, 0, Fp - F)), pad(gate_w, (0, 0, 0, Fp - F))], dim=0))
-        b.fc1_b = h.f32(torch.cat([pad(up_b, (0, Fp - F)), pad(gate_b, (0, Fp - F))]))
+        fc1_w = torch.cat([pad(up_w, (0, 0, 0, Fp - F)), pad(gate_w, (0, 0, 0, Fp - F))], dim=0)
+        fc1_b = torch.cat([pad(up_b, (0, Fp - F)), pad(gate_b, (0, Fp - F))])
+        b.fc1_w, b.fc1_b = h.bf16(fc1_w), h.f32(fc1_b)
         if p + "mlp.norm.weight" in sd:
             b.mlp_ln_g, b.mlp_ln_b = h.f32(pad(f32("mlp.norm.weight", (F,)), (0, Fp - F))), h.f32(pad(f32("mlp.norm.bias", (F,)), (0, Fp - F)))
         b.fc2_w, b.fc2_b = h.bf16(pad(f32("mlp.fc2.weight", (W, F)), (0, Fp - F))), h.f32(f32("mlp.fc2.bias", (W,)))
+        if LN_FOLD:   # norm1 into the QKV GEMM, norm2 into the (up | gate) GEMM (as _clip_blocks; the sub-LayerNorms stay kernels)
+            for name, w32, b32, lg in (("qkv", qkv_w, qkv_b, "norm1"), ("fc1", fc1_w, fc1_b, "norm2")):
+                wf = (w32 * f32(lg + ".weight", (W,)).unsqueeze(0)).to(torch.bfloat16)
+                setattr(b, name + "_wf", h.bf16(wf))
+                setattr(b, name + "_sf", h.f32(wf.to(torch.float32).sum(dim=1)))
+                setattr(b, name + "_bf", h.f32(b32 + w32 @ f32(lg + ".bias", (W,))))
     return arr
 
 
@@ -851,7 +859,7 @@ class VitTower(_TowerBase):
         if precision == "fp8":
             self._enable_fp8(self._blocks, arch.layers, W, _ceil64(arch.mlp_dim))
         self.cfg.enc.residual_stream = 2
-        if precision == "bf16" and not arch.eva:      # (the EVA02 blocks keep the fp32 stream: towers.hip, eva_form)
+        if precision == "bf16":
             self.tune_residual_default()
 
     def tune_residual_default(self) -> str:

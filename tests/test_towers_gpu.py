@@ -513,7 +513,7 @@ def test_coca_towers_vs_oracle(name, layers, n):
 
 
 @pytest.mark.parametrize("name,layers,n", [("EVA02-B-16", 12, 5), ("EVA02-L-14", 2, 3), ("EVA02-L-14-336", 1, 2), ("tiny", 2, 7)])
-def test_eva02_tower_vs_oracle(name, layers, n):
+def test_eva02_tower_vs_oracle(name, layers, n, monkeypatch):
     """EVA02-CLIP vision towers (model_registry.py:441-460; timm Eva behind open_clip's TimmModel): class token + learned positions + 2-D rotary
     positions on the patch tokens' q / k (the 336 px tower: a 24 x 24 grid rescaled to the 16 x 16 pre-training grid), separate q / k / v with
     a bias-free k, LayerNorm between attention and out-projection, SwiGLU with a LayerNorm behind the gate (hidden 2 730 at L/14 -> zero-padded
@@ -531,7 +531,7 @@ def test_eva02_tower_vs_oracle(name, layers, n):
     u8 = O.synthetic_images_u8(n, varch.image_size, seed=8)
     ref = O.eva_vit_forward(sd, cfg, O.preprocess_u8_exact_size(u8))
     vt = T.VitTower(varch, sd, "cuda")
-    assert vt.cfg.enc.mlp_glu == 1 and vt.cfg.enc.mlp_ln_dim == varch.mlp_dim and vt.cfg.enc.mlp_dim % 64 == 0 and vt.residual_stream == "fp32"
+    assert vt.cfg.enc.mlp_glu == 1 and vt.cfg.enc.mlp_ln_dim == varch.mlp_dim and vt.cfg.enc.mlp_dim % 64 == 0 and vt.residual_stream in ("bf16", "fp32")
     out = vt.encode_u8(u8.cuda())
     assert out.shape == (n, varch.out_dim) and _cos_err(out, ref) < COS_TIGHT
     assert _cos_err(vt.encode_u8(u8[:1].cuda()), ref[:1]) < COS_TIGHT
@@ -548,6 +548,16 @@ def test_eva02_tower_vs_oracle(name, layers, n):
         assert torch.equal(T.VitTower(varch, fused, "cuda").encode_u8(u8.cuda()), out)
     with pytest.raises(ValueError):
         T.VitTower(varch, sd, "cuda", precision="fp8")
+    # both residual-stream forms, forced: fp32 (LayerNorm kernels) and bf16 (norm1 / norm2 folded into the QKV / (up | gate) GEMMs, bf16 epilogues)
+    big = O.synthetic_images_u8(max(n, 24), varch.image_size, seed=9)        # enough rows for the tiled / folded GEMM family
+    bref = O.eva_vit_forward(sd, cfg, O.preprocess_u8_exact_size(big[:n]))
+    for mode in ("fp32", "bf16"):
+        monkeypatch.setenv("MARQO_AMD_RESIDUAL_STREAM", mode)
+        tw = T.VitTower(varch, sd, "cuda")
+        assert tw.residual_stream == mode
+        got = tw.encode_u8(big.cuda())
+        assert _cos_err(got[:n], bref) < COS_TIGHT, mode
+        assert _cos_err(tw.encode_u8(big[:n].cuda()), got[:n]) < COS_TIGHT          # (another batch size = other GEMM kernel families: last bits only)
 
 
 def test_single_request_graph_replay_is_bit_identical(monkeypatch):
