@@ -112,6 +112,11 @@ PIPELINE_MIN = max(2, int(os.environ.get("MARQO_AMD_IMAGE_PIPELINE_MIN", "256"))
 # The stages alternate between this many HIP streams (1 = all on the request stream): stage k + 1's tower starts beside the tail of stage k's
 # instead of behind it (+1.5 ... 8 %, same bits).
 PIPELINE_STREAMS = max(1, int(os.environ.get("MARQO_AMD_IMAGE_PIPELINE_STREAMS", "2")))
+# A stage's tower is ~90 launches = 0.35 ms of host time through the boundary (GIL released inside the op): enqueued by a helper thread, the calling
+# thread packs the next stage meanwhile instead of afterwards.  Used where the GPU waits for the host — stages smaller than PIPELINE_CHUNK, i.e. calls
+# of fewer than 2 * PIPELINE_CHUNK images (256 images: 4.58 -> 4.36 ms; with 256-image stages the host is ahead anyway and the hand-over costs 2 %:
+# profiles/r05w_e2e_stages.txt).  MARQO_AMD_IMAGE_PIPELINE_THREAD=0: everything on the calling thread.
+PIPELINE_THREAD = os.environ.get("MARQO_AMD_IMAGE_PIPELINE_THREAD", "1") != "0"
 
 
 def _pipeline_stages(n: int) -> list:
@@ -471,16 +476,34 @@ class OPEN_CLIP(AbstractCLIPModel):
                 outs, pxs = [], []
                 main = torch.cuda.current_stream(self.device)
                 sides = self._pipeline_streams(main) if PIPELINE_STREAMS > 1 else [main]
-                for k, (a, b) in enumerate(_pipeline_stages(len(images))):
+                stages = _pipeline_stages(len(images))
+                helper = self._pipeline_helper() if PIPELINE_THREAD and max(b - a for a, b in stages) < PIPELINE_CHUNK else None
+
+                def tower(st, kind, px):     # (on the helper thread: its own current-stream / current-device state)
+                    with torch.cuda.device(self.device), torch.cuda.stream(st):
+                        return run(kind, px)
+                for k, (a, b) in enumerate(stages):
                     st = sides[k % len(sides)]
                     with torch.cuda.stream(st):
                         kind, px = self._preprocess_images(images[a:b], image_download_headers)
-                        o = run(kind, px)
-                    if st is not main:      # allocated on the side stream, read by the request stream below
-                        px.record_stream(main)
-                        o.record_stream(main)
+                        o = helper.submit(tower, st, kind, px) if helper is not None else run(kind, px)
                     pxs.append(px)
                     outs.append(o)
+                if helper is not None:
+                    done = []
+                    for o in outs:          # (every stage is waited for even when one raised: nothing of this call is left running on the helper)
+                        try:
+                            done.append(o.result())
+                        except BaseException as e:
+                            done.append(e)
+                    for o in done:
+                        if isinstance(o, BaseException):
+                            raise o
+                    outs = done
+                for k, (px, o) in enumerate(zip(pxs, outs)):
+                    if sides[k % len(sides)] is not main:      # allocated on a side stream, read by the request stream below
+                        px.record_stream(main)
+                        o.record_stream(main)
                 for st in sides:
                     if st is not main:
                         main.wait_stream(st)
@@ -493,6 +516,14 @@ class OPEN_CLIP(AbstractCLIPModel):
             return out if return_device else self._convert_output(out)
 
     _pipeline_tls = threading.local()
+
+    def _pipeline_helper(self):
+        """this calling thread's helper (one worker: the stages' towers are enqueued in stage order)"""
+        ex = getattr(self._pipeline_tls, "helper", None)
+        if ex is None:
+            from concurrent.futures import ThreadPoolExecutor
+            ex = self._pipeline_tls.helper = ThreadPoolExecutor(max_workers=1, thread_name_prefix="mq-stage-tower")
+        return ex
 
     def _pipeline_streams(self, main) -> list:
         """[the request stream, this thread's side streams ...] of the two-stream image pipeline; the side streams start behind the request

@@ -672,9 +672,19 @@ def test_large_image_call_is_pipelined_in_stages(s2, monkeypatch, streams):
     monkeypatch.setattr(M, "PIPELINE_STREAMS", 1)
     one_stream = model.encode_image(imgs)
     monkeypatch.setattr(M, "PIPELINE_STREAMS", streams)
-    for _ in range(3):      # (repeated: the side streams' buffers are recycled between calls)
+    for helper in (True, False, True):      # (repeated: the side streams' buffers are recycled between calls; towers enqueued by the helper thread or not)
+        monkeypatch.setattr(M, "PIPELINE_THREAD", helper)
+        monkeypatch.setattr(M, "PIPELINE_CHUNK", 9 if helper else 8)      # (the helper serves stages SMALLER than PIPELINE_CHUNK)
+        assert [b - a for a, b in M._pipeline_stages(37)] == ([10, 10, 10, 7] if helper else [8, 8, 8, 8, 5])
         staged = model.encode_image(imgs)
-        assert np.array_equal(staged, one_stream)
+        assert _cos_err(staged, one_stream) < 3e-5 and (helper or np.array_equal(staged, one_stream))
+    bad = list(imgs)
+    bad[30] = "not an image, not a path"      # a stage that raises on the calling thread while earlier towers sit on the helper: the error comes out, nothing hangs
+    with pytest.raises(Exception):
+        model.encode_image(bad)
+    monkeypatch.setattr(M, "PIPELINE_CHUNK", 8)
+    monkeypatch.setattr(M, "PIPELINE_THREAD", False)
+    staged = model.encode_image(imgs)
     assert staged.shape == whole.shape and _cos_err(staged, whole) < 3e-5      # (8-image stages of 17 tokens cross GEMM kernel families)
     assert tuple(model.image_input_processed.shape) == (37, 64, 64, 3)
     dev_rows = model.encode_image(imgs, return_device=True)                   # the ingest path's form: rows stay in HBM, ordered behind the caller's stream

@@ -28,18 +28,18 @@ def stages_of(split):
     return f
 
 
-# (stage sizes, streams)
+# (stage sizes, streams, towers enqueued by the helper thread)
 if n <= 384:
     h = n // 2
-    configs = [((n,), 1), ((h, n - h), 2), ((h, n - h), 1), ((64, n - 64), 2), ((128, n - 128), 2)]
+    configs = [((n,), 1, True), ((h, n - h), 2, True), ((h, n - h), 2, False), ((h, n - h), 1, True), ((h, n - h), 1, False), ((64, n - 64), 2, True)]
 else:
     q = n // 4
-    configs = [((n,), 1), ((n // 2, n // 2), 2), ((n // 2, n // 2), 1), ((q, q, q, q), 2), ((q, q, q, q), 1), ((q, n - q), 2), ((128,) * (n // 128), 2), ((q // 2, q, q, q, q // 2), 2)]
+    configs = [((n,), 1, True), ((n // 2, n // 2), 2, True), ((n // 2, n // 2), 2, False), ((q, q, q, q), 2, True), ((q, q, q, q), 2, False), ((q, n - q), 2, True)]
 ref, res = None, {c: [] for c in configs}
 ocm.PIPELINE_CHUNK = 1      # every list call takes the staged path
 for rep in range(int(os.environ.get('REPS', '3'))):
     for c in configs:
-        ocm._pipeline_stages, ocm.PIPELINE_STREAMS = stages_of(c[0]), c[1]
+        ocm._pipeline_stages, ocm.PIPELINE_STREAMS, ocm.PIPELINE_THREAD = stages_of(c[0]), c[1], c[2]
         for _ in range(3):
             out = s2.vectorise_ndarray(name, pil, **kw)
         if ref is None:
@@ -54,4 +54,4 @@ for rep in range(int(os.environ.get('REPS', '3'))):
         res[c].append(sorted(ts)[5])
 for c in configs:
     m = sorted(res[c])[len(res[c]) // 2]
-    print(f"stages={c[0]} streams={c[1]}: median of medians {m * 1e3:.3f} ms = {n / m:.0f} emb/s   ({', '.join(f'{t * 1e3:.3f}' for t in res[c])})")
+    print(f"stages={c[0]} streams={c[1]} helper_thread={c[2]}: median of medians {m * 1e3:.3f} ms = {n / m:.0f} emb/s   ({', '.join(f'{t * 1e3:.3f}' for t in res[c])})")

@@ -48,17 +48,17 @@ def run(depth, n):
 if os.environ.get("STAGES_AB"):     # the merged image call in one batch against the staged form of open_clip_model.encode_image (PIPELINE_MIN / _STREAMS)
     from marqo_amd.s2_inference import open_clip_model as ocm
     ing.merge_images = 512
-    forms = [("one batch", 10 ** 9, 1), ("stages, 1 stream", 256, 1), ("stages, 2 streams", 256, 2)]
-    for _, mn, st in forms:
-        ocm.PIPELINE_MIN, ocm.PIPELINE_STREAMS = mn, st
+    forms = [("one batch", 10 ** 9, 1, False), ("stages, 2 streams", 256, 2, False), ("stages, 2 streams, helper", 256, 2, True)]
+    for _, mn, st, hp in forms:
+        ocm.PIPELINE_MIN, ocm.PIPELINE_STREAMS, ocm.PIPELINE_THREAD = mn, st, hp
         for _ in range(8):
             step()
         ing.collect()
     for rep in range(4):
-        for label, mn, st in forms:
-            ocm.PIPELINE_MIN, ocm.PIPELINE_STREAMS = mn, st
+        for label, mn, st, hp in forms:
+            ocm.PIPELINE_MIN, ocm.PIPELINE_STREAMS, ocm.PIPELINE_THREAD = mn, st, hp
             ms = run(1, 96) * 1e3
-            print(f"merged image call: {label:18s}: {ms:.3f} ms per {docs}-document request = {2 * docs / ms * 1e3:.0f} embeddings/s", flush=True)
+            print(f"merged image call: {label:26s}: {ms:.3f} ms per {docs}-document request = {2 * docs / ms * 1e3:.0f} embeddings/s", flush=True)
     sys.exit(0)
 for m in merges:            # every group shape once, untimed (workspaces, pinned blocks, LDS attributes)
     ing.merge_images = m
