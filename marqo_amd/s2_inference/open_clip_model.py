@@ -482,24 +482,22 @@ class OPEN_CLIP(AbstractCLIPModel):
                 def tower(st, kind, px):     # (on the helper thread: its own current-stream / current-device state)
                     with torch.cuda.device(self.device), torch.cuda.stream(st):
                         return run(kind, px)
-                for k, (a, b) in enumerate(stages):
-                    st = sides[k % len(sides)]
-                    with torch.cuda.stream(st):
-                        kind, px = self._preprocess_images(images[a:b], image_download_headers)
-                        o = helper.submit(tower, st, kind, px) if helper is not None else run(kind, px)
-                    pxs.append(px)
-                    outs.append(o)
+                try:
+                    for k, (a, b) in enumerate(stages):
+                        st = sides[k % len(sides)]
+                        with torch.cuda.stream(st):
+                            kind, px = self._preprocess_images(images[a:b], image_download_headers)
+                            o = helper.submit(tower, st, kind, px) if helper is not None else run(kind, px)
+                        pxs.append(px)
+                        outs.append(o)
+                finally:      # (also when a later stage raised on this thread: nothing of this call is left running on the helper)
+                    if helper is not None:
+                        errs = [o.exception() for o in outs]
                 if helper is not None:
-                    done = []
-                    for o in outs:          # (every stage is waited for even when one raised: nothing of this call is left running on the helper)
-                        try:
-                            done.append(o.result())
-                        except BaseException as e:
-                            done.append(e)
-                    for o in done:
-                        if isinstance(o, BaseException):
-                            raise o
-                    outs = done
+                    for e in errs:
+                        if e is not None:
+                            raise e
+                    outs = [o.result() for o in outs]
                 for k, (px, o) in enumerate(zip(pxs, outs)):
                     if sides[k % len(sides)] is not main:      # allocated on a side stream, read by the request stream below
                         px.record_stream(main)
