@@ -88,6 +88,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the headline baseline sample")
     ap.add_argument("--no-extras", action="store_true", help="skip e2e_vectorise and the `also` workloads (profiling runs)")
+    ap.add_argument("--no-also", action="store_true", help="keep e2e_vectorise but skip the `also` workloads (host-side A/B runs)")
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port when bench.py spawns its own ranks (0 = pick a free one)")
     return ap.parse_args()
 
@@ -874,7 +875,7 @@ def main():
         also = []
         del w
         torch.cuda.empty_cache()
-        for name in ALSO_DEFAULT:
+        for name in (() if args.no_also else ALSO_DEFAULT):
             try:
                 if WORKLOADS[name]["kind"] == "stream":      # BASELINE configs[3]: end-to-end by definition (host PIL + strings in, host rows out)
                     sa = argparse.Namespace(**{**vars(args), "steps": 0, "warmup": 8, "batch": 0, "cpu_seconds": 8.0, "workload": name})   # steps 0 = the full 100 000 documents

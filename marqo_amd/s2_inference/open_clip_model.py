@@ -117,6 +117,7 @@ PIPELINE_STREAMS = max(1, int(os.environ.get("MARQO_AMD_IMAGE_PIPELINE_STREAMS",
 # of fewer than 2 * PIPELINE_CHUNK images (256 images: 4.58 -> 4.36 ms; with 256-image stages the host is ahead anyway and the hand-over costs 2 %:
 # profiles/r05w_e2e_stages.txt).  MARQO_AMD_IMAGE_PIPELINE_THREAD=0: everything on the calling thread.
 PIPELINE_THREAD = os.environ.get("MARQO_AMD_IMAGE_PIPELINE_THREAD", "1") != "0"
+PIPELINE_ALWAYS = os.environ.get("MARQO_AMD_IMAGE_PIPELINE_ALWAYS", "0") == "1"   # stage a call also while other image calls are in flight on the model
 
 
 def _pipeline_stages(n: int) -> list:
@@ -156,6 +157,8 @@ class OPEN_CLIP(AbstractCLIPModel):
         self.model_properties = self._build_model_properties(model_properties or {})
         self.preprocess_config = None
         self._local = threading.local()
+        self._image_calls = 0               # encode_image calls in flight on this model (a call stages itself only when it is alone)
+        self._image_calls_lock = threading.Lock()
         self.vision_arch: Optional[archs.VitArch] = None
         self.text_arch: Optional[archs.ClipTextArch] = None
         self.weights_source = None
@@ -469,10 +472,23 @@ class OPEN_CLIP(AbstractCLIPModel):
         device tensor (no D2H: bulk ingest gathers shards over RCCL straight from HBM)"""
         if self.model is None:
             self.load()
+        with self._image_calls_lock:
+            self._image_calls += 1
+            alone = self._image_calls == 1
+        try:
+            return self._encode_image(images, image_download_headers, normalize, return_device, alone)
+        finally:
+            with self._image_calls_lock:
+                self._image_calls -= 1
+
+    def _encode_image(self, images, image_download_headers, normalize, return_device: bool, alone: bool):
         with request_stream(self.device, device_output=return_device):
             run = lambda kind, px: (self.vision.encode_u8(px, normalize=bool(normalize)) if kind == "u8"
                                     else self.vision.encode_f32(px, normalize=bool(normalize)))
-            if isinstance(images, list) and len(images) >= PIPELINE_MIN:      # in stages (above); one D2H copy at the end
+            # in stages (above), one D2H copy at the end — when this call has the model to itself: with other image calls in flight the GPU is
+            # kept busy by them, and smaller towers only cost GEMM efficiency (4 concurrent 256-image callers: 77 k embeddings/s in one batch
+            # each, 71 k staged; profiles/r05w_e2e_stages.txt)
+            if isinstance(images, list) and len(images) >= PIPELINE_MIN and (alone or PIPELINE_ALWAYS):
                 outs, pxs = [], []
                 main = torch.cuda.current_stream(self.device)
                 sides = self._pipeline_streams(main) if PIPELINE_STREAMS > 1 else [main]

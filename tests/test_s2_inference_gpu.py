@@ -684,7 +684,18 @@ def test_large_image_call_is_pipelined_in_stages(s2, monkeypatch, streams):
         model.encode_image(bad)
     monkeypatch.setattr(M, "PIPELINE_CHUNK", 8)
     monkeypatch.setattr(M, "PIPELINE_THREAD", False)
+    # a call that finds another image call in flight on the model runs in one batch (the other call keeps the GPU busy)
+    seen = []
+    real_stages = M._pipeline_stages
+    monkeypatch.setattr(M, "_pipeline_stages", lambda n_: seen.append(n_) or real_stages(n_))
+    model._image_calls += 1
+    try:
+        assert _cos_err(model.encode_image(imgs), whole) < 3e-5 and not seen
+    finally:
+        model._image_calls -= 1
+    assert model._image_calls == 0
     staged = model.encode_image(imgs)
+    assert seen == [37]
     assert staged.shape == whole.shape and _cos_err(staged, whole) < 3e-5      # (8-image stages of 17 tokens cross GEMM kernel families)
     assert tuple(model.image_input_processed.shape) == (37, 64, 64, 3)
     dev_rows = model.encode_image(imgs, return_device=True)                   # the ingest path's form: rows stay in HBM, ordered behind the caller's stream
