@@ -554,8 +554,8 @@ def e2e_vectorise(dev, images_cpu_u8, tower_only_rate, reps=9):
     out["best_e2e_over_tower_only"] = round(best / tower_only_rate, 3)
     # THE end-to-end figure: one synchronous caller handing over PIL images, as add_documents / search hand them to vectorise()
     out["headline_e2e"] = {"form": "ndarray_from_pil", "value": out["ndarray_from_pil"], "over_tower_only": round(out["ndarray_from_pil"] / tower_only_rate, 3),
-                           "note": "a single synchronous caller: host pack of 51 MB of Pillow RGBX (1.3 ms, H2D of 64-image slices under it) + tower enqueue (0.3 ms), then "
-                                   "the GPU's resize + tower + D2H (profiles/r04ah_e2e_phases.txt); the call in pipelined halves is a wash (r04ah)"}
+                           "note": "a single synchronous caller: the call runs in two 128-image stages (host pack of 2 x 25 MB of Pillow RGBX, H2D of 64-image slices under it; "
+                                   "the stages' towers on two HIP streams, enqueued by a helper thread) + D2H (profiles/r05w_e2e_stages.txt; host-side: +-5 % between runs)"}
     s2.clear_loaded_models()
     return out
 
