@@ -109,8 +109,8 @@ STAGE_BYTES = int(os.environ.get("MARQO_AMD_IMAGE_STAGE_BYTES", str(1 << 30)))  
 # PIPELINE_CHUNK images, equal in size, at least two of them.
 PIPELINE_CHUNK = max(1, int(os.environ.get("MARQO_AMD_IMAGE_PIPELINE_CHUNK", "256")))
 PIPELINE_MIN = max(2, int(os.environ.get("MARQO_AMD_IMAGE_PIPELINE_MIN", "256")))
-# The stages alternate between this many HIP streams (1 = all on the request stream): stage k + 1's tower starts beside the tail of stage k's
-# instead of behind it (+1.5 ... 8 %, same bits).
+# The stages alternate between this many HIP streams (1 = all on the request stream): stage k + 1's launches interleave with stage k's and fill
+# their tails instead of queueing behind the whole tower (+1.5 ... 8 %, same bits; profiles/r05ah_e2e_two_stream_timeline.txt).
 PIPELINE_STREAMS = max(1, int(os.environ.get("MARQO_AMD_IMAGE_PIPELINE_STREAMS", "2")))
 # A stage's tower is ~90 launches = 0.35 ms of host time through the boundary (GIL released inside the op): enqueued by a helper thread, the calling
 # thread packs the next stage meanwhile instead of afterwards.  Used where the GPU waits for the host — stages smaller than PIPELINE_CHUNK, i.e. calls
