@@ -533,10 +533,11 @@ class OPEN_CLIP(AbstractCLIPModel):
 
     def _pipeline_helper(self):
         """this calling thread's helper (one worker: the stages' towers are enqueued in stage order)"""
-        ex = getattr(self._pipeline_tls, "helper", None)
-        if ex is None:
+        ex, pid = getattr(self._pipeline_tls, "helper", (None, None))
+        if ex is None or pid != os.getpid():      # (a fork()ed child inherits the object but not its worker thread)
             from concurrent.futures import ThreadPoolExecutor
-            ex = self._pipeline_tls.helper = ThreadPoolExecutor(max_workers=1, thread_name_prefix="mq-stage-tower")
+            ex = ThreadPoolExecutor(max_workers=1, thread_name_prefix="mq-stage-tower")
+            self._pipeline_tls.helper = (ex, os.getpid())
         return ex
 
     def _pipeline_streams(self, main) -> list:
