@@ -487,8 +487,10 @@ class OPEN_CLIP(AbstractCLIPModel):
                                     else self.vision.encode_f32(px, normalize=bool(normalize)))
             # in stages (above), one D2H copy at the end — when this call has the model to itself: with other image calls in flight the GPU is
             # kept busy by them, and smaller towers only cost GEMM efficiency (4 concurrent 256-image callers: 77 k embeddings/s in one batch
-            # each, 71 k staged; profiles/r05w_e2e_stages.txt)
-            if isinstance(images, list) and len(images) >= PIPELINE_MIN and (alone or PIPELINE_ALWAYS):
+            # each, 71 k staged; profiles/r05w_e2e_stages.txt).  Not for callers that take device rows either: they are the ingest pipelines
+            # (ingest.py), which pack group g + 1 while group g runs — their chip-filling groups stay whole (the stream: 119.9 k embeddings/s at
+            # gemm_frac 0.31 whole, 119.0 k at 0.26 staged)
+            if isinstance(images, list) and len(images) >= PIPELINE_MIN and ((alone and not return_device) or PIPELINE_ALWAYS):
                 outs, pxs = [], []
                 main = torch.cuda.current_stream(self.device)
                 sides = self._pipeline_streams(main) if PIPELINE_STREAMS > 1 else [main]

@@ -698,8 +698,11 @@ def test_large_image_call_is_pipelined_in_stages(s2, monkeypatch, streams):
     assert seen == [37]
     assert staged.shape == whole.shape and _cos_err(staged, whole) < 3e-5      # (8-image stages of 17 tokens cross GEMM kernel families)
     assert tuple(model.image_input_processed.shape) == (37, 64, 64, 3)
-    dev_rows = model.encode_image(imgs, return_device=True)                   # the ingest path's form: rows stay in HBM, ordered behind the caller's stream
-    assert np.array_equal(dev_rows.cpu().numpy(), one_stream)
+    seen.clear()
+    dev_rows = model.encode_image(imgs, return_device=True)                   # the ingest path's form: rows stay in HBM, the call stays whole
+    assert not seen and _cos_err(dev_rows.cpu().numpy(), whole) < 3e-5
+    monkeypatch.setattr(M, "PIPELINE_ALWAYS", True)                           # forced: staged, rows ordered behind the caller's stream
+    assert np.array_equal(model.encode_image(imgs, return_device=True).cpu().numpy(), one_stream) and seen == [37]
 
 
 def test_image_staging_is_bounded_by_bytes(s2, monkeypatch):

@@ -47,6 +47,7 @@ def run(depth, n):
 
 if os.environ.get("STAGES_AB"):     # the merged image call in one batch against the staged form of open_clip_model.encode_image (PIPELINE_MIN / _STREAMS)
     from marqo_amd.s2_inference import open_clip_model as ocm
+    ocm.PIPELINE_ALWAYS = True      # (device-row callers are not staged by default)
     ing.merge_images = 512
     forms = [("one batch", 10 ** 9, 1, False), ("stages, 2 streams", 256, 2, False), ("stages, 2 streams, helper", 256, 2, True)]
     for _, mn, st, hp in forms:
