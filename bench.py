@@ -466,7 +466,7 @@ def gemm_roofline(lib, L, run_local, prof_steps, precision, workload_name):
 
 
 # ---- end-to-end vectorise() from host memory (wall time includes preprocessing + H2D + towers + D2H) -------------------
-def e2e_vectorise(dev, images_cpu_u8, tower_only_rate, reps=9):
+def e2e_vectorise(dev, images_cpu_u8, tower_only_rate, reps=21):
     """the SAME images as the headline step, but handed over from HOST memory through the product API (random-init weights via
     MARQO_AMD_SYNTHETIC_WEIGHTS, the registry name of the headline model)"""
     from PIL import Image
@@ -483,7 +483,7 @@ def e2e_vectorise(dev, images_cpu_u8, tower_only_rate, reps=9):
     dev_tensors = [pre["image"](p) for p in pil]        # what add_documents' download threads hand over (add_docs.py:130-134)
     torch.cuda.synchronize()
 
-    def rate(fn, reps=reps, warm=3):
+    def rate(fn, reps=reps, warm=5):
         """items per second of the MEDIAN call (every call is synchronous: it returns host rows).  Three warm-up calls: the first ones of a form
         allocate its pinned staging blocks and workspaces (tens of ms each), and a mean over six calls is hostage to one host hiccup —
         profiles/r03final_bench_default.json reported 20.3 k for a form whose sibling measured 33.3 k seconds later"""
