@@ -290,7 +290,7 @@ __global__ __launch_bounds__(NW * 64) MQ_ATTN_OCC void attention_kernel(
 
 }  // namespace
 
-int mq_attention_waves = 0;  // mq_tune("attn_waves", 0 = auto / 4 / 8 / 5 = five waves for 65..80-token sequences, else auto): A/B knob
+mq_knob mq_attention_waves{0};  // mq_tune("attn_waves", 0 = auto / 4 / 8 / 5 = five waves for 65..80-token sequences, else auto): A/B knob
 
 static int attention_impl(const void* d_qkv, void* d_out, const int32_t* d_cu_seqlens, int64_t nseq,
                           int32_t fixed_len, int32_t max_len, int32_t W, int32_t heads, int32_t mask,
@@ -323,7 +323,8 @@ static int attention_impl(const void* d_qkv, void* d_out, const int32_t* d_cu_se
     // with three waves idle, measured neutral to slower: CLIP text -0.7 %, BERT-base +3.6 % attention time, profiles/r02p_attention_five_waves_ab.txt;
     // kept behind mq_tune("attn_waves", 5) with its bit-identity test)
     const bool five = mq_attention_waves == 5 && maxl > 64 && maxl <= 80 && hs == 64 && !d_rel_bias;
-    const int nw = five ? 5 : (mq_attention_waves == 4 || mq_attention_waves == 8 ? mq_attention_waves : (maxl > 128 ? 8 : 4));
+    const int knob_waves = mq_attention_waves;
+    const int nw = five ? 5 : (knob_waves == 4 || knob_waves == 8 ? knob_waves : (maxl > 128 ? 8 : 4));
     const float scale_log2e = 1.44269504088896340736f / sqrtf((float)hs);  // 1/sqrt(head dim) * log2(e)
     MqProfScope prof(2, s);
     auto launch = [&](auto kern) -> int {

@@ -90,7 +90,9 @@ __device__ __forceinline__ float quick_gelu(float x) {
 // band of output tiles, i.e. of activation ROWS; the row-wise kernels between them (LayerNorm, attention) use the same banding, so the
 // rows one XCD writes are the rows the same XCD reads in the next launch and find them in its own L2 (a kernel boundary writes dirty
 // lines back but keeps them) instead of fetching them from the Infinity Cache behind another die's L2.  Bijective for any grid size.
-extern int mq_xcd_band;   // runtime.hip: mq_tune("xcd_band", 0 | 1)
+// Run-time knobs (mq_tune, test / bench only) are relaxed atomics: request threads read them in their launch code while a test thread may set them
+typedef std::atomic<int> mq_knob;
+extern mq_knob mq_xcd_band;   // runtime.hip: mq_tune("xcd_band", 0 | 1)
 __device__ __forceinline__ unsigned xcd_banded_block(unsigned b, unsigned nb, int on) {
     if (!on) return b;
     const unsigned q = nb >> 3, r = nb & 7, xcd = b & 7, idx = b >> 3;

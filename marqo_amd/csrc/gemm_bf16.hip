@@ -37,16 +37,16 @@
 #include "common.h"
 #include "gemm_epilogue.h"
 
-extern int mq_gemm_fp8_force_mt;  // gemm_fp8.hip
-extern int mq_tower_row_select;   // towers.hip
-extern int mq_tower_ln_fold;      // towers.hip
-extern int mq_attention_waves;    // attention.hip
-extern int mq_tower_residual_bf16;  // towers.hip
-extern int mq_gemm_small_max_rows;  // gemm_small.hip
+extern mq_knob mq_gemm_fp8_force_mt;  // gemm_fp8.hip
+extern mq_knob mq_tower_row_select;   // towers.hip
+extern mq_knob mq_tower_ln_fold;      // towers.hip
+extern mq_knob mq_attention_waves;    // attention.hip
+extern mq_knob mq_tower_residual_bf16;  // towers.hip
+extern mq_knob mq_gemm_small_max_rows;  // gemm_small.hip
 bool mq_gemm_small_ok(int64_t M, int64_t N, int64_t K, bool ln);
 bool mq_gemm_small_grouped_ok(int64_t M, int64_t N, int64_t K);
-extern int mq_gemm_small_group_rows;
-extern int mq_ln_prefetch;        // rowops.hip
+extern mq_knob mq_gemm_small_group_rows;
+extern mq_knob mq_ln_prefetch;        // rowops.hip
 int mq_gemm_small(const void* d_A, int64_t lda, const void* d_W, int64_t ldw, const float* d_bias, const void* d_residual, void* d_out,
                   int64_t ldc, int64_t M, int64_t N, int64_t K, int flags, hipStream_t s);
 
@@ -478,17 +478,17 @@ struct GemmTune {
     // depend on whether its tokens sit in the last partial row tile of a batch — the towers promise the same bits wherever an item stands
     // (tests/test_towers_gpu.py permutation equivariance; the coalescer and the ingest merging lean on it) — for +1.6 % / +3.9 % on the ViT-L/14 rows
     // (profiles/r05p).  mq_tune("gemm_tail", 1) / MQ_GEMM_TAIL=1 turns it on; without it a ragged last row tile is a tile like any other.
-    int mt, cgroup, nh, tail;
+    mq_knob mt, cgroup, nh, tail;
     static int env(const char* k, int d) { const char* v = getenv(k); return v ? atoi(v) : d; }
     GemmTune() : mt(env("MQ_GEMM_MT", 0)), cgroup(env("MQ_GEMM_CGROUP", 8)), nh(env("MQ_GEMM_NH", 0)), tail(env("MQ_GEMM_TAIL", 0)) {}
 };
 GemmTune g_tune;
 }  // namespace
 // mirrors of the knobs for gemm_fp8.hip
-int mq_gemm_knob_persist = 1, mq_gemm_knob_cgroup = g_tune.cgroup, mq_gemm_knob_wide = 2;
+mq_knob mq_gemm_knob_persist{1}, mq_gemm_knob_cgroup{(int)g_tune.cgroup}, mq_gemm_knob_wide{2};
 // operands are addressed through 32-bit buffer offsets: bytes below 4 GiB per launch and operand; a taller A goes in row chunks.
 // mq_tune("gemm_addr_limit_mb", v) lowers it so that the chunking can be tested at small sizes (0 = back to 4 GiB).
-uint64_t mq_gemm_addr_limit = 0xffffffffull;
+std::atomic<uint64_t> mq_gemm_addr_limit{0xffffffffull};
 namespace {
 
 // pick the tile height: minimise rounds x (MT + fixed per-tile overhead in 16-row units).  The tile HEIGHT is a free parameter because rows
@@ -590,7 +590,8 @@ int launch_gemm_mt(const void* A, int64_t lda, const void* W, int64_t ldw, const
         }
         const int num_tiles = tiles_m * tiles_n;
         // L2 blocking only when there is something to block: more column tiles than one group and at least two row panels per XCD
-        const int cgroup = (g_tune.cgroup > 0 && tiles_n > g_tune.cgroup && tiles_m >= 16) ? g_tune.cgroup : 0;
+        const int knob_cgroup = g_tune.cgroup;
+        const int cgroup = (knob_cgroup > 0 && tiles_n > knob_cgroup && tiles_m >= 16) ? knob_cgroup : 0;
         const int band_rows = (tiles_m + 7) / 8;
         const int grid = sk.tail_splits > 0 ? SLOTS : (num_tiles > SLOTS ? SLOTS : num_tiles);
         const uint64_t a_bytes = ((uint64_t)(m - 1) * (uint64_t)lda + (uint64_t)K) * 2;
@@ -681,7 +682,8 @@ int launch_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const fl
         if (residual) residual = (const float*)((const char*)residual + (size_t)big_rows * res_row);
         out = (char*)out + (size_t)big_rows * out_row;
         M -= big_rows;
-        const int mt2 = g_tune.mt ? g_tune.mt : choose_mt(M, N);
+        const int knob_mt2 = g_tune.mt;
+        const int mt2 = knob_mt2 ? knob_mt2 : choose_mt(M, N);
         switch (mt2) {
             case 2: return launch_gemm_mt<FLAGS, 2>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s, ln2);
             case 5: return launch_gemm_mt<FLAGS, 5>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s, ln2);
@@ -689,7 +691,8 @@ int launch_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const fl
             default: return launch_gemm_mt<FLAGS, 4>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s, ln2);
         }
     }
-    const int mt = g_tune.mt ? g_tune.mt : choose_mt(M, N);
+    const int knob_mt = g_tune.mt;
+    const int mt = knob_mt ? knob_mt : choose_mt(M, N);
     switch (mt) {
         case 2: return launch_gemm_mt<FLAGS, 2>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s, ln);
         case 5: return launch_gemm_mt<FLAGS, 5>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s, ln);
@@ -780,15 +783,16 @@ extern "C" int mq_gemm_bf16_rs(const void* d_A, int64_t lda, const void* d_W, in
     return launch_gemm<MQ_EPI_BIAS | MQ_EPI_RESIDUAL | MQ_EPI_ROW_STATS>(d_A, lda, d_W, ldw, d_bias, (const float*)d_residual, d_out, ldc, (int)M, (int)N, (int)K, s, ln);
 }
 
-// Run-time knobs (A/B benchmarking and the parity tests of every code path in one process).  TEST / BENCH ONLY: plain ints read by the
-// launch code of every request thread without synchronisation — set them while no request is in flight (the loaders never touch them).
+// Run-time knobs (A/B benchmarking and the parity tests of every code path in one process).  TEST / BENCH ONLY (the loaders never touch them):
+// atomics (common.h, mq_knob) that the launch code of every request thread reads — a change takes effect from the next launch that reads it,
+// so set them while no request is in flight if one call must run under one setting.
 // keys: "gemm_mt" (0 = auto, else tile height in 32-row units), "gemm_cgroup", "row_select", "ln_fold", "residual_bf16", "small_m", "small_m_grouped",
 // "ln_prefetch", "xcd_band", "attn_waves", "gemm_addr_limit_mb", "gemm_nh" (0 = default plan, 1 = (32*MT) x 128 tiles only, 3 = the big 256 x 256 tile on every row wherever N >= 256, 4 = the eager row-split plan).
 extern "C" int mq_tune(const char* key, int value) {
     MQ_CHECK_ARG(key, "mq_tune: null key");
     const std::string k(key);
     if (k == "gemm_mt") { g_tune.mt = value; mq_gemm_fp8_force_mt = value; }
-    else if (k == "gemm_cgroup") mq_gemm_knob_cgroup = g_tune.cgroup = value;
+    else if (k == "gemm_cgroup") { g_tune.cgroup = value; mq_gemm_knob_cgroup = value; }
     else if (k == "gemm_nh") g_tune.nh = value;
     else if (k == "gemm_tail") g_tune.tail = value;
     else if (k == "row_select") mq_tower_row_select = value;

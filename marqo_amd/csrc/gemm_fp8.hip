@@ -29,8 +29,8 @@
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 
 // scheduling knobs shared with gemm_bf16.hip (mq_tune "gemm_cgroup"; the widened epilogue stores are always on)
-extern int mq_gemm_knob_cgroup, mq_gemm_knob_wide;
-extern uint64_t mq_gemm_addr_limit;   // gemm_bf16.hip: bytes one launch may address per operand (4 GiB - 1; tests lower it)
+extern mq_knob mq_gemm_knob_cgroup, mq_gemm_knob_wide;
+extern std::atomic<uint64_t> mq_gemm_addr_limit;   // gemm_bf16.hip: bytes one launch may address per operand (4 GiB - 1; tests lower it)
 
 namespace {
 
@@ -495,7 +495,8 @@ int launch_fp8_mt(const Fp8Args& a, hipStream_t s) {
         const int m = (int)((a.M - r0) < max_rows ? (a.M - r0) : max_rows);
         const int tiles_m = (m + BM - 1) / BM;
         const int num_tiles = tiles_m * tiles_n;
-        const int cgroup = (mq_gemm_knob_cgroup > 0 && tiles_n > mq_gemm_knob_cgroup && tiles_m >= 16) ? mq_gemm_knob_cgroup : 0;
+        const int knob_cgroup = mq_gemm_knob_cgroup;
+        const int cgroup = (knob_cgroup > 0 && tiles_n > knob_cgroup && tiles_m >= 16) ? knob_cgroup : 0;
         const int band_rows = (tiles_m + 7) / 8;
         const int grid = num_tiles > RESIDENT_SLOTS ? RESIDENT_SLOTS : num_tiles;
         const uint64_t a_bytes = (uint64_t)(m - 1) * (uint64_t)a.lda + (uint64_t)a.K;
@@ -547,7 +548,7 @@ __global__ __launch_bounds__(256) void quantize_rows_kernel(const bf16_t* __rest
 
 }  // namespace
 
-int mq_gemm_fp8_force_mt = 0;  // set through mq_tune("gemm_mt", v) (shared knob, see gemm_bf16.hip)
+mq_knob mq_gemm_fp8_force_mt{0};  // set through mq_tune("gemm_mt", v) (shared knob, see gemm_bf16.hip)
 
 extern "C" int mq_gemm_fp8(const void* d_A8, int64_t lda, const void* d_W8, int64_t ldw, const float* d_a_scale, int a_scale_per_row,
                            const float* d_w_scale, const float* d_bias, const float* d_residual, void* d_out, int64_t ldc,

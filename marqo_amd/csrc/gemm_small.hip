@@ -261,12 +261,12 @@ int dispatch_nw(const void* A, int64_t lda, int a_stream16, const void* W, int64
 }  // namespace
 
 // knob: rows up to which the towers take the skinny path (0 = never).  mq_tune("small_m", v) / MQ_SMALL_M
-int mq_gemm_small_max_rows = getenv("MQ_SMALL_M") ? atoi(getenv("MQ_SMALL_M")) : 80;
+mq_knob mq_gemm_small_max_rows{getenv("MQ_SMALL_M") ? atoi(getenv("MQ_SMALL_M")) : 80};
 
 // knob: rows up to which a plain GEMM call (no fused LayerNorm) still takes the skinny kernel, in row groups of <= 80 (0 = no grouping).
 // mq_tune("small_m_grouped", v) / MQ_SMALL_M_GROUPED.  This is what the pooled-rows-only last block of a 256-item batch runs (M = 256: the
 // tiled kernel gave those calls 12-48 workgroups, 11-28 us each) and what a request of a few items runs in every block.
-int mq_gemm_small_group_rows = getenv("MQ_SMALL_M_GROUPED") ? atoi(getenv("MQ_SMALL_M_GROUPED")) : 320;
+mq_knob mq_gemm_small_group_rows{getenv("MQ_SMALL_M_GROUPED") ? atoi(getenv("MQ_SMALL_M_GROUPED")) : 320};
 
 bool mq_gemm_small_grouped_ok(int64_t M, int64_t N, int64_t K) {
     if (mq_gemm_small_max_rows <= 0 || M <= mq_gemm_small_max_rows || M <= SM_MAX_MT * 16 || M > mq_gemm_small_group_rows) return false;

@@ -396,7 +396,7 @@ extern "C" int mq_layernorm(const float* d_x, const int32_t* d_row_idx, const fl
 }
 
 // knob: the LayerNorms of the towers prefetch the weights of the GEMMs behind them (0 = off).  mq_tune("ln_prefetch", v) / MQ_LN_PREFETCH
-int mq_ln_prefetch = getenv("MQ_LN_PREFETCH") ? atoi(getenv("MQ_LN_PREFETCH")) : 1;
+mq_knob mq_ln_prefetch{getenv("MQ_LN_PREFETCH") ? atoi(getenv("MQ_LN_PREFETCH")) : 1};
 
 static LnExtra ln_extra(int band, int64_t rows, const void* pf_a, size_t bytes_a, const void* pf_b, size_t bytes_b) {
     LnExtra ex{band, 0u, 0u, nullptr, nullptr, 32u};

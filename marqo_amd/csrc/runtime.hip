@@ -17,7 +17,7 @@ void mq_set_error(const char* fmt, ...) {
 
 extern "C" const char* mq_last_error(void) { return g_err; }
 extern "C" int mq_abi_version(void) { return MQ_ABI_VERSION; }
-int mq_xcd_band = getenv("MQ_XCD_BAND") ? atoi(getenv("MQ_XCD_BAND")) : 1;   // row-wise kernels follow the GEMMs' XCD banding (common.h)
+mq_knob mq_xcd_band{getenv("MQ_XCD_BAND") ? atoi(getenv("MQ_XCD_BAND")) : 1};   // row-wise kernels follow the GEMMs' XCD banding (common.h)
 extern "C" const char* mq_build_arch(void) { return "gfx950"; }
 
 // ---- profiling -----------------------------------------------------------------------------

@@ -36,18 +36,18 @@ static_assert(sizeof(mq_vit_cfg) == 168 && sizeof(mq_clip_text_cfg) == 128 && si
 static_assert(sizeof(mq_vit_weights) == 11 * 8 && sizeof(mq_map_head) == 11 * 8 && sizeof(mq_clip_text_weights) == 7 * 8, "tower weight layouts");
 
 // mq_tune("row_select", 0) runs the last block on every row (A/B and parity tests of the pooled-rows-only last block)
-int mq_tower_row_select = getenv("MQ_ROW_SELECT") ? atoi(getenv("MQ_ROW_SELECT")) : 1;
+mq_knob mq_tower_row_select{getenv("MQ_ROW_SELECT") ? atoi(getenv("MQ_ROW_SELECT")) : 1};
 // LayerNorm folding (gemm_epilogue.h, MQ_EPI_LN_APPLY): on the bf16 residual stream the QKV / fc1 GEMMs of a pre-LN block read the stream itself and
 // apply the LayerNorm in their epilogue ((mean, rstd) per row handed in) whenever the block carries the folded tensors (*_wf / *_bf / *_sf,
 // engine/towers.py) and the call is large enough for the tiled GEMM.  mq_tune("ln_fold", v) / MQ_LN_FOLD=v:
 // 0 = LayerNorm kernels; 1 = folded, statistics from a read pass over the stream; 2 = folded, statistics from the residual GEMMs' partial sums
-int mq_tower_ln_fold = getenv("MQ_LN_FOLD") ? atoi(getenv("MQ_LN_FOLD")) : 2;
+mq_knob mq_tower_ln_fold{getenv("MQ_LN_FOLD") ? atoi(getenv("MQ_LN_FOLD")) : 2};
 // bf16 residual stream for the pre-LN bf16 towers (mq_tune("residual_bf16", 1) / MQ_RESIDUAL_BF16=1): x is kept in bf16 between
 // blocks.  The residual GEMMs of a K = 768 tower are memory-bound on their epilogue (out-proj: 15 GFLOP against 39 MB read + 39 MB
 // written of fp32 residual) and every LayerNorm re-reads the stream: bf16 halves those bytes.  Cost: one bf16 rounding per residual
 // add (measured 1 - cos 5e-5 .. 1.2e-4 against the fp32 oracle at full depth, well inside the 1e-3 tolerance; the reference's own GPU path
 // keeps its activations in fp16 under autocast, open_clip_model.py:255-260).  Post-LN (BERT) and fp8 towers keep the fp32 stream.
-int mq_tower_residual_bf16 = getenv("MQ_RESIDUAL_BF16") ? atoi(getenv("MQ_RESIDUAL_BF16")) : 0;
+mq_knob mq_tower_residual_bf16{getenv("MQ_RESIDUAL_BF16") ? atoi(getenv("MQ_RESIDUAL_BF16")) : 0};
 extern "C" int mq_layernorm_ex(const void* d_x, int x_bf16, const int32_t* d_row_idx, const float* d_g, const float* d_b, void* d_out_bf16,
                                float* d_out_f32, int64_t rows, int32_t W, float eps, void* stream);
 // search path (rows <= 80): LayerNorm fused into the skinny GEMM's prologue (gemm_small.hip)
@@ -282,6 +282,204 @@ int last_block_selected(const mq_encoder_cfg* cfg, const mq_block_weights& b, in
     return MQ_OK;
 }
 
+// One pass of the encoder over `rows` token rows: the scratch buffers carved from the caller's workspace, the decisions that hold for the whole pass,
+// and ONE member function per block dataflow (round 5: split out of what had grown into a 250-line loop of eight variants; each body is the launch
+// sequence of that variant, nothing else).  `x_has_partials` is the only state a block leaves for the next one.
+struct EncoderPass {
+    const mq_encoder_cfg* cfg;
+    const mq_block_weights* blocks;
+    float* d_x;
+    int64_t rows;
+    const int32_t* d_cu_seqlens;
+    int64_t nseq;
+    int32_t fixed_len, max_len;
+    const int32_t* d_sel;
+    int64_t nsel;
+    hipStream_t s;
+    int W, F, Wa;
+    void *h, *a, *qf;                // h bf16 [rows, W] | a bf16 [rows, Wa] | qf bf16 [rows, max(3 Wa, fc1 columns)]: qkv, then the fc1 output
+    float *row_scale, *row_stats, *row_part, *xn;
+    bool x_has_partials;             // row_part describes the current d_x (the last GEMM that wrote it emitted them)
+    int act_flag, res_flags, first8;
+
+    int block_fp8(const mq_block_weights& b, int l);            // e4m3 GEMM operands, post-LN or pre-LN
+    int block_eva(const mq_block_weights& b, int l);            // pre-LN with rotary table / sub-LayerNorms / gated MLP (EVA02)
+    int block_pre_ln(const mq_block_weights& b, int l);         // CLIP blocks: fp32 or bf16 stream, folded LayerNorms, MLP-only e4m3
+    int block_post_ln_small(const mq_block_weights& b, int l);  // BERT blocks on the search path: LayerNorms inside the skinny GEMMs
+    int block_post_ln_bf16(const mq_block_weights& b, int l);   // BERT blocks, the normalised bf16 rows are the residual
+    int block_post_ln(const mq_block_weights& b, int l);        // BERT / NewModel blocks on the fp32 stream (rotary positions, gated MLP)
+};
+
+int EncoderPass::block_fp8(const mq_block_weights& b, int l) {
+    // same dataflow with e4m3 GEMM operands: h / a / fc1-out are fp8 (h with a dynamic per-row scale from the LN,
+    // a and fc1-out with static per-tensor scales), qkv stays bf16 for the attention MFMAs, x stays fp32
+    const float* s_attn = cfg->d_fp8_act_scale + 2 * l;
+    const float* s_mlp = s_attn + 1;
+    float* m_attn = cfg->d_fp8_act_amax ? cfg->d_fp8_act_amax + 2 * l : nullptr;
+    float* m_mlp = m_attn ? m_attn + 1 : nullptr;
+    const int act8 = (cfg->act == MQ_ACT_QUICKGELU ? MQ_EPI_QUICKGELU : MQ_EPI_GELU) | MQ_EPI_BIAS | MQ_EPI_OUT_FP8;
+    if (cfg->post_ln) {
+        // x = ln1(x + out(attn(qkv(x)))) ; x = ln2(x + fc2(act(fc1(x)))): each LayerNorm rewrites x (fp32, in place:
+        // a wave holds its whole row before it stores) and leaves the e4m3 row + scale for the next GEMM
+        MQ_TRY(mq_gemm_fp8(h, W, b.qkv_w8, W, row_scale, 1, b.qkv_ws, b.qkv_b, nullptr, qf, 3 * Wa, nullptr, nullptr, rows, 3 * Wa, W,
+                           MQ_EPI_BIAS, s));
+        MQ_TRY(mq_attention_ex(qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, cfg->heads, cfg->mask, 1, s_attn, m_attn, s));
+        MQ_TRY(mq_gemm_fp8(a, Wa, b.out_w8, Wa, s_attn, 0, b.out_ws, b.out_b, d_x, d_x, W, nullptr, nullptr, rows, W, Wa, res_flags, s));
+        MQ_TRY(mq_layernorm_fp8(d_x, b.ln1_g, b.ln1_b, h, row_scale, d_x, rows, W, cfg->ln_eps, s));
+        MQ_TRY(mq_gemm_fp8(h, W, b.fc1_w8, W, row_scale, 1, b.fc1_ws, b.fc1_b, nullptr, qf, F, s_mlp, m_mlp, rows, F, W, act8, s));
+        MQ_TRY(mq_gemm_fp8(qf, F, b.fc2_w8, F, s_mlp, 0, b.fc2_ws, b.fc2_b, d_x, d_x, W, nullptr, nullptr, rows, W, F, res_flags, s));
+        MQ_TRY(mq_layernorm_fp8(d_x, b.ln2_g, b.ln2_b, h, row_scale, d_x, rows, W, cfg->ln_eps, s));
+        return MQ_OK;
+    }
+    const int xb = stream_bf16(cfg) ? 1 : 0;     // the stream itself may be bf16 (decided per model at load): bf16 RMW epilogues, bf16-in LN
+    const int rflags = xb ? (MQ_EPI_BIAS | MQ_EPI_RESIDUAL) : res_flags;
+    MQ_TRY(mq_layernorm_fp8_pf(d_x, xb, b.ln1_g, b.ln1_b, h, row_scale, nullptr, rows, W, cfg->ln_eps, pf(b.qkv_w8), (size_t)3 * Wa * W,
+                               pf(b.out_w8), (size_t)W * Wa, s));
+    MQ_TRY(mq_gemm_fp8(h, W, b.qkv_w8, W, row_scale, 1, b.qkv_ws, b.qkv_b, nullptr, qf, 3 * Wa, nullptr, nullptr, rows, 3 * Wa, W,
+                       MQ_EPI_BIAS, s));
+    MQ_TRY(mq_attention_ex(qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, cfg->heads, cfg->mask, 1, s_attn, m_attn, s));
+    MQ_TRY(mq_gemm_fp8(a, Wa, b.out_w8, Wa, s_attn, 0, b.out_ws, b.out_b, d_x, d_x, W, nullptr, nullptr, rows, W, Wa, rflags, s));
+    MQ_TRY(mq_layernorm_fp8_pf(d_x, xb, b.ln2_g, b.ln2_b, h, row_scale, nullptr, rows, W, cfg->ln_eps, pf(b.fc1_w8), (size_t)F * W,
+                               pf(b.fc2_w8), (size_t)W * F, s));
+    MQ_TRY(mq_gemm_fp8(h, W, b.fc1_w8, W, row_scale, 1, b.fc1_ws, b.fc1_b, nullptr, qf, F, s_mlp, m_mlp, rows, F, W, act8, s));
+    MQ_TRY(mq_gemm_fp8(qf, F, b.fc2_w8, F, s_mlp, 0, b.fc2_ws, b.fc2_b, d_x, d_x, W, nullptr, nullptr, rows, W, F, rflags, s));
+    return MQ_OK;
+}
+
+int EncoderPass::block_eva(const mq_block_weights& b, int l) {
+    // x += out(ln_attn(attn(rope(qkv(ln1(x)))))) ; x += fc2(ln_mlp(up * silu(gate)))  with (up | gate) = fc1(ln2(x))     (x fp32, or bf16 in the bf16-stream form)
+    MQ_CHECK_ARG(!cfg->d_rope_table || (fixed_len > 0 && !d_cu_seqlens && rows == nseq * fixed_len && fixed_len > cfg->rope_prefix),
+                 "mq_encoder_forward: d_rope_table needs fixed-length sequences longer than rope_prefix");
+    MQ_CHECK_ARG(!b.attn_ln_g == !b.attn_ln_b && !b.mlp_ln_g == !b.mlp_ln_b && (!b.mlp_ln_g || cfg->mlp_glu), "mq_encoder_forward: layer %d: sub-LayerNorm weights must come in pairs (mlp_ln: gated MLPs only)", l);
+    const int xb = stream_bf16(cfg) ? 1 : 0;
+    const int rflags = xb ? (MQ_EPI_BIAS | MQ_EPI_RESIDUAL) : res_flags;
+    const int fc1_cols = cfg->mlp_glu ? 2 * F : F;
+    MQ_TRY(ln_gemm(d_x, xb, b.ln1_g, b.ln1_b, cfg->ln_eps, h, b.qkv_w, b.qkv_b, qf, rows, 3 * Wa, W, MQ_EPI_BIAS, s, b.out_w, (size_t)W * Wa * 2,
+                   b.qkv_wf, b.qkv_bf, b.qkv_sf, row_stats, x_has_partials ? row_part : nullptr));
+    x_has_partials = false;
+    if (cfg->d_rope_table) MQ_TRY(mq_rope_table(qf, rows, fixed_len, cfg->rope_prefix, Wa, cfg->heads, cfg->d_rope_table, s));
+    MQ_TRY(attn_bf16(cfg, qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, s));
+    if (b.attn_ln_g) MQ_TRY(mq_layernorm_ex(a, 1, nullptr, b.attn_ln_g, b.attn_ln_b, a, nullptr, rows, Wa, cfg->ln_eps, s));   // (in place: a wave holds its row before it stores)
+    const bool fold_mlp = mq_tower_ln_fold >= 2 && fold_ok(xb, b.fc1_wf, b.fc1_bf, b.fc1_sf, rows, fc1_cols, W) && !mq_gemm_small_ok(rows, W, Wa, false) &&
+                          !mq_gemm_small_grouped_ok(rows, W, Wa);
+    if (fold_mlp) MQ_TRY(mq_gemm_bf16_rs(a, Wa, b.out_w, Wa, b.out_b, d_x, d_x, W, rows, W, Wa, rflags, row_part, s));
+    else MQ_TRY(mq_gemm_bf16(a, Wa, b.out_w, Wa, b.out_b, (const float*)d_x, d_x, W, rows, W, Wa, rflags, s));
+    MQ_TRY(ln_gemm(d_x, xb, b.ln2_g, b.ln2_b, cfg->ln_eps, h, b.fc1_w, b.fc1_b, qf, rows, fc1_cols, W, MQ_EPI_BIAS | (cfg->mlp_glu ? 0 : act_flag), s, b.fc2_w,
+                   (size_t)W * F * 2, b.fc1_wf, b.fc1_bf, b.fc1_sf, row_stats, fold_mlp ? row_part : nullptr));
+    if (cfg->mlp_glu) {
+        if (b.mlp_ln_g) MQ_TRY(mq_glu_ln(qf, rows, F, cfg->mlp_ln_dim ? cfg->mlp_ln_dim : F, cfg->act, b.mlp_ln_g, b.mlp_ln_b, cfg->ln_eps, s));
+        else MQ_TRY(mq_glu(qf, rows, F, cfg->act, s));
+    }
+    // fc2 (reads the F-wide product at the (up | gate) buffer's row stride) writes the x the NEXT block's QKV normalises
+    const mq_block_weights* nbk = l + 1 < cfg->layers ? &blocks[l + 1] : nullptr;
+    const bool fold_next = mq_tower_ln_fold >= 2 && nbk && fold_ok(xb, nbk->qkv_wf, nbk->qkv_bf, nbk->qkv_sf, rows, 3 * Wa, W) && !mq_gemm_small_ok(rows, W, F, false) &&
+                           !mq_gemm_small_grouped_ok(rows, W, F);
+    if (fold_next) MQ_TRY(mq_gemm_bf16_rs(qf, fc1_cols, b.fc2_w, F, b.fc2_b, d_x, d_x, W, rows, W, F, rflags, row_part, s));
+    else MQ_TRY(mq_gemm_bf16(qf, fc1_cols, b.fc2_w, F, b.fc2_b, (const float*)d_x, d_x, W, rows, W, F, rflags, s));
+    x_has_partials = fold_next;
+    return MQ_OK;
+}
+
+int EncoderPass::block_pre_ln(const mq_block_weights& b, int l) {
+    // x += out(attn(qkv(ln1(x)))) ; x += fc2(act(fc1(ln2(x))))   (x fp32, or bf16 in the bf16-stream form)
+    const int xb = stream_bf16(cfg) ? 1 : 0;
+    const int rflags = xb ? (MQ_EPI_BIAS | MQ_EPI_RESIDUAL) : res_flags;
+    MQ_TRY(ln_gemm(d_x, xb, b.ln1_g, b.ln1_b, cfg->ln_eps, h, b.qkv_w, b.qkv_b, qf, rows, 3 * Wa, W, MQ_EPI_BIAS, s, b.out_w, (size_t)W * Wa * 2,
+                   b.qkv_wf, b.qkv_bf, b.qkv_sf, row_stats, x_has_partials ? row_part : nullptr));
+    x_has_partials = false;
+    MQ_TRY(attn_bf16(cfg, qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, s));
+    // the residual GEMMs leave the rows' partial sums behind whenever the GEMM after them folds its LayerNorm (tiled family, bf16 stream)
+    const bool last_pooled = d_sel && nsel > 0 && l == cfg->layers - 1;
+    const bool mlp_fp8 = cfg->precision == MQ_PREC_FP8 && l >= first8 - cfg->fp8_mlp_extra;
+    const bool fold_mlp = mq_tower_ln_fold >= 2 && !last_pooled && !mlp_fp8 && fold_ok(xb, b.fc1_wf, b.fc1_bf, b.fc1_sf, rows, F, W) &&
+                          !mq_gemm_small_ok(rows, W, Wa, false) && !mq_gemm_small_grouped_ok(rows, W, Wa);
+    if (fold_mlp) MQ_TRY(mq_gemm_bf16_rs(a, Wa, b.out_w, Wa, b.out_b, d_x, d_x, W, rows, W, Wa, rflags, row_part, s));
+    else MQ_TRY(mq_gemm_bf16(a, Wa, b.out_w, Wa, b.out_b, (const float*)d_x, d_x, W, rows, W, Wa, rflags, s));
+    if (mlp_fp8) {
+        // MLP-only e4m3 block (fp8_mlp_extra): the attention half above ran on bf16 operands
+        MQ_CHECK_ARG(b.fc1_w8 && b.fc1_ws && b.fc2_w8 && b.fc2_ws, "mq_encoder_forward: layer %d has no fp8 MLP weights", l);
+        const float* s_mlp = cfg->d_fp8_act_scale + 2 * l + 1;
+        float* m_mlp = cfg->d_fp8_act_amax ? cfg->d_fp8_act_amax + 2 * l + 1 : nullptr;
+        const int act8 = (cfg->act == MQ_ACT_QUICKGELU ? MQ_EPI_QUICKGELU : MQ_EPI_GELU) | MQ_EPI_BIAS | MQ_EPI_OUT_FP8;
+        MQ_TRY(mq_layernorm_fp8_pf(d_x, xb, b.ln2_g, b.ln2_b, h, row_scale, nullptr, rows, W, cfg->ln_eps, pf(b.fc1_w8), (size_t)F * W,
+                                   pf(b.fc2_w8), (size_t)W * F, s));
+        MQ_TRY(mq_gemm_fp8(h, W, b.fc1_w8, W, row_scale, 1, b.fc1_ws, b.fc1_b, nullptr, qf, F, s_mlp, m_mlp, rows, F, W, act8, s));
+        MQ_TRY(mq_gemm_fp8(qf, F, b.fc2_w8, F, s_mlp, 0, b.fc2_ws, b.fc2_b, (const float*)d_x, d_x, W, nullptr, nullptr, rows, W, F, rflags, s));
+        return MQ_OK;
+    }
+    // (the LAST block of a call that reads only pooled rows never folds its MLP: the pooled rows take the small-call kernels — LayerNorm
+    // kernel + un-folded weights — and dead-row elimination stays bit-identical to this all-rows form, tests/test_towers_gpu.py)
+    MQ_TRY(ln_gemm(d_x, xb, b.ln2_g, b.ln2_b, cfg->ln_eps, h, b.fc1_w, b.fc1_b, qf, rows, F, W, MQ_EPI_BIAS | act_flag, s, b.fc2_w, (size_t)W * F * 2,
+                   last_pooled ? nullptr : b.fc1_wf, b.fc1_bf, b.fc1_sf, row_stats, fold_mlp ? row_part : nullptr));
+    // fc2 writes the x the NEXT block's QKV normalises
+    const mq_block_weights* nbk = l + 1 < cfg->layers && l + 1 < first8 ? &blocks[l + 1] : nullptr;
+    const bool fold_next = mq_tower_ln_fold >= 2 && nbk && fold_ok(xb, nbk->qkv_wf, nbk->qkv_bf, nbk->qkv_sf, rows, 3 * Wa, W) && !mq_gemm_small_ok(rows, W, F, false) &&
+                           !mq_gemm_small_grouped_ok(rows, W, F);
+    if (fold_next) MQ_TRY(mq_gemm_bf16_rs(qf, F, b.fc2_w, F, b.fc2_b, d_x, d_x, W, rows, W, F, rflags, row_part, s));
+    else MQ_TRY(mq_gemm_bf16(qf, F, b.fc2_w, F, b.fc2_b, (const float*)d_x, d_x, W, rows, W, F, rflags, s));
+    x_has_partials = fold_next;
+    return MQ_OK;
+}
+
+int EncoderPass::block_post_ln_small(const mq_block_weights& b, int l) {
+    // search path: both LayerNorms ride in the prologue of the GEMM that consumes them (gemm_small.hip).  d_x holds the pre-LN sums
+    // t, xn the normalised rows (the residual): t1 = r + out(attn(qkv(r))) ; fc1 normalises t1 -> xn ; t2 = xn + fc2(..) ;
+    // the NEXT block's QKV GEMM normalises t2 -> xn (its ln2 belongs to this block); after the last block a plain LayerNorm.
+    const float* res = d_x;      // block 0: the embedding LayerNorm's output is the residual, h its bf16 copy
+    if (l == 0) MQ_TRY(mq_gemm_bf16(h, W, b.qkv_w, W, b.qkv_b, nullptr, qf, 3 * Wa, rows, 3 * Wa, W, MQ_EPI_BIAS, s));
+    else {
+        const mq_block_weights& pb = blocks[l - 1];
+        MQ_TRY(mq_ln_gemm_small(d_x, W, 0, pb.ln2_g, pb.ln2_b, cfg->ln_eps, b.qkv_w, W, b.qkv_b, qf, 3 * Wa, rows, 3 * Wa, W, MQ_EPI_BIAS, xn, nullptr, s));
+        res = xn;
+    }
+    MQ_TRY(attn_bf16(cfg, qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, s));
+    MQ_TRY(mq_gemm_bf16(a, Wa, b.out_w, Wa, b.out_b, res, d_x, W, rows, W, Wa, res_flags, s));
+    MQ_TRY(mq_ln_gemm_small(d_x, W, 0, b.ln1_g, b.ln1_b, cfg->ln_eps, b.fc1_w, W, b.fc1_b, qf, F, rows, F, W, MQ_EPI_BIAS | act_flag, xn, nullptr, s));
+    MQ_TRY(mq_gemm_bf16(qf, F, b.fc2_w, F, b.fc2_b, xn, d_x, W, rows, W, F, res_flags, s));
+    if (l == cfg->layers - 1) MQ_TRY(mq_layernorm(d_x, nullptr, b.ln2_g, b.ln2_b, h, d_x, rows, W, cfg->ln_eps, s));
+    return MQ_OK;
+}
+
+int EncoderPass::block_post_ln_bf16(const mq_block_weights& b, int l) {
+    // h = ln1(h + out(attn(qkv(h)))) ; h = ln2(h + fc2(act(fc1(h)))), all in place on the bf16 rows; the LAST LayerNorm writes fp32 x
+    const int rflags = MQ_EPI_BIAS | MQ_EPI_RESIDUAL;
+    const bool last = l == cfg->layers - 1;
+    MQ_TRY(mq_gemm_bf16(h, W, b.qkv_w, W, b.qkv_b, nullptr, qf, 3 * Wa, rows, 3 * Wa, W, MQ_EPI_BIAS, s));
+    MQ_TRY(attn_bf16(cfg, qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, s));
+    MQ_TRY(mq_gemm_bf16(a, Wa, b.out_w, Wa, b.out_b, (const float*)h, h, W, rows, W, Wa, rflags, s));
+    MQ_TRY(mq_layernorm_pf(h, 1, nullptr, b.ln1_g, b.ln1_b, h, nullptr, rows, W, cfg->ln_eps, pf(b.fc1_w), (size_t)F * W * 2, pf(b.fc2_w),
+                           (size_t)W * F * 2, s));
+    MQ_TRY(mq_gemm_bf16(h, W, b.fc1_w, W, b.fc1_b, nullptr, qf, F, rows, F, W, MQ_EPI_BIAS | act_flag, s));
+    MQ_TRY(mq_gemm_bf16(qf, F, b.fc2_w, F, b.fc2_b, (const float*)h, h, W, rows, W, F, rflags, s));
+    const mq_block_weights* nb = !last ? &blocks[l + 1] : nullptr;
+    MQ_TRY(mq_layernorm_pf(h, 1, nullptr, b.ln2_g, b.ln2_b, last ? nullptr : h, last ? d_x : nullptr, rows, W, cfg->ln_eps,
+                           pf(nb ? nb->qkv_w : nullptr), (size_t)3 * Wa * W * 2, pf(nb ? nb->out_w : nullptr), (size_t)W * Wa * 2, s));
+    return MQ_OK;
+}
+
+int EncoderPass::block_post_ln(const mq_block_weights& b, int l) {
+    // x = ln1(x + out(attn(qkv(x)))) ; x = ln2(x + fc2(act(fc1(x))))
+    MQ_TRY(mq_gemm_bf16(h, W, b.qkv_w, W, b.qkv_b, nullptr, qf, 3 * Wa, rows, 3 * Wa, W, MQ_EPI_BIAS, s));
+    if (cfg->d_rope_inv_freq) MQ_TRY(mq_rope(qf, d_cu_seqlens, nseq, fixed_len, Wa, cfg->heads, cfg->d_rope_inv_freq, s));
+    MQ_TRY(attn_bf16(cfg, qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, s));
+    MQ_TRY(mq_gemm_bf16(a, Wa, b.out_w, Wa, b.out_b, d_x, d_x, W, rows, W, Wa, res_flags, s));
+    MQ_TRY(mq_layernorm_pf(d_x, 0, nullptr, b.ln1_g, b.ln1_b, h, d_x, rows, W, cfg->ln_eps, pf(b.fc1_w), (size_t)(cfg->mlp_glu ? 2 : 1) * F * W * 2,
+                           pf(b.fc2_w), (size_t)W * F * 2, s));
+    if (cfg->mlp_glu) {
+        // gated MLP: fc1 = (up | gate) rows [2F, W] (bias optional), hidden = up * act(gate) in place, fc2 reads it with lda = 2F
+        MQ_TRY(mq_gemm_bf16(h, W, b.fc1_w, W, b.fc1_b, nullptr, qf, 2 * F, rows, 2 * F, W, b.fc1_b ? MQ_EPI_BIAS : 0, s));
+        MQ_TRY(mq_glu(qf, rows, F, cfg->act, s));
+        MQ_TRY(mq_gemm_bf16(qf, 2 * F, b.fc2_w, F, b.fc2_b, d_x, d_x, W, rows, W, F, res_flags, s));
+    } else {
+        MQ_TRY(mq_gemm_bf16(h, W, b.fc1_w, W, b.fc1_b, nullptr, qf, F, rows, F, W, MQ_EPI_BIAS | act_flag, s));
+        MQ_TRY(mq_gemm_bf16(qf, F, b.fc2_w, F, b.fc2_b, d_x, d_x, W, rows, W, F, res_flags, s));
+    }
+    const mq_block_weights* nb = l + 1 < cfg->layers && l + 1 < first8 ? &blocks[l + 1] : nullptr;   // the next block's QKV / out-proj weights
+    MQ_TRY(mq_layernorm_pf(d_x, 0, nullptr, b.ln2_g, b.ln2_b, h, d_x, rows, W, cfg->ln_eps, pf(nb ? nb->qkv_w : nullptr), (size_t)3 * Wa * W * 2,
+                           pf(nb ? nb->out_w : nullptr), (size_t)W * Wa * 2, s));
+    return MQ_OK;
+}
+
 int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* blocks, float* d_x, int64_t rows,
                          const int32_t* d_cu_seqlens, int64_t nseq, int32_t fixed_len, int32_t max_len,
                          const int32_t* d_sel, int64_t nsel, void* d_workspace, size_t workspace_bytes, hipStream_t s) {
@@ -303,10 +501,7 @@ int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* bloc
     float* row_scale = (float*)(wsb + cv.take((size_t)rows * 4));
     float* row_stats = (float*)(wsb + cv.take((size_t)rows * 8));
     float* row_part = (float*)(wsb + cv.take((size_t)rows * ((W + 63) / 64) * 8));
-    bool x_has_partials = false;   // row_part describes the current d_x (the last GEMM that wrote it emitted them)
     float* xn = (float*)(wsb + cv.take((size_t)(rows < SMALL_LN_ROWS ? rows : SMALL_LN_ROWS) * W * 4));
-    const int act_flag = cfg->act == MQ_ACT_QUICKGELU ? MQ_EPI_QUICKGELU : MQ_EPI_GELU;
-    const int res_flags = MQ_EPI_BIAS | MQ_EPI_RESIDUAL | MQ_EPI_OUT_F32;
 
     // pooled-rows-only last block: worth it when it at least halves the row count; not during fp8 calibration (the
     // activation maxima must see every row); x_sel must fit behind the fc1 output inside `qf`
@@ -331,6 +526,8 @@ int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* bloc
     if (cfg->post_ln && first8 == 0) MQ_TRY(mq_rowquant_fp8(d_x, h, row_scale, rows, W, s));
     else if (cfg->post_ln) MQ_TRY(mq_cast_bf16(d_x, h, rows * W, s));
 
+    EncoderPass p{cfg, blocks, d_x, rows, d_cu_seqlens, nseq, fixed_len, max_len, d_sel, nsel, s, W, F, Wa, h, a, qf, row_scale, row_stats, row_part, xn,
+                  /*x_has_partials*/ false, cfg->act == MQ_ACT_QUICKGELU ? MQ_EPI_QUICKGELU : MQ_EPI_GELU, MQ_EPI_BIAS | MQ_EPI_RESIDUAL | MQ_EPI_OUT_F32, first8};
     for (int l = 0; l < cfg->layers; ++l) {
         const mq_block_weights& b = blocks[l];
         const bool f8 = l >= first8;
@@ -341,167 +538,19 @@ int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* bloc
         // post-LN: the previous (bf16) block left its output as a bf16 operand; the first e4m3 block wants e4m3 rows + row scales
         if (cfg->post_ln && f8 && l == first8 && l > 0) MQ_TRY(mq_rowquant_fp8(d_x, h, row_scale, rows, W, s));
         if (select_last && l == cfg->layers - 1) {
-            MQ_TRY(last_block_selected(cfg, b, l, d_x, rows, d_cu_seqlens, nseq, fixed_len, max_len, d_sel, nsel, h, a, qf, row_scale, row_stats, x_has_partials ? row_part : nullptr,
+            MQ_TRY(last_block_selected(cfg, b, l, d_x, rows, d_cu_seqlens, nseq, fixed_len, max_len, d_sel, nsel, h, a, qf, row_scale, row_stats, p.x_has_partials ? row_part : nullptr,
                                        (float*)((char*)qf + xsel_off), f8, s));
             break;
         }
-        if (f8) {
-            // same dataflow with e4m3 GEMM operands: h / a / fc1-out are fp8 (h with a dynamic per-row scale from the LN,
-            // a and fc1-out with static per-tensor scales), qkv stays bf16 for the attention MFMAs, x stays fp32
-            const float* s_attn = cfg->d_fp8_act_scale + 2 * l;
-            const float* s_mlp = s_attn + 1;
-            float* m_attn = cfg->d_fp8_act_amax ? cfg->d_fp8_act_amax + 2 * l : nullptr;
-            float* m_mlp = m_attn ? m_attn + 1 : nullptr;
-            const int act8 = (cfg->act == MQ_ACT_QUICKGELU ? MQ_EPI_QUICKGELU : MQ_EPI_GELU) | MQ_EPI_BIAS | MQ_EPI_OUT_FP8;
-            if (cfg->post_ln) {
-                // x = ln1(x + out(attn(qkv(x)))) ; x = ln2(x + fc2(act(fc1(x)))): each LayerNorm rewrites x (fp32, in place:
-                // a wave holds its whole row before it stores) and leaves the e4m3 row + scale for the next GEMM
-                MQ_TRY(mq_gemm_fp8(h, W, b.qkv_w8, W, row_scale, 1, b.qkv_ws, b.qkv_b, nullptr, qf, 3 * Wa, nullptr, nullptr, rows, 3 * Wa, W,
-                                   MQ_EPI_BIAS, s));
-                MQ_TRY(mq_attention_ex(qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, cfg->heads, cfg->mask, 1, s_attn, m_attn, s));
-                MQ_TRY(mq_gemm_fp8(a, Wa, b.out_w8, Wa, s_attn, 0, b.out_ws, b.out_b, d_x, d_x, W, nullptr, nullptr, rows, W, Wa, res_flags, s));
-                MQ_TRY(mq_layernorm_fp8(d_x, b.ln1_g, b.ln1_b, h, row_scale, d_x, rows, W, cfg->ln_eps, s));
-                MQ_TRY(mq_gemm_fp8(h, W, b.fc1_w8, W, row_scale, 1, b.fc1_ws, b.fc1_b, nullptr, qf, F, s_mlp, m_mlp, rows, F, W, act8, s));
-                MQ_TRY(mq_gemm_fp8(qf, F, b.fc2_w8, F, s_mlp, 0, b.fc2_ws, b.fc2_b, d_x, d_x, W, nullptr, nullptr, rows, W, F, res_flags, s));
-                MQ_TRY(mq_layernorm_fp8(d_x, b.ln2_g, b.ln2_b, h, row_scale, d_x, rows, W, cfg->ln_eps, s));
-                continue;
-            }
-            const int xb = stream_bf16(cfg) ? 1 : 0;     // the stream itself may be bf16 (decided per model at load): bf16 RMW epilogues, bf16-in LN
-            const int rflags = xb ? (MQ_EPI_BIAS | MQ_EPI_RESIDUAL) : res_flags;
-            MQ_TRY(mq_layernorm_fp8_pf(d_x, xb, b.ln1_g, b.ln1_b, h, row_scale, nullptr, rows, W, cfg->ln_eps, pf(b.qkv_w8), (size_t)3 * Wa * W,
-                                       pf(b.out_w8), (size_t)W * Wa, s));
-            MQ_TRY(mq_gemm_fp8(h, W, b.qkv_w8, W, row_scale, 1, b.qkv_ws, b.qkv_b, nullptr, qf, 3 * Wa, nullptr, nullptr, rows, 3 * Wa, W,
-                               MQ_EPI_BIAS, s));
-            MQ_TRY(mq_attention_ex(qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, cfg->heads, cfg->mask, 1, s_attn, m_attn, s));
-            MQ_TRY(mq_gemm_fp8(a, Wa, b.out_w8, Wa, s_attn, 0, b.out_ws, b.out_b, d_x, d_x, W, nullptr, nullptr, rows, W, Wa, rflags, s));
-            MQ_TRY(mq_layernorm_fp8_pf(d_x, xb, b.ln2_g, b.ln2_b, h, row_scale, nullptr, rows, W, cfg->ln_eps, pf(b.fc1_w8), (size_t)F * W,
-                                       pf(b.fc2_w8), (size_t)W * F, s));
-            MQ_TRY(mq_gemm_fp8(h, W, b.fc1_w8, W, row_scale, 1, b.fc1_ws, b.fc1_b, nullptr, qf, F, s_mlp, m_mlp, rows, F, W, act8, s));
-            MQ_TRY(mq_gemm_fp8(qf, F, b.fc2_w8, F, s_mlp, 0, b.fc2_ws, b.fc2_b, d_x, d_x, W, nullptr, nullptr, rows, W, F, rflags, s));
-        } else if (eva_form(cfg)) {
-            // x += out(ln_attn(attn(rope(qkv(ln1(x)))))) ; x += fc2(ln_mlp(up * silu(gate)))  with (up | gate) = fc1(ln2(x))     (x fp32, or bf16 in the bf16-stream form)
-            MQ_CHECK_ARG(!cfg->d_rope_table || (fixed_len > 0 && !d_cu_seqlens && rows == nseq * fixed_len && fixed_len > cfg->rope_prefix),
-                         "mq_encoder_forward: d_rope_table needs fixed-length sequences longer than rope_prefix");
-            MQ_CHECK_ARG(!b.attn_ln_g == !b.attn_ln_b && !b.mlp_ln_g == !b.mlp_ln_b && (!b.mlp_ln_g || cfg->mlp_glu), "mq_encoder_forward: layer %d: sub-LayerNorm weights must come in pairs (mlp_ln: gated MLPs only)", l);
-            const int xb = stream_bf16(cfg) ? 1 : 0;
-            const int rflags = xb ? (MQ_EPI_BIAS | MQ_EPI_RESIDUAL) : res_flags;
-            const int fc1_cols = cfg->mlp_glu ? 2 * F : F;
-            MQ_TRY(ln_gemm(d_x, xb, b.ln1_g, b.ln1_b, cfg->ln_eps, h, b.qkv_w, b.qkv_b, qf, rows, 3 * Wa, W, MQ_EPI_BIAS, s, b.out_w, (size_t)W * Wa * 2,
-                           b.qkv_wf, b.qkv_bf, b.qkv_sf, row_stats, x_has_partials ? row_part : nullptr));
-            x_has_partials = false;
-            if (cfg->d_rope_table) MQ_TRY(mq_rope_table(qf, rows, fixed_len, cfg->rope_prefix, Wa, cfg->heads, cfg->d_rope_table, s));
-            MQ_TRY(attn_bf16(cfg, qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, s));
-            if (b.attn_ln_g) MQ_TRY(mq_layernorm_ex(a, 1, nullptr, b.attn_ln_g, b.attn_ln_b, a, nullptr, rows, Wa, cfg->ln_eps, s));   // (in place: a wave holds its row before it stores)
-            const bool fold_mlp = mq_tower_ln_fold >= 2 && fold_ok(xb, b.fc1_wf, b.fc1_bf, b.fc1_sf, rows, fc1_cols, W) && !mq_gemm_small_ok(rows, W, Wa, false) &&
-                                  !mq_gemm_small_grouped_ok(rows, W, Wa);
-            if (fold_mlp) MQ_TRY(mq_gemm_bf16_rs(a, Wa, b.out_w, Wa, b.out_b, d_x, d_x, W, rows, W, Wa, rflags, row_part, s));
-            else MQ_TRY(mq_gemm_bf16(a, Wa, b.out_w, Wa, b.out_b, (const float*)d_x, d_x, W, rows, W, Wa, rflags, s));
-            MQ_TRY(ln_gemm(d_x, xb, b.ln2_g, b.ln2_b, cfg->ln_eps, h, b.fc1_w, b.fc1_b, qf, rows, fc1_cols, W, MQ_EPI_BIAS | (cfg->mlp_glu ? 0 : act_flag), s, b.fc2_w,
-                           (size_t)W * F * 2, b.fc1_wf, b.fc1_bf, b.fc1_sf, row_stats, fold_mlp ? row_part : nullptr));
-            if (cfg->mlp_glu) {
-                if (b.mlp_ln_g) MQ_TRY(mq_glu_ln(qf, rows, F, cfg->mlp_ln_dim ? cfg->mlp_ln_dim : F, cfg->act, b.mlp_ln_g, b.mlp_ln_b, cfg->ln_eps, s));
-                else MQ_TRY(mq_glu(qf, rows, F, cfg->act, s));
-            }
-            // fc2 (reads the F-wide product at the (up | gate) buffer's row stride) writes the x the NEXT block's QKV normalises
-            const mq_block_weights* nbk = l + 1 < cfg->layers ? &blocks[l + 1] : nullptr;
-            const bool fold_next = mq_tower_ln_fold >= 2 && nbk && fold_ok(xb, nbk->qkv_wf, nbk->qkv_bf, nbk->qkv_sf, rows, 3 * Wa, W) && !mq_gemm_small_ok(rows, W, F, false) &&
-                                   !mq_gemm_small_grouped_ok(rows, W, F);
-            if (fold_next) MQ_TRY(mq_gemm_bf16_rs(qf, fc1_cols, b.fc2_w, F, b.fc2_b, d_x, d_x, W, rows, W, F, rflags, row_part, s));
-            else MQ_TRY(mq_gemm_bf16(qf, fc1_cols, b.fc2_w, F, b.fc2_b, (const float*)d_x, d_x, W, rows, W, F, rflags, s));
-            x_has_partials = fold_next;
-        } else if (!cfg->post_ln) {
-            // x += out(attn(qkv(ln1(x)))) ; x += fc2(act(fc1(ln2(x))))   (x fp32, or bf16 in the bf16-stream form)
-            const int xb = stream_bf16(cfg) ? 1 : 0;
-            const int rflags = xb ? (MQ_EPI_BIAS | MQ_EPI_RESIDUAL) : res_flags;
-            MQ_TRY(ln_gemm(d_x, xb, b.ln1_g, b.ln1_b, cfg->ln_eps, h, b.qkv_w, b.qkv_b, qf, rows, 3 * Wa, W, MQ_EPI_BIAS, s, b.out_w, (size_t)W * Wa * 2,
-                           b.qkv_wf, b.qkv_bf, b.qkv_sf, row_stats, x_has_partials ? row_part : nullptr));
-            x_has_partials = false;
-            MQ_TRY(attn_bf16(cfg, qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, s));
-            // the residual GEMMs leave the rows' partial sums behind whenever the GEMM after them folds its LayerNorm (tiled family, bf16 stream)
-            const bool last_pooled = d_sel && nsel > 0 && l == cfg->layers - 1;
-            const bool mlp_fp8 = cfg->precision == MQ_PREC_FP8 && l >= first8 - cfg->fp8_mlp_extra;
-            const bool fold_mlp = mq_tower_ln_fold >= 2 && !last_pooled && !mlp_fp8 && fold_ok(xb, b.fc1_wf, b.fc1_bf, b.fc1_sf, rows, F, W) &&
-                                  !mq_gemm_small_ok(rows, W, Wa, false) && !mq_gemm_small_grouped_ok(rows, W, Wa);
-            if (fold_mlp) MQ_TRY(mq_gemm_bf16_rs(a, Wa, b.out_w, Wa, b.out_b, d_x, d_x, W, rows, W, Wa, rflags, row_part, s));
-            else MQ_TRY(mq_gemm_bf16(a, Wa, b.out_w, Wa, b.out_b, (const float*)d_x, d_x, W, rows, W, Wa, rflags, s));
-            if (mlp_fp8) {
-                // MLP-only e4m3 block (fp8_mlp_extra): the attention half above ran on bf16 operands
-                MQ_CHECK_ARG(b.fc1_w8 && b.fc1_ws && b.fc2_w8 && b.fc2_ws, "mq_encoder_forward: layer %d has no fp8 MLP weights", l);
-                const float* s_mlp = cfg->d_fp8_act_scale + 2 * l + 1;
-                float* m_mlp = cfg->d_fp8_act_amax ? cfg->d_fp8_act_amax + 2 * l + 1 : nullptr;
-                const int act8 = (cfg->act == MQ_ACT_QUICKGELU ? MQ_EPI_QUICKGELU : MQ_EPI_GELU) | MQ_EPI_BIAS | MQ_EPI_OUT_FP8;
-                MQ_TRY(mq_layernorm_fp8_pf(d_x, xb, b.ln2_g, b.ln2_b, h, row_scale, nullptr, rows, W, cfg->ln_eps, pf(b.fc1_w8), (size_t)F * W,
-                                           pf(b.fc2_w8), (size_t)W * F, s));
-                MQ_TRY(mq_gemm_fp8(h, W, b.fc1_w8, W, row_scale, 1, b.fc1_ws, b.fc1_b, nullptr, qf, F, s_mlp, m_mlp, rows, F, W, act8, s));
-                MQ_TRY(mq_gemm_fp8(qf, F, b.fc2_w8, F, s_mlp, 0, b.fc2_ws, b.fc2_b, (const float*)d_x, d_x, W, nullptr, nullptr, rows, W, F, rflags, s));
-                continue;
-            }
-            // (the LAST block of a call that reads only pooled rows never folds its MLP: the pooled rows take the small-call kernels — LayerNorm
-            // kernel + un-folded weights — and dead-row elimination stays bit-identical to this all-rows form, tests/test_towers_gpu.py)
-            MQ_TRY(ln_gemm(d_x, xb, b.ln2_g, b.ln2_b, cfg->ln_eps, h, b.fc1_w, b.fc1_b, qf, rows, F, W, MQ_EPI_BIAS | act_flag, s, b.fc2_w, (size_t)W * F * 2,
-                           last_pooled ? nullptr : b.fc1_wf, b.fc1_bf, b.fc1_sf, row_stats, fold_mlp ? row_part : nullptr));
-            // fc2 writes the x the NEXT block's QKV normalises
-            const mq_block_weights* nbk = l + 1 < cfg->layers && l + 1 < first8 ? &blocks[l + 1] : nullptr;
-            const bool fold_next = mq_tower_ln_fold >= 2 && nbk && fold_ok(xb, nbk->qkv_wf, nbk->qkv_bf, nbk->qkv_sf, rows, 3 * Wa, W) && !mq_gemm_small_ok(rows, W, F, false) &&
-                                   !mq_gemm_small_grouped_ok(rows, W, F);
-            if (fold_next) MQ_TRY(mq_gemm_bf16_rs(qf, F, b.fc2_w, F, b.fc2_b, d_x, d_x, W, rows, W, F, rflags, row_part, s));
-            else MQ_TRY(mq_gemm_bf16(qf, F, b.fc2_w, F, b.fc2_b, (const float*)d_x, d_x, W, rows, W, F, rflags, s));
-            x_has_partials = fold_next;
-        } else if (small_post_ln) {
-            // search path: both LayerNorms ride in the prologue of the GEMM that consumes them (gemm_small.hip).  d_x holds the pre-LN sums
-            // t, xn the normalised rows (the residual): t1 = r + out(attn(qkv(r))) ; fc1 normalises t1 -> xn ; t2 = xn + fc2(..) ;
-            // the NEXT block's QKV GEMM normalises t2 -> xn (its ln2 belongs to this block); after the last block a plain LayerNorm.
-            const float* res = d_x;      // block 0: the embedding LayerNorm's output is the residual, h its bf16 copy
-            if (l == 0) MQ_TRY(mq_gemm_bf16(h, W, b.qkv_w, W, b.qkv_b, nullptr, qf, 3 * Wa, rows, 3 * Wa, W, MQ_EPI_BIAS, s));
-            else {
-                const mq_block_weights& pb = blocks[l - 1];
-                MQ_TRY(mq_ln_gemm_small(d_x, W, 0, pb.ln2_g, pb.ln2_b, cfg->ln_eps, b.qkv_w, W, b.qkv_b, qf, 3 * Wa, rows, 3 * Wa, W, MQ_EPI_BIAS, xn, nullptr, s));
-                res = xn;
-            }
-            MQ_TRY(attn_bf16(cfg, qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, s));
-            MQ_TRY(mq_gemm_bf16(a, Wa, b.out_w, Wa, b.out_b, res, d_x, W, rows, W, Wa, res_flags, s));
-            MQ_TRY(mq_ln_gemm_small(d_x, W, 0, b.ln1_g, b.ln1_b, cfg->ln_eps, b.fc1_w, W, b.fc1_b, qf, F, rows, F, W, MQ_EPI_BIAS | act_flag, xn, nullptr, s));
-            MQ_TRY(mq_gemm_bf16(qf, F, b.fc2_w, F, b.fc2_b, xn, d_x, W, rows, W, F, res_flags, s));
-            if (l == cfg->layers - 1) MQ_TRY(mq_layernorm(d_x, nullptr, b.ln2_g, b.ln2_b, h, d_x, rows, W, cfg->ln_eps, s));
-        } else if (post16) {
-            // h = ln1(h + out(attn(qkv(h)))) ; h = ln2(h + fc2(act(fc1(h)))), all in place on the bf16 rows; the LAST LayerNorm writes fp32 x
-            const int rflags = MQ_EPI_BIAS | MQ_EPI_RESIDUAL;
-            const bool last = l == cfg->layers - 1;
-            MQ_TRY(mq_gemm_bf16(h, W, b.qkv_w, W, b.qkv_b, nullptr, qf, 3 * Wa, rows, 3 * Wa, W, MQ_EPI_BIAS, s));
-            MQ_TRY(attn_bf16(cfg, qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, s));
-            MQ_TRY(mq_gemm_bf16(a, Wa, b.out_w, Wa, b.out_b, (const float*)h, h, W, rows, W, Wa, rflags, s));
-            MQ_TRY(mq_layernorm_pf(h, 1, nullptr, b.ln1_g, b.ln1_b, h, nullptr, rows, W, cfg->ln_eps, pf(b.fc1_w), (size_t)F * W * 2, pf(b.fc2_w),
-                                   (size_t)W * F * 2, s));
-            MQ_TRY(mq_gemm_bf16(h, W, b.fc1_w, W, b.fc1_b, nullptr, qf, F, rows, F, W, MQ_EPI_BIAS | act_flag, s));
-            MQ_TRY(mq_gemm_bf16(qf, F, b.fc2_w, F, b.fc2_b, (const float*)h, h, W, rows, W, F, rflags, s));
-            const mq_block_weights* nb = !last ? &blocks[l + 1] : nullptr;
-            MQ_TRY(mq_layernorm_pf(h, 1, nullptr, b.ln2_g, b.ln2_b, last ? nullptr : h, last ? d_x : nullptr, rows, W, cfg->ln_eps,
-                                   pf(nb ? nb->qkv_w : nullptr), (size_t)3 * Wa * W * 2, pf(nb ? nb->out_w : nullptr), (size_t)W * Wa * 2, s));
-        } else {
-            // x = ln1(x + out(attn(qkv(x)))) ; x = ln2(x + fc2(act(fc1(x))))
-            MQ_TRY(mq_gemm_bf16(h, W, b.qkv_w, W, b.qkv_b, nullptr, qf, 3 * Wa, rows, 3 * Wa, W, MQ_EPI_BIAS, s));
-            if (cfg->d_rope_inv_freq) MQ_TRY(mq_rope(qf, d_cu_seqlens, nseq, fixed_len, Wa, cfg->heads, cfg->d_rope_inv_freq, s));
-            MQ_TRY(attn_bf16(cfg, qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, s));
-            MQ_TRY(mq_gemm_bf16(a, Wa, b.out_w, Wa, b.out_b, d_x, d_x, W, rows, W, Wa, res_flags, s));
-            MQ_TRY(mq_layernorm_pf(d_x, 0, nullptr, b.ln1_g, b.ln1_b, h, d_x, rows, W, cfg->ln_eps, pf(b.fc1_w), (size_t)(cfg->mlp_glu ? 2 : 1) * F * W * 2,
-                                   pf(b.fc2_w), (size_t)W * F * 2, s));
-            if (cfg->mlp_glu) {
-                // gated MLP: fc1 = (up | gate) rows [2F, W] (bias optional), hidden = up * act(gate) in place, fc2 reads it with lda = 2F
-                MQ_TRY(mq_gemm_bf16(h, W, b.fc1_w, W, b.fc1_b, nullptr, qf, 2 * F, rows, 2 * F, W, b.fc1_b ? MQ_EPI_BIAS : 0, s));
-                MQ_TRY(mq_glu(qf, rows, F, cfg->act, s));
-                MQ_TRY(mq_gemm_bf16(qf, 2 * F, b.fc2_w, F, b.fc2_b, d_x, d_x, W, rows, W, F, res_flags, s));
-            } else {
-                MQ_TRY(mq_gemm_bf16(h, W, b.fc1_w, W, b.fc1_b, nullptr, qf, F, rows, F, W, MQ_EPI_BIAS | act_flag, s));
-                MQ_TRY(mq_gemm_bf16(qf, F, b.fc2_w, F, b.fc2_b, d_x, d_x, W, rows, W, F, res_flags, s));
-            }
-            const mq_block_weights* nb = l + 1 < cfg->layers && l + 1 < first8 ? &blocks[l + 1] : nullptr;   // the next block's QKV / out-proj weights
-            MQ_TRY(mq_layernorm_pf(d_x, 0, nullptr, b.ln2_g, b.ln2_b, h, d_x, rows, W, cfg->ln_eps, pf(nb ? nb->qkv_w : nullptr), (size_t)3 * Wa * W * 2,
-                                   pf(nb ? nb->out_w : nullptr), (size_t)W * Wa * 2, s));
-        }
+        if (f8) MQ_TRY(p.block_fp8(b, l));
+        else if (eva_form(cfg)) MQ_TRY(p.block_eva(b, l));
+        else if (!cfg->post_ln) MQ_TRY(p.block_pre_ln(b, l));
+        else if (small_post_ln) MQ_TRY(p.block_post_ln_small(b, l));
+        else if (post16) MQ_TRY(p.block_post_ln_bf16(b, l));
+        else MQ_TRY(p.block_post_ln(b, l));
     }
     return MQ_OK;
 }
-
 }  // namespace
 
 extern "C" int mq_encoder_forward(const mq_encoder_cfg* cfg, const mq_block_weights* blocks, float* d_x, int64_t rows,
