@@ -45,7 +45,7 @@ extern "C" {
 #define MQ_ERR_HIP (-2)       /* a HIP runtime call or launch failed */
 #define MQ_ERR_WORKSPACE (-3) /* caller's workspace too small */
 
-#define MQ_ABI_VERSION 10
+#define MQ_ABI_VERSION 11
 
 /* ---- activation / mask / pooling selectors ---------------------------------------- */
 #define MQ_ACT_NONE 0
@@ -461,6 +461,15 @@ int mq_ln_gemm_small_bf16(const void* d_x, int64_t ldx, int x_bf16, const float*
 int mq_gemm_bf16_rs(const void* d_A, int64_t lda, const void* d_W, int64_t ldw, const float* d_bias, const void* d_residual, void* d_out, int64_t ldc,
                     int64_t M, int64_t N, int64_t K, int flags, float* d_partials, void* stream);
 int mq_row_stats_finalize(const float* d_partials, int32_t nslots, float* d_stats, int64_t rows, int32_t W, float eps, void* stream);
+/* ABI 11 — mq_gemm_bf16_rsf = mq_gemm_bf16_rs + the finalise, in ONE launch: on return (stream order) d_stats holds (mean, rstd) of every row of d_out,
+ * bit for bit what mq_row_stats_finalize would have written (same slot order, same expression).  The last wave to arrive at a row band's counter sums
+ * the band's partials inside the GEMM's own launch (csrc/gemm_epilogue.h, GemmLn::band_ctr); d_band_ctr: mq_gemm_band_counters(M) 32-bit counters, all
+ * zero on entry, all zero again when the launch has finished (NULL: the finalise runs as a second launch, as before ABI 11).  d_pf_a / d_pf_b
+ * (nullable): weight ranges of the GEMMs behind this one, touched one dword per 128-byte line on the way out (the prefetch the finalise launch carried). */
+int64_t mq_gemm_band_counters(int64_t M);
+int mq_gemm_bf16_rsf(const void* d_A, int64_t lda, const void* d_W, int64_t ldw, const float* d_bias, const void* d_residual, void* d_out, int64_t ldc,
+                     int64_t M, int64_t N, int64_t K, int flags, float* d_partials, float* d_stats, float eps, uint32_t* d_band_ctr,
+                     const void* d_pf_a, size_t pf_a_bytes, const void* d_pf_b, size_t pf_b_bytes, void* stream);
 int mq_row_stats(const void* d_x_bf16, float* d_stats, int64_t rows, int32_t W, float eps, void* stream);
 int mq_gemm_bf16_ln(const void* d_A, int64_t lda, const void* d_W, int64_t ldw, const float* d_bias, const float* d_colsum, const float* d_rowstats,
                     void* d_out, int64_t ldc, int64_t M, int64_t N, int64_t K, int flags, void* stream);
@@ -601,14 +610,20 @@ int mq_weighted_combine(const float* d_emb, int64_t ld, const int32_t* d_rows, c
                         void* stream);
 
 /* Run-time selection of a kernel variant (benchmark A/B and parity tests of every variant in one process).  TEST / BENCH ONLY: the
- * knobs are plain ints read without synchronisation by the launch code of every request thread — set them while no request is in
- * flight; the loaders never touch them.
+ * knobs are relaxed atomics (csrc/common.h, mq_knob) that the launch code of every request thread reads — a new value takes effect from
+ * the next launch that reads it, so set them while no request is in flight if one call must run under one setting; the loaders never
+ * touch them.
  * keys: "gemm_mt" (0 = auto, else GEMM tile height in 32-row units), "gemm_cgroup" (column tiles per L2 group, 0 = row-major walk),
+ * "gemm_nh" (0 = the default tile plan, 1 = the (32 MT) x 128 tiles only, 3 = the 8-wave 256 x 256 tile on every row wherever N >= 256,
+ * 4 = the eager row-split plan), "gemm_tail" (1 = the big tile's in-kernel split-K tail for a ragged last row of tiles),
+ * "gemm_wd" (csrc/gemm_wd.hip, the W-operand-from-global main loop: 0 = off, 2 / 3 = on with that many LDS stages of A, 6 / 7 = the same
+ * with both k-halves' W loads issued together), "rs_finalize" (1 = mq_gemm_bf16_rsf finalises the row statistics inside the GEMM's launch),
  * "gemm_addr_limit_mb" (bytes / 2^20 one launch may address per operand, 0 = the 4 GiB of a 32-bit buffer offset: taller matrices go in
  * row chunks), "row_select" (0 = the towers run their last block on every row instead of the pooled rows only), "ln_fold" (0 = LayerNorm
  * kernels, 1 = folded into the QKV GEMM, 2 = and into fc1; needs the folded weights), "residual_bf16", "small_m" / "small_m_grouped"
  * (row limits of the skinny GEMM kernels), "ln_prefetch", "xcd_band", "attn_waves" (0 = auto, 4 / 8 wave64s per attention workgroup).
- * Initial values come from the environment (MQ_GEMM_MT, MQ_GEMM_CGROUP, MQ_ROW_SELECT, MQ_LN_FOLD, ...). */
+ * Initial values come from the environment (MQ_GEMM_MT, MQ_GEMM_CGROUP, MQ_GEMM_NH, MQ_GEMM_TAIL, MQ_GEMM_WD, MQ_GEMM_RS_FIN, MQ_ROW_SELECT,
+ * MQ_LN_FOLD, ...). */
 int mq_tune(const char* key, int value);
 
 /* ---- per-kernel timing (bench.py roofline) ------------------------------------------- */

@@ -28,8 +28,8 @@ STAGE_SRC = CSRC_DIR / "py_stage.cpp"
 STAGE_PATH = LIB_DIR / "_mq_stage.so"                # CPython extension: a batch of Pillow images -> the pinned staging buffer in one call
 
 MQ_OK = 0
-NO_SCRATCH_UNITS = ("rowops", "gemm_bf16", "gemm_fp8", "gemm_small", "attention", "embed")  # build() refuses register spills in these
-ABI_VERSION = 10
+NO_SCRATCH_UNITS = ("rowops", "gemm_bf16", "gemm_wd", "gemm_fp8", "gemm_small", "attention", "embed")  # build() refuses register spills in these
+ABI_VERSION = 11
 MQ_PREC_BF16, MQ_PREC_FP8 = 0, 1
 MQ_ACT_GELU, MQ_ACT_QUICKGELU, MQ_ACT_SILU = 1, 2, 3
 MQ_MASK_NONE, MQ_MASK_CAUSAL = 0, 1
@@ -153,6 +153,9 @@ _SIGNATURES = {
     "mq_row_stats": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_float, _P]),
     "mq_row_stats_finalize": (C.c_int, [_P, C.c_int32, _P, C.c_int64, C.c_int32, C.c_float, _P]),
     "mq_gemm_bf16_rs": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, _P, _P]),
+    "mq_gemm_band_counters": (C.c_int64, [C.c_int64]),
+    "mq_gemm_bf16_rsf": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, _P, _P, C.c_float, _P,
+                                   _P, C.c_size_t, _P, C.c_size_t, _P]),
     "mq_gemm_fp8": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, C.c_int, _P, _P, _P, _P, C.c_int64, _P, _P, C.c_int64, C.c_int64,
                               C.c_int64, C.c_int, _P]),
     "mq_quantize_weights_fp8": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, C.c_int64, C.c_int64, _P]),

@@ -111,6 +111,14 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// (mean, rstd) of a row from its (sum, sum of squares): ONE expression for every kernel that finalises row statistics (row_stats_finalize_kernel and the
+// residual GEMM's in-launch finalise must give the same bits); the explicit fma is the contraction hipcc had picked for the stand-alone kernel
+__device__ __forceinline__ float2 mq_finalize_stats(float s1, float s2, float inv_w, float eps) {
+    const float mean = s1 * inv_w;
+    const float var = __builtin_fmaf(-mean, mean, s2 * inv_w);
+    return make_float2(mean, rsqrtf(fmaxf(var, 0.f) + eps));
+}
+
 // ---- host-side error plumbing --------------------------------------------------------------
 void mq_set_error(const char* fmt, ...);
 

@@ -36,6 +36,7 @@
 #include <type_traits>
 #include "common.h"
 #include "gemm_epilogue.h"
+#include "gemm_loop.h"
 
 extern mq_knob mq_gemm_fp8_force_mt;  // gemm_fp8.hip
 extern mq_knob mq_tower_row_select;   // towers.hip
@@ -49,38 +50,12 @@ extern mq_knob mq_gemm_small_group_rows;
 extern mq_knob mq_ln_prefetch;        // rowops.hip
 int mq_gemm_small(const void* d_A, int64_t lda, const void* d_W, int64_t ldw, const float* d_bias, const void* d_residual, void* d_out,
                   int64_t ldc, int64_t M, int64_t N, int64_t K, int flags, hipStream_t s);
+// gemm_wd.hip: the W-direct main loop on the same tile plan (-1: combination not instantiated, the caller launches its own kernel)
+int mq_gemm_wd_launch(int flags, int mt, int ns, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* residual, void* out,
+                      int64_t ldc, int M, int N, int K, int tiles_n, int num_tiles, int cgroup, int band_rows, int grid, int wide, unsigned a_bytes,
+                      unsigned w_bytes, const GemmLn& ln, hipStream_t s);
 
 namespace {
-
-constexpr int BK = 64;
-
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) void lds_void_t;
-
-__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, unsigned lds_wave_base) {
-    // 16 B per lane; LDS destination = wave-uniform base (M0) + lane * 16; source = descriptor base + voff (per lane) + soff (scalar)
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(uintptr_t)lds_wave_base, 16, voff, soff, 0, 0);
-}
-template <int OFF>
-__device__ __forceinline__ bf16x8 lds_read16(unsigned addr) {
-    i32x4 v;
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
-    return __builtin_bit_cast(bf16x8, v);
-}
-
-// The compiler takes an inline asm's outputs as valid the moment the statement has executed, and a register-only consumer (an MFMA, a v_dot2c)
-// has no ordering against the hand-placed `s_waitcnt lgkmcnt(0)` asm: the optimiser may sink it to right behind the ds_read that defines its operand —
-// it did exactly that with the LN_APPLY statistics (40 v_dot2c moved into the loop latch, in front of the wait; tests/test_gemm_isa.py caught it).
-// Passing the registers through an EMPTY asm behind the wait ties their consumers to it by data flow (volatile asms keep their order); no instruction.
-template <class T>
-__device__ __forceinline__ void landed(T& v) { asm volatile("" : "+v"(v)); }
-
-template <int... Is, class F>
-__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F&& f) { (f(std::integral_constant<int, Is>{}), ...); }
-// f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>): every index is a compile-time constant inside f (register arrays stay
-// registers; a run-time counter that the unroller has to fold first sent the fragment arrays to scratch)
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
 
 // The rows that do not fill a 256-row tile (257 tokens per ViT-L/14 image never make a multiple of 256) — the TAIL of the big-tile kernel (WM = 4).
 // A second launch for them is pure latency (tiles_n workgroups walking K / 64 dependent k-steps: 13-33 us, what the big tile saves per GEMM:
@@ -348,6 +323,16 @@ __global__ __launch_bounds__(128 * WM, (NH == 1 && WM == 2) ? 2 : 1) void gemm_n
             constexpr int h = decltype(h_tag)::value;
             gemm_epilogue<FLAGS, MT, ERG, true, NH == 2 && WM == 2>(acc[h], bias, residual, out, ldc, M, N, cm0 + wm * (16 * MT), cn0 + wn * (16 * NTW) + h * 64, l15e, ge, wide_store != 0, &ln, nullptr);
         });
+        if constexpr ((FLAGS & MQ_EPI_ROW_STATS) != 0) {
+            // in-launch finalise of the row statistics (GemmLn::band_ctr): behind a workgroup's FIRST tile the carried weight prefetch goes out
+            // (its cold loads drain with the tile's stores), then every wave arrives at its row band's counter
+            if (ln.band_ctr) {
+                unsigned pf_regs[2] = {0u, 0u};
+                if (c_vbid == (int)blockIdx.x) gemm_pf_issue(ln, pf_regs);
+                gemm_band_arrive(ln, (cm0 / BM) * WM + wm, cm0 + wm * (16 * MT), 16 * MT, M, lane);
+                landed(pf_regs[0]); landed(pf_regs[1]);   // (retired by the arrival's vmcnt(0); nothing may reuse the registers before)
+            }
+        }
 
         c_vbid += gridDim.x;
         if (c_vbid >= num_tiles) break;
@@ -478,9 +463,12 @@ struct GemmTune {
     // depend on whether its tokens sit in the last partial row tile of a batch — the towers promise the same bits wherever an item stands
     // (tests/test_towers_gpu.py permutation equivariance; the coalescer and the ingest merging lean on it) — for +1.6 % / +3.9 % on the ViT-L/14 rows
     // (profiles/r05p).  mq_tune("gemm_tail", 1) / MQ_GEMM_TAIL=1 turns it on; without it a ragged last row tile is a tile like any other.
-    mq_knob mt, cgroup, nh, tail;
+    // wd: the W-direct main loop (gemm_wd.hip) on the narrow tiles: 0 = off, 2 / 3 = on with that many LDS stages of A
+    // rs_fin: the residual GEMMs of the bf16 stream finalise the row statistics inside their own launch (mq_gemm_bf16_rsf; 0 = a row_stats_finalize_kernel
+    // launch behind them, the round 4-5 form)
+    mq_knob mt, cgroup, nh, tail, wd, rs_fin;
     static int env(const char* k, int d) { const char* v = getenv(k); return v ? atoi(v) : d; }
-    GemmTune() : mt(env("MQ_GEMM_MT", 0)), cgroup(env("MQ_GEMM_CGROUP", 8)), nh(env("MQ_GEMM_NH", 0)), tail(env("MQ_GEMM_TAIL", 0)) {}
+    GemmTune() : mt(env("MQ_GEMM_MT", 0)), cgroup(env("MQ_GEMM_CGROUP", 8)), nh(env("MQ_GEMM_NH", 0)), tail(env("MQ_GEMM_TAIL", 0)), wd(env("MQ_GEMM_WD", 0)), rs_fin(env("MQ_GEMM_RS_FIN", 0)) {}
 };
 GemmTune g_tune;
 }  // namespace
@@ -600,6 +588,23 @@ int launch_gemm_mt(const void* A, int64_t lda, const void* W, int64_t ldw, const
         GemmLn ln_chunk = ln;
         if (ln_chunk.rowstats) ln_chunk.rowstats += r0;
         if (ln_chunk.partials) ln_chunk.partials += r0 * ln_chunk.nslots;
+        if (ln_chunk.band_ctr) {   // in-launch finalise: this launch's row bands (chunks are whole tiles), every wave of a band's column tiles arrives once
+            ln_chunk.band_ctr += (r0 / BM) * WM;
+            ln_chunk.stats_out += r0;
+            ln_chunk.band_target = tiles_n * 2;
+            if (sk.tail_splits > 0) {
+                mq_set_error("mq_gemm_bf16: the in-launch row-statistics finalise and the in-kernel tail exclude each other");
+                return MQ_ERR_INVALID;
+            }
+        }
+        if constexpr (NH == 1 && WM == 2) {
+            if (const int wd = g_tune.wd; (wd == 2 || wd == 3 || wd == 6 || wd == 7) && !ln_chunk.band_ctr) {
+                const int rc = mq_gemm_wd_launch(FLAGS, MT, wd, (const bf16_t*)A + r0 * lda, lda, W, ldw, bias,
+                                                 residual ? (const float*)((const char*)residual + (size_t)r0 * res_row) : nullptr, (void*)((char*)out + (size_t)r0 * out_row),
+                                                 ldc, m, N, K, tiles_n, num_tiles, cgroup, band_rows, grid, wide, (unsigned)a_bytes, (unsigned)w_bytes, ln_chunk, s);
+                if (rc >= 0) { if (rc != MQ_OK) return rc; continue; }
+            }
+        }
         hipLaunchKernelGGL(kern, dim3(grid), dim3(128 * WM), LDS, s, (const bf16_t*)A + r0 * lda, lda, (const bf16_t*)W, ldw, bias,
                            residual ? (const float*)((const char*)residual + (size_t)r0 * res_row) : nullptr, (void*)((char*)out + (size_t)r0 * out_row),
                            ldc, m, N, K, tiles_n, num_tiles, cgroup, band_rows, wide, (unsigned)a_bytes, (unsigned)w_bytes, ln_chunk, sk);
@@ -678,6 +683,7 @@ int launch_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const fl
         GemmLn ln2 = ln;
         if (ln2.rowstats) ln2.rowstats += big_rows;
         if (ln2.partials) ln2.partials += (int64_t)big_rows * ln2.nslots;
+        if (ln2.band_ctr) { ln2.band_ctr += (big_rows / 256) * 4; ln2.stats_out += big_rows; ln2.pf_na = ln2.pf_nb = 0; }   // (the first launch carried the prefetch)
         A = (const bf16_t*)A + (int64_t)big_rows * lda;
         if (residual) residual = (const float*)((const char*)residual + (size_t)big_rows * res_row);
         out = (char*)out + (size_t)big_rows * out_row;
@@ -783,11 +789,53 @@ extern "C" int mq_gemm_bf16_rs(const void* d_A, int64_t lda, const void* d_W, in
     return launch_gemm<MQ_EPI_BIAS | MQ_EPI_RESIDUAL | MQ_EPI_ROW_STATS>(d_A, lda, d_W, ldw, d_bias, (const float*)d_residual, d_out, ldc, (int)M, (int)N, (int)K, s, ln);
 }
 
+// mq_gemm_bf16_rs + the finalise of the row statistics: on return (stream order) d_stats holds (mean, rstd) of every row of d_out.  The finalise runs
+// INSIDE the GEMM's launch — the last wave to arrive at a row band's counter sums the band's partials (GemmLn::band_ctr, gemm_epilogue.h) — and the
+// launch carries the weight prefetch of the GEMMs behind it; d_band_ctr: mq_gemm_band_counters(M) zeroed 32-bit counters (left zeroed).  With
+// mq_tune("rs_finalize", 0), the in-kernel tail (MQ_GEMM_TAIL) or no counters: the round 4-5 form, a row_stats_finalize_kernel launch behind the GEMM.
+// Same bits either way (mq_finalize_stats, slot order).
+int mq_row_stats_finalize_pf(const float* d_partials, int32_t nslots, float* d_stats, int64_t rows, int32_t W, float eps, const void* pf_a, size_t bytes_a,
+                             const void* pf_b, size_t bytes_b, hipStream_t s);
+extern "C" int64_t mq_gemm_band_counters(int64_t M) { return M / 32 + 16; }
+bool mq_gemm_rs_in_launch() { return g_tune.rs_fin && !g_tune.tail; }   // towers.hip: whether a pass needs (zeroed) band counters at all
+extern "C" int mq_gemm_bf16_rsf(const void* d_A, int64_t lda, const void* d_W, int64_t ldw, const float* d_bias, const void* d_residual, void* d_out,
+                                int64_t ldc, int64_t M, int64_t N, int64_t K, int flags, float* d_partials, float* d_stats, float eps,
+                                uint32_t* d_band_ctr, const void* d_pf_a, size_t pf_a_bytes, const void* d_pf_b, size_t pf_b_bytes, void* stream) {
+    MQ_CHECK_ARG(d_A && d_W && d_out && d_bias && d_residual && d_partials && d_stats, "mq_gemm_bf16_rsf: null operand");
+    MQ_CHECK_ARG((flags | MQ_EPI_ROW_STATS) == (MQ_EPI_BIAS | MQ_EPI_RESIDUAL | MQ_EPI_ROW_STATS), "mq_gemm_bf16_rsf: flags must be MQ_EPI_BIAS | MQ_EPI_RESIDUAL");
+    MQ_CHECK_ARG(M >= 1 && N >= 4 && K >= BK && K % BK == 0 && N % 4 == 0, "mq_gemm_bf16_rsf: bad shape M=%ld N=%ld K=%ld", (long)M, (long)N, (long)K);
+    MQ_CHECK_ARG(lda % 8 == 0 && ldw % 8 == 0 && ldc % 4 == 0, "mq_gemm_bf16_rsf: leading dims must keep 16-byte rows");
+    MQ_CHECK_ARG(M < (1 << 30) && N < (1 << 30) && K < (1 << 30), "mq_gemm_bf16_rsf: shape too large");
+    hipStream_t s = (hipStream_t)stream;
+    const int nslots = (int)((N + 63) / 64);
+    const bool in_launch = d_band_ctr && g_tune.rs_fin && !g_tune.tail;
+    {
+        MqProfScope prof(0, s, 2.0 * (double)M * (double)N * (double)K);
+        GemmLn ln{};
+        ln.partials = (float2*)d_partials;
+        ln.nslots = nslots;
+        if (in_launch) {
+            ln.band_ctr = d_band_ctr;
+            ln.stats_out = (float2*)d_stats;
+            ln.inv_w = 1.0f / (float)N;
+            ln.eps = eps;
+            ln.pf_a = (const unsigned*)d_pf_a;
+            ln.pf_b = (const unsigned*)d_pf_b;
+            ln.pf_na = d_pf_a ? (unsigned)(pf_a_bytes / 128) : 0u;
+            ln.pf_nb = d_pf_b ? (unsigned)(pf_b_bytes / 128) : 0u;
+        }
+        MQ_TRY(launch_gemm<MQ_EPI_BIAS | MQ_EPI_RESIDUAL | MQ_EPI_ROW_STATS>(d_A, lda, d_W, ldw, d_bias, (const float*)d_residual, d_out, ldc, (int)M, (int)N, (int)K, s, ln));
+    }
+    if (in_launch) return MQ_OK;
+    return mq_row_stats_finalize_pf(d_partials, nslots, d_stats, M, (int32_t)N, eps, d_pf_a, pf_a_bytes, d_pf_b, pf_b_bytes, s);
+}
+
 // Run-time knobs (A/B benchmarking and the parity tests of every code path in one process).  TEST / BENCH ONLY (the loaders never touch them):
 // atomics (common.h, mq_knob) that the launch code of every request thread reads — a change takes effect from the next launch that reads it,
 // so set them while no request is in flight if one call must run under one setting.
 // keys: "gemm_mt" (0 = auto, else tile height in 32-row units), "gemm_cgroup", "row_select", "ln_fold", "residual_bf16", "small_m", "small_m_grouped",
-// "ln_prefetch", "xcd_band", "attn_waves", "gemm_addr_limit_mb", "gemm_nh" (0 = default plan, 1 = (32*MT) x 128 tiles only, 3 = the big 256 x 256 tile on every row wherever N >= 256, 4 = the eager row-split plan).
+// "ln_prefetch", "xcd_band", "attn_waves", "gemm_addr_limit_mb", "gemm_nh" (0 = default plan, 1 = (32*MT) x 128 tiles only, 3 = the big 256 x 256 tile on every row wherever N >= 256, 4 = the eager row-split plan),
+// "gemm_tail", "gemm_wd" (gemm_wd.hip: 0 = off, 2 / 3 / 6 / 7), "rs_finalize" (1 = the row statistics are finalised inside the residual GEMM's launch).
 extern "C" int mq_tune(const char* key, int value) {
     MQ_CHECK_ARG(key, "mq_tune: null key");
     const std::string k(key);
@@ -795,6 +843,8 @@ extern "C" int mq_tune(const char* key, int value) {
     else if (k == "gemm_cgroup") { g_tune.cgroup = value; mq_gemm_knob_cgroup = value; }
     else if (k == "gemm_nh") g_tune.nh = value;
     else if (k == "gemm_tail") g_tune.tail = value;
+    else if (k == "gemm_wd") g_tune.wd = value;
+    else if (k == "rs_finalize") g_tune.rs_fin = value;
     else if (k == "row_select") mq_tower_row_select = value;
     else if (k == "ln_fold") mq_tower_ln_fold = value;
     else if (k == "xcd_band") mq_xcd_band = value;

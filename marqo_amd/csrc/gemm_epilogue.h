@@ -25,7 +25,69 @@ struct GemmLn {
     const float2* rowstats;  // LN_APPLY: [M]  (mean, rstd) of row m of A
     float2* partials;        // ROW_STATS: [M][nslots]  (sum, sum of squares) of the bf16 values this launch leaves in columns 64 s .. 64 s + 63 of row m
     int nslots;              // ROW_STATS: ceil(N / 64)
+    // ROW_STATS with the finalise INSIDE the launch (round 6, mq_gemm_bf16_rsf): every wave, when its rows' partials have left, arrives at the counter of
+    // its row band (a row tile x its position along M); the LAST wave to arrive — the band's partials are then all written — sums them in slot order
+    // and writes (mean, rstd), exactly as row_stats_finalize_kernel would (mq_finalize_stats), and puts the counter back to zero.  Partials travel as
+    // agent-scope (write-through) stores and are read back with agent-scope loads: the band's tiles may run on different XCDs.
+    unsigned* band_ctr;      // [row tiles x waves along M], zero between launches; nullptr = no in-launch finalise (the caller runs mq_row_stats_finalize)
+    float2* stats_out;       // [M]
+    float inv_w, eps;
+    int band_target;         // arrivals that complete a band: column tiles x 2 waves along N
+    // the weight prefetch the finalise launch used to carry (one dword per 128-byte line of the next GEMMs' weights), issued behind the epilogue of a
+    // workgroup's first tile: the (cold) loads ride out with the tile's stores, in front of the arrival's vmcnt(0)
+    const unsigned* pf_a;
+    const unsigned* pf_b;
+    unsigned pf_na, pf_nb;
 };
+
+// the carried weight prefetch (GemmLn::pf_*): thread t of the grid touches lines t and t + (threads of the grid).  Inline asm, so that the loads stay
+// where they are issued (vector-memory operations retire in order: a cold load in FRONT of a load somebody waits for would make that wait a cold one);
+// the caller passes pf_regs through an empty asm behind the next vmcnt(0) (gemm_band_arrive's), so that nothing reuses the registers before the loads return
+__device__ __forceinline__ void gemm_pf_issue(const GemmLn& ln, unsigned (&pf_regs)[2]) {
+    const unsigned nt = gridDim.x * blockDim.x, t = blockIdx.x * blockDim.x + threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const unsigned c = t + j * nt;
+        const unsigned* src = c < ln.pf_na ? ln.pf_a + (size_t)c * 32 : (c - ln.pf_na < ln.pf_nb ? ln.pf_b + (size_t)(c - ln.pf_na) * 32 : nullptr);
+        if (src) asm volatile("global_load_dword %0, %1, off" : "=v"(pf_regs[j]) : "v"(src) : "memory");
+    }
+}
+
+// the last-arriver finalise of a row band (see GemmLn): called by every wave behind its epilogue; rows [row0, row0 + nrows) x all column slots
+__device__ __forceinline__ void gemm_band_arrive(const GemmLn& ln, int band, int row0, int nrows, int M, int lane) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my partials (write-through stores) have been acknowledged
+    unsigned old = 0;
+    if (lane == 0) old = __hip_atomic_fetch_add(ln.band_ctr + band, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
+    if ((int)old + 1 != ln.band_target) return;
+    if (lane == 0) __hip_atomic_store(ln.band_ctr + band, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // one lane per row (a wave's band is at most 96 rows: two rows per lane), a row's partials fetched 16 at a time BEFORE any of them is added — the
+    // first form (one dependent L2 round trip per slot) left the band's last wave 12-16 round trips behind the kernel's tail (profiles/r06c)
+    const int m0 = row0 + lane, m1 = row0 + 64 + lane;
+    const bool ok0 = lane < nrows && m0 < M, ok1 = 64 + lane < nrows && m1 < M;
+    const unsigned long long* p0 = (const unsigned long long*)(ln.partials + (int64_t)(ok0 ? m0 : row0) * ln.nslots);
+    const unsigned long long* p1 = (const unsigned long long*)(ln.partials + (int64_t)(ok1 ? m1 : row0) * ln.nslots);
+    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+    for (int i0 = 0; i0 < ln.nslots; i0 += 16) {
+        unsigned long long q[2][16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            q[0][j] = (ok0 && i0 + j < ln.nslots) ? __hip_atomic_load(p0 + i0 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+            q[1][j] = (ok1 && i0 + j < ln.nslots) ? __hip_atomic_load(p1 + i0 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j)   // slot order, as row_stats_finalize_kernel adds them
+            if (i0 + j < ln.nslots) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    s1[h] += __uint_as_float((unsigned)q[h][j]);
+                    s2[h] += __uint_as_float((unsigned)(q[h][j] >> 32));
+                }
+            }
+    }
+    if (ok0) ln.stats_out[m0] = mq_finalize_stats(s1[0], s2[0], ln.inv_w, ln.eps);
+    if (ok1) ln.stats_out[m1] = mq_finalize_stats(s1[1], s2[1], ln.inv_w, ln.eps);
+}
 
 // RG = rows (16-row units) whose residual is prefetched together: the whole tile where the registers allow (the 4-wave kernel
 // after its k-loop), a few rows at a time in the 8-wave kernel whose accumulators already fill the file.
@@ -179,7 +241,9 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][4], const float* 
         if (ROW_STATS) {  // the row's 4 lanes (g = 0..3) add up in a fixed order; one writer per (row, slot)
             st1 += __shfl_xor(st1, 16, 64); st2 += __shfl_xor(st2, 16, 64);
             st1 += __shfl_xor(st1, 32, 64); st2 += __shfl_xor(st2, 32, 64);
-            if (g == 0 && m_ok && wave_n0 < N) lnp->partials[(int64_t)m * lnp->nslots + (wave_n0 >> 6)] = make_float2(st1, st2);
+            if (g == 0 && m_ok && wave_n0 < N)
+                __hip_atomic_store((unsigned long long*)(lnp->partials + (int64_t)m * lnp->nslots + (wave_n0 >> 6)),
+                                   (unsigned long long)__float_as_uint(st1) | ((unsigned long long)__float_as_uint(st2) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (FENCE_ROWS) __builtin_amdgcn_sched_barrier(0);
     }

@@ -539,10 +539,7 @@ __global__ __launch_bounds__(256) void row_stats_finalize_kernel(const float2* _
     }
     unsigned pq[LN_PF];
     ln_prefetch_issue(ex, pq);
-    if (row < rows) {
-        const float mean = s1 * inv_w;
-        stats[row] = make_float2(mean, rsqrtf(fmaxf(s2 * inv_w - mean * mean, 0.f) + eps));
-    }
+    if (row < rows) stats[row] = mq_finalize_stats(s1, s2, inv_w, eps);
     ln_prefetch_retire(pq);
 }
 int mq_row_stats_finalize_pf(const float* d_partials, int32_t nslots, float* d_stats, int64_t rows, int32_t W, float eps, const void* pf_a, size_t bytes_a,

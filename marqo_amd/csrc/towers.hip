@@ -75,6 +75,11 @@ extern "C" int mq_gemm_bf16_ln(const void* d_A, int64_t lda, const void* d_W, in
                                const float* d_rowstats, void* d_out, int64_t ldc, int64_t M, int64_t N, int64_t K, int flags, void* stream);
 extern "C" int mq_gemm_bf16_rs(const void* d_A, int64_t lda, const void* d_W, int64_t ldw, const float* d_bias, const void* d_residual, void* d_out,
                                int64_t ldc, int64_t M, int64_t N, int64_t K, int flags, float* d_partials, void* stream);
+extern "C" int mq_gemm_bf16_rsf(const void* d_A, int64_t lda, const void* d_W, int64_t ldw, const float* d_bias, const void* d_residual, void* d_out,
+                                int64_t ldc, int64_t M, int64_t N, int64_t K, int flags, float* d_partials, float* d_stats, float eps,
+                                uint32_t* d_band_ctr, const void* d_pf_a, size_t pf_a_bytes, const void* d_pf_b, size_t pf_b_bytes, void* stream);
+extern "C" int64_t mq_gemm_band_counters(int64_t M);
+bool mq_gemm_rs_in_launch();
 int mq_row_stats_finalize_pf(const float* d_partials, int32_t nslots, float* d_stats, int64_t rows, int32_t W, float eps, const void* pf_a, size_t bytes_a,
                              const void* pf_b, size_t bytes_b, hipStream_t s);
 bool mq_row_stats_ok(int32_t W);
@@ -87,13 +92,12 @@ static bool fold_ok(int xb, const void* wf, const float* bf, const float* sf, in
 static int ln_gemm(const void* d_x, int xb, const float* g, const float* b, float eps, void* h, const void* W, const float* bias, void* out,
                    int64_t rows, int N, int K, int flags, hipStream_t s, const void* next_w = nullptr, size_t next_bytes = 0,
                    const void* wf = nullptr, const float* bf = nullptr, const float* sf = nullptr, float* row_stats = nullptr,
-                   const float* row_partials = nullptr /* non-NULL: the GEMM that wrote d_x left its rows' partial sums here */) {
+                   bool stats_ready = false /* the residual GEMM that wrote d_x left its rows' (mean, rstd) in row_stats (mq_gemm_bf16_rsf) */) {
     if (mq_gemm_small_ok(rows, N, K, true)) return mq_ln_gemm_small(d_x, K, xb, g, b, eps, W, K, bias, out, N, rows, N, K, flags, nullptr, nullptr, s);
     if (row_stats && fold_ok(xb, wf, bf, sf, rows, N, K)) {
-        // folded: (mean, rstd) per row — from the partial sums the residual GEMM in front left behind (a finalise over K / 64 partials per row),
-        // else from ONE read pass over the stream; either launch carries the weight prefetch — then the GEMM reads the stream itself
-        if (row_partials) MQ_TRY(mq_row_stats_finalize_pf(row_partials, (K + 63) / 64, row_stats, rows, K, eps, pf(wf), (size_t)N * K * 2, pf(next_w), next_bytes, s));
-        else MQ_TRY(mq_row_stats_pf(d_x, row_stats, rows, K, eps, pf(wf), (size_t)N * K * 2, pf(next_w), next_bytes, s));
+        // folded: (mean, rstd) per row — left behind by the residual GEMM in front (finalised inside its launch, which also carried the weight
+        // prefetch), else from ONE read pass over the stream (which carries the prefetch) — then the GEMM reads the stream itself
+        if (!stats_ready) MQ_TRY(mq_row_stats_pf(d_x, row_stats, rows, K, eps, pf(wf), (size_t)N * K * 2, pf(next_w), next_bytes, s));
         return mq_gemm_bf16_ln(d_x, K, wf, K, bf, sf, row_stats, out, N, rows, N, K, flags, s);
     }
     MQ_TRY(mq_layernorm_pf(d_x, xb, nullptr, g, b, h, nullptr, rows, K, eps, pf(W), (size_t)N * K * 2, pf(next_w), next_bytes, s));
@@ -194,6 +198,7 @@ size_t encoder_ws(const mq_encoder_cfg* c, int64_t rows) {
     cv.take((size_t)rows * 8);  // (mean, rstd) per row: the statistics of a folded LayerNorm
     cv.take((size_t)rows * ((c->width + 63) / 64) * 8);  // ... and the partial sums a residual GEMM leaves for them: (sum, sum of squares) per row and 64-column slot
     cv.take((size_t)(rows < SMALL_LN_ROWS ? rows : SMALL_LN_ROWS) * c->width * 4);  // search path, post-LN: the normalised residual (fp32)
+    cv.take((size_t)mq_gemm_band_counters(rows) * 4);  // arrival counters of the in-launch statistics finalise
     return cv.end();
 }
 
@@ -218,7 +223,7 @@ namespace {
 // behind the fc1 output (all of h / a / qkv are dead by the time they are overwritten).
 int last_block_selected(const mq_encoder_cfg* cfg, const mq_block_weights& b, int l, float* d_x, int64_t rows,
                         const int32_t* d_cu_seqlens, int64_t nseq, int32_t fixed_len, int32_t max_len,
-                        const int32_t* d_sel, int64_t nsel, void* h, void* a, void* qf, float* row_scale, float* row_stats, const float* row_partials, float* x_sel,
+                        const int32_t* d_sel, int64_t nsel, void* h, void* a, void* qf, float* row_scale, float* row_stats, bool stats_ready, float* x_sel,
                         bool f8, hipStream_t s) {
     const int W = cfg->width, F = cfg->mlp_dim, Wa = attn_width(cfg);
     const int act_flag = cfg->act == MQ_ACT_QUICKGELU ? MQ_EPI_QUICKGELU : MQ_EPI_GELU;
@@ -243,7 +248,7 @@ int last_block_selected(const mq_encoder_cfg* cfg, const mq_block_weights& b, in
         const int xb = stream_bf16(cfg) ? 1 : 0;                 // bf16 residual stream: rows of 2 bytes per element, bf16 RMW epilogues
         const int rflags = xb ? (MQ_EPI_BIAS | MQ_EPI_RESIDUAL) : res_flags;
         const int64_t xrow = (int64_t)W * (xb ? 2 : 4);
-        MQ_TRY(ln_gemm(d_x, xb, b.ln1_g, b.ln1_b, cfg->ln_eps, h, b.qkv_w, b.qkv_b, qf, rows, 3 * Wa, W, MQ_EPI_BIAS, s, nullptr, 0, b.qkv_wf, b.qkv_bf, b.qkv_sf, row_stats, row_partials));
+        MQ_TRY(ln_gemm(d_x, xb, b.ln1_g, b.ln1_b, cfg->ln_eps, h, b.qkv_w, b.qkv_b, qf, rows, 3 * Wa, W, MQ_EPI_BIAS, s, nullptr, 0, b.qkv_wf, b.qkv_bf, b.qkv_sf, row_stats, stats_ready));
         MQ_TRY(attn_bf16(cfg, qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, s));
         MQ_TRY(mq_move_rows(a, d_sel, h, nsel, (int64_t)Wa * 2, false, s));
         MQ_TRY(mq_move_rows(d_x, d_sel, x_sel, nsel, xrow, false, s));
@@ -299,7 +304,8 @@ struct EncoderPass {
     int W, F, Wa;
     void *h, *a, *qf;                // h bf16 [rows, W] | a bf16 [rows, Wa] | qf bf16 [rows, max(3 Wa, fc1 columns)]: qkv, then the fc1 output
     float *row_scale, *row_stats, *row_part, *xn;
-    bool x_has_partials;             // row_part describes the current d_x (the last GEMM that wrote it emitted them)
+    uint32_t* band_ctr;              // arrival counters of the residual GEMMs' in-launch statistics finalise (mq_gemm_bf16_rsf), zeroed once per pass
+    bool x_has_partials;             // row_stats holds (mean, rstd) of the current d_x (the residual GEMM that wrote it left them behind)
     int act_flag, res_flags, first8;
 
     int block_fp8(const mq_block_weights& b, int l);            // e4m3 GEMM operands, post-LN or pre-LN
@@ -355,17 +361,18 @@ int EncoderPass::block_eva(const mq_block_weights& b, int l) {
     const int rflags = xb ? (MQ_EPI_BIAS | MQ_EPI_RESIDUAL) : res_flags;
     const int fc1_cols = cfg->mlp_glu ? 2 * F : F;
     MQ_TRY(ln_gemm(d_x, xb, b.ln1_g, b.ln1_b, cfg->ln_eps, h, b.qkv_w, b.qkv_b, qf, rows, 3 * Wa, W, MQ_EPI_BIAS, s, b.out_w, (size_t)W * Wa * 2,
-                   b.qkv_wf, b.qkv_bf, b.qkv_sf, row_stats, x_has_partials ? row_part : nullptr));
+                   b.qkv_wf, b.qkv_bf, b.qkv_sf, row_stats, x_has_partials));
     x_has_partials = false;
     if (cfg->d_rope_table) MQ_TRY(mq_rope_table(qf, rows, fixed_len, cfg->rope_prefix, Wa, cfg->heads, cfg->d_rope_table, s));
     MQ_TRY(attn_bf16(cfg, qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, s));
     if (b.attn_ln_g) MQ_TRY(mq_layernorm_ex(a, 1, nullptr, b.attn_ln_g, b.attn_ln_b, a, nullptr, rows, Wa, cfg->ln_eps, s));   // (in place: a wave holds its row before it stores)
     const bool fold_mlp = mq_tower_ln_fold >= 2 && fold_ok(xb, b.fc1_wf, b.fc1_bf, b.fc1_sf, rows, fc1_cols, W) && !mq_gemm_small_ok(rows, W, Wa, false) &&
                           !mq_gemm_small_grouped_ok(rows, W, Wa);
-    if (fold_mlp) MQ_TRY(mq_gemm_bf16_rs(a, Wa, b.out_w, Wa, b.out_b, d_x, d_x, W, rows, W, Wa, rflags, row_part, s));
+    if (fold_mlp) MQ_TRY(mq_gemm_bf16_rsf(a, Wa, b.out_w, Wa, b.out_b, d_x, d_x, W, rows, W, Wa, rflags, row_part, row_stats, cfg->ln_eps, band_ctr, pf(b.fc1_wf),
+                                          (size_t)fc1_cols * W * 2, pf(b.fc2_w), (size_t)W * F * 2, s));
     else MQ_TRY(mq_gemm_bf16(a, Wa, b.out_w, Wa, b.out_b, (const float*)d_x, d_x, W, rows, W, Wa, rflags, s));
     MQ_TRY(ln_gemm(d_x, xb, b.ln2_g, b.ln2_b, cfg->ln_eps, h, b.fc1_w, b.fc1_b, qf, rows, fc1_cols, W, MQ_EPI_BIAS | (cfg->mlp_glu ? 0 : act_flag), s, b.fc2_w,
-                   (size_t)W * F * 2, b.fc1_wf, b.fc1_bf, b.fc1_sf, row_stats, fold_mlp ? row_part : nullptr));
+                   (size_t)W * F * 2, b.fc1_wf, b.fc1_bf, b.fc1_sf, row_stats, fold_mlp));
     if (cfg->mlp_glu) {
         if (b.mlp_ln_g) MQ_TRY(mq_glu_ln(qf, rows, F, cfg->mlp_ln_dim ? cfg->mlp_ln_dim : F, cfg->act, b.mlp_ln_g, b.mlp_ln_b, cfg->ln_eps, s));
         else MQ_TRY(mq_glu(qf, rows, F, cfg->act, s));
@@ -374,7 +381,8 @@ int EncoderPass::block_eva(const mq_block_weights& b, int l) {
     const mq_block_weights* nbk = l + 1 < cfg->layers ? &blocks[l + 1] : nullptr;
     const bool fold_next = mq_tower_ln_fold >= 2 && nbk && fold_ok(xb, nbk->qkv_wf, nbk->qkv_bf, nbk->qkv_sf, rows, 3 * Wa, W) && !mq_gemm_small_ok(rows, W, F, false) &&
                            !mq_gemm_small_grouped_ok(rows, W, F);
-    if (fold_next) MQ_TRY(mq_gemm_bf16_rs(qf, fc1_cols, b.fc2_w, F, b.fc2_b, d_x, d_x, W, rows, W, F, rflags, row_part, s));
+    if (fold_next) MQ_TRY(mq_gemm_bf16_rsf(qf, fc1_cols, b.fc2_w, F, b.fc2_b, d_x, d_x, W, rows, W, F, rflags, row_part, row_stats, cfg->ln_eps, band_ctr, pf(nbk->qkv_wf),
+                                           (size_t)3 * Wa * W * 2, pf(nbk->out_w), (size_t)W * Wa * 2, s));
     else MQ_TRY(mq_gemm_bf16(qf, fc1_cols, b.fc2_w, F, b.fc2_b, (const float*)d_x, d_x, W, rows, W, F, rflags, s));
     x_has_partials = fold_next;
     return MQ_OK;
@@ -385,7 +393,7 @@ int EncoderPass::block_pre_ln(const mq_block_weights& b, int l) {
     const int xb = stream_bf16(cfg) ? 1 : 0;
     const int rflags = xb ? (MQ_EPI_BIAS | MQ_EPI_RESIDUAL) : res_flags;
     MQ_TRY(ln_gemm(d_x, xb, b.ln1_g, b.ln1_b, cfg->ln_eps, h, b.qkv_w, b.qkv_b, qf, rows, 3 * Wa, W, MQ_EPI_BIAS, s, b.out_w, (size_t)W * Wa * 2,
-                   b.qkv_wf, b.qkv_bf, b.qkv_sf, row_stats, x_has_partials ? row_part : nullptr));
+                   b.qkv_wf, b.qkv_bf, b.qkv_sf, row_stats, x_has_partials));
     x_has_partials = false;
     MQ_TRY(attn_bf16(cfg, qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, s));
     // the residual GEMMs leave the rows' partial sums behind whenever the GEMM after them folds its LayerNorm (tiled family, bf16 stream)
@@ -393,7 +401,8 @@ int EncoderPass::block_pre_ln(const mq_block_weights& b, int l) {
     const bool mlp_fp8 = cfg->precision == MQ_PREC_FP8 && l >= first8 - cfg->fp8_mlp_extra;
     const bool fold_mlp = mq_tower_ln_fold >= 2 && !last_pooled && !mlp_fp8 && fold_ok(xb, b.fc1_wf, b.fc1_bf, b.fc1_sf, rows, F, W) &&
                           !mq_gemm_small_ok(rows, W, Wa, false) && !mq_gemm_small_grouped_ok(rows, W, Wa);
-    if (fold_mlp) MQ_TRY(mq_gemm_bf16_rs(a, Wa, b.out_w, Wa, b.out_b, d_x, d_x, W, rows, W, Wa, rflags, row_part, s));
+    if (fold_mlp) MQ_TRY(mq_gemm_bf16_rsf(a, Wa, b.out_w, Wa, b.out_b, d_x, d_x, W, rows, W, Wa, rflags, row_part, row_stats, cfg->ln_eps, band_ctr, pf(b.fc1_wf),
+                                          (size_t)F * W * 2, pf(b.fc2_w), (size_t)W * F * 2, s));
     else MQ_TRY(mq_gemm_bf16(a, Wa, b.out_w, Wa, b.out_b, (const float*)d_x, d_x, W, rows, W, Wa, rflags, s));
     if (mlp_fp8) {
         // MLP-only e4m3 block (fp8_mlp_extra): the attention half above ran on bf16 operands
@@ -410,12 +419,13 @@ int EncoderPass::block_pre_ln(const mq_block_weights& b, int l) {
     // (the LAST block of a call that reads only pooled rows never folds its MLP: the pooled rows take the small-call kernels — LayerNorm
     // kernel + un-folded weights — and dead-row elimination stays bit-identical to this all-rows form, tests/test_towers_gpu.py)
     MQ_TRY(ln_gemm(d_x, xb, b.ln2_g, b.ln2_b, cfg->ln_eps, h, b.fc1_w, b.fc1_b, qf, rows, F, W, MQ_EPI_BIAS | act_flag, s, b.fc2_w, (size_t)W * F * 2,
-                   last_pooled ? nullptr : b.fc1_wf, b.fc1_bf, b.fc1_sf, row_stats, fold_mlp ? row_part : nullptr));
+                   last_pooled ? nullptr : b.fc1_wf, b.fc1_bf, b.fc1_sf, row_stats, fold_mlp));
     // fc2 writes the x the NEXT block's QKV normalises
     const mq_block_weights* nbk = l + 1 < cfg->layers && l + 1 < first8 ? &blocks[l + 1] : nullptr;
     const bool fold_next = mq_tower_ln_fold >= 2 && nbk && fold_ok(xb, nbk->qkv_wf, nbk->qkv_bf, nbk->qkv_sf, rows, 3 * Wa, W) && !mq_gemm_small_ok(rows, W, F, false) &&
                            !mq_gemm_small_grouped_ok(rows, W, F);
-    if (fold_next) MQ_TRY(mq_gemm_bf16_rs(qf, F, b.fc2_w, F, b.fc2_b, d_x, d_x, W, rows, W, F, rflags, row_part, s));
+    if (fold_next) MQ_TRY(mq_gemm_bf16_rsf(qf, F, b.fc2_w, F, b.fc2_b, d_x, d_x, W, rows, W, F, rflags, row_part, row_stats, cfg->ln_eps, band_ctr, pf(nbk->qkv_wf),
+                                           (size_t)3 * Wa * W * 2, pf(nbk->out_w), (size_t)W * Wa * 2, s));
     else MQ_TRY(mq_gemm_bf16(qf, F, b.fc2_w, F, b.fc2_b, (const float*)d_x, d_x, W, rows, W, F, rflags, s));
     x_has_partials = fold_next;
     return MQ_OK;
@@ -502,6 +512,10 @@ int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* bloc
     float* row_stats = (float*)(wsb + cv.take((size_t)rows * 8));
     float* row_part = (float*)(wsb + cv.take((size_t)rows * ((W + 63) / 64) * 8));
     float* xn = (float*)(wsb + cv.take((size_t)(rows < SMALL_LN_ROWS ? rows : SMALL_LN_ROWS) * W * 4));
+    uint32_t* band_ctr = (uint32_t*)(wsb + cv.take((size_t)mq_gemm_band_counters(rows) * 4));
+    // (the in-launch finalise is opt-in, mq_tune("rs_finalize", 1): without it the residual GEMMs get no counters and a finalise launch follows them)
+    if (stream_bf16(cfg) && mq_gemm_rs_in_launch()) MQ_CHECK_HIP(hipMemsetAsync(band_ctr, 0, (size_t)mq_gemm_band_counters(rows) * 4, s));   // (every launch leaves them zeroed again)
+    else band_ctr = nullptr;
 
     // pooled-rows-only last block: worth it when it at least halves the row count; not during fp8 calibration (the
     // activation maxima must see every row); x_sel must fit behind the fc1 output inside `qf`
@@ -526,7 +540,7 @@ int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* bloc
     if (cfg->post_ln && first8 == 0) MQ_TRY(mq_rowquant_fp8(d_x, h, row_scale, rows, W, s));
     else if (cfg->post_ln) MQ_TRY(mq_cast_bf16(d_x, h, rows * W, s));
 
-    EncoderPass p{cfg, blocks, d_x, rows, d_cu_seqlens, nseq, fixed_len, max_len, d_sel, nsel, s, W, F, Wa, h, a, qf, row_scale, row_stats, row_part, xn,
+    EncoderPass p{cfg, blocks, d_x, rows, d_cu_seqlens, nseq, fixed_len, max_len, d_sel, nsel, s, W, F, Wa, h, a, qf, row_scale, row_stats, row_part, xn, band_ctr,
                   /*x_has_partials*/ false, cfg->act == MQ_ACT_QUICKGELU ? MQ_EPI_QUICKGELU : MQ_EPI_GELU, MQ_EPI_BIAS | MQ_EPI_RESIDUAL | MQ_EPI_OUT_F32, first8};
     for (int l = 0; l < cfg->layers; ++l) {
         const mq_block_weights& b = blocks[l];
@@ -538,7 +552,7 @@ int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* bloc
         // post-LN: the previous (bf16) block left its output as a bf16 operand; the first e4m3 block wants e4m3 rows + row scales
         if (cfg->post_ln && f8 && l == first8 && l > 0) MQ_TRY(mq_rowquant_fp8(d_x, h, row_scale, rows, W, s));
         if (select_last && l == cfg->layers - 1) {
-            MQ_TRY(last_block_selected(cfg, b, l, d_x, rows, d_cu_seqlens, nseq, fixed_len, max_len, d_sel, nsel, h, a, qf, row_scale, row_stats, p.x_has_partials ? row_part : nullptr,
+            MQ_TRY(last_block_selected(cfg, b, l, d_x, rows, d_cu_seqlens, nseq, fixed_len, max_len, d_sel, nsel, h, a, qf, row_scale, row_stats, p.x_has_partials,
                                        (float*)((char*)qf + xsel_off), f8, s));
             break;
         }

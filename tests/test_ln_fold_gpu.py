@@ -139,6 +139,77 @@ def test_residual_gemm_leaves_the_row_sums_the_next_layernorm_needs(M, N, K):
         assert torch.allclose(fin[:, 1].double(), 1.0 / torch.sqrt(xd.var(1, unbiased=False) + eps), rtol=1e-4)
 
 
+@pytest.mark.parametrize("plan", ["default", "row_split", "mt2"])
+@pytest.mark.parametrize("M,N,K", [(12800, 768, 768), (12800, 768, 3072), (16448, 1024, 4096), (1500, 512, 2048), (333, 1024, 1024), (700, 1664, 1664), (130, 72, 64), (4099, 1280, 128)])
+def test_in_launch_finalise_gives_the_finalise_kernels_bits(M, N, K, plan, tiled_gemm_only):
+    """round 6, mq_gemm_bf16_rsf: the residual GEMM finalises the row statistics inside its own launch (the last wave to arrive at a row band's counter sums
+    the band's partials) — the same (mean, rstd) bits as mq_gemm_bf16_rs + mq_row_stats_finalize, the same stream and partials, counters left at zero, for
+    every tile plan (ragged M and N, the big-tile row split, the smallest tile), launch after launch on the same counters, weight prefetch carried"""
+    lib = L.load()
+    g = torch.Generator(device="cuda").manual_seed(M * 3 + N)
+    a = (torch.randn(M, K, device="cuda", generator=g)).to(torch.bfloat16)
+    W = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).to(torch.bfloat16)
+    b = 0.1 * torch.randn(N, device="cuda", generator=g)
+    x0 = (torch.randn(M, N, device="cuda", generator=g) * 2 + 0.5).to(torch.bfloat16)
+    flags = L.MQ_EPI_BIAS | L.MQ_EPI_RESIDUAL
+    nslots = (N + 63) // 64
+    eps = 1e-5
+    pf = torch.randn(3 << 20, device="cuda")       # 12 MB "weights of the next GEMM"
+    try:
+        _tune("rs_finalize", 1)
+        if plan == "row_split":
+            _tune("gemm_nh", 4)
+        elif plan == "mt2":
+            _tune("gemm_mt", 2)
+        x = x0.clone()
+        part = torch.full((M, nslots, 2), float("nan"), device="cuda")
+        L.check(lib.mq_gemm_bf16_rs(a.data_ptr(), K, W.data_ptr(), K, b.data_ptr(), x.data_ptr(), x.data_ptr(), N, M, N, K, flags, part.data_ptr(), _stream()))
+        want = torch.empty(M, 2, device="cuda")
+        L.check(lib.mq_row_stats_finalize(part.data_ptr(), nslots, want.data_ptr(), M, N, eps, _stream()))
+        ctr = torch.zeros(int(lib.mq_gemm_band_counters(M)), device="cuda", dtype=torch.int32)
+        for rep in range(3):
+            x2 = x0.clone()
+            part2 = torch.full((M, nslots, 2), float("nan"), device="cuda")
+            got = torch.full((M, 2), float("nan"), device="cuda")
+            L.check(lib.mq_gemm_bf16_rsf(a.data_ptr(), K, W.data_ptr(), K, b.data_ptr(), x2.data_ptr(), x2.data_ptr(), N, M, N, K, flags, part2.data_ptr(), got.data_ptr(), eps,
+                                         ctr.data_ptr(), pf.data_ptr(), pf.numel() * 4, pf.data_ptr(), 4096, _stream()))
+            assert torch.equal(x2.view(torch.int16), x.view(torch.int16)) and torch.equal(part2, part)
+            assert torch.equal(got.view(torch.int32), want.view(torch.int32)), (rep, int((got != want).sum()))
+            assert int(ctr.abs().sum()) == 0
+        # the two-launch form behind the same entry point (mq_tune rs_finalize = 0; no counters)
+        for kw in (dict(rs=0, ctr=ctr.data_ptr()), dict(rs=1, ctr=0)):
+            _tune("rs_finalize", kw["rs"])
+            x3 = x0.clone()
+            got = torch.full((M, 2), float("nan"), device="cuda")
+            L.check(lib.mq_gemm_bf16_rsf(a.data_ptr(), K, W.data_ptr(), K, b.data_ptr(), x3.data_ptr(), x3.data_ptr(), N, M, N, K, flags, part.data_ptr(), got.data_ptr(), eps,
+                                         kw["ctr"], 0, 0, 0, 0, _stream()))
+            assert torch.equal(got.view(torch.int32), want.view(torch.int32)) and torch.equal(x3.view(torch.int16), x.view(torch.int16))
+    finally:
+        _tune("gemm_nh", 0); _tune("gemm_mt", 0); _tune("rs_finalize", 0)
+
+
+def test_towers_give_the_same_bits_with_the_finalise_in_or_behind_the_launch():
+    from marqo_amd.engine import archs, towers
+    varch = archs.VitArch(224, 32, 768, 4, 12, 3072, 512)
+    cfg = O.VitConfig(224, 32, 768, 4, 12, 3072, 512)
+    sd = O.synthetic_vit_state_dict(cfg, seed=17)
+    u8 = O.synthetic_images_u8(64, 224, seed=18).cuda()
+    tower = towers.VitTower(varch, sd, "cuda")
+    tarch = archs.ClipTextArch(49408, 77, 512, 3, 8, 2048, 512)
+    sdt = O.synthetic_clip_text_state_dict(O.ClipTextConfig(49408, 77, 512, 3, 8, 2048, 512), seed=19)
+    ids = O.synthetic_clip_ids(200, seed=20)
+    tt = towers.ClipTextTower(tarch, sdt, "cuda")
+    try:
+        _tune("rs_finalize", 1)
+        a1, t1 = tower.encode_u8(u8), tt.encode_ids(ids)
+        assert torch.equal(a1, tower.encode_u8(u8)) and torch.equal(t1, tt.encode_ids(ids))
+        _tune("rs_finalize", 0)
+        a0, t0 = tower.encode_u8(u8), tt.encode_ids(ids)
+    finally:
+        _tune("rs_finalize", 0)
+    assert torch.equal(a1, a0) and torch.equal(t1, t0)
+
+
 def test_folded_towers_match_unfolded_and_oracle():
     from marqo_amd.engine import archs, towers
     assert towers.LN_FOLD

@@ -29,7 +29,7 @@ for (M, N, K) in [(12800, 768, 768), (12800, 3072, 768), (4099, 2304, 768), (164
         out = r.clone() if r is not None else torch.empty(M, N, device="cuda", dtype=torch.float32 if f & L.MQ_EPI_OUT_F32 else torch.bfloat16)
         L.check(lib.mq_gemm_bf16(A.data_ptr(), K, W.data_ptr(), K, b.data_ptr(), out.data_ptr() if r is not None else 0, out.data_ptr(), N, M, N, K, f, s))
         return out
-    for k in ("gemm_nh", "gemm_mt"):
+    for k in ("gemm_nh", "gemm_mt", "gemm_wd"):
         L.check(lib.mq_tune(k.encode(), 1 if k == "gemm_nh" else 0))
     base = [run(f, r) for f, r in forms]
     for name, kvs in variants:
@@ -51,7 +51,8 @@ for (M, N, K) in [(12800, 768, 768), (12800, 3072, 768), (4099, 2304, 768), (164
                         print(f"MISMATCH {name} {(M, N, K)} flags={f} rep={rep}: max abs diff {float(d.max()):.3e} (rel {rel:.2e}), {int((d > 0).sum())} elements, rows {int(rows.min())}..{int(rows.max())}")
                     elif rep == 0:
                         tails.add((name, (M, N, K), f, round(rel, 7)))
-        L.check(lib.mq_tune(b"gemm_nh", 0))
+        for k in (b"gemm_nh", b"gemm_wd", b"gemm_mt"):
+            L.check(lib.mq_tune(k, 0))
 for t in sorted(tails, key=str)[:12]:
     print("  tail rows differ by fp32 association only:", t)
 print("gemm_check:", ("all variants bit-identical to the narrow tile" + (f" except the in-kernel tail rows of {len(tails)} cases (fp32 association)" if tails else "")) if not bad else f"{bad} mismatches")
