@@ -55,6 +55,11 @@ extern "C" {
 
 #define MQ_MASK_NONE 0   /* ViT: full attention inside a sequence */
 #define MQ_MASK_CAUSAL 1 /* CLIP text tower */
+#define MQ_MASK_CAUSAL_CLS 2 /* ABI 11 — CoCa text tower (open_clip TextTransformer embed_cls): causal, and the LAST row of a sequence — the appended class
+                              * token — does not attend its own key.  open_clip 2.24.0 build_cls_mask pads the key axis of the class row's mask on the LEFT
+                              * (F.pad(cls_mask, (1, 0, S, 0), value=True)): the class row sees key 0 and key j + 1 wherever text[j] != pad — i.e. the text, the
+                              * FIRST pad position, and itself only when the text fills all S positions.  The caller packs [text, one pad row, class row]
+                              * (text shorter than S) or [text, class row, class row] (full text: the twin stands for "itself"). */
 /* key-padding masks (BERT) are expressed by packing: only real tokens are rows. */
 
 #define MQ_PREC_BF16 0
@@ -218,7 +223,8 @@ typedef struct mq_clip_text_cfg {
     int32_t ctx;      /* 77 */
     int32_t out_dim;
     int32_t cls_pos;  /* > 0 (CoCa text towers, open_clip TextTransformer embed_cls): the LAST row of every sequence is the appended class
-                       * embedding — it takes position `cls_pos` (= the text context length) instead of its index; 0 = off */
+                       * embedding — it takes position `cls_pos` (= the text context length) instead of its index; sequences may then hold
+                       * ctx + 1 rows (MQ_MASK_CAUSAL_CLS: a full-length text carries the class row twice); 0 = off */
 } mq_clip_text_cfg;
 
 typedef struct mq_bert_weights {

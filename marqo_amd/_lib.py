@@ -32,7 +32,7 @@ NO_SCRATCH_UNITS = ("rowops", "gemm_bf16", "gemm_wd", "gemm_fp8", "gemm_small", 
 ABI_VERSION = 11
 MQ_PREC_BF16, MQ_PREC_FP8 = 0, 1
 MQ_ACT_GELU, MQ_ACT_QUICKGELU, MQ_ACT_SILU = 1, 2, 3
-MQ_MASK_NONE, MQ_MASK_CAUSAL = 0, 1
+MQ_MASK_NONE, MQ_MASK_CAUSAL, MQ_MASK_CAUSAL_CLS = 0, 1, 2
 MQ_POOL_MEAN, MQ_POOL_CLS = 0, 1
 MQ_VIT_POOL_CLS, MQ_VIT_POOL_MAP, MQ_VIT_POOL_AVG, MQ_VIT_POOL_QUERY = 0, 1, 2, 3
 MQ_EPI_BIAS, MQ_EPI_GELU, MQ_EPI_QUICKGELU, MQ_EPI_RESIDUAL, MQ_EPI_OUT_F32, MQ_EPI_OUT_FP8 = 1, 2, 4, 8, 16, 32

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(NW * 64) MQ_ATTN_OCC void attention_kernel(
         for (int dt = 0; dt < NDT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
         int kt_end = nkt;
-        if (MASK == MQ_MASK_CAUSAL) {
+        if (MASK != MQ_MASK_NONE) {
             const int last = (qblk * 16 + 15) >> 6;  // last key tile any query of this block may see
             kt_end = last + 1 < nkt ? last + 1 : nkt;
         }
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(NW * 64) MQ_ATTN_OCC void attention_kernel(
             // masking is needed only on the ragged last tile and (causal) on tiles that reach past the block's first query:
             // a wave-uniform test, so interior tiles skip the per-element compares / selects
             bool need_mask = (kt == nkt - 1) && (len & 63);
-            if (MASK == MQ_MASK_CAUSAL) need_mask = need_mask || (kt * 64 + 63 > qblk * 16);
+            if (MASK != MQ_MASK_NONE) need_mask = need_mask || (kt * 64 + 63 > qblk * 16);
             if (need_mask) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
@@ -194,7 +194,9 @@ __global__ __launch_bounds__(NW * 64) MQ_ATTN_OCC void attention_kernel(
                     for (int r = 0; r < 4; ++r) {
                         const int key = kt * 64 + t * 16 + g * 4 + r;
                         bool valid = key < len;
-                        if (MASK == MQ_MASK_CAUSAL) valid = valid && (key <= q);
+                        if (MASK != MQ_MASK_NONE) valid = valid && (key <= q);
+                        // CoCa's class-token row (the sequence's LAST row) does not see its own key (open_clip build_cls_mask, see marqo_hip.h)
+                        if (MASK == MQ_MASK_CAUSAL_CLS) valid = valid && !(q == len - 1 && key == q && len > 1);
                         sc[t][r] = valid ? sc[t][r] : -INFINITY;
                     }
             }
@@ -301,7 +303,8 @@ static int attention_impl(const void* d_qkv, void* d_out, const int32_t* d_cu_se
     MQ_CHECK_ARG(hs == 64 || hs == 96 || hs == 112 || hs == 128, "mq_attention: head dim must be 64, 96, 112 or 128 (W=%d heads=%d)", W, heads);
     const int hd = hs == 64 ? 64 : 128;   // LDS row width
     MQ_CHECK_ARG(fixed_len > 0 || d_cu_seqlens, "mq_attention: need fixed_len or cu_seqlens");
-    MQ_CHECK_ARG(mask == MQ_MASK_NONE || mask == MQ_MASK_CAUSAL, "mq_attention: bad mask %d", mask);
+    MQ_CHECK_ARG(mask == MQ_MASK_NONE || mask == MQ_MASK_CAUSAL || mask == MQ_MASK_CAUSAL_CLS, "mq_attention: bad mask %d", mask);
+    MQ_CHECK_ARG(mask != MQ_MASK_CAUSAL_CLS || !out_fp8, "mq_attention: MQ_MASK_CAUSAL_CLS runs with bf16 output only");
     if (nseq <= 0) return MQ_OK;
     const int maxl = fixed_len > 0 ? fixed_len : max_len;
     MQ_CHECK_ARG(maxl >= 1 && maxl <= 8192, "mq_attention: max sequence length %d unsupported (1..8192)", maxl);
@@ -348,6 +351,7 @@ static int attention_impl(const void* d_qkv, void* d_out, const int32_t* d_cu_se
     auto pick_nw = [&](auto hd_tag, auto hs_tag, auto nw_tag) -> int {
         constexpr int HD_ = decltype(hd_tag)::value, HS_ = decltype(hs_tag)::value, NW_ = decltype(nw_tag)::value;
         if (out_fp8) return (mask == MQ_MASK_CAUSAL) ? launch(attention_kernel<MQ_MASK_CAUSAL, true, HD_, HS_, NW_>) : launch(attention_kernel<MQ_MASK_NONE, true, HD_, HS_, NW_>);
+        if (mask == MQ_MASK_CAUSAL_CLS) return launch(attention_kernel<MQ_MASK_CAUSAL_CLS, false, HD_, HS_, NW_>);
         return (mask == MQ_MASK_CAUSAL) ? launch(attention_kernel<MQ_MASK_CAUSAL, false, HD_, HS_, NW_>) : launch(attention_kernel<MQ_MASK_NONE, false, HD_, HS_, NW_>);
     };
     auto pick = [&](auto hd_tag, auto hs_tag) -> int {

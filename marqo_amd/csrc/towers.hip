@@ -810,7 +810,7 @@ extern "C" int mq_encode_clip_text(const mq_clip_text_cfg* cfg, const mq_clip_te
     MQ_CHECK_ARG(h_cu_seqlens[0] == 0, "mq_encode_clip_text: cu_seqlens[0] must be 0");
     int64_t rows = 0;
     const int maxl = max_seq_len(h_cu_seqlens, nseq, &rows);
-    MQ_CHECK_ARG(maxl >= 1 && maxl <= cfg->ctx, "mq_encode_clip_text: sequence lengths must be in [1, ctx=%d]", cfg->ctx);
+    MQ_CHECK_ARG(maxl >= 1 && maxl <= cfg->ctx + (cfg->cls_pos > 0 ? 1 : 0), "mq_encode_clip_text: sequence lengths must be in [1, ctx=%d]", cfg->ctx);
     MQ_CHECK_ARG(cfg->cls_pos >= 0 && cfg->cls_pos < cfg->ctx, "mq_encode_clip_text: cls_pos %d outside the position table [0, %d)", cfg->cls_pos, cfg->ctx);
     const TextPlan p = text_plan(&cfg->enc, rows, nseq);
     if (workspace_bytes < p.total) { mq_set_error("mq_encode_clip_text: workspace %zu < required %zu", workspace_bytes, p.total); return MQ_ERR_WORKSPACE; }

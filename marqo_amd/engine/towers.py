@@ -1072,10 +1072,13 @@ class ClipTextTower(_TextTowerBase):
             proj_b = None
         tok_emb = _need(sd, px + "token_embedding.weight", (arch.vocab, W))
         if arch.cls_embed:
-            # CoCa: the learned class embedding rides as one more row of the token table (id = vocab); encode_ids appends that id behind every
-            # text's EOT, the embedding kernel gives the sequence's last row position ctx - 1 (cfg.cls_pos) — the padding between the text and
-            # the class token in the reference's layout is never a key of any row that is read (oracle.coca_text_forward restates the mask)
-            tok_emb = torch.cat([tok_emb.detach().to(torch.float32), _need(sd, px + "cls_emb", (W,)).detach().to(torch.float32)[None]], dim=0)
+            # CoCa: the learned class embedding rides as two more rows of the token table (ids vocab, vocab + 1: the same vector); encode_ids packs
+            # [text, ONE pad row, class] — or [text, class, class] for a text that fills all ctx - 1 positions — and the embedding kernel gives a
+            # sequence's last row position ctx - 1 (cfg.cls_pos).  Why a pad row: open_clip 2.24.0's build_cls_mask pads the class row's key mask on
+            # the LEFT, so the class token sees the text, the FIRST pad position and NOT itself (itself only behind a full-length text: the twin row
+            # has the class token's K / V) — MQ_MASK_CAUSAL_CLS (marqo_hip.h); the pretrained coca_* checkpoints were trained with that mask.
+            cls = _need(sd, px + "cls_emb", (W,)).detach().to(torch.float32)[None]
+            tok_emb = torch.cat([tok_emb.detach().to(torch.float32), cls, cls], dim=0)
         self.w = L.ClipTextWeights(
             tok_emb=h.f32(tok_emb),
             pos=h.f32(_need(sd, px + "positional_embedding", (arch.ctx, W))),
@@ -1083,11 +1086,13 @@ class ClipTextTower(_TextTowerBase):
             ln_final_g=h.f32(_need(sd, px + "ln_final.weight", (W,))), ln_final_b=h.f32(_need(sd, px + "ln_final.bias", (W,))),
             proj_w=h.bf16(proj_w), proj_b=proj_b)
         self.cfg = L.ClipTextCfg(enc=_encoder_cfg(W, arch.layers, arch.heads, arch.mlp_dim, arch.quick_gelu, False,
-                                                  L.MQ_MASK_CAUSAL if arch.causal else L.MQ_MASK_NONE, arch.ln_eps),
-                                 vocab=arch.vocab + (1 if arch.cls_embed else 0), ctx=arch.ctx, out_dim=arch.out_dim,
+                                                  (L.MQ_MASK_CAUSAL_CLS if arch.cls_embed else L.MQ_MASK_CAUSAL) if arch.causal else L.MQ_MASK_NONE, arch.ln_eps),
+                                 vocab=arch.vocab + (2 if arch.cls_embed else 0), ctx=arch.ctx, out_dim=arch.out_dim,
                                  cls_pos=arch.ctx - 1 if arch.cls_embed else 0)
         if arch.cls_embed and not arch.causal:
             raise ValueError("a class-embedding text tower is causal (CoCa)")
+        if arch.cls_embed and precision == "fp8":
+            raise ValueError("a class-embedding text tower (CoCa) runs on bf16 operands (its attention mask has no e4m3-output kernel)")
         if precision == "fp8":
             self._enable_fp8(self._blocks, arch.layers, W, _ceil64(arch.mlp_dim))
         self.cfg.enc.residual_stream = 2
@@ -1095,14 +1100,22 @@ class ClipTextTower(_TextTowerBase):
             self.tune_residual_default()
 
     def _with_cls(self, ids_h: np.ndarray) -> np.ndarray:
-        """CoCa: [n, S <= ctx - 1] token ids (SOT ... EOT 0 ...) -> [n, S + 1] with the class id (= vocab) right behind each text's EOT.
-        The class id is the largest id of its row, so the EOT logic downstream (argmax = pooled position, rows up to it) lands on it."""
+        """CoCa: [n, S <= ctx - 1] token ids (SOT ... EOT 0 ...) -> [n, ctx + 1] rows  text, 0 (ONE pad position), class id  — or, for a text that
+        fills all ctx - 1 positions,  text, class id, class twin id  (see __init__: the class token attends the first pad position and not
+        itself; behind a full text it attends itself, which the twin row stands for).  The last id of a row is its largest, so the EOT logic
+        downstream (argmax = pooled position, rows up to it) lands on it."""
         n, S = ids_h.shape
-        if S > self.arch.ctx - 1:
-            raise ValueError(f"a class-embedding text tower takes at most {self.arch.ctx - 1} token positions, got {S}")
-        out = np.zeros((n, S + 1), dtype=np.int64)
+        full = self.arch.ctx - 1
+        if S > full:
+            raise ValueError(f"a class-embedding text tower takes at most {full} token positions, got {S}")
+        out = np.zeros((n, full + 2), dtype=np.int64)
         out[:, :S] = ids_h
-        out[np.arange(n), ids_h.argmax(axis=1) + 1] = self.arch.vocab
+        L_ = ids_h.argmax(axis=1) + 1                    # text length SOT .. EOT
+        r = np.arange(n)
+        is_full = L_ >= full
+        out[r[~is_full], L_[~is_full] + 1] = self.arch.vocab          # text, pad (0), class
+        out[r[is_full], full] = self.arch.vocab                       # text, class, twin
+        out[r[is_full], full + 1] = self.arch.vocab + 1
         return out
 
     def tune_residual_default(self) -> str:

@@ -73,6 +73,73 @@ class _DeferredRows:
         return self.rows.cpu().numpy() if isinstance(self.rows, torch.Tensor) else self.rows
 
 
+    def numpy_into(self, dst: np.ndarray) -> None:
+        """the rows straight into `dst` ([n, D] float32, e.g. a slice of RequestShardedIngest's row slab): ONE host copy, no intermediate array"""
+        import torch
+        if self.event is not None:
+            self.event.synchronize()
+            np.copyto(dst, self.host.numpy())
+            self.rows = self.host = self.event = None
+            return
+        np.copyto(dst, self.rows.cpu().numpy() if isinstance(self.rows, torch.Tensor) else self.rows)
+
+
+class _DeviceRows:
+    """[n, D] rows a tower has been enqueued for that STAY in HBM (RequestShardedIngest on RCCL ranks: the rows meet their first host at the root,
+    behind the gather).  `tensor()` waits for the tower (an asynchronous device fault surfaces there, like at _DeferredRows' copy) and hands the
+    device tensor over."""
+
+    def __init__(self, rows):
+        import torch
+        self.rows = rows
+        self.event = torch.cuda.Event()
+        self.event.record(torch.cuda.current_stream(rows.device))
+
+    @property
+    def shape(self):
+        return self.rows.shape
+
+    def tensor(self):
+        self.event.synchronize()
+        return self.rows
+
+    def numpy(self) -> np.ndarray:
+        return self.tensor().cpu().numpy()
+
+    def numpy_into(self, dst: np.ndarray) -> None:
+        np.copyto(dst, self.numpy())
+
+
+class _RowSlab:
+    """one growing [capacity, D] float32 host array per rank: every settled group's rows are copied ONCE, from the pinned block their D2H landed in,
+    to the slab's tail — so collect() has one contiguous [n, D] array to hand to the gather (or to slice rows from) without stacking anything."""
+
+    def __init__(self):
+        self.buf: Optional[np.ndarray] = None
+        self.n = 0
+
+    def tail(self, n: int, D: int) -> np.ndarray:
+        """a writable view of the next n rows (commit() makes them part of the slab)"""
+        if self.buf is not None and self.buf.shape[1] != D:
+            raise ValueError(f"row width changed inside one stream: {self.buf.shape[1]} -> {D}")
+        cap = 0 if self.buf is None else self.buf.shape[0]
+        if self.n + n > cap:
+            grown = np.empty((max(2 * cap, self.n + n, 4096), D), dtype=np.float32)
+            if self.n:
+                grown[:self.n] = self.buf[:self.n]
+            self.buf = grown
+        return self.buf[self.n:self.n + n]
+
+    def commit(self, n: int) -> int:
+        base, self.n = self.n, self.n + n
+        return base
+
+    def take(self) -> Optional[np.ndarray]:
+        out = None if self.buf is None else self.buf[:self.n]
+        self.buf, self.n = None, 0
+        return out
+
+
 class BulkVectoriser:
     def __init__(self, model_name: str, device: str, model_properties: Optional[dict] = None, normalize_embeddings: bool = True,
                  max_pending: int = 0, vectorise_fn: Optional[Callable] = None):
@@ -88,6 +155,7 @@ class BulkVectoriser:
         self._done: Dict[Hashable, np.ndarray] = {}
         self.force_collective = False   # tests: take the sharded path (and run the collective) even in a 1-rank process group
         self.local_only = False         # RequestShardedIngest: requests are owned by ONE rank, nothing is sharded inside a request
+        self.rows_on_device = False     # RequestShardedIngest on RCCL ranks: a flush's rows stay in HBM (_DeviceRows) instead of starting their D2H
         self._helper = None             # second host thread of a two-modality flush (created on first use)
         self.two_threads = True         # (False: both modalities on the caller's thread; measurement knob)
         self._model_loaded = False      # a vectorise call of this object has returned (the model is in the cache)
@@ -196,7 +264,9 @@ class BulkVectoriser:
             self._model_loaded = True
             if emb.shape[0] != len(items):
                 raise RuntimeError(f"vectorise returned {emb.shape[0]} embeddings for {len(items)} items")
-            return (modality, items, emb if isinstance(emb, np.ndarray) else _DeferredRows(emb)), None
+            if not isinstance(emb, np.ndarray):
+                emb = _DeviceRows(emb) if self.rows_on_device and emb.is_cuda else _DeferredRows(emb)
+            return (modality, items, emb), None
         except BaseException as e:  # noqa: BLE001 - re-raised by the caller, after the modalities that did run are stored
             with self._lock:
                 self._pending[modality] = items + self._pending[modality]
@@ -339,6 +409,20 @@ class PendingFlush:
         return self._rows
 
 
+    def result_blocks(self):
+        """the same hand-over WITHOUT the per-key dictionary: [(modality, items, rows)] with rows = the flush's [n, D] block per modality, still
+        lazy (_DeferredRows / _DeviceRows: the caller copies it where it wants it) or an ndarray.  Waits for nothing; a device error surfaces when
+        the caller touches the rows — `requeue(modality, items)` then puts that modality back, as result() does."""
+        if self._rows:
+            raise RuntimeError("result_blocks(): rows of an automatic max_pending flush are pending; use result()")
+        enqueued, self._enqueued = self._enqueued, None
+        return enqueued or []
+
+    def requeue(self, modality, items) -> None:
+        with self._bulk._lock:
+            self._bulk._pending[modality] = items + self._bulk._pending[modality]
+
+
 # Cross-request micro-batching of the ingest stream (north_star: "documents are dynamically micro-batched").  A 128-document request is
 # 6 400 image rows + ~4 300 packed text rows: every GEMM of its towers fills about half of the chip's 512 resident tile slots, so the stream ran
 # at ~47 % of what the same kernels deliver at full batches (profiles/r04ad_stream_procs.txt).  Requests are therefore MERGED until one side is
@@ -365,10 +449,11 @@ def _deadline_loop(ref) -> None:
 
 class _Request:
     """one submitted request, as RequestShardedIngest keeps it until its rows are filed"""
-    __slots__ = ("keys", "texts", "images")
+    __slots__ = ("keys", "texts", "images", "kinds")
 
     def __init__(self):
         self.keys: List[Tuple[int, Hashable]] = []                 # (request index, key) in submission order
+        self.kinds = bytearray()                                   # 0 = text, 1 = image per key (the row's place inside its group's blocks)
         self.texts: List[Tuple[Tuple[int, Hashable], Any]] = []    # ((request index, key), content) per modality
         self.images: List[Tuple[Tuple[int, Hashable], Any]] = []
 
@@ -406,8 +491,16 @@ class RequestShardedIngest:
         self.root, self.device = root, device
         self._bulk = BulkVectoriser(model_name, device, model_properties, normalize_embeddings, vectorise_fn=vectorise_fn)
         self._bulk.local_only = True
-        self._rows: List[np.ndarray] = []                     # this rank's embeddings, in submission order
-        self._index: List[Tuple[int, Hashable]] = []          # (request index, key) per row
+        # this rank's embeddings: every settled group leaves its [n, D] block(s) WHOLE — on the host in ONE growing slab (the group's D2H lands in
+        # pinned memory and is copied once, to the slab's tail), on RCCL ranks as device tensors that never visit the host before the gather — plus,
+        # per request, the positions of its rows in the rank's row space (NumPy arithmetic per request, nothing per row)
+        self._slab = _RowSlab()
+        self._dev_blocks: list = []                           # RCCL ranks: the groups' blocks in HBM, in slab order
+        self._nrows = 0                                       # rows filed (slab rows or rows of _dev_blocks)
+        self._index: List[Tuple[int, Hashable]] = []          # (request index, key) per filed row, in submission order
+        self._perm: List[np.ndarray] = []                     # per filed request: position of each of its keys in the rank's row space
+        self._on_device = bool(self._dist) and self.world > 1 and self._dist.get_backend() == "nccl" and str(device).startswith("cuda")
+        self._bulk.rows_on_device = self._on_device
         self.touched: List[int] = []                          # request indices this rank was handed (tests: ownership)
         self.failed: List[int] = []                           # owned requests whose encode raised since the last collect()
         self.failed_requests: List[int] = []                  # after collect(): every rank's failed requests (root), own ones elsewhere
@@ -447,12 +540,70 @@ class RequestShardedIngest:
         self.failed.append(request_index)
         self.errors[request_index] = error
 
+    @property
+    def _rows(self):
+        """the filed rows in submission order (tests / diagnostics: the stream itself never touches single rows before collect())"""
+        if not self._nrows:
+            return []
+        host = torch_cat_host(self._dev_blocks) if self._on_device else self._slab.buf
+        return [host[p] for p in np.concatenate(self._perm)]
+
+    def _place(self, group, base: int, n_text: int) -> None:
+        """labels and row positions of a filed group whose rows sit at [base, ...) of the rank's row space as [the group's texts | its images]"""
+        t_off, i_off = base, base + n_text
+        for _, req in group:
+            kinds = np.frombuffer(req.kinds, dtype=np.uint8)
+            is_img = kinds.astype(bool)
+            pos = np.where(is_img, i_off + np.cumsum(is_img) - 1, t_off + np.cumsum(~is_img) - 1)
+            self._perm.append(pos.astype(np.int64, copy=False))
+            self._index.extend(req.keys)
+            n_img = int(is_img.sum())
+            t_off += len(kinds) - n_img
+            i_off += n_img
+
+    def _file_blocks(self, group, blocks) -> None:
+        """a settled group's blocks ([(modality, items, rows)], texts first) into the rank's row space.  Touching the rows is where an asynchronous
+        device fault surfaces: nothing is filed then, the modality is re-queued by the caller's handler (PendingFlush.requeue)"""
+        by_mod = {m: (items, rows) for m, items, rows in blocks}
+        parts = [by_mod[m] for m in (Modality.TEXT, Modality.IMAGE) if m in by_mod]
+        n_text = len(by_mod[Modality.TEXT][0]) if Modality.TEXT in by_mod else 0
+        total = sum(len(items) for items, _ in parts)
+        if total != sum(len(req.keys) for _, req in group):
+            raise RuntimeError("a flush returned a different number of rows than its group queued")
+        if self._on_device:
+            tensors = [rows.tensor() if isinstance(rows, _DeviceRows) else rows for _, rows in parts]   # (waits for the towers; raises a device fault)
+            self._dev_blocks.extend(tensors)
+        else:
+            D = int(parts[0][1].shape[1])
+            tail = self._slab.tail(total, D)
+            at = 0
+            for items, rows in parts:
+                n = len(items)
+                if isinstance(rows, np.ndarray):
+                    np.copyto(tail[at:at + n], rows)
+                else:
+                    rows.numpy_into(tail[at:at + n])
+                at += n
+            self._slab.commit(total)
+        self._place(group, self._nrows, n_text)
+        self._nrows += total
+
     def _file(self, group, out) -> None:
-        rows, index = self._rows, self._index
+        """the same from a {key: row} dictionary (the one-by-one re-run of a failed group: BulkVectoriser.flush())"""
         for request_index, req in group:
-            for ck in req.keys:
-                rows.append(out[ck])
-            index.extend(req.keys)
+            if not req.keys:
+                continue
+            block = np.stack([out[ck] for ck in req.keys]).astype(np.float32, copy=False)
+            n = block.shape[0]
+            if self._on_device:
+                import torch
+                self._dev_blocks.append(torch.from_numpy(block).to(self.device))
+            else:
+                np.copyto(self._slab.tail(n, block.shape[1]), block)
+                self._slab.commit(n)
+            self._perm.append(np.arange(self._nrows, self._nrows + n, dtype=np.int64))
+            self._index.extend(req.keys)
+            self._nrows += n
 
     def _queue(self, group) -> None:
         """the group's items into the BulkVectoriser's queues; keys are made unique across requests by the request index (done once, in submit)"""
@@ -484,8 +635,10 @@ class RequestShardedIngest:
         """wait for a launched group's rows and file them; a failure that surfaces here (an asynchronous device error at the deferred copy)
         fails a lone request, and sends a merged group through `_run_alone`"""
         group, handle = inflight
+        blocks = []
         try:
-            out = handle.result()
+            blocks = handle.result_blocks()
+            self._file_blocks(group, blocks)
         except BaseException as e:  # noqa: BLE001
             self._bulk.reset()
             if len(group) == 1:
@@ -497,7 +650,6 @@ class RequestShardedIngest:
             if reraise and first is not None:
                 raise first
             return
-        self._file(group, out)
 
     @property
     def _inflight(self):
@@ -615,9 +767,11 @@ class RequestShardedIngest:
             req.keys.append(ck)
             if m == Modality.TEXT:
                 req.texts.append((ck, content))
+                req.kinds.append(0)
                 n_tokens += 2.0 + len(content) / 4.0 if isinstance(content, str) else 1.0     # (= estimate_tokens)
             elif m == Modality.IMAGE:
                 req.images.append((ck, content))
+                req.kinds.append(1)
             else:
                 raise ValueError(f"unsupported modality {m}")
         items = req
@@ -636,7 +790,11 @@ class RequestShardedIngest:
                 self._cv.notify_all()
 
     def collect(self) -> Dict[int, Dict[Hashable, np.ndarray]]:
-        """gather every rank's rows on the root -> {request index: {key: row}} there, {} elsewhere; resets the store"""
+        """gather every rank's rows on the root -> {request index: {key: row}} there, {} elsewhere; resets the store.
+        What travels: ONE [n_r, D] tensor per rank — the rank's slab as it stands, or, on RCCL ranks, the concatenation IN HBM of the groups' device
+        blocks (the rows' first host is the root, behind the gather) — plus, as Python objects, the (request, key) labels and one int64 position per
+        label.  A non-root rank runs no per-row Python here or anywhere before: its work in collect() is the all_gather_object of its labels and the
+        gather."""
         import torch
         with self._lock:
             try:
@@ -644,45 +802,57 @@ class RequestShardedIngest:
             except BaseException:  # noqa: BLE001 - reported through failed_requests; every rank must reach the collective
                 pass
             self._settle(reraise=False)
-            rows, index = self._rows, self._index
-            self._rows, self._index = [], []
+            index, perms, n = self._index, self._perm, self._nrows
+            local = self._slab.take()
+            dev_blocks, self._dev_blocks = self._dev_blocks, []
+            self._index, self._perm, self._nrows = [], [], 0
             failed, self.failed = self.failed, []
             self.groups_launched = []
             self.errors = {i: e for i, e in self.errors.items() if i in failed}   # kept until the NEXT collect() for the caller to inspect
         self.failed_requests = sorted(failed)
-        if self.world == 1:
-            # (no copy: the rows are views of the groups' host arrays — stacking 200 000 of them, which the collective below needs, took as long
-            # as the whole stream's GPU work)
-            out: Dict[int, Dict[Hashable, np.ndarray]] = {}
+        perm = np.concatenate(perms) if perms else np.zeros(0, dtype=np.int64)
+
+        def scatter(out, labels, positions, rows):
             cur_ri, cur = None, None
-            for (ri, key), row in zip(index, rows):
+            for (ri, key), p in zip(labels, positions):
                 if ri != cur_ri:
                     cur_ri, cur = ri, out.setdefault(ri, {})
-                cur[key] = row
+                cur[key] = rows[p]
             return out
-        local = np.stack(rows).astype(np.float32, copy=False) if rows else None
+        if self.world == 1:
+            # (no copy: the rows are views of the slab)
+            return scatter({}, index, perm.tolist(), local) if n else {}
         dist = self._dist
-        on_gpu = dist.get_backend() == "nccl" and str(self.device).startswith("cuda")
-        where = self.device if on_gpu else "cpu"
-        # who holds what: (row count, width) per rank + the (request, key) labels, as python objects (tiny next to the rows)
+        where = self.device if self._on_device else "cpu"
+        # who holds what: (row count, width) per rank + the labels and their row positions (tiny next to the rows)
+        if self._on_device:
+            t = torch.cat(dev_blocks) if len(dev_blocks) > 1 else (dev_blocks[0] if dev_blocks else None)
+        else:
+            t = torch.from_numpy(local) if local is not None and n else None
         meta = [None] * self.world
-        dist.all_gather_object(meta, (len(index), int(local.shape[1]) if local is not None else 0, index if self.rank != self.root else None, failed))
+        mine = (n, int(t.shape[1]) if t is not None else 0, (index, perm) if self.rank != self.root else None, failed)
+        dist.all_gather_object(meta, mine)
         if self.rank == self.root:
             self.failed_requests = sorted(i for m in meta for i in m[3])
         D = max(m[1] for m in meta)
         counts = [m[0] for m in meta]
         if sum(counts) == 0:
             return {}
-        t = torch.from_numpy(local).to(where) if local is not None else torch.zeros(0, D, dtype=torch.float32, device=where)
-        full = gather_embeddings_to_root(t, counts, root=self.root)
+        if t is None:
+            t = torch.zeros(0, D, dtype=torch.float32, device=where)
+        full = gather_embeddings_to_root(t.to(dtype=torch.float32), counts, root=self.root)
         if self.rank != self.root:
             return {}
-        full = full.cpu().numpy()
-        out = {}
-        pos = 0
+        full = full.cpu().numpy()          # the ONE device -> host copy of the stream's rows (RCCL ranks)
+        out: Dict[int, Dict[Hashable, np.ndarray]] = {}
+        base = 0
         for r in range(self.world):
-            labels = index if r == self.root else meta[r][2]
-            for (ri, key) in labels:
-                out.setdefault(ri, {})[key] = full[pos]
-                pos += 1
+            labels, positions = (index, perm) if r == self.root else meta[r][2]
+            scatter(out, labels, (positions + base).tolist(), full)
+            base += counts[r]
         return out
+
+
+def torch_cat_host(blocks) -> np.ndarray:
+    import torch
+    return torch.cat(blocks).cpu().numpy() if blocks else np.zeros((0, 0), dtype=np.float32)

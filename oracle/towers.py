@@ -237,6 +237,21 @@ class CocaVitConfig(VitConfig):
     n_queries: int = 256      # attn_pooler_queries (only query 0 reaches the contrastive embedding)
 
 
+def coca_pooler_attention(sd: Dict[str, Tensor], a: str, q: Tensor, kx: Tensor, heads: int) -> Tensor:
+    """The attention of open_clip's AttentionalPooler = torch.nn.MultiheadAttention(embed_dim = D, heads, kdim = vdim = W, batch_first = True) with its
+    separate projection weights (`q_proj_weight` [D, D], `k_proj_weight` / `v_proj_weight` [D, W], one `in_proj_bias` [3 D]): q [Q, D] (shared by the batch),
+    kx [B, T, W] -> [B, Q, D].  PINNED to the installed torch.nn.MultiheadAttention (tests/test_oracle_pins.py)."""
+    B, D = kx.shape[0], q.shape[-1]
+    hd = D // heads
+    bq, bk, bv = sd[a + "in_proj_bias"].split(D)
+    qh = F.linear(q, sd[a + "q_proj_weight"], bq).view(1, -1, heads, hd).transpose(1, 2)                   # [1, H, Q, hd]
+    kh = F.linear(kx, sd[a + "k_proj_weight"], bk).view(B, -1, heads, hd).transpose(1, 2)                  # [B, H, T, hd]
+    vh = F.linear(kx, sd[a + "v_proj_weight"], bv).view(B, -1, heads, hd).transpose(1, 2)
+    p = torch.softmax((qh @ kh.transpose(-1, -2)) / math.sqrt(hd), dim=-1)                                 # [B, H, Q, T]
+    o = (p @ vh).transpose(1, 2).reshape(B, -1, D)
+    return F.linear(o, sd[a + "out_proj.weight"], sd[a + "out_proj.bias"])
+
+
 @torch.no_grad()
 def coca_vit_forward(sd: Dict[str, Tensor], cfg: CocaVitConfig, pixels: Tensor, normalize: bool = True) -> Tensor:
     """VisionTransformer(attentional_pool=True, output_dim = embed_dim) as CoCa builds it: conv1 -> class token + positions -> ln_pre -> blocks;
@@ -254,15 +269,7 @@ def coca_vit_forward(sd: Dict[str, Tensor], cfg: CocaVitConfig, pixels: Tensor, 
     a = "visual.attn_pool."
     kx = F.layer_norm(x, (W,), sd[a + "ln_k.weight"], sd[a + "ln_k.bias"], cfg.ln_eps)                     # [B, T, W]
     q = F.layer_norm(sd[a + "query"], (D,), sd[a + "ln_q.weight"], sd[a + "ln_q.bias"], cfg.ln_eps)        # [n_queries, D]
-    bq, bk, bv = sd[a + "attn.in_proj_bias"].split(D)
-    H = cfg.pool_heads
-    hd = D // H
-    qh = F.linear(q, sd[a + "attn.q_proj_weight"], bq).view(1, -1, H, hd).transpose(1, 2)                  # [1, H, Q, hd]
-    kh = F.linear(kx, sd[a + "attn.k_proj_weight"], bk).view(B, -1, H, hd).transpose(1, 2)                 # [B, H, T, hd]
-    vh = F.linear(kx, sd[a + "attn.v_proj_weight"], bv).view(B, -1, H, hd).transpose(1, 2)
-    p = torch.softmax((qh @ kh.transpose(-1, -2)) / math.sqrt(hd), dim=-1)                                 # [B, H, Q, T]
-    o = (p @ vh).transpose(1, 2).reshape(B, -1, D)
-    o = F.linear(o, sd[a + "attn.out_proj.weight"], sd[a + "attn.out_proj.bias"])
+    o = coca_pooler_attention(sd, a + "attn.", q, kx, cfg.pool_heads)
     o = F.layer_norm(o, (D,), sd["visual.ln_post.weight"], sd["visual.ln_post.bias"], cfg.ln_eps)
     out = o[:, 0] @ sd["visual.proj"]
     return l2_normalize_clip(out) if normalize else out
@@ -271,16 +278,29 @@ def coca_vit_forward(sd: Dict[str, Tensor], cfg: CocaVitConfig, pixels: Tensor, 
 @torch.no_grad()
 def coca_text_forward(sd: Dict[str, Tensor], cfg: ClipTextConfig, ids: Tensor, pad_id: int = 0, normalize: bool = True) -> Tensor:
     """TextTransformer(embed_cls=True) as CoCa builds it (keys under `text.`): ids int64 [B, ctx - 1] (SOT ... EOT, zero-padded); the learned class
-    embedding is appended BEHIND the padding -> ctx positions; attention mask = causal + a class-token row that is blind to padding keys
-    (build_cls_mask); blocks; pooled = the LAST position (the class token), ln_final applied to the pooled row, @ text_projection."""
+    embedding is appended BEHIND the padding -> ctx positions; attention mask = causal + build_cls_mask; blocks; pooled = the LAST position (the
+    class token), ln_final applied to the pooled row, @ text_projection.
+
+    The class-token mask is written with the SAME tensor operations as open_clip 2.24.0 (transformer.py, TextTransformer.build_cls_mask / forward):
+        cls_mask = (text != self.pad_id).unsqueeze(1)
+        cls_mask = F.pad(cls_mask, (1, 0, cls_mask.shape[2], 0), value=True)
+        additive_mask = zeros.masked_fill(~cls_mask, -inf)          # [B, S + 1, S + 1], repeated per head
+        attn_mask = self.attn_mask[None, :seq_len, :seq_len] + cls_mask[:, :seq_len, :seq_len]
+    The key axis is padded on the LEFT: the class row (the only row that is not all-True) allows key 0 and key j + 1 wherever text[j] != pad, i.e. the text,
+    the FIRST pad position, and the class token itself only when the text fills all S positions.  (Round 5 restated this mask as "text keys + itself";
+    that was wrong against this code — ADVICE r5 — and the pretrained coca_* checkpoints were trained with the shifted form.)  open_clip is not in this
+    image: the four lines above are quoted from memory of the published source, the arithmetic below executes them literally; unpinned."""
     B, T = ids.shape
     W = cfg.width
     if T + 1 != cfg.ctx:
         raise ValueError(f"CoCa text towers take {cfg.ctx - 1} token positions + the class embedding")
     x = torch.cat([sd["text.token_embedding.weight"][ids], sd["text.cls_emb"].expand(B, 1, W)], dim=1) + sd["text.positional_embedding"][:T + 1]
-    mask = torch.full((T + 1, T + 1), float("-inf")).triu(1)[None, None].repeat(B, 1, 1, 1)               # causal, [B, 1, T + 1, T + 1]
-    keys_ok = torch.cat([ids != pad_id, torch.ones(B, 1, dtype=torch.bool)], dim=1)                        # the class token sees itself
-    mask[:, 0, T, :] = mask[:, 0, T, :].masked_fill(~keys_ok, float("-inf"))                               # only the class-token QUERY row is masked
+    seq_len = T + 1
+    causal = torch.full((cfg.ctx, cfg.ctx), float("-inf")).triu(1)                                         # TextTransformer.build_causal_mask
+    cls_mask = (ids != pad_id).unsqueeze(1)                                                                # [B, 1, S]
+    cls_mask = F.pad(cls_mask, (1, 0, cls_mask.shape[2], 0), value=True)                                   # [B, S + 1, S + 1]
+    additive = torch.zeros(cls_mask.shape).masked_fill(~cls_mask, float("-inf"))
+    mask = (causal[None, :seq_len, :seq_len] + additive[:, :seq_len, :seq_len])[:, None]                   # [B, 1, S + 1, S + 1] (broadcast over heads)
     x = _clip_resblocks(x, sd, "text.transformer.", cfg.layers, cfg.heads, cfg.quick_gelu, cfg.ln_eps, mask)
     pooled = F.layer_norm(x[:, -1], (W,), sd["text.ln_final.weight"], sd["text.ln_final.bias"], cfg.ln_eps)
     out = pooled @ sd["text.text_projection"]
@@ -354,6 +374,18 @@ def _eva_rot(x: Tensor) -> Tensor:
     return torch.stack([-x[..., 1::2], x[..., ::2]], -1).reshape(x.shape)
 
 
+def eva_apply_rope(x: Tensor, sin: Tensor, cos: Tensor) -> Tensor:
+    """timm apply_rot_embed_cat on [..., tokens, head_dim]: x * cos + rot(x) * sin with the interleaved-pair rotation — the same function as GPT-J's rotary
+    (rotate_every_two).  PINNED to transformers.models.gptj.modeling_gptj.apply_rotary_pos_emb (tests/test_oracle_pins.py)."""
+    return x * cos + _eva_rot(x) * sin
+
+
+def eva_swiglu_gate(h: Tensor, wg: Tensor, bg: Tensor, wx: Tensor, bx: Tensor) -> Tensor:
+    """timm SwiGLU up to its inner norm: silu(fc1_g(h)) * fc1_x(h) — the gate / up pair of a Llama MLP.  PINNED to transformers' LlamaMLP
+    (gate_proj = fc1_g, up_proj = fc1_x, identity down_proj; tests/test_oracle_pins.py)."""
+    return F.silu(F.linear(h, wg, bg)) * F.linear(h, wx, bx)
+
+
 @torch.no_grad()
 def eva_vit_forward(sd: Dict[str, Tensor], cfg: EvaVitConfig, pixels: Tensor, normalize: bool = True) -> Tensor:
     """timm Eva.forward as open_clip's TimmModel(pool='token', proj=None) runs it (keys under `visual.trunk.`): patch_embed (conv WITH bias) ->
@@ -378,13 +410,13 @@ def eva_vit_forward(sd: Dict[str, Tensor], cfg: EvaVitConfig, pixels: Tensor, no
         q = F.linear(h, sd[p + "attn.q_proj.weight"], sd[p + "attn.q_proj.bias"]).view(B, T, H, hd).transpose(1, 2)
         k = F.linear(h, sd[p + "attn.k_proj.weight"], None).view(B, T, H, hd).transpose(1, 2)
         v = F.linear(h, sd[p + "attn.v_proj.weight"], sd[p + "attn.v_proj.bias"]).view(B, T, H, hd).transpose(1, 2)
-        q = torch.cat([q[:, :, :1], q[:, :, 1:] * cos + _eva_rot(q[:, :, 1:]) * sin], dim=2)
-        k = torch.cat([k[:, :, :1], k[:, :, 1:] * cos + _eva_rot(k[:, :, 1:]) * sin], dim=2)
+        q = torch.cat([q[:, :, :1], eva_apply_rope(q[:, :, 1:], sin, cos)], dim=2)
+        k = torch.cat([k[:, :, :1], eva_apply_rope(k[:, :, 1:], sin, cos)], dim=2)
         a = torch.softmax((q @ k.transpose(-1, -2)) / math.sqrt(hd), dim=-1) @ v
         a = ln(a.transpose(1, 2).reshape(B, T, W), "attn.norm", W)
         x = x + F.linear(a, sd[p + "attn.proj.weight"], sd[p + "attn.proj.bias"])
         h = ln(x, "norm2", W)
-        m = F.silu(F.linear(h, sd[p + "mlp.fc1_g.weight"], sd[p + "mlp.fc1_g.bias"])) * F.linear(h, sd[p + "mlp.fc1_x.weight"], sd[p + "mlp.fc1_x.bias"])
+        m = eva_swiglu_gate(h, sd[p + "mlp.fc1_g.weight"], sd[p + "mlp.fc1_g.bias"], sd[p + "mlp.fc1_x.weight"], sd[p + "mlp.fc1_x.bias"])
         m = ln(m, "mlp.norm", cfg.mlp_dim)
         x = x + F.linear(m, sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"])
     x = F.layer_norm(x, (W,), sd[t + "norm.weight"], sd[t + "norm.bias"], cfg.ln_eps)

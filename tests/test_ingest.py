@@ -495,3 +495,60 @@ def test_settle_overlaps_the_next_launch_without_changing_order_or_isolation():
     assert sorted(rows) == [0, 1, 2, 3, 4, 6, 7, 8] and ing.failed_requests == [5]
     for i in rows:
         _check_rows(rows, i)
+
+
+def test_collect_moves_blocks_not_rows():
+    """round 6: a rank's rows stay in ONE slab (host) / in the groups' device blocks (RCCL) — settled groups are copied once,
+    whole; nothing is stacked per row.  On a NON-root rank collect() is: take the slab, concatenate one position array per request, hand both to
+    the collectives.  25 000 rows x 512: that local part takes milliseconds and runs no Python statement per row."""
+    import sys
+    import time
+    from marqo_amd import ingest as I
+
+    D, per_req, n_req = 512, 125, 200
+    rng = np.random.default_rng(0)
+    table = rng.standard_normal((n_req * per_req, D)).astype(np.float32)
+
+    def fake(model, content, **kw):
+        return table[[int(c) for c in content]]
+
+    ing = I.RequestShardedIngest("m", "cpu", vectorise_fn=fake, merge_images=512, merge_deadline_ms=0)
+    for i in range(n_req):
+        items = []
+        for j in range(per_req):          # texts and images interleaved, as a document's fields come
+            m = Modality.IMAGE if j % 3 == 0 else Modality.TEXT
+            items.append(((i, j), str(i * per_req + j), m))
+        ing.submit(i, items)
+    ing.drain()
+    assert ing._nrows == n_req * per_req and len(ing._perm) == n_req and ing._slab.n == ing._nrows
+    assert isinstance(ing._slab.buf, np.ndarray) and ing._slab.buf.shape[1] == D                      # ONE array, not a list of rows
+    # what a non-root rank does inside collect() before the collectives, with a line counter on: no per-row Python
+    lines = [0]
+
+    def tracer(frame, event, arg):
+        if event == "line":
+            lines[0] += 1
+        return tracer
+    t0 = time.perf_counter()
+    sys.settrace(tracer)
+    try:
+        index, perms, n = ing._index, ing._perm, ing._nrows
+        local = ing._slab.buf[:ing._slab.n]
+        perm = np.concatenate(perms)
+        payload = (n, int(local.shape[1]), (index, perm), [])
+    finally:
+        sys.settrace(None)
+    dt = time.perf_counter() - t0
+    assert lines[0] < 50 and dt < 5e-3, (lines[0], dt)
+    assert local.flags["C_CONTIGUOUS"] and payload[0] == 25000
+    # ... and the root's view is right: every key has its row, in submission order per request
+    t0 = time.perf_counter()
+    rows = ing.collect()
+    t_collect = time.perf_counter() - t0
+    assert sorted(rows) == list(range(n_req))
+    for i in (0, 57, n_req - 1):
+        assert list(rows[i]) == [(i, j) for j in range(per_req)]
+        for j in (0, 1, 3, per_req - 1):
+            assert np.array_equal(rows[i][(i, j)], table[i * per_req + j])
+    assert t_collect < 0.5            # (the root / single rank builds 25 000 dictionary entries: tens of milliseconds)
+    assert ing.collect() == {} and ing._nrows == 0 and ing._slab.n == 0

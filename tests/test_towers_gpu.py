@@ -475,8 +475,10 @@ def test_coca_towers_vs_oracle(name, layers, n):
     """CoCa (model_registry.py:344-370): the ViT trunk + attentional pooler (one learned query over ln_k(tokens), pooler width = embedding width, 8
     heads: 64-wide at B/32, 96-wide at L/14) and the text tower with the appended class embedding (position ctx - 1, pooled row), registry shapes
     (L/14 depth cut to keep the fp32 CPU oracle in seconds), against oracle.coca_*_forward (restated from open_clip 2.24.0; unpinned — no open_clip
-    in this image).  Ragged texts incl. one that fills all 76 positions; single-text call (graph path); device-id entry point."""
+    in this image; the class-token mask executes build_cls_mask's own tensor operations: the class token attends the text, the FIRST pad position and
+    not itself).  Ragged texts incl. one that fills all 76 positions and one that leaves a single pad; single-text call (graph path); device ids."""
     from dataclasses import replace
+    from marqo_amd import _lib as L
     T, A = _towers()
     varch, tarch = A.resolve_open_clip(name)
     varch, tarch = replace(varch, layers=layers), replace(tarch, layers=layers)
@@ -495,16 +497,24 @@ def test_coca_towers_vs_oracle(name, layers, n):
     # text: 76 token positions + the class embedding
     g = torch.Generator().manual_seed(6)
     S = tarch.ctx - 1
-    ids = torch.zeros(6, S, dtype=torch.int64)
-    for i, ln in enumerate([1, 74, 9, 17, 40, 30]):          # ln random ids between SOT and EOT; 74 fills every position
+    ids = torch.zeros(7, S, dtype=torch.int64)
+    for i, ln in enumerate([1, 74, 9, 17, 40, 30, 73]):      # ln random ids between SOT and EOT; 74 fills every position (the class token then sees itself:
+                                                              # twin row), 73 leaves exactly one pad position (which the class token attends instead of itself)
         ids[i, 0] = tarch.vocab - 2
         ids[i, 1:1 + ln] = torch.randint(1, tarch.vocab - 2, (ln,), generator=g)
         ids[i, 1 + ln] = tarch.vocab - 1
     tref = O.coca_text_forward(sd, tcfg, ids)
     tt = T.ClipTextTower(tarch, sd, "cuda")
-    assert tt.cfg.cls_pos == tarch.ctx - 1 and tt.cfg.vocab == tarch.vocab + 1
+    assert tt.cfg.cls_pos == tarch.ctx - 1 and tt.cfg.vocab == tarch.vocab + 2 and tt.cfg.enc.mask == L.MQ_MASK_CAUSAL_CLS
     tout = tt.encode_ids(ids)
-    assert tout.shape == (6, tarch.out_dim) and _cos_err(tout, tref) < COS_TIGHT
+    assert tout.shape == (7, tarch.out_dim) and _cos_err(tout, tref) < COS_TIGHT
+    # the mask matters: under the plain causal mask (the class token sees itself instead of the first pad position) the short texts move
+    plain = tt.cfg.enc.mask
+    try:
+        tt.cfg.enc.mask = L.MQ_MASK_CAUSAL
+        assert _cos_err(tt.encode_ids(ids)[[0, 2, 3]], tref[[0, 2, 3]]) > 10 * COS_TIGHT
+    finally:
+        tt.cfg.enc.mask = plain
     assert _cos_err(tt.encode_ids(ids[2:3]), tref[2:3]) < COS_TIGHT                         # single query
     lengths = ids.argmax(dim=1) + 1
     assert _cos_err(tt.encode_device(ids.to(torch.int32).cuda(), lengths), tref) < COS_TIGHT
