@@ -44,6 +44,7 @@ extern "C" {
 #define MQ_ERR_INVALID (-1)   /* bad argument / unsupported shape */
 #define MQ_ERR_HIP (-2)       /* a HIP runtime call or launch failed */
 #define MQ_ERR_WORKSPACE (-3) /* caller's workspace too small */
+#define MQ_ERR_UNSUPPORTED (-4) /* ABI 11: the device is not the one this library is built for (mq_check_device) */
 
 #define MQ_ABI_VERSION 11
 
@@ -257,6 +258,10 @@ int         mq_abi_version(void);
 const char* mq_last_error(void);
 /* name of the code object arch this library was built for ("gfx950") */
 const char* mq_build_arch(void);
+/* ABI 11 — MQ_OK when `device` (-1 = the current one) is what the kernels are laid out for: gfx950 with 256 CUs (one whole MI355X, 8 XCDs).  The
+ * persistent GEMM grids, the XCD-aware tile order and the in-kernel tail are sized for exactly that; a DPX / CPX partition or another part is
+ * refused (MQ_ERR_UNSUPPORTED) by every tiled GEMM launch and, earlier, by the Python loaders at load(). */
+int mq_check_device(int device);
 
 /* Host-side staging helper (no GPU work): copy n host buffers to h_dst + h_dst_off[i] with up to `threads` copy threads, in one call
  * (the Python loaders pack a request's decoded images into one pinned buffer this way: one GIL release per request). */

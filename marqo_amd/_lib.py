@@ -153,6 +153,7 @@ _SIGNATURES = {
     "mq_row_stats": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_float, _P]),
     "mq_row_stats_finalize": (C.c_int, [_P, C.c_int32, _P, C.c_int64, C.c_int32, C.c_float, _P]),
     "mq_gemm_bf16_rs": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, _P, _P]),
+    "mq_check_device": (C.c_int, [C.c_int]),
     "mq_gemm_band_counters": (C.c_int64, [C.c_int64]),
     "mq_gemm_bf16_rsf": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, _P, _P, C.c_float, _P,
                                    _P, C.c_size_t, _P, C.c_size_t, _P]),

@@ -40,6 +40,22 @@ class CopyPool {
             pending_ = n;
             ++epoch_;
         }
+        // From here on workers may be executing job(k), which lives in the CALLER's frame: whatever makes this function leave — normally, or by an
+        // exception of a mutex / of the job itself — it first withdraws the ranges nobody has claimed and waits for the claimed ones (a
+        // caller's catch(...) used to run while workers were still inside its job).
+        struct Drain {
+            CopyPool* p;
+            ~Drain() {
+                try {
+                    std::unique_lock<std::mutex> g(p->mu_);
+                    p->pending_ -= p->total_ - p->next_;
+                    p->next_ = p->total_;
+                    p->done_.wait(g, [this] { return p->pending_ <= 0; });
+                    p->job_ = nullptr;
+                } catch (...) {
+                }
+            }
+        } drain{this};
         wake_.notify_all();
         for (;;) {                                                // the caller takes ranges too (and all of them when no worker could be created)
             int k;
@@ -48,13 +64,16 @@ class CopyPool {
                 if (next_ >= total_) break;
                 k = next_++;
             }
-            job(k);
+            try {
+                job(k);
+            } catch (...) {
+                std::lock_guard<std::mutex> g(mu_);
+                --pending_;
+                throw;
+            }
             std::lock_guard<std::mutex> g(mu_);
             --pending_;
         }
-        std::unique_lock<std::mutex> g(mu_);
-        done_.wait(g, [this] { return pending_ == 0; });
-        job_ = nullptr;
     }
     void forget_threads() {                                        // in a fork()ed child: the parent's workers do not exist here
         new (&workers_) std::vector<std::thread>();

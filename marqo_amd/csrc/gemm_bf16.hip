@@ -39,6 +39,7 @@
 #include "gemm_loop.h"
 
 extern mq_knob mq_gemm_fp8_force_mt;  // gemm_fp8.hip
+extern mq_knob mq_gemm_fp8_big;       // gemm_fp8.hip: 0 = plan, 1 = never the big tile, 3 = always
 extern mq_knob mq_tower_row_select;   // towers.hip
 extern mq_knob mq_tower_ln_fold;      // towers.hip
 extern mq_knob mq_attention_waves;    // attention.hip
@@ -54,6 +55,8 @@ int mq_gemm_small(const void* d_A, int64_t lda, const void* d_W, int64_t ldw, co
 int mq_gemm_wd_launch(int flags, int mt, int ns, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* residual, void* out,
                       int64_t ldc, int M, int N, int K, int tiles_n, int num_tiles, int cgroup, int band_rows, int grid, int wide, unsigned a_bytes,
                       unsigned w_bytes, const GemmLn& ln, hipStream_t s);
+
+int mq_device_ok();   // runtime.hip
 
 namespace {
 
@@ -88,6 +91,7 @@ __global__ __launch_bounds__(128 * WM, (NH == 1 && WM == 2) ? 2 : 1) void gemm_n
     const float* __restrict__ bias, const float* residual, void* out, int64_t ldc,
     int M, int N, int K, int tiles_n, int num_tiles, int cgroup, int band_rows, int wide_store,
     unsigned a_bytes, unsigned w_bytes, GemmLn ln, GemmSk sk) {
+    static_assert(!(NH == 2 && WM == 2), "the 4-wave 224 x 256 tile (one wave per SIMD) lost on every shape (profiles/r05a, r05b) and was removed in round 6");
     constexpr int BM = 16 * MT * WM, BN = 128 * NH;
     constexpr bool TAIL = WM == 4;   // the big tile handles a ragged last row of tiles in-kernel (GemmSk)
     constexpr int NTW = 4 * NH;     // 16-column W sub-tiles per wave (a wave spans half of BN)
@@ -321,7 +325,7 @@ __global__ __launch_bounds__(128 * WM, (NH == 1 && WM == 2) ? 2 : 1) void gemm_n
         if (NH == 2 || WM == 4) asm volatile("" : "+v"(l15e), "+v"(ge));
         static_for<NH>([&](auto h_tag) {
             constexpr int h = decltype(h_tag)::value;
-            gemm_epilogue<FLAGS, MT, ERG, true, NH == 2 && WM == 2>(acc[h], bias, residual, out, ldc, M, N, cm0 + wm * (16 * MT), cn0 + wn * (16 * NTW) + h * 64, l15e, ge, wide_store != 0, &ln, nullptr);
+            gemm_epilogue<FLAGS, MT, ERG, true>(acc[h], bias, residual, out, ldc, M, N, cm0 + wm * (16 * MT), cn0 + wn * (16 * NTW) + h * 64, l15e, ge, wide_store != 0, &ln, nullptr);
         });
         if constexpr ((FLAGS & MQ_EPI_ROW_STATS) != 0) {
             // in-launch finalise of the row statistics (GemmLn::band_ctr): behind a workgroup's FIRST tile the carried weight prefetch goes out
@@ -401,7 +405,9 @@ __global__ __launch_bounds__(128 * WM, (NH == 1 && WM == 2) ? 2 : 1) void gemm_n
                     for (int e = 0; e < 4; ++e) __hip_atomic_store((float*)(dst + j * 64) + e, acc[h][i][j][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 dst += 256;
             });
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // my stores have left (vmcnt); no cache maintenance
+            // my (write-through, agent-scope) stores have been acknowledged before the flag goes out — as inline asm: the compiler may drop the wait
+            // of a fence whose scoreboard it believes empty (MI355X_MICROARCH.md, "Compiler hazard"); no cache maintenance needed for sc1 stores
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             if (tid == 0) {
                 __hip_atomic_store(sk.flags + blockIdx.x, sk.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -438,7 +444,7 @@ __global__ __launch_bounds__(128 * WM, (NH == 1 && WM == 2) ? 2 : 1) void gemm_n
 #pragma unroll
                     for (int e = 0; e < 4; ++e) piece[0][j][e] += __hip_atomic_load((const float*)(src + j * 64) + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            gemm_epilogue<FLAGS, 1, 1, false, false>(piece, bias, residual, out, ldc, M, N, cm0 + (region >> 1) * (16 * MT) + pi * 16,
+            gemm_epilogue<FLAGS, 1, 1, false>(piece, bias, residual, out, ldc, M, N, cm0 + (region >> 1) * (16 * MT) + pi * 16,
                                                      cn0 + (region & 1) * (16 * NTW) + ph * 64, l15e, ge, wide_store != 0, &ln, nullptr);
         }
     }
@@ -511,6 +517,12 @@ int sk_workspace(hipStream_t s, GemmSk& out) {
     int dev = 0;
     hipGetDevice(&dev);
     std::lock_guard<std::mutex> g(g_sk_mu);
+    // The tail's workgroups WAIT for each other: all 256 of a launch must be resident.  One stream's launches are ordered, so that holds; two tail
+    // launches on two streams could each hold part of the CUs and starve the other's unscheduled workgroups until the bounded spin gives up (the rows
+    // would then be wrong: ADVICE r5).  So the tail is refused — the ragged last row of tiles runs as ordinary tiles — from the moment a SECOND stream
+    // of this device asks for it.
+    for (const auto& kv : g_sk_ws)
+        if (kv.first.first == dev && kv.first.second != s && kv.second.partials) { out = GemmSk{}; return MQ_OK; }
     SkWorkspace& w = g_sk_ws[{dev, s}];
     if (!w.partials) {
         void* p = nullptr;
@@ -570,10 +582,12 @@ int launch_gemm_mt(const void* A, int64_t lda, const void* W, int64_t ldw, const
             const int nk = K / BK;
             if (g_tune.tail && m % BM != 0 && m >= BM && tiles_n <= SLOTS && MT * NH == 8) {
                 if (int rc = sk_workspace(s, sk); rc != MQ_OK) return rc;
-                int S = 8;                                         // ranges per tail tile: a power of two <= 8 (the tile's 8 regions are shared out over them)
-                while (S > 1 && (S * tiles_n > SLOTS || S > nk)) S >>= 1;
-                sk.tail_splits = S;
-                tiles_m = m / BM;
+                if (sk.partials) {                                 // (nullptr: refused — a second stream of this device uses the tail)
+                    int S = 8;                                     // ranges per tail tile: a power of two <= 8 (the tile's 8 regions are shared out over them)
+                    while (S > 1 && (S * tiles_n > SLOTS || S > nk)) S >>= 1;
+                    sk.tail_splits = S;
+                    tiles_m = m / BM;
+                }
             }
         }
         const int num_tiles = tiles_m * tiles_n;
@@ -626,8 +640,7 @@ int launch_gemm_mt(const void* A, int64_t lda, const void* W, int64_t ldw, const
 // ViT-L/14 fc2 at large batches); the towers' other GEMMs stay on the narrow tile.
 // mq_tune("gemm_nh", 3) forces the big tile on every row (N >= 256), 4 = the row-split plan without the long-K / 8 % restriction (the A/B above),
 // 1 forbids it, 0 = the default plan.
-// (The 4-wave 224 x 256 tile, NH = 2 / WM = 2 — one wave per SIMD — lost on every shape, profiles/r05a, r05b: it is not instantiated any more; the
-// template still takes it and tests/test_gemm_isa.py still checks its ISA.)
+// (The 4-wave 224 x 256 tile, NH = 2 / WM = 2 — one wave per SIMD — lost on every shape, profiles/r05a, r05b: removed in round 6, the template refuses it.)
 constexpr double BIG_TILE_SPEEDUP = 1.12;   // k-loop advantage priced into the plan (measured 1.14-1.18 at full rounds)
 
 // rows (a multiple of 256, 0 = none) the big tile should take of an M x N x K problem
@@ -673,6 +686,7 @@ int plan_big_rows(int M, int N, int K) {
 template <int FLAGS>
 int launch_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* residual, void* out, int64_t ldc,
                 int M, int N, int K, hipStream_t s, const GemmLn& ln = GemmLn{}) {
+    MQ_TRY(mq_device_ok());   // 256 CUs in 8 XCDs or nothing (runtime.hip)
     const int big_rows = plan_big_rows(M, N, K);
     if (big_rows >= M) return launch_gemm_mt<FLAGS, 4, 2, 2, 4>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s, ln);
     if (big_rows > 0) {
@@ -841,7 +855,7 @@ extern "C" int mq_tune(const char* key, int value) {
     const std::string k(key);
     if (k == "gemm_mt") { g_tune.mt = value; mq_gemm_fp8_force_mt = value; }
     else if (k == "gemm_cgroup") { g_tune.cgroup = value; mq_gemm_knob_cgroup = value; }
-    else if (k == "gemm_nh") g_tune.nh = value;
+    else if (k == "gemm_nh") { g_tune.nh = value; mq_gemm_fp8_big = value == 4 ? 0 : value; }
     else if (k == "gemm_tail") g_tune.tail = value;
     else if (k == "gemm_wd") g_tune.wd = value;
     else if (k == "rs_finalize") g_tune.rs_fin = value;

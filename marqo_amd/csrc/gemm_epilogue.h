@@ -95,10 +95,7 @@ __device__ __forceinline__ void gemm_band_arrive(const GemmLn& ln, int band, int
 // the next tile in flight here, so hipcc cannot count past them: without the explicit wait it re-waits vmcnt(0) at the first use of the
 // bias in every row group — draining the row groups' own stores one after the other — and, seeing the fragment registers as possibly
 // pending load destinations, puts another vmcnt(0) into the k-loop.
-// FENCE_ROWS (the wide tile, whose 256 accumulators live in AGPRs): a scheduling fence behind every 16-row group, so that the copies out of the
-// accumulator file are made group by group — left alone, the scheduler hoists all of a half's 128 v_accvgpr_read in front of the first store
-// and the kernel spills.
-template <int FLAGS, int MT, int RG = MT, bool WAIT_LOADS = false, bool FENCE_ROWS = false>
+template <int FLAGS, int MT, int RG = MT, bool WAIT_LOADS = false>
 __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][4], const float* __restrict__ bias, const float* residual, void* out,
                                               int64_t ldc, int M, int N, int wave_m0, int wave_n0, int l15, int g, bool wide = false,
                                               const GemmLn* lnp = nullptr, const float* lds_bias = nullptr) {
@@ -245,6 +242,5 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][4], const float* 
                 __hip_atomic_store((unsigned long long*)(lnp->partials + (int64_t)m * lnp->nslots + (wave_n0 >> 6)),
                                    (unsigned long long)__float_as_uint(st1) | ((unsigned long long)__float_as_uint(st2) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (FENCE_ROWS) __builtin_amdgcn_sched_barrier(0);
     }
 }

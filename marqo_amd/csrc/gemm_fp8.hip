@@ -30,14 +30,17 @@ typedef int i32x8 __attribute__((ext_vector_type(8)));
 
 // scheduling knobs shared with gemm_bf16.hip (mq_tune "gemm_cgroup"; the widened epilogue stores are always on)
 extern mq_knob mq_gemm_knob_cgroup, mq_gemm_knob_wide;
+int mq_device_ok();   // runtime.hip
 extern std::atomic<uint64_t> mq_gemm_addr_limit;   // gemm_bf16.hip: bytes one launch may address per operand (4 GiB - 1; tests lower it)
+
+mq_knob mq_gemm_fp8_big{getenv("MQ_GEMM_FP8_NH") ? atoi(getenv("MQ_GEMM_FP8_NH")) : 0};   // mq_tune("gemm_nh", v) sets it too (gemm_bf16.hip)
 
 namespace {
 
-constexpr int BN = 128, BK = 128;          // BK in fp8 elements == bytes
-constexpr int W_TILE_BYTES = BN * BK;      // 16 KiB
+constexpr int BK = 128;                    // BK in fp8 elements == bytes
 constexpr int UNIT_SCALE = 0x7F7F7F7F;     // e8m0 127 = 2^0 in every byte
 constexpr int RESIDENT_SLOTS = 512;        // 256 CUs x 2 workgroups
+constexpr int RESIDENT_SLOTS_BIG = 256;    // the 8-wave 256 x 256 tile: one workgroup per CU
 
 typedef int i32x4_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void_t;
@@ -77,16 +80,23 @@ __device__ __forceinline__ float clamp448(float v) { return fminf(fmaxf(v, -448.
 // the per-tile overheads weigh even more than in the bf16 kernel).  Widened stores: bf16 out -> 16 B per lane after one v_permlane16_swap per
 // pair; e4m3 out -> a lane's 4 codes per sub-tile become 16 CONSECUTIVE codes after a permlane16 stage (pairs of sub-tiles) and a permlane32
 // stage (the two pairs), i.e. one 16-byte store per 16-row sub-tile instead of four 4-byte ones.
-template <int FLAGS, int MT, bool ROWSCALE>
-__global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(
+// NH / WM (round 6): the tile shapes of gemm_bf16.hip.  NH = 1, WM = 2: the (32 MT) x 128 tiles, 4 waves as 2 x 2, two workgroups per CU.  NH = 2, WM = 4, MT = 4:
+// the BIG tile, 256 x 256 x 128 as 8 waves (4 x 2, 64 x 128 per wave: 8 W sub-tiles), one workgroup per CU, two waves per SIMD — half the LDS-DMA
+// and vector-memory bytes per MFMA (64 KB per 2 048 MFMA cycles where two 160 x 128 workgroups move 72 KB per 1 280).  Same k-step: the halves are
+// the W side (NTW / 2 sub-tiles each), same staging, swizzle, waits and epilogue (once per 64-column half of the wave's columns).
+template <int FLAGS, int MT, bool ROWSCALE, int NH = 1, int WM = 2>
+__global__ __launch_bounds__(128 * WM, (NH == 1 && WM == 2) ? 2 : 1) void gemm_fp8_kernel(
     const uint8_t* __restrict__ A, int64_t lda, const uint8_t* __restrict__ Wt, int64_t ldw,
     const float* __restrict__ a_scale, const float* __restrict__ w_scale,
     const float* __restrict__ bias, const float* residual, void* out, int64_t ldc,
     const float* __restrict__ out_scale, float* amax_out,
     int M, int N, int K, int tiles_n, int num_tiles, int cgroup, int band_rows, int wide, unsigned a_bytes, unsigned w_bytes) {
-    constexpr int BM = 32 * MT;
-    constexpr int A_TILE_BYTES = BM * BK;
+    constexpr int BM = 16 * MT * WM, BN = 128 * NH;
+    constexpr int NTW = 4 * NH;                 // 16-column W sub-tiles per wave (a wave spans half of BN)
+    constexpr int HW = NTW / 2;                 // ... per half of the k-step
+    constexpr int A_TILE_BYTES = BM * BK, W_TILE_BYTES = BN * BK;
     constexpr int STAGE_BYTES = A_TILE_BYTES + W_TILE_BYTES;
+    constexpr int NPW = 8 * NH / WM;            // W pieces (8 rows x 128 B) per wave per stage: BN / (2 WM) rows
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int q = num_tiles >> 3, r = num_tiles & 7;
@@ -113,8 +123,8 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(
         n0 = tn * BN;
     };
 
-    constexpr int NL = MT + 4;     // LDS-DMA pieces (8 rows x 128 B) per wave per stage
-    constexpr int NB = 2 * MT;     // MFMAs per wave per half
+    constexpr int NL = MT + NPW;   // LDS-DMA pieces (8 rows x 128 B) per wave per stage
+    constexpr int NB = HW * MT;    // MFMAs per wave per half
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -124,7 +134,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(
     // ---- staging: wave w owns A rows [8*MT*w, 8*MT*(w+1)) and W rows [32w, 32w+32) of a stage; lane -> (row = base + lane/8, physical 16-B
     // chunk = lane%8), it fetches logical chunk (lane%8) ^ f(row): the swizzle lives on the SOURCE address, the LDS image is lane-linear
     const int srow = lane >> 3;
-    unsigned a_vo[MT], w_vo[4];
+    unsigned a_vo[MT], w_vo[NPW];
     auto set_sources = [&](int m0, int n0) {
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
@@ -133,8 +143,8 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(
             a_vo[i] = (unsigned)gm * (unsigned)lda + (unsigned)(((lane & 7) ^ fswz(row)) * 16);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = wave * 32 + i * 8 + srow;
+        for (int i = 0; i < NPW; ++i) {
+            const int row = wave * (8 * NPW) + i * 8 + srow;
             int gn = n0 + row; gn = gn < N ? gn : N - 1;
             w_vo[i] = (unsigned)gn * (unsigned)ldw + (unsigned)(((lane & 7) ^ fswz(row)) * 16);
         }
@@ -150,7 +160,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(
         set_sources(m0, n0);
     }
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    const unsigned dma_a0 = lds0 + (unsigned)wave * (8 * MT * 128), dma_w0 = lds0 + A_TILE_BYTES + (unsigned)wave * (32 * 128);   // scalars
+    const unsigned dma_a0 = lds0 + (unsigned)wave * (8 * MT * 128), dma_w0 = lds0 + A_TILE_BYTES + (unsigned)wave * (8 * NPW * 128);   // scalars
     auto issue_piece = [&](int i, unsigned bufoff) {
         const unsigned soff = (unsigned)d_k * BK;
         if (i < MT) dma16(__builtin_amdgcn_make_buffer_rsrc((void*)A, 0, a_rec, 0x00020000), a_vo[i < MT ? i : 0], soff, dma_a0 + bufoff + (unsigned)i * 1024u);
@@ -175,11 +185,11 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(
     const int fr = fswz(l15);
     const unsigned c0 = (unsigned)(((2 * g) ^ fr) << 4), c1 = (unsigned)(((2 * g + 1) ^ fr) << 4);
     const unsigned a_row = lds0 + (unsigned)((wm * (16 * MT) + l15) * 128);
-    const unsigned w_row = lds0 + A_TILE_BYTES + (unsigned)((wn * 64 + l15) * 128);
+    const unsigned w_row = lds0 + A_TILE_BYTES + (unsigned)((wn * (16 * NTW) + l15) * 128);
     const unsigned aB0 = a_row + c0, aB1 = a_row + c1, wB0 = w_row + c0, wB1 = w_row + c1;
 
-    f32x4 acc[MT][4];
-    i32x8 af[MT], wf[4];
+    f32x4 acc[NH][MT][4];
+    i32x8 af[MT], wf[NTW];
     const float a_scalar = ROWSCALE ? 1.f : a_scale[0];
     const float inv_out = (FLAGS & MQ_EPI_OUT_FP8) ? 1.0f / out_scale[0] : 1.f;
     float amax = 0.f;
@@ -203,21 +213,24 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(
     // after the epilogue instead: one exposed LDS latency per tile.
     auto kstep = [&](auto last_tag) {
         constexpr bool LAST = decltype(last_tag)::value;
-        // -------- half A: MFMAs (mt, nt = 0 | 1); reads of this stage's W sub-tiles 2, 3 between them
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // af[*], wf[0], wf[1] landed
-        landed(wf[0]); landed(wf[1]);
+        // -------- half A: MFMAs (mt, nt < HW); reads of this stage's W sub-tiles HW .. NTW - 1 between them
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // af[*], wf[0 .. HW) landed
+#pragma unroll
+        for (int t = 0; t < HW; ++t) landed(wf[t]);
 #pragma unroll
         for (int t = 0; t < MT; ++t) landed(af[t]);
         __builtin_amdgcn_sched_barrier(0);
         {
             const unsigned b0 = wB0 + bufoff, b1 = wB1 + bufoff;
             static_for<NB>([&](auto idx_tag) {
-                constexpr int idx = decltype(idx_tag)::value, mt = idx / 2, nt = idx % 2;
-                acc[mt][nt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[nt], af[mt], acc[mt][nt], 0, 0, 0, UNIT_SCALE, 0, UNIT_SCALE);
-                if constexpr (idx == 0 || idx == (NB > 2 ? 2 : 1)) {
+                constexpr int idx = decltype(idx_tag)::value, mt = idx / HW, nt = idx % HW;
+                acc[nt / 4][mt][nt % 4] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[nt], af[mt], acc[nt / 4][mt][nt % 4], 0, 0, 0, UNIT_SCALE, 0, UNIT_SCALE);
+                // read r of the second half's HW sub-tiles goes behind MFMA r * RPOS (NH = 1: behind MFMAs 0 and 2, as before)
+                constexpr int RPOS = NB > HW ? 2 : 1;
+                if constexpr (idx % RPOS == 0 && idx / RPOS < HW) {
+                    constexpr int r = HW + idx / RPOS;
                     __builtin_amdgcn_sched_barrier(0);
-                    if constexpr (idx == 0) wf[2] = lds_read32<2 * 2048>(b0, b1);
-                    else wf[3] = lds_read32<3 * 2048>(b0, b1);
+                    wf[r] = lds_read32<r * 2048>(b0, b1);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             });
@@ -227,36 +240,43 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(
         // (the two halves write DIFFERENT accumulators: nothing but these empty asms keeps half A's MFMAs — pure, results unused until the next
         // k-step — in front of the barrier; without them the optimiser sank all 4 MT MFMAs into the loop latch, behind every wait and read)
 #pragma unroll
-        for (int t = 0; t < MT; ++t) { landed(acc[t][0]); landed(acc[t][1]); }
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int nt = 0; nt < HW; ++nt) landed(acc[nt / 4][t][nt % 4]);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) — as a builtin: the compiler's own scoreboard must see that nothing is pending
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        landed(wf[2]); landed(wf[3]);
+#pragma unroll
+        for (int t = HW; t < NTW; ++t) landed(wf[t]);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        // -------- half B: MFMAs (mt, nt = 2 | 3); behind MFMA idx: LDS-DMA piece idx of the stage after next (the rest behind the last one);
-        // behind idx 0 / 2 the next stage's W sub-tiles 0 / 1; behind a row group's second MFMA the next stage's A fragment of that row group
+        // -------- half B: MFMAs (mt, nt >= HW); behind MFMA idx: LDS-DMA piece idx of the stage after next (the rest behind the last one);
+        // behind the first MFMAs of the first row groups the next stage's W sub-tiles 0 .. HW - 1; behind a row group's LAST MFMA the next stage's
+        // A fragment of that row group (into the same registers: an MFMA has read its operands long before a ds_read issued behind it returns)
         {
             const unsigned nb = bufoff ^ (unsigned)STAGE_BYTES;
             const unsigned nw0 = wB0 + nb, nw1 = wB1 + nb, na0 = aB0 + nb, na1 = aB1 + nb;
             static_for<NB>([&](auto idx_tag) {
-                constexpr int idx = decltype(idx_tag)::value, mt = idx / 2, nt = 2 + idx % 2;
-                acc[mt][nt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[nt], af[mt], acc[mt][nt], 0, 0, 0, UNIT_SCALE, 0, UNIT_SCALE);
+                constexpr int idx = decltype(idx_tag)::value, mt = idx / HW, nt = HW + idx % HW;
+                acc[nt / 4][mt][nt % 4] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[nt], af[mt], acc[nt / 4][mt][nt % 4], 0, 0, 0, UNIT_SCALE, 0, UNIT_SCALE);
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (idx < NL) issue_piece(idx, bufoff);
                 if constexpr (idx == NB - 1) {
 #pragma unroll
                     for (int i = NB; i < NL; ++i) issue_piece(i, bufoff);
                 }
-                if constexpr (!LAST && idx == 0) wf[0] = lds_read32<0>(nw0, nw1);
-                if constexpr (!LAST && idx == (NB > 2 ? 2 : 1)) wf[1] = lds_read32<2048>(nw0, nw1);
-                if constexpr (!LAST && idx % 2 == 1) af[mt] = lds_read32<mt * 2048>(na0, na1);
+                // next stage's W sub-tile r (< HW) behind MFMA r * WSTEP: wf[r] was last used in half A
+                constexpr int RPOS = NB > HW ? 2 : 1;
+                if constexpr (!LAST && idx % RPOS == 0 && idx / RPOS < HW) wf[idx / RPOS] = lds_read32<(idx / RPOS) * 2048>(nw0, nw1);
+                if constexpr (!LAST && idx % HW == HW - 1) af[mt] = lds_read32<mt * 2048>(na0, na1);
                 __builtin_amdgcn_sched_barrier(0);
             });
         }
 #pragma unroll
-        for (int t = 0; t < MT; ++t) { landed(acc[t][2]); landed(acc[t][3]); }
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int nt = HW; nt < NTW; ++nt) landed(acc[nt / 4][t][nt % 4]);
         advance_cursor();
         bufoff ^= (unsigned)STAGE_BYTES;
     };
@@ -265,15 +285,16 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(
         int cm0, cn0;
         tile_origin(c_vbid, cm0, cn0);
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+        for (int h = 0; h < NH; ++h)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[h][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         // the tile's first stage is in LDS and visible (the prologue's barrier / the previous tile's last mid-step barrier): its A fragments and W
         // sub-tiles 0, 1
         {
             const unsigned w0 = wB0 + bufoff, w1 = wB1 + bufoff, a0 = aB0 + bufoff, a1 = aB1 + bufoff;
-            wf[0] = lds_read32<0>(w0, w1);
-            wf[1] = lds_read32<2048>(w0, w1);
+            static_for<HW>([&](auto t_tag) { constexpr int t = decltype(t_tag)::value; wf[t] = lds_read32<t * 2048>(w0, w1); });
             static_for<MT>([&](auto t_tag) { constexpr int t = decltype(t_tag)::value; af[t] = lds_read32<t * 2048>(a0, a1); });
         }
         for (int kt = 0; kt < nk - 1; ++kt) kstep(std::false_type{});
@@ -282,7 +303,10 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(
         // ---- epilogue: lane owns out[m][n .. n+3]; dequantise with a_scale[m] * w_scale[n] ----------------------------
         // everything the epilogue READS is fetched up front (residual tile first): left inside the (mt, nt) loop every
         // sub-tile's scale / bias / residual load was waited for on its own (gemm_epilogue.h, tools/probes/gemm_trace.py)
-        const int wave_n0 = cn0 + wn * 64;
+        static_for<NH>([&](auto h_tag) {
+        constexpr int hh = decltype(h_tag)::value;
+        f32x4 (&acch)[MT][4] = acc[hh];
+        const int wave_n0 = cn0 + wn * (16 * NTW) + hh * 64;
         asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);  // keep the prefetch below the k-loop: hoisted into it, it collides with the fragments' registers
         // (the residual tile is prefetched in 2-3 groups of the tile's rows: the whole 160-row tile next to the e4m3 fragments'
@@ -327,7 +351,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(
         // past them and would otherwise re-wait vmcnt(0) at the first use in every row group (gemm_epilogue.h, WAIT_LOADS)
         __builtin_amdgcn_s_waitcnt(0x0F70);
         auto value = [&](int mt, int nt, int m, int n, bool ok, float sa) {
-            f32x4 v = acc[mt][nt];
+            f32x4 v = acch[mt][nt];
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] *= sa * sw_v[nt][e];
             if (FLAGS & MQ_EPI_BIAS) v += bias_v[nt];
@@ -427,6 +451,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(
                 }
             }
         }
+        });
         c_vbid += gridDim.x;
         if (c_vbid >= num_tiles) break;
     }
@@ -439,10 +464,17 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(
 }
 
 #ifdef MQ_GEMM_PROBE   // compile-and-inspect builds (tests/test_gemm_isa.py): ONE instantiation
-__attribute__((used)) void* mq_gemm_fp8_probe() { return (void*)gemm_fp8_kernel<MQ_GEMM_PROBE, MQ_GEMM_PROBE_MT, (MQ_GEMM_PROBE_ROWSCALE != 0)>; }
+#ifndef MQ_GEMM_PROBE_NH
+#define MQ_GEMM_PROBE_NH 1
+#endif
+#ifndef MQ_GEMM_PROBE_WM
+#define MQ_GEMM_PROBE_WM 2
+#endif
+__attribute__((used)) void* mq_gemm_fp8_probe() { return (void*)gemm_fp8_kernel<MQ_GEMM_PROBE, MQ_GEMM_PROBE_MT, (MQ_GEMM_PROBE_ROWSCALE != 0), MQ_GEMM_PROBE_NH, MQ_GEMM_PROBE_WM>; }
 }  // namespace
 #else
 int choose_mt(int M, int N) {
+    constexpr int BN = 128;
     const int tiles_n = (N + BN - 1) / BN;
     const int cands[4] = {2, 4, 5, 6};
     int best = 4;
@@ -462,12 +494,13 @@ struct Fp8Args {
     const float* residual; void* out; int64_t ldc; const float* out_scale; float* amax; int M, N, K;
 };
 
-template <int FLAGS, int MT, bool ROWSCALE>
+template <int FLAGS, int MT, bool ROWSCALE, int NH = 1, int WM = 2>
 int launch_fp8_mt(const Fp8Args& a, hipStream_t s) {
-    constexpr int BM = 32 * MT;
-    constexpr int LDS = 2 * (BM * BK + W_TILE_BYTES);
+    constexpr int BM = 16 * MT * WM, BN = 128 * NH;
+    constexpr int LDS = 2 * (BM + BN) * BK;
+    constexpr int SLOTS = (NH == 1 && WM == 2) ? RESIDENT_SLOTS : RESIDENT_SLOTS_BIG;
     static std::atomic<uint64_t> attr_done{0};
-    if (hipError_t e = mq_ensure_dyn_lds((const void*)gemm_fp8_kernel<FLAGS, MT, ROWSCALE>, LDS, attr_done); e != hipSuccess) {
+    if (hipError_t e = mq_ensure_dyn_lds((const void*)gemm_fp8_kernel<FLAGS, MT, ROWSCALE, NH, WM>, LDS, attr_done); e != hipSuccess) {
         mq_set_error("mq_gemm_fp8: hipFuncSetAttribute: %s", hipGetErrorString(e));
         return MQ_ERR_HIP;
     }
@@ -498,9 +531,9 @@ int launch_fp8_mt(const Fp8Args& a, hipStream_t s) {
         const int knob_cgroup = mq_gemm_knob_cgroup;
         const int cgroup = (knob_cgroup > 0 && tiles_n > knob_cgroup && tiles_m >= 16) ? knob_cgroup : 0;
         const int band_rows = (tiles_m + 7) / 8;
-        const int grid = num_tiles > RESIDENT_SLOTS ? RESIDENT_SLOTS : num_tiles;
+        const int grid = num_tiles > SLOTS ? SLOTS : num_tiles;
         const uint64_t a_bytes = (uint64_t)(m - 1) * (uint64_t)a.lda + (uint64_t)a.K;
-        hipLaunchKernelGGL((gemm_fp8_kernel<FLAGS, MT, ROWSCALE>), dim3(grid), dim3(256), LDS, s, (const uint8_t*)a.A + r0 * a.lda, a.lda,
+        hipLaunchKernelGGL((gemm_fp8_kernel<FLAGS, MT, ROWSCALE, NH, WM>), dim3(grid), dim3(128 * WM), LDS, s, (const uint8_t*)a.A + r0 * a.lda, a.lda,
                            (const uint8_t*)a.W, a.ldw, ROWSCALE ? a.a_scale + r0 : a.a_scale, a.w_scale, a.bias,
                            a.residual ? (const float*)((const char*)a.residual + (size_t)r0 * res_row) : nullptr, (void*)((char*)a.out + (size_t)r0 * out_row),
                            a.ldc, a.out_scale, a.amax, m, a.N, a.K, tiles_n, num_tiles, cgroup, band_rows, wide, (unsigned)a_bytes, (unsigned)w_bytes);
@@ -509,8 +542,25 @@ int launch_fp8_mt(const Fp8Args& a, hipStream_t s) {
     return MQ_OK;
 }
 
+// The BIG tile (192 x 256 x 128, 8 waves; MT = 3: the 256-row form needs 274 registers, this one 232-242) takes a problem whose tiles fill the chip's
+// 256 workgroups for at least two rounds at >= 85 % fill, whose columns fill their last 256-wide tile and whose K is long (>= 2 048: the ViT-L/14 fc2
+// at >= 128 images, square GEMMs of the C ABI); everything else stays on the (32 MT) x 128 tiles.  mq_tune("gemm_nh", 1) forbids it, 3 forces it wherever N >= 256.
+bool plan_fp8_big(int M, int N, int K) {
+    const int nh = mq_gemm_fp8_big;
+    if (nh == 1 || N < 256) return false;
+    if (nh == 3) return true;
+    const int tiles_n = (N + 255) / 256;
+    if ((double)N / (tiles_n * 256.0) < 0.9) return false;
+    const int64_t tiles = (int64_t)((M + 191) / 192) * tiles_n;
+    const int64_t rounds = (tiles + RESIDENT_SLOTS_BIG - 1) / RESIDENT_SLOTS_BIG;
+    // measured (profiles/r06e_fp8_big_tile_ab.txt): -17 % at 8192^3 (2.13 -> 2.56 PF), -5 ... -9 % on the ViT-L/14 fc2 (K = 4 096) at 128 / 240 images; at
+    // K = 1 024 the tile's un-overlapped prologue / epilogue (one workgroup per CU) costs more than its k-loop saves (+1 ... +20 %): long K only
+    return K >= 2048 && rounds >= 2 && (double)tiles / (double)(rounds * RESIDENT_SLOTS_BIG) >= 0.85;
+}
+
 template <int FLAGS, bool ROWSCALE>
 int launch_fp8(const Fp8Args& a, int force_mt, hipStream_t s) {
+    if (!force_mt && plan_fp8_big(a.M, a.N, a.K)) return launch_fp8_mt<FLAGS, 3, ROWSCALE, 2, 4>(a, s);
     const int mt = force_mt ? force_mt : choose_mt(a.M, a.N);
     switch (mt) {
         case 2: return launch_fp8_mt<FLAGS, 2, ROWSCALE>(a, s);
@@ -562,6 +612,7 @@ extern "C" int mq_gemm_fp8(const void* d_A8, int64_t lda, const void* d_W8, int6
     MQ_CHECK_ARG(!(flags & MQ_EPI_BIAS) || d_bias, "mq_gemm_fp8: MQ_EPI_BIAS without bias");
     MQ_CHECK_ARG(!(flags & MQ_EPI_RESIDUAL) || d_residual, "mq_gemm_fp8: MQ_EPI_RESIDUAL without residual");
     MQ_CHECK_ARG(!(flags & MQ_EPI_OUT_FP8) || d_out_scale, "mq_gemm_fp8: MQ_EPI_OUT_FP8 without out_scale");
+    MQ_TRY(mq_device_ok());   // 256 CUs in 8 XCDs or nothing (runtime.hip)
     hipStream_t s = (hipStream_t)stream;
     MqProfScope prof(0, s, 2.0 * (double)M * (double)N * (double)K);
     const Fp8Args a{d_A8, lda, d_W8, ldw, d_a_scale, d_w_scale, d_bias, d_residual, d_out, ldc, d_out_scale, d_amax, (int)M, (int)N, (int)K};

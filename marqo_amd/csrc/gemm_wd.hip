@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wd_kernel(
 #pragma unroll
         for (int t = 0; t < MT; ++t) landed(af0[t]);
 
-        gemm_epilogue<FLAGS, MT, ERG, true, false>(acc, bias, residual, out, ldc, M, N, cm0 + wm * (16 * MT), cn0 + wn * 64, l15, g, wide_store != 0, &ln, nullptr);
+        gemm_epilogue<FLAGS, MT, ERG, true>(acc, bias, residual, out, ldc, M, N, cm0 + wm * (16 * MT), cn0 + wn * 64, l15, g, wide_store != 0, &ln, nullptr);
 
         c_vbid += gridDim.x;
         if (c_vbid >= num_tiles) break;

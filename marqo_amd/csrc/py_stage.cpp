@@ -170,9 +170,14 @@ PyObject* gather_rgbx(PyObject*, PyObject* args) {
         // No C++ exception may unwind through this CPython frame (the GIL is released: it would end in std::terminate): whatever the range setup
         // or the pool throws (bad_alloc, a system_error from a mutex) falls back to a serial copy of everything — memcpy is idempotent, ranges a
         // worker already copied are simply copied again.
+        // (`ranges` and `job` live OUTSIDE the try: the pool's workers run `job` — CopyPool::run does not return, not even by an exception, while one
+        // of them is inside it, and the fallback below must not find them destroyed)
+        std::vector<std::pair<size_t, size_t>> ranges;
+        const std::function<void(int)> job = [&](int r) {
+            for (size_t k = ranges[r].first; k < ranges[r].second; ++k) memcpy(dst + items[k].dst_off, items[k].src, (size_t)items[k].bytes);
+        };
         try {
             // ranges of about equal bytes, whole images each
-            std::vector<std::pair<size_t, size_t>> ranges;
             {
                 const int64_t share = (total + t - 1) / t;
                 size_t lo = 0;
@@ -186,9 +191,6 @@ PyObject* gather_rgbx(PyObject*, PyObject* args) {
                     }
                 }
             }
-            const std::function<void(int)> job = [&](int r) {
-                for (size_t k = ranges[r].first; k < ranges[r].second; ++k) memcpy(dst + items[k].dst_off, items[k].src, (size_t)items[k].bytes);
-            };
             mq_copy_pool().run((int)ranges.size(), job);
         } catch (...) {
             for (size_t k = 0; k < items.size(); ++k) memcpy(dst + items[k].dst_off, items[k].src, (size_t)items[k].bytes);

@@ -1,6 +1,7 @@
 #include <stdlib.h>
 // Library-wide host plumbing: thread-local error text, ABI/arch info, per-family launch timing.
 #include <stdarg.h>
+#include <string.h>
 #include <mutex>
 #include <vector>
 #include "common.h"
@@ -19,6 +20,34 @@ extern "C" const char* mq_last_error(void) { return g_err; }
 extern "C" int mq_abi_version(void) { return MQ_ABI_VERSION; }
 mq_knob mq_xcd_band{getenv("MQ_XCD_BAND") ? atoi(getenv("MQ_XCD_BAND")) : 1};   // row-wise kernels follow the GEMMs' XCD banding (common.h)
 extern "C" const char* mq_build_arch(void) { return "gfx950"; }
+
+// ---- the device this library was written for -------------------------------------------------------------------------------------------------
+// The persistent GEMM grids, the XCD-aware tile order and the in-kernel tail count on 256 CUs in 8 XCDs (an MI355X in SPX mode); a partitioned
+// (DPX / CPX) or different device would silently mis-tile or strand the tail's workgroups — refuse it loudly instead.  mq_check_device(-1) = the
+// current device.  The tiled GEMM launchers call mq_device_ok() (cached per device ordinal).
+extern "C" int mq_check_device(int device) {
+    int dev = device;
+    if (dev < 0) MQ_CHECK_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    MQ_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+    const bool arch_ok = strncmp(prop.gcnArchName, "gfx950", 6) == 0;
+    if (!arch_ok || prop.multiProcessorCount != 256) {
+        mq_set_error("libmarqo_hip is built for one whole MI355X (gfx950, 256 CUs in 8 XCDs); device %d is %s with %d CUs (a DPX / CPX partition?)", dev,
+                     prop.gcnArchName, prop.multiProcessorCount);
+        return MQ_ERR_UNSUPPORTED;
+    }
+    return MQ_OK;
+}
+int mq_device_ok() {
+    static std::atomic<uint64_t> checked{0};
+    int dev = 0;
+    MQ_CHECK_HIP(hipGetDevice(&dev));
+    const uint64_t bit = 1ull << (dev & 63);
+    if (checked.load(std::memory_order_acquire) & bit) return MQ_OK;
+    MQ_TRY(mq_check_device(dev));
+    checked.fetch_or(bit, std::memory_order_release);
+    return MQ_OK;
+}
 
 // ---- profiling -----------------------------------------------------------------------------
 namespace {
@@ -96,8 +125,9 @@ extern "C" int mq_host_gather(const void* const* h_src, const int64_t* h_bytes, 
     if (t == 1) { work(0, n); return MQ_OK; }
     // contiguous item ranges of about total / t bytes each, copied by the kept worker threads + the calling thread (copy_pool.h; a worker that
     // cannot be created — pid / thread limits of a container — just means the calling thread copies more)
+    std::vector<std::pair<int64_t, int64_t>> ranges;   // (outside the try: the workers run `job` over them, see CopyPool::run)
+    const std::function<void(int)> job = [&](int r) { work(ranges[r].first, ranges[r].second); };
     try {
-        std::vector<std::pair<int64_t, int64_t>> ranges;
         int64_t lo = 0, acc = 0;
         const int64_t share = (total + t - 1) / t;
         for (int64_t i = 0; i < n; ++i) {
@@ -108,7 +138,6 @@ extern "C" int mq_host_gather(const void* const* h_src, const int64_t* h_bytes, 
                 acc = 0;
             }
         }
-        const std::function<void(int)> job = [&](int r) { work(ranges[r].first, ranges[r].second); };
         mq_copy_pool().run((int)ranges.size(), job);
     } catch (...) {   // (allocation failure while setting up: nothing was copied by halves that matter — copy everything here)
         work(0, n);

@@ -39,6 +39,9 @@ def _env_int(name: str, default: int, lo: int = 1) -> int:
     return v if v >= lo else default
 
 
+_checked_devices: set = set()
+
+
 def _require_gpu(device: str) -> torch.device:
     if not str(device).startswith("cuda"):
         raise L.MarqoHipUnavailableError(
@@ -48,7 +51,15 @@ def _require_gpu(device: str) -> torch.device:
         raise L.MarqoHipUnavailableError("no GPU is visible to PyTorch-ROCm; the marqo_amd engine has no CPU fallback")
     d = torch.device(device)
     # 'cuda' -> 'cuda:<current>': tensors report an indexed device, and the towers compare devices
-    return d if d.index is not None else torch.device("cuda", torch.cuda.current_device())
+    d = d if d.index is not None else torch.device("cuda", torch.cuda.current_device())
+    # the kernels' grids and tile orders are laid out for ONE whole MI355X (gfx950, 256 CUs in 8 XCDs): anything else is refused at load
+    # (mq_check_device; the tiled GEMM launchers check again for callers of the C ABI)
+    if d.index not in _checked_devices:
+        lib = L.load()
+        if lib.mq_check_device(int(d.index)) != L.MQ_OK:
+            raise L.MarqoHipUnavailableError(lib.mq_last_error().decode())
+        _checked_devices.add(d.index)
+    return d
 
 
 class _Holder:

@@ -144,16 +144,6 @@ def test_asm_fragment_reads_are_waited_for_before_any_use(tmp_path, flags, mt):
 
 
 @pytest.mark.skipif(not shutil.which(HIPCC), reason="hipcc not installed")
-@pytest.mark.parametrize("flags", [BIAS, BIAS | RESIDUAL, BIAS | RESIDUAL | OUT_F32, BIAS | GELU | LN_APPLY, BIAS | RESIDUAL | ROW_STATS])
-def test_wide_tile_follows_the_same_rules(tmp_path, flags):
-    """round 5: the 224 x 256 tile (NH = 2: 8 W sub-tiles per wave, one workgroup per CU, accumulators in AGPRs) is the same loop: 2 * 8 * MT MFMAs
-    in ONE k-step body, 3 * (MT + 8) fragment reads, one vmcnt wait, one barrier, no scratch"""
-    isa, remarks = _compile(tmp_path, flags, 7, nh=2)
-    _check(isa, remarks, "v_mfma_f32_16x16x32_bf16", 2 * 8 * 7, 3 * (7 + 8))
-    assert re.search(r"AGPRs: (\d+)", remarks) and int(re.search(r"AGPRs: (\d+)", remarks).group(1)) >= 224      # the accumulators live in the AGPR half
-
-
-@pytest.mark.skipif(not shutil.which(HIPCC), reason="hipcc not installed")
 @pytest.mark.parametrize("flags", [0, BIAS, BIAS | GELU, BIAS | RESIDUAL, BIAS | RESIDUAL | OUT_F32, BIAS | GELU | LN_APPLY, BIAS | RESIDUAL | ROW_STATS])
 def test_big_8_wave_tile_follows_the_same_rules(tmp_path, flags):
     """round 5: the 256 x 256 tile of 8 waves (WM = 4, MT = 4, NH = 2: 64 x 128 per wave, two waves per SIMD, 8 LDS-DMA pieces and 12 fragment reads per
@@ -178,3 +168,15 @@ def test_fp8_loop_follows_the_same_rules(tmp_path, flags, mt, rowscale):
     the tile top, MT + 4 in the steady k-step, 2 in the last one"""
     isa, remarks = _compile(tmp_path, flags, mt, src=SRC.replace("gemm_bf16.hip", "gemm_fp8.hip"), rowscale=rowscale)
     _check(isa, remarks, "v_mfma_scale_f32_16x16x128_f8f6f4", 8 * mt, 2 * (mt + 2) + 2 * (mt + 4) + 2 * 2, hot_regions=2)
+
+
+@pytest.mark.skipif(not shutil.which(HIPCC), reason="hipcc not installed")
+@pytest.mark.parametrize("flags,rowscale", [(BIAS, 1), (BIAS | GELU | OUT_FP8, 1), (BIAS | RESIDUAL, 0), (BIAS | RESIDUAL | OUT_F32, 0), (OUT_F32, 0)])
+def test_fp8_big_tile_follows_the_same_rules(tmp_path, flags, rowscale):
+    """round 6: the 8-wave 192 x 256 x 128 tile of csrc/gemm_fp8.hip (WM = 4, NH = 2, MT = 3: 48 x 128 per wave, 8 W sub-tiles, two waves per SIMD): the
+    same two k-step bodies — 8 * MT MFMAs each — one vmcnt wait and one barrier per body, no scratch inside 256 registers; fragment reads (two
+    ds_read_b128 each): MT + 4 at the tile top, MT + 8 in the steady k-step, 4 in a tile's last one"""
+    mt = 3
+    isa, remarks = _compile(tmp_path, flags, mt, src=SRC.replace("gemm_bf16.hip", "gemm_fp8.hip"), rowscale=rowscale, nh=2, wm=4)
+    _check(isa, remarks, "v_mfma_scale_f32_16x16x128_f8f6f4", 2 * 8 * mt, 2 * (mt + 4) + 2 * (mt + 8) + 2 * 4, hot_regions=2)
+    assert re.search(r"Occupancy \[waves/SIMD\]: 2\b", remarks)

@@ -295,6 +295,48 @@ def test_registry_models_synthetic_weights(s2):
     s2i.eject_model(name, DEV)
 
 
+KNOB_SWEEP = [("gemm_nh", 3), ("gemm_nh", 4), ("gemm_nh", 1), ("gemm_tail", 1), ("gemm_wd", 3), ("gemm_wd", 6), ("rs_finalize", 1), ("ln_fold", 0), ("ln_fold", 1),
+              ("small_m", 0), ("small_m_grouped", 0), ("row_select", 0), ("attn_waves", 8), ("attn_waves", 4), ("ln_prefetch", 0),
+              ("gemm_mt", 2), ("gemm_mt", 6), ("gemm_cgroup", 0), ("xcd_band", 0)]
+
+
+def test_every_kernel_family_knob_keeps_vectorise_right(s2):
+    """every mq_tune key that switches a kernel family, at its NON-default value, through vectorise() itself (registry ViT-B/32 on
+    seeded weights; 40 images = 2 000 token rows: the tiled GEMM families; 33 texts; one lone query: the skinny families): still the oracle's
+    embeddings inside the north-star tolerance, and within 3e-4 of the default configuration's."""
+    s2i, _ = s2
+    from marqo_amd import _lib as L
+    from marqo_amd.engine import archs, synthetic
+    os.environ["MARQO_AMD_SYNTHETIC_WEIGHTS"] = "1"
+    lib = L.load()
+    name = "open_clip/ViT-B-32/laion2b_s34b_b79k"
+    rng = np.random.default_rng(5)
+    pil = [Image.fromarray(rng.integers(0, 256, (224, 224, 3), dtype=np.uint8)) for _ in range(40)]
+    texts = [f"a photo of object number {i} " + "with many details " * (i % 7) for i in range(33)]
+    run = lambda: (np.asarray(s2i.vectorise(name, pil, device=DEV, modality=s2i.Modality.IMAGE)), np.asarray(s2i.vectorise(name, texts, device=DEV)),
+                   np.asarray(s2i.vectorise(name, texts[3], device=DEV)))
+    base_i, base_t, base_q = run()
+    varch, tarch = archs.resolve_open_clip("ViT-B-32")
+    sdc = synthetic.random_open_clip_state_dict(vision=varch, text=tarch, seed=0)
+    refi = O.vit_forward(sdc, O.VitConfig(224, 32, 768, 12, 12, 3072, 512), torch.from_numpy(np.stack([OP.clip_transform(np.asarray(p)) for p in pil[:6]]))).numpy()
+    assert _cos_err(base_i[:6], refi) < COS_TOL and _cos_err(base_q, base_t[3:4]) < 3e-4
+    defaults = {k: 0 for k, _ in KNOB_SWEEP}
+    defaults.update(gemm_cgroup=8, ln_fold=2, small_m=80, small_m_grouped=320, row_select=1, ln_prefetch=1, xcd_band=1)
+    worst = {}
+    for key, value in KNOB_SWEEP:
+        try:
+            L.check(lib.mq_tune(key.encode(), value), "mq_tune")
+            i, t, q = run()
+        finally:
+            L.check(lib.mq_tune(key.encode(), defaults[key]), "mq_tune")
+        worst[(key, value)] = max(_cos_err(i, base_i), _cos_err(t, base_t), _cos_err(q, base_q))
+        assert _cos_err(i[:6], refi) < COS_TOL, (key, value)
+        assert worst[(key, value)] < 3e-4, (key, value, worst[(key, value)])
+    i, t, q = run()
+    assert np.array_equal(i, base_i) and np.array_equal(t, base_t) and np.array_equal(q, base_q)      # the defaults are back
+    print("knob sweep, max 1 - cos vs the default configuration:", {f"{k}={v}": f"{e:.1e}" for (k, v), e in worst.items()})
+
+
 def test_hf_xlm_roberta_from_disk(s2, tmp_path):
     """an XLM-RoBERTa checkpoint directory (multilingual-e5 layout: config.json model_type xlm-roberta, `roberta.`-prefixed
     safetensors, sentencepiece.bpe.model) through the `hf` loader: SentencePiece tokeniser on the host, BERT tower with the

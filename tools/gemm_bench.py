@@ -73,6 +73,37 @@ def main():
             def run8():
                 L.check(lib.mq_gemm_fp8(A8.data_ptr(), K, W8.data_ptr(), K, sa.data_ptr(), 1, sw.data_ptr(), b8.data_ptr(), L.ptr(res8),
                                         o8.data_ptr(), N, osc.data_ptr(), 0, M, N, K, fl8, s))
+            if args.ab:   # interleaved A/B of mq_tune settings, as for the bf16 GEMM below; the first variant's output is the reference for bit-identity
+                variants = []
+                for spec in args.ab.split(";"):
+                    vname, _, kv = spec.partition(":")
+                    variants.append((vname, [(k, int(v)) for k, v in (p.split("=") for p in kv.split(",") if p)]))
+                times = {vn: [] for vn, _ in variants}
+                outs = {}
+                for rnd in range(args.rounds + 1):
+                    for vn, kvs in variants:
+                        for k, v in kvs:
+                            L.check(lib.mq_tune(k.encode(), v))
+                        if res8 is None:
+                            o8.zero_()
+                        run8(); run8()
+                        if rnd == 0 and res8 is None:
+                            outs[vn] = o8.clone()
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        for _ in range(args.iters):
+                            run8()
+                        e1.record()
+                        torch.cuda.synchronize()
+                        if rnd:
+                            times[vn].append(e0.elapsed_time(e1) * 1e3 / args.iters)
+                fl = 2.0 * M * N * K
+                med = {vn: sorted(t)[len(t) // 2] for vn, t in times.items()}
+                base = med[variants[0][0]]
+                same = "" if not outs else "  bits: " + " ".join(f"{vn}={'same' if torch.equal(outs[vn], outs[variants[0][0]]) else 'DIFFER'}" for vn, _ in variants[1:])
+                print(f"fp8 {name:10s} M={M:6d} N={N:5d} K={K:5d} " + "  ".join(
+                    f"{vn}={med[vn]:7.1f}us ({fl / med[vn] / 1e6:6.0f}TF {100 * (med[vn] / base - 1):+5.1f}%)" for vn, _ in variants) + same)
+                continue
             for _ in range(5):
                 run8()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
