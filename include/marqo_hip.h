@@ -130,7 +130,9 @@ typedef struct mq_encoder_cfg {
                               * Quantisation noise injected in EARLY blocks is amplified by every later one (measured: the first 12 of
                               * ViT-L/14's 24 blocks cost 2-7x the cosine error of the last 12), so the loaders pick the smallest value
                               * that keeps the calibrated error inside the budget (engine/towers.py::tune_fp8); 0 = every block fp8 */
-    int32_t mlp_glu;         /* 1: gated MLP: fc1_w is [2F, W] = (up | gate) rows, hidden = up * act(gate), fc2 takes the F-wide product.  bf16 path only:
+    int32_t mlp_glu;         /* 1: gated MLP: fc1_w is [2F, W] = (up | gate) rows, hidden = up * act(gate), fc2 takes the F-wide product.  2 (ABI 11, pre-LN
+                              * blocks with MQ_ACT_SILU): the same with fc1_w / fc1_b (and the folded copies) interleaved 16 rows at a time as MQ_EPI_GLU
+                              * takes them — the product is formed in the GEMM's epilogue.  bf16 path only:
                               * post-LN = the "NewModel" encoders (stella_en_400M_v5, gte-*-en-v1.5); pre-LN = the EVA02 vision blocks (SwiGLU:
                               * act = MQ_ACT_SILU, up = fc1_x, gate = fc1_g, optional mlp_ln). */
     /* fp8 path: static per-tensor activation scales, device fp32 [layers][2] = (attention output, MLP hidden), and the
@@ -469,6 +471,10 @@ int mq_ln_gemm_small_bf16(const void* d_x, int64_t ldx, int x_bf16, const float*
  *                    flags of mq_gemm_bf16_rs: MQ_EPI_BIAS | MQ_EPI_RESIDUAL (bf16 in / out, in place). */
 #define MQ_EPI_ROW_STATS 64
 #define MQ_EPI_LN_APPLY 128
+/* ABI 11 — MQ_EPI_GLU (mq_gemm_bf16 / mq_gemm_bf16_ln with MQ_EPI_BIAS): the gated MLP's product in the (up | gate) GEMM's epilogue.  d_W's N = 2 F rows
+ * come INTERLEAVED 16 at a time — rows 32 j .. 32 j + 15 = up units 16 j .. 16 j + 15, rows 32 j + 16 .. 32 j + 31 = the same units' gate rows — so one lane
+ * holds up AND gate of the same hidden units; out bf16 [M, F] at row stride ldc: out[m, u] = (up + b_up) * silu(gate + b_gate).  N % 32 == 0. */
+#define MQ_EPI_GLU 256
 int mq_gemm_bf16_rs(const void* d_A, int64_t lda, const void* d_W, int64_t ldw, const float* d_bias, const void* d_residual, void* d_out, int64_t ldc,
                     int64_t M, int64_t N, int64_t K, int flags, float* d_partials, void* stream);
 int mq_row_stats_finalize(const float* d_partials, int32_t nslots, float* d_stats, int64_t rows, int32_t W, float eps, void* stream);

@@ -85,6 +85,8 @@ __device__ __forceinline__ float quick_gelu(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x));
 }
 
+__device__ __forceinline__ float silu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }   // (as quick_gelu: v_rcp_f32, rounded to bf16 right after)
+
 // ---- XCD-banded block order -----------------------------------------------------------------
 // Block b of a launch runs on XCD b % 8 (observed placement, used for speed only).  The tiled GEMMs give XCD k the k-th contiguous
 // band of output tiles, i.e. of activation ROWS; the row-wise kernels between them (LayerNorm, attention) use the same banding, so the

@@ -491,7 +491,6 @@ int mq_rope(void* d_qkv, const int32_t* d_cu, int64_t nseq, int fixed_len, int W
 }
 
 // ---- gated MLP: buf [rows, 2F] = (up | gate) from the fc1 GEMM -> buf[:, :F] = up * act(gate), in place (row stride stays 2F) -----
-__device__ __forceinline__ float silu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }   // (as quick_gelu: v_rcp_f32, rounded to bf16 right after)
 __device__ __forceinline__ float glu_act(float g, int act) { return act == MQ_ACT_SILU ? silu(g) : act == MQ_ACT_QUICKGELU ? quick_gelu(g) : gelu_erf(g); }
 
 __global__ __launch_bounds__(256) void glu_kernel(bf16_t* __restrict__ buf, int64_t rows, int F, int act) {
@@ -514,11 +513,18 @@ __global__ __launch_bounds__(256) void glu_kernel(bf16_t* __restrict__ buf, int6
     }
 }
 
-int mq_glu(void* d_buf, int64_t rows, int F, int act, hipStream_t s) {
-    MQ_CHECK_ARG(F % 8 == 0, "glu: F=%d must be a multiple of 8", F);
+int mq_glu_il_rows(void* d_buf, int64_t rows, int F, int act, hipStream_t s);
+int mq_glu(void* d_buf, int64_t rows, int F, int act, hipStream_t s, int interleaved) {
+    MQ_CHECK_ARG(F % 8 == 0 && (!interleaved || F % 16 == 0), "glu: F=%d must be a multiple of 8 (16 interleaved)", F);
     if (rows <= 0) return MQ_OK;
     MqProfScope prof(3, s);
     const int64_t blocks = cdiv64(rows * (F >> 3), 256);
+    if (interleaved) {
+        // (up, gate) interleaved 16 by 16 — MQ_EPI_GLU's weight layout behind a GEMM without the gated epilogue (the skinny kernels): the product is
+        // written compactly, in place; one wave per row with the whole row in registers before anything is written (glu_ln_kernel, MODE 3)
+        MQ_CHECK_ARG(F <= 4096, "glu (interleaved): F=%d > 4096", F);
+        return mq_glu_il_rows(d_buf, rows, F, act, s);
+    }
     hipLaunchKernelGGL(glu_kernel, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, s, (bf16_t*)d_buf, rows, F, act);
     MQ_CHECK_LAUNCH("glu");
     return MQ_OK;
@@ -528,7 +534,10 @@ int mq_glu(void* d_buf, int64_t rows, int F, int act, hipStream_t s) {
 // buf[:, :F] = LN(up * act(gate)) * g + b, in place (row stride stays 2F).  One wave per row, the row's products stay in registers (fp32) between the
 // two passes of the statistics; mean / variance over the first Ft columns (F = Ft zero-padded to a multiple of 64: the padded products are exactly 0,
 // g = b = 0 there, so the padding stays 0 for fc2).  CH = 16-byte chunks per lane: F <= 512 * CH.
-template <int CH>
+// MODE 0: (up | gate) halves -> LN(product).  MODE 1: (up, gate) interleaved 16 by 16 (MQ_EPI_GLU's weight layout behind a GEMM WITHOUT the gated
+// epilogue: the skinny kernels) -> LN(product), written compactly.  MODE 2: the product is already there (the GEMM's MQ_EPI_GLU epilogue formed it) ->
+// LN only.  MODE 3: interleaved -> product, NO LayerNorm (towers without mlp.norm).  Row stride 2F in every mode.
+template <int CH, int MODE = 0>
 __global__ __launch_bounds__(256) void glu_ln_kernel(bf16_t* __restrict__ buf, int64_t rows, int F, int Ft, int act, const float* __restrict__ g,
                                                      const float* __restrict__ b, float eps) {
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -543,18 +552,40 @@ __global__ __launch_bounds__(256) void glu_ln_kernel(bf16_t* __restrict__ buf, i
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[j][e] = 0.f;
         if (col < F) {
-            const uint4 up = *(const uint4*)(p + col), gt = *(const uint4*)(p + F + col);
+            const int src = (MODE == 1 || MODE == 3) ? 32 * (col >> 4) + (col & 15) : col;     // (col & 15) is 0 or 8
+            const uint4 up = *(const uint4*)(p + src);
             const uint32_t* a = (const uint32_t*)&up;
-            const uint32_t* q = (const uint32_t*)&gt;
+            if (MODE == 2) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                v[j][2 * e] = bf16_to_f32((bf16_t)(a[e] & 0xffff)) * glu_act(bf16_to_f32((bf16_t)(q[e] & 0xffff)), act);
-                v[j][2 * e + 1] = bf16_to_f32((bf16_t)(a[e] >> 16)) * glu_act(bf16_to_f32((bf16_t)(q[e] >> 16)), act);
+                for (int e = 0; e < 4; ++e) {
+                    v[j][2 * e] = bf16_to_f32((bf16_t)(a[e] & 0xffff));
+                    v[j][2 * e + 1] = bf16_to_f32((bf16_t)(a[e] >> 16));
+                }
+            } else {
+                const uint4 gt = *(const uint4*)(p + src + (MODE == 0 ? F : 16));
+                const uint32_t* q = (const uint32_t*)&gt;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[j][2 * e] = bf16_to_f32((bf16_t)(a[e] & 0xffff)) * glu_act(bf16_to_f32((bf16_t)(q[e] & 0xffff)), act);
+                    v[j][2 * e + 1] = bf16_to_f32((bf16_t)(a[e] >> 16)) * glu_act(bf16_to_f32((bf16_t)(q[e] >> 16)), act);
+                }
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e)
                 if (col + e < Ft) s1 += v[j][e];
         }
+    }
+    if (MODE == 3) {   // (every source of the row is in this wave's registers: the compaction may overwrite them now)
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int col = (lane + j * 64) * 8;
+            if (col < F) {
+                uint4 o;
+                o.x = pack_bf16x2(v[j][0], v[j][1]); o.y = pack_bf16x2(v[j][2], v[j][3]); o.z = pack_bf16x2(v[j][4], v[j][5]); o.w = pack_bf16x2(v[j][6], v[j][7]);
+                *(uint4*)(p + col) = o;
+            }
+        }
+        return;
     }
     const float mean = wave_sum(s1) / (float)Ft;
     float s2 = 0.f;
@@ -581,17 +612,22 @@ __global__ __launch_bounds__(256) void glu_ln_kernel(bf16_t* __restrict__ buf, i
     }
 }
 
-int mq_glu_ln(void* d_buf, int64_t rows, int F, int Ft, int act, const float* g, const float* b, float eps, hipStream_t s) {
-    MQ_CHECK_ARG(F % 8 == 0 && F >= 8 && F <= 4096 && Ft >= 1 && Ft <= F && g && b, "glu_ln: F=%d (a multiple of 8, <= 4096) / Ft=%d unsupported", F, Ft);
+int mq_glu_ln(void* d_buf, int64_t rows, int F, int Ft, int act, const float* g, const float* b, float eps, hipStream_t s, int mode = 0) {
+    MQ_CHECK_ARG(F % 8 == 0 && F >= 8 && F <= 4096 && Ft >= 1 && Ft <= F && ((g && b) || mode == 3), "glu_ln: F=%d (a multiple of 8, <= 4096) / Ft=%d unsupported", F, Ft);
+    MQ_CHECK_ARG(mode >= 0 && mode <= 3 && (mode == 0 || mode == 2 || F % 16 == 0), "glu_ln: mode %d / F=%d", mode, F);
     if (rows <= 0) return MQ_OK;
     MqProfScope prof(1, s);
     const unsigned grid = (unsigned)cdiv64(rows, 4);
-#define MQ_GL(C) hipLaunchKernelGGL((glu_ln_kernel<C>), dim3(grid), dim3(256), 0, s, (bf16_t*)d_buf, rows, F, Ft, act, g, b, eps)
-    if (F <= 1024) MQ_GL(2); else if (F <= 2048) MQ_GL(4); else if (F <= 3072) MQ_GL(6); else MQ_GL(8);
+#define MQ_GL(C, MD) hipLaunchKernelGGL((glu_ln_kernel<C, MD>), dim3(grid), dim3(256), 0, s, (bf16_t*)d_buf, rows, F, Ft, act, g, b, eps)
+#define MQ_GLC(MD) do { if (F <= 1024) MQ_GL(2, MD); else if (F <= 2048) MQ_GL(4, MD); else if (F <= 3072) MQ_GL(6, MD); else MQ_GL(8, MD); } while (0)
+    if (mode == 0) MQ_GLC(0); else if (mode == 1) MQ_GLC(1); else if (mode == 2) MQ_GLC(2); else MQ_GLC(3);
+#undef MQ_GLC
 #undef MQ_GL
     MQ_CHECK_LAUNCH("glu_ln");
     return MQ_OK;
 }
+// the un-normalised interleaved product (mq_glu's il form): one wave per row
+int mq_glu_il_rows(void* d_buf, int64_t rows, int F, int act, hipStream_t s) { return mq_glu_ln(d_buf, rows, F, F, act, nullptr, nullptr, 0.f, s, 3); }
 
 // ---- 2-D rotary position embedding of the EVA02 vision towers (timm RotaryEmbeddingCat + apply_rot_embed_cat) on the Q and K columns of the QKV
 // buffer, in place.  table: fp32 [T - prefix][2][hs] = (cos | sin) per rotated position, the same for every head; the first `prefix` rows of every

@@ -734,7 +734,12 @@ extern "C" int mq_gemm_bf16(const void* d_A, int64_t lda, const void* d_W, int64
     MQ_CHECK_ARG(M < (1 << 30) && N < (1 << 30) && K < (1 << 30), "mq_gemm_bf16: shape too large");
     MQ_CHECK_ARG(!(flags & MQ_EPI_BIAS) || d_bias, "mq_gemm_bf16: MQ_EPI_BIAS without bias");
     MQ_CHECK_ARG(!(flags & MQ_EPI_RESIDUAL) || d_residual, "mq_gemm_bf16: MQ_EPI_RESIDUAL without residual");
+    MQ_CHECK_ARG(!(flags & MQ_EPI_GLU) || N % 32 == 0, "mq_gemm_bf16: MQ_EPI_GLU needs N %% 32 == 0 (16 up + 16 gate rows per group)");
     hipStream_t s = (hipStream_t)stream;
+    if (flags & MQ_EPI_GLU) {   // (the skinny kernels have no gated epilogue: the tiled family for any row count)
+        MqProfScope prof(0, s, 2.0 * (double)M * (double)N * (double)K);
+        return launch_gemm<MQ_EPI_BIAS | MQ_EPI_GLU>(d_A, lda, d_W, ldw, d_bias, d_residual ? (const float*)d_residual : nullptr, d_out, ldc, (int)M, (int)N, (int)K, s);
+    }
     // a handful of rows (single queries, pooled rows of a small batch): the column-sliced skinny kernel spreads the weight stream over the
     // whole chip instead of N/128 workgroups (gemm_small.hip)
     if (mq_gemm_small_ok(M, N, K, false) || mq_gemm_small_grouped_ok(M, N, K)) return mq_gemm_small(d_A, lda, d_W, ldw, d_bias, d_residual, d_out, ldc, M, N, K, flags, s);
@@ -751,6 +756,7 @@ extern "C" int mq_gemm_bf16(const void* d_A, int64_t lda, const void* d_W, int64
         MQ_GEMM_CASE(MQ_EPI_BIAS | MQ_EPI_QUICKGELU);
         MQ_GEMM_CASE(MQ_EPI_BIAS | MQ_EPI_RESIDUAL | MQ_EPI_OUT_F32);
         MQ_GEMM_CASE(MQ_EPI_BIAS | MQ_EPI_RESIDUAL);   // bf16 residual in (d_residual is bf16), bf16 out
+        MQ_GEMM_CASE(MQ_EPI_BIAS | MQ_EPI_GLU);        // gated MLP: out [M, N / 2] = up * silu(gate), W rows interleaved 16 by 16
         default:
             mq_set_error("mq_gemm_bf16: unsupported epilogue flag combination 0x%x", flags);
             return MQ_ERR_INVALID;
@@ -765,6 +771,7 @@ extern "C" int mq_gemm_bf16_ln(const void* d_A, int64_t lda, const void* d_W, in
                                const float* d_rowstats, void* d_out, int64_t ldc, int64_t M, int64_t N, int64_t K, int flags, void* stream) {
     MQ_CHECK_ARG(d_A && d_W && d_out && d_bias && d_colsum && d_rowstats, "mq_gemm_bf16_ln: null operand");
     MQ_CHECK_ARG(M >= 1 && N >= 4 && K >= BK && K % BK == 0 && N % 4 == 0, "mq_gemm_bf16_ln: bad shape M=%ld N=%ld K=%ld", (long)M, (long)N, (long)K);
+    MQ_CHECK_ARG(!(flags & MQ_EPI_GLU) || N % 32 == 0, "mq_gemm_bf16_ln: MQ_EPI_GLU needs N %% 32 == 0");
     MQ_CHECK_ARG(lda % 8 == 0 && ldw % 8 == 0 && ldc % 4 == 0, "mq_gemm_bf16_ln: leading dims must keep 16-byte rows");
     MQ_CHECK_ARG(M < (1 << 30) && N < (1 << 30) && K < (1 << 30), "mq_gemm_bf16_ln: shape too large");
     hipStream_t s = (hipStream_t)stream;
@@ -779,6 +786,7 @@ extern "C" int mq_gemm_bf16_ln(const void* d_A, int64_t lda, const void* d_W, in
         MQ_GEMM_LN_CASE(MQ_EPI_BIAS | MQ_EPI_LN_APPLY);
         MQ_GEMM_LN_CASE(MQ_EPI_BIAS | MQ_EPI_GELU | MQ_EPI_LN_APPLY);
         MQ_GEMM_LN_CASE(MQ_EPI_BIAS | MQ_EPI_QUICKGELU | MQ_EPI_LN_APPLY);
+        MQ_GEMM_LN_CASE(MQ_EPI_BIAS | MQ_EPI_GLU | MQ_EPI_LN_APPLY);
         default:
             mq_set_error("mq_gemm_bf16_ln: unsupported epilogue flag combination 0x%x", flags);
             return MQ_ERR_INVALID;

@@ -103,7 +103,8 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][4], const float* 
     // bf16 residual stream (towers.hip): MQ_EPI_RESIDUAL without MQ_EPI_OUT_F32 = the residual is read as bf16 and the sum written
     // as bf16, in place — half the epilogue bytes of the fp32 stream, the memory-bound part of the K = 768 residual GEMMs
     constexpr bool RES_BF16 = (FLAGS & MQ_EPI_RESIDUAL) && BF16_OUT;
-    constexpr bool LN_APPLY = (FLAGS & MQ_EPI_LN_APPLY) != 0, ROW_STATS = (FLAGS & MQ_EPI_ROW_STATS) != 0;
+    constexpr bool LN_APPLY = (FLAGS & MQ_EPI_LN_APPLY) != 0, ROW_STATS = (FLAGS & MQ_EPI_ROW_STATS) != 0, GLU = (FLAGS & MQ_EPI_GLU) != 0;
+    static_assert(!GLU || (BF16_OUT && !(FLAGS & (MQ_EPI_RESIDUAL | MQ_EPI_GELU | MQ_EPI_QUICKGELU | MQ_EPI_ROW_STATS))), "GLU: bias (+ LN apply), bf16 out");
     static_assert(!ROW_STATS || RES_BF16, "ROW_STATS rides on the bf16 read-modify-write residual epilogue");
     static_assert(!LN_APPLY || (BF16_OUT && !(FLAGS & MQ_EPI_RESIDUAL)), "LN_APPLY: the QKV / fc1 epilogues (bf16 out, no residual)");
     float row_mean = 0.f, row_rstd = 1.f;
@@ -192,7 +193,34 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][4], const float* 
                 st2 += (e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3);
             }
         };
-        if (BF16_OUT && wide) {  // `wide` is wave-uniform: every lane takes part in the swaps
+        if constexpr (GLU) {
+            // gated MLP (marqo_hip.h, MQ_EPI_GLU): sub-tiles (0, 1) and (2, 3) are (up, gate) of the same 16 hidden units — the lane's 4 consecutive GEMM
+            // columns of sub-tile 2 p are units u .. u + 3 with u = wave_n0 / 2 + 16 p + 4 g, their gates sit in the same registers of sub-tile 2 p + 1
+            uint2 pk[2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int n = wave_n0 + (2 * p) * 16 + g * 4;
+                const bool ok = m_ok && n < N;
+                const f32x4 up = value(mt, 2 * p, m, n, ok), gt = value(mt, 2 * p + 1, m, n + 16, ok);
+                pk[p].x = pack_bf16x2(up[0] * silu(gt[0]), up[1] * silu(gt[1]));
+                pk[p].y = pack_bf16x2(up[2] * silu(gt[2]), up[3] * silu(gt[3]));
+            }
+            const int u0 = wave_n0 >> 1, NU = N >> 1;
+            if (wide) {   // the two 16-unit blocks exchanged between lanes 16 apart: a lane then owns 8 consecutive units (one 16-byte store)
+                const auto r0 = __builtin_amdgcn_permlane16_swap(pk[0].x, pk[1].x, false, false);
+                const auto r1 = __builtin_amdgcn_permlane16_swap(pk[0].y, pk[1].y, false, false);
+                const int u = u0 + (g & 1) * 16 + (g >> 1) * 8;
+                bf16_t* dst = (bf16_t*)out + (int64_t)m * ldc + u;
+                if (m_ok && u + 8 <= NU) *(uint4*)dst = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+                else if (m_ok && u < NU) *(uint2*)dst = make_uint2(r0[0], r1[0]);
+            } else {
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const int u = u0 + 16 * p + 4 * g;
+                    if (m_ok && u < NU) *(uint2*)((bf16_t*)out + (int64_t)m * ldc + u) = pk[p];
+                }
+            }
+        } else if (BF16_OUT && wide) {  // `wide` is wave-uniform: every lane takes part in the swaps
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
                 uint2 a, b;

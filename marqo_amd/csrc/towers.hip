@@ -24,8 +24,8 @@ int mq_map_pool(const void* d_kv, const float* d_q, void* d_out, int64_t n, int 
 int mq_avg_tokens(const void* d_x, int x_bf16, float* d_out, int64_t n, int T, int first, int W, hipStream_t s);
 int mq_move_rows(void* d_sparse, const int32_t* d_idx, void* d_dense, int64_t n, int64_t row_bytes, bool scatter, hipStream_t s);
 int mq_rope(void* d_qkv, const int32_t* d_cu, int64_t nseq, int fixed_len, int Wa, int heads, const float* d_inv_freq, hipStream_t s);
-int mq_glu(void* d_buf, int64_t rows, int F, int act, hipStream_t s);
-int mq_glu_ln(void* d_buf, int64_t rows, int F, int Ft, int act, const float* g, const float* b, float eps, hipStream_t s);
+int mq_glu(void* d_buf, int64_t rows, int F, int act, hipStream_t s, int interleaved = 0);
+int mq_glu_ln(void* d_buf, int64_t rows, int F, int Ft, int act, const float* g, const float* b, float eps, hipStream_t s, int mode = 0);
 int mq_rope_table(void* d_qkv, int64_t rows, int T, int prefix, int Wa, int heads, const float* d_table, hipStream_t s);
 extern "C" int mq_rowquant_fp8(const float* d_x, void* d_out_fp8, float* d_row_scale, int64_t rows, int32_t W, void* stream);
 
@@ -156,6 +156,8 @@ int check_encoder_cfg(const mq_encoder_cfg* c) {
     MQ_CHECK_ARG(c->mlp_dim >= 64 && c->mlp_dim % 64 == 0, "encoder mlp_dim %d must be a multiple of 64", c->mlp_dim);
     MQ_CHECK_ARG(c->layers >= 0, "encoder layers < 0");
     MQ_CHECK_ARG(c->act == MQ_ACT_GELU || c->act == MQ_ACT_QUICKGELU || (c->act == MQ_ACT_SILU && c->mlp_glu), "encoder act %d unsupported (MQ_ACT_SILU: gated MLPs only)", c->act);
+    MQ_CHECK_ARG(c->mlp_glu >= 0 && c->mlp_glu <= 2 && (c->mlp_glu != 2 || (!c->post_ln && c->act == MQ_ACT_SILU && c->mlp_dim % 16 == 0)),
+                 "mlp_glu = 2 (fc1 rows interleaved for MQ_EPI_GLU): pre-LN blocks with MQ_ACT_SILU and mlp_dim %% 16 == 0");
     MQ_CHECK_ARG(c->precision == MQ_PREC_BF16 || c->precision == MQ_PREC_FP8, "encoder precision %d unsupported", c->precision);
     if (c->precision == MQ_PREC_FP8) {
         MQ_CHECK_ARG(c->width % 128 == 0 && c->mlp_dim % 128 == 0 && wa % 128 == 0, "fp8 path needs width / mlp_dim multiples of 128");
@@ -371,11 +373,17 @@ int EncoderPass::block_eva(const mq_block_weights& b, int l) {
     if (fold_mlp) MQ_TRY(mq_gemm_bf16_rsf(a, Wa, b.out_w, Wa, b.out_b, d_x, d_x, W, rows, W, Wa, rflags, row_part, row_stats, cfg->ln_eps, band_ctr, pf(b.fc1_wf),
                                           (size_t)fc1_cols * W * 2, pf(b.fc2_w), (size_t)W * F * 2, s));
     else MQ_TRY(mq_gemm_bf16(a, Wa, b.out_w, Wa, b.out_b, (const float*)d_x, d_x, W, rows, W, Wa, rflags, s));
-    MQ_TRY(ln_gemm(d_x, xb, b.ln2_g, b.ln2_b, cfg->ln_eps, h, b.fc1_w, b.fc1_b, qf, rows, fc1_cols, W, MQ_EPI_BIAS | (cfg->mlp_glu ? 0 : act_flag), s, b.fc2_w,
-                   (size_t)W * F * 2, b.fc1_wf, b.fc1_bf, b.fc1_sf, row_stats, fold_mlp));
+    // mlp_glu == 2: (up, gate) rows interleaved 16 by 16 — the tiled GEMM forms up * silu(gate) in its epilogue (MQ_EPI_GLU: the (up | gate) tensor is never
+    // written: -206 MB written and -206 MB read per block at EVA02-B/16 x 256), the sub-LayerNorm then normalises the product in place; a call of a few
+    // rows (the skinny kernels have no gated epilogue) multiplies behind the GEMM, from the interleaved columns.  Row stride 2 F either way.
+    const bool il = cfg->mlp_glu == 2;
+    const bool glu_epi = il && !mq_gemm_small_ok(rows, fc1_cols, W, true) && !mq_gemm_small_ok(rows, fc1_cols, W, false) && !mq_gemm_small_grouped_ok(rows, fc1_cols, W);
+    MQ_TRY(ln_gemm(d_x, xb, b.ln2_g, b.ln2_b, cfg->ln_eps, h, b.fc1_w, b.fc1_b, qf, rows, fc1_cols, W, MQ_EPI_BIAS | (cfg->mlp_glu ? (glu_epi ? MQ_EPI_GLU : 0) : act_flag), s,
+                   b.fc2_w, (size_t)W * F * 2, b.fc1_wf, b.fc1_bf, b.fc1_sf, row_stats, fold_mlp));
     if (cfg->mlp_glu) {
-        if (b.mlp_ln_g) MQ_TRY(mq_glu_ln(qf, rows, F, cfg->mlp_ln_dim ? cfg->mlp_ln_dim : F, cfg->act, b.mlp_ln_g, b.mlp_ln_b, cfg->ln_eps, s));
-        else MQ_TRY(mq_glu(qf, rows, F, cfg->act, s));
+        const int mode = glu_epi ? 2 : il ? 1 : 0;
+        if (b.mlp_ln_g) MQ_TRY(mq_glu_ln(qf, rows, F, cfg->mlp_ln_dim ? cfg->mlp_ln_dim : F, cfg->act, b.mlp_ln_g, b.mlp_ln_b, cfg->ln_eps, s, mode));
+        else if (!glu_epi) MQ_TRY(mq_glu(qf, rows, F, cfg->act, s, il ? 1 : 0));
     }
     // fc2 (reads the F-wide product at the (up | gate) buffer's row stride) writes the x the NEXT block's QKV normalises
     const mq_block_weights* nbk = l + 1 < cfg->layers ? &blocks[l + 1] : nullptr;

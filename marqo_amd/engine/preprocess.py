@@ -454,13 +454,17 @@ class ImagePreprocessor:
             self._keep = p
         return out, boxes
 
-    def to_tensor_normalize(self, u8: torch.Tensor) -> torch.Tensor:
-        """uint8 [n, S, S, 3] -> fp32 [n, 3, S, S] (ToTensor + Normalize)."""
+    def to_tensor_normalize(self, u8: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """uint8 [n, S, S, 3] -> fp32 [n, 3, S, S] (ToTensor + Normalize); `out`: a contiguous fp32 [n, 3, S, S] destination on the device (a slice
+        of the loaders' preprocess slab)"""
         if u8.dtype != torch.uint8 or u8.ndim != 4 or tuple(u8.shape[1:]) != (self.S, self.S, 3):
             raise ValueError(f"expected uint8 [n, {self.S}, {self.S}, 3], got {u8.dtype} {tuple(u8.shape)}")
         with torch.cuda.device(self.device):
             u8 = u8.to(self.device).contiguous()
-            out = torch.empty(u8.shape[0], 3, self.S, self.S, dtype=torch.float32, device=self.device)
+            if out is None:
+                out = torch.empty(u8.shape[0], 3, self.S, self.S, dtype=torch.float32, device=self.device)
+            elif out.dtype != torch.float32 or tuple(out.shape) != (u8.shape[0], 3, self.S, self.S) or not out.is_contiguous() or out.device != u8.device:
+                raise ValueError("to_tensor_normalize: `out` must be a contiguous fp32 [n, 3, S, S] tensor on the preprocessor's device")
             L.check(self.lib.mq_to_tensor_normalize(u8.data_ptr(), out.data_ptr(), u8.shape[0], self.S, self.mean, self.std,
                                                     self._stream()), "mq_to_tensor_normalize")
         return out

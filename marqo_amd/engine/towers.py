@@ -249,10 +249,14 @@ def _clip_blocks(h: _Holder, sd, prefix: str, layers: int, W: int, F: int, heads
     return arr
 
 
+# EVA02 blocks: up * silu(gate) in the (up | gate) GEMM's epilogue (MQ_EPI_GLU; 0 = the round-5 form: the GEMM writes (up | gate), glu_ln_kernel multiplies)
+EVA_GLU_EPILOGUE = os.environ.get("MARQO_AMD_EVA_GLU_EPILOGUE", "1") != "0"
+
+
 def _eva_blocks(h: _Holder, sd, prefix: str, layers: int, W: int, F: int, heads: int):
     """timm EvaBlock tensors (eva.py; `blocks.{i}.`): norm1, attn.{q_proj, k_proj (no bias), v_proj} or the fused attn.qkv + q_bias / v_bias,
     attn.norm (the LayerNorm in front of attn.proj; absent without `scale_attn_inner`), attn.proj, norm2, mlp.{fc1_g, fc1_x, norm, fc2}
-    (timm SwiGLU: fc2(norm(silu(fc1_g(x)) * fc1_x(x)))).  fc1 is stored as (up | gate) = (fc1_x | fc1_g) rows, the hidden width F zero-padded
+    (timm SwiGLU: fc2(norm(silu(fc1_g(x)) * fc1_x(x)))).  fc1 is stored as (up, gate) = (fc1_x, fc1_g) rows interleaved 16 by 16, the hidden width F zero-padded
     to a multiple of 64: silu(0) * 0 = 0 meets zero LayerNorm weights and zero fc2 columns — exact; the statistics run over F (mlp_ln_dim)."""
     if _head_dim(W, heads) != _kernel_head_dim(_head_dim(W, heads), heads):
         raise ValueError("EVA02 towers with heads that are not 64 / 96 / 112 / 128 wide are not runnable (rotary positions on padded heads)")
@@ -280,8 +284,12 @@ def _eva_blocks(h: _Holder, sd, prefix: str, layers: int, W: int, F: int, heads:
         b.ln2_g, b.ln2_b = h.f32(f32("norm2.weight", (W,))), h.f32(f32("norm2.bias", (W,)))
         up_w, up_b = f32("mlp.fc1_x.weight", (F, W)), f32("mlp.fc1_x.bias", (F,))
         gate_w, gate_b = f32("mlp.fc1_g.weight", (F, W)), f32("mlp.fc1_g.bias", (F,))
-        fc1_w = torch.cat([pad(up_w, (0, 0, 0, Fp - F)), pad(gate_w, (0, 0, 0, Fp - F))], dim=0)
-        fc1_b = torch.cat([pad(up_b, (0, Fp - F)), pad(gate_b, (0, Fp - F))])
+        # (up, gate) rows interleaved 16 by 16 (mq_encoder_cfg.mlp_glu = 2): a lane of the GEMM's epilogue then holds up AND gate of the same hidden
+        # units and forms up * silu(gate) itself (MQ_EPI_GLU) — the (up | gate) tensor is never written
+        il = (lambda u, g_: torch.stack([u.reshape(Fp // 16, 16, *u.shape[1:]), g_.reshape(Fp // 16, 16, *g_.shape[1:])], dim=1).reshape(2 * Fp, *u.shape[1:])) \
+            if EVA_GLU_EPILOGUE else (lambda u, g_: torch.cat([u, g_], dim=0))
+        fc1_w = il(pad(up_w, (0, 0, 0, Fp - F)), pad(gate_w, (0, 0, 0, Fp - F)))
+        fc1_b = il(pad(up_b, (0, Fp - F)), pad(gate_b, (0, Fp - F)))
         b.fc1_w, b.fc1_b = h.bf16(fc1_w), h.f32(fc1_b)
         if p + "mlp.norm.weight" in sd:
             b.mlp_ln_g, b.mlp_ln_b = h.f32(pad(f32("mlp.norm.weight", (F,)), (0, Fp - F))), h.f32(pad(f32("mlp.norm.bias", (F,)), (0, Fp - F)))
@@ -862,7 +870,7 @@ class VitTower(_TowerBase):
                             pool_dim=arch.out_dim if arch.pool == "query" else 0, pool_heads=arch.pool_heads if arch.pool == "query" else 0)
         if arch.eva:
             enc = self.cfg.enc
-            enc.mlp_glu, enc.act, enc.mlp_ln_dim = 1, L.MQ_ACT_SILU, arch.mlp_dim
+            enc.mlp_glu, enc.act, enc.mlp_ln_dim = (2 if EVA_GLU_EPILOGUE else 1), L.MQ_ACT_SILU, arch.mlp_dim     # 2: fc1 rows interleaved 16 by 16 (_eva_blocks), the product in the GEMM's epilogue
             enc.d_rope_table, enc.rope_prefix = self._rope, 1
         self.max_images_per_call = max(1, MAX_ROWS_PER_CALL // arch.tokens)
         self.n_streams = max(1, int(os.environ.get("MARQO_AMD_STREAMS", "1")))

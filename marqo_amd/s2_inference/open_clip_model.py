@@ -118,6 +118,8 @@ PIPELINE_STREAMS = max(1, int(os.environ.get("MARQO_AMD_IMAGE_PIPELINE_STREAMS",
 # profiles/r05w_e2e_stages.txt).  MARQO_AMD_IMAGE_PIPELINE_THREAD=0: everything on the calling thread.
 PIPELINE_THREAD = os.environ.get("MARQO_AMD_IMAGE_PIPELINE_THREAD", "1") != "0"
 PIPELINE_ALWAYS = os.environ.get("MARQO_AMD_IMAGE_PIPELINE_ALWAYS", "0") == "1"   # stage a call also while other image calls are in flight on the model
+# `.preprocess` results live in per-model device slabs of this many image slots (0 = one tensor per image, as before round 6)
+PREPROCESS_SLAB_SLOTS = int(os.environ.get("MARQO_AMD_PREPROCESS_SLAB", "128"))
 
 
 def _pipeline_stages(n: int) -> list:
@@ -159,6 +161,9 @@ class OPEN_CLIP(AbstractCLIPModel):
         self._local = threading.local()
         self._image_calls = 0               # encode_image calls in flight on this model (a call stages itself only when it is alone)
         self._image_calls_lock = threading.Lock()
+        self._slab_lock = threading.Lock()
+        self._slab_block: Optional[torch.Tensor] = None      # the preprocess slab's current block (fp32 [slots, 3, S, S]) and its next free slot
+        self._slab_next = 0
         self.vision_arch: Optional[archs.VitArch] = None
         self.text_arch: Optional[archs.ClipTextArch] = None
         self.weights_source = None
@@ -387,10 +392,54 @@ class OPEN_CLIP(AbstractCLIPModel):
 
     def _preprocess_one(self, image: ImageType) -> torch.Tensor:
         """PIL image -> Tensor[3, S, S] fp32 (normalised), ALREADY on the device: resize / crop / normalise run on the GPU.
-        Callers' `.to(device)` (add_docs.py:134) is then a no-op."""
+        Callers' `.to(device)` (add_docs.py:134) is then a no-op.
+        The result is written into the next slot of a per-model device SLAB (blocks of PREPROCESS_SLAB_SLOTS images) and returned as a view of it:
+        the reference's download threads call this image by image (add_docs.py:129-141) and hand encode_image a LIST of such tensors, which used
+        to be gathered again into one batch (a 154 MB copy per 256 images + a Python loop).  encode_image recognises runs of neighbouring slots
+        (`_mq_block` / `_mq_slot` on the view: attributes of that tensor object, gone with any copy of it) and hands the tower the slab slice
+        itself.  A slot is written once; a block lives as long as any of its views."""
         pre = self._pre()
         u8 = self._resize(pre, [pil_to_pixels(image)])
-        return pre.to_tensor_normalize(u8)[0]
+        if PREPROCESS_SLAB_SLOTS <= 0:
+            return pre.to_tensor_normalize(u8)[0]
+        block, k = self._slab_take()
+        pre.to_tensor_normalize(u8, out=block[k:k + 1])
+        view = block[k]
+        view._mq_block, view._mq_slot = block, k
+        return view
+
+    def _slab_take(self):
+        S = self.vision_arch.image_size
+        with self._slab_lock:
+            if self._slab_block is None or self._slab_next >= self._slab_block.shape[0]:
+                with torch.cuda.device(self.device):
+                    # (allocated on the caller's current stream; the views are consumed on request streams: torch's allocator would only re-use the
+                    # block after every view is gone, and a slot is never rewritten, so no stream hand-over is needed beyond the tensors' own)
+                    self._slab_block = torch.empty(PREPROCESS_SLAB_SLOTS, 3, S, S, dtype=torch.float32, device=self.device)
+                self._slab_next = 0
+            k = self._slab_next
+            self._slab_next += 1
+            return self._slab_block, k
+
+    @staticmethod
+    def _slab_runs(tensors):
+        """a list of preprocess-slab views -> [slab slices] in list order (neighbouring slots of one block merge into one slice), or None when any
+        item is not a slab view (its tensor object carries no slot: a copy, a caller's own tensor)"""
+        runs, cur_block, k0, k1 = [], None, 0, 0
+        for t in tensors:
+            block = getattr(t, "_mq_block", None)
+            if block is None:
+                return None
+            k = t._mq_slot
+            if block is cur_block and k == k1:
+                k1 += 1
+                continue
+            if cur_block is not None:
+                runs.append(cur_block[k0:k1])
+            cur_block, k0, k1 = block, k, k + 1
+        if cur_block is not None:
+            runs.append(cur_block[k0:k1])
+        return runs
 
     def _resize(self, pre, raw, pil_sizes=None) -> torch.Tensor:
         """list of uint8 [H, W, 3] -> uint8 [n, S, S, 3] on the device: Resize(S) + CenterCrop(S), or Resize((S, S)) ('squash').
@@ -455,6 +504,9 @@ class OPEN_CLIP(AbstractCLIPModel):
         tensors = [i for i in loaded if isinstance(i, torch.Tensor)]
         pre = self._pre()
         if len(tensors) == len(loaded):
+            runs = self._slab_runs(tensors)         # what `.preprocess` handed out: slices of the slab instead of a 256-tensor gather
+            if runs is not None and len(runs) <= max(1, len(tensors) // 8):
+                return "f32", runs[0] if len(runs) == 1 else torch.cat(runs)
             return "f32", torch.stack([t.to(self.device) for t in tensors])
         raw = [i if isinstance(i, np.ndarray) else pil_to_pixels(i) for i in loaded if not isinstance(i, torch.Tensor)]
         u8 = self._resize(pre, raw)
@@ -490,6 +542,19 @@ class OPEN_CLIP(AbstractCLIPModel):
             # each, 71 k staged; profiles/r05w_e2e_stages.txt).  Not for callers that take device rows either: they are the ingest pipelines
             # (ingest.py), which pack group g + 1 while group g runs — their chip-filling groups stay whole (the stream: 119.9 k embeddings/s at
             # gemm_frac 0.31 whole, 119.0 k at 0.26 staged)
+            if isinstance(images, list) and images and isinstance(images[0], torch.Tensor) and getattr(images[0], "_mq_block", None) is not None:
+                # what `.preprocess` handed out (the reference's download threads, add_docs.py:129-141): the images already sit side by side in
+                # the preprocess slab — the tower reads the slab slice(s); no per-image Python, no gather, no staging (nothing to overlap: the
+                # pixels are in HBM)
+                runs = self._slab_runs(images)
+                if runs is not None and len(runs) <= max(1, len(images) // 8):
+                    cur = torch.cuda.current_stream(self.device)
+                    for r in runs:
+                        r.record_stream(cur)           # (the block was allocated on a download thread's stream)
+                    px = runs[0] if len(runs) == 1 else torch.cat(runs)
+                    self.image_input_processed = px
+                    out = run("f32", px)
+                    return out if return_device else self._convert_output(out)
             if isinstance(images, list) and len(images) >= PIPELINE_MIN and ((alone and not return_device) or PIPELINE_ALWAYS):
                 outs, pxs = [], []
                 main = torch.cuda.current_stream(self.device)

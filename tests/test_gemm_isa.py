@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "marqo_amd", "csrc", "gemm_bf16.hip")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
-BIAS, GELU, RESIDUAL, OUT_F32, ROW_STATS, LN_APPLY = 1, 2, 8, 16, 64, 128
+BIAS, GELU, RESIDUAL, OUT_F32, ROW_STATS, LN_APPLY, GLU = 1, 2, 8, 16, 64, 128, 256
 
 
 def _compile(tmp_path, flags, mt, src=SRC, rowscale=0, nh=1, wm=2):
@@ -137,7 +137,7 @@ def _check(isa, remarks, mfma_name, n_mfma, n_reads_expected, hot_regions=1):
 
 @pytest.mark.skipif(not shutil.which(HIPCC), reason="hipcc not installed")
 @pytest.mark.parametrize("flags,mt", [(BIAS, 5), (BIAS | RESIDUAL, 5), (BIAS | GELU, 4), (BIAS | RESIDUAL | OUT_F32, 6), (BIAS | GELU | LN_APPLY, 5), (BIAS | RESIDUAL | ROW_STATS, 5),
-                                      (BIAS | RESIDUAL | ROW_STATS, 3), (0, 2)])
+                                      (BIAS | RESIDUAL | ROW_STATS, 3), (0, 2), (BIAS | GLU | LN_APPLY, 5), (BIAS | GLU, 6)])
 def test_asm_fragment_reads_are_waited_for_before_any_use(tmp_path, flags, mt):
     isa, remarks = _compile(tmp_path, flags, mt)
     _check(isa, remarks, "v_mfma_f32_16x16x32_bf16", 8 * mt, 3 * (mt + 4))    # reads: prologue + both half-steps

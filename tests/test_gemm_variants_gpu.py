@@ -184,3 +184,36 @@ def test_the_big_tile_is_bit_identical_to_the_narrow_one_except_its_tail(nh, tai
                     assert all(torch.equal(p, q) for p, q in zip(first, big)), (nh, (M, N, K), rep)
     finally:
         _tune(lib, **DEFAULTS)
+
+
+@pytest.mark.parametrize("M,F,K,ldc_mult", [(4099, 192, 128, 2), (12800, 2048, 768, 2), (300, 64, 64, 1), (1000, 2752, 1024, 2)])
+def test_gated_epilogue_forms_the_swiglu_product(M, F, K, ldc_mult):
+    """round 6, MQ_EPI_GLU: W = (up, gate) rows interleaved 16 by 16 -> out[m, u] = (A W_up^T + b_up) * silu(A W_gate^T + b_gate), written at row stride ldc
+    (2 F inside the towers: the product takes the place of the (up | gate) tensor's first half); every tile height, the big tile, ragged M"""
+    lib = L.load()
+    g = torch.Generator(device="cuda").manual_seed(M + F)
+    A = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+    Wu = (torch.randn(F, K, device="cuda", generator=g) / K ** 0.5).to(torch.bfloat16)
+    Wg = (torch.randn(F, K, device="cuda", generator=g) / K ** 0.5).to(torch.bfloat16)
+    bu, bg = torch.randn(F, device="cuda", generator=g), torch.randn(F, device="cuda", generator=g)
+    il = lambda u, v: torch.stack([u.reshape(F // 16, 16, *u.shape[1:]), v.reshape(F // 16, 16, *v.shape[1:])], dim=1).reshape(2 * F, *u.shape[1:]).contiguous()
+    W, b = il(Wu, Wg), il(bu, bg)
+    up = A.float() @ Wu.float().t() + bu
+    gt = A.float() @ Wg.float().t() + bg
+    want = up * torch.nn.functional.silu(gt)
+    ldc = ldc_mult * F
+    GLU = 256
+    outs = []
+    try:
+        for kw in (dict(), dict(gemm_mt=2), dict(gemm_mt=6), dict(gemm_nh=3)):
+            _tune(lib, **{**DEFAULTS, **kw})
+            out = torch.full((M, ldc), 7.0, device="cuda", dtype=torch.bfloat16)
+            L.check(lib.mq_gemm_bf16(A.data_ptr(), K, W.data_ptr(), K, b.data_ptr(), 0, out.data_ptr(), ldc, M, 2 * F, K, L.MQ_EPI_BIAS | GLU, torch.cuda.current_stream().cuda_stream))
+            err = (out[:, :F].float() - want).abs().max().item() / (want.abs().max().item() + 1e-6)
+            assert err < 2e-2, (kw, err)
+            if ldc > F:
+                assert bool((out[:, F:] == 7.0).all())          # nothing is written behind the product
+            outs.append(out)
+        assert all(torch.equal(o, outs[0]) for o in outs[1:])   # tile shapes change scheduling only
+    finally:
+        _tune(lib, **DEFAULTS)

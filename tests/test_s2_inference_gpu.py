@@ -337,6 +337,62 @@ def test_every_kernel_family_knob_keeps_vectorise_right(s2):
     print("knob sweep, max 1 - cos vs the default configuration:", {f"{k}={v}": f"{e:.1e}" for (k, v), e in worst.items()})
 
 
+def test_preprocess_slab_views_are_encoded_without_a_gather(s2):
+    """round 6: `.preprocess` (called image by image from the reference's download threads, add_docs.py:129-141) returns a
+    Tensor (3, 224, 224) on the device — the add_documents contract (test_add_documents_combined.py:411-439) — that is a VIEW of a per-model slab;
+    a list of such views is encoded from the slab slices themselves.  Same bits as the gather of the same tensors, for neighbouring slots, for a
+    shuffled list (few long runs or the stacked fallback), for copies (no slot information: fallback), from several threads at once."""
+    import threading
+    s2i, _ = s2
+    os.environ["MARQO_AMD_SYNTHETIC_WEIGHTS"] = "1"
+    name = "open_clip/ViT-B-32/laion2b_s34b_b79k"
+    props = s2i.get_model_properties_from_registry(name)
+    model, pre = s2i.load_multimodal_model_and_get_preprocessors(name, props, DEV)
+    enc = s2i.get_available_models()[s2i._create_model_cache_key(name, DEV, props)]["model"]
+    rng = np.random.default_rng(11)
+    pil = [Image.fromarray(rng.integers(0, 256, (200 + 3 * i, 260 - 2 * i, 3), dtype=np.uint8)) for i in range(40)]
+    views = [pre["image"](p) for p in pil]
+    for v in views:
+        assert isinstance(v, torch.Tensor) and tuple(v.shape) == (3, 224, 224) and v.dtype == torch.float32 and v.is_cuda and v.to(DEV) is v
+    assert all(v._mq_block is views[0]._mq_block and v._mq_slot == views[0]._mq_slot + k for k, v in enumerate(views))      # side by side in one block
+    want = enc.encode_image(torch.stack([v.clone() for v in views]))                       # the batch form (no slot information)
+    got = enc.encode_image(views)
+    assert np.array_equal(got, want)
+    assert enc.image_input_processed.data_ptr() == views[0].data_ptr()                      # the tower read the slab itself
+    ref = O.vit_forward(__import__("marqo_amd.engine.synthetic", fromlist=["x"]).random_open_clip_state_dict(
+        vision=__import__("marqo_amd.engine.archs", fromlist=["x"]).resolve_open_clip("ViT-B-32")[0],
+        text=__import__("marqo_amd.engine.archs", fromlist=["x"]).resolve_open_clip("ViT-B-32")[1], seed=0),
+        O.VitConfig(224, 32, 768, 12, 12, 3072, 512), torch.from_numpy(np.stack([OP.clip_transform(np.asarray(p)) for p in pil[:4]]))).numpy()
+    assert _cos_err(got[:4], ref) < COS_TOL
+    order = list(rng.permutation(40))
+    assert np.array_equal(enc.encode_image([views[i] for i in order]), want[order])         # scattered slots: the stacked fallback
+    two_runs = views[20:] + views[:20]
+    assert np.array_equal(enc.encode_image(two_runs), np.concatenate([want[20:], want[:20]]))
+    mixed = [v if i % 2 else v.clone() for i, v in enumerate(views)]
+    assert np.array_equal(enc.encode_image(mixed), want)                                    # copies carry no slot: fallback
+    assert np.array_equal(np.asarray(s2i.vectorise_ndarray(name, views, model_properties=props, device=DEV, modality=s2i.Modality.IMAGE)), want)
+    # four "download threads" preprocess at once (slots interleave between them), each document batch is then encoded: still right
+    outs, errs = {}, []
+
+    def worker(t):
+        try:
+            mine = [pre["image"](pil[i]) for i in range(t, 40, 4)]
+            outs[t] = enc.encode_image(mine)
+        except BaseException as e:  # noqa: BLE001
+            errs.append(e)
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    assert not errs
+    for t in range(4):
+        assert np.array_equal(outs[t], want[t::4])
+    # an in-place edit of a view IS an edit of the slab: the tower sees it
+    views[3].mul_(0.5)
+    assert not np.array_equal(enc.encode_image(views)[3], want[3])
+
+
 def test_hf_xlm_roberta_from_disk(s2, tmp_path):
     """an XLM-RoBERTa checkpoint directory (multilingual-e5 layout: config.json model_type xlm-roberta, `roberta.`-prefixed
     safetensors, sentencepiece.bpe.model) through the `hf` loader: SentencePiece tokeniser on the host, BERT tower with the

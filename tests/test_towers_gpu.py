@@ -541,7 +541,7 @@ def test_eva02_tower_vs_oracle(name, layers, n, monkeypatch):
     u8 = O.synthetic_images_u8(n, varch.image_size, seed=8)
     ref = O.eva_vit_forward(sd, cfg, O.preprocess_u8_exact_size(u8))
     vt = T.VitTower(varch, sd, "cuda")
-    assert vt.cfg.enc.mlp_glu == 1 and vt.cfg.enc.mlp_ln_dim == varch.mlp_dim and vt.cfg.enc.mlp_dim % 64 == 0 and vt.residual_stream in ("bf16", "fp32")
+    assert vt.cfg.enc.mlp_glu == 2 and vt.cfg.enc.mlp_ln_dim == varch.mlp_dim and vt.cfg.enc.mlp_dim % 64 == 0 and vt.residual_stream in ("bf16", "fp32")
     out = vt.encode_u8(u8.cuda())
     assert out.shape == (n, varch.out_dim) and _cos_err(out, ref) < COS_TIGHT
     assert _cos_err(vt.encode_u8(u8[:1].cuda()), ref[:1]) < COS_TIGHT
