@@ -111,33 +111,45 @@ class _DeviceRows:
 
 
 class _RowSlab:
-    """one growing [capacity, D] float32 host array per rank: every settled group's rows are copied ONCE, from the pinned block their D2H landed in,
-    to the slab's tail — so collect() has one contiguous [n, D] array to hand to the gather (or to slice rows from) without stacking anything."""
+    """a rank's filed rows on the host: a short list of large [chunk, D] float32 arrays.  Every settled group's rows are copied ONCE, from the pinned
+    block their D2H landed in, to the current chunk's tail (a group never straddles two chunks); a full chunk is followed by a fresh one — nothing is
+    ever re-copied while the stream runs.  Row positions count the rows in filing order, i.e. positions in the concatenation of the chunks' used
+    parts: collect() slices rows out of the chunks (single rank: no copy at all) or concatenates them once for the gather."""
+    CHUNK_ROWS = 65536
 
     def __init__(self):
-        self.buf: Optional[np.ndarray] = None
+        self.chunks: List[np.ndarray] = []
+        self.used: List[int] = []
         self.n = 0
 
     def tail(self, n: int, D: int) -> np.ndarray:
         """a writable view of the next n rows (commit() makes them part of the slab)"""
-        if self.buf is not None and self.buf.shape[1] != D:
-            raise ValueError(f"row width changed inside one stream: {self.buf.shape[1]} -> {D}")
-        cap = 0 if self.buf is None else self.buf.shape[0]
-        if self.n + n > cap:
-            grown = np.empty((max(2 * cap, self.n + n, 4096), D), dtype=np.float32)
-            if self.n:
-                grown[:self.n] = self.buf[:self.n]
-            self.buf = grown
-        return self.buf[self.n:self.n + n]
+        if self.chunks and self.chunks[-1].shape[1] != D:
+            raise ValueError(f"row width changed inside one stream: {self.chunks[-1].shape[1]} -> {D}")
+        if not self.chunks or self.used[-1] + n > self.chunks[-1].shape[0]:
+            self.chunks.append(np.empty((max(self.CHUNK_ROWS, n), D), dtype=np.float32))
+            self.used.append(0)
+        return self.chunks[-1][self.used[-1]:self.used[-1] + n]
 
     def commit(self, n: int) -> int:
-        base, self.n = self.n, self.n + n
+        base = self.n
+        self.used[-1] += n
+        self.n += n
         return base
 
-    def take(self) -> Optional[np.ndarray]:
-        out = None if self.buf is None else self.buf[:self.n]
-        self.buf, self.n = None, 0
+    def take(self) -> List[np.ndarray]:
+        """the used parts of the chunks, in filing order; the slab is empty afterwards"""
+        out = [c[:u] for c, u in zip(self.chunks, self.used) if u]
+        self.chunks, self.used, self.n = [], [], 0
         return out
+
+
+def _rows_at(parts: List[np.ndarray], positions: np.ndarray):
+    """(chunk index, row inside the chunk) per position of the concatenation of `parts`, vectorised"""
+    starts = np.zeros(len(parts) + 1, dtype=np.int64)
+    np.cumsum([p.shape[0] for p in parts], out=starts[1:])
+    which = np.searchsorted(starts, positions, side="right") - 1
+    return which, positions - starts[which]
 
 
 class BulkVectoriser:
@@ -545,8 +557,9 @@ class RequestShardedIngest:
         """the filed rows in submission order (tests / diagnostics: the stream itself never touches single rows before collect())"""
         if not self._nrows:
             return []
-        host = torch_cat_host(self._dev_blocks) if self._on_device else self._slab.buf
-        return [host[p] for p in np.concatenate(self._perm)]
+        parts = [torch_cat_host(self._dev_blocks)] if self._on_device else [c[:u] for c, u in zip(self._slab.chunks, self._slab.used) if u]
+        which, local = _rows_at(parts, np.concatenate(self._perm))
+        return [parts[b][l] for b, l in zip(which.tolist(), local.tolist())]
 
     def _place(self, group, base: int, n_text: int) -> None:
         """labels and row positions of a filed group whose rows sit at [base, ...) of the rank's row space as [the group's texts | its images]"""
@@ -812,23 +825,24 @@ class RequestShardedIngest:
         self.failed_requests = sorted(failed)
         perm = np.concatenate(perms) if perms else np.zeros(0, dtype=np.int64)
 
-        def scatter(out, labels, positions, rows):
+        def scatter(out, labels, positions, parts):
+            which, at = _rows_at(parts, positions)
             cur_ri, cur = None, None
-            for (ri, key), p in zip(labels, positions):
+            for (ri, key), b, l in zip(labels, which.tolist(), at.tolist()):
                 if ri != cur_ri:
                     cur_ri, cur = ri, out.setdefault(ri, {})
-                cur[key] = rows[p]
+                cur[key] = parts[b][l]
             return out
         if self.world == 1:
-            # (no copy: the rows are views of the slab)
-            return scatter({}, index, perm.tolist(), local) if n else {}
+            # (no copy: the rows are views of the slab's chunks)
+            return scatter({}, index, perm, local) if n else {}
         dist = self._dist
         where = self.device if self._on_device else "cpu"
         # who holds what: (row count, width) per rank + the labels and their row positions (tiny next to the rows)
         if self._on_device:
             t = torch.cat(dev_blocks) if len(dev_blocks) > 1 else (dev_blocks[0] if dev_blocks else None)
         else:
-            t = torch.from_numpy(local) if local is not None and n else None
+            t = torch.from_numpy(local[0] if len(local) == 1 else np.concatenate(local)) if n else None      # (the ONE host copy a multi-chunk rank pays, at the end of the stream)
         meta = [None] * self.world
         mine = (n, int(t.shape[1]) if t is not None else 0, (index, perm) if self.rank != self.root else None, failed)
         dist.all_gather_object(meta, mine)
@@ -848,7 +862,7 @@ class RequestShardedIngest:
         base = 0
         for r in range(self.world):
             labels, positions = (index, perm) if r == self.root else meta[r][2]
-            scatter(out, labels, (positions + base).tolist(), full)
+            scatter(out, labels, positions + base, [full])
             base += counts[r]
         return out
 

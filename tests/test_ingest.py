@@ -521,7 +521,7 @@ def test_collect_moves_blocks_not_rows():
         ing.submit(i, items)
     ing.drain()
     assert ing._nrows == n_req * per_req and len(ing._perm) == n_req and ing._slab.n == ing._nrows
-    assert isinstance(ing._slab.buf, np.ndarray) and ing._slab.buf.shape[1] == D                      # ONE array, not a list of rows
+    assert len(ing._slab.chunks) == 1 and ing._slab.chunks[0].shape[1] == D                           # ONE array (a few for long streams), not a list of rows
     # what a non-root rank does inside collect() before the collectives, with a line counter on: no per-row Python
     lines = [0]
 
@@ -533,7 +533,8 @@ def test_collect_moves_blocks_not_rows():
     sys.settrace(tracer)
     try:
         index, perms, n = ing._index, ing._perm, ing._nrows
-        local = ing._slab.buf[:ing._slab.n]
+        local = [c[:u] for c, u in zip(ing._slab.chunks, ing._slab.used) if u]
+        local = local[0] if len(local) == 1 else np.concatenate(local)
         perm = np.concatenate(perms)
         payload = (n, int(local.shape[1]), (index, perm), [])
     finally:
@@ -552,3 +553,21 @@ def test_collect_moves_blocks_not_rows():
             assert np.array_equal(rows[i][(i, j)], table[i * per_req + j])
     assert t_collect < 0.5            # (the root / single rank builds 25 000 dictionary entries: tens of milliseconds)
     assert ing.collect() == {} and ing._nrows == 0 and ing._slab.n == 0
+
+
+def test_row_slab_spills_into_further_chunks_without_recopying(monkeypatch):
+    from marqo_amd import ingest as I
+    monkeypatch.setattr(I._RowSlab, "CHUNK_ROWS", 50)
+    table = np.arange(400 * 8, dtype=np.float32).reshape(400, 8)
+    ing = I.RequestShardedIngest("m", "cpu", vectorise_fn=lambda model, content, **kw: table[[int(c) for c in content]], merge_images=8, merge_deadline_ms=0)
+    for i in range(40):
+        ing.submit(i, [((i, j), str(i * 10 + j), Modality.IMAGE if j % 2 else Modality.TEXT) for j in range(10)])
+    ing.drain()
+    assert len(ing._slab.chunks) > 3 and sum(ing._slab.used) == 400 and all(u <= 50 for u in ing._slab.used)
+    first = ing._slab.chunks[0]
+    rows = ing.collect()
+    assert np.shares_memory(rows[0][(0, 0)], first)                       # single rank: views of the chunks, nothing copied
+    for i in range(40):
+        assert list(rows[i]) == [(i, j) for j in range(10)]
+        for j in range(10):
+            assert np.array_equal(rows[i][(i, j)], table[i * 10 + j])
