@@ -644,36 +644,41 @@ class RequestShardedIngest:
             raise mine
         return first
 
-    def _resolve(self, inflight, reraise: bool) -> None:
+    def _resolve(self, inflight, reraise: bool, deferred: Optional[list] = None) -> None:
         """wait for a launched group's rows and file them; a failure that surfaces here (an asynchronous device error at the deferred copy)
-        fails a lone request, and sends a merged group through `_run_alone`"""
+        fails a lone request, and sends a merged group through `_run_alone`.  `deferred` (the overlapped settle: a launcher thread is inside
+        flush_async on the SAME BulkVectoriser right now): the failed group is only noted — its recovery resets and re-uses that BulkVectoriser and
+        must wait until the launcher has returned (a concurrent reset() could drop the new group's queued items)"""
         group, handle = inflight
-        blocks = []
         try:
-            blocks = handle.result_blocks()
-            self._file_blocks(group, blocks)
+            self._file_blocks(group, handle.result_blocks())
         except BaseException as e:  # noqa: BLE001
-            self._bulk.reset()
-            if len(group) == 1:
-                self._fail(group[0][0], e)
-                if reraise:
-                    raise
+            if deferred is not None:
+                deferred.append((group, e))
                 return
-            first = self._run_alone(group)
-            if reraise and first is not None:
-                raise first
+            self._recover(group, e, reraise)
+
+    def _recover(self, group, e: BaseException, reraise: bool) -> None:
+        self._bulk.reset()
+        if len(group) == 1:
+            self._fail(group[0][0], e)
+            if reraise:
+                raise e
             return
+        first = self._run_alone(group)
+        if reraise and first is not None:
+            raise first
 
     @property
     def _inflight(self):
         """the youngest group in flight (tests / diagnostics)"""
         return self._inflight_q[-1] if self._inflight_q else None
 
-    def _settle(self, reraise: bool, keep: int = 0) -> None:
+    def _settle(self, reraise: bool, keep: int = 0, deferred: Optional[list] = None) -> None:
         """file the rows of all but the `keep` youngest groups in flight, oldest first; `reraise`: raise the LAST settled group's error"""
         while len(self._inflight_q) > keep:
             inflight = self._inflight_q.pop(0)
-            self._resolve(inflight, reraise and len(self._inflight_q) == keep)
+            self._resolve(inflight, reraise and len(self._inflight_q) == keep, deferred)
 
     def _launch_open(self, raise_for: Optional[int] = None) -> None:
         """(lock held) everything waiting becomes ONE group: queued, tokenised / packed / enqueued now; the previous group's rows are filed
@@ -693,10 +698,18 @@ class RequestShardedIngest:
                     from concurrent.futures import ThreadPoolExecutor
                     self._launcher = ThreadPoolExecutor(max_workers=1, thread_name_prefix="marqo-amd-ingest-launch")
                 fut = self._launcher.submit(self._bulk.flush_async)
+                late: list = []
                 try:
-                    self._settle(reraise=False, keep=self.pipeline_depth - 1)
+                    self._settle(reraise=False, keep=self.pipeline_depth - 1, deferred=late)
                 finally:
-                    handle = fut.result()
+                    try:
+                        handle = fut.result()
+                    finally:
+                        # groups whose rows failed at the deferred copy: re-run request by request NOW — the launcher is out of the
+                        # BulkVectoriser (its group's items sit in `handle`, not in the queue `_recover` resets), the order of filing is kept
+                        # (the new group is filed later)
+                        for g_, e_ in late:
+                            self._recover(g_, e_, reraise=False)
             else:
                 handle = self._bulk.flush_async()
         except BaseException as e:
