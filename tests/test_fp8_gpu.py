@@ -495,3 +495,41 @@ def test_fp8_tower_on_the_bf16_residual_stream(tiled_gemm_only, monkeypatch):
                 L.check(L.load().mq_tune(b"row_select", 1))
             assert torch.equal(full, out)
     assert not torch.equal(outs["fp32"], outs["bf16"])
+
+
+@pytest.mark.parametrize("M,N,K", [(4099, 768, 256), (1000, 260, 128), (16448, 1024, 4096)])
+def test_big_8_wave_tile_is_bit_identical_to_the_narrow_tiles(M, N, K):
+    """round 6: the 192 x 256 x 128 tile of 8 waves (gemm_fp8_kernel NH = 2, WM = 4) — same k-order per output element as the (32 MT) x 128 tiles, so the
+    same bits, with every epilogue: per-row scales + bias -> bf16; GELU -> e4m3 (+ amax); bias + bf16 residual in place; bias + fp32 residual; plain fp32;
+    ragged M and N (N % 256 != 0, N < 256 falls back to the narrow tile by itself)"""
+    lib = L.load()
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    A8 = torch.randint(0, 0x78, (M, K), dtype=torch.uint8, device="cuda", generator=g)
+    W8 = torch.randint(0, 0x78, (N, K), dtype=torch.uint8, device="cuda", generator=g)
+    sa_row = torch.rand(M, device="cuda", generator=g) + 0.5
+    sa_one = torch.tensor([0.7], device="cuda")
+    sw = torch.rand(N, device="cuda", generator=g) * 1e-3
+    bias = torch.randn(N, device="cuda", generator=g)
+    res32 = torch.randn(M, N, device="cuda", generator=g)
+    osc = torch.tensor([0.05], device="cuda")
+    forms = [(L.MQ_EPI_BIAS, 1, torch.bfloat16, None), (L.MQ_EPI_BIAS | L.MQ_EPI_GELU | L.MQ_EPI_OUT_FP8, 1, torch.uint8, None),
+             (L.MQ_EPI_BIAS | L.MQ_EPI_RESIDUAL, 0, torch.bfloat16, res32.to(torch.bfloat16)), (L.MQ_EPI_BIAS | L.MQ_EPI_RESIDUAL | L.MQ_EPI_OUT_F32, 0, torch.float32, res32),
+             (L.MQ_EPI_OUT_F32, 0, torch.float32, None)]
+
+    def run(flags, rowscale, dtype, res):
+        out = res.clone() if res is not None else torch.empty(M, N, device="cuda", dtype=dtype)
+        amax = torch.zeros(1, device="cuda")
+        L.check(lib.mq_gemm_fp8(A8.data_ptr(), K, W8.data_ptr(), K, (sa_row if rowscale else sa_one).data_ptr(), rowscale, sw.data_ptr(), bias.data_ptr(),
+                                out.data_ptr() if res is not None else 0, out.data_ptr(), N, osc.data_ptr(), amax.data_ptr(), M, N, K, flags, _stream()))
+        return out, amax
+    try:
+        L.check(lib.mq_tune(b"gemm_nh", 1))
+        narrow = [run(*f) for f in forms]
+        L.check(lib.mq_tune(b"gemm_nh", 3))
+        for f, (want, want_amax) in zip(forms, narrow):
+            for _ in range(2):
+                got, amax = run(*f)
+                assert torch.equal(got.view(torch.uint8) if got.dtype == torch.uint8 else got, want), f[0]
+                assert torch.equal(amax, want_amax)
+    finally:
+        L.check(lib.mq_tune(b"gemm_nh", 0))
