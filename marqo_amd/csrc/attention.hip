@@ -325,6 +325,9 @@ static int attention_impl(const void* d_qkv, void* d_out, const int32_t* d_cu_se
     // (65..80 tokens are FIVE query blocks — the 77-token CLIP / BERT rows; five-wave workgroups, one block per wave instead of a second round
     // with three waves idle, measured neutral to slower: CLIP text -0.7 %, BERT-base +3.6 % attention time, profiles/r02p_attention_five_waves_ab.txt;
     // kept behind mq_tune("attn_waves", 5) with its bit-identity test)
+    // (round 6: NINE waves where they save a whole round of query blocks — 257 tokens = 17 blocks: 3 rounds of 8 waves, 2 of 9; 576 tokens: 5 -> 4 — were
+    // built and measured: +10-11 % attention time on ViT-L/14, EVA02-L-14 and SigLIP-L-16-384, profiles/r06l_attention_nine_waves_ab.txt — an odd wave
+    // count sits 3 + 2 + 2 + 2 on the SIMDs; not kept)
     const bool five = mq_attention_waves == 5 && maxl > 64 && maxl <= 80 && hs == 64 && !d_rel_bias;
     const int knob_waves = mq_attention_waves;
     const int nw = five ? 5 : (knob_waves == 4 || knob_waves == 8 ? knob_waves : (maxl > 128 ? 8 : 4));
