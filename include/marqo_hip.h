@@ -46,7 +46,7 @@ extern "C" {
 #define MQ_ERR_WORKSPACE (-3) /* caller's workspace too small */
 #define MQ_ERR_UNSUPPORTED (-4) /* ABI 11: the device is not the one this library is built for (mq_check_device) */
 
-#define MQ_ABI_VERSION 11
+#define MQ_ABI_VERSION 12
 
 /* ---- activation / mask / pooling selectors ---------------------------------------- */
 #define MQ_ACT_NONE 0
@@ -112,6 +112,12 @@ typedef struct mq_block_weights {
      * over the first mq_encoder_cfg.mlp_ln_dim columns — the checkpoint's hidden width — when F is that width zero-padded to a multiple of 64). */
     const float* attn_ln_g; const float* attn_ln_b;
     const float* mlp_ln_g;  const float* mlp_ln_b;
+    /* ABI 12 — the sub-LayerNorms folded into the GEMMs behind them (bf16 stream, tiled GEMM family; all six NULL = the LayerNorm kernels run):
+     * out_wf = bf16(attn_ln_g[k] * out_w[n,k]) [W, attn_width], out_sf its row sums, out_bf = out_b + out_w @ attn_ln_b;
+     * fc2_wf = bf16(mlp_ln_g[k] * fc2_w[n,k]) [W, F], fc2_sf, fc2_bf likewise.  The rows' (mean, rstd) come from the launch that wrote them: the
+     * attention kernel's per-head sums (mq_attention_stats), the gated epilogue's per-slot sums (mq_gemm_bf16_lnrs with MQ_EPI_GLU). */
+    const void*  out_wf; const float* out_sf; const float* out_bf;
+    const void*  fc2_wf; const float* fc2_sf; const float* fc2_bf;
 } mq_block_weights;
 
 typedef struct mq_encoder_cfg {
@@ -466,7 +472,7 @@ int mq_ln_gemm_small_bf16(const void* d_x, int64_t ldx, int x_bf16, const float*
  * Replaces what open_clip's ResidualAttentionBlock computes as ln_1 -> attn.in_proj / ln_2 -> mlp.c_fc
  * (reached from /root/reference/src/marqo/core/inference/embedding_models/open_clip_model.py:249-266).
  *   mq_gemm_bf16_rs + mq_row_stats_finalize: when the rows were just written by a residual GEMM of the bf16 stream, that GEMM can leave
- *                    per-row partial sums behind (d_partials fp32 [M][ceil(N/64)][2]: (sum, sum of squares) of the bf16 values it stored per
+ *                    per-row partial sums behind (d_partials fp32 [ceil(N/64)][M][2], SLOT-major since ABI 12: (sum, sum of squares) of the bf16 values it stored per
  *                    64-column slot) and the statistics pass shrinks to a finalise over those partials — same d_stats layout as mq_row_stats.
  *                    flags of mq_gemm_bf16_rs: MQ_EPI_BIAS | MQ_EPI_RESIDUAL (bf16 in / out, in place). */
 #define MQ_EPI_ROW_STATS 64
@@ -478,6 +484,16 @@ int mq_ln_gemm_small_bf16(const void* d_x, int64_t ldx, int x_bf16, const float*
 int mq_gemm_bf16_rs(const void* d_A, int64_t lda, const void* d_W, int64_t ldw, const float* d_bias, const void* d_residual, void* d_out, int64_t ldc,
                     int64_t M, int64_t N, int64_t K, int flags, float* d_partials, void* stream);
 int mq_row_stats_finalize(const float* d_partials, int32_t nslots, float* d_stats, int64_t rows, int32_t W, float eps, void* stream);
+/* ABI 12 — LN_APPLY and ROW_STATS in one launch (csrc/gemm_bf16.hip; the EVA02 sub-LayerNorms, timm eva.py EvaAttention.norm / SwiGLU.norm, reached from
+ * /root/reference/src/marqo/core/inference/embedding_models/open_clip_model.py:249-266): out = [residual +] LN(A) @ W0^T + b0 with d_W / d_bias / d_colsum
+ * folded as for mq_gemm_bf16_ln, d_rowstats = (mean, rstd) of A's rows, and d_partials = (sum, sum of squares) per row and 64-column slot of what the
+ * launch stores.  flags: MQ_EPI_BIAS | MQ_EPI_RESIDUAL (bf16 residual read-modify-write; d_partials [ceil(N/64)][M][2]) or MQ_EPI_BIAS | MQ_EPI_GLU
+ * (d_residual NULL; out [M, N/2]; a slot = 64 GEMM columns = 32 hidden units: d_partials [ceil(N/64)][M][2] of the rounded products).
+ * mq_attention_stats = mq_attention that also writes (sum, sum of squares) of every output row's rounded values per head: d_row_part [heads][rows][2] (slot-major; rows = the call's token rows). */
+int mq_gemm_bf16_lnrs(const void* d_A, int64_t lda, const void* d_W, int64_t ldw, const float* d_bias, const float* d_colsum, const float* d_rowstats,
+                      const void* d_residual, void* d_out, int64_t ldc, int64_t M, int64_t N, int64_t K, int flags, float* d_partials, void* stream);
+int mq_attention_stats(const void* d_qkv, void* d_out, const int32_t* d_cu_seqlens, int64_t nseq, int32_t fixed_len, int32_t max_len, int32_t W,
+                       int32_t heads, int32_t mask, float* d_row_part, int64_t rows, void* stream);
 /* ABI 11 — mq_gemm_bf16_rsf = mq_gemm_bf16_rs + the finalise, in ONE launch: on return (stream order) d_stats holds (mean, rstd) of every row of d_out,
  * bit for bit what mq_row_stats_finalize would have written (same slot order, same expression).  The last wave to arrive at a row band's counter sums
  * the band's partials inside the GEMM's own launch (csrc/gemm_epilogue.h, GemmLn::band_ctr); d_band_ctr: mq_gemm_band_counters(M) 32-bit counters, all
@@ -637,7 +653,8 @@ int mq_weighted_combine(const float* d_emb, int64_t ld, const int32_t* d_rows, c
  * with both k-halves' W loads issued together), "rs_finalize" (1 = mq_gemm_bf16_rsf finalises the row statistics inside the GEMM's launch),
  * "gemm_addr_limit_mb" (bytes / 2^20 one launch may address per operand, 0 = the 4 GiB of a 32-bit buffer offset: taller matrices go in
  * row chunks), "row_select" (0 = the towers run their last block on every row instead of the pooled rows only), "ln_fold" (0 = LayerNorm
- * kernels, 1 = folded into the QKV GEMM, 2 = and into fc1; needs the folded weights), "residual_bf16", "small_m" / "small_m_grouped"
+ * kernels, 1 = folded into the QKV GEMM, 2 = and into fc1; needs the folded weights), "subln_fold" (ABI 12: 0 = the EVA02 sub-LayerNorms run as
+ * LayerNorm passes instead of inside the out-projection / fc2 GEMMs; MQ_SUBLN_FOLD), "residual_bf16", "small_m" / "small_m_grouped"
  * (row limits of the skinny GEMM kernels), "ln_prefetch", "xcd_band", "attn_waves" (0 = auto, 4 / 8 wave64s per attention workgroup).
  * Initial values come from the environment (MQ_GEMM_MT, MQ_GEMM_CGROUP, MQ_GEMM_NH, MQ_GEMM_TAIL, MQ_GEMM_WD, MQ_GEMM_RS_FIN, MQ_ROW_SELECT,
  * MQ_LN_FOLD, ...). */

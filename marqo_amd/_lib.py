@@ -29,7 +29,7 @@ STAGE_PATH = LIB_DIR / "_mq_stage.so"                # CPython extension: a batc
 
 MQ_OK = 0
 NO_SCRATCH_UNITS = ("rowops", "gemm_bf16", "gemm_wd", "gemm_fp8", "gemm_small", "attention", "embed")  # build() refuses register spills in these
-ABI_VERSION = 11
+ABI_VERSION = 12
 MQ_PREC_BF16, MQ_PREC_FP8 = 0, 1
 MQ_ACT_GELU, MQ_ACT_QUICKGELU, MQ_ACT_SILU = 1, 2, 3
 MQ_MASK_NONE, MQ_MASK_CAUSAL, MQ_MASK_CAUSAL_CLS = 0, 1, 2
@@ -58,7 +58,8 @@ class BlockWeights(C.Structure):
         "ln2_g", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b",
         "qkv_w8", "qkv_ws", "out_w8", "out_ws", "fc1_w8", "fc1_ws", "fc2_w8", "fc2_ws",
         "qkv_wf", "qkv_sf", "qkv_bf", "fc1_wf", "fc1_sf", "fc1_bf",
-        "attn_ln_g", "attn_ln_b", "mlp_ln_g", "mlp_ln_b")]
+        "attn_ln_g", "attn_ln_b", "mlp_ln_g", "mlp_ln_b",
+        "out_wf", "out_sf", "out_bf", "fc2_wf", "fc2_sf", "fc2_bf")]
 
 
 class EncoderCfg(C.Structure):
@@ -152,6 +153,8 @@ _SIGNATURES = {
     "mq_gemm_bf16_ln": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, _P]),
     "mq_row_stats": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_float, _P]),
     "mq_row_stats_finalize": (C.c_int, [_P, C.c_int32, _P, C.c_int64, C.c_int32, C.c_float, _P]),
+    "mq_gemm_bf16_lnrs": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, _P, _P]),
+    "mq_attention_stats": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int64, _P]),
     "mq_gemm_bf16_rs": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, _P, _P]),
     "mq_check_device": (C.c_int, [C.c_int]),
     "mq_gemm_band_counters": (C.c_int64, [C.c_int64]),

@@ -49,7 +49,7 @@ template <int MASK, bool OUT_FP8, int HD, int HS, int NW, bool BIAS = false>
 __global__ __launch_bounds__(NW * 64) MQ_ATTN_OCC void attention_kernel(
     const bf16_t* __restrict__ qkv, void* __restrict__ out_v, const int32_t* __restrict__ cu,
     int fixed_len, int W, int heads, int kpad, float scale_log2e, const float* __restrict__ out_scale, float* amax_out,
-    const float* __restrict__ rel_bias = nullptr, int rel_span = 0, int band = 0) {
+    const float* __restrict__ rel_bias = nullptr, int rel_span = 0, int band = 0, float2* __restrict__ row_part = nullptr, int64_t part_ld = 0) {
     bf16_t* out = (bf16_t*)out_v;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     static_assert(HS <= HD && HS % 16 == 0 && (HD == 64 || HD == 128), "head stride: multiple of 16, at most the LDS row");
@@ -272,12 +272,33 @@ __global__ __launch_bounds__(NW * 64) MQ_ATTN_OCC void attention_kernel(
                 }
             } else {
                 bf16_t* orow = out + (int64_t)(row0 + q) * W + h * HS + 4 * g;
+                float st1 = 0.f, st2 = 0.f;   // row_part: (sum, sum of squares) of this row's ROUNDED values over the head's columns
 #pragma unroll
                 for (int dt = 0; dt < NDT; ++dt) {
                     uint2 p;
                     p.x = pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv);
                     p.y = pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv);
                     *(uint2*)(orow + dt * 16) = p;
+                    if (row_part) {
+                        const float e0 = __uint_as_float(p.x << 16), e1 = __uint_as_float(p.x & 0xffff0000u), e2 = __uint_as_float(p.y << 16),
+                                    e3 = __uint_as_float(p.y & 0xffff0000u);
+                        st1 += (e0 + e1) + (e2 + e3);
+                        st2 += (e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3);
+                    }
+                }
+                // mq_attention_stats: one (sum, sum of squares) per (row, head) — the slot layout of the GEMMs' MQ_EPI_ROW_STATS, nslots = heads — for the
+                // LayerNorm that follows the attention (EVA02 attn.norm), folded into the out-projection.  The row's 4 lanes (g = 0..3) share q: all four
+                // are inside this branch together; fixed order, one writer
+                if (row_part) {
+                    auto fold = [](float v) {   // (VALU swaps instead of ds_bpermute, as gemm_epilogue.h)
+                        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+                        const float w = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+                        const auto u = __builtin_amdgcn_permlane32_swap(__float_as_uint(w), __float_as_uint(w), false, false);
+                        return __uint_as_float(u[0]) + __uint_as_float(u[1]);
+                    };
+                    st1 = fold(st1);
+                    st2 = fold(st2);
+                    if (g == 0) row_part[(int64_t)h * part_ld + (row0 + q)] = make_float2(st1, st2);   // slot-major [heads][rows], as GemmLn::partials
                 }
             }
         }
@@ -296,8 +317,10 @@ mq_knob mq_attention_waves{0};  // mq_tune("attn_waves", 0 = auto / 4 / 8 / 5 = 
 
 static int attention_impl(const void* d_qkv, void* d_out, const int32_t* d_cu_seqlens, int64_t nseq,
                           int32_t fixed_len, int32_t max_len, int32_t W, int32_t heads, int32_t mask,
-                          int32_t out_fp8, const float* d_out_scale, float* d_amax, const float* d_rel_bias, int32_t rel_span, void* stream) {
+                          int32_t out_fp8, const float* d_out_scale, float* d_amax, const float* d_rel_bias, int32_t rel_span, void* stream,
+                          float* d_row_part = nullptr, int64_t part_ld = 0) {
     MQ_CHECK_ARG(d_qkv && d_out, "mq_attention: null pointer");
+    MQ_CHECK_ARG(!d_row_part || (!out_fp8 && !d_rel_bias), "mq_attention_stats: bf16 output, no relative-position bias");
     MQ_CHECK_ARG(heads >= 1 && W % heads == 0, "mq_attention: W=%d is not a multiple of heads=%d", W, heads);
     const int hs = W / heads;             // head stride in memory = dims computed
     MQ_CHECK_ARG(hs == 64 || hs == 96 || hs == 112 || hs == 128, "mq_attention: head dim must be 64, 96, 112 or 128 (W=%d heads=%d)", W, heads);
@@ -340,7 +363,7 @@ static int attention_impl(const void* d_qkv, void* d_out, const int32_t* d_cu_se
         }
         hipLaunchKernelGGL(kern, dim3((unsigned)(nseq * heads)), dim3(nw * 64), lds, s, (const bf16_t*)d_qkv,
                            d_out, d_cu_seqlens, (int)fixed_len, (int)W, (int)heads, kpad, scale_log2e, d_out_scale, d_amax, d_rel_bias, (int)rel_span,
-                           (mq_xcd_band && nseq * heads >= 2048) ? 1 : 0);
+                           (mq_xcd_band && nseq * heads >= 2048) ? 1 : 0, (float2*)d_row_part, part_ld);
         return MQ_OK;
     };
     if (d_rel_bias) {
@@ -389,4 +412,13 @@ extern "C" int mq_attention_bias(const void* d_qkv, void* d_out, const int32_t* 
 extern "C" int mq_attention(const void* d_qkv, void* d_out, const int32_t* d_cu_seqlens, int64_t nseq, int32_t fixed_len,
                             int32_t max_len, int32_t W, int32_t heads, int32_t mask, void* stream) {
     return mq_attention_ex(d_qkv, d_out, d_cu_seqlens, nseq, fixed_len, max_len, W, heads, mask, 0, nullptr, nullptr, stream);
+}
+
+// mq_attention that also leaves (sum, sum of squares) of every output row's ROUNDED values per head behind: d_row_part fp32 [heads][rows][2] (slot-major, `rows` =
+// the token rows of the whole call) — the partials mq_row_stats_finalize(nslots = heads, rows, W) turns into the (mean, rstd) of a LayerNorm over the attention
+// output (EVA02 attn.norm, folded into the out-projection: mq_gemm_bf16_lnrs)
+extern "C" int mq_attention_stats(const void* d_qkv, void* d_out, const int32_t* d_cu_seqlens, int64_t nseq, int32_t fixed_len, int32_t max_len, int32_t W,
+                                  int32_t heads, int32_t mask, float* d_row_part, int64_t rows, void* stream) {
+    MQ_CHECK_ARG(d_row_part && rows >= 1 && (fixed_len <= 0 || rows == nseq * fixed_len), "mq_attention_stats: null partials / rows does not match the sequences");
+    return attention_impl(d_qkv, d_out, d_cu_seqlens, nseq, fixed_len, max_len, W, heads, mask, 0, nullptr, nullptr, nullptr, 0, stream, d_row_part, rows);
 }

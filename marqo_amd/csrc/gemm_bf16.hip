@@ -42,6 +42,7 @@ extern mq_knob mq_gemm_fp8_force_mt;  // gemm_fp8.hip
 extern mq_knob mq_gemm_fp8_big;       // gemm_fp8.hip: 0 = plan, 1 = never the big tile, 3 = always
 extern mq_knob mq_tower_row_select;   // towers.hip
 extern mq_knob mq_tower_ln_fold;      // towers.hip
+extern mq_knob mq_tower_subln_fold;
 extern mq_knob mq_attention_waves;    // attention.hip
 extern mq_knob mq_tower_residual_bf16;  // towers.hip
 extern mq_knob mq_gemm_small_max_rows;  // gemm_small.hip
@@ -102,7 +103,10 @@ __global__ __launch_bounds__(128 * WM, (NH == 1 && WM == 2) ? 2 : 1) void gemm_n
     constexpr int NLR = MT + NTW;   // fragment reads per wave per k-half (= NLD in the 4-wave kernels)
     constexpr int NM = NTW * MT;    // MFMAs per wave per k-half
     // residual rows prefetched together by the epilogue (16-row units): the next tile's first fragments are live across it
-    constexpr int ERG = !(FLAGS & MQ_EPI_RESIDUAL) ? MT : (NH == 2 || WM == 4) ? MT : (FLAGS & MQ_EPI_OUT_F32) ? (MT <= 3 ? MT : (MT + 1) / 2) : (MT <= 5 ? MT : 3);
+    // (LN_APPLY on top of the residual epilogue — mq_gemm_bf16_lnrs — holds 16 colsum + 2 MT statistics registers more: smaller residual groups)
+    constexpr bool LN_RES = (FLAGS & MQ_EPI_LN_APPLY) && (FLAGS & MQ_EPI_RESIDUAL);
+    constexpr int ERG = !(FLAGS & MQ_EPI_RESIDUAL) ? MT : LN_RES ? ((NH == 2 || WM == 4) ? 1 : MT <= 4 ? MT : 2) : (NH == 2 || WM == 4) ? MT
+                        : (FLAGS & MQ_EPI_OUT_F32) ? (MT <= 3 ? MT : (MT + 1) / 2) : (MT <= 5 ? MT : 3);
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     // ---- XCD-aware, bijective (virtual) block -> tile map, L2-blocked order inside an XCD's share (as in rounds 1-3) --------------
@@ -601,7 +605,7 @@ int launch_gemm_mt(const void* A, int64_t lda, const void* W, int64_t ldw, const
         const size_t res_row = (size_t)ldc * (((FLAGS & MQ_EPI_RESIDUAL) && !(FLAGS & MQ_EPI_OUT_F32)) ? 2 : 4);
         GemmLn ln_chunk = ln;
         if (ln_chunk.rowstats) ln_chunk.rowstats += r0;
-        if (ln_chunk.partials) ln_chunk.partials += r0 * ln_chunk.nslots;
+        if (ln_chunk.partials) ln_chunk.partials += r0;   // (slot-major: a row offset is a row offset)
         if (ln_chunk.band_ctr) {   // in-launch finalise: this launch's row bands (chunks are whole tiles), every wave of a band's column tiles arrives once
             ln_chunk.band_ctr += (r0 / BM) * WM;
             ln_chunk.stats_out += r0;
@@ -683,6 +687,21 @@ int plan_big_rows(int M, int N, int K) {
     return best_rows;
 }
 
+// the narrow tile at height mt (32-row units).  LN_APPLY on top of the residual epilogue (mq_gemm_bf16_lnrs) has no registers for the tallest tile: 5 instead
+template <int FLAGS>
+int launch_narrow(int mt, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* residual, void* out, int64_t ldc,
+                  int M, int N, int K, hipStream_t s, const GemmLn& ln) {
+    constexpr bool LN_RES = (FLAGS & MQ_EPI_LN_APPLY) && (FLAGS & MQ_EPI_RESIDUAL);
+    switch (mt) {
+        case 2: return launch_gemm_mt<FLAGS, 2>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s, ln);
+        case 5: return launch_gemm_mt<FLAGS, 5>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s, ln);
+        case 6:
+            if constexpr (LN_RES) return launch_gemm_mt<FLAGS, 5>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s, ln);
+            else return launch_gemm_mt<FLAGS, 6>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s, ln);
+        default: return launch_gemm_mt<FLAGS, 4>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s, ln);
+    }
+}
+
 template <int FLAGS>
 int launch_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* residual, void* out, int64_t ldc,
                 int M, int N, int K, hipStream_t s, const GemmLn& ln = GemmLn{}) {
@@ -696,7 +715,7 @@ int launch_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const fl
         const size_t res_row = (size_t)ldc * (((FLAGS & MQ_EPI_RESIDUAL) && !(FLAGS & MQ_EPI_OUT_F32)) ? 2 : 4);
         GemmLn ln2 = ln;
         if (ln2.rowstats) ln2.rowstats += big_rows;
-        if (ln2.partials) ln2.partials += (int64_t)big_rows * ln2.nslots;
+        if (ln2.partials) ln2.partials += big_rows;
         if (ln2.band_ctr) { ln2.band_ctr += (big_rows / 256) * 4; ln2.stats_out += big_rows; ln2.pf_na = ln2.pf_nb = 0; }   // (the first launch carried the prefetch)
         A = (const bf16_t*)A + (int64_t)big_rows * lda;
         if (residual) residual = (const float*)((const char*)residual + (size_t)big_rows * res_row);
@@ -704,21 +723,11 @@ int launch_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const fl
         M -= big_rows;
         const int knob_mt2 = g_tune.mt;
         const int mt2 = knob_mt2 ? knob_mt2 : choose_mt(M, N);
-        switch (mt2) {
-            case 2: return launch_gemm_mt<FLAGS, 2>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s, ln2);
-            case 5: return launch_gemm_mt<FLAGS, 5>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s, ln2);
-            case 6: return launch_gemm_mt<FLAGS, 6>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s, ln2);
-            default: return launch_gemm_mt<FLAGS, 4>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s, ln2);
-        }
+        return launch_narrow<FLAGS>(mt2, A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s, ln2);
     }
     const int knob_mt = g_tune.mt;
     const int mt = knob_mt ? knob_mt : choose_mt(M, N);
-    switch (mt) {
-        case 2: return launch_gemm_mt<FLAGS, 2>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s, ln);
-        case 5: return launch_gemm_mt<FLAGS, 5>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s, ln);
-        case 6: return launch_gemm_mt<FLAGS, 6>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s, ln);
-        default: return launch_gemm_mt<FLAGS, 4>(A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s, ln);
-    }
+    return launch_narrow<FLAGS>(mt, A, lda, W, ldw, bias, residual, out, ldc, M, N, K, s, ln);
 }
 
 }  // namespace
@@ -795,7 +804,7 @@ extern "C" int mq_gemm_bf16_ln(const void* d_A, int64_t lda, const void* d_W, in
 }
 
 // mq_gemm_bf16 (bias + bf16 residual read-modify-write) that also leaves the rows' partial statistics behind (gemm_epilogue.h, MQ_EPI_ROW_STATS):
-// d_partials fp32 [M][ceil(N/64)][2]
+// d_partials fp32 [ceil(N/64)][M][2] (slot-major)
 extern "C" int mq_gemm_bf16_rs(const void* d_A, int64_t lda, const void* d_W, int64_t ldw, const float* d_bias, const void* d_residual, void* d_out,
                                int64_t ldc, int64_t M, int64_t N, int64_t K, int flags, float* d_partials, void* stream) {
     MQ_CHECK_ARG(d_A && d_W && d_out && d_bias && d_residual && d_partials, "mq_gemm_bf16_rs: null operand");
@@ -808,7 +817,37 @@ extern "C" int mq_gemm_bf16_rs(const void* d_A, int64_t lda, const void* d_W, in
     GemmLn ln{};
     ln.partials = (float2*)d_partials;
     ln.nslots = (int)((N + 63) / 64);
+    ln.part_ld = M;
     return launch_gemm<MQ_EPI_BIAS | MQ_EPI_RESIDUAL | MQ_EPI_ROW_STATS>(d_A, lda, d_W, ldw, d_bias, (const float*)d_residual, d_out, ldc, (int)M, (int)N, (int)K, s, ln);
+}
+
+// LN_APPLY and ROW_STATS together (ABI 12; the EVA02 sub-LayerNorms folded into the GEMMs around them): out = [residual +] LN(A) @ W0^T + b0 with
+// d_W / d_bias / d_colsum folded as for mq_gemm_bf16_ln and d_rowstats = (mean, rstd) of A's rows — which come from the launch that WROTE A (the
+// attention kernel's per-head sums, mq_attention_stats; the gated epilogue's, below) through mq_row_stats_finalize — and, in d_partials, the (sum, sum of
+// squares) per row and 64-column slot of what THIS launch stores, for the LayerNorm behind it.  flags:
+//   MQ_EPI_BIAS | MQ_EPI_RESIDUAL  the out-projection / fc2 form: bf16 residual read-modify-write, d_partials [ceil(N / 64)][M][2] (slot-major)
+//   MQ_EPI_BIAS | MQ_EPI_GLU       the (up | gate) form: out [M, N / 2] = up * silu(gate); a slot = a wave's 64 GEMM columns = 32 hidden units:
+//                                  d_partials [ceil(N / 64)][M][2] of the rounded products
+extern "C" int mq_gemm_bf16_lnrs(const void* d_A, int64_t lda, const void* d_W, int64_t ldw, const float* d_bias, const float* d_colsum, const float* d_rowstats,
+                                 const void* d_residual, void* d_out, int64_t ldc, int64_t M, int64_t N, int64_t K, int flags, float* d_partials, void* stream) {
+    MQ_CHECK_ARG(d_A && d_W && d_out && d_bias && d_colsum && d_rowstats && d_partials, "mq_gemm_bf16_lnrs: null operand");
+    MQ_CHECK_ARG(flags == (MQ_EPI_BIAS | MQ_EPI_RESIDUAL) || flags == (MQ_EPI_BIAS | MQ_EPI_GLU), "mq_gemm_bf16_lnrs: flags must be MQ_EPI_BIAS | MQ_EPI_RESIDUAL or MQ_EPI_BIAS | MQ_EPI_GLU");
+    MQ_CHECK_ARG(!(flags & MQ_EPI_RESIDUAL) || d_residual, "mq_gemm_bf16_lnrs: MQ_EPI_RESIDUAL without residual");
+    MQ_CHECK_ARG(M >= 1 && N >= 4 && K >= BK && K % BK == 0 && N % 4 == 0, "mq_gemm_bf16_lnrs: bad shape M=%ld N=%ld K=%ld", (long)M, (long)N, (long)K);
+    MQ_CHECK_ARG(!(flags & MQ_EPI_GLU) || N % 32 == 0, "mq_gemm_bf16_lnrs: MQ_EPI_GLU needs N %% 32 == 0");
+    MQ_CHECK_ARG(lda % 8 == 0 && ldw % 8 == 0 && ldc % 4 == 0, "mq_gemm_bf16_lnrs: leading dims must keep 16-byte rows");
+    MQ_CHECK_ARG(M < (1 << 30) && N < (1 << 30) && K < (1 << 30), "mq_gemm_bf16_lnrs: shape too large");
+    hipStream_t s = (hipStream_t)stream;
+    MqProfScope prof(0, s, 2.0 * (double)M * (double)N * (double)K);
+    GemmLn ln{};
+    ln.colsum = d_colsum;
+    ln.rowstats = (const float2*)d_rowstats;
+    ln.partials = (float2*)d_partials;
+    ln.nslots = (int)((N + 63) / 64);
+    ln.part_ld = M;
+    if (flags & MQ_EPI_GLU)
+        return launch_gemm<MQ_EPI_BIAS | MQ_EPI_GLU | MQ_EPI_LN_APPLY | MQ_EPI_ROW_STATS>(d_A, lda, d_W, ldw, d_bias, nullptr, d_out, ldc, (int)M, (int)N, (int)K, s, ln);
+    return launch_gemm<MQ_EPI_BIAS | MQ_EPI_RESIDUAL | MQ_EPI_LN_APPLY | MQ_EPI_ROW_STATS>(d_A, lda, d_W, ldw, d_bias, (const float*)d_residual, d_out, ldc, (int)M, (int)N, (int)K, s, ln);
 }
 
 // mq_gemm_bf16_rs + the finalise of the row statistics: on return (stream order) d_stats holds (mean, rstd) of every row of d_out.  The finalise runs
@@ -836,6 +875,7 @@ extern "C" int mq_gemm_bf16_rsf(const void* d_A, int64_t lda, const void* d_W, i
         GemmLn ln{};
         ln.partials = (float2*)d_partials;
         ln.nslots = nslots;
+        ln.part_ld = M;
         if (in_launch) {
             ln.band_ctr = d_band_ctr;
             ln.stats_out = (float2*)d_stats;
@@ -857,7 +897,8 @@ extern "C" int mq_gemm_bf16_rsf(const void* d_A, int64_t lda, const void* d_W, i
 // so set them while no request is in flight if one call must run under one setting.
 // keys: "gemm_mt" (0 = auto, else tile height in 32-row units), "gemm_cgroup", "row_select", "ln_fold", "residual_bf16", "small_m", "small_m_grouped",
 // "ln_prefetch", "xcd_band", "attn_waves", "gemm_addr_limit_mb", "gemm_nh" (0 = default plan, 1 = (32*MT) x 128 tiles only, 3 = the big 256 x 256 tile on every row wherever N >= 256, 4 = the eager row-split plan),
-// "gemm_tail", "gemm_wd" (gemm_wd.hip: 0 = off, 2 / 3 / 6 / 7), "rs_finalize" (1 = the row statistics are finalised inside the residual GEMM's launch).
+// "gemm_tail", "gemm_wd" (gemm_wd.hip: 0 = off, 2 / 3 / 6 / 7), "rs_finalize" (1 = the row statistics are finalised inside the residual GEMM's launch),
+// "subln_fold" (0 = the EVA02 sub-LayerNorms run as LayerNorm passes instead of inside the out-projection / fc2 GEMMs).
 extern "C" int mq_tune(const char* key, int value) {
     MQ_CHECK_ARG(key, "mq_tune: null key");
     const std::string k(key);
@@ -869,6 +910,7 @@ extern "C" int mq_tune(const char* key, int value) {
     else if (k == "rs_finalize") g_tune.rs_fin = value;
     else if (k == "row_select") mq_tower_row_select = value;
     else if (k == "ln_fold") mq_tower_ln_fold = value;
+    else if (k == "subln_fold") mq_tower_subln_fold = value;
     else if (k == "xcd_band") mq_xcd_band = value;
     else if (k == "attn_waves") mq_attention_waves = value;
     else if (k == "residual_bf16") mq_tower_residual_bf16 = value;

@@ -23,8 +23,12 @@
 struct GemmLn {
     const float* colsum;     // LN_APPLY: [N]  sum_k bf16(gamma_k * W[n,k])
     const float2* rowstats;  // LN_APPLY: [M]  (mean, rstd) of row m of A
-    float2* partials;        // ROW_STATS: [M][nslots]  (sum, sum of squares) of the bf16 values this launch leaves in columns 64 s .. 64 s + 63 of row m
+    // ROW_STATS: [nslots][part_ld]  (sum, sum of squares) of the bf16 values this launch leaves in columns 64 s .. 64 s + 63 of row m, SLOT-major (round 6: a
+    // store instruction's 16 row lanes write 128 contiguous bytes, and the finalise kernel's threads — one per row — read coalesced; row-major, every lane
+    // touched a line of its own: the gated GEMM's 64 slots per row cost it 12 %)
+    float2* partials;
     int nslots;              // ROW_STATS: ceil(N / 64)
+    int64_t part_ld;         // ROW_STATS: rows of the whole partials buffer (the slot stride)
     // ROW_STATS with the finalise INSIDE the launch (round 6, mq_gemm_bf16_rsf): every wave, when its rows' partials have left, arrives at the counter of
     // its row band (a row tile x its position along M); the LAST wave to arrive — the band's partials are then all written — sums them in slot order
     // and writes (mean, rstd), exactly as row_stats_finalize_kernel would (mq_finalize_stats), and puts the counter back to zero.  Partials travel as
@@ -65,15 +69,15 @@ __device__ __forceinline__ void gemm_band_arrive(const GemmLn& ln, int band, int
     // first form (one dependent L2 round trip per slot) left the band's last wave 12-16 round trips behind the kernel's tail (profiles/r06c)
     const int m0 = row0 + lane, m1 = row0 + 64 + lane;
     const bool ok0 = lane < nrows && m0 < M, ok1 = 64 + lane < nrows && m1 < M;
-    const unsigned long long* p0 = (const unsigned long long*)(ln.partials + (int64_t)(ok0 ? m0 : row0) * ln.nslots);
-    const unsigned long long* p1 = (const unsigned long long*)(ln.partials + (int64_t)(ok1 ? m1 : row0) * ln.nslots);
+    const unsigned long long* p0 = (const unsigned long long*)(ln.partials + (ok0 ? m0 : row0));   // (slot i at + i * part_ld)
+    const unsigned long long* p1 = (const unsigned long long*)(ln.partials + (ok1 ? m1 : row0));
     float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
     for (int i0 = 0; i0 < ln.nslots; i0 += 16) {
         unsigned long long q[2][16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            q[0][j] = (ok0 && i0 + j < ln.nslots) ? __hip_atomic_load(p0 + i0 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-            q[1][j] = (ok1 && i0 + j < ln.nslots) ? __hip_atomic_load(p1 + i0 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+            q[0][j] = (ok0 && i0 + j < ln.nslots) ? __hip_atomic_load(p0 + (i0 + j) * ln.part_ld, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+            q[1][j] = (ok1 && i0 + j < ln.nslots) ? __hip_atomic_load(p1 + (i0 + j) * ln.part_ld, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
         }
 #pragma unroll
         for (int j = 0; j < 16; ++j)   // slot order, as row_stats_finalize_kernel adds them
@@ -104,9 +108,11 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][4], const float* 
     // as bf16, in place — half the epilogue bytes of the fp32 stream, the memory-bound part of the K = 768 residual GEMMs
     constexpr bool RES_BF16 = (FLAGS & MQ_EPI_RESIDUAL) && BF16_OUT;
     constexpr bool LN_APPLY = (FLAGS & MQ_EPI_LN_APPLY) != 0, ROW_STATS = (FLAGS & MQ_EPI_ROW_STATS) != 0, GLU = (FLAGS & MQ_EPI_GLU) != 0;
-    static_assert(!GLU || (BF16_OUT && !(FLAGS & (MQ_EPI_RESIDUAL | MQ_EPI_GELU | MQ_EPI_QUICKGELU | MQ_EPI_ROW_STATS))), "GLU: bias (+ LN apply), bf16 out");
-    static_assert(!ROW_STATS || RES_BF16, "ROW_STATS rides on the bf16 read-modify-write residual epilogue");
-    static_assert(!LN_APPLY || (BF16_OUT && !(FLAGS & MQ_EPI_RESIDUAL)), "LN_APPLY: the QKV / fc1 epilogues (bf16 out, no residual)");
+    static_assert(!GLU || (BF16_OUT && !(FLAGS & (MQ_EPI_RESIDUAL | MQ_EPI_GELU | MQ_EPI_QUICKGELU))), "GLU: bias (+ LN apply, + row statistics of the product), bf16 out");
+    static_assert(!ROW_STATS || RES_BF16 || GLU, "ROW_STATS rides on the bf16 read-modify-write residual epilogue or on the gated product");
+    // (LN_APPLY with the bf16 residual: the EVA02 sub-LayerNorms — attn.norm in front of the out-projection, mlp.norm in front of fc2 — folded into
+    // those GEMMs, whose A rows' statistics come from the attention kernel / the gated epilogue; mq_gemm_bf16_lnrs)
+    static_assert(!LN_APPLY || (BF16_OUT && (!(FLAGS & MQ_EPI_RESIDUAL) || RES_BF16)), "LN_APPLY: bf16 out (QKV / fc1, or the bf16 residual epilogue)");
     float row_mean = 0.f, row_rstd = 1.f;
     // Everything the epilogue READS is fetched up front, the long-latency residual tile first.  Measured with the phase trace
     // (tools/probes/gemm_trace.py): left inside the (mt, nt) loop, each sub-tile's bias / residual load was waited for on its
@@ -116,11 +122,15 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][4], const float* 
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);  // keep the prefetch below the k-loop (hoisted into it, it collides with the fragments' registers)
     f32x4 res_v[(FLAGS & MQ_EPI_RESIDUAL) ? RG : 1][4];
+    // LN_APPLY on top of the residual epilogue: the rows' (mean, rstd) travel with their residual group instead of all MT up front (registers)
+    constexpr bool LN_RES = LN_APPLY && (FLAGS & MQ_EPI_RESIDUAL) != 0;
+    float2 ms_g[LN_RES ? RG : 1];
     auto prefetch_residual = [&](int mt_lo) {
         if (FLAGS & MQ_EPI_RESIDUAL) {
 #pragma unroll
             for (int h = 0; h < RG; ++h) {
                 const int m = wave_m0 + (mt_lo + h) * 16 + l15;
+                if constexpr (LN_RES) ms_g[h] = (mt_lo + h < MT && m < M) ? lnp->rowstats[m] : make_float2(0.f, 1.f);
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) {
                     const int n = wave_n0 + nt * 16 + g * 4;
@@ -148,8 +158,8 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][4], const float* 
         else bias_v[nt] = ((FLAGS & MQ_EPI_BIAS) && n < N) ? *(const f32x4*)(bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
         cs_v[nt] = (LN_APPLY && n < N) ? *(const f32x4*)(lnp->colsum + n) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    float2 ms_v[LN_APPLY ? MT : 1];
-    if (LN_APPLY) {
+    float2 ms_v[(LN_APPLY && !LN_RES) ? MT : 1];
+    if (LN_APPLY && !LN_RES) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int m = wave_m0 + mt * 16 + l15;
@@ -180,17 +190,22 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][4], const float* 
         if (mt > 0 && mt % RG == 0) prefetch_residual(mt);  // (the previous group is finished: its registers are free)
         const int m = wave_m0 + mt * 16 + l15;
         const bool m_ok = m < M;
-        if (LN_APPLY) {
+        if constexpr (LN_RES) {
+            row_mean = ms_g[mt % RG].x;
+            row_rstd = ms_g[mt % RG].y;
+        } else if (LN_APPLY) {
             row_mean = ms_v[LN_APPLY ? mt : 0].x;
             row_rstd = ms_v[LN_APPLY ? mt : 0].y;
         }
-        float st1 = 0.f, st2 = 0.f;   // ROW_STATS: this lane's share of (sum, sum of squares) of row m over the wave's 64 columns
+        // ROW_STATS: this lane's share of (sum, sum of squares) of row m over the wave's 64 columns, as (even, odd) element pairs: packed adds / fmas, no
+        // branch (columns past N count as zeros) — the scalar, branched form cost the gated GEMM's epilogue 6 % (tools/probes/lnrs_bench.py)
+        f32x2_t st1v = {0.f, 0.f}, st2v = {0.f, 0.f};
         auto stat_add = [&](uint2 pk, bool ok) {   // of the ROUNDED values: they are what the next GEMM multiplies
-            if (ROW_STATS && ok) {
-                const float e0 = __uint_as_float(pk.x << 16), e1 = __uint_as_float(pk.x & 0xffff0000u), e2 = __uint_as_float(pk.y << 16),
-                            e3 = __uint_as_float(pk.y & 0xffff0000u);
-                st1 += (e0 + e1) + (e2 + e3);
-                st2 += (e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3);
+            if (ROW_STATS) {
+                const unsigned x = ok ? pk.x : 0u, y = ok ? pk.y : 0u;
+                const f32x2_t a = {__uint_as_float(x << 16), __uint_as_float(x & 0xffff0000u)}, b = {__uint_as_float(y << 16), __uint_as_float(y & 0xffff0000u)};
+                st1v += a + b;
+                st2v = __builtin_elementwise_fma(a, a, __builtin_elementwise_fma(b, b, st2v));
             }
         };
         if constexpr (GLU) {
@@ -204,6 +219,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][4], const float* 
                 const f32x4 up = value(mt, 2 * p, m, n, ok), gt = value(mt, 2 * p + 1, m, n + 16, ok);
                 pk[p].x = pack_bf16x2(up[0] * silu(gt[0]), up[1] * silu(gt[1]));
                 pk[p].y = pack_bf16x2(up[2] * silu(gt[2]), up[3] * silu(gt[3]));
+                stat_add(pk[p], ok);   // (ROW_STATS: of the rounded product — slot = this wave's 64 GEMM columns = 32 hidden units)
             }
             const int u0 = wave_n0 >> 1, NU = N >> 1;
             if (wide) {   // the two 16-unit blocks exchanged between lanes 16 apart: a lane then owns 8 consecutive units (one 16-byte store)
@@ -264,11 +280,26 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][4], const float* 
             }
         }
         if (ROW_STATS) {  // the row's 4 lanes (g = 0..3) add up in a fixed order; one writer per (row, slot)
-            st1 += __shfl_xor(st1, 16, 64); st2 += __shfl_xor(st2, 16, 64);
-            st1 += __shfl_xor(st1, 32, 64); st2 += __shfl_xor(st2, 32, 64);
-            if (g == 0 && m_ok && wave_n0 < N)
-                __hip_atomic_store((unsigned long long*)(lnp->partials + (int64_t)m * lnp->nslots + (wave_n0 >> 6)),
-                                   (unsigned long long)__float_as_uint(st1) | ((unsigned long long)__float_as_uint(st2) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            float st1 = st1v[0] + st1v[1], st2 = st2v[0] + st2v[1];
+            // across the row's 4 lanes with the swap instructions (VALU; bit for bit the sums of the __shfl_xor form they replace — same operands, same order
+            // — without its ds_bpermute round trips: -5 us on the gated GEMM): rows (0,1) and (2,3) of 16 lanes, then the wave's halves
+            auto fold = [](float v) {
+                const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+                const float w = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+                const auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(w), __float_as_uint(w), false, false);
+                return __uint_as_float(q[0]) + __uint_as_float(q[1]);
+            };
+            st1 = fold(st1);
+            st2 = fold(st2);
+            if (g == 0 && m_ok && wave_n0 < N) {
+                float2* dst = lnp->partials + (int64_t)(wave_n0 >> 6) * lnp->part_ld + m;
+                // in-launch finalise (band_ctr): write-through, the band's last wave reads them back inside this launch.  Otherwise a plain store: the next
+                // LAUNCH reads them (measured neutral on the gated GEMM; it keeps memory-side acknowledgements out of a persistent tile walk's vmcnt waits)
+                if (lnp->band_ctr)
+                    __hip_atomic_store((unsigned long long*)dst, (unsigned long long)__float_as_uint(st1) | ((unsigned long long)__float_as_uint(st2) << 32), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                else *dst = make_float2(st1, st2);
+            }
         }
     }
 }

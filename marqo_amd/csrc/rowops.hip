@@ -527,15 +527,21 @@ int mq_cast_bf16(const float* d_x, void* d_out, int64_t n, hipStream_t s) {
 }
 
 
-// (mean, rstd) per row from the partial sums a residual GEMM left behind (gemm_epilogue.h, MQ_EPI_ROW_STATS): one thread per row, nslots float2 each
+// (mean, rstd) per row from the partial sums a residual GEMM left behind (gemm_epilogue.h, MQ_EPI_ROW_STATS): one thread per row, nslots float2 each (slot-major)
 // (summed in slot order: deterministic); carries the weight prefetch like the LayerNorm kernels
 __global__ __launch_bounds__(256) void row_stats_finalize_kernel(const float2* __restrict__ partials, int nslots, float2* __restrict__ stats, int64_t rows,
                                                                  float inv_w, float eps, LnExtra ex) {
     const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
     float s1 = 0.f, s2 = 0.f;
     if (row < rows) {
-        const float2* p = partials + row * nslots;
-        for (int i = 0; i < nslots; ++i) { const float2 v = p[i]; s1 += v.x; s2 += v.y; }
+        const float2* p = partials + row;   // slot-major [nslots][rows]: the block's threads read 2 KB runs
+        for (int i0 = 0; i0 < nslots; i0 += 8) {   // 8 independent loads in flight (every slot is a line of its own), added in slot order
+            float2 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = i0 + j < nslots ? p[(int64_t)(i0 + j) * rows] : make_float2(0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { s1 += v[j].x; s2 += v[j].y; }
+        }
     }
     unsigned pq[LN_PF];
     ln_prefetch_issue(ex, pq);

@@ -30,7 +30,7 @@ int mq_rope_table(void* d_qkv, int64_t rows, int T, int prefix, int Wa, int head
 extern "C" int mq_rowquant_fp8(const float* d_x, void* d_out_fp8, float* d_row_scale, int64_t rows, int32_t W, void* stream);
 
 // layouts the ctypes binding (marqo_amd/_lib.py) and tests/test_abi.py assume
-static_assert(sizeof(mq_block_weights) == 30 * 8, "mq_block_weights layout");
+static_assert(sizeof(mq_block_weights) == 36 * 8, "mq_block_weights layout");
 static_assert(sizeof(mq_encoder_cfg) == 112, "mq_encoder_cfg layout");
 static_assert(sizeof(mq_vit_cfg) == 168 && sizeof(mq_clip_text_cfg) == 128 && sizeof(mq_bert_cfg) == 136, "tower cfg layouts");
 static_assert(sizeof(mq_vit_weights) == 11 * 8 && sizeof(mq_map_head) == 11 * 8 && sizeof(mq_clip_text_weights) == 7 * 8, "tower weight layouts");
@@ -42,6 +42,9 @@ mq_knob mq_tower_row_select{getenv("MQ_ROW_SELECT") ? atoi(getenv("MQ_ROW_SELECT
 // engine/towers.py) and the call is large enough for the tiled GEMM.  mq_tune("ln_fold", v) / MQ_LN_FOLD=v:
 // 0 = LayerNorm kernels; 1 = folded, statistics from a read pass over the stream; 2 = folded, statistics from the residual GEMMs' partial sums
 mq_knob mq_tower_ln_fold{getenv("MQ_LN_FOLD") ? atoi(getenv("MQ_LN_FOLD")) : 2};
+// the EVA02 sub-LayerNorms (attn.norm in front of the out-projection, mlp.norm in front of fc2) folded into those GEMMs (round 6, ABI 12; block_eva):
+// mq_tune("subln_fold", 0) / MQ_SUBLN_FOLD=0 keeps them as LayerNorm passes over the attention output / the gated product
+mq_knob mq_tower_subln_fold{getenv("MQ_SUBLN_FOLD") ? atoi(getenv("MQ_SUBLN_FOLD")) : 1};
 // bf16 residual stream for the pre-LN bf16 towers (mq_tune("residual_bf16", 1) / MQ_RESIDUAL_BF16=1): x is kept in bf16 between
 // blocks.  The residual GEMMs of a K = 768 tower are memory-bound on their epilogue (out-proj: 15 GFLOP against 39 MB read + 39 MB
 // written of fp32 residual) and every LayerNorm re-reads the stream: bf16 halves those bytes.  Cost: one bf16 rounding per residual
@@ -187,6 +190,18 @@ int attn_width(const mq_encoder_cfg* c) { return c->attn_width ? c->attn_width :
 
 constexpr int64_t SMALL_LN_ROWS = 32;  // rows up to which the skinny GEMMs fuse the LayerNorm (gemm_small.hip)
 
+// slots per row of the partial-sums buffer: a residual GEMM's 64-column slots; for the EVA02 sub-LayerNorm folds also the attention's heads and the gated
+// GEMM's 64-column slots over (up | gate)
+size_t part_slots(const mq_encoder_cfg* c) {
+    size_t n = (size_t)(c->width + 63) / 64;
+    if (c->mlp_glu == 2) {
+        const size_t g = (size_t)(2 * c->mlp_dim + 63) / 64, hd = (size_t)c->heads;
+        n = n > g ? n : g;
+        n = n > hd ? n : hd;
+    }
+    return n;
+}
+
 // scratch of one encoder pass: h bf16 [rows,W] | a bf16 [rows,Wa] | big bf16 [rows, max(3Wa,F)]
 size_t encoder_ws(const mq_encoder_cfg* c, int64_t rows) {
     Off cv;
@@ -198,7 +213,7 @@ size_t encoder_ws(const mq_encoder_cfg* c, int64_t rows) {
     cv.take((size_t)rows * big * 2);
     cv.take((size_t)rows * 4);  // per-row activation scales of the fp8 path
     cv.take((size_t)rows * 8);  // (mean, rstd) per row: the statistics of a folded LayerNorm
-    cv.take((size_t)rows * ((c->width + 63) / 64) * 8);  // ... and the partial sums a residual GEMM leaves for them: (sum, sum of squares) per row and 64-column slot
+    cv.take((size_t)rows * part_slots(c) * 8);  // ... and the partial sums a GEMM / the attention leaves for them: (sum, sum of squares) per row and slot
     cv.take((size_t)(rows < SMALL_LN_ROWS ? rows : SMALL_LN_ROWS) * c->width * 4);  // search path, post-LN: the normalised residual (fp32)
     cv.take((size_t)mq_gemm_band_counters(rows) * 4);  // arrival counters of the in-launch statistics finalise
     return cv.end();
@@ -362,22 +377,51 @@ int EncoderPass::block_eva(const mq_block_weights& b, int l) {
     const int xb = stream_bf16(cfg) ? 1 : 0;
     const int rflags = xb ? (MQ_EPI_BIAS | MQ_EPI_RESIDUAL) : res_flags;
     const int fc1_cols = cfg->mlp_glu ? 2 * F : F;
-    MQ_TRY(ln_gemm(d_x, xb, b.ln1_g, b.ln1_b, cfg->ln_eps, h, b.qkv_w, b.qkv_b, qf, rows, 3 * Wa, W, MQ_EPI_BIAS, s, b.out_w, (size_t)W * Wa * 2,
+    // the sub-LayerNorms folded into the GEMMs behind them (mq_gemm_bf16_lnrs): the rows' statistics come from the launch that wrote the rows — the
+    // attention kernel's per-head sums, the gated epilogue's per-slot sums — through the finalise kernel; no pass over [rows, Wa] / [rows, F] of its own
+    const bool sub_fold = mq_tower_subln_fold && mq_tower_ln_fold >= 2 && xb;
+    const bool fold_attn_ln = sub_fold && b.attn_ln_g && b.out_wf && b.out_sf && b.out_bf && !cfg->d_rel_bias && !mq_gemm_small_ok(rows, W, Wa, false) &&
+                              !mq_gemm_small_grouped_ok(rows, W, Wa);
+    const void* out_w_run = fold_attn_ln ? b.out_wf : b.out_w;
+    MQ_TRY(ln_gemm(d_x, xb, b.ln1_g, b.ln1_b, cfg->ln_eps, h, b.qkv_w, b.qkv_b, qf, rows, 3 * Wa, W, MQ_EPI_BIAS, s, out_w_run, (size_t)W * Wa * 2,
                    b.qkv_wf, b.qkv_bf, b.qkv_sf, row_stats, x_has_partials));
     x_has_partials = false;
     if (cfg->d_rope_table) MQ_TRY(mq_rope_table(qf, rows, fixed_len, cfg->rope_prefix, Wa, cfg->heads, cfg->d_rope_table, s));
-    MQ_TRY(attn_bf16(cfg, qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, s));
-    if (b.attn_ln_g) MQ_TRY(mq_layernorm_ex(a, 1, nullptr, b.attn_ln_g, b.attn_ln_b, a, nullptr, rows, Wa, cfg->ln_eps, s));   // (in place: a wave holds its row before it stores)
     const bool fold_mlp = mq_tower_ln_fold >= 2 && fold_ok(xb, b.fc1_wf, b.fc1_bf, b.fc1_sf, rows, fc1_cols, W) && !mq_gemm_small_ok(rows, W, Wa, false) &&
                           !mq_gemm_small_grouped_ok(rows, W, Wa);
-    if (fold_mlp) MQ_TRY(mq_gemm_bf16_rsf(a, Wa, b.out_w, Wa, b.out_b, d_x, d_x, W, rows, W, Wa, rflags, row_part, row_stats, cfg->ln_eps, band_ctr, pf(b.fc1_wf),
-                                          (size_t)fc1_cols * W * 2, pf(b.fc2_w), (size_t)W * F * 2, s));
-    else MQ_TRY(mq_gemm_bf16(a, Wa, b.out_w, Wa, b.out_b, (const float*)d_x, d_x, W, rows, W, Wa, rflags, s));
+    if (fold_attn_ln) {
+        MQ_TRY(mq_attention_stats(qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, cfg->heads, cfg->mask, row_part, rows, s));
+        MQ_TRY(mq_row_stats_finalize_pf(row_part, cfg->heads, row_stats, rows, Wa, cfg->ln_eps, nullptr, 0, nullptr, 0, s));
+        MQ_TRY(mq_gemm_bf16_lnrs(a, Wa, b.out_wf, Wa, b.out_bf, b.out_sf, row_stats, d_x, d_x, W, rows, W, Wa, rflags, row_part, s));
+        if (fold_mlp) MQ_TRY(mq_row_stats_finalize_pf(row_part, (W + 63) / 64, row_stats, rows, W, cfg->ln_eps, pf(b.fc1_wf), (size_t)fc1_cols * W * 2, pf(b.fc2_w), (size_t)W * F * 2, s));
+    } else {
+        MQ_TRY(attn_bf16(cfg, qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, s));
+        if (b.attn_ln_g) MQ_TRY(mq_layernorm_ex(a, 1, nullptr, b.attn_ln_g, b.attn_ln_b, a, nullptr, rows, Wa, cfg->ln_eps, s));   // (in place: a wave holds its row before it stores)
+        if (fold_mlp) MQ_TRY(mq_gemm_bf16_rsf(a, Wa, b.out_w, Wa, b.out_b, d_x, d_x, W, rows, W, Wa, rflags, row_part, row_stats, cfg->ln_eps, band_ctr, pf(b.fc1_wf),
+                                              (size_t)fc1_cols * W * 2, pf(b.fc2_w), (size_t)W * F * 2, s));
+        else MQ_TRY(mq_gemm_bf16(a, Wa, b.out_w, Wa, b.out_b, (const float*)d_x, d_x, W, rows, W, Wa, rflags, s));
+    }
     // mlp_glu == 2: (up, gate) rows interleaved 16 by 16 — the tiled GEMM forms up * silu(gate) in its epilogue (MQ_EPI_GLU: the (up | gate) tensor is never
     // written: -206 MB written and -206 MB read per block at EVA02-B/16 x 256), the sub-LayerNorm then normalises the product in place; a call of a few
     // rows (the skinny kernels have no gated epilogue) multiplies behind the GEMM, from the interleaved columns.  Row stride 2 F either way.
     const bool il = cfg->mlp_glu == 2;
     const bool glu_epi = il && !mq_gemm_small_ok(rows, fc1_cols, W, true) && !mq_gemm_small_ok(rows, fc1_cols, W, false) && !mq_gemm_small_grouped_ok(rows, fc1_cols, W);
+    const mq_block_weights* nbk = l + 1 < cfg->layers ? &blocks[l + 1] : nullptr;
+    const bool fold_next = mq_tower_ln_fold >= 2 && nbk && fold_ok(xb, nbk->qkv_wf, nbk->qkv_bf, nbk->qkv_sf, rows, 3 * Wa, W) && !mq_gemm_small_ok(rows, W, F, false) &&
+                           !mq_gemm_small_grouped_ok(rows, W, F);
+    const bool fold_mlp_ln = sub_fold && fold_mlp && glu_epi && b.mlp_ln_g && b.fc2_wf && b.fc2_sf && b.fc2_bf && !mq_gemm_small_ok(rows, W, F, false) &&
+                             !mq_gemm_small_grouped_ok(rows, W, F);
+    if (fold_mlp_ln) {
+        // (up | gate) GEMM: norm2 applied, up * silu(gate) stored, the product's row sums left per 32-unit slot -> (mean, rstd) of mlp.norm -> fc2 applies it
+        const int Fln = cfg->mlp_ln_dim ? cfg->mlp_ln_dim : F;
+        MQ_TRY(mq_gemm_bf16_lnrs(d_x, W, b.fc1_wf, W, b.fc1_bf, b.fc1_sf, row_stats, nullptr, qf, fc1_cols, rows, fc1_cols, W, MQ_EPI_BIAS | MQ_EPI_GLU, row_part, s));
+        MQ_TRY(mq_row_stats_finalize_pf(row_part, (fc1_cols + 63) / 64, row_stats, rows, Fln, cfg->ln_eps, pf(b.fc2_wf), (size_t)W * F * 2, nullptr, 0, s));
+        MQ_TRY(mq_gemm_bf16_lnrs(qf, fc1_cols, b.fc2_wf, F, b.fc2_bf, b.fc2_sf, row_stats, d_x, d_x, W, rows, W, F, rflags, row_part, s));
+        if (fold_next) MQ_TRY(mq_row_stats_finalize_pf(row_part, (W + 63) / 64, row_stats, rows, W, cfg->ln_eps, pf(nbk->qkv_wf), (size_t)3 * Wa * W * 2, pf(nbk->out_w),
+                                                       (size_t)W * Wa * 2, s));
+        x_has_partials = fold_next;
+        return MQ_OK;
+    }
     MQ_TRY(ln_gemm(d_x, xb, b.ln2_g, b.ln2_b, cfg->ln_eps, h, b.fc1_w, b.fc1_b, qf, rows, fc1_cols, W, MQ_EPI_BIAS | (cfg->mlp_glu ? (glu_epi ? MQ_EPI_GLU : 0) : act_flag), s,
                    b.fc2_w, (size_t)W * F * 2, b.fc1_wf, b.fc1_bf, b.fc1_sf, row_stats, fold_mlp));
     if (cfg->mlp_glu) {
@@ -386,9 +430,6 @@ int EncoderPass::block_eva(const mq_block_weights& b, int l) {
         else if (!glu_epi) MQ_TRY(mq_glu(qf, rows, F, cfg->act, s, il ? 1 : 0));
     }
     // fc2 (reads the F-wide product at the (up | gate) buffer's row stride) writes the x the NEXT block's QKV normalises
-    const mq_block_weights* nbk = l + 1 < cfg->layers ? &blocks[l + 1] : nullptr;
-    const bool fold_next = mq_tower_ln_fold >= 2 && nbk && fold_ok(xb, nbk->qkv_wf, nbk->qkv_bf, nbk->qkv_sf, rows, 3 * Wa, W) && !mq_gemm_small_ok(rows, W, F, false) &&
-                           !mq_gemm_small_grouped_ok(rows, W, F);
     if (fold_next) MQ_TRY(mq_gemm_bf16_rsf(qf, fc1_cols, b.fc2_w, F, b.fc2_b, d_x, d_x, W, rows, W, F, rflags, row_part, row_stats, cfg->ln_eps, band_ctr, pf(nbk->qkv_wf),
                                            (size_t)3 * Wa * W * 2, pf(nbk->out_w), (size_t)W * Wa * 2, s));
     else MQ_TRY(mq_gemm_bf16(qf, fc1_cols, b.fc2_w, F, b.fc2_b, (const float*)d_x, d_x, W, rows, W, F, rflags, s));
@@ -518,7 +559,7 @@ int encoder_forward_impl(const mq_encoder_cfg* cfg, const mq_block_weights* bloc
     void* qf = wsb + cv.take((size_t)rows * big * 2);  // qkv [rows,3W] then fc1 output [rows,F]
     float* row_scale = (float*)(wsb + cv.take((size_t)rows * 4));
     float* row_stats = (float*)(wsb + cv.take((size_t)rows * 8));
-    float* row_part = (float*)(wsb + cv.take((size_t)rows * ((W + 63) / 64) * 8));
+    float* row_part = (float*)(wsb + cv.take((size_t)rows * part_slots(cfg) * 8));
     float* xn = (float*)(wsb + cv.take((size_t)(rows < SMALL_LN_ROWS ? rows : SMALL_LN_ROWS) * W * 4));
     uint32_t* band_ctr = (uint32_t*)(wsb + cv.take((size_t)mq_gemm_band_counters(rows) * 4));
     // (the in-launch finalise is opt-in, mq_tune("rs_finalize", 1): without it the residual GEMMs get no counters and a finalise launch follows them)

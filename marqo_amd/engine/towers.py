@@ -294,12 +294,25 @@ def _eva_blocks(h: _Holder, sd, prefix: str, layers: int, W: int, F: int, heads:
         if p + "mlp.norm.weight" in sd:
             b.mlp_ln_g, b.mlp_ln_b = h.f32(pad(f32("mlp.norm.weight", (F,)), (0, Fp - F))), h.f32(pad(f32("mlp.norm.bias", (F,)), (0, Fp - F)))
         b.fc2_w, b.fc2_b = h.bf16(pad(f32("mlp.fc2.weight", (W, F)), (0, Fp - F))), h.f32(f32("mlp.fc2.bias", (W,)))
-        if LN_FOLD:   # norm1 into the QKV GEMM, norm2 into the (up | gate) GEMM (as _clip_blocks; the sub-LayerNorms stay kernels)
+        if LN_FOLD:   # norm1 into the QKV GEMM, norm2 into the (up | gate) GEMM (as _clip_blocks)
             for name, w32, b32, lg in (("qkv", qkv_w, qkv_b, "norm1"), ("fc1", fc1_w, fc1_b, "norm2")):
                 wf = (w32 * f32(lg + ".weight", (W,)).unsqueeze(0)).to(torch.bfloat16)
                 setattr(b, name + "_wf", h.bf16(wf))
                 setattr(b, name + "_sf", h.f32(wf.to(torch.float32).sum(dim=1)))
                 setattr(b, name + "_bf", h.f32(b32 + w32 @ f32(lg + ".bias", (W,))))
+            # ... and the sub-LayerNorms into the GEMMs behind them (ABI 12, csrc/towers.hip block_eva): attn.norm into attn.proj, mlp.norm into mlp.fc2 (over
+            # the padded hidden width: zero LayerNorm weights meet zero fc2 columns).  Their rows' statistics come from the attention kernel / the gated epilogue.
+            subs = []
+            if p + "attn.norm.weight" in sd:
+                subs.append(("out", f32("attn.proj.weight", (W, W)), f32("attn.proj.bias", (W,)), f32("attn.norm.weight", (W,)), f32("attn.norm.bias", (W,))))
+            if p + "mlp.norm.weight" in sd and EVA_GLU_EPILOGUE:
+                subs.append(("fc2", pad(f32("mlp.fc2.weight", (W, F)), (0, Fp - F)), f32("mlp.fc2.bias", (W,)), pad(f32("mlp.norm.weight", (F,)), (0, Fp - F)),
+                             pad(f32("mlp.norm.bias", (F,)), (0, Fp - F))))
+            for name, w32, b32, gam, bet in subs:
+                wf = (w32 * gam.unsqueeze(0)).to(torch.bfloat16)
+                setattr(b, name + "_wf", h.bf16(wf))
+                setattr(b, name + "_sf", h.f32(wf.to(torch.float32).sum(dim=1)))
+                setattr(b, name + "_bf", h.f32(b32 + w32 @ bet))
     return arr
 
 

@@ -24,11 +24,11 @@ def test_header_symbols_are_exported_and_bound():
         assert hasattr(raw, n), f"libmarqo_hip.so does not export {n}"
         assert n in L.EXPORTED_SYMBOLS, f"ctypes binding is missing {n}"
     assert set(L.EXPORTED_SYMBOLS) <= set(names), set(L.EXPORTED_SYMBOLS) - set(names)
-    assert lib.mq_abi_version() == L.ABI_VERSION == 11 and lib.mq_build_arch() == b"gfx950"
+    assert lib.mq_abi_version() == L.ABI_VERSION == 12 and lib.mq_build_arch() == b"gfx950"
 
 
 def test_struct_layouts_match_header():
-    assert C.sizeof(L.BlockWeights) == 30 * 8           # ABI 10: + attn_ln_g / _b, mlp_ln_g / _b (the EVA02 blocks' sub-LayerNorms)
+    assert C.sizeof(L.BlockWeights) == 36 * 8           # ABI 10: + attn_ln_g / _b, mlp_ln_g / _b (the EVA02 blocks' sub-LayerNorms); ABI 12: + their folded out / fc2 tensors
     # ... + d_rel_bias, rel_span, residual_stream (ABI 5: reserved0), fp8_mlp_extra, rope_prefix (ABI 6: reserved1) + ABI 10: d_rope_table, mlp_ln_dim, reserved2
     ENC = 8 * 4 + 4 * 4 + 3 * 8 + 8 + 2 * 4 + 2 * 4 + 8 + 2 * 4
     assert C.sizeof(L.EncoderCfg) == ENC

@@ -137,14 +137,16 @@ def _check(isa, remarks, mfma_name, n_mfma, n_reads_expected, hot_regions=1):
 
 @pytest.mark.skipif(not shutil.which(HIPCC), reason="hipcc not installed")
 @pytest.mark.parametrize("flags,mt", [(BIAS, 5), (BIAS | RESIDUAL, 5), (BIAS | GELU, 4), (BIAS | RESIDUAL | OUT_F32, 6), (BIAS | GELU | LN_APPLY, 5), (BIAS | RESIDUAL | ROW_STATS, 5),
-                                      (BIAS | RESIDUAL | ROW_STATS, 3), (0, 2), (BIAS | GLU | LN_APPLY, 5), (BIAS | GLU, 6)])
+                                      (BIAS | RESIDUAL | ROW_STATS, 3), (0, 2), (BIAS | GLU | LN_APPLY, 5), (BIAS | GLU, 6),
+                                      (BIAS | RESIDUAL | ROW_STATS | LN_APPLY, 5), (BIAS | RESIDUAL | ROW_STATS | LN_APPLY, 4), (BIAS | GLU | LN_APPLY | ROW_STATS, 6)])
 def test_asm_fragment_reads_are_waited_for_before_any_use(tmp_path, flags, mt):
     isa, remarks = _compile(tmp_path, flags, mt)
     _check(isa, remarks, "v_mfma_f32_16x16x32_bf16", 8 * mt, 3 * (mt + 4))    # reads: prologue + both half-steps
 
 
 @pytest.mark.skipif(not shutil.which(HIPCC), reason="hipcc not installed")
-@pytest.mark.parametrize("flags", [0, BIAS, BIAS | GELU, BIAS | RESIDUAL, BIAS | RESIDUAL | OUT_F32, BIAS | GELU | LN_APPLY, BIAS | RESIDUAL | ROW_STATS])
+@pytest.mark.parametrize("flags", [0, BIAS, BIAS | GELU, BIAS | RESIDUAL, BIAS | RESIDUAL | OUT_F32, BIAS | GELU | LN_APPLY, BIAS | RESIDUAL | ROW_STATS,
+                                   BIAS | RESIDUAL | ROW_STATS | LN_APPLY, BIAS | GLU | LN_APPLY | ROW_STATS])
 def test_big_8_wave_tile_follows_the_same_rules(tmp_path, flags):
     """round 5: the 256 x 256 tile of 8 waves (WM = 4, MT = 4, NH = 2: 64 x 128 per wave, two waves per SIMD, 8 LDS-DMA pieces and 12 fragment reads per
     wave and k-half): the same loop — 2 * 32 MFMAs in ONE k-step body, one vmcnt wait, one barrier, no scratch inside the 256 registers of a

@@ -100,7 +100,7 @@ def test_row_statistics_do_not_depend_on_the_tile_a_row_falls_into():
 @pytest.mark.parametrize("M,N,K", [(12800, 768, 768), (12800, 768, 3072), (1500, 512, 2048), (333, 1024, 1024), (700, 1664, 1664), (130, 72, 64), (9000, 1280, 5120)])
 def test_residual_gemm_leaves_the_row_sums_the_next_layernorm_needs(M, N, K):
     """MQ_EPI_ROW_STATS: the out-proj / fc2 GEMM (bf16 read-modify-write of the stream) writes (sum, sum of squares) of every row's ROUNDED new values per
-    64-column slot; mq_row_stats_finalize turns them into the (mean, rstd) mq_row_stats would have read back — the statistics pass over the stream goes"""
+    64-column slot (slot-major: [slots][M]); mq_row_stats_finalize turns them into the (mean, rstd) mq_row_stats would have read back — the statistics pass over the stream goes"""
     lib = L.load()
     g = torch.Generator(device="cuda").manual_seed(M + N)
     a = (torch.randn(M, K, device="cuda", generator=g)).to(torch.bfloat16)
@@ -114,7 +114,7 @@ def test_residual_gemm_leaves_the_row_sums_the_next_layernorm_needs(M, N, K):
     L.check(lib.mq_gemm_bf16(a.data_ptr(), K, W.data_ptr(), K, b.data_ptr(), plain.data_ptr(), plain.data_ptr(), N, M, N, K, flags, _stream()))
     nslots = (N + 63) // 64
     x = x0.clone()
-    part = torch.full((M, nslots, 2), float("nan"), device="cuda")
+    part = torch.full((nslots, M, 2), float("nan"), device="cuda")      # slot-major (ABI 12)
     L.check(lib.mq_gemm_bf16_rs(a.data_ptr(), K, W.data_ptr(), K, b.data_ptr(), x.data_ptr(), x.data_ptr(), N, M, N, K, flags, part.data_ptr(), _stream()))
     assert torch.equal(x.view(torch.int16), plain.view(torch.int16))                # the stream itself: same bits with and without the by-product
     assert not torch.isnan(part).any()                                              # every (row, slot) written
@@ -122,8 +122,8 @@ def test_residual_gemm_leaves_the_row_sums_the_next_layernorm_needs(M, N, K):
     pad = torch.zeros(M, nslots * 64, device="cuda", dtype=torch.float64)
     pad[:, :N] = xd
     pad = pad.view(M, nslots, 64)
-    assert torch.allclose(part[..., 0].double(), pad.sum(-1), rtol=1e-5, atol=1e-3)
-    assert torch.allclose(part[..., 1].double(), pad.pow(2).sum(-1), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(part[..., 0].double().t(), pad.sum(-1), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(part[..., 1].double().t(), pad.pow(2).sum(-1), rtol=1e-5, atol=1e-3)
     again = torch.empty_like(part)
     x2 = x0.clone()
     L.check(lib.mq_gemm_bf16_rs(a.data_ptr(), K, W.data_ptr(), K, b.data_ptr(), x2.data_ptr(), x2.data_ptr(), N, M, N, K, flags, again.data_ptr(), _stream()))
@@ -162,14 +162,14 @@ def test_in_launch_finalise_gives_the_finalise_kernels_bits(M, N, K, plan, tiled
         elif plan == "mt2":
             _tune("gemm_mt", 2)
         x = x0.clone()
-        part = torch.full((M, nslots, 2), float("nan"), device="cuda")
+        part = torch.full((nslots, M, 2), float("nan"), device="cuda")      # slot-major (ABI 12)
         L.check(lib.mq_gemm_bf16_rs(a.data_ptr(), K, W.data_ptr(), K, b.data_ptr(), x.data_ptr(), x.data_ptr(), N, M, N, K, flags, part.data_ptr(), _stream()))
         want = torch.empty(M, 2, device="cuda")
         L.check(lib.mq_row_stats_finalize(part.data_ptr(), nslots, want.data_ptr(), M, N, eps, _stream()))
         ctr = torch.zeros(int(lib.mq_gemm_band_counters(M)), device="cuda", dtype=torch.int32)
         for rep in range(3):
             x2 = x0.clone()
-            part2 = torch.full((M, nslots, 2), float("nan"), device="cuda")
+            part2 = torch.full((nslots, M, 2), float("nan"), device="cuda")
             got = torch.full((M, 2), float("nan"), device="cuda")
             L.check(lib.mq_gemm_bf16_rsf(a.data_ptr(), K, W.data_ptr(), K, b.data_ptr(), x2.data_ptr(), x2.data_ptr(), N, M, N, K, flags, part2.data_ptr(), got.data_ptr(), eps,
                                          ctr.data_ptr(), pf.data_ptr(), pf.numel() * 4, pf.data_ptr(), 4096, _stream()))

@@ -531,6 +531,7 @@ def test_eva02_tower_vs_oracle(name, layers, n, monkeypatch):
     the fp32 CPU oracle in seconds) against oracle.eva_vit_forward (restated from timm; unpinned — no timm in this image).  One image (the
     small-row kernel families), un-normalised output, and the fused-qkv checkpoint form."""
     from dataclasses import replace
+    from marqo_amd import _lib as L
     T, A = _towers()
     if name == "tiny":
         varch = A.VitArch(64, 16, 128, layers, 2, 170, 64, ln_eps=1e-6, ln_pre=False, eva=True)
@@ -568,6 +569,16 @@ def test_eva02_tower_vs_oracle(name, layers, n, monkeypatch):
         got = tw.encode_u8(big.cuda())
         assert _cos_err(got[:n], bref) < COS_TIGHT, mode
         assert _cos_err(tw.encode_u8(big[:n].cuda()), got[:n]) < COS_TIGHT          # (another batch size = other GEMM kernel families: last bits only)
+        if mode == "bf16":
+            # round 6 (ABI 12): attn.norm / mlp.norm folded into the out-projection / fc2 GEMMs (default) against the LayerNorm passes (mq_tune("subln_fold", 0))
+            assert tw._blocks[0].out_wf and tw._blocks[0].fc2_wf and tw._blocks[0].fc2_sf
+            assert torch.equal(tw.encode_u8(big.cuda()), got)                         # deterministic
+            try:
+                L.check(L.load().mq_tune(b"subln_fold", 0))
+                passes = tw.encode_u8(big.cuda())
+            finally:
+                L.check(L.load().mq_tune(b"subln_fold", 1))
+            assert _cos_err(passes[:n], bref) < COS_TIGHT and _cos_err(passes, got) < 1e-4
 
 
 def test_single_request_graph_replay_is_bit_identical(monkeypatch):
