@@ -54,3 +54,34 @@ def case(N, K, glu):
 case(4096, 768, True)
 case(768, 2048, False)
 case(768, 768, False)
+
+
+def rope_case(T, W, heads):
+    """QKV GEMM: mq_gemm_bf16_ln vs mq_gemm_bf16_ln_rope per tile height (ROPE=1; needs docs/experiments/r06r_rope_in_qkv_epilogue.patch applied)"""
+    nseq = M // T
+    m, K, N, hs = nseq * T, W, 3 * W, W // heads
+    x = torch.randn(m, K, device="cuda", generator=g).to(torch.bfloat16)
+    wf = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).to(torch.bfloat16)
+    bf = torch.randn(N, device="cuda", generator=g)
+    cs = wf.float().sum(1).contiguous()
+    st = torch.empty(m, 2, device="cuda")
+    L.check(lib.mq_row_stats(x.data_ptr(), st.data_ptr(), m, K, 1e-6, s()))
+    pairs = torch.rand(T, hs // 2, 2, device="cuda", generator=g).to(torch.float16)
+    out = torch.empty(m, N, device="cuda", dtype=torch.bfloat16)
+    base = lambda: L.check(lib.mq_gemm_bf16_ln(x.data_ptr(), K, wf.data_ptr(), K, bf.data_ptr(), cs.data_ptr(), st.data_ptr(), out.data_ptr(), N, m, N, K, L.MQ_EPI_BIAS, s()))
+    new = lambda: L.check(lib.mq_gemm_bf16_ln_rope(x.data_ptr(), K, wf.data_ptr(), K, bf.data_ptr(), cs.data_ptr(), st.data_ptr(), out.data_ptr(), N, m, N, K, pairs.data_ptr(), T, int(os.environ.get('ROPE_COLS', 2 * W)), hs, s()))
+    res = {}
+    for rep in range(2):
+        for mt in (0, 4):
+            L.check(lib.mq_tune(b"gemm_mt", mt))
+            res.setdefault(f"ln mt={mt}", []).append(round(timeit(base), 1))
+            for e in os.environ.get('EXPS', '0').split(','):
+                os.environ['MQ_EXP'] = e
+                res.setdefault(f"rope mt={mt} exp={e}", []).append(round(timeit(new), 1))
+    L.check(lib.mq_tune(b"gemm_mt", 0))
+    print(f"QKV m={m} T={T} W={W}:", res)
+
+
+if os.environ.get("ROPE"):
+    rope_case(197, 768, 12)
+    rope_case(257, 1024, 16)
