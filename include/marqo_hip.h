@@ -46,7 +46,7 @@ extern "C" {
 #define MQ_ERR_WORKSPACE (-3) /* caller's workspace too small */
 #define MQ_ERR_UNSUPPORTED (-4) /* ABI 11: the device is not the one this library is built for (mq_check_device) */
 
-#define MQ_ABI_VERSION 12
+#define MQ_ABI_VERSION 13
 
 /* ---- activation / mask / pooling selectors ---------------------------------------- */
 #define MQ_ACT_NONE 0
@@ -494,6 +494,20 @@ int mq_gemm_bf16_lnrs(const void* d_A, int64_t lda, const void* d_W, int64_t ldw
                       const void* d_residual, void* d_out, int64_t ldc, int64_t M, int64_t N, int64_t K, int flags, float* d_partials, void* stream);
 int mq_attention_stats(const void* d_qkv, void* d_out, const int32_t* d_cu_seqlens, int64_t nseq, int32_t fixed_len, int32_t max_len, int32_t W,
                        int32_t heads, int32_t mask, float* d_row_part, int64_t rows, void* stream);
+/* ABI 13 — attention + out-projection + residual + the LayerNorm statistics behind it in ONE launch (csrc/attn_proj.hip), for the short fixed-length
+ * sequences of the ViT-B/32 image tower (the x = x + out_proj(attention(qkv)) half of open_clip's residual attention block, reached from
+ * /root/reference/src/marqo/core/inference/embedding_models/open_clip_model.py:249-266): one workgroup per sequence keeps the attention output in LDS as
+ * the GEMM's A operand, streams the weight, adds bias and residual in place and — holding complete rows — writes their (mean, rstd).
+ *   d_qkv bf16 [rows, 3 W] (q | k | v, head-major), d_w bf16 [W, W] row-major, d_bias fp32 [W], d_x bf16 [rows, W] updated in place, d_rowstats fp32
+ *   [rows][2] = (mean, rstd) with the LayerNorm's eps, as mq_row_stats_finalize leaves them (NULL: not written); rows = nseq * fixed_len, no mask.
+ * The rows of d_x carry the same bits as mq_attention + mq_gemm_bf16(MQ_EPI_BIAS | MQ_EPI_RESIDUAL) would leave (same operations, same order); the
+ * statistics differ from the partial-sum path's by the fp32 association of the row sums.  mq_attention_proj_ok: 1 for the shapes it takes
+ * (1..64 tokens, W = 768, 12 heads), which is what the towers ask before planning a block around it (mq_tune("attn_proj", 0) turns that off).
+ * d_pf_a / d_pf_b (may be NULL): weight ranges of the GEMMs behind the launch, touched one dword per 128-byte line so that they sit in the Infinity
+ * Cache when those GEMMs start (what mq_gemm_bf16_rsf's d_pf_* are to the finalise this launch replaces). */
+int mq_attention_proj_ok(int64_t nseq, int32_t fixed_len, int32_t W, int32_t heads);
+int mq_attention_proj(const void* d_qkv, const void* d_w, const float* d_bias, void* d_x, float* d_rowstats, int64_t nseq, int32_t fixed_len, int32_t W,
+                      int32_t heads, float eps, const void* d_pf_a, size_t pf_a_bytes, const void* d_pf_b, size_t pf_b_bytes, void* stream);
 /* ABI 11 — mq_gemm_bf16_rsf = mq_gemm_bf16_rs + the finalise, in ONE launch: on return (stream order) d_stats holds (mean, rstd) of every row of d_out,
  * bit for bit what mq_row_stats_finalize would have written (same slot order, same expression).  The last wave to arrive at a row band's counter sums
  * the band's partials inside the GEMM's own launch (csrc/gemm_epilogue.h, GemmLn::band_ctr); d_band_ctr: mq_gemm_band_counters(M) 32-bit counters, all

@@ -29,7 +29,7 @@ STAGE_PATH = LIB_DIR / "_mq_stage.so"                # CPython extension: a batc
 
 MQ_OK = 0
 NO_SCRATCH_UNITS = ("rowops", "gemm_bf16", "gemm_wd", "gemm_fp8", "gemm_small", "attention", "embed")  # build() refuses register spills in these
-ABI_VERSION = 12
+ABI_VERSION = 13
 MQ_PREC_BF16, MQ_PREC_FP8 = 0, 1
 MQ_ACT_GELU, MQ_ACT_QUICKGELU, MQ_ACT_SILU = 1, 2, 3
 MQ_MASK_NONE, MQ_MASK_CAUSAL, MQ_MASK_CAUSAL_CLS = 0, 1, 2
@@ -155,6 +155,8 @@ _SIGNATURES = {
     "mq_row_stats_finalize": (C.c_int, [_P, C.c_int32, _P, C.c_int64, C.c_int32, C.c_float, _P]),
     "mq_gemm_bf16_lnrs": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, _P, _P]),
     "mq_attention_stats": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int64, _P]),
+    "mq_attention_proj_ok": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
+    "mq_attention_proj": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_float, _P, C.c_size_t, _P, C.c_size_t, _P]),
     "mq_gemm_bf16_rs": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, _P, _P]),
     "mq_check_device": (C.c_int, [C.c_int]),
     "mq_gemm_band_counters": (C.c_int64, [C.c_int64]),

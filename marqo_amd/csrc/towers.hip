@@ -45,6 +45,8 @@ mq_knob mq_tower_ln_fold{getenv("MQ_LN_FOLD") ? atoi(getenv("MQ_LN_FOLD")) : 2};
 // the EVA02 sub-LayerNorms (attn.norm in front of the out-projection, mlp.norm in front of fc2) folded into those GEMMs (round 6, ABI 12; block_eva):
 // mq_tune("subln_fold", 0) / MQ_SUBLN_FOLD=0 keeps them as LayerNorm passes over the attention output / the gated product
 mq_knob mq_tower_subln_fold{getenv("MQ_SUBLN_FOLD") ? atoi(getenv("MQ_SUBLN_FOLD")) : 1};
+// attention + out-projection + residual + statistics in one launch (attn_proj.hip) from this many fixed-length sequences up (0 = never)
+mq_knob mq_tower_attn_proj{getenv("MQ_ATTN_PROJ") ? atoi(getenv("MQ_ATTN_PROJ")) : 64};
 // bf16 residual stream for the pre-LN bf16 towers (mq_tune("residual_bf16", 1) / MQ_RESIDUAL_BF16=1): x is kept in bf16 between
 // blocks.  The residual GEMMs of a K = 768 tower are memory-bound on their epilogue (out-proj: 15 GFLOP against 39 MB read + 39 MB
 // written of fp32 residual) and every LayerNorm re-reads the stream: bf16 halves those bytes.  Cost: one bf16 rounding per residual
@@ -444,15 +446,22 @@ int EncoderPass::block_pre_ln(const mq_block_weights& b, int l) {
     MQ_TRY(ln_gemm(d_x, xb, b.ln1_g, b.ln1_b, cfg->ln_eps, h, b.qkv_w, b.qkv_b, qf, rows, 3 * Wa, W, MQ_EPI_BIAS, s, b.out_w, (size_t)W * Wa * 2,
                    b.qkv_wf, b.qkv_bf, b.qkv_sf, row_stats, x_has_partials));
     x_has_partials = false;
-    MQ_TRY(attn_bf16(cfg, qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, s));
     // the residual GEMMs leave the rows' partial sums behind whenever the GEMM after them folds its LayerNorm (tiled family, bf16 stream)
     const bool last_pooled = d_sel && nsel > 0 && l == cfg->layers - 1;
     const bool mlp_fp8 = cfg->precision == MQ_PREC_FP8 && l >= first8 - cfg->fp8_mlp_extra;
     const bool fold_mlp = mq_tower_ln_fold >= 2 && !last_pooled && !mlp_fp8 && fold_ok(xb, b.fc1_wf, b.fc1_bf, b.fc1_sf, rows, F, W) &&
                           !mq_gemm_small_ok(rows, W, Wa, false) && !mq_gemm_small_grouped_ok(rows, W, Wa);
+    // short fixed-length image sequences (ViT-B/32: 50 tokens): attention, out-projection, residual and the statistics of norm2 in ONE launch, one workgroup
+    // per image (attn_proj.hip) — the rows of x carry the same bits as the three launches below leave
+    if (mq_tower_attn_proj && fold_mlp && xb && !d_cu_seqlens && fixed_len > 0 && rows == nseq * fixed_len && Wa == W && cfg->mask == MQ_MASK_NONE && !cfg->d_rel_bias &&
+        nseq >= mq_tower_attn_proj && mq_attention_proj_ok(nseq, fixed_len, W, cfg->heads)) {
+        MQ_TRY(mq_attention_proj(qf, b.out_w, b.out_b, d_x, row_stats, nseq, fixed_len, W, cfg->heads, cfg->ln_eps, pf(b.fc1_wf), (size_t)F * W * 2, pf(b.fc2_w), (size_t)W * F * 2, s));
+    } else {
+    MQ_TRY(attn_bf16(cfg, qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, s));
     if (fold_mlp) MQ_TRY(mq_gemm_bf16_rsf(a, Wa, b.out_w, Wa, b.out_b, d_x, d_x, W, rows, W, Wa, rflags, row_part, row_stats, cfg->ln_eps, band_ctr, pf(b.fc1_wf),
                                           (size_t)F * W * 2, pf(b.fc2_w), (size_t)W * F * 2, s));
     else MQ_TRY(mq_gemm_bf16(a, Wa, b.out_w, Wa, b.out_b, (const float*)d_x, d_x, W, rows, W, Wa, rflags, s));
+    }
     if (mlp_fp8) {
         // MLP-only e4m3 block (fp8_mlp_extra): the attention half above ran on bf16 operands
         MQ_CHECK_ARG(b.fc1_w8 && b.fc1_ws && b.fc2_w8 && b.fc2_ws, "mq_encoder_forward: layer %d has no fp8 MLP weights", l);

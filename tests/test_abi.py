@@ -24,7 +24,7 @@ def test_header_symbols_are_exported_and_bound():
         assert hasattr(raw, n), f"libmarqo_hip.so does not export {n}"
         assert n in L.EXPORTED_SYMBOLS, f"ctypes binding is missing {n}"
     assert set(L.EXPORTED_SYMBOLS) <= set(names), set(L.EXPORTED_SYMBOLS) - set(names)
-    assert lib.mq_abi_version() == L.ABI_VERSION == 12 and lib.mq_build_arch() == b"gfx950"
+    assert lib.mq_abi_version() == L.ABI_VERSION == 13 and lib.mq_build_arch() == b"gfx950"
 
 
 def test_struct_layouts_match_header():

@@ -297,7 +297,7 @@ def test_registry_models_synthetic_weights(s2):
 
 KNOB_SWEEP = [("gemm_nh", 3), ("gemm_nh", 4), ("gemm_nh", 1), ("gemm_tail", 1), ("gemm_wd", 3), ("gemm_wd", 6), ("rs_finalize", 1), ("ln_fold", 0), ("ln_fold", 1),
               ("small_m", 0), ("small_m_grouped", 0), ("row_select", 0), ("attn_waves", 8), ("attn_waves", 4), ("ln_prefetch", 0),
-              ("gemm_mt", 2), ("gemm_mt", 6), ("gemm_cgroup", 0), ("xcd_band", 0)]
+              ("gemm_mt", 2), ("gemm_mt", 6), ("gemm_cgroup", 0), ("xcd_band", 0), ("attn_proj", 0), ("attn_proj", 1)]
 
 
 def test_every_kernel_family_knob_keeps_vectorise_right(s2):
@@ -321,7 +321,7 @@ def test_every_kernel_family_knob_keeps_vectorise_right(s2):
     refi = O.vit_forward(sdc, O.VitConfig(224, 32, 768, 12, 12, 3072, 512), torch.from_numpy(np.stack([OP.clip_transform(np.asarray(p)) for p in pil[:6]]))).numpy()
     assert _cos_err(base_i[:6], refi) < COS_TOL and _cos_err(base_q, base_t[3:4]) < 3e-4
     defaults = {k: 0 for k, _ in KNOB_SWEEP}
-    defaults.update(gemm_cgroup=8, ln_fold=2, small_m=80, small_m_grouped=320, row_select=1, ln_prefetch=1, xcd_band=1)
+    defaults.update(gemm_cgroup=8, ln_fold=2, small_m=80, small_m_grouped=320, row_select=1, ln_prefetch=1, xcd_band=1, attn_proj=64)
     worst = {}
     for key, value in KNOB_SWEEP:
         try:
