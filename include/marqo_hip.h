@@ -500,8 +500,8 @@ int mq_attention_stats(const void* d_qkv, void* d_out, const int32_t* d_cu_seqle
  * the GEMM's A operand, streams the weight, adds bias and residual in place and — holding complete rows — writes their (mean, rstd).
  *   d_qkv bf16 [rows, 3 W] (q | k | v, head-major), d_w bf16 [W, W] row-major, d_bias fp32 [W], d_x bf16 [rows, W] updated in place, d_rowstats fp32
  *   [rows][2] = (mean, rstd) with the LayerNorm's eps, as mq_row_stats_finalize leaves them (NULL: not written); rows = nseq * fixed_len, no mask.
- * The rows of d_x carry the same bits as mq_attention + mq_gemm_bf16(MQ_EPI_BIAS | MQ_EPI_RESIDUAL) would leave (same operations, same order); the
- * statistics differ from the partial-sum path's by the fp32 association of the row sums.  mq_attention_proj_ok: 1 for the shapes it takes
+ * The rows of d_x carry the same bits as mq_attention + mq_gemm_bf16(MQ_EPI_BIAS | MQ_EPI_RESIDUAL) would leave (same operations, same order), and the
+ * statistics the bits of mq_gemm_bf16_rs + mq_row_stats_finalize (same per-lane chains, lane folds and slot order).  mq_attention_proj_ok: 1 for the shapes it takes
  * (1..64 tokens, W = 768, 12 heads), which is what the towers ask before planning a block around it (mq_tune("attn_proj", 0) turns that off).
  * d_pf_a / d_pf_b (may be NULL): weight ranges of the GEMMs behind the launch, touched one dword per 128-byte line so that they sit in the Infinity
  * Cache when those GEMMs start (what mq_gemm_bf16_rsf's d_pf_* are to the finalise this launch replaces). */
@@ -669,7 +669,9 @@ int mq_weighted_combine(const float* d_emb, int64_t ld, const int32_t* d_rows, c
  * row chunks), "row_select" (0 = the towers run their last block on every row instead of the pooled rows only), "ln_fold" (0 = LayerNorm
  * kernels, 1 = folded into the QKV GEMM, 2 = and into fc1; needs the folded weights), "subln_fold" (ABI 12: 0 = the EVA02 sub-LayerNorms run as
  * LayerNorm passes instead of inside the out-projection / fc2 GEMMs; MQ_SUBLN_FOLD), "residual_bf16", "small_m" / "small_m_grouped"
- * (row limits of the skinny GEMM kernels), "ln_prefetch", "xcd_band", "attn_waves" (0 = auto, 4 / 8 wave64s per attention workgroup).
+ * (row limits of the skinny GEMM kernels), "ln_prefetch", "xcd_band", "attn_waves" (0 = auto, 4 / 8 wave64s per attention workgroup),
+ * "attn_proj" (ABI 13: fewest fixed-length sequences from which a ViT-B/32-shaped block runs mq_attention_proj instead of attention + out-projection +
+ * finalise, 0 = never; default 128, MQ_ATTN_PROJ).
  * Initial values come from the environment (MQ_GEMM_MT, MQ_GEMM_CGROUP, MQ_GEMM_NH, MQ_GEMM_TAIL, MQ_GEMM_WD, MQ_GEMM_RS_FIN, MQ_ROW_SELECT,
  * MQ_LN_FOLD, ...). */
 int mq_tune(const char* key, int value);

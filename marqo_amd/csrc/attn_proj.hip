@@ -16,8 +16,8 @@
 //            flight — no workgroup barrier anywhere in the GEMM, only counted vmcnt waits; the k order (head by head, two 32-deep halves) is the tiled
 //            GEMM's, so the accumulators carry the same bits as gemm_nt_kernel's;
 //   epilogue x = bf16((acc + bias) + x) in place (the tiled GEMM's order of operations: bit-identical rows), and because the workgroup holds COMPLETE rows
-//            the (mean, rstd) of the LayerNorm behind it are finished here — per-wave sums over 96 columns, eight of them added through LDS — instead of
-//            12 partial slots per row + a finalise launch.
+//            the (mean, rstd) of the LayerNorm behind it are finished here instead of 12 partial slots per row in memory + a finalise launch — summed in
+//            the partial-sum path's own order (per 64-column slot, lane chains handed between wave pairs through LDS), so the statistics carry its bits too.
 // The price: 64-row MFMA tiles for 50 tokens (78 % useful) and the whole of Wo (1.2 MB) through every CU's vector-memory path once per image.
 #include "common.h"
 #include "gemm_loop.h"
@@ -44,12 +44,6 @@ __device__ __forceinline__ bf16x8 gload16(const void* p) {
     i32x4 v;
     asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(v) : "v"(p), "n"(OFF));
     return __builtin_bit_cast(bf16x8, v);
-}
-template <int OFF>
-__device__ __forceinline__ u32x2 gload8(const void* p) {
-    u32x2 v;
-    asm volatile("global_load_dwordx2 %0, %1, off offset:%2" : "=v"(v) : "v"(p), "n"(OFF));
-    return v;
 }
 // weight lines the launch touches for the GEMMs behind it (one dword per 128-byte line, values unused): a, b = two ranges, na / nb lines
 struct ApPrefetch { const unsigned* a; const unsigned* b; unsigned na, nb; };
@@ -127,11 +121,12 @@ __global__ __launch_bounds__(512, 1) void attn_proj_kernel(const bf16_t* __restr
 
     // the epilogue's residual rows travel with the rounds too: round r (< 4) fetches the lane's 6 x 8 bytes of token tile r (asm loads the compiler does
     // not track; 48 registers held across the GEMM) — at the epilogue's own time all 256 workgroups would ask for their 77 KB at once and wait for HBM
-    u32x2 res[4][NT3][2];
+    // (in the STORE layout: 16 bytes = the 8 consecutive columns the lane writes after the epilogue's lane exchange — 64-byte runs per row instead of 32)
+    i32x4 res[4][NT3];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int a = 0; a < NT3; ++a) { res[mt][a][0] = u32x2{0u, 0u}; res[mt][a][1] = u32x2{0u, 0u}; }
+        for (int a = 0; a < NT3; ++a) res[mt][a] = i32x4{0, 0, 0, 0};
     // ... and the weight prefetch the finalise launch used to carry (rowops.hip, LnExtra): thread t of the grid touches lines t and t + (threads of the grid)
     unsigned pf_reg[2] = {0u, 0u};
     const unsigned pf_nt = gridDim.x * 512u, pf_t = blockIdx.x * 512u + (unsigned)tid;
@@ -155,11 +150,10 @@ __global__ __launch_bounds__(512, 1) void attn_proj_kernel(const bf16_t* __restr
         }
         if constexpr (grp < 4) {
             const int m = grp * 16 + l15;
-            const bf16_t* xr = x + (row0 + (m < len ? m : 0)) * W + wave * 32 + 4 * g;
+            const bf16_t* xr = x + (row0 + (m < len ? m : 0)) * W + wave * (W / 8) + (g & 1) * 16 + (g >> 1) * 8;
             static_for<NT3>([&](auto a_tag) {
                 constexpr int a = decltype(a_tag)::value;
-                res[grp][a][0] = gload8<a * 512>(xr);
-                res[grp][a][1] = gload8<a * 512 + 32>(xr);
+                res[grp][a] = __builtin_bit_cast(i32x4, gload16<a * 64>(xr));
             });
         }
         if constexpr (grp == 1 || grp == 3) {
@@ -251,7 +245,7 @@ __global__ __launch_bounds__(512, 1) void attn_proj_kernel(const bf16_t* __restr
         landed(qn[0]); landed(qn[1]);
         if constexpr (grp < 4) {
 #pragma unroll
-            for (int a = 0; a < NT3; ++a) { landed(res[grp][a][0]); landed(res[grp][a][1]); }
+            for (int a = 0; a < NT3; ++a) landed(res[grp][a]);
         }
         if constexpr (grp == 1 || grp == 3) landed(pf_reg[grp >> 1]);
     });
@@ -268,7 +262,7 @@ __global__ __launch_bounds__(512, 1) void attn_proj_kernel(const bf16_t* __restr
     constexpr unsigned W_BYTES = (unsigned)W * W * 2;
     auto issue_unit = [&](int kt, int i, int slot, bool live) {   // i = 2 nt3 + j
         const unsigned rec = live ? W_BYTES : 0u;                // past the last unit: out of range for every lane — no traffic, the counters still tick
-        const unsigned soff = (unsigned)(((i >> 1) * 256 + wave * 32 + (i & 1) * 16) * (W * 2) + kt * 128);
+        const unsigned soff = (unsigned)((wave * (W / 8) + i * 16) * (W * 2) + kt * 128);
         const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)Wo, 0, rec, 0x00020000);
         dma16(rs, w_vo, soff, slot0 + (unsigned)slot * 2048u);
         dma16(rs, w_vo + 8u * (W * 2), soff, slot0 + (unsigned)slot * 2048u + 1024u);
@@ -343,52 +337,94 @@ __global__ __launch_bounds__(512, 1) void attn_proj_kernel(const bf16_t* __restr
 
     // =============================== epilogue: x = bf16((acc + bias) + x) in place; (mean, rstd) of the complete rows ====================================
     if (dbg & 4) return;
+    // Column map: wave w owns columns [96 w, 96 w + 96) = 6 sixteen-column tiles i = 2 a + j.  The LayerNorm statistics must carry the BITS of the partial-sum
+    // path (gemm_epilogue.h MQ_EPI_ROW_STATS + row_stats_finalize_kernel): an image's embedding may not depend on whether its batch was big enough for this
+    // kernel (the coalescer and the ingest merging lean on that; tests/test_towers_gpu.py batch-split invariance).  That path sums, per row and 64-column slot,
+    // a lane's rounded values tile by tile (chain_add below, tiles in ascending order), adds the lane's two halves, then the row's 4 lanes (fold_sum), and
+    // the finalise adds the 12 slots in order.  Here an even wave holds slot 3 k whole (tiles 0-3) and the first half of slot 3 k + 1 (tiles 4, 5), its odd
+    // partner the second half of that slot (tiles 0, 1) and slot 3 k + 2 whole (tiles 2-5): the shared slot's chain is handed over through LDS.
+    constexpr int WC = W / 8;               // columns per wave (96)
     f32x4 bias_v[NT3][2];
 #pragma unroll
     for (int a = 0; a < NT3; ++a)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) bias_v[a][j] = *(const f32x4*)(bias + a * 256 + wave * 32 + j * 16 + 4 * g);
-    float2* part = (float2*)(smem + PANEL + wave * 8192);   // this wave's own ring region: [64 tokens] (sum, sum of squares) over its 96 columns
+        for (int j = 0; j < 2; ++j) bias_v[a][j] = *(const f32x4*)(bias + wave * WC + a * 32 + j * 16 + 4 * g);
+    char* mine = smem + PANEL + wave * 8192;   // this wave's own ring region: [0, 512) whole-slot sums [64 rows], [512, 1024) shared-slot sums, [1024, 5120) chain state [4][64 lanes]
+    const bool odd = (wave & 1) != 0;          // wave-uniform
+    auto chain_add = [](f32x2_t& s1, f32x2_t& s2, unsigned px, unsigned py) {
+        const f32x2_t e0 = {__uint_as_float(px << 16), __uint_as_float(px & 0xffff0000u)}, e1 = {__uint_as_float(py << 16), __uint_as_float(py & 0xffff0000u)};
+        s1 += e0 + e1;
+        s2 = __builtin_elementwise_fma(e0, e0, __builtin_elementwise_fma(e1, e1, s2));
+    };
+    unsigned held[4][4];   // odd waves: the rounded values of tiles 0, 1 (the shared slot's second half) until the partner's chain state is there
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
         const int m = mt * 16 + l15;
         const bool m_ok = m < len;
-        bf16_t* xr = x + (row0 + (m_ok ? m : 0)) * W + wave * 32;
-        f32x2_t st1v = {0.f, 0.f}, st2v = {0.f, 0.f};
+        bf16_t* xr = x + (row0 + (m_ok ? m : 0)) * W + wave * WC;
+        f32x2_t w1 = {0.f, 0.f}, w2 = {0.f, 0.f};   // the whole slot's chain
+        f32x2_t h1 = {0.f, 0.f}, h2 = {0.f, 0.f};   // even waves: the shared slot's first half
 #pragma unroll
         for (int a = 0; a < NT3; ++a) {
             uint2 pk[2];
+            // the residual quad back into the accumulators' layout: (low, high) halves exchanged between lanes 16 apart — the inverse of the store's exchange
+            const auto q0 = __builtin_amdgcn_permlane16_swap((unsigned)res[mt][a][0], (unsigned)res[mt][a][2], false, false);
+            const auto q1 = __builtin_amdgcn_permlane16_swap((unsigned)res[mt][a][1], (unsigned)res[mt][a][3], false, false);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 f32x4 v = acc[a][mt][j];
                 v += bias_v[a][j];
-                const u32x2 rq = res[mt][a][j];
+                const unsigned rq[2] = {q0[j], q1[j]};
                 v += f32x4{__uint_as_float(rq[0] << 16), __uint_as_float(rq[0] & 0xffff0000u), __uint_as_float(rq[1] << 16), __uint_as_float(rq[1] & 0xffff0000u)};
                 pk[j].x = pack_bf16x2(v[0], v[1]);
                 pk[j].y = pack_bf16x2(v[2], v[3]);
                 // statistics of the ROUNDED values (what the next GEMM multiplies), rows past the sequence count as zeros
                 const unsigned px = m_ok ? pk[j].x : 0u, py = m_ok ? pk[j].y : 0u;
-                const f32x2_t e0 = {__uint_as_float(px << 16), __uint_as_float(px & 0xffff0000u)}, e1 = {__uint_as_float(py << 16), __uint_as_float(py & 0xffff0000u)};
-                st1v += e0 + e1;
-                st2v = __builtin_elementwise_fma(e0, e0, __builtin_elementwise_fma(e1, e1, st2v));
+                if constexpr (NT3 == 3) {
+                    if (a == 1) chain_add(w1, w2, px, py);                       // tiles 2, 3: the whole slot of either parity
+                    else if (a == 0) {
+                        if (odd) { held[mt][2 * j] = px; held[mt][2 * j + 1] = py; }
+                        else chain_add(w1, w2, px, py);
+                    } else {
+                        if (odd) chain_add(w1, w2, px, py);
+                        else chain_add(h1, h2, px, py);
+                    }
+                }
             }
             // the two 16-column blocks exchanged between lanes 16 apart: a lane then owns 8 consecutive columns (one 16-byte store), as gemm_epilogue.h
             const auto r0 = __builtin_amdgcn_permlane16_swap(pk[0].x, pk[1].x, false, false);
             const auto r1 = __builtin_amdgcn_permlane16_swap(pk[0].y, pk[1].y, false, false);
-            if (m_ok) *(uint4*)(xr + a * 256 + (g & 1) * 16 + (g >> 1) * 8) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+            if (m_ok) *(uint4*)(xr + a * 32 + (g & 1) * 16 + (g >> 1) * 8) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
         }
         if (rowstats) {
-            const float st1 = fold_sum(st1v[0] + st1v[1]), st2 = fold_sum(st2v[0] + st2v[1]);
-            if (g == 0) part[m] = make_float2(st1, st2);
+            const float st1 = fold_sum(w1[0] + w1[1]), st2 = fold_sum(w2[0] + w2[1]);
+            if (g == 0) ((float2*)mine)[m] = make_float2(st1, st2);
+            if (!odd) ((f32x4*)(mine + 1024))[mt * 64 + lane] = f32x4{h1[0], h1[1], h2[0], h2[1]};
         }
     }
     if (rowstats) {
+        static_assert(NT3 == 3, "the slot hand-over is written for 96 columns per wave");
+        __syncthreads();
+        if (odd) {
+            const f32x4* theirs = (const f32x4*)(smem + PANEL + (wave - 1) * 8192 + 1024);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const f32x4 st = theirs[mt * 64 + lane];
+                f32x2_t h1 = {st[0], st[1]}, h2 = {st[2], st[3]};
+                chain_add(h1, h2, held[mt][0], held[mt][1]);
+                chain_add(h1, h2, held[mt][2], held[mt][3]);
+                const float st1 = fold_sum(h1[0] + h1[1]), st2 = fold_sum(h2[0] + h2[1]);
+                if (g == 0) ((float2*)(mine + 512))[mt * 16 + l15] = make_float2(st1, st2);
+            }
+        }
         __syncthreads();
         if (tid < len) {
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-            for (int w = 0; w < 8; ++w) {   // fixed order
-                const float2 p = ((const float2*)(smem + PANEL + w * 8192))[tid];
+            for (int slot = 0; slot < W / 64; ++slot) {   // slot order, as row_stats_finalize_kernel
+                const int k = slot / 3, r = slot % 3;
+                const char* src = smem + PANEL + (2 * k + (r ? 1 : 0)) * 8192 + (r == 1 ? 512 : 0);
+                const float2 p = ((const float2*)src)[tid];
                 s1 += p.x;
                 s2 += p.y;
             }

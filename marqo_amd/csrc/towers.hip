@@ -45,8 +45,10 @@ mq_knob mq_tower_ln_fold{getenv("MQ_LN_FOLD") ? atoi(getenv("MQ_LN_FOLD")) : 2};
 // the EVA02 sub-LayerNorms (attn.norm in front of the out-projection, mlp.norm in front of fc2) folded into those GEMMs (round 6, ABI 12; block_eva):
 // mq_tune("subln_fold", 0) / MQ_SUBLN_FOLD=0 keeps them as LayerNorm passes over the attention output / the gated product
 mq_knob mq_tower_subln_fold{getenv("MQ_SUBLN_FOLD") ? atoi(getenv("MQ_SUBLN_FOLD")) : 1};
-// attention + out-projection + residual + statistics in one launch (attn_proj.hip) from this many fixed-length sequences up (0 = never)
-mq_knob mq_tower_attn_proj{getenv("MQ_ATTN_PROJ") ? atoi(getenv("MQ_ATTN_PROJ")) : 64};
+// attention + out-projection + residual + statistics in one launch (attn_proj.hip) from this many fixed-length sequences up (0 = never).  One workgroup
+// per image: below ~half the chip's 256 CUs the three launches it replaces win (measured, profiles/r06x_attn_proj_batch_ab.txt: +3.4 % at 256 images,
+// +2 % at 128, -1 % at 96, -4.5 % at 64)
+mq_knob mq_tower_attn_proj{getenv("MQ_ATTN_PROJ") ? atoi(getenv("MQ_ATTN_PROJ")) : 128};
 // bf16 residual stream for the pre-LN bf16 towers (mq_tune("residual_bf16", 1) / MQ_RESIDUAL_BF16=1): x is kept in bf16 between
 // blocks.  The residual GEMMs of a K = 768 tower are memory-bound on their epilogue (out-proj: 15 GFLOP against 39 MB read + 39 MB
 // written of fp32 residual) and every LayerNorm re-reads the stream: bf16 halves those bytes.  Cost: one bf16 rounding per residual

@@ -60,12 +60,12 @@ def test_one_launch_equals_the_three_it_replaces_and_fp32_torch(nseq, T):
     torch.cuda.synchronize()
     # the rows: the same operations in the same order -> the same bits
     assert torch.equal(x1.view(torch.int16), x3.view(torch.int16))
-    # the statistics: (mean, rstd) of the rounded rows, summed in another association
+    # the statistics: the partial-sum path's bits too (same per-lane chains, same lane folds, same slot order: an embedding may not depend on which path its batch took)
+    assert torch.equal(s1, s3)
     xd = x1.double()
     mean, rstd = xd.mean(1), 1.0 / torch.sqrt(xd.var(1, unbiased=False) + eps)
     assert torch.allclose(s1[:, 0].double(), mean, rtol=0, atol=2e-6 * float(xd.abs().max()))
     assert torch.allclose(s1[:, 1].double(), rstd, rtol=2e-5, atol=0)
-    assert torch.allclose(s1, s3, rtol=2e-5, atol=2e-6 * float(xd.abs().max()))
     # ... and plain PyTorch fp32 (bf16 rounding of P and of the attention output are the kernel's own)
     q, k, v = (qkv.float().view(nseq, T, 3, HEADS, 64).permute(2, 0, 3, 1, 4))
     o = torch.softmax(q @ k.transpose(-1, -2) / 8.0, dim=-1) @ v
@@ -107,8 +107,7 @@ def test_shapes_it_does_not_take_are_refused():
 
 
 def test_vit_b32_tower_with_and_without_the_fused_launch():
-    """the tower (bf16 residual stream, folded LayerNorms) with the block's attention half as one launch vs as three: the embeddings agree to the fp32
-    association of the row statistics, and both sit on the oracle"""
+    """the tower (bf16 residual stream, folded LayerNorms) with the block's attention half as one launch vs as three: bit-identical embeddings, on the oracle"""
     from marqo_amd.engine import archs, towers
     from oracle import towers as O
     lib = L.load()
@@ -124,9 +123,8 @@ def test_vit_b32_tower_with_and_without_the_fused_launch():
         one = tower.encode_u8(u8).cpu()
         one_small = tower.encode_u8(u8[:5]).cpu()
     finally:
-        L.check(lib.mq_tune(b"attn_proj", 64))
-    cos = torch.nn.functional.cosine_similarity(one.double(), three.double(), dim=-1)
-    assert float((1 - cos).max()) < 1e-4, float((1 - cos).max())
+        L.check(lib.mq_tune(b"attn_proj", 128))
+    assert torch.equal(one, three)          # rows AND statistics carry the three launches' bits: so do the embeddings
     ref = O.vit_forward(sd, cfg, O.preprocess_u8_exact_size(u8[:6].cpu()))
     for got in (one[:6], three[:6]):
         c = torch.nn.functional.cosine_similarity(got.double(), ref.double(), dim=-1)

@@ -321,7 +321,7 @@ def test_every_kernel_family_knob_keeps_vectorise_right(s2):
     refi = O.vit_forward(sdc, O.VitConfig(224, 32, 768, 12, 12, 3072, 512), torch.from_numpy(np.stack([OP.clip_transform(np.asarray(p)) for p in pil[:6]]))).numpy()
     assert _cos_err(base_i[:6], refi) < COS_TOL and _cos_err(base_q, base_t[3:4]) < 3e-4
     defaults = {k: 0 for k, _ in KNOB_SWEEP}
-    defaults.update(gemm_cgroup=8, ln_fold=2, small_m=80, small_m_grouped=320, row_select=1, ln_prefetch=1, xcd_band=1, attn_proj=64)
+    defaults.update(gemm_cgroup=8, ln_fold=2, small_m=80, small_m_grouped=320, row_select=1, ln_prefetch=1, xcd_band=1, attn_proj=128)
     worst = {}
     for key, value in KNOB_SWEEP:
         try:
