@@ -508,6 +508,16 @@ int mq_attention_stats(const void* d_qkv, void* d_out, const int32_t* d_cu_seqle
 int mq_attention_proj_ok(int64_t nseq, int32_t fixed_len, int32_t W, int32_t heads);
 int mq_attention_proj(const void* d_qkv, const void* d_w, const float* d_bias, void* d_x, float* d_rowstats, int64_t nseq, int32_t fixed_len, int32_t W,
                       int32_t heads, float eps, const void* d_pf_a, size_t pf_a_bytes, const void* d_pf_b, size_t pf_b_bytes, void* stream);
+/* ABI 13 — mq_gemm_bf16_ln for fixed-length sequences of <= 64 rows, one workgroup per sequence (csrc/panel_gemm.hip: the QKV and fc1 GEMMs of the ViT-B/32
+ * image tower at chip-filling batches; same reference call site as mq_attention_proj): the sequence's rows are staged once in LDS as the MFMA token operand
+ * and the weight streams through per-wave rings in passes of 768 output columns.  Operands as mq_gemm_bf16_ln (d_W / d_bias / d_colsum folded, d_rowstats =
+ * (mean, rstd) per row), K = 768, N a multiple of 768, rows = nseq * fixed_len; flags MQ_EPI_BIAS [| MQ_EPI_GELU | MQ_EPI_QUICKGELU]; d_out bf16 [rows, ldc].
+ * Output bits = mq_gemm_bf16_ln's (same k order, same epilogue order).  Measured 17-30 % slower than the tiled kernel at the tower's shapes (3.5 / 4.7 MB of
+ * weight per CU and image; profiles/r07a_panel_gemm_ab.txt): an opt-in — mq_encoder_forward takes it only under mq_tune("panel_gemm", n) / MQ_PANEL_GEMM=n,
+ * from n sequences up when they fill the chip's 256 CUs in whole rounds to >= 3/4 (default 0 = never). */
+int mq_panel_gemm_ln_ok(int64_t nseq, int32_t fixed_len, int64_t N, int64_t K);
+int mq_panel_gemm_ln(const void* d_x, const void* d_W, const float* d_bias, const float* d_colsum, const float* d_rowstats, void* d_out, int64_t ldc,
+                     int64_t nseq, int32_t fixed_len, int64_t N, int64_t K, int flags, void* stream);
 /* ABI 11 — mq_gemm_bf16_rsf = mq_gemm_bf16_rs + the finalise, in ONE launch: on return (stream order) d_stats holds (mean, rstd) of every row of d_out,
  * bit for bit what mq_row_stats_finalize would have written (same slot order, same expression).  The last wave to arrive at a row band's counter sums
  * the band's partials inside the GEMM's own launch (csrc/gemm_epilogue.h, GemmLn::band_ctr); d_band_ctr: mq_gemm_band_counters(M) 32-bit counters, all
@@ -671,7 +681,8 @@ int mq_weighted_combine(const float* d_emb, int64_t ld, const int32_t* d_rows, c
  * LayerNorm passes instead of inside the out-projection / fc2 GEMMs; MQ_SUBLN_FOLD), "residual_bf16", "small_m" / "small_m_grouped"
  * (row limits of the skinny GEMM kernels), "ln_prefetch", "xcd_band", "attn_waves" (0 = auto, 4 / 8 wave64s per attention workgroup),
  * "attn_proj" (ABI 13: fewest fixed-length sequences from which a ViT-B/32-shaped block runs mq_attention_proj instead of attention + out-projection +
- * finalise, 0 = never; default 128, MQ_ATTN_PROJ).
+ * finalise, 0 = never; default 128, MQ_ATTN_PROJ), "panel_gemm" (ABI 13: fewest fixed-length sequences from which the folded QKV / fc1 GEMMs of a 768-wide
+ * tower run as mq_panel_gemm_ln; default 0 = never, MQ_PANEL_GEMM).
  * Initial values come from the environment (MQ_GEMM_MT, MQ_GEMM_CGROUP, MQ_GEMM_NH, MQ_GEMM_TAIL, MQ_GEMM_WD, MQ_GEMM_RS_FIN, MQ_ROW_SELECT,
  * MQ_LN_FOLD, ...). */
 int mq_tune(const char* key, int value);

@@ -156,6 +156,8 @@ _SIGNATURES = {
     "mq_gemm_bf16_lnrs": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, _P, _P]),
     "mq_attention_stats": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int64, _P]),
     "mq_attention_proj_ok": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
+    "mq_panel_gemm_ln_ok": (C.c_int, [C.c_int64, C.c_int32, C.c_int64, C.c_int64]),
+    "mq_panel_gemm_ln": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_int32, C.c_int64, C.c_int64, C.c_int, _P]),
     "mq_attention_proj": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_float, _P, C.c_size_t, _P, C.c_size_t, _P]),
     "mq_gemm_bf16_rs": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, _P, _P]),
     "mq_check_device": (C.c_int, [C.c_int]),

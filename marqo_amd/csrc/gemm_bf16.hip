@@ -44,6 +44,7 @@ extern mq_knob mq_tower_row_select;   // towers.hip
 extern mq_knob mq_tower_ln_fold;      // towers.hip
 extern mq_knob mq_tower_subln_fold;
 extern mq_knob mq_tower_attn_proj;
+extern mq_knob mq_tower_panel_gemm;
 extern mq_knob mq_attention_waves;    // attention.hip
 extern mq_knob mq_tower_residual_bf16;  // towers.hip
 extern mq_knob mq_gemm_small_max_rows;  // gemm_small.hip
@@ -901,7 +902,8 @@ extern "C" int mq_gemm_bf16_rsf(const void* d_A, int64_t lda, const void* d_W, i
 // "gemm_tail", "gemm_wd" (gemm_wd.hip: 0 = off, 2 / 3 / 6 / 7), "rs_finalize" (1 = the row statistics are finalised inside the residual GEMM's launch),
 // "subln_fold" (0 = the EVA02 sub-LayerNorms run as LayerNorm passes instead of inside the out-projection / fc2 GEMMs),
 // "attn_proj" (fewest fixed-length sequences from which a ViT-B/32-shaped block runs attention + out-projection + residual + statistics as ONE launch,
-// attn_proj.hip; 0 = never).
+// attn_proj.hip; 0 = never), "panel_gemm" (fewest fixed-length sequences from which the folded QKV / fc1 GEMMs of a 768-wide tower run one workgroup per
+// sequence, panel_gemm.hip; 0 = never).
 extern "C" int mq_tune(const char* key, int value) {
     MQ_CHECK_ARG(key, "mq_tune: null key");
     const std::string k(key);
@@ -915,6 +917,7 @@ extern "C" int mq_tune(const char* key, int value) {
     else if (k == "ln_fold") mq_tower_ln_fold = value;
     else if (k == "subln_fold") mq_tower_subln_fold = value;
     else if (k == "attn_proj") mq_tower_attn_proj = value;
+    else if (k == "panel_gemm") mq_tower_panel_gemm = value;
     else if (k == "xcd_band") mq_xcd_band = value;
     else if (k == "attn_waves") mq_attention_waves = value;
     else if (k == "residual_bf16") mq_tower_residual_bf16 = value;

@@ -49,6 +49,13 @@ mq_knob mq_tower_subln_fold{getenv("MQ_SUBLN_FOLD") ? atoi(getenv("MQ_SUBLN_FOLD
 // per image: below ~half the chip's 256 CUs the three launches it replaces win (measured, profiles/r06x_attn_proj_batch_ab.txt: +3.4 % at 256 images,
 // +2 % at 128, -1 % at 96, -4.5 % at 64)
 mq_knob mq_tower_attn_proj{getenv("MQ_ATTN_PROJ") ? atoi(getenv("MQ_ATTN_PROJ")) : 128};
+// the folded QKV / fc1 GEMMs one workgroup per image (panel_gemm.hip) from this many fixed-length sequences up, when whole rounds of the 256 CUs are filled
+// to >= 3/4.  0 = never, the default: bit-identical and 17-30 % slower than the tiled kernel at these shapes (profiles/r07a_panel_gemm_ab.txt)
+mq_knob mq_tower_panel_gemm{getenv("MQ_PANEL_GEMM") ? atoi(getenv("MQ_PANEL_GEMM")) : 0};
+static bool panel_fill_ok(int64_t nseq) {
+    const int64_t rounds = (nseq + 255) / 256;
+    return mq_tower_panel_gemm > 0 && nseq >= mq_tower_panel_gemm && nseq * 4 >= rounds * 256 * 3;
+}
 // bf16 residual stream for the pre-LN bf16 towers (mq_tune("residual_bf16", 1) / MQ_RESIDUAL_BF16=1): x is kept in bf16 between
 // blocks.  The residual GEMMs of a K = 768 tower are memory-bound on their epilogue (out-proj: 15 GFLOP against 39 MB read + 39 MB
 // written of fp32 residual) and every LayerNorm re-reads the stream: bf16 halves those bytes.  Cost: one bf16 rounding per residual
@@ -109,6 +116,18 @@ static int ln_gemm(const void* d_x, int xb, const float* g, const float* b, floa
     }
     MQ_TRY(mq_layernorm_pf(d_x, xb, nullptr, g, b, h, nullptr, rows, K, eps, pf(W), (size_t)N * K * 2, pf(next_w), next_bytes, s));
     return mq_gemm_bf16(h, K, W, K, bias, nullptr, out, N, rows, N, K, flags, s);
+}
+// ln_gemm's folded form for fixed-length image sequences that fill the chip: one workgroup per image (panel_gemm.hip; same output bits).  false = not taken
+static int ln_gemm_panel(bool& taken, const void* d_x, int xb, float eps, void* out, int64_t rows, int64_t nseq, int32_t fixed_len, const int32_t* d_cu_seqlens, int N, int K,
+                         int flags, hipStream_t s, const void* next_w, size_t next_bytes, const void* wf, const float* bf, const float* sf, float* row_stats, bool stats_ready) {
+    taken = false;
+    if (!(row_stats && xb && !d_cu_seqlens && fixed_len > 0 && rows == nseq * fixed_len && panel_fill_ok(nseq) && fold_ok(xb, wf, bf, sf, rows, N, K) &&
+          mq_panel_gemm_ln_ok(nseq, fixed_len, N, K)))
+        return MQ_OK;
+    if (!stats_ready) MQ_TRY(mq_row_stats_pf(d_x, row_stats, rows, K, eps, pf(wf), (size_t)N * K * 2, pf(next_w), next_bytes, s));
+    MQ_TRY(mq_panel_gemm_ln(d_x, wf, bf, sf, row_stats, out, N, nseq, fixed_len, N, K, flags, s));
+    taken = true;
+    return MQ_OK;
 }
 // true when a tower with this encoder config keeps its residual stream in bf16
 static bool stream_bf16(const mq_encoder_cfg* c) {
@@ -445,8 +464,12 @@ int EncoderPass::block_pre_ln(const mq_block_weights& b, int l) {
     // x += out(attn(qkv(ln1(x)))) ; x += fc2(act(fc1(ln2(x))))   (x fp32, or bf16 in the bf16-stream form)
     const int xb = stream_bf16(cfg) ? 1 : 0;
     const int rflags = xb ? (MQ_EPI_BIAS | MQ_EPI_RESIDUAL) : res_flags;
-    MQ_TRY(ln_gemm(d_x, xb, b.ln1_g, b.ln1_b, cfg->ln_eps, h, b.qkv_w, b.qkv_b, qf, rows, 3 * Wa, W, MQ_EPI_BIAS, s, b.out_w, (size_t)W * Wa * 2,
-                   b.qkv_wf, b.qkv_bf, b.qkv_sf, row_stats, x_has_partials));
+    bool panel = false;
+    MQ_TRY(ln_gemm_panel(panel, d_x, xb, cfg->ln_eps, qf, rows, nseq, fixed_len, d_cu_seqlens, 3 * Wa, W, MQ_EPI_BIAS, s, b.out_w, (size_t)W * Wa * 2, b.qkv_wf, b.qkv_bf,
+                         b.qkv_sf, row_stats, x_has_partials));
+    if (!panel)
+        MQ_TRY(ln_gemm(d_x, xb, b.ln1_g, b.ln1_b, cfg->ln_eps, h, b.qkv_w, b.qkv_b, qf, rows, 3 * Wa, W, MQ_EPI_BIAS, s, b.out_w, (size_t)W * Wa * 2,
+                       b.qkv_wf, b.qkv_bf, b.qkv_sf, row_stats, x_has_partials));
     x_has_partials = false;
     // the residual GEMMs leave the rows' partial sums behind whenever the GEMM after them folds its LayerNorm (tiled family, bf16 stream)
     const bool last_pooled = d_sel && nsel > 0 && l == cfg->layers - 1;
@@ -478,8 +501,13 @@ int EncoderPass::block_pre_ln(const mq_block_weights& b, int l) {
     }
     // (the LAST block of a call that reads only pooled rows never folds its MLP: the pooled rows take the small-call kernels — LayerNorm
     // kernel + un-folded weights — and dead-row elimination stays bit-identical to this all-rows form, tests/test_towers_gpu.py)
-    MQ_TRY(ln_gemm(d_x, xb, b.ln2_g, b.ln2_b, cfg->ln_eps, h, b.fc1_w, b.fc1_b, qf, rows, F, W, MQ_EPI_BIAS | act_flag, s, b.fc2_w, (size_t)W * F * 2,
-                   last_pooled ? nullptr : b.fc1_wf, b.fc1_bf, b.fc1_sf, row_stats, fold_mlp));
+    panel = false;
+    if (!last_pooled)
+        MQ_TRY(ln_gemm_panel(panel, d_x, xb, cfg->ln_eps, qf, rows, nseq, fixed_len, d_cu_seqlens, F, W, MQ_EPI_BIAS | act_flag, s, b.fc2_w, (size_t)W * F * 2, b.fc1_wf, b.fc1_bf,
+                             b.fc1_sf, row_stats, fold_mlp));
+    if (!panel)
+        MQ_TRY(ln_gemm(d_x, xb, b.ln2_g, b.ln2_b, cfg->ln_eps, h, b.fc1_w, b.fc1_b, qf, rows, F, W, MQ_EPI_BIAS | act_flag, s, b.fc2_w, (size_t)W * F * 2,
+                       last_pooled ? nullptr : b.fc1_wf, b.fc1_bf, b.fc1_sf, row_stats, fold_mlp));
     // fc2 writes the x the NEXT block's QKV normalises
     const mq_block_weights* nbk = l + 1 < cfg->layers && l + 1 < first8 ? &blocks[l + 1] : nullptr;
     const bool fold_next = mq_tower_ln_fold >= 2 && nbk && fold_ok(xb, nbk->qkv_wf, nbk->qkv_bf, nbk->qkv_sf, rows, 3 * Wa, W) && !mq_gemm_small_ok(rows, W, F, false) &&
