@@ -428,6 +428,10 @@ def gemm_roofline(lib, L, run_local, prof_steps, precision, workload_name):
         "launches_per_step": gemm_launches // max(prof_steps, 1),
         "per_family": families,
     }
+    # (ViT-B/32-shaped blocks at chip-filling batches run attention + out-projection + residual + statistics as ONE launch, csrc/attn_proj.hip: that launch's
+    # time and count sit in the `attention` family, its out-projection FLOPs — 15.1 GF per block at the headline — in neither `achieved` nor its divisor)
+    roofline["note"] = ("`achieved` = the tiled GEMM launches' own FLOPs / their own time; where a block takes mq_attention_proj (attention + out-projection + residual + "
+                        "LayerNorm statistics in one launch) its out-projection is timed in per_family.attention")
     if precision == "bf16":
         # what a register-resident v_mfma_f32_16x16x32_bf16 burn sustains on THIS chip, in THIS run, at the clock it holds under full MFMA load
         # (csrc/probe.hip; boxes of the pool hold 1.86-2.03 GHz): `peak` / `frac` stay priced against the guide's 2.4 GHz dense figure,
