@@ -513,7 +513,7 @@ int mq_attention_proj(const void* d_qkv, const void* d_w, const float* d_bias, v
  * and the weight streams through per-wave rings in passes of 768 output columns.  Operands as mq_gemm_bf16_ln (d_W / d_bias / d_colsum folded, d_rowstats =
  * (mean, rstd) per row), K = 768, N a multiple of 768, rows = nseq * fixed_len; flags MQ_EPI_BIAS [| MQ_EPI_GELU | MQ_EPI_QUICKGELU]; d_out bf16 [rows, ldc].
  * Output bits = mq_gemm_bf16_ln's (same k order, same epilogue order).  Measured 17-30 % slower than the tiled kernel at the tower's shapes (3.5 / 4.7 MB of
- * weight per CU and image; profiles/r07a_panel_gemm_ab.txt): an opt-in — mq_encoder_forward takes it only under mq_tune("panel_gemm", n) / MQ_PANEL_GEMM=n,
+ * weight per CU and image; profiles/r06za_panel_gemm_ab.txt): an opt-in — mq_encoder_forward takes it only under mq_tune("panel_gemm", n) / MQ_PANEL_GEMM=n,
  * from n sequences up when they fill the chip's 256 CUs in whole rounds to >= 3/4 (default 0 = never). */
 int mq_panel_gemm_ln_ok(int64_t nseq, int32_t fixed_len, int64_t N, int64_t K);
 int mq_panel_gemm_ln(const void* d_x, const void* d_W, const float* d_bias, const float* d_colsum, const float* d_rowstats, void* d_out, int64_t ldc,

@@ -15,7 +15,7 @@
 // around it.  The price: 64-row tiles for 50 tokens (78 % useful), every CU streams the whole weight.  The k order (k-steps of 64, two 32-deep halves) and
 // the epilogue's operation order are the tiled kernel's: bit-identical output (tests/test_panel_gemm_gpu.py).
 //
-// MEASURED, AND NOT THE DEFAULT (profiles/r07a_panel_gemm_ab.txt): correct and bit-identical, and 17-30 % SLOWER than the tiled kernel at these shapes
+// MEASURED, AND NOT THE DEFAULT (profiles/r06za_panel_gemm_ab.txt): correct and bit-identical, and 17-30 % SLOWER than the tiled kernel at these shapes
 // (256 images: QKV 62.5 vs 53.2 us, fc1 83.0 vs 70.9 us; headline -6 %).  Where the form wins — attn_proj.hip's out-projection — the weight is 1.2 MB and
 // lives in every XCD's L2; here 3.5 / 4.7 MB stream per CU with 48 KB in flight (the ring is what the 96 KB panel leaves of the LDS), 15-16 us per 768-column
 // pass against 13 us there, and even with the epilogue switched off (53 us) the QKV GEMM only ties the tiled kernel.  mq_tune("panel_gemm", n) / MQ_PANEL_GEMM=n

@@ -49,8 +49,13 @@ mq_knob mq_tower_subln_fold{getenv("MQ_SUBLN_FOLD") ? atoi(getenv("MQ_SUBLN_FOLD
 // per image: below ~half the chip's 256 CUs the three launches it replaces win (measured, profiles/r06x_attn_proj_batch_ab.txt: +3.4 % at 256 images,
 // +2 % at 128, -1 % at 96, -4.5 % at 64)
 mq_knob mq_tower_attn_proj{getenv("MQ_ATTN_PROJ") ? atoi(getenv("MQ_ATTN_PROJ")) : 128};
+// (one workgroup per image: a second round of the 256 CUs has to be filled to 3/4 — 300 images would run 44 workgroups behind 256 — or the launches win)
+static bool attn_proj_fill_ok(int64_t nseq) {
+    const int64_t rounds = (nseq + 255) / 256;
+    return mq_tower_attn_proj > 0 && nseq >= mq_tower_attn_proj && (rounds == 1 || nseq * 4 >= rounds * 256 * 3);
+}
 // the folded QKV / fc1 GEMMs one workgroup per image (panel_gemm.hip) from this many fixed-length sequences up, when whole rounds of the 256 CUs are filled
-// to >= 3/4.  0 = never, the default: bit-identical and 17-30 % slower than the tiled kernel at these shapes (profiles/r07a_panel_gemm_ab.txt)
+// to >= 3/4.  0 = never, the default: bit-identical and 17-30 % slower than the tiled kernel at these shapes (profiles/r06za_panel_gemm_ab.txt)
 mq_knob mq_tower_panel_gemm{getenv("MQ_PANEL_GEMM") ? atoi(getenv("MQ_PANEL_GEMM")) : 0};
 static bool panel_fill_ok(int64_t nseq) {
     const int64_t rounds = (nseq + 255) / 256;
@@ -479,7 +484,7 @@ int EncoderPass::block_pre_ln(const mq_block_weights& b, int l) {
     // short fixed-length image sequences (ViT-B/32: 50 tokens): attention, out-projection, residual and the statistics of norm2 in ONE launch, one workgroup
     // per image (attn_proj.hip) — the rows of x carry the same bits as the three launches below leave
     if (mq_tower_attn_proj && fold_mlp && xb && !d_cu_seqlens && fixed_len > 0 && rows == nseq * fixed_len && Wa == W && cfg->mask == MQ_MASK_NONE && !cfg->d_rel_bias &&
-        nseq >= mq_tower_attn_proj && mq_attention_proj_ok(nseq, fixed_len, W, cfg->heads)) {
+        attn_proj_fill_ok(nseq) && mq_attention_proj_ok(nseq, fixed_len, W, cfg->heads)) {
         MQ_TRY(mq_attention_proj(qf, b.out_w, b.out_b, d_x, row_stats, nseq, fixed_len, W, cfg->heads, cfg->ln_eps, pf(b.fc1_wf), (size_t)F * W * 2, pf(b.fc2_w), (size_t)W * F * 2, s));
     } else {
     MQ_TRY(attn_bf16(cfg, qf, a, d_cu_seqlens, nseq, fixed_len, max_len, Wa, s));

@@ -76,7 +76,7 @@ def test_repeatable_and_refusals():
 
 def test_vit_b32_tower_under_the_knob_has_the_same_bits():
     """200 images under mq_tune("panel_gemm", 192) (one round of the 256 CUs filled to 78 %) run the QKV / fc1 GEMMs one workgroup per image; the same images
-    without the knob (the default: the form is slower, profiles/r07a) run the tiled kernels: the same embeddings, bit for bit"""
+    without the knob (the default: the form is slower, profiles/r06za) run the tiled kernels: the same embeddings, bit for bit"""
     from marqo_amd.engine import archs, towers
     from oracle import towers as O
     lib = L.load()
