@@ -28,7 +28,7 @@ STAGE_SRC = CSRC_DIR / "py_stage.cpp"
 STAGE_PATH = LIB_DIR / "_mq_stage.so"                # CPython extension: a batch of Pillow images -> the pinned staging buffer in one call
 
 MQ_OK = 0
-NO_SCRATCH_UNITS = ("rowops", "gemm_bf16", "gemm_wd", "gemm_fp8", "gemm_small", "attention", "embed")  # build() refuses register spills in these
+NO_SCRATCH_UNITS = ("rowops", "gemm_bf16", "gemm_wd", "gemm_fp8", "gemm_small", "attention", "attn_proj", "panel_gemm", "embed")  # build() refuses register spills in these
 ABI_VERSION = 13
 MQ_PREC_BF16, MQ_PREC_FP8 = 0, 1
 MQ_ACT_GELU, MQ_ACT_QUICKGELU, MQ_ACT_SILU = 1, 2, 3
