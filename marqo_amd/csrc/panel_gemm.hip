@@ -157,11 +157,13 @@ __global__ __launch_bounds__(512, 1) void panel_gemm_kernel(const bf16_t* __rest
         }
         // (the first fragments of the next pass's first unit are in flight: retire them here — the compiler takes an asm's outputs as valid once the statement
         // has executed and may move them while the epilogue runs)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // (the wait carries the epilogue's column base as an operand: whatever the epilogue computes — its addresses first of all — depends on n0 and so cannot be
+        // hoisted above the wait into registers an LDS read may still be writing; tests/test_attn_proj_isa.py walks the ISA for exactly that)
+        int n0 = pass * W + wave * WC;
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(n0)::"memory");
         landed(wf[0][0]); landed(wf[0][1]); landed(wf[1][0]); landed(wf[1][1]);
         // ---- the pass's epilogue (gemm_epilogue.h's LN_APPLY order: rstd * (acc - mean * colsum), + bias, activation, round, 16-byte stores); the next
         // pass's first fragments stay in flight / in registers across it
-        const int n0 = pass * W + wave * WC;
         f32x4 bias_v[3][2], cs_v[3][2];
 #pragma unroll
         for (int a = 0; a < 3; ++a)
