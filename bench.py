@@ -560,8 +560,69 @@ def e2e_vectorise(dev, images_cpu_u8, tower_only_rate, reps=21):
     out["headline_e2e"] = {"form": "ndarray_from_pil", "value": out["ndarray_from_pil"], "over_tower_only": round(out["ndarray_from_pil"] / tower_only_rate, 3),
                            "note": "a single synchronous caller: the call runs in two 128-image stages (host pack of 2 x 25 MB of Pillow RGBX, H2D of 64-image slices under it; "
                                    "the stages' towers on two HIP streams, enqueued by a helper thread) + D2H (profiles/r05w_e2e_stages.txt; host-side: +-5 % between runs)"}
+    try:
+        out["small_text_calls"] = small_text_calls(s2, name, props, dev)
+    except Exception as e:  # noqa: BLE001
+        out["small_text_calls"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     s2.clear_loaded_models()
     return out
+
+
+def small_text_calls(s2, name, props, dev, threads=16, calls=60):
+    """the reference's serving load on the text side: 8 indexing + 8 search request threads (api/configs.py:27-28), each calling vectorise() with ONE
+    query (search) or 4 texts (the chunks of a document field) at a time — merged across threads by the tower's native request queue (mq_queue_*,
+    csrc/queue.hip); requests/s, embeddings/s and the median call latency a request thread sees, beside one thread calling alone"""
+    from marqo_amd.engine import native_queue as NQ
+    from marqo_amd.s2_inference.enums import AvailableModelsKey, Modality
+    kw = dict(device=dev, modality=Modality.TEXT, model_properties=props)
+    words = ["alpha", "beta", "gamma", "delta", "marqo", "tensor", "search", "image", "text", "vector"]
+    rng = np.random.default_rng(0)
+    s2.vectorise_ndarray(name, ["warm"], **kw)
+    res = {"model": name, "threads": threads, "calls_per_thread": calls, "native_queue": bool(NQ.ENABLED), "queue_depth": NQ.DEPTH, "queue_max_seqs": NQ.MAX_SEQS}
+    for items in (1, 4):
+        content = {(t, c): [" ".join(words[int(j)] for j in rng.integers(0, 10, 12)) + f" {t} {c} {i}" for i in range(items)]
+                   for t in range(threads) for c in range(calls)}
+        lat, errors = [], []
+        start = threading.Barrier(threads + 1)
+
+        def worker(t):
+            try:
+                s2.vectorise_ndarray(name, content[(t, 0)], **kw)
+                start.wait()
+                for c in range(calls):
+                    t0 = time.perf_counter()
+                    s2.vectorise_ndarray(name, content[(t, c)], **kw)
+                    lat.append(time.perf_counter() - t0)
+            except BaseException as e:  # noqa: BLE001
+                errors.append(e)
+                start.abort()
+        ts = [threading.Thread(target=worker, args=(t,)) for t in range(threads)]
+        for t in ts:
+            t.start()
+        try:
+            start.wait()
+        except threading.BrokenBarrierError:
+            pass
+        t0 = time.perf_counter()
+        for t in ts:
+            t.join()
+        dt = time.perf_counter() - t0
+        if errors:
+            raise errors[0]
+        lat.sort()
+        t0 = time.perf_counter()
+        for c in range(calls):
+            s2.vectorise_ndarray(name, content[(0, c)], **kw)
+        alone = (time.perf_counter() - t0) / calls
+        res[f"{items}_per_call"] = {"requests_per_s": round(threads * calls / dt, 1), "embeddings_per_s": round(threads * calls * items / dt, 1),
+                                    "latency_p50_ms": round(lat[len(lat) // 2] * 1e3, 3), "latency_p95_ms": round(lat[int(len(lat) * 0.95)] * 1e3, 3),
+                                    "one_thread_ms_per_call": round(alone * 1e3, 3), "one_thread_embeddings_per_s": round(items / alone, 1)}
+    model = s2.get_available_models()[s2._create_model_cache_key(name, dev, props)][AvailableModelsKey.model]
+    st = getattr(model.text, "queue_stats", lambda: {})().get(True)
+    if st:
+        res["queue"] = {"requests": st["requests"], "tower_calls": st["calls"], "sequences_per_call": round(st["sequences"] / max(st["calls"], 1), 2),
+                        "largest_call": st["max_call_sequences"], "failed_calls": st["failed_calls"]}
+    return res
 
 
 # ---- BASELINE configs[3] in miniature ------------------------------------------------------------------------------------------------

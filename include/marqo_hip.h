@@ -21,7 +21,8 @@
  *
  * Conventions
  *   - every pointer named d_* is a DEVICE pointer (HBM) owned by the caller (the Python
- *     host allocates through PyTorch-ROCm; the library never allocates device memory);
+ *     host allocates through PyTorch-ROCm; the library never allocates device memory —
+ *     the one exception is mq_queue_create, ABI 14, which sizes its own staging once);
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); every entry
  *     point only ENQUEUES work on it and returns; results are valid after the caller
  *     synchronises that stream;
@@ -46,7 +47,7 @@ extern "C" {
 #define MQ_ERR_WORKSPACE (-3) /* caller's workspace too small */
 #define MQ_ERR_UNSUPPORTED (-4) /* ABI 11: the device is not the one this library is built for (mq_check_device) */
 
-#define MQ_ABI_VERSION 13
+#define MQ_ABI_VERSION 14
 
 /* ---- activation / mask / pooling selectors ---------------------------------------- */
 #define MQ_ACT_NONE 0
@@ -665,6 +666,53 @@ int mq_pack_ids(const int32_t* d_padded, int64_t ld, const int32_t* d_cu_seqlens
 int mq_weighted_combine(const float* d_emb, int64_t ld, const int32_t* d_rows, const float* d_weights,
                         const int32_t* d_cu_terms, int64_t n_groups, int32_t D, int32_t mode, float* d_out,
                         void* stream);
+
+/* ---- native request queue: cross-request batching of small text calls (ABI 14) -------------------------------------------------------------------
+ * The reference runs up to 8 indexing + 8 search request threads (src/marqo/api/configs.py:27-28), each calling vectorise() with one query
+ * (src/marqo/tensor_search/tensor_search.py, the query vectorisation) or the few chunks of one document field
+ * (src/marqo/core/inference/tensor_fields_container.py:179-223).  A queue merges what concurrent callers hand over into ONE
+ * mq_encode_clip_text / mq_encode_bert call per group on worker threads of its own — no interpreter lock anywhere between a caller's hand-over and
+ * its wake-up (the Python-level coalescer, marqo_amd/s2_inference/coalesce.py, pays that lock on every hand-off; csrc/queue.hip).
+ *   - a request = nseq sequences, PACKED host token ids (h_ids int32 [sum of h_lens], sequence s at its running offset) + h_lens int32 [nseq];
+ *     mq_queue_encode blocks until the request's rows are in h_out (fp32 [nseq, out_dim]); any number of threads may call it on one queue;
+ *   - "natural" batching: a lone caller's request runs at once; requests that arrive while a merged call executes form the next group (up to
+ *     max_seqs sequences / max_rows token rows per tower call).  depth = worker threads = merged calls in flight (each with its own HIP stream, device
+ *     scratch and pinned staging, all allocated in mq_queue_create and nowhere else); window_us = how long a group that is not full is held back for
+ *     company WHILE another merged call is executing (0 = never);
+ *   - tower_cfg / tower_weights: mq_clip_text_cfg + mq_clip_text_weights (MQ_QUEUE_CLIP_TEXT) or mq_bert_cfg + mq_bert_weights (MQ_QUEUE_BERT); the queue
+ *     keeps the POINTERS (a tower whose policy fields change after load — fp8 calibration, residual stream — is seen as it is at each call): both
+ *     structs and everything they point to must outlive the queue;
+ *   - a request is validated on its caller's thread (lengths within the tower's context, ids inside the embedding table): a bad request fails alone,
+ *     before it can join a group.  If a merged call itself fails every request of that group gets its status and text;
+ *   - embeddings are those of the merged call: rows of a batch are independent in these towers, so a request's rows do not depend on its company
+ *     as long as lone and merged call take the same kernel family (the small-row families end at 320 token rows). */
+#define MQ_QUEUE_CLIP_TEXT 0
+#define MQ_QUEUE_BERT 1
+typedef struct mq_queue mq_queue;   /* opaque */
+typedef struct mq_queue_cfg {
+    int32_t kind;        /* MQ_QUEUE_* */
+    int32_t device;      /* HIP device ordinal the tower's weights live on */
+    int32_t max_seqs;    /* sequences per merged tower call (and per request) */
+    int32_t max_rows;    /* token rows per merged tower call (and per request): >= the tower's context length */
+    int32_t normalize;   /* != 0: L2-normalised rows */
+    int32_t depth;       /* worker threads = merged calls in flight: 1..4 (2: one call's host part runs under the other's GPU part) */
+    int32_t window_us;   /* see above; 0 = a group never waits */
+    int32_t reserved;
+} mq_queue_cfg;
+typedef struct mq_queue_stats {
+    uint64_t requests;            /* served (mq_queue_encode calls that reached a worker) */
+    uint64_t calls;               /* tower calls */
+    uint64_t merged_calls;        /* ... of more than one request */
+    uint64_t failed_calls;
+    uint64_t sequences, rows;     /* totals over all calls */
+    uint64_t max_call_sequences;  /* the largest group so far */
+} mq_queue_stats;
+int mq_queue_create(const mq_queue_cfg* cfg, const void* tower_cfg, const void* tower_weights, mq_queue** out);
+int mq_queue_encode(mq_queue* q, const int32_t* h_ids, const int32_t* h_lens, int64_t nseq, float* h_out);
+int mq_queue_get_stats(mq_queue* q, mq_queue_stats* out);
+/* serves what is still pending, joins the workers, frees the staging; no mq_queue_encode may be entered after this starts */
+int mq_queue_destroy(mq_queue* q);
+
 
 /* Run-time selection of a kernel variant (benchmark A/B and parity tests of every variant in one process).  TEST / BENCH ONLY: the
  * knobs are relaxed atomics (csrc/common.h, mq_knob) that the launch code of every request thread reads — a new value takes effect from

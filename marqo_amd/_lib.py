@@ -29,7 +29,7 @@ STAGE_PATH = LIB_DIR / "_mq_stage.so"                # CPython extension: a batc
 
 MQ_OK = 0
 NO_SCRATCH_UNITS = ("rowops", "gemm_bf16", "gemm_wd", "gemm_fp8", "gemm_small", "attention", "attn_proj", "panel_gemm", "embed")  # build() refuses register spills in these
-ABI_VERSION = 13
+ABI_VERSION = 14
 MQ_PREC_BF16, MQ_PREC_FP8 = 0, 1
 MQ_ACT_GELU, MQ_ACT_QUICKGELU, MQ_ACT_SILU = 1, 2, 3
 MQ_MASK_NONE, MQ_MASK_CAUSAL, MQ_MASK_CAUSAL_CLS = 0, 1, 2
@@ -129,6 +129,19 @@ class SentencePieceVocab(C.Structure):
                 ("pad_id", C.c_int32), ("id_offset", C.c_int32), ("unk_out", C.c_int32)]
 
 
+class QueueCfg(C.Structure):
+    """mq_queue_cfg (ABI 14): the native request queue of a text tower (csrc/queue.hip)"""
+    _fields_ = [("kind", C.c_int32), ("device", C.c_int32), ("max_seqs", C.c_int32), ("max_rows", C.c_int32), ("normalize", C.c_int32),
+                ("depth", C.c_int32), ("window_us", C.c_int32), ("reserved", C.c_int32)]
+
+
+class QueueStats(C.Structure):
+    _fields_ = [("requests", C.c_uint64), ("calls", C.c_uint64), ("merged_calls", C.c_uint64), ("failed_calls", C.c_uint64),
+                ("sequences", C.c_uint64), ("rows", C.c_uint64), ("max_call_sequences", C.c_uint64)]
+
+
+QUEUE_CLIP_TEXT, QUEUE_BERT = 0, 1
+
 _P = C.c_void_p
 _SIGNATURES = {
     # name: (restype, argtypes)
@@ -207,6 +220,10 @@ _SIGNATURES = {
                                             C.c_size_t, _P]),
     "mq_pack_ids": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P]),
     "mq_weighted_combine": (C.c_int, [_P, C.c_int64, _P, _P, _P, C.c_int64, C.c_int32, C.c_int32, _P, _P]),
+    "mq_queue_create": (C.c_int, [C.POINTER(QueueCfg), _P, _P, C.POINTER(_P)]),
+    "mq_queue_encode": (C.c_int, [_P, _P, _P, C.c_int64, _P]),
+    "mq_queue_get_stats": (C.c_int, [_P, C.POINTER(QueueStats)]),
+    "mq_queue_destroy": (C.c_int, [_P]),
     "mq_tune": (C.c_int, [C.c_char_p, C.c_int]),
     "mq_profile_enable": (C.c_int, [C.c_int]),
     "mq_profile_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),

@@ -1,0 +1,298 @@
+// Native cross-request batching of small text calls (ABI 14): mq_queue_* — host code only, no kernels of its own.
+//
+// What it stands in for: the reference serves up to 8 indexing + 8 search request threads at once (/root/reference/src/marqo/api/configs.py:27-28), each
+// calling s2_inference.vectorise() with a handful of texts (a search query: ONE — src/marqo/tensor_search/tensor_search.py's query vectorisation; a
+// PER_DOCUMENT add_documents: the chunks of one field — src/marqo/core/inference/tensor_fields_container.py:179-223).  Run one by one a tower pass of 1-4
+// sequences keeps a few CUs busy; merged, 16 callers' sequences cost about what one caller's do.  marqo_amd/s2_inference/coalesce.py does that merge in Python:
+// its leader / follower hand-offs, the tokenised-batch assembly and the torch calls of the merged launch all run under the interpreter lock, which the
+// measured merged call pays for (0.92 ms alone, 2.05 ms with 15 other request threads in the interpreter: profiles/r03o_coalesce_profile.txt).  Here the
+// merge, the staging and the ~100 launches of the tower pass run on worker threads that never touch the interpreter: a caller blocks inside ONE foreign call
+// (ctypes / cgo / JNI release their runtime's lock around it) and wakes up with its rows in its own buffer.
+//
+// Batching is "natural": a worker that finds requests waiting takes as many as fit one tower call (max_seqs sequences / max_rows token rows) and runs them
+// as ONE mq_encode_clip_text / mq_encode_bert on its own stream; whatever arrives meanwhile waits for the next free worker, i.e. groups grow with the load
+// and a lone caller is never delayed.  `depth` workers (1 or 2, each with its own stream, device scratch and pinned staging) keep one merged call's host
+// part (pack, H2D, enqueue) under the GPU part of the call before it.  While another call is executing, a worker holds a small group back for up to
+// window_us so that requests a few microseconds apart share a launch.
+// Rows of a batch are independent in these towers (per-row normalisation, no cross-sequence reduction): a request's embeddings are those of the merged call,
+// bit-identical to a lone call of the same kernel family (the small-row families take over at <= 320 rows: DESIGN.md section 3, Numerics).
+#include <chrono>
+#include <condition_variable>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+struct QRequest {
+    const int32_t* ids;
+    const int32_t* lens;
+    int64_t nseq, rows;
+    float* out;
+    int status = MQ_OK;
+    bool done = false;
+    std::string err;
+    std::chrono::steady_clock::time_point t_in;
+};
+
+struct QLane {            // one worker: everything a merged call touches is its own
+    hipStream_t stream = nullptr;
+    int32_t *d_ids = nullptr, *d_cu = nullptr;
+    float* d_out = nullptr;
+    void* d_ws = nullptr;
+    size_t ws_bytes = 0;
+    int32_t *h_ids = nullptr, *h_cu = nullptr;   // pinned
+    float* h_out = nullptr;                      // pinned
+    std::thread th;
+};
+
+}  // namespace
+
+struct mq_queue {
+    mq_queue_cfg cfg;
+    const void* tower_cfg;
+    const void* tower_w;
+    int32_t max_len = 0, vocab = 0, out_dim = 0;
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    std::deque<QRequest*> pending;
+    int64_t pending_seqs = 0;
+    int busy = 0;
+    bool stop = false;
+    std::vector<QLane> lanes;
+    mq_queue_stats st{};
+};
+
+namespace {
+
+void lane_free(QLane& ln) {
+    if (ln.stream) (void)hipStreamDestroy(ln.stream);
+    if (ln.d_ids) (void)hipFree(ln.d_ids);
+    if (ln.d_cu) (void)hipFree(ln.d_cu);
+    if (ln.d_out) (void)hipFree(ln.d_out);
+    if (ln.d_ws) (void)hipFree(ln.d_ws);
+    if (ln.h_ids) (void)hipHostFree(ln.h_ids);
+    if (ln.h_cu) (void)hipHostFree(ln.h_cu);
+    if (ln.h_out) (void)hipHostFree(ln.h_out);
+    ln = QLane{};
+}
+
+int lane_alloc(mq_queue* q, QLane& ln) {
+    const size_t rows = (size_t)q->cfg.max_rows, seqs = (size_t)q->cfg.max_seqs, D = (size_t)q->out_dim;
+    ln.ws_bytes = q->cfg.kind == MQ_QUEUE_CLIP_TEXT ? mq_clip_text_workspace_bytes((const mq_clip_text_cfg*)q->tower_cfg, (int64_t)rows, (int64_t)seqs)
+                                                    : mq_bert_workspace_bytes((const mq_bert_cfg*)q->tower_cfg, (int64_t)rows, (int64_t)seqs);
+    MQ_CHECK_ARG(ln.ws_bytes > 0, "mq_queue_create: the tower reports no workspace for %zu rows / %zu sequences (bad tower cfg?)", rows, seqs);
+    ln.ws_bytes += 256;
+    MQ_CHECK_HIP(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
+    MQ_CHECK_HIP(hipMalloc((void**)&ln.d_ids, rows * 4));
+    MQ_CHECK_HIP(hipMalloc((void**)&ln.d_cu, (seqs + 1) * 4));
+    MQ_CHECK_HIP(hipMalloc((void**)&ln.d_out, seqs * D * 4));
+    MQ_CHECK_HIP(hipMalloc(&ln.d_ws, ln.ws_bytes));
+    MQ_CHECK_HIP(hipHostMalloc((void**)&ln.h_ids, rows * 4, hipHostMallocDefault));
+    MQ_CHECK_HIP(hipHostMalloc((void**)&ln.h_cu, (seqs + 1) * 4, hipHostMallocDefault));
+    MQ_CHECK_HIP(hipHostMalloc((void**)&ln.h_out, seqs * D * 4, hipHostMallocDefault));
+    return MQ_OK;
+}
+
+// one merged tower call for `group` on the lane's stream; every request's rows are in its own buffer when this returns MQ_OK
+int lane_execute(mq_queue* q, QLane& ln, const std::vector<QRequest*>& group) {
+    int64_t nseq = 0, rows = 0;
+    ln.h_cu[0] = 0;
+    for (const QRequest* r : group) {
+        for (int64_t s = 0; s < r->nseq; ++s, ++nseq) ln.h_cu[nseq + 1] = ln.h_cu[nseq] + r->lens[s];
+        std::memcpy(ln.h_ids + rows, r->ids, (size_t)r->rows * 4);
+        rows += r->rows;
+    }
+    const size_t D = (size_t)q->out_dim;
+    MQ_CHECK_HIP(hipMemcpyAsync(ln.d_ids, ln.h_ids, (size_t)rows * 4, hipMemcpyHostToDevice, ln.stream));
+    MQ_CHECK_HIP(hipMemcpyAsync(ln.d_cu, ln.h_cu, (size_t)(nseq + 1) * 4, hipMemcpyHostToDevice, ln.stream));
+    if (q->cfg.kind == MQ_QUEUE_CLIP_TEXT)
+        MQ_TRY(mq_encode_clip_text((const mq_clip_text_cfg*)q->tower_cfg, (const mq_clip_text_weights*)q->tower_w, ln.d_ids, ln.d_cu, ln.h_cu, nseq, nullptr,
+                                   ln.d_out, q->cfg.normalize, ln.d_ws, ln.ws_bytes, ln.stream));
+    else
+        MQ_TRY(mq_encode_bert((const mq_bert_cfg*)q->tower_cfg, (const mq_bert_weights*)q->tower_w, ln.d_ids, ln.d_cu, ln.h_cu, nseq, ln.d_out,
+                              q->cfg.normalize, ln.d_ws, ln.ws_bytes, ln.stream));
+    MQ_CHECK_HIP(hipMemcpyAsync(ln.h_out, ln.d_out, (size_t)nseq * D * 4, hipMemcpyDeviceToHost, ln.stream));
+    MQ_CHECK_HIP(hipStreamSynchronize(ln.stream));
+    size_t off = 0;
+    for (QRequest* r : group) {
+        std::memcpy(r->out, ln.h_out + off * D, (size_t)r->nseq * D * 4);
+        off += (size_t)r->nseq;
+    }
+    return MQ_OK;
+}
+
+void lane_run(mq_queue* q, int lane_idx) {
+    QLane& ln = q->lanes[(size_t)lane_idx];
+    (void)hipSetDevice(q->cfg.device);
+    std::vector<QRequest*> group;
+    const auto window = std::chrono::microseconds(q->cfg.window_us);
+    for (;;) {
+        group.clear();
+        {
+            std::unique_lock<std::mutex> lk(q->mu);
+            q->cv_work.wait(lk, [&] { return q->stop || !q->pending.empty(); });
+            if (q->pending.empty()) return;   // stop, and nothing left to serve
+            // company: while another merged call is executing (the GPU is busy anyway) a group that is not full waits until its oldest request is
+            // window_us old; arrivals and the other lane's completion wake it
+            if (q->cfg.window_us > 0) {
+                while (!q->stop && q->busy > 0 && !q->pending.empty() && q->pending_seqs < q->cfg.max_seqs) {
+                    const auto deadline = q->pending.front()->t_in + window;
+                    if (std::chrono::steady_clock::now() >= deadline) break;
+                    q->cv_work.wait_until(lk, deadline);
+                }
+                if (q->pending.empty()) continue;   // the other lane took them
+            }
+            int64_t seqs = 0, rows = 0;
+            while (!q->pending.empty()) {
+                QRequest* r = q->pending.front();
+                if (!group.empty() && (seqs + r->nseq > q->cfg.max_seqs || rows + r->rows > q->cfg.max_rows)) break;
+                group.push_back(r);
+                seqs += r->nseq;
+                rows += r->rows;
+                q->pending.pop_front();
+            }
+            q->pending_seqs -= seqs;
+            ++q->busy;
+            ++q->st.calls;
+            q->st.requests += (uint64_t)group.size();
+            q->st.sequences += (uint64_t)seqs;
+            q->st.rows += (uint64_t)rows;
+            if ((uint64_t)seqs > q->st.max_call_sequences) q->st.max_call_sequences = (uint64_t)seqs;
+            if (group.size() > 1) ++q->st.merged_calls;
+        }
+        const int rc = lane_execute(q, ln, group);
+        std::string err = rc == MQ_OK ? std::string() : std::string(mq_last_error());
+        if (rc != MQ_OK) (void)hipStreamSynchronize(ln.stream);   // nothing of a failed call may still be writing when the buffers are reused
+        {
+            std::lock_guard<std::mutex> lk(q->mu);
+            for (QRequest* r : group) {
+                r->status = rc;
+                r->err = err;
+                r->done = true;
+            }
+            --q->busy;
+            if (rc != MQ_OK) ++q->st.failed_calls;
+        }
+        q->cv_done.notify_all();
+        q->cv_work.notify_all();    // a lane holding a group back for company: the GPU is free now
+    }
+}
+
+}  // namespace
+
+extern "C" int mq_queue_create(const mq_queue_cfg* cfg, const void* tower_cfg, const void* tower_weights, mq_queue** out) {
+    MQ_CHECK_ARG(cfg && tower_cfg && tower_weights && out, "mq_queue_create: null pointer");
+    *out = nullptr;
+    MQ_CHECK_ARG(cfg->kind == MQ_QUEUE_CLIP_TEXT || cfg->kind == MQ_QUEUE_BERT, "mq_queue_create: kind %d is neither MQ_QUEUE_CLIP_TEXT nor MQ_QUEUE_BERT", cfg->kind);
+    MQ_CHECK_ARG(cfg->max_seqs >= 1 && cfg->max_seqs <= 4096, "mq_queue_create: max_seqs %d outside [1, 4096]", cfg->max_seqs);
+    MQ_CHECK_ARG(cfg->depth >= 1 && cfg->depth <= 4, "mq_queue_create: depth %d outside [1, 4]", cfg->depth);
+    MQ_CHECK_ARG(cfg->window_us >= 0 && cfg->window_us <= 100000, "mq_queue_create: window_us %d outside [0, 100000]", cfg->window_us);
+    int32_t max_len, vocab, out_dim;
+    if (cfg->kind == MQ_QUEUE_CLIP_TEXT) {
+        const mq_clip_text_cfg* t = (const mq_clip_text_cfg*)tower_cfg;
+        max_len = t->ctx + (t->cls_pos > 0 ? 1 : 0);
+        vocab = t->vocab;
+        out_dim = t->out_dim;
+    } else {
+        const mq_bert_cfg* t = (const mq_bert_cfg*)tower_cfg;
+        max_len = t->max_pos;
+        vocab = t->vocab;
+        out_dim = t->out_dim > 0 ? t->out_dim : t->enc.width;
+    }
+    MQ_CHECK_ARG(max_len >= 1 && vocab >= 1 && out_dim >= 1, "mq_queue_create: tower cfg without context length / vocabulary / output width");
+    MQ_CHECK_ARG(cfg->max_rows >= max_len && (int64_t)cfg->max_rows <= (int64_t)cfg->max_seqs * max_len,
+                 "mq_queue_create: max_rows %d outside [longest sequence = %d, max_seqs * that = %ld]", cfg->max_rows, max_len, (long)cfg->max_seqs * max_len);
+    int ndev = 0;
+    MQ_CHECK_HIP(hipGetDeviceCount(&ndev));
+    MQ_CHECK_ARG(cfg->device >= 0 && cfg->device < ndev, "mq_queue_create: device %d of %d", cfg->device, ndev);
+    MQ_TRY(mq_check_device(cfg->device));
+    int prev = 0;
+    MQ_CHECK_HIP(hipGetDevice(&prev));
+    MQ_CHECK_HIP(hipSetDevice(cfg->device));
+    mq_queue* q = new mq_queue();
+    q->cfg = *cfg;
+    q->tower_cfg = tower_cfg;
+    q->tower_w = tower_weights;
+    q->max_len = max_len;
+    q->vocab = vocab;
+    q->out_dim = out_dim;
+    q->lanes.resize((size_t)cfg->depth);
+    int rc = MQ_OK;
+    for (QLane& ln : q->lanes)
+        if ((rc = lane_alloc(q, ln)) != MQ_OK) break;
+    (void)hipSetDevice(prev);
+    if (rc != MQ_OK) {
+        for (QLane& ln : q->lanes) lane_free(ln);
+        delete q;
+        return rc;
+    }
+    for (int i = 0; i < cfg->depth; ++i) q->lanes[(size_t)i].th = std::thread(lane_run, q, i);
+    *out = q;
+    return MQ_OK;
+}
+
+extern "C" int mq_queue_encode(mq_queue* q, const int32_t* h_ids, const int32_t* h_lens, int64_t nseq, float* h_out) {
+    MQ_CHECK_ARG(q, "mq_queue_encode: null queue");
+    if (nseq == 0) return MQ_OK;
+    MQ_CHECK_ARG(h_ids && h_lens && h_out, "mq_queue_encode: null buffer");
+    MQ_CHECK_ARG(nseq > 0 && nseq <= q->cfg.max_seqs, "mq_queue_encode: %ld sequences, the queue takes 1..%d per request", (long)nseq, q->cfg.max_seqs);
+    int64_t rows = 0;
+    for (int64_t s = 0; s < nseq; ++s) {
+        MQ_CHECK_ARG(h_lens[s] >= 1 && h_lens[s] <= q->max_len, "mq_queue_encode: sequence %ld has %d tokens, the tower takes 1..%d", (long)s, h_lens[s], q->max_len);
+        rows += h_lens[s];
+    }
+    MQ_CHECK_ARG(rows <= q->cfg.max_rows, "mq_queue_encode: %ld token rows, the queue takes up to %d per request", (long)rows, q->cfg.max_rows);
+    // an id outside the embedding table would fault on the device and take every request of the merged call with it: refused here, per request
+    for (int64_t i = 0; i < rows; ++i) MQ_CHECK_ARG(h_ids[i] >= 0 && h_ids[i] < q->vocab, "mq_queue_encode: token id %d at %ld outside [0, %d)", h_ids[i], (long)i, q->vocab);
+    QRequest r;
+    r.ids = h_ids;
+    r.lens = h_lens;
+    r.nseq = nseq;
+    r.rows = rows;
+    r.out = h_out;
+    r.t_in = std::chrono::steady_clock::now();
+    {
+        std::unique_lock<std::mutex> lk(q->mu);
+        if (q->stop) {
+            mq_set_error("mq_queue_encode: the queue is being destroyed");
+            return MQ_ERR_INVALID;
+        }
+        q->pending.push_back(&r);
+        q->pending_seqs += nseq;
+        q->cv_work.notify_one();
+        q->cv_done.wait(lk, [&] { return r.done; });
+    }
+    if (r.status != MQ_OK) mq_set_error("mq_queue_encode: the merged tower call failed: %s", r.err.c_str());
+    return r.status;
+}
+
+extern "C" int mq_queue_get_stats(mq_queue* q, mq_queue_stats* out) {
+    MQ_CHECK_ARG(q && out, "mq_queue_get_stats: null pointer");
+    std::lock_guard<std::mutex> lk(q->mu);
+    *out = q->st;
+    return MQ_OK;
+}
+
+extern "C" int mq_queue_destroy(mq_queue* q) {
+    if (!q) return MQ_OK;
+    {
+        std::lock_guard<std::mutex> lk(q->mu);
+        q->stop = true;
+    }
+    q->cv_work.notify_all();
+    for (QLane& ln : q->lanes)
+        if (ln.th.joinable()) ln.th.join();   // (workers drain what is still pending: no caller is left blocked)
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    (void)hipSetDevice(q->cfg.device);
+    for (QLane& ln : q->lanes) lane_free(ln);
+    (void)hipSetDevice(prev);
+    delete q;
+    return MQ_OK;
+}

@@ -1,0 +1,102 @@
+"""Python face of the native request queue (`mq_queue_*`, csrc/queue.hip, ABI 14): concurrent small text calls of one tower are merged into ONE tower
+call on worker threads that never hold the interpreter lock.
+
+Where the reference has this load: up to 8 indexing + 8 search request threads (/root/reference/src/marqo/api/configs.py:27-28), each calling
+`vectorise()` with one query or the chunks of one document field (src/marqo/core/inference/tensor_fields_container.py:179-223).  A caller tokenises
+its own texts on its own thread and blocks inside `mq_queue_encode` (ctypes drops the GIL around the call); packing, H2D, the ~100 launches of the tower
+pass, D2H and the wake-up are native.  The Python-level coalescer (s2_inference/coalesce.py) stays for everything that has no queue (image calls, loaders
+without an engine tower) and steps aside for text calls of a tower that has one.
+
+MARQO_AMD_NATIVE_QUEUE=0 turns the queue off (the coalescer then merges text calls as before round 6); _SEQS / _DEPTH / _WINDOW_US size it."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+from typing import Dict, Optional
+
+import numpy as np
+
+from marqo_amd import _lib as L
+
+
+def _env_int(name: str, default: int, lo: int, hi: int) -> int:
+    try:
+        return min(hi, max(lo, int(os.environ.get(name, str(default)))))
+    except ValueError:
+        return default
+
+
+ENABLED = os.environ.get("MARQO_AMD_NATIVE_QUEUE", "1") != "0"
+# a request of more sequences than this goes the direct way (it fills enough of the chip on its own, and the merged call's staging is sized by it)
+MAX_SEQS = _env_int("MARQO_AMD_NATIVE_QUEUE_SEQS", 64, 1, 4096)
+DEPTH = _env_int("MARQO_AMD_NATIVE_QUEUE_DEPTH", 1, 1, 4)
+WINDOW_US = _env_int("MARQO_AMD_NATIVE_QUEUE_WINDOW_US", 100, 0, 100000)
+
+
+class TextQueue:
+    """one `mq_queue` of a text tower for one value of `normalize`.  `cfg` / `w` are the tower's ctypes structs (kept alive here: the queue reads them
+    at every call); thread-safe; recreated in a fork()ed child (worker threads do not survive a fork)."""
+
+    def __init__(self, lib, kind: int, cfg, w, device_index: int, out_dim: int, max_len: int, normalize: bool,
+                 max_seqs: int = 0, depth: int = 0, window_us: Optional[int] = None):
+        self._lib, self._kind, self._cfg, self._w = lib, kind, cfg, w
+        self.out_dim, self.max_len = int(out_dim), int(max_len)
+        self.max_seqs = int(max_seqs or MAX_SEQS)
+        self.max_rows = self.max_seqs * self.max_len
+        self._qcfg = L.QueueCfg(kind=kind, device=int(device_index), max_seqs=self.max_seqs, max_rows=self.max_rows, normalize=1 if normalize else 0,
+                                depth=int(depth or DEPTH), window_us=int(WINDOW_US if window_us is None else window_us), reserved=0)
+        self._h = C.c_void_p()
+        self._pid = os.getpid()
+        self._lock = threading.Lock()
+        L.check(lib.mq_queue_create(C.byref(self._qcfg), C.cast(C.byref(cfg), C.c_void_p), C.cast(C.byref(w), C.c_void_p), C.byref(self._h)), "mq_queue_create")
+
+    def takes(self, nseq: int, rows: int) -> bool:
+        return 1 <= nseq <= self.max_seqs and rows <= self.max_rows
+
+    def _handle(self) -> C.c_void_p:
+        if self._pid != os.getpid():        # fork()ed child: the parent's workers are not here; a queue of our own (the parent's handle is left alone)
+            with self._lock:
+                if self._pid != os.getpid():
+                    h = C.c_void_p()
+                    L.check(self._lib.mq_queue_create(C.byref(self._qcfg), C.cast(C.byref(self._cfg), C.c_void_p), C.cast(C.byref(self._w), C.c_void_p),
+                                                      C.byref(h)), "mq_queue_create")
+                    self._h, self._pid = h, os.getpid()
+        return self._h
+
+    def encode(self, packed_ids: np.ndarray, lengths: np.ndarray) -> np.ndarray:
+        """packed_ids int32 [sum(lengths)], lengths int32 [n] -> fp32 [n, out_dim] (host).  Blocks (GIL released) until the merged call that carried
+        this request has finished."""
+        ids = np.ascontiguousarray(packed_ids, dtype=np.int32)
+        lens = np.ascontiguousarray(lengths, dtype=np.int32)
+        n = int(lens.size)
+        if int(lens.sum()) != int(ids.size):
+            raise ValueError(f"packed ids hold {ids.size} tokens, the lengths add up to {int(lens.sum())}")
+        out = np.empty((n, self.out_dim), dtype=np.float32)
+        if n:
+            L.check(self._lib.mq_queue_encode(self._handle(), ids.ctypes.data, lens.ctypes.data, n, out.ctypes.data), "mq_queue_encode")
+        return out
+
+    def encode_raw(self, ids32: np.ndarray, lens32: np.ndarray, n: int) -> np.ndarray:
+        """`encode` for callers that vouch for their arrays (contiguous int32, lengths adding up to the ids): the towers' per-request path, where
+        every NumPy call is interpreter time that 16 request threads queue up for"""
+        out = np.empty((n, self.out_dim), dtype=np.float32)
+        L.check(self._lib.mq_queue_encode(self._handle(), ids32.ctypes.data, lens32.ctypes.data, n, out.ctypes.data), "mq_queue_encode")
+        return out
+
+    def stats(self) -> Dict[str, int]:
+        st = L.QueueStats()
+        L.check(self._lib.mq_queue_get_stats(self._handle(), C.byref(st)), "mq_queue_get_stats")
+        return {name: int(getattr(st, name)) for name, _ in L.QueueStats._fields_}
+
+    def close(self) -> None:
+        with self._lock:
+            h, self._h = self._h, C.c_void_p()
+            if h and self._pid == os.getpid():
+                self._lib.mq_queue_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -21,6 +21,7 @@ import numpy as np
 import torch
 
 from marqo_amd import _lib as L
+from marqo_amd.engine import native_queue as NQ
 from marqo_amd.engine.archs import BertArch, ClipTextArch, VitArch, OPENAI_DATASET_MEAN, OPENAI_DATASET_STD
 
 Tensor = torch.Tensor
@@ -1028,6 +1029,91 @@ class _TextTowerBase(_TowerBase):
         """small host -> device copy through pinned memory (a pageable copy would synchronise the stream)"""
         return t.pin_memory().to(self.device, non_blocking=True)
 
+    # ---- native request queue (engine/native_queue.py, csrc/queue.hip): concurrent small calls of the request threads share tower calls ----------
+    _queues: Optional[Dict[bool, tuple]] = None
+    _queues_off = False
+    _active = 0                       # request-thread calls of the small-call path in flight on this tower
+    _active_lock = threading.Lock()   # (class-wide: two increments)
+
+    def _queue(self, normalize: bool, clip: bool) -> Optional["NQ.TextQueue"]:
+        """this tower's queue for `normalize` (created at first use, re-created when the tower's policy fields have changed since: its scratch is
+        sized from them), or None — switched off, or it could not be created (logged once; the direct path stays)"""
+        if not NQ.ENABLED or self._queues_off or (self._fp8 is not None and not self._fp8.calibrated):
+            return None
+        sig = bytes(self.cfg)
+        ent = (self._queues or {}).get(bool(normalize))
+        if ent is not None and ent[0] == sig:
+            return ent[1]
+        with self._lock:
+            if self._queues is None:
+                self._queues = {}
+            ent = self._queues.get(bool(normalize))
+            if ent is not None and ent[0] == sig:
+                return ent[1]
+            if ent is not None:
+                ent[1].close()
+            try:
+                idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+                max_len = (self.arch.ctx + (1 if getattr(self.arch, "cls_embed", False) else 0)) if clip else self.arch.max_pos
+                q = NQ.TextQueue(self.lib, L.QUEUE_CLIP_TEXT if clip else L.QUEUE_BERT, self.cfg, self.w, idx,
+                                 self.arch.out_dim if clip else self.out_width, max_len, bool(normalize))
+            except (L.MarqoHipUnavailableError, L.MarqoHipError) as e:
+                self._queues_off = True
+                import logging
+                logging.getLogger(__name__).warning("native request queue unavailable (%s); small text calls keep the direct path", e)
+                return None
+            self._queues[bool(normalize)] = (sig, q)
+            return q
+
+    def _small_call(self, ids_h: np.ndarray, lengths: np.ndarray, normalize: bool, clip: bool) -> Optional[Tensor]:
+        """the request threads' small calls (loaders inside `request_stream`, host rows wanted): a LONE single-sequence call replays the captured
+        launch sequence of its token count (lowest latency: no worker hand-over, ~100 launches as one graph); calls that find others in flight
+        go through the native queue and share tower calls with them.  None: not a small call / neither is available — the caller launches eagerly."""
+        n = int(lengths.size)
+        if not getattr(_request_tls, "host_output", False) or n < 1 or n > NQ.MAX_SEQS:
+            return None
+        with _TextTowerBase._active_lock:
+            self._active += 1
+            alone = self._active == 1
+        try:
+            if n == 1 and alone and self._graphs_ok():
+                one = self._encode_one(torch.from_numpy(ids_h[0, :int(lengths[0])]), normalize, clip)
+                if one is not None:
+                    return one
+            q = self._queue(normalize, clip)
+            if q is None or not q.takes(n, int(lengths.sum())):
+                return None
+            packed, _ = _pack(ids_h, lengths)
+            return torch.from_numpy(q.encode(packed.numpy(), lengths))
+        finally:
+            with _TextTowerBase._active_lock:
+                self._active -= 1
+
+    def queue_rows(self, ids_h: np.ndarray, lengths: np.ndarray, normalize: bool, clip: bool) -> Optional[np.ndarray]:
+        """the loaders' LEAN small-call path — host ids in, host rows out, no stream context, no torch call, a handful of NumPy calls (with 16
+        request threads in the interpreter every statement here is time the others wait for): this request's rows through the native queue, or None
+        when the call belongs to the regular path (a lone single query: its captured graph; no queue; too many sequences)"""
+        n = int(lengths.size)
+        if n < 1 or n > NQ.MAX_SEQS:
+            return None
+        with _TextTowerBase._active_lock:
+            self._active += 1
+            alone = self._active == 1
+        try:
+            if n == 1 and alone and self._graphs_ok():
+                return None
+            q = self._queue(normalize, clip)
+            if q is None or not q.takes(n, int(lengths.sum())):
+                return None
+            packed = ids_h[0, :int(lengths[0])] if n == 1 else ids_h[np.arange(ids_h.shape[1])[None, :] < lengths[:, None]]
+            return q.encode_raw(np.ascontiguousarray(packed, dtype=np.int32), np.ascontiguousarray(lengths, dtype=np.int32), n)
+        finally:
+            with _TextTowerBase._active_lock:
+                self._active -= 1
+
+    def queue_stats(self) -> Dict[bool, Dict[str, int]]:
+        return {k: ent[1].stats() for k, ent in (self._queues or {}).items()}
+
     def _encode_one(self, src_ids: Tensor, normalize: bool, clip: bool) -> Optional[Tensor]:
         """ONE sequence (1-D ids of its real length, host or device) through the captured launch sequence of that token count
         (None: capture is not available, the caller launches eagerly)"""
@@ -1197,6 +1283,10 @@ class ClipTextTower(_TextTowerBase):
             pack = False
         eot = np.full(n, S - 1, dtype=np.int64) if not self.arch.causal else ids_h.argmax(axis=1)
         lengths = (eot + 1) if pack else np.full(n, S, dtype=np.int64)
+        if pack or not self.arch.causal:          # (the pooled row is each sequence's last: what the queue and the captured graphs pool)
+            small = self._small_call(ids_h, lengths, normalize, clip=True)
+            if small is not None:
+                return small
         if n == 1 and (pack or not self.arch.causal) and self._graphs_ok():
             one = self._encode_one(torch.from_numpy(ids_h[0, :int(lengths[0])]), normalize, clip=True)
             if one is not None:
@@ -1214,6 +1304,13 @@ class ClipTextTower(_TextTowerBase):
                 self._call_text(True, d_ids, d_cu, cu, nseq, d_pool, out[a:b], normalize, self._workspace(need))
         return out
 
+
+    def queue_rows_ids(self, ids_h: np.ndarray, normalize: bool = True) -> Optional[np.ndarray]:
+        """`queue_rows` for the tokeniser's [n, <= ctx] id matrix (SOT ... EOT 0 ...): each sequence up to its EOT, as encode_ids(pack=True) runs it.
+        None for the towers whose rows are not 'text up to EOT' (unmasked SigLIP towers, CoCa's appended class token): they keep the regular path."""
+        if not self.arch.causal or self.arch.cls_embed or ids_h.ndim != 2 or ids_h.shape[1] > self.arch.ctx:
+            return None
+        return self.queue_rows(ids_h, ids_h.argmax(axis=1) + 1, normalize, clip=True)
 
     def encode_device(self, d_ids: Tensor, lengths: Tensor, normalize: bool = True) -> Tensor:
         """ids already on the device (engine/gpu_tokenizers.py): int32 [n, S] rows SOT ... EOT 0 ..., lengths int64 [n] on the
@@ -1366,6 +1463,9 @@ class BertTower(_TextTowerBase):
             raise ValueError("attention_mask must be right-padded (a prefix of ones per row)")
         if n and int(lengths.max()) > self.arch.max_pos:
             raise ValueError(f"sequence longer than max_position_embeddings={self.arch.max_pos}")
+        small = self._small_call(ids_h, lengths, normalize, clip=False)
+        if small is not None:
+            return small
         if n == 1 and self._graphs_ok():
             one = self._encode_one(torch.from_numpy(ids_h[0, :int(lengths[0])]), normalize, clip=False)
             if one is not None:
@@ -1380,6 +1480,16 @@ class BertTower(_TextTowerBase):
                 need = self.lib.mq_bert_workspace_bytes(C.byref(self.cfg), rows, nseq)
                 self._call_text(False, d_ids, d_cu, cu, nseq, None, out[a:b], normalize, self._workspace(need))
         return out
+
+    def queue_rows_ids(self, ids_h: np.ndarray, mask_h: np.ndarray, normalize: bool = True) -> Optional[np.ndarray]:
+        """`queue_rows` for the tokeniser's right-padded [n, S] ids + attention mask (the engine's own tokenisers: the mask is a prefix of ones by
+        construction; encode_ids checks that for foreign callers)"""
+        if ids_h.ndim != 2 or ids_h.shape != mask_h.shape:
+            return None
+        lengths = mask_h.sum(axis=1)
+        if ids_h.shape[0] and (int(lengths.min()) < 1 or int(lengths.max()) > self.arch.max_pos):
+            return None        # (the regular path raises the error with its text)
+        return self.queue_rows(ids_h, lengths, normalize, clip=False)
 
     def encode_device(self, d_ids: Tensor, lengths: Tensor, normalize: bool = True) -> Tensor:
         """ids already on the device (engine/gpu_tokenizers.py): int32 [n, S] rows [CLS] ... [SEP] pad..., lengths int64 [n] on the

@@ -192,6 +192,17 @@ class HuggingFaceModel(AbstractEmbeddingModel):
                     pass
         return True
 
+    def native_queue_takes(self, texts) -> bool:
+        """True when `encode(texts)` goes through the tower's native request queue (engine/native_queue.py): `vectorise()` then leaves the merging
+        of concurrent calls to it instead of the Python coalescer (host-tokenised small calls only)"""
+        from marqo_amd.engine import native_queue as NQ
+        if not NQ.ENABLED or self._model is None or not hasattr(self._model, "_small_call"):
+            return False
+        texts = [texts] if isinstance(texts, str) else texts
+        if not (1 <= len(texts) <= NQ.MAX_SEQS) or not all(isinstance(t, str) for t in texts):
+            return False
+        return getattr(self, "_device_tokenizer", None) is None or prefers_host(texts)
+
     def encode(self, sentence: Union[str, List[str]], normalize=True, **kwargs) -> np.ndarray:
         """-> np.ndarray [n, D] fp32 (hugging_face_model.py:172-203); engine extension `return_device=True`: the same rows as a device
         tensor.  Other kwargs the callers pass (`modality`, `infer`, `image_download_headers`) are tolerated and ignored."""
@@ -200,12 +211,21 @@ class HuggingFaceModel(AbstractEmbeddingModel):
         if self._model is None:
             self.load()
         return_device = bool(kwargs.get("return_device", False))
+        tok = None
+        if not return_device and self.native_queue_takes(sentence):
+            # a request thread's small call: tokenise here, hand the ids to the tower's native queue, block outside the interpreter; a LONE single
+            # query comes back None and replays its captured graph below (with the ids made here)
+            tok = self._tokenizer(sentence, max_length=self.model_properties.tokens)
+            rows = self._model.queue_rows_ids(tok["input_ids"], tok["attention_mask"], bool(normalize))
+            if rows is not None:
+                return rows
         with request_stream(self.device, device_output=return_device):
-            if getattr(self, "_device_tokenizer", None) is not None and not prefers_host(sentence):
+            if tok is None and getattr(self, "_device_tokenizer", None) is not None and not prefers_host(sentence):
                 d_ids, lens = self._device_tokenizer.encode_device(sentence, self.model_properties.tokens)
                 out = self._model.encode_device(d_ids, lens, normalize=bool(normalize))
             else:
-                tok = self._tokenizer(sentence, max_length=self.model_properties.tokens)
+                if tok is None:
+                    tok = self._tokenizer(sentence, max_length=self.model_properties.tokens)
                 ids, mask = torch.from_numpy(tok["input_ids"]), torch.from_numpy(tok["attention_mask"])
                 out = self._model.encode_ids(ids, mask, normalize=bool(normalize))
             return out if return_device else out.cpu().numpy()

@@ -617,9 +617,29 @@ class OPEN_CLIP(AbstractCLIPModel):
             st.wait_stream(main)
         return [main] + side
 
+    def native_queue_takes(self, texts) -> bool:
+        """True when `encode_text(texts)` goes through the text tower's native request queue (engine/native_queue.py): `vectorise()` then leaves
+        the merging of concurrent calls to it instead of the Python coalescer.  Host-tokenised small calls only — ids from the device tokeniser
+        stay in HBM and take the direct path."""
+        from marqo_amd.engine import native_queue as NQ
+        if not NQ.ENABLED or self.model is None or getattr(self, "text", None) is None or not hasattr(self.text, "_small_call"):
+            return False
+        texts = [texts] if isinstance(texts, str) else texts
+        if not (1 <= len(texts) <= NQ.MAX_SEQS) or not all(isinstance(t, str) for t in texts):
+            return False
+        return getattr(self, "_device_tokenizer", None) is None or prefers_host(texts)
+
     def encode_text(self, sentence: Union[str, List[str]], normalize=True, return_device: bool = False):
         if self.model is None:
             self.load()
+        ids_np = None
+        if not return_device and not isinstance(self.text_arch, archs.HfClipTextArch) and self.native_queue_takes(sentence):
+            # a request thread's small call: tokenise here, hand the ids to the tower's native queue, block outside the interpreter; a LONE single
+            # query comes back None and replays its captured graph below (with the ids made here)
+            ids_np = np.asarray(self.tokenizer(sentence))
+            rows = self.text.queue_rows_ids(ids_np, bool(normalize))
+            if rows is not None:
+                return rows
         with request_stream(self.device, device_output=return_device):
             if isinstance(self.text_arch, archs.HfClipTextArch):
                 texts = [_clean_text(t) for t in ([sentence] if isinstance(sentence, str) else list(sentence))]
@@ -637,7 +657,7 @@ class OPEN_CLIP(AbstractCLIPModel):
                     lens = torch.full((len(texts),), self.text_arch.ctx, dtype=torch.int64)
                 out = self.text.encode_device(d_ids, lens, normalize=bool(normalize))
             else:
-                ids = torch.as_tensor(np.asarray(self.tokenizer(sentence)))
+                ids = torch.as_tensor(ids_np if ids_np is not None else np.asarray(self.tokenizer(sentence)))
                 out = self.text.encode_ids(ids, normalize=bool(normalize))
             return out if return_device else self._convert_output(out)
 

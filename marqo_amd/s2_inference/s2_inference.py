@@ -301,6 +301,12 @@ def _encode_to_array(model_cache_key: str, content, normalize_embeddings: bool, 
                 ckey = _coalesce_key(model_cache_key, modality, normalize_embeddings, infer, kwargs) if coalesce_window > 0 else None
                 if ckey is not None and not _coalesce.explicit() and _coalesce.fetches_content(batch, modality == Modality.TEXT):
                     ckey = None         # image URLs: every request thread keeps downloading its own (coalesce.fetches_content)
+                if ckey is not None and modality == Modality.TEXT and not _coalesce.explicit():
+                    # a text tower with a native request queue (engine/native_queue.py, csrc/queue.hip) merges concurrent small calls itself, on
+                    # worker threads outside the interpreter: this thread tokenises its own texts and blocks in ONE foreign call
+                    takes = getattr(model, "native_queue_takes", None)
+                    if callable(takes) and takes(batch) is True:
+                        ckey = None
                 if ckey is not None:
                     def run_merged(items, _m=modality, _i=infer, _kw=dict(kwargs)):
                         return encoder.encode(items, modality=_m, normalize=normalize_embeddings, infer=_i, **_kw)

@@ -24,7 +24,7 @@ def test_header_symbols_are_exported_and_bound():
         assert hasattr(raw, n), f"libmarqo_hip.so does not export {n}"
         assert n in L.EXPORTED_SYMBOLS, f"ctypes binding is missing {n}"
     assert set(L.EXPORTED_SYMBOLS) <= set(names), set(L.EXPORTED_SYMBOLS) - set(names)
-    assert lib.mq_abi_version() == L.ABI_VERSION == 13 and lib.mq_build_arch() == b"gfx950"
+    assert lib.mq_abi_version() == L.ABI_VERSION == 14 and lib.mq_build_arch() == b"gfx950"
 
 
 def test_struct_layouts_match_header():
@@ -36,6 +36,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(L.VitWeights) == 11 * 8 and C.sizeof(L.MapHead) == 11 * 8
     assert C.sizeof(L.ClipTextCfg) == ENC + 4 * 4 and C.sizeof(L.ClipTextWeights) == 7 * 8
     assert C.sizeof(L.BertCfg) == ENC + 5 * 4 + 4 and C.sizeof(L.BertWeights) == 9 * 8   # + proj_hidden, out_dim / proj1_w, proj1_b, proj2_w
+    assert C.sizeof(L.QueueCfg) == 8 * 4 and C.sizeof(L.QueueStats) == 7 * 8   # ABI 14: the native request queue
 
 
 def test_argument_errors_are_reported_without_a_gpu():
@@ -48,6 +49,15 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert lib.mq_encoder_workspace_bytes(C.byref(L.EncoderCfg(width=768, layers=12, heads=12, mlp_dim=3072, act=1)), 100, 2) > 0
     assert lib.mq_chunk_grid_count(3, 3, 0) == 10 and lib.mq_chunk_grid_count(3, 3, 1) == 14 and lib.mq_chunk_grid_count(0, 3, 0) == 0
     assert lib.mq_resample_ksize(640, 224) == 13 and lib.mq_resample_ksize(80, 224) == 5
+    # ABI 14, the native request queue: arguments are judged before any device is asked for
+    h = C.c_void_p()
+    assert lib.mq_queue_create(None, None, None, C.byref(h)) == -1 and b"null pointer" in lib.mq_last_error() and not h
+    qc = L.QueueCfg(kind=L.QUEUE_BERT, device=0, max_seqs=0, max_rows=512, normalize=1, depth=2, window_us=0, reserved=0)
+    bc, bw = L.BertCfg(), L.BertWeights()
+    assert lib.mq_queue_create(C.byref(qc), C.cast(C.byref(bc), C.c_void_p), C.cast(C.byref(bw), C.c_void_p), C.byref(h)) == -1 and not h
+    assert b"max_seqs" in lib.mq_last_error()
+    assert lib.mq_queue_encode(None, None, None, 1, None) == -1 and b"null queue" in lib.mq_last_error()
+    assert lib.mq_queue_get_stats(None, None) == -1 and lib.mq_queue_destroy(None) == 0
 
 
 def test_product_never_imports_the_oracle():

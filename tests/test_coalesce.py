@@ -209,3 +209,27 @@ def test_image_url_calls_stay_out_of_the_default_coalescing():
     assert len(calls) < 32                                                      # explicit opt-in: merged
     calls = run({"MARQO_AMD_COALESCE_US": ""}, lambda t, c, i: (t, c, i))       # decoded content (no I/O in the engine call): merged by default
     assert len(calls) < 32
+
+
+def test_text_calls_of_a_model_with_a_native_queue_stay_out_of_the_python_coalescer():
+    """a loader whose text tower merges concurrent small calls natively (`native_queue_takes`, engine/native_queue.py) gets every request thread's call
+    as it is — the tower's queue does the merging, outside the interpreter; MARQO_AMD_COALESCE_US set explicitly keeps the Python coalescer in charge"""
+    class QueueModel(FakeEngineModel):
+        asked = 0
+
+        def native_queue_takes(self, texts):
+            QueueModel.asked += 1
+            return all(isinstance(t, str) for t in texts) and len(texts) <= 4
+
+    model = QueueModel()
+    props, avail = _setup(model)
+    out, errs = _run_threads(model, props, avail, 8, 3, 4, {"MARQO_AMD_COALESCE_US": ""})
+    assert not errs and len(model.calls) == 32 and all(len(c) == 3 for c in model.calls) and QueueModel.asked == 32
+    for content, rows in out.values():
+        assert rows.shape == (3, model.dim)
+    model.calls.clear()
+    out, errs = _run_threads(model, props, avail, 8, 5, 4, {"MARQO_AMD_COALESCE_US": ""})     # 5 texts: the queue does not take them -> coalesced as before
+    assert not errs and len(model.calls) < 32
+    model.calls.clear()
+    out, errs = _run_threads(model, props, avail, 8, 3, 4, {"MARQO_AMD_COALESCE_US": "20000"})  # the operator's explicit window wins
+    assert not errs and len(model.calls) < 32

@@ -1,0 +1,220 @@
+"""The native request queue (mq_queue_*, csrc/queue.hip, ABI 14; engine/native_queue.py): concurrent small text calls share tower calls on worker threads
+outside the interpreter.  What is checked: a request's rows equal the DIRECT tower call's bit for bit whoever it shared a launch with (same kernel family),
+against the golden vectors `transformers` made, under 16 request threads, through `vectorise()`, and that bad requests fail alone.
+Reference load being served: 8 indexing + 8 search threads calling vectorise() (/root/reference/src/marqo/api/configs.py:27-28)."""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+from tests import golden_util as G
+
+pytestmark = pytest.mark.gpu
+
+COS_TIGHT = 3e-4
+
+
+def _cos_err(a, b) -> float:
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return float((1 - (a * b).sum(-1) / (a.norm(dim=-1) * b.norm(dim=-1))).max())
+
+
+def _clip_text():
+    from marqo_amd.engine import archs as A, towers as T
+    sd, z = G.load("clip_text_small")
+    V, ctx, W, L, H, F, D = [int(v) for v in z["cfg"]]
+    return T.ClipTextTower(A.ClipTextArch(V, ctx, W, L, H, F, D), sd, "cuda"), z
+
+
+def _bert(pooling="mean"):
+    from marqo_amd.engine import archs as A, towers as T
+    sd, z = G.load("bert_small")
+    V, P, W, L, H, F = [int(v) for v in z["cfg"]]
+    return T.BertTower(A.BertArch(vocab=V, max_pos=P, width=W, layers=L, heads=H, mlp_dim=F), sd, "cuda", pooling=pooling), z
+
+
+def _packed(ids: np.ndarray, lengths: np.ndarray):
+    keep = np.arange(ids.shape[1])[None, :] < lengths[:, None]
+    return np.ascontiguousarray(ids[keep], dtype=np.int32), np.ascontiguousarray(lengths, dtype=np.int32)
+
+
+def test_queue_rows_are_the_direct_calls_rows_and_the_golden_ones():
+    """one request through mq_queue_encode == the same sequences through mq_encode_clip_text / mq_encode_bert directly (same entry point underneath, same
+    packing: bit-identical), and both within the tolerance of the vectors `transformers` produced"""
+    from marqo_amd.engine import native_queue as NQ
+    tower, z = _clip_text()
+    ids = z["ids"].astype(np.int64)
+    lengths = ids.argmax(axis=1) + 1
+    direct = tower.encode_ids(torch.from_numpy(ids), normalize=False, pack=True).cpu().numpy()
+    q = tower._queue(False, clip=True)
+    assert isinstance(q, NQ.TextQueue) and q is tower._queue(False, clip=True) and q is not tower._queue(True, clip=True)
+    rows = q.encode(*_packed(ids, lengths))
+    assert rows.shape == direct.shape and np.array_equal(rows, direct)
+    assert _cos_err(rows, z["emb"]) < COS_TIGHT
+    st = q.stats()
+    assert st["requests"] == 1 and st["calls"] == 1 and st["merged_calls"] == 0 and st["sequences"] == ids.shape[0] and st["failed_calls"] == 0
+
+    for pooling, key in (("mean", "mean_norm"), ("cls", "cls_norm")):
+        bert, zb = _bert(pooling)
+        bids, mask = zb["ids"].astype(np.int64), zb["mask"].astype(np.int64)
+        direct = bert.encode_ids(torch.from_numpy(bids), torch.from_numpy(mask), normalize=True).cpu().numpy()
+        rows = bert._queue(True, clip=False).encode(*_packed(bids, mask.sum(axis=1)))
+        assert np.array_equal(rows, direct) and _cos_err(rows, zb[key]) < COS_TIGHT
+
+
+def test_sixteen_threads_share_tower_calls_and_every_request_gets_its_own_rows():
+    """16 request threads x 12 requests of 1-4 sequences against ONE queue: every request's rows are those of the same sequences encoded alone (the small-row
+    kernel family serves lone and merged calls alike here: bit-identical), the stats show merged tower calls, nothing is lost or swapped"""
+    tower, z = _clip_text()
+    ids = z["ids"].astype(np.int64)
+    n_all = ids.shape[0]
+    lengths = ids.argmax(axis=1) + 1
+    alone = tower.encode_ids(torch.from_numpy(ids), normalize=True, pack=True).cpu().numpy()
+    one_by_one = np.concatenate([tower.encode_ids(torch.from_numpy(ids[i:i + 1]), normalize=True, pack=True).cpu().numpy() for i in range(n_all)])
+    q = tower._queue(True, clip=True)
+    errs, results = [], {}
+    start = threading.Barrier(16)
+
+    def worker(t):
+        try:
+            rng = np.random.default_rng(t)
+            start.wait(30)
+            for c in range(12):
+                pick = rng.integers(0, n_all, size=int(rng.integers(1, 5)))
+                results[(t, c)] = (pick, q.encode(*_packed(ids[pick], lengths[pick])))
+        except BaseException as e:  # noqa: BLE001
+            errs.append((t, e))
+    ts = [threading.Thread(target=worker, args=(t,)) for t in range(16)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(120)
+    assert not errs, errs
+    assert len(results) == 16 * 12
+    for pick, rows in results.values():
+        assert rows.shape == (len(pick), alone.shape[1])
+        assert np.array_equal(rows, alone[pick]) or np.array_equal(rows, one_by_one[pick]) or _cos_err(rows, alone[pick]) < 1e-5
+    st = q.stats()
+    assert st["requests"] == 16 * 12 and st["failed_calls"] == 0
+    assert st["calls"] < st["requests"] and st["merged_calls"] >= 1 and st["max_call_sequences"] > 4, st    # launches were shared
+    assert st["max_call_sequences"] <= q.max_seqs
+
+
+def test_bad_requests_fail_alone_and_on_their_own_thread():
+    from marqo_amd import _lib as L
+    tower, z = _clip_text()
+    ids = z["ids"].astype(np.int64)
+    lengths = ids.argmax(axis=1) + 1
+    q = tower._queue(True, clip=True)
+    good = q.encode(*_packed(ids[:2], lengths[:2]))
+    with pytest.raises(L.MarqoHipError, match="outside"):          # an id outside the embedding table would fault on the device for everybody
+        bad = ids[:1].copy()
+        bad[0, 1] = tower.arch.vocab + 7
+        q.encode(*_packed(bad, lengths[:1]))
+    with pytest.raises(L.MarqoHipError, match="tokens"):           # longer than the tower's context
+        q.encode(np.ones(tower.arch.ctx + 5, dtype=np.int32), np.asarray([tower.arch.ctx + 5], dtype=np.int32))
+    with pytest.raises(L.MarqoHipError, match="sequences"):        # more sequences than one merged call carries
+        n = q.max_seqs + 1
+        q.encode(np.ones(n, dtype=np.int32), np.ones(n, dtype=np.int32))
+    with pytest.raises(ValueError):
+        q.encode(np.ones(5, dtype=np.int32), np.asarray([4], dtype=np.int32))
+    assert q.encode(np.zeros(0, dtype=np.int32), np.zeros(0, dtype=np.int32)).shape == (0, tower.arch.out_dim)
+    again = q.encode(*_packed(ids[:2], lengths[:2]))               # the queue is as good as before
+    assert np.array_equal(good, again) and q.stats()["failed_calls"] == 0
+    # create-time argument checks (no queue comes back)
+    lib, h = tower.lib, C.c_void_p()
+    cfg = L.QueueCfg(kind=7, device=0, max_seqs=8, max_rows=8 * tower.arch.ctx, normalize=1, depth=1, window_us=0, reserved=0)
+    assert lib.mq_queue_create(C.byref(cfg), C.cast(C.byref(tower.cfg), C.c_void_p), C.cast(C.byref(tower.w), C.c_void_p), C.byref(h)) == -1 and not h
+    cfg.kind, cfg.max_rows = L.QUEUE_CLIP_TEXT, 3
+    assert lib.mq_queue_create(C.byref(cfg), C.cast(C.byref(tower.cfg), C.c_void_p), C.cast(C.byref(tower.w), C.c_void_p), C.byref(h)) == -1 and not h
+    assert b"max_rows" in lib.mq_last_error()
+
+
+def test_destroy_serves_what_is_pending_and_policy_changes_rebuild_the_queue():
+    from marqo_amd.engine import native_queue as NQ
+    tower, z = _clip_text()
+    ids = z["ids"].astype(np.int64)
+    lengths = ids.argmax(axis=1) + 1
+    q = NQ.TextQueue(tower.lib, 0, tower.cfg, tower.w, 0, tower.arch.out_dim, tower.arch.ctx, True, max_seqs=8, depth=1, window_us=0)
+    outs, errs = {}, []
+
+    def worker(t):
+        try:
+            outs[t] = q.encode(*_packed(ids[t:t + 1], lengths[t:t + 1]))
+        except BaseException as e:  # noqa: BLE001
+            errs.append(e)
+    nt = min(6, ids.shape[0])
+    ts = [threading.Thread(target=worker, args=(t,)) for t in range(nt)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(60)
+    q.close()
+    q.close()                                                      # idempotent
+    assert not errs and len(outs) == nt
+    ref = tower.encode_ids(torch.from_numpy(ids[:nt]), normalize=True).cpu().numpy()
+    for t in range(nt):
+        assert _cos_err(outs[t], ref[t:t + 1]) < 1e-5
+    # the tower's queue follows the tower's policy fields: a changed cfg gets a queue of its own (its scratch is sized from the cfg)
+    q1 = tower._queue(True, clip=True)
+    before = bytes(tower.cfg)
+    tower.cfg.enc.residual_stream = 0 if tower.cfg.enc.residual_stream else 1
+    try:
+        if bytes(tower.cfg) != before:
+            q2 = tower._queue(True, clip=True)
+            assert q2 is not q1
+            assert _cos_err(q2.encode(*_packed(ids[:3], lengths[:3])), ref[:3]) < 1e-3
+    finally:
+        tower.cfg.enc.residual_stream = 1 - tower.cfg.enc.residual_stream
+
+
+def test_vectorise_from_request_threads_goes_through_the_queue(monkeypatch):
+    """the product path: 12 threads call vectorise() with 1-3 texts each on a registry CLIP model (synthetic weights); the loader's text tower serves them
+    through its queue (the Python coalescer steps aside), rows equal the lone calls' within the kernel-family bound, and a LONE single query still takes the
+    captured graph"""
+    monkeypatch.setenv("MARQO_AMD_SYNTHETIC_WEIGHTS", "1")
+    monkeypatch.setenv("MARQO_MAX_CUDA_MODEL_MEMORY", "64")
+    monkeypatch.delenv("MARQO_AMD_COALESCE_US", raising=False)
+    from marqo_amd.s2_inference import coalesce, s2_inference as s2
+    from marqo_amd.s2_inference.enums import AvailableModelsKey, Modality
+    name = "open_clip/ViT-B-32/laion2b_s34b_b79k"
+    props = s2.get_model_properties_from_registry(name)
+    kw = dict(device="cuda:0", modality=Modality.TEXT, model_properties=props)
+    texts = [f"a photo of object number {i} on a table" for i in range(40)]
+    lone = np.concatenate([s2.vectorise_ndarray(name, [t], **kw) for t in texts])
+    key = s2._create_model_cache_key(name, "cuda:0", props)
+    model = s2.get_available_models()[key][AvailableModelsKey.model]
+    assert model.native_queue_takes(texts[:3]) is True and model.native_queue_takes(texts * 3) is False and model.native_queue_takes([object()]) is False
+    tower = model.text
+    st0 = {k: dict(v) for k, v in tower.queue_stats().items()}
+    assert not st0 or st0.get(True, {}).get("requests", 0) == 0          # lone single queries replayed their graphs
+    merged_before = coalesce.get_coalescer().stats["calls"]
+    errs, out = [], {}
+    start = threading.Barrier(12)
+
+    def worker(t):
+        try:
+            start.wait(30)
+            for c in range(10):
+                pick = [(7 * t + 3 * c + j) % len(texts) for j in range(1 + (t + c) % 3)]
+                out[(t, c)] = (pick, s2.vectorise_ndarray(name, [texts[i] for i in pick], **kw))
+        except BaseException as e:  # noqa: BLE001
+            errs.append((t, e))
+    ts = [threading.Thread(target=worker, args=(t,)) for t in range(12)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(180)
+    assert not errs, errs
+    for pick, rows in out.values():
+        assert rows.shape == (len(pick), lone.shape[1]) and _cos_err(rows, lone[pick]) < 1e-4
+    st = tower.queue_stats()[True]
+    assert st["requests"] >= 60 and st["failed_calls"] == 0 and st["calls"] < st["requests"], st
+    assert coalesce.get_coalescer().stats["calls"] == merged_before        # the Python coalescer saw none of them
+    # MARQO_AMD_COALESCE_US set explicitly: the operator's choice wins, the coalescer merges as before
+    monkeypatch.setenv("MARQO_AMD_COALESCE_US", "500")
+    r = s2.vectorise_ndarray(name, texts[:2], **kw)
+    assert _cos_err(r, lone[:2]) < 1e-4
