@@ -887,8 +887,8 @@ class VitTower(_TowerBase):
             enc.mlp_glu, enc.act, enc.mlp_ln_dim = (2 if EVA_GLU_EPILOGUE else 1), L.MQ_ACT_SILU, arch.mlp_dim     # 2: fc1 rows interleaved 16 by 16 (_eva_blocks), the product in the GEMM's epilogue
             enc.d_rope_table, enc.rope_prefix = self._rope, 1
         self.max_images_per_call = max(1, MAX_ROWS_PER_CALL // arch.tokens)
-        self.n_streams = max(1, int(os.environ.get("MARQO_AMD_STREAMS", "1")))
-        self._side: list = []
+        # (rounds 1-6 kept a knob here that split a call into k sub-batches on k HIP streams; measured on the round-6 kernels: 256 images 93.1 k ->
+        # 68.9 k embeddings/s at k = 2, 62.5 k at k = 3 — persistent GEMM grids leave a second stream nothing to fill — profiles/r08a_*; removed)
         if precision == "fp8":
             self._enable_fp8(self._blocks, arch.layers, W, _ceil64(arch.mlp_dim))
         self.cfg.enc.residual_stream = 2
@@ -900,7 +900,6 @@ class VitTower(_TowerBase):
         return self.tune_residual_stream(lambda: self.encode_u8(u8))
 
     def _run(self, kind: str, pixels: Tensor, normalize: bool) -> Tensor:
-        fn = self.lib.mq_encode_image_u8 if kind == "u8" else self.lib.mq_encode_image_f32   # (the multi-stream experiment below)
         n = pixels.shape[0]
         if n == 1 and self._graphs_ok():
             with self._lock, torch.cuda.device(self.device):
@@ -914,28 +913,6 @@ class VitTower(_TowerBase):
                 if g is not None:
                     return g(pixels)
         out = torch.empty(n, self.arch.out_dim, dtype=torch.float32, device=self.device)
-        k = self.n_streams
-        if k > 1 and n >= 2 * k:
-            # independent images: run k sub-batches on k HIP streams so that one sub-batch's kernels fill the tail /
-            # prologue / epilogue bubbles of the other's (every kernel of the tower is a dependent chain on ONE stream)
-            with self._lock, torch.cuda.device(self.device):
-                cur = torch.cuda.current_stream(self.device)
-                start = torch.cuda.Event()
-                start.record(cur)
-                if len(self._side) < k:
-                    self._side = [(torch.cuda.Stream(self.device), [None]) for _ in range(k)]
-                bounds = [(j * n // k, (j + 1) * n // k) for j in range(k)]
-                for (a, b), (st, ws_box) in zip(bounds, self._side):
-                    st.wait_event(start)
-                    need = self.lib.mq_vit_workspace_bytes(C.byref(self.cfg), b - a)
-                    if ws_box[0] is None or ws_box[0].numel() < need:
-                        ws_box[0] = torch.empty(int(need * 1.25) + 256, dtype=torch.uint8, device=self.device)
-                    L.check(fn(C.byref(self.cfg), C.byref(self.w), pixels[a:b].data_ptr(), b - a, out[a:b].data_ptr(),
-                               1 if normalize else 0, ws_box[0].data_ptr(), ws_box[0].numel(), st.cuda_stream), "mq_encode_image")
-                    done = torch.cuda.Event()
-                    done.record(st)
-                    cur.wait_event(done)
-            return out
         with torch.cuda.device(self.device), _large_call(self.device, n * self.arch.tokens):
             for i in range(0, n, self.max_images_per_call):
                 m = min(self.max_images_per_call, n - i)
