@@ -1,7 +1,7 @@
 """Python face of the native request queue (`mq_queue_*`, csrc/queue.hip, ABI 14): concurrent small text calls of one tower are merged into ONE tower
 call on worker threads that never hold the interpreter lock.
 
-Where the reference has this load: up to 8 indexing + 8 search request threads (/root/reference/src/marqo/api/configs.py:27-28), each calling
+Where the reference has this load: up to 8 indexing + 8 search request threads (reference: src/marqo/api/configs.py:27-28), each calling
 `vectorise()` with one query or the chunks of one document field (src/marqo/core/inference/tensor_fields_container.py:179-223).  A caller tokenises
 its own texts on its own thread and blocks inside `mq_queue_encode` (ctypes drops the GIL around the call); packing, H2D, the ~100 launches of the tower
 pass, D2H and the wake-up are native.  The Python-level coalescer (s2_inference/coalesce.py) stays for everything that has no queue (image calls, loaders
