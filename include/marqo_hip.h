@@ -697,7 +697,8 @@ typedef struct mq_queue_cfg {
     int32_t normalize;   /* != 0: L2-normalised rows */
     int32_t depth;       /* worker threads = merged calls in flight: 1..4 (2: one call's host part runs under the other's GPU part) */
     int32_t window_us;   /* see above; 0 = a group never waits */
-    int32_t reserved;
+    int32_t graphs;      /* != 0: a group of ONE sequence (the search path's lone query) replays a hipGraph of its token count, captured at the second
+                          * call of that count on a worker (~100 dependent small launches: 0.45 ms enqueued one by one, 0.3 ms as a graph) */
 } mq_queue_cfg;
 typedef struct mq_queue_stats {
     uint64_t requests;            /* served (mq_queue_encode calls that reached a worker) */
@@ -706,6 +707,8 @@ typedef struct mq_queue_stats {
     uint64_t failed_calls;
     uint64_t sequences, rows;     /* totals over all calls */
     uint64_t max_call_sequences;  /* the largest group so far */
+    uint64_t graphs;              /* single-sequence launch sequences captured */
+    uint64_t graph_replays;       /* tower calls that were one hipGraphLaunch */
 } mq_queue_stats;
 int mq_queue_create(const mq_queue_cfg* cfg, const void* tower_cfg, const void* tower_weights, mq_queue** out);
 int mq_queue_encode(mq_queue* q, const int32_t* h_ids, const int32_t* h_lens, int64_t nseq, float* h_out);

@@ -132,12 +132,12 @@ class SentencePieceVocab(C.Structure):
 class QueueCfg(C.Structure):
     """mq_queue_cfg (ABI 14): the native request queue of a text tower (csrc/queue.hip)"""
     _fields_ = [("kind", C.c_int32), ("device", C.c_int32), ("max_seqs", C.c_int32), ("max_rows", C.c_int32), ("normalize", C.c_int32),
-                ("depth", C.c_int32), ("window_us", C.c_int32), ("reserved", C.c_int32)]
+                ("depth", C.c_int32), ("window_us", C.c_int32), ("graphs", C.c_int32)]
 
 
 class QueueStats(C.Structure):
     _fields_ = [("requests", C.c_uint64), ("calls", C.c_uint64), ("merged_calls", C.c_uint64), ("failed_calls", C.c_uint64),
-                ("sequences", C.c_uint64), ("rows", C.c_uint64), ("max_call_sequences", C.c_uint64)]
+                ("sequences", C.c_uint64), ("rows", C.c_uint64), ("max_call_sequences", C.c_uint64), ("graphs", C.c_uint64), ("graph_replays", C.c_uint64)]
 
 
 QUEUE_CLIP_TEXT, QUEUE_BERT = 0, 1

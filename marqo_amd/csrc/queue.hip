@@ -23,6 +23,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "common.h"
@@ -40,8 +41,16 @@ struct QRequest {
     std::chrono::steady_clock::time_point t_in;
 };
 
+struct QGraph {           // the captured launch sequence of ONE sequence of a given token count on a lane (its buffers and stream are baked in)
+    hipGraphExec_t exec = nullptr;
+    int seen = 0;
+    bool failed = false;
+};
+constexpr size_t MAX_GRAPHS_PER_LANE = 160;
+
 struct QLane {            // one worker: everything a merged call touches is its own
     hipStream_t stream = nullptr;
+    std::unordered_map<int, QGraph> graphs;
     int32_t *d_ids = nullptr, *d_cu = nullptr;
     float* d_out = nullptr;
     void* d_ws = nullptr;
@@ -71,6 +80,9 @@ struct mq_queue {
 namespace {
 
 void lane_free(QLane& ln) {
+    for (auto& kv : ln.graphs)
+        if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+    ln.graphs.clear();
     if (ln.stream) (void)hipStreamDestroy(ln.stream);
     if (ln.d_ids) (void)hipFree(ln.d_ids);
     if (ln.d_cu) (void)hipFree(ln.d_cu);
@@ -99,15 +111,8 @@ int lane_alloc(mq_queue* q, QLane& ln) {
     return MQ_OK;
 }
 
-// one merged tower call for `group` on the lane's stream; every request's rows are in its own buffer when this returns MQ_OK
-int lane_execute(mq_queue* q, QLane& ln, const std::vector<QRequest*>& group) {
-    int64_t nseq = 0, rows = 0;
-    ln.h_cu[0] = 0;
-    for (const QRequest* r : group) {
-        for (int64_t s = 0; s < r->nseq; ++s, ++nseq) ln.h_cu[nseq + 1] = ln.h_cu[nseq] + r->lens[s];
-        std::memcpy(ln.h_ids + rows, r->ids, (size_t)r->rows * 4);
-        rows += r->rows;
-    }
+// H2D of the staged ids / cu_seqlens, the tower pass, D2H of the rows: everything one call ENQUEUES on the lane's stream (eagerly, or into a capture)
+int lane_enqueue(mq_queue* q, QLane& ln, int64_t nseq, int64_t rows) {
     const size_t D = (size_t)q->out_dim;
     MQ_CHECK_HIP(hipMemcpyAsync(ln.d_ids, ln.h_ids, (size_t)rows * 4, hipMemcpyHostToDevice, ln.stream));
     MQ_CHECK_HIP(hipMemcpyAsync(ln.d_cu, ln.h_cu, (size_t)(nseq + 1) * 4, hipMemcpyHostToDevice, ln.stream));
@@ -118,7 +123,71 @@ int lane_execute(mq_queue* q, QLane& ln, const std::vector<QRequest*>& group) {
         MQ_TRY(mq_encode_bert((const mq_bert_cfg*)q->tower_cfg, (const mq_bert_weights*)q->tower_w, ln.d_ids, ln.d_cu, ln.h_cu, nseq, ln.d_out,
                               q->cfg.normalize, ln.d_ws, ln.ws_bytes, ln.stream));
     MQ_CHECK_HIP(hipMemcpyAsync(ln.h_out, ln.d_out, (size_t)nseq * D * 4, hipMemcpyDeviceToHost, ln.stream));
-    MQ_CHECK_HIP(hipStreamSynchronize(ln.stream));
+    return MQ_OK;
+}
+
+// A group of ONE sequence (the search path's lone query) is ~100 dependent small launches: enqueued eagerly the GPU waits for the host between them
+// (~0.45 ms), replayed as a hipGraph it does not (~0.3 ms).  The first call of a token count runs eagerly (one-time host work of the kernels it meets —
+// function attributes — happens outside any capture), the second is captured and instantiated, later ones are one hipGraphLaunch.  The lane's staging,
+// device buffers and stream are the graph's operands; the tower's cfg / weights are baked in as they are at capture (the Python tower re-creates its queue
+// when its policy fields change).  Returns 1 = the rows are in h_out, 0 = not taken (run eagerly), < 0 = error.
+int lane_graph_one(mq_queue* q, QLane& ln, int rows, bool* stream_poisoned) {
+    if (!q->cfg.graphs) return 0;
+    auto it = ln.graphs.find(rows);
+    if (it == ln.graphs.end()) {
+        if (ln.graphs.size() >= MAX_GRAPHS_PER_LANE) return 0;
+        it = ln.graphs.emplace(rows, QGraph{}).first;
+    }
+    QGraph& g = it->second;
+    if (g.failed) return 0;
+    if (!g.exec) {
+        if (g.seen++ == 0) return 0;                       // first sighting: eagerly
+        hipGraph_t graph = nullptr;
+        if (hipStreamBeginCapture(ln.stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { g.failed = true; (void)hipGetLastError(); return 0; }
+        const int rc = lane_enqueue(q, ln, 1, rows);
+        const hipError_t e = hipStreamEndCapture(ln.stream, &graph);
+        if (rc != MQ_OK || e != hipSuccess || !graph || hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+            if (graph) (void)hipGraphDestroy(graph);
+            g.exec = nullptr;
+            g.failed = true;                               // this token count keeps launching eagerly
+            (void)hipGetLastError();
+            *stream_poisoned = true;
+            return 0;
+        }
+        (void)hipGraphDestroy(graph);
+        std::lock_guard<std::mutex> lk(q->mu);
+        ++q->st.graphs;
+    }
+    if (hipGraphLaunch(g.exec, ln.stream) != hipSuccess || hipStreamSynchronize(ln.stream) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipGraphExecDestroy(g.exec);
+        g.exec = nullptr;
+        g.failed = true;
+        return 0;
+    }
+    return 1;
+}
+
+// one merged tower call for `group` on the lane's stream; every request's rows are in its own buffer when this returns MQ_OK
+int lane_execute(mq_queue* q, QLane& ln, const std::vector<QRequest*>& group) {
+    int64_t nseq = 0, rows = 0;
+    ln.h_cu[0] = 0;
+    for (const QRequest* r : group) {
+        for (int64_t s = 0; s < r->nseq; ++s, ++nseq) ln.h_cu[nseq + 1] = ln.h_cu[nseq] + r->lens[s];
+        std::memcpy(ln.h_ids + rows, r->ids, (size_t)r->rows * 4);
+        rows += r->rows;
+    }
+    const size_t D = (size_t)q->out_dim;
+    bool poisoned = false;
+    const int replayed = nseq == 1 ? lane_graph_one(q, ln, (int)rows, &poisoned) : 0;
+    if (replayed < 0) return replayed;
+    if (replayed == 1) {
+        std::lock_guard<std::mutex> lk(q->mu);
+        ++q->st.graph_replays;
+    } else {
+        MQ_TRY(lane_enqueue(q, ln, nseq, rows));
+        MQ_CHECK_HIP(hipStreamSynchronize(ln.stream));
+    }
     size_t off = 0;
     for (QRequest* r : group) {
         std::memcpy(r->out, ln.h_out + off * D, (size_t)r->nseq * D * 4);

@@ -7,7 +7,8 @@ its own texts on its own thread and blocks inside `mq_queue_encode` (ctypes drop
 pass, D2H and the wake-up are native.  The Python-level coalescer (s2_inference/coalesce.py) stays for everything that has no queue (image calls, loaders
 without an engine tower) and steps aside for text calls of a tower that has one.
 
-MARQO_AMD_NATIVE_QUEUE=0 turns the queue off (the coalescer then merges text calls as before round 6); _SEQS / _DEPTH / _WINDOW_US size it."""
+MARQO_AMD_NATIVE_QUEUE=0 turns the queue off (the coalescer then merges text calls as before round 6); _SEQS / _DEPTH / _WINDOW_US size it, _GRAPHS=0 keeps
+lone single queries on the tower's own captured graph."""
 from __future__ import annotations
 
 import ctypes as C
@@ -32,6 +33,8 @@ ENABLED = os.environ.get("MARQO_AMD_NATIVE_QUEUE", "1") != "0"
 MAX_SEQS = _env_int("MARQO_AMD_NATIVE_QUEUE_SEQS", 64, 1, 4096)
 DEPTH = _env_int("MARQO_AMD_NATIVE_QUEUE_DEPTH", 1, 1, 4)
 WINDOW_US = _env_int("MARQO_AMD_NATIVE_QUEUE_WINDOW_US", 100, 0, 100000)
+# a LONE single query goes through the queue too and replays a hipGraph captured on the worker (0 = it keeps the tower's own captured graph, through torch)
+GRAPHS = os.environ.get("MARQO_AMD_NATIVE_QUEUE_GRAPHS", "1") != "0"
 
 
 class TextQueue:
@@ -39,13 +42,14 @@ class TextQueue:
     at every call); thread-safe; recreated in a fork()ed child (worker threads do not survive a fork)."""
 
     def __init__(self, lib, kind: int, cfg, w, device_index: int, out_dim: int, max_len: int, normalize: bool,
-                 max_seqs: int = 0, depth: int = 0, window_us: Optional[int] = None):
+                 max_seqs: int = 0, depth: int = 0, window_us: Optional[int] = None, graphs: Optional[bool] = None):
         self._lib, self._kind, self._cfg, self._w = lib, kind, cfg, w
         self.out_dim, self.max_len = int(out_dim), int(max_len)
         self.max_seqs = int(max_seqs or MAX_SEQS)
         self.max_rows = self.max_seqs * self.max_len
         self._qcfg = L.QueueCfg(kind=kind, device=int(device_index), max_seqs=self.max_seqs, max_rows=self.max_rows, normalize=1 if normalize else 0,
-                                depth=int(depth or DEPTH), window_us=int(WINDOW_US if window_us is None else window_us), reserved=0)
+                                depth=int(depth or DEPTH), window_us=int(WINDOW_US if window_us is None else window_us),
+                                graphs=1 if (GRAPHS if graphs is None else graphs) else 0)
         self._h = C.c_void_p()
         self._pid = os.getpid()
         self._lock = threading.Lock()

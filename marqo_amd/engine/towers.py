@@ -660,6 +660,10 @@ class _TowerBase:
                         setattr(b, name + suffix, None)
         if freed:
             getattr(self, "_graphs", {}).clear()     # captured launch sequences may have baked the folded form in
+            for _, q in (getattr(self, "_queues", None) or {}).values():    # ... and so may the native queues' (engine/native_queue.py)
+                q.close()
+            if getattr(self, "_queues", None):
+                self._queues = {}
         return freed
 
     # towers whose output is ONE row per item (class token / EOT): the last block's out-proj and MLP run on those rows only (towers.hip,
@@ -1068,8 +1072,9 @@ class _TextTowerBase(_TowerBase):
 
     def queue_rows(self, ids_h: np.ndarray, lengths: np.ndarray, normalize: bool, clip: bool) -> Optional[np.ndarray]:
         """the loaders' LEAN small-call path — host ids in, host rows out, no stream context, no torch call, a handful of NumPy calls (with 16
-        request threads in the interpreter every statement here is time the others wait for): this request's rows through the native queue, or None
-        when the call belongs to the regular path (a lone single query: its captured graph; no queue; too many sequences)"""
+        request threads in the interpreter every statement here is time the others wait for): this request's rows through the native queue (a lone
+        single query included: the worker replays a hipGraph of its token count), or None when the call belongs to the regular path (no queue; too
+        many sequences)"""
         n = int(lengths.size)
         if n < 1 or n > NQ.MAX_SEQS:
             return None
@@ -1077,8 +1082,8 @@ class _TextTowerBase(_TowerBase):
             self._active += 1
             alone = self._active == 1
         try:
-            if n == 1 and alone and self._graphs_ok():
-                return None
+            if n == 1 and alone and not NQ.GRAPHS and self._graphs_ok():
+                return None                       # (MARQO_AMD_NATIVE_QUEUE_GRAPHS=0: the lone query replays the tower's own captured graph, through torch)
             q = self._queue(normalize, clip)
             if q is None or not q.takes(n, int(lengths.sum())):
                 return None

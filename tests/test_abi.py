@@ -36,7 +36,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(L.VitWeights) == 11 * 8 and C.sizeof(L.MapHead) == 11 * 8
     assert C.sizeof(L.ClipTextCfg) == ENC + 4 * 4 and C.sizeof(L.ClipTextWeights) == 7 * 8
     assert C.sizeof(L.BertCfg) == ENC + 5 * 4 + 4 and C.sizeof(L.BertWeights) == 9 * 8   # + proj_hidden, out_dim / proj1_w, proj1_b, proj2_w
-    assert C.sizeof(L.QueueCfg) == 8 * 4 and C.sizeof(L.QueueStats) == 7 * 8   # ABI 14: the native request queue
+    assert C.sizeof(L.QueueCfg) == 8 * 4 and C.sizeof(L.QueueStats) == 9 * 8   # ABI 14: the native request queue
 
 
 def test_argument_errors_are_reported_without_a_gpu():
@@ -52,7 +52,7 @@ def test_argument_errors_are_reported_without_a_gpu():
     # ABI 14, the native request queue: arguments are judged before any device is asked for
     h = C.c_void_p()
     assert lib.mq_queue_create(None, None, None, C.byref(h)) == -1 and b"null pointer" in lib.mq_last_error() and not h
-    qc = L.QueueCfg(kind=L.QUEUE_BERT, device=0, max_seqs=0, max_rows=512, normalize=1, depth=2, window_us=0, reserved=0)
+    qc = L.QueueCfg(kind=L.QUEUE_BERT, device=0, max_seqs=0, max_rows=512, normalize=1, depth=2, window_us=0, graphs=0)
     bc, bw = L.BertCfg(), L.BertWeights()
     assert lib.mq_queue_create(C.byref(qc), C.cast(C.byref(bc), C.c_void_p), C.cast(C.byref(bw), C.c_void_p), C.byref(h)) == -1 and not h
     assert b"max_seqs" in lib.mq_last_error()
