@@ -448,7 +448,7 @@ def gemm_roofline(lib, L, run_local, prof_steps, precision, workload_name):
     # HBM-side traffic of the dominant kernel from the committed PMC passes of this same command (tools/gpu_evidence.sh:
     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH doubled per MI355X_MICROARCH.md; PMC cannot be sampled
     # from inside this process).  Bytes per launch, averaged over the GEMM launches like `achieved`.
-    for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
+    for rnd in ("r08f", "r06", "r05", "r04", "r03", "r02", "r01"):
         tpath = os.path.join(ROOT, "profiles", f"{rnd}_traffic_{workload_name}_{precision}.json")
         if not os.path.isfile(tpath):
             continue
