@@ -688,6 +688,10 @@ int mq_weighted_combine(const float* d_emb, int64_t ld, const int32_t* d_rows, c
  *     as long as lone and merged call take the same kernel family (the small-row families end at 320 token rows). */
 #define MQ_QUEUE_CLIP_TEXT 0
 #define MQ_QUEUE_BERT 1
+#define MQ_QUEUE_IMAGE_F32 2 /* an image tower (mq_vit_cfg + mq_vit_weights) on preprocessed images: a request = n DEVICE pointers to fp32 [3, S, S] tensors
+                              * (what the reference's `.preprocess` returns, add_docs.py:130-134) anywhere in HBM; the worker gathers a group's images into
+                              * one batch (device-to-device) and runs ONE mq_encode_image_f32.  max_rows = max_seqs (an image is one "row" here).  The
+                              * images must be complete when mq_queue_encode_images is entered (the workers' streams are not ordered behind any other) */
 typedef struct mq_queue mq_queue;   /* opaque */
 typedef struct mq_queue_cfg {
     int32_t kind;        /* MQ_QUEUE_* */
@@ -712,6 +716,7 @@ typedef struct mq_queue_stats {
 } mq_queue_stats;
 int mq_queue_create(const mq_queue_cfg* cfg, const void* tower_cfg, const void* tower_weights, mq_queue** out);
 int mq_queue_encode(mq_queue* q, const int32_t* h_ids, const int32_t* h_lens, int64_t nseq, float* h_out);
+int mq_queue_encode_images(mq_queue* q, const float* const* d_images, int64_t n, float* h_out);   /* MQ_QUEUE_IMAGE_F32: d_images = HOST array of n device pointers */
 int mq_queue_get_stats(mq_queue* q, mq_queue_stats* out);
 /* serves what is still pending, joins the workers, frees the staging; no mq_queue_encode may be entered after this starts */
 int mq_queue_destroy(mq_queue* q);

@@ -140,7 +140,7 @@ class QueueStats(C.Structure):
                 ("sequences", C.c_uint64), ("rows", C.c_uint64), ("max_call_sequences", C.c_uint64), ("graphs", C.c_uint64), ("graph_replays", C.c_uint64)]
 
 
-QUEUE_CLIP_TEXT, QUEUE_BERT = 0, 1
+QUEUE_CLIP_TEXT, QUEUE_BERT, QUEUE_IMAGE_F32 = 0, 1, 2
 
 _P = C.c_void_p
 _SIGNATURES = {
@@ -222,6 +222,7 @@ _SIGNATURES = {
     "mq_weighted_combine": (C.c_int, [_P, C.c_int64, _P, _P, _P, C.c_int64, C.c_int32, C.c_int32, _P, _P]),
     "mq_queue_create": (C.c_int, [C.POINTER(QueueCfg), _P, _P, C.POINTER(_P)]),
     "mq_queue_encode": (C.c_int, [_P, _P, _P, C.c_int64, _P]),
+    "mq_queue_encode_images": (C.c_int, [_P, _P, C.c_int64, _P]),
     "mq_queue_get_stats": (C.c_int, [_P, C.POINTER(QueueStats)]),
     "mq_queue_destroy": (C.c_int, [_P]),
     "mq_tune": (C.c_int, [C.c_char_p, C.c_int]),

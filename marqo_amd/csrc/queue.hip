@@ -33,6 +33,7 @@ namespace {
 struct QRequest {
     const int32_t* ids;
     const int32_t* lens;
+    const float* const* imgs;   // MQ_QUEUE_IMAGE_F32: nseq device pointers to [3, S, S] fp32 images (ids / lens unused)
     int64_t nseq, rows;
     float* out;
     int status = MQ_OK;
@@ -52,6 +53,7 @@ struct QLane {            // one worker: everything a merged call touches is its
     hipStream_t stream = nullptr;
     std::unordered_map<int, QGraph> graphs;
     int32_t *d_ids = nullptr, *d_cu = nullptr;
+    float* d_in = nullptr;                       // MQ_QUEUE_IMAGE_F32: the gathered batch [max_seqs, 3, S, S]
     float* d_out = nullptr;
     void* d_ws = nullptr;
     size_t ws_bytes = 0;
@@ -67,6 +69,7 @@ struct mq_queue {
     const void* tower_cfg;
     const void* tower_w;
     int32_t max_len = 0, vocab = 0, out_dim = 0;
+    size_t img_elems = 0;        // MQ_QUEUE_IMAGE_F32: 3 * S * S
     std::mutex mu;
     std::condition_variable cv_work, cv_done;
     std::deque<QRequest*> pending;
@@ -86,6 +89,7 @@ void lane_free(QLane& ln) {
     if (ln.stream) (void)hipStreamDestroy(ln.stream);
     if (ln.d_ids) (void)hipFree(ln.d_ids);
     if (ln.d_cu) (void)hipFree(ln.d_cu);
+    if (ln.d_in) (void)hipFree(ln.d_in);
     if (ln.d_out) (void)hipFree(ln.d_out);
     if (ln.d_ws) (void)hipFree(ln.d_ws);
     if (ln.h_ids) (void)hipHostFree(ln.h_ids);
@@ -96,17 +100,23 @@ void lane_free(QLane& ln) {
 
 int lane_alloc(mq_queue* q, QLane& ln) {
     const size_t rows = (size_t)q->cfg.max_rows, seqs = (size_t)q->cfg.max_seqs, D = (size_t)q->out_dim;
-    ln.ws_bytes = q->cfg.kind == MQ_QUEUE_CLIP_TEXT ? mq_clip_text_workspace_bytes((const mq_clip_text_cfg*)q->tower_cfg, (int64_t)rows, (int64_t)seqs)
-                                                    : mq_bert_workspace_bytes((const mq_bert_cfg*)q->tower_cfg, (int64_t)rows, (int64_t)seqs);
+    const bool image = q->cfg.kind == MQ_QUEUE_IMAGE_F32;
+    ln.ws_bytes = image ? mq_vit_workspace_bytes((const mq_vit_cfg*)q->tower_cfg, (int64_t)seqs)
+                  : q->cfg.kind == MQ_QUEUE_CLIP_TEXT ? mq_clip_text_workspace_bytes((const mq_clip_text_cfg*)q->tower_cfg, (int64_t)rows, (int64_t)seqs)
+                                                      : mq_bert_workspace_bytes((const mq_bert_cfg*)q->tower_cfg, (int64_t)rows, (int64_t)seqs);
     MQ_CHECK_ARG(ln.ws_bytes > 0, "mq_queue_create: the tower reports no workspace for %zu rows / %zu sequences (bad tower cfg?)", rows, seqs);
     ln.ws_bytes += 256;
     MQ_CHECK_HIP(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
-    MQ_CHECK_HIP(hipMalloc((void**)&ln.d_ids, rows * 4));
-    MQ_CHECK_HIP(hipMalloc((void**)&ln.d_cu, (seqs + 1) * 4));
+    if (image) {
+        MQ_CHECK_HIP(hipMalloc((void**)&ln.d_in, seqs * q->img_elems * 4));
+    } else {
+        MQ_CHECK_HIP(hipMalloc((void**)&ln.d_ids, rows * 4));
+        MQ_CHECK_HIP(hipMalloc((void**)&ln.d_cu, (seqs + 1) * 4));
+        MQ_CHECK_HIP(hipHostMalloc((void**)&ln.h_ids, rows * 4, hipHostMallocDefault));
+        MQ_CHECK_HIP(hipHostMalloc((void**)&ln.h_cu, (seqs + 1) * 4, hipHostMallocDefault));
+    }
     MQ_CHECK_HIP(hipMalloc((void**)&ln.d_out, seqs * D * 4));
     MQ_CHECK_HIP(hipMalloc(&ln.d_ws, ln.ws_bytes));
-    MQ_CHECK_HIP(hipHostMalloc((void**)&ln.h_ids, rows * 4, hipHostMallocDefault));
-    MQ_CHECK_HIP(hipHostMalloc((void**)&ln.h_cu, (seqs + 1) * 4, hipHostMallocDefault));
     MQ_CHECK_HIP(hipHostMalloc((void**)&ln.h_out, seqs * D * 4, hipHostMallocDefault));
     return MQ_OK;
 }
@@ -114,14 +124,19 @@ int lane_alloc(mq_queue* q, QLane& ln) {
 // H2D of the staged ids / cu_seqlens, the tower pass, D2H of the rows: everything one call ENQUEUES on the lane's stream (eagerly, or into a capture)
 int lane_enqueue(mq_queue* q, QLane& ln, int64_t nseq, int64_t rows) {
     const size_t D = (size_t)q->out_dim;
-    MQ_CHECK_HIP(hipMemcpyAsync(ln.d_ids, ln.h_ids, (size_t)rows * 4, hipMemcpyHostToDevice, ln.stream));
-    MQ_CHECK_HIP(hipMemcpyAsync(ln.d_cu, ln.h_cu, (size_t)(nseq + 1) * 4, hipMemcpyHostToDevice, ln.stream));
-    if (q->cfg.kind == MQ_QUEUE_CLIP_TEXT)
-        MQ_TRY(mq_encode_clip_text((const mq_clip_text_cfg*)q->tower_cfg, (const mq_clip_text_weights*)q->tower_w, ln.d_ids, ln.d_cu, ln.h_cu, nseq, nullptr,
-                                   ln.d_out, q->cfg.normalize, ln.d_ws, ln.ws_bytes, ln.stream));
-    else
-        MQ_TRY(mq_encode_bert((const mq_bert_cfg*)q->tower_cfg, (const mq_bert_weights*)q->tower_w, ln.d_ids, ln.d_cu, ln.h_cu, nseq, ln.d_out,
-                              q->cfg.normalize, ln.d_ws, ln.ws_bytes, ln.stream));
+    if (q->cfg.kind == MQ_QUEUE_IMAGE_F32) {   // (the gather into d_in went ahead on this stream: its sources differ from call to call, so it is never part of a graph)
+        MQ_TRY(mq_encode_image_f32((const mq_vit_cfg*)q->tower_cfg, (const mq_vit_weights*)q->tower_w, ln.d_in, nseq, ln.d_out, q->cfg.normalize, ln.d_ws,
+                                   ln.ws_bytes, ln.stream));
+    } else {
+        MQ_CHECK_HIP(hipMemcpyAsync(ln.d_ids, ln.h_ids, (size_t)rows * 4, hipMemcpyHostToDevice, ln.stream));
+        MQ_CHECK_HIP(hipMemcpyAsync(ln.d_cu, ln.h_cu, (size_t)(nseq + 1) * 4, hipMemcpyHostToDevice, ln.stream));
+        if (q->cfg.kind == MQ_QUEUE_CLIP_TEXT)
+            MQ_TRY(mq_encode_clip_text((const mq_clip_text_cfg*)q->tower_cfg, (const mq_clip_text_weights*)q->tower_w, ln.d_ids, ln.d_cu, ln.h_cu, nseq, nullptr,
+                                       ln.d_out, q->cfg.normalize, ln.d_ws, ln.ws_bytes, ln.stream));
+        else
+            MQ_TRY(mq_encode_bert((const mq_bert_cfg*)q->tower_cfg, (const mq_bert_weights*)q->tower_w, ln.d_ids, ln.d_cu, ln.h_cu, nseq, ln.d_out,
+                                  q->cfg.normalize, ln.d_ws, ln.ws_bytes, ln.stream));
+    }
     MQ_CHECK_HIP(hipMemcpyAsync(ln.h_out, ln.d_out, (size_t)nseq * D * 4, hipMemcpyDeviceToHost, ln.stream));
     return MQ_OK;
 }
@@ -131,7 +146,7 @@ int lane_enqueue(mq_queue* q, QLane& ln, int64_t nseq, int64_t rows) {
 // function attributes — happens outside any capture), the second is captured and instantiated, later ones are one hipGraphLaunch.  The lane's staging,
 // device buffers and stream are the graph's operands; the tower's cfg / weights are baked in as they are at capture (the Python tower re-creates its queue
 // when its policy fields change).  Returns 1 = the rows are in h_out, 0 = not taken (run eagerly), < 0 = error.
-int lane_graph_one(mq_queue* q, QLane& ln, int rows, bool* stream_poisoned) {
+int lane_graph_one(mq_queue* q, QLane& ln, int rows) {
     if (!q->cfg.graphs) return 0;
     auto it = ln.graphs.find(rows);
     if (it == ln.graphs.end()) {
@@ -151,7 +166,6 @@ int lane_graph_one(mq_queue* q, QLane& ln, int rows, bool* stream_poisoned) {
             g.exec = nullptr;
             g.failed = true;                               // this token count keeps launching eagerly
             (void)hipGetLastError();
-            *stream_poisoned = true;
             return 0;
         }
         (void)hipGraphDestroy(graph);
@@ -171,15 +185,22 @@ int lane_graph_one(mq_queue* q, QLane& ln, int rows, bool* stream_poisoned) {
 // one merged tower call for `group` on the lane's stream; every request's rows are in its own buffer when this returns MQ_OK
 int lane_execute(mq_queue* q, QLane& ln, const std::vector<QRequest*>& group) {
     int64_t nseq = 0, rows = 0;
-    ln.h_cu[0] = 0;
-    for (const QRequest* r : group) {
-        for (int64_t s = 0; s < r->nseq; ++s, ++nseq) ln.h_cu[nseq + 1] = ln.h_cu[nseq] + r->lens[s];
-        std::memcpy(ln.h_ids + rows, r->ids, (size_t)r->rows * 4);
-        rows += r->rows;
+    if (q->cfg.kind == MQ_QUEUE_IMAGE_F32) {
+        // the callers' images ([3, S, S] fp32 each, anywhere in HBM: slots of the loaders' preprocess slab) side by side into the lane's batch
+        for (const QRequest* r : group)
+            for (int64_t i = 0; i < r->nseq; ++i, ++nseq)
+                MQ_CHECK_HIP(hipMemcpyAsync(ln.d_in + (size_t)nseq * q->img_elems, r->imgs[i], q->img_elems * 4, hipMemcpyDeviceToDevice, ln.stream));
+        rows = nseq;
+    } else {
+        ln.h_cu[0] = 0;
+        for (const QRequest* r : group) {
+            for (int64_t s = 0; s < r->nseq; ++s, ++nseq) ln.h_cu[nseq + 1] = ln.h_cu[nseq] + r->lens[s];
+            std::memcpy(ln.h_ids + rows, r->ids, (size_t)r->rows * 4);
+            rows += r->rows;
+        }
     }
     const size_t D = (size_t)q->out_dim;
-    bool poisoned = false;
-    const int replayed = nseq == 1 ? lane_graph_one(q, ln, (int)rows, &poisoned) : 0;
+    const int replayed = nseq == 1 ? lane_graph_one(q, ln, (int)rows) : 0;
     if (replayed < 0) return replayed;
     if (replayed == 1) {
         std::lock_guard<std::mutex> lk(q->mu);
@@ -258,12 +279,21 @@ void lane_run(mq_queue* q, int lane_idx) {
 extern "C" int mq_queue_create(const mq_queue_cfg* cfg, const void* tower_cfg, const void* tower_weights, mq_queue** out) {
     MQ_CHECK_ARG(cfg && tower_cfg && tower_weights && out, "mq_queue_create: null pointer");
     *out = nullptr;
-    MQ_CHECK_ARG(cfg->kind == MQ_QUEUE_CLIP_TEXT || cfg->kind == MQ_QUEUE_BERT, "mq_queue_create: kind %d is neither MQ_QUEUE_CLIP_TEXT nor MQ_QUEUE_BERT", cfg->kind);
+    MQ_CHECK_ARG(cfg->kind == MQ_QUEUE_CLIP_TEXT || cfg->kind == MQ_QUEUE_BERT || cfg->kind == MQ_QUEUE_IMAGE_F32,
+                 "mq_queue_create: kind %d is none of MQ_QUEUE_CLIP_TEXT / MQ_QUEUE_BERT / MQ_QUEUE_IMAGE_F32", cfg->kind);
     MQ_CHECK_ARG(cfg->max_seqs >= 1 && cfg->max_seqs <= 4096, "mq_queue_create: max_seqs %d outside [1, 4096]", cfg->max_seqs);
     MQ_CHECK_ARG(cfg->depth >= 1 && cfg->depth <= 4, "mq_queue_create: depth %d outside [1, 4]", cfg->depth);
     MQ_CHECK_ARG(cfg->window_us >= 0 && cfg->window_us <= 100000, "mq_queue_create: window_us %d outside [0, 100000]", cfg->window_us);
     int32_t max_len, vocab, out_dim;
-    if (cfg->kind == MQ_QUEUE_CLIP_TEXT) {
+    size_t img_elems = 0;
+    if (cfg->kind == MQ_QUEUE_IMAGE_F32) {      // a "sequence" is an image, a "row" too: max_rows = max_seqs
+        const mq_vit_cfg* t = (const mq_vit_cfg*)tower_cfg;
+        max_len = 1;
+        vocab = 1;
+        out_dim = t->out_dim;
+        MQ_CHECK_ARG(t->image_size >= 1 && t->image_size <= 4096, "mq_queue_create: image tower cfg with image_size %d", t->image_size);
+        img_elems = (size_t)3 * t->image_size * t->image_size;
+    } else if (cfg->kind == MQ_QUEUE_CLIP_TEXT) {
         const mq_clip_text_cfg* t = (const mq_clip_text_cfg*)tower_cfg;
         max_len = t->ctx + (t->cls_pos > 0 ? 1 : 0);
         vocab = t->vocab;
@@ -291,6 +321,7 @@ extern "C" int mq_queue_create(const mq_queue_cfg* cfg, const void* tower_cfg, c
     q->max_len = max_len;
     q->vocab = vocab;
     q->out_dim = out_dim;
+    q->img_elems = img_elems;
     q->lanes.resize((size_t)cfg->depth);
     int rc = MQ_OK;
     for (QLane& ln : q->lanes)
@@ -306,8 +337,46 @@ extern "C" int mq_queue_create(const mq_queue_cfg* cfg, const void* tower_cfg, c
     return MQ_OK;
 }
 
+namespace {
+// hand a validated request to the workers and block until its rows are in r.out
+int submit_and_wait(mq_queue* q, QRequest& r, const char* who) {
+    r.t_in = std::chrono::steady_clock::now();
+    {
+        std::unique_lock<std::mutex> lk(q->mu);
+        if (q->stop) {
+            mq_set_error("%s: the queue is being destroyed", who);
+            return MQ_ERR_INVALID;
+        }
+        q->pending.push_back(&r);
+        q->pending_seqs += r.nseq;
+        if (q->lanes.size() > 1) q->cv_work.notify_all();   // (a lane that is holding a group back for company must not swallow the only wake-up)
+        else q->cv_work.notify_one();
+        q->cv_done.wait(lk, [&] { return r.done; });
+    }
+    if (r.status != MQ_OK) mq_set_error("%s: the merged tower call failed: %s", who, r.err.c_str());
+    return r.status;
+}
+}  // namespace
+
+extern "C" int mq_queue_encode_images(mq_queue* q, const float* const* d_images, int64_t n, float* h_out) {
+    MQ_CHECK_ARG(q, "mq_queue_encode_images: null queue");
+    MQ_CHECK_ARG(q->cfg.kind == MQ_QUEUE_IMAGE_F32, "mq_queue_encode_images: this queue serves a text tower (kind %d)", q->cfg.kind);
+    if (n == 0) return MQ_OK;
+    MQ_CHECK_ARG(d_images && h_out, "mq_queue_encode_images: null buffer");
+    MQ_CHECK_ARG(n > 0 && n <= q->cfg.max_seqs, "mq_queue_encode_images: %ld images, the queue takes 1..%d per request", (long)n, q->cfg.max_seqs);
+    for (int64_t i = 0; i < n; ++i)
+        MQ_CHECK_ARG(d_images[i] && ((uintptr_t)d_images[i] & 15) == 0, "mq_queue_encode_images: image %ld is null or not 16-byte aligned", (long)i);
+    QRequest r{};
+    r.imgs = d_images;
+    r.nseq = n;
+    r.rows = n;
+    r.out = h_out;
+    return submit_and_wait(q, r, "mq_queue_encode_images");
+}
+
 extern "C" int mq_queue_encode(mq_queue* q, const int32_t* h_ids, const int32_t* h_lens, int64_t nseq, float* h_out) {
     MQ_CHECK_ARG(q, "mq_queue_encode: null queue");
+    MQ_CHECK_ARG(q->cfg.kind != MQ_QUEUE_IMAGE_F32, "mq_queue_encode: this queue serves an image tower (mq_queue_encode_images)");
     if (nseq == 0) return MQ_OK;
     MQ_CHECK_ARG(h_ids && h_lens && h_out, "mq_queue_encode: null buffer");
     MQ_CHECK_ARG(nseq > 0 && nseq <= q->cfg.max_seqs, "mq_queue_encode: %ld sequences, the queue takes 1..%d per request", (long)nseq, q->cfg.max_seqs);
@@ -319,26 +388,13 @@ extern "C" int mq_queue_encode(mq_queue* q, const int32_t* h_ids, const int32_t*
     MQ_CHECK_ARG(rows <= q->cfg.max_rows, "mq_queue_encode: %ld token rows, the queue takes up to %d per request", (long)rows, q->cfg.max_rows);
     // an id outside the embedding table would fault on the device and take every request of the merged call with it: refused here, per request
     for (int64_t i = 0; i < rows; ++i) MQ_CHECK_ARG(h_ids[i] >= 0 && h_ids[i] < q->vocab, "mq_queue_encode: token id %d at %ld outside [0, %d)", h_ids[i], (long)i, q->vocab);
-    QRequest r;
+    QRequest r{};
     r.ids = h_ids;
     r.lens = h_lens;
     r.nseq = nseq;
     r.rows = rows;
     r.out = h_out;
-    r.t_in = std::chrono::steady_clock::now();
-    {
-        std::unique_lock<std::mutex> lk(q->mu);
-        if (q->stop) {
-            mq_set_error("mq_queue_encode: the queue is being destroyed");
-            return MQ_ERR_INVALID;
-        }
-        q->pending.push_back(&r);
-        q->pending_seqs += nseq;
-        q->cv_work.notify_one();
-        q->cv_done.wait(lk, [&] { return r.done; });
-    }
-    if (r.status != MQ_OK) mq_set_error("mq_queue_encode: the merged tower call failed: %s", r.err.c_str());
-    return r.status;
+    return submit_and_wait(q, r, "mq_queue_encode");
 }
 
 extern "C" int mq_queue_get_stats(mq_queue* q, mq_queue_stats* out) {

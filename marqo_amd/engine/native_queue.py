@@ -31,10 +31,20 @@ def _env_int(name: str, default: int, lo: int, hi: int) -> int:
 ENABLED = os.environ.get("MARQO_AMD_NATIVE_QUEUE", "1") != "0"
 # a request of more sequences than this goes the direct way (it fills enough of the chip on its own, and the merged call's staging is sized by it)
 MAX_SEQS = _env_int("MARQO_AMD_NATIVE_QUEUE_SEQS", 64, 1, 4096)
+# token rows per merged call (and per request): bounds the queue's device scratch (sized once, for the largest call) on towers with long contexts —
+# 64 sequences x 512 positions would reserve a 32 k-row workspace per (tower, normalize) for calls that are a few hundred rows in practice
+MAX_ROWS = _env_int("MARQO_AMD_NATIVE_QUEUE_ROWS", 16384, 64, 1 << 18)
 DEPTH = _env_int("MARQO_AMD_NATIVE_QUEUE_DEPTH", 1, 1, 4)
 WINDOW_US = _env_int("MARQO_AMD_NATIVE_QUEUE_WINDOW_US", 100, 0, 100000)
 # a LONE single query goes through the queue too and replays a hipGraph captured on the worker (0 = it keeps the tower's own captured graph, through torch)
 GRAPHS = os.environ.get("MARQO_AMD_NATIVE_QUEUE_GRAPHS", "1") != "0"
+
+
+# image towers: a request of at most this many preprocessed images goes through the queue (the per-document, per-field calls of an unmodified Marqo:
+# 1-4 tensors from `.preprocess`); a merged call carries up to IMAGE_MAX_SEQS.  Larger lists are the slab path's (open_clip_model._encode_image).
+IMAGE_REQUEST_MAX = _env_int("MARQO_AMD_NATIVE_QUEUE_IMAGE_REQUEST", 8, 0, 64)
+IMAGE_MAX_SEQS = _env_int("MARQO_AMD_NATIVE_QUEUE_IMAGE_SEQS", 32, 1, 256)
+IMAGE_DEPTH = _env_int("MARQO_AMD_NATIVE_QUEUE_IMAGE_DEPTH", 1, 1, 4)
 
 
 class TextQueue:
@@ -46,7 +56,7 @@ class TextQueue:
         self._lib, self._kind, self._cfg, self._w = lib, kind, cfg, w
         self.out_dim, self.max_len = int(out_dim), int(max_len)
         self.max_seqs = int(max_seqs or MAX_SEQS)
-        self.max_rows = self.max_seqs * self.max_len
+        self.max_rows = max(self.max_len, min(self.max_seqs * self.max_len, MAX_ROWS))
         self._qcfg = L.QueueCfg(kind=kind, device=int(device_index), max_seqs=self.max_seqs, max_rows=self.max_rows, normalize=1 if normalize else 0,
                                 depth=int(depth or DEPTH), window_us=int(WINDOW_US if window_us is None else window_us),
                                 graphs=1 if (GRAPHS if graphs is None else graphs) else 0)
@@ -104,3 +114,34 @@ class TextQueue:
             self.close()
         except Exception:
             pass
+
+
+class ImageQueue(TextQueue):
+    """one `mq_queue` (MQ_QUEUE_IMAGE_F32) of an image tower for one value of `normalize`: a request = device pointers of preprocessed fp32 [3, S, S]
+    images (the views `.preprocess` hands out), gathered with the other callers' into one `mq_encode_image_f32` per group"""
+
+    def __init__(self, lib, cfg, w, device_index: int, out_dim: int, normalize: bool, max_seqs: int = 0, depth: int = 0, graphs: Optional[bool] = None):
+        self._lib, self._kind, self._cfg, self._w = lib, L.QUEUE_IMAGE_F32, cfg, w
+        self.out_dim, self.max_len = int(out_dim), 1
+        self.max_seqs = int(max_seqs or IMAGE_MAX_SEQS)
+        self.max_rows = self.max_seqs
+        self._qcfg = L.QueueCfg(kind=L.QUEUE_IMAGE_F32, device=int(device_index), max_seqs=self.max_seqs, max_rows=self.max_rows, normalize=1 if normalize else 0,
+                                depth=int(depth or IMAGE_DEPTH), window_us=int(WINDOW_US), graphs=1 if (GRAPHS if graphs is None else graphs) else 0)
+        self._h = C.c_void_p()
+        self._pid = os.getpid()
+        self._lock = threading.Lock()
+        L.check(lib.mq_queue_create(C.byref(self._qcfg), C.cast(C.byref(cfg), C.c_void_p), C.cast(C.byref(w), C.c_void_p), C.byref(self._h)), "mq_queue_create")
+
+    def encode_ptrs(self, ptrs) -> np.ndarray:
+        """ptrs: device addresses of n complete fp32 [3, S, S] images -> fp32 [n, out_dim] (host); blocks with the GIL released"""
+        n = len(ptrs)
+        out = np.empty((n, self.out_dim), dtype=np.float32)
+        if n:
+            arr = (C.c_void_p * n)(*ptrs)
+            L.check(self._lib.mq_queue_encode_images(self._handle(), arr, n, out.ctypes.data), "mq_queue_encode_images")
+        return out
+
+    def encode(self, *a, **k):
+        raise TypeError("an image queue takes device pointers: encode_ptrs")
+
+    encode_raw = encode

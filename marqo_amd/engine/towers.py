@@ -925,6 +925,57 @@ class VitTower(_TowerBase):
                 self._call_image(kind, pixels[i:i + m], m, out[i:i + m], normalize, ws)
         return out
 
+    # ---- native request queue (engine/native_queue.py, csrc/queue.hip): the request threads' small calls on preprocessed images share tower calls ----
+    _queues: Optional[Dict[bool, tuple]] = None
+    _queues_off = False
+
+    def _queue(self, normalize: bool) -> Optional["NQ.ImageQueue"]:
+        """this tower's image queue for `normalize` (created at first use, re-created when the tower's policy fields have changed), or None"""
+        if not NQ.ENABLED or NQ.IMAGE_REQUEST_MAX <= 0 or self._queues_off or (self._fp8 is not None and not self._fp8.calibrated):
+            return None
+        sig = bytes(self.cfg)
+        ent = (self._queues or {}).get(bool(normalize))
+        if ent is not None and ent[0] == sig:
+            return ent[1]
+        with self._lock:
+            if self._queues is None:
+                self._queues = {}
+            ent = self._queues.get(bool(normalize))
+            if ent is not None and ent[0] == sig:
+                return ent[1]
+            if ent is not None:
+                ent[1].close()
+            try:
+                idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+                q = NQ.ImageQueue(self.lib, self.cfg, self.w, idx, self.arch.out_dim, bool(normalize))
+            except (L.MarqoHipUnavailableError, L.MarqoHipError) as e:
+                self._queues_off = True
+                import logging
+                logging.getLogger(__name__).warning("native request queue unavailable (%s); small image calls keep the direct path", e)
+                return None
+            self._queues[bool(normalize)] = (sig, q)
+            return q
+
+    def queue_rows_images(self, tensors: Sequence[Tensor], normalize: bool = True) -> Optional[np.ndarray]:
+        """the loaders' lean small-call path for preprocessed images: fp32 [3, S, S] device tensors (complete: the caller has seen their stream idle) ->
+        host rows through the native queue, or None (no queue / not the queue's kind of call)"""
+        n = len(tensors)
+        if n < 1 or n > NQ.IMAGE_REQUEST_MAX:
+            return None
+        q = self._queue(normalize)
+        if q is None:
+            return None
+        S = self.arch.image_size
+        ptrs = []
+        for t in tensors:
+            if t.dtype != torch.float32 or t.device != self.device or tuple(t.shape) != (3, S, S) or not t.is_contiguous():
+                return None
+            ptrs.append(t.data_ptr())
+        return q.encode_ptrs(ptrs)
+
+    def queue_stats(self) -> Dict[bool, Dict[str, int]]:
+        return {k: ent[1].stats() for k, ent in (self._queues or {}).items()}
+
     def calibration_images(self, n: int = 16, seed: int = 0) -> Tensor:
         """the fixed, seeded calibration batch of the fp8 policy: half uniform pixel noise, half smooth low-frequency fields plus
         mild noise (closer to the spectrum of photographs) — uint8 [n, S, S, 3] on the device.  The same for every load of a

@@ -524,6 +524,16 @@ class OPEN_CLIP(AbstractCLIPModel):
         device tensor (no D2H: bulk ingest gathers shards over RCCL straight from HBM)"""
         if self.model is None:
             self.load()
+        if not return_device and self.native_queue_takes_images(images):
+            # a request thread's few `.preprocess` tensors (one document field): their addresses go to the image tower's native queue, this thread
+            # blocks outside the interpreter while a worker gathers them with the other callers' and runs one tower call.  The tensors were written on
+            # the producers' current stream — the device's default stream (`_preprocess_one`); the workers' streams are ordered behind nothing
+            for st in (torch.cuda.current_stream(self.device), torch.cuda.default_stream(self.device)):
+                if not st.query():
+                    st.synchronize()
+            rows = self.vision.queue_rows_images(images, bool(normalize))
+            if rows is not None:
+                return rows
         with self._image_calls_lock:
             self._image_calls += 1
             alone = self._image_calls == 1
@@ -616,6 +626,16 @@ class OPEN_CLIP(AbstractCLIPModel):
         for st in side:
             st.wait_stream(main)
         return [main] + side
+
+    def native_queue_takes_images(self, images) -> bool:
+        """True when `encode_image(images)` goes through the image tower's native request queue: a short list of the views `.preprocess` handed out
+        (`vectorise()` then leaves the merging of concurrent calls to it instead of the Python coalescer)"""
+        from marqo_amd.engine import native_queue as NQ
+        if not NQ.ENABLED or self.model is None or not isinstance(images, list) or not (1 <= len(images) <= NQ.IMAGE_REQUEST_MAX):
+            return False
+        if getattr(self, "vision", None) is None or not hasattr(self.vision, "queue_rows_images"):
+            return False
+        return all(isinstance(t, torch.Tensor) and getattr(t, "_mq_block", None) is not None for t in images)
 
     def native_queue_takes(self, texts) -> bool:
         """True when `encode_text(texts)` goes through the text tower's native request queue (engine/native_queue.py): `vectorise()` then leaves

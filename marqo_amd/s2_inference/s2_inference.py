@@ -307,6 +307,10 @@ def _encode_to_array(model_cache_key: str, content, normalize_embeddings: bool, 
                     takes = getattr(model, "native_queue_takes", None)
                     if callable(takes) and takes(batch) is True:
                         ckey = None
+                elif ckey is not None and modality == Modality.IMAGE and not _coalesce.explicit() and not kwargs.get("return_device"):
+                    takes = getattr(model, "native_queue_takes_images", None)     # (... and so does an image tower's, for the tensors `.preprocess` returns)
+                    if callable(takes) and takes(batch) is True:
+                        ckey = None
                 if ckey is not None:
                     def run_merged(items, _m=modality, _i=infer, _kw=dict(kwargs)):
                         return encoder.encode(items, modality=_m, normalize=normalize_embeddings, infer=_i, **_kw)

@@ -260,3 +260,60 @@ def test_a_lone_sequence_replays_a_graph_with_the_eager_calls_bits():
         r0 = [q0.encode(*_packed(ids[0:1], lengths[0:1])) for _ in range(3)]
         assert q0.stats()["graphs"] == 0 and q0.stats()["graph_replays"] == 0 and np.array_equal(r0[0], rows[0])
         q0.close()
+
+
+def test_preprocessed_images_of_request_threads_share_tower_calls(monkeypatch):
+    """MQ_QUEUE_IMAGE_F32: the few tensors `.preprocess` hands a request thread (one document field: add_docs.py:129-141 -> vectorise per field) go to the image
+    tower's queue by address; a worker gathers the waiting callers' images into one batch and runs ONE mq_encode_image_f32.  Rows = the batch call's rows;
+    larger lists keep the slab path; through vectorise() from 12 threads"""
+    monkeypatch.setenv("MARQO_AMD_SYNTHETIC_WEIGHTS", "1")
+    monkeypatch.setenv("MARQO_MAX_CUDA_MODEL_MEMORY", "64")
+    monkeypatch.delenv("MARQO_AMD_COALESCE_US", raising=False)
+    from PIL import Image
+    from marqo_amd.engine import native_queue as NQ
+    from marqo_amd.s2_inference import coalesce, s2_inference as s2
+    from marqo_amd.s2_inference.enums import AvailableModelsKey, Modality
+    name = "open_clip/ViT-B-32/laion2b_s34b_b79k"
+    props = s2.get_model_properties_from_registry(name)
+    model, pre = s2.load_multimodal_model_and_get_preprocessors(name, props, "cuda:0")
+    enc = s2.get_available_models()[s2._create_model_cache_key(name, "cuda:0", props)][AvailableModelsKey.model]
+    rng = np.random.default_rng(5)
+    pil = [Image.fromarray(rng.integers(0, 256, (180 + 5 * i, 240 - 3 * i, 3), dtype=np.uint8)) for i in range(24)]
+    views = [pre["image"](p) for p in pil]
+    want = enc.encode_image(torch.stack([v.clone() for v in views]))            # the batch form, no queue (a tensor, not a list of views)
+    assert enc.native_queue_takes_images(views[:3]) is True and enc.native_queue_takes_images(views) is False
+    assert enc.native_queue_takes_images([v.clone() for v in views[:2]]) is False and enc.native_queue_takes_images(views[0]) is False
+    got3 = enc.encode_image(views[:3])
+    st = enc.vision.queue_stats()[True]
+    assert st["requests"] == 1 and st["sequences"] == 3 and st["failed_calls"] == 0
+    assert got3.shape == (3, want.shape[1]) and _cos_err(got3, want[:3]) < 1e-4      # (3 images and 24 sit in different kernel families)
+    one = [enc.encode_image([views[7]]) for _ in range(3)]                     # a lone image: eager, captured, replayed
+    assert np.array_equal(one[0], one[2]) and _cos_err(one[0], want[7:8]) < 1e-4
+    if NQ.GRAPHS:
+        assert enc.vision.queue_stats()[True]["graph_replays"] >= 2
+    big = enc.encode_image(views)                                               # 24 views: the slab path, as before
+    assert np.array_equal(big, want) and enc.vision.queue_stats()[True]["requests"] == 4
+    kw = dict(device="cuda:0", modality=Modality.IMAGE, model_properties=props)
+    before_c = coalesce.get_coalescer().stats["calls"]
+    errs, out = [], {}
+    start = threading.Barrier(12)
+
+    def worker(t):
+        try:
+            start.wait(30)
+            for c in range(8):
+                pick = [(5 * t + 3 * c + j) % len(views) for j in range(1 + (t + c) % 3)]
+                out[(t, c)] = (pick, s2.vectorise_ndarray(name, [views[i] for i in pick], **kw))
+        except BaseException as e:  # noqa: BLE001
+            errs.append((t, e))
+    ts = [threading.Thread(target=worker, args=(t,)) for t in range(12)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(180)
+    assert not errs, errs
+    for pick, rows in out.values():
+        assert rows.shape == (len(pick), want.shape[1]) and _cos_err(rows, want[pick]) < 1e-4
+    st = enc.vision.queue_stats()[True]
+    assert st["requests"] == 4 + 96 and st["failed_calls"] == 0 and st["merged_calls"] >= 1 and st["calls"] < st["requests"], st
+    assert coalesce.get_coalescer().stats["calls"] == before_c                  # the Python coalescer saw none of them
