@@ -1,4 +1,4 @@
-// Native cross-request batching of small text calls (ABI 14): mq_queue_* — host code only, no kernels of its own.
+// Native cross-request batching of the request threads' small calls (ABI 14): mq_queue_* — host code only, no kernels of its own.
 //
 // What it stands in for: the reference serves up to 8 indexing + 8 search request threads at once (/root/reference/src/marqo/api/configs.py:27-28), each
 // calling s2_inference.vectorise() with a handful of texts (a search query: ONE — src/marqo/tensor_search/tensor_search.py's query vectorisation; a
@@ -11,9 +11,11 @@
 //
 // Batching is "natural": a worker that finds requests waiting takes as many as fit one tower call (max_seqs sequences / max_rows token rows) and runs them
 // as ONE mq_encode_clip_text / mq_encode_bert on its own stream; whatever arrives meanwhile waits for the next free worker, i.e. groups grow with the load
-// and a lone caller is never delayed.  `depth` workers (1 or 2, each with its own stream, device scratch and pinned staging) keep one merged call's host
-// part (pack, H2D, enqueue) under the GPU part of the call before it.  While another call is executing, a worker holds a small group back for up to
-// window_us so that requests a few microseconds apart share a launch.
+// and a lone caller is never delayed.  `depth` workers (each with its own stream, device scratch and pinned staging; 1 by default: one worker forms the largest
+// groups and a small-row tower call is host-launch-bound whatever its size — depth 1 > 4 > 3 > 2 measured, profiles/r08d_queue_depth_window_sweep.txt); with
+// more than one, a worker holds a group that is not full back for up to window_us while another call is executing, so that requests a few microseconds apart
+// share a launch.  A group of ONE sequence replays a hipGraph of its token count (lane_graph_one).  MQ_QUEUE_IMAGE_F32: the same in front of
+// mq_encode_image_f32, a request = device addresses of preprocessed images, gathered per group into the lane's batch buffer.
 // Rows of a batch are independent in these towers (per-row normalisation, no cross-sequence reduction): a request's embeddings are those of the merged call,
 // bit-identical to a lone call of the same kernel family (the small-row families take over at <= 320 rows: DESIGN.md section 3, Numerics).
 #include <chrono>
