@@ -564,24 +564,21 @@ def e2e_vectorise(dev, images_cpu_u8, tower_only_rate, reps=21):
         out["small_text_calls"] = small_text_calls(s2, name, props, dev)
     except Exception as e:  # noqa: BLE001
         out["small_text_calls"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    try:
+        out["small_image_calls"] = small_image_calls(s2, name, props, dev, dev_tensors[:64])
+    except Exception as e:  # noqa: BLE001
+        out["small_image_calls"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     s2.clear_loaded_models()
     return out
 
 
-def small_text_calls(s2, name, props, dev, threads=16, calls=60):
-    """the reference's serving load on the text side: 8 indexing + 8 search request threads (api/configs.py:27-28), each calling vectorise() with ONE
-    query (search) or 4 texts (the chunks of a document field) at a time — merged across threads by the tower's native request queue (mq_queue_*,
-    csrc/queue.hip); requests/s, embeddings/s and the median call latency a request thread sees, beside one thread calling alone"""
-    from marqo_amd.engine import native_queue as NQ
-    from marqo_amd.s2_inference.enums import AvailableModelsKey, Modality
-    kw = dict(device=dev, modality=Modality.TEXT, model_properties=props)
-    words = ["alpha", "beta", "gamma", "delta", "marqo", "tensor", "search", "image", "text", "vector"]
-    rng = np.random.default_rng(0)
-    s2.vectorise_ndarray(name, ["warm"], **kw)
-    res = {"model": name, "threads": threads, "calls_per_thread": calls, "native_queue": bool(NQ.ENABLED), "queue_depth": NQ.DEPTH, "queue_max_seqs": NQ.MAX_SEQS}
+def _small_calls(s2, name, kw, make_content, threads, calls):
+    """`threads` request threads x `calls` synchronous vectorise_ndarray() calls of 1 and of 4 items: requests/s, embeddings/s, the median / p95 latency a
+    thread sees, and one thread calling alone.  No device-wide synchronise anywhere near the threads (on ROCm one issued while another thread captures a
+    hipGraph invalidates the capture)"""
+    res = {}
     for items in (1, 4):
-        content = {(t, c): [" ".join(words[int(j)] for j in rng.integers(0, 10, 12)) + f" {t} {c} {i}" for i in range(items)]
-                   for t in range(threads) for c in range(calls)}
+        content = {(t, c): make_content(t, c, items) for t in range(threads) for c in range(calls)}
         lat, errors = [], []
         start = threading.Barrier(threads + 1)
 
@@ -617,11 +614,52 @@ def small_text_calls(s2, name, props, dev, threads=16, calls=60):
         res[f"{items}_per_call"] = {"requests_per_s": round(threads * calls / dt, 1), "embeddings_per_s": round(threads * calls * items / dt, 1),
                                     "latency_p50_ms": round(lat[len(lat) // 2] * 1e3, 3), "latency_p95_ms": round(lat[int(len(lat) * 0.95)] * 1e3, 3),
                                     "one_thread_ms_per_call": round(alone * 1e3, 3), "one_thread_embeddings_per_s": round(items / alone, 1)}
+    return res
+
+
+def _queue_summary(tower):
+    st = getattr(tower, "queue_stats", lambda: {})().get(True)
+    if not st:
+        return None
+    return {"requests": st["requests"], "tower_calls": st["calls"], "sequences_per_call": round(st["sequences"] / max(st["calls"], 1), 2),
+            "largest_call": st["max_call_sequences"], "graph_replays": st.get("graph_replays", 0), "failed_calls": st["failed_calls"]}
+
+
+def small_text_calls(s2, name, props, dev, threads=16, calls=60):
+    """the reference's serving load on the text side: 8 indexing + 8 search request threads (api/configs.py:27-28), each calling vectorise() with ONE
+    query (search) or 4 texts (the chunks of a document field) at a time — merged across threads by the tower's native request queue (mq_queue_*,
+    csrc/queue.hip)"""
+    from marqo_amd.engine import native_queue as NQ
+    from marqo_amd.s2_inference.enums import AvailableModelsKey, Modality
+    kw = dict(device=dev, modality=Modality.TEXT, model_properties=props)
+    words = ["alpha", "beta", "gamma", "delta", "marqo", "tensor", "search", "image", "text", "vector"]
+    rng = np.random.default_rng(0)
+    s2.vectorise_ndarray(name, ["warm"], **kw)
+    res = {"model": name, "threads": threads, "calls_per_thread": calls, "native_queue": bool(NQ.ENABLED), "queue_depth": NQ.DEPTH, "queue_max_seqs": NQ.MAX_SEQS}
+    res.update(_small_calls(s2, name, kw, lambda t, c, items: [" ".join(words[int(j)] for j in rng.integers(0, 10, 12)) + f" {t} {c} {i}" for i in range(items)],
+                            threads, calls))
     model = s2.get_available_models()[s2._create_model_cache_key(name, dev, props)][AvailableModelsKey.model]
-    st = getattr(model.text, "queue_stats", lambda: {})().get(True)
-    if st:
-        res["queue"] = {"requests": st["requests"], "tower_calls": st["calls"], "sequences_per_call": round(st["sequences"] / max(st["calls"], 1), 2),
-                        "largest_call": st["max_call_sequences"], "failed_calls": st["failed_calls"]}
+    q = _queue_summary(model.text)
+    if q:
+        res["queue"] = q
+    return res
+
+
+def small_image_calls(s2, name, props, dev, views, threads=16, calls=40):
+    """the indexing threads' image side: vectorise() per document field with the one to four tensors `.preprocess` returned (add_docs.py:129-141) — their
+    device addresses go to the image tower's queue (MQ_QUEUE_IMAGE_F32)"""
+    from marqo_amd.engine import native_queue as NQ
+    from marqo_amd.s2_inference.enums import AvailableModelsKey, Modality
+    kw = dict(device=dev, modality=Modality.IMAGE, model_properties=props)
+    for k in (1, 4):
+        s2.vectorise_ndarray(name, views[:k], **kw)
+    res = {"model": name, "threads": threads, "calls_per_thread": calls, "content": "fp32 [3, 224, 224] device tensors from .preprocess",
+           "native_queue": bool(NQ.ENABLED and NQ.IMAGE_REQUEST_MAX > 0)}
+    res.update(_small_calls(s2, name, kw, lambda t, c, items: [views[(7 * t + 3 * c + i) % len(views)] for i in range(items)], threads, calls))
+    model = s2.get_available_models()[s2._create_model_cache_key(name, dev, props)][AvailableModelsKey.model]
+    q = _queue_summary(model.vision)
+    if q:
+        res["queue"] = q
     return res
 
 
