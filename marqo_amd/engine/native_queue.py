@@ -47,6 +47,13 @@ IMAGE_MAX_SEQS = _env_int("MARQO_AMD_NATIVE_QUEUE_IMAGE_SEQS", 32, 1, 256)
 IMAGE_DEPTH = _env_int("MARQO_AMD_NATIVE_QUEUE_IMAGE_DEPTH", 1, 1, 4)
 
 
+def gone(e: Exception) -> bool:
+    """a queue call that failed because the queue was closed under it (the tower re-creates its queue when its policy fields change): the caller takes
+    the regular path for this one request"""
+    msg = str(e)
+    return "null queue" in msg or "being destroyed" in msg
+
+
 class TextQueue:
     """one `mq_queue` of a text tower for one value of `normalize`.  `cfg` / `w` are the tower's ctypes structs (kept alive here: the queue reads them
     at every call); thread-safe; recreated in a fork()ed child (worker threads do not survive a fork)."""

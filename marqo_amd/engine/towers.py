@@ -698,6 +698,13 @@ class _TowerBase:
         self._ops = L.load_torch_ops() if L.boundary() == "torch_ops" else None
         self._blobs = None
 
+    def _forget_queue(self, q) -> None:
+        """a native queue that was closed under a caller (engine/native_queue.gone): the next small call creates a fresh one"""
+        with self._lock:
+            for k, ent in list((getattr(self, "_queues", None) or {}).items()):
+                if ent[1] is q:
+                    del self._queues[k]
+
     def _desc(self):
         """(cfg, weights) descriptors as the CPU byte tensors the custom ops take — zero-copy aliases of the ctypes structs"""
         if self._blobs is None:
@@ -971,7 +978,13 @@ class VitTower(_TowerBase):
             if t.dtype != torch.float32 or t.device != self.device or tuple(t.shape) != (3, S, S) or not t.is_contiguous():
                 return None
             ptrs.append(t.data_ptr())
-        return q.encode_ptrs(ptrs)
+        try:
+            return q.encode_ptrs(ptrs)
+        except L.MarqoHipError as e:
+            if NQ.gone(e):
+                self._forget_queue(q)
+                return None
+            raise
 
     def queue_stats(self) -> Dict[bool, Dict[str, int]]:
         return {k: ent[1].stats() for k, ent in (self._queues or {}).items()}
@@ -1116,7 +1129,13 @@ class _TextTowerBase(_TowerBase):
             if q is None or not q.takes(n, int(lengths.sum())):
                 return None
             packed, _ = _pack(ids_h, lengths)
-            return torch.from_numpy(q.encode(packed.numpy(), lengths))
+            try:
+                return torch.from_numpy(q.encode(packed.numpy(), lengths))
+            except L.MarqoHipError as e:
+                if NQ.gone(e):
+                    self._forget_queue(q)
+                    return None
+                raise
         finally:
             with _TextTowerBase._active_lock:
                 self._active -= 1
@@ -1139,7 +1158,13 @@ class _TextTowerBase(_TowerBase):
             if q is None or not q.takes(n, int(lengths.sum())):
                 return None
             packed = ids_h[0, :int(lengths[0])] if n == 1 else ids_h[np.arange(ids_h.shape[1])[None, :] < lengths[:, None]]
-            return q.encode_raw(np.ascontiguousarray(packed, dtype=np.int32), np.ascontiguousarray(lengths, dtype=np.int32), n)
+            try:
+                return q.encode_raw(np.ascontiguousarray(packed, dtype=np.int32), np.ascontiguousarray(lengths, dtype=np.int32), n)
+            except L.MarqoHipError as e:
+                if NQ.gone(e):
+                    self._forget_queue(q)
+                    return None
+                raise
         finally:
             with _TextTowerBase._active_lock:
                 self._active -= 1

@@ -158,6 +158,11 @@ def test_destroy_serves_what_is_pending_and_policy_changes_rebuild_the_queue():
     ref = tower.encode_ids(torch.from_numpy(ids[:nt]), normalize=True).cpu().numpy()
     for t in range(nt):
         assert _cos_err(outs[t], ref[t:t + 1]) < 1e-5
+    # a queue closed under a caller (the tower re-creates its queue when its policy changes): that one request takes the regular path, the next a new queue
+    qd = tower._queue(True, clip=True)
+    qd.close()
+    assert tower.queue_rows_ids(ids[:2], True) is None and tower._queue(True, clip=True) is not qd
+    assert _cos_err(tower.queue_rows_ids(ids[:2], True), ref[:2]) < 1e-5
     # the tower's queue follows the tower's policy fields: a changed cfg gets a queue of its own (its scratch is sized from the cfg)
     q1 = tower._queue(True, clip=True)
     before = bytes(tower.cfg)
