@@ -44,7 +44,6 @@ GRAPHS = os.environ.get("MARQO_AMD_NATIVE_QUEUE_GRAPHS", "1") != "0"
 # 1-4 tensors from `.preprocess`); a merged call carries up to IMAGE_MAX_SEQS.  Larger lists are the slab path's (open_clip_model._encode_image).
 IMAGE_REQUEST_MAX = _env_int("MARQO_AMD_NATIVE_QUEUE_IMAGE_REQUEST", 8, 0, 64)
 IMAGE_MAX_SEQS = _env_int("MARQO_AMD_NATIVE_QUEUE_IMAGE_SEQS", 32, 1, 256)
-IMAGE_DEPTH = _env_int("MARQO_AMD_NATIVE_QUEUE_IMAGE_DEPTH", 1, 1, 4)
 
 
 def gone(e: Exception) -> bool:
@@ -133,7 +132,7 @@ class ImageQueue(TextQueue):
         self.max_seqs = int(max_seqs or IMAGE_MAX_SEQS)
         self.max_rows = self.max_seqs
         self._qcfg = L.QueueCfg(kind=L.QUEUE_IMAGE_F32, device=int(device_index), max_seqs=self.max_seqs, max_rows=self.max_rows, normalize=1 if normalize else 0,
-                                depth=int(depth or IMAGE_DEPTH), window_us=int(WINDOW_US), graphs=1 if (GRAPHS if graphs is None else graphs) else 0)
+                                depth=int(depth or DEPTH), window_us=int(WINDOW_US), graphs=1 if (GRAPHS if graphs is None else graphs) else 0)
         self._h = C.c_void_p()
         self._pid = os.getpid()
         self._lock = threading.Lock()
