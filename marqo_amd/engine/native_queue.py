@@ -68,7 +68,8 @@ class TextQueue:
                                 graphs=1 if (GRAPHS if graphs is None else graphs) else 0)
         self._h = C.c_void_p()
         self._pid = os.getpid()
-        self._lock = threading.Lock()
+        self._lock = threading.Condition()
+        self._inflight, self._closing = 0, False
         L.check(lib.mq_queue_create(C.byref(self._qcfg), C.cast(C.byref(cfg), C.c_void_p), C.cast(C.byref(w), C.c_void_p), C.byref(self._h)), "mq_queue_create")
 
     def takes(self, nseq: int, rows: int) -> bool:
@@ -81,8 +82,24 @@ class TextQueue:
                     h = C.c_void_p()
                     L.check(self._lib.mq_queue_create(C.byref(self._qcfg), C.cast(C.byref(self._cfg), C.c_void_p), C.cast(C.byref(self._w), C.c_void_p),
                                                       C.byref(h)), "mq_queue_create")
-                    self._h, self._pid = h, os.getpid()
+                    self._h, self._pid, self._inflight, self._closing = h, os.getpid(), 0, False
         return self._h
+
+    def _call(self, fn, *args) -> None:
+        """one foreign call on the live queue.  `close()` waits for the calls that are inside (they finish by themselves: the workers keep serving until
+        the queue is destroyed) and refuses new ones, so the handle is never used after mq_queue_destroy has started"""
+        h = self._handle()
+        with self._lock:
+            if self._closing or not h:
+                raise L.MarqoHipError("mq_queue: null queue (closed)")
+            self._inflight += 1
+        try:
+            L.check(fn(h, *args), fn.__name__)
+        finally:
+            with self._lock:
+                self._inflight -= 1
+                if self._inflight == 0:
+                    self._lock.notify_all()
 
     def encode(self, packed_ids: np.ndarray, lengths: np.ndarray) -> np.ndarray:
         """packed_ids int32 [sum(lengths)], lengths int32 [n] -> fp32 [n, out_dim] (host).  Blocks (GIL released) until the merged call that carried
@@ -94,26 +111,31 @@ class TextQueue:
             raise ValueError(f"packed ids hold {ids.size} tokens, the lengths add up to {int(lens.sum())}")
         out = np.empty((n, self.out_dim), dtype=np.float32)
         if n:
-            L.check(self._lib.mq_queue_encode(self._handle(), ids.ctypes.data, lens.ctypes.data, n, out.ctypes.data), "mq_queue_encode")
+            self._call(self._lib.mq_queue_encode, ids.ctypes.data, lens.ctypes.data, n, out.ctypes.data)
         return out
 
     def encode_raw(self, ids32: np.ndarray, lens32: np.ndarray, n: int) -> np.ndarray:
         """`encode` for callers that vouch for their arrays (contiguous int32, lengths adding up to the ids): the towers' per-request path, where
         every NumPy call is interpreter time that 16 request threads queue up for"""
         out = np.empty((n, self.out_dim), dtype=np.float32)
-        L.check(self._lib.mq_queue_encode(self._handle(), ids32.ctypes.data, lens32.ctypes.data, n, out.ctypes.data), "mq_queue_encode")
+        self._call(self._lib.mq_queue_encode, ids32.ctypes.data, lens32.ctypes.data, n, out.ctypes.data)
         return out
 
     def stats(self) -> Dict[str, int]:
         st = L.QueueStats()
-        L.check(self._lib.mq_queue_get_stats(self._handle(), C.byref(st)), "mq_queue_get_stats")
+        self._call(self._lib.mq_queue_get_stats, C.byref(st))
         return {name: int(getattr(st, name)) for name, _ in L.QueueStats._fields_}
 
     def close(self) -> None:
         with self._lock:
+            if self._closing:
+                return
+            self._closing = True
+            while self._inflight > 0:
+                self._lock.wait(1.0)
             h, self._h = self._h, C.c_void_p()
-            if h and self._pid == os.getpid():
-                self._lib.mq_queue_destroy(h)
+        if h and self._pid == os.getpid():
+            self._lib.mq_queue_destroy(h)
 
     def __del__(self):
         try:
@@ -135,7 +157,8 @@ class ImageQueue(TextQueue):
                                 depth=int(depth or DEPTH), window_us=int(WINDOW_US), graphs=1 if (GRAPHS if graphs is None else graphs) else 0)
         self._h = C.c_void_p()
         self._pid = os.getpid()
-        self._lock = threading.Lock()
+        self._lock = threading.Condition()
+        self._inflight, self._closing = 0, False
         L.check(lib.mq_queue_create(C.byref(self._qcfg), C.cast(C.byref(cfg), C.c_void_p), C.cast(C.byref(w), C.c_void_p), C.byref(self._h)), "mq_queue_create")
 
     def encode_ptrs(self, ptrs) -> np.ndarray:
@@ -144,7 +167,7 @@ class ImageQueue(TextQueue):
         out = np.empty((n, self.out_dim), dtype=np.float32)
         if n:
             arr = (C.c_void_p * n)(*ptrs)
-            L.check(self._lib.mq_queue_encode_images(self._handle(), arr, n, out.ctypes.data), "mq_queue_encode_images")
+            self._call(self._lib.mq_queue_encode_images, arr, n, out.ctypes.data)
         return out
 
     def encode(self, *a, **k):

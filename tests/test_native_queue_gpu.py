@@ -322,3 +322,65 @@ def test_preprocessed_images_of_request_threads_share_tower_calls(monkeypatch):
     st = enc.vision.queue_stats()[True]
     assert st["requests"] == 4 + 96 and st["failed_calls"] == 0 and st["merged_calls"] >= 1 and st["calls"] < st["requests"], st
     assert coalesce.get_coalescer().stats["calls"] == before_c                  # the Python coalescer saw none of them
+
+
+def test_stress_depth_two_with_a_window_and_close_under_load():
+    """depth 2 + a 50 us window (the paths the default, depth 1, never takes): 24 threads x 40 requests of 1-6 ragged sequences — every row right, both
+    workers used; then the queue is closed while 8 threads keep calling: no caller hangs, each call either returns its rows or fails with the queue's
+    'being destroyed' / 'null queue' error"""
+    from marqo_amd import _lib as L
+    from marqo_amd.engine import native_queue as NQ
+    tower, z = _bert("mean")
+    ids, mask = z["ids"].astype(np.int64), z["mask"].astype(np.int64)
+    lengths = mask.sum(axis=1)
+    n_all = ids.shape[0]
+    ref = tower.encode_ids(torch.from_numpy(ids), torch.from_numpy(mask), normalize=True).cpu().numpy()
+    q = NQ.TextQueue(tower.lib, 1, tower.cfg, tower.w, 0, tower.out_width, tower.arch.max_pos, True, max_seqs=16, depth=2, window_us=50, graphs=True)
+    errs, bad = [], []
+    start = threading.Barrier(24)
+
+    def worker(t):
+        try:
+            rng = np.random.default_rng(100 + t)
+            start.wait(30)
+            for _ in range(40):
+                pick = rng.integers(0, n_all, size=int(rng.integers(1, 7)))
+                rows = q.encode(*_packed(ids[pick], lengths[pick]))
+                if rows.shape != (len(pick), ref.shape[1]) or _cos_err(rows, ref[pick]) > 1e-5:
+                    bad.append(pick)
+        except BaseException as e:  # noqa: BLE001
+            errs.append(e)
+    ts = [threading.Thread(target=worker, args=(t,)) for t in range(24)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(180)
+    assert not errs and not bad and not any(t.is_alive() for t in ts), (errs[:1], bad[:1])
+    st = q.stats()
+    assert st["requests"] == 24 * 40 and st["failed_calls"] == 0 and st["merged_calls"] >= 1 and st["max_call_sequences"] <= 16, st
+
+    stop, served, refused, other = threading.Event(), [0], [0], []
+
+    def hammer(t):
+        rng = np.random.default_rng(t)
+        while not stop.is_set():
+            pick = rng.integers(0, n_all, size=2)
+            try:
+                q.encode(*_packed(ids[pick], lengths[pick]))
+                served[0] += 1
+            except L.MarqoHipError as e:
+                if NQ.gone(e):
+                    refused[0] += 1
+                else:
+                    other.append(e)
+    hs = [threading.Thread(target=hammer, args=(t,)) for t in range(8)]
+    for t in hs:
+        t.start()
+    import time
+    time.sleep(0.05)
+    q.close()                      # serves what is pending, joins the workers; callers that arrive later are refused
+    time.sleep(0.05)
+    stop.set()
+    for t in hs:
+        t.join(60)
+    assert not any(t.is_alive() for t in hs) and not other and served[0] > 0 and refused[0] > 0, (served, refused, other[:1])
