@@ -704,6 +704,11 @@ typedef struct mq_queue_cfg {
     int32_t window_us;   /* see above; 0 = a group never waits */
     int32_t graphs;      /* != 0: a group of ONE sequence (the search path's lone query) replays a hipGraph of its token count, captured at the second
                           * call of that count on a worker (~100 dependent small launches: 0.45 ms enqueued one by one, 0.3 ms as a graph) */
+    int32_t helper_seqs; /* > 0 (with depth > 1): the lanes beyond the first are HELPERS — they take what is waiting only while that is at most this many
+                          * sequences AND the group the first lane is executing is that small too.  Light load (two or three request threads: never more than
+                          * one request waiting, nothing to merge) then runs its calls side by side instead of one behind the other; under heavy load the first
+                          * lane's groups are large, the helpers sleep and it forms them alone.  0 = every lane takes whatever waits */
+    int32_t reserved;
 } mq_queue_cfg;
 typedef struct mq_queue_stats {
     uint64_t requests;            /* served (mq_queue_encode calls that reached a worker) */

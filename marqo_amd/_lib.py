@@ -132,7 +132,7 @@ class SentencePieceVocab(C.Structure):
 class QueueCfg(C.Structure):
     """mq_queue_cfg (ABI 14): the native request queue of a text tower (csrc/queue.hip)"""
     _fields_ = [("kind", C.c_int32), ("device", C.c_int32), ("max_seqs", C.c_int32), ("max_rows", C.c_int32), ("normalize", C.c_int32),
-                ("depth", C.c_int32), ("window_us", C.c_int32), ("graphs", C.c_int32)]
+                ("depth", C.c_int32), ("window_us", C.c_int32), ("graphs", C.c_int32), ("helper_seqs", C.c_int32), ("reserved", C.c_int32)]
 
 
 class QueueStats(C.Structure):

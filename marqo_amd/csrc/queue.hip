@@ -77,6 +77,8 @@ struct mq_queue {
     std::deque<QRequest*> pending;
     int64_t pending_seqs = 0;
     int busy = 0;
+    bool lane0_busy = false;     // the first lane is executing a group ...
+    int64_t lane0_seqs = 0;      // ... of this many sequences (what the helper lanes judge the load by)
     bool stop = false;
     std::vector<QLane> lanes;
     mq_queue_stats st{};
@@ -228,11 +230,18 @@ void lane_run(mq_queue* q, int lane_idx) {
         group.clear();
         {
             std::unique_lock<std::mutex> lk(q->mu);
-            q->cv_work.wait(lk, [&] { return q->stop || !q->pending.empty(); });
+            // helper lanes (helper_seqs > 0: every lane but the first) exist for LIGHT load: two or three request threads never have more than one
+            // request waiting, so nothing ever merges and a single lane would run their calls one behind the other (2 threads: 1.0 ms per call where the
+            // call itself is 0.5).  A helper takes what is waiting only while that is at most helper_seqs sequences — under heavy load the backlog is larger
+            // than that almost always, the helpers sleep and the first lane forms its large groups alone
+            // — and only while the group the first lane is running is that small too (a large running group IS heavy load, whatever happens to wait now)
+            const bool helper = lane_idx > 0 && q->cfg.helper_seqs > 0;
+            auto light = [&] { return q->pending_seqs <= q->cfg.helper_seqs && q->lane0_busy && q->lane0_seqs <= q->cfg.helper_seqs; };
+            q->cv_work.wait(lk, [&] { return q->stop || (!q->pending.empty() && (!helper || light())); });
             if (q->pending.empty()) return;   // stop, and nothing left to serve
             // company: while another merged call is executing (the GPU is busy anyway) a group that is not full waits until its oldest request is
             // window_us old; arrivals and the other lane's completion wake it
-            if (q->cfg.window_us > 0) {
+            if (q->cfg.window_us > 0 && !helper) {
                 while (!q->stop && q->busy > 0 && !q->pending.empty() && q->pending_seqs < q->cfg.max_seqs) {
                     const auto deadline = q->pending.front()->t_in + window;
                     if (std::chrono::steady_clock::now() >= deadline) break;
@@ -250,6 +259,7 @@ void lane_run(mq_queue* q, int lane_idx) {
                 q->pending.pop_front();
             }
             q->pending_seqs -= seqs;
+            if (lane_idx == 0) { q->lane0_busy = true; q->lane0_seqs = seqs; }
             ++q->busy;
             ++q->st.calls;
             q->st.requests += (uint64_t)group.size();
@@ -269,6 +279,7 @@ void lane_run(mq_queue* q, int lane_idx) {
                 r->done = true;
             }
             --q->busy;
+            if (lane_idx == 0) { q->lane0_busy = false; q->lane0_seqs = 0; }
             if (rc != MQ_OK) ++q->st.failed_calls;
         }
         q->cv_done.notify_all();
@@ -286,6 +297,7 @@ extern "C" int mq_queue_create(const mq_queue_cfg* cfg, const void* tower_cfg, c
     MQ_CHECK_ARG(cfg->max_seqs >= 1 && cfg->max_seqs <= 4096, "mq_queue_create: max_seqs %d outside [1, 4096]", cfg->max_seqs);
     MQ_CHECK_ARG(cfg->depth >= 1 && cfg->depth <= 4, "mq_queue_create: depth %d outside [1, 4]", cfg->depth);
     MQ_CHECK_ARG(cfg->window_us >= 0 && cfg->window_us <= 100000, "mq_queue_create: window_us %d outside [0, 100000]", cfg->window_us);
+    MQ_CHECK_ARG(cfg->helper_seqs >= 0 && cfg->helper_seqs <= cfg->max_seqs, "mq_queue_create: helper_seqs %d outside [0, max_seqs]", cfg->helper_seqs);
     int32_t max_len, vocab, out_dim;
     size_t img_elems = 0;
     if (cfg->kind == MQ_QUEUE_IMAGE_F32) {      // a "sequence" is an image, a "row" too: max_rows = max_seqs

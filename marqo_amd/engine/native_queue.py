@@ -34,8 +34,12 @@ MAX_SEQS = _env_int("MARQO_AMD_NATIVE_QUEUE_SEQS", 64, 1, 4096)
 # token rows per merged call (and per request): bounds the queue's device scratch (sized once, for the largest call) on towers with long contexts —
 # 64 sequences x 512 positions would reserve a 32 k-row workspace per (tower, normalize) for calls that are a few hundred rows in practice
 MAX_ROWS = _env_int("MARQO_AMD_NATIVE_QUEUE_ROWS", 16384, 64, 1 << 18)
-DEPTH = _env_int("MARQO_AMD_NATIVE_QUEUE_DEPTH", 1, 1, 4)
-WINDOW_US = _env_int("MARQO_AMD_NATIVE_QUEUE_WINDOW_US", 100, 0, 100000)
+DEPTH = _env_int("MARQO_AMD_NATIVE_QUEUE_DEPTH", 2, 1, 4)
+# with DEPTH > 1: the lanes beyond the first are HELPERS — they take a backlog of at most this many sequences, and only while the group the first lane is
+# running is that small too (light load runs side by side: 2 request threads 1.00 -> 0.61 ms per one-query call; heavy load keeps one lane's large groups:
+# unchanged within noise; profiles/r08t_queue_helper_lanes_sweep.txt); 0 = every lane takes whatever waits (measured worse under heavy load, r08d)
+HELPER_SEQS = _env_int("MARQO_AMD_NATIVE_QUEUE_HELPER_SEQS", 4, 0, 64)
+WINDOW_US = _env_int("MARQO_AMD_NATIVE_QUEUE_WINDOW_US", 0, 0, 100000)
 # a LONE single query goes through the queue too and replays a hipGraph captured on the worker (0 = it keeps the tower's own captured graph, through torch)
 GRAPHS = os.environ.get("MARQO_AMD_NATIVE_QUEUE_GRAPHS", "1") != "0"
 
@@ -65,7 +69,7 @@ class TextQueue:
         self.max_rows = max(self.max_len, min(self.max_seqs * self.max_len, MAX_ROWS))
         self._qcfg = L.QueueCfg(kind=kind, device=int(device_index), max_seqs=self.max_seqs, max_rows=self.max_rows, normalize=1 if normalize else 0,
                                 depth=int(depth or DEPTH), window_us=int(WINDOW_US if window_us is None else window_us),
-                                graphs=1 if (GRAPHS if graphs is None else graphs) else 0)
+                                graphs=1 if (GRAPHS if graphs is None else graphs) else 0, helper_seqs=min(HELPER_SEQS, self.max_seqs), reserved=0)
         self._h = C.c_void_p()
         self._pid = os.getpid()
         self._lock = threading.Condition()
@@ -154,7 +158,7 @@ class ImageQueue(TextQueue):
         self.max_seqs = int(max_seqs or IMAGE_MAX_SEQS)
         self.max_rows = self.max_seqs
         self._qcfg = L.QueueCfg(kind=L.QUEUE_IMAGE_F32, device=int(device_index), max_seqs=self.max_seqs, max_rows=self.max_rows, normalize=1 if normalize else 0,
-                                depth=int(depth or DEPTH), window_us=int(WINDOW_US), graphs=1 if (GRAPHS if graphs is None else graphs) else 0)
+                                depth=int(depth or DEPTH), window_us=int(WINDOW_US), graphs=1 if (GRAPHS if graphs is None else graphs) else 0, helper_seqs=min(HELPER_SEQS, self.max_seqs), reserved=0)
         self._h = C.c_void_p()
         self._pid = os.getpid()
         self._lock = threading.Condition()

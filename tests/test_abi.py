@@ -36,7 +36,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(L.VitWeights) == 11 * 8 and C.sizeof(L.MapHead) == 11 * 8
     assert C.sizeof(L.ClipTextCfg) == ENC + 4 * 4 and C.sizeof(L.ClipTextWeights) == 7 * 8
     assert C.sizeof(L.BertCfg) == ENC + 5 * 4 + 4 and C.sizeof(L.BertWeights) == 9 * 8   # + proj_hidden, out_dim / proj1_w, proj1_b, proj2_w
-    assert C.sizeof(L.QueueCfg) == 8 * 4 and C.sizeof(L.QueueStats) == 9 * 8   # ABI 14: the native request queue
+    assert C.sizeof(L.QueueCfg) == 10 * 4 and C.sizeof(L.QueueStats) == 9 * 8   # ABI 14: the native request queue
 
 
 def test_argument_errors_are_reported_without_a_gpu():
