@@ -699,8 +699,9 @@ typedef struct mq_queue_cfg {
     int32_t max_seqs;    /* sequences per merged tower call (and per request) */
     int32_t max_rows;    /* token rows per merged tower call (and per request): >= the tower's context length */
     int32_t normalize;   /* != 0: L2-normalised rows */
-    int32_t depth;       /* worker threads = merged calls in flight: 1..4.  1 is what the loaders use: one worker forms the largest groups, and a small-row tower
-                          * call is host-launch-bound whatever its size (measured: depth 1 > 4 > 3 > 2, profiles/r08d_queue_depth_window_sweep.txt) */
+    int32_t depth;       /* worker threads (lanes) = merged calls in flight: 1..4.  EQUAL lanes cost heavy load its large groups (measured: depth 1 > 4 > 3 > 2,
+                          * profiles/r08d_queue_depth_window_sweep.txt: a small-row tower call is host-launch-bound whatever its size); the loaders use 2 with
+                          * helper_seqs = 4 — the second lane only works under light load */
     int32_t window_us;   /* see above; 0 = a group never waits */
     int32_t graphs;      /* != 0: a group of ONE sequence (the search path's lone query) replays a hipGraph of its token count, captured at the second
                           * call of that count on a worker (~100 dependent small launches: 0.45 ms enqueued one by one, 0.3 ms as a graph) */

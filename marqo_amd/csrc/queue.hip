@@ -11,10 +11,10 @@
 //
 // Batching is "natural": a worker that finds requests waiting takes as many as fit one tower call (max_seqs sequences / max_rows token rows) and runs them
 // as ONE mq_encode_clip_text / mq_encode_bert on its own stream; whatever arrives meanwhile waits for the next free worker, i.e. groups grow with the load
-// and a lone caller is never delayed.  `depth` workers (each with its own stream, device scratch and pinned staging; 1 by default: one worker forms the largest
-// groups and a small-row tower call is host-launch-bound whatever its size — depth 1 > 4 > 3 > 2 measured, profiles/r08d_queue_depth_window_sweep.txt); with
-// more than one, a worker holds a group that is not full back for up to window_us while another call is executing, so that requests a few microseconds apart
-// share a launch.  A group of ONE sequence replays a hipGraph of its token count (lane_graph_one).  MQ_QUEUE_IMAGE_F32: the same in front of
+// and a lone caller is never delayed.  `depth` workers (lanes; each with its own stream, device scratch and pinned staging).  Equal lanes cost heavy load its large
+// groups (one worker forms the largest ones and a small-row tower call is host-launch-bound whatever its size — depth 1 > 4 > 3 > 2 measured,
+// profiles/r08d_queue_depth_window_sweep.txt), one lane makes two or three callers wait for each other: with helper_seqs > 0 the lanes beyond the first work
+// only under light load (lane_run).  window_us > 0: a non-helper lane holds a group that is not full back that long while another call is executing.  A group of ONE sequence replays a hipGraph of its token count (lane_graph_one).  MQ_QUEUE_IMAGE_F32: the same in front of
 // mq_encode_image_f32, a request = device addresses of preprocessed images, gathered per group into the lane's batch buffer.
 // Rows of a batch are independent in these towers (per-row normalisation, no cross-sequence reduction): a request's embeddings are those of the merged call,
 // bit-identical to a lone call of the same kernel family (the small-row families take over at <= 320 rows: DESIGN.md section 3, Numerics).
