@@ -18,6 +18,7 @@
 // mq_encode_image_f32, a request = device addresses of preprocessed images, gathered per group into the lane's batch buffer.
 // Rows of a batch are independent in these towers (per-row normalisation, no cross-sequence reduction): a request's embeddings are those of the merged call,
 // bit-identical to a lone call of the same kernel family (the small-row families take over at <= 320 rows: DESIGN.md section 3, Numerics).
+#include <algorithm>
 #include <chrono>
 #include <condition_variable>
 #include <cstring>
@@ -53,6 +54,7 @@ constexpr size_t MAX_GRAPHS_PER_LANE = 160;
 
 struct QLane {            // one worker: everything a merged call touches is its own
     hipStream_t stream = nullptr;
+    int32_t cap_seqs = 0, cap_rows = 0;          // what this lane's buffers hold: the queue's limits, or a helper lane's small share
     std::unordered_map<int, QGraph> graphs;
     int32_t *d_ids = nullptr, *d_cu = nullptr;
     float* d_in = nullptr;                       // MQ_QUEUE_IMAGE_F32: the gathered batch [max_seqs, 3, S, S]
@@ -102,9 +104,12 @@ void lane_free(QLane& ln) {
     ln = QLane{};
 }
 
-int lane_alloc(mq_queue* q, QLane& ln) {
-    const size_t rows = (size_t)q->cfg.max_rows, seqs = (size_t)q->cfg.max_seqs, D = (size_t)q->out_dim;
+int lane_alloc(mq_queue* q, QLane& ln, bool helper) {
+    // a helper lane only ever runs groups of at most helper_seqs sequences: its scratch is sized for those (a 512-position tower: 2 k rows instead of 16 k)
     const bool image = q->cfg.kind == MQ_QUEUE_IMAGE_F32;
+    ln.cap_seqs = helper ? q->cfg.helper_seqs : q->cfg.max_seqs;
+    ln.cap_rows = image ? ln.cap_seqs : helper ? (int32_t)std::min<int64_t>(q->cfg.max_rows, (int64_t)q->cfg.helper_seqs * q->max_len) : q->cfg.max_rows;
+    const size_t rows = (size_t)ln.cap_rows, seqs = (size_t)ln.cap_seqs, D = (size_t)q->out_dim;
     ln.ws_bytes = image ? mq_vit_workspace_bytes((const mq_vit_cfg*)q->tower_cfg, (int64_t)seqs)
                   : q->cfg.kind == MQ_QUEUE_CLIP_TEXT ? mq_clip_text_workspace_bytes((const mq_clip_text_cfg*)q->tower_cfg, (int64_t)rows, (int64_t)seqs)
                                                       : mq_bert_workspace_bytes((const mq_bert_cfg*)q->tower_cfg, (int64_t)rows, (int64_t)seqs);
@@ -237,12 +242,16 @@ void lane_run(mq_queue* q, int lane_idx) {
             // — and only while the group the first lane is running is that small too (a large running group IS heavy load, whatever happens to wait now)
             const bool helper = lane_idx > 0 && q->cfg.helper_seqs > 0;
             auto light = [&] { return q->pending_seqs <= q->cfg.helper_seqs && q->lane0_busy && q->lane0_seqs <= q->cfg.helper_seqs; };
-            q->cv_work.wait(lk, [&] { return q->stop || (!q->pending.empty() && (!helper || light())); });
+            auto fits = [&](const QRequest* r) { return r->nseq <= ln.cap_seqs && r->rows <= ln.cap_rows; };   // (always, on the first lane)
+            q->cv_work.wait(lk, [&] {
+                if (q->pending.empty()) return q->stop;
+                return fits(q->pending.front()) && (q->stop || !helper || light());   // (a helper drains what fits it when the queue is being destroyed)
+            });
             if (q->pending.empty()) return;   // stop, and nothing left to serve
             // company: while another merged call is executing (the GPU is busy anyway) a group that is not full waits until its oldest request is
             // window_us old; arrivals and the other lane's completion wake it
             if (q->cfg.window_us > 0 && !helper) {
-                while (!q->stop && q->busy > 0 && !q->pending.empty() && q->pending_seqs < q->cfg.max_seqs) {
+                while (!q->stop && q->busy > 0 && !q->pending.empty() && q->pending_seqs < ln.cap_seqs) {
                     const auto deadline = q->pending.front()->t_in + window;
                     if (std::chrono::steady_clock::now() >= deadline) break;
                     q->cv_work.wait_until(lk, deadline);
@@ -252,12 +261,13 @@ void lane_run(mq_queue* q, int lane_idx) {
             int64_t seqs = 0, rows = 0;
             while (!q->pending.empty()) {
                 QRequest* r = q->pending.front();
-                if (!group.empty() && (seqs + r->nseq > q->cfg.max_seqs || rows + r->rows > q->cfg.max_rows)) break;
+                if (seqs + r->nseq > ln.cap_seqs || rows + r->rows > ln.cap_rows) break;   // (the front request fits: the wait above saw to it)
                 group.push_back(r);
                 seqs += r->nseq;
                 rows += r->rows;
                 q->pending.pop_front();
             }
+            if (group.empty()) continue;          // (another lane was faster)
             q->pending_seqs -= seqs;
             if (lane_idx == 0) { q->lane0_busy = true; q->lane0_seqs = seqs; }
             ++q->busy;
@@ -338,8 +348,8 @@ extern "C" int mq_queue_create(const mq_queue_cfg* cfg, const void* tower_cfg, c
     q->img_elems = img_elems;
     q->lanes.resize((size_t)cfg->depth);
     int rc = MQ_OK;
-    for (QLane& ln : q->lanes)
-        if ((rc = lane_alloc(q, ln)) != MQ_OK) break;
+    for (size_t i = 0; i < q->lanes.size(); ++i)
+        if ((rc = lane_alloc(q, q->lanes[i], i > 0 && cfg->helper_seqs > 0)) != MQ_OK) break;
     (void)hipSetDevice(prev);
     if (rc != MQ_OK) {
         for (QLane& ln : q->lanes) lane_free(ln);
