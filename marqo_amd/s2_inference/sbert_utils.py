@@ -109,6 +109,11 @@ class SBERT(Model):
             sentence = [sentence]
         return self.model.encode(sentence, normalize=bool(normalize) or self.always_normalized, **kwargs)
 
+    def native_queue_takes(self, texts) -> bool:
+        """the wrapped Hugging Face loader's answer (engine/native_queue.py): its small text calls merge in the tower's native request queue, so
+        `vectorise()` keeps them out of the Python coalescer.  (TEST truncates device rows and never takes that path.)"""
+        return type(self) is SBERT and self.model is not None and self.model.native_queue_takes(texts)
+
     def encode(self, sentence: Union[str, List[str]], normalize=True, **kwargs) -> np.ndarray:
         kw = {"return_device": True} if kwargs.get("return_device") else {}
         out = self._embed(sentence, normalize, **kw)
