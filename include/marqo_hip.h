@@ -667,7 +667,7 @@ int mq_weighted_combine(const float* d_emb, int64_t ld, const int32_t* d_rows, c
                         const int32_t* d_cu_terms, int64_t n_groups, int32_t D, int32_t mode, float* d_out,
                         void* stream);
 
-/* ---- native request queue: cross-request batching of small text calls (ABI 14) -------------------------------------------------------------------
+/* ---- native request queue: cross-request batching of the request threads' small calls (ABI 14) -----------------------------------------------------
  * The reference runs up to 8 indexing + 8 search request threads (src/marqo/api/configs.py:27-28), each calling vectorise() with one query
  * (src/marqo/tensor_search/tensor_search.py, the query vectorisation) or the few chunks of one document field
  * (src/marqo/core/inference/tensor_fields_container.py:179-223).  A queue merges what concurrent callers hand over into ONE
